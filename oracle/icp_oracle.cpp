@@ -1,0 +1,865 @@
+// TEST INFRASTRUCTURE ONLY -- see oracle_common.h.
+//
+// CPU restatement of the ICP half of the hot path:
+//   hybrid search      cpp/open3d/core/nns/NanoFlannImpl.h:305-370 (call site);
+//                      arithmetic lives in nanoflann v1.5.0 (pinned by
+//                      3rdparty/nanoflann/nanoflann.cmake:6, NOT vendored):
+//                      KDTreeSingleIndexAdaptor::radiusSearch with
+//                      L2_Adaptor (NanoFlannImpl.h:55-58): d2 accumulated as
+//                      ((dx*dx)+dy*dy)+dz*dz with dx = query - point, in T;
+//                      RadiusResultSet::addPoint keeps `dist < radius`
+//                      (strict); SearchParameters.sorted=true sorts ascending
+//                      by distance. Ties: std::sort order is unspecified in
+//                      the reference -> here lowest index wins (documented).
+//   GetJacobianPointToPlane   cpp/open3d/t/pipelines/kernel/RegistrationImpl.h:251-287
+//   29-reduction              cpp/open3d/t/pipelines/kernel/RegistrationCPU.cpp:30-122
+//   robust kernels            cpp/open3d/t/pipelines/registration/RobustKernelImpl.h:35-126
+//   DecodeAndSolve6x6         cpp/open3d/t/pipelines/kernel/TransformationConverter.cpp:189-226
+//   PoseToTransformation      .../TransformationConverter.cpp:81-104, ...Impl.h:23-42
+//   TransformPoints/Normals   cpp/open3d/t/geometry/kernel/TransformImpl.h:19-60
+//   ICP / MultiScaleICP       cpp/open3d/t/pipelines/registration/Registration.cpp:24-62,275-444
+//   VoxelDownSample           cpp/open3d/t/geometry/PointCloud.cpp:496-567
+//   P2Plane ComputeRMSE       cpp/open3d/t/pipelines/registration/TransformationEstimation.cpp:160-193
+//
+// Pinned by the reference's in-source known answers (tests/test_oracle_goldens.py):
+//   point-to-plane 0.335499 -> 0.601422  (cpp/tests/t/pipelines/registration/TransformationEstimation.cpp:33-86,148,176)
+//   hybrid search {1,4,-1} / {0.00626358,0.00747938,0} / 2 (cpp/tests/core/NearestNeighborSearch.cpp:321-377)
+//   robust kernel weights at r=0.98 (cpp/tests/t/pipelines/registration/Registration.cpp:411-490)
+//   Solve {3,1;1,2} x = {9,8} -> {2,3} (cpp/tests/core/Linalg.cpp:454-480)
+//   Pose zeros -> identity (cpp/tests/t/pipelines/TransformationConverter.cpp:37-48)
+// Parity unpinned: TBB parallel_reduce split order (float rounding of the
+// 29-sum) -- the oracle offers a sequential scalar_t sum and a double sum.
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <unordered_map>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+using std::abs;
+using std::exp;
+using std::max;
+using std::min;
+using std::pow;
+
+template <typename scalar_t>
+scalar_t Square(const scalar_t& x) {
+    return x * x;
+}
+
+// GeometryMacros.h:58-63 (note: with y == 0 this is never true).
+template <typename scalar_t, typename T>
+bool IsClose(const scalar_t& x, const T& y, const double rtol = 1e-4) {
+    return ((x > (1.0 - rtol) * y) && (x < (1.0 + rtol) * y));
+}
+
+// RobustKernelImpl.h:35-126, literal (including the double-typed literals that
+// promote parts of the expression to double before the scalar_t return).
+template <typename scalar_t>
+scalar_t RobustWeight(int method, double scaling_parameter,
+                      double shape_parameter, scalar_t residual) {
+    scalar_t scale = static_cast<scalar_t>(scaling_parameter);
+    switch (method) {
+        case 0:  // L2Loss
+            return 1.0;
+        case 1:  // L1Loss
+            return 1.0 / abs(residual);
+        case 2:  // HuberLoss
+            return scale / max(abs(residual), scale);
+        case 3:  // CauchyLoss
+            return 1.0 / (1.0 + Square(residual / scale));
+        case 4:  // GMLoss
+            return scale / Square(scale + Square(residual));
+        case 5:  // TukeyLoss
+            return Square(1.0 - Square(min((scalar_t)1.0,
+                                           abs(residual) / scale)));
+        case 6:  // GeneralizedLoss
+            if (IsClose(shape_parameter, 2.0, 1e-3)) {
+                auto const_val = 1.0 / Square(scale);
+                return const_val;
+            } else if (IsClose(shape_parameter, 0.0, 1e-3)) {
+                return 2.0 / (Square(residual) + 2 * Square(scale));
+            } else if (shape_parameter < -1e7) {
+                return exp(Square(residual / scale) / (-2.0)) / Square(scale);
+            } else {
+                return pow((Square(residual / scale) /
+                                    abs(shape_parameter - 2.0) +
+                            1),
+                           ((shape_parameter / 2.0) - 1.0)) /
+                       Square(scale);
+            }
+        default:
+            return 1.0;
+    }
+}
+
+// RegistrationImpl.h:251-287
+template <typename scalar_t>
+inline bool GetJacobianPointToPlane(int64_t workload_idx,
+                                    const scalar_t* source_points_ptr,
+                                    const scalar_t* target_points_ptr,
+                                    const scalar_t* target_normals_ptr,
+                                    const int64_t* correspondence_indices,
+                                    scalar_t* J_ij, scalar_t& r) {
+    if (correspondence_indices[workload_idx] == -1) {
+        return false;
+    }
+    const int64_t target_idx = 3 * correspondence_indices[workload_idx];
+    const int64_t source_idx = 3 * workload_idx;
+
+    const scalar_t& sx = source_points_ptr[source_idx + 0];
+    const scalar_t& sy = source_points_ptr[source_idx + 1];
+    const scalar_t& sz = source_points_ptr[source_idx + 2];
+    const scalar_t& tx = target_points_ptr[target_idx + 0];
+    const scalar_t& ty = target_points_ptr[target_idx + 1];
+    const scalar_t& tz = target_points_ptr[target_idx + 2];
+    const scalar_t& nx = target_normals_ptr[target_idx + 0];
+    const scalar_t& ny = target_normals_ptr[target_idx + 1];
+    const scalar_t& nz = target_normals_ptr[target_idx + 2];
+
+    r = (sx - tx) * nx + (sy - ty) * ny + (sz - tz) * nz;
+
+    J_ij[0] = nz * sy - ny * sz;
+    J_ij[1] = nx * sz - nz * sx;
+    J_ij[2] = ny * sx - nx * sy;
+    J_ij[3] = nx;
+    J_ij[4] = ny;
+    J_ij[5] = nz;
+    return true;
+}
+
+// RegistrationCPU.cpp:30-90, as ONE sequential range (TBB would split it).
+// acc_t = scalar_t reproduces the reference arithmetic for a single range;
+// acc_t = double keeps the per-term products in scalar_t (as the reference)
+// but sums them in double.
+template <typename scalar_t, typename acc_t>
+void ComputePosePointToPlaneKernel(const scalar_t* source_points_ptr,
+                                   const scalar_t* target_points_ptr,
+                                   const scalar_t* target_normals_ptr,
+                                   const int64_t* correspondence_indices,
+                                   int64_t n, acc_t* global_sum, int method,
+                                   double scaling, double shape) {
+    acc_t A[29];
+    for (int i = 0; i < 29; ++i) A[i] = 0;
+    for (int64_t workload_idx = 0; workload_idx < n; ++workload_idx) {
+        scalar_t J_ij[6];
+        scalar_t r = 0;
+        bool valid = GetJacobianPointToPlane<scalar_t>(
+                workload_idx, source_points_ptr, target_points_ptr,
+                target_normals_ptr, correspondence_indices, J_ij, r);
+        scalar_t w = RobustWeight<scalar_t>(method, scaling, shape, r);
+        if (valid) {
+            int i = 0;
+            for (int j = 0; j < 6; ++j) {
+                for (int k = 0; k <= j; ++k) {
+                    A[i] += J_ij[j] * w * J_ij[k];
+                    ++i;
+                }
+                A[21 + j] += J_ij[j] * w * r;
+            }
+            A[27] += r;
+            A[28] += 1;
+        }
+    }
+    for (int i = 0; i < 29; ++i) global_sum[i] = A[i];
+}
+
+// LAPACK ?gesv restated: LU with partial (row) pivoting, then two triangular
+// solves (core/linalg/SolveCPU.cpp:15-30 -> LAPACKE_dgesv). Returns 0 on
+// success, >0 if U is exactly singular (gesv's info>0 -> OPEN3D_LAPACK_CHECK
+// throws, core/linalg/LinalgUtils.h:35-42).
+int SolveLU(int n, double* A /*row-major n*n, destroyed*/, double* b) {
+    std::vector<int> piv(n);
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        double mx = std::abs(A[k * n + k]);
+        for (int i = k + 1; i < n; ++i) {
+            double v = std::abs(A[i * n + k]);
+            if (v > mx) {
+                mx = v;
+                p = i;
+            }
+        }
+        if (mx == 0.0) return k + 1;
+        if (p != k) {
+            for (int j = 0; j < n; ++j) std::swap(A[k * n + j], A[p * n + j]);
+            std::swap(b[k], b[p]);
+        }
+        for (int i = k + 1; i < n; ++i) {
+            double l = A[i * n + k] / A[k * n + k];
+            A[i * n + k] = l;
+            for (int j = k + 1; j < n; ++j) A[i * n + j] -= l * A[k * n + j];
+        }
+    }
+    // forward (unit lower)
+    for (int i = 1; i < n; ++i)
+        for (int j = 0; j < i; ++j) b[i] -= A[i * n + j] * b[j];
+    // backward
+    for (int i = n - 1; i >= 0; --i) {
+        for (int j = i + 1; j < n; ++j) b[i] -= A[i * n + j] * b[j];
+        b[i] /= A[i * n + i];
+    }
+    return 0;
+}
+
+// TransformationConverter.cpp:189-226
+int DecodeAndSolve6x6(const double* A_1x29, double* delta,
+                      float* inlier_residual, int* inlier_count) {
+    double AtA[36], Atb[6];
+    for (int j = 0; j < 6; j++) {
+        Atb[j] = A_1x29[21 + j];
+        const int64_t reduction_idx = ((j * (j + 1)) / 2);
+        for (int k = 0; k <= j; k++) {
+            AtA[j * 6 + k] = A_1x29[reduction_idx + k];
+            AtA[k * 6 + j] = A_1x29[reduction_idx + k];
+        }
+    }
+    double rhs[6];
+    for (int j = 0; j < 6; ++j) rhs[j] = -Atb[j];
+    int info = SolveLU(6, AtA, rhs);
+    if (info != 0) {
+        // Reference: LogError("Singular 6x6 linear system detected, tracking
+        // failed.") throws.
+        for (int j = 0; j < 6; ++j) delta[j] = 0;
+        *inlier_residual = 0;
+        *inlier_count = 0;
+        return 1;
+    }
+    for (int j = 0; j < 6; ++j) delta[j] = rhs[j];
+    *inlier_residual = (float)A_1x29[27];
+    *inlier_count = static_cast<int>(A_1x29[28]);
+    return 0;
+}
+
+// TransformationConverterImpl.h:23-42 + TransformationConverter.cpp:81-104
+void PoseToTransformation(const double* pose_ptr, double* transformation_ptr) {
+    for (int i = 0; i < 16; ++i) transformation_ptr[i] = 0;
+    transformation_ptr[0] = cos(pose_ptr[2]) * cos(pose_ptr[1]);
+    transformation_ptr[1] =
+            -1 * sin(pose_ptr[2]) * cos(pose_ptr[0]) +
+            cos(pose_ptr[2]) * sin(pose_ptr[1]) * sin(pose_ptr[0]);
+    transformation_ptr[2] =
+            sin(pose_ptr[2]) * sin(pose_ptr[0]) +
+            cos(pose_ptr[2]) * sin(pose_ptr[1]) * cos(pose_ptr[0]);
+    transformation_ptr[4] = sin(pose_ptr[2]) * cos(pose_ptr[1]);
+    transformation_ptr[5] =
+            cos(pose_ptr[2]) * cos(pose_ptr[0]) +
+            sin(pose_ptr[2]) * sin(pose_ptr[1]) * sin(pose_ptr[0]);
+    transformation_ptr[6] =
+            -1 * cos(pose_ptr[2]) * sin(pose_ptr[0]) +
+            sin(pose_ptr[2]) * sin(pose_ptr[1]) * cos(pose_ptr[0]);
+    transformation_ptr[8] = -1 * sin(pose_ptr[1]);
+    transformation_ptr[9] = cos(pose_ptr[1]) * sin(pose_ptr[0]);
+    transformation_ptr[10] = cos(pose_ptr[1]) * cos(pose_ptr[0]);
+    transformation_ptr[3] = pose_ptr[3];
+    transformation_ptr[7] = pose_ptr[4];
+    transformation_ptr[11] = pose_ptr[5];
+    transformation_ptr[15] = 1;
+}
+
+// TransformImpl.h:19-44 -- transformation is first cast to the point dtype
+// (kernel/Transform.cpp:20-45).
+template <typename scalar_t>
+void TransformPoints(const double* T, scalar_t* points, int64_t n) {
+    scalar_t t[16];
+    for (int i = 0; i < 16; ++i) t[i] = (scalar_t)T[i];
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        scalar_t* p = points + 3 * i;
+        scalar_t x[4] = {t[0] * p[0] + t[1] * p[1] + t[2] * p[2] + t[3],
+                         t[4] * p[0] + t[5] * p[1] + t[6] * p[2] + t[7],
+                         t[8] * p[0] + t[9] * p[1] + t[10] * p[2] + t[11],
+                         t[12] * p[0] + t[13] * p[1] + t[14] * p[2] + t[15]};
+        p[0] = x[0] / x[3];
+        p[1] = x[1] / x[3];
+        p[2] = x[2] / x[3];
+    }
+}
+
+// TransformImpl.h:46-60
+template <typename scalar_t>
+void TransformNormals(const double* T, scalar_t* normals, int64_t n) {
+    scalar_t t[16];
+    for (int i = 0; i < 16; ++i) t[i] = (scalar_t)T[i];
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        scalar_t* p = normals + 3 * i;
+        scalar_t x[3] = {t[0] * p[0] + t[1] * p[1] + t[2] * p[2],
+                         t[4] * p[0] + t[5] * p[1] + t[6] * p[2],
+                         t[8] * p[0] + t[9] * p[1] + t[10] * p[2]};
+        p[0] = x[0];
+        p[1] = x[1];
+        p[2] = x[2];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Exact fixed-radius "hybrid" search with nanoflann semantics.
+struct CellKey {
+    int64_t x, y, z;
+    bool operator==(const CellKey& o) const {
+        return x == o.x && y == o.y && z == o.z;
+    }
+};
+struct CellKeyHash {
+    size_t operator()(const CellKey& k) const {
+        uint64_t h = 1469598103934665603ull;
+        for (uint64_t v : {(uint64_t)k.x, (uint64_t)k.y, (uint64_t)k.z}) {
+            h ^= v;
+            h *= 1099511628211ull;
+        }
+        return (size_t)h;
+    }
+};
+
+template <typename T>
+struct GridIndex {
+    const T* points;
+    int64_t n;
+    double cell;
+    std::unordered_map<CellKey, std::vector<int64_t>, CellKeyHash> cells;
+
+    GridIndex(const T* pts, int64_t n_, double radius) : points(pts), n(n_) {
+        // Slightly larger than the radius so that float rounding of d2 can
+        // never reach a point two cells away.
+        cell = radius * 1.001 + 1e-12;
+        cells.reserve((size_t)n);
+        for (int64_t i = 0; i < n; ++i) {
+            cells[Key(pts + 3 * i)].push_back(i);
+        }
+    }
+    CellKey Key(const T* p) const {
+        return CellKey{(int64_t)std::floor((double)p[0] / cell),
+                       (int64_t)std::floor((double)p[1] / cell),
+                       (int64_t)std::floor((double)p[2] / cell)};
+    }
+    // Collect all (d2, idx) with d2 < r2, sorted ascending by (d2, idx).
+    void Query(const T* q, T radius_squared,
+               std::vector<std::pair<T, int64_t>>& out) const {
+        out.clear();
+        CellKey c = Key(q);
+        for (int64_t dx = -1; dx <= 1; ++dx)
+            for (int64_t dy = -1; dy <= 1; ++dy)
+                for (int64_t dz = -1; dz <= 1; ++dz) {
+                    auto it = cells.find(CellKey{c.x + dx, c.y + dy, c.z + dz});
+                    if (it == cells.end()) continue;
+                    for (int64_t idx : it->second) {
+                        const T* p = points + 3 * idx;
+                        // nanoflann::L2_Adaptor::evalMetric, size==3 tail loop.
+                        T result = T();
+                        const T d0 = q[0] - p[0];
+                        result += d0 * d0;
+                        const T d1 = q[1] - p[1];
+                        result += d1 * d1;
+                        const T d2 = q[2] - p[2];
+                        result += d2 * d2;
+                        // RadiusResultSet::addPoint: strict.
+                        if (result < radius_squared)
+                            out.emplace_back(result, idx);
+                    }
+                }
+        std::sort(out.begin(), out.end());
+    }
+};
+
+// NanoFlannImpl.h:305-370 (_HybridSearchCPU).
+template <typename T>
+void HybridSearch(const T* points, int64_t num_points, const T* queries,
+                  int64_t num_queries, double radius_d, int max_knn,
+                  int32_t* indices_ptr, T* distances_ptr, int32_t* counts_ptr) {
+    if (num_queries == 0 || num_points == 0) return;
+    const T radius = (T)radius_d;
+    T radius_squared = radius * radius;
+    GridIndex<T> grid(points, num_points, radius_d);
+#pragma omp parallel
+    {
+        std::vector<std::pair<T, int64_t>> ret_matches;
+#pragma omp for schedule(dynamic, 64)
+        for (int64_t i = 0; i < num_queries; ++i) {
+            grid.Query(queries + 3 * i, radius_squared, ret_matches);
+            size_t num_results = ret_matches.size();
+            int32_t count_i = static_cast<int32_t>(num_results);
+            count_i = count_i < max_knn ? count_i : max_knn;
+            counts_ptr[i] = count_i;
+
+            int neighbor_idx = 0;
+            for (auto it = ret_matches.begin();
+                 it < ret_matches.end() && neighbor_idx < max_knn;
+                 it++, neighbor_idx++) {
+                indices_ptr[i * max_knn + neighbor_idx] = (int32_t)it->second;
+                distances_ptr[i * max_knn + neighbor_idx] = it->first;
+            }
+            while (neighbor_idx < max_knn) {
+                indices_ptr[i * max_knn + neighbor_idx] = -1;
+                distances_ptr[i * max_knn + neighbor_idx] = 0;
+                neighbor_idx += 1;
+            }
+        }
+    }
+}
+
+// Brute-force variant (no grid) used to cross-check the grid on small inputs.
+template <typename T>
+void HybridSearchBrute(const T* points, int64_t num_points, const T* queries,
+                       int64_t num_queries, double radius_d, int max_knn,
+                       int32_t* indices_ptr, T* distances_ptr,
+                       int32_t* counts_ptr) {
+    const T radius = (T)radius_d;
+    T radius_squared = radius * radius;
+    std::vector<std::pair<T, int64_t>> m;
+    for (int64_t i = 0; i < num_queries; ++i) {
+        m.clear();
+        const T* q = queries + 3 * i;
+        for (int64_t j = 0; j < num_points; ++j) {
+            const T* p = points + 3 * j;
+            T result = T();
+            const T d0 = q[0] - p[0];
+            result += d0 * d0;
+            const T d1 = q[1] - p[1];
+            result += d1 * d1;
+            const T d2 = q[2] - p[2];
+            result += d2 * d2;
+            if (result < radius_squared) m.emplace_back(result, j);
+        }
+        std::sort(m.begin(), m.end());
+        int32_t c = (int32_t)m.size();
+        c = c < max_knn ? c : max_knn;
+        counts_ptr[i] = c;
+        int k = 0;
+        for (; k < c; ++k) {
+            indices_ptr[i * max_knn + k] = (int32_t)m[k].second;
+            distances_ptr[i * max_knn + k] = m[k].first;
+        }
+        for (; k < max_knn; ++k) {
+            indices_ptr[i * max_knn + k] = -1;
+            distances_ptr[i * max_knn + k] = 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// PointCloud::VoxelDownSample, PointCloud.cpp:496-567, sequential semantics:
+// voxel label = order of first occurrence; every attribute is summed in
+// Float32 in point order (IndexAdd_), divided by the Float32 count, cast back.
+template <typename T>
+int64_t VoxelDownSample(const T* positions, const T* normals, int64_t n,
+                        double voxel_size, T* out_positions, T* out_normals) {
+    std::unordered_map<CellKey, int64_t, CellKeyHash> map;
+    map.reserve((size_t)n);
+    std::vector<int64_t> point2voxel((size_t)n);
+    const T vs = (T)voxel_size;  // Tensor / scalar: scalar cast to dtype
+    int64_t num_voxels = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        CellKey k{(int64_t)std::floor(positions[3 * i + 0] / vs),
+                  (int64_t)std::floor(positions[3 * i + 1] / vs),
+                  (int64_t)std::floor(positions[3 * i + 2] / vs)};
+        auto res = map.insert({k, num_voxels});
+        if (res.second) ++num_voxels;
+        point2voxel[(size_t)i] = res.first->second;
+    }
+    std::vector<float> cnt((size_t)num_voxels, 0.f);
+    std::vector<float> sp((size_t)num_voxels * 3, 0.f);
+    std::vector<float> sn(normals ? (size_t)num_voxels * 3 : 0, 0.f);
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t v = point2voxel[(size_t)i];
+        cnt[(size_t)v] += 1.0f;
+        for (int c = 0; c < 3; ++c) {
+            sp[(size_t)v * 3 + c] += (float)positions[3 * i + c];
+            if (normals) sn[(size_t)v * 3 + c] += (float)normals[3 * i + c];
+        }
+    }
+    for (int64_t v = 0; v < num_voxels; ++v) {
+        for (int c = 0; c < 3; ++c) {
+            out_positions[3 * v + c] = (T)(sp[(size_t)v * 3 + c] / cnt[(size_t)v]);
+            if (normals)
+                out_normals[3 * v + c] =
+                        (T)(sn[(size_t)v * 3 + c] / cnt[(size_t)v]);
+        }
+    }
+    return num_voxels;
+}
+
+// ---------------------------------------------------------------------------
+// ComputeRegistrationResult, Registration.cpp:24-62.
+struct RegResult {
+    double T[16];
+    double fitness = 0, inlier_rmse = 0;
+    bool converged = false;
+    int num_iterations = 0;
+    std::vector<int64_t> correspondences;
+};
+
+void Eye4(double* T) {
+    for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+}
+
+void Matmul4(const double* A, const double* B, double* C) {
+    double R[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double s = 0;
+            for (int k = 0; k < 4; ++k) s += A[i * 4 + k] * B[k * 4 + j];
+            R[i * 4 + j] = s;
+        }
+    std::memcpy(C, R, sizeof(R));
+}
+
+template <typename T>
+RegResult ComputeRegistrationResult(const T* source, int64_t ns,
+                                    const T* target, int64_t nt,
+                                    double max_correspondence_distance,
+                                    const double* transformation) {
+    RegResult result;
+    std::memcpy(result.T, transformation, sizeof(result.T));
+    std::vector<int32_t> idx((size_t)ns), counts((size_t)ns);
+    std::vector<T> distances((size_t)ns);
+    HybridSearch<T>(target, nt, source, ns, max_correspondence_distance, 1,
+                    idx.data(), distances.data(), counts.data());
+    result.correspondences.resize((size_t)ns);
+    // counts.Sum / distances.Sum: reduction in the tensor dtype
+    // (int32 / T), then cast to Float64 (Registration.cpp:38-46).
+    int64_t num = 0;
+    T sq = 0;
+    for (int64_t i = 0; i < ns; ++i) {
+        result.correspondences[(size_t)i] = idx[(size_t)i];
+        num += counts[(size_t)i];
+        sq += distances[(size_t)i];
+    }
+    double num_correspondences = (double)num;
+    if (num_correspondences != 0) {
+        const double squared_error = (double)sq;
+        result.fitness = num_correspondences / static_cast<double>(ns);
+        result.inlier_rmse = std::sqrt(squared_error / num_correspondences);
+    } else {
+        result.fitness = 0.0;
+        result.inlier_rmse = 0.0;
+        Eye4(result.T);
+    }
+    return result;
+}
+
+typedef void (*icp_callback_t)(int64_t iteration_index, int64_t scale_index,
+                               int64_t scale_iteration_index, double inlier_rmse,
+                               double fitness, const double* transformation,
+                               void* user);
+
+// MultiScaleICP, Registration.cpp:362-444 (+ DoSingleScaleICPIterations
+// :275-360, InitializePointCloudPyramid :221-273), point-to-plane estimator.
+template <typename T>
+int MultiScaleICP(const T* source_in, int64_t ns_in, const T* target_in,
+                  const T* target_normals_in, int64_t nt_in, int num_scales,
+                  const double* voxel_sizes, const int* max_iterations,
+                  const double* relative_fitness, const double* relative_rmse,
+                  const double* max_dists, const double* init, int kernel_method,
+                  double kernel_scale, double kernel_shape, int accumulate_double,
+                  double* out_T, double* out_fitness, double* out_rmse,
+                  int* out_converged, int* out_num_iterations,
+                  int64_t* out_correspondences, int64_t* out_num_corr,
+                  icp_callback_t cb, void* user) {
+    // Pyramid.
+    std::vector<std::vector<T>> src_p(num_scales), tgt_p(num_scales),
+            tgt_n(num_scales);
+    auto down = [&](const std::vector<T>& p, const std::vector<T>* nrm,
+                    double v, std::vector<T>& op, std::vector<T>* on) {
+        int64_t n = (int64_t)p.size() / 3;
+        op.resize(p.size());
+        if (on) on->resize(p.size());
+        int64_t m = VoxelDownSample<T>(p.data(), nrm ? nrm->data() : nullptr, n,
+                                       v, op.data(), on ? on->data() : nullptr);
+        op.resize((size_t)m * 3);
+        if (on) on->resize((size_t)m * 3);
+    };
+    std::vector<T> s0(source_in, source_in + 3 * ns_in);
+    std::vector<T> t0(target_in, target_in + 3 * nt_in);
+    std::vector<T> n0(target_normals_in, target_normals_in + 3 * nt_in);
+    int last = num_scales - 1;
+    if (voxel_sizes[last] <= 0) {
+        src_p[last] = s0;
+        tgt_p[last] = t0;
+        tgt_n[last] = n0;
+    } else {
+        down(s0, nullptr, voxel_sizes[last], src_p[last], nullptr);
+        down(t0, &n0, voxel_sizes[last], tgt_p[last], &tgt_n[last]);
+    }
+    for (int k = num_scales - 2; k >= 0; k--) {
+        down(src_p[k + 1], nullptr, voxel_sizes[k], src_p[k], nullptr);
+        down(tgt_p[k + 1], &tgt_n[k + 1], voxel_sizes[k], tgt_p[k], &tgt_n[k]);
+    }
+
+    RegResult result;
+    std::memcpy(result.T, init, sizeof(result.T));
+    int iteration_count = 0;
+    int status = 0;
+
+    for (int scale_idx = 0; scale_idx < num_scales; ++scale_idx) {
+        std::vector<T>& source = src_p[scale_idx];
+        const std::vector<T>& target = tgt_p[scale_idx];
+        const std::vector<T>& normals = tgt_n[scale_idx];
+        int64_t ns = (int64_t)source.size() / 3;
+        int64_t nt = (int64_t)target.size() / 3;
+        TransformPoints<T>(result.T, source.data(), ns);
+
+        // DoSingleScaleICPIterations
+        RegResult current_result = result;
+        {
+            RegResult r2;
+            std::memcpy(r2.T, current_result.T, sizeof(r2.T));
+            double prev_fitness = current_result.fitness;
+            double prev_inlier_rmse = current_result.inlier_rmse;
+            int it = 0;
+            bool early_return = false;
+            for (it = 0; it < max_iterations[scale_idx]; ++it) {
+                double keepT[16];
+                std::memcpy(keepT, r2.T, sizeof(keepT));
+                r2 = ComputeRegistrationResult<T>(source.data(), ns,
+                                                  target.data(), nt,
+                                                  max_dists[scale_idx], keepT);
+                if (r2.fitness <= std::numeric_limits<double>::min()) {
+                    r2.converged = false;
+                    r2.num_iterations = it;
+                    early_return = true;
+                    break;
+                }
+                double A[29];
+                if (accumulate_double) {
+                    ComputePosePointToPlaneKernel<T, double>(
+                            source.data(), target.data(), normals.data(),
+                            r2.correspondences.data(), ns, A, kernel_method,
+                            kernel_scale, kernel_shape);
+                } else {
+                    T Af[29];
+                    ComputePosePointToPlaneKernel<T, T>(
+                            source.data(), target.data(), normals.data(),
+                            r2.correspondences.data(), ns, Af, kernel_method,
+                            kernel_scale, kernel_shape);
+                    for (int i = 0; i < 29; ++i) A[i] = (double)Af[i];
+                }
+                double pose[6];
+                float residual;
+                int inlier_count;
+                if (DecodeAndSolve6x6(A, pose, &residual, &inlier_count) != 0) {
+                    status = 2;  // singular: the reference throws.
+                }
+                double update[16];
+                PoseToTransformation(pose, update);
+                Matmul4(update, r2.T, r2.T);
+                TransformPoints<T>(update, source.data(), ns);
+
+                if (cb) {
+                    cb(iteration_count + it, scale_idx, it, r2.inlier_rmse,
+                       r2.fitness, r2.T, user);
+                }
+                if (it != 0 &&
+                    std::abs(prev_fitness - r2.fitness) <
+                            relative_fitness[scale_idx] &&
+                    std::abs(prev_inlier_rmse - r2.inlier_rmse) <
+                            relative_rmse[scale_idx]) {
+                    r2.converged = true;
+                    break;
+                }
+                prev_fitness = r2.fitness;
+                prev_inlier_rmse = r2.inlier_rmse;
+            }
+            (void)early_return;
+            result = r2;
+            iteration_count = iteration_count + it;
+        }
+
+        if (scale_idx == num_scales - 1) {
+            bool preserved = result.converged;
+            double keepT[16];
+            std::memcpy(keepT, result.T, sizeof(keepT));
+            result = ComputeRegistrationResult<T>(source.data(), ns,
+                                                  target.data(), nt,
+                                                  max_dists[scale_idx], keepT);
+            result.converged = preserved;
+        }
+        if (result.fitness <= std::numeric_limits<double>::min()) {
+            result.converged = false;
+            break;
+        }
+    }
+    result.num_iterations = iteration_count;
+
+    std::memcpy(out_T, result.T, sizeof(result.T));
+    *out_fitness = result.fitness;
+    *out_rmse = result.inlier_rmse;
+    *out_converged = result.converged ? 1 : 0;
+    *out_num_iterations = result.num_iterations;
+    *out_num_corr = (int64_t)result.correspondences.size();
+    if (out_correspondences) {
+        for (size_t i = 0; i < result.correspondences.size(); ++i)
+            out_correspondences[i] = result.correspondences[i];
+    }
+    return status;
+}
+
+}  // namespace
+
+// ===========================================================================
+extern "C" {
+
+double orc_robust_weight(int is_f64, int method, double scaling, double shape,
+                         double residual) {
+    if (is_f64) return RobustWeight<double>(method, scaling, shape, residual);
+    return (double)RobustWeight<float>(method, scaling, shape, (float)residual);
+}
+
+void orc_hybrid_search(const void* points, int64_t n, const void* queries,
+                       int64_t q, int is_f64, double radius, int max_knn,
+                       int brute, int32_t* idx, void* dist, int32_t* counts) {
+    if (is_f64) {
+        if (brute)
+            HybridSearchBrute<double>((const double*)points, n,
+                                      (const double*)queries, q, radius,
+                                      max_knn, idx, (double*)dist, counts);
+        else
+            HybridSearch<double>((const double*)points, n,
+                                 (const double*)queries, q, radius, max_knn,
+                                 idx, (double*)dist, counts);
+    } else {
+        if (brute)
+            HybridSearchBrute<float>((const float*)points, n,
+                                     (const float*)queries, q, radius, max_knn,
+                                     idx, (float*)dist, counts);
+        else
+            HybridSearch<float>((const float*)points, n, (const float*)queries,
+                                q, radius, max_knn, idx, (float*)dist, counts);
+    }
+}
+
+// out29 is always double[29]; accumulate_double selects the accumulator type.
+void orc_p2plane_accumulate(const void* src, const void* tgt, const void* tgt_n,
+                            const int64_t* corr, int64_t n, int is_f64,
+                            int method, double scaling, double shape,
+                            int accumulate_double, double* out29) {
+    if (is_f64) {
+        ComputePosePointToPlaneKernel<double, double>(
+                (const double*)src, (const double*)tgt, (const double*)tgt_n,
+                corr, n, out29, method, scaling, shape);
+    } else if (accumulate_double) {
+        ComputePosePointToPlaneKernel<float, double>(
+                (const float*)src, (const float*)tgt, (const float*)tgt_n, corr,
+                n, out29, method, scaling, shape);
+    } else {
+        float A[29];
+        ComputePosePointToPlaneKernel<float, float>(
+                (const float*)src, (const float*)tgt, (const float*)tgt_n, corr,
+                n, A, method, scaling, shape);
+        for (int i = 0; i < 29; ++i) out29[i] = (double)A[i];
+    }
+}
+
+int orc_decode_and_solve6x6(const double* A29, double* pose, float* residual,
+                            int* count) {
+    return DecodeAndSolve6x6(A29, pose, residual, count);
+}
+
+int orc_solve(int n, const double* A, const double* b, double* x) {
+    std::vector<double> a(A, A + (size_t)n * n), r(b, b + n);
+    int info = SolveLU(n, a.data(), r.data());
+    if (info) return info;
+    for (int i = 0; i < n; ++i) x[i] = r[i];
+    return 0;
+}
+
+void orc_pose_to_transformation(const double* pose, double* T) {
+    PoseToTransformation(pose, T);
+}
+
+void orc_transform_points(const double* T, void* pts, int64_t n, int is_f64) {
+    if (is_f64) TransformPoints<double>(T, (double*)pts, n);
+    else TransformPoints<float>(T, (float*)pts, n);
+}
+
+void orc_transform_normals(const double* T, void* nrm, int64_t n, int is_f64) {
+    if (is_f64) TransformNormals<double>(T, (double*)nrm, n);
+    else TransformNormals<float>(T, (float*)nrm, n);
+}
+
+// TransformationEstimationPointToPlane::ComputeRMSE,
+// TransformationEstimation.cpp:160-193: element-wise (s-t)*n, squared, summed
+// over all elements (in the cloud dtype), / n_corr, sqrt.
+double orc_p2plane_rmse(const void* src, const void* tgt, const void* tgt_n,
+                        const int64_t* corr, int64_t n, int is_f64) {
+    int64_t cnt = 0;
+    if (is_f64) {
+        const double *s = (const double*)src, *t = (const double*)tgt,
+                     *nn = (const double*)tgt_n;
+        double e = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            if (corr[i] == -1) continue;
+            ++cnt;
+            for (int c = 0; c < 3; ++c) {
+                double v = (s[3 * i + c] - t[3 * corr[i] + c]) *
+                           nn[3 * corr[i] + c];
+                e += v * v;
+            }
+        }
+        return std::sqrt(e / (double)cnt);
+    }
+    const float *s = (const float*)src, *t = (const float*)tgt,
+                *nn = (const float*)tgt_n;
+    float e = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (corr[i] == -1) continue;
+        ++cnt;
+        for (int c = 0; c < 3; ++c) {
+            float v = (s[3 * i + c] - t[3 * corr[i] + c]) * nn[3 * corr[i] + c];
+            e += v * v;
+        }
+    }
+    return std::sqrt((double)e / (double)cnt);
+}
+
+int64_t orc_voxel_down_sample(const void* pos, const void* nrm, int64_t n,
+                              int is_f64, double voxel_size, void* out_pos,
+                              void* out_nrm) {
+    if (is_f64)
+        return VoxelDownSample<double>((const double*)pos, (const double*)nrm,
+                                       n, voxel_size, (double*)out_pos,
+                                       (double*)out_nrm);
+    return VoxelDownSample<float>((const float*)pos, (const float*)nrm, n,
+                                  voxel_size, (float*)out_pos, (float*)out_nrm);
+}
+
+int orc_multiscale_icp(const void* source, int64_t ns, const void* target,
+                       const void* target_normals, int64_t nt, int is_f64,
+                       int num_scales, const double* voxel_sizes,
+                       const int* max_iterations, const double* rel_fitness,
+                       const double* rel_rmse, const double* max_dists,
+                       const double* init, int kernel_method,
+                       double kernel_scale, double kernel_shape,
+                       int accumulate_double, double* out_T,
+                       double* out_fitness, double* out_rmse,
+                       int* out_converged, int* out_num_iterations,
+                       int64_t* out_correspondences, int64_t* out_num_corr,
+                       icp_callback_t cb, void* user) {
+    if (is_f64)
+        return MultiScaleICP<double>(
+                (const double*)source, ns, (const double*)target,
+                (const double*)target_normals, nt, num_scales, voxel_sizes,
+                max_iterations, rel_fitness, rel_rmse, max_dists, init,
+                kernel_method, kernel_scale, kernel_shape, accumulate_double,
+                out_T, out_fitness, out_rmse, out_converged,
+                out_num_iterations, out_correspondences, out_num_corr, cb,
+                user);
+    return MultiScaleICP<float>(
+            (const float*)source, ns, (const float*)target,
+            (const float*)target_normals, nt, num_scales, voxel_sizes,
+            max_iterations, rel_fitness, rel_rmse, max_dists, init,
+            kernel_method, kernel_scale, kernel_shape, accumulate_double, out_T,
+            out_fitness, out_rmse, out_converged, out_num_iterations,
+            out_correspondences, out_num_corr, cb, user);
+}
+
+}  // extern "C"

@@ -1,0 +1,396 @@
+"""ctypes binding of oracle/libo3d_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+this module. The product package (open3d_amd/) never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ORACLE_DIR = os.path.join(_ROOT, "oracle")
+_SO = os.path.join(_ORACLE_DIR, "libo3d_oracle.so")
+
+_lib = None
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int)
+c_fp = C.POINTER(C.c_float)
+c_vp = C.c_void_p
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _ORACLE_DIR, "libo3d_oracle.so"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        srcs = [os.path.join(_ORACLE_DIR, f) for f in
+                ("vbg_oracle.cpp", "icp_oracle.cpp", "oracle_common.h")]
+        if (not os.path.exists(_SO)) or any(
+                os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_SO)
+                for s in srcs):
+            build()
+        _lib = C.CDLL(_SO)
+        L = _lib
+        L.orc_depth_touch.restype = C.c_int64
+        L.orc_pointcloud_touch.restype = C.c_int64
+        L.orc_hash_create.restype = c_vp
+        L.orc_hash_size.restype = C.c_int64
+        L.orc_hash_capacity.restype = C.c_int64
+        L.orc_hash_key_buffer.restype = c_vp
+        L.orc_hash_active_indices.restype = C.c_int64
+        L.orc_unproject.restype = C.c_int64
+        L.orc_robust_weight.restype = C.c_double
+        L.orc_p2plane_rmse.restype = C.c_double
+        L.orc_voxel_down_sample.restype = C.c_int64
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(c_vp)
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def set_threads(n):
+    lib().orc_set_threads(C.c_int(int(n)))
+
+
+def max_threads():
+    return int(lib().orc_max_threads())
+
+
+def inverse_transformation(T):
+    T = _f64(T)
+    out = np.zeros((4, 4), np.float64)
+    lib().orc_inverse_transformation(_p(T), _p(out))
+    return out
+
+
+def depth_touch(depth, K, T, resolution, voxel_size, sdf_trunc, depth_scale,
+                depth_max, stride=4):
+    depth = np.ascontiguousarray(depth)
+    is_f32 = int(depth.dtype == np.float32)
+    rows, cols = depth.shape[:2]
+    cap = (rows // stride) * (cols // stride) * 4 + 16
+    out = np.zeros((cap, 3), np.int32)
+    K, T = _f64(K), _f64(T)
+    n = lib().orc_depth_touch(_p(depth), is_f32, rows, cols, _p(K), _p(T),
+                              int(resolution), C.c_float(voxel_size),
+                              C.c_float(sdf_trunc), C.c_float(depth_scale),
+                              C.c_float(depth_max), int(stride), _p(out),
+                              C.c_int64(cap))
+    return out[:n].copy()
+
+
+def pointcloud_touch(points, resolution, voxel_size, sdf_trunc):
+    points = np.ascontiguousarray(points, dtype=np.float32)
+    n = points.shape[0]
+    cap = n * 27 + 16
+    out = np.zeros((cap, 3), np.int32)
+    m = lib().orc_pointcloud_touch(_p(points), C.c_int64(n), int(resolution),
+                                   C.c_float(voxel_size), C.c_float(sdf_trunc),
+                                   _p(out), C.c_int64(cap))
+    return out[:m].copy()
+
+
+class HashMap:
+    """Insert-if-absent map int3 -> buf_index with heap-ordered indices."""
+
+    def __init__(self, capacity):
+        self.h = c_vp(lib().orc_hash_create(C.c_int64(int(capacity))))
+        self.capacity = int(capacity)
+
+    def __del__(self):
+        try:
+            lib().orc_hash_destroy(self.h)
+        except Exception:
+            pass
+
+    def size(self):
+        return int(lib().orc_hash_size(self.h))
+
+    def activate(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.int32)
+        n = keys.shape[0]
+        buf = np.zeros(n, np.int32)
+        masks = np.zeros(n, np.uint8)
+        st = lib().orc_hash_activate(self.h, _p(keys), C.c_int64(n), _p(buf),
+                                     _p(masks))
+        if st != 0:
+            raise RuntimeError("oracle hash map capacity exceeded")
+        return buf, masks.astype(bool)
+
+    def find(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.int32)
+        n = keys.shape[0]
+        buf = np.zeros(n, np.int32)
+        masks = np.zeros(n, np.uint8)
+        lib().orc_hash_find(self.h, _p(keys), C.c_int64(n), _p(buf), _p(masks))
+        return buf, masks.astype(bool)
+
+    def key_buffer(self):
+        ptr = lib().orc_hash_key_buffer(self.h)
+        arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int32)),
+                                    shape=(self.capacity, 3))
+        return arr
+
+    def active_indices(self):
+        out = np.zeros(self.size(), np.int32)
+        lib().orc_hash_active_indices(self.h, _p(out))
+        return out
+
+
+def integrate(depth, color, indices, block_keys, tsdf, weight, color_buf, K_d,
+              K_c, T, resolution, voxel_size, sdf_trunc, depth_scale,
+              depth_max):
+    """In-place on tsdf / weight / color_buf (numpy arrays)."""
+    depth = np.ascontiguousarray(depth)
+    input_is_f32 = int(depth.dtype == np.float32)
+    grid_is_f32 = int(weight.dtype == np.float32)
+    if color is not None and color.size > 0:
+        color = np.ascontiguousarray(color)
+        assert color.dtype == (np.float32 if input_is_f32 else np.uint8)
+        crow, ccol = color.shape[:2]
+    else:
+        color, crow, ccol = None, 0, 0
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    block_keys = np.ascontiguousarray(block_keys, dtype=np.int32)
+    assert tsdf.dtype == np.float32 and tsdf.flags.c_contiguous
+    assert weight.flags.c_contiguous
+    K_d, K_c, T = _f64(K_d), _f64(K_c), _f64(T)
+    lib().orc_integrate(_p(depth), depth.shape[0], depth.shape[1], _p(color),
+                        crow, ccol, input_is_f32, _p(indices),
+                        C.c_int64(indices.shape[0]), _p(block_keys), _p(tsdf),
+                        _p(weight), _p(color_buf), grid_is_f32, _p(K_d),
+                        _p(K_c), _p(T), int(resolution), C.c_float(voxel_size),
+                        C.c_float(sdf_trunc), C.c_float(depth_scale),
+                        C.c_float(depth_max))
+
+
+def estimate_range(block_keys, K, T, h, w, down_factor, block_resolution,
+                   voxel_size, depth_min, depth_max, frag_buffer_size=0):
+    block_keys = np.ascontiguousarray(block_keys, dtype=np.int32)
+    out = np.zeros((h // down_factor, w // down_factor, 2), np.float32)
+    K, T = _f64(K), _f64(T)
+    needed = lib().orc_estimate_range(
+            _p(block_keys), C.c_int64(block_keys.shape[0]), _p(out), _p(K),
+            _p(T), int(h), int(w), int(down_factor),
+            C.c_int64(block_resolution), C.c_float(voxel_size),
+            C.c_float(depth_min), C.c_float(depth_max), int(frag_buffer_size))
+    return out, int(needed)
+
+
+def raycast(hashmap, tsdf, weight, color_buf, range_map, K, T, h, w,
+            block_resolution, voxel_size, depth_scale, depth_min, depth_max,
+            weight_threshold, trunc_voxel_multiplier, range_map_down_factor,
+            attrs=("depth", "color")):
+    grid_is_f32 = int(weight.dtype == np.float32)
+    K, T = _f64(K), _f64(T)
+    shapes = {"depth": (1, np.float32), "vertex": (3, np.float32),
+              "color": (3, np.float32), "normal": (3, np.float32),
+              "index": (8, np.int64), "mask": (8, np.uint8),
+              "interp_ratio": (8, np.float32),
+              "interp_ratio_dx": (8, np.float32),
+              "interp_ratio_dy": (8, np.float32),
+              "interp_ratio_dz": (8, np.float32)}
+    out = {}
+    for a in attrs:
+        c, dt = shapes[a]
+        # Garbage-fill to make sure the kernel initialises every pixel.
+        out[a] = np.full((h, w, c), 77, dt)
+    g = lambda a: _p(out[a]) if a in out else None
+    range_map = np.ascontiguousarray(range_map, dtype=np.float32)
+    lib().orc_raycast(hashmap.h, _p(tsdf), _p(weight), _p(color_buf),
+                      grid_is_f32, _p(range_map), g("depth"), g("vertex"),
+                      g("color"), g("normal"), g("index"), g("mask"),
+                      g("interp_ratio"), g("interp_ratio_dx"),
+                      g("interp_ratio_dy"), g("interp_ratio_dz"), _p(K), _p(T),
+                      int(h), int(w), int(block_resolution),
+                      C.c_float(voxel_size), C.c_float(depth_scale),
+                      C.c_float(depth_min), C.c_float(depth_max),
+                      C.c_float(weight_threshold),
+                      C.c_float(trunc_voxel_multiplier),
+                      int(range_map_down_factor))
+    if "mask" in out:
+        out["mask"] = out["mask"].astype(bool)
+    return out
+
+
+def unproject(depth, colors_f32, K, T, depth_scale, depth_max, stride=1):
+    depth = np.ascontiguousarray(depth)
+    is_f32 = int(depth.dtype == np.float32)
+    rows, cols = depth.shape[:2]
+    n = (rows // stride) * (cols // stride)
+    pts = np.zeros((n, 3), np.float32)
+    cols_out = None
+    if colors_f32 is not None:
+        colors_f32 = np.ascontiguousarray(colors_f32, dtype=np.float32)
+        cols_out = np.zeros((n, 3), np.float32)
+    K, T = _f64(K), _f64(T)
+    m = lib().orc_unproject(_p(depth), is_f32, rows, cols, _p(colors_f32),
+                            _p(pts), _p(cols_out), _p(K), _p(T),
+                            C.c_float(depth_scale), C.c_float(depth_max),
+                            C.c_int64(stride))
+    if cols_out is None:
+        return pts[:m].copy(), None
+    return pts[:m].copy(), cols_out[:m].copy()
+
+
+# ---------------------------------------------------------------- ICP side --
+def robust_weight(method, scaling, shape, residual, f64=False):
+    return float(lib().orc_robust_weight(int(f64), int(method),
+                                         C.c_double(scaling),
+                                         C.c_double(shape),
+                                         C.c_double(residual)))
+
+
+def hybrid_search(points, queries, radius, max_knn, brute=False):
+    points = np.ascontiguousarray(points)
+    queries = np.ascontiguousarray(queries, dtype=points.dtype)
+    is_f64 = int(points.dtype == np.float64)
+    q = queries.shape[0]
+    idx = np.zeros((q, max_knn), np.int32)
+    dist = np.zeros((q, max_knn), points.dtype)
+    cnt = np.zeros(q, np.int32)
+    lib().orc_hybrid_search(_p(points), C.c_int64(points.shape[0]),
+                            _p(queries), C.c_int64(q), is_f64,
+                            C.c_double(radius), int(max_knn), int(brute),
+                            _p(idx), _p(dist), _p(cnt))
+    return idx, dist, cnt
+
+
+def p2plane_accumulate(src, tgt, tgt_n, corr, method=0, scaling=1.0, shape=1.0,
+                       accumulate_double=False):
+    src = np.ascontiguousarray(src)
+    tgt = np.ascontiguousarray(tgt, dtype=src.dtype)
+    tgt_n = np.ascontiguousarray(tgt_n, dtype=src.dtype)
+    corr = np.ascontiguousarray(corr, dtype=np.int64).reshape(-1)
+    out = np.zeros(29, np.float64)
+    lib().orc_p2plane_accumulate(_p(src), _p(tgt), _p(tgt_n), _p(corr),
+                                 C.c_int64(src.shape[0]),
+                                 int(src.dtype == np.float64), int(method),
+                                 C.c_double(scaling), C.c_double(shape),
+                                 int(accumulate_double), _p(out))
+    return out
+
+
+def decode_and_solve6x6(A29):
+    A29 = _f64(A29)
+    pose = np.zeros(6, np.float64)
+    residual = C.c_float(0)
+    count = C.c_int(0)
+    st = lib().orc_decode_and_solve6x6(_p(A29), _p(pose), C.byref(residual),
+                                       C.byref(count))
+    return st, pose, residual.value, count.value
+
+
+def solve(A, b):
+    A, b = _f64(A), _f64(b)
+    n = A.shape[0]
+    x = np.zeros(n, np.float64)
+    st = lib().orc_solve(int(n), _p(A), _p(b), _p(x))
+    if st != 0:
+        raise RuntimeError("singular matrix")
+    return x
+
+
+def pose_to_transformation(pose):
+    pose = _f64(pose)
+    T = np.zeros((4, 4), np.float64)
+    lib().orc_pose_to_transformation(_p(pose), _p(T))
+    return T
+
+
+def transform_points(T, pts):
+    """Returns a transformed copy."""
+    T = _f64(T)
+    pts = np.array(pts, copy=True, order="C")
+    lib().orc_transform_points(_p(T), _p(pts), C.c_int64(pts.shape[0]),
+                               int(pts.dtype == np.float64))
+    return pts
+
+
+def transform_normals(T, nrm):
+    T = _f64(T)
+    nrm = np.array(nrm, copy=True, order="C")
+    lib().orc_transform_normals(_p(T), _p(nrm), C.c_int64(nrm.shape[0]),
+                                int(nrm.dtype == np.float64))
+    return nrm
+
+
+def p2plane_rmse(src, tgt, tgt_n, corr):
+    src = np.ascontiguousarray(src)
+    tgt = np.ascontiguousarray(tgt, dtype=src.dtype)
+    tgt_n = np.ascontiguousarray(tgt_n, dtype=src.dtype)
+    corr = np.ascontiguousarray(corr, dtype=np.int64).reshape(-1)
+    return float(lib().orc_p2plane_rmse(_p(src), _p(tgt), _p(tgt_n), _p(corr),
+                                        C.c_int64(src.shape[0]),
+                                        int(src.dtype == np.float64)))
+
+
+def voxel_down_sample(pos, nrm, voxel_size):
+    pos = np.ascontiguousarray(pos)
+    n = pos.shape[0]
+    op = np.zeros_like(pos)
+    if nrm is not None:
+        nrm = np.ascontiguousarray(nrm, dtype=pos.dtype)
+        on = np.zeros_like(pos)
+    else:
+        on = None
+    m = lib().orc_voxel_down_sample(_p(pos), _p(nrm), C.c_int64(n),
+                                    int(pos.dtype == np.float64),
+                                    C.c_double(voxel_size), _p(op), _p(on))
+    return op[:m].copy(), (None if on is None else on[:m].copy())
+
+
+ICP_CB = C.CFUNCTYPE(None, C.c_int64, C.c_int64, C.c_int64, C.c_double,
+                     C.c_double, c_dp, c_vp)
+
+
+def multiscale_icp(source, target, target_normals, voxel_sizes, criterias,
+                   max_dists, init=None, kernel=(0, 1.0, 1.0),
+                   accumulate_double=False, callback=None):
+    """criterias: list of (relative_fitness, relative_rmse, max_iteration)."""
+    source = np.ascontiguousarray(source)
+    dt = source.dtype
+    target = np.ascontiguousarray(target, dtype=dt)
+    target_normals = np.ascontiguousarray(target_normals, dtype=dt)
+    ns, nt = source.shape[0], target.shape[0]
+    S = len(criterias)
+    vs = _f64(voxel_sizes)
+    mi = np.ascontiguousarray([c[2] for c in criterias], dtype=np.int32)
+    rf = _f64([c[0] for c in criterias])
+    rr = _f64([c[1] for c in criterias])
+    md = _f64(max_dists)
+    init = _f64(np.eye(4) if init is None else init)
+    T = np.zeros((4, 4), np.float64)
+    fit, rmse = C.c_double(0), C.c_double(0)
+    conv, nit = C.c_int(0), C.c_int(0)
+    corr = np.full(ns, -1, np.int64)
+    ncorr = C.c_int64(0)
+    cb = ICP_CB(0)
+    if callback is not None:
+        def _cb(it, sc, sit, r, f, Tp, user):
+            callback(dict(iteration_index=it, scale_index=sc,
+                          scale_iteration_index=sit, inlier_rmse=r, fitness=f,
+                          transformation=np.ctypeslib.as_array(
+                                  Tp, shape=(16,)).reshape(4, 4).copy()))
+        cb = ICP_CB(_cb)
+    st = lib().orc_multiscale_icp(
+            _p(source), C.c_int64(ns), _p(target), _p(target_normals),
+            C.c_int64(nt), int(dt == np.float64), int(S), _p(vs), _p(mi),
+            _p(rf), _p(rr), _p(md), _p(init), int(kernel[0]),
+            C.c_double(kernel[1]), C.c_double(kernel[2]),
+            int(accumulate_double), _p(T), C.byref(fit), C.byref(rmse),
+            C.byref(conv), C.byref(nit), _p(corr), C.byref(ncorr), cb, None)
+    return dict(status=st, transformation=T, fitness=fit.value,
+                inlier_rmse=rmse.value, converged=bool(conv.value),
+                num_iterations=nit.value,
+                correspondences=corr[:ncorr.value].copy())
