@@ -1,0 +1,221 @@
+#!/usr/bin/env python
+"""bench.py -- RGB-D frames/s of the MI355X dense-SLAM hot path.
+
+Workload at N=1 (BASELINE.json configs[1]): synthetic 640x480 RGB-D frames with
+known poses integrated into an 8 mm / 16^3-block VoxelBlockGrid (tsdf f32,
+weight u16, colour u16 -- the slam::Model layout) on one MI355X: per frame
+block touch + hash activation + per-voxel TSDF/weight/colour update.
+A "step" is one batch of `--batch` frames; frames are resident in HBM before
+the timed region starts. With --gpus N every rank integrates its own shard of
+the stream (frames r, r+N, ...) into a private grid (weak scaling, no data-path
+collective); the activated block IDs are all-gathered over RCCL once, inside
+the timed region, as the closing exchange step.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+`roofline` (Integrate kernel: algorithmic bytes / HIP-event kernel time vs the
+8 TB/s HBM peak) and `cpu_baseline` (the CPU oracle -- a port of Open3D's CPU
+tensor path -- timed on this host's cores on a bounded sample of the same
+workload, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+VOXEL = 0.008
+RES = 16
+TRUNC = 8.0
+DEPTH_SCALE = 1000.0
+DEPTH_MAX = 3.0
+W, H = 640, 480
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+# u16 grid with colour, read+write per voxel
+BYTES_PER_BLOCK = 4096 * 24
+IMAGE_BYTES = W * H * 2 + W * H * 3
+BLOCK_HEADER_BYTES = 16  # buf index + key
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=50,
+                    help="frames per step (per GPU)")
+    ap.add_argument("--block-count", type=int, default=131072)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(frames_cpu, K, Ts, budget_s):
+    """Oracle (port of the reference CPU path) on a bounded sample: touch +
+    activate + integrate of the first frames of the same stream, all host
+    threads (OpenMP stand-in for TBB's parallel_for)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as orc
+    cores = os.cpu_count() or 1
+    orc.set_threads(cores)
+    cap = 16384
+    h = orc.HashMap(cap)
+    tsdf = np.zeros((cap, RES, RES, RES), np.float32)
+    wgt = np.zeros((cap, RES, RES, RES), np.uint16)
+    col = np.zeros((cap, RES, RES, RES, 3), np.uint16)
+    n = 0
+    t0 = time.perf_counter()
+    for (d, c), T in zip(frames_cpu, Ts):
+        keys = orc.depth_touch(d, K, T, RES, VOXEL, VOXEL * TRUNC, DEPTH_SCALE,
+                               DEPTH_MAX)
+        h.activate(keys)
+        buf, _ = h.find(keys)
+        orc.integrate(d, c, buf, h.key_buffer(), tsdf, wgt, col, K, K, T, RES,
+                      VOXEL, VOXEL * TRUNC, DEPTH_SCALE, DEPTH_MAX)
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": cores,
+            "kind": "port",
+            "sample": "first %d frames of the same 640x480 stream "
+                      "(touch+activate+integrate, u16 grid with colour), "
+                      "%.1f s wall" % (n, dt)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    import __graft_entry__ as ge
+    if rank == 0 and not os.path.exists(
+            os.path.join(ROOT, "open3d_amd", "lib", "libo3d_mi355x.so")):
+        ge.build()
+    if dist is not None:
+        dist.barrier()
+    from open3d_amd import geometry, synthetic
+    from open3d_amd.sharding import allgather_block_keys
+
+    n_steps = a.steps + a.warmup
+    n_local = n_steps * a.batch
+    # Frame-sharded stream: rank r owns global frames r, r+world, ...
+    frame_ids = [rank + world * i for i in range(n_local)]
+    K = synthetic.intrinsics(W, H)
+    depths, colors, Ts = [], [], []
+    for i0 in range(0, n_local, 25):
+        ids = frame_ids[i0:i0 + 25]
+        for k in ids:
+            d, c, _, T = synthetic.render_frames(k, 1, W, H, device=dev)
+            depths.append(d[0].contiguous())
+            colors.append(c[0].contiguous())
+            Ts.append(T[0])
+    torch.cuda.synchronize()
+
+    g = geometry.VoxelBlockGrid(["tsdf", "weight", "color"],
+                                [torch.float32, torch.uint16, torch.uint16],
+                                [1, 1, 3], VOXEL, RES, a.block_count)
+
+    def run_step(s):
+        for j in range(a.batch):
+            i = s * a.batch + j
+            g.integrate_frame(depths[i], colors[i], K, K, Ts[i], DEPTH_SCALE,
+                              DEPTH_MAX, TRUNC)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for s in range(a.warmup):
+        run_step(s)
+    torch.cuda.synchronize()
+    barrier()
+
+    g.profile_begin(a.steps * a.batch)
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(a.warmup, n_steps):
+        run_step(s)
+    n_union = None
+    if dist is not None:
+        hm = g.hashmap()
+        act = hm.active_buf_indices()
+        keys = hm.key_tensor()[act.long()]
+        n_union = int(allgather_block_keys(keys, dist).shape[0])
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    prof = g.profile_end()
+    n_blocks = g.hashmap().size()
+
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    total_frames = a.steps * a.batch * world
+    fps = total_frames / elapsed
+
+    launches = max(1, prof["launches"])
+    alg_bytes = (prof["block_frames"] * (BYTES_PER_BLOCK + BLOCK_HEADER_BYTES)
+                 + launches * IMAGE_BYTES) / launches
+    k_ms = prof["integrate_ms"] / launches
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+
+    out = {
+        "metric": "RGB-D frames/s (TSDF integrate into 8 mm / 16^3 "
+                  "VoxelBlockGrid: touch + activate + integrate)",
+        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: %d synthetic 640x480 RGB-D frames "
+                               "per GPU -> 8 mm VoxelBlockGrid(16^3), grid "
+                               "(tsdf f32, weight u16, color u16), known poses"
+                               % (a.steps * a.batch),
+                   "frames_per_step": a.batch, "block_count": a.block_count,
+                   "active_blocks": int(n_blocks),
+                   "avg_blocks_per_frame": prof["block_frames"] / launches,
+                   "sharding": "frames r, r+N, ... per rank; block-ID "
+                               "all-gather at the end" if world > 1 else "none",
+                   "union_blocks": n_union},
+        "roofline": {"bound": "hbm", "kernel": "IntegrateQuadKernel",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "avg_kernel_ms": k_ms,
+                     "avg_touch_ms": prof["touch_ms"] / launches},
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        nb = 64
+        frames_cpu = [(depths[i].cpu().numpy(), colors[i].cpu().numpy())
+                      for i in range(min(nb, len(depths)))]
+        out["cpu_baseline"] = cpu_baseline(frames_cpu, K, Ts, a.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,298 @@
+/* o3d_mi355x.h -- C ABI of the MI355X (gfx950) backend for Open3D's tensor
+ * dense-SLAM hot path: point-to-plane ICP (fixed-radius correspondence search
+ * + 6x6 Gauss-Newton reduction) and VoxelBlockGrid TSDF integration /
+ * ray-casting over spatially hashed voxel blocks.
+ *
+ * The entry points sit exactly where Open3D's per-device kernels sit: each
+ * `o3dmi_*` kernel function replaces one `...CUDA(...)` function that the
+ * device dispatchers in cpp/open3d/t/{geometry,pipelines}/kernel/ *.cpp and
+ * cpp/open3d/core/{nns,hashmap} call (file:line cited per function, relative
+ * to the Open3D source tree). INTEGRATION.md shows the `...HIP` branch a
+ * maintainer adds to each dispatcher.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer named *_dev is device (HBM)
+ *    memory of the current HIP device; K (3x3) and T (4x4) are host, row-major
+ *    double -- the same placement Open3D enforces (t/geometry/Utility.h
+ *    CheckIntrinsicTensor / CheckExtrinsicTensor);
+ *  - tensors are contiguous row-major with Open3D's layouts: positions/normals
+ *    {N,3}, images {H,W,C}, block keys {M,3} int32, voxel values
+ *    {capacity,res,res,res,C} (x fastest; GeometryIndexer.h:244-249);
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
+ *    functions return without synchronising unless stated;
+ *  - return value: 0 = O3DMI_OK, otherwise an o3dmi_status_t; nothing throws.
+ *    o3dmi_last_error() gives a thread-local message.
+ *  - arithmetic is IEEE float32 without FMA contraction and with correctly
+ *    rounded division/sqrt so that results match Open3D's CPU tensor path.
+ */
+#ifndef O3D_MI355X_H_
+#define O3D_MI355X_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define O3DMI_ABI_VERSION 1
+
+typedef enum {
+    O3DMI_OK = 0,
+    O3DMI_ERR_INVALID_ARG = 1,
+    O3DMI_ERR_HIP = 2,          /* a HIP runtime call failed               */
+    O3DMI_ERR_CAPACITY = 3,     /* output buffer / hash capacity too small */
+    O3DMI_ERR_KEY_RANGE = 4,    /* |block coordinate| >= 2^20              */
+    O3DMI_ERR_SINGULAR = 5,     /* singular 6x6 system                     */
+    O3DMI_ERR_NO_BLOCKS = 6,    /* "No block is touched in TSDF volume"    */
+    O3DMI_ERR_UNSUPPORTED = 7
+} o3dmi_status_t;
+
+typedef enum {
+    O3DMI_F32 = 0,
+    O3DMI_F64 = 1,
+    O3DMI_U16 = 2,
+    O3DMI_U8 = 3,
+    O3DMI_I32 = 4,
+    O3DMI_I64 = 5
+} o3dmi_dtype_t;
+
+/* RobustKernelMethod, t/pipelines/registration/RobustKernel.h:15-23 */
+typedef enum {
+    O3DMI_L2_LOSS = 0,
+    O3DMI_L1_LOSS = 1,
+    O3DMI_HUBER_LOSS = 2,
+    O3DMI_CAUCHY_LOSS = 3,
+    O3DMI_GM_LOSS = 4,
+    O3DMI_TUKEY_LOSS = 5,
+    O3DMI_GENERALIZED_LOSS = 6
+} o3dmi_robust_kernel_t;
+
+typedef void* o3dmi_stream_t;
+
+int o3dmi_abi_version(void);
+const char* o3dmi_status_string(int status);
+const char* o3dmi_last_error(void);
+/* Fills `name` with the gcnArchName of the current device; fails with
+ * O3DMI_ERR_HIP when no HIP device is usable. */
+int o3dmi_device_info(char* name, size_t name_len, int* cu_count,
+                      int64_t* hbm_bytes);
+
+/* ------------------------------------------------------------------------ */
+/* Spatial hash of int32x3 block keys -> buffer indices.                     */
+/* Replaces a DeviceHashBackend (core/hashmap/DeviceHashBackend.h:20-107;    */
+/* CUDA: core/hashmap/CUDA/StdGPUHashBackend.h:178-209,305-383) for          */
+/* key dtype Int32, key shape {3}. Owns the key buffer {capacity,3} and      */
+/* `n_values` value buffers of `value_dsizes[i]` bytes per entry, zero       */
+/* filled at allocation (CPUHashBackendBufferAccessor.hpp:30-37).            */
+/* buf_indices are NOT guaranteed dense after Erase.                         */
+/* ------------------------------------------------------------------------ */
+typedef struct o3dmi_hash o3dmi_hash_t;
+
+int o3dmi_hash_create(int64_t capacity, int n_values,
+                      const int64_t* value_dsizes, o3dmi_stream_t stream,
+                      o3dmi_hash_t** out);
+int o3dmi_hash_destroy(o3dmi_hash_t* h);
+/* DeviceHashBackend::Clear */
+int o3dmi_hash_clear(o3dmi_hash_t* h, o3dmi_stream_t stream);
+/* DeviceHashBackend::Insert with no values (HashMap::Activate,
+ * core/hashmap/HashMap.cpp:166-181). Per key i: masks[i] = 1 and
+ * buf_indices[i] = new index for exactly one of the duplicates of a new key;
+ * otherwise masks[i] = 0, buf_indices[i] = 0 (TBBHashBackend.h:203-247).
+ * `n_dev` (optional, may be NULL) is a device int32 holding the live count
+ * (<= n); when given, only the first *n_dev keys are processed.
+ * Caller guarantees size + n <= capacity (HashMap::Activate reserves first). */
+int o3dmi_hash_activate(o3dmi_hash_t* h, const int32_t* keys_dev, int64_t n,
+                        const int32_t* n_dev, int32_t* buf_indices_dev,
+                        uint8_t* masks_dev, o3dmi_stream_t stream);
+/* DeviceHashBackend::Insert with values: value i of the winner of key k is
+ * copied from values_soa_dev[j] + k * value_dsizes[j]. */
+int o3dmi_hash_insert(o3dmi_hash_t* h, const int32_t* keys_dev,
+                      const void* const* values_soa_dev, int64_t n,
+                      int32_t* buf_indices_dev, uint8_t* masks_dev,
+                      o3dmi_stream_t stream);
+/* DeviceHashBackend::Find */
+int o3dmi_hash_find(o3dmi_hash_t* h, const int32_t* keys_dev, int64_t n,
+                    const int32_t* n_dev, int32_t* buf_indices_dev,
+                    uint8_t* masks_dev, o3dmi_stream_t stream);
+/* DeviceHashBackend::Erase */
+int o3dmi_hash_erase(o3dmi_hash_t* h, const int32_t* keys_dev, int64_t n,
+                     uint8_t* masks_dev, o3dmi_stream_t stream);
+/* DeviceHashBackend::Size -- synchronises `stream`. Also surfaces deferred
+ * device-side errors (key range / capacity). */
+int o3dmi_hash_size(o3dmi_hash_t* h, o3dmi_stream_t stream, int64_t* size);
+int64_t o3dmi_hash_capacity(const o3dmi_hash_t* h);
+int64_t o3dmi_hash_bucket_count(const o3dmi_hash_t* h);
+/* DeviceHashBackend::GetActiveIndices: writes Size() indices (unordered);
+ * out_dev must hold `capacity` entries; count returned on the host
+ * (synchronises). */
+int o3dmi_hash_active_indices(o3dmi_hash_t* h, int32_t* out_dev,
+                              o3dmi_stream_t stream, int64_t* count);
+/* HashMap::Reserve (core/hashmap/HashMap.cpp:47-77): export active
+ * key/values, reallocate at `capacity`, re-insert. buf_indices change. */
+int o3dmi_hash_reserve(o3dmi_hash_t* h, int64_t capacity,
+                       o3dmi_stream_t stream);
+/* HashMap::GetKeyTensor / GetValueTensor(i) storage. */
+int32_t* o3dmi_hash_key_buffer(o3dmi_hash_t* h);
+void* o3dmi_hash_value_buffer(o3dmi_hash_t* h, int i);
+
+/* ------------------------------------------------------------------------ */
+/* VoxelBlockGrid kernels (t/geometry/kernel/VoxelBlockGrid.h:338-410).      */
+/* ------------------------------------------------------------------------ */
+
+/* DepthTouchCUDA (t/geometry/kernel/VoxelBlockGridCUDA.cu:106-227): every
+ * `stride`-th pixel with 0 < d < depth_max emits floor((o + t*dir)/block_size)
+ * at 4 samples t in [max(d-trunc,0), min(d+trunc,depth_max)]; the unique set
+ * is written to out_coords_dev ({out_capacity,3} int32, order unspecified)
+ * and its size to *out_count_dev (device int32). `frustum_hash` is scratch
+ * (capacity >= (rows/stride)*(cols/stride)*4) and is cleared here.
+ * depth_dtype: O3DMI_U16 or O3DMI_F32. Asynchronous. */
+int o3dmi_vbg_depth_touch(o3dmi_hash_t* frustum_hash, const void* depth_dev,
+                          int depth_dtype, int rows, int cols,
+                          const double* intrinsic, const double* extrinsic,
+                          int32_t* out_coords_dev, int64_t out_capacity,
+                          int32_t* out_count_dev, int resolution,
+                          float voxel_size, float sdf_trunc, float depth_scale,
+                          float depth_max, int stride, o3dmi_stream_t stream);
+
+/* PointCloudTouchCUDA (VoxelBlockGridCUDA.cu:42-104): blocks within
+ * +-sdf_trunc of each point. frustum_hash capacity >= n*8 (the reference's
+ * estimate); overflow reports O3DMI_ERR_CAPACITY at the next size query. */
+int o3dmi_vbg_pointcloud_touch(o3dmi_hash_t* frustum_hash,
+                               const float* points_dev, int64_t n,
+                               int32_t* out_coords_dev, int64_t out_capacity,
+                               int32_t* out_count_dev, int resolution,
+                               float voxel_size, float sdf_trunc,
+                               o3dmi_stream_t stream);
+
+/* IntegrateCUDA<input_depth_t,input_color_t,tsdf_t,weight_t,color_t>
+ * (t/geometry/kernel/VoxelBlockGridImpl.h:151-308). input_dtype: O3DMI_U16
+ * (u16 depth + u8 colour) or O3DMI_F32 (f32 depth + f32 colour in [0,1]);
+ * grid_dtype: O3DMI_U16 (f32 tsdf, u16 weight, u16 colour) or O3DMI_F32.
+ * color_dev / color_buf_dev may be NULL (depth-only). `n_indices_dev`
+ * optional device-side count as in o3dmi_hash_activate. Asynchronous. */
+int o3dmi_vbg_integrate(const void* depth_dev, int depth_rows, int depth_cols,
+                        const void* color_dev, int color_rows, int color_cols,
+                        int input_dtype, const int32_t* indices_dev,
+                        int64_t n_indices, const int32_t* n_indices_dev,
+                        const int32_t* block_keys_dev, float* tsdf_dev,
+                        void* weight_dev, void* color_buf_dev, int grid_dtype,
+                        const double* depth_intrinsic,
+                        const double* color_intrinsic, const double* extrinsic,
+                        int resolution, float voxel_size, float sdf_trunc,
+                        float depth_scale, float depth_max,
+                        o3dmi_stream_t stream);
+
+/* Fused per-frame front end used by the frame-stream fast path: DepthTouch
+ * candidates are activated directly in `block_hash` and the frame's unique
+ * buffer indices are emitted (device-resident, no host round trip). Result
+ * (set of activated keys, set of per-frame indices) is identical to
+ * DepthTouch -> Activate -> Find. `frame_stamp` must increase by one per call
+ * on a given hash. */
+int o3dmi_vbg_touch_activate(o3dmi_hash_t* block_hash, const void* depth_dev,
+                             int depth_dtype, int rows, int cols,
+                             const double* intrinsic, const double* extrinsic,
+                             int32_t* out_buf_indices_dev,
+                             int64_t out_capacity, int32_t* out_count_dev,
+                             int resolution, float voxel_size, float sdf_trunc,
+                             float depth_scale, float depth_max, int stride,
+                             int32_t frame_stamp, o3dmi_stream_t stream);
+
+/* EstimateRangeCUDA (VoxelBlockGridImpl.h:310-555): range_minmax_map_dev is
+ * {h/down, w/down, 2} float32 (min,max). No fragment buffer is needed; the
+ * result equals the reference's when its fragment buffer does not overflow. */
+int o3dmi_vbg_estimate_range(const int32_t* block_keys_dev, int64_t n_blocks,
+                             float* range_minmax_map_dev,
+                             const double* intrinsic, const double* extrinsic,
+                             int h, int w, int down_factor,
+                             int64_t block_resolution, float voxel_size,
+                             float depth_min, float depth_max,
+                             o3dmi_stream_t stream);
+
+/* RayCastCUDA<tsdf_t,weight_t,color_t> (VoxelBlockGridImpl.h:578-1120).
+ * Output maps may be NULL when not requested: depth {h,w,1}, vertex/color/
+ * normal {h,w,3} float32; index {h,w,8} int64; mask {h,w,8} bool;
+ * interp_ratio{,_dx,_dy,_dz} {h,w,8} float32. */
+int o3dmi_vbg_raycast(o3dmi_hash_t* block_hash, const float* tsdf_dev,
+                      const void* weight_dev, const void* color_buf_dev,
+                      int grid_dtype, const float* range_map_dev,
+                      float* out_depth, float* out_vertex, float* out_color,
+                      float* out_normal, int64_t* out_index, uint8_t* out_mask,
+                      float* out_ratio, float* out_ratio_dx,
+                      float* out_ratio_dy, float* out_ratio_dz,
+                      const double* intrinsic, const double* extrinsic, int h,
+                      int w, int block_resolution, float voxel_size,
+                      float depth_scale, float depth_min, float depth_max,
+                      float weight_threshold, float trunc_voxel_multiplier,
+                      int range_map_down_factor, o3dmi_stream_t stream);
+
+/* UnprojectCUDA (t/geometry/kernel/PointCloudImpl.h:42-143): strided depth ->
+ * compacted world points (order unspecified). points_dev holds
+ * (rows/stride)*(cols/stride) x 3 floats; count to *out_count_dev. */
+int o3dmi_unproject(const void* depth_dev, int depth_dtype, int rows, int cols,
+                    const float* image_colors_dev, float* points_dev,
+                    float* colors_dev, int32_t* out_count_dev,
+                    const double* intrinsic, const double* extrinsic,
+                    float depth_scale, float depth_max, int64_t stride,
+                    o3dmi_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* ICP kernels.                                                              */
+/* ------------------------------------------------------------------------ */
+
+/* Fixed-radius index (core/nns/FixedRadiusIndex.h:227-233,364-377;
+ * BuildSpatialHashTableCUDA / HybridSearchCUDA, FixedRadiusSearchOps.cu:
+ * 20-57). Results follow the CPU path's nanoflann semantics
+ * (core/nns/NanoFlannImpl.h:305-370): neighbours with d2 < r2 (strict),
+ * nearest first, ties by lower index. dtype O3DMI_F32 or O3DMI_F64. */
+typedef struct o3dmi_nns o3dmi_nns_t;
+int o3dmi_nns_create(const void* points_dev, int64_t n, int dtype,
+                     double radius, o3dmi_stream_t stream, o3dmi_nns_t** out);
+int o3dmi_nns_destroy(o3dmi_nns_t* nns);
+/* HybridSearch(max_knn = 1): idx {Q} int32 (-1 when none), dist2 {Q} in the
+ * point dtype (0 when none), counts {Q} int32. */
+int o3dmi_nns_hybrid_search_k1(const o3dmi_nns_t* nns, const void* queries_dev,
+                               int64_t q, int32_t* idx_dev, void* dist2_dev,
+                               int32_t* counts_dev, o3dmi_stream_t stream);
+
+/* ComputePosePointToPlaneCUDA up to the reduction
+ * (t/pipelines/kernel/RegistrationCUDA.cu:29-117, RegistrationImpl.h:251-287):
+ * the 29 sums (21 JtJ lower-triangular row-major, 6 Jtr, sum r, count) are
+ * written to sums29_dev as float64. Per-correspondence terms are formed in the
+ * point dtype exactly as the reference; accumulation is in float64 with a
+ * fixed reduction tree (run-to-run deterministic). corr is int64, -1 = none. */
+int o3dmi_icp_p2plane_accumulate(const void* src_dev, const void* tgt_dev,
+                                 const void* tgt_normals_dev,
+                                 const int64_t* corr_dev, int64_t n, int dtype,
+                                 int robust_kernel, double scaling_parameter,
+                                 double shape_parameter, double* sums29_dev,
+                                 o3dmi_stream_t stream);
+
+/* One fused ICP iteration front end: search (k=1) + fitness/rmse sums +
+ * point-to-plane accumulation. sums32_dev (float64[32]): [0..28] as above,
+ * [29] = sum of d2 over matches (accumulated in float64), [30] = number of
+ * matches, [31] unused. corr_out_dev may be NULL. */
+int o3dmi_icp_search_accumulate(const o3dmi_nns_t* nns, const void* src_dev,
+                                const void* tgt_normals_dev, int64_t n,
+                                int robust_kernel, double scaling_parameter,
+                                double shape_parameter, int64_t* corr_out_dev,
+                                double* sums32_dev, o3dmi_stream_t stream);
+
+/* TransformPointsCUDA / TransformNormalsCUDA
+ * (t/geometry/kernel/Transform.h:42-47, TransformImpl.h:19-60): in place;
+ * `transformation` is host float64 4x4, cast to the point dtype first. */
+int o3dmi_transform_points(const double* transformation, void* points_dev,
+                           int64_t n, int dtype, o3dmi_stream_t stream);
+int o3dmi_transform_normals(const double* transformation, void* normals_dev,
+                            int64_t n, int dtype, o3dmi_stream_t stream);
+
+/* Host-side helpers with the reference's arithmetic
+ * (t/pipelines/kernel/TransformationConverter.cpp:81-104,189-226). */
+int o3dmi_decode_and_solve6x6(const double* sums29_host, double* pose6,
+                              float* residual, int* inlier_count);
+void o3dmi_pose_to_transformation(const double* pose6, double* T16);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* O3D_MI355X_H_ */

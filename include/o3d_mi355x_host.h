@@ -1,0 +1,172 @@
+/* o3d_mi355x_host.h -- host-side mirror (C++ implementation, C linkage) of the
+ * Open3D classes that drive the hot path, built on top of the kernel C ABI in
+ * o3d_mi355x.h. These are what a language binding (pybind / ctypes / cgo)
+ * calls when it wants the whole operator rather than one kernel:
+ *
+ *   o3dmi_registration_multiscale_icp  <- t::pipelines::registration::MultiScaleICP / ICP
+ *                                         (t/pipelines/registration/Registration.cpp:93-106,362-444)
+ *   o3dmi_vbg_*                        <- t::geometry::VoxelBlockGrid
+ *                                         (t/geometry/VoxelBlockGrid.cpp:65-117,212-402)
+ *
+ * Same argument meaning, defaults and error behaviour as the reference
+ * (errors are status codes + o3dmi_last_error() instead of exceptions).
+ */
+#ifndef O3D_MI355X_HOST_H_
+#define O3D_MI355X_HOST_H_
+
+#include "o3d_mi355x.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ICPConvergenceCriteria (t/pipelines/registration/Registration.h:31-58):
+ * defaults relative_fitness 1e-6, relative_rmse 1e-6, max_iteration 30. */
+typedef struct {
+    double relative_fitness;
+    double relative_rmse;
+    int max_iteration;
+} o3dmi_icp_criteria_t;
+
+/* RegistrationResult (Registration.h:61-98). */
+typedef struct {
+    double transformation[16]; /* 4x4 float64, row-major, host            */
+    double inlier_rmse;
+    double fitness;
+    int converged;
+    int num_iterations;
+    int64_t num_correspondences; /* rows written to correspondences_dev   */
+} o3dmi_registration_result_t;
+
+/* callback_after_iteration (Registration.cpp:330-345): iteration_index,
+ * scale_index, scale_iteration_index, inlier_rmse, fitness, transformation. */
+typedef void (*o3dmi_icp_callback_t)(int64_t iteration_index,
+                                     int64_t scale_index,
+                                     int64_t scale_iteration_index,
+                                     double inlier_rmse, double fitness,
+                                     const double* transformation, void* user);
+
+/* Cross-GPU hook: in-place SUM over all ranks of `n` host doubles (the 29
+ * Gauss-Newton sums, sum d2, match count and the local source-point count).
+ * NULL = single GPU. Each rank holds a shard of the source cloud and the whole
+ * target; every rank then solves the same 6x6 system. */
+typedef int (*o3dmi_allreduce_sum_t)(double* host_buf, int n, void* user);
+
+/* MultiScaleICP with TransformationEstimationPointToPlane(kernel).
+ * source/target/normals: device, {N,3}, dtype O3DMI_F32 or O3DMI_F64.
+ * voxel_sizes[i] <= 0 means "no down-sampling" for the finest level, as in
+ * the reference (Registration.cpp:233-236).
+ * correspondences_dev: optional device int64 buffer of ns entries receiving
+ * the final correspondence set of the finest scale (-1 = none).
+ * Status O3DMI_ERR_SINGULAR mirrors the reference's "Singular 6x6 linear
+ * system detected, tracking failed." exception. */
+int o3dmi_registration_multiscale_icp(
+        const void* source_dev, int64_t ns, const void* target_dev,
+        const void* target_normals_dev, int64_t nt, int dtype, int num_scales,
+        const double* voxel_sizes, const o3dmi_icp_criteria_t* criterias,
+        const double* max_correspondence_distances,
+        const double* init_source_to_target /* 4x4, may be NULL = identity */,
+        int robust_kernel, double scaling_parameter, double shape_parameter,
+        o3dmi_icp_callback_t callback, void* callback_user,
+        o3dmi_allreduce_sum_t allreduce, void* allreduce_user,
+        int64_t* correspondences_dev, o3dmi_registration_result_t* result,
+        o3dmi_stream_t stream);
+
+/* PointCloud::VoxelDownSample (t/geometry/PointCloud.cpp:496-567) for
+ * positions (+ optional normals): mean per voxel in float32, voxel order =
+ * order of first occurrence. Outputs must hold n rows; *m_out receives the
+ * number of voxels (synchronises). */
+int o3dmi_voxel_down_sample(const void* positions_dev, const void* normals_dev,
+                            int64_t n, int dtype, double voxel_size,
+                            void* out_positions_dev, void* out_normals_dev,
+                            int64_t* m_out, o3dmi_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* VoxelBlockGrid                                                            */
+/* ------------------------------------------------------------------------ */
+typedef struct o3dmi_vbg o3dmi_vbg_t;
+
+/* VoxelBlockGrid(attr_names, attr_dtypes, attr_channels, voxel_size,
+ * block_resolution, block_count) (VoxelBlockGrid.cpp:65-117). Attribute i has
+ * dtype attr_dtypes[i] (O3DMI_F32 / O3DMI_U16 / ...) and attr_channels[i]
+ * channels; "tsdf" and "weight" are required by Integrate/RayCast. */
+int o3dmi_vbg_create(int n_attrs, const char* const* attr_names,
+                     const int* attr_dtypes, const int* attr_channels,
+                     float voxel_size, int64_t block_resolution,
+                     int64_t block_count, o3dmi_stream_t stream,
+                     o3dmi_vbg_t** out);
+int o3dmi_vbg_destroy(o3dmi_vbg_t* g);
+o3dmi_hash_t* o3dmi_vbg_hashmap(o3dmi_vbg_t* g);
+/* GetAttribute(name): device pointer of the {capacity,res,res,res,C} buffer
+ * (NULL + warning semantics: returns NULL when absent). */
+void* o3dmi_vbg_attribute(o3dmi_vbg_t* g, const char* name, int* dtype,
+                          int* channels);
+
+/* GetUniqueBlockCoordinates(depth, intrinsic, extrinsic, depth_scale,
+ * depth_max, trunc_voxel_multiplier) (VoxelBlockGrid.cpp:212-245).
+ * out_coords_dev must hold (rows/4)*(cols/4)*4 rows; *m_out = number of
+ * unique blocks (synchronises; O3DMI_ERR_NO_BLOCKS when zero). */
+int o3dmi_vbg_get_unique_block_coordinates(
+        o3dmi_vbg_t* g, const void* depth_dev, int depth_dtype, int rows,
+        int cols, const double* intrinsic, const double* extrinsic,
+        float depth_scale, float depth_max, float trunc_voxel_multiplier,
+        int32_t* out_coords_dev, int64_t* m_out, o3dmi_stream_t stream);
+
+/* Integrate(block_coords, depth, color, depth_intrinsic, color_intrinsic,
+ * extrinsic, depth_scale, depth_max, trunc_voxel_multiplier)
+ * (VoxelBlockGrid.cpp:292-326): Activate + Find + per-voxel update. May
+ * Reserve (rehash) when size + m exceeds the capacity, as the reference. */
+int o3dmi_vbg_integrate_blocks(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
+                               int64_t m, const void* depth_dev,
+                               int depth_rows, int depth_cols,
+                               const void* color_dev, int color_rows,
+                               int color_cols, int input_dtype,
+                               const double* depth_intrinsic,
+                               const double* color_intrinsic,
+                               const double* extrinsic, float depth_scale,
+                               float depth_max, float trunc_voxel_multiplier,
+                               o3dmi_stream_t stream);
+
+/* Frame-stream fast path: GetUniqueBlockCoordinates + Integrate of one frame
+ * with every count kept on the device (no host round trip unless the hash map
+ * must grow). Results are identical to the two calls above. */
+int o3dmi_vbg_integrate_frame(o3dmi_vbg_t* g, const void* depth_dev,
+                              int depth_rows, int depth_cols,
+                              const void* color_dev, int color_rows,
+                              int color_cols, int input_dtype,
+                              const double* depth_intrinsic,
+                              const double* color_intrinsic,
+                              const double* extrinsic, float depth_scale,
+                              float depth_max, float trunc_voxel_multiplier,
+                              o3dmi_stream_t stream);
+
+/* Measurement hook for bench.py: while profiling is on, every
+ * o3dmi_vbg_integrate_frame call brackets its touch and integrate kernels with
+ * HIP events on the caller's stream and records the frame's active-block
+ * count. o3dmi_vbg_profile_end synchronises and returns the summed kernel
+ * times (ms), the number of integrate launches and the sum of active blocks
+ * over those launches (the roofline's "units"). */
+int o3dmi_vbg_profile_begin(o3dmi_vbg_t* g, int max_frames);
+int o3dmi_vbg_profile_end(o3dmi_vbg_t* g, o3dmi_stream_t stream,
+                          double* integrate_ms, double* touch_ms,
+                          int64_t* launches, int64_t* block_frames);
+
+/* RayCast(block_coords, intrinsic, extrinsic, width, height, attrs, ...)
+ * (VoxelBlockGrid.cpp:328-402). Output pointers follow o3dmi_vbg_raycast;
+ * range_map_dev {h/down, w/down, 2} is also an output ("range"). */
+int o3dmi_vbg_ray_cast(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
+                       int64_t m, const double* intrinsic,
+                       const double* extrinsic, int width, int height,
+                       float* range_map_dev, float* out_depth,
+                       float* out_vertex, float* out_color, float* out_normal,
+                       int64_t* out_index, uint8_t* out_mask, float* out_ratio,
+                       float* out_ratio_dx, float* out_ratio_dy,
+                       float* out_ratio_dz, float depth_scale, float depth_min,
+                       float depth_max, float weight_threshold,
+                       float trunc_voxel_multiplier, int range_map_down_factor,
+                       o3dmi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* O3D_MI355X_HOST_H_ */

@@ -1,0 +1,170 @@
+"""ctypes binding of the C ABI in include/o3d_mi355x.h.
+
+The HIP library is mandatory: there is no CPU or PyTorch fallback. If
+libo3d_mi355x.so is missing or fails to load, importing a compute entry point
+raises immediately.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "lib", "libo3d_mi355x.so")
+
+OK = 0
+F32, F64, U16, U8, I32, I64 = 0, 1, 2, 3, 4, 5
+
+_vp = C.c_void_p
+_i64 = C.c_int64
+_i32 = C.c_int
+_f = C.c_float
+_d = C.c_double
+_dp = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes). Kept in one table so that tests can check that
+# every symbol the header declares is exported.
+PROTOTYPES = {
+    "o3dmi_abi_version": (_i32, []),
+    "o3dmi_status_string": (C.c_char_p, [_i32]),
+    "o3dmi_last_error": (C.c_char_p, []),
+    "o3dmi_device_info": (_i32, [C.c_char_p, C.c_size_t, C.POINTER(_i32),
+                                 C.POINTER(_i64)]),
+    "o3dmi_hash_create": (_i32, [_i64, _i32, C.POINTER(_i64), _vp,
+                                 C.POINTER(_vp)]),
+    "o3dmi_hash_destroy": (_i32, [_vp]),
+    "o3dmi_hash_clear": (_i32, [_vp, _vp]),
+    "o3dmi_hash_activate": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "o3dmi_hash_insert": (_i32, [_vp, _vp, C.POINTER(_vp), _i64, _vp, _vp,
+                                 _vp]),
+    "o3dmi_hash_find": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "o3dmi_hash_erase": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "o3dmi_hash_size": (_i32, [_vp, _vp, C.POINTER(_i64)]),
+    "o3dmi_hash_capacity": (_i64, [_vp]),
+    "o3dmi_hash_bucket_count": (_i64, [_vp]),
+    "o3dmi_hash_active_indices": (_i32, [_vp, _vp, _vp, C.POINTER(_i64)]),
+    "o3dmi_hash_reserve": (_i32, [_vp, _i64, _vp]),
+    "o3dmi_hash_key_buffer": (_vp, [_vp]),
+    "o3dmi_hash_value_buffer": (_vp, [_vp, _i32]),
+    "o3dmi_vbg_depth_touch": (_i32, [_vp, _vp, _i32, _i32, _i32, _dp, _dp,
+                                     _vp, _i64, _vp, _i32, _f, _f, _f, _f,
+                                     _i32, _vp]),
+    "o3dmi_vbg_pointcloud_touch": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp,
+                                          _i32, _f, _f, _vp]),
+    "o3dmi_vbg_integrate": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32,
+                                   _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32,
+                                   _dp, _dp, _dp, _i32, _f, _f, _f, _f, _vp]),
+    "o3dmi_vbg_touch_activate": (_i32, [_vp, _vp, _i32, _i32, _i32, _dp, _dp,
+                                        _vp, _i64, _vp, _i32, _f, _f, _f, _f,
+                                        _i32, _i32, _vp]),
+    "o3dmi_vbg_estimate_range": (_i32, [_vp, _i64, _vp, _dp, _dp, _i32, _i32,
+                                        _i32, _i64, _f, _f, _f, _vp]),
+    "o3dmi_vbg_raycast": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp] + [_vp] * 10 +
+                          [_dp, _dp, _i32, _i32, _i32, _f, _f, _f, _f, _f, _f,
+                           _i32, _vp]),
+    "o3dmi_unproject": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _dp,
+                               _dp, _f, _f, _i64, _vp]),
+    "o3dmi_nns_create": (_i32, [_vp, _i64, _i32, _d, _vp, C.POINTER(_vp)]),
+    "o3dmi_nns_destroy": (_i32, [_vp]),
+    "o3dmi_nns_hybrid_search_k1": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp,
+                                          _vp]),
+    "o3dmi_icp_p2plane_accumulate": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32,
+                                            _i32, _d, _d, _vp, _vp]),
+    "o3dmi_icp_search_accumulate": (_i32, [_vp, _vp, _vp, _i64, _i32, _d, _d,
+                                           _vp, _vp, _vp]),
+    "o3dmi_transform_points": (_i32, [_dp, _vp, _i64, _i32, _vp]),
+    "o3dmi_transform_normals": (_i32, [_dp, _vp, _i64, _i32, _vp]),
+    "o3dmi_decode_and_solve6x6": (_i32, [_dp, _dp, C.POINTER(_f),
+                                         C.POINTER(_i32)]),
+    "o3dmi_pose_to_transformation": (None, [_dp, _dp]),
+}
+
+# include/o3d_mi355x_host.h
+class IcpCriteria(C.Structure):
+    _fields_ = [("relative_fitness", _d), ("relative_rmse", _d),
+                ("max_iteration", _i32)]
+
+
+class RegistrationResultC(C.Structure):
+    _fields_ = [("transformation", _d * 16), ("inlier_rmse", _d),
+                ("fitness", _d), ("converged", _i32),
+                ("num_iterations", _i32), ("num_correspondences", _i64)]
+
+
+ICP_CALLBACK = C.CFUNCTYPE(None, _i64, _i64, _i64, _d, _d, _dp, _vp)
+ALLREDUCE_SUM = C.CFUNCTYPE(_i32, _dp, _i32, _vp)
+
+PROTOTYPES.update({
+    "o3dmi_registration_multiscale_icp": (
+        _i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _dp,
+               C.POINTER(IcpCriteria), _dp, _dp, _i32, _d, _d, ICP_CALLBACK,
+               _vp, ALLREDUCE_SUM, _vp, _vp, C.POINTER(RegistrationResultC),
+               _vp]),
+    "o3dmi_voxel_down_sample": (_i32, [_vp, _vp, _i64, _i32, _d, _vp, _vp,
+                                       C.POINTER(_i64), _vp]),
+    "o3dmi_vbg_create": (_i32, [_i32, C.POINTER(C.c_char_p), C.POINTER(_i32),
+                                C.POINTER(_i32), _f, _i64, _i64, _vp,
+                                C.POINTER(_vp)]),
+    "o3dmi_vbg_destroy": (_i32, [_vp]),
+    "o3dmi_vbg_hashmap": (_vp, [_vp]),
+    "o3dmi_vbg_attribute": (_vp, [_vp, C.c_char_p, C.POINTER(_i32),
+                                  C.POINTER(_i32)]),
+    "o3dmi_vbg_get_unique_block_coordinates": (
+        _i32, [_vp, _vp, _i32, _i32, _i32, _dp, _dp, _f, _f, _f, _vp,
+               C.POINTER(_i64), _vp]),
+    "o3dmi_vbg_integrate_blocks": (
+        _i32, [_vp, _vp, _i64, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _dp,
+               _dp, _dp, _f, _f, _f, _vp]),
+    "o3dmi_vbg_integrate_frame": (
+        _i32, [_vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _dp, _dp, _dp, _f,
+               _f, _f, _vp]),
+    "o3dmi_vbg_profile_begin": (_i32, [_vp, _i32]),
+    "o3dmi_vbg_profile_end": (_i32, [_vp, _vp, C.POINTER(_d), C.POINTER(_d),
+                                     C.POINTER(_i64), C.POINTER(_i64)]),
+    "o3dmi_vbg_ray_cast": (
+        _i32, [_vp, _vp, _i64, _dp, _dp, _i32, _i32, _vp] + [_vp] * 10 +
+        [_f, _f, _f, _f, _f, _i32, _vp]),
+})
+
+_lib = None
+
+
+class O3DMIError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        msg = lib().o3dmi_status_string(status).decode()
+        detail = lib().o3dmi_last_error().decode()
+        super().__init__("%s failed: %s (%s)" % (where, msg, detail))
+
+
+def lib():
+    """Loads the HIP library; raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                "open3d_amd: %s not found -- the HIP extension is mandatory "
+                "(run `python -m open3d_amd.build`); there is no CPU "
+                "fallback." % SO_PATH)
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)  # AttributeError if a symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status, where):
+    if status != OK:
+        raise O3DMIError(status, where)
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor / None."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def f64p(a):
+    """numpy float64 contiguous array -> double*."""
+    return a.ctypes.data_as(_dp)

@@ -1,0 +1,525 @@
+// Spatial hash of voxel-block keys for MI355X: open addressing with linear
+// probing over packed 64-bit keys (one CAS decides slot ownership), buffer
+// indices handed out from a free-index heap exactly as Open3D's
+// HashBackendBuffer does (core/hashmap/HashBackendBuffer.cpp:16-78,
+// CPUHashBackendBufferAccessor.hpp:39-42: heap initialised to identity,
+// allocate = heap[top++], free = heap[--top] = idx).
+//
+// Semantics follow DeviceHashBackend (core/hashmap/DeviceHashBackend.h:20-107)
+// as exercised through HashMap::{Activate,Insert,Find,Erase,GetActiveIndices,
+// Reserve,Clear} (core/hashmap/HashMap.cpp:47-216); the probing scheme itself
+// is new (the reference's GPU backends are stdgpu / slab hash).
+//
+// Load factor <= 0.5 (n_slots = next_pow2(2 * capacity)), so probe sequences
+// stay within one or two 64-byte lines.
+
+#include <vector>
+
+#include "common.h"
+
+namespace o3dmi {
+
+static thread_local std::string g_last_error;
+void SetLastError(const std::string& msg) { g_last_error = msg; }
+
+namespace {
+
+__global__ void InitHeapKernel(int* heap, int capacity) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < capacity;
+         i += gridDim.x * blockDim.x)
+        heap[i] = i;
+}
+
+// Insert-if-absent. One thread per input key; duplicates in the same launch
+// resolve through the CAS: exactly one thread per distinct new key wins.
+template <bool kHasValues>
+__global__ void ActivateKernel(HashView hv, const int* __restrict__ keys,
+                               int64_t n, const int* __restrict__ n_dev,
+                               int* __restrict__ buf_indices,
+                               uint8_t* __restrict__ masks, int n_values,
+                               const void* const* values_src,
+                               void* const* values_dst,
+                               const int64_t* value_dsizes) {
+    if (n_dev) {
+        int64_t live = *n_dev;
+        n = live < n ? live : n;
+    }
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int x = keys[3 * i + 0], y = keys[3 * i + 1], z = keys[3 * i + 2];
+        int out_idx = 0;
+        uint8_t out_mask = 0;
+        if (!KeyInRange(x, y, z)) {
+            atomicOr(&hv.counters[1], kErrKeyRange);
+        } else {
+            unsigned long long k = PackKey(x, y, z);
+            unsigned h = HashKey(k) & hv.mask;
+            while (true) {
+                unsigned long long cur = hv.slot_keys[h];
+                if (cur == k) break;  // already present (or a duplicate won)
+                if (cur == kEmptyKey) {
+                    unsigned long long old =
+                            atomicCAS(&hv.slot_keys[h], kEmptyKey, k);
+                    if (old == kEmptyKey) {
+                        int top = atomicAdd(&hv.counters[0], 1);
+                        if (top >= hv.capacity) {
+                            atomicOr(&hv.counters[1], kErrCapacity);
+                            break;
+                        }
+                        int idx = hv.heap[top];
+                        hv.key_buffer[3 * idx + 0] = x;
+                        hv.key_buffer[3 * idx + 1] = y;
+                        hv.key_buffer[3 * idx + 2] = z;
+                        hv.slot_vals[h] = idx;
+                        if (kHasValues) {
+                            for (int j = 0; j < n_values; ++j) {
+                                int64_t sz = value_dsizes[j];
+                                const uint8_t* s =
+                                        (const uint8_t*)values_src[j] + sz * i;
+                                uint8_t* d = (uint8_t*)values_dst[j] +
+                                             sz * (int64_t)idx;
+                                for (int64_t b = 0; b < sz; ++b) d[b] = s[b];
+                            }
+                        }
+                        out_idx = idx;
+                        out_mask = 1;
+                        break;
+                    }
+                    if (old == k) break;
+                }
+                h = (h + 1) & hv.mask;
+            }
+        }
+        if (buf_indices) buf_indices[i] = out_idx;
+        if (masks) masks[i] = out_mask;
+    }
+}
+
+__global__ void FindKernel(HashView hv, const int* __restrict__ keys,
+                           int64_t n, const int* __restrict__ n_dev,
+                           int* __restrict__ buf_indices,
+                           uint8_t* __restrict__ masks) {
+    if (n_dev) {
+        int64_t live = *n_dev;
+        n = live < n ? live : n;
+    }
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int idx = hv.Find(keys[3 * i + 0], keys[3 * i + 1], keys[3 * i + 2]);
+        if (buf_indices) buf_indices[i] = idx < 0 ? 0 : idx;
+        if (masks) masks[i] = idx >= 0;
+    }
+}
+
+__global__ void EraseKernel(HashView hv, const int* __restrict__ keys,
+                            int64_t n, uint8_t* __restrict__ masks) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int x = keys[3 * i + 0], y = keys[3 * i + 1], z = keys[3 * i + 2];
+        uint8_t ok = 0;
+        if (KeyInRange(x, y, z)) {
+            unsigned long long k = PackKey(x, y, z);
+            unsigned h = HashKey(k) & hv.mask;
+            while (true) {
+                unsigned long long cur = hv.slot_keys[h];
+                if (cur == kEmptyKey) break;
+                if (cur == k) {
+                    // One winner among duplicate erase requests.
+                    if (atomicCAS(&hv.slot_keys[h], k, kTombKey) == k) {
+                        int idx = hv.slot_vals[h];
+                        int top = atomicSub(&hv.counters[0], 1);
+                        hv.heap[top - 1] = idx;
+                        ok = 1;
+                    }
+                    break;
+                }
+                h = (h + 1) & hv.mask;
+            }
+        }
+        if (masks) masks[i] = ok;
+    }
+}
+
+// Compacts the buffer indices of all occupied slots (unordered), one
+// wave-aggregated atomic per wavefront.
+__global__ void ActiveIndicesKernel(HashView hv, int64_t n_slots, int* out,
+                                    int* count) {
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+         s < ((n_slots + 63) / 64) * 64; s += (int64_t)gridDim.x * blockDim.x) {
+        bool occ = false;
+        if (s < n_slots) {
+            unsigned long long k = hv.slot_keys[s];
+            occ = (k != kEmptyKey) && (k != kTombKey);
+        }
+        unsigned long long ballot = __ballot(occ);
+        int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == 0 && ballot) base = atomicAdd(count, __popcll(ballot));
+        base = __shfl(base, 0);
+        if (occ) {
+            int off = __popcll(ballot & ((1ull << lane) - 1ull));
+            out[base + off] = hv.slot_vals[s];
+        }
+    }
+}
+
+template <typename T>
+int DevAlloc(T** p, int64_t n) {
+    O3DMI_HIP_CHECK(hipMalloc((void**)p, (size_t)(n > 0 ? n : 1) * sizeof(T)));
+    return O3DMI_OK;
+}
+
+int64_t NextPow2(int64_t v) {
+    int64_t p = 64;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+int AllocateStorage(o3dmi_hash* h, int64_t capacity, hipStream_t s) {
+    h->capacity = capacity;
+    h->n_slots = NextPow2(2 * capacity);
+    HashView& v = h->view;
+    int st;
+    if ((st = DevAlloc(&v.slot_keys, h->n_slots))) return st;
+    if ((st = DevAlloc(&v.slot_vals, h->n_slots))) return st;
+    if ((st = DevAlloc(&v.slot_stamp, h->n_slots))) return st;
+    if ((st = DevAlloc(&v.heap, capacity))) return st;
+    if ((st = DevAlloc(&v.counters, 4))) return st;
+    if ((st = DevAlloc(&v.key_buffer, capacity * 3))) return st;
+    if (!h->scratch_count)
+        if ((st = DevAlloc(&h->scratch_count, 4))) return st;
+    v.mask = (unsigned)(h->n_slots - 1);
+    v.capacity = (int)capacity;
+    for (int j = 0; j < h->n_values; ++j) {
+        size_t bytes = (size_t)h->value_dsizes[j] * (size_t)capacity;
+        O3DMI_HIP_CHECK(hipMalloc(&h->value_buffers[j], bytes ? bytes : 1));
+        O3DMI_HIP_CHECK(hipMemsetAsync(h->value_buffers[j], 0, bytes, s));
+    }
+    O3DMI_HIP_CHECK(hipMemsetAsync(v.key_buffer, 0,
+                                   sizeof(int) * 3 * (size_t)capacity, s));
+    O3DMI_HIP_CHECK(hipMemsetAsync(v.slot_stamp, 0,
+                                   sizeof(int) * (size_t)h->n_slots, s));
+    return O3DMI_OK;
+}
+
+void FreeStorage(o3dmi_hash* h) {
+    HashView& v = h->view;
+    (void)hipFree(v.slot_keys);
+    (void)hipFree(v.slot_vals);
+    (void)hipFree(v.slot_stamp);
+    (void)hipFree(v.heap);
+    (void)hipFree(v.counters);
+    (void)hipFree(v.key_buffer);
+    for (int j = 0; j < h->n_values; ++j) {
+        (void)hipFree(h->value_buffers[j]);
+        h->value_buffers[j] = nullptr;
+    }
+    v = HashView{};
+}
+
+int ClearImpl(o3dmi_hash* h, hipStream_t s) {
+    HashView& v = h->view;
+    O3DMI_HIP_CHECK(hipMemsetAsync(v.slot_keys, 0xFF,
+                                   sizeof(unsigned long long) *
+                                           (size_t)h->n_slots, s));
+    O3DMI_HIP_CHECK(hipMemsetAsync(v.counters, 0, sizeof(int) * 4, s));
+    hipLaunchKernelGGL(InitHeapKernel, dim3(GridFor(h->capacity, kBlock)),
+                       dim3(kBlock), 0, s, v.heap, (int)h->capacity);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+int CheckDeferred(o3dmi_hash* h, hipStream_t s, int* top_out) {
+    int host[2] = {0, 0};
+    O3DMI_HIP_CHECK(hipMemcpyAsync(host, h->view.counters, sizeof(host),
+                                   hipMemcpyDeviceToHost, s));
+    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    if (top_out) *top_out = host[0];
+    if (host[1] & kErrKeyRange) {
+        SetLastError("block coordinate outside +-2^20");
+        return O3DMI_ERR_KEY_RANGE;
+    }
+    if (host[1] & kErrCapacity) {
+        SetLastError("hash map capacity exceeded (caller must Reserve first)");
+        return O3DMI_ERR_CAPACITY;
+    }
+    return O3DMI_OK;
+}
+
+}  // namespace
+}  // namespace o3dmi
+
+using namespace o3dmi;
+
+extern "C" {
+
+int o3dmi_abi_version(void) { return O3DMI_ABI_VERSION; }
+
+const char* o3dmi_status_string(int status) {
+    switch (status) {
+        case O3DMI_OK: return "ok";
+        case O3DMI_ERR_INVALID_ARG: return "invalid argument";
+        case O3DMI_ERR_HIP: return "HIP runtime error";
+        case O3DMI_ERR_CAPACITY: return "capacity exceeded";
+        case O3DMI_ERR_KEY_RANGE: return "block key out of range";
+        case O3DMI_ERR_SINGULAR:
+            return "Singular 6x6 linear system detected, tracking failed.";
+        case O3DMI_ERR_NO_BLOCKS:
+            return "No block is touched in TSDF volume, abort integration. "
+                   "Please check specified parameters, especially depth_scale "
+                   "and voxel_size";
+        case O3DMI_ERR_UNSUPPORTED: return "unsupported";
+        default: return "unknown status";
+    }
+}
+
+const char* o3dmi_last_error(void) { return g_last_error.c_str(); }
+
+int o3dmi_device_info(char* name, size_t name_len, int* cu_count,
+                      int64_t* hbm_bytes) {
+    int dev = 0;
+    O3DMI_HIP_CHECK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    O3DMI_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    if (name && name_len) {
+        std::strncpy(name, prop.gcnArchName, name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return O3DMI_OK;
+}
+
+int o3dmi_hash_create(int64_t capacity, int n_values,
+                      const int64_t* value_dsizes, o3dmi_stream_t stream,
+                      o3dmi_hash_t** out) {
+    O3DMI_REQUIRE(out != nullptr, "out is null");
+    O3DMI_REQUIRE(capacity > 0 && capacity < (1ll << 30),
+                  "capacity must be in (0, 2^30)");
+    O3DMI_REQUIRE(n_values >= 0 && n_values <= 8, "n_values must be in [0,8]");
+    auto* h = new o3dmi_hash();
+    h->n_values = n_values;
+    for (int j = 0; j < n_values; ++j) h->value_dsizes[j] = value_dsizes[j];
+    hipStream_t s = (hipStream_t)stream;
+    int st = AllocateStorage(h, capacity, s);
+    if (st == O3DMI_OK) st = ClearImpl(h, s);
+    if (st != O3DMI_OK) {
+        FreeStorage(h);
+        delete h;
+        return st;
+    }
+    *out = h;
+    return O3DMI_OK;
+}
+
+int o3dmi_hash_destroy(o3dmi_hash_t* h) {
+    if (!h) return O3DMI_OK;
+    FreeStorage(h);
+    (void)hipFree(h->scratch_count);
+    delete h;
+    return O3DMI_OK;
+}
+
+int o3dmi_hash_clear(o3dmi_hash_t* h, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(h != nullptr, "hash is null");
+    return ClearImpl(h, (hipStream_t)stream);
+}
+
+int o3dmi_hash_activate(o3dmi_hash_t* h, const int32_t* keys_dev, int64_t n,
+                        const int32_t* n_dev, int32_t* buf_indices_dev,
+                        uint8_t* masks_dev, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(h != nullptr, "hash is null");
+    O3DMI_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return O3DMI_OK;
+    hipLaunchKernelGGL(ActivateKernel<false>, dim3(GridFor(n, kBlock)),
+                       dim3(kBlock), 0, (hipStream_t)stream, h->view, keys_dev,
+                       n, n_dev, buf_indices_dev, masks_dev, 0, nullptr,
+                       nullptr, nullptr);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+int o3dmi_hash_insert(o3dmi_hash_t* h, const int32_t* keys_dev,
+                      const void* const* values_soa_dev, int64_t n,
+                      int32_t* buf_indices_dev, uint8_t* masks_dev,
+                      o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(h != nullptr, "hash is null");
+    O3DMI_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return O3DMI_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (h->n_values == 0 || values_soa_dev == nullptr) {
+        return o3dmi_hash_activate(h, keys_dev, n, nullptr, buf_indices_dev,
+                                   masks_dev, stream);
+    }
+    // Small argument block on the device: src ptrs, dst ptrs, sizes.
+    struct Args {
+        const void* src[8];
+        void* dst[8];
+        int64_t sz[8];
+    } host_args;
+    for (int j = 0; j < h->n_values; ++j) {
+        host_args.src[j] = values_soa_dev[j];
+        host_args.dst[j] = h->value_buffers[j];
+        host_args.sz[j] = h->value_dsizes[j];
+    }
+    Args* dev_args = nullptr;
+    O3DMI_HIP_CHECK(hipMalloc((void**)&dev_args, sizeof(Args)));
+    O3DMI_HIP_CHECK(hipMemcpyAsync(dev_args, &host_args, sizeof(Args),
+                                   hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(ActivateKernel<true>, dim3(GridFor(n, kBlock)),
+                       dim3(kBlock), 0, s, h->view, keys_dev, n,
+                       (const int*)nullptr, buf_indices_dev, masks_dev,
+                       h->n_values, (const void* const*)dev_args->src,
+                       (void* const*)dev_args->dst,
+                       (const int64_t*)dev_args->sz);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    (void)hipFree(dev_args);
+    return O3DMI_OK;
+}
+
+int o3dmi_hash_find(o3dmi_hash_t* h, const int32_t* keys_dev, int64_t n,
+                    const int32_t* n_dev, int32_t* buf_indices_dev,
+                    uint8_t* masks_dev, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(h != nullptr, "hash is null");
+    O3DMI_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return O3DMI_OK;
+    hipLaunchKernelGGL(FindKernel, dim3(GridFor(n, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, h->view, keys_dev, n, n_dev,
+                       buf_indices_dev, masks_dev);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+int o3dmi_hash_erase(o3dmi_hash_t* h, const int32_t* keys_dev, int64_t n,
+                     uint8_t* masks_dev, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(h != nullptr, "hash is null");
+    O3DMI_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return O3DMI_OK;
+    hipLaunchKernelGGL(EraseKernel, dim3(GridFor(n, kBlock)), dim3(kBlock), 0,
+                       (hipStream_t)stream, h->view, keys_dev, n, masks_dev);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+int o3dmi_hash_size(o3dmi_hash_t* h, o3dmi_stream_t stream, int64_t* size) {
+    O3DMI_REQUIRE(h != nullptr && size != nullptr, "null argument");
+    int top = 0;
+    int st = CheckDeferred(h, (hipStream_t)stream, &top);
+    *size = top;
+    return st;
+}
+
+int64_t o3dmi_hash_capacity(const o3dmi_hash_t* h) {
+    return h ? h->capacity : 0;
+}
+int64_t o3dmi_hash_bucket_count(const o3dmi_hash_t* h) {
+    return h ? h->n_slots : 0;
+}
+
+int o3dmi_hash_active_indices(o3dmi_hash_t* h, int32_t* out_dev,
+                              o3dmi_stream_t stream, int64_t* count) {
+    O3DMI_REQUIRE(h != nullptr && out_dev != nullptr && count != nullptr,
+                  "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    O3DMI_HIP_CHECK(hipMemsetAsync(h->scratch_count, 0, sizeof(int), s));
+    hipLaunchKernelGGL(ActiveIndicesKernel, dim3(GridFor(h->n_slots, kBlock)),
+                       dim3(kBlock), 0, s, h->view, h->n_slots, out_dev,
+                       h->scratch_count);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    int c = 0;
+    O3DMI_HIP_CHECK(hipMemcpyAsync(&c, h->scratch_count, sizeof(int),
+                                   hipMemcpyDeviceToHost, s));
+    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    *count = c;
+    return O3DMI_OK;
+}
+
+int o3dmi_hash_reserve(o3dmi_hash_t* h, int64_t capacity,
+                       o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(h != nullptr, "hash is null");
+    hipStream_t s = (hipStream_t)stream;
+    int64_t count = 0;
+    int st = o3dmi_hash_size(h, stream, &count);
+    if (st != O3DMI_OK) return st;
+    if (capacity <= count) return O3DMI_OK;  // HashMap.cpp:49-52
+
+    // Export active keys/values (HashMap.cpp:54-66).
+    int* active = nullptr;
+    int* keys = nullptr;
+    void* vals[8] = {nullptr};
+    if (count > 0) {
+        O3DMI_HIP_CHECK(hipMalloc((void**)&active, sizeof(int) * h->capacity));
+        int64_t c2 = 0;
+        st = o3dmi_hash_active_indices(h, active, stream, &c2);
+        if (st != O3DMI_OK) return st;
+        std::vector<int> host_active((size_t)c2);
+        O3DMI_HIP_CHECK(hipMemcpy(host_active.data(), active, sizeof(int) * c2,
+                                  hipMemcpyDeviceToHost));
+        O3DMI_HIP_CHECK(hipMalloc((void**)&keys, sizeof(int) * 3 * c2));
+        for (int j = 0; j < h->n_values; ++j)
+            O3DMI_HIP_CHECK(hipMalloc(&vals[j], h->value_dsizes[j] * c2));
+        // Gather rows (value rows are large: one async D2D copy per row).
+        for (int64_t i = 0; i < c2; ++i) {
+            int b = host_active[(size_t)i];
+            O3DMI_HIP_CHECK(hipMemcpyAsync(keys + 3 * i,
+                                           h->view.key_buffer + 3 * (int64_t)b,
+                                           sizeof(int) * 3,
+                                           hipMemcpyDeviceToDevice, s));
+            for (int j = 0; j < h->n_values; ++j) {
+                int64_t sz = h->value_dsizes[j];
+                O3DMI_HIP_CHECK(hipMemcpyAsync(
+                        (uint8_t*)vals[j] + sz * i,
+                        (uint8_t*)h->value_buffers[j] + sz * b, sz,
+                        hipMemcpyDeviceToDevice, s));
+            }
+        }
+        O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+        count = c2;
+    }
+    FreeStorage(h);
+    st = AllocateStorage(h, capacity, s);
+    if (st == O3DMI_OK) st = ClearImpl(h, s);
+    if (st != O3DMI_OK) return st;
+    if (count > 0) {
+        // Re-insert: winners copy their value rows (HashMap.cpp:72-76).
+        int* buf = nullptr;
+        O3DMI_HIP_CHECK(hipMalloc((void**)&buf, sizeof(int) * count));
+        hipLaunchKernelGGL(ActivateKernel<false>,
+                           dim3(GridFor(count, kBlock)), dim3(kBlock), 0, s,
+                           h->view, keys, count, (const int*)nullptr, buf,
+                           (uint8_t*)nullptr, 0, nullptr, nullptr, nullptr);
+        O3DMI_HIP_CHECK(hipGetLastError());
+        std::vector<int> host_buf((size_t)count);
+        O3DMI_HIP_CHECK(hipMemcpyAsync(host_buf.data(), buf,
+                                       sizeof(int) * count,
+                                       hipMemcpyDeviceToHost, s));
+        O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+        for (int64_t i = 0; i < count; ++i) {
+            for (int j = 0; j < h->n_values; ++j) {
+                int64_t sz = h->value_dsizes[j];
+                O3DMI_HIP_CHECK(hipMemcpyAsync(
+                        (uint8_t*)h->value_buffers[j] +
+                                sz * (int64_t)host_buf[(size_t)i],
+                        (uint8_t*)vals[j] + sz * i, sz,
+                        hipMemcpyDeviceToDevice, s));
+            }
+        }
+        O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+        (void)hipFree(buf);
+    }
+    (void)hipFree(active);
+    (void)hipFree(keys);
+    for (int j = 0; j < h->n_values; ++j) (void)hipFree(vals[j]);
+    return O3DMI_OK;
+}
+
+int32_t* o3dmi_hash_key_buffer(o3dmi_hash_t* h) {
+    return h ? h->view.key_buffer : nullptr;
+}
+void* o3dmi_hash_value_buffer(o3dmi_hash_t* h, int i) {
+    if (!h || i < 0 || i >= h->n_values) return nullptr;
+    return h->value_buffers[i];
+}
+
+}  // extern "C"

@@ -1,0 +1,294 @@
+// Host-side ICP driver for the MI355X backend: the control flow of
+// t::pipelines::registration::MultiScaleICP (cpp/open3d/t/pipelines/
+// registration/Registration.cpp:24-62 ComputeRegistrationResult, :221-273
+// pyramid, :275-360 DoSingleScaleICPIterations, :362-444 MultiScaleICP) with
+// TransformationEstimationPointToPlane (TransformationEstimation.cpp:196-227),
+// re-cut for the GPU:
+//
+//   reference, per iteration          here, per iteration
+//   ------------------------------    -----------------------------------------
+//   HybridSearch kernel               one fused kernel: search + sum d2 + count
+//   counts.Sum  -> D2H sync             + Jacobian/29-sum accumulation
+//   dist.Sum    -> D2H sync           one 256-byte D2H copy (the only sync)
+//   29-sum kernel -> D2H sync         [optional cross-GPU all-reduce hook]
+//   6x6 solve on host (F64)           6x6 solve on host (F64), same arithmetic
+//   4x4 upload + transform kernel     transform kernel (matrix by value)
+//
+// The source cloud is transformed incrementally in its own dtype every
+// iteration exactly like the reference (Registration.cpp:322), not re-derived
+// from the cumulative transform, so float rounding accumulates the same way.
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "../common.h"
+#include "o3d_mi355x_host.h"
+
+extern "C" int o3dmi_nns_set_normals(o3dmi_nns_t* nns, const void* normals_dev,
+                                     o3dmi_stream_t stream);
+
+using namespace o3dmi;
+
+namespace {
+
+void Eye4(double* T) {
+    for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+}
+
+// update.Matmul(transformation), Registration.cpp:319 (host F64).
+void Matmul4(const double* A, const double* B, double* C) {
+    double R[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double s = 0;
+            for (int k = 0; k < 4; ++k) s += A[i * 4 + k] * B[k * 4 + j];
+            R[i * 4 + j] = s;
+        }
+    std::memcpy(C, R, sizeof(R));
+}
+
+struct DeviceBuffer {
+    void* p = nullptr;
+    ~DeviceBuffer() { (void)hipFree(p); }
+    int Alloc(size_t bytes) {
+        (void)hipFree(p);
+        p = nullptr;
+        O3DMI_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 1));
+        return O3DMI_OK;
+    }
+};
+
+struct Level {
+    DeviceBuffer src, tgt, nrm;
+    int64_t ns = 0, nt = 0;
+    const void* tgt_ptr = nullptr;  // may alias the caller's buffers
+    const void* nrm_ptr = nullptr;
+};
+
+struct NnsGuard {
+    o3dmi_nns_t* nns = nullptr;
+    ~NnsGuard() { o3dmi_nns_destroy(nns); }
+};
+
+struct SearchResult {
+    double fitness = 0, inlier_rmse = 0;
+    double sums[32];
+};
+
+}  // namespace
+
+extern "C" int o3dmi_registration_multiscale_icp(
+        const void* source_dev, int64_t ns, const void* target_dev,
+        const void* target_normals_dev, int64_t nt, int dtype, int num_scales,
+        const double* voxel_sizes, const o3dmi_icp_criteria_t* criterias,
+        const double* max_dists, const double* init, int robust_kernel,
+        double scaling_parameter, double shape_parameter,
+        o3dmi_icp_callback_t callback, void* callback_user,
+        o3dmi_allreduce_sum_t allreduce, void* allreduce_user,
+        int64_t* correspondences_dev, o3dmi_registration_result_t* result,
+        o3dmi_stream_t stream) {
+    // AssertInputMultiScaleICP, Registration.cpp:119-219.
+    O3DMI_REQUIRE(result != nullptr, "result is null");
+    O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
+                  "Only Float32 and Float64 point clouds are supported.");
+    O3DMI_REQUIRE(source_dev && target_dev && ns > 0 && nt > 0,
+                  "Source and/or Target pointcloud is empty.");
+    O3DMI_REQUIRE(target_normals_dev != nullptr,
+                  "Target pointcloud missing normals attribute.");
+    O3DMI_REQUIRE(num_scales > 0 && voxel_sizes && criterias && max_dists,
+                  "Size of criterias, voxel_size, max_correspondence_distances "
+                  "vectors must be same.");
+    for (int i = 0; i < num_scales; ++i) {
+        O3DMI_REQUIRE(max_dists[i] > 0,
+                      "max_correspondence_distance must be positive");
+        if (i + 1 < num_scales)
+            O3DMI_REQUIRE(voxel_sizes[i + 1] <= 0 ||
+                                  voxel_sizes[i] > voxel_sizes[i + 1],
+                          "Decreasing order of voxel_sizes is required.");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t esz = dtype == O3DMI_F64 ? 8 : 4;
+
+    // InitializePointCloudPyramidForMultiScaleICP, Registration.cpp:221-273.
+    std::vector<Level> pyr((size_t)num_scales);
+    const int last = num_scales - 1;
+    int st;
+    {
+        Level& L = pyr[(size_t)last];
+        if (voxel_sizes[last] <= 0) {
+            L.ns = ns;
+            L.nt = nt;
+            if ((st = L.src.Alloc((size_t)ns * 3 * esz))) return st;
+            O3DMI_HIP_CHECK(hipMemcpyAsync(L.src.p, source_dev,
+                                           (size_t)ns * 3 * esz,
+                                           hipMemcpyDeviceToDevice, s));
+            L.tgt_ptr = target_dev;
+            L.nrm_ptr = target_normals_dev;
+        } else {
+            if ((st = L.src.Alloc((size_t)ns * 3 * esz))) return st;
+            if ((st = L.tgt.Alloc((size_t)nt * 3 * esz))) return st;
+            if ((st = L.nrm.Alloc((size_t)nt * 3 * esz))) return st;
+            st = o3dmi_voxel_down_sample(source_dev, nullptr, ns, dtype,
+                                         voxel_sizes[last], L.src.p, nullptr,
+                                         &L.ns, stream);
+            if (st) return st;
+            st = o3dmi_voxel_down_sample(target_dev, target_normals_dev, nt,
+                                         dtype, voxel_sizes[last], L.tgt.p,
+                                         L.nrm.p, &L.nt, stream);
+            if (st) return st;
+            L.tgt_ptr = L.tgt.p;
+            L.nrm_ptr = L.nrm.p;
+        }
+    }
+    for (int k = num_scales - 2; k >= 0; --k) {
+        Level& L = pyr[(size_t)k];
+        Level& F = pyr[(size_t)k + 1];
+        if ((st = L.src.Alloc((size_t)F.ns * 3 * esz))) return st;
+        if ((st = L.tgt.Alloc((size_t)F.nt * 3 * esz))) return st;
+        if ((st = L.nrm.Alloc((size_t)F.nt * 3 * esz))) return st;
+        st = o3dmi_voxel_down_sample(F.src.p, nullptr, F.ns, dtype,
+                                     voxel_sizes[k], L.src.p, nullptr, &L.ns,
+                                     stream);
+        if (st) return st;
+        st = o3dmi_voxel_down_sample(F.tgt_ptr, F.nrm_ptr, F.nt, dtype,
+                                     voxel_sizes[k], L.tgt.p, L.nrm.p, &L.nt,
+                                     stream);
+        if (st) return st;
+        L.tgt_ptr = L.tgt.p;
+        L.nrm_ptr = L.nrm.p;
+    }
+
+    DeviceBuffer sums_dev;
+    if ((st = sums_dev.Alloc(sizeof(double) * 32))) return st;
+    double* sums_host = nullptr;
+    O3DMI_HIP_CHECK(hipHostMalloc((void**)&sums_host, sizeof(double) * 32));
+    struct HostFree {
+        double* p;
+        ~HostFree() { (void)hipHostFree(p); }
+    } host_free{sums_host};
+
+    double T[16];
+    if (init) std::memcpy(T, init, sizeof(T));
+    else Eye4(T);
+    double fitness = 0, inlier_rmse = 0;
+    bool converged = false;
+    int iteration_count = 0;
+    int status = O3DMI_OK;
+    int64_t last_ns = 0;
+
+    // ComputeRegistrationResult (+ the Jacobian sums of the same pass).
+    auto search = [&](o3dmi_nns_t* nns, const Level& L, int64_t* corr_out,
+                      SearchResult& r) -> int {
+        int e = o3dmi_icp_search_accumulate(nns, L.src.p, nullptr, L.ns,
+                                            robust_kernel, scaling_parameter,
+                                            shape_parameter, corr_out,
+                                            (double*)sums_dev.p, stream);
+        if (e) return e;
+        O3DMI_HIP_CHECK(hipMemcpyAsync(sums_host, sums_dev.p,
+                                       sizeof(double) * 32,
+                                       hipMemcpyDeviceToHost, s));
+        O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+        std::memcpy(r.sums, sums_host, sizeof(r.sums));
+        r.sums[31] = (double)L.ns;
+        if (allreduce) {
+            if (allreduce(r.sums, 32, allreduce_user) != 0) {
+                SetLastError("all-reduce hook failed");
+                return O3DMI_ERR_INVALID_ARG;
+            }
+        }
+        const double num_correspondences = r.sums[30];
+        if (num_correspondences != 0) {
+            const double squared_error = r.sums[29];
+            r.fitness = num_correspondences / r.sums[31];
+            r.inlier_rmse = std::sqrt(squared_error / num_correspondences);
+        } else {
+            // "0 correspondence present between the pointclouds."
+            r.fitness = 0;
+            r.inlier_rmse = 0;
+        }
+        return O3DMI_OK;
+    };
+
+    for (int scale_idx = 0; scale_idx < num_scales; ++scale_idx) {
+        Level& L = pyr[(size_t)scale_idx];
+        last_ns = L.ns;
+        // source_down_pyramid[scale].Transform(result.transformation_) :404
+        if ((st = o3dmi_transform_points(T, L.src.p, L.ns, dtype, stream)))
+            return st;
+        // target_nns.HybridIndex(max_correspondence_distance) :406-412
+        NnsGuard guard;
+        if ((st = o3dmi_nns_create(L.tgt_ptr, L.nt, dtype, max_dists[scale_idx],
+                                   stream, &guard.nns)))
+            return st;
+        if ((st = o3dmi_nns_set_normals(guard.nns, L.nrm_ptr, stream)))
+            return st;
+
+        // DoSingleScaleICPIterations :275-360
+        double prev_fitness = fitness, prev_inlier_rmse = inlier_rmse;
+        converged = false;
+        int it = 0;
+        bool no_corr = false;
+        const o3dmi_icp_criteria_t& crit = criterias[scale_idx];
+        for (it = 0; it < crit.max_iteration; ++it) {
+            SearchResult r;
+            if ((st = search(guard.nns, L, nullptr, r))) return st;
+            fitness = r.fitness;
+            inlier_rmse = r.inlier_rmse;
+            converged = false;
+            if (r.sums[30] == 0) Eye4(T);  // Registration.cpp:56-58
+            if (fitness <= std::numeric_limits<double>::min()) {
+                no_corr = true;
+                break;
+            }
+            double pose[6], update[16];
+            float residual;
+            int inlier_count;
+            int e = o3dmi_decode_and_solve6x6(r.sums, pose, &residual,
+                                              &inlier_count);
+            if (e) status = e;  // reference throws; report after the loop
+            o3dmi_pose_to_transformation(pose, update);
+            Matmul4(update, T, T);
+            if ((st = o3dmi_transform_points(update, L.src.p, L.ns, dtype,
+                                             stream)))
+                return st;
+            if (callback)
+                callback(iteration_count + it, scale_idx, it, inlier_rmse,
+                         fitness, T, callback_user);
+            if (it != 0 &&
+                std::abs(prev_fitness - fitness) < crit.relative_fitness &&
+                std::abs(prev_inlier_rmse - inlier_rmse) < crit.relative_rmse) {
+                converged = true;
+                break;
+            }
+            prev_fitness = fitness;
+            prev_inlier_rmse = inlier_rmse;
+        }
+        iteration_count += it;
+        (void)no_corr;
+
+        if (scale_idx == num_scales - 1) {
+            // Final fitness / rmse for the stored transformation :424-431
+            bool preserved = converged;
+            SearchResult r;
+            if ((st = search(guard.nns, L, correspondences_dev, r))) return st;
+            fitness = r.fitness;
+            inlier_rmse = r.inlier_rmse;
+            if (r.sums[30] == 0) Eye4(T);
+            converged = preserved;
+        }
+        if (fitness <= std::numeric_limits<double>::min()) {
+            converged = false;
+            break;
+        }
+    }
+
+    std::memcpy(result->transformation, T, sizeof(T));
+    result->fitness = fitness;
+    result->inlier_rmse = inlier_rmse;
+    result->converged = converged ? 1 : 0;
+    result->num_iterations = iteration_count;
+    result->num_correspondences = correspondences_dev ? last_ns : 0;
+    return status;
+}

@@ -1,0 +1,505 @@
+// Host-side VoxelBlockGrid for the MI355X backend: the orchestration of
+// t::geometry::VoxelBlockGrid (cpp/open3d/t/geometry/VoxelBlockGrid.cpp:65-117
+// ctor, :212-245 GetUniqueBlockCoordinates, :292-326 Integrate, :328-402
+// RayCast) and of core::HashMap::Activate's capacity policy
+// (cpp/open3d/core/hashmap/HashMap.cpp:166-181) on top of the kernel C ABI.
+//
+// What differs from the reference is where counts live: the reference reads
+// Size() and the candidate count back to the host every frame; here the
+// host keeps an upper bound of the map size and only synchronises when that
+// bound says a Reserve() might be needed, so the steady-state frame stream
+// (o3dmi_vbg_integrate_frame) issues kernels back to back.
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../common.h"
+#include "o3d_mi355x_host.h"
+
+using namespace o3dmi;
+
+struct o3dmi_vbg {
+    float voxel_size = 0;
+    int64_t block_resolution = 0;
+    std::vector<std::string> attr_names;
+    std::vector<int> attr_dtypes;
+    std::vector<int> attr_channels;
+    o3dmi_hash_t* block_hashmap = nullptr;
+    o3dmi_hash_t* frustum_hashmap = nullptr;  // lazily created (cpp:224-235)
+    int64_t frustum_capacity = 0;
+    // Host-side upper bound of block_hashmap's Size().
+    int64_t size_bound = 0;
+    // Device scratch for the frame-stream path.
+    int32_t* frame_indices = nullptr;
+    int64_t frame_indices_capacity = 0;
+    int32_t* frame_count = nullptr;
+    int32_t* scratch_buf_indices = nullptr;
+    int64_t scratch_capacity = 0;
+    int32_t frame_stamp = 0;
+    // Pinned read-back of {heap_top, error flags} behind each frame's touch.
+    int* size_host = nullptr;
+    hipEvent_t size_event = nullptr;
+    bool size_event_pending = false;
+    // bench.py measurement hook (o3dmi_vbg_profile_begin/end).
+    bool profiling = false;
+    std::vector<hipEvent_t> prof_events;  // 3 per frame: t0, t1 (touch), t2
+    int prof_frames = 0, prof_max = 0;
+    int32_t* prof_counts = nullptr;  // device, one per frame
+
+    int AttrIndex(const char* name) const {
+        for (size_t i = 0; i < attr_names.size(); ++i)
+            if (attr_names[i] == name) return (int)i;
+        return -1;
+    }
+};
+
+namespace {
+
+int DtypeSize(int dt) {
+    switch (dt) {
+        case O3DMI_F32: return 4;
+        case O3DMI_F64: return 8;
+        case O3DMI_U16: return 2;
+        case O3DMI_U8: return 1;
+        case O3DMI_I32: return 4;
+        case O3DMI_I64: return 8;
+        default: return 0;
+    }
+}
+
+// HashMap::Activate's pre-amble (HashMap.cpp:166-176): if Size()+length would
+// exceed the capacity, Reserve(max(new_size, 2*capacity)). `size_bound` avoids
+// the Size() read-back while it proves no growth is needed.
+int EnsureCapacity(o3dmi_vbg* g, int64_t length, o3dmi_stream_t stream) {
+    if (g->size_event_pending) {
+        O3DMI_HIP_CHECK(hipEventSynchronize(g->size_event));
+        g->size_event_pending = false;
+        g->size_bound = g->size_host[0];
+    }
+    int64_t capacity = o3dmi_hash_capacity(g->block_hashmap);
+    if (g->size_bound + length <= capacity) {
+        g->size_bound += length;
+        return O3DMI_OK;
+    }
+    int64_t size = 0;
+    int st = o3dmi_hash_size(g->block_hashmap, stream, &size);
+    if (st) return st;
+    int64_t new_size = size + length;
+    if (new_size > capacity) {
+        int64_t target = new_size > capacity * 2 ? new_size : capacity * 2;
+        st = o3dmi_hash_reserve(g->block_hashmap, target, stream);
+        if (st) return st;
+    }
+    g->size_bound = new_size;
+    return O3DMI_OK;
+}
+
+int EnsureScratch(o3dmi_vbg* g, int64_t m) {
+    if (m <= g->scratch_capacity) return O3DMI_OK;
+    (void)hipFree(g->scratch_buf_indices);
+    g->scratch_buf_indices = nullptr;
+    O3DMI_HIP_CHECK(hipMalloc((void**)&g->scratch_buf_indices,
+                              sizeof(int32_t) * (size_t)m));
+    g->scratch_capacity = m;
+    return O3DMI_OK;
+}
+
+int GridDtype(o3dmi_vbg* g, int* out) {
+    int wi = g->AttrIndex("weight");
+    int ci = g->AttrIndex("color");
+    int wdt = wi >= 0 ? g->attr_dtypes[(size_t)wi] : O3DMI_F32;
+    int cdt = ci >= 0 ? g->attr_dtypes[(size_t)ci] : wdt;
+    if (wdt == O3DMI_F32 && cdt == O3DMI_F32) *out = O3DMI_F32;
+    else if (wdt == O3DMI_U16 && cdt == O3DMI_U16) *out = O3DMI_U16;
+    else {
+        SetLastError(
+                "Unsupported value data type combination. Expected (float, "
+                "float) or (uint16, uint16)");
+        return O3DMI_ERR_INVALID_ARG;
+    }
+    return O3DMI_OK;
+}
+
+int RunIntegrate(o3dmi_vbg* g, const int32_t* indices, int64_t n,
+                 const int32_t* n_dev, const void* depth, int drows, int dcols,
+                 const void* color, int crows, int ccols, int input_dtype,
+                 const double* Kd, const double* Kc, const double* T,
+                 float depth_scale, float depth_max, float trunc_mult,
+                 o3dmi_stream_t stream) {
+    int ti = g->AttrIndex("tsdf"), wi = g->AttrIndex("weight"),
+        ci = g->AttrIndex("color");
+    if (ti < 0 || wi < 0) {
+        SetLastError(
+                "TSDF and/or weight not allocated in blocks, please implement "
+                "customized integration.");
+        return O3DMI_ERR_INVALID_ARG;
+    }
+    O3DMI_REQUIRE(g->attr_dtypes[(size_t)ti] == O3DMI_F32,
+                  "tsdf must be Float32");
+    int grid_dtype;
+    int st = GridDtype(g, &grid_dtype);
+    if (st) return st;
+    bool integrate_color = color != nullptr && (int64_t)crows * ccols > 0;
+    void* cbuf = (ci >= 0 && integrate_color)
+                         ? o3dmi_hash_value_buffer(g->block_hashmap, ci)
+                         : nullptr;
+    return o3dmi_vbg_integrate(
+            depth, drows, dcols, integrate_color ? color : nullptr, crows,
+            ccols, input_dtype, indices, n, n_dev,
+            o3dmi_hash_key_buffer(g->block_hashmap),
+            (float*)o3dmi_hash_value_buffer(g->block_hashmap, ti),
+            o3dmi_hash_value_buffer(g->block_hashmap, wi), cbuf, grid_dtype, Kd,
+            Kc ? Kc : Kd, T, (int)g->block_resolution, g->voxel_size,
+            g->voxel_size * trunc_mult, depth_scale, depth_max, stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int o3dmi_vbg_create(int n_attrs, const char* const* attr_names,
+                     const int* attr_dtypes, const int* attr_channels,
+                     float voxel_size, int64_t block_resolution,
+                     int64_t block_count, o3dmi_stream_t stream,
+                     o3dmi_vbg_t** out) {
+    O3DMI_REQUIRE(out != nullptr, "out is null");
+    O3DMI_REQUIRE(voxel_size > 0, "voxel size must be positive");
+    O3DMI_REQUIRE(block_resolution > 0, "block resolution must be positive");
+    O3DMI_REQUIRE(n_attrs > 0 && n_attrs <= 8 && attr_names && attr_dtypes &&
+                          attr_channels,
+                  "Number of attribute dtypes/channels mismatch with names.");
+    auto* g = new o3dmi_vbg();
+    g->voxel_size = voxel_size;
+    g->block_resolution = block_resolution;
+    int64_t dsizes[8];
+    int64_t res3 = block_resolution * block_resolution * block_resolution;
+    for (int i = 0; i < n_attrs; ++i) {
+        int sz = DtypeSize(attr_dtypes[i]);
+        if (sz == 0 || attr_channels[i] <= 0) {
+            delete g;
+            SetLastError("bad attribute dtype / channels");
+            return O3DMI_ERR_INVALID_ARG;
+        }
+        g->attr_names.emplace_back(attr_names[i]);
+        g->attr_dtypes.push_back(attr_dtypes[i]);
+        g->attr_channels.push_back(attr_channels[i]);
+        dsizes[i] = res3 * attr_channels[i] * sz;
+    }
+    int st = o3dmi_hash_create(block_count, n_attrs, dsizes, stream,
+                               &g->block_hashmap);
+    if (st == O3DMI_OK) {
+        hipError_t e = hipMalloc((void**)&g->frame_count, sizeof(int32_t) * 4);
+        if (e == hipSuccess)
+            e = hipHostMalloc((void**)&g->size_host, sizeof(int) * 4);
+        if (e == hipSuccess)
+            e = hipEventCreateWithFlags(&g->size_event, hipEventDisableTiming);
+        if (e != hipSuccess) st = O3DMI_ERR_HIP;
+    }
+    if (st != O3DMI_OK) {
+        o3dmi_vbg_destroy(g);
+        return st;
+    }
+    *out = g;
+    return O3DMI_OK;
+}
+
+int o3dmi_vbg_destroy(o3dmi_vbg_t* g) {
+    if (!g) return O3DMI_OK;
+    o3dmi_hash_destroy(g->block_hashmap);
+    o3dmi_hash_destroy(g->frustum_hashmap);
+    (void)hipFree(g->frame_indices);
+    (void)hipFree(g->frame_count);
+    (void)hipFree(g->scratch_buf_indices);
+    if (g->size_host) (void)hipHostFree(g->size_host);
+    if (g->size_event) (void)hipEventDestroy(g->size_event);
+    for (hipEvent_t e : g->prof_events) (void)hipEventDestroy(e);
+    (void)hipFree(g->prof_counts);
+    delete g;
+    return O3DMI_OK;
+}
+
+o3dmi_hash_t* o3dmi_vbg_hashmap(o3dmi_vbg_t* g) {
+    return g ? g->block_hashmap : nullptr;
+}
+
+void* o3dmi_vbg_attribute(o3dmi_vbg_t* g, const char* name, int* dtype,
+                          int* channels) {
+    if (!g || !name) return nullptr;
+    int i = g->AttrIndex(name);
+    if (i < 0) return nullptr;  // "Attribute {} not found, return empty tensor."
+    if (dtype) *dtype = g->attr_dtypes[(size_t)i];
+    if (channels) *channels = g->attr_channels[(size_t)i];
+    return o3dmi_hash_value_buffer(g->block_hashmap, i);
+}
+
+int o3dmi_vbg_get_unique_block_coordinates(
+        o3dmi_vbg_t* g, const void* depth_dev, int depth_dtype, int rows,
+        int cols, const double* intrinsic, const double* extrinsic,
+        float depth_scale, float depth_max, float trunc_voxel_multiplier,
+        int32_t* out_coords_dev, int64_t* m_out, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(g && depth_dev && out_coords_dev && m_out, "null argument");
+    const int64_t down_factor = 4;
+    const int64_t est_sample_multiplier = 4;
+    int64_t capacity = (cols / down_factor) * (rows / down_factor) *
+                       est_sample_multiplier;
+    O3DMI_REQUIRE(capacity > 0, "depth image too small");
+    if (g->frustum_hashmap == nullptr || g->frustum_capacity < capacity) {
+        o3dmi_hash_destroy(g->frustum_hashmap);
+        g->frustum_hashmap = nullptr;
+        int st = o3dmi_hash_create(capacity, 0, nullptr, stream,
+                                   &g->frustum_hashmap);
+        if (st) return st;
+        g->frustum_capacity = capacity;
+    }
+    int st = o3dmi_vbg_depth_touch(
+            g->frustum_hashmap, depth_dev, depth_dtype, rows, cols, intrinsic,
+            extrinsic, out_coords_dev, capacity, g->frame_count,
+            (int)g->block_resolution, g->voxel_size,
+            g->voxel_size * trunc_voxel_multiplier, depth_scale, depth_max,
+            (int)down_factor, stream);
+    if (st) return st;
+    int32_t count = 0;
+    O3DMI_HIP_CHECK(hipMemcpyAsync(&count, g->frame_count, sizeof(int32_t),
+                                   hipMemcpyDeviceToHost,
+                                   (hipStream_t)stream));
+    int64_t dummy = 0;
+    st = o3dmi_hash_size(g->frustum_hashmap, stream, &dummy);  // syncs + errors
+    if (st) return st;
+    *m_out = count;
+    if (count == 0) {
+        SetLastError(o3dmi_status_string(O3DMI_ERR_NO_BLOCKS));
+        return O3DMI_ERR_NO_BLOCKS;
+    }
+    return O3DMI_OK;
+}
+
+int o3dmi_vbg_integrate_blocks(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
+                               int64_t m, const void* depth_dev,
+                               int depth_rows, int depth_cols,
+                               const void* color_dev, int color_rows,
+                               int color_cols, int input_dtype,
+                               const double* depth_intrinsic,
+                               const double* color_intrinsic,
+                               const double* extrinsic, float depth_scale,
+                               float depth_max, float trunc_voxel_multiplier,
+                               o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(g && block_coords_dev && depth_dev && depth_intrinsic &&
+                          extrinsic,
+                  "null argument");
+    O3DMI_REQUIRE(m >= 0, "m < 0");
+    if (m == 0) return O3DMI_OK;
+    int st = EnsureCapacity(g, m, stream);
+    if (st) return st;
+    if ((st = EnsureScratch(g, m))) return st;
+    // block_hashmap_->Activate(block_coords, ...); ->Find(block_coords, ...)
+    st = o3dmi_hash_activate(g->block_hashmap, block_coords_dev, m, nullptr,
+                             nullptr, nullptr, stream);
+    if (st) return st;
+    st = o3dmi_hash_find(g->block_hashmap, block_coords_dev, m, nullptr,
+                         g->scratch_buf_indices, nullptr, stream);
+    if (st) return st;
+    return RunIntegrate(g, g->scratch_buf_indices, m, nullptr, depth_dev,
+                        depth_rows, depth_cols, color_dev, color_rows,
+                        color_cols, input_dtype, depth_intrinsic,
+                        color_intrinsic, extrinsic, depth_scale, depth_max,
+                        trunc_voxel_multiplier, stream);
+}
+
+int o3dmi_vbg_integrate_frame(o3dmi_vbg_t* g, const void* depth_dev,
+                              int depth_rows, int depth_cols,
+                              const void* color_dev, int color_rows,
+                              int color_cols, int input_dtype,
+                              const double* depth_intrinsic,
+                              const double* color_intrinsic,
+                              const double* extrinsic, float depth_scale,
+                              float depth_max, float trunc_voxel_multiplier,
+                              o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(g && depth_dev && depth_intrinsic && extrinsic,
+                  "null argument");
+    const int stride = 4;
+    int64_t max_new = (int64_t)(depth_cols / stride) * (depth_rows / stride) * 4;
+    O3DMI_REQUIRE(max_new > 0, "depth image too small");
+    if (g->frame_indices_capacity < max_new) {
+        (void)hipFree(g->frame_indices);
+        g->frame_indices = nullptr;
+        O3DMI_HIP_CHECK(hipMalloc((void**)&g->frame_indices,
+                                  sizeof(int32_t) * (size_t)max_new));
+        g->frame_indices_capacity = max_new;
+    }
+    // Capacity policy (HashMap::Activate, HashMap.cpp:166-176, with `length`
+    // = the most blocks one frame can create). The exact map size after the
+    // previous frame's activation was copied to pinned memory right behind
+    // that frame's touch kernel; waiting for it does not drain the GPU (the
+    // previous frame's integrate kernel is still running) and keeps the
+    // Reserve decision exact instead of heuristic.
+    hipStream_t s = (hipStream_t)stream;
+    if (g->size_event_pending) {
+        O3DMI_HIP_CHECK(hipEventSynchronize(g->size_event));
+        g->size_event_pending = false;
+        if (g->size_host[1] & kErrKeyRange) {
+            SetLastError("block coordinate outside +-2^20");
+            return O3DMI_ERR_KEY_RANGE;
+        }
+        if (g->size_host[1] & kErrCapacity) {
+            SetLastError("hash map capacity exceeded");
+            return O3DMI_ERR_CAPACITY;
+        }
+        g->size_bound = g->size_host[0];
+    }
+    int64_t capacity = o3dmi_hash_capacity(g->block_hashmap);
+    if (g->size_bound + max_new > capacity) {
+        int64_t size = 0;
+        int st = o3dmi_hash_size(g->block_hashmap, stream, &size);
+        if (st) return st;
+        g->size_bound = size;
+        if (size + max_new > capacity) {
+            int64_t need = size + max_new;
+            int64_t target = need > capacity * 2 ? need : capacity * 2;
+            st = o3dmi_hash_reserve(g->block_hashmap, target, stream);
+            if (st) return st;
+        }
+    }
+
+    int dt = input_dtype == O3DMI_F32 ? O3DMI_F32 : O3DMI_U16;
+    g->frame_stamp += 1;
+    const bool prof = g->profiling && g->prof_frames < g->prof_max;
+    if (prof)
+        O3DMI_HIP_CHECK(hipEventRecord(
+                g->prof_events[(size_t)g->prof_frames * 3 + 0], s));
+    int st = o3dmi_vbg_touch_activate(
+            g->block_hashmap, depth_dev, dt, depth_rows, depth_cols,
+            depth_intrinsic, extrinsic, g->frame_indices, max_new,
+            g->frame_count, (int)g->block_resolution, g->voxel_size,
+            g->voxel_size * trunc_voxel_multiplier, depth_scale, depth_max,
+            stride, g->frame_stamp, stream);
+    if (st) return st;
+    O3DMI_HIP_CHECK(hipMemcpyAsync(g->size_host, g->block_hashmap->view.counters,
+                                   sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+    O3DMI_HIP_CHECK(hipEventRecord(g->size_event, s));
+    g->size_event_pending = true;
+    g->size_bound += max_new;  // until the read-back lands
+    if (prof) {
+        O3DMI_HIP_CHECK(hipMemcpyAsync(g->prof_counts + g->prof_frames,
+                                       g->frame_count, sizeof(int32_t),
+                                       hipMemcpyDeviceToDevice, s));
+        O3DMI_HIP_CHECK(hipEventRecord(
+                g->prof_events[(size_t)g->prof_frames * 3 + 1], s));
+    }
+    st = RunIntegrate(g, g->frame_indices, max_new, g->frame_count, depth_dev,
+                      depth_rows, depth_cols, color_dev, color_rows,
+                      color_cols, input_dtype, depth_intrinsic,
+                      color_intrinsic, extrinsic, depth_scale, depth_max,
+                      trunc_voxel_multiplier, stream);
+    if (prof) {
+        O3DMI_HIP_CHECK(hipEventRecord(
+                g->prof_events[(size_t)g->prof_frames * 3 + 2], s));
+        g->prof_frames += 1;
+    }
+    return st;
+}
+
+int o3dmi_vbg_ray_cast(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
+                       int64_t m, const double* intrinsic,
+                       const double* extrinsic, int width, int height,
+                       float* range_map_dev, float* out_depth,
+                       float* out_vertex, float* out_color, float* out_normal,
+                       int64_t* out_index, uint8_t* out_mask, float* out_ratio,
+                       float* out_ratio_dx, float* out_ratio_dy,
+                       float* out_ratio_dz, float depth_scale, float depth_min,
+                       float depth_max, float weight_threshold,
+                       float trunc_voxel_multiplier, int range_map_down_factor,
+                       o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(g && range_map_dev && intrinsic && extrinsic,
+                  "null argument");
+    int ti = g->AttrIndex("tsdf"), wi = g->AttrIndex("weight"),
+        ci = g->AttrIndex("color");
+    if (ti < 0 || wi < 0) {
+        SetLastError(
+                "TSDF and/or weight not allocated in blocks, please implement "
+                "customized integration.");
+        return O3DMI_ERR_INVALID_ARG;
+    }
+    int grid_dtype;
+    int st = GridDtype(g, &grid_dtype);
+    if (st) return st;
+    st = o3dmi_vbg_estimate_range(block_coords_dev, m, range_map_dev, intrinsic,
+                                  extrinsic, height, width,
+                                  range_map_down_factor, g->block_resolution,
+                                  g->voxel_size, depth_min, depth_max, stream);
+    if (st) return st;
+    const void* cbuf = (ci >= 0 && out_color)
+                               ? o3dmi_hash_value_buffer(g->block_hashmap, ci)
+                               : nullptr;
+    return o3dmi_vbg_raycast(
+            g->block_hashmap,
+            (const float*)o3dmi_hash_value_buffer(g->block_hashmap, ti),
+            o3dmi_hash_value_buffer(g->block_hashmap, wi), cbuf, grid_dtype,
+            range_map_dev, out_depth, out_vertex, out_color, out_normal,
+            out_index, out_mask, out_ratio, out_ratio_dx, out_ratio_dy,
+            out_ratio_dz, intrinsic, extrinsic, height, width,
+            (int)g->block_resolution, g->voxel_size, depth_scale, depth_min,
+            depth_max, weight_threshold, trunc_voxel_multiplier,
+            range_map_down_factor, stream);
+}
+
+int o3dmi_vbg_profile_begin(o3dmi_vbg_t* g, int max_frames) {
+    O3DMI_REQUIRE(g && max_frames > 0, "bad argument");
+    while ((int)g->prof_events.size() < max_frames * 3) {
+        hipEvent_t e;
+        O3DMI_HIP_CHECK(hipEventCreate(&e));
+        g->prof_events.push_back(e);
+    }
+    if (g->prof_max < max_frames) {
+        (void)hipFree(g->prof_counts);
+        g->prof_counts = nullptr;
+        O3DMI_HIP_CHECK(hipMalloc((void**)&g->prof_counts,
+                                  sizeof(int32_t) * (size_t)max_frames));
+    }
+    g->prof_max = max_frames;
+    g->prof_frames = 0;
+    g->profiling = true;
+    return O3DMI_OK;
+}
+
+int o3dmi_vbg_profile_end(o3dmi_vbg_t* g, o3dmi_stream_t stream,
+                          double* integrate_ms, double* touch_ms,
+                          int64_t* launches, int64_t* block_frames) {
+    O3DMI_REQUIRE(g && integrate_ms && touch_ms && launches && block_frames,
+                  "null argument");
+    g->profiling = false;
+    O3DMI_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    double ti = 0, tt = 0;
+    for (int f = 0; f < g->prof_frames; ++f) {
+        float ms = 0;
+        O3DMI_HIP_CHECK(hipEventElapsedTime(
+                &ms, g->prof_events[(size_t)f * 3 + 0],
+                g->prof_events[(size_t)f * 3 + 1]));
+        tt += ms;
+        O3DMI_HIP_CHECK(hipEventElapsedTime(
+                &ms, g->prof_events[(size_t)f * 3 + 1],
+                g->prof_events[(size_t)f * 3 + 2]));
+        ti += ms;
+    }
+    std::vector<int32_t> counts((size_t)g->prof_frames);
+    if (g->prof_frames > 0)
+        O3DMI_HIP_CHECK(hipMemcpy(counts.data(), g->prof_counts,
+                                  sizeof(int32_t) * (size_t)g->prof_frames,
+                                  hipMemcpyDeviceToHost));
+    int64_t bf = 0;
+    for (int32_t c : counts) bf += c;
+    *integrate_ms = ti;
+    *touch_ms = tt;
+    *launches = g->prof_frames;
+    *block_frames = bf;
+    return O3DMI_OK;
+}
+
+// Placeholder until the device implementation lands (next milestone).
+int o3dmi_voxel_down_sample(const void*, const void*, int64_t, int, double,
+                            void*, void*, int64_t*, o3dmi_stream_t) {
+    SetLastError("VoxelDownSample on device: not implemented yet");
+    return O3DMI_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

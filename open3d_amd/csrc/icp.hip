@@ -1,0 +1,850 @@
+// Point-to-plane ICP kernels for MI355X.
+//
+//   o3dmi_nns_create              <- BuildSpatialHashTableCUDA (core/nns/FixedRadiusIndex.h:227-233,
+//                                    FixedRadiusSearchImpl.cuh:63-135,732-824)
+//   o3dmi_nns_hybrid_search_k1    <- HybridSearchCUDA (FixedRadiusIndex.h:364-377,
+//                                    FixedRadiusSearchImpl.cuh:514-632) with the CPU path's
+//                                    nanoflann semantics (core/nns/NanoFlannImpl.h:305-370)
+//   o3dmi_icp_p2plane_accumulate  <- ComputePosePointToPlaneCUDA (t/pipelines/kernel/
+//                                    RegistrationCUDA.cu:29-117, RegistrationImpl.h:251-287)
+//   o3dmi_icp_search_accumulate   fused search + fitness/rmse sums + accumulation
+//   o3dmi_transform_points/normals<- TransformPointsCUDA/TransformNormalsCUDA
+//                                    (t/geometry/kernel/TransformImpl.h:19-60)
+//   o3dmi_decode_and_solve6x6, o3dmi_pose_to_transformation (host)
+//                                 <- TransformationConverter.cpp:81-104,189-226
+//
+// Index design (new): a bucketed uniform grid with cell edge = radius*(1+1e-3).
+// Target points are *reordered* by bucket into 16-byte (32-byte for f64)
+// records {x,y,z,original index}, normals likewise, so a query's 27 cell
+// visits read contiguous memory instead of chasing a CSR index through 12-byte
+// AoS points. Cell coordinates are computed in float64 on both the build and
+// the query side so that large-offset clouds (1000 m + 5 cm radius, cf.
+// cpp/tests/core/NearestNeighborSearch.cpp:831-869) bin consistently.
+//
+// Reduction design (new): a fixed persistent grid; each lane keeps the 29 (+2)
+// sums in float64 registers, a wave64 __shfl_down tree, one LDS stage per
+// workgroup, one partial row per workgroup, and a single-workgroup second
+// stage in fixed order => run-to-run deterministic (the reference's CUDA path
+// uses float atomics, its CPU path a TBB tree of unspecified shape).
+
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+
+namespace o3dmi {
+namespace {
+
+constexpr int kNumSums = 32;  // 29 + sum d2 + match count + pad
+
+template <typename T> struct Rec4;  // {x,y,z,w}
+template <> struct alignas(16) Rec4<float> { float x, y, z; int w; };
+template <> struct alignas(32) Rec4<double> { double x, y, z; long long w; };
+
+__device__ __forceinline__ unsigned HashCell(long long cx, long long cy,
+                                             long long cz) {
+    unsigned long long k = (unsigned long long)cx * 0x9E3779B97F4A7C15ull;
+    k ^= (unsigned long long)cy * 0xC2B2AE3D27D4EB4Full + (k >> 29);
+    k ^= (unsigned long long)cz * 0x165667B19E3779F9ull + (k << 17);
+    return HashKey(k);
+}
+
+template <typename T>
+__device__ __forceinline__ void CellOf(const T* p, double inv_cell,
+                                       long long& cx, long long& cy,
+                                       long long& cz) {
+    cx = (long long)floor((double)p[0] * inv_cell);
+    cy = (long long)floor((double)p[1] * inv_cell);
+    cz = (long long)floor((double)p[2] * inv_cell);
+}
+
+// K1: bucket histogram.
+template <typename T>
+__global__ void CountKernel(const T* __restrict__ pts, int64_t n,
+                            double inv_cell, unsigned mask,
+                            unsigned* __restrict__ counts) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        long long cx, cy, cz;
+        CellOf(pts + 3 * i, inv_cell, cx, cy, cz);
+        atomicAdd(&counts[HashCell(cx, cy, cz) & mask], 1u);
+    }
+}
+
+// K2: exclusive scan in three passes (1024 elements per workgroup).
+constexpr int kScanBlock = 256;
+constexpr int kScanItems = 4;
+__global__ void ScanLocalKernel(const unsigned* __restrict__ in,
+                                unsigned* __restrict__ out,
+                                unsigned* __restrict__ block_sums, int64_t n) {
+    __shared__ unsigned lds[kScanBlock];
+    int64_t base = (int64_t)blockIdx.x * kScanBlock * kScanItems;
+    unsigned v[kScanItems];
+    unsigned sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        int64_t i = base + (int64_t)threadIdx.x * kScanItems + k;
+        v[k] = i < n ? in[i] : 0u;
+        sum += v[k];
+    }
+    lds[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < kScanBlock; off <<= 1) {
+        unsigned t = threadIdx.x >= off ? lds[threadIdx.x - off] : 0u;
+        __syncthreads();
+        lds[threadIdx.x] += t;
+        __syncthreads();
+    }
+    unsigned excl = lds[threadIdx.x] - sum;
+    if (threadIdx.x == kScanBlock - 1) block_sums[blockIdx.x] = lds[threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        int64_t i = base + (int64_t)threadIdx.x * kScanItems + k;
+        if (i < n) out[i] = excl;
+        excl += v[k];
+    }
+}
+__global__ void ScanBlockSumsKernel(unsigned* block_sums, int n_blocks) {
+    // single workgroup, sequential over chunks of 256
+    __shared__ unsigned lds[kScanBlock];
+    __shared__ unsigned carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_blocks; base += kScanBlock) {
+        int i = base + threadIdx.x;
+        unsigned v = i < n_blocks ? block_sums[i] : 0u;
+        lds[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < kScanBlock; off <<= 1) {
+            unsigned t = threadIdx.x >= off ? lds[threadIdx.x - off] : 0u;
+            __syncthreads();
+            lds[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n_blocks) block_sums[i] = carry + lds[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == kScanBlock - 1) carry += lds[threadIdx.x];
+        __syncthreads();
+    }
+}
+__global__ void ScanAddKernel(unsigned* __restrict__ out,
+                              const unsigned* __restrict__ block_sums,
+                              int64_t n) {
+    int64_t base = (int64_t)blockIdx.x * kScanBlock * kScanItems;
+    unsigned add = block_sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        int64_t i = base + (int64_t)threadIdx.x * kScanItems + k;
+        if (i < n) out[i] += add;
+    }
+}
+
+// K3: scatter points into bucket order as {x,y,z,idx} records.
+template <typename T>
+__global__ void ScatterKernel(const T* __restrict__ pts, int64_t n,
+                              double inv_cell, unsigned mask,
+                              const unsigned* __restrict__ starts,
+                              unsigned* __restrict__ cursor,
+                              Rec4<T>* __restrict__ sorted) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        long long cx, cy, cz;
+        CellOf(pts + 3 * i, inv_cell, cx, cy, cz);
+        unsigned b = HashCell(cx, cy, cz) & mask;
+        unsigned pos = starts[b] + atomicAdd(&cursor[b], 1u);
+        Rec4<T> r;
+        r.x = pts[3 * i + 0];
+        r.y = pts[3 * i + 1];
+        r.z = pts[3 * i + 2];
+        r.w = i;
+        sorted[pos] = r;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ int RecIndex(const Rec4<T>& r) {
+    return (int)r.w;
+}
+
+// Gather an {N,3} attribute (normals) into sorted record order.
+template <typename T>
+__global__ void GatherAttrKernel(const T* __restrict__ attr,
+                                 const Rec4<T>* __restrict__ sorted_pts,
+                                 int64_t n, Rec4<T>* __restrict__ out) {
+    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n;
+         j += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i = RecIndex(sorted_pts[j]);
+        Rec4<T> r;
+        r.x = attr[3 * i + 0];
+        r.y = attr[3 * i + 1];
+        r.z = attr[3 * i + 2];
+        r.w = 0;
+        out[j] = r;
+    }
+}
+
+template <typename T>
+struct NnsView {
+    const Rec4<T>* sorted;      // [n] bucket-ordered {x,y,z,idx}
+    const unsigned* starts;     // [n_buckets + 1]
+    double inv_cell;
+    unsigned mask;
+    T radius_squared;
+};
+
+// Nearest neighbour with d2 < r2 (strict), ties -> lowest original index.
+// Returns the position in the sorted array (or -1); idx/d2 by reference.
+// Distance arithmetic: nanoflann::L2_Adaptor::evalMetric for dim 3,
+// ((dx*dx) + dy*dy) + dz*dz with dx = query - point, in T.
+template <typename T>
+__device__ __forceinline__ int SearchNearest(const NnsView<T>& nv, const T* q,
+                                             int& best_idx, T& best_d2) {
+    long long cx, cy, cz;
+    CellOf(q, nv.inv_cell, cx, cy, cz);
+    int best_pos = -1;
+    best_idx = -1;
+    best_d2 = 0;
+    const T qx = q[0], qy = q[1], qz = q[2];
+    for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                unsigned b = HashCell(cx + dx, cy + dy, cz + dz) & nv.mask;
+                unsigned s = nv.starts[b], e = nv.starts[b + 1];
+                for (unsigned j = s; j < e; ++j) {
+                    Rec4<T> p = nv.sorted[j];
+                    T result = T(0);
+                    const T d0 = qx - p.x;
+                    result += d0 * d0;
+                    const T d1 = qy - p.y;
+                    result += d1 * d1;
+                    const T d2 = qz - p.z;
+                    result += d2 * d2;
+                    if (result < nv.radius_squared) {
+                        int idx = RecIndex(p);
+                        if (best_pos < 0 || result < best_d2 ||
+                            (result == best_d2 && idx < best_idx)) {
+                            best_pos = (int)j;
+                            best_idx = idx;
+                            best_d2 = result;
+                        }
+                    }
+                }
+            }
+    return best_pos;
+}
+
+template <typename T>
+__global__ void HybridSearchK1Kernel(NnsView<T> nv, const T* __restrict__ q,
+                                     int64_t nq, int* __restrict__ idx_out,
+                                     T* __restrict__ d2_out,
+                                     int* __restrict__ cnt_out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nq;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        T qq[3] = {q[3 * i + 0], q[3 * i + 1], q[3 * i + 2]};
+        int idx;
+        T d2;
+        int pos = SearchNearest(nv, qq, idx, d2);
+        if (idx_out) idx_out[i] = pos >= 0 ? idx : -1;
+        if (d2_out) d2_out[i] = pos >= 0 ? d2 : T(0);
+        if (cnt_out) cnt_out[i] = pos >= 0 ? 1 : 0;
+    }
+}
+
+// ---- robust kernels ---------------------------------------------------------
+// RobustKernelImpl.h:35-126, literal: the double-typed literals promote parts
+// of each expression to float64 before the result is narrowed to scalar_t.
+template <typename T>
+__device__ __forceinline__ T SquareT(T x) { return x * x; }
+
+struct RobustParams {
+    int method;
+    double scaling, shape;
+    int generalized_case;  // 0: ~2, 1: ~0 (never true, see below), 2: <-1e7, 3: else
+};
+
+inline bool IsCloseHost(double x, double y, double rtol) {
+    // GeometryMacros.h:58-63; with y == 0 this is never true.
+    return (x > (1.0 - rtol) * y) && (x < (1.0 + rtol) * y);
+}
+
+template <typename T>
+__device__ __forceinline__ T RobustWeight(const RobustParams& rp, T residual) {
+    const T scale = (T)rp.scaling;
+    switch (rp.method) {
+        case O3DMI_L2_LOSS:
+            return (T)1.0;
+        case O3DMI_L1_LOSS:
+            return (T)(1.0 / (double)fabs(residual));
+        case O3DMI_HUBER_LOSS: {
+            T a = fabs(residual);
+            return scale / (a < scale ? scale : a);
+        }
+        case O3DMI_CAUCHY_LOSS:
+            return (T)(1.0 / (1.0 + (double)SquareT<T>(residual / scale)));
+        case O3DMI_GM_LOSS:
+            return scale / SquareT<T>(scale + SquareT<T>(residual));
+        case O3DMI_TUKEY_LOSS: {
+            T a = fabs(residual) / scale;
+            T m = (T)1.0 < a ? (T)1.0 : a;
+            double v = 1.0 - (double)SquareT<T>(m);
+            return (T)(v * v);
+        }
+        case O3DMI_GENERALIZED_LOSS: {
+            if (rp.generalized_case == 0) {
+                return (T)(1.0 / (double)SquareT<T>(scale));
+            } else if (rp.generalized_case == 1) {
+                return (T)(2.0 / (double)(SquareT<T>(residual) +
+                                          2 * SquareT<T>(scale)));
+            } else if (rp.generalized_case == 2) {
+                return (T)(exp((double)SquareT<T>(residual / scale) / (-2.0)) /
+                           (double)SquareT<T>(scale));
+            } else {
+                return (T)(pow(((double)SquareT<T>(residual / scale) /
+                                        fabs(rp.shape - 2.0) +
+                                1),
+                               ((rp.shape / 2.0) - 1.0)) /
+                           (double)SquareT<T>(scale));
+            }
+        }
+        default:
+            return (T)1.0;
+    }
+}
+
+RobustParams MakeRobust(int method, double scaling, double shape) {
+    RobustParams rp;
+    rp.method = method;
+    rp.scaling = scaling;
+    rp.shape = shape;
+    if (IsCloseHost(shape, 2.0, 1e-3)) rp.generalized_case = 0;
+    else if (IsCloseHost(shape, 0.0, 1e-3)) rp.generalized_case = 1;
+    else if (shape < -1e7) rp.generalized_case = 2;
+    else rp.generalized_case = 3;
+    return rp;
+}
+
+// ---- 29(+2)-value reduction -------------------------------------------------
+// Per-correspondence terms in T exactly as RegistrationCPU.cpp:62-74; the
+// running sums are float64.
+template <typename T>
+__device__ __forceinline__ void AccumulateP2Plane(
+        double (&A)[kNumSums], T sx, T sy, T sz, T tx, T ty, T tz, T nx, T ny,
+        T nz, const RobustParams& rp) {
+    // RegistrationImpl.h:274-284
+    T r = (sx - tx) * nx + (sy - ty) * ny + (sz - tz) * nz;
+    T J[6];
+    J[0] = nz * sy - ny * sz;
+    J[1] = nx * sz - nz * sx;
+    J[2] = ny * sx - nx * sy;
+    J[3] = nx;
+    J[4] = ny;
+    J[5] = nz;
+    T w = RobustWeight<T>(rp, r);
+    int i = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+#pragma unroll
+        for (int k = 0; k <= j; ++k) {
+            A[i] += (double)(J[j] * w * J[k]);
+            ++i;
+        }
+        A[21 + j] += (double)(J[j] * w * r);
+    }
+    A[27] += (double)r;
+    A[28] += 1.0;
+}
+
+constexpr int kReduceBlock = 256;
+
+// Wave64 tree, then LDS across the 4 waves, then one row per workgroup.
+__device__ __forceinline__ void BlockReduceAndStore(double (&A)[kNumSums],
+                                                    double* __restrict__ partials) {
+    __shared__ double lds[kReduceBlock / 64][kNumSums];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kNumSums; ++k) {
+        double v = A[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) lds[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumSums) {
+        double v = 0;
+#pragma unroll
+        for (int wv = 0; wv < kReduceBlock / 64; ++wv) v += lds[wv][threadIdx.x];
+        partials[(int64_t)blockIdx.x * kNumSums + threadIdx.x] = v;
+    }
+}
+
+__global__ void FinalReduceKernel(const double* __restrict__ partials,
+                                  int n_rows, double* __restrict__ out,
+                                  int n_out) {
+    // one wave per output column would waste lanes; 32 columns x 8 row-lanes.
+    __shared__ double lds[8][kNumSums];
+    int col = threadIdx.x % kNumSums;
+    int rl = threadIdx.x / kNumSums;  // 0..7
+    double v = 0;
+    for (int r = rl; r < n_rows; r += 8) v += partials[(int64_t)r * kNumSums + col];
+    lds[rl][col] = v;
+    __syncthreads();
+    if (threadIdx.x < n_out) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += lds[k][threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kReduceBlock)
+P2PlaneAccumulateKernel(const T* __restrict__ src, const T* __restrict__ tgt,
+                        const T* __restrict__ tgt_n,
+                        const int64_t* __restrict__ corr, int64_t n,
+                        RobustParams rp, double* __restrict__ partials) {
+    double A[kNumSums];
+#pragma unroll
+    for (int k = 0; k < kNumSums; ++k) A[k] = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t c = corr[i];
+        if (c == -1) continue;
+        AccumulateP2Plane<T>(A, src[3 * i + 0], src[3 * i + 1], src[3 * i + 2],
+                             tgt[3 * c + 0], tgt[3 * c + 1], tgt[3 * c + 2],
+                             tgt_n[3 * c + 0], tgt_n[3 * c + 1],
+                             tgt_n[3 * c + 2], rp);
+    }
+    BlockReduceAndStore(A, partials);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kReduceBlock)
+SearchAccumulateKernel(NnsView<T> nv, const Rec4<T>* __restrict__ sorted_n,
+                       const T* __restrict__ src, int64_t n, RobustParams rp,
+                       int64_t* __restrict__ corr_out,
+                       double* __restrict__ partials) {
+    double A[kNumSums];
+#pragma unroll
+    for (int k = 0; k < kNumSums; ++k) A[k] = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        T q[3] = {src[3 * i + 0], src[3 * i + 1], src[3 * i + 2]};
+        int idx;
+        T d2;
+        int pos = SearchNearest(nv, q, idx, d2);
+        if (corr_out) corr_out[i] = pos >= 0 ? (int64_t)idx : (int64_t)-1;
+        if (pos < 0) continue;
+        Rec4<T> t = nv.sorted[pos];
+        Rec4<T> nn = sorted_n[pos];
+        AccumulateP2Plane<T>(A, q[0], q[1], q[2], t.x, t.y, t.z, nn.x, nn.y,
+                             nn.z, rp);
+        A[29] += (double)d2;
+        A[30] += 1.0;
+    }
+    BlockReduceAndStore(A, partials);
+}
+
+// TransformImpl.h:19-44
+template <typename T>
+struct Mat4 { T m[16]; };
+
+template <typename T>
+__global__ void TransformPointsKernel(Mat4<T> t, T* __restrict__ pts,
+                                      int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        T* p = pts + 3 * i;
+        T p0 = p[0], p1 = p[1], p2 = p[2];
+        T x0 = t.m[0] * p0 + t.m[1] * p1 + t.m[2] * p2 + t.m[3];
+        T x1 = t.m[4] * p0 + t.m[5] * p1 + t.m[6] * p2 + t.m[7];
+        T x2 = t.m[8] * p0 + t.m[9] * p1 + t.m[10] * p2 + t.m[11];
+        T x3 = t.m[12] * p0 + t.m[13] * p1 + t.m[14] * p2 + t.m[15];
+        p[0] = x0 / x3;
+        p[1] = x1 / x3;
+        p[2] = x2 / x3;
+    }
+}
+// TransformImpl.h:46-60
+template <typename T>
+__global__ void TransformNormalsKernel(Mat4<T> t, T* __restrict__ nrm,
+                                       int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        T* p = nrm + 3 * i;
+        T p0 = p[0], p1 = p[1], p2 = p[2];
+        T x0 = t.m[0] * p0 + t.m[1] * p1 + t.m[2] * p2;
+        T x1 = t.m[4] * p0 + t.m[5] * p1 + t.m[6] * p2;
+        T x2 = t.m[8] * p0 + t.m[9] * p1 + t.m[10] * p2;
+        p[0] = x0;
+        p[1] = x1;
+        p[2] = x2;
+    }
+}
+
+int ReduceGrid(int64_t n) {
+    int64_t g = (n + kReduceBlock - 1) / kReduceBlock;
+    int64_t cap = (int64_t)kCUs * 4;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+}  // namespace o3dmi
+
+using namespace o3dmi;
+
+struct o3dmi_nns {
+    int dtype = O3DMI_F32;
+    int64_t n = 0;
+    double radius = 0, inv_cell = 0;
+    int64_t n_buckets = 0;
+    void* sorted_pts = nullptr;      // Rec4<T>[n]
+    void* sorted_normals = nullptr;  // Rec4<T>[n], optional
+    unsigned* starts = nullptr;      // [n_buckets + 1]
+    double* partials = nullptr;      // [kCUs*4, kNumSums]
+};
+
+namespace {
+
+template <typename T>
+int BuildIndex(o3dmi_nns* nns, const T* pts, hipStream_t s) {
+    const int64_t n = nns->n;
+    int64_t nb = 1024;
+    while (nb < 2 * n && nb < (1ll << 27)) nb <<= 1;
+    nns->n_buckets = nb;
+    unsigned mask = (unsigned)(nb - 1);
+    unsigned *counts = nullptr, *cursor = nullptr, *block_sums = nullptr;
+    int64_t n_scan = nb + 1;
+    int n_scan_blocks =
+            (int)((n_scan + kScanBlock * kScanItems - 1) / (kScanBlock * kScanItems));
+    O3DMI_HIP_CHECK(hipMalloc((void**)&counts, sizeof(unsigned) * n_scan));
+    O3DMI_HIP_CHECK(hipMalloc((void**)&cursor, sizeof(unsigned) * nb));
+    O3DMI_HIP_CHECK(hipMalloc((void**)&block_sums,
+                              sizeof(unsigned) * (n_scan_blocks + 1)));
+    O3DMI_HIP_CHECK(hipMalloc((void**)&nns->starts, sizeof(unsigned) * n_scan));
+    O3DMI_HIP_CHECK(hipMalloc(&nns->sorted_pts,
+                              sizeof(Rec4<T>) * (size_t)(n > 0 ? n : 1)));
+    O3DMI_HIP_CHECK(hipMalloc((void**)&nns->partials,
+                              sizeof(double) * kCUs * 4 * kNumSums));
+    O3DMI_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(unsigned) * n_scan, s));
+    O3DMI_HIP_CHECK(hipMemsetAsync(cursor, 0, sizeof(unsigned) * nb, s));
+    if (n > 0) {
+        hipLaunchKernelGGL(CountKernel<T>, dim3(GridFor(n, kBlock)),
+                           dim3(kBlock), 0, s, pts, n, nns->inv_cell, mask,
+                           counts);
+    }
+    hipLaunchKernelGGL(ScanLocalKernel, dim3(n_scan_blocks), dim3(kScanBlock),
+                       0, s, counts, nns->starts, block_sums, n_scan);
+    hipLaunchKernelGGL(ScanBlockSumsKernel, dim3(1), dim3(kScanBlock), 0, s,
+                       block_sums, n_scan_blocks);
+    hipLaunchKernelGGL(ScanAddKernel, dim3(n_scan_blocks), dim3(kScanBlock), 0,
+                       s, nns->starts, block_sums, n_scan);
+    if (n > 0) {
+        hipLaunchKernelGGL(ScatterKernel<T>, dim3(GridFor(n, kBlock)),
+                           dim3(kBlock), 0, s, pts, n, nns->inv_cell, mask,
+                           nns->starts, cursor, (Rec4<T>*)nns->sorted_pts);
+    }
+    O3DMI_HIP_CHECK(hipGetLastError());
+    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    (void)hipFree(counts);
+    (void)hipFree(cursor);
+    (void)hipFree(block_sums);
+    return O3DMI_OK;
+}
+
+template <typename T>
+NnsView<T> MakeView(const o3dmi_nns* nns) {
+    NnsView<T> v;
+    v.sorted = (const Rec4<T>*)nns->sorted_pts;
+    v.starts = nns->starts;
+    v.inv_cell = nns->inv_cell;
+    v.mask = (unsigned)(nns->n_buckets - 1);
+    const T r = (T)nns->radius;  // NanoFlannImpl.h:332: T radius_squared
+    v.radius_squared = r * r;
+    return v;
+}
+
+template <typename T>
+int EnsureSortedNormals(o3dmi_nns* nns, const T* normals, hipStream_t s) {
+    if (!nns->sorted_normals)
+        O3DMI_HIP_CHECK(hipMalloc(&nns->sorted_normals,
+                                  sizeof(Rec4<T>) * (size_t)(nns->n > 0 ? nns->n : 1)));
+    if (nns->n > 0)
+        hipLaunchKernelGGL(GatherAttrKernel<T>, dim3(GridFor(nns->n, kBlock)),
+                           dim3(kBlock), 0, s, normals,
+                           (const Rec4<T>*)nns->sorted_pts, nns->n,
+                           (Rec4<T>*)nns->sorted_normals);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+}  // namespace
+
+// Internal (not in the public header): attach target normals to an index so
+// that the fused search+accumulate kernel can gather them in bucket order.
+extern "C" int o3dmi_nns_set_normals(o3dmi_nns_t* nns, const void* normals_dev,
+                                     o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(nns && normals_dev, "null argument");
+    if (nns->dtype == O3DMI_F64)
+        return EnsureSortedNormals<double>(nns, (const double*)normals_dev,
+                                           (hipStream_t)stream);
+    return EnsureSortedNormals<float>(nns, (const float*)normals_dev,
+                                      (hipStream_t)stream);
+}
+
+extern "C" {
+
+int o3dmi_nns_create(const void* points_dev, int64_t n, int dtype,
+                     double radius, o3dmi_stream_t stream, o3dmi_nns_t** out) {
+    O3DMI_REQUIRE(out != nullptr, "out is null");
+    O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
+                  "points must be Float32 or Float64");
+    O3DMI_REQUIRE(radius > 0, "radius must be positive");
+    O3DMI_REQUIRE(n >= 0 && n < (1ll << 31), "n out of range");
+    O3DMI_REQUIRE(n == 0 || points_dev != nullptr, "points is null");
+    auto* nns = new o3dmi_nns();
+    nns->dtype = dtype;
+    nns->n = n;
+    nns->radius = radius;
+    nns->inv_cell = 1.0 / (radius * 1.001);
+    int st = dtype == O3DMI_F64
+                     ? BuildIndex<double>(nns, (const double*)points_dev,
+                                          (hipStream_t)stream)
+                     : BuildIndex<float>(nns, (const float*)points_dev,
+                                         (hipStream_t)stream);
+    if (st != O3DMI_OK) {
+        o3dmi_nns_destroy(nns);
+        return st;
+    }
+    *out = nns;
+    return O3DMI_OK;
+}
+
+int o3dmi_nns_destroy(o3dmi_nns_t* nns) {
+    if (!nns) return O3DMI_OK;
+    (void)hipFree(nns->sorted_pts);
+    (void)hipFree(nns->sorted_normals);
+    (void)hipFree(nns->starts);
+    (void)hipFree(nns->partials);
+    delete nns;
+    return O3DMI_OK;
+}
+
+int o3dmi_nns_hybrid_search_k1(const o3dmi_nns_t* nns, const void* queries_dev,
+                               int64_t q, int32_t* idx_dev, void* dist2_dev,
+                               int32_t* counts_dev, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(nns != nullptr, "index is null");
+    O3DMI_REQUIRE(q >= 0, "q < 0");
+    if (q == 0) return O3DMI_OK;
+    O3DMI_REQUIRE(queries_dev != nullptr, "queries is null");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(GridFor(q, kBlock)), block(kBlock);
+    if (nns->dtype == O3DMI_F64)
+        hipLaunchKernelGGL(HybridSearchK1Kernel<double>, grid, block, 0, s,
+                           MakeView<double>(nns), (const double*)queries_dev, q,
+                           idx_dev, (double*)dist2_dev, counts_dev);
+    else
+        hipLaunchKernelGGL(HybridSearchK1Kernel<float>, grid, block, 0, s,
+                           MakeView<float>(nns), (const float*)queries_dev, q,
+                           idx_dev, (float*)dist2_dev, counts_dev);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+int o3dmi_icp_p2plane_accumulate(const void* src_dev, const void* tgt_dev,
+                                 const void* tgt_normals_dev,
+                                 const int64_t* corr_dev, int64_t n, int dtype,
+                                 int robust_kernel, double scaling_parameter,
+                                 double shape_parameter, double* sums29_dev,
+                                 o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(src_dev && tgt_dev && tgt_normals_dev && corr_dev &&
+                          sums29_dev,
+                  "null argument");
+    O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
+                  "points must be Float32 or Float64");
+    O3DMI_REQUIRE(robust_kernel >= 0 && robust_kernel <= 6,
+                  "Unsupported method.");
+    hipStream_t s = (hipStream_t)stream;
+    int g = ReduceGrid(n);
+    double* partials = nullptr;
+    O3DMI_HIP_CHECK(hipMallocAsync((void**)&partials,
+                                   sizeof(double) * (size_t)g * kNumSums, s));
+    RobustParams rp = MakeRobust(robust_kernel, scaling_parameter,
+                                 shape_parameter);
+    if (dtype == O3DMI_F64)
+        hipLaunchKernelGGL(P2PlaneAccumulateKernel<double>, dim3(g),
+                           dim3(kReduceBlock), 0, s, (const double*)src_dev,
+                           (const double*)tgt_dev,
+                           (const double*)tgt_normals_dev, corr_dev, n, rp,
+                           partials);
+    else
+        hipLaunchKernelGGL(P2PlaneAccumulateKernel<float>, dim3(g),
+                           dim3(kReduceBlock), 0, s, (const float*)src_dev,
+                           (const float*)tgt_dev, (const float*)tgt_normals_dev,
+                           corr_dev, n, rp, partials);
+    hipLaunchKernelGGL(FinalReduceKernel, dim3(1), dim3(256), 0, s, partials, g,
+                       sums29_dev, 29);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    O3DMI_HIP_CHECK(hipFreeAsync(partials, s));
+    return O3DMI_OK;
+}
+
+int o3dmi_icp_search_accumulate(const o3dmi_nns_t* nns, const void* src_dev,
+                                const void* tgt_normals_dev, int64_t n,
+                                int robust_kernel, double scaling_parameter,
+                                double shape_parameter, int64_t* corr_out_dev,
+                                double* sums32_dev, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(nns && src_dev && sums32_dev, "null argument");
+    O3DMI_REQUIRE(robust_kernel >= 0 && robust_kernel <= 6,
+                  "Unsupported method.");
+    hipStream_t s = (hipStream_t)stream;
+    if (tgt_normals_dev) {
+        int st = o3dmi_nns_set_normals(const_cast<o3dmi_nns_t*>(nns),
+                                       tgt_normals_dev, stream);
+        if (st != O3DMI_OK) return st;
+    }
+    O3DMI_REQUIRE(nns->sorted_normals != nullptr,
+                  "Target pointcloud missing normals attribute.");
+    int g = ReduceGrid(n);
+    RobustParams rp = MakeRobust(robust_kernel, scaling_parameter,
+                                 shape_parameter);
+    if (nns->dtype == O3DMI_F64)
+        hipLaunchKernelGGL(SearchAccumulateKernel<double>, dim3(g),
+                           dim3(kReduceBlock), 0, s, MakeView<double>(nns),
+                           (const Rec4<double>*)nns->sorted_normals,
+                           (const double*)src_dev, n, rp, corr_out_dev,
+                           nns->partials);
+    else
+        hipLaunchKernelGGL(SearchAccumulateKernel<float>, dim3(g),
+                           dim3(kReduceBlock), 0, s, MakeView<float>(nns),
+                           (const Rec4<float>*)nns->sorted_normals,
+                           (const float*)src_dev, n, rp, corr_out_dev,
+                           nns->partials);
+    hipLaunchKernelGGL(FinalReduceKernel, dim3(1), dim3(256), 0, s,
+                       nns->partials, g, sums32_dev, kNumSums);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+int o3dmi_transform_points(const double* transformation, void* points_dev,
+                           int64_t n, int dtype, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(transformation && (points_dev || n == 0), "null argument");
+    O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
+                  "points must be Float32 or Float64");
+    if (n == 0) return O3DMI_OK;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(GridFor(n, kBlock)), block(kBlock);
+    if (dtype == O3DMI_F64) {
+        Mat4<double> t;
+        for (int i = 0; i < 16; ++i) t.m[i] = transformation[i];
+        hipLaunchKernelGGL(TransformPointsKernel<double>, grid, block, 0, s, t,
+                           (double*)points_dev, n);
+    } else {
+        Mat4<float> t;
+        for (int i = 0; i < 16; ++i) t.m[i] = (float)transformation[i];
+        hipLaunchKernelGGL(TransformPointsKernel<float>, grid, block, 0, s, t,
+                           (float*)points_dev, n);
+    }
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+int o3dmi_transform_normals(const double* transformation, void* normals_dev,
+                            int64_t n, int dtype, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(transformation && (normals_dev || n == 0), "null argument");
+    O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
+                  "normals must be Float32 or Float64");
+    if (n == 0) return O3DMI_OK;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(GridFor(n, kBlock)), block(kBlock);
+    if (dtype == O3DMI_F64) {
+        Mat4<double> t;
+        for (int i = 0; i < 16; ++i) t.m[i] = transformation[i];
+        hipLaunchKernelGGL(TransformNormalsKernel<double>, grid, block, 0, s,
+                           t, (double*)normals_dev, n);
+    } else {
+        Mat4<float> t;
+        for (int i = 0; i < 16; ++i) t.m[i] = (float)transformation[i];
+        hipLaunchKernelGGL(TransformNormalsKernel<float>, grid, block, 0, s, t,
+                           (float*)normals_dev, n);
+    }
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+// TransformationConverter.cpp:189-226; the solve is LAPACK ?gesv restated
+// (LU with partial pivoting), core/linalg/SolveCPU.cpp:15-30.
+int o3dmi_decode_and_solve6x6(const double* A, double* pose6, float* residual,
+                              int* inlier_count) {
+    O3DMI_REQUIRE(A && pose6 && residual && inlier_count, "null argument");
+    double M[36], b[6];
+    for (int j = 0; j < 6; j++) {
+        b[j] = -A[21 + j];
+        const int reduction_idx = (j * (j + 1)) / 2;
+        for (int k = 0; k <= j; k++) {
+            M[j * 6 + k] = A[reduction_idx + k];
+            M[k * 6 + j] = A[reduction_idx + k];
+        }
+    }
+    const int n = 6;
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        double mx = std::fabs(M[k * n + k]);
+        for (int i = k + 1; i < n; ++i) {
+            double v = std::fabs(M[i * n + k]);
+            if (v > mx) { mx = v; p = i; }
+        }
+        if (mx == 0.0 || !(mx == mx)) {
+            for (int j = 0; j < 6; ++j) pose6[j] = 0;
+            *residual = 0;
+            *inlier_count = 0;
+            SetLastError("Singular 6x6 linear system detected, tracking failed.");
+            return O3DMI_ERR_SINGULAR;
+        }
+        if (p != k) {
+            for (int j = 0; j < n; ++j) std::swap(M[k * n + j], M[p * n + j]);
+            std::swap(b[k], b[p]);
+        }
+        for (int i = k + 1; i < n; ++i) {
+            double l = M[i * n + k] / M[k * n + k];
+            M[i * n + k] = l;
+            for (int j = k + 1; j < n; ++j) M[i * n + j] -= l * M[k * n + j];
+        }
+    }
+    for (int i = 1; i < n; ++i)
+        for (int j = 0; j < i; ++j) b[i] -= M[i * n + j] * b[j];
+    for (int i = n - 1; i >= 0; --i) {
+        for (int j = i + 1; j < n; ++j) b[i] -= M[i * n + j] * b[j];
+        b[i] /= M[i * n + i];
+    }
+    for (int j = 0; j < 6; ++j) pose6[j] = b[j];
+    *residual = (float)A[27];
+    *inlier_count = (int)A[28];
+    return O3DMI_OK;
+}
+
+// TransformationConverterImpl.h:23-42 + TransformationConverter.cpp:81-104
+void o3dmi_pose_to_transformation(const double* pose_ptr, double* T) {
+    for (int i = 0; i < 16; ++i) T[i] = 0;
+    T[0] = cos(pose_ptr[2]) * cos(pose_ptr[1]);
+    T[1] = -1 * sin(pose_ptr[2]) * cos(pose_ptr[0]) +
+           cos(pose_ptr[2]) * sin(pose_ptr[1]) * sin(pose_ptr[0]);
+    T[2] = sin(pose_ptr[2]) * sin(pose_ptr[0]) +
+           cos(pose_ptr[2]) * sin(pose_ptr[1]) * cos(pose_ptr[0]);
+    T[4] = sin(pose_ptr[2]) * cos(pose_ptr[1]);
+    T[5] = cos(pose_ptr[2]) * cos(pose_ptr[0]) +
+           sin(pose_ptr[2]) * sin(pose_ptr[1]) * sin(pose_ptr[0]);
+    T[6] = -1 * cos(pose_ptr[2]) * sin(pose_ptr[0]) +
+           sin(pose_ptr[2]) * sin(pose_ptr[1]) * cos(pose_ptr[0]);
+    T[8] = -1 * sin(pose_ptr[1]);
+    T[9] = cos(pose_ptr[1]) * sin(pose_ptr[0]);
+    T[10] = cos(pose_ptr[1]) * cos(pose_ptr[0]);
+    T[3] = pose_ptr[3];
+    T[7] = pose_ptr[4];
+    T[11] = pose_ptr[5];
+    T[15] = 1;
+}
+
+}  // extern "C"

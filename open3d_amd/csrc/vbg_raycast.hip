@@ -1,0 +1,486 @@
+// Surface prediction for VoxelBlockGrid on MI355X.
+//
+//   o3dmi_vbg_estimate_range <- EstimateRangeCUDA (t/geometry/kernel/VoxelBlockGridImpl.h:310-555)
+//   o3dmi_vbg_raycast        <- RayCastCUDA<tsdf_t,weight_t,color_t> (VoxelBlockGridImpl.h:578-1120)
+//
+// EstimateRange: the reference expands every block's projected rectangle into
+// 16x16 "fragments" through an atomically grown buffer (3 passes, one host
+// sync, overflow drops fragments for the current call). Min/max are
+// order-independent, so here one wavefront per block rasterises its rectangle
+// straight into the range map with integer atomics on the float bit patterns;
+// no fragment buffer, no overflow case, same result.
+//
+// RayCast: one lane per pixel; the per-ray arithmetic is the reference's. The
+// hash lookup is the open-addressing probe of block_hash.hip (packed 64-bit
+// key compare), guarded by the same 1-entry block cache the reference keeps.
+
+#include "common.h"
+
+namespace o3dmi {
+namespace {
+
+__device__ __forceinline__ void AtomicMinF(float* addr, float value) {
+    // GeometryMacros.h:69-77
+    if (value >= 0) atomicMin((int*)addr, __float_as_int(value));
+    else atomicMax((unsigned int*)addr, __float_as_uint(value));
+}
+__device__ __forceinline__ void AtomicMaxF(float* addr, float value) {
+    // GeometryMacros.h:79-87
+    if (value >= 0) atomicMax((int*)addr, __float_as_int(value));
+    else atomicMin((unsigned int*)addr, __float_as_uint(value));
+}
+
+__global__ void RangeFillKernel(float* __restrict__ range, int64_t n,
+                                float depth_min, float depth_max) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        range[2 * i + 0] = depth_max;
+        range[2 * i + 1] = depth_min;
+    }
+}
+
+// One wave per block key (4 waves per workgroup).
+__global__ void EstimateRangeKernel(const int* __restrict__ block_keys,
+                                    int64_t n_blocks, float* __restrict__ range,
+                                    Camera cam, int h_down, int w_down,
+                                    int down_factor, int64_t block_resolution,
+                                    float voxel_size, float depth_min,
+                                    float depth_max) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_id =
+            ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t b = wave_id; b < n_blocks; b += n_waves) {
+        const int* key = block_keys + 3 * b;
+        int u_min = w_down - 1, v_min = h_down - 1, u_max = 0, v_max = 0;
+        float z_min = depth_max, z_max = depth_min;
+        // VoxelBlockGridImpl.h:386-412 (all lanes compute the same rectangle)
+        for (int i = 0; i < 8; ++i) {
+            float xw = (key[0] + ((i & 1) > 0)) * block_resolution * voxel_size;
+            float yw = (key[1] + ((i & 2) > 0)) * block_resolution * voxel_size;
+            float zw = (key[2] + ((i & 4) > 0)) * block_resolution * voxel_size;
+            float xc, yc, zc, u, v;
+            cam.RigidTransform(xw, yw, zw, xc, yc, zc);
+            if (zc <= 0) continue;
+            cam.Project(xc, yc, zc, u, v);
+            u /= down_factor;
+            v /= down_factor;
+            v_min = min((int)floorf(v), v_min);
+            v_max = max((int)ceilf(v), v_max);
+            u_min = min((int)floorf(u), u_min);
+            u_max = max((int)ceilf(u), u_max);
+            z_min = fminf(z_min, zc);
+            z_max = fmaxf(z_max, zc);
+        }
+        v_min = max(0, v_min);
+        v_max = min(h_down - 1, v_max);
+        u_min = max(0, u_min);
+        u_max = min(w_down - 1, u_max);
+        if (v_min >= v_max || u_min >= u_max || z_min >= z_max) continue;
+
+        const int rw = u_max - u_min + 1;
+        const int area = rw * (v_max - v_min + 1);
+        for (int k = lane; k < area; k += 64) {
+            int v = v_min + k / rw;
+            int u = u_min + k % rw;
+            float* range_ptr = range + 2 * ((int64_t)v * w_down + u);
+            AtomicMinF(range_ptr + 0, z_min);
+            AtomicMaxF(range_ptr + 1, z_max);
+        }
+    }
+}
+
+struct RayCastParams {
+    Camera c2w;  // intrinsics + inverse extrinsic
+    Camera w2c;  // intrinsics + extrinsic
+    int h, w;
+    int block_resolution;
+    float voxel_size, block_size;
+    float depth_scale, weight_threshold, sdf_trunc;
+    int range_down, w_down;
+    float *depth, *vertex, *color, *normal;
+    long long* index;
+    uint8_t* mask;
+    float *ratio, *ratio_dx, *ratio_dy, *ratio_dz;
+};
+
+struct BlockCache {
+    int x, y, z, block_idx;
+    __device__ __forceinline__ int Check(int xi, int yi, int zi) const {
+        return (xi == x && yi == y && zi == z) ? block_idx : -1;
+    }
+    __device__ __forceinline__ void Update(int xi, int yi, int zi, int b) {
+        x = xi; y = yi; z = zi; block_idx = b;
+    }
+};
+
+__device__ __forceinline__ int SignI(int x) {
+    return (x > 0) ? 1 : ((x < 0) ? -1 : 0);
+}
+
+template <typename weight_t, typename color_t>
+__global__ void __launch_bounds__(256)
+RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
+              const weight_t* __restrict__ weight_base,
+              const color_t* __restrict__ color_base,
+              const float* __restrict__ range_map) {
+    const int64_t n = (int64_t)p.h * p.w;
+    const int res = p.block_resolution;
+    const int res2 = res * res;
+    const int res3 = res2 * res;
+    const bool render_color = color_base != nullptr && p.color != nullptr;
+    const bool visit_neighbors = render_color || p.normal || p.mask ||
+                                 p.index || p.ratio || p.ratio_dx ||
+                                 p.ratio_dy || p.ratio_dz;
+
+    for (int64_t workload_idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+         workload_idx < n; workload_idx += (int64_t)gridDim.x * blockDim.x) {
+        const int y = (int)(workload_idx / p.w);
+        const int x = (int)(workload_idx % p.w);
+        const float* range =
+                range_map + 2 * ((int64_t)(y / p.range_down) * p.w_down +
+                                 (x / p.range_down));
+
+        float* depth_ptr = p.depth ? p.depth + workload_idx : nullptr;
+        float* vertex_ptr = p.vertex ? p.vertex + 3 * workload_idx : nullptr;
+        float* color_ptr = p.color ? p.color + 3 * workload_idx : nullptr;
+        float* normal_ptr = p.normal ? p.normal + 3 * workload_idx : nullptr;
+        long long* index_ptr = p.index ? p.index + 8 * workload_idx : nullptr;
+        uint8_t* mask_ptr = p.mask ? p.mask + 8 * workload_idx : nullptr;
+        float* ratio_ptr = p.ratio ? p.ratio + 8 * workload_idx : nullptr;
+        float* ratio_dx_ptr = p.ratio_dx ? p.ratio_dx + 8 * workload_idx : nullptr;
+        float* ratio_dy_ptr = p.ratio_dy ? p.ratio_dy + 8 * workload_idx : nullptr;
+        float* ratio_dz_ptr = p.ratio_dz ? p.ratio_dz + 8 * workload_idx : nullptr;
+
+        // Outputs are accumulated in registers and written once.
+        float out_depth = 0;
+        float out_vertex[3] = {0, 0, 0};
+        float out_color[3] = {0, 0, 0};
+        float out_normal[3] = {0, 0, 0};
+        float o_ratio[8], o_dx[8], o_dy[8], o_dz[8];
+        long long o_index[8];
+        uint8_t o_mask[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            o_ratio[k] = o_dx[k] = o_dy[k] = o_dz[k] = 0;
+            o_index[k] = 0;
+            o_mask[k] = 0;
+        }
+
+        float t = range[0];
+        const float t_max = range[1];
+        if (t < t_max) {
+            float x_c, y_c, z_c, x_g, y_g, z_g, x_o, y_o, z_o;
+            float t_prev = t;
+            float tsdf_prev = -1.0f;
+            float tsdf = 1.0f;
+            float wgt = 0.0f;
+
+            p.c2w.RigidTransform(0, 0, 0, x_o, y_o, z_o);
+            p.c2w.Unproject((float)x, (float)y, 1.0f, x_c, y_c, z_c);
+            p.c2w.RigidTransform(x_c, y_c, z_c, x_g, y_g, z_g);
+            const float x_d = x_g - x_o, y_d = y_g - y_o, z_d = z_g - z_o;
+
+            BlockCache cache{0, 0, 0, -1};
+            bool surface_found = false;
+            while (t < t_max) {
+                // GetLinearIdxAtT, VoxelBlockGridImpl.h:784-823
+                float xg = x_o + t * x_d;
+                float yg = y_o + t * y_d;
+                float zg = z_o + t * z_d;
+                int x_b = (int)floorf(xg / p.block_size);
+                int y_b = (int)floorf(yg / p.block_size);
+                int z_b = (int)floorf(zg / p.block_size);
+                int block_buf_idx = cache.Check(x_b, y_b, z_b);
+                if (block_buf_idx < 0) {
+                    block_buf_idx = hv.Find(x_b, y_b, z_b);
+                    if (block_buf_idx >= 0)
+                        cache.Update(x_b, y_b, z_b, block_buf_idx);
+                }
+                if (block_buf_idx < 0) {
+                    t_prev = t;
+                    t += p.block_size;
+                } else {
+                    int x_v = (int)((xg - x_b * p.block_size) / p.voxel_size);
+                    int y_v = (int)((yg - y_b * p.block_size) / p.voxel_size);
+                    int z_v = (int)((zg - z_b * p.block_size) / p.voxel_size);
+                    int64_t linear_idx = (int64_t)block_buf_idx * res3 +
+                                         z_v * res2 + y_v * res + x_v;
+                    tsdf_prev = tsdf;
+                    tsdf = tsdf_base[linear_idx];
+                    wgt = (float)weight_base[linear_idx];
+                    if (tsdf_prev > 0 && wgt >= p.weight_threshold &&
+                        tsdf <= 0) {
+                        surface_found = true;
+                        break;
+                    }
+                    t_prev = t;
+                    float delta = tsdf * p.sdf_trunc;
+                    t += delta < p.voxel_size ? p.voxel_size : delta;
+                }
+            }
+
+            if (surface_found) {
+                float t_intersect =
+                        (t * tsdf_prev - t_prev * tsdf) / (tsdf_prev - tsdf);
+                x_g = x_o + t_intersect * x_d;
+                y_g = y_o + t_intersect * y_d;
+                z_g = z_o + t_intersect * z_d;
+
+                out_depth = t_intersect * p.depth_scale;
+                if (vertex_ptr)
+                    p.w2c.RigidTransform(x_g, y_g, z_g, out_vertex[0],
+                                         out_vertex[1], out_vertex[2]);
+
+                bool go = visit_neighbors;
+                int x_b = 0, y_b = 0, z_b = 0, block_buf_idx = -1;
+                float x_v = 0, y_v = 0, z_v = 0;
+                if (go) {
+                    x_b = (int)floorf(x_g / p.block_size);
+                    y_b = (int)floorf(y_g / p.block_size);
+                    z_b = (int)floorf(z_g / p.block_size);
+                    x_v = (x_g - (float)x_b * p.block_size) / p.voxel_size;
+                    y_v = (y_g - (float)y_b * p.block_size) / p.voxel_size;
+                    z_v = (z_g - (float)z_b * p.block_size) / p.voxel_size;
+                    block_buf_idx = cache.Check(x_b, y_b, z_b);
+                    if (block_buf_idx < 0) {
+                        block_buf_idx = hv.Find(x_b, y_b, z_b);
+                        if (block_buf_idx < 0) go = false;
+                        else cache.Update(x_b, y_b, z_b, block_buf_idx);
+                    }
+                }
+                if (go) {
+                    int x_v_floor = (int)floorf(x_v);
+                    int y_v_floor = (int)floorf(y_v);
+                    int z_v_floor = (int)floorf(z_v);
+                    float ratio_x = x_v - (float)x_v_floor;
+                    float ratio_y = y_v - (float)y_v_floor;
+                    float ratio_z = z_v - (float)z_v_floor;
+
+                    float sum_r = 0.0f;
+                    for (int k = 0; k < 8; ++k) {
+                        int dx_v = (k & 1) > 0 ? 1 : 0;
+                        int dy_v = (k & 2) > 0 ? 1 : 0;
+                        int dz_v = (k & 4) > 0 ? 1 : 0;
+
+                        // GetLinearIdxAtP, VoxelBlockGridImpl.h:742-782
+                        int xv = x_v_floor + dx_v, yv = y_v_floor + dy_v,
+                            zv = z_v_floor + dz_v;
+                        int x_vn = (xv + res) % res;
+                        int y_vn = (yv + res) % res;
+                        int z_vn = (zv + res) % res;
+                        int dx_b = SignI(xv - x_vn);
+                        int dy_b = SignI(yv - y_vn);
+                        int dz_b = SignI(zv - z_vn);
+                        int64_t linear_idx_k;
+                        if (dx_b == 0 && dy_b == 0 && dz_b == 0) {
+                            linear_idx_k = (int64_t)block_buf_idx * res3 +
+                                           zv * res2 + yv * res + xv;
+                        } else {
+                            int kx = x_b + dx_b, ky = y_b + dy_b,
+                                kz = z_b + dz_b;
+                            int nb = cache.Check(kx, ky, kz);
+                            if (nb < 0) {
+                                nb = hv.Find(kx, ky, kz);
+                                if (nb >= 0) cache.Update(kx, ky, kz, nb);
+                            }
+                            linear_idx_k =
+                                    nb < 0 ? -1
+                                           : (int64_t)nb * res3 + z_vn * res2 +
+                                                     y_vn * res + x_vn;
+                        }
+
+                        if (linear_idx_k >= 0 &&
+                            weight_base[linear_idx_k] > 0) {
+                            float rx = dx_v * (ratio_x) +
+                                       (1 - dx_v) * (1 - ratio_x);
+                            float ry = dy_v * (ratio_y) +
+                                       (1 - dy_v) * (1 - ratio_y);
+                            float rz = dz_v * (ratio_z) +
+                                       (1 - dz_v) * (1 - ratio_z);
+                            float r = rx * ry * rz;
+
+                            o_ratio[k] = r;
+                            o_mask[k] = 1;
+                            o_index[k] = linear_idx_k;
+
+                            float tsdf_k = tsdf_base[linear_idx_k];
+                            float rdx = ry * rz * (2 * dx_v - 1);
+                            float rdy = rx * rz * (2 * dy_v - 1);
+                            float rdz = rx * ry * (2 * dz_v - 1);
+                            o_dx[k] = rdx;
+                            o_dy[k] = rdy;
+                            o_dz[k] = rdz;
+
+                            if (normal_ptr) {
+                                out_normal[0] += rdx * tsdf_k;
+                                out_normal[1] += rdy * tsdf_k;
+                                out_normal[2] += rdz * tsdf_k;
+                            }
+                            if (render_color) {
+                                int64_t ci = linear_idx_k * 3;
+                                out_color[0] += r * (float)color_base[ci + 0];
+                                out_color[1] += r * (float)color_base[ci + 1];
+                                out_color[2] += r * (float)color_base[ci + 2];
+                            }
+                            sum_r += r;
+                        }
+                    }
+
+                    if (sum_r > 0) {
+                        // `sum_r *= 255.0` is a double multiply narrowed back
+                        // to float (VoxelBlockGridImpl.h:1095).
+                        sum_r = (float)((double)sum_r * 255.0);
+                        if (render_color) {
+                            out_color[0] /= sum_r;
+                            out_color[1] /= sum_r;
+                            out_color[2] /= sum_r;
+                        }
+                        if (normal_ptr) {
+                            const float EPSILON = 1e-5f;
+                            float norm = sqrtf(out_normal[0] * out_normal[0] +
+                                               out_normal[1] * out_normal[1] +
+                                               out_normal[2] * out_normal[2]);
+                            norm = fmaxf(norm, EPSILON);
+                            float nx, ny, nz;
+                            p.w2c.Rotate(-out_normal[0] / norm,
+                                         -out_normal[1] / norm,
+                                         -out_normal[2] / norm, nx, ny, nz);
+                            out_normal[0] = nx;
+                            out_normal[1] = ny;
+                            out_normal[2] = nz;
+                        }
+                    }
+                }
+            }
+        }
+
+        if (depth_ptr) *depth_ptr = out_depth;
+        if (vertex_ptr) {
+            vertex_ptr[0] = out_vertex[0];
+            vertex_ptr[1] = out_vertex[1];
+            vertex_ptr[2] = out_vertex[2];
+        }
+        if (color_ptr) {
+            color_ptr[0] = out_color[0];
+            color_ptr[1] = out_color[1];
+            color_ptr[2] = out_color[2];
+        }
+        if (normal_ptr) {
+            normal_ptr[0] = out_normal[0];
+            normal_ptr[1] = out_normal[1];
+            normal_ptr[2] = out_normal[2];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (ratio_ptr) ratio_ptr[k] = o_ratio[k];
+            if (ratio_dx_ptr) ratio_dx_ptr[k] = o_dx[k];
+            if (ratio_dy_ptr) ratio_dy_ptr[k] = o_dy[k];
+            if (ratio_dz_ptr) ratio_dz_ptr[k] = o_dz[k];
+            if (index_ptr) index_ptr[k] = o_index[k];
+            if (mask_ptr) mask_ptr[k] = o_mask[k];
+        }
+    }
+}
+
+}  // namespace
+}  // namespace o3dmi
+
+using namespace o3dmi;
+
+extern "C" {
+
+int o3dmi_vbg_estimate_range(const int32_t* block_keys_dev, int64_t n_blocks,
+                             float* range_minmax_map_dev,
+                             const double* intrinsic, const double* extrinsic,
+                             int h, int w, int down_factor,
+                             int64_t block_resolution, float voxel_size,
+                             float depth_min, float depth_max,
+                             o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(range_minmax_map_dev && intrinsic && extrinsic,
+                  "null argument");
+    O3DMI_REQUIRE(down_factor > 0 && h >= down_factor && w >= down_factor,
+                  "bad image size / down factor");
+    O3DMI_REQUIRE(n_blocks == 0 || block_keys_dev != nullptr,
+                  "block keys is null");
+    hipStream_t s = (hipStream_t)stream;
+    int h_down = h / down_factor, w_down = w / down_factor;
+    int64_t n_px = (int64_t)h_down * w_down;
+    hipLaunchKernelGGL(RangeFillKernel, dim3(GridFor(n_px, kBlock)),
+                       dim3(kBlock), 0, s, range_minmax_map_dev, n_px,
+                       depth_min, depth_max);
+    if (n_blocks > 0) {
+        Camera cam = Camera::Make(intrinsic, extrinsic, 1.0f);
+        hipLaunchKernelGGL(EstimateRangeKernel, dim3(GridFor(n_blocks, 4)),
+                           dim3(kBlock), 0, s, block_keys_dev, n_blocks,
+                           range_minmax_map_dev, cam, h_down, w_down,
+                           down_factor, block_resolution, voxel_size, depth_min,
+                           depth_max);
+    }
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+int o3dmi_vbg_raycast(o3dmi_hash_t* block_hash, const float* tsdf_dev,
+                      const void* weight_dev, const void* color_buf_dev,
+                      int grid_dtype, const float* range_map_dev,
+                      float* out_depth, float* out_vertex, float* out_color,
+                      float* out_normal, int64_t* out_index, uint8_t* out_mask,
+                      float* out_ratio, float* out_ratio_dx,
+                      float* out_ratio_dy, float* out_ratio_dz,
+                      const double* intrinsic, const double* extrinsic, int h,
+                      int w, int block_resolution, float voxel_size,
+                      float depth_scale, float depth_min, float depth_max,
+                      float weight_threshold, float trunc_voxel_multiplier,
+                      int range_map_down_factor, o3dmi_stream_t stream) {
+    (void)depth_min;
+    (void)depth_max;
+    O3DMI_REQUIRE(block_hash && tsdf_dev && weight_dev && range_map_dev &&
+                          intrinsic && extrinsic,
+                  "null argument");
+    O3DMI_REQUIRE(grid_dtype == O3DMI_U16 || grid_dtype == O3DMI_F32,
+                  "Unsupported value data type combination.");
+    O3DMI_REQUIRE(h > 0 && w > 0 && range_map_down_factor > 0, "bad size");
+    RayCastParams p;
+    double pose[16];
+    InverseTransformation(extrinsic, pose);
+    p.c2w = Camera::Make(intrinsic, pose, 1.0f);
+    p.w2c = Camera::Make(intrinsic, extrinsic, 1.0f);
+    p.h = h;
+    p.w = w;
+    p.block_resolution = block_resolution;
+    p.voxel_size = voxel_size;
+    p.block_size = voxel_size * block_resolution;
+    p.depth_scale = depth_scale;
+    p.weight_threshold = weight_threshold;
+    p.sdf_trunc = voxel_size * trunc_voxel_multiplier;
+    p.range_down = range_map_down_factor;
+    p.w_down = w / range_map_down_factor;
+    p.depth = out_depth;
+    p.vertex = out_vertex;
+    p.color = out_color;
+    p.normal = out_normal;
+    p.index = (long long*)out_index;
+    p.mask = out_mask;
+    p.ratio = out_ratio;
+    p.ratio_dx = out_ratio_dx;
+    p.ratio_dy = out_ratio_dy;
+    p.ratio_dz = out_ratio_dz;
+    hipStream_t s = (hipStream_t)stream;
+    int64_t n = (int64_t)h * w;
+    dim3 grid(GridFor(n, kBlock, kCUs * 16)), block(kBlock);
+    if (grid_dtype == O3DMI_F32)
+        hipLaunchKernelGGL((RayCastKernel<float, float>), grid, block, 0, s,
+                           block_hash->view, p, tsdf_dev,
+                           (const float*)weight_dev,
+                           (const float*)color_buf_dev, range_map_dev);
+    else
+        hipLaunchKernelGGL((RayCastKernel<uint16_t, uint16_t>), grid, block, 0,
+                           s, block_hash->view, p, tsdf_dev,
+                           (const uint16_t*)weight_dev,
+                           (const uint16_t*)color_buf_dev, range_map_dev);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,455 @@
+// Block "touch" kernels for VoxelBlockGrid on MI355X.
+//
+//   o3dmi_vbg_depth_touch       <- DepthTouchCUDA  (t/geometry/kernel/VoxelBlockGridCUDA.cu:106-227)
+//                                  arithmetic as DepthTouchCPU (VoxelBlockGridCPU.cpp:117-201)
+//   o3dmi_vbg_pointcloud_touch  <- PointCloudTouchCUDA (VoxelBlockGridCUDA.cu:42-104)
+//   o3dmi_vbg_touch_activate    fused front end for the frame-stream fast path
+//   o3dmi_unproject             <- UnprojectCUDA (t/geometry/kernel/PointCloudImpl.h:42-143)
+//
+// Design: the reference materialises 4 candidates per ray, activates them in a
+// scratch hash map and compacts by mask (3 kernels + 2 host syncs). Here each
+// ray inserts its candidates directly into the hash with a single CAS per
+// *distinct* key per wave (neighbouring rays mostly hit the same block: a
+// wave-level match-any dedup removes ~95 % of the atomics), and the winner of
+// each key appends it to the output list. Counts stay on the device.
+
+#include "common.h"
+
+namespace o3dmi {
+namespace {
+
+// Insert-if-absent of a packed key; returns the slot index and whether this
+// thread created the entry. `val_out` receives the buffer index for creators
+// when kAllocate (main block hash); scratch hashes do not allocate.
+template <bool kAllocate>
+__device__ __forceinline__ bool InsertKey(const HashView& hv, int x, int y,
+                                          int z, unsigned& slot_out) {
+    unsigned long long k = PackKey(x, y, z);
+    unsigned h = HashKey(k) & hv.mask;
+    while (true) {
+        unsigned long long cur = hv.slot_keys[h];
+        if (cur == k) {
+            slot_out = h;
+            return false;
+        }
+        if (cur == kEmptyKey) {
+            unsigned long long old = atomicCAS(&hv.slot_keys[h], kEmptyKey, k);
+            if (old == kEmptyKey) {
+                slot_out = h;
+                if (kAllocate) {
+                    int top = atomicAdd(&hv.counters[0], 1);
+                    if (top >= hv.capacity) {
+                        atomicOr(&hv.counters[1], kErrCapacity);
+                        // Leave a valid (but shared) index so later kernels
+                        // stay in bounds; the error is reported at sync.
+                        hv.slot_vals[h] = 0;
+                        return true;
+                    }
+                    int idx = hv.heap[top];
+                    hv.key_buffer[3 * idx + 0] = x;
+                    hv.key_buffer[3 * idx + 1] = y;
+                    hv.key_buffer[3 * idx + 2] = z;
+                    hv.slot_vals[h] = idx;
+                }
+                return true;
+            }
+            if (old == k) {
+                slot_out = h;
+                return false;
+            }
+        }
+        h = (h + 1) & hv.mask;
+    }
+}
+
+// True for exactly one lane among the active lanes of the wave that hold the
+// same packed key (the lowest such lane). Lanes with valid == false never lead.
+__device__ __forceinline__ bool WaveLeaderForKey(unsigned long long k,
+                                                 bool valid) {
+    // Cheap neighbour filter first: adjacent rays nearly always agree.
+    bool leader = valid;
+    unsigned long long remaining = __ballot(valid);
+    int lane = threadIdx.x & 63;
+    bool decided = !valid;
+    while (remaining) {
+        int first = __ffsll((long long)remaining) - 1;
+        unsigned long long kf = __shfl(k, first);
+        bool same = valid && (k == kf);
+        unsigned long long same_mask = __ballot(same);
+        if (same && !decided) {
+            leader = (lane == first);
+            decided = true;
+        }
+        remaining &= ~same_mask;
+    }
+    return leader;
+}
+
+struct TouchParams {
+    Camera cam;  // intrinsics + POSE (inverse extrinsic), scale 1
+    int rows, cols, stride;
+    int rows_strided, cols_strided;
+    float block_size, sdf_trunc, depth_scale, depth_max;
+};
+
+// Computes the 4 candidate block keys of strided pixel `workload_idx`
+// (VoxelBlockGridCPU.cpp:144-180). Returns false when the pixel is invalid.
+template <typename depth_t>
+__device__ __forceinline__ bool RayCandidates(const TouchParams& p,
+                                              const depth_t* __restrict__ depth,
+                                              int workload_idx, int (&xb)[4],
+                                              int (&yb)[4], int (&zb)[4]) {
+    int y = (workload_idx / p.cols_strided) * p.stride;
+    int x = (workload_idx % p.cols_strided) * p.stride;
+    float d = (float)depth[(int64_t)y * p.cols + x] / p.depth_scale;
+    if (!(d > 0 && d < p.depth_max)) return false;
+
+    float x_c, y_c, z_c, x_g, y_g, z_g;
+    p.cam.Unproject((float)x, (float)y, 1.0f, x_c, y_c, z_c);
+    p.cam.RigidTransform(x_c, y_c, z_c, x_g, y_g, z_g);
+    float x_o = p.cam.e[0][3], y_o = p.cam.e[1][3], z_o = p.cam.e[2][3];
+    float x_d = x_g - x_o, y_d = y_g - y_o, z_d = z_g - z_o;
+
+    const float t_min = fmaxf(d - p.sdf_trunc, 0.0f);
+    const float t_max = fminf(d + p.sdf_trunc, p.depth_max);
+    const float t_step = (t_max - t_min) / 3;
+    float t = t_min;
+#pragma unroll
+    for (int step = 0; step < 4; ++step) {
+        xb[step] = (int)floorf((x_o + t * x_d) / p.block_size);
+        yb[step] = (int)floorf((y_o + t * y_d) / p.block_size);
+        zb[step] = (int)floorf((z_o + t * z_d) / p.block_size);
+        t += t_step;
+    }
+    return true;
+}
+
+template <typename depth_t>
+__global__ void DepthTouchKernel(HashView hv, TouchParams p,
+                                 const depth_t* __restrict__ depth,
+                                 int* __restrict__ out_coords,
+                                 int64_t out_capacity,
+                                 int* __restrict__ out_count) {
+    int n = p.rows_strided * p.cols_strided;
+    int n_padded = ((n + 63) / 64) * 64;  // keep whole waves in the loop
+    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < n_padded;
+         w += gridDim.x * blockDim.x) {
+        int xb[4], yb[4], zb[4];
+        bool valid = (w < n) && RayCandidates(p, depth, w, xb, yb, zb);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bool ok = valid;
+            // Within a ray consecutive samples often repeat the block.
+            if (ok && s > 0 && xb[s] == xb[s - 1] && yb[s] == yb[s - 1] &&
+                zb[s] == zb[s - 1])
+                ok = false;
+            if (ok && !KeyInRange(xb[s], yb[s], zb[s])) {
+                atomicOr(&hv.counters[1], kErrKeyRange);
+                ok = false;
+            }
+            unsigned long long k = ok ? PackKey(xb[s], yb[s], zb[s]) : 0ull;
+            if (WaveLeaderForKey(k, ok)) {
+                unsigned slot;
+                if (InsertKey<false>(hv, xb[s], yb[s], zb[s], slot)) {
+                    int o = atomicAdd(out_count, 1);
+                    if (o < out_capacity) {
+                        out_coords[3 * o + 0] = xb[s];
+                        out_coords[3 * o + 1] = yb[s];
+                        out_coords[3 * o + 2] = zb[s];
+                    } else {
+                        atomicOr(&hv.counters[1], kErrCapacity);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Fused: candidates -> find-or-create in the MAIN block hash -> first toucher
+// of a slot in this frame (slot_stamp exchange) appends the slot to the list.
+template <typename depth_t>
+__global__ void TouchActivateKernel(HashView hv, TouchParams p,
+                                    const depth_t* __restrict__ depth,
+                                    int* __restrict__ out_slots,
+                                    int64_t out_capacity,
+                                    int* __restrict__ out_count,
+                                    int frame_stamp) {
+    int n = p.rows_strided * p.cols_strided;
+    int n_padded = ((n + 63) / 64) * 64;
+    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < n_padded;
+         w += gridDim.x * blockDim.x) {
+        int xb[4], yb[4], zb[4];
+        bool valid = (w < n) && RayCandidates(p, depth, w, xb, yb, zb);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bool ok = valid;
+            if (ok && s > 0 && xb[s] == xb[s - 1] && yb[s] == yb[s - 1] &&
+                zb[s] == zb[s - 1])
+                ok = false;
+            if (ok && !KeyInRange(xb[s], yb[s], zb[s])) {
+                atomicOr(&hv.counters[1], kErrKeyRange);
+                ok = false;
+            }
+            unsigned long long k = ok ? PackKey(xb[s], yb[s], zb[s]) : 0ull;
+            if (WaveLeaderForKey(k, ok)) {
+                unsigned slot;
+                InsertKey<true>(hv, xb[s], yb[s], zb[s], slot);
+                int old = atomicExch(&hv.slot_stamp[slot], frame_stamp);
+                if (old != frame_stamp) {
+                    int o = atomicAdd(out_count, 1);
+                    if (o < out_capacity) out_slots[o] = (int)slot;
+                    else atomicOr(&hv.counters[1], kErrCapacity);
+                }
+            }
+        }
+    }
+}
+
+// slot list -> buffer indices (slot_vals are published by the previous kernel).
+__global__ void SlotsToIndicesKernel(HashView hv, int* __restrict__ io,
+                                     const int* __restrict__ count,
+                                     int64_t capacity) {
+    int64_t n = *count;
+    if (n > capacity) n = capacity;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        io[i] = hv.slot_vals[io[i]];
+}
+
+__global__ void PointCloudTouchKernel(HashView hv,
+                                      const float* __restrict__ pcd, int64_t n,
+                                      float block_size, float sdf_trunc,
+                                      int* __restrict__ out_coords,
+                                      int64_t out_capacity,
+                                      int* __restrict__ out_count) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float x = pcd[3 * i + 0], y = pcd[3 * i + 1], z = pcd[3 * i + 2];
+        int xb_lo = (int)floorf((x - sdf_trunc) / block_size);
+        int xb_hi = (int)floorf((x + sdf_trunc) / block_size);
+        int yb_lo = (int)floorf((y - sdf_trunc) / block_size);
+        int yb_hi = (int)floorf((y + sdf_trunc) / block_size);
+        int zb_lo = (int)floorf((z - sdf_trunc) / block_size);
+        int zb_hi = (int)floorf((z + sdf_trunc) / block_size);
+        for (int xb = xb_lo; xb <= xb_hi; ++xb)
+            for (int yb = yb_lo; yb <= yb_hi; ++yb)
+                for (int zb = zb_lo; zb <= zb_hi; ++zb) {
+                    if (!KeyInRange(xb, yb, zb)) {
+                        atomicOr(&hv.counters[1], kErrKeyRange);
+                        continue;
+                    }
+                    unsigned slot;
+                    if (InsertKey<false>(hv, xb, yb, zb, slot)) {
+                        int o = atomicAdd(out_count, 1);
+                        if (o < out_capacity) {
+                            out_coords[3 * o + 0] = xb;
+                            out_coords[3 * o + 1] = yb;
+                            out_coords[3 * o + 2] = zb;
+                        } else {
+                            atomicOr(&hv.counters[1], kErrCapacity);
+                        }
+                    }
+                }
+    }
+}
+
+template <typename depth_t>
+__global__ void UnprojectKernel(TouchParams p,
+                                const depth_t* __restrict__ depth,
+                                const float* __restrict__ image_colors,
+                                float* __restrict__ points,
+                                float* __restrict__ colors,
+                                int* __restrict__ count) {
+    int64_t n = (int64_t)p.rows_strided * p.cols_strided;
+    int64_t n_padded = ((n + 63) / 64) * 64;
+    for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+         w < n_padded; w += (int64_t)gridDim.x * blockDim.x) {
+        bool valid = false;
+        int64_t y = 0, x = 0;
+        float d = 0;
+        if (w < n) {
+            y = (w / p.cols_strided) * p.stride;
+            x = (w % p.cols_strided) * p.stride;
+            d = (float)depth[y * p.cols + x] / p.depth_scale;
+            valid = d > 0 && d < p.depth_max;
+        }
+        // Wave-aggregated compaction (one atomic per wave).
+        unsigned long long ballot = __ballot(valid);
+        int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == 0 && ballot) base = atomicAdd(count, __popcll(ballot));
+        base = __shfl(base, 0);
+        if (valid) {
+            int idx = base + __popcll(ballot & ((1ull << lane) - 1ull));
+            float x_c, y_c, z_c, xo, yo, zo;
+            p.cam.Unproject((float)x, (float)y, d, x_c, y_c, z_c);
+            p.cam.RigidTransform(x_c, y_c, z_c, xo, yo, zo);
+            points[3 * (int64_t)idx + 0] = xo;
+            points[3 * (int64_t)idx + 1] = yo;
+            points[3 * (int64_t)idx + 2] = zo;
+            if (colors && image_colors) {
+                const float* ip = image_colors + 3 * (y * p.cols + x);
+                colors[3 * (int64_t)idx + 0] = ip[0];
+                colors[3 * (int64_t)idx + 1] = ip[1];
+                colors[3 * (int64_t)idx + 2] = ip[2];
+            }
+        }
+    }
+}
+
+TouchParams MakeTouchParams(const double* intrinsic, const double* extrinsic,
+                            int rows, int cols, int stride, int resolution,
+                            float voxel_size, float sdf_trunc,
+                            float depth_scale, float depth_max) {
+    TouchParams p;
+    double pose[16];
+    InverseTransformation(extrinsic, pose);
+    p.cam = Camera::Make(intrinsic, pose, 1.0f);
+    p.rows = rows;
+    p.cols = cols;
+    p.stride = stride;
+    p.rows_strided = rows / stride;
+    p.cols_strided = cols / stride;
+    p.block_size = voxel_size * resolution;
+    p.sdf_trunc = sdf_trunc;
+    p.depth_scale = depth_scale;
+    p.depth_max = depth_max;
+    return p;
+}
+
+}  // namespace
+}  // namespace o3dmi
+
+using namespace o3dmi;
+
+extern "C" {
+
+int o3dmi_vbg_depth_touch(o3dmi_hash_t* fh, const void* depth_dev,
+                          int depth_dtype, int rows, int cols,
+                          const double* intrinsic, const double* extrinsic,
+                          int32_t* out_coords_dev, int64_t out_capacity,
+                          int32_t* out_count_dev, int resolution,
+                          float voxel_size, float sdf_trunc, float depth_scale,
+                          float depth_max, int stride, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(fh && depth_dev && intrinsic && extrinsic && out_coords_dev &&
+                          out_count_dev,
+                  "null argument");
+    O3DMI_REQUIRE(depth_dtype == O3DMI_U16 || depth_dtype == O3DMI_F32,
+                  "depth dtype must be UInt16 or Float32");
+    O3DMI_REQUIRE(stride > 0 && rows >= stride && cols >= stride,
+                  "bad image size / stride");
+    hipStream_t s = (hipStream_t)stream;
+    TouchParams p = MakeTouchParams(intrinsic, extrinsic, rows, cols, stride,
+                                    resolution, voxel_size, sdf_trunc,
+                                    depth_scale, depth_max);
+    int st = o3dmi_hash_clear(fh, stream);
+    if (st != O3DMI_OK) return st;
+    O3DMI_HIP_CHECK(hipMemsetAsync(out_count_dev, 0, sizeof(int), s));
+    int n = p.rows_strided * p.cols_strided;
+    dim3 grid(GridFor(n, kBlock)), block(kBlock);
+    if (depth_dtype == O3DMI_U16)
+        hipLaunchKernelGGL(DepthTouchKernel<uint16_t>, grid, block, 0, s,
+                           fh->view, p, (const uint16_t*)depth_dev,
+                           out_coords_dev, out_capacity, out_count_dev);
+    else
+        hipLaunchKernelGGL(DepthTouchKernel<float>, grid, block, 0, s, fh->view,
+                           p, (const float*)depth_dev, out_coords_dev,
+                           out_capacity, out_count_dev);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+int o3dmi_vbg_touch_activate(o3dmi_hash_t* bh, const void* depth_dev,
+                             int depth_dtype, int rows, int cols,
+                             const double* intrinsic, const double* extrinsic,
+                             int32_t* out_buf_indices_dev,
+                             int64_t out_capacity, int32_t* out_count_dev,
+                             int resolution, float voxel_size, float sdf_trunc,
+                             float depth_scale, float depth_max, int stride,
+                             int32_t frame_stamp, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(bh && depth_dev && intrinsic && extrinsic &&
+                          out_buf_indices_dev && out_count_dev,
+                  "null argument");
+    O3DMI_REQUIRE(depth_dtype == O3DMI_U16 || depth_dtype == O3DMI_F32,
+                  "depth dtype must be UInt16 or Float32");
+    O3DMI_REQUIRE(stride > 0 && rows >= stride && cols >= stride,
+                  "bad image size / stride");
+    O3DMI_REQUIRE(frame_stamp > 0, "frame_stamp must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    TouchParams p = MakeTouchParams(intrinsic, extrinsic, rows, cols, stride,
+                                    resolution, voxel_size, sdf_trunc,
+                                    depth_scale, depth_max);
+    O3DMI_HIP_CHECK(hipMemsetAsync(out_count_dev, 0, sizeof(int), s));
+    int n = p.rows_strided * p.cols_strided;
+    dim3 grid(GridFor(n, kBlock)), block(kBlock);
+    if (depth_dtype == O3DMI_U16)
+        hipLaunchKernelGGL(TouchActivateKernel<uint16_t>, grid, block, 0, s,
+                           bh->view, p, (const uint16_t*)depth_dev,
+                           out_buf_indices_dev, out_capacity, out_count_dev,
+                           frame_stamp);
+    else
+        hipLaunchKernelGGL(TouchActivateKernel<float>, grid, block, 0, s,
+                           bh->view, p, (const float*)depth_dev,
+                           out_buf_indices_dev, out_capacity, out_count_dev,
+                           frame_stamp);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(SlotsToIndicesKernel, dim3(64), dim3(kBlock), 0, s,
+                       bh->view, out_buf_indices_dev, out_count_dev,
+                       out_capacity);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+int o3dmi_vbg_pointcloud_touch(o3dmi_hash_t* fh, const float* points_dev,
+                               int64_t n, int32_t* out_coords_dev,
+                               int64_t out_capacity, int32_t* out_count_dev,
+                               int resolution, float voxel_size,
+                               float sdf_trunc, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(fh && points_dev && out_coords_dev && out_count_dev,
+                  "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    int st = o3dmi_hash_clear(fh, stream);
+    if (st != O3DMI_OK) return st;
+    O3DMI_HIP_CHECK(hipMemsetAsync(out_count_dev, 0, sizeof(int), s));
+    if (n == 0) return O3DMI_OK;
+    hipLaunchKernelGGL(PointCloudTouchKernel, dim3(GridFor(n, kBlock)),
+                       dim3(kBlock), 0, s, fh->view, points_dev, n,
+                       voxel_size * resolution, sdf_trunc, out_coords_dev,
+                       out_capacity, out_count_dev);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+int o3dmi_unproject(const void* depth_dev, int depth_dtype, int rows, int cols,
+                    const float* image_colors_dev, float* points_dev,
+                    float* colors_dev, int32_t* out_count_dev,
+                    const double* intrinsic, const double* extrinsic,
+                    float depth_scale, float depth_max, int64_t stride,
+                    o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(depth_dev && points_dev && out_count_dev && intrinsic &&
+                          extrinsic,
+                  "null argument");
+    O3DMI_REQUIRE(depth_dtype == O3DMI_U16 || depth_dtype == O3DMI_F32,
+                  "depth dtype must be UInt16 or Float32");
+    O3DMI_REQUIRE(stride > 0 && rows >= stride && cols >= stride,
+                  "bad image size / stride");
+    hipStream_t s = (hipStream_t)stream;
+    TouchParams p = MakeTouchParams(intrinsic, extrinsic, rows, cols,
+                                    (int)stride, 1, 1.0f, 0.0f, depth_scale,
+                                    depth_max);
+    O3DMI_HIP_CHECK(hipMemsetAsync(out_count_dev, 0, sizeof(int), s));
+    int64_t n = (int64_t)p.rows_strided * p.cols_strided;
+    dim3 grid(GridFor(n, kBlock)), block(kBlock);
+    if (depth_dtype == O3DMI_U16)
+        hipLaunchKernelGGL(UnprojectKernel<uint16_t>, grid, block, 0, s, p,
+                           (const uint16_t*)depth_dev, image_colors_dev,
+                           points_dev, colors_dev, out_count_dev);
+    else
+        hipLaunchKernelGGL(UnprojectKernel<float>, grid, block, 0, s, p,
+                           (const float*)depth_dev, image_colors_dev,
+                           points_dev, colors_dev, out_count_dev);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+}  // extern "C"

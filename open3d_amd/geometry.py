@@ -1,0 +1,247 @@
+"""Python mirror of open3d.t.geometry.VoxelBlockGrid for the MI355X backend.
+
+Same constructor and method names / defaults as the reference's binding
+(cpp/pybind/t/geometry/voxel_block_grid.cpp:31-178); tensors are torch device
+tensors (depth {H,W} or {H,W,1} uint16|float32, colour {H,W,3} uint8|float32,
+block_coords {M,3} int32), intrinsic / extrinsic are Float64 host matrices.
+All compute goes through libo3d_mi355x.so (no fallback).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .core import (TORCH_TO_O3DMI, host_mat, require_cuda, stream,
+                   tensor_from_ptr)
+
+
+class HashMapView:
+    """Read-only view of the grid's block hash map (o3d.core.HashMap subset)."""
+
+    def __init__(self, handle, owner):
+        self._h = handle
+        self._owner = owner
+
+    def size(self):
+        n = C.c_int64(0)
+        _lib.check(_lib.lib().o3dmi_hash_size(self._h, stream(), C.byref(n)),
+                   "HashMap.size")
+        return int(n.value)
+
+    def capacity(self):
+        return int(_lib.lib().o3dmi_hash_capacity(self._h))
+
+    def key_tensor(self):
+        p = _lib.lib().o3dmi_hash_key_buffer(self._h)
+        return tensor_from_ptr(p, (self.capacity(), 3), _lib.I32, self._owner)
+
+    def active_buf_indices(self):
+        out = torch.empty(self.capacity(), dtype=torch.int32, device="cuda")
+        n = C.c_int64(0)
+        _lib.check(_lib.lib().o3dmi_hash_active_indices(
+            self._h, _lib.ptr(out), stream(), C.byref(n)),
+            "HashMap.active_buf_indices")
+        return out[:n.value]
+
+    def find(self, keys):
+        keys = require_cuda(keys, "keys")
+        n = keys.shape[0]
+        buf = torch.empty(n, dtype=torch.int32, device="cuda")
+        masks = torch.empty(n, dtype=torch.bool, device="cuda")
+        _lib.check(_lib.lib().o3dmi_hash_find(
+            self._h, _lib.ptr(keys), n, None, _lib.ptr(buf), _lib.ptr(masks),
+            stream()), "HashMap.find")
+        return buf, masks
+
+
+def _image(t, name, channels):
+    t = require_cuda(t, name)
+    if t.dim() == 3 and t.shape[2] == 1 and channels == 1:
+        t = t[:, :, 0]
+    if channels == 1 and t.dim() != 2:
+        raise ValueError("%s must be {H,W} or {H,W,1}" % name)
+    if channels == 3 and (t.dim() != 3 or t.shape[2] != 3):
+        raise ValueError("%s must be {H,W,3}" % name)
+    return t
+
+
+class VoxelBlockGrid:
+    _CHANNELS = {"vertex": 3, "normal": 3, "depth": 1, "color": 3, "index": 8,
+                 "mask": 8, "interp_ratio": 8, "interp_ratio_dx": 8,
+                 "interp_ratio_dy": 8, "interp_ratio_dz": 8}
+
+    def __init__(self, attr_names, attr_dtypes, attr_channels,
+                 voxel_size=0.0058, block_resolution=16, block_count=10000,
+                 device="cuda:0"):
+        if len(attr_dtypes) != len(attr_names):
+            raise ValueError("Number of attribute dtypes (%d) mismatch with "
+                             "names (%d)." % (len(attr_dtypes),
+                                              len(attr_names)))
+        if len(attr_channels) != len(attr_names):
+            raise ValueError("Number of attribute channels (%d) mismatch with "
+                             "names (%d)." % (len(attr_channels),
+                                              len(attr_names)))
+        self.voxel_size = float(voxel_size)
+        self.block_resolution = int(block_resolution)
+        self.attr_names = list(attr_names)
+        n = len(attr_names)
+        names = (C.c_char_p * n)(*[s.encode() for s in attr_names])
+        dts = (C.c_int * n)(*[TORCH_TO_O3DMI[d] for d in attr_dtypes])
+        chans = []
+        for c in attr_channels:
+            c = tuple(c) if isinstance(c, (tuple, list)) else (c,)
+            chans.append(int(np.prod(c)))
+        chs = (C.c_int * n)(*chans)
+        self._chans = dict(zip(attr_names, chans))
+        h = C.c_void_p()
+        _lib.check(_lib.lib().o3dmi_vbg_create(
+            n, names, dts, chs, C.c_float(voxel_size), int(block_resolution),
+            int(block_count), stream(), C.byref(h)), "VoxelBlockGrid")
+        self._g = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "_g", None):
+                _lib.lib().o3dmi_vbg_destroy(self._g)
+                self._g = None
+        except Exception:
+            pass
+
+    def hashmap(self):
+        return HashMapView(C.c_void_p(_lib.lib().o3dmi_vbg_hashmap(self._g)),
+                           self)
+
+    def attribute(self, attribute_name):
+        dt, ch = C.c_int(0), C.c_int(0)
+        p = _lib.lib().o3dmi_vbg_attribute(self._g, attribute_name.encode(),
+                                           C.byref(dt), C.byref(ch))
+        if not p:
+            return torch.empty(0)
+        r = self.block_resolution
+        return tensor_from_ptr(p, (self.hashmap().capacity(), r, r, r,
+                                   ch.value), dt.value, self)
+
+    def compute_unique_block_coordinates(self, depth, intrinsic, extrinsic,
+                                         depth_scale=1000.0, depth_max=3.0,
+                                         trunc_voxel_multiplier=8.0):
+        depth = _image(depth, "depth", 1)
+        K = host_mat(intrinsic, (3, 3), "intrinsic")
+        T = host_mat(extrinsic, (4, 4), "extrinsic")
+        rows, cols = depth.shape
+        cap = (rows // 4) * (cols // 4) * 4
+        out = torch.empty((cap, 3), dtype=torch.int32, device="cuda")
+        m = C.c_int64(0)
+        _lib.check(_lib.lib().o3dmi_vbg_get_unique_block_coordinates(
+            self._g, _lib.ptr(depth), TORCH_TO_O3DMI[depth.dtype], rows, cols,
+            _lib.f64p(K), _lib.f64p(T), C.c_float(depth_scale),
+            C.c_float(depth_max), C.c_float(trunc_voxel_multiplier),
+            _lib.ptr(out), C.byref(m), stream()),
+            "VoxelBlockGrid.compute_unique_block_coordinates")
+        return out[:m.value]
+
+    def integrate(self, block_coords, depth, color=None, depth_intrinsic=None,
+                  color_intrinsic=None, extrinsic=None, depth_scale=1000.0,
+                  depth_max=3.0, trunc_voxel_multiplier=8.0):
+        block_coords = require_cuda(block_coords, "block_coords")
+        if block_coords.dtype != torch.int32:
+            raise ValueError("Unsupported block coordinate dtype %s"
+                             % block_coords.dtype)
+        depth = _image(depth, "depth", 1)
+        if color_intrinsic is None:
+            color_intrinsic = depth_intrinsic
+        Kd = host_mat(depth_intrinsic, (3, 3), "intrinsic")
+        Kc = host_mat(color_intrinsic, (3, 3), "intrinsic")
+        T = host_mat(extrinsic, (4, 4), "extrinsic")
+        crows = ccols = 0
+        if color is not None and color.numel() > 0:
+            color = _image(color, "color", 3)
+            crows, ccols = color.shape[:2]
+            want = torch.float32 if depth.dtype == torch.float32 \
+                else torch.uint8
+            if color.dtype != want:
+                raise ValueError(
+                    "Unsupported input data type combination. Expected "
+                    "(float, float) or (uint16, uint8), but received (%s %s)"
+                    % (depth.dtype, color.dtype))
+        else:
+            color = None
+        _lib.check(_lib.lib().o3dmi_vbg_integrate_blocks(
+            self._g, _lib.ptr(block_coords), block_coords.shape[0],
+            _lib.ptr(depth), depth.shape[0], depth.shape[1], _lib.ptr(color),
+            crows, ccols, TORCH_TO_O3DMI[depth.dtype], _lib.f64p(Kd),
+            _lib.f64p(Kc), _lib.f64p(T), C.c_float(depth_scale),
+            C.c_float(depth_max), C.c_float(trunc_voxel_multiplier),
+            stream()), "VoxelBlockGrid.integrate")
+
+    def integrate_frame(self, depth, color, depth_intrinsic, color_intrinsic,
+                        extrinsic, depth_scale=1000.0, depth_max=3.0,
+                        trunc_voxel_multiplier=8.0):
+        """compute_unique_block_coordinates + integrate of one frame with all
+        counts device-resident (frame-stream fast path; same results)."""
+        depth = _image(depth, "depth", 1)
+        if color_intrinsic is None:
+            color_intrinsic = depth_intrinsic
+        Kd = host_mat(depth_intrinsic, (3, 3), "intrinsic")
+        Kc = host_mat(color_intrinsic, (3, 3), "intrinsic")
+        T = host_mat(extrinsic, (4, 4), "extrinsic")
+        crows = ccols = 0
+        if color is not None and color.numel() > 0:
+            color = _image(color, "color", 3)
+            crows, ccols = color.shape[:2]
+        else:
+            color = None
+        _lib.check(_lib.lib().o3dmi_vbg_integrate_frame(
+            self._g, _lib.ptr(depth), depth.shape[0], depth.shape[1],
+            _lib.ptr(color), crows, ccols, TORCH_TO_O3DMI[depth.dtype],
+            _lib.f64p(Kd), _lib.f64p(Kc), _lib.f64p(T), C.c_float(depth_scale),
+            C.c_float(depth_max), C.c_float(trunc_voxel_multiplier),
+            stream()), "VoxelBlockGrid.integrate_frame")
+
+    def profile_begin(self, max_frames):
+        _lib.check(_lib.lib().o3dmi_vbg_profile_begin(self._g, int(max_frames)),
+                   "profile_begin")
+
+    def profile_end(self):
+        """-> dict(integrate_ms, touch_ms, launches, block_frames)."""
+        ti, tt = C.c_double(0), C.c_double(0)
+        n, bf = C.c_int64(0), C.c_int64(0)
+        _lib.check(_lib.lib().o3dmi_vbg_profile_end(
+            self._g, stream(), C.byref(ti), C.byref(tt), C.byref(n),
+            C.byref(bf)), "profile_end")
+        return dict(integrate_ms=ti.value, touch_ms=tt.value,
+                    launches=n.value, block_frames=bf.value)
+
+    def ray_cast(self, block_coords, intrinsic, extrinsic, width, height,
+                 render_attributes=("depth", "color"), depth_scale=1000.0,
+                 depth_min=0.1, depth_max=3.0, weight_threshold=3.0,
+                 trunc_voxel_multiplier=8.0, range_map_down_factor=8):
+        block_coords = require_cuda(block_coords, "block_coords")
+        if block_coords.dtype != torch.int32:
+            raise ValueError("Unsupported block coordinate dtype %s"
+                             % block_coords.dtype)
+        K = host_mat(intrinsic, (3, 3), "intrinsic")
+        T = host_mat(extrinsic, (4, 4), "extrinsic")
+        out = {}
+        for a in render_attributes:
+            if a not in self._CHANNELS:
+                raise ValueError("Unsupported attribute %s, please implement "
+                                 "customized ray casting." % a)
+            dt = torch.bool if a == "mask" else (
+                torch.int64 if a == "index" else torch.float32)
+            out[a] = torch.empty((height, width, self._CHANNELS[a]), dtype=dt,
+                                 device="cuda")
+        d = range_map_down_factor
+        out["range"] = torch.empty((height // d, width // d, 2),
+                                   dtype=torch.float32, device="cuda")
+        g = lambda a: _lib.ptr(out.get(a))
+        _lib.check(_lib.lib().o3dmi_vbg_ray_cast(
+            self._g, _lib.ptr(block_coords), block_coords.shape[0],
+            _lib.f64p(K), _lib.f64p(T), int(width), int(height), g("range"),
+            g("depth"), g("vertex"), g("color"), g("normal"), g("index"),
+            g("mask"), g("interp_ratio"), g("interp_ratio_dx"),
+            g("interp_ratio_dy"), g("interp_ratio_dz"), C.c_float(depth_scale),
+            C.c_float(depth_min), C.c_float(depth_max),
+            C.c_float(weight_threshold), C.c_float(trunc_voxel_multiplier),
+            int(range_map_down_factor), stream()), "VoxelBlockGrid.ray_cast")
+        return out

@@ -1,0 +1,127 @@
+"""Python mirror of open3d.t.pipelines.registration.{icp, multi_scale_icp}
+for the MI355X backend (point-to-plane estimator).
+
+Argument names / defaults follow the reference's binding
+(cpp/pybind/t/pipelines/registration/registration.cpp) and
+t/pipelines/registration/Registration.h:31-98,133-208. Point clouds are given
+as torch device tensors {N,3} (float32 or float64).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .core import TORCH_TO_O3DMI, require_cuda, stream
+
+
+class ICPConvergenceCriteria:
+    def __init__(self, relative_fitness=1e-6, relative_rmse=1e-6,
+                 max_iteration=30):
+        self.relative_fitness = relative_fitness
+        self.relative_rmse = relative_rmse
+        self.max_iteration = max_iteration
+
+
+class RobustKernel:
+    L2Loss, L1Loss, HuberLoss, CauchyLoss, GMLoss, TukeyLoss, \
+        GeneralizedLoss = range(7)
+
+    def __init__(self, type=0, scaling_parameter=1.0, shape_parameter=1.0):
+        self.type = type
+        self.scaling_parameter = scaling_parameter
+        self.shape_parameter = shape_parameter
+
+
+class TransformationEstimationPointToPlane:
+    def __init__(self, kernel=None):
+        self.kernel = kernel or RobustKernel()
+
+
+class RegistrationResult:
+    def __init__(self):
+        self.transformation = np.eye(4)
+        self.correspondence_set = None
+        self.inlier_rmse = 0.0
+        self.fitness = 0.0
+        self.converged = False
+        self.num_iterations = 0
+
+
+def multi_scale_icp(source, target, target_normals, voxel_sizes, criteria_list,
+                    max_correspondence_distances, init_source_to_target=None,
+                    estimation_method=None, callback_after_iteration=None,
+                    allreduce=None):
+    """source/target/target_normals: device tensors {N,3}. `allreduce`
+    (optional) sums a length-32 numpy float64 array over ranks in place."""
+    source = require_cuda(source, "source")
+    target = require_cuda(target, "target")
+    target_normals = require_cuda(target_normals, "target_normals")
+    if source.dtype not in (torch.float32, torch.float64):
+        raise ValueError("Only Float32 and Float64 point clouds are supported.")
+    if target.dtype != source.dtype or target_normals.dtype != source.dtype:
+        raise ValueError("source / target dtype mismatch")
+    est = estimation_method or TransformationEstimationPointToPlane()
+    S = len(criteria_list)
+    if not (len(voxel_sizes) == S and len(max_correspondence_distances) == S):
+        raise ValueError("Size of criterias, voxel_size, "
+                         "max_correspondence_distances vectors must be same.")
+    vs = np.ascontiguousarray(voxel_sizes, dtype=np.float64)
+    md = np.ascontiguousarray(max_correspondence_distances, dtype=np.float64)
+    crit = (_lib.IcpCriteria * S)(*[
+        _lib.IcpCriteria(c.relative_fitness, c.relative_rmse, c.max_iteration)
+        for c in criteria_list])
+    init = np.ascontiguousarray(
+        np.eye(4) if init_source_to_target is None else init_source_to_target,
+        dtype=np.float64)
+    if init.shape != (4, 4):
+        raise ValueError("init_source_to_target must be 4x4")
+    ns, nt = source.shape[0], target.shape[0]
+    corr = torch.full((ns,), -1, dtype=torch.int64, device="cuda")
+    res = _lib.RegistrationResultC()
+
+    cb = _lib.ICP_CALLBACK(0)
+    if callback_after_iteration is not None:
+        def _cb(it, sc, sit, rmse, fit, Tp, user):
+            callback_after_iteration({
+                "iteration_index": it, "scale_index": sc,
+                "scale_iteration_index": sit, "inlier_rmse": rmse,
+                "fitness": fit,
+                "transformation": np.ctypeslib.as_array(
+                    Tp, shape=(16,)).reshape(4, 4).copy()})
+        cb = _lib.ICP_CALLBACK(_cb)
+    ar = _lib.ALLREDUCE_SUM(0)
+    if allreduce is not None:
+        def _ar(buf, n, user):
+            a = np.ctypeslib.as_array(buf, shape=(n,))
+            allreduce(a)
+            return 0
+        ar = _lib.ALLREDUCE_SUM(_ar)
+
+    st = _lib.lib().o3dmi_registration_multiscale_icp(
+        _lib.ptr(source), ns, _lib.ptr(target), _lib.ptr(target_normals), nt,
+        TORCH_TO_O3DMI[source.dtype], S, _lib.f64p(vs), crit, _lib.f64p(md),
+        _lib.f64p(init), int(est.kernel.type),
+        C.c_double(est.kernel.scaling_parameter),
+        C.c_double(est.kernel.shape_parameter), cb, None, ar, None,
+        _lib.ptr(corr), C.byref(res), stream())
+    _lib.check(st, "multi_scale_icp")
+    out = RegistrationResult()
+    out.transformation = np.array(res.transformation[:]).reshape(4, 4)
+    out.inlier_rmse = res.inlier_rmse
+    out.fitness = res.fitness
+    out.converged = bool(res.converged)
+    out.num_iterations = res.num_iterations
+    out.correspondence_set = corr[:res.num_correspondences]
+    return out
+
+
+def icp(source, target, target_normals, max_correspondence_distance,
+        init_source_to_target=None, estimation_method=None, criteria=None,
+        voxel_size=-1.0, callback_after_iteration=None, allreduce=None):
+    """t::pipelines::registration::ICP (Registration.cpp:93-106)."""
+    return multi_scale_icp(source, target, target_normals, [voxel_size],
+                           [criteria or ICPConvergenceCriteria()],
+                           [max_correspondence_distance],
+                           init_source_to_target, estimation_method,
+                           callback_after_iteration, allreduce)

@@ -1,0 +1,278 @@
+"""GPU parity tests of the ICP path: HIP (through the C ABI) vs the CPU oracle.
+
+Bars (BASELINE.json north_star): correspondence indices exact; pose within
+1e-6 rad / 1e-5 m of the CPU path."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import _oracle as orc
+from test_oracle_goldens import CORR, SRC, TGT, TGT_N
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from open3d_amd import _lib, registration
+    return _lib, registration
+
+
+def _pair(n=20000, seed=0, dtype=np.float32, **kw):
+    from open3d_amd import synthetic as syn
+    return syn.make_icp_pair(n, n, seed=seed, dtype=dtype, **kw)
+
+
+def _search(_lib, pts, qrs, radius):
+    from open3d_amd.core import TORCH_TO_O3DMI, stream
+    L = _lib.lib()
+    tp = torch.from_numpy(pts).cuda()
+    tq = torch.from_numpy(qrs).cuda()
+    h = C.c_void_p()
+    _lib.check(L.o3dmi_nns_create(_lib.ptr(tp), tp.shape[0],
+                                  TORCH_TO_O3DMI[tp.dtype], C.c_double(radius),
+                                  stream(), C.byref(h)), "nns_create")
+    q = tq.shape[0]
+    idx = torch.zeros(q, dtype=torch.int32, device="cuda")
+    d2 = torch.zeros(q, dtype=tp.dtype, device="cuda")
+    cnt = torch.zeros(q, dtype=torch.int32, device="cuda")
+    _lib.check(L.o3dmi_nns_hybrid_search_k1(h, _lib.ptr(tq), q, _lib.ptr(idx),
+                                            _lib.ptr(d2), _lib.ptr(cnt),
+                                            stream()), "search")
+    torch.cuda.synchronize()
+    L.o3dmi_nns_destroy(h)
+    return idx.cpu().numpy(), d2.cpu().numpy(), cnt.cpu().numpy()
+
+
+def _angle(Ra, Rb):
+    c = (np.trace(Ra.T @ Rb) - 1) / 2
+    return float(np.arccos(np.clip(c, -1, 1)))
+
+
+def _pose_err(Ta, Tb):
+    """Rotation angle (rad) and translation distance (m) between two poses."""
+    d = np.linalg.inv(Ta) @ Tb
+    # small-angle safe
+    skew = d[:3, :3] - d[:3, :3].T
+    ang = float(np.linalg.norm([skew[2, 1], skew[0, 2], skew[1, 0]]) / 2)
+    return ang, float(np.linalg.norm(Ta[:3, 3] - Tb[:3, 3]))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_hybrid_search_golden_through_gpu(dtype):
+    """cpp/tests/core/NearestNeighborSearch.cpp:321-377 (k=1 column)."""
+    _lib, _ = _gpu()
+    pts = np.array([[0.0, 0.0, 0.0], [0.0, 0.0, 0.1], [0.0, 0.0, 0.2],
+                    [0.0, 0.1, 0.0], [0.0, 0.1, 0.1], [0.0, 0.1, 0.2],
+                    [0.0, 0.2, 0.0], [0.0, 0.2, 0.1], [0.0, 0.2, 0.2],
+                    [0.1, 0.0, 0.0]], dtype)
+    q = np.array([[0.064705, 0.043921, 0.087843]], dtype)
+    idx, d2, cnt = _search(_lib, pts, q, 0.1)
+    assert idx.tolist() == [1] and cnt.tolist() == [1]
+    assert abs(d2[0] - 0.00626358) < 1e-7
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_hybrid_search_parity_exact(dtype):
+    _lib, _ = _gpu()
+    p = _pair(30000, seed=1, dtype=dtype)
+    for radius in (0.03, 0.07):
+        wi, wd, wc = orc.hybrid_search(p["target"], p["source"], radius, 1)
+        gi, gd, gc = _search(_lib, p["target"], p["source"], radius)
+        assert np.array_equal(gi, wi[:, 0])
+        assert np.array_equal(gd, wd[:, 0])  # same float op order: bit-exact
+        assert np.array_equal(gc, wc)
+        assert 0 < gc.sum() < gc.shape[0]
+
+
+def test_hybrid_search_large_offset_recipe():
+    """NNSParityTest.HybridSearchLargeOffsetParityCPU recipe
+    (NearestNeighborSearch.cpp:831-869): 1000 m offset, r = 0.05."""
+    _lib, _ = _gpu()
+    rng = np.random.RandomState(7)
+    n = 4000
+    base = (1000.0 + rng.uniform(0, 3, (n, 3))).astype(np.float32)
+    qrs = (base + rng.uniform(-0.02, 0.02, (n, 3)).astype(np.float32))
+    wi, wd, wc = orc.hybrid_search(base, qrs, 0.05, 1)
+    gi, gd, gc = _search(_lib, base, qrs, 0.05)
+    assert gc.sum() > n // 2 and gc.sum() == wc.sum()
+    assert np.array_equal(gi, wi[:, 0]) and np.array_equal(gd, wd[:, 0])
+
+
+def test_hybrid_search_radius_strict_and_empty():
+    _lib, _ = _gpu()
+    pts = np.array([[0.0, 0.0, 0.0], [0.5, 0.0, 0.0]], np.float32)
+    q = np.array([[0.25, 0.0, 0.0], [9, 9, 9]], np.float32)
+    idx, d2, cnt = _search(_lib, pts, q, 0.25)
+    assert cnt.tolist() == [0, 0] and idx.tolist() == [-1, -1]
+    assert d2.tolist() == [0, 0]
+    idx, d2, cnt = _search(_lib, pts, q, 0.2500001)
+    assert cnt.tolist() == [1, 0] and idx.tolist() == [0, -1]  # tie -> low idx
+
+
+def _accumulate(_lib, s, t, n, corr, kernel=(0, 1.0, 1.0)):
+    from open3d_amd.core import TORCH_TO_O3DMI, stream
+    ts, tt, tn = (torch.from_numpy(np.ascontiguousarray(a)).cuda()
+                  for a in (s, t, n))
+    tc = torch.from_numpy(np.ascontiguousarray(corr, dtype=np.int64)).cuda()
+    out = torch.zeros(29, dtype=torch.float64, device="cuda")
+    _lib.check(_lib.lib().o3dmi_icp_p2plane_accumulate(
+        _lib.ptr(ts), _lib.ptr(tt), _lib.ptr(tn), _lib.ptr(tc), ts.shape[0],
+        TORCH_TO_O3DMI[ts.dtype], kernel[0], C.c_double(kernel[1]),
+        C.c_double(kernel[2]), _lib.ptr(out), stream()), "accumulate")
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_p2plane_golden_through_gpu(dtype):
+    """14/11-point vectors -> RMSE 0.601422 after the estimated transform
+    (cpp/tests/t/pipelines/registration/TransformationEstimation.cpp:176)."""
+    _lib, _ = _gpu()
+    from open3d_amd.core import TORCH_TO_O3DMI, stream
+    L = _lib.lib()
+    s, t, n = SRC.astype(dtype), TGT.astype(dtype), TGT_N.astype(dtype)
+    A = _accumulate(_lib, s, t, n, CORR)
+    assert A[28] == 14
+    pose = np.zeros(6)
+    res, cnt = C.c_float(0), C.c_int(0)
+    assert L.o3dmi_decode_and_solve6x6(_lib.f64p(A), _lib.f64p(pose),
+                                       C.byref(res), C.byref(cnt)) == 0
+    assert cnt.value == 14
+    T = np.zeros((4, 4))
+    L.o3dmi_pose_to_transformation(_lib.f64p(pose), _lib.f64p(T))
+    ts = torch.from_numpy(s.copy()).cuda()
+    _lib.check(L.o3dmi_transform_points(_lib.f64p(T), _lib.ptr(ts), 14,
+                                        TORCH_TO_O3DMI[ts.dtype], stream()),
+               "transform")
+    r = orc.p2plane_rmse(ts.cpu().numpy(), t, n, CORR)
+    assert abs(r - 0.601422) < 1e-4
+    # host helpers agree with the oracle's
+    st, opose, _, _ = orc.decode_and_solve6x6(A)
+    assert st == 0 and np.allclose(pose, opose, rtol=0, atol=1e-15)
+    assert np.array_equal(T, orc.pose_to_transformation(pose))
+    # singular system -> status, zero pose
+    assert L.o3dmi_decode_and_solve6x6(_lib.f64p(np.zeros(29)),
+                                       _lib.f64p(pose), C.byref(res),
+                                       C.byref(cnt)) == 5
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kernel", [(0, 1.0, 1.0), (2, 0.05, 1.0),
+                                    (3, 0.1, 1.0), (5, 0.1, 1.0),
+                                    (6, 0.1, 1.0), (6, 0.2, -2.0),
+                                    (4, 0.5, 1.0), (1, 1.0, 1.0)])
+def test_p2plane_accumulate_parity(dtype, kernel):
+    """29 sums vs the oracle's float64-accumulating variant (same per-term
+    arithmetic in the cloud dtype)."""
+    _lib, _ = _gpu()
+    p = _pair(50000, seed=2, dtype=dtype)
+    idx, _, _ = orc.hybrid_search(p["target"], p["source"], 0.08, 1)
+    corr = idx[:, 0].astype(np.int64)
+    if kernel[0] == 1:
+        # L1: w = 1/|r| is inf at r == 0 exactly; keep only r != 0 rows.
+        r = ((p["source"] - p["target"][np.maximum(corr, 0)]) *
+             p["target_normals"][np.maximum(corr, 0)]).sum(1)
+        corr = np.where(r == 0, -1, corr)
+    want = orc.p2plane_accumulate(p["source"], p["target"],
+                                  p["target_normals"], corr, *kernel,
+                                  accumulate_double=True)
+    got = _accumulate(_lib, p["source"], p["target"], p["target_normals"],
+                      corr, kernel)
+    assert got[28] == want[28] > 1000
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 1e-9 * scale
+    # run-to-run deterministic
+    again = _accumulate(_lib, p["source"], p["target"], p["target_normals"],
+                        corr, kernel)
+    assert np.array_equal(got, again)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_transform_points_normals_exact(dtype):
+    _lib, _ = _gpu()
+    from open3d_amd.core import TORCH_TO_O3DMI, stream
+    L = _lib.lib()
+    p = _pair(10000, seed=3, dtype=dtype)
+    T = p["T_gt"]
+    tp = torch.from_numpy(p["target"].copy()).cuda()
+    tn = torch.from_numpy(p["target_normals"].copy()).cuda()
+    _lib.check(L.o3dmi_transform_points(_lib.f64p(T), _lib.ptr(tp), 10000,
+                                        TORCH_TO_O3DMI[tp.dtype], stream()),
+               "tp")
+    _lib.check(L.o3dmi_transform_normals(_lib.f64p(T), _lib.ptr(tn), 10000,
+                                         TORCH_TO_O3DMI[tn.dtype], stream()),
+               "tn")
+    assert np.array_equal(tp.cpu().numpy(),
+                          orc.transform_points(T, p["target"]))
+    assert np.array_equal(tn.cpu().numpy(),
+                          orc.transform_normals(T, p["target_normals"]))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_icp_pose_parity(dtype):
+    """Full ICP (30 iterations max) vs the oracle driver: pose within
+    1e-6 rad / 1e-5 m, same iteration count, same correspondence set."""
+    _lib, reg = _gpu()
+    p = _pair(20000, seed=4, dtype=dtype)
+    want = orc.multiscale_icp(p["source"], p["target"], p["target_normals"],
+                              [-1.0], [(1e-6, 1e-6, 30)], [0.07],
+                              accumulate_double=True)
+    log = []
+    got = reg.icp(torch.from_numpy(p["source"]).cuda(),
+                  torch.from_numpy(p["target"]).cuda(),
+                  torch.from_numpy(p["target_normals"]).cuda(), 0.07,
+                  criteria=reg.ICPConvergenceCriteria(1e-6, 1e-6, 30),
+                  callback_after_iteration=log.append)
+    ang, tr = _pose_err(want["transformation"], got.transformation)
+    assert ang <= 1e-6 and tr <= 1e-5, (ang, tr)
+    assert got.num_iterations == want["num_iterations"]
+    assert got.converged == want["converged"]
+    assert abs(got.fitness - want["fitness"]) < 1e-12
+    assert abs(got.inlier_rmse - want["inlier_rmse"]) < 1e-6
+    assert len(log) in (got.num_iterations, got.num_iterations + 1)
+    assert log[0]["iteration_index"] == 0 and log[0]["scale_index"] == 0
+    c = got.correspondence_set.cpu().numpy()
+    assert (c == want["correspondences"]).mean() > 0.9999
+    # ICP actually converged to the ground-truth motion
+    ang_gt, tr_gt = _pose_err(p["T_gt"], got.transformation)
+    assert ang_gt < 2e-3 and tr_gt < 5e-3
+    # distance to the reference-arithmetic (float32-accumulating) oracle
+    ref = orc.multiscale_icp(p["source"], p["target"], p["target_normals"],
+                             [-1.0], [(1e-6, 1e-6, 30)], [0.07],
+                             accumulate_double=False)
+    a2, t2 = _pose_err(ref["transformation"], got.transformation)
+    assert a2 < 1e-4 and t2 < 1e-4
+
+
+def test_icp_robust_kernel_and_init():
+    _lib, reg = _gpu()
+    p = _pair(20000, seed=5)
+    init = np.eye(4)
+    init[:3, 3] = [0.01, -0.01, 0.005]
+    want = orc.multiscale_icp(p["source"], p["target"], p["target_normals"],
+                              [-1.0], [(1e-6, 1e-6, 20)], [0.1], init=init,
+                              kernel=(5, 0.05, 1.0), accumulate_double=True)
+    est = reg.TransformationEstimationPointToPlane(
+        reg.RobustKernel(reg.RobustKernel.TukeyLoss, 0.05))
+    got = reg.icp(torch.from_numpy(p["source"]).cuda(),
+                  torch.from_numpy(p["target"]).cuda(),
+                  torch.from_numpy(p["target_normals"]).cuda(), 0.1, init, est,
+                  reg.ICPConvergenceCriteria(1e-6, 1e-6, 20))
+    ang, tr = _pose_err(want["transformation"], got.transformation)
+    assert ang <= 1e-6 and tr <= 1e-5, (ang, tr)
+
+
+def test_icp_no_correspondences():
+    """Registration.cpp:51-60,301-306: fitness 0, identity, not converged."""
+    _lib, reg = _gpu()
+    p = _pair(2000, seed=6)
+    far = p["source"] + np.float32(100.0)
+    got = reg.icp(torch.from_numpy(far).cuda(),
+                  torch.from_numpy(p["target"]).cuda(),
+                  torch.from_numpy(p["target_normals"]).cuda(), 0.05)
+    assert got.fitness == 0 and got.inlier_rmse == 0 and not got.converged
+    assert np.array_equal(got.transformation, np.eye(4))
+    assert got.num_iterations == 0

@@ -1,0 +1,382 @@
+"""GPU parity tests of the VoxelBlockGrid path: HIP (through the C ABI) vs the
+CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): activated block sets bit-exact; TSDF within
+1e-4 (weights / u16 colours are compared exactly -- the arithmetic is the
+same float32 sequence, so in practice everything is bit-identical)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import _oracle as orc
+import _scene as sc
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from open3d_amd import _lib, geometry
+    return _lib, geometry
+
+
+def _mk_grid(geometry, grid_f32, block_count=4096, with_color=True, res=sc.RES):
+    wd = torch.float32 if grid_f32 else torch.uint16
+    names = ["tsdf", "weight"] + (["color"] if with_color else [])
+    dts = [torch.float32, wd] + ([wd] if with_color else [])
+    ch = [1, 1] + ([3] if with_color else [])
+    return geometry.VoxelBlockGrid(names, dts, ch, voxel_size=sc.VOXEL,
+                                   block_resolution=res,
+                                   block_count=block_count)
+
+
+class OracleGrid:
+    """Oracle-side VoxelBlockGrid: hash + numpy value buffers."""
+
+    def __init__(self, grid_f32, capacity, with_color=True, res=sc.RES):
+        self.h = orc.HashMap(capacity)
+        wd = np.float32 if grid_f32 else np.uint16
+        self.res = res
+        self.tsdf = np.zeros((capacity, res, res, res), np.float32)
+        self.weight = np.zeros((capacity, res, res, res), wd)
+        self.color = np.zeros((capacity, res, res, res, 3), wd) \
+            if with_color else None
+
+    def integrate(self, depth, color, K, T, keys=None):
+        if keys is None:
+            keys = orc.depth_touch(depth, K, T, self.res, sc.VOXEL,
+                                   sc.VOXEL * sc.TRUNC_MULT, sc.DEPTH_SCALE,
+                                   sc.DEPTH_MAX, 4)
+        self.h.activate(keys)
+        buf, m = self.h.find(keys)
+        assert m.all()
+        orc.integrate(depth, color, buf, self.h.key_buffer(), self.tsdf,
+                      self.weight, self.color, K, K, T, self.res, sc.VOXEL,
+                      sc.VOXEL * sc.TRUNC_MULT, sc.DEPTH_SCALE, sc.DEPTH_MAX)
+        return keys
+
+
+def _compare_grids(og, g, tsdf_tol=1e-4):
+    """Per-key comparison (buffer indices differ between implementations)."""
+    hm = g.hashmap()
+    n = og.h.size()
+    assert hm.size() == n
+    okeys = og.h.key_buffer()[:n].copy()
+    obuf, _ = og.h.find(okeys)
+    gbuf, gm = hm.find(torch.from_numpy(okeys).cuda())
+    assert bool(gm.all())
+    gbuf = gbuf.cpu().numpy().astype(np.int64)
+    # bit-exact activation set: same keys, nothing extra
+    gkeys = hm.key_tensor().cpu().numpy()[hm.active_buf_indices().cpu().numpy()]
+    assert np.array_equal(sc.sort_rows(gkeys), sc.sort_rows(okeys))
+    t = g.attribute("tsdf").cpu().numpy()[gbuf][..., 0]
+    w = g.attribute("weight").cpu().numpy()[gbuf][..., 0]
+    assert np.array_equal(w, og.weight[obuf])
+    err = np.abs(t - og.tsdf[obuf]).max()
+    assert err <= tsdf_tol, err
+    if og.color is not None:
+        c = g.attribute("color").cpu().numpy()[gbuf]
+        if og.color.dtype == np.uint16:
+            assert np.array_equal(c, og.color[obuf])
+        else:
+            assert np.abs(c - og.color[obuf]).max() <= 1e-2
+    return float(err), bool(np.array_equal(t, og.tsdf[obuf]))
+
+
+def test_extension_loaded_and_device():
+    _lib, _ = _gpu()
+    name = C.create_string_buffer(64)
+    cus = C.c_int(0)
+    mem = C.c_int64(0)
+    _lib.check(_lib.lib().o3dmi_device_info(name, 64, C.byref(cus),
+                                            C.byref(mem)), "device_info")
+    assert name.value.decode().startswith("gfx950"), name.value
+    assert cus.value == 256
+
+
+def test_hash_semantics():
+    """cpp/tests/core/HashMap.cpp:138-191 style: duplicates -> one success;
+    Find; Erase; GetActiveIndices; Reserve keeps key -> value association."""
+    _lib, _ = _gpu()
+    from open3d_amd.core import stream
+    L = _lib.lib()
+    h = C.c_void_p()
+    ds = (C.c_int64 * 1)(4)
+    _lib.check(L.o3dmi_hash_create(8, 1, ds, stream(), C.byref(h)), "create")
+    keys = torch.tensor([[1, 2, 3], [1, 2, 3], [-1, 0, 5], [1, 2, 3],
+                         [7, 7, 7]], dtype=torch.int32, device="cuda")
+    vals = torch.tensor([10, 11, 12, 13, 14], dtype=torch.int32, device="cuda")
+    buf = torch.zeros(5, dtype=torch.int32, device="cuda")
+    m = torch.zeros(5, dtype=torch.bool, device="cuda")
+    vp = (C.c_void_p * 1)(vals.data_ptr())
+    _lib.check(L.o3dmi_hash_insert(h, _lib.ptr(keys), vp, 5, _lib.ptr(buf),
+                                   _lib.ptr(m), stream()), "insert")
+    n = C.c_int64(0)
+    _lib.check(L.o3dmi_hash_size(h, stream(), C.byref(n)), "size")
+    assert n.value == 3 and int(m.sum()) == 3
+    mk = m.cpu().numpy()
+    assert mk[2] and mk[4] and mk[[0, 1, 3]].sum() == 1
+    buf2 = torch.zeros(5, dtype=torch.int32, device="cuda")
+    m2 = torch.zeros(5, dtype=torch.bool, device="cuda")
+    _lib.check(L.o3dmi_hash_find(h, _lib.ptr(keys), 5, None, _lib.ptr(buf2),
+                                 _lib.ptr(m2), stream()), "find")
+    assert bool(m2.all())
+    b2 = buf2.cpu().numpy()
+    assert b2[0] == b2[1] == b2[3] and len(set(b2.tolist())) == 3
+    # reserve (rehash) keeps values attached to keys
+    _lib.check(L.o3dmi_hash_reserve(h, 64, stream()), "reserve")
+    assert L.o3dmi_hash_capacity(h) == 64
+    _lib.check(L.o3dmi_hash_find(h, _lib.ptr(keys), 5, None, _lib.ptr(buf2),
+                                 _lib.ptr(m2), stream()), "find")
+    assert bool(m2.all())
+    from open3d_amd.core import tensor_from_ptr
+    vb = tensor_from_ptr(L.o3dmi_hash_value_buffer(h, 0), (64,), _lib.I32,
+                         None).cpu().numpy()
+    got = vb[buf2.cpu().numpy()]
+    assert got[2] == 12 and got[4] == 14 and got[0] in (10, 11, 13)
+    # erase
+    ek = keys[2:3].contiguous()
+    em = torch.zeros(1, dtype=torch.bool, device="cuda")
+    _lib.check(L.o3dmi_hash_erase(h, _lib.ptr(ek), 1, _lib.ptr(em), stream()),
+               "erase")
+    _lib.check(L.o3dmi_hash_size(h, stream(), C.byref(n)), "size")
+    assert bool(em[0]) and n.value == 2
+    _lib.check(L.o3dmi_hash_find(h, _lib.ptr(keys), 5, None, _lib.ptr(buf2),
+                                 _lib.ptr(m2), stream()), "find")
+    assert m2.cpu().numpy().tolist() == [True, True, False, True, True]
+    act = torch.zeros(64, dtype=torch.int32, device="cuda")
+    _lib.check(L.o3dmi_hash_active_indices(h, _lib.ptr(act), stream(),
+                                           C.byref(n)), "active")
+    assert n.value == 2
+    # out-of-range key is reported, not silently dropped
+    bad = torch.tensor([[1 << 21, 0, 0]], dtype=torch.int32, device="cuda")
+    _lib.check(L.o3dmi_hash_activate(h, _lib.ptr(bad), 1, None, None, None,
+                                     stream()), "activate")
+    assert L.o3dmi_hash_size(h, stream(), C.byref(n)) == 4  # KEY_RANGE
+    L.o3dmi_hash_destroy(h)
+
+
+@pytest.mark.parametrize("k", [0, 300, 700])
+@pytest.mark.parametrize("f32", [False, True])
+def test_depth_touch_block_set_bit_exact(k, f32):
+    _lib, geometry = _gpu()
+    d, c, K, Ts = sc.frames(k, 1)
+    depth = d[0].astype(np.float32) if f32 else d[0]
+    want = orc.depth_touch(depth, K, Ts[0], sc.RES, sc.VOXEL,
+                           sc.VOXEL * sc.TRUNC_MULT, sc.DEPTH_SCALE,
+                           sc.DEPTH_MAX, 4)
+    g = _mk_grid(geometry, False)
+    got = g.compute_unique_block_coordinates(
+        torch.from_numpy(depth).cuda(), K, Ts[0], sc.DEPTH_SCALE, sc.DEPTH_MAX,
+        sc.TRUNC_MULT).cpu().numpy()
+    assert got.shape[0] == want.shape[0] > 100
+    assert np.array_equal(sc.sort_rows(got), want)
+    # no duplicates
+    assert len({tuple(r) for r in got.tolist()}) == got.shape[0]
+
+
+def test_depth_touch_no_blocks_is_an_error():
+    _lib, geometry = _gpu()
+    _, _, K, Ts = sc.frames(0, 1)
+    g = _mk_grid(geometry, False)
+    with pytest.raises(_lib.O3DMIError) as e:
+        g.compute_unique_block_coordinates(
+            torch.zeros((480, 640), dtype=torch.uint16, device="cuda"), K,
+            Ts[0])
+    assert "No block is touched" in str(e.value)
+
+
+@pytest.mark.parametrize("input_f32", [False, True])
+@pytest.mark.parametrize("grid_f32", [False, True])
+def test_integrate_parity_all_dtype_combos(input_f32, grid_f32):
+    """The four instantiations of VoxelBlockGridCPU.cpp:212-218, 3 frames."""
+    _lib, geometry = _gpu()
+    g = _mk_grid(geometry, grid_f32)
+    og = OracleGrid(grid_f32, 4096)
+    for k in (0, 40, 80):
+        d, c, K, Ts = sc.frames(k, 1)
+        depth, color = d[0], c[0]
+        if input_f32:
+            depth, color = sc.as_f32_inputs(depth, color)
+        keys = og.integrate(depth, color, K, Ts[0])
+        g.integrate(torch.from_numpy(keys).cuda(),
+                    torch.from_numpy(depth).cuda(),
+                    torch.from_numpy(color).cuda(), K, K, Ts[0],
+                    sc.DEPTH_SCALE, sc.DEPTH_MAX, sc.TRUNC_MULT)
+    err, exact = _compare_grids(og, g)
+    assert exact, "TSDF not bit-identical (max err %g)" % err
+
+
+def test_integrate_depth_only_and_res8():
+    _lib, geometry = _gpu()
+    g = _mk_grid(geometry, False, with_color=False, res=8)
+    og = OracleGrid(False, 4096, with_color=False, res=8)
+    for k in (10, 20):
+        d, c, K, Ts = sc.frames(k, 1)
+        keys = og.integrate(d[0], None, K, Ts[0])
+        g.integrate(torch.from_numpy(keys).cuda(),
+                    torch.from_numpy(d[0]).cuda(), None, K, K, Ts[0],
+                    sc.DEPTH_SCALE, sc.DEPTH_MAX, sc.TRUNC_MULT)
+    _compare_grids(og, g)
+
+
+def test_integrate_scalar_kernel_odd_resolution():
+    _lib, geometry = _gpu()
+    g = _mk_grid(geometry, True, res=6, block_count=8192)
+    og = OracleGrid(True, 8192, res=6)
+    d, c, K, Ts = sc.frames(5, 1)
+    keys = og.integrate(d[0], c[0], K, Ts[0])
+    g.integrate(torch.from_numpy(keys).cuda(), torch.from_numpy(d[0]).cuda(),
+                torch.from_numpy(c[0]).cuda(), K, K, Ts[0], sc.DEPTH_SCALE,
+                sc.DEPTH_MAX, sc.TRUNC_MULT)
+    _compare_grids(og, g)
+
+
+def test_integrate_different_color_intrinsics_and_size():
+    """Colour camera with its own intrinsics / resolution (320x240)."""
+    _lib, geometry = _gpu()
+    from open3d_amd import synthetic as syn
+    d, c, K, Ts = sc.frames(60, 1)
+    d2, c2, K2, _ = sc.frames(60, 1, 320, 240)
+    g = _mk_grid(geometry, False)
+    og = OracleGrid(False, 4096)
+    keys = orc.depth_touch(d[0], K, Ts[0], sc.RES, sc.VOXEL,
+                           sc.VOXEL * sc.TRUNC_MULT, sc.DEPTH_SCALE,
+                           sc.DEPTH_MAX, 4)
+    og.h.activate(keys)
+    buf, _ = og.h.find(keys)
+    orc.integrate(d[0], c2[0], buf, og.h.key_buffer(), og.tsdf, og.weight,
+                  og.color, K, K2, Ts[0], sc.RES, sc.VOXEL,
+                  sc.VOXEL * sc.TRUNC_MULT, sc.DEPTH_SCALE, sc.DEPTH_MAX)
+    g.integrate(torch.from_numpy(keys).cuda(), torch.from_numpy(d[0]).cuda(),
+                torch.from_numpy(c2[0]).cuda(), K, K2, Ts[0], sc.DEPTH_SCALE,
+                sc.DEPTH_MAX, sc.TRUNC_MULT)
+    _compare_grids(og, g)
+
+
+def test_frame_stream_fast_path_equals_two_step_path():
+    """integrate_frame (device-resident counts, fused touch+activate) vs
+    compute_unique_block_coordinates + integrate vs the oracle; 6 frames,
+    small initial capacity to force a Reserve (rehash) on the way."""
+    _lib, geometry = _gpu()
+    ga = _mk_grid(geometry, False, block_count=512)
+    gb = _mk_grid(geometry, False, block_count=512)
+    og = OracleGrid(False, 8192)
+    for k in range(100, 160, 10):
+        d, c, K, Ts = sc.frames(k, 1)
+        dt, ct = torch.from_numpy(d[0]).cuda(), torch.from_numpy(c[0]).cuda()
+        og.integrate(d[0], c[0], K, Ts[0])
+        ga.integrate_frame(dt, ct, K, K, Ts[0], sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                           sc.TRUNC_MULT)
+        keys = gb.compute_unique_block_coordinates(dt, K, Ts[0], sc.DEPTH_SCALE,
+                                                   sc.DEPTH_MAX, sc.TRUNC_MULT)
+        gb.integrate(keys, dt, ct, K, K, Ts[0], sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                     sc.TRUNC_MULT)
+    assert _compare_grids(og, ga)[1]
+    assert _compare_grids(og, gb)[1]
+    assert gb.hashmap().capacity() > 512  # grew through Reserve
+
+
+def test_pointcloud_touch_parity():
+    _lib, geometry = _gpu()
+    from open3d_amd.core import stream
+    L = _lib.lib()
+    rng = np.random.RandomState(3)
+    pts = rng.uniform(-2, 2, (5000, 3)).astype(np.float32)
+    want = orc.pointcloud_touch(pts, sc.RES, sc.VOXEL, sc.VOXEL * 8)
+    h = C.c_void_p()
+    _lib.check(L.o3dmi_hash_create(5000 * 8, 0, None, stream(), C.byref(h)),
+               "create")
+    out = torch.zeros((5000 * 8, 3), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(L.o3dmi_vbg_pointcloud_touch(
+        h, _lib.ptr(torch.from_numpy(pts).cuda()), 5000, _lib.ptr(out),
+        5000 * 8, _lib.ptr(cnt), sc.RES, C.c_float(sc.VOXEL),
+        C.c_float(sc.VOXEL * 8), stream()), "pcd touch")
+    n = int(cnt.item())
+    assert np.array_equal(sc.sort_rows(out[:n].cpu().numpy()), want)
+    L.o3dmi_hash_destroy(h)
+
+
+def test_unproject_parity():
+    _lib, geometry = _gpu()
+    from open3d_amd.core import stream
+    L = _lib.lib()
+    d, c, K, Ts = sc.frames(33, 1)
+    cf = (c[0].astype(np.float32) / 255.0).astype(np.float32)
+    for stride in (1, 4):
+        want_p, want_c = orc.unproject(d[0], cf, K, Ts[0], sc.DEPTH_SCALE,
+                                       sc.DEPTH_MAX, stride)
+        n = (480 // stride) * (640 // stride)
+        pts = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+        cols = torch.zeros((n, 3), dtype=torch.float32, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        _lib.check(L.o3dmi_unproject(
+            _lib.ptr(torch.from_numpy(d[0]).cuda()), _lib.U16, 480, 640,
+            _lib.ptr(torch.from_numpy(cf).cuda()), _lib.ptr(pts),
+            _lib.ptr(cols), _lib.ptr(cnt), _lib.f64p(K), _lib.f64p(Ts[0]),
+            C.c_float(sc.DEPTH_SCALE), C.c_float(sc.DEPTH_MAX), stride,
+            stream()), "unproject")
+        m = int(cnt.item())
+        assert m == want_p.shape[0]
+        got = np.concatenate([pts[:m].cpu().numpy(), cols[:m].cpu().numpy()], 1)
+        want = np.concatenate([want_p, want_c], 1)
+        assert np.array_equal(sc.sort_rows(got), sc.sort_rows(want))
+
+
+@pytest.mark.parametrize("grid_f32", [False, True])
+def test_raycast_parity(grid_f32):
+    """EstimateRange + RayCast vs the oracle after integrating 12 frames;
+    every render attribute the reference supports."""
+    _lib, geometry = _gpu()
+    g = _mk_grid(geometry, grid_f32)
+    og = OracleGrid(grid_f32, 4096)
+    for k in range(200, 212):
+        d, c, K, Ts = sc.frames(k, 1)
+        keys = og.integrate(d[0], c[0], K, Ts[0])
+        g.integrate(torch.from_numpy(keys).cuda(),
+                    torch.from_numpy(d[0]).cuda(),
+                    torch.from_numpy(c[0]).cuda(), K, K, Ts[0],
+                    sc.DEPTH_SCALE, sc.DEPTH_MAX, sc.TRUNC_MULT)
+    assert _compare_grids(og, g)[1]
+    d, c, K, Ts = sc.frames(206, 1)
+    T = Ts[0]
+    keys = orc.depth_touch(d[0], K, T, sc.RES, sc.VOXEL,
+                           sc.VOXEL * sc.TRUNC_MULT, sc.DEPTH_SCALE,
+                           sc.DEPTH_MAX, 4)
+    attrs = ("depth", "vertex", "color", "normal", "index", "mask",
+             "interp_ratio", "interp_ratio_dx", "interp_ratio_dy",
+             "interp_ratio_dz")
+    range_o, needed = orc.estimate_range(keys, K, T, 480, 640, 8, sc.RES,
+                                         sc.VOXEL, 0.1, sc.DEPTH_MAX,
+                                         frag_buffer_size=65536)
+    assert needed < 65536
+    want = orc.raycast(og.h, og.tsdf, og.weight, og.color, range_o, K, T, 480,
+                       640, sc.RES, sc.VOXEL, sc.DEPTH_SCALE, 0.1,
+                       sc.DEPTH_MAX, 3.0, sc.TRUNC_MULT, 8, attrs)
+    got = g.ray_cast(torch.from_numpy(keys).cuda(), K, T, 640, 480, attrs,
+                     sc.DEPTH_SCALE, 0.1, sc.DEPTH_MAX, 3.0, sc.TRUNC_MULT, 8)
+    assert np.array_equal(got["range"].cpu().numpy(), range_o)
+    hit = want["depth"][..., 0] > 0
+    assert hit.mean() > 0.5
+    gd = got["depth"].cpu().numpy()
+    assert np.array_equal(gd > 0, want["depth"] > 0)
+    assert np.abs(gd - want["depth"]).max() <= 1e-3  # depth units (mm)
+    for a in ("vertex", "normal", "interp_ratio", "interp_ratio_dx",
+              "interp_ratio_dy", "interp_ratio_dz"):
+        assert np.abs(got[a].cpu().numpy() - want[a]).max() <= 1e-5, a
+    assert np.abs(got["color"].cpu().numpy() - want["color"]).max() <= 1e-5
+    assert np.array_equal(got["mask"].cpu().numpy(), want["mask"])
+    # voxel indices are buffer-index based: compare through the key of the
+    # block they point into.
+    res3 = sc.RES ** 3
+    gi = got["index"].cpu().numpy()
+    wi = want["index"]
+    m = want["mask"]
+    gk = g.hashmap().key_tensor().cpu().numpy()[(gi // res3)[m]]
+    wk = og.h.key_buffer()[(wi // res3)[m]]
+    assert np.array_equal(gk, wk)
+    assert np.array_equal((gi % res3)[m], (wi % res3)[m])
