@@ -12,6 +12,7 @@ KiB; on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced read
 stream, so the read side is reported both raw and doubled ("corrected").
 """
 import csv
+import re
 import glob
 import json
 import os
@@ -26,10 +27,12 @@ def find(root, pattern):
 
 
 def short(name):
-    name = name.split("(")[0]
-    for pre in ("void ", "o3dmi::(anonymous namespace)::", "o3dmi::"):
-        name = name.replace(pre, "")
-    return name.split("<")[0].strip()
+    """Kernel base name: strips return type, namespaces, template and call
+    arguments ("void o3dmi::(anonymous namespace)::Foo<int>(args)" -> "Foo")."""
+    name = name.replace("(anonymous namespace)::", "")
+    name = re.sub(r"^void\s+", "", name.strip())
+    name = re.split(r"[<(]", name, maxsplit=1)[0]
+    return name.split("::")[-1].strip()
 
 
 def main():
