@@ -50,6 +50,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=50,
                     help="frames per step (per GPU)")
     ap.add_argument("--block-count", type=int, default=131072)
+    ap.add_argument("--per-frame-calls", action="store_true",
+                    help="one o3dmi_vbg_integrate_frame call per frame instead "
+                         "of one o3dmi_vbg_integrate_frames call per step")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="keep touch and integrate kernels on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -134,10 +139,15 @@ def main():
                                 [1, 1, 3], VOXEL, RES, a.block_count)
 
     def run_step(s):
-        for j in range(a.batch):
-            i = s * a.batch + j
-            g.integrate_frame(depths[i], colors[i], K, K, Ts[i], DEPTH_SCALE,
-                              DEPTH_MAX, TRUNC)
+        lo, hi = s * a.batch, (s + 1) * a.batch
+        if a.per_frame_calls:
+            for i in range(lo, hi):
+                g.integrate_frame(depths[i], colors[i], K, K, Ts[i],
+                                  DEPTH_SCALE, DEPTH_MAX, TRUNC)
+        else:
+            g.integrate_frames(depths[lo:hi], colors[lo:hi], K, K, Ts[lo:hi],
+                               DEPTH_SCALE, DEPTH_MAX, TRUNC,
+                               overlap=not a.no_overlap)
 
     def barrier():
         if dist is not None:
@@ -193,12 +203,16 @@ def main():
                                "(tsdf f32, weight u16, color u16), known poses"
                                % (a.steps * a.batch),
                    "frames_per_step": a.batch, "block_count": a.block_count,
+                   "api": "integrate_frame per frame" if a.per_frame_calls
+                          else "integrate_frames per step",
+                   "touch_integrate_overlap": not (a.no_overlap or
+                                                   a.per_frame_calls),
                    "active_blocks": int(n_blocks),
                    "avg_blocks_per_frame": prof["block_frames"] / launches,
                    "sharding": "frames r, r+N, ... per rank; block-ID "
                                "all-gather at the end" if world > 1 else "none",
                    "union_blocks": n_union},
-        "roofline": {"bound": "hbm", "kernel": "IntegrateQuadKernel",
+        "roofline": {"bound": "hbm", "kernel": "IntegrateStreamKernel",
                      "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None,

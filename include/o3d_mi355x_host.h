@@ -140,10 +140,29 @@ int o3dmi_vbg_integrate_frame(o3dmi_vbg_t* g, const void* depth_dev,
                               float depth_max, float trunc_voxel_multiplier,
                               o3dmi_stream_t stream);
 
+/* The same for a batch of frames sharing intrinsics and image sizes:
+ * depth_devs / color_devs are host arrays of n_frames device pointers,
+ * extrinsics is n_frames x 16 host doubles. Frames are integrated strictly in
+ * order (frame f sees the grid left by frame f-1), so the result is identical
+ * to n_frames calls of o3dmi_vbg_integrate_frame. With overlap != 0 the touch /
+ * prepare kernel of frame f+1 runs on an internal stream concurrently with the
+ * integrate kernel of frame f (it only inserts new hash entries and writes
+ * double-buffered per-frame scratch); all integrate kernels are issued on
+ * `stream`, which therefore observes completion of the whole batch. */
+int o3dmi_vbg_integrate_frames(o3dmi_vbg_t* g, int n_frames,
+                               const void* const* depth_devs, int depth_rows,
+                               int depth_cols, const void* const* color_devs,
+                               int color_rows, int color_cols, int input_dtype,
+                               const double* depth_intrinsic,
+                               const double* color_intrinsic,
+                               const double* extrinsics, float depth_scale,
+                               float depth_max, float trunc_voxel_multiplier,
+                               int overlap, o3dmi_stream_t stream);
+
 /* Measurement hook for bench.py: while profiling is on, every
- * o3dmi_vbg_integrate_frame call brackets its touch and integrate kernels with
- * HIP events on the caller's stream and records the frame's active-block
- * count. o3dmi_vbg_profile_end synchronises and returns the summed kernel
+ * o3dmi_vbg_integrate_frame(s) call brackets its front (touch) and integrate
+ * kernels with HIP events on the streams they are launched on and records the
+ * frame's active-block count. o3dmi_vbg_profile_end synchronises and returns the summed kernel
  * times (ms), the number of integrate launches and the sum of active blocks
  * over those launches (the roofline's "units"). */
 int o3dmi_vbg_profile_begin(o3dmi_vbg_t* g, int max_frames);

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../common.h"
+#include "../stream_path.h"
 #include "o3d_mi355x_host.h"
 
 using namespace o3dmi;
@@ -41,9 +42,28 @@ struct o3dmi_vbg {
     int* size_host = nullptr;
     hipEvent_t size_event = nullptr;
     bool size_event_pending = false;
+    // Frame-stream fast path (stream_path.h): double-buffered prepared pixel
+    // records and block lists, a ring of 4 device counters, a host-mapped
+    // status word written by the integrate kernel, and an auxiliary stream so
+    // that frame k+1's front kernel overlaps frame k's integrate kernel.
+    PixelRec* recs[2] = {nullptr, nullptr};
+    int64_t recs_pixels = 0;
+    FrameBlock* lists[2] = {nullptr, nullptr};
+    int64_t lists_capacity = 0;
+    int* ring_counters = nullptr;        // device int[4]
+    volatile int* stream_status = nullptr;  // host-mapped int[4]
+    int64_t stream_seq = 0;              // frames issued on the fast path
+    int known_size = 0;                  // map size after frame `known_stamp`
+    int known_stamp = 0;
+    bool known_valid = false;            // false after any non-stream activation
+    int last_count = 1024;
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_front[2] = {nullptr, nullptr};
+    hipEvent_t ev_int[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr;
     // bench.py measurement hook (o3dmi_vbg_profile_begin/end).
     bool profiling = false;
-    std::vector<hipEvent_t> prof_events;  // 3 per frame: t0, t1 (touch), t2
+    std::vector<hipEvent_t> prof_events;  // 4 per frame: front t0,t1; integrate t2,t3
     int prof_frames = 0, prof_max = 0;
     int32_t* prof_counts = nullptr;  // device, one per frame
 
@@ -213,6 +233,16 @@ int o3dmi_vbg_destroy(o3dmi_vbg_t* g) {
     (void)hipFree(g->scratch_buf_indices);
     if (g->size_host) (void)hipHostFree(g->size_host);
     if (g->size_event) (void)hipEventDestroy(g->size_event);
+    for (int i = 0; i < 2; ++i) {
+        (void)hipFree(g->recs[i]);
+        (void)hipFree(g->lists[i]);
+        if (g->ev_front[i]) (void)hipEventDestroy(g->ev_front[i]);
+        if (g->ev_int[i]) (void)hipEventDestroy(g->ev_int[i]);
+    }
+    if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
+    if (g->aux_stream) (void)hipStreamDestroy(g->aux_stream);
+    (void)hipFree(g->ring_counters);
+    if (g->stream_status) (void)hipHostFree((void*)g->stream_status);
     for (hipEvent_t e : g->prof_events) (void)hipEventDestroy(e);
     (void)hipFree(g->prof_counts);
     delete g;
@@ -289,6 +319,7 @@ int o3dmi_vbg_integrate_blocks(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
                   "null argument");
     O3DMI_REQUIRE(m >= 0, "m < 0");
     if (m == 0) return O3DMI_OK;
+    g->known_valid = false;
     int st = EnsureCapacity(g, m, stream);
     if (st) return st;
     if ((st = EnsureScratch(g, m))) return st;
@@ -306,7 +337,7 @@ int o3dmi_vbg_integrate_blocks(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
                         trunc_voxel_multiplier, stream);
 }
 
-int o3dmi_vbg_integrate_frame(o3dmi_vbg_t* g, const void* depth_dev,
+static int IntegrateFrameGeneric(o3dmi_vbg_t* g, const void* depth_dev,
                               int depth_rows, int depth_cols,
                               const void* color_dev, int color_rows,
                               int color_cols, int input_dtype,
@@ -362,11 +393,12 @@ int o3dmi_vbg_integrate_frame(o3dmi_vbg_t* g, const void* depth_dev,
     }
 
     int dt = input_dtype == O3DMI_F32 ? O3DMI_F32 : O3DMI_U16;
+    g->known_valid = false;
     g->frame_stamp += 1;
     const bool prof = g->profiling && g->prof_frames < g->prof_max;
     if (prof)
         O3DMI_HIP_CHECK(hipEventRecord(
-                g->prof_events[(size_t)g->prof_frames * 3 + 0], s));
+                g->prof_events[(size_t)g->prof_frames * 4 + 0], s));
     int st = o3dmi_vbg_touch_activate(
             g->block_hashmap, depth_dev, dt, depth_rows, depth_cols,
             depth_intrinsic, extrinsic, g->frame_indices, max_new,
@@ -384,7 +416,9 @@ int o3dmi_vbg_integrate_frame(o3dmi_vbg_t* g, const void* depth_dev,
                                        g->frame_count, sizeof(int32_t),
                                        hipMemcpyDeviceToDevice, s));
         O3DMI_HIP_CHECK(hipEventRecord(
-                g->prof_events[(size_t)g->prof_frames * 3 + 1], s));
+                g->prof_events[(size_t)g->prof_frames * 4 + 1], s));
+        O3DMI_HIP_CHECK(hipEventRecord(
+                g->prof_events[(size_t)g->prof_frames * 4 + 2], s));
     }
     st = RunIntegrate(g, g->frame_indices, max_new, g->frame_count, depth_dev,
                       depth_rows, depth_cols, color_dev, color_rows,
@@ -393,10 +427,313 @@ int o3dmi_vbg_integrate_frame(o3dmi_vbg_t* g, const void* depth_dev,
                       trunc_voxel_multiplier, stream);
     if (prof) {
         O3DMI_HIP_CHECK(hipEventRecord(
-                g->prof_events[(size_t)g->prof_frames * 3 + 2], s));
+                g->prof_events[(size_t)g->prof_frames * 4 + 3], s));
         g->prof_frames += 1;
     }
     return st;
+}
+
+
+// ---- frame-stream fast path ------------------------------------------------
+
+static int EnsureStreamBuffers(o3dmi_vbg* g, int rows, int cols,
+                               int64_t max_new) {
+    const int64_t px = (int64_t)rows * cols;
+    if (g->recs_pixels < px) {
+        for (int i = 0; i < 2; ++i) {
+            (void)hipFree(g->recs[i]);
+            g->recs[i] = nullptr;
+            O3DMI_HIP_CHECK(hipMalloc((void**)&g->recs[i],
+                                      sizeof(PixelRec) * (size_t)px));
+        }
+        g->recs_pixels = px;
+    }
+    if (g->lists_capacity < max_new) {
+        for (int i = 0; i < 2; ++i) {
+            (void)hipFree(g->lists[i]);
+            g->lists[i] = nullptr;
+            O3DMI_HIP_CHECK(hipMalloc((void**)&g->lists[i],
+                                      sizeof(FrameBlock) * (size_t)max_new));
+        }
+        g->lists_capacity = max_new;
+    }
+    if (!g->ring_counters) {
+        O3DMI_HIP_CHECK(hipMalloc((void**)&g->ring_counters, sizeof(int) * 4));
+        O3DMI_HIP_CHECK(hipMemset(g->ring_counters, 0, sizeof(int) * 4));
+        int* st = nullptr;
+        O3DMI_HIP_CHECK(hipHostMalloc((void**)&st, sizeof(int) * 4,
+                                      hipHostMallocMapped |
+                                              hipHostMallocCoherent));
+        st[0] = st[1] = st[2] = st[3] = 0;
+        g->stream_status = st;
+        O3DMI_HIP_CHECK(hipStreamCreateWithFlags(&g->aux_stream,
+                                                 hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            O3DMI_HIP_CHECK(hipEventCreateWithFlags(&g->ev_front[i],
+                                                    hipEventDisableTiming));
+            O3DMI_HIP_CHECK(hipEventCreateWithFlags(&g->ev_int[i],
+                                                    hipEventDisableTiming));
+        }
+        O3DMI_HIP_CHECK(hipEventCreateWithFlags(&g->ev_fork,
+                                                hipEventDisableTiming));
+    }
+    return O3DMI_OK;
+}
+
+// Reads the status word the integrate kernels publish ({map size, error
+// flags, frame block count, stamp}); never blocks.
+static int PollStreamStatus(o3dmi_vbg* g) {
+    const int stamp = __atomic_load_n((const int*)&g->stream_status[3],
+                                      __ATOMIC_ACQUIRE);
+    if (stamp != g->known_stamp && stamp != 0) {
+        g->known_size = g->stream_status[0];
+        const int err = g->stream_status[1];
+        g->last_count = g->stream_status[2];
+        // Re-check the stamp: a newer frame may have overwritten the words.
+        const int stamp2 = __atomic_load_n((const int*)&g->stream_status[3],
+                                           __ATOMIC_ACQUIRE);
+        if (stamp2 == stamp) g->known_stamp = stamp;
+        if (err & kErrKeyRange) {
+            SetLastError("block coordinate outside +-2^20");
+            return O3DMI_ERR_KEY_RANGE;
+        }
+        if (err & kErrCapacity) {
+            SetLastError("hash map capacity exceeded");
+            return O3DMI_ERR_CAPACITY;
+        }
+    }
+    return O3DMI_OK;
+}
+
+// HashMap::Activate's capacity policy (HashMap.cpp:166-176) for the fast
+// path: Reserve only when Size() + (most blocks the in-flight frames can
+// still create) exceeds the capacity. Waits for the in-flight integrate
+// kernels' status words only while that bound says a Reserve may be needed.
+static int StreamEnsureCapacity(o3dmi_vbg* g, int64_t max_new,
+                                hipStream_t front, hipStream_t integ) {
+    int st = PollStreamStatus(g);
+    if (st) return st;
+    const int64_t capacity = o3dmi_hash_capacity(g->block_hashmap);
+    auto bound = [&]() {
+        // frames issued after the one known_size reflects may each still
+        // create up to max_new blocks, and so may the frame about to start
+        const int64_t unknown = (int64_t)g->frame_stamp - g->known_stamp;
+        return (int64_t)g->known_size + (unknown + 1) * max_new;
+    };
+    if (!g->known_valid) {
+        // Something else activated blocks since the last fast-path frame (or
+        // this is the first one): take the exact size from the map itself.
+        O3DMI_HIP_CHECK(hipStreamSynchronize(front));
+        if (integ != front) O3DMI_HIP_CHECK(hipStreamSynchronize(integ));
+        int64_t size = 0;
+        st = o3dmi_hash_size(g->block_hashmap, (o3dmi_stream_t)integ, &size);
+        if (st) return st;
+        g->known_size = (int)size;
+        g->known_stamp = g->frame_stamp;
+        g->known_valid = true;
+    }
+    if (bound() <= capacity) return O3DMI_OK;
+    // Spin (bounded) until the newest in-flight frame has reported.
+    for (int64_t spin = 0; spin < 2000000 && g->known_stamp != g->frame_stamp;
+         ++spin) {
+        st = PollStreamStatus(g);
+        if (st) return st;
+    }
+    if (g->known_stamp != g->frame_stamp || bound() > capacity) {
+        O3DMI_HIP_CHECK(hipStreamSynchronize(front));
+        if (integ != front) O3DMI_HIP_CHECK(hipStreamSynchronize(integ));
+        int64_t size = 0;
+        st = o3dmi_hash_size(g->block_hashmap, (o3dmi_stream_t)integ, &size);
+        if (st) return st;
+        g->known_size = (int)size;
+        g->known_stamp = g->frame_stamp;
+        if (size + max_new > capacity) {
+            const int64_t need = size + max_new;
+            const int64_t target = need > capacity * 2 ? need : capacity * 2;
+            st = o3dmi_hash_reserve(g->block_hashmap, target,
+                                    (o3dmi_stream_t)integ);
+            if (st) return st;
+            // The rehash is queued on `integ`; the front stream must not
+            // touch the new table before it is complete.
+            O3DMI_HIP_CHECK(hipStreamSynchronize(integ));
+        }
+    }
+    return O3DMI_OK;
+}
+
+static int IntegrateFrameStream(o3dmi_vbg_t* g, const void* depth_dev,
+                                int depth_rows, int depth_cols,
+                                const void* color_dev, int color_rows,
+                                int color_cols, const double* depth_intrinsic,
+                                const double* color_intrinsic,
+                                const double* extrinsic, float depth_scale,
+                                float depth_max, float trunc_voxel_multiplier,
+                                hipStream_t front, hipStream_t integ) {
+    const int stride = 4;
+    const int64_t max_new =
+            (int64_t)(depth_cols / stride) * (depth_rows / stride) * 4;
+    O3DMI_REQUIRE(max_new > 0, "depth image too small");
+    int ti = g->AttrIndex("tsdf"), wi = g->AttrIndex("weight"),
+        ci = g->AttrIndex("color");
+    int grid_dtype;
+    int st = GridDtype(g, &grid_dtype);
+    if (st) return st;
+    if ((st = EnsureStreamBuffers(g, depth_rows, depth_cols, max_new)))
+        return st;
+    if ((st = StreamEnsureCapacity(g, max_new, front, integ))) return st;
+
+    g->size_bound = o3dmi_hash_capacity(g->block_hashmap);  // generic path: re-read
+    const bool overlapped = front != integ;
+    const int64_t k = g->stream_seq;
+    const int par = (int)(k & 1);
+    g->frame_stamp += 1;
+    const bool with_color = color_dev != nullptr && ci >= 0 &&
+                            (int64_t)color_rows * color_cols > 0;
+    const bool prof = g->profiling && g->prof_frames < g->prof_max;
+    hipEvent_t* pe = prof ? &g->prof_events[(size_t)g->prof_frames * 4]
+                          : nullptr;
+
+    // Frame k re-uses the buffers of frame k-2: its integrate must be done.
+    if (overlapped && k >= 2)
+        O3DMI_HIP_CHECK(hipStreamWaitEvent(front, g->ev_int[par], 0));
+    FrameFrontArgs fa;
+    fa.depth = (const uint16_t*)depth_dev;
+    fa.color = with_color ? (const uint8_t*)color_dev : nullptr;
+    fa.rows = depth_rows;
+    fa.cols = depth_cols;
+    fa.color_rows = color_rows;
+    fa.color_cols = color_cols;
+    fa.depth_intrinsic = depth_intrinsic;
+    fa.color_intrinsic = color_intrinsic ? color_intrinsic : depth_intrinsic;
+    fa.extrinsic = extrinsic;
+    fa.resolution = (int)g->block_resolution;
+    fa.voxel_size = g->voxel_size;
+    fa.sdf_trunc = g->voxel_size * trunc_voxel_multiplier;
+    fa.depth_scale = depth_scale;
+    fa.depth_max = depth_max;
+    fa.stride = stride;
+    fa.frame_stamp = g->frame_stamp;
+    fa.recs = g->recs[par];
+    fa.list = g->lists[par];
+    fa.list_capacity = g->lists_capacity;
+    fa.count = g->ring_counters + (k & 3);
+    if (pe) O3DMI_HIP_CHECK(hipEventRecord(pe[0], front));
+    if ((st = LaunchFrameFront(g->block_hashmap, fa, front))) return st;
+    if (pe) O3DMI_HIP_CHECK(hipEventRecord(pe[1], front));
+    if (overlapped) {
+        O3DMI_HIP_CHECK(hipEventRecord(g->ev_front[par], front));
+        O3DMI_HIP_CHECK(hipStreamWaitEvent(integ, g->ev_front[par], 0));
+    }
+
+    IntegrateStreamArgs ia;
+    ia.recs = g->recs[par];
+    ia.rows = depth_rows;
+    ia.cols = depth_cols;
+    ia.with_color = with_color;
+    ia.list = g->lists[par];
+    ia.count = g->ring_counters + (k & 3);
+    ia.list_capacity = g->lists_capacity;
+    ia.grid_hint = g->last_count;
+    ia.tsdf = (float*)o3dmi_hash_value_buffer(g->block_hashmap, ti);
+    ia.weight = o3dmi_hash_value_buffer(g->block_hashmap, wi);
+    ia.color = with_color ? o3dmi_hash_value_buffer(g->block_hashmap, ci)
+                          : nullptr;
+    ia.grid_dtype = grid_dtype;
+    ia.depth_intrinsic = depth_intrinsic;
+    ia.extrinsic = extrinsic;
+    ia.resolution = (int)g->block_resolution;
+    ia.voxel_size = g->voxel_size;
+    ia.sdf_trunc = g->voxel_size * trunc_voxel_multiplier;
+    ia.depth_max = depth_max;
+    ia.zero_counter = g->ring_counters + ((k + 2) & 3);
+    ia.size_host = (int*)g->stream_status;
+    ia.frame_stamp = g->frame_stamp;
+    ia.prof_count = prof ? g->prof_counts + g->prof_frames : nullptr;
+    if (pe) O3DMI_HIP_CHECK(hipEventRecord(pe[2], integ));
+    if ((st = LaunchIntegrateStream(g->block_hashmap, ia, integ))) return st;
+    if (pe) {
+        O3DMI_HIP_CHECK(hipEventRecord(pe[3], integ));
+        g->prof_frames += 1;
+    }
+    if (overlapped) O3DMI_HIP_CHECK(hipEventRecord(g->ev_int[par], integ));
+    g->stream_seq += 1;
+    return O3DMI_OK;
+}
+
+static bool StreamPathApplies(const o3dmi_vbg* g, int input_dtype) {
+    int ti = g->AttrIndex("tsdf"), wi = g->AttrIndex("weight");
+    return input_dtype == O3DMI_U16 && (g->block_resolution % 4) == 0 &&
+           ti >= 0 && wi >= 0 && g->attr_dtypes[(size_t)ti] == O3DMI_F32;
+}
+
+int o3dmi_vbg_integrate_frame(o3dmi_vbg_t* g, const void* depth_dev,
+                              int depth_rows, int depth_cols,
+                              const void* color_dev, int color_rows,
+                              int color_cols, int input_dtype,
+                              const double* depth_intrinsic,
+                              const double* color_intrinsic,
+                              const double* extrinsic, float depth_scale,
+                              float depth_max, float trunc_voxel_multiplier,
+                              o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(g && depth_dev && depth_intrinsic && extrinsic,
+                  "null argument");
+    if (!StreamPathApplies(g, input_dtype))
+        return IntegrateFrameGeneric(g, depth_dev, depth_rows, depth_cols,
+                                     color_dev, color_rows, color_cols,
+                                     input_dtype, depth_intrinsic,
+                                     color_intrinsic, extrinsic, depth_scale,
+                                     depth_max, trunc_voxel_multiplier, stream);
+    hipStream_t s = (hipStream_t)stream;
+    return IntegrateFrameStream(g, depth_dev, depth_rows, depth_cols, color_dev,
+                                color_rows, color_cols, depth_intrinsic,
+                                color_intrinsic, extrinsic, depth_scale,
+                                depth_max, trunc_voxel_multiplier, s, s);
+}
+
+int o3dmi_vbg_integrate_frames(o3dmi_vbg_t* g, int n_frames,
+                               const void* const* depth_devs, int depth_rows,
+                               int depth_cols, const void* const* color_devs,
+                               int color_rows, int color_cols, int input_dtype,
+                               const double* depth_intrinsic,
+                               const double* color_intrinsic,
+                               const double* extrinsics, float depth_scale,
+                               float depth_max, float trunc_voxel_multiplier,
+                               int overlap, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(g && depth_devs && depth_intrinsic && extrinsics &&
+                          n_frames >= 0,
+                  "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const bool fast = StreamPathApplies(g, input_dtype);
+    const bool two = fast && overlap != 0 && n_frames > 1;
+    if (two) {
+        int st = EnsureStreamBuffers(
+                g, depth_rows, depth_cols,
+                (int64_t)(depth_cols / 4) * (depth_rows / 4) * 4);
+        if (st) return st;
+        // Fork: the front stream starts behind everything queued on `stream`.
+        O3DMI_HIP_CHECK(hipEventRecord(g->ev_fork, s));
+        O3DMI_HIP_CHECK(hipStreamWaitEvent(g->aux_stream, g->ev_fork, 0));
+    }
+    for (int f = 0; f < n_frames; ++f) {
+        const void* c = color_devs ? color_devs[f] : nullptr;
+        int st;
+        if (fast)
+            st = IntegrateFrameStream(
+                    g, depth_devs[f], depth_rows, depth_cols, c, color_rows,
+                    color_cols, depth_intrinsic, color_intrinsic,
+                    extrinsics + 16 * (size_t)f, depth_scale, depth_max,
+                    trunc_voxel_multiplier, two ? g->aux_stream : s, s);
+        else
+            st = IntegrateFrameGeneric(
+                    g, depth_devs[f], depth_rows, depth_cols, c, color_rows,
+                    color_cols, input_dtype, depth_intrinsic, color_intrinsic,
+                    extrinsics + 16 * (size_t)f, depth_scale, depth_max,
+                    trunc_voxel_multiplier, stream);
+        if (st) return st;
+    }
+    // Join is implicit: every integrate kernel is on `stream` and waits for
+    // its front kernel; the front stream has nothing after the last of them.
+    return O3DMI_OK;
 }
 
 int o3dmi_vbg_ray_cast(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
@@ -445,7 +782,7 @@ int o3dmi_vbg_ray_cast(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
 
 int o3dmi_vbg_profile_begin(o3dmi_vbg_t* g, int max_frames) {
     O3DMI_REQUIRE(g && max_frames > 0, "bad argument");
-    while ((int)g->prof_events.size() < max_frames * 3) {
+    while ((int)g->prof_events.size() < max_frames * 4) {
         hipEvent_t e;
         O3DMI_HIP_CHECK(hipEventCreate(&e));
         g->prof_events.push_back(e);
@@ -469,16 +806,17 @@ int o3dmi_vbg_profile_end(o3dmi_vbg_t* g, o3dmi_stream_t stream,
                   "null argument");
     g->profiling = false;
     O3DMI_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    if (g->aux_stream) O3DMI_HIP_CHECK(hipStreamSynchronize(g->aux_stream));
     double ti = 0, tt = 0;
     for (int f = 0; f < g->prof_frames; ++f) {
         float ms = 0;
         O3DMI_HIP_CHECK(hipEventElapsedTime(
-                &ms, g->prof_events[(size_t)f * 3 + 0],
-                g->prof_events[(size_t)f * 3 + 1]));
+                &ms, g->prof_events[(size_t)f * 4 + 0],
+                g->prof_events[(size_t)f * 4 + 1]));
         tt += ms;
         O3DMI_HIP_CHECK(hipEventElapsedTime(
-                &ms, g->prof_events[(size_t)f * 3 + 1],
-                g->prof_events[(size_t)f * 3 + 2]));
+                &ms, g->prof_events[(size_t)f * 4 + 2],
+                g->prof_events[(size_t)f * 4 + 3]));
         ti += ms;
     }
     std::vector<int32_t> counts((size_t)g->prof_frames);

@@ -1,0 +1,83 @@
+// Internal interface of the frame-stream fast path (not part of the C ABI):
+// the two kernels one RGB-D frame costs when it is integrated with
+// o3dmi_vbg_integrate_frame(s).
+//
+//   FrameFront  (vbg_touch.hip)      block touch + activation in the main hash
+//                                    (first workgroups) fused with a per-pixel
+//                                    "prepare" pass (remaining workgroups)
+//   IntegrateStream (vbg_integrate.hip) per-voxel TSDF / weight / colour update
+//                                    over the frame's block list
+//
+// Both are pure re-cuts of the reference's arithmetic (DepthTouchCPU,
+// VoxelBlockGridCPU.cpp:117-201; IntegrateCPU, VoxelBlockGridImpl.h:151-308):
+// every per-pixel sub-expression of the integrate lambda that does not depend
+// on the voxel -- float(depth)/depth_scale and the colour pixel selected by
+// Unproject(depth K) -> Project(colour K) -> round -- is evaluated once per
+// pixel by the prepare pass with the reference's exact operation order and
+// stored as an 8-byte record, so the per-voxel kernel gathers one record
+// instead of a depth sample plus three colour bytes and skips four of its
+// seven correctly-rounded divisions. Results are bit-identical.
+#pragma once
+
+#include "common.h"
+
+namespace o3dmi {
+
+// One entry of a frame's block list: hash slot + block key.
+struct alignas(16) FrameBlock {
+    int slot, x, y, z;
+};
+
+// Per-pixel prepared record (u16 depth / u8 colour inputs).
+struct alignas(8) PixelRec {
+    float d;        // float(depth) / depth_scale
+    unsigned rgba;  // r | g<<8 | b<<16 | (colour pixel in bounds)<<24
+};
+
+struct FrameFrontArgs {
+    const uint16_t* depth;  // {rows, cols}
+    const uint8_t* color;   // {color_rows, color_cols, 3} or null
+    int rows, cols, color_rows, color_cols;
+    const double* depth_intrinsic;  // host 3x3
+    const double* color_intrinsic;  // host 3x3
+    const double* extrinsic;        // host 4x4
+    int resolution;
+    float voxel_size, sdf_trunc, depth_scale, depth_max;
+    int stride;
+    int frame_stamp;
+    PixelRec* recs;       // {rows, cols} out
+    FrameBlock* list;     // out
+    int64_t list_capacity;
+    int* count;           // device, must be 0 on entry
+};
+
+int LaunchFrameFront(o3dmi_hash* block_hash, const FrameFrontArgs& a,
+                     hipStream_t s);
+
+struct IntegrateStreamArgs {
+    const PixelRec* recs;
+    int rows, cols;
+    bool with_color;
+    const FrameBlock* list;
+    const int* count;     // device: live length of `list`
+    int64_t list_capacity;
+    int grid_hint;        // expected number of blocks (sizes the grid)
+    float* tsdf;
+    void* weight;
+    void* color;          // may be null
+    int grid_dtype;       // O3DMI_U16 | O3DMI_F32
+    const double* depth_intrinsic;
+    const double* extrinsic;
+    int resolution;
+    float voxel_size, sdf_trunc, depth_max;
+    // bookkeeping done by workgroup 0 (any may be null):
+    int* zero_counter;    // device int reset to 0 (a future frame's count)
+    int* size_host;       // host-mapped {heap_top, error flags, count, stamp}
+    int frame_stamp;
+    int* prof_count;      // device int receiving the live count
+};
+
+int LaunchIntegrateStream(o3dmi_hash* block_hash, const IntegrateStreamArgs& a,
+                          hipStream_t s);
+
+}  // namespace o3dmi

@@ -14,6 +14,7 @@
 // each key appends it to the output list. Counts stay on the device.
 
 #include "common.h"
+#include "stream_path.h"
 
 namespace o3dmi {
 namespace {
@@ -205,6 +206,92 @@ __global__ void TouchActivateKernel(HashView hv, TouchParams p,
     }
 }
 
+// Frame-stream front end (stream_path.h). Workgroups [0, n_touch_wg) run the
+// fused touch+activate of TouchActivateKernel, emitting {slot, key} entries;
+// the remaining workgroups run the per-pixel prepare pass. The two roles share
+// one launch so that the latency-bound hash work (75 workgroups at VGA) and the
+// streaming prepare pass (all other CUs) overlap.
+struct PrepParams {
+    Camera color_cam;  // colour intrinsics, identity extrinsic, scale 1
+    int color_rows, color_cols;
+    bool with_color;
+};
+
+__global__ void __launch_bounds__(256)
+FrameFrontKernel(HashView hv, TouchParams p, PrepParams pp,
+                 const uint16_t* __restrict__ depth,
+                 const uint8_t* __restrict__ color,
+                 PixelRec* __restrict__ recs, FrameBlock* __restrict__ list,
+                 int64_t list_capacity, int* __restrict__ out_count,
+                 int frame_stamp, int n_touch_wg) {
+    if ((int)blockIdx.x < n_touch_wg) {
+        int n = p.rows_strided * p.cols_strided;
+        int n_padded = ((n + 63) / 64) * 64;
+        for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < n_padded;
+             w += n_touch_wg * blockDim.x) {
+            int xb[4], yb[4], zb[4];
+            bool valid = (w < n) && RayCandidates(p, depth, w, xb, yb, zb);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bool ok = valid;
+                if (ok && s > 0 && xb[s] == xb[s - 1] && yb[s] == yb[s - 1] &&
+                    zb[s] == zb[s - 1])
+                    ok = false;
+                if (ok && !KeyInRange(xb[s], yb[s], zb[s])) {
+                    atomicOr(&hv.counters[1], kErrKeyRange);
+                    ok = false;
+                }
+                unsigned long long k = ok ? PackKey(xb[s], yb[s], zb[s]) : 0ull;
+                if (WaveLeaderForKey(k, ok)) {
+                    unsigned slot;
+                    InsertKey<true>(hv, xb[s], yb[s], zb[s], slot);
+                    int old = atomicExch(&hv.slot_stamp[slot], frame_stamp);
+                    if (old != frame_stamp) {
+                        int o = atomicAdd(out_count, 1);
+                        if (o < list_capacity) {
+                            FrameBlock fb;
+                            fb.slot = (int)slot;
+                            fb.x = xb[s];
+                            fb.y = yb[s];
+                            fb.z = zb[s];
+                            list[o] = fb;
+                        } else {
+                            atomicOr(&hv.counters[1], kErrCapacity);
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // Prepare pass: the voxel-independent sub-expressions of the integrate
+    // lambda (VoxelBlockGridImpl.h:258-262 depth, :277-289 colour pixel).
+    const int n_px = p.rows * p.cols;
+    const int n_wg = (int)gridDim.x - n_touch_wg;
+    for (int i = ((int)blockIdx.x - n_touch_wg) * blockDim.x + threadIdx.x;
+         i < n_px; i += n_wg * blockDim.x) {
+        const int vi = i / p.cols;
+        const int ui = i - vi * p.cols;
+        PixelRec r;
+        r.d = (float)depth[i] / p.depth_scale;
+        r.rgba = 0u;
+        if (pp.with_color) {
+            float x, y, z, uf, vf;
+            p.cam.Unproject((float)ui, (float)vi, 1.0f, x, y, z);
+            pp.color_cam.Project(x, y, z, uf, vf);
+            if (InBoundary2D(uf, vf, pp.color_rows, pp.color_cols)) {
+                int uc = (int)roundf(uf);
+                int vc = (int)roundf(vf);
+                const uint8_t* in =
+                        color + ((int64_t)vc * pp.color_cols + uc) * 3;
+                r.rgba = (unsigned)in[0] | ((unsigned)in[1] << 8) |
+                         ((unsigned)in[2] << 16) | (1u << 24);
+            }
+        }
+        recs[i] = r;
+    }
+}
+
 // slot list -> buffer indices (slot_vals are published by the previous kernel).
 __global__ void SlotsToIndicesKernel(HashView hv, int* __restrict__ io,
                                      const int* __restrict__ count,
@@ -318,6 +405,35 @@ TouchParams MakeTouchParams(const double* intrinsic, const double* extrinsic,
 }
 
 }  // namespace
+
+int LaunchFrameFront(o3dmi_hash* bh, const FrameFrontArgs& a, hipStream_t s) {
+    TouchParams p = MakeTouchParams(a.depth_intrinsic, a.extrinsic, a.rows,
+                                    a.cols, a.stride, a.resolution,
+                                    a.voxel_size, a.sdf_trunc, a.depth_scale,
+                                    a.depth_max);
+    static const double eye4[16] = {1, 0, 0, 0, 0, 1, 0, 0,
+                                    0, 0, 1, 0, 0, 0, 0, 1};
+    PrepParams pp;
+    pp.color_cam = Camera::Make(a.color_intrinsic ? a.color_intrinsic
+                                                  : a.depth_intrinsic,
+                                eye4, 1.0f);
+    pp.color_rows = a.color_rows;
+    pp.color_cols = a.color_cols;
+    pp.with_color = a.color != nullptr;
+    const int n_rays = p.rows_strided * p.cols_strided;
+    const int n_touch_wg = (n_rays + kBlock - 1) / kBlock;
+    // 4 pixels per prepare lane keeps the whole launch at ~1 wave of
+    // workgroups per CU beyond the touch workgroups.
+    int n_prep_wg = (a.rows * a.cols + kBlock * 4 - 1) / (kBlock * 4);
+    if (n_prep_wg < 1) n_prep_wg = 1;
+    hipLaunchKernelGGL(FrameFrontKernel, dim3(n_touch_wg + n_prep_wg),
+                       dim3(kBlock), 0, s, bh->view, p, pp, a.depth, a.color,
+                       a.recs, a.list, a.list_capacity, a.count,
+                       a.frame_stamp, n_touch_wg);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
 }  // namespace o3dmi
 
 using namespace o3dmi;

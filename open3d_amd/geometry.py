@@ -198,6 +198,37 @@ class VoxelBlockGrid:
             C.c_float(depth_max), C.c_float(trunc_voxel_multiplier),
             stream()), "VoxelBlockGrid.integrate_frame")
 
+    def integrate_frames(self, depths, colors, depth_intrinsic,
+                         color_intrinsic, extrinsics, depth_scale=1000.0,
+                         depth_max=3.0, trunc_voxel_multiplier=8.0,
+                         overlap=True):
+        """integrate_frame over a list of frames (same intrinsics / sizes),
+        strictly in order; one native call, kernels issued back to back."""
+        n = len(depths)
+        if n == 0:
+            return
+        ds = [_image(d, "depth", 1) for d in depths]
+        rows, cols = ds[0].shape
+        if color_intrinsic is None:
+            color_intrinsic = depth_intrinsic
+        Kd = host_mat(depth_intrinsic, (3, 3), "intrinsic")
+        Kc = host_mat(color_intrinsic, (3, 3), "intrinsic")
+        Ts = np.ascontiguousarray(
+            np.stack([host_mat(T, (4, 4), "extrinsic") for T in extrinsics]),
+            dtype=np.float64)
+        dptr = (C.c_void_p * n)(*[d.data_ptr() for d in ds])
+        cptr, crows, ccols = None, 0, 0
+        if colors is not None:
+            cs = [_image(c, "color", 3) for c in colors]
+            crows, ccols = cs[0].shape[:2]
+            cptr = (C.c_void_p * n)(*[c.data_ptr() for c in cs])
+        _lib.check(_lib.lib().o3dmi_vbg_integrate_frames(
+            self._g, n, dptr, rows, cols, cptr, crows, ccols,
+            TORCH_TO_O3DMI[ds[0].dtype], _lib.f64p(Kd), _lib.f64p(Kc),
+            _lib.f64p(Ts), C.c_float(depth_scale), C.c_float(depth_max),
+            C.c_float(trunc_voxel_multiplier), 1 if overlap else 0, stream()),
+            "VoxelBlockGrid.integrate_frames")
+
     def profile_begin(self, max_frames):
         _lib.check(_lib.lib().o3dmi_vbg_profile_begin(self._g, int(max_frames)),
                    "profile_begin")

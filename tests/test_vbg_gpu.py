@@ -280,6 +280,51 @@ def test_frame_stream_fast_path_equals_two_step_path():
     assert gb.hashmap().capacity() > 512  # grew through Reserve
 
 
+@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("grid_f32", [False, True])
+def test_frame_batch_equals_oracle(overlap, grid_f32):
+    """integrate_frames (one native call; with `overlap` the front kernel of
+    frame f+1 runs concurrently with the integrate kernel of frame f) vs the
+    oracle, bit-exact, 12 frames, Reserve forced by a small capacity, mixed
+    with a two-step-API frame in the middle (capacity bookkeeping hand-over)."""
+    _lib, geometry = _gpu()
+    g = _mk_grid(geometry, grid_f32, block_count=600)
+    og = OracleGrid(grid_f32, 16384)
+    ks = list(range(200, 320, 10))
+    ds, cs, Ts = [], [], []
+    for k in ks:
+        d, c, K, T = sc.frames(k, 1)
+        ds.append(d[0]); cs.append(c[0]); Ts.append(T[0])
+    dt = [torch.from_numpy(d).cuda() for d in ds]
+    ct = [torch.from_numpy(c).cuda() for c in cs]
+    for i in range(len(ks)):
+        og.integrate(ds[i], cs[i], K, Ts[i])
+    g.integrate_frames(dt[:5], ct[:5], K, K, Ts[:5], sc.DEPTH_SCALE,
+                       sc.DEPTH_MAX, sc.TRUNC_MULT, overlap=overlap)
+    keys = g.compute_unique_block_coordinates(dt[5], K, Ts[5], sc.DEPTH_SCALE,
+                                              sc.DEPTH_MAX, sc.TRUNC_MULT)
+    g.integrate(keys, dt[5], ct[5], K, K, Ts[5], sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                sc.TRUNC_MULT)
+    g.integrate_frames(dt[6:], ct[6:], K, K, Ts[6:], sc.DEPTH_SCALE,
+                       sc.DEPTH_MAX, sc.TRUNC_MULT, overlap=overlap)
+    assert _compare_grids(og, g)[1]
+    assert g.hashmap().capacity() > 600
+
+
+def test_frame_batch_depth_only_and_res8():
+    _lib, geometry = _gpu()
+    g = _mk_grid(geometry, False, with_color=False, res=8, block_count=8192)
+    og = OracleGrid(False, 8192, with_color=False, res=8)
+    ds, Ts = [], []
+    for k in (400, 410, 420):
+        d, c, K, T = sc.frames(k, 1)
+        ds.append(d[0]); Ts.append(T[0])
+        og.integrate(d[0], None, K, T[0])
+    g.integrate_frames([torch.from_numpy(d).cuda() for d in ds], None, K, K,
+                       Ts, sc.DEPTH_SCALE, sc.DEPTH_MAX, sc.TRUNC_MULT)
+    assert _compare_grids(og, g)[1]
+
+
 def test_pointcloud_touch_parity():
     _lib, geometry = _gpu()
     from open3d_amd.core import stream
