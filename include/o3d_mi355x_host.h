@@ -144,11 +144,12 @@ int o3dmi_vbg_integrate_frame(o3dmi_vbg_t* g, const void* depth_dev,
  * depth_devs / color_devs are host arrays of n_frames device pointers,
  * extrinsics is n_frames x 16 host doubles. Frames are integrated strictly in
  * order (frame f sees the grid left by frame f-1), so the result is identical
- * to n_frames calls of o3dmi_vbg_integrate_frame. With overlap != 0 the touch /
- * prepare kernel of frame f+1 runs on an internal stream concurrently with the
- * integrate kernel of frame f (it only inserts new hash entries and writes
- * double-buffered per-frame scratch); all integrate kernels are issued on
- * `stream`, which therefore observes completion of the whole batch. */
+ * to n_frames calls of o3dmi_vbg_integrate_frame. With overlap != 0 the launch
+ * that integrates frame f also carries the touch / prepare work of frame f+1
+ * (it only inserts new hash entries and writes double-buffered per-frame
+ * scratch), so a frame costs one kernel launch and the latency-bound hash
+ * work hides beside the bandwidth-bound voxel update. All work is issued on
+ * `stream`. */
 int o3dmi_vbg_integrate_frames(o3dmi_vbg_t* g, int n_frames,
                                const void* const* depth_devs, int depth_rows,
                                int depth_cols, const void* const* color_devs,
@@ -161,11 +162,12 @@ int o3dmi_vbg_integrate_frames(o3dmi_vbg_t* g, int n_frames,
 
 /* Measurement hook for bench.py: while profiling is on, every
  * o3dmi_vbg_integrate_frame(s) call brackets its front (touch) and integrate
- * kernels with HIP events on the streams they are launched on and records the
- * frame's active-block count. o3dmi_vbg_profile_end synchronises and returns the summed kernel
+ * kernels with HIP events on the stream they are launched on and records the
+ * frame's active-block count; `stride` > 1 brackets only every stride-th
+ * frame (less perturbation of the stream), 0 none. o3dmi_vbg_profile_end synchronises and returns the summed kernel
  * times (ms), the number of integrate launches and the sum of active blocks
  * over those launches (the roofline's "units"). */
-int o3dmi_vbg_profile_begin(o3dmi_vbg_t* g, int max_frames);
+int o3dmi_vbg_profile_begin(o3dmi_vbg_t* g, int max_frames, int stride);
 int o3dmi_vbg_profile_end(o3dmi_vbg_t* g, o3dmi_stream_t stream,
                           double* integrate_ms, double* touch_ms,
                           int64_t* launches, int64_t* block_frames);

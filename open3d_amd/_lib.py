@@ -119,7 +119,7 @@ PROTOTYPES.update({
     "o3dmi_vbg_integrate_frames": (
         _i32, [_vp, _i32, C.POINTER(_vp), _i32, _i32, C.POINTER(_vp), _i32,
                _i32, _i32, _dp, _dp, _dp, _f, _f, _f, _i32, _vp]),
-    "o3dmi_vbg_profile_begin": (_i32, [_vp, _i32]),
+    "o3dmi_vbg_profile_begin": (_i32, [_vp, _i32, _i32]),
     "o3dmi_vbg_profile_end": (_i32, [_vp, _vp, C.POINTER(_d), C.POINTER(_d),
                                      C.POINTER(_i64), C.POINTER(_i64)]),
     "o3dmi_vbg_ray_cast": (

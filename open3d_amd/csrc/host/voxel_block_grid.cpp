@@ -43,9 +43,8 @@ struct o3dmi_vbg {
     hipEvent_t size_event = nullptr;
     bool size_event_pending = false;
     // Frame-stream fast path (stream_path.h): double-buffered prepared pixel
-    // records and block lists, a ring of 4 device counters, a host-mapped
-    // status word written by the integrate kernel, and an auxiliary stream so
-    // that frame k+1's front kernel overlaps frame k's integrate kernel.
+    // records and block lists, a ring of 4 device counters and a host-mapped
+    // status word written by the integrate role.
     PixelRec* recs[2] = {nullptr, nullptr};
     int64_t recs_pixels = 0;
     FrameBlock* lists[2] = {nullptr, nullptr};
@@ -57,14 +56,10 @@ struct o3dmi_vbg {
     int known_stamp = 0;
     bool known_valid = false;            // false after any non-stream activation
     int last_count = 1024;
-    hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_front[2] = {nullptr, nullptr};
-    hipEvent_t ev_int[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr;
     // bench.py measurement hook (o3dmi_vbg_profile_begin/end).
     bool profiling = false;
-    std::vector<hipEvent_t> prof_events;  // 4 per frame: front t0,t1; integrate t2,t3
-    int prof_frames = 0, prof_max = 0;
+    std::vector<hipEvent_t> prof_events;  // 2 per frame, around the launch carrying the integrate work
+    int prof_frames = 0, prof_max = 0, prof_stride = 1, prof_seen = 0;
     int32_t* prof_counts = nullptr;  // device, one per frame
 
     int AttrIndex(const char* name) const {
@@ -236,11 +231,7 @@ int o3dmi_vbg_destroy(o3dmi_vbg_t* g) {
     for (int i = 0; i < 2; ++i) {
         (void)hipFree(g->recs[i]);
         (void)hipFree(g->lists[i]);
-        if (g->ev_front[i]) (void)hipEventDestroy(g->ev_front[i]);
-        if (g->ev_int[i]) (void)hipEventDestroy(g->ev_int[i]);
     }
-    if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
-    if (g->aux_stream) (void)hipStreamDestroy(g->aux_stream);
     (void)hipFree(g->ring_counters);
     if (g->stream_status) (void)hipHostFree((void*)g->stream_status);
     for (hipEvent_t e : g->prof_events) (void)hipEventDestroy(e);
@@ -395,10 +386,9 @@ static int IntegrateFrameGeneric(o3dmi_vbg_t* g, const void* depth_dev,
     int dt = input_dtype == O3DMI_F32 ? O3DMI_F32 : O3DMI_U16;
     g->known_valid = false;
     g->frame_stamp += 1;
-    const bool prof = g->profiling && g->prof_frames < g->prof_max;
-    if (prof)
-        O3DMI_HIP_CHECK(hipEventRecord(
-                g->prof_events[(size_t)g->prof_frames * 4 + 0], s));
+    const bool prof = g->profiling && g->prof_frames < g->prof_max &&
+                      g->prof_stride > 0 &&
+                      (g->prof_seen++ % g->prof_stride) == 0;
     int st = o3dmi_vbg_touch_activate(
             g->block_hashmap, depth_dev, dt, depth_rows, depth_cols,
             depth_intrinsic, extrinsic, g->frame_indices, max_new,
@@ -416,9 +406,7 @@ static int IntegrateFrameGeneric(o3dmi_vbg_t* g, const void* depth_dev,
                                        g->frame_count, sizeof(int32_t),
                                        hipMemcpyDeviceToDevice, s));
         O3DMI_HIP_CHECK(hipEventRecord(
-                g->prof_events[(size_t)g->prof_frames * 4 + 1], s));
-        O3DMI_HIP_CHECK(hipEventRecord(
-                g->prof_events[(size_t)g->prof_frames * 4 + 2], s));
+                g->prof_events[(size_t)g->prof_frames * 2 + 0], s));
     }
     st = RunIntegrate(g, g->frame_indices, max_new, g->frame_count, depth_dev,
                       depth_rows, depth_cols, color_dev, color_rows,
@@ -427,7 +415,7 @@ static int IntegrateFrameGeneric(o3dmi_vbg_t* g, const void* depth_dev,
                       trunc_voxel_multiplier, stream);
     if (prof) {
         O3DMI_HIP_CHECK(hipEventRecord(
-                g->prof_events[(size_t)g->prof_frames * 4 + 3], s));
+                g->prof_events[(size_t)g->prof_frames * 2 + 1], s));
         g->prof_frames += 1;
     }
     return st;
@@ -466,16 +454,6 @@ static int EnsureStreamBuffers(o3dmi_vbg* g, int rows, int cols,
                                               hipHostMallocCoherent));
         st[0] = st[1] = st[2] = st[3] = 0;
         g->stream_status = st;
-        O3DMI_HIP_CHECK(hipStreamCreateWithFlags(&g->aux_stream,
-                                                 hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) {
-            O3DMI_HIP_CHECK(hipEventCreateWithFlags(&g->ev_front[i],
-                                                    hipEventDisableTiming));
-            O3DMI_HIP_CHECK(hipEventCreateWithFlags(&g->ev_int[i],
-                                                    hipEventDisableTiming));
-        }
-        O3DMI_HIP_CHECK(hipEventCreateWithFlags(&g->ev_fork,
-                                                hipEventDisableTiming));
     }
     return O3DMI_OK;
 }
@@ -561,109 +539,167 @@ static int StreamEnsureCapacity(o3dmi_vbg* g, int64_t max_new,
     return O3DMI_OK;
 }
 
-static int IntegrateFrameStream(o3dmi_vbg_t* g, const void* depth_dev,
-                                int depth_rows, int depth_cols,
-                                const void* color_dev, int color_rows,
-                                int color_cols, const double* depth_intrinsic,
-                                const double* color_intrinsic,
-                                const double* extrinsic, float depth_scale,
-                                float depth_max, float trunc_voxel_multiplier,
-                                hipStream_t front, hipStream_t integ) {
-    const int stride = 4;
-    const int64_t max_new =
-            (int64_t)(depth_cols / stride) * (depth_rows / stride) * 4;
-    O3DMI_REQUIRE(max_new > 0, "depth image too small");
-    int ti = g->AttrIndex("tsdf"), wi = g->AttrIndex("weight"),
-        ci = g->AttrIndex("color");
-    int grid_dtype;
-    int st = GridDtype(g, &grid_dtype);
-    if (st) return st;
-    if ((st = EnsureStreamBuffers(g, depth_rows, depth_cols, max_new)))
-        return st;
-    if ((st = StreamEnsureCapacity(g, max_new, front, integ))) return st;
+// Non-blocking form of the capacity policy: true when the map provably has
+// room for one more frame's worth of new blocks on top of every frame whose
+// front role is already issued.
+static bool StreamCapacityBoundOK(o3dmi_vbg* g, int64_t max_new) {
+    if (!g->known_valid) return false;
+    if (PollStreamStatus(g) != O3DMI_OK) return false;  // surfaced later
+    const int64_t unknown = (int64_t)g->frame_stamp - g->known_stamp;
+    return (int64_t)g->known_size + (unknown + 1) * max_new <=
+           o3dmi_hash_capacity(g->block_hashmap);
+}
 
-    g->size_bound = o3dmi_hash_capacity(g->block_hashmap);  // generic path: re-read
-    const bool overlapped = front != integ;
-    const int64_t k = g->stream_seq;
+// Per-frame inputs of the fast path.
+struct StreamFrame {
+    const void* depth;
+    const void* color;
+    const double* extrinsic;
+};
+struct StreamCommon {
+    int depth_rows, depth_cols, color_rows, color_cols;
+    const double* depth_intrinsic;
+    const double* color_intrinsic;
+    float depth_scale, depth_max, trunc;
+    int64_t max_new;
+    int grid_dtype;
+    int ti, wi, ci;
+};
+
+// Fills the front-role arguments of the next frame and advances the stamp.
+static void MakeFrontArgs(o3dmi_vbg* g, const StreamCommon& c,
+                          const StreamFrame& f, FrameFrontArgs* fa) {
+    const int64_t k = g->stream_seq;  // sequence number of this frame
     const int par = (int)(k & 1);
     g->frame_stamp += 1;
-    const bool with_color = color_dev != nullptr && ci >= 0 &&
-                            (int64_t)color_rows * color_cols > 0;
-    const bool prof = g->profiling && g->prof_frames < g->prof_max;
-    hipEvent_t* pe = prof ? &g->prof_events[(size_t)g->prof_frames * 4]
-                          : nullptr;
-
-    // Frame k re-uses the buffers of frame k-2: its integrate must be done.
-    if (overlapped && k >= 2)
-        O3DMI_HIP_CHECK(hipStreamWaitEvent(front, g->ev_int[par], 0));
-    FrameFrontArgs fa;
-    fa.depth = (const uint16_t*)depth_dev;
-    fa.color = with_color ? (const uint8_t*)color_dev : nullptr;
-    fa.rows = depth_rows;
-    fa.cols = depth_cols;
-    fa.color_rows = color_rows;
-    fa.color_cols = color_cols;
-    fa.depth_intrinsic = depth_intrinsic;
-    fa.color_intrinsic = color_intrinsic ? color_intrinsic : depth_intrinsic;
-    fa.extrinsic = extrinsic;
-    fa.resolution = (int)g->block_resolution;
-    fa.voxel_size = g->voxel_size;
-    fa.sdf_trunc = g->voxel_size * trunc_voxel_multiplier;
-    fa.depth_scale = depth_scale;
-    fa.depth_max = depth_max;
-    fa.stride = stride;
-    fa.frame_stamp = g->frame_stamp;
-    fa.recs = g->recs[par];
-    fa.list = g->lists[par];
-    fa.list_capacity = g->lists_capacity;
-    fa.count = g->ring_counters + (k & 3);
-    if (pe) O3DMI_HIP_CHECK(hipEventRecord(pe[0], front));
-    if ((st = LaunchFrameFront(g->block_hashmap, fa, front))) return st;
-    if (pe) O3DMI_HIP_CHECK(hipEventRecord(pe[1], front));
-    if (overlapped) {
-        O3DMI_HIP_CHECK(hipEventRecord(g->ev_front[par], front));
-        O3DMI_HIP_CHECK(hipStreamWaitEvent(integ, g->ev_front[par], 0));
-    }
-
-    IntegrateStreamArgs ia;
-    ia.recs = g->recs[par];
-    ia.rows = depth_rows;
-    ia.cols = depth_cols;
-    ia.with_color = with_color;
-    ia.list = g->lists[par];
-    ia.count = g->ring_counters + (k & 3);
-    ia.list_capacity = g->lists_capacity;
-    ia.grid_hint = g->last_count;
-    ia.tsdf = (float*)o3dmi_hash_value_buffer(g->block_hashmap, ti);
-    ia.weight = o3dmi_hash_value_buffer(g->block_hashmap, wi);
-    ia.color = with_color ? o3dmi_hash_value_buffer(g->block_hashmap, ci)
-                          : nullptr;
-    ia.grid_dtype = grid_dtype;
-    ia.depth_intrinsic = depth_intrinsic;
-    ia.extrinsic = extrinsic;
-    ia.resolution = (int)g->block_resolution;
-    ia.voxel_size = g->voxel_size;
-    ia.sdf_trunc = g->voxel_size * trunc_voxel_multiplier;
-    ia.depth_max = depth_max;
-    ia.zero_counter = g->ring_counters + ((k + 2) & 3);
-    ia.size_host = (int*)g->stream_status;
-    ia.frame_stamp = g->frame_stamp;
-    ia.prof_count = prof ? g->prof_counts + g->prof_frames : nullptr;
-    if (pe) O3DMI_HIP_CHECK(hipEventRecord(pe[2], integ));
-    if ((st = LaunchIntegrateStream(g->block_hashmap, ia, integ))) return st;
-    if (pe) {
-        O3DMI_HIP_CHECK(hipEventRecord(pe[3], integ));
-        g->prof_frames += 1;
-    }
-    if (overlapped) O3DMI_HIP_CHECK(hipEventRecord(g->ev_int[par], integ));
+    const bool with_color = f.color != nullptr && c.ci >= 0 &&
+                            (int64_t)c.color_rows * c.color_cols > 0;
+    fa->depth = (const uint16_t*)f.depth;
+    fa->color = with_color ? (const uint8_t*)f.color : nullptr;
+    fa->rows = c.depth_rows;
+    fa->cols = c.depth_cols;
+    fa->color_rows = c.color_rows;
+    fa->color_cols = c.color_cols;
+    fa->depth_intrinsic = c.depth_intrinsic;
+    fa->color_intrinsic = c.color_intrinsic ? c.color_intrinsic
+                                            : c.depth_intrinsic;
+    fa->extrinsic = f.extrinsic;
+    fa->resolution = (int)g->block_resolution;
+    fa->voxel_size = g->voxel_size;
+    fa->sdf_trunc = g->voxel_size * c.trunc;
+    fa->depth_scale = c.depth_scale;
+    fa->depth_max = c.depth_max;
+    fa->stride = 4;
+    fa->frame_stamp = g->frame_stamp;
+    fa->recs = g->recs[par];
+    fa->list = g->lists[par];
+    fa->list_capacity = g->lists_capacity;
+    fa->count = g->ring_counters + (k & 3);
     g->stream_seq += 1;
-    return O3DMI_OK;
+    g->size_bound = o3dmi_hash_capacity(g->block_hashmap);  // generic path: re-read
+}
+
+// Integrate-role arguments of the frame whose front role was issued with
+// sequence number `k` and stamp `stamp`.
+static void MakeIntegArgs(o3dmi_vbg* g, const StreamCommon& c,
+                          const StreamFrame& f, int64_t k, int stamp,
+                          bool prof, IntegrateStreamArgs* ia) {
+    const int par = (int)(k & 1);
+    const bool with_color = f.color != nullptr && c.ci >= 0 &&
+                            (int64_t)c.color_rows * c.color_cols > 0;
+    ia->recs = g->recs[par];
+    ia->rows = c.depth_rows;
+    ia->cols = c.depth_cols;
+    ia->with_color = with_color;
+    ia->list = g->lists[par];
+    ia->count = g->ring_counters + (k & 3);
+    ia->list_capacity = g->lists_capacity;
+    ia->grid_hint = g->last_count;
+    ia->tsdf = (float*)o3dmi_hash_value_buffer(g->block_hashmap, c.ti);
+    ia->weight = o3dmi_hash_value_buffer(g->block_hashmap, c.wi);
+    ia->color = with_color ? o3dmi_hash_value_buffer(g->block_hashmap, c.ci)
+                           : nullptr;
+    ia->grid_dtype = c.grid_dtype;
+    ia->depth_intrinsic = c.depth_intrinsic;
+    ia->extrinsic = f.extrinsic;
+    ia->resolution = (int)g->block_resolution;
+    ia->voxel_size = g->voxel_size;
+    ia->sdf_trunc = g->voxel_size * c.trunc;
+    ia->depth_max = c.depth_max;
+    ia->zero_counter = g->ring_counters + ((k + 2) & 3);
+    ia->size_host = (int*)g->stream_status;
+    ia->frame_stamp = stamp;
+    ia->prof_count = prof ? g->prof_counts + g->prof_frames : nullptr;
 }
 
 static bool StreamPathApplies(const o3dmi_vbg* g, int input_dtype) {
     int ti = g->AttrIndex("tsdf"), wi = g->AttrIndex("weight");
     return input_dtype == O3DMI_U16 && (g->block_resolution % 4) == 0 &&
            ti >= 0 && wi >= 0 && g->attr_dtypes[(size_t)ti] == O3DMI_F32;
+}
+
+// Integrates frames[0..n) strictly in order on stream `s`. With `pipelined`
+// the front role of frame f+1 shares the launch of frame f's integrate role
+// whenever the capacity bound allows it without waiting.
+static int StreamIntegrate(o3dmi_vbg* g, const StreamCommon& c0,
+                           const StreamFrame* frames, int n, bool pipelined,
+                           hipStream_t s) {
+    StreamCommon c = c0;
+    c.max_new = (int64_t)(c.depth_cols / 4) * (c.depth_rows / 4) * 4;
+    O3DMI_REQUIRE(c.max_new > 0, "depth image too small");
+    c.ti = g->AttrIndex("tsdf");
+    c.wi = g->AttrIndex("weight");
+    c.ci = g->AttrIndex("color");
+    int st = GridDtype(g, &c.grid_dtype);
+    if (st) return st;
+    if ((st = EnsureStreamBuffers(g, c.depth_rows, c.depth_cols, c.max_new)))
+        return st;
+
+    bool front_issued = false;  // front role of frame f already in flight
+    int64_t cur_seq = 0;
+    int cur_stamp = 0;
+    for (int f = 0; f < n; ++f) {
+        if (!front_issued) {
+            // Pipeline is drained: every issued front has its integrate
+            // launched, so the blocking form of the policy cannot dead-lock.
+            if ((st = StreamEnsureCapacity(g, c.max_new, s, s))) return st;
+            FrameFrontArgs fa;
+            cur_seq = g->stream_seq;
+            MakeFrontArgs(g, c, frames[f], &fa);
+            cur_stamp = fa.frame_stamp;
+            if ((st = LaunchFrameStep(g->block_hashmap, &fa, nullptr, s)))
+                return st;
+        }
+        const bool prof = g->profiling && g->prof_frames < g->prof_max &&
+                          g->prof_stride > 0 &&
+                          (g->prof_seen++ % g->prof_stride) == 0;
+        hipEvent_t* pe = prof ? &g->prof_events[(size_t)g->prof_frames * 2]
+                              : nullptr;
+        IntegrateStreamArgs ia;
+        MakeIntegArgs(g, c, frames[f], cur_seq, cur_stamp, prof, &ia);
+        FrameFrontArgs fa;
+        const bool fuse = pipelined && f + 1 < n &&
+                          StreamCapacityBoundOK(g, c.max_new);
+        int64_t next_seq = 0;
+        if (fuse) {
+            next_seq = g->stream_seq;
+            MakeFrontArgs(g, c, frames[f + 1], &fa);
+        }
+        if (pe) O3DMI_HIP_CHECK(hipEventRecord(pe[0], s));
+        if ((st = LaunchFrameStep(g->block_hashmap, fuse ? &fa : nullptr, &ia,
+                                  s)))
+            return st;
+        if (pe) {
+            O3DMI_HIP_CHECK(hipEventRecord(pe[1], s));
+            g->prof_frames += 1;
+        }
+        front_issued = fuse;
+        if (fuse) {
+            cur_seq = next_seq;
+            cur_stamp = fa.frame_stamp;
+        }
+    }
+    return O3DMI_OK;
 }
 
 int o3dmi_vbg_integrate_frame(o3dmi_vbg_t* g, const void* depth_dev,
@@ -683,11 +719,18 @@ int o3dmi_vbg_integrate_frame(o3dmi_vbg_t* g, const void* depth_dev,
                                      input_dtype, depth_intrinsic,
                                      color_intrinsic, extrinsic, depth_scale,
                                      depth_max, trunc_voxel_multiplier, stream);
-    hipStream_t s = (hipStream_t)stream;
-    return IntegrateFrameStream(g, depth_dev, depth_rows, depth_cols, color_dev,
-                                color_rows, color_cols, depth_intrinsic,
-                                color_intrinsic, extrinsic, depth_scale,
-                                depth_max, trunc_voxel_multiplier, s, s);
+    StreamCommon c = {};
+    c.depth_rows = depth_rows;
+    c.depth_cols = depth_cols;
+    c.color_rows = color_rows;
+    c.color_cols = color_cols;
+    c.depth_intrinsic = depth_intrinsic;
+    c.color_intrinsic = color_intrinsic;
+    c.depth_scale = depth_scale;
+    c.depth_max = depth_max;
+    c.trunc = trunc_voxel_multiplier;
+    StreamFrame fr = {depth_dev, color_dev, extrinsic};
+    return StreamIntegrate(g, c, &fr, 1, false, (hipStream_t)stream);
 }
 
 int o3dmi_vbg_integrate_frames(o3dmi_vbg_t* g, int n_frames,
@@ -702,38 +745,36 @@ int o3dmi_vbg_integrate_frames(o3dmi_vbg_t* g, int n_frames,
     O3DMI_REQUIRE(g && depth_devs && depth_intrinsic && extrinsics &&
                           n_frames >= 0,
                   "null argument");
-    hipStream_t s = (hipStream_t)stream;
-    const bool fast = StreamPathApplies(g, input_dtype);
-    const bool two = fast && overlap != 0 && n_frames > 1;
-    if (two) {
-        int st = EnsureStreamBuffers(
-                g, depth_rows, depth_cols,
-                (int64_t)(depth_cols / 4) * (depth_rows / 4) * 4);
-        if (st) return st;
-        // Fork: the front stream starts behind everything queued on `stream`.
-        O3DMI_HIP_CHECK(hipEventRecord(g->ev_fork, s));
-        O3DMI_HIP_CHECK(hipStreamWaitEvent(g->aux_stream, g->ev_fork, 0));
-    }
-    for (int f = 0; f < n_frames; ++f) {
-        const void* c = color_devs ? color_devs[f] : nullptr;
-        int st;
-        if (fast)
-            st = IntegrateFrameStream(
-                    g, depth_devs[f], depth_rows, depth_cols, c, color_rows,
-                    color_cols, depth_intrinsic, color_intrinsic,
-                    extrinsics + 16 * (size_t)f, depth_scale, depth_max,
-                    trunc_voxel_multiplier, two ? g->aux_stream : s, s);
-        else
-            st = IntegrateFrameGeneric(
-                    g, depth_devs[f], depth_rows, depth_cols, c, color_rows,
+    if (!StreamPathApplies(g, input_dtype)) {
+        for (int f = 0; f < n_frames; ++f) {
+            int st = IntegrateFrameGeneric(
+                    g, depth_devs[f], depth_rows, depth_cols,
+                    color_devs ? color_devs[f] : nullptr, color_rows,
                     color_cols, input_dtype, depth_intrinsic, color_intrinsic,
                     extrinsics + 16 * (size_t)f, depth_scale, depth_max,
                     trunc_voxel_multiplier, stream);
-        if (st) return st;
+            if (st) return st;
+        }
+        return O3DMI_OK;
     }
-    // Join is implicit: every integrate kernel is on `stream` and waits for
-    // its front kernel; the front stream has nothing after the last of them.
-    return O3DMI_OK;
+    StreamCommon c = {};
+    c.depth_rows = depth_rows;
+    c.depth_cols = depth_cols;
+    c.color_rows = color_rows;
+    c.color_cols = color_cols;
+    c.depth_intrinsic = depth_intrinsic;
+    c.color_intrinsic = color_intrinsic;
+    c.depth_scale = depth_scale;
+    c.depth_max = depth_max;
+    c.trunc = trunc_voxel_multiplier;
+    std::vector<StreamFrame> frames((size_t)n_frames);
+    for (int f = 0; f < n_frames; ++f) {
+        frames[(size_t)f].depth = depth_devs[f];
+        frames[(size_t)f].color = color_devs ? color_devs[f] : nullptr;
+        frames[(size_t)f].extrinsic = extrinsics + 16 * (size_t)f;
+    }
+    return StreamIntegrate(g, c, frames.data(), n_frames, overlap != 0,
+                           (hipStream_t)stream);
 }
 
 int o3dmi_vbg_ray_cast(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
@@ -780,9 +821,11 @@ int o3dmi_vbg_ray_cast(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
             range_map_down_factor, stream);
 }
 
-int o3dmi_vbg_profile_begin(o3dmi_vbg_t* g, int max_frames) {
-    O3DMI_REQUIRE(g && max_frames > 0, "bad argument");
-    while ((int)g->prof_events.size() < max_frames * 4) {
+int o3dmi_vbg_profile_begin(o3dmi_vbg_t* g, int max_frames, int stride) {
+    O3DMI_REQUIRE(g && max_frames > 0 && stride >= 0, "bad argument");
+    g->prof_stride = stride;
+    g->prof_seen = 0;
+    while ((int)g->prof_events.size() < max_frames * 2) {
         hipEvent_t e;
         O3DMI_HIP_CHECK(hipEventCreate(&e));
         g->prof_events.push_back(e);
@@ -806,17 +849,12 @@ int o3dmi_vbg_profile_end(o3dmi_vbg_t* g, o3dmi_stream_t stream,
                   "null argument");
     g->profiling = false;
     O3DMI_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-    if (g->aux_stream) O3DMI_HIP_CHECK(hipStreamSynchronize(g->aux_stream));
-    double ti = 0, tt = 0;
+    double ti = 0, tt = 0;  // touch time is no longer bracketed separately
     for (int f = 0; f < g->prof_frames; ++f) {
         float ms = 0;
         O3DMI_HIP_CHECK(hipEventElapsedTime(
-                &ms, g->prof_events[(size_t)f * 4 + 0],
-                g->prof_events[(size_t)f * 4 + 1]));
-        tt += ms;
-        O3DMI_HIP_CHECK(hipEventElapsedTime(
-                &ms, g->prof_events[(size_t)f * 4 + 2],
-                g->prof_events[(size_t)f * 4 + 3]));
+                &ms, g->prof_events[(size_t)f * 2 + 0],
+                g->prof_events[(size_t)f * 2 + 1]));
         ti += ms;
     }
     std::vector<int32_t> counts((size_t)g->prof_frames);

@@ -2,11 +2,12 @@
 // the two kernels one RGB-D frame costs when it is integrated with
 // o3dmi_vbg_integrate_frame(s).
 //
-//   FrameFront  (vbg_touch.hip)      block touch + activation in the main hash
-//                                    (first workgroups) fused with a per-pixel
-//                                    "prepare" pass (remaining workgroups)
-//   IntegrateStream (vbg_integrate.hip) per-voxel TSDF / weight / colour update
-//                                    over the frame's block list
+//   front role      block touch + activation in the main hash (first
+//                   workgroups) fused with a per-pixel "prepare" pass
+//   integrate role  per-voxel TSDF / weight / colour update over the frame's
+//                   block list
+// (vbg_stream.hip; one launch can carry the front role of frame k+1 next to
+// the integrate role of frame k)
 //
 // Both are pure re-cuts of the reference's arithmetic (DepthTouchCPU,
 // VoxelBlockGridCPU.cpp:117-201; IntegrateCPU, VoxelBlockGridImpl.h:151-308):
@@ -51,9 +52,6 @@ struct FrameFrontArgs {
     int* count;           // device, must be 0 on entry
 };
 
-int LaunchFrameFront(o3dmi_hash* block_hash, const FrameFrontArgs& a,
-                     hipStream_t s);
-
 struct IntegrateStreamArgs {
     const PixelRec* recs;
     int rows, cols;
@@ -77,7 +75,12 @@ struct IntegrateStreamArgs {
     int* prof_count;      // device int receiving the live count
 };
 
-int LaunchIntegrateStream(o3dmi_hash* block_hash, const IntegrateStreamArgs& a,
-                          hipStream_t s);
+// One launch running either role or both. With both, the workgroups of the
+// front role (frame k+1) are dispatched first and overlap the integrate role
+// (frame k) inside the same kernel: the two touch disjoint scratch (double
+// buffered lists / records / counters) and the hash map tolerates concurrent
+// insertion of new keys next to lookups of existing ones.
+int LaunchFrameStep(o3dmi_hash* block_hash, const FrameFrontArgs* front,
+                    const IntegrateStreamArgs* integ, hipStream_t s);
 
 }  // namespace o3dmi

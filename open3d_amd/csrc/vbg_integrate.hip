@@ -24,7 +24,6 @@
 // VGA) stay resident in the 4 MiB per-XCD L2.
 
 #include "common.h"
-#include "stream_path.h"
 
 namespace o3dmi {
 namespace {
@@ -245,149 +244,6 @@ IntegrateScalarKernel(IntegrateParams p,
     }
 }
 
-// ---- frame-stream kernel (stream_path.h) -----------------------------------
-// Work item = (block of the frame's list, 256-quad part of that block); the
-// grid strides over items so that a frame's ~10^3 blocks spread as ~4x10^3
-// workgroups over the 256 CUs. Depth and colour come from the prepared
-// PixelRec image (one 8-byte gather per voxel).
-struct StreamParams {
-    Camera cam;  // depth intrinsics + extrinsic, scale = voxel_size
-    int rows, cols, resolution;
-    float sdf_trunc, depth_max;
-};
-
-template <typename weight_t, typename color_t, bool kColor>
-__global__ void __launch_bounds__(256)
-IntegrateStreamKernel(StreamParams p, const PixelRec* __restrict__ recs,
-                      const FrameBlock* __restrict__ list,
-                      const int* __restrict__ count, int64_t list_capacity,
-                      const int* __restrict__ slot_vals,
-                      const int* __restrict__ hash_counters,
-                      float* __restrict__ tsdf_base,
-                      weight_t* __restrict__ weight_base,
-                      color_t* __restrict__ color_base,
-                      int* __restrict__ zero_counter,
-                      int* __restrict__ size_host, int frame_stamp,
-                      int* __restrict__ prof_count) {
-    using TVec = Vec<float, 4, 16>;
-    using WVec = Vec<weight_t, 4, 4 * sizeof(weight_t)>;
-    using CVec = Vec<color_t, 12, 4 * sizeof(color_t)>;
-    int64_t n_blocks = *count;
-    if (n_blocks > list_capacity) n_blocks = list_capacity;
-
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (zero_counter) *zero_counter = 0;
-        if (prof_count) *prof_count = (int)n_blocks;
-        if (size_host) {
-            // The touch kernel of this frame has completed (stream order), so
-            // heap_top is the exact map size after this frame's activation.
-            size_host[0] = hash_counters[0];
-            size_host[1] = hash_counters[1];
-            size_host[2] = (int)n_blocks;
-            __hip_atomic_store(&size_host[3], frame_stamp, __ATOMIC_RELEASE,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-
-    const int res = p.resolution;
-    const int res3 = res * res * res;
-    const int quads_per_row = res >> 2;
-    const int n_quads = res3 >> 2;
-    const int parts = (n_quads + 255) >> 8;
-    const int64_t n_items = n_blocks * parts;
-
-    for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int64_t b = item / parts;
-        const int part = (int)(item - b * parts);
-        // Wave-uniform block header: {slot, key} -> buffer index.
-        const FrameBlock fb = list[b];
-        const int slot = __builtin_amdgcn_readfirstlane(fb.slot);
-        const int xb = __builtin_amdgcn_readfirstlane(fb.x);
-        const int yb = __builtin_amdgcn_readfirstlane(fb.y);
-        const int zb = __builtin_amdgcn_readfirstlane(fb.z);
-        const int block_idx = __builtin_amdgcn_readfirstlane(slot_vals[slot]);
-        const int64_t block_base = (int64_t)block_idx * res3;
-
-        const int q = (part << 8) + threadIdx.x;
-        if (q >= n_quads) continue;
-        const int qx = q % quads_per_row;
-        const int row = q / quads_per_row;
-        const int yv = row % res;
-        const int zv = row / res;
-        const int x0 = xb * res + (qx << 2);
-        const int y = yb * res + yv;
-        const int z = zb * res + zv;
-        const int64_t lin0 = block_base + ((int64_t)q << 2);
-
-        // VoxelBlockGridImpl.h:244-267 with depth taken from the record.
-        float sdf[4];
-        unsigned rgba[4];
-        bool ok[4];
-        bool any = false;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float xc, yc, zc, u, v;
-            p.cam.RigidTransform((float)(x0 + j), (float)y, (float)z, xc, yc,
-                                 zc);
-            p.cam.Project(xc, yc, zc, u, v);
-            ok[j] = InBoundary2D(u, v, p.rows, p.cols);
-            sdf[j] = 0.f;
-            rgba[j] = 0u;
-            if (ok[j]) {
-                const int ui = (int)u;
-                const int vi = (int)v;
-                const PixelRec r = recs[(int64_t)vi * p.cols + ui];
-                const float d = r.d;
-                float sd = d - zc;
-                if (d <= 0 || d > p.depth_max || zc <= 0 || sd < -p.sdf_trunc) {
-                    ok[j] = false;
-                } else {
-                    sd = sd < p.sdf_trunc ? sd : p.sdf_trunc;
-                    sdf[j] = sd / p.sdf_trunc;
-                    rgba[j] = r.rgba;
-                }
-            }
-            any |= ok[j];
-        }
-        if (!any) continue;
-
-        TVec t4 = *reinterpret_cast<const TVec*>(tsdf_base + lin0);
-        WVec w4 = *reinterpret_cast<const WVec*>(weight_base + lin0);
-        CVec c12;
-        if constexpr (kColor)
-            c12 = *reinterpret_cast<const CVec*>(color_base + 3 * lin0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (!ok[j]) continue;
-            // VoxelBlockGridImpl.h:269-302
-            float inv_wsum;
-            if constexpr (sizeof(weight_t) == 2)
-                inv_wsum = 1.0f / (float)((int)w4.v[j] + 1);
-            else
-                inv_wsum = 1.0f / (w4.v[j] + 1);
-            const float weight = (float)w4.v[j];
-            t4.v[j] = (weight * t4.v[j] + sdf[j]) * inv_wsum;
-            if constexpr (kColor) {
-                if (rgba[j] >> 24) {
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        const float in = (float)((rgba[j] >> (8 * i)) & 0xffu);
-                        // colour multiplier is 1 for uint8 input
-                        c12.v[3 * j + i] = (color_t)(
-                                (weight * (float)c12.v[3 * j + i] + in * 1.0f) *
-                                inv_wsum);
-                    }
-                }
-            }
-            w4.v[j] = (weight_t)(weight + 1);
-        }
-        *reinterpret_cast<TVec*>(tsdf_base + lin0) = t4;
-        *reinterpret_cast<WVec*>(weight_base + lin0) = w4;
-        if constexpr (kColor)
-            *reinterpret_cast<CVec*>(color_base + 3 * lin0) = c12;
-    }
-}
-
 template <typename DT, typename CT, typename WT, typename VT>
 int Launch(const IntegrateParams& p, const void* depth, const void* color,
            const int* indices, int64_t n, const int* n_dev, const int* keys,
@@ -415,45 +271,6 @@ int Launch(const IntegrateParams& p, const void* depth, const void* color,
 }
 
 }  // namespace
-
-int LaunchIntegrateStream(o3dmi_hash* bh, const IntegrateStreamArgs& a,
-                          hipStream_t s) {
-    O3DMI_REQUIRE(a.resolution % 4 == 0,
-                  "frame-stream path needs block_resolution % 4 == 0");
-    StreamParams p;
-    p.cam = Camera::Make(a.depth_intrinsic, a.extrinsic, a.voxel_size);
-    p.rows = a.rows;
-    p.cols = a.cols;
-    p.resolution = a.resolution;
-    p.sdf_trunc = a.sdf_trunc;
-    p.depth_max = a.depth_max;
-    const int n_quads = (a.resolution * a.resolution * a.resolution) >> 2;
-    const int parts = (n_quads + 255) >> 8;
-    // Grid from the expected block count (previous frame + slack); the kernel
-    // strides, so an under-estimate only costs balance, never correctness.
-    int64_t g = ((int64_t)a.grid_hint + (a.grid_hint >> 2) + 64) * parts;
-    const int64_t g_max = (int64_t)kCUs * 32;
-    if (g > g_max) g = g_max;
-    if (g < kCUs) g = kCUs;
-    dim3 grid((unsigned)g), block(256);
-    const bool col = a.with_color && a.color != nullptr;
-#define O3DMI_LAUNCH_STREAM(WT, VT, COLOR)                                    \
-    hipLaunchKernelGGL((IntegrateStreamKernel<WT, VT, COLOR>), grid, block, 0, \
-                       s, p, a.recs, a.list, a.count, a.list_capacity,        \
-                       bh->view.slot_vals, bh->view.counters, a.tsdf,         \
-                       (WT*)a.weight, (VT*)a.color, a.zero_counter,           \
-                       a.size_host, a.frame_stamp, a.prof_count)
-    if (a.grid_dtype == O3DMI_U16) {
-        if (col) O3DMI_LAUNCH_STREAM(uint16_t, uint16_t, true);
-        else O3DMI_LAUNCH_STREAM(uint16_t, uint16_t, false);
-    } else {
-        if (col) O3DMI_LAUNCH_STREAM(float, float, true);
-        else O3DMI_LAUNCH_STREAM(float, float, false);
-    }
-#undef O3DMI_LAUNCH_STREAM
-    O3DMI_HIP_CHECK(hipGetLastError());
-    return O3DMI_OK;
-}
 
 }  // namespace o3dmi
 

@@ -14,116 +14,10 @@
 // each key appends it to the output list. Counts stay on the device.
 
 #include "common.h"
-#include "stream_path.h"
+#include "touch_device.h"
 
 namespace o3dmi {
 namespace {
-
-// Insert-if-absent of a packed key; returns the slot index and whether this
-// thread created the entry. `val_out` receives the buffer index for creators
-// when kAllocate (main block hash); scratch hashes do not allocate.
-template <bool kAllocate>
-__device__ __forceinline__ bool InsertKey(const HashView& hv, int x, int y,
-                                          int z, unsigned& slot_out) {
-    unsigned long long k = PackKey(x, y, z);
-    unsigned h = HashKey(k) & hv.mask;
-    while (true) {
-        unsigned long long cur = hv.slot_keys[h];
-        if (cur == k) {
-            slot_out = h;
-            return false;
-        }
-        if (cur == kEmptyKey) {
-            unsigned long long old = atomicCAS(&hv.slot_keys[h], kEmptyKey, k);
-            if (old == kEmptyKey) {
-                slot_out = h;
-                if (kAllocate) {
-                    int top = atomicAdd(&hv.counters[0], 1);
-                    if (top >= hv.capacity) {
-                        atomicOr(&hv.counters[1], kErrCapacity);
-                        // Leave a valid (but shared) index so later kernels
-                        // stay in bounds; the error is reported at sync.
-                        hv.slot_vals[h] = 0;
-                        return true;
-                    }
-                    int idx = hv.heap[top];
-                    hv.key_buffer[3 * idx + 0] = x;
-                    hv.key_buffer[3 * idx + 1] = y;
-                    hv.key_buffer[3 * idx + 2] = z;
-                    hv.slot_vals[h] = idx;
-                }
-                return true;
-            }
-            if (old == k) {
-                slot_out = h;
-                return false;
-            }
-        }
-        h = (h + 1) & hv.mask;
-    }
-}
-
-// True for exactly one lane among the active lanes of the wave that hold the
-// same packed key (the lowest such lane). Lanes with valid == false never lead.
-__device__ __forceinline__ bool WaveLeaderForKey(unsigned long long k,
-                                                 bool valid) {
-    // Cheap neighbour filter first: adjacent rays nearly always agree.
-    bool leader = valid;
-    unsigned long long remaining = __ballot(valid);
-    int lane = threadIdx.x & 63;
-    bool decided = !valid;
-    while (remaining) {
-        int first = __ffsll((long long)remaining) - 1;
-        unsigned long long kf = __shfl(k, first);
-        bool same = valid && (k == kf);
-        unsigned long long same_mask = __ballot(same);
-        if (same && !decided) {
-            leader = (lane == first);
-            decided = true;
-        }
-        remaining &= ~same_mask;
-    }
-    return leader;
-}
-
-struct TouchParams {
-    Camera cam;  // intrinsics + POSE (inverse extrinsic), scale 1
-    int rows, cols, stride;
-    int rows_strided, cols_strided;
-    float block_size, sdf_trunc, depth_scale, depth_max;
-};
-
-// Computes the 4 candidate block keys of strided pixel `workload_idx`
-// (VoxelBlockGridCPU.cpp:144-180). Returns false when the pixel is invalid.
-template <typename depth_t>
-__device__ __forceinline__ bool RayCandidates(const TouchParams& p,
-                                              const depth_t* __restrict__ depth,
-                                              int workload_idx, int (&xb)[4],
-                                              int (&yb)[4], int (&zb)[4]) {
-    int y = (workload_idx / p.cols_strided) * p.stride;
-    int x = (workload_idx % p.cols_strided) * p.stride;
-    float d = (float)depth[(int64_t)y * p.cols + x] / p.depth_scale;
-    if (!(d > 0 && d < p.depth_max)) return false;
-
-    float x_c, y_c, z_c, x_g, y_g, z_g;
-    p.cam.Unproject((float)x, (float)y, 1.0f, x_c, y_c, z_c);
-    p.cam.RigidTransform(x_c, y_c, z_c, x_g, y_g, z_g);
-    float x_o = p.cam.e[0][3], y_o = p.cam.e[1][3], z_o = p.cam.e[2][3];
-    float x_d = x_g - x_o, y_d = y_g - y_o, z_d = z_g - z_o;
-
-    const float t_min = fmaxf(d - p.sdf_trunc, 0.0f);
-    const float t_max = fminf(d + p.sdf_trunc, p.depth_max);
-    const float t_step = (t_max - t_min) / 3;
-    float t = t_min;
-#pragma unroll
-    for (int step = 0; step < 4; ++step) {
-        xb[step] = (int)floorf((x_o + t * x_d) / p.block_size);
-        yb[step] = (int)floorf((y_o + t * y_d) / p.block_size);
-        zb[step] = (int)floorf((z_o + t * z_d) / p.block_size);
-        t += t_step;
-    }
-    return true;
-}
 
 template <typename depth_t>
 __global__ void DepthTouchKernel(HashView hv, TouchParams p,
@@ -203,92 +97,6 @@ __global__ void TouchActivateKernel(HashView hv, TouchParams p,
                 }
             }
         }
-    }
-}
-
-// Frame-stream front end (stream_path.h). Workgroups [0, n_touch_wg) run the
-// fused touch+activate of TouchActivateKernel, emitting {slot, key} entries;
-// the remaining workgroups run the per-pixel prepare pass. The two roles share
-// one launch so that the latency-bound hash work (75 workgroups at VGA) and the
-// streaming prepare pass (all other CUs) overlap.
-struct PrepParams {
-    Camera color_cam;  // colour intrinsics, identity extrinsic, scale 1
-    int color_rows, color_cols;
-    bool with_color;
-};
-
-__global__ void __launch_bounds__(256)
-FrameFrontKernel(HashView hv, TouchParams p, PrepParams pp,
-                 const uint16_t* __restrict__ depth,
-                 const uint8_t* __restrict__ color,
-                 PixelRec* __restrict__ recs, FrameBlock* __restrict__ list,
-                 int64_t list_capacity, int* __restrict__ out_count,
-                 int frame_stamp, int n_touch_wg) {
-    if ((int)blockIdx.x < n_touch_wg) {
-        int n = p.rows_strided * p.cols_strided;
-        int n_padded = ((n + 63) / 64) * 64;
-        for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < n_padded;
-             w += n_touch_wg * blockDim.x) {
-            int xb[4], yb[4], zb[4];
-            bool valid = (w < n) && RayCandidates(p, depth, w, xb, yb, zb);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                bool ok = valid;
-                if (ok && s > 0 && xb[s] == xb[s - 1] && yb[s] == yb[s - 1] &&
-                    zb[s] == zb[s - 1])
-                    ok = false;
-                if (ok && !KeyInRange(xb[s], yb[s], zb[s])) {
-                    atomicOr(&hv.counters[1], kErrKeyRange);
-                    ok = false;
-                }
-                unsigned long long k = ok ? PackKey(xb[s], yb[s], zb[s]) : 0ull;
-                if (WaveLeaderForKey(k, ok)) {
-                    unsigned slot;
-                    InsertKey<true>(hv, xb[s], yb[s], zb[s], slot);
-                    int old = atomicExch(&hv.slot_stamp[slot], frame_stamp);
-                    if (old != frame_stamp) {
-                        int o = atomicAdd(out_count, 1);
-                        if (o < list_capacity) {
-                            FrameBlock fb;
-                            fb.slot = (int)slot;
-                            fb.x = xb[s];
-                            fb.y = yb[s];
-                            fb.z = zb[s];
-                            list[o] = fb;
-                        } else {
-                            atomicOr(&hv.counters[1], kErrCapacity);
-                        }
-                    }
-                }
-            }
-        }
-        return;
-    }
-    // Prepare pass: the voxel-independent sub-expressions of the integrate
-    // lambda (VoxelBlockGridImpl.h:258-262 depth, :277-289 colour pixel).
-    const int n_px = p.rows * p.cols;
-    const int n_wg = (int)gridDim.x - n_touch_wg;
-    for (int i = ((int)blockIdx.x - n_touch_wg) * blockDim.x + threadIdx.x;
-         i < n_px; i += n_wg * blockDim.x) {
-        const int vi = i / p.cols;
-        const int ui = i - vi * p.cols;
-        PixelRec r;
-        r.d = (float)depth[i] / p.depth_scale;
-        r.rgba = 0u;
-        if (pp.with_color) {
-            float x, y, z, uf, vf;
-            p.cam.Unproject((float)ui, (float)vi, 1.0f, x, y, z);
-            pp.color_cam.Project(x, y, z, uf, vf);
-            if (InBoundary2D(uf, vf, pp.color_rows, pp.color_cols)) {
-                int uc = (int)roundf(uf);
-                int vc = (int)roundf(vf);
-                const uint8_t* in =
-                        color + ((int64_t)vc * pp.color_cols + uc) * 3;
-                r.rgba = (unsigned)in[0] | ((unsigned)in[1] << 8) |
-                         ((unsigned)in[2] << 16) | (1u << 24);
-            }
-        }
-        recs[i] = r;
     }
 }
 
@@ -384,55 +192,7 @@ __global__ void UnprojectKernel(TouchParams p,
     }
 }
 
-TouchParams MakeTouchParams(const double* intrinsic, const double* extrinsic,
-                            int rows, int cols, int stride, int resolution,
-                            float voxel_size, float sdf_trunc,
-                            float depth_scale, float depth_max) {
-    TouchParams p;
-    double pose[16];
-    InverseTransformation(extrinsic, pose);
-    p.cam = Camera::Make(intrinsic, pose, 1.0f);
-    p.rows = rows;
-    p.cols = cols;
-    p.stride = stride;
-    p.rows_strided = rows / stride;
-    p.cols_strided = cols / stride;
-    p.block_size = voxel_size * resolution;
-    p.sdf_trunc = sdf_trunc;
-    p.depth_scale = depth_scale;
-    p.depth_max = depth_max;
-    return p;
-}
-
 }  // namespace
-
-int LaunchFrameFront(o3dmi_hash* bh, const FrameFrontArgs& a, hipStream_t s) {
-    TouchParams p = MakeTouchParams(a.depth_intrinsic, a.extrinsic, a.rows,
-                                    a.cols, a.stride, a.resolution,
-                                    a.voxel_size, a.sdf_trunc, a.depth_scale,
-                                    a.depth_max);
-    static const double eye4[16] = {1, 0, 0, 0, 0, 1, 0, 0,
-                                    0, 0, 1, 0, 0, 0, 0, 1};
-    PrepParams pp;
-    pp.color_cam = Camera::Make(a.color_intrinsic ? a.color_intrinsic
-                                                  : a.depth_intrinsic,
-                                eye4, 1.0f);
-    pp.color_rows = a.color_rows;
-    pp.color_cols = a.color_cols;
-    pp.with_color = a.color != nullptr;
-    const int n_rays = p.rows_strided * p.cols_strided;
-    const int n_touch_wg = (n_rays + kBlock - 1) / kBlock;
-    // 4 pixels per prepare lane keeps the whole launch at ~1 wave of
-    // workgroups per CU beyond the touch workgroups.
-    int n_prep_wg = (a.rows * a.cols + kBlock * 4 - 1) / (kBlock * 4);
-    if (n_prep_wg < 1) n_prep_wg = 1;
-    hipLaunchKernelGGL(FrameFrontKernel, dim3(n_touch_wg + n_prep_wg),
-                       dim3(kBlock), 0, s, bh->view, p, pp, a.depth, a.color,
-                       a.recs, a.list, a.list_capacity, a.count,
-                       a.frame_stamp, n_touch_wg);
-    O3DMI_HIP_CHECK(hipGetLastError());
-    return O3DMI_OK;
-}
 
 }  // namespace o3dmi
 

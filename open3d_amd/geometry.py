@@ -229,9 +229,9 @@ class VoxelBlockGrid:
             C.c_float(trunc_voxel_multiplier), 1 if overlap else 0, stream()),
             "VoxelBlockGrid.integrate_frames")
 
-    def profile_begin(self, max_frames):
-        _lib.check(_lib.lib().o3dmi_vbg_profile_begin(self._g, int(max_frames)),
-                   "profile_begin")
+    def profile_begin(self, max_frames, stride=1):
+        _lib.check(_lib.lib().o3dmi_vbg_profile_begin(
+            self._g, int(max_frames), int(stride)), "profile_begin")
 
     def profile_end(self):
         """-> dict(integrate_ms, touch_ms, launches, block_frames)."""
