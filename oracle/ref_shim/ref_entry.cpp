@@ -1,0 +1,423 @@
+// TEST INFRASTRUCTURE ONLY.
+//
+// C entry points over the reference's OWN hot-path kernel files, compiled
+// from where they lie under /root/reference/cpp/open3d (see README.md in this
+// directory and `make -C oracle ref`). Nothing below re-implements reference
+// arithmetic: each function wraps raw pointers into the stand-in Tensor and
+// calls the reference function named in its comment.
+//
+// The signatures deliberately mirror the oracle's orc_* functions
+// (oracle/vbg_oracle.cpp, oracle/icp_oracle.cpp) so tests can run the same
+// inputs through both and compare bit for bit.
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+// The reference translation units, unmodified.
+#include "open3d/t/geometry/kernel/PointCloudCPU.cpp"
+#include "open3d/t/geometry/kernel/TransformImpl.h"
+#include "open3d/t/geometry/kernel/VoxelBlockGridCPU.cpp"
+#include "open3d/t/pipelines/kernel/RegistrationCPU.cpp"
+#include "open3d/t/pipelines/kernel/TransformationConverter.cpp"
+
+// PointCloudCPU.cpp also holds the search-based normal / colour-gradient
+// estimators, which call core::nns::NearestNeighborSearch (nanoflann, not
+// available here). They are off the paths exercised through this file; the
+// definitions below only satisfy the linker.
+namespace open3d {
+namespace core {
+namespace nns {
+#define REF_NNS_UNAVAILABLE utility::LogError("shim: nanoflann search is not available")
+NearestNeighborSearch::~NearestNeighborSearch() {}
+bool NearestNeighborSearch::KnnIndex() { REF_NNS_UNAVAILABLE; }
+bool NearestNeighborSearch::FixedRadiusIndex(std::optional<double>) { REF_NNS_UNAVAILABLE; }
+bool NearestNeighborSearch::HybridIndex(std::optional<double>) { REF_NNS_UNAVAILABLE; }
+std::pair<Tensor, Tensor> NearestNeighborSearch::KnnSearch(const Tensor&, int) { REF_NNS_UNAVAILABLE; }
+std::tuple<Tensor, Tensor, Tensor> NearestNeighborSearch::FixedRadiusSearch(const Tensor&, double, bool) { REF_NNS_UNAVAILABLE; }
+std::tuple<Tensor, Tensor, Tensor> NearestNeighborSearch::HybridSearch(const Tensor&, double, int) const { REF_NNS_UNAVAILABLE; }
+#undef REF_NNS_UNAVAILABLE
+}  // namespace nns
+}  // namespace core
+}  // namespace open3d
+
+using namespace open3d;
+using core::Tensor;
+namespace vg = open3d::t::geometry::kernel::voxel_grid;
+namespace pk = open3d::t::pipelines::kernel;
+namespace reg = open3d::t::pipelines::registration;
+
+namespace {
+
+thread_local std::string g_err;
+
+Tensor Wrap(const void* p, core::SizeVector shape, core::Dtype dt) {
+    return Tensor::FromPtr(p, shape, dt);
+}
+Tensor Mat(const double* p, int r, int c) {
+    // K / T are Float64 host tensors (t/geometry/Utility.h checks).
+    return Tensor::FromPtr(p, {r, c}, core::Float64).Clone();
+}
+
+using Key = utility::MiniVec<int, 3>;
+using Hash = utility::MiniVecHash<int, 3>;
+using Eq = utility::MiniVecEq<int, 3>;
+
+std::shared_ptr<core::HashMap> MakeHashMap(const int* keys,
+                                           const int* buf_indices, int64_t n) {
+    auto backend = std::make_shared<core::TBBHashBackend<Key, Hash, Eq>>();
+    auto impl = backend->GetImpl();
+    for (int64_t i = 0; i < n; ++i) {
+        Key k;
+        k[0] = keys[3 * i + 0];
+        k[1] = keys[3 * i + 1];
+        k[2] = keys[3 * i + 2];
+        (*impl)[k] = (core::buf_index_t)buf_indices[i];
+    }
+    return std::make_shared<core::HashMap>(backend);
+}
+
+template <typename F>
+int Guard(F&& f) {
+    try {
+        f();
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return 1;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ref_last_error() { return g_err.c_str(); }
+
+void ref_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : 1);
+#else
+    (void)n;
+#endif
+}
+
+// DepthTouchCPU, t/geometry/kernel/VoxelBlockGridCPU.cpp:117-201.
+// Returns the number of unique blocks, -1 on error ("No block is touched").
+int64_t ref_depth_touch(const void* depth, int depth_is_f32, int rows, int cols,
+                        const double* intrinsic, const double* extrinsic,
+                        int resolution, float voxel_size, float sdf_trunc,
+                        float depth_scale, float depth_max, int stride,
+                        int* out_coords, int64_t out_capacity) {
+    int64_t m = -1;
+    Guard([&] {
+        Tensor d = Wrap(depth, {rows, cols, 1},
+                        depth_is_f32 ? core::Float32 : core::UInt16);
+        std::shared_ptr<core::HashMap> unused;
+        Tensor coords;
+        vg::DepthTouchCPU(unused, d, Mat(intrinsic, 3, 3), Mat(extrinsic, 4, 4),
+                          coords, resolution, voxel_size, sdf_trunc,
+                          depth_scale, depth_max, stride);
+        m = coords.GetLength();
+        if (m > out_capacity) m = out_capacity;
+        std::memcpy(out_coords, coords.GetDataPtr<int>(),
+                    sizeof(int) * 3 * (size_t)m);
+    });
+    return m;
+}
+
+// PointCloudTouchCPU, VoxelBlockGridCPU.cpp:55-115.
+int64_t ref_pointcloud_touch(const float* pcd, int64_t n, int resolution,
+                             float voxel_size, float sdf_trunc, int* out_coords,
+                             int64_t out_capacity) {
+    int64_t m = -1;
+    Guard([&] {
+        Tensor p = Wrap(pcd, {n, 3}, core::Float32);
+        std::shared_ptr<core::HashMap> unused;
+        Tensor coords;
+        vg::PointCloudTouchCPU(unused, p, coords, resolution, voxel_size,
+                               sdf_trunc);
+        m = coords.GetLength();
+        if (m > out_capacity) m = out_capacity;
+        std::memcpy(out_coords, coords.GetDataPtr<int>(),
+                    sizeof(int) * 3 * (size_t)m);
+    });
+    return m;
+}
+
+// IntegrateCPU<...>, t/geometry/kernel/VoxelBlockGridImpl.h:151-308, with the
+// dtype dispatch of t/geometry/kernel/VoxelBlockGrid.cpp:107-146.
+int ref_integrate(const void* depth, int depth_rows, int depth_cols,
+                  const void* color, int color_rows, int color_cols,
+                  int input_is_f32, const int* indices, int64_t n_indices,
+                  const int* block_keys, int64_t capacity, float* tsdf,
+                  void* weight, void* color_buf, int grid_is_f32,
+                  const double* depth_intrinsic, const double* color_intrinsic,
+                  const double* extrinsics, int resolution, float voxel_size,
+                  float sdf_trunc, float depth_scale, float depth_max) {
+    return Guard([&] {
+        const core::Dtype ddt = input_is_f32 ? core::Float32 : core::UInt16;
+        const core::Dtype cdt = input_is_f32 ? core::Float32 : core::UInt8;
+        const core::Dtype gdt = grid_is_f32 ? core::Float32 : core::UInt16;
+        Tensor d = Wrap(depth, {depth_rows, depth_cols, 1}, ddt);
+        Tensor c = color ? Wrap(color, {color_rows, color_cols, 3}, cdt)
+                         : Tensor({0}, cdt);
+        Tensor idx = Wrap(indices, {n_indices}, core::Int32);
+        Tensor keys = Wrap(block_keys, {capacity, 3}, core::Int32);
+        const int64_t r = resolution;
+        t::geometry::TensorMap vm("tsdf");
+        vm["tsdf"] = Wrap(tsdf, {capacity, r, r, r, 1}, core::Float32);
+        vm["weight"] = Wrap(weight, {capacity, r, r, r, 1}, gdt);
+        if (color_buf) vm["color"] = Wrap(color_buf, {capacity, r, r, r, 3}, gdt);
+        Tensor Kd = Mat(depth_intrinsic, 3, 3);
+        Tensor Kc = Mat(color_intrinsic ? color_intrinsic : depth_intrinsic, 3, 3);
+        Tensor T = Mat(extrinsics, 4, 4);
+#define REF_CALL(DT, CT, WT, VT)                                              \
+    vg::IntegrateCPU<DT, CT, float, WT, VT>(d, c, idx, keys, vm, Kd, Kc, T,   \
+                                            resolution, voxel_size,           \
+                                            sdf_trunc, depth_scale, depth_max)
+        if (!input_is_f32 && !grid_is_f32)
+            REF_CALL(uint16_t, uint8_t, uint16_t, uint16_t);
+        else if (!input_is_f32 && grid_is_f32)
+            REF_CALL(uint16_t, uint8_t, float, float);
+        else if (input_is_f32 && !grid_is_f32)
+            REF_CALL(float, float, uint16_t, uint16_t);
+        else
+            REF_CALL(float, float, float, float);
+#undef REF_CALL
+    });
+}
+
+// EstimateRangeCPU, VoxelBlockGridImpl.h:310-555. frag_buffer_size <= 0 passes
+// an empty fragment buffer, which is what VoxelBlockGrid::RayCast does on its
+// first call (member fragment_buffer_, t/geometry/VoxelBlockGrid.cpp:352): the
+// kernel then sizes it by its own heuristic (Impl.h:342-349) and may drop
+// fragments. > 0 allocates that many fragments up front.
+int ref_estimate_range(const int* block_keys, int64_t n_blocks,
+                       float* range_minmax_map, const double* intrinsics,
+                       const double* extrinsics, int h, int w, int down_factor,
+                       int64_t block_resolution, float voxel_size,
+                       float depth_min, float depth_max, int frag_buffer_size) {
+    return Guard([&] {
+        Tensor keys = Wrap(block_keys, {n_blocks, 3}, core::Int32);
+        Tensor range;
+        Tensor frag;
+        if (frag_buffer_size > 0)
+            frag = Tensor({(int64_t)frag_buffer_size, 6}, core::Float32);
+        vg::EstimateRangeCPU(keys, range, Mat(intrinsics, 3, 3),
+                             Mat(extrinsics, 4, 4), h, w, down_factor,
+                             block_resolution, voxel_size, depth_min, depth_max,
+                             frag);
+        std::memcpy(range_minmax_map, range.GetDataPtr<float>(),
+                    sizeof(float) * (size_t)range.NumElements());
+    });
+}
+
+// RayCastCPU<...>, VoxelBlockGridImpl.h:578-1120. The hash map is given as
+// (key, buffer index) pairs.
+int ref_raycast(const int* hash_keys, const int* hash_buf_indices,
+                int64_t n_hash, int64_t capacity, const float* tsdf,
+                const void* weight, const void* color_buf, int grid_is_f32,
+                const float* range_map, float* out_depth, float* out_vertex,
+                float* out_color, float* out_normal, int64_t* out_index,
+                uint8_t* out_mask, float* out_ratio, float* out_ratio_dx,
+                float* out_ratio_dy, float* out_ratio_dz,
+                const double* intrinsic, const double* extrinsics, int h, int w,
+                int block_resolution, float voxel_size, float depth_scale,
+                float depth_min, float depth_max, float weight_threshold,
+                float trunc_voxel_multiplier, int range_map_down_factor) {
+    return Guard([&] {
+        auto hm = MakeHashMap(hash_keys, hash_buf_indices, n_hash);
+        const core::Dtype gdt = grid_is_f32 ? core::Float32 : core::UInt16;
+        const int64_t r = block_resolution;
+        t::geometry::TensorMap vm("tsdf");
+        vm["tsdf"] = Wrap(tsdf, {capacity, r, r, r, 1}, core::Float32);
+        vm["weight"] = Wrap(weight, {capacity, r, r, r, 1}, gdt);
+        if (color_buf) vm["color"] = Wrap(color_buf, {capacity, r, r, r, 3}, gdt);
+        Tensor range = Wrap(range_map,
+                            {h / range_map_down_factor,
+                             w / range_map_down_factor, 2},
+                            core::Float32);
+        t::geometry::TensorMap rm("depth");
+        if (out_depth) rm["depth"] = Wrap(out_depth, {h, w, 1}, core::Float32);
+        if (out_vertex) rm["vertex"] = Wrap(out_vertex, {h, w, 3}, core::Float32);
+        if (out_color) rm["color"] = Wrap(out_color, {h, w, 3}, core::Float32);
+        if (out_normal) rm["normal"] = Wrap(out_normal, {h, w, 3}, core::Float32);
+        if (out_index) rm["index"] = Wrap(out_index, {h, w, 8}, core::Int64);
+        if (out_mask) rm["mask"] = Wrap(out_mask, {h, w, 8}, core::Bool);
+        if (out_ratio)
+            rm["interp_ratio"] = Wrap(out_ratio, {h, w, 8}, core::Float32);
+        if (out_ratio_dx)
+            rm["interp_ratio_dx"] = Wrap(out_ratio_dx, {h, w, 8}, core::Float32);
+        if (out_ratio_dy)
+            rm["interp_ratio_dy"] = Wrap(out_ratio_dy, {h, w, 8}, core::Float32);
+        if (out_ratio_dz)
+            rm["interp_ratio_dz"] = Wrap(out_ratio_dz, {h, w, 8}, core::Float32);
+        Tensor K = Mat(intrinsic, 3, 3), T = Mat(extrinsics, 4, 4);
+        if (grid_is_f32)
+            vg::RayCastCPU<float, float, float>(
+                    hm, vm, range, rm, K, T, h, w, block_resolution, voxel_size,
+                    depth_scale, depth_min, depth_max, weight_threshold,
+                    trunc_voxel_multiplier, range_map_down_factor);
+        else
+            vg::RayCastCPU<float, uint16_t, uint16_t>(
+                    hm, vm, range, rm, K, T, h, w, block_resolution, voxel_size,
+                    depth_scale, depth_min, depth_max, weight_threshold,
+                    trunc_voxel_multiplier, range_map_down_factor);
+    });
+}
+
+// UnprojectCPU, t/geometry/kernel/PointCloudImpl.h:42-143.
+int64_t ref_unproject(const void* depth, int depth_is_f32, int rows, int cols,
+                      const float* colors_f32, float* points, float* colors,
+                      const double* intrinsics, const double* extrinsics,
+                      float depth_scale, float depth_max, int64_t stride) {
+    int64_t m = -1;
+    Guard([&] {
+        Tensor d = Wrap(depth, {rows, cols, 1},
+                        depth_is_f32 ? core::Float32 : core::UInt16);
+        Tensor pts, cols_out;
+        Tensor img;
+        std::optional<std::reference_wrapper<const Tensor>> in_c = std::nullopt;
+        std::optional<std::reference_wrapper<Tensor>> out_c = std::nullopt;
+        if (colors_f32 && colors) {
+            img = Wrap(colors_f32, {rows, cols, 3}, core::Float32);
+            in_c = std::cref(img);
+            out_c = std::ref(cols_out);
+        }
+        t::geometry::kernel::pointcloud::UnprojectCPU(
+                d, in_c, pts, out_c, Mat(intrinsics, 3, 3),
+                Mat(extrinsics, 4, 4), depth_scale, depth_max, stride);
+        m = pts.GetLength();
+        std::memcpy(points, pts.GetDataPtr<float>(),
+                    sizeof(float) * 3 * (size_t)m);
+        if (colors_f32 && colors)
+            std::memcpy(colors, cols_out.GetDataPtr<float>(),
+                        sizeof(float) * 3 * (size_t)m);
+    });
+    return m;
+}
+
+// ComputePosePointToPlaneKernelCPU, t/pipelines/kernel/RegistrationCPU.cpp:
+// 30-90: the 29 sums in the point dtype (widened to double for the caller).
+// The stand-in tbb::parallel_reduce runs it as one sequential chunk.
+int ref_p2plane_accumulate(const void* src, const void* tgt, const void* tgt_n,
+                           const int64_t* corr, int64_t n, int is_f64,
+                           int method, double scaling, double shape,
+                           double* sums29) {
+    return Guard([&] {
+        reg::RobustKernel kernel((reg::RobustKernelMethod)method, scaling,
+                                 shape);
+        using reg::RobustKernelMethod;
+        if (is_f64) {
+            std::vector<double> g(29, 0.0);
+            using scalar_t = double;
+            DISPATCH_ROBUST_KERNEL_FUNCTION(
+                    kernel.type_, scalar_t, kernel.scaling_parameter_,
+                    kernel.shape_parameter_, [&]() {
+                        pk::ComputePosePointToPlaneKernelCPU(
+                                (const double*)src, (const double*)tgt,
+                                (const double*)tgt_n, corr, (int)n, g.data(),
+                                GetWeightFromRobustKernel);
+                    });
+            for (int i = 0; i < 29; ++i) sums29[i] = g[(size_t)i];
+        } else {
+            std::vector<float> g(29, 0.0f);
+            using scalar_t = float;
+            DISPATCH_ROBUST_KERNEL_FUNCTION(
+                    kernel.type_, scalar_t, kernel.scaling_parameter_,
+                    kernel.shape_parameter_, [&]() {
+                        pk::ComputePosePointToPlaneKernelCPU(
+                                (const float*)src, (const float*)tgt,
+                                (const float*)tgt_n, corr, (int)n, g.data(),
+                                GetWeightFromRobustKernel);
+                    });
+            for (int i = 0; i < 29; ++i) sums29[i] = g[(size_t)i];
+        }
+    });
+}
+
+// ComputePosePointToPlaneCPU, RegistrationCPU.cpp:92-122 (reduction + decode +
+// solve): pose {6} float64, residual, inlier count.
+int ref_compute_pose_p2plane(const void* src, const void* tgt,
+                             const void* tgt_n, const int64_t* corr, int64_t n,
+                             int64_t n_tgt, int is_f64, int method,
+                             double scaling, double shape, double* pose6,
+                             float* residual, int* inlier_count) {
+    return Guard([&] {
+        const core::Dtype dt = is_f64 ? core::Float64 : core::Float32;
+        Tensor s = Wrap(src, {n, 3}, dt), t = Wrap(tgt, {n_tgt, 3}, dt),
+               tn = Wrap(tgt_n, {n_tgt, 3}, dt),
+               c = Wrap(corr, {n}, core::Int64);
+        Tensor pose = Tensor::Empty({6}, core::Float64);
+        reg::RobustKernel kernel((reg::RobustKernelMethod)method, scaling,
+                                 shape);
+        pk::ComputePosePointToPlaneCPU(s, t, tn, c, pose, *residual,
+                                       *inlier_count, dt, core::Device("CPU:0"),
+                                       kernel);
+        std::memcpy(pose6, pose.GetDataPtr<double>(), sizeof(double) * 6);
+    });
+}
+
+// DecodeAndSolve6x6, t/pipelines/kernel/TransformationConverter.cpp:189-226
+// (the 6x6 solve itself is the stand-in Tensor::Solve: LU, partial pivoting).
+int ref_decode_and_solve6x6(const double* A29, double* pose6, float* residual,
+                            int* inlier_count) {
+    return Guard([&] {
+        Tensor A = Wrap(A29, {29}, core::Float64);
+        Tensor delta = Tensor::Empty({6}, core::Float64);
+        pk::DecodeAndSolve6x6(A, delta, *residual, *inlier_count);
+        std::memcpy(pose6, delta.GetDataPtr<double>(), sizeof(double) * 6);
+    });
+}
+
+// PoseToTransformation, TransformationConverter.cpp:81-104 (+Impl.h:23-42).
+int ref_pose_to_transformation(const double* pose6, double* T16) {
+    return Guard([&] {
+        Tensor T = pk::PoseToTransformation(Wrap(pose6, {6}, core::Float64));
+        std::memcpy(T16, T.GetDataPtr<double>(), sizeof(double) * 16);
+    });
+}
+
+// TransformPointsCPU / TransformNormalsCPU, t/geometry/kernel/TransformImpl.h:
+// 83-118 (in place; T is cast to the point dtype first as
+// t/geometry/kernel/Transform.cpp:20-75 does).
+int ref_transform_points(const double* T16, void* pts, int64_t n, int is_f64) {
+    return Guard([&] {
+        const core::Dtype dt = is_f64 ? core::Float64 : core::Float32;
+        Tensor p = Wrap(pts, {n, 3}, dt);
+        Tensor T = Wrap(T16, {4, 4}, core::Float64).To(dt);
+        t::geometry::kernel::transform::TransformPointsCPU(T, p);
+    });
+}
+int ref_transform_normals(const double* T16, void* nrm, int64_t n, int is_f64) {
+    return Guard([&] {
+        const core::Dtype dt = is_f64 ? core::Float64 : core::Float32;
+        Tensor p = Wrap(nrm, {n, 3}, dt);
+        Tensor T = Wrap(T16, {4, 4}, core::Float64).To(dt);
+        t::geometry::kernel::transform::TransformNormalsCPU(T, p);
+    });
+}
+
+// DISPATCH_ROBUST_KERNEL_FUNCTION, registration/RobustKernelImpl.h:35-126.
+double ref_robust_weight(int is_f64, int method, double scaling, double shape,
+                         double residual) {
+    using reg::RobustKernelMethod;
+    reg::RobustKernelMethod m = (reg::RobustKernelMethod)method;
+    double out = 0;
+    if (is_f64) {
+        using scalar_t = double;
+        DISPATCH_ROBUST_KERNEL_FUNCTION(m, scalar_t, scaling, shape, [&]() {
+            out = (double)GetWeightFromRobustKernel((scalar_t)residual);
+        });
+    } else {
+        using scalar_t = float;
+        DISPATCH_ROBUST_KERNEL_FUNCTION(m, scalar_t, scaling, shape, [&]() {
+            out = (double)GetWeightFromRobustKernel((scalar_t)residual);
+        });
+    }
+    return out;
+}
+
+}  // extern "C"

@@ -1,0 +1,269 @@
+"""ctypes binding of oracle/_ref/libo3d_ref.so -- TEST INFRASTRUCTURE ONLY.
+
+libo3d_ref.so holds the reference's OWN hot-path kernel files
+(VoxelBlockGridCPU.cpp + VoxelBlockGridImpl.h, RegistrationCPU.cpp,
+TransformationConverter.cpp, TransformImpl.h, PointCloudCPU.cpp ...) compiled
+from /root/reference through the stand-in headers in oracle/ref_shim
+(`make -C oracle ref`). It exists only where /root/reference exists (this build
+container) or where a prebuilt copy travelled with the tree (the GPU box).
+`available()` says whether it can be used; tests skip otherwise.
+
+Function names and argument order mirror tests/_oracle.py so the same inputs
+can be run through both.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ORACLE_DIR = os.path.join(_ROOT, "oracle")
+_SO = os.path.join(_ORACLE_DIR, "_ref", "libo3d_ref.so")
+_REFERENCE = "/root/reference/cpp/open3d"
+
+_lib = None
+c_vp = C.c_void_p
+
+
+def available():
+    if os.path.exists(_SO):
+        return True
+    if os.path.isdir(_REFERENCE):
+        try:
+            subprocess.check_call(["make", "-s", "-C", _ORACLE_DIR, "ref"])
+        except Exception:
+            return False
+        return os.path.exists(_SO)
+    return False
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not available():
+            raise RuntimeError("oracle/_ref/libo3d_ref.so is not available")
+        _lib = C.CDLL(_SO)
+        L = _lib
+        L.ref_last_error.restype = C.c_char_p
+        L.ref_depth_touch.restype = C.c_int64
+        L.ref_pointcloud_touch.restype = C.c_int64
+        L.ref_unproject.restype = C.c_int64
+        L.ref_robust_weight.restype = C.c_double
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(c_vp)
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def _check(st, what):
+    if st != 0:
+        raise RuntimeError("%s: %s" % (what, lib().ref_last_error().decode()))
+
+
+def set_threads(n):
+    lib().ref_set_threads(int(n))
+
+
+def depth_touch(depth, K, T, resolution, voxel_size, sdf_trunc, depth_scale,
+                depth_max, stride=4):
+    depth = np.ascontiguousarray(depth)
+    rows, cols = depth.shape[:2]
+    cap = (rows // stride) * (cols // stride) * 4 + 16
+    out = np.zeros((cap, 3), np.int32)
+    K, T = _f64(K), _f64(T)
+    n = lib().ref_depth_touch(_p(depth), int(depth.dtype == np.float32), rows,
+                              cols, _p(K), _p(T), int(resolution),
+                              C.c_float(voxel_size), C.c_float(sdf_trunc),
+                              C.c_float(depth_scale), C.c_float(depth_max),
+                              int(stride), _p(out), C.c_int64(cap))
+    if n < 0:
+        raise RuntimeError(lib().ref_last_error().decode())
+    return out[:n].copy()
+
+
+def pointcloud_touch(points, resolution, voxel_size, sdf_trunc):
+    points = np.ascontiguousarray(points, dtype=np.float32)
+    n = points.shape[0]
+    cap = n * 27 + 16
+    out = np.zeros((cap, 3), np.int32)
+    m = lib().ref_pointcloud_touch(_p(points), C.c_int64(n), int(resolution),
+                                   C.c_float(voxel_size), C.c_float(sdf_trunc),
+                                   _p(out), C.c_int64(cap))
+    if m < 0:
+        raise RuntimeError(lib().ref_last_error().decode())
+    return out[:m].copy()
+
+
+def integrate(depth, color, indices, block_keys, tsdf, weight, color_buf, K_d,
+              K_c, T, resolution, voxel_size, sdf_trunc, depth_scale,
+              depth_max):
+    """In place on tsdf / weight / color_buf."""
+    depth = np.ascontiguousarray(depth)
+    input_is_f32 = int(depth.dtype == np.float32)
+    grid_is_f32 = int(weight.dtype == np.float32)
+    if color is not None and color.size > 0:
+        color = np.ascontiguousarray(color)
+        crow, ccol = color.shape[:2]
+    else:
+        color, crow, ccol = None, 0, 0
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    block_keys = np.ascontiguousarray(block_keys, dtype=np.int32)
+    K_d, K_c, T = _f64(K_d), _f64(K_c), _f64(T)
+    _check(lib().ref_integrate(
+        _p(depth), depth.shape[0], depth.shape[1], _p(color), crow, ccol,
+        input_is_f32, _p(indices), C.c_int64(indices.shape[0]), _p(block_keys),
+        C.c_int64(tsdf.shape[0]), _p(tsdf), _p(weight), _p(color_buf),
+        grid_is_f32, _p(K_d), _p(K_c), _p(T), int(resolution),
+        C.c_float(voxel_size), C.c_float(sdf_trunc), C.c_float(depth_scale),
+        C.c_float(depth_max)), "ref_integrate")
+
+
+def estimate_range(block_keys, K, T, h, w, down_factor, block_resolution,
+                   voxel_size, depth_min, depth_max, frag_buffer_size=0):
+    block_keys = np.ascontiguousarray(block_keys, dtype=np.int32)
+    out = np.zeros((h // down_factor, w // down_factor, 2), np.float32)
+    K, T = _f64(K), _f64(T)
+    _check(lib().ref_estimate_range(
+        _p(block_keys), C.c_int64(block_keys.shape[0]), _p(out), _p(K), _p(T),
+        int(h), int(w), int(down_factor), C.c_int64(block_resolution),
+        C.c_float(voxel_size), C.c_float(depth_min), C.c_float(depth_max),
+        int(frag_buffer_size)), "ref_estimate_range")
+    return out
+
+
+def raycast(hash_keys, hash_buf_indices, tsdf, weight, color_buf, range_map, K,
+            T, h, w, block_resolution, voxel_size, depth_scale, depth_min,
+            depth_max, weight_threshold, trunc_voxel_multiplier,
+            range_map_down_factor, attrs=("depth", "color")):
+    grid_is_f32 = int(weight.dtype == np.float32)
+    K, T = _f64(K), _f64(T)
+    shapes = {"depth": (1, np.float32), "vertex": (3, np.float32),
+              "color": (3, np.float32), "normal": (3, np.float32),
+              "index": (8, np.int64), "mask": (8, np.uint8),
+              "interp_ratio": (8, np.float32),
+              "interp_ratio_dx": (8, np.float32),
+              "interp_ratio_dy": (8, np.float32),
+              "interp_ratio_dz": (8, np.float32)}
+    out = {}
+    for a in attrs:
+        c, dt = shapes[a]
+        out[a] = np.full((h, w, c), 77, dt)
+    g = lambda a: _p(out[a]) if a in out else None
+    hash_keys = np.ascontiguousarray(hash_keys, dtype=np.int32)
+    hash_buf_indices = np.ascontiguousarray(hash_buf_indices, dtype=np.int32)
+    range_map = np.ascontiguousarray(range_map, dtype=np.float32)
+    _check(lib().ref_raycast(
+        _p(hash_keys), _p(hash_buf_indices), C.c_int64(hash_keys.shape[0]),
+        C.c_int64(tsdf.shape[0]), _p(tsdf), _p(weight), _p(color_buf),
+        grid_is_f32, _p(range_map), g("depth"), g("vertex"), g("color"),
+        g("normal"), g("index"), g("mask"), g("interp_ratio"),
+        g("interp_ratio_dx"), g("interp_ratio_dy"), g("interp_ratio_dz"),
+        _p(K), _p(T), int(h), int(w), int(block_resolution),
+        C.c_float(voxel_size), C.c_float(depth_scale), C.c_float(depth_min),
+        C.c_float(depth_max), C.c_float(weight_threshold),
+        C.c_float(trunc_voxel_multiplier), int(range_map_down_factor)),
+        "ref_raycast")
+    if "mask" in out:
+        out["mask"] = out["mask"].astype(bool)
+    return out
+
+
+def unproject(depth, colors_f32, K, T, depth_scale, depth_max, stride=1):
+    depth = np.ascontiguousarray(depth)
+    rows, cols = depth.shape[:2]
+    n = (rows // stride) * (cols // stride)
+    pts = np.zeros((n, 3), np.float32)
+    cols_out = None
+    if colors_f32 is not None:
+        colors_f32 = np.ascontiguousarray(colors_f32, dtype=np.float32)
+        cols_out = np.zeros((n, 3), np.float32)
+    K, T = _f64(K), _f64(T)
+    m = lib().ref_unproject(_p(depth), int(depth.dtype == np.float32), rows,
+                            cols, _p(colors_f32), _p(pts), _p(cols_out), _p(K),
+                            _p(T), C.c_float(depth_scale),
+                            C.c_float(depth_max), C.c_int64(stride))
+    if m < 0:
+        raise RuntimeError(lib().ref_last_error().decode())
+    if cols_out is None:
+        return pts[:m].copy(), None
+    return pts[:m].copy(), cols_out[:m].copy()
+
+
+def robust_weight(method, scaling, shape, residual, f64=False):
+    return float(lib().ref_robust_weight(int(f64), int(method),
+                                         C.c_double(scaling),
+                                         C.c_double(shape),
+                                         C.c_double(residual)))
+
+
+def p2plane_accumulate(src, tgt, tgt_n, corr, method=0, scaling=1.0,
+                       shape=1.0):
+    """29 sums accumulated in the point dtype (sequential order)."""
+    src = np.ascontiguousarray(src)
+    tgt = np.ascontiguousarray(tgt, dtype=src.dtype)
+    tgt_n = np.ascontiguousarray(tgt_n, dtype=src.dtype)
+    corr = np.ascontiguousarray(corr, dtype=np.int64).reshape(-1)
+    out = np.zeros(29, np.float64)
+    _check(lib().ref_p2plane_accumulate(
+        _p(src), _p(tgt), _p(tgt_n), _p(corr), C.c_int64(src.shape[0]),
+        int(src.dtype == np.float64), int(method), C.c_double(scaling),
+        C.c_double(shape), _p(out)), "ref_p2plane_accumulate")
+    return out
+
+
+def compute_pose_p2plane(src, tgt, tgt_n, corr, method=0, scaling=1.0,
+                         shape=1.0):
+    src = np.ascontiguousarray(src)
+    tgt = np.ascontiguousarray(tgt, dtype=src.dtype)
+    tgt_n = np.ascontiguousarray(tgt_n, dtype=src.dtype)
+    corr = np.ascontiguousarray(corr, dtype=np.int64).reshape(-1)
+    pose = np.zeros(6, np.float64)
+    residual, count = C.c_float(0), C.c_int(0)
+    _check(lib().ref_compute_pose_p2plane(
+        _p(src), _p(tgt), _p(tgt_n), _p(corr), C.c_int64(src.shape[0]),
+        C.c_int64(tgt.shape[0]), int(src.dtype == np.float64), int(method),
+        C.c_double(scaling), C.c_double(shape), _p(pose), C.byref(residual),
+        C.byref(count)), "ref_compute_pose_p2plane")
+    return pose, residual.value, count.value
+
+
+def decode_and_solve6x6(A29):
+    A29 = _f64(A29)
+    pose = np.zeros(6, np.float64)
+    residual, count = C.c_float(0), C.c_int(0)
+    st = lib().ref_decode_and_solve6x6(_p(A29), _p(pose), C.byref(residual),
+                                       C.byref(count))
+    return st, pose, residual.value, count.value
+
+
+def pose_to_transformation(pose):
+    pose = _f64(pose)
+    T = np.zeros((4, 4), np.float64)
+    _check(lib().ref_pose_to_transformation(_p(pose), _p(T)),
+           "ref_pose_to_transformation")
+    return T
+
+
+def transform_points(T, pts):
+    T = _f64(T)
+    pts = np.array(pts, copy=True, order="C")
+    _check(lib().ref_transform_points(_p(T), _p(pts), C.c_int64(pts.shape[0]),
+                                      int(pts.dtype == np.float64)),
+           "ref_transform_points")
+    return pts
+
+
+def transform_normals(T, nrm):
+    T = _f64(T)
+    nrm = np.array(nrm, copy=True, order="C")
+    _check(lib().ref_transform_normals(_p(T), _p(nrm),
+                                       C.c_int64(nrm.shape[0]),
+                                       int(nrm.dtype == np.float64)),
+           "ref_transform_normals")
+    return nrm
