@@ -10,6 +10,7 @@
 // bound says a Reserve() might be needed, so the steady-state frame stream
 // (o3dmi_vbg_integrate_frame) issues kernels back to back.
 
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -544,10 +545,24 @@ static int StreamEnsureCapacity(o3dmi_vbg* g, int64_t max_new,
 // front role is already issued.
 static bool StreamCapacityBoundOK(o3dmi_vbg* g, int64_t max_new) {
     if (!g->known_valid) return false;
-    if (PollStreamStatus(g) != O3DMI_OK) return false;  // surfaced later
-    const int64_t unknown = (int64_t)g->frame_stamp - g->known_stamp;
-    return (int64_t)g->known_size + (unknown + 1) * max_new <=
-           o3dmi_hash_capacity(g->block_hashmap);
+    const int64_t capacity = o3dmi_hash_capacity(g->block_hashmap);
+    // The host runs ahead of the GPU; when the bound fails only because too
+    // many issued frames have not reported their map size yet, give the
+    // status word a moment to catch up (each integrate role publishes it as
+    // its first action) instead of draining the pipeline.
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        if (PollStreamStatus(g) != O3DMI_OK) return false;  // surfaced later
+        const int64_t unknown = (int64_t)g->frame_stamp - g->known_stamp;
+        if ((int64_t)g->known_size + (unknown + 1) * max_new <= capacity)
+            return true;
+        // Even a fully reported pipeline would not fit: a Reserve is due.
+        if ((int64_t)g->known_size + 2 * max_new > capacity) return false;
+        if (unknown <= 1) return false;
+        if (std::chrono::steady_clock::now() - t0 >
+            std::chrono::microseconds(500))
+            return false;
+    }
 }
 
 // Per-frame inputs of the fast path.
@@ -869,13 +884,6 @@ int o3dmi_vbg_profile_end(o3dmi_vbg_t* g, o3dmi_stream_t stream,
     *launches = g->prof_frames;
     *block_frames = bf;
     return O3DMI_OK;
-}
-
-// Placeholder until the device implementation lands (next milestone).
-int o3dmi_voxel_down_sample(const void*, const void*, int64_t, int, double,
-                            void*, void*, int64_t*, o3dmi_stream_t) {
-    SetLastError("VoxelDownSample on device: not implemented yet");
-    return O3DMI_ERR_UNSUPPORTED;
 }
 
 }  // extern "C"

@@ -125,3 +125,23 @@ def icp(source, target, target_normals, max_correspondence_distance,
                            [max_correspondence_distance],
                            init_source_to_target, estimation_method,
                            callback_after_iteration, allreduce)
+
+
+def voxel_down_sample(positions, normals, voxel_size):
+    """t::geometry::PointCloud::VoxelDownSample (PointCloud.cpp:496-567) for
+    positions (+ optional normals): -> (positions {M,3}, normals {M,3}|None),
+    voxels in order of first occurrence."""
+    positions = require_cuda(positions, "positions")
+    n = positions.shape[0]
+    out_p = torch.empty_like(positions)
+    out_n = None
+    if normals is not None:
+        normals = require_cuda(normals, "normals")
+        out_n = torch.empty_like(normals)
+    m = C.c_int64(0)
+    _lib.check(_lib.lib().o3dmi_voxel_down_sample(
+        _lib.ptr(positions), _lib.ptr(normals), n,
+        TORCH_TO_O3DMI[positions.dtype], C.c_double(voxel_size),
+        _lib.ptr(out_p), _lib.ptr(out_n), C.byref(m), stream()),
+        "voxel_down_sample")
+    return out_p[:m.value], (None if out_n is None else out_n[:m.value])

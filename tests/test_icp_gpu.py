@@ -276,3 +276,52 @@ def test_icp_no_correspondences():
     assert got.fitness == 0 and got.inlier_rmse == 0 and not got.converged
     assert np.array_equal(got.transformation, np.eye(4))
     assert got.num_iterations == 0
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("voxel", [0.05, 0.0125])
+def test_voxel_down_sample_bit_exact(dtype, voxel):
+    """PointCloud::VoxelDownSample: same voxels in the same (first occurrence)
+    order, float32 sums in point order -> bit-identical means."""
+    _lib, reg = _gpu()
+    p = _pair(30000, seed=8, dtype=dtype)
+    wp, wn = orc.voxel_down_sample(p["target"], p["target_normals"], voxel)
+    gp, gn = reg.voxel_down_sample(torch.from_numpy(p["target"]).cuda(),
+                                   torch.from_numpy(p["target_normals"]).cuda(),
+                                   voxel)
+    assert gp.shape[0] == wp.shape[0] and 100 < wp.shape[0] < 30000
+    assert np.array_equal(gp.cpu().numpy(), wp)
+    assert np.array_equal(gn.cpu().numpy(), wn)
+    # positions only, negative coordinates, empty input
+    q = (p["source"] - np.asarray([3.0, 3.0, 3.0], dtype)).astype(dtype)
+    wp2, _ = orc.voxel_down_sample(q, None, voxel)
+    gp2, gn2 = reg.voxel_down_sample(torch.from_numpy(q).cuda(), None, voxel)
+    assert gn2 is None and np.array_equal(gp2.cpu().numpy(), wp2)
+    e, _ = reg.voxel_down_sample(torch.empty((0, 3), dtype=gp.dtype,
+                                             device="cuda"), None, voxel)
+    assert e.shape[0] == 0
+
+
+def test_multiscale_icp_pose_parity():
+    """BASELINE configs[2] pyramid (5 / 2.5 / 1.25 cm voxels, iterations
+    20/10/5): device VoxelDownSample pyramid + per-scale index + fused
+    iterations vs the oracle driver."""
+    _lib, reg = _gpu()
+    p = _pair(60000, seed=12)
+    vs = [0.05, 0.025, 0.0125]
+    crit = [(1e-6, 1e-6, 20), (1e-6, 1e-6, 10), (1e-6, 1e-6, 5)]
+    md = [0.15, 0.075, 0.0375]
+    want = orc.multiscale_icp(p["source"], p["target"], p["target_normals"],
+                              vs, crit, md, accumulate_double=True)
+    got = reg.multi_scale_icp(
+        torch.from_numpy(p["source"]).cuda(),
+        torch.from_numpy(p["target"]).cuda(),
+        torch.from_numpy(p["target_normals"]).cuda(), vs,
+        [reg.ICPConvergenceCriteria(*c) for c in crit], md)
+    ang, tr = _pose_err(want["transformation"], got.transformation)
+    assert ang <= 1e-6 and tr <= 1e-5, (ang, tr)
+    assert got.num_iterations == want["num_iterations"]
+    assert abs(got.fitness - want["fitness"]) < 1e-12
+    assert abs(got.inlier_rmse - want["inlier_rmse"]) < 1e-6
+    ang_gt, tr_gt = _pose_err(p["T_gt"], got.transformation)
+    assert ang_gt < 2e-3 and tr_gt < 5e-3
