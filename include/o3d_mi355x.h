@@ -77,6 +77,11 @@ const char* o3dmi_last_error(void);
  * O3DMI_ERR_HIP when no HIP device is usable. */
 int o3dmi_device_info(char* name, size_t name_len, int* cu_count,
                       int64_t* hbm_bytes);
+/* Transient scratch (search indices, pyramid levels, sort temporaries) comes
+ * from a caching pool inside the library -- the role MemoryManagerCached plays
+ * in the reference (core/MemoryManagerCached.cpp). This returns every cached
+ * block to the driver. */
+int o3dmi_release_cached_memory(void);
 
 /* ------------------------------------------------------------------------ */
 /* Spatial hash of int32x3 block keys -> buffer indices.                     */

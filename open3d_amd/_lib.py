@@ -28,6 +28,7 @@ PROTOTYPES = {
     "o3dmi_last_error": (C.c_char_p, []),
     "o3dmi_device_info": (_i32, [C.c_char_p, C.c_size_t, C.POINTER(_i32),
                                  C.POINTER(_i64)]),
+    "o3dmi_release_cached_memory": (_i32, []),
     "o3dmi_hash_create": (_i32, [_i64, _i32, C.POINTER(_i64), _vp,
                                  C.POINTER(_vp)]),
     "o3dmi_hash_destroy": (_i32, [_vp]),

@@ -17,6 +17,11 @@ namespace o3dmi {
 
 void SetLastError(const std::string& msg);
 
+// Caching scratch allocator (pool.cpp). PoolFree must only be called once the
+// work using the block has completed.
+int PoolAlloc(void** out, size_t bytes);
+void PoolFree(void* p);
+
 #define O3DMI_HIP_CHECK(expr)                                              \
     do {                                                                   \
         hipError_t _e = (expr);                                            \

@@ -51,12 +51,13 @@ void Matmul4(const double* A, const double* B, double* C) {
 
 struct DeviceBuffer {
     void* p = nullptr;
-    ~DeviceBuffer() { (void)hipFree(p); }
+    // The driver drains the stream before its buffers go out of scope
+    // (SyncOnExit below).
+    ~DeviceBuffer() { PoolFree(p); }
     int Alloc(size_t bytes) {
-        (void)hipFree(p);
+        PoolFree(p);
         p = nullptr;
-        O3DMI_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 1));
-        return O3DMI_OK;
+        return PoolAlloc(&p, bytes ? bytes : 1);
     }
 };
 
@@ -113,6 +114,12 @@ extern "C" int o3dmi_registration_multiscale_icp(
 
     // InitializePointCloudPyramidForMultiScaleICP, Registration.cpp:221-273.
     std::vector<Level> pyr((size_t)num_scales);
+    // Declared after the pyramid so that it runs first on every exit path:
+    // pooled buffers may only be released once the stream has drained.
+    struct SyncOnExit {
+        hipStream_t s;
+        ~SyncOnExit() { (void)hipStreamSynchronize(s); }
+    } sync_on_exit{s};
     const int last = num_scales - 1;
     int st;
     {

@@ -519,15 +519,12 @@ int BuildIndex(o3dmi_nns* nns, const T* pts, hipStream_t s) {
     int64_t n_scan = nb + 1;
     int n_scan_blocks =
             (int)((n_scan + kScanBlock * kScanItems - 1) / (kScanBlock * kScanItems));
-    O3DMI_HIP_CHECK(hipMalloc((void**)&counts, sizeof(unsigned) * n_scan));
-    O3DMI_HIP_CHECK(hipMalloc((void**)&cursor, sizeof(unsigned) * nb));
-    O3DMI_HIP_CHECK(hipMalloc((void**)&block_sums,
-                              sizeof(unsigned) * (n_scan_blocks + 1)));
-    O3DMI_HIP_CHECK(hipMalloc((void**)&nns->starts, sizeof(unsigned) * n_scan));
-    O3DMI_HIP_CHECK(hipMalloc(&nns->sorted_pts,
-                              sizeof(Rec4<T>) * (size_t)(n > 0 ? n : 1)));
-    O3DMI_HIP_CHECK(hipMalloc((void**)&nns->partials,
-                              sizeof(double) * kCUs * 4 * kNumSums));
+    { int st_; if ((st_ = PoolAlloc((void**)&counts, sizeof(unsigned) * n_scan))) return st_; }
+    { int st_; if ((st_ = PoolAlloc((void**)&cursor, sizeof(unsigned) * nb))) return st_; }
+    { int st_; if ((st_ = PoolAlloc((void**)&block_sums, sizeof(unsigned) * (n_scan_blocks + 1)))) return st_; }
+    { int st_; if ((st_ = PoolAlloc((void**)&nns->starts, sizeof(unsigned) * n_scan))) return st_; }
+    { int st_; if ((st_ = PoolAlloc(&nns->sorted_pts, sizeof(Rec4<T>) * (size_t)(n > 0 ? n : 1)))) return st_; }
+    { int st_; if ((st_ = PoolAlloc((void**)&nns->partials, sizeof(double) * kCUs * 4 * kNumSums))) return st_; }
     O3DMI_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(unsigned) * n_scan, s));
     O3DMI_HIP_CHECK(hipMemsetAsync(cursor, 0, sizeof(unsigned) * nb, s));
     if (n > 0) {
@@ -548,9 +545,9 @@ int BuildIndex(o3dmi_nns* nns, const T* pts, hipStream_t s) {
     }
     O3DMI_HIP_CHECK(hipGetLastError());
     O3DMI_HIP_CHECK(hipStreamSynchronize(s));
-    (void)hipFree(counts);
-    (void)hipFree(cursor);
-    (void)hipFree(block_sums);
+    PoolFree(counts);
+    PoolFree(cursor);
+    PoolFree(block_sums);
     return O3DMI_OK;
 }
 
@@ -569,8 +566,7 @@ NnsView<T> MakeView(const o3dmi_nns* nns) {
 template <typename T>
 int EnsureSortedNormals(o3dmi_nns* nns, const T* normals, hipStream_t s) {
     if (!nns->sorted_normals)
-        O3DMI_HIP_CHECK(hipMalloc(&nns->sorted_normals,
-                                  sizeof(Rec4<T>) * (size_t)(nns->n > 0 ? nns->n : 1)));
+        { int st_; if ((st_ = PoolAlloc(&nns->sorted_normals, sizeof(Rec4<T>) * (size_t)(nns->n > 0 ? nns->n : 1)))) return st_; }
     if (nns->n > 0)
         hipLaunchKernelGGL(GatherAttrKernel<T>, dim3(GridFor(nns->n, kBlock)),
                            dim3(kBlock), 0, s, normals,
@@ -624,10 +620,12 @@ int o3dmi_nns_create(const void* points_dev, int64_t n, int dtype,
 
 int o3dmi_nns_destroy(o3dmi_nns_t* nns) {
     if (!nns) return O3DMI_OK;
-    (void)hipFree(nns->sorted_pts);
-    (void)hipFree(nns->sorted_normals);
-    (void)hipFree(nns->starts);
-    (void)hipFree(nns->partials);
+    // Searches on this index may still be in flight on any stream.
+    (void)hipDeviceSynchronize();
+    PoolFree(nns->sorted_pts);
+    PoolFree(nns->sorted_normals);
+    PoolFree(nns->starts);
+    PoolFree(nns->partials);
     delete nns;
     return O3DMI_OK;
 }

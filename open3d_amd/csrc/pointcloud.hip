@@ -134,13 +134,18 @@ __global__ void VdsReduceKernel(const T* __restrict__ pos,
 
 struct Scratch {
     std::vector<void*> ptrs;
+    hipStream_t stream = nullptr;
     ~Scratch() {
-        for (void* p : ptrs) (void)hipFree(p);
+        // Pooled blocks may only be released once the stream has drained
+        // (already the case on the success path).
+        (void)hipStreamSynchronize(stream);
+        for (void* p : ptrs) PoolFree(p);
     }
     template <typename T>
     int Alloc(T** p, size_t count) {
         void* q = nullptr;
-        O3DMI_HIP_CHECK(hipMalloc(&q, sizeof(T) * (count ? count : 1)));
+        int st_ = PoolAlloc(&q, sizeof(T) * (count ? count : 1));
+        if (st_) return st_;
         ptrs.push_back(q);
         *p = (T*)q;
         return O3DMI_OK;
@@ -155,6 +160,7 @@ int VoxelDownSampleImpl(const T* pos, const T* nrm, int64_t n,
     if (n == 0) return O3DMI_OK;
     O3DMI_REQUIRE(n < (1ll << 31), "VoxelDownSample: too many points");
     Scratch sc;
+    sc.stream = s;
     int64_t n_slots = 1024;
     while (n_slots < 2 * n) n_slots <<= 1;
     VdsTable tb;
