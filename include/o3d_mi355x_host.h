@@ -144,12 +144,13 @@ int o3dmi_vbg_integrate_frame(o3dmi_vbg_t* g, const void* depth_dev,
  * depth_devs / color_devs are host arrays of n_frames device pointers,
  * extrinsics is n_frames x 16 host doubles. Frames are integrated strictly in
  * order (frame f sees the grid left by frame f-1), so the result is identical
- * to n_frames calls of o3dmi_vbg_integrate_frame. With overlap != 0 the launch
- * that integrates frame f also carries the touch / prepare work of frame f+1
- * (it only inserts new hash entries and writes double-buffered per-frame
- * scratch), so a frame costs one kernel launch and the latency-bound hash
- * work hides beside the bandwidth-bound voxel update. All work is issued on
- * `stream`. */
+ * to n_frames calls of o3dmi_vbg_integrate_frame.
+ * frames_per_launch (1..4, <= 0 = 4): consecutive frames are grouped; one
+ * launch applies the frames of a group, in order, to each touched block while
+ * its voxel state stays in registers (state is read / written once per group
+ * instead of once per frame; a block only receives the frames that touched
+ * it), and the same launch already carries the touch / prepare work of the
+ * next group. All work is issued on `stream`. */
 int o3dmi_vbg_integrate_frames(o3dmi_vbg_t* g, int n_frames,
                                const void* const* depth_devs, int depth_rows,
                                int depth_cols, const void* const* color_devs,
@@ -158,19 +159,19 @@ int o3dmi_vbg_integrate_frames(o3dmi_vbg_t* g, int n_frames,
                                const double* color_intrinsic,
                                const double* extrinsics, float depth_scale,
                                float depth_max, float trunc_voxel_multiplier,
-                               int overlap, o3dmi_stream_t stream);
+                               int frames_per_launch, o3dmi_stream_t stream);
 
-/* Measurement hook for bench.py: while profiling is on, every
- * o3dmi_vbg_integrate_frame(s) call brackets its front (touch) and integrate
- * kernels with HIP events on the stream they are launched on and records the
- * frame's active-block count; `stride` > 1 brackets only every stride-th
- * frame (less perturbation of the stream), 0 none. o3dmi_vbg_profile_end synchronises and returns the summed kernel
- * times (ms), the number of integrate launches and the sum of active blocks
- * over those launches (the roofline's "units"). */
-int o3dmi_vbg_profile_begin(o3dmi_vbg_t* g, int max_frames, int stride);
+/* Measurement hook for bench.py: while profiling is on, every stride-th
+ * launch that carries integrate work (o3dmi_vbg_integrate_frame(s)) is
+ * bracketed with HIP events on the stream it is launched on (stride 0 = none).
+ * o3dmi_vbg_profile_end synchronises and returns, over the bracketed launches:
+ * their summed duration (ms), their number, the number of block-frames they
+ * integrated (sum over touched blocks of the frames applied to each -- the
+ * roofline's unit) and the number of frames they carried. */
+int o3dmi_vbg_profile_begin(o3dmi_vbg_t* g, int max_launches, int stride);
 int o3dmi_vbg_profile_end(o3dmi_vbg_t* g, o3dmi_stream_t stream,
-                          double* integrate_ms, double* touch_ms,
-                          int64_t* launches, int64_t* block_frames);
+                          double* integrate_ms, int64_t* launches,
+                          int64_t* block_frames, int64_t* frames);
 
 /* RayCast(block_coords, intrinsic, extrinsic, width, height, attrs, ...)
  * (VoxelBlockGrid.cpp:328-402). Output pointers follow o3dmi_vbg_raycast;

@@ -121,7 +121,7 @@ PROTOTYPES.update({
         _i32, [_vp, _i32, C.POINTER(_vp), _i32, _i32, C.POINTER(_vp), _i32,
                _i32, _i32, _dp, _dp, _dp, _f, _f, _f, _i32, _vp]),
     "o3dmi_vbg_profile_begin": (_i32, [_vp, _i32, _i32]),
-    "o3dmi_vbg_profile_end": (_i32, [_vp, _vp, C.POINTER(_d), C.POINTER(_d),
+    "o3dmi_vbg_profile_end": (_i32, [_vp, _vp, C.POINTER(_d), C.POINTER(_i64),
                                      C.POINTER(_i64), C.POINTER(_i64)]),
     "o3dmi_vbg_ray_cast": (
         _i32, [_vp, _vp, _i64, _dp, _dp, _i32, _i32, _vp] + [_vp] * 10 +

@@ -182,7 +182,7 @@ int AllocateStorage(o3dmi_hash* h, int64_t capacity, hipStream_t s) {
     int st;
     if ((st = DevAlloc(&v.slot_keys, h->n_slots))) return st;
     if ((st = DevAlloc(&v.slot_vals, h->n_slots))) return st;
-    if ((st = DevAlloc(&v.slot_stamp, h->n_slots))) return st;
+    if ((st = DevAlloc(&v.slot_touch, h->n_slots))) return st;
     if ((st = DevAlloc(&v.heap, capacity))) return st;
     if ((st = DevAlloc(&v.counters, 4))) return st;
     if ((st = DevAlloc(&v.key_buffer, capacity * 3))) return st;
@@ -197,8 +197,9 @@ int AllocateStorage(o3dmi_hash* h, int64_t capacity, hipStream_t s) {
     }
     O3DMI_HIP_CHECK(hipMemsetAsync(v.key_buffer, 0,
                                    sizeof(int) * 3 * (size_t)capacity, s));
-    O3DMI_HIP_CHECK(hipMemsetAsync(v.slot_stamp, 0,
-                                   sizeof(int) * (size_t)h->n_slots, s));
+    O3DMI_HIP_CHECK(hipMemsetAsync(v.slot_touch, 0,
+                                   sizeof(unsigned long long) *
+                                           (size_t)h->n_slots, s));
     return O3DMI_OK;
 }
 
@@ -206,7 +207,7 @@ void FreeStorage(o3dmi_hash* h) {
     HashView& v = h->view;
     (void)hipFree(v.slot_keys);
     (void)hipFree(v.slot_vals);
-    (void)hipFree(v.slot_stamp);
+    (void)hipFree(v.slot_touch);
     (void)hipFree(v.heap);
     (void)hipFree(v.counters);
     (void)hipFree(v.key_buffer);

@@ -161,7 +161,7 @@ __host__ __device__ __forceinline__ unsigned HashKey(unsigned long long k) {
 struct HashView {
     unsigned long long* slot_keys;  // [n_slots] packed key / empty / tombstone
     int* slot_vals;                 // [n_slots] buffer index of the slot
-    int* slot_stamp;                // [n_slots] last frame that touched it
+    unsigned long long* slot_touch; // [n_slots] (touch stamp << 8) | frame bits
     int* heap;                      // [capacity] free buffer indices
     int* counters;                  // [0]=heap_top, [1]=error flags
     int* key_buffer;                // [capacity,3]
@@ -181,6 +181,25 @@ struct HashView {
         }
     }
 };
+
+// Marks `slot` as touched by frame `bit` of the frame group `stamp`. The word
+// holds (stamp << 8) | one bit per frame of the group; a word carrying an older
+// stamp is stale and is replaced. Returns true for exactly one caller per
+// (slot, stamp): the one that moved the word to this stamp.
+__device__ __forceinline__ bool TouchSlot(const HashView& hv, unsigned slot,
+                                          unsigned long long stamp, int bit) {
+    unsigned long long* w = &hv.slot_touch[slot];
+    unsigned long long cur = *w;  // possibly stale; the CAS corrects it
+    while (true) {
+        const bool fresh = (cur >> 8) != stamp;
+        const unsigned long long want =
+                fresh ? ((stamp << 8) | (1ull << bit)) : (cur | (1ull << bit));
+        if (want == cur) return false;
+        const unsigned long long old = atomicCAS(w, cur, want);
+        if (old == cur) return fresh;
+        cur = old;
+    }
+}
 
 constexpr int kErrKeyRange = 1;
 constexpr int kErrCapacity = 2;

@@ -46,13 +46,13 @@ struct o3dmi_vbg {
     // Frame-stream fast path (stream_path.h): double-buffered prepared pixel
     // records and block lists, a ring of 4 device counters and a host-mapped
     // status word written by the integrate role.
-    PixelRec* recs[2] = {nullptr, nullptr};
+    PixelRec* recs[2][kMaxGroup] = {};
     int64_t recs_pixels = 0;
     FrameBlock* lists[2] = {nullptr, nullptr};
     int64_t lists_capacity = 0;
     int* ring_counters = nullptr;        // device int[4]
     volatile int* stream_status = nullptr;  // host-mapped int[4]
-    int64_t stream_seq = 0;              // frames issued on the fast path
+    int64_t stream_seq = 0;              // groups issued on the fast path
     int known_size = 0;                  // map size after frame `known_stamp`
     int known_stamp = 0;
     bool known_valid = false;            // false after any non-stream activation
@@ -61,6 +61,7 @@ struct o3dmi_vbg {
     bool profiling = false;
     std::vector<hipEvent_t> prof_events;  // 2 per frame, around the launch carrying the integrate work
     int prof_frames = 0, prof_max = 0, prof_stride = 1, prof_seen = 0;
+    int64_t prof_launch_frames = 0;  // frames carried by the bracketed launches
     int32_t* prof_counts = nullptr;  // device, one per frame
 
     int AttrIndex(const char* name) const {
@@ -230,7 +231,7 @@ int o3dmi_vbg_destroy(o3dmi_vbg_t* g) {
     if (g->size_host) (void)hipHostFree(g->size_host);
     if (g->size_event) (void)hipEventDestroy(g->size_event);
     for (int i = 0; i < 2; ++i) {
-        (void)hipFree(g->recs[i]);
+        for (int f = 0; f < kMaxGroup; ++f) (void)hipFree(g->recs[i][f]);
         (void)hipFree(g->lists[i]);
     }
     (void)hipFree(g->ring_counters);
@@ -417,6 +418,7 @@ static int IntegrateFrameGeneric(o3dmi_vbg_t* g, const void* depth_dev,
     if (prof) {
         O3DMI_HIP_CHECK(hipEventRecord(
                 g->prof_events[(size_t)g->prof_frames * 2 + 1], s));
+        g->prof_launch_frames += 1;
         g->prof_frames += 1;
     }
     return st;
@@ -426,25 +428,26 @@ static int IntegrateFrameGeneric(o3dmi_vbg_t* g, const void* depth_dev,
 // ---- frame-stream fast path ------------------------------------------------
 
 static int EnsureStreamBuffers(o3dmi_vbg* g, int rows, int cols,
-                               int64_t max_new) {
+                               int64_t list_cap) {
     const int64_t px = (int64_t)rows * cols;
     if (g->recs_pixels < px) {
-        for (int i = 0; i < 2; ++i) {
-            (void)hipFree(g->recs[i]);
-            g->recs[i] = nullptr;
-            O3DMI_HIP_CHECK(hipMalloc((void**)&g->recs[i],
-                                      sizeof(PixelRec) * (size_t)px));
-        }
+        for (int i = 0; i < 2; ++i)
+            for (int f = 0; f < kMaxGroup; ++f) {
+                (void)hipFree(g->recs[i][f]);
+                g->recs[i][f] = nullptr;
+                O3DMI_HIP_CHECK(hipMalloc((void**)&g->recs[i][f],
+                                          sizeof(PixelRec) * (size_t)px));
+            }
         g->recs_pixels = px;
     }
-    if (g->lists_capacity < max_new) {
+    if (g->lists_capacity < list_cap) {
         for (int i = 0; i < 2; ++i) {
             (void)hipFree(g->lists[i]);
             g->lists[i] = nullptr;
             O3DMI_HIP_CHECK(hipMalloc((void**)&g->lists[i],
-                                      sizeof(FrameBlock) * (size_t)max_new));
+                                      sizeof(FrameBlock) * (size_t)list_cap));
         }
-        g->lists_capacity = max_new;
+        g->lists_capacity = list_cap;
     }
     if (!g->ring_counters) {
         O3DMI_HIP_CHECK(hipMalloc((void**)&g->ring_counters, sizeof(int) * 4));
@@ -459,19 +462,23 @@ static int EnsureStreamBuffers(o3dmi_vbg* g, int rows, int cols,
     return O3DMI_OK;
 }
 
-// Reads the status word the integrate kernels publish ({map size, error
-// flags, frame block count, stamp}); never blocks.
+// Reads the status word the integrate roles publish ({map size, error flags,
+// group block count, stamp}); never blocks.
 static int PollStreamStatus(o3dmi_vbg* g) {
     const int stamp = __atomic_load_n((const int*)&g->stream_status[3],
                                       __ATOMIC_ACQUIRE);
     if (stamp != g->known_stamp && stamp != 0) {
-        g->known_size = g->stream_status[0];
+        const int size = g->stream_status[0];
         const int err = g->stream_status[1];
-        g->last_count = g->stream_status[2];
-        // Re-check the stamp: a newer frame may have overwritten the words.
+        const int count = g->stream_status[2];
+        // Re-check the stamp: a newer group may have overwritten the words.
         const int stamp2 = __atomic_load_n((const int*)&g->stream_status[3],
                                            __ATOMIC_ACQUIRE);
-        if (stamp2 == stamp) g->known_stamp = stamp;
+        if (stamp2 == stamp) {
+            g->known_size = size;
+            g->last_count = count;
+            g->known_stamp = stamp;
+        }
         if (err & kErrKeyRange) {
             SetLastError("block coordinate outside +-2^20");
             return O3DMI_ERR_KEY_RANGE;
@@ -485,79 +492,64 @@ static int PollStreamStatus(o3dmi_vbg* g) {
 }
 
 // HashMap::Activate's capacity policy (HashMap.cpp:166-176) for the fast
-// path: Reserve only when Size() + (most blocks the in-flight frames can
-// still create) exceeds the capacity. Waits for the in-flight integrate
-// kernels' status words only while that bound says a Reserve may be needed.
-static int StreamEnsureCapacity(o3dmi_vbg* g, int64_t max_new,
-                                hipStream_t front, hipStream_t integ) {
+// path, blocking form: Reserve when Size() + (most blocks the groups in flight
+// plus the next one can still create) exceeds the capacity. Only called while
+// the pipeline is drained (every issued front role has its integrate role
+// launched), so waiting for the newest status word cannot dead-lock.
+static int StreamEnsureCapacity(o3dmi_vbg* g, int64_t group_new,
+                                hipStream_t s) {
     int st = PollStreamStatus(g);
     if (st) return st;
     const int64_t capacity = o3dmi_hash_capacity(g->block_hashmap);
     auto bound = [&]() {
-        // frames issued after the one known_size reflects may each still
-        // create up to max_new blocks, and so may the frame about to start
         const int64_t unknown = (int64_t)g->frame_stamp - g->known_stamp;
-        return (int64_t)g->known_size + (unknown + 1) * max_new;
+        return (int64_t)g->known_size + (unknown + 1) * group_new;
     };
     if (!g->known_valid) {
-        // Something else activated blocks since the last fast-path frame (or
+        // Something else activated blocks since the last fast-path group (or
         // this is the first one): take the exact size from the map itself.
-        O3DMI_HIP_CHECK(hipStreamSynchronize(front));
-        if (integ != front) O3DMI_HIP_CHECK(hipStreamSynchronize(integ));
+        O3DMI_HIP_CHECK(hipStreamSynchronize(s));
         int64_t size = 0;
-        st = o3dmi_hash_size(g->block_hashmap, (o3dmi_stream_t)integ, &size);
+        st = o3dmi_hash_size(g->block_hashmap, (o3dmi_stream_t)s, &size);
         if (st) return st;
         g->known_size = (int)size;
         g->known_stamp = g->frame_stamp;
         g->known_valid = true;
     }
     if (bound() <= capacity) return O3DMI_OK;
-    // Spin (bounded) until the newest in-flight frame has reported.
-    for (int64_t spin = 0; spin < 2000000 && g->known_stamp != g->frame_stamp;
-         ++spin) {
-        st = PollStreamStatus(g);
+    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    int64_t size = 0;
+    st = o3dmi_hash_size(g->block_hashmap, (o3dmi_stream_t)s, &size);
+    if (st) return st;
+    g->known_size = (int)size;
+    g->known_stamp = g->frame_stamp;
+    if (size + group_new > capacity) {
+        const int64_t need = size + group_new;
+        const int64_t target = need > capacity * 2 ? need : capacity * 2;
+        st = o3dmi_hash_reserve(g->block_hashmap, target, (o3dmi_stream_t)s);
         if (st) return st;
-    }
-    if (g->known_stamp != g->frame_stamp || bound() > capacity) {
-        O3DMI_HIP_CHECK(hipStreamSynchronize(front));
-        if (integ != front) O3DMI_HIP_CHECK(hipStreamSynchronize(integ));
-        int64_t size = 0;
-        st = o3dmi_hash_size(g->block_hashmap, (o3dmi_stream_t)integ, &size);
-        if (st) return st;
-        g->known_size = (int)size;
-        g->known_stamp = g->frame_stamp;
-        if (size + max_new > capacity) {
-            const int64_t need = size + max_new;
-            const int64_t target = need > capacity * 2 ? need : capacity * 2;
-            st = o3dmi_hash_reserve(g->block_hashmap, target,
-                                    (o3dmi_stream_t)integ);
-            if (st) return st;
-            // The rehash is queued on `integ`; the front stream must not
-            // touch the new table before it is complete.
-            O3DMI_HIP_CHECK(hipStreamSynchronize(integ));
-        }
+        O3DMI_HIP_CHECK(hipStreamSynchronize(s));
     }
     return O3DMI_OK;
 }
 
-// Non-blocking form of the capacity policy: true when the map provably has
-// room for one more frame's worth of new blocks on top of every frame whose
-// front role is already issued.
-static bool StreamCapacityBoundOK(o3dmi_vbg* g, int64_t max_new) {
+// Non-blocking form: true when the map provably has room for one more group
+// on top of every group whose front roles are already issued.
+static bool StreamCapacityBoundOK(o3dmi_vbg* g, int64_t group_new) {
     if (!g->known_valid) return false;
     const int64_t capacity = o3dmi_hash_capacity(g->block_hashmap);
     // The host runs ahead of the GPU; when the bound fails only because too
-    // many issued frames have not reported their map size yet, give the
+    // many issued groups have not reported their map size yet, give the
     // status word a moment to catch up (each integrate role publishes it as
     // its first action) instead of draining the pipeline.
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         if (PollStreamStatus(g) != O3DMI_OK) return false;  // surfaced later
         const int64_t unknown = (int64_t)g->frame_stamp - g->known_stamp;
-        if ((int64_t)g->known_size + (unknown + 1) * max_new <= capacity)
+        if ((int64_t)g->known_size + (unknown + 1) * group_new <= capacity)
             return true;
         // Even a fully reported pipeline would not fit: a Reserve is due.
-        if ((int64_t)g->known_size + 2 * max_new > capacity) return false;
+        if ((int64_t)g->known_size + 2 * group_new > capacity) return false;
         if (unknown <= 1) return false;
         if (std::chrono::steady_clock::now() - t0 >
             std::chrono::microseconds(500))
@@ -576,75 +568,93 @@ struct StreamCommon {
     const double* depth_intrinsic;
     const double* color_intrinsic;
     float depth_scale, depth_max, trunc;
-    int64_t max_new;
+    int64_t frame_new;  // strict bound on blocks one frame can touch
     int grid_dtype;
     int ti, wi, ci;
+    bool with_color;
 };
 
-// Fills the front-role arguments of the next frame and advances the stamp.
-static void MakeFrontArgs(o3dmi_vbg* g, const StreamCommon& c,
-                          const StreamFrame& f, FrameFrontArgs* fa) {
-    const int64_t k = g->stream_seq;  // sequence number of this frame
-    const int par = (int)(k & 1);
+// A group of up to kMaxGroup consecutive frames whose front roles have been
+// (or are being) issued.
+struct StreamGroup {
+    int n = 0;
+    int64_t seq = 0;  // group sequence number (selects the scratch buffers)
+    int stamp = 0;    // touch / status stamp
+    const StreamFrame* frames = nullptr;
+};
+
+// Front-role arguments of the frames of a new group; advances the stamp.
+static StreamGroup MakeGroup(o3dmi_vbg* g, const StreamCommon& c,
+                             const StreamFrame* frames, int n,
+                             FrameFrontArgs* fa) {
+    StreamGroup grp;
+    grp.n = n;
+    grp.seq = g->stream_seq;
     g->frame_stamp += 1;
-    const bool with_color = f.color != nullptr && c.ci >= 0 &&
-                            (int64_t)c.color_rows * c.color_cols > 0;
-    fa->depth = (const uint16_t*)f.depth;
-    fa->color = with_color ? (const uint8_t*)f.color : nullptr;
-    fa->rows = c.depth_rows;
-    fa->cols = c.depth_cols;
-    fa->color_rows = c.color_rows;
-    fa->color_cols = c.color_cols;
-    fa->depth_intrinsic = c.depth_intrinsic;
-    fa->color_intrinsic = c.color_intrinsic ? c.color_intrinsic
-                                            : c.depth_intrinsic;
-    fa->extrinsic = f.extrinsic;
-    fa->resolution = (int)g->block_resolution;
-    fa->voxel_size = g->voxel_size;
-    fa->sdf_trunc = g->voxel_size * c.trunc;
-    fa->depth_scale = c.depth_scale;
-    fa->depth_max = c.depth_max;
-    fa->stride = 4;
-    fa->frame_stamp = g->frame_stamp;
-    fa->recs = g->recs[par];
-    fa->list = g->lists[par];
-    fa->list_capacity = g->lists_capacity;
-    fa->count = g->ring_counters + (k & 3);
+    grp.stamp = g->frame_stamp;
+    grp.frames = frames;
+    const int par = (int)(grp.seq & 1);
+    for (int f = 0; f < n; ++f) {
+        FrameFrontArgs& a = fa[f];
+        a.depth = (const uint16_t*)frames[f].depth;
+        a.color = c.with_color ? (const uint8_t*)frames[f].color : nullptr;
+        a.rows = c.depth_rows;
+        a.cols = c.depth_cols;
+        a.color_rows = c.color_rows;
+        a.color_cols = c.color_cols;
+        a.depth_intrinsic = c.depth_intrinsic;
+        a.color_intrinsic = c.color_intrinsic ? c.color_intrinsic
+                                              : c.depth_intrinsic;
+        a.extrinsic = frames[f].extrinsic;
+        a.resolution = (int)g->block_resolution;
+        a.voxel_size = g->voxel_size;
+        a.sdf_trunc = g->voxel_size * c.trunc;
+        a.depth_scale = c.depth_scale;
+        a.depth_max = c.depth_max;
+        a.stride = 4;
+        a.group_stamp = (unsigned long long)grp.stamp;
+        a.group_bit = f;
+        a.recs = g->recs[par][f];
+        a.list = g->lists[par];
+        a.list_capacity = g->lists_capacity;
+        a.count = g->ring_counters + (grp.seq & 3);
+    }
     g->stream_seq += 1;
     g->size_bound = o3dmi_hash_capacity(g->block_hashmap);  // generic path: re-read
+    return grp;
 }
 
-// Integrate-role arguments of the frame whose front role was issued with
-// sequence number `k` and stamp `stamp`.
 static void MakeIntegArgs(o3dmi_vbg* g, const StreamCommon& c,
-                          const StreamFrame& f, int64_t k, int stamp,
-                          bool prof, IntegrateStreamArgs* ia) {
-    const int par = (int)(k & 1);
-    const bool with_color = f.color != nullptr && c.ci >= 0 &&
-                            (int64_t)c.color_rows * c.color_cols > 0;
-    ia->recs = g->recs[par];
+                          const StreamGroup& grp, bool prof,
+                          IntegrateStreamArgs* ia) {
+    const int par = (int)(grp.seq & 1);
+    ia->n_frames = grp.n;
+    for (int f = 0; f < grp.n; ++f) {
+        ia->recs[f] = g->recs[par][f];
+        ia->extrinsic[f] = grp.frames[f].extrinsic;
+    }
     ia->rows = c.depth_rows;
     ia->cols = c.depth_cols;
-    ia->with_color = with_color;
+    ia->with_color = c.with_color;
     ia->list = g->lists[par];
-    ia->count = g->ring_counters + (k & 3);
+    ia->count = g->ring_counters + (grp.seq & 3);
     ia->list_capacity = g->lists_capacity;
     ia->grid_hint = g->last_count;
     ia->tsdf = (float*)o3dmi_hash_value_buffer(g->block_hashmap, c.ti);
     ia->weight = o3dmi_hash_value_buffer(g->block_hashmap, c.wi);
-    ia->color = with_color ? o3dmi_hash_value_buffer(g->block_hashmap, c.ci)
-                           : nullptr;
+    ia->color = c.with_color ? o3dmi_hash_value_buffer(g->block_hashmap, c.ci)
+                             : nullptr;
     ia->grid_dtype = c.grid_dtype;
     ia->depth_intrinsic = c.depth_intrinsic;
-    ia->extrinsic = f.extrinsic;
     ia->resolution = (int)g->block_resolution;
     ia->voxel_size = g->voxel_size;
     ia->sdf_trunc = g->voxel_size * c.trunc;
     ia->depth_max = c.depth_max;
-    ia->zero_counter = g->ring_counters + ((k + 2) & 3);
+    ia->zero_counter = g->ring_counters + ((grp.seq + 2) & 3);
     ia->size_host = (int*)g->stream_status;
-    ia->frame_stamp = stamp;
-    ia->prof_count = prof ? g->prof_counts + g->prof_frames : nullptr;
+    ia->status_stamp = grp.stamp;
+    ia->prof_count = nullptr;
+    ia->prof_frame_blocks = prof ? g->prof_counts + g->prof_frames : nullptr;
 }
 
 static bool StreamPathApplies(const o3dmi_vbg* g, int input_dtype) {
@@ -653,68 +663,89 @@ static bool StreamPathApplies(const o3dmi_vbg* g, int input_dtype) {
            ti >= 0 && wi >= 0 && g->attr_dtypes[(size_t)ti] == O3DMI_F32;
 }
 
-// Integrates frames[0..n) strictly in order on stream `s`. With `pipelined`
-// the front role of frame f+1 shares the launch of frame f's integrate role
-// whenever the capacity bound allows it without waiting.
+// Integrates frames[0..n) strictly in order on stream `s`, `group` frames per
+// integrate launch. The front roles of group k+1 share the launch of group
+// k's integrate role whenever the capacity bound allows it without waiting.
 static int StreamIntegrate(o3dmi_vbg* g, const StreamCommon& c0,
-                           const StreamFrame* frames, int n, bool pipelined,
+                           const StreamFrame* frames, int n, int group,
                            hipStream_t s) {
     StreamCommon c = c0;
-    c.max_new = (int64_t)(c.depth_cols / 4) * (c.depth_rows / 4) * 4;
-    O3DMI_REQUIRE(c.max_new > 0, "depth image too small");
+    if (group < 1) group = 1;
+    if (group > kMaxGroup) group = kMaxGroup;
+    c.frame_new = FrustumBlockBound(
+            c.depth_intrinsic, c.depth_rows, c.depth_cols, c.depth_max,
+            g->voxel_size * (float)g->block_resolution, 4);
+    O3DMI_REQUIRE(c.frame_new > 0, "depth image too small");
+    const int64_t group_new = c.frame_new * group;
     c.ti = g->AttrIndex("tsdf");
     c.wi = g->AttrIndex("weight");
     c.ci = g->AttrIndex("color");
+    c.with_color = c.ci >= 0 && (int64_t)c.color_rows * c.color_cols > 0 &&
+                   n > 0 && frames[0].color != nullptr;
     int st = GridDtype(g, &c.grid_dtype);
     if (st) return st;
-    if ((st = EnsureStreamBuffers(g, c.depth_rows, c.depth_cols, c.max_new)))
+    if ((st = EnsureStreamBuffers(g, c.depth_rows, c.depth_cols,
+                                  c.frame_new * kMaxGroup)))
         return st;
 
-    bool front_issued = false;  // front role of frame f already in flight
-    int64_t cur_seq = 0;
-    int cur_stamp = 0;
-    for (int f = 0; f < n; ++f) {
-        if (!front_issued) {
-            // Pipeline is drained: every issued front has its integrate
-            // launched, so the blocking form of the policy cannot dead-lock.
-            if ((st = StreamEnsureCapacity(g, c.max_new, s, s))) return st;
-            FrameFrontArgs fa;
-            cur_seq = g->stream_seq;
-            MakeFrontArgs(g, c, frames[f], &fa);
-            cur_stamp = fa.frame_stamp;
-            if ((st = LaunchFrameStep(g->block_hashmap, &fa, nullptr, s)))
+    bool issued = false;  // front roles of `cur` already in flight
+    StreamGroup cur;
+    FrameFrontArgs fa[kMaxGroup];
+    int f = 0;
+    while (f < n) {
+        if (!issued) {
+            if ((st = StreamEnsureCapacity(g, group_new, s))) return st;
+            const int m = n - f < group ? n - f : group;
+            cur = MakeGroup(g, c, frames + f, m, fa);
+            if ((st = LaunchFrameStep(g->block_hashmap, fa, m, nullptr, s)))
                 return st;
         }
+        const int next_f = f + cur.n;
         const bool prof = g->profiling && g->prof_frames < g->prof_max &&
                           g->prof_stride > 0 &&
                           (g->prof_seen++ % g->prof_stride) == 0;
         hipEvent_t* pe = prof ? &g->prof_events[(size_t)g->prof_frames * 2]
                               : nullptr;
         IntegrateStreamArgs ia;
-        MakeIntegArgs(g, c, frames[f], cur_seq, cur_stamp, prof, &ia);
-        FrameFrontArgs fa;
-        const bool fuse = pipelined && f + 1 < n &&
-                          StreamCapacityBoundOK(g, c.max_new);
-        int64_t next_seq = 0;
+        MakeIntegArgs(g, c, cur, prof, &ia);
+        StreamGroup nxt;
+        const bool fuse = next_f < n && StreamCapacityBoundOK(g, group_new);
+        int m = 0;
         if (fuse) {
-            next_seq = g->stream_seq;
-            MakeFrontArgs(g, c, frames[f + 1], &fa);
+            m = n - next_f < group ? n - next_f : group;
+            nxt = MakeGroup(g, c, frames + next_f, m, fa);
         }
         if (pe) O3DMI_HIP_CHECK(hipEventRecord(pe[0], s));
-        if ((st = LaunchFrameStep(g->block_hashmap, fuse ? &fa : nullptr, &ia,
-                                  s)))
+        if ((st = LaunchFrameStep(g->block_hashmap, fuse ? fa : nullptr, m,
+                                  &ia, s)))
             return st;
         if (pe) {
             O3DMI_HIP_CHECK(hipEventRecord(pe[1], s));
+            g->prof_launch_frames += cur.n;
             g->prof_frames += 1;
         }
-        front_issued = fuse;
-        if (fuse) {
-            cur_seq = next_seq;
-            cur_stamp = fa.frame_stamp;
-        }
+        issued = fuse;
+        if (fuse) cur = nxt;
+        f = next_f;
     }
     return O3DMI_OK;
+}
+
+static StreamCommon MakeCommon(int depth_rows, int depth_cols, int color_rows,
+                               int color_cols, const double* depth_intrinsic,
+                               const double* color_intrinsic, float depth_scale,
+                               float depth_max, float trunc) {
+    StreamCommon c = {};
+    c.depth_rows = depth_rows;
+    c.depth_cols = depth_cols;
+    c.color_rows = color_rows;
+    c.color_cols = color_cols;
+    c.depth_intrinsic = depth_intrinsic;
+    c.color_intrinsic = color_intrinsic;
+    c.depth_scale = depth_scale;
+    c.depth_max = depth_max;
+    c.trunc = trunc;
+    return c;
 }
 
 int o3dmi_vbg_integrate_frame(o3dmi_vbg_t* g, const void* depth_dev,
@@ -734,18 +765,11 @@ int o3dmi_vbg_integrate_frame(o3dmi_vbg_t* g, const void* depth_dev,
                                      input_dtype, depth_intrinsic,
                                      color_intrinsic, extrinsic, depth_scale,
                                      depth_max, trunc_voxel_multiplier, stream);
-    StreamCommon c = {};
-    c.depth_rows = depth_rows;
-    c.depth_cols = depth_cols;
-    c.color_rows = color_rows;
-    c.color_cols = color_cols;
-    c.depth_intrinsic = depth_intrinsic;
-    c.color_intrinsic = color_intrinsic;
-    c.depth_scale = depth_scale;
-    c.depth_max = depth_max;
-    c.trunc = trunc_voxel_multiplier;
+    StreamCommon c = MakeCommon(depth_rows, depth_cols, color_rows, color_cols,
+                                depth_intrinsic, color_intrinsic, depth_scale,
+                                depth_max, trunc_voxel_multiplier);
     StreamFrame fr = {depth_dev, color_dev, extrinsic};
-    return StreamIntegrate(g, c, &fr, 1, false, (hipStream_t)stream);
+    return StreamIntegrate(g, c, &fr, 1, 1, (hipStream_t)stream);
 }
 
 int o3dmi_vbg_integrate_frames(o3dmi_vbg_t* g, int n_frames,
@@ -756,7 +780,7 @@ int o3dmi_vbg_integrate_frames(o3dmi_vbg_t* g, int n_frames,
                                const double* color_intrinsic,
                                const double* extrinsics, float depth_scale,
                                float depth_max, float trunc_voxel_multiplier,
-                               int overlap, o3dmi_stream_t stream) {
+                               int frames_per_launch, o3dmi_stream_t stream) {
     O3DMI_REQUIRE(g && depth_devs && depth_intrinsic && extrinsics &&
                           n_frames >= 0,
                   "null argument");
@@ -772,23 +796,18 @@ int o3dmi_vbg_integrate_frames(o3dmi_vbg_t* g, int n_frames,
         }
         return O3DMI_OK;
     }
-    StreamCommon c = {};
-    c.depth_rows = depth_rows;
-    c.depth_cols = depth_cols;
-    c.color_rows = color_rows;
-    c.color_cols = color_cols;
-    c.depth_intrinsic = depth_intrinsic;
-    c.color_intrinsic = color_intrinsic;
-    c.depth_scale = depth_scale;
-    c.depth_max = depth_max;
-    c.trunc = trunc_voxel_multiplier;
+    StreamCommon c = MakeCommon(depth_rows, depth_cols, color_rows, color_cols,
+                                depth_intrinsic, color_intrinsic, depth_scale,
+                                depth_max, trunc_voxel_multiplier);
     std::vector<StreamFrame> frames((size_t)n_frames);
     for (int f = 0; f < n_frames; ++f) {
         frames[(size_t)f].depth = depth_devs[f];
         frames[(size_t)f].color = color_devs ? color_devs[f] : nullptr;
         frames[(size_t)f].extrinsic = extrinsics + 16 * (size_t)f;
     }
-    return StreamIntegrate(g, c, frames.data(), n_frames, overlap != 0,
+    return StreamIntegrate(g, c, frames.data(), n_frames,
+                           frames_per_launch <= 0 ? kMaxGroup
+                                                  : frames_per_launch,
                            (hipStream_t)stream);
 }
 
@@ -845,26 +864,29 @@ int o3dmi_vbg_profile_begin(o3dmi_vbg_t* g, int max_frames, int stride) {
         O3DMI_HIP_CHECK(hipEventCreate(&e));
         g->prof_events.push_back(e);
     }
-    if (g->prof_max < max_frames) {
+    if (g->prof_max < max_frames || !g->prof_counts) {
         (void)hipFree(g->prof_counts);
         g->prof_counts = nullptr;
         O3DMI_HIP_CHECK(hipMalloc((void**)&g->prof_counts,
                                   sizeof(int32_t) * (size_t)max_frames));
     }
+    O3DMI_HIP_CHECK(hipMemset(g->prof_counts, 0,
+                              sizeof(int32_t) * (size_t)max_frames));
     g->prof_max = max_frames;
     g->prof_frames = 0;
+    g->prof_launch_frames = 0;
     g->profiling = true;
     return O3DMI_OK;
 }
 
 int o3dmi_vbg_profile_end(o3dmi_vbg_t* g, o3dmi_stream_t stream,
-                          double* integrate_ms, double* touch_ms,
-                          int64_t* launches, int64_t* block_frames) {
-    O3DMI_REQUIRE(g && integrate_ms && touch_ms && launches && block_frames,
+                          double* integrate_ms, int64_t* launches,
+                          int64_t* block_frames, int64_t* frames) {
+    O3DMI_REQUIRE(g && integrate_ms && launches && block_frames && frames,
                   "null argument");
     g->profiling = false;
     O3DMI_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-    double ti = 0, tt = 0;  // touch time is no longer bracketed separately
+    double ti = 0;
     for (int f = 0; f < g->prof_frames; ++f) {
         float ms = 0;
         O3DMI_HIP_CHECK(hipEventElapsedTime(
@@ -880,9 +902,9 @@ int o3dmi_vbg_profile_end(o3dmi_vbg_t* g, o3dmi_stream_t stream,
     int64_t bf = 0;
     for (int32_t c : counts) bf += c;
     *integrate_ms = ti;
-    *touch_ms = tt;
     *launches = g->prof_frames;
     *block_frames = bf;
+    *frames = g->prof_launch_frames;
     return O3DMI_OK;
 }
 

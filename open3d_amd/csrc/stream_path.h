@@ -24,7 +24,16 @@
 
 namespace o3dmi {
 
-// One entry of a frame's block list: hash slot + block key.
+// Frames are processed in groups of up to kMaxGroup consecutive frames: the
+// integrate role applies the frames of a group one after the other to a block
+// whose voxel state stays in registers, so that state is read and written
+// once per group instead of once per frame. Frame order inside the group is
+// preserved and a block only receives the frames that touched it (per-slot
+// frame bits, TouchSlot), so the result is identical to frame-by-frame
+// integration.
+constexpr int kMaxGroup = 4;
+
+// One entry of a group's block list: hash slot + block key.
 struct alignas(16) FrameBlock {
     int slot, x, y, z;
 };
@@ -35,6 +44,7 @@ struct alignas(8) PixelRec {
     unsigned rgba;  // r | g<<8 | b<<16 | (colour pixel in bounds)<<24
 };
 
+// Front role of ONE frame.
 struct FrameFrontArgs {
     const uint16_t* depth;  // {rows, cols}
     const uint8_t* color;   // {color_rows, color_cols, 3} or null
@@ -45,15 +55,19 @@ struct FrameFrontArgs {
     int resolution;
     float voxel_size, sdf_trunc, depth_scale, depth_max;
     int stride;
-    int frame_stamp;
+    unsigned long long group_stamp;  // > 0, increases per group
+    int group_bit;                   // index of this frame in its group
     PixelRec* recs;       // {rows, cols} out
-    FrameBlock* list;     // out
+    FrameBlock* list;     // the group's list (shared by its frames)
     int64_t list_capacity;
-    int* count;           // device, must be 0 on entry
+    int* count;           // the group's count; 0 before the group's first frame
 };
 
+// Integrate role of ONE group.
 struct IntegrateStreamArgs {
-    const PixelRec* recs;
+    int n_frames;                          // 1..kMaxGroup
+    const PixelRec* recs[kMaxGroup];
+    const double* extrinsic[kMaxGroup];    // host 4x4 each
     int rows, cols;
     bool with_color;
     const FrameBlock* list;
@@ -65,22 +79,32 @@ struct IntegrateStreamArgs {
     void* color;          // may be null
     int grid_dtype;       // O3DMI_U16 | O3DMI_F32
     const double* depth_intrinsic;
-    const double* extrinsic;
     int resolution;
     float voxel_size, sdf_trunc, depth_max;
     // bookkeeping done by workgroup 0 (any may be null):
-    int* zero_counter;    // device int reset to 0 (a future frame's count)
+    int* zero_counter;    // device int reset to 0 (a future group's count)
     int* size_host;       // host-mapped {heap_top, error flags, count, stamp}
-    int frame_stamp;
+    int status_stamp;     // value published in size_host[3]
     int* prof_count;      // device int receiving the live count
+    int* prof_frame_blocks;  // device int receiving sum over blocks of
+                             // popcount(frame bits) = block-frames integrated
 };
 
-// One launch running either role or both. With both, the workgroups of the
-// front role (frame k+1) are dispatched first and overlap the integrate role
-// (frame k) inside the same kernel: the two touch disjoint scratch (double
-// buffered lists / records / counters) and the hash map tolerates concurrent
-// insertion of new keys next to lookups of existing ones.
-int LaunchFrameStep(o3dmi_hash* block_hash, const FrameFrontArgs* front,
-                    const IntegrateStreamArgs* integ, hipStream_t s);
+// One launch running the front roles of up to kMaxGroup frames and / or the
+// integrate role of one group. The workgroups of the front roles are
+// dispatched first and overlap the integrate role inside the same kernel: the
+// two touch disjoint scratch (double-buffered lists / records / counters) and
+// the hash map tolerates concurrent insertion of new keys next to lookups of
+// existing ones.
+int LaunchFrameStep(o3dmi_hash* block_hash, const FrameFrontArgs* fronts,
+                    int n_fronts, const IntegrateStreamArgs* integ,
+                    hipStream_t s);
+
+// Strict upper bound on the number of distinct blocks one depth frame can
+// touch: every touched block lies inside the viewing pyramid (z-depth <=
+// depth_max) dilated by one block diagonal, so their count is at most that
+// volume / block volume (and at most 4 per ray).
+int64_t FrustumBlockBound(const double* intrinsic, int rows, int cols,
+                          float depth_max, float block_size, int stride);
 
 }  // namespace o3dmi

@@ -6,13 +6,15 @@
 //                      + the per-pixel part of IntegrateCPU's lambda
 //                        (t/geometry/kernel/VoxelBlockGridImpl.h:258-262,277-289)
 //   integrate role  <- the per-voxel part of IntegrateCPU's lambda
-//                        (VoxelBlockGridImpl.h:220-257,263-303)
+//                        (VoxelBlockGridImpl.h:220-257,263-303), applied for
+//                        each frame of a group in frame order
 //
-// FrameStepKernel runs the front role of frame k+1 and the integrate role of
-// frame k in ONE launch: the front role is a latency chain of hash atomics on
-// ~75 workgroups, the integrate role a bandwidth-bound sweep over ~4x10^3
-// work items; side by side they cost max() instead of sum() and a frame costs
-// a single kernel launch.
+// FrameStepKernel runs the front roles of group g+1 and the integrate role of
+// group g in ONE launch: the front role is a latency chain of hash atomics on
+// ~75 workgroups per frame, the integrate role a bandwidth-bound sweep over
+// ~4x10^3 work items; side by side they cost max() instead of sum().
+
+#include <cmath>
 
 #include "common.h"
 #include "stream_path.h"
@@ -26,11 +28,6 @@ struct alignas(A) Vec {
     T v[N];
 };
 
-// Frame-stream front end (stream_path.h). Workgroups [0, n_touch_wg) run the
-// fused touch+activate of TouchActivateKernel, emitting {slot, key} entries;
-// the remaining workgroups run the per-pixel prepare pass. The two roles share
-// one launch so that the latency-bound hash work (75 workgroups at VGA) and the
-// streaming prepare pass (all other CUs) overlap.
 struct PrepParams {
     Camera color_cam;  // colour intrinsics, identity extrinsic, scale 1
     int color_rows, color_cols;
@@ -38,7 +35,6 @@ struct PrepParams {
 };
 
 struct FrontParams {
-    HashView hv;
     TouchParams p;
     PrepParams pp;
     const uint16_t* depth;
@@ -47,23 +43,23 @@ struct FrontParams {
     FrameBlock* list;
     int64_t list_capacity;
     int* out_count;
-    int frame_stamp;
+    unsigned long long group_stamp;
+    int group_bit;
     int n_touch_wg, n_prep_wg;
 };
 
-// `wg` = index of this workgroup within the front role, [0, n_touch_wg +
-// n_prep_wg).
-__device__ __forceinline__ void FrontRole(const FrontParams& fp, int wg) {
-    const HashView& hv = fp.hv;
+// `wg` = index of this workgroup within one frame's front role,
+// [0, n_touch_wg + n_prep_wg). Workgroups [0, n_touch_wg) run the fused
+// touch + activate, emitting {slot, key} entries for blocks not yet listed in
+// this group; the rest run the per-pixel prepare pass.
+__device__ __forceinline__ void FrontRole(const HashView& hv,
+                                          const FrontParams& fp, int wg) {
     const TouchParams& p = fp.p;
     const PrepParams& pp = fp.pp;
     const uint16_t* __restrict__ depth = fp.depth;
     const uint8_t* __restrict__ color = fp.color;
     PixelRec* __restrict__ recs = fp.recs;
     FrameBlock* __restrict__ list = fp.list;
-    const int64_t list_capacity = fp.list_capacity;
-    int* __restrict__ out_count = fp.out_count;
-    const int frame_stamp = fp.frame_stamp;
     const int n_touch_wg = fp.n_touch_wg;
     if (wg < n_touch_wg) {
         int n = p.rows_strided * p.cols_strided;
@@ -86,10 +82,9 @@ __device__ __forceinline__ void FrontRole(const FrontParams& fp, int wg) {
                 if (WaveLeaderForKey(k, ok)) {
                     unsigned slot;
                     InsertKey<true>(hv, xb[s], yb[s], zb[s], slot);
-                    int old = atomicExch(&hv.slot_stamp[slot], frame_stamp);
-                    if (old != frame_stamp) {
-                        int o = atomicAdd(out_count, 1);
-                        if (o < list_capacity) {
+                    if (TouchSlot(hv, slot, fp.group_stamp, fp.group_bit)) {
+                        int o = atomicAdd(fp.out_count, 1);
+                        if (o < fp.list_capacity) {
                             FrameBlock fb;
                             fb.slot = (int)slot;
                             fb.x = xb[s];
@@ -109,8 +104,8 @@ __device__ __forceinline__ void FrontRole(const FrontParams& fp, int wg) {
     // lambda (VoxelBlockGridImpl.h:258-262 depth, :277-289 colour pixel).
     const int n_px = p.rows * p.cols;
     const int n_wg = fp.n_prep_wg;
-    for (int i = (wg - n_touch_wg) * blockDim.x + threadIdx.x;
-         i < n_px; i += n_wg * blockDim.x) {
+    for (int i = (wg - n_touch_wg) * blockDim.x + threadIdx.x; i < n_px;
+         i += n_wg * blockDim.x) {
         const int vi = i / p.cols;
         const int ui = i - vi * p.cols;
         PixelRec r;
@@ -133,91 +128,86 @@ __device__ __forceinline__ void FrontRole(const FrontParams& fp, int wg) {
     }
 }
 
-// ---- frame-stream kernel (stream_path.h) -----------------------------------
-// Work item = (block of the frame's list, 256-quad part of that block); the
-// grid strides over items so that a frame's ~10^3 blocks spread as ~4x10^3
-// workgroups over the 256 CUs. Depth and colour come from the prepared
-// PixelRec image (one 8-byte gather per voxel).
-struct StreamParams {
-    Camera cam;  // depth intrinsics + extrinsic, scale = voxel_size
+// ---- integrate role ---------------------------------------------------------
+// Work item = (block of the group's list, 256-quad part of that block); the
+// role strides over items so that a group's ~10^3 blocks spread as ~4x10^3
+// workgroups over the 256 CUs. A lane owns 4 x-consecutive voxels: tsdf moves
+// as one 16-byte access, u16 weight as 8 bytes, u16 colour as 24 bytes. Depth
+// and colour come from the prepared PixelRec images (one 8-byte gather per
+// voxel and frame).
+struct IntegParams {
+    Camera cam[kMaxGroup];  // depth intrinsics + extrinsic, scale = voxel_size
+    const PixelRec* recs[kMaxGroup];
+    int n_frames;
     int rows, cols, resolution;
     float sdf_trunc, depth_max;
-};
-
-struct IntegParams {
-    StreamParams p;
-    const PixelRec* recs;
     const FrameBlock* list;
     const int* count;
     int64_t list_capacity;
-    const int* slot_vals;
-    const int* hash_counters;
     float* tsdf;
     void* weight;
     void* color;
     int* zero_counter;
     int* size_host;
-    int frame_stamp;
+    int status_stamp;
     int* prof_count;
+    int* prof_frame_blocks;
 };
 
-// `wg` / `n_wg` = index of this workgroup within the integrate role and the
-// number of workgroups the role was given.
 template <typename weight_t, typename color_t, bool kColor>
-__device__ __forceinline__ void IntegrateRole(const IntegParams& ip, int wg,
+__device__ __forceinline__ void IntegrateRole(const HashView& hv,
+                                              const IntegParams& ip, int wg,
                                               int n_wg) {
-    const StreamParams& p = ip.p;
-    const PixelRec* __restrict__ recs = ip.recs;
-    const FrameBlock* __restrict__ list = ip.list;
-    const int* __restrict__ count = ip.count;
-    const int64_t list_capacity = ip.list_capacity;
-    const int* __restrict__ slot_vals = ip.slot_vals;
-    const int* __restrict__ hash_counters = ip.hash_counters;
-    float* __restrict__ tsdf_base = ip.tsdf;
-    weight_t* __restrict__ weight_base = (weight_t*)ip.weight;
-    color_t* __restrict__ color_base = (color_t*)ip.color;
-    int* __restrict__ zero_counter = ip.zero_counter;
-    int* __restrict__ size_host = ip.size_host;
-    const int frame_stamp = ip.frame_stamp;
-    int* __restrict__ prof_count = ip.prof_count;
     using TVec = Vec<float, 4, 16>;
     using WVec = Vec<weight_t, 4, 4 * sizeof(weight_t)>;
     using CVec = Vec<color_t, 12, 4 * sizeof(color_t)>;
-    int64_t n_blocks = *count;
-    if (n_blocks > list_capacity) n_blocks = list_capacity;
+    float* __restrict__ tsdf_base = ip.tsdf;
+    weight_t* __restrict__ weight_base = (weight_t*)ip.weight;
+    color_t* __restrict__ color_base = (color_t*)ip.color;
+    const FrameBlock* __restrict__ list = ip.list;
+    int64_t n_blocks = *ip.count;
+    if (n_blocks > ip.list_capacity) n_blocks = ip.list_capacity;
 
     if (wg == 0 && threadIdx.x == 0) {
-        if (zero_counter) *zero_counter = 0;
-        if (prof_count) *prof_count = (int)n_blocks;
-        if (size_host) {
-            // The touch kernel of this frame has completed (stream order), so
-            // heap_top is the exact map size after this frame's activation.
-            size_host[0] = hash_counters[0];
-            size_host[1] = hash_counters[1];
-            size_host[2] = (int)n_blocks;
-            __hip_atomic_store(&size_host[3], frame_stamp, __ATOMIC_RELEASE,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
+        if (ip.zero_counter) *ip.zero_counter = 0;
+        if (ip.prof_count) *ip.prof_count = (int)n_blocks;
+        if (ip.size_host) {
+            // The front roles of this group completed in an earlier launch,
+            // so heap_top is at least the map size after this group's
+            // activation (front roles of the next group may already be adding
+            // to it; the host only needs an upper bound).
+            ip.size_host[0] = hv.counters[0];
+            ip.size_host[1] = hv.counters[1];
+            ip.size_host[2] = (int)n_blocks;
+            __hip_atomic_store(&ip.size_host[3], ip.status_stamp,
+                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 
-    const int res = p.resolution;
+    const int res = ip.resolution;
     const int res3 = res * res * res;
     const int quads_per_row = res >> 2;
     const int n_quads = res3 >> 2;
     const int parts = (n_quads + 255) >> 8;
     const int64_t n_items = n_blocks * parts;
+    int frame_blocks = 0;  // lane 0 of part 0 counts block-frames
 
     for (int64_t item = wg; item < n_items; item += n_wg) {
         const int64_t b = item / parts;
         const int part = (int)(item - b * parts);
-        // Wave-uniform block header: {slot, key} -> buffer index.
+        // Wave-uniform block header: {slot, key} -> buffer index, frame bits.
         const FrameBlock fb = list[b];
         const int slot = __builtin_amdgcn_readfirstlane(fb.slot);
         const int xb = __builtin_amdgcn_readfirstlane(fb.x);
         const int yb = __builtin_amdgcn_readfirstlane(fb.y);
         const int zb = __builtin_amdgcn_readfirstlane(fb.z);
-        const int block_idx = __builtin_amdgcn_readfirstlane(slot_vals[slot]);
+        const int block_idx =
+                __builtin_amdgcn_readfirstlane(hv.slot_vals[slot]);
+        const unsigned bits = __builtin_amdgcn_readfirstlane(
+                (unsigned)(hv.slot_touch[slot] & 0xffull));
         const int64_t block_base = (int64_t)block_idx * res3;
+        if (part == 0 && threadIdx.x == 0 && ip.prof_frame_blocks)
+            frame_blocks += __popc(bits);
 
         const int q = (part << 8) + threadIdx.x;
         if (q >= n_quads) continue;
@@ -226,110 +216,164 @@ __device__ __forceinline__ void IntegrateRole(const IntegParams& ip, int wg,
         const int yv = row % res;
         const int zv = row / res;
         const int x0 = xb * res + (qx << 2);
-        const int y = yb * res + yv;
-        const int z = zb * res + zv;
+        const float fy = (float)(yb * res + yv);
+        const float fz = (float)(zb * res + zv);
         const int64_t lin0 = block_base + ((int64_t)q << 2);
 
-        // VoxelBlockGridImpl.h:244-267 with depth taken from the record.
-        float sdf[4];
-        unsigned rgba[4];
-        bool ok[4];
-        bool any = false;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float xc, yc, zc, u, v;
-            p.cam.RigidTransform((float)(x0 + j), (float)y, (float)z, xc, yc,
-                                 zc);
-            p.cam.Project(xc, yc, zc, u, v);
-            ok[j] = InBoundary2D(u, v, p.rows, p.cols);
-            sdf[j] = 0.f;
-            rgba[j] = 0u;
-            if (ok[j]) {
-                const int ui = (int)u;
-                const int vi = (int)v;
-                const PixelRec r = recs[(int64_t)vi * p.cols + ui];
-                const float d = r.d;
-                float sd = d - zc;
-                if (d <= 0 || d > p.depth_max || zc <= 0 || sd < -p.sdf_trunc) {
-                    ok[j] = false;
-                } else {
-                    sd = sd < p.sdf_trunc ? sd : p.sdf_trunc;
-                    sdf[j] = sd / p.sdf_trunc;
-                    rgba[j] = r.rgba;
-                }
-            }
-            any |= ok[j];
-        }
-        if (!any) continue;
-
-        TVec t4 = *reinterpret_cast<const TVec*>(tsdf_base + lin0);
-        WVec w4 = *reinterpret_cast<const WVec*>(weight_base + lin0);
+        TVec t4;
+        WVec w4;
         CVec c12;
-        if constexpr (kColor)
-            c12 = *reinterpret_cast<const CVec*>(color_base + 3 * lin0);
+        bool loaded = false;
+
+        for (int f = 0; f < ip.n_frames; ++f) {
+            if (!((bits >> f) & 1u)) continue;  // wave-uniform
+            const Camera& cam = ip.cam[f];
+            const PixelRec* __restrict__ recs = ip.recs[f];
+            // VoxelBlockGridImpl.h:244-267 with depth taken from the record.
+            float sdf[4];
+            unsigned rgba[4];
+            bool ok[4];
+            bool any = false;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (!ok[j]) continue;
-            // VoxelBlockGridImpl.h:269-302
-            float inv_wsum;
-            if constexpr (sizeof(weight_t) == 2)
-                inv_wsum = 1.0f / (float)((int)w4.v[j] + 1);
-            else
-                inv_wsum = 1.0f / (w4.v[j] + 1);
-            const float weight = (float)w4.v[j];
-            t4.v[j] = (weight * t4.v[j] + sdf[j]) * inv_wsum;
-            if constexpr (kColor) {
-                if (rgba[j] >> 24) {
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        const float in = (float)((rgba[j] >> (8 * i)) & 0xffu);
-                        // colour multiplier is 1 for uint8 input
-                        c12.v[3 * j + i] = (color_t)(
-                                (weight * (float)c12.v[3 * j + i] + in * 1.0f) *
-                                inv_wsum);
+            for (int j = 0; j < 4; ++j) {
+                float xc, yc, zc, u, v;
+                cam.RigidTransform((float)(x0 + j), fy, fz, xc, yc, zc);
+                cam.Project(xc, yc, zc, u, v);
+                ok[j] = InBoundary2D(u, v, ip.rows, ip.cols);
+                sdf[j] = 0.f;
+                rgba[j] = 0u;
+                if (ok[j]) {
+                    const int ui = (int)u;
+                    const int vi = (int)v;
+                    const PixelRec r = recs[(int64_t)vi * ip.cols + ui];
+                    const float d = r.d;
+                    float sd = d - zc;
+                    if (d <= 0 || d > ip.depth_max || zc <= 0 ||
+                        sd < -ip.sdf_trunc) {
+                        ok[j] = false;
+                    } else {
+                        sd = sd < ip.sdf_trunc ? sd : ip.sdf_trunc;
+                        sdf[j] = sd / ip.sdf_trunc;
+                        rgba[j] = r.rgba;
                     }
                 }
+                any |= ok[j];
             }
-            w4.v[j] = (weight_t)(weight + 1);
+            if (!any) continue;
+            if (!loaded) {
+                t4 = *reinterpret_cast<const TVec*>(tsdf_base + lin0);
+                w4 = *reinterpret_cast<const WVec*>(weight_base + lin0);
+                if constexpr (kColor)
+                    c12 = *reinterpret_cast<const CVec*>(color_base + 3 * lin0);
+                loaded = true;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!ok[j]) continue;
+                // VoxelBlockGridImpl.h:269-302
+                float inv_wsum;
+                if constexpr (sizeof(weight_t) == 2)
+                    inv_wsum = 1.0f / (float)((int)w4.v[j] + 1);
+                else
+                    inv_wsum = 1.0f / (w4.v[j] + 1);
+                const float weight = (float)w4.v[j];
+                t4.v[j] = (weight * t4.v[j] + sdf[j]) * inv_wsum;
+                if constexpr (kColor) {
+                    if (rgba[j] >> 24) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            // colour multiplier is 1 for uint8 input
+                            const float in =
+                                    (float)((rgba[j] >> (8 * i)) & 0xffu);
+                            c12.v[3 * j + i] = (color_t)(
+                                    (weight * (float)c12.v[3 * j + i] + in) *
+                                    inv_wsum);
+                        }
+                    }
+                }
+                w4.v[j] = (weight_t)(weight + 1);
+            }
         }
-        *reinterpret_cast<TVec*>(tsdf_base + lin0) = t4;
-        *reinterpret_cast<WVec*>(weight_base + lin0) = w4;
-        if constexpr (kColor)
-            *reinterpret_cast<CVec*>(color_base + 3 * lin0) = c12;
+        if (loaded) {
+            *reinterpret_cast<TVec*>(tsdf_base + lin0) = t4;
+            *reinterpret_cast<WVec*>(weight_base + lin0) = w4;
+            if constexpr (kColor)
+                *reinterpret_cast<CVec*>(color_base + 3 * lin0) = c12;
+        }
     }
+    if (frame_blocks) atomicAdd(ip.prof_frame_blocks, frame_blocks);
 }
 
+struct StepParams {
+    HashView hv;
+    FrontParams front[kMaxGroup];
+    IntegParams integ;
+    int n_fronts;
+    int front_wg;  // workgroups per front role
+};
 
 template <typename weight_t, typename color_t, bool kColor>
-__global__ void __launch_bounds__(256)
-FrameStepKernel(FrontParams fp, IntegParams ip, int n_front_wg) {
+__global__ void __launch_bounds__(256) FrameStepKernel(StepParams sp) {
     const int b = (int)blockIdx.x;
+    const int n_front_wg = sp.n_fronts * sp.front_wg;
     if (b < n_front_wg) {
-        FrontRole(fp, b);
+        const int f = b / sp.front_wg;
+        FrontRole(sp.hv, sp.front[f], b - f * sp.front_wg);
     } else {
-        IntegrateRole<weight_t, color_t, kColor>(ip, b - n_front_wg,
-                                                 (int)gridDim.x - n_front_wg);
+        IntegrateRole<weight_t, color_t, kColor>(
+                sp.hv, sp.integ, b - n_front_wg, (int)gridDim.x - n_front_wg);
     }
 }
 
 }  // namespace
 
-int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* f,
+int64_t FrustumBlockBound(const double* K, int rows, int cols, float depth_max,
+                          float block_size, int stride) {
+    const int64_t rays = (int64_t)(rows / stride) * (cols / stride);
+    const int64_t by_rays = rays * 4;
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    if (!(fx > 0) || !(fy > 0) || !(block_size > 0) || !(depth_max > 0))
+        return by_rays;
+    // |x| <= tx*z, |y| <= ty*z, 0 <= z <= depth_max contains every sample
+    // o + t*dir (dir.z = 1, t <= depth_max) in the camera frame.
+    const double tx = std::fmax(std::fabs(cx), std::fabs(cols - 1 - cx)) / fx;
+    const double ty = std::fmax(std::fabs(cy), std::fabs(rows - 1 - cy)) / fy;
+    const double r = std::sqrt(3.0) * block_size;  // block diagonal
+    const double sx = tx / std::sqrt(1 + tx * tx), sy = ty / std::sqrt(1 + ty * ty);
+    if (!(sx > 0) || !(sy > 0)) return by_rays;
+    // The r-dilation of the pyramid lies inside the pyramid with the same
+    // side slopes, apex moved back by a and far plane at depth_max + r.
+    const double a = r / std::fmin(sx, sy);
+    const double h = (double)depth_max + r + a;
+    const double vol = 4.0 / 3.0 * tx * ty * h * h * h;
+    const double nb = vol / ((double)block_size * block_size * block_size);
+    if (!(nb < 9e15)) return by_rays;
+    const int64_t by_volume = (int64_t)std::ceil(nb) + 1;
+    return by_volume < by_rays ? by_volume : by_rays;
+}
+
+int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
                     const IntegrateStreamArgs* a, hipStream_t s) {
-    O3DMI_REQUIRE(f || a, "nothing to launch");
-    FrontParams fp = {};
-    IntegParams ip = {};
-    int n_front_wg = 0, n_int_wg = 0;
+    O3DMI_REQUIRE((n_fronts > 0 && fronts) || a, "nothing to launch");
+    O3DMI_REQUIRE(n_fronts >= 0 && n_fronts <= kMaxGroup, "bad group size");
+    StepParams sp = {};
+    sp.hv = bh->view;
+    sp.n_fronts = n_fronts;
+    int n_int_wg = 0;
     int grid_dtype = O3DMI_U16;
     bool col = false;
-    if (f) {
-        fp.hv = bh->view;
+    static const double eye4[16] = {1, 0, 0, 0, 0, 1, 0, 0,
+                                    0, 0, 1, 0, 0, 0, 0, 1};
+    for (int i = 0; i < n_fronts; ++i) {
+        const FrameFrontArgs* f = &fronts[i];
+        FrontParams& fp = sp.front[i];
+        O3DMI_REQUIRE(f->group_bit >= 0 && f->group_bit < kMaxGroup &&
+                              f->group_stamp > 0,
+                      "bad group bit / stamp");
         fp.p = MakeTouchParams(f->depth_intrinsic, f->extrinsic, f->rows,
                                f->cols, f->stride, f->resolution,
                                f->voxel_size, f->sdf_trunc, f->depth_scale,
                                f->depth_max);
-        static const double eye4[16] = {1, 0, 0, 0, 0, 1, 0, 0,
-                                        0, 0, 1, 0, 0, 0, 0, 1};
         fp.pp.color_cam = Camera::Make(f->color_intrinsic ? f->color_intrinsic
                                                           : f->depth_intrinsic,
                                        eye4, 1.0f);
@@ -342,41 +386,51 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* f,
         fp.list = f->list;
         fp.list_capacity = f->list_capacity;
         fp.out_count = f->count;
-        fp.frame_stamp = f->frame_stamp;
+        fp.group_stamp = f->group_stamp;
+        fp.group_bit = f->group_bit;
         const int n_rays = fp.p.rows_strided * fp.p.cols_strided;
         fp.n_touch_wg = (n_rays + kBlock - 1) / kBlock;
         // 4 pixels per prepare lane
         fp.n_prep_wg = (f->rows * f->cols + kBlock * 4 - 1) / (kBlock * 4);
         if (fp.n_prep_wg < 1) fp.n_prep_wg = 1;
-        n_front_wg = fp.n_touch_wg + fp.n_prep_wg;
+        const int wg = fp.n_touch_wg + fp.n_prep_wg;
+        // all frames of a launch share the image size
+        O3DMI_REQUIRE(i == 0 || wg == sp.front_wg,
+                      "frames of one launch must share the image size");
+        sp.front_wg = wg;
     }
     if (a) {
         O3DMI_REQUIRE(a->resolution % 4 == 0,
                       "frame-stream path needs block_resolution % 4 == 0");
-        ip.p.cam = Camera::Make(a->depth_intrinsic, a->extrinsic,
-                                a->voxel_size);
-        ip.p.rows = a->rows;
-        ip.p.cols = a->cols;
-        ip.p.resolution = a->resolution;
-        ip.p.sdf_trunc = a->sdf_trunc;
-        ip.p.depth_max = a->depth_max;
-        ip.recs = a->recs;
+        O3DMI_REQUIRE(a->n_frames >= 1 && a->n_frames <= kMaxGroup,
+                      "bad group size");
+        IntegParams& ip = sp.integ;
+        ip.n_frames = a->n_frames;
+        for (int f = 0; f < a->n_frames; ++f) {
+            ip.cam[f] = Camera::Make(a->depth_intrinsic, a->extrinsic[f],
+                                     a->voxel_size);
+            ip.recs[f] = a->recs[f];
+        }
+        ip.rows = a->rows;
+        ip.cols = a->cols;
+        ip.resolution = a->resolution;
+        ip.sdf_trunc = a->sdf_trunc;
+        ip.depth_max = a->depth_max;
         ip.list = a->list;
         ip.count = a->count;
         ip.list_capacity = a->list_capacity;
-        ip.slot_vals = bh->view.slot_vals;
-        ip.hash_counters = bh->view.counters;
         ip.tsdf = a->tsdf;
         ip.weight = a->weight;
         ip.color = a->color;
         ip.zero_counter = a->zero_counter;
         ip.size_host = a->size_host;
-        ip.frame_stamp = a->frame_stamp;
+        ip.status_stamp = a->status_stamp;
         ip.prof_count = a->prof_count;
+        ip.prof_frame_blocks = a->prof_frame_blocks;
         const int n_quads =
                 (a->resolution * a->resolution * a->resolution) >> 2;
         const int parts = (n_quads + 255) >> 8;
-        // Grid from the expected block count (previous frame + slack); the
+        // Grid from the expected block count (previous group + slack); the
         // role strides, so an under-estimate only costs balance.
         int64_t g = ((int64_t)a->grid_hint + (a->grid_hint >> 2) + 64) * parts;
         const int64_t g_max = (int64_t)kCUs * 32;
@@ -386,10 +440,9 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* f,
         grid_dtype = a->grid_dtype;
         col = a->with_color && a->color != nullptr;
     }
-    dim3 grid((unsigned)(n_front_wg + n_int_wg)), block(256);
+    dim3 grid((unsigned)(n_fronts * sp.front_wg + n_int_wg)), block(256);
 #define O3DMI_LAUNCH_STEP(WT, VT, COLOR)                                      \
-    hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR>), grid, block, 0, s,   \
-                       fp, ip, n_front_wg)
+    hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR>), grid, block, 0, s, sp)
     if (grid_dtype == O3DMI_U16) {
         if (col) O3DMI_LAUNCH_STEP(uint16_t, uint16_t, true);
         else O3DMI_LAUNCH_STEP(uint16_t, uint16_t, false);

@@ -61,7 +61,7 @@ __global__ void DepthTouchKernel(HashView hv, TouchParams p,
 }
 
 // Fused: candidates -> find-or-create in the MAIN block hash -> first toucher
-// of a slot in this frame (slot_stamp exchange) appends the slot to the list.
+// of a slot in this frame (TouchSlot) appends the slot to the list.
 template <typename depth_t>
 __global__ void TouchActivateKernel(HashView hv, TouchParams p,
                                     const depth_t* __restrict__ depth,
@@ -89,8 +89,7 @@ __global__ void TouchActivateKernel(HashView hv, TouchParams p,
             if (WaveLeaderForKey(k, ok)) {
                 unsigned slot;
                 InsertKey<true>(hv, xb[s], yb[s], zb[s], slot);
-                int old = atomicExch(&hv.slot_stamp[slot], frame_stamp);
-                if (old != frame_stamp) {
+                if (TouchSlot(hv, slot, (unsigned long long)frame_stamp, 0)) {
                     int o = atomicAdd(out_count, 1);
                     if (o < out_capacity) out_slots[o] = (int)slot;
                     else atomicOr(&hv.counters[1], kErrCapacity);

@@ -201,9 +201,11 @@ class VoxelBlockGrid:
     def integrate_frames(self, depths, colors, depth_intrinsic,
                          color_intrinsic, extrinsics, depth_scale=1000.0,
                          depth_max=3.0, trunc_voxel_multiplier=8.0,
-                         overlap=True):
+                         frames_per_launch=0):
         """integrate_frame over a list of frames (same intrinsics / sizes),
-        strictly in order; one native call, kernels issued back to back."""
+        strictly in order, in one native call. frames_per_launch (1..4, 0 =
+        4) frames are applied per launch to each touched block while its
+        voxels stay in registers; results are identical for every value."""
         n = len(depths)
         if n == 0:
             return
@@ -226,7 +228,7 @@ class VoxelBlockGrid:
             self._g, n, dptr, rows, cols, cptr, crows, ccols,
             TORCH_TO_O3DMI[ds[0].dtype], _lib.f64p(Kd), _lib.f64p(Kc),
             _lib.f64p(Ts), C.c_float(depth_scale), C.c_float(depth_max),
-            C.c_float(trunc_voxel_multiplier), 1 if overlap else 0, stream()),
+            C.c_float(trunc_voxel_multiplier), int(frames_per_launch), stream()),
             "VoxelBlockGrid.integrate_frames")
 
     def profile_begin(self, max_frames, stride=1):
@@ -234,14 +236,15 @@ class VoxelBlockGrid:
             self._g, int(max_frames), int(stride)), "profile_begin")
 
     def profile_end(self):
-        """-> dict(integrate_ms, touch_ms, launches, block_frames)."""
-        ti, tt = C.c_double(0), C.c_double(0)
-        n, bf = C.c_int64(0), C.c_int64(0)
+        """-> dict(integrate_ms, launches, block_frames, frames) over the
+        bracketed launches."""
+        ti = C.c_double(0)
+        n, bf, fr = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         _lib.check(_lib.lib().o3dmi_vbg_profile_end(
-            self._g, stream(), C.byref(ti), C.byref(tt), C.byref(n),
-            C.byref(bf)), "profile_end")
-        return dict(integrate_ms=ti.value, touch_ms=tt.value,
-                    launches=n.value, block_frames=bf.value)
+            self._g, stream(), C.byref(ti), C.byref(n), C.byref(bf),
+            C.byref(fr)), "profile_end")
+        return dict(integrate_ms=ti.value, launches=n.value,
+                    block_frames=bf.value, frames=fr.value)
 
     def ray_cast(self, block_coords, intrinsic, extrinsic, width, height,
                  render_attributes=("depth", "color"), depth_scale=1000.0,

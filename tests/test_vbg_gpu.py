@@ -280,13 +280,14 @@ def test_frame_stream_fast_path_equals_two_step_path():
     assert gb.hashmap().capacity() > 512  # grew through Reserve
 
 
-@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("group", [1, 2, 3, 4])
 @pytest.mark.parametrize("grid_f32", [False, True])
-def test_frame_batch_equals_oracle(overlap, grid_f32):
-    """integrate_frames (one native call; with `overlap` the front kernel of
-    frame f+1 runs concurrently with the integrate kernel of frame f) vs the
-    oracle, bit-exact, 12 frames, Reserve forced by a small capacity, mixed
-    with a two-step-API frame in the middle (capacity bookkeeping hand-over)."""
+def test_frame_batch_equals_oracle(group, grid_f32):
+    """integrate_frames (one native call; `group` frames applied per launch to
+    register-resident blocks, next group's touch work in the same launch) vs
+    the frame-by-frame oracle, bit-exact, 12 frames, Reserve forced by a small
+    capacity, mixed with a two-step-API frame in the middle (capacity
+    bookkeeping hand-over)."""
     _lib, geometry = _gpu()
     g = _mk_grid(geometry, grid_f32, block_count=600)
     og = OracleGrid(grid_f32, 16384)
@@ -300,13 +301,13 @@ def test_frame_batch_equals_oracle(overlap, grid_f32):
     for i in range(len(ks)):
         og.integrate(ds[i], cs[i], K, Ts[i])
     g.integrate_frames(dt[:5], ct[:5], K, K, Ts[:5], sc.DEPTH_SCALE,
-                       sc.DEPTH_MAX, sc.TRUNC_MULT, overlap=overlap)
+                       sc.DEPTH_MAX, sc.TRUNC_MULT, frames_per_launch=group)
     keys = g.compute_unique_block_coordinates(dt[5], K, Ts[5], sc.DEPTH_SCALE,
                                               sc.DEPTH_MAX, sc.TRUNC_MULT)
     g.integrate(keys, dt[5], ct[5], K, K, Ts[5], sc.DEPTH_SCALE, sc.DEPTH_MAX,
                 sc.TRUNC_MULT)
     g.integrate_frames(dt[6:], ct[6:], K, K, Ts[6:], sc.DEPTH_SCALE,
-                       sc.DEPTH_MAX, sc.TRUNC_MULT, overlap=overlap)
+                       sc.DEPTH_MAX, sc.TRUNC_MULT, frames_per_launch=group)
     assert _compare_grids(og, g)[1]
     assert g.hashmap().capacity() > 600
 
