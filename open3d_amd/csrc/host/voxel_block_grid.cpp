@@ -11,6 +11,7 @@
 // (o3dmi_vbg_integrate_frame) issues kernels back to back.
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -709,7 +710,11 @@ static int StreamIntegrate(o3dmi_vbg* g, const StreamCommon& c0,
         IntegrateStreamArgs ia;
         MakeIntegArgs(g, c, cur, prof, &ia);
         StreamGroup nxt;
-        const bool fuse = next_f < n && StreamCapacityBoundOK(g, group_new);
+        // O3DMI_NO_FUSE=1 (diagnostics): front roles in their own launches so
+        // that a kernel trace shows the two roles separately.
+        static const bool no_fuse = std::getenv("O3DMI_NO_FUSE") != nullptr;
+        const bool fuse = !no_fuse && next_f < n &&
+                          StreamCapacityBoundOK(g, group_new);
         int m = 0;
         if (fuse) {
             m = n - next_f < group ? n - next_f : group;
