@@ -3,6 +3,7 @@
 Bars (BASELINE.json north_star): correspondence indices exact; pose within
 1e-6 rad / 1e-5 m of the CPU path."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -325,3 +326,22 @@ def test_multiscale_icp_pose_parity():
     assert abs(got.inlier_rmse - want["inlier_rmse"]) < 1e-6
     ang_gt, tr_gt = _pose_err(p["T_gt"], got.transformation)
     assert ang_gt < 2e-3 and tr_gt < 5e-3
+
+
+def test_icp_full_size_100k_pose_parity():
+    """BASELINE configs[0] size: 2 x 100k points, (1e-6, 1e-6, 30), 0.07."""
+    _lib, reg = _gpu()
+    p = _pair(100000, seed=0)
+    orc.set_threads(min(64, os.cpu_count() or 1))
+    want = orc.multiscale_icp(p["source"], p["target"], p["target_normals"],
+                              [-1.0], [(1e-6, 1e-6, 30)], [0.07],
+                              accumulate_double=True)
+    got = reg.icp(torch.from_numpy(p["source"]).cuda(),
+                  torch.from_numpy(p["target"]).cuda(),
+                  torch.from_numpy(p["target_normals"]).cuda(), 0.07,
+                  criteria=reg.ICPConvergenceCriteria(1e-6, 1e-6, 30))
+    ang, tr = _pose_err(want["transformation"], got.transformation)
+    assert ang <= 1e-6 and tr <= 1e-5, (ang, tr)
+    assert got.num_iterations == want["num_iterations"]
+    c = got.correspondence_set.cpu().numpy()
+    assert np.array_equal(c, want["correspondences"])
