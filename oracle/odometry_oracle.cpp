@@ -1,0 +1,994 @@
+// TEST INFRASTRUCTURE ONLY -- CPU restatement ("oracle") of the Open3D CPU
+// tensor path for RGB-D odometry: the depth image
+// pyramid ops, the three per-pixel Jacobians, the 29-value reductions, the
+// multi-scale driver. Nothing under oracle/ is shipped or measured as product.
+//
+// Follows (relative to /root/reference/cpp/open3d):
+//   t/geometry/kernel/ImageImpl.h:35-85     To (linear transform, saturate)
+//   t/geometry/kernel/ImageImpl.h:94-128    ClipTransform
+//   t/geometry/kernel/ImageImpl.h:132-206   PyrDownDepth
+//   t/geometry/kernel/ImageImpl.h:208-256   CreateVertexMap
+//   t/geometry/kernel/ImageImpl.h:257-322   CreateNormalMap
+//   t/geometry/Image.cpp:119-162            RGBToGray (in-tree tensor-op branch)
+//   t/geometry/Image.cpp:404-407            PyrDown = FilterGaussian(5,1) + Resize(0.5,Nearest)
+//   t/pipelines/kernel/RGBDOdometryJacobianImpl.h:29-343  Huber, Jacobians
+//   t/pipelines/kernel/RGBDOdometryCPU.cpp:26-364         reductions
+//   t/pipelines/odometry/RGBDOdometry.cpp:56-517          drivers
+//
+// Pinned bit for bit against the reference's own bodies (oracle/_ref,
+// tests/test_odometry_oracle.py) for everything that has in-tree arithmetic.
+//
+// PARITY UNPINNED (no in-tree arithmetic): FilterBilateral, FilterGaussian,
+// FilterSobel and Resize are Intel IPP calls on the reference's CPU path
+// (t/geometry/kernel/IPPImage.cpp:202-306,  t/geometry/Image.cpp:165-402; a
+// build without IPP throws). They are restated here from the published IPP
+// semantics and pinned to the reference's golden vectors for the IPP path
+// (cpp/tests/t/geometry/Image.cpp:239-326 bilateral, :328-400 gaussian,
+// :491-556 sobel, :558-592 resize nearest, :649-686 pyrdown) at the tests'
+// AllClose tolerance (rtol 1e-5); the summation order inside IPP is unknown.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "oracle_common.h"
+
+extern "C" {
+int orc_decode_and_solve6x6(const double* A29, double* pose, float* residual,
+                            int* count);
+void orc_pose_to_transformation(const double* pose, double* T);
+}
+
+namespace {
+
+using orc::InBoundary2D;
+using orc::TransformIndexer;
+
+// ---------------------------------------------------------------------------
+// Image ops with in-tree arithmetic
+// ---------------------------------------------------------------------------
+
+// ImageImpl.h:94-128
+template <typename S>
+void ClipTransform(const S* src, float* dst, int64_t rows, int64_t cols,
+                   float scale, float min_value, float max_value,
+                   float clip_fill) {
+    int64_t n = rows * cols;
+    for (int64_t i = 0; i < n; ++i) {
+        float in = static_cast<float>(src[i]);
+        float out = in / scale;
+        out = out <= min_value ? clip_fill : out;
+        out = out >= max_value ? clip_fill : out;
+        dst[i] = out;
+    }
+}
+
+// ImageImpl.h:132-206
+void PyrDownDepth(const float* src, float* dst, int rows, int cols,
+                  float depth_diff, float invalid_fill) {
+    int rows_down = rows / 2, cols_down = cols / 2;
+    const int gkernel_size_2 = 2;
+    const float gweights[3] = {0.375f, 0.25f, 0.0625f};
+    for (int y = 0; y < rows_down; ++y) {
+        for (int x = 0; x < cols_down; ++x) {
+            int y_src = 2 * y, x_src = 2 * x;
+            float v_center = src[(int64_t)y_src * cols + x_src];
+            float* out = &dst[(int64_t)y * cols_down + x];
+            if (v_center == invalid_fill) {
+                *out = invalid_fill;
+                continue;
+            }
+            int x_min = std::max(0, x_src - gkernel_size_2);
+            int y_min = std::max(0, y_src - gkernel_size_2);
+            int x_max = std::min(cols - 1, x_src + gkernel_size_2);
+            int y_max = std::min(rows - 1, y_src + gkernel_size_2);
+            float v_sum = 0, w_sum = 0;
+            for (int yk = y_min; yk <= y_max; ++yk) {
+                for (int xk = x_min; xk <= x_max; ++xk) {
+                    float v = src[(int64_t)yk * cols + xk];
+                    int dy = std::abs(yk - y_src);
+                    int dx = std::abs(xk - x_src);
+                    if (v != invalid_fill && std::abs(v - v_center) < depth_diff) {
+                        float w = gweights[dx] * gweights[dy];
+                        v_sum += w * v;
+                        w_sum += w;
+                    }
+                }
+            }
+            *out = w_sum == 0 ? invalid_fill : v_sum / w_sum;
+        }
+    }
+}
+
+inline bool IsInvalid(float v, float invalid_fill) {
+    if (std::isinf(invalid_fill)) return std::isinf(v);
+    if (std::isnan(invalid_fill)) return std::isnan(v);
+    return v == invalid_fill;
+}
+
+// ImageImpl.h:208-256 (extrinsic = identity)
+void CreateVertexMap(const float* src, float* dst, int64_t rows, int64_t cols,
+                     const double* K, float invalid_fill) {
+    const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    TransformIndexer ti(K, eye);
+    for (int64_t y = 0; y < rows; ++y) {
+        for (int64_t x = 0; x < cols; ++x) {
+            float d = src[y * cols + x];
+            float* vertex = &dst[(y * cols + x) * 3];
+            if (!IsInvalid(d, invalid_fill)) {
+                ti.Unproject(static_cast<float>(x), static_cast<float>(y), d,
+                             vertex + 0, vertex + 1, vertex + 2);
+            } else {
+                vertex[0] = invalid_fill;
+                vertex[1] = invalid_fill;
+                vertex[2] = invalid_fill;
+            }
+        }
+    }
+}
+
+// ImageImpl.h:257-322. Note the `== invalid_fill` tests: with invalid_fill =
+// NaN they are never true and NaNs simply propagate through the arithmetic.
+void CreateNormalMap(const float* src, float* dst, int64_t rows, int64_t cols,
+                     float invalid_fill) {
+    for (int64_t y = 0; y < rows; ++y) {
+        for (int64_t x = 0; x < cols; ++x) {
+            float* normal = &dst[(y * cols + x) * 3];
+            if (y < rows - 1 && x < cols - 1) {
+                const float* v00 = &src[(y * cols + x) * 3];
+                const float* v10 = &src[(y * cols + x + 1) * 3];
+                const float* v01 = &src[((y + 1) * cols + x) * 3];
+                if ((v00[0] == invalid_fill && v00[1] == invalid_fill &&
+                     v00[2] == invalid_fill) ||
+                    (v01[0] == invalid_fill && v01[1] == invalid_fill &&
+                     v01[2] == invalid_fill) ||
+                    (v10[0] == invalid_fill && v10[1] == invalid_fill &&
+                     v10[2] == invalid_fill)) {
+                    normal[0] = invalid_fill;
+                    normal[1] = invalid_fill;
+                    normal[2] = invalid_fill;
+                    continue;
+                }
+                float dx0 = v01[0] - v00[0];
+                float dy0 = v01[1] - v00[1];
+                float dz0 = v01[2] - v00[2];
+                float dx1 = v10[0] - v00[0];
+                float dy1 = v10[1] - v00[1];
+                float dz1 = v10[2] - v00[2];
+                normal[0] = dy0 * dz1 - dz0 * dy1;
+                normal[1] = dz0 * dx1 - dx0 * dz1;
+                normal[2] = dx0 * dy1 - dy0 * dx1;
+                constexpr float EPSILON = 1e-5f;
+                float normal_norm =
+                        std::sqrt(normal[0] * normal[0] + normal[1] * normal[1] +
+                                  normal[2] * normal[2]);
+                normal_norm = std::max(normal_norm, EPSILON);
+                normal[0] /= normal_norm;
+                normal[1] /= normal_norm;
+                normal[2] /= normal_norm;
+            } else {
+                normal[0] = invalid_fill;
+                normal[1] = invalid_fill;
+                normal[2] = invalid_fill;
+            }
+        }
+    }
+}
+
+// ImageImpl.h:35-85 for the dtype pairs the odometry front end uses:
+// u8/u16/f32 -> f32 (calc_t = float).
+template <typename S>
+void ToFloat(const S* src, float* dst, int64_t n, double scale, double offset) {
+    float limits[2] = {std::numeric_limits<float>::min(),
+                       std::numeric_limits<float>::max()};
+    float c_scale = static_cast<float>(scale);
+    float c_offset = static_cast<float>(offset);
+    for (int64_t i = 0; i < n; ++i) {
+        float out = static_cast<float>(src[i]) * c_scale + c_offset;
+        // elem_t = float: numeric_limits<float>::min() is the smallest
+        // positive normal, so every value below it (zero and negatives
+        // included) is clamped up to it -- reproduced as written.
+        out = out < limits[0] ? limits[0] : out;
+        out = out > limits[1] ? limits[1] : out;
+        dst[i] = out;
+    }
+}
+
+// Image.cpp:149-161: R*0.299f + G*0.587f + B*0.114f with float32 tensor ops
+// (two rounded products added, then the third), Round() = std::round through
+// double, Clip, cast.
+template <typename S>
+void RGBToGray(const S* src, S* dst, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) {
+        float R = static_cast<float>(src[3 * i + 0]);
+        float G = static_cast<float>(src[3 * i + 1]);
+        float B = static_cast<float>(src[3 * i + 2]);
+        float r = R * 0.299f;
+        float g = G * 0.587f;
+        float b = B * 0.114f;
+        float gray = (r + g) + b;
+        if (std::is_same<S, float>::value) {
+            dst[i] = static_cast<S>(gray);
+        } else {
+            float rounded =
+                    static_cast<float>(std::round(static_cast<double>(gray)));
+            float hi = std::is_same<S, uint8_t>::value ? 255.f : 65535.f;
+            rounded = rounded < 0.f ? 0.f : (rounded > hi ? hi : rounded);
+            dst[i] = static_cast<S>(rounded);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// IPP-semantics filters (parity unpinned beyond the reference's goldens)
+// ---------------------------------------------------------------------------
+inline int Clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ippiFilterBilateral (iwiFilterBilateral, IPPImage.cpp:202-231): circular
+// neighbourhood dx^2+dy^2 <= radius^2, radius = kernel_size/2, replicate
+// border; w = exp(-dv^2 / (2 sigma_v^2)) * exp(-d^2 / (2 sigma_d^2)).
+void FilterBilateral(const float* src, float* dst, int rows, int cols,
+                     int kernel_size, float value_sigma, float distance_sigma) {
+    const int radius = kernel_size / 2;
+    const float val_sqr = value_sigma * value_sigma;
+    const float pos_sqr = distance_sigma * distance_sigma;
+    for (int y = 0; y < rows; ++y) {
+        for (int x = 0; x < cols; ++x) {
+            float c = src[(int64_t)y * cols + x];
+            float v_sum = 0, w_sum = 0;
+            for (int dy = -radius; dy <= radius; ++dy) {
+                for (int dx = -radius; dx <= radius; ++dx) {
+                    int d2 = dx * dx + dy * dy;
+                    if (d2 > radius * radius) continue;
+                    int yy = Clampi(y + dy, 0, rows - 1);
+                    int xx = Clampi(x + dx, 0, cols - 1);
+                    float v = src[(int64_t)yy * cols + xx];
+                    float dv = v - c;
+                    float w = expf(-(dv * dv) / (2.0f * val_sqr)) *
+                              expf(-(float)d2 / (2.0f * pos_sqr));
+                    v_sum += w * v;
+                    w_sum += w;
+                }
+            }
+            dst[(int64_t)y * cols + x] = v_sum / w_sum;
+        }
+    }
+}
+
+// Normalised 1-D Gaussian taps, computed as NPPImage.cpp:389-396 does
+// (float exp of -0.5 d^2 / sigma^2, divided by their sum).
+void GaussianTaps(int kernel_size, float sigma, std::vector<float>& w) {
+    w.resize(kernel_size);
+    float sum = 0;
+    for (int i = 0; i < kernel_size; ++i) {
+        float d = static_cast<float>(i - kernel_size / 2);
+        w[i] = expf((d * d) * (-0.5f / (sigma * sigma)));
+        sum += w[i];
+    }
+    for (int i = 0; i < kernel_size; ++i) w[i] = w[i] / sum;
+}
+
+// FilterGaussian: 2-D kernel = outer product of the taps, replicate border,
+// row-major accumulation.
+void FilterGaussian(const float* src, float* dst, int rows, int cols,
+                    int kernel_size, float sigma) {
+    std::vector<float> w;
+    GaussianTaps(kernel_size, sigma, w);
+    const int r = kernel_size / 2;
+    for (int y = 0; y < rows; ++y) {
+        for (int x = 0; x < cols; ++x) {
+            float acc = 0;
+            for (int dy = -r; dy <= r; ++dy) {
+                for (int dx = -r; dx <= r; ++dx) {
+                    int yy = Clampi(y + dy, 0, rows - 1);
+                    int xx = Clampi(x + dx, 0, cols - 1);
+                    acc += (w[dy + r] * w[dx + r]) * src[(int64_t)yy * cols + xx];
+                }
+            }
+            dst[(int64_t)y * cols + x] = acc;
+        }
+    }
+}
+
+// Resize(0.5, Nearest): dst(y, x) = src(2y, 2x); dst size = (int)(rows*0.5f).
+void ResizeHalfNearest(const float* src, float* dst, int rows, int cols) {
+    int rd = (int)(rows * 0.5f), cd = (int)(cols * 0.5f);
+    for (int y = 0; y < rd; ++y)
+        for (int x = 0; x < cd; ++x)
+            dst[(int64_t)y * cd + x] = src[(int64_t)(2 * y) * cols + 2 * x];
+}
+
+// FilterSobel 3x3: dx = right - left with (1,2,1) smoothing across rows,
+// dy = bottom - top with (1,2,1) across columns; replicate border.
+void FilterSobel3(const float* src, float* dx, float* dy, int rows, int cols) {
+    for (int y = 0; y < rows; ++y) {
+        int y0 = Clampi(y - 1, 0, rows - 1), y2 = Clampi(y + 1, 0, rows - 1);
+        for (int x = 0; x < cols; ++x) {
+            int x0 = Clampi(x - 1, 0, cols - 1), x2 = Clampi(x + 1, 0, cols - 1);
+            auto S = [&](int yy, int xx) { return src[(int64_t)yy * cols + xx]; };
+            float right = S(y0, x2) + 2.0f * S(y, x2) + S(y2, x2);
+            float left = S(y0, x0) + 2.0f * S(y, x0) + S(y2, x0);
+            float bottom = S(y2, x0) + 2.0f * S(y2, x) + S(y2, x2);
+            float top = S(y0, x0) + 2.0f * S(y0, x) + S(y0, x2);
+            dx[(int64_t)y * cols + x] = right - left;
+            dy[(int64_t)y * cols + x] = bottom - top;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Jacobians, RGBDOdometryJacobianImpl.h
+// ---------------------------------------------------------------------------
+struct Map {
+    const float* p;
+    int rows, cols, ch;
+    const float* at(int x, int y) const {
+        return p + ((int64_t)y * cols + x) * ch;
+    }
+    // NDArrayIndexer::InBoundary(float, float), GeometryIndexer.h:294-297
+    bool InBoundary(float x, float y) const {
+        return InBoundary2D(x, y, rows, cols);
+    }
+};
+
+// :29-32. Sign takes an int (GeometryMacros.h:92-94): r is truncated first.
+inline float HuberDeriv(float r, float delta) {
+    float abs_r = std::abs(r);
+    return abs_r < delta ? r : delta * orc::Sign(static_cast<int>(r));
+}
+// :34-37 (the 0.5 literals are double)
+inline float HuberLoss(float r, float delta) {
+    float abs_r = std::abs(r);
+    return abs_r < delta ? 0.5 * r * r : delta * abs_r - 0.5 * delta * delta;
+}
+
+// float -> int as x86-64 cvttss2si does (what the reference's CPU build
+// executes for int(roundf(u))): out of range / NaN -> INT_MIN.
+inline int ToIntX86(float v) {
+    if (!(v > -2147483904.0f && v < 2147483648.0f)) return INT32_MIN;
+    return static_cast<int>(v);
+}
+
+// :39-104
+bool GetJacobianPointToPoint(int x, int y, float square_dist_thr,
+                             const Map& source_vertex, const Map& target_vertex,
+                             const TransformIndexer& ti, float* J_x, float* J_y,
+                             float* J_z, float& rx, float& ry, float& rz) {
+    const float* source_v = source_vertex.at(x, y);
+    if (std::isnan(source_v[0])) return false;
+    float T_v[3], u, v;
+    ti.RigidTransform(source_v[0], source_v[1], source_v[2], &T_v[0], &T_v[1],
+                      &T_v[2]);
+    ti.Project(T_v[0], T_v[1], T_v[2], &u, &v);
+    u = roundf(u);
+    v = roundf(v);
+    if (T_v[2] < 0 || !target_vertex.InBoundary(u, v)) return false;
+    int ui = static_cast<int>(u);
+    int vi = static_cast<int>(v);
+    const float* target_v = target_vertex.at(ui, vi);
+    if (std::isnan(target_v[0])) return false;
+    rx = (T_v[0] - target_v[0]);
+    ry = (T_v[1] - target_v[1]);
+    rz = (T_v[2] - target_v[2]);
+    float r2 = rx * rx + ry * ry + rz * rz;
+    if (r2 > square_dist_thr) return false;
+    J_x[0] = J_x[4] = J_x[5] = 0.0;
+    J_x[1] = T_v[2];
+    J_x[2] = -T_v[1];
+    J_x[3] = 1.0;
+    J_y[1] = J_y[3] = J_y[5] = 0.0;
+    J_y[0] = -T_v[2];
+    J_y[2] = T_v[0];
+    J_y[4] = 1.0;
+    J_z[2] = J_z[3] = J_z[4] = 0.0;
+    J_z[0] = T_v[1];
+    J_z[1] = -T_v[0];
+    J_z[5] = 1.0;
+    return true;
+}
+
+// :106-162
+bool GetJacobianPointToPlane(int x, int y, float depth_outlier_trunc,
+                             const Map& source_vertex, const Map& target_vertex,
+                             const Map& target_normal,
+                             const TransformIndexer& ti, float* J_ij, float& r) {
+    const float* source_v = source_vertex.at(x, y);
+    if (std::isnan(source_v[0])) return false;
+    float T_v[3], u, v;
+    ti.RigidTransform(source_v[0], source_v[1], source_v[2], &T_v[0], &T_v[1],
+                      &T_v[2]);
+    ti.Project(T_v[0], T_v[1], T_v[2], &u, &v);
+    u = roundf(u);
+    v = roundf(v);
+    if (T_v[2] < 0 || !target_vertex.InBoundary(u, v)) return false;
+    int ui = static_cast<int>(u);
+    int vi = static_cast<int>(v);
+    const float* target_v = target_vertex.at(ui, vi);
+    const float* target_n = target_normal.at(ui, vi);
+    if (std::isnan(target_v[0]) || std::isnan(target_n[0])) return false;
+    r = (T_v[0] - target_v[0]) * target_n[0] +
+        (T_v[1] - target_v[1]) * target_n[1] +
+        (T_v[2] - target_v[2]) * target_n[2];
+    if (std::abs(r) > depth_outlier_trunc) return false;
+    J_ij[0] = -T_v[2] * target_n[1] + T_v[1] * target_n[2];
+    J_ij[1] = T_v[2] * target_n[0] - T_v[0] * target_n[2];
+    J_ij[2] = -T_v[1] * target_n[0] + T_v[0] * target_n[1];
+    J_ij[3] = target_n[0];
+    J_ij[4] = target_n[1];
+    J_ij[5] = target_n[2];
+    return true;
+}
+
+// :164-233
+bool GetJacobianIntensity(int x, int y, float depth_outlier_trunc,
+                          const Map& target_depth, const Map& source_intensity,
+                          const Map& target_intensity,
+                          const Map& target_intensity_dx,
+                          const Map& target_intensity_dy,
+                          const Map& source_vertex, const TransformIndexer& ti,
+                          float* J_I, float& r_I) {
+    const float sobel_scale = 0.125;
+    const float* source_v = source_vertex.at(x, y);
+    if (std::isnan(source_v[0])) return false;
+    float T_v[3], u_tf, v_tf;
+    ti.RigidTransform(source_v[0], source_v[1], source_v[2], &T_v[0], &T_v[1],
+                      &T_v[2]);
+    ti.Project(T_v[0], T_v[1], T_v[2], &u_tf, &v_tf);
+    int u_t = ToIntX86(roundf(u_tf));
+    int v_t = ToIntX86(roundf(v_tf));
+    if (T_v[2] < 0 || !target_depth.InBoundary(u_t, v_t)) return false;
+    float fx = ti.fx_, fy = ti.fy_;
+    float depth_t = *target_depth.at(u_t, v_t);
+    float diff_D = depth_t - T_v[2];
+    if (std::isnan(depth_t) || std::abs(diff_D) > depth_outlier_trunc)
+        return false;
+    float diff_I = *target_intensity.at(u_t, v_t) - *source_intensity.at(x, y);
+    float dIdx = sobel_scale * (*target_intensity_dx.at(u_t, v_t));
+    float dIdy = sobel_scale * (*target_intensity_dy.at(u_t, v_t));
+    float invz = 1 / T_v[2];
+    float c0 = dIdx * fx * invz;
+    float c1 = dIdy * fy * invz;
+    float c2 = -(c0 * T_v[0] + c1 * T_v[1]) * invz;
+    J_I[0] = (-T_v[2] * c1 + T_v[1] * c2);
+    J_I[1] = (T_v[2] * c0 - T_v[0] * c2);
+    J_I[2] = (-T_v[1] * c0 + T_v[0] * c1);
+    J_I[3] = (c0);
+    J_I[4] = (c1);
+    J_I[5] = (c2);
+    r_I = diff_I;
+    return true;
+}
+
+// :235-336
+bool GetJacobianHybrid(int x, int y, float depth_outlier_trunc,
+                       const Map& target_depth, const Map& source_intensity,
+                       const Map& target_intensity, const Map& target_depth_dx,
+                       const Map& target_depth_dy,
+                       const Map& target_intensity_dx,
+                       const Map& target_intensity_dy, const Map& source_vertex,
+                       const TransformIndexer& ti, float* J_I, float* J_D,
+                       float& r_I, float& r_D) {
+    const float sqrt_lambda_intensity = 0.707;
+    const float sqrt_lambda_depth = 0.707;
+    const float sobel_scale = 0.125;
+    const float* source_v = source_vertex.at(x, y);
+    if (std::isnan(source_v[0])) return false;
+    float T_v[3], u_tf, v_tf;
+    ti.RigidTransform(source_v[0], source_v[1], source_v[2], &T_v[0], &T_v[1],
+                      &T_v[2]);
+    ti.Project(T_v[0], T_v[1], T_v[2], &u_tf, &v_tf);
+    int u_t = ToIntX86(roundf(u_tf));
+    int v_t = ToIntX86(roundf(v_tf));
+    if (T_v[2] < 0 || !target_depth.InBoundary(u_t, v_t)) return false;
+    float fx = ti.fx_, fy = ti.fy_;
+    float depth_t = *target_depth.at(u_t, v_t);
+    float diff_D = depth_t - T_v[2];
+    if (std::isnan(depth_t) || std::abs(diff_D) > depth_outlier_trunc)
+        return false;
+    float dDdx = sobel_scale * (*target_depth_dx.at(u_t, v_t));
+    float dDdy = sobel_scale * (*target_depth_dy.at(u_t, v_t));
+    if (std::isnan(dDdx) || std::isnan(dDdy)) return false;
+    float diff_I = *target_intensity.at(u_t, v_t) - *source_intensity.at(x, y);
+    float dIdx = sobel_scale * (*target_intensity_dx.at(u_t, v_t));
+    float dIdy = sobel_scale * (*target_intensity_dy.at(u_t, v_t));
+    float invz = 1 / T_v[2];
+    float c0 = dIdx * fx * invz;
+    float c1 = dIdy * fy * invz;
+    float c2 = -(c0 * T_v[0] + c1 * T_v[1]) * invz;
+    float d0 = dDdx * fx * invz;
+    float d1 = dDdy * fy * invz;
+    float d2 = -(d0 * T_v[0] + d1 * T_v[1]) * invz;
+    J_I[0] = sqrt_lambda_intensity * (-T_v[2] * c1 + T_v[1] * c2);
+    J_I[1] = sqrt_lambda_intensity * (T_v[2] * c0 - T_v[0] * c2);
+    J_I[2] = sqrt_lambda_intensity * (-T_v[1] * c0 + T_v[0] * c1);
+    J_I[3] = sqrt_lambda_intensity * (c0);
+    J_I[4] = sqrt_lambda_intensity * (c1);
+    J_I[5] = sqrt_lambda_intensity * (c2);
+    r_I = sqrt_lambda_intensity * diff_I;
+    J_D[0] = sqrt_lambda_depth * ((-T_v[2] * d1 + T_v[1] * d2) - T_v[1]);
+    J_D[1] = sqrt_lambda_depth * ((T_v[2] * d0 - T_v[0] * d2) + T_v[0]);
+    J_D[2] = sqrt_lambda_depth * ((-T_v[1] * d0 + T_v[0] * d1));
+    J_D[3] = sqrt_lambda_depth * (d0);
+    J_D[4] = sqrt_lambda_depth * (d1);
+    J_D[5] = sqrt_lambda_depth * (d2 - 1.0f);
+    r_D = sqrt_lambda_depth * diff_D;
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// Reductions, RGBDOdometryCPU.cpp. ACC = float reproduces the reference's
+// float accumulators under a sequential schedule (one valid TBB split);
+// ACC = double is the variant the HIP kernels (float64 accumulators, fixed
+// tree) are compared with. Per-pixel terms are float in both.
+// ---------------------------------------------------------------------------
+enum { kP2Plane = 0, kIntensity = 1, kHybrid = 2 };
+
+struct OdoInputs {
+    Map source_depth, target_depth;          // {H,W,1}
+    Map source_intensity, target_intensity;  // {H,W,1}
+    Map target_depth_dx, target_depth_dy;
+    Map target_intensity_dx, target_intensity_dy;
+    Map source_vertex, target_vertex, target_normal;  // {H,W,3}
+};
+
+template <typename ACC>
+void Reduce29(int method, const OdoInputs& in, const double* K,
+              const double* T, float depth_outlier_trunc,
+              float depth_huber_delta, float intensity_huber_delta,
+              double* out29) {
+    TransformIndexer ti(K, T);
+    int rows = in.source_vertex.rows, cols = in.source_vertex.cols;
+    int n = rows * cols;
+    ACC A[29];
+    for (int i = 0; i < 29; ++i) A[i] = 0;
+    for (int w = 0; w < n; ++w) {
+        int y = w / cols, x = w % cols;
+        if (method == kP2Plane) {
+            float J[6], r;
+            if (!GetJacobianPointToPlane(x, y, depth_outlier_trunc,
+                                         in.source_vertex, in.target_vertex,
+                                         in.target_normal, ti, J, r))
+                continue;
+            float d_huber = HuberDeriv(r, depth_huber_delta);
+            float r_huber = HuberLoss(r, depth_huber_delta);
+            for (int i = 0, j = 0; j < 6; j++) {
+                for (int k = 0; k <= j; k++) {
+                    A[i] += J[j] * J[k];
+                    i++;
+                }
+                A[21 + j] += J[j] * d_huber;
+            }
+            A[27] += r_huber;
+            A[28] += 1;
+        } else if (method == kIntensity) {
+            float J[6], r;
+            if (!GetJacobianIntensity(x, y, depth_outlier_trunc,
+                                      in.target_depth, in.source_intensity,
+                                      in.target_intensity,
+                                      in.target_intensity_dx,
+                                      in.target_intensity_dy, in.source_vertex,
+                                      ti, J, r))
+                continue;
+            float d_huber = HuberDeriv(r, intensity_huber_delta);
+            float r_huber = HuberLoss(r, intensity_huber_delta);
+            for (int i = 0, j = 0; j < 6; j++) {
+                for (int k = 0; k <= j; k++) {
+                    A[i] += J[j] * J[k];
+                    i++;
+                }
+                A[21 + j] += J[j] * d_huber;
+            }
+            A[27] += r_huber;
+            A[28] += 1;
+        } else {
+            float J_I[6], J_D[6], r_I, r_D;
+            if (!GetJacobianHybrid(x, y, depth_outlier_trunc, in.target_depth,
+                                   in.source_intensity, in.target_intensity,
+                                   in.target_depth_dx, in.target_depth_dy,
+                                   in.target_intensity_dx,
+                                   in.target_intensity_dy, in.source_vertex, ti,
+                                   J_I, J_D, r_I, r_D))
+                continue;
+            float d_huber_I = HuberDeriv(r_I, intensity_huber_delta);
+            float d_huber_D = HuberDeriv(r_D, depth_huber_delta);
+            float r_huber_I = HuberLoss(r_I, intensity_huber_delta);
+            float r_huber_D = HuberLoss(r_D, depth_huber_delta);
+            for (int i = 0, j = 0; j < 6; j++) {
+                for (int k = 0; k <= j; k++) {
+                    A[i] += J_I[j] * J_I[k] + J_D[j] * J_D[k];
+                    i++;
+                }
+                A[21 + j] += J_I[j] * d_huber_I + J_D[j] * d_huber_D;
+            }
+            A[27] += r_huber_I + r_huber_D;
+            A[28] += 1;
+        }
+    }
+    for (int i = 0; i < 29; ++i) out29[i] = (double)A[i];
+}
+
+// ComputeOdometryInformationMatrixCPU, RGBDOdometryCPU.cpp:26-96
+template <typename ACC>
+void Information(const Map& source_vertex, const Map& target_vertex,
+                 const double* K, const double* T, float square_dist_thr,
+                 double* info36) {
+    TransformIndexer ti(K, T);
+    int rows = source_vertex.rows, cols = source_vertex.cols;
+    int n = rows * cols;
+    ACC A[21];
+    for (int i = 0; i < 21; ++i) A[i] = 0;
+    for (int w = 0; w < n; ++w) {
+        int y = w / cols, x = w % cols;
+        float J_x[6], J_y[6], J_z[6], rx, ry, rz;
+        if (!GetJacobianPointToPoint(x, y, square_dist_thr, source_vertex,
+                                     target_vertex, ti, J_x, J_y, J_z, rx, ry,
+                                     rz))
+            continue;
+        for (int i = 0, j = 0; j < 6; j++) {
+            for (int k = 0; k <= j; k++) {
+                A[i] += J_x[j] * J_x[k];
+                A[i] += J_y[j] * J_y[k];
+                A[i] += J_z[j] * J_z[k];
+                i++;
+            }
+        }
+    }
+    for (int j = 0; j < 6; j++) {
+        const int64_t reduction_idx = ((j * (j + 1)) / 2);
+        for (int k = 0; k <= j; k++) {
+            info36[j * 6 + k] = (double)A[reduction_idx + k];
+            info36[k * 6 + j] = (double)A[reduction_idx + k];
+        }
+    }
+}
+
+void Matmul4(const double* A, const double* B, double* C) {
+    double R[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double s = 0;
+            for (int k = 0; k < 4; ++k) s += A[i * 4 + k] * B[k * 4 + j];
+            R[i * 4 + j] = s;
+        }
+    std::memcpy(C, R, sizeof(R));
+}
+
+struct Level {
+    int rows = 0, cols = 0;
+    double K[9];
+    std::vector<float> source_depth, target_depth;
+    std::vector<float> source_intensity, target_intensity;
+    std::vector<float> target_depth_dx, target_depth_dy;
+    std::vector<float> target_intensity_dx, target_intensity_dy;
+    std::vector<float> source_vertex, target_vertex, target_normal;
+};
+
+template <typename S>
+void PrepareDepth(const S* depth, int rows, int cols, float depth_scale,
+                  float depth_max, std::vector<float>& out) {
+    out.resize((size_t)rows * cols);
+    // RGBDOdometry.cpp:86-89: ClipTransform(depth_scale, 0, depth_max, NAN)
+    ClipTransform<S>(depth, out.data(), rows, cols, depth_scale, 0.0f,
+                     depth_max, NAN);
+}
+
+// color {H,W,3} u8 or f32 -> RGBToGray().To(Float32) (RGBDOdometry.cpp:223-224)
+void PrepareIntensity(const void* color, int color_is_f32, int rows, int cols,
+                      std::vector<float>& out) {
+    int64_t n = (int64_t)rows * cols;
+    out.resize((size_t)n);
+    if (color_is_f32) {
+        RGBToGray<float>((const float*)color, out.data(), n);
+        // To(Float32) of a Float32 image without scale is the identity
+        // (Image.cpp:76-78).
+    } else {
+        std::vector<uint8_t> gray((size_t)n);
+        RGBToGray<uint8_t>((const uint8_t*)color, gray.data(), n);
+        // To(Float32) from UInt8: scale 1/255, offset 0 (Image.cpp:86-95);
+        // the IPP conversion is restated by the in-tree kernel.
+        ToFloat<uint8_t>(gray.data(), out.data(), n, 1. / 255, 0.0);
+    }
+}
+
+struct OdoResult {
+    double T[16];
+    double inlier_rmse = 0, fitness = 0;
+    int status = 0;  // 0 ok, 1 invalid inlier count, 2 singular
+    int iterations = 0;
+};
+
+// RGBDOdometryMultiScale, RGBDOdometry.cpp:56-108 and the three per-method
+// drivers :110-187, :189-273, :275-380.
+template <typename ACC, typename S>
+OdoResult MultiScale(int method, const S* src_depth, const void* src_color,
+                     const S* tgt_depth, const void* tgt_color, int color_is_f32,
+                     int rows, int cols, const double* intrinsics,
+                     const double* init, float depth_scale, float depth_max,
+                     int n_levels, const int* max_iterations,
+                     const double* relative_rmse,
+                     const double* relative_fitness, float depth_outlier_trunc,
+                     float depth_huber_delta, float intensity_huber_delta) {
+    std::vector<Level> levels((size_t)n_levels);
+    std::vector<float> sd, td, si, tis;
+    PrepareDepth<S>(src_depth, rows, cols, depth_scale, depth_max, sd);
+    PrepareDepth<S>(tgt_depth, rows, cols, depth_scale, depth_max, td);
+    if (method != kP2Plane) {
+        PrepareIntensity(src_color, color_is_f32, rows, cols, si);
+        PrepareIntensity(tgt_color, color_is_f32, rows, cols, tis);
+    }
+    double Kp[9];
+    std::memcpy(Kp, intrinsics, sizeof(Kp));
+    int r = rows, c = cols;
+    for (int i = 0; i < n_levels; ++i) {
+        Level& L = levels[(size_t)(n_levels - 1 - i)];
+        L.rows = r;
+        L.cols = c;
+        std::memcpy(L.K, Kp, sizeof(Kp));
+        size_t n = (size_t)r * c;
+        L.source_vertex.resize(n * 3);
+        CreateVertexMap(sd.data(), L.source_vertex.data(), r, c, Kp, NAN);
+        if (method == kP2Plane) {
+            L.target_vertex.resize(n * 3);
+            CreateVertexMap(td.data(), L.target_vertex.data(), r, c, Kp, NAN);
+            std::vector<float> smooth(n), vsmooth(n * 3);
+            FilterBilateral(td.data(), smooth.data(), r, c, 5, 5.0f, 10.0f);
+            CreateVertexMap(smooth.data(), vsmooth.data(), r, c, Kp, NAN);
+            L.target_normal.resize(n * 3);
+            CreateNormalMap(vsmooth.data(), L.target_normal.data(), r, c, NAN);
+        } else {
+            L.source_depth = sd;
+            L.target_depth = td;
+            L.source_intensity = si;
+            L.target_intensity = tis;
+            L.target_intensity_dx.resize(n);
+            L.target_intensity_dy.resize(n);
+            FilterSobel3(tis.data(), L.target_intensity_dx.data(),
+                         L.target_intensity_dy.data(), r, c);
+            if (method == kHybrid) {
+                L.target_depth_dx.resize(n);
+                L.target_depth_dy.resize(n);
+                FilterSobel3(td.data(), L.target_depth_dx.data(),
+                             L.target_depth_dy.data(), r, c);
+            }
+        }
+        if (i != n_levels - 1) {
+            int r2 = r / 2, c2 = c / 2;
+            std::vector<float> sd2((size_t)r2 * c2), td2((size_t)r2 * c2);
+            PyrDownDepth(sd.data(), sd2.data(), r, c, depth_outlier_trunc * 2,
+                         NAN);
+            PyrDownDepth(td.data(), td2.data(), r, c, depth_outlier_trunc * 2,
+                         NAN);
+            if (method != kP2Plane) {
+                // Image::PyrDown: FilterGaussian(5, 1.0f) + Resize(0.5, Nearest)
+                std::vector<float> blur(n), si2((size_t)r2 * c2),
+                        ti2((size_t)r2 * c2);
+                FilterGaussian(si.data(), blur.data(), r, c, 5, 1.0f);
+                ResizeHalfNearest(blur.data(), si2.data(), r, c);
+                FilterGaussian(tis.data(), blur.data(), r, c, 5, 1.0f);
+                ResizeHalfNearest(blur.data(), ti2.data(), r, c);
+                si.swap(si2);
+                tis.swap(ti2);
+            }
+            sd.swap(sd2);
+            td.swap(td2);
+            r = r2;
+            c = c2;
+            for (int k = 0; k < 9; ++k) Kp[k] /= 2;
+            Kp[8] = 1;
+        }
+    }
+
+    OdoResult result;
+    std::memcpy(result.T, init, sizeof(result.T));
+    result.inlier_rmse = 0.0;
+    result.fitness = 1.0;
+    for (int i = 0; i < n_levels; ++i) {
+        Level& L = levels[(size_t)i];
+        OdoInputs in;
+        auto M = [&](std::vector<float>& v, int ch) {
+            return Map{v.data(), L.rows, L.cols, ch};
+        };
+        in.source_depth = M(L.source_depth, 1);
+        in.target_depth = M(L.target_depth, 1);
+        in.source_intensity = M(L.source_intensity, 1);
+        in.target_intensity = M(L.target_intensity, 1);
+        in.target_depth_dx = M(L.target_depth_dx, 1);
+        in.target_depth_dy = M(L.target_depth_dy, 1);
+        in.target_intensity_dx = M(L.target_intensity_dx, 1);
+        in.target_intensity_dy = M(L.target_intensity_dy, 1);
+        in.source_vertex = M(L.source_vertex, 3);
+        in.target_vertex = M(L.target_vertex, 3);
+        in.target_normal = M(L.target_normal, 3);
+        for (int iter = 0; iter < max_iterations[i]; ++iter) {
+            double A[29], pose[6], dT[16];
+            float residual;
+            int count;
+            Reduce29<ACC>(method, in, L.K, result.T, depth_outlier_trunc,
+                          depth_huber_delta, intensity_huber_delta, A);
+            if (orc_decode_and_solve6x6(A, pose, &residual, &count) != 0) {
+                result.status = 2;
+                return result;
+            }
+            if (count <= 0) {
+                result.status = 1;
+                return result;
+            }
+            orc_pose_to_transformation(pose, dT);
+            // OdometryResult(T, inlier_residual / inlier_count (float / int),
+            // double(count) / double(rows * cols)), RGBDOdometry.cpp:404-409
+            double delta_rmse = (double)(residual / count);
+            double delta_fitness = double(count) / double((int64_t)L.rows * L.cols);
+            Matmul4(dT, result.T, result.T);
+            result.iterations++;
+            if (std::abs(result.fitness - delta_fitness) / result.fitness <
+                        relative_fitness[i] &&
+                std::abs(result.inlier_rmse - delta_rmse) / result.inlier_rmse <
+                        relative_rmse[i]) {
+                break;
+            }
+            result.inlier_rmse = delta_rmse;
+            result.fitness = delta_fitness;
+        }
+    }
+    return result;
+}
+
+Map MakeMap(const float* p, int rows, int cols, int ch) {
+    return Map{p, rows, cols, ch};
+}
+
+}  // namespace
+
+extern "C" {
+
+void orc_clip_transform(const void* src, int src_is_f32, int64_t rows,
+                        int64_t cols, float scale, float min_value,
+                        float max_value, float clip_fill, float* dst) {
+    if (src_is_f32)
+        ClipTransform<float>((const float*)src, dst, rows, cols, scale,
+                             min_value, max_value, clip_fill);
+    else
+        ClipTransform<uint16_t>((const uint16_t*)src, dst, rows, cols, scale,
+                                min_value, max_value, clip_fill);
+}
+
+void orc_pyrdown_depth(const float* src, int rows, int cols, float depth_diff,
+                       float invalid_fill, float* dst) {
+    PyrDownDepth(src, dst, rows, cols, depth_diff, invalid_fill);
+}
+
+void orc_create_vertex_map(const float* src, int64_t rows, int64_t cols,
+                           const double* K, float invalid_fill, float* dst) {
+    CreateVertexMap(src, dst, rows, cols, K, invalid_fill);
+}
+
+void orc_create_normal_map(const float* src, int64_t rows, int64_t cols,
+                           float invalid_fill, float* dst) {
+    CreateNormalMap(src, dst, rows, cols, invalid_fill);
+}
+
+// src_dtype: 0 = u8, 1 = u16, 2 = f32
+void orc_image_to_float(const void* src, int src_dtype, int64_t n, double scale,
+                        double offset, float* dst) {
+    if (src_dtype == 0) ToFloat<uint8_t>((const uint8_t*)src, dst, n, scale, offset);
+    else if (src_dtype == 1) ToFloat<uint16_t>((const uint16_t*)src, dst, n, scale, offset);
+    else ToFloat<float>((const float*)src, dst, n, scale, offset);
+}
+
+void orc_rgb_to_gray(const void* src, int src_dtype, int64_t n, void* dst) {
+    if (src_dtype == 0) RGBToGray<uint8_t>((const uint8_t*)src, (uint8_t*)dst, n);
+    else if (src_dtype == 1) RGBToGray<uint16_t>((const uint16_t*)src, (uint16_t*)dst, n);
+    else RGBToGray<float>((const float*)src, (float*)dst, n);
+}
+
+void orc_filter_bilateral(const float* src, int rows, int cols, int kernel_size,
+                          float value_sigma, float distance_sigma, float* dst) {
+    FilterBilateral(src, dst, rows, cols, kernel_size, value_sigma,
+                    distance_sigma);
+}
+
+void orc_filter_gaussian(const float* src, int rows, int cols, int kernel_size,
+                         float sigma, float* dst) {
+    FilterGaussian(src, dst, rows, cols, kernel_size, sigma);
+}
+
+void orc_filter_sobel(const float* src, int rows, int cols, float* dx,
+                      float* dy) {
+    FilterSobel3(src, dx, dy, rows, cols);
+}
+
+void orc_resize_half_nearest(const float* src, int rows, int cols, float* dst) {
+    ResizeHalfNearest(src, dst, rows, cols);
+}
+
+void orc_pyrdown(const float* src, int rows, int cols, float* dst) {
+    std::vector<float> blur((size_t)rows * cols);
+    FilterGaussian(src, blur.data(), rows, cols, 5, 1.0f);
+    ResizeHalfNearest(blur.data(), dst, rows, cols);
+}
+
+// 29 sums of one odometry iteration. method: 0 point-to-plane, 1 intensity,
+// 2 hybrid. Unused maps may be NULL. accumulate_double: 0 = float
+// accumulators, sequential (the reference under one TBB schedule), 1 = double.
+void orc_odometry_sums(int method, int rows, int cols, const float* source_depth,
+                       const float* target_depth, const float* source_intensity,
+                       const float* target_intensity,
+                       const float* target_depth_dx,
+                       const float* target_depth_dy,
+                       const float* target_intensity_dx,
+                       const float* target_intensity_dy,
+                       const float* source_vertex, const float* target_vertex,
+                       const float* target_normal, const double* K,
+                       const double* T, float depth_outlier_trunc,
+                       float depth_huber_delta, float intensity_huber_delta,
+                       int accumulate_double, double* out29) {
+    OdoInputs in;
+    in.source_depth = MakeMap(source_depth, rows, cols, 1);
+    in.target_depth = MakeMap(target_depth, rows, cols, 1);
+    in.source_intensity = MakeMap(source_intensity, rows, cols, 1);
+    in.target_intensity = MakeMap(target_intensity, rows, cols, 1);
+    in.target_depth_dx = MakeMap(target_depth_dx, rows, cols, 1);
+    in.target_depth_dy = MakeMap(target_depth_dy, rows, cols, 1);
+    in.target_intensity_dx = MakeMap(target_intensity_dx, rows, cols, 1);
+    in.target_intensity_dy = MakeMap(target_intensity_dy, rows, cols, 1);
+    in.source_vertex = MakeMap(source_vertex, rows, cols, 3);
+    in.target_vertex = MakeMap(target_vertex, rows, cols, 3);
+    in.target_normal = MakeMap(target_normal, rows, cols, 3);
+    if (accumulate_double)
+        Reduce29<double>(method, in, K, T, depth_outlier_trunc,
+                         depth_huber_delta, intensity_huber_delta, out29);
+    else
+        Reduce29<float>(method, in, K, T, depth_outlier_trunc,
+                        depth_huber_delta, intensity_huber_delta, out29);
+}
+
+void orc_odometry_information(int rows, int cols, const float* source_vertex,
+                              const float* target_vertex, const double* K,
+                              const double* T, float square_dist_thr,
+                              int accumulate_double, double* info36) {
+    Map s = MakeMap(source_vertex, rows, cols, 3);
+    Map t = MakeMap(target_vertex, rows, cols, 3);
+    if (accumulate_double)
+        Information<double>(s, t, K, T, square_dist_thr, info36);
+    else
+        Information<float>(s, t, K, T, square_dist_thr, info36);
+}
+
+// RGBDOdometryMultiScale. depth: u16 or f32 {H,W}; color: u8 or f32 {H,W,3}
+// (may be NULL for point-to-plane). Returns status (0 ok, 1 invalid inlier
+// count, 2 singular system).
+int orc_rgbd_odometry_multiscale(
+        int method, const void* src_depth, const void* src_color,
+        const void* tgt_depth, const void* tgt_color, int depth_is_f32,
+        int color_is_f32, int rows, int cols, const double* intrinsics,
+        const double* init_source_to_target, float depth_scale, float depth_max,
+        int n_levels, const int* max_iterations, const double* relative_rmse,
+        const double* relative_fitness, float depth_outlier_trunc,
+        float depth_huber_delta, float intensity_huber_delta,
+        int accumulate_double, double* T_out, double* rmse_out,
+        double* fitness_out, int* iterations_out) {
+    OdoResult r;
+#define ORC_CALL(ACC, S)                                                        \
+    r = MultiScale<ACC, S>(method, (const S*)src_depth, src_color,             \
+                           (const S*)tgt_depth, tgt_color, color_is_f32, rows, \
+                           cols, intrinsics, init_source_to_target,            \
+                           depth_scale, depth_max, n_levels, max_iterations,   \
+                           relative_rmse, relative_fitness,                    \
+                           depth_outlier_trunc, depth_huber_delta,             \
+                           intensity_huber_delta)
+    if (accumulate_double) {
+        if (depth_is_f32) ORC_CALL(double, float); else ORC_CALL(double, uint16_t);
+    } else {
+        if (depth_is_f32) ORC_CALL(float, float); else ORC_CALL(float, uint16_t);
+    }
+#undef ORC_CALL
+    std::memcpy(T_out, r.T, sizeof(r.T));
+    *rmse_out = r.inlier_rmse;
+    *fitness_out = r.fitness;
+    if (iterations_out) *iterations_out = r.iterations;
+    return r.status;
+}
+
+}  // extern "C"

@@ -33,6 +33,14 @@ public:
     int64_t start = 0, stop = 0, step = 1;
 };
 
+/// Test hook: the values of the last std::vector a Tensor was constructed
+/// from, as doubles (lets ref_entry read the reference's reduction result,
+/// e.g. RGBDOdometryCPU.cpp's A_1x29, before it is decoded and solved).
+inline std::vector<double>& LastVectorInit() {
+    static thread_local std::vector<double> v;
+    return v;
+}
+
 class Tensor {
 public:
     Tensor() = default;
@@ -51,6 +59,7 @@ public:
         if ((int64_t)init_vals.size() != NumElements())
             utility::LogError("init_vals size mismatch");
         std::memcpy(data_, init_vals.data(), sizeof(T) * init_vals.size());
+        LastVectorInit().assign(init_vals.begin(), init_vals.end());
     }
     /// Wraps foreign memory (no ownership).
     static Tensor FromPtr(const void* ptr, const SizeVector& shape,

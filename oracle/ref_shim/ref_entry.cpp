@@ -421,3 +421,141 @@ double ref_robust_weight(int is_f64, int method, double scaling, double shape,
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// RGB-D odometry front end: the reference's image
+// pyramid kernels and per-pixel Jacobian reductions, unmodified.
+// ---------------------------------------------------------------------------
+#include "open3d/t/geometry/kernel/ImageCPU.cpp"
+#include "open3d/t/pipelines/kernel/RGBDOdometryCPU.cpp"
+
+namespace img = open3d::t::geometry::kernel::image;
+namespace odo = open3d::t::pipelines::kernel::odometry;
+
+extern "C" {
+
+// ClipTransformCPU, t/geometry/kernel/ImageImpl.h:94-128.
+int ref_clip_transform(const void* src, int src_is_f32, int64_t rows,
+                       int64_t cols, float scale, float min_value,
+                       float max_value, float clip_fill, float* dst) {
+    return Guard([&] {
+        Tensor s = Wrap(src, {rows, cols, 1},
+                        src_is_f32 ? core::Float32 : core::UInt16);
+        Tensor d = Wrap(dst, {rows, cols, 1}, core::Float32);
+        img::ClipTransformCPU(s, d, scale, min_value, max_value, clip_fill);
+    });
+}
+
+// PyrDownDepthCPU, ImageImpl.h:132-206; dst is {rows/2, cols/2, 1}
+// (t/geometry/Image.cpp:419-420).
+int ref_pyrdown_depth(const float* src, int rows, int cols, float depth_diff,
+                      float invalid_fill, float* dst) {
+    return Guard([&] {
+        Tensor s = Wrap(src, {rows, cols, 1}, core::Float32);
+        Tensor d = Wrap(dst, {rows / 2, cols / 2, 1}, core::Float32);
+        img::PyrDownDepthCPU(s, d, depth_diff, invalid_fill);
+    });
+}
+
+// CreateVertexMapCPU, ImageImpl.h:208-256.
+int ref_create_vertex_map(const float* src, int64_t rows, int64_t cols,
+                          const double* K, float invalid_fill, float* dst) {
+    return Guard([&] {
+        Tensor s = Wrap(src, {rows, cols, 1}, core::Float32);
+        Tensor d = Wrap(dst, {rows, cols, 3}, core::Float32);
+        img::CreateVertexMapCPU(s, d, Mat(K, 3, 3), invalid_fill);
+    });
+}
+
+// CreateNormalMapCPU, ImageImpl.h:257-322.
+int ref_create_normal_map(const float* src, int64_t rows, int64_t cols,
+                          float invalid_fill, float* dst) {
+    return Guard([&] {
+        Tensor s = Wrap(src, {rows, cols, 3}, core::Float32);
+        Tensor d = Wrap(dst, {rows, cols, 3}, core::Float32);
+        img::CreateNormalMapCPU(s, d, invalid_fill);
+    });
+}
+
+// ToCPU, ImageImpl.h:35-85, dst Float32. src_dtype: 0 u8, 1 u16, 2 f32.
+int ref_image_to_float(const void* src, int src_dtype, int64_t n, double scale,
+                       double offset, float* dst) {
+    return Guard([&] {
+        const core::Dtype dt = src_dtype == 0   ? core::UInt8
+                               : src_dtype == 1 ? core::UInt16
+                                                : core::Float32;
+        Tensor s = Wrap(src, {n}, dt);
+        Tensor d = Wrap(dst, {n}, core::Float32);
+        img::ToCPU(s, d, scale, offset);
+    });
+}
+
+// ComputeOdometryResult{PointToPlane,Intensity,Hybrid}CPU,
+// t/pipelines/kernel/RGBDOdometryCPU.cpp:98-364. Outputs the decoded result
+// (delta pose, residual, count) and the float A_1x29 the reference reduced
+// (read back through the stand-in Tensor's vector-constructor hook).
+int ref_odometry(int method, int rows, int cols, const float* source_depth,
+                 const float* target_depth, const float* source_intensity,
+                 const float* target_intensity, const float* target_depth_dx,
+                 const float* target_depth_dy, const float* target_intensity_dx,
+                 const float* target_intensity_dy, const float* source_vertex,
+                 const float* target_vertex, const float* target_normal,
+                 const double* K, const double* T, float depth_outlier_trunc,
+                 float depth_huber_delta, float intensity_huber_delta,
+                 double* delta6, float* residual, int* count, double* sums29) {
+    return Guard([&] {
+        auto M1 = [&](const float* p) {
+            return Wrap(p, {rows, cols, 1}, core::Float32);
+        };
+        auto M3 = [&](const float* p) {
+            return Wrap(p, {rows, cols, 3}, core::Float32);
+        };
+        Tensor delta;
+        float res = 0;
+        int cnt = 0;
+        core::LastVectorInit().clear();
+        if (method == 0) {
+            odo::ComputeOdometryResultPointToPlaneCPU(
+                    M3(source_vertex), M3(target_vertex), M3(target_normal),
+                    Mat(K, 3, 3), Mat(T, 4, 4), delta, res, cnt,
+                    depth_outlier_trunc, depth_huber_delta);
+        } else if (method == 1) {
+            odo::ComputeOdometryResultIntensityCPU(
+                    M1(source_depth), M1(target_depth), M1(source_intensity),
+                    M1(target_intensity), M1(target_intensity_dx),
+                    M1(target_intensity_dy), M3(source_vertex), Mat(K, 3, 3),
+                    Mat(T, 4, 4), delta, res, cnt, depth_outlier_trunc,
+                    intensity_huber_delta);
+        } else {
+            odo::ComputeOdometryResultHybridCPU(
+                    M1(source_depth), M1(target_depth), M1(source_intensity),
+                    M1(target_intensity), M1(target_depth_dx),
+                    M1(target_depth_dy), M1(target_intensity_dx),
+                    M1(target_intensity_dy), M3(source_vertex), Mat(K, 3, 3),
+                    Mat(T, 4, 4), delta, res, cnt, depth_outlier_trunc,
+                    depth_huber_delta, intensity_huber_delta);
+        }
+        const std::vector<double>& A = core::LastVectorInit();
+        for (int i = 0; i < 29; ++i) sums29[i] = i < (int)A.size() ? A[i] : 0.0;
+        for (int i = 0; i < 6; ++i) delta6[i] = delta.GetDouble(i);
+        *residual = res;
+        *count = cnt;
+    });
+}
+
+// ComputeOdometryInformationMatrixCPU, RGBDOdometryCPU.cpp:26-96.
+int ref_odometry_information(int rows, int cols, const float* source_vertex,
+                             const float* target_vertex, const double* K,
+                             const double* T, float square_dist_thr,
+                             double* info36) {
+    return Guard([&] {
+        Tensor info;
+        odo::ComputeOdometryInformationMatrixCPU(
+                Wrap(source_vertex, {rows, cols, 3}, core::Float32),
+                Wrap(target_vertex, {rows, cols, 3}, core::Float32),
+                Mat(K, 3, 3), Mat(T, 4, 4), square_dist_thr, info);
+        for (int i = 0; i < 36; ++i) info36[i] = info.GetDouble(i);
+    });
+}
+
+}  // extern "C"

@@ -29,7 +29,8 @@ def lib():
     global _lib
     if _lib is None:
         srcs = [os.path.join(_ORACLE_DIR, f) for f in
-                ("vbg_oracle.cpp", "icp_oracle.cpp", "oracle_common.h")]
+                ("vbg_oracle.cpp", "icp_oracle.cpp", "odometry_oracle.cpp",
+                 "oracle_common.h")]
         if (not os.path.exists(_SO)) or any(
                 os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_SO)
                 for s in srcs):
@@ -394,3 +395,194 @@ def multiscale_icp(source, target, target_normals, voxel_sizes, criterias,
                 inlier_rmse=rmse.value, converged=bool(conv.value),
                 num_iterations=nit.value,
                 correspondences=corr[:ncorr.value].copy())
+
+
+# ---------------------------------------------------------------------------
+# RGB-D odometry front end (oracle/odometry_oracle.cpp)
+# ---------------------------------------------------------------------------
+def _f32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def _img_dtype_code(a):
+    return {np.dtype(np.uint8): 0, np.dtype(np.uint16): 1,
+            np.dtype(np.float32): 2}[a.dtype]
+
+
+def clip_transform(src, scale, min_value, max_value, clip_fill):
+    src = np.ascontiguousarray(src)
+    rows, cols = src.shape[:2]
+    dst = np.empty((rows, cols), np.float32)
+    lib().orc_clip_transform(_p(src), int(src.dtype == np.float32),
+                             C.c_int64(rows), C.c_int64(cols),
+                             C.c_float(scale), C.c_float(min_value),
+                             C.c_float(max_value), C.c_float(clip_fill),
+                             _p(dst))
+    return dst
+
+
+def pyrdown_depth(src, depth_diff, invalid_fill):
+    src = _f32(src)
+    rows, cols = src.shape[:2]
+    dst = np.empty((rows // 2, cols // 2), np.float32)
+    lib().orc_pyrdown_depth(_p(src), rows, cols, C.c_float(depth_diff),
+                            C.c_float(invalid_fill), _p(dst))
+    return dst
+
+
+def create_vertex_map(src, K, invalid_fill):
+    src = _f32(src)
+    rows, cols = src.shape[:2]
+    dst = np.empty((rows, cols, 3), np.float32)
+    lib().orc_create_vertex_map(_p(src), C.c_int64(rows), C.c_int64(cols),
+                                _p(_f64(K)), C.c_float(invalid_fill), _p(dst))
+    return dst
+
+
+def create_normal_map(src, invalid_fill):
+    src = _f32(src)
+    rows, cols = src.shape[:2]
+    dst = np.empty((rows, cols, 3), np.float32)
+    lib().orc_create_normal_map(_p(src), C.c_int64(rows), C.c_int64(cols),
+                                C.c_float(invalid_fill), _p(dst))
+    return dst
+
+
+def image_to_float(src, scale, offset=0.0):
+    src = np.ascontiguousarray(src)
+    dst = np.empty(src.shape, np.float32)
+    lib().orc_image_to_float(_p(src), _img_dtype_code(src),
+                             C.c_int64(src.size), C.c_double(scale),
+                             C.c_double(offset), _p(dst))
+    return dst
+
+
+def rgb_to_gray(src):
+    src = np.ascontiguousarray(src)
+    rows, cols = src.shape[:2]
+    dst = np.empty((rows, cols), src.dtype)
+    lib().orc_rgb_to_gray(_p(src), _img_dtype_code(src),
+                          C.c_int64(rows * cols), _p(dst))
+    return dst
+
+
+def filter_bilateral(src, kernel_size, value_sigma, distance_sigma):
+    src = _f32(src)
+    rows, cols = src.shape[:2]
+    dst = np.empty((rows, cols), np.float32)
+    lib().orc_filter_bilateral(_p(src), rows, cols, int(kernel_size),
+                               C.c_float(value_sigma),
+                               C.c_float(distance_sigma), _p(dst))
+    return dst
+
+
+def filter_gaussian(src, kernel_size=3, sigma=1.0):
+    src = _f32(src)
+    rows, cols = src.shape[:2]
+    dst = np.empty((rows, cols), np.float32)
+    lib().orc_filter_gaussian(_p(src), rows, cols, int(kernel_size),
+                              C.c_float(sigma), _p(dst))
+    return dst
+
+
+def filter_sobel(src):
+    src = _f32(src)
+    rows, cols = src.shape[:2]
+    dx = np.empty((rows, cols), np.float32)
+    dy = np.empty((rows, cols), np.float32)
+    lib().orc_filter_sobel(_p(src), rows, cols, _p(dx), _p(dy))
+    return dx, dy
+
+
+def resize_half_nearest(src):
+    src = _f32(src)
+    rows, cols = src.shape[:2]
+    dst = np.empty((int(rows * 0.5), int(cols * 0.5)), np.float32)
+    lib().orc_resize_half_nearest(_p(src), rows, cols, _p(dst))
+    return dst
+
+
+def pyrdown(src):
+    src = _f32(src)
+    rows, cols = src.shape[:2]
+    dst = np.empty((int(rows * 0.5), int(cols * 0.5)), np.float32)
+    lib().orc_pyrdown(_p(src), rows, cols, _p(dst))
+    return dst
+
+
+ODO_P2PLANE, ODO_INTENSITY, ODO_HYBRID = 0, 1, 2
+
+
+def _opt32(a):
+    return None if a is None else _f32(a)
+
+
+def odometry_sums(method, K, T, source_vertex, target_vertex=None,
+                  target_normal=None, source_depth=None, target_depth=None,
+                  source_intensity=None, target_intensity=None,
+                  target_depth_dx=None, target_depth_dy=None,
+                  target_intensity_dx=None, target_intensity_dy=None,
+                  depth_outlier_trunc=0.07, depth_huber_delta=0.05,
+                  intensity_huber_delta=0.1, accumulate_double=False):
+    sv = _f32(source_vertex)
+    rows, cols = sv.shape[:2]
+    arrs = [_opt32(a) for a in (source_depth, target_depth, source_intensity,
+                                target_intensity, target_depth_dx,
+                                target_depth_dy, target_intensity_dx,
+                                target_intensity_dy)]
+    tv, tn = _opt32(target_vertex), _opt32(target_normal)
+    out = np.zeros(29, np.float64)
+    lib().orc_odometry_sums(int(method), rows, cols, *[_p(a) for a in arrs],
+                            _p(sv), _p(tv), _p(tn), _p(_f64(K)), _p(_f64(T)),
+                            C.c_float(depth_outlier_trunc),
+                            C.c_float(depth_huber_delta),
+                            C.c_float(intensity_huber_delta),
+                            int(bool(accumulate_double)), _p(out))
+    return out
+
+
+def odometry_information(source_vertex, target_vertex, K, T, square_dist_thr,
+                         accumulate_double=False):
+    sv, tv = _f32(source_vertex), _f32(target_vertex)
+    rows, cols = sv.shape[:2]
+    out = np.zeros((6, 6), np.float64)
+    lib().orc_odometry_information(rows, cols, _p(sv), _p(tv), _p(_f64(K)),
+                                   _p(_f64(T)), C.c_float(square_dist_thr),
+                                   int(bool(accumulate_double)), _p(out))
+    return out
+
+
+def rgbd_odometry_multiscale(method, src_depth, tgt_depth, K, init=None,
+                             src_color=None, tgt_color=None,
+                             depth_scale=1000.0, depth_max=3.0,
+                             criteria=((6, 1e-6, 1e-6), (3, 1e-6, 1e-6),
+                                       (1, 1e-6, 1e-6)),
+                             depth_outlier_trunc=0.07, depth_huber_delta=0.05,
+                             intensity_huber_delta=0.1,
+                             accumulate_double=False):
+    """criteria: list of (max_iteration, relative_rmse, relative_fitness),
+    coarse to fine (OdometryConvergenceCriteria, RGBDOdometry.h:38-68)."""
+    sd = np.ascontiguousarray(src_depth)
+    td = np.ascontiguousarray(tgt_depth)
+    assert sd.dtype == td.dtype and sd.dtype in (np.uint16, np.float32)
+    rows, cols = sd.shape[:2]
+    sc = None if src_color is None else np.ascontiguousarray(src_color)
+    tc = None if tgt_color is None else np.ascontiguousarray(tgt_color)
+    color_f32 = int(sc is not None and sc.dtype == np.float32)
+    init = np.eye(4) if init is None else init
+    iters = np.array([c[0] for c in criteria], np.int32)
+    rr = np.array([c[1] for c in criteria], np.float64)
+    rf = np.array([c[2] for c in criteria], np.float64)
+    T = np.zeros((4, 4), np.float64)
+    rmse, fit = C.c_double(0), C.c_double(0)
+    it = C.c_int(0)
+    st = lib().orc_rgbd_odometry_multiscale(
+        int(method), _p(sd), _p(sc), _p(td), _p(tc),
+        int(sd.dtype == np.float32), color_f32, rows, cols, _p(_f64(K)),
+        _p(_f64(init)), C.c_float(depth_scale), C.c_float(depth_max),
+        len(criteria), _p(iters), _p(rr), _p(rf),
+        C.c_float(depth_outlier_trunc), C.c_float(depth_huber_delta),
+        C.c_float(intensity_huber_delta), int(bool(accumulate_double)), _p(T),
+        C.byref(rmse), C.byref(fit), C.byref(it))
+    return {"status": int(st), "transformation": T, "inlier_rmse": rmse.value,
+            "fitness": fit.value, "iterations": it.value}

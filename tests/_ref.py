@@ -267,3 +267,109 @@ def transform_normals(T, nrm):
                                        int(nrm.dtype == np.float64)),
            "ref_transform_normals")
     return nrm
+
+
+# ---------------------------------------------------------------------------
+# RGB-D odometry front end: ImageCPU.cpp / RGBDOdometryCPU.cpp bodies
+# ---------------------------------------------------------------------------
+def _f32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def clip_transform(src, scale, min_value, max_value, clip_fill):
+    src = np.ascontiguousarray(src)
+    rows, cols = src.shape[:2]
+    dst = np.empty((rows, cols), np.float32)
+    _check(lib().ref_clip_transform(_p(src), int(src.dtype == np.float32),
+                                    C.c_int64(rows), C.c_int64(cols),
+                                    C.c_float(scale), C.c_float(min_value),
+                                    C.c_float(max_value), C.c_float(clip_fill),
+                                    _p(dst)), "ClipTransformCPU")
+    return dst
+
+
+def pyrdown_depth(src, depth_diff, invalid_fill):
+    src = _f32(src)
+    rows, cols = src.shape[:2]
+    dst = np.empty((rows // 2, cols // 2), np.float32)
+    _check(lib().ref_pyrdown_depth(_p(src), rows, cols, C.c_float(depth_diff),
+                                   C.c_float(invalid_fill), _p(dst)),
+           "PyrDownDepthCPU")
+    return dst
+
+
+def create_vertex_map(src, K, invalid_fill):
+    src = _f32(src)
+    rows, cols = src.shape[:2]
+    dst = np.empty((rows, cols, 3), np.float32)
+    _check(lib().ref_create_vertex_map(_p(src), C.c_int64(rows),
+                                       C.c_int64(cols), _p(_f64(K)),
+                                       C.c_float(invalid_fill), _p(dst)),
+           "CreateVertexMapCPU")
+    return dst
+
+
+def create_normal_map(src, invalid_fill):
+    src = _f32(src)
+    rows, cols = src.shape[:2]
+    dst = np.empty((rows, cols, 3), np.float32)
+    _check(lib().ref_create_normal_map(_p(src), C.c_int64(rows),
+                                       C.c_int64(cols),
+                                       C.c_float(invalid_fill), _p(dst)),
+           "CreateNormalMapCPU")
+    return dst
+
+
+def image_to_float(src, scale, offset=0.0):
+    src = np.ascontiguousarray(src)
+    code = {np.dtype(np.uint8): 0, np.dtype(np.uint16): 1,
+            np.dtype(np.float32): 2}[src.dtype]
+    dst = np.empty(src.shape, np.float32)
+    _check(lib().ref_image_to_float(_p(src), code, C.c_int64(src.size),
+                                    C.c_double(scale), C.c_double(offset),
+                                    _p(dst)), "ToCPU")
+    return dst
+
+
+def _opt32(a):
+    return None if a is None else _f32(a)
+
+
+def odometry(method, K, T, source_vertex, target_vertex=None,
+             target_normal=None, source_depth=None, target_depth=None,
+             source_intensity=None, target_intensity=None,
+             target_depth_dx=None, target_depth_dy=None,
+             target_intensity_dx=None, target_intensity_dy=None,
+             depth_outlier_trunc=0.07, depth_huber_delta=0.05,
+             intensity_huber_delta=0.1):
+    """Returns (delta pose {6}, residual float, count int, A_1x29 float sums)."""
+    sv = _f32(source_vertex)
+    rows, cols = sv.shape[:2]
+    arrs = [_opt32(a) for a in (source_depth, target_depth, source_intensity,
+                                target_intensity, target_depth_dx,
+                                target_depth_dy, target_intensity_dx,
+                                target_intensity_dy)]
+    tv, tn = _opt32(target_vertex), _opt32(target_normal)
+    delta = np.zeros(6, np.float64)
+    sums = np.zeros(29, np.float64)
+    res, cnt = C.c_float(0), C.c_int(0)
+    _check(lib().ref_odometry(int(method), rows, cols,
+                              *[_p(a) for a in arrs], _p(sv), _p(tv), _p(tn),
+                              _p(_f64(K)), _p(_f64(T)),
+                              C.c_float(depth_outlier_trunc),
+                              C.c_float(depth_huber_delta),
+                              C.c_float(intensity_huber_delta), _p(delta),
+                              C.byref(res), C.byref(cnt), _p(sums)),
+           "ComputeOdometryResultCPU")
+    return delta, res.value, cnt.value, sums
+
+
+def odometry_information(source_vertex, target_vertex, K, T, square_dist_thr):
+    sv, tv = _f32(source_vertex), _f32(target_vertex)
+    rows, cols = sv.shape[:2]
+    out = np.zeros((6, 6), np.float64)
+    _check(lib().ref_odometry_information(rows, cols, _p(sv), _p(tv),
+                                          _p(_f64(K)), _p(_f64(T)),
+                                          C.c_float(square_dist_thr), _p(out)),
+           "ComputeOdometryInformationMatrixCPU")
+    return out
