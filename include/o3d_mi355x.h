@@ -45,7 +45,8 @@ typedef enum {
     O3DMI_ERR_KEY_RANGE = 4,    /* |block coordinate| >= 2^20              */
     O3DMI_ERR_SINGULAR = 5,     /* singular 6x6 system                     */
     O3DMI_ERR_NO_BLOCKS = 6,    /* "No block is touched in TSDF volume"    */
-    O3DMI_ERR_UNSUPPORTED = 7
+    O3DMI_ERR_UNSUPPORTED = 7,
+    O3DMI_ERR_NO_INLIERS = 8    /* "Invalid inlier_count value, must be > 0." */
 } o3dmi_status_t;
 
 typedef enum {
@@ -296,6 +297,127 @@ int o3dmi_transform_normals(const double* transformation, void* normals_dev,
 int o3dmi_decode_and_solve6x6(const double* sums29_host, double* pose6,
                               float* residual, int* inlier_count);
 void o3dmi_pose_to_transformation(const double* pose6, double* T16);
+
+/* ------------------------------------------------------------------------ */
+/* RGB-D odometry front end                        */
+/* ------------------------------------------------------------------------ */
+/* odometry::Method, t/pipelines/odometry/RGBDOdometry.h:23-27 */
+typedef enum {
+    O3DMI_ODOMETRY_POINT_TO_PLANE = 0,
+    O3DMI_ODOMETRY_INTENSITY = 1,
+    O3DMI_ODOMETRY_HYBRID = 2
+} o3dmi_odometry_method_t;
+
+/* Image kernels: all images are contiguous {rows, cols[, C]} device buffers.
+ *
+ * ClipTransformCUDA (t/geometry/kernel/Image.h:88-93, ImageImpl.h:94-128):
+ * out = in / scale; out <= min -> fill; out >= max -> fill. src U16 or F32. */
+int o3dmi_image_clip_transform(const void* src_dev, int src_dtype, int rows,
+                               int cols, float scale, float min_value,
+                               float max_value, float clip_fill, float* dst_dev,
+                               o3dmi_stream_t stream);
+/* PyrDownDepthCUDA (Image.h:95-98, ImageImpl.h:132-206): dst {rows/2, cols/2};
+ * 5x5 Gaussian over the neighbours within depth_diff of the centre. */
+int o3dmi_image_pyrdown_depth(const float* src_dev, int rows, int cols,
+                              float depth_diff, float invalid_fill,
+                              float* dst_dev, o3dmi_stream_t stream);
+/* CreateVertexMapCUDA (Image.h:100-103, ImageImpl.h:208-256): dst {rows,cols,3};
+ * `intrinsics` host 3x3 float64. */
+int o3dmi_image_create_vertex_map(const float* src_dev, int rows, int cols,
+                                  const double* intrinsics, float invalid_fill,
+                                  float* dst_dev, o3dmi_stream_t stream);
+/* CreateNormalMapCUDA (Image.h:105-107, ImageImpl.h:257-322): src and dst
+ * {rows,cols,3}. */
+int o3dmi_image_create_normal_map(const float* src_dev, int rows, int cols,
+                                  float invalid_fill, float* dst_dev,
+                                  o3dmi_stream_t stream);
+/* ToCUDA (Image.h:83-86, ImageImpl.h:35-85) for U8 / U16 / F32 -> F32:
+ * out = in * scale + offset, saturated to the float limits as upstream. */
+int o3dmi_image_to_float(const void* src_dev, int src_dtype, int64_t n,
+                         double scale, double offset, float* dst_dev,
+                         o3dmi_stream_t stream);
+/* npp::RGBToGray (NPPImage.h:17; arithmetic of the in-tree tensor-op branch
+ * t/geometry/Image.cpp:149-161): {n,3} -> {n}, same dtype (U8 / U16 / F32). */
+int o3dmi_image_rgb_to_gray(const void* src_dev, int dtype, int64_t n_pixels,
+                            void* dst_dev, o3dmi_stream_t stream);
+/* RGBToGray().To(Float32) as RGBDOdometry.cpp:223-224 applies it (U8 colour is
+ * scaled by 1/255, F32 colour is not), in one pass. */
+int o3dmi_image_rgb_to_intensity(const void* src_dev, int dtype,
+                                 int64_t n_pixels, float* dst_dev,
+                                 o3dmi_stream_t stream);
+/* npp::FilterBilateral / FilterGaussian / FilterSobel / Resize (NPPImage.h:
+ * 27-48). The reference has no in-tree arithmetic for these (IPP / NPP);
+ * semantics: replicate border; bilateral over the circular neighbourhood of
+ * radius kernel_size/2 with w = exp(-dv^2/(2 sv^2)) exp(-d^2/(2 sd^2));
+ * Gaussian = outer product of normalised exp(-d^2/(2 s^2)) taps; Sobel 3x3
+ * unnormalised; Resize = nearest, factor 0.5. dst must not alias src. */
+int o3dmi_image_filter_bilateral(const float* src_dev, int rows, int cols,
+                                 int kernel_size, float value_sigma,
+                                 float distance_sigma, float* dst_dev,
+                                 o3dmi_stream_t stream);
+int o3dmi_image_filter_gaussian(const float* src_dev, int rows, int cols,
+                                int kernel_size, float sigma, float* dst_dev,
+                                o3dmi_stream_t stream);
+int o3dmi_image_filter_sobel(const float* src_dev, int rows, int cols,
+                             float* dx_dev, float* dy_dev,
+                             o3dmi_stream_t stream);
+int o3dmi_image_resize_half_nearest(const float* src_dev, int rows, int cols,
+                                    float* dst_dev, o3dmi_stream_t stream);
+/* Image::PyrDown (t/geometry/Image.cpp:404-407) = FilterGaussian(5, 1) +
+ * Resize(0.5, Nearest), evaluated at the kept pixels only. */
+int o3dmi_image_pyrdown(const float* src_dev, int rows, int cols,
+                        float* dst_dev, o3dmi_stream_t stream);
+
+/* One pyramid level of the point-to-plane method in a single pass
+ * (RGBDOdometry.cpp:124-153): source / target vertex maps and the target
+ * normal map of the bilateral-smoothed (5, 5, 10) target depth; NaN = invalid.
+ * Output identical to the CreateVertexMap / FilterBilateral / CreateNormalMap
+ * sequence above. */
+int o3dmi_odometry_p2plane_level(const float* source_depth_dev,
+                                 const float* target_depth_dev, int rows,
+                                 int cols, const double* intrinsics,
+                                 float* source_vertex_dev,
+                                 float* target_vertex_dev,
+                                 float* target_normal_dev,
+                                 o3dmi_stream_t stream);
+
+/* ComputeOdometryResult{PointToPlane,Intensity,Hybrid}CUDA up to the reduction
+ * (t/pipelines/kernel/RGBDOdometryImpl.h:74-118; per-pixel terms
+ * RGBDOdometryJacobianImpl.h:106-336, RGBDOdometryCPU.cpp:98-364): the 29
+ * sums (21 JtJ lower-triangular, 6 Jt*huber'(r), sum huber(r), count) as
+ * float64 in sums29_dev; per-pixel terms are float32 exactly as the
+ * reference, running sums float64 with a fixed tree. Maps a method does not
+ * read may be NULL. scratch_dev: NULL or o3dmi_odometry_sums_scratch_doubles()
+ * float64 (NULL allocates internally and synchronises). Solve on the host
+ * with o3dmi_decode_and_solve6x6 / o3dmi_pose_to_transformation. */
+int o3dmi_odometry_sums_scratch_doubles(void);
+int o3dmi_odometry_sums(int method, int rows, int cols,
+                        const float* source_depth_dev,
+                        const float* target_depth_dev,
+                        const float* source_intensity_dev,
+                        const float* target_intensity_dev,
+                        const float* target_depth_dx_dev,
+                        const float* target_depth_dy_dev,
+                        const float* target_intensity_dx_dev,
+                        const float* target_intensity_dy_dev,
+                        const float* source_vertex_dev,
+                        const float* target_vertex_dev,
+                        const float* target_normal_dev,
+                        const double* intrinsics,
+                        const double* init_source_to_target,
+                        float depth_outlier_trunc, float depth_huber_delta,
+                        float intensity_huber_delta, double* scratch_dev,
+                        double* sums29_dev, o3dmi_stream_t stream);
+/* ComputeOdometryInformationMatrixCUDA (RGBDOdometryImpl.h:120-125,
+ * RGBDOdometryCPU.cpp:26-96): information_host = 6x6 float64 on the host
+ * (synchronises). */
+int o3dmi_odometry_information(int rows, int cols,
+                               const float* source_vertex_dev,
+                               const float* target_vertex_dev,
+                               const double* intrinsics,
+                               const double* source_to_target,
+                               float square_dist_thr, double* information_host,
+                               o3dmi_stream_t stream);
 
 #ifdef __cplusplus
 }

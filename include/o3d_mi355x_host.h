@@ -188,6 +188,54 @@ int o3dmi_vbg_ray_cast(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
                        float trunc_voxel_multiplier, int range_map_down_factor,
                        o3dmi_stream_t stream);
 
+/* ------------------------------------------------------------------------ */
+/* RGB-D odometry (t/pipelines/odometry/RGBDOdometry.h)                      */
+/* ------------------------------------------------------------------------ */
+/* OdometryConvergenceCriteria (RGBDOdometry.h:30-57): defaults relative_rmse
+ * 1e-6, relative_fitness 1e-6. */
+typedef struct {
+    int max_iteration;
+    double relative_rmse;
+    double relative_fitness;
+} o3dmi_odometry_criteria_t;
+
+/* OdometryResult (RGBDOdometry.h:59-86) + the number of iterations run. */
+typedef struct {
+    double transformation[16]; /* 4x4 float64, row-major, host */
+    double inlier_rmse;
+    double fitness;
+    int num_iterations;
+} o3dmi_odometry_result_t;
+
+/* RGBDOdometryMultiScale(source, target, intrinsics, init_source_to_target,
+ * depth_scale, depth_max, criteria_list, method, params)
+ * (RGBDOdometry.cpp:56-108; drivers :110-380). depth {rows,cols} U16 or F32;
+ * colour {rows,cols,3} U8 or F32, may be NULL for point-to-plane; criteria are
+ * ordered coarse to fine, one per pyramid level; OdometryLossParams defaults
+ * (RGBDOdometry.h:88-120): depth_outlier_trunc 0.07, depth_huber_delta 0.05,
+ * intensity_huber_delta 0.1. init NULL = identity.
+ * Status: O3DMI_ERR_NO_INLIERS ("Invalid inlier_count value ..., must be > 0."),
+ * O3DMI_ERR_SINGULAR -- the reference's two exceptions on this path. */
+int o3dmi_rgbd_odometry_multiscale(
+        const void* source_depth_dev, const void* source_color_dev,
+        const void* target_depth_dev, const void* target_color_dev,
+        int depth_dtype, int color_dtype, int rows, int cols,
+        const double* intrinsics, const double* init_source_to_target,
+        float depth_scale, float depth_max, int n_levels,
+        const o3dmi_odometry_criteria_t* criteria, int method,
+        float depth_outlier_trunc, float depth_huber_delta,
+        float intensity_huber_delta, o3dmi_odometry_result_t* result,
+        o3dmi_stream_t stream);
+
+/* ComputeOdometryInformationMatrix(source_depth, target_depth, intrinsic,
+ * source_to_target, dist_thr, depth_scale, depth_max)
+ * (RGBDOdometry.cpp:488-513): 6x6 float64 on the host. */
+int o3dmi_rgbd_odometry_information_matrix(
+        const void* source_depth_dev, const void* target_depth_dev,
+        int depth_dtype, int rows, int cols, const double* intrinsics,
+        const double* source_to_target, float dist_thr, float depth_scale,
+        float depth_max, double* information_host, o3dmi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

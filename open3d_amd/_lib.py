@@ -76,6 +76,29 @@ PROTOTYPES = {
     "o3dmi_decode_and_solve6x6": (_i32, [_dp, _dp, C.POINTER(_f),
                                          C.POINTER(_i32)]),
     "o3dmi_pose_to_transformation": (None, [_dp, _dp]),
+    "o3dmi_image_clip_transform": (_i32, [_vp, _i32, _i32, _i32, _f, _f, _f,
+                                          _f, _vp, _vp]),
+    "o3dmi_image_pyrdown_depth": (_i32, [_vp, _i32, _i32, _f, _f, _vp, _vp]),
+    "o3dmi_image_create_vertex_map": (_i32, [_vp, _i32, _i32, _dp, _f, _vp,
+                                             _vp]),
+    "o3dmi_image_create_normal_map": (_i32, [_vp, _i32, _i32, _f, _vp, _vp]),
+    "o3dmi_image_to_float": (_i32, [_vp, _i32, _i64, _d, _d, _vp, _vp]),
+    "o3dmi_image_rgb_to_gray": (_i32, [_vp, _i32, _i64, _vp, _vp]),
+    "o3dmi_image_rgb_to_intensity": (_i32, [_vp, _i32, _i64, _vp, _vp]),
+    "o3dmi_image_filter_bilateral": (_i32, [_vp, _i32, _i32, _i32, _f, _f,
+                                            _vp, _vp]),
+    "o3dmi_image_filter_gaussian": (_i32, [_vp, _i32, _i32, _i32, _f, _vp,
+                                           _vp]),
+    "o3dmi_image_filter_sobel": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "o3dmi_image_resize_half_nearest": (_i32, [_vp, _i32, _i32, _vp, _vp]),
+    "o3dmi_image_pyrdown": (_i32, [_vp, _i32, _i32, _vp, _vp]),
+    "o3dmi_odometry_p2plane_level": (_i32, [_vp, _vp, _i32, _i32, _dp, _vp,
+                                            _vp, _vp, _vp]),
+    "o3dmi_odometry_sums_scratch_doubles": (_i32, []),
+    "o3dmi_odometry_sums": (_i32, [_i32, _i32, _i32] + [_vp] * 11 +
+                            [_dp, _dp, _f, _f, _f, _vp, _vp, _vp]),
+    "o3dmi_odometry_information": (_i32, [_i32, _i32, _vp, _vp, _dp, _dp, _f,
+                                          _dp, _vp]),
 }
 
 # include/o3d_mi355x_host.h
@@ -88,6 +111,16 @@ class RegistrationResultC(C.Structure):
     _fields_ = [("transformation", _d * 16), ("inlier_rmse", _d),
                 ("fitness", _d), ("converged", _i32),
                 ("num_iterations", _i32), ("num_correspondences", _i64)]
+
+
+class OdometryCriteriaC(C.Structure):
+    _fields_ = [("max_iteration", _i32), ("relative_rmse", _d),
+                ("relative_fitness", _d)]
+
+
+class OdometryResultC(C.Structure):
+    _fields_ = [("transformation", _d * 16), ("inlier_rmse", _d),
+                ("fitness", _d), ("num_iterations", _i32)]
 
 
 ICP_CALLBACK = C.CFUNCTYPE(None, _i64, _i64, _i64, _d, _d, _dp, _vp)
@@ -123,6 +156,12 @@ PROTOTYPES.update({
     "o3dmi_vbg_profile_begin": (_i32, [_vp, _i32, _i32]),
     "o3dmi_vbg_profile_end": (_i32, [_vp, _vp, C.POINTER(_d), C.POINTER(_i64),
                                      C.POINTER(_i64), C.POINTER(_i64)]),
+    "o3dmi_rgbd_odometry_multiscale": (
+        _i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _dp, _dp, _f, _f,
+               _i32, C.POINTER(OdometryCriteriaC), _i32, _f, _f, _f,
+               C.POINTER(OdometryResultC), _vp]),
+    "o3dmi_rgbd_odometry_information_matrix": (
+        _i32, [_vp, _vp, _i32, _i32, _i32, _dp, _dp, _f, _f, _f, _dp, _vp]),
     "o3dmi_vbg_ray_cast": (
         _i32, [_vp, _vp, _i64, _dp, _dp, _i32, _i32, _vp] + [_vp] * 10 +
         [_f, _f, _f, _f, _f, _i32, _vp]),

@@ -270,6 +270,8 @@ const char* o3dmi_status_string(int status) {
                    "Please check specified parameters, especially depth_scale "
                    "and voxel_size";
         case O3DMI_ERR_UNSUPPORTED: return "unsupported";
+        case O3DMI_ERR_NO_INLIERS:
+            return "Invalid inlier_count value, must be > 0.";
         default: return "unknown status";
     }
 }

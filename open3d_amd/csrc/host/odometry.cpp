@@ -1,0 +1,351 @@
+// Host-side RGB-D odometry driver for the MI355X backend: the control flow of
+// t::pipelines::odometry::RGBDOdometryMultiScale (cpp/open3d/t/pipelines/
+// odometry/RGBDOdometry.cpp:56-108) and its three per-method drivers
+// (:110-187 point-to-plane, :189-273 intensity, :275-380 hybrid), re-cut for
+// the GPU:
+//
+//   reference, per level                   here, per level
+//   -----------------------------------    ----------------------------------
+//   CreateVertexMap(source)                one launch (point-to-plane): both
+//   CreateVertexMap(target)                vertex maps + bilateral-smoothed
+//   FilterBilateral -> CreateVertexMap       target normals, nothing
+//     -> CreateNormalMap                     intermediate touches HBM
+//   PyrDownDepth x2                        PyrDownDepth x2 (PyrDown = Gaussian
+//   [PyrDown x2, FilterSobel x1-2]           evaluated at kept pixels only)
+//
+//   per iteration: kernel + .Item() syncs  29-sum kernel + final-sum kernel +
+//   + 6x6 solve on host                    one 232-byte D2H copy, then the
+//                                          same host solve (float64)
+//
+// All image buffers of a call come from one pooled slab; all work is issued on
+// the caller's stream; the only host waits are the per-iteration sums.
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../common.h"
+#include "o3d_mi355x_host.h"
+
+using namespace o3dmi;
+
+namespace {
+
+void Matmul4(const double* A, const double* B, double* C) {
+    double R[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double s = 0;
+            for (int k = 0; k < 4; ++k) s += A[i * 4 + k] * B[k * 4 + j];
+            R[i * 4 + j] = s;
+        }
+    std::memcpy(C, R, sizeof(R));
+}
+
+struct Level {
+    int rows = 0, cols = 0;
+    double K[9];
+    float *source_depth = nullptr, *target_depth = nullptr;
+    float *source_intensity = nullptr, *target_intensity = nullptr;
+    float *target_depth_dx = nullptr, *target_depth_dy = nullptr;
+    float *target_intensity_dx = nullptr, *target_intensity_dy = nullptr;
+    float *source_vertex = nullptr, *target_vertex = nullptr,
+          *target_normal = nullptr;
+};
+
+// Bump allocator over one pooled slab (256-byte aligned pieces).
+struct Slab {
+    char* base = nullptr;
+    size_t used = 0, size = 0;
+    float* Floats(size_t n) {
+        size_t bytes = (n * sizeof(float) + 255) & ~(size_t)255;
+        float* p = (float*)(base + used);
+        used += bytes;
+        return p;
+    }
+};
+
+size_t Padded(size_t n_floats) {
+    return (n_floats * sizeof(float) + 255) & ~(size_t)255;
+}
+
+}  // namespace
+
+extern "C" int o3dmi_rgbd_odometry_multiscale(
+        const void* source_depth_dev, const void* source_color_dev,
+        const void* target_depth_dev, const void* target_color_dev,
+        int depth_dtype, int color_dtype, int rows, int cols,
+        const double* intrinsics, const double* init_source_to_target,
+        float depth_scale, float depth_max, int n_levels,
+        const o3dmi_odometry_criteria_t* criteria, int method,
+        float depth_outlier_trunc, float depth_huber_delta,
+        float intensity_huber_delta, o3dmi_odometry_result_t* result,
+        o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(result != nullptr, "result is null");
+    O3DMI_REQUIRE(method >= 0 && method <= 2, "Odometry method not implemented.");
+    O3DMI_REQUIRE(source_depth_dev && target_depth_dev, "depth image is null");
+    O3DMI_REQUIRE(depth_dtype == O3DMI_U16 || depth_dtype == O3DMI_F32,
+                  "depth must be UInt16 or Float32");
+    O3DMI_REQUIRE(rows > 0 && cols > 0, "empty image");
+    O3DMI_REQUIRE(intrinsics != nullptr, "intrinsics is null");
+    O3DMI_REQUIRE(n_levels > 0 && n_levels <= 16 && criteria != nullptr,
+                  "criteria list is empty");
+    const bool use_intensity = method != O3DMI_ODOMETRY_POINT_TO_PLANE;
+    if (use_intensity) {
+        O3DMI_REQUIRE(source_color_dev && target_color_dev,
+                      "intensity / hybrid odometry needs colour images");
+        O3DMI_REQUIRE(color_dtype == O3DMI_U8 || color_dtype == O3DMI_F32,
+                      "colour must be UInt8 or Float32");
+    }
+    hipStream_t s = (hipStream_t)stream;
+
+    // ---- sizes of the whole pyramid ----------------------------------------
+    std::vector<Level> levels((size_t)n_levels);
+    size_t total = 0;
+    {
+        int r = rows, c = cols;
+        for (int i = 0; i < n_levels; ++i) {
+            const size_t n = (size_t)r * c;
+            // depth x2 (+ intensity x2) live at every level; per-method maps.
+            total += 2 * Padded(n);
+            total += 3 * Padded(3 * n);  // vertex maps / normal map (<= 3)
+            if (use_intensity) total += 2 * Padded(n) + 4 * Padded(n);
+            r /= 2;
+            c /= 2;
+            if (i + 1 < n_levels)
+                O3DMI_REQUIRE(r > 0 && c > 0, "too many pyramid levels");
+        }
+    }
+    const int n_scratch = o3dmi_odometry_sums_scratch_doubles();
+    const size_t sums_bytes = sizeof(double) * ((size_t)n_scratch + 32);
+    Slab slab;
+    int st = PoolAlloc((void**)&slab.base, total + sums_bytes + 256);
+    if (st) return st;
+    slab.size = total + sums_bytes + 256;
+    struct SlabFree {
+        hipStream_t s;
+        void* p;
+        ~SlabFree() {
+            (void)hipStreamSynchronize(s);
+            PoolFree(p);
+        }
+    } slab_free{s, slab.base};
+    double* scratch_dev = (double*)slab.base;
+    double* sums_dev = scratch_dev + n_scratch;
+    slab.used = (sums_bytes + 255) & ~(size_t)255;
+
+    double* sums_host = nullptr;
+    O3DMI_HIP_CHECK(hipHostMalloc((void**)&sums_host, sizeof(double) * 32));
+    struct HostFree {
+        double* p;
+        ~HostFree() { (void)hipHostFree(p); }
+    } host_free{sums_host};
+
+    // ---- pre-processing: RGBDOdometry.cpp:86-89, :223-228 --------------------
+    const float kNan = std::nanf("");
+    float* sd = slab.Floats((size_t)rows * cols);
+    float* td = slab.Floats((size_t)rows * cols);
+    if ((st = o3dmi_image_clip_transform(source_depth_dev, depth_dtype, rows,
+                                         cols, depth_scale, 0.0f, depth_max,
+                                         kNan, sd, stream)))
+        return st;
+    if ((st = o3dmi_image_clip_transform(target_depth_dev, depth_dtype, rows,
+                                         cols, depth_scale, 0.0f, depth_max,
+                                         kNan, td, stream)))
+        return st;
+    float *si = nullptr, *ti = nullptr;
+    if (use_intensity) {
+        si = slab.Floats((size_t)rows * cols);
+        ti = slab.Floats((size_t)rows * cols);
+        if ((st = o3dmi_image_rgb_to_intensity(source_color_dev, color_dtype,
+                                               (int64_t)rows * cols, si,
+                                               stream)))
+            return st;
+        if ((st = o3dmi_image_rgb_to_intensity(target_color_dev, color_dtype,
+                                               (int64_t)rows * cols, ti,
+                                               stream)))
+            return st;
+    }
+
+    // ---- pyramid, fine to coarse (stored coarse first) ------------------------
+    double Kp[9];
+    std::memcpy(Kp, intrinsics, sizeof(Kp));
+    int r = rows, c = cols;
+    for (int i = 0; i < n_levels; ++i) {
+        Level& L = levels[(size_t)(n_levels - 1 - i)];
+        L.rows = r;
+        L.cols = c;
+        std::memcpy(L.K, Kp, sizeof(Kp));
+        const size_t n = (size_t)r * c;
+        L.source_vertex = slab.Floats(3 * n);
+        if (method == O3DMI_ODOMETRY_POINT_TO_PLANE) {
+            L.target_vertex = slab.Floats(3 * n);
+            L.target_normal = slab.Floats(3 * n);
+            if ((st = o3dmi_odometry_p2plane_level(sd, td, r, c, Kp,
+                                                   L.source_vertex,
+                                                   L.target_vertex,
+                                                   L.target_normal, stream)))
+                return st;
+        } else {
+            if ((st = o3dmi_image_create_vertex_map(sd, r, c, Kp, kNan,
+                                                    L.source_vertex, stream)))
+                return st;
+            L.source_depth = sd;
+            L.target_depth = td;
+            L.source_intensity = si;
+            L.target_intensity = ti;
+            L.target_intensity_dx = slab.Floats(n);
+            L.target_intensity_dy = slab.Floats(n);
+            if ((st = o3dmi_image_filter_sobel(ti, r, c, L.target_intensity_dx,
+                                               L.target_intensity_dy, stream)))
+                return st;
+            if (method == O3DMI_ODOMETRY_HYBRID) {
+                L.target_depth_dx = slab.Floats(n);
+                L.target_depth_dy = slab.Floats(n);
+                if ((st = o3dmi_image_filter_sobel(td, r, c, L.target_depth_dx,
+                                                   L.target_depth_dy, stream)))
+                    return st;
+            }
+        }
+        if (i != n_levels - 1) {
+            const int r2 = r / 2, c2 = c / 2;
+            float* sd2 = slab.Floats((size_t)r2 * c2);
+            float* td2 = slab.Floats((size_t)r2 * c2);
+            if ((st = o3dmi_image_pyrdown_depth(sd, r, c,
+                                                depth_outlier_trunc * 2, kNan,
+                                                sd2, stream)))
+                return st;
+            if ((st = o3dmi_image_pyrdown_depth(td, r, c,
+                                                depth_outlier_trunc * 2, kNan,
+                                                td2, stream)))
+                return st;
+            if (use_intensity) {
+                float* si2 = slab.Floats((size_t)r2 * c2);
+                float* ti2 = slab.Floats((size_t)r2 * c2);
+                if ((st = o3dmi_image_pyrdown(si, r, c, si2, stream))) return st;
+                if ((st = o3dmi_image_pyrdown(ti, r, c, ti2, stream))) return st;
+                si = si2;
+                ti = ti2;
+            }
+            sd = sd2;
+            td = td2;
+            r = r2;
+            c = c2;
+            for (int k = 0; k < 9; ++k) Kp[k] /= 2;
+            Kp[8] = 1;
+        }
+    }
+    if (slab.used > slab.size) {
+        SetLastError("internal: odometry slab overrun");
+        return O3DMI_ERR_CAPACITY;
+    }
+
+    // ---- iterations, coarse to fine -------------------------------------------
+    double T[16];
+    if (init_source_to_target)
+        std::memcpy(T, init_source_to_target, sizeof(T));
+    else
+        for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    double inlier_rmse = 0.0, fitness = 1.0;
+    int iterations = 0;
+    for (int i = 0; i < n_levels; ++i) {
+        const Level& L = levels[(size_t)i];
+        for (int iter = 0; iter < criteria[i].max_iteration; ++iter) {
+            if ((st = o3dmi_odometry_sums(
+                         method, L.rows, L.cols, L.source_depth, L.target_depth,
+                         L.source_intensity, L.target_intensity,
+                         L.target_depth_dx, L.target_depth_dy,
+                         L.target_intensity_dx, L.target_intensity_dy,
+                         L.source_vertex, L.target_vertex, L.target_normal, L.K,
+                         T, depth_outlier_trunc, depth_huber_delta,
+                         intensity_huber_delta, scratch_dev, sums_dev, stream)))
+                return st;
+            O3DMI_HIP_CHECK(hipMemcpyAsync(sums_host, sums_dev,
+                                           sizeof(double) * 29,
+                                           hipMemcpyDeviceToHost, s));
+            O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+            double pose[6], dT[16];
+            float residual;
+            int count;
+            if ((st = o3dmi_decode_and_solve6x6(sums_host, pose, &residual,
+                                                &count)))
+                return st;
+            if (count <= 0) {
+                SetLastError("Invalid inlier_count value " +
+                             std::to_string(count) + ", must be > 0.");
+                return O3DMI_ERR_NO_INLIERS;
+            }
+            o3dmi_pose_to_transformation(pose, dT);
+            // OdometryResult(T, inlier_residual / inlier_count, count / (H*W)),
+            // RGBDOdometry.cpp:404-409.
+            const double delta_rmse = (double)(residual / count);
+            const double delta_fitness =
+                    double(count) / double((int64_t)L.rows * L.cols);
+            Matmul4(dT, T, T);
+            ++iterations;
+            // RGBDOdometry.cpp:168-176 (relative change; NaN / inf on the
+            // first iteration of a call never satisfies the test).
+            if (std::abs(fitness - delta_fitness) / fitness <
+                        criteria[i].relative_fitness &&
+                std::abs(inlier_rmse - delta_rmse) / inlier_rmse <
+                        criteria[i].relative_rmse) {
+                break;
+            }
+            inlier_rmse = delta_rmse;
+            fitness = delta_fitness;
+        }
+    }
+    std::memcpy(result->transformation, T, sizeof(T));
+    result->inlier_rmse = inlier_rmse;
+    result->fitness = fitness;
+    result->num_iterations = iterations;
+    return O3DMI_OK;
+}
+
+// ComputeOdometryInformationMatrix(source_depth, target_depth, intrinsic,
+// source_to_target, dist_thr, depth_scale, depth_max), RGBDOdometry.cpp:488-513.
+extern "C" int o3dmi_rgbd_odometry_information_matrix(
+        const void* source_depth_dev, const void* target_depth_dev,
+        int depth_dtype, int rows, int cols, const double* intrinsics,
+        const double* source_to_target, float dist_thr, float depth_scale,
+        float depth_max, double* information_host, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(source_depth_dev && target_depth_dev && intrinsics &&
+                          source_to_target && information_host,
+                  "null argument");
+    O3DMI_REQUIRE(rows > 0 && cols > 0, "empty image");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)rows * cols;
+    Slab slab;
+    int st = PoolAlloc((void**)&slab.base, 2 * Padded(n) + 2 * Padded(3 * n));
+    if (st) return st;
+    struct SlabFree {
+        hipStream_t s;
+        void* p;
+        ~SlabFree() {
+            (void)hipStreamSynchronize(s);
+            PoolFree(p);
+        }
+    } slab_free{s, slab.base};
+    const float kNan = std::nanf("");
+    float* sd = slab.Floats(n);
+    float* td = slab.Floats(n);
+    float* sv = slab.Floats(3 * n);
+    float* tv = slab.Floats(3 * n);
+    if ((st = o3dmi_image_clip_transform(source_depth_dev, depth_dtype, rows,
+                                         cols, depth_scale, 0.0f, depth_max,
+                                         kNan, sd, stream)))
+        return st;
+    if ((st = o3dmi_image_clip_transform(target_depth_dev, depth_dtype, rows,
+                                         cols, depth_scale, 0.0f, depth_max,
+                                         kNan, td, stream)))
+        return st;
+    if ((st = o3dmi_image_create_vertex_map(sd, rows, cols, intrinsics, kNan, sv,
+                                            stream)))
+        return st;
+    if ((st = o3dmi_image_create_vertex_map(td, rows, cols, intrinsics, kNan, tv,
+                                            stream)))
+        return st;
+    return o3dmi_odometry_information(rows, cols, sv, tv, intrinsics,
+                                      source_to_target, dist_thr * dist_thr,
+                                      information_host, stream);
+}

@@ -1,0 +1,71 @@
+// Deterministic N-value sum reduction for the Gauss-Newton style kernels
+// (29 sums of RGB-D odometry, 21 sums of the information matrix): float64
+// running sums per lane, wave64 __shfl_down tree, LDS across the waves of a
+// workgroup, one partial row per workgroup, and a single-workgroup final pass
+// over the rows. The launch geometry is a function of the element count only,
+// so results are run-to-run identical (the reference's TBB parallel_reduce /
+// CUDA atomicAdd versions are not: RGBDOdometryCPU.cpp:315-360,
+// RGBDOdometryCUDA.cu).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace o3dmi {
+
+constexpr int kSumsBlock = 256;
+constexpr int kSumsMaxGrid = 1024;  // 4 workgroups per CU
+
+inline int SumsGrid(int64_t n) {
+    int64_t g = (n + kSumsBlock - 1) / kSumsBlock;
+    if (g > kSumsMaxGrid) g = kSumsMaxGrid;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// partials: [gridDim.x][N] float64.
+template <int N>
+__device__ __forceinline__ void BlockSumAndStore(double (&A)[N],
+                                                 double* __restrict__ partials) {
+    __shared__ double lds[kSumsBlock / 64][N];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double v = A[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) lds[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < N) {
+        double v = 0;
+#pragma unroll
+        for (int wv = 0; wv < kSumsBlock / 64; ++wv) v += lds[wv][threadIdx.x];
+        partials[(int64_t)blockIdx.x * N + threadIdx.x] = v;
+    }
+}
+
+// One workgroup of 256 lanes: lane (r, c) = (tid / 32, tid % 32) strides over
+// the rows, 8 row-lanes are then added in a fixed order. N <= 32.
+template <int N>
+__global__ void FinalSumKernel(const double* __restrict__ partials, int n_rows,
+                               double* __restrict__ out) {
+    __shared__ double lds[8][32];
+    const int col = threadIdx.x & 31;
+    const int rl = threadIdx.x >> 5;
+    double v = 0;
+    if (col < N)
+        for (int r = rl; r < n_rows; r += 8) v += partials[(int64_t)r * N + col];
+    lds[rl][col] = v;
+    __syncthreads();
+    if (threadIdx.x < N) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += lds[k][threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+}
+
+}  // namespace o3dmi
