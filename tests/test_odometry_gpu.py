@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import _oracle as orc
-from test_odometry_oracle import NAN, _holes, _levels, _pair, same_bits
+from test_odometry_oracle import NAN, _holes, _levels, _pair
 
 pytestmark = pytest.mark.gpu
 
@@ -21,6 +21,23 @@ def _gpu():
         pytest.skip("needs a GPU")
     from open3d_amd import odometry
     return odometry
+
+
+def same_bits(a, b):
+    """Bit-identical values; NaNs match NaNs whatever their sign / payload (an
+    x86 invalid operation yields the negative default NaN, the GPU the
+    positive one -- neither is a value)."""
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    if a.shape != b.shape or a.dtype != b.dtype:
+        return False
+    if a.dtype.kind != "f":
+        return a.tobytes() == b.tobytes()
+    na, nb = np.isnan(a), np.isnan(b)
+    if not np.array_equal(na, nb):
+        return False
+    iv = a.view(np.uint32 if a.dtype == np.float32 else np.uint64)
+    jv = b.view(iv.dtype)
+    return bool(np.array_equal(iv[~na], jv[~nb]))
 
 
 def _dev(a):
