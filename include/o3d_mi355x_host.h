@@ -210,7 +210,9 @@ typedef struct {
 /* RGBDOdometryMultiScale(source, target, intrinsics, init_source_to_target,
  * depth_scale, depth_max, criteria_list, method, params)
  * (RGBDOdometry.cpp:56-108; drivers :110-380). depth {rows,cols} U16 or F32;
- * colour {rows,cols,3} U8 or F32, may be NULL for point-to-plane; criteria are
+ * colour {rows,cols,3} U8 or F32, may be NULL for point-to-plane; source and
+ * target dtypes are independent (slam::Model tracks a U16 / U8 input frame
+ * against the F32 ray-cast frame, slam/Model.cpp:72-92); criteria are
  * ordered coarse to fine, one per pyramid level; OdometryLossParams defaults
  * (RGBDOdometry.h:88-120): depth_outlier_trunc 0.07, depth_huber_delta 0.05,
  * intensity_huber_delta 0.1. init NULL = identity.
@@ -219,9 +221,10 @@ typedef struct {
 int o3dmi_rgbd_odometry_multiscale(
         const void* source_depth_dev, const void* source_color_dev,
         const void* target_depth_dev, const void* target_color_dev,
-        int depth_dtype, int color_dtype, int rows, int cols,
-        const double* intrinsics, const double* init_source_to_target,
-        float depth_scale, float depth_max, int n_levels,
+        int source_depth_dtype, int source_color_dtype, int target_depth_dtype,
+        int target_color_dtype, int rows, int cols, const double* intrinsics,
+        const double* init_source_to_target, float depth_scale,
+        float depth_max, int n_levels,
         const o3dmi_odometry_criteria_t* criteria, int method,
         float depth_outlier_trunc, float depth_huber_delta,
         float intensity_huber_delta, o3dmi_odometry_result_t* result,

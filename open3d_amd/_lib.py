@@ -157,8 +157,9 @@ PROTOTYPES.update({
     "o3dmi_vbg_profile_end": (_i32, [_vp, _vp, C.POINTER(_d), C.POINTER(_i64),
                                      C.POINTER(_i64), C.POINTER(_i64)]),
     "o3dmi_rgbd_odometry_multiscale": (
-        _i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _dp, _dp, _f, _f,
-               _i32, C.POINTER(OdometryCriteriaC), _i32, _f, _f, _f,
+        _i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _dp,
+               _dp, _f, _f, _i32, C.POINTER(OdometryCriteriaC), _i32, _f, _f,
+               _f,
                C.POINTER(OdometryResultC), _vp]),
     "o3dmi_rgbd_odometry_information_matrix": (
         _i32, [_vp, _vp, _i32, _i32, _i32, _dp, _dp, _f, _f, _f, _dp, _vp]),

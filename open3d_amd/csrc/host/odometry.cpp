@@ -74,9 +74,10 @@ size_t Padded(size_t n_floats) {
 extern "C" int o3dmi_rgbd_odometry_multiscale(
         const void* source_depth_dev, const void* source_color_dev,
         const void* target_depth_dev, const void* target_color_dev,
-        int depth_dtype, int color_dtype, int rows, int cols,
-        const double* intrinsics, const double* init_source_to_target,
-        float depth_scale, float depth_max, int n_levels,
+        int source_depth_dtype, int source_color_dtype, int target_depth_dtype,
+        int target_color_dtype, int rows, int cols, const double* intrinsics,
+        const double* init_source_to_target, float depth_scale,
+        float depth_max, int n_levels,
         const o3dmi_odometry_criteria_t* criteria, int method,
         float depth_outlier_trunc, float depth_huber_delta,
         float intensity_huber_delta, o3dmi_odometry_result_t* result,
@@ -84,7 +85,10 @@ extern "C" int o3dmi_rgbd_odometry_multiscale(
     O3DMI_REQUIRE(result != nullptr, "result is null");
     O3DMI_REQUIRE(method >= 0 && method <= 2, "Odometry method not implemented.");
     O3DMI_REQUIRE(source_depth_dev && target_depth_dev, "depth image is null");
-    O3DMI_REQUIRE(depth_dtype == O3DMI_U16 || depth_dtype == O3DMI_F32,
+    O3DMI_REQUIRE((source_depth_dtype == O3DMI_U16 ||
+                   source_depth_dtype == O3DMI_F32) &&
+                          (target_depth_dtype == O3DMI_U16 ||
+                           target_depth_dtype == O3DMI_F32),
                   "depth must be UInt16 or Float32");
     O3DMI_REQUIRE(rows > 0 && cols > 0, "empty image");
     O3DMI_REQUIRE(intrinsics != nullptr, "intrinsics is null");
@@ -94,7 +98,10 @@ extern "C" int o3dmi_rgbd_odometry_multiscale(
     if (use_intensity) {
         O3DMI_REQUIRE(source_color_dev && target_color_dev,
                       "intensity / hybrid odometry needs colour images");
-        O3DMI_REQUIRE(color_dtype == O3DMI_U8 || color_dtype == O3DMI_F32,
+        O3DMI_REQUIRE((source_color_dtype == O3DMI_U8 ||
+                       source_color_dtype == O3DMI_F32) &&
+                              (target_color_dtype == O3DMI_U8 ||
+                               target_color_dtype == O3DMI_F32),
                       "colour must be UInt8 or Float32");
     }
     hipStream_t s = (hipStream_t)stream;
@@ -145,23 +152,25 @@ extern "C" int o3dmi_rgbd_odometry_multiscale(
     const float kNan = std::nanf("");
     float* sd = slab.Floats((size_t)rows * cols);
     float* td = slab.Floats((size_t)rows * cols);
-    if ((st = o3dmi_image_clip_transform(source_depth_dev, depth_dtype, rows,
-                                         cols, depth_scale, 0.0f, depth_max,
-                                         kNan, sd, stream)))
+    if ((st = o3dmi_image_clip_transform(source_depth_dev, source_depth_dtype,
+                                         rows, cols, depth_scale, 0.0f,
+                                         depth_max, kNan, sd, stream)))
         return st;
-    if ((st = o3dmi_image_clip_transform(target_depth_dev, depth_dtype, rows,
-                                         cols, depth_scale, 0.0f, depth_max,
-                                         kNan, td, stream)))
+    if ((st = o3dmi_image_clip_transform(target_depth_dev, target_depth_dtype,
+                                         rows, cols, depth_scale, 0.0f,
+                                         depth_max, kNan, td, stream)))
         return st;
     float *si = nullptr, *ti = nullptr;
     if (use_intensity) {
         si = slab.Floats((size_t)rows * cols);
         ti = slab.Floats((size_t)rows * cols);
-        if ((st = o3dmi_image_rgb_to_intensity(source_color_dev, color_dtype,
+        if ((st = o3dmi_image_rgb_to_intensity(source_color_dev,
+                                               source_color_dtype,
                                                (int64_t)rows * cols, si,
                                                stream)))
             return st;
-        if ((st = o3dmi_image_rgb_to_intensity(target_color_dev, color_dtype,
+        if ((st = o3dmi_image_rgb_to_intensity(target_color_dev,
+                                               target_color_dtype,
                                                (int64_t)rows * cols, ti,
                                                stream)))
             return st;

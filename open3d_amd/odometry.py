@@ -64,8 +64,9 @@ def rgbd_odometry_multi_scale(source_depth, target_depth, intrinsics,
     (the reference's implicit int -> criteria conversion)."""
     sd = _img2(source_depth, "source depth")
     td = _img2(target_depth, "target depth")
-    if sd.dtype not in (torch.uint16, torch.float32) or td.dtype != sd.dtype:
-        raise ValueError("depth must be UInt16 or Float32 (same for both)")
+    for d in (sd, td):
+        if d.dtype not in (torch.uint16, torch.float32):
+            raise ValueError("depth must be UInt16 or Float32")
     if sd.shape != td.shape:
         raise ValueError("source / target size mismatch")
     K = host_mat(intrinsics, (3, 3), "intrinsics")
@@ -79,21 +80,21 @@ def rgbd_odometry_multi_scale(source_depth, target_depth, intrinsics,
         _lib.OdometryCriteriaC(c.max_iteration, c.relative_rmse,
                                c.relative_fitness) for c in crit])
     sc = tc = None
-    cdt = _lib.U8
+    scdt = tcdt = _lib.U8
     if source_color is not None or target_color is not None:
         sc = require_cuda(source_color, "source color")
         tc = require_cuda(target_color, "target color")
-        if sc.dtype != tc.dtype or sc.dtype not in (torch.uint8,
-                                                    torch.float32):
-            raise ValueError("colour must be UInt8 or Float32")
-        if tuple(sc.shape) != (sd.shape[0], sd.shape[1], 3) or \
-                sc.shape != tc.shape:
-            raise ValueError("colour must be {rows, cols, 3}")
-        cdt = TORCH_TO_O3DMI[sc.dtype]
+        for c in (sc, tc):
+            if c.dtype not in (torch.uint8, torch.float32):
+                raise ValueError("colour must be UInt8 or Float32")
+            if tuple(c.shape) != (sd.shape[0], sd.shape[1], 3):
+                raise ValueError("colour must be {rows, cols, 3}")
+        scdt, tcdt = TORCH_TO_O3DMI[sc.dtype], TORCH_TO_O3DMI[tc.dtype]
     res = _lib.OdometryResultC()
     st = _lib.lib().o3dmi_rgbd_odometry_multiscale(
         _lib.ptr(sd), _lib.ptr(sc), _lib.ptr(td), _lib.ptr(tc),
-        TORCH_TO_O3DMI[sd.dtype], cdt, sd.shape[0], sd.shape[1],
+        TORCH_TO_O3DMI[sd.dtype], scdt, TORCH_TO_O3DMI[td.dtype], tcdt,
+        sd.shape[0], sd.shape[1],
         _lib.f64p(K), _lib.f64p(init), C.c_float(depth_scale),
         C.c_float(depth_max), len(crit), cc, int(method),
         C.c_float(params.depth_outlier_trunc),

@@ -707,9 +707,13 @@ struct OdoResult {
 
 // RGBDOdometryMultiScale, RGBDOdometry.cpp:56-108 and the three per-method
 // drivers :110-187, :189-273, :275-380.
-template <typename ACC, typename S>
-OdoResult MultiScale(int method, const S* src_depth, const void* src_color,
-                     const S* tgt_depth, const void* tgt_color, int color_is_f32,
+// Source and target may differ in dtype (slam::Model tracks a UInt16 / UInt8
+// input frame against the Float32 ray-cast model frame, Model.cpp:72-92).
+template <typename ACC>
+OdoResult MultiScale(int method, const void* src_depth, int src_depth_is_f32,
+                     const void* src_color, int src_color_is_f32,
+                     const void* tgt_depth, int tgt_depth_is_f32,
+                     const void* tgt_color, int tgt_color_is_f32,
                      int rows, int cols, const double* intrinsics,
                      const double* init, float depth_scale, float depth_max,
                      int n_levels, const int* max_iterations,
@@ -718,11 +722,19 @@ OdoResult MultiScale(int method, const S* src_depth, const void* src_color,
                      float depth_huber_delta, float intensity_huber_delta) {
     std::vector<Level> levels((size_t)n_levels);
     std::vector<float> sd, td, si, tis;
-    PrepareDepth<S>(src_depth, rows, cols, depth_scale, depth_max, sd);
-    PrepareDepth<S>(tgt_depth, rows, cols, depth_scale, depth_max, td);
+    auto prepare_depth = [&](const void* d, int is_f32, std::vector<float>& o) {
+        if (is_f32)
+            PrepareDepth<float>((const float*)d, rows, cols, depth_scale,
+                                depth_max, o);
+        else
+            PrepareDepth<uint16_t>((const uint16_t*)d, rows, cols, depth_scale,
+                                   depth_max, o);
+    };
+    prepare_depth(src_depth, src_depth_is_f32, sd);
+    prepare_depth(tgt_depth, tgt_depth_is_f32, td);
     if (method != kP2Plane) {
-        PrepareIntensity(src_color, color_is_f32, rows, cols, si);
-        PrepareIntensity(tgt_color, color_is_f32, rows, cols, tis);
+        PrepareIntensity(src_color, src_color_is_f32, rows, cols, si);
+        PrepareIntensity(tgt_color, tgt_color_is_f32, rows, cols, tis);
     }
     double Kp[9];
     std::memcpy(Kp, intrinsics, sizeof(Kp));
@@ -963,12 +975,13 @@ void orc_odometry_information(int rows, int cols, const float* source_vertex,
 }
 
 // RGBDOdometryMultiScale. depth: u16 or f32 {H,W}; color: u8 or f32 {H,W,3}
-// (may be NULL for point-to-plane). Returns status (0 ok, 1 invalid inlier
-// count, 2 singular system).
+// (may be NULL for point-to-plane); source and target dtypes are independent.
+// Returns status (0 ok, 1 invalid inlier count, 2 singular system).
 int orc_rgbd_odometry_multiscale(
         int method, const void* src_depth, const void* src_color,
-        const void* tgt_depth, const void* tgt_color, int depth_is_f32,
-        int color_is_f32, int rows, int cols, const double* intrinsics,
+        const void* tgt_depth, const void* tgt_color, int src_depth_is_f32,
+        int tgt_depth_is_f32, int src_color_is_f32, int tgt_color_is_f32,
+        int rows, int cols, const double* intrinsics,
         const double* init_source_to_target, float depth_scale, float depth_max,
         int n_levels, const int* max_iterations, const double* relative_rmse,
         const double* relative_fitness, float depth_outlier_trunc,
@@ -976,19 +989,15 @@ int orc_rgbd_odometry_multiscale(
         int accumulate_double, double* T_out, double* rmse_out,
         double* fitness_out, int* iterations_out) {
     OdoResult r;
-#define ORC_CALL(ACC, S)                                                        \
-    r = MultiScale<ACC, S>(method, (const S*)src_depth, src_color,             \
-                           (const S*)tgt_depth, tgt_color, color_is_f32, rows, \
-                           cols, intrinsics, init_source_to_target,            \
-                           depth_scale, depth_max, n_levels, max_iterations,   \
-                           relative_rmse, relative_fitness,                    \
-                           depth_outlier_trunc, depth_huber_delta,             \
-                           intensity_huber_delta)
-    if (accumulate_double) {
-        if (depth_is_f32) ORC_CALL(double, float); else ORC_CALL(double, uint16_t);
-    } else {
-        if (depth_is_f32) ORC_CALL(float, float); else ORC_CALL(float, uint16_t);
-    }
+#define ORC_CALL(ACC)                                                          \
+    r = MultiScale<ACC>(method, src_depth, src_depth_is_f32, src_color,        \
+                        src_color_is_f32, tgt_depth, tgt_depth_is_f32,         \
+                        tgt_color, tgt_color_is_f32, rows, cols, intrinsics,   \
+                        init_source_to_target, depth_scale, depth_max,         \
+                        n_levels, max_iterations, relative_rmse,               \
+                        relative_fitness, depth_outlier_trunc,                 \
+                        depth_huber_delta, intensity_huber_delta)
+    if (accumulate_double) ORC_CALL(double); else ORC_CALL(float);
 #undef ORC_CALL
     std::memcpy(T_out, r.T, sizeof(r.T));
     *rmse_out = r.inlier_rmse;

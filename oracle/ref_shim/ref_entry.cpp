@@ -268,6 +268,53 @@ int ref_raycast(const int* hash_keys, const int* hash_buf_indices,
     });
 }
 
+// ExtractPointCloudCPU<...>, VoxelBlockGridImpl.h:1122-1365 (instantiations
+// VoxelBlockGridCPU.cpp:234-245). nb tables are {27, n, 1} as
+// BufferRadiusNeighbors builds them. valid_size < 0 runs the counting pass.
+// Returns the number of points (total count), -1 on error. Output order is
+// the atomic counter's (sequential with ref_set_threads(1)).
+int64_t ref_extract_point_cloud(const int* indices, const int* nb_indices,
+                                const uint8_t* nb_masks, const int* block_keys,
+                                int64_t capacity, const float* tsdf,
+                                const void* weight, const void* color_buf,
+                                int grid_is_f32, int64_t n_blocks,
+                                int resolution, float voxel_size,
+                                float weight_threshold, float* points,
+                                float* normals, float* colors,
+                                int64_t out_capacity, int valid_size_in) {
+    int valid_size = valid_size_in;
+    int rc = Guard([&] {
+        const core::Dtype gdt = grid_is_f32 ? core::Float32 : core::UInt16;
+        const int64_t r = resolution;
+        Tensor idx = Wrap(indices, {n_blocks}, core::Int32);
+        Tensor nbi = Wrap(nb_indices, {27, n_blocks, 1}, core::Int32);
+        Tensor nbm = Wrap(nb_masks, {27, n_blocks, 1}, core::Bool);
+        Tensor keys = Wrap(block_keys, {capacity, 3}, core::Int32);
+        t::geometry::TensorMap vm("tsdf");
+        vm["tsdf"] = Wrap(tsdf, {capacity, r, r, r, 1}, core::Float32);
+        vm["weight"] = Wrap(weight, {capacity, r, r, r, 1}, gdt);
+        if (color_buf) vm["color"] = Wrap(color_buf, {capacity, r, r, r, 3}, gdt);
+        Tensor p, n, c;
+        if (grid_is_f32)
+            vg::ExtractPointCloudCPU<float, float, float>(
+                    idx, nbi, nbm, keys, vm, p, n, c, resolution, voxel_size,
+                    weight_threshold, valid_size);
+        else
+            vg::ExtractPointCloudCPU<float, uint16_t, uint16_t>(
+                    idx, nbi, nbm, keys, vm, p, n, c, resolution, voxel_size,
+                    weight_threshold, valid_size);
+        int64_t m = std::min<int64_t>(std::min<int64_t>(valid_size, p.GetLength()),
+                                      out_capacity);
+        if (points && m > 0)
+            std::memcpy(points, p.GetDataPtr<float>(), sizeof(float) * 3 * m);
+        if (normals && m > 0)
+            std::memcpy(normals, n.GetDataPtr<float>(), sizeof(float) * 3 * m);
+        if (colors && color_buf && m > 0)
+            std::memcpy(colors, c.GetDataPtr<float>(), sizeof(float) * 3 * m);
+    });
+    return rc == 0 ? (int64_t)valid_size : -1;
+}
+
 // UnprojectCPU, t/geometry/kernel/PointCloudImpl.h:42-143.
 int64_t ref_unproject(const void* depth, int depth_is_f32, int rows, int cols,
                       const float* colors_f32, float* points, float* colors,

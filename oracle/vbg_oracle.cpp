@@ -782,6 +782,127 @@ int64_t UnprojectImpl(const depth_t* depth, int rows, int cols,
     return count;
 }
 
+// ---------------------------------------------------------------------------
+// ExtractPointCloudCPU, VoxelBlockGridImpl.h:1122-1365 with DeviceGetLinearIdx
+// / DeviceGetNormal (:94-149). Sequential: output order = workload order
+// (active block, voxel, axis); the reference's order is whatever its atomic
+// counter hands out. nb_indices / nb_masks are the {27, n} tables of
+// BufferRadiusNeighbors (VoxelBlockGrid.cpp:22-51).
+//
+// `sqrt` in ExtractPointCloudCPU is unqualified; with libstdc++'s <cmath> the
+// float overload is visible in the global namespace, so this is a float sqrt
+// whose result is then added to the double literal 1e-5 (checked against the
+// compiled reference body: the float -> double variant differs by 1 ulp).
+#define EXTRACT_SQRT(v) std::sqrt((float)(v))
+
+inline int64_t ExtractLinearIdx(int xo, int yo, int zo, int64_t curr_block_idx,
+                                int resolution, int64_t n_blocks,
+                                const int* nb_indices, const uint8_t* nb_masks) {
+    int xn = (xo + resolution) % resolution;
+    int yn = (yo + resolution) % resolution;
+    int zn = (zo + resolution) % resolution;
+    int dxb = orc::Sign(xo - xn);
+    int dyb = orc::Sign(yo - yn);
+    int dzb = orc::Sign(zo - zn);
+    int nb_idx = (dxb + 1) + (dyb + 1) * 3 + (dzb + 1) * 9;
+    if (!nb_masks[(int64_t)nb_idx * n_blocks + curr_block_idx]) return -1;
+    int64_t block_idx_i = nb_indices[(int64_t)nb_idx * n_blocks + curr_block_idx];
+    return (((block_idx_i * resolution) + zn) * resolution + yn) * resolution +
+           xn;
+}
+
+template <typename weight_t, typename color_t>
+int64_t ExtractPointCloudImpl(const int* indices, const int* nb_indices,
+                              const uint8_t* nb_masks, const int* block_keys,
+                              const float* tsdf_base_ptr,
+                              const weight_t* weight_base_ptr,
+                              const color_t* color_base_ptr, int64_t n_blocks,
+                              int resolution, float voxel_size,
+                              float weight_threshold, float* points,
+                              float* normals, float* colors,
+                              int64_t valid_size) {
+    const int64_t resolution3 = (int64_t)resolution * resolution * resolution;
+    auto L = [&](int xo, int yo, int zo, int64_t b) {
+        return ExtractLinearIdx(xo, yo, zo, b, resolution, n_blocks, nb_indices,
+                                nb_masks);
+    };
+    auto GetNormal = [&](int xo, int yo, int zo, int64_t b, float* n) {
+        int64_t vxp = L(xo + 1, yo, zo, b), vxn = L(xo - 1, yo, zo, b);
+        int64_t vyp = L(xo, yo + 1, zo, b), vyn = L(xo, yo - 1, zo, b);
+        int64_t vzp = L(xo, yo, zo + 1, b), vzn = L(xo, yo, zo - 1, b);
+        if (vxp >= 0 && vxn >= 0) n[0] = tsdf_base_ptr[vxp] - tsdf_base_ptr[vxn];
+        if (vyp >= 0 && vyn >= 0) n[1] = tsdf_base_ptr[vyp] - tsdf_base_ptr[vyn];
+        if (vzp >= 0 && vzn >= 0) n[2] = tsdf_base_ptr[vzp] - tsdf_base_ptr[vzn];
+    };
+    int64_t count = 0;
+    const int64_t n = n_blocks * resolution3;
+    for (int64_t workload_idx = 0; workload_idx < n; ++workload_idx) {
+        int64_t workload_block_idx = workload_idx / resolution3;
+        int64_t block_idx = indices[workload_block_idx];
+        int64_t voxel_idx = workload_idx % resolution3;
+        const int* key = block_keys + 3 * block_idx;
+        int xb = key[0], yb = key[1], zb = key[2];
+        int xv = (int)(voxel_idx % resolution);
+        int yv = (int)((voxel_idx / resolution) % resolution);
+        int zv = (int)(voxel_idx / ((int64_t)resolution * resolution));
+        int64_t linear_idx = block_idx * resolution3 + voxel_idx;
+        float tsdf_o = tsdf_base_ptr[linear_idx];
+        float weight_o = weight_base_ptr[linear_idx];
+        if (weight_o <= weight_threshold) continue;
+        // no / ne persist across the three axes of a voxel exactly as in the
+        // reference (ne is NOT reset between axes).
+        float no[3] = {0}, ne[3] = {0};
+        if (points) GetNormal(xv, yv, zv, workload_block_idx, no);
+        int x = xb * resolution + xv;
+        int y = yb * resolution + yv;
+        int z = zb * resolution + zv;
+        for (int i = 0; i < 3; ++i) {
+            int64_t linear_idx_i = L(xv + (i == 0), yv + (i == 1), zv + (i == 2),
+                                     workload_block_idx);
+            if (linear_idx_i < 0) continue;
+            float tsdf_i = tsdf_base_ptr[linear_idx_i];
+            float weight_i = weight_base_ptr[linear_idx_i];
+            if (weight_i > weight_threshold && tsdf_i * tsdf_o < 0) {
+                int64_t idx = count++;
+                if (!points) continue;         // counting pass
+                if (idx >= valid_size) break;  // the reference `return`s
+                float ratio = (0 - tsdf_o) / (tsdf_i - tsdf_o);
+                float* point_ptr = points + 3 * idx;
+                point_ptr[0] = voxel_size * (x + ratio * int(i == 0));
+                point_ptr[1] = voxel_size * (y + ratio * int(i == 1));
+                point_ptr[2] = voxel_size * (z + ratio * int(i == 2));
+                float* normal_ptr = normals + 3 * idx;
+                GetNormal(xv + (i == 0), yv + (i == 1), zv + (i == 2),
+                          workload_block_idx, ne);
+                float nx = (1 - ratio) * no[0] + ratio * ne[0];
+                float ny = (1 - ratio) * no[1] + ratio * ne[1];
+                float nz = (1 - ratio) * no[2] + ratio * ne[2];
+                float norm = static_cast<float>(
+                        EXTRACT_SQRT(nx * nx + ny * ny + nz * nz) + 1e-5);
+                normal_ptr[0] = nx / norm;
+                normal_ptr[1] = ny / norm;
+                normal_ptr[2] = nz / norm;
+                if (color_base_ptr && colors) {
+                    float* color_ptr = colors + 3 * idx;
+                    const color_t* color_o_ptr = color_base_ptr + 3 * linear_idx;
+                    float r_o = color_o_ptr[0];
+                    float g_o = color_o_ptr[1];
+                    float b_o = color_o_ptr[2];
+                    const color_t* color_i_ptr =
+                            color_base_ptr + 3 * linear_idx_i;
+                    float r_i = color_i_ptr[0];
+                    float g_i = color_i_ptr[1];
+                    float b_i = color_i_ptr[2];
+                    color_ptr[0] = ((1 - ratio) * r_o + ratio * r_i) / 255.0f;
+                    color_ptr[1] = ((1 - ratio) * g_o + ratio * g_i) / 255.0f;
+                    color_ptr[2] = ((1 - ratio) * b_o + ratio * b_i) / 255.0f;
+                }
+            }
+        }
+    }
+    return count;
+}
+
 }  // namespace
 
 // ===========================================================================
@@ -969,6 +1090,44 @@ void orc_raycast(void* hp, const float* tsdf, const void* weight,
                 extrinsics, h, w, block_resolution, voxel_size, depth_scale,
                 depth_min, depth_max, weight_threshold, trunc_voxel_multiplier,
                 range_map_down_factor);
+}
+
+// BufferRadiusNeighbors, VoxelBlockGrid.cpp:22-51: {27, n} tables.
+void orc_buffer_radius_neighbors(void* hp, const int* active_buf_indices,
+                                 int64_t n, int* nb_indices, uint8_t* nb_masks) {
+    auto* h = (OrcHashMap*)hp;
+    for (int nb = 0; nb < 27; ++nb) {
+        int dz = nb / 9, dy = (nb % 9) / 3, dx = nb % 3;
+        for (int64_t i = 0; i < n; ++i) {
+            const int* k = h->keys.data() + 3 * (size_t)active_buf_indices[i];
+            Coord3i q{k[0] + dx - 1, k[1] + dy - 1, k[2] + dz - 1};
+            auto it = h->map.find(q);
+            nb_indices[(int64_t)nb * n + i] = it == h->map.end() ? 0 : it->second;
+            nb_masks[(int64_t)nb * n + i] = it == h->map.end() ? 0 : 1;
+        }
+    }
+}
+
+// points == NULL: counting pass (valid_size < 0 in the reference).
+int64_t orc_extract_point_cloud(const int* indices, const int* nb_indices,
+                                const uint8_t* nb_masks, const int* block_keys,
+                                const float* tsdf, const void* weight,
+                                const void* color_buf, int grid_is_f32,
+                                int64_t n_blocks, int resolution,
+                                float voxel_size, float weight_threshold,
+                                float* points, float* normals, float* colors,
+                                int64_t valid_size) {
+    if (grid_is_f32)
+        return ExtractPointCloudImpl<float, float>(
+                indices, nb_indices, nb_masks, block_keys, tsdf,
+                (const float*)weight, (const float*)color_buf, n_blocks,
+                resolution, voxel_size, weight_threshold, points, normals,
+                colors, valid_size);
+    return ExtractPointCloudImpl<uint16_t, uint16_t>(
+            indices, nb_indices, nb_masks, block_keys, tsdf,
+            (const uint16_t*)weight, (const uint16_t*)color_buf, n_blocks,
+            resolution, voxel_size, weight_threshold, points, normals, colors,
+            valid_size);
 }
 
 int64_t orc_unproject(const void* depth, int depth_is_f32, int rows, int cols,

@@ -224,6 +224,47 @@ def raycast(hashmap, tsdf, weight, color_buf, range_map, K, T, h, w,
     return out
 
 
+def buffer_radius_neighbors(hashmap, active_buf_indices):
+    """BufferRadiusNeighbors (VoxelBlockGrid.cpp:22-51): ({27,n} int32,
+    {27,n} bool)."""
+    idx = np.ascontiguousarray(active_buf_indices, dtype=np.int32)
+    n = idx.shape[0]
+    nbi = np.zeros((27, n), np.int32)
+    nbm = np.zeros((27, n), np.uint8)
+    lib().orc_buffer_radius_neighbors(hashmap.h, _p(idx), C.c_int64(n),
+                                      _p(nbi), _p(nbm))
+    return nbi, nbm
+
+
+def extract_point_cloud(indices, nb_indices, nb_masks, block_keys, tsdf,
+                        weight, color_buf, resolution, voxel_size,
+                        weight_threshold, estimated_number=-1):
+    """ExtractPointCloudCPU: (points, normals, colors|None, total_count)."""
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    nb_indices = np.ascontiguousarray(nb_indices, dtype=np.int32)
+    nb_masks = np.ascontiguousarray(nb_masks, dtype=np.uint8)
+    block_keys = np.ascontiguousarray(block_keys, dtype=np.int32)
+    n = indices.shape[0]
+    grid_is_f32 = int(weight.dtype == np.float32)
+    L = lib()
+    L.orc_extract_point_cloud.restype = C.c_int64
+    args = [_p(indices), _p(nb_indices), _p(nb_masks), _p(block_keys),
+            _p(tsdf), _p(weight), _p(color_buf), grid_is_f32, C.c_int64(n),
+            int(resolution), C.c_float(voxel_size),
+            C.c_float(weight_threshold)]
+    cap = int(estimated_number)
+    if cap < 0:
+        cap = int(L.orc_extract_point_cloud(*args, None, None, None,
+                                            C.c_int64(0)))
+    pts = np.zeros((cap, 3), np.float32)
+    nrm = np.zeros((cap, 3), np.float32)
+    col = np.zeros((cap, 3), np.float32) if color_buf is not None else None
+    total = int(L.orc_extract_point_cloud(*args, _p(pts), _p(nrm), _p(col),
+                                          C.c_int64(cap)))
+    m = min(total, cap)
+    return pts[:m], nrm[:m], (None if col is None else col[:m]), total
+
+
 def unproject(depth, colors_f32, K, T, depth_scale, depth_max, stride=1):
     depth = np.ascontiguousarray(depth)
     is_f32 = int(depth.dtype == np.float32)
@@ -564,11 +605,11 @@ def rgbd_odometry_multiscale(method, src_depth, tgt_depth, K, init=None,
     coarse to fine (OdometryConvergenceCriteria, RGBDOdometry.h:38-68)."""
     sd = np.ascontiguousarray(src_depth)
     td = np.ascontiguousarray(tgt_depth)
-    assert sd.dtype == td.dtype and sd.dtype in (np.uint16, np.float32)
+    assert sd.dtype in (np.uint16, np.float32)
+    assert td.dtype in (np.uint16, np.float32)
     rows, cols = sd.shape[:2]
     sc = None if src_color is None else np.ascontiguousarray(src_color)
     tc = None if tgt_color is None else np.ascontiguousarray(tgt_color)
-    color_f32 = int(sc is not None and sc.dtype == np.float32)
     init = np.eye(4) if init is None else init
     iters = np.array([c[0] for c in criteria], np.int32)
     rr = np.array([c[1] for c in criteria], np.float64)
@@ -578,7 +619,10 @@ def rgbd_odometry_multiscale(method, src_depth, tgt_depth, K, init=None,
     it = C.c_int(0)
     st = lib().orc_rgbd_odometry_multiscale(
         int(method), _p(sd), _p(sc), _p(td), _p(tc),
-        int(sd.dtype == np.float32), color_f32, rows, cols, _p(_f64(K)),
+        int(sd.dtype == np.float32), int(td.dtype == np.float32),
+        int(sc is not None and sc.dtype == np.float32),
+        int(tc is not None and tc.dtype == np.float32), rows, cols,
+        _p(_f64(K)),
         _p(_f64(init)), C.c_float(depth_scale), C.c_float(depth_max),
         len(criteria), _p(iters), _p(rr), _p(rf),
         C.c_float(depth_outlier_trunc), C.c_float(depth_huber_delta),

@@ -373,3 +373,38 @@ def odometry_information(source_vertex, target_vertex, K, T, square_dist_thr):
                                           C.c_float(square_dist_thr), _p(out)),
            "ComputeOdometryInformationMatrixCPU")
     return out
+
+
+def extract_point_cloud(indices, nb_indices, nb_masks, block_keys, tsdf,
+                        weight, color_buf, resolution, voxel_size,
+                        weight_threshold, estimated_number=-1,
+                        out_capacity=None):
+    """The reference's ExtractPointCloudCPU body: (points, normals,
+    colors|None, total_count). Output order is sequential only under
+    set_threads(1)."""
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    nb_indices = np.ascontiguousarray(nb_indices, dtype=np.int32)
+    nb_masks = np.ascontiguousarray(nb_masks, dtype=np.uint8)
+    block_keys = np.ascontiguousarray(block_keys, dtype=np.int32)
+    n = indices.shape[0]
+    capacity = block_keys.shape[0]
+    grid_is_f32 = int(weight.dtype == np.float32)
+    cap = int(out_capacity if out_capacity is not None else
+              (estimated_number if estimated_number >= 0
+               else n * resolution ** 3 * 3))
+    pts = np.zeros((cap, 3), np.float32)
+    nrm = np.zeros((cap, 3), np.float32)
+    col = np.zeros((cap, 3), np.float32) if color_buf is not None else None
+    L = lib()
+    L.ref_extract_point_cloud.restype = C.c_int64
+    total = int(L.ref_extract_point_cloud(
+        _p(indices), _p(nb_indices), _p(nb_masks), _p(block_keys),
+        C.c_int64(capacity), _p(tsdf), _p(weight), _p(color_buf), grid_is_f32,
+        C.c_int64(n), int(resolution), C.c_float(voxel_size),
+        C.c_float(weight_threshold), _p(pts), _p(nrm), _p(col),
+        C.c_int64(cap), int(estimated_number)))
+    if total < 0:
+        raise RuntimeError("extract_point_cloud: %s"
+                           % L.ref_last_error().decode())
+    m = min(total, cap)
+    return pts[:m], nrm[:m], (None if col is None else col[:m]), total

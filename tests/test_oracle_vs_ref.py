@@ -264,3 +264,65 @@ def test_robust_weights_bit_exact(f64):
                 b = ref.robust_weight(method, s, shape, r, f64)
                 assert a == b or (np.isnan(a) and np.isnan(b)), \
                     (method, shape, r, s, a, b)
+
+
+# ---------------------------------------------------------------------------
+# ExtractPointCloud
+# ---------------------------------------------------------------------------
+def _integrated_grid(grid_f32, n_frames=3, w=160, h=120, res=8, voxel=0.02):
+    """A small grid integrated with the oracle (res 8, 2 cm: a few hundred
+    blocks) -> (hashmap, tsdf, weight, color)."""
+    cap = 4096
+    wd = np.float32 if grid_f32 else np.uint16
+    tsdf = np.zeros((cap, res, res, res), np.float32)
+    wgt = np.zeros((cap, res, res, res), wd)
+    col = np.zeros((cap, res, res, res, 3), wd)
+    hm = orc.HashMap(cap)
+    from open3d_amd import synthetic
+    d, c, K, Ts = synthetic.render_frames(0, n_frames, w, h, device="cpu")
+    for i in range(n_frames):
+        dn, cn = d[i].numpy(), c[i].numpy()
+        keys = orc.depth_touch(dn, K, Ts[i], res, voxel, voxel * 4, 1000.0,
+                               3.0)
+        hm.activate(keys)
+        buf, _ = hm.find(keys)
+        orc.integrate(dn, cn, buf, hm.key_buffer(), tsdf, wgt, col, K, K,
+                      Ts[i], res, voxel, voxel * 4, 1000.0, 3.0)
+    return hm, tsdf, wgt, col, res, voxel
+
+
+@pytest.mark.parametrize("grid_f32", [False, True])
+@pytest.mark.parametrize("with_color", [True, False])
+def test_extract_point_cloud_vs_reference_body(grid_f32, with_color):
+    hm, tsdf, wgt, col, res, voxel = _integrated_grid(grid_f32)
+    if not with_color:
+        col = None
+    active = hm.active_indices()
+    nbi, nbm = orc.buffer_radius_neighbors(hm, active)
+    # interior blocks have all 27 neighbours' lookups answered
+    assert nbm[13].all() and np.array_equal(nbi[13], active)
+    ref.set_threads(1)  # sequential: the atomic counter follows workload order
+    for thr in (0.0, 1.0, 2.0):
+        a = orc.extract_point_cloud(active, nbi, nbm, hm.key_buffer(), tsdf,
+                                    wgt, col, res, voxel, thr)
+        b = ref.extract_point_cloud(active, nbi, nbm, hm.key_buffer(), tsdf,
+                                    wgt, col, res, voxel, thr)
+        assert a[3] == b[3]
+        if thr == 0.0:
+            assert a[3] > 2000
+        assert a[0].tobytes() == b[0].tobytes()      # points
+        assert a[1].tobytes() == b[1].tobytes()      # normals
+        if with_color:
+            assert a[2].tobytes() == b[2].tobytes()  # colours
+    # estimated size smaller than the surface: the first `est` in order
+    est = a[3] // 2
+    a2 = orc.extract_point_cloud(active, nbi, nbm, hm.key_buffer(), tsdf, wgt,
+                                 col, res, voxel, 2.0, estimated_number=est)
+    assert a2[3] >= est and a2[0].shape[0] == est
+    assert np.array_equal(a2[0], a[0][:est])
+    ref.set_threads(8)
+    b8 = ref.extract_point_cloud(active, nbi, nbm, hm.key_buffer(), tsdf, wgt,
+                                 col, res, voxel, 2.0)
+    assert b8[3] == a[3]
+    key = lambda p: sc.sort_rows(np.concatenate(p[:2], axis=1))
+    assert np.array_equal(key(b8), key(a))
