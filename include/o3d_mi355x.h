@@ -232,6 +232,29 @@ int o3dmi_vbg_raycast(o3dmi_hash_t* block_hash, const float* tsdf_dev,
                       float weight_threshold, float trunc_voxel_multiplier,
                       int range_map_down_factor, o3dmi_stream_t stream);
 
+/* ExtractPointCloudCUDA<tsdf_t,weight_t,color_t> (VoxelBlockGridImpl.h:
+ * 1122-1365) fused with BufferRadiusNeighbors (t/geometry/VoxelBlockGrid.cpp:
+ * 22-51): zero crossings of the TSDF along +x/+y/+z between voxels with
+ * weight > weight_threshold. indices_dev = active buffer indices. The 27
+ * neighbour blocks are looked up in `block_hash` inside the kernel.
+ * capacity < 0: count only (the reference's valid_size < 0 pass);
+ * otherwise at most `capacity` points are written (points / normals / colors
+ * {capacity,3} float32; colors_dev and color_dev may be NULL). Output order is
+ * (position in indices_dev, voxel, axis) -- deterministic, where the
+ * reference's is its atomic counter's. *total_out = number of crossings
+ * (synchronises). */
+int o3dmi_vbg_extract_points(o3dmi_hash_t* block_hash,
+                             const int32_t* indices_dev, int64_t n_blocks,
+                             const float* tsdf_dev, const void* weight_dev,
+                             const void* color_dev, int grid_dtype,
+                             int resolution, float voxel_size,
+                             float weight_threshold, float* points_dev,
+                             float* normals_dev, float* colors_dev,
+                             int64_t capacity, int64_t* total_out,
+                             o3dmi_stream_t stream);
+/* Ascending in-place sort of int32 indices (synchronises). */
+int o3dmi_sort_indices(int32_t* indices_dev, int64_t n, o3dmi_stream_t stream);
+
 /* UnprojectCUDA (t/geometry/kernel/PointCloudImpl.h:42-143): strided depth ->
  * compacted world points (order unspecified). points_dev holds
  * (rows/stride)*(cols/stride) x 3 floats; count to *out_count_dev. */

@@ -239,6 +239,81 @@ int o3dmi_rgbd_odometry_information_matrix(
         const double* source_to_target, float dist_thr, float depth_scale,
         float depth_max, double* information_host, o3dmi_stream_t stream);
 
+/* ExtractPointCloud(weight_threshold, estimated_point_number)
+ * (VoxelBlockGrid.cpp:404-434). capacity < 0: only counts (the reference's
+ * 2-pass estimation) -> *total_out; otherwise writes up to `capacity` points:
+ * points / normals {capacity,3} float32, colors {capacity,3} float32 in [0,1]
+ * when the grid has a "color" attribute (colors_dev may be NULL).
+ * *total_out = number of surface points found (synchronises). Order: active
+ * blocks by ascending buffer index, then voxel, then axis. */
+int o3dmi_vbg_extract_point_cloud(o3dmi_vbg_t* g, float weight_threshold,
+                                  int64_t capacity, float* points_dev,
+                                  float* normals_dev, float* colors_dev,
+                                  int64_t* total_out, o3dmi_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* slam::Model (t/pipelines/slam/Model.h:24-137, Model.cpp:23-118)           */
+/* ------------------------------------------------------------------------ */
+typedef struct o3dmi_slam_model o3dmi_slam_model_t;
+
+/* Model(voxel_size, block_resolution = 16, block_count = 1000, T_init = I):
+ * grid attributes ("tsdf" F32 x1, "weight" U16 x1, "color" U16 x3)
+ * (Model.cpp:23-38). T_init host 4x4 float64 or NULL. */
+int o3dmi_slam_model_create(float voxel_size, int block_resolution,
+                            int64_t block_count, const double* T_init,
+                            o3dmi_stream_t stream, o3dmi_slam_model_t** out);
+int o3dmi_slam_model_destroy(o3dmi_slam_model_t* m);
+o3dmi_vbg_t* o3dmi_slam_model_voxel_grid(o3dmi_slam_model_t* m);
+/* GetCurrentFramePose / UpdateFramePose (Model.h:45-54); frame ids that do
+ * not advance by one only warn in the reference, here they are accepted. */
+int o3dmi_slam_model_get_current_frame_pose(const o3dmi_slam_model_t* m,
+                                            double* T_frame_to_world);
+int o3dmi_slam_model_update_frame_pose(o3dmi_slam_model_t* m, int frame_id,
+                                       const double* T_frame_to_world);
+int o3dmi_slam_model_frame_id(const o3dmi_slam_model_t* m);
+/* SynthesizeModelFrame (Model.cpp:40-68): ray-casts the frustum blocks of the
+ * last Integrate at the current pose into depth {h,w,1} F32 (raw units) and,
+ * if color_out_dev != NULL, colour {h,w,3} F32 in [0,1]. weight_threshold < 0
+ * = min(frame_id, 3). */
+int o3dmi_slam_model_synthesize_model_frame(
+        o3dmi_slam_model_t* m, const double* intrinsics, int width, int height,
+        float depth_scale, float depth_min, float depth_max,
+        float trunc_voxel_multiplier, float weight_threshold,
+        float* depth_out_dev, float* color_out_dev, o3dmi_stream_t stream);
+/* TrackFrameToModel (Model.cpp:70-92): RGBDOdometryMultiScale(input frame,
+ * ray-cast frame, intrinsics, identity, depth_scale, depth_max, criteria,
+ * method, OdometryLossParams(depth_diff)). Defaults: depth_diff 0.07, method
+ * point-to-plane, criteria {6, 3, 1}. raycast_* are Float32. */
+int o3dmi_slam_model_track_frame_to_model(
+        o3dmi_slam_model_t* m, const void* input_depth_dev,
+        int input_depth_dtype, const void* input_color_dev,
+        int input_color_dtype, const float* raycast_depth_dev,
+        const float* raycast_color_dev, int rows, int cols,
+        const double* intrinsics, float depth_scale, float depth_max,
+        float depth_diff, int method, int n_levels,
+        const o3dmi_odometry_criteria_t* criteria,
+        o3dmi_odometry_result_t* result, o3dmi_stream_t stream);
+/* Integrate (Model.cpp:94-108): GetUniqueBlockCoordinates + Integrate at
+ * InverseTransformation(current pose); remembers the frustum blocks. Colour
+ * may be NULL (depth-only integration). */
+int o3dmi_slam_model_integrate(o3dmi_slam_model_t* m, const void* depth_dev,
+                               int depth_dtype, const void* color_dev,
+                               int rows, int cols, const double* intrinsics,
+                               float depth_scale, float depth_max,
+                               float trunc_voxel_multiplier,
+                               o3dmi_stream_t stream);
+/* Number of frustum blocks of the last Integrate and their keys (device,
+ * {n,3} int32; valid until the next Integrate). */
+int64_t o3dmi_slam_model_frustum_block_count(const o3dmi_slam_model_t* m);
+const int32_t* o3dmi_slam_model_frustum_block_coords(const o3dmi_slam_model_t* m);
+/* ExtractPointCloud (Model.cpp:110-113). */
+int o3dmi_slam_model_extract_point_cloud(o3dmi_slam_model_t* m,
+                                         float weight_threshold,
+                                         int64_t capacity, float* points_dev,
+                                         float* normals_dev, float* colors_dev,
+                                         int64_t* total_out,
+                                         o3dmi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

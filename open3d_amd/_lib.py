@@ -76,6 +76,10 @@ PROTOTYPES = {
     "o3dmi_decode_and_solve6x6": (_i32, [_dp, _dp, C.POINTER(_f),
                                          C.POINTER(_i32)]),
     "o3dmi_pose_to_transformation": (None, [_dp, _dp]),
+    "o3dmi_vbg_extract_points": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _i32,
+                                        _i32, _f, _f, _vp, _vp, _vp, _i64,
+                                        C.POINTER(_i64), _vp]),
+    "o3dmi_sort_indices": (_i32, [_vp, _i64, _vp]),
     "o3dmi_image_clip_transform": (_i32, [_vp, _i32, _i32, _i32, _f, _f, _f,
                                           _f, _vp, _vp]),
     "o3dmi_image_pyrdown_depth": (_i32, [_vp, _i32, _i32, _f, _f, _vp, _vp]),
@@ -163,6 +167,28 @@ PROTOTYPES.update({
                C.POINTER(OdometryResultC), _vp]),
     "o3dmi_rgbd_odometry_information_matrix": (
         _i32, [_vp, _vp, _i32, _i32, _i32, _dp, _dp, _f, _f, _f, _dp, _vp]),
+    "o3dmi_vbg_extract_point_cloud": (_i32, [_vp, _f, _i64, _vp, _vp, _vp,
+                                             C.POINTER(_i64), _vp]),
+    "o3dmi_slam_model_create": (_i32, [_f, _i32, _i64, _dp, _vp,
+                                       C.POINTER(_vp)]),
+    "o3dmi_slam_model_destroy": (_i32, [_vp]),
+    "o3dmi_slam_model_voxel_grid": (_vp, [_vp]),
+    "o3dmi_slam_model_get_current_frame_pose": (_i32, [_vp, _dp]),
+    "o3dmi_slam_model_update_frame_pose": (_i32, [_vp, _i32, _dp]),
+    "o3dmi_slam_model_frame_id": (_i32, [_vp]),
+    "o3dmi_slam_model_synthesize_model_frame": (
+        _i32, [_vp, _dp, _i32, _i32, _f, _f, _f, _f, _f, _vp, _vp, _vp]),
+    "o3dmi_slam_model_track_frame_to_model": (
+        _i32, [_vp, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _dp, _f, _f,
+               _f, _i32, _i32, C.POINTER(OdometryCriteriaC),
+               C.POINTER(OdometryResultC), _vp]),
+    "o3dmi_slam_model_integrate": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32,
+                                          _dp, _f, _f, _f, _vp]),
+    "o3dmi_slam_model_frustum_block_count": (_i64, [_vp]),
+    "o3dmi_slam_model_frustum_block_coords": (_vp, [_vp]),
+    "o3dmi_slam_model_extract_point_cloud": (_i32, [_vp, _f, _i64, _vp, _vp,
+                                                    _vp, C.POINTER(_i64),
+                                                    _vp]),
     "o3dmi_vbg_ray_cast": (
         _i32, [_vp, _vp, _i64, _dp, _dp, _i32, _i32, _vp] + [_vp] * 10 +
         [_f, _f, _f, _f, _f, _i32, _vp]),

@@ -860,6 +860,47 @@ int o3dmi_vbg_ray_cast(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
             range_map_down_factor, stream);
 }
 
+int o3dmi_vbg_extract_point_cloud(o3dmi_vbg_t* g, float weight_threshold,
+                                  int64_t capacity, float* points_dev,
+                                  float* normals_dev, float* colors_dev,
+                                  int64_t* total_out, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(g && total_out, "null argument");
+    int ti = g->AttrIndex("tsdf"), wi = g->AttrIndex("weight"),
+        ci = g->AttrIndex("color");
+    if (ti < 0 || wi < 0) {
+        SetLastError(
+                "TSDF and/or weight not allocated in blocks, please implement "
+                "customized integration.");
+        return O3DMI_ERR_INVALID_ARG;
+    }
+    int grid_dtype;
+    int st = GridDtype(g, &grid_dtype);
+    if (st) return st;
+    // block_hashmap_->GetActiveIndices(active_buf_indices), sorted so that the
+    // output order is a function of the grid state only.
+    int32_t* active = nullptr;
+    const int64_t cap = o3dmi_hash_capacity(g->block_hashmap);
+    if ((st = PoolAlloc((void**)&active, sizeof(int32_t) * (size_t)cap)))
+        return st;
+    int64_t n = 0;
+    st = o3dmi_hash_active_indices(g->block_hashmap, active, stream, &n);
+    if (!st) st = o3dmi_sort_indices(active, n, stream);
+    if (!st)
+        st = o3dmi_vbg_extract_points(
+                g->block_hashmap, active, n,
+                (const float*)o3dmi_hash_value_buffer(g->block_hashmap, ti),
+                o3dmi_hash_value_buffer(g->block_hashmap, wi),
+                ci >= 0 ? o3dmi_hash_value_buffer(g->block_hashmap, ci)
+                        : nullptr,
+                grid_dtype, (int)g->block_resolution, g->voxel_size,
+                weight_threshold, points_dev, normals_dev,
+                ci >= 0 ? colors_dev : nullptr, capacity, total_out, stream);
+    // extract_points synchronised the stream (or failed before launching).
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    PoolFree(active);
+    return st;
+}
+
 int o3dmi_vbg_profile_begin(o3dmi_vbg_t* g, int max_frames, int stride) {
     O3DMI_REQUIRE(g && max_frames > 0 && stride >= 0, "bad argument");
     g->prof_stride = stride;

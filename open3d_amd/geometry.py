@@ -66,6 +66,27 @@ def _image(t, name, channels):
     return t
 
 
+def _extract(call, has_color, weight_threshold, estimated_point_number):
+    total = C.c_int64(0)
+    cap = int(estimated_point_number)
+    if cap < 0:
+        _lib.check(call(C.c_float(weight_threshold), C.c_int64(-1), None, None,
+                        None, C.byref(total), stream()), "extract_point_cloud")
+        cap = int(total.value)
+    pts = torch.empty((cap, 3), dtype=torch.float32, device="cuda")
+    nrm = torch.empty((cap, 3), dtype=torch.float32, device="cuda")
+    col = torch.empty((cap, 3), dtype=torch.float32, device="cuda") \
+        if has_color else None
+    _lib.check(call(C.c_float(weight_threshold), C.c_int64(cap), _lib.ptr(pts),
+                    _lib.ptr(nrm), _lib.ptr(col), C.byref(total), stream()),
+               "extract_point_cloud")
+    m = min(cap, int(total.value))
+    out = {"positions": pts[:m], "normals": nrm[:m]}
+    if col is not None:
+        out["colors"] = col[:m]
+    return out
+
+
 class VoxelBlockGrid:
     _CHANNELS = {"vertex": 3, "normal": 3, "depth": 1, "color": 3, "index": 8,
                  "mask": 8, "interp_ratio": 8, "interp_ratio_dx": 8,
@@ -230,6 +251,16 @@ class VoxelBlockGrid:
             _lib.f64p(Ts), C.c_float(depth_scale), C.c_float(depth_max),
             C.c_float(trunc_voxel_multiplier), int(frames_per_launch), stream()),
             "VoxelBlockGrid.integrate_frames")
+
+    def extract_point_cloud(self, weight_threshold=3.0,
+                            estimated_point_number=-1):
+        """ExtractPointCloud (VoxelBlockGrid.cpp:404-434) -> dict(positions,
+        normals[, colors]) of device tensors {N,3} float32. A negative
+        estimate runs the counting pass first (the reference's 2-pass mode);
+        otherwise at most `estimated_point_number` points are returned."""
+        return _extract(lambda *a: _lib.lib().o3dmi_vbg_extract_point_cloud(
+            self._g, *a), "color" in self.attr_names, weight_threshold,
+            estimated_point_number)
 
     def profile_begin(self, max_frames, stride=1):
         _lib.check(_lib.lib().o3dmi_vbg_profile_begin(

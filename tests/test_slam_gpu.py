@@ -1,0 +1,227 @@
+"""GPU parity tests of SURVEY section 8 row f2: VoxelBlockGrid::ExtractPointCloud
+and the slam::Model loop (TrackFrameToModel / Integrate / SynthesizeModelFrame)
+through the C ABI, against the CPU oracle (pinned to the reference's own
+ExtractPointCloudCPU / RGBDOdometryCPU / IntegrateCPU / RayCastCPU bodies).
+
+Bars: extracted points / normals / colours bit-exact and in the oracle's
+sequential order; per-frame tracking pose within 1e-6 rad / 1e-5 m of the
+oracle on identical inputs; the integrated grid bit-exact; the synthesized model
+frame within 1e-3 depth units / 1e-5 colour of the oracle's ray cast."""
+import numpy as np
+import pytest
+import torch
+
+import _oracle as orc
+import _ref as ref
+import _scene as sc
+from test_vbg_gpu import OracleGrid, _compare_grids, _mk_grid
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from open3d_amd import _lib, geometry, slam
+    return _lib, geometry, slam
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _nb_tables(hm, active):
+    """BufferRadiusNeighbors through the GPU hash map's Find."""
+    keys = hm.key_tensor().cpu().numpy()[active]
+    n = keys.shape[0]
+    nbi = np.zeros((27, n), np.int32)
+    nbm = np.zeros((27, n), np.uint8)
+    for nb in range(27):
+        d = np.array([nb % 3 - 1, (nb % 9) // 3 - 1, nb // 9 - 1], np.int32)
+        b, m = hm.find(_dev((keys + d).astype(np.int32)))
+        nbi[nb] = np.where(m.cpu().numpy(), b.cpu().numpy(), 0)
+        nbm[nb] = m.cpu().numpy()
+    return nbi, nbm
+
+
+@pytest.mark.parametrize("grid_f32", [False, True])
+@pytest.mark.parametrize("with_color", [True, False])
+def test_extract_point_cloud_bit_exact(grid_f32, with_color):
+    _lib, geometry, _ = _gpu()
+    g = _mk_grid(geometry, grid_f32, block_count=8192, with_color=with_color)
+    for k in range(100, 108):
+        d, c, K, Ts = sc.frames(k * 3, 1, 320, 240)
+        g.integrate_frame(_dev(d[0]), _dev(c[0]) if with_color else None, K,
+                          K, Ts[0])
+    hm = g.hashmap()
+    active = np.sort(hm.active_buf_indices().cpu().numpy())
+    assert active.shape[0] > 300
+    nbi, nbm = _nb_tables(hm, active)
+    tsdf = g.attribute("tsdf").cpu().numpy()[..., 0]
+    wgt = g.attribute("weight").cpu().numpy()[..., 0]
+    col = g.attribute("color").cpu().numpy() if with_color else None
+    keys = hm.key_tensor().cpu().numpy()
+    for thr in (0.0, 3.0):
+        want = orc.extract_point_cloud(active, nbi, nbm, keys, tsdf, wgt, col,
+                                       sc.RES, sc.VOXEL, thr)
+        got = g.extract_point_cloud(thr)
+        assert want[3] > 5000
+        assert got["positions"].shape[0] == want[3]
+        assert got["positions"].cpu().numpy().tobytes() == want[0].tobytes()
+        assert got["normals"].cpu().numpy().tobytes() == want[1].tobytes()
+        if with_color:
+            assert got["colors"].cpu().numpy().tobytes() == want[2].tobytes()
+        else:
+            assert "colors" not in got
+    # an estimate below the surface size keeps the first points in order
+    est = want[3] // 3
+    part = g.extract_point_cloud(3.0, est)
+    assert part["positions"].shape[0] == est
+    assert torch.equal(part["positions"], got["positions"][:est])
+    assert torch.equal(part["normals"], got["normals"][:est])
+    # larger estimate: exactly the surface
+    big = g.extract_point_cloud(3.0, want[3] + 1000)
+    assert torch.equal(big["positions"], got["positions"])
+    # same set as the reference's own body (its order is the atomic counter's)
+    if ref.available():
+        ref.set_threads(8)
+        b = ref.extract_point_cloud(active, nbi, nbm, keys, tsdf, wgt, col,
+                                    sc.RES, sc.VOXEL, 3.0)
+        assert b[3] == want[3]
+        key = lambda p, n: sc.sort_rows(np.concatenate([p, n], axis=1))
+        assert np.array_equal(key(b[0], b[1]),
+                              key(got["positions"].cpu().numpy(),
+                                  got["normals"].cpu().numpy()))
+    # points lie on the synthetic room's surfaces: within a voxel of z-range
+    p = got["positions"].cpu().numpy()
+    assert np.isfinite(p).all() and np.abs(p).max() < 10
+    nn = np.linalg.norm(got["normals"].cpu().numpy(), axis=1)
+    assert ((nn > 0.99) | (nn == 0)).all()
+
+
+def test_extract_point_cloud_empty_and_res8():
+    _lib, geometry, _ = _gpu()
+    g = _mk_grid(geometry, False, block_count=256)
+    out = g.extract_point_cloud(3.0)
+    assert out["positions"].shape == (0, 3)
+    g8 = _mk_grid(geometry, False, block_count=4096, res=8)
+    og = OracleGrid(False, 4096, res=8)
+    for k in (0, 5, 10, 15):
+        d, c, K, Ts = sc.frames(k, 1, 320, 240)
+        og.integrate(d[0], c[0], K, Ts[0])
+        g8.integrate_frame(_dev(d[0]), _dev(c[0]), K, K, Ts[0])
+    hm = g8.hashmap()
+    active = np.sort(hm.active_buf_indices().cpu().numpy())
+    nbi, nbm = _nb_tables(hm, active)
+    want = orc.extract_point_cloud(
+        active, nbi, nbm, hm.key_tensor().cpu().numpy(),
+        g8.attribute("tsdf").cpu().numpy()[..., 0],
+        g8.attribute("weight").cpu().numpy()[..., 0],
+        g8.attribute("color").cpu().numpy(), 8, sc.VOXEL, 1.0)
+    got = g8.extract_point_cloud(1.0)
+    assert want[3] > 1000
+    assert got["positions"].cpu().numpy().tobytes() == want[0].tobytes()
+    assert got["normals"].cpu().numpy().tobytes() == want[1].tobytes()
+    assert got["colors"].cpu().numpy().tobytes() == want[2].tobytes()
+
+
+def _pose_err(Ta, Tb):
+    d = np.linalg.inv(Ta) @ Tb
+    c = (np.trace(d[:3, :3]) - 1) / 2
+    return float(np.arccos(np.clip(c, -1, 1))), \
+        float(np.linalg.norm(d[:3, 3]))
+
+
+@pytest.mark.parametrize("method", [0, 2])
+def test_model_loop_matches_oracle_operator_by_operator(method):
+    """The reference's dense-SLAM loop (examples/python/t_reconstruction_system/
+    dense_slam.py): track -> update pose -> integrate -> synthesize. The oracle
+    runs in lock-step on the same inputs."""
+    _lib, geometry, slam = _gpu()
+    from open3d_amd import odometry as odo
+    W, H, n = 320, 240, 6
+    frames = [sc.frames(k * 2, 1, W, H) for k in range(n)]
+    K = frames[0][2]
+    # render_frames returns extrinsics (world -> camera)
+    T_f2w = np.linalg.inv(np.array(frames[0][3][0]))
+    model = slam.Model(sc.VOXEL, sc.RES, 8192, T_f2w)
+    assert np.array_equal(model.get_current_frame_pose(), T_f2w)
+    assert model.frame_id == -1
+    input_frame = slam.Frame(H, W, K)
+    raycast_frame = slam.Frame(H, W, K)
+    og = OracleGrid(False, 8192)
+    crit = ((6, 1e-6, 1e-6), (3, 1e-6, 1e-6), (1, 1e-6, 1e-6))
+    max_track = (0.0, 0.0)
+    for i in range(n):
+        d, c, _, Ts = frames[i]
+        input_frame.set_data_from_image("depth", _dev(d[0]))
+        input_frame.set_data_from_image("color", _dev(c[0]))
+        if i > 0:
+            r = model.track_frame_to_model(input_frame, raycast_frame,
+                                           sc.DEPTH_SCALE, sc.DEPTH_MAX, 0.07,
+                                           method)
+            rd = raycast_frame.get_data("depth").cpu().numpy()[..., 0]
+            rc = raycast_frame.get_data("color").cpu().numpy()
+            want = orc.rgbd_odometry_multiscale(
+                method, d[0], rd, K, src_color=c[0], tgt_color=rc,
+                criteria=crit, depth_outlier_trunc=0.07,
+                accumulate_double=True)
+            assert want["status"] == 0
+            e = _pose_err(r.transformation, want["transformation"])
+            max_track = (max(max_track[0], e[0]), max(max_track[1], e[1]))
+            assert e[0] <= 1e-6 and e[1] <= 1e-5, (i, e)
+            assert r.num_iterations == want["iterations"]
+            T_f2w = T_f2w @ r.transformation
+        model.update_frame_pose(i, T_f2w)
+        assert model.frame_id == i
+        assert np.array_equal(model.get_current_frame_pose(), T_f2w)
+        model.integrate(input_frame, sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                        sc.TRUNC_MULT)
+        extr = orc.inverse_transformation(T_f2w)
+        keys = og.integrate(d[0], c[0], K, extr)
+        fk = model.frustum_block_coords.cpu().numpy()
+        assert np.array_equal(sc.sort_rows(fk), sc.sort_rows(keys))
+        model.synthesize_model_frame(raycast_frame, sc.DEPTH_SCALE, 0.1,
+                                     sc.DEPTH_MAX, sc.TRUNC_MULT, True)
+        wthr = min(float(i), 3.0)
+        range_o, needed = orc.estimate_range(keys, K, extr, H, W, 8, sc.RES,
+                                             sc.VOXEL, 0.1, sc.DEPTH_MAX,
+                                             frag_buffer_size=65536)
+        want_rc = orc.raycast(og.h, og.tsdf, og.weight, og.color, range_o, K,
+                              extr, H, W, sc.RES, sc.VOXEL, sc.DEPTH_SCALE,
+                              0.1, sc.DEPTH_MAX, wthr, sc.TRUNC_MULT, 8,
+                              ("depth", "color"))
+        gd = raycast_frame.get_data("depth").cpu().numpy()
+        gc = raycast_frame.get_data("color").cpu().numpy()
+        assert np.array_equal(gd > 0, want_rc["depth"] > 0)
+        assert (gd > 0).mean() > 0.5
+        assert np.abs(gd - want_rc["depth"]).max() <= 1e-3
+        assert np.abs(gc - want_rc["color"]).max() <= 1e-5
+    assert _compare_grids(og, model.voxel_grid)[1]  # whole grid bit-exact
+    # the trajectory follows the ground truth of the synthetic stream
+    gt = np.linalg.inv(np.array(frames[-1][3][0]))
+    e = _pose_err(gt, T_f2w)
+    assert e[0] < 5e-3 and e[1] < 1e-2, e
+    pcd = model.extract_pointcloud(3.0)
+    assert pcd["positions"].shape[0] > 1000
+    assert set(pcd) == {"positions", "normals", "colors"}
+
+
+def test_model_depth_only_and_dummy_colour():
+    _lib, geometry, slam = _gpu()
+    W, H = 320, 240
+    d, c, K, Ts = sc.frames(0, 1, W, H)
+    model = slam.Model(sc.VOXEL, sc.RES, 4096)
+    model.update_frame_pose(0, np.linalg.inv(np.array(Ts[0])))
+    f = slam.Frame(H, W, K)
+    f.set_data("depth", _dev(d[0]))
+    model.integrate(f)                       # no colour: depth-only update
+    rf = slam.Frame(H, W, K)
+    model.synthesize_model_frame(rf, enable_color=False)
+    assert rf.get_data("color").shape == (H, W, 3)
+    assert float(rf.get_data("color").abs().max()) == 0.0
+    assert (rf.get_data("depth") > 0).float().mean() > 0.5
+    r = model.track_frame_to_model(f, rf)    # point-to-plane ignores colour
+    assert np.abs(r.transformation - np.eye(4)).max() < 5e-3
+    with pytest.raises(RuntimeError, match="previous Integrate"):
+        slam.Model(sc.VOXEL).synthesize_model_frame(slam.Frame(H, W, K))
