@@ -25,7 +25,15 @@
 #include <vector>
 
 #include "../common.h"
+#include "../mailbox.h"
 #include "o3d_mi355x_host.h"
+
+extern "C" int o3dmi_odometry_sums_post(
+        int method, int rows, int cols, const float* const* maps11,
+        const double* intrinsics, const double* init_source_to_target,
+        float depth_outlier_trunc, float depth_huber_delta,
+        float intensity_huber_delta, double* scratch_dev, double* sums29_dev,
+        double* mail_data, int* mail_flag, int mail_seq, o3dmi_stream_t stream);
 
 using namespace o3dmi;
 
@@ -141,12 +149,9 @@ extern "C" int o3dmi_rgbd_odometry_multiscale(
     double* sums_dev = scratch_dev + n_scratch;
     slab.used = (sums_bytes + 255) & ~(size_t)255;
 
-    double* sums_host = nullptr;
-    O3DMI_HIP_CHECK(hipHostMalloc((void**)&sums_host, sizeof(double) * 32));
-    struct HostFree {
-        double* p;
-        ~HostFree() { (void)hipHostFree(p); }
-    } host_free{sums_host};
+    Mailbox* mb = ThreadMailbox();
+    O3DMI_REQUIRE(mb != nullptr, "host mailbox allocation failed");
+    const double* sums_host = mb->data;
 
     // ---- pre-processing: RGBDOdometry.cpp:86-89, :223-228 --------------------
     const float kNan = std::nanf("");
@@ -260,19 +265,21 @@ extern "C" int o3dmi_rgbd_odometry_multiscale(
     for (int i = 0; i < n_levels; ++i) {
         const Level& L = levels[(size_t)i];
         for (int iter = 0; iter < criteria[i].max_iteration; ++iter) {
-            if ((st = o3dmi_odometry_sums(
-                         method, L.rows, L.cols, L.source_depth, L.target_depth,
-                         L.source_intensity, L.target_intensity,
-                         L.target_depth_dx, L.target_depth_dy,
-                         L.target_intensity_dx, L.target_intensity_dy,
-                         L.source_vertex, L.target_vertex, L.target_normal, L.K,
-                         T, depth_outlier_trunc, depth_huber_delta,
-                         intensity_huber_delta, scratch_dev, sums_dev, stream)))
+            const float* maps[11] = {
+                    L.source_depth,        L.target_depth,
+                    L.source_intensity,    L.target_intensity,
+                    L.target_depth_dx,     L.target_depth_dy,
+                    L.target_intensity_dx, L.target_intensity_dy,
+                    L.source_vertex,       L.target_vertex,
+                    L.target_normal};
+            const int seq = ++mb->seq;
+            if ((st = o3dmi_odometry_sums_post(
+                         method, L.rows, L.cols, maps, L.K, T,
+                         depth_outlier_trunc, depth_huber_delta,
+                         intensity_huber_delta, scratch_dev, sums_dev, mb->data,
+                         mb->flag, seq, stream)))
                 return st;
-            O3DMI_HIP_CHECK(hipMemcpyAsync(sums_host, sums_dev,
-                                           sizeof(double) * 29,
-                                           hipMemcpyDeviceToHost, s));
-            O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+            O3DMI_HIP_CHECK(MailboxWait(mb, seq, s));
             double pose[6], dT[16];
             float residual;
             int count;

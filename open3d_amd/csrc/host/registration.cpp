@@ -9,7 +9,8 @@
 //   ------------------------------    -----------------------------------------
 //   HybridSearch kernel               one fused kernel: search + sum d2 + count
 //   counts.Sum  -> D2H sync             + Jacobian/29-sum accumulation
-//   dist.Sum    -> D2H sync           one 256-byte D2H copy (the only sync)
+//   dist.Sum    -> D2H sync           sums posted to a host mailbox by the final
+//                                     reduction kernel (no copy / sync call)
 //   29-sum kernel -> D2H sync         [optional cross-GPU all-reduce hook]
 //   6x6 solve on host (F64)           6x6 solve on host (F64), same arithmetic
 //   4x4 upload + transform kernel     transform kernel (matrix by value)
@@ -24,7 +25,15 @@
 #include <vector>
 
 #include "../common.h"
+#include "../mailbox.h"
 #include "o3d_mi355x_host.h"
+
+extern "C" int o3dmi_icp_search_accumulate_post(
+        const o3dmi_nns_t* nns, const void* src_dev,
+        const void* tgt_normals_dev, int64_t n, int robust_kernel,
+        double scaling_parameter, double shape_parameter,
+        int64_t* corr_out_dev, double* sums32_dev, double* mail_data,
+        int* mail_flag, int mail_seq, o3dmi_stream_t stream);
 
 extern "C" int o3dmi_nns_set_normals(o3dmi_nns_t* nns, const void* normals_dev,
                                      o3dmi_stream_t stream);
@@ -167,14 +176,12 @@ extern "C" int o3dmi_registration_multiscale_icp(
         L.nrm_ptr = L.nrm.p;
     }
 
-    DeviceBuffer sums_dev;
-    if ((st = sums_dev.Alloc(sizeof(double) * 32))) return st;
-    double* sums_host = nullptr;
-    O3DMI_HIP_CHECK(hipHostMalloc((void**)&sums_host, sizeof(double) * 32));
-    struct HostFree {
-        double* p;
-        ~HostFree() { (void)hipHostFree(p); }
-    } host_free{sums_host};
+    // Per-iteration sums arrive through the thread's host mailbox: the final
+    // reduction kernel writes them into host-mapped memory and bumps a
+    // sequence word the host spins on (no copy / stream synchronise call).
+    Mailbox* mb = ThreadMailbox();
+    O3DMI_REQUIRE(mb != nullptr, "host mailbox allocation failed");
+    const double* sums_host = mb->data;
 
     double T[16];
     if (init) std::memcpy(T, init, sizeof(T));
@@ -188,15 +195,13 @@ extern "C" int o3dmi_registration_multiscale_icp(
     // ComputeRegistrationResult (+ the Jacobian sums of the same pass).
     auto search = [&](o3dmi_nns_t* nns, const Level& L, int64_t* corr_out,
                       SearchResult& r) -> int {
-        int e = o3dmi_icp_search_accumulate(nns, L.src.p, nullptr, L.ns,
-                                            robust_kernel, scaling_parameter,
-                                            shape_parameter, corr_out,
-                                            (double*)sums_dev.p, stream);
+        const int seq = ++mb->seq;
+        int e = o3dmi_icp_search_accumulate_post(
+                nns, L.src.p, nullptr, L.ns, robust_kernel, scaling_parameter,
+                shape_parameter, corr_out, nullptr, mb->data, mb->flag, seq,
+                stream);
         if (e) return e;
-        O3DMI_HIP_CHECK(hipMemcpyAsync(sums_host, sums_dev.p,
-                                       sizeof(double) * 32,
-                                       hipMemcpyDeviceToHost, s));
-        O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+        O3DMI_HIP_CHECK(MailboxWait(mb, seq, s));
         std::memcpy(r.sums, sums_host, sizeof(r.sums));
         r.sums[31] = (double)L.ns;
         if (allreduce) {

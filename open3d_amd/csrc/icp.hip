@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "common.h"
+#include "mailbox.h"
 
 namespace o3dmi {
 namespace {
@@ -380,7 +381,8 @@ __device__ __forceinline__ void BlockReduceAndStore(double (&A)[kNumSums],
 
 __global__ void FinalReduceKernel(const double* __restrict__ partials,
                                   int n_rows, double* __restrict__ out,
-                                  int n_out) {
+                                  int n_out, double* mail_data, int* mail_flag,
+                                  int mail_seq) {
     // one wave per output column would waste lanes; 32 columns x 8 row-lanes.
     __shared__ double lds[8][kNumSums];
     int col = threadIdx.x % kNumSums;
@@ -393,8 +395,12 @@ __global__ void FinalReduceKernel(const double* __restrict__ partials,
         double s = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) s += lds[k][threadIdx.x];
-        out[threadIdx.x] = s;
+        if (out) out[threadIdx.x] = s;
+        if (mail_data) mail_data[threadIdx.x] = s;
     }
+    // Host mailbox (mailbox.h): the driver spins on the sequence word instead
+    // of a copy + stream synchronise per iteration.
+    if (mail_flag) MailboxPublish(mail_flag, mail_seq);
 }
 
 template <typename T>
@@ -683,18 +689,40 @@ int o3dmi_icp_p2plane_accumulate(const void* src_dev, const void* tgt_dev,
                            (const float*)tgt_dev, (const float*)tgt_normals_dev,
                            corr_dev, n, rp, partials);
     hipLaunchKernelGGL(FinalReduceKernel, dim3(1), dim3(256), 0, s, partials, g,
-                       sums29_dev, 29);
+                       sums29_dev, 29, (double*)nullptr, (int*)nullptr, 0);
     O3DMI_HIP_CHECK(hipGetLastError());
     O3DMI_HIP_CHECK(hipFreeAsync(partials, s));
     return O3DMI_OK;
 }
+
+int o3dmi_icp_search_accumulate_post(
+        const o3dmi_nns_t* nns, const void* src_dev,
+        const void* tgt_normals_dev, int64_t n, int robust_kernel,
+        double scaling_parameter, double shape_parameter,
+        int64_t* corr_out_dev, double* sums32_dev, double* mail_data,
+        int* mail_flag, int mail_seq, o3dmi_stream_t stream);
 
 int o3dmi_icp_search_accumulate(const o3dmi_nns_t* nns, const void* src_dev,
                                 const void* tgt_normals_dev, int64_t n,
                                 int robust_kernel, double scaling_parameter,
                                 double shape_parameter, int64_t* corr_out_dev,
                                 double* sums32_dev, o3dmi_stream_t stream) {
-    O3DMI_REQUIRE(nns && src_dev && sums32_dev, "null argument");
+    O3DMI_REQUIRE(sums32_dev != nullptr, "null argument");
+    return o3dmi_icp_search_accumulate_post(
+            nns, src_dev, tgt_normals_dev, n, robust_kernel, scaling_parameter,
+            shape_parameter, corr_out_dev, sums32_dev, nullptr, nullptr, 0,
+            stream);
+}
+
+// Internal (not in the public header): also posts the 32 sums to a host
+// mailbox (mailbox.h) when mail_data != NULL; sums32_dev may then be NULL.
+int o3dmi_icp_search_accumulate_post(
+        const o3dmi_nns_t* nns, const void* src_dev,
+        const void* tgt_normals_dev, int64_t n, int robust_kernel,
+        double scaling_parameter, double shape_parameter,
+        int64_t* corr_out_dev, double* sums32_dev, double* mail_data,
+        int* mail_flag, int mail_seq, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(nns && src_dev && (sums32_dev || mail_data), "null argument");
     O3DMI_REQUIRE(robust_kernel >= 0 && robust_kernel <= 6,
                   "Unsupported method.");
     hipStream_t s = (hipStream_t)stream;
@@ -721,7 +749,8 @@ int o3dmi_icp_search_accumulate(const o3dmi_nns_t* nns, const void* src_dev,
                            (const float*)src_dev, n, rp, corr_out_dev,
                            nns->partials);
     hipLaunchKernelGGL(FinalReduceKernel, dim3(1), dim3(256), 0, s,
-                       nns->partials, g, sums32_dev, kNumSums);
+                       nns->partials, g, sums32_dev, kNumSums, mail_data,
+                       mail_flag, mail_seq);
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
 }

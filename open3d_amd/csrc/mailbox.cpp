@@ -1,0 +1,53 @@
+#include "mailbox.h"
+
+#include <chrono>
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+namespace o3dmi {
+
+Mailbox* ThreadMailbox() {
+    thread_local Mailbox mb;
+    thread_local bool tried = false;
+    if (!tried) {
+        tried = true;
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 512, hipHostMallocMapped | hipHostMallocCoherent) ==
+            hipSuccess) {
+            mb.data = (double*)p;
+            mb.flag = (int*)((char*)p + 384);
+            *mb.flag = 0;
+            mb.seq = 0;
+        }
+    }
+    return mb.data ? &mb : nullptr;
+}
+
+hipError_t MailboxWait(Mailbox* mb, int seq, hipStream_t s) {
+    using clock = std::chrono::steady_clock;
+    auto next_query = clock::now() + std::chrono::milliseconds(2);
+    for (;;) {
+        for (int spin = 0; spin < 256; ++spin) {
+            if (__atomic_load_n(mb->flag, __ATOMIC_ACQUIRE) == seq)
+                return hipSuccess;
+#if defined(__x86_64__)
+            _mm_pause();
+#endif
+        }
+        if (clock::now() >= next_query) {
+            // A failed launch / device fault never posts: ask the stream.
+            hipError_t e = hipStreamQuery(s);
+            if (e == hipSuccess) {
+                if (__atomic_load_n(mb->flag, __ATOMIC_ACQUIRE) == seq)
+                    return hipSuccess;
+                return hipErrorUnknown;  // finished without posting
+            }
+            if (e != hipErrorNotReady) return e;
+            next_query = clock::now() + std::chrono::milliseconds(2);
+        }
+    }
+}
+
+}  // namespace o3dmi

@@ -965,6 +965,18 @@ int o3dmi_odometry_sums_scratch_doubles(void) {
     return kSumsMaxGrid * kOdoSums;
 }
 
+// Internal (not in the public header): the same reduction, with the result
+// also posted to a host mailbox (mailbox.h) when mail_data != NULL.
+int o3dmi_odometry_sums_post(int method, int rows, int cols,
+                             const float* const* maps11,
+                             const double* intrinsics,
+                             const double* init_source_to_target,
+                             float depth_outlier_trunc, float depth_huber_delta,
+                             float intensity_huber_delta, double* scratch_dev,
+                             double* sums29_dev, double* mail_data,
+                             int* mail_flag, int mail_seq,
+                             o3dmi_stream_t stream);
+
 int o3dmi_odometry_sums(int method, int rows, int cols,
                         const float* source_depth_dev,
                         const float* target_depth_dev,
@@ -982,10 +994,44 @@ int o3dmi_odometry_sums(int method, int rows, int cols,
                         float depth_outlier_trunc, float depth_huber_delta,
                         float intensity_huber_delta, double* scratch_dev,
                         double* sums29_dev, o3dmi_stream_t stream) {
+    const float* maps[11] = {source_depth_dev,        target_depth_dev,
+                             source_intensity_dev,    target_intensity_dev,
+                             target_depth_dx_dev,     target_depth_dy_dev,
+                             target_intensity_dx_dev, target_intensity_dy_dev,
+                             source_vertex_dev,       target_vertex_dev,
+                             target_normal_dev};
+    O3DMI_REQUIRE(sums29_dev != nullptr, "null argument");
+    return o3dmi_odometry_sums_post(method, rows, cols, maps, intrinsics,
+                                    init_source_to_target, depth_outlier_trunc,
+                                    depth_huber_delta, intensity_huber_delta,
+                                    scratch_dev, sums29_dev, nullptr, nullptr,
+                                    0, stream);
+}
+
+int o3dmi_odometry_sums_post(int method, int rows, int cols,
+                             const float* const* maps11,
+                             const double* intrinsics,
+                             const double* init_source_to_target,
+                             float depth_outlier_trunc, float depth_huber_delta,
+                             float intensity_huber_delta, double* scratch_dev,
+                             double* sums29_dev, double* mail_data,
+                             int* mail_flag, int mail_seq,
+                             o3dmi_stream_t stream) {
+    const float* source_depth_dev = maps11[0];
+    const float* target_depth_dev = maps11[1];
+    const float* source_intensity_dev = maps11[2];
+    const float* target_intensity_dev = maps11[3];
+    const float* target_depth_dx_dev = maps11[4];
+    const float* target_depth_dy_dev = maps11[5];
+    const float* target_intensity_dx_dev = maps11[6];
+    const float* target_intensity_dy_dev = maps11[7];
+    const float* source_vertex_dev = maps11[8];
+    const float* target_vertex_dev = maps11[9];
+    const float* target_normal_dev = maps11[10];
     O3DMI_REQUIRE(method >= 0 && method <= 2, "Odometry method not implemented.");
     O3DMI_REQUIRE(rows > 0 && cols > 0, "empty image");
-    O3DMI_REQUIRE(intrinsics && init_source_to_target && sums29_dev &&
-                          source_vertex_dev,
+    O3DMI_REQUIRE(intrinsics && init_source_to_target && source_vertex_dev &&
+                          (sums29_dev || mail_data),
                   "null argument");
     if (method == O3DMI_ODOMETRY_POINT_TO_PLANE) {
         O3DMI_REQUIRE(target_vertex_dev && target_normal_dev,
@@ -1037,7 +1083,7 @@ int o3dmi_odometry_sums(int method, int rows, int cols,
                            s, m, ti, depth_outlier_trunc, depth_huber_delta,
                            intensity_huber_delta, partials);
     hipLaunchKernelGGL(FinalSumKernel<kOdoSums>, dim3(1), dim3(256), 0, s,
-                       partials, g, sums29_dev);
+                       partials, g, sums29_dev, mail_data, mail_flag, mail_seq);
     hipError_t e = hipGetLastError();
     if (own) {
         // The pool hands the block out again only to later work; drain first.
@@ -1071,7 +1117,7 @@ int o3dmi_odometry_information(int rows, int cols,
                        Camera::Make(intrinsics, source_to_target),
                        square_dist_thr, partials);
     hipLaunchKernelGGL(FinalSumKernel<kInfoSums>, dim3(1), dim3(256), 0, s,
-                       partials, g, out_dev);
+                       partials, g, out_dev, (double*)nullptr, (int*)nullptr, 0);
     double A[kInfoSums];
     hipError_t e = hipMemcpyAsync(A, out_dev, sizeof(A), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);

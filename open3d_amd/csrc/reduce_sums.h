@@ -12,6 +12,8 @@
 
 #include <cstdint>
 
+#include "mailbox.h"
+
 namespace o3dmi {
 
 constexpr int kSumsBlock = 256;
@@ -49,9 +51,11 @@ __device__ __forceinline__ void BlockSumAndStore(double (&A)[N],
 
 // One workgroup of 256 lanes: lane (r, c) = (tid / 32, tid % 32) strides over
 // the rows, 8 row-lanes are then added in a fixed order. N <= 32.
+// mail_data / mail_flag (optional): host mailbox, see mailbox.h.
 template <int N>
 __global__ void FinalSumKernel(const double* __restrict__ partials, int n_rows,
-                               double* __restrict__ out) {
+                               double* __restrict__ out, double* mail_data,
+                               int* mail_flag, int mail_seq) {
     __shared__ double lds[8][32];
     const int col = threadIdx.x & 31;
     const int rl = threadIdx.x >> 5;
@@ -64,8 +68,10 @@ __global__ void FinalSumKernel(const double* __restrict__ partials, int n_rows,
         double s = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) s += lds[k][threadIdx.x];
-        out[threadIdx.x] = s;
+        if (out) out[threadIdx.x] = s;
+        if (mail_data) mail_data[threadIdx.x] = s;
     }
+    if (mail_flag) MailboxPublish(mail_flag, mail_seq);
 }
 
 }  // namespace o3dmi

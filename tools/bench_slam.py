@@ -13,6 +13,14 @@
                 for the next frame. frames/s and pose drift against the
                 ground-truth trajectory.
 
+  --mode model  the reference's own dense-SLAM loop (examples/python/
+                t_reconstruction_system/dense_slam.py) through slam::Model:
+                TrackFrameToModel (RGB-D odometry, point-to-plane, {6,3,1}
+                iterations) -> UpdateFramePose -> Integrate ->
+                SynthesizeModelFrame, on a synthetic VGA or 720p stream; with
+                per-operator times (HIP events) and, with --cpu-frames > 0, the
+                same operators through the CPU oracle on the first frames.
+
 One JSON line per mode on stdout. torch is used as an array library for the
 glue between operators (mask / reshape / 4x4 products), as an Open3D user
 would use Tensor ops there.
@@ -169,9 +177,129 @@ def mode_slam(a):
     print(json.dumps(out), flush=True)
 
 
+def mode_model(a):
+    from open3d_amd import slam, synthetic
+    from open3d_amd.odometry import Method
+    W, H = (1280, 720) if a.hd else (640, 480)
+    voxel, res, trunc = 0.008, 16, 8.0
+    ds, dmax = 1000.0, 3.0
+    n = a.frames
+    K = synthetic.intrinsics(W, H)
+    depths, colors, Ts = [], [], []
+    for k in range(n):
+        d, c, _, T = synthetic.render_frames(k * a.frame_step, 1, W, H,
+                                             device="cuda")
+        depths.append(d[0].contiguous())
+        colors.append(c[0].contiguous())
+        Ts.append(np.linalg.inv(np.array(T[0])))  # frame -> world
+    method = {"p2plane": Method.PointToPlane, "intensity": Method.Intensity,
+              "hybrid": Method.Hybrid}[a.method]
+
+    def run(timed):
+        model = slam.Model(voxel, res, a.block_count, Ts[0])
+        fin, frc = slam.Frame(H, W, K), slam.Frame(H, W, K)
+        T = np.array(Ts[0])
+        ev = []
+        iters = 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            fin.set_data("depth", depths[i])
+            fin.set_data("color", colors[i])
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)] \
+                if timed else None
+            if timed:
+                e[0].record()
+            if i > 0:
+                r = model.track_frame_to_model(fin, frc, ds, dmax, 0.07,
+                                               method)
+                iters += r.num_iterations
+                T = T @ r.transformation
+            model.update_frame_pose(i, T)
+            if timed:
+                e[1].record()
+            model.integrate(fin, ds, dmax, trunc)
+            if timed:
+                e[2].record()
+            model.synthesize_model_frame(frc, ds, 0.1, dmax, trunc,
+                                         a.method != "p2plane")
+            if timed:
+                e[3].record()
+                ev.append(e)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return model, T, dt, ev, iters
+
+    run(False)                     # warm-up (allocations, code objects)
+    model, T, dt, _, iters = run(False)
+    _, _, _, ev, _ = run(True)
+    op = np.array([[e[k].elapsed_time(e[k + 1]) for k in range(3)]
+                   for e in ev[1:]])
+    err = pose_err(Ts[-1], T)
+    moved = pose_err(Ts[0], Ts[-1])
+    out = {"mode": "model", "workload": "dense_slam.py loop through slam::Model"
+           ", %dx%d synthetic stream, method %s, criteria {6,3,1}, 8 mm / 16^3"
+           % (W, H, a.method),
+           "frames": n, "frames_per_s": n / dt, "ms_per_frame": dt / n * 1e3,
+           "odometry_iterations_per_frame": iters / max(1, n - 1),
+           "ms_track_integrate_synthesize": [float(x) for x in op.mean(0)],
+           "final_pose_err_rad_m": err, "trajectory_moved_rad_m": moved,
+           "active_blocks": model.get_hashmap().size()}
+    if a.cpu_frames > 0:
+        import _oracle as orc
+        orc.set_threads(min(64, os.cpu_count() or 1))
+        cap = 16384
+        h = orc.HashMap(cap)
+        tsdf = np.zeros((cap, res, res, res), np.float32)
+        wgt = np.zeros((cap, res, res, res), np.uint16)
+        col = np.zeros((cap, res, res, res, 3), np.uint16)
+        Tc = np.array(Ts[0])
+        rd = rc = None
+        tt = np.zeros(3)
+        crit = ((6, 1e-6, 1e-6), (3, 1e-6, 1e-6), (1, 1e-6, 1e-6))
+        for i in range(min(a.cpu_frames, n)):
+            dn, cn = depths[i].cpu().numpy(), colors[i].cpu().numpy()
+            t0 = time.perf_counter()
+            if i > 0:
+                r = orc.rgbd_odometry_multiscale(
+                    int(method), dn, rd, K, src_color=cn, tgt_color=rc,
+                    criteria=crit, accumulate_double=False)
+                Tc = Tc @ r["transformation"]
+            t1 = time.perf_counter()
+            extr = orc.inverse_transformation(Tc)
+            keys = orc.depth_touch(dn, K, extr, res, voxel, voxel * trunc, ds,
+                                   dmax)
+            h.activate(keys)
+            buf, _ = h.find(keys)
+            orc.integrate(dn, cn, buf, h.key_buffer(), tsdf, wgt, col, K, K,
+                          extr, res, voxel, voxel * trunc, ds, dmax)
+            t2 = time.perf_counter()
+            rng, _ = orc.estimate_range(keys, K, extr, H, W, 8, res, voxel, 0.1,
+                                        dmax, frag_buffer_size=262144)
+            o = orc.raycast(h, tsdf, wgt, col, rng, K, extr, H, W, res, voxel,
+                            ds, 0.1, dmax, min(float(i), 3.0), trunc, 8,
+                            ("depth", "color"))
+            t3 = time.perf_counter()
+            rd, rc = o["depth"][..., 0].copy(), o["color"]
+            if i > 0:
+                tt += (t1 - t0, t2 - t1, t3 - t2)
+        k = max(1, min(a.cpu_frames, n) - 1)
+        out["cpu_oracle_ms_track_integrate_synthesize"] = \
+            [float(x) for x in tt / k * 1e3]
+        out["cpu_oracle_threads"] = {"track": 1, "integrate_raycast":
+                                     min(64, os.cpu_count() or 1)}
+        out["cpu_oracle_frames_per_s"] = float(k / tt.sum()) if tt.sum() else 0
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", choices=["icp", "slam", "both"], default="both")
+    ap.add_argument("--mode", choices=["icp", "slam", "model", "both"],
+                    default="both")
+    ap.add_argument("--hd", action="store_true", help="1280x720 (model mode)")
+    ap.add_argument("--method", default="p2plane",
+                    choices=["p2plane", "intensity", "hybrid"])
+    ap.add_argument("--cpu-frames", type=int, default=0)
     ap.add_argument("--points", type=int, default=100000)
     ap.add_argument("--repeat", type=int, default=5)
     ap.add_argument("--frames", type=int, default=40)
@@ -184,6 +312,8 @@ def main():
         mode_icp(a)
     if a.mode in ("slam", "both"):
         mode_slam(a)
+    if a.mode == "model":
+        mode_model(a)
 
 
 if __name__ == "__main__":
