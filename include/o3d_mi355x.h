@@ -55,7 +55,13 @@ typedef enum {
     O3DMI_U16 = 2,
     O3DMI_U8 = 3,
     O3DMI_I32 = 4,
-    O3DMI_I64 = 5
+    O3DMI_I64 = 5,
+    /* NPZ interchange only (t/io/NumpyIO.cpp:132-155): */
+    O3DMI_I8 = 6,
+    O3DMI_I16 = 7,
+    O3DMI_U32 = 8,
+    O3DMI_U64 = 9,
+    O3DMI_BOOL = 10
 } o3dmi_dtype_t;
 
 /* RobustKernelMethod, t/pipelines/registration/RobustKernel.h:15-23 */

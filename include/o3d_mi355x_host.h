@@ -314,6 +314,48 @@ int o3dmi_slam_model_extract_point_cloud(o3dmi_slam_model_t* m,
                                          int64_t* total_out,
                                          o3dmi_stream_t stream);
 
+/* ------------------------------------------------------------------------ */
+/* NPZ interchange (t/io/NumpyIO.cpp) and VoxelBlockGrid::Save / Load        */
+/* ------------------------------------------------------------------------ */
+/* An in-memory set of named host arrays. o3dmi_npz_write = t::io::WriteNpz
+ * (NumpyIO.cpp:759-789; NPY 1.0 headers and stored zip entries formatted as
+ * the reference does, ZIP64 where its 32-bit fields would wrap);
+ * o3dmi_npz_read = t::io::ReadNpz (:675-757; also reads numpy's own savez /
+ * savez_compressed output). Little-endian C-order arrays only. */
+typedef struct o3dmi_npz o3dmi_npz_t;
+int o3dmi_npz_create(o3dmi_npz_t** out);
+int o3dmi_npz_destroy(o3dmi_npz_t* z);
+/* Copies `data_host`; an existing entry of the same name is replaced. */
+int o3dmi_npz_add(o3dmi_npz_t* z, const char* name, int dtype, int ndim,
+                  const int64_t* shape, const void* data_host);
+int o3dmi_npz_count(const o3dmi_npz_t* z);
+const char* o3dmi_npz_name(const o3dmi_npz_t* z, int i);
+/* shape8 must hold 8 entries; *data_host points into the set. */
+int o3dmi_npz_get(const o3dmi_npz_t* z, const char* name, int* dtype, int* ndim,
+                  int64_t* shape8, const void** data_host);
+int o3dmi_npz_write(const o3dmi_npz_t* z, const char* file_name);
+int o3dmi_npz_read(const char* file_name, o3dmi_npz_t** out);
+
+/* VoxelBlockGrid::Save(file_name) (VoxelBlockGrid.cpp:474-524): entries
+ * "voxel_size" {1} f32, "block_resolution" {1} i64, a 0-d u8 placeholder named
+ * after the device ("HIP:0" -- stock Open3D ignores unknown prefixes and loads
+ * on CPU:0), "attr_name_<name>" {1} i32 = value index, "key" {n,3} i32 and
+ * "value_%03d" {n,res,res,res,C} of the ACTIVE blocks (ascending buffer
+ * index). ".npz" is appended when missing, as the reference. */
+int o3dmi_vbg_save(o3dmi_vbg_t* g, const char* file_name,
+                   o3dmi_stream_t stream);
+/* VoxelBlockGrid::Load(file_name) (VoxelBlockGrid.cpp:538-596): capacity =
+ * number of stored keys; keys and value rows are inserted into a new grid on
+ * the current device. */
+int o3dmi_vbg_load(const char* file_name, o3dmi_stream_t stream,
+                   o3dmi_vbg_t** out);
+/* Introspection of a grid (needed after Load): attribute count / i-th name,
+ * voxel size, block resolution. */
+int o3dmi_vbg_attribute_count(const o3dmi_vbg_t* g);
+const char* o3dmi_vbg_attribute_name(const o3dmi_vbg_t* g, int i);
+float o3dmi_vbg_voxel_size(const o3dmi_vbg_t* g);
+int64_t o3dmi_vbg_block_resolution(const o3dmi_vbg_t* g);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,7 @@ SO_PATH = os.path.join(_HERE, "lib", "libo3d_mi355x.so")
 
 OK = 0
 F32, F64, U16, U8, I32, I64 = 0, 1, 2, 3, 4, 5
+I8, I16, U32, U64, BOOL = 6, 7, 8, 9, 10
 
 _vp = C.c_void_p
 _i64 = C.c_int64
@@ -189,6 +190,23 @@ PROTOTYPES.update({
     "o3dmi_slam_model_extract_point_cloud": (_i32, [_vp, _f, _i64, _vp, _vp,
                                                     _vp, C.POINTER(_i64),
                                                     _vp]),
+    "o3dmi_npz_create": (_i32, [C.POINTER(_vp)]),
+    "o3dmi_npz_destroy": (_i32, [_vp]),
+    "o3dmi_npz_add": (_i32, [_vp, C.c_char_p, _i32, _i32, C.POINTER(_i64),
+                             _vp]),
+    "o3dmi_npz_count": (_i32, [_vp]),
+    "o3dmi_npz_name": (C.c_char_p, [_vp, _i32]),
+    "o3dmi_npz_get": (_i32, [_vp, C.c_char_p, C.POINTER(_i32),
+                             C.POINTER(_i32), C.POINTER(_i64),
+                             C.POINTER(_vp)]),
+    "o3dmi_npz_write": (_i32, [_vp, C.c_char_p]),
+    "o3dmi_npz_read": (_i32, [C.c_char_p, C.POINTER(_vp)]),
+    "o3dmi_vbg_save": (_i32, [_vp, C.c_char_p, _vp]),
+    "o3dmi_vbg_load": (_i32, [C.c_char_p, _vp, C.POINTER(_vp)]),
+    "o3dmi_vbg_attribute_count": (_i32, [_vp]),
+    "o3dmi_vbg_attribute_name": (C.c_char_p, [_vp, _i32]),
+    "o3dmi_vbg_voxel_size": (_f, [_vp]),
+    "o3dmi_vbg_block_resolution": (_i64, [_vp]),
     "o3dmi_vbg_ray_cast": (
         _i32, [_vp, _vp, _i64, _dp, _dp, _i32, _i32, _vp] + [_vp] * 10 +
         [_f, _f, _f, _f, _f, _i32, _vp]),

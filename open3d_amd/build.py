@@ -90,7 +90,7 @@ def build(force=False, verbose=True):
     objs = [_obj(s) for s in srcs]
     if force or todo or _stale(SO, objs):
         cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + \
-              ["-o", SO]
+              ["-lz", "-o", SO]  # zlib: CRC-32 / inflate of the NPZ codec
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))

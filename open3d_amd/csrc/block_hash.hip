@@ -456,27 +456,17 @@ int o3dmi_hash_reserve(o3dmi_hash_t* h, int64_t capacity,
         int64_t c2 = 0;
         st = o3dmi_hash_active_indices(h, active, stream, &c2);
         if (st != O3DMI_OK) return st;
-        std::vector<int> host_active((size_t)c2);
-        O3DMI_HIP_CHECK(hipMemcpy(host_active.data(), active, sizeof(int) * c2,
-                                  hipMemcpyDeviceToHost));
         O3DMI_HIP_CHECK(hipMalloc((void**)&keys, sizeof(int) * 3 * c2));
         for (int j = 0; j < h->n_values; ++j)
             O3DMI_HIP_CHECK(hipMalloc(&vals[j], h->value_dsizes[j] * c2));
-        // Gather rows (value rows are large: one async D2D copy per row).
-        for (int64_t i = 0; i < c2; ++i) {
-            int b = host_active[(size_t)i];
-            O3DMI_HIP_CHECK(hipMemcpyAsync(keys + 3 * i,
-                                           h->view.key_buffer + 3 * (int64_t)b,
-                                           sizeof(int) * 3,
-                                           hipMemcpyDeviceToDevice, s));
-            for (int j = 0; j < h->n_values; ++j) {
-                int64_t sz = h->value_dsizes[j];
-                O3DMI_HIP_CHECK(hipMemcpyAsync(
-                        (uint8_t*)vals[j] + sz * i,
-                        (uint8_t*)h->value_buffers[j] + sz * b, sz,
-                        hipMemcpyDeviceToDevice, s));
-            }
-        }
+        // Gather the active rows (rows.hip).
+        if ((st = GatherRows(h->view.key_buffer, active, c2, sizeof(int) * 3,
+                             keys, s)))
+            return st;
+        for (int j = 0; j < h->n_values; ++j)
+            if ((st = GatherRows(h->value_buffers[j], active, c2,
+                                 h->value_dsizes[j], vals[j], s)))
+                return st;
         O3DMI_HIP_CHECK(hipStreamSynchronize(s));
         count = c2;
     }
@@ -493,21 +483,10 @@ int o3dmi_hash_reserve(o3dmi_hash_t* h, int64_t capacity,
                            h->view, keys, count, (const int*)nullptr, buf,
                            (uint8_t*)nullptr, 0, nullptr, nullptr, nullptr);
         O3DMI_HIP_CHECK(hipGetLastError());
-        std::vector<int> host_buf((size_t)count);
-        O3DMI_HIP_CHECK(hipMemcpyAsync(host_buf.data(), buf,
-                                       sizeof(int) * count,
-                                       hipMemcpyDeviceToHost, s));
-        O3DMI_HIP_CHECK(hipStreamSynchronize(s));
-        for (int64_t i = 0; i < count; ++i) {
-            for (int j = 0; j < h->n_values; ++j) {
-                int64_t sz = h->value_dsizes[j];
-                O3DMI_HIP_CHECK(hipMemcpyAsync(
-                        (uint8_t*)h->value_buffers[j] +
-                                sz * (int64_t)host_buf[(size_t)i],
-                        (uint8_t*)vals[j] + sz * i, sz,
-                        hipMemcpyDeviceToDevice, s));
-            }
-        }
+        for (int j = 0; j < h->n_values; ++j)
+            if ((st = ScatterRows(vals[j], buf, count, h->value_dsizes[j],
+                                  h->value_buffers[j], s)))
+                return st;
         O3DMI_HIP_CHECK(hipStreamSynchronize(s));
         (void)hipFree(buf);
     }

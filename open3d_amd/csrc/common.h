@@ -22,6 +22,13 @@ void SetLastError(const std::string& msg);
 int PoolAlloc(void** out, size_t bytes);
 void PoolFree(void* p);
 
+// Row gather / scatter by index (rows.hip): dst[r] = src[idx[r]] and
+// dst[idx[r]] = src[r] for rows of row_bytes bytes.
+int GatherRows(const void* src, const int* indices_dev, int64_t n,
+               int64_t row_bytes, void* dst, hipStream_t s);
+int ScatterRows(const void* src, const int* indices_dev, int64_t n,
+                int64_t row_bytes, void* dst, hipStream_t s);
+
 #define O3DMI_HIP_CHECK(expr)                                              \
     do {                                                                   \
         hipError_t _e = (expr);                                            \

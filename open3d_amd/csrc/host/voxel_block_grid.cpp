@@ -10,13 +10,16 @@
 // bound says a Reserve() might be needed, so the steady-state frame stream
 // (o3dmi_vbg_integrate_frame) issues kernels back to back.
 
+#include <cctype>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "../common.h"
+#include "../npz.h"
 #include "../stream_path.h"
 #include "o3d_mi355x_host.h"
 
@@ -899,6 +902,216 @@ int o3dmi_vbg_extract_point_cloud(o3dmi_vbg_t* g, float weight_threshold,
     (void)hipStreamSynchronize((hipStream_t)stream);
     PoolFree(active);
     return st;
+}
+
+int o3dmi_vbg_attribute_count(const o3dmi_vbg_t* g) {
+    return g ? (int)g->attr_names.size() : 0;
+}
+const char* o3dmi_vbg_attribute_name(const o3dmi_vbg_t* g, int i) {
+    if (!g || i < 0 || i >= (int)g->attr_names.size()) return nullptr;
+    return g->attr_names[(size_t)i].c_str();
+}
+float o3dmi_vbg_voxel_size(const o3dmi_vbg_t* g) {
+    return g ? g->voxel_size : 0.f;
+}
+int64_t o3dmi_vbg_block_resolution(const o3dmi_vbg_t* g) {
+    return g ? g->block_resolution : 0;
+}
+
+int o3dmi_vbg_save(o3dmi_vbg_t* g, const char* file_name,
+                   o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(g && file_name, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t cap = o3dmi_hash_capacity(g->block_hashmap);
+    int32_t* active = nullptr;
+    int st = PoolAlloc((void**)&active, sizeof(int32_t) * (size_t)cap);
+    if (st) return st;
+    struct Scratch {
+        hipStream_t s;
+        std::vector<void*> p;
+        ~Scratch() {
+            (void)hipStreamSynchronize(s);
+            for (void* q : p) PoolFree(q);
+        }
+    } scratch{s, {active}};
+    int64_t n = 0;
+    if ((st = o3dmi_hash_active_indices(g->block_hashmap, active, stream, &n)))
+        return st;
+    if ((st = o3dmi_sort_indices(active, n, stream))) return st;
+
+    o3dmi_npz z;
+    auto scalar = [&](const std::string& name, int dtype, const void* v,
+                      size_t bytes, bool zero_d) {
+        NpzArray a;
+        a.name = name;
+        a.dtype = dtype;
+        if (!zero_d) a.shape = {1};
+        a.data.assign((const uint8_t*)v, (const uint8_t*)v + bytes);
+        z.arrays.push_back(std::move(a));
+    };
+    const float vs = g->voxel_size;
+    const int64_t res = g->block_resolution;
+    const uint8_t zero = 0;
+    scalar("voxel_size", O3DMI_F32, &vs, sizeof(vs), false);
+    scalar("block_resolution", O3DMI_I64, &res, sizeof(res), false);
+    scalar("HIP:0", O3DMI_U8, &zero, 1, true);  // device placeholder
+    for (size_t i = 0; i < g->attr_names.size(); ++i) {
+        const int32_t id = (int32_t)i;
+        scalar("attr_name_" + g->attr_names[i], O3DMI_I32, &id, sizeof(id),
+               false);
+    }
+    // keys.IndexGet(active) / values[i].IndexGet(active) -> host
+    auto gathered = [&](const void* src, int64_t row_bytes, NpzArray* a) -> int {
+        a->data.resize((size_t)(n * row_bytes));
+        if (n == 0) return O3DMI_OK;
+        void* tmp = nullptr;
+        int e = PoolAlloc(&tmp, (size_t)(n * row_bytes));
+        if (e) return e;
+        scratch.p.push_back(tmp);
+        if ((e = GatherRows(src, active, n, row_bytes, tmp, s))) return e;
+        O3DMI_HIP_CHECK(hipMemcpyAsync(a->data.data(), tmp,
+                                       (size_t)(n * row_bytes),
+                                       hipMemcpyDeviceToHost, s));
+        O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+        return O3DMI_OK;
+    };
+    {
+        NpzArray a;
+        a.name = "key";
+        a.dtype = O3DMI_I32;
+        a.shape = {n, 3};
+        if ((st = gathered(o3dmi_hash_key_buffer(g->block_hashmap), 12, &a)))
+            return st;
+        z.arrays.push_back(std::move(a));
+    }
+    for (size_t i = 0; i < g->attr_names.size(); ++i) {
+        NpzArray a;
+        char nm[32];
+        std::snprintf(nm, sizeof(nm), "value_%03d", (int)i);
+        a.name = nm;
+        a.dtype = g->attr_dtypes[i];
+        a.shape = {n, res, res, res, (int64_t)g->attr_channels[i]};
+        const int64_t row = res * res * res * g->attr_channels[i] *
+                            DtypeSize(g->attr_dtypes[i]);
+        if ((st = gathered(o3dmi_hash_value_buffer(g->block_hashmap, (int)i),
+                           row, &a)))
+            return st;
+        z.arrays.push_back(std::move(a));
+    }
+    std::string path = file_name;
+    std::string ext;
+    {
+        const size_t dot = path.find_last_of('.');
+        if (dot != std::string::npos) ext = path.substr(dot + 1);
+        for (auto& c : ext) c = (char)std::tolower((unsigned char)c);
+    }
+    // "File name for a voxel grid should be with the extension .npz."
+    if (ext != "npz") path += ".npz";
+    return o3dmi_npz_write(&z, path.c_str());
+}
+
+int o3dmi_vbg_load(const char* file_name, o3dmi_stream_t stream,
+                   o3dmi_vbg_t** out) {
+    O3DMI_REQUIRE(file_name && out, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    o3dmi_npz_t* zp = nullptr;
+    int st = o3dmi_npz_read(file_name, &zp);
+    if (st) return st;
+    struct ZFree {
+        o3dmi_npz_t* z;
+        ~ZFree() { o3dmi_npz_destroy(z); }
+    } zfree{zp};
+    const std::string prefix = "attr_name_";
+    std::vector<std::string> names;
+    for (const NpzArray& a : zp->arrays) {
+        if (a.name.compare(0, prefix.size(), prefix) == 0) {
+            O3DMI_REQUIRE(a.dtype == O3DMI_I32 && a.NumElements() >= 1,
+                          "malformed attr_name entry");
+            const int id = *(const int32_t*)a.data.data();
+            O3DMI_REQUIRE(id >= 0 && id < 8, "attribute index out of range");
+            if ((int)names.size() <= id) names.resize((size_t)id + 1);
+            names[(size_t)id] = a.name.substr(prefix.size());
+        }
+    }
+    O3DMI_REQUIRE(!names.empty(),
+                  "Attribute names not found, not a valid file for voxel block "
+                  "grids.");
+    const NpzArray* key = zp->Find("key");
+    const NpzArray* vsz = zp->Find("voxel_size");
+    const NpzArray* bres = zp->Find("block_resolution");
+    O3DMI_REQUIRE(key && vsz && bres, "key / voxel_size / block_resolution "
+                                      "missing, not a valid voxel block grid "
+                                      "file.");
+    O3DMI_REQUIRE(key->dtype == O3DMI_I32 && key->shape.size() == 2 &&
+                          key->shape[1] == 3,
+                  "key must be {n,3} Int32");
+    O3DMI_REQUIRE(vsz->dtype == O3DMI_F32 && vsz->NumElements() >= 1 &&
+                          bres->dtype == O3DMI_I64 && bres->NumElements() >= 1,
+                  "voxel_size must be Float32, block_resolution Int64");
+    const float voxel_size = *(const float*)vsz->data.data();
+    const int64_t res = *(const int64_t*)bres->data.data();
+    const int64_t n = key->shape[0];
+    std::vector<const NpzArray*> vals(names.size());
+    std::vector<int> dtypes(names.size()), chans(names.size());
+    std::vector<const char*> cnames(names.size());
+    for (size_t i = 0; i < names.size(); ++i) {
+        char nm[32];
+        std::snprintf(nm, sizeof(nm), "value_%03d", (int)i);
+        vals[i] = zp->Find(nm);
+        O3DMI_REQUIRE(vals[i] != nullptr && !names[i].empty(),
+                      "value tensor missing for an attribute");
+        const auto& sh = vals[i]->shape;
+        O3DMI_REQUIRE(sh.size() >= 4 && sh[0] == n && sh[1] == res &&
+                              sh[2] == res && sh[3] == res,
+                      "value tensor shape mismatch");
+        int64_t c = 1;
+        for (size_t k = 4; k < sh.size(); ++k) c *= sh[k];
+        dtypes[i] = vals[i]->dtype;
+        chans[i] = (int)c;
+        cnames[i] = names[i].c_str();
+    }
+    o3dmi_vbg_t* g = nullptr;
+    // VoxelBlockGrid(attr_names, attr_dtypes, attr_channels, voxel_size,
+    //                block_resolution, keys.GetLength(), device)
+    st = o3dmi_vbg_create((int)names.size(), cnames.data(), dtypes.data(),
+                          chans.data(), voxel_size, res, n > 0 ? n : 1, stream,
+                          &g);
+    if (st) return st;
+    if (n > 0) {
+        // block_hashmap.Insert(keys, soa_value_tensor)
+        std::vector<void*> dev;
+        auto cleanup = [&]() {
+            (void)hipStreamSynchronize(s);
+            for (void* p : dev) PoolFree(p);
+        };
+        auto upload = [&](const std::vector<uint8_t>& h, void** d) -> int {
+            int e = PoolAlloc(d, h.size() ? h.size() : 1);
+            if (e) return e;
+            dev.push_back(*d);
+            O3DMI_HIP_CHECK(hipMemcpyAsync(*d, h.data(), h.size(),
+                                           hipMemcpyHostToDevice, s));
+            return O3DMI_OK;
+        };
+        void* kd = nullptr;
+        std::vector<const void*> vd(names.size());
+        st = upload(key->data, &kd);
+        for (size_t i = 0; i < names.size() && !st; ++i) {
+            void* p = nullptr;
+            st = upload(vals[i]->data, &p);
+            vd[i] = p;
+        }
+        if (!st)
+            st = o3dmi_hash_insert(g->block_hashmap, (const int32_t*)kd,
+                                   vd.data(), n, nullptr, nullptr, stream);
+        cleanup();
+        if (st) {
+            o3dmi_vbg_destroy(g);
+            return st;
+        }
+        g->size_bound = n;
+    }
+    *out = g;
+    return O3DMI_OK;
 }
 
 int o3dmi_vbg_profile_begin(o3dmi_vbg_t* g, int max_frames, int stride) {

@@ -252,6 +252,33 @@ class VoxelBlockGrid:
             C.c_float(trunc_voxel_multiplier), int(frames_per_launch), stream()),
             "VoxelBlockGrid.integrate_frames")
 
+    def save(self, file_name):
+        """VoxelBlockGrid::Save (VoxelBlockGrid.cpp:474-524): NPZ of the
+        active blocks; ".npz" is appended when missing."""
+        _lib.check(_lib.lib().o3dmi_vbg_save(self._g, str(file_name).encode(),
+                                             stream()), "VoxelBlockGrid.save")
+
+    @staticmethod
+    def load(file_name):
+        """VoxelBlockGrid::Load (VoxelBlockGrid.cpp:538-596)."""
+        h = C.c_void_p()
+        _lib.check(_lib.lib().o3dmi_vbg_load(str(file_name).encode(), stream(),
+                                             C.byref(h)),
+                   "VoxelBlockGrid.load")
+        L = _lib.lib()
+        g = VoxelBlockGrid.__new__(VoxelBlockGrid)
+        g._g = h
+        g.voxel_size = float(L.o3dmi_vbg_voxel_size(h))
+        g.block_resolution = int(L.o3dmi_vbg_block_resolution(h))
+        g.attr_names = [L.o3dmi_vbg_attribute_name(h, i).decode()
+                        for i in range(L.o3dmi_vbg_attribute_count(h))]
+        g._chans = {}
+        for nm in g.attr_names:
+            dt, ch = C.c_int(0), C.c_int(0)
+            L.o3dmi_vbg_attribute(h, nm.encode(), C.byref(dt), C.byref(ch))
+            g._chans[nm] = ch.value
+        return g
+
     def extract_point_cloud(self, weight_threshold=3.0,
                             estimated_point_number=-1):
         """ExtractPointCloud (VoxelBlockGrid.cpp:404-434) -> dict(positions,
