@@ -221,6 +221,18 @@ int o3dmi_vbg_estimate_range(const int32_t* block_keys_dev, int64_t n_blocks,
                              float depth_min, float depth_max,
                              o3dmi_stream_t stream);
 
+/* The same with the number of keys resident on the device (*n_blocks_dev <=
+ * max_blocks): frame-stream callers never read the count back. */
+int o3dmi_vbg_estimate_range_dev(const int32_t* block_keys_dev,
+                                 int64_t max_blocks,
+                                 const int32_t* n_blocks_dev,
+                                 float* range_minmax_map_dev,
+                                 const double* intrinsic,
+                                 const double* extrinsic, int h, int w,
+                                 int down_factor, int64_t block_resolution,
+                                 float voxel_size, float depth_min,
+                                 float depth_max, o3dmi_stream_t stream);
+
 /* RayCastCUDA<tsdf_t,weight_t,color_t> (VoxelBlockGridImpl.h:578-1120).
  * Output maps may be NULL when not requested: depth {h,w,1}, vertex/color/
  * normal {h,w,3} float32; index {h,w,8} int64; mask {h,w,8} bool;
@@ -400,15 +412,28 @@ int o3dmi_image_pyrdown(const float* src_dev, int rows, int cols,
 /* One pyramid level of the point-to-plane method in a single pass
  * (RGBDOdometry.cpp:124-153): source / target vertex maps and the target
  * normal map of the bilateral-smoothed (5, 5, 10) target depth; NaN = invalid.
- * Output identical to the CreateVertexMap / FilterBilateral / CreateNormalMap
- * sequence above. */
+ * When source_depth_next_dev / target_depth_next_dev are given ({rows/2,
+ * cols/2}), the same launch also writes PyrDownDepth(depth_diff, NaN) of both
+ * depth images for the next coarser level. Output identical to the
+ * CreateVertexMap / FilterBilateral / CreateNormalMap / PyrDownDepth sequence
+ * above. */
 int o3dmi_odometry_p2plane_level(const float* source_depth_dev,
                                  const float* target_depth_dev, int rows,
                                  int cols, const double* intrinsics,
                                  float* source_vertex_dev,
                                  float* target_vertex_dev,
                                  float* target_normal_dev,
-                                 o3dmi_stream_t stream);
+                                 float* source_depth_next_dev,
+                                 float* target_depth_next_dev,
+                                 float depth_diff, o3dmi_stream_t stream);
+/* ClipTransform of two images (source and target depth, dtypes independent)
+ * in one launch. */
+int o3dmi_image_clip_transform_pair(const void* src0_dev, int src0_dtype,
+                                    const void* src1_dev, int src1_dtype,
+                                    int rows, int cols, float scale,
+                                    float min_value, float max_value,
+                                    float clip_fill, float* dst0_dev,
+                                    float* dst1_dev, o3dmi_stream_t stream);
 
 /* ComputeOdometryResult{PointToPlane,Intensity,Hybrid}CUDA up to the reduction
  * (t/pipelines/kernel/RGBDOdometryImpl.h:74-118; per-pixel terms

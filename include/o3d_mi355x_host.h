@@ -239,6 +239,23 @@ int o3dmi_rgbd_odometry_information_matrix(
         const double* source_to_target, float dist_thr, float depth_scale,
         float depth_max, double* information_host, o3dmi_stream_t stream);
 
+/* RayCast with the number of block coordinates resident on the device
+ * (*m_dev <= max_m; m_dev NULL = max_m): no host round trip between the
+ * integration that produced the block list and the ray cast that uses it. */
+int o3dmi_vbg_ray_cast_dev(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
+                           int64_t max_m, const int32_t* m_dev,
+                           const double* intrinsic, const double* extrinsic,
+                           int width, int height, float* range_map_dev,
+                           float* out_depth, float* out_vertex,
+                           float* out_color, float* out_normal,
+                           int64_t* out_index, uint8_t* out_mask,
+                           float* out_ratio, float* out_ratio_dx,
+                           float* out_ratio_dy, float* out_ratio_dz,
+                           float depth_scale, float depth_min, float depth_max,
+                           float weight_threshold,
+                           float trunc_voxel_multiplier,
+                           int range_map_down_factor, o3dmi_stream_t stream);
+
 /* ExtractPointCloud(weight_threshold, estimated_point_number)
  * (VoxelBlockGrid.cpp:404-434). capacity < 0: only counts (the reference's
  * 2-pass estimation) -> *total_out; otherwise writes up to `capacity` points:
@@ -302,8 +319,9 @@ int o3dmi_slam_model_integrate(o3dmi_slam_model_t* m, const void* depth_dev,
                                float depth_scale, float depth_max,
                                float trunc_voxel_multiplier,
                                o3dmi_stream_t stream);
-/* Number of frustum blocks of the last Integrate and their keys (device,
- * {n,3} int32; valid until the next Integrate). */
+/* Number of frustum blocks of the last Integrate (reads the device-resident
+ * count back: synchronises) and their keys (device, {n,3} int32; valid until
+ * the next Integrate). */
 int64_t o3dmi_slam_model_frustum_block_count(const o3dmi_slam_model_t* m);
 const int32_t* o3dmi_slam_model_frustum_block_coords(const o3dmi_slam_model_t* m);
 /* ExtractPointCloud (Model.cpp:110-113). */

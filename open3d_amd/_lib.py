@@ -59,6 +59,9 @@ PROTOTYPES = {
                                         _i32, _i32, _vp]),
     "o3dmi_vbg_estimate_range": (_i32, [_vp, _i64, _vp, _dp, _dp, _i32, _i32,
                                         _i32, _i64, _f, _f, _f, _vp]),
+    "o3dmi_vbg_estimate_range_dev": (_i32, [_vp, _i64, _vp, _vp, _dp, _dp,
+                                            _i32, _i32, _i32, _i64, _f, _f,
+                                            _f, _vp]),
     "o3dmi_vbg_raycast": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp] + [_vp] * 10 +
                           [_dp, _dp, _i32, _i32, _i32, _f, _f, _f, _f, _f, _f,
                            _i32, _vp]),
@@ -98,7 +101,10 @@ PROTOTYPES = {
     "o3dmi_image_resize_half_nearest": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "o3dmi_image_pyrdown": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "o3dmi_odometry_p2plane_level": (_i32, [_vp, _vp, _i32, _i32, _dp, _vp,
-                                            _vp, _vp, _vp]),
+                                            _vp, _vp, _vp, _vp, _f, _vp]),
+    "o3dmi_image_clip_transform_pair": (_i32, [_vp, _i32, _vp, _i32, _i32,
+                                               _i32, _f, _f, _f, _f, _vp, _vp,
+                                               _vp]),
     "o3dmi_odometry_sums_scratch_doubles": (_i32, []),
     "o3dmi_odometry_sums": (_i32, [_i32, _i32, _i32] + [_vp] * 11 +
                             [_dp, _dp, _f, _f, _f, _vp, _vp, _vp]),
@@ -168,6 +174,9 @@ PROTOTYPES.update({
                C.POINTER(OdometryResultC), _vp]),
     "o3dmi_rgbd_odometry_information_matrix": (
         _i32, [_vp, _vp, _i32, _i32, _i32, _dp, _dp, _f, _f, _f, _dp, _vp]),
+    "o3dmi_vbg_ray_cast_dev": (
+        _i32, [_vp, _vp, _i64, _vp, _dp, _dp, _i32, _i32, _vp] + [_vp] * 10 +
+        [_f, _f, _f, _f, _f, _i32, _vp]),
     "o3dmi_vbg_extract_point_cloud": (_i32, [_vp, _f, _i64, _vp, _vp, _vp,
                                              C.POINTER(_i64), _vp]),
     "o3dmi_slam_model_create": (_i32, [_f, _i32, _i64, _dp, _vp,

@@ -157,13 +157,10 @@ extern "C" int o3dmi_rgbd_odometry_multiscale(
     const float kNan = std::nanf("");
     float* sd = slab.Floats((size_t)rows * cols);
     float* td = slab.Floats((size_t)rows * cols);
-    if ((st = o3dmi_image_clip_transform(source_depth_dev, source_depth_dtype,
-                                         rows, cols, depth_scale, 0.0f,
-                                         depth_max, kNan, sd, stream)))
-        return st;
-    if ((st = o3dmi_image_clip_transform(target_depth_dev, target_depth_dtype,
-                                         rows, cols, depth_scale, 0.0f,
-                                         depth_max, kNan, td, stream)))
+    if ((st = o3dmi_image_clip_transform_pair(
+                 source_depth_dev, source_depth_dtype, target_depth_dev,
+                 target_depth_dtype, rows, cols, depth_scale, 0.0f, depth_max,
+                 kNan, sd, td, stream)))
         return st;
     float *si = nullptr, *ti = nullptr;
     if (use_intensity) {
@@ -192,13 +189,21 @@ extern "C" int o3dmi_rgbd_odometry_multiscale(
         std::memcpy(L.K, Kp, sizeof(Kp));
         const size_t n = (size_t)r * c;
         L.source_vertex = slab.Floats(3 * n);
+        const bool last = i == n_levels - 1;
+        const int r2 = r / 2, c2 = c / 2;
+        float *sd2 = nullptr, *td2 = nullptr;
+        if (!last) {
+            sd2 = slab.Floats((size_t)r2 * c2);
+            td2 = slab.Floats((size_t)r2 * c2);
+        }
         if (method == O3DMI_ODOMETRY_POINT_TO_PLANE) {
             L.target_vertex = slab.Floats(3 * n);
             L.target_normal = slab.Floats(3 * n);
-            if ((st = o3dmi_odometry_p2plane_level(sd, td, r, c, Kp,
-                                                   L.source_vertex,
-                                                   L.target_vertex,
-                                                   L.target_normal, stream)))
+            // maps of this level + PyrDownDepth to the next one, one launch
+            if ((st = o3dmi_odometry_p2plane_level(
+                         sd, td, r, c, Kp, L.source_vertex, L.target_vertex,
+                         L.target_normal, sd2, td2, depth_outlier_trunc * 2,
+                         stream)))
                 return st;
         } else {
             if ((st = o3dmi_image_create_vertex_map(sd, r, c, Kp, kNan,
@@ -220,19 +225,18 @@ extern "C" int o3dmi_rgbd_odometry_multiscale(
                                                    L.target_depth_dy, stream)))
                     return st;
             }
+            if (!last) {
+                if ((st = o3dmi_image_pyrdown_depth(
+                             sd, r, c, depth_outlier_trunc * 2, kNan, sd2,
+                             stream)))
+                    return st;
+                if ((st = o3dmi_image_pyrdown_depth(
+                             td, r, c, depth_outlier_trunc * 2, kNan, td2,
+                             stream)))
+                    return st;
+            }
         }
-        if (i != n_levels - 1) {
-            const int r2 = r / 2, c2 = c / 2;
-            float* sd2 = slab.Floats((size_t)r2 * c2);
-            float* td2 = slab.Floats((size_t)r2 * c2);
-            if ((st = o3dmi_image_pyrdown_depth(sd, r, c,
-                                                depth_outlier_trunc * 2, kNan,
-                                                sd2, stream)))
-                return st;
-            if ((st = o3dmi_image_pyrdown_depth(td, r, c,
-                                                depth_outlier_trunc * 2, kNan,
-                                                td2, stream)))
-                return st;
+        if (!last) {
             if (use_intensity) {
                 float* si2 = slab.Floats((size_t)r2 * c2);
                 float* ti2 = slab.Floats((size_t)r2 * c2);

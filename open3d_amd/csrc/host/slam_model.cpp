@@ -11,6 +11,12 @@
 #include "../common.h"
 #include "o3d_mi355x_host.h"
 
+extern "C" int o3dmi_vbg_export_last_frame_blocks(o3dmi_vbg_t* g,
+                                                  int32_t* out_keys_dev,
+                                                  int64_t out_capacity,
+                                                  int32_t* out_count_dev,
+                                                  o3dmi_stream_t stream);
+
 using namespace o3dmi;
 
 struct o3dmi_slam_model {
@@ -20,7 +26,12 @@ struct o3dmi_slam_model {
     // frustum_block_coords_ of the last Integrate.
     int32_t* frustum_coords = nullptr;
     int64_t frustum_capacity = 0;
-    int64_t frustum_count = 0;
+    // Number of frustum blocks: device-resident (frustum_count_dev) after the
+    // fused Integrate path, mirrored on the host only on demand.
+    int64_t frustum_count = 0;       // valid when !count_on_device
+    int32_t* frustum_count_dev = nullptr;
+    bool count_on_device = false;
+    bool integrated = false;
     float* range_map = nullptr;
     int64_t range_capacity = 0;
 };
@@ -55,6 +66,7 @@ int o3dmi_slam_model_destroy(o3dmi_slam_model_t* m) {
     (void)hipDeviceSynchronize();
     o3dmi_vbg_destroy(m->grid);
     (void)hipFree(m->frustum_coords);
+    (void)hipFree(m->frustum_count_dev);
     (void)hipFree(m->range_map);
     delete m;
     return O3DMI_OK;
@@ -93,7 +105,7 @@ int o3dmi_slam_model_synthesize_model_frame(
         float* depth_out_dev, float* color_out_dev, o3dmi_stream_t stream) {
     O3DMI_REQUIRE(m && intrinsics && depth_out_dev, "null argument");
     O3DMI_REQUIRE(width > 0 && height > 0, "empty frame");
-    O3DMI_REQUIRE(m->frustum_count > 0,
+    O3DMI_REQUIRE(m->integrated,
                   "SynthesizeModelFrame needs a previous Integrate");
     if (weight_threshold < 0)
         weight_threshold = std::fmin(m->frame_id * 1.0f, 3.0f);  // Model.cpp:45-47
@@ -108,9 +120,12 @@ int o3dmi_slam_model_synthesize_model_frame(
     }
     double extrinsic[16];
     InverseTransformation(m->T_frame_to_world, extrinsic);
-    return o3dmi_vbg_ray_cast(
-            m->grid, m->frustum_coords, m->frustum_count, intrinsics, extrinsic,
-            width, height, m->range_map, depth_out_dev, nullptr, color_out_dev,
+    return o3dmi_vbg_ray_cast_dev(
+            m->grid, m->frustum_coords,
+            m->count_on_device ? m->frustum_capacity : m->frustum_count,
+            m->count_on_device ? m->frustum_count_dev : nullptr, intrinsics,
+            extrinsic, width, height, m->range_map, depth_out_dev, nullptr,
+            color_out_dev,
             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
             depth_scale, depth_min, depth_max, weight_threshold,
             trunc_voxel_multiplier, down, stream);
@@ -160,25 +175,41 @@ int o3dmi_slam_model_integrate(o3dmi_slam_model_t* m, const void* depth_dev,
                                   sizeof(int32_t) * 3 * (size_t)cap));
         m->frustum_capacity = cap;
     }
+    if (!m->frustum_count_dev)
+        O3DMI_HIP_CHECK(hipMalloc((void**)&m->frustum_count_dev,
+                                  sizeof(int32_t)));
     double extrinsic[16];
     InverseTransformation(m->T_frame_to_world, extrinsic);
     m->frustum_count = 0;
-    int64_t count = 0;
-    int st = o3dmi_vbg_get_unique_block_coordinates(
-            m->grid, depth_dev, depth_dtype, rows, cols, intrinsics, extrinsic,
-            depth_scale, depth_max, trunc_voxel_multiplier, m->frustum_coords,
-            &count, stream);
+    m->integrated = false;
+    // GetUniqueBlockCoordinates + Integrate in the fused form: block touch,
+    // activation and the voxel update are issued back to back, the touched
+    // block keys (frustum_block_coords_) and their number stay on the device
+    // for the next SynthesizeModelFrame. The reference's "No block is touched"
+    // error needs that number on the host; here it surfaces when
+    // o3dmi_slam_model_frustum_block_count is asked for.
+    int st = o3dmi_vbg_integrate_frame(
+            m->grid, depth_dev, rows, cols, color_dev, color_dev ? rows : 0,
+            color_dev ? cols : 0, depth_dtype, intrinsics, intrinsics, extrinsic,
+            depth_scale, depth_max, trunc_voxel_multiplier, stream);
     if (st) return st;
-    m->frustum_count = count;
-    return o3dmi_vbg_integrate_blocks(
-            m->grid, m->frustum_coords, count, depth_dev, rows, cols, color_dev,
-            color_dev ? rows : 0, color_dev ? cols : 0, depth_dtype, intrinsics,
-            intrinsics, extrinsic, depth_scale, depth_max,
-            trunc_voxel_multiplier, stream);
+    st = o3dmi_vbg_export_last_frame_blocks(m->grid, m->frustum_coords,
+                                            m->frustum_capacity,
+                                            m->frustum_count_dev, stream);
+    if (st) return st;
+    m->count_on_device = true;
+    m->integrated = true;
+    return O3DMI_OK;
 }
 
 int64_t o3dmi_slam_model_frustum_block_count(const o3dmi_slam_model_t* m) {
-    return m ? m->frustum_count : 0;
+    if (!m || !m->integrated) return 0;
+    if (!m->count_on_device) return m->frustum_count;
+    int32_t n = 0;
+    if (hipMemcpy(&n, m->frustum_count_dev, sizeof(n), hipMemcpyDeviceToHost) !=
+        hipSuccess)
+        return 0;
+    return n;
 }
 
 const int32_t* o3dmi_slam_model_frustum_block_coords(

@@ -61,6 +61,10 @@ struct o3dmi_vbg {
     int known_stamp = 0;
     bool known_valid = false;            // false after any non-stream activation
     int last_count = 1024;
+    // Which path integrated the most recent frame (for
+    // o3dmi_vbg_export_last_frame_blocks): 0 none, 1 frame-stream, 2 generic.
+    int last_path = 0;
+    int64_t last_seq = 0;                // frame-stream group sequence number
     // bench.py measurement hook (o3dmi_vbg_profile_begin/end).
     bool profiling = false;
     std::vector<hipEvent_t> prof_events;  // 2 per frame, around the launch carrying the integrate work
@@ -173,6 +177,47 @@ int RunIntegrate(o3dmi_vbg* g, const int32_t* indices, int64_t n,
             o3dmi_hash_value_buffer(g->block_hashmap, wi), cbuf, grid_dtype, Kd,
             Kc ? Kc : Kd, T, (int)g->block_resolution, g->voxel_size,
             g->voxel_size * trunc_mult, depth_scale, depth_max, stream);
+}
+
+}  // namespace
+
+namespace {
+
+// Block keys of a frame-stream group list -> {n,3} int32, count copied.
+__global__ void ExportListKeysKernel(const FrameBlock* __restrict__ list,
+                                     const int* __restrict__ count,
+                                     int64_t capacity,
+                                     int32_t* __restrict__ out_keys,
+                                     int32_t* __restrict__ out_count) {
+    int64_t n = *count;
+    if (n > capacity) n = capacity;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const FrameBlock b = list[i];
+        out_keys[3 * i + 0] = b.x;
+        out_keys[3 * i + 1] = b.y;
+        out_keys[3 * i + 2] = b.z;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = (int32_t)n;
+}
+
+// Same from a list of buffer indices (generic path).
+__global__ void ExportIndexKeysKernel(const int32_t* __restrict__ indices,
+                                      const int* __restrict__ count,
+                                      int64_t capacity,
+                                      const int32_t* __restrict__ key_buffer,
+                                      int32_t* __restrict__ out_keys,
+                                      int32_t* __restrict__ out_count) {
+    int64_t n = *count;
+    if (n > capacity) n = capacity;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t* k = key_buffer + 3 * (int64_t)indices[i];
+        out_keys[3 * i + 0] = k[0];
+        out_keys[3 * i + 1] = k[1];
+        out_keys[3 * i + 2] = k[2];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = (int32_t)n;
 }
 
 }  // namespace
@@ -414,6 +459,7 @@ static int IntegrateFrameGeneric(o3dmi_vbg_t* g, const void* depth_dev,
         O3DMI_HIP_CHECK(hipEventRecord(
                 g->prof_events[(size_t)g->prof_frames * 2 + 0], s));
     }
+    g->last_path = 2;
     st = RunIntegrate(g, g->frame_indices, max_new, g->frame_count, depth_dev,
                       depth_rows, depth_cols, color_dev, color_rows,
                       color_cols, input_dtype, depth_intrinsic,
@@ -704,6 +750,8 @@ static int StreamIntegrate(o3dmi_vbg* g, const StreamCommon& c0,
             if ((st = LaunchFrameStep(g->block_hashmap, fa, m, nullptr, s)))
                 return st;
         }
+        g->last_path = 1;
+        g->last_seq = cur.seq;
         const int next_f = f + cur.n;
         const bool prof = g->profiling && g->prof_frames < g->prof_max &&
                           g->prof_stride > 0 &&
@@ -830,6 +878,59 @@ int o3dmi_vbg_ray_cast(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
                        float depth_max, float weight_threshold,
                        float trunc_voxel_multiplier, int range_map_down_factor,
                        o3dmi_stream_t stream) {
+    return o3dmi_vbg_ray_cast_dev(
+            g, block_coords_dev, m, nullptr, intrinsic, extrinsic, width,
+            height, range_map_dev, out_depth, out_vertex, out_color, out_normal,
+            out_index, out_mask, out_ratio, out_ratio_dx, out_ratio_dy,
+            out_ratio_dz, depth_scale, depth_min, depth_max, weight_threshold,
+            trunc_voxel_multiplier, range_map_down_factor, stream);
+}
+
+// Internal (slam_model.cpp): copies the block keys the most recent
+// o3dmi_vbg_integrate_frame touched (its GetUniqueBlockCoordinates result) to
+// out_keys_dev {capacity,3} and their number to out_count_dev, on the stream,
+// without a host round trip. Must be issued right behind that call.
+int o3dmi_vbg_export_last_frame_blocks(o3dmi_vbg_t* g, int32_t* out_keys_dev,
+                                       int64_t out_capacity,
+                                       int32_t* out_count_dev,
+                                       o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(g && out_keys_dev && out_count_dev, "null argument");
+    O3DMI_REQUIRE(g->last_path != 0, "no frame has been integrated");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(64), block(kBlock);
+    if (g->last_path == 1) {
+        const int64_t cap = out_capacity < g->lists_capacity ? out_capacity
+                                                            : g->lists_capacity;
+        hipLaunchKernelGGL(ExportListKeysKernel, grid, block, 0, s,
+                           g->lists[g->last_seq & 1],
+                           g->ring_counters + (g->last_seq & 3), cap,
+                           out_keys_dev, out_count_dev);
+    } else {
+        const int64_t cap = out_capacity < g->frame_indices_capacity
+                                    ? out_capacity
+                                    : g->frame_indices_capacity;
+        hipLaunchKernelGGL(ExportIndexKeysKernel, grid, block, 0, s,
+                           g->frame_indices, g->frame_count, cap,
+                           o3dmi_hash_key_buffer(g->block_hashmap),
+                           out_keys_dev, out_count_dev);
+    }
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+int o3dmi_vbg_ray_cast_dev(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
+                           int64_t max_m, const int32_t* m_dev,
+                           const double* intrinsic, const double* extrinsic,
+                           int width, int height, float* range_map_dev,
+                           float* out_depth, float* out_vertex,
+                           float* out_color, float* out_normal,
+                           int64_t* out_index, uint8_t* out_mask,
+                           float* out_ratio, float* out_ratio_dx,
+                           float* out_ratio_dy, float* out_ratio_dz,
+                           float depth_scale, float depth_min, float depth_max,
+                           float weight_threshold,
+                           float trunc_voxel_multiplier,
+                           int range_map_down_factor, o3dmi_stream_t stream) {
     O3DMI_REQUIRE(g && range_map_dev && intrinsic && extrinsic,
                   "null argument");
     int ti = g->AttrIndex("tsdf"), wi = g->AttrIndex("weight"),
@@ -843,10 +944,10 @@ int o3dmi_vbg_ray_cast(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
     int grid_dtype;
     int st = GridDtype(g, &grid_dtype);
     if (st) return st;
-    st = o3dmi_vbg_estimate_range(block_coords_dev, m, range_map_dev, intrinsic,
-                                  extrinsic, height, width,
-                                  range_map_down_factor, g->block_resolution,
-                                  g->voxel_size, depth_min, depth_max, stream);
+    st = o3dmi_vbg_estimate_range_dev(
+            block_coords_dev, max_m, m_dev, range_map_dev, intrinsic, extrinsic,
+            height, width, range_map_down_factor, g->block_resolution,
+            g->voxel_size, depth_min, depth_max, stream);
     if (st) return st;
     const void* cbuf = (ci >= 0 && out_color)
                                ? o3dmi_hash_value_buffer(g->block_hashmap, ci)

@@ -64,37 +64,66 @@ __global__ void ClipTransformKernel(const S* __restrict__ src,
 }
 
 // ---- ImageImpl.h:132-206 ----------------------------------------------------
+__device__ __forceinline__ float PyrDownDepthAt(const float* __restrict__ src,
+                                                int rows, int cols, int x,
+                                                int y, float depth_diff,
+                                                float invalid_fill) {
+    const float gweights[3] = {0.375f, 0.25f, 0.0625f};
+    const int y_src = 2 * y, x_src = 2 * x;
+    const float v_center = src[(int64_t)y_src * cols + x_src];
+    if (v_center == invalid_fill) return invalid_fill;
+    const int x_min = max(0, x_src - 2), y_min = max(0, y_src - 2);
+    const int x_max = min(cols - 1, x_src + 2);
+    const int y_max = min(rows - 1, y_src + 2);
+    float v_sum = 0, w_sum = 0;
+    for (int yk = y_min; yk <= y_max; ++yk) {
+        for (int xk = x_min; xk <= x_max; ++xk) {
+            const float v = src[(int64_t)yk * cols + xk];
+            const int dy = abs(yk - y_src), dx = abs(xk - x_src);
+            if (v != invalid_fill && fabsf(v - v_center) < depth_diff) {
+                const float wt = gweights[dx] * gweights[dy];
+                v_sum += wt * v;
+                w_sum += wt;
+            }
+        }
+    }
+    return w_sum == 0 ? invalid_fill : v_sum / w_sum;
+}
+
 __global__ void PyrDownDepthKernel(const float* __restrict__ src,
                                    float* __restrict__ dst, int rows, int cols,
                                    float depth_diff, float invalid_fill) {
     const int rows_down = rows / 2, cols_down = cols / 2;
     const int64_t n = (int64_t)rows_down * cols_down;
-    const float gweights[3] = {0.375f, 0.25f, 0.0625f};
     for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < n;
          w += (int64_t)gridDim.x * blockDim.x) {
         const int y = (int)(w / cols_down), x = (int)(w % cols_down);
-        const int y_src = 2 * y, x_src = 2 * x;
-        const float v_center = src[(int64_t)y_src * cols + x_src];
-        if (v_center == invalid_fill) {
-            dst[w] = invalid_fill;
-            continue;
-        }
-        const int x_min = max(0, x_src - 2), y_min = max(0, y_src - 2);
-        const int x_max = min(cols - 1, x_src + 2);
-        const int y_max = min(rows - 1, y_src + 2);
-        float v_sum = 0, w_sum = 0;
-        for (int yk = y_min; yk <= y_max; ++yk) {
-            for (int xk = x_min; xk <= x_max; ++xk) {
-                const float v = src[(int64_t)yk * cols + xk];
-                const int dy = abs(yk - y_src), dx = abs(xk - x_src);
-                if (v != invalid_fill && fabsf(v - v_center) < depth_diff) {
-                    const float wt = gweights[dx] * gweights[dy];
-                    v_sum += wt * v;
-                    w_sum += wt;
-                }
-            }
-        }
-        dst[w] = w_sum == 0 ? invalid_fill : v_sum / w_sum;
+        dst[w] = PyrDownDepthAt(src, rows, cols, x, y, depth_diff,
+                                invalid_fill);
+    }
+}
+
+// ClipTransform of the source and the target depth in one launch
+// (blockIdx.y selects the image; their dtypes may differ).
+__global__ void ClipTransformPairKernel(const void* __restrict__ src0,
+                                        int src0_is_f32,
+                                        const void* __restrict__ src1,
+                                        int src1_is_f32,
+                                        float* __restrict__ dst0,
+                                        float* __restrict__ dst1, int64_t n,
+                                        float scale, float min_value,
+                                        float max_value, float clip_fill) {
+    const void* src = blockIdx.y == 0 ? src0 : src1;
+    const int is_f32 = blockIdx.y == 0 ? src0_is_f32 : src1_is_f32;
+    float* dst = blockIdx.y == 0 ? dst0 : dst1;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float in = is_f32 ? ((const float*)src)[i]
+                                : static_cast<float>(((const uint16_t*)src)[i]);
+        float out = in / scale;
+        out = out <= min_value ? clip_fill : out;
+        out = out >= max_value ? clip_fill : out;
+        dst[i] = out;
     }
 }
 
@@ -351,51 +380,91 @@ __global__ void FilterSobel3Kernel(const float* __restrict__ src,
 // (RGBDOdometry.cpp:124-153): source vertex map, target vertex map, and the
 // target normal map = CreateNormalMap(CreateVertexMap(FilterBilateral(target
 // depth, 5, 5, 10))) without materialising the smoothed depth or its vertex
-// map (the three smoothed depths a normal needs are evaluated in registers).
-// Same per-pixel arithmetic as the separate kernels, hence identical output.
-__global__ void P2PlaneLevelKernel(const float* __restrict__ src_depth,
-                                   const float* __restrict__ tgt_depth,
-                                   float* __restrict__ src_vertex,
-                                   float* __restrict__ tgt_vertex,
-                                   float* __restrict__ tgt_normal, int rows,
-                                   int cols, Camera cam, BilateralParams bp) {
+// map in HBM. A workgroup owns a 32 x 8 pixel tile: the bilateral-smoothed
+// depth of the tile plus one halo column / row (what the forward differences
+// of the normal need) is evaluated once into LDS, then every lane forms its
+// normal from three LDS values. Same per-pixel arithmetic as the separate
+// kernels, hence identical output.
+constexpr int kTileW = 32, kTileH = 8;
+
+__global__ void __launch_bounds__(kTileW* kTileH)
+P2PlaneLevelKernel(const float* __restrict__ src_depth,
+                   const float* __restrict__ tgt_depth,
+                   float* __restrict__ src_vertex,
+                   float* __restrict__ tgt_vertex,
+                   float* __restrict__ tgt_normal, int rows, int cols,
+                   Camera cam, BilateralParams bp,
+                   float* __restrict__ src_depth_next,
+                   float* __restrict__ tgt_depth_next, float depth_diff) {
+    __shared__ float smooth[kTileH + 1][kTileW + 1];
     const float kNan = __builtin_nanf("");
-    const int64_t n = (int64_t)rows * cols;
-    for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < n;
-         w += (int64_t)gridDim.x * blockDim.x) {
-        const int y = (int)(w / cols), x = (int)(w % cols);
-        float v[3];
-        const float ds = src_depth[w];
-        v[0] = v[1] = v[2] = kNan;
-        if (!IsNan(ds)) cam.Unproject((float)x, (float)y, ds, v[0], v[1], v[2]);
-        src_vertex[3 * w + 0] = v[0];
-        src_vertex[3 * w + 1] = v[1];
-        src_vertex[3 * w + 2] = v[2];
-        const float dt = tgt_depth[w];
-        v[0] = v[1] = v[2] = kNan;
-        if (!IsNan(dt)) cam.Unproject((float)x, (float)y, dt, v[0], v[1], v[2]);
-        tgt_vertex[3 * w + 0] = v[0];
-        tgt_vertex[3 * w + 1] = v[1];
-        tgt_vertex[3 * w + 2] = v[2];
-        float normal[3] = {kNan, kNan, kNan};
-        if (y < rows - 1 && x < cols - 1) {
-            float v00[3], v10[3], v01[3];
-            auto smooth_vertex = [&](int xx, int yy, float* out) {
-                const float d = BilateralAt(tgt_depth, rows, cols, xx, yy, bp);
-                out[0] = out[1] = out[2] = kNan;
-                if (!IsNan(d))
-                    cam.Unproject((float)xx, (float)yy, d, out[0], out[1],
-                                  out[2]);
-            };
-            smooth_vertex(x, y, v00);
-            smooth_vertex(x + 1, y, v10);
-            smooth_vertex(x, y + 1, v01);
-            NormalFromVertices(v00, v10, v01, kNan, normal);
+    const int tx = threadIdx.x % kTileW, ty = threadIdx.x / kTileW;
+    const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
+    const int x = x0 + tx, y = y0 + ty;
+    const bool inside = x < cols && y < rows;
+    // PyrDownDepth of both images for the next (coarser) level rides along:
+    // this tile covers a 16 x 4 patch of it; lanes 0..63 take the source,
+    // lanes 64..127 the target (RGBDOdometry.cpp:146-153).
+    if (src_depth_next != nullptr && threadIdx.x < 2 * (kTileW / 2) * (kTileH / 2)) {
+        const int k = threadIdx.x % ((kTileW / 2) * (kTileH / 2));
+        const int x2 = x0 / 2 + k % (kTileW / 2), y2 = y0 / 2 + k / (kTileW / 2);
+        const int rows2 = rows / 2, cols2 = cols / 2;
+        if (x2 < cols2 && y2 < rows2) {
+            const bool is_src = threadIdx.x < (kTileW / 2) * (kTileH / 2);
+            const float v = PyrDownDepthAt(is_src ? src_depth : tgt_depth, rows,
+                                           cols, x2, y2, depth_diff, kNan);
+            (is_src ? src_depth_next : tgt_depth_next)[(int64_t)y2 * cols2 + x2] = v;
         }
-        tgt_normal[3 * w + 0] = normal[0];
-        tgt_normal[3 * w + 1] = normal[1];
-        tgt_normal[3 * w + 2] = normal[2];
     }
+    if (inside) smooth[ty][tx] = BilateralAt(tgt_depth, rows, cols, x, y, bp);
+    // halo: right column (kTileH + 1 values, corner included), bottom row
+    if (threadIdx.x < kTileH + 1 + kTileW) {
+        int hx, hy;
+        if (threadIdx.x <= kTileH) {
+            hx = kTileW;
+            hy = threadIdx.x;
+        } else {
+            hx = threadIdx.x - (kTileH + 1);
+            hy = kTileH;
+        }
+        const int gx = x0 + hx, gy = y0 + hy;
+        if (gx < cols && gy < rows)
+            smooth[hy][hx] = BilateralAt(tgt_depth, rows, cols, gx, gy, bp);
+    }
+    __syncthreads();
+    if (!inside) return;
+    const int64_t w = (int64_t)y * cols + x;
+    float v[3];
+    const float ds = src_depth[w];
+    v[0] = v[1] = v[2] = kNan;
+    if (!IsNan(ds)) cam.Unproject((float)x, (float)y, ds, v[0], v[1], v[2]);
+    src_vertex[3 * w + 0] = v[0];
+    src_vertex[3 * w + 1] = v[1];
+    src_vertex[3 * w + 2] = v[2];
+    const float dt = tgt_depth[w];
+    v[0] = v[1] = v[2] = kNan;
+    if (!IsNan(dt)) cam.Unproject((float)x, (float)y, dt, v[0], v[1], v[2]);
+    tgt_vertex[3 * w + 0] = v[0];
+    tgt_vertex[3 * w + 1] = v[1];
+    tgt_vertex[3 * w + 2] = v[2];
+    float normal[3] = {kNan, kNan, kNan};
+    if (y < rows - 1 && x < cols - 1) {
+        float v00[3], v10[3], v01[3];
+        auto smooth_vertex = [&](int dx, int dy, float* out) {
+            const float d = smooth[ty + dy][tx + dx];
+            out[0] = out[1] = out[2] = kNan;
+            if (!IsNan(d))
+                cam.Unproject((float)(x + dx), (float)(y + dy), d, out[0],
+                              out[1], out[2]);
+        };
+        smooth_vertex(0, 0, v00);
+        smooth_vertex(1, 0, v10);
+        smooth_vertex(0, 1, v01);
+        NormalFromVertices(v00, v10, v01, kNan, normal);
+    }
+    tgt_normal[3 * w + 0] = normal[0];
+    tgt_normal[3 * w + 1] = normal[1];
+    tgt_normal[3 * w + 2] = normal[2];
 }
 
 // ---- Jacobians, RGBDOdometryJacobianImpl.h ------------------------------------
@@ -942,7 +1011,9 @@ int o3dmi_odometry_p2plane_level(const float* source_depth_dev,
                                  float* source_vertex_dev,
                                  float* target_vertex_dev,
                                  float* target_normal_dev,
-                                 o3dmi_stream_t stream) {
+                                 float* source_depth_next_dev,
+                                 float* target_depth_next_dev,
+                                 float depth_diff, o3dmi_stream_t stream) {
     int st = CheckImage(source_depth_dev, rows, cols);
     if (st) return st;
     O3DMI_REQUIRE(intrinsics != nullptr, "intrinsics is null");
@@ -951,12 +1022,41 @@ int o3dmi_odometry_p2plane_level(const float* source_depth_dev,
     O3DMI_REQUIRE(target_depth_dev && source_vertex_dev && target_vertex_dev &&
                           target_normal_dev,
                   "null argument");
-    hipLaunchKernelGGL(P2PlaneLevelKernel, dim3(GridFor(n, kBlock)),
-                       dim3(kBlock), 0, (hipStream_t)stream, source_depth_dev,
+    O3DMI_REQUIRE((source_depth_next_dev == nullptr) ==
+                          (target_depth_next_dev == nullptr),
+                  "next-level depth outputs come in pairs");
+    const dim3 tiles((cols + kTileW - 1) / kTileW, (rows + kTileH - 1) / kTileH);
+    hipLaunchKernelGGL(P2PlaneLevelKernel, tiles, dim3(kTileW * kTileH), 0,
+                       (hipStream_t)stream, source_depth_dev,
                        target_depth_dev, source_vertex_dev, target_vertex_dev,
                        target_normal_dev, rows, cols,
                        Camera::Make(intrinsics, kEye4),
-                       MakeBilateral(5, 5.0f, 10.0f));
+                       MakeBilateral(5, 5.0f, 10.0f), source_depth_next_dev,
+                       target_depth_next_dev, depth_diff);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+int o3dmi_image_clip_transform_pair(const void* src0_dev, int src0_dtype,
+                                    const void* src1_dev, int src1_dtype,
+                                    int rows, int cols, float scale,
+                                    float min_value, float max_value,
+                                    float clip_fill, float* dst0_dev,
+                                    float* dst1_dev, o3dmi_stream_t stream) {
+    int st = CheckImage(src0_dev, rows, cols);
+    if (st) return st;
+    if ((st = CheckImage(src1_dev, rows, cols))) return st;
+    O3DMI_REQUIRE((src0_dtype == O3DMI_U16 || src0_dtype == O3DMI_F32) &&
+                          (src1_dtype == O3DMI_U16 || src1_dtype == O3DMI_F32),
+                  "ClipTransform: depth must be UInt16 or Float32");
+    const int64_t n = (int64_t)rows * cols;
+    if (n == 0) return O3DMI_OK;
+    O3DMI_REQUIRE(dst0_dev && dst1_dev, "dst is null");
+    hipLaunchKernelGGL(ClipTransformPairKernel, dim3(GridFor(n, kBlock), 2),
+                       dim3(kBlock), 0, (hipStream_t)stream, src0_dev,
+                       (int)(src0_dtype == O3DMI_F32), src1_dev,
+                       (int)(src1_dtype == O3DMI_F32), dst0_dev, dst1_dev, n,
+                       scale, min_value, max_value, clip_fill);
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
 }
@@ -1082,7 +1182,7 @@ int o3dmi_odometry_sums_post(int method, int rows, int cols,
         hipLaunchKernelGGL(OdometrySumsKernel<2>, dim3(g), dim3(kSumsBlock), 0,
                            s, m, ti, depth_outlier_trunc, depth_huber_delta,
                            intensity_huber_delta, partials);
-    hipLaunchKernelGGL(FinalSumKernel<kOdoSums>, dim3(1), dim3(256), 0, s,
+    hipLaunchKernelGGL(FinalSumKernel<kOdoSums>, dim3(1), dim3(kFinalThreads), 0, s,
                        partials, g, sums29_dev, mail_data, mail_flag, mail_seq);
     hipError_t e = hipGetLastError();
     if (own) {
@@ -1116,7 +1216,7 @@ int o3dmi_odometry_information(int rows, int cols,
                        source_vertex_dev, target_vertex_dev, rows, cols,
                        Camera::Make(intrinsics, source_to_target),
                        square_dist_thr, partials);
-    hipLaunchKernelGGL(FinalSumKernel<kInfoSums>, dim3(1), dim3(256), 0, s,
+    hipLaunchKernelGGL(FinalSumKernel<kInfoSums>, dim3(1), dim3(kFinalThreads), 0, s,
                        partials, g, out_dev, (double*)nullptr, (int*)nullptr, 0);
     double A[kInfoSums];
     hipError_t e = hipMemcpyAsync(A, out_dev, sizeof(A), hipMemcpyDeviceToHost, s);

@@ -17,9 +17,13 @@
 namespace o3dmi {
 
 constexpr int kSumsBlock = 256;
-constexpr int kSumsMaxGrid = 1024;  // 4 workgroups per CU
-
+// One workgroup per CU at most: every lane then carries several elements
+// before the (comparatively expensive) 29-value wave reduction, and the final
+// pass has at most 256 partial rows to read.
+constexpr int kSumsMaxGrid = 256;
 inline int SumsGrid(int64_t n) {
+    // Coarse pyramid levels (<= 64k elements) are pure latency: one element
+    // per lane keeps their dependent-load chain as short as it can be.
     int64_t g = (n + kSumsBlock - 1) / kSumsBlock;
     if (g > kSumsMaxGrid) g = kSumsMaxGrid;
     if (g < 1) g = 1;
@@ -49,25 +53,31 @@ __device__ __forceinline__ void BlockSumAndStore(double (&A)[N],
     }
 }
 
-// One workgroup of 256 lanes: lane (r, c) = (tid / 32, tid % 32) strides over
-// the rows, 8 row-lanes are then added in a fixed order. N <= 32.
+// One workgroup of kFinalThreads lanes: lane (r, c) = (tid / 32, tid % 32)
+// strides over the rows (32 row-lanes, independent loads), the row-lanes are
+// then added in a fixed order. N <= 32.
 // mail_data / mail_flag (optional): host mailbox, see mailbox.h.
+constexpr int kFinalThreads = 1024;
+constexpr int kFinalRowLanes = kFinalThreads / 32;
+
 template <int N>
-__global__ void FinalSumKernel(const double* __restrict__ partials, int n_rows,
-                               double* __restrict__ out, double* mail_data,
-                               int* mail_flag, int mail_seq) {
-    __shared__ double lds[8][32];
+__global__ void __launch_bounds__(kFinalThreads)
+FinalSumKernel(const double* __restrict__ partials, int n_rows,
+               double* __restrict__ out, double* mail_data, int* mail_flag,
+               int mail_seq) {
+    __shared__ double lds[kFinalRowLanes][32];
     const int col = threadIdx.x & 31;
     const int rl = threadIdx.x >> 5;
     double v = 0;
     if (col < N)
-        for (int r = rl; r < n_rows; r += 8) v += partials[(int64_t)r * N + col];
+        for (int r = rl; r < n_rows; r += kFinalRowLanes)
+            v += partials[(int64_t)r * N + col];
     lds[rl][col] = v;
     __syncthreads();
     if (threadIdx.x < N) {
         double s = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s += lds[k][threadIdx.x];
+        for (int k = 0; k < kFinalRowLanes; ++k) s += lds[k][threadIdx.x];
         if (out) out[threadIdx.x] = s;
         if (mail_data) mail_data[threadIdx.x] = s;
     }

@@ -41,7 +41,9 @@ __global__ void RangeFillKernel(float* __restrict__ range, int64_t n,
 
 // One wave per block key (4 waves per workgroup).
 __global__ void EstimateRangeKernel(const int* __restrict__ block_keys,
-                                    int64_t n_blocks, float* __restrict__ range,
+                                    int64_t n_blocks,
+                                    const int* __restrict__ n_blocks_dev,
+                                    float* __restrict__ range,
                                     Camera cam, int h_down, int w_down,
                                     int down_factor, int64_t block_resolution,
                                     float voxel_size, float depth_min,
@@ -50,6 +52,12 @@ __global__ void EstimateRangeKernel(const int* __restrict__ block_keys,
     const int64_t wave_id =
             ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    // Device-resident count (frame-stream callers): the live length of the
+    // key list, bounded by the host-side capacity n_blocks.
+    if (n_blocks_dev) {
+        const int64_t live = *n_blocks_dev;
+        if (live < n_blocks) n_blocks = live;
+    }
     for (int64_t b = wave_id; b < n_blocks; b += n_waves) {
         const int* key = block_keys + 3 * b;
         int u_min = w_down - 1, v_min = h_down - 1, u_max = 0, v_max = 0;
@@ -118,7 +126,11 @@ __device__ __forceinline__ int SignI(int x) {
     return (x > 0) ? 1 : ((x < 0) ? -1 : 0);
 }
 
-template <typename weight_t, typename color_t>
+// FULL = the per-neighbour maps (index / mask / interp_ratio*) are requested.
+// The common depth / vertex / colour / normal rendering (slam::Model) runs the
+// slim instantiation: without the 8-entry output arrays it needs half the
+// registers, so every ray of a 720p frame is resident at once.
+template <typename weight_t, typename color_t, bool FULL>
 __global__ void __launch_bounds__(256)
 RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
               const weight_t* __restrict__ weight_base,
@@ -157,11 +169,12 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
         float out_vertex[3] = {0, 0, 0};
         float out_color[3] = {0, 0, 0};
         float out_normal[3] = {0, 0, 0};
-        float o_ratio[8], o_dx[8], o_dy[8], o_dz[8];
-        long long o_index[8];
-        uint8_t o_mask[8];
+        constexpr int kNb = FULL ? 8 : 1;
+        float o_ratio[kNb], o_dx[kNb], o_dy[kNb], o_dz[kNb];
+        long long o_index[kNb];
+        uint8_t o_mask[kNb];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < kNb; ++k) {
             o_ratio[k] = o_dx[k] = o_dy[k] = o_dz[k] = 0;
             o_index[k] = 0;
             o_mask[k] = 0;
@@ -300,19 +313,23 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
                                        (1 - dz_v) * (1 - ratio_z);
                             float r = rx * ry * rz;
 
-                            o_ratio[k] = r;
-                            o_mask[k] = 1;
-                            o_index[k] = linear_idx_k;
+                            if (FULL) {
+                                o_ratio[k] = r;
+                                o_mask[k] = 1;
+                                o_index[k] = linear_idx_k;
+                            }
 
-                            float tsdf_k = tsdf_base[linear_idx_k];
                             float rdx = ry * rz * (2 * dx_v - 1);
                             float rdy = rx * rz * (2 * dy_v - 1);
                             float rdz = rx * ry * (2 * dz_v - 1);
-                            o_dx[k] = rdx;
-                            o_dy[k] = rdy;
-                            o_dz[k] = rdz;
+                            if (FULL) {
+                                o_dx[k] = rdx;
+                                o_dy[k] = rdy;
+                                o_dz[k] = rdz;
+                            }
 
                             if (normal_ptr) {
+                                float tsdf_k = tsdf_base[linear_idx_k];
                                 out_normal[0] += rdx * tsdf_k;
                                 out_normal[1] += rdy * tsdf_k;
                                 out_normal[2] += rdz * tsdf_k;
@@ -372,7 +389,7 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
             normal_ptr[2] = out_normal[2];
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < (FULL ? 8 : 0); ++k) {
             if (ratio_ptr) ratio_ptr[k] = o_ratio[k];
             if (ratio_dx_ptr) ratio_dx_ptr[k] = o_dx[k];
             if (ratio_dy_ptr) ratio_dy_ptr[k] = o_dy[k];
@@ -397,11 +414,26 @@ int o3dmi_vbg_estimate_range(const int32_t* block_keys_dev, int64_t n_blocks,
                              int64_t block_resolution, float voxel_size,
                              float depth_min, float depth_max,
                              o3dmi_stream_t stream) {
+    return o3dmi_vbg_estimate_range_dev(
+            block_keys_dev, n_blocks, nullptr, range_minmax_map_dev, intrinsic,
+            extrinsic, h, w, down_factor, block_resolution, voxel_size,
+            depth_min, depth_max, stream);
+}
+
+int o3dmi_vbg_estimate_range_dev(const int32_t* block_keys_dev,
+                                 int64_t max_blocks,
+                                 const int32_t* n_blocks_dev,
+                                 float* range_minmax_map_dev,
+                                 const double* intrinsic,
+                                 const double* extrinsic, int h, int w,
+                                 int down_factor, int64_t block_resolution,
+                                 float voxel_size, float depth_min,
+                                 float depth_max, o3dmi_stream_t stream) {
     O3DMI_REQUIRE(range_minmax_map_dev && intrinsic && extrinsic,
                   "null argument");
     O3DMI_REQUIRE(down_factor > 0 && h >= down_factor && w >= down_factor,
                   "bad image size / down factor");
-    O3DMI_REQUIRE(n_blocks == 0 || block_keys_dev != nullptr,
+    O3DMI_REQUIRE(max_blocks == 0 || block_keys_dev != nullptr,
                   "block keys is null");
     hipStream_t s = (hipStream_t)stream;
     int h_down = h / down_factor, w_down = w / down_factor;
@@ -409,10 +441,14 @@ int o3dmi_vbg_estimate_range(const int32_t* block_keys_dev, int64_t n_blocks,
     hipLaunchKernelGGL(RangeFillKernel, dim3(GridFor(n_px, kBlock)),
                        dim3(kBlock), 0, s, range_minmax_map_dev, n_px,
                        depth_min, depth_max);
-    if (n_blocks > 0) {
+    if (max_blocks > 0) {
         Camera cam = Camera::Make(intrinsic, extrinsic, 1.0f);
-        hipLaunchKernelGGL(EstimateRangeKernel, dim3(GridFor(n_blocks, 4)),
-                           dim3(kBlock), 0, s, block_keys_dev, n_blocks,
+        // With a device-resident count the list is usually far shorter than
+        // its capacity: a fixed grid (2 workgroups per CU) strides over it.
+        const int grid = n_blocks_dev ? GridFor(max_blocks, 4, kCUs * 2)
+                                      : GridFor(max_blocks, 4);
+        hipLaunchKernelGGL(EstimateRangeKernel, dim3(grid), dim3(kBlock), 0, s,
+                           block_keys_dev, max_blocks, n_blocks_dev,
                            range_minmax_map_dev, cam, h_down, w_down,
                            down_factor, block_resolution, voxel_size, depth_min,
                            depth_max);
@@ -469,16 +505,20 @@ int o3dmi_vbg_raycast(o3dmi_hash_t* block_hash, const float* tsdf_dev,
     hipStream_t s = (hipStream_t)stream;
     int64_t n = (int64_t)h * w;
     dim3 grid(GridFor(n, kBlock, kCUs * 16)), block(kBlock);
-    if (grid_dtype == O3DMI_F32)
-        hipLaunchKernelGGL((RayCastKernel<float, float>), grid, block, 0, s,
-                           block_hash->view, p, tsdf_dev,
-                           (const float*)weight_dev,
-                           (const float*)color_buf_dev, range_map_dev);
-    else
-        hipLaunchKernelGGL((RayCastKernel<uint16_t, uint16_t>), grid, block, 0,
-                           s, block_hash->view, p, tsdf_dev,
-                           (const uint16_t*)weight_dev,
-                           (const uint16_t*)color_buf_dev, range_map_dev);
+    const bool full = out_index || out_mask || out_ratio || out_ratio_dx ||
+                      out_ratio_dy || out_ratio_dz;
+#define O3DMI_RAYCAST(WT, CT, FULL)                                           \
+    hipLaunchKernelGGL((RayCastKernel<WT, CT, FULL>), grid, block, 0, s,      \
+                       block_hash->view, p, tsdf_dev, (const WT*)weight_dev,  \
+                       (const CT*)color_buf_dev, range_map_dev)
+    if (grid_dtype == O3DMI_F32) {
+        if (full) O3DMI_RAYCAST(float, float, true);
+        else O3DMI_RAYCAST(float, float, false);
+    } else {
+        if (full) O3DMI_RAYCAST(uint16_t, uint16_t, true);
+        else O3DMI_RAYCAST(uint16_t, uint16_t, false);
+    }
+#undef O3DMI_RAYCAST
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
 }

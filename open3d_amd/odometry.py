@@ -299,9 +299,12 @@ def pyrdown(image):
     return out
 
 
-def p2plane_level(source_depth, target_depth, intrinsics):
+def p2plane_level(source_depth, target_depth, intrinsics,
+                  next_level_depth_diff=None):
     """One pyramid level of the point-to-plane method in a single launch:
-    (source_vertex, target_vertex, target_normal)."""
+    (source_vertex, target_vertex, target_normal[, source_depth_next,
+    target_depth_next]); the next-level depths (PyrDownDepth with
+    `next_level_depth_diff`, NaN fill) are produced when it is given."""
     sd = _img2(source_depth, "source depth")
     td = _img2(target_depth, "target depth")
     K = host_mat(intrinsics, (3, 3), "intrinsics")
@@ -309,7 +312,15 @@ def p2plane_level(source_depth, target_depth, intrinsics):
     sv = torch.empty(shp, dtype=torch.float32, device="cuda")
     tv = torch.empty(shp, dtype=torch.float32, device="cuda")
     tn = torch.empty(shp, dtype=torch.float32, device="cuda")
+    sn = tdn = None
+    if next_level_depth_diff is not None:
+        half = (sd.shape[0] // 2, sd.shape[1] // 2)
+        sn = torch.empty(half, dtype=torch.float32, device="cuda")
+        tdn = torch.empty(half, dtype=torch.float32, device="cuda")
     _lib.check(_lib.lib().o3dmi_odometry_p2plane_level(
         _lib.ptr(sd), _lib.ptr(td), sd.shape[0], sd.shape[1], _lib.f64p(K),
-        _lib.ptr(sv), _lib.ptr(tv), _lib.ptr(tn), stream()), "p2plane_level")
-    return sv, tv, tn
+        _lib.ptr(sv), _lib.ptr(tv), _lib.ptr(tn), _lib.ptr(sn), _lib.ptr(tdn),
+        C.c_float(next_level_depth_diff or 0.0), stream()), "p2plane_level")
+    if sn is None:
+        return sv, tv, tn
+    return sv, tv, tn, sn, tdn

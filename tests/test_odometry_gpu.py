@@ -158,6 +158,16 @@ def test_p2plane_level_equals_separate_ops():
         odo.create_vertex_map(odo.filter_bilateral(t, 5, 5.0, 10.0), K, NAN),
         NAN)
     assert same_bits(_host(tn), _host(want))
+    # with the next level's depths riding along (odd sizes too)
+    for sl in (np.s_[:, :], np.s_[:119, :157]):
+        s2, t2 = s[sl].contiguous(), t[sl].contiguous()
+        sv, tv, tn, sn, tdn = odo.p2plane_level(s2, t2, K, 0.14)
+        assert same_bits(_host(sv), _host(odo.create_vertex_map(s2, K, NAN)))
+        assert same_bits(_host(tn), _host(odo.create_normal_map(
+            odo.create_vertex_map(odo.filter_bilateral(t2, 5, 5.0, 10.0), K,
+                                  NAN), NAN)))
+        assert same_bits(_host(sn), _host(odo.pyrdown_depth(s2, 0.14, NAN)))
+        assert same_bits(_host(tdn), _host(odo.pyrdown_depth(t2, 0.14, NAN)))
 
 
 @pytest.mark.parametrize("method", [orc.ODO_P2PLANE, orc.ODO_INTENSITY,
