@@ -30,8 +30,11 @@
 #include <cmath>
 #include <vector>
 
+#include <cstdlib>
+
 #include "common.h"
 #include "mailbox.h"
+#include "reduce_sums.h"
 
 namespace o3dmi {
 namespace {
@@ -424,7 +427,16 @@ P2PlaneAccumulateKernel(const T* __restrict__ src, const T* __restrict__ tgt,
     BlockReduceAndStore(A, partials);
 }
 
-template <typename T>
+// Fused search + accumulate, one query per 32 lanes. The 27 neighbour cells of
+// a query are independent look-ups (bucket bounds -> a handful of candidate
+// records); walking them one after the other from a single lane is a chain of
+// ~54 dependent memory round trips (~100 us per launch whatever the number of
+// queries). Here lane c of a 32-lane group scans cell c, the group then takes
+// the minimum by (d2, original index) -- the same winner the sequential scan
+// picks -- and its lane 0 forms the Jacobian terms. A wave serves two queries.
+// G = lanes per query (1, 2, 4, ... 32): few queries want G = 32 (latency),
+// many queries want a small G (every lane busy); the winner is the same.
+template <typename T, int G>
 __global__ void __launch_bounds__(kReduceBlock)
 SearchAccumulateKernel(NnsView<T> nv, const Rec4<T>* __restrict__ sorted_n,
                        const T* __restrict__ src, int64_t n, RobustParams rp,
@@ -433,20 +445,74 @@ SearchAccumulateKernel(NnsView<T> nv, const Rec4<T>* __restrict__ sorted_n,
     double A[kNumSums];
 #pragma unroll
     for (int k = 0; k < kNumSums; ++k) A[k] = 0;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        T q[3] = {src[3 * i + 0], src[3 * i + 1], src[3 * i + 2]};
-        int idx;
-        T d2;
-        int pos = SearchNearest(nv, q, idx, d2);
-        if (corr_out) corr_out[i] = pos >= 0 ? (int64_t)idx : (int64_t)-1;
-        if (pos < 0) continue;
-        Rec4<T> t = nv.sorted[pos];
-        Rec4<T> nn = sorted_n[pos];
-        AccumulateP2Plane<T>(A, q[0], q[1], q[2], t.x, t.y, t.z, nn.x, nn.y,
-                             nn.z, rp);
-        A[29] += (double)d2;
-        A[30] += 1.0;
+    constexpr int kPerWave = 64 / G;  // queries per wave
+    const int c0 = threadIdx.x & (G - 1);  // first neighbour cell of this lane
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int sub = (threadIdx.x & 63) / G;
+    for (int64_t base = wave * kPerWave; base < n; base += n_waves * kPerWave) {
+        const int64_t i = base + sub;
+        const bool valid = i < n;
+        T q[3] = {T(0), T(0), T(0)};
+        int pos = -1, idx = -1;
+        T d2 = T(0);
+        if (valid) {
+            q[0] = src[3 * i + 0];
+            q[1] = src[3 * i + 1];
+            q[2] = src[3 * i + 2];
+            long long cx, cy, cz;
+            CellOf(q, nv.inv_cell, cx, cy, cz);
+            for (int c = c0; c < 27; c += G) {
+                const int dz = c / 9 - 1, dy = (c % 9) / 3 - 1, dx = c % 3 - 1;
+                const unsigned b =
+                        HashCell(cx + dx, cy + dy, cz + dz) & nv.mask;
+                const unsigned s0 = nv.starts[b], e0 = nv.starts[b + 1];
+                for (unsigned j = s0; j < e0; ++j) {
+                    const Rec4<T> p = nv.sorted[j];
+                    T result = T(0);
+                    const T d0 = q[0] - p.x;
+                    result += d0 * d0;
+                    const T d1 = q[1] - p.y;
+                    result += d1 * d1;
+                    const T dd = q[2] - p.z;
+                    result += dd * dd;
+                    if (result < nv.radius_squared) {
+                        const int pi = RecIndex(p);
+                        if (pos < 0 || result < d2 ||
+                            (result == d2 && pi < idx)) {
+                            pos = (int)j;
+                            idx = pi;
+                            d2 = result;
+                        }
+                    }
+                }
+            }
+        }
+        // minimum by (d2, idx) over the G lanes of the group
+#pragma unroll
+        for (int m = G / 2; m > 0; m >>= 1) {
+            const int opos = __shfl_xor(pos, m, G);
+            const int oidx = __shfl_xor(idx, m, G);
+            const T od2 = __shfl_xor(d2, m, G);
+            const bool take = opos >= 0 &&
+                              (pos < 0 || od2 < d2 || (od2 == d2 && oidx < idx));
+            if (take) {
+                pos = opos;
+                idx = oidx;
+                d2 = od2;
+            }
+        }
+        if (valid && c0 == 0) {
+            if (corr_out) corr_out[i] = pos >= 0 ? (int64_t)idx : (int64_t)-1;
+            if (pos >= 0) {
+                const Rec4<T> t = nv.sorted[pos];
+                const Rec4<T> nn = sorted_n[pos];
+                AccumulateP2Plane<T>(A, q[0], q[1], q[2], t.x, t.y, t.z, nn.x,
+                                     nn.y, nn.z, rp);
+                A[29] += (double)d2;
+                A[30] += 1.0;
+            }
+        }
     }
     BlockReduceAndStore(A, partials);
 }
@@ -490,7 +556,10 @@ __global__ void TransformNormalsKernel(Mat4<T> t, T* __restrict__ nrm,
 
 int ReduceGrid(int64_t n) {
     int64_t g = (n + kReduceBlock - 1) / kReduceBlock;
-    int64_t cap = (int64_t)kCUs * 4;
+    // Two workgroups per CU at most: enough waves to hide the gather latency,
+    // and the final pass (a single workgroup, linear in the row count) reads
+    // <= 512 partial rows.
+    int64_t cap = (int64_t)kCUs * 2;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (int)g;
@@ -733,24 +802,37 @@ int o3dmi_icp_search_accumulate_post(
     }
     O3DMI_REQUIRE(nns->sorted_normals != nullptr,
                   "Target pointcloud missing normals attribute.");
-    int g = ReduceGrid(n);
+    // Lanes per query: as many as keep the whole chip busy about once.
+    int group = 32;
+    while (group > 1 && n * group > (int64_t)kCUs * 2048) group >>= 1;
+    if (const char* e = std::getenv("O3DMI_NNS_GROUP")) {
+        const int v = std::atoi(e);
+        if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) group = v;
+    }
+    int g = ReduceGrid(n * group);
     RobustParams rp = MakeRobust(robust_kernel, scaling_parameter,
                                  shape_parameter);
-    if (nns->dtype == O3DMI_F64)
-        hipLaunchKernelGGL(SearchAccumulateKernel<double>, dim3(g),
-                           dim3(kReduceBlock), 0, s, MakeView<double>(nns),
-                           (const Rec4<double>*)nns->sorted_normals,
-                           (const double*)src_dev, n, rp, corr_out_dev,
-                           nns->partials);
-    else
-        hipLaunchKernelGGL(SearchAccumulateKernel<float>, dim3(g),
-                           dim3(kReduceBlock), 0, s, MakeView<float>(nns),
-                           (const Rec4<float>*)nns->sorted_normals,
-                           (const float*)src_dev, n, rp, corr_out_dev,
-                           nns->partials);
-    hipLaunchKernelGGL(FinalReduceKernel, dim3(1), dim3(256), 0, s,
-                       nns->partials, g, sums32_dev, kNumSums, mail_data,
-                       mail_flag, mail_seq);
+#define O3DMI_SEARCH(T, G)                                                     \
+    hipLaunchKernelGGL((SearchAccumulateKernel<T, G>), dim3(g),               \
+                       dim3(kReduceBlock), 0, s, MakeView<T>(nns),            \
+                       (const Rec4<T>*)nns->sorted_normals,                   \
+                       (const T*)src_dev, n, rp, corr_out_dev, nns->partials)
+#define O3DMI_SEARCH_G(T)                                                      \
+    switch (group) {                                                          \
+        case 32: O3DMI_SEARCH(T, 32); break;                                  \
+        case 16: O3DMI_SEARCH(T, 16); break;                                  \
+        case 8: O3DMI_SEARCH(T, 8); break;                                    \
+        case 4: O3DMI_SEARCH(T, 4); break;                                    \
+        case 2: O3DMI_SEARCH(T, 2); break;                                    \
+        default: O3DMI_SEARCH(T, 1); break;                                   \
+    }
+    if (nns->dtype == O3DMI_F64) { O3DMI_SEARCH_G(double) }
+    else { O3DMI_SEARCH_G(float) }
+#undef O3DMI_SEARCH_G
+#undef O3DMI_SEARCH
+    hipLaunchKernelGGL(FinalSumKernel<kNumSums>, dim3(1), dim3(kFinalThreads),
+                       0, s, nns->partials, g, sums32_dev, mail_data, mail_flag,
+                       mail_seq);
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
 }

@@ -122,25 +122,34 @@ def mode_slam(a):
             C.c_float(dmax), C.c_int64(stride), stream()), "unproject")
         return pts_buf[:int(cnt.item())]
 
+    mpts = torch.empty(((H // stride) * (W // stride), 3),
+                       dtype=torch.float32, device="cuda")
+    mnrm = torch.empty_like(mpts)
+    mcnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+
     def model_cloud(T_wc):
+        """Model cloud at the previous pose: ray-cast depth + normal maps,
+        PointCloud::CreateFromDepthImage(ray-cast depth, stride) with the
+        normal map carried along as the per-pixel attribute, normals rotated
+        into the world frame -- library calls only, no tensor glue."""
         keys = g.compute_unique_block_coordinates(depth_pred, K, T_wc, ds, dmax,
                                                   trunc)
         out = g.ray_cast(keys, K, T_wc, W, H,
-                         render_attributes=("depth", "vertex", "normal"),
+                         render_attributes=("depth", "normal"),
                          depth_scale=ds, depth_min=0.1, depth_max=dmax,
                          weight_threshold=1.0, trunc_voxel_multiplier=trunc)
-        valid = (out["depth"][..., 0] > 0) & \
-                torch.isfinite(out["normal"]).all(-1) & \
-                (out["normal"].abs().sum(-1) > 0)
-        valid[::2, :] = False   # same density as the stride-2 frame cloud
-        valid[:, ::2] = False
-        v = out["vertex"][valid]
-        nn = out["normal"][valid]
-        Tinv = torch.from_numpy(np.linalg.inv(T_wc)).to(v.device,
-                                                        torch.float32)
-        pw = v @ Tinv[:3, :3].T + Tinv[:3, 3]
-        nw = nn @ Tinv[:3, :3].T
-        return pw.contiguous(), nw.contiguous(), out["depth"]
+        T = np.ascontiguousarray(T_wc, dtype=np.float64)
+        _lib.check(L.o3dmi_unproject(
+            _lib.ptr(out["depth"]), _lib.F32, H, W, _lib.ptr(out["normal"]),
+            _lib.ptr(mpts), _lib.ptr(mnrm), _lib.ptr(mcnt), _lib.f64p(K),
+            _lib.f64p(T), C.c_float(ds), C.c_float(dmax), C.c_int64(stride),
+            stream()), "unproject")
+        m = int(mcnt.item())
+        Tinv = np.ascontiguousarray(np.linalg.inv(T_wc), dtype=np.float64)
+        _lib.check(L.o3dmi_transform_normals(_lib.f64p(Tinv), _lib.ptr(mnrm),
+                                             m, _lib.F32, stream()),
+                   "transform_normals")
+        return mpts[:m], mnrm[:m], out["depth"]
 
     # bootstrap with frame 0 at its true pose
     T_est = [np.array(Ts[0])]
@@ -148,20 +157,33 @@ def mode_slam(a):
     depth_pred = depths[0]
     torch.cuda.synchronize()
     iters = 0
+    phase = np.zeros(4)
+
+    def tick():
+        if a.phases:
+            torch.cuda.synchronize()
+        return time.perf_counter()
+
     t0 = time.perf_counter()
     for k in range(1, n):
         T_prev = T_est[-1]
+        p0 = tick()
         tp, tn, dpred = model_cloud(T_prev)
+        p1 = tick()
         # source in the previous camera's world alignment: ICP estimates the
         # world-frame correction from the previous pose to the current one
         src = frame_cloud(depths[k], T_prev)
+        p2 = tick()
         r = reg.multi_scale_icp(src, tp, tn, vs, crit, md)
+        p3 = tick()
         iters += r.num_iterations
         # points_world = r.T * (T_prev^-1 * p_cam)  =>  extrinsic_k = T_prev * r.T^-1
         T_k = T_prev @ np.linalg.inv(r.transformation)
         T_est.append(T_k)
         g.integrate_frame(depths[k], colors[k], K, K, T_k, ds, dmax, trunc)
         depth_pred = depths[k]
+        p4 = tick()
+        phase += (p1 - p0, p2 - p1, p3 - p2, p4 - p3)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     errs = [pose_err(Ts[k], T_est[k]) for k in range(n)]
@@ -174,6 +196,11 @@ def mode_slam(a):
            "max_pose_err_rad_m": [max(e[0] for e in errs),
                                   max(e[1] for e in errs)],
            "active_blocks": g.hashmap().size()}
+    if a.phases:
+        out["ms_model_cloud_frame_cloud_icp_integrate"] = \
+            [float(x) for x in phase / (n - 1) * 1e3]
+        out["source_points"] = int(src.shape[0])
+        out["target_points"] = int(tp.shape[0])
     print(json.dumps(out), flush=True)
 
 
@@ -300,6 +327,9 @@ def main():
     ap.add_argument("--method", default="p2plane",
                     choices=["p2plane", "intensity", "hybrid"])
     ap.add_argument("--cpu-frames", type=int, default=0)
+    ap.add_argument("--phases", action="store_true",
+                    help="slam mode: synchronise between phases and report "
+                         "their times")
     ap.add_argument("--points", type=int, default=100000)
     ap.add_argument("--repeat", type=int, default=5)
     ap.add_argument("--frames", type=int, default=40)
