@@ -706,6 +706,279 @@ int MultiScaleICP(const T* source_in, int64_t ns_in, const T* target_in,
 }  // namespace
 
 // ===========================================================================
+
+// ---------------------------------------------------------------------------
+// Normal estimation: PointCloud::EstimateNormals with
+// hybrid search (t/geometry/PointCloud.cpp:856-976) =
+//   EstimateCovariancesUsingHybridSearchCPU   (PointCloudImpl.h:588-638)
+//   EstimatePointWiseRobustNormalizedCovarianceKernel (:512-585)
+//   EstimateNormalsFromCovariancesCPU         (:1011-1063)
+//   EstimatePointWiseNormalsWithFastEigen3x3  (:875-1009), ComputeEigenvector0
+//   (:746-793), ComputeEigenvector1 (:795-873); cross / dot / matmul helpers
+//   core/linalg/kernel/Matrix.h.
+// Mixed float / double literals are kept as written (they promote parts of an
+// expression to double). Unqualified sqrt / abs / acos / cos / min / max
+// resolve to the std:: float overloads with libstdc++'s <cmath> (checked
+// against the compiled reference body in tests/test_oracle_vs_ref.py).
+namespace normals {
+
+template <typename T>
+void Cross(const T* a, const T* b, T* c) {
+    c[0] = (a[1] * b[2]) - (a[2] * b[1]);
+    c[1] = (a[2] * b[0]) - (a[0] * b[2]);
+    c[2] = (a[0] * b[1]) - (a[1] * b[0]);
+}
+template <typename T>
+T Dot(const T* a, const T* b) {
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+template <typename T>
+void Matmul3x3_3x1(const T* A, const T* b, T* c) {
+    c[0] = A[0] * b[0] + A[1] * b[1] + A[2] * b[2];
+    c[1] = A[3] * b[0] + A[4] * b[1] + A[5] * b[2];
+    c[2] = A[6] * b[0] + A[7] * b[1] + A[8] * b[2];
+}
+
+template <typename T>
+void Covariance(const T* points_ptr, const int32_t* indices_ptr,
+                int32_t indices_count, T* covariance_ptr) {
+    if (indices_count < 3) {
+        for (int i = 0; i < 9; ++i) covariance_ptr[i] = (i % 4 == 0) ? 1.0 : 0.0;
+        return;
+    }
+    double centroid[3] = {0};
+    for (int32_t i = 0; i < indices_count; ++i) {
+        int32_t idx = 3 * indices_ptr[i];
+        centroid[0] += points_ptr[idx];
+        centroid[1] += points_ptr[idx + 1];
+        centroid[2] += points_ptr[idx + 2];
+    }
+    centroid[0] /= indices_count;
+    centroid[1] /= indices_count;
+    centroid[2] /= indices_count;
+    double cumulants[6] = {0};
+    for (int32_t i = 0; i < indices_count; ++i) {
+        int32_t idx = 3 * indices_ptr[i];
+        const double x = static_cast<double>(points_ptr[idx]) - centroid[0];
+        const double y = static_cast<double>(points_ptr[idx + 1]) - centroid[1];
+        const double z = static_cast<double>(points_ptr[idx + 2]) - centroid[2];
+        cumulants[0] += x * x;
+        cumulants[1] += y * y;
+        cumulants[2] += z * z;
+        cumulants[3] += x * y;
+        cumulants[4] += x * z;
+        cumulants[5] += y * z;
+    }
+    const double normalization_factor = static_cast<double>(indices_count - 1);
+    for (int i = 0; i < 6; ++i) cumulants[i] /= normalization_factor;
+    covariance_ptr[0] = static_cast<T>(cumulants[0]);
+    covariance_ptr[4] = static_cast<T>(cumulants[1]);
+    covariance_ptr[8] = static_cast<T>(cumulants[2]);
+    covariance_ptr[1] = static_cast<T>(cumulants[3]);
+    covariance_ptr[3] = covariance_ptr[1];
+    covariance_ptr[2] = static_cast<T>(cumulants[4]);
+    covariance_ptr[6] = covariance_ptr[2];
+    covariance_ptr[5] = static_cast<T>(cumulants[5]);
+    covariance_ptr[7] = covariance_ptr[5];
+}
+
+template <typename T>
+void Eigenvector0(const T* A, const T eval0, T* eigen_vector0) {
+    T row0[3] = {A[0] - eval0, A[1], A[2]};
+    T row1[3] = {A[1], A[4] - eval0, A[5]};
+    T row2[3] = {A[2], A[5], A[8] - eval0};
+    T r0xr1[3], r0xr2[3], r1xr2[3];
+    Cross(row0, row1, r0xr1);
+    Cross(row0, row2, r0xr2);
+    Cross(row1, row2, r1xr2);
+    T d0 = Dot(r0xr1, r0xr1);
+    T d1 = Dot(r0xr2, r0xr2);
+    T d2 = Dot(r1xr2, r1xr2);
+    T dmax = d0;
+    int imax = 0;
+    if (d1 > dmax) {
+        dmax = d1;
+        imax = 1;
+    }
+    if (d2 > dmax) imax = 2;
+    const T* v = imax == 0 ? r0xr1 : (imax == 1 ? r0xr2 : r1xr2);
+    T sqrt_d = std::sqrt(imax == 0 ? d0 : (imax == 1 ? d1 : d2));
+    eigen_vector0[0] = v[0] / sqrt_d;
+    eigen_vector0[1] = v[1] / sqrt_d;
+    eigen_vector0[2] = v[2] / sqrt_d;
+}
+
+template <typename T>
+void Eigenvector1(const T* A, const T* evec0, const T eval1,
+                  T* eigen_vector1) {
+    T U[3];
+    if (std::abs(evec0[0]) > std::abs(evec0[1])) {
+        T inv_length =
+                1.0 / std::sqrt(evec0[0] * evec0[0] + evec0[2] * evec0[2]);
+        U[0] = -evec0[2] * inv_length;
+        U[1] = 0.0;
+        U[2] = evec0[0] * inv_length;
+    } else {
+        T inv_length =
+                1.0 / std::sqrt(evec0[1] * evec0[1] + evec0[2] * evec0[2]);
+        U[0] = 0.0;
+        U[1] = evec0[2] * inv_length;
+        U[2] = -evec0[1] * inv_length;
+    }
+    T V[3], AU[3], AV[3];
+    Cross(evec0, U, V);
+    Matmul3x3_3x1(A, U, AU);
+    Matmul3x3_3x1(A, V, AV);
+    T m00 = Dot(U, AU) - eval1;
+    T m01 = Dot(U, AV);
+    T m11 = Dot(V, AV) - eval1;
+    T absM00 = std::abs(m00);
+    T absM01 = std::abs(m01);
+    T absM11 = std::abs(m11);
+    T max_abs_comp;
+    if (absM00 >= absM11) {
+        max_abs_comp = std::max(absM00, absM01);
+        if (max_abs_comp > 0) {
+            if (absM00 >= absM01) {
+                m01 /= m00;
+                m00 = 1 / std::sqrt(1 + m01 * m01);
+                m01 *= m00;
+            } else {
+                m00 /= m01;
+                m01 = 1 / std::sqrt(1 + m00 * m00);
+                m00 *= m01;
+            }
+            eigen_vector1[0] = m01 * U[0] - m00 * V[0];
+            eigen_vector1[1] = m01 * U[1] - m00 * V[1];
+            eigen_vector1[2] = m01 * U[2] - m00 * V[2];
+        } else {
+            eigen_vector1[0] = U[0];
+            eigen_vector1[1] = U[1];
+            eigen_vector1[2] = U[2];
+        }
+    } else {
+        max_abs_comp = std::max(absM11, absM01);
+        if (max_abs_comp > 0) {
+            if (absM11 >= absM01) {
+                m01 /= m11;
+                m11 = 1 / std::sqrt(1 + m01 * m01);
+                m01 *= m11;
+            } else {
+                m11 /= m01;
+                m01 = 1 / std::sqrt(1 + m11 * m11);
+                m11 *= m01;
+            }
+            eigen_vector1[0] = m11 * U[0] - m01 * V[0];
+            eigen_vector1[1] = m11 * U[1] - m01 * V[1];
+            eigen_vector1[2] = m11 * U[2] - m01 * V[2];
+        } else {
+            eigen_vector1[0] = U[0];
+            eigen_vector1[1] = U[1];
+            eigen_vector1[2] = U[2];
+        }
+    }
+}
+
+template <typename T>
+void FastEigen3x3(const T* covariance_ptr, T* normals_ptr) {
+    T max_coeff = covariance_ptr[0];
+    for (int i = 1; i < 9; ++i)
+        if (max_coeff < covariance_ptr[i]) max_coeff = covariance_ptr[i];
+    if (max_coeff == 0) {
+        normals_ptr[0] = normals_ptr[1] = normals_ptr[2] = 0.0;
+        return;
+    }
+    T A[9] = {0};
+    for (int i = 0; i < 9; ++i) A[i] = covariance_ptr[i] / max_coeff;
+    T norm = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    if (norm > 0) {
+        T eval[3], evec0[3], evec1[3], evec2[3];
+        T q = (A[0] + A[4] + A[8]) / 3.0;
+        T b00 = A[0] - q;
+        T b11 = A[4] - q;
+        T b22 = A[8] - q;
+        T p = std::sqrt((b00 * b00 + b11 * b11 + b22 * b22 + norm * 2.0) / 6.0);
+        T c00 = b11 * b22 - A[5] * A[5];
+        T c01 = A[1] * b22 - A[5] * A[2];
+        T c02 = A[1] * A[5] - b11 * A[2];
+        T det = (b00 * c00 - A[1] * c01 + A[2] * c02) / (p * p * p);
+        T half_det = det * 0.5;
+        half_det = std::min(std::max(half_det, static_cast<T>(-1.0)),
+                            static_cast<T>(1.0));
+        T angle = std::acos(half_det) / 3.0;
+        const T two_thrids_pi = 2.09439510239319549;
+        T beta2 = std::cos(angle) * 2.0;
+        T beta0 = std::cos(angle + two_thrids_pi) * 2.0;
+        T beta1 = -(beta0 + beta2);
+        eval[0] = q + p * beta0;
+        eval[1] = q + p * beta1;
+        eval[2] = q + p * beta2;
+        if (half_det >= 0) {
+            Eigenvector0<T>(A, eval[2], evec2);
+            if (eval[2] < eval[0] && eval[2] < eval[1]) {
+                for (int i = 0; i < 3; ++i) normals_ptr[i] = evec2[i];
+                return;
+            }
+            Eigenvector1<T>(A, evec2, eval[1], evec1);
+            if (eval[1] < eval[0] && eval[1] < eval[2]) {
+                for (int i = 0; i < 3; ++i) normals_ptr[i] = evec1[i];
+                return;
+            }
+            normals_ptr[0] = evec1[1] * evec2[2] - evec1[2] * evec2[1];
+            normals_ptr[1] = evec1[2] * evec2[0] - evec1[0] * evec2[2];
+            normals_ptr[2] = evec1[0] * evec2[1] - evec1[1] * evec2[0];
+        } else {
+            Eigenvector0<T>(A, eval[0], evec0);
+            if (eval[0] < eval[1] && eval[0] < eval[2]) {
+                for (int i = 0; i < 3; ++i) normals_ptr[i] = evec0[i];
+                return;
+            }
+            Eigenvector1<T>(A, evec0, eval[1], evec1);
+            if (eval[1] < eval[0] && eval[1] < eval[2]) {
+                for (int i = 0; i < 3; ++i) normals_ptr[i] = evec1[i];
+                return;
+            }
+            normals_ptr[0] = evec0[1] * evec1[2] - evec0[2] * evec1[1];
+            normals_ptr[1] = evec0[2] * evec1[0] - evec0[0] * evec1[2];
+            normals_ptr[2] = evec0[0] * evec1[1] - evec0[1] * evec1[0];
+        }
+    } else {
+        if (covariance_ptr[0] < covariance_ptr[4] &&
+            covariance_ptr[0] < covariance_ptr[8]) {
+            normals_ptr[0] = 1.0; normals_ptr[1] = 0.0; normals_ptr[2] = 0.0;
+        } else if (covariance_ptr[4] < covariance_ptr[0] &&
+                   covariance_ptr[4] < covariance_ptr[8]) {
+            normals_ptr[0] = 0.0; normals_ptr[1] = 1.0; normals_ptr[2] = 0.0;
+        } else {
+            normals_ptr[0] = 0.0; normals_ptr[1] = 0.0; normals_ptr[2] = 1.0;
+        }
+    }
+}
+
+template <typename T>
+void NormalsFromCovariances(const T* covariances, int64_t n, T* normals_ptr,
+                            bool has_normals) {
+    for (int64_t w = 0; w < n; ++w) {
+        T out[3] = {0};
+        FastEigen3x3<T>(covariances + 9 * w, out);
+        if ((out[0] * out[0] + out[1] * out[1] + out[2] * out[2]) == 0.0 &&
+            !has_normals) {
+            out[0] = 0.0; out[1] = 0.0; out[2] = 1.0;
+        }
+        if (has_normals) {
+            if ((normals_ptr[3 * w] * out[0] + normals_ptr[3 * w + 1] * out[1] +
+                 normals_ptr[3 * w + 2] * out[2]) < 0.0) {
+                out[0] *= -1; out[1] *= -1; out[2] *= -1;
+            }
+        }
+        normals_ptr[3 * w] = out[0];
+        normals_ptr[3 * w + 1] = out[1];
+        normals_ptr[3 * w + 2] = out[2];
+    }
+}
+
+}  // namespace normals
+
 extern "C" {
 
 double orc_robust_weight(int is_f64, int method, double scaling, double shape,
@@ -713,6 +986,38 @@ double orc_robust_weight(int is_f64, int method, double scaling, double shape,
     if (is_f64) return RobustWeight<double>(method, scaling, shape, residual);
     return (double)RobustWeight<float>(method, scaling, shape, (float)residual);
 }
+
+// EstimatePointWiseRobustNormalizedCovarianceKernel over hybrid-search results
+// (indices {n, max_nn} int32, counts {n}); covariances {n,3,3}.
+void orc_estimate_covariances(const void* points, const int32_t* indices,
+                              const int32_t* counts, int64_t n, int max_nn,
+                              int is_f64, void* covariances) {
+    for (int64_t w = 0; w < n; ++w) {
+        if (is_f64)
+            normals::Covariance<double>((const double*)points,
+                                        indices + (int64_t)max_nn * w, counts[w],
+                                        (double*)covariances + 9 * w);
+        else
+            normals::Covariance<float>((const float*)points,
+                                       indices + (int64_t)max_nn * w, counts[w],
+                                       (float*)covariances + 9 * w);
+    }
+}
+
+// EstimateNormalsFromCovariancesCPU; normals is in/out when has_normals.
+void orc_normals_from_covariances(const void* covariances, int64_t n,
+                                  int is_f64, void* normals_io,
+                                  int has_normals) {
+    if (is_f64)
+        normals::NormalsFromCovariances<double>((const double*)covariances, n,
+                                                (double*)normals_io,
+                                                has_normals != 0);
+    else
+        normals::NormalsFromCovariances<float>((const float*)covariances, n,
+                                               (float*)normals_io,
+                                               has_normals != 0);
+}
+
 
 void orc_hybrid_search(const void* points, int64_t n, const void* queries,
                        int64_t q, int is_f64, double radius, int max_knn,

@@ -315,6 +315,40 @@ int64_t ref_extract_point_cloud(const int* indices, const int* nb_indices,
     return rc == 0 ? (int64_t)valid_size : -1;
 }
 
+// EstimatePointWiseRobustNormalizedCovarianceKernel (PointCloudImpl.h:512-585)
+// per point over given hybrid-search results, and
+// EstimateNormalsFromCovariancesCPU (:1011-1063). The search itself
+// (nanoflann) is not part of this build.
+int ref_estimate_covariances(const void* points, const int32_t* indices,
+                             const int32_t* counts, int64_t n, int max_nn,
+                             int is_f64, void* covariances) {
+    return Guard([&] {
+        namespace pc = open3d::t::geometry::kernel::pointcloud;
+        for (int64_t w = 0; w < n; ++w) {
+            const int32_t cnt = counts[w];
+            if (is_f64)
+                pc::EstimatePointWiseRobustNormalizedCovarianceKernel<double>(
+                        (const double*)points, indices + (int64_t)max_nn * w, cnt,
+                        (double*)covariances + 9 * w);
+            else
+                pc::EstimatePointWiseRobustNormalizedCovarianceKernel<float>(
+                        (const float*)points, indices + (int64_t)max_nn * w, cnt,
+                        (float*)covariances + 9 * w);
+        }
+    });
+}
+
+int ref_normals_from_covariances(const void* covariances, int64_t n, int is_f64,
+                                 void* normals_io, int has_normals) {
+    return Guard([&] {
+        namespace pc = open3d::t::geometry::kernel::pointcloud;
+        const core::Dtype dt = is_f64 ? core::Float64 : core::Float32;
+        Tensor cov = Wrap(covariances, {n, 3, 3}, dt);
+        Tensor nrm = Wrap(normals_io, {n, 3}, dt);
+        pc::EstimateNormalsFromCovariancesCPU(cov, nrm, has_normals != 0);
+    });
+}
+
 // UnprojectCPU, t/geometry/kernel/PointCloudImpl.h:42-143.
 int64_t ref_unproject(const void* depth, int depth_is_f32, int rows, int cols,
                       const float* colors_f32, float* points, float* colors,

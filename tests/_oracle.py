@@ -630,3 +630,37 @@ def rgbd_odometry_multiscale(method, src_depth, tgt_depth, K, init=None,
         C.byref(rmse), C.byref(fit), C.byref(it))
     return {"status": int(st), "transformation": T, "inlier_rmse": rmse.value,
             "fitness": fit.value, "iterations": it.value}
+
+
+# ---------------------------------------------------------------------------
+# Normal estimation (row f4)
+# ---------------------------------------------------------------------------
+def estimate_covariances(points, indices, counts):
+    points = np.ascontiguousarray(points)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    n, max_nn = indices.shape
+    cov = np.zeros((n, 3, 3), points.dtype)
+    lib().orc_estimate_covariances(_p(points), _p(indices), _p(counts),
+                                   C.c_int64(n), int(max_nn),
+                                   int(points.dtype == np.float64), _p(cov))
+    return cov
+
+
+def normals_from_covariances(cov, normals=None):
+    cov = np.ascontiguousarray(cov)
+    n = cov.shape[0]
+    has = normals is not None
+    out = np.ascontiguousarray(normals, dtype=cov.dtype).copy() if has \
+        else np.zeros((n, 3), cov.dtype)
+    lib().orc_normals_from_covariances(_p(cov), C.c_int64(n),
+                                       int(cov.dtype == np.float64), _p(out),
+                                       int(has))
+    return out
+
+
+def estimate_normals(points, radius, max_nn, normals=None):
+    """PointCloud::EstimateNormals(max_nn, radius) -- hybrid search."""
+    idx, _, cnt = hybrid_search(points, points, radius, max_nn)
+    return normals_from_covariances(estimate_covariances(points, idx, cnt),
+                                    normals)

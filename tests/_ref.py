@@ -408,3 +408,27 @@ def extract_point_cloud(indices, nb_indices, nb_masks, block_keys, tsdf,
                            % L.ref_last_error().decode())
     m = min(total, cap)
     return pts[:m], nrm[:m], (None if col is None else col[:m]), total
+
+
+def estimate_covariances(points, indices, counts):
+    points = np.ascontiguousarray(points)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    n, max_nn = indices.shape
+    cov = np.zeros((n, 3, 3), points.dtype)
+    _check(lib().ref_estimate_covariances(
+        _p(points), _p(indices), _p(counts), C.c_int64(n), int(max_nn),
+        int(points.dtype == np.float64), _p(cov)), "estimate_covariances")
+    return cov
+
+
+def normals_from_covariances(cov, normals=None):
+    cov = np.ascontiguousarray(cov)
+    n = cov.shape[0]
+    has = normals is not None
+    out = np.ascontiguousarray(normals, dtype=cov.dtype).copy() if has \
+        else np.zeros((n, 3), cov.dtype)
+    _check(lib().ref_normals_from_covariances(
+        _p(cov), C.c_int64(n), int(cov.dtype == np.float64), _p(out),
+        int(has)), "normals_from_covariances")
+    return out

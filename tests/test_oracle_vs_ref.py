@@ -326,3 +326,43 @@ def test_extract_point_cloud_vs_reference_body(grid_f32, with_color):
     assert b8[3] == a[3]
     key = lambda p: sc.sort_rows(np.concatenate(p[:2], axis=1))
     assert np.array_equal(key(b8), key(a))
+
+
+# ---------------------------------------------------------------------------
+# Normal estimation
+# ---------------------------------------------------------------------------
+def _surface_cloud(n, seed, dtype):
+    from open3d_amd import synthetic
+    p = synthetic.make_icp_pair(n, n, seed=seed, dtype=dtype)
+    return p["target"], p["target_normals"]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_normals_vs_reference_bodies(dtype):
+    pts, nrm_true = _surface_cloud(4000, 5, dtype)
+    # degenerate inputs ride along: isolated points (< 3 neighbours), exact
+    # duplicates, points on an axis-aligned plane / line
+    extra = np.array([[50, 50, 50], [60, 60, 60], [60, 60, 60.001]], dtype)
+    line = np.stack([np.linspace(70, 70.2, 40), np.full(40, 1.0),
+                     np.full(40, 2.0)], 1).astype(dtype)
+    gx, gy = np.meshgrid(np.linspace(80, 80.3, 12), np.linspace(0, 0.3, 12))
+    plane = np.stack([gx.ravel(), gy.ravel(), np.full(144, 3.0)], 1).astype(dtype)
+    pts = np.ascontiguousarray(np.concatenate([pts, extra, line, plane]))
+    idx, _, cnt = orc.hybrid_search(pts, pts, 0.08, 30)
+    assert cnt.max() == 30 and cnt.min() <= 2
+    a = orc.estimate_covariances(pts, idx, cnt)
+    b = ref.estimate_covariances(pts, idx, cnt)
+    assert a.tobytes() == b.tobytes()
+    na = orc.normals_from_covariances(a)
+    nb = ref.normals_from_covariances(b)
+    assert na.tobytes() == nb.tobytes()
+    # with existing normals: orientation is kept consistent with them
+    prior = np.concatenate([nrm_true, np.tile([[0, 0, 1.0]], (187, 1))]) \
+        .astype(dtype)
+    pa = orc.normals_from_covariances(a, prior)
+    pb = ref.normals_from_covariances(b, prior)
+    assert pa.tobytes() == pb.tobytes()
+    assert ((pa * prior).sum(1) >= 0).all()
+    # and they are the surface normals up to sign
+    cosang = np.abs((na[:4000] * nrm_true).sum(1))
+    assert np.median(cosang) > 0.98
