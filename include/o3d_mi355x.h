@@ -302,6 +302,33 @@ int o3dmi_nns_hybrid_search_k1(const o3dmi_nns_t* nns, const void* queries_dev,
                                int64_t q, int32_t* idx_dev, void* dist2_dev,
                                int32_t* counts_dev, o3dmi_stream_t stream);
 
+/* HybridSearchCUDA<T,TIndex> for general max_knn <= 64 (same nanoflann
+ * semantics as the k = 1 form): idx {Q,max_knn} int32 ascending by (d2,
+ * index), -1 padded; dist2 {Q,max_knn} in the point dtype, 0 padded (may be
+ * NULL); counts {Q} = min(found, max_knn). */
+int o3dmi_nns_hybrid_search(const o3dmi_nns_t* nns, const void* queries_dev,
+                            int64_t q, int max_knn, int32_t* idx_dev,
+                            void* dist2_dev, int32_t* counts_dev,
+                            o3dmi_stream_t stream);
+
+/* EstimateCovariancesUsingHybridSearchCUDA after the search
+ * (t/geometry/kernel/PointCloudImpl.h:588-638; per-point body :512-585):
+ * covariances {n,3,3} in the point dtype from hybrid-search results. */
+int o3dmi_pointcloud_estimate_covariances(const void* points_dev,
+                                          const int32_t* indices_dev,
+                                          const int32_t* counts_dev, int64_t n,
+                                          int max_nn, int dtype,
+                                          void* covariances_dev,
+                                          o3dmi_stream_t stream);
+/* EstimateNormalsFromCovariancesCUDA (PointCloudImpl.h:1011-1063, fast 3x3
+ * symmetric eigen solver :746-1009). normals {n,3} is in/out when
+ * has_normals (orientation is kept consistent with the existing normals). */
+int o3dmi_pointcloud_normals_from_covariances(const void* covariances_dev,
+                                              int64_t n, int dtype,
+                                              void* normals_dev,
+                                              int has_normals,
+                                              o3dmi_stream_t stream);
+
 /* ComputePosePointToPlaneCUDA up to the reduction
  * (t/pipelines/kernel/RegistrationCUDA.cu:29-117, RegistrationImpl.h:251-287):
  * the 29 sums (21 JtJ lower-triangular row-major, 6 Jtr, sum r, count) are

@@ -81,6 +81,15 @@ int o3dmi_voxel_down_sample(const void* positions_dev, const void* normals_dev,
                             void* out_positions_dev, void* out_normals_dev,
                             int64_t* m_out, o3dmi_stream_t stream);
 
+/* PointCloud::EstimateNormals(max_nn, radius) (t/geometry/PointCloud.cpp:
+ * 856-976), hybrid-search variant: normals {n,3} (in/out when has_normals).
+ * The knn-only / radius-only variants need KnnIndex / unbounded neighbour
+ * lists and are not implemented (status O3DMI_ERR_INVALID_ARG). Synchronises. */
+int o3dmi_pointcloud_estimate_normals(const void* points_dev, int64_t n,
+                                      int dtype, int max_nn, double radius,
+                                      void* normals_dev, int has_normals,
+                                      o3dmi_stream_t stream);
+
 /* ------------------------------------------------------------------------ */
 /* VoxelBlockGrid                                                            */
 /* ------------------------------------------------------------------------ */

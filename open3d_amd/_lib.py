@@ -71,6 +71,12 @@ PROTOTYPES = {
     "o3dmi_nns_destroy": (_i32, [_vp]),
     "o3dmi_nns_hybrid_search_k1": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp,
                                           _vp]),
+    "o3dmi_nns_hybrid_search": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp,
+                                       _vp]),
+    "o3dmi_pointcloud_estimate_covariances": (_i32, [_vp, _vp, _vp, _i64, _i32,
+                                                     _i32, _vp, _vp]),
+    "o3dmi_pointcloud_normals_from_covariances": (_i32, [_vp, _i64, _i32, _vp,
+                                                         _i32, _vp]),
     "o3dmi_icp_p2plane_accumulate": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32,
                                             _i32, _d, _d, _vp, _vp]),
     "o3dmi_icp_search_accumulate": (_i32, [_vp, _vp, _vp, _i64, _i32, _d, _d,
@@ -143,6 +149,8 @@ PROTOTYPES.update({
                C.POINTER(IcpCriteria), _dp, _dp, _i32, _d, _d, ICP_CALLBACK,
                _vp, ALLREDUCE_SUM, _vp, _vp, C.POINTER(RegistrationResultC),
                _vp]),
+    "o3dmi_pointcloud_estimate_normals": (_i32, [_vp, _i64, _i32, _i32, _d,
+                                                 _vp, _i32, _vp]),
     "o3dmi_voxel_down_sample": (_i32, [_vp, _vp, _i64, _i32, _d, _vp, _vp,
                                        C.POINTER(_i64), _vp]),
     "o3dmi_vbg_create": (_i32, [_i32, C.POINTER(C.c_char_p), C.POINTER(_i32),

@@ -255,6 +255,69 @@ __global__ void HybridSearchK1Kernel(NnsView<T> nv, const T* __restrict__ q,
 }
 
 // ---- robust kernels ---------------------------------------------------------
+// HybridSearch for general max_knn (core/nns/NanoFlannImpl.h:305-370 semantics:
+// neighbours with d2 < r2, ascending by (d2, index), the first max_knn kept;
+// idx padded with -1, dist with 0, count = min(found, max_knn)). One lane per
+// query; the running top-k list lives in private memory.
+constexpr int kMaxKnn = 64;
+
+template <typename T>
+__global__ void HybridSearchKernel(NnsView<T> nv, const T* __restrict__ q,
+                                   int64_t nq, int max_knn,
+                                   int* __restrict__ idx_out,
+                                   T* __restrict__ d2_out,
+                                   int* __restrict__ cnt_out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nq;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const T qq[3] = {q[3 * i + 0], q[3 * i + 1], q[3 * i + 2]};
+        T bd[kMaxKnn];
+        int bi[kMaxKnn];
+        int found = 0;
+        long long cx, cy, cz;
+        CellOf(qq, nv.inv_cell, cx, cy, cz);
+        for (int c = 0; c < 27; ++c) {
+            const int dz = c / 9 - 1, dy = (c % 9) / 3 - 1, dx = c % 3 - 1;
+            const unsigned b = HashCell(cx + dx, cy + dy, cz + dz) & nv.mask;
+            const unsigned s0 = nv.starts[b], e0 = nv.starts[b + 1];
+            for (unsigned j = s0; j < e0; ++j) {
+                const Rec4<T> p = nv.sorted[j];
+                T result = T(0);
+                const T d0 = qq[0] - p.x;
+                result += d0 * d0;
+                const T d1 = qq[1] - p.y;
+                result += d1 * d1;
+                const T dd = qq[2] - p.z;
+                result += dd * dd;
+                if (!(result < nv.radius_squared)) continue;
+                const int pi = RecIndex(p);
+                // position in the ascending (d2, index) list
+                const int len = found < max_knn ? found : max_knn;
+                int pos = len;
+                while (pos > 0 && (result < bd[pos - 1] ||
+                                   (result == bd[pos - 1] && pi < bi[pos - 1])))
+                    --pos;
+                // two neighbour cells can hash to the same bucket: the record
+                // was seen before (same index => same distance, adjacent)
+                if (pos > 0 && bi[pos - 1] == pi) continue;
+                if (pos >= max_knn) continue;
+                for (int k = (found < max_knn ? found : max_knn - 1); k > pos;
+                     --k) {
+                    bd[k] = bd[k - 1];
+                    bi[k] = bi[k - 1];
+                }
+                bd[pos] = result;
+                bi[pos] = pi;
+                if (found < max_knn) ++found;
+            }
+        }
+        for (int k = 0; k < max_knn; ++k) {
+            if (idx_out) idx_out[i * max_knn + k] = k < found ? bi[k] : -1;
+            if (d2_out) d2_out[i * max_knn + k] = k < found ? bd[k] : T(0);
+        }
+        if (cnt_out) cnt_out[i] = found;
+    }
+}
+
 // RobustKernelImpl.h:35-126, literal: the double-typed literals promote parts
 // of each expression to float64 before the result is narrowed to scalar_t.
 template <typename T>
@@ -722,6 +785,30 @@ int o3dmi_nns_hybrid_search_k1(const o3dmi_nns_t* nns, const void* queries_dev,
         hipLaunchKernelGGL(HybridSearchK1Kernel<float>, grid, block, 0, s,
                            MakeView<float>(nns), (const float*)queries_dev, q,
                            idx_dev, (float*)dist2_dev, counts_dev);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+int o3dmi_nns_hybrid_search(const o3dmi_nns_t* nns, const void* queries_dev,
+                            int64_t q, int max_knn, int32_t* idx_dev,
+                            void* dist2_dev, int32_t* counts_dev,
+                            o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(nns != nullptr, "index is null");
+    O3DMI_REQUIRE(q >= 0, "q < 0");
+    O3DMI_REQUIRE(max_knn >= 1 && max_knn <= kMaxKnn,
+                  "max_knn must be in [1, 64]");
+    if (q == 0) return O3DMI_OK;
+    O3DMI_REQUIRE(queries_dev != nullptr, "queries is null");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(GridFor(q, kBlock)), block(kBlock);
+    if (nns->dtype == O3DMI_F64)
+        hipLaunchKernelGGL(HybridSearchKernel<double>, grid, block, 0, s,
+                           MakeView<double>(nns), (const double*)queries_dev, q,
+                           max_knn, idx_dev, (double*)dist2_dev, counts_dev);
+    else
+        hipLaunchKernelGGL(HybridSearchKernel<float>, grid, block, 0, s,
+                           MakeView<float>(nns), (const float*)queries_dev, q,
+                           max_knn, idx_dev, (float*)dist2_dev, counts_dev);
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
 }

@@ -1,0 +1,408 @@
+// Point-cloud normal estimation on MI355X:
+// PointCloud::EstimateNormals(max_nn, radius) with hybrid search
+// (cpp/open3d/t/geometry/PointCloud.cpp:856-976). Replaces
+//   EstimateCovariancesUsingHybridSearchCUDA  (t/geometry/kernel/PointCloudImpl.h:588-638,
+//       per-point body EstimatePointWiseRobustNormalizedCovarianceKernel :512-585)
+//   EstimateNormalsFromCovariancesCUDA        (:1011-1063, per-point body
+//       EstimatePointWiseNormalsWithFastEigen3x3 :875-1009, ComputeEigenvector0/1 :746-873)
+// Per-point arithmetic follows the reference statement by statement, including
+// where its double literals promote a sub-expression to float64; acos / cos
+// come from the device math library (a few ulp from the host's), so normals
+// agree with the CPU path to ~1e-6, not bit for bit.
+// Gather-bound: 30 neighbours x 12 B per point, L2-resident for a sorted cloud.
+
+#include <cmath>
+
+#include "common.h"
+
+namespace o3dmi {
+namespace {
+
+template <typename T>
+__device__ __forceinline__ void Cross(const T* a, const T* b, T* c) {
+    c[0] = (a[1] * b[2]) - (a[2] * b[1]);
+    c[1] = (a[2] * b[0]) - (a[0] * b[2]);
+    c[2] = (a[0] * b[1]) - (a[1] * b[0]);
+}
+template <typename T>
+__device__ __forceinline__ T Dot(const T* a, const T* b) {
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+template <typename T>
+__device__ __forceinline__ void Matmul3x3_3x1(const T* A, const T* b, T* c) {
+    c[0] = A[0] * b[0] + A[1] * b[1] + A[2] * b[2];
+    c[1] = A[3] * b[0] + A[4] * b[1] + A[5] * b[2];
+    c[2] = A[6] * b[0] + A[7] * b[1] + A[8] * b[2];
+}
+__device__ __forceinline__ float Sqrt(float v) { return sqrtf(v); }
+__device__ __forceinline__ double Sqrt(double v) { return sqrt(v); }
+__device__ __forceinline__ float Abs(float v) { return fabsf(v); }
+__device__ __forceinline__ double Abs(double v) { return fabs(v); }
+__device__ __forceinline__ float Acos(float v) { return acosf(v); }
+__device__ __forceinline__ double Acos(double v) { return acos(v); }
+__device__ __forceinline__ float Cos(float v) { return cosf(v); }
+__device__ __forceinline__ double Cos(double v) { return cos(v); }
+
+// PointCloudImpl.h:512-585
+template <typename T>
+__global__ void CovariancesKernel(const T* __restrict__ points,
+                                  const int32_t* __restrict__ indices,
+                                  const int32_t* __restrict__ counts, int64_t n,
+                                  int max_nn, T* __restrict__ covariances) {
+    for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < n;
+         w += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t* idx = indices + (int64_t)max_nn * w;
+        const int32_t cnt = counts[w];
+        T* cov = covariances + 9 * w;
+        if (cnt < 3) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) cov[i] = (i % 4 == 0) ? T(1.0) : T(0.0);
+            continue;
+        }
+        double centroid[3] = {0, 0, 0};
+        for (int32_t i = 0; i < cnt; ++i) {
+            const int64_t o = 3 * (int64_t)idx[i];
+            centroid[0] += points[o];
+            centroid[1] += points[o + 1];
+            centroid[2] += points[o + 2];
+        }
+        centroid[0] /= cnt;
+        centroid[1] /= cnt;
+        centroid[2] /= cnt;
+        double cumulants[6] = {0, 0, 0, 0, 0, 0};
+        for (int32_t i = 0; i < cnt; ++i) {
+            const int64_t o = 3 * (int64_t)idx[i];
+            const double x = static_cast<double>(points[o]) - centroid[0];
+            const double y = static_cast<double>(points[o + 1]) - centroid[1];
+            const double z = static_cast<double>(points[o + 2]) - centroid[2];
+            cumulants[0] += x * x;
+            cumulants[1] += y * y;
+            cumulants[2] += z * z;
+            cumulants[3] += x * y;
+            cumulants[4] += x * z;
+            cumulants[5] += y * z;
+        }
+        const double normalization_factor = static_cast<double>(cnt - 1);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) cumulants[i] /= normalization_factor;
+        cov[0] = static_cast<T>(cumulants[0]);
+        cov[4] = static_cast<T>(cumulants[1]);
+        cov[8] = static_cast<T>(cumulants[2]);
+        cov[1] = static_cast<T>(cumulants[3]);
+        cov[3] = cov[1];
+        cov[2] = static_cast<T>(cumulants[4]);
+        cov[6] = cov[2];
+        cov[5] = static_cast<T>(cumulants[5]);
+        cov[7] = cov[5];
+    }
+}
+
+// PointCloudImpl.h:746-793
+template <typename T>
+__device__ void Eigenvector0(const T* A, const T eval0, T* ev) {
+    T row0[3] = {A[0] - eval0, A[1], A[2]};
+    T row1[3] = {A[1], A[4] - eval0, A[5]};
+    T row2[3] = {A[2], A[5], A[8] - eval0};
+    T r0xr1[3], r0xr2[3], r1xr2[3];
+    Cross(row0, row1, r0xr1);
+    Cross(row0, row2, r0xr2);
+    Cross(row1, row2, r1xr2);
+    const T d0 = Dot(r0xr1, r0xr1);
+    const T d1 = Dot(r0xr2, r0xr2);
+    const T d2 = Dot(r1xr2, r1xr2);
+    T dmax = d0;
+    int imax = 0;
+    if (d1 > dmax) {
+        dmax = d1;
+        imax = 1;
+    }
+    if (d2 > dmax) imax = 2;
+    if (imax == 0) {
+        const T s = Sqrt(d0);
+        ev[0] = r0xr1[0] / s; ev[1] = r0xr1[1] / s; ev[2] = r0xr1[2] / s;
+    } else if (imax == 1) {
+        const T s = Sqrt(d1);
+        ev[0] = r0xr2[0] / s; ev[1] = r0xr2[1] / s; ev[2] = r0xr2[2] / s;
+    } else {
+        const T s = Sqrt(d2);
+        ev[0] = r1xr2[0] / s; ev[1] = r1xr2[1] / s; ev[2] = r1xr2[2] / s;
+    }
+}
+
+// PointCloudImpl.h:795-873
+template <typename T>
+__device__ void Eigenvector1(const T* A, const T* evec0, const T eval1, T* ev) {
+    T U[3];
+    if (Abs(evec0[0]) > Abs(evec0[1])) {
+        const T inv_length = (T)(
+                1.0 / (double)Sqrt(evec0[0] * evec0[0] + evec0[2] * evec0[2]));
+        U[0] = -evec0[2] * inv_length;
+        U[1] = 0.0;
+        U[2] = evec0[0] * inv_length;
+    } else {
+        const T inv_length = (T)(
+                1.0 / (double)Sqrt(evec0[1] * evec0[1] + evec0[2] * evec0[2]));
+        U[0] = 0.0;
+        U[1] = evec0[2] * inv_length;
+        U[2] = -evec0[1] * inv_length;
+    }
+    T V[3], AU[3], AV[3];
+    Cross(evec0, U, V);
+    Matmul3x3_3x1(A, U, AU);
+    Matmul3x3_3x1(A, V, AV);
+    T m00 = Dot(U, AU) - eval1;
+    T m01 = Dot(U, AV);
+    T m11 = Dot(V, AV) - eval1;
+    const T absM00 = Abs(m00), absM01 = Abs(m01), absM11 = Abs(m11);
+    if (absM00 >= absM11) {
+        const T max_abs_comp = absM00 < absM01 ? absM01 : absM00;
+        if (max_abs_comp > 0) {
+            if (absM00 >= absM01) {
+                m01 /= m00;
+                m00 = 1 / Sqrt(1 + m01 * m01);
+                m01 *= m00;
+            } else {
+                m00 /= m01;
+                m01 = 1 / Sqrt(1 + m00 * m00);
+                m00 *= m01;
+            }
+            ev[0] = m01 * U[0] - m00 * V[0];
+            ev[1] = m01 * U[1] - m00 * V[1];
+            ev[2] = m01 * U[2] - m00 * V[2];
+        } else {
+            ev[0] = U[0]; ev[1] = U[1]; ev[2] = U[2];
+        }
+    } else {
+        const T max_abs_comp = absM11 < absM01 ? absM01 : absM11;
+        if (max_abs_comp > 0) {
+            if (absM11 >= absM01) {
+                m01 /= m11;
+                m11 = 1 / Sqrt(1 + m01 * m01);
+                m01 *= m11;
+            } else {
+                m11 /= m01;
+                m01 = 1 / Sqrt(1 + m11 * m11);
+                m11 *= m01;
+            }
+            ev[0] = m11 * U[0] - m01 * V[0];
+            ev[1] = m11 * U[1] - m01 * V[1];
+            ev[2] = m11 * U[2] - m01 * V[2];
+        } else {
+            ev[0] = U[0]; ev[1] = U[1]; ev[2] = U[2];
+        }
+    }
+}
+
+// PointCloudImpl.h:875-1009
+template <typename T>
+__device__ void FastEigen3x3(const T* cov, T* nrm) {
+    T max_coeff = cov[0];
+#pragma unroll
+    for (int i = 1; i < 9; ++i)
+        if (max_coeff < cov[i]) max_coeff = cov[i];
+    if (max_coeff == 0) {
+        nrm[0] = nrm[1] = nrm[2] = 0.0;
+        return;
+    }
+    T A[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) A[i] = cov[i] / max_coeff;
+    const T norm = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    if (norm > 0) {
+        T eval[3], evec0[3], evec1[3], evec2[3];
+        const T q = (T)((double)(A[0] + A[4] + A[8]) / 3.0);
+        const T b00 = A[0] - q;
+        const T b11 = A[4] - q;
+        const T b22 = A[8] - q;
+        // (b00*b00 + b11*b11 + b22*b22 + norm * 2.0) / 6.0: the sum of the
+        // three squares is scalar_t, `norm * 2.0` and everything after it
+        // float64; sqrt of the float64 value, narrowed to scalar_t.
+        const T p = (T)sqrt(((double)(b00 * b00 + b11 * b11 + b22 * b22) +
+                             (double)norm * 2.0) /
+                            6.0);
+        const T c00 = b11 * b22 - A[5] * A[5];
+        const T c01 = A[1] * b22 - A[5] * A[2];
+        const T c02 = A[1] * A[5] - b11 * A[2];
+        const T det = (b00 * c00 - A[1] * c01 + A[2] * c02) / (p * p * p);
+        T half_det = (T)((double)det * 0.5);
+        half_det = half_det < (T)-1.0 ? (T)-1.0 : half_det;  // max(half_det,-1)
+        half_det = (T)1.0 < half_det ? (T)1.0 : half_det;    // min(.., 1)
+        const T angle = (T)((double)Acos(half_det) / 3.0);
+        const T two_thrids_pi = (T)2.09439510239319549;
+        const T beta2 = (T)((double)Cos(angle) * 2.0);
+        const T beta0 = (T)((double)Cos(angle + two_thrids_pi) * 2.0);
+        const T beta1 = -(beta0 + beta2);
+        eval[0] = q + p * beta0;
+        eval[1] = q + p * beta1;
+        eval[2] = q + p * beta2;
+        if (half_det >= 0) {
+            Eigenvector0<T>(A, eval[2], evec2);
+            if (eval[2] < eval[0] && eval[2] < eval[1]) {
+                nrm[0] = evec2[0]; nrm[1] = evec2[1]; nrm[2] = evec2[2];
+                return;
+            }
+            Eigenvector1<T>(A, evec2, eval[1], evec1);
+            if (eval[1] < eval[0] && eval[1] < eval[2]) {
+                nrm[0] = evec1[0]; nrm[1] = evec1[1]; nrm[2] = evec1[2];
+                return;
+            }
+            nrm[0] = evec1[1] * evec2[2] - evec1[2] * evec2[1];
+            nrm[1] = evec1[2] * evec2[0] - evec1[0] * evec2[2];
+            nrm[2] = evec1[0] * evec2[1] - evec1[1] * evec2[0];
+        } else {
+            Eigenvector0<T>(A, eval[0], evec0);
+            if (eval[0] < eval[1] && eval[0] < eval[2]) {
+                nrm[0] = evec0[0]; nrm[1] = evec0[1]; nrm[2] = evec0[2];
+                return;
+            }
+            Eigenvector1<T>(A, evec0, eval[1], evec1);
+            if (eval[1] < eval[0] && eval[1] < eval[2]) {
+                nrm[0] = evec1[0]; nrm[1] = evec1[1]; nrm[2] = evec1[2];
+                return;
+            }
+            nrm[0] = evec0[1] * evec1[2] - evec0[2] * evec1[1];
+            nrm[1] = evec0[2] * evec1[0] - evec0[0] * evec1[2];
+            nrm[2] = evec0[0] * evec1[1] - evec0[1] * evec1[0];
+        }
+    } else {
+        if (cov[0] < cov[4] && cov[0] < cov[8]) {
+            nrm[0] = 1.0; nrm[1] = 0.0; nrm[2] = 0.0;
+        } else if (cov[4] < cov[0] && cov[4] < cov[8]) {
+            nrm[0] = 0.0; nrm[1] = 1.0; nrm[2] = 0.0;
+        } else {
+            nrm[0] = 0.0; nrm[1] = 0.0; nrm[2] = 1.0;
+        }
+    }
+}
+
+// PointCloudImpl.h:1011-1063
+template <typename T>
+__global__ void NormalsFromCovariancesKernel(const T* __restrict__ covariances,
+                                             int64_t n, T* __restrict__ normals,
+                                             bool has_normals) {
+    for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < n;
+         w += (int64_t)gridDim.x * blockDim.x) {
+        T cov[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) cov[i] = covariances[9 * w + i];
+        T out[3] = {0, 0, 0};
+        FastEigen3x3<T>(cov, out);
+        if ((out[0] * out[0] + out[1] * out[1] + out[2] * out[2]) == 0.0 &&
+            !has_normals) {
+            out[0] = 0.0; out[1] = 0.0; out[2] = 1.0;
+        }
+        if (has_normals) {
+            if ((normals[3 * w] * out[0] + normals[3 * w + 1] * out[1] +
+                 normals[3 * w + 2] * out[2]) < 0.0) {
+                out[0] *= -1; out[1] *= -1; out[2] *= -1;
+            }
+        }
+        normals[3 * w] = out[0];
+        normals[3 * w + 1] = out[1];
+        normals[3 * w + 2] = out[2];
+    }
+}
+
+}  // namespace
+}  // namespace o3dmi
+
+using namespace o3dmi;
+
+extern "C" {
+
+int o3dmi_pointcloud_estimate_covariances(const void* points_dev,
+                                          const int32_t* indices_dev,
+                                          const int32_t* counts_dev, int64_t n,
+                                          int max_nn, int dtype,
+                                          void* covariances_dev,
+                                          o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
+                  "points must be Float32 or Float64");
+    O3DMI_REQUIRE(n >= 0 && max_nn >= 1, "bad sizes");
+    if (n == 0) return O3DMI_OK;
+    O3DMI_REQUIRE(points_dev && indices_dev && counts_dev && covariances_dev,
+                  "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(GridFor(n, kBlock)), block(kBlock);
+    if (dtype == O3DMI_F64)
+        hipLaunchKernelGGL(CovariancesKernel<double>, grid, block, 0, s,
+                           (const double*)points_dev, indices_dev, counts_dev,
+                           n, max_nn, (double*)covariances_dev);
+    else
+        hipLaunchKernelGGL(CovariancesKernel<float>, grid, block, 0, s,
+                           (const float*)points_dev, indices_dev, counts_dev, n,
+                           max_nn, (float*)covariances_dev);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+int o3dmi_pointcloud_normals_from_covariances(const void* covariances_dev,
+                                              int64_t n, int dtype,
+                                              void* normals_dev,
+                                              int has_normals,
+                                              o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
+                  "covariances must be Float32 or Float64");
+    O3DMI_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return O3DMI_OK;
+    O3DMI_REQUIRE(covariances_dev && normals_dev, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(GridFor(n, kBlock)), block(kBlock);
+    if (dtype == O3DMI_F64)
+        hipLaunchKernelGGL(NormalsFromCovariancesKernel<double>, grid, block, 0,
+                           s, (const double*)covariances_dev, n,
+                           (double*)normals_dev, has_normals != 0);
+    else
+        hipLaunchKernelGGL(NormalsFromCovariancesKernel<float>, grid, block, 0,
+                           s, (const float*)covariances_dev, n,
+                           (float*)normals_dev, has_normals != 0);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+// PointCloud::EstimateNormals(max_knn, radius), PointCloud.cpp:856-976 (hybrid
+// search branch): index over the cloud itself, hybrid search, covariances,
+// normals; the "covariances" attribute is a temporary, as in the reference.
+int o3dmi_pointcloud_estimate_normals(const void* points_dev, int64_t n,
+                                      int dtype, int max_nn, double radius,
+                                      void* normals_dev, int has_normals,
+                                      o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
+                  "Only Float32 and Float64 point clouds are supported.");
+    O3DMI_REQUIRE(max_nn > 0 && radius > 0,
+                  "EstimateNormals: this backend implements the hybrid search "
+                  "variant (both max_nn and radius given).");
+    O3DMI_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return O3DMI_OK;
+    O3DMI_REQUIRE(points_dev && normals_dev, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t esz = dtype == O3DMI_F64 ? 8 : 4;
+    o3dmi_nns_t* nns = nullptr;
+    int st = o3dmi_nns_create(points_dev, n, dtype, radius, stream, &nns);
+    if (st) return st;
+    char* scratch = nullptr;
+    const size_t idx_bytes = (sizeof(int32_t) * (size_t)n * max_nn + 255) & ~(size_t)255;
+    const size_t cnt_bytes = (sizeof(int32_t) * (size_t)n + 255) & ~(size_t)255;
+    const size_t cov_bytes = esz * 9 * (size_t)n;
+    st = PoolAlloc((void**)&scratch, idx_bytes + cnt_bytes + cov_bytes);
+    if (!st) {
+        int32_t* idx = (int32_t*)scratch;
+        int32_t* cnt = (int32_t*)(scratch + idx_bytes);
+        void* cov = scratch + idx_bytes + cnt_bytes;
+        st = o3dmi_nns_hybrid_search(nns, points_dev, n, max_nn, idx, nullptr,
+                                     cnt, stream);
+        if (!st)
+            st = o3dmi_pointcloud_estimate_covariances(points_dev, idx, cnt, n,
+                                                       max_nn, dtype, cov,
+                                                       stream);
+        if (!st)
+            st = o3dmi_pointcloud_normals_from_covariances(
+                    cov, n, dtype, normals_dev, has_normals, stream);
+        (void)hipStreamSynchronize(s);
+        PoolFree(scratch);
+    }
+    o3dmi_nns_destroy(nns);
+    return st;
+}
+
+}  // extern "C"

@@ -145,3 +145,24 @@ def voxel_down_sample(positions, normals, voxel_size):
         _lib.ptr(out_p), _lib.ptr(out_n), C.byref(m), stream()),
         "voxel_down_sample")
     return out_p[:m.value], (None if out_n is None else out_n[:m.value])
+
+
+def estimate_normals(positions, max_nn=30, radius=None, normals=None):
+    """t::geometry::PointCloud::EstimateNormals(max_nn, radius)
+    (PointCloud.cpp:856-976), hybrid-search variant: returns normals {N,3};
+    `normals` (optional) are existing normals whose orientation is kept."""
+    positions = require_cuda(positions, "positions")
+    if radius is None or max_nn is None:
+        raise ValueError("this backend implements the hybrid search variant: "
+                         "give both max_nn and radius")
+    if normals is None:
+        out = torch.empty_like(positions)
+        has = 0
+    else:
+        out = require_cuda(normals, "normals").clone()
+        has = 1
+    _lib.check(_lib.lib().o3dmi_pointcloud_estimate_normals(
+        _lib.ptr(positions), positions.shape[0],
+        TORCH_TO_O3DMI[positions.dtype], int(max_nn), C.c_double(radius),
+        _lib.ptr(out), has, stream()), "estimate_normals")
+    return out
