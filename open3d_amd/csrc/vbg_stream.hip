@@ -17,6 +17,13 @@
 #include <cmath>
 
 #include "common.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+
 #include "stream_path.h"
 #include "touch_device.h"
 
@@ -141,6 +148,7 @@ struct IntegParams {
     int n_frames;
     int rows, cols, resolution;
     float sdf_trunc, depth_max;
+    float inv_sdf_trunc;  // RN(1 / sdf_trunc), used by the kFastDiv variant
     const FrameBlock* list;
     const int* count;
     int64_t list_capacity;
@@ -154,7 +162,67 @@ struct IntegParams {
     int* prof_frame_blocks;
 };
 
-template <typename weight_t, typename color_t, bool kColor>
+// ---- exact division without the division sequence ---------------------------
+// The per-voxel update has three correctly rounded float divisions; a full
+// IEEE sequence is ~11 VALU instructions and the role is VALU-bound. Two of
+// them have a special shape:
+//   sdf / sdf_trunc   -- the divisor is a per-launch constant: with
+//                        y = RN(1/b): q0 = RN(a y), r = fma(-b, q0, a) (exact),
+//                        q = fma(r, y, q0)            (Markstein's correction);
+//                        |a| < 1e-30 (zeros, the underflow range) keeps the
+//                        IEEE sequence
+//   1 / (w + 1)       -- w + 1 is an integer in [1, 65536] (uint16 weights):
+//                        hardware reciprocal + one Newton step.
+// Neither identity is taken on trust: before a kernel uses the short forms,
+// VerifyFastDivision() compares them on the device against the IEEE division
+// for EVERY float |a| <= b (the whole range the update can produce) and every
+// integer 1..65536; any mismatch keeps the IEEE sequence. The check costs a
+// few ms once per distinct truncation distance.
+__device__ __forceinline__ float DivByConst(float a, float b, float y) {
+    const float q0 = a * y;
+    const float r = __builtin_fmaf(-b, q0, a);
+    return __builtin_fmaf(r, y, q0);
+}
+__device__ __forceinline__ float RcpSmallInt(float b) {
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r0, 1.0f);
+    return __builtin_fmaf(e, r0, r0);
+}
+
+// Lower bound of the magnitudes DivByConst handles itself; smaller inputs
+// (zeros, denormals and their neighbourhood, where the exact-residual argument
+// needs gradual underflow to cooperate) take the IEEE sequence.
+constexpr float kDivTiny = 1.0e-30f;
+
+__device__ __forceinline__ float DivByConstGuarded(float a, float b, float y) {
+    return fabsf(a) < kDivTiny ? a / b : DivByConst(a, b, y);
+}
+
+__global__ void VerifyDivKernel(float b, float y, unsigned max_bits,
+                                int* __restrict__ mismatch) {
+    int bad = 0;
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x +
+                                threadIdx.x;
+         i <= max_bits; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const float a = __uint_as_float((unsigned)i);
+        const float want_p = a / b, want_n = (-a) / b;
+        const float got_p = DivByConstGuarded(a, b, y);
+        const float got_n = DivByConstGuarded(-a, b, y);
+        if (__float_as_uint(want_p) != __float_as_uint(got_p) ||
+            __float_as_uint(want_n) != __float_as_uint(got_n))
+            bad |= 1;
+    }
+    if (bad) atomicOr(mismatch, bad);
+}
+__global__ void VerifyRcpKernel(int* __restrict__ mismatch) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (i > 65536) return;
+    const float b = (float)i;
+    if (__float_as_uint(1.0f / b) != __float_as_uint(RcpSmallInt(b)))
+        atomicOr(mismatch, 2);
+}
+
+template <typename weight_t, typename color_t, bool kColor, bool kFastDiv>
 __device__ __forceinline__ void IntegrateRole(const HashView& hv,
                                               const IntegParams& ip, int wg,
                                               int n_wg) {
@@ -253,7 +321,10 @@ __device__ __forceinline__ void IntegrateRole(const HashView& hv,
                         ok[j] = false;
                     } else {
                         sd = sd < ip.sdf_trunc ? sd : ip.sdf_trunc;
-                        sdf[j] = sd / ip.sdf_trunc;
+                        sdf[j] = kFastDiv
+                                         ? DivByConstGuarded(sd, ip.sdf_trunc,
+                                                             ip.inv_sdf_trunc)
+                                         : sd / ip.sdf_trunc;
                         rgba[j] = r.rgba;
                     }
                 }
@@ -273,7 +344,9 @@ __device__ __forceinline__ void IntegrateRole(const HashView& hv,
                 // VoxelBlockGridImpl.h:269-302
                 float inv_wsum;
                 if constexpr (sizeof(weight_t) == 2)
-                    inv_wsum = 1.0f / (float)((int)w4.v[j] + 1);
+                    inv_wsum = kFastDiv
+                                       ? RcpSmallInt((float)((int)w4.v[j] + 1))
+                                       : 1.0f / (float)((int)w4.v[j] + 1);
                 else
                     inv_wsum = 1.0f / (w4.v[j] + 1);
                 const float weight = (float)w4.v[j];
@@ -312,7 +385,7 @@ struct StepParams {
     int front_wg;  // workgroups per front role
 };
 
-template <typename weight_t, typename color_t, bool kColor>
+template <typename weight_t, typename color_t, bool kColor, bool kFastDiv>
 __global__ void __launch_bounds__(256) FrameStepKernel(StepParams sp) {
     const int b = (int)blockIdx.x;
     const int n_front_wg = sp.n_fronts * sp.front_wg;
@@ -320,7 +393,7 @@ __global__ void __launch_bounds__(256) FrameStepKernel(StepParams sp) {
         const int f = b / sp.front_wg;
         FrontRole(sp.hv, sp.front[f], b - f * sp.front_wg);
     } else {
-        IntegrateRole<weight_t, color_t, kColor>(
+        IntegrateRole<weight_t, color_t, kColor, kFastDiv>(
                 sp.hv, sp.integ, b - n_front_wg, (int)gridDim.x - n_front_wg);
     }
 }
@@ -352,6 +425,54 @@ int64_t FrustumBlockBound(const double* K, int rows, int cols, float depth_max,
     return by_volume < by_rays ? by_volume : by_rays;
 }
 
+// Exhaustive on-device proof that the short division forms equal the IEEE
+// division for this truncation distance (see DivByConst); cached per value.
+static bool VerifyFastDivision(float b, float* y_out) {
+    static std::mutex mu;
+    static std::map<unsigned, bool> cache;
+    unsigned key;
+    std::memcpy(&key, &b, sizeof(key));
+    const float y = 1.0f / b;  // IEEE: correctly rounded reciprocal
+    *y_out = y;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    bool ok = false;
+    static const bool disabled = std::getenv("O3DMI_EXACT_DIV") != nullptr;
+    if (!disabled && b > 0.0f && std::isfinite(b) && std::isfinite(y)) {
+        int* flag = nullptr;
+        if (hipMalloc((void**)&flag, sizeof(int)) == hipSuccess) {
+            // A private stream: the caller's stream may be mid-pipeline.
+            hipStream_t vs = nullptr;
+            if (hipStreamCreateWithFlags(&vs, hipStreamNonBlocking) ==
+                hipSuccess) {
+                int host = -1;
+                (void)hipMemsetAsync(flag, 0, sizeof(int), vs);
+                hipLaunchKernelGGL(VerifyDivKernel, dim3(kCUs * 16), dim3(256),
+                                   0, vs, b, y, key, flag);
+                hipLaunchKernelGGL(VerifyRcpKernel, dim3(256), dim3(256), 0, vs,
+                                   flag);
+                if (hipGetLastError() == hipSuccess &&
+                    hipMemcpyAsync(&host, flag, sizeof(int),
+                                   hipMemcpyDeviceToHost, vs) == hipSuccess &&
+                    hipStreamSynchronize(vs) == hipSuccess)
+                    ok = host == 0;
+                if (std::getenv("O3DMI_VERBOSE"))
+                    std::fprintf(stderr, "[o3dmi] division check flags: %d\n",
+                                 host);
+                (void)hipStreamDestroy(vs);
+            }
+            (void)hipFree(flag);
+        }
+    }
+    if (std::getenv("O3DMI_VERBOSE"))
+        std::fprintf(stderr,
+                     "[o3dmi] exact short division for sdf_trunc = %.9g: %s\n",
+                     (double)b, ok ? "verified" : "not used");
+    cache[key] = ok;
+    return ok;
+}
+
 int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
                     const IntegrateStreamArgs* a, hipStream_t s) {
     O3DMI_REQUIRE((n_fronts > 0 && fronts) || a, "nothing to launch");
@@ -362,6 +483,7 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
     int n_int_wg = 0;
     int grid_dtype = O3DMI_U16;
     bool col = false;
+    bool fast_div = false;
     static const double eye4[16] = {1, 0, 0, 0, 0, 1, 0, 0,
                                     0, 0, 1, 0, 0, 0, 0, 1};
     for (int i = 0; i < n_fronts; ++i) {
@@ -416,6 +538,7 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         ip.resolution = a->resolution;
         ip.sdf_trunc = a->sdf_trunc;
         ip.depth_max = a->depth_max;
+        fast_div = VerifyFastDivision(a->sdf_trunc, &ip.inv_sdf_trunc);
         ip.list = a->list;
         ip.count = a->count;
         ip.list_capacity = a->list_capacity;
@@ -442,7 +565,14 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
     }
     dim3 grid((unsigned)(n_fronts * sp.front_wg + n_int_wg)), block(256);
 #define O3DMI_LAUNCH_STEP(WT, VT, COLOR)                                      \
-    hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR>), grid, block, 0, s, sp)
+    do {                                                                      \
+        if (fast_div)                                                         \
+            hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR, true>), grid,  \
+                               block, 0, s, sp);                              \
+        else                                                                  \
+            hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR, false>), grid, \
+                               block, 0, s, sp);                              \
+    } while (0)
     if (grid_dtype == O3DMI_U16) {
         if (col) O3DMI_LAUNCH_STEP(uint16_t, uint16_t, true);
         else O3DMI_LAUNCH_STEP(uint16_t, uint16_t, false);

@@ -319,9 +319,42 @@ def mode_model(a):
     print(json.dumps(out), flush=True)
 
 
+def mode_normals(a):
+    """PointCloud::EstimateNormals(max_nn=30, radius) on an `--points` cloud:
+    index build + hybrid search (k = 30) + covariances + eigen solve."""
+    from open3d_amd import registration as reg, synthetic
+    p = synthetic.make_icp_pair(a.points, a.points, seed=0)
+    pts = torch.from_numpy(p["target"]).cuda()
+    radius = 0.05
+    for _ in range(2):
+        n = reg.estimate_normals(pts, 30, radius)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.repeat):
+        n = reg.estimate_normals(pts, 30, radius)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / a.repeat * 1e3
+    cosang = (n.cpu().numpy() * p["target_normals"]).sum(1)
+    out = {"mode": "normals", "points": a.points, "max_nn": 30,
+           "radius": radius, "ms_per_call": ms,
+           "points_per_s": a.points / ms * 1e3,
+           "median_abs_cos_to_true_normal": float(np.median(np.abs(cosang)))}
+    if not a.no_cpu:
+        import _oracle as orc
+        orc.set_threads(min(64, os.cpu_count() or 1))
+        m = min(a.points, 20000)
+        sub = np.ascontiguousarray(p["target"][:m])
+        t0 = time.perf_counter()
+        orc.estimate_normals(sub, radius, 30)
+        dt = time.perf_counter() - t0
+        out["cpu_oracle_points_per_s"] = m / dt
+        out["cpu_oracle_sample_points"] = m
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", choices=["icp", "slam", "model", "both"],
+    ap.add_argument("--mode", choices=["icp", "slam", "model", "normals", "both"],
                     default="both")
     ap.add_argument("--hd", action="store_true", help="1280x720 (model mode)")
     ap.add_argument("--method", default="p2plane",
@@ -344,6 +377,8 @@ def main():
         mode_slam(a)
     if a.mode == "model":
         mode_model(a)
+    if a.mode == "normals":
+        mode_normals(a)
 
 
 if __name__ == "__main__":
