@@ -195,7 +195,9 @@ __device__ __forceinline__ float RcpSmallInt(float b) {
 constexpr float kDivTiny = 1.0e-30f;
 
 __device__ __forceinline__ float DivByConstGuarded(float a, float b, float y) {
-    return fabsf(a) < kDivTiny ? a / b : DivByConst(a, b, y);
+    // wave-uniform branch: the IEEE sequence only when some lane needs it
+    if (__builtin_amdgcn_ballot_w64(fabsf(a) < kDivTiny) != 0ull) return a / b;
+    return DivByConst(a, b, y);
 }
 
 __global__ void VerifyDivKernel(float b, float y, unsigned max_bits,
@@ -214,6 +216,39 @@ __global__ void VerifyDivKernel(float b, float y, unsigned max_bits,
     }
     if (bad) atomicOr(mismatch, bad);
 }
+// 1 / z of the projection (z arbitrary): hardware reciprocal + kRcpSteps
+// Newton steps inside [2^-60, 2^60]; IEEE outside. Verified for every float of
+// that range (all 2^23 x 120 of them) before use.
+template <int kSteps>
+__device__ __forceinline__ float RcpGuarded(float z) {
+    // One unsigned compare on the bit pattern covers sign, zero, denormals,
+    // inf / NaN and both ends of the verified range; the branch is made
+    // wave-uniform so that the common case is a straight scalar jump.
+    const bool out = (__float_as_uint(z) - 0x21800000u) >= (0x5E000000u - 0x21800000u);
+    if (__builtin_amdgcn_ballot_w64(out) != 0ull) return 1.0f / z;
+    float r = __builtin_amdgcn_rcpf(z);
+#pragma unroll
+    for (int k = 0; k < kSteps; ++k) {
+        const float e = __builtin_fmaf(-z, r, 1.0f);
+        r = __builtin_fmaf(e, r, r);
+    }
+    return r;
+}
+template <int kSteps>
+__global__ void VerifyRcpZKernel(int* __restrict__ mismatch, int bit) {
+    // every positive float between 2^-61 and 2^61 (a margin around the range)
+    const unsigned lo = 0x21000000u, hi = 0x5E800000u;
+    bool bad = false;
+    for (unsigned long long i = lo + blockIdx.x * (unsigned long long)blockDim.x +
+                                threadIdx.x;
+         i <= hi; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const float z = __uint_as_float((unsigned)i);
+        bad |= __float_as_uint(1.0f / z) !=
+               __float_as_uint(RcpGuarded<kSteps>(z));
+    }
+    if (bad) atomicOr(mismatch, bit);
+}
+
 __global__ void VerifyRcpKernel(int* __restrict__ mismatch) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x + 1;
     if (i > 65536) return;
@@ -222,7 +257,9 @@ __global__ void VerifyRcpKernel(int* __restrict__ mismatch) {
         atomicOr(mismatch, 2);
 }
 
-template <typename weight_t, typename color_t, bool kColor, bool kFastDiv>
+// kDiv: 0 = IEEE divisions; 1 = short sdf / trunc and 1 / (w + 1); 2, 3 = also
+// the short 1 / z with one / two Newton steps (whichever verified).
+template <typename weight_t, typename color_t, bool kColor, int kDiv>
 __device__ __forceinline__ void IntegrateRole(const HashView& hv,
                                               const IntegParams& ip, int wg,
                                               int n_wg) {
@@ -306,7 +343,14 @@ __device__ __forceinline__ void IntegrateRole(const HashView& hv,
             for (int j = 0; j < 4; ++j) {
                 float xc, yc, zc, u, v;
                 cam.RigidTransform((float)(x0 + j), fy, fz, xc, yc, zc);
-                cam.Project(xc, yc, zc, u, v);
+                if constexpr (kDiv >= 2) {
+                    // Camera::Project with the verified short reciprocal
+                    const float inv_z = RcpGuarded<kDiv - 1>(zc);
+                    u = cam.fx * xc * inv_z + cam.cx;
+                    v = cam.fy * yc * inv_z + cam.cy;
+                } else {
+                    cam.Project(xc, yc, zc, u, v);
+                }
                 ok[j] = InBoundary2D(u, v, ip.rows, ip.cols);
                 sdf[j] = 0.f;
                 rgba[j] = 0u;
@@ -321,7 +365,7 @@ __device__ __forceinline__ void IntegrateRole(const HashView& hv,
                         ok[j] = false;
                     } else {
                         sd = sd < ip.sdf_trunc ? sd : ip.sdf_trunc;
-                        sdf[j] = kFastDiv
+                        sdf[j] = kDiv >= 1
                                          ? DivByConstGuarded(sd, ip.sdf_trunc,
                                                              ip.inv_sdf_trunc)
                                          : sd / ip.sdf_trunc;
@@ -344,7 +388,7 @@ __device__ __forceinline__ void IntegrateRole(const HashView& hv,
                 // VoxelBlockGridImpl.h:269-302
                 float inv_wsum;
                 if constexpr (sizeof(weight_t) == 2)
-                    inv_wsum = kFastDiv
+                    inv_wsum = kDiv >= 1
                                        ? RcpSmallInt((float)((int)w4.v[j] + 1))
                                        : 1.0f / (float)((int)w4.v[j] + 1);
                 else
@@ -385,7 +429,7 @@ struct StepParams {
     int front_wg;  // workgroups per front role
 };
 
-template <typename weight_t, typename color_t, bool kColor, bool kFastDiv>
+template <typename weight_t, typename color_t, bool kColor, int kDiv>
 __global__ void __launch_bounds__(256) FrameStepKernel(StepParams sp) {
     const int b = (int)blockIdx.x;
     const int n_front_wg = sp.n_fronts * sp.front_wg;
@@ -393,7 +437,7 @@ __global__ void __launch_bounds__(256) FrameStepKernel(StepParams sp) {
         const int f = b / sp.front_wg;
         FrontRole(sp.hv, sp.front[f], b - f * sp.front_wg);
     } else {
-        IntegrateRole<weight_t, color_t, kColor, kFastDiv>(
+        IntegrateRole<weight_t, color_t, kColor, kDiv>(
                 sp.hv, sp.integ, b - n_front_wg, (int)gridDim.x - n_front_wg);
     }
 }
@@ -427,9 +471,9 @@ int64_t FrustumBlockBound(const double* K, int rows, int cols, float depth_max,
 
 // Exhaustive on-device proof that the short division forms equal the IEEE
 // division for this truncation distance (see DivByConst); cached per value.
-static bool VerifyFastDivision(float b, float* y_out) {
+static int VerifyFastDivision(float b, float* y_out) {
     static std::mutex mu;
-    static std::map<unsigned, bool> cache;
+    static std::map<unsigned, int> cache;
     unsigned key;
     std::memcpy(&key, &b, sizeof(key));
     const float y = 1.0f / b;  // IEEE: correctly rounded reciprocal
@@ -437,7 +481,7 @@ static bool VerifyFastDivision(float b, float* y_out) {
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
-    bool ok = false;
+    int ok = 0;
     static const bool disabled = std::getenv("O3DMI_EXACT_DIV") != nullptr;
     if (!disabled && b > 0.0f && std::isfinite(b) && std::isfinite(y)) {
         int* flag = nullptr;
@@ -452,11 +496,16 @@ static bool VerifyFastDivision(float b, float* y_out) {
                                    0, vs, b, y, key, flag);
                 hipLaunchKernelGGL(VerifyRcpKernel, dim3(256), dim3(256), 0, vs,
                                    flag);
+                hipLaunchKernelGGL(VerifyRcpZKernel<1>, dim3(kCUs * 16),
+                                   dim3(256), 0, vs, flag, 4);
+                hipLaunchKernelGGL(VerifyRcpZKernel<2>, dim3(kCUs * 16),
+                                   dim3(256), 0, vs, flag, 8);
                 if (hipGetLastError() == hipSuccess &&
                     hipMemcpyAsync(&host, flag, sizeof(int),
                                    hipMemcpyDeviceToHost, vs) == hipSuccess &&
                     hipStreamSynchronize(vs) == hipSuccess)
-                    ok = host == 0;
+                    // bits 1|2: sdf / w forms; 4: 1/z one step; 8: two steps
+                    ok = (host & 3) ? 0 : (!(host & 4) ? 2 : (!(host & 8) ? 3 : 1));
                 if (std::getenv("O3DMI_VERBOSE"))
                     std::fprintf(stderr, "[o3dmi] division check flags: %d\n",
                                  host);
@@ -468,7 +517,11 @@ static bool VerifyFastDivision(float b, float* y_out) {
     if (std::getenv("O3DMI_VERBOSE"))
         std::fprintf(stderr,
                      "[o3dmi] exact short division for sdf_trunc = %.9g: %s\n",
-                     (double)b, ok ? "verified" : "not used");
+                     (double)b,
+                     ok == 0 ? "not used"
+                             : (ok == 1 ? "sdf, 1/(w+1)"
+                                        : (ok == 2 ? "sdf, 1/(w+1), 1/z (1 step)"
+                                                   : "sdf, 1/(w+1), 1/z (2 steps)")));
     cache[key] = ok;
     return ok;
 }
@@ -483,7 +536,7 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
     int n_int_wg = 0;
     int grid_dtype = O3DMI_U16;
     bool col = false;
-    bool fast_div = false;
+    int fast_div = 0;
     static const double eye4[16] = {1, 0, 0, 0, 0, 1, 0, 0,
                                     0, 0, 1, 0, 0, 0, 0, 1};
     for (int i = 0; i < n_fronts; ++i) {
@@ -564,14 +617,17 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         col = a->with_color && a->color != nullptr;
     }
     dim3 grid((unsigned)(n_fronts * sp.front_wg + n_int_wg)), block(256);
+#define O3DMI_LAUNCH_STEP_D(WT, VT, COLOR, D)                                 \
+    hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR, D>), grid, block, 0, s, \
+                       sp)
 #define O3DMI_LAUNCH_STEP(WT, VT, COLOR)                                      \
     do {                                                                      \
-        if (fast_div)                                                         \
-            hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR, true>), grid,  \
-                               block, 0, s, sp);                              \
-        else                                                                  \
-            hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR, false>), grid, \
-                               block, 0, s, sp);                              \
+        switch (fast_div) {                                                   \
+            case 3: O3DMI_LAUNCH_STEP_D(WT, VT, COLOR, 3); break;             \
+            case 2: O3DMI_LAUNCH_STEP_D(WT, VT, COLOR, 2); break;             \
+            case 1: O3DMI_LAUNCH_STEP_D(WT, VT, COLOR, 1); break;             \
+            default: O3DMI_LAUNCH_STEP_D(WT, VT, COLOR, 0); break;            \
+        }                                                                     \
     } while (0)
     if (grid_dtype == O3DMI_U16) {
         if (col) O3DMI_LAUNCH_STEP(uint16_t, uint16_t, true);
@@ -581,6 +637,7 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         else O3DMI_LAUNCH_STEP(float, float, false);
     }
 #undef O3DMI_LAUNCH_STEP
+#undef O3DMI_LAUNCH_STEP_D
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
 }
