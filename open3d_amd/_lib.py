@@ -249,6 +249,10 @@ def lib():
                 "open3d_amd: %s not found -- the HIP extension is mandatory "
                 "(run `python -m open3d_amd.build`); there is no CPU "
                 "fallback." % SO_PATH)
+        # torch first: it ships its own HIP runtime, and the process must end
+        # up with ONE libamdhip64 (the first one loaded wins the soname). With
+        # the order reversed the second runtime sees no device.
+        import torch  # noqa: F401
         L = C.CDLL(SO_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)  # AttributeError if a symbol is missing
