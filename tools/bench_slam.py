@@ -319,6 +319,46 @@ def mode_model(a):
     print(json.dumps(out), flush=True)
 
 
+def mode_extract(a):
+    """VoxelBlockGrid::ExtractPointCloud on the grid the C2 stream leaves
+    behind (`--frames` VGA frames, 8 mm / 16^3): count pass + write pass."""
+    from open3d_amd import geometry, synthetic
+    W, H = 640, 480
+    K = synthetic.intrinsics(W, H)
+    g = geometry.VoxelBlockGrid(["tsdf", "weight", "color"],
+                                [torch.float32, torch.uint16, torch.uint16],
+                                [1, 1, 3], 0.008, 16, a.block_count)
+    ds, cs, Ts = [], [], []
+    for k in range(a.frames):
+        d, c, _, T = synthetic.render_frames(k * a.frame_step, 1, W, H,
+                                             device="cuda")
+        ds.append(d[0].contiguous())
+        cs.append(c[0].contiguous())
+        Ts.append(T[0])
+    g.integrate_frames(ds, cs, K, K, Ts, 1000.0, 3.0, 8.0)
+    torch.cuda.synchronize()
+    for _ in range(2):
+        pcd = g.extract_point_cloud(3.0)
+    n_pts = pcd["positions"].shape[0]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.repeat):
+        pcd = g.extract_point_cloud(3.0)                  # 2-pass estimation
+    torch.cuda.synchronize()
+    ms2 = (time.perf_counter() - t0) / a.repeat * 1e3
+    t0 = time.perf_counter()
+    for _ in range(a.repeat):
+        pcd = g.extract_point_cloud(3.0, n_pts)           # size given
+    torch.cuda.synchronize()
+    ms1 = (time.perf_counter() - t0) / a.repeat * 1e3
+    nb = g.hashmap().size()
+    out = {"mode": "extract", "active_blocks": nb, "points": n_pts,
+           "ms_two_pass": ms2, "ms_with_estimate": ms1,
+           "algorithmic_GBps_with_estimate":
+               (nb * 4096 * 6 * 2 + n_pts * 36) / (ms1 * 1e-3) / 1e9}
+    print(json.dumps(out), flush=True)
+
+
 def mode_normals(a):
     """PointCloud::EstimateNormals(max_nn=30, radius) on an `--points` cloud:
     index build + hybrid search (k = 30) + covariances + eigen solve."""
@@ -354,7 +394,7 @@ def mode_normals(a):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", choices=["icp", "slam", "model", "normals", "both"],
+    ap.add_argument("--mode", choices=["icp", "slam", "model", "normals", "extract", "both"],
                     default="both")
     ap.add_argument("--hd", action="store_true", help="1280x720 (model mode)")
     ap.add_argument("--method", default="p2plane",
@@ -379,6 +419,8 @@ def main():
         mode_model(a)
     if a.mode == "normals":
         mode_normals(a)
+    if a.mode == "extract":
+        mode_extract(a)
 
 
 if __name__ == "__main__":
