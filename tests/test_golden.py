@@ -187,3 +187,130 @@ def test_hip_reproduces_icp_golden(name):
     _lib.check(L.o3dmi_transform_points(_lib.f64p(T), _lib.ptr(pts), n, dt,
                                         stream()), "transform")
     assert np.array_equal(pts.cpu().numpy(), g["transformed_" + name])
+
+
+# ------------------------------------------------- rows f1 / f2 / f4 goldens --
+ODO_MAPS = ("source_vertex", "target_vertex", "target_normal", "source_depth",
+            "target_depth", "source_intensity", "target_intensity",
+            "target_depth_dx", "target_depth_dy", "target_intensity_dx",
+            "target_intensity_dy")
+
+
+def _odo_level(g):
+    L = {k: g[k] for k in ODO_MAPS if k in g.files}
+    L["source_depth"], L["target_depth"] = g["source_clip"], g["target_clip"]
+    return L
+
+
+def _nan_equal_bits(a, b):
+    na, nb = np.isnan(a), np.isnan(b)
+    return a.shape == b.shape and np.array_equal(na, nb) and \
+        np.array_equal(a[~na].view(np.uint32), b[~nb].view(np.uint32))
+
+
+def test_oracle_reproduces_odometry_golden():
+    g = _load("odometry_qqvga.npz")
+    nan = float("nan")
+    s = orc.clip_transform(g["source_depth_u16"], 1000.0, 0.0, 3.0, nan)
+    assert _nan_equal_bits(s, g["source_clip"])
+    assert _nan_equal_bits(orc.pyrdown_depth(s, 0.14, nan), g["source_pyrdown"])
+    assert _nan_equal_bits(orc.create_vertex_map(s, g["K"], nan),
+                           g["source_vertex"])
+    L = _odo_level(g)
+    for m, name in ((0, "p2plane"), (1, "intensity"), (2, "hybrid")):
+        sums = orc.odometry_sums(m, g["K"], g["T"], **L,
+                                 accumulate_double=False)
+        assert np.array_equal(sums.astype(np.float32), g["sums29_" + name])
+        st, pose, res, cnt = orc.decode_and_solve6x6(sums)
+        assert st == 0 and cnt == int(g["count_" + name][0])
+        assert np.array_equal(pose, g["delta_" + name])
+    info = orc.odometry_information(g["source_vertex"], g["target_vertex"],
+                                    g["K"], g["T"], 0.07 * 0.07)
+    assert np.array_equal(info, g["information"])
+
+
+def test_oracle_reproduces_extract_and_normals_golden():
+    v, g = _load("vbg_qqvga_res8.npz"), _load("extract_normals.npz")
+    keys = v["block_keys"]
+    n = keys.shape[0]
+    h = orc.HashMap(n)
+    h.activate(keys)
+    active = np.arange(n, dtype=np.int32)
+    nbi, nbm = orc.buffer_radius_neighbors(h, active)
+    voxel, res = float(v["params"][0]), int(v["params"][1])
+    got = orc.extract_point_cloud(active, nbi, nbm, keys, v["tsdf_u16"],
+                                  v["weight_u16"], v["color_u16"], res, voxel,
+                                  float(g["weight_threshold"][0]))
+    assert got[0].tobytes() == g["points"].tobytes()
+    assert got[1].tobytes() == g["normals"].tobytes()
+    assert got[2].tobytes() == g["colors"].tobytes()
+    r, k = float(g["radius_max_nn"][0]), int(g["radius_max_nn"][1])
+    idx, _, cnt = orc.hybrid_search(g["cloud"], g["cloud"], r, k)
+    assert np.array_equal(idx, g["nn_idx"]) and np.array_equal(cnt, g["nn_cnt"])
+    cov = orc.estimate_covariances(g["cloud"], idx, cnt)
+    assert cov.tobytes() == g["cov"].tobytes()
+    assert orc.normals_from_covariances(cov).tobytes() == \
+        g["cloud_normals"].tobytes()
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_odometry_golden():
+    _gpu()
+    import torch
+    from open3d_amd import odometry as odo
+    g = _load("odometry_qqvga.npz")
+    nan = float("nan")
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    s = odo.clip_transform(dev(g["source_depth_u16"]), 1000.0, 0.0, 3.0, nan)
+    assert _nan_equal_bits(s.cpu().numpy(), g["source_clip"])
+    assert _nan_equal_bits(odo.pyrdown_depth(s, 0.14, nan).cpu().numpy(),
+                           g["source_pyrdown"])
+    assert _nan_equal_bits(odo.create_vertex_map(s, g["K"], nan).cpu().numpy(),
+                           g["source_vertex"])
+    L = {k: dev(v) for k, v in _odo_level(g).items()}
+    for m, name in ((0, "p2plane"), (1, "intensity"), (2, "hybrid")):
+        sums = odo.compute_odometry_sums(m, g["K"], g["T"], **L)
+        want = g["sums29_" + name].astype(np.float64)
+        # the reference's sums are float32 accumulations; ours float64
+        assert sums[28] == want[28]
+        assert np.allclose(sums, want, rtol=2e-3, atol=1e-3)
+        A = np.ascontiguousarray(sums)
+        from open3d_amd import _lib
+        import ctypes as C
+        pose = np.zeros(6)
+        res, cnt = C.c_float(0), C.c_int(0)
+        _lib.check(_lib.lib().o3dmi_decode_and_solve6x6(
+            _lib.f64p(A), _lib.f64p(pose), C.byref(res), C.byref(cnt)), "solve")
+        assert cnt.value == int(g["count_" + name][0])
+        assert np.abs(pose - g["delta_" + name]).max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_extract_and_normals_golden(tmp_path):
+    _gpu()
+    import torch
+    from open3d_amd import geometry, registration
+    v, g = _load("vbg_qqvga_res8.npz"), _load("extract_normals.npz")
+    voxel, res = float(v["params"][0]), int(v["params"][1])
+    # put the fixture's grid on the device through the NPZ loader: buffer
+    # index i <-> key i, exactly the fixture's ordering
+    path = str(tmp_path / "grid.npz")
+    np.savez(path, voxel_size=np.array([voxel], np.float32),
+             block_resolution=np.array([res], np.int64),
+             **{"CPU:0": np.zeros((), np.uint8)},
+             attr_name_tsdf=np.array([0], np.int32),
+             attr_name_weight=np.array([1], np.int32),
+             attr_name_color=np.array([2], np.int32), key=v["block_keys"],
+             value_000=v["tsdf_u16"][..., None], value_001=v["weight_u16"][..., None],
+             value_002=v["color_u16"])
+    grid = geometry.VoxelBlockGrid.load(path)
+    pcd = grid.extract_point_cloud(float(g["weight_threshold"][0]))
+    key = lambda p, n, c: _sort_rows(np.concatenate([p, n, c], axis=1))
+    assert np.array_equal(
+        key(pcd["positions"].cpu().numpy(), pcd["normals"].cpu().numpy(),
+            pcd["colors"].cpu().numpy()),
+        key(g["points"], g["normals"], g["colors"]))
+    r, k = float(g["radius_max_nn"][0]), int(g["radius_max_nn"][1])
+    nrm = registration.estimate_normals(torch.from_numpy(g["cloud"]).cuda(), k,
+                                        r).cpu().numpy()
+    assert np.abs(nrm - g["cloud_normals"]).max() <= 1e-4
