@@ -59,6 +59,14 @@ def parse():
     ap.add_argument("--event-stride", type=int, default=8,
                     help="bracket every n-th integrate launch with HIP events "
                          "(0 = none; the roofline is then not measured)")
+    ap.add_argument("--sharding", choices=["frames", "blocks"],
+                    default="frames",
+                    help="multi-GPU scheme: 'frames' = every rank integrates "
+                         "its own frames into a private grid (weak scaling, "
+                         "the default); 'blocks' = every rank sees the SAME "
+                         "stream and integrates only the blocks it owns "
+                         "(strong scaling, union of the grids bit-identical "
+                         "to one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -145,8 +153,13 @@ def main():
 
     n_steps = a.steps + a.warmup
     n_local = n_steps * a.batch
-    # Frame-sharded stream: rank r owns global frames r, r+world, ...
-    frame_ids = [rank + world * i for i in range(n_local)]
+    by_blocks = a.sharding == "blocks" and world > 1
+    if by_blocks:
+        # One stream seen by every rank; blocks are split by ownership.
+        frame_ids = list(range(n_local))
+    else:
+        # Frame-sharded stream: rank r owns global frames r, r+world, ...
+        frame_ids = [rank + world * i for i in range(n_local)]
     K = synthetic.intrinsics(W, H)
     depths, colors, Ts = [], [], []
     for i0 in range(0, n_local, 25):
@@ -161,6 +174,8 @@ def main():
     g = geometry.VoxelBlockGrid(["tsdf", "weight", "color"],
                                 [torch.float32, torch.uint16, torch.uint16],
                                 [1, 1, 3], VOXEL, RES, a.block_count)
+    if by_blocks:
+        g.set_block_ownership(rank, world)
 
     def run_step(s):
         lo, hi = s * a.batch, (s + 1) * a.batch
@@ -206,7 +221,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    total_frames = a.steps * a.batch * world
+    total_frames = a.steps * a.batch * (1 if by_blocks else world)
     fps = total_frames / elapsed
 
     # Roofline of the dominant kernel over the HIP-event-bracketed launches:
@@ -242,7 +257,8 @@ def main():
                   "VoxelBlockGrid: touch + activate + integrate)",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True,
+        "scaling": "strong" if by_blocks else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "configs[1]: %d synthetic 640x480 RGB-D frames "
                                "per GPU -> 8 mm VoxelBlockGrid(16^3), grid "
@@ -256,8 +272,11 @@ def main():
                    "active_blocks": int(n_blocks),
                    "avg_blocks_per_frame": prof["block_frames"] /
                                            max(1, prof["frames"]),
-                   "sharding": "frames r, r+N, ... per rank; block-ID "
-                               "all-gather at the end" if world > 1 else "none",
+                   "sharding": ("none" if world == 1 else
+                                "one stream, blocks split by ownership; "
+                                "block-ID all-gather at the end" if by_blocks
+                                else "frames r, r+N, ... per rank; block-ID "
+                                     "all-gather at the end"),
                    "union_blocks": n_union},
         "roofline": {"bound": "hbm", "kernel": "FrameStepKernel",
                      "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -140,6 +140,17 @@ int64_t o3dmi_hash_bucket_count(const o3dmi_hash_t* h);
  * (synchronises). */
 int o3dmi_hash_active_indices(o3dmi_hash_t* h, int32_t* out_dev,
                               o3dmi_stream_t stream, int64_t* count);
+/* Block-ownership sharding for multi-GPU integration (no counterpart in the
+ * reference, which is single-device; SURVEY section 8e scheme A): with world >
+ * 1 the block-touch kernels that insert into / list from this map
+ * (o3dmi_vbg_depth_touch, o3dmi_vbg_touch_activate, the frame-stream path)
+ * only see the blocks whose owner -- o3dmi_block_owner(key, world), a fixed
+ * 64-bit mix of the packed key -- equals `rank`. Every rank runs the same
+ * frames; the union of the per-rank grids is bit-identical to the single-GPU
+ * grid and the per-voxel work is split `world` ways. */
+int o3dmi_hash_set_ownership(o3dmi_hash_t* h, int rank, int world);
+/* Owner rank of one block key (host int32[3]); -1 for bad arguments. */
+int o3dmi_block_owner(const int32_t* key3, int world);
 /* HashMap::Reserve (core/hashmap/HashMap.cpp:47-77): export active
  * key/values, reallocate at `capacity`, re-insert. buf_indices change. */
 int o3dmi_hash_reserve(o3dmi_hash_t* h, int64_t capacity,

@@ -111,6 +111,13 @@ o3dmi_hash_t* o3dmi_vbg_hashmap(o3dmi_vbg_t* g);
 void* o3dmi_vbg_attribute(o3dmi_vbg_t* g, const char* name, int* dtype,
                           int* channels);
 
+/* Block-ownership sharding of a grid across `world` GPUs (one process per
+ * GPU): this grid only activates and integrates the blocks it owns
+ * (o3dmi_hash_set_ownership); applies to GetUniqueBlockCoordinates and to the
+ * frame(s) paths. Explicit block lists given to o3dmi_vbg_integrate_blocks
+ * are taken as they are. */
+int o3dmi_vbg_set_block_ownership(o3dmi_vbg_t* g, int rank, int world);
+
 /* GetUniqueBlockCoordinates(depth, intrinsic, extrinsic, depth_scale,
  * depth_max, trunc_voxel_multiplier) (VoxelBlockGrid.cpp:212-245).
  * out_coords_dev must hold (rows/4)*(cols/4)*4 rows; *m_out = number of

@@ -44,6 +44,8 @@ PROTOTYPES = {
     "o3dmi_hash_bucket_count": (_i64, [_vp]),
     "o3dmi_hash_active_indices": (_i32, [_vp, _vp, _vp, C.POINTER(_i64)]),
     "o3dmi_hash_reserve": (_i32, [_vp, _i64, _vp]),
+    "o3dmi_hash_set_ownership": (_i32, [_vp, _i32, _i32]),
+    "o3dmi_block_owner": (_i32, [C.POINTER(_i32), _i32]),
     "o3dmi_hash_key_buffer": (_vp, [_vp]),
     "o3dmi_hash_value_buffer": (_vp, [_vp, _i32]),
     "o3dmi_vbg_depth_touch": (_i32, [_vp, _vp, _i32, _i32, _i32, _dp, _dp,
@@ -158,6 +160,7 @@ PROTOTYPES.update({
                                 C.POINTER(_vp)]),
     "o3dmi_vbg_destroy": (_i32, [_vp]),
     "o3dmi_vbg_hashmap": (_vp, [_vp]),
+    "o3dmi_vbg_set_block_ownership": (_i32, [_vp, _i32, _i32]),
     "o3dmi_vbg_attribute": (_vp, [_vp, C.c_char_p, C.POINTER(_i32),
                                   C.POINTER(_i32)]),
     "o3dmi_vbg_get_unique_block_coordinates": (

@@ -496,6 +496,20 @@ int o3dmi_hash_reserve(o3dmi_hash_t* h, int64_t capacity,
     return O3DMI_OK;
 }
 
+int o3dmi_hash_set_ownership(o3dmi_hash_t* h, int rank, int world) {
+    O3DMI_REQUIRE(h != nullptr, "hash is null");
+    O3DMI_REQUIRE(world >= 1 && rank >= 0 && rank < world,
+                  "ownership: need 0 <= rank < world");
+    h->view.owner_rank = rank;
+    h->view.owner_world = world;
+    return O3DMI_OK;
+}
+
+int o3dmi_block_owner(const int32_t* key3, int world) {
+    if (!key3 || world < 1 || !KeyInRange(key3[0], key3[1], key3[2])) return -1;
+    return OwnerOf(PackKey(key3[0], key3[1], key3[2]), world);
+}
+
 int32_t* o3dmi_hash_key_buffer(o3dmi_hash_t* h) {
     return h ? h->view.key_buffer : nullptr;
 }

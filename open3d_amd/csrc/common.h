@@ -164,6 +164,18 @@ __host__ __device__ __forceinline__ unsigned HashKey(unsigned long long k) {
     return (unsigned)k;
 }
 
+// Owner rank of a packed block key: a 64-bit finaliser independent of HashKey
+// (murmur3 constants), upper half modulo the world size.
+__host__ __device__ __forceinline__ int OwnerOf(unsigned long long k,
+                                                int world) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return (int)((unsigned)(k >> 32) % (unsigned)world);
+}
+
 // Device view of the spatial hash, passed by value to kernels.
 struct HashView {
     unsigned long long* slot_keys;  // [n_slots] packed key / empty / tombstone
@@ -174,6 +186,17 @@ struct HashView {
     int* key_buffer;                // [capacity,3]
     unsigned mask;                  // n_slots - 1
     int capacity;
+    // Block-ownership sharding (multi-GPU, SURVEY 8e scheme A): with
+    // owner_world > 1 the touch kernels only activate / list the blocks whose
+    // OwnerOf(key) equals owner_rank; every rank then holds a disjoint part of
+    // the same grid, each part bit-identical to the single-GPU result.
+    int owner_rank;
+    int owner_world;
+
+    // True when this rank integrates block key k.
+    __device__ __forceinline__ bool Owns(unsigned long long k) const {
+        return owner_world <= 1 || OwnerOf(k, owner_world) == owner_rank;
+    }
 
     // Lookup; -1 when absent.
     __device__ __forceinline__ int Find(int x, int y, int z) const {

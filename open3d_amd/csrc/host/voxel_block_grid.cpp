@@ -34,6 +34,7 @@ struct o3dmi_vbg {
     o3dmi_hash_t* block_hashmap = nullptr;
     o3dmi_hash_t* frustum_hashmap = nullptr;  // lazily created (cpp:224-235)
     int64_t frustum_capacity = 0;
+    int owner_rank = 0, owner_world = 1;      // block-ownership sharding
     // Host-side upper bound of block_hashmap's Size().
     int64_t size_bound = 0;
     // Device scratch for the frame-stream path.
@@ -291,6 +292,18 @@ int o3dmi_vbg_destroy(o3dmi_vbg_t* g) {
     return O3DMI_OK;
 }
 
+int o3dmi_vbg_set_block_ownership(o3dmi_vbg_t* g, int rank, int world) {
+    O3DMI_REQUIRE(g != nullptr, "grid is null");
+    int st = o3dmi_hash_set_ownership(g->block_hashmap, rank, world);
+    if (st) return st;
+    if (g->frustum_hashmap &&
+        (st = o3dmi_hash_set_ownership(g->frustum_hashmap, rank, world)))
+        return st;
+    g->owner_rank = rank;
+    g->owner_world = world;
+    return O3DMI_OK;
+}
+
 o3dmi_hash_t* o3dmi_vbg_hashmap(o3dmi_vbg_t* g) {
     return g ? g->block_hashmap : nullptr;
 }
@@ -323,6 +336,9 @@ int o3dmi_vbg_get_unique_block_coordinates(
                                    &g->frustum_hashmap);
         if (st) return st;
         g->frustum_capacity = capacity;
+        if ((st = o3dmi_hash_set_ownership(g->frustum_hashmap, g->owner_rank,
+                                           g->owner_world)))
+            return st;
     }
     int st = o3dmi_vbg_depth_touch(
             g->frustum_hashmap, depth_dev, depth_dtype, rows, cols, intrinsic,

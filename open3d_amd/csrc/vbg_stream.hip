@@ -86,6 +86,7 @@ __device__ __forceinline__ void FrontRole(const HashView& hv,
                     ok = false;
                 }
                 unsigned long long k = ok ? PackKey(xb[s], yb[s], zb[s]) : 0ull;
+                if (ok && !hv.Owns(k)) ok = false;  // another rank's block
                 if (WaveLeaderForKey(k, ok)) {
                     unsigned slot;
                     InsertKey<true>(hv, xb[s], yb[s], zb[s], slot);

@@ -43,6 +43,7 @@ __global__ void DepthTouchKernel(HashView hv, TouchParams p,
                 ok = false;
             }
             unsigned long long k = ok ? PackKey(xb[s], yb[s], zb[s]) : 0ull;
+            if (ok && !hv.Owns(k)) ok = false;  // another rank's block
             if (WaveLeaderForKey(k, ok)) {
                 unsigned slot;
                 if (InsertKey<false>(hv, xb[s], yb[s], zb[s], slot)) {
@@ -86,6 +87,7 @@ __global__ void TouchActivateKernel(HashView hv, TouchParams p,
                 ok = false;
             }
             unsigned long long k = ok ? PackKey(xb[s], yb[s], zb[s]) : 0ull;
+            if (ok && !hv.Owns(k)) ok = false;  // another rank's block
             if (WaveLeaderForKey(k, ok)) {
                 unsigned slot;
                 InsertKey<true>(hv, xb[s], yb[s], zb[s], slot);

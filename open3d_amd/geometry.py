@@ -129,6 +129,12 @@ class VoxelBlockGrid:
         except Exception:
             pass
 
+    def set_block_ownership(self, rank, world):
+        """Multi-GPU block-ownership sharding: this grid only activates and
+        integrates the blocks whose owner (sharding.block_owner) is `rank`."""
+        _lib.check(_lib.lib().o3dmi_vbg_set_block_ownership(
+            self._g, int(rank), int(world)), "set_block_ownership")
+
     def hashmap(self):
         return HashMapView(C.c_void_p(_lib.lib().o3dmi_vbg_hashmap(self._g)),
                            self)

@@ -8,9 +8,15 @@ this layer is new. Exchanges are tiny and latency-bound:
     replicated; per iteration one all-reduce of 32 float64 (29 Gauss-Newton
     sums, sum d2, match count, shard size) -- every rank then solves the same
     6x6 system, so no broadcast is needed.
-  * Integration: frames are sharded across ranks (rank r owns frames r, r+N,
-    ...) into private grids; the activated block IDs are unioned with one
-    padded all-gather.
+  * Integration, frame-sharded (independent streams, weak scaling): rank r
+    owns frames r, r+N, ... into a private grid; the activated block IDs are
+    unioned with one padded all-gather.
+  * Integration, block-ownership (ONE stream, strong scaling, bit-parity with
+    one GPU): every rank sees every frame and runs the cheap block touch, but
+    only activates / integrates the blocks it owns
+    (VoxelBlockGrid.set_block_ownership(rank, world)); no data-path
+    collective at all, the per-voxel work is split N ways and the union of the
+    per-rank grids equals the single-GPU grid bit for bit.
 """
 import numpy as np
 import torch
@@ -31,6 +37,24 @@ def make_allreduce_sum(dist, device):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         a[:] = t.cpu().numpy()
     return _f
+
+
+def block_owner(keys, world):
+    """Owner rank of each {M,3} int32 block key under block-ownership sharding
+    (host mirror of the device-side OwnerOf: murmur3 finaliser of the packed
+    21-bit-per-coordinate key, upper half modulo `world`)."""
+    k = np.asarray(keys, dtype=np.int64)
+    bias = 1 << 20
+    packed = ((k[:, 0] + bias).astype(np.uint64) << np.uint64(42)) | \
+             ((k[:, 1] + bias).astype(np.uint64) << np.uint64(21)) | \
+             (k[:, 2] + bias).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        packed ^= packed >> np.uint64(33)
+        packed *= np.uint64(0xff51afd7ed558ccd)
+        packed ^= packed >> np.uint64(33)
+        packed *= np.uint64(0xc4ceb9fe1a85ec53)
+        packed ^= packed >> np.uint64(33)
+    return ((packed >> np.uint64(32)) % np.uint64(world)).astype(np.int32)
 
 
 def allgather_block_keys(keys, dist):

@@ -92,3 +92,27 @@ def test_shard_range_covers_everything():
                 b, e = shard_range(n, r, w)
                 got += list(range(b, e))
             assert got == list(range(n))
+
+
+def test_block_owner_host_mirror_matches_library():
+    """sharding.block_owner (numpy) == o3dmi_block_owner (the function the
+    touch kernels use), and it is a balanced partition."""
+    import ctypes as C
+    import __graft_entry__ as ge
+    ge.build()
+    from open3d_amd import _lib, sharding
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    keys = np.concatenate([rng.integers(-400, 400, (3000, 3)),
+                           [[0, 0, 0], [-1, -1, -1], [(1 << 20) - 1] * 3,
+                            [-(1 << 20)] * 3]]).astype(np.int32)
+    for world in (1, 2, 3, 8):
+        host = sharding.block_owner(keys, world)
+        dev = np.array([L.o3dmi_block_owner(
+            np.ascontiguousarray(k).ctypes.data_as(C.POINTER(C.c_int)), world)
+            for k in keys])
+        assert np.array_equal(host, dev)
+        counts = np.bincount(host, minlength=world)
+        assert counts.min() > 0.8 * len(keys) / world
+    bad = np.array([1 << 20, 0, 0], np.int32)
+    assert L.o3dmi_block_owner(bad.ctypes.data_as(C.POINTER(C.c_int)), 4) == -1

@@ -541,3 +541,53 @@ def test_c5_voxel_size_4mm_grid():
     assert np.array_equal(g.attribute("color").cpu().numpy()[gbuf], col[obuf])
     pcd = g.extract_point_cloud(2.0)
     assert pcd["positions"].shape[0] > 100000
+
+
+@pytest.mark.parametrize("path", ["frames", "two_step"])
+def test_block_ownership_sharding_is_bit_identical(path):
+    """Multi-GPU scheme A on one device: `world` grids see the same stream, grid
+    r only takes the blocks it owns. Their key sets are the ownership classes of
+    the unsharded grid's keys and every block is bit-identical to it."""
+    _lib, geometry = _gpu()
+    from open3d_amd import sharding
+    world = 3
+    fr = [sc.frames(k, 1, 320, 240) for k in range(0, 40, 4)]
+    K = fr[0][2]
+    ds = [torch.from_numpy(f[0][0]).cuda() for f in fr]
+    cs = [torch.from_numpy(f[1][0]).cuda() for f in fr]
+    Ts = [f[3][0] for f in fr]
+
+    def run(rank, w):
+        g = _mk_grid(geometry, False, block_count=4096)
+        if w > 1:
+            g.set_block_ownership(rank, w)
+        if path == "frames":
+            g.integrate_frames(ds, cs, K, K, Ts, sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                               sc.TRUNC_MULT)
+        else:
+            for d, c, T in zip(ds, cs, Ts):
+                keys = g.compute_unique_block_coordinates(
+                    d, K, T, sc.DEPTH_SCALE, sc.DEPTH_MAX, sc.TRUNC_MULT)
+                g.integrate(keys, d, c, K, K, T, sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                            sc.TRUNC_MULT)
+        hm = g.hashmap()
+        act = hm.active_buf_indices().cpu().numpy().astype(np.int64)
+        keys = hm.key_tensor().cpu().numpy()[act]
+        order = np.lexsort(keys.T[::-1])
+        return (keys[order],
+                g.attribute("tsdf").cpu().numpy()[act][order],
+                g.attribute("weight").cpu().numpy()[act][order],
+                g.attribute("color").cpu().numpy()[act][order])
+
+    full = run(0, 1)
+    owner = sharding.block_owner(full[0], world)
+    assert np.bincount(owner, minlength=world).min() > 100
+    total = 0
+    for r in range(world):
+        part = run(r, world)
+        sel = owner == r
+        assert np.array_equal(part[0], full[0][sel])
+        for a, b in zip(part[1:], full[1:]):
+            assert a.tobytes() == b[sel].tobytes()
+        total += part[0].shape[0]
+    assert total == full[0].shape[0]
