@@ -215,7 +215,12 @@ void FreeStorage(o3dmi_hash* h) {
         (void)hipFree(h->value_buffers[j]);
         h->value_buffers[j] = nullptr;
     }
+    // Storage is gone; the sharding role of the map is not (Reserve re-uses
+    // the object).
+    const int owner_rank = v.owner_rank, owner_world = v.owner_world;
     v = HashView{};
+    v.owner_rank = owner_rank;
+    v.owner_world = owner_world;
 }
 
 int ClearImpl(o3dmi_hash* h, hipStream_t s) {
