@@ -30,20 +30,42 @@ inline int SumsGrid(int64_t n) {
     return (int)g;
 }
 
+// Sum of up to 32 float64 values per lane over the 64 lanes of a wave, as a
+// reduce-scatter: each butterfly step (lane ^ 32, 16, 8, 4, 2) halves the
+// number of values a lane carries, a last step (lane ^ 1) joins the two halves.
+// 32 double shuffles instead of N x 6 for one-value-at-a-time trees (the LDS
+// crossbar, not the adds, is what a 29-value reduction costs). On return lane l
+// holds the wave total of value (l >> 1). Fixed order: run-to-run identical.
+template <int N>
+__device__ __forceinline__ double WaveReduceScatter(const double (&A)[N]) {
+    static_assert(N <= 32, "at most 32 values");
+    double v[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) v[k] = k < N ? A[k] : 0.0;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int half = 16; half >= 1; half >>= 1) {
+        // lanes with bit (2 * half) of the lane id set keep the upper half
+        const bool upper = (lane & (2 * half)) != 0;
+#pragma unroll
+        for (int k = 0; k < half; ++k) {
+            const double send = upper ? v[k] : v[k + half];
+            const double keep = upper ? v[k + half] : v[k];
+            v[k] = keep + __shfl_xor(send, 2 * half, 64);
+        }
+    }
+    return v[0] + __shfl_xor(v[0], 1, 64);
+}
+
 // partials: [gridDim.x][N] float64.
 template <int N>
 __device__ __forceinline__ void BlockSumAndStore(double (&A)[N],
                                                  double* __restrict__ partials) {
-    __shared__ double lds[kSumsBlock / 64][N];
+    __shared__ double lds[kSumsBlock / 64][32];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        double v = A[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) lds[wave][k] = v;
-    }
+    const double t = WaveReduceScatter<N>(A);
+    if ((lane & 1) == 0) lds[wave][lane >> 1] = t;
     __syncthreads();
     if (threadIdx.x < N) {
         double v = 0;
