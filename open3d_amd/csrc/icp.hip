@@ -423,26 +423,12 @@ __device__ __forceinline__ void AccumulateP2Plane(
 
 constexpr int kReduceBlock = 256;
 
-// Wave64 tree, then LDS across the 4 waves, then one row per workgroup.
+// Reduce-scatter wave reduction (reduce_sums.h), LDS across the 4 waves, one
+// row per workgroup.
 __device__ __forceinline__ void BlockReduceAndStore(double (&A)[kNumSums],
                                                     double* __restrict__ partials) {
-    __shared__ double lds[kReduceBlock / 64][kNumSums];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < kNumSums; ++k) {
-        double v = A[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) lds[wave][k] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < kNumSums) {
-        double v = 0;
-#pragma unroll
-        for (int wv = 0; wv < kReduceBlock / 64; ++wv) v += lds[wv][threadIdx.x];
-        partials[(int64_t)blockIdx.x * kNumSums + threadIdx.x] = v;
-    }
+    static_assert(kReduceBlock == kSumsBlock, "shared reduction geometry");
+    BlockSumAndStore<kNumSums>(A, partials);
 }
 
 __global__ void FinalReduceKernel(const double* __restrict__ partials,
