@@ -145,3 +145,28 @@ def test_estimate_normals_operator(dtype):
     assert ((got2 * prior).sum(1) >= -1e-6).all()
     with pytest.raises(ValueError, match="hybrid"):
         reg.estimate_normals(tp, 30, None)
+
+
+def test_empty_and_tiny_inputs():
+    _lib, reg = _gpu()
+    from open3d_amd.core import stream
+    L = _lib.lib()
+    empty = torch.empty((0, 3), dtype=torch.float32, device="cuda")
+    assert reg.estimate_normals(empty, 30, 0.1).shape == (0, 3)
+    # one and two points: every neighbourhood has < 3 members -> +z
+    for n in (1, 2):
+        p = torch.rand((n, 3), dtype=torch.float32, device="cuda")
+        nr = reg.estimate_normals(p, 30, 0.5).cpu().numpy()
+        assert np.array_equal(nr, np.tile([[0, 0, 1.0]], (n, 1)).astype(np.float32))
+    # q = 0 queries, max_knn out of range
+    pts = torch.rand((100, 3), dtype=torch.float32, device="cuda")
+    h = C.c_void_p()
+    _lib.check(L.o3dmi_nns_create(_lib.ptr(pts), 100, _lib.F32, C.c_double(0.2),
+                                  stream(), C.byref(h)), "nns_create")
+    assert L.o3dmi_nns_hybrid_search(h, None, 0, 5, None, None, None,
+                                     stream()) == 0
+    idx = torch.zeros((100, 65), dtype=torch.int32, device="cuda")
+    assert L.o3dmi_nns_hybrid_search(h, _lib.ptr(pts), 100, 65, _lib.ptr(idx),
+                                     None, None, stream()) != 0
+    assert b"max_knn" in L.o3dmi_last_error()
+    L.o3dmi_nns_destroy(h)

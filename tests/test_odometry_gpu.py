@@ -278,3 +278,36 @@ def test_error_paths():
         odo.rgbd_odometry_multi_scale(z, z, K, method=odo.Method.PointToPlane)
     with pytest.raises(RuntimeError, match="colour"):
         odo.rgbd_odometry_multi_scale(z, z, K, method=odo.Method.Hybrid)
+
+
+def test_degenerate_frames():
+    """Edge cases of the driver: a frame pair with a band of valid depth only
+    (most pixels NaN), identical frames (zero motion), minimum-size pyramids."""
+    odo = _gpu()
+    sd, sc, td, tc, K, Ts, Tt = _pair(w=160, h=120, step=1)
+    band = np.zeros_like(sd)
+    band[40:80] = sd[40:80]
+    crit = ((4, 1e-6, 1e-6), (2, 1e-6, 1e-6))
+    for a, b in ((band, td), (sd, sd)):
+        want = orc.rgbd_odometry_multiscale(orc.ODO_P2PLANE, a, b, K,
+                                            criteria=crit,
+                                            accumulate_double=True)
+        got = odo.rgbd_odometry_multi_scale(
+            _dev(a), _dev(b), K, criteria_list=[
+                odo.OdometryConvergenceCriteria(*c) for c in crit],
+            method=odo.Method.PointToPlane)
+        assert want["status"] == 0
+        rot, trans = _pose_err(got.transformation, want["transformation"])
+        assert rot <= 1e-6 and trans <= 1e-5
+        assert got.num_iterations == want["iterations"]
+    # identical frames: the estimate stays at the identity to rounding
+    assert np.abs(got.transformation - np.eye(4)).max() < 1e-4
+    # an 8 x 8 image with 3 levels bottoms out at 2 x 2
+    tiny = np.full((8, 8), 1500, np.uint16)
+    Kt = np.array([[10.0, 0, 3.5], [0, 10.0, 3.5], [0, 0, 1]])
+    try:
+        odo.rgbd_odometry_multi_scale(_dev(tiny), _dev(tiny), Kt,
+                                      criteria_list=(1, 1, 1),
+                                      method=odo.Method.PointToPlane)
+    except RuntimeError as e:   # a flat wall is rank deficient: the reference
+        assert "Singular" in str(e) or "inlier" in str(e)   # throws as well
