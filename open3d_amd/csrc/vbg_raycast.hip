@@ -271,40 +271,53 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
                     float ratio_z = z_v - (float)z_v_floor;
 
                     float sum_r = 0.0f;
+                    // Pass 1: the 8 neighbour voxel indices (block look-ups
+                    // only at block faces). Pass 2: all weight loads in
+                    // flight together, then the per-neighbour terms in the
+                    // reference's order (k = 0..7).
+                    int64_t lin[8];
+#pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        int dx_v = (k & 1) > 0 ? 1 : 0;
-                        int dy_v = (k & 2) > 0 ? 1 : 0;
-                        int dz_v = (k & 4) > 0 ? 1 : 0;
-
+                        const int dx_v = (k & 1) > 0 ? 1 : 0;
+                        const int dy_v = (k & 2) > 0 ? 1 : 0;
+                        const int dz_v = (k & 4) > 0 ? 1 : 0;
                         // GetLinearIdxAtP, VoxelBlockGridImpl.h:742-782
-                        int xv = x_v_floor + dx_v, yv = y_v_floor + dy_v,
-                            zv = z_v_floor + dz_v;
-                        int x_vn = (xv + res) % res;
-                        int y_vn = (yv + res) % res;
-                        int z_vn = (zv + res) % res;
-                        int dx_b = SignI(xv - x_vn);
-                        int dy_b = SignI(yv - y_vn);
-                        int dz_b = SignI(zv - z_vn);
-                        int64_t linear_idx_k;
+                        const int xv = x_v_floor + dx_v, yv = y_v_floor + dy_v,
+                                  zv = z_v_floor + dz_v;
+                        const int x_vn = (xv + res) % res;
+                        const int y_vn = (yv + res) % res;
+                        const int z_vn = (zv + res) % res;
+                        const int dx_b = SignI(xv - x_vn);
+                        const int dy_b = SignI(yv - y_vn);
+                        const int dz_b = SignI(zv - z_vn);
                         if (dx_b == 0 && dy_b == 0 && dz_b == 0) {
-                            linear_idx_k = (int64_t)block_buf_idx * res3 +
-                                           zv * res2 + yv * res + xv;
+                            lin[k] = (int64_t)block_buf_idx * res3 + zv * res2 +
+                                     yv * res + xv;
                         } else {
-                            int kx = x_b + dx_b, ky = y_b + dy_b,
-                                kz = z_b + dz_b;
+                            const int kx = x_b + dx_b, ky = y_b + dy_b,
+                                      kz = z_b + dz_b;
                             int nb = cache.Check(kx, ky, kz);
                             if (nb < 0) {
                                 nb = hv.Find(kx, ky, kz);
                                 if (nb >= 0) cache.Update(kx, ky, kz, nb);
                             }
-                            linear_idx_k =
-                                    nb < 0 ? -1
-                                           : (int64_t)nb * res3 + z_vn * res2 +
-                                                     y_vn * res + x_vn;
+                            lin[k] = nb < 0 ? -1
+                                            : (int64_t)nb * res3 + z_vn * res2 +
+                                                      y_vn * res + x_vn;
                         }
+                    }
+                    weight_t wk[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        wk[k] = lin[k] >= 0 ? weight_base[lin[k]] : (weight_t)0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int dx_v = (k & 1) > 0 ? 1 : 0;
+                        const int dy_v = (k & 2) > 0 ? 1 : 0;
+                        const int dz_v = (k & 4) > 0 ? 1 : 0;
+                        const int64_t linear_idx_k = lin[k];
 
-                        if (linear_idx_k >= 0 &&
-                            weight_base[linear_idx_k] > 0) {
+                        if (linear_idx_k >= 0 && wk[k] > 0) {
                             float rx = dx_v * (ratio_x) +
                                        (1 - dx_v) * (1 - ratio_x);
                             float ry = dy_v * (ratio_y) +
