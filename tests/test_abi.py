@@ -59,3 +59,21 @@ def test_missing_extension_fails_loudly(built, monkeypatch):
     monkeypatch.setattr(built, "_lib", None)
     with pytest.raises(RuntimeError, match="no CPU"):
         built.lib()
+
+
+def test_headers_are_plain_c(tmp_path):
+    """The boundary is a C ABI: both headers must compile as C99 (what a cgo /
+    JNI / ctypes-cffi binding would feed to its C compiler)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "o3d_mi355x.h"\n#include "o3d_mi355x_host.h"\n'
+                   "int main(void) { return (int)sizeof(o3dmi_odometry_result_t)"
+                   " > 0 ? 0 : 1; }\n")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic",
+                        "-Werror", "-I", os.path.join(ROOT, "include"),
+                        "-fsyntax-only", str(src)], capture_output=True,
+                       text=True)
+    assert r.returncode == 0, r.stderr
