@@ -363,6 +363,44 @@ int o3dmi_icp_search_accumulate(const o3dmi_nns_t* nns, const void* src_dev,
                                 double shape_parameter, int64_t* corr_out_dev,
                                 double* sums32_dev, o3dmi_stream_t stream);
 
+/* TransformationEstimationPointToPoint: the reduction of ComputeRtPointToPoint
+ * (t/pipelines/kernel/Registration.cpp:365-404; CPU body Get3x3SxyLinearSystem,
+ * RegistrationCPU.cpp:495-617; the reference's own GPU branch is tensor ops
+ * with a "TODO: Implement optimized CUDA reduction kernel", Registration.cpp:
+ * 383). One pass instead of the reference's two: sums16_dev (float64[16]) =
+ * [0..2] sum of source xyz, [3..5] sum of matched target xyz, [6 + 3 j + k] =
+ * sum of target_j * source_k, [15] = number of correspondences; products and
+ * sums are float64 (exact products for Float32 clouds), fixed reduction tree.
+ * o3dmi_compute_rt_p2point turns them into R, t. */
+int o3dmi_icp_p2point_accumulate(const void* src_dev, const void* tgt_dev,
+                                 const int64_t* corr_dev, int64_t n, int dtype,
+                                 double* sums16_dev, o3dmi_stream_t stream);
+
+/* Fused search (k=1) + fitness/rmse sums + point-to-point accumulation:
+ * sums32_dev[0..15] as o3dmi_icp_p2point_accumulate, [29] = sum of d2 over
+ * matches, [30] = number of matches. The index needs no normals. */
+int o3dmi_icp_search_accumulate_p2point(const o3dmi_nns_t* nns,
+                                        const void* src_dev, int64_t n,
+                                        int64_t* corr_out_dev,
+                                        double* sums32_dev,
+                                        o3dmi_stream_t stream);
+
+/* Host: mean_s, mean_t, Sxy = sum(t s^T)/n - mean_t mean_s^T, SVD of Sxy
+ * (one-sided Jacobi, float64), R = U diag(1,1,det(U)det(V)) V^T,
+ * t = mean_t - R mean_s (RegistrationCPU.cpp:640-650). R9 row-major.
+ * O3DMI_ERR_NO_INLIERS ("No valid correspondence present.") when count = 0. */
+int o3dmi_compute_rt_p2point(const double* sums16_host, double* R9, double* t3);
+
+/* ComputeInformationMatrixCUDA up to the reduction
+ * (t/pipelines/kernel/RegistrationCUDA.cu ComputeInformationMatrixKernelCUDA,
+ * CPU body RegistrationCPU.cpp:652-735, Jacobians RegistrationImpl.h:686-715):
+ * the 21 packed-lower-triangle sums of G^T G over matched target points,
+ * float64; sums21[j (j + 1) / 2 + k] = GTG[j][k] = GTG[k][j]. */
+int o3dmi_icp_information_accumulate(const void* tgt_dev,
+                                     const int64_t* corr_dev, int64_t n,
+                                     int dtype, double* sums21_dev,
+                                     o3dmi_stream_t stream);
+
 /* TransformPointsCUDA / TransformNormalsCUDA
  * (t/geometry/kernel/Transform.h:42-47, TransformImpl.h:19-60): in place;
  * `transformation` is host float64 4x4, cast to the point dtype first. */

@@ -72,6 +72,52 @@ int o3dmi_registration_multiscale_icp(
         int64_t* correspondences_dev, o3dmi_registration_result_t* result,
         o3dmi_stream_t stream);
 
+/* TransformationEstimation choice for o3dmi_registration_multiscale_icp_ex
+ * (t/pipelines/registration/TransformationEstimation.h:28-34). */
+typedef enum {
+    O3DMI_ICP_POINT_TO_PLANE = 0,
+    O3DMI_ICP_POINT_TO_POINT = 1
+} o3dmi_icp_estimation_t;
+
+/* MultiScaleICP with a selectable estimator. POINT_TO_PLANE is exactly
+ * o3dmi_registration_multiscale_icp; POINT_TO_POINT
+ * (TransformationEstimationPointToPoint, TransformationEstimation.cpp:101-160)
+ * ignores target_normals_dev (may be NULL) and the robust kernel. */
+int o3dmi_registration_multiscale_icp_ex(
+        const void* source_dev, int64_t ns, const void* target_dev,
+        const void* target_normals_dev, int64_t nt, int dtype, int num_scales,
+        const double* voxel_sizes, const o3dmi_icp_criteria_t* criterias,
+        const double* max_correspondence_distances,
+        const double* init_source_to_target, int estimation, int robust_kernel,
+        double scaling_parameter, double shape_parameter,
+        o3dmi_icp_callback_t callback, void* callback_user,
+        o3dmi_allreduce_sum_t allreduce, void* allreduce_user,
+        int64_t* correspondences_dev, o3dmi_registration_result_t* result,
+        o3dmi_stream_t stream);
+
+/* registration::EvaluateRegistration (Registration.cpp:64-91): fitness,
+ * inlier_rmse and the correspondence set of `source` moved by `transformation`
+ * (host 4x4 float64, NULL = identity) against `target`. result->transformation
+ * is `transformation` (identity when nothing matches, Registration.cpp:56-58),
+ * converged = 0, num_iterations = 0. correspondences_dev: optional int64[ns]. */
+int o3dmi_registration_evaluate(const void* source_dev, int64_t ns,
+                                const void* target_dev, int64_t nt, int dtype,
+                                double max_correspondence_distance,
+                                const double* transformation,
+                                int64_t* correspondences_dev,
+                                o3dmi_registration_result_t* result,
+                                o3dmi_stream_t stream);
+
+/* registration::GetInformationMatrix (Registration.cpp:446-486): 6x6 float64
+ * (host, row-major). O3DMI_ERR_NO_INLIERS mirrors "0 correspondence present
+ * between the pointclouds. Try increasing the max_correspondence_distance
+ * parameter.". */
+int o3dmi_registration_information_matrix(
+        const void* source_dev, int64_t ns, const void* target_dev, int64_t nt,
+        int dtype, double max_correspondence_distance,
+        const double* transformation, double* information36,
+        o3dmi_stream_t stream);
+
 /* PointCloud::VoxelDownSample (t/geometry/PointCloud.cpp:496-567) for
  * positions (+ optional normals): mean per voxel in float32, voxel order =
  * order of first occurrence. Outputs must hold n rows; *m_out receives the

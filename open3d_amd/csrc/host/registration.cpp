@@ -30,8 +30,8 @@
 
 extern "C" int o3dmi_icp_search_accumulate_post(
         const o3dmi_nns_t* nns, const void* src_dev,
-        const void* tgt_normals_dev, int64_t n, int robust_kernel,
-        double scaling_parameter, double shape_parameter,
+        const void* tgt_normals_dev, int64_t n, int estimation,
+        int robust_kernel, double scaling_parameter, double shape_parameter,
         int64_t* corr_out_dev, double* sums32_dev, double* mail_data,
         int* mail_flag, int mail_seq, o3dmi_stream_t stream);
 
@@ -99,13 +99,36 @@ extern "C" int o3dmi_registration_multiscale_icp(
         o3dmi_allreduce_sum_t allreduce, void* allreduce_user,
         int64_t* correspondences_dev, o3dmi_registration_result_t* result,
         o3dmi_stream_t stream) {
+    return o3dmi_registration_multiscale_icp_ex(
+            source_dev, ns, target_dev, target_normals_dev, nt, dtype,
+            num_scales, voxel_sizes, criterias, max_dists, init,
+            O3DMI_ICP_POINT_TO_PLANE, robust_kernel, scaling_parameter,
+            shape_parameter, callback, callback_user, allreduce, allreduce_user,
+            correspondences_dev, result, stream);
+}
+
+extern "C" int o3dmi_registration_multiscale_icp_ex(
+        const void* source_dev, int64_t ns, const void* target_dev,
+        const void* target_normals_dev, int64_t nt, int dtype, int num_scales,
+        const double* voxel_sizes, const o3dmi_icp_criteria_t* criterias,
+        const double* max_dists, const double* init, int estimation,
+        int robust_kernel, double scaling_parameter, double shape_parameter,
+        o3dmi_icp_callback_t callback, void* callback_user,
+        o3dmi_allreduce_sum_t allreduce, void* allreduce_user,
+        int64_t* correspondences_dev, o3dmi_registration_result_t* result,
+        o3dmi_stream_t stream) {
     // AssertInputMultiScaleICP, Registration.cpp:119-219.
     O3DMI_REQUIRE(result != nullptr, "result is null");
     O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
                   "Only Float32 and Float64 point clouds are supported.");
     O3DMI_REQUIRE(source_dev && target_dev && ns > 0 && nt > 0,
                   "Source and/or Target pointcloud is empty.");
-    O3DMI_REQUIRE(target_normals_dev != nullptr,
+    O3DMI_REQUIRE(estimation == O3DMI_ICP_POINT_TO_PLANE ||
+                          estimation == O3DMI_ICP_POINT_TO_POINT,
+                  "estimation must be point-to-plane or point-to-point");
+    const bool p2plane = estimation == O3DMI_ICP_POINT_TO_PLANE;
+    if (!p2plane) target_normals_dev = nullptr;
+    O3DMI_REQUIRE(!p2plane || target_normals_dev != nullptr,
                   "Target pointcloud missing normals attribute.");
     O3DMI_REQUIRE(num_scales > 0 && voxel_sizes && criterias && max_dists,
                   "Size of criterias, voxel_size, max_correspondence_distances "
@@ -145,7 +168,8 @@ extern "C" int o3dmi_registration_multiscale_icp(
         } else {
             if ((st = L.src.Alloc((size_t)ns * 3 * esz))) return st;
             if ((st = L.tgt.Alloc((size_t)nt * 3 * esz))) return st;
-            if ((st = L.nrm.Alloc((size_t)nt * 3 * esz))) return st;
+            if (p2plane && (st = L.nrm.Alloc((size_t)nt * 3 * esz)))
+                return st;
             st = o3dmi_voxel_down_sample(source_dev, nullptr, ns, dtype,
                                          voxel_sizes[last], L.src.p, nullptr,
                                          &L.ns, stream);
@@ -155,7 +179,7 @@ extern "C" int o3dmi_registration_multiscale_icp(
                                          L.nrm.p, &L.nt, stream);
             if (st) return st;
             L.tgt_ptr = L.tgt.p;
-            L.nrm_ptr = L.nrm.p;
+            L.nrm_ptr = L.nrm.p;  // stays NULL without normals
         }
     }
     for (int k = num_scales - 2; k >= 0; --k) {
@@ -163,7 +187,7 @@ extern "C" int o3dmi_registration_multiscale_icp(
         Level& F = pyr[(size_t)k + 1];
         if ((st = L.src.Alloc((size_t)F.ns * 3 * esz))) return st;
         if ((st = L.tgt.Alloc((size_t)F.nt * 3 * esz))) return st;
-        if ((st = L.nrm.Alloc((size_t)F.nt * 3 * esz))) return st;
+        if (p2plane && (st = L.nrm.Alloc((size_t)F.nt * 3 * esz))) return st;
         st = o3dmi_voxel_down_sample(F.src.p, nullptr, F.ns, dtype,
                                      voxel_sizes[k], L.src.p, nullptr, &L.ns,
                                      stream);
@@ -197,9 +221,9 @@ extern "C" int o3dmi_registration_multiscale_icp(
                       SearchResult& r) -> int {
         const int seq = ++mb->seq;
         int e = o3dmi_icp_search_accumulate_post(
-                nns, L.src.p, nullptr, L.ns, robust_kernel, scaling_parameter,
-                shape_parameter, corr_out, nullptr, mb->data, mb->flag, seq,
-                stream);
+                nns, L.src.p, nullptr, L.ns, estimation, robust_kernel,
+                scaling_parameter, shape_parameter, corr_out, nullptr, mb->data,
+                mb->flag, seq, stream);
         if (e) return e;
         O3DMI_HIP_CHECK(MailboxWait(mb, seq, s));
         std::memcpy(r.sums, sums_host, sizeof(r.sums));
@@ -234,7 +258,8 @@ extern "C" int o3dmi_registration_multiscale_icp(
         if ((st = o3dmi_nns_create(L.tgt_ptr, L.nt, dtype, max_dists[scale_idx],
                                    stream, &guard.nns)))
             return st;
-        if ((st = o3dmi_nns_set_normals(guard.nns, L.nrm_ptr, stream)))
+        if (p2plane &&
+            (st = o3dmi_nns_set_normals(guard.nns, L.nrm_ptr, stream)))
             return st;
 
         // DoSingleScaleICPIterations :275-360
@@ -255,12 +280,25 @@ extern "C" int o3dmi_registration_multiscale_icp(
                 break;
             }
             double pose[6], update[16];
-            float residual;
-            int inlier_count;
-            int e = o3dmi_decode_and_solve6x6(r.sums, pose, &residual,
-                                              &inlier_count);
-            if (e) status = e;  // reference throws; report after the loop
-            o3dmi_pose_to_transformation(pose, update);
+            if (p2plane) {
+                float residual;
+                int inlier_count;
+                int e = o3dmi_decode_and_solve6x6(r.sums, pose, &residual,
+                                                  &inlier_count);
+                if (e) status = e;  // reference throws; report after the loop
+                o3dmi_pose_to_transformation(pose, update);
+            } else {
+                // ComputeRtPointToPoint + RtToTransformation
+                // (TransformationEstimation.cpp:150-159)
+                double R[9], t[3];
+                int e = o3dmi_compute_rt_p2point(r.sums, R, t);
+                if (e) return e;
+                Eye4(update);
+                for (int j = 0; j < 3; ++j) {
+                    for (int k = 0; k < 3; ++k) update[j * 4 + k] = R[j * 3 + k];
+                    update[j * 4 + 3] = t[j];
+                }
+            }
             Matmul4(update, T, T);
             if ((st = o3dmi_transform_points(update, L.src.p, L.ns, dtype,
                                              stream)))
@@ -303,4 +341,104 @@ extern "C" int o3dmi_registration_multiscale_icp(
     result->num_iterations = iteration_count;
     result->num_correspondences = correspondences_dev ? last_ns : 0;
     return status;
+}
+
+namespace {
+
+// Shared front end of EvaluateRegistration / GetInformationMatrix: clone +
+// transform the source, index the target, one fused search + sums pass.
+int TransformSearch(const void* source_dev, int64_t ns, const void* target_dev,
+                    int64_t nt, int dtype, double max_dist, const double* T,
+                    int estimation, int64_t* corr_dev, double* sums32,
+                    o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
+                  "Only Float32 and Float64 point clouds are supported.");
+    O3DMI_REQUIRE(source_dev && target_dev && ns > 0 && nt > 0,
+                  "Source and/or Target pointcloud is empty.");
+    O3DMI_REQUIRE(max_dist > 0, "max_correspondence_distance must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t esz = dtype == O3DMI_F64 ? 8 : 4;
+    DeviceBuffer src;
+    struct SyncOnExit {
+        hipStream_t s;
+        ~SyncOnExit() { (void)hipStreamSynchronize(s); }
+    } sync_on_exit{s};
+    int st;
+    if ((st = src.Alloc((size_t)ns * 3 * esz))) return st;
+    O3DMI_HIP_CHECK(hipMemcpyAsync(src.p, source_dev, (size_t)ns * 3 * esz,
+                                   hipMemcpyDeviceToDevice, s));
+    if (T && (st = o3dmi_transform_points(T, src.p, ns, dtype, stream)))
+        return st;
+    NnsGuard guard;
+    if ((st = o3dmi_nns_create(target_dev, nt, dtype, max_dist, stream,
+                               &guard.nns)))
+        return st;
+    Mailbox* mb = ThreadMailbox();
+    O3DMI_REQUIRE(mb != nullptr, "host mailbox allocation failed");
+    const int seq = ++mb->seq;
+    if ((st = o3dmi_icp_search_accumulate_post(
+                 guard.nns, src.p, nullptr, ns, estimation, 0, 1.0, 1.0,
+                 corr_dev, nullptr, mb->data, mb->flag, seq, stream)))
+        return st;
+    O3DMI_HIP_CHECK(MailboxWait(mb, seq, s));
+    std::memcpy(sums32, mb->data, sizeof(double) * 32);
+    return O3DMI_OK;
+}
+
+}  // namespace
+
+extern "C" int o3dmi_registration_evaluate(
+        const void* source_dev, int64_t ns, const void* target_dev, int64_t nt,
+        int dtype, double max_dist, const double* transformation,
+        int64_t* correspondences_dev, o3dmi_registration_result_t* result,
+        o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(result != nullptr, "result is null");
+    double sums[32];
+    int st = TransformSearch(source_dev, ns, target_dev, nt, dtype, max_dist,
+                             transformation, O3DMI_ICP_POINT_TO_POINT,
+                             correspondences_dev, sums, stream);
+    if (st) return st;
+    // ComputeRegistrationResult, Registration.cpp:24-62.
+    const double num = sums[30];
+    if (transformation)
+        std::memcpy(result->transformation, transformation, sizeof(double) * 16);
+    else
+        Eye4(result->transformation);
+    if (num != 0) {
+        result->fitness = num / (double)ns;
+        result->inlier_rmse = std::sqrt(sums[29] / num);
+    } else {
+        result->fitness = 0;
+        result->inlier_rmse = 0;
+        Eye4(result->transformation);
+    }
+    result->converged = 0;
+    result->num_iterations = 0;
+    result->num_correspondences = correspondences_dev ? ns : 0;
+    return O3DMI_OK;
+}
+
+extern "C" int o3dmi_registration_information_matrix(
+        const void* source_dev, int64_t ns, const void* target_dev, int64_t nt,
+        int dtype, double max_dist, const double* transformation,
+        double* information36, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(information36 != nullptr, "information36 is null");
+    double sums[32];
+    int st = TransformSearch(source_dev, ns, target_dev, nt, dtype, max_dist,
+                             transformation, 2, nullptr, sums, stream);
+    if (st) return st;
+    if (sums[30] == 0) {
+        SetLastError(
+                "0 correspondence present between the pointclouds. Try "
+                "increasing the max_correspondence_distance parameter.");
+        return O3DMI_ERR_NO_INLIERS;
+    }
+    // RegistrationCPU.cpp:727-733
+    int i = 0;
+    for (int j = 0; j < 6; j++)
+        for (int k = 0; k <= j; k++) {
+            information36[j * 6 + k] = information36[k * 6 + j] = sums[i];
+            ++i;
+        }
+    return O3DMI_OK;
 }

@@ -421,6 +421,49 @@ __device__ __forceinline__ void AccumulateP2Plane(
     A[28] += 1.0;
 }
 
+// Point-to-point (Horn) sums in one pass: sum s, sum t, sum t s^T, count
+// (RegistrationCPU.cpp:495-617 forms the means first and the centred products
+// in a second pass; the centred covariance follows on the host from these raw
+// moments in float64, where products of two Float32 values are exact).
+template <typename T>
+__device__ __forceinline__ void AccumulateP2Point(double (&A)[kNumSums], T sx,
+                                                  T sy, T sz, T tx, T ty,
+                                                  T tz) {
+    const double s[3] = {(double)sx, (double)sy, (double)sz};
+    const double t[3] = {(double)tx, (double)ty, (double)tz};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        A[k] += s[k];
+        A[3 + k] += t[k];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) A[6 + 3 * j + k] += t[j] * s[k];
+    A[15] += 1.0;
+}
+
+// GetInformationJacobians + the 21 sums of ComputeInformationMatrixKernelCPU
+// (RegistrationImpl.h:686-715, RegistrationCPU.cpp:652-701): per matched target
+// point G^T G with G = [-[t]x | I], each packed-lower-triangle term formed in T
+// as J_x[j] J_x[k] + J_y[j] J_y[k] + J_z[j] J_z[k], summed in float64.
+template <typename T>
+__device__ __forceinline__ void AccumulateInformation(double (&A)[kNumSums],
+                                                      T tx, T ty, T tz) {
+    const T Jx[6] = {T(0), tz, -ty, T(1), T(0), T(0)};
+    const T Jy[6] = {-tz, T(0), tx, T(0), T(1), T(0)};
+    const T Jz[6] = {ty, -tx, T(0), T(0), T(0), T(1)};
+    int i = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+#pragma unroll
+        for (int k = 0; k <= j; ++k) {
+            A[i] += (double)(Jx[j] * Jx[k] + Jy[j] * Jy[k] + Jz[j] * Jz[k]);
+            ++i;
+        }
+    }
+}
+
 constexpr int kReduceBlock = 256;
 
 // Reduce-scatter wave reduction (reduce_sums.h), LDS across the 4 waves, one
@@ -476,6 +519,42 @@ P2PlaneAccumulateKernel(const T* __restrict__ src, const T* __restrict__ tgt,
     BlockReduceAndStore(A, partials);
 }
 
+template <typename T>
+__global__ void __launch_bounds__(kReduceBlock)
+P2PointAccumulateKernel(const T* __restrict__ src, const T* __restrict__ tgt,
+                        const int64_t* __restrict__ corr, int64_t n,
+                        double* __restrict__ partials) {
+    double A[kNumSums];
+#pragma unroll
+    for (int k = 0; k < kNumSums; ++k) A[k] = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t c = corr[i];
+        if (c == -1) continue;
+        AccumulateP2Point<T>(A, src[3 * i + 0], src[3 * i + 1], src[3 * i + 2],
+                             tgt[3 * c + 0], tgt[3 * c + 1], tgt[3 * c + 2]);
+    }
+    BlockReduceAndStore(A, partials);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kReduceBlock)
+InformationAccumulateKernel(const T* __restrict__ tgt,
+                            const int64_t* __restrict__ corr, int64_t n,
+                            double* __restrict__ partials) {
+    double A[kNumSums];
+#pragma unroll
+    for (int k = 0; k < kNumSums; ++k) A[k] = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t c = corr[i];
+        if (c == -1) continue;
+        AccumulateInformation<T>(A, tgt[3 * c + 0], tgt[3 * c + 1],
+                                 tgt[3 * c + 2]);
+    }
+    BlockReduceAndStore(A, partials);
+}
+
 // Fused search + accumulate, one query per 32 lanes. The 27 neighbour cells of
 // a query are independent look-ups (bucket bounds -> a handful of candidate
 // records); walking them one after the other from a single lane is a chain of
@@ -485,7 +564,9 @@ P2PlaneAccumulateKernel(const T* __restrict__ src, const T* __restrict__ tgt,
 // picks -- and its lane 0 forms the Jacobian terms. A wave serves two queries.
 // G = lanes per query (1, 2, 4, ... 32): few queries want G = 32 (latency),
 // many queries want a small G (every lane busy); the winner is the same.
-template <typename T, int G>
+// EST: 0 = point-to-plane terms (needs sorted normals), 1 = point-to-point
+// moments, 2 = information-matrix terms of the matched target point.
+template <typename T, int G, int EST>
 __global__ void __launch_bounds__(kReduceBlock)
 SearchAccumulateKernel(NnsView<T> nv, const Rec4<T>* __restrict__ sorted_n,
                        const T* __restrict__ src, int64_t n, RobustParams rp,
@@ -555,9 +636,15 @@ SearchAccumulateKernel(NnsView<T> nv, const Rec4<T>* __restrict__ sorted_n,
             if (corr_out) corr_out[i] = pos >= 0 ? (int64_t)idx : (int64_t)-1;
             if (pos >= 0) {
                 const Rec4<T> t = nv.sorted[pos];
-                const Rec4<T> nn = sorted_n[pos];
-                AccumulateP2Plane<T>(A, q[0], q[1], q[2], t.x, t.y, t.z, nn.x,
-                                     nn.y, nn.z, rp);
+                if constexpr (EST == 0) {
+                    const Rec4<T> nn = sorted_n[pos];
+                    AccumulateP2Plane<T>(A, q[0], q[1], q[2], t.x, t.y, t.z,
+                                         nn.x, nn.y, nn.z, rp);
+                } else if constexpr (EST == 1) {
+                    AccumulateP2Point<T>(A, q[0], q[1], q[2], t.x, t.y, t.z);
+                } else {
+                    AccumulateInformation<T>(A, t.x, t.y, t.z);
+                }
                 A[29] += (double)d2;
                 A[30] += 1.0;
             }
@@ -837,12 +924,77 @@ int o3dmi_icp_p2plane_accumulate(const void* src_dev, const void* tgt_dev,
     return O3DMI_OK;
 }
 
+int o3dmi_icp_p2point_accumulate(const void* src_dev, const void* tgt_dev,
+                                 const int64_t* corr_dev, int64_t n, int dtype,
+                                 double* sums16_dev, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(src_dev && tgt_dev && corr_dev && sums16_dev,
+                  "null argument");
+    O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
+                  "points must be Float32 or Float64");
+    hipStream_t s = (hipStream_t)stream;
+    int g = ReduceGrid(n);
+    double* partials = nullptr;
+    O3DMI_HIP_CHECK(hipMallocAsync((void**)&partials,
+                                   sizeof(double) * (size_t)g * kNumSums, s));
+    if (dtype == O3DMI_F64)
+        hipLaunchKernelGGL(P2PointAccumulateKernel<double>, dim3(g),
+                           dim3(kReduceBlock), 0, s, (const double*)src_dev,
+                           (const double*)tgt_dev, corr_dev, n, partials);
+    else
+        hipLaunchKernelGGL(P2PointAccumulateKernel<float>, dim3(g),
+                           dim3(kReduceBlock), 0, s, (const float*)src_dev,
+                           (const float*)tgt_dev, corr_dev, n, partials);
+    hipLaunchKernelGGL(FinalReduceKernel, dim3(1), dim3(256), 0, s, partials, g,
+                       sums16_dev, 16, (double*)nullptr, (int*)nullptr, 0);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    O3DMI_HIP_CHECK(hipFreeAsync(partials, s));
+    return O3DMI_OK;
+}
+
+int o3dmi_icp_information_accumulate(const void* tgt_dev,
+                                     const int64_t* corr_dev, int64_t n,
+                                     int dtype, double* sums21_dev,
+                                     o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(tgt_dev && corr_dev && sums21_dev, "null argument");
+    O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
+                  "points must be Float32 or Float64");
+    hipStream_t s = (hipStream_t)stream;
+    int g = ReduceGrid(n);
+    double* partials = nullptr;
+    O3DMI_HIP_CHECK(hipMallocAsync((void**)&partials,
+                                   sizeof(double) * (size_t)g * kNumSums, s));
+    if (dtype == O3DMI_F64)
+        hipLaunchKernelGGL(InformationAccumulateKernel<double>, dim3(g),
+                           dim3(kReduceBlock), 0, s, (const double*)tgt_dev,
+                           corr_dev, n, partials);
+    else
+        hipLaunchKernelGGL(InformationAccumulateKernel<float>, dim3(g),
+                           dim3(kReduceBlock), 0, s, (const float*)tgt_dev,
+                           corr_dev, n, partials);
+    hipLaunchKernelGGL(FinalReduceKernel, dim3(1), dim3(256), 0, s, partials, g,
+                       sums21_dev, 21, (double*)nullptr, (int*)nullptr, 0);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    O3DMI_HIP_CHECK(hipFreeAsync(partials, s));
+    return O3DMI_OK;
+}
+
 int o3dmi_icp_search_accumulate_post(
         const o3dmi_nns_t* nns, const void* src_dev,
-        const void* tgt_normals_dev, int64_t n, int robust_kernel,
-        double scaling_parameter, double shape_parameter,
+        const void* tgt_normals_dev, int64_t n, int estimation,
+        int robust_kernel, double scaling_parameter, double shape_parameter,
         int64_t* corr_out_dev, double* sums32_dev, double* mail_data,
         int* mail_flag, int mail_seq, o3dmi_stream_t stream);
+
+int o3dmi_icp_search_accumulate_p2point(const o3dmi_nns_t* nns,
+                                        const void* src_dev, int64_t n,
+                                        int64_t* corr_out_dev,
+                                        double* sums32_dev,
+                                        o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(sums32_dev != nullptr, "null argument");
+    return o3dmi_icp_search_accumulate_post(nns, src_dev, nullptr, n, 1, 0, 1.0,
+                                            1.0, corr_out_dev, sums32_dev,
+                                            nullptr, nullptr, 0, stream);
+}
 
 int o3dmi_icp_search_accumulate(const o3dmi_nns_t* nns, const void* src_dev,
                                 const void* tgt_normals_dev, int64_t n,
@@ -851,30 +1003,35 @@ int o3dmi_icp_search_accumulate(const o3dmi_nns_t* nns, const void* src_dev,
                                 double* sums32_dev, o3dmi_stream_t stream) {
     O3DMI_REQUIRE(sums32_dev != nullptr, "null argument");
     return o3dmi_icp_search_accumulate_post(
-            nns, src_dev, tgt_normals_dev, n, robust_kernel, scaling_parameter,
-            shape_parameter, corr_out_dev, sums32_dev, nullptr, nullptr, 0,
-            stream);
+            nns, src_dev, tgt_normals_dev, n, 0, robust_kernel,
+            scaling_parameter, shape_parameter, corr_out_dev, sums32_dev,
+            nullptr, nullptr, 0, stream);
 }
 
 // Internal (not in the public header): also posts the 32 sums to a host
 // mailbox (mailbox.h) when mail_data != NULL; sums32_dev may then be NULL.
 int o3dmi_icp_search_accumulate_post(
         const o3dmi_nns_t* nns, const void* src_dev,
-        const void* tgt_normals_dev, int64_t n, int robust_kernel,
-        double scaling_parameter, double shape_parameter,
+        const void* tgt_normals_dev, int64_t n, int estimation,
+        int robust_kernel, double scaling_parameter, double shape_parameter,
         int64_t* corr_out_dev, double* sums32_dev, double* mail_data,
         int* mail_flag, int mail_seq, o3dmi_stream_t stream) {
     O3DMI_REQUIRE(nns && src_dev && (sums32_dev || mail_data), "null argument");
+    O3DMI_REQUIRE(estimation >= 0 && estimation <= 2,
+                  "estimation must be point-to-plane (0), point-to-point (1) "
+                  "or information (2)");
     O3DMI_REQUIRE(robust_kernel >= 0 && robust_kernel <= 6,
                   "Unsupported method.");
     hipStream_t s = (hipStream_t)stream;
-    if (tgt_normals_dev) {
-        int st = o3dmi_nns_set_normals(const_cast<o3dmi_nns_t*>(nns),
-                                       tgt_normals_dev, stream);
-        if (st != O3DMI_OK) return st;
+    if (estimation == 0) {
+        if (tgt_normals_dev) {
+            int st = o3dmi_nns_set_normals(const_cast<o3dmi_nns_t*>(nns),
+                                           tgt_normals_dev, stream);
+            if (st != O3DMI_OK) return st;
+        }
+        O3DMI_REQUIRE(nns->sorted_normals != nullptr,
+                      "Target pointcloud missing normals attribute.");
     }
-    O3DMI_REQUIRE(nns->sorted_normals != nullptr,
-                  "Target pointcloud missing normals attribute.");
     // Lanes per query: as many as keep the whole chip busy about once.
     int group = 32;
     while (group > 1 && n * group > (int64_t)kCUs * 2048) group >>= 1;
@@ -885,11 +1042,17 @@ int o3dmi_icp_search_accumulate_post(
     int g = ReduceGrid(n * group);
     RobustParams rp = MakeRobust(robust_kernel, scaling_parameter,
                                  shape_parameter);
-#define O3DMI_SEARCH(T, G)                                                     \
-    hipLaunchKernelGGL((SearchAccumulateKernel<T, G>), dim3(g),               \
+#define O3DMI_SEARCH_E(T, G, E)                                                \
+    hipLaunchKernelGGL((SearchAccumulateKernel<T, G, E>), dim3(g),            \
                        dim3(kReduceBlock), 0, s, MakeView<T>(nns),            \
                        (const Rec4<T>*)nns->sorted_normals,                   \
                        (const T*)src_dev, n, rp, corr_out_dev, nns->partials)
+#define O3DMI_SEARCH(T, G)                                                     \
+    do {                                                                      \
+        if (estimation == 0) O3DMI_SEARCH_E(T, G, 0);                         \
+        else if (estimation == 1) O3DMI_SEARCH_E(T, G, 1);                    \
+        else O3DMI_SEARCH_E(T, G, 2);                                         \
+    } while (0)
 #define O3DMI_SEARCH_G(T)                                                      \
     switch (group) {                                                          \
         case 32: O3DMI_SEARCH(T, 32); break;                                  \
@@ -903,6 +1066,7 @@ int o3dmi_icp_search_accumulate_post(
     else { O3DMI_SEARCH_G(float) }
 #undef O3DMI_SEARCH_G
 #undef O3DMI_SEARCH
+#undef O3DMI_SEARCH_E
     hipLaunchKernelGGL(FinalSumKernel<kNumSums>, dim3(1), dim3(kFinalThreads),
                        0, s, nns->partials, g, sums32_dev, mail_data, mail_flag,
                        mail_seq);
@@ -1004,6 +1168,127 @@ int o3dmi_decode_and_solve6x6(const double* A, double* pose6, float* residual,
     for (int j = 0; j < 6; ++j) pose6[j] = b[j];
     *residual = (float)A[27];
     *inlier_count = (int)A[28];
+    return O3DMI_OK;
+}
+
+// ComputeRtPointToPointCPU after its reduction (RegistrationCPU.cpp:640-650):
+// Sxy = U D V^T, R = U diag(1, 1, det(U) det(V)) V^T, t = mean_t - R mean_s.
+// The reference calls LAPACK gesvd; here a one-sided (Hestenes) Jacobi SVD in
+// float64: columns of G = Sxy V are rotated pairwise until orthogonal, then
+// u_i = g_i / |g_i|. The third left vector is taken as u_1 x u_2, which folds
+// the reflection test into det(V): with u_3 = e (u_1 x u_2), e = det(U),
+// det(U) det(V) u_3 = det(V) (u_1 x u_2). That also covers planar
+// correspondence sets (sigma_3 = 0) without dividing by sigma_3.
+int o3dmi_compute_rt_p2point(const double* sums, double* R9, double* t3) {
+    O3DMI_REQUIRE(sums && R9 && t3, "null argument");
+    const double cnt = sums[15];
+    if (!(cnt > 0)) {
+        SetLastError("No valid correspondence present.");
+        return O3DMI_ERR_NO_INLIERS;
+    }
+    double ms[3], mt[3];
+    for (int k = 0; k < 3; ++k) {
+        ms[k] = sums[k] / cnt;
+        mt[k] = sums[3 + k] / cnt;
+    }
+    double G[3][3], V[3][3];  // G[row][col]
+    for (int j = 0; j < 3; ++j)
+        for (int k = 0; k < 3; ++k) {
+            G[j][k] = sums[6 + 3 * j + k] / cnt - mt[j] * ms[k];
+            V[j][k] = j == k ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int r = 0; r < 3; ++r) {
+                    alpha += G[r][p] * G[r][p];
+                    beta += G[r][q] * G[r][q];
+                    gamma += G[r][p] * G[r][q];
+                }
+                if (gamma == 0.0 ||
+                    std::fabs(gamma) <= 1e-17 * std::sqrt(alpha * beta))
+                    continue;
+                rotated = true;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double tn = (zeta >= 0 ? 1.0 : -1.0) /
+                                  (std::fabs(zeta) +
+                                   std::sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / std::sqrt(1.0 + tn * tn);
+                const double sn = c * tn;
+                for (int r = 0; r < 3; ++r) {
+                    const double gp = G[r][p], gq = G[r][q];
+                    G[r][p] = c * gp - sn * gq;
+                    G[r][q] = sn * gp + c * gq;
+                    const double vp = V[r][p], vq = V[r][q];
+                    V[r][p] = c * vp - sn * vq;
+                    V[r][q] = sn * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    // column order by decreasing singular value
+    double sig[3];
+    int ord[3] = {0, 1, 2};
+    for (int c = 0; c < 3; ++c)
+        sig[c] = std::sqrt(G[0][c] * G[0][c] + G[1][c] * G[1][c] +
+                           G[2][c] * G[2][c]);
+    for (int a = 0; a < 2; ++a)
+        for (int b = a + 1; b < 3; ++b)
+            if (sig[ord[b]] > sig[ord[a]]) std::swap(ord[a], ord[b]);
+    double u[3][3], v[3][3];  // u[i] / v[i] = i-th singular vectors
+    for (int i = 0; i < 3; ++i)
+        for (int r = 0; r < 3; ++r) v[i][r] = V[r][ord[i]];
+    const double s0 = sig[ord[0]], s1 = sig[ord[1]];
+    if (!(s0 > 0)) {
+        // all correspondences coincide with their means: rotation undetermined,
+        // the least-squares answer is the pure translation.
+        for (int i = 0; i < 9; ++i) R9[i] = (i % 4 == 0) ? 1.0 : 0.0;
+        for (int k = 0; k < 3; ++k) t3[k] = mt[k] - ms[k];
+        return O3DMI_OK;
+    }
+    for (int r = 0; r < 3; ++r) u[0][r] = G[r][ord[0]] / s0;
+    if (s1 > 1e-300 && s1 > 1e-15 * s0) {
+        double d = 0, nrm = 0;
+        for (int r = 0; r < 3; ++r) u[1][r] = G[r][ord[1]] / s1;
+        for (int r = 0; r < 3; ++r) d += u[1][r] * u[0][r];
+        for (int r = 0; r < 3; ++r) {
+            u[1][r] -= d * u[0][r];
+            nrm += u[1][r] * u[1][r];
+        }
+        nrm = std::sqrt(nrm);
+        for (int r = 0; r < 3; ++r) u[1][r] /= nrm;
+    } else {
+        // rank one: any unit vector orthogonal to u_0
+        int m = 0;
+        for (int r = 1; r < 3; ++r)
+            if (std::fabs(u[0][r]) < std::fabs(u[0][m])) m = r;
+        double e[3] = {0, 0, 0};
+        e[m] = 1.0;
+        double d = u[0][m], nrm = 0;
+        for (int r = 0; r < 3; ++r) {
+            u[1][r] = e[r] - d * u[0][r];
+            nrm += u[1][r] * u[1][r];
+        }
+        nrm = std::sqrt(nrm);
+        for (int r = 0; r < 3; ++r) u[1][r] /= nrm;
+    }
+    u[2][0] = u[0][1] * u[1][2] - u[0][2] * u[1][1];
+    u[2][1] = u[0][2] * u[1][0] - u[0][0] * u[1][2];
+    u[2][2] = u[0][0] * u[1][1] - u[0][1] * u[1][0];
+    const double detV =
+            v[0][0] * (v[1][1] * v[2][2] - v[1][2] * v[2][1]) -
+            v[0][1] * (v[1][0] * v[2][2] - v[1][2] * v[2][0]) +
+            v[0][2] * (v[1][0] * v[2][1] - v[1][1] * v[2][0]);
+    const double sgn = detV < 0 ? -1.0 : 1.0;
+    for (int j = 0; j < 3; ++j)
+        for (int k = 0; k < 3; ++k)
+            R9[j * 3 + k] = u[0][j] * v[0][k] + u[1][j] * v[1][k] +
+                            sgn * u[2][j] * v[2][k];
+    for (int j = 0; j < 3; ++j)
+        t3[j] = mt[j] - (R9[j * 3 + 0] * ms[0] + R9[j * 3 + 1] * ms[1] +
+                         R9[j * 3 + 2] * ms[2]);
     return O3DMI_OK;
 }
 

@@ -1,5 +1,5 @@
 """Python mirror of open3d.t.pipelines.registration.{icp, multi_scale_icp}
-for the MI355X backend (point-to-plane estimator).
+for the MI355X backend (point-to-plane and point-to-point estimators).
 
 Argument names / defaults follow the reference's binding
 (cpp/pybind/t/pipelines/registration/registration.cpp) and
@@ -38,6 +38,11 @@ class TransformationEstimationPointToPlane:
         self.kernel = kernel or RobustKernel()
 
 
+class TransformationEstimationPointToPoint:
+    """TransformationEstimation.h:76-118; no robust kernel, no normals."""
+    kernel = RobustKernel()
+
+
 class RegistrationResult:
     def __init__(self):
         self.transformation = np.eye(4)
@@ -54,14 +59,22 @@ def multi_scale_icp(source, target, target_normals, voxel_sizes, criteria_list,
                     allreduce=None):
     """source/target/target_normals: device tensors {N,3}. `allreduce`
     (optional) sums a length-32 numpy float64 array over ranks in place."""
+    est = estimation_method or TransformationEstimationPointToPlane()
+    p2point = isinstance(est, TransformationEstimationPointToPoint)
     source = require_cuda(source, "source")
     target = require_cuda(target, "target")
-    target_normals = require_cuda(target_normals, "target_normals")
     if source.dtype not in (torch.float32, torch.float64):
         raise ValueError("Only Float32 and Float64 point clouds are supported.")
-    if target.dtype != source.dtype or target_normals.dtype != source.dtype:
+    if target.dtype != source.dtype:
         raise ValueError("source / target dtype mismatch")
-    est = estimation_method or TransformationEstimationPointToPlane()
+    if p2point:
+        target_normals = None
+    else:
+        if target_normals is None:
+            raise ValueError("Target pointcloud missing normals attribute.")
+        target_normals = require_cuda(target_normals, "target_normals")
+        if target_normals.dtype != source.dtype:
+            raise ValueError("source / target dtype mismatch")
     S = len(criteria_list)
     if not (len(voxel_sizes) == S and len(max_correspondence_distances) == S):
         raise ValueError("Size of criterias, voxel_size, "
@@ -98,10 +111,11 @@ def multi_scale_icp(source, target, target_normals, voxel_sizes, criteria_list,
             return 0
         ar = _lib.ALLREDUCE_SUM(_ar)
 
-    st = _lib.lib().o3dmi_registration_multiscale_icp(
-        _lib.ptr(source), ns, _lib.ptr(target), _lib.ptr(target_normals), nt,
+    st = _lib.lib().o3dmi_registration_multiscale_icp_ex(
+        _lib.ptr(source), ns, _lib.ptr(target),
+        _lib.ptr(target_normals) if target_normals is not None else None, nt,
         TORCH_TO_O3DMI[source.dtype], S, _lib.f64p(vs), crit, _lib.f64p(md),
-        _lib.f64p(init), int(est.kernel.type),
+        _lib.f64p(init), 1 if p2point else 0, int(est.kernel.type),
         C.c_double(est.kernel.scaling_parameter),
         C.c_double(est.kernel.shape_parameter), cb, None, ar, None,
         _lib.ptr(corr), C.byref(res), stream())
@@ -125,6 +139,56 @@ def icp(source, target, target_normals, max_correspondence_distance,
                            [max_correspondence_distance],
                            init_source_to_target, estimation_method,
                            callback_after_iteration, allreduce)
+
+
+def _check_pair(source, target):
+    source = require_cuda(source, "source")
+    target = require_cuda(target, "target")
+    if source.dtype not in (torch.float32, torch.float64):
+        raise ValueError("Only Float32 and Float64 point clouds are supported.")
+    if target.dtype != source.dtype:
+        raise ValueError("source / target dtype mismatch")
+    return source, target
+
+
+def evaluate_registration(source, target, max_correspondence_distance,
+                          transformation=None):
+    """t::pipelines::registration::EvaluateRegistration
+    (Registration.cpp:64-91)."""
+    source, target = _check_pair(source, target)
+    T = np.ascontiguousarray(
+        np.eye(4) if transformation is None else transformation,
+        dtype=np.float64)
+    ns = source.shape[0]
+    corr = torch.full((ns,), -1, dtype=torch.int64, device="cuda")
+    res = _lib.RegistrationResultC()
+    _lib.check(_lib.lib().o3dmi_registration_evaluate(
+        _lib.ptr(source), ns, _lib.ptr(target), target.shape[0],
+        TORCH_TO_O3DMI[source.dtype], C.c_double(max_correspondence_distance),
+        _lib.f64p(T), _lib.ptr(corr), C.byref(res), stream()),
+        "evaluate_registration")
+    out = RegistrationResult()
+    out.transformation = np.array(res.transformation[:]).reshape(4, 4)
+    out.inlier_rmse = res.inlier_rmse
+    out.fitness = res.fitness
+    out.correspondence_set = corr
+    return out
+
+
+def get_information_matrix(source, target, max_correspondence_distance,
+                           transformation=None):
+    """t::pipelines::registration::GetInformationMatrix
+    (Registration.cpp:446-486) -> {6,6} float64 (host)."""
+    source, target = _check_pair(source, target)
+    T = np.ascontiguousarray(
+        np.eye(4) if transformation is None else transformation,
+        dtype=np.float64)
+    G = np.zeros((6, 6), np.float64)
+    _lib.check(_lib.lib().o3dmi_registration_information_matrix(
+        _lib.ptr(source), source.shape[0], _lib.ptr(target), target.shape[0],
+        TORCH_TO_O3DMI[source.dtype], C.c_double(max_correspondence_distance),
+        _lib.f64p(T), _lib.f64p(G), stream()), "get_information_matrix")
+    return G
 
 
 def voxel_down_sample(positions, normals, voxel_size):

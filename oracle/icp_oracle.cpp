@@ -547,6 +547,283 @@ RegResult ComputeRegistrationResult(const T* source, int64_t ns,
     return result;
 }
 
+// ---------------------------------------------------------------------------
+// GetInformationMatrix, Registration.cpp:446-486 ->
+// ComputeInformationMatrixCPU, RegistrationCPU.cpp:652-735, with
+// GetInformationJacobians, RegistrationImpl.h:686-715. T = point dtype (each
+// term J_x[j] J_x[k] + J_y[j] J_y[k] + J_z[j] J_z[k] is formed in T), ACC =
+// accumulator type (T in the reference).
+template <typename T, typename ACC>
+void ComputeInformationMatrixKernel(const T* target_points_ptr,
+                                    const int64_t* correspondence_indices,
+                                    int64_t n, ACC* global_sum) {
+    ACC AtA[21];
+    for (int i = 0; i < 21; ++i) AtA[i] = 0;
+    for (int64_t w = 0; w < n; ++w) {
+        T J_x[6] = {0}, J_y[6] = {0}, J_z[6] = {0};
+        if (correspondence_indices[w] == -1) continue;
+        const int64_t target_idx = 3 * correspondence_indices[w];
+        J_x[0] = J_x[4] = J_x[5] = 0.0;
+        J_x[1] = target_points_ptr[target_idx + 2];
+        J_x[2] = -target_points_ptr[target_idx + 1];
+        J_x[3] = 1.0;
+        J_y[1] = J_y[3] = J_y[5] = 0.0;
+        J_y[0] = -target_points_ptr[target_idx + 2];
+        J_y[2] = target_points_ptr[target_idx];
+        J_y[4] = 1.0;
+        J_z[2] = J_z[3] = J_z[4] = 0.0;
+        J_z[0] = target_points_ptr[target_idx + 1];
+        J_z[1] = -target_points_ptr[target_idx];
+        J_z[5] = 1.0;
+        int i = 0;
+        for (int j = 0; j < 6; ++j) {
+            for (int k = 0; k <= j; ++k) {
+                AtA[i] += J_x[j] * J_x[k] + J_y[j] * J_y[k] + J_z[j] * J_z[k];
+                ++i;
+            }
+        }
+    }
+    for (int i = 0; i < 21; ++i) global_sum[i] = AtA[i];
+}
+
+template <typename T>
+int InformationMatrix(const T* source_in, int64_t ns, const T* target,
+                      int64_t nt, double max_dist, const double* transformation,
+                      int accumulate_double, double* GTG) {
+    std::vector<T> source(source_in, source_in + 3 * ns);
+    TransformPoints<T>(transformation, source.data(), ns);
+    std::vector<int32_t> idx((size_t)ns), counts((size_t)ns);
+    std::vector<T> distances((size_t)ns);
+    HybridSearch<T>(target, nt, source.data(), ns, max_dist, 1, idx.data(),
+                    distances.data(), counts.data());
+    std::vector<int64_t> corr((size_t)ns);
+    int64_t num = 0;
+    for (int64_t i = 0; i < ns; ++i) {
+        corr[(size_t)i] = idx[(size_t)i];
+        num += counts[(size_t)i];
+    }
+    if (num == 0) return 1;  // "0 correspondence present ..."
+    double sum[21];
+    if (accumulate_double) {
+        ComputeInformationMatrixKernel<T, double>(target, corr.data(), ns, sum);
+    } else {
+        T sf[21];
+        ComputeInformationMatrixKernel<T, T>(target, corr.data(), ns, sf);
+        for (int i = 0; i < 21; ++i) sum[i] = (double)sf[i];
+    }
+    int i = 0;
+    for (int j = 0; j < 6; j++)
+        for (int k = 0; k <= j; k++) {
+            GTG[j * 6 + k] = GTG[k * 6 + j] = sum[i];
+            ++i;
+        }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// TransformationEstimationPointToPoint
+// Get3x3SxyLinearSystem, t/pipelines/kernel/RegistrationCPU.cpp:495-617: means
+// of the matched source / target points (first reduction, :509-552), then the
+// centred cross products Sxy[j][k] = sum (t_j - mt_j)(s_k - ms_k) / count
+// (second reduction, :555-591, index i = 3 col + row with row = source
+// component, col = target component). T = point dtype (products and
+// differences in T as the reference), ACC = accumulator type (the reference
+// accumulates in T through tbb::parallel_reduce; one left-to-right pass is one
+// valid schedule of it).
+template <typename T, typename ACC>
+int64_t Get3x3Sxy(const T* source_points_ptr, const T* target_points_ptr,
+                  const int64_t* correspondence_indices, int64_t n, ACC* Sxy,
+                  ACC* source_mean, ACC* target_mean) {
+    ACC mean_1x7[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int64_t w = 0; w < n; ++w) {
+        if (correspondence_indices[w] != -1) {
+            int64_t target_idx = 3 * correspondence_indices[w];
+            mean_1x7[0] += source_points_ptr[3 * w];
+            mean_1x7[1] += source_points_ptr[3 * w + 1];
+            mean_1x7[2] += source_points_ptr[3 * w + 2];
+            mean_1x7[3] += target_points_ptr[target_idx];
+            mean_1x7[4] += target_points_ptr[target_idx + 1];
+            mean_1x7[5] += target_points_ptr[target_idx + 2];
+            mean_1x7[6] += 1;
+        }
+    }
+    if (mean_1x7[6] == 0) return 0;  // "No valid correspondence present."
+    for (int i = 0; i < 6; ++i) mean_1x7[i] = mean_1x7[i] / mean_1x7[6];
+    ACC sxy_1x9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t w = 0; w < n; ++w) {
+        if (correspondence_indices[w] != -1) {
+            for (int i = 0; i < 9; ++i) {
+                const int row = i % 3;
+                const int col = i / 3;
+                const int64_t source_idx = 3 * w + row;
+                const int64_t target_idx = 3 * correspondence_indices[w] + col;
+                sxy_1x9[i] += (source_points_ptr[source_idx] - mean_1x7[row]) *
+                              (target_points_ptr[target_idx] - mean_1x7[3 + col]);
+            }
+        }
+    }
+    int i = 0;
+    for (int j = 0; j < 3; ++j) {
+        for (int k = 0; k < 3; ++k) {
+            Sxy[j * 3 + k] = sxy_1x9[i] / mean_1x7[6];
+            ++i;
+        }
+        source_mean[j] = mean_1x7[j];
+        target_mean[j] = mean_1x7[j + 3];
+    }
+    return (int64_t)mean_1x7[6];
+}
+
+// Tensor::SVD is LAPACK ?gesvd (core/linalg/SVD.cpp), absent from
+// /root/reference: restated as the textbook route for a 3x3 matrix --
+// eigen-decomposition of S^T S by cyclic Jacobi rotations (V, sigma^2), then
+// u_i = S v_i / sigma_i, completed to an orthonormal basis when sigma_i = 0.
+// For a non-degenerate S the product U diag(1,1,det U det V) V^T below does not
+// depend on which SVD routine produced U and V; tests pin this against
+// numpy.linalg.svd (also LAPACK).
+template <typename S>
+void SVD3x3(const S* A, S* U, S* D, S* V) {
+    S B[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            S v = 0;
+            for (int k = 0; k < 3; ++k) v += A[k * 3 + i] * A[k * 3 + j];
+            B[i * 3 + j] = v;
+        }
+    for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? S(1) : S(0);
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        S off = std::abs(B[1]) + std::abs(B[2]) + std::abs(B[5]);
+        S diag = std::abs(B[0]) + std::abs(B[4]) + std::abs(B[8]);
+        if (off <= std::numeric_limits<S>::epsilon() * S(1e-3) * diag) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                S apq = B[p * 3 + q];
+                if (apq == S(0)) continue;
+                S theta = (B[q * 3 + q] - B[p * 3 + p]) / (S(2) * apq);
+                S t = (theta >= 0 ? S(1) : S(-1)) /
+                      (std::abs(theta) + std::sqrt(theta * theta + S(1)));
+                S c = S(1) / std::sqrt(t * t + S(1)), sn = t * c;
+                for (int k = 0; k < 3; ++k) {  // B <- B J
+                    S bkp = B[k * 3 + p], bkq = B[k * 3 + q];
+                    B[k * 3 + p] = c * bkp - sn * bkq;
+                    B[k * 3 + q] = sn * bkp + c * bkq;
+                }
+                for (int k = 0; k < 3; ++k) {  // B <- J^T B
+                    S bpk = B[p * 3 + k], bqk = B[q * 3 + k];
+                    B[p * 3 + k] = c * bpk - sn * bqk;
+                    B[q * 3 + k] = sn * bpk + c * bqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    S vkp = V[k * 3 + p], vkq = V[k * 3 + q];
+                    V[k * 3 + p] = c * vkp - sn * vkq;
+                    V[k * 3 + q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    int ord[3] = {0, 1, 2};
+    for (int a = 0; a < 2; ++a)
+        for (int b = a + 1; b < 3; ++b)
+            if (B[ord[b] * 4] > B[ord[a] * 4]) std::swap(ord[a], ord[b]);
+    S Vs[9];
+    for (int i = 0; i < 3; ++i)
+        for (int r = 0; r < 3; ++r) Vs[r * 3 + i] = V[r * 3 + ord[i]];
+    std::memcpy(V, Vs, sizeof(Vs));
+    S u[3][3];
+    int have = 0;
+    for (int i = 0; i < 3; ++i) {
+        S g[3], nn = 0;
+        for (int r = 0; r < 3; ++r) {
+            g[r] = A[r * 3 + 0] * V[0 * 3 + i] + A[r * 3 + 1] * V[1 * 3 + i] +
+                   A[r * 3 + 2] * V[2 * 3 + i];
+        }
+        for (int r = 0; r < 3; ++r) nn += g[r] * g[r];
+        nn = std::sqrt(nn);
+        D[i] = nn;
+        S lim = (i == 0) ? S(0)
+                         : D[0] * std::numeric_limits<S>::epsilon() * S(16);
+        if (nn > lim) {
+            for (int h = 0; h < have; ++h) {
+                S d = g[0] * u[h][0] + g[1] * u[h][1] + g[2] * u[h][2];
+                for (int r = 0; r < 3; ++r) g[r] -= d * u[h][r];
+            }
+            S n2 = std::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+            for (int r = 0; r < 3; ++r) u[i][r] = g[r] / n2;
+        } else if (have == 2) {
+            u[2][0] = u[0][1] * u[1][2] - u[0][2] * u[1][1];
+            u[2][1] = u[0][2] * u[1][0] - u[0][0] * u[1][2];
+            u[2][2] = u[0][0] * u[1][1] - u[0][1] * u[1][0];
+        } else {
+            int m = 0;
+            if (have == 1) {
+                for (int r = 1; r < 3; ++r)
+                    if (std::abs(u[0][r]) < std::abs(u[0][m])) m = r;
+            }
+            S e[3] = {0, 0, 0};
+            e[m] = 1;
+            for (int h = 0; h < have; ++h) {
+                S d = e[0] * u[h][0] + e[1] * u[h][1] + e[2] * u[h][2];
+                for (int r = 0; r < 3; ++r) e[r] -= d * u[h][r];
+            }
+            S n2 = std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+            for (int r = 0; r < 3; ++r) u[i][r] = e[r] / n2;
+        }
+        ++have;
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int r = 0; r < 3; ++r) U[r * 3 + i] = u[i][r];
+}
+
+template <typename S>
+S Det3(const S* M) {
+    return M[0] * (M[4] * M[8] - M[5] * M[7]) -
+           M[1] * (M[3] * M[8] - M[5] * M[6]) +
+           M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+// ComputeRtPointToPointCPU after the reduction, RegistrationCPU.cpp:640-650:
+//   U, D, VT = Sxy.SVD();  S = I;  if det(U) det(VT^T) < 0: S[2][2] = -1
+//   R = U S VT;  t = target_mean - R source_mean            (all in dtype S)
+template <typename S>
+void RtFromSxy(const S* Sxy, const S* source_mean, const S* target_mean,
+               double* R9, double* t3) {
+    S U[9], D[3], V[9];
+    SVD3x3<S>(Sxy, U, D, V);
+    S sg = (Det3(U) * Det3(V) < 0) ? S(-1) : S(1);
+    S R[9];
+    for (int j = 0; j < 3; ++j)
+        for (int k = 0; k < 3; ++k)
+            R[j * 3 + k] = U[j * 3 + 0] * V[k * 3 + 0] +
+                           U[j * 3 + 1] * V[k * 3 + 1] +
+                           sg * U[j * 3 + 2] * V[k * 3 + 2];
+    for (int j = 0; j < 3; ++j) {
+        S rt = R[j * 3 + 0] * source_mean[0] + R[j * 3 + 1] * source_mean[1] +
+               R[j * 3 + 2] * source_mean[2];
+        t3[j] = (double)(S)(target_mean[j] - rt);
+    }
+    for (int i = 0; i < 9; ++i) R9[i] = (double)R[i];
+}
+
+// ComputeRtPointToPoint for point dtype T; accumulate_double widens the
+// accumulators, the SVD and R, t to float64 (the comparison target for the
+// GPU path, which reduces in float64).
+template <typename T>
+int64_t ComputeRtPointToPoint(const T* src, const T* tgt, const int64_t* corr,
+                              int64_t n, int accumulate_double, double* R9,
+                              double* t3) {
+    if (accumulate_double || sizeof(T) == 8) {
+        double Sxy[9], ms[3], mt[3];
+        int64_t c = Get3x3Sxy<T, double>(src, tgt, corr, n, Sxy, ms, mt);
+        if (c == 0) return 0;
+        RtFromSxy<double>(Sxy, ms, mt, R9, t3);
+        return c;
+    }
+    T Sxy[9], ms[3], mt[3];
+    int64_t c = Get3x3Sxy<T, T>(src, tgt, corr, n, Sxy, ms, mt);
+    if (c == 0) return 0;
+    RtFromSxy<T>(Sxy, ms, mt, R9, t3);
+    return c;
+}
+
 typedef void (*icp_callback_t)(int64_t iteration_index, int64_t scale_index,
                                int64_t scale_iteration_index, double inlier_rmse,
                                double fitness, const double* transformation,
@@ -561,7 +838,8 @@ int MultiScaleICP(const T* source_in, int64_t ns_in, const T* target_in,
                   const double* relative_fitness, const double* relative_rmse,
                   const double* max_dists, const double* init, int kernel_method,
                   double kernel_scale, double kernel_shape, int accumulate_double,
-                  double* out_T, double* out_fitness, double* out_rmse,
+                  int estimation, double* out_T, double* out_fitness,
+                  double* out_rmse,
                   int* out_converged, int* out_num_iterations,
                   int64_t* out_correspondences, int64_t* out_num_corr,
                   icp_callback_t cb, void* user) {
@@ -580,7 +858,11 @@ int MultiScaleICP(const T* source_in, int64_t ns_in, const T* target_in,
     };
     std::vector<T> s0(source_in, source_in + 3 * ns_in);
     std::vector<T> t0(target_in, target_in + 3 * nt_in);
-    std::vector<T> n0(target_normals_in, target_normals_in + 3 * nt_in);
+    std::vector<T> n0;
+    if (target_normals_in)
+        n0.assign(target_normals_in, target_normals_in + 3 * nt_in);
+    else
+        n0.assign((size_t)(3 * nt_in), T(0));  // point-to-point: unused
     int last = num_scales - 1;
     if (voxel_sizes[last] <= 0) {
         src_p[last] = s0;
@@ -628,6 +910,38 @@ int MultiScaleICP(const T* source_in, int64_t ns_in, const T* target_in,
                     r2.num_iterations = it;
                     early_return = true;
                     break;
+                }
+                if (estimation == 1) {
+                    // TransformationEstimationPointToPoint::
+                    // ComputeTransformation, TransformationEstimation.cpp:
+                    // 132-160 (RtToTransformation: R, t into a Float64 4x4).
+                    double R9[9], t3[3], update[16];
+                    ComputeRtPointToPoint<T>(source.data(), target.data(),
+                                             r2.correspondences.data(), ns,
+                                             accumulate_double, R9, t3);
+                    Eye4(update);
+                    for (int j = 0; j < 3; ++j) {
+                        for (int k = 0; k < 3; ++k)
+                            update[j * 4 + k] = R9[j * 3 + k];
+                        update[j * 4 + 3] = t3[j];
+                    }
+                    Matmul4(update, r2.T, r2.T);
+                    TransformPoints<T>(update, source.data(), ns);
+                    if (cb) {
+                        cb(iteration_count + it, scale_idx, it, r2.inlier_rmse,
+                           r2.fitness, r2.T, user);
+                    }
+                    if (it != 0 &&
+                        std::abs(prev_fitness - r2.fitness) <
+                                relative_fitness[scale_idx] &&
+                        std::abs(prev_inlier_rmse - r2.inlier_rmse) <
+                                relative_rmse[scale_idx]) {
+                        r2.converged = true;
+                        break;
+                    }
+                    prev_fitness = r2.fitness;
+                    prev_inlier_rmse = r2.inlier_rmse;
+                    continue;
                 }
                 double A[29];
                 if (accumulate_double) {
@@ -1137,6 +1451,147 @@ int64_t orc_voxel_down_sample(const void* pos, const void* nrm, int64_t n,
                                   voxel_size, (float*)out_pos, (float*)out_nrm);
 }
 
+void orc_information_accumulate(const void* tgt, const int64_t* corr,
+                                int64_t n, int is_f64, int accumulate_double,
+                                double* out21) {
+    if (is_f64) {
+        ComputeInformationMatrixKernel<double, double>((const double*)tgt, corr,
+                                                       n, out21);
+    } else if (accumulate_double) {
+        ComputeInformationMatrixKernel<float, double>((const float*)tgt, corr,
+                                                      n, out21);
+    } else {
+        float A[21];
+        ComputeInformationMatrixKernel<float, float>((const float*)tgt, corr, n,
+                                                     A);
+        for (int i = 0; i < 21; ++i) out21[i] = (double)A[i];
+    }
+}
+
+int orc_information_matrix(const void* source, int64_t ns, const void* target,
+                           int64_t nt, int is_f64, double max_dist,
+                           const double* transformation, int accumulate_double,
+                           double* GTG36) {
+    if (is_f64)
+        return InformationMatrix<double>((const double*)source, ns,
+                                         (const double*)target, nt, max_dist,
+                                         transformation, 1, GTG36);
+    return InformationMatrix<float>((const float*)source, ns,
+                                    (const float*)target, nt, max_dist,
+                                    transformation, accumulate_double, GTG36);
+}
+
+// EvaluateRegistration, Registration.cpp:64-91.
+void orc_evaluate_registration(const void* source, int64_t ns,
+                               const void* target, int64_t nt, int is_f64,
+                               double max_dist, const double* transformation,
+                               double* out_T, double* out_fitness,
+                               double* out_rmse, int64_t* out_corr) {
+    RegResult r;
+    if (is_f64) {
+        std::vector<double> s((const double*)source,
+                              (const double*)source + 3 * ns);
+        TransformPoints<double>(transformation, s.data(), ns);
+        r = ComputeRegistrationResult<double>(s.data(), ns,
+                                              (const double*)target, nt,
+                                              max_dist, transformation);
+    } else {
+        std::vector<float> s((const float*)source,
+                             (const float*)source + 3 * ns);
+        TransformPoints<float>(transformation, s.data(), ns);
+        r = ComputeRegistrationResult<float>(s.data(), ns, (const float*)target,
+                                             nt, max_dist, transformation);
+    }
+    std::memcpy(out_T, r.T, sizeof(r.T));
+    *out_fitness = r.fitness;
+    *out_rmse = r.inlier_rmse;
+    if (out_corr)
+        for (int64_t i = 0; i < ns; ++i) out_corr[i] = r.correspondences[(size_t)i];
+}
+
+// R9 (row-major), t3 as float64; returns the number of correspondences.
+int64_t orc_compute_rt_p2point(const void* src, const void* tgt,
+                               const int64_t* corr, int64_t n, int is_f64,
+                               int accumulate_double, double* R9, double* t3) {
+    if (is_f64)
+        return ComputeRtPointToPoint<double>((const double*)src,
+                                             (const double*)tgt, corr, n, 1, R9,
+                                             t3);
+    return ComputeRtPointToPoint<float>((const float*)src, (const float*)tgt,
+                                        corr, n, accumulate_double, R9, t3);
+}
+
+// Sxy {3,3}, means {3}: in the point dtype widened to double (what the
+// reference's Get3x3SxyLinearSystem returns), or accumulated in double.
+int64_t orc_p2point_sxy(const void* src, const void* tgt, const int64_t* corr,
+                        int64_t n, int is_f64, int accumulate_double,
+                        double* Sxy9, double* source_mean3,
+                        double* target_mean3) {
+    if (is_f64)
+        return Get3x3Sxy<double, double>((const double*)src, (const double*)tgt,
+                                         corr, n, Sxy9, source_mean3,
+                                         target_mean3);
+    if (accumulate_double)
+        return Get3x3Sxy<float, double>((const float*)src, (const float*)tgt,
+                                        corr, n, Sxy9, source_mean3,
+                                        target_mean3);
+    float S[9], ms[3], mt[3];
+    int64_t c = Get3x3Sxy<float, float>((const float*)src, (const float*)tgt,
+                                        corr, n, S, ms, mt);
+    for (int i = 0; i < 9; ++i) Sxy9[i] = S[i];
+    for (int i = 0; i < 3; ++i) {
+        source_mean3[i] = ms[i];
+        target_mean3[i] = mt[i];
+    }
+    return c;
+}
+
+void orc_rt_from_sxy(const double* Sxy9, const double* source_mean3,
+                     const double* target_mean3, int as_f32, double* R9,
+                     double* t3) {
+    if (as_f32) {
+        float S[9], ms[3], mt[3];
+        for (int i = 0; i < 9; ++i) S[i] = (float)Sxy9[i];
+        for (int i = 0; i < 3; ++i) {
+            ms[i] = (float)source_mean3[i];
+            mt[i] = (float)target_mean3[i];
+        }
+        RtFromSxy<float>(S, ms, mt, R9, t3);
+    } else {
+        RtFromSxy<double>(Sxy9, source_mean3, target_mean3, R9, t3);
+    }
+}
+
+int orc_multiscale_icp_ex(const void* source, int64_t ns, const void* target,
+                          const void* target_normals, int64_t nt, int is_f64,
+                          int num_scales, const double* voxel_sizes,
+                          const int* max_iterations, const double* rel_fitness,
+                          const double* rel_rmse, const double* max_dists,
+                          const double* init, int estimation, int kernel_method,
+                          double kernel_scale, double kernel_shape,
+                          int accumulate_double, double* out_T,
+                          double* out_fitness, double* out_rmse,
+                          int* out_converged, int* out_num_iterations,
+                          int64_t* out_correspondences, int64_t* out_num_corr,
+                          icp_callback_t cb, void* user) {
+    if (is_f64)
+        return MultiScaleICP<double>(
+                (const double*)source, ns, (const double*)target,
+                (const double*)target_normals, nt, num_scales, voxel_sizes,
+                max_iterations, rel_fitness, rel_rmse, max_dists, init,
+                kernel_method, kernel_scale, kernel_shape, accumulate_double,
+                estimation, out_T, out_fitness, out_rmse, out_converged,
+                out_num_iterations, out_correspondences, out_num_corr, cb,
+                user);
+    return MultiScaleICP<float>(
+            (const float*)source, ns, (const float*)target,
+            (const float*)target_normals, nt, num_scales, voxel_sizes,
+            max_iterations, rel_fitness, rel_rmse, max_dists, init,
+            kernel_method, kernel_scale, kernel_shape, accumulate_double,
+            estimation, out_T, out_fitness, out_rmse, out_converged,
+            out_num_iterations, out_correspondences, out_num_corr, cb, user);
+}
+
 int orc_multiscale_icp(const void* source, int64_t ns, const void* target,
                        const void* target_normals, int64_t nt, int is_f64,
                        int num_scales, const double* voxel_sizes,
@@ -1155,15 +1610,15 @@ int orc_multiscale_icp(const void* source, int64_t ns, const void* target,
                 (const double*)target_normals, nt, num_scales, voxel_sizes,
                 max_iterations, rel_fitness, rel_rmse, max_dists, init,
                 kernel_method, kernel_scale, kernel_shape, accumulate_double,
-                out_T, out_fitness, out_rmse, out_converged,
+                0, out_T, out_fitness, out_rmse, out_converged,
                 out_num_iterations, out_correspondences, out_num_corr, cb,
                 user);
     return MultiScaleICP<float>(
             (const float*)source, ns, (const float*)target,
             (const float*)target_normals, nt, num_scales, voxel_sizes,
             max_iterations, rel_fitness, rel_rmse, max_dists, init,
-            kernel_method, kernel_scale, kernel_shape, accumulate_double, out_T,
-            out_fitness, out_rmse, out_converged, out_num_iterations,
+            kernel_method, kernel_scale, kernel_shape, accumulate_double, 0,
+            out_T, out_fitness, out_rmse, out_converged, out_num_iterations,
             out_correspondences, out_num_corr, cb, user);
 }
 

@@ -419,6 +419,50 @@ int ref_p2plane_accumulate(const void* src, const void* tgt, const void* tgt_n,
     });
 }
 
+// ComputeInformationMatrixCPU, RegistrationCPU.cpp:703-735: GTG {6,6} float64
+// (the 21 sums are accumulated in the point dtype).
+int ref_information_matrix(const void* tgt, const int64_t* corr, int64_t n,
+                           int64_t n_tgt, int is_f64, double* GTG36) {
+    return Guard([&] {
+        const core::Dtype dt = is_f64 ? core::Float64 : core::Float32;
+        Tensor t = Wrap(tgt, {n_tgt, 3}, dt), c = Wrap(corr, {n}, core::Int64);
+        Tensor info = Tensor::Empty({6, 6}, core::Float64);
+        pk::ComputeInformationMatrixCPU(t, c, info, dt, core::Device("CPU:0"));
+        std::memcpy(GTG36, info.GetDataPtr<double>(), sizeof(double) * 36);
+    });
+}
+
+// Get3x3SxyLinearSystem, RegistrationCPU.cpp:495-617 (the reduction of
+// ComputeRtPointToPointCPU): Sxy {3,3}, source_mean, target_mean in the point
+// dtype (widened to double for the caller), inlier count.
+int ref_p2point_sxy(const void* src, const void* tgt, const int64_t* corr,
+                    int64_t n, int is_f64, double* Sxy9, double* source_mean3,
+                    double* target_mean3, int* inlier_count) {
+    return Guard([&] {
+        const core::Dtype dt = is_f64 ? core::Float64 : core::Float32;
+        Tensor Sxy, target_mean, source_mean;
+        if (is_f64)
+            pk::Get3x3SxyLinearSystem<double>(
+                    (const double*)src, (const double*)tgt, corr, (int)n, dt,
+                    core::Device("CPU:0"), Sxy, target_mean, source_mean,
+                    *inlier_count);
+        else
+            pk::Get3x3SxyLinearSystem<float>(
+                    (const float*)src, (const float*)tgt, corr, (int)n, dt,
+                    core::Device("CPU:0"), Sxy, target_mean, source_mean,
+                    *inlier_count);
+        for (int i = 0; i < 9; ++i)
+            Sxy9[i] = is_f64 ? Sxy.GetDataPtr<double>()[i]
+                             : (double)Sxy.GetDataPtr<float>()[i];
+        for (int i = 0; i < 3; ++i) {
+            source_mean3[i] = is_f64 ? source_mean.GetDataPtr<double>()[i]
+                                     : (double)source_mean.GetDataPtr<float>()[i];
+            target_mean3[i] = is_f64 ? target_mean.GetDataPtr<double>()[i]
+                                     : (double)target_mean.GetDataPtr<float>()[i];
+        }
+    });
+}
+
 // ComputePosePointToPlaneCPU, RegistrationCPU.cpp:92-122 (reduction + decode +
 // solve): pose {6} float64, residual, inlier count.
 int ref_compute_pose_p2plane(const void* src, const void* tgt,

@@ -323,6 +323,97 @@ def p2plane_accumulate(src, tgt, tgt_n, corr, method=0, scaling=1.0, shape=1.0,
     return out
 
 
+def information_accumulate(tgt, corr, accumulate_double=False):
+    """The 21 packed sums of ComputeInformationMatrixKernelCPU."""
+    tgt = np.ascontiguousarray(tgt)
+    corr = np.ascontiguousarray(corr, dtype=np.int64).reshape(-1)
+    out = np.zeros(21, np.float64)
+    lib().orc_information_accumulate(_p(tgt), _p(corr),
+                                     C.c_int64(corr.shape[0]),
+                                     int(tgt.dtype == np.float64),
+                                     int(accumulate_double), _p(out))
+    return out
+
+
+def unpack21(sums21):
+    G = np.zeros((6, 6))
+    i = 0
+    for j in range(6):
+        for k in range(j + 1):
+            G[j, k] = G[k, j] = sums21[i]
+            i += 1
+    return G
+
+
+def information_matrix(source, target, max_dist, transformation=None,
+                       accumulate_double=False):
+    """registration::GetInformationMatrix -> (status, GTG {6,6})."""
+    source = np.ascontiguousarray(source)
+    target = np.ascontiguousarray(target, dtype=source.dtype)
+    T = _f64(np.eye(4) if transformation is None else transformation)
+    G = np.zeros((6, 6), np.float64)
+    st = lib().orc_information_matrix(
+        _p(source), C.c_int64(source.shape[0]), _p(target),
+        C.c_int64(target.shape[0]), int(source.dtype == np.float64),
+        C.c_double(max_dist), _p(T), int(accumulate_double), _p(G))
+    return st, G
+
+
+def evaluate_registration(source, target, max_dist, transformation=None):
+    """registration::EvaluateRegistration."""
+    source = np.ascontiguousarray(source)
+    target = np.ascontiguousarray(target, dtype=source.dtype)
+    T = _f64(np.eye(4) if transformation is None else transformation)
+    outT = np.zeros((4, 4), np.float64)
+    fit, rmse = C.c_double(0), C.c_double(0)
+    corr = np.zeros(source.shape[0], np.int64)
+    lib().orc_evaluate_registration(
+        _p(source), C.c_int64(source.shape[0]), _p(target),
+        C.c_int64(target.shape[0]), int(source.dtype == np.float64),
+        C.c_double(max_dist), _p(T), _p(outT), C.byref(fit), C.byref(rmse),
+        _p(corr))
+    return dict(transformation=outT, fitness=fit.value, inlier_rmse=rmse.value,
+                correspondences=corr)
+
+
+def compute_rt_p2point(src, tgt, corr, accumulate_double=False):
+    """ComputeRtPointToPoint: (R {3,3}, t {3}, count)."""
+    src = np.ascontiguousarray(src)
+    tgt = np.ascontiguousarray(tgt, dtype=src.dtype)
+    corr = np.ascontiguousarray(corr, dtype=np.int64).reshape(-1)
+    R = np.zeros((3, 3), np.float64)
+    t = np.zeros(3, np.float64)
+    f = lib().orc_compute_rt_p2point
+    f.restype = C.c_int64
+    c = f(_p(src), _p(tgt), _p(corr), C.c_int64(src.shape[0]),
+          int(src.dtype == np.float64), int(accumulate_double), _p(R), _p(t))
+    return R, t, int(c)
+
+
+def p2point_sxy(src, tgt, corr, accumulate_double=False):
+    """Get3x3SxyLinearSystem: (Sxy {3,3}, source_mean, target_mean, count)."""
+    src = np.ascontiguousarray(src)
+    tgt = np.ascontiguousarray(tgt, dtype=src.dtype)
+    corr = np.ascontiguousarray(corr, dtype=np.int64).reshape(-1)
+    S = np.zeros((3, 3), np.float64)
+    ms = np.zeros(3, np.float64)
+    mt = np.zeros(3, np.float64)
+    f = lib().orc_p2point_sxy
+    f.restype = C.c_int64
+    c = f(_p(src), _p(tgt), _p(corr), C.c_int64(src.shape[0]),
+          int(src.dtype == np.float64), int(accumulate_double), _p(S), _p(ms),
+          _p(mt))
+    return S, ms, mt, int(c)
+
+
+def rt_from_sxy(Sxy, source_mean, target_mean, as_f32=False):
+    R = np.zeros((3, 3), np.float64)
+    t = np.zeros(3, np.float64)
+    lib().orc_rt_from_sxy(_p(_f64(Sxy)), _p(_f64(source_mean)),
+                          _p(_f64(target_mean)), int(as_f32), _p(R), _p(t))
+    return R, t
+
+
 def decode_and_solve6x6(A29):
     A29 = _f64(A29)
     pose = np.zeros(6, np.float64)
@@ -398,12 +489,14 @@ ICP_CB = C.CFUNCTYPE(None, C.c_int64, C.c_int64, C.c_int64, C.c_double,
 
 def multiscale_icp(source, target, target_normals, voxel_sizes, criterias,
                    max_dists, init=None, kernel=(0, 1.0, 1.0),
-                   accumulate_double=False, callback=None):
-    """criterias: list of (relative_fitness, relative_rmse, max_iteration)."""
+                   accumulate_double=False, callback=None, estimation=0):
+    """criterias: list of (relative_fitness, relative_rmse, max_iteration).
+    estimation: 0 = point-to-plane, 1 = point-to-point (normals unused)."""
     source = np.ascontiguousarray(source)
     dt = source.dtype
     target = np.ascontiguousarray(target, dtype=dt)
-    target_normals = np.ascontiguousarray(target_normals, dtype=dt)
+    if target_normals is not None:
+        target_normals = np.ascontiguousarray(target_normals, dtype=dt)
     ns, nt = source.shape[0], target.shape[0]
     S = len(criterias)
     vs = _f64(voxel_sizes)
@@ -425,10 +518,11 @@ def multiscale_icp(source, target, target_normals, voxel_sizes, criterias,
                           transformation=np.ctypeslib.as_array(
                                   Tp, shape=(16,)).reshape(4, 4).copy()))
         cb = ICP_CB(_cb)
-    st = lib().orc_multiscale_icp(
-            _p(source), C.c_int64(ns), _p(target), _p(target_normals),
+    st = lib().orc_multiscale_icp_ex(
+            _p(source), C.c_int64(ns), _p(target),
+            _p(target_normals) if target_normals is not None else None,
             C.c_int64(nt), int(dt == np.float64), int(S), _p(vs), _p(mi),
-            _p(rf), _p(rr), _p(md), _p(init), int(kernel[0]),
+            _p(rf), _p(rr), _p(md), _p(init), int(estimation), int(kernel[0]),
             C.c_double(kernel[1]), C.c_double(kernel[2]),
             int(accumulate_double), _p(T), C.byref(fit), C.byref(rmse),
             C.byref(conv), C.byref(nit), _p(corr), C.byref(ncorr), cb, None)

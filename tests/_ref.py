@@ -217,6 +217,34 @@ def p2plane_accumulate(src, tgt, tgt_n, corr, method=0, scaling=1.0,
     return out
 
 
+def information_matrix(tgt, corr):
+    """ComputeInformationMatrixCPU: GTG {6,6} float64."""
+    tgt = np.ascontiguousarray(tgt)
+    corr = np.ascontiguousarray(corr, dtype=np.int64).reshape(-1)
+    G = np.zeros((6, 6), np.float64)
+    _check(lib().ref_information_matrix(
+        _p(tgt), _p(corr), C.c_int64(corr.shape[0]), C.c_int64(tgt.shape[0]),
+        int(tgt.dtype == np.float64), _p(G)), "ref_information_matrix")
+    return G
+
+
+def p2point_sxy(src, tgt, corr):
+    """Get3x3SxyLinearSystem (RegistrationCPU.cpp:495-617) in the point dtype:
+    (Sxy {3,3}, source_mean {3}, target_mean {3}, inlier_count)."""
+    src = np.ascontiguousarray(src)
+    tgt = np.ascontiguousarray(tgt, dtype=src.dtype)
+    corr = np.ascontiguousarray(corr, dtype=np.int64).reshape(-1)
+    S = np.zeros((3, 3), np.float64)
+    ms = np.zeros(3, np.float64)
+    mt = np.zeros(3, np.float64)
+    cnt = C.c_int(0)
+    _check(lib().ref_p2point_sxy(
+        _p(src), _p(tgt), _p(corr), C.c_int64(src.shape[0]),
+        int(src.dtype == np.float64), _p(S), _p(ms), _p(mt), C.byref(cnt)),
+        "ref_p2point_sxy")
+    return S, ms, mt, cnt.value
+
+
 def compute_pose_p2plane(src, tgt, tgt_n, corr, method=0, scaling=1.0,
                          shape=1.0):
     src = np.ascontiguousarray(src)

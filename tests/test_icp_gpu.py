@@ -367,3 +367,214 @@ def test_icp_c5_size_1m_points():
     assert np.array_equal(got.correspondence_set.cpu().numpy(),
                           want["correspondences"])
     assert abs(got.fitness - want["fitness"]) < 1e-12
+
+
+# ------------------------------------------------------- point-to-point (f4)
+def _p2point_sums(_lib, s, t, corr):
+    from open3d_amd.core import TORCH_TO_O3DMI, stream
+    ts, tt = torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda()
+    tc = torch.from_numpy(corr).cuda()
+    out = torch.zeros(16, dtype=torch.float64, device="cuda")
+    _lib.check(_lib.lib().o3dmi_icp_p2point_accumulate(
+        _lib.ptr(ts), _lib.ptr(tt), _lib.ptr(tc), ts.shape[0],
+        TORCH_TO_O3DMI[ts.dtype], _lib.ptr(out), stream()), "p2point")
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_p2point_accumulate_and_rt_parity(dtype):
+    """ComputeRtPointToPoint: the one-pass float64 moments vs numpy, and the
+    R, t they give vs the oracle's two-pass restatement of
+    Get3x3SxyLinearSystem + SVD (accumulating in float64)."""
+    _lib, reg = _gpu()
+    p = _pair(30000, seed=21, dtype=dtype)
+    idx, d2, cnt = orc.hybrid_search(p["target"], p["source"], 0.07, 1)
+    corr = idx[:, 0].astype(np.int64)
+    assert 0 < (corr < 0).sum() < corr.size
+    sums = _p2point_sums(_lib, p["source"], p["target"], corr)
+    m = corr >= 0
+    s64 = p["source"][m].astype(np.float64)
+    t64 = p["target"][corr[m]].astype(np.float64)
+    want = np.concatenate([s64.sum(0), t64.sum(0), (t64.T @ s64).reshape(-1),
+                           [m.sum()]])
+    assert sums[15] == m.sum()
+    assert np.allclose(sums, want, rtol=1e-12, atol=1e-9)
+    R = np.zeros(9)
+    t = np.zeros(3)
+    _lib.check(_lib.lib().o3dmi_compute_rt_p2point(
+        _lib.f64p(sums), _lib.f64p(R), _lib.f64p(t)), "rt")
+    Ro, to, c = orc.compute_rt_p2point(p["source"], p["target"], corr,
+                                       accumulate_double=True)
+    assert c == m.sum()
+    assert np.abs(R.reshape(3, 3) - Ro).max() < 1e-10
+    assert np.abs(t - to).max() < 1e-10
+    # the reference-arithmetic (scalar_t accumulating, scalar_t SVD) variant
+    Rr, tr_, _ = orc.compute_rt_p2point(p["source"], p["target"], corr)
+    tol = 1e-4 if dtype == np.float32 else 1e-10
+    assert np.abs(R.reshape(3, 3) - Rr).max() < tol
+    assert np.abs(t - tr_).max() < tol
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_p2point_golden_through_gpu(dtype):
+    """14/11-point vectors -> RMSE 0.578255 after the estimated transform
+    (cpp/tests/t/pipelines/registration/TransformationEstimation.cpp:130)."""
+    _lib, _ = _gpu()
+    from open3d_amd.core import TORCH_TO_O3DMI, stream
+    from test_oracle_goldens import _p2point_rmse
+    L = _lib.lib()
+    s, t = SRC.astype(dtype), TGT.astype(dtype)
+    sums = _p2point_sums(_lib, s, t, CORR)
+    assert sums[15] == 14
+    R, tr = np.zeros(9), np.zeros(3)
+    _lib.check(L.o3dmi_compute_rt_p2point(_lib.f64p(sums), _lib.f64p(R),
+                                          _lib.f64p(tr)), "rt")
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R.reshape(3, 3), tr
+    ts = torch.from_numpy(s.copy()).cuda()
+    _lib.check(L.o3dmi_transform_points(_lib.f64p(T), _lib.ptr(ts), 14,
+                                        TORCH_TO_O3DMI[ts.dtype], stream()),
+               "transform")
+    assert abs(_p2point_rmse(ts.cpu().numpy(), t, CORR) - 0.578255) < 1e-4
+
+
+def test_p2point_fused_search_equals_two_step():
+    """search + accumulate fused == hybrid search then accumulate; the index
+    needs no normals for this estimator."""
+    _lib, reg = _gpu()
+    from open3d_amd.core import TORCH_TO_O3DMI, stream
+    L = _lib.lib()
+    p = _pair(20000, seed=22)
+    tp = torch.from_numpy(p["target"]).cuda()
+    tq = torch.from_numpy(p["source"]).cuda()
+    h = C.c_void_p()
+    _lib.check(L.o3dmi_nns_create(_lib.ptr(tp), tp.shape[0],
+                                  TORCH_TO_O3DMI[tp.dtype], C.c_double(0.07),
+                                  stream(), C.byref(h)), "nns_create")
+    corr = torch.zeros(tq.shape[0], dtype=torch.int64, device="cuda")
+    sums = torch.zeros(32, dtype=torch.float64, device="cuda")
+    _lib.check(L.o3dmi_icp_search_accumulate_p2point(
+        h, _lib.ptr(tq), tq.shape[0], _lib.ptr(corr), _lib.ptr(sums),
+        stream()), "search_p2point")
+    torch.cuda.synchronize()
+    L.o3dmi_nns_destroy(h)
+    idx, d2, cnt = orc.hybrid_search(p["target"], p["source"], 0.07, 1)
+    want_corr = idx[:, 0].astype(np.int64)
+    assert np.array_equal(corr.cpu().numpy(), want_corr)
+    two = _p2point_sums(_lib, p["source"], p["target"], want_corr)
+    got = sums.cpu().numpy()
+    assert got[15] == two[15] == got[30]
+    assert np.allclose(got[:16], two, rtol=1e-13, atol=1e-10)
+    assert abs(got[29] - d2[want_corr >= 0, 0].astype(np.float64).sum()) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_icp_point_to_point_pose_parity(dtype):
+    """ICP with TransformationEstimationPointToPoint vs the oracle driver."""
+    _lib, reg = _gpu()
+    p = _pair(20000, seed=4, dtype=dtype)
+    want = orc.multiscale_icp(p["source"], p["target"], None, [-1.0],
+                              [(1e-6, 1e-6, 30)], [0.07],
+                              accumulate_double=True, estimation=1)
+    got = reg.icp(torch.from_numpy(p["source"]).cuda(),
+                  torch.from_numpy(p["target"]).cuda(), None, 0.07,
+                  estimation_method=reg.TransformationEstimationPointToPoint(),
+                  criteria=reg.ICPConvergenceCriteria(1e-6, 1e-6, 30))
+    ang, tr = _pose_err(want["transformation"], got.transformation)
+    assert ang <= 1e-6 and tr <= 1e-5, (ang, tr)
+    assert got.num_iterations == want["num_iterations"]
+    assert got.converged == want["converged"]
+    assert abs(got.fitness - want["fitness"]) < 1e-12
+    assert abs(got.inlier_rmse - want["inlier_rmse"]) < 1e-6
+    c = got.correspondence_set.cpu().numpy()
+    assert (c == want["correspondences"]).mean() > 0.9999
+    ang_gt, tr_gt = _pose_err(p["T_gt"], got.transformation)
+    assert ang_gt < 5e-3 and tr_gt < 1e-2
+    if dtype == np.float32:
+        ref = orc.multiscale_icp(p["source"], p["target"], None, [-1.0],
+                                 [(1e-6, 1e-6, 30)], [0.07],
+                                 accumulate_double=False, estimation=1)
+        a2, t2 = _pose_err(ref["transformation"], got.transformation)
+        assert a2 < 1e-3 and t2 < 1e-3
+
+
+def test_multiscale_icp_point_to_point():
+    """Pyramid without normals (VoxelDownSample of positions only)."""
+    _lib, reg = _gpu()
+    p = _pair(60000, seed=12)
+    vs = [0.05, 0.025, 0.0125]
+    crit = [(1e-6, 1e-6, 20), (1e-6, 1e-6, 10), (1e-6, 1e-6, 5)]
+    md = [0.15, 0.075, 0.0375]
+    want = orc.multiscale_icp(p["source"], p["target"], None, vs, crit, md,
+                              accumulate_double=True, estimation=1)
+    got = reg.multi_scale_icp(
+        torch.from_numpy(p["source"]).cuda(),
+        torch.from_numpy(p["target"]).cuda(), None, vs,
+        [reg.ICPConvergenceCriteria(*c) for c in crit], md,
+        estimation_method=reg.TransformationEstimationPointToPoint())
+    ang, tr = _pose_err(want["transformation"], got.transformation)
+    assert ang <= 1e-6 and tr <= 1e-5, (ang, tr)
+    assert got.num_iterations == want["num_iterations"]
+    assert abs(got.fitness - want["fitness"]) < 1e-12
+
+
+# ---------------------------------- EvaluateRegistration / GetInformationMatrix
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_evaluate_registration_parity(dtype):
+    """EvaluateRegistration (Registration.cpp:64-91): same correspondence set,
+    fitness exact, rmse from the same d2 values."""
+    _lib, reg = _gpu()
+    p = _pair(20000, seed=31, dtype=dtype)
+    T = orc.pose_to_transformation([0.01, -0.02, 0.015, 0.02, -0.01, 0.03])
+    want = orc.evaluate_registration(p["source"], p["target"], 0.07, T)
+    got = reg.evaluate_registration(torch.from_numpy(p["source"]).cuda(),
+                                    torch.from_numpy(p["target"]).cuda(),
+                                    0.07, T)
+    assert np.array_equal(got.correspondence_set.cpu().numpy(),
+                          want["correspondences"])
+    assert got.fitness == want["fitness"] and 0 < got.fitness < 1
+    assert abs(got.inlier_rmse - want["inlier_rmse"]) < 1e-6
+    assert np.array_equal(got.transformation, T)
+    # nothing within reach: fitness 0, identity (Registration.cpp:51-60)
+    far = torch.from_numpy(p["source"] + dtype(100)).cuda()
+    e = reg.evaluate_registration(far, torch.from_numpy(p["target"]).cuda(),
+                                  0.07, T)
+    assert e.fitness == 0 and e.inlier_rmse == 0
+    assert np.array_equal(e.transformation, np.eye(4))
+    assert (e.correspondence_set.cpu().numpy() == -1).all()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_information_matrix_parity(dtype):
+    """GetInformationMatrix (Registration.cpp:446-486): fused search + 21 sums
+    vs the oracle (float64 accumulation), the kernel-seam entry on given
+    correspondences, and the zero-correspondence error."""
+    _lib, reg = _gpu()
+    from open3d_amd.core import TORCH_TO_O3DMI, stream
+    p = _pair(20000, seed=32, dtype=dtype)
+    T = orc.pose_to_transformation([0.0, 0.01, -0.01, 0.01, 0.0, -0.02])
+    st, want = orc.information_matrix(p["source"], p["target"], 0.07, T,
+                                      accumulate_double=True)
+    assert st == 0
+    src, tgt = (torch.from_numpy(p[k]).cuda() for k in ("source", "target"))
+    got = reg.get_information_matrix(src, tgt, 0.07, T)
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-9)
+    assert np.array_equal(got, got.T) and got[3, 3] == got[4, 4] == got[5, 5]
+    # reference-arithmetic variant (sums in the point dtype)
+    _, ref_like = orc.information_matrix(p["source"], p["target"], 0.07, T)
+    assert np.allclose(got, ref_like, rtol=2e-3 if dtype == np.float32
+                       else 1e-12)
+    # kernel seam on explicit correspondences
+    ev = orc.evaluate_registration(p["source"], p["target"], 0.07, T)
+    corr = torch.from_numpy(ev["correspondences"]).cuda()
+    sums = torch.zeros(21, dtype=torch.float64, device="cuda")
+    _lib.check(_lib.lib().o3dmi_icp_information_accumulate(
+        _lib.ptr(tgt), _lib.ptr(corr), corr.shape[0],
+        TORCH_TO_O3DMI[tgt.dtype], _lib.ptr(sums), stream()), "info")
+    torch.cuda.synchronize()
+    assert np.allclose(orc.unpack21(sums.cpu().numpy()), want, rtol=1e-12,
+                       atol=1e-9)
+    far = torch.from_numpy(p["source"] + dtype(100)).cuda()
+    with pytest.raises(RuntimeError, match="0 correspondence present"):
+        reg.get_information_matrix(far, tgt, 0.07, T)

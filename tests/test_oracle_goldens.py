@@ -60,6 +60,29 @@ def test_p2plane_transformation_golden(dtype, acc_double):
     assert abs(r - 0.601422) < 1e-4
 
 
+def _p2point_rmse(s, t, corr):
+    """TransformationEstimationPointToPoint::ComputeRMSE,
+    TransformationEstimation.cpp:101-130."""
+    m = corr >= 0
+    d = s[m].astype(np.float64) - t[corr[m]].astype(np.float64)
+    return float(np.sqrt((d * d).sum() / m.sum()))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("acc_double", [False, True])
+def test_p2point_transformation_golden(dtype, acc_double):
+    """ComputeRMSEPointToPoint 0.706437; ComputeTransformationPointToPoint ->
+    RMSE 0.578255 after applying it (TransformationEstimation.cpp:103,130)."""
+    s, t = SRC.astype(dtype), TGT.astype(dtype)
+    assert abs(_p2point_rmse(s, t, CORR) - 0.706437) < 1e-4
+    R, tr, c = orc.compute_rt_p2point(s, t, CORR, accumulate_double=acc_double)
+    assert c == 14
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R, tr
+    s2 = orc.transform_points(T, s)
+    assert abs(_p2point_rmse(s2, t, CORR) - 0.578255) < 1e-4
+
+
 def test_hybrid_search_golden():
     """NNSPermuteDevices.HybridSearch (cpp/tests/core/NearestNeighborSearch.cpp:321-377)."""
     pts = np.array([[0.0, 0.0, 0.0], [0.0, 0.0, 0.1], [0.0, 0.0, 0.2],

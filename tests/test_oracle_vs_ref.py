@@ -236,6 +236,72 @@ def test_compute_pose_decode_solve_match(dtype):
                           ref.pose_to_transformation(pose))
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_p2point_sxy_bit_exact_sequential(dtype):
+    """Get3x3SxyLinearSystem (the reduction of ComputeRtPointToPointCPU) run as
+    one sequential chunk == the oracle's scalar_t-accumulating variant."""
+    p, corr = _pairs(3000, dtype, 4)
+    assert (corr >= 0).sum() > 1000
+    corr[::17] = -1
+    S, ms, mt, c = orc.p2point_sxy(p["source"], p["target"], corr)
+    Sr, msr, mtr, cr = ref.p2point_sxy(p["source"], p["target"], corr)
+    assert c == cr == (corr >= 0).sum()
+    assert np.array_equal(S, Sr)
+    assert np.array_equal(ms, msr) and np.array_equal(mt, mtr)
+
+
+def _rt_numpy(S, ms, mt):
+    """ComputeRtPointToPointCPU after the reduction, written with numpy's
+    LAPACK SVD exactly as RegistrationCPU.cpp:640-650 reads."""
+    U, D, VT = np.linalg.svd(S)
+    Sg = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(VT.T) < 0:
+        Sg[-1, -1] = -1
+    R = U @ (Sg @ VT)
+    return R, mt - R @ ms
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_p2point_rt_matches_lapack_svd(dtype):
+    """The oracle's restated 3x3 SVD route gives the R, t that LAPACK's SVD
+    gives (Tensor::SVD is gesvd, not in /root/reference), on the reference's
+    own Sxy / means; also a reflection case (det(U) det(V) < 0) and a planar
+    correspondence set (sigma_3 = 0)."""
+    p, corr = _pairs(4000, dtype, 9)
+    Sr, msr, mtr, _ = ref.p2point_sxy(p["source"], p["target"], corr)
+    f32 = dtype == np.float32
+    R, t = orc.rt_from_sxy(Sr, msr, mtr, as_f32=f32)
+    Rn, tn = _rt_numpy(Sr.astype(dtype), msr.astype(dtype), mtr.astype(dtype))
+    tol = 5e-6 if f32 else 1e-12
+    assert np.abs(R - Rn).max() < tol and np.abs(t - tn).max() < tol
+    assert abs(np.linalg.det(R) - 1) < (1e-5 if f32 else 1e-12)
+    rng = np.random.default_rng(3)
+    for trial in range(20):
+        S = rng.standard_normal((3, 3))
+        if trial % 3 == 0:
+            S[:, 2] = 0          # rank 2: planar source set
+        if trial % 5 == 1:
+            S = -S               # flips the sign of det
+        ms, mt = rng.standard_normal(3), rng.standard_normal(3)
+        R, t = orc.rt_from_sxy(S, ms, mt)
+        Rn, tn = _rt_numpy(S, ms, mt)
+        assert np.abs(R - Rn).max() < 1e-9, (trial, R, Rn)
+        assert np.abs(t - tn).max() < 1e-9
+        assert abs(np.linalg.det(R) - 1) < 1e-12
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_information_matrix_bit_exact_sequential(dtype):
+    """ComputeInformationMatrixCPU (one sequential chunk) == the oracle's
+    scalar_t-accumulating 21 sums unpacked to GTG."""
+    p, corr = _pairs(3000, dtype, 6)
+    corr[::13] = -1
+    a = orc.unpack21(orc.information_accumulate(p["target"], corr))
+    b = ref.information_matrix(p["target"], corr)
+    assert np.array_equal(a, b)
+    assert a[3, 3] == a[4, 4] == a[5, 5] == (corr >= 0).sum()
+
+
 def test_singular_system_is_an_error_in_both():
     A = np.zeros(29)
     assert orc.decode_and_solve6x6(A)[0] != 0

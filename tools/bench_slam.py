@@ -52,16 +52,24 @@ def mode_icp(a):
     tgt = torch.from_numpy(p["target"]).cuda()
     nrm = torch.from_numpy(p["target_normals"]).cuda()
     crit = reg.ICPConvergenceCriteria(1e-6, 1e-6, 30)
+    p2point = a.estimation == "p2point"
+    est = (reg.TransformationEstimationPointToPoint() if p2point
+           else reg.TransformationEstimationPointToPlane())
+    if p2point:
+        nrm = None
     res = None
     for _ in range(2):
-        res = reg.icp(src, tgt, nrm, 0.07, criteria=crit)
+        res = reg.icp(src, tgt, nrm, 0.07, criteria=crit,
+                      estimation_method=est)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.repeat):
-        res = reg.icp(src, tgt, nrm, 0.07, criteria=crit)
+        res = reg.icp(src, tgt, nrm, 0.07, criteria=crit,
+                      estimation_method=est)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / a.repeat * 1e3
-    out = {"mode": "icp", "points": a.points, "ms_per_icp": ms,
+    out = {"mode": "icp", "estimation": a.estimation, "points": a.points,
+           "ms_per_icp": ms,
            "iterations": res.num_iterations,
            "ms_per_iteration": ms / max(1, res.num_iterations),
            "fitness": res.fitness, "inlier_rmse": res.inlier_rmse,
@@ -72,9 +80,10 @@ def mode_icp(a):
         orc.set_threads(min(64, os.cpu_count() or 1))
         t0 = time.perf_counter()
         want = orc.multiscale_icp(p["source"], p["target"],
-                                  p["target_normals"], [-1.0],
-                                  [(1e-6, 1e-6, 30)], [0.07],
-                                  accumulate_double=True)
+                                  None if p2point else p["target_normals"],
+                                  [-1.0], [(1e-6, 1e-6, 30)], [0.07],
+                                  accumulate_double=True,
+                                  estimation=1 if p2point else 0)
         out["cpu_oracle_ms_per_icp"] = (time.perf_counter() - t0) * 1e3
         out["cpu_oracle_threads"] = min(64, os.cpu_count() or 1)
         out["pose_err_vs_oracle_rad_m"] = pose_err(want["transformation"],
@@ -399,6 +408,8 @@ def main():
     ap.add_argument("--hd", action="store_true", help="1280x720 (model mode)")
     ap.add_argument("--method", default="p2plane",
                     choices=["p2plane", "intensity", "hybrid"])
+    ap.add_argument("--estimation", default="p2plane",
+                    choices=["p2plane", "p2point"], help="icp mode")
     ap.add_argument("--cpu-frames", type=int, default=0)
     ap.add_argument("--phases", action="store_true",
                     help="slam mode: synchronise between phases and report "
