@@ -322,6 +322,17 @@ int o3dmi_nns_hybrid_search(const o3dmi_nns_t* nns, const void* queries_dev,
                             void* dist2_dev, int32_t* counts_dev,
                             o3dmi_stream_t stream);
 
+/* NearestNeighborSearch::KnnIndex + KnnSearch (core/nns/
+ * NearestNeighborSearch.cpp:28-45,93-112; GPU form KnnSearchCUDA, core/nns/
+ * KnnIndex.h): the k = min(knn, n) nearest dataset points of every query,
+ * ascending by (d2, index); idx {Q,k} int32, dist2 {Q,k} in the point dtype
+ * (may be NULL). k <= 64. Builds its own grid over the dataset (cell size from
+ * the measured point density) and synchronises. */
+int o3dmi_nns_knn_search(const void* points_dev, int64_t n,
+                         const void* queries_dev, int64_t q, int dtype, int knn,
+                         int32_t* idx_dev, void* dist2_dev,
+                         o3dmi_stream_t stream);
+
 /* EstimateCovariancesUsingHybridSearchCUDA after the search
  * (t/geometry/kernel/PointCloudImpl.h:588-638; per-point body :512-585):
  * covariances {n,3,3} in the point dtype from hybrid-search results. */

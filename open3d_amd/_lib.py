@@ -156,6 +156,8 @@ PROTOTYPES.update({
                C.POINTER(IcpCriteria), _dp, _dp, _i32, _i32, _d, _d,
                ICP_CALLBACK, _vp, ALLREDUCE_SUM, _vp, _vp,
                C.POINTER(RegistrationResultC), _vp]),
+    "o3dmi_nns_knn_search": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp,
+                                    _vp, _vp]),
     "o3dmi_registration_evaluate": (
         _i32, [_vp, _i64, _vp, _i64, _i32, _d, _dp, _vp,
                C.POINTER(RegistrationResultC), _vp]),

@@ -27,10 +27,12 @@
 // stage in fixed order => run-to-run deterministic (the reference's CUDA path
 // uses float atomics, its CPU path a TBB tree of unspecified shape).
 
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
 #include <cstdlib>
+#include <cstring>
 
 #include "common.h"
 #include "mailbox.h"
@@ -316,6 +318,210 @@ __global__ void HybridSearchKernel(NnsView<T> nv, const T* __restrict__ q,
         }
         if (cnt_out) cnt_out[i] = found;
     }
+}
+
+// ---- k nearest neighbours without a radius (KnnIndex / KnnSearch) ----------
+// NearestNeighborSearch::KnnSearch semantics (core/nns/NanoFlannImpl.h:
+// _KnnSearchCPU, nanoflann KNNResultSet): the min(knn, N) nearest points,
+// ascending by distance (ties by lower index here; nanoflann's tie order
+// depends on its tree traversal). The reference's GPU path is a brute-force
+// distance matrix + block select (core/nns/KnnSearchOps.cu); points in 3-D do
+// better on the same bucketed grid as the radius index, searched in growing
+// cubic shells: after shell r every unvisited point is farther than
+// r * cell + (distance from the query to the nearest face of its own cell),
+// so the walk stops as soon as the k-th distance is below that bound. The
+// cell size is chosen by the host so that an occupied cell holds ~knn / 2
+// points (shells 0 and 1 then usually suffice).
+template <typename T>
+struct KnnGrid {
+    NnsView<T> nv;
+    double cell;
+    long long cmin[3], cmax[3];  // occupied cell box
+};
+
+template <typename T>
+__device__ __forceinline__ void KnnVisitCell(const NnsView<T>& nv, const T* qq,
+                                             long long x, long long y,
+                                             long long z, int knn, T* bd,
+                                             int* bi, int& found) {
+    const unsigned b = HashCell(x, y, z) & nv.mask;
+    const unsigned s0 = nv.starts[b], e0 = nv.starts[b + 1];
+    for (unsigned j = s0; j < e0; ++j) {
+        const Rec4<T> p = nv.sorted[j];
+        T result = T(0);
+        const T d0 = qq[0] - p.x;
+        result += d0 * d0;
+        const T d1 = qq[1] - p.y;
+        result += d1 * d1;
+        const T dd = qq[2] - p.z;
+        result += dd * dd;
+        const int pi = RecIndex(p);
+        const int len = found < knn ? found : knn;
+        int pos = len;
+        while (pos > 0 && (result < bd[pos - 1] ||
+                           (result == bd[pos - 1] && pi < bi[pos - 1])))
+            --pos;
+        // a bucket can serve several cells: the record was seen before
+        if (pos > 0 && bi[pos - 1] == pi) continue;
+        if (pos >= knn) continue;
+        for (int k = (found < knn ? found : knn - 1); k > pos; --k) {
+            bd[k] = bd[k - 1];
+            bi[k] = bi[k - 1];
+        }
+        bd[pos] = result;
+        bi[pos] = pi;
+        if (found < knn) ++found;
+    }
+}
+
+// A query in a sparse region would walk thousands of empty shells on a single
+// fine grid, so the index is a pyramid: level l has cells 4^l times the finest;
+// a level is searched for at most kKnnShells shells, then the walk restarts on
+// the next coarser level (re-seen records are recognised in the list). The
+// coarsest level spans the whole cloud in a handful of cells and is searched
+// exhaustively.
+constexpr int kKnnMaxLevels = 12;
+constexpr int kKnnShells = 2;
+
+template <typename T>
+struct KnnPyramid {
+    int n_levels;
+    KnnGrid<T> level[kKnnMaxLevels];
+};
+
+template <typename T>
+__global__ void KnnSearchKernel(KnnPyramid<T> pyr, const T* __restrict__ q,
+                                int64_t nq, int knn, int* __restrict__ idx_out,
+                                T* __restrict__ d2_out,
+                                int* __restrict__ cnt_out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nq;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const T qq[3] = {q[3 * i + 0], q[3 * i + 1], q[3 * i + 2]};
+        T bd[kMaxKnn];
+        int bi[kMaxKnn];
+        int found = 0;
+        bool done = false;
+        for (int l = 0; l < pyr.n_levels && !done; ++l) {
+            const KnnGrid<T>& g = pyr.level[l];
+            const bool last = l == pyr.n_levels - 1;
+            long long c[3];
+            CellOf(qq, g.nv.inv_cell, c[0], c[1], c[2]);
+            // distance to the nearest face of the query's own cell
+            double margin = g.cell;
+            long long r0 = 0, rmax = 0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double lo = (double)qq[a] - (double)c[a] * g.cell;
+                const double hi = (double)(c[a] + 1) * g.cell - (double)qq[a];
+                margin = fmin(margin, fmin(lo, hi));
+                const long long below = g.cmin[a] - c[a];
+                const long long above = c[a] - g.cmax[a];
+                r0 = max(r0, max(below, above));        // shells before the box
+                rmax = max(rmax, max(-below, -above));  // shell covering the box
+            }
+            // cell assignment rounds in float64: keep a small absolute slack
+            margin -= 1e-7 * g.cell;
+            if (!(margin > 0)) margin = 0;
+            if (!last) {
+                if (r0 > kKnnShells) continue;  // the box is out of reach here
+                rmax = min(rmax, (long long)kKnnShells);
+            }
+            for (long long r = r0; r <= rmax; ++r) {
+                const long long zlo = max(c[2] - r, g.cmin[2]);
+                const long long zhi = min(c[2] + r, g.cmax[2]);
+                for (long long z = zlo; z <= zhi; ++z) {
+                    const bool zface = (z == c[2] - r) || (z == c[2] + r);
+                    const long long ylo = max(c[1] - r, g.cmin[1]);
+                    const long long yhi = min(c[1] + r, g.cmax[1]);
+                    for (long long y = ylo; y <= yhi; ++y) {
+                        const bool face =
+                                zface || (y == c[1] - r) || (y == c[1] + r);
+                        if (face) {
+                            const long long xlo = max(c[0] - r, g.cmin[0]);
+                            const long long xhi = min(c[0] + r, g.cmax[0]);
+                            for (long long x = xlo; x <= xhi; ++x)
+                                KnnVisitCell(g.nv, qq, x, y, z, knn, bd, bi,
+                                             found);
+                        } else {
+                            const long long xa = c[0] - r, xb = c[0] + r;
+                            if (xa >= g.cmin[0] && xa <= g.cmax[0])
+                                KnnVisitCell(g.nv, qq, xa, y, z, knn, bd, bi,
+                                             found);
+                            if (xb != xa && xb >= g.cmin[0] && xb <= g.cmax[0])
+                                KnnVisitCell(g.nv, qq, xb, y, z, knn, bd, bi,
+                                             found);
+                        }
+                    }
+                }
+                if (found == knn) {
+                    const double bound = (double)r * g.cell + margin;
+                    if ((double)bd[knn - 1] < bound * bound * (1.0 - 1e-6)) {
+                        done = true;
+                        break;
+                    }
+                }
+            }
+        }
+        for (int k = 0; k < knn; ++k) {
+            if (idx_out) idx_out[i * knn + k] = k < found ? bi[k] : -1;
+            if (d2_out) d2_out[i * knn + k] = k < found ? bd[k] : T(0);
+        }
+        if (cnt_out) cnt_out[i] = found;
+    }
+}
+
+// Bounding box of a cloud, as order-preserving 64-bit keys of the float64
+// coordinates (atomicMin / atomicMax work on them).
+__device__ __forceinline__ unsigned long long OrderedKey(double v) {
+    unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+inline double FromOrderedKey(unsigned long long u) {
+    u = (u >> 63) ? (u & 0x7fffffffffffffffull) : ~u;
+    double v;
+    std::memcpy(&v, &u, sizeof(v));
+    return v;
+}
+
+template <typename T>
+__global__ void BoundsKernel(const T* __restrict__ pts, int64_t n,
+                             unsigned long long* __restrict__ mn,
+                             unsigned long long* __restrict__ mx) {
+    double lo[3] = {INFINITY, INFINITY, INFINITY};
+    double hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double v = (double)pts[3 * i + a];
+            if (v < lo[a]) lo[a] = v;
+            if (v > hi[a]) hi[a] = v;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int m = 32; m > 0; m >>= 1) {
+            lo[a] = fmin(lo[a], __shfl_xor(lo[a], m));
+            hi[a] = fmax(hi[a], __shfl_xor(hi[a], m));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (lo[a] <= hi[a]) {
+                atomicMin(&mn[a], OrderedKey(lo[a]));
+                atomicMax(&mx[a], OrderedKey(hi[a]));
+            }
+        }
+    }
+}
+
+__global__ void CountOccupiedKernel(const unsigned* __restrict__ starts,
+                                    int64_t n_buckets,
+                                    unsigned* __restrict__ occupied) {
+    unsigned local = 0;
+    for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+         b < n_buckets; b += (int64_t)gridDim.x * blockDim.x)
+        local += starts[b + 1] > starts[b] ? 1u : 0u;
+    for (int m = 32; m > 0; m >>= 1) local += __shfl_xor(local, m);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(occupied, local);
 }
 
 // RobustKernelImpl.h:35-126, literal: the double-typed literals promote parts
@@ -884,6 +1090,160 @@ int o3dmi_nns_hybrid_search(const o3dmi_nns_t* nns, const void* queries_dev,
                            max_knn, idx_dev, (float*)dist2_dev, counts_dev);
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
+}
+
+// Internal form (also fills counts_dev {q} with the row width when given).
+int o3dmi_nns_knn_search_counts(const void* points_dev, int64_t n,
+                                const void* queries_dev, int64_t q, int dtype,
+                                int knn, int32_t* idx_dev, void* dist2_dev,
+                                int32_t* counts_dev, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
+                  "points must be Float32 or Float64");
+    O3DMI_REQUIRE(knn > 0, "knn should be larger than 0.");
+    O3DMI_REQUIRE(n > 0 && n < (1ll << 31) && points_dev, "empty dataset");
+    O3DMI_REQUIRE(q >= 0, "q < 0");
+    const int k = (int)(n < (int64_t)knn ? n : (int64_t)knn);
+    O3DMI_REQUIRE(k <= kMaxKnn, "knn > 64 is not supported");
+    if (q == 0) return O3DMI_OK;
+    O3DMI_REQUIRE(queries_dev && idx_dev, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+
+    // bounding box
+    unsigned long long* box = nullptr;  // [0..2] min keys, [3..5] max keys
+    unsigned* occupied = nullptr;
+    { int st_; if ((st_ = PoolAlloc((void**)&box, 64))) return st_; }
+    occupied = (unsigned*)(box + 6);
+    O3DMI_HIP_CHECK(hipMemsetAsync(box, 0xff, 24, s));
+    O3DMI_HIP_CHECK(hipMemsetAsync(box + 3, 0, 24, s));
+    {
+        int g = GridFor(n, kBlock);
+        if (g > kCUs * 4) g = kCUs * 4;
+        if (dtype == O3DMI_F64)
+            hipLaunchKernelGGL(BoundsKernel<double>, dim3(g), dim3(kBlock), 0,
+                               s, (const double*)points_dev, n, box, box + 3);
+        else
+            hipLaunchKernelGGL(BoundsKernel<float>, dim3(g), dim3(kBlock), 0, s,
+                               (const float*)points_dev, n, box, box + 3);
+    }
+    unsigned long long hbox[6];
+    O3DMI_HIP_CHECK(hipMemcpyAsync(hbox, box, sizeof(hbox),
+                                   hipMemcpyDeviceToHost, s));
+    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    double lo[3], ext[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = FromOrderedKey(hbox[a]);
+        const double hi = FromOrderedKey(hbox[3 + a]);
+        if (!(lo[a] <= hi)) {  // no finite coordinate on this axis
+            PoolFree(box);
+            SetLastError("KnnSearch: dataset has no finite points");
+            return O3DMI_ERR_INVALID_ARG;
+        }
+        ext[a] = hi - lo[a];
+    }
+    // first guess: a surface spanning the two largest extents, or a filled
+    // volume, whichever gives the larger cell (shrinking is the cheap
+    // direction: few occupied cells -> reliable estimate of the density)
+    const double target = k / 2.0 < 2.0 ? 2.0 : k / 2.0;
+    double e[3] = {ext[0], ext[1], ext[2]};
+    std::sort(e, e + 3);
+    const double emax = e[2] > 0 ? e[2] : 1.0;
+    const double h_min = emax * 1e-6;
+    double h = std::sqrt(std::max(e[2] * e[1], 0.0) * target / (double)n);
+    h = std::max(h, std::cbrt(std::max(e[0] * e[1] * e[2], 0.0) * target /
+                              (double)n));
+    h = std::max(h, e[2] * target / (double)n);  // points along a line
+    if (!(h > h_min)) h = h_min;
+    if (!(e[2] > 0)) h = 1.0;
+
+    o3dmi_nns* nns = nullptr;
+    int st = O3DMI_OK;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        if (nns) o3dmi_nns_destroy(nns);
+        nns = new o3dmi_nns();
+        nns->dtype = dtype;
+        nns->n = n;
+        nns->radius = h;
+        nns->inv_cell = 1.0 / h;
+        st = dtype == O3DMI_F64
+                     ? BuildIndex<double>(nns, (const double*)points_dev, s)
+                     : BuildIndex<float>(nns, (const float*)points_dev, s);
+        if (st) break;
+        O3DMI_HIP_CHECK(hipMemsetAsync(occupied, 0, sizeof(unsigned), s));
+        int g = GridFor(nns->n_buckets, kBlock);
+        if (g > kCUs * 4) g = kCUs * 4;
+        hipLaunchKernelGGL(CountOccupiedKernel, dim3(g), dim3(kBlock), 0, s,
+                           nns->starts, nns->n_buckets, occupied);
+        unsigned occ = 0;
+        O3DMI_HIP_CHECK(hipMemcpyAsync(&occ, occupied, sizeof(occ),
+                                       hipMemcpyDeviceToHost, s));
+        O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+        const double ppc = (double)n / (double)(occ ? occ : 1);
+        if (attempt == 5 || (ppc >= 0.5 * target && ppc <= 2.0 * target)) break;
+        double h_next = h * std::pow(target / ppc, 0.4);
+        if (h_next < h_min) h_next = h_min;
+        if (h_next == h) break;
+        h = h_next;
+    }
+    PoolFree(box);
+    if (st) {
+        if (nns) o3dmi_nns_destroy(nns);
+        return st;
+    }
+    // coarser levels, up to one that spans the cloud in <= 4 cells per axis
+    std::vector<o3dmi_nns*> levels{nns};
+    while ((int)levels.size() < kKnnMaxLevels &&
+           emax / levels.back()->radius > 3.0) {
+        auto* up = new o3dmi_nns();
+        up->dtype = dtype;
+        up->n = n;
+        up->radius = levels.back()->radius * 4.0;
+        up->inv_cell = 1.0 / up->radius;
+        levels.push_back(up);
+        st = dtype == O3DMI_F64
+                     ? BuildIndex<double>(up, (const double*)points_dev, s)
+                     : BuildIndex<float>(up, (const float*)points_dev, s);
+        if (st) break;
+    }
+    if (!st) {
+        const dim3 grid(GridFor(q, 64)), block(64);
+#define O3DMI_KNN(T)                                                           \
+    do {                                                                       \
+        KnnPyramid<T> pyr;                                                     \
+        pyr.n_levels = (int)levels.size();                                     \
+        for (int l = 0; l < pyr.n_levels; ++l) {                               \
+            KnnGrid<T>& kg = pyr.level[l];                                     \
+            kg.nv = MakeView<T>(levels[l]);                                    \
+            kg.cell = levels[l]->radius;                                       \
+            for (int a = 0; a < 3; ++a) {                                      \
+                kg.cmin[a] = (long long)std::floor(lo[a] *                     \
+                                                   levels[l]->inv_cell) - 1;   \
+                kg.cmax[a] = (long long)std::floor((lo[a] + ext[a]) *          \
+                                                   levels[l]->inv_cell) + 1;   \
+            }                                                                  \
+        }                                                                      \
+        hipLaunchKernelGGL(KnnSearchKernel<T>, grid, block, 0, s, pyr,         \
+                           (const T*)queries_dev, q, k, idx_dev,               \
+                           (T*)dist2_dev, counts_dev);                         \
+    } while (0)
+        if (dtype == O3DMI_F64) O3DMI_KNN(double);
+        else O3DMI_KNN(float);
+#undef O3DMI_KNN
+        if (hipGetLastError() != hipSuccess) {
+            SetLastError("KnnSearch kernel launch failed");
+            st = O3DMI_ERR_HIP;
+        }
+    }
+    for (o3dmi_nns* lv : levels) o3dmi_nns_destroy(lv);  // drains the device
+    return st;
+}
+
+int o3dmi_nns_knn_search(const void* points_dev, int64_t n,
+                         const void* queries_dev, int64_t q, int dtype, int knn,
+                         int32_t* idx_dev, void* dist2_dev,
+                         o3dmi_stream_t stream) {
+    return o3dmi_nns_knn_search_counts(points_dev, n, queries_dev, q, dtype,
+                                       knn, idx_dev, dist2_dev, nullptr,
+                                       stream);
 }
 
 int o3dmi_icp_p2plane_accumulate(const void* src_dev, const void* tgt_dev,

@@ -360,8 +360,14 @@ int o3dmi_pointcloud_normals_from_covariances(const void* covariances_dev,
     return O3DMI_OK;
 }
 
-// PointCloud::EstimateNormals(max_knn, radius), PointCloud.cpp:856-976 (hybrid
-// search branch): index over the cloud itself, hybrid search, covariances,
+int o3dmi_nns_knn_search_counts(const void* points_dev, int64_t n,
+                                const void* queries_dev, int64_t q, int dtype,
+                                int knn, int32_t* idx_dev, void* dist2_dev,
+                                int32_t* counts_dev, o3dmi_stream_t stream);
+
+// PointCloud::EstimateNormals(max_knn, radius), PointCloud.cpp:856-976: index
+// over the cloud itself, hybrid search (both given) or KNN search (radius <= 0,
+// the reference's default max_nn = 30 / radius = nullopt), covariances,
 // normals; the "covariances" attribute is a temporary, as in the reference.
 int o3dmi_pointcloud_estimate_normals(const void* points_dev, int64_t n,
                                       int dtype, int max_nn, double radius,
@@ -369,14 +375,43 @@ int o3dmi_pointcloud_estimate_normals(const void* points_dev, int64_t n,
                                       o3dmi_stream_t stream) {
     O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
                   "Only Float32 and Float64 point clouds are supported.");
-    O3DMI_REQUIRE(max_nn > 0 && radius > 0,
-                  "EstimateNormals: this backend implements the hybrid search "
-                  "variant (both max_nn and radius given).");
+    O3DMI_REQUIRE(max_nn > 0 || radius > 0, "Both max_nn and radius are none.");
+    O3DMI_REQUIRE(max_nn > 0,
+                  "EstimateNormals: the radius-only variant (unbounded "
+                  "neighbour lists) is not implemented by this backend.");
     O3DMI_REQUIRE(n >= 0, "n < 0");
     if (n == 0) return O3DMI_OK;
     O3DMI_REQUIRE(points_dev && normals_dev, "null argument");
     hipStream_t s = (hipStream_t)stream;
     const size_t esz = dtype == O3DMI_F64 ? 8 : 4;
+    if (!(radius > 0)) {
+        // EstimateCovariancesUsingKNNSearch, PointCloudImpl.h:692-744
+        const int k = (int)(n < (int64_t)max_nn ? n : (int64_t)max_nn);
+        O3DMI_REQUIRE(k >= 3,
+                      "Not enough neighbors to compute Covariances / Normals. "
+                      "Try increasing the max_nn parameter.");
+        char* scratch = nullptr;
+        const size_t idx_bytes =
+                (sizeof(int32_t) * (size_t)n * k + 255) & ~(size_t)255;
+        const size_t cnt_bytes = (sizeof(int32_t) * (size_t)n + 255) & ~(size_t)255;
+        int st = PoolAlloc((void**)&scratch,
+                           idx_bytes + cnt_bytes + esz * 9 * (size_t)n);
+        if (st) return st;
+        int32_t* idx = (int32_t*)scratch;
+        int32_t* cnt = (int32_t*)(scratch + idx_bytes);
+        void* cov = scratch + idx_bytes + cnt_bytes;
+        st = o3dmi_nns_knn_search_counts(points_dev, n, points_dev, n, dtype, k,
+                                         idx, nullptr, cnt, stream);
+        if (!st)
+            st = o3dmi_pointcloud_estimate_covariances(points_dev, idx, cnt, n,
+                                                       k, dtype, cov, stream);
+        if (!st)
+            st = o3dmi_pointcloud_normals_from_covariances(
+                    cov, n, dtype, normals_dev, has_normals, stream);
+        (void)hipStreamSynchronize(s);
+        PoolFree(scratch);
+        return st;
+    }
     o3dmi_nns_t* nns = nullptr;
     int st = o3dmi_nns_create(points_dev, n, dtype, radius, stream, &nns);
     if (st) return st;

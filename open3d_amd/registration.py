@@ -213,12 +213,17 @@ def voxel_down_sample(positions, normals, voxel_size):
 
 def estimate_normals(positions, max_nn=30, radius=None, normals=None):
     """t::geometry::PointCloud::EstimateNormals(max_nn, radius)
-    (PointCloud.cpp:856-976), hybrid-search variant: returns normals {N,3};
+    (PointCloud.cpp:856-976): hybrid search when both are given, KNN search
+    when radius is None (the reference's default); returns normals {N,3};
     `normals` (optional) are existing normals whose orientation is kept."""
     positions = require_cuda(positions, "positions")
-    if radius is None or max_nn is None:
-        raise ValueError("this backend implements the hybrid search variant: "
-                         "give both max_nn and radius")
+    if radius is None and max_nn is None:
+        raise ValueError("Both max_nn and radius are none.")
+    if max_nn is None:
+        raise ValueError("the radius-only variant is not implemented by this "
+                         "backend: give max_nn")
+    if radius is None:
+        radius = -1.0
     if normals is None:
         out = torch.empty_like(positions)
         has = 0
@@ -230,3 +235,21 @@ def estimate_normals(positions, max_nn=30, radius=None, normals=None):
         TORCH_TO_O3DMI[positions.dtype], int(max_nn), C.c_double(radius),
         _lib.ptr(out), has, stream()), "estimate_normals")
     return out
+
+
+def knn_search(points, queries, knn):
+    """core::nns::NearestNeighborSearch(points).KnnIndex() + KnnSearch(queries,
+    knn) -> (indices {Q,k} int32, squared distances {Q,k}), k = min(knn, N)."""
+    points = require_cuda(points, "points")
+    queries = require_cuda(queries, "queries")
+    if queries.dtype != points.dtype:
+        raise ValueError("points / queries dtype mismatch")
+    n, q = points.shape[0], queries.shape[0]
+    k = min(int(knn), n)
+    idx = torch.empty((q, k), dtype=torch.int32, device="cuda")
+    d2 = torch.empty((q, k), dtype=points.dtype, device="cuda")
+    _lib.check(_lib.lib().o3dmi_nns_knn_search(
+        _lib.ptr(points), n, _lib.ptr(queries), q,
+        TORCH_TO_O3DMI[points.dtype], int(knn), _lib.ptr(idx), _lib.ptr(d2),
+        stream()), "knn_search")
+    return idx, d2

@@ -446,6 +446,43 @@ void HybridSearchBrute(const T* points, int64_t num_points, const T* queries,
     }
 }
 
+// NearestNeighborSearch::KnnSearch on CPU = NanoFlannIndex::SearchKnn ->
+// _KnnSearchCPU (core/nns/NanoFlannImpl.h:129-203): num_neighbors =
+// min(dataset size, knn) per query, ascending by distance (nanoflann
+// KNNResultSet; nanoflann v1.5.0 is not vendored, tie order follows its tree
+// traversal -- here ties go to the lower index). L2_Adaptor distance
+// arithmetic as in HybridSearch above. Exhaustive scan, OpenMP over queries.
+template <typename T>
+void KnnSearchBrute(const T* points, int64_t num_points, const T* queries,
+                    int64_t num_queries, int knn, int32_t* indices_ptr,
+                    T* distances_ptr) {
+    const int64_t k = num_points < (int64_t)knn ? num_points : (int64_t)knn;
+#pragma omp parallel
+    {
+        std::vector<std::pair<T, int64_t>> m((size_t)num_points);
+#pragma omp for schedule(dynamic, 64)
+        for (int64_t i = 0; i < num_queries; ++i) {
+            const T* q = queries + 3 * i;
+            for (int64_t j = 0; j < num_points; ++j) {
+                const T* p = points + 3 * j;
+                T result = T();
+                const T d0 = q[0] - p[0];
+                result += d0 * d0;
+                const T d1 = q[1] - p[1];
+                result += d1 * d1;
+                const T d2 = q[2] - p[2];
+                result += d2 * d2;
+                m[(size_t)j] = {result, j};
+            }
+            std::partial_sort(m.begin(), m.begin() + k, m.end());
+            for (int64_t c = 0; c < k; ++c) {
+                indices_ptr[i * k + c] = (int32_t)m[(size_t)c].second;
+                if (distances_ptr) distances_ptr[i * k + c] = m[(size_t)c].first;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // PointCloud::VoxelDownSample, PointCloud.cpp:496-567, sequential semantics:
 // voxel label = order of first occurrence; every attribute is summed in
@@ -1354,6 +1391,17 @@ void orc_hybrid_search(const void* points, int64_t n, const void* queries,
             HybridSearch<float>((const float*)points, n, (const float*)queries,
                                 q, radius, max_knn, idx, (float*)dist, counts);
     }
+}
+
+// idx {q, min(knn, n)} int32, dist {q, min(knn, n)} in the point dtype.
+void orc_knn_search(const void* points, int64_t n, const void* queries,
+                    int64_t q, int is_f64, int knn, int32_t* idx, void* dist) {
+    if (is_f64)
+        KnnSearchBrute<double>((const double*)points, n, (const double*)queries,
+                               q, knn, idx, (double*)dist);
+    else
+        KnnSearchBrute<float>((const float*)points, n, (const float*)queries, q,
+                              knn, idx, (float*)dist);
 }
 
 // out29 is always double[29]; accumulate_double selects the accumulator type.

@@ -308,6 +308,20 @@ def hybrid_search(points, queries, radius, max_knn, brute=False):
     return idx, dist, cnt
 
 
+def knn_search(points, queries, knn):
+    """NearestNeighborSearch::KnnSearch: (idx {q,k} int32, dist2 {q,k})."""
+    points = np.ascontiguousarray(points)
+    queries = np.ascontiguousarray(queries, dtype=points.dtype)
+    k = min(int(knn), points.shape[0])
+    q = queries.shape[0]
+    idx = np.zeros((q, k), np.int32)
+    dist = np.zeros((q, k), points.dtype)
+    lib().orc_knn_search(_p(points), C.c_int64(points.shape[0]), _p(queries),
+                         C.c_int64(q), int(points.dtype == np.float64),
+                         int(knn), _p(idx), _p(dist))
+    return idx, dist
+
+
 def p2plane_accumulate(src, tgt, tgt_n, corr, method=0, scaling=1.0, shape=1.0,
                        accumulate_double=False):
     src = np.ascontiguousarray(src)

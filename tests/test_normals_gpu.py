@@ -143,8 +143,10 @@ def test_estimate_normals_operator(dtype):
     want2 = orc.estimate_normals(pts, 0.08, 30, prior)
     assert np.abs(got2 - want2).max() <= tol
     assert ((got2 * prior).sum(1) >= -1e-6).all()
-    with pytest.raises(ValueError, match="hybrid"):
-        reg.estimate_normals(tp, 30, None)
+    with pytest.raises(ValueError, match="radius-only"):
+        reg.estimate_normals(tp, None, 0.08)
+    with pytest.raises(ValueError, match="Both max_nn and radius are none"):
+        reg.estimate_normals(tp, None, None)
 
 
 def test_empty_and_tiny_inputs():
@@ -170,3 +172,74 @@ def test_empty_and_tiny_inputs():
                                      None, None, stream()) != 0
     assert b"max_knn" in L.o3dmi_last_error()
     L.o3dmi_nns_destroy(h)
+
+
+# ------------------------------------------------------------ KNN (no radius)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("k", [1, 8, 30, 64])
+def test_knn_search_parity(dtype, k):
+    """KnnIndex + KnnSearch: indices exact, squared distances bit-exact vs an
+    exhaustive scan, on a cloud with isolated / duplicate points, a regular
+    lattice (distance ties) and queries far outside the cloud (the multi-level
+    walk)."""
+    _lib, reg = _gpu()
+    pts, _ = _cloud(6000, 3, dtype)
+    rng = np.random.default_rng(2)
+    qrs = np.ascontiguousarray(np.concatenate(
+        [pts[::3], (pts[:500] + rng.normal(0, 0.01, (500, 3))).astype(dtype),
+         np.array([[-500, 20, 3], [1e4, 1e4, 1e4], [65, 65, 65],
+                   [80.15, 0.15, 3.2]], dtype)]))
+    widx, wd2 = orc.knn_search(pts, qrs, k)
+    idx, d2 = reg.knn_search(torch.from_numpy(pts).cuda(),
+                             torch.from_numpy(qrs).cuda(), k)
+    assert idx.shape == (qrs.shape[0], k)
+    assert np.array_equal(idx.cpu().numpy(), widx)
+    assert d2.cpu().numpy().tobytes() == wd2.tobytes()
+
+
+def test_knn_search_golden_and_edges():
+    """The reference's KnnSearch golden (cpp/tests/core/
+    NearestNeighborSearch.cpp:36-111) through the GPU; k > N; k <= 0; N = 1;
+    all points identical."""
+    _lib, reg = _gpu()
+    from test_oracle_goldens import KNN_D2, KNN_IDX, KNN_PTS, KNN_Q
+    tp, tq = torch.from_numpy(KNN_PTS).cuda(), torch.from_numpy(KNN_Q).cuda()
+    idx, d2 = reg.knn_search(tp, tq, 3)
+    assert idx.cpu().numpy().tolist() == [KNN_IDX[:3]]
+    assert np.allclose(d2.cpu().numpy(), [KNN_D2[:3]], rtol=1e-5, atol=1e-8)
+    idx, d2 = reg.knn_search(tp, tq, 14)
+    assert idx.shape == (1, 12) and idx.cpu().numpy().tolist() == [KNN_IDX]
+    assert np.allclose(d2.cpu().numpy(), [KNN_D2], rtol=1e-5, atol=1e-8)
+    for bad in (0, -1):
+        with pytest.raises(RuntimeError, match="knn should be larger than 0"):
+            reg.knn_search(tp, tq, bad)
+    with pytest.raises(RuntimeError, match="knn > 64"):
+        reg.knn_search(torch.rand((100, 3), device="cuda"), tq, 65)
+    one = torch.tensor([[1.0, 2.0, 3.0]], device="cuda")
+    idx, d2 = reg.knn_search(one, tq, 5)
+    assert idx.cpu().numpy().tolist() == [[0]]
+    same = one.repeat(10, 1)
+    idx, d2 = reg.knn_search(same, one, 4)
+    assert idx.cpu().numpy().tolist() == [[0, 1, 2, 3]]
+    assert (d2.cpu().numpy() == 0).all()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_estimate_normals_knn_variant(dtype):
+    """EstimateNormals(max_nn = 30, radius = nullopt) -- the reference's default
+    (EstimateCovariancesUsingKNNSearch, PointCloudImpl.h:692-744)."""
+    _lib, reg = _gpu()
+    pts, nrm_true = _cloud(12000, 9, dtype)
+    tp = torch.from_numpy(pts).cuda()
+    got = reg.estimate_normals(tp, 30).cpu().numpy()
+    widx, _ = orc.knn_search(pts, pts, 30)
+    wcnt = np.full(pts.shape[0], 30, np.int32)
+    want = orc.normals_from_covariances(
+        orc.estimate_covariances(pts, widx, wcnt))
+    tol = 1e-4 if dtype == np.float32 else 1e-10
+    assert np.abs(got - want).max() <= tol
+    cosang = np.abs((got[:12000] * nrm_true).sum(1))
+    assert np.median(cosang) > 0.99
+    # fewer than 3 points in the whole cloud is the reference's error
+    with pytest.raises(RuntimeError, match="Not enough neighbors"):
+        reg.estimate_normals(tp[:2].contiguous(), 30)

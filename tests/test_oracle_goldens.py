@@ -98,6 +98,28 @@ def test_hybrid_search_golden():
         assert cnt.tolist() == [2]
 
 
+KNN_PTS = np.array([[0.0, 0.0, 0.0], [0.0, 0.0, 0.1], [0.0, 0.0, 0.2],
+                    [0.0, 0.1, 0.0], [0.0, 0.1, 0.1], [0.0, 0.1, 0.2],
+                    [0.0, 0.2, 0.0], [0.0, 0.2, 0.1], [0.0, 0.2, 0.2],
+                    [0.1, 0.0, 0.0], [0.1, 0.0, 0.1], [0.1, 0.1, 0.0]],
+                   np.float32)
+KNN_Q = np.array([[0.064705, 0.043921, 0.087843]], np.float32)
+KNN_IDX = [10, 1, 4, 9, 11, 0, 3, 2, 5, 7, 6, 8]
+KNN_D2 = [0.00332258, 0.00626358, 0.00747938, 0.0108912, 0.0121070, 0.0138322,
+          0.015048, 0.018695, 0.0199108, 0.0286952, 0.0362638, 0.0411266]
+
+
+def test_knn_search_golden():
+    """NNSPermuteDevices.KnnSearch (cpp/tests/core/NearestNeighborSearch.cpp:
+    36-111): k = 3 and k > dataset size (row width = dataset size)."""
+    idx, d2 = orc.knn_search(KNN_PTS, KNN_Q, 3)
+    assert idx.tolist() == [KNN_IDX[:3]]
+    assert np.allclose(d2, [KNN_D2[:3]], rtol=1e-5, atol=1e-8)
+    idx, d2 = orc.knn_search(KNN_PTS, KNN_Q, 14)
+    assert idx.shape == (1, 12) and idx.tolist() == [KNN_IDX]
+    assert np.allclose(d2, [KNN_D2], rtol=1e-5, atol=1e-8)
+
+
 def test_hybrid_search_radius_is_strict():
     """nanoflann v1.5.0 RadiusResultSet::addPoint keeps dist < radius only."""
     pts = np.array([[0.0, 0.0, 0.0], [0.5, 0.0, 0.0]], np.float32)

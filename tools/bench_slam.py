@@ -374,7 +374,7 @@ def mode_normals(a):
     from open3d_amd import registration as reg, synthetic
     p = synthetic.make_icp_pair(a.points, a.points, seed=0)
     pts = torch.from_numpy(p["target"]).cuda()
-    radius = 0.05
+    radius = None if a.knn_only else 0.05
     for _ in range(2):
         n = reg.estimate_normals(pts, 30, radius)
     torch.cuda.synchronize()
@@ -388,7 +388,7 @@ def mode_normals(a):
            "radius": radius, "ms_per_call": ms,
            "points_per_s": a.points / ms * 1e3,
            "median_abs_cos_to_true_normal": float(np.median(np.abs(cosang)))}
-    if not a.no_cpu:
+    if not a.no_cpu and not a.knn_only:
         import _oracle as orc
         orc.set_threads(min(64, os.cpu_count() or 1))
         m = min(a.points, 20000)
@@ -410,6 +410,9 @@ def main():
                     choices=["p2plane", "intensity", "hybrid"])
     ap.add_argument("--estimation", default="p2plane",
                     choices=["p2plane", "p2point"], help="icp mode")
+    ap.add_argument("--knn-only", action="store_true",
+                    help="normals mode: EstimateNormals(max_nn=30) without a "
+                         "radius (KNN search)")
     ap.add_argument("--cpu-frames", type=int, default=0)
     ap.add_argument("--phases", action="store_true",
                     help="slam mode: synchronise between phases and report "
