@@ -31,6 +31,7 @@
 #include <cmath>
 #include <vector>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -262,19 +263,78 @@ __global__ void HybridSearchK1Kernel(NnsView<T> nv, const T* __restrict__ q,
 // idx padded with -1, dist with 0, count = min(found, max_knn)). One lane per
 // query; the running top-k list lives in private memory.
 constexpr int kMaxKnn = 64;
+constexpr int kTopKBlock = 64;  // one wave per workgroup, one query per lane
+
+// Running top-k list of one query, ascending by (d2, index). The list lives in
+// LDS, entry k of lane l at [k * kTopKBlock + l] (conflict-free whatever k each
+// lane touches); private arrays would sit in scratch memory, and the insertion
+// shifts are a dependent load/store chain. The current k-th entry is mirrored
+// in registers so that the common case -- a candidate that does not make the
+// list -- costs no memory access.
+template <typename T>
+struct TopK {
+    T* bd;
+    int* bi;
+    int knn;
+    int found;
+    T kth_d2;
+    int kth_idx;
+
+    __device__ __forceinline__ void Init(char* lds, int k) {
+        knn = k;
+        found = 0;
+        kth_d2 = T(0);
+        kth_idx = -1;
+        bd = (T*)lds + threadIdx.x;
+        bi = (int*)(lds + sizeof(T) * kTopKBlock * k) + threadIdx.x;
+    }
+    __device__ __forceinline__ T& D(int k) { return bd[k * kTopKBlock]; }
+    __device__ __forceinline__ int& I(int k) { return bi[k * kTopKBlock]; }
+
+    __device__ __forceinline__ void Insert(T result, int pi) {
+        if (found == knn) {
+            // not better than the k-th (or the k-th itself, seen again)
+            if (result > kth_d2 || (result == kth_d2 && pi >= kth_idx)) return;
+        }
+        const int len = found;
+        int pos = len;
+        while (pos > 0) {
+            const T dp = D(pos - 1);
+            if (result < dp || (result == dp && pi < I(pos - 1))) --pos;
+            else break;
+        }
+        // a bucket can serve several cells: the record was seen before (same
+        // index => same distance => it sits right below the insertion point)
+        if (pos > 0 && I(pos - 1) == pi) return;
+        for (int k = (found < knn ? found : knn - 1); k > pos; --k) {
+            D(k) = D(k - 1);
+            I(k) = I(k - 1);
+        }
+        D(pos) = result;
+        I(pos) = pi;
+        if (found < knn) ++found;
+        if (found == knn) {
+            kth_d2 = D(knn - 1);
+            kth_idx = I(knn - 1);
+        }
+    }
+};
+
+inline size_t TopKLdsBytes(int k, size_t elem) {
+    return (elem + sizeof(int)) * (size_t)kTopKBlock * (size_t)k;
+}
 
 template <typename T>
-__global__ void HybridSearchKernel(NnsView<T> nv, const T* __restrict__ q,
-                                   int64_t nq, int max_knn,
-                                   int* __restrict__ idx_out,
-                                   T* __restrict__ d2_out,
-                                   int* __restrict__ cnt_out) {
+__global__ void __launch_bounds__(kTopKBlock)
+HybridSearchKernel(NnsView<T> nv, const T* __restrict__ q, int64_t nq,
+                   int max_knn, int* __restrict__ idx_out,
+                   T* __restrict__ d2_out, int* __restrict__ cnt_out) {
+    extern __shared__ __align__(16) char topk_lds[];
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nq;
          i += (int64_t)gridDim.x * blockDim.x) {
         const T qq[3] = {q[3 * i + 0], q[3 * i + 1], q[3 * i + 2]};
-        T bd[kMaxKnn];
-        int bi[kMaxKnn];
-        int found = 0;
+        TopK<T> list;
+        list.Init(topk_lds, max_knn);
         long long cx, cy, cz;
         CellOf(qq, nv.inv_cell, cx, cy, cz);
         for (int c = 0; c < 27; ++c) {
@@ -291,32 +351,16 @@ __global__ void HybridSearchKernel(NnsView<T> nv, const T* __restrict__ q,
                 const T dd = qq[2] - p.z;
                 result += dd * dd;
                 if (!(result < nv.radius_squared)) continue;
-                const int pi = RecIndex(p);
-                // position in the ascending (d2, index) list
-                const int len = found < max_knn ? found : max_knn;
-                int pos = len;
-                while (pos > 0 && (result < bd[pos - 1] ||
-                                   (result == bd[pos - 1] && pi < bi[pos - 1])))
-                    --pos;
-                // two neighbour cells can hash to the same bucket: the record
-                // was seen before (same index => same distance, adjacent)
-                if (pos > 0 && bi[pos - 1] == pi) continue;
-                if (pos >= max_knn) continue;
-                for (int k = (found < max_knn ? found : max_knn - 1); k > pos;
-                     --k) {
-                    bd[k] = bd[k - 1];
-                    bi[k] = bi[k - 1];
-                }
-                bd[pos] = result;
-                bi[pos] = pi;
-                if (found < max_knn) ++found;
+                list.Insert(result, RecIndex(p));
             }
         }
         for (int k = 0; k < max_knn; ++k) {
-            if (idx_out) idx_out[i * max_knn + k] = k < found ? bi[k] : -1;
-            if (d2_out) d2_out[i * max_knn + k] = k < found ? bd[k] : T(0);
+            if (idx_out)
+                idx_out[i * max_knn + k] = k < list.found ? list.I(k) : -1;
+            if (d2_out)
+                d2_out[i * max_knn + k] = k < list.found ? list.D(k) : T(0);
         }
-        if (cnt_out) cnt_out[i] = found;
+        if (cnt_out) cnt_out[i] = list.found;
     }
 }
 
@@ -342,8 +386,7 @@ struct KnnGrid {
 template <typename T>
 __device__ __forceinline__ void KnnVisitCell(const NnsView<T>& nv, const T* qq,
                                              long long x, long long y,
-                                             long long z, int knn, T* bd,
-                                             int* bi, int& found) {
+                                             long long z, TopK<T>& list) {
     const unsigned b = HashCell(x, y, z) & nv.mask;
     const unsigned s0 = nv.starts[b], e0 = nv.starts[b + 1];
     for (unsigned j = s0; j < e0; ++j) {
@@ -355,22 +398,7 @@ __device__ __forceinline__ void KnnVisitCell(const NnsView<T>& nv, const T* qq,
         result += d1 * d1;
         const T dd = qq[2] - p.z;
         result += dd * dd;
-        const int pi = RecIndex(p);
-        const int len = found < knn ? found : knn;
-        int pos = len;
-        while (pos > 0 && (result < bd[pos - 1] ||
-                           (result == bd[pos - 1] && pi < bi[pos - 1])))
-            --pos;
-        // a bucket can serve several cells: the record was seen before
-        if (pos > 0 && bi[pos - 1] == pi) continue;
-        if (pos >= knn) continue;
-        for (int k = (found < knn ? found : knn - 1); k > pos; --k) {
-            bd[k] = bd[k - 1];
-            bi[k] = bi[k - 1];
-        }
-        bd[pos] = result;
-        bi[pos] = pi;
-        if (found < knn) ++found;
+        list.Insert(result, RecIndex(p));
     }
 }
 
@@ -390,16 +418,16 @@ struct KnnPyramid {
 };
 
 template <typename T>
-__global__ void KnnSearchKernel(KnnPyramid<T> pyr, const T* __restrict__ q,
-                                int64_t nq, int knn, int* __restrict__ idx_out,
-                                T* __restrict__ d2_out,
-                                int* __restrict__ cnt_out) {
+__global__ void __launch_bounds__(kTopKBlock)
+KnnSearchKernel(KnnPyramid<T> pyr, const T* __restrict__ q, int64_t nq, int knn,
+                int* __restrict__ idx_out, T* __restrict__ d2_out,
+                int* __restrict__ cnt_out) {
+    extern __shared__ __align__(16) char topk_lds[];
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nq;
          i += (int64_t)gridDim.x * blockDim.x) {
         const T qq[3] = {q[3 * i + 0], q[3 * i + 1], q[3 * i + 2]};
-        T bd[kMaxKnn];
-        int bi[kMaxKnn];
-        int found = 0;
+        TopK<T> list;
+        list.Init(topk_lds, knn);
         bool done = false;
         for (int l = 0; l < pyr.n_levels && !done; ++l) {
             const KnnGrid<T>& g = pyr.level[l];
@@ -440,22 +468,19 @@ __global__ void KnnSearchKernel(KnnPyramid<T> pyr, const T* __restrict__ q,
                             const long long xlo = max(c[0] - r, g.cmin[0]);
                             const long long xhi = min(c[0] + r, g.cmax[0]);
                             for (long long x = xlo; x <= xhi; ++x)
-                                KnnVisitCell(g.nv, qq, x, y, z, knn, bd, bi,
-                                             found);
+                                KnnVisitCell(g.nv, qq, x, y, z, list);
                         } else {
                             const long long xa = c[0] - r, xb = c[0] + r;
                             if (xa >= g.cmin[0] && xa <= g.cmax[0])
-                                KnnVisitCell(g.nv, qq, xa, y, z, knn, bd, bi,
-                                             found);
+                                KnnVisitCell(g.nv, qq, xa, y, z, list);
                             if (xb != xa && xb >= g.cmin[0] && xb <= g.cmax[0])
-                                KnnVisitCell(g.nv, qq, xb, y, z, knn, bd, bi,
-                                             found);
+                                KnnVisitCell(g.nv, qq, xb, y, z, list);
                         }
                     }
                 }
-                if (found == knn) {
+                if (list.found == knn) {
                     const double bound = (double)r * g.cell + margin;
-                    if ((double)bd[knn - 1] < bound * bound * (1.0 - 1e-6)) {
+                    if ((double)list.kth_d2 < bound * bound * (1.0 - 1e-6)) {
                         done = true;
                         break;
                     }
@@ -463,10 +488,10 @@ __global__ void KnnSearchKernel(KnnPyramid<T> pyr, const T* __restrict__ q,
             }
         }
         for (int k = 0; k < knn; ++k) {
-            if (idx_out) idx_out[i * knn + k] = k < found ? bi[k] : -1;
-            if (d2_out) d2_out[i * knn + k] = k < found ? bd[k] : T(0);
+            if (idx_out) idx_out[i * knn + k] = k < list.found ? list.I(k) : -1;
+            if (d2_out) d2_out[i * knn + k] = k < list.found ? list.D(k) : T(0);
         }
-        if (cnt_out) cnt_out[i] = found;
+        if (cnt_out) cnt_out[i] = list.found;
     }
 }
 
@@ -1079,13 +1104,15 @@ int o3dmi_nns_hybrid_search(const o3dmi_nns_t* nns, const void* queries_dev,
     if (q == 0) return O3DMI_OK;
     O3DMI_REQUIRE(queries_dev != nullptr, "queries is null");
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(GridFor(q, kBlock)), block(kBlock);
+    dim3 grid(GridFor(q, kTopKBlock)), block(kTopKBlock);
     if (nns->dtype == O3DMI_F64)
-        hipLaunchKernelGGL(HybridSearchKernel<double>, grid, block, 0, s,
+        hipLaunchKernelGGL(HybridSearchKernel<double>, grid, block,
+                           TopKLdsBytes(max_knn, sizeof(double)), s,
                            MakeView<double>(nns), (const double*)queries_dev, q,
                            max_knn, idx_dev, (double*)dist2_dev, counts_dev);
     else
-        hipLaunchKernelGGL(HybridSearchKernel<float>, grid, block, 0, s,
+        hipLaunchKernelGGL(HybridSearchKernel<float>, grid, block,
+                           TopKLdsBytes(max_knn, sizeof(float)), s,
                            MakeView<float>(nns), (const float*)queries_dev, q,
                            max_knn, idx_dev, (float*)dist2_dev, counts_dev);
     O3DMI_HIP_CHECK(hipGetLastError());
@@ -1143,7 +1170,11 @@ int o3dmi_nns_knn_search_counts(const void* points_dev, int64_t n,
     // first guess: a surface spanning the two largest extents, or a filled
     // volume, whichever gives the larger cell (shrinking is the cheap
     // direction: few occupied cells -> reliable estimate of the density)
-    const double target = k / 2.0 < 2.0 ? 2.0 : k / 2.0;
+    double target = k / 2.0 < 2.0 ? 2.0 : k / 2.0;
+    if (const char* e_ = std::getenv("O3DMI_KNN_PPC")) {  // tuning: points/cell
+        const double v = std::atof(e_);
+        if (v > 0) target = v;
+    }
     double e[3] = {ext[0], ext[1], ext[2]};
     std::sort(e, e + 3);
     const double emax = e[2] > 0 ? e[2] : 1.0;
@@ -1204,6 +1235,10 @@ int o3dmi_nns_knn_search_counts(const void* points_dev, int64_t n,
                      : BuildIndex<float>(up, (const float*)points_dev, s);
         if (st) break;
     }
+    if (std::getenv("O3DMI_VERBOSE"))
+        std::fprintf(stderr,
+                     "[o3dmi] knn: n=%lld k=%d cell=%g levels=%d target=%g\n",
+                     (long long)n, k, h, (int)levels.size(), target);
     if (!st) {
         const dim3 grid(GridFor(q, 64)), block(64);
 #define O3DMI_KNN(T)                                                           \
@@ -1221,7 +1256,8 @@ int o3dmi_nns_knn_search_counts(const void* points_dev, int64_t n,
                                                    levels[l]->inv_cell) + 1;   \
             }                                                                  \
         }                                                                      \
-        hipLaunchKernelGGL(KnnSearchKernel<T>, grid, block, 0, s, pyr,         \
+        hipLaunchKernelGGL(KnnSearchKernel<T>, grid, block,                    \
+                           TopKLdsBytes(k, sizeof(T)), s, pyr,                 \
                            (const T*)queries_dev, q, k, idx_dev,               \
                            (T*)dist2_dev, counts_dev);                         \
     } while (0)

@@ -246,8 +246,9 @@ def knn_search(points, queries, knn):
         raise ValueError("points / queries dtype mismatch")
     n, q = points.shape[0], queries.shape[0]
     k = min(int(knn), n)
-    idx = torch.empty((q, k), dtype=torch.int32, device="cuda")
-    d2 = torch.empty((q, k), dtype=points.dtype, device="cuda")
+    ka = max(k, 1)  # knn <= 0 is rejected by the library, as in the reference
+    idx = torch.empty((q, ka), dtype=torch.int32, device="cuda")
+    d2 = torch.empty((q, ka), dtype=points.dtype, device="cuda")
     _lib.check(_lib.lib().o3dmi_nns_knn_search(
         _lib.ptr(points), n, _lib.ptr(queries), q,
         TORCH_TO_O3DMI[points.dtype], int(knn), _lib.ptr(idx), _lib.ptr(d2),
