@@ -257,92 +257,237 @@ __global__ void HybridSearchK1Kernel(NnsView<T> nv, const T* __restrict__ q,
     }
 }
 
-// ---- robust kernels ---------------------------------------------------------
-// HybridSearch for general max_knn (core/nns/NanoFlannImpl.h:305-370 semantics:
-// neighbours with d2 < r2, ascending by (d2, index), the first max_knn kept;
-// idx padded with -1, dist with 0, count = min(found, max_knn)). One lane per
-// query; the running top-k list lives in private memory.
-constexpr int kMaxKnn = 64;
-constexpr int kTopKBlock = 64;  // one wave per workgroup, one query per lane
+constexpr int kMaxKnn = 64;  // general-k searches: k <= one wave
 
-// Running top-k list of one query, ascending by (d2, index). The list lives in
-// LDS, entry k of lane l at [k * kTopKBlock + l] (conflict-free whatever k each
-// lane touches); private arrays would sit in scratch memory, and the insertion
-// shifts are a dependent load/store chain. The current k-th entry is mirrored
-// in registers so that the common case -- a candidate that does not make the
-// list -- costs no memory access.
+// ---- general-k searches: one wave per query --------------------------------
+// A lane-per-query search keeps a sorted k-list per lane and pays a dependent
+// chain of ~2 loads per neighbour cell plus an insertion shift per candidate,
+// with the 64 lanes of a wave diverging on every one of them (2.7 ms for
+// 100 k queries at k = 30 even with the lists in LDS). Here a wave serves one
+// query:
+//   * lane c looks up neighbour cell c (bucket bounds), a wave prefix sum
+//     turns the per-cell counts into one candidate range, and lane t fetches
+//     candidate t (owner cell found by a 6-step search over the prefix) --
+//     two memory round trips for any number of cells. A record is accepted
+//     only if its own cell is the cell it was fetched for, so records that
+//     merely share the bucket (hash collisions) never show up twice;
+//   * accepted candidates are compacted into an LDS buffer of the wave;
+//   * the k best are found by rank counting: candidate p reads every buffered
+//     candidate q (a broadcast LDS read) and counts those that sort before it
+//     by (d2, index); rank < k means "rank-th neighbour". No dependent chain,
+//     no divergence, ties impossible because indices are unique.
+constexpr int kCoopCap = 512;    // buffered candidates per wave before a merge
+constexpr int kCoopBlock = 256;  // 4 waves = 4 queries in flight per workgroup
+constexpr int kNoIndex = 0x7fffffff;
+
 template <typename T>
-struct TopK {
-    T* bd;
-    int* bi;
+__device__ __forceinline__ T InfOf() { return (T)INFINITY; }
+
+template <typename T>
+__device__ __forceinline__ bool PairLess(T ad, int ai, T bd, int bi) {
+    return ad < bd || (ad == bd && ai < bi);
+}
+
+__device__ __forceinline__ void WaveLdsSync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Buffer rows: kCoopCap, + one more batch of 64 (the merge is triggered after
+// the batch that crosses kCoopCap), + the current list of <= 64 entries that
+// competes again in a merge; then the 64 ranked rows.
+constexpr int kCoopRows = kCoopCap + 128;
+
+template <typename T>
+constexpr size_t CoopLdsBytesPerWave() {
+    return (sizeof(T) + sizeof(int)) * (size_t)(kCoopRows + 64);
+}
+
+template <typename T> struct Quad;
+template <> struct Quad<float> { using type = float4; };
+template <> struct Quad<double> { using type = double4; };
+
+template <typename T>
+struct WaveTopK {
+    T* cd;       // LDS: candidates [kCoopRows], then ranked list [64]
+    int* ci;
+    T* rd;
+    int* ri;
+    int m;       // buffered candidates (wave-uniform)
+    T best_d;    // rank = lane, valid for lane < nbest
+    int best_i;
+    int nbest;   // wave-uniform
     int knn;
-    int found;
-    T kth_d2;
-    int kth_idx;
+    T kth_d;     // the k-th entry once nbest == knn (wave-uniform)
+    int kth_i;
 
-    __device__ __forceinline__ void Init(char* lds, int k) {
-        knn = k;
-        found = 0;
-        kth_d2 = T(0);
-        kth_idx = -1;
-        bd = (T*)lds + threadIdx.x;
-        bi = (int*)(lds + sizeof(T) * kTopKBlock * k) + threadIdx.x;
+    __device__ __forceinline__ void Init(char* lds) {
+        char* base = lds + CoopLdsBytesPerWave<T>() * (threadIdx.x >> 6);
+        cd = (T*)base;
+        rd = cd + kCoopRows;
+        ci = (int*)(rd + 64);
+        ri = ci + kCoopRows;
     }
-    __device__ __forceinline__ T& D(int k) { return bd[k * kTopKBlock]; }
-    __device__ __forceinline__ int& I(int k) { return bi[k * kTopKBlock]; }
 
-    __device__ __forceinline__ void Insert(T result, int pi) {
-        if (found == knn) {
-            // not better than the k-th (or the k-th itself, seen again)
-            if (result > kth_d2 || (result == kth_d2 && pi >= kth_idx)) return;
+    __device__ __forceinline__ void Reset(int k) {
+        m = 0;
+        best_d = InfOf<T>();
+        best_i = kNoIndex;
+        nbest = 0;
+        knn = k;
+        kth_d = InfOf<T>();
+        kth_i = kNoIndex;
+    }
+
+    // Candidate of this lane (kNoIndex = none).
+    __device__ __forceinline__ void Push(T d, int i) {
+        // what cannot make the list any more is dropped here
+        bool valid = i != kNoIndex;
+        if (valid && nbest == knn && !PairLess(d, i, kth_d, kth_i)) valid = false;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(valid);
+        if (mask == 0) return;
+        const int lane = threadIdx.x & 63;
+        const int at = m + __popcll(mask & ((1ull << lane) - 1ull));
+        if (valid) {
+            cd[at] = d;
+            ci[at] = i;
         }
-        const int len = found;
-        int pos = len;
-        while (pos > 0) {
-            const T dp = D(pos - 1);
-            if (result < dp || (result == dp && pi < I(pos - 1))) --pos;
-            else break;
+        m += __popcll(mask);
+        if (m > kCoopCap) Select();  // room for one more batch of 64 is kept
+    }
+
+    __device__ __forceinline__ void Flush() {
+        if (m > 0) Select();
+    }
+
+    // Merge the buffer into the ranked list.
+    __device__ __forceinline__ void Select() {
+        const int lane = threadIdx.x & 63;
+        // the current list competes again
+        int total = m;
+        if (lane < nbest) {
+            cd[total + lane] = best_d;
+            ci[total + lane] = best_i;
         }
-        // a bucket can serve several cells: the record was seen before (same
-        // index => same distance => it sits right below the insertion point)
-        if (pos > 0 && I(pos - 1) == pi) return;
-        for (int k = (found < knn ? found : knn - 1); k > pos; --k) {
-            D(k) = D(k - 1);
-            I(k) = I(k - 1);
+        total += nbest;
+        // pad to whole quads with entries that sort after everything
+        const int padded = (total + 3) & ~3;
+        if (lane < padded - total) {
+            cd[total + lane] = InfOf<T>();
+            ci[total + lane] = kNoIndex;
         }
-        D(pos) = result;
-        I(pos) = pi;
-        if (found < knn) ++found;
-        if (found == knn) {
-            kth_d2 = D(knn - 1);
-            kth_idx = I(knn - 1);
+        WaveLdsSync();
+        using Q = typename Quad<T>::type;
+        // two candidates per lane per pass over the buffer (quad LDS reads,
+        // every lane reads the same address: broadcast)
+        for (int p0 = 0; p0 < total; p0 += 128) {
+            const int pa = p0 + lane, pb = p0 + 64 + lane;
+            const bool ha = pa < total, hb = pb < total;
+            const T a_d = ha ? cd[pa] : InfOf<T>();
+            const int a_i = ha ? ci[pa] : kNoIndex;
+            const T b_d = hb ? cd[pb] : InfOf<T>();
+            const int b_i = hb ? ci[pb] : kNoIndex;
+            int ra = 0, rb = 0;
+#pragma unroll 2
+            for (int qi = 0; qi < padded; qi += 4) {
+                const Q d4 = *(const Q*)(cd + qi);
+                const int4 i4 = *(const int4*)(ci + qi);
+                ra += (PairLess(d4.x, i4.x, a_d, a_i) ? 1 : 0) +
+                      (PairLess(d4.y, i4.y, a_d, a_i) ? 1 : 0) +
+                      (PairLess(d4.z, i4.z, a_d, a_i) ? 1 : 0) +
+                      (PairLess(d4.w, i4.w, a_d, a_i) ? 1 : 0);
+                rb += (PairLess(d4.x, i4.x, b_d, b_i) ? 1 : 0) +
+                      (PairLess(d4.y, i4.y, b_d, b_i) ? 1 : 0) +
+                      (PairLess(d4.z, i4.z, b_d, b_i) ? 1 : 0) +
+                      (PairLess(d4.w, i4.w, b_d, b_i) ? 1 : 0);
+            }
+            if (ha && ra < knn) {
+                rd[ra] = a_d;
+                ri[ra] = a_i;
+            }
+            if (hb && rb < knn) {
+                rd[rb] = b_d;
+                ri[rb] = b_i;
+            }
         }
+        WaveLdsSync();
+        nbest = total < knn ? total : knn;
+        best_d = lane < nbest ? rd[lane] : InfOf<T>();
+        best_i = lane < nbest ? ri[lane] : kNoIndex;
+        if (nbest == knn) {
+            kth_d = rd[knn - 1];
+            kth_i = ri[knn - 1];
+        }
+        WaveLdsSync();
+        m = 0;
     }
 };
 
-inline size_t TopKLdsBytes(int k, size_t elem) {
-    return (elem + sizeof(int)) * (size_t)kTopKBlock * (size_t)k;
-}
-
-template <typename T>
-__global__ void __launch_bounds__(kTopKBlock)
-HybridSearchKernel(NnsView<T> nv, const T* __restrict__ q, int64_t nq,
-                   int max_knn, int* __restrict__ idx_out,
-                   T* __restrict__ d2_out, int* __restrict__ cnt_out) {
-    extern __shared__ __align__(16) char topk_lds[];
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nq;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const T qq[3] = {q[3 * i + 0], q[3 * i + 1], q[3 * i + 2]};
-        TopK<T> list;
-        list.Init(topk_lds, max_knn);
-        long long cx, cy, cz;
-        CellOf(qq, nv.inv_cell, cx, cy, cz);
-        for (int c = 0; c < 27; ++c) {
-            const int dz = c / 9 - 1, dy = (c % 9) / 3 - 1, dx = c % 3 - 1;
-            const unsigned b = HashCell(cx + dx, cy + dy, cz + dz) & nv.mask;
-            const unsigned s0 = nv.starts[b], e0 = nv.starts[b + 1];
-            for (unsigned j = s0; j < e0; ++j) {
-                const Rec4<T> p = nv.sorted[j];
+// Candidates of the cells [x0..x1] x [y0..y1] x [z0..z1] whose Chebyshev cell
+// distance to (cx, cy, cz) is >= r_skip. RADIUS: keep d2 < nv.radius_squared.
+template <typename T, bool RADIUS>
+__device__ __forceinline__ void GatherCells(const NnsView<T>& nv, const T* qq,
+                                            long long cx, long long cy,
+                                            long long cz, long long x0,
+                                            long long x1, long long y0,
+                                            long long y1, long long z0,
+                                            long long z1, long long r_skip,
+                                            WaveTopK<T>& list) {
+    if (x1 < x0 || y1 < y0 || z1 < z0) return;
+    const int lane = threadIdx.x & 63;
+    const int nx = (int)(x1 - x0 + 1), ny = (int)(y1 - y0 + 1);
+    const int nz = (int)(z1 - z0 + 1);
+    const int ncell = nx * ny * nz;
+    for (int base = 0; base < ncell; base += 64) {
+        const int ci = base + lane;
+        unsigned s0 = 0, cnt = 0;
+        if (ci < ncell) {
+            const long long x = x0 + ci % nx, y = y0 + (ci / nx) % ny,
+                            z = z0 + ci / (nx * ny);
+            long long ax = x - cx, ay = y - cy, az = z - cz;
+            ax = ax < 0 ? -ax : ax;
+            ay = ay < 0 ? -ay : ay;
+            az = az < 0 ? -az : az;
+            const long long cheb = max(ax, max(ay, az));
+            if (cheb >= r_skip) {
+                const unsigned b = HashCell(x, y, z) & nv.mask;
+                s0 = nv.starts[b];
+                cnt = nv.starts[b + 1] - s0;
+            }
+        }
+        unsigned incl = cnt;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const unsigned o = __shfl_up(incl, m);
+            if (lane >= m) incl += o;
+        }
+        const unsigned total = __shfl(incl, 63);
+        const unsigned excl = incl - cnt;
+        for (unsigned t0 = 0; t0 < total; t0 += 64) {
+            const unsigned t = t0 + lane;
+            const unsigned tc = t < total ? t : total - 1;
+            // owner cell: number of lanes whose inclusive prefix is <= t
+            int pos = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1) {
+                const unsigned v = __shfl(incl, pos + step - 1);
+                if (v <= tc) pos += step;
+            }
+            const unsigned oe = __shfl(excl, pos);
+            const unsigned os = __shfl(s0, pos);
+            T d = InfOf<T>();
+            int pi = kNoIndex;
+            if (t < total) {
+                const Rec4<T> p = nv.sorted[os + (t - oe)];
+                // the record's own cell must be the cell it was fetched for
+                const T pp[3] = {p.x, p.y, p.z};
+                long long rx, ry, rz;
+                CellOf(pp, nv.inv_cell, rx, ry, rz);
+                const bool own = rx >= x0 && rx <= x1 && ry >= y0 && ry <= y1 &&
+                                 rz >= z0 && rz <= z1 &&
+                                 (int)(rx - x0) + nx * ((int)(ry - y0) +
+                                                        ny * (int)(rz - z0)) ==
+                                         base + pos;
                 T result = T(0);
                 const T d0 = qq[0] - p.x;
                 result += d0 * d0;
@@ -350,17 +495,52 @@ HybridSearchKernel(NnsView<T> nv, const T* __restrict__ q, int64_t nq,
                 result += d1 * d1;
                 const T dd = qq[2] - p.z;
                 result += dd * dd;
-                if (!(result < nv.radius_squared)) continue;
-                list.Insert(result, RecIndex(p));
+                if (own && (!RADIUS || result < nv.radius_squared)) {
+                    d = result;
+                    pi = RecIndex(p);
+                }
             }
+            list.Push(d, pi);
         }
-        for (int k = 0; k < max_knn; ++k) {
-            if (idx_out)
-                idx_out[i * max_knn + k] = k < list.found ? list.I(k) : -1;
-            if (d2_out)
-                d2_out[i * max_knn + k] = k < list.found ? list.D(k) : T(0);
-        }
-        if (cnt_out) cnt_out[i] = list.found;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void WriteTopK(const WaveTopK<T>& list, int64_t i,
+                                          int* __restrict__ idx_out,
+                                          T* __restrict__ d2_out,
+                                          int* __restrict__ cnt_out) {
+    const int lane = threadIdx.x & 63;
+    if (lane < list.knn) {
+        const bool ok = lane < list.nbest;
+        if (idx_out) idx_out[i * list.knn + lane] = ok ? list.best_i : -1;
+        if (d2_out) d2_out[i * list.knn + lane] = ok ? list.best_d : T(0);
+    }
+    if (cnt_out && lane == 0) cnt_out[i] = list.nbest;
+}
+
+// HybridSearch for general max_knn (core/nns/NanoFlannImpl.h:305-370 semantics:
+// neighbours with d2 < r2, ascending by (d2, index), the first max_knn kept;
+// idx padded with -1, dist with 0, count = min(found, max_knn)).
+template <typename T>
+__global__ void __launch_bounds__(kCoopBlock)
+HybridSearchKernel(NnsView<T> nv, const T* __restrict__ q, int64_t nq,
+                   int max_knn, int* __restrict__ idx_out,
+                   T* __restrict__ d2_out, int* __restrict__ cnt_out) {
+    extern __shared__ __align__(16) char coop_lds[];
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    WaveTopK<T> list;
+    list.Init(coop_lds);
+    for (int64_t i = wave; i < nq; i += n_waves) {
+        const T qq[3] = {q[3 * i + 0], q[3 * i + 1], q[3 * i + 2]};
+        list.Reset(max_knn);
+        long long cx, cy, cz;
+        CellOf(qq, nv.inv_cell, cx, cy, cz);
+        GatherCells<T, true>(nv, qq, cx, cy, cz, cx - 1, cx + 1, cy - 1, cy + 1,
+                             cz - 1, cz + 1, 0, list);
+        list.Flush();
+        WriteTopK(list, i, idx_out, d2_out, cnt_out);
     }
 }
 
@@ -376,6 +556,12 @@ HybridSearchKernel(NnsView<T> nv, const T* __restrict__ q, int64_t nq,
 // so the walk stops as soon as the k-th distance is below that bound. The
 // cell size is chosen by the host so that an occupied cell holds ~knn / 2
 // points (shells 0 and 1 then usually suffice).
+// A query in a sparse region would walk thousands of empty shells on a single
+// fine grid, so the index is a pyramid: level l has cells 4^l times the finest;
+// a level is searched for at most kKnnShells shells, then the walk restarts on
+// the next coarser level (the list starts over there). The
+// coarsest level spans the whole cloud in a handful of cells and is searched
+// exhaustively.
 template <typename T>
 struct KnnGrid {
     NnsView<T> nv;
@@ -383,55 +569,74 @@ struct KnnGrid {
     long long cmin[3], cmax[3];  // occupied cell box
 };
 
-template <typename T>
-__device__ __forceinline__ void KnnVisitCell(const NnsView<T>& nv, const T* qq,
-                                             long long x, long long y,
-                                             long long z, TopK<T>& list) {
-    const unsigned b = HashCell(x, y, z) & nv.mask;
-    const unsigned s0 = nv.starts[b], e0 = nv.starts[b + 1];
-    for (unsigned j = s0; j < e0; ++j) {
-        const Rec4<T> p = nv.sorted[j];
-        T result = T(0);
-        const T d0 = qq[0] - p.x;
-        result += d0 * d0;
-        const T d1 = qq[1] - p.y;
-        result += d1 * d1;
-        const T dd = qq[2] - p.z;
-        result += dd * dd;
-        list.Insert(result, RecIndex(p));
-    }
-}
-
-// A query in a sparse region would walk thousands of empty shells on a single
-// fine grid, so the index is a pyramid: level l has cells 4^l times the finest;
-// a level is searched for at most kKnnShells shells, then the walk restarts on
-// the next coarser level (re-seen records are recognised in the list). The
-// coarsest level spans the whole cloud in a handful of cells and is searched
-// exhaustively.
 constexpr int kKnnMaxLevels = 12;
 constexpr int kKnnShells = 2;
 
 template <typename T>
 struct KnnPyramid {
     int n_levels;
+    int first_radius;  // cube radius of the first step on a level
+    int first_level;   // levels [first_level, n_levels) are walked
+    int exhaustive_last;  // the last level covers the cloud: search all of it
+    int brute;            // scan all n_points records instead of walking cells
+    int64_t n_points;
     KnnGrid<T> level[kKnnMaxLevels];
 };
 
 template <typename T>
-__global__ void __launch_bounds__(kTopKBlock)
+__global__ void __launch_bounds__(kCoopBlock)
+__attribute__((amdgpu_waves_per_eu(4)))
 KnnSearchKernel(KnnPyramid<T> pyr, const T* __restrict__ q, int64_t nq, int knn,
-                int* __restrict__ idx_out, T* __restrict__ d2_out,
-                int* __restrict__ cnt_out) {
-    extern __shared__ __align__(16) char topk_lds[];
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nq;
-         i += (int64_t)gridDim.x * blockDim.x) {
+                const int* __restrict__ query_ids, int* __restrict__ retry_ids,
+                int* __restrict__ retry_count, int* __restrict__ idx_out,
+                T* __restrict__ d2_out, int* __restrict__ cnt_out) {
+    extern __shared__ __align__(16) char coop_lds[];
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    WaveTopK<T> list;
+    list.Init(coop_lds);
+    for (int64_t w = wave; w < nq; w += n_waves) {
+        // second pass: only the queries the finest level could not finish
+        const int64_t i = query_ids ? (int64_t)query_ids[w] : w;
         const T qq[3] = {q[3 * i + 0], q[3 * i + 1], q[3 * i + 2]};
-        TopK<T> list;
-        list.Init(topk_lds, knn);
         bool done = false;
-        for (int l = 0; l < pyr.n_levels && !done; ++l) {
+        if (pyr.brute) {
+            // few leftover queries: one coalesced sweep over the records, the
+            // k-th distance prunes almost every batch after the first merges
+            list.Reset(knn);
+            const Rec4<T>* rec = pyr.level[0].nv.sorted;
+            const int lane = threadIdx.x & 63;
+            constexpr int kAhead = 8;  // record loads in flight per lane
+            for (int64_t t0 = 0; t0 < pyr.n_points; t0 += 64 * kAhead) {
+                Rec4<T> p[kAhead];
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) {
+                    const int64_t t = t0 + 64 * u + lane;
+                    p[u] = rec[t < pyr.n_points ? t : pyr.n_points - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) {
+                    const int64_t t = t0 + 64 * u + lane;
+                    T result = T(0);
+                    const T d0 = qq[0] - p[u].x;
+                    result += d0 * d0;
+                    const T d1 = qq[1] - p[u].y;
+                    result += d1 * d1;
+                    const T dd = qq[2] - p[u].z;
+                    result += dd * dd;
+                    const bool in = t < pyr.n_points;
+                    list.Push(in ? result : InfOf<T>(),
+                              in ? RecIndex(p[u]) : kNoIndex);
+                }
+            }
+            list.Flush();
+            done = true;
+        }
+        for (int l = pyr.first_level; l < pyr.n_levels && !done; ++l) {
+            // a coarser level covers the finer one's cells again: start over
+            list.Reset(knn);
             const KnnGrid<T>& g = pyr.level[l];
-            const bool last = l == pyr.n_levels - 1;
+            const bool last = pyr.exhaustive_last && l == pyr.n_levels - 1;
             long long c[3];
             CellOf(qq, g.nv.inv_cell, c[0], c[1], c[2]);
             // distance to the nearest face of the query's own cell
@@ -450,48 +655,48 @@ KnnSearchKernel(KnnPyramid<T> pyr, const T* __restrict__ q, int64_t nq, int knn,
             // cell assignment rounds in float64: keep a small absolute slack
             margin -= 1e-7 * g.cell;
             if (!(margin > 0)) margin = 0;
-            if (!last) {
-                if (r0 > kKnnShells) continue;  // the box is out of reach here
-                rmax = min(rmax, (long long)kKnnShells);
+            if (last) {
+                // the whole occupied box in one step
+                GatherCells<T, false>(g.nv, qq, c[0], c[1], c[2], g.cmin[0],
+                                      g.cmax[0], g.cmin[1], g.cmax[1],
+                                      g.cmin[2], g.cmax[2], 0, list);
+                list.Flush();
+                done = true;
+                break;
             }
-            for (long long r = r0; r <= rmax; ++r) {
-                const long long zlo = max(c[2] - r, g.cmin[2]);
-                const long long zhi = min(c[2] + r, g.cmax[2]);
-                for (long long z = zlo; z <= zhi; ++z) {
-                    const bool zface = (z == c[2] - r) || (z == c[2] + r);
-                    const long long ylo = max(c[1] - r, g.cmin[1]);
-                    const long long yhi = min(c[1] + r, g.cmax[1]);
-                    for (long long y = ylo; y <= yhi; ++y) {
-                        const bool face =
-                                zface || (y == c[1] - r) || (y == c[1] + r);
-                        if (face) {
-                            const long long xlo = max(c[0] - r, g.cmin[0]);
-                            const long long xhi = min(c[0] + r, g.cmax[0]);
-                            for (long long x = xlo; x <= xhi; ++x)
-                                KnnVisitCell(g.nv, qq, x, y, z, list);
-                        } else {
-                            const long long xa = c[0] - r, xb = c[0] + r;
-                            if (xa >= g.cmin[0] && xa <= g.cmax[0])
-                                KnnVisitCell(g.nv, qq, xa, y, z, list);
-                            if (xb != xa && xb >= g.cmin[0] && xb <= g.cmax[0])
-                                KnnVisitCell(g.nv, qq, xb, y, z, list);
-                        }
-                    }
-                }
-                if (list.found == knn) {
+            if (r0 > kKnnShells) continue;  // the box is out of reach here
+            bool first = true;
+            for (long long r = r0 > pyr.first_radius ? r0 : pyr.first_radius;
+                 r <= kKnnShells; ++r) {
+                // first step: the whole cube of radius r (shells 0..r); then
+                // one shell at a time
+                GatherCells<T, false>(
+                        g.nv, qq, c[0], c[1], c[2], max(c[0] - r, g.cmin[0]),
+                        min(c[0] + r, g.cmax[0]), max(c[1] - r, g.cmin[1]),
+                        min(c[1] + r, g.cmax[1]), max(c[2] - r, g.cmin[2]),
+                        min(c[2] + r, g.cmax[2]), first ? 0 : r, list);
+                first = false;
+                list.Flush();
+                if (list.nbest == knn) {
                     const double bound = (double)r * g.cell + margin;
-                    if ((double)list.kth_d2 < bound * bound * (1.0 - 1e-6)) {
+                    if ((double)list.kth_d < bound * bound * (1.0 - 1e-6)) {
                         done = true;
                         break;
                     }
                 }
+                if (r >= rmax) {  // nothing of the box lies beyond: complete
+                    done = true;
+                    break;
+                }
             }
         }
-        for (int k = 0; k < knn; ++k) {
-            if (idx_out) idx_out[i * knn + k] = k < list.found ? list.I(k) : -1;
-            if (d2_out) d2_out[i * knn + k] = k < list.found ? list.D(k) : T(0);
+        if (!done) {
+            // first pass on the finest level only: leave it to the second
+            if (retry_ids && (threadIdx.x & 63) == 0)
+                retry_ids[atomicAdd(retry_count, 1)] = (int)i;
+            continue;
         }
-        if (cnt_out) cnt_out[i] = list.found;
+        WriteTopK(list, i, idx_out, d2_out, cnt_out);
     }
 }
 
@@ -549,6 +754,7 @@ __global__ void CountOccupiedKernel(const unsigned* __restrict__ starts,
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(occupied, local);
 }
 
+// ---- robust kernels ---------------------------------------------------------
 // RobustKernelImpl.h:35-126, literal: the double-typed literals promote parts
 // of each expression to float64 before the result is narrowed to scalar_t.
 template <typename T>
@@ -1104,15 +1310,16 @@ int o3dmi_nns_hybrid_search(const o3dmi_nns_t* nns, const void* queries_dev,
     if (q == 0) return O3DMI_OK;
     O3DMI_REQUIRE(queries_dev != nullptr, "queries is null");
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(GridFor(q, kTopKBlock)), block(kTopKBlock);
+    // one wave per query
+    dim3 grid(GridFor(q, kCoopBlock / 64, kCUs * 16)), block(kCoopBlock);
     if (nns->dtype == O3DMI_F64)
         hipLaunchKernelGGL(HybridSearchKernel<double>, grid, block,
-                           TopKLdsBytes(max_knn, sizeof(double)), s,
+                           CoopLdsBytesPerWave<double>() * (kCoopBlock / 64), s,
                            MakeView<double>(nns), (const double*)queries_dev, q,
                            max_knn, idx_dev, (double*)dist2_dev, counts_dev);
     else
         hipLaunchKernelGGL(HybridSearchKernel<float>, grid, block,
-                           TopKLdsBytes(max_knn, sizeof(float)), s,
+                           CoopLdsBytesPerWave<float>() * (kCoopBlock / 64), s,
                            MakeView<float>(nns), (const float*)queries_dev, q,
                            max_knn, idx_dev, (float*)dist2_dev, counts_dev);
     O3DMI_HIP_CHECK(hipGetLastError());
@@ -1128,7 +1335,7 @@ int o3dmi_nns_knn_search_counts(const void* points_dev, int64_t n,
                   "points must be Float32 or Float64");
     O3DMI_REQUIRE(knn > 0, "knn should be larger than 0.");
     O3DMI_REQUIRE(n > 0 && n < (1ll << 31) && points_dev, "empty dataset");
-    O3DMI_REQUIRE(q >= 0, "q < 0");
+    O3DMI_REQUIRE(q >= 0 && q < (1ll << 31) - 1, "q out of range");
     const int k = (int)(n < (int64_t)knn ? n : (int64_t)knn);
     O3DMI_REQUIRE(k <= kMaxKnn, "knn > 64 is not supported");
     if (q == 0) return O3DMI_OK;
@@ -1144,7 +1351,7 @@ int o3dmi_nns_knn_search_counts(const void* points_dev, int64_t n,
     O3DMI_HIP_CHECK(hipMemsetAsync(box + 3, 0, 24, s));
     {
         int g = GridFor(n, kBlock);
-        if (g > kCUs * 4) g = kCUs * 4;
+        if (g > kCUs) g = kCUs;  // 6 atomics per wave on 6 addresses
         if (dtype == O3DMI_F64)
             hipLaunchKernelGGL(BoundsKernel<double>, dim3(g), dim3(kBlock), 0,
                                s, (const double*)points_dev, n, box, box + 3);
@@ -1170,7 +1377,11 @@ int o3dmi_nns_knn_search_counts(const void* points_dev, int64_t n,
     // first guess: a surface spanning the two largest extents, or a filled
     // volume, whichever gives the larger cell (shrinking is the cheap
     // direction: few occupied cells -> reliable estimate of the density)
-    double target = k / 2.0 < 2.0 ? 2.0 : k / 2.0;
+    // points per occupied cell: small cells keep the candidate sets (and the
+    // quadratic rank counting) small, shell 1 yields a first list whose k-th
+    // distance prunes shell 2. Measured on MI355X, k = 30, 100 k queries:
+    // 3 per cell 1.8 ms, 4.5: 0.71 ms, 6: 0.84 ms, 8: 1.26 ms, 15: 2.5 ms.
+    double target = k * 0.15 < 2.0 ? 2.0 : k * 0.15;
     if (const char* e_ = std::getenv("O3DMI_KNN_PPC")) {  // tuning: points/cell
         const double v = std::atof(e_);
         if (v > 0) target = v;
@@ -1220,31 +1431,33 @@ int o3dmi_nns_knn_search_counts(const void* points_dev, int64_t n,
         if (nns) o3dmi_nns_destroy(nns);
         return st;
     }
-    // coarser levels, up to one that spans the cloud in <= 4 cells per axis
+    // First pass on the finest level alone; the queries it cannot finish (too
+    // few points within kKnnShells shells: sparse regions, outliers, queries
+    // away from the cloud) are collected and walked up a pyramid of coarser
+    // levels, built only then, whose last level spans the cloud in <= 4 cells
+    // per axis and is searched exhaustively.
     std::vector<o3dmi_nns*> levels{nns};
-    while ((int)levels.size() < kKnnMaxLevels &&
-           emax / levels.back()->radius > 3.0) {
-        auto* up = new o3dmi_nns();
-        up->dtype = dtype;
-        up->n = n;
-        up->radius = levels.back()->radius * 4.0;
-        up->inv_cell = 1.0 / up->radius;
-        levels.push_back(up);
-        st = dtype == O3DMI_F64
-                     ? BuildIndex<double>(up, (const double*)points_dev, s)
-                     : BuildIndex<float>(up, (const float*)points_dev, s);
-        if (st) break;
+    const bool single = !(emax / h > 3.0);
+    int* retry = nullptr;  // [0] = count, [1..q] = query ids
+    if (!single) {
+        st = PoolAlloc((void**)&retry, sizeof(int) * (size_t)(q + 1));
+        if (!st && hipMemsetAsync(retry, 0, sizeof(int), s) != hipSuccess)
+            st = O3DMI_ERR_HIP;
     }
-    if (std::getenv("O3DMI_VERBOSE"))
-        std::fprintf(stderr,
-                     "[o3dmi] knn: n=%lld k=%d cell=%g levels=%d target=%g\n",
-                     (long long)n, k, h, (int)levels.size(), target);
-    if (!st) {
-        const dim3 grid(GridFor(q, 64)), block(64);
+    auto launch = [&](int first_level, bool exhaustive, bool brute,
+                      const int* ids, int64_t count, int* retry_ids,
+                      int* retry_count) {
+        const dim3 grid(GridFor(count, kCoopBlock / 64, kCUs * 16)),
+                block(kCoopBlock);
 #define O3DMI_KNN(T)                                                           \
     do {                                                                       \
         KnnPyramid<T> pyr;                                                     \
         pyr.n_levels = (int)levels.size();                                     \
+        pyr.first_radius = 1;                                                  \
+        pyr.first_level = first_level;                                         \
+        pyr.exhaustive_last = exhaustive ? 1 : 0;                              \
+        pyr.brute = brute ? 1 : 0;                                             \
+        pyr.n_points = n;                                                      \
         for (int l = 0; l < pyr.n_levels; ++l) {                               \
             KnnGrid<T>& kg = pyr.level[l];                                     \
             kg.nv = MakeView<T>(levels[l]);                                    \
@@ -1257,19 +1470,69 @@ int o3dmi_nns_knn_search_counts(const void* points_dev, int64_t n,
             }                                                                  \
         }                                                                      \
         hipLaunchKernelGGL(KnnSearchKernel<T>, grid, block,                    \
-                           TopKLdsBytes(k, sizeof(T)), s, pyr,                 \
-                           (const T*)queries_dev, q, k, idx_dev,               \
-                           (T*)dist2_dev, counts_dev);                         \
+                           CoopLdsBytesPerWave<T>() * (kCoopBlock / 64), s,    \
+                           pyr, (const T*)queries_dev, count, k, ids,          \
+                           retry_ids, retry_count, idx_dev, (T*)dist2_dev,     \
+                           counts_dev);                                        \
     } while (0)
         if (dtype == O3DMI_F64) O3DMI_KNN(double);
         else O3DMI_KNN(float);
 #undef O3DMI_KNN
-        if (hipGetLastError() != hipSuccess) {
+        return hipGetLastError() == hipSuccess;
+    };
+    int n_retry = 0;
+    if (!st) {
+        if (!launch(0, single, false, nullptr, q, retry ? retry + 1 : nullptr,
+                    retry)) {
             SetLastError("KnnSearch kernel launch failed");
             st = O3DMI_ERR_HIP;
         }
     }
+    if (!st && !single) {
+        if (hipMemcpyAsync(&n_retry, retry, sizeof(int), hipMemcpyDeviceToHost,
+                           s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess)
+            st = O3DMI_ERR_HIP;
+    }
+    // a handful of leftovers is cheaper to sweep than to index again
+    double sweep_limit = 2e9;  // leftover queries x points
+    if (const char* e_ = std::getenv("O3DMI_KNN_SWEEP_LIMIT"))
+        sweep_limit = std::atof(e_);
+    const bool brute = (double)n_retry * (double)n <= sweep_limit;
+    if (!st && n_retry > 0 && brute) {
+        if (!launch(0, false, true, retry + 1, n_retry, nullptr, nullptr)) {
+            SetLastError("KnnSearch kernel launch failed");
+            st = O3DMI_ERR_HIP;
+        }
+    }
+    if (!st && n_retry > 0 && !brute) {
+        while ((int)levels.size() < kKnnMaxLevels &&
+               emax / levels.back()->radius > 3.0) {
+            auto* up = new o3dmi_nns();
+            up->dtype = dtype;
+            up->n = n;
+            up->radius = levels.back()->radius * 4.0;
+            up->inv_cell = 1.0 / up->radius;
+            levels.push_back(up);
+            st = dtype == O3DMI_F64
+                         ? BuildIndex<double>(up, (const double*)points_dev, s)
+                         : BuildIndex<float>(up, (const float*)points_dev, s);
+            if (st) break;
+        }
+        if (!st &&
+            !launch(1, true, false, retry + 1, n_retry, nullptr, nullptr)) {
+            SetLastError("KnnSearch kernel launch failed");
+            st = O3DMI_ERR_HIP;
+        }
+    }
+    if (std::getenv("O3DMI_VERBOSE"))
+        std::fprintf(stderr,
+                     "[o3dmi] knn: n=%lld k=%d cell=%g levels=%d target=%g "
+                     "second-pass queries=%d (%s)\n",
+                     (long long)n, k, h, (int)levels.size(), target, n_retry,
+                     brute ? "sweep" : "pyramid");
     for (o3dmi_nns* lv : levels) o3dmi_nns_destroy(lv);  // drains the device
+    PoolFree(retry);
     return st;
 }
 

@@ -177,12 +177,16 @@ def test_empty_and_tiny_inputs():
 # ------------------------------------------------------------ KNN (no radius)
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("k", [1, 8, 30, 64])
-def test_knn_search_parity(dtype, k):
+@pytest.mark.parametrize("second_pass", ["sweep", "pyramid"])
+def test_knn_search_parity(dtype, k, second_pass, monkeypatch):
     """KnnIndex + KnnSearch: indices exact, squared distances bit-exact vs an
     exhaustive scan, on a cloud with isolated / duplicate points, a regular
-    lattice (distance ties) and queries far outside the cloud (the multi-level
-    walk)."""
+    lattice (distance ties) and queries far outside the cloud. Queries the
+    finest grid level cannot finish go through the second pass: a sweep over
+    all records (few leftovers) or the multi-level walk (many)."""
     _lib, reg = _gpu()
+    monkeypatch.setenv("O3DMI_KNN_SWEEP_LIMIT",
+                       "1e30" if second_pass == "sweep" else "0")
     pts, _ = _cloud(6000, 3, dtype)
     rng = np.random.default_rng(2)
     qrs = np.ascontiguousarray(np.concatenate(
