@@ -402,6 +402,26 @@ int o3dmi_icp_search_accumulate_p2point(const o3dmi_nns_t* nns,
  * O3DMI_ERR_NO_INLIERS ("No valid correspondence present.") when count = 0. */
 int o3dmi_compute_rt_p2point(const double* sums16_host, double* R9, double* t3);
 
+/* ComputePoseSymmetricCUDA up to the reduction (TransformationEstimation
+ * Symmetric; t/pipelines/kernel/RegistrationCUDA.cu, CPU body RegistrationCPU.
+ * cpp:124-218, Jacobian RegistrationImpl.h:323-386): 29 sums as for point-to-
+ * plane except [27] = sum of squared un-centred residuals. source / target
+ * means of the matched points (host float64, rounded to the point dtype) are
+ * what ComputeTransformationSymmetric passes (kernel/Registration.cpp:96-97);
+ * the moments of o3dmi_icp_p2point_accumulate / the fused p2point search give
+ * them. o3dmi_symmetric_pose_to_transformation is PoseToSymmetricTransformation
+ * (TransformationConverter.cpp:106-133). */
+int o3dmi_icp_symmetric_accumulate(
+        const void* src_dev, const void* src_normals_dev, const void* tgt_dev,
+        const void* tgt_normals_dev, const int64_t* corr_dev, int64_t n,
+        int dtype, const double* source_mean3, const double* target_mean3,
+        int robust_kernel, double scaling_parameter, double shape_parameter,
+        double* sums29_dev, o3dmi_stream_t stream);
+void o3dmi_symmetric_pose_to_transformation(const double* pose6,
+                                            const double* source_mean3,
+                                            const double* target_mean3,
+                                            double* T16);
+
 /* ComputeInformationMatrixCUDA up to the reduction
  * (t/pipelines/kernel/RegistrationCUDA.cu ComputeInformationMatrixKernelCUDA,
  * CPU body RegistrationCPU.cpp:652-735, Jacobians RegistrationImpl.h:686-715):

@@ -76,15 +76,21 @@ int o3dmi_registration_multiscale_icp(
  * (t/pipelines/registration/TransformationEstimation.h:28-34). */
 typedef enum {
     O3DMI_ICP_POINT_TO_PLANE = 0,
-    O3DMI_ICP_POINT_TO_POINT = 1
+    O3DMI_ICP_POINT_TO_POINT = 1,
+    O3DMI_ICP_SYMMETRIC = 2
 } o3dmi_icp_estimation_t;
 
 /* MultiScaleICP with a selectable estimator. POINT_TO_PLANE is exactly
  * o3dmi_registration_multiscale_icp; POINT_TO_POINT
  * (TransformationEstimationPointToPoint, TransformationEstimation.cpp:101-160)
- * ignores target_normals_dev (may be NULL) and the robust kernel. */
+ * ignores the normals (may be NULL) and the robust kernel; SYMMETRIC
+ * (TransformationEstimationSymmetric, :229-292) needs source_normals_dev and
+ * target_normals_dev ({N,3}, point dtype) -- the source normals are carried
+ * through the pyramid and rotated with the source, as PointCloud::Transform
+ * does. source_normals_dev is ignored by the other estimators. */
 int o3dmi_registration_multiscale_icp_ex(
-        const void* source_dev, int64_t ns, const void* target_dev,
+        const void* source_dev, const void* source_normals_dev, int64_t ns,
+        const void* target_dev,
         const void* target_normals_dev, int64_t nt, int dtype, int num_scales,
         const double* voxel_sizes, const o3dmi_icp_criteria_t* criterias,
         const double* max_correspondence_distances,

@@ -152,7 +152,7 @@ PROTOTYPES.update({
                _vp, ALLREDUCE_SUM, _vp, _vp, C.POINTER(RegistrationResultC),
                _vp]),
     "o3dmi_registration_multiscale_icp_ex": (
-        _i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _dp,
+        _i32, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _dp,
                C.POINTER(IcpCriteria), _dp, _dp, _i32, _i32, _d, _d,
                ICP_CALLBACK, _vp, ALLREDUCE_SUM, _vp, _vp,
                C.POINTER(RegistrationResultC), _vp]),
@@ -165,6 +165,10 @@ PROTOTYPES.update({
         _i32, [_vp, _i64, _vp, _i64, _i32, _d, _dp, _dp, _vp]),
     "o3dmi_icp_information_accumulate": (_i32, [_vp, _vp, _i64, _i32, _vp,
                                                 _vp]),
+    "o3dmi_icp_symmetric_accumulate": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64,
+                                              _i32, _dp, _dp, _i32, _d, _d,
+                                              _vp, _vp]),
+    "o3dmi_symmetric_pose_to_transformation": (None, [_dp, _dp, _dp, _dp]),
     "o3dmi_icp_p2point_accumulate": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp,
                                             _vp]),
     "o3dmi_icp_search_accumulate_p2point": (_i32, [_vp, _vp, _i64, _vp, _vp,

@@ -38,6 +38,14 @@ extern "C" int o3dmi_icp_search_accumulate_post(
 extern "C" int o3dmi_nns_set_normals(o3dmi_nns_t* nns, const void* normals_dev,
                                      o3dmi_stream_t stream);
 
+extern "C" int o3dmi_icp_symmetric_accumulate_post(
+        const void* src_dev, const void* src_normals_dev, const void* tgt_dev,
+        const void* tgt_normals_dev, const int64_t* corr_dev, int64_t n,
+        int dtype, const double* source_mean3, const double* target_mean3,
+        int robust_kernel, double scaling_parameter, double shape_parameter,
+        double* sums29_dev, double* partials_dev, double* mail_data,
+        int* mail_flag, int mail_seq, o3dmi_stream_t stream);
+
 using namespace o3dmi;
 
 namespace {
@@ -71,7 +79,7 @@ struct DeviceBuffer {
 };
 
 struct Level {
-    DeviceBuffer src, tgt, nrm;
+    DeviceBuffer src, srcn, tgt, nrm;
     int64_t ns = 0, nt = 0;
     const void* tgt_ptr = nullptr;  // may alias the caller's buffers
     const void* nrm_ptr = nullptr;
@@ -100,7 +108,7 @@ extern "C" int o3dmi_registration_multiscale_icp(
         int64_t* correspondences_dev, o3dmi_registration_result_t* result,
         o3dmi_stream_t stream) {
     return o3dmi_registration_multiscale_icp_ex(
-            source_dev, ns, target_dev, target_normals_dev, nt, dtype,
+            source_dev, nullptr, ns, target_dev, target_normals_dev, nt, dtype,
             num_scales, voxel_sizes, criterias, max_dists, init,
             O3DMI_ICP_POINT_TO_PLANE, robust_kernel, scaling_parameter,
             shape_parameter, callback, callback_user, allreduce, allreduce_user,
@@ -108,7 +116,8 @@ extern "C" int o3dmi_registration_multiscale_icp(
 }
 
 extern "C" int o3dmi_registration_multiscale_icp_ex(
-        const void* source_dev, int64_t ns, const void* target_dev,
+        const void* source_dev, const void* source_normals_dev, int64_t ns,
+        const void* target_dev,
         const void* target_normals_dev, int64_t nt, int dtype, int num_scales,
         const double* voxel_sizes, const o3dmi_icp_criteria_t* criterias,
         const double* max_dists, const double* init, int estimation,
@@ -124,12 +133,23 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
     O3DMI_REQUIRE(source_dev && target_dev && ns > 0 && nt > 0,
                   "Source and/or Target pointcloud is empty.");
     O3DMI_REQUIRE(estimation == O3DMI_ICP_POINT_TO_PLANE ||
-                          estimation == O3DMI_ICP_POINT_TO_POINT,
-                  "estimation must be point-to-plane or point-to-point");
+                          estimation == O3DMI_ICP_POINT_TO_POINT ||
+                          estimation == O3DMI_ICP_SYMMETRIC,
+                  "estimation must be point-to-plane, point-to-point or "
+                  "symmetric");
     const bool p2plane = estimation == O3DMI_ICP_POINT_TO_PLANE;
-    if (!p2plane) target_normals_dev = nullptr;
+    const bool symmetric = estimation == O3DMI_ICP_SYMMETRIC;
+    const bool need_tn = p2plane || symmetric;  // target normals in the pyramid
+    if (!need_tn) target_normals_dev = nullptr;
+    if (!symmetric) source_normals_dev = nullptr;
     O3DMI_REQUIRE(!p2plane || target_normals_dev != nullptr,
                   "Target pointcloud missing normals attribute.");
+    O3DMI_REQUIRE(!symmetric || (source_normals_dev && target_normals_dev),
+                  "SymmetricICP requires both source and target to have "
+                  "normals.");
+    // the fused search kernel accumulates the point-to-plane terms itself;
+    // the other estimators take the point-to-point moments from it
+    const int search_mode = p2plane ? 0 : 1;
     O3DMI_REQUIRE(num_scales > 0 && voxel_sizes && criterias && max_dists,
                   "Size of criterias, voxel_size, max_correspondence_distances "
                   "vectors must be same.");
@@ -163,16 +183,24 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
             O3DMI_HIP_CHECK(hipMemcpyAsync(L.src.p, source_dev,
                                            (size_t)ns * 3 * esz,
                                            hipMemcpyDeviceToDevice, s));
+            if (symmetric) {
+                if ((st = L.srcn.Alloc((size_t)ns * 3 * esz))) return st;
+                O3DMI_HIP_CHECK(hipMemcpyAsync(L.srcn.p, source_normals_dev,
+                                               (size_t)ns * 3 * esz,
+                                               hipMemcpyDeviceToDevice, s));
+            }
             L.tgt_ptr = target_dev;
             L.nrm_ptr = target_normals_dev;
         } else {
             if ((st = L.src.Alloc((size_t)ns * 3 * esz))) return st;
             if ((st = L.tgt.Alloc((size_t)nt * 3 * esz))) return st;
-            if (p2plane && (st = L.nrm.Alloc((size_t)nt * 3 * esz)))
+            if (need_tn && (st = L.nrm.Alloc((size_t)nt * 3 * esz)))
                 return st;
-            st = o3dmi_voxel_down_sample(source_dev, nullptr, ns, dtype,
-                                         voxel_sizes[last], L.src.p, nullptr,
-                                         &L.ns, stream);
+            if (symmetric && (st = L.srcn.Alloc((size_t)ns * 3 * esz)))
+                return st;
+            st = o3dmi_voxel_down_sample(source_dev, source_normals_dev, ns,
+                                         dtype, voxel_sizes[last], L.src.p,
+                                         L.srcn.p, &L.ns, stream);
             if (st) return st;
             st = o3dmi_voxel_down_sample(target_dev, target_normals_dev, nt,
                                          dtype, voxel_sizes[last], L.tgt.p,
@@ -187,9 +215,10 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         Level& F = pyr[(size_t)k + 1];
         if ((st = L.src.Alloc((size_t)F.ns * 3 * esz))) return st;
         if ((st = L.tgt.Alloc((size_t)F.nt * 3 * esz))) return st;
-        if (p2plane && (st = L.nrm.Alloc((size_t)F.nt * 3 * esz))) return st;
-        st = o3dmi_voxel_down_sample(F.src.p, nullptr, F.ns, dtype,
-                                     voxel_sizes[k], L.src.p, nullptr, &L.ns,
+        if (need_tn && (st = L.nrm.Alloc((size_t)F.nt * 3 * esz))) return st;
+        if (symmetric && (st = L.srcn.Alloc((size_t)F.ns * 3 * esz))) return st;
+        st = o3dmi_voxel_down_sample(F.src.p, F.srcn.p, F.ns, dtype,
+                                     voxel_sizes[k], L.src.p, L.srcn.p, &L.ns,
                                      stream);
         if (st) return st;
         st = o3dmi_voxel_down_sample(F.tgt_ptr, F.nrm_ptr, F.nt, dtype,
@@ -221,7 +250,7 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                       SearchResult& r) -> int {
         const int seq = ++mb->seq;
         int e = o3dmi_icp_search_accumulate_post(
-                nns, L.src.p, nullptr, L.ns, estimation, robust_kernel,
+                nns, L.src.p, nullptr, L.ns, search_mode, robust_kernel,
                 scaling_parameter, shape_parameter, corr_out, nullptr, mb->data,
                 mb->flag, seq, stream);
         if (e) return e;
@@ -251,8 +280,18 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         Level& L = pyr[(size_t)scale_idx];
         last_ns = L.ns;
         // source_down_pyramid[scale].Transform(result.transformation_) :404
+        // (positions and, when the estimator reads them, normals)
         if ((st = o3dmi_transform_points(T, L.src.p, L.ns, dtype, stream)))
             return st;
+        if (symmetric &&
+            (st = o3dmi_transform_normals(T, L.srcn.p, L.ns, dtype, stream)))
+            return st;
+        DeviceBuffer corr_buf, sym_partials;
+        if (symmetric) {
+            if ((st = corr_buf.Alloc(sizeof(int64_t) * (size_t)L.ns))) return st;
+            if ((st = sym_partials.Alloc(sizeof(double) * 32 * 1024)))
+                return st;
+        }
         // target_nns.HybridIndex(max_correspondence_distance) :406-412
         NnsGuard guard;
         if ((st = o3dmi_nns_create(L.tgt_ptr, L.nt, dtype, max_dists[scale_idx],
@@ -270,7 +309,9 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         const o3dmi_icp_criteria_t& crit = criterias[scale_idx];
         for (it = 0; it < crit.max_iteration; ++it) {
             SearchResult r;
-            if ((st = search(guard.nns, L, nullptr, r))) return st;
+            if ((st = search(guard.nns, L,
+                             symmetric ? (int64_t*)corr_buf.p : nullptr, r)))
+                return st;
             fitness = r.fitness;
             inlier_rmse = r.inlier_rmse;
             converged = false;
@@ -287,6 +328,46 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                                                   &inlier_count);
                 if (e) status = e;  // reference throws; report after the loop
                 o3dmi_pose_to_transformation(pose, update);
+            } else if (symmetric) {
+                // ComputeTransformationSymmetric, kernel/Registration.cpp:
+                // 80-135: means of the matched points (from the search pass'
+                // moments), 29 sums about them, solve, half-angle pose ->
+                // transformation.
+                const double cnt = r.sums[15];
+                double ms[3], mt[3];
+                for (int k = 0; k < 3; ++k) {
+                    ms[k] = r.sums[k] / cnt;
+                    mt[k] = r.sums[3 + k] / cnt;
+                }
+                if (dtype == O3DMI_F32)
+                    for (int k = 0; k < 3; ++k) {
+                        ms[k] = (double)(float)ms[k];
+                        mt[k] = (double)(float)mt[k];
+                    }
+                const int seq = ++mb->seq;
+                int e = o3dmi_icp_symmetric_accumulate_post(
+                        L.src.p, L.srcn.p, L.tgt_ptr, L.nrm_ptr,
+                        (const int64_t*)corr_buf.p, L.ns, dtype, ms, mt,
+                        robust_kernel, scaling_parameter, shape_parameter,
+                        nullptr, (double*)sym_partials.p, mb->data, mb->flag,
+                        seq, stream);
+                if (e) return e;
+                O3DMI_HIP_CHECK(MailboxWait(mb, seq, s));
+                double sums29[32];
+                std::memcpy(sums29, sums_host, sizeof(double) * 29);
+                if (allreduce) {
+                    sums29[29] = sums29[30] = sums29[31] = 0;
+                    if (allreduce(sums29, 32, allreduce_user) != 0) {
+                        SetLastError("all-reduce hook failed");
+                        return O3DMI_ERR_INVALID_ARG;
+                    }
+                }
+                float residual;
+                int inlier_count;
+                e = o3dmi_decode_and_solve6x6(sums29, pose, &residual,
+                                              &inlier_count);
+                if (e) status = e;
+                o3dmi_symmetric_pose_to_transformation(pose, ms, mt, update);
             } else {
                 // ComputeRtPointToPoint + RtToTransformation
                 // (TransformationEstimation.cpp:150-159)
@@ -302,6 +383,9 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
             Matmul4(update, T, T);
             if ((st = o3dmi_transform_points(update, L.src.p, L.ns, dtype,
                                              stream)))
+                return st;
+            if (symmetric && (st = o3dmi_transform_normals(
+                                      update, L.srcn.p, L.ns, dtype, stream)))
                 return st;
             if (callback)
                 callback(iteration_count + it, scale_idx, it, inlier_rmse,

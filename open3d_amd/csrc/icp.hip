@@ -901,6 +901,60 @@ __device__ __forceinline__ void AccumulateInformation(double (&A)[kNumSums],
     }
 }
 
+// GetJacobianSymmetric + the 29 sums of ComputePoseSymmetricKernelCPU
+// (RegistrationImpl.h:323-386, RegistrationCPU.cpp:124-180): plane normal
+// n_t + sign(n_s . n_t) n_s, Jacobian and right-hand side about the
+// correspondence means, robust weight from the un-centred residual; A[27] is
+// the sum of squared un-centred residuals.
+template <typename T>
+struct Means3 { T s[3], t[3]; };
+
+template <typename T>
+__device__ __forceinline__ void AccumulateSymmetric(
+        double (&A)[kNumSums], T sx, T sy, T sz, T tx, T ty, T tz, T snx, T sny,
+        T snz, T tnx, T tny, T tnz, const Means3<T>& mean,
+        const RobustParams& rp) {
+    const T normal_dot = snx * tnx + sny * tny + snz * tnz;
+    const T normal_sign = normal_dot < T(0) ? T(-1) : T(1);
+    const T nx = tnx + normal_sign * snx;
+    const T ny = tny + normal_sign * sny;
+    const T nz = tnz + normal_sign * snz;
+    const T sx_centered = sx - mean.s[0];
+    const T sy_centered = sy - mean.s[1];
+    const T sz_centered = sz - mean.s[2];
+    const T tx_centered = tx - mean.t[0];
+    const T ty_centered = ty - mean.t[1];
+    const T tz_centered = tz - mean.t[2];
+    const T sum_x = sx_centered + tx_centered;
+    const T sum_y = sy_centered + ty_centered;
+    const T sum_z = sz_centered + tz_centered;
+    T J[6];
+    J[0] = sum_y * nz - sum_z * ny;
+    J[1] = sum_z * nx - sum_x * nz;
+    J[2] = sum_x * ny - sum_y * nx;
+    J[3] = nx;
+    J[4] = ny;
+    J[5] = nz;
+    const T centered_residual = (sx_centered - tx_centered) * nx +
+                                (sy_centered - ty_centered) * ny +
+                                (sz_centered - tz_centered) * nz;
+    const T objective_residual =
+            (sx - tx) * nx + (sy - ty) * ny + (sz - tz) * nz;
+    const T w = RobustWeight<T>(rp, objective_residual);
+    int i = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+#pragma unroll
+        for (int k = 0; k <= j; ++k) {
+            A[i] += (double)(J[j] * w * J[k]);
+            ++i;
+        }
+        A[21 + j] += (double)(J[j] * w * centered_residual);
+    }
+    A[27] += (double)(objective_residual * objective_residual);
+    A[28] += 1.0;
+}
+
 constexpr int kReduceBlock = 256;
 
 // Reduce-scatter wave reduction (reduce_sums.h), LDS across the 4 waves, one
@@ -952,6 +1006,29 @@ P2PlaneAccumulateKernel(const T* __restrict__ src, const T* __restrict__ tgt,
                              tgt[3 * c + 0], tgt[3 * c + 1], tgt[3 * c + 2],
                              tgt_n[3 * c + 0], tgt_n[3 * c + 1],
                              tgt_n[3 * c + 2], rp);
+    }
+    BlockReduceAndStore(A, partials);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kReduceBlock)
+SymmetricAccumulateKernel(const T* __restrict__ src, const T* __restrict__ src_n,
+                          const T* __restrict__ tgt, const T* __restrict__ tgt_n,
+                          const int64_t* __restrict__ corr, int64_t n,
+                          Means3<T> mean, RobustParams rp,
+                          double* __restrict__ partials) {
+    double A[kNumSums];
+#pragma unroll
+    for (int k = 0; k < kNumSums; ++k) A[k] = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t c = corr[i];
+        if (c == -1) continue;
+        AccumulateSymmetric<T>(A, src[3 * i + 0], src[3 * i + 1], src[3 * i + 2],
+                               tgt[3 * c + 0], tgt[3 * c + 1], tgt[3 * c + 2],
+                               src_n[3 * i + 0], src_n[3 * i + 1],
+                               src_n[3 * i + 2], tgt_n[3 * c + 0],
+                               tgt_n[3 * c + 1], tgt_n[3 * c + 2], mean, rp);
     }
     BlockReduceAndStore(A, partials);
 }
@@ -1610,6 +1687,75 @@ int o3dmi_icp_p2point_accumulate(const void* src_dev, const void* tgt_dev,
     return O3DMI_OK;
 }
 
+// Internal: also posts the 29 sums to a host mailbox when mail_data != NULL.
+int o3dmi_icp_symmetric_accumulate_post(
+        const void* src_dev, const void* src_normals_dev, const void* tgt_dev,
+        const void* tgt_normals_dev, const int64_t* corr_dev, int64_t n,
+        int dtype, const double* source_mean3, const double* target_mean3,
+        int robust_kernel, double scaling_parameter, double shape_parameter,
+        double* sums29_dev, double* partials_dev, double* mail_data,
+        int* mail_flag, int mail_seq, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(src_dev && src_normals_dev && tgt_dev && tgt_normals_dev &&
+                          corr_dev && source_mean3 && target_mean3 &&
+                          (sums29_dev || mail_data),
+                  "null argument");
+    O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
+                  "points must be Float32 or Float64");
+    O3DMI_REQUIRE(robust_kernel >= 0 && robust_kernel <= 6,
+                  "Unsupported method.");
+    hipStream_t s = (hipStream_t)stream;
+    int g = ReduceGrid(n);
+    double* partials = partials_dev;
+    if (!partials)
+        O3DMI_HIP_CHECK(hipMallocAsync((void**)&partials,
+                                       sizeof(double) * (size_t)g * kNumSums,
+                                       s));
+    RobustParams rp = MakeRobust(robust_kernel, scaling_parameter,
+                                 shape_parameter);
+    if (dtype == O3DMI_F64) {
+        Means3<double> m;
+        for (int k = 0; k < 3; ++k) {
+            m.s[k] = source_mean3[k];
+            m.t[k] = target_mean3[k];
+        }
+        hipLaunchKernelGGL(SymmetricAccumulateKernel<double>, dim3(g),
+                           dim3(kReduceBlock), 0, s, (const double*)src_dev,
+                           (const double*)src_normals_dev,
+                           (const double*)tgt_dev,
+                           (const double*)tgt_normals_dev, corr_dev, n, m, rp,
+                           partials);
+    } else {
+        Means3<float> m;
+        for (int k = 0; k < 3; ++k) {
+            m.s[k] = (float)source_mean3[k];
+            m.t[k] = (float)target_mean3[k];
+        }
+        hipLaunchKernelGGL(SymmetricAccumulateKernel<float>, dim3(g),
+                           dim3(kReduceBlock), 0, s, (const float*)src_dev,
+                           (const float*)src_normals_dev, (const float*)tgt_dev,
+                           (const float*)tgt_normals_dev, corr_dev, n, m, rp,
+                           partials);
+    }
+    hipLaunchKernelGGL(FinalReduceKernel, dim3(1), dim3(256), 0, s, partials, g,
+                       sums29_dev, 29, mail_data, mail_flag, mail_seq);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    if (!partials_dev) O3DMI_HIP_CHECK(hipFreeAsync(partials, s));
+    return O3DMI_OK;
+}
+
+int o3dmi_icp_symmetric_accumulate(
+        const void* src_dev, const void* src_normals_dev, const void* tgt_dev,
+        const void* tgt_normals_dev, const int64_t* corr_dev, int64_t n,
+        int dtype, const double* source_mean3, const double* target_mean3,
+        int robust_kernel, double scaling_parameter, double shape_parameter,
+        double* sums29_dev, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(sums29_dev != nullptr, "null argument");
+    return o3dmi_icp_symmetric_accumulate_post(
+            src_dev, src_normals_dev, tgt_dev, tgt_normals_dev, corr_dev, n,
+            dtype, source_mean3, target_mean3, robust_kernel, scaling_parameter,
+            shape_parameter, sums29_dev, nullptr, nullptr, nullptr, 0, stream);
+}
+
 int o3dmi_icp_information_accumulate(const void* tgt_dev,
                                      const int64_t* corr_dev, int64_t n,
                                      int dtype, double* sums21_dev,
@@ -1949,6 +2095,52 @@ int o3dmi_compute_rt_p2point(const double* sums, double* R9, double* t3) {
         t3[j] = mt[j] - (R9[j * 3 + 0] * ms[0] + R9[j * 3 + 1] * ms[1] +
                          R9[j * 3 + 2] * ms[2]);
     return O3DMI_OK;
+}
+
+// PoseToSymmetricTransformation (TransformationConverter.cpp:106-133) =
+// TransformSymmetricPoseToMatrix4d (pipelines/registration/SymmetricICPImpl.h:
+// 19-44): theta = atan |g|, H = AngleAxis(theta, g / |g|) (Rodrigues), R = H H,
+// t = target_mean + H (t' cos theta) - R source_mean.
+void o3dmi_symmetric_pose_to_transformation(const double* pose,
+                                            const double* source_mean,
+                                            const double* target_mean,
+                                            double* T) {
+    const double g_norm = std::sqrt(pose[0] * pose[0] + pose[1] * pose[1] +
+                                    pose[2] * pose[2]);
+    const double theta = std::atan(g_norm);
+    double H[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (g_norm > 0.0) {
+        const double ax = pose[0] / g_norm, ay = pose[1] / g_norm,
+                     az = pose[2] / g_norm;
+        const double c = std::cos(theta), sn = std::sin(theta), v = 1.0 - c;
+        H[0] = c + v * ax * ax;
+        H[1] = v * ax * ay - sn * az;
+        H[2] = v * ax * az + sn * ay;
+        H[3] = v * ax * ay + sn * az;
+        H[4] = c + v * ay * ay;
+        H[5] = v * ay * az - sn * ax;
+        H[6] = v * ax * az - sn * ay;
+        H[7] = v * ay * az + sn * ax;
+        H[8] = c + v * az * az;
+    }
+    double R[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            R[i * 3 + j] = H[i * 3 + 0] * H[0 * 3 + j] +
+                           H[i * 3 + 1] * H[1 * 3 + j] +
+                           H[i * 3 + 2] * H[2 * 3 + j];
+    const double ct = std::cos(theta);
+    const double u[3] = {pose[3] * ct, pose[4] * ct, pose[5] * ct};
+    for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) T[i * 4 + j] = R[i * 3 + j];
+        T[i * 4 + 3] = target_mean[i] +
+                       (H[i * 3 + 0] * u[0] + H[i * 3 + 1] * u[1] +
+                        H[i * 3 + 2] * u[2]) -
+                       (R[i * 3 + 0] * source_mean[0] +
+                        R[i * 3 + 1] * source_mean[1] +
+                        R[i * 3 + 2] * source_mean[2]);
+    }
 }
 
 // TransformationConverterImpl.h:23-42 + TransformationConverter.cpp:81-104

@@ -43,6 +43,13 @@ class TransformationEstimationPointToPoint:
     kernel = RobustKernel()
 
 
+class TransformationEstimationSymmetric:
+    """TransformationEstimation.h (Symmetric ICP, Rusinkiewicz 2019): needs
+    source and target normals."""
+    def __init__(self, kernel=None):
+        self.kernel = kernel or RobustKernel()
+
+
 class RegistrationResult:
     def __init__(self):
         self.transformation = np.eye(4)
@@ -56,11 +63,20 @@ class RegistrationResult:
 def multi_scale_icp(source, target, target_normals, voxel_sizes, criteria_list,
                     max_correspondence_distances, init_source_to_target=None,
                     estimation_method=None, callback_after_iteration=None,
-                    allreduce=None):
+                    allreduce=None, source_normals=None):
     """source/target/target_normals: device tensors {N,3}. `allreduce`
-    (optional) sums a length-32 numpy float64 array over ranks in place."""
+    (optional) sums a length-32 numpy float64 array over ranks in place.
+    `source_normals` is read by the symmetric estimator only."""
     est = estimation_method or TransformationEstimationPointToPlane()
     p2point = isinstance(est, TransformationEstimationPointToPoint)
+    symmetric = isinstance(est, TransformationEstimationSymmetric)
+    if symmetric:
+        if source_normals is None or target_normals is None:
+            raise ValueError("SymmetricICP requires both source and target to "
+                             "have normals.")
+        source_normals = require_cuda(source_normals, "source_normals")
+    else:
+        source_normals = None
     source = require_cuda(source, "source")
     target = require_cuda(target, "target")
     if source.dtype not in (torch.float32, torch.float64):
@@ -112,10 +128,11 @@ def multi_scale_icp(source, target, target_normals, voxel_sizes, criteria_list,
         ar = _lib.ALLREDUCE_SUM(_ar)
 
     st = _lib.lib().o3dmi_registration_multiscale_icp_ex(
-        _lib.ptr(source), ns, _lib.ptr(target),
+        _lib.ptr(source), _lib.ptr(source_normals), ns, _lib.ptr(target),
         _lib.ptr(target_normals) if target_normals is not None else None, nt,
         TORCH_TO_O3DMI[source.dtype], S, _lib.f64p(vs), crit, _lib.f64p(md),
-        _lib.f64p(init), 1 if p2point else 0, int(est.kernel.type),
+        _lib.f64p(init), 1 if p2point else (2 if symmetric else 0),
+        int(est.kernel.type),
         C.c_double(est.kernel.scaling_parameter),
         C.c_double(est.kernel.shape_parameter), cb, None, ar, None,
         _lib.ptr(corr), C.byref(res), stream())
@@ -132,13 +149,14 @@ def multi_scale_icp(source, target, target_normals, voxel_sizes, criteria_list,
 
 def icp(source, target, target_normals, max_correspondence_distance,
         init_source_to_target=None, estimation_method=None, criteria=None,
-        voxel_size=-1.0, callback_after_iteration=None, allreduce=None):
+        voxel_size=-1.0, callback_after_iteration=None, allreduce=None,
+        source_normals=None):
     """t::pipelines::registration::ICP (Registration.cpp:93-106)."""
     return multi_scale_icp(source, target, target_normals, [voxel_size],
                            [criteria or ICPConvergenceCriteria()],
                            [max_correspondence_distance],
                            init_source_to_target, estimation_method,
-                           callback_after_iteration, allreduce)
+                           callback_after_iteration, allreduce, source_normals)
 
 
 def _check_pair(source, target):

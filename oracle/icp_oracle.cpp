@@ -585,6 +585,216 @@ RegResult ComputeRegistrationResult(const T* source, int64_t ns,
 }
 
 // ---------------------------------------------------------------------------
+// TransformationEstimationSymmetric (Rusinkiewicz 2019).
+// GetJacobianSymmetric, RegistrationImpl.h:323-386: n = n_t + sign(n_s . n_t)
+// n_s; Jacobian and the right-hand-side residual about the correspondence
+// means, the robust weight from the un-centred ("objective") residual.
+template <typename scalar_t>
+bool GetJacobianSymmetric(int64_t workload_idx,
+                          const scalar_t* source_points_ptr,
+                          const scalar_t* target_points_ptr,
+                          const scalar_t* source_normals_ptr,
+                          const scalar_t* target_normals_ptr,
+                          const int64_t* correspondence_indices,
+                          const scalar_t* source_mean_ptr,
+                          const scalar_t* target_mean_ptr, scalar_t* J_ij,
+                          scalar_t& centered_residual,
+                          scalar_t& objective_residual) {
+    if (correspondence_indices[workload_idx] == -1) return false;
+    const int64_t target_idx = 3 * correspondence_indices[workload_idx];
+    const int64_t source_idx = 3 * workload_idx;
+    const scalar_t& sx = source_points_ptr[source_idx + 0];
+    const scalar_t& sy = source_points_ptr[source_idx + 1];
+    const scalar_t& sz = source_points_ptr[source_idx + 2];
+    const scalar_t& tx = target_points_ptr[target_idx + 0];
+    const scalar_t& ty = target_points_ptr[target_idx + 1];
+    const scalar_t& tz = target_points_ptr[target_idx + 2];
+    const scalar_t normal_dot =
+            source_normals_ptr[source_idx + 0] * target_normals_ptr[target_idx + 0] +
+            source_normals_ptr[source_idx + 1] * target_normals_ptr[target_idx + 1] +
+            source_normals_ptr[source_idx + 2] * target_normals_ptr[target_idx + 2];
+    const scalar_t normal_sign =
+            normal_dot < scalar_t(0) ? scalar_t(-1) : scalar_t(1);
+    const scalar_t nx = target_normals_ptr[target_idx + 0] +
+                        normal_sign * source_normals_ptr[source_idx + 0];
+    const scalar_t ny = target_normals_ptr[target_idx + 1] +
+                        normal_sign * source_normals_ptr[source_idx + 1];
+    const scalar_t nz = target_normals_ptr[target_idx + 2] +
+                        normal_sign * source_normals_ptr[source_idx + 2];
+    const scalar_t sx_centered = sx - source_mean_ptr[0];
+    const scalar_t sy_centered = sy - source_mean_ptr[1];
+    const scalar_t sz_centered = sz - source_mean_ptr[2];
+    const scalar_t tx_centered = tx - target_mean_ptr[0];
+    const scalar_t ty_centered = ty - target_mean_ptr[1];
+    const scalar_t tz_centered = tz - target_mean_ptr[2];
+    const scalar_t sum_x = sx_centered + tx_centered;
+    const scalar_t sum_y = sy_centered + ty_centered;
+    const scalar_t sum_z = sz_centered + tz_centered;
+    J_ij[0] = sum_y * nz - sum_z * ny;
+    J_ij[1] = sum_z * nx - sum_x * nz;
+    J_ij[2] = sum_x * ny - sum_y * nx;
+    J_ij[3] = nx;
+    J_ij[4] = ny;
+    J_ij[5] = nz;
+    centered_residual = (sx_centered - tx_centered) * nx +
+                        (sy_centered - ty_centered) * ny +
+                        (sz_centered - tz_centered) * nz;
+    objective_residual = (sx - tx) * nx + (sy - ty) * ny + (sz - tz) * nz;
+    return true;
+}
+
+// ComputePoseSymmetricKernelCPU, RegistrationCPU.cpp:124-180 (one sequential
+// range); A[27] is the sum of squared objective residuals here.
+template <typename scalar_t, typename acc_t>
+void ComputePoseSymmetricKernel(const scalar_t* source_points_ptr,
+                                const scalar_t* target_points_ptr,
+                                const scalar_t* source_normals_ptr,
+                                const scalar_t* target_normals_ptr,
+                                const int64_t* correspondence_indices,
+                                const scalar_t* source_mean_ptr,
+                                const scalar_t* target_mean_ptr, int64_t n,
+                                acc_t* global_sum, int method, double scaling,
+                                double shape) {
+    acc_t A[29];
+    for (int i = 0; i < 29; ++i) A[i] = 0;
+    for (int64_t workload_idx = 0; workload_idx < n; ++workload_idx) {
+        scalar_t J_ij[6] = {0};
+        scalar_t centered_residual = 0;
+        scalar_t objective_residual = 0;
+        const bool valid = GetJacobianSymmetric<scalar_t>(
+                workload_idx, source_points_ptr, target_points_ptr,
+                source_normals_ptr, target_normals_ptr, correspondence_indices,
+                source_mean_ptr, target_mean_ptr, J_ij, centered_residual,
+                objective_residual);
+        if (valid) {
+            const scalar_t weight = RobustWeight<scalar_t>(
+                    method, scaling, shape, objective_residual);
+            int i = 0;
+            for (int j = 0; j < 6; ++j) {
+                for (int k = 0; k <= j; ++k) {
+                    A[i++] += J_ij[j] * weight * J_ij[k];
+                }
+                A[21 + j] += J_ij[j] * weight * centered_residual;
+            }
+            A[27] += objective_residual * objective_residual;
+            A[28] += 1;
+        }
+    }
+    for (int i = 0; i < 29; ++i) global_sum[i] = A[i];
+}
+
+// TransformSymmetricPoseToMatrix4d, pipelines/registration/SymmetricICPImpl.h:
+// 19-44: pose = (g, t'); theta = atan(|g|); half rotation = AngleAxis(theta,
+// g / |g|) (Eigen's toRotationMatrix = Rodrigues' formula, Eigen is not
+// vendored); R = H H; t = target_mean + H (t' cos theta) - R source_mean.
+void TransformSymmetricPoseToMatrix4d(const double* pose,
+                                      const double* source_mean,
+                                      const double* target_mean, double* T) {
+    const double g_norm = std::sqrt(pose[0] * pose[0] + pose[1] * pose[1] +
+                                    pose[2] * pose[2]);
+    const double theta = std::atan(g_norm);
+    double H[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (g_norm > 0.0) {
+        const double ax = pose[0] / g_norm, ay = pose[1] / g_norm,
+                     az = pose[2] / g_norm;
+        const double c = std::cos(theta), s = std::sin(theta), v = 1.0 - c;
+        H[0] = c + v * ax * ax;
+        H[1] = v * ax * ay - s * az;
+        H[2] = v * ax * az + s * ay;
+        H[3] = v * ax * ay + s * az;
+        H[4] = c + v * ay * ay;
+        H[5] = v * ay * az - s * ax;
+        H[6] = v * ax * az - s * ay;
+        H[7] = v * ay * az + s * ax;
+        H[8] = c + v * az * az;
+    }
+    double R[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            R[i * 3 + j] = H[i * 3 + 0] * H[0 * 3 + j] +
+                           H[i * 3 + 1] * H[1 * 3 + j] +
+                           H[i * 3 + 2] * H[2 * 3 + j];
+    const double ct = std::cos(theta);
+    const double u[3] = {pose[3] * ct, pose[4] * ct, pose[5] * ct};
+    for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) T[i * 4 + j] = R[i * 3 + j];
+        T[i * 4 + 3] = target_mean[i] +
+                       (H[i * 3 + 0] * u[0] + H[i * 3 + 1] * u[1] +
+                        H[i * 3 + 2] * u[2]) -
+                       (R[i * 3 + 0] * source_mean[0] +
+                        R[i * 3 + 1] * source_mean[1] +
+                        R[i * 3 + 2] * source_mean[2]);
+    }
+}
+
+// ComputeTransformationSymmetric, t/pipelines/kernel/Registration.cpp:80-135:
+// means of the matched points in the point dtype (Tensor::Mean; with
+// accumulate_double the sums are float64 and only the mean is rounded to the
+// dtype), 29 sums, DecodeAndSolve6x6, PoseToSymmetricTransformation. Returns
+// 0, or 2 when the 6x6 system is singular; no correspondence -> identity.
+template <typename T>
+int ComputeTransformationSymmetric(const T* src, const T* tgt, const T* sn,
+                                   const T* tn, const int64_t* corr, int64_t n,
+                                   int method, double scaling, double shape,
+                                   int accumulate_double, double* T16,
+                                   double* sums29_out) {
+    for (int i = 0; i < 16; ++i) T16[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    T ms[3], mt[3];
+    int64_t cnt = 0;
+    if (accumulate_double || sizeof(T) == 8) {
+        double a[6] = {0, 0, 0, 0, 0, 0};
+        for (int64_t w = 0; w < n; ++w)
+            if (corr[w] != -1) {
+                for (int k = 0; k < 3; ++k) {
+                    a[k] += src[3 * w + k];
+                    a[3 + k] += tgt[3 * corr[w] + k];
+                }
+                ++cnt;
+            }
+        if (cnt == 0) return 0;
+        for (int k = 0; k < 3; ++k) {
+            ms[k] = (T)(a[k] / (double)cnt);
+            mt[k] = (T)(a[3 + k] / (double)cnt);
+        }
+    } else {
+        T a[6] = {0, 0, 0, 0, 0, 0};
+        for (int64_t w = 0; w < n; ++w)
+            if (corr[w] != -1) {
+                for (int k = 0; k < 3; ++k) {
+                    a[k] += src[3 * w + k];
+                    a[3 + k] += tgt[3 * corr[w] + k];
+                }
+                ++cnt;
+            }
+        if (cnt == 0) return 0;
+        for (int k = 0; k < 3; ++k) {
+            ms[k] = a[k] / (T)cnt;
+            mt[k] = a[3 + k] / (T)cnt;
+        }
+    }
+    double A[29];
+    if (accumulate_double || sizeof(T) == 8) {
+        ComputePoseSymmetricKernel<T, double>(src, tgt, sn, tn, corr, ms, mt, n,
+                                              A, method, scaling, shape);
+    } else {
+        T Af[29];
+        ComputePoseSymmetricKernel<T, T>(src, tgt, sn, tn, corr, ms, mt, n, Af,
+                                         method, scaling, shape);
+        for (int i = 0; i < 29; ++i) A[i] = (double)Af[i];
+    }
+    if (sums29_out) std::memcpy(sums29_out, A, sizeof(A));
+    double pose[6];
+    float residual;
+    int inlier_count;
+    int st = DecodeAndSolve6x6(A, pose, &residual, &inlier_count) != 0 ? 2 : 0;
+    const double msd[3] = {(double)ms[0], (double)ms[1], (double)ms[2]};
+    const double mtd[3] = {(double)mt[0], (double)mt[1], (double)mt[2]};
+    TransformSymmetricPoseToMatrix4d(pose, msd, mtd, T16);
+    return st;
+}
+
+// ---------------------------------------------------------------------------
 // GetInformationMatrix, Registration.cpp:446-486 ->
 // ComputeInformationMatrixCPU, RegistrationCPU.cpp:652-735, with
 // GetInformationJacobians, RegistrationImpl.h:686-715. T = point dtype (each
@@ -869,8 +1079,9 @@ typedef void (*icp_callback_t)(int64_t iteration_index, int64_t scale_index,
 // MultiScaleICP, Registration.cpp:362-444 (+ DoSingleScaleICPIterations
 // :275-360, InitializePointCloudPyramid :221-273), point-to-plane estimator.
 template <typename T>
-int MultiScaleICP(const T* source_in, int64_t ns_in, const T* target_in,
-                  const T* target_normals_in, int64_t nt_in, int num_scales,
+int MultiScaleICP(const T* source_in, const T* source_normals_in, int64_t ns_in,
+                  const T* target_in, const T* target_normals_in,
+                  int64_t nt_in, int num_scales,
                   const double* voxel_sizes, const int* max_iterations,
                   const double* relative_fitness, const double* relative_rmse,
                   const double* max_dists, const double* init, int kernel_method,
@@ -882,7 +1093,8 @@ int MultiScaleICP(const T* source_in, int64_t ns_in, const T* target_in,
                   icp_callback_t cb, void* user) {
     // Pyramid.
     std::vector<std::vector<T>> src_p(num_scales), tgt_p(num_scales),
-            tgt_n(num_scales);
+            tgt_n(num_scales), src_n(num_scales);
+    const bool with_sn = estimation == 2;  // symmetric: source normals too
     auto down = [&](const std::vector<T>& p, const std::vector<T>* nrm,
                     double v, std::vector<T>& op, std::vector<T>* on) {
         int64_t n = (int64_t)p.size() / 3;
@@ -900,17 +1112,22 @@ int MultiScaleICP(const T* source_in, int64_t ns_in, const T* target_in,
         n0.assign(target_normals_in, target_normals_in + 3 * nt_in);
     else
         n0.assign((size_t)(3 * nt_in), T(0));  // point-to-point: unused
+    std::vector<T> sn0;
+    if (with_sn) sn0.assign(source_normals_in, source_normals_in + 3 * ns_in);
     int last = num_scales - 1;
     if (voxel_sizes[last] <= 0) {
         src_p[last] = s0;
+        src_n[last] = sn0;
         tgt_p[last] = t0;
         tgt_n[last] = n0;
     } else {
-        down(s0, nullptr, voxel_sizes[last], src_p[last], nullptr);
+        down(s0, with_sn ? &sn0 : nullptr, voxel_sizes[last], src_p[last],
+             with_sn ? &src_n[last] : nullptr);
         down(t0, &n0, voxel_sizes[last], tgt_p[last], &tgt_n[last]);
     }
     for (int k = num_scales - 2; k >= 0; k--) {
-        down(src_p[k + 1], nullptr, voxel_sizes[k], src_p[k], nullptr);
+        down(src_p[k + 1], with_sn ? &src_n[k + 1] : nullptr, voxel_sizes[k],
+             src_p[k], with_sn ? &src_n[k] : nullptr);
         down(tgt_p[k + 1], &tgt_n[k + 1], voxel_sizes[k], tgt_p[k], &tgt_n[k]);
     }
 
@@ -926,6 +1143,10 @@ int MultiScaleICP(const T* source_in, int64_t ns_in, const T* target_in,
         int64_t ns = (int64_t)source.size() / 3;
         int64_t nt = (int64_t)target.size() / 3;
         TransformPoints<T>(result.T, source.data(), ns);
+        // PointCloud::Transform also rotates the normals (PointCloud.cpp:
+        // 352-372); only the symmetric estimator reads the source's.
+        std::vector<T>& source_normals = src_n[scale_idx];
+        if (with_sn) TransformNormals<T>(result.T, source_normals.data(), ns);
 
         // DoSingleScaleICPIterations
         RegResult current_result = result;
@@ -947,6 +1168,36 @@ int MultiScaleICP(const T* source_in, int64_t ns_in, const T* target_in,
                     r2.num_iterations = it;
                     early_return = true;
                     break;
+                }
+                if (estimation == 2) {
+                    // TransformationEstimationSymmetric::ComputeTransformation,
+                    // TransformationEstimation.cpp:276-292.
+                    double update[16];
+                    if (ComputeTransformationSymmetric<T>(
+                                source.data(), target.data(),
+                                source_normals.data(), normals.data(),
+                                r2.correspondences.data(), ns, kernel_method,
+                                kernel_scale, kernel_shape, accumulate_double,
+                                update, nullptr) != 0)
+                        status = 2;
+                    Matmul4(update, r2.T, r2.T);
+                    TransformPoints<T>(update, source.data(), ns);
+                    TransformNormals<T>(update, source_normals.data(), ns);
+                    if (cb) {
+                        cb(iteration_count + it, scale_idx, it, r2.inlier_rmse,
+                           r2.fitness, r2.T, user);
+                    }
+                    if (it != 0 &&
+                        std::abs(prev_fitness - r2.fitness) <
+                                relative_fitness[scale_idx] &&
+                        std::abs(prev_inlier_rmse - r2.inlier_rmse) <
+                                relative_rmse[scale_idx]) {
+                        r2.converged = true;
+                        break;
+                    }
+                    prev_fitness = r2.fitness;
+                    prev_inlier_rmse = r2.inlier_rmse;
+                    continue;
                 }
                 if (estimation == 1) {
                     // TransformationEstimationPointToPoint::
@@ -1557,6 +1808,62 @@ void orc_evaluate_registration(const void* source, int64_t ns,
         for (int64_t i = 0; i < ns; ++i) out_corr[i] = r.correspondences[(size_t)i];
 }
 
+// 29 sums of ComputePoseSymmetricKernelCPU; means given in float64 and rounded
+// to the point dtype (as the Tensor the reference passes).
+void orc_symmetric_accumulate(const void* src, const void* tgt, const void* sn,
+                              const void* tn, const int64_t* corr, int64_t n,
+                              int is_f64, const double* source_mean3,
+                              const double* target_mean3, int method,
+                              double scaling, double shape,
+                              int accumulate_double, double* out29) {
+    if (is_f64) {
+        ComputePoseSymmetricKernel<double, double>(
+                (const double*)src, (const double*)tgt, (const double*)sn,
+                (const double*)tn, corr, source_mean3, target_mean3, n, out29,
+                method, scaling, shape);
+        return;
+    }
+    float ms[3], mt[3];
+    for (int k = 0; k < 3; ++k) {
+        ms[k] = (float)source_mean3[k];
+        mt[k] = (float)target_mean3[k];
+    }
+    if (accumulate_double) {
+        ComputePoseSymmetricKernel<float, double>(
+                (const float*)src, (const float*)tgt, (const float*)sn,
+                (const float*)tn, corr, ms, mt, n, out29, method, scaling,
+                shape);
+    } else {
+        float A[29];
+        ComputePoseSymmetricKernel<float, float>(
+                (const float*)src, (const float*)tgt, (const float*)sn,
+                (const float*)tn, corr, ms, mt, n, A, method, scaling, shape);
+        for (int i = 0; i < 29; ++i) out29[i] = (double)A[i];
+    }
+}
+
+void orc_symmetric_pose_to_transformation(const double* pose6,
+                                          const double* source_mean3,
+                                          const double* target_mean3,
+                                          double* T16) {
+    TransformSymmetricPoseToMatrix4d(pose6, source_mean3, target_mean3, T16);
+}
+
+int orc_compute_transformation_symmetric(
+        const void* src, const void* tgt, const void* sn, const void* tn,
+        const int64_t* corr, int64_t n, int is_f64, int method, double scaling,
+        double shape, int accumulate_double, double* T16, double* sums29) {
+    if (is_f64)
+        return ComputeTransformationSymmetric<double>(
+                (const double*)src, (const double*)tgt, (const double*)sn,
+                (const double*)tn, corr, n, method, scaling, shape, 1, T16,
+                sums29);
+    return ComputeTransformationSymmetric<float>(
+            (const float*)src, (const float*)tgt, (const float*)sn,
+            (const float*)tn, corr, n, method, scaling, shape,
+            accumulate_double, T16, sums29);
+}
+
 // R9 (row-major), t3 as float64; returns the number of correspondences.
 int64_t orc_compute_rt_p2point(const void* src, const void* tgt,
                                const int64_t* corr, int64_t n, int is_f64,
@@ -1610,7 +1917,8 @@ void orc_rt_from_sxy(const double* Sxy9, const double* source_mean3,
     }
 }
 
-int orc_multiscale_icp_ex(const void* source, int64_t ns, const void* target,
+int orc_multiscale_icp_ex(const void* source, const void* source_normals,
+                          int64_t ns, const void* target,
                           const void* target_normals, int64_t nt, int is_f64,
                           int num_scales, const double* voxel_sizes,
                           const int* max_iterations, const double* rel_fitness,
@@ -1624,17 +1932,17 @@ int orc_multiscale_icp_ex(const void* source, int64_t ns, const void* target,
                           icp_callback_t cb, void* user) {
     if (is_f64)
         return MultiScaleICP<double>(
-                (const double*)source, ns, (const double*)target,
-                (const double*)target_normals, nt, num_scales, voxel_sizes,
-                max_iterations, rel_fitness, rel_rmse, max_dists, init,
-                kernel_method, kernel_scale, kernel_shape, accumulate_double,
-                estimation, out_T, out_fitness, out_rmse, out_converged,
+                (const double*)source, (const double*)source_normals, ns,
+                (const double*)target, (const double*)target_normals, nt,
+                num_scales, voxel_sizes, max_iterations, rel_fitness, rel_rmse,
+                max_dists, init, kernel_method, kernel_scale, kernel_shape,
+                accumulate_double, estimation, out_T, out_fitness, out_rmse, out_converged,
                 out_num_iterations, out_correspondences, out_num_corr, cb,
                 user);
     return MultiScaleICP<float>(
-            (const float*)source, ns, (const float*)target,
-            (const float*)target_normals, nt, num_scales, voxel_sizes,
-            max_iterations, rel_fitness, rel_rmse, max_dists, init,
+            (const float*)source, (const float*)source_normals, ns,
+            (const float*)target, (const float*)target_normals, nt, num_scales,
+            voxel_sizes, max_iterations, rel_fitness, rel_rmse, max_dists, init,
             kernel_method, kernel_scale, kernel_shape, accumulate_double,
             estimation, out_T, out_fitness, out_rmse, out_converged,
             out_num_iterations, out_correspondences, out_num_corr, cb, user);
@@ -1654,7 +1962,7 @@ int orc_multiscale_icp(const void* source, int64_t ns, const void* target,
                        icp_callback_t cb, void* user) {
     if (is_f64)
         return MultiScaleICP<double>(
-                (const double*)source, ns, (const double*)target,
+                (const double*)source, nullptr, ns, (const double*)target,
                 (const double*)target_normals, nt, num_scales, voxel_sizes,
                 max_iterations, rel_fitness, rel_rmse, max_dists, init,
                 kernel_method, kernel_scale, kernel_shape, accumulate_double,
@@ -1662,7 +1970,7 @@ int orc_multiscale_icp(const void* source, int64_t ns, const void* target,
                 out_num_iterations, out_correspondences, out_num_corr, cb,
                 user);
     return MultiScaleICP<float>(
-            (const float*)source, ns, (const float*)target,
+            (const float*)source, nullptr, ns, (const float*)target,
             (const float*)target_normals, nt, num_scales, voxel_sizes,
             max_iterations, rel_fitness, rel_rmse, max_dists, init,
             kernel_method, kernel_scale, kernel_shape, accumulate_double, 0,

@@ -419,6 +419,54 @@ int ref_p2plane_accumulate(const void* src, const void* tgt, const void* tgt_n,
     });
 }
 
+// ComputePoseSymmetricKernelCPU, RegistrationCPU.cpp:124-180 (with
+// GetJacobianSymmetric, RegistrationImpl.h:323-386): the 29 sums in the point
+// dtype, widened to double. Means are given in float64 and rounded to the
+// dtype, as the {3} Tensor the reference passes.
+int ref_symmetric_accumulate(const void* src, const void* tgt, const void* sn,
+                             const void* tn, const int64_t* corr, int64_t n,
+                             int is_f64, const double* source_mean3,
+                             const double* target_mean3, int method,
+                             double scaling, double shape, double* sums29) {
+    return Guard([&] {
+        reg::RobustKernel kernel((reg::RobustKernelMethod)method, scaling,
+                                 shape);
+        using reg::RobustKernelMethod;
+        if (is_f64) {
+            std::vector<double> g(29, 0.0);
+            using scalar_t = double;
+            DISPATCH_ROBUST_KERNEL_FUNCTION(
+                    kernel.type_, scalar_t, kernel.scaling_parameter_,
+                    kernel.shape_parameter_, [&]() {
+                        pk::ComputePoseSymmetricKernelCPU(
+                                (const double*)src, (const double*)tgt,
+                                (const double*)sn, (const double*)tn, corr,
+                                source_mean3, target_mean3, (int)n, g.data(),
+                                GetWeightFromRobustKernel);
+                    });
+            for (int i = 0; i < 29; ++i) sums29[i] = g[(size_t)i];
+        } else {
+            float ms[3], mt[3];
+            for (int k = 0; k < 3; ++k) {
+                ms[k] = (float)source_mean3[k];
+                mt[k] = (float)target_mean3[k];
+            }
+            std::vector<float> g(29, 0.0f);
+            using scalar_t = float;
+            DISPATCH_ROBUST_KERNEL_FUNCTION(
+                    kernel.type_, scalar_t, kernel.scaling_parameter_,
+                    kernel.shape_parameter_, [&]() {
+                        pk::ComputePoseSymmetricKernelCPU(
+                                (const float*)src, (const float*)tgt,
+                                (const float*)sn, (const float*)tn, corr, ms,
+                                mt, (int)n, g.data(),
+                                GetWeightFromRobustKernel);
+                    });
+            for (int i = 0; i < 29; ++i) sums29[i] = g[(size_t)i];
+        }
+    });
+}
+
 // ComputeInformationMatrixCPU, RegistrationCPU.cpp:703-735: GTG {6,6} float64
 // (the 21 sums are accumulated in the point dtype).
 int ref_information_matrix(const void* tgt, const int64_t* corr, int64_t n,

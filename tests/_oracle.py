@@ -390,6 +390,47 @@ def evaluate_registration(source, target, max_dist, transformation=None):
                 correspondences=corr)
 
 
+def symmetric_accumulate(src, tgt, sn, tn, corr, source_mean, target_mean,
+                         method=0, scaling=1.0, shape=1.0,
+                         accumulate_double=False):
+    src = np.ascontiguousarray(src)
+    dt = src.dtype
+    tgt, sn, tn = (np.ascontiguousarray(a, dtype=dt) for a in (tgt, sn, tn))
+    corr = np.ascontiguousarray(corr, dtype=np.int64).reshape(-1)
+    out = np.zeros(29, np.float64)
+    lib().orc_symmetric_accumulate(
+        _p(src), _p(tgt), _p(sn), _p(tn), _p(corr), C.c_int64(src.shape[0]),
+        int(dt == np.float64), _p(_f64(source_mean)), _p(_f64(target_mean)),
+        int(method), C.c_double(scaling), C.c_double(shape),
+        int(accumulate_double), _p(out))
+    return out
+
+
+def symmetric_pose_to_transformation(pose, source_mean, target_mean):
+    T = np.zeros((4, 4), np.float64)
+    lib().orc_symmetric_pose_to_transformation(
+        _p(_f64(pose)), _p(_f64(source_mean)), _p(_f64(target_mean)), _p(T))
+    return T
+
+
+def compute_transformation_symmetric(src, tgt, sn, tn, corr, method=0,
+                                     scaling=1.0, shape=1.0,
+                                     accumulate_double=False):
+    """TransformationEstimationSymmetric::ComputeTransformation ->
+    (status, T {4,4}, sums29)."""
+    src = np.ascontiguousarray(src)
+    dt = src.dtype
+    tgt, sn, tn = (np.ascontiguousarray(a, dtype=dt) for a in (tgt, sn, tn))
+    corr = np.ascontiguousarray(corr, dtype=np.int64).reshape(-1)
+    T = np.zeros((4, 4), np.float64)
+    sums = np.zeros(29, np.float64)
+    st = lib().orc_compute_transformation_symmetric(
+        _p(src), _p(tgt), _p(sn), _p(tn), _p(corr), C.c_int64(src.shape[0]),
+        int(dt == np.float64), int(method), C.c_double(scaling),
+        C.c_double(shape), int(accumulate_double), _p(T), _p(sums))
+    return st, T, sums
+
+
 def compute_rt_p2point(src, tgt, corr, accumulate_double=False):
     """ComputeRtPointToPoint: (R {3,3}, t {3}, count)."""
     src = np.ascontiguousarray(src)
@@ -503,11 +544,15 @@ ICP_CB = C.CFUNCTYPE(None, C.c_int64, C.c_int64, C.c_int64, C.c_double,
 
 def multiscale_icp(source, target, target_normals, voxel_sizes, criterias,
                    max_dists, init=None, kernel=(0, 1.0, 1.0),
-                   accumulate_double=False, callback=None, estimation=0):
+                   accumulate_double=False, callback=None, estimation=0,
+                   source_normals=None):
     """criterias: list of (relative_fitness, relative_rmse, max_iteration).
-    estimation: 0 = point-to-plane, 1 = point-to-point (normals unused)."""
+    estimation: 0 = point-to-plane, 1 = point-to-point (normals unused),
+    2 = symmetric (needs source_normals)."""
     source = np.ascontiguousarray(source)
     dt = source.dtype
+    if source_normals is not None:
+        source_normals = np.ascontiguousarray(source_normals, dtype=dt)
     target = np.ascontiguousarray(target, dtype=dt)
     if target_normals is not None:
         target_normals = np.ascontiguousarray(target_normals, dtype=dt)
@@ -533,7 +578,9 @@ def multiscale_icp(source, target, target_normals, voxel_sizes, criterias,
                                   Tp, shape=(16,)).reshape(4, 4).copy()))
         cb = ICP_CB(_cb)
     st = lib().orc_multiscale_icp_ex(
-            _p(source), C.c_int64(ns), _p(target),
+            _p(source),
+            _p(source_normals) if source_normals is not None else None,
+            C.c_int64(ns), _p(target),
             _p(target_normals) if target_normals is not None else None,
             C.c_int64(nt), int(dt == np.float64), int(S), _p(vs), _p(mi),
             _p(rf), _p(rr), _p(md), _p(init), int(estimation), int(kernel[0]),

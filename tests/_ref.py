@@ -217,6 +217,24 @@ def p2plane_accumulate(src, tgt, tgt_n, corr, method=0, scaling=1.0,
     return out
 
 
+def symmetric_accumulate(src, tgt, sn, tn, corr, source_mean, target_mean,
+                         method=0, scaling=1.0, shape=1.0):
+    """ComputePoseSymmetricKernelCPU: 29 sums in the point dtype."""
+    src = np.ascontiguousarray(src)
+    dt = src.dtype
+    tgt, sn, tn = (np.ascontiguousarray(a, dtype=dt) for a in (tgt, sn, tn))
+    corr = np.ascontiguousarray(corr, dtype=np.int64).reshape(-1)
+    out = np.zeros(29, np.float64)
+    ms = np.ascontiguousarray(source_mean, dtype=np.float64)
+    mt = np.ascontiguousarray(target_mean, dtype=np.float64)
+    _check(lib().ref_symmetric_accumulate(
+        _p(src), _p(tgt), _p(sn), _p(tn), _p(corr), C.c_int64(src.shape[0]),
+        int(dt == np.float64), _p(ms), _p(mt), int(method),
+        C.c_double(scaling), C.c_double(shape), _p(out)),
+        "ref_symmetric_accumulate")
+    return out
+
+
 def information_matrix(tgt, corr):
     """ComputeInformationMatrixCPU: GTG {6,6} float64."""
     tgt = np.ascontiguousarray(tgt)

@@ -578,3 +578,157 @@ def test_information_matrix_parity(dtype):
     far = torch.from_numpy(p["source"] + dtype(100)).cuda()
     with pytest.raises(RuntimeError, match="0 correspondence present"):
         reg.get_information_matrix(far, tgt, 0.07, T)
+
+
+# ------------------------------------------------------------- symmetric (f4)
+def _symmetric_step(_lib, s, sn, t, tn, corr, kernel=(0, 1.0, 1.0)):
+    """One ComputeTransformationSymmetric through the kernel seam: moments ->
+    means -> 29 sums -> solve -> half-angle pose -> transformation."""
+    from open3d_amd.core import TORCH_TO_O3DMI, stream
+    L = _lib.lib()
+    mom = _p2point_sums(_lib, s, t, corr)
+    if mom[15] == 0:
+        return np.eye(4), None
+    ms, mt = mom[0:3] / mom[15], mom[3:6] / mom[15]
+    if s.dtype == np.float32:
+        ms, mt = (ms.astype(np.float32).astype(np.float64),
+                  mt.astype(np.float32).astype(np.float64))
+    ts, tsn, tt, ttn = (torch.from_numpy(np.ascontiguousarray(a)).cuda()
+                        for a in (s, sn, t, tn))
+    tc = torch.from_numpy(np.ascontiguousarray(corr, dtype=np.int64)).cuda()
+    sums = torch.zeros(29, dtype=torch.float64, device="cuda")
+    _lib.check(L.o3dmi_icp_symmetric_accumulate(
+        _lib.ptr(ts), _lib.ptr(tsn), _lib.ptr(tt), _lib.ptr(ttn),
+        _lib.ptr(tc), ts.shape[0], TORCH_TO_O3DMI[ts.dtype],
+        _lib.f64p(np.ascontiguousarray(ms)),
+        _lib.f64p(np.ascontiguousarray(mt)), kernel[0],
+        C.c_double(kernel[1]), C.c_double(kernel[2]), _lib.ptr(sums),
+        stream()), "symmetric_accumulate")
+    torch.cuda.synchronize()
+    A = sums.cpu().numpy()
+    pose = np.zeros(6)
+    res, cnt = C.c_float(0), C.c_int(0)
+    _lib.check(L.o3dmi_decode_and_solve6x6(_lib.f64p(A), _lib.f64p(pose),
+                                           C.byref(res), C.byref(cnt)),
+               "solve")
+    T = np.zeros((4, 4))
+    L.o3dmi_symmetric_pose_to_transformation(
+        _lib.f64p(pose), _lib.f64p(np.ascontiguousarray(ms)),
+        _lib.f64p(np.ascontiguousarray(mt)), _lib.f64p(T))
+    return T, A
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_symmetric_golden_through_gpu(dtype):
+    """The reference's ComputeTransformationSymmetric vectors
+    (cpp/tests/t/pipelines/registration/TransformationEstimation.cpp:220-420)
+    through the HIP kernels: exact recovery, alternating normal signs, the
+    Cauchy-kernel matrix."""
+    _lib, _ = _gpu()
+    from test_oracle_goldens import (SYM_EXPECTED, SYM_ROBUST_EXPECTED,
+                                     sym_case)
+    tol = 1e-4 if dtype == np.float32 else 1e-8
+    s, nr, t, tn = sym_case(dtype, 6)
+    T, _ = _symmetric_step(_lib, s, nr, t, tn, np.arange(6))
+    assert np.allclose(T, SYM_EXPECTED, rtol=tol, atol=tol)
+    signs = np.array([[-1.0], [1.0], [-1.0], [1.0], [-1.0], [1.0]], dtype)
+    T, _ = _symmetric_step(_lib, s, nr, t, (tn * signs).astype(dtype),
+                           np.arange(6))
+    assert np.allclose(T, SYM_EXPECTED, rtol=tol, atol=tol)
+    T, _ = _symmetric_step(_lib, s, nr, t, tn, np.full(6, -1))
+    assert np.array_equal(T, np.eye(4))
+    s, nr, t, tn = sym_case(dtype, 10, noise=True)
+    T, _ = _symmetric_step(_lib, s, nr, t, tn, np.arange(10), (3, 0.5, 1.0))
+    assert np.allclose(T, SYM_ROBUST_EXPECTED, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kernel", [(0, 1.0, 1.0), (3, 0.05, 1.0),
+                                    (5, 0.05, 1.0)])
+def test_symmetric_accumulate_parity(dtype, kernel):
+    _lib, _ = _gpu()
+    p = _pair(30000, seed=41, dtype=dtype)
+    idx, d2, cnt = orc.hybrid_search(p["target"], p["source"], 0.07, 1)
+    corr = idx[:, 0].astype(np.int64)
+    rng = np.random.default_rng(3)
+    sn = np.ascontiguousarray(
+        p["target_normals"][rng.integers(0, 30000, 30000)])
+    sn[::2] *= -1
+    T, A = _symmetric_step(_lib, p["source"], sn, p["target"],
+                           p["target_normals"], corr, kernel)
+    st, Tw, Aw = orc.compute_transformation_symmetric(
+        p["source"], p["target"], sn, p["target_normals"], corr, *kernel,
+        accumulate_double=True)
+    assert st == 0 and A[28] == Aw[28] == (corr >= 0).sum()
+    assert np.allclose(A, Aw, rtol=1e-11, atol=1e-9)
+    assert np.abs(T - Tw).max() < 1e-9
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_icp_symmetric_pose_parity(dtype):
+    """ICP with TransformationEstimationSymmetric vs the oracle driver (source
+    normals carried and rotated with the source)."""
+    _lib, reg = _gpu()
+    p = _pair(20000, seed=4, dtype=dtype)
+    # source normals: the target's normal field moved back by the true motion
+    idx, _, _ = orc.hybrid_search(p["target"],
+                                  orc.transform_points(p["T_gt"], p["source"]),
+                                  0.2, 1)
+    sn = orc.transform_normals(np.linalg.inv(p["T_gt"]),
+                               p["target_normals"][np.maximum(idx[:, 0], 0)])
+    want = orc.multiscale_icp(p["source"], p["target"], p["target_normals"],
+                              [-1.0], [(1e-6, 1e-6, 30)], [0.07],
+                              accumulate_double=True, estimation=2,
+                              source_normals=sn)
+    assert want["status"] == 0
+    got = reg.icp(torch.from_numpy(p["source"]).cuda(),
+                  torch.from_numpy(p["target"]).cuda(),
+                  torch.from_numpy(p["target_normals"]).cuda(), 0.07,
+                  estimation_method=reg.TransformationEstimationSymmetric(),
+                  criteria=reg.ICPConvergenceCriteria(1e-6, 1e-6, 30),
+                  source_normals=torch.from_numpy(sn).cuda())
+    ang, tr = _pose_err(want["transformation"], got.transformation)
+    assert ang <= 1e-6 and tr <= 1e-5, (ang, tr)
+    assert got.num_iterations == want["num_iterations"]
+    assert got.converged == want["converged"]
+    assert abs(got.fitness - want["fitness"]) < 1e-12
+    assert abs(got.inlier_rmse - want["inlier_rmse"]) < 1e-6
+    c = got.correspondence_set.cpu().numpy()
+    assert (c == want["correspondences"]).mean() > 0.9999
+    ang_gt, tr_gt = _pose_err(p["T_gt"], got.transformation)
+    assert ang_gt < 2e-3 and tr_gt < 5e-3
+    with pytest.raises(ValueError, match="SymmetricICP requires"):
+        reg.icp(torch.from_numpy(p["source"]).cuda(),
+                torch.from_numpy(p["target"]).cuda(),
+                torch.from_numpy(p["target_normals"]).cuda(), 0.07,
+                estimation_method=reg.TransformationEstimationSymmetric())
+
+
+def test_multiscale_icp_symmetric():
+    """Pyramid with source normals (VoxelDownSample averages them too)."""
+    _lib, reg = _gpu()
+    p = _pair(60000, seed=12)
+    idx, _, _ = orc.hybrid_search(p["target"],
+                                  orc.transform_points(p["T_gt"], p["source"]),
+                                  0.2, 1)
+    sn = orc.transform_normals(np.linalg.inv(p["T_gt"]),
+                               p["target_normals"][np.maximum(idx[:, 0], 0)])
+    vs = [0.05, 0.025, 0.0125]
+    crit = [(1e-6, 1e-6, 20), (1e-6, 1e-6, 10), (1e-6, 1e-6, 5)]
+    md = [0.15, 0.075, 0.0375]
+    est = reg.TransformationEstimationSymmetric(
+        reg.RobustKernel(reg.RobustKernel.TukeyLoss, 0.1))
+    want = orc.multiscale_icp(p["source"], p["target"], p["target_normals"],
+                              vs, crit, md, kernel=(5, 0.1, 1.0),
+                              accumulate_double=True, estimation=2,
+                              source_normals=sn)
+    got = reg.multi_scale_icp(
+        torch.from_numpy(p["source"]).cuda(),
+        torch.from_numpy(p["target"]).cuda(),
+        torch.from_numpy(p["target_normals"]).cuda(), vs,
+        [reg.ICPConvergenceCriteria(*c) for c in crit], md,
+        estimation_method=est, source_normals=torch.from_numpy(sn).cuda())
+    ang, tr = _pose_err(want["transformation"], got.transformation)
+    assert ang <= 1e-6 and tr <= 1e-5, (ang, tr)
+    assert got.num_iterations == want["num_iterations"]
+    assert abs(got.fitness - want["fitness"]) < 1e-12

@@ -98,6 +98,84 @@ def test_hybrid_search_golden():
         assert cnt.tolist() == [2]
 
 
+# cpp/tests/t/pipelines/registration/TransformationEstimation.cpp:220-420
+def _axis_angle(angle, axis):
+    a = np.asarray(axis, np.float64)
+    a = a / np.linalg.norm(a)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * (K @ K)
+
+
+SYM_EXPECTED = np.eye(4)
+SYM_EXPECTED[:3, :3] = _axis_angle(0.3, [1.0, 2.0, -1.0])
+SYM_EXPECTED[:3, 3] = [0.2, -0.1, 0.15]
+SYM_SRC = np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0],
+                    [0.0, 0.0, 1.0], [1.0, 1.0, 0.0], [1.0, 0.0, 1.0],
+                    [0.0, 1.0, 1.0], [1.0, 1.0, 1.0], [2.0, -1.0, 0.5],
+                    [-0.5, 1.5, 2.0]])
+SYM_NRM = np.array([[1.0, 2.0, 3.0], [2.0, -1.0, 1.0], [-1.0, 3.0, 2.0],
+                    [3.0, 1.0, -2.0], [-2.0, -1.0, 3.0], [1.0, -3.0, 2.0],
+                    [-3.0, 2.0, 1.0], [2.0, 3.0, -1.0], [1.0, 1.0, -2.0],
+                    [-2.0, 1.0, -3.0]])
+SYM_NOISE = np.array([[0.02, -0.01, 0.0], [-0.03, 0.02, 0.01],
+                      [0.0, 0.04, -0.02], [0.01, -0.03, 0.03],
+                      [-0.04, 0.0, 0.02], [0.03, 0.01, -0.04],
+                      [-0.02, -0.02, 0.03], [0.04, -0.03, -0.01],
+                      [0.85, -0.55, 0.45], [-0.65, 0.70, -0.50]])
+SYM_ROBUST_EXPECTED = np.array(
+    [[0.978808528971923, 0.011598608561290, -0.204448858865149,
+      0.374573231881982],
+     [-0.033468146467010, 0.994030976876383, -0.103837855246761,
+      0.105509532797345],
+     [0.202024124262134, 0.108479902699193, 0.973354182159039,
+      -0.112542276940963],
+     [0.0, 0.0, 0.0, 1.0]])
+
+
+def sym_case(dtype, n, noise=False):
+    """Source / target clouds of the reference's symmetric tests: normals
+    normalised in the dtype (PointCloud::NormalizeNormals), target = source
+    moved by SYM_EXPECTED with the dtype's TransformPoints / TransformNormals
+    arithmetic."""
+    s = SYM_SRC[:n].astype(dtype)
+    nr = SYM_NRM[:n].astype(dtype)
+    nr = (nr / np.sqrt((nr * nr).sum(1, keepdims=True))).astype(dtype)
+    t = orc.transform_points(SYM_EXPECTED, s)
+    tn = orc.transform_normals(SYM_EXPECTED, nr)
+    if noise:
+        t = (t + SYM_NOISE[:n].astype(dtype)).astype(dtype)
+    return s, nr, t, tn
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("acc_double", [False, True])
+def test_symmetric_transformation_golden(dtype, acc_double):
+    """ComputeTransformationSymmetric (TransformationEstimation.cpp:220-420):
+    an exact rigid motion is recovered in one step (also with alternating
+    target-normal signs), no correspondence -> identity, and the Cauchy-kernel
+    case reproduces the reference's printed matrix."""
+    tol = 1e-4 if dtype == np.float32 else 1e-8
+    s, nr, t, tn = sym_case(dtype, 6)
+    corr = np.arange(6)
+    st, T, _ = orc.compute_transformation_symmetric(
+        s, t, nr, tn, corr, accumulate_double=acc_double)
+    assert st == 0 and np.allclose(T, SYM_EXPECTED, rtol=tol, atol=tol)
+    signs = np.array([[-1.0], [1.0], [-1.0], [1.0], [-1.0], [1.0]], dtype)
+    st, T, _ = orc.compute_transformation_symmetric(
+        s, t, nr, (tn * signs).astype(dtype), corr,
+        accumulate_double=acc_double)
+    assert st == 0 and np.allclose(T, SYM_EXPECTED, rtol=tol, atol=tol)
+    st, T, _ = orc.compute_transformation_symmetric(
+        s, t, nr, tn, np.full(6, -1), accumulate_double=acc_double)
+    assert st == 0 and np.array_equal(T, np.eye(4))
+    s, nr, t, tn = sym_case(dtype, 10, noise=True)
+    st, T, _ = orc.compute_transformation_symmetric(
+        s, t, nr, tn, np.arange(10), method=3, scaling=0.5, shape=1.0,
+        accumulate_double=acc_double)
+    assert st == 0
+    assert np.allclose(T, SYM_ROBUST_EXPECTED, rtol=tol, atol=tol)
+
+
 KNN_PTS = np.array([[0.0, 0.0, 0.0], [0.0, 0.0, 0.1], [0.0, 0.0, 0.2],
                     [0.0, 0.1, 0.0], [0.0, 0.1, 0.1], [0.0, 0.1, 0.2],
                     [0.0, 0.2, 0.0], [0.0, 0.2, 0.1], [0.0, 0.2, 0.2],

@@ -302,6 +302,29 @@ def test_information_matrix_bit_exact_sequential(dtype):
     assert a[3, 3] == a[4, 4] == a[5, 5] == (corr >= 0).sum()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kernel", [(0, 1.0, 1.0), (2, 0.05, 1.0),
+                                    (3, 0.5, 1.0), (5, 0.05, 1.0)])
+def test_symmetric_29_sums_bit_exact_sequential(dtype, kernel):
+    """ComputePoseSymmetricKernelCPU (GetJacobianSymmetric, weight from the
+    objective residual, centred right-hand side) as one sequential chunk ==
+    the oracle's scalar_t-accumulating variant, bit for bit."""
+    p, corr = _pairs(3000, dtype, 8)
+    corr[::11] = -1
+    rng = np.random.default_rng(5)
+    sn = p["target_normals"][rng.integers(0, 3000, 3000)]  # any unit normals
+    sn[::2] *= -1                                          # both signs of n_s.n_t
+    m = corr >= 0
+    ms = p["source"][m].astype(np.float64).mean(0)
+    mt = p["target"][corr[m]].astype(np.float64).mean(0)
+    a = orc.symmetric_accumulate(p["source"], p["target"], sn,
+                                 p["target_normals"], corr, ms, mt, *kernel)
+    b = ref.symmetric_accumulate(p["source"], p["target"], sn,
+                                 p["target_normals"], corr, ms, mt, *kernel)
+    assert np.array_equal(a, b)
+    assert a[28] == m.sum() and a[27] > 0
+
+
 def test_singular_system_is_an_error_in_both():
     A = np.zeros(29)
     assert orc.decode_and_solve6x6(A)[0] != 0

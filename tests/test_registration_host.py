@@ -110,3 +110,36 @@ def test_rt_no_correspondence_is_an_error():
     st, R, t = _rt(_moments(s, s + [0.5, 0, -1]))
     assert st == 0 and np.array_equal(R, np.eye(3))
     assert np.allclose(t, [0.5, 0, -1], atol=1e-12)
+
+
+def test_symmetric_pose_to_transformation_matches_oracle():
+    """PoseToSymmetricTransformation (TransformationConverter.cpp:106-133):
+    the library's host function vs the oracle restatement, and the closed form
+    for a pure half-angle rotation about z."""
+    L = _lib()
+    rng = np.random.default_rng(7)
+    for _ in range(20):
+        pose = rng.standard_normal(6) * [0.3, 0.3, 0.3, 1, 1, 1]
+        ms, mt = rng.standard_normal(3), rng.standard_normal(3)
+        T = np.zeros((4, 4))
+        L.lib().o3dmi_symmetric_pose_to_transformation(
+            L.f64p(pose), L.f64p(ms), L.f64p(mt), L.f64p(T))
+        want = orc.symmetric_pose_to_transformation(pose, ms, mt)
+        assert np.abs(T - want).max() < 1e-15
+        assert abs(np.linalg.det(T[:3, :3]) - 1) < 1e-12
+    # g = tan(theta) z, no translation, zero means: rotation by 2 theta about z
+    theta = 0.2
+    pose = np.array([0, 0, np.tan(theta), 0, 0, 0.0])
+    T = np.zeros((4, 4))
+    z = np.zeros(3)
+    L.lib().o3dmi_symmetric_pose_to_transformation(L.f64p(pose), L.f64p(z),
+                                                   L.f64p(z), L.f64p(T))
+    c, s = np.cos(2 * theta), np.sin(2 * theta)
+    assert np.allclose(T[:3, :3], [[c, -s, 0], [s, c, 0], [0, 0, 1]],
+                       atol=1e-15)
+    # zero pose: identity rotation, translation = target_mean - source_mean
+    L.lib().o3dmi_symmetric_pose_to_transformation(
+        L.f64p(np.zeros(6)), L.f64p(np.array([1.0, 2, 3])),
+        L.f64p(np.array([2.0, 2, 2])), L.f64p(T))
+    assert np.array_equal(T[:3, :3], np.eye(3))
+    assert np.array_equal(T[:3, 3], [1.0, 0, -1])
