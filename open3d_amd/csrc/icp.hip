@@ -1403,6 +1403,39 @@ int o3dmi_nns_hybrid_search(const o3dmi_nns_t* nns, const void* queries_dev,
     return O3DMI_OK;
 }
 
+namespace {
+
+// Everything a KnnSearch call owns; released on every exit path (the index
+// destructor drains the device first, so the pooled scratch is idle by then).
+struct KnnResources {
+    unsigned long long* box = nullptr;  // [0..2] min keys, [3..5] max, [6] count
+    int* retry = nullptr;               // [0] = count, [1..q] = query ids
+    std::vector<o3dmi_nns*> levels;     // finest first
+    ~KnnResources() {
+        for (o3dmi_nns* lv : levels) o3dmi_nns_destroy(lv);
+        PoolFree(box);
+        PoolFree(retry);
+    }
+    int AddLevel(const void* points, int64_t n, int dtype, double cell,
+                 hipStream_t s) {
+        auto* lv = new o3dmi_nns();
+        lv->dtype = dtype;
+        lv->n = n;
+        lv->radius = cell;
+        lv->inv_cell = 1.0 / cell;
+        levels.push_back(lv);
+        return dtype == O3DMI_F64
+                       ? BuildIndex<double>(lv, (const double*)points, s)
+                       : BuildIndex<float>(lv, (const float*)points, s);
+    }
+    void DropLevels() {
+        for (o3dmi_nns* lv : levels) o3dmi_nns_destroy(lv);
+        levels.clear();
+    }
+};
+
+}  // namespace
+
 // Internal form (also fills counts_dev {q} with the row width when given).
 int o3dmi_nns_knn_search_counts(const void* points_dev, int64_t n,
                                 const void* queries_dev, int64_t q, int dtype,
@@ -1418,51 +1451,51 @@ int o3dmi_nns_knn_search_counts(const void* points_dev, int64_t n,
     if (q == 0) return O3DMI_OK;
     O3DMI_REQUIRE(queries_dev && idx_dev, "null argument");
     hipStream_t s = (hipStream_t)stream;
+    KnnResources res;
+    int st;
 
-    // bounding box
-    unsigned long long* box = nullptr;  // [0..2] min keys, [3..5] max keys
-    unsigned* occupied = nullptr;
-    { int st_; if ((st_ = PoolAlloc((void**)&box, 64))) return st_; }
-    occupied = (unsigned*)(box + 6);
-    O3DMI_HIP_CHECK(hipMemsetAsync(box, 0xff, 24, s));
-    O3DMI_HIP_CHECK(hipMemsetAsync(box + 3, 0, 24, s));
+    // 1. Bounding box of the dataset.
+    if ((st = PoolAlloc((void**)&res.box, 64))) return st;
+    unsigned* occupied = (unsigned*)(res.box + 6);
+    O3DMI_HIP_CHECK(hipMemsetAsync(res.box, 0xff, 24, s));
+    O3DMI_HIP_CHECK(hipMemsetAsync(res.box + 3, 0, 24, s));
     {
         int g = GridFor(n, kBlock);
         if (g > kCUs) g = kCUs;  // 6 atomics per wave on 6 addresses
         if (dtype == O3DMI_F64)
             hipLaunchKernelGGL(BoundsKernel<double>, dim3(g), dim3(kBlock), 0,
-                               s, (const double*)points_dev, n, box, box + 3);
+                               s, (const double*)points_dev, n, res.box,
+                               res.box + 3);
         else
             hipLaunchKernelGGL(BoundsKernel<float>, dim3(g), dim3(kBlock), 0, s,
-                               (const float*)points_dev, n, box, box + 3);
+                               (const float*)points_dev, n, res.box,
+                               res.box + 3);
     }
     unsigned long long hbox[6];
-    O3DMI_HIP_CHECK(hipMemcpyAsync(hbox, box, sizeof(hbox),
+    O3DMI_HIP_CHECK(hipMemcpyAsync(hbox, res.box, sizeof(hbox),
                                    hipMemcpyDeviceToHost, s));
     O3DMI_HIP_CHECK(hipStreamSynchronize(s));
     double lo[3], ext[3];
     for (int a = 0; a < 3; ++a) {
         lo[a] = FromOrderedKey(hbox[a]);
         const double hi = FromOrderedKey(hbox[3 + a]);
-        if (!(lo[a] <= hi)) {  // no finite coordinate on this axis
-            PoolFree(box);
-            SetLastError("KnnSearch: dataset has no finite points");
-            return O3DMI_ERR_INVALID_ARG;
-        }
+        O3DMI_REQUIRE(lo[a] <= hi, "KnnSearch: dataset has no finite points");
         ext[a] = hi - lo[a];
     }
-    // first guess: a surface spanning the two largest extents, or a filled
-    // volume, whichever gives the larger cell (shrinking is the cheap
-    // direction: few occupied cells -> reliable estimate of the density)
+
+    // 2. Cell size of the finest level from the measured density. Target
     // points per occupied cell: small cells keep the candidate sets (and the
     // quadratic rank counting) small, shell 1 yields a first list whose k-th
     // distance prunes shell 2. Measured on MI355X, k = 30, 100 k queries:
     // 3 per cell 1.8 ms, 4.5: 0.71 ms, 6: 0.84 ms, 8: 1.26 ms, 15: 2.5 ms.
     double target = k * 0.15 < 2.0 ? 2.0 : k * 0.15;
-    if (const char* e_ = std::getenv("O3DMI_KNN_PPC")) {  // tuning: points/cell
+    if (const char* e_ = std::getenv("O3DMI_KNN_PPC")) {  // tuning knob
         const double v = std::atof(e_);
         if (v > 0) target = v;
     }
+    // First guess: a surface spanning the two largest extents, a filled
+    // volume or a line, whichever gives the largest cell (shrinking is the
+    // cheap direction: few occupied cells estimate the density reliably).
     double e[3] = {ext[0], ext[1], ext[2]};
     std::sort(e, e + 3);
     const double emax = e[2] > 0 ? e[2] : 1.0;
@@ -1470,28 +1503,18 @@ int o3dmi_nns_knn_search_counts(const void* points_dev, int64_t n,
     double h = std::sqrt(std::max(e[2] * e[1], 0.0) * target / (double)n);
     h = std::max(h, std::cbrt(std::max(e[0] * e[1] * e[2], 0.0) * target /
                               (double)n));
-    h = std::max(h, e[2] * target / (double)n);  // points along a line
+    h = std::max(h, e[2] * target / (double)n);
     if (!(h > h_min)) h = h_min;
     if (!(e[2] > 0)) h = 1.0;
-
-    o3dmi_nns* nns = nullptr;
-    int st = O3DMI_OK;
     for (int attempt = 0; attempt < 6; ++attempt) {
-        if (nns) o3dmi_nns_destroy(nns);
-        nns = new o3dmi_nns();
-        nns->dtype = dtype;
-        nns->n = n;
-        nns->radius = h;
-        nns->inv_cell = 1.0 / h;
-        st = dtype == O3DMI_F64
-                     ? BuildIndex<double>(nns, (const double*)points_dev, s)
-                     : BuildIndex<float>(nns, (const float*)points_dev, s);
-        if (st) break;
+        res.DropLevels();
+        if ((st = res.AddLevel(points_dev, n, dtype, h, s))) return st;
+        const o3dmi_nns* lv = res.levels[0];
         O3DMI_HIP_CHECK(hipMemsetAsync(occupied, 0, sizeof(unsigned), s));
-        int g = GridFor(nns->n_buckets, kBlock);
+        int g = GridFor(lv->n_buckets, kBlock);
         if (g > kCUs * 4) g = kCUs * 4;
         hipLaunchKernelGGL(CountOccupiedKernel, dim3(g), dim3(kBlock), 0, s,
-                           nns->starts, nns->n_buckets, occupied);
+                           lv->starts, lv->n_buckets, occupied);
         unsigned occ = 0;
         O3DMI_HIP_CHECK(hipMemcpyAsync(&occ, occupied, sizeof(occ),
                                        hipMemcpyDeviceToHost, s));
@@ -1503,47 +1526,39 @@ int o3dmi_nns_knn_search_counts(const void* points_dev, int64_t n,
         if (h_next == h) break;
         h = h_next;
     }
-    PoolFree(box);
-    if (st) {
-        if (nns) o3dmi_nns_destroy(nns);
-        return st;
-    }
-    // First pass on the finest level alone; the queries it cannot finish (too
-    // few points within kKnnShells shells: sparse regions, outliers, queries
-    // away from the cloud) are collected and walked up a pyramid of coarser
-    // levels, built only then, whose last level spans the cloud in <= 4 cells
-    // per axis and is searched exhaustively.
-    std::vector<o3dmi_nns*> levels{nns};
-    const bool single = !(emax / h > 3.0);
-    int* retry = nullptr;  // [0] = count, [1..q] = query ids
+
+    // 3. First pass on the finest level alone; the queries it cannot finish
+    // (too few points within kKnnShells shells: sparse regions, outliers,
+    // queries away from the cloud) are collected for a second pass.
+    const bool single = !(emax / h > 3.0);  // one level already spans the cloud
     if (!single) {
-        st = PoolAlloc((void**)&retry, sizeof(int) * (size_t)(q + 1));
-        if (!st && hipMemsetAsync(retry, 0, sizeof(int), s) != hipSuccess)
-            st = O3DMI_ERR_HIP;
+        if ((st = PoolAlloc((void**)&res.retry, sizeof(int) * (size_t)(q + 1))))
+            return st;
+        O3DMI_HIP_CHECK(hipMemsetAsync(res.retry, 0, sizeof(int), s));
     }
     auto launch = [&](int first_level, bool exhaustive, bool brute,
                       const int* ids, int64_t count, int* retry_ids,
-                      int* retry_count) {
+                      int* retry_count) -> int {
         const dim3 grid(GridFor(count, kCoopBlock / 64, kCUs * 16)),
                 block(kCoopBlock);
 #define O3DMI_KNN(T)                                                           \
     do {                                                                       \
         KnnPyramid<T> pyr;                                                     \
-        pyr.n_levels = (int)levels.size();                                     \
+        pyr.n_levels = (int)res.levels.size();                                 \
         pyr.first_radius = 1;                                                  \
         pyr.first_level = first_level;                                         \
         pyr.exhaustive_last = exhaustive ? 1 : 0;                              \
         pyr.brute = brute ? 1 : 0;                                             \
         pyr.n_points = n;                                                      \
         for (int l = 0; l < pyr.n_levels; ++l) {                               \
+            const o3dmi_nns* lv = res.levels[l];                               \
             KnnGrid<T>& kg = pyr.level[l];                                     \
-            kg.nv = MakeView<T>(levels[l]);                                    \
-            kg.cell = levels[l]->radius;                                       \
+            kg.nv = MakeView<T>(lv);                                           \
+            kg.cell = lv->radius;                                              \
             for (int a = 0; a < 3; ++a) {                                      \
-                kg.cmin[a] = (long long)std::floor(lo[a] *                     \
-                                                   levels[l]->inv_cell) - 1;   \
+                kg.cmin[a] = (long long)std::floor(lo[a] * lv->inv_cell) - 1;  \
                 kg.cmax[a] = (long long)std::floor((lo[a] + ext[a]) *          \
-                                                   levels[l]->inv_cell) + 1;   \
+                                                   lv->inv_cell) + 1;          \
             }                                                                  \
         }                                                                      \
         hipLaunchKernelGGL(KnnSearchKernel<T>, grid, block,                    \
@@ -1555,62 +1570,49 @@ int o3dmi_nns_knn_search_counts(const void* points_dev, int64_t n,
         if (dtype == O3DMI_F64) O3DMI_KNN(double);
         else O3DMI_KNN(float);
 #undef O3DMI_KNN
-        return hipGetLastError() == hipSuccess;
+        O3DMI_HIP_CHECK(hipGetLastError());
+        return O3DMI_OK;
     };
+    if ((st = launch(0, single, false, nullptr, q,
+                     res.retry ? res.retry + 1 : nullptr, res.retry)))
+        return st;
     int n_retry = 0;
-    if (!st) {
-        if (!launch(0, single, false, nullptr, q, retry ? retry + 1 : nullptr,
-                    retry)) {
-            SetLastError("KnnSearch kernel launch failed");
-            st = O3DMI_ERR_HIP;
-        }
+    if (!single) {
+        O3DMI_HIP_CHECK(hipMemcpyAsync(&n_retry, res.retry, sizeof(int),
+                                       hipMemcpyDeviceToHost, s));
+        O3DMI_HIP_CHECK(hipStreamSynchronize(s));
     }
-    if (!st && !single) {
-        if (hipMemcpyAsync(&n_retry, retry, sizeof(int), hipMemcpyDeviceToHost,
-                           s) != hipSuccess ||
-            hipStreamSynchronize(s) != hipSuccess)
-            st = O3DMI_ERR_HIP;
-    }
-    // a handful of leftovers is cheaper to sweep than to index again
+
+    // 4. Second pass: a coalesced sweep over all records when the leftovers
+    // are few, else a pyramid of 4x coarser levels (built only now) whose
+    // last level spans the cloud in <= 4 cells per axis and is searched
+    // exhaustively.
     double sweep_limit = 2e9;  // leftover queries x points
     if (const char* e_ = std::getenv("O3DMI_KNN_SWEEP_LIMIT"))
         sweep_limit = std::atof(e_);
     const bool brute = (double)n_retry * (double)n <= sweep_limit;
-    if (!st && n_retry > 0 && brute) {
-        if (!launch(0, false, true, retry + 1, n_retry, nullptr, nullptr)) {
-            SetLastError("KnnSearch kernel launch failed");
-            st = O3DMI_ERR_HIP;
+    if (n_retry > 0 && brute) {
+        if ((st = launch(0, false, true, res.retry + 1, n_retry, nullptr,
+                         nullptr)))
+            return st;
+    } else if (n_retry > 0) {
+        while ((int)res.levels.size() < kKnnMaxLevels &&
+               emax / res.levels.back()->radius > 3.0) {
+            if ((st = res.AddLevel(points_dev, n, dtype,
+                                   res.levels.back()->radius * 4.0, s)))
+                return st;
         }
-    }
-    if (!st && n_retry > 0 && !brute) {
-        while ((int)levels.size() < kKnnMaxLevels &&
-               emax / levels.back()->radius > 3.0) {
-            auto* up = new o3dmi_nns();
-            up->dtype = dtype;
-            up->n = n;
-            up->radius = levels.back()->radius * 4.0;
-            up->inv_cell = 1.0 / up->radius;
-            levels.push_back(up);
-            st = dtype == O3DMI_F64
-                         ? BuildIndex<double>(up, (const double*)points_dev, s)
-                         : BuildIndex<float>(up, (const float*)points_dev, s);
-            if (st) break;
-        }
-        if (!st &&
-            !launch(1, true, false, retry + 1, n_retry, nullptr, nullptr)) {
-            SetLastError("KnnSearch kernel launch failed");
-            st = O3DMI_ERR_HIP;
-        }
+        if ((st = launch(1, true, false, res.retry + 1, n_retry, nullptr,
+                         nullptr)))
+            return st;
     }
     if (std::getenv("O3DMI_VERBOSE"))
         std::fprintf(stderr,
                      "[o3dmi] knn: n=%lld k=%d cell=%g levels=%d target=%g "
                      "second-pass queries=%d (%s)\n",
-                     (long long)n, k, h, (int)levels.size(), target, n_retry,
-                     brute ? "sweep" : "pyramid");
-    for (o3dmi_nns* lv : levels) o3dmi_nns_destroy(lv);  // drains the device
-    PoolFree(retry);
-    return st;
+                     (long long)n, k, h, (int)res.levels.size(), target,
+                     n_retry, brute ? "sweep" : "pyramid");
+    return O3DMI_OK;
 }
 
 int o3dmi_nns_knn_search(const void* points_dev, int64_t n,
