@@ -422,6 +422,30 @@ void o3dmi_symmetric_pose_to_transformation(const double* pose6,
                                             const double* target_mean3,
                                             double* T16);
 
+/* ComputePoseColoredICPCUDA up to the reduction (TransformationEstimationFor
+ * ColoredICP; CPU body RegistrationCPU.cpp:220-340, Jacobians RegistrationImpl.
+ * h:388-466): 29 sums, [27] = sum r_G^2 + r_I^2. Colours {N,3} in the point
+ * dtype, target_color_gradients {Nt,3} from EstimateColorGradients. */
+int o3dmi_icp_colored_accumulate(
+        const void* src_dev, const void* src_colors_dev, const void* tgt_dev,
+        const void* tgt_normals_dev, const void* tgt_colors_dev,
+        const void* tgt_color_gradients_dev, const int64_t* corr_dev, int64_t n,
+        int dtype, double lambda_geometric, int robust_kernel,
+        double scaling_parameter, double shape_parameter, double* sums29_dev,
+        o3dmi_stream_t stream);
+
+/* EstimateColorGradientsUsing{Hybrid,KNN}SearchCUDA after the search
+ * (t/geometry/kernel/PointCloudImpl.h:1067-1290): per point, least squares of
+ * the intensity over its neighbours projected on the tangent plane plus the
+ * constraint gradient . normal = 0. The 3x3 normal equations are solved
+ * exactly (converged Jacobi, eigenvalues < 1e-10 dropped) where the reference
+ * uses its approximate solve_svd3x3: results agree with the reference to the
+ * accuracy of that routine, not bit for bit. */
+int o3dmi_pointcloud_color_gradients_from_neighbors(
+        const void* points_dev, const void* normals_dev, const void* colors_dev,
+        const int32_t* indices_dev, const int32_t* counts_dev, int64_t n,
+        int max_nn, int dtype, void* gradients_dev, o3dmi_stream_t stream);
+
 /* ComputeInformationMatrixCUDA up to the reduction
  * (t/pipelines/kernel/RegistrationCUDA.cu ComputeInformationMatrixKernelCUDA,
  * CPU body RegistrationCPU.cpp:652-735, Jacobians RegistrationImpl.h:686-715):

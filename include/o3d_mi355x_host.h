@@ -77,24 +77,41 @@ int o3dmi_registration_multiscale_icp(
 typedef enum {
     O3DMI_ICP_POINT_TO_PLANE = 0,
     O3DMI_ICP_POINT_TO_POINT = 1,
-    O3DMI_ICP_SYMMETRIC = 2
+    O3DMI_ICP_SYMMETRIC = 2,
+    O3DMI_ICP_COLORED = 3
 } o3dmi_icp_estimation_t;
+
+/* Point attributes beyond positions / target normals that some estimators
+ * read (device, {N,3}, point dtype). Unused members may be NULL. */
+typedef struct {
+    const void* source_normals;         /* SYMMETRIC                          */
+    const void* source_colors;          /* COLORED                            */
+    const void* target_colors;          /* COLORED                            */
+    const void* target_color_gradients; /* COLORED, optional: estimated on the
+                                           finest level when NULL, as
+                                           Registration.cpp:243-262 does     */
+    double lambda_geometric;            /* COLORED; outside [0,1] -> 0.968    */
+} o3dmi_icp_attributes_t;
 
 /* MultiScaleICP with a selectable estimator. POINT_TO_PLANE is exactly
  * o3dmi_registration_multiscale_icp; POINT_TO_POINT
  * (TransformationEstimationPointToPoint, TransformationEstimation.cpp:101-160)
  * ignores the normals (may be NULL) and the robust kernel; SYMMETRIC
- * (TransformationEstimationSymmetric, :229-292) needs source_normals_dev and
- * target_normals_dev ({N,3}, point dtype) -- the source normals are carried
- * through the pyramid and rotated with the source, as PointCloud::Transform
- * does. source_normals_dev is ignored by the other estimators. */
+ * (TransformationEstimationSymmetric, :229-292) needs attrs->source_normals
+ * and target_normals_dev -- the source normals are carried through the pyramid
+ * and rotated with the source, as PointCloud::Transform does; COLORED
+ * (TransformationEstimationForColoredICP, :296-440) needs target normals and
+ * both colour sets, every attribute is averaged through the VoxelDownSample
+ * pyramid, and missing colour gradients are estimated on the finest level
+ * with EstimateColorGradients(30, 4 voxel_size or 2 max_distance).
+ * attrs may be NULL for the first two estimators. */
 int o3dmi_registration_multiscale_icp_ex(
-        const void* source_dev, const void* source_normals_dev, int64_t ns,
-        const void* target_dev,
+        const void* source_dev, int64_t ns, const void* target_dev,
         const void* target_normals_dev, int64_t nt, int dtype, int num_scales,
         const double* voxel_sizes, const o3dmi_icp_criteria_t* criterias,
         const double* max_correspondence_distances,
-        const double* init_source_to_target, int estimation, int robust_kernel,
+        const double* init_source_to_target, int estimation,
+        const o3dmi_icp_attributes_t* attrs, int robust_kernel,
         double scaling_parameter, double shape_parameter,
         o3dmi_icp_callback_t callback, void* callback_user,
         o3dmi_allreduce_sum_t allreduce, void* allreduce_user,
@@ -143,6 +160,14 @@ int o3dmi_pointcloud_estimate_normals(const void* points_dev, int64_t n,
                                       int dtype, int max_nn, double radius,
                                       void* normals_dev, int has_normals,
                                       o3dmi_stream_t stream);
+
+/* PointCloud::EstimateColorGradients(max_nn, radius) (t/geometry/PointCloud.
+ * cpp:987-1060): hybrid search when radius > 0, KNN search otherwise;
+ * gradients {n,3} in the point dtype. max_nn <= 64. Synchronises. */
+int o3dmi_pointcloud_estimate_color_gradients(
+        const void* points_dev, const void* normals_dev, const void* colors_dev,
+        int64_t n, int dtype, int max_nn, double radius, void* gradients_dev,
+        o3dmi_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
 /* VoxelBlockGrid                                                            */

@@ -142,6 +142,12 @@ class OdometryResultC(C.Structure):
                 ("fitness", _d), ("num_iterations", _i32)]
 
 
+class IcpAttributes(C.Structure):
+    _fields_ = [("source_normals", _vp), ("source_colors", _vp),
+                ("target_colors", _vp), ("target_color_gradients", _vp),
+                ("lambda_geometric", _d)]
+
+
 ICP_CALLBACK = C.CFUNCTYPE(None, _i64, _i64, _i64, _d, _d, _dp, _vp)
 ALLREDUCE_SUM = C.CFUNCTYPE(_i32, _dp, _i32, _vp)
 
@@ -152,10 +158,17 @@ PROTOTYPES.update({
                _vp, ALLREDUCE_SUM, _vp, _vp, C.POINTER(RegistrationResultC),
                _vp]),
     "o3dmi_registration_multiscale_icp_ex": (
-        _i32, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _dp,
-               C.POINTER(IcpCriteria), _dp, _dp, _i32, _i32, _d, _d,
-               ICP_CALLBACK, _vp, ALLREDUCE_SUM, _vp, _vp,
-               C.POINTER(RegistrationResultC), _vp]),
+        _i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _dp,
+               C.POINTER(IcpCriteria), _dp, _dp, _i32,
+               C.POINTER(IcpAttributes), _i32, _d, _d, ICP_CALLBACK, _vp,
+               ALLREDUCE_SUM, _vp, _vp, C.POINTER(RegistrationResultC), _vp]),
+    "o3dmi_icp_colored_accumulate": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                            _i64, _i32, _d, _i32, _d, _d, _vp,
+                                            _vp]),
+    "o3dmi_pointcloud_color_gradients_from_neighbors": (
+        _i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "o3dmi_pointcloud_estimate_color_gradients": (
+        _i32, [_vp, _vp, _vp, _i64, _i32, _i32, _d, _vp, _vp]),
     "o3dmi_nns_knn_search": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp,
                                     _vp, _vp]),
     "o3dmi_registration_evaluate": (

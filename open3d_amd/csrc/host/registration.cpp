@@ -21,7 +21,9 @@
 
 #include <cmath>
 #include <cstring>
+#include <initializer_list>
 #include <limits>
+#include <utility>
 #include <vector>
 
 #include "../common.h"
@@ -37,6 +39,15 @@ extern "C" int o3dmi_icp_search_accumulate_post(
 
 extern "C" int o3dmi_nns_set_normals(o3dmi_nns_t* nns, const void* normals_dev,
                                      o3dmi_stream_t stream);
+
+extern "C" int o3dmi_icp_colored_accumulate_post(
+        const void* src_dev, const void* src_colors_dev, const void* tgt_dev,
+        const void* tgt_normals_dev, const void* tgt_colors_dev,
+        const void* tgt_color_gradients_dev, const int64_t* corr_dev, int64_t n,
+        int dtype, double lambda_geometric, int robust_kernel,
+        double scaling_parameter, double shape_parameter, double* sums29_dev,
+        double* partials_dev, double* mail_data, int* mail_flag, int mail_seq,
+        o3dmi_stream_t stream);
 
 extern "C" int o3dmi_icp_symmetric_accumulate_post(
         const void* src_dev, const void* src_normals_dev, const void* tgt_dev,
@@ -79,11 +90,35 @@ struct DeviceBuffer {
 };
 
 struct Level {
-    DeviceBuffer src, srcn, tgt, nrm;
+    // source: positions, normals (symmetric), colours (coloured);
+    // target: positions, normals, colours, colour gradients
+    DeviceBuffer src, srcn, srcc, tgt, nrm, tgtc, tgtg;
     int64_t ns = 0, nt = 0;
     const void* tgt_ptr = nullptr;  // may alias the caller's buffers
     const void* nrm_ptr = nullptr;
+    const void* tgtc_ptr = nullptr;
+    const void* tgtg_ptr = nullptr;
 };
+
+// PointCloud::VoxelDownSample averages every attribute; the kernel seam takes
+// positions + one attribute, so further attributes go through it again (the
+// voxel order, first occurrence, is the same every time).
+int DownSampleAttrs(const void* pos, int64_t n, int dtype, double voxel,
+                    void* out_pos, int64_t* m, o3dmi_stream_t stream,
+                    std::initializer_list<std::pair<const void*, void*>> attrs) {
+    bool done = false;
+    for (const auto& a : attrs) {
+        if (!a.first) continue;
+        int st = o3dmi_voxel_down_sample(pos, a.first, n, dtype, voxel, out_pos,
+                                         a.second, m, stream);
+        if (st) return st;
+        done = true;
+    }
+    if (!done)
+        return o3dmi_voxel_down_sample(pos, nullptr, n, dtype, voxel, out_pos,
+                                       nullptr, m, stream);
+    return O3DMI_OK;
+}
 
 struct NnsGuard {
     o3dmi_nns_t* nns = nullptr;
@@ -108,20 +143,20 @@ extern "C" int o3dmi_registration_multiscale_icp(
         int64_t* correspondences_dev, o3dmi_registration_result_t* result,
         o3dmi_stream_t stream) {
     return o3dmi_registration_multiscale_icp_ex(
-            source_dev, nullptr, ns, target_dev, target_normals_dev, nt, dtype,
+            source_dev, ns, target_dev, target_normals_dev, nt, dtype,
             num_scales, voxel_sizes, criterias, max_dists, init,
-            O3DMI_ICP_POINT_TO_PLANE, robust_kernel, scaling_parameter,
+            O3DMI_ICP_POINT_TO_PLANE, nullptr, robust_kernel, scaling_parameter,
             shape_parameter, callback, callback_user, allreduce, allreduce_user,
             correspondences_dev, result, stream);
 }
 
 extern "C" int o3dmi_registration_multiscale_icp_ex(
-        const void* source_dev, const void* source_normals_dev, int64_t ns,
-        const void* target_dev,
+        const void* source_dev, int64_t ns, const void* target_dev,
         const void* target_normals_dev, int64_t nt, int dtype, int num_scales,
         const double* voxel_sizes, const o3dmi_icp_criteria_t* criterias,
         const double* max_dists, const double* init, int estimation,
-        int robust_kernel, double scaling_parameter, double shape_parameter,
+        const o3dmi_icp_attributes_t* attrs, int robust_kernel,
+        double scaling_parameter, double shape_parameter,
         o3dmi_icp_callback_t callback, void* callback_user,
         o3dmi_allreduce_sum_t allreduce, void* allreduce_user,
         int64_t* correspondences_dev, o3dmi_registration_result_t* result,
@@ -132,21 +167,35 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                   "Only Float32 and Float64 point clouds are supported.");
     O3DMI_REQUIRE(source_dev && target_dev && ns > 0 && nt > 0,
                   "Source and/or Target pointcloud is empty.");
-    O3DMI_REQUIRE(estimation == O3DMI_ICP_POINT_TO_PLANE ||
-                          estimation == O3DMI_ICP_POINT_TO_POINT ||
-                          estimation == O3DMI_ICP_SYMMETRIC,
-                  "estimation must be point-to-plane, point-to-point or "
-                  "symmetric");
+    O3DMI_REQUIRE(estimation >= O3DMI_ICP_POINT_TO_PLANE &&
+                          estimation <= O3DMI_ICP_COLORED,
+                  "estimation must be point-to-plane, point-to-point, "
+                  "symmetric or colored");
     const bool p2plane = estimation == O3DMI_ICP_POINT_TO_PLANE;
     const bool symmetric = estimation == O3DMI_ICP_SYMMETRIC;
-    const bool need_tn = p2plane || symmetric;  // target normals in the pyramid
+    const bool colored = estimation == O3DMI_ICP_COLORED;
+    const bool need_tn = p2plane || symmetric || colored;
     if (!need_tn) target_normals_dev = nullptr;
-    if (!symmetric) source_normals_dev = nullptr;
-    O3DMI_REQUIRE(!p2plane || target_normals_dev != nullptr,
+    const void* source_normals_dev =
+            symmetric && attrs ? attrs->source_normals : nullptr;
+    const void* source_colors_dev =
+            colored && attrs ? attrs->source_colors : nullptr;
+    const void* target_colors_dev =
+            colored && attrs ? attrs->target_colors : nullptr;
+    const void* target_gradients_dev =
+            colored && attrs ? attrs->target_color_gradients : nullptr;
+    double lambda_geometric = colored && attrs ? attrs->lambda_geometric : 0.968;
+    // TransformationEstimationForColoredICP ctor, TransformationEstimation.h:
+    // 293-299
+    if (!(lambda_geometric >= 0 && lambda_geometric <= 1.0))
+        lambda_geometric = 0.968;
+    O3DMI_REQUIRE(!(p2plane || colored) || target_normals_dev != nullptr,
                   "Target pointcloud missing normals attribute.");
     O3DMI_REQUIRE(!symmetric || (source_normals_dev && target_normals_dev),
                   "SymmetricICP requires both source and target to have "
                   "normals.");
+    O3DMI_REQUIRE(!colored || (source_colors_dev && target_colors_dev),
+                  "Source and/or Target pointcloud missing colors attribute.");
     // the fused search kernel accumulates the point-to-plane terms itself;
     // the other estimators take the point-to-point moments from it
     const int search_mode = p2plane ? 0 : 1;
@@ -174,23 +223,26 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
     } sync_on_exit{s};
     const int last = num_scales - 1;
     int st;
+    auto clone = [&](DeviceBuffer& dst, const void* src, int64_t n) -> int {
+        int e = dst.Alloc((size_t)n * 3 * esz);
+        if (e) return e;
+        O3DMI_HIP_CHECK(hipMemcpyAsync(dst.p, src, (size_t)n * 3 * esz,
+                                       hipMemcpyDeviceToDevice, s));
+        return O3DMI_OK;
+    };
     {
         Level& L = pyr[(size_t)last];
         if (voxel_sizes[last] <= 0) {
             L.ns = ns;
             L.nt = nt;
-            if ((st = L.src.Alloc((size_t)ns * 3 * esz))) return st;
-            O3DMI_HIP_CHECK(hipMemcpyAsync(L.src.p, source_dev,
-                                           (size_t)ns * 3 * esz,
-                                           hipMemcpyDeviceToDevice, s));
-            if (symmetric) {
-                if ((st = L.srcn.Alloc((size_t)ns * 3 * esz))) return st;
-                O3DMI_HIP_CHECK(hipMemcpyAsync(L.srcn.p, source_normals_dev,
-                                               (size_t)ns * 3 * esz,
-                                               hipMemcpyDeviceToDevice, s));
-            }
+            // the source is moved in place every iteration: private copies
+            if ((st = clone(L.src, source_dev, ns))) return st;
+            if (symmetric && (st = clone(L.srcn, source_normals_dev, ns)))
+                return st;
             L.tgt_ptr = target_dev;
             L.nrm_ptr = target_normals_dev;
+            L.tgtc_ptr = target_colors_dev;
+            L.tgtg_ptr = target_gradients_dev;
         } else {
             if ((st = L.src.Alloc((size_t)ns * 3 * esz))) return st;
             if ((st = L.tgt.Alloc((size_t)nt * 3 * esz))) return st;
@@ -198,16 +250,45 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                 return st;
             if (symmetric && (st = L.srcn.Alloc((size_t)ns * 3 * esz)))
                 return st;
-            st = o3dmi_voxel_down_sample(source_dev, source_normals_dev, ns,
-                                         dtype, voxel_sizes[last], L.src.p,
-                                         L.srcn.p, &L.ns, stream);
+            if (colored) {
+                if ((st = L.srcc.Alloc((size_t)ns * 3 * esz))) return st;
+                if ((st = L.tgtc.Alloc((size_t)nt * 3 * esz))) return st;
+                if (target_gradients_dev &&
+                    (st = L.tgtg.Alloc((size_t)nt * 3 * esz)))
+                    return st;
+            }
+            st = DownSampleAttrs(source_dev, ns, dtype, voxel_sizes[last],
+                                 L.src.p, &L.ns, stream,
+                                 {{source_normals_dev, L.srcn.p},
+                                  {source_colors_dev, L.srcc.p}});
             if (st) return st;
-            st = o3dmi_voxel_down_sample(target_dev, target_normals_dev, nt,
-                                         dtype, voxel_sizes[last], L.tgt.p,
-                                         L.nrm.p, &L.nt, stream);
+            st = DownSampleAttrs(target_dev, nt, dtype, voxel_sizes[last],
+                                 L.tgt.p, &L.nt, stream,
+                                 {{target_normals_dev, L.nrm.p},
+                                  {target_colors_dev, L.tgtc.p},
+                                  {target_gradients_dev, L.tgtg.p}});
             if (st) return st;
             L.tgt_ptr = L.tgt.p;
             L.nrm_ptr = L.nrm.p;  // stays NULL without normals
+            L.tgtc_ptr = L.tgtc.p;
+            L.tgtg_ptr = L.tgtg.p;
+        }
+        // the finest level's source colours: the caller's, or the averaged
+        if (colored && voxel_sizes[last] <= 0 &&
+            (st = clone(L.srcc, source_colors_dev, ns)))
+            return st;
+        if (colored && !L.tgtg_ptr) {
+            // Registration.cpp:243-262: EstimateColorGradients(30, radius) on
+            // the finest level of the target pyramid.
+            const double radius = voxel_sizes[last] <= 0
+                                          ? max_dists[last] * 2.0
+                                          : voxel_sizes[last] * 4.0;
+            if ((st = L.tgtg.Alloc((size_t)L.nt * 3 * esz))) return st;
+            st = o3dmi_pointcloud_estimate_color_gradients(
+                    L.tgt_ptr, L.nrm_ptr, L.tgtc_ptr, L.nt, dtype, 30, radius,
+                    L.tgtg.p, stream);
+            if (st) return st;
+            L.tgtg_ptr = L.tgtg.p;
         }
     }
     for (int k = num_scales - 2; k >= 0; --k) {
@@ -217,16 +298,25 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         if ((st = L.tgt.Alloc((size_t)F.nt * 3 * esz))) return st;
         if (need_tn && (st = L.nrm.Alloc((size_t)F.nt * 3 * esz))) return st;
         if (symmetric && (st = L.srcn.Alloc((size_t)F.ns * 3 * esz))) return st;
-        st = o3dmi_voxel_down_sample(F.src.p, F.srcn.p, F.ns, dtype,
-                                     voxel_sizes[k], L.src.p, L.srcn.p, &L.ns,
-                                     stream);
+        if (colored) {
+            if ((st = L.srcc.Alloc((size_t)F.ns * 3 * esz))) return st;
+            if ((st = L.tgtc.Alloc((size_t)F.nt * 3 * esz))) return st;
+            if ((st = L.tgtg.Alloc((size_t)F.nt * 3 * esz))) return st;
+        }
+        st = DownSampleAttrs(F.src.p, F.ns, dtype, voxel_sizes[k], L.src.p,
+                             &L.ns, stream,
+                             {{F.srcn.p, L.srcn.p}, {F.srcc.p, L.srcc.p}});
         if (st) return st;
-        st = o3dmi_voxel_down_sample(F.tgt_ptr, F.nrm_ptr, F.nt, dtype,
-                                     voxel_sizes[k], L.tgt.p, L.nrm.p, &L.nt,
-                                     stream);
+        st = DownSampleAttrs(F.tgt_ptr, F.nt, dtype, voxel_sizes[k], L.tgt.p,
+                             &L.nt, stream,
+                             {{F.nrm_ptr, L.nrm.p},
+                              {F.tgtc_ptr, L.tgtc.p},
+                              {F.tgtg_ptr, L.tgtg.p}});
         if (st) return st;
         L.tgt_ptr = L.tgt.p;
         L.nrm_ptr = L.nrm.p;
+        L.tgtc_ptr = L.tgtc.p;
+        L.tgtg_ptr = L.tgtg.p;
     }
 
     // Per-iteration sums arrive through the thread's host mailbox: the final
@@ -287,7 +377,7 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
             (st = o3dmi_transform_normals(T, L.srcn.p, L.ns, dtype, stream)))
             return st;
         DeviceBuffer corr_buf, sym_partials;
-        if (symmetric) {
+        if (symmetric || colored) {
             if ((st = corr_buf.Alloc(sizeof(int64_t) * (size_t)L.ns))) return st;
             if ((st = sym_partials.Alloc(sizeof(double) * 32 * 1024)))
                 return st;
@@ -310,7 +400,9 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         for (it = 0; it < crit.max_iteration; ++it) {
             SearchResult r;
             if ((st = search(guard.nns, L,
-                             symmetric ? (int64_t*)corr_buf.p : nullptr, r)))
+                             symmetric || colored ? (int64_t*)corr_buf.p
+                                                  : nullptr,
+                             r)))
                 return st;
             fitness = r.fitness;
             inlier_rmse = r.inlier_rmse;
@@ -368,6 +460,33 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                                               &inlier_count);
                 if (e) status = e;
                 o3dmi_symmetric_pose_to_transformation(pose, ms, mt, update);
+            } else if (colored) {
+                // ComputePoseColoredICP + PoseToTransformation
+                // (TransformationEstimation.cpp:420-432)
+                const int seq = ++mb->seq;
+                int e = o3dmi_icp_colored_accumulate_post(
+                        L.src.p, L.srcc.p, L.tgt_ptr, L.nrm_ptr, L.tgtc_ptr,
+                        L.tgtg_ptr, (const int64_t*)corr_buf.p, L.ns, dtype,
+                        lambda_geometric, robust_kernel, scaling_parameter,
+                        shape_parameter, nullptr, (double*)sym_partials.p,
+                        mb->data, mb->flag, seq, stream);
+                if (e) return e;
+                O3DMI_HIP_CHECK(MailboxWait(mb, seq, s));
+                double sums29[32];
+                std::memcpy(sums29, sums_host, sizeof(double) * 29);
+                if (allreduce) {
+                    sums29[29] = sums29[30] = sums29[31] = 0;
+                    if (allreduce(sums29, 32, allreduce_user) != 0) {
+                        SetLastError("all-reduce hook failed");
+                        return O3DMI_ERR_INVALID_ARG;
+                    }
+                }
+                float residual;
+                int inlier_count;
+                e = o3dmi_decode_and_solve6x6(sums29, pose, &residual,
+                                              &inlier_count);
+                if (e) status = e;
+                o3dmi_pose_to_transformation(pose, update);
             } else {
                 // ComputeRtPointToPoint + RtToTransformation
                 // (TransformationEstimation.cpp:150-159)

@@ -955,6 +955,58 @@ __device__ __forceinline__ void AccumulateSymmetric(
     A[28] += 1.0;
 }
 
+// GetJacobianColoredICP + the 29 sums of ComputePoseColoredICPKernelCPU
+// (RegistrationImpl.h:388-466, RegistrationCPU.cpp:220-290): geometric and
+// photometric rows, each with its own robust weight; A[27] = sum r_G^2 + r_I^2.
+template <typename T>
+__device__ __forceinline__ void AccumulateColored(
+        double (&A)[kNumSums], const T* vs, const T* cs, const T* vt,
+        const T* nt, const T* ct, const T* dit, T sqrt_lambda_geometric,
+        T sqrt_lambda_photometric, const RobustParams& rp) {
+    const T d = (vs[0] - vt[0]) * nt[0] + (vs[1] - vt[1]) * nt[1] +
+                (vs[2] - vt[2]) * nt[2];
+    T J_G[6], J_I[6];
+    J_G[0] = sqrt_lambda_geometric * (-vs[2] * nt[1] + vs[1] * nt[2]);
+    J_G[1] = sqrt_lambda_geometric * (vs[2] * nt[0] - vs[0] * nt[2]);
+    J_G[2] = sqrt_lambda_geometric * (-vs[1] * nt[0] + vs[0] * nt[1]);
+    J_G[3] = sqrt_lambda_geometric * nt[0];
+    J_G[4] = sqrt_lambda_geometric * nt[1];
+    J_G[5] = sqrt_lambda_geometric * nt[2];
+    const T r_G = sqrt_lambda_geometric * d;
+    const T vs_proj[3] = {vs[0] - d * nt[0], vs[1] - d * nt[1],
+                          vs[2] - d * nt[2]};
+    // "/ 3.0": float64 division, then narrowed
+    const T intensity_source = (cs[0] + cs[1] + cs[2]) / 3.0;
+    const T intensity_target = (ct[0] + ct[1] + ct[2]) / 3.0;
+    const T is_proj = dit[0] * (vs_proj[0] - vt[0]) +
+                      dit[1] * (vs_proj[1] - vt[1]) +
+                      dit[2] * (vs_proj[2] - vt[2]) + intensity_target;
+    const T s = dit[0] * nt[0] + dit[1] * nt[1] + dit[2] * nt[2];
+    const T ditM[3] = {s * nt[0] - dit[0], s * nt[1] - dit[1],
+                       s * nt[2] - dit[2]};
+    J_I[0] = sqrt_lambda_photometric * (-vs[2] * ditM[1] + vs[1] * ditM[2]);
+    J_I[1] = sqrt_lambda_photometric * (vs[2] * ditM[0] - vs[0] * ditM[2]);
+    J_I[2] = sqrt_lambda_photometric * (-vs[1] * ditM[0] + vs[0] * ditM[1]);
+    J_I[3] = sqrt_lambda_photometric * ditM[0];
+    J_I[4] = sqrt_lambda_photometric * ditM[1];
+    J_I[5] = sqrt_lambda_photometric * ditM[2];
+    const T r_I = sqrt_lambda_photometric * (intensity_source - is_proj);
+    const T w_G = RobustWeight<T>(rp, r_G);
+    const T w_I = RobustWeight<T>(rp, r_I);
+    int i = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+#pragma unroll
+        for (int k = 0; k <= j; ++k) {
+            A[i] += (double)(J_G[j] * w_G * J_G[k] + J_I[j] * w_I * J_I[k]);
+            ++i;
+        }
+        A[21 + j] += (double)(J_G[j] * w_G * r_G + J_I[j] * w_I * r_I);
+    }
+    A[27] += (double)(r_G * r_G + r_I * r_I);
+    A[28] += 1.0;
+}
+
 constexpr int kReduceBlock = 256;
 
 // Reduce-scatter wave reduction (reduce_sums.h), LDS across the 4 waves, one
@@ -1029,6 +1081,33 @@ SymmetricAccumulateKernel(const T* __restrict__ src, const T* __restrict__ src_n
                                src_n[3 * i + 0], src_n[3 * i + 1],
                                src_n[3 * i + 2], tgt_n[3 * c + 0],
                                tgt_n[3 * c + 1], tgt_n[3 * c + 2], mean, rp);
+    }
+    BlockReduceAndStore(A, partials);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kReduceBlock)
+ColoredAccumulateKernel(const T* __restrict__ src, const T* __restrict__ src_c,
+                        const T* __restrict__ tgt, const T* __restrict__ tgt_n,
+                        const T* __restrict__ tgt_c, const T* __restrict__ tgt_g,
+                        const int64_t* __restrict__ corr, int64_t n,
+                        T sqrt_lambda_geometric, T sqrt_lambda_photometric,
+                        RobustParams rp, double* __restrict__ partials) {
+    double A[kNumSums];
+#pragma unroll
+    for (int k = 0; k < kNumSums; ++k) A[k] = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t c = corr[i];
+        if (c == -1) continue;
+        const T vs[3] = {src[3 * i], src[3 * i + 1], src[3 * i + 2]};
+        const T cs[3] = {src_c[3 * i], src_c[3 * i + 1], src_c[3 * i + 2]};
+        const T vt[3] = {tgt[3 * c], tgt[3 * c + 1], tgt[3 * c + 2]};
+        const T nt[3] = {tgt_n[3 * c], tgt_n[3 * c + 1], tgt_n[3 * c + 2]};
+        const T ct[3] = {tgt_c[3 * c], tgt_c[3 * c + 1], tgt_c[3 * c + 2]};
+        const T dit[3] = {tgt_g[3 * c], tgt_g[3 * c + 1], tgt_g[3 * c + 2]};
+        AccumulateColored<T>(A, vs, cs, vt, nt, ct, dit, sqrt_lambda_geometric,
+                             sqrt_lambda_photometric, rp);
     }
     BlockReduceAndStore(A, partials);
 }
@@ -1687,6 +1766,76 @@ int o3dmi_icp_p2point_accumulate(const void* src_dev, const void* tgt_dev,
     O3DMI_HIP_CHECK(hipGetLastError());
     O3DMI_HIP_CHECK(hipFreeAsync(partials, s));
     return O3DMI_OK;
+}
+
+// Internal: also posts the 29 sums to a host mailbox when mail_data != NULL.
+int o3dmi_icp_colored_accumulate_post(
+        const void* src_dev, const void* src_colors_dev, const void* tgt_dev,
+        const void* tgt_normals_dev, const void* tgt_colors_dev,
+        const void* tgt_color_gradients_dev, const int64_t* corr_dev, int64_t n,
+        int dtype, double lambda_geometric, int robust_kernel,
+        double scaling_parameter, double shape_parameter, double* sums29_dev,
+        double* partials_dev, double* mail_data, int* mail_flag, int mail_seq,
+        o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(src_dev && src_colors_dev && tgt_dev && tgt_normals_dev &&
+                          tgt_colors_dev && tgt_color_gradients_dev &&
+                          corr_dev && (sums29_dev || mail_data),
+                  "null argument");
+    O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
+                  "points must be Float32 or Float64");
+    O3DMI_REQUIRE(robust_kernel >= 0 && robust_kernel <= 6,
+                  "Unsupported method.");
+    O3DMI_REQUIRE(lambda_geometric >= 0 && lambda_geometric <= 1.0,
+                  "lambda_geometric must be in [0, 1]");
+    hipStream_t s = (hipStream_t)stream;
+    int g = ReduceGrid(n);
+    double* partials = partials_dev;
+    if (!partials)
+        O3DMI_HIP_CHECK(hipMallocAsync((void**)&partials,
+                                       sizeof(double) * (size_t)g * kNumSums,
+                                       s));
+    RobustParams rp = MakeRobust(robust_kernel, scaling_parameter,
+                                 shape_parameter);
+    // ComputePoseColoredICPCPU, RegistrationCPU.cpp:310-313
+    const double slg = std::sqrt(lambda_geometric);
+    const double slp = std::sqrt(1.0 - lambda_geometric);
+    if (dtype == O3DMI_F64)
+        hipLaunchKernelGGL(ColoredAccumulateKernel<double>, dim3(g),
+                           dim3(kReduceBlock), 0, s, (const double*)src_dev,
+                           (const double*)src_colors_dev,
+                           (const double*)tgt_dev,
+                           (const double*)tgt_normals_dev,
+                           (const double*)tgt_colors_dev,
+                           (const double*)tgt_color_gradients_dev, corr_dev, n,
+                           slg, slp, rp, partials);
+    else
+        hipLaunchKernelGGL(ColoredAccumulateKernel<float>, dim3(g),
+                           dim3(kReduceBlock), 0, s, (const float*)src_dev,
+                           (const float*)src_colors_dev, (const float*)tgt_dev,
+                           (const float*)tgt_normals_dev,
+                           (const float*)tgt_colors_dev,
+                           (const float*)tgt_color_gradients_dev, corr_dev, n,
+                           (float)slg, (float)slp, rp, partials);
+    hipLaunchKernelGGL(FinalReduceKernel, dim3(1), dim3(256), 0, s, partials, g,
+                       sums29_dev, 29, mail_data, mail_flag, mail_seq);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    if (!partials_dev) O3DMI_HIP_CHECK(hipFreeAsync(partials, s));
+    return O3DMI_OK;
+}
+
+int o3dmi_icp_colored_accumulate(
+        const void* src_dev, const void* src_colors_dev, const void* tgt_dev,
+        const void* tgt_normals_dev, const void* tgt_colors_dev,
+        const void* tgt_color_gradients_dev, const int64_t* corr_dev, int64_t n,
+        int dtype, double lambda_geometric, int robust_kernel,
+        double scaling_parameter, double shape_parameter, double* sums29_dev,
+        o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(sums29_dev != nullptr, "null argument");
+    return o3dmi_icp_colored_accumulate_post(
+            src_dev, src_colors_dev, tgt_dev, tgt_normals_dev, tgt_colors_dev,
+            tgt_color_gradients_dev, corr_dev, n, dtype, lambda_geometric,
+            robust_kernel, scaling_parameter, shape_parameter, sums29_dev,
+            nullptr, nullptr, nullptr, 0, stream);
 }
 
 // Internal: also posts the 29 sums to a host mailbox when mail_data != NULL.

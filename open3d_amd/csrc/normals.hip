@@ -303,6 +303,139 @@ __global__ void NormalsFromCovariancesKernel(const T* __restrict__ covariances,
     }
 }
 
+// x = pinv(AtA) Atb for a symmetric 3x3 AtA: cyclic Jacobi eigen-decomposition
+// (8 sweeps, converged for 3x3), eigenvalues below 1e-10 dropped. The
+// reference calls solve_svd3x3 (core/linalg/kernel/SVD3x3.h: McAdams'
+// approximate SVD with 4 fixed sweeps); this is the exact solution of the
+// same normal equations, see DESIGN.md.
+template <typename T>
+__device__ __forceinline__ void PinvSolveSym3(const T* AtA, const T* Atb,
+                                              T* x) {
+    T a[3][3], V[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            a[i][j] = AtA[i * 3 + j];
+            V[i][j] = i == j ? T(1) : T(0);
+        }
+    for (int sweep = 0; sweep < 8; ++sweep) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                const T apq = a[p][q];
+                if (apq == T(0)) continue;
+                const T theta = (a[q][q] - a[p][p]) / (T(2) * apq);
+                const T t = (theta >= T(0) ? T(1) : T(-1)) /
+                            (Abs(theta) + Sqrt(theta * theta + T(1)));
+                const T c = T(1) / Sqrt(t * t + T(1));
+                const T sn = t * c;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const T akp = a[k][p], akq = a[k][q];
+                    a[k][p] = c * akp - sn * akq;
+                    a[k][q] = sn * akp + c * akq;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const T apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = c * apk - sn * aqk;
+                    a[q][k] = sn * apk + c * aqk;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const T vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    const T epsilon = (T)1e-10;
+    x[0] = x[1] = x[2] = T(0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const T lam = a[i][i];
+        const T inv = Abs(lam) < epsilon ? T(0) : T(1) / lam;
+        const T proj = V[0][i] * Atb[0] + V[1][i] * Atb[1] + V[2][i] * Atb[2];
+        const T w = inv * proj;
+        x[0] += V[0][i] * w;
+        x[1] += V[1][i] * w;
+        x[2] += V[2][i] * w;
+    }
+}
+
+// EstimatePointWiseColorGradientKernel, PointCloudImpl.h:1067-1165: intensity
+// least squares over the neighbours projected on the tangent plane + the
+// constraint gradient . normal = 0 (the first neighbour is the point itself).
+template <typename T>
+__global__ void ColorGradientsKernel(const T* __restrict__ points,
+                                     const T* __restrict__ normals,
+                                     const T* __restrict__ colors,
+                                     const int32_t* __restrict__ indices,
+                                     const int32_t* __restrict__ counts,
+                                     int64_t n, int max_nn,
+                                     T* __restrict__ gradients) {
+    for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < n;
+         w += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t* idx = indices + (int64_t)max_nn * w;
+        const int32_t cnt = counts[w];
+        T* out = gradients + 3 * w;
+        if (cnt < 4) {
+            out[0] = 0;
+            out[1] = 0;
+            out[2] = 0;
+            continue;
+        }
+        const T vt[3] = {points[3 * w], points[3 * w + 1], points[3 * w + 2]};
+        const T nt[3] = {normals[3 * w], normals[3 * w + 1],
+                         normals[3 * w + 2]};
+        const T it = (colors[3 * w] + colors[3 * w + 1] + colors[3 * w + 2]) /
+                     3.0;
+        T AtA[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        T Atb[3] = {0, 0, 0};
+        const T s = vt[0] * nt[0] + vt[1] * nt[1] + vt[2] * nt[2];
+        int i = 1;
+        for (; i < cnt; i++) {
+            const int64_t o = 3 * (int64_t)idx[i];
+            const T vt_adj[3] = {points[o], points[o + 1], points[o + 2]};
+            const T d = vt_adj[0] * nt[0] + vt_adj[1] * nt[1] +
+                        vt_adj[2] * nt[2] - s;
+            const T vt_proj[3] = {vt_adj[0] - d * nt[0], vt_adj[1] - d * nt[1],
+                                  vt_adj[2] - d * nt[2]};
+            const T it_adj = (colors[o + 0] + colors[o + 1] + colors[o + 2]) /
+                             3.0;
+            const T A[3] = {vt_proj[0] - vt[0], vt_proj[1] - vt[1],
+                            vt_proj[2] - vt[2]};
+            AtA[0] += A[0] * A[0];
+            AtA[1] += A[1] * A[0];
+            AtA[2] += A[2] * A[0];
+            AtA[4] += A[1] * A[1];
+            AtA[5] += A[2] * A[1];
+            AtA[8] += A[2] * A[2];
+            const T b = it_adj - it;
+            Atb[0] += A[0] * b;
+            Atb[1] += A[1] * b;
+            Atb[2] += A[2] * b;
+        }
+        const T A[3] = {(i - 1) * nt[0], (i - 1) * nt[1], (i - 1) * nt[2]};
+        AtA[0] += A[0] * A[0];
+        AtA[1] += A[0] * A[1];
+        AtA[2] += A[0] * A[2];
+        AtA[4] += A[1] * A[1];
+        AtA[5] += A[1] * A[2];
+        AtA[8] += A[2] * A[2];
+        AtA[3] = AtA[1];
+        AtA[6] = AtA[2];
+        AtA[7] = AtA[5];
+        T x[3];
+        PinvSolveSym3<T>(AtA, Atb, x);
+        out[0] = x[0];
+        out[1] = x[1];
+        out[2] = x[2];
+    }
+}
+
 }  // namespace
 }  // namespace o3dmi
 
@@ -437,6 +570,81 @@ int o3dmi_pointcloud_estimate_normals(const void* points_dev, int64_t n,
         PoolFree(scratch);
     }
     o3dmi_nns_destroy(nns);
+    return st;
+}
+
+// EstimateColorGradientsUsing{Hybrid,KNN}SearchCUDA after the search
+// (PointCloudImpl.h:1170-1290): gradients {n,3} from given neighbour lists.
+int o3dmi_pointcloud_color_gradients_from_neighbors(
+        const void* points_dev, const void* normals_dev, const void* colors_dev,
+        const int32_t* indices_dev, const int32_t* counts_dev, int64_t n,
+        int max_nn, int dtype, void* gradients_dev, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
+                  "points must be Float32 or Float64");
+    O3DMI_REQUIRE(n >= 0 && max_nn >= 1, "bad sizes");
+    if (n == 0) return O3DMI_OK;
+    O3DMI_REQUIRE(points_dev && normals_dev && colors_dev && indices_dev &&
+                          counts_dev && gradients_dev,
+                  "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(GridFor(n, kBlock)), block(kBlock);
+    if (dtype == O3DMI_F64)
+        hipLaunchKernelGGL(ColorGradientsKernel<double>, grid, block, 0, s,
+                           (const double*)points_dev,
+                           (const double*)normals_dev,
+                           (const double*)colors_dev, indices_dev, counts_dev,
+                           n, max_nn, (double*)gradients_dev);
+    else
+        hipLaunchKernelGGL(ColorGradientsKernel<float>, grid, block, 0, s,
+                           (const float*)points_dev, (const float*)normals_dev,
+                           (const float*)colors_dev, indices_dev, counts_dev, n,
+                           max_nn, (float*)gradients_dev);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+// PointCloud::EstimateColorGradients(max_knn, radius), PointCloud.cpp:987-1060
+// (hybrid search when radius > 0, KNN search otherwise). Synchronises.
+int o3dmi_pointcloud_estimate_color_gradients(
+        const void* points_dev, const void* normals_dev, const void* colors_dev,
+        int64_t n, int dtype, int max_nn, double radius, void* gradients_dev,
+        o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
+                  "Only Float32 and Float64 point clouds are supported.");
+    O3DMI_REQUIRE(max_nn > 0,
+                  "EstimateColorGradients: the radius-only variant is not "
+                  "implemented by this backend.");
+    O3DMI_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return O3DMI_OK;
+    O3DMI_REQUIRE(points_dev && normals_dev && colors_dev && gradients_dev,
+                  "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int k = (int)(n < (int64_t)max_nn ? n : (int64_t)max_nn);
+    char* scratch = nullptr;
+    const size_t idx_bytes =
+            (sizeof(int32_t) * (size_t)n * k + 255) & ~(size_t)255;
+    const size_t cnt_bytes = (sizeof(int32_t) * (size_t)n + 255) & ~(size_t)255;
+    int st = PoolAlloc((void**)&scratch, idx_bytes + cnt_bytes);
+    if (st) return st;
+    int32_t* idx = (int32_t*)scratch;
+    int32_t* cnt = (int32_t*)(scratch + idx_bytes);
+    o3dmi_nns_t* nns = nullptr;
+    if (radius > 0) {
+        st = o3dmi_nns_create(points_dev, n, dtype, radius, stream, &nns);
+        if (!st)
+            st = o3dmi_nns_hybrid_search(nns, points_dev, n, k, idx, nullptr,
+                                         cnt, stream);
+    } else {
+        st = o3dmi_nns_knn_search_counts(points_dev, n, points_dev, n, dtype, k,
+                                         idx, nullptr, cnt, stream);
+    }
+    if (!st)
+        st = o3dmi_pointcloud_color_gradients_from_neighbors(
+                points_dev, normals_dev, colors_dev, idx, cnt, n, k, dtype,
+                gradients_dev, stream);
+    (void)hipStreamSynchronize(s);
+    PoolFree(scratch);
+    if (nns) o3dmi_nns_destroy(nns);
     return st;
 }
 

@@ -50,6 +50,15 @@ class TransformationEstimationSymmetric:
         self.kernel = kernel or RobustKernel()
 
 
+class TransformationEstimationForColoredICP:
+    """TransformationEstimation.h:283-349 (Park et al. 2017): needs target
+    normals and colours on both clouds; `color_gradients` of the target are
+    estimated when not given."""
+    def __init__(self, lambda_geometric=0.968, kernel=None):
+        self.lambda_geometric = lambda_geometric
+        self.kernel = kernel or RobustKernel()
+
+
 class RegistrationResult:
     def __init__(self):
         self.transformation = np.eye(4)
@@ -63,10 +72,12 @@ class RegistrationResult:
 def multi_scale_icp(source, target, target_normals, voxel_sizes, criteria_list,
                     max_correspondence_distances, init_source_to_target=None,
                     estimation_method=None, callback_after_iteration=None,
-                    allreduce=None, source_normals=None):
+                    allreduce=None, source_normals=None, source_colors=None,
+                    target_colors=None, target_color_gradients=None):
     """source/target/target_normals: device tensors {N,3}. `allreduce`
     (optional) sums a length-32 numpy float64 array over ranks in place.
-    `source_normals` is read by the symmetric estimator only."""
+    `source_normals` is read by the symmetric estimator, the colours (and the
+    optional target colour gradients) by the coloured one."""
     est = estimation_method or TransformationEstimationPointToPlane()
     p2point = isinstance(est, TransformationEstimationPointToPoint)
     symmetric = isinstance(est, TransformationEstimationSymmetric)
@@ -77,6 +88,23 @@ def multi_scale_icp(source, target, target_normals, voxel_sizes, criteria_list,
         source_normals = require_cuda(source_normals, "source_normals")
     else:
         source_normals = None
+    colored = isinstance(est, TransformationEstimationForColoredICP)
+    attrs = _lib.IcpAttributes()
+    attrs.lambda_geometric = getattr(est, "lambda_geometric", 0.968)
+    if colored:
+        if source_colors is None or target_colors is None:
+            raise ValueError("Source and/or Target pointcloud missing colors "
+                             "attribute.")
+        source_colors = require_cuda(source_colors, "source_colors")
+        target_colors = require_cuda(target_colors, "target_colors")
+        attrs.source_colors = source_colors.data_ptr()
+        attrs.target_colors = target_colors.data_ptr()
+        if target_color_gradients is not None:
+            target_color_gradients = require_cuda(target_color_gradients,
+                                                  "target_color_gradients")
+            attrs.target_color_gradients = target_color_gradients.data_ptr()
+    if symmetric:
+        attrs.source_normals = source_normals.data_ptr()
     source = require_cuda(source, "source")
     target = require_cuda(target, "target")
     if source.dtype not in (torch.float32, torch.float64):
@@ -128,11 +156,12 @@ def multi_scale_icp(source, target, target_normals, voxel_sizes, criteria_list,
         ar = _lib.ALLREDUCE_SUM(_ar)
 
     st = _lib.lib().o3dmi_registration_multiscale_icp_ex(
-        _lib.ptr(source), _lib.ptr(source_normals), ns, _lib.ptr(target),
+        _lib.ptr(source), ns, _lib.ptr(target),
         _lib.ptr(target_normals) if target_normals is not None else None, nt,
         TORCH_TO_O3DMI[source.dtype], S, _lib.f64p(vs), crit, _lib.f64p(md),
-        _lib.f64p(init), 1 if p2point else (2 if symmetric else 0),
-        int(est.kernel.type),
+        _lib.f64p(init),
+        1 if p2point else (2 if symmetric else (3 if colored else 0)),
+        C.byref(attrs), int(est.kernel.type),
         C.c_double(est.kernel.scaling_parameter),
         C.c_double(est.kernel.shape_parameter), cb, None, ar, None,
         _lib.ptr(corr), C.byref(res), stream())
@@ -150,13 +179,16 @@ def multi_scale_icp(source, target, target_normals, voxel_sizes, criteria_list,
 def icp(source, target, target_normals, max_correspondence_distance,
         init_source_to_target=None, estimation_method=None, criteria=None,
         voxel_size=-1.0, callback_after_iteration=None, allreduce=None,
-        source_normals=None):
+        source_normals=None, source_colors=None, target_colors=None,
+        target_color_gradients=None):
     """t::pipelines::registration::ICP (Registration.cpp:93-106)."""
     return multi_scale_icp(source, target, target_normals, [voxel_size],
                            [criteria or ICPConvergenceCriteria()],
                            [max_correspondence_distance],
                            init_source_to_target, estimation_method,
-                           callback_after_iteration, allreduce, source_normals)
+                           callback_after_iteration, allreduce, source_normals,
+                           source_colors, target_colors,
+                           target_color_gradients)
 
 
 def _check_pair(source, target):
@@ -272,3 +304,22 @@ def knn_search(points, queries, knn):
         TORCH_TO_O3DMI[points.dtype], int(knn), _lib.ptr(idx), _lib.ptr(d2),
         stream()), "knn_search")
     return idx, d2
+
+
+def estimate_color_gradients(positions, normals, colors, max_nn=30,
+                             radius=None):
+    """t::geometry::PointCloud::EstimateColorGradients(max_nn, radius)
+    (PointCloud.cpp:987-1060) -> gradients {N,3}."""
+    positions = require_cuda(positions, "positions")
+    normals = require_cuda(normals, "normals")
+    colors = require_cuda(colors, "colors")
+    if max_nn is None:
+        raise ValueError("the radius-only variant is not implemented by this "
+                         "backend: give max_nn")
+    out = torch.empty_like(positions)
+    _lib.check(_lib.lib().o3dmi_pointcloud_estimate_color_gradients(
+        _lib.ptr(positions), _lib.ptr(normals), _lib.ptr(colors),
+        positions.shape[0], TORCH_TO_O3DMI[positions.dtype], int(max_nn),
+        C.c_double(-1.0 if radius is None else radius), _lib.ptr(out),
+        stream()), "estimate_color_gradients")
+    return out

@@ -795,6 +795,120 @@ int ComputeTransformationSymmetric(const T* src, const T* tgt, const T* sn,
 }
 
 // ---------------------------------------------------------------------------
+// TransformationEstimationForColoredICP (Park et al. 2017).
+// GetJacobianColoredICP, RegistrationImpl.h:388-466: geometric term
+// sqrt(lambda) (vs - vt) . nt, photometric term sqrt(1 - lambda) (Is - Is_proj)
+// with the source point projected onto the target's tangent plane and the
+// target intensity extrapolated by its colour gradient. The "/ 3.0" promotes
+// the intensity means to float64 before they are narrowed to scalar_t.
+template <typename scalar_t>
+bool GetJacobianColoredICP(int64_t workload_idx,
+                           const scalar_t* source_points_ptr,
+                           const scalar_t* source_colors_ptr,
+                           const scalar_t* target_points_ptr,
+                           const scalar_t* target_normals_ptr,
+                           const scalar_t* target_colors_ptr,
+                           const scalar_t* target_color_gradients_ptr,
+                           const int64_t* correspondence_indices,
+                           const scalar_t& sqrt_lambda_geometric,
+                           const scalar_t& sqrt_lambda_photometric,
+                           scalar_t* J_G, scalar_t* J_I, scalar_t& r_G,
+                           scalar_t& r_I) {
+    if (correspondence_indices[workload_idx] == -1) return false;
+    const int64_t target_idx = 3 * correspondence_indices[workload_idx];
+    const int64_t source_idx = 3 * workload_idx;
+    const scalar_t vs[3] = {source_points_ptr[source_idx],
+                            source_points_ptr[source_idx + 1],
+                            source_points_ptr[source_idx + 2]};
+    const scalar_t vt[3] = {target_points_ptr[target_idx],
+                            target_points_ptr[target_idx + 1],
+                            target_points_ptr[target_idx + 2]};
+    const scalar_t nt[3] = {target_normals_ptr[target_idx],
+                            target_normals_ptr[target_idx + 1],
+                            target_normals_ptr[target_idx + 2]};
+    const scalar_t d = (vs[0] - vt[0]) * nt[0] + (vs[1] - vt[1]) * nt[1] +
+                       (vs[2] - vt[2]) * nt[2];
+    J_G[0] = sqrt_lambda_geometric * (-vs[2] * nt[1] + vs[1] * nt[2]);
+    J_G[1] = sqrt_lambda_geometric * (vs[2] * nt[0] - vs[0] * nt[2]);
+    J_G[2] = sqrt_lambda_geometric * (-vs[1] * nt[0] + vs[0] * nt[1]);
+    J_G[3] = sqrt_lambda_geometric * nt[0];
+    J_G[4] = sqrt_lambda_geometric * nt[1];
+    J_G[5] = sqrt_lambda_geometric * nt[2];
+    r_G = sqrt_lambda_geometric * d;
+    const scalar_t vs_proj[3] = {vs[0] - d * nt[0], vs[1] - d * nt[1],
+                                 vs[2] - d * nt[2]};
+    const scalar_t intensity_source =
+            (source_colors_ptr[source_idx] + source_colors_ptr[source_idx + 1] +
+             source_colors_ptr[source_idx + 2]) /
+            3.0;
+    const scalar_t intensity_target =
+            (target_colors_ptr[target_idx] + target_colors_ptr[target_idx + 1] +
+             target_colors_ptr[target_idx + 2]) /
+            3.0;
+    const scalar_t dit[3] = {target_color_gradients_ptr[target_idx],
+                             target_color_gradients_ptr[target_idx + 1],
+                             target_color_gradients_ptr[target_idx + 2]};
+    const scalar_t is_proj = dit[0] * (vs_proj[0] - vt[0]) +
+                             dit[1] * (vs_proj[1] - vt[1]) +
+                             dit[2] * (vs_proj[2] - vt[2]) + intensity_target;
+    const scalar_t s = dit[0] * nt[0] + dit[1] * nt[1] + dit[2] * nt[2];
+    const scalar_t ditM[3] = {s * nt[0] - dit[0], s * nt[1] - dit[1],
+                              s * nt[2] - dit[2]};
+    J_I[0] = sqrt_lambda_photometric * (-vs[2] * ditM[1] + vs[1] * ditM[2]);
+    J_I[1] = sqrt_lambda_photometric * (vs[2] * ditM[0] - vs[0] * ditM[2]);
+    J_I[2] = sqrt_lambda_photometric * (-vs[1] * ditM[0] + vs[0] * ditM[1]);
+    J_I[3] = sqrt_lambda_photometric * ditM[0];
+    J_I[4] = sqrt_lambda_photometric * ditM[1];
+    J_I[5] = sqrt_lambda_photometric * ditM[2];
+    r_I = sqrt_lambda_photometric * (intensity_source - is_proj);
+    return true;
+}
+
+// ComputePoseColoredICPKernelCPU, RegistrationCPU.cpp:220-290 (one range).
+template <typename scalar_t, typename acc_t>
+void ComputePoseColoredICPKernel(
+        const scalar_t* source_points_ptr, const scalar_t* source_colors_ptr,
+        const scalar_t* target_points_ptr, const scalar_t* target_normals_ptr,
+        const scalar_t* target_colors_ptr,
+        const scalar_t* target_color_gradients_ptr,
+        const int64_t* correspondence_indices, double lambda_geometric,
+        int64_t n, acc_t* global_sum, int method, double scaling,
+        double shape) {
+    // ComputePoseColoredICPCPU :310-313
+    const scalar_t sqrt_lambda_geometric =
+            static_cast<scalar_t>(std::sqrt(lambda_geometric));
+    const scalar_t sqrt_lambda_photometric =
+            static_cast<scalar_t>(std::sqrt(1.0 - lambda_geometric));
+    acc_t A[29];
+    for (int i = 0; i < 29; ++i) A[i] = 0;
+    for (int64_t workload_idx = 0; workload_idx < n; ++workload_idx) {
+        scalar_t J_G[6] = {0}, J_I[6] = {0};
+        scalar_t r_G = 0, r_I = 0;
+        bool valid = GetJacobianColoredICP<scalar_t>(
+                workload_idx, source_points_ptr, source_colors_ptr,
+                target_points_ptr, target_normals_ptr, target_colors_ptr,
+                target_color_gradients_ptr, correspondence_indices,
+                sqrt_lambda_geometric, sqrt_lambda_photometric, J_G, J_I, r_G,
+                r_I);
+        scalar_t w_G = RobustWeight<scalar_t>(method, scaling, shape, r_G);
+        scalar_t w_I = RobustWeight<scalar_t>(method, scaling, shape, r_I);
+        if (valid) {
+            int i = 0;
+            for (int j = 0; j < 6; ++j) {
+                for (int k = 0; k <= j; ++k) {
+                    A[i] += J_G[j] * w_G * J_G[k] + J_I[j] * w_I * J_I[k];
+                    ++i;
+                }
+                A[21 + j] += J_G[j] * w_G * r_G + J_I[j] * w_I * r_I;
+            }
+            A[27] += r_G * r_G + r_I * r_I;
+            A[28] += 1;
+        }
+    }
+    for (int i = 0; i < 29; ++i) global_sum[i] = A[i];
+}
+
+// ---------------------------------------------------------------------------
 // GetInformationMatrix, Registration.cpp:446-486 ->
 // ComputeInformationMatrixCPU, RegistrationCPU.cpp:652-735, with
 // GetInformationJacobians, RegistrationImpl.h:686-715. T = point dtype (each
@@ -1078,8 +1192,24 @@ typedef void (*icp_callback_t)(int64_t iteration_index, int64_t scale_index,
 
 // MultiScaleICP, Registration.cpp:362-444 (+ DoSingleScaleICPIterations
 // :275-360, InitializePointCloudPyramid :221-273), point-to-plane estimator.
+// normals::EstimateColorGradients (defined further down, with the other
+// point-attribute kernels).
 template <typename T>
-int MultiScaleICP(const T* source_in, const T* source_normals_in, int64_t ns_in,
+void ColorGradientsForIcp(const T* points, const T* normals, const T* colors,
+                          const int32_t* indices, const int32_t* counts,
+                          int64_t n, int max_nn, T* gradients);
+
+// Attributes some estimators read beyond positions / target normals.
+struct IcpExtra {
+    const void* source_normals = nullptr;         // symmetric
+    const void* source_colors = nullptr;          // colored
+    const void* target_colors = nullptr;          // colored
+    const void* target_color_gradients = nullptr; // colored, optional
+    double lambda_geometric = 0.968;
+};
+
+template <typename T>
+int MultiScaleICP(const T* source_in, const IcpExtra& extra, int64_t ns_in,
                   const T* target_in, const T* target_normals_in,
                   int64_t nt_in, int num_scales,
                   const double* voxel_sizes, const int* max_iterations,
@@ -1093,8 +1223,14 @@ int MultiScaleICP(const T* source_in, const T* source_normals_in, int64_t ns_in,
                   icp_callback_t cb, void* user) {
     // Pyramid.
     std::vector<std::vector<T>> src_p(num_scales), tgt_p(num_scales),
-            tgt_n(num_scales), src_n(num_scales);
+            tgt_n(num_scales), src_n(num_scales), src_c(num_scales),
+            tgt_c(num_scales), tgt_g(num_scales);
     const bool with_sn = estimation == 2;  // symmetric: source normals too
+    const bool colored = estimation == 3;  // colours + target colour gradients
+    const T* source_normals_in = (const T*)extra.source_normals;
+    double lambda_geometric = extra.lambda_geometric;
+    if (!(lambda_geometric >= 0 && lambda_geometric <= 1.0))
+        lambda_geometric = 0.968;
     auto down = [&](const std::vector<T>& p, const std::vector<T>* nrm,
                     double v, std::vector<T>& op, std::vector<T>* on) {
         int64_t n = (int64_t)p.size() / 3;
@@ -1125,7 +1261,57 @@ int MultiScaleICP(const T* source_in, const T* source_normals_in, int64_t ns_in,
              with_sn ? &src_n[last] : nullptr);
         down(t0, &n0, voxel_sizes[last], tgt_p[last], &tgt_n[last]);
     }
+    if (colored) {
+        // every attribute is averaged by VoxelDownSample (the voxel order is
+        // the same whichever attribute rides along)
+        std::vector<T> sc0((const T*)extra.source_colors,
+                           (const T*)extra.source_colors + 3 * ns_in);
+        std::vector<T> tc0((const T*)extra.target_colors,
+                           (const T*)extra.target_colors + 3 * nt_in);
+        std::vector<T> scratch;
+        if (voxel_sizes[last] <= 0) {
+            src_c[last] = sc0;
+            tgt_c[last] = tc0;
+            if (extra.target_color_gradients)
+                tgt_g[last].assign(
+                        (const T*)extra.target_color_gradients,
+                        (const T*)extra.target_color_gradients + 3 * nt_in);
+        } else {
+            down(s0, &sc0, voxel_sizes[last], scratch, &src_c[last]);
+            down(t0, &tc0, voxel_sizes[last], scratch, &tgt_c[last]);
+            if (extra.target_color_gradients) {
+                std::vector<T> tg0(
+                        (const T*)extra.target_color_gradients,
+                        (const T*)extra.target_color_gradients + 3 * nt_in);
+                down(t0, &tg0, voxel_sizes[last], scratch, &tgt_g[last]);
+            }
+        }
+        if (tgt_g[last].empty()) {
+            // Registration.cpp:243-262
+            const double radius = voxel_sizes[last] <= 0
+                                          ? max_dists[last] * 2.0
+                                          : voxel_sizes[last] * 4.0;
+            const int64_t m = (int64_t)tgt_p[last].size() / 3;
+            std::vector<int32_t> idx((size_t)m * 30), cnt((size_t)m);
+            std::vector<T> dist((size_t)m * 30);
+            HybridSearch<T>(tgt_p[last].data(), m, tgt_p[last].data(), m,
+                            radius, 30, idx.data(), dist.data(), cnt.data());
+            tgt_g[last].resize((size_t)m * 3);
+            ColorGradientsForIcp<T>(
+                    tgt_p[last].data(), tgt_n[last].data(), tgt_c[last].data(),
+                    idx.data(), cnt.data(), m, 30, tgt_g[last].data());
+        }
+    }
     for (int k = num_scales - 2; k >= 0; k--) {
+        if (colored) {
+            std::vector<T> scratch;
+            down(src_p[k + 1], &src_c[k + 1], voxel_sizes[k], scratch,
+                 &src_c[k]);
+            down(tgt_p[k + 1], &tgt_c[k + 1], voxel_sizes[k], scratch,
+                 &tgt_c[k]);
+            down(tgt_p[k + 1], &tgt_g[k + 1], voxel_sizes[k], scratch,
+                 &tgt_g[k]);
+        }
         down(src_p[k + 1], with_sn ? &src_n[k + 1] : nullptr, voxel_sizes[k],
              src_p[k], with_sn ? &src_n[k] : nullptr);
         down(tgt_p[k + 1], &tgt_n[k + 1], voxel_sizes[k], tgt_p[k], &tgt_n[k]);
@@ -1168,6 +1354,57 @@ int MultiScaleICP(const T* source_in, const T* source_normals_in, int64_t ns_in,
                     r2.num_iterations = it;
                     early_return = true;
                     break;
+                }
+                if (estimation == 3) {
+                    // TransformationEstimationForColoredICP::
+                    // ComputeTransformation, TransformationEstimation.cpp:
+                    // 380-432.
+                    double A[29];
+                    if (accumulate_double) {
+                        ComputePoseColoredICPKernel<T, double>(
+                                source.data(), src_c[scale_idx].data(),
+                                target.data(), normals.data(),
+                                tgt_c[scale_idx].data(),
+                                tgt_g[scale_idx].data(),
+                                r2.correspondences.data(), lambda_geometric,
+                                ns, A, kernel_method, kernel_scale,
+                                kernel_shape);
+                    } else {
+                        T Af[29];
+                        ComputePoseColoredICPKernel<T, T>(
+                                source.data(), src_c[scale_idx].data(),
+                                target.data(), normals.data(),
+                                tgt_c[scale_idx].data(),
+                                tgt_g[scale_idx].data(),
+                                r2.correspondences.data(), lambda_geometric,
+                                ns, Af, kernel_method, kernel_scale,
+                                kernel_shape);
+                        for (int i = 0; i < 29; ++i) A[i] = (double)Af[i];
+                    }
+                    double pose[6], update[16];
+                    float residual;
+                    int inlier_count;
+                    if (DecodeAndSolve6x6(A, pose, &residual, &inlier_count) !=
+                        0)
+                        status = 2;
+                    PoseToTransformation(pose, update);
+                    Matmul4(update, r2.T, r2.T);
+                    TransformPoints<T>(update, source.data(), ns);
+                    if (cb) {
+                        cb(iteration_count + it, scale_idx, it, r2.inlier_rmse,
+                           r2.fitness, r2.T, user);
+                    }
+                    if (it != 0 &&
+                        std::abs(prev_fitness - r2.fitness) <
+                                relative_fitness[scale_idx] &&
+                        std::abs(prev_inlier_rmse - r2.inlier_rmse) <
+                                relative_rmse[scale_idx]) {
+                        r2.converged = true;
+                        break;
+                    }
+                    prev_fitness = r2.fitness;
+                    prev_inlier_rmse = r2.inlier_rmse;
+                    continue;
                 }
                 if (estimation == 2) {
                     // TransformationEstimationSymmetric::ComputeTransformation,
@@ -1579,7 +1816,153 @@ void NormalsFromCovariances(const T* covariances, int64_t n, T* normals_ptr,
     }
 }
 
+// ---------------------------------------------------------------------------
+// PointCloud::EstimateColorGradients (t/geometry/PointCloud.cpp:987-1060):
+// EstimatePointWiseColorGradientKernel, PointCloudImpl.h:1067-1165, per point
+// over its neighbour list (the first neighbour is the point itself): least
+// squares fit of the intensity over the neighbours projected on the tangent
+// plane, plus the constraint gradient . normal = 0 weighted by the neighbour
+// count.
+// PARITY NOTE: the reference solves the 3x3 normal equations with
+// core::linalg::kernel::solve_svd3x3 (core/linalg/kernel/SVD3x3.h, 2.2 k lines:
+// McAdams' approximate SVD -- 4 fixed Jacobi sweeps, pi/8 clamps applied
+// through 32-bit masks, pseudo-inverse with 1e-10 cut-off). That routine is
+// not restated; x = pinv(AtA) Atb is formed here from a converged Jacobi
+// eigen-decomposition of the symmetric AtA with the same 1e-10 cut-off. The
+// accumulation of AtA / Atb is the reference's, statement by statement; the
+// result agrees with the compiled reference body to the accuracy of its
+// approximate SVD (tests/test_oracle_vs_ref.py states the tolerance).
+template <typename T>
+void PinvSolveSym3(const T* AtA, const T* Atb, T* x) {
+    T a[3][3], V[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            a[i][j] = AtA[i * 3 + j];
+            V[i][j] = i == j ? T(1) : T(0);
+        }
+    for (int sweep = 0; sweep < 8; ++sweep) {
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                const T apq = a[p][q];
+                if (apq == T(0)) continue;
+                const T theta = (a[q][q] - a[p][p]) / (T(2) * apq);
+                const T t = (theta >= T(0) ? T(1) : T(-1)) /
+                            (std::abs(theta) + std::sqrt(theta * theta + T(1)));
+                const T c = T(1) / std::sqrt(t * t + T(1));
+                const T sn = t * c;
+                for (int k = 0; k < 3; ++k) {  // a <- a J
+                    const T akp = a[k][p], akq = a[k][q];
+                    a[k][p] = c * akp - sn * akq;
+                    a[k][q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {  // a <- J^T a
+                    const T apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = c * apk - sn * aqk;
+                    a[q][k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const T vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    const T epsilon = (T)1e-10;
+    x[0] = x[1] = x[2] = T(0);
+    for (int i = 0; i < 3; ++i) {
+        const T lam = a[i][i];
+        const T inv = std::abs(lam) < epsilon ? T(0) : T(1) / lam;
+        const T proj = V[0][i] * Atb[0] + V[1][i] * Atb[1] + V[2][i] * Atb[2];
+        const T w = inv * proj;
+        x[0] += V[0][i] * w;
+        x[1] += V[1][i] * w;
+        x[2] += V[2][i] * w;
+    }
+}
+
+template <typename scalar_t>
+void ColorGradient(const scalar_t* points_ptr, const scalar_t* normals_ptr,
+                   const scalar_t* colors_ptr, int64_t idx_offset,
+                   const int32_t* indices_ptr, int32_t indices_count,
+                   scalar_t* color_gradients_ptr) {
+    if (indices_count < 4) {
+        color_gradients_ptr[idx_offset] = 0;
+        color_gradients_ptr[idx_offset + 1] = 0;
+        color_gradients_ptr[idx_offset + 2] = 0;
+        return;
+    }
+    scalar_t vt[3] = {points_ptr[idx_offset], points_ptr[idx_offset + 1],
+                      points_ptr[idx_offset + 2]};
+    scalar_t nt[3] = {normals_ptr[idx_offset], normals_ptr[idx_offset + 1],
+                      normals_ptr[idx_offset + 2]};
+    scalar_t it = (colors_ptr[idx_offset] + colors_ptr[idx_offset + 1] +
+                   colors_ptr[idx_offset + 2]) /
+                  3.0;
+    scalar_t AtA[9] = {0};
+    scalar_t Atb[3] = {0};
+    scalar_t s = vt[0] * nt[0] + vt[1] * nt[1] + vt[2] * nt[2];
+    int i = 1;
+    for (; i < indices_count; i++) {
+        int64_t neighbour_idx_offset = 3 * (int64_t)indices_ptr[i];
+        if (neighbour_idx_offset == -1) break;  // (never true; kept as written)
+        scalar_t vt_adj[3] = {points_ptr[neighbour_idx_offset],
+                              points_ptr[neighbour_idx_offset + 1],
+                              points_ptr[neighbour_idx_offset + 2]};
+        scalar_t d = vt_adj[0] * nt[0] + vt_adj[1] * nt[1] +
+                     vt_adj[2] * nt[2] - s;
+        scalar_t vt_proj[3] = {vt_adj[0] - d * nt[0], vt_adj[1] - d * nt[1],
+                               vt_adj[2] - d * nt[2]};
+        scalar_t it_adj = (colors_ptr[neighbour_idx_offset + 0] +
+                           colors_ptr[neighbour_idx_offset + 1] +
+                           colors_ptr[neighbour_idx_offset + 2]) /
+                          3.0;
+        scalar_t A[3] = {vt_proj[0] - vt[0], vt_proj[1] - vt[1],
+                         vt_proj[2] - vt[2]};
+        AtA[0] += A[0] * A[0];
+        AtA[1] += A[1] * A[0];
+        AtA[2] += A[2] * A[0];
+        AtA[4] += A[1] * A[1];
+        AtA[5] += A[2] * A[1];
+        AtA[8] += A[2] * A[2];
+        scalar_t b = it_adj - it;
+        Atb[0] += A[0] * b;
+        Atb[1] += A[1] * b;
+        Atb[2] += A[2] * b;
+    }
+    scalar_t A[3] = {(i - 1) * nt[0], (i - 1) * nt[1], (i - 1) * nt[2]};
+    AtA[0] += A[0] * A[0];
+    AtA[1] += A[0] * A[1];
+    AtA[2] += A[0] * A[2];
+    AtA[4] += A[1] * A[1];
+    AtA[5] += A[1] * A[2];
+    AtA[8] += A[2] * A[2];
+    AtA[3] = AtA[1];
+    AtA[6] = AtA[2];
+    AtA[7] = AtA[5];
+    PinvSolveSym3<scalar_t>(AtA, Atb, color_gradients_ptr + idx_offset);
+}
+
+template <typename T>
+void EstimateColorGradients(const T* points, const T* normals, const T* colors,
+                            const int32_t* indices, const int32_t* counts,
+                            int64_t n, int max_nn, T* gradients) {
+#pragma omp parallel for schedule(static)
+    for (int64_t w = 0; w < n; ++w)
+        ColorGradient<T>(points, normals, colors, 3 * w,
+                         indices + (int64_t)max_nn * w, counts[w], gradients);
+}
+
 }  // namespace normals
+
+namespace {
+template <typename T>
+void ColorGradientsForIcp(const T* points, const T* normals_, const T* colors,
+                          const int32_t* indices, const int32_t* counts,
+                          int64_t n, int max_nn, T* gradients) {
+    normals::EstimateColorGradients<T>(points, normals_, colors, indices,
+                                       counts, n, max_nn, gradients);
+}
+}  // namespace
 
 extern "C" {
 
@@ -1642,6 +2025,22 @@ void orc_hybrid_search(const void* points, int64_t n, const void* queries,
             HybridSearch<float>((const float*)points, n, (const float*)queries,
                                 q, radius, max_knn, idx, (float*)dist, counts);
     }
+}
+
+void orc_estimate_color_gradients(const void* points, const void* normals,
+                                  const void* colors, const int32_t* indices,
+                                  const int32_t* counts, int64_t n, int max_nn,
+                                  int is_f64, void* gradients) {
+    if (is_f64)
+        normals::EstimateColorGradients<double>(
+                (const double*)points, (const double*)normals,
+                (const double*)colors, indices, counts, n, max_nn,
+                (double*)gradients);
+    else
+        normals::EstimateColorGradients<float>(
+                (const float*)points, (const float*)normals,
+                (const float*)colors, indices, counts, n, max_nn,
+                (float*)gradients);
 }
 
 // idx {q, min(knn, n)} int32, dist {q, min(knn, n)} in the point dtype.
@@ -1842,6 +2241,32 @@ void orc_symmetric_accumulate(const void* src, const void* tgt, const void* sn,
     }
 }
 
+void orc_colored_accumulate(const void* src, const void* src_c, const void* tgt,
+                            const void* tn, const void* tc, const void* tg,
+                            const int64_t* corr, int64_t n, int is_f64,
+                            double lambda_geometric, int method, double scaling,
+                            double shape, int accumulate_double,
+                            double* out29) {
+    if (is_f64) {
+        ComputePoseColoredICPKernel<double, double>(
+                (const double*)src, (const double*)src_c, (const double*)tgt,
+                (const double*)tn, (const double*)tc, (const double*)tg, corr,
+                lambda_geometric, n, out29, method, scaling, shape);
+    } else if (accumulate_double) {
+        ComputePoseColoredICPKernel<float, double>(
+                (const float*)src, (const float*)src_c, (const float*)tgt,
+                (const float*)tn, (const float*)tc, (const float*)tg, corr,
+                lambda_geometric, n, out29, method, scaling, shape);
+    } else {
+        float A[29];
+        ComputePoseColoredICPKernel<float, float>(
+                (const float*)src, (const float*)src_c, (const float*)tgt,
+                (const float*)tn, (const float*)tc, (const float*)tg, corr,
+                lambda_geometric, n, A, method, scaling, shape);
+        for (int i = 0; i < 29; ++i) out29[i] = (double)A[i];
+    }
+}
+
 void orc_symmetric_pose_to_transformation(const double* pose6,
                                           const double* source_mean3,
                                           const double* target_mean3,
@@ -1918,8 +2343,11 @@ void orc_rt_from_sxy(const double* Sxy9, const double* source_mean3,
 }
 
 int orc_multiscale_icp_ex(const void* source, const void* source_normals,
-                          int64_t ns, const void* target,
-                          const void* target_normals, int64_t nt, int is_f64,
+                          const void* source_colors, const void* target_colors,
+                          const void* target_color_gradients,
+                          double lambda_geometric, int64_t ns,
+                          const void* target, const void* target_normals,
+                          int64_t nt, int is_f64,
                           int num_scales, const double* voxel_sizes,
                           const int* max_iterations, const double* rel_fitness,
                           const double* rel_rmse, const double* max_dists,
@@ -1930,18 +2358,22 @@ int orc_multiscale_icp_ex(const void* source, const void* source_normals,
                           int* out_converged, int* out_num_iterations,
                           int64_t* out_correspondences, int64_t* out_num_corr,
                           icp_callback_t cb, void* user) {
+    IcpExtra extra;
+    extra.source_normals = source_normals;
+    extra.source_colors = source_colors;
+    extra.target_colors = target_colors;
+    extra.target_color_gradients = target_color_gradients;
+    extra.lambda_geometric = lambda_geometric;
     if (is_f64)
         return MultiScaleICP<double>(
-                (const double*)source, (const double*)source_normals, ns,
-                (const double*)target, (const double*)target_normals, nt,
+                (const double*)source, extra, ns, (const double*)target, (const double*)target_normals, nt,
                 num_scales, voxel_sizes, max_iterations, rel_fitness, rel_rmse,
                 max_dists, init, kernel_method, kernel_scale, kernel_shape,
                 accumulate_double, estimation, out_T, out_fitness, out_rmse, out_converged,
                 out_num_iterations, out_correspondences, out_num_corr, cb,
                 user);
     return MultiScaleICP<float>(
-            (const float*)source, (const float*)source_normals, ns,
-            (const float*)target, (const float*)target_normals, nt, num_scales,
+            (const float*)source, extra, ns, (const float*)target, (const float*)target_normals, nt, num_scales,
             voxel_sizes, max_iterations, rel_fitness, rel_rmse, max_dists, init,
             kernel_method, kernel_scale, kernel_shape, accumulate_double,
             estimation, out_T, out_fitness, out_rmse, out_converged,
@@ -1962,7 +2394,7 @@ int orc_multiscale_icp(const void* source, int64_t ns, const void* target,
                        icp_callback_t cb, void* user) {
     if (is_f64)
         return MultiScaleICP<double>(
-                (const double*)source, nullptr, ns, (const double*)target,
+                (const double*)source, IcpExtra(), ns, (const double*)target,
                 (const double*)target_normals, nt, num_scales, voxel_sizes,
                 max_iterations, rel_fitness, rel_rmse, max_dists, init,
                 kernel_method, kernel_scale, kernel_shape, accumulate_double,
@@ -1970,7 +2402,7 @@ int orc_multiscale_icp(const void* source, int64_t ns, const void* target,
                 out_num_iterations, out_correspondences, out_num_corr, cb,
                 user);
     return MultiScaleICP<float>(
-            (const float*)source, nullptr, ns, (const float*)target,
+            (const float*)source, IcpExtra(), ns, (const float*)target,
             (const float*)target_normals, nt, num_scales, voxel_sizes,
             max_iterations, rel_fitness, rel_rmse, max_dists, init,
             kernel_method, kernel_scale, kernel_shape, accumulate_double, 0,

@@ -338,6 +338,31 @@ int ref_estimate_covariances(const void* points, const int32_t* indices,
     });
 }
 
+// EstimatePointWiseColorGradientKernel (PointCloudImpl.h:1067-1165, with the
+// reference's own solve_svd3x3) per point over given neighbour lists.
+int ref_estimate_color_gradients(const void* points, const void* normals,
+                                 const void* colors, const int32_t* indices,
+                                 const int32_t* counts, int64_t n, int max_nn,
+                                 int is_f64, void* gradients) {
+    return Guard([&] {
+        namespace pc = open3d::t::geometry::kernel::pointcloud;
+        for (int64_t w = 0; w < n; ++w) {
+            const int32_t idx_offset = (int32_t)(3 * w);
+            const int32_t cnt = counts[w];
+            if (is_f64)
+                pc::EstimatePointWiseColorGradientKernel<double>(
+                        (const double*)points, (const double*)normals,
+                        (const double*)colors, idx_offset,
+                        indices + (int64_t)max_nn * w, cnt, (double*)gradients);
+            else
+                pc::EstimatePointWiseColorGradientKernel<float>(
+                        (const float*)points, (const float*)normals,
+                        (const float*)colors, idx_offset,
+                        indices + (int64_t)max_nn * w, cnt, (float*)gradients);
+        }
+    });
+}
+
 int ref_normals_from_covariances(const void* covariances, int64_t n, int is_f64,
                                  void* normals_io, int has_normals) {
     return Guard([&] {
@@ -460,6 +485,54 @@ int ref_symmetric_accumulate(const void* src, const void* tgt, const void* sn,
                                 (const float*)src, (const float*)tgt,
                                 (const float*)sn, (const float*)tn, corr, ms,
                                 mt, (int)n, g.data(),
+                                GetWeightFromRobustKernel);
+                    });
+            for (int i = 0; i < 29; ++i) sums29[i] = g[(size_t)i];
+        }
+    });
+}
+
+// ComputePoseColoredICPKernelCPU, RegistrationCPU.cpp:220-290 (with
+// GetJacobianColoredICP, RegistrationImpl.h:388-466): 29 sums in the point
+// dtype, widened to double; sqrt(lambda) as ComputePoseColoredICPCPU forms it.
+int ref_colored_accumulate(const void* src, const void* src_c, const void* tgt,
+                           const void* tn, const void* tc, const void* tg,
+                           const int64_t* corr, int64_t n, int is_f64,
+                           double lambda_geometric, int method, double scaling,
+                           double shape, double* sums29) {
+    return Guard([&] {
+        reg::RobustKernel kernel((reg::RobustKernelMethod)method, scaling,
+                                 shape);
+        using reg::RobustKernelMethod;
+        if (is_f64) {
+            std::vector<double> g(29, 0.0);
+            using scalar_t = double;
+            scalar_t slg = static_cast<scalar_t>(sqrt(lambda_geometric));
+            scalar_t slp = static_cast<scalar_t>(sqrt(1.0 - lambda_geometric));
+            DISPATCH_ROBUST_KERNEL_FUNCTION(
+                    kernel.type_, scalar_t, kernel.scaling_parameter_,
+                    kernel.shape_parameter_, [&]() {
+                        pk::ComputePoseColoredICPKernelCPU(
+                                (const double*)src, (const double*)src_c,
+                                (const double*)tgt, (const double*)tn,
+                                (const double*)tc, (const double*)tg, corr, slg,
+                                slp, (int)n, g.data(),
+                                GetWeightFromRobustKernel);
+                    });
+            for (int i = 0; i < 29; ++i) sums29[i] = g[(size_t)i];
+        } else {
+            std::vector<float> g(29, 0.0f);
+            using scalar_t = float;
+            scalar_t slg = static_cast<scalar_t>(sqrt(lambda_geometric));
+            scalar_t slp = static_cast<scalar_t>(sqrt(1.0 - lambda_geometric));
+            DISPATCH_ROBUST_KERNEL_FUNCTION(
+                    kernel.type_, scalar_t, kernel.scaling_parameter_,
+                    kernel.shape_parameter_, [&]() {
+                        pk::ComputePoseColoredICPKernelCPU(
+                                (const float*)src, (const float*)src_c,
+                                (const float*)tgt, (const float*)tn,
+                                (const float*)tc, (const float*)tg, corr, slg,
+                                slp, (int)n, g.data(),
                                 GetWeightFromRobustKernel);
                     });
             for (int i = 0; i < 29; ++i) sums29[i] = g[(size_t)i];

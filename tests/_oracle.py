@@ -406,6 +406,23 @@ def symmetric_accumulate(src, tgt, sn, tn, corr, source_mean, target_mean,
     return out
 
 
+def colored_accumulate(src, src_c, tgt, tn, tc, tg, corr, lambda_geometric,
+                       method=0, scaling=1.0, shape=1.0,
+                       accumulate_double=False):
+    src = np.ascontiguousarray(src)
+    dt = src.dtype
+    src_c, tgt, tn, tc, tg = (np.ascontiguousarray(a, dtype=dt)
+                              for a in (src_c, tgt, tn, tc, tg))
+    corr = np.ascontiguousarray(corr, dtype=np.int64).reshape(-1)
+    out = np.zeros(29, np.float64)
+    lib().orc_colored_accumulate(
+        _p(src), _p(src_c), _p(tgt), _p(tn), _p(tc), _p(tg), _p(corr),
+        C.c_int64(src.shape[0]), int(dt == np.float64),
+        C.c_double(lambda_geometric), int(method), C.c_double(scaling),
+        C.c_double(shape), int(accumulate_double), _p(out))
+    return out
+
+
 def symmetric_pose_to_transformation(pose, source_mean, target_mean):
     T = np.zeros((4, 4), np.float64)
     lib().orc_symmetric_pose_to_transformation(
@@ -545,14 +562,22 @@ ICP_CB = C.CFUNCTYPE(None, C.c_int64, C.c_int64, C.c_int64, C.c_double,
 def multiscale_icp(source, target, target_normals, voxel_sizes, criterias,
                    max_dists, init=None, kernel=(0, 1.0, 1.0),
                    accumulate_double=False, callback=None, estimation=0,
-                   source_normals=None):
+                   source_normals=None, source_colors=None, target_colors=None,
+                   target_color_gradients=None, lambda_geometric=0.968):
     """criterias: list of (relative_fitness, relative_rmse, max_iteration).
     estimation: 0 = point-to-plane, 1 = point-to-point (normals unused),
-    2 = symmetric (needs source_normals)."""
+    2 = symmetric (needs source_normals), 3 = colored (needs the colours)."""
     source = np.ascontiguousarray(source)
     dt = source.dtype
     if source_normals is not None:
         source_normals = np.ascontiguousarray(source_normals, dtype=dt)
+    if source_colors is not None:
+        source_colors = np.ascontiguousarray(source_colors, dtype=dt)
+    if target_colors is not None:
+        target_colors = np.ascontiguousarray(target_colors, dtype=dt)
+    if target_color_gradients is not None:
+        target_color_gradients = np.ascontiguousarray(target_color_gradients,
+                                                      dtype=dt)
     target = np.ascontiguousarray(target, dtype=dt)
     if target_normals is not None:
         target_normals = np.ascontiguousarray(target_normals, dtype=dt)
@@ -580,7 +605,11 @@ def multiscale_icp(source, target, target_normals, voxel_sizes, criterias,
     st = lib().orc_multiscale_icp_ex(
             _p(source),
             _p(source_normals) if source_normals is not None else None,
-            C.c_int64(ns), _p(target),
+            _p(source_colors) if source_colors is not None else None,
+            _p(target_colors) if target_colors is not None else None,
+            _p(target_color_gradients)
+            if target_color_gradients is not None else None,
+            C.c_double(lambda_geometric), C.c_int64(ns), _p(target),
             _p(target_normals) if target_normals is not None else None,
             C.c_int64(nt), int(dt == np.float64), int(S), _p(vs), _p(mi),
             _p(rf), _p(rr), _p(md), _p(init), int(estimation), int(kernel[0]),
@@ -800,6 +829,21 @@ def estimate_covariances(points, indices, counts):
                                    C.c_int64(n), int(max_nn),
                                    int(points.dtype == np.float64), _p(cov))
     return cov
+
+
+def estimate_color_gradients(points, normals, colors, indices, counts):
+    points = np.ascontiguousarray(points)
+    dt = points.dtype
+    normals = np.ascontiguousarray(normals, dtype=dt)
+    colors = np.ascontiguousarray(colors, dtype=dt)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    n, max_nn = indices.shape
+    g = np.zeros((n, 3), dt)
+    lib().orc_estimate_color_gradients(
+        _p(points), _p(normals), _p(colors), _p(indices), _p(counts),
+        C.c_int64(n), int(max_nn), int(dt == np.float64), _p(g))
+    return g
 
 
 def normals_from_covariances(cov, normals=None):

@@ -235,6 +235,23 @@ def symmetric_accumulate(src, tgt, sn, tn, corr, source_mean, target_mean,
     return out
 
 
+def colored_accumulate(src, src_c, tgt, tn, tc, tg, corr, lambda_geometric,
+                       method=0, scaling=1.0, shape=1.0):
+    """ComputePoseColoredICPKernelCPU: 29 sums in the point dtype."""
+    src = np.ascontiguousarray(src)
+    dt = src.dtype
+    src_c, tgt, tn, tc, tg = (np.ascontiguousarray(a, dtype=dt)
+                              for a in (src_c, tgt, tn, tc, tg))
+    corr = np.ascontiguousarray(corr, dtype=np.int64).reshape(-1)
+    out = np.zeros(29, np.float64)
+    _check(lib().ref_colored_accumulate(
+        _p(src), _p(src_c), _p(tgt), _p(tn), _p(tc), _p(tg), _p(corr),
+        C.c_int64(src.shape[0]), int(dt == np.float64),
+        C.c_double(lambda_geometric), int(method), C.c_double(scaling),
+        C.c_double(shape), _p(out)), "ref_colored_accumulate")
+    return out
+
+
 def information_matrix(tgt, corr):
     """ComputeInformationMatrixCPU: GTG {6,6} float64."""
     tgt = np.ascontiguousarray(tgt)
@@ -466,6 +483,22 @@ def estimate_covariances(points, indices, counts):
         _p(points), _p(indices), _p(counts), C.c_int64(n), int(max_nn),
         int(points.dtype == np.float64), _p(cov)), "estimate_covariances")
     return cov
+
+
+def estimate_color_gradients(points, normals, colors, indices, counts):
+    points = np.ascontiguousarray(points)
+    dt = points.dtype
+    normals = np.ascontiguousarray(normals, dtype=dt)
+    colors = np.ascontiguousarray(colors, dtype=dt)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    n, max_nn = indices.shape
+    g = np.zeros((n, 3), dt)
+    _check(lib().ref_estimate_color_gradients(
+        _p(points), _p(normals), _p(colors), _p(indices), _p(counts),
+        C.c_int64(n), int(max_nn), int(dt == np.float64), _p(g)),
+        "estimate_color_gradients")
+    return g
 
 
 def normals_from_covariances(cov, normals=None):

