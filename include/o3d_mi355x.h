@@ -333,6 +333,15 @@ int o3dmi_nns_knn_search(const void* points_dev, int64_t n,
                          int32_t* idx_dev, void* dist2_dev,
                          o3dmi_stream_t stream);
 
+/* EstimateCovariancesUsingRadiusSearchCUDA (t/geometry/kernel/PointCloudImpl.h:
+ * 641-689): covariances {Q,3,3} (point dtype) of ALL index points with
+ * d2 < r2 of every query, r = the index radius; fewer than 3 -> identity.
+ * The moments are summed by a wave in float64 (parallel order: the last bits
+ * of the float64 sums may differ from the reference's one-by-one order). */
+int o3dmi_nns_radius_covariances(const o3dmi_nns_t* nns, const void* queries_dev,
+                                 int64_t q, void* covariances_dev,
+                                 o3dmi_stream_t stream);
+
 /* EstimateCovariancesUsingHybridSearchCUDA after the search
  * (t/geometry/kernel/PointCloudImpl.h:588-638; per-point body :512-585):
  * covariances {n,3,3} in the point dtype from hybrid-search results. */

@@ -153,9 +153,8 @@ int o3dmi_voxel_down_sample(const void* positions_dev, const void* normals_dev,
 /* PointCloud::EstimateNormals(max_nn, radius) (t/geometry/PointCloud.cpp:
  * 856-976): normals {n,3} (in/out when has_normals). radius > 0 and max_nn > 0
  * = hybrid search; radius <= 0 = KNN search (the reference's default
- * max_nn = 30, radius = nullopt); max_nn <= 64. The radius-only variant
- * (max_nn <= 0: unbounded neighbour lists) is not implemented (status
- * O3DMI_ERR_INVALID_ARG). Synchronises. */
+ * max_nn = 30, radius = nullopt); max_nn <= 0 = radius search (every
+ * neighbour within radius); max_nn <= 64 otherwise. Synchronises. */
 int o3dmi_pointcloud_estimate_normals(const void* points_dev, int64_t n,
                                       int dtype, int max_nn, double radius,
                                       void* normals_dev, int has_normals,

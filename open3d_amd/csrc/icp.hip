@@ -340,6 +340,7 @@ struct WaveTopK {
     }
 
     // Candidate of this lane (kNoIndex = none).
+    __device__ __forceinline__ void Push(T d, int i, T, T, T) { Push(d, i); }
     __device__ __forceinline__ void Push(T d, int i) {
         // what cannot make the list any more is dropped here
         bool valid = i != kNoIndex;
@@ -425,14 +426,16 @@ struct WaveTopK {
 
 // Candidates of the cells [x0..x1] x [y0..y1] x [z0..z1] whose Chebyshev cell
 // distance to (cx, cy, cz) is >= r_skip. RADIUS: keep d2 < nv.radius_squared.
-template <typename T, bool RADIUS>
+// Sink::Push(d2, index, x, y, z) receives every lane's candidate of a batch
+// (index == kNoIndex: none).
+template <typename T, bool RADIUS, typename Sink>
 __device__ __forceinline__ void GatherCells(const NnsView<T>& nv, const T* qq,
                                             long long cx, long long cy,
                                             long long cz, long long x0,
                                             long long x1, long long y0,
                                             long long y1, long long z0,
                                             long long z1, long long r_skip,
-                                            WaveTopK<T>& list) {
+                                            Sink& list) {
     if (x1 < x0 || y1 < y0 || z1 < z0) return;
     const int lane = threadIdx.x & 63;
     const int nx = (int)(x1 - x0 + 1), ny = (int)(y1 - y0 + 1);
@@ -477,8 +480,12 @@ __device__ __forceinline__ void GatherCells(const NnsView<T>& nv, const T* qq,
             const unsigned os = __shfl(s0, pos);
             T d = InfOf<T>();
             int pi = kNoIndex;
+            T px = T(0), py = T(0), pz = T(0);
             if (t < total) {
                 const Rec4<T> p = nv.sorted[os + (t - oe)];
+                px = p.x;
+                py = p.y;
+                pz = p.z;
                 // the record's own cell must be the cell it was fetched for
                 const T pp[3] = {p.x, p.y, p.z};
                 long long rx, ry, rz;
@@ -500,7 +507,7 @@ __device__ __forceinline__ void GatherCells(const NnsView<T>& nv, const T* qq,
                     pi = RecIndex(p);
                 }
             }
-            list.Push(d, pi);
+            list.Push(d, pi, px, py, pz);
         }
     }
 }
@@ -541,6 +548,97 @@ HybridSearchKernel(NnsView<T> nv, const T* __restrict__ q, int64_t nq,
                              cz - 1, cz + 1, 0, list);
         list.Flush();
         WriteTopK(list, i, idx_out, d2_out, cnt_out);
+    }
+}
+
+// EstimateCovariancesUsingRadiusSearch (t/geometry/kernel/PointCloudImpl.h:
+// 641-689): every neighbour with d2 < r2, no cap. One wave per point, two
+// sweeps over the 27 cells: count + centroid, then the six cumulants about it
+// (EstimatePointWiseRobustNormalizedCovarianceKernel, :512-585, float64 sums).
+// The reference adds the neighbours one by one in ascending distance; the wave
+// adds them in parallel, so the float64 sums can differ in their last bits
+// (the stored covariance is their rounding to the point dtype).
+template <typename T>
+struct MomentSink {
+    double acc[6];
+    double c[3];
+    int count;
+    bool second;
+    __device__ __forceinline__ void Push(T, int i, T x, T y, T z) {
+        if (i == kNoIndex) return;
+        if (!second) {
+            acc[0] += (double)x;
+            acc[1] += (double)y;
+            acc[2] += (double)z;
+            ++count;
+        } else {
+            const double dx = (double)x - c[0], dy = (double)y - c[1],
+                         dz = (double)z - c[2];
+            acc[0] += dx * dx;
+            acc[1] += dy * dy;
+            acc[2] += dz * dz;
+            acc[3] += dx * dy;
+            acc[4] += dx * dz;
+            acc[5] += dy * dz;
+        }
+    }
+    __device__ __forceinline__ void WaveSum(int n) {
+        for (int k = 0; k < n; ++k)
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) acc[k] += __shfl_xor(acc[k], m);
+    }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kCoopBlock)
+RadiusCovariancesKernel(NnsView<T> nv, const T* __restrict__ q, int64_t nq,
+                        T* __restrict__ covariances) {
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    for (int64_t i = wave; i < nq; i += n_waves) {
+        const T qq[3] = {q[3 * i + 0], q[3 * i + 1], q[3 * i + 2]};
+        long long cx, cy, cz;
+        CellOf(qq, nv.inv_cell, cx, cy, cz);
+        MomentSink<T> sink;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sink.acc[k] = 0;
+        sink.count = 0;
+        sink.second = false;
+        GatherCells<T, true>(nv, qq, cx, cy, cz, cx - 1, cx + 1, cy - 1, cy + 1,
+                             cz - 1, cz + 1, 0, sink);
+        sink.WaveSum(3);
+        int cnt = sink.count;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) cnt += __shfl_xor(cnt, m);
+        T* cov = covariances + 9 * i;
+        if (cnt < 3) {
+            if (lane < 9) cov[lane] = (lane % 4 == 0) ? T(1.0) : T(0.0);
+            continue;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sink.c[k] = sink.acc[k] / cnt;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sink.acc[k] = 0;
+        sink.second = true;
+        GatherCells<T, true>(nv, qq, cx, cy, cz, cx - 1, cx + 1, cy - 1, cy + 1,
+                             cz - 1, cz + 1, 0, sink);
+        sink.WaveSum(6);
+        if (lane == 0) {
+            const double nf = (double)(cnt - 1);
+            double cm[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) cm[k] = sink.acc[k] / nf;
+            cov[0] = (T)cm[0];
+            cov[4] = (T)cm[1];
+            cov[8] = (T)cm[2];
+            cov[1] = (T)cm[3];
+            cov[3] = cov[1];
+            cov[2] = (T)cm[4];
+            cov[6] = cov[2];
+            cov[5] = (T)cm[5];
+            cov[7] = cov[5];
+        }
     }
 }
 
@@ -1478,6 +1576,29 @@ int o3dmi_nns_hybrid_search(const o3dmi_nns_t* nns, const void* queries_dev,
                            CoopLdsBytesPerWave<float>() * (kCoopBlock / 64), s,
                            MakeView<float>(nns), (const float*)queries_dev, q,
                            max_knn, idx_dev, (float*)dist2_dev, counts_dev);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+// EstimateCovariancesUsingRadiusSearchCUDA: covariances {q,3,3} of all index
+// points within the index radius of every query.
+int o3dmi_nns_radius_covariances(const o3dmi_nns_t* nns, const void* queries_dev,
+                                 int64_t q, void* covariances_dev,
+                                 o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(nns != nullptr, "index is null");
+    O3DMI_REQUIRE(q >= 0, "q < 0");
+    if (q == 0) return O3DMI_OK;
+    O3DMI_REQUIRE(queries_dev && covariances_dev, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(GridFor(q, kCoopBlock / 64, kCUs * 16)), block(kCoopBlock);
+    if (nns->dtype == O3DMI_F64)
+        hipLaunchKernelGGL(RadiusCovariancesKernel<double>, grid, block, 0, s,
+                           MakeView<double>(nns), (const double*)queries_dev, q,
+                           (double*)covariances_dev);
+    else
+        hipLaunchKernelGGL(RadiusCovariancesKernel<float>, grid, block, 0, s,
+                           MakeView<float>(nns), (const float*)queries_dev, q,
+                           (float*)covariances_dev);
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
 }

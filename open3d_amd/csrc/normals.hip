@@ -499,9 +499,9 @@ int o3dmi_nns_knn_search_counts(const void* points_dev, int64_t n,
                                 int32_t* counts_dev, o3dmi_stream_t stream);
 
 // PointCloud::EstimateNormals(max_knn, radius), PointCloud.cpp:856-976: index
-// over the cloud itself, hybrid search (both given) or KNN search (radius <= 0,
-// the reference's default max_nn = 30 / radius = nullopt), covariances,
-// normals; the "covariances" attribute is a temporary, as in the reference.
+// over the cloud itself, hybrid search (both given), KNN search (radius <= 0,
+// the reference's default max_nn = 30 / radius = nullopt) or radius search
+// (max_nn <= 0), covariances, normals; the "covariances" attribute is a temporary, as in the reference.
 int o3dmi_pointcloud_estimate_normals(const void* points_dev, int64_t n,
                                       int dtype, int max_nn, double radius,
                                       void* normals_dev, int has_normals,
@@ -509,14 +509,29 @@ int o3dmi_pointcloud_estimate_normals(const void* points_dev, int64_t n,
     O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
                   "Only Float32 and Float64 point clouds are supported.");
     O3DMI_REQUIRE(max_nn > 0 || radius > 0, "Both max_nn and radius are none.");
-    O3DMI_REQUIRE(max_nn > 0,
-                  "EstimateNormals: the radius-only variant (unbounded "
-                  "neighbour lists) is not implemented by this backend.");
     O3DMI_REQUIRE(n >= 0, "n < 0");
     if (n == 0) return O3DMI_OK;
     O3DMI_REQUIRE(points_dev && normals_dev, "null argument");
     hipStream_t s = (hipStream_t)stream;
     const size_t esz = dtype == O3DMI_F64 ? 8 : 4;
+    if (max_nn <= 0) {
+        // EstimateCovariancesUsingRadiusSearch, PointCloudImpl.h:641-689:
+        // no neighbour lists, the wave accumulates the moments directly
+        o3dmi_nns_t* index = nullptr;
+        int st = o3dmi_nns_create(points_dev, n, dtype, radius, stream, &index);
+        if (st) return st;
+        void* cov = nullptr;
+        st = PoolAlloc(&cov, esz * 9 * (size_t)n);
+        if (!st)
+            st = o3dmi_nns_radius_covariances(index, points_dev, n, cov, stream);
+        if (!st)
+            st = o3dmi_pointcloud_normals_from_covariances(
+                    cov, n, dtype, normals_dev, has_normals, stream);
+        (void)hipStreamSynchronize(s);
+        PoolFree(cov);
+        o3dmi_nns_destroy(index);
+        return st;
+    }
     if (!(radius > 0)) {
         // EstimateCovariancesUsingKNNSearch, PointCloudImpl.h:692-744
         const int k = (int)(n < (int64_t)max_nn ? n : (int64_t)max_nn);

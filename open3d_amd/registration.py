@@ -264,16 +264,16 @@ def voxel_down_sample(positions, normals, voxel_size):
 def estimate_normals(positions, max_nn=30, radius=None, normals=None):
     """t::geometry::PointCloud::EstimateNormals(max_nn, radius)
     (PointCloud.cpp:856-976): hybrid search when both are given, KNN search
-    when radius is None (the reference's default); returns normals {N,3};
+    when radius is None (the reference's default), radius search when max_nn
+    is None; returns normals {N,3};
     `normals` (optional) are existing normals whose orientation is kept."""
     positions = require_cuda(positions, "positions")
     if radius is None and max_nn is None:
         raise ValueError("Both max_nn and radius are none.")
     if max_nn is None:
-        raise ValueError("the radius-only variant is not implemented by this "
-                         "backend: give max_nn")
+        max_nn = -1      # radius search: every neighbour within radius
     if radius is None:
-        radius = -1.0
+        radius = -1.0    # KNN search
     if normals is None:
         out = torch.empty_like(positions)
         has = 0
