@@ -4,9 +4,17 @@
  * calls when it wants the whole operator rather than one kernel:
  *
  *   o3dmi_registration_multiscale_icp  <- t::pipelines::registration::MultiScaleICP / ICP
- *                                         (t/pipelines/registration/Registration.cpp:93-106,362-444)
- *   o3dmi_vbg_*                        <- t::geometry::VoxelBlockGrid
- *                                         (t/geometry/VoxelBlockGrid.cpp:65-117,212-402)
+ *   (_ex: estimator choice)               (t/pipelines/registration/Registration.cpp:93-106,362-444)
+ *   o3dmi_registration_evaluate,       <- EvaluateRegistration, GetInformationMatrix
+ *   o3dmi_registration_information_matrix (Registration.cpp:64-91,446-486)
+ *   o3dmi_voxel_down_sample,           <- t::geometry::PointCloud::{VoxelDownSample, EstimateNormals,
+ *   o3dmi_pointcloud_estimate_*           EstimateColorGradients} (t/geometry/PointCloud.cpp:496-567,856-1060)
+ *   o3dmi_vbg_*                        <- t::geometry::VoxelBlockGrid (+ Save / Load)
+ *                                         (t/geometry/VoxelBlockGrid.cpp:65-117,212-602)
+ *   o3dmi_rgbd_odometry_multiscale     <- t::pipelines::odometry::RGBDOdometryMultiScale
+ *                                         (t/pipelines/odometry/RGBDOdometry.cpp:56-513)
+ *   o3dmi_slam_model_*                 <- t::pipelines::slam::Model (t/pipelines/slam/Model.cpp:23-118)
+ *   o3dmi_npz_*                        <- t::io::WriteNpz / ReadNpz (t/io/NumpyIO.cpp:157-789)
  *
  * Same argument meaning, defaults and error behaviour as the reference
  * (errors are status codes + o3dmi_last_error() instead of exceptions).

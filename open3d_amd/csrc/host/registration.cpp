@@ -18,6 +18,14 @@
 // The source cloud is transformed incrementally in its own dtype every
 // iteration exactly like the reference (Registration.cpp:322), not re-derived
 // from the cumulative transform, so float rounding accumulates the same way.
+//
+// Other estimators (o3dmi_registration_multiscale_icp_ex): the same fused
+// search launch in its point-to-point form (correspondences + raw moments),
+// then per estimator: point-to-point -> R, t from the moments on the host;
+// symmetric / coloured -> a second launch that gathers by correspondence and
+// accumulates their 29 sums (two mailbox waits per iteration). Also
+// EvaluateRegistration and GetInformationMatrix (Registration.cpp:64-91,
+// 446-486) at the end of this file.
 
 #include <cmath>
 #include <cstring>
