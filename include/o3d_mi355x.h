@@ -446,10 +446,11 @@ int o3dmi_icp_colored_accumulate(
 /* EstimateColorGradientsUsing{Hybrid,KNN}SearchCUDA after the search
  * (t/geometry/kernel/PointCloudImpl.h:1067-1290): per point, least squares of
  * the intensity over its neighbours projected on the tangent plane plus the
- * constraint gradient . normal = 0. The 3x3 normal equations are solved
- * exactly (converged Jacobi, eigenvalues < 1e-10 dropped) where the reference
- * uses its approximate solve_svd3x3: results agree with the reference to the
- * accuracy of that routine, not bit for bit. */
+ * constraint gradient . normal = 0. The 3x3 normal equations go through the
+ * reference's approximate solve_svd3x3 (core/linalg/kernel/SVD3x3.h) restated
+ * bit for bit (csrc/svd3x3.h) -- including its Float64 quirks, which yield NaN
+ * on some neighbourhoods; O3DMI_EXACT_COLOR_GRADIENTS=1 selects an exact
+ * solve instead. */
 int o3dmi_pointcloud_color_gradients_from_neighbors(
         const void* points_dev, const void* normals_dev, const void* colors_dev,
         const int32_t* indices_dev, const int32_t* counts_dev, int64_t n,

@@ -12,8 +12,10 @@
 // Gather-bound: 30 neighbours x 12 B per point, L2-resident for a sorted cloud.
 
 #include <cmath>
+#include <cstdlib>
 
 #include "common.h"
+#include "svd3x3.h"
 
 namespace o3dmi {
 namespace {
@@ -304,10 +306,11 @@ __global__ void NormalsFromCovariancesKernel(const T* __restrict__ covariances,
 }
 
 // x = pinv(AtA) Atb for a symmetric 3x3 AtA: cyclic Jacobi eigen-decomposition
-// (8 sweeps, converged for 3x3), eigenvalues below 1e-10 dropped. The
-// reference calls solve_svd3x3 (core/linalg/kernel/SVD3x3.h: McAdams'
-// approximate SVD with 4 fixed sweeps); this is the exact solution of the
-// same normal equations, see DESIGN.md.
+// (8 sweeps, converged for 3x3), eigenvalues below 1e-10 dropped -- the exact
+// solution of the normal equations. The default is the reference's
+// solve_svd3x3 (svd3x3.h, bit for bit); this one is selected by
+// O3DMI_EXACT_COLOR_GRADIENTS=1 (the reference's Float64 path returns NaN on
+// some neighbourhoods).
 template <typename T>
 __device__ __forceinline__ void PinvSolveSym3(const T* AtA, const T* Atb,
                                               T* x) {
@@ -368,7 +371,7 @@ __device__ __forceinline__ void PinvSolveSym3(const T* AtA, const T* Atb,
 // EstimatePointWiseColorGradientKernel, PointCloudImpl.h:1067-1165: intensity
 // least squares over the neighbours projected on the tangent plane + the
 // constraint gradient . normal = 0 (the first neighbour is the point itself).
-template <typename T>
+template <typename T, bool EXACT>
 __global__ void ColorGradientsKernel(const T* __restrict__ points,
                                      const T* __restrict__ normals,
                                      const T* __restrict__ colors,
@@ -429,7 +432,8 @@ __global__ void ColorGradientsKernel(const T* __restrict__ points,
         AtA[6] = AtA[2];
         AtA[7] = AtA[5];
         T x[3];
-        PinvSolveSym3<T>(AtA, Atb, x);
+        if constexpr (EXACT) PinvSolveSym3<T>(AtA, Atb, x);
+        else svd3::SolveSvd3x3<T>(AtA, Atb, x);
         out[0] = x[0];
         out[1] = x[1];
         out[2] = x[2];
@@ -603,17 +607,21 @@ int o3dmi_pointcloud_color_gradients_from_neighbors(
                   "null argument");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(GridFor(n, kBlock)), block(kBlock);
-    if (dtype == O3DMI_F64)
-        hipLaunchKernelGGL(ColorGradientsKernel<double>, grid, block, 0, s,
-                           (const double*)points_dev,
-                           (const double*)normals_dev,
-                           (const double*)colors_dev, indices_dev, counts_dev,
-                           n, max_nn, (double*)gradients_dev);
-    else
-        hipLaunchKernelGGL(ColorGradientsKernel<float>, grid, block, 0, s,
-                           (const float*)points_dev, (const float*)normals_dev,
-                           (const float*)colors_dev, indices_dev, counts_dev, n,
-                           max_nn, (float*)gradients_dev);
+    const char* e = std::getenv("O3DMI_EXACT_COLOR_GRADIENTS");
+    const bool exact = e && e[0] == '1';
+#define O3DMI_GRAD(T, X)                                                       \
+    hipLaunchKernelGGL((ColorGradientsKernel<T, X>), grid, block, 0, s,        \
+                       (const T*)points_dev, (const T*)normals_dev,            \
+                       (const T*)colors_dev, indices_dev, counts_dev, n,       \
+                       max_nn, (T*)gradients_dev)
+    if (dtype == O3DMI_F64) {
+        if (exact) O3DMI_GRAD(double, true);
+        else O3DMI_GRAD(double, false);
+    } else {
+        if (exact) O3DMI_GRAD(float, true);
+        else O3DMI_GRAD(float, false);
+    }
+#undef O3DMI_GRAD
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
 }

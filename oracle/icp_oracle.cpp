@@ -43,6 +43,8 @@
 #include <omp.h>
 #endif
 
+#include "svd3x3_oracle.h"
+
 namespace {
 
 using std::abs;
@@ -1884,7 +1886,7 @@ template <typename scalar_t>
 void ColorGradient(const scalar_t* points_ptr, const scalar_t* normals_ptr,
                    const scalar_t* colors_ptr, int64_t idx_offset,
                    const int32_t* indices_ptr, int32_t indices_count,
-                   scalar_t* color_gradients_ptr) {
+                   scalar_t* color_gradients_ptr, bool exact_solve) {
     if (indices_count < 4) {
         color_gradients_ptr[idx_offset] = 0;
         color_gradients_ptr[idx_offset + 1] = 0;
@@ -1939,17 +1941,22 @@ void ColorGradient(const scalar_t* points_ptr, const scalar_t* normals_ptr,
     AtA[3] = AtA[1];
     AtA[6] = AtA[2];
     AtA[7] = AtA[5];
-    PinvSolveSym3<scalar_t>(AtA, Atb, color_gradients_ptr + idx_offset);
+    if (exact_solve)
+        PinvSolveSym3<scalar_t>(AtA, Atb, color_gradients_ptr + idx_offset);
+    else  // core::linalg::kernel::solve_svd3x3, restated in svd3x3_oracle.h
+        svd3::SolveSvd3x3<scalar_t>(AtA, Atb, color_gradients_ptr + idx_offset);
 }
 
 template <typename T>
 void EstimateColorGradients(const T* points, const T* normals, const T* colors,
                             const int32_t* indices, const int32_t* counts,
-                            int64_t n, int max_nn, T* gradients) {
+                            int64_t n, int max_nn, T* gradients,
+                            bool exact_solve = false) {
 #pragma omp parallel for schedule(static)
     for (int64_t w = 0; w < n; ++w)
         ColorGradient<T>(points, normals, colors, 3 * w,
-                         indices + (int64_t)max_nn * w, counts[w], gradients);
+                         indices + (int64_t)max_nn * w, counts[w], gradients,
+                         exact_solve);
 }
 
 }  // namespace normals
@@ -2030,17 +2037,34 @@ void orc_hybrid_search(const void* points, int64_t n, const void* queries,
 void orc_estimate_color_gradients(const void* points, const void* normals,
                                   const void* colors, const int32_t* indices,
                                   const int32_t* counts, int64_t n, int max_nn,
-                                  int is_f64, void* gradients) {
+                                  int is_f64, int exact_solve,
+                                  void* gradients) {
     if (is_f64)
         normals::EstimateColorGradients<double>(
                 (const double*)points, (const double*)normals,
                 (const double*)colors, indices, counts, n, max_nn,
-                (double*)gradients);
+                (double*)gradients, exact_solve != 0);
     else
         normals::EstimateColorGradients<float>(
                 (const float*)points, (const float*)normals,
                 (const float*)colors, indices, counts, n, max_nn,
-                (float*)gradients);
+                (float*)gradients, exact_solve != 0);
+}
+
+// svd3x3 / solve_svd3x3 restated (svd3x3_oracle.h): row-major 3x3.
+void orc_svd3x3(const void* A, int is_f64, void* U, void* S, void* V) {
+    if (is_f64)
+        svd3::Svd3x3<double>((const double*)A, (double*)U, (double*)S,
+                             (double*)V);
+    else
+        svd3::Svd3x3<float>((const float*)A, (float*)U, (float*)S, (float*)V);
+}
+void orc_solve_svd3x3(const void* A, const void* b, int is_f64, void* x) {
+    if (is_f64)
+        svd3::SolveSvd3x3<double>((const double*)A, (const double*)b,
+                                  (double*)x);
+    else
+        svd3::SolveSvd3x3<float>((const float*)A, (const float*)b, (float*)x);
 }
 
 // idx {q, min(knn, n)} int32, dist {q, min(knn, n)} in the point dtype.

@@ -363,6 +363,31 @@ int ref_estimate_color_gradients(const void* points, const void* normals,
     });
 }
 
+// core::linalg::kernel::svd3x3 / solve_svd3x3 (core/linalg/kernel/SVD3x3.h),
+// row-major 3x3.
+int ref_svd3x3(const void* A, int is_f64, void* U, void* S, void* V) {
+    return Guard([&] {
+        namespace lk = open3d::core::linalg::kernel;
+        if (is_f64)
+            lk::svd3x3<double>((const double*)A, (double*)U, (double*)S,
+                               (double*)V);
+        else
+            lk::svd3x3<float>((const float*)A, (float*)U, (float*)S,
+                              (float*)V);
+    });
+}
+int ref_solve_svd3x3(const void* A, const void* b, int is_f64, void* x) {
+    return Guard([&] {
+        namespace lk = open3d::core::linalg::kernel;
+        if (is_f64)
+            lk::solve_svd3x3<double>((const double*)A, (const double*)b,
+                                     (double*)x);
+        else
+            lk::solve_svd3x3<float>((const float*)A, (const float*)b,
+                                    (float*)x);
+    });
+}
+
 int ref_normals_from_covariances(const void* covariances, int64_t n, int is_f64,
                                  void* normals_io, int has_normals) {
     return Guard([&] {

@@ -831,7 +831,24 @@ def estimate_covariances(points, indices, counts):
     return cov
 
 
-def estimate_color_gradients(points, normals, colors, indices, counts):
+def svd3x3(A):
+    A = np.ascontiguousarray(A)
+    U, S, V = np.zeros((3, 3), A.dtype), np.zeros(3, A.dtype), \
+        np.zeros((3, 3), A.dtype)
+    lib().orc_svd3x3(_p(A), int(A.dtype == np.float64), _p(U), _p(S), _p(V))
+    return U, S, V
+
+
+def solve_svd3x3(A, b):
+    A = np.ascontiguousarray(A)
+    b = np.ascontiguousarray(b, dtype=A.dtype)
+    x = np.zeros(3, A.dtype)
+    lib().orc_solve_svd3x3(_p(A), _p(b), int(A.dtype == np.float64), _p(x))
+    return x
+
+
+def estimate_color_gradients(points, normals, colors, indices, counts,
+                             exact_solve=False):
     points = np.ascontiguousarray(points)
     dt = points.dtype
     normals = np.ascontiguousarray(normals, dtype=dt)
@@ -842,7 +859,8 @@ def estimate_color_gradients(points, normals, colors, indices, counts):
     g = np.zeros((n, 3), dt)
     lib().orc_estimate_color_gradients(
         _p(points), _p(normals), _p(colors), _p(indices), _p(counts),
-        C.c_int64(n), int(max_nn), int(dt == np.float64), _p(g))
+        C.c_int64(n), int(max_nn), int(dt == np.float64), int(exact_solve),
+        _p(g))
     return g
 
 

@@ -485,6 +485,24 @@ def estimate_covariances(points, indices, counts):
     return cov
 
 
+def svd3x3(A):
+    A = np.ascontiguousarray(A)
+    U, S, V = np.zeros((3, 3), A.dtype), np.zeros(3, A.dtype), \
+        np.zeros((3, 3), A.dtype)
+    _check(lib().ref_svd3x3(_p(A), int(A.dtype == np.float64), _p(U), _p(S),
+                            _p(V)), "svd3x3")
+    return U, S, V
+
+
+def solve_svd3x3(A, b):
+    A = np.ascontiguousarray(A)
+    b = np.ascontiguousarray(b, dtype=A.dtype)
+    x = np.zeros(3, A.dtype)
+    _check(lib().ref_solve_svd3x3(_p(A), _p(b), int(A.dtype == np.float64),
+                                  _p(x)), "solve_svd3x3")
+    return x
+
+
 def estimate_color_gradients(points, normals, colors, indices, counts):
     points = np.ascontiguousarray(points)
     dt = points.dtype

@@ -750,16 +750,21 @@ def _colored_pair(n, seed, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_color_gradients_parity(dtype):
-    """EstimateColorGradients: the per-point kernel on given neighbour lists
-    (same arithmetic as the oracle: bit-exact), then the operator with hybrid
-    and with KNN search."""
+@pytest.mark.parametrize("exact", [False, True])
+def test_color_gradients_parity(dtype, exact, monkeypatch):
+    """EstimateColorGradients: the per-point kernel on given neighbour lists,
+    then the operator with hybrid and with KNN search. Default = the
+    reference's solve_svd3x3 restated (bit for bit; Float64 NaN positions
+    equal -- the reference's Float64 path produces them), exact = the exact
+    normal-equation solve behind O3DMI_EXACT_COLOR_GRADIENTS=1."""
     _lib, reg = _gpu()
     from open3d_amd.core import TORCH_TO_O3DMI, stream
+    monkeypatch.setenv("O3DMI_EXACT_COLOR_GRADIENTS", "1" if exact else "0")
     p, _, tc = _colored_pair(8000, 51, dtype)
     pts, nrm = p["target"], p["target_normals"]
     idx, _, cnt = orc.hybrid_search(pts, pts, 0.15, 30)
-    want = orc.estimate_color_gradients(pts, nrm, tc, idx, cnt)
+    want = orc.estimate_color_gradients(pts, nrm, tc, idx, cnt,
+                                        exact_solve=exact)
     tp, tn, tcol = (torch.from_numpy(a).cuda() for a in (pts, nrm, tc))
     g = torch.zeros_like(tp)
     tidx, tcnt = torch.from_numpy(idx).cuda(), torch.from_numpy(cnt).cuda()
@@ -768,17 +773,21 @@ def test_color_gradients_parity(dtype):
         _lib.ptr(tcnt), tp.shape[0], 30,
         TORCH_TO_O3DMI[tp.dtype], _lib.ptr(g), stream()), "gradients")
     torch.cuda.synchronize()
-    assert g.cpu().numpy().tobytes() == want.tobytes()
+    assert np.array_equal(g.cpu().numpy(), want, equal_nan=True)
+    if exact or dtype == np.float32:
+        assert not np.isnan(want).any()
     got = reg.estimate_color_gradients(tp, tn, tcol, 30, 0.15).cpu().numpy()
-    assert got.tobytes() == want.tobytes()
+    assert np.array_equal(got, want, equal_nan=True)
     kidx, _ = orc.knn_search(pts, pts, 30)
     kwant = orc.estimate_color_gradients(pts, nrm, tc, kidx,
-                                         np.full(pts.shape[0], 30, np.int32))
+                                         np.full(pts.shape[0], 30, np.int32),
+                                         exact_solve=exact)
     kgot = reg.estimate_color_gradients(tp, tn, tcol, 30).cpu().numpy()
-    assert kgot.tobytes() == kwant.tobytes()
-    # the gradient of a smooth colour field lies in the tangent plane
-    dots = np.abs((got * nrm).sum(1))[cnt >= 10]
-    assert np.median(dots) < 1e-3
+    assert np.array_equal(kgot, kwant, equal_nan=True)
+    if exact:
+        # the gradient of a smooth colour field lies in the tangent plane
+        dots = np.abs((got * nrm).sum(1))[cnt >= 10]
+        assert np.median(dots) < 1e-3
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -791,7 +800,7 @@ def test_colored_accumulate_parity(dtype, kernel):
     corr = idx[:, 0].astype(np.int64)
     nidx, _, ncnt = orc.hybrid_search(p["target"], p["target"], 0.15, 30)
     tg = orc.estimate_color_gradients(p["target"], p["target_normals"], tc,
-                                      nidx, ncnt)
+                                      nidx, ncnt, exact_solve=True)
     want = orc.colored_accumulate(p["source"], sc, p["target"],
                                   p["target_normals"], tc, tg, corr, 0.968,
                                   *kernel, accumulate_double=True)
@@ -817,12 +826,15 @@ def test_icp_colored_pose_parity(dtype, given_gradients):
     colour gradients estimated by the driver (radius = 2 max distance) or
     handed in."""
     _lib, reg = _gpu()
+    if dtype == np.float64 and not given_gradients:
+        pytest.skip("the reference's Float64 solve_svd3x3 yields NaN "
+                    "gradients (reproduced); Float64 runs on given gradients")
     p, sc, tc = _colored_pair(20000, 4, dtype)
     tg = None
     if given_gradients:
         nidx, _, ncnt = orc.hybrid_search(p["target"], p["target"], 0.1, 30)
         tg = orc.estimate_color_gradients(p["target"], p["target_normals"],
-                                          tc, nidx, ncnt)
+                                          tc, nidx, ncnt, exact_solve=True)
     want = orc.multiscale_icp(p["source"], p["target"], p["target_normals"],
                               [-1.0], [(1e-6, 1e-6, 30)], [0.07],
                               accumulate_double=True, estimation=3,
