@@ -27,7 +27,10 @@
 // EvaluateRegistration and GetInformationMatrix (Registration.cpp:64-91,
 // 446-486) at the end of this file.
 
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <initializer_list>
 #include <limits>
@@ -327,6 +330,20 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         L.tgtg_ptr = L.tgtg.p;
     }
 
+    const bool timing = std::getenv("O3DMI_ICP_TIMING") != nullptr;
+    auto now = [] {
+        return std::chrono::duration<double, std::micro>(
+                       std::chrono::steady_clock::now().time_since_epoch())
+                .count();
+    };
+    double t_mark = 0;
+    if (timing) {
+        (void)hipStreamSynchronize(s);
+        t_mark = now();
+        std::fprintf(stderr, "[o3dmi] icp: pyramid built\n");
+    }
+    const double t_start = t_mark;
+
     // Per-iteration sums arrive through the thread's host mailbox: the final
     // reduction kernel writes them into host-mapped memory and bumps a
     // sequence word the host spins on (no copy / stream synchronise call).
@@ -399,6 +416,16 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
             (st = o3dmi_nns_set_normals(guard.nns, L.nrm_ptr, stream)))
             return st;
 
+        if (timing) {
+            (void)hipStreamSynchronize(s);
+            const double t = now();
+            std::fprintf(stderr,
+                         "[o3dmi] icp: scale %d (ns %lld nt %lld) index + "
+                         "transform %.0f us\n",
+                         scale_idx, (long long)L.ns, (long long)L.nt,
+                         t - t_mark);
+            t_mark = t;
+        }
         // DoSingleScaleICPIterations :275-360
         double prev_fitness = fitness, prev_inlier_rmse = inlier_rmse;
         converged = false;
@@ -528,6 +555,14 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         }
         iteration_count += it;
         (void)no_corr;
+        if (timing) {
+            (void)hipStreamSynchronize(s);
+            const double t = now();
+            std::fprintf(stderr,
+                         "[o3dmi] icp: scale %d %d iterations %.0f us\n",
+                         scale_idx, it, t - t_mark);
+            t_mark = t;
+        }
 
         if (scale_idx == num_scales - 1) {
             // Final fitness / rmse for the stored transformation :424-431
@@ -545,6 +580,9 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         }
     }
 
+    if (timing)
+        std::fprintf(stderr, "[o3dmi] icp: after pyramid %.0f us in total\n",
+                     now() - t_start);
     std::memcpy(result->transformation, T, sizeof(T));
     result->fitness = fitness;
     result->inlier_rmse = inlier_rmse;
