@@ -1,25 +1,19 @@
-// Point-to-plane ICP kernels for MI355X.
+// ICP estimator kernels for MI355X.
 //
-//   o3dmi_nns_create              <- BuildSpatialHashTableCUDA (core/nns/FixedRadiusIndex.h:227-233,
-//                                    FixedRadiusSearchImpl.cuh:63-135,732-824)
-//   o3dmi_nns_hybrid_search_k1    <- HybridSearchCUDA (FixedRadiusIndex.h:364-377,
-//                                    FixedRadiusSearchImpl.cuh:514-632) with the CPU path's
-//                                    nanoflann semantics (core/nns/NanoFlannImpl.h:305-370)
 //   o3dmi_icp_p2plane_accumulate  <- ComputePosePointToPlaneCUDA (t/pipelines/kernel/
 //                                    RegistrationCUDA.cu:29-117, RegistrationImpl.h:251-287)
+//   o3dmi_icp_{p2point,symmetric,colored,information}_accumulate
+//                                 <- the other reductions of RegistrationCUDA.cu /
+//                                    RegistrationCPU.cpp:124-340,495-735
 //   o3dmi_icp_search_accumulate   fused search + fitness/rmse sums + accumulation
 //   o3dmi_transform_points/normals<- TransformPointsCUDA/TransformNormalsCUDA
 //                                    (t/geometry/kernel/TransformImpl.h:19-60)
-//   o3dmi_decode_and_solve6x6, o3dmi_pose_to_transformation (host)
-//                                 <- TransformationConverter.cpp:81-104,189-226
+//   o3dmi_decode_and_solve6x6, o3dmi_pose_to_transformation,
+//   o3dmi_compute_rt_p2point, o3dmi_symmetric_pose_to_transformation (host)
+//                                 <- TransformationConverter.cpp:81-133,189-226,
+//                                    RegistrationCPU.cpp:640-650
 //
-// Index design (new): a bucketed uniform grid with cell edge = radius*(1+1e-3).
-// Target points are *reordered* by bucket into 16-byte (32-byte for f64)
-// records {x,y,z,original index}, normals likewise, so a query's 27 cell
-// visits read contiguous memory instead of chasing a CSR index through 12-byte
-// AoS points. Cell coordinates are computed in float64 on both the build and
-// the query side so that large-offset clouds (1000 m + 5 cm radius, cf.
-// cpp/tests/core/NearestNeighborSearch.cpp:831-869) bin consistently.
+// The search index (nns.h, nns.hip) is shared with the stand-alone searches.
 //
 // Reduction design (new): a fixed persistent grid; each lane keeps the 29 (+2)
 // sums in float64 registers, a wave64 __shfl_down tree, one LDS stage per
@@ -35,822 +29,12 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "common.h"
+#include "nns.h"
 #include "mailbox.h"
 #include "reduce_sums.h"
 
 namespace o3dmi {
 namespace {
-
-constexpr int kNumSums = 32;  // 29 + sum d2 + match count + pad
-
-template <typename T> struct Rec4;  // {x,y,z,w}
-template <> struct alignas(16) Rec4<float> { float x, y, z; int w; };
-template <> struct alignas(32) Rec4<double> { double x, y, z; long long w; };
-
-__device__ __forceinline__ unsigned HashCell(long long cx, long long cy,
-                                             long long cz) {
-    unsigned long long k = (unsigned long long)cx * 0x9E3779B97F4A7C15ull;
-    k ^= (unsigned long long)cy * 0xC2B2AE3D27D4EB4Full + (k >> 29);
-    k ^= (unsigned long long)cz * 0x165667B19E3779F9ull + (k << 17);
-    return HashKey(k);
-}
-
-template <typename T>
-__device__ __forceinline__ void CellOf(const T* p, double inv_cell,
-                                       long long& cx, long long& cy,
-                                       long long& cz) {
-    cx = (long long)floor((double)p[0] * inv_cell);
-    cy = (long long)floor((double)p[1] * inv_cell);
-    cz = (long long)floor((double)p[2] * inv_cell);
-}
-
-// K1: bucket histogram.
-template <typename T>
-__global__ void CountKernel(const T* __restrict__ pts, int64_t n,
-                            double inv_cell, unsigned mask,
-                            unsigned* __restrict__ counts) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        long long cx, cy, cz;
-        CellOf(pts + 3 * i, inv_cell, cx, cy, cz);
-        atomicAdd(&counts[HashCell(cx, cy, cz) & mask], 1u);
-    }
-}
-
-// K2: exclusive scan in three passes (1024 elements per workgroup).
-constexpr int kScanBlock = 256;
-constexpr int kScanItems = 4;
-__global__ void ScanLocalKernel(const unsigned* __restrict__ in,
-                                unsigned* __restrict__ out,
-                                unsigned* __restrict__ block_sums, int64_t n) {
-    __shared__ unsigned lds[kScanBlock];
-    int64_t base = (int64_t)blockIdx.x * kScanBlock * kScanItems;
-    unsigned v[kScanItems];
-    unsigned sum = 0;
-#pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        int64_t i = base + (int64_t)threadIdx.x * kScanItems + k;
-        v[k] = i < n ? in[i] : 0u;
-        sum += v[k];
-    }
-    lds[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < kScanBlock; off <<= 1) {
-        unsigned t = threadIdx.x >= off ? lds[threadIdx.x - off] : 0u;
-        __syncthreads();
-        lds[threadIdx.x] += t;
-        __syncthreads();
-    }
-    unsigned excl = lds[threadIdx.x] - sum;
-    if (threadIdx.x == kScanBlock - 1) block_sums[blockIdx.x] = lds[threadIdx.x];
-#pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        int64_t i = base + (int64_t)threadIdx.x * kScanItems + k;
-        if (i < n) out[i] = excl;
-        excl += v[k];
-    }
-}
-__global__ void ScanBlockSumsKernel(unsigned* block_sums, int n_blocks) {
-    // single workgroup, sequential over chunks of 256
-    __shared__ unsigned lds[kScanBlock];
-    __shared__ unsigned carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < n_blocks; base += kScanBlock) {
-        int i = base + threadIdx.x;
-        unsigned v = i < n_blocks ? block_sums[i] : 0u;
-        lds[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < kScanBlock; off <<= 1) {
-            unsigned t = threadIdx.x >= off ? lds[threadIdx.x - off] : 0u;
-            __syncthreads();
-            lds[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < n_blocks) block_sums[i] = carry + lds[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == kScanBlock - 1) carry += lds[threadIdx.x];
-        __syncthreads();
-    }
-}
-__global__ void ScanAddKernel(unsigned* __restrict__ out,
-                              const unsigned* __restrict__ block_sums,
-                              int64_t n) {
-    int64_t base = (int64_t)blockIdx.x * kScanBlock * kScanItems;
-    unsigned add = block_sums[blockIdx.x];
-#pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        int64_t i = base + (int64_t)threadIdx.x * kScanItems + k;
-        if (i < n) out[i] += add;
-    }
-}
-
-// K3: scatter points into bucket order as {x,y,z,idx} records.
-template <typename T>
-__global__ void ScatterKernel(const T* __restrict__ pts, int64_t n,
-                              double inv_cell, unsigned mask,
-                              const unsigned* __restrict__ starts,
-                              unsigned* __restrict__ cursor,
-                              Rec4<T>* __restrict__ sorted) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        long long cx, cy, cz;
-        CellOf(pts + 3 * i, inv_cell, cx, cy, cz);
-        unsigned b = HashCell(cx, cy, cz) & mask;
-        unsigned pos = starts[b] + atomicAdd(&cursor[b], 1u);
-        Rec4<T> r;
-        r.x = pts[3 * i + 0];
-        r.y = pts[3 * i + 1];
-        r.z = pts[3 * i + 2];
-        r.w = i;
-        sorted[pos] = r;
-    }
-}
-
-template <typename T>
-__device__ __forceinline__ int RecIndex(const Rec4<T>& r) {
-    return (int)r.w;
-}
-
-// Gather an {N,3} attribute (normals) into sorted record order.
-template <typename T>
-__global__ void GatherAttrKernel(const T* __restrict__ attr,
-                                 const Rec4<T>* __restrict__ sorted_pts,
-                                 int64_t n, Rec4<T>* __restrict__ out) {
-    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n;
-         j += (int64_t)gridDim.x * blockDim.x) {
-        int64_t i = RecIndex(sorted_pts[j]);
-        Rec4<T> r;
-        r.x = attr[3 * i + 0];
-        r.y = attr[3 * i + 1];
-        r.z = attr[3 * i + 2];
-        r.w = 0;
-        out[j] = r;
-    }
-}
-
-template <typename T>
-struct NnsView {
-    const Rec4<T>* sorted;      // [n] bucket-ordered {x,y,z,idx}
-    const unsigned* starts;     // [n_buckets + 1]
-    double inv_cell;
-    unsigned mask;
-    T radius_squared;
-};
-
-// Nearest neighbour with d2 < r2 (strict), ties -> lowest original index.
-// Returns the position in the sorted array (or -1); idx/d2 by reference.
-// Distance arithmetic: nanoflann::L2_Adaptor::evalMetric for dim 3,
-// ((dx*dx) + dy*dy) + dz*dz with dx = query - point, in T.
-template <typename T>
-__device__ __forceinline__ int SearchNearest(const NnsView<T>& nv, const T* q,
-                                             int& best_idx, T& best_d2) {
-    long long cx, cy, cz;
-    CellOf(q, nv.inv_cell, cx, cy, cz);
-    int best_pos = -1;
-    best_idx = -1;
-    best_d2 = 0;
-    const T qx = q[0], qy = q[1], qz = q[2];
-    for (int dz = -1; dz <= 1; ++dz)
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dx = -1; dx <= 1; ++dx) {
-                unsigned b = HashCell(cx + dx, cy + dy, cz + dz) & nv.mask;
-                unsigned s = nv.starts[b], e = nv.starts[b + 1];
-                for (unsigned j = s; j < e; ++j) {
-                    Rec4<T> p = nv.sorted[j];
-                    T result = T(0);
-                    const T d0 = qx - p.x;
-                    result += d0 * d0;
-                    const T d1 = qy - p.y;
-                    result += d1 * d1;
-                    const T d2 = qz - p.z;
-                    result += d2 * d2;
-                    if (result < nv.radius_squared) {
-                        int idx = RecIndex(p);
-                        if (best_pos < 0 || result < best_d2 ||
-                            (result == best_d2 && idx < best_idx)) {
-                            best_pos = (int)j;
-                            best_idx = idx;
-                            best_d2 = result;
-                        }
-                    }
-                }
-            }
-    return best_pos;
-}
-
-template <typename T>
-__global__ void HybridSearchK1Kernel(NnsView<T> nv, const T* __restrict__ q,
-                                     int64_t nq, int* __restrict__ idx_out,
-                                     T* __restrict__ d2_out,
-                                     int* __restrict__ cnt_out) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nq;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        T qq[3] = {q[3 * i + 0], q[3 * i + 1], q[3 * i + 2]};
-        int idx;
-        T d2;
-        int pos = SearchNearest(nv, qq, idx, d2);
-        if (idx_out) idx_out[i] = pos >= 0 ? idx : -1;
-        if (d2_out) d2_out[i] = pos >= 0 ? d2 : T(0);
-        if (cnt_out) cnt_out[i] = pos >= 0 ? 1 : 0;
-    }
-}
-
-constexpr int kMaxKnn = 64;  // general-k searches: k <= one wave
-
-// ---- general-k searches: one wave per query --------------------------------
-// A lane-per-query search keeps a sorted k-list per lane and pays a dependent
-// chain of ~2 loads per neighbour cell plus an insertion shift per candidate,
-// with the 64 lanes of a wave diverging on every one of them (2.7 ms for
-// 100 k queries at k = 30 even with the lists in LDS). Here a wave serves one
-// query:
-//   * lane c looks up neighbour cell c (bucket bounds), a wave prefix sum
-//     turns the per-cell counts into one candidate range, and lane t fetches
-//     candidate t (owner cell found by a 6-step search over the prefix) --
-//     two memory round trips for any number of cells. A record is accepted
-//     only if its own cell is the cell it was fetched for, so records that
-//     merely share the bucket (hash collisions) never show up twice;
-//   * accepted candidates are compacted into an LDS buffer of the wave;
-//   * the k best are found by rank counting: candidate p reads every buffered
-//     candidate q (a broadcast LDS read) and counts those that sort before it
-//     by (d2, index); rank < k means "rank-th neighbour". No dependent chain,
-//     no divergence, ties impossible because indices are unique.
-constexpr int kCoopCap = 512;    // buffered candidates per wave before a merge
-constexpr int kCoopBlock = 256;  // 4 waves = 4 queries in flight per workgroup
-constexpr int kNoIndex = 0x7fffffff;
-
-template <typename T>
-__device__ __forceinline__ T InfOf() { return (T)INFINITY; }
-
-template <typename T>
-__device__ __forceinline__ bool PairLess(T ad, int ai, T bd, int bi) {
-    return ad < bd || (ad == bd && ai < bi);
-}
-
-__device__ __forceinline__ void WaveLdsSync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// Buffer rows: kCoopCap, + one more batch of 64 (the merge is triggered after
-// the batch that crosses kCoopCap), + the current list of <= 64 entries that
-// competes again in a merge; then the 64 ranked rows.
-constexpr int kCoopRows = kCoopCap + 128;
-
-template <typename T>
-constexpr size_t CoopLdsBytesPerWave() {
-    return (sizeof(T) + sizeof(int)) * (size_t)(kCoopRows + 64);
-}
-
-template <typename T> struct Quad;
-template <> struct Quad<float> { using type = float4; };
-template <> struct Quad<double> { using type = double4; };
-
-template <typename T>
-struct WaveTopK {
-    T* cd;       // LDS: candidates [kCoopRows], then ranked list [64]
-    int* ci;
-    T* rd;
-    int* ri;
-    int m;       // buffered candidates (wave-uniform)
-    T best_d;    // rank = lane, valid for lane < nbest
-    int best_i;
-    int nbest;   // wave-uniform
-    int knn;
-    T kth_d;     // the k-th entry once nbest == knn (wave-uniform)
-    int kth_i;
-
-    __device__ __forceinline__ void Init(char* lds) {
-        char* base = lds + CoopLdsBytesPerWave<T>() * (threadIdx.x >> 6);
-        cd = (T*)base;
-        rd = cd + kCoopRows;
-        ci = (int*)(rd + 64);
-        ri = ci + kCoopRows;
-    }
-
-    __device__ __forceinline__ void Reset(int k) {
-        m = 0;
-        best_d = InfOf<T>();
-        best_i = kNoIndex;
-        nbest = 0;
-        knn = k;
-        kth_d = InfOf<T>();
-        kth_i = kNoIndex;
-    }
-
-    // Candidate of this lane (kNoIndex = none).
-    __device__ __forceinline__ void Push(T d, int i, T, T, T) { Push(d, i); }
-    __device__ __forceinline__ void Push(T d, int i) {
-        // what cannot make the list any more is dropped here
-        bool valid = i != kNoIndex;
-        if (valid && nbest == knn && !PairLess(d, i, kth_d, kth_i)) valid = false;
-        const unsigned long long mask = __builtin_amdgcn_ballot_w64(valid);
-        if (mask == 0) return;
-        const int lane = threadIdx.x & 63;
-        const int at = m + __popcll(mask & ((1ull << lane) - 1ull));
-        if (valid) {
-            cd[at] = d;
-            ci[at] = i;
-        }
-        m += __popcll(mask);
-        if (m > kCoopCap) Select();  // room for one more batch of 64 is kept
-    }
-
-    __device__ __forceinline__ void Flush() {
-        if (m > 0) Select();
-    }
-
-    // Merge the buffer into the ranked list.
-    __device__ __forceinline__ void Select() {
-        const int lane = threadIdx.x & 63;
-        // the current list competes again
-        int total = m;
-        if (lane < nbest) {
-            cd[total + lane] = best_d;
-            ci[total + lane] = best_i;
-        }
-        total += nbest;
-        // pad to whole quads with entries that sort after everything
-        const int padded = (total + 3) & ~3;
-        if (lane < padded - total) {
-            cd[total + lane] = InfOf<T>();
-            ci[total + lane] = kNoIndex;
-        }
-        WaveLdsSync();
-        using Q = typename Quad<T>::type;
-        // two candidates per lane per pass over the buffer (quad LDS reads,
-        // every lane reads the same address: broadcast)
-        for (int p0 = 0; p0 < total; p0 += 128) {
-            const int pa = p0 + lane, pb = p0 + 64 + lane;
-            const bool ha = pa < total, hb = pb < total;
-            const T a_d = ha ? cd[pa] : InfOf<T>();
-            const int a_i = ha ? ci[pa] : kNoIndex;
-            const T b_d = hb ? cd[pb] : InfOf<T>();
-            const int b_i = hb ? ci[pb] : kNoIndex;
-            int ra = 0, rb = 0;
-#pragma unroll 2
-            for (int qi = 0; qi < padded; qi += 4) {
-                const Q d4 = *(const Q*)(cd + qi);
-                const int4 i4 = *(const int4*)(ci + qi);
-                ra += (PairLess(d4.x, i4.x, a_d, a_i) ? 1 : 0) +
-                      (PairLess(d4.y, i4.y, a_d, a_i) ? 1 : 0) +
-                      (PairLess(d4.z, i4.z, a_d, a_i) ? 1 : 0) +
-                      (PairLess(d4.w, i4.w, a_d, a_i) ? 1 : 0);
-                rb += (PairLess(d4.x, i4.x, b_d, b_i) ? 1 : 0) +
-                      (PairLess(d4.y, i4.y, b_d, b_i) ? 1 : 0) +
-                      (PairLess(d4.z, i4.z, b_d, b_i) ? 1 : 0) +
-                      (PairLess(d4.w, i4.w, b_d, b_i) ? 1 : 0);
-            }
-            if (ha && ra < knn) {
-                rd[ra] = a_d;
-                ri[ra] = a_i;
-            }
-            if (hb && rb < knn) {
-                rd[rb] = b_d;
-                ri[rb] = b_i;
-            }
-        }
-        WaveLdsSync();
-        nbest = total < knn ? total : knn;
-        best_d = lane < nbest ? rd[lane] : InfOf<T>();
-        best_i = lane < nbest ? ri[lane] : kNoIndex;
-        if (nbest == knn) {
-            kth_d = rd[knn - 1];
-            kth_i = ri[knn - 1];
-        }
-        WaveLdsSync();
-        m = 0;
-    }
-};
-
-// Candidates of the cells [x0..x1] x [y0..y1] x [z0..z1] whose Chebyshev cell
-// distance to (cx, cy, cz) is >= r_skip. RADIUS: keep d2 < nv.radius_squared.
-// Sink::Push(d2, index, x, y, z) receives every lane's candidate of a batch
-// (index == kNoIndex: none).
-template <typename T, bool RADIUS, typename Sink>
-__device__ __forceinline__ void GatherCells(const NnsView<T>& nv, const T* qq,
-                                            long long cx, long long cy,
-                                            long long cz, long long x0,
-                                            long long x1, long long y0,
-                                            long long y1, long long z0,
-                                            long long z1, long long r_skip,
-                                            Sink& list) {
-    if (x1 < x0 || y1 < y0 || z1 < z0) return;
-    const int lane = threadIdx.x & 63;
-    const int nx = (int)(x1 - x0 + 1), ny = (int)(y1 - y0 + 1);
-    const int nz = (int)(z1 - z0 + 1);
-    const int ncell = nx * ny * nz;
-    for (int base = 0; base < ncell; base += 64) {
-        const int ci = base + lane;
-        unsigned s0 = 0, cnt = 0;
-        if (ci < ncell) {
-            const long long x = x0 + ci % nx, y = y0 + (ci / nx) % ny,
-                            z = z0 + ci / (nx * ny);
-            long long ax = x - cx, ay = y - cy, az = z - cz;
-            ax = ax < 0 ? -ax : ax;
-            ay = ay < 0 ? -ay : ay;
-            az = az < 0 ? -az : az;
-            const long long cheb = max(ax, max(ay, az));
-            if (cheb >= r_skip) {
-                const unsigned b = HashCell(x, y, z) & nv.mask;
-                s0 = nv.starts[b];
-                cnt = nv.starts[b + 1] - s0;
-            }
-        }
-        unsigned incl = cnt;
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-            const unsigned o = __shfl_up(incl, m);
-            if (lane >= m) incl += o;
-        }
-        const unsigned total = __shfl(incl, 63);
-        const unsigned excl = incl - cnt;
-        for (unsigned t0 = 0; t0 < total; t0 += 64) {
-            const unsigned t = t0 + lane;
-            const unsigned tc = t < total ? t : total - 1;
-            // owner cell: number of lanes whose inclusive prefix is <= t
-            int pos = 0;
-#pragma unroll
-            for (int step = 32; step > 0; step >>= 1) {
-                const unsigned v = __shfl(incl, pos + step - 1);
-                if (v <= tc) pos += step;
-            }
-            const unsigned oe = __shfl(excl, pos);
-            const unsigned os = __shfl(s0, pos);
-            T d = InfOf<T>();
-            int pi = kNoIndex;
-            T px = T(0), py = T(0), pz = T(0);
-            if (t < total) {
-                const Rec4<T> p = nv.sorted[os + (t - oe)];
-                px = p.x;
-                py = p.y;
-                pz = p.z;
-                // the record's own cell must be the cell it was fetched for
-                const T pp[3] = {p.x, p.y, p.z};
-                long long rx, ry, rz;
-                CellOf(pp, nv.inv_cell, rx, ry, rz);
-                const bool own = rx >= x0 && rx <= x1 && ry >= y0 && ry <= y1 &&
-                                 rz >= z0 && rz <= z1 &&
-                                 (int)(rx - x0) + nx * ((int)(ry - y0) +
-                                                        ny * (int)(rz - z0)) ==
-                                         base + pos;
-                T result = T(0);
-                const T d0 = qq[0] - p.x;
-                result += d0 * d0;
-                const T d1 = qq[1] - p.y;
-                result += d1 * d1;
-                const T dd = qq[2] - p.z;
-                result += dd * dd;
-                if (own && (!RADIUS || result < nv.radius_squared)) {
-                    d = result;
-                    pi = RecIndex(p);
-                }
-            }
-            list.Push(d, pi, px, py, pz);
-        }
-    }
-}
-
-template <typename T>
-__device__ __forceinline__ void WriteTopK(const WaveTopK<T>& list, int64_t i,
-                                          int* __restrict__ idx_out,
-                                          T* __restrict__ d2_out,
-                                          int* __restrict__ cnt_out) {
-    const int lane = threadIdx.x & 63;
-    if (lane < list.knn) {
-        const bool ok = lane < list.nbest;
-        if (idx_out) idx_out[i * list.knn + lane] = ok ? list.best_i : -1;
-        if (d2_out) d2_out[i * list.knn + lane] = ok ? list.best_d : T(0);
-    }
-    if (cnt_out && lane == 0) cnt_out[i] = list.nbest;
-}
-
-// HybridSearch for general max_knn (core/nns/NanoFlannImpl.h:305-370 semantics:
-// neighbours with d2 < r2, ascending by (d2, index), the first max_knn kept;
-// idx padded with -1, dist with 0, count = min(found, max_knn)).
-template <typename T>
-__global__ void __launch_bounds__(kCoopBlock)
-HybridSearchKernel(NnsView<T> nv, const T* __restrict__ q, int64_t nq,
-                   int max_knn, int* __restrict__ idx_out,
-                   T* __restrict__ d2_out, int* __restrict__ cnt_out) {
-    extern __shared__ __align__(16) char coop_lds[];
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    WaveTopK<T> list;
-    list.Init(coop_lds);
-    for (int64_t i = wave; i < nq; i += n_waves) {
-        const T qq[3] = {q[3 * i + 0], q[3 * i + 1], q[3 * i + 2]};
-        list.Reset(max_knn);
-        long long cx, cy, cz;
-        CellOf(qq, nv.inv_cell, cx, cy, cz);
-        GatherCells<T, true>(nv, qq, cx, cy, cz, cx - 1, cx + 1, cy - 1, cy + 1,
-                             cz - 1, cz + 1, 0, list);
-        list.Flush();
-        WriteTopK(list, i, idx_out, d2_out, cnt_out);
-    }
-}
-
-// EstimateCovariancesUsingRadiusSearch (t/geometry/kernel/PointCloudImpl.h:
-// 641-689): every neighbour with d2 < r2, no cap. One wave per point, two
-// sweeps over the 27 cells: count + centroid, then the six cumulants about it
-// (EstimatePointWiseRobustNormalizedCovarianceKernel, :512-585, float64 sums).
-// The reference adds the neighbours one by one in ascending distance; the wave
-// adds them in parallel, so the float64 sums can differ in their last bits
-// (the stored covariance is their rounding to the point dtype).
-template <typename T>
-struct MomentSink {
-    double acc[6];
-    double c[3];
-    int count;
-    bool second;
-    __device__ __forceinline__ void Push(T, int i, T x, T y, T z) {
-        if (i == kNoIndex) return;
-        if (!second) {
-            acc[0] += (double)x;
-            acc[1] += (double)y;
-            acc[2] += (double)z;
-            ++count;
-        } else {
-            const double dx = (double)x - c[0], dy = (double)y - c[1],
-                         dz = (double)z - c[2];
-            acc[0] += dx * dx;
-            acc[1] += dy * dy;
-            acc[2] += dz * dz;
-            acc[3] += dx * dy;
-            acc[4] += dx * dz;
-            acc[5] += dy * dz;
-        }
-    }
-    __device__ __forceinline__ void WaveSum(int n) {
-        for (int k = 0; k < n; ++k)
-#pragma unroll
-            for (int m = 32; m > 0; m >>= 1) acc[k] += __shfl_xor(acc[k], m);
-    }
-};
-
-template <typename T>
-__global__ void __launch_bounds__(kCoopBlock)
-RadiusCovariancesKernel(NnsView<T> nv, const T* __restrict__ q, int64_t nq,
-                        T* __restrict__ covariances) {
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    for (int64_t i = wave; i < nq; i += n_waves) {
-        const T qq[3] = {q[3 * i + 0], q[3 * i + 1], q[3 * i + 2]};
-        long long cx, cy, cz;
-        CellOf(qq, nv.inv_cell, cx, cy, cz);
-        MomentSink<T> sink;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) sink.acc[k] = 0;
-        sink.count = 0;
-        sink.second = false;
-        GatherCells<T, true>(nv, qq, cx, cy, cz, cx - 1, cx + 1, cy - 1, cy + 1,
-                             cz - 1, cz + 1, 0, sink);
-        sink.WaveSum(3);
-        int cnt = sink.count;
-#pragma unroll
-        for (int m = 32; m > 0; m >>= 1) cnt += __shfl_xor(cnt, m);
-        T* cov = covariances + 9 * i;
-        if (cnt < 3) {
-            if (lane < 9) cov[lane] = (lane % 4 == 0) ? T(1.0) : T(0.0);
-            continue;
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) sink.c[k] = sink.acc[k] / cnt;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) sink.acc[k] = 0;
-        sink.second = true;
-        GatherCells<T, true>(nv, qq, cx, cy, cz, cx - 1, cx + 1, cy - 1, cy + 1,
-                             cz - 1, cz + 1, 0, sink);
-        sink.WaveSum(6);
-        if (lane == 0) {
-            const double nf = (double)(cnt - 1);
-            double cm[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) cm[k] = sink.acc[k] / nf;
-            cov[0] = (T)cm[0];
-            cov[4] = (T)cm[1];
-            cov[8] = (T)cm[2];
-            cov[1] = (T)cm[3];
-            cov[3] = cov[1];
-            cov[2] = (T)cm[4];
-            cov[6] = cov[2];
-            cov[5] = (T)cm[5];
-            cov[7] = cov[5];
-        }
-    }
-}
-
-// ---- k nearest neighbours without a radius (KnnIndex / KnnSearch) ----------
-// NearestNeighborSearch::KnnSearch semantics (core/nns/NanoFlannImpl.h:
-// _KnnSearchCPU, nanoflann KNNResultSet): the min(knn, N) nearest points,
-// ascending by distance (ties by lower index here; nanoflann's tie order
-// depends on its tree traversal). The reference's GPU path is a brute-force
-// distance matrix + block select (core/nns/KnnSearchOps.cu); points in 3-D do
-// better on the same bucketed grid as the radius index, searched in growing
-// cubic shells: after shell r every unvisited point is farther than
-// r * cell + (distance from the query to the nearest face of its own cell),
-// so the walk stops as soon as the k-th distance is below that bound. The
-// cell size is chosen by the host so that an occupied cell holds ~knn / 2
-// points (shells 0 and 1 then usually suffice).
-// A query in a sparse region would walk thousands of empty shells on a single
-// fine grid, so the index is a pyramid: level l has cells 4^l times the finest;
-// a level is searched for at most kKnnShells shells, then the walk restarts on
-// the next coarser level (the list starts over there). The
-// coarsest level spans the whole cloud in a handful of cells and is searched
-// exhaustively.
-template <typename T>
-struct KnnGrid {
-    NnsView<T> nv;
-    double cell;
-    long long cmin[3], cmax[3];  // occupied cell box
-};
-
-constexpr int kKnnMaxLevels = 12;
-constexpr int kKnnShells = 2;
-
-template <typename T>
-struct KnnPyramid {
-    int n_levels;
-    int first_radius;  // cube radius of the first step on a level
-    int first_level;   // levels [first_level, n_levels) are walked
-    int exhaustive_last;  // the last level covers the cloud: search all of it
-    int brute;            // scan all n_points records instead of walking cells
-    int64_t n_points;
-    KnnGrid<T> level[kKnnMaxLevels];
-};
-
-template <typename T>
-__global__ void __launch_bounds__(kCoopBlock)
-__attribute__((amdgpu_waves_per_eu(4)))
-KnnSearchKernel(KnnPyramid<T> pyr, const T* __restrict__ q, int64_t nq, int knn,
-                const int* __restrict__ query_ids, int* __restrict__ retry_ids,
-                int* __restrict__ retry_count, int* __restrict__ idx_out,
-                T* __restrict__ d2_out, int* __restrict__ cnt_out) {
-    extern __shared__ __align__(16) char coop_lds[];
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    WaveTopK<T> list;
-    list.Init(coop_lds);
-    for (int64_t w = wave; w < nq; w += n_waves) {
-        // second pass: only the queries the finest level could not finish
-        const int64_t i = query_ids ? (int64_t)query_ids[w] : w;
-        const T qq[3] = {q[3 * i + 0], q[3 * i + 1], q[3 * i + 2]};
-        bool done = false;
-        if (pyr.brute) {
-            // few leftover queries: one coalesced sweep over the records, the
-            // k-th distance prunes almost every batch after the first merges
-            list.Reset(knn);
-            const Rec4<T>* rec = pyr.level[0].nv.sorted;
-            const int lane = threadIdx.x & 63;
-            constexpr int kAhead = 8;  // record loads in flight per lane
-            for (int64_t t0 = 0; t0 < pyr.n_points; t0 += 64 * kAhead) {
-                Rec4<T> p[kAhead];
-#pragma unroll
-                for (int u = 0; u < kAhead; ++u) {
-                    const int64_t t = t0 + 64 * u + lane;
-                    p[u] = rec[t < pyr.n_points ? t : pyr.n_points - 1];
-                }
-#pragma unroll
-                for (int u = 0; u < kAhead; ++u) {
-                    const int64_t t = t0 + 64 * u + lane;
-                    T result = T(0);
-                    const T d0 = qq[0] - p[u].x;
-                    result += d0 * d0;
-                    const T d1 = qq[1] - p[u].y;
-                    result += d1 * d1;
-                    const T dd = qq[2] - p[u].z;
-                    result += dd * dd;
-                    const bool in = t < pyr.n_points;
-                    list.Push(in ? result : InfOf<T>(),
-                              in ? RecIndex(p[u]) : kNoIndex);
-                }
-            }
-            list.Flush();
-            done = true;
-        }
-        for (int l = pyr.first_level; l < pyr.n_levels && !done; ++l) {
-            // a coarser level covers the finer one's cells again: start over
-            list.Reset(knn);
-            const KnnGrid<T>& g = pyr.level[l];
-            const bool last = pyr.exhaustive_last && l == pyr.n_levels - 1;
-            long long c[3];
-            CellOf(qq, g.nv.inv_cell, c[0], c[1], c[2]);
-            // distance to the nearest face of the query's own cell
-            double margin = g.cell;
-            long long r0 = 0, rmax = 0;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const double lo = (double)qq[a] - (double)c[a] * g.cell;
-                const double hi = (double)(c[a] + 1) * g.cell - (double)qq[a];
-                margin = fmin(margin, fmin(lo, hi));
-                const long long below = g.cmin[a] - c[a];
-                const long long above = c[a] - g.cmax[a];
-                r0 = max(r0, max(below, above));        // shells before the box
-                rmax = max(rmax, max(-below, -above));  // shell covering the box
-            }
-            // cell assignment rounds in float64: keep a small absolute slack
-            margin -= 1e-7 * g.cell;
-            if (!(margin > 0)) margin = 0;
-            if (last) {
-                // the whole occupied box in one step
-                GatherCells<T, false>(g.nv, qq, c[0], c[1], c[2], g.cmin[0],
-                                      g.cmax[0], g.cmin[1], g.cmax[1],
-                                      g.cmin[2], g.cmax[2], 0, list);
-                list.Flush();
-                done = true;
-                break;
-            }
-            if (r0 > kKnnShells) continue;  // the box is out of reach here
-            bool first = true;
-            for (long long r = r0 > pyr.first_radius ? r0 : pyr.first_radius;
-                 r <= kKnnShells; ++r) {
-                // first step: the whole cube of radius r (shells 0..r); then
-                // one shell at a time
-                GatherCells<T, false>(
-                        g.nv, qq, c[0], c[1], c[2], max(c[0] - r, g.cmin[0]),
-                        min(c[0] + r, g.cmax[0]), max(c[1] - r, g.cmin[1]),
-                        min(c[1] + r, g.cmax[1]), max(c[2] - r, g.cmin[2]),
-                        min(c[2] + r, g.cmax[2]), first ? 0 : r, list);
-                first = false;
-                list.Flush();
-                if (list.nbest == knn) {
-                    const double bound = (double)r * g.cell + margin;
-                    if ((double)list.kth_d < bound * bound * (1.0 - 1e-6)) {
-                        done = true;
-                        break;
-                    }
-                }
-                if (r >= rmax) {  // nothing of the box lies beyond: complete
-                    done = true;
-                    break;
-                }
-            }
-        }
-        if (!done) {
-            // first pass on the finest level only: leave it to the second
-            if (retry_ids && (threadIdx.x & 63) == 0)
-                retry_ids[atomicAdd(retry_count, 1)] = (int)i;
-            continue;
-        }
-        WriteTopK(list, i, idx_out, d2_out, cnt_out);
-    }
-}
-
-// Bounding box of a cloud, as order-preserving 64-bit keys of the float64
-// coordinates (atomicMin / atomicMax work on them).
-__device__ __forceinline__ unsigned long long OrderedKey(double v) {
-    unsigned long long u = (unsigned long long)__double_as_longlong(v);
-    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-}
-inline double FromOrderedKey(unsigned long long u) {
-    u = (u >> 63) ? (u & 0x7fffffffffffffffull) : ~u;
-    double v;
-    std::memcpy(&v, &u, sizeof(v));
-    return v;
-}
-
-template <typename T>
-__global__ void BoundsKernel(const T* __restrict__ pts, int64_t n,
-                             unsigned long long* __restrict__ mn,
-                             unsigned long long* __restrict__ mx) {
-    double lo[3] = {INFINITY, INFINITY, INFINITY};
-    double hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const double v = (double)pts[3 * i + a];
-            if (v < lo[a]) lo[a] = v;
-            if (v > hi[a]) hi[a] = v;
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        for (int m = 32; m > 0; m >>= 1) {
-            lo[a] = fmin(lo[a], __shfl_xor(lo[a], m));
-            hi[a] = fmax(hi[a], __shfl_xor(hi[a], m));
-        }
-        if ((threadIdx.x & 63) == 0) {
-            if (lo[a] <= hi[a]) {
-                atomicMin(&mn[a], OrderedKey(lo[a]));
-                atomicMax(&mx[a], OrderedKey(hi[a]));
-            }
-        }
-    }
-}
-
-__global__ void CountOccupiedKernel(const unsigned* __restrict__ starts,
-                                    int64_t n_buckets,
-                                    unsigned* __restrict__ occupied) {
-    unsigned local = 0;
-    for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-         b < n_buckets; b += (int64_t)gridDim.x * blockDim.x)
-        local += starts[b + 1] > starts[b] ? 1u : 0u;
-    for (int m = 32; m > 0; m >>= 1) local += __shfl_xor(local, m);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(occupied, local);
-}
 
 // ---- robust kernels ---------------------------------------------------------
 // RobustKernelImpl.h:35-126, literal: the double-typed literals promote parts
@@ -1397,432 +581,10 @@ int ReduceGrid(int64_t n) {
 
 using namespace o3dmi;
 
-struct o3dmi_nns {
-    int dtype = O3DMI_F32;
-    int64_t n = 0;
-    double radius = 0, inv_cell = 0;
-    int64_t n_buckets = 0;
-    void* sorted_pts = nullptr;      // Rec4<T>[n]
-    void* sorted_normals = nullptr;  // Rec4<T>[n], optional
-    unsigned* starts = nullptr;      // [n_buckets + 1]
-    double* partials = nullptr;      // [kCUs*4, kNumSums]
-};
-
-namespace {
-
-template <typename T>
-int BuildIndex(o3dmi_nns* nns, const T* pts, hipStream_t s) {
-    const int64_t n = nns->n;
-    int64_t nb = 1024;
-    while (nb < 2 * n && nb < (1ll << 27)) nb <<= 1;
-    nns->n_buckets = nb;
-    unsigned mask = (unsigned)(nb - 1);
-    unsigned *counts = nullptr, *cursor = nullptr, *block_sums = nullptr;
-    int64_t n_scan = nb + 1;
-    int n_scan_blocks =
-            (int)((n_scan + kScanBlock * kScanItems - 1) / (kScanBlock * kScanItems));
-    { int st_; if ((st_ = PoolAlloc((void**)&counts, sizeof(unsigned) * n_scan))) return st_; }
-    { int st_; if ((st_ = PoolAlloc((void**)&cursor, sizeof(unsigned) * nb))) return st_; }
-    { int st_; if ((st_ = PoolAlloc((void**)&block_sums, sizeof(unsigned) * (n_scan_blocks + 1)))) return st_; }
-    { int st_; if ((st_ = PoolAlloc((void**)&nns->starts, sizeof(unsigned) * n_scan))) return st_; }
-    { int st_; if ((st_ = PoolAlloc(&nns->sorted_pts, sizeof(Rec4<T>) * (size_t)(n > 0 ? n : 1)))) return st_; }
-    { int st_; if ((st_ = PoolAlloc((void**)&nns->partials, sizeof(double) * kCUs * 4 * kNumSums))) return st_; }
-    O3DMI_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(unsigned) * n_scan, s));
-    O3DMI_HIP_CHECK(hipMemsetAsync(cursor, 0, sizeof(unsigned) * nb, s));
-    if (n > 0) {
-        hipLaunchKernelGGL(CountKernel<T>, dim3(GridFor(n, kBlock)),
-                           dim3(kBlock), 0, s, pts, n, nns->inv_cell, mask,
-                           counts);
-    }
-    hipLaunchKernelGGL(ScanLocalKernel, dim3(n_scan_blocks), dim3(kScanBlock),
-                       0, s, counts, nns->starts, block_sums, n_scan);
-    hipLaunchKernelGGL(ScanBlockSumsKernel, dim3(1), dim3(kScanBlock), 0, s,
-                       block_sums, n_scan_blocks);
-    hipLaunchKernelGGL(ScanAddKernel, dim3(n_scan_blocks), dim3(kScanBlock), 0,
-                       s, nns->starts, block_sums, n_scan);
-    if (n > 0) {
-        hipLaunchKernelGGL(ScatterKernel<T>, dim3(GridFor(n, kBlock)),
-                           dim3(kBlock), 0, s, pts, n, nns->inv_cell, mask,
-                           nns->starts, cursor, (Rec4<T>*)nns->sorted_pts);
-    }
-    O3DMI_HIP_CHECK(hipGetLastError());
-    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
-    PoolFree(counts);
-    PoolFree(cursor);
-    PoolFree(block_sums);
-    return O3DMI_OK;
-}
-
-template <typename T>
-NnsView<T> MakeView(const o3dmi_nns* nns) {
-    NnsView<T> v;
-    v.sorted = (const Rec4<T>*)nns->sorted_pts;
-    v.starts = nns->starts;
-    v.inv_cell = nns->inv_cell;
-    v.mask = (unsigned)(nns->n_buckets - 1);
-    const T r = (T)nns->radius;  // NanoFlannImpl.h:332: T radius_squared
-    v.radius_squared = r * r;
-    return v;
-}
-
-template <typename T>
-int EnsureSortedNormals(o3dmi_nns* nns, const T* normals, hipStream_t s) {
-    if (!nns->sorted_normals)
-        { int st_; if ((st_ = PoolAlloc(&nns->sorted_normals, sizeof(Rec4<T>) * (size_t)(nns->n > 0 ? nns->n : 1)))) return st_; }
-    if (nns->n > 0)
-        hipLaunchKernelGGL(GatherAttrKernel<T>, dim3(GridFor(nns->n, kBlock)),
-                           dim3(kBlock), 0, s, normals,
-                           (const Rec4<T>*)nns->sorted_pts, nns->n,
-                           (Rec4<T>*)nns->sorted_normals);
-    O3DMI_HIP_CHECK(hipGetLastError());
-    return O3DMI_OK;
-}
-
-}  // namespace
-
-// Internal (not in the public header): attach target normals to an index so
-// that the fused search+accumulate kernel can gather them in bucket order.
 extern "C" int o3dmi_nns_set_normals(o3dmi_nns_t* nns, const void* normals_dev,
-                                     o3dmi_stream_t stream) {
-    O3DMI_REQUIRE(nns && normals_dev, "null argument");
-    if (nns->dtype == O3DMI_F64)
-        return EnsureSortedNormals<double>(nns, (const double*)normals_dev,
-                                           (hipStream_t)stream);
-    return EnsureSortedNormals<float>(nns, (const float*)normals_dev,
-                                      (hipStream_t)stream);
-}
+                                     o3dmi_stream_t stream);
 
 extern "C" {
-
-int o3dmi_nns_create(const void* points_dev, int64_t n, int dtype,
-                     double radius, o3dmi_stream_t stream, o3dmi_nns_t** out) {
-    O3DMI_REQUIRE(out != nullptr, "out is null");
-    O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
-                  "points must be Float32 or Float64");
-    O3DMI_REQUIRE(radius > 0, "radius must be positive");
-    O3DMI_REQUIRE(n >= 0 && n < (1ll << 31), "n out of range");
-    O3DMI_REQUIRE(n == 0 || points_dev != nullptr, "points is null");
-    auto* nns = new o3dmi_nns();
-    nns->dtype = dtype;
-    nns->n = n;
-    nns->radius = radius;
-    nns->inv_cell = 1.0 / (radius * 1.001);
-    int st = dtype == O3DMI_F64
-                     ? BuildIndex<double>(nns, (const double*)points_dev,
-                                          (hipStream_t)stream)
-                     : BuildIndex<float>(nns, (const float*)points_dev,
-                                         (hipStream_t)stream);
-    if (st != O3DMI_OK) {
-        o3dmi_nns_destroy(nns);
-        return st;
-    }
-    *out = nns;
-    return O3DMI_OK;
-}
-
-int o3dmi_nns_destroy(o3dmi_nns_t* nns) {
-    if (!nns) return O3DMI_OK;
-    // Searches on this index may still be in flight on any stream.
-    (void)hipDeviceSynchronize();
-    PoolFree(nns->sorted_pts);
-    PoolFree(nns->sorted_normals);
-    PoolFree(nns->starts);
-    PoolFree(nns->partials);
-    delete nns;
-    return O3DMI_OK;
-}
-
-int o3dmi_nns_hybrid_search_k1(const o3dmi_nns_t* nns, const void* queries_dev,
-                               int64_t q, int32_t* idx_dev, void* dist2_dev,
-                               int32_t* counts_dev, o3dmi_stream_t stream) {
-    O3DMI_REQUIRE(nns != nullptr, "index is null");
-    O3DMI_REQUIRE(q >= 0, "q < 0");
-    if (q == 0) return O3DMI_OK;
-    O3DMI_REQUIRE(queries_dev != nullptr, "queries is null");
-    hipStream_t s = (hipStream_t)stream;
-    dim3 grid(GridFor(q, kBlock)), block(kBlock);
-    if (nns->dtype == O3DMI_F64)
-        hipLaunchKernelGGL(HybridSearchK1Kernel<double>, grid, block, 0, s,
-                           MakeView<double>(nns), (const double*)queries_dev, q,
-                           idx_dev, (double*)dist2_dev, counts_dev);
-    else
-        hipLaunchKernelGGL(HybridSearchK1Kernel<float>, grid, block, 0, s,
-                           MakeView<float>(nns), (const float*)queries_dev, q,
-                           idx_dev, (float*)dist2_dev, counts_dev);
-    O3DMI_HIP_CHECK(hipGetLastError());
-    return O3DMI_OK;
-}
-
-int o3dmi_nns_hybrid_search(const o3dmi_nns_t* nns, const void* queries_dev,
-                            int64_t q, int max_knn, int32_t* idx_dev,
-                            void* dist2_dev, int32_t* counts_dev,
-                            o3dmi_stream_t stream) {
-    O3DMI_REQUIRE(nns != nullptr, "index is null");
-    O3DMI_REQUIRE(q >= 0, "q < 0");
-    O3DMI_REQUIRE(max_knn >= 1 && max_knn <= kMaxKnn,
-                  "max_knn must be in [1, 64]");
-    if (q == 0) return O3DMI_OK;
-    O3DMI_REQUIRE(queries_dev != nullptr, "queries is null");
-    hipStream_t s = (hipStream_t)stream;
-    // one wave per query
-    dim3 grid(GridFor(q, kCoopBlock / 64, kCUs * 16)), block(kCoopBlock);
-    if (nns->dtype == O3DMI_F64)
-        hipLaunchKernelGGL(HybridSearchKernel<double>, grid, block,
-                           CoopLdsBytesPerWave<double>() * (kCoopBlock / 64), s,
-                           MakeView<double>(nns), (const double*)queries_dev, q,
-                           max_knn, idx_dev, (double*)dist2_dev, counts_dev);
-    else
-        hipLaunchKernelGGL(HybridSearchKernel<float>, grid, block,
-                           CoopLdsBytesPerWave<float>() * (kCoopBlock / 64), s,
-                           MakeView<float>(nns), (const float*)queries_dev, q,
-                           max_knn, idx_dev, (float*)dist2_dev, counts_dev);
-    O3DMI_HIP_CHECK(hipGetLastError());
-    return O3DMI_OK;
-}
-
-// EstimateCovariancesUsingRadiusSearchCUDA: covariances {q,3,3} of all index
-// points within the index radius of every query.
-int o3dmi_nns_radius_covariances(const o3dmi_nns_t* nns, const void* queries_dev,
-                                 int64_t q, void* covariances_dev,
-                                 o3dmi_stream_t stream) {
-    O3DMI_REQUIRE(nns != nullptr, "index is null");
-    O3DMI_REQUIRE(q >= 0, "q < 0");
-    if (q == 0) return O3DMI_OK;
-    O3DMI_REQUIRE(queries_dev && covariances_dev, "null argument");
-    hipStream_t s = (hipStream_t)stream;
-    dim3 grid(GridFor(q, kCoopBlock / 64, kCUs * 16)), block(kCoopBlock);
-    if (nns->dtype == O3DMI_F64)
-        hipLaunchKernelGGL(RadiusCovariancesKernel<double>, grid, block, 0, s,
-                           MakeView<double>(nns), (const double*)queries_dev, q,
-                           (double*)covariances_dev);
-    else
-        hipLaunchKernelGGL(RadiusCovariancesKernel<float>, grid, block, 0, s,
-                           MakeView<float>(nns), (const float*)queries_dev, q,
-                           (float*)covariances_dev);
-    O3DMI_HIP_CHECK(hipGetLastError());
-    return O3DMI_OK;
-}
-
-namespace {
-
-// Everything a KnnSearch call owns; released on every exit path (the index
-// destructor drains the device first, so the pooled scratch is idle by then).
-struct KnnResources {
-    unsigned long long* box = nullptr;  // [0..2] min keys, [3..5] max, [6] count
-    int* retry = nullptr;               // [0] = count, [1..q] = query ids
-    std::vector<o3dmi_nns*> levels;     // finest first
-    ~KnnResources() {
-        for (o3dmi_nns* lv : levels) o3dmi_nns_destroy(lv);
-        PoolFree(box);
-        PoolFree(retry);
-    }
-    int AddLevel(const void* points, int64_t n, int dtype, double cell,
-                 hipStream_t s) {
-        auto* lv = new o3dmi_nns();
-        lv->dtype = dtype;
-        lv->n = n;
-        lv->radius = cell;
-        lv->inv_cell = 1.0 / cell;
-        levels.push_back(lv);
-        return dtype == O3DMI_F64
-                       ? BuildIndex<double>(lv, (const double*)points, s)
-                       : BuildIndex<float>(lv, (const float*)points, s);
-    }
-    void DropLevels() {
-        for (o3dmi_nns* lv : levels) o3dmi_nns_destroy(lv);
-        levels.clear();
-    }
-};
-
-}  // namespace
-
-// Internal form (also fills counts_dev {q} with the row width when given).
-int o3dmi_nns_knn_search_counts(const void* points_dev, int64_t n,
-                                const void* queries_dev, int64_t q, int dtype,
-                                int knn, int32_t* idx_dev, void* dist2_dev,
-                                int32_t* counts_dev, o3dmi_stream_t stream) {
-    O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
-                  "points must be Float32 or Float64");
-    O3DMI_REQUIRE(knn > 0, "knn should be larger than 0.");
-    O3DMI_REQUIRE(n > 0 && n < (1ll << 31) && points_dev, "empty dataset");
-    O3DMI_REQUIRE(q >= 0 && q < (1ll << 31) - 1, "q out of range");
-    const int k = (int)(n < (int64_t)knn ? n : (int64_t)knn);
-    O3DMI_REQUIRE(k <= kMaxKnn, "knn > 64 is not supported");
-    if (q == 0) return O3DMI_OK;
-    O3DMI_REQUIRE(queries_dev && idx_dev, "null argument");
-    hipStream_t s = (hipStream_t)stream;
-    KnnResources res;
-    int st;
-
-    // 1. Bounding box of the dataset.
-    if ((st = PoolAlloc((void**)&res.box, 64))) return st;
-    unsigned* occupied = (unsigned*)(res.box + 6);
-    O3DMI_HIP_CHECK(hipMemsetAsync(res.box, 0xff, 24, s));
-    O3DMI_HIP_CHECK(hipMemsetAsync(res.box + 3, 0, 24, s));
-    {
-        int g = GridFor(n, kBlock);
-        if (g > kCUs) g = kCUs;  // 6 atomics per wave on 6 addresses
-        if (dtype == O3DMI_F64)
-            hipLaunchKernelGGL(BoundsKernel<double>, dim3(g), dim3(kBlock), 0,
-                               s, (const double*)points_dev, n, res.box,
-                               res.box + 3);
-        else
-            hipLaunchKernelGGL(BoundsKernel<float>, dim3(g), dim3(kBlock), 0, s,
-                               (const float*)points_dev, n, res.box,
-                               res.box + 3);
-    }
-    unsigned long long hbox[6];
-    O3DMI_HIP_CHECK(hipMemcpyAsync(hbox, res.box, sizeof(hbox),
-                                   hipMemcpyDeviceToHost, s));
-    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
-    double lo[3], ext[3];
-    for (int a = 0; a < 3; ++a) {
-        lo[a] = FromOrderedKey(hbox[a]);
-        const double hi = FromOrderedKey(hbox[3 + a]);
-        O3DMI_REQUIRE(lo[a] <= hi, "KnnSearch: dataset has no finite points");
-        ext[a] = hi - lo[a];
-    }
-
-    // 2. Cell size of the finest level from the measured density. Target
-    // points per occupied cell: small cells keep the candidate sets (and the
-    // quadratic rank counting) small, shell 1 yields a first list whose k-th
-    // distance prunes shell 2. Measured on MI355X, k = 30, 100 k queries:
-    // 3 per cell 1.8 ms, 4.5: 0.71 ms, 6: 0.84 ms, 8: 1.26 ms, 15: 2.5 ms.
-    double target = k * 0.15 < 2.0 ? 2.0 : k * 0.15;
-    if (const char* e_ = std::getenv("O3DMI_KNN_PPC")) {  // tuning knob
-        const double v = std::atof(e_);
-        if (v > 0) target = v;
-    }
-    // First guess: a surface spanning the two largest extents, a filled
-    // volume or a line, whichever gives the largest cell (shrinking is the
-    // cheap direction: few occupied cells estimate the density reliably).
-    double e[3] = {ext[0], ext[1], ext[2]};
-    std::sort(e, e + 3);
-    const double emax = e[2] > 0 ? e[2] : 1.0;
-    const double h_min = emax * 1e-6;
-    double h = std::sqrt(std::max(e[2] * e[1], 0.0) * target / (double)n);
-    h = std::max(h, std::cbrt(std::max(e[0] * e[1] * e[2], 0.0) * target /
-                              (double)n));
-    h = std::max(h, e[2] * target / (double)n);
-    if (!(h > h_min)) h = h_min;
-    if (!(e[2] > 0)) h = 1.0;
-    for (int attempt = 0; attempt < 6; ++attempt) {
-        res.DropLevels();
-        if ((st = res.AddLevel(points_dev, n, dtype, h, s))) return st;
-        const o3dmi_nns* lv = res.levels[0];
-        O3DMI_HIP_CHECK(hipMemsetAsync(occupied, 0, sizeof(unsigned), s));
-        int g = GridFor(lv->n_buckets, kBlock);
-        if (g > kCUs * 4) g = kCUs * 4;
-        hipLaunchKernelGGL(CountOccupiedKernel, dim3(g), dim3(kBlock), 0, s,
-                           lv->starts, lv->n_buckets, occupied);
-        unsigned occ = 0;
-        O3DMI_HIP_CHECK(hipMemcpyAsync(&occ, occupied, sizeof(occ),
-                                       hipMemcpyDeviceToHost, s));
-        O3DMI_HIP_CHECK(hipStreamSynchronize(s));
-        const double ppc = (double)n / (double)(occ ? occ : 1);
-        if (attempt == 5 || (ppc >= 0.5 * target && ppc <= 2.0 * target)) break;
-        double h_next = h * std::pow(target / ppc, 0.4);
-        if (h_next < h_min) h_next = h_min;
-        if (h_next == h) break;
-        h = h_next;
-    }
-
-    // 3. First pass on the finest level alone; the queries it cannot finish
-    // (too few points within kKnnShells shells: sparse regions, outliers,
-    // queries away from the cloud) are collected for a second pass.
-    const bool single = !(emax / h > 3.0);  // one level already spans the cloud
-    if (!single) {
-        if ((st = PoolAlloc((void**)&res.retry, sizeof(int) * (size_t)(q + 1))))
-            return st;
-        O3DMI_HIP_CHECK(hipMemsetAsync(res.retry, 0, sizeof(int), s));
-    }
-    auto launch = [&](int first_level, bool exhaustive, bool brute,
-                      const int* ids, int64_t count, int* retry_ids,
-                      int* retry_count) -> int {
-        const dim3 grid(GridFor(count, kCoopBlock / 64, kCUs * 16)),
-                block(kCoopBlock);
-#define O3DMI_KNN(T)                                                           \
-    do {                                                                       \
-        KnnPyramid<T> pyr;                                                     \
-        pyr.n_levels = (int)res.levels.size();                                 \
-        pyr.first_radius = 1;                                                  \
-        pyr.first_level = first_level;                                         \
-        pyr.exhaustive_last = exhaustive ? 1 : 0;                              \
-        pyr.brute = brute ? 1 : 0;                                             \
-        pyr.n_points = n;                                                      \
-        for (int l = 0; l < pyr.n_levels; ++l) {                               \
-            const o3dmi_nns* lv = res.levels[l];                               \
-            KnnGrid<T>& kg = pyr.level[l];                                     \
-            kg.nv = MakeView<T>(lv);                                           \
-            kg.cell = lv->radius;                                              \
-            for (int a = 0; a < 3; ++a) {                                      \
-                kg.cmin[a] = (long long)std::floor(lo[a] * lv->inv_cell) - 1;  \
-                kg.cmax[a] = (long long)std::floor((lo[a] + ext[a]) *          \
-                                                   lv->inv_cell) + 1;          \
-            }                                                                  \
-        }                                                                      \
-        hipLaunchKernelGGL(KnnSearchKernel<T>, grid, block,                    \
-                           CoopLdsBytesPerWave<T>() * (kCoopBlock / 64), s,    \
-                           pyr, (const T*)queries_dev, count, k, ids,          \
-                           retry_ids, retry_count, idx_dev, (T*)dist2_dev,     \
-                           counts_dev);                                        \
-    } while (0)
-        if (dtype == O3DMI_F64) O3DMI_KNN(double);
-        else O3DMI_KNN(float);
-#undef O3DMI_KNN
-        O3DMI_HIP_CHECK(hipGetLastError());
-        return O3DMI_OK;
-    };
-    if ((st = launch(0, single, false, nullptr, q,
-                     res.retry ? res.retry + 1 : nullptr, res.retry)))
-        return st;
-    int n_retry = 0;
-    if (!single) {
-        O3DMI_HIP_CHECK(hipMemcpyAsync(&n_retry, res.retry, sizeof(int),
-                                       hipMemcpyDeviceToHost, s));
-        O3DMI_HIP_CHECK(hipStreamSynchronize(s));
-    }
-
-    // 4. Second pass: a coalesced sweep over all records when the leftovers
-    // are few, else a pyramid of 4x coarser levels (built only now) whose
-    // last level spans the cloud in <= 4 cells per axis and is searched
-    // exhaustively.
-    double sweep_limit = 2e9;  // leftover queries x points
-    if (const char* e_ = std::getenv("O3DMI_KNN_SWEEP_LIMIT"))
-        sweep_limit = std::atof(e_);
-    const bool brute = (double)n_retry * (double)n <= sweep_limit;
-    if (n_retry > 0 && brute) {
-        if ((st = launch(0, false, true, res.retry + 1, n_retry, nullptr,
-                         nullptr)))
-            return st;
-    } else if (n_retry > 0) {
-        while ((int)res.levels.size() < kKnnMaxLevels &&
-               emax / res.levels.back()->radius > 3.0) {
-            if ((st = res.AddLevel(points_dev, n, dtype,
-                                   res.levels.back()->radius * 4.0, s)))
-                return st;
-        }
-        if ((st = launch(1, true, false, res.retry + 1, n_retry, nullptr,
-                         nullptr)))
-            return st;
-    }
-    if (std::getenv("O3DMI_VERBOSE"))
-        std::fprintf(stderr,
-                     "[o3dmi] knn: n=%lld k=%d cell=%g levels=%d target=%g "
-                     "second-pass queries=%d (%s)\n",
-                     (long long)n, k, h, (int)res.levels.size(), target,
-                     n_retry, brute ? "sweep" : "pyramid");
-    return O3DMI_OK;
-}
-
-int o3dmi_nns_knn_search(const void* points_dev, int64_t n,
-                         const void* queries_dev, int64_t q, int dtype, int knn,
-                         int32_t* idx_dev, void* dist2_dev,
-                         o3dmi_stream_t stream) {
-    return o3dmi_nns_knn_search_counts(points_dev, n, queries_dev, q, dtype,
-                                       knn, idx_dev, dist2_dev, nullptr,
-                                       stream);
-}
 
 int o3dmi_icp_p2plane_accumulate(const void* src_dev, const void* tgt_dev,
                                  const void* tgt_normals_dev,

@@ -1,0 +1,79 @@
+// Private header shared by nns.hip (index build + searches) and icp.hip (the
+// fused search + accumulate kernel): the bucketed uniform grid of the
+// fixed-radius / KNN index.
+//
+// Index design: cell edge = radius * (1 + 1e-3) (KNN: chosen from the measured
+// density). Target points are *reordered* by bucket into 16-byte (32-byte for
+// f64) records {x,y,z,original index}, normals likewise, so a query's cell
+// visits read contiguous memory instead of chasing a CSR index through 12-byte
+// AoS points. Cell coordinates are computed in float64 on both the build and
+// the query side so that large-offset clouds (1000 m + 5 cm radius, cf.
+// cpp/tests/core/NearestNeighborSearch.cpp:831-869) bin consistently.
+#pragma once
+
+#include "common.h"
+
+struct o3dmi_nns {
+    int dtype = O3DMI_F32;
+    int64_t n = 0;
+    double radius = 0, inv_cell = 0;
+    int64_t n_buckets = 0;
+    void* sorted_pts = nullptr;      // Rec4<T>[n]
+    void* sorted_normals = nullptr;  // Rec4<T>[n], optional
+    unsigned* starts = nullptr;      // [n_buckets + 1]
+    double* partials = nullptr;      // [kCUs*4, kNumSums]
+};
+
+namespace o3dmi {
+
+constexpr int kNumSums = 32;  // 29 + sum d2 + match count + pad
+
+template <typename T> struct Rec4;  // {x,y,z,w}
+template <> struct alignas(16) Rec4<float> { float x, y, z; int w; };
+template <> struct alignas(32) Rec4<double> { double x, y, z; long long w; };
+
+__device__ __forceinline__ unsigned HashCell(long long cx, long long cy,
+                                             long long cz) {
+    unsigned long long k = (unsigned long long)cx * 0x9E3779B97F4A7C15ull;
+    k ^= (unsigned long long)cy * 0xC2B2AE3D27D4EB4Full + (k >> 29);
+    k ^= (unsigned long long)cz * 0x165667B19E3779F9ull + (k << 17);
+    return HashKey(k);
+}
+
+template <typename T>
+__device__ __forceinline__ void CellOf(const T* p, double inv_cell,
+                                       long long& cx, long long& cy,
+                                       long long& cz) {
+    cx = (long long)floor((double)p[0] * inv_cell);
+    cy = (long long)floor((double)p[1] * inv_cell);
+    cz = (long long)floor((double)p[2] * inv_cell);
+}
+
+template <typename T>
+__device__ __forceinline__ int RecIndex(const Rec4<T>& r) {
+    return (int)r.w;
+}
+
+// Gather an {N,3} attribute (normals) into sorted record order.
+template <typename T>
+struct NnsView {
+    const Rec4<T>* sorted;      // [n] bucket-ordered {x,y,z,idx}
+    const unsigned* starts;     // [n_buckets + 1]
+    double inv_cell;
+    unsigned mask;
+    T radius_squared;
+};
+
+template <typename T>
+inline NnsView<T> MakeView(const o3dmi_nns* nns) {
+    NnsView<T> v;
+    v.sorted = (const Rec4<T>*)nns->sorted_pts;
+    v.starts = nns->starts;
+    v.inv_cell = nns->inv_cell;
+    v.mask = (unsigned)(nns->n_buckets - 1);
+    const T r = (T)nns->radius;  // NanoFlannImpl.h:332: T radius_squared
+    v.radius_squared = r * r;
+    return v;
+}
+
+}  // namespace o3dmi
