@@ -34,6 +34,8 @@
 #include <cstring>
 #include <initializer_list>
 #include <limits>
+#include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -129,6 +131,15 @@ int DownSampleAttrs(const void* pos, int64_t n, int dtype, double voxel,
         return o3dmi_voxel_down_sample(pos, nullptr, n, dtype, voxel, out_pos,
                                        nullptr, m, stream);
     return O3DMI_OK;
+}
+
+// One side stream per host thread for the overlapped pyramid build.
+hipStream_t SideStream() {
+    static thread_local hipStream_t side = nullptr;
+    if (!side &&
+        hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess)
+        side = nullptr;
+    return side;
 }
 
 struct NnsGuard {
@@ -234,100 +245,155 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
     } sync_on_exit{s};
     const int last = num_scales - 1;
     int st;
-    auto clone = [&](DeviceBuffer& dst, const void* src, int64_t n) -> int {
+    // The source pyramid and the target pyramid are independent chains of
+    // VoxelDownSample calls, each a string of small launches with read-backs
+    // in between (voxel counts size the next level) -- latency, not
+    // throughput. The target chain runs on a side stream from a helper thread
+    // while this thread builds the source chain: the pyramid of a 720p frame
+    // (2 x 230 k points, 3 levels) takes about as long as one chain.
+    auto clone = [&](DeviceBuffer& dst, const void* src, int64_t n,
+                     hipStream_t cs) -> int {
         int e = dst.Alloc((size_t)n * 3 * esz);
         if (e) return e;
         O3DMI_HIP_CHECK(hipMemcpyAsync(dst.p, src, (size_t)n * 3 * esz,
-                                       hipMemcpyDeviceToDevice, s));
+                                       hipMemcpyDeviceToDevice, cs));
         return O3DMI_OK;
     };
-    {
+    auto source_chain = [&](hipStream_t cs) -> int {
+        o3dmi_stream_t cstream = (o3dmi_stream_t)cs;
+        int e;
         Level& L = pyr[(size_t)last];
         if (voxel_sizes[last] <= 0) {
             L.ns = ns;
-            L.nt = nt;
             // the source is moved in place every iteration: private copies
-            if ((st = clone(L.src, source_dev, ns))) return st;
-            if (symmetric && (st = clone(L.srcn, source_normals_dev, ns)))
-                return st;
+            if ((e = clone(L.src, source_dev, ns, cs))) return e;
+            if (symmetric && (e = clone(L.srcn, source_normals_dev, ns, cs)))
+                return e;
+            if (colored && (e = clone(L.srcc, source_colors_dev, ns, cs)))
+                return e;
+        } else {
+            if ((e = L.src.Alloc((size_t)ns * 3 * esz))) return e;
+            if (symmetric && (e = L.srcn.Alloc((size_t)ns * 3 * esz))) return e;
+            if (colored && (e = L.srcc.Alloc((size_t)ns * 3 * esz))) return e;
+            e = DownSampleAttrs(source_dev, ns, dtype, voxel_sizes[last],
+                                L.src.p, &L.ns, cstream,
+                                {{source_normals_dev, L.srcn.p},
+                                 {source_colors_dev, L.srcc.p}});
+            if (e) return e;
+        }
+        for (int k = num_scales - 2; k >= 0; --k) {
+            Level& C = pyr[(size_t)k];
+            Level& F = pyr[(size_t)k + 1];
+            if ((e = C.src.Alloc((size_t)F.ns * 3 * esz))) return e;
+            if (symmetric && (e = C.srcn.Alloc((size_t)F.ns * 3 * esz)))
+                return e;
+            if (colored && (e = C.srcc.Alloc((size_t)F.ns * 3 * esz))) return e;
+            e = DownSampleAttrs(F.src.p, F.ns, dtype, voxel_sizes[k], C.src.p,
+                                &C.ns, cstream,
+                                {{F.srcn.p, C.srcn.p}, {F.srcc.p, C.srcc.p}});
+            if (e) return e;
+        }
+        return O3DMI_OK;
+    };
+    auto target_chain = [&](hipStream_t cs) -> int {
+        o3dmi_stream_t cstream = (o3dmi_stream_t)cs;
+        int e;
+        Level& L = pyr[(size_t)last];
+        if (voxel_sizes[last] <= 0) {
+            L.nt = nt;
             L.tgt_ptr = target_dev;
             L.nrm_ptr = target_normals_dev;
             L.tgtc_ptr = target_colors_dev;
             L.tgtg_ptr = target_gradients_dev;
         } else {
-            if ((st = L.src.Alloc((size_t)ns * 3 * esz))) return st;
-            if ((st = L.tgt.Alloc((size_t)nt * 3 * esz))) return st;
-            if (need_tn && (st = L.nrm.Alloc((size_t)nt * 3 * esz)))
-                return st;
-            if (symmetric && (st = L.srcn.Alloc((size_t)ns * 3 * esz)))
-                return st;
+            if ((e = L.tgt.Alloc((size_t)nt * 3 * esz))) return e;
+            if (need_tn && (e = L.nrm.Alloc((size_t)nt * 3 * esz))) return e;
             if (colored) {
-                if ((st = L.srcc.Alloc((size_t)ns * 3 * esz))) return st;
-                if ((st = L.tgtc.Alloc((size_t)nt * 3 * esz))) return st;
+                if ((e = L.tgtc.Alloc((size_t)nt * 3 * esz))) return e;
                 if (target_gradients_dev &&
-                    (st = L.tgtg.Alloc((size_t)nt * 3 * esz)))
-                    return st;
+                    (e = L.tgtg.Alloc((size_t)nt * 3 * esz)))
+                    return e;
             }
-            st = DownSampleAttrs(source_dev, ns, dtype, voxel_sizes[last],
-                                 L.src.p, &L.ns, stream,
-                                 {{source_normals_dev, L.srcn.p},
-                                  {source_colors_dev, L.srcc.p}});
-            if (st) return st;
-            st = DownSampleAttrs(target_dev, nt, dtype, voxel_sizes[last],
-                                 L.tgt.p, &L.nt, stream,
-                                 {{target_normals_dev, L.nrm.p},
-                                  {target_colors_dev, L.tgtc.p},
-                                  {target_gradients_dev, L.tgtg.p}});
-            if (st) return st;
+            e = DownSampleAttrs(target_dev, nt, dtype, voxel_sizes[last],
+                                L.tgt.p, &L.nt, cstream,
+                                {{target_normals_dev, L.nrm.p},
+                                 {target_colors_dev, L.tgtc.p},
+                                 {target_gradients_dev, L.tgtg.p}});
+            if (e) return e;
             L.tgt_ptr = L.tgt.p;
             L.nrm_ptr = L.nrm.p;  // stays NULL without normals
             L.tgtc_ptr = L.tgtc.p;
             L.tgtg_ptr = L.tgtg.p;
         }
-        // the finest level's source colours: the caller's, or the averaged
-        if (colored && voxel_sizes[last] <= 0 &&
-            (st = clone(L.srcc, source_colors_dev, ns)))
-            return st;
         if (colored && !L.tgtg_ptr) {
             // Registration.cpp:243-262: EstimateColorGradients(30, radius) on
             // the finest level of the target pyramid.
             const double radius = voxel_sizes[last] <= 0
                                           ? max_dists[last] * 2.0
                                           : voxel_sizes[last] * 4.0;
-            if ((st = L.tgtg.Alloc((size_t)L.nt * 3 * esz))) return st;
-            st = o3dmi_pointcloud_estimate_color_gradients(
+            if ((e = L.tgtg.Alloc((size_t)L.nt * 3 * esz))) return e;
+            e = o3dmi_pointcloud_estimate_color_gradients(
                     L.tgt_ptr, L.nrm_ptr, L.tgtc_ptr, L.nt, dtype, 30, radius,
-                    L.tgtg.p, stream);
-            if (st) return st;
+                    L.tgtg.p, cstream);
+            if (e) return e;
             L.tgtg_ptr = L.tgtg.p;
         }
-    }
-    for (int k = num_scales - 2; k >= 0; --k) {
-        Level& L = pyr[(size_t)k];
-        Level& F = pyr[(size_t)k + 1];
-        if ((st = L.src.Alloc((size_t)F.ns * 3 * esz))) return st;
-        if ((st = L.tgt.Alloc((size_t)F.nt * 3 * esz))) return st;
-        if (need_tn && (st = L.nrm.Alloc((size_t)F.nt * 3 * esz))) return st;
-        if (symmetric && (st = L.srcn.Alloc((size_t)F.ns * 3 * esz))) return st;
-        if (colored) {
-            if ((st = L.srcc.Alloc((size_t)F.ns * 3 * esz))) return st;
-            if ((st = L.tgtc.Alloc((size_t)F.nt * 3 * esz))) return st;
-            if ((st = L.tgtg.Alloc((size_t)F.nt * 3 * esz))) return st;
+        for (int k = num_scales - 2; k >= 0; --k) {
+            Level& C = pyr[(size_t)k];
+            Level& F = pyr[(size_t)k + 1];
+            if ((e = C.tgt.Alloc((size_t)F.nt * 3 * esz))) return e;
+            if (need_tn && (e = C.nrm.Alloc((size_t)F.nt * 3 * esz))) return e;
+            if (colored) {
+                if ((e = C.tgtc.Alloc((size_t)F.nt * 3 * esz))) return e;
+                if ((e = C.tgtg.Alloc((size_t)F.nt * 3 * esz))) return e;
+            }
+            e = DownSampleAttrs(F.tgt_ptr, F.nt, dtype, voxel_sizes[k], C.tgt.p,
+                                &C.nt, cstream,
+                                {{F.nrm_ptr, C.nrm.p},
+                                 {F.tgtc_ptr, C.tgtc.p},
+                                 {F.tgtg_ptr, C.tgtg.p}});
+            if (e) return e;
+            C.tgt_ptr = C.tgt.p;
+            C.nrm_ptr = C.nrm.p;
+            C.tgtc_ptr = C.tgtc.p;
+            C.tgtg_ptr = C.tgtg.p;
         }
-        st = DownSampleAttrs(F.src.p, F.ns, dtype, voxel_sizes[k], L.src.p,
-                             &L.ns, stream,
-                             {{F.srcn.p, L.srcn.p}, {F.srcc.p, L.srcc.p}});
+        return O3DMI_OK;
+    };
+    // Anything to overlap? (a single level without down-sampling is two
+    // copies and no read-back)
+    const bool overlap = (num_scales > 1 || voxel_sizes[last] > 0) &&
+                         std::getenv("O3DMI_SERIAL_PYRAMID") == nullptr;
+    if (!overlap) {
+        if ((st = source_chain(s))) return st;
+        if ((st = target_chain(s))) return st;
+    } else {
+        // inputs may still be in flight on the caller's stream
+        O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+        hipStream_t side = SideStream();
+        O3DMI_REQUIRE(side != nullptr, "side stream creation failed");
+        int st_target = O3DMI_OK;
+        std::string err_target;
+        int device = 0;
+        O3DMI_HIP_CHECK(hipGetDevice(&device));
+        std::thread helper([&] {
+            // a new thread starts on device 0: follow the caller's device
+            if (hipSetDevice(device) != hipSuccess) {
+                st_target = O3DMI_ERR_HIP;
+                err_target = "hipSetDevice failed in the pyramid helper";
+                return;
+            }
+            st_target = target_chain(side);
+            if (st_target) err_target = o3dmi_last_error();
+            (void)hipStreamSynchronize(side);
+        });
+        st = source_chain(s);
+        helper.join();
         if (st) return st;
-        st = DownSampleAttrs(F.tgt_ptr, F.nt, dtype, voxel_sizes[k], L.tgt.p,
-                             &L.nt, stream,
-                             {{F.nrm_ptr, L.nrm.p},
-                              {F.tgtc_ptr, L.tgtc.p},
-                              {F.tgtg_ptr, L.tgtg.p}});
-        if (st) return st;
-        L.tgt_ptr = L.tgt.p;
-        L.nrm_ptr = L.nrm.p;
-        L.tgtc_ptr = L.tgtc.p;
-        L.tgtg_ptr = L.tgtg.p;
+        if (st_target) {
+            SetLastError(err_target);  // the message was set in the helper
+            return st_target;
+        }
     }
 
     const bool timing = std::getenv("O3DMI_ICP_TIMING") != nullptr;
