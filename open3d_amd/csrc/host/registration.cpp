@@ -376,7 +376,7 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         std::string err_target;
         int device = 0;
         O3DMI_HIP_CHECK(hipGetDevice(&device));
-        std::thread helper([&] {
+        auto helper_body = [&] {
             // a new thread starts on device 0: follow the caller's device
             if (hipSetDevice(device) != hipSuccess) {
                 st_target = O3DMI_ERR_HIP;
@@ -386,9 +386,17 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
             st_target = target_chain(side);
             if (st_target) err_target = o3dmi_last_error();
             (void)hipStreamSynchronize(side);
-        });
+        };
+        std::thread helper;
+        bool threaded = true;
+        try {
+            helper = std::thread(helper_body);
+        } catch (...) {  // no thread to be had: build the chains one by one
+            threaded = false;
+        }
         st = source_chain(s);
-        helper.join();
+        if (threaded) helper.join();
+        else helper_body();
         if (st) return st;
         if (st_target) {
             SetLastError(err_target);  // the message was set in the helper
