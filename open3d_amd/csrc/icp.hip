@@ -467,27 +467,46 @@ SearchAccumulateKernel(NnsView<T> nv, const Rec4<T>* __restrict__ sorted_n,
             q[2] = src[3 * i + 2];
             long long cx, cy, cz;
             CellOf(q, nv.inv_cell, cx, cy, cz);
-            for (int c = c0; c < 27; c += G) {
-                const int dz = c / 9 - 1, dy = (c % 9) / 3 - 1, dx = c % 3 - 1;
-                const unsigned b =
-                        HashCell(cx + dx, cy + dy, cz + dz) & nv.mask;
-                const unsigned s0 = nv.starts[b], e0 = nv.starts[b + 1];
-                for (unsigned j = s0; j < e0; ++j) {
-                    const Rec4<T> p = nv.sorted[j];
-                    T result = T(0);
-                    const T d0 = q[0] - p.x;
-                    result += d0 * d0;
-                    const T d1 = q[1] - p.y;
-                    result += d1 * d1;
-                    const T dd = q[2] - p.z;
-                    result += dd * dd;
-                    if (result < nv.radius_squared) {
-                        const int pi = RecIndex(p);
-                        if (pos < 0 || result < d2 ||
-                            (result == d2 && pi < idx)) {
-                            pos = (int)j;
-                            idx = pi;
-                            d2 = result;
+            // A lane owns cells c0, c0 + G, ...: the bucket bounds of a batch
+            // of them are fetched first (independent loads in flight
+            // together), then the records -- one dependent round trip per
+            // batch instead of two per cell.
+            constexpr int kOwn = (27 + G - 1) / G;
+            constexpr int kBatch = kOwn < 9 ? kOwn : 9;
+            for (int cb = 0; cb < kOwn; cb += kBatch) {
+                unsigned s0[kBatch], e0[kBatch];
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k) {
+                    const int c = c0 + (cb + k) * G;
+                    s0[k] = e0[k] = 0;
+                    if (c < 27) {
+                        const int dz = c / 9 - 1, dy = (c % 9) / 3 - 1,
+                                  dx = c % 3 - 1;
+                        const unsigned b =
+                                HashCell(cx + dx, cy + dy, cz + dz) & nv.mask;
+                        s0[k] = nv.starts[b];
+                        e0[k] = nv.starts[b + 1];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k) {
+                    for (unsigned j = s0[k]; j < e0[k]; ++j) {
+                        const Rec4<T> p = nv.sorted[j];
+                        T result = T(0);
+                        const T d0 = q[0] - p.x;
+                        result += d0 * d0;
+                        const T d1 = q[1] - p.y;
+                        result += d1 * d1;
+                        const T dd = q[2] - p.z;
+                        result += dd * dd;
+                        if (result < nv.radius_squared) {
+                            const int pi = RecIndex(p);
+                            if (pos < 0 || result < d2 ||
+                                (result == d2 && pi < idx)) {
+                                pos = (int)j;
+                                idx = pi;
+                                d2 = result;
+                            }
                         }
                     }
                 }
