@@ -770,6 +770,9 @@ __global__ void BoundsKernel(const T* __restrict__ pts, int64_t n,
             if (v > hi[a]) hi[a] = v;
         }
     }
+    // wave, then workgroup (LDS), then one atomic pair per axis and workgroup:
+    // atomics on six addresses serialise, a few hundred of them are noise
+    __shared__ double wlo[kBlock / 64][3], whi[kBlock / 64][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         for (int m = 32; m > 0; m >>= 1) {
@@ -777,10 +780,21 @@ __global__ void BoundsKernel(const T* __restrict__ pts, int64_t n,
             hi[a] = fmax(hi[a], __shfl_xor(hi[a], m));
         }
         if ((threadIdx.x & 63) == 0) {
-            if (lo[a] <= hi[a]) {
-                atomicMin(&mn[a], OrderedKey(lo[a]));
-                atomicMax(&mx[a], OrderedKey(hi[a]));
-            }
+            wlo[threadIdx.x >> 6][a] = lo[a];
+            whi[threadIdx.x >> 6][a] = hi[a];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        double l = wlo[0][a], h = whi[0][a];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+            l = fmin(l, wlo[w][a]);
+            h = fmax(h, whi[w][a]);
+        }
+        if (l <= h) {
+            atomicMin(&mn[a], OrderedKey(l));
+            atomicMax(&mx[a], OrderedKey(h));
         }
     }
 }
@@ -793,7 +807,14 @@ __global__ void CountOccupiedKernel(const unsigned* __restrict__ starts,
          b < n_buckets; b += (int64_t)gridDim.x * blockDim.x)
         local += starts[b + 1] > starts[b] ? 1u : 0u;
     for (int m = 32; m > 0; m >>= 1) local += __shfl_xor(local, m);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(occupied, local);
+    __shared__ unsigned wsum[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += wsum[w];
+        if (t) atomicAdd(occupied, t);
+    }
 }
 
 }  // namespace
@@ -1093,7 +1114,7 @@ int o3dmi_nns_knn_search_counts(const void* points_dev, int64_t n,
         const o3dmi_nns* lv = res.levels[0];
         O3DMI_HIP_CHECK(hipMemsetAsync(occupied, 0, sizeof(unsigned), s));
         int g = GridFor(lv->n_buckets, kBlock);
-        if (g > kCUs * 4) g = kCUs * 4;
+        if (g > kCUs) g = kCUs;
         hipLaunchKernelGGL(CountOccupiedKernel, dim3(g), dim3(kBlock), 0, s,
                            lv->starts, lv->n_buckets, occupied);
         unsigned occ = 0;
