@@ -612,7 +612,7 @@ struct KnnGrid {
 };
 
 constexpr int kKnnMaxLevels = 12;
-constexpr int kKnnShells = 2;
+constexpr int kKnnShells = 3;
 
 template <typename T>
 struct KnnPyramid {
