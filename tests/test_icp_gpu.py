@@ -892,3 +892,27 @@ def test_multiscale_icp_colored():
     assert ang <= 1e-6 and tr <= 1e-5, (ang, tr)
     assert got.num_iterations == want["num_iterations"]
     assert abs(got.fitness - want["fitness"]) < 1e-12
+
+
+def test_multiscale_icp_is_run_to_run_identical(monkeypatch):
+    """The pyramid is built by two threads on two streams, the reductions have
+    a fixed order: 20 calls give the same bits, and the same bits as the
+    serial pyramid build."""
+    _lib, reg = _gpu()
+    p = _pair(60000, seed=13)
+    vs = [0.05, 0.025, 0.0125]
+    crit = [reg.ICPConvergenceCriteria(1e-6, 1e-6, n) for n in (20, 10, 5)]
+    md = [0.15, 0.075, 0.0375]
+    dev = [torch.from_numpy(p[k]).cuda()
+           for k in ("source", "target", "target_normals")]
+
+    def run():
+        r = reg.multi_scale_icp(dev[0], dev[1], dev[2], vs, crit, md)
+        return (r.transformation.tobytes(), r.fitness, r.inlier_rmse,
+                r.num_iterations,
+                r.correspondence_set.cpu().numpy().tobytes())
+    first = run()
+    for _ in range(19):
+        assert run() == first
+    monkeypatch.setenv("O3DMI_SERIAL_PYRAMID", "1")
+    assert run() == first
