@@ -126,6 +126,20 @@ int o3dmi_registration_multiscale_icp_ex(
         int64_t* correspondences_dev, o3dmi_registration_result_t* result,
         o3dmi_stream_t stream);
 
+/* TransformationEstimation*::ComputeRMSE (TransformationEstimation.cpp:
+ * 101-130 point-to-point, 160-193 point-to-plane, 229-274 symmetric, 296-378
+ * coloured) on given correspondences (int64, -1 = none). The reference's
+ * definitions are kept as they are: point-to-plane squares every component
+ * of (s - t) * n; the coloured estimator returns the SUM of squared geometric
+ * and photometric residuals, not a root mean. *rmse_out is a host double; the
+ * call synchronises. No correspondence: 0 for the symmetric estimator (as the
+ * reference), O3DMI_ERR_NO_INLIERS otherwise (the reference divides by 0). */
+int o3dmi_registration_compute_rmse(
+        int estimation, const void* source_dev, int64_t ns,
+        const void* target_dev, const void* target_normals_dev, int dtype,
+        const o3dmi_icp_attributes_t* attrs, const int64_t* correspondences_dev,
+        double* rmse_out, o3dmi_stream_t stream);
+
 /* registration::EvaluateRegistration (Registration.cpp:64-91): fitness,
  * inlier_rmse and the correspondence set of `source` moved by `transformation`
  * (host 4x4 float64, NULL = identity) against `target`. result->transformation

@@ -172,6 +172,9 @@ PROTOTYPES.update({
     "o3dmi_nns_radius_covariances": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "o3dmi_nns_knn_search": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp,
                                     _vp, _vp]),
+    "o3dmi_registration_compute_rmse": (
+        _i32, [_i32, _vp, _i64, _vp, _vp, _i32, C.POINTER(IcpAttributes), _vp,
+               C.POINTER(_d), _vp]),
     "o3dmi_registration_evaluate": (
         _i32, [_vp, _i64, _vp, _i64, _i32, _d, _dp, _vp,
                C.POINTER(RegistrationResultC), _vp]),

@@ -765,3 +765,97 @@ extern "C" int o3dmi_registration_information_matrix(
         }
     return O3DMI_OK;
 }
+
+extern "C" int o3dmi_icp_residual_squares(const void* src_dev,
+                                          const void* tgt_dev,
+                                          const void* tgt_normals_dev,
+                                          const int64_t* corr_dev, int64_t n,
+                                          int dtype, double* sums2_dev,
+                                          o3dmi_stream_t stream);
+
+extern "C" int o3dmi_registration_compute_rmse(
+        int estimation, const void* source_dev, int64_t ns,
+        const void* target_dev, const void* target_normals_dev, int dtype,
+        const o3dmi_icp_attributes_t* attrs, const int64_t* correspondences_dev,
+        double* rmse_out, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(rmse_out != nullptr, "rmse_out is null");
+    O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
+                  "Only Float32 and Float64 point clouds are supported.");
+    O3DMI_REQUIRE(source_dev && target_dev && ns > 0 && correspondences_dev,
+                  "Source and/or Target pointcloud is empty.");
+    O3DMI_REQUIRE(estimation >= O3DMI_ICP_POINT_TO_PLANE &&
+                          estimation <= O3DMI_ICP_COLORED,
+                  "unknown estimation");
+    hipStream_t s = (hipStream_t)stream;
+    DeviceBuffer sums;
+    struct SyncOnExit {
+        hipStream_t s;
+        ~SyncOnExit() { (void)hipStreamSynchronize(s); }
+    } sync_on_exit{s};
+    int st = sums.Alloc(sizeof(double) * 32);
+    if (st) return st;
+    double h[32] = {0};
+    const double zero3[3] = {0, 0, 0};
+    switch (estimation) {
+        case O3DMI_ICP_POINT_TO_PLANE:
+            O3DMI_REQUIRE(target_normals_dev,
+                          "Target pointcloud missing normals attribute.");
+            st = o3dmi_icp_residual_squares(source_dev, target_dev,
+                                            target_normals_dev,
+                                            correspondences_dev, ns, dtype,
+                                            (double*)sums.p, stream);
+            break;
+        case O3DMI_ICP_POINT_TO_POINT:
+            st = o3dmi_icp_residual_squares(source_dev, target_dev, nullptr,
+                                            correspondences_dev, ns, dtype,
+                                            (double*)sums.p, stream);
+            break;
+        case O3DMI_ICP_SYMMETRIC:
+            O3DMI_REQUIRE(attrs && attrs->source_normals && target_normals_dev,
+                          "SymmetricICP requires both source and target to "
+                          "have normals.");
+            // the un-centred residual does not depend on the means
+            st = o3dmi_icp_symmetric_accumulate(
+                    source_dev, attrs->source_normals, target_dev,
+                    target_normals_dev, correspondences_dev, ns, dtype, zero3,
+                    zero3, 0, 1.0, 1.0, (double*)sums.p, stream);
+            break;
+        default: {
+            O3DMI_REQUIRE(target_normals_dev,
+                          "Target pointcloud missing normals attribute.");
+            O3DMI_REQUIRE(attrs && attrs->source_colors && attrs->target_colors,
+                          "Source and/or Target pointcloud missing colors "
+                          "attribute.");
+            O3DMI_REQUIRE(attrs->target_color_gradients,
+                          "Target pointcloud missing color_gradients "
+                          "attribute.");
+            double lambda = attrs->lambda_geometric;
+            if (!(lambda >= 0 && lambda <= 1.0)) lambda = 0.968;
+            st = o3dmi_icp_colored_accumulate(
+                    source_dev, attrs->source_colors, target_dev,
+                    target_normals_dev, attrs->target_colors,
+                    attrs->target_color_gradients, correspondences_dev, ns,
+                    dtype, lambda, 0, 1.0, 1.0, (double*)sums.p, stream);
+        }
+    }
+    if (st) return st;
+    const int n_read = (estimation == O3DMI_ICP_POINT_TO_PLANE ||
+                        estimation == O3DMI_ICP_POINT_TO_POINT)
+                               ? 2
+                               : 29;
+    O3DMI_HIP_CHECK(hipMemcpyAsync(h, sums.p, sizeof(double) * n_read,
+                                   hipMemcpyDeviceToHost, s));
+    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    if (n_read == 2) {
+        if (h[1] == 0) {
+            SetLastError("No valid correspondence present.");
+            return O3DMI_ERR_NO_INLIERS;
+        }
+        *rmse_out = std::sqrt(h[0] / h[1]);
+    } else if (estimation == O3DMI_ICP_SYMMETRIC) {
+        *rmse_out = h[28] == 0 ? 0.0 : std::sqrt(h[27] / h[28]);
+    } else {
+        *rmse_out = h[27];
+    }
+    return O3DMI_OK;
+}

@@ -394,6 +394,35 @@ ColoredAccumulateKernel(const T* __restrict__ src, const T* __restrict__ src_c,
     BlockReduceAndStore(A, partials);
 }
 
+// TransformationEstimationPointTo{Plane,Point}::ComputeRMSE
+// (TransformationEstimation.cpp:101-130,160-193): the tensor expressions are
+// element-wise -- point-to-plane squares every COMPONENT of (s - t) * n, it is
+// not the squared point-to-plane distance -- formed in T, summed in float64
+// here. A[0] = sum, A[1] = number of correspondences.
+template <typename T, bool PLANE>
+__global__ void __launch_bounds__(kReduceBlock)
+ResidualSquaresKernel(const T* __restrict__ src, const T* __restrict__ tgt,
+                      const T* __restrict__ tgt_n,
+                      const int64_t* __restrict__ corr, int64_t n,
+                      double* __restrict__ partials) {
+    double A[kNumSums];
+#pragma unroll
+    for (int k = 0; k < kNumSums; ++k) A[k] = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t c = corr[i];
+        if (c == -1) continue;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            T e = src[3 * i + k] - tgt[3 * c + k];
+            if (PLANE) e = e * tgt_n[3 * c + k];
+            A[0] += (double)(e * e);
+        }
+        A[1] += 1.0;
+    }
+    BlockReduceAndStore(A, partials);
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kReduceBlock)
 P2PointAccumulateKernel(const T* __restrict__ src, const T* __restrict__ tgt,
@@ -638,6 +667,40 @@ int o3dmi_icp_p2plane_accumulate(const void* src_dev, const void* tgt_dev,
                            corr_dev, n, rp, partials);
     hipLaunchKernelGGL(FinalReduceKernel, dim3(1), dim3(256), 0, s, partials, g,
                        sums29_dev, 29, (double*)nullptr, (int*)nullptr, 0);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    O3DMI_HIP_CHECK(hipFreeAsync(partials, s));
+    return O3DMI_OK;
+}
+
+// Internal (host header: o3dmi_registration_compute_rmse): sums2_dev[0] = sum
+// of squared residual components, [1] = number of correspondences.
+int o3dmi_icp_residual_squares(const void* src_dev, const void* tgt_dev,
+                               const void* tgt_normals_dev,
+                               const int64_t* corr_dev, int64_t n, int dtype,
+                               double* sums2_dev, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(src_dev && tgt_dev && corr_dev && sums2_dev, "null argument");
+    O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
+                  "points must be Float32 or Float64");
+    hipStream_t s = (hipStream_t)stream;
+    int g = ReduceGrid(n);
+    double* partials = nullptr;
+    O3DMI_HIP_CHECK(hipMallocAsync((void**)&partials,
+                                   sizeof(double) * (size_t)g * kNumSums, s));
+#define O3DMI_RESID(T, P)                                                      \
+    hipLaunchKernelGGL((ResidualSquaresKernel<T, P>), dim3(g),                 \
+                       dim3(kReduceBlock), 0, s, (const T*)src_dev,            \
+                       (const T*)tgt_dev, (const T*)tgt_normals_dev, corr_dev, \
+                       n, partials)
+    if (dtype == O3DMI_F64) {
+        if (tgt_normals_dev) O3DMI_RESID(double, true);
+        else O3DMI_RESID(double, false);
+    } else {
+        if (tgt_normals_dev) O3DMI_RESID(float, true);
+        else O3DMI_RESID(float, false);
+    }
+#undef O3DMI_RESID
+    hipLaunchKernelGGL(FinalReduceKernel, dim3(1), dim3(256), 0, s, partials, g,
+                       sums2_dev, 2, (double*)nullptr, (int*)nullptr, 0);
     O3DMI_HIP_CHECK(hipGetLastError());
     O3DMI_HIP_CHECK(hipFreeAsync(partials, s));
     return O3DMI_OK;

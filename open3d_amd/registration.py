@@ -323,3 +323,37 @@ def estimate_color_gradients(positions, normals, colors, max_nn=30,
         C.c_double(-1.0 if radius is None else radius), _lib.ptr(out),
         stream()), "estimate_color_gradients")
     return out
+
+
+def compute_rmse(estimation_method, source, target, target_normals,
+                 correspondences, source_normals=None, source_colors=None,
+                 target_colors=None, target_color_gradients=None):
+    """TransformationEstimation*::ComputeRMSE on device tensors (the
+    reference's definitions, see o3dmi_registration_compute_rmse)."""
+    est = estimation_method
+    code = (1 if isinstance(est, TransformationEstimationPointToPoint) else
+            2 if isinstance(est, TransformationEstimationSymmetric) else
+            3 if isinstance(est, TransformationEstimationForColoredICP) else 0)
+    source, target = _check_pair(source, target)
+    corr = require_cuda(correspondences, "correspondences")
+    attrs = _lib.IcpAttributes()
+    attrs.lambda_geometric = getattr(est, "lambda_geometric", 0.968)
+    keep = [require_cuda(t, "attribute") for t in
+            (source_normals, source_colors, target_colors,
+             target_color_gradients, target_normals) if t is not None]
+    if source_normals is not None:
+        attrs.source_normals = source_normals.data_ptr()
+    if source_colors is not None:
+        attrs.source_colors = source_colors.data_ptr()
+    if target_colors is not None:
+        attrs.target_colors = target_colors.data_ptr()
+    if target_color_gradients is not None:
+        attrs.target_color_gradients = target_color_gradients.data_ptr()
+    out = C.c_double(0)
+    _lib.check(_lib.lib().o3dmi_registration_compute_rmse(
+        code, _lib.ptr(source), source.shape[0], _lib.ptr(target),
+        _lib.ptr(target_normals), TORCH_TO_O3DMI[source.dtype],
+        C.byref(attrs), _lib.ptr(corr), C.byref(out), stream()),
+        "compute_rmse")
+    del keep
+    return out.value

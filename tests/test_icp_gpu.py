@@ -916,3 +916,69 @@ def test_multiscale_icp_is_run_to_run_identical(monkeypatch):
         assert run() == first
     monkeypatch.setenv("O3DMI_SERIAL_PYRAMID", "1")
     assert run() == first
+
+
+# ------------------------------------------------ TransformationEstimation RMSE
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_compute_rmse_goldens_through_gpu(dtype):
+    """ComputeRMSEPointToPoint 0.706437, ComputeRMSEPointToPlane 0.335499 and
+    the four ComputeRMSESymmetric cases (cpp/tests/t/pipelines/registration/
+    TransformationEstimation.cpp:89-104,134-150,180-218)."""
+    _lib, reg = _gpu()
+    s, t, n = (torch.from_numpy(a.astype(dtype)).cuda()
+               for a in (SRC, TGT, TGT_N))
+    corr = torch.from_numpy(CORR).cuda()
+    r = reg.compute_rmse(reg.TransformationEstimationPointToPoint(), s, t,
+                         None, corr)
+    assert abs(r - 0.706437) < 1e-4
+    r = reg.compute_rmse(reg.TransformationEstimationPointToPlane(), s, t, n,
+                         corr)
+    assert abs(r - 0.335499) < 1e-4
+    assert abs(r - orc.p2plane_rmse(SRC.astype(dtype), TGT.astype(dtype),
+                                    TGT_N.astype(dtype), CORR)) < 1e-6
+    tol = 1e-6 if dtype == np.float32 else 1e-12
+    sym = reg.TransformationEstimationSymmetric()
+    src = torch.tensor([[1.0, 0.0, 0.0]], dtype=s.dtype, device="cuda")
+    tg = torch.tensor([[0.5, np.sqrt(3.0) / 2.0, 0.0]], dtype=s.dtype,
+                      device="cuda")
+    c0 = torch.zeros(1, dtype=torch.int64, device="cuda")
+    assert abs(reg.compute_rmse(sym, src, tg, tg.clone(), c0,
+                                source_normals=src.clone())) < tol
+    assert abs(reg.compute_rmse(sym, src, tg, -tg, c0,
+                                source_normals=src.clone())) < tol
+    zero = torch.zeros_like(src)
+    assert abs(reg.compute_rmse(sym, src, zero, src.clone(), c0,
+                                source_normals=src.clone()) - 2.0) < tol
+    assert abs(reg.compute_rmse(sym, src, zero, -src, c0,
+                                source_normals=src.clone()) - 2.0) < tol
+    none = torch.full((1,), -1, dtype=torch.int64, device="cuda")
+    assert reg.compute_rmse(sym, src, zero, src.clone(), none,
+                            source_normals=src.clone()) == 0.0
+    with pytest.raises(RuntimeError, match="No valid correspondence"):
+        reg.compute_rmse(reg.TransformationEstimationPointToPoint(), src,
+                         zero, None, none)
+
+
+def test_compute_rmse_colored_is_the_residual_sum():
+    """TransformationEstimationForColoredICP::ComputeRMSE returns the sum of
+    squared geometric + photometric residuals (TransformationEstimation.cpp:
+    296-378) = entry 27 of the estimator's 29 sums."""
+    _lib, reg = _gpu()
+    p, sc, tc = _colored_pair(20000, 61, np.float32)
+    idx, d2, cnt = orc.hybrid_search(p["target"], p["source"], 0.07, 1)
+    corr = idx[:, 0].astype(np.int64)
+    nidx, _, ncnt = orc.hybrid_search(p["target"], p["target"], 0.15, 30)
+    tg = orc.estimate_color_gradients(p["target"], p["target_normals"], tc,
+                                      nidx, ncnt)
+    want = orc.colored_accumulate(p["source"], sc, p["target"],
+                                  p["target_normals"], tc, tg, corr, 0.968,
+                                  accumulate_double=True)[27]
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda()
+           for k, v in dict(s=p["source"], t=p["target"],
+                            n=p["target_normals"], sc=sc, tc=tc, tg=tg,
+                            c=corr).items()}
+    got = reg.compute_rmse(reg.TransformationEstimationForColoredICP(),
+                           dev["s"], dev["t"], dev["n"], dev["c"],
+                           source_colors=dev["sc"], target_colors=dev["tc"],
+                           target_color_gradients=dev["tg"])
+    assert abs(got - want) <= 1e-10 * abs(want)
