@@ -333,6 +333,22 @@ int o3dmi_nns_knn_search(const void* points_dev, int64_t n,
                          int32_t* idx_dev, void* dist2_dev,
                          o3dmi_stream_t stream);
 
+/* FixedRadiusSearchCUDA (core/nns/FixedRadiusIndex.h:281-290, FixedRadius
+ * SearchImpl.cuh:826-1072) in its two passes, the prefix sum in between left
+ * to the caller as in the reference (neighbors_row_splits): counts {Q} int32
+ * of the index points with d2 < r2 (r = the index radius); then, given
+ * row_splits {Q+1} int64 (exclusive prefix of the counts), the neighbour
+ * indices {total} int32 and squared distances {total} (point dtype, may be
+ * NULL) of every query, ascending by (d2, index). No cap on the number of
+ * neighbours of a query. */
+int o3dmi_nns_radius_count(const o3dmi_nns_t* nns, const void* queries_dev,
+                           int64_t q, int32_t* counts_dev,
+                           o3dmi_stream_t stream);
+int o3dmi_nns_radius_search(const o3dmi_nns_t* nns, const void* queries_dev,
+                            int64_t q, const int64_t* row_splits_dev,
+                            int32_t* idx_dev, void* dist2_dev,
+                            o3dmi_stream_t stream);
+
 /* EstimateCovariancesUsingRadiusSearchCUDA (t/geometry/kernel/PointCloudImpl.h:
  * 641-689): covariances {Q,3,3} (point dtype) of ALL index points with
  * d2 < r2 of every query, r = the index radius; fewer than 3 -> identity.

@@ -169,6 +169,8 @@ PROTOTYPES.update({
         _i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "o3dmi_pointcloud_estimate_color_gradients": (
         _i32, [_vp, _vp, _vp, _i64, _i32, _i32, _d, _vp, _vp]),
+    "o3dmi_nns_radius_count": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "o3dmi_nns_radius_search": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "o3dmi_nns_radius_covariances": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "o3dmi_nns_knn_search": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp,
                                     _vp, _vp]),

@@ -495,6 +495,98 @@ HybridSearchKernel(NnsView<T> nv, const T* __restrict__ q, int64_t nq,
     }
 }
 
+// FixedRadiusSearch (core/nns/NearestNeighborSearch.cpp:114-142; GPU form
+// FixedRadiusSearchCUDA, core/nns/FixedRadiusSearchOps.cu / FixedRadiusSearch
+// Impl.cuh:826-1072 -- count pass, prefix sum, write pass): every neighbour
+// with d2 < r2 (strict, the CPU path's nanoflann semantics), ascending by
+// (d2, index), as a CSR list. A wave serves a query. The write pass emits 64
+// neighbours per round: the 64 smallest pairs above the last one emitted are
+// selected from the 27 cells, written, and the round repeats until a round
+// comes back short -- no cap on the neighbourhood size, one round for the
+// usual one.
+template <typename T>
+struct CountSink {
+    int count;
+    __device__ __forceinline__ void Push(T, int i, T, T, T) {
+        if (i != kNoIndex) ++count;
+    }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kCoopBlock)
+RadiusCountKernel(NnsView<T> nv, const T* __restrict__ q, int64_t nq,
+                  int* __restrict__ counts) {
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < nq; i += n_waves) {
+        const T qq[3] = {q[3 * i + 0], q[3 * i + 1], q[3 * i + 2]};
+        long long cx, cy, cz;
+        CellOf(qq, nv.inv_cell, cx, cy, cz);
+        CountSink<T> sink;
+        sink.count = 0;
+        GatherCells<T, true>(nv, qq, cx, cy, cz, cx - 1, cx + 1, cy - 1, cy + 1,
+                             cz - 1, cz + 1, 0, sink);
+        int c = sink.count;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) c += __shfl_xor(c, m);
+        if ((threadIdx.x & 63) == 0) counts[i] = c;
+    }
+}
+
+// Candidates at or below the floor pair were emitted in an earlier round.
+template <typename T>
+struct FloorSink {
+    WaveTopK<T>* list;
+    T floor_d;
+    int floor_i;
+    bool has_floor;
+    __device__ __forceinline__ void Push(T d, int i, T, T, T) {
+        if (has_floor && i != kNoIndex && !PairLess(floor_d, floor_i, d, i))
+            i = kNoIndex;
+        list->Push(d, i);
+    }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kCoopBlock)
+RadiusWriteKernel(NnsView<T> nv, const T* __restrict__ q, int64_t nq,
+                  const int64_t* __restrict__ row_splits,
+                  int* __restrict__ idx_out, T* __restrict__ d2_out) {
+    extern __shared__ __align__(16) char coop_lds[];
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    WaveTopK<T> list;
+    list.Init(coop_lds);
+    for (int64_t i = wave; i < nq; i += n_waves) {
+        const T qq[3] = {q[3 * i + 0], q[3 * i + 1], q[3 * i + 2]};
+        long long cx, cy, cz;
+        CellOf(qq, nv.inv_cell, cx, cy, cz);
+        const int64_t begin = row_splits[i], end = row_splits[i + 1];
+        int64_t at = begin;
+        FloorSink<T> sink;
+        sink.list = &list;
+        sink.floor_d = T(0);
+        sink.floor_i = -1;
+        sink.has_floor = false;
+        while (at < end) {
+            list.Reset(kMaxKnn);
+            GatherCells<T, true>(nv, qq, cx, cy, cz, cx - 1, cx + 1, cy - 1,
+                                 cy + 1, cz - 1, cz + 1, 0, sink);
+            list.Flush();
+            if (lane < list.nbest && at + lane < end) {
+                idx_out[at + lane] = list.best_i;
+                if (d2_out) d2_out[at + lane] = list.best_d;
+            }
+            at += list.nbest;
+            if (list.nbest < kMaxKnn) break;
+            sink.floor_d = list.kth_d;
+            sink.floor_i = list.kth_i;
+            sink.has_floor = true;
+        }
+    }
+}
+
 // EstimateCovariancesUsingRadiusSearch (t/geometry/kernel/PointCloudImpl.h:
 // 641-689): every neighbour with d2 < r2, no cap. One wave per point, two
 // sweeps over the 27 cells: count + centroid, then the six cumulants about it
@@ -978,6 +1070,51 @@ int o3dmi_nns_hybrid_search(const o3dmi_nns_t* nns, const void* queries_dev,
                            CoopLdsBytesPerWave<float>() * (kCoopBlock / 64), s,
                            MakeView<float>(nns), (const float*)queries_dev, q,
                            max_knn, idx_dev, (float*)dist2_dev, counts_dev);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+int o3dmi_nns_radius_count(const o3dmi_nns_t* nns, const void* queries_dev,
+                           int64_t q, int32_t* counts_dev,
+                           o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(nns != nullptr, "index is null");
+    O3DMI_REQUIRE(q >= 0, "q < 0");
+    if (q == 0) return O3DMI_OK;
+    O3DMI_REQUIRE(queries_dev && counts_dev, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(GridFor(q, kCoopBlock / 64, kCUs * 16)), block(kCoopBlock);
+    if (nns->dtype == O3DMI_F64)
+        hipLaunchKernelGGL(RadiusCountKernel<double>, grid, block, 0, s,
+                           MakeView<double>(nns), (const double*)queries_dev, q,
+                           counts_dev);
+    else
+        hipLaunchKernelGGL(RadiusCountKernel<float>, grid, block, 0, s,
+                           MakeView<float>(nns), (const float*)queries_dev, q,
+                           counts_dev);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+int o3dmi_nns_radius_search(const o3dmi_nns_t* nns, const void* queries_dev,
+                            int64_t q, const int64_t* row_splits_dev,
+                            int32_t* idx_dev, void* dist2_dev,
+                            o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(nns != nullptr, "index is null");
+    O3DMI_REQUIRE(q >= 0, "q < 0");
+    if (q == 0) return O3DMI_OK;
+    O3DMI_REQUIRE(queries_dev && row_splits_dev && idx_dev, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(GridFor(q, kCoopBlock / 64, kCUs * 16)), block(kCoopBlock);
+    if (nns->dtype == O3DMI_F64)
+        hipLaunchKernelGGL(RadiusWriteKernel<double>, grid, block,
+                           CoopLdsBytesPerWave<double>() * (kCoopBlock / 64), s,
+                           MakeView<double>(nns), (const double*)queries_dev, q,
+                           row_splits_dev, idx_dev, (double*)dist2_dev);
+    else
+        hipLaunchKernelGGL(RadiusWriteKernel<float>, grid, block,
+                           CoopLdsBytesPerWave<float>() * (kCoopBlock / 64), s,
+                           MakeView<float>(nns), (const float*)queries_dev, q,
+                           row_splits_dev, idx_dev, (float*)dist2_dev);
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
 }

@@ -357,3 +357,39 @@ def compute_rmse(estimation_method, source, target, target_normals,
         "compute_rmse")
     del keep
     return out.value
+
+
+def fixed_radius_search(points, queries, radius):
+    """core::nns::NearestNeighborSearch(points).FixedRadiusIndex(radius) +
+    FixedRadiusSearch(queries, radius) -> (indices {total} int32, squared
+    distances {total}, neighbors_row_splits {Q+1} int64), neighbours of a
+    query ascending by (distance, index)."""
+    points = require_cuda(points, "points")
+    queries = require_cuda(queries, "queries")
+    if queries.dtype != points.dtype:
+        raise ValueError("points / queries dtype mismatch")
+    L = _lib.lib()
+    h = C.c_void_p()
+    _lib.check(L.o3dmi_nns_create(_lib.ptr(points), points.shape[0],
+                                  TORCH_TO_O3DMI[points.dtype],
+                                  C.c_double(radius), stream(), C.byref(h)),
+               "nns_create")
+    try:
+        q = queries.shape[0]
+        counts = torch.zeros(q, dtype=torch.int32, device="cuda")
+        _lib.check(L.o3dmi_nns_radius_count(h, _lib.ptr(queries), q,
+                                            _lib.ptr(counts), stream()),
+                   "radius_count")
+        splits = torch.zeros(q + 1, dtype=torch.int64, device="cuda")
+        torch.cumsum(counts, 0, out=splits[1:])
+        total = int(splits[-1].item())
+        idx = torch.empty(max(total, 1), dtype=torch.int32, device="cuda")
+        d2 = torch.empty(max(total, 1), dtype=points.dtype, device="cuda")
+        _lib.check(L.o3dmi_nns_radius_search(h, _lib.ptr(queries), q,
+                                             _lib.ptr(splits), _lib.ptr(idx),
+                                             _lib.ptr(d2), stream()),
+                   "radius_search")
+        torch.cuda.synchronize()
+        return idx[:total], d2[:total], splits
+    finally:
+        L.o3dmi_nns_destroy(h)

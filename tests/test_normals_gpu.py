@@ -287,3 +287,39 @@ def test_estimate_normals_radius_variant(dtype):
     assert np.quantile(cosang, 0.01) > 1 - 1e-4
     cos_true = np.abs((got[:12000] * nrm_true).sum(1))
     assert np.median(cos_true) > 0.99
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fixed_radius_search_parity(dtype):
+    """FixedRadiusSearch (CSR lists, no cap): vs the oracle's hybrid search
+    with a cap above the largest neighbourhood; neighbourhoods beyond 64
+    exercise the multi-round emission. Plus the reference's golden
+    (cpp/tests/core/NearestNeighborSearch.cpp:166-216)."""
+    _lib, reg = _gpu()
+    pts, _ = _cloud(8000, 17, dtype)
+    rng = np.random.default_rng(4)
+    qrs = np.ascontiguousarray(np.concatenate(
+        [pts[::2], (pts[:300] + rng.normal(0, 0.02, (300, 3))).astype(dtype),
+         np.array([[500, 500, 500]], dtype)]))
+    radius = 0.35
+    widx, wd2, wcnt = orc.hybrid_search(pts, qrs, radius, 1500)
+    assert 130 < wcnt.max() < 1500 and wcnt.min() == 0
+    idx, d2, splits = reg.fixed_radius_search(torch.from_numpy(pts).cuda(),
+                                              torch.from_numpy(qrs).cuda(),
+                                              radius)
+    splits = splits.cpu().numpy()
+    assert np.array_equal(np.diff(splits), wcnt)
+    flat_i = np.concatenate([widx[i, :c] for i, c in enumerate(wcnt)])
+    flat_d = np.concatenate([wd2[i, :c] for i, c in enumerate(wcnt)])
+    assert np.array_equal(idx.cpu().numpy(), flat_i)
+    assert d2.cpu().numpy().tobytes() == flat_d.tobytes()
+    ref_pts = np.array([[0.0, 0.0, 0.0], [0.0, 0.0, 0.1], [0.0, 0.0, 0.2],
+                        [0.0, 0.1, 0.0], [0.0, 0.1, 0.1], [0.0, 0.1, 0.2],
+                        [0.0, 0.2, 0.0], [0.0, 0.2, 0.1], [0.0, 0.2, 0.2],
+                        [0.1, 0.0, 0.0]], dtype)
+    q1 = np.array([[0.064705, 0.043921, 0.087843]], dtype)
+    i1, dd1, s1 = reg.fixed_radius_search(torch.from_numpy(ref_pts).cuda(),
+                                          torch.from_numpy(q1).cuda(), 0.1)
+    assert i1.cpu().numpy().tolist() == [1, 4]
+    assert s1.cpu().numpy().tolist() == [0, 2]
+    assert np.allclose(dd1.cpu().numpy(), [0.00626358, 0.00747938], atol=1e-6)
