@@ -183,8 +183,10 @@ int o3dmi_pointcloud_estimate_normals(const void* points_dev, int64_t n,
                                       o3dmi_stream_t stream);
 
 /* PointCloud::EstimateColorGradients(max_nn, radius) (t/geometry/PointCloud.
- * cpp:987-1060): hybrid search when radius > 0, KNN search otherwise;
- * gradients {n,3} in the point dtype. max_nn <= 64. Synchronises. */
+ * cpp:987-1060): hybrid search when both are given, KNN search when
+ * radius <= 0, radius search (every neighbour within radius) when
+ * max_nn <= 0; gradients {n,3} in the point dtype. max_nn <= 64 otherwise.
+ * Synchronises. */
 int o3dmi_pointcloud_estimate_color_gradients(
         const void* points_dev, const void* normals_dev, const void* colors_dev,
         int64_t n, int dtype, int max_nn, double radius, void* gradients_dev,

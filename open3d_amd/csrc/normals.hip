@@ -11,6 +11,8 @@
 // agree with the CPU path to ~1e-6, not bit for bit.
 // Gather-bound: 30 neighbours x 12 B per point, L2-resident for a sorted cloud.
 
+#include <hipcub/hipcub.hpp>
+
 #include <cmath>
 #include <cstdlib>
 
@@ -371,18 +373,24 @@ __device__ __forceinline__ void PinvSolveSym3(const T* AtA, const T* Atb,
 // EstimatePointWiseColorGradientKernel, PointCloudImpl.h:1067-1165: intensity
 // least squares over the neighbours projected on the tangent plane + the
 // constraint gradient . normal = 0 (the first neighbour is the point itself).
+// Neighbour lists: fixed-width rows (indices + max_nn * w, counts[w]) or, when
+// row_splits != NULL, CSR (radius search).
 template <typename T, bool EXACT>
 __global__ void ColorGradientsKernel(const T* __restrict__ points,
                                      const T* __restrict__ normals,
                                      const T* __restrict__ colors,
                                      const int32_t* __restrict__ indices,
                                      const int32_t* __restrict__ counts,
+                                     const int64_t* __restrict__ row_splits,
                                      int64_t n, int max_nn,
                                      T* __restrict__ gradients) {
     for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < n;
          w += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t* idx = indices + (int64_t)max_nn * w;
-        const int32_t cnt = counts[w];
+        const int32_t* idx = row_splits ? indices + row_splits[w]
+                                        : indices + (int64_t)max_nn * w;
+        const int32_t cnt = row_splits
+                                    ? (int32_t)(row_splits[w + 1] - row_splits[w])
+                                    : counts[w];
         T* out = gradients + 3 * w;
         if (cnt < 4) {
             out[0] = 0;
@@ -594,16 +602,33 @@ int o3dmi_pointcloud_estimate_normals(const void* points_dev, int64_t n,
 
 // EstimateColorGradientsUsing{Hybrid,KNN}SearchCUDA after the search
 // (PointCloudImpl.h:1170-1290): gradients {n,3} from given neighbour lists.
+static int ColorGradientsLaunch(
+        const void* points_dev, const void* normals_dev, const void* colors_dev,
+        const int32_t* indices_dev, const int32_t* counts_dev,
+        const int64_t* row_splits_dev, int64_t n, int max_nn, int dtype,
+        void* gradients_dev, o3dmi_stream_t stream);
+
 int o3dmi_pointcloud_color_gradients_from_neighbors(
         const void* points_dev, const void* normals_dev, const void* colors_dev,
         const int32_t* indices_dev, const int32_t* counts_dev, int64_t n,
         int max_nn, int dtype, void* gradients_dev, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(n == 0 || counts_dev != nullptr, "null argument");
+    return ColorGradientsLaunch(points_dev, normals_dev, colors_dev,
+                                indices_dev, counts_dev, nullptr, n, max_nn,
+                                dtype, gradients_dev, stream);
+}
+
+static int ColorGradientsLaunch(
+        const void* points_dev, const void* normals_dev, const void* colors_dev,
+        const int32_t* indices_dev, const int32_t* counts_dev,
+        const int64_t* row_splits_dev, int64_t n, int max_nn, int dtype,
+        void* gradients_dev, o3dmi_stream_t stream) {
     O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
                   "points must be Float32 or Float64");
     O3DMI_REQUIRE(n >= 0 && max_nn >= 1, "bad sizes");
     if (n == 0) return O3DMI_OK;
     O3DMI_REQUIRE(points_dev && normals_dev && colors_dev && indices_dev &&
-                          counts_dev && gradients_dev,
+                          (counts_dev || row_splits_dev) && gradients_dev,
                   "null argument");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(GridFor(n, kBlock)), block(kBlock);
@@ -612,8 +637,8 @@ int o3dmi_pointcloud_color_gradients_from_neighbors(
 #define O3DMI_GRAD(T, X)                                                       \
     hipLaunchKernelGGL((ColorGradientsKernel<T, X>), grid, block, 0, s,        \
                        (const T*)points_dev, (const T*)normals_dev,            \
-                       (const T*)colors_dev, indices_dev, counts_dev, n,       \
-                       max_nn, (T*)gradients_dev)
+                       (const T*)colors_dev, indices_dev, counts_dev,          \
+                       row_splits_dev, n, max_nn, (T*)gradients_dev)
     if (dtype == O3DMI_F64) {
         if (exact) O3DMI_GRAD(double, true);
         else O3DMI_GRAD(double, false);
@@ -634,14 +659,63 @@ int o3dmi_pointcloud_estimate_color_gradients(
         o3dmi_stream_t stream) {
     O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
                   "Only Float32 and Float64 point clouds are supported.");
-    O3DMI_REQUIRE(max_nn > 0,
-                  "EstimateColorGradients: the radius-only variant is not "
-                  "implemented by this backend.");
+    O3DMI_REQUIRE(max_nn > 0 || radius > 0, "Both max_nn and radius are none.");
     O3DMI_REQUIRE(n >= 0, "n < 0");
     if (n == 0) return O3DMI_OK;
     O3DMI_REQUIRE(points_dev && normals_dev && colors_dev && gradients_dev,
                   "null argument");
     hipStream_t s = (hipStream_t)stream;
+    if (max_nn <= 0) {
+        // EstimateColorGradientsUsingRadiusSearch (PointCloudImpl.h): CSR
+        // lists from the fixed-radius search (count, prefix sum, write).
+        O3DMI_REQUIRE(n < (1ll << 31), "too many points");
+        o3dmi_nns_t* index = nullptr;
+        int st = o3dmi_nns_create(points_dev, n, dtype, radius, stream, &index);
+        if (st) return st;
+        char* buf = nullptr;
+        const size_t cnt_bytes = (sizeof(int32_t) * (size_t)n + 255) & ~(size_t)255;
+        const size_t spl_bytes = (sizeof(int64_t) * (size_t)(n + 1) + 255) & ~(size_t)255;
+        size_t tmp_bytes = 0;
+        (void)hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, (int32_t*)nullptr,
+                                               (int64_t*)nullptr, (int)n, s);
+        tmp_bytes = (tmp_bytes + 255) & ~(size_t)255;
+        st = PoolAlloc((void**)&buf, cnt_bytes + spl_bytes + tmp_bytes);
+        int32_t* lists = nullptr;
+        if (!st) {
+            int32_t* cnt = (int32_t*)buf;
+            int64_t* splits = (int64_t*)(buf + cnt_bytes);
+            void* tmp = buf + cnt_bytes + spl_bytes;
+            st = o3dmi_nns_radius_count(index, points_dev, n, cnt, stream);
+            int64_t total = 0;
+            if (!st) {
+                if (hipMemsetAsync(splits, 0, sizeof(int64_t), s) != hipSuccess ||
+                    hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, cnt,
+                                                     splits + 1, (int)n, s) !=
+                            hipSuccess ||
+                    hipMemcpyAsync(&total, splits + n, sizeof(int64_t),
+                                   hipMemcpyDeviceToHost, s) != hipSuccess ||
+                    hipStreamSynchronize(s) != hipSuccess) {
+                    SetLastError("EstimateColorGradients: prefix sum failed");
+                    st = O3DMI_ERR_HIP;
+                }
+            }
+            if (!st)
+                st = PoolAlloc((void**)&lists,
+                               sizeof(int32_t) * (size_t)(total > 0 ? total : 1));
+            if (!st)
+                st = o3dmi_nns_radius_search(index, points_dev, n, splits, lists,
+                                             nullptr, stream);
+            if (!st)
+                st = ColorGradientsLaunch(points_dev, normals_dev, colors_dev,
+                                          lists, nullptr, splits, n, 1, dtype,
+                                          gradients_dev, stream);
+        }
+        (void)hipStreamSynchronize(s);
+        PoolFree(lists);
+        PoolFree(buf);
+        o3dmi_nns_destroy(index);
+        return st;
+    }
     const int k = (int)(n < (int64_t)max_nn ? n : (int64_t)max_nn);
     char* scratch = nullptr;
     const size_t idx_bytes =

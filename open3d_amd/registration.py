@@ -313,9 +313,10 @@ def estimate_color_gradients(positions, normals, colors, max_nn=30,
     positions = require_cuda(positions, "positions")
     normals = require_cuda(normals, "normals")
     colors = require_cuda(colors, "colors")
+    if max_nn is None and radius is None:
+        raise ValueError("Both max_nn and radius are none.")
     if max_nn is None:
-        raise ValueError("the radius-only variant is not implemented by this "
-                         "backend: give max_nn")
+        max_nn = -1      # radius search
     out = torch.empty_like(positions)
     _lib.check(_lib.lib().o3dmi_pointcloud_estimate_color_gradients(
         _lib.ptr(positions), _lib.ptr(normals), _lib.ptr(colors),

@@ -982,3 +982,19 @@ def test_compute_rmse_colored_is_the_residual_sum():
                            source_colors=dev["sc"], target_colors=dev["tc"],
                            target_color_gradients=dev["tg"])
     assert abs(got - want) <= 1e-10 * abs(want)
+
+
+def test_color_gradients_radius_variant():
+    """EstimateColorGradients(max_nn = nullopt, radius): CSR lists from the
+    fixed-radius search; vs the oracle on the same (sorted) lists."""
+    _lib, reg = _gpu()
+    p, _, tc = _colored_pair(6000, 71, np.float32)
+    pts, nrm = p["target"], p["target_normals"]
+    radius = 0.4
+    idx, _, cnt = orc.hybrid_search(pts, pts, radius, 400)
+    assert 64 < cnt.max() < 400
+    want = orc.estimate_color_gradients(pts, nrm, tc, idx, cnt)
+    got = reg.estimate_color_gradients(
+        torch.from_numpy(pts).cuda(), torch.from_numpy(nrm).cuda(),
+        torch.from_numpy(tc).cuda(), None, radius).cpu().numpy()
+    assert np.array_equal(got, want, equal_nan=True)
