@@ -48,15 +48,21 @@ __device__ __forceinline__ float Cos(float v) { return cosf(v); }
 __device__ __forceinline__ double Cos(double v) { return cos(v); }
 
 // PointCloudImpl.h:512-585
+// Neighbour lists: fixed-width rows, or CSR when row_splits != NULL.
 template <typename T>
 __global__ void CovariancesKernel(const T* __restrict__ points,
                                   const int32_t* __restrict__ indices,
-                                  const int32_t* __restrict__ counts, int64_t n,
-                                  int max_nn, T* __restrict__ covariances) {
+                                  const int32_t* __restrict__ counts,
+                                  const int64_t* __restrict__ row_splits,
+                                  int64_t n, int max_nn,
+                                  T* __restrict__ covariances) {
     for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < n;
          w += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t* idx = indices + (int64_t)max_nn * w;
-        const int32_t cnt = counts[w];
+        const int32_t* idx = row_splits ? indices + row_splits[w]
+                                        : indices + (int64_t)max_nn * w;
+        const int32_t cnt = row_splits
+                                    ? (int32_t)(row_splits[w + 1] - row_splits[w])
+                                    : counts[w];
         T* cov = covariances + 9 * w;
         if (cnt < 3) {
 #pragma unroll
@@ -453,6 +459,59 @@ __global__ void ColorGradientsKernel(const T* __restrict__ points,
 
 using namespace o3dmi;
 
+namespace {
+
+// Sorted neighbour lists of every point of a cloud within the index radius,
+// CSR: FixedRadiusSearch = count pass, prefix sum, write pass.
+struct CsrLists {
+    char* buf = nullptr;         // counts | splits | scan scratch
+    int64_t* splits = nullptr;   // [n + 1]
+    int32_t* indices = nullptr;  // [total]
+    void Free() {
+        PoolFree(indices);
+        PoolFree(buf);
+        indices = nullptr;
+        buf = nullptr;
+    }
+};
+
+int BuildRadiusLists(const o3dmi_nns_t* index, const void* points_dev,
+                     int64_t n, hipStream_t s, CsrLists* out) {
+    o3dmi_stream_t stream = (o3dmi_stream_t)s;
+    const size_t cnt_bytes = (sizeof(int32_t) * (size_t)n + 255) & ~(size_t)255;
+    const size_t spl_bytes =
+            (sizeof(int64_t) * (size_t)(n + 1) + 255) & ~(size_t)255;
+    size_t tmp_bytes = 0;
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes,
+                                           (int32_t*)nullptr,
+                                           (int64_t*)nullptr, (int)n, s);
+    tmp_bytes = (tmp_bytes + 255) & ~(size_t)255;
+    int st = PoolAlloc((void**)&out->buf, cnt_bytes + spl_bytes + tmp_bytes);
+    if (st) return st;
+    int32_t* cnt = (int32_t*)out->buf;
+    out->splits = (int64_t*)(out->buf + cnt_bytes);
+    void* tmp = out->buf + cnt_bytes + spl_bytes;
+    if ((st = o3dmi_nns_radius_count(index, points_dev, n, cnt, stream)))
+        return st;
+    int64_t total = 0;
+    if (hipMemsetAsync(out->splits, 0, sizeof(int64_t), s) != hipSuccess ||
+        hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, cnt, out->splits + 1,
+                                         (int)n, s) != hipSuccess ||
+        hipMemcpyAsync(&total, out->splits + n, sizeof(int64_t),
+                       hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+        SetLastError("radius lists: prefix sum failed");
+        return O3DMI_ERR_HIP;
+    }
+    if ((st = PoolAlloc((void**)&out->indices,
+                        sizeof(int32_t) * (size_t)(total > 0 ? total : 1))))
+        return st;
+    return o3dmi_nns_radius_search(index, points_dev, n, out->splits,
+                                   out->indices, nullptr, stream);
+}
+
+}  // namespace
+
 extern "C" {
 
 int o3dmi_pointcloud_estimate_covariances(const void* points_dev,
@@ -472,11 +531,13 @@ int o3dmi_pointcloud_estimate_covariances(const void* points_dev,
     if (dtype == O3DMI_F64)
         hipLaunchKernelGGL(CovariancesKernel<double>, grid, block, 0, s,
                            (const double*)points_dev, indices_dev, counts_dev,
-                           n, max_nn, (double*)covariances_dev);
+                           (const int64_t*)nullptr, n, max_nn,
+                           (double*)covariances_dev);
     else
         hipLaunchKernelGGL(CovariancesKernel<float>, grid, block, 0, s,
-                           (const float*)points_dev, indices_dev, counts_dev, n,
-                           max_nn, (float*)covariances_dev);
+                           (const float*)points_dev, indices_dev, counts_dev,
+                           (const int64_t*)nullptr, n, max_nn,
+                           (float*)covariances_dev);
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
 }
@@ -527,20 +588,42 @@ int o3dmi_pointcloud_estimate_normals(const void* points_dev, int64_t n,
     hipStream_t s = (hipStream_t)stream;
     const size_t esz = dtype == O3DMI_F64 ? 8 : 4;
     if (max_nn <= 0) {
-        // EstimateCovariancesUsingRadiusSearch, PointCloudImpl.h:641-689:
-        // no neighbour lists, the wave accumulates the moments directly
+        // EstimateCovariancesUsingRadiusSearch, PointCloudImpl.h:641-689: CSR
+        // lists from the fixed-radius search (sorted by distance, as the
+        // reference's), then the same per-point covariance body -- bit for
+        // bit. (o3dmi_nns_radius_covariances is the list-free fast form:
+        // float64 wave sums, equal to rounding.)
+        O3DMI_REQUIRE(n < (1ll << 31), "too many points");
         o3dmi_nns_t* index = nullptr;
         int st = o3dmi_nns_create(points_dev, n, dtype, radius, stream, &index);
         if (st) return st;
+        CsrLists lists;
+        st = BuildRadiusLists(index, points_dev, n, s, &lists);
         void* cov = nullptr;
-        st = PoolAlloc(&cov, esz * 9 * (size_t)n);
-        if (!st)
-            st = o3dmi_nns_radius_covariances(index, points_dev, n, cov, stream);
+        if (!st) st = PoolAlloc(&cov, esz * 9 * (size_t)n);
+        if (!st) {
+            dim3 grid(GridFor(n, kBlock)), block(kBlock);
+            if (dtype == O3DMI_F64)
+                hipLaunchKernelGGL(CovariancesKernel<double>, grid, block, 0, s,
+                                   (const double*)points_dev, lists.indices,
+                                   (const int32_t*)nullptr, lists.splits, n, 1,
+                                   (double*)cov);
+            else
+                hipLaunchKernelGGL(CovariancesKernel<float>, grid, block, 0, s,
+                                   (const float*)points_dev, lists.indices,
+                                   (const int32_t*)nullptr, lists.splits, n, 1,
+                                   (float*)cov);
+            if (hipGetLastError() != hipSuccess) {
+                SetLastError("covariance kernel launch failed");
+                st = O3DMI_ERR_HIP;
+            }
+        }
         if (!st)
             st = o3dmi_pointcloud_normals_from_covariances(
                     cov, n, dtype, normals_dev, has_normals, stream);
         (void)hipStreamSynchronize(s);
         PoolFree(cov);
+        lists.Free();
         o3dmi_nns_destroy(index);
         return st;
     }
@@ -672,47 +755,14 @@ int o3dmi_pointcloud_estimate_color_gradients(
         o3dmi_nns_t* index = nullptr;
         int st = o3dmi_nns_create(points_dev, n, dtype, radius, stream, &index);
         if (st) return st;
-        char* buf = nullptr;
-        const size_t cnt_bytes = (sizeof(int32_t) * (size_t)n + 255) & ~(size_t)255;
-        const size_t spl_bytes = (sizeof(int64_t) * (size_t)(n + 1) + 255) & ~(size_t)255;
-        size_t tmp_bytes = 0;
-        (void)hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, (int32_t*)nullptr,
-                                               (int64_t*)nullptr, (int)n, s);
-        tmp_bytes = (tmp_bytes + 255) & ~(size_t)255;
-        st = PoolAlloc((void**)&buf, cnt_bytes + spl_bytes + tmp_bytes);
-        int32_t* lists = nullptr;
-        if (!st) {
-            int32_t* cnt = (int32_t*)buf;
-            int64_t* splits = (int64_t*)(buf + cnt_bytes);
-            void* tmp = buf + cnt_bytes + spl_bytes;
-            st = o3dmi_nns_radius_count(index, points_dev, n, cnt, stream);
-            int64_t total = 0;
-            if (!st) {
-                if (hipMemsetAsync(splits, 0, sizeof(int64_t), s) != hipSuccess ||
-                    hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, cnt,
-                                                     splits + 1, (int)n, s) !=
-                            hipSuccess ||
-                    hipMemcpyAsync(&total, splits + n, sizeof(int64_t),
-                                   hipMemcpyDeviceToHost, s) != hipSuccess ||
-                    hipStreamSynchronize(s) != hipSuccess) {
-                    SetLastError("EstimateColorGradients: prefix sum failed");
-                    st = O3DMI_ERR_HIP;
-                }
-            }
-            if (!st)
-                st = PoolAlloc((void**)&lists,
-                               sizeof(int32_t) * (size_t)(total > 0 ? total : 1));
-            if (!st)
-                st = o3dmi_nns_radius_search(index, points_dev, n, splits, lists,
-                                             nullptr, stream);
-            if (!st)
-                st = ColorGradientsLaunch(points_dev, normals_dev, colors_dev,
-                                          lists, nullptr, splits, n, 1, dtype,
-                                          gradients_dev, stream);
-        }
+        CsrLists lists;
+        st = BuildRadiusLists(index, points_dev, n, s, &lists);
+        if (!st)
+            st = ColorGradientsLaunch(points_dev, normals_dev, colors_dev,
+                                      lists.indices, nullptr, lists.splits, n,
+                                      1, dtype, gradients_dev, stream);
         (void)hipStreamSynchronize(s);
-        PoolFree(lists);
-        PoolFree(buf);
+        lists.Free();
         o3dmi_nns_destroy(index);
         return st;
     }
