@@ -464,7 +464,7 @@ int o3dmi_icp_colored_accumulate(
  * the intensity over its neighbours projected on the tangent plane plus the
  * constraint gradient . normal = 0. The 3x3 normal equations go through the
  * reference's approximate solve_svd3x3 (core/linalg/kernel/SVD3x3.h) restated
- * bit for bit (csrc/svd3x3.h) -- including its Float64 quirks, which yield NaN
+ * bit for bit (csrc/approx_svd3.h) -- including its Float64 quirks, which yield NaN
  * on some neighbourhoods; O3DMI_EXACT_COLOR_GRADIENTS=1 selects an exact
  * solve instead. */
 int o3dmi_pointcloud_color_gradients_from_neighbors(

@@ -17,7 +17,7 @@
 #include <cstdlib>
 
 #include "common.h"
-#include "svd3x3.h"
+#include "approx_svd3.h"
 
 namespace o3dmi {
 namespace {
@@ -316,7 +316,7 @@ __global__ void NormalsFromCovariancesKernel(const T* __restrict__ covariances,
 // x = pinv(AtA) Atb for a symmetric 3x3 AtA: cyclic Jacobi eigen-decomposition
 // (8 sweeps, converged for 3x3), eigenvalues below 1e-10 dropped -- the exact
 // solution of the normal equations. The default is the reference's
-// solve_svd3x3 (svd3x3.h, bit for bit); this one is selected by
+// solve_svd3x3 (approx_svd3.h, bit for bit); this one is selected by
 // O3DMI_EXACT_COLOR_GRADIENTS=1 (the reference's Float64 path returns NaN on
 // some neighbourhoods).
 template <typename T>

@@ -43,7 +43,7 @@
 #include <omp.h>
 #endif
 
-#include "svd3x3_oracle.h"
+#include "approx_svd3_oracle.h"
 
 namespace {
 
@@ -1943,7 +1943,7 @@ void ColorGradient(const scalar_t* points_ptr, const scalar_t* normals_ptr,
     AtA[7] = AtA[5];
     if (exact_solve)
         PinvSolveSym3<scalar_t>(AtA, Atb, color_gradients_ptr + idx_offset);
-    else  // core::linalg::kernel::solve_svd3x3, restated in svd3x3_oracle.h
+    else  // core::linalg::kernel::solve_svd3x3, restated in approx_svd3_oracle.h
         svd3::SolveSvd3x3<scalar_t>(AtA, Atb, color_gradients_ptr + idx_offset);
 }
 
@@ -2051,7 +2051,7 @@ void orc_estimate_color_gradients(const void* points, const void* normals,
                 (float*)gradients, exact_solve != 0);
 }
 
-// svd3x3 / solve_svd3x3 restated (svd3x3_oracle.h): row-major 3x3.
+// svd3x3 / solve_svd3x3 restated (approx_svd3_oracle.h): row-major 3x3.
 void orc_svd3x3(const void* A, int is_f64, void* U, void* S, void* V) {
     if (is_f64)
         svd3::Svd3x3<double>((const double*)A, (double*)U, (double*)S,

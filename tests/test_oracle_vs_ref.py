@@ -488,7 +488,7 @@ def _color_field(P):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_svd3x3_restatement_bit_exact(dtype):
     """core::linalg::kernel::svd3x3 / solve_svd3x3 (SVD3x3.h) vs the
-    restatement in oracle/svd3x3_oracle.h on random, symmetric, rank-deficient
+    restatement in oracle/approx_svd3_oracle.h on random, symmetric, rank-deficient
     and diagonal matrices (the last make the masked guards fire). Float64: the
     reference's 32-bit masks on a double's low word make it return NaN on some
     inputs; NaN positions must agree, NaN payloads are not compared."""
