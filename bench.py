@@ -97,26 +97,37 @@ def cpu_baseline(frames_cpu, K, Ts, budget_s):
         wgt = np.zeros((cap, RES, RES, RES), np.uint16)
         col = np.zeros((cap, RES, RES, RES, 3), np.uint16)
         n = 0
+        phase = [0.0, 0.0, 0.0]  # touch, activate + find, integrate (seconds)
         t0 = time.perf_counter()
         for (d, c), T in frames:
+            ta = time.perf_counter()
             keys = impl.depth_touch(d, K, T, RES, VOXEL, VOXEL * TRUNC,
                                     DEPTH_SCALE, DEPTH_MAX)
+            tb = time.perf_counter()
             h.activate(keys)
             buf, _ = h.find(keys)
+            tc = time.perf_counter()
             impl.integrate(d, c, buf, h.key_buffer(), tsdf, wgt, col, K, K, T,
                            RES, VOXEL, VOXEL * TRUNC, DEPTH_SCALE, DEPTH_MAX)
+            td = time.perf_counter()
+            phase[0] += tb - ta
+            phase[1] += tc - tb
+            phase[2] += td - tc
             n += 1
             if time.perf_counter() - t0 > budget:
                 break
-        return n / (time.perf_counter() - t0), n
+        return n / (time.perf_counter() - t0), n, [1e3 * x / n for x in phase]
 
     frames = list(zip(frames_cpu, Ts))
     cands = sorted({c for c in (8, 16, 32, 64, 128, cores) if c <= cores})
     probe = {c: run(c, frames[:6], budget_s * 0.08)[0] for c in cands}
     best = max(probe, key=probe.get)
-    fps, n = run(best, frames, budget_s * 0.5)
+    fps, n, phase_ms = run(best, frames, budget_s * 0.5)
     return {"value": fps, "unit": "frames/s", "cores": best,
             "kind": "reference" if use_ref else "port",
+            "ms_per_frame": {"touch": phase_ms[0],
+                             "activate_find": phase_ms[1],
+                             "integrate": phase_ms[2]},
             "sample": "first %d frames of the same 640x480 stream (touch + "
                       "activate + integrate, u16 grid with colour); %s; best "
                       "of %s threads on a %d-thread host"
