@@ -86,6 +86,22 @@ def mode_icp(a):
                                   estimation=1 if p2point else 0)
         out["cpu_oracle_ms_per_icp"] = (time.perf_counter() - t0) * 1e3
         out["cpu_oracle_threads"] = min(64, os.cpu_count() or 1)
+        if not p2point:
+            # one iteration, phase by phase: search, 29-sum
+            # accumulation, transform
+            ta = time.perf_counter()
+            idx, _, _ = orc.hybrid_search(p["target"], p["source"], 0.07, 1)
+            tb = time.perf_counter()
+            orc.p2plane_accumulate(p["source"], p["target"],
+                                   p["target_normals"],
+                                   idx[:, 0].astype(np.int64),
+                                   accumulate_double=True)
+            tc = time.perf_counter()
+            orc.transform_points(np.eye(4), p["source"])
+            td = time.perf_counter()
+            out["cpu_oracle_ms_per_iteration_phase"] = {
+                "search": (tb - ta) * 1e3, "accumulate": (tc - tb) * 1e3,
+                "transform": (td - tc) * 1e3}
         out["pose_err_vs_oracle_rad_m"] = pose_err(want["transformation"],
                                                    res.transformation)
         out["same_iterations_as_oracle"] = (want["num_iterations"] ==
