@@ -998,3 +998,88 @@ def test_color_gradients_radius_variant():
         torch.from_numpy(pts).cuda(), torch.from_numpy(nrm).cuda(),
         torch.from_numpy(tc).cuda(), None, radius).cpu().numpy()
     assert np.array_equal(got, want, equal_nan=True)
+
+
+@pytest.mark.parametrize("estimation", ["plane", "point", "symmetric",
+                                        "colored"])
+def test_icp_source_sharded_two_ranks_equal_one_rank(estimation):
+    """the source cloud split over two ranks (here two host
+    threads, each with its own stream, mailbox and search index on the one
+    GPU), the target replicated, one all-reduce of the 32 sums per reduction
+    through the driver's hook. Both ranks must finish with the same pose as the
+    unsharded run (sums differ only in the order of the last double adds)."""
+    import threading
+    _lib, reg = _gpu()
+    from open3d_amd.sharding import shard_range
+    p, sc, tc = _colored_pair(20000, 7, np.float32)
+    idx, _, _ = orc.hybrid_search(p["target"],
+                                  orc.transform_points(p["T_gt"], p["source"]),
+                                  0.2, 1)
+    sn = orc.transform_normals(np.linalg.inv(p["T_gt"]),
+                               p["target_normals"][np.maximum(idx[:, 0], 0)])
+    nidx, _, ncnt = orc.hybrid_search(p["target"], p["target"], 0.1, 30)
+    tg = orc.estimate_color_gradients(p["target"], p["target_normals"], tc,
+                                      nidx, ncnt, exact_solve=True)
+    est = {"plane": reg.TransformationEstimationPointToPlane,
+           "point": reg.TransformationEstimationPointToPoint,
+           "symmetric": reg.TransformationEstimationSymmetric,
+           "colored": reg.TransformationEstimationForColoredICP}[estimation]
+    tgt, tn, tcol, tgrad = (torch.from_numpy(a).cuda() for a in
+                            (p["target"], p["target_normals"], tc, tg))
+
+    def run(b, e, allreduce):
+        return reg.icp(
+            torch.from_numpy(p["source"][b:e]).cuda(), tgt, tn, 0.07,
+            estimation_method=est(),
+            criteria=reg.ICPConvergenceCriteria(1e-6, 1e-6, 30),
+            allreduce=allreduce,
+            source_normals=torch.from_numpy(sn[b:e]).cuda(),
+            source_colors=torch.from_numpy(sc[b:e]).cuda(),
+            target_colors=tcol, target_color_gradients=tgrad)
+
+    n = p["source"].shape[0]
+    one = run(0, n, None)
+
+    world = 2
+    barrier = threading.Barrier(world, timeout=60)
+    slots = [None] * world
+    calls = [0] * world
+    out = [None] * world
+
+    def rank_main(rank):
+        def allreduce(a):
+            slots[rank] = a.copy()
+            barrier.wait()
+            total = sum(slots[r] for r in range(world))
+            barrier.wait()
+            a[:] = total
+            calls[rank] += 1
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                out[rank] = run(*shard_range(n, rank, world), allreduce)
+                torch.cuda.synchronize()
+        except BaseException as ex:  # noqa: BLE001 - reported below
+            out[rank] = ex
+            barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,))
+               for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    for r in range(world):
+        assert not isinstance(out[r], BaseException), out[r]
+        assert out[r] is not None, "rank %d did not finish" % r
+    per_iteration = 2 if estimation in ("symmetric", "colored") else 1
+    assert calls[0] == calls[1] >= one.num_iterations * per_iteration
+    for r in range(world):
+        ang, tr = _pose_err(one.transformation, out[r].transformation)
+        assert ang <= 1e-9 and tr <= 1e-9, (r, ang, tr)
+        assert out[r].num_iterations == one.num_iterations
+        assert abs(out[r].fitness - one.fitness) < 1e-12
+        assert abs(out[r].inlier_rmse - one.inlier_rmse) < 1e-9
+    assert np.array_equal(out[0].transformation, out[1].transformation)
+    both = np.concatenate([out[r].correspondence_set.cpu().numpy()
+                           for r in range(world)])
+    assert np.array_equal(both, one.correspondence_set.cpu().numpy())
