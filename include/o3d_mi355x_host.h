@@ -485,6 +485,31 @@ int o3dmi_vbg_save(o3dmi_vbg_t* g, const char* file_name,
  * the current device. */
 int o3dmi_vbg_load(const char* file_name, o3dmi_stream_t stream,
                    o3dmi_vbg_t** out);
+/* Frame-sharded multi-GPU integration, the merge step (SURVEY section 8e
+ * scheme B; no counterpart in the reference, which is single-device). Each
+ * rank integrates its own frames into a private grid; the grids are then
+ * combined block by block.
+ * o3dmi_vbg_export_blocks writes the ACTIVE blocks in ascending buffer index
+ * (the order of Save): keys {n,3} int32 and, per attribute i, the value rows
+ * {n,res,res,res,C_i} into values_dev[i] (device, caller-allocated for
+ * `capacity` blocks). keys_dev == NULL only counts. *n_out = number of active
+ * blocks (synchronises); O3DMI_ERR_CAPACITY if it exceeds `capacity`.
+ * o3dmi_vbg_merge_blocks folds n foreign blocks of the same attribute layout
+ * into `g`: missing blocks are activated (HashMap::Activate's capacity policy),
+ * then per voxel, with w1 / w2 the weights of `g` / of the foreign block:
+ *   w2 == 0: unchanged;  w1 == 0: the foreign voxel is copied;
+ *   else inv = 1 / (w1 + w2), tsdf = (w1 tsdf1 + w2 tsdf2) inv,
+ *        colour likewise per channel, weight = w1 + w2
+ * in float32 with Integrate's store conversions -- the running mean Integrate
+ * itself computes (VoxelBlockGridImpl.h:258-300), so folding a one-frame grid
+ * in is bit-identical to integrating that frame. Keys must be unique. */
+int o3dmi_vbg_export_blocks(o3dmi_vbg_t* g, int64_t capacity,
+                            int32_t* keys_dev, void* const* values_dev,
+                            int64_t* n_out, o3dmi_stream_t stream);
+int o3dmi_vbg_merge_blocks(o3dmi_vbg_t* g, const int32_t* keys_dev,
+                           const void* const* values_dev, int64_t n,
+                           o3dmi_stream_t stream);
+
 /* Introspection of a grid (needed after Load): attribute count / i-th name,
  * voxel size, block resolution. */
 int o3dmi_vbg_attribute_count(const o3dmi_vbg_t* g);

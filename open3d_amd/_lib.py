@@ -263,6 +263,9 @@ PROTOTYPES.update({
                              C.POINTER(_vp)]),
     "o3dmi_npz_write": (_i32, [_vp, C.c_char_p]),
     "o3dmi_npz_read": (_i32, [C.c_char_p, C.POINTER(_vp)]),
+    "o3dmi_vbg_export_blocks": (_i32, [_vp, _i64, _vp, C.POINTER(_vp),
+                                       C.POINTER(_i64), _vp]),
+    "o3dmi_vbg_merge_blocks": (_i32, [_vp, _vp, C.POINTER(_vp), _i64, _vp]),
     "o3dmi_vbg_save": (_i32, [_vp, C.c_char_p, _vp]),
     "o3dmi_vbg_load": (_i32, [C.c_char_p, _vp, C.POINTER(_vp)]),
     "o3dmi_vbg_attribute_count": (_i32, [_vp]),

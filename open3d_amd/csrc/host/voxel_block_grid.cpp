@@ -221,6 +221,44 @@ __global__ void ExportIndexKeysKernel(const int32_t* __restrict__ indices,
     if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = (int32_t)n;
 }
 
+
+// Folds foreign blocks into the grid (o3dmi_vbg_merge_blocks): one thread per
+// voxel, block b of the foreign set lands in buffer row indices[b]. Streaming:
+// reads both sides once, writes the grid side once.
+template <typename W>
+__global__ void MergeBlocksKernel(const int32_t* __restrict__ indices,
+                                  int64_t n_voxels_total, int voxels_per_block,
+                                  float* __restrict__ tsdf,
+                                  W* __restrict__ weight, W* __restrict__ color,
+                                  const float* __restrict__ src_tsdf,
+                                  const W* __restrict__ src_weight,
+                                  const W* __restrict__ src_color) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+         i < n_voxels_total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / voxels_per_block;
+        const int64_t v = i - b * voxels_per_block;
+        const int64_t d = (int64_t)indices[b] * voxels_per_block + v;
+        const float w2 = (float)src_weight[i];
+        if (w2 == 0) continue;
+        const float w1 = (float)weight[d];
+        if (w1 == 0) {
+            tsdf[d] = src_tsdf[i];
+            weight[d] = src_weight[i];
+            if (color)
+                for (int c = 0; c < 3; ++c) color[3 * d + c] = src_color[3 * i + c];
+            continue;
+        }
+        const float inv = 1.0f / (w1 + w2);
+        tsdf[d] = (w1 * tsdf[d] + w2 * src_tsdf[i]) * inv;
+        if (color)
+            for (int c = 0; c < 3; ++c)
+                color[3 * d + c] = (W)((w1 * (float)color[3 * d + c] +
+                                        w2 * (float)src_color[3 * i + c]) *
+                                       inv);
+        weight[d] = (W)(w1 + w2);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1125,6 +1163,112 @@ int o3dmi_vbg_save(o3dmi_vbg_t* g, const char* file_name,
     // "File name for a voxel grid should be with the extension .npz."
     if (ext != "npz") path += ".npz";
     return o3dmi_npz_write(&z, path.c_str());
+}
+
+int o3dmi_vbg_export_blocks(o3dmi_vbg_t* g, int64_t capacity,
+                            int32_t* keys_dev, void* const* values_dev,
+                            int64_t* n_out, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(g && n_out, "null argument");
+    O3DMI_REQUIRE(keys_dev == nullptr || values_dev != nullptr,
+                  "values_dev is null");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t cap = o3dmi_hash_capacity(g->block_hashmap);
+    int32_t* active = nullptr;
+    int st = PoolAlloc((void**)&active, sizeof(int32_t) * (size_t)cap);
+    if (st) return st;
+    struct Scratch {
+        hipStream_t s;
+        void* p;
+        ~Scratch() {
+            (void)hipStreamSynchronize(s);
+            PoolFree(p);
+        }
+    } scratch{s, active};
+    int64_t n = 0;
+    if ((st = o3dmi_hash_active_indices(g->block_hashmap, active, stream, &n)))
+        return st;
+    *n_out = n;
+    if (!keys_dev || n == 0) return O3DMI_OK;
+    if (n > capacity) {
+        SetLastError("export_blocks: more active blocks than `capacity`");
+        return O3DMI_ERR_CAPACITY;
+    }
+    if ((st = o3dmi_sort_indices(active, n, stream))) return st;
+    if ((st = GatherRows(o3dmi_hash_key_buffer(g->block_hashmap), active, n, 12,
+                         keys_dev, s)))
+        return st;
+    const int64_t res = g->block_resolution;
+    for (size_t i = 0; i < g->attr_names.size(); ++i) {
+        O3DMI_REQUIRE(values_dev[i] != nullptr, "values_dev[i] is null");
+        const int64_t row = res * res * res * g->attr_channels[i] *
+                            DtypeSize(g->attr_dtypes[i]);
+        if ((st = GatherRows(o3dmi_hash_value_buffer(g->block_hashmap, (int)i),
+                             active, n, row, values_dev[i], s)))
+            return st;
+    }
+    return O3DMI_OK;
+}
+
+int o3dmi_vbg_merge_blocks(o3dmi_vbg_t* g, const int32_t* keys_dev,
+                           const void* const* values_dev, int64_t n,
+                           o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(g != nullptr, "grid is null");
+    O3DMI_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return O3DMI_OK;
+    O3DMI_REQUIRE(keys_dev && values_dev, "null argument");
+    const int ti = g->AttrIndex("tsdf"), wi = g->AttrIndex("weight"),
+              ci = g->AttrIndex("color");
+    if (ti < 0 || wi < 0) {
+        SetLastError("TSDF and/or weight not allocated in blocks");
+        return O3DMI_ERR_INVALID_ARG;
+    }
+    O3DMI_REQUIRE(g->attr_dtypes[(size_t)ti] == O3DMI_F32,
+                  "tsdf must be Float32");
+    O3DMI_REQUIRE((int)g->attr_names.size() ==
+                          2 + (ci >= 0 ? 1 : 0),
+                  "merge_blocks handles the tsdf / weight / color attributes");
+    O3DMI_REQUIRE(ci < 0 || g->attr_channels[(size_t)ci] == 3,
+                  "color must have 3 channels");
+    int grid_dtype;
+    int st = GridDtype(g, &grid_dtype);
+    if (st) return st;
+    O3DMI_REQUIRE(values_dev[ti] && values_dev[wi] &&
+                          (ci < 0 || values_dev[ci]),
+                  "values_dev[i] is null");
+    g->known_valid = false;
+    if ((st = EnsureCapacity(g, n, stream))) return st;
+    if ((st = EnsureScratch(g, n))) return st;
+    if ((st = o3dmi_hash_activate(g->block_hashmap, keys_dev, n, nullptr,
+                                  nullptr, nullptr, stream)))
+        return st;
+    if ((st = o3dmi_hash_find(g->block_hashmap, keys_dev, n, nullptr,
+                              g->scratch_buf_indices, nullptr, stream)))
+        return st;
+    const int64_t res = g->block_resolution;
+    const int vpb = (int)(res * res * res);
+    const int64_t total = n * vpb;
+    const int block = 256;
+    const int64_t want = (total + block - 1) / block;
+    const int grid = (int)(want < 65536 ? want : 65536);
+    float* tsdf = (float*)o3dmi_hash_value_buffer(g->block_hashmap, ti);
+    void* weight = o3dmi_hash_value_buffer(g->block_hashmap, wi);
+    void* color = ci >= 0 ? o3dmi_hash_value_buffer(g->block_hashmap, ci)
+                          : nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    if (grid_dtype == O3DMI_F32)
+        MergeBlocksKernel<float><<<grid, block, 0, s>>>(
+                g->scratch_buf_indices, total, vpb, tsdf, (float*)weight,
+                (float*)color, (const float*)values_dev[ti],
+                (const float*)values_dev[wi],
+                ci >= 0 ? (const float*)values_dev[ci] : nullptr);
+    else
+        MergeBlocksKernel<uint16_t><<<grid, block, 0, s>>>(
+                g->scratch_buf_indices, total, vpb, tsdf, (uint16_t*)weight,
+                (uint16_t*)color, (const float*)values_dev[ti],
+                (const uint16_t*)values_dev[wi],
+                ci >= 0 ? (const uint16_t*)values_dev[ci] : nullptr);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
 }
 
 int o3dmi_vbg_load(const char* file_name, o3dmi_stream_t stream,

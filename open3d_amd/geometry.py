@@ -12,8 +12,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from .core import (TORCH_TO_O3DMI, host_mat, require_cuda, stream,
-                   tensor_from_ptr)
+from .core import (O3DMI_TO_TORCH, TORCH_TO_O3DMI, host_mat, require_cuda,
+                   stream, tensor_from_ptr)
 
 
 class HashMapView:
@@ -257,6 +257,59 @@ class VoxelBlockGrid:
             _lib.f64p(Ts), C.c_float(depth_scale), C.c_float(depth_max),
             C.c_float(trunc_voxel_multiplier), int(frames_per_launch), stream()),
             "VoxelBlockGrid.integrate_frames")
+
+    def _attr_layout(self):
+        out = []
+        for nm in self.attr_names:
+            dt, ch = C.c_int(0), C.c_int(0)
+            _lib.lib().o3dmi_vbg_attribute(self._g, nm.encode(), C.byref(dt),
+                                           C.byref(ch))
+            out.append((O3DMI_TO_TORCH[dt.value], ch.value))
+        return out
+
+    def export_blocks(self):
+        """The active blocks in ascending buffer index (the order of save):
+        keys {n,3} int32 and one {n,res,res,res,C} tensor per attribute, on the
+        device. The payload of the frame-sharded merge (sharding.py)."""
+        n = C.c_int64(0)
+        _lib.check(_lib.lib().o3dmi_vbg_export_blocks(
+            self._g, 0, None, None, C.byref(n), stream()), "export_blocks")
+        n = n.value
+        r = self.block_resolution
+        keys = torch.empty((n, 3), dtype=torch.int32, device="cuda")
+        vals = [torch.empty((n, r, r, r, ch), dtype=dt, device="cuda")
+                for dt, ch in self._attr_layout()]
+        if n:
+            ptrs = (C.c_void_p * len(vals))(*[v.data_ptr() for v in vals])
+            m = C.c_int64(0)
+            _lib.check(_lib.lib().o3dmi_vbg_export_blocks(
+                self._g, n, _lib.ptr(keys), ptrs, C.byref(m), stream()),
+                "export_blocks")
+            assert m.value == n
+        return keys, vals
+
+    def merge_blocks(self, keys, values):
+        """Folds foreign blocks (keys {n,3} int32 unique, one value tensor per
+        attribute in this grid's layout) into the grid: weighted running mean
+        per voxel, weights added (o3dmi_vbg_merge_blocks)."""
+        keys = require_cuda(keys, "keys")
+        if keys.dtype != torch.int32 or keys.dim() != 2 or keys.shape[1] != 3:
+            raise ValueError("keys must be {n,3} Int32")
+        layout = self._attr_layout()
+        if len(values) != len(layout):
+            raise ValueError("one value tensor per attribute expected")
+        n = keys.shape[0]
+        r = self.block_resolution
+        vals = []
+        for v, (dt, ch) in zip(values, layout):
+            v = require_cuda(v, "values")
+            if v.dtype != dt or v.numel() != n * r * r * r * ch:
+                raise ValueError("value tensor does not match the grid's "
+                                 "attribute layout")
+            vals.append(v)
+        ptrs = (C.c_void_p * len(vals))(*[v.data_ptr() for v in vals])
+        _lib.check(_lib.lib().o3dmi_vbg_merge_blocks(
+            self._g, _lib.ptr(keys), ptrs, n, stream()), "merge_blocks")
 
     def save(self, file_name):
         """VoxelBlockGrid::Save (VoxelBlockGrid.cpp:474-524): NPZ of the

@@ -17,6 +17,11 @@ this layer is new. Exchanges are tiny and latency-bound:
     (VoxelBlockGrid.set_block_ownership(rank, world)); no data-path
     collective at all, the per-voxel work is split N ways and the union of the
     per-rank grids equals the single-GPU grid bit for bit.
+  * Frame-sharded grids are combined into one model, when one is wanted, by
+    merge_frame_sharded_grid: each rank exports its active blocks, one padded
+    all-gather of keys and value rows, and every rank folds the other ranks'
+    blocks into its own grid (VoxelBlockGrid.merge_blocks: the weighted
+    running mean Integrate itself computes, weights added).
 """
 import numpy as np
 import torch
@@ -72,3 +77,47 @@ def allgather_block_keys(keys, dist):
     dist.all_gather(bufs, pad)
     allk = torch.cat([b[:int(c.item())] for b, c in zip(bufs, ns)], 0)
     return torch.unique(allk, dim=0)
+
+
+def allgather_blocks(keys, values, dist):
+    """All-gather of every rank's exported blocks (keys {M_r,3} int32 and the
+    per-attribute value tensors {M_r,...}); returns a list over ranks of
+    (keys, [values]) trimmed to each rank's count. Padded to the largest
+    M_r so that one collective per tensor is enough."""
+    world = dist.get_world_size()
+    dev = keys.device
+    n = torch.tensor([keys.shape[0]], dtype=torch.int64, device=dev)
+    ns = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(ns, n)
+    counts = [int(x.item()) for x in ns]
+    m = max(counts)
+
+    def gather(t):
+        pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+        pad[:t.shape[0]] = t
+        bufs = [torch.zeros_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad)
+        return bufs
+
+    # no uint16 collectives in gloo / RCCL: 16-bit rows travel as byte views
+    def wire(t):
+        return t.contiguous().view(torch.uint8) if t.dtype == torch.uint16 \
+            else t
+
+    gk = gather(keys)
+    gv = [[b.view(v.dtype) for b in gather(wire(v))] for v in values]
+    return [(gk[r][:counts[r]], [g[r][:counts[r]] for g in gv])
+            for r in range(world)]
+
+
+def merge_frame_sharded_grid(grid, dist):
+    """Folds every other rank's blocks into `grid` (ascending rank order).
+    Afterwards each rank holds the model of the whole stream: identical block
+    sets and weights on every rank, TSDF / colour equal to the single-GPU
+    stream up to the rounding of the running mean (a different association of
+    the same weighted sum; bit-identical for world = 2 on both ranks)."""
+    keys, values = grid.export_blocks()
+    rank = dist.get_rank()
+    for r, (k, v) in enumerate(allgather_blocks(keys, values, dist)):
+        if r != rank and k.shape[0]:
+            grid.merge_blocks(k.contiguous(), [x.contiguous() for x in v])

@@ -116,3 +116,31 @@ def test_block_owner_host_mirror_matches_library():
         assert counts.min() > 0.8 * len(keys) / world
     bad = np.array([1 << 20, 0, 0], np.int32)
     assert L.o3dmi_block_owner(bad.ctypes.data_as(C.POINTER(C.c_int)), 4) == -1
+
+
+def _blocks_gather(rank, world):
+    from open3d_amd.sharding import allgather_blocks
+    rng = np.random.RandomState(10 + rank)
+    m = 5 + 3 * rank
+    keys = rng.randint(-9, 9, (m, 3)).astype(np.int32)
+    tsdf = rng.rand(m, 4, 4, 4, 1).astype(np.float32)
+    weight = rng.randint(0, 60000, (m, 4, 4, 4, 1)).astype(np.uint16)
+    got = allgather_blocks(torch.from_numpy(keys),
+                           [torch.from_numpy(tsdf), torch.from_numpy(weight)],
+                           dist)
+    return (keys, tsdf, weight), [(k.numpy(), [v.numpy() for v in vs])
+                                  for k, vs in got]
+
+
+def test_allgather_blocks_returns_every_ranks_payload():
+    """Ragged block payloads (uint16 rows travel as byte views) arrive intact
+    and in rank order on every rank."""
+    out = _run(_blocks_gather)
+    sent = [o[0] for o in out]
+    for _, got in out:
+        assert len(got) == 2
+        for r in range(2):
+            k, (t, w) = got[r]
+            assert np.array_equal(k, sent[r][0])
+            assert t.dtype == np.float32 and np.array_equal(t, sent[r][1])
+            assert w.dtype == np.uint16 and np.array_equal(w, sent[r][2])
