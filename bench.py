@@ -67,6 +67,11 @@ def parse():
                          "stream and integrates only the blocks it owns "
                          "(strong scaling, union of the grids bit-identical "
                          "to one GPU)")
+    ap.add_argument("--merge-model", action="store_true",
+                    help="frame sharding, N > 1: after the timed region fold "
+                         "every other rank's blocks into this rank's grid "
+                         "(sharding.merge_frame_sharded_grid) and report its "
+                         "time as config.merge_ms; not part of `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -226,6 +231,15 @@ def main():
     elapsed = t1 - t0
     prof = g.profile_end()
     n_blocks = g.hashmap().size()
+    merge_ms = None
+    if a.merge_model and dist is not None and not by_blocks:
+        from open3d_amd.sharding import merge_frame_sharded_grid
+        barrier()
+        tm = time.perf_counter()
+        merge_frame_sharded_grid(g, dist)
+        torch.cuda.synchronize()
+        barrier()
+        merge_ms = (time.perf_counter() - tm) * 1e3
 
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -288,7 +302,7 @@ def main():
                                 "block-ID all-gather at the end" if by_blocks
                                 else "frames r, r+N, ... per rank; block-ID "
                                      "all-gather at the end"),
-                   "union_blocks": n_union},
+                   "union_blocks": n_union, "merge_ms": merge_ms},
         "roofline": {"bound": "hbm", "kernel": "FrameStepKernel",
                      "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
