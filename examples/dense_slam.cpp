@@ -1,0 +1,270 @@
+// Dense RGB-D SLAM loop driven from plain C++ through the C ABI only (no Python,
+// no torch): what a C++ caller of the reference's slam::Model does in
+// examples/cpp/.../DenseSLAM (track -> update pose -> integrate -> synthesize),
+// here against libo3d_mi355x.so. Device memory comes from hipMalloc, everything
+// else is include/o3d_mi355x_host.h.
+//
+// The input is an analytic scene rendered on the host: the inside of a box room
+// (V-shaped back wall) with a sphere in it, seen by a camera that slides 5 mm per frame. Because the
+// poses are known in closed form the program checks its own result: the tracked
+// trajectory must stay within 6 cm / 1 degree of the truth and the extracted
+// surface must be non-empty. Exit code 0 = ok. (Frame-to-model tracking against
+// a projectively integrated TSDF drifts by a few centimetres on such a stream --
+// that is the algorithm, the reference's included; value-level parity with the
+// reference is what tests/ establish. This check catches gross breakage: a
+// wrong convention shows up as > 10 cm / > 10 degrees.)
+//
+//   hipcc -O2 -std=c++17 examples/dense_slam.cpp -Iinclude \
+//         -Lopen3d_amd/lib -lo3d_mi355x -Wl,-rpath,'$ORIGIN/../open3d_amd/lib' \
+//         -o examples/dense_slam
+//   examples/dense_slam [frames=40] [width=640] [height=480]
+
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "o3d_mi355x_host.h"
+
+namespace {
+
+#define CHECK_HIP(expr)                                                      \
+    do {                                                                     \
+        hipError_t e_ = (expr);                                              \
+        if (e_ != hipSuccess) {                                              \
+            std::fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #expr, \
+                         hipGetErrorString(e_));                             \
+            std::exit(2);                                                    \
+        }                                                                    \
+    } while (0)
+
+#define CHECK_O3D(expr)                                                       \
+    do {                                                                      \
+        int s_ = (expr);                                                      \
+        if (s_ != 0) {                                                        \
+            std::fprintf(stderr, "%s:%d %s -> %d: %s\n", __FILE__, __LINE__,  \
+                         #expr, s_, o3dmi_last_error());                      \
+            std::exit(2);                                                     \
+        }                                                                     \
+    } while (0)
+
+struct Camera {
+    double fx, fy, cx, cy;
+    int width, height;
+};
+
+// Distance along the viewing ray (direction (x, y, 1) in the camera frame, the
+// camera looks down +z and is only translated) to the first surface; returns
+// the z-depth in metres and the hit point in the world.
+double CastRay(const double eye[3], double dx, double dy, double hit[3]) {
+    const double dir[3] = {dx, dy, 1.0};
+    // small enough that the side walls, floor and ceiling are inside the field
+    // of view: a lone front wall + sphere would leave one rotation free
+    const double lo[3] = {-1.2, -0.9, -1.0}, hi[3] = {1.3, 0.8, 2.2};
+    double t = 1e30;
+    for (int a = 0; a < 3; ++a) {
+        if (dir[a] > 1e-12) t = std::fmin(t, (hi[a] - eye[a]) / dir[a]);
+        if (dir[a] < -1e-12) t = std::fmin(t, (lo[a] - eye[a]) / dir[a]);
+    }
+    // the back of the room is a shallow V (two walls meeting at x = 0): their
+    // normals carry an x component, which is what lets point-to-plane
+    // tracking see the sideways motion
+    for (int side = -1; side <= 1; side += 2) {
+        const double n[3] = {0.6 * side, 0.0, 1.0}, d = 2.0;
+        const double denom = n[0] * dir[0] + n[2] * dir[2];
+        const double num = d - (n[0] * eye[0] + n[2] * eye[2]);
+        if (denom > 1e-12) t = std::fmin(t, num / denom);
+    }
+    // sphere
+    const double c[3] = {0.3, 0.2, 1.5}, r = 0.35;
+    double oc[3] = {eye[0] - c[0], eye[1] - c[1], eye[2] - c[2]};
+    const double A = dir[0] * dir[0] + dir[1] * dir[1] + 1.0;
+    const double B = 2 * (oc[0] * dir[0] + oc[1] * dir[1] + oc[2] * dir[2]);
+    const double Cq = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2] - r * r;
+    const double disc = B * B - 4 * A * Cq;
+    if (disc > 0) {
+        const double ts = (-B - std::sqrt(disc)) / (2 * A);
+        if (ts > 0 && ts < t) t = ts;
+    }
+    for (int a = 0; a < 3; ++a) hit[a] = eye[a] + t * dir[a];
+    return t;  // dir.z == 1: the ray parameter is the z-depth
+}
+
+void RenderFrame(const Camera& cam, const double eye[3],
+                 std::vector<uint16_t>& depth, std::vector<uint8_t>& color) {
+    depth.resize((size_t)cam.width * cam.height);
+    color.resize((size_t)cam.width * cam.height * 3);
+    for (int v = 0; v < cam.height; ++v)
+        for (int u = 0; u < cam.width; ++u) {
+            double hit[3];
+            const double z = CastRay(eye, (u - cam.cx) / cam.fx,
+                                     (v - cam.cy) / cam.fy, hit);
+            const double mm = z * 1000.0;
+            const size_t i = (size_t)v * cam.width + u;
+            depth[i] = mm < 65535.0 ? (uint16_t)(mm + 0.5) : 0;
+            for (int a = 0; a < 3; ++a) {
+                // smooth texture so that every pixel carries a gradient
+                const double s = 0.5 + 0.5 * std::sin(5.0 * hit[a] + a);
+                color[3 * i + a] = (uint8_t)(40 + 170 * s);
+            }
+        }
+}
+
+template <typename T>
+T* DeviceAlloc(size_t n) {
+    void* p = nullptr;
+    CHECK_HIP(hipMalloc(&p, sizeof(T) * (n ? n : 1)));
+    return (T*)p;
+}
+
+void Matmul4(const double* A, const double* B, double* out) {
+    double r[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double s = 0;
+            for (int k = 0; k < 4; ++k) s += A[i * 4 + k] * B[k * 4 + j];
+            r[i * 4 + j] = s;
+        }
+    for (int i = 0; i < 16; ++i) out[i] = r[i];
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    const int n_frames = argc > 1 ? std::atoi(argv[1]) : 40;
+    Camera cam;
+    cam.width = argc > 2 ? std::atoi(argv[2]) : 640;
+    cam.height = argc > 3 ? std::atoi(argv[3]) : 480;
+    // PrimeSense-like intrinsics scaled with the image
+    cam.fx = 525.0 * cam.width / 640.0;
+    cam.fy = 525.0 * cam.height / 480.0;
+    cam.cx = 0.5 * cam.width - 0.5;
+    cam.cy = 0.5 * cam.height - 0.5;
+    const double K[9] = {cam.fx, 0, cam.cx, 0, cam.fy, cam.cy, 0, 0, 1};
+    const float depth_scale = 1000.0f, depth_max = 3.0f, trunc_multiplier = 8.0f;
+    const size_t pixels = (size_t)cam.width * cam.height;
+
+    hipStream_t stream;
+    CHECK_HIP(hipStreamCreate(&stream));
+
+    // Frames: rendered on the host, uploaded once (the loop below is the part
+    // being demonstrated and timed).
+    std::vector<uint16_t*> depth_dev((size_t)n_frames);
+    std::vector<uint8_t*> color_dev((size_t)n_frames);
+    std::vector<double> eye((size_t)n_frames * 3);
+    {
+        std::vector<uint16_t> d;
+        std::vector<uint8_t> c;
+        for (int k = 0; k < n_frames; ++k) {
+            double* e = &eye[(size_t)k * 3];
+            e[0] = -0.2 + 0.005 * k;
+            e[1] = 0.03 * std::sin(0.1 * k);
+            e[2] = 0.0;
+            RenderFrame(cam, e, d, c);
+            depth_dev[(size_t)k] = DeviceAlloc<uint16_t>(pixels);
+            color_dev[(size_t)k] = DeviceAlloc<uint8_t>(pixels * 3);
+            CHECK_HIP(hipMemcpy(depth_dev[(size_t)k], d.data(),
+                                sizeof(uint16_t) * pixels,
+                                hipMemcpyHostToDevice));
+            CHECK_HIP(hipMemcpy(color_dev[(size_t)k], c.data(), pixels * 3,
+                                hipMemcpyHostToDevice));
+        }
+    }
+
+    double T[16] = {1, 0, 0, eye[0], 0, 1, 0, eye[1], 0, 0, 1, eye[2], 0, 0, 0, 1};
+    o3dmi_slam_model_t* model = nullptr;
+    CHECK_O3D(o3dmi_slam_model_create(0.008f, 16, 40000, T, stream, &model));
+    float* raycast_depth = DeviceAlloc<float>(pixels);
+    float* raycast_color = DeviceAlloc<float>(pixels * 3);
+
+    // coarse-to-fine iteration counts; the reference's dense-SLAM default is
+    // {6, 3, 1}, which under-converges on noise-free synthetic walls
+    const o3dmi_odometry_criteria_t criteria[3] = {
+            {20, 1e-6, 1e-6}, {10, 1e-6, 1e-6}, {5, 1e-6, 1e-6}};
+    double worst_translation = 0, worst_angle = 0;
+    int iterations = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < n_frames; ++k) {
+        if (k > 0) {
+            // TrackFrameToModel: input frame against the ray-cast model frame
+            o3dmi_odometry_result_t r;
+            CHECK_O3D(o3dmi_slam_model_track_frame_to_model(
+                    model, depth_dev[(size_t)k], O3DMI_U16,
+                    color_dev[(size_t)k], O3DMI_U8, raycast_depth,
+                    raycast_color, cam.height, cam.width, K, depth_scale,
+                    depth_max, 0.07f, /*method: point-to-plane*/ 0, 3, criteria,
+                    &r, stream));
+            Matmul4(T, r.transformation, T);
+            iterations += r.num_iterations;
+        }
+        CHECK_O3D(o3dmi_slam_model_update_frame_pose(model, k, T));
+        CHECK_O3D(o3dmi_slam_model_integrate(
+                model, depth_dev[(size_t)k], O3DMI_U16, color_dev[(size_t)k],
+                cam.height, cam.width, K, depth_scale, depth_max,
+                trunc_multiplier, stream));
+        CHECK_O3D(o3dmi_slam_model_synthesize_model_frame(
+                model, K, cam.width, cam.height, depth_scale, 0.1f, depth_max,
+                trunc_multiplier, -1.0f, raycast_depth, raycast_color, stream));
+
+        const double* e = &eye[(size_t)k * 3];
+        const double dt = std::sqrt((T[3] - e[0]) * (T[3] - e[0]) +
+                                    (T[7] - e[1]) * (T[7] - e[1]) +
+                                    (T[11] - e[2]) * (T[11] - e[2]));
+        const double tr = (T[0] + T[5] + T[10] - 1.0) * 0.5;
+        const double ang = std::acos(std::fmax(-1.0, std::fmin(1.0, tr)));
+        if (std::getenv("DENSE_SLAM_VERBOSE"))
+            std::fprintf(stderr, "frame %d error %+.4f %+.4f %+.4f m, %.4f rad\n",
+                         k, T[3] - e[0], T[7] - e[1], T[11] - e[2], ang);
+        worst_translation = std::fmax(worst_translation, dt);
+        worst_angle = std::fmax(worst_angle, ang);
+    }
+    CHECK_HIP(hipStreamSynchronize(stream));
+    const double seconds =
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0)
+                    .count();
+
+    // ExtractPointCloud: count first (capacity < 0), then fetch.
+    int64_t total = 0;
+    CHECK_O3D(o3dmi_slam_model_extract_point_cloud(model, 3.0f, -1, nullptr,
+                                                   nullptr, nullptr, &total,
+                                                   stream));
+    float* points = DeviceAlloc<float>((size_t)total * 3);
+    float* normals = DeviceAlloc<float>((size_t)total * 3);
+    float* colors = DeviceAlloc<float>((size_t)total * 3);
+    int64_t written = 0;
+    if (total > 0)
+        CHECK_O3D(o3dmi_slam_model_extract_point_cloud(
+                model, 3.0f, total, points, normals, colors, &written, stream));
+    CHECK_HIP(hipStreamSynchronize(stream));
+
+    std::printf(
+            "{\"example\": \"dense_slam.cpp\", \"frames\": %d, \"width\": %d, "
+            "\"height\": %d, \"frames_per_s\": %.1f, \"odometry_iterations\": %d, "
+            "\"max_translation_error_m\": %.3g, \"max_rotation_error_rad\": %.3g, "
+            "\"frustum_blocks\": %lld, \"surface_points\": %lld}\n",
+            n_frames, cam.width, cam.height, n_frames / seconds, iterations,
+            worst_translation, worst_angle,
+            (long long)o3dmi_slam_model_frustum_block_count(model),
+            (long long)written);
+
+    (void)hipFree(points);
+    (void)hipFree(normals);
+    (void)hipFree(colors);
+    (void)hipFree(raycast_depth);
+    (void)hipFree(raycast_color);
+    CHECK_O3D(o3dmi_slam_model_destroy(model));
+    for (int k = 0; k < n_frames; ++k) {
+        (void)hipFree(depth_dev[(size_t)k]);
+        (void)hipFree(color_dev[(size_t)k]);
+    }
+    (void)hipStreamDestroy(stream);
+
+    const bool ok = worst_translation < 0.06 && worst_angle < 0.01745 &&
+                    written > 1000 && total == written;
+    if (!ok) std::fprintf(stderr, "dense_slam: self-check FAILED\n");
+    return ok ? 0 : 1;
+}

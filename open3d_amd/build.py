@@ -99,5 +99,32 @@ def build(force=False, verbose=True):
     return SO
 
 
+def build_examples(verbose=True):
+    """examples/*.cpp: plain C++ callers of the C ABI (no Python, no torch),
+    linked against the library built above."""
+    out = []
+    exdir = os.path.join(ROOT, "examples")
+    for f in sorted(os.listdir(exdir)) if os.path.isdir(exdir) else []:
+        if not f.endswith(".cpp"):
+            continue
+        src = os.path.join(exdir, f)
+        exe = src[:-4]
+        if _stale(exe, [src, SO] + headers() +
+                  [os.path.join(ROOT, "include", "o3d_mi355x_host.h")]):
+            cmd = [HIPCC, "-O2", "-std=c++17", src,
+                   "-I" + os.path.join(ROOT, "include"), "-L" + LIBDIR,
+                   "-lo3d_mi355x", "-Wl,-rpath,$ORIGIN/../open3d_amd/lib",
+                   "-o", exe]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("example build failed for %s:\n%s\n%s" %
+                                   (src, r.stdout, r.stderr))
+            if verbose:
+                print("[open3d_amd.build] built", exe, flush=True)
+        out.append(exe)
+    return out
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_examples()

@@ -7,6 +7,8 @@ Bars: extracted points / normals / colours bit-exact and in the oracle's
 sequential order; per-frame tracking pose within 1e-6 rad / 1e-5 m of the
 oracle on identical inputs; the integrated grid bit-exact; the synthesized model
 frame within 1e-3 depth units / 1e-5 colour of the oracle's ray cast."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -232,3 +234,22 @@ def test_model_depth_only_and_dummy_colour():
     assert r.fitness > 0.5
     with pytest.raises(RuntimeError, match="previous Integrate"):
         slam.Model(sc.VOXEL).synthesize_model_frame(slam.Frame(H, W, K))
+
+
+def test_cpp_host_example_runs_the_loop_through_the_c_abi():
+    """examples/dense_slam.cpp: a plain C++ program (hipMalloc + the C ABI, no
+    Python / torch in the process) runs the slam::Model loop on an analytic
+    scene and checks its own trajectory against the closed-form poses."""
+    import json
+    import subprocess
+    import __graft_entry__ as ge
+    ge.build()
+    exe = os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "examples", "dense_slam")
+    r = subprocess.run([exe, "30", "320", "240"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["frames"] == 30 and out["surface_points"] > 1000
+    assert out["max_translation_error_m"] < 0.06
+    assert out["max_rotation_error_rad"] < 0.01745
