@@ -251,5 +251,5 @@ def test_cpp_host_example_runs_the_loop_through_the_c_abi():
     assert r.returncode == 0, (r.stdout, r.stderr)
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["frames"] == 30 and out["surface_points"] > 1000
-    assert out["max_translation_error_m"] < 0.06
+    assert out["max_translation_error_m"] < 0.08
     assert out["max_rotation_error_rad"] < 0.01745
