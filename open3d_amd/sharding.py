@@ -86,18 +86,22 @@ def allgather_blocks(keys, values, dist):
     M_r so that one collective per tensor is enough."""
     world = dist.get_world_size()
     dev = keys.device
-    n = torch.tensor([keys.shape[0]], dtype=torch.int64, device=dev)
+    # gloo moves host memory: device tensors are staged through the host there
+    # (the CPU tests, and single-GPU multi-process runs); RCCL takes them as is
+    wire_dev = torch.device("cpu") if dist.get_backend() == "gloo" else dev
+    n = torch.tensor([keys.shape[0]], dtype=torch.int64, device=wire_dev)
     ns = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(ns, n)
     counts = [int(x.item()) for x in ns]
     m = max(counts)
 
     def gather(t):
-        pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
-        pad[:t.shape[0]] = t
+        pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype,
+                          device=wire_dev)
+        pad[:t.shape[0]] = t.to(wire_dev)
         bufs = [torch.zeros_like(pad) for _ in range(world)]
         dist.all_gather(bufs, pad)
-        return bufs
+        return [b.to(dev) for b in bufs]
 
     # no uint16 collectives in gloo / RCCL: 16-bit rows travel as byte views
     def wire(t):
