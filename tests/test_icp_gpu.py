@@ -1083,3 +1083,14 @@ def test_icp_source_sharded_two_ranks_equal_one_rank(estimation):
     both = np.concatenate([out[r].correspondence_set.cpu().numpy()
                            for r in range(world)])
     assert np.array_equal(both, one.correspondence_set.cpu().numpy())
+
+
+def test_voxel_down_sample_golden_through_gpu():
+    """cpp/tests/t/geometry/PointCloud.cpp:1300-1314."""
+    _lib, reg = _gpu()
+    pts = np.array([[0.1, 0.3, 0.9], [0.9, 0.2, 0.4], [0.3, 0.6, 0.8],
+                    [0.2, 0.4, 0.2]], np.float32)
+    down, _ = reg.voxel_down_sample(torch.from_numpy(pts).cuda(), None, 1.0)
+    assert tuple(down.shape) == (1, 3)
+    assert np.allclose(down.cpu().numpy(), [[0.375, 0.375, 0.575]],
+                       rtol=1e-5, atol=1e-8)

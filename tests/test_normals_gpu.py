@@ -324,3 +324,17 @@ def test_fixed_radius_search_parity(dtype):
     assert i1.cpu().numpy().tolist() == [1, 4]
     assert s1.cpu().numpy().tolist() == [0, 2]
     assert np.allclose(dd1.cpu().numpy(), [0.00626358, 0.00747938], atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_estimate_normals_cube_golden_through_gpu(dtype):
+    """cpp/tests/t/geometry/PointCloud.cpp:630-668: the reference's own
+    EstimateNormals value test (signs included), all three search variants, on
+    an 8-point cloud (far below one wave: the searches' small-n paths)."""
+    from test_oracle_goldens import CUBE, CUBE_NORMALS
+    _lib, reg = _gpu()
+    tp = torch.from_numpy(CUBE.astype(dtype)).cuda()
+    for kw in ({"max_nn": 4, "radius": 2.0}, {"max_nn": 4},
+               {"max_nn": None, "radius": 1.1}):
+        got = reg.estimate_normals(tp, **kw).cpu().numpy()
+        assert np.allclose(got, CUBE_NORMALS, rtol=1e-4, atol=1e-4), kw

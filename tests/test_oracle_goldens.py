@@ -281,3 +281,39 @@ def test_hashmap_semantics():
     assert not m3[0]
     buf4, m4 = h.activate(keys)
     assert not m4.any() and h.size() == 3
+
+
+# cpp/tests/t/geometry/PointCloud.cpp:630-668 (EstimateNormals): the unit cube's
+# corners; hybrid (4, 2.0), KNN (4) and radius (1.1) all see a corner plus its
+# three edge neighbours.
+CUBE = np.array([[0, 0, 0], [0, 0, 1], [0, 1, 0], [0, 1, 1],
+                 [1, 0, 0], [1, 0, 1], [1, 1, 0], [1, 1, 1]], np.float64)
+S3 = 0.57735
+CUBE_NORMALS = np.array([[S3, S3, S3], [-S3, -S3, S3], [S3, -S3, S3],
+                         [-S3, S3, S3], [-S3, S3, S3], [S3, -S3, S3],
+                         [-S3, -S3, S3], [S3, S3, S3]])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_estimate_normals_cube_golden(dtype):
+    pts = CUBE.astype(dtype)
+    lists = {
+        "hybrid": orc.hybrid_search(pts, pts, 2.0, 4)[::2],
+        "knn": (orc.knn_search(pts, pts, 4)[0], np.full(8, 4, np.int32)),
+        "radius": orc.hybrid_search(pts, pts, 1.1, 8)[::2],
+    }
+    for name, (idx, cnt) in lists.items():
+        assert np.array_equal(cnt, np.full(8, 4)), name
+        nrm = orc.normals_from_covariances(
+            orc.estimate_covariances(pts, idx, cnt))
+        assert np.allclose(nrm, CUBE_NORMALS, rtol=1e-4, atol=1e-4), name
+
+
+def test_voxel_down_sample_golden():
+    """cpp/tests/t/geometry/PointCloud.cpp:1300-1314: four points in one unit
+    voxel -> their mean."""
+    pts = np.array([[0.1, 0.3, 0.9], [0.9, 0.2, 0.4], [0.3, 0.6, 0.8],
+                    [0.2, 0.4, 0.2]], np.float32)
+    down, _ = orc.voxel_down_sample(pts, None, 1.0)
+    assert down.shape == (1, 3)
+    assert np.allclose(down, [[0.375, 0.375, 0.575]], rtol=1e-5, atol=1e-8)
