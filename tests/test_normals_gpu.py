@@ -338,3 +338,20 @@ def test_estimate_normals_cube_golden_through_gpu(dtype):
                {"max_nn": None, "radius": 1.1}):
         got = reg.estimate_normals(tp, **kw).cpu().numpy()
         assert np.allclose(got, CUBE_NORMALS, rtol=1e-4, atol=1e-4), kw
+
+
+def test_nns_coincident_and_tie_break_cases_through_gpu():
+    """cpp/tests/core/NearestNeighborSearch.cpp:495-533,780-794 (C1, C4)."""
+    _lib, reg = _gpu()
+    from test_oracle_goldens import KNN_PTS
+    tp = torch.from_numpy(KNN_PTS).cuda()
+    q = torch.tensor([[0.0, 0.1, 0.1]], device="cuda")    # dataset point 4
+    idx, d2 = reg.knn_search(tp, q, 3)
+    assert int(idx[0, 0]) == 4 and float(d2[0, 0]) == 0.0
+    ridx, rd2, splits = reg.fixed_radius_search(tp, q, 0.05)
+    assert splits.cpu().tolist() == [0, 1]
+    assert int(ridx[0]) == 4 and float(rd2[0]) == 0.0
+    tri = torch.eye(3, device="cuda")
+    idx, d2 = reg.knn_search(tri, torch.zeros((1, 3), device="cuda"), 3)
+    assert idx.cpu().tolist() == [[0, 1, 2]]
+    assert np.allclose(d2.cpu().numpy(), 1.0, atol=1e-5)

@@ -317,3 +317,17 @@ def test_voxel_down_sample_golden():
     down, _ = orc.voxel_down_sample(pts, None, 1.0)
     assert down.shape == (1, 3)
     assert np.allclose(down, [[0.375, 0.375, 0.575]], rtol=1e-5, atol=1e-8)
+
+
+def test_nns_coincident_and_tie_break_cases():
+    """cpp/tests/core/NearestNeighborSearch.cpp:495-533,780-794: a query on a
+    dataset point has distance exactly 0 (C1); equidistant neighbours come in
+    index order (C4)."""
+    q = np.array([[0.0, 0.1, 0.1]], np.float32)           # dataset point 4
+    idx, d2 = orc.knn_search(KNN_PTS, q, 3)
+    assert idx[0, 0] == 4 and d2[0, 0] == 0.0
+    ridx, rd2, rcnt = orc.hybrid_search(KNN_PTS, q, 0.05, 12)
+    assert rcnt[0] == 1 and ridx[0, 0] == 4 and rd2[0, 0] == 0.0
+    tri = np.eye(3, dtype=np.float32)
+    idx, d2 = orc.knn_search(tri, np.zeros((1, 3), np.float32), 3)
+    assert idx.tolist() == [[0, 1, 2]] and np.allclose(d2, 1.0, atol=1e-5)
