@@ -73,6 +73,12 @@ def parse():
                          "(sharding.merge_frame_sharded_grid) and report its "
                          "time as config.merge_ms; not part of `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--depth-only", action="store_true",
+                    help="diagnostics: grid without colour (tsdf + weight)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the live rocprofv3 counter passes")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the ICP legs (configs[0] / configs[2])")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -187,9 +193,16 @@ def main():
             Ts.append(T[0])
     torch.cuda.synchronize()
 
-    g = geometry.VoxelBlockGrid(["tsdf", "weight", "color"],
-                                [torch.float32, torch.uint16, torch.uint16],
-                                [1, 1, 3], VOXEL, RES, a.block_count)
+    if a.depth_only:
+        g = geometry.VoxelBlockGrid(["tsdf", "weight"],
+                                    [torch.float32, torch.uint16], [1, 1],
+                                    VOXEL, RES, a.block_count)
+        colors = None
+    else:
+        g = geometry.VoxelBlockGrid(["tsdf", "weight", "color"],
+                                    [torch.float32, torch.uint16,
+                                     torch.uint16],
+                                    [1, 1, 3], VOXEL, RES, a.block_count)
     if by_blocks:
         g.set_block_ownership(rank, world)
 
@@ -200,7 +213,9 @@ def main():
                 g.integrate_frame(depths[i], colors[i], K, K, Ts[i],
                                   DEPTH_SCALE, DEPTH_MAX, TRUNC)
         else:
-            g.integrate_frames(depths[lo:hi], colors[lo:hi], K, K, Ts[lo:hi],
+            g.integrate_frames(depths[lo:hi],
+                               colors[lo:hi] if colors is not None else None,
+                               K, K, Ts[lo:hi],
                                DEPTH_SCALE, DEPTH_MAX, TRUNC,
                                frames_per_launch=a.frames_per_launch)
 

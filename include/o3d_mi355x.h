@@ -46,7 +46,8 @@ typedef enum {
     O3DMI_ERR_SINGULAR = 5,     /* singular 6x6 system                     */
     O3DMI_ERR_NO_BLOCKS = 6,    /* "No block is touched in TSDF volume"    */
     O3DMI_ERR_UNSUPPORTED = 7,
-    O3DMI_ERR_NO_INLIERS = 8    /* "Invalid inlier_count value, must be > 0." */
+    O3DMI_ERR_NO_INLIERS = 8,   /* "Invalid inlier_count value, must be > 0." */
+    O3DMI_ERR_INTERNAL = 9      /* a device-side consistency check failed  */
 } o3dmi_status_t;
 
 typedef enum {

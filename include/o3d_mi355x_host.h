@@ -499,10 +499,13 @@ int o3dmi_vbg_load(const char* file_name, o3dmi_stream_t stream,
  * then per voxel, with w1 / w2 the weights of `g` / of the foreign block:
  *   w2 == 0: unchanged;  w1 == 0: the foreign voxel is copied;
  *   else inv = 1 / (w1 + w2), tsdf = (w1 tsdf1 + w2 tsdf2) inv,
- *        colour likewise per channel, weight = w1 + w2
+ *        colour likewise per channel, weight = w1 + w2 (uint16 grids:
+ *        saturating at 65535)
  * in float32 with Integrate's store conversions -- the running mean Integrate
  * itself computes (VoxelBlockGridImpl.h:258-300), so folding a one-frame grid
- * in is bit-identical to integrating that frame. Keys must be unique. */
+ * in is bit-identical to integrating that frame. Precondition (not checked):
+ * the n keys are pairwise distinct -- two rows with one key would race on
+ * the same voxels. */
 int o3dmi_vbg_export_blocks(o3dmi_vbg_t* g, int64_t capacity,
                             int32_t* keys_dev, void* const* values_dev,
                             int64_t* n_out, o3dmi_stream_t stream);

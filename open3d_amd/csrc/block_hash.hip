@@ -52,42 +52,32 @@ __global__ void ActivateKernel(HashView hv, const int* __restrict__ keys,
         if (!KeyInRange(x, y, z)) {
             atomicOr(&hv.counters[1], kErrKeyRange);
         } else {
-            unsigned long long k = PackKey(x, y, z);
-            unsigned h = HashKey(k) & hv.mask;
-            while (true) {
-                unsigned long long cur = hv.slot_keys[h];
-                if (cur == k) break;  // already present (or a duplicate won)
-                if (cur == kEmptyKey) {
-                    unsigned long long old =
-                            atomicCAS(&hv.slot_keys[h], kEmptyKey, k);
-                    if (old == kEmptyKey) {
-                        int top = atomicAdd(&hv.counters[0], 1);
-                        if (top >= hv.capacity) {
-                            atomicOr(&hv.counters[1], kErrCapacity);
-                            break;
+            unsigned h = 0;
+            // 1 = this thread created the entry (duplicates in one launch:
+            // exactly one thread per distinct new key)
+            if (ClaimSlot(hv, PackKey(x, y, z), h) == 1) {
+                int top = atomicAdd(&hv.counters[0], 1);
+                if (top >= hv.capacity) {
+                    atomicOr(&hv.counters[1], kErrCapacity);
+                } else {
+                    int idx = hv.heap[top];
+                    hv.key_buffer[3 * idx + 0] = x;
+                    hv.key_buffer[3 * idx + 1] = y;
+                    hv.key_buffer[3 * idx + 2] = z;
+                    hv.slot_vals[h] = idx;
+                    if (kHasValues) {
+                        for (int j = 0; j < n_values; ++j) {
+                            int64_t sz = value_dsizes[j];
+                            const uint8_t* s =
+                                    (const uint8_t*)values_src[j] + sz * i;
+                            uint8_t* d = (uint8_t*)values_dst[j] +
+                                         sz * (int64_t)idx;
+                            for (int64_t b = 0; b < sz; ++b) d[b] = s[b];
                         }
-                        int idx = hv.heap[top];
-                        hv.key_buffer[3 * idx + 0] = x;
-                        hv.key_buffer[3 * idx + 1] = y;
-                        hv.key_buffer[3 * idx + 2] = z;
-                        hv.slot_vals[h] = idx;
-                        if (kHasValues) {
-                            for (int j = 0; j < n_values; ++j) {
-                                int64_t sz = value_dsizes[j];
-                                const uint8_t* s =
-                                        (const uint8_t*)values_src[j] + sz * i;
-                                uint8_t* d = (uint8_t*)values_dst[j] +
-                                             sz * (int64_t)idx;
-                                for (int64_t b = 0; b < sz; ++b) d[b] = s[b];
-                            }
-                        }
-                        out_idx = idx;
-                        out_mask = 1;
-                        break;
                     }
-                    if (old == k) break;
+                    out_idx = idx;
+                    out_mask = 1;
                 }
-                h = (h + 1) & hv.mask;
             }
         }
         if (buf_indices) buf_indices[i] = out_idx;
@@ -120,7 +110,7 @@ __global__ void EraseKernel(HashView hv, const int* __restrict__ keys,
         if (KeyInRange(x, y, z)) {
             unsigned long long k = PackKey(x, y, z);
             unsigned h = HashKey(k) & hv.mask;
-            while (true) {
+            for (unsigned step = 0; step <= hv.mask; ++step) {
                 unsigned long long cur = hv.slot_keys[h];
                 if (cur == kEmptyKey) break;
                 if (cur == k) {
@@ -163,6 +153,23 @@ __global__ void ActiveIndicesKernel(HashView hv, int64_t n_slots, int* out,
     }
 }
 
+// Slot-table rebuild (same capacity, buffer indices unchanged): puts the keys
+// of the listed buffer indices back into a cleared table.
+__global__ void ReinsertKernel(HashView hv, const int* __restrict__ active,
+                               int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int idx = active[i];
+        unsigned h = 0;
+        if (ClaimSlot(hv,
+                      PackKey(hv.key_buffer[3 * idx + 0],
+                              hv.key_buffer[3 * idx + 1],
+                              hv.key_buffer[3 * idx + 2]),
+                      h) == 1)
+            hv.slot_vals[h] = idx;
+    }
+}
+
 template <typename T>
 int DevAlloc(T** p, int64_t n) {
     O3DMI_HIP_CHECK(hipMalloc((void**)p, (size_t)(n > 0 ? n : 1) * sizeof(T)));
@@ -182,7 +189,7 @@ int AllocateStorage(o3dmi_hash* h, int64_t capacity, hipStream_t s) {
     int st;
     if ((st = DevAlloc(&v.slot_keys, h->n_slots))) return st;
     if ((st = DevAlloc(&v.slot_vals, h->n_slots))) return st;
-    if ((st = DevAlloc(&v.slot_touch, h->n_slots))) return st;
+    if ((st = DevAlloc(&v.slot_touch, 2 * h->n_slots))) return st;
     if ((st = DevAlloc(&v.heap, capacity))) return st;
     if ((st = DevAlloc(&v.counters, 4))) return st;
     if ((st = DevAlloc(&v.key_buffer, capacity * 3))) return st;
@@ -198,7 +205,7 @@ int AllocateStorage(o3dmi_hash* h, int64_t capacity, hipStream_t s) {
     O3DMI_HIP_CHECK(hipMemsetAsync(v.key_buffer, 0,
                                    sizeof(int) * 3 * (size_t)capacity, s));
     O3DMI_HIP_CHECK(hipMemsetAsync(v.slot_touch, 0,
-                                   sizeof(unsigned long long) *
+                                   sizeof(unsigned long long) * 2 *
                                            (size_t)h->n_slots, s));
     return O3DMI_OK;
 }
@@ -249,6 +256,49 @@ int CheckDeferred(o3dmi_hash* h, hipStream_t s, int* top_out) {
         SetLastError("hash map capacity exceeded (caller must Reserve first)");
         return O3DMI_ERR_CAPACITY;
     }
+    if (host[1] & (kErrProbe | kErrTouchStamp)) {
+        SetLastError(host[1] & kErrProbe
+                             ? "hash map probe sequence wrapped (table full)"
+                             : "frame-stream touch word of another group");
+        return O3DMI_ERR_INTERNAL;
+    }
+    return O3DMI_OK;
+}
+
+// Erase leaves tombstones; inserts reuse the ones on their probe path, the
+// others stay. Once live + tombstone slots pass 3/4 of the table, the table is
+// rebuilt in place from the key buffer (live keys <= capacity <= half the
+// slots), so walks always end at an empty slot.
+int RebuildSlotsIfCrowded(o3dmi_hash* h, hipStream_t s) {
+    int host[3] = {0, 0, 0};
+    O3DMI_HIP_CHECK(hipMemcpyAsync(host, h->view.counters, sizeof(host),
+                                   hipMemcpyDeviceToHost, s));
+    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    if ((int64_t)host[2] * 4 < h->n_slots * 3) return O3DMI_OK;
+    int* active = nullptr;
+    O3DMI_HIP_CHECK(hipMalloc((void**)&active, sizeof(int) * h->capacity));
+    O3DMI_HIP_CHECK(hipMemsetAsync(h->scratch_count, 0, sizeof(int), s));
+    hipLaunchKernelGGL(ActiveIndicesKernel, dim3(GridFor(h->n_slots, kBlock)),
+                       dim3(kBlock), 0, s, h->view, h->n_slots, active,
+                       h->scratch_count);
+    int n = 0;
+    O3DMI_HIP_CHECK(hipMemcpyAsync(&n, h->scratch_count, sizeof(int),
+                                   hipMemcpyDeviceToHost, s));
+    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    HashView& v = h->view;
+    O3DMI_HIP_CHECK(hipMemsetAsync(v.slot_keys, 0xFF,
+                                   sizeof(unsigned long long) *
+                                           (size_t)h->n_slots, s));
+    O3DMI_HIP_CHECK(hipMemsetAsync(v.slot_touch, 0,
+                                   sizeof(unsigned long long) * 2 *
+                                           (size_t)h->n_slots, s));
+    O3DMI_HIP_CHECK(hipMemsetAsync(v.counters + 2, 0, sizeof(int), s));
+    if (n > 0)
+        hipLaunchKernelGGL(ReinsertKernel, dim3(GridFor(n, kBlock)),
+                           dim3(kBlock), 0, s, v, active, (int64_t)n);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    (void)hipFree(active);
     return O3DMI_OK;
 }
 
@@ -277,6 +327,7 @@ const char* o3dmi_status_string(int status) {
         case O3DMI_ERR_UNSUPPORTED: return "unsupported";
         case O3DMI_ERR_NO_INLIERS:
             return "Invalid inlier_count value, must be > 0.";
+        case O3DMI_ERR_INTERNAL: return "device-side consistency check failed";
         default: return "unknown status";
     }
 }
@@ -407,7 +458,7 @@ int o3dmi_hash_erase(o3dmi_hash_t* h, const int32_t* keys_dev, int64_t n,
     hipLaunchKernelGGL(EraseKernel, dim3(GridFor(n, kBlock)), dim3(kBlock), 0,
                        (hipStream_t)stream, h->view, keys_dev, n, masks_dev);
     O3DMI_HIP_CHECK(hipGetLastError());
-    return O3DMI_OK;
+    return RebuildSlotsIfCrowded(h, (hipStream_t)stream);
 }
 
 int o3dmi_hash_size(o3dmi_hash_t* h, o3dmi_stream_t stream, int64_t* size) {

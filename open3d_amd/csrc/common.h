@@ -176,13 +176,25 @@ __host__ __device__ __forceinline__ int OwnerOf(unsigned long long k,
     return (int)((unsigned)(k >> 32) % (unsigned)world);
 }
 
+constexpr int kErrKeyRange = 1;
+constexpr int kErrCapacity = 2;
+constexpr int kErrTouchStamp = 4;  // integrate role met a foreign touch word
+constexpr int kErrProbe = 8;       // probe sequence wrapped (table full)
+
 // Device view of the spatial hash, passed by value to kernels.
 struct HashView {
     unsigned long long* slot_keys;  // [n_slots] packed key / empty / tombstone
     int* slot_vals;                 // [n_slots] buffer index of the slot
-    unsigned long long* slot_touch; // [n_slots] (touch stamp << 8) | frame bits
+    // [2][n_slots] (touch stamp << 8) | frame bits. Two planes: consecutive
+    // frame groups of the frame-stream path alternate planes, because the
+    // front roles of group g+1 run in the same launch as the integrate role of
+    // group g, which still reads group g's words (plane = group sequence & 1;
+    // every other user takes plane 0).
+    unsigned long long* slot_touch;
     int* heap;                      // [capacity] free buffer indices
-    int* counters;                  // [0]=heap_top, [1]=error flags
+    int* counters;                  // [0]=heap_top, [1]=error flags,
+                                    // [2]=slots ever taken from the empty
+                                    //     state (live + tombstones)
     int* key_buffer;                // [capacity,3]
     unsigned mask;                  // n_slots - 1
     int capacity;
@@ -198,27 +210,89 @@ struct HashView {
         return owner_world <= 1 || OwnerOf(k, owner_world) == owner_rank;
     }
 
-    // Lookup; -1 when absent.
+    // Lookup; -1 when absent. The walk is bounded by the table size: with
+    // tombstone reuse (ClaimSlot) and the rebuild behind Erase the table always
+    // keeps empty slots, the bound only guards a corrupted table.
     __device__ __forceinline__ int Find(int x, int y, int z) const {
         if (!KeyInRange(x, y, z)) return -1;
         unsigned long long k = PackKey(x, y, z);
         unsigned h = HashKey(k) & mask;
-        while (true) {
+        for (unsigned step = 0; step <= mask; ++step) {
             unsigned long long cur = slot_keys[h];
             if (cur == k) return slot_vals[h];
             if (cur == kEmptyKey) return -1;
             h = (h + 1) & mask;
         }
+        return -1;
     }
 };
+
+// Insert-if-absent of packed key k into the slot table. Returns 1 when this
+// thread created the entry, 0 when the key is (or concurrently became)
+// present, -1 when the probe sequence wrapped (error flag set). `slot_out`
+// receives the slot in the first two cases.
+//
+// A new key takes the FIRST TOMBSTONE of its probe sequence if there is one,
+// else the first empty slot; the walk always continues to that empty slot
+// first, because the key may live behind the tombstone. Every inserter of the
+// same key therefore competes for the same slot and the CAS picks one winner;
+// a thread that loses its target to a different key walks on from there. Only
+// inserts may run concurrently (Erase is its own launch, as in the
+// reference's backends), so a slot's state only moves empty / tombstone ->
+// key during the walk and a stale read is always corrected by the CAS result.
+__device__ __forceinline__ int ClaimSlot(const HashView& hv,
+                                         unsigned long long k,
+                                         unsigned& slot_out) {
+    constexpr unsigned kNone = 0xFFFFFFFFu;
+    unsigned h = HashKey(k) & hv.mask;
+    unsigned tomb = kNone;
+    // 2 x table size: a lost tombstone re-walks part of the sequence
+    for (unsigned long long step = 0; step <= 2ull * hv.mask + 1; ++step) {
+        const unsigned long long cur = hv.slot_keys[h];
+        if (cur == k) {
+            slot_out = h;
+            return 0;
+        }
+        if (cur == kTombKey) {
+            if (tomb == kNone) tomb = h;
+        } else if (cur == kEmptyKey) {
+            const unsigned target = tomb != kNone ? tomb : h;
+            const unsigned long long expect =
+                    tomb != kNone ? kTombKey : kEmptyKey;
+            const unsigned long long old =
+                    atomicCAS(&hv.slot_keys[target], expect, k);
+            if (old == expect) {
+                if (tomb == kNone) atomicAdd(&hv.counters[2], 1);
+                slot_out = target;
+                return 1;
+            }
+            if (old == k) {
+                slot_out = target;
+                return 0;
+            }
+            // lost `target` to another key: go on behind it
+            h = target;
+            tomb = kNone;
+        }
+        h = (h + 1) & hv.mask;
+    }
+    atomicOr(&hv.counters[1], kErrProbe);
+    return -1;
+}
 
 // Marks `slot` as touched by frame `bit` of the frame group `stamp`. The word
 // holds (stamp << 8) | one bit per frame of the group; a word carrying an older
 // stamp is stale and is replaced. Returns true for exactly one caller per
 // (slot, stamp): the one that moved the word to this stamp.
+__device__ __forceinline__ unsigned long long* TouchWord(const HashView& hv,
+                                                         unsigned slot,
+                                                         int plane) {
+    return hv.slot_touch + ((size_t)plane * ((size_t)hv.mask + 1) + slot);
+}
 __device__ __forceinline__ bool TouchSlot(const HashView& hv, unsigned slot,
-                                          unsigned long long stamp, int bit) {
-    unsigned long long* w = &hv.slot_touch[slot];
+                                          unsigned long long stamp, int bit,
+                                          int plane = 0) {
+    unsigned long long* w = TouchWord(hv, slot, plane);
     unsigned long long cur = *w;  // possibly stale; the CAS corrects it
     while (true) {
         const bool fresh = (cur >> 8) != stamp;
@@ -231,8 +305,6 @@ __device__ __forceinline__ bool TouchSlot(const HashView& hv, unsigned slot,
     }
 }
 
-constexpr int kErrKeyRange = 1;
-constexpr int kErrCapacity = 2;
 
 }  // namespace o3dmi
 

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 
 #include "../common.h"
 #include "../npz.h"
@@ -138,7 +139,9 @@ int ParseNpy(const uint8_t* buf, size_t len, NpzArray* out, size_t* data_off) {
     size_t loc = h.find("fortran_order");
     if (loc == std::string::npos)
         return Fail("Failed to find header keyword: 'fortran_order'");
-    const bool fortran = h.compare(loc + 16, 4, "True") == 0;
+    // the value follows "fortran_order': " (16 characters)
+    const bool fortran =
+            loc + 20 <= h.size() && h.compare(loc + 16, 4, "True") == 0;
     size_t l1 = h.find('('), l2 = h.find(')');
     if (l1 == std::string::npos || l2 == std::string::npos || l2 < l1)
         return Fail("Failed to find header keyword: '(' or ')'");
@@ -372,9 +375,22 @@ int o3dmi_npz_write(const o3dmi_npz_t* z, const char* file_name) {
     return O3DMI_OK;
 }
 
-// ReadNpz, NumpyIO.cpp:675-757.
+// ReadNpz, NumpyIO.cpp:675-757. Nothing may throw across the C ABI: a
+// malformed file can still make a container allocation fail.
+static int NpzReadImpl(const char* file_name, o3dmi_npz_t** out);
 int o3dmi_npz_read(const char* file_name, o3dmi_npz_t** out) {
     O3DMI_REQUIRE(file_name && out, "null argument");
+    try {
+        return NpzReadImpl(file_name, out);
+    } catch (const std::exception& e) {
+        return Fail(std::string("Malformed npz file: ") + e.what());
+    } catch (...) {
+        return Fail("Malformed npz file.");
+    }
+}
+}  // extern "C"
+
+static int NpzReadImpl(const char* file_name, o3dmi_npz_t** out) {
     FILE* fp = fopen(file_name, "rb");
     if (!fp) return Fail(std::string("Failed to open file ") + file_name);
     FileCloser closer{fp};
@@ -451,6 +467,10 @@ int o3dmi_npz_read(const char* file_name, o3dmi_npz_t** out) {
             return Fail("Failed to read local header in npz.");
         const uint64_t data_off = lho + 30 + R16(lh + 26) + R16(lh + 28);
         if (data_off + csize > fsize) return Fail("Corrupt npz entry.");
+        // deflate expands by at most ~1032:1; anything larger is not a size
+        // this entry can have (and must not drive the allocation below)
+        if (usize > (method == 0 ? csize : csize * 1032 + 65536))
+            return Fail("Corrupt npz entry (uncompressed size).");
         std::vector<uint8_t> raw((size_t)usize);
         if (method == 0) {
             if (csize != usize) return Fail("Corrupt stored entry.");
@@ -508,5 +528,3 @@ int o3dmi_npz_read(const char* file_name, o3dmi_npz_t** out) {
     *out = z;
     return O3DMI_OK;
 }
-
-}  // extern "C"

@@ -61,6 +61,13 @@ struct o3dmi_vbg {
     int known_size = 0;                  // map size after frame `known_stamp`
     int known_stamp = 0;
     bool known_valid = false;            // false after any non-stream activation
+    // Prepare-pass tables (stream_path.h PrepTables) and what they were
+    // built for.
+    int* prep_col = nullptr;
+    int* prep_row = nullptr;
+    std::vector<int> prep_host;
+    double prep_key[24] = {0};
+    bool prep_valid = false, prep_div_short = false;
     int last_count = 1024;
     // Which path integrated the most recent frame (for
     // o3dmi_vbg_export_last_frame_blocks): 0 none, 1 frame-stream, 2 generic.
@@ -255,7 +262,13 @@ __global__ void MergeBlocksKernel(const int32_t* __restrict__ indices,
                 color[3 * d + c] = (W)((w1 * (float)color[3 * d + c] +
                                         w2 * (float)src_color[3 * i + c]) *
                                        inv);
-        weight[d] = (W)(w1 + w2);
+        // a uint16 weight saturates (long per-rank streams can pass 65535;
+        // float -> uint16 of a larger value is undefined)
+        const float wsum = w1 + w2;
+        if constexpr (sizeof(W) == 2)
+            weight[d] = (W)(wsum < 65535.0f ? wsum : 65535.0f);
+        else
+            weight[d] = (W)wsum;
     }
 }
 
@@ -321,6 +334,7 @@ int o3dmi_vbg_destroy(o3dmi_vbg_t* g) {
     for (int i = 0; i < 2; ++i) {
         for (int f = 0; f < kMaxGroup; ++f) (void)hipFree(g->recs[i][f]);
         (void)hipFree(g->lists[i]);
+        if (i == 0) (void)hipFree(g->prep_col);
     }
     (void)hipFree(g->ring_counters);
     if (g->stream_status) (void)hipHostFree((void*)g->stream_status);
@@ -539,8 +553,9 @@ static int EnsureStreamBuffers(o3dmi_vbg* g, int rows, int cols,
             for (int f = 0; f < kMaxGroup; ++f) {
                 (void)hipFree(g->recs[i][f]);
                 g->recs[i][f] = nullptr;
+                // + 1: the sentinel record behind the image
                 O3DMI_HIP_CHECK(hipMalloc((void**)&g->recs[i][f],
-                                          sizeof(PixelRec) * (size_t)px));
+                                          sizeof(PixelRec) * (size_t)(px + 1)));
             }
         g->recs_pixels = px;
     }
@@ -563,6 +578,38 @@ static int EnsureStreamBuffers(o3dmi_vbg* g, int rows, int cols,
         st[0] = st[1] = st[2] = st[3] = 0;
         g->stream_status = st;
     }
+    return O3DMI_OK;
+}
+
+// Builds / re-uses the prepare-pass tables for this image geometry.
+static int EnsurePrepTables(o3dmi_vbg* g, const double* dk, const double* ck,
+                            int rows, int cols, int crows, int ccols,
+                            float depth_scale, hipStream_t s) {
+    double key[24] = {0};
+    for (int i = 0; i < 9; ++i) key[i] = dk[i];
+    for (int i = 0; i < 9; ++i) key[9 + i] = (ck ? ck : dk)[i];
+    key[18] = rows; key[19] = cols; key[20] = crows; key[21] = ccols;
+    key[22] = depth_scale;
+    if (g->prep_valid && std::memcmp(key, g->prep_key, sizeof(key)) == 0)
+        return O3DMI_OK;
+    // the previous tables may still be read by launches in flight
+    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    (void)hipFree(g->prep_col);
+    g->prep_col = g->prep_row = nullptr;
+    g->prep_valid = false;
+    O3DMI_HIP_CHECK(hipMalloc((void**)&g->prep_col,
+                              sizeof(int) * (size_t)(rows + cols)));
+    g->prep_row = g->prep_col + cols;
+    g->prep_host.assign((size_t)(rows + cols), -1);
+    g->prep_div_short =
+            PrepTables(dk, ck, rows, cols, crows, ccols, depth_scale,
+                       g->prep_host.data(), g->prep_host.data() + cols);
+    O3DMI_HIP_CHECK(hipMemcpyAsync(g->prep_col, g->prep_host.data(),
+                                   sizeof(int) * (size_t)(rows + cols),
+                                   hipMemcpyHostToDevice, s));
+    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    std::memcpy(g->prep_key, key, sizeof(key));
+    g->prep_valid = true;
     return O3DMI_OK;
 }
 
@@ -590,6 +637,12 @@ static int PollStreamStatus(o3dmi_vbg* g) {
         if (err & kErrCapacity) {
             SetLastError("hash map capacity exceeded");
             return O3DMI_ERR_CAPACITY;
+        }
+        if (err & (kErrTouchStamp | kErrProbe)) {
+            SetLastError(err & kErrProbe
+                                 ? "hash map probe sequence wrapped"
+                                 : "frame-stream touch word of another group");
+            return O3DMI_ERR_INTERNAL;
         }
     }
     return O3DMI_OK;
@@ -718,6 +771,10 @@ static StreamGroup MakeGroup(o3dmi_vbg* g, const StreamCommon& c,
         a.stride = 4;
         a.group_stamp = (unsigned long long)grp.stamp;
         a.group_bit = f;
+        a.touch_plane = par;
+        a.col_lut = g->prep_valid ? g->prep_col : nullptr;
+        a.row_lut = g->prep_valid ? g->prep_row : nullptr;
+        a.depth_div_short = g->prep_valid && g->prep_div_short;
         a.recs = g->recs[par][f];
         a.list = g->lists[par];
         a.list_capacity = g->lists_capacity;
@@ -733,6 +790,8 @@ static void MakeIntegArgs(o3dmi_vbg* g, const StreamCommon& c,
                           IntegrateStreamArgs* ia) {
     const int par = (int)(grp.seq & 1);
     ia->n_frames = grp.n;
+    ia->group_stamp = (unsigned long long)grp.stamp;
+    ia->touch_plane = par;
     for (int f = 0; f < grp.n; ++f) {
         ia->recs[f] = g->recs[par][f];
         ia->extrinsic[f] = grp.frames[f].extrinsic;
@@ -791,6 +850,16 @@ static int StreamIntegrate(o3dmi_vbg* g, const StreamCommon& c0,
     if ((st = EnsureStreamBuffers(g, c.depth_rows, c.depth_cols,
                                   c.frame_new * kMaxGroup)))
         return st;
+
+    static const bool no_tables = std::getenv("O3DMI_NO_PREP_TABLES") != nullptr;
+    if (no_tables) {
+        g->prep_valid = false;
+    } else if ((st = EnsurePrepTables(g, c.depth_intrinsic, c.color_intrinsic,
+                                      c.depth_rows, c.depth_cols,
+                                      c.color_rows, c.color_cols,
+                                      c.depth_scale, s))) {
+        return st;
+    }
 
     bool issued = false;  // front roles of `cur` already in flight
     StreamGroup cur;
@@ -1271,9 +1340,23 @@ int o3dmi_vbg_merge_blocks(o3dmi_vbg_t* g, const int32_t* keys_dev,
     return O3DMI_OK;
 }
 
+static int VbgLoadImpl(const char* file_name, o3dmi_stream_t stream,
+                       o3dmi_vbg_t** out);
 int o3dmi_vbg_load(const char* file_name, o3dmi_stream_t stream,
                    o3dmi_vbg_t** out) {
     O3DMI_REQUIRE(file_name && out, "null argument");
+    try {  // nothing may throw across the C ABI
+        return VbgLoadImpl(file_name, stream, out);
+    } catch (const std::exception& e) {
+        SetLastError(std::string("o3dmi_vbg_load: ") + e.what());
+        return O3DMI_ERR_INVALID_ARG;
+    } catch (...) {
+        SetLastError("o3dmi_vbg_load: malformed file");
+        return O3DMI_ERR_INVALID_ARG;
+    }
+}
+static int VbgLoadImpl(const char* file_name, o3dmi_stream_t stream,
+                       o3dmi_vbg_t** out) {
     hipStream_t s = (hipStream_t)stream;
     o3dmi_npz_t* zp = nullptr;
     int st = o3dmi_npz_read(file_name, &zp);

@@ -20,8 +20,12 @@
 namespace o3dmi {
 namespace {
 std::mutex g_mu;
-std::map<size_t, std::vector<void*>> g_free;       // size class -> blocks
-std::unordered_map<void*, size_t> g_size;          // live or cached -> class
+// Free lists are per HIP device: a process may drive several GPUs (one host
+// thread per device), and a block must only be handed out on the device it
+// was allocated on.
+using DevClass = std::pair<int, size_t>;           // (device, size class)
+std::map<DevClass, std::vector<void*>> g_free;     // -> cached blocks
+std::unordered_map<void*, DevClass> g_size;        // live or cached -> class
 size_t g_cached_bytes = 0;
 
 size_t SizeClass(size_t bytes) {
@@ -33,9 +37,11 @@ size_t SizeClass(size_t bytes) {
 
 int PoolAlloc(void** out, size_t bytes) {
     const size_t c = SizeClass(bytes ? bytes : 1);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        auto it = g_free.find(c);
+        auto it = g_free.find(DevClass(dev, c));
         if (it != g_free.end() && !it->second.empty()) {
             *out = it->second.back();
             it->second.pop_back();
@@ -55,7 +61,7 @@ int PoolAlloc(void** out, size_t bytes) {
         return O3DMI_ERR_HIP;
     }
     std::lock_guard<std::mutex> lk(g_mu);
-    g_size[p] = c;
+    g_size[p] = DevClass(dev, c);
     *out = p;
     return O3DMI_OK;
 }
@@ -69,7 +75,7 @@ void PoolFree(void* p) {
         return;
     }
     g_free[it->second].push_back(p);
-    g_cached_bytes += it->second;
+    g_cached_bytes += it->second.second;
 }
 
 }  // namespace o3dmi

@@ -57,7 +57,19 @@ struct FrameFrontArgs {
     int stride;
     unsigned long long group_stamp;  // > 0, increases per group
     int group_bit;                   // index of this frame in its group
-    PixelRec* recs;       // {rows, cols} out
+    int touch_plane;                 // plane of the per-slot touch words
+                                     // (group sequence & 1)
+    // Optional per-column / per-row tables of the prepare pass (device, cols /
+    // rows ints): the colour pixel Unproject -> Project -> round selects is
+    // separable, column of the colour image from the depth column alone and
+    // row from the row alone (-1 = outside the colour image). Built on the
+    // host with the same float32 operations (PrepTables); null = evaluate per
+    // pixel. depth_div_short: float(depth) / depth_scale may take the short
+    // constant-divisor form (host-verified for all 65536 depth values).
+    const int* col_lut;
+    const int* row_lut;
+    bool depth_div_short;
+    PixelRec* recs;       // {rows, cols} out, + 1 sentinel record {0, 0}
     FrameBlock* list;     // the group's list (shared by its frames)
     int64_t list_capacity;
     int* count;           // the group's count; 0 before the group's first frame
@@ -66,6 +78,8 @@ struct FrameFrontArgs {
 // Integrate role of ONE group.
 struct IntegrateStreamArgs {
     int n_frames;                          // 1..kMaxGroup
+    unsigned long long group_stamp;        // the stamp the group's front roles
+    int touch_plane;                       // used, and their touch plane
     const PixelRec* recs[kMaxGroup];
     const double* extrinsic[kMaxGroup];    // host 4x4 each
     int rows, cols;
@@ -93,12 +107,23 @@ struct IntegrateStreamArgs {
 // One launch running the front roles of up to kMaxGroup frames and / or the
 // integrate role of one group. The workgroups of the front roles are
 // dispatched first and overlap the integrate role inside the same kernel: the
-// two touch disjoint scratch (double-buffered lists / records / counters) and
-// the hash map tolerates concurrent insertion of new keys next to lookups of
-// existing ones.
+// two touch disjoint scratch (double-buffered lists / records / counters /
+// per-slot touch words, all selected by the group's sequence parity) and the
+// hash map tolerates concurrent insertion of new keys next to lookups of
+// existing ones. The integrate role verifies the stamp of every touch word it
+// reads and raises kErrTouchStamp on a foreign one.
 int LaunchFrameStep(o3dmi_hash* block_hash, const FrameFrontArgs* fronts,
                     int n_fronts, const IntegrateStreamArgs* integ,
                     hipStream_t s);
+
+// Host evaluation of the prepare pass's per-column / per-row sub-expressions
+// (IntegrateCPU's colour-pixel selection, VoxelBlockGridImpl.h:277-289, with
+// TransformIndexer's float32 arithmetic): col[u] / row[v] = rounded colour
+// pixel coordinate or -1. Returns whether the short constant-divisor form of
+// float(depth) / depth_scale equals the IEEE division for all 65536 depths.
+bool PrepTables(const double* depth_intrinsic, const double* color_intrinsic,
+                int rows, int cols, int color_rows, int color_cols,
+                float depth_scale, int* col, int* row);
 
 // Strict upper bound on the number of distinct blocks one depth frame can
 // touch: every touched block lies inside the viewing pyramid (z-depth <=

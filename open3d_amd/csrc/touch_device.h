@@ -14,42 +14,25 @@ namespace o3dmi {
 template <bool kAllocate>
 __device__ __forceinline__ bool InsertKey(const HashView& hv, int x, int y,
                                           int z, unsigned& slot_out) {
-    unsigned long long k = PackKey(x, y, z);
-    unsigned h = HashKey(k) & hv.mask;
-    while (true) {
-        unsigned long long cur = hv.slot_keys[h];
-        if (cur == k) {
-            slot_out = h;
-            return false;
+    slot_out = 0;
+    if (ClaimSlot(hv, PackKey(x, y, z), slot_out) != 1) return false;
+    if (kAllocate) {
+        const unsigned h = slot_out;
+        int top = atomicAdd(&hv.counters[0], 1);
+        if (top >= hv.capacity) {
+            atomicOr(&hv.counters[1], kErrCapacity);
+            // Leave a valid (but shared) index so later kernels stay in
+            // bounds; the error is reported at sync.
+            hv.slot_vals[h] = 0;
+            return true;
         }
-        if (cur == kEmptyKey) {
-            unsigned long long old = atomicCAS(&hv.slot_keys[h], kEmptyKey, k);
-            if (old == kEmptyKey) {
-                slot_out = h;
-                if (kAllocate) {
-                    int top = atomicAdd(&hv.counters[0], 1);
-                    if (top >= hv.capacity) {
-                        atomicOr(&hv.counters[1], kErrCapacity);
-                        // Leave a valid (but shared) index so later kernels
-                        // stay in bounds; the error is reported at sync.
-                        hv.slot_vals[h] = 0;
-                        return true;
-                    }
-                    int idx = hv.heap[top];
-                    hv.key_buffer[3 * idx + 0] = x;
-                    hv.key_buffer[3 * idx + 1] = y;
-                    hv.key_buffer[3 * idx + 2] = z;
-                    hv.slot_vals[h] = idx;
-                }
-                return true;
-            }
-            if (old == k) {
-                slot_out = h;
-                return false;
-            }
-        }
-        h = (h + 1) & hv.mask;
+        int idx = hv.heap[top];
+        hv.key_buffer[3 * idx + 0] = x;
+        hv.key_buffer[3 * idx + 1] = y;
+        hv.key_buffer[3 * idx + 2] = z;
+        hv.slot_vals[h] = idx;
     }
+    return true;
 }
 
 // True for exactly one lane among the active lanes of the wave that hold the

@@ -35,6 +35,11 @@ struct alignas(A) Vec {
     T v[N];
 };
 
+__device__ __forceinline__ float DivByConst(float a, float b, float y) {
+    const float q0 = a * y;
+    const float r = __builtin_fmaf(-b, q0, a);
+    return __builtin_fmaf(r, y, q0);
+}
 struct PrepParams {
     Camera color_cam;  // colour intrinsics, identity extrinsic, scale 1
     int color_rows, color_cols;
@@ -46,12 +51,17 @@ struct FrontParams {
     PrepParams pp;
     const uint16_t* depth;
     const uint8_t* color;
+    const int* col_lut;
+    const int* row_lut;
+    bool depth_div_short;
+    float inv_depth_scale;  // RN(1 / depth_scale)
     PixelRec* recs;
     FrameBlock* list;
     int64_t list_capacity;
     int* out_count;
     unsigned long long group_stamp;
     int group_bit;
+    int touch_plane;
     int n_touch_wg, n_prep_wg;
 };
 
@@ -90,7 +100,8 @@ __device__ __forceinline__ void FrontRole(const HashView& hv,
                 if (WaveLeaderForKey(k, ok)) {
                     unsigned slot;
                     InsertKey<true>(hv, xb[s], yb[s], zb[s], slot);
-                    if (TouchSlot(hv, slot, fp.group_stamp, fp.group_bit)) {
+                    if (TouchSlot(hv, slot, fp.group_stamp, fp.group_bit,
+                                  fp.touch_plane)) {
                         int o = atomicAdd(fp.out_count, 1);
                         if (o < fp.list_capacity) {
                             FrameBlock fb;
@@ -112,6 +123,85 @@ __device__ __forceinline__ void FrontRole(const HashView& hv,
     // lambda (VoxelBlockGridImpl.h:258-262 depth, :277-289 colour pixel).
     const int n_px = p.rows * p.cols;
     const int n_wg = fp.n_prep_wg;
+    // sentinel behind the image: what a voxel outside the image reads
+    if (wg == n_touch_wg && threadIdx.x == 0) {
+        PixelRec r;
+        r.d = 0.0f;
+        r.rgba = 0u;
+        recs[n_px] = r;
+    }
+    if (fp.col_lut) {
+        // Table form: no division per pixel (the per-column / per-row parts
+        // come from PrepTables, the depth division takes the short form when
+        // the host verified it for every uint16 depth). Four pixels per lane
+        // with every load of a stage requested before the first is used
+        // (clamped indices instead of branches; only the store is
+        // predicated).
+        const int* __restrict__ col_lut = fp.col_lut;
+        const int* __restrict__ row_lut = fp.row_lut;
+        const int step = n_wg * blockDim.x;
+        const int step_v = step / p.cols, step_u = step - step_v * p.cols;
+        for (int first = (wg - n_touch_wg) * blockDim.x + threadIdx.x;
+             first < n_px; first += 4 * step) {
+            int idx[4], uc[4], vc[4];
+            float df[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = first + k * step;
+                idx[k] = i < n_px ? i : n_px - 1;
+                df[k] = (float)depth[idx[k]];
+            }
+            if (pp.with_color) {
+                int vi = first / p.cols;
+                int ui = first - vi * p.cols;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    // (a clamped tail pixel may read another pixel's table
+                    // entries: its record is not stored)
+                    uc[k] = col_lut[ui];
+                    vc[k] = row_lut[vi < p.rows ? vi : p.rows - 1];
+                    ui += step_u;
+                    vi += step_v;
+                    if (ui >= p.cols) {
+                        ui -= p.cols;
+                        ++vi;
+                    }
+                }
+            }
+            unsigned rgba[4] = {0u, 0u, 0u, 0u};
+            if (pp.with_color) {
+                unsigned c0[4], c1[4], c2[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool has = (uc[k] | vc[k]) >= 0;
+                    const uint8_t* in =
+                            color + (has ? ((int64_t)vc[k] * pp.color_cols +
+                                            uc[k]) * 3
+                                         : 0);
+                    c0[k] = in[0];
+                    c1[k] = in[1];
+                    c2[k] = in[2];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    rgba[k] = (uc[k] | vc[k]) >= 0
+                                      ? (c0[k] | (c1[k] << 8) | (c2[k] << 16) |
+                                         (1u << 24))
+                                      : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                PixelRec r;
+                r.d = fp.depth_div_short
+                              ? DivByConst(df[k], p.depth_scale,
+                                           fp.inv_depth_scale)
+                              : df[k] / p.depth_scale;
+                r.rgba = rgba[k];
+                if (first + k * step < n_px) recs[idx[k]] = r;
+            }
+        }
+        return;
+    }
     for (int i = (wg - n_touch_wg) * blockDim.x + threadIdx.x; i < n_px;
          i += n_wg * blockDim.x) {
         const int vi = i / p.cols;
@@ -145,9 +235,15 @@ __device__ __forceinline__ void FrontRole(const HashView& hv,
 // voxel and frame).
 struct IntegParams {
     Camera cam[kMaxGroup];  // depth intrinsics + extrinsic, scale = voxel_size
+    // the same for the wide role: the group's frames share intrinsics and
+    // scale (cam[0]'s), only the extrinsics differ -- fewer scalar registers
+    float ext[kMaxGroup][3][4];
     const PixelRec* recs[kMaxGroup];
     int n_frames;
+    unsigned long long group_stamp;
+    int touch_plane;
     int rows, cols, resolution;
+    int res_shift;  // log2(resolution) when it is a power of two, else -1
     float sdf_trunc, depth_max;
     float inv_sdf_trunc;  // RN(1 / sdf_trunc), used by the kFastDiv variant
     const FrameBlock* list;
@@ -179,11 +275,6 @@ struct IntegParams {
 // for EVERY float |a| <= b (the whole range the update can produce) and every
 // integer 1..65536; any mismatch keeps the IEEE sequence. The check costs a
 // few ms once per distinct truncation distance.
-__device__ __forceinline__ float DivByConst(float a, float b, float y) {
-    const float q0 = a * y;
-    const float r = __builtin_fmaf(-b, q0, a);
-    return __builtin_fmaf(r, y, q0);
-}
 __device__ __forceinline__ float RcpSmallInt(float b) {
     const float r0 = __builtin_amdgcn_rcpf(b);
     const float e = __builtin_fmaf(-b, r0, 1.0f);
@@ -227,6 +318,20 @@ __device__ __forceinline__ float RcpGuarded(float z) {
     // wave-uniform so that the common case is a straight scalar jump.
     const bool out = (__float_as_uint(z) - 0x21800000u) >= (0x5E000000u - 0x21800000u);
     if (__builtin_amdgcn_ballot_w64(out) != 0ull) return 1.0f / z;
+    float r = __builtin_amdgcn_rcpf(z);
+#pragma unroll
+    for (int k = 0; k < kSteps; ++k) {
+        const float e = __builtin_fmaf(-z, r, 1.0f);
+        r = __builtin_fmaf(e, r, r);
+    }
+    return r;
+}
+__device__ __forceinline__ bool RcpOutOfRange(float z) {
+    return (__float_as_uint(z) - 0x21800000u) >= (0x5E000000u - 0x21800000u);
+}
+// RcpGuarded's short path alone (the caller has checked the range)
+template <int kSteps>
+__device__ __forceinline__ float RcpNewton(float z) {
     float r = __builtin_amdgcn_rcpf(z);
 #pragma unroll
     for (int k = 0; k < kSteps; ++k) {
@@ -309,8 +414,16 @@ __device__ __forceinline__ void IntegrateRole(const HashView& hv,
         const int zb = __builtin_amdgcn_readfirstlane(fb.z);
         const int block_idx =
                 __builtin_amdgcn_readfirstlane(hv.slot_vals[slot]);
+        // Frame bits of THIS group: its own plane of touch words (the front
+        // roles of the next group, running beside this role, write the other
+        // plane). A word of another stamp cannot occur; if it does, nothing
+        // is integrated for the block and the error surfaces on the host.
+        const unsigned long long word = *TouchWord(hv, slot, ip.touch_plane);
+        const bool own = (word >> 8) == ip.group_stamp;
+        if (!own && threadIdx.x == 0 && part == 0)
+            atomicOr(&hv.counters[1], kErrTouchStamp);
         const unsigned bits = __builtin_amdgcn_readfirstlane(
-                (unsigned)(hv.slot_touch[slot] & 0xffull));
+                own ? (unsigned)(word & 0xffull) : 0u);
         const int64_t block_base = (int64_t)block_idx * res3;
         if (part == 0 && threadIdx.x == 0 && ip.prof_frame_blocks)
             frame_blocks += __popc(bits);
@@ -422,6 +535,347 @@ __device__ __forceinline__ void IntegrateRole(const HashView& hv,
     if (frame_blocks) atomicAdd(ip.prof_frame_blocks, frame_blocks);
 }
 
+// ---- integrate role, wide form ---------------------------------------------
+// Same arithmetic, different schedule and instruction selection. The role is
+// bound by vector-ALU issue (profiles/r2a: ~55 % of the SIMD cycles issue VALU
+// work, HBM traffic is a third of what the fabric can carry), so the form
+// below is about instructions per voxel and about keeping the SIMDs fed:
+//   1. every load of a work item is in flight at once: the voxel state (3
+//      vector loads) is requested first, then for every frame of the group
+//      the lane's 4 voxels are projected and their 8-byte records requested,
+//      and only then the frames are applied, in frame order, from registers
+//      (the form above walks gather -> lazy state load -> gather -> ...);
+//   2. the float32 multiplies / adds / fused steps run as PACKED pairs
+//      (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two voxels per instruction
+//      at the same issue cost) -- lane-wise the very same IEEE operations in
+//      the same order, so results do not change;
+//   3. selects instead of exec-mask branches; a voxel that projects outside
+//      the image reads a sentinel record (depth 0 = invalid) instead of
+//      carrying a predicate; uint16 weights / colours are widened to float
+//      once per work item and re-created in float form between the frames;
+//   4. work items are dealt so that the parts of one block run on ONE XCD
+//      (block b -> XCD b mod 8; observed dispatch: workgroup w runs on XCD
+//      w mod 8): the parts share most of their projected pixel footprint,
+//      which then sits in that XCD's L2 once instead of in four of them.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 Splat(float a) { return f2{a, a}; }
+__device__ __forceinline__ f2 PkFma(f2 a, f2 b, f2 c) {
+    return __builtin_elementwise_fma(a, b, c);
+}
+
+template <typename weight_t, typename color_t, bool kColor, int kDiv,
+          int kChunk>
+__device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
+                                                  const IntegParams& ip,
+                                                  int wg, int n_wg,
+                                                  int first_wg) {
+    using TVec = Vec<float, 4, 16>;
+    using WVec = Vec<weight_t, 4, 4 * sizeof(weight_t)>;
+    using CVec = Vec<color_t, 12, 4 * sizeof(color_t)>;
+    constexpr bool kU16 = sizeof(weight_t) == 2;
+    float* __restrict__ tsdf_base = ip.tsdf;
+    weight_t* __restrict__ weight_base = (weight_t*)ip.weight;
+    color_t* __restrict__ color_base = (color_t*)ip.color;
+    const FrameBlock* __restrict__ list = ip.list;
+    int64_t n_blocks = *ip.count;
+    if (n_blocks > ip.list_capacity) n_blocks = ip.list_capacity;
+
+    if (wg == 0 && threadIdx.x == 0) {
+        if (ip.zero_counter) *ip.zero_counter = 0;
+        if (ip.prof_count) *ip.prof_count = (int)n_blocks;
+        if (ip.size_host) {
+            ip.size_host[0] = hv.counters[0];
+            ip.size_host[1] = hv.counters[1];
+            ip.size_host[2] = (int)n_blocks;
+            __hip_atomic_store(&ip.size_host[3], ip.status_stamp,
+                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+
+    const int res = ip.resolution;
+    const int res3 = res * res * res;
+    const int quads_per_row = res >> 2;
+    const int n_quads = res3 >> 2;
+    const int parts = (n_quads + 255) >> 8;
+    const int res_shift = ip.res_shift;  // log2(res) or -1
+    int frame_blocks = 0;  // lane 0 of part 0 counts block-frames
+
+    // XCD-aware deal: this workgroup's XCD, its rank among the role's
+    // workgroups of that XCD and their number.
+    const int xcd = (first_wg + wg) & 7;
+    const int first_of_xcd = (xcd - first_wg) & 7;  // lowest wg on this XCD
+    const int rank = (wg - first_of_xcd) >> 3;
+    const int n_on_xcd =
+            first_of_xcd < n_wg ? ((n_wg - 1 - first_of_xcd) >> 3) + 1 : 0;
+    const int64_t blocks_on_xcd = (n_blocks + 7 - xcd) >> 3;  // b = xcd + 8k
+    const int64_t n_items = blocks_on_xcd * parts;
+    const unsigned sentinel_off =
+            (unsigned)(ip.rows * ip.cols) * (unsigned)sizeof(PixelRec);
+    const unsigned row_bytes = (unsigned)ip.cols * (unsigned)sizeof(PixelRec);
+    const float vscale = ip.cam[0].scale;
+    const float fx = ip.cam[0].fx, fyk = ip.cam[0].fy;
+    const float cx = ip.cam[0].cx, cy = ip.cam[0].cy;
+    const float u_max = ip.cols - 1.0f, v_max = ip.rows - 1.0f;
+
+    for (int64_t m = rank; m < n_items; m += n_on_xcd) {
+        int64_t kb;
+        int part;
+        if (res_shift >= 0) {  // parts is a power of two as well
+            const int ps = res_shift >= 4 ? 3 * res_shift - 10 : 0;
+            kb = m >> ps;
+            part = (int)(m & ((1 << ps) - 1));
+        } else {
+            kb = m / parts;
+            part = (int)(m - kb * parts);
+        }
+        const int64_t b = (int64_t)xcd + (kb << 3);
+        const FrameBlock fb = list[b];
+        const int slot = __builtin_amdgcn_readfirstlane(fb.slot);
+        const int xb = __builtin_amdgcn_readfirstlane(fb.x);
+        const int yb = __builtin_amdgcn_readfirstlane(fb.y);
+        const int zb = __builtin_amdgcn_readfirstlane(fb.z);
+        const int block_idx =
+                __builtin_amdgcn_readfirstlane(hv.slot_vals[slot]);
+        const unsigned long long word = *TouchWord(hv, slot, ip.touch_plane);
+        const bool own = (word >> 8) == ip.group_stamp;
+        if (!own && threadIdx.x == 0 && part == 0)
+            atomicOr(&hv.counters[1], kErrTouchStamp);
+        const unsigned bits = __builtin_amdgcn_readfirstlane(
+                own ? (unsigned)(word & 0xffull) : 0u);
+        const int64_t block_base = (int64_t)block_idx * res3;
+        if (part == 0 && threadIdx.x == 0 && ip.prof_frame_blocks)
+            frame_blocks += __popc(bits);
+        int opaque = 0;  // a zero the optimiser cannot see through
+        asm volatile("" : "+s"(opaque));
+
+        const int q = (part << 8) + threadIdx.x;
+        if (q >= n_quads || bits == 0u) continue;
+        int qx, yv, zv;
+        if (res_shift >= 0) {
+            qx = q & (quads_per_row - 1);
+            const int row = q >> (res_shift - 2);
+            yv = row & (res - 1);
+            zv = row >> res_shift;
+        } else {
+            qx = q % quads_per_row;
+            const int row = q / quads_per_row;
+            yv = row % res;
+            zv = row / res;
+        }
+        const int x0 = xb * res + (qx << 2);
+        const float fy = (float)(yb * res + yv);
+        const float fz = (float)(zb * res + zv);
+        const int64_t lin0 = block_base + ((int64_t)q << 2);
+
+        // 1. voxel state, widened to float once per work item. A uint16
+        // weight / colour is an exact float; between the frames of the group
+        // the stored value is re-created in float form (truncation toward
+        // zero = the float -> uint16 store conversion of a non-negative value
+        // below 65536; the weight's wrap at 65536 = what the uint16 store
+        // keeps of it). Voxel pair p = voxels 2p, 2p + 1 of the lane.
+        const TVec t4 = *reinterpret_cast<const TVec*>(tsdf_base + lin0);
+        f2 ts[2] = {f2{t4.v[0], t4.v[1]}, f2{t4.v[2], t4.v[3]}};
+        f2 wf[2];
+        f2 cf[2][3];
+        {
+            const WVec w4 = *reinterpret_cast<const WVec*>(weight_base + lin0);
+            wf[0] = f2{(float)w4.v[0], (float)w4.v[1]};
+            wf[1] = f2{(float)w4.v[2], (float)w4.v[3]};
+            if constexpr (kColor) {
+                const CVec c12 =
+                        *reinterpret_cast<const CVec*>(color_base + 3 * lin0);
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        cf[p][i] = f2{(float)c12.v[6 * p + i],
+                                      (float)c12.v[6 * p + 3 + i]};
+            }
+        }
+
+        // 2. projections + record requests of every frame.
+        // Camera::RigidTransform (GeometryIndexer.h:62-78): x * scale, then
+        // ((x e0 + y e1) + z e2) + e3 per row; the y and z products are the
+        // same for the lane's 4 voxels.
+        const float ys = fy * vscale, zs = fz * vscale;
+        const f2 xs[2] = {f2{(float)x0, (float)(x0 + 1)} * vscale,
+                          f2{(float)(x0 + 2), (float)(x0 + 3)} * vscale};
+        // (kChunk frames at a time: all of the group's when registers allow,
+        // two when more resident waves pay better than more loads in flight)
+        bool touched = false;
+#pragma unroll
+        for (int c0 = 0; c0 < kMaxGroup; c0 += kChunk) {
+        f2 zc[kMaxGroup][2];
+        PixelRec rec[kMaxGroup][4];
+#pragma unroll
+        for (int f = c0; f < c0 + kChunk; ++f) {
+            if (!((bits >> f) & 1u)) continue;  // wave-uniform
+            // The frame's constants are fetched here, per work item (scalar
+            // loads from the argument block): hoisted out of the item loop
+            // they would occupy ~60 scalar registers and spill.
+            const float(&e)[3][4] =
+                    *reinterpret_cast<const float(*)[3][4]>(
+                            &ip.ext[f][0][0] + opaque);
+            const char* __restrict__ recs = reinterpret_cast<const char*>(
+                    *(&ip.recs[f] + opaque));
+            const float y0 = ys * e[0][1], z0 = zs * e[0][2];
+            const float y1 = ys * e[1][1], z1 = zs * e[1][2];
+            const float y2 = ys * e[2][1], z2 = zs * e[2][2];
+            f2 xc[2], yc[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                xc[p] = xs[p] * e[0][0] + y0 + z0 + e[0][3];
+                yc[p] = xs[p] * e[1][0] + y1 + z1 + e[1][3];
+                zc[f][p] = xs[p] * e[2][0] + y2 + z2 + e[2][3];
+            }
+            // Camera::Project's 1 / z: the verified short reciprocal unless a
+            // lane of the wave is outside its range. z is monotone along the
+            // lane's 4 voxels, so the two end voxels decide.
+            f2 inv_z[2];
+            const bool out = RcpOutOfRange(zc[f][0].x) ||
+                             RcpOutOfRange(zc[f][1].y);
+            if (kDiv < 2 || __builtin_amdgcn_ballot_w64(out) != 0ull) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    inv_z[p] = f2{1.0f / zc[f][p].x, 1.0f / zc[f][p].y};
+            } else {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    f2 r = f2{__builtin_amdgcn_rcpf(zc[f][p].x),
+                              __builtin_amdgcn_rcpf(zc[f][p].y)};
+#pragma unroll
+                    for (int k = 0; k < (kDiv >= 2 ? kDiv - 1 : 1); ++k)
+                        r = PkFma(PkFma(-zc[f][p], r, Splat(1.0f)), r, r);
+                    inv_z[p] = r;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                // u = fx * x * inv_z + cx (GeometryIndexer.h:100-108)
+                const f2 u = xc[p] * fx * inv_z[p] + cx;
+                const f2 v = yc[p] * fyk * inv_z[p] + cy;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float uh = h ? u.y : u.x, vh = h ? v.y : v.x;
+                    const bool in = vh >= 0 && uh >= 0 && vh <= v_max &&
+                                    uh <= u_max;
+                    // 32-bit byte offset from a wave-uniform base; the
+                    // sentinel record (depth 0) for voxels outside the image
+                    // (24-bit multiply: rows and the row pitch are far below
+                    // 2^24, and it issues at full rate)
+                    const unsigned off =
+                            __umul24((unsigned)(int)vh, row_bytes) +
+                            (unsigned)(int)uh * (unsigned)sizeof(PixelRec);
+                    rec[f][2 * p + h] = *reinterpret_cast<const PixelRec*>(
+                            recs + (in ? off : sentinel_off));
+                }
+            }
+        }
+
+        // 3. frames applied in order (VoxelBlockGridImpl.h:258-302)
+#pragma unroll
+        for (int f = c0; f < c0 + kChunk; ++f) {
+            if (!((bits >> f) & 1u)) continue;  // wave-uniform
+            f2 sdf[2];
+            bool ok[4];
+            bool tiny = false;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float dh = rec[f][2 * p + h].d;
+                    const float zh = h ? zc[f][p].y : zc[f][p].x;
+                    const float sh = dh - zh;
+                    ok[2 * p + h] = !(dh <= 0) && !(dh > ip.depth_max) &&
+                                    !(zh <= 0) && !(sh < -ip.sdf_trunc);
+                    const float cl = sh < ip.sdf_trunc ? sh : ip.sdf_trunc;
+                    if (h) sdf[p].y = cl; else sdf[p].x = cl;
+                    tiny |= ok[2 * p + h] && fabsf(cl) < kDivTiny;
+                    touched |= ok[2 * p + h];
+                }
+            }
+            // sdf / sdf_trunc: short form unless a value of the wave is in the
+            // underflow range
+            if (kDiv < 1 || __builtin_amdgcn_ballot_w64(tiny) != 0ull) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    sdf[p] = f2{sdf[p].x / ip.sdf_trunc,
+                                sdf[p].y / ip.sdf_trunc};
+            } else {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const f2 q0 = sdf[p] * ip.inv_sdf_trunc;
+                    const f2 r = PkFma(Splat(-ip.sdf_trunc), q0, sdf[p]);
+                    sdf[p] = PkFma(r, Splat(ip.inv_sdf_trunc), q0);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const f2 weight = wf[p];
+                const f2 wsum = weight + 1.0f;  // exact (integers <= 65536)
+                f2 inv_wsum;
+                if constexpr (kU16 && kDiv >= 1) {
+                    // RcpSmallInt, packed
+                    const f2 r0 = f2{__builtin_amdgcn_rcpf(wsum.x),
+                                     __builtin_amdgcn_rcpf(wsum.y)};
+                    inv_wsum = PkFma(PkFma(-wsum, r0, Splat(1.0f)), r0, r0);
+                } else {
+                    inv_wsum = f2{1.0f / wsum.x, 1.0f / wsum.y};
+                }
+                const f2 t_new = (weight * ts[p] + sdf[p]) * inv_wsum;
+                ts[p] = f2{ok[2 * p] ? t_new.x : ts[p].x,
+                           ok[2 * p + 1] ? t_new.y : ts[p].y};
+                if constexpr (kColor) {
+                    const unsigned rg0 = rec[f][2 * p].rgba;
+                    const unsigned rg1 = rec[f][2 * p + 1].rgba;
+                    const bool has0 = ok[2 * p] && (rg0 >> 24);
+                    const bool has1 = ok[2 * p + 1] && (rg1 >> 24);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const f2 in = f2{(float)((rg0 >> (8 * i)) & 0xffu),
+                                         (float)((rg1 >> (8 * i)) & 0xffu)};
+                        f2 c_new = (weight * cf[p][i] + in) * inv_wsum;
+                        if constexpr (sizeof(color_t) == 2)
+                            c_new = f2{truncf(c_new.x), truncf(c_new.y)};
+                        cf[p][i] = f2{has0 ? c_new.x : cf[p][i].x,
+                                      has1 ? c_new.y : cf[p][i].y};
+                    }
+                }
+                f2 w_new = wsum;
+                if constexpr (kU16)
+                    w_new = f2{w_new.x >= 65536.0f ? 0.0f : w_new.x,
+                               w_new.y >= 65536.0f ? 0.0f : w_new.y};
+                wf[p] = f2{ok[2 * p] ? w_new.x : weight.x,
+                           ok[2 * p + 1] ? w_new.y : weight.y};
+            }
+        }
+        }  // chunk
+        if (touched) {
+            TVec t_out;
+            t_out.v[0] = ts[0].x; t_out.v[1] = ts[0].y;
+            t_out.v[2] = ts[1].x; t_out.v[3] = ts[1].y;
+            *reinterpret_cast<TVec*>(tsdf_base + lin0) = t_out;
+            WVec w4;
+            w4.v[0] = (weight_t)wf[0].x; w4.v[1] = (weight_t)wf[0].y;
+            w4.v[2] = (weight_t)wf[1].x; w4.v[3] = (weight_t)wf[1].y;
+            *reinterpret_cast<WVec*>(weight_base + lin0) = w4;
+            if constexpr (kColor) {
+                CVec c12;
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        c12.v[6 * p + i] = (color_t)cf[p][i].x;
+                        c12.v[6 * p + 3 + i] = (color_t)cf[p][i].y;
+                    }
+                *reinterpret_cast<CVec*>(color_base + 3 * lin0) = c12;
+            }
+        }
+    }
+    if (frame_blocks) atomicAdd(ip.prof_frame_blocks, frame_blocks);
+}
+
 struct StepParams {
     HashView hv;
     FrontParams front[kMaxGroup];
@@ -430,13 +884,24 @@ struct StepParams {
     int front_wg;  // workgroups per front role
 };
 
-template <typename weight_t, typename color_t, bool kColor, int kDiv>
-__global__ void __launch_bounds__(256) FrameStepKernel(StepParams sp) {
+// kForm: 0 = first form of the integrate role; 1 = wide form (all frames of
+// the group in flight, 4 waves per SIMD). Chunks of two frames were tried to
+// lower the register count: the compiler's schedule keeps ~125 registers live
+// either way (colour temporaries), so the chunked form is not instantiated.
+template <typename weight_t, typename color_t, bool kColor, int kDiv,
+          int kForm>
+__global__ void __launch_bounds__(256, kForm == 0 ? 1 : 4)
+FrameStepKernel(StepParams sp) {
     const int b = (int)blockIdx.x;
     const int n_front_wg = sp.n_fronts * sp.front_wg;
     if (b < n_front_wg) {
         const int f = b / sp.front_wg;
         FrontRole(sp.hv, sp.front[f], b - f * sp.front_wg);
+    } else if constexpr (kForm != 0) {
+        IntegrateRoleWide<weight_t, color_t, kColor, kDiv,
+                          kMaxGroup>(
+                sp.hv, sp.integ, b - n_front_wg, (int)gridDim.x - n_front_wg,
+                n_front_wg);
     } else {
         IntegrateRole<weight_t, color_t, kColor, kDiv>(
                 sp.hv, sp.integ, b - n_front_wg, (int)gridDim.x - n_front_wg);
@@ -444,6 +909,45 @@ __global__ void __launch_bounds__(256) FrameStepKernel(StepParams sp) {
 }
 
 }  // namespace
+
+bool PrepTables(const double* depth_intrinsic, const double* color_intrinsic,
+                int rows, int cols, int color_rows, int color_cols,
+                float depth_scale, int* col, int* row) {
+    // TransformIndexer keeps float copies (GeometryIndexer.h:46-58); the
+    // expressions below are Unproject(u, v, 1) -> Project -> InBoundary ->
+    // round exactly as the per-pixel form above evaluates them (this file is
+    // compiled without FMA contraction, x86-64 float arithmetic is IEEE).
+    const float fx = (float)depth_intrinsic[0], fy = (float)depth_intrinsic[4];
+    const float cx = (float)depth_intrinsic[2], cy = (float)depth_intrinsic[5];
+    const double* ck = color_intrinsic ? color_intrinsic : depth_intrinsic;
+    const float fx2 = (float)ck[0], fy2 = (float)ck[4];
+    const float cx2 = (float)ck[2], cy2 = (float)ck[5];
+    volatile float one = 1.0f;  // d = 1, inv_z = 1 / 1: keep the operations
+    const float inv_z = 1.0f / one;
+    for (int u = 0; u < cols; ++u) {
+        const float x = ((float)u - cx) * one / fx;
+        const float uf = fx2 * x * inv_z + cx2;
+        col[u] = (uf >= 0 && uf <= color_cols - 1.0f) ? (int)roundf(uf) : -1;
+    }
+    for (int v = 0; v < rows; ++v) {
+        const float y = ((float)v - cy) * one / fy;
+        const float vf = fy2 * y * inv_z + cy2;
+        row[v] = (vf >= 0 && vf <= color_rows - 1.0f) ? (int)roundf(vf) : -1;
+    }
+    if (!(depth_scale > 0.0f) || !std::isfinite(depth_scale)) return false;
+    static const bool exact_div = std::getenv("O3DMI_EXACT_DIV") != nullptr;
+    if (exact_div) return false;
+    const float y = 1.0f / depth_scale;
+    for (int dv = 0; dv < 65536; ++dv) {
+        const float a = (float)dv;
+        const float q0 = a * y;
+        const float r = std::fmaf(-depth_scale, q0, a);
+        const float q = std::fmaf(r, y, q0);
+        const float want = a / depth_scale;
+        if (std::memcmp(&q, &want, sizeof(float)) != 0) return false;
+    }
+    return true;
+}
 
 int64_t FrustumBlockBound(const double* K, int rows, int cols, float depth_max,
                           float block_size, int stride) {
@@ -558,12 +1062,17 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         fp.pp.with_color = f->color != nullptr;
         fp.depth = f->depth;
         fp.color = f->color;
+        fp.col_lut = f->col_lut;
+        fp.row_lut = f->col_lut ? f->row_lut : nullptr;
+        fp.depth_div_short = f->depth_div_short;
+        fp.inv_depth_scale = 1.0f / f->depth_scale;
         fp.recs = f->recs;
         fp.list = f->list;
         fp.list_capacity = f->list_capacity;
         fp.out_count = f->count;
         fp.group_stamp = f->group_stamp;
         fp.group_bit = f->group_bit;
+        fp.touch_plane = f->touch_plane & 1;
         const int n_rays = fp.p.rows_strided * fp.p.cols_strided;
         fp.n_touch_wg = (n_rays + kBlock - 1) / kBlock;
         // 4 pixels per prepare lane
@@ -582,14 +1091,20 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
                       "bad group size");
         IntegParams& ip = sp.integ;
         ip.n_frames = a->n_frames;
+        ip.group_stamp = a->group_stamp;
+        ip.touch_plane = a->touch_plane & 1;
         for (int f = 0; f < a->n_frames; ++f) {
             ip.cam[f] = Camera::Make(a->depth_intrinsic, a->extrinsic[f],
                                      a->voxel_size);
+            std::memcpy(ip.ext[f], ip.cam[f].e, sizeof(ip.ext[f]));
             ip.recs[f] = a->recs[f];
         }
         ip.rows = a->rows;
         ip.cols = a->cols;
         ip.resolution = a->resolution;
+        ip.res_shift = -1;
+        for (int sh = 2; sh < 12; ++sh)
+            if ((1 << sh) == a->resolution) ip.res_shift = sh;
         ip.sdf_trunc = a->sdf_trunc;
         ip.depth_max = a->depth_max;
         fast_div = VerifyFastDivision(a->sdf_trunc, &ip.inv_sdf_trunc);
@@ -613,14 +1128,36 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         const int64_t g_max = (int64_t)kCUs * 32;
         if (g > g_max) g = g_max;
         if (g < kCUs) g = kCUs;
+        // O3DMI_STEP_GRID=n (diagnostics): fixed number of integrate
+        // workgroups, e.g. 1024 = the resident set, each striding over items
+        static const int fixed_grid = []() {
+            const char* e = std::getenv("O3DMI_STEP_GRID");
+            return e ? std::atoi(e) : 0;
+        }();
+        if (fixed_grid > 0) g = fixed_grid;
         n_int_wg = (int)g;
         grid_dtype = a->grid_dtype;
         col = a->with_color && a->color != nullptr;
     }
     dim3 grid((unsigned)(n_fronts * sp.front_wg + n_int_wg)), block(256);
+    // O3DMI_STEP_VARIANT=0 selects the first form of the integrate role
+    // (diagnostics / A-B measurements); results are identical.
+    static const int form = []() {
+        const char* e = std::getenv("O3DMI_STEP_VARIANT");
+        return e && e[0] == '0' ? 0 : 1;
+    }();
 #define O3DMI_LAUNCH_STEP_D(WT, VT, COLOR, D)                                 \
-    hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR, D>), grid, block, 0, s, \
-                       sp)
+    do {                                                                      \
+        switch (form) {                                                       \
+            case 0:                                                           \
+                hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR, D, 0>),    \
+                                   grid, block, 0, s, sp);                    \
+                break;                                                        \
+            default:                                                          \
+                hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR, D, 1>),    \
+                                   grid, block, 0, s, sp);                    \
+        }                                                                     \
+    } while (0)
 #define O3DMI_LAUNCH_STEP(WT, VT, COLOR)                                      \
     do {                                                                      \
         switch (fast_div) {                                                   \

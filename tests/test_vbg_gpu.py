@@ -159,6 +159,71 @@ def test_hash_semantics():
     L.o3dmi_hash_destroy(h)
 
 
+@pytest.mark.timeout(300)
+def test_hash_insert_erase_churn_reuses_tombstones():
+    """HashMap supports unbounded insert / erase cycling (cpp/tests/core/
+    HashMap.cpp:138-191 erases and re-inserts on one map). 200 rounds of
+    insert-48 / erase-48 on a 64-block map (128 slots) leave far more
+    tombstones behind than there are slots unless inserts reuse them and the
+    table is rebuilt when crowded; lookups of absent keys must still end."""
+    _lib, _ = _gpu()
+    from open3d_amd.core import stream
+    L = _lib.lib()
+    h = C.c_void_p()
+    ds = (C.c_int64 * 1)(4)
+    _lib.check(L.o3dmi_hash_create(64, 1, ds, stream(), C.byref(h)), "create")
+    rng = np.random.default_rng(5)
+    n = C.c_int64(0)
+    keep = torch.tensor([[5, 5, 5], [-9, 1, 2]], dtype=torch.int32,
+                        device="cuda")
+    _lib.check(L.o3dmi_hash_activate(h, _lib.ptr(keep), 2, None, None, None,
+                                     stream()), "activate")
+    kb = torch.zeros(2, dtype=torch.int32, device="cuda")
+    km = torch.zeros(2, dtype=torch.bool, device="cuda")
+    _lib.check(L.o3dmi_hash_find(h, _lib.ptr(keep), 2, None, _lib.ptr(kb),
+                                 _lib.ptr(km), stream()), "find")
+    keep_idx = kb.cpu().numpy().copy()
+    for r in range(200):
+        k = rng.integers(-1000, 1000, size=(48, 3)).astype(np.int32)
+        k = np.unique(k, axis=0)
+        kt = torch.from_numpy(k).cuda()
+        m = torch.zeros(len(k), dtype=torch.bool, device="cuda")
+        b = torch.zeros(len(k), dtype=torch.int32, device="cuda")
+        _lib.check(L.o3dmi_hash_activate(h, _lib.ptr(kt), len(k), None,
+                                         _lib.ptr(b), _lib.ptr(m), stream()),
+                   "activate")
+        assert bool(m.all())
+        _lib.check(L.o3dmi_hash_size(h, stream(), C.byref(n)), "size")
+        assert n.value == len(k) + 2
+        # distinct buffer indices, none of them the two long-lived ones
+        bi = b.cpu().numpy()
+        assert len(set(bi.tolist())) == len(k)
+        assert not set(bi.tolist()) & set(keep_idx.tolist())
+        absent = torch.from_numpy(
+            rng.integers(2000, 3000, size=(64, 3)).astype(np.int32)).cuda()
+        am = torch.ones(64, dtype=torch.bool, device="cuda")
+        ab = torch.zeros(64, dtype=torch.int32, device="cuda")
+        _lib.check(L.o3dmi_hash_find(h, _lib.ptr(absent), 64, None,
+                                     _lib.ptr(ab), _lib.ptr(am), stream()),
+                   "find")
+        assert not bool(am.any())
+        em = torch.zeros(len(k), dtype=torch.bool, device="cuda")
+        _lib.check(L.o3dmi_hash_erase(h, _lib.ptr(kt), len(k), _lib.ptr(em),
+                                      stream()), "erase")
+        assert bool(em.all())
+        _lib.check(L.o3dmi_hash_find(h, _lib.ptr(kt), len(k), None,
+                                     _lib.ptr(b), _lib.ptr(m), stream()),
+                   "find")
+        assert not bool(m.any())
+    _lib.check(L.o3dmi_hash_size(h, stream(), C.byref(n)), "size")
+    assert n.value == 2
+    # the long-lived keys kept their buffer indices through every rebuild
+    _lib.check(L.o3dmi_hash_find(h, _lib.ptr(keep), 2, None, _lib.ptr(kb),
+                                 _lib.ptr(km), stream()), "find")
+    assert bool(km.all()) and np.array_equal(kb.cpu().numpy(), keep_idx)
+    L.o3dmi_hash_destroy(h)
+
+
 @pytest.mark.parametrize("k", [0, 300, 700])
 @pytest.mark.parametrize("f32", [False, True])
 def test_depth_touch_block_set_bit_exact(k, f32):
@@ -310,6 +375,61 @@ def test_frame_batch_equals_oracle(group, grid_f32):
                        sc.DEPTH_MAX, sc.TRUNC_MULT, frames_per_launch=group)
     assert _compare_grids(og, g)[1]
     assert g.hashmap().capacity() > 600
+
+
+def _all_blocks(g):
+    """{key: (tsdf, weight, colour) bytes} of every active block."""
+    hm = g.hashmap()
+    act = hm.active_buf_indices().cpu().numpy().astype(np.int64)
+    keys = hm.key_tensor().cpu().numpy()[act]
+    order = np.lexsort(keys.T[::-1])
+    act, keys = act[order], keys[order]
+    return (keys, g.attribute("tsdf").cpu().numpy()[act],
+            g.attribute("weight").cpu().numpy()[act],
+            g.attribute("color").cpu().numpy()[act])
+
+
+@pytest.mark.timeout(900)
+def test_fused_frame_groups_with_disjoint_frame_bits_stress():
+    """The front roles of group g+1 run in the same launch as the integrate
+    role of group g and both use the per-slot touch words (frame bits); the
+    two groups must not see each other's words (two planes, by group parity).
+    Small images and a view that jumps between frames make consecutive groups
+    touch overlapping block sets with DIFFERENT frame bits, many fused 4-frame
+    groups per call, repeated: the grid must equal frame-by-frame integration
+    (frames_per_launch = 1) bit for bit every time, and the oracle's."""
+    _lib, geometry = _gpu()
+    w, h = 160, 120
+    ks = [(i * 137) % 1000 for i in range(96)]
+    ds, cs, Ts = [], [], []
+    for k in ks:
+        d, c, K, T = sc.frames(k, 1, w, h)
+        ds.append(d[0]); cs.append(c[0]); Ts.append(T[0])
+    dt = [torch.from_numpy(d).cuda() for d in ds]
+    ct = [torch.from_numpy(c).cuda() for c in cs]
+    ref_g = _mk_grid(geometry, False, block_count=16384)
+    ref_g.integrate_frames(dt, ct, K, K, Ts, sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                           sc.TRUNC_MULT, frames_per_launch=1)
+    want = _all_blocks(ref_g)
+    og = OracleGrid(False, 16384)
+    for i in range(24):
+        og.integrate(ds[i], cs[i], K, Ts[i])
+    for rep in range(6):
+        g = _mk_grid(geometry, False, block_count=16384)
+        if rep == 0:
+            g.integrate_frames(dt[:24], ct[:24], K, K, Ts[:24], sc.DEPTH_SCALE,
+                               sc.DEPTH_MAX, sc.TRUNC_MULT,
+                               frames_per_launch=4)
+            assert _compare_grids(og, g)[1]
+            g.integrate_frames(dt[24:], ct[24:], K, K, Ts[24:],
+                               sc.DEPTH_SCALE, sc.DEPTH_MAX, sc.TRUNC_MULT,
+                               frames_per_launch=4)
+        else:
+            g.integrate_frames(dt, ct, K, K, Ts, sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                               sc.TRUNC_MULT, frames_per_launch=2 + rep % 3)
+        got = _all_blocks(g)
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b), rep
 
 
 def test_frame_batch_depth_only_and_res8():
