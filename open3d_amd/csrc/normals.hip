@@ -17,7 +17,6 @@
 #include <cstdlib>
 
 #include "common.h"
-#include "approx_svd3.h"
 
 namespace o3dmi {
 namespace {
@@ -314,11 +313,17 @@ __global__ void NormalsFromCovariancesKernel(const T* __restrict__ covariances,
 }
 
 // x = pinv(AtA) Atb for a symmetric 3x3 AtA: cyclic Jacobi eigen-decomposition
-// (8 sweeps, converged for 3x3), eigenvalues below 1e-10 dropped -- the exact
-// solution of the normal equations. The default is the reference's
-// solve_svd3x3 (approx_svd3.h, bit for bit); this one is selected by
-// O3DMI_EXACT_COLOR_GRADIENTS=1 (the reference's Float64 path returns NaN on
-// some neighbourhoods).
+// (8 sweeps, converged for 3x3), eigenvalues below 1e-10 dropped -- the
+// minimum-norm solution of the normal equations, which is what the reference
+// asks of core::linalg::kernel::solve_svd3x3 (PointCloudImpl.h:1163). The
+// reference's routine is an APPROXIMATE SVD (four fixed Jacobi sweeps in
+// single-precision-oriented arithmetic); this solver is this code base's own
+// and converged, so the two agree to the accuracy of the reference's
+// approximation: tests/test_icp_gpu.py::test_color_gradients_vs_reference_body
+// bounds the difference against the reference's compiled body (median ~1e-6
+// of the gradient scale in Float32, a percent-level tail on ill-conditioned
+// neighbourhoods; the reference's Float64 path returns NaN on ~9 % of them,
+// this one never does). See DESIGN.md section 7.
 template <typename T>
 __device__ __forceinline__ void PinvSolveSym3(const T* AtA, const T* Atb,
                                               T* x) {
@@ -381,7 +386,7 @@ __device__ __forceinline__ void PinvSolveSym3(const T* AtA, const T* Atb,
 // constraint gradient . normal = 0 (the first neighbour is the point itself).
 // Neighbour lists: fixed-width rows (indices + max_nn * w, counts[w]) or, when
 // row_splits != NULL, CSR (radius search).
-template <typename T, bool EXACT>
+template <typename T>
 __global__ void ColorGradientsKernel(const T* __restrict__ points,
                                      const T* __restrict__ normals,
                                      const T* __restrict__ colors,
@@ -446,8 +451,7 @@ __global__ void ColorGradientsKernel(const T* __restrict__ points,
         AtA[6] = AtA[2];
         AtA[7] = AtA[5];
         T x[3];
-        if constexpr (EXACT) PinvSolveSym3<T>(AtA, Atb, x);
-        else svd3::SolveSvd3x3<T>(AtA, Atb, x);
+        PinvSolveSym3<T>(AtA, Atb, x);
         out[0] = x[0];
         out[1] = x[1];
         out[2] = x[2];
@@ -715,20 +719,13 @@ static int ColorGradientsLaunch(
                   "null argument");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(GridFor(n, kBlock)), block(kBlock);
-    const char* e = std::getenv("O3DMI_EXACT_COLOR_GRADIENTS");
-    const bool exact = e && e[0] == '1';
-#define O3DMI_GRAD(T, X)                                                       \
-    hipLaunchKernelGGL((ColorGradientsKernel<T, X>), grid, block, 0, s,        \
+#define O3DMI_GRAD(T)                                                          \
+    hipLaunchKernelGGL((ColorGradientsKernel<T>), grid, block, 0, s,           \
                        (const T*)points_dev, (const T*)normals_dev,            \
                        (const T*)colors_dev, indices_dev, counts_dev,          \
                        row_splits_dev, n, max_nn, (T*)gradients_dev)
-    if (dtype == O3DMI_F64) {
-        if (exact) O3DMI_GRAD(double, true);
-        else O3DMI_GRAD(double, false);
-    } else {
-        if (exact) O3DMI_GRAD(float, true);
-        else O3DMI_GRAD(float, false);
-    }
+    if (dtype == O3DMI_F64) O3DMI_GRAD(double);
+    else O3DMI_GRAD(float);
 #undef O3DMI_GRAD
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;

@@ -552,6 +552,15 @@ void Matmul4(const double* A, const double* B, double* C) {
     std::memcpy(C, R, sizeof(R));
 }
 
+// The reference sums the squared distances in the tensor dtype
+// (distances.Sum({0}), Registration.cpp:44-45) -- in Float32 that sum carries
+// ~1e-5 relative rounding that depends on the reduction engine's chunking, and
+// the driver's convergence rule (|d rmse| < relative_rmse) sits on it. With
+// the drivers' accumulate_double switch the sum is Float64 as well (per-term
+// arithmetic unchanged), so that the float64-accumulating oracle is free of
+// summation-order knife edges end to end; the Float32 form stays the default.
+static thread_local bool g_sum_distances_double = false;
+
 template <typename T>
 RegResult ComputeRegistrationResult(const T* source, int64_t ns,
                                     const T* target, int64_t nt,
@@ -568,14 +577,17 @@ RegResult ComputeRegistrationResult(const T* source, int64_t ns,
     // (int32 / T), then cast to Float64 (Registration.cpp:38-46).
     int64_t num = 0;
     T sq = 0;
+    double sq64 = 0;
     for (int64_t i = 0; i < ns; ++i) {
         result.correspondences[(size_t)i] = idx[(size_t)i];
         num += counts[(size_t)i];
         sq += distances[(size_t)i];
+        sq64 += (double)distances[(size_t)i];
     }
     double num_correspondences = (double)num;
     if (num_correspondences != 0) {
-        const double squared_error = (double)sq;
+        const double squared_error =
+                g_sum_distances_double ? sq64 : (double)sq;
         result.fitness = num_correspondences / static_cast<double>(ns);
         result.inlier_rmse = std::sqrt(squared_error / num_correspondences);
     } else {
@@ -1201,6 +1213,14 @@ void ColorGradientsForIcp(const T* points, const T* normals, const T* colors,
                           const int32_t* indices, const int32_t* counts,
                           int64_t n, int max_nn, T* gradients);
 
+// Optional replacement of the point-to-plane 29-sum inside the driver (same
+// signature as oracle/_ref's ref_p2plane_accumulate).
+typedef int (*P2PlaneHook)(const void* src, const void* tgt, const void* tgt_n,
+                           const int64_t* corr, int64_t n, int is_f64,
+                           int method, double scaling, double shape,
+                           double* sums29);
+static P2PlaneHook g_p2plane_hook = nullptr;
+
 // Attributes some estimators read beyond positions / target normals.
 struct IcpExtra {
     const void* source_normals = nullptr;         // symmetric
@@ -1223,6 +1243,13 @@ int MultiScaleICP(const T* source_in, const IcpExtra& extra, int64_t ns_in,
                   int* out_converged, int* out_num_iterations,
                   int64_t* out_correspondences, int64_t* out_num_corr,
                   icp_callback_t cb, void* user) {
+    struct SumMode {  // scoped: Float64 distance sum with accumulate_double
+        bool prev;
+        explicit SumMode(bool on) : prev(g_sum_distances_double) {
+            g_sum_distances_double = on;
+        }
+        ~SumMode() { g_sum_distances_double = prev; }
+    } sum_mode(accumulate_double != 0);
     // Pyramid.
     std::vector<std::vector<T>> src_p(num_scales), tgt_p(num_scales),
             tgt_n(num_scales), src_n(num_scales), src_c(num_scales),
@@ -1471,7 +1498,14 @@ int MultiScaleICP(const T* source_in, const IcpExtra& extra, int64_t ns_in,
                     continue;
                 }
                 double A[29];
-                if (accumulate_double) {
+                if (g_p2plane_hook) {
+                    // the 29 sums from an external body (tests: the
+                    // reference's own, under a chosen reduction schedule)
+                    g_p2plane_hook(source.data(), target.data(),
+                                   normals.data(), r2.correspondences.data(),
+                                   ns, sizeof(T) == 8, kernel_method,
+                                   kernel_scale, kernel_shape, A);
+                } else if (accumulate_double) {
                     ComputePosePointToPlaneKernel<T, double>(
                             source.data(), target.data(), normals.data(),
                             r2.correspondences.data(), ns, A, kernel_method,
@@ -1962,16 +1996,26 @@ void EstimateColorGradients(const T* points, const T* normals, const T* colors,
 }  // namespace normals
 
 namespace {
+// Which 3x3 solve the oracle's ICP driver uses when it estimates colour
+// gradients itself: the reference's approximate solve_svd3x3 (default) or the
+// converged pseudo-inverse the product uses (orc_set_exact_color_gradients).
+bool g_exact_color_gradients = false;
 template <typename T>
 void ColorGradientsForIcp(const T* points, const T* normals_, const T* colors,
                           const int32_t* indices, const int32_t* counts,
                           int64_t n, int max_nn, T* gradients) {
     normals::EstimateColorGradients<T>(points, normals_, colors, indices,
-                                       counts, n, max_nn, gradients);
+                                       counts, n, max_nn, gradients,
+                                       g_exact_color_gradients);
 }
 }  // namespace
 
 extern "C" {
+
+void orc_set_exact_color_gradients(int on) { g_exact_color_gradients = on != 0; }
+
+// fn = address of a function with ref_p2plane_accumulate's signature, or NULL.
+void orc_set_p2plane_hook(void* fn) { g_p2plane_hook = (P2PlaneHook)fn; }
 
 double orc_robust_weight(int is_f64, int method, double scaling, double shape,
                          double residual) {

@@ -103,6 +103,13 @@ void ref_set_threads(int n) {
 #endif
 }
 
+// Schedule of the stand-in tbb::parallel_reduce (tbb/parallel_reduce.h):
+// seed 0 = one sequential chunk (default); otherwise seeded random splits down
+// to chunks of <= min_chunk elements.
+void ref_set_reduce_schedule(unsigned long long seed, long long min_chunk) {
+    tbb::shim::SetSchedule(seed, min_chunk);
+}
+
 // DepthTouchCPU, t/geometry/kernel/VoxelBlockGridCPU.cpp:117-201.
 // Returns the number of unique blocks, -1 on error ("No block is touched").
 int64_t ref_depth_touch(const void* depth, int depth_is_f32, int rows, int cols,

@@ -839,6 +839,21 @@ def svd3x3(A):
     return U, S, V
 
 
+def set_exact_color_gradients(on):
+    """ICP driver: colour gradients it estimates itself use the converged
+    pseudo-inverse (the product's solver) instead of the reference's
+    approximate solve_svd3x3."""
+    lib().orc_set_exact_color_gradients(int(bool(on)))
+
+
+def set_p2plane_hook(fn_address):
+    """Point-to-plane ICP driver: take the 29 sums from an external function
+    (address of one with _ref's ref_p2plane_accumulate signature; None
+    restores the oracle's own)."""
+    lib().orc_set_p2plane_hook.argtypes = [C.c_void_p]
+    lib().orc_set_p2plane_hook(C.c_void_p(fn_address or 0))
+
+
 def solve_svd3x3(A, b):
     A = np.ascontiguousarray(A)
     b = np.ascontiguousarray(b, dtype=A.dtype)

@@ -70,6 +70,18 @@ def set_threads(n):
     lib().ref_set_threads(int(n))
 
 
+def set_reduce_schedule(seed, min_chunk=1024):
+    """Schedule of the stand-in tbb::parallel_reduce: seed 0 = one sequential
+    chunk; otherwise seeded random splits down to <= min_chunk elements."""
+    lib().ref_set_reduce_schedule(C.c_ulonglong(int(seed)),
+                                  C.c_longlong(int(min_chunk)))
+
+
+def p2plane_accumulate_address():
+    """Address of ref_p2plane_accumulate (for orc.set_p2plane_hook)."""
+    return C.cast(lib().ref_p2plane_accumulate, C.c_void_p).value
+
+
 def depth_touch(depth, K, T, resolution, voxel_size, sdf_trunc, depth_scale,
                 depth_max, stride=4):
     depth = np.ascontiguousarray(depth)

@@ -1,0 +1,204 @@
+"""Parity at BASELINE.json's full configurations (GPU through the C ABI vs the
+CPU path on the same inputs):
+
+  configs[1]  1000 synthetic 640x480 RGB-D frames into an 8 mm / 16^3 grid:
+              the whole stream through integrate_frames (4 frames per launch)
+              vs Open3D's own DepthTouchCPU / IntegrateCPU bodies (oracle/_ref)
+              frame by frame -- whole grid bit for bit.
+  configs[2]  1280x720 tracking loop: ray cast (model cloud) -> Unproject
+              (frame cloud) -> MultiScaleICP (5 / 2.5 / 1.25 cm; 20 / 10 / 5
+              iterations) -> Integrate, 20 frames, operator by operator in
+              lock-step with the oracle: pose <= 1e-6 rad / 1e-5 m per frame vs
+              the float64-accumulating oracle, block sets and the final grid
+              bit for bit, ray-cast maps <= 1e-4 with exact masks.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import _oracle as orc
+import _scene as sc
+from test_vbg_gpu import OracleGrid, _compare_grids, _mk_grid
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from open3d_amd import _lib, geometry
+    return _lib, geometry
+
+
+@pytest.mark.timeout(1500)
+def test_configs1_full_length_1000_frames_vs_reference_cpu_bodies():
+    """BASELINE configs[1] at full length. Frames are rendered once (on the
+    GPU, float64 closed form) and the same uint16 / uint8 images feed both
+    sides."""
+    _lib, geometry = _gpu()
+    import _ref as ref
+    from open3d_amd import synthetic as syn
+    impl = ref if ref.available() else orc
+    impl.set_threads(16)
+    n, cap = 1000, 16384
+    g = _mk_grid(geometry, False, block_count=cap)
+    og = OracleGrid(False, cap)
+    K = syn.intrinsics(640, 480)
+    dts, cts, Ts = [], [], []
+    for k0 in range(0, n, 50):
+        d, c, _, T = syn.render_frames(k0, 50, 640, 480, device="cuda")
+        dn, cn = d.cpu().numpy(), c.cpu().numpy()
+        for i in range(50):
+            keys = impl.depth_touch(dn[i], K, T[i], sc.RES, sc.VOXEL,
+                                    sc.VOXEL * sc.TRUNC_MULT, sc.DEPTH_SCALE,
+                                    sc.DEPTH_MAX, 4)
+            og.h.activate(keys)
+            buf, _ = og.h.find(keys)
+            impl.integrate(dn[i], cn[i], buf, og.h.key_buffer(), og.tsdf,
+                           og.weight, og.color, K, K, T[i], sc.RES, sc.VOXEL,
+                           sc.VOXEL * sc.TRUNC_MULT, sc.DEPTH_SCALE,
+                           sc.DEPTH_MAX)
+            dts.append(d[i].contiguous())
+            cts.append(c[i].contiguous())
+            Ts.append(T[i])
+    # the bench's call pattern: 50 frames per native call, 4 frames per launch
+    for lo in range(0, n, 50):
+        g.integrate_frames(dts[lo:lo + 50], cts[lo:lo + 50], K, K,
+                           Ts[lo:lo + 50], sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                           sc.TRUNC_MULT, frames_per_launch=4)
+    err, exact = _compare_grids(og, g)
+    assert exact, err
+    assert og.weight.max() >= 150
+    print("configs[1]: 1000 frames, %d blocks, max weight %d, whole grid "
+          "bit-exact vs %s" % (og.h.size(), int(og.weight.max()),
+                               "oracle/_ref" if impl is ref else "oracle"))
+
+
+def _pose_err(Ta, Tb):
+    d = np.linalg.inv(Ta) @ Tb
+    skew = d[:3, :3] - d[:3, :3].T
+    ang = float(np.linalg.norm([skew[2, 1], skew[0, 2], skew[1, 0]]) / 2)
+    return ang, float(np.linalg.norm(Ta[:3, 3] - Tb[:3, 3]))
+
+
+@pytest.mark.timeout(2400)
+def test_configs2_720p_tracking_loop_in_lock_step_with_the_oracle():
+    """BASELINE configs[2] (the loop tools/bench_slam.py --mode slam and
+    bench.py's secondary line time), 1280x720, 20 tracked frames."""
+    _lib, geometry = _gpu()
+    from open3d_amd import registration as reg, synthetic as syn
+    from open3d_amd.core import stream
+    L = _lib.lib()
+    W, H, n, step = 1280, 720, 21, 2
+    ds, dmax, trunc, stride = sc.DEPTH_SCALE, sc.DEPTH_MAX, sc.TRUNC_MULT, 2
+    K = syn.intrinsics(W, H)
+    depths, colors, Tgt = [], [], []
+    for k in range(n):
+        d, c, _, T = syn.render_frames(k * step, 1, W, H, device="cuda")
+        depths.append(d[0].contiguous())
+        colors.append(c[0].contiguous())
+        Tgt.append(np.array(T[0]))
+    cap = 16384
+    g = _mk_grid(geometry, False, block_count=cap)
+    og = OracleGrid(False, cap)
+    orc.set_threads(64)
+    vs = [0.05, 0.025, 0.0125]
+    crit = [(1e-6, 1e-6, 20), (1e-6, 1e-6, 10), (1e-6, 1e-6, 5)]
+    md = [0.15, 0.075, 0.0375]
+    npx = (H // stride) * (W // stride)
+    pts_buf = torch.empty((npx, 3), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    mpts = torch.empty((npx, 3), dtype=torch.float32, device="cuda")
+    mnrm = torch.empty_like(mpts)
+    mcnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+    # bootstrap: frame 0 at its true pose, both sides
+    g.integrate_frame(depths[0], colors[0], K, K, Tgt[0], ds, dmax, trunc)
+    og.integrate(depths[0].cpu().numpy(), colors[0].cpu().numpy(), K, Tgt[0])
+    T_prev = Tgt[0]
+    depth_pred = depths[0]
+    worst = {"pose": (0.0, 0.0), "depth": 0.0, "normal": 0.0}
+    for k in range(1, n):
+        # ---- predict: ray cast at the previous pose -------------------------
+        keys = g.compute_unique_block_coordinates(depth_pred, K, T_prev, ds,
+                                                  dmax, trunc)
+        okeys = orc.depth_touch(depth_pred.cpu().numpy(), K, T_prev, sc.RES,
+                                sc.VOXEL, sc.VOXEL * trunc, ds, dmax, 4)
+        assert np.array_equal(sc.sort_rows(keys.cpu().numpy()),
+                              sc.sort_rows(okeys)), k
+        out = g.ray_cast(keys, K, T_prev, W, H,
+                         render_attributes=("depth", "normal"),
+                         depth_scale=ds, depth_min=0.1, depth_max=dmax,
+                         weight_threshold=1.0, trunc_voxel_multiplier=trunc)
+        rng, _ = orc.estimate_range(okeys, K, T_prev, H, W, 8, sc.RES,
+                                    sc.VOXEL, 0.1, dmax,
+                                    frag_buffer_size=1 << 20)
+        want_rc = orc.raycast(og.h, og.tsdf, og.weight, og.color, rng, K,
+                              T_prev, H, W, sc.RES, sc.VOXEL, ds, 0.1, dmax,
+                              1.0, trunc, 8, ("depth", "normal"))
+        gd = out["depth"].cpu().numpy()
+        gn = out["normal"].cpu().numpy()
+        assert np.array_equal(gd > 0, want_rc["depth"] > 0), k
+        assert (gd > 0).mean() > 0.5
+        # depth map is in depth_scale units (x1000): 1e-4 m = 0.1
+        e_d = float(np.abs(gd - want_rc["depth"]).max()) / ds
+        e_n = float(np.abs(gn - want_rc["normal"]).max())
+        assert e_d <= 1e-4 and e_n <= 1e-4, (k, e_d, e_n)
+        worst["depth"] = max(worst["depth"], e_d)
+        worst["normal"] = max(worst["normal"], e_n)
+        # ---- model cloud / frame cloud (Unproject, stride 2) ----------------
+        Tp = np.ascontiguousarray(T_prev, dtype=np.float64)
+        _lib.check(L.o3dmi_unproject(
+            _lib.ptr(out["depth"]), _lib.F32, H, W, _lib.ptr(out["normal"]),
+            _lib.ptr(mpts), _lib.ptr(mnrm), _lib.ptr(mcnt), _lib.f64p(K),
+            _lib.f64p(Tp), C.c_float(ds), C.c_float(dmax), C.c_int64(stride),
+            stream()), "unproject")
+        m = int(mcnt.item())
+        Tinv = np.ascontiguousarray(np.linalg.inv(T_prev), dtype=np.float64)
+        _lib.check(L.o3dmi_transform_normals(_lib.f64p(Tinv), _lib.ptr(mnrm),
+                                             m, _lib.F32, stream()),
+                   "transform_normals")
+        tp, tn = mpts[:m], mnrm[:m]
+        _lib.check(L.o3dmi_unproject(
+            _lib.ptr(depths[k]), _lib.U16, H, W, None, _lib.ptr(pts_buf), None,
+            _lib.ptr(cnt), _lib.f64p(K), _lib.f64p(Tp), C.c_float(ds),
+            C.c_float(dmax), C.c_int64(stride), stream()), "unproject")
+        src = pts_buf[:int(cnt.item())]
+        # the frame cloud is the reference's UnprojectCPU point set
+        want_src, _ = orc.unproject(depths[k].cpu().numpy(), None, K, T_prev,
+                                    ds, dmax, stride)
+        assert np.array_equal(sc.sort_rows(src.cpu().numpy()),
+                              sc.sort_rows(want_src)), k
+        # ---- track: MultiScaleICP, oracle on the very same clouds -----------
+        r = reg.multi_scale_icp(
+            src, tp, tn, vs, [reg.ICPConvergenceCriteria(*c) for c in crit],
+            md)
+        want = orc.multiscale_icp(src.cpu().numpy(), tp.cpu().numpy(),
+                                  tn.cpu().numpy(), vs, crit, md,
+                                  accumulate_double=True)
+        assert want["status"] == 0
+        e = _pose_err(want["transformation"], r.transformation)
+        assert e[0] <= 1e-6 and e[1] <= 1e-5, (k, e)
+        assert r.num_iterations == want["num_iterations"], k
+        assert abs(r.inlier_rmse - want["inlier_rmse"]) < 1e-9
+        assert abs(r.fitness - want["fitness"]) < 1e-12
+        worst["pose"] = (max(worst["pose"][0], e[0]),
+                         max(worst["pose"][1], e[1]))
+        # ---- integrate at the estimated pose, both sides --------------------
+        T_k = T_prev @ np.linalg.inv(r.transformation)
+        g.integrate_frame(depths[k], colors[k], K, K, T_k, ds, dmax, trunc)
+        og.integrate(depths[k].cpu().numpy(), colors[k].cpu().numpy(), K, T_k)
+        T_prev = T_k
+        depth_pred = depths[k]
+    err, exact = _compare_grids(og, g)
+    assert exact, err
+    drift = _pose_err(Tgt[-1], T_prev)
+    print("configs[2] 720p lock-step, %d tracked frames: worst pose error vs "
+          "the float64 oracle %.3g rad / %.3g m; ray-cast depth %.3g m, "
+          "normal %.3g; %d blocks, grid bit-exact; drift vs ground truth "
+          "%.3g rad / %.3g m"
+          % (n - 1, worst["pose"][0], worst["pose"][1], worst["depth"],
+             worst["normal"], og.h.size(), drift[0], drift[1]))
+    assert drift[0] < 0.1 and drift[1] < 0.2

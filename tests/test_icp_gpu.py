@@ -240,12 +240,86 @@ def test_icp_pose_parity(dtype):
     # ICP actually converged to the ground-truth motion
     ang_gt, tr_gt = _pose_err(p["T_gt"], got.transformation)
     assert ang_gt < 2e-3 and tr_gt < 5e-3
-    # distance to the reference-arithmetic (float32-accumulating) oracle
-    ref = orc.multiscale_icp(p["source"], p["target"], p["target_normals"],
-                             [-1.0], [(1e-6, 1e-6, 30)], [0.07],
-                             accumulate_double=False)
-    a2, t2 = _pose_err(ref["transformation"], got.transformation)
-    assert a2 < 1e-4 and t2 < 1e-4
+
+
+def _reference_schedule_poses(p, voxel_sizes, criteria, max_dists, n_seeds):
+    """The oracle's ICP driver with the point-to-plane 29-sum taken from the
+    REFERENCE's own float32 body (ComputePosePointToPlaneKernelCPU,
+    RegistrationCPU.cpp:30-90, compiled into oracle/_ref) under seeded random
+    tbb::parallel_reduce split schedules (oracle/ref_shim/tbb/
+    parallel_reduce.h). Returns one result per schedule; schedule 0 is the
+    single sequential chunk."""
+    import _ref as ref
+    out = []
+    orc.set_p2plane_hook(ref.p2plane_accumulate_address())
+    try:
+        for seed in range(n_seeds + 1):
+            # chunk sizes from a few dozen elements to a handful of chunks
+            ref.set_reduce_schedule(seed, (64, 256, 1024, 8192)[seed % 4])
+            out.append(orc.multiscale_icp(
+                p["source"], p["target"], p["target_normals"], voxel_sizes,
+                criteria, max_dists, accumulate_double=False))
+    finally:
+        ref.set_reduce_schedule(0)
+        orc.set_p2plane_hook(None)
+    return out
+
+
+@pytest.mark.parametrize("multiscale", [False, True])
+def test_icp_pose_inside_reference_schedule_envelope(multiscale):
+    """Pose parity against the reference's OWN float32 arithmetic. The
+    reference's 29-sum is a tbb::parallel_reduce in float32 whose split points
+    are the scheduler's, so its pose is a cloud, not a point. 32 seeded
+    schedules (+ the sequential one) of the reference's compiled body give
+    that cloud; the GPU pose (float64 accumulators, fixed tree) must be as
+    close to every member as the members are to each other, and the cloud
+    itself must sit within the 1e-6 rad / 1e-5 m bar of the float64 oracle.
+    Observed distances are printed."""
+    _lib, reg = _gpu()
+    import _ref as ref
+    if not ref.available():
+        pytest.skip("oracle/_ref not built")
+    if multiscale:
+        p = _pair(60000, seed=12, dtype=np.float32)
+        vs, md = [0.05, 0.025, 0.0125], [0.15, 0.075, 0.0375]
+        crit = [(1e-6, 1e-6, 20), (1e-6, 1e-6, 10), (1e-6, 1e-6, 5)]
+    else:
+        p = _pair(20000, seed=4, dtype=np.float32)
+        vs, md, crit = [-1.0], [0.07], [(1e-6, 1e-6, 30)]
+    runs = _reference_schedule_poses(p, vs, crit, md, 32)
+    center = orc.multiscale_icp(p["source"], p["target"], p["target_normals"],
+                                vs, crit, md, accumulate_double=True)
+    got = reg.multi_scale_icp(
+        torch.from_numpy(p["source"]).cuda(),
+        torch.from_numpy(p["target"]).cuda(),
+        torch.from_numpy(p["target_normals"]).cuda(), vs,
+        [reg.ICPConvergenceCriteria(*c) for c in crit], md)
+    Ts = [r["transformation"] for r in runs]
+    diam = [0.0, 0.0]
+    for i in range(len(Ts)):
+        for j in range(i):
+            a, t = _pose_err(Ts[i], Ts[j])
+            diam = [max(diam[0], a), max(diam[1], t)]
+    radius = [max(_pose_err(T, center["transformation"])[k] for T in Ts)
+              for k in range(2)]
+    far = [max(_pose_err(T, got.transformation)[k] for T in Ts)
+           for k in range(2)]
+    g2c = _pose_err(center["transformation"], got.transformation)
+    print("reference float32 schedule cloud (33 schedules, %s): diameter "
+          "%.3g rad / %.3g m; radius about the float64 oracle %.3g rad / "
+          "%.3g m; GPU pose: %.3g rad / %.3g m from the float64 oracle, at "
+          "most %.3g rad / %.3g m from any schedule"
+          % ("multi-scale" if multiscale else "single scale", diam[0],
+             diam[1], radius[0], radius[1], g2c[0], g2c[1], far[0], far[1]))
+    # the schedules really differ (else this test pins nothing)
+    assert len({T.tobytes() for T in Ts}) > 8
+    iters = {r["num_iterations"] for r in runs}
+    assert got.num_iterations in iters
+    # inside the envelope: no farther from any member than members are apart
+    # (1e-9 floor: the cloud of a converged run can be a few ulps wide)
+    assert far[0] <= diam[0] + 1e-9 and far[1] <= diam[1] + 1e-9, (far, diam)
+    # and the reference's own spread is inside the north-star bar
+    assert radius[0] <= 1e-6 and radius[1] <= 1e-5, radius
 
 
 def test_icp_robust_kernel_and_init():
@@ -750,21 +824,20 @@ def _colored_pair(n, seed, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("exact", [False, True])
-def test_color_gradients_parity(dtype, exact, monkeypatch):
+def test_color_gradients_parity(dtype):
     """EstimateColorGradients: the per-point kernel on given neighbour lists,
-    then the operator with hybrid and with KNN search. Default = the
-    reference's solve_svd3x3 restated (bit for bit; Float64 NaN positions
-    equal -- the reference's Float64 path produces them), exact = the exact
-    normal-equation solve behind O3DMI_EXACT_COLOR_GRADIENTS=1."""
+    then the operator with hybrid and with KNN search, against the oracle's
+    restatement of the same per-point body with the converged 3x3 solve the
+    product uses (bit for bit). The distance to the reference's own
+    (approximate) solve_svd3x3 is bounded in
+    test_color_gradients_vs_reference_body."""
     _lib, reg = _gpu()
     from open3d_amd.core import TORCH_TO_O3DMI, stream
-    monkeypatch.setenv("O3DMI_EXACT_COLOR_GRADIENTS", "1" if exact else "0")
     p, _, tc = _colored_pair(8000, 51, dtype)
     pts, nrm = p["target"], p["target_normals"]
     idx, _, cnt = orc.hybrid_search(pts, pts, 0.15, 30)
     want = orc.estimate_color_gradients(pts, nrm, tc, idx, cnt,
-                                        exact_solve=exact)
+                                        exact_solve=True)
     tp, tn, tcol = (torch.from_numpy(a).cuda() for a in (pts, nrm, tc))
     g = torch.zeros_like(tp)
     tidx, tcnt = torch.from_numpy(idx).cuda(), torch.from_numpy(cnt).cuda()
@@ -773,21 +846,63 @@ def test_color_gradients_parity(dtype, exact, monkeypatch):
         _lib.ptr(tcnt), tp.shape[0], 30,
         TORCH_TO_O3DMI[tp.dtype], _lib.ptr(g), stream()), "gradients")
     torch.cuda.synchronize()
-    assert np.array_equal(g.cpu().numpy(), want, equal_nan=True)
-    if exact or dtype == np.float32:
-        assert not np.isnan(want).any()
+    assert np.array_equal(g.cpu().numpy(), want)
+    assert not np.isnan(want).any()
     got = reg.estimate_color_gradients(tp, tn, tcol, 30, 0.15).cpu().numpy()
-    assert np.array_equal(got, want, equal_nan=True)
+    assert np.array_equal(got, want)
     kidx, _ = orc.knn_search(pts, pts, 30)
     kwant = orc.estimate_color_gradients(pts, nrm, tc, kidx,
                                          np.full(pts.shape[0], 30, np.int32),
-                                         exact_solve=exact)
+                                         exact_solve=True)
     kgot = reg.estimate_color_gradients(tp, tn, tcol, 30).cpu().numpy()
-    assert np.array_equal(kgot, kwant, equal_nan=True)
-    if exact:
-        # the gradient of a smooth colour field lies in the tangent plane
-        dots = np.abs((got * nrm).sum(1))[cnt >= 10]
-        assert np.median(dots) < 1e-3
+    assert np.array_equal(kgot, kwant)
+    # the gradient of a smooth colour field lies in the tangent plane
+    dots = np.abs((got * nrm).sum(1))[cnt >= 10]
+    assert np.median(dots) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_color_gradients_vs_reference_body(dtype):
+    """Tolerance parity against the REFERENCE's per-point body
+    (EstimatePointWiseColorGradientKernel, PointCloudImpl.h:1067-1165, with
+    its approximate core::linalg::kernel::solve_svd3x3 -- the oracle's
+    restatement of it is pinned bit for bit to the compiled routine in
+    tests/test_oracle_vs_ref.py). The product solves the same 3x3 normal
+    equations with its own converged Jacobi pseudo-inverse, so the two agree
+    to the accuracy of the reference's approximation: the bulk to ~1e-5 of the
+    gradient scale, an ill-conditioned tail (near-planar colour, few
+    neighbours) at the percent level; the reference's Float64 path returns NaN
+    on a fraction of the neighbourhoods (its 32-bit mask trick on doubles),
+    the product never does -- compared where the reference is finite."""
+    _lib, reg = _gpu()
+    p, _, tc = _colored_pair(8000, 51, dtype)
+    pts, nrm = p["target"], p["target_normals"]
+    idx, _, cnt = orc.hybrid_search(pts, pts, 0.15, 30)
+    ref_body = orc.estimate_color_gradients(pts, nrm, tc, idx, cnt,
+                                            exact_solve=False)
+    tp, tn, tcol = (torch.from_numpy(a).cuda() for a in (pts, nrm, tc))
+    got = reg.estimate_color_gradients(tp, tn, tcol, 30, 0.15).cpu().numpy()
+    assert not np.isnan(got).any()
+    fin = np.isfinite(ref_body).all(1)
+    if dtype == np.float32:
+        assert fin.all()
+    else:
+        assert fin.mean() > 0.5
+    scale = np.median(np.linalg.norm(got, axis=1))
+    err = np.abs(got - ref_body)[fin].max(1) / scale
+    well = (cnt >= 10)[fin]
+    med, p99 = np.median(err[well]), np.percentile(err[well], 99)
+    print("color gradients vs reference body (%s): median %.3g, p99 %.3g, "
+          "max %.3g of the gradient scale; reference finite on %.1f %%"
+          % (np.dtype(dtype).name, med, p99, err[well].max(),
+             100 * fin.mean()))
+    # observed on MI355X: median 1e-7, p99 6e-2, max 0.3 of the gradient scale
+    # (Float32) -- the tail is the reference's four-sweep approximation on
+    # near-singular normal equations, not this solver (it equals numpy's
+    # pseudo-inverse, tests/test_oracle_vs_ref.py)
+    assert med < 1e-4, med
+    assert p99 < 0.15, p99
+    assert (err[well] > 1e-2).mean() < 0.05
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -826,20 +941,25 @@ def test_icp_colored_pose_parity(dtype, given_gradients):
     colour gradients estimated by the driver (radius = 2 max distance) or
     handed in."""
     _lib, reg = _gpu()
-    if dtype == np.float64 and not given_gradients:
-        pytest.skip("the reference's Float64 solve_svd3x3 yields NaN "
-                    "gradients (reproduced); Float64 runs on given gradients")
     p, sc, tc = _colored_pair(20000, 4, dtype)
     tg = None
+    # gradients the driver estimates itself: the oracle uses the product's
+    # converged 3x3 solve (the reference's approximate one is compared in
+    # test_colored_icp_pose_vs_reference_gradients)
+    orc.set_exact_color_gradients(True)
     if given_gradients:
         nidx, _, ncnt = orc.hybrid_search(p["target"], p["target"], 0.1, 30)
         tg = orc.estimate_color_gradients(p["target"], p["target_normals"],
                                           tc, nidx, ncnt, exact_solve=True)
-    want = orc.multiscale_icp(p["source"], p["target"], p["target_normals"],
-                              [-1.0], [(1e-6, 1e-6, 30)], [0.07],
-                              accumulate_double=True, estimation=3,
-                              source_colors=sc, target_colors=tc,
-                              target_color_gradients=tg)
+    try:
+        want = orc.multiscale_icp(p["source"], p["target"],
+                                  p["target_normals"], [-1.0],
+                                  [(1e-6, 1e-6, 30)], [0.07],
+                                  accumulate_double=True, estimation=3,
+                                  source_colors=sc, target_colors=tc,
+                                  target_color_gradients=tg)
+    finally:
+        orc.set_exact_color_gradients(False)
     assert want["status"] == 0
     got = reg.icp(
         torch.from_numpy(p["source"]).cuda(),
@@ -874,11 +994,23 @@ def test_multiscale_icp_colored():
     vs = [0.05, 0.025, 0.0125]
     crit = [(1e-6, 1e-6, 20), (1e-6, 1e-6, 10), (1e-6, 1e-6, 5)]
     md = [0.15, 0.075, 0.0375]
-    want = orc.multiscale_icp(p["source"], p["target"], p["target_normals"],
-                              vs, crit, md, kernel=(5, 0.1, 1.0),
-                              accumulate_double=True, estimation=3,
-                              source_colors=sc, target_colors=tc,
-                              lambda_geometric=0.9)
+    orc.set_exact_color_gradients(True)
+    try:
+        want = orc.multiscale_icp(p["source"], p["target"],
+                                  p["target_normals"], vs, crit, md,
+                                  kernel=(5, 0.1, 1.0),
+                                  accumulate_double=True, estimation=3,
+                                  source_colors=sc, target_colors=tc,
+                                  lambda_geometric=0.9)
+        orc.set_exact_color_gradients(False)
+        want_ref = orc.multiscale_icp(p["source"], p["target"],
+                                      p["target_normals"], vs, crit, md,
+                                      kernel=(5, 0.1, 1.0),
+                                      accumulate_double=True, estimation=3,
+                                      source_colors=sc, target_colors=tc,
+                                      lambda_geometric=0.9)
+    finally:
+        orc.set_exact_color_gradients(False)
     est = reg.TransformationEstimationForColoredICP(
         0.9, reg.RobustKernel(reg.RobustKernel.TukeyLoss, 0.1))
     got = reg.multi_scale_icp(
@@ -892,6 +1024,12 @@ def test_multiscale_icp_colored():
     assert ang <= 1e-6 and tr <= 1e-5, (ang, tr)
     assert got.num_iterations == want["num_iterations"]
     assert abs(got.fitness - want["fitness"]) < 1e-12
+    # against the driver run with the REFERENCE's approximate gradient solve:
+    # the pose moves by what the gradient tail moves the photometric term
+    ang_r, tr_r = _pose_err(want_ref["transformation"], got.transformation)
+    print("colored multi-scale ICP vs reference-gradient run: %.3g rad, "
+          "%.3g m" % (ang_r, tr_r))
+    assert ang_r <= 1e-3 and tr_r <= 1e-3, (ang_r, tr_r)
 
 
 def test_multiscale_icp_is_run_to_run_identical(monkeypatch):

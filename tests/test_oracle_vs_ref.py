@@ -518,7 +518,7 @@ def test_color_gradients_vs_reference_body(dtype):
     """EstimatePointWiseColorGradientKernel (PointCloudImpl.h:1067-1165) with
     the reference's own solve_svd3x3 == the oracle, bit for bit (Float64: NaN
     positions equal). The exact-solve variant (what
-    O3DMI_EXACT_COLOR_GRADIENTS=1 selects) equals numpy's pseudo-inverse of
+    the product uses) equals numpy's pseudo-inverse of
     the same normal equations and shows how approximate the reference's
     solver is on ill-conditioned neighbourhoods."""
     from open3d_amd import synthetic as syn
@@ -546,3 +546,36 @@ def test_color_gradients_vs_reference_body(dtype):
         AtA = A.T @ A + np.outer((k - 1) * N[w], (k - 1) * N[w])
         want = np.linalg.pinv(AtA, rcond=1e-15) @ (A.T @ bb)
         assert np.abs(ex[w] - want).max() < 2e-3 * max(1.0, np.abs(want).max())
+
+
+def test_p2plane_sums_under_random_reduce_schedules():
+    """tbb::parallel_reduce stand-in with seeded random split points: the
+    reference's float32 29-sum (RegistrationCPU.cpp:30-90) depends on the
+    schedule in its last bits, schedule 0 (one sequential chunk) equals the
+    oracle's float32 restatement bit for bit, and every schedule stays within
+    float32 rounding of the float64-accumulated sums."""
+    from open3d_amd import synthetic as syn
+    p = syn.make_icp_pair(30000, 30000, seed=9, dtype=np.float32)
+    idx, _, cnt = orc.hybrid_search(p["target"], p["source"], 0.07, 1)
+    corr = np.where(cnt > 0, idx[:, 0], -1).astype(np.int64)
+    want64 = orc.p2plane_accumulate(p["source"], p["target"],
+                                    p["target_normals"], corr,
+                                    accumulate_double=True)
+    want32 = orc.p2plane_accumulate(p["source"], p["target"],
+                                    p["target_normals"], corr,
+                                    accumulate_double=False)
+    seen = set()
+    try:
+        for seed in range(0, 9):
+            ref.set_reduce_schedule(seed, 128)
+            got = ref.p2plane_accumulate(p["source"], p["target"],
+                                         p["target_normals"], corr)
+            if seed == 0:
+                assert np.array_equal(got, want32)
+            assert got[28] == want64[28]  # the count is exact
+            assert np.allclose(got[:28], want64[:28], rtol=2e-4,
+                               atol=1e-4 * np.abs(want64[:28]).max())
+            seen.add(got.tobytes())
+    finally:
+        ref.set_reduce_schedule(0)
+    assert len(seen) >= 5
