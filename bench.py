@@ -1,30 +1,57 @@
 #!/usr/bin/env python
 """bench.py -- RGB-D frames/s of the MI355X dense-SLAM hot path.
 
-Workload at N=1 (BASELINE.json configs[1]): synthetic 640x480 RGB-D frames with
-known poses integrated into an 8 mm / 16^3-block VoxelBlockGrid (tsdf f32,
-weight u16, colour u16 -- the slam::Model layout) on one MI355X: per frame
-block touch + hash activation + per-voxel TSDF/weight/colour update.
-A "step" is one batch of `--batch` frames; frames are resident in HBM before
-the timed region starts. With --gpus N every rank integrates its own shard of
-the stream (frames r, r+N, ...) into a private grid (weak scaling, no data-path
-collective); the activated block IDs are all-gathered over RCCL once, inside
-the timed region, as the closing exchange step.
+Headline (N = 1, BASELINE.json configs[1]): the synthetic 640x480 RGB-D stream
+with known poses (1000 distinct frames, resident in HBM before the timed region)
+integrated into an 8 mm / 16^3-block VoxelBlockGrid (tsdf f32, weight u16,
+colour u16 -- the slam::Model layout): per frame block touch + hash activation
++ per-voxel TSDF / weight / colour update. A "step" is one batch of `--batch`
+frames (default 5000 = five passes over the stream, so that the driver's 20
+timed steps last about a second); every frame does the full per-frame work, the
+uint16 weights stay far below their range (a voxel is seen by <= 183 frames of
+a pass).
+
+Multi-GPU (`--gpus N`; launched by torchrun, or self-spawned when WORLD_SIZE is
+unset): one process per GPU over RCCL. Frame sharding (default, weak scaling:
+rank r integrates frames r, r + N, ... of the stream into its own grid, no
+data-path collective) closes INSIDE the timed region with the exchange that
+turns N partial models into one: all-gather of the activated block IDs and of
+the blocks' voxel rows, folded in by the running-mean merge kernel
+(sharding.merge_frame_sharded_grid). `config.block_sharded` reports the other
+scheme beside it (strong scaling: every rank sees the whole stream and
+integrates only the blocks it owns; the union of the grids is bit-identical to
+one GPU's).
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-`roofline` (Integrate kernel: algorithmic bytes / HIP-event kernel time vs the
-8 TB/s HBM peak) and `cpu_baseline` (Open3D's own CPU kernel bodies through oracle/_ref
-when that prebuilt library is present, else the restated oracle, timed on this
-host's cores on a bounded sample of the same workload, N=1 only).
+  roofline      dominant kernel (FrameStepKernel): SURVEY 8(d) algorithmic
+                bytes / HIP-event kernel time (`frac`), counter-measured fabric
+                bytes / the same time (`frac_hbm`: FETCH_SIZE x2 + WRITE_SIZE,
+                factors calibrated in profiles/r2a_hbm_calibration.json) and the
+                share of SIMD cycles that issue vector-ALU work (`frac_valu`,
+                SQ counters). The counters are collected live by rocprofv3
+                passes over a short run of this same script (rank 0, N = 1).
+  secondary     the ICP half of BASELINE's metric: configs[0] (point-to-plane
+                ICP on two 100k-point clouds) and the configs[2] tracking loop
+                (multi-scale ICP + integrate + ray cast) at 1280x720 and
+                640x480, each with its 8(d) byte accounting and the CPU oracle
+                timed beside it.
+  cpu_baseline  Open3D's own DepthTouchCPU / IntegrateCPU bodies (oracle/_ref)
+                on this host's cores over a bounded sample of the same stream.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
+import types
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -35,11 +62,15 @@ TRUNC = 8.0
 DEPTH_SCALE = 1000.0
 DEPTH_MAX = 3.0
 W, H = 640, 480
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+N_UNIQUE = 1000           # configs[1]: the 1000-frame stream
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
 # u16 grid with colour, read+write per voxel
 BYTES_PER_BLOCK = 4096 * 24
 IMAGE_BYTES = W * H * 2 + W * H * 3
-BLOCK_HEADER_BYTES = 16  # buf index + key
+BLOCK_HEADER_BYTES = 16   # buf index + key
+N_SIMD = 256 * 4
+N_XCD = 8
+KERNEL = "FrameStepKernel"
 
 
 def parse():
@@ -47,40 +78,54 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=50,
+    ap.add_argument("--batch", type=int, default=5000,
                     help="frames per step (per GPU)")
-    ap.add_argument("--block-count", type=int, default=262144)
-    ap.add_argument("--per-frame-calls", action="store_true",
-                    help="one o3dmi_vbg_integrate_frame call per frame instead "
-                         "of one o3dmi_vbg_integrate_frames call per step")
+    ap.add_argument("--block-count", type=int, default=65536)
     ap.add_argument("--frames-per-launch", type=int, default=4,
                     help="consecutive frames applied per launch to register-"
                          "resident blocks (1..4); results are identical")
-    ap.add_argument("--event-stride", type=int, default=8,
+    ap.add_argument("--event-stride", type=int, default=16,
                     help="bracket every n-th integrate launch with HIP events "
                          "(0 = none; the roofline is then not measured)")
     ap.add_argument("--sharding", choices=["frames", "blocks"],
                     default="frames",
-                    help="multi-GPU scheme: 'frames' = every rank integrates "
-                         "its own frames into a private grid (weak scaling, "
-                         "the default); 'blocks' = every rank sees the SAME "
-                         "stream and integrates only the blocks it owns "
-                         "(strong scaling, union of the grids bit-identical "
-                         "to one GPU)")
-    ap.add_argument("--merge-model", action="store_true",
-                    help="frame sharding, N > 1: after the timed region fold "
-                         "every other rank's blocks into this rank's grid "
-                         "(sharding.merge_frame_sharded_grid) and report its "
-                         "time as config.merge_ms; not part of `value`")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+                    help="multi-GPU scheme of the headline value")
     ap.add_argument("--depth-only", action="store_true",
                     help="diagnostics: grid without colour (tsdf + weight)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the live rocprofv3 counter passes")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the ICP legs (configs[0] / configs[2])")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--pmc-inner", action="store_true",
+                    help=argparse.SUPPRESS)  # the run rocprofv3 wraps
     return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------
+# multi-GPU launch
+
+
+def maybe_spawn(a):
+    """`python bench.py --gpus N` without torchrun: re-exec under
+    torch.distributed.run, one rank per GPU."""
+    if a.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + \
+        sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+# ---------------------------------------------------------------------------
+# CPU baseline (checker code, timed only here)
 
 
 def cpu_baseline(frames_cpu, K, Ts, budget_s):
@@ -89,10 +134,11 @@ def cpu_baseline(frames_cpu, K, Ts, budget_s):
 
     kind "reference": oracle/_ref -- Open3D's own DepthTouchCPU / IntegrateCPU
     bodies compiled from the reference sources (OpenMP stand-in for TBB's
-    parallel_for), block activation through the oracle's hash map. Falls back
-    to kind "port" (the restated oracle) when the prebuilt _ref is absent.
-    A few thread counts are tried on the first frames and the fastest is kept
-    (the reference lets TBB pick)."""
+    parallel_for, a sharded concurrent set for tbb::concurrent_unordered_set),
+    block activation through the oracle's hash map. Falls back to kind "port"
+    (the restated oracle) when the prebuilt _ref is absent. A few thread
+    counts are tried on the first frames and the fastest is kept (the
+    reference lets TBB pick)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as orc
     import _ref as ref
@@ -147,8 +193,131 @@ def cpu_baseline(frames_cpu, K, Ts, budget_s):
                          cands, cores)}
 
 
+# ---------------------------------------------------------------------------
+# live counters: rocprofv3 passes over a short run of this script
+
+PMC_PASSES = {
+    "fetch": ["FETCH_SIZE"],
+    "write": ["WRITE_SIZE"],
+    "sq": ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU",
+           "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY",
+           "SQ_WAIT_INST_ANY", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"],
+}
+
+
+def _pmc_pass(counters, tmp, tag):
+    """One rocprofv3 --pmc run (kernel trace only beside it, as the pool
+    requires); returns {counter: mean per FrameStepKernel launch}, n."""
+    out_dir = os.path.join(tmp, tag)
+    inner = [sys.executable, os.path.abspath(__file__), "--pmc-inner",
+             "--steps", "2", "--warmup", "1", "--batch", "200",
+             "--no-cpu-baseline", "--no-pmc", "--no-secondary"]
+    cmd = ["rocprofv3", "--pmc"] + counters + \
+        ["--kernel-trace", "--output-format", "csv", "-d", out_dir, "-o",
+         "pmc", "--"] + inner
+    env = dict(os.environ, TMPDIR="/tmp")
+    r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True,
+                       text=True, timeout=420)
+    files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"),
+                      recursive=True)
+    if r.returncode != 0 or not files:
+        raise RuntimeError("rocprofv3 %s: rc %d %s" % (tag, r.returncode,
+                                                       r.stderr[-300:]))
+    acc, disp = {}, set()
+    for f in files:
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                name = row["Kernel_Name"]
+                # the fused colour instantiation: <u16, u16, true, div, form>
+                if KERNEL not in name or ", true," not in name:
+                    continue
+                acc[row["Counter_Name"]] = acc.get(row["Counter_Name"], 0.0) + \
+                    float(row["Counter_Value"])
+                disp.add(row["Dispatch_Id"])
+    n = max(1, len(disp))
+    return {k: v / n for k, v in acc.items()}, n
+
+
+def pmc_live():
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    tmp = tempfile.mkdtemp(prefix="o3dmi_pmc_", dir="/tmp")
+    try:
+        res, n = {}, 0
+        for tag, counters in PMC_PASSES.items():
+            vals, n = _pmc_pass(counters, tmp, tag)
+            res.update(vals)
+        res["launches"] = n
+        return res, None
+    except Exception as e:  # counters are evidence, not the product
+        return None, str(e)[:300]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def pmc_committed():
+    """Fallback: the newest committed summary of tools/profile_step_pmc.sh."""
+    pdir = os.path.join(ROOT, "profiles")
+    for fn in sorted(os.listdir(pdir) if os.path.isdir(pdir) else [],
+                     reverse=True):
+        if "_step_pmc" in fn and fn.endswith(".json"):
+            try:
+                with open(os.path.join(pdir, fn)) as f:
+                    d = json.load(f)
+                for k, v in d.items():
+                    if KERNEL in k and ", true," in k and "FETCH_SIZE" in v:
+                        v = dict(v)
+                        v["launches"] = v.pop("dispatches", 0)
+                        return v, "profiles/" + fn
+            except Exception:
+                pass
+    return None, None
+
+
+# ---------------------------------------------------------------------------
+# secondary: the ICP half of the metric
+
+
+def secondary_legs():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "bench_slam", os.path.join(ROOT, "tools", "bench_slam.py"))
+    bs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bs)
+    out = {}
+    a = types.SimpleNamespace(points=100000, repeat=10, estimation="p2plane",
+                              no_cpu=False)
+    r = bs.mode_icp(a)
+    out["configs0_icp_2x100k"] = {
+        k: r[k] for k in ("ms_per_icp", "iterations", "ms_per_iteration",
+                          "fitness", "inlier_rmse", "roofline",
+                          "cpu_oracle_ms_per_icp", "cpu_oracle_threads",
+                          "cpu_oracle_ms_per_iteration_phase",
+                          "pose_err_vs_oracle_rad_m",
+                          "same_iterations_as_oracle") if k in r}
+    for tag, vga in (("configs2_loop_1280x720", False),
+                     ("configs2_loop_640x480", True)):
+        base = dict(frames=60, frame_step=2, block_count=65536, phases=False,
+                    vga=vga, cpu_frames=1)
+        bs.mode_slam(types.SimpleNamespace(**dict(base, frames=8,
+                                                  cpu_frames=0)))  # warm-up
+        r = bs.mode_slam(types.SimpleNamespace(**base))
+        out[tag] = {k: r[k] for k in (
+            "workload", "frames", "frames_per_s", "ms_per_frame",
+            "icp_iterations_per_frame", "source_points", "target_points",
+            "final_pose_err_rad_m", "roofline",
+            "cpu_oracle_ms_per_multiscale_icp", "cpu_oracle_threads")
+            if k in r}
+    return out
+
+
+# ---------------------------------------------------------------------------
+
+
 def main():
     a = parse()
+    maybe_spawn(a)
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -160,8 +329,11 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world)
+        assert dist.get_world_size() == world
     else:
         torch.cuda.set_device(0)
+    assert a.gpus == world, \
+        "--gpus %d but %d rank(s) were launched" % (a.gpus, world)
     dev = torch.device("cuda", torch.cuda.current_device())
 
     import __graft_entry__ as ge
@@ -171,165 +343,227 @@ def main():
     if dist is not None:
         dist.barrier()
     from open3d_amd import geometry, synthetic
-    from open3d_amd.sharding import allgather_block_keys
+    from open3d_amd.sharding import merge_frame_sharded_grid
 
-    n_steps = a.steps + a.warmup
-    n_local = n_steps * a.batch
-    by_blocks = a.sharding == "blocks" and world > 1
-    if by_blocks:
-        # One stream seen by every rank; blocks are split by ownership.
-        frame_ids = list(range(n_local))
-    else:
-        # Frame-sharded stream: rank r owns global frames r, r+world, ...
-        frame_ids = [rank + world * i for i in range(n_local)]
     K = synthetic.intrinsics(W, H)
-    depths, colors, Ts = [], [], []
-    for i0 in range(0, n_local, 25):
-        ids = frame_ids[i0:i0 + 25]
-        for k in ids:
+
+    def render(frame_ids):
+        ds, cs, ts = [], [], []
+        for k in frame_ids:
             d, c, _, T = synthetic.render_frames(k, 1, W, H, device=dev)
-            depths.append(d[0].contiguous())
-            colors.append(c[0].contiguous())
-            Ts.append(T[0])
-    torch.cuda.synchronize()
+            ds.append(d[0].contiguous())
+            cs.append(c[0].contiguous())
+            ts.append(T[0])
+        return ds, cs, ts
 
-    if a.depth_only:
-        g = geometry.VoxelBlockGrid(["tsdf", "weight"],
-                                    [torch.float32, torch.uint16], [1, 1],
-                                    VOXEL, RES, a.block_count)
-        colors = None
-    else:
-        g = geometry.VoxelBlockGrid(["tsdf", "weight", "color"],
-                                    [torch.float32, torch.uint16,
-                                     torch.uint16],
-                                    [1, 1, 3], VOXEL, RES, a.block_count)
-    if by_blocks:
-        g.set_block_ownership(rank, world)
-
-    def run_step(s):
-        lo, hi = s * a.batch, (s + 1) * a.batch
-        if a.per_frame_calls:
-            for i in range(lo, hi):
-                g.integrate_frame(depths[i], colors[i], K, K, Ts[i],
-                                  DEPTH_SCALE, DEPTH_MAX, TRUNC)
+    def make_grid(owner=None):
+        if a.depth_only:
+            g = geometry.VoxelBlockGrid(["tsdf", "weight"],
+                                        [torch.float32, torch.uint16], [1, 1],
+                                        VOXEL, RES, a.block_count)
         else:
-            g.integrate_frames(depths[lo:hi],
-                               colors[lo:hi] if colors is not None else None,
-                               K, K, Ts[lo:hi],
-                               DEPTH_SCALE, DEPTH_MAX, TRUNC,
-                               frames_per_launch=a.frames_per_launch)
+            g = geometry.VoxelBlockGrid(
+                ["tsdf", "weight", "color"],
+                [torch.float32, torch.uint16, torch.uint16], [1, 1, 3], VOXEL,
+                RES, a.block_count)
+        if owner is not None:
+            g.set_block_ownership(*owner)
+        return g
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    for s in range(a.warmup):
-        run_step(s)
-    torch.cuda.synchronize()
-    barrier()
+    def timed_run(g, depths, colors, Ts, steps, warmup, merge):
+        """`warmup` untimed steps, then exactly `steps` steps between barrier
+        + synchronize pairs; a step = a.batch frames, the stream looped."""
+        n_u = len(depths)
 
-    g.profile_begin(a.steps * a.batch, a.event_stride)
-    torch.cuda.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    for s in range(a.warmup, n_steps):
-        run_step(s)
-    n_union = None
-    if dist is not None:
-        hm = g.hashmap()
-        act = hm.active_buf_indices()
-        keys = hm.key_tensor()[act.long()]
-        n_union = int(allgather_block_keys(keys, dist).shape[0])
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    prof = g.profile_end()
-    n_blocks = g.hashmap().size()
-    merge_ms = None
-    if a.merge_model and dist is not None and not by_blocks:
-        from open3d_amd.sharding import merge_frame_sharded_grid
-        barrier()
-        tm = time.perf_counter()
-        merge_frame_sharded_grid(g, dist)
+        def run_step(s):
+            lo = (s * a.batch) % n_u
+            left = a.batch
+            while left > 0:
+                m = min(left, n_u - lo)
+                g.integrate_frames(
+                    depths[lo:lo + m],
+                    colors[lo:lo + m] if colors is not None else None, K, K,
+                    Ts[lo:lo + m], DEPTH_SCALE, DEPTH_MAX, TRUNC,
+                    frames_per_launch=a.frames_per_launch)
+                left -= m
+                lo = (lo + m) % n_u
+
+        for s in range(warmup):
+            run_step(s)
         torch.cuda.synchronize()
         barrier()
-        merge_ms = (time.perf_counter() - tm) * 1e3
+        # capacity = bracketed launches (every event_stride-th), not frames
+        n_launch = steps * a.batch // max(1, a.frames_per_launch)
+        g.profile_begin(min(8192, n_launch // max(1, a.event_stride) + 64),
+                        a.event_stride)
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for s in range(warmup, warmup + steps):
+            run_step(s)
+        merge_ms = None
+        if merge:
+            torch.cuda.synchronize()
+            tm = time.perf_counter()
+            merge_frame_sharded_grid(g, dist)
+            torch.cuda.synchronize()
+            merge_ms = (time.perf_counter() - tm) * 1e3
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        prof = g.profile_end()
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed, prof, merge_ms
 
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    by_blocks = a.sharding == "blocks" and world > 1
+    if by_blocks:
+        frame_ids = list(range(N_UNIQUE))
+    else:  # frame-sharded stream: rank r owns global frames r, r + world, ...
+        frame_ids = [rank + world * i for i in range(N_UNIQUE)]
+    depths, colors, Ts = render(frame_ids)
+    if a.depth_only:
+        colors = None
+    torch.cuda.synchronize()
 
+    g = make_grid((rank, world) if by_blocks else None)
+    elapsed, prof, merge_ms = timed_run(
+        g, depths, colors, Ts, a.steps, a.warmup,
+        merge=(dist is not None and not by_blocks))
+    n_blocks = g.hashmap().size()
     total_frames = a.steps * a.batch * (1 if by_blocks else world)
     fps = total_frames / elapsed
 
-    # Roofline of the dominant kernel over the HIP-event-bracketed launches:
-    # unit = one active block x one frame (98 304 B of voxel
-    # state read+written, + 16 B header), + the frame's images once.
+    if a.pmc_inner:  # the run rocprofv3 wraps: nothing else to do
+        return
+
+    # the other multi-GPU scheme beside the headline (short run)
+    other = None
+    if dist is not None:
+        del g
+        torch.cuda.empty_cache()
+        o_blocks = not by_blocks
+        if o_blocks:
+            depths, colors, Ts = render(list(range(N_UNIQUE)))
+        else:
+            depths, colors, Ts = render(
+                [rank + world * i for i in range(N_UNIQUE)])
+        if a.depth_only:
+            colors = None
+        g2 = make_grid((rank, world) if o_blocks else None)
+        st = max(2, a.steps // 5)
+        e2, _, m2 = timed_run(g2, depths, colors, Ts, st, 1,
+                              merge=not o_blocks)
+        f2 = st * a.batch * (1 if o_blocks else world)
+        other = {"sharding": "blocks" if o_blocks else "frames",
+                 "scaling": "strong" if o_blocks else "weak",
+                 "frames_per_s": f2 / e2, "steps": st,
+                 "ms_per_step": e2 / st * 1e3, "merge_ms": m2}
+        del g2
+
+    # ---- roofline of the dominant kernel over the bracketed launches --------
+    # 8(d) unit = one active block x one frame (98 304 B of voxel state
+    # read + written, + 16 B header), + the frame's images once.
     launches = max(1, prof["launches"])
     alg_bytes = (prof["block_frames"] * (BYTES_PER_BLOCK + BLOCK_HEADER_BYTES)
                  + prof["frames"] * IMAGE_BYTES) / launches
     k_ms = prof["integrate_ms"] / launches
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-
-    # HBM traffic per launch of the same kernel from the committed rocprofv3
-    # PMC passes of this command (tools/profile_gpu.sh: FETCH_SIZE and
-    # WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 note in
-    # MI355X_MICROARCH.md); null when no summary is present.
-    traffic, traffic_src = None, None
-    pdir = os.path.join(ROOT, "profiles")
-    if os.path.isdir(pdir):
-        for fn in sorted(os.listdir(pdir), reverse=True):
-            if fn.endswith("_hbm_traffic.json"):
-                try:
-                    with open(os.path.join(pdir, fn)) as f:
-                        t = json.load(f).get("FrameStepKernel")
-                    if t:
-                        traffic = t["hbm_bytes_per_launch_corrected"]
-                        traffic_src = "profiles/" + fn
-                        break
-                except Exception:
-                    pass
+    roof = {"bound": "valu", "kernel": KERNEL, "achieved": achieved,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "avg_kernel_ms": k_ms,
+            "frames_per_launch": prof["frames"] / launches,
+            "traffic": None, "frac_hbm": None, "frac_valu": None,
+            "note": "`frac` is SURVEY 8(d)'s convention (voxel state charged "
+                    "per frame) over the HBM peak: an equivalent bandwidth, "
+                    "it can exceed what DRAM carries because state crosses "
+                    "the fabric once per 4-frame launch. `frac_hbm` = counter"
+                    " bytes (FETCH_SIZE x 2 + WRITE_SIZE, both factors "
+                    "calibrated on copy kernels with this kernel's 8 / 16 / "
+                    "24 B-per-lane accesses: profiles/r2a_hbm_calibration."
+                    "json) / the same kernel time / 8 TB/s. `frac_valu` = "
+                    "SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x "
+                    "GRBM_GUI_ACTIVE / 8 XCDs): the share of SIMD cycles "
+                    "issuing vector-ALU work, measured under the profiler. "
+                    "The kernel's binding roof is vector-ALU issue (bit-exact "
+                    "float32 arithmetic per voxel), not DRAM."}
+    if world == 1 and rank == 0 and not a.no_pmc:
+        pmc, why = pmc_live()
+        src = "live rocprofv3 passes (this run)"
+        if pmc is None:
+            pmc, src2 = pmc_committed()
+            src = "%s (live collection failed: %s)" % (src2, why) \
+                if pmc else None
+        if pmc:
+            traffic = 2.0 * pmc.get("FETCH_SIZE", 0.0) * 1024.0 + \
+                pmc.get("WRITE_SIZE", 0.0) * 1024.0
+            roof["traffic"] = traffic
+            roof["traffic_read_bytes"] = 2.0 * pmc.get("FETCH_SIZE", 0) * 1024
+            roof["traffic_write_bytes"] = pmc.get("WRITE_SIZE", 0) * 1024.0
+            roof["traffic_source"] = src
+            if k_ms > 0:
+                roof["frac_hbm"] = traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if pmc.get("GRBM_GUI_ACTIVE") and pmc.get("SQ_ACTIVE_INST_VALU"):
+                cyc = pmc["GRBM_GUI_ACTIVE"] / N_XCD
+                roof["frac_valu"] = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / \
+                    (N_SIMD * cyc)
+                roof["valu_insts_per_launch"] = pmc.get("SQ_INSTS_VALU")
+                roof["kernel_cycles_profiled"] = cyc
+                roof["avg_waves_per_simd"] = pmc.get("SQ_WAVE_CYCLES", 0) * \
+                    4.0 / (N_SIMD * cyc)
+                wc = max(1.0, pmc.get("SQ_WAVE_CYCLES", 1.0))
+                roof["wave_cycle_split"] = {
+                    "issuing": pmc.get("SQ_ACTIVE_INST_ANY", 0) / wc,
+                    "waiting_memory_or_barrier": pmc.get("SQ_WAIT_ANY", 0) / wc,
+                    "issue_stalled": pmc.get("SQ_WAIT_INST_ANY", 0) / wc}
+            roof["counter_launches"] = pmc.get("launches")
 
     out = {
         "metric": "RGB-D frames/s (TSDF integrate into 8 mm / 16^3 "
-                  "VoxelBlockGrid: touch + activate + integrate)",
+                  "VoxelBlockGrid: touch + activate + integrate; ICP leg in "
+                  "`secondary`)",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
         "higher_is_better": True,
         "scaling": "strong" if by_blocks else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: %d synthetic 640x480 RGB-D frames "
-                               "per GPU -> 8 mm VoxelBlockGrid(16^3), grid "
-                               "(tsdf f32, weight u16, color u16), known poses"
-                               % (a.steps * a.batch),
+        "config": {"workload": "configs[1]: the 1000-frame synthetic 640x480 "
+                               "RGB-D stream (looped, %d frames per GPU in the "
+                               "timed region) -> 8 mm VoxelBlockGrid(16^3), "
+                               "grid (tsdf f32, weight u16, color u16), known "
+                               "poses" % (a.steps * a.batch),
                    "frames_per_step": a.batch, "block_count": a.block_count,
-                   "api": "integrate_frame per frame" if a.per_frame_calls
-                          else "integrate_frames per step",
-                   "frames_per_launch": 1 if a.per_frame_calls
-                                        else a.frames_per_launch,
+                   "timed_region_s": elapsed,
+                   "api": "integrate_frames, <= 1000 frames per call",
+                   "frames_per_launch": a.frames_per_launch,
                    "active_blocks": int(n_blocks),
                    "avg_blocks_per_frame": prof["block_frames"] /
                                            max(1, prof["frames"]),
                    "sharding": ("none" if world == 1 else
-                                "one stream, blocks split by ownership; "
-                                "block-ID all-gather at the end" if by_blocks
-                                else "frames r, r+N, ... per rank; block-ID "
-                                     "all-gather at the end"),
-                   "union_blocks": n_union, "merge_ms": merge_ms},
-        "roofline": {"bound": "hbm", "kernel": "FrameStepKernel",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": traffic_src,
-                     "algorithmic_bytes_per_launch": alg_bytes,
-                     "avg_kernel_ms": k_ms,
-                     "frames_per_launch": prof["frames"] / launches,
-                     "note": "frac can exceed the DRAM bound when several "
-                             "frames are applied per launch: voxel state is "
-                             "then read/written once per launch, not once per "
-                             "frame (compare `traffic`)"},
+                                "one stream, blocks split by ownership "
+                                "(no data-path collective)" if by_blocks
+                                else "frames r, r+N, ... per rank; closing "
+                                     "exchange inside the timed region: all-"
+                                     "gather of block IDs + voxel rows, "
+                                     "merged into one model on every rank"),
+                   "merge_ms": merge_ms,
+                   "block_sharded" if not by_blocks else "frame_sharded":
+                       other},
+        "roofline": roof,
     }
+    if world == 1 and not a.no_secondary:
+        try:
+            out["secondary"] = secondary_legs()
+        except Exception as e:
+            out["secondary"] = {"error": str(e)[:300]}
     if world == 1 and not a.no_cpu_baseline:
         nb = 64
         frames_cpu = [(depths[i].cpu().numpy(), colors[i].cpu().numpy())

@@ -152,6 +152,15 @@ int o3dmi_hash_active_indices(o3dmi_hash_t* h, int32_t* out_dev,
 int o3dmi_hash_set_ownership(o3dmi_hash_t* h, int rank, int world);
 /* Owner rank of one block key (host int32[3]); -1 for bad arguments. */
 int o3dmi_block_owner(const int32_t* key3, int world);
+/* HashMap::To(device, copy = true) (core/hashmap/HashMap.cpp:230-255): a new
+ * map of the same capacity and value layout on HIP device `device`, holding
+ * the same key -> value-row association (active keys and their value rows are
+ * gathered, copied device to device and inserted; buffer indices are the new
+ * map's own, ownership sharding settings are carried over). `device` may be
+ * the map's own device (a deep copy). Synchronises both devices; the calling
+ * thread's current device is restored. The new map is driven like any other,
+ * with streams of its own device. */
+int o3dmi_hash_to_device(o3dmi_hash_t* h, int device, o3dmi_hash_t** out);
 /* HashMap::Reserve (core/hashmap/HashMap.cpp:47-77): export active
  * key/values, reallocate at `capacity`, re-insert. buf_indices change. */
 int o3dmi_hash_reserve(o3dmi_hash_t* h, int64_t capacity,

@@ -60,6 +60,20 @@ typedef void (*o3dmi_icp_callback_t)(int64_t iteration_index,
  * target; every rank then solves the same 6x6 system. */
 typedef int (*o3dmi_allreduce_sum_t)(double* host_buf, int n, void* user);
 
+/* The same exchange on the DEVICE: the hook enqueues an in-place sum
+ * all-reduce of dev_buf[0..n) (float64) over all ranks on `stream`
+ * (asynchronously -- e.g. RCCL's ncclAllReduce, or torch.distributed's
+ * all_reduce under that stream) and returns 0. When set for the calling host
+ * thread it takes precedence over the host hook of the driver functions: the
+ * per-iteration sums then stay on the device from the final reduction kernel
+ * through the collective to the kernel that posts them to the host mailbox
+ * (one host wait per iteration, no staging copies). fn = NULL restores the
+ * host path. Thread-local: one rank per process, or one host thread per
+ * device. */
+typedef int (*o3dmi_allreduce_device_t)(double* dev_buf, int n,
+                                        o3dmi_stream_t stream, void* user);
+int o3dmi_set_device_allreduce(o3dmi_allreduce_device_t fn, void* user);
+
 /* MultiScaleICP with TransformationEstimationPointToPlane(kernel).
  * source/target/normals: device, {N,3}, dtype O3DMI_F32 or O3DMI_F64.
  * voxel_sizes[i] <= 0 means "no down-sampling" for the finest level, as in
@@ -206,6 +220,13 @@ int o3dmi_vbg_create(int n_attrs, const char* const* attr_names,
                      float voxel_size, int64_t block_resolution,
                      int64_t block_count, o3dmi_stream_t stream,
                      o3dmi_vbg_t** out);
+/* VoxelBlockGrid::To(device, copy = true) (through HashMap::To,
+ * core/hashmap/HashMap.cpp:230-255): the grid on HIP device `device` (may be
+ * its own: a deep copy) with the same attributes, voxel size, block keys and
+ * voxel values; buffer indices are the new grid's own. The caller's current
+ * device must be the source grid's; it is restored. The new grid is used with
+ * `device` current and streams of that device. */
+int o3dmi_vbg_to_device(o3dmi_vbg_t* g, int device, o3dmi_vbg_t** out);
 int o3dmi_vbg_destroy(o3dmi_vbg_t* g);
 o3dmi_hash_t* o3dmi_vbg_hashmap(o3dmi_vbg_t* g);
 /* GetAttribute(name): device pointer of the {capacity,res,res,res,C} buffer

@@ -150,8 +150,10 @@ class IcpAttributes(C.Structure):
 
 ICP_CALLBACK = C.CFUNCTYPE(None, _i64, _i64, _i64, _d, _d, _dp, _vp)
 ALLREDUCE_SUM = C.CFUNCTYPE(_i32, _dp, _i32, _vp)
+ALLREDUCE_DEVICE = C.CFUNCTYPE(_i32, _vp, _i32, _vp, _vp)
 
 PROTOTYPES.update({
+    "o3dmi_set_device_allreduce": (_i32, [ALLREDUCE_DEVICE, _vp]),
     "o3dmi_registration_multiscale_icp": (
         _i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _dp,
                C.POINTER(IcpCriteria), _dp, _dp, _i32, _d, _d, ICP_CALLBACK,
@@ -197,6 +199,8 @@ PROTOTYPES.update({
                                                  _vp, _i32, _vp]),
     "o3dmi_voxel_down_sample": (_i32, [_vp, _vp, _i64, _i32, _d, _vp, _vp,
                                        C.POINTER(_i64), _vp]),
+    "o3dmi_vbg_to_device": (_i32, [_vp, _i32, C.POINTER(_vp)]),
+    "o3dmi_hash_to_device": (_i32, [_vp, _i32, C.POINTER(_vp)]),
     "o3dmi_vbg_create": (_i32, [_i32, C.POINTER(C.c_char_p), C.POINTER(_i32),
                                 C.POINTER(_i32), _f, _i64, _i64, _vp,
                                 C.POINTER(_vp)]),

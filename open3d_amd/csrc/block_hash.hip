@@ -552,6 +552,104 @@ int o3dmi_hash_reserve(o3dmi_hash_t* h, int64_t capacity,
     return O3DMI_OK;
 }
 
+int o3dmi_hash_to_device(o3dmi_hash_t* h, int device, o3dmi_hash_t** out) {
+    O3DMI_REQUIRE(h != nullptr && out != nullptr, "null argument");
+    int n_dev = 0, src_dev = 0;
+    O3DMI_HIP_CHECK(hipGetDeviceCount(&n_dev));
+    O3DMI_REQUIRE(device >= 0 && device < n_dev, "no such HIP device");
+    O3DMI_HIP_CHECK(hipGetDevice(&src_dev));
+    struct Restore {
+        int dev;
+        ~Restore() { (void)hipSetDevice(dev); }
+    } restore{src_dev};
+    // Export the active keys / value rows on the source device
+    // (HashMap.cpp:238-247: GetActiveIndices + IndexGet).
+    int64_t count = 0;
+    int st = o3dmi_hash_size(h, nullptr, &count);
+    if (st != O3DMI_OK) return st;
+    int* active = nullptr;
+    int* keys = nullptr;
+    void* vals[8] = {nullptr};
+    int* keys_dst = nullptr;
+    void* vals_dst[8] = {nullptr};
+    o3dmi_hash_t* nh = nullptr;
+    auto cleanup = [&](int code) {
+        (void)hipSetDevice(src_dev);
+        (void)hipFree(active);
+        (void)hipFree(keys);
+        for (int j = 0; j < h->n_values; ++j) (void)hipFree(vals[j]);
+        (void)hipSetDevice(device);
+        (void)hipFree(keys_dst);
+        for (int j = 0; j < h->n_values; ++j) (void)hipFree(vals_dst[j]);
+        if (code != O3DMI_OK && nh) o3dmi_hash_destroy(nh);
+        return code;
+    };
+    if (count > 0) {
+        if (hipMalloc((void**)&active, sizeof(int) * h->capacity) != hipSuccess)
+            return cleanup(O3DMI_ERR_HIP);
+        int64_t c2 = 0;
+        if ((st = o3dmi_hash_active_indices(h, active, nullptr, &c2)))
+            return cleanup(st);
+        count = c2;
+        if (hipMalloc((void**)&keys, sizeof(int) * 3 * count) != hipSuccess)
+            return cleanup(O3DMI_ERR_HIP);
+        if ((st = GatherRows(h->view.key_buffer, active, count, sizeof(int) * 3,
+                             keys, nullptr)))
+            return cleanup(st);
+        for (int j = 0; j < h->n_values; ++j) {
+            if (hipMalloc(&vals[j], h->value_dsizes[j] * count) != hipSuccess)
+                return cleanup(O3DMI_ERR_HIP);
+            if ((st = GatherRows(h->value_buffers[j], active, count,
+                                 h->value_dsizes[j], vals[j], nullptr)))
+                return cleanup(st);
+        }
+        if (hipStreamSynchronize(nullptr) != hipSuccess)
+            return cleanup(O3DMI_ERR_HIP);
+    }
+    // The new map on the target device (HashMap.cpp:249-253).
+    if (hipSetDevice(device) != hipSuccess) return cleanup(O3DMI_ERR_HIP);
+    if ((st = o3dmi_hash_create(h->capacity, h->n_values, h->value_dsizes,
+                                nullptr, &nh)))
+        return cleanup(st);
+    nh->view.owner_rank = h->view.owner_rank;
+    nh->view.owner_world = h->view.owner_world;
+    if (count > 0) {
+        // device -> device: peer copy across devices, plain copy on one
+        auto copy = [&](void* dst, const void* src, size_t bytes) {
+            return device == src_dev
+                           ? hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice)
+                           : hipMemcpyPeer(dst, device, src, src_dev, bytes);
+        };
+        if (hipMalloc((void**)&keys_dst, sizeof(int) * 3 * count) !=
+                    hipSuccess ||
+            copy(keys_dst, keys, sizeof(int) * 3 * count) != hipSuccess)
+            return cleanup(O3DMI_ERR_HIP);
+        for (int j = 0; j < h->n_values; ++j)
+            if (hipMalloc(&vals_dst[j], h->value_dsizes[j] * count) !=
+                        hipSuccess ||
+                copy(vals_dst[j], vals[j], h->value_dsizes[j] * count) !=
+                        hipSuccess)
+                return cleanup(O3DMI_ERR_HIP);
+        // Insert: keys first, then the value rows land in the winners' rows
+        // (one scatter per attribute -- the same association
+        // DeviceHashBackend::Insert produces, without its per-byte copy).
+        int* buf = nullptr;
+        if (hipMalloc((void**)&buf, sizeof(int) * count) != hipSuccess)
+            return cleanup(O3DMI_ERR_HIP);
+        st = o3dmi_hash_activate(nh, keys_dst, count, nullptr, buf, nullptr,
+                                 nullptr);
+        for (int j = 0; st == O3DMI_OK && j < h->n_values; ++j)
+            st = ScatterRows(vals_dst[j], buf, count, h->value_dsizes[j],
+                             nh->value_buffers[j], nullptr);
+        if (st == O3DMI_OK && hipStreamSynchronize(nullptr) != hipSuccess)
+            st = O3DMI_ERR_HIP;
+        (void)hipFree(buf);
+        if (st != O3DMI_OK) return cleanup(st);
+    }
+    *out = nh;
+    return cleanup(O3DMI_OK);
+}
+
 int o3dmi_hash_set_ownership(o3dmi_hash_t* h, int rank, int world) {
     O3DMI_REQUIRE(h != nullptr, "hash is null");
     O3DMI_REQUIRE(world >= 1 && rank >= 0 && rank < world,

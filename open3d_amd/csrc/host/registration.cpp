@@ -70,7 +70,26 @@ extern "C" int o3dmi_icp_symmetric_accumulate_post(
         double* sums29_dev, double* partials_dev, double* mail_data,
         int* mail_flag, int mail_seq, o3dmi_stream_t stream);
 
+extern "C" int o3dmi_internal_sums_tail(double* sums32_dev, double t29,
+                                        double t30, double t31,
+                                        o3dmi_stream_t stream);
+extern "C" int o3dmi_internal_sums_post(const double* sums32_dev,
+                                        double* mail_data, int* mail_flag,
+                                        int seq, o3dmi_stream_t stream);
+
 using namespace o3dmi;
+
+// Device-side all-reduce hook of the calling host thread (one rank = one
+// process, or one thread per device): see o3dmi_set_device_allreduce.
+static thread_local o3dmi_allreduce_device_t g_dev_allreduce = nullptr;
+static thread_local void* g_dev_allreduce_user = nullptr;
+
+extern "C" int o3dmi_set_device_allreduce(o3dmi_allreduce_device_t fn,
+                                          void* user) {
+    g_dev_allreduce = fn;
+    g_dev_allreduce_user = user;
+    return O3DMI_OK;
+}
 
 namespace {
 
@@ -425,6 +444,53 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
     O3DMI_REQUIRE(mb != nullptr, "host mailbox allocation failed");
     const double* sums_host = mb->data;
 
+    // The iteration's 32 sums, summed over the ranks when the cloud is
+    // sharded. `launch(sums_dev, mail_data, mail_flag, seq)` issues the
+    // accumulate + final-sum chain. t29..t31: values for out[29..31] (NaN =
+    // keep what the kernels computed); they are set BEFORE the rank sum.
+    //   no hook      final sum posts to the host mailbox
+    //   device hook  final sum -> device buffer -> tail -> caller's collective
+    //                on the launch stream (RCCL) -> post kernel -> mailbox:
+    //                one host wait per iteration, nothing staged by the host
+    //   host hook    as "no hook", then allreduce(host buffer)
+    DeviceBuffer dev_sums;
+    if (g_dev_allreduce && (st = dev_sums.Alloc(32 * sizeof(double))))
+        return st;
+    auto fetch_sums = [&](auto&& launch, double* out32, double t29, double t30,
+                          double t31) -> int {
+        const int seq = ++mb->seq;
+        if (g_dev_allreduce) {
+            double* d = (double*)dev_sums.p;
+            int e = launch(d, (double*)nullptr, (int*)nullptr, 0);
+            if (e) return e;
+            if ((e = o3dmi_internal_sums_tail(d, t29, t30, t31, stream)))
+                return e;
+            if (g_dev_allreduce(d, 32, stream, g_dev_allreduce_user) != 0) {
+                SetLastError("device all-reduce hook failed");
+                return O3DMI_ERR_INVALID_ARG;
+            }
+            if ((e = o3dmi_internal_sums_post(d, mb->data, mb->flag, seq,
+                                              stream)))
+                return e;
+            O3DMI_HIP_CHECK(MailboxWait(mb, seq, s));
+            std::memcpy(out32, sums_host, sizeof(double) * 32);
+            return O3DMI_OK;
+        }
+        int e = launch((double*)nullptr, mb->data, mb->flag, seq);
+        if (e) return e;
+        O3DMI_HIP_CHECK(MailboxWait(mb, seq, s));
+        std::memcpy(out32, sums_host, sizeof(double) * 32);
+        if (t29 == t29) out32[29] = t29;
+        if (t30 == t30) out32[30] = t30;
+        if (t31 == t31) out32[31] = t31;
+        if (allreduce && allreduce(out32, 32, allreduce_user) != 0) {
+            SetLastError("all-reduce hook failed");
+            return O3DMI_ERR_INVALID_ARG;
+        }
+        return O3DMI_OK;
+    };
+    const double kKeep = std::nan("");
+
     double T[16];
     if (init) std::memcpy(T, init, sizeof(T));
     else Eye4(T);
@@ -437,21 +503,17 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
     // ComputeRegistrationResult (+ the Jacobian sums of the same pass).
     auto search = [&](o3dmi_nns_t* nns, const Level& L, int64_t* corr_out,
                       SearchResult& r) -> int {
-        const int seq = ++mb->seq;
-        int e = o3dmi_icp_search_accumulate_post(
-                nns, L.src.p, nullptr, L.ns, search_mode, robust_kernel,
-                scaling_parameter, shape_parameter, corr_out, nullptr, mb->data,
-                mb->flag, seq, stream);
+        int e = fetch_sums(
+                [&](double* sums_dev, double* mail_data, int* mail_flag,
+                    int seq) {
+                    return o3dmi_icp_search_accumulate_post(
+                            nns, L.src.p, nullptr, L.ns, search_mode,
+                            robust_kernel, scaling_parameter, shape_parameter,
+                            corr_out, sums_dev, mail_data, mail_flag, seq,
+                            stream);
+                },
+                r.sums, kKeep, kKeep, (double)L.ns);
         if (e) return e;
-        O3DMI_HIP_CHECK(MailboxWait(mb, seq, s));
-        std::memcpy(r.sums, sums_host, sizeof(r.sums));
-        r.sums[31] = (double)L.ns;
-        if (allreduce) {
-            if (allreduce(r.sums, 32, allreduce_user) != 0) {
-                SetLastError("all-reduce hook failed");
-                return O3DMI_ERR_INVALID_ARG;
-            }
-        }
         const double num_correspondences = r.sums[30];
         if (num_correspondences != 0) {
             const double squared_error = r.sums[29];
@@ -545,24 +607,20 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                         ms[k] = (double)(float)ms[k];
                         mt[k] = (double)(float)mt[k];
                     }
-                const int seq = ++mb->seq;
-                int e = o3dmi_icp_symmetric_accumulate_post(
-                        L.src.p, L.srcn.p, L.tgt_ptr, L.nrm_ptr,
-                        (const int64_t*)corr_buf.p, L.ns, dtype, ms, mt,
-                        robust_kernel, scaling_parameter, shape_parameter,
-                        nullptr, (double*)sym_partials.p, mb->data, mb->flag,
-                        seq, stream);
-                if (e) return e;
-                O3DMI_HIP_CHECK(MailboxWait(mb, seq, s));
                 double sums29[32];
-                std::memcpy(sums29, sums_host, sizeof(double) * 29);
-                if (allreduce) {
-                    sums29[29] = sums29[30] = sums29[31] = 0;
-                    if (allreduce(sums29, 32, allreduce_user) != 0) {
-                        SetLastError("all-reduce hook failed");
-                        return O3DMI_ERR_INVALID_ARG;
-                    }
-                }
+                int e = fetch_sums(
+                        [&](double* sums_dev, double* mail_data,
+                            int* mail_flag, int seq) {
+                            return o3dmi_icp_symmetric_accumulate_post(
+                                    L.src.p, L.srcn.p, L.tgt_ptr, L.nrm_ptr,
+                                    (const int64_t*)corr_buf.p, L.ns, dtype,
+                                    ms, mt, robust_kernel, scaling_parameter,
+                                    shape_parameter, sums_dev,
+                                    (double*)sym_partials.p, mail_data,
+                                    mail_flag, seq, stream);
+                        },
+                        sums29, 0.0, 0.0, 0.0);
+                if (e) return e;
                 float residual;
                 int inlier_count;
                 e = o3dmi_decode_and_solve6x6(sums29, pose, &residual,
@@ -572,24 +630,21 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
             } else if (colored) {
                 // ComputePoseColoredICP + PoseToTransformation
                 // (TransformationEstimation.cpp:420-432)
-                const int seq = ++mb->seq;
-                int e = o3dmi_icp_colored_accumulate_post(
-                        L.src.p, L.srcc.p, L.tgt_ptr, L.nrm_ptr, L.tgtc_ptr,
-                        L.tgtg_ptr, (const int64_t*)corr_buf.p, L.ns, dtype,
-                        lambda_geometric, robust_kernel, scaling_parameter,
-                        shape_parameter, nullptr, (double*)sym_partials.p,
-                        mb->data, mb->flag, seq, stream);
-                if (e) return e;
-                O3DMI_HIP_CHECK(MailboxWait(mb, seq, s));
                 double sums29[32];
-                std::memcpy(sums29, sums_host, sizeof(double) * 29);
-                if (allreduce) {
-                    sums29[29] = sums29[30] = sums29[31] = 0;
-                    if (allreduce(sums29, 32, allreduce_user) != 0) {
-                        SetLastError("all-reduce hook failed");
-                        return O3DMI_ERR_INVALID_ARG;
-                    }
-                }
+                int e = fetch_sums(
+                        [&](double* sums_dev, double* mail_data,
+                            int* mail_flag, int seq) {
+                            return o3dmi_icp_colored_accumulate_post(
+                                    L.src.p, L.srcc.p, L.tgt_ptr, L.nrm_ptr,
+                                    L.tgtc_ptr, L.tgtg_ptr,
+                                    (const int64_t*)corr_buf.p, L.ns, dtype,
+                                    lambda_geometric, robust_kernel,
+                                    scaling_parameter, shape_parameter,
+                                    sums_dev, (double*)sym_partials.p,
+                                    mail_data, mail_flag, seq, stream);
+                        },
+                        sums29, 0.0, 0.0, 0.0);
+                if (e) return e;
                 float residual;
                 int inlier_count;
                 e = o3dmi_decode_and_solve6x6(sums29, pose, &residual,

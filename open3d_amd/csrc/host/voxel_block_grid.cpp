@@ -322,6 +322,45 @@ int o3dmi_vbg_create(int n_attrs, const char* const* attr_names,
     return O3DMI_OK;
 }
 
+// VoxelBlockGrid::To(device, copy) (VoxelBlockGrid.cpp, via
+// HashMap::To, core/hashmap/HashMap.cpp:230-255): the same grid on another
+// (or the same) device -- attribute layout and voxel size carried over, the
+// block hash map cloned with its value rows, scratch state fresh.
+int o3dmi_vbg_to_device(o3dmi_vbg_t* g, int device, o3dmi_vbg_t** out) {
+    O3DMI_REQUIRE(g != nullptr && out != nullptr, "null argument");
+    int cur = 0;
+    O3DMI_HIP_CHECK(hipGetDevice(&cur));
+    o3dmi_hash_t* hm = nullptr;
+    int st = o3dmi_hash_to_device(g->block_hashmap, device, &hm);
+    if (st) return st;
+    auto* n = new o3dmi_vbg();
+    n->voxel_size = g->voxel_size;
+    n->block_resolution = g->block_resolution;
+    n->attr_names = g->attr_names;
+    n->attr_dtypes = g->attr_dtypes;
+    n->attr_channels = g->attr_channels;
+    n->owner_rank = g->owner_rank;
+    n->owner_world = g->owner_world;
+    n->block_hashmap = hm;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess)
+        e = hipMalloc((void**)&n->frame_count, sizeof(int32_t) * 4);
+    if (e == hipSuccess)
+        e = hipHostMalloc((void**)&n->size_host, sizeof(int) * 4);
+    if (e == hipSuccess)
+        e = hipEventCreateWithFlags(&n->size_event, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        o3dmi_vbg_destroy(n);
+        (void)hipSetDevice(cur);
+        SetLastError(std::string("o3dmi_vbg_to_device: ") +
+                     hipGetErrorString(e));
+        return O3DMI_ERR_HIP;
+    }
+    (void)hipSetDevice(cur);
+    *out = n;
+    return O3DMI_OK;
+}
+
 int o3dmi_vbg_destroy(o3dmi_vbg_t* g) {
     if (!g) return O3DMI_OK;
     o3dmi_hash_destroy(g->block_hashmap);

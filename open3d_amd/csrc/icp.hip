@@ -1282,3 +1282,46 @@ void o3dmi_pose_to_transformation(const double* pose_ptr, double* T) {
 }
 
 }  // extern "C"
+
+// ---- device-side all-reduce support (multi-GPU source-sharded ICP) ----------
+// The driver keeps the iteration's 32 sums on the device, lets the caller's
+// collective (RCCL all-reduce through the hook of o3dmi_set_device_allreduce)
+// run on the launch stream, and only then posts them to the host mailbox:
+//   final sum -> SumsTailKernel -> [all-reduce on the stream] -> SumsPostKernel
+namespace o3dmi {
+namespace {
+// tail[k] >= 0: sums[29 + k] = tail[k]; NaN: left as computed.
+__global__ void SumsTailKernel(double* __restrict__ sums, double t29,
+                               double t30, double t31) {
+    if (threadIdx.x == 0) {
+        if (t29 == t29) sums[29] = t29;
+        if (t30 == t30) sums[30] = t30;
+        if (t31 == t31) sums[31] = t31;
+    }
+}
+__global__ void SumsPostKernel(const double* __restrict__ sums,
+                               double* mail_data, int* mail_flag, int seq) {
+    if (threadIdx.x < 32) mail_data[threadIdx.x] = sums[threadIdx.x];
+    MailboxPublish(mail_flag, seq);
+}
+}  // namespace
+}  // namespace o3dmi
+
+extern "C" int o3dmi_internal_sums_tail(double* sums32_dev, double t29,
+                                        double t30, double t31,
+                                        o3dmi_stream_t stream) {
+    hipLaunchKernelGGL(o3dmi::SumsTailKernel, dim3(1), dim3(64), 0,
+                       (hipStream_t)stream, sums32_dev, t29, t30, t31);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+extern "C" int o3dmi_internal_sums_post(const double* sums32_dev,
+                                        double* mail_data, int* mail_flag,
+                                        int seq, o3dmi_stream_t stream) {
+    hipLaunchKernelGGL(o3dmi::SumsPostKernel, dim3(1), dim3(64), 0,
+                       (hipStream_t)stream, sums32_dev, mail_data, mail_flag,
+                       seq);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}

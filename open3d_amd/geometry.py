@@ -317,6 +317,19 @@ class VoxelBlockGrid:
         _lib.check(_lib.lib().o3dmi_vbg_save(self._g, str(file_name).encode(),
                                              stream()), "VoxelBlockGrid.save")
 
+    def to(self, device):
+        """VoxelBlockGrid::To(device, copy=True): the grid on HIP device
+        `device` (index or "cuda:i"; its own device gives a deep copy). Use the
+        result with that device current (torch.cuda.device(i))."""
+        idx = torch.device(device).index if not isinstance(device, int) \
+            else device
+        torch.cuda.synchronize()
+        h = C.c_void_p()
+        _lib.check(_lib.lib().o3dmi_vbg_to_device(self._g, int(idx or 0),
+                                                  C.byref(h)),
+                   "VoxelBlockGrid.to")
+        return VoxelBlockGrid._adopt(h)
+
     @staticmethod
     def load(file_name):
         """VoxelBlockGrid::Load (VoxelBlockGrid.cpp:538-596)."""
@@ -324,6 +337,10 @@ class VoxelBlockGrid:
         _lib.check(_lib.lib().o3dmi_vbg_load(str(file_name).encode(), stream(),
                                              C.byref(h)),
                    "VoxelBlockGrid.load")
+        return VoxelBlockGrid._adopt(h)
+
+    @staticmethod
+    def _adopt(h):
         L = _lib.lib()
         g = VoxelBlockGrid.__new__(VoxelBlockGrid)
         g._g = h

@@ -73,9 +73,12 @@ def multi_scale_icp(source, target, target_normals, voxel_sizes, criteria_list,
                     max_correspondence_distances, init_source_to_target=None,
                     estimation_method=None, callback_after_iteration=None,
                     allreduce=None, source_normals=None, source_colors=None,
-                    target_colors=None, target_color_gradients=None):
+                    target_colors=None, target_color_gradients=None,
+                    device_allreduce=None):
     """source/target/target_normals: device tensors {N,3}. `allreduce`
-    (optional) sums a length-32 numpy float64 array over ranks in place.
+    (optional) sums a length-32 numpy float64 array over ranks in place;
+    `device_allreduce(dev_ptr, n, stream_ptr)` (optional, takes precedence;
+    sharding.make_device_allreduce) enqueues the same sum on the device.
     `source_normals` is read by the symmetric estimator, the colours (and the
     optional target colour gradients) by the coloured one."""
     est = estimation_method or TransformationEstimationPointToPlane()
@@ -155,16 +158,26 @@ def multi_scale_icp(source, target, target_normals, voxel_sizes, criteria_list,
             return 0
         ar = _lib.ALLREDUCE_SUM(_ar)
 
-    st = _lib.lib().o3dmi_registration_multiscale_icp_ex(
-        _lib.ptr(source), ns, _lib.ptr(target),
-        _lib.ptr(target_normals) if target_normals is not None else None, nt,
-        TORCH_TO_O3DMI[source.dtype], S, _lib.f64p(vs), crit, _lib.f64p(md),
-        _lib.f64p(init),
-        1 if p2point else (2 if symmetric else (3 if colored else 0)),
-        C.byref(attrs), int(est.kernel.type),
-        C.c_double(est.kernel.scaling_parameter),
-        C.c_double(est.kernel.shape_parameter), cb, None, ar, None,
-        _lib.ptr(corr), C.byref(res), stream())
+    dar = None
+    if device_allreduce is not None:
+        def _dar(buf, n, strm, user):
+            try:
+                device_allreduce(int(buf or 0), int(n), int(strm or 0))
+                return 0
+            except Exception:  # surfaces as the driver's error status
+                import traceback
+                traceback.print_exc()
+                return 1
+        dar = _lib.ALLREDUCE_DEVICE(_dar)
+        _lib.lib().o3dmi_set_device_allreduce(dar, None)
+    try:
+        st = _icp_call(source, ns, target, target_normals, nt, S, vs, crit, md,
+                       init, p2point, symmetric, colored, attrs, est, cb, ar,
+                       corr, res)
+    finally:
+        if dar is not None:
+            _lib.lib().o3dmi_set_device_allreduce(_lib.ALLREDUCE_DEVICE(0),
+                                                  None)
     _lib.check(st, "multi_scale_icp")
     out = RegistrationResult()
     out.transformation = np.array(res.transformation[:]).reshape(4, 4)
@@ -176,11 +189,25 @@ def multi_scale_icp(source, target, target_normals, voxel_sizes, criteria_list,
     return out
 
 
+def _icp_call(source, ns, target, target_normals, nt, S, vs, crit, md, init,
+              p2point, symmetric, colored, attrs, est, cb, ar, corr, res):
+    return _lib.lib().o3dmi_registration_multiscale_icp_ex(
+        _lib.ptr(source), ns, _lib.ptr(target),
+        _lib.ptr(target_normals) if target_normals is not None else None, nt,
+        TORCH_TO_O3DMI[source.dtype], S, _lib.f64p(vs), crit, _lib.f64p(md),
+        _lib.f64p(init),
+        1 if p2point else (2 if symmetric else (3 if colored else 0)),
+        C.byref(attrs), int(est.kernel.type),
+        C.c_double(est.kernel.scaling_parameter),
+        C.c_double(est.kernel.shape_parameter), cb, None, ar, None,
+        _lib.ptr(corr), C.byref(res), stream())
+
+
 def icp(source, target, target_normals, max_correspondence_distance,
         init_source_to_target=None, estimation_method=None, criteria=None,
         voxel_size=-1.0, callback_after_iteration=None, allreduce=None,
         source_normals=None, source_colors=None, target_colors=None,
-        target_color_gradients=None):
+        target_color_gradients=None, device_allreduce=None):
     """t::pipelines::registration::ICP (Registration.cpp:93-106)."""
     return multi_scale_icp(source, target, target_normals, [voxel_size],
                            [criteria or ICPConvergenceCriteria()],
@@ -188,7 +215,7 @@ def icp(source, target, target_normals, max_correspondence_distance,
                            init_source_to_target, estimation_method,
                            callback_after_iteration, allreduce, source_normals,
                            source_colors, target_colors,
-                           target_color_gradients)
+                           target_color_gradients, device_allreduce)
 
 
 def _check_pair(source, target):

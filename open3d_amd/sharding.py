@@ -7,7 +7,10 @@ this layer is new. Exchanges are tiny and latency-bound:
   * ICP: the source cloud is split across ranks, the target (and its index) is
     replicated; per iteration one all-reduce of 32 float64 (29 Gauss-Newton
     sums, sum d2, match count, shard size) -- every rank then solves the same
-    6x6 system, so no broadcast is needed.
+    6x6 system, so no broadcast is needed. make_device_allreduce keeps that
+    exchange on the device (RCCL on the launch stream, between the final
+    reduction kernel and the mailbox post); make_allreduce_sum is the host
+    form (numpy buffer), kept for callers without a device collective.
   * Integration, frame-sharded (independent streams, weak scaling): rank r
     owns frames r, r+N, ... into a private grid; the activated block IDs are
     unioned with one padded all-gather.
@@ -41,6 +44,38 @@ def make_allreduce_sum(dist, device):
         t = torch.from_numpy(np.ascontiguousarray(a)).to(device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         a[:] = t.cpu().numpy()
+    return _f
+
+
+def make_device_allreduce(dist):
+    """The on-device form of the ICP exchange: returns a callable suitable for
+    registration.icp / multi_scale_icp's `device_allreduce` argument. The
+    driver hands it the device address of the iteration's 32 float64 sums and
+    the launch stream; the all-reduce (RCCL under backend "nccl") is enqueued
+    on that stream, in place, between the final reduction kernel and the
+    kernel that posts the sums to the host mailbox -- no host staging, no
+    numpy round trip. Under "gloo" (CPU tests, single-GPU multi-process runs)
+    the buffer is staged through the host, which only serves correctness."""
+    from . import _lib
+    from .core import tensor_from_ptr
+
+    def _f(dev_ptr, n, stream_ptr):
+        t = tensor_from_ptr(dev_ptr, (n,), _lib.F64, None)
+        cur = torch.cuda.current_stream().cuda_stream
+        ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream_ptr)) \
+            if stream_ptr and stream_ptr != cur else None
+        if ctx is not None:
+            ctx.__enter__()
+        try:
+            if dist.get_backend() == "gloo":
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
     return _f
 
 

@@ -1232,3 +1232,59 @@ def test_voxel_down_sample_golden_through_gpu():
     assert tuple(down.shape) == (1, 3)
     assert np.allclose(down.cpu().numpy(), [[0.375, 0.375, 0.575]],
                        rtol=1e-5, atol=1e-8)
+
+
+def _icp_two_process_rank(rank, world):
+    """One rank of the two-process source-sharded ICP: own process, own HIP
+    context, the 32 sums all-reduced ON THE DEVICE through
+    sharding.make_device_allreduce (RCCL when every rank has its own GPU, else
+    gloo staged through the host)."""
+    import torch.distributed as dist
+    from open3d_amd import registration as reg
+    from open3d_amd.sharding import make_device_allreduce, shard_range
+    p = _pair(20000, seed=7, dtype=np.float32)
+    n = p["source"].shape[0]
+    b, e = shard_range(n, rank, world)
+    r = reg.multi_scale_icp(
+        torch.from_numpy(p["source"][b:e]).cuda(),
+        torch.from_numpy(p["target"]).cuda(),
+        torch.from_numpy(p["target_normals"]).cuda(), [-1.0, -1.0],
+        [reg.ICPConvergenceCriteria(1e-6, 1e-6, 10),
+         reg.ICPConvergenceCriteria(1e-6, 1e-6, 20)], [0.1, 0.07],
+        device_allreduce=make_device_allreduce(dist))
+    torch.cuda.synchronize()
+    return (r.transformation, r.num_iterations, r.fitness, r.inlier_rmse,
+            dist.get_backend(), torch.cuda.current_device())
+
+
+@pytest.mark.timeout(600)
+def test_icp_source_sharded_two_processes_device_allreduce():
+    """SURVEY 8(e) with real processes: two ranks, each its own process (and
+    its own GPU + RCCL when the box has two; both on this GPU with gloo as the
+    transport otherwise), the per-iteration exchange through the driver's
+    DEVICE all-reduce hook (final sum -> tail -> collective on the launch
+    stream -> post kernel -> host mailbox). Both ranks end with the unsharded
+    pose."""
+    from test_sharding import _run
+    _lib, reg = _gpu()
+    p = _pair(20000, seed=7, dtype=np.float32)
+    one = reg.multi_scale_icp(
+        torch.from_numpy(p["source"]).cuda(),
+        torch.from_numpy(p["target"]).cuda(),
+        torch.from_numpy(p["target_normals"]).cuda(), [-1.0, -1.0],
+        [reg.ICPConvergenceCriteria(1e-6, 1e-6, 10),
+         reg.ICPConvergenceCriteria(1e-6, 1e-6, 20)], [0.1, 0.07])
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    got = _run(_icp_two_process_rank, backend=backend)
+    assert got[0][4] == backend
+    if backend == "nccl":
+        assert {got[0][5], got[1][5]} == {0, 1}
+    for r in range(2):
+        ang, tr = _pose_err(one.transformation, got[r][0])
+        assert ang <= 1e-9 and tr <= 1e-9, (r, ang, tr)
+        assert got[r][1] == one.num_iterations
+        assert abs(got[r][2] - one.fitness) < 1e-12
+        assert abs(got[r][3] - one.inlier_rmse) < 1e-9
+    assert np.array_equal(got[0][0], got[1][0])  # identical on both ranks
+    print("two-process source-sharded ICP over %s: pose equals the unsharded "
+          "run" % backend)

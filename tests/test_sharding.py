@@ -18,21 +18,24 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, fn, ret):
+def _worker(rank, world, port, fn, ret, backend="gloo"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":  # RCCL: one GPU per rank
+        torch.cuda.set_device(rank)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         ret[rank] = fn(rank, world)
     finally:
         dist.destroy_process_group()
 
 
-def _run(fn, world=2):
+def _run(fn, world=2, backend="gloo"):
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), fn, ret), nprocs=world,
-             join=True)
+    mp.spawn(_worker, args=(world, _free_port(), fn, ret, backend),
+             nprocs=world, join=True)
     return [ret[r] for r in range(world)]
 
 

@@ -135,3 +135,62 @@ def test_empty_grid_round_trip(tmp_path):
     assert z["key"].shape == (0, 3) and z["value_000"].shape == (0, 16, 16, 16, 1)
     g2 = geometry.VoxelBlockGrid.load(p)
     assert g2.hashmap().size() == 0
+
+
+def test_grid_to_device_clone_keeps_blocks_and_keeps_integrating():
+    """VoxelBlockGrid::To(device) (HashMap::To, core/hashmap/HashMap.cpp:
+    230-255): active keys and voxel rows are gathered, copied device to device
+    and inserted into a new map of the same capacity. On a one-GPU box the
+    target is the grid's own device (a deep copy: the same gather / copy /
+    insert path with a plain instead of a peer copy); with two GPUs the clone
+    lands on device 1. The clone equals the source per block key, is
+    independent of it, and integrates further frames to the same result."""
+    import _scene as sc
+    from open3d_amd import geometry
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+    def mk():
+        return geometry.VoxelBlockGrid(
+            ["tsdf", "weight", "color"],
+            [torch.float32, torch.uint16, torch.uint16], [1, 1, 3], sc.VOXEL,
+            sc.RES, 2048)
+
+    def blocks(g):
+        hm = g.hashmap()
+        act = hm.active_buf_indices().cpu().numpy().astype(np.int64)
+        keys = hm.key_tensor().cpu().numpy()[act]
+        o = np.lexsort(keys.T[::-1])
+        act, keys = act[o], keys[o]
+        return (keys, g.attribute("tsdf").cpu().numpy()[act],
+                g.attribute("weight").cpu().numpy()[act],
+                g.attribute("color").cpu().numpy()[act])
+
+    fr = [sc.frames(k, 1, 320, 240) for k in (0, 8, 16, 24)]
+    K = fr[0][2]
+    dev = [(torch.from_numpy(f[0][0]).cuda(), torch.from_numpy(f[1][0]).cuda(),
+            f[3][0]) for f in fr]
+    g = mk()
+    for d, c, T in dev[:2]:
+        g.integrate_frame(d, c, K, K, T)
+    target = 1 if torch.cuda.device_count() >= 2 else 0
+    clone = g.to(target)
+    a = blocks(g)
+    with torch.cuda.device(target):
+        b = blocks(clone)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert clone.hashmap().capacity() == g.hashmap().capacity()
+    # independent storage: the source moves on, the clone does not
+    g.integrate_frame(*dev[2][:2], K, K, dev[2][2])
+    with torch.cuda.device(target):
+        assert np.array_equal(blocks(clone)[2], b[2])
+        # and the clone integrates the same frame to the same grid
+        if target == 0:
+            clone.integrate_frame(*dev[2][:2], K, K, dev[2][2])
+        else:
+            clone.integrate_frame(dev[2][0].to("cuda:1"),
+                                  dev[2][1].to("cuda:1"), K, K, dev[2][2])
+        c = blocks(clone)
+    for x, y in zip(blocks(g), c):
+        assert np.array_equal(x, y)

@@ -106,7 +106,47 @@ def mode_icp(a):
                                                    res.transformation)
         out["same_iterations_as_oracle"] = (want["num_iterations"] ==
                                             res.num_iterations)
-    print(json.dumps(out), flush=True)
+    # SURVEY 8(d) unit = source point x iteration: 12 B query + 27 bucket
+    # heads (8 B) + visited records x 16 B + 44 B accumulate (12 src + 8 corr +
+    # 24 gathered target point + normal) + 24 B transform. The time is the
+    # whole iteration (search + accumulate + final sum + host hop + transform),
+    # so the fraction is a lower bound for the search kernel's own.
+    if not p2point:
+        visited = mean_visited_records(p["target"], p["source"], 0.07)
+        unit = 12 + 27 * 8 + visited * 16 + 44 + 24
+        gbs = a.points * unit / (out["ms_per_iteration"] * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "unit": "GB/s",
+                           "bytes_per_point_iteration": unit,
+                           "visited_records_per_query": visited,
+                           "achieved": gbs, "peak": 8000.0,
+                           "frac": gbs / 8000.0,
+                           "basis": "whole-iteration wall time (lower bound "
+                                    "for SearchAccumulateKernel)"}
+    return out
+
+
+def mean_visited_records(target, queries, radius, sample=4000):
+    """Average number of index records in the 27 cells (edge = radius) around a
+    query -- the 'visited records' of SURVEY 8(d), counted on the host."""
+    t = np.floor(np.asarray(target, np.float64) / radius).astype(np.int64)
+    key = (t[:, 0] + (1 << 20)) << 42 | (t[:, 1] + (1 << 20)) << 21 | \
+        (t[:, 2] + (1 << 20))
+    uk, cnt = np.unique(key, return_counts=True)
+    q = np.asarray(queries, np.float64)
+    if q.shape[0] > sample:
+        q = q[:: q.shape[0] // sample]
+    qc = np.floor(q / radius).astype(np.int64)
+    tot = np.zeros(q.shape[0], np.int64)
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                k = (qc[:, 0] + dx + (1 << 20)) << 42 | \
+                    (qc[:, 1] + dy + (1 << 20)) << 21 | \
+                    (qc[:, 2] + dz + (1 << 20))
+                i = np.searchsorted(uk, k)
+                i = np.minimum(i, uk.shape[0] - 1)
+                tot += np.where(uk[i] == k, cnt[i], 0)
+    return float(tot.mean())
 
 
 def mode_slam(a):
@@ -114,7 +154,7 @@ def mode_slam(a):
     from open3d_amd import _lib
     from open3d_amd.core import stream
     import ctypes as C
-    W, H = 1280, 720
+    W, H = (640, 480) if getattr(a, "vga", False) else (1280, 720)
     voxel, res, trunc = 0.008, 16, 8.0
     ds, dmax = 1000.0, 3.0
     n = a.frames
@@ -212,8 +252,9 @@ def mode_slam(a):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     errs = [pose_err(Ts[k], T_est[k]) for k in range(n)]
-    out = {"mode": "slam", "workload": "configs[2]: 1280x720 synthetic stream, "
-           "multi-scale ICP (5/2.5/1.25 cm; 20/10/5 it) + integrate + ray cast",
+    out = {"mode": "slam", "workload": "configs[2]: %dx%d synthetic stream, "
+           "multi-scale ICP (5/2.5/1.25 cm; 20/10/5 it) + integrate + ray cast"
+           % (W, H),
            "frames": n - 1, "frames_per_s": (n - 1) / dt,
            "ms_per_frame": dt / (n - 1) * 1e3,
            "icp_iterations_per_frame": iters / (n - 1),
@@ -224,9 +265,34 @@ def mode_slam(a):
     if a.phases:
         out["ms_model_cloud_frame_cloud_icp_integrate"] = \
             [float(x) for x in phase / (n - 1) * 1e3]
-        out["source_points"] = int(src.shape[0])
-        out["target_points"] = int(tp.shape[0])
-    print(json.dumps(out), flush=True)
+    out["source_points"] = int(src.shape[0])
+    out["target_points"] = int(tp.shape[0])
+    # SURVEY 8(d) accounting of the ICP leg on the finest level's clouds
+    # (points x iterations x bytes over the whole frame time: a lower bound)
+    src_np, tp_np, tn_np = (t.cpu().numpy() for t in (src, tp, tn))
+    visited = mean_visited_records(tp_np, src_np, md[-1])
+    unit = 12 + 27 * 8 + visited * 16 + 44 + 24
+    it_pf = iters / (n - 1)
+    gbs = src_np.shape[0] * it_pf * unit / (dt / (n - 1)) / 1e9
+    out["roofline"] = {"bound": "hbm", "unit": "GB/s",
+                       "bytes_per_point_iteration": unit,
+                       "visited_records_per_query": visited,
+                       "achieved": gbs, "peak": 8000.0, "frac": gbs / 8000.0,
+                       "basis": "finest-level cloud size x all iterations "
+                                "over the whole frame time (track + "
+                                "integrate + ray cast): a lower bound"}
+    if getattr(a, "cpu_frames", 0) > 0:
+        import _oracle as orc
+        orc.set_threads(min(64, os.cpu_count() or 1))
+        crit_o = [(1e-6, 1e-6, it) for it in (20, 10, 5)]
+        t0c = time.perf_counter()
+        for _ in range(a.cpu_frames):
+            orc.multiscale_icp(src_np, tp_np, tn_np, vs, crit_o, md,
+                               accumulate_double=True)
+        out["cpu_oracle_ms_per_multiscale_icp"] = \
+            (time.perf_counter() - t0c) / a.cpu_frames * 1e3
+        out["cpu_oracle_threads"] = min(64, os.cpu_count() or 1)
+    return out
 
 
 def mode_model(a):
@@ -341,7 +407,7 @@ def mode_model(a):
         out["cpu_oracle_threads"] = {"track": 1, "integrate_raycast":
                                      min(64, os.cpu_count() or 1)}
         out["cpu_oracle_frames_per_s"] = float(k / tt.sum()) if tt.sum() else 0
-    print(json.dumps(out), flush=True)
+    return out
 
 
 def mode_extract(a):
@@ -381,7 +447,7 @@ def mode_extract(a):
            "ms_two_pass": ms2, "ms_with_estimate": ms1,
            "algorithmic_GBps_with_estimate":
                (nb * 4096 * 6 * 2 + n_pts * 36) / (ms1 * 1e-3) / 1e9}
-    print(json.dumps(out), flush=True)
+    return out
 
 
 def mode_normals(a):
@@ -414,7 +480,7 @@ def mode_normals(a):
         dt = time.perf_counter() - t0
         out["cpu_oracle_points_per_s"] = m / dt
         out["cpu_oracle_sample_points"] = m
-    print(json.dumps(out), flush=True)
+    return out
 
 
 def main():
@@ -422,6 +488,7 @@ def main():
     ap.add_argument("--mode", choices=["icp", "slam", "model", "normals", "extract", "both"],
                     default="both")
     ap.add_argument("--hd", action="store_true", help="1280x720 (model mode)")
+    ap.add_argument("--vga", action="store_true", help="640x480 (slam mode)")
     ap.add_argument("--method", default="p2plane",
                     choices=["p2plane", "intensity", "hybrid"])
     ap.add_argument("--estimation", default="p2plane",
@@ -441,16 +508,18 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     a = ap.parse_args()
     torch.cuda.set_device(0)
+    def emit(o):
+        print(json.dumps(o), flush=True)
     if a.mode in ("icp", "both"):
-        mode_icp(a)
+        emit(mode_icp(a))
     if a.mode in ("slam", "both"):
-        mode_slam(a)
+        emit(mode_slam(a))
     if a.mode == "model":
-        mode_model(a)
+        emit(mode_model(a))
     if a.mode == "normals":
-        mode_normals(a)
+        emit(mode_normals(a))
     if a.mode == "extract":
-        mode_extract(a)
+        emit(mode_extract(a))
 
 
 if __name__ == "__main__":
