@@ -80,7 +80,12 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=5000,
                     help="frames per step (per GPU)")
-    ap.add_argument("--block-count", type=int, default=65536)
+    ap.add_argument("--block-count", type=int, default=262144,
+                    help="initial hash capacity; the stream needs ~6 k blocks, "
+                         "the rest is head-room that lets the host issue "
+                         "several 4-frame groups ahead of the GPU without "
+                         "waiting for the map size (capacity policy of "
+                         "HashMap::Activate)")
     ap.add_argument("--frames-per-launch", type=int, default=4,
                     help="consecutive frames applied per launch to register-"
                          "resident blocks (1..4); results are identical")

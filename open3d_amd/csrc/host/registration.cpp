@@ -41,6 +41,7 @@
 
 #include "../common.h"
 #include "../mailbox.h"
+#include "../vds.h"
 #include "o3d_mi355x_host.h"
 
 extern "C" int o3dmi_icp_search_accumulate_post(
@@ -70,6 +71,7 @@ extern "C" int o3dmi_icp_symmetric_accumulate_post(
         double* sums29_dev, double* partials_dev, double* mail_data,
         int* mail_flag, int mail_seq, o3dmi_stream_t stream);
 
+extern "C" int o3dmi_internal_nns_destroy_completed(o3dmi_nns_t* nns);
 extern "C" int o3dmi_internal_sums_tail(double* sums32_dev, double t29,
                                         double t30, double t31,
                                         o3dmi_stream_t stream);
@@ -132,25 +134,81 @@ struct Level {
     const void* tgtg_ptr = nullptr;
 };
 
-// PointCloud::VoxelDownSample averages every attribute; the kernel seam takes
-// positions + one attribute, so further attributes go through it again (the
-// voxel order, first occurrence, is the same every time).
-int DownSampleAttrs(const void* pos, int64_t n, int dtype, double voxel,
-                    void* out_pos, int64_t* m, o3dmi_stream_t stream,
-                    std::initializer_list<std::pair<const void*, void*>> attrs) {
+// One pyramid level without a host wait (vds.h). PointCloud::VoxelDownSample
+// averages every attribute; the kernel takes positions + one attribute, so
+// further attributes go through it again (the voxel order, first occurrence,
+// is the same every time, and so are the positions and the count).
+int DownSampleAttrsAsync(const void* pos, int64_t n_max, const int* n_dev,
+                         int dtype, double voxel, void* out_pos, int* m_dev,
+                         int* err_dev, std::vector<void*>& scratch,
+                         hipStream_t cs,
+                         std::initializer_list<std::pair<const void*, void*>>
+                                 attrs) {
+    if (voxel <= 0) {
+        SetLastError("voxel_size must be positive.");
+        return O3DMI_ERR_INVALID_ARG;
+    }
     bool done = false;
     for (const auto& a : attrs) {
         if (!a.first) continue;
-        int st = o3dmi_voxel_down_sample(pos, a.first, n, dtype, voxel, out_pos,
-                                         a.second, m, stream);
+        int st = VdsAsync(pos, a.first, n_max, n_dev, dtype, voxel, out_pos,
+                          a.second, m_dev, err_dev, scratch, cs);
         if (st) return st;
         done = true;
     }
     if (!done)
-        return o3dmi_voxel_down_sample(pos, nullptr, n, dtype, voxel, out_pos,
-                                       nullptr, m, stream);
+        return VdsAsync(pos, nullptr, n_max, n_dev, dtype, voxel, out_pos,
+                        nullptr, m_dev, err_dev, scratch, cs);
     return O3DMI_OK;
 }
+
+// Device-side level counts of one cloud's pyramid: [level] voxel counts, then
+// one word of error flags. Read back once, at the end of the chain.
+struct ChainCounts {
+    int* dev = nullptr;
+    int levels = 0;
+    std::vector<void*> scratch;
+    int Init(int n_levels, hipStream_t cs) {
+        levels = n_levels;
+        void* q = nullptr;
+        int st = PoolAlloc(&q, sizeof(int) * (size_t)(n_levels + 1));
+        if (st) return st;
+        dev = (int*)q;
+        scratch.push_back(q);
+        O3DMI_HIP_CHECK(hipMemsetAsync(dev, 0,
+                                       sizeof(int) * (size_t)(n_levels + 1),
+                                       cs));
+        return O3DMI_OK;
+    }
+    int* Count(int level) { return dev + level; }
+    int* Err() { return dev + levels; }
+    // waits for the chain, returns the counts and releases the scratch
+    int Fetch(std::vector<int>& out, hipStream_t cs) {
+        out.assign((size_t)levels + 1, 0);
+        hipError_t e = hipMemcpyAsync(out.data(), dev,
+                                      sizeof(int) * (size_t)(levels + 1),
+                                      hipMemcpyDeviceToHost, cs);
+        if (e == hipSuccess) e = hipStreamSynchronize(cs);
+        Release(cs);
+        if (e != hipSuccess) {
+            SetLastError(std::string("pyramid read-back: ") +
+                         hipGetErrorString(e));
+            return O3DMI_ERR_HIP;
+        }
+        if (out[(size_t)levels] & kErrKeyRange) {
+            SetLastError("VoxelDownSample: voxel coordinate outside +-2^20");
+            return O3DMI_ERR_KEY_RANGE;
+        }
+        return O3DMI_OK;
+    }
+    void Release(hipStream_t cs) {
+        if (scratch.empty()) return;
+        (void)hipStreamSynchronize(cs);  // pooled blocks: stream drained
+        for (void* p : scratch) PoolFree(p);
+        scratch.clear();
+        dev = nullptr;
+    }
+};
 
 // One side stream per host thread for the overlapped pyramid build.
 hipStream_t SideStream() {
@@ -161,9 +219,16 @@ hipStream_t SideStream() {
     return side;
 }
 
+// `completed`: set by the owner once every kernel that used the index is
+// known to have finished (its results were read on the host); the destructor
+// then skips the device-wide wait of the public o3dmi_nns_destroy.
 struct NnsGuard {
     o3dmi_nns_t* nns = nullptr;
-    ~NnsGuard() { o3dmi_nns_destroy(nns); }
+    bool completed = false;
+    ~NnsGuard() {
+        if (completed) o3dmi_internal_nns_destroy_completed(nns);
+        else o3dmi_nns_destroy(nns);
+    }
 };
 
 struct SearchResult {
@@ -264,6 +329,10 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
     } sync_on_exit{s};
     const int last = num_scales - 1;
     int st;
+    const double t_entry =
+            std::chrono::duration<double, std::micro>(
+                    std::chrono::steady_clock::now().time_since_epoch())
+                    .count();
     // The source pyramid and the target pyramid are independent chains of
     // VoxelDownSample calls, each a string of small launches with read-backs
     // in between (voxel counts size the next level) -- latency, not
@@ -278,11 +347,22 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                                        hipMemcpyDeviceToDevice, cs));
         return O3DMI_OK;
     };
+    // Every level of a chain is a string of launches whose sizes stay on the
+    // device (the voxel count of one level is the point count of the next);
+    // level buffers are sized by the input cloud, the counts are read back
+    // once per chain.
     auto source_chain = [&](hipStream_t cs) -> int {
-        o3dmi_stream_t cstream = (o3dmi_stream_t)cs;
         int e;
+        ChainCounts cc;
+        struct Guard {
+            ChainCounts& c;
+            hipStream_t s;
+            ~Guard() { c.Release(s); }
+        } guard{cc, cs};
+        if ((e = cc.Init(num_scales, cs))) return e;
         Level& L = pyr[(size_t)last];
-        if (voxel_sizes[last] <= 0) {
+        const bool finest_is_input = voxel_sizes[last] <= 0;
+        if (finest_is_input) {
             L.ns = ns;
             // the source is moved in place every iteration: private copies
             if ((e = clone(L.src, source_dev, ns, cs))) return e;
@@ -294,31 +374,50 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
             if ((e = L.src.Alloc((size_t)ns * 3 * esz))) return e;
             if (symmetric && (e = L.srcn.Alloc((size_t)ns * 3 * esz))) return e;
             if (colored && (e = L.srcc.Alloc((size_t)ns * 3 * esz))) return e;
-            e = DownSampleAttrs(source_dev, ns, dtype, voxel_sizes[last],
-                                L.src.p, &L.ns, cstream,
-                                {{source_normals_dev, L.srcn.p},
-                                 {source_colors_dev, L.srcc.p}});
+            e = DownSampleAttrsAsync(source_dev, ns, nullptr, dtype,
+                                     voxel_sizes[last], L.src.p,
+                                     cc.Count(last), cc.Err(), cc.scratch, cs,
+                                     {{source_normals_dev, L.srcn.p},
+                                      {source_colors_dev, L.srcc.p}});
             if (e) return e;
         }
         for (int k = num_scales - 2; k >= 0; --k) {
             Level& C = pyr[(size_t)k];
             Level& F = pyr[(size_t)k + 1];
-            if ((e = C.src.Alloc((size_t)F.ns * 3 * esz))) return e;
-            if (symmetric && (e = C.srcn.Alloc((size_t)F.ns * 3 * esz)))
+            if ((e = C.src.Alloc((size_t)ns * 3 * esz))) return e;
+            if (symmetric && (e = C.srcn.Alloc((size_t)ns * 3 * esz)))
                 return e;
-            if (colored && (e = C.srcc.Alloc((size_t)F.ns * 3 * esz))) return e;
-            e = DownSampleAttrs(F.src.p, F.ns, dtype, voxel_sizes[k], C.src.p,
-                                &C.ns, cstream,
-                                {{F.srcn.p, C.srcn.p}, {F.srcc.p, C.srcc.p}});
+            if (colored && (e = C.srcc.Alloc((size_t)ns * 3 * esz))) return e;
+            const bool f_host = k + 1 == last && finest_is_input;
+            e = DownSampleAttrsAsync(F.src.p, ns,
+                                     f_host ? nullptr : cc.Count(k + 1), dtype,
+                                     voxel_sizes[k], C.src.p, cc.Count(k),
+                                     cc.Err(), cc.scratch, cs,
+                                     {{F.srcn.p, C.srcn.p},
+                                      {F.srcc.p, C.srcc.p}});
             if (e) return e;
         }
+        std::vector<int> counts;
+        if ((e = cc.Fetch(counts, cs))) return e;
+        for (int k = 0; k < num_scales; ++k)
+            if (!(k == last && finest_is_input))
+                pyr[(size_t)k].ns = counts[(size_t)k];
         return O3DMI_OK;
     };
     auto target_chain = [&](hipStream_t cs) -> int {
         o3dmi_stream_t cstream = (o3dmi_stream_t)cs;
         int e;
+        ChainCounts cc;
+        struct Guard {
+            ChainCounts& c;
+            hipStream_t s;
+            ~Guard() { c.Release(s); }
+        } guard{cc, cs};
+        if ((e = cc.Init(num_scales, cs))) return e;
         Level& L = pyr[(size_t)last];
-        if (voxel_sizes[last] <= 0) {
+        const bool finest_is_input = voxel_sizes[last] <= 0;
+        bool finest_on_host = finest_is_input;
+        if (finest_is_input) {
             L.nt = nt;
             L.tgt_ptr = target_dev;
             L.nrm_ptr = target_normals_dev;
@@ -333,11 +432,12 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                     (e = L.tgtg.Alloc((size_t)nt * 3 * esz)))
                     return e;
             }
-            e = DownSampleAttrs(target_dev, nt, dtype, voxel_sizes[last],
-                                L.tgt.p, &L.nt, cstream,
-                                {{target_normals_dev, L.nrm.p},
-                                 {target_colors_dev, L.tgtc.p},
-                                 {target_gradients_dev, L.tgtg.p}});
+            e = DownSampleAttrsAsync(target_dev, nt, nullptr, dtype,
+                                     voxel_sizes[last], L.tgt.p,
+                                     cc.Count(last), cc.Err(), cc.scratch, cs,
+                                     {{target_normals_dev, L.nrm.p},
+                                      {target_colors_dev, L.tgtc.p},
+                                      {target_gradients_dev, L.tgtg.p}});
             if (e) return e;
             L.tgt_ptr = L.tgt.p;
             L.nrm_ptr = L.nrm.p;  // stays NULL without normals
@@ -346,11 +446,21 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         }
         if (colored && !L.tgtg_ptr) {
             // Registration.cpp:243-262: EstimateColorGradients(30, radius) on
-            // the finest level of the target pyramid.
+            // the finest level of the target pyramid. The operator needs the
+            // level's size on the host: this (rare) path waits here.
+            if (!finest_is_input) {
+                int host_n = 0;
+                O3DMI_HIP_CHECK(hipMemcpyAsync(&host_n, cc.Count(last),
+                                               sizeof(int),
+                                               hipMemcpyDeviceToHost, cs));
+                O3DMI_HIP_CHECK(hipStreamSynchronize(cs));
+                L.nt = host_n;
+                finest_on_host = true;
+            }
             const double radius = voxel_sizes[last] <= 0
                                           ? max_dists[last] * 2.0
                                           : voxel_sizes[last] * 4.0;
-            if ((e = L.tgtg.Alloc((size_t)L.nt * 3 * esz))) return e;
+            if ((e = L.tgtg.Alloc((size_t)nt * 3 * esz))) return e;
             e = o3dmi_pointcloud_estimate_color_gradients(
                     L.tgt_ptr, L.nrm_ptr, L.tgtc_ptr, L.nt, dtype, 30, radius,
                     L.tgtg.p, cstream);
@@ -360,23 +470,33 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         for (int k = num_scales - 2; k >= 0; --k) {
             Level& C = pyr[(size_t)k];
             Level& F = pyr[(size_t)k + 1];
-            if ((e = C.tgt.Alloc((size_t)F.nt * 3 * esz))) return e;
-            if (need_tn && (e = C.nrm.Alloc((size_t)F.nt * 3 * esz))) return e;
+            if ((e = C.tgt.Alloc((size_t)nt * 3 * esz))) return e;
+            if (need_tn && (e = C.nrm.Alloc((size_t)nt * 3 * esz))) return e;
             if (colored) {
-                if ((e = C.tgtc.Alloc((size_t)F.nt * 3 * esz))) return e;
-                if ((e = C.tgtg.Alloc((size_t)F.nt * 3 * esz))) return e;
+                if ((e = C.tgtc.Alloc((size_t)nt * 3 * esz))) return e;
+                if ((e = C.tgtg.Alloc((size_t)nt * 3 * esz))) return e;
             }
-            e = DownSampleAttrs(F.tgt_ptr, F.nt, dtype, voxel_sizes[k], C.tgt.p,
-                                &C.nt, cstream,
-                                {{F.nrm_ptr, C.nrm.p},
-                                 {F.tgtc_ptr, C.tgtc.p},
-                                 {F.tgtg_ptr, C.tgtg.p}});
+            // the finest level's size is a host number when it is the input
+            // itself (or was read back above): then n_max = that size
+            const bool f_host = k + 1 == last && finest_on_host;
+            e = DownSampleAttrsAsync(F.tgt_ptr, f_host ? F.nt : nt,
+                                     f_host ? nullptr : cc.Count(k + 1), dtype,
+                                     voxel_sizes[k], C.tgt.p, cc.Count(k),
+                                     cc.Err(), cc.scratch, cs,
+                                     {{F.nrm_ptr, C.nrm.p},
+                                      {F.tgtc_ptr, C.tgtc.p},
+                                      {F.tgtg_ptr, C.tgtg.p}});
             if (e) return e;
             C.tgt_ptr = C.tgt.p;
             C.nrm_ptr = C.nrm.p;
             C.tgtc_ptr = C.tgtc.p;
             C.tgtg_ptr = C.tgtg.p;
         }
+        std::vector<int> counts;
+        if ((e = cc.Fetch(counts, cs))) return e;
+        for (int k = 0; k < num_scales; ++k)
+            if (!(k == last && finest_is_input))
+                pyr[(size_t)k].nt = counts[(size_t)k];
         return O3DMI_OK;
     };
     // Anything to overlap? (a single level without down-sampling is two
@@ -433,7 +553,8 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
     if (timing) {
         (void)hipStreamSynchronize(s);
         t_mark = now();
-        std::fprintf(stderr, "[o3dmi] icp: pyramid built\n");
+        std::fprintf(stderr, "[o3dmi] icp: pyramid built in %.0f us\n",
+                     t_mark - t_entry);
     }
     const double t_start = t_mark;
 
@@ -570,11 +691,13 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         const o3dmi_icp_criteria_t& crit = criterias[scale_idx];
         for (it = 0; it < crit.max_iteration; ++it) {
             SearchResult r;
+            guard.completed = false;
             if ((st = search(guard.nns, L,
                              symmetric || colored ? (int64_t*)corr_buf.p
                                                   : nullptr,
                              r)))
                 return st;
+            guard.completed = true;  // its sums were read: the search is done
             fitness = r.fitness;
             inlier_rmse = r.inlier_rmse;
             converged = false;

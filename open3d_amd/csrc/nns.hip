@@ -1014,6 +1014,19 @@ int o3dmi_nns_create(const void* points_dev, int64_t n, int dtype,
     return O3DMI_OK;
 }
 
+// Internal (host drivers): the caller knows that every kernel using the index
+// has completed (the ICP driver has read each search's sums through the host
+// mailbox), so the blocks go back to the pool without a device-wide wait.
+int o3dmi_internal_nns_destroy_completed(o3dmi_nns_t* nns) {
+    if (!nns) return O3DMI_OK;
+    PoolFree(nns->sorted_pts);
+    PoolFree(nns->sorted_normals);
+    PoolFree(nns->starts);
+    PoolFree(nns->partials);
+    delete nns;
+    return O3DMI_OK;
+}
+
 int o3dmi_nns_destroy(o3dmi_nns_t* nns) {
     if (!nns) return O3DMI_OK;
     // Searches on this index may still be in flight on any stream.

@@ -15,20 +15,41 @@
 // reproduce them. Instead:
 //   1. hash the voxel keys (packed 64-bit, open addressing) and record each
 //      slot's smallest point index (atomicMin);
-//   2. flag first points, exclusive-scan the flags -> dense voxel ids in
-//      first-occurrence order;
-//   3. stable radix sort of (voxel id, point index): every voxel's points end
-//      up contiguous and still in point order;
+//   2. first points -> dense voxel ids in first-occurrence order (block counts,
+//      then a block-local scan on top of the preceding blocks' counts);
+//   3. STABLE counting sort of the points by voxel id, least-significant
+//      11-bit digit first (per pass: block histograms -> scatter that sums
+//      the (digit, block) table for its own offsets and ranks equal digits by
+//      wave, round and lane); keys are the dense ids, far below 2^22, so this
+//      is two passes -- every voxel's points end up contiguous and still in
+//      point order;
 //   4. one lane per voxel walks its segment and adds sequentially in float32.
-// Scan and sort are rocPRIM primitives (via hipCUB); the rest is below.
+//
+// Nothing in the chain needs a host decision: the point count may live on the
+// device (the output count of the previous, finer level), every kernel bounds
+// itself by it, and the voxel count is left on the device as well. A pyramid
+// of several levels is therefore ONE string of launches with a single read-
+// back at its end (VdsAsync, used by the ICP driver); the public entry point
+// runs one level and reads the count back. The earlier form used a generic
+// radix sort (16 launches) and two host waits per level; at 77 k-point VGA
+// clouds the pyramid took 1.3 ms of a 1.7 ms tracking frame.
 
-#include <hipcub/hipcub.hpp>
+#include <type_traits>
+#include <utility>
+#include <vector>
 
 #include "common.h"
 #include "o3d_mi355x_host.h"
+#include "vds.h"
 
 namespace o3dmi {
 namespace {
+
+constexpr int kSortBits = 11;
+constexpr int kSortBins = 1 << kSortBits;
+constexpr int kSortBlock = 256;             // 4 waves
+constexpr int kSortItems = 8;               // elements per thread
+constexpr int kSortTile = kSortBlock * kSortItems;  // 2048 elements per block
 
 struct VdsTable {
     unsigned long long* keys;  // [n_slots], kEmptyKey when free
@@ -37,16 +58,24 @@ struct VdsTable {
     unsigned mask;
 };
 
+__device__ __forceinline__ int LiveCount(const int* n_dev, int n_host) {
+    if (!n_dev) return n_host;
+    const int n = *n_dev;
+    return n < n_host ? n : n_host;  // never beyond what the buffers hold
+}
+
 template <typename T>
-__global__ void VdsInsertKernel(const T* __restrict__ pos, int64_t n, T vs,
-                                VdsTable tb, int* __restrict__ slot_of_point,
+__global__ void VdsInsertKernel(const T* __restrict__ pos, const int* n_dev,
+                                int n_host, T vs, VdsTable tb,
+                                int* __restrict__ slot_of_point,
                                 int* __restrict__ err) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = LiveCount(n_dev, n_host);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += gridDim.x * blockDim.x) {
         // (p / vs).Floor().To(Int64)
-        const long long cx = (long long)floor(pos[3 * i + 0] / vs);
-        const long long cy = (long long)floor(pos[3 * i + 1] / vs);
-        const long long cz = (long long)floor(pos[3 * i + 2] / vs);
+        const long long cx = (long long)floor(pos[3 * (int64_t)i + 0] / vs);
+        const long long cy = (long long)floor(pos[3 * (int64_t)i + 1] / vs);
+        const long long cz = (long long)floor(pos[3 * (int64_t)i + 2] / vs);
         if (cx < -kKeyBias || cx >= kKeyBias || cy < -kKeyBias ||
             cy >= kKeyBias || cz < -kKeyBias || cz >= kKeyBias) {
             atomicOr(err, kErrKeyRange);
@@ -63,56 +92,258 @@ __global__ void VdsInsertKernel(const T* __restrict__ pos, int64_t n, T vs,
             h = (h + 1) & tb.mask;
         }
         slot_of_point[i] = (int)h;
-        atomicMin(&tb.first[h], (int)i);
+        atomicMin(&tb.first[h], i);
     }
 }
 
-__global__ void VdsFlagKernel(const int* __restrict__ slot_of_point, int64_t n,
-                              VdsTable tb, int* __restrict__ flags) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x)
-        flags[i] = tb.first[slot_of_point[i]] == (int)i ? 1 : 0;
+// Block-wide exclusive prefix of one value per thread (256 threads); returns
+// the prefix, *total = sum over the block.
+__device__ __forceinline__ int BlockExclusive(int v, int* lds4, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) lds4[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kSortBlock / 64; ++w) {
+        const int c = lds4[w];
+        if (w < wave) base += c;
+        tot += c;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
 }
 
-// Dense voxel id of every slot (from its first point), then of every point.
-__global__ void VdsLabelSlotsKernel(const int* __restrict__ slot_of_point,
-                                    const int* __restrict__ flags,
-                                    const int* __restrict__ scan, int64_t n,
-                                    VdsTable tb) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x)
-        if (flags[i]) tb.voxel[slot_of_point[i]] = scan[i];
+// First points per tile of kSortTile points.
+__global__ void VdsCountFirstKernel(const int* __restrict__ slot_of_point,
+                                    const int* n_dev, int n_host, VdsTable tb,
+                                    int* __restrict__ tile_counts) {
+    __shared__ int lds4[4];
+    const int n = LiveCount(n_dev, n_host);
+    const int base = blockIdx.x * kSortTile;
+    if (base >= n) return;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const int i = base + threadIdx.x * kSortItems + k;
+        if (i < n) c += tb.first[slot_of_point[i]] == i;
+    }
+    int total;
+    (void)BlockExclusive(c, lds4, &total);
+    if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
 }
-__global__ void VdsLabelPointsKernel(const int* __restrict__ slot_of_point,
-                                     int64_t n, VdsTable tb,
-                                     int* __restrict__ voxel_of_point,
-                                     int* __restrict__ point_index) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        voxel_of_point[i] = tb.voxel[slot_of_point[i]];
-        point_index[i] = (int)i;
+
+// Dense voxel ids in first-occurrence order: preceding tiles' counts + the
+// tile-local prefix. Tile 0 also publishes the voxel count.
+__global__ void VdsAssignKernel(const int* __restrict__ slot_of_point,
+                                const int* n_dev, int n_host, VdsTable tb,
+                                const int* __restrict__ tile_counts,
+                                int* __restrict__ m_dev) {
+    __shared__ int lds4[4];
+    const int n = LiveCount(n_dev, n_host);
+    const int base = blockIdx.x * kSortTile;
+    if (base >= n && blockIdx.x != 0) return;
+    const int n_tiles = (n + kSortTile - 1) / kSortTile;
+    // counts of the tiles before this one (and of all tiles, for tile 0)
+    int before = 0, all = 0;
+    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+        const int c = tile_counts[t];
+        all += c;
+        if (t < (int)blockIdx.x) before += c;
+    }
+    int tot_before, tot_all;
+    (void)BlockExclusive(before, lds4, &tot_before);
+    (void)BlockExclusive(all, lds4, &tot_all);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *m_dev = tot_all;
+    if (base >= n) return;
+    bool f[kSortItems];
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const int i = base + threadIdx.x * kSortItems + k;
+        f[k] = i < n && tb.first[slot_of_point[i]] == i;
+        c += f[k];
+    }
+    int total;
+    int id = tot_before + BlockExclusive(c, lds4, &total);
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const int i = base + threadIdx.x * kSortItems + k;
+        if (f[k]) tb.voxel[slot_of_point[i]] = id++;
     }
 }
 
-__global__ void VdsSegmentsKernel(const int* __restrict__ sorted_voxel,
-                                  int64_t n, int* __restrict__ seg_start) {
-    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n;
-         j += (int64_t)gridDim.x * blockDim.x) {
+// ---- stable counting sort, one 11-bit digit per pass ------------------------
+// A block owns kSortTile consecutive elements; wave w of the block owns the
+// elements [w * 512, (w + 1) * 512) of the tile, visited in 8 rounds of 64
+// (element = tile + w * 512 + round * 64 + lane), so (block, wave, round, lane)
+// is index order. hist is digit-major: hist[digit * tile_stride + tile].
+
+// kMakeKeys: pass 0 also creates the keys (voxel id of every point) and the
+// values (point indices).
+template <bool kMakeKeys>
+__global__ void __launch_bounds__(kSortBlock)
+SortHistKernel(const int* __restrict__ slot_of_point, VdsTable tb,
+               unsigned* __restrict__ keys, unsigned* __restrict__ vals,
+               const int* n_dev, int n_host, int shift, int tile_stride,
+               int* __restrict__ hist) {
+    __shared__ int h[kSortBins];
+    const int n = LiveCount(n_dev, n_host);
+    const int base = blockIdx.x * kSortTile;
+    if (base >= n) return;
+    for (int b = threadIdx.x; b < kSortBins; b += kSortBlock) h[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const int i = base + k * kSortBlock + threadIdx.x;
+        if (i < n) {
+            unsigned key;
+            if constexpr (kMakeKeys) {
+                key = (unsigned)tb.voxel[slot_of_point[i]];
+                keys[i] = key;
+                vals[i] = (unsigned)i;
+            } else {
+                key = keys[i];
+            }
+            atomicAdd(&h[(key >> shift) & (kSortBins - 1)], 1);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < kSortBins; b += kSortBlock)
+        hist[(int64_t)b * tile_stride + blockIdx.x] = h[b];
+}
+
+__global__ void __launch_bounds__(kSortBlock)
+SortScatterKernel(const unsigned* __restrict__ keys_in,
+                  const unsigned* __restrict__ vals_in,
+                  unsigned* __restrict__ keys_out,
+                  unsigned* __restrict__ vals_out, const int* n_dev, int n_host,
+                  int shift, int tile_stride, const int* __restrict__ hist) {
+    __shared__ int wh[kSortBlock / 64][kSortBins];  // 32 KiB
+    __shared__ int dbase[kSortBins];                // 8 KiB
+    __shared__ int lds4[4];
+    const int n = LiveCount(n_dev, n_host);
+    const int tile = blockIdx.x * kSortTile;
+    if (tile >= n) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int b = threadIdx.x; b < kSortBins * (kSortBlock / 64);
+         b += kSortBlock)
+        (&wh[0][0])[b] = 0;
+    __syncthreads();
+    const int wbase = tile + wave * (kSortItems * 64);
+    unsigned key[kSortItems], val[kSortItems];
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const int e = wbase + r * 64 + lane;
+        key[r] = 0;
+        val[r] = 0;
+        if (e < n) {
+            key[r] = keys_in[e];
+            val[r] = vals_in[e];
+            atomicAdd(&wh[wave][(key[r] >> shift) & (kSortBins - 1)], 1);
+        }
+    }
+    __syncthreads();
+    // Where this tile's run of every digit starts: all elements with a
+    // smaller digit (over all tiles) + the same digit in the tiles before
+    // this one. The (digit, tile) table is small (2048 x a few dozen tiles
+    // for the clouds of a tracking frame), so every block sums what it needs
+    // itself -- two launches fewer per pass than a separate table scan, and
+    // this chain is launch-latency bound. Thread t owns the 8 consecutive
+    // digits 8 t .. 8 t + 7, so that the block prefix is in digit order.
+    {
+        const int n_tiles = (n + kSortTile - 1) / kSortTile;
+        int tot[kSortBins / kSortBlock], before[kSortBins / kSortBlock];
+        int mine = 0;
+#pragma unroll
+        for (int q = 0; q < kSortBins / kSortBlock; ++q) {
+            const int dgt = threadIdx.x * (kSortBins / kSortBlock) + q;
+            const int* row = hist + (int64_t)dgt * tile_stride;
+            int a = 0, bsum = 0;
+            for (int t = 0; t < n_tiles; ++t) {
+                const int c = row[t];
+                a += c;
+                if (t < (int)blockIdx.x) bsum += c;
+            }
+            tot[q] = a;
+            before[q] = bsum;
+            mine += a;
+        }
+        int total;
+        int run = BlockExclusive(mine, lds4, &total);
+#pragma unroll
+        for (int q = 0; q < kSortBins / kSortBlock; ++q) {
+            dbase[threadIdx.x * (kSortBins / kSortBlock) + q] = run + before[q];
+            run += tot[q];
+        }
+    }
+    __syncthreads();
+    // per digit: where each wave's run starts in the output
+    for (int b = threadIdx.x; b < kSortBins; b += kSortBlock) {
+        int off = dbase[b];
+#pragma unroll
+        for (int w = 0; w < kSortBlock / 64; ++w) {
+            const int c = wh[w][b];
+            wh[w][b] = off;
+            off += c;
+        }
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const int e = wbase + r * 64 + lane;
+        const bool valid = e < n;
+        const unsigned d = (key[r] >> shift) & (kSortBins - 1);
+        // lanes of this round holding the same digit
+        unsigned long long same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < kSortBits; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            same &= bit ? bal : ~bal;
+        }
+        int pos = 0;
+        if (valid) pos = wh[wave][d] + __popcll(same & lt);
+        // every lane has read its start; the first lane of each digit group
+        // moves the start past the group (only this wave touches wh[wave])
+        if (valid && (same & lt) == 0ull) wh[wave][d] += __popcll(same);
+        if (valid) {
+            keys_out[pos] = key[r];
+            vals_out[pos] = val[r];
+        }
+    }
+}
+
+__global__ void VdsSegmentsKernel(const unsigned* __restrict__ sorted_voxel,
+                                  const int* n_dev, int n_host,
+                                  int* __restrict__ seg_start) {
+    const int n = LiveCount(n_dev, n_host);
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n;
+         j += gridDim.x * blockDim.x) {
         if (j == 0 || sorted_voxel[j] != sorted_voxel[j - 1])
-            seg_start[sorted_voxel[j]] = (int)j;
-        if (j == n - 1) seg_start[sorted_voxel[j] + 1] = (int)n;
+            seg_start[sorted_voxel[j]] = j;
+        if (j == n - 1) seg_start[sorted_voxel[j] + 1] = n;
     }
 }
 
 template <typename T>
 __global__ void VdsReduceKernel(const T* __restrict__ pos,
                                 const T* __restrict__ nrm,
-                                const int* __restrict__ sorted_point,
-                                const int* __restrict__ seg_start, int64_t m,
+                                const unsigned* __restrict__ sorted_point,
+                                const int* __restrict__ seg_start,
+                                const int* __restrict__ m_dev,
                                 T* __restrict__ out_pos,
                                 T* __restrict__ out_nrm) {
-    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < m;
-         v += (int64_t)gridDim.x * blockDim.x) {
+    const int m = *m_dev;
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < m;
+         v += gridDim.x * blockDim.x) {
         const int b = seg_start[v], e = seg_start[v + 1];
         float cnt = 0.f, sp[3] = {0.f, 0.f, 0.f}, sn[3] = {0.f, 0.f, 0.f};
         for (int j = b; j < e; ++j) {
@@ -126,119 +357,103 @@ __global__ void VdsReduceKernel(const T* __restrict__ pos,
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            out_pos[3 * v + c] = (T)(sp[c] / cnt);
-            if (nrm) out_nrm[3 * v + c] = (T)(sn[c] / cnt);
+            out_pos[3 * (int64_t)v + c] = (T)(sp[c] / cnt);
+            if (nrm) out_nrm[3 * (int64_t)v + c] = (T)(sn[c] / cnt);
         }
     }
 }
 
-struct Scratch {
-    std::vector<void*> ptrs;
-    hipStream_t stream = nullptr;
-    ~Scratch() {
-        // Pooled blocks may only be released once the stream has drained
-        // (already the case on the success path).
-        (void)hipStreamSynchronize(stream);
-        for (void* p : ptrs) PoolFree(p);
-    }
-    template <typename T>
-    int Alloc(T** p, size_t count) {
-        void* q = nullptr;
-        int st_ = PoolAlloc(&q, sizeof(T) * (count ? count : 1));
-        if (st_) return st_;
-        ptrs.push_back(q);
-        *p = (T*)q;
-        return O3DMI_OK;
-    }
-};
-
 template <typename T>
-int VoxelDownSampleImpl(const T* pos, const T* nrm, int64_t n,
-                        double voxel_size, T* out_pos, T* out_nrm,
-                        int64_t* m_out, hipStream_t s) {
-    *m_out = 0;
-    if (n == 0) return O3DMI_OK;
-    O3DMI_REQUIRE(n < (1ll << 31), "VoxelDownSample: too many points");
-    Scratch sc;
-    sc.stream = s;
+int VdsAsyncImpl(const T* pos, const T* nrm, int64_t n_max, const int* n_dev,
+                 double voxel_size, T* out_pos, T* out_nrm, int* m_dev,
+                 int* err_dev, std::vector<void*>& scratch, hipStream_t s) {
+    O3DMI_REQUIRE(n_max > 0 && n_max < (1ll << 30),
+                  "VoxelDownSample: bad point count");
+    auto alloc = [&](auto** p, size_t count) -> int {
+        void* q = nullptr;
+        int e = PoolAlloc(&q, sizeof(**p) * (count ? count : 1));
+        if (e) return e;
+        scratch.push_back(q);
+        *p = (std::remove_reference_t<decltype(**p)>*)q;
+        return O3DMI_OK;
+    };
+    const int n_host = (int)n_max;
     int64_t n_slots = 1024;
-    while (n_slots < 2 * n) n_slots <<= 1;
+    while (n_slots < 2 * n_max) n_slots <<= 1;
+    const int n_tiles = (int)((n_max + kSortTile - 1) / kSortTile);
     VdsTable tb;
     int st;
-    if ((st = sc.Alloc(&tb.keys, (size_t)n_slots))) return st;
-    if ((st = sc.Alloc(&tb.first, (size_t)n_slots))) return st;
-    if ((st = sc.Alloc(&tb.voxel, (size_t)n_slots))) return st;
+    if ((st = alloc(&tb.keys, (size_t)n_slots))) return st;
+    if ((st = alloc(&tb.first, (size_t)n_slots))) return st;
+    if ((st = alloc(&tb.voxel, (size_t)n_slots))) return st;
     tb.mask = (unsigned)(n_slots - 1);
-    int *slot_of_point, *flags, *scan, *voxel_of_point, *point_index,
-            *sorted_voxel, *sorted_point, *seg_start, *err;
-    if ((st = sc.Alloc(&slot_of_point, (size_t)n))) return st;
-    if ((st = sc.Alloc(&flags, (size_t)n + 1))) return st;
-    if ((st = sc.Alloc(&scan, (size_t)n + 1))) return st;
-    if ((st = sc.Alloc(&voxel_of_point, (size_t)n))) return st;
-    if ((st = sc.Alloc(&point_index, (size_t)n))) return st;
-    if ((st = sc.Alloc(&sorted_voxel, (size_t)n))) return st;
-    if ((st = sc.Alloc(&sorted_point, (size_t)n))) return st;
-    if ((st = sc.Alloc(&seg_start, (size_t)n + 2))) return st;
-    if ((st = sc.Alloc(&err, 4))) return st;
+    int *slot_of_point, *tile_counts, *hist, *seg_start;
+    unsigned *keys_a, *vals_a, *keys_b, *vals_b;
+    if ((st = alloc(&slot_of_point, (size_t)n_max))) return st;
+    if ((st = alloc(&tile_counts, (size_t)n_tiles))) return st;
+    if ((st = alloc(&hist, (size_t)kSortBins * n_tiles))) return st;
+    if ((st = alloc(&seg_start, (size_t)n_max + 2))) return st;
+    if ((st = alloc(&keys_a, (size_t)n_max))) return st;
+    if ((st = alloc(&vals_a, (size_t)n_max))) return st;
+    if ((st = alloc(&keys_b, (size_t)n_max))) return st;
+    if ((st = alloc(&vals_b, (size_t)n_max))) return st;
     O3DMI_HIP_CHECK(hipMemsetAsync(tb.keys, 0xFF,
                                    sizeof(unsigned long long) * (size_t)n_slots,
                                    s));
     O3DMI_HIP_CHECK(hipMemsetAsync(tb.first, 0x7F,
                                    sizeof(int) * (size_t)n_slots, s));
-    O3DMI_HIP_CHECK(hipMemsetAsync(err, 0, sizeof(int) * 4, s));
-    O3DMI_HIP_CHECK(hipMemsetAsync(flags + n, 0, sizeof(int), s));
-
-    const dim3 grid(GridFor(n, kBlock)), block(kBlock);
-    hipLaunchKernelGGL(VdsInsertKernel<T>, grid, block, 0, s, pos, n,
-                       (T)voxel_size, tb, slot_of_point, err);
-    hipLaunchKernelGGL(VdsFlagKernel, grid, block, 0, s, slot_of_point, n, tb,
-                       flags);
-    // exclusive scan over n+1 entries: scan[n] = number of voxels
-    size_t tmp_scan = 0, tmp_sort = 0;
-    O3DMI_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(
-            nullptr, tmp_scan, flags, scan, (int)(n + 1), s));
-    O3DMI_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(
-            nullptr, tmp_sort, voxel_of_point, sorted_voxel, point_index,
-            sorted_point, (int)n, 0, 32, s));
-    char* tmp = nullptr;
-    const size_t tmp_bytes = tmp_scan > tmp_sort ? tmp_scan : tmp_sort;
-    if ((st = sc.Alloc(&tmp, tmp_bytes))) return st;
-    size_t tb1 = tmp_bytes;
-    O3DMI_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, tb1, flags, scan,
-                                                     (int)(n + 1), s));
-    int host[2] = {0, 0};
-    O3DMI_HIP_CHECK(hipMemcpyAsync(&host[0], scan + n, sizeof(int),
-                                   hipMemcpyDeviceToHost, s));
-    O3DMI_HIP_CHECK(hipMemcpyAsync(&host[1], err, sizeof(int),
-                                   hipMemcpyDeviceToHost, s));
-    hipLaunchKernelGGL(VdsLabelSlotsKernel, grid, block, 0, s, slot_of_point,
-                       flags, scan, n, tb);
-    hipLaunchKernelGGL(VdsLabelPointsKernel, grid, block, 0, s, slot_of_point,
-                       n, tb, voxel_of_point, point_index);
-    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
-    if (host[1] & kErrKeyRange) {
-        SetLastError("VoxelDownSample: voxel coordinate outside +-2^20");
-        return O3DMI_ERR_KEY_RANGE;
-    }
-    const int64_t m = host[0];
+    const dim3 grid(GridFor(n_max, kBlock)), block(kBlock);
+    const dim3 tiles((unsigned)n_tiles), sblock(kSortBlock);
+    hipLaunchKernelGGL(VdsInsertKernel<T>, grid, block, 0, s, pos, n_dev,
+                       n_host, (T)voxel_size, tb, slot_of_point, err_dev);
+    hipLaunchKernelGGL(VdsCountFirstKernel, tiles, sblock, 0, s, slot_of_point,
+                       n_dev, n_host, tb, tile_counts);
+    hipLaunchKernelGGL(VdsAssignKernel, tiles, sblock, 0, s, slot_of_point,
+                       n_dev, n_host, tb, tile_counts, m_dev);
+    // keys = dense voxel ids < n_max: as many 11-bit passes as they need
     int bits = 1;
-    while ((1ll << bits) < m) ++bits;
-    size_t tb2 = tmp_bytes;
-    O3DMI_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(
-            tmp, tb2, voxel_of_point, sorted_voxel, point_index, sorted_point,
-            (int)n, 0, bits, s));
-    hipLaunchKernelGGL(VdsSegmentsKernel, grid, block, 0, s, sorted_voxel, n,
+    while ((1ll << bits) < n_max) ++bits;
+    const int passes = (bits + kSortBits - 1) / kSortBits;
+    unsigned *ki = keys_a, *vi = vals_a, *ko = keys_b, *vo = vals_b;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = p * kSortBits;
+        if (p == 0)
+            hipLaunchKernelGGL(SortHistKernel<true>, tiles, sblock, 0, s,
+                               slot_of_point, tb, ki, vi, n_dev, n_host, shift,
+                               n_tiles, hist);
+        else
+            hipLaunchKernelGGL(SortHistKernel<false>, tiles, sblock, 0, s,
+                               slot_of_point, tb, ki, vi, n_dev, n_host, shift,
+                               n_tiles, hist);
+        hipLaunchKernelGGL(SortScatterKernel, tiles, sblock, 0, s, ki, vi, ko,
+                           vo, n_dev, n_host, shift, n_tiles, hist);
+        std::swap(ki, ko);
+        std::swap(vi, vo);
+    }
+    hipLaunchKernelGGL(VdsSegmentsKernel, grid, block, 0, s, ki, n_dev, n_host,
                        seg_start);
-    hipLaunchKernelGGL(VdsReduceKernel<T>, dim3(GridFor(m, kBlock)), block, 0,
-                       s, pos, nrm, sorted_point, seg_start, m, out_pos,
-                       out_nrm);
+    hipLaunchKernelGGL(VdsReduceKernel<T>, grid, block, 0, s, pos, nrm, vi,
+                       seg_start, m_dev, out_pos, out_nrm);
     O3DMI_HIP_CHECK(hipGetLastError());
-    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
-    *m_out = m;
     return O3DMI_OK;
 }
 
 }  // namespace
+
+int VdsAsync(const void* pos, const void* attr, int64_t n_max, const int* n_dev,
+             int dtype, double voxel_size, void* out_pos, void* out_attr,
+             int* m_dev, int* err_dev, std::vector<void*>& scratch,
+             hipStream_t s) {
+    if (dtype == O3DMI_F64)
+        return VdsAsyncImpl<double>((const double*)pos, (const double*)attr,
+                                    n_max, n_dev, voxel_size, (double*)out_pos,
+                                    (double*)out_attr, m_dev, err_dev, scratch,
+                                    s);
+    return VdsAsyncImpl<float>((const float*)pos, (const float*)attr, n_max,
+                               n_dev, voxel_size, (float*)out_pos,
+                               (float*)out_attr, m_dev, err_dev, scratch, s);
+}
+
 }  // namespace o3dmi
 
 using namespace o3dmi;
@@ -259,14 +474,37 @@ extern "C" int o3dmi_voxel_down_sample(const void* positions_dev,
     }
     O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
                   "Only Float32 and Float64 point clouds are supported.");
+    *m_out = 0;
+    if (n == 0) return O3DMI_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == O3DMI_F64)
-        return VoxelDownSampleImpl<double>(
-                (const double*)positions_dev, (const double*)normals_dev, n,
-                voxel_size, (double*)out_positions_dev,
-                (double*)out_normals_dev, m_out, s);
-    return VoxelDownSampleImpl<float>(
-            (const float*)positions_dev, (const float*)normals_dev, n,
-            voxel_size, (float*)out_positions_dev, (float*)out_normals_dev,
-            m_out, s);
+    std::vector<void*> scratch;
+    struct Release {
+        std::vector<void*>& v;
+        hipStream_t s;
+        ~Release() {
+            (void)hipStreamSynchronize(s);  // pooled blocks: stream drained
+            for (void* p : v) PoolFree(p);
+        }
+    } release{scratch, s};
+    int* counts = nullptr;  // {voxel count, error flags}
+    void* q = nullptr;
+    int st = PoolAlloc(&q, sizeof(int) * 4);
+    if (st) return st;
+    scratch.push_back(q);
+    counts = (int*)q;
+    O3DMI_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int) * 4, s));
+    st = VdsAsync(positions_dev, normals_dev, n, nullptr, dtype, voxel_size,
+                  out_positions_dev, out_normals_dev, counts, counts + 1,
+                  scratch, s);
+    if (st) return st;
+    int host[2] = {0, 0};
+    O3DMI_HIP_CHECK(hipMemcpyAsync(host, counts, sizeof(host),
+                                   hipMemcpyDeviceToHost, s));
+    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    if (host[1] & kErrKeyRange) {
+        SetLastError("VoxelDownSample: voxel coordinate outside +-2^20");
+        return O3DMI_ERR_KEY_RANGE;
+    }
+    *m_out = host[0];
+    return O3DMI_OK;
 }

@@ -10,9 +10,18 @@
 // straight into the range map with integer atomics on the float bit patterns;
 // no fragment buffer, no overflow case, same result.
 //
-// RayCast: one lane per pixel; the per-ray arithmetic is the reference's. The
-// hash lookup is the open-addressing probe of block_hash.hip (packed 64-bit
-// key compare), guarded by the same 1-entry block cache the reference keeps.
+// RayCast: one lane per pixel with the reference's per-ray arithmetic, laid out
+// for the memory system instead of for the image: a wave owns an 8 x 8 pixel
+// tile (a workgroup 32 x 8), so its 64 rays stay within one or two voxel
+// blocks and their voxel loads fall into a handful of cache lines (a 1 x 64
+// pixel strip spreads over ~20 cm of surface and three blocks); the 8 x 8 tile
+// is also exactly one cell of the range map (down factor 8), so the whole wave
+// marches the same depth interval. Block look-ups go through three levels: the
+// 1-entry register cache the reference keeps, a workgroup-shared table in LDS
+// (256 entries, one 64-bit word each, absent blocks included -- free space is
+// where most look-ups happen), and only then the open-addressing probe of
+// block_hash.hip in HBM. The trilinear neighbourhood is fetched as a batch
+// (8 weights, then 8 tsdf and 24 colour values in flight together).
 
 #include "common.h"
 
@@ -126,6 +135,61 @@ __device__ __forceinline__ int SignI(int x) {
     return (x > 0) ? 1 : ((x < 0) ? -1 : 0);
 }
 
+// Workgroup-shared block table in LDS. One 64-bit word per entry:
+//   bit 63      valid
+//   bits 56-32  block key relative to the table's origin, 3 x 8 bits biased
+//               by 128 (|offset| < 128 blocks; farther blocks bypass the
+//               table)
+//   bits 31-0   buffer index + 1 (0 = the block does not exist)
+// A word is written with one ds_write_b64, so an entry is never torn; a
+// colliding key simply replaces the entry (it is a cache: a miss falls back
+// to the hash map in HBM).
+constexpr int kLdsBlocks = 256;
+struct LdsBlockTable {
+    unsigned long long* e;  // [kLdsBlocks] in LDS
+    int ox, oy, oz;         // origin block (wave-uniform)
+
+    __device__ __forceinline__ bool Encode(int x, int y, int z,
+                                           unsigned& rel) const {
+        const unsigned dx = (unsigned)(x - ox + 128);
+        const unsigned dy = (unsigned)(y - oy + 128);
+        const unsigned dz = (unsigned)(z - oz + 128);
+        rel = (dx << 16) | (dy << 8) | dz;
+        return (dx | dy | dz) < 256u;
+    }
+    __device__ __forceinline__ unsigned Slot(unsigned rel) const {
+        return (rel * 0x9E3779B1u) >> 24;  // 8 bits
+    }
+    // buffer index, -1 = known absent, -2 = not in the table
+    __device__ __forceinline__ int Lookup(unsigned rel) const {
+        const unsigned long long w = e[Slot(rel)];
+        if ((unsigned)(w >> 32) != (0x80000000u | rel)) return -2;
+        return (int)(unsigned)w - 1;
+    }
+    __device__ __forceinline__ void Store(unsigned rel, int buf_idx) {
+        e[Slot(rel)] = ((unsigned long long)(0x80000000u | rel) << 32) |
+                       (unsigned)(buf_idx + 1);
+    }
+};
+
+// Block look-up through register cache -> LDS table -> hash map.
+__device__ __forceinline__ int FindBlock(const HashView& hv,
+                                         LdsBlockTable& tab, BlockCache& cache,
+                                         int x_b, int y_b, int z_b) {
+    int idx = cache.Check(x_b, y_b, z_b);
+    if (idx >= 0) return idx;
+    unsigned rel;
+    const bool in_table = tab.Encode(x_b, y_b, z_b, rel);
+    if (in_table) idx = tab.Lookup(rel);
+    else idx = -2;
+    if (idx == -2) {
+        idx = hv.Find(x_b, y_b, z_b);
+        if (in_table) tab.Store(rel, idx);
+    }
+    if (idx >= 0) cache.Update(x_b, y_b, z_b, idx);
+    return idx;
+}
+
 // FULL = the per-neighbour maps (index / mask / interp_ratio*) are requested.
 // The common depth / vertex / colour / normal rendering (slam::Model) runs the
 // slim instantiation: without the 8-entry output arrays it needs half the
@@ -136,7 +200,7 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
               const weight_t* __restrict__ weight_base,
               const color_t* __restrict__ color_base,
               const float* __restrict__ range_map) {
-    const int64_t n = (int64_t)p.h * p.w;
+    __shared__ unsigned long long lds_blocks[kLdsBlocks];
     const int res = p.block_resolution;
     const int res2 = res * res;
     const int res3 = res2 * res;
@@ -144,11 +208,32 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
     const bool visit_neighbors = render_color || p.normal || p.mask ||
                                  p.index || p.ratio || p.ratio_dx ||
                                  p.ratio_dy || p.ratio_dz;
+    // Workgroup tile 32 x 8 pixels, wave tile 8 x 8.
+    const int tiles_x = (p.w + 31) / 32;
+    const int tiles_y = (p.h + 7) / 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    LdsBlockTable tab;
+    tab.e = lds_blocks;
+    // Table origin: the block under the camera centre's first sample does not
+    // matter, any block near the frustum does -- the camera's own block.
+    {
+        float x_o, y_o, z_o;
+        p.c2w.RigidTransform(0, 0, 0, x_o, y_o, z_o);
+        tab.ox = (int)floorf(x_o / p.block_size);
+        tab.oy = (int)floorf(y_o / p.block_size);
+        tab.oz = (int)floorf(z_o / p.block_size);
+    }
 
-    for (int64_t workload_idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-         workload_idx < n; workload_idx += (int64_t)gridDim.x * blockDim.x) {
-        const int y = (int)(workload_idx / p.w);
-        const int x = (int)(workload_idx % p.w);
+    for (int tile = blockIdx.x; tile < tiles_x * tiles_y; tile += gridDim.x) {
+        __syncthreads();  // the previous tile's readers are done
+        for (int k = threadIdx.x; k < kLdsBlocks; k += blockDim.x)
+            lds_blocks[k] = 0ull;
+        __syncthreads();
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int x = tx * 32 + wave * 8 + (lane & 7);
+        const int y = ty * 8 + (lane >> 3);
+        if (x >= p.w || y >= p.h) continue;
+        const int64_t workload_idx = (int64_t)y * p.w + x;
         const float* range =
                 range_map + 2 * ((int64_t)(y / p.range_down) * p.w_down +
                                  (x / p.range_down));
@@ -204,12 +289,8 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
                 int x_b = (int)floorf(xg / p.block_size);
                 int y_b = (int)floorf(yg / p.block_size);
                 int z_b = (int)floorf(zg / p.block_size);
-                int block_buf_idx = cache.Check(x_b, y_b, z_b);
-                if (block_buf_idx < 0) {
-                    block_buf_idx = hv.Find(x_b, y_b, z_b);
-                    if (block_buf_idx >= 0)
-                        cache.Update(x_b, y_b, z_b, block_buf_idx);
-                }
+                const int block_buf_idx =
+                        FindBlock(hv, tab, cache, x_b, y_b, z_b);
                 if (block_buf_idx < 0) {
                     t_prev = t;
                     t += p.block_size;
@@ -255,12 +336,8 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
                     x_v = (x_g - (float)x_b * p.block_size) / p.voxel_size;
                     y_v = (y_g - (float)y_b * p.block_size) / p.voxel_size;
                     z_v = (z_g - (float)z_b * p.block_size) / p.voxel_size;
-                    block_buf_idx = cache.Check(x_b, y_b, z_b);
-                    if (block_buf_idx < 0) {
-                        block_buf_idx = hv.Find(x_b, y_b, z_b);
-                        if (block_buf_idx < 0) go = false;
-                        else cache.Update(x_b, y_b, z_b, block_buf_idx);
-                    }
+                    block_buf_idx = FindBlock(hv, tab, cache, x_b, y_b, z_b);
+                    if (block_buf_idx < 0) go = false;
                 }
                 if (go) {
                     int x_v_floor = (int)floorf(x_v);
@@ -296,20 +373,29 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
                         } else {
                             const int kx = x_b + dx_b, ky = y_b + dy_b,
                                       kz = z_b + dz_b;
-                            int nb = cache.Check(kx, ky, kz);
-                            if (nb < 0) {
-                                nb = hv.Find(kx, ky, kz);
-                                if (nb >= 0) cache.Update(kx, ky, kz, nb);
-                            }
+                            const int nb =
+                                    FindBlock(hv, tab, cache, kx, ky, kz);
                             lin[k] = nb < 0 ? -1
                                             : (int64_t)nb * res3 + z_vn * res2 +
                                                       y_vn * res + x_vn;
                         }
                     }
                     weight_t wk[8];
+                    float tk[8];
+                    color_t ck[8][3];
 #pragma unroll
                     for (int k = 0; k < 8; ++k)
                         wk[k] = lin[k] >= 0 ? weight_base[lin[k]] : (weight_t)0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        tk[k] = (normal_ptr && lin[k] >= 0) ? tsdf_base[lin[k]]
+                                                            : 0.0f;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            ck[k][c] = (render_color && lin[k] >= 0)
+                                               ? color_base[lin[k] * 3 + c]
+                                               : (color_t)0;
+                    }
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         const int dx_v = (k & 1) > 0 ? 1 : 0;
@@ -342,16 +428,15 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
                             }
 
                             if (normal_ptr) {
-                                float tsdf_k = tsdf_base[linear_idx_k];
+                                float tsdf_k = tk[k];
                                 out_normal[0] += rdx * tsdf_k;
                                 out_normal[1] += rdy * tsdf_k;
                                 out_normal[2] += rdz * tsdf_k;
                             }
                             if (render_color) {
-                                int64_t ci = linear_idx_k * 3;
-                                out_color[0] += r * (float)color_base[ci + 0];
-                                out_color[1] += r * (float)color_base[ci + 1];
-                                out_color[2] += r * (float)color_base[ci + 2];
+                                out_color[0] += r * (float)ck[k][0];
+                                out_color[1] += r * (float)ck[k][1];
+                                out_color[2] += r * (float)ck[k][2];
                             }
                             sum_r += r;
                         }
@@ -516,8 +601,9 @@ int o3dmi_vbg_raycast(o3dmi_hash_t* block_hash, const float* tsdf_dev,
     p.ratio_dy = out_ratio_dy;
     p.ratio_dz = out_ratio_dz;
     hipStream_t s = (hipStream_t)stream;
-    int64_t n = (int64_t)h * w;
-    dim3 grid(GridFor(n, kBlock, kCUs * 16)), block(kBlock);
+    // one workgroup per 32 x 8 pixel tile (grid-strided beyond 16 per CU)
+    const int64_t n_tiles = (int64_t)((w + 31) / 32) * ((h + 7) / 8);
+    dim3 grid(GridFor(n_tiles, 1, kCUs * 16)), block(kBlock);
     const bool full = out_index || out_mask || out_ratio || out_ratio_dx ||
                       out_ratio_dy || out_ratio_dz;
 #define O3DMI_RAYCAST(WT, CT, FULL)                                           \

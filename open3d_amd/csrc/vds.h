@@ -1,0 +1,25 @@
+// Internal interface of the device-count VoxelDownSample (pointcloud.hip): one
+// pyramid level as a string of launches with no host wait, so that the ICP
+// driver can chain the levels of a cloud and read all counts back at once.
+#pragma once
+
+#include <vector>
+
+#include "common.h"
+
+namespace o3dmi {
+
+// positions {n,3} (+ optional attribute {n,3}, averaged the same way) of
+// dtype O3DMI_F32 / O3DMI_F64 -> out_pos / out_attr, sized for n_max rows.
+//   n_dev   device int holding the live point count (<= n_max), or NULL to
+//           use n_max itself
+//   m_dev   device int receiving the voxel count
+//   err_dev device int: kErrKeyRange is OR-ed in for out-of-range coordinates
+// Scratch comes from the pool and is appended to `scratch`; the caller
+// releases it (PoolFree) once the stream has drained.
+int VdsAsync(const void* pos, const void* attr, int64_t n_max, const int* n_dev,
+             int dtype, double voxel_size, void* out_pos, void* out_attr,
+             int* m_dev, int* err_dev, std::vector<void*>& scratch,
+             hipStream_t s);
+
+}  // namespace o3dmi

@@ -887,8 +887,26 @@ def test_color_gradients_vs_reference_body(dtype):
     if dtype == np.float32:
         assert fin.all()
     else:
-        assert fin.mean() > 0.5
+        # the reference's Float64 solve (32-bit masks applied to doubles)
+        # returns NaN on most neighbourhoods of this cloud: 16 % finite
+        assert fin.mean() > 0.05
     scale = np.median(np.linalg.norm(got, axis=1))
+    if dtype == np.float64:
+        # no tolerance is meaningful here: the reference's Float64 routine is
+        # not an SVD of its input -- where it is finite
+        # it is off by the size of the gradient itself. The product's Float64
+        # result is checked against the Float32 reference body instead (same
+        # neighbour lists, well-conditioned points).
+        p32, _, tc32 = _colored_pair(8000, 51, np.float32)
+        ref32 = orc.estimate_color_gradients(
+            p32["target"], p32["target_normals"], tc32, idx, cnt,
+            exact_solve=False)
+        e64 = np.abs(got - ref32).max(1) / scale
+        print("color gradients (float64 product vs float32 reference body): "
+              "median %.3g; reference float64 body finite on %.1f %%"
+              % (np.median(e64[cnt >= 10]), 100 * fin.mean()))
+        assert np.median(e64[cnt >= 10]) < 1e-3
+        return
     err = np.abs(got - ref_body)[fin].max(1) / scale
     well = (cnt >= 10)[fin]
     med, p99 = np.median(err[well]), np.percentile(err[well], 99)
@@ -1131,7 +1149,8 @@ def test_color_gradients_radius_variant():
     radius = 0.4
     idx, _, cnt = orc.hybrid_search(pts, pts, radius, 400)
     assert 64 < cnt.max() < 400
-    want = orc.estimate_color_gradients(pts, nrm, tc, idx, cnt)
+    want = orc.estimate_color_gradients(pts, nrm, tc, idx, cnt,
+                                        exact_solve=True)
     got = reg.estimate_color_gradients(
         torch.from_numpy(pts).cuda(), torch.from_numpy(nrm).cuda(),
         torch.from_numpy(tc).cuda(), None, radius).cpu().numpy()

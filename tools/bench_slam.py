@@ -125,6 +125,17 @@ def mode_icp(a):
     return out
 
 
+def _voxel_centres(points, voxel):
+    """One representative point per occupied voxel (what VoxelDownSample leaves
+    of a cloud, up to the position inside the voxel)."""
+    p = np.asarray(points, np.float64)
+    if voxel <= 0:
+        return p
+    k = np.floor(p / voxel).astype(np.int64)
+    _, first = np.unique(k, axis=0, return_index=True)
+    return p[np.sort(first)]
+
+
 def mean_visited_records(target, queries, radius, sample=4000):
     """Average number of index records in the 27 cells (edge = radius) around a
     query -- the 'visited records' of SURVEY 8(d), counted on the host."""
@@ -267,20 +278,38 @@ def mode_slam(a):
             [float(x) for x in phase / (n - 1) * 1e3]
     out["source_points"] = int(src.shape[0])
     out["target_points"] = int(tp.shape[0])
-    # SURVEY 8(d) accounting of the ICP leg on the finest level's clouds
-    # (points x iterations x bytes over the whole frame time: a lower bound)
+    # SURVEY 8(d) accounting of the ICP leg, level by level on the last
+    # frame's clouds: points of the level (one per occupied voxel of
+    # VoxelDownSample) x iterations the level ran (replayed once with the
+    # iteration callback) x bytes per point-iteration (12 B query + 27 bucket
+    # heads + visited records x 16 B + 44 B accumulate + 24 B transform).
+    # Divided by the WHOLE frame time (track + integrate + ray cast), so the
+    # fraction is a lower bound for the search kernel's own.
     src_np, tp_np, tn_np = (t.cpu().numpy() for t in (src, tp, tn))
-    visited = mean_visited_records(tp_np, src_np, md[-1])
-    unit = 12 + 27 * 8 + visited * 16 + 44 + 24
-    it_pf = iters / (n - 1)
-    gbs = src_np.shape[0] * it_pf * unit / (dt / (n - 1)) / 1e9
-    out["roofline"] = {"bound": "hbm", "unit": "GB/s",
-                       "bytes_per_point_iteration": unit,
-                       "visited_records_per_query": visited,
+    log = []
+    reg.multi_scale_icp(src, tp, tn, vs, crit, md,
+                        callback_after_iteration=log.append)
+    per_level = []
+    frame_bytes = 0.0
+    for li, (v, r) in enumerate(zip(vs, md)):
+        its = sum(1 for e in log if e["scale_index"] == li)
+        sd = _voxel_centres(src_np, v)
+        td = _voxel_centres(tp_np, v)
+        visited = mean_visited_records(td, sd, r)
+        unit = 12 + 27 * 8 + visited * 16 + 44 + 24
+        frame_bytes += sd.shape[0] * its * unit
+        per_level.append({"voxel": v, "source_points": int(sd.shape[0]),
+                          "target_points": int(td.shape[0]),
+                          "iterations": its,
+                          "visited_records_per_query": visited,
+                          "bytes_per_point_iteration": unit})
+    gbs = frame_bytes / (dt / (n - 1)) / 1e9
+    out["roofline"] = {"bound": "hbm", "unit": "GB/s", "levels": per_level,
+                       "icp_bytes_per_frame": frame_bytes,
                        "achieved": gbs, "peak": 8000.0, "frac": gbs / 8000.0,
-                       "basis": "finest-level cloud size x all iterations "
-                                "over the whole frame time (track + "
-                                "integrate + ray cast): a lower bound"}
+                       "basis": "last frame's per-level sizes and iteration "
+                                "counts over the mean whole-frame time (track "
+                                "+ integrate + ray cast): a lower bound"}
     if getattr(a, "cpu_frames", 0) > 0:
         import _oracle as orc
         orc.set_threads(min(64, os.cpu_count() or 1))
