@@ -23,6 +23,10 @@
 // block_hash.hip in HBM. The trilinear neighbourhood is fetched as a batch
 // (8 weights, then 8 tsdf and 24 colour values in flight together).
 
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
 #include "common.h"
 
 namespace o3dmi {
@@ -119,6 +123,7 @@ struct RayCastParams {
     long long* index;
     uint8_t* mask;
     float *ratio, *ratio_dx, *ratio_dy, *ratio_dz;
+    int* steps;  // diagnostics (O3DMI_RAYCAST_STEPS=1): march steps per pixel
 };
 
 struct BlockCache {
@@ -281,7 +286,9 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
 
             BlockCache cache{0, 0, 0, -1};
             bool surface_found = false;
+            int n_steps = 0;
             while (t < t_max) {
+                ++n_steps;
                 // GetLinearIdxAtT, VoxelBlockGridImpl.h:784-823
                 float xg = x_o + t * x_d;
                 float yg = y_o + t * y_d;
@@ -314,6 +321,7 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
                 }
             }
 
+            if (p.steps) p.steps[workload_idx] = n_steps;
             if (surface_found) {
                 float t_intersect =
                         (t * tsdf_prev - t_prev * tsdf) / (tsdf_prev - tsdf);
@@ -601,6 +609,12 @@ int o3dmi_vbg_raycast(o3dmi_hash_t* block_hash, const float* tsdf_dev,
     p.ratio_dy = out_ratio_dy;
     p.ratio_dz = out_ratio_dz;
     hipStream_t s = (hipStream_t)stream;
+    p.steps = nullptr;
+    static const bool count_steps = std::getenv("O3DMI_RAYCAST_STEPS") != nullptr;
+    if (count_steps) {
+        O3DMI_HIP_CHECK(hipMalloc((void**)&p.steps, sizeof(int) * (size_t)h * w));
+        O3DMI_HIP_CHECK(hipMemsetAsync(p.steps, 0, sizeof(int) * (size_t)h * w, s));
+    }
     // one workgroup per 32 x 8 pixel tile (grid-strided beyond 16 per CU)
     const int64_t n_tiles = (int64_t)((w + 31) / 32) * ((h + 7) / 8);
     dim3 grid(GridFor(n_tiles, 1, kCUs * 16)), block(kBlock);
@@ -619,6 +633,36 @@ int o3dmi_vbg_raycast(o3dmi_hash_t* block_hash, const float* tsdf_dev,
     }
 #undef O3DMI_RAYCAST
     O3DMI_HIP_CHECK(hipGetLastError());
+    if (count_steps) {
+        std::vector<int> hs((size_t)h * w);
+        O3DMI_HIP_CHECK(hipMemcpyAsync(hs.data(), p.steps, sizeof(int) * hs.size(),
+                                       hipMemcpyDeviceToHost, s));
+        O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+        (void)hipFree(p.steps);
+        // per-pixel and per-8x8-tile (= per wave) statistics
+        long long sum = 0, wsum = 0;
+        int mx = 0, nw = 0, wmax_max = 0;
+        for (int v : hs) { sum += v; mx = v > mx ? v : mx; }
+        std::vector<int> wmaxes;
+        for (int ty = 0; ty < h / 8; ++ty)
+            for (int tx = 0; tx < w / 8; ++tx) {
+                int m = 0;
+                for (int dy = 0; dy < 8; ++dy)
+                    for (int dx = 0; dx < 8; ++dx) {
+                        const int v = hs[(size_t)(ty * 8 + dy) * w + tx * 8 + dx];
+                        m = v > m ? v : m;
+                    }
+                wsum += m; ++nw; wmax_max = m > wmax_max ? m : wmax_max;
+                wmaxes.push_back(m);
+            }
+        std::sort(wmaxes.begin(), wmaxes.end());
+        std::fprintf(stderr,
+                     "[o3dmi] raycast steps: mean per ray %.1f, max %d; per "
+                     "wave tile: mean of max %.1f, p50 %d, p90 %d, p99 %d, max %d\n",
+                     (double)sum / hs.size(), mx, (double)wsum / nw,
+                     wmaxes[wmaxes.size() / 2], wmaxes[wmaxes.size() * 9 / 10],
+                     wmaxes[wmaxes.size() * 99 / 100], wmax_max);
+    }
     return O3DMI_OK;
 }
 

@@ -1267,9 +1267,8 @@ def _icp_two_process_rank(rank, world):
     r = reg.multi_scale_icp(
         torch.from_numpy(p["source"][b:e]).cuda(),
         torch.from_numpy(p["target"]).cuda(),
-        torch.from_numpy(p["target_normals"]).cuda(), [-1.0, -1.0],
-        [reg.ICPConvergenceCriteria(1e-6, 1e-6, 10),
-         reg.ICPConvergenceCriteria(1e-6, 1e-6, 20)], [0.1, 0.07],
+        torch.from_numpy(p["target_normals"]).cuda(), [-1.0],
+        [reg.ICPConvergenceCriteria(1e-6, 1e-6, 30)], [0.07],
         device_allreduce=make_device_allreduce(dist))
     torch.cuda.synchronize()
     return (r.transformation, r.num_iterations, r.fitness, r.inlier_rmse,
@@ -1283,16 +1282,16 @@ def test_icp_source_sharded_two_processes_device_allreduce():
     transport otherwise), the per-iteration exchange through the driver's
     DEVICE all-reduce hook (final sum -> tail -> collective on the launch
     stream -> post kernel -> host mailbox). Both ranks end with the unsharded
-    pose."""
+    pose (single scale: a down-sampled level would average each shard's voxels
+    separately, which is a different -- equally valid -- coarse cloud)."""
     from test_sharding import _run
     _lib, reg = _gpu()
     p = _pair(20000, seed=7, dtype=np.float32)
     one = reg.multi_scale_icp(
         torch.from_numpy(p["source"]).cuda(),
         torch.from_numpy(p["target"]).cuda(),
-        torch.from_numpy(p["target_normals"]).cuda(), [-1.0, -1.0],
-        [reg.ICPConvergenceCriteria(1e-6, 1e-6, 10),
-         reg.ICPConvergenceCriteria(1e-6, 1e-6, 20)], [0.1, 0.07])
+        torch.from_numpy(p["target_normals"]).cuda(), [-1.0],
+        [reg.ICPConvergenceCriteria(1e-6, 1e-6, 30)], [0.07])
     backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
     got = _run(_icp_two_process_rank, backend=backend)
     assert got[0][4] == backend
