@@ -67,7 +67,7 @@ struct o3dmi_vbg {
     int* prep_row = nullptr;
     std::vector<int> prep_host;
     double prep_key[24] = {0};
-    bool prep_valid = false, prep_div_short = false;
+    bool prep_valid = false, prep_div_short = false, prep_identity = false;
     int last_count = 1024;
     // Which path integrated the most recent frame (for
     // o3dmi_vbg_export_last_frame_blocks): 0 none, 1 frame-stream, 2 generic.
@@ -643,6 +643,11 @@ static int EnsurePrepTables(o3dmi_vbg* g, const double* dk, const double* ck,
     g->prep_div_short =
             PrepTables(dk, ck, rows, cols, crows, ccols, depth_scale,
                        g->prep_host.data(), g->prep_host.data() + cols);
+    g->prep_identity = crows == rows && ccols == cols;
+    for (int u = 0; u < cols && g->prep_identity; ++u)
+        g->prep_identity = g->prep_host[(size_t)u] == u;
+    for (int v = 0; v < rows && g->prep_identity; ++v)
+        g->prep_identity = g->prep_host[(size_t)cols + (size_t)v] == v;
     O3DMI_HIP_CHECK(hipMemcpyAsync(g->prep_col, g->prep_host.data(),
                                    sizeof(int) * (size_t)(rows + cols),
                                    hipMemcpyHostToDevice, s));
@@ -814,6 +819,7 @@ static StreamGroup MakeGroup(o3dmi_vbg* g, const StreamCommon& c,
         a.col_lut = g->prep_valid ? g->prep_col : nullptr;
         a.row_lut = g->prep_valid ? g->prep_row : nullptr;
         a.depth_div_short = g->prep_valid && g->prep_div_short;
+        a.prep_identity = g->prep_valid && g->prep_identity;
         a.recs = g->recs[par][f];
         a.list = g->lists[par];
         a.list_capacity = g->lists_capacity;

@@ -69,6 +69,7 @@ struct FrameFrontArgs {
     const int* col_lut;
     const int* row_lut;
     bool depth_div_short;
+    bool prep_identity;   // col_lut[u] == u and row_lut[v] == v everywhere
     PixelRec* recs;       // {rows, cols} out, + 1 sentinel record {0, 0}
     FrameBlock* list;     // the group's list (shared by its frames)
     int64_t list_capacity;

@@ -46,6 +46,9 @@ struct PrepParams {
     bool with_color;
 };
 
+// LDS key set of one 16 x 16 ray tile (<= 1024 candidates).
+constexpr int kTileKeys = 2048;
+
 struct FrontParams {
     TouchParams p;
     PrepParams pp;
@@ -54,6 +57,7 @@ struct FrontParams {
     const int* col_lut;
     const int* row_lut;
     bool depth_div_short;
+    bool prep_identity;     // tables are the identity, cols % 4 == 0
     float inv_depth_scale;  // RN(1 / depth_scale)
     PixelRec* recs;
     FrameBlock* list;
@@ -79,41 +83,72 @@ __device__ __forceinline__ void FrontRole(const HashView& hv,
     FrameBlock* __restrict__ list = fp.list;
     const int n_touch_wg = fp.n_touch_wg;
     if (wg < n_touch_wg) {
-        int n = p.rows_strided * p.cols_strided;
-        int n_padded = ((n + 63) / 64) * 64;
-        for (int w = wg * blockDim.x + threadIdx.x; w < n_padded;
-             w += n_touch_wg * blockDim.x) {
+        // Block touch of a 16 x 16 tile of rays (DepthTouchCPU,
+        // VoxelBlockGridCPU.cpp:144-180). The ~1000 candidate keys of a tile
+        // are a few dozen distinct blocks: they are de-duplicated in an LDS
+        // set first (LDS atomics, ~100 ns), and only the distinct keys go
+        // through the chain of global atomics -- insert into the block hash,
+        // frame bit in the touch word, list append -- one lane per key, all
+        // keys of the tile in flight together. (One lane per ray walked that
+        // chain four times in sequence, behind a wave-wide leader election
+        // per candidate: ~20 us per wave, as long as the whole integrate
+        // sweep it is supposed to hide behind.)
+        __shared__ unsigned long long tile_keys[kTileKeys];
+        for (int e = threadIdx.x; e < kTileKeys; e += blockDim.x)
+            tile_keys[e] = kEmptyKey;
+        __syncthreads();
+        const int tiles_x = (p.cols_strided + 15) >> 4;
+        const int ty = wg / tiles_x, tx = wg - ty * tiles_x;
+        const int rx = tx * 16 + (threadIdx.x & 15);
+        const int ry = ty * 16 + (threadIdx.x >> 4);
+        if (rx < p.cols_strided && ry < p.rows_strided) {
             int xb[4], yb[4], zb[4];
-            bool valid = (w < n) && RayCandidates(p, depth, w, xb, yb, zb);
+            if (RayCandidates(p, depth, ry * p.cols_strided + rx, xb, yb, zb)) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                bool ok = valid;
-                if (ok && s > 0 && xb[s] == xb[s - 1] && yb[s] == yb[s - 1] &&
-                    zb[s] == zb[s - 1])
-                    ok = false;
-                if (ok && !KeyInRange(xb[s], yb[s], zb[s])) {
-                    atomicOr(&hv.counters[1], kErrKeyRange);
-                    ok = false;
-                }
-                unsigned long long k = ok ? PackKey(xb[s], yb[s], zb[s]) : 0ull;
-                if (ok && !hv.Owns(k)) ok = false;  // another rank's block
-                if (WaveLeaderForKey(k, ok)) {
-                    unsigned slot;
-                    InsertKey<true>(hv, xb[s], yb[s], zb[s], slot);
-                    if (TouchSlot(hv, slot, fp.group_stamp, fp.group_bit,
-                                  fp.touch_plane)) {
-                        int o = atomicAdd(fp.out_count, 1);
-                        if (o < fp.list_capacity) {
-                            FrameBlock fb;
-                            fb.slot = (int)slot;
-                            fb.x = xb[s];
-                            fb.y = yb[s];
-                            fb.z = zb[s];
-                            list[o] = fb;
-                        } else {
-                            atomicOr(&hv.counters[1], kErrCapacity);
-                        }
+                for (int s = 0; s < 4; ++s) {
+                    if (s > 0 && xb[s] == xb[s - 1] && yb[s] == yb[s - 1] &&
+                        zb[s] == zb[s - 1])
+                        continue;
+                    if (!KeyInRange(xb[s], yb[s], zb[s])) {
+                        atomicOr(&hv.counters[1], kErrKeyRange);
+                        continue;
                     }
+                    const unsigned long long k = PackKey(xb[s], yb[s], zb[s]);
+                    if (!hv.Owns(k)) continue;  // another rank's block
+                    unsigned h = HashKey(k) & (kTileKeys - 1);
+                    while (true) {  // <= 1024 keys in 2048 slots: terminates
+                        unsigned long long cur = tile_keys[h];
+                        if (cur == k) break;
+                        if (cur == kEmptyKey) {
+                            cur = atomicCAS(&tile_keys[h], kEmptyKey, k);
+                            if (cur == kEmptyKey || cur == k) break;
+                        }
+                        h = (h + 1) & (kTileKeys - 1);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < kTileKeys; e += blockDim.x) {
+            const unsigned long long k = tile_keys[e];
+            if (k == kEmptyKey) continue;
+            const int x = (int)((k >> 42) & 0x1FFFFFull) - kKeyBias;
+            const int y = (int)((k >> 21) & 0x1FFFFFull) - kKeyBias;
+            const int z = (int)(k & 0x1FFFFFull) - kKeyBias;
+            unsigned slot;
+            InsertKey<true>(hv, x, y, z, slot);
+            if (TouchSlot(hv, slot, fp.group_stamp, fp.group_bit,
+                          fp.touch_plane)) {
+                int o = atomicAdd(fp.out_count, 1);
+                if (o < fp.list_capacity) {
+                    FrameBlock fb;
+                    fb.slot = (int)slot;
+                    fb.x = x;
+                    fb.y = y;
+                    fb.z = z;
+                    list[o] = fb;
+                } else {
+                    atomicOr(&hv.counters[1], kErrCapacity);
                 }
             }
         }
@@ -129,6 +164,73 @@ __device__ __forceinline__ void FrontRole(const HashView& hv,
         r.d = 0.0f;
         r.rgba = 0u;
         recs[n_px] = r;
+    }
+    if (fp.col_lut && fp.prep_identity) {
+        // Identity form (the tables map every depth pixel onto the colour
+        // pixel of the same coordinates: same intrinsics and image size --
+        // the usual RGB-D pair): 4 consecutive pixels per step as ONE 8-byte
+        // depth load, three 4-byte colour loads and two 16-byte record stores,
+        // 16 pixels per lane with all loads of the lane in flight together.
+        // A prepare wave then lives for one memory round trip instead of
+        // several dependent ones (it runs in a 128-register slot of the fused
+        // launch, so its life is what it costs the integrate sweep).
+        const int n_groups = n_px >> 2;  // cols % 4 == 0 (checked on the host)
+        const int gstep = n_wg * blockDim.x;
+        constexpr int kG = 4;
+        for (int g0 = (wg - n_touch_wg) * blockDim.x + threadIdx.x;
+             g0 < n_groups; g0 += kG * gstep) {
+            uint2 dq[kG];
+            unsigned cw[kG][3];
+#pragma unroll
+            for (int k = 0; k < kG; ++k) {
+                const int g = g0 + k * gstep;
+                const int gc = g < n_groups ? g : n_groups - 1;
+                dq[k] = *reinterpret_cast<const uint2*>(depth + 4 * (int64_t)gc);
+                if (pp.with_color) {
+                    const unsigned* c = reinterpret_cast<const unsigned*>(
+                            color + 12 * (int64_t)gc);
+                    cw[k][0] = c[0];
+                    cw[k][1] = c[1];
+                    cw[k][2] = c[2];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kG; ++k) {
+                const int g = g0 + k * gstep;
+                if (g >= n_groups) continue;
+                const unsigned dv[4] = {dq[k].x & 0xffffu, dq[k].x >> 16,
+                                        dq[k].y & 0xffffu, dq[k].y >> 16};
+                unsigned rgba[4] = {0u, 0u, 0u, 0u};
+                if (pp.with_color) {
+                    // 12 bytes r0 g0 b0 r1 g1 b1 r2 g2 b2 r3 g3 b3
+                    rgba[0] = (cw[k][0] & 0xffffffu) | (1u << 24);
+                    rgba[1] = ((cw[k][0] >> 24) | ((cw[k][1] & 0xffffu) << 8)) |
+                              (1u << 24);
+                    rgba[2] = ((cw[k][1] >> 16) | ((cw[k][2] & 0xffu) << 16)) |
+                              (1u << 24);
+                    rgba[3] = (cw[k][2] >> 8) | (1u << 24);
+                }
+                uint4 o[2];
+                unsigned w[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float df = (float)dv[j];
+                    const float d =
+                            fp.depth_div_short
+                                    ? DivByConst(df, p.depth_scale,
+                                                 fp.inv_depth_scale)
+                                    : df / p.depth_scale;
+                    w[2 * j] = __float_as_uint(d);
+                    w[2 * j + 1] = rgba[j];
+                }
+                o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+                o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+                uint4* dst = reinterpret_cast<uint4*>(recs + 4 * (int64_t)g);
+                dst[0] = o[0];
+                dst[1] = o[1];
+            }
+        }
+        return;
     }
     if (fp.col_lut) {
         // Table form: no division per pixel (the per-column / per-row parts
@@ -557,6 +659,10 @@ __device__ __forceinline__ void IntegrateRole(const HashView& hv,
 //      (block b -> XCD b mod 8; observed dispatch: workgroup w runs on XCD
 //      w mod 8): the parts share most of their projected pixel footprint,
 //      which then sits in that XCD's L2 once instead of in four of them.
+//      (Dealing whole neighbourhoods of blocks to one XCD -- per-class
+//      sublists keyed by block position -- cut the fabric reads by 17 % and
+//      cost 50 % in time: with ~760 blocks per group, classes that keep
+//      neighbours together are too uneven. Measured and dropped, r2n.)
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f2 Splat(float a) { return f2{a, a}; }
@@ -564,15 +670,20 @@ __device__ __forceinline__ f2 PkFma(f2 a, f2 b, f2 c) {
     return __builtin_elementwise_fma(a, b, c);
 }
 
+// kP = voxel pairs per lane: 2 (a lane owns 4 x-consecutive voxels; 16 / 8 /
+// 24-byte state accesses, ~127 registers, 4 waves per SIMD) or 1 (2 voxels per
+// lane: twice the work items at half the size and ~2/3 of the registers).
 template <typename weight_t, typename color_t, bool kColor, int kDiv,
-          int kChunk>
+          int kChunk, int kP>
 __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                                                   const IntegParams& ip,
                                                   int wg, int n_wg,
                                                   int first_wg) {
-    using TVec = Vec<float, 4, 16>;
-    using WVec = Vec<weight_t, 4, 4 * sizeof(weight_t)>;
-    using CVec = Vec<color_t, 12, 4 * sizeof(color_t)>;
+    constexpr int kV = 2 * kP;             // voxels per lane
+    constexpr int kVShift = kP == 2 ? 2 : 1;
+    using TVec = Vec<float, kV, 4 * kV>;
+    using WVec = Vec<weight_t, kV, kV * sizeof(weight_t)>;
+    using CVec = Vec<color_t, 3 * kV, kV * sizeof(color_t)>;
     constexpr bool kU16 = sizeof(weight_t) == 2;
     float* __restrict__ tsdf_base = ip.tsdf;
     weight_t* __restrict__ weight_base = (weight_t*)ip.weight;
@@ -595,8 +706,8 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
 
     const int res = ip.resolution;
     const int res3 = res * res * res;
-    const int quads_per_row = res >> 2;
-    const int n_quads = res3 >> 2;
+    const int quads_per_row = res >> kVShift;
+    const int n_quads = res3 >> kVShift;
     const int parts = (n_quads + 255) >> 8;
     const int res_shift = ip.res_shift;  // log2(res) or -1
     int frame_blocks = 0;  // lane 0 of part 0 counts block-frames
@@ -618,11 +729,18 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
     const float cx = ip.cam[0].cx, cy = ip.cam[0].cy;
     const float u_max = ip.cols - 1.0f, v_max = ip.rows - 1.0f;
 
+    // (Measured and dropped, profiles/r2l: persistent workgroups -- 1024 to
+    // 1536 of them striding over the items, with the next item's block header
+    // prefetched behind the current item's gathers -- are 8 % SLOWER than one
+    // workgroup per item: the dispatcher's dynamic assignment balances the
+    // uneven item times better than a static stride, and the prefetched
+    // header costs registers the colour form does not have.)
     for (int64_t m = rank; m < n_items; m += n_on_xcd) {
         int64_t kb;
         int part;
         if (res_shift >= 0) {  // parts is a power of two as well
-            const int ps = res_shift >= 4 ? 3 * res_shift - 10 : 0;
+            const int ps0 = 3 * res_shift - kVShift - 8;
+            const int ps = ps0 > 0 ? ps0 : 0;
             kb = m >> ps;
             part = (int)(m & ((1 << ps) - 1));
         } else {
@@ -654,7 +772,7 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
         int qx, yv, zv;
         if (res_shift >= 0) {
             qx = q & (quads_per_row - 1);
-            const int row = q >> (res_shift - 2);
+            const int row = q >> (res_shift - kVShift);
             yv = row & (res - 1);
             zv = row >> res_shift;
         } else {
@@ -663,10 +781,10 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
             yv = row % res;
             zv = row / res;
         }
-        const int x0 = xb * res + (qx << 2);
+        const int x0 = xb * res + (qx << kVShift);
         const float fy = (float)(yb * res + yv);
         const float fz = (float)(zb * res + zv);
-        const int64_t lin0 = block_base + ((int64_t)q << 2);
+        const int64_t lin0 = block_base + ((int64_t)q << kVShift);
 
         // 1. voxel state, widened to float once per work item. A uint16
         // weight / colour is an exact float; between the frames of the group
@@ -675,18 +793,21 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
         // below 65536; the weight's wrap at 65536 = what the uint16 store
         // keeps of it). Voxel pair p = voxels 2p, 2p + 1 of the lane.
         const TVec t4 = *reinterpret_cast<const TVec*>(tsdf_base + lin0);
-        f2 ts[2] = {f2{t4.v[0], t4.v[1]}, f2{t4.v[2], t4.v[3]}};
-        f2 wf[2];
-        f2 cf[2][3];
+        f2 ts[kP];
+        f2 wf[kP];
+        f2 cf[kP][3];
+#pragma unroll
+        for (int p = 0; p < kP; ++p) ts[p] = f2{t4.v[2 * p], t4.v[2 * p + 1]};
         {
             const WVec w4 = *reinterpret_cast<const WVec*>(weight_base + lin0);
-            wf[0] = f2{(float)w4.v[0], (float)w4.v[1]};
-            wf[1] = f2{(float)w4.v[2], (float)w4.v[3]};
+#pragma unroll
+            for (int p = 0; p < kP; ++p)
+                wf[p] = f2{(float)w4.v[2 * p], (float)w4.v[2 * p + 1]};
             if constexpr (kColor) {
                 const CVec c12 =
                         *reinterpret_cast<const CVec*>(color_base + 3 * lin0);
 #pragma unroll
-                for (int p = 0; p < 2; ++p)
+                for (int p = 0; p < kP; ++p)
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
                         cf[p][i] = f2{(float)c12.v[6 * p + i],
@@ -699,15 +820,17 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
         // ((x e0 + y e1) + z e2) + e3 per row; the y and z products are the
         // same for the lane's 4 voxels.
         const float ys = fy * vscale, zs = fz * vscale;
-        const f2 xs[2] = {f2{(float)x0, (float)(x0 + 1)} * vscale,
-                          f2{(float)(x0 + 2), (float)(x0 + 3)} * vscale};
+        f2 xs[kP];
+#pragma unroll
+        for (int p = 0; p < kP; ++p)
+            xs[p] = f2{(float)(x0 + 2 * p), (float)(x0 + 2 * p + 1)} * vscale;
         // (kChunk frames at a time: all of the group's when registers allow,
         // two when more resident waves pay better than more loads in flight)
         bool touched = false;
 #pragma unroll
         for (int c0 = 0; c0 < kMaxGroup; c0 += kChunk) {
-        f2 zc[kMaxGroup][2];
-        PixelRec rec[kMaxGroup][4];
+        f2 zc[kMaxGroup][kP];
+        PixelRec rec[kMaxGroup][kV];
 #pragma unroll
         for (int f = c0; f < c0 + kChunk; ++f) {
             if (!((bits >> f) & 1u)) continue;  // wave-uniform
@@ -722,9 +845,9 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
             const float y0 = ys * e[0][1], z0 = zs * e[0][2];
             const float y1 = ys * e[1][1], z1 = zs * e[1][2];
             const float y2 = ys * e[2][1], z2 = zs * e[2][2];
-            f2 xc[2], yc[2];
+            f2 xc[kP], yc[kP];
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < kP; ++p) {
                 xc[p] = xs[p] * e[0][0] + y0 + z0 + e[0][3];
                 yc[p] = xs[p] * e[1][0] + y1 + z1 + e[1][3];
                 zc[f][p] = xs[p] * e[2][0] + y2 + z2 + e[2][3];
@@ -732,16 +855,16 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
             // Camera::Project's 1 / z: the verified short reciprocal unless a
             // lane of the wave is outside its range. z is monotone along the
             // lane's 4 voxels, so the two end voxels decide.
-            f2 inv_z[2];
+            f2 inv_z[kP];
             const bool out = RcpOutOfRange(zc[f][0].x) ||
-                             RcpOutOfRange(zc[f][1].y);
+                             RcpOutOfRange(zc[f][kP - 1].y);
             if (kDiv < 2 || __builtin_amdgcn_ballot_w64(out) != 0ull) {
 #pragma unroll
-                for (int p = 0; p < 2; ++p)
+                for (int p = 0; p < kP; ++p)
                     inv_z[p] = f2{1.0f / zc[f][p].x, 1.0f / zc[f][p].y};
             } else {
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
+                for (int p = 0; p < kP; ++p) {
                     f2 r = f2{__builtin_amdgcn_rcpf(zc[f][p].x),
                               __builtin_amdgcn_rcpf(zc[f][p].y)};
 #pragma unroll
@@ -751,7 +874,7 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                 }
             }
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < kP; ++p) {
                 // u = fx * x * inv_z + cx (GeometryIndexer.h:100-108)
                 const f2 u = xc[p] * fx * inv_z[p] + cx;
                 const f2 v = yc[p] * fyk * inv_z[p] + cy;
@@ -777,11 +900,11 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
 #pragma unroll
         for (int f = c0; f < c0 + kChunk; ++f) {
             if (!((bits >> f) & 1u)) continue;  // wave-uniform
-            f2 sdf[2];
-            bool ok[4];
+            f2 sdf[kP];
+            bool ok[kV];
             bool tiny = false;
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < kP; ++p) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const float dh = rec[f][2 * p + h].d;
@@ -799,19 +922,19 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
             // underflow range
             if (kDiv < 1 || __builtin_amdgcn_ballot_w64(tiny) != 0ull) {
 #pragma unroll
-                for (int p = 0; p < 2; ++p)
+                for (int p = 0; p < kP; ++p)
                     sdf[p] = f2{sdf[p].x / ip.sdf_trunc,
                                 sdf[p].y / ip.sdf_trunc};
             } else {
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
+                for (int p = 0; p < kP; ++p) {
                     const f2 q0 = sdf[p] * ip.inv_sdf_trunc;
                     const f2 r = PkFma(Splat(-ip.sdf_trunc), q0, sdf[p]);
                     sdf[p] = PkFma(r, Splat(ip.inv_sdf_trunc), q0);
                 }
             }
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < kP; ++p) {
                 const f2 weight = wf[p];
                 const f2 wsum = weight + 1.0f;  // exact (integers <= 65536)
                 f2 inv_wsum;
@@ -853,17 +976,20 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
         }  // chunk
         if (touched) {
             TVec t_out;
-            t_out.v[0] = ts[0].x; t_out.v[1] = ts[0].y;
-            t_out.v[2] = ts[1].x; t_out.v[3] = ts[1].y;
-            *reinterpret_cast<TVec*>(tsdf_base + lin0) = t_out;
             WVec w4;
-            w4.v[0] = (weight_t)wf[0].x; w4.v[1] = (weight_t)wf[0].y;
-            w4.v[2] = (weight_t)wf[1].x; w4.v[3] = (weight_t)wf[1].y;
+#pragma unroll
+            for (int p = 0; p < kP; ++p) {
+                t_out.v[2 * p] = ts[p].x;
+                t_out.v[2 * p + 1] = ts[p].y;
+                w4.v[2 * p] = (weight_t)wf[p].x;
+                w4.v[2 * p + 1] = (weight_t)wf[p].y;
+            }
+            *reinterpret_cast<TVec*>(tsdf_base + lin0) = t_out;
             *reinterpret_cast<WVec*>(weight_base + lin0) = w4;
             if constexpr (kColor) {
                 CVec c12;
 #pragma unroll
-                for (int p = 0; p < 2; ++p)
+                for (int p = 0; p < kP; ++p)
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
                         c12.v[6 * p + i] = (color_t)cf[p][i].x;
@@ -890,7 +1016,7 @@ struct StepParams {
 // either way (colour temporaries), so the chunked form is not instantiated.
 template <typename weight_t, typename color_t, bool kColor, int kDiv,
           int kForm>
-__global__ void __launch_bounds__(256, kForm == 0 ? 1 : 4)
+__global__ void __launch_bounds__(256, kForm == 0 ? 1 : (kForm == 1 ? 4 : 6))
 FrameStepKernel(StepParams sp) {
     const int b = (int)blockIdx.x;
     const int n_front_wg = sp.n_fronts * sp.front_wg;
@@ -898,8 +1024,8 @@ FrameStepKernel(StepParams sp) {
         const int f = b / sp.front_wg;
         FrontRole(sp.hv, sp.front[f], b - f * sp.front_wg);
     } else if constexpr (kForm != 0) {
-        IntegrateRoleWide<weight_t, color_t, kColor, kDiv,
-                          kMaxGroup>(
+        IntegrateRoleWide<weight_t, color_t, kColor, kDiv, kMaxGroup,
+                          kForm == 2 ? 1 : 2>(
                 sp.hv, sp.integ, b - n_front_wg, (int)gridDim.x - n_front_wg,
                 n_front_wg);
     } else {
@@ -1031,6 +1157,16 @@ static int VerifyFastDivision(float b, float* y_out) {
     return ok;
 }
 
+// O3DMI_STEP_VARIANT: 0 = first form of the integrate role, 1 = wide form
+// with 4 voxels per lane (default), 2 = wide form with 2 voxels per lane.
+static int StepForm() {
+    static const int form = []() {
+        const char* e = std::getenv("O3DMI_STEP_VARIANT");
+        return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1;
+    }();
+    return form;
+}
+
 int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
                     const IntegrateStreamArgs* a, hipStream_t s) {
     O3DMI_REQUIRE((n_fronts > 0 && fronts) || a, "nothing to launch");
@@ -1065,6 +1201,9 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         fp.col_lut = f->col_lut;
         fp.row_lut = f->col_lut ? f->row_lut : nullptr;
         fp.depth_div_short = f->depth_div_short;
+        fp.prep_identity = f->col_lut && f->prep_identity &&
+                           (f->cols % 4) == 0 && f->rows == f->color_rows &&
+                           f->cols == f->color_cols;
         fp.inv_depth_scale = 1.0f / f->depth_scale;
         fp.recs = f->recs;
         fp.list = f->list;
@@ -1073,10 +1212,11 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         fp.group_stamp = f->group_stamp;
         fp.group_bit = f->group_bit;
         fp.touch_plane = f->touch_plane & 1;
-        const int n_rays = fp.p.rows_strided * fp.p.cols_strided;
-        fp.n_touch_wg = (n_rays + kBlock - 1) / kBlock;
-        // 4 pixels per prepare lane
-        fp.n_prep_wg = (f->rows * f->cols + kBlock * 4 - 1) / (kBlock * 4);
+        // one touch workgroup per 16 x 16 tile of rays
+        fp.n_touch_wg = ((fp.p.cols_strided + 15) / 16) *
+                        ((fp.p.rows_strided + 15) / 16);
+        // 16 pixels per prepare lane
+        fp.n_prep_wg = (f->rows * f->cols + kBlock * 16 - 1) / (kBlock * 16);
         if (fp.n_prep_wg < 1) fp.n_prep_wg = 1;
         const int wg = fp.n_touch_wg + fp.n_prep_wg;
         // all frames of a launch share the image size
@@ -1120,7 +1260,8 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         ip.prof_count = a->prof_count;
         ip.prof_frame_blocks = a->prof_frame_blocks;
         const int n_quads =
-                (a->resolution * a->resolution * a->resolution) >> 2;
+                (a->resolution * a->resolution * a->resolution) >>
+                (StepForm() == 2 ? 1 : 2);
         const int parts = (n_quads + 255) >> 8;
         // Grid from the expected block count (previous group + slack); the
         // role strides, so an under-estimate only costs balance.
@@ -1142,15 +1283,16 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
     dim3 grid((unsigned)(n_fronts * sp.front_wg + n_int_wg)), block(256);
     // O3DMI_STEP_VARIANT=0 selects the first form of the integrate role
     // (diagnostics / A-B measurements); results are identical.
-    static const int form = []() {
-        const char* e = std::getenv("O3DMI_STEP_VARIANT");
-        return e && e[0] == '0' ? 0 : 1;
-    }();
+    const int form = StepForm();
 #define O3DMI_LAUNCH_STEP_D(WT, VT, COLOR, D)                                 \
     do {                                                                      \
         switch (form) {                                                       \
             case 0:                                                           \
                 hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR, D, 0>),    \
+                                   grid, block, 0, s, sp);                    \
+                break;                                                        \
+            case 2:                                                           \
+                hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR, D, 2>),    \
                                    grid, block, 0, s, sp);                    \
                 break;                                                        \
             default:                                                          \

@@ -13,7 +13,7 @@ mkdir -p "$OUT" "$SUM"
 export TMPDIR=/tmp
 cd /tmp
 for kv in "$@"; do export "$kv"; done
-BENCH="python $ROOT/bench.py --no-cpu-baseline --no-pmc --steps 2 --warmup 1 --no-secondary"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-pmc --steps 2 --warmup 1 --batch 200 --no-secondary"
 declare -A SETS
 SETS[sq1]="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE GRBM_COUNT"
 SETS[sq2]="SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_BRANCH"
