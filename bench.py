@@ -6,7 +6,7 @@ with known poses (1000 distinct frames, resident in HBM before the timed region)
 integrated into an 8 mm / 16^3-block VoxelBlockGrid (tsdf f32, weight u16,
 colour u16 -- the slam::Model layout): per frame block touch + hash activation
 + per-voxel TSDF / weight / colour update. A "step" is one batch of `--batch`
-frames (default 5000 = five passes over the stream, so that the driver's 20
+frames (default 6000 = six passes over the stream, so that the driver's 20
 timed steps last about a second); every frame does the full per-frame work, the
 uint16 weights stay far below their range (a voxel is seen by <= 183 frames of
 a pass).
@@ -78,7 +78,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=5000,
+    ap.add_argument("--batch", type=int, default=6000,
                     help="frames per step (per GPU)")
     ap.add_argument("--block-count", type=int, default=262144,
                     help="initial hash capacity; the stream needs ~6 k blocks, "
@@ -86,9 +86,9 @@ def parse():
                          "several 4-frame groups ahead of the GPU without "
                          "waiting for the map size (capacity policy of "
                          "HashMap::Activate)")
-    ap.add_argument("--frames-per-launch", type=int, default=4,
+    ap.add_argument("--frames-per-launch", type=int, default=8,
                     help="consecutive frames applied per launch to register-"
-                         "resident blocks (1..4); results are identical")
+                         "resident blocks (1..8); results are identical")
     ap.add_argument("--event-stride", type=int, default=16,
                     help="bracket every n-th integrate launch with HIP events "
                          "(0 = none; the roofline is then not measured)")

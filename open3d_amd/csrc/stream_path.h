@@ -31,7 +31,11 @@ namespace o3dmi {
 // preserved and a block only receives the frames that touched it (per-slot
 // frame bits, TouchSlot), so the result is identical to frame-by-frame
 // integration.
-constexpr int kMaxGroup = 4;
+constexpr int kMaxGroup = 8;  // = the frame bits of a touch word
+// The integrate role's wide form keeps the records of kGroupChunk frames in
+// registers at a time (a group of 8 = two chunks on the same register-resident
+// voxel state).
+constexpr int kGroupChunk = 4;
 
 // One entry of a group's block list: hash slot + block key.
 struct alignas(16) FrameBlock {

@@ -346,6 +346,8 @@ struct IntegParams {
     int touch_plane;
     int rows, cols, resolution;
     int res_shift;  // log2(resolution) when it is a power of two, else -1
+    int diag;       // O3DMI_STEP_DIAG (timing experiments, WRONG results):
+                    // 1 = every gather reads record 0, 2 = no state stores
     float sdf_trunc, depth_max;
     float inv_sdf_trunc;  // RN(1 / sdf_trunc), used by the kFastDiv variant
     const FrameBlock* list;
@@ -824,15 +826,20 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
 #pragma unroll
         for (int p = 0; p < kP; ++p)
             xs[p] = f2{(float)(x0 + 2 * p), (float)(x0 + 2 * p + 1)} * vscale;
-        // (kChunk frames at a time: all of the group's when registers allow,
-        // two when more resident waves pay better than more loads in flight)
+        // (kChunk frames at a time: a group of up to kMaxGroup frames is
+        // applied chunk after chunk to the same register-resident state; the
+        // chunk loop is a real loop, so that the second chunk's gathers are
+        // not hoisted above the first chunk's arithmetic -- they would double
+        // the live registers)
         bool touched = false;
-#pragma unroll
+#pragma nounroll
         for (int c0 = 0; c0 < kMaxGroup; c0 += kChunk) {
-        f2 zc[kMaxGroup][kP];
-        PixelRec rec[kMaxGroup][kV];
+        if (((bits >> c0) & ((1u << kChunk) - 1u)) == 0u) continue;  // uniform
+        f2 zc[kChunk][kP];
+        PixelRec rec[kChunk][kV];
 #pragma unroll
-        for (int f = c0; f < c0 + kChunk; ++f) {
+        for (int fk = 0; fk < kChunk; ++fk) {
+            const int f = c0 + fk;
             if (!((bits >> f) & 1u)) continue;  // wave-uniform
             // The frame's constants are fetched here, per work item (scalar
             // loads from the argument block): hoisted out of the item loop
@@ -850,26 +857,26 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
             for (int p = 0; p < kP; ++p) {
                 xc[p] = xs[p] * e[0][0] + y0 + z0 + e[0][3];
                 yc[p] = xs[p] * e[1][0] + y1 + z1 + e[1][3];
-                zc[f][p] = xs[p] * e[2][0] + y2 + z2 + e[2][3];
+                zc[fk][p] = xs[p] * e[2][0] + y2 + z2 + e[2][3];
             }
             // Camera::Project's 1 / z: the verified short reciprocal unless a
             // lane of the wave is outside its range. z is monotone along the
             // lane's 4 voxels, so the two end voxels decide.
             f2 inv_z[kP];
-            const bool out = RcpOutOfRange(zc[f][0].x) ||
-                             RcpOutOfRange(zc[f][kP - 1].y);
+            const bool out = RcpOutOfRange(zc[fk][0].x) ||
+                             RcpOutOfRange(zc[fk][kP - 1].y);
             if (kDiv < 2 || __builtin_amdgcn_ballot_w64(out) != 0ull) {
 #pragma unroll
                 for (int p = 0; p < kP; ++p)
-                    inv_z[p] = f2{1.0f / zc[f][p].x, 1.0f / zc[f][p].y};
+                    inv_z[p] = f2{1.0f / zc[fk][p].x, 1.0f / zc[fk][p].y};
             } else {
 #pragma unroll
                 for (int p = 0; p < kP; ++p) {
-                    f2 r = f2{__builtin_amdgcn_rcpf(zc[f][p].x),
-                              __builtin_amdgcn_rcpf(zc[f][p].y)};
+                    f2 r = f2{__builtin_amdgcn_rcpf(zc[fk][p].x),
+                              __builtin_amdgcn_rcpf(zc[fk][p].y)};
 #pragma unroll
                     for (int k = 0; k < (kDiv >= 2 ? kDiv - 1 : 1); ++k)
-                        r = PkFma(PkFma(-zc[f][p], r, Splat(1.0f)), r, r);
+                        r = PkFma(PkFma(-zc[fk][p], r, Splat(1.0f)), r, r);
                     inv_z[p] = r;
                 }
             }
@@ -890,15 +897,17 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                     const unsigned off =
                             __umul24((unsigned)(int)vh, row_bytes) +
                             (unsigned)(int)uh * (unsigned)sizeof(PixelRec);
-                    rec[f][2 * p + h] = *reinterpret_cast<const PixelRec*>(
-                            recs + (in ? off : sentinel_off));
+                    rec[fk][2 * p + h] = *reinterpret_cast<const PixelRec*>(
+                            recs + (ip.diag == 1 ? 0u
+                                                 : (in ? off : sentinel_off)));
                 }
             }
         }
 
         // 3. frames applied in order (VoxelBlockGridImpl.h:258-302)
 #pragma unroll
-        for (int f = c0; f < c0 + kChunk; ++f) {
+        for (int fk = 0; fk < kChunk; ++fk) {
+            const int f = c0 + fk;
             if (!((bits >> f) & 1u)) continue;  // wave-uniform
             f2 sdf[kP];
             bool ok[kV];
@@ -907,8 +916,8 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
             for (int p = 0; p < kP; ++p) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const float dh = rec[f][2 * p + h].d;
-                    const float zh = h ? zc[f][p].y : zc[f][p].x;
+                    const float dh = rec[fk][2 * p + h].d;
+                    const float zh = h ? zc[fk][p].y : zc[fk][p].x;
                     const float sh = dh - zh;
                     ok[2 * p + h] = !(dh <= 0) && !(dh > ip.depth_max) &&
                                     !(zh <= 0) && !(sh < -ip.sdf_trunc);
@@ -950,8 +959,8 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                 ts[p] = f2{ok[2 * p] ? t_new.x : ts[p].x,
                            ok[2 * p + 1] ? t_new.y : ts[p].y};
                 if constexpr (kColor) {
-                    const unsigned rg0 = rec[f][2 * p].rgba;
-                    const unsigned rg1 = rec[f][2 * p + 1].rgba;
+                    const unsigned rg0 = rec[fk][2 * p].rgba;
+                    const unsigned rg1 = rec[fk][2 * p + 1].rgba;
                     const bool has0 = ok[2 * p] && (rg0 >> 24);
                     const bool has1 = ok[2 * p + 1] && (rg1 >> 24);
 #pragma unroll
@@ -974,7 +983,7 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
             }
         }
         }  // chunk
-        if (touched) {
+        if (touched && ip.diag != 2) {
             TVec t_out;
             WVec w4;
 #pragma unroll
@@ -1010,13 +1019,13 @@ struct StepParams {
     int front_wg;  // workgroups per front role
 };
 
-// kForm: 0 = first form of the integrate role; 1 = wide form (all frames of
-// the group in flight, 4 waves per SIMD). Chunks of two frames were tried to
-// lower the register count: the compiler's schedule keeps ~125 registers live
-// either way (colour temporaries), so the chunked form is not instantiated.
+// kForm: 0 = first form of the integrate role; 1 = wide form, 4 voxels per
+// lane (119 registers, 4 waves per SIMD); 2 = wide form, 2 voxels per lane
+// (72 registers, 7 waves per SIMD). Both wide forms apply a group of up to 8
+// frames in chunks of kGroupChunk = 4 to the register-resident voxel state.
 template <typename weight_t, typename color_t, bool kColor, int kDiv,
           int kForm>
-__global__ void __launch_bounds__(256, kForm == 0 ? 1 : (kForm == 1 ? 4 : 6))
+__global__ void __launch_bounds__(256, kForm == 0 ? 1 : (kForm == 1 ? 4 : 7))
 FrameStepKernel(StepParams sp) {
     const int b = (int)blockIdx.x;
     const int n_front_wg = sp.n_fronts * sp.front_wg;
@@ -1024,7 +1033,7 @@ FrameStepKernel(StepParams sp) {
         const int f = b / sp.front_wg;
         FrontRole(sp.hv, sp.front[f], b - f * sp.front_wg);
     } else if constexpr (kForm != 0) {
-        IntegrateRoleWide<weight_t, color_t, kColor, kDiv, kMaxGroup,
+        IntegrateRoleWide<weight_t, color_t, kColor, kDiv, kGroupChunk,
                           kForm == 2 ? 1 : 2>(
                 sp.hv, sp.integ, b - n_front_wg, (int)gridDim.x - n_front_wg,
                 n_front_wg);
@@ -1157,12 +1166,15 @@ static int VerifyFastDivision(float b, float* y_out) {
     return ok;
 }
 
-// O3DMI_STEP_VARIANT: 0 = first form of the integrate role, 1 = wide form
-// with 4 voxels per lane (default), 2 = wide form with 2 voxels per lane.
+// O3DMI_STEP_VARIANT (diagnostics / A-B measurements, results identical):
+// 0 = first form of the integrate role, 1 = wide form with 4 voxels per lane,
+// 2 = wide form with 2 voxels per lane (default: 72 registers, 7 waves per
+// SIMD; with 8-frame groups 107 k frames/s against 98 k for form 1 and 72 k
+// for form 0, profiles/r2q).
 static int StepForm() {
     static const int form = []() {
         const char* e = std::getenv("O3DMI_STEP_VARIANT");
-        return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1;
+        return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 2;
     }();
     return form;
 }
@@ -1242,6 +1254,11 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         ip.rows = a->rows;
         ip.cols = a->cols;
         ip.resolution = a->resolution;
+        static const int diag = []() {
+            const char* e = std::getenv("O3DMI_STEP_DIAG");
+            return e ? std::atoi(e) : 0;
+        }();
+        ip.diag = diag;
         ip.res_shift = -1;
         for (int sh = 2; sh < 12; ++sh)
             if ((1 << sh) == a->resolution) ip.res_shift = sh;
@@ -1291,12 +1308,12 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
                 hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR, D, 0>),    \
                                    grid, block, 0, s, sp);                    \
                 break;                                                        \
-            case 2:                                                           \
-                hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR, D, 2>),    \
+            case 1:                                                           \
+                hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR, D, 1>),    \
                                    grid, block, 0, s, sp);                    \
                 break;                                                        \
             default:                                                          \
-                hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR, D, 1>),    \
+                hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR, D, 2>),    \
                                    grid, block, 0, s, sp);                    \
         }                                                                     \
     } while (0)

@@ -230,7 +230,7 @@ class VoxelBlockGrid:
                          depth_max=3.0, trunc_voxel_multiplier=8.0,
                          frames_per_launch=0):
         """integrate_frame over a list of frames (same intrinsics / sizes),
-        strictly in order, in one native call. frames_per_launch (1..4, 0 =
+        strictly in order, in one native call. frames_per_launch (1..8, 0 =
         4) frames are applied per launch to each touched block while its
         voxels stay in registers; results are identical for every value."""
         n = len(depths)

@@ -345,7 +345,7 @@ def test_frame_stream_fast_path_equals_two_step_path():
     assert gb.hashmap().capacity() > 512  # grew through Reserve
 
 
-@pytest.mark.parametrize("group", [1, 2, 3, 4])
+@pytest.mark.parametrize("group", [1, 2, 3, 4, 6, 8])
 @pytest.mark.parametrize("grid_f32", [False, True])
 def test_frame_batch_equals_oracle(group, grid_f32):
     """integrate_frames (one native call; `group` frames applied per launch to
@@ -395,8 +395,8 @@ def test_fused_frame_groups_with_disjoint_frame_bits_stress():
     role of group g and both use the per-slot touch words (frame bits); the
     two groups must not see each other's words (two planes, by group parity).
     Small images and a view that jumps between frames make consecutive groups
-    touch overlapping block sets with DIFFERENT frame bits, many fused 4-frame
-    groups per call, repeated: the grid must equal frame-by-frame integration
+    touch overlapping block sets with DIFFERENT frame bits, many fused groups
+    (2 to 8 frames) per call, repeated: the grid must equal frame-by-frame integration
     (frames_per_launch = 1) bit for bit every time, and the oracle's."""
     _lib, geometry = _gpu()
     w, h = 160, 120
@@ -426,7 +426,7 @@ def test_fused_frame_groups_with_disjoint_frame_bits_stress():
                                frames_per_launch=4)
         else:
             g.integrate_frames(dt, ct, K, K, Ts, sc.DEPTH_SCALE, sc.DEPTH_MAX,
-                               sc.TRUNC_MULT, frames_per_launch=2 + rep % 3)
+                               sc.TRUNC_MULT, frames_per_launch=(2, 3, 8, 5, 8)[rep - 1])
         got = _all_blocks(g)
         for a, b in zip(want, got):
             assert np.array_equal(a, b), rep

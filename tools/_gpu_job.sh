@@ -1,11 +1,14 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2o
-timeout 1800 python -m pytest tests/test_vbg_gpu.py tests/test_golden.py tests/test_slam_gpu.py tests/test_configs_gpu.py tests/test_vbg_io_gpu.py -x -q -m gpu > gpurun_out/r2o/pytest.log 2>&1; tail -3 gpurun_out/r2o/pytest.log
-run() { tag=$1; shift; env "$@" python bench.py --no-cpu-baseline --no-pmc --no-secondary --steps 10 --warmup 3 > gpurun_out/r2o/bench_$tag.json 2> gpurun_out/r2o/bench_$tag.err; python - <<PY
+mkdir -p gpurun_out/r2r
+timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/r2r/pytest.log 2>&1; tail -3 gpurun_out/r2r/pytest.log
+timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r2r/bench.json 2> gpurun_out/r2r/bench.err; python - <<'PY'
 import json
-d=json.loads(open("gpurun_out/r2o/bench_$tag.json").read().strip().splitlines()[-1])
-print("$tag", round(d["value"]), "fps  kernel", round(d["roofline"]["avg_kernel_ms"]*1e3,2), "us")
+d=json.loads(open("gpurun_out/r2r/bench.json").read().strip().splitlines()[-1])
+print("value", round(d["value"]), "timed_s", round(d["config"]["timed_region_s"],3))
+r=d["roofline"]; print({k:r.get(k) for k in ("frac","frac_hbm","frac_valu","avg_kernel_ms","traffic","valu_insts_per_launch","avg_waves_per_simd","frames_per_launch","traffic_source")})
+s=d.get("secondary",{})
+for k,v in s.items():
+    print(k, {a:v[a] for a in v if a in ("ms_per_icp","ms_per_iteration","frames_per_s","ms_per_frame","cpu_oracle_ms_per_icp","cpu_oracle_ms_per_multiscale_icp","error")}, "frac", v.get("roofline",{}).get("frac") if isinstance(v,dict) else None)
+print(d.get("cpu_baseline"))
 PY
-}
-run form1 O3DMI_STEP_VARIANT=1
-run form0 O3DMI_STEP_VARIANT=0
+tail -2 gpurun_out/r2r/bench.err
