@@ -83,7 +83,7 @@ def parse():
     ap.add_argument("--block-count", type=int, default=262144,
                     help="initial hash capacity; the stream needs ~6 k blocks, "
                          "the rest is head-room that lets the host issue "
-                         "several 4-frame groups ahead of the GPU without "
+                         "several frame groups ahead of the GPU without "
                          "waiting for the map size (capacity policy of "
                          "HashMap::Activate)")
     ap.add_argument("--frames-per-launch", type=int, default=8,
@@ -490,7 +490,7 @@ def main():
             "note": "`frac` is SURVEY 8(d)'s convention (voxel state charged "
                     "per frame) over the HBM peak: an equivalent bandwidth, "
                     "it can exceed what DRAM carries because state crosses "
-                    "the fabric once per 4-frame launch. `frac_hbm` = counter"
+                    "the fabric once per launch (a group of up to 8 frames). `frac_hbm` = counter"
                     " bytes (FETCH_SIZE x 2 + WRITE_SIZE, both factors "
                     "calibrated on copy kernels with this kernel's 8 / 16 / "
                     "24 B-per-lane accesses: profiles/r2a_hbm_calibration."
