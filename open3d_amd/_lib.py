@@ -8,7 +8,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "lib", "libo3d_mi355x.so")
+# O3DMI_LIB: another build of the same library (A/B measurements of two
+# builds on one box); the default is the in-tree build.
+SO_PATH = os.environ.get("O3DMI_LIB") or os.path.join(
+    _HERE, "lib", "libo3d_mi355x.so")
 
 OK = 0
 F32, F64, U16, U8, I32, I64 = 0, 1, 2, 3, 4, 5

@@ -72,6 +72,15 @@ extern "C" int o3dmi_icp_symmetric_accumulate_post(
         int* mail_flag, int mail_seq, o3dmi_stream_t stream);
 
 extern "C" int o3dmi_internal_nns_destroy_completed(o3dmi_nns_t* nns);
+extern "C" int o3dmi_internal_nns_create_with_normals(
+        const void* points_dev, const void* normals_dev, int64_t n, int dtype,
+        double radius, o3dmi_stream_t stream, o3dmi_nns_t** out);
+extern "C" int o3dmi_internal_icp_transform_search_accumulate(
+        const o3dmi_nns_t* nns, void* src_dev, const double* transformation,
+        const void* tgt_normals_dev, int64_t n, int estimation,
+        int robust_kernel, double scaling_parameter, double shape_parameter,
+        int64_t* corr_out_dev, double* sums32_dev, double* mail_data,
+        int* mail_flag, int mail_seq, o3dmi_stream_t stream);
 extern "C" int o3dmi_internal_sums_tail(double* sums32_dev, double t29,
                                         double t30, double t31,
                                         o3dmi_stream_t stream);
@@ -319,6 +328,34 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
     hipStream_t s = (hipStream_t)stream;
     const size_t esz = dtype == O3DMI_F64 ? 8 : 4;
 
+    // O3DMI_ICP_TIMING=2: wall time of the whole call including the exit path
+    // (declared first: destroyed last), without the per-phase waits of =1.
+    struct ExitTimer {
+        bool on = false;
+        double t0 = 0;
+        std::string marks;
+        void Mark(const char* what) {
+            if (!on) return;
+            char buf[64];
+            std::snprintf(buf, sizeof(buf), " %s@%.0f", what, Now() - t0);
+            marks += buf;
+        }
+        static double Now() {
+            return std::chrono::duration<double, std::micro>(
+                           std::chrono::steady_clock::now().time_since_epoch())
+                    .count();
+        }
+        ~ExitTimer() {
+            if (on)
+                std::fprintf(stderr, "[o3dmi] icp: whole call %.0f us;%s\n",
+                             Now() - t0, marks.c_str());
+        }
+    } exit_timer;
+    if (const char* e = std::getenv("O3DMI_ICP_TIMING")) {
+        exit_timer.on = true;
+        exit_timer.t0 = ExitTimer::Now();
+        (void)e;
+    }
     // InitializePointCloudPyramidForMultiScaleICP, Registration.cpp:221-273.
     std::vector<Level> pyr((size_t)num_scales);
     // Declared after the pyramid so that it runs first on every exit path:
@@ -329,6 +366,11 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
     } sync_on_exit{s};
     const int last = num_scales - 1;
     int st;
+    // One index per scale (target_nns.HybridIndex(max_correspondence_distance),
+    // Registration.cpp:406-412), built by the target chain right behind the
+    // level it indexes -- on the side stream, while the source pyramid is
+    // still being built -- so no scale waits for its index.
+    std::vector<NnsGuard> guards((size_t)num_scales);
     const double t_entry =
             std::chrono::duration<double, std::micro>(
                     std::chrono::steady_clock::now().time_since_epoch())
@@ -497,6 +539,14 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         for (int k = 0; k < num_scales; ++k)
             if (!(k == last && finest_is_input))
                 pyr[(size_t)k].nt = counts[(size_t)k];
+        for (int k = 0; k < num_scales; ++k) {
+            const Level& Lk = pyr[(size_t)k];
+            if ((e = o3dmi_internal_nns_create_with_normals(
+                         Lk.tgt_ptr, p2plane ? Lk.nrm_ptr : nullptr, Lk.nt,
+                         dtype, max_dists[k], cstream,
+                         &guards[(size_t)k].nns)))
+                return e;
+        }
         return O3DMI_OK;
     };
     // Anything to overlap? (a single level without down-sampling is two
@@ -543,7 +593,9 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         }
     }
 
-    const bool timing = std::getenv("O3DMI_ICP_TIMING") != nullptr;
+    exit_timer.Mark("pyramid");
+    const char* timing_env = std::getenv("O3DMI_ICP_TIMING");
+    const bool timing = timing_env && std::atoi(timing_env) != 2;
     auto now = [] {
         return std::chrono::duration<double, std::micro>(
                        std::chrono::steady_clock::now().time_since_epoch())
@@ -622,13 +674,20 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
     int64_t last_ns = 0;
 
     // ComputeRegistrationResult (+ the Jacobian sums of the same pass).
+    // `pending`: the transformation the source still has to be moved by
+    // (`source.Transform(...)`, Registration.cpp:322,404) -- applied by the
+    // search launch itself, in place, before it searches.
+    double pending[16];
+    bool has_pending = false;
     auto search = [&](o3dmi_nns_t* nns, const Level& L, int64_t* corr_out,
                       SearchResult& r) -> int {
+        const double* xf = has_pending ? pending : nullptr;
+        has_pending = false;
         int e = fetch_sums(
                 [&](double* sums_dev, double* mail_data, int* mail_flag,
                     int seq) {
-                    return o3dmi_icp_search_accumulate_post(
-                            nns, L.src.p, nullptr, L.ns, search_mode,
+                    return o3dmi_internal_icp_transform_search_accumulate(
+                            nns, L.src.p, xf, nullptr, L.ns, search_mode,
                             robust_kernel, scaling_parameter, shape_parameter,
                             corr_out, sums_dev, mail_data, mail_flag, seq,
                             stream);
@@ -653,8 +712,8 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         last_ns = L.ns;
         // source_down_pyramid[scale].Transform(result.transformation_) :404
         // (positions and, when the estimator reads them, normals)
-        if ((st = o3dmi_transform_points(T, L.src.p, L.ns, dtype, stream)))
-            return st;
+        std::memcpy(pending, T, sizeof(pending));
+        has_pending = true;
         if (symmetric &&
             (st = o3dmi_transform_normals(T, L.srcn.p, L.ns, dtype, stream)))
             return st;
@@ -664,14 +723,9 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
             if ((st = sym_partials.Alloc(sizeof(double) * 32 * 1024)))
                 return st;
         }
-        // target_nns.HybridIndex(max_correspondence_distance) :406-412
-        NnsGuard guard;
-        if ((st = o3dmi_nns_create(L.tgt_ptr, L.nt, dtype, max_dists[scale_idx],
-                                   stream, &guard.nns)))
-            return st;
-        if (p2plane &&
-            (st = o3dmi_nns_set_normals(guard.nns, L.nrm_ptr, stream)))
-            return st;
+        // target_nns.HybridIndex(max_correspondence_distance) :406-412:
+        // built behind the target pyramid (above)
+        NnsGuard& guard = guards[(size_t)scale_idx];
 
         if (timing) {
             (void)hipStreamSynchronize(s);
@@ -787,9 +841,11 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                 }
             }
             Matmul4(update, T, T);
-            if ((st = o3dmi_transform_points(update, L.src.p, L.ns, dtype,
-                                             stream)))
-                return st;
+            // source.Transform(update): rides in the next search launch of
+            // this scale (a scale that ends here has no further use for its
+            // source cloud)
+            std::memcpy(pending, update, sizeof(pending));
+            has_pending = true;
             if (symmetric && (st = o3dmi_transform_normals(
                                       update, L.srcn.p, L.ns, dtype, stream)))
                 return st;
@@ -807,6 +863,7 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         }
         iteration_count += it;
         (void)no_corr;
+        exit_timer.Mark("scale");
         if (timing) {
             (void)hipStreamSynchronize(s);
             const double t = now();
@@ -835,6 +892,7 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
     if (timing)
         std::fprintf(stderr, "[o3dmi] icp: after pyramid %.0f us in total\n",
                      now() - t_start);
+    exit_timer.Mark("final");
     std::memcpy(result->transformation, T, sizeof(T));
     result->fitness = fitness;
     result->inlier_rmse = inlier_rmse;

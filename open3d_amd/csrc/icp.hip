@@ -112,9 +112,9 @@ RobustParams MakeRobust(int method, double scaling, double shape) {
 // ---- 29(+2)-value reduction -------------------------------------------------
 // Per-correspondence terms in T exactly as RegistrationCPU.cpp:62-74; the
 // running sums are float64.
-template <typename T>
+template <typename T, typename Sums = double[kNumSums], bool kL2 = false>
 __device__ __forceinline__ void AccumulateP2Plane(
-        double (&A)[kNumSums], T sx, T sy, T sz, T tx, T ty, T tz, T nx, T ny,
+        Sums& A, T sx, T sy, T sz, T tx, T ty, T tz, T nx, T ny,
         T nz, const RobustParams& rp) {
     // RegistrationImpl.h:274-284
     T r = (sx - tx) * nx + (sy - ty) * ny + (sz - tz) * nz;
@@ -125,18 +125,20 @@ __device__ __forceinline__ void AccumulateP2Plane(
     J[3] = nx;
     J[4] = ny;
     J[5] = nz;
-    T w = RobustWeight<T>(rp, r);
+    // kL2: the caller knows the kernel is L2Loss (weight 1, the common case);
+    // the general form drags float64 pow / exp through the register file
+    T w = kL2 ? T(1) : RobustWeight<T>(rp, r);
     int i = 0;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
 #pragma unroll
         for (int k = 0; k <= j; ++k) {
-            A[i] += (double)(J[j] * w * J[k]);
+            A[i] += J[j] * w * J[k];  // widened by the sum
             ++i;
         }
-        A[21 + j] += (double)(J[j] * w * r);
+        A[21 + j] += J[j] * w * r;
     }
-    A[27] += (double)r;
+    A[27] += r;
     A[28] += 1.0;
 }
 
@@ -144,8 +146,8 @@ __device__ __forceinline__ void AccumulateP2Plane(
 // (RegistrationCPU.cpp:495-617 forms the means first and the centred products
 // in a second pass; the centred covariance follows on the host from these raw
 // moments in float64, where products of two Float32 values are exact).
-template <typename T>
-__device__ __forceinline__ void AccumulateP2Point(double (&A)[kNumSums], T sx,
+template <typename T, typename Sums = double[kNumSums]>
+__device__ __forceinline__ void AccumulateP2Point(Sums& A, T sx,
                                                   T sy, T sz, T tx, T ty,
                                                   T tz) {
     const double s[3] = {(double)sx, (double)sy, (double)sz};
@@ -166,8 +168,8 @@ __device__ __forceinline__ void AccumulateP2Point(double (&A)[kNumSums], T sx,
 // (RegistrationImpl.h:686-715, RegistrationCPU.cpp:652-701): per matched target
 // point G^T G with G = [-[t]x | I], each packed-lower-triangle term formed in T
 // as J_x[j] J_x[k] + J_y[j] J_y[k] + J_z[j] J_z[k], summed in float64.
-template <typename T>
-__device__ __forceinline__ void AccumulateInformation(double (&A)[kNumSums],
+template <typename T, typename Sums = double[kNumSums]>
+__device__ __forceinline__ void AccumulateInformation(Sums& A,
                                                       T tx, T ty, T tz) {
     const T Jx[6] = {T(0), tz, -ty, T(1), T(0), T(0)};
     const T Jy[6] = {-tz, T(0), tx, T(0), T(1), T(0)};
@@ -228,7 +230,7 @@ __device__ __forceinline__ void AccumulateSymmetric(
     for (int j = 0; j < 6; ++j) {
 #pragma unroll
         for (int k = 0; k <= j; ++k) {
-            A[i] += (double)(J[j] * w * J[k]);
+            A[i] += J[j] * w * J[k];  // widened by the sum
             ++i;
         }
         A[21 + j] += (double)(J[j] * w * centered_residual);
@@ -459,31 +461,84 @@ InformationAccumulateKernel(const T* __restrict__ tgt,
     BlockReduceAndStore(A, partials);
 }
 
-// Fused search + accumulate, one query per 32 lanes. The 27 neighbour cells of
-// a query are independent look-ups (bucket bounds -> a handful of candidate
-// records); walking them one after the other from a single lane is a chain of
-// ~54 dependent memory round trips (~100 us per launch whatever the number of
-// queries). Here lane c of a 32-lane group scans cell c, the group then takes
-// the minimum by (d2, original index) -- the same winner the sequential scan
-// picks -- and its lane 0 forms the Jacobian terms. A wave serves two queries.
-// G = lanes per query (1, 2, 4, ... 32): few queries want G = 32 (latency),
-// many queries want a small G (every lane busy); the winner is the same.
+// TransformImpl.h:19-44
+template <typename T>
+struct Mat4 { T m[16]; };
+
+// Fused (transform +) search + accumulate. The 27 neighbour cells of a query
+// are independent look-ups (bucket range -> a handful of candidate records);
+// walking them one after the other from a single lane is a chain of ~54
+// dependent memory round trips. Here G lanes (1, 2, 4 ... 32) share a query:
+// lane c scans cells c, c + G, ..., the group takes the minimum by (d2,
+// original index) -- the same winner the sequential scan picks.
+//
+// A pass is a short chain of memory round trips per query whatever the bucket
+// sizes: (1) the query, (2) the ranges of all cells a lane owns, (3) their
+// records taken as one list, kFlight in flight together (a scanned surface at
+// the ICP radii has ~85 candidates per query, i.e. 85 / G per lane), (4) the
+// winner's record and normal. G is chosen so that all queries are in flight
+// at once (n G / 64 waves <= what the chip holds).
+//
+// The sums: every lane of the group forms the winner's terms (same inputs ->
+// same values) and keeps only the 32 / G of them it owns, term c + m * G in
+// register m -- so the running sums cost 2 * 32 / G registers instead of 64,
+// which is what bounds how many waves a SIMD holds while they wait on memory.
+// At the end the groups of a wave are added by xor shuffles, the waves through
+// LDS, one row per workgroup; the geometry is a function of (n, G) only, so
+// the result is run-to-run identical.
+//
+// apply_xf: the source point is first moved by `xf` exactly like
+// TransformPointsKernel would and stored back (the ICP driver's per-iteration
+// `source.Transform(update)` rides in the next search launch).
 // EST: 0 = point-to-plane terms (needs sorted normals), 1 = point-to-point
-// moments, 2 = information-matrix terms of the matched target point.
+// moments, 2 = information-matrix terms of the matched target point, 3 =
+// point-to-plane with L2Loss (weight 1).
+constexpr int kSearchBlock = 512;  // 8 waves; <= 512 rows for the final pass
+
+// The sums a lane of a G-lane group owns: term i lives in lane i % G, register
+// i / G. `S[i] += v` (i a compile-time constant once the callers' loops are
+// unrolled) adds v there and nothing (+0.0) elsewhere, so a term is consumed
+// the moment it is formed -- no 32-value temporary.
+template <int G>
+struct OwnedSums {
+    double (&mine)[kNumSums / G];
+    int c0;
+    struct Ref {
+        OwnedSums& o;
+        int i;
+        __device__ __forceinline__ void operator+=(double v) {
+            o.mine[i / G] += (i % G) == o.c0 ? v : 0.0;
+        }
+        // a float term is picked as a float and widened once
+        __device__ __forceinline__ void operator+=(float v) {
+            o.mine[i / G] += (double)((i % G) == o.c0 ? v : 0.0f);
+        }
+    };
+    __device__ __forceinline__ Ref operator[](int i) { return Ref{*this, i}; }
+};
+
 template <typename T, int G, int EST>
-__global__ void __launch_bounds__(kReduceBlock)
+__global__ void __launch_bounds__(kSearchBlock,
+                                  EST == 0 ? 2 : (G >= 8 ? 4 : (G >= 2 ? 3 : 2)))
 SearchAccumulateKernel(NnsView<T> nv, const Rec4<T>* __restrict__ sorted_n,
-                       const T* __restrict__ src, int64_t n, RobustParams rp,
+                       T* __restrict__ src, int64_t n, Mat4<T> xf,
+                       int apply_xf, RobustParams rp,
                        int64_t* __restrict__ corr_out,
                        double* __restrict__ partials) {
-    double A[kNumSums];
-#pragma unroll
-    for (int k = 0; k < kNumSums; ++k) A[k] = 0;
     constexpr int kPerWave = 64 / G;  // queries per wave
+    constexpr int kM = kNumSums / G;  // sums a lane owns
+    static_assert(kNumSums % G == 0, "G divides the number of sums");
+    double mine[kM];
+#pragma unroll
+    for (int m = 0; m < kM; ++m) mine[m] = 0;
     const int c0 = threadIdx.x & (G - 1);  // first neighbour cell of this lane
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int sub = (threadIdx.x & 63) / G;
+    constexpr int kOwn = (27 + G - 1) / G;        // cells a lane owns
+    constexpr int kBatch = kOwn < 9 ? kOwn : 9;   // cells per batch
+    // candidate records in flight per lane and round trip
+    constexpr int kFlight = sizeof(T) == 4 ? 16 : 8;
     for (int64_t base = wave * kPerWave; base < n; base += n_waves * kPerWave) {
         const int64_t i = base + sub;
         const bool valid = i < n;
@@ -494,51 +549,97 @@ SearchAccumulateKernel(NnsView<T> nv, const Rec4<T>* __restrict__ sorted_n,
             q[0] = src[3 * i + 0];
             q[1] = src[3 * i + 1];
             q[2] = src[3 * i + 2];
+            if (apply_xf) {
+                // TransformPointsKernel, statement by statement
+                const T p0 = q[0], p1 = q[1], p2 = q[2];
+                const T x0 = xf.m[0] * p0 + xf.m[1] * p1 + xf.m[2] * p2 + xf.m[3];
+                const T x1 = xf.m[4] * p0 + xf.m[5] * p1 + xf.m[6] * p2 + xf.m[7];
+                const T x2 = xf.m[8] * p0 + xf.m[9] * p1 + xf.m[10] * p2 + xf.m[11];
+                const T x3 = xf.m[12] * p0 + xf.m[13] * p1 + xf.m[14] * p2 + xf.m[15];
+                q[0] = x0 / x3;
+                q[1] = x1 / x3;
+                q[2] = x2 / x3;
+                if (c0 == 0) {
+                    src[3 * i + 0] = q[0];
+                    src[3 * i + 1] = q[1];
+                    src[3 * i + 2] = q[2];
+                }
+            }
             long long cx, cy, cz;
             CellOf(q, nv.inv_cell, cx, cy, cz);
-            // A lane owns cells c0, c0 + G, ...: the bucket bounds of a batch
-            // of them are fetched first (independent loads in flight
-            // together), then the records -- one dependent round trip per
-            // batch instead of two per cell.
-            constexpr int kOwn = (27 + G - 1) / G;
-            constexpr int kBatch = kOwn < 9 ? kOwn : 9;
+            // records by 32-bit byte offset off one scalar base (the index
+            // holds < 2^27 points): half the address registers per load in
+            // flight
+            auto record = [&](unsigned j) -> Rec4<T> {
+                const unsigned off = j * (unsigned)sizeof(Rec4<T>);
+                return *(const Rec4<T>*)((const char*)nv.sorted + off);
+            };
+            // branch-free; `live` = entry t of the list exists. The winner is
+            // remembered by its list entry and turned into a record position
+            // once per batch of cells.
+            bool have = false;
+            unsigned best_t = 0;
+            auto consider = [&](const Rec4<T>& p, unsigned t, bool live) {
+                T result = T(0);
+                const T d0 = q[0] - p.x;
+                result += d0 * d0;
+                const T d1 = q[1] - p.y;
+                result += d1 * d1;
+                const T dd = q[2] - p.z;
+                result += dd * dd;
+                const int pi = RecIndex(p);
+                const bool better =
+                        live && result < nv.radius_squared &&
+                        (!have || result < d2 || (result == d2 && pi < idx));
+                best_t = better ? t : best_t;
+                idx = better ? pi : idx;
+                d2 = better ? result : d2;
+                have = have || better;
+            };
             for (int cb = 0; cb < kOwn; cb += kBatch) {
-                unsigned s0[kBatch], e0[kBatch];
+                // ranges of the owned cells (one round trip), then their
+                // records as ONE list: entry t of the list is record
+                // t - first[k] of the cell k it falls into, so a round trip
+                // fetches kFlight candidates whatever the bucket sizes are
+                unsigned s0[kBatch], first[kBatch + 1];
+                first[0] = 0;
 #pragma unroll
                 for (int k = 0; k < kBatch; ++k) {
+                    // cells past the 27th: look at cell 26 again, keep nothing
                     const int c = c0 + (cb + k) * G;
-                    s0[k] = e0[k] = 0;
-                    if (c < 27) {
-                        const int dz = c / 9 - 1, dy = (c % 9) / 3 - 1,
-                                  dx = c % 3 - 1;
-                        const unsigned b =
-                                HashCell(cx + dx, cy + dy, cz + dz) & nv.mask;
-                        s0[k] = nv.starts[b];
-                        e0[k] = nv.starts[b + 1];
-                    }
+                    const int cc = c < 27 ? c : 26;
+                    const int dz = cc / 9 - 1, dy = (cc % 9) / 3 - 1,
+                              dx = cc % 3 - 1;
+                    const unsigned b =
+                            HashCell(cx + dx, cy + dy, cz + dz) & nv.mask;
+                    unsigned e;
+                    BucketRange(nv, b, s0[k], e);
+                    first[k + 1] = first[k] + (c < 27 ? e - s0[k] : 0u);
                 }
+                const unsigned total = first[kBatch];
+                auto position = [&](unsigned t) {
+                    unsigned j = s0[0] + t;
 #pragma unroll
-                for (int k = 0; k < kBatch; ++k) {
-                    for (unsigned j = s0[k]; j < e0[k]; ++j) {
-                        const Rec4<T> p = nv.sorted[j];
-                        T result = T(0);
-                        const T d0 = q[0] - p.x;
-                        result += d0 * d0;
-                        const T d1 = q[1] - p.y;
-                        result += d1 * d1;
-                        const T dd = q[2] - p.z;
-                        result += dd * dd;
-                        if (result < nv.radius_squared) {
-                            const int pi = RecIndex(p);
-                            if (pos < 0 || result < d2 ||
-                                (result == d2 && pi < idx)) {
-                                pos = (int)j;
-                                idx = pi;
-                                d2 = result;
-                            }
-                        }
+                    for (int k = 1; k < kBatch; ++k)
+                        j = t >= first[k] ? s0[k] + (t - first[k]) : j;
+                    return j;
+                };
+                const int idx_before = idx;
+                const bool had = have;
+                for (unsigned t0 = 0; t0 < total; t0 += kFlight) {
+                    Rec4<T> cand[kFlight];
+#pragma unroll
+                    for (int u = 0; u < kFlight; ++u) {
+                        const unsigned t = t0 + u;
+                        cand[u] = record(t < total ? position(t) : 0u);
                     }
+#pragma unroll
+                    for (int u = 0; u < kFlight; ++u)
+                        consider(cand[u], t0 + u, t0 + u < total);
                 }
+                // a new winner out of this batch of cells?
+                if (have && (!had || idx != idx_before))
+                    pos = (int)position(best_t);
             }
         }
         // minimum by (d2, idx) over the G lanes of the group
@@ -555,30 +656,49 @@ SearchAccumulateKernel(NnsView<T> nv, const Rec4<T>* __restrict__ sorted_n,
                 d2 = od2;
             }
         }
-        if (valid && c0 == 0) {
-            if (corr_out) corr_out[i] = pos >= 0 ? (int64_t)idx : (int64_t)-1;
-            if (pos >= 0) {
-                const Rec4<T> t = nv.sorted[pos];
-                if constexpr (EST == 0) {
-                    const Rec4<T> nn = sorted_n[pos];
-                    AccumulateP2Plane<T>(A, q[0], q[1], q[2], t.x, t.y, t.z,
-                                         nn.x, nn.y, nn.z, rp);
-                } else if constexpr (EST == 1) {
-                    AccumulateP2Point<T>(A, q[0], q[1], q[2], t.x, t.y, t.z);
-                } else {
-                    AccumulateInformation<T>(A, t.x, t.y, t.z);
-                }
-                A[29] += (double)d2;
-                A[30] += 1.0;
+        if (valid && c0 == 0 && corr_out)
+            corr_out[i] = pos >= 0 ? (int64_t)idx : (int64_t)-1;
+        if (pos >= 0) {  // the whole group agrees
+            const Rec4<T> t = nv.sorted[pos];
+            OwnedSums<G> S{mine, c0};
+            if constexpr (EST == 0 || EST == 3) {
+                const Rec4<T> nn = sorted_n[pos];
+                AccumulateP2Plane<T, OwnedSums<G>, EST == 3>(
+                        S, q[0], q[1], q[2], t.x, t.y, t.z, nn.x, nn.y, nn.z,
+                        rp);
+            } else if constexpr (EST == 1) {
+                AccumulateP2Point<T>(S, q[0], q[1], q[2], t.x, t.y, t.z);
+            } else {
+                AccumulateInformation<T>(S, t.x, t.y, t.z);
             }
+            S[29] += (double)d2;
+            S[30] += 1.0;
         }
     }
-    BlockReduceAndStore(A, partials);
+    // groups of the wave, then the waves of the workgroup
+    __shared__ double lds[kSearchBlock / 64][kNumSums];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if constexpr (G == 1) {
+        const double t = WaveReduceScatter<kNumSums>(mine);
+        if ((lane & 1) == 0) lds[wv][lane >> 1] = t;
+    } else {
+#pragma unroll
+        for (int m = 0; m < kM; ++m) {
+#pragma unroll
+            for (int sft = G; sft < 64; sft <<= 1)
+                mine[m] += __shfl_xor(mine[m], sft, 64);
+            if (lane < G) lds[wv][c0 + m * G] = mine[m];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumSums) {
+        double t = 0;
+#pragma unroll
+        for (int w = 0; w < kSearchBlock / 64; ++w) t += lds[w][threadIdx.x];
+        partials[(int64_t)blockIdx.x * kNumSums + threadIdx.x] = t;
+    }
 }
 
-// TransformImpl.h:19-44
-template <typename T>
-struct Mat4 { T m[16]; };
 
 template <typename T>
 __global__ void TransformPointsKernel(Mat4<T> t, T* __restrict__ pts,
@@ -906,6 +1026,13 @@ int o3dmi_icp_search_accumulate_post(
         int64_t* corr_out_dev, double* sums32_dev, double* mail_data,
         int* mail_flag, int mail_seq, o3dmi_stream_t stream);
 
+int o3dmi_internal_icp_transform_search_accumulate(
+        const o3dmi_nns_t* nns, void* src_dev, const double* transformation,
+        const void* tgt_normals_dev, int64_t n, int estimation,
+        int robust_kernel, double scaling_parameter, double shape_parameter,
+        int64_t* corr_out_dev, double* sums32_dev, double* mail_data,
+        int* mail_flag, int mail_seq, o3dmi_stream_t stream);
+
 int o3dmi_icp_search_accumulate_p2point(const o3dmi_nns_t* nns,
                                         const void* src_dev, int64_t n,
                                         int64_t* corr_out_dev,
@@ -937,6 +1064,21 @@ int o3dmi_icp_search_accumulate_post(
         int robust_kernel, double scaling_parameter, double shape_parameter,
         int64_t* corr_out_dev, double* sums32_dev, double* mail_data,
         int* mail_flag, int mail_seq, o3dmi_stream_t stream) {
+    return o3dmi_internal_icp_transform_search_accumulate(
+            nns, const_cast<void*>(src_dev), nullptr, tgt_normals_dev, n,
+            estimation, robust_kernel, scaling_parameter, shape_parameter,
+            corr_out_dev, sums32_dev, mail_data, mail_flag, mail_seq, stream);
+}
+
+// Internal: as above, and when `transformation` (row-major 4x4, float64) is
+// given the source points are first moved by it IN PLACE, with
+// o3dmi_transform_points' arithmetic, inside the same launch.
+int o3dmi_internal_icp_transform_search_accumulate(
+        const o3dmi_nns_t* nns, void* src_dev, const double* transformation,
+        const void* tgt_normals_dev, int64_t n, int estimation,
+        int robust_kernel, double scaling_parameter, double shape_parameter,
+        int64_t* corr_out_dev, double* sums32_dev, double* mail_data,
+        int* mail_flag, int mail_seq, o3dmi_stream_t stream) {
     O3DMI_REQUIRE(nns && src_dev && (sums32_dev || mail_data), "null argument");
     O3DMI_REQUIRE(estimation >= 0 && estimation <= 2,
                   "estimation must be point-to-plane (0), point-to-point (1) "
@@ -953,24 +1095,57 @@ int o3dmi_icp_search_accumulate_post(
         O3DMI_REQUIRE(nns->sorted_normals != nullptr,
                       "Target pointcloud missing normals attribute.");
     }
-    // Lanes per query: as many as keep the whole chip busy about once.
-    int group = 32;
-    while (group > 1 && n * group > (int64_t)kCUs * 2048) group >>= 1;
+    // Lanes per query, from the launch timings of tools/bench_search.py on
+    // the levels of a tracking frame (2 k ... 230 k queries): G = 32 only
+    // while it still leaves half the chip free (a lane then owns one cell,
+    // mostly an empty one); otherwise the largest G <= 16 that puts every
+    // query in flight at once (n G / 64 waves against the 4 waves per SIMD the
+    // kernel's registers allow); beyond that two rounds of waves at G = 4 / 2
+    // beat one round of lanes that own 14 or 27 cells each.
+    static const int64_t lane_scale = [] {
+        const char* e = std::getenv("O3DMI_NNS_LANES");
+        const int64_t v = e ? std::atoll(e) : 0;
+        return v > 0 ? v : (int64_t)kCUs * 1024;  // 4 waves per SIMD
+    }();
+    int group;
+    if (n * 32 <= lane_scale / 2) group = 32;
+    else if (n * 16 <= lane_scale) group = 16;
+    else if (n * 8 <= lane_scale) group = 8;
+    else if (n * 4 <= 2 * lane_scale) group = 4;
+    else if (n * 2 <= 4 * lane_scale) group = 2;
+    else group = 1;
     if (const char* e = std::getenv("O3DMI_NNS_GROUP")) {
         const int v = std::atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) group = v;
     }
-    int g = ReduceGrid(n * group);
+    // <= 512 workgroups of 8 waves: at most 512 rows for the final pass
+    int64_t g64 = (n * group + kSearchBlock - 1) / kSearchBlock;
+    if (g64 > (int64_t)kCUs * 2) g64 = (int64_t)kCUs * 2;
+    if (g64 < 1) g64 = 1;
+    const int g = (int)g64;
     RobustParams rp = MakeRobust(robust_kernel, scaling_parameter,
                                  shape_parameter);
+    const int apply_xf = transformation != nullptr;
+    Mat4<double> xd;
+    Mat4<float> xfl;
+    for (int k = 0; k < 16; ++k) {
+        xd.m[k] = transformation ? transformation[k] : (k % 5 == 0 ? 1.0 : 0.0);
+        xfl.m[k] = (float)xd.m[k];
+    }
+    auto xf_of = [&](auto tag) {
+        if constexpr (sizeof(tag) == 8) return xd;
+        else return xfl;
+    };
 #define O3DMI_SEARCH_E(T, G, E)                                                \
     hipLaunchKernelGGL((SearchAccumulateKernel<T, G, E>), dim3(g),            \
-                       dim3(kReduceBlock), 0, s, MakeView<T>(nns),            \
-                       (const Rec4<T>*)nns->sorted_normals,                   \
-                       (const T*)src_dev, n, rp, corr_out_dev, nns->partials)
+                       dim3(kSearchBlock), 0, s, MakeView<T>(nns),            \
+                       (const Rec4<T>*)nns->sorted_normals, (T*)src_dev, n,   \
+                       xf_of(T()), apply_xf, rp, corr_out_dev, nns->partials)
 #define O3DMI_SEARCH(T, G)                                                     \
     do {                                                                      \
-        if (estimation == 0) O3DMI_SEARCH_E(T, G, 0);                         \
+        if (estimation == 0 && robust_kernel == O3DMI_L2_LOSS)                \
+            O3DMI_SEARCH_E(T, G, 3);                                          \
+        else if (estimation == 0) O3DMI_SEARCH_E(T, G, 0);                    \
         else if (estimation == 1) O3DMI_SEARCH_E(T, G, 1);                    \
         else O3DMI_SEARCH_E(T, G, 2);                                         \
     } while (0)

@@ -6,7 +6,13 @@
 // density). Target points are *reordered* by bucket into 16-byte (32-byte for
 // f64) records {x,y,z,original index}, normals likewise, so a query's cell
 // visits read contiguous memory instead of chasing a CSR index through 12-byte
-// AoS points. Cell coordinates are computed in float64 on both the build and
+// AoS points. A bucket's records are contiguous, but buckets lie in memory in
+// the order their ranges were handed out (one wave-aggregated atomic per 64
+// buckets) -- no prefix sum over the table: the build is a memset and three
+// launches (count, hand out ranges, scatter points + normals) with no scratch
+// and nothing to wait for. ranges[b] = {end, count} of bucket b: one 8-byte
+// load per visited cell. Nothing a search returns depends on the order in
+// memory (every result is defined by (d2, original index)). Cell coordinates are computed in float64 on both the build and
 // the query side so that large-offset clouds (1000 m + 5 cm radius, cf.
 // cpp/tests/core/NearestNeighborSearch.cpp:831-869) bin consistently.
 #pragma once
@@ -20,7 +26,8 @@ struct o3dmi_nns {
     int64_t n_buckets = 0;
     void* sorted_pts = nullptr;      // Rec4<T>[n]
     void* sorted_normals = nullptr;  // Rec4<T>[n], optional
-    unsigned* starts = nullptr;      // [n_buckets + 1]
+    uint2* ranges = nullptr;         // [n_buckets + 1] {end, count}; the last
+                                     // entry is the build's running total
     double* partials = nullptr;      // [kCUs*4, kNumSums]
 };
 
@@ -58,17 +65,26 @@ __device__ __forceinline__ int RecIndex(const Rec4<T>& r) {
 template <typename T>
 struct NnsView {
     const Rec4<T>* sorted;      // [n] bucket-ordered {x,y,z,idx}
-    const unsigned* starts;     // [n_buckets + 1]
+    const uint2* ranges;        // [n_buckets] {end, count}
     double inv_cell;
     unsigned mask;
     T radius_squared;
 };
 
+// Records of bucket b: sorted[s .. e).
+template <typename T>
+__device__ __forceinline__ void BucketRange(const NnsView<T>& nv, unsigned b,
+                                            unsigned& s, unsigned& e) {
+    const uint2 r = nv.ranges[b];
+    e = r.x;
+    s = r.x - r.y;
+}
+
 template <typename T>
 inline NnsView<T> MakeView(const o3dmi_nns* nns) {
     NnsView<T> v;
     v.sorted = (const Rec4<T>*)nns->sorted_pts;
-    v.starts = nns->starts;
+    v.ranges = nns->ranges;
     v.inv_cell = nns->inv_cell;
     v.mask = (unsigned)(nns->n_buckets - 1);
     const T r = (T)nns->radius;  // NanoFlannImpl.h:332: T radius_squared

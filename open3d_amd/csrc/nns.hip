@@ -24,106 +24,89 @@
 namespace o3dmi {
 namespace {
 
-// K1: bucket histogram.
+// K1: bucket histogram into ranges[b].y.
 template <typename T>
 __global__ void CountKernel(const T* __restrict__ pts, int64_t n,
                             double inv_cell, unsigned mask,
-                            unsigned* __restrict__ counts) {
+                            uint2* __restrict__ ranges) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         long long cx, cy, cz;
         CellOf(pts + 3 * i, inv_cell, cx, cy, cz);
-        atomicAdd(&counts[HashCell(cx, cy, cz) & mask], 1u);
+        atomicAdd(&ranges[HashCell(cx, cy, cz) & mask].y, 1u);
     }
 }
 
-// K2: exclusive scan in three passes (1024 elements per workgroup).
-constexpr int kScanBlock = 256;
-constexpr int kScanItems = 4;
-__global__ void ScanLocalKernel(const unsigned* __restrict__ in,
-                                unsigned* __restrict__ out,
-                                unsigned* __restrict__ block_sums, int64_t n) {
-    __shared__ unsigned lds[kScanBlock];
-    int64_t base = (int64_t)blockIdx.x * kScanBlock * kScanItems;
-    unsigned v[kScanItems];
-    unsigned sum = 0;
+// K2: every bucket gets a contiguous range of records: a workgroup sums the
+// counts of its 1024 buckets (wave prefix, then the 16 wave totals through
+// LDS), one lane takes that many records off the running total
+// (ranges[n_buckets].x -- one atomic per 1024 buckets: same-address atomics
+// serialise, and a table has up to 2^27 buckets), the prefix places the
+// buckets. ranges[b].x = start here; the scatter moves it to the end.
+// n_buckets is a power of two >= 1024, so every workgroup is full.
+constexpr int kAssignBlock = 1024;
+__global__ void __launch_bounds__(kAssignBlock)
+AssignRangesKernel(uint2* __restrict__ ranges, int64_t n_buckets) {
+    __shared__ unsigned wave_total[kAssignBlock / 64];
+    __shared__ unsigned block_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t b0 = (int64_t)blockIdx.x * kAssignBlock; b0 < n_buckets;
+         b0 += (int64_t)gridDim.x * kAssignBlock) {
+        const int64_t b = b0 + threadIdx.x;
+        const unsigned c = ranges[b].y;
+        unsigned incl = c;
 #pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        int64_t i = base + (int64_t)threadIdx.x * kScanItems + k;
-        v[k] = i < n ? in[i] : 0u;
-        sum += v[k];
-    }
-    lds[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < kScanBlock; off <<= 1) {
-        unsigned t = threadIdx.x >= off ? lds[threadIdx.x - off] : 0u;
-        __syncthreads();
-        lds[threadIdx.x] += t;
-        __syncthreads();
-    }
-    unsigned excl = lds[threadIdx.x] - sum;
-    if (threadIdx.x == kScanBlock - 1) block_sums[blockIdx.x] = lds[threadIdx.x];
-#pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        int64_t i = base + (int64_t)threadIdx.x * kScanItems + k;
-        if (i < n) out[i] = excl;
-        excl += v[k];
-    }
-}
-__global__ void ScanBlockSumsKernel(unsigned* block_sums, int n_blocks) {
-    // single workgroup, sequential over chunks of 256
-    __shared__ unsigned lds[kScanBlock];
-    __shared__ unsigned carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < n_blocks; base += kScanBlock) {
-        int i = base + threadIdx.x;
-        unsigned v = i < n_blocks ? block_sums[i] : 0u;
-        lds[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < kScanBlock; off <<= 1) {
-            unsigned t = threadIdx.x >= off ? lds[threadIdx.x - off] : 0u;
-            __syncthreads();
-            lds[threadIdx.x] += t;
-            __syncthreads();
+        for (int m = 1; m < 64; m <<= 1) {
+            const unsigned o = __shfl_up(incl, m);
+            if (lane >= m) incl += o;
         }
-        if (i < n_blocks) block_sums[i] = carry + lds[threadIdx.x] - v;
+        if (lane == 63) wave_total[wave] = incl;
         __syncthreads();
-        if (threadIdx.x == kScanBlock - 1) carry += lds[threadIdx.x];
-        __syncthreads();
-    }
-}
-__global__ void ScanAddKernel(unsigned* __restrict__ out,
-                              const unsigned* __restrict__ block_sums,
-                              int64_t n) {
-    int64_t base = (int64_t)blockIdx.x * kScanBlock * kScanItems;
-    unsigned add = block_sums[blockIdx.x];
+        unsigned before = 0, total = 0;
 #pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        int64_t i = base + (int64_t)threadIdx.x * kScanItems + k;
-        if (i < n) out[i] += add;
+        for (int w = 0; w < kAssignBlock / 64; ++w) {
+            const unsigned t = wave_total[w];
+            before += w < wave ? t : 0u;
+            total += t;
+        }
+        if (threadIdx.x == 0)
+            block_base = total ? atomicAdd(&ranges[n_buckets].x, total) : 0u;
+        __syncthreads();
+        ranges[b].x = block_base + before + incl - c;
+        __syncthreads();  // block_base / wave_total are reused
     }
 }
 
-// K3: scatter points into bucket order as {x,y,z,idx} records.
+// K3: scatter points (and, when given, their normals) into bucket order as
+// {x,y,z,idx} records.
 template <typename T>
-__global__ void ScatterKernel(const T* __restrict__ pts, int64_t n,
+__global__ void ScatterKernel(const T* __restrict__ pts,
+                              const T* __restrict__ normals, int64_t n,
                               double inv_cell, unsigned mask,
-                              const unsigned* __restrict__ starts,
-                              unsigned* __restrict__ cursor,
-                              Rec4<T>* __restrict__ sorted) {
+                              uint2* __restrict__ ranges,
+                              Rec4<T>* __restrict__ sorted,
+                              Rec4<T>* __restrict__ sorted_normals) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
-        long long cx, cy, cz;
-        CellOf(pts + 3 * i, inv_cell, cx, cy, cz);
-        unsigned b = HashCell(cx, cy, cz) & mask;
-        unsigned pos = starts[b] + atomicAdd(&cursor[b], 1u);
         Rec4<T> r;
         r.x = pts[3 * i + 0];
         r.y = pts[3 * i + 1];
         r.z = pts[3 * i + 2];
         r.w = i;
+        const T p[3] = {r.x, r.y, r.z};
+        long long cx, cy, cz;
+        CellOf(p, inv_cell, cx, cy, cz);
+        const unsigned b = HashCell(cx, cy, cz) & mask;
+        const unsigned pos = atomicAdd(&ranges[b].x, 1u);
         sorted[pos] = r;
+        if (normals) {
+            Rec4<T> m;
+            m.x = normals[3 * i + 0];
+            m.y = normals[3 * i + 1];
+            m.z = normals[3 * i + 2];
+            m.w = 0;
+            sorted_normals[pos] = m;
+        }
     }
 }
 
@@ -160,7 +143,8 @@ __device__ __forceinline__ int SearchNearest(const NnsView<T>& nv, const T* q,
         for (int dy = -1; dy <= 1; ++dy)
             for (int dx = -1; dx <= 1; ++dx) {
                 unsigned b = HashCell(cx + dx, cy + dy, cz + dz) & nv.mask;
-                unsigned s = nv.starts[b], e = nv.starts[b + 1];
+                unsigned s, e;
+                BucketRange(nv, b, s, e);
                 for (unsigned j = s; j < e; ++j) {
                     Rec4<T> p = nv.sorted[j];
                     T result = T(0);
@@ -398,8 +382,9 @@ __device__ __forceinline__ void GatherCells(const NnsView<T>& nv, const T* qq,
             const long long cheb = max(ax, max(ay, az));
             if (cheb >= r_skip) {
                 const unsigned b = HashCell(x, y, z) & nv.mask;
-                s0 = nv.starts[b];
-                cnt = nv.starts[b + 1] - s0;
+                unsigned e0;
+                BucketRange(nv, b, s0, e0);
+                cnt = e0 - s0;
             }
         }
         unsigned incl = cnt;
@@ -891,13 +876,13 @@ __global__ void BoundsKernel(const T* __restrict__ pts, int64_t n,
     }
 }
 
-__global__ void CountOccupiedKernel(const unsigned* __restrict__ starts,
+__global__ void CountOccupiedKernel(const uint2* __restrict__ ranges,
                                     int64_t n_buckets,
                                     unsigned* __restrict__ occupied) {
     unsigned local = 0;
     for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
          b < n_buckets; b += (int64_t)gridDim.x * blockDim.x)
-        local += starts[b + 1] > starts[b] ? 1u : 0u;
+        local += ranges[b].y ? 1u : 0u;
     for (int m = 32; m > 0; m >>= 1) local += __shfl_xor(local, m);
     __shared__ unsigned wsum[kBlock / 64];
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = local;
@@ -917,45 +902,33 @@ using namespace o3dmi;
 namespace {
 
 template <typename T>
-int BuildIndex(o3dmi_nns* nns, const T* pts, hipStream_t s) {
+int BuildIndex(o3dmi_nns* nns, const T* pts, const T* normals, hipStream_t s) {
     const int64_t n = nns->n;
     int64_t nb = 1024;
     while (nb < 2 * n && nb < (1ll << 27)) nb <<= 1;
     nns->n_buckets = nb;
     unsigned mask = (unsigned)(nb - 1);
-    unsigned *counts = nullptr, *cursor = nullptr, *block_sums = nullptr;
-    int64_t n_scan = nb + 1;
-    int n_scan_blocks =
-            (int)((n_scan + kScanBlock * kScanItems - 1) / (kScanBlock * kScanItems));
-    { int st_; if ((st_ = PoolAlloc((void**)&counts, sizeof(unsigned) * n_scan))) return st_; }
-    { int st_; if ((st_ = PoolAlloc((void**)&cursor, sizeof(unsigned) * nb))) return st_; }
-    { int st_; if ((st_ = PoolAlloc((void**)&block_sums, sizeof(unsigned) * (n_scan_blocks + 1)))) return st_; }
-    { int st_; if ((st_ = PoolAlloc((void**)&nns->starts, sizeof(unsigned) * n_scan))) return st_; }
-    { int st_; if ((st_ = PoolAlloc(&nns->sorted_pts, sizeof(Rec4<T>) * (size_t)(n > 0 ? n : 1)))) return st_; }
+    const size_t recs = sizeof(Rec4<T>) * (size_t)(n > 0 ? n : 1);
+    { int st_; if ((st_ = PoolAlloc((void**)&nns->ranges, sizeof(uint2) * (size_t)(nb + 1)))) return st_; }
+    { int st_; if ((st_ = PoolAlloc(&nns->sorted_pts, recs))) return st_; }
+    if (normals)
+        { int st_; if ((st_ = PoolAlloc(&nns->sorted_normals, recs))) return st_; }
     { int st_; if ((st_ = PoolAlloc((void**)&nns->partials, sizeof(double) * kCUs * 4 * kNumSums))) return st_; }
-    O3DMI_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(unsigned) * n_scan, s));
-    O3DMI_HIP_CHECK(hipMemsetAsync(cursor, 0, sizeof(unsigned) * nb, s));
+    O3DMI_HIP_CHECK(hipMemsetAsync(nns->ranges, 0,
+                                   sizeof(uint2) * (size_t)(nb + 1), s));
     if (n > 0) {
         hipLaunchKernelGGL(CountKernel<T>, dim3(GridFor(n, kBlock)),
                            dim3(kBlock), 0, s, pts, n, nns->inv_cell, mask,
-                           counts);
-    }
-    hipLaunchKernelGGL(ScanLocalKernel, dim3(n_scan_blocks), dim3(kScanBlock),
-                       0, s, counts, nns->starts, block_sums, n_scan);
-    hipLaunchKernelGGL(ScanBlockSumsKernel, dim3(1), dim3(kScanBlock), 0, s,
-                       block_sums, n_scan_blocks);
-    hipLaunchKernelGGL(ScanAddKernel, dim3(n_scan_blocks), dim3(kScanBlock), 0,
-                       s, nns->starts, block_sums, n_scan);
-    if (n > 0) {
+                           nns->ranges);
+        hipLaunchKernelGGL(AssignRangesKernel,
+                           dim3(GridFor(nb, kAssignBlock)), dim3(kAssignBlock),
+                           0, s, nns->ranges, nb);
         hipLaunchKernelGGL(ScatterKernel<T>, dim3(GridFor(n, kBlock)),
-                           dim3(kBlock), 0, s, pts, n, nns->inv_cell, mask,
-                           nns->starts, cursor, (Rec4<T>*)nns->sorted_pts);
+                           dim3(kBlock), 0, s, pts, normals, n, nns->inv_cell,
+                           mask, nns->ranges, (Rec4<T>*)nns->sorted_pts,
+                           (Rec4<T>*)nns->sorted_normals);
     }
     O3DMI_HIP_CHECK(hipGetLastError());
-    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
-    PoolFree(counts);
-    PoolFree(cursor);
-    PoolFree(block_sums);
     return O3DMI_OK;
 }
 
@@ -988,13 +961,32 @@ extern "C" int o3dmi_nns_set_normals(o3dmi_nns_t* nns, const void* normals_dev,
 
 extern "C" {
 
+int o3dmi_internal_nns_create_with_normals(const void* points_dev,
+                                           const void* normals_dev, int64_t n,
+                                           int dtype, double radius,
+                                           o3dmi_stream_t stream,
+                                           o3dmi_nns_t** out);
+
 int o3dmi_nns_create(const void* points_dev, int64_t n, int dtype,
                      double radius, o3dmi_stream_t stream, o3dmi_nns_t** out) {
+    return o3dmi_internal_nns_create_with_normals(points_dev, nullptr, n,
+                                                  dtype, radius, stream, out);
+}
+
+// Internal (host drivers): the index with the target normals scattered into
+// record order by the build itself (o3dmi_nns_set_normals is a second pass
+// over a finished index). Stream-ordered: returns without waiting.
+int o3dmi_internal_nns_create_with_normals(const void* points_dev,
+                                           const void* normals_dev, int64_t n,
+                                           int dtype, double radius,
+                                           o3dmi_stream_t stream,
+                                           o3dmi_nns_t** out) {
     O3DMI_REQUIRE(out != nullptr, "out is null");
     O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
                   "points must be Float32 or Float64");
     O3DMI_REQUIRE(radius > 0, "radius must be positive");
-    O3DMI_REQUIRE(n >= 0 && n < (1ll << 31), "n out of range");
+    // records are addressed by 32-bit byte offsets (32 bytes each for f64)
+    O3DMI_REQUIRE(n >= 0 && n < (1ll << 27), "n out of range (< 2^27 points)");
     O3DMI_REQUIRE(n == 0 || points_dev != nullptr, "points is null");
     auto* nns = new o3dmi_nns();
     nns->dtype = dtype;
@@ -1003,8 +995,10 @@ int o3dmi_nns_create(const void* points_dev, int64_t n, int dtype,
     nns->inv_cell = 1.0 / (radius * 1.001);
     int st = dtype == O3DMI_F64
                      ? BuildIndex<double>(nns, (const double*)points_dev,
+                                          (const double*)normals_dev,
                                           (hipStream_t)stream)
                      : BuildIndex<float>(nns, (const float*)points_dev,
+                                         (const float*)normals_dev,
                                          (hipStream_t)stream);
     if (st != O3DMI_OK) {
         o3dmi_nns_destroy(nns);
@@ -1021,7 +1015,7 @@ int o3dmi_internal_nns_destroy_completed(o3dmi_nns_t* nns) {
     if (!nns) return O3DMI_OK;
     PoolFree(nns->sorted_pts);
     PoolFree(nns->sorted_normals);
-    PoolFree(nns->starts);
+    PoolFree(nns->ranges);
     PoolFree(nns->partials);
     delete nns;
     return O3DMI_OK;
@@ -1033,7 +1027,7 @@ int o3dmi_nns_destroy(o3dmi_nns_t* nns) {
     (void)hipDeviceSynchronize();
     PoolFree(nns->sorted_pts);
     PoolFree(nns->sorted_normals);
-    PoolFree(nns->starts);
+    PoolFree(nns->ranges);
     PoolFree(nns->partials);
     delete nns;
     return O3DMI_OK;
@@ -1177,8 +1171,8 @@ struct KnnResources {
         lv->inv_cell = 1.0 / cell;
         levels.push_back(lv);
         return dtype == O3DMI_F64
-                       ? BuildIndex<double>(lv, (const double*)points, s)
-                       : BuildIndex<float>(lv, (const float*)points, s);
+                       ? BuildIndex<double>(lv, (const double*)points, nullptr, s)
+                       : BuildIndex<float>(lv, (const float*)points, nullptr, s);
     }
     void DropLevels() {
         for (o3dmi_nns* lv : levels) o3dmi_nns_destroy(lv);
@@ -1266,7 +1260,7 @@ int o3dmi_nns_knn_search_counts(const void* points_dev, int64_t n,
         int g = GridFor(lv->n_buckets, kBlock);
         if (g > kCUs) g = kCUs;
         hipLaunchKernelGGL(CountOccupiedKernel, dim3(g), dim3(kBlock), 0, s,
-                           lv->starts, lv->n_buckets, occupied);
+                           lv->ranges, lv->n_buckets, occupied);
         unsigned occ = 0;
         O3DMI_HIP_CHECK(hipMemcpyAsync(&occ, occupied, sizeof(occ),
                                        hipMemcpyDeviceToHost, s));

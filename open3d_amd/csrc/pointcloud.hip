@@ -14,25 +14,35 @@
 // The float sums are order dependent, so a scatter-add with atomics would not
 // reproduce them. Instead:
 //   1. hash the voxel keys (packed 64-bit, open addressing) and record each
-//      slot's smallest point index (atomicMin);
-//   2. first points -> dense voxel ids in first-occurrence order (block counts,
-//      then a block-local scan on top of the preceding blocks' counts);
-//   3. STABLE counting sort of the points by voxel id, least-significant
-//      11-bit digit first (per pass: block histograms -> scatter that sums
-//      the (digit, block) table for its own offsets and ranks equal digits by
-//      wave, round and lane); keys are the dense ids, far below 2^22, so this
-//      is two passes -- every voxel's points end up contiguous and still in
-//      point order;
-//   4. one lane per voxel walks its segment and adds sequentially in float32.
+//      slot's smallest point index (atomicMin): the voxel's FIRST POINT;
+//   2. STABLE counting sort of the points by the index of their voxel's first
+//      point, least-significant digit first (<= 9 bits per digit, two passes
+//      up to 2^18 points; per pass: block histograms -> scatter that sums the
+//      (tile, digit) table down its columns for its own offsets and ranks
+//      equal digits by wave, round and lane): every voxel's points end up
+//      contiguous, still in point order, and the voxels in the order of their
+//      first points -- which is the output order;
+//   3. the rank of every first point among the first points (= the output row
+//      of its voxel) falls out of the same two launches of pass 0: the
+//      histogram launch counts the first points per tile, the scatter launch
+//      (which walks the points in index order) adds the preceding tiles'
+//      counts to a tile-local prefix;
+//   4. one lane per sorted element: a lane whose key differs from its left
+//      neighbour's starts a run, walks it (eight elements in flight at a
+//      time) adding sequentially in float32, and writes the voxel's row.
+// Seven launches per level (clear the table, insert, 2 x (histogram,
+// scatter), reduce).
 //
 // Nothing in the chain needs a host decision: the point count may live on the
 // device (the output count of the previous, finer level), every kernel bounds
 // itself by it, and the voxel count is left on the device as well. A pyramid
 // of several levels is therefore ONE string of launches with a single read-
 // back at its end (VdsAsync, used by the ICP driver); the public entry point
-// runs one level and reads the count back. The earlier form used a generic
-// radix sort (16 launches) and two host waits per level; at 77 k-point VGA
-// clouds the pyramid took 1.3 ms of a 1.7 ms tracking frame.
+// runs one level and reads the count back. History: a generic radix sort (16
+// launches) and two host waits per level took 1.3 ms of a 1.7 ms tracking
+// frame at VGA; dense voxel ids from a separate two-launch scan before the
+// sort, a segment-start launch after it and 2048-element tiles (whose scatter
+// spent 26 of its 32 us summing the offset table) came next.
 
 #include <type_traits>
 #include <utility>
@@ -45,16 +55,16 @@
 namespace o3dmi {
 namespace {
 
-constexpr int kSortBits = 11;
+constexpr int kSortBits = 9;                // at most; see SortPlan
 constexpr int kSortBins = 1 << kSortBits;
-constexpr int kSortBlock = 256;             // 4 waves
+constexpr int kSortBlock = 1024;            // 16 waves
+constexpr int kSortWaves = kSortBlock / 64;
 constexpr int kSortItems = 8;               // elements per thread
-constexpr int kSortTile = kSortBlock * kSortItems;  // 2048 elements per block
+constexpr int kSortTile = kSortBlock * kSortItems;  // 8192 elements per block
 
 struct VdsTable {
     unsigned long long* keys;  // [n_slots], kEmptyKey when free
     int* first;                // [n_slots] smallest point index
-    int* voxel;                // [n_slots] dense voxel id
     unsigned mask;
 };
 
@@ -78,8 +88,10 @@ __global__ void VdsInsertKernel(const T* __restrict__ pos, const int* n_dev,
         const long long cz = (long long)floor(pos[3 * (int64_t)i + 2] / vs);
         if (cx < -kKeyBias || cx >= kKeyBias || cy < -kKeyBias ||
             cy >= kKeyBias || cz < -kKeyBias || cz >= kKeyBias) {
+            // reported to the caller; the point stays a voxel of its own so
+            // that the rest of the chain sees consistent keys
             atomicOr(err, kErrKeyRange);
-            slot_of_point[i] = 0;
+            slot_of_point[i] = -1;
             continue;
         }
         const unsigned long long k = PackKey((int)cx, (int)cy, (int)cz);
@@ -96,8 +108,8 @@ __global__ void VdsInsertKernel(const T* __restrict__ pos, const int* n_dev,
     }
 }
 
-// Block-wide exclusive prefix of one value per thread (256 threads); returns
-// the prefix, *total = sum over the block.
+// Block-wide exclusive prefix of one value per thread (kSortBlock threads);
+// returns the prefix, *total = sum over the block. lds4: kSortWaves ints.
 __device__ __forceinline__ int BlockExclusive(int v, int* lds4, int* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int incl = v;
@@ -120,120 +132,116 @@ __device__ __forceinline__ int BlockExclusive(int v, int* lds4, int* total) {
     return base + incl - v;
 }
 
-// First points per tile of kSortTile points.
-__global__ void VdsCountFirstKernel(const int* __restrict__ slot_of_point,
-                                    const int* n_dev, int n_host, VdsTable tb,
-                                    int* __restrict__ tile_counts) {
-    __shared__ int lds4[4];
-    const int n = LiveCount(n_dev, n_host);
-    const int base = blockIdx.x * kSortTile;
-    if (base >= n) return;
-    int c = 0;
-#pragma unroll
-    for (int k = 0; k < kSortItems; ++k) {
-        const int i = base + threadIdx.x * kSortItems + k;
-        if (i < n) c += tb.first[slot_of_point[i]] == i;
-    }
-    int total;
-    (void)BlockExclusive(c, lds4, &total);
-    if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
-}
-
-// Dense voxel ids in first-occurrence order: preceding tiles' counts + the
-// tile-local prefix. Tile 0 also publishes the voxel count.
-__global__ void VdsAssignKernel(const int* __restrict__ slot_of_point,
-                                const int* n_dev, int n_host, VdsTable tb,
-                                const int* __restrict__ tile_counts,
-                                int* __restrict__ m_dev) {
-    __shared__ int lds4[4];
-    const int n = LiveCount(n_dev, n_host);
-    const int base = blockIdx.x * kSortTile;
-    if (base >= n && blockIdx.x != 0) return;
-    const int n_tiles = (n + kSortTile - 1) / kSortTile;
-    // counts of the tiles before this one (and of all tiles, for tile 0)
-    int before = 0, all = 0;
-    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
-        const int c = tile_counts[t];
-        all += c;
-        if (t < (int)blockIdx.x) before += c;
-    }
-    int tot_before, tot_all;
-    (void)BlockExclusive(before, lds4, &tot_before);
-    (void)BlockExclusive(all, lds4, &tot_all);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *m_dev = tot_all;
-    if (base >= n) return;
-    bool f[kSortItems];
-    int c = 0;
-#pragma unroll
-    for (int k = 0; k < kSortItems; ++k) {
-        const int i = base + threadIdx.x * kSortItems + k;
-        f[k] = i < n && tb.first[slot_of_point[i]] == i;
-        c += f[k];
-    }
-    int total;
-    int id = tot_before + BlockExclusive(c, lds4, &total);
-#pragma unroll
-    for (int k = 0; k < kSortItems; ++k) {
-        const int i = base + threadIdx.x * kSortItems + k;
-        if (f[k]) tb.voxel[slot_of_point[i]] = id++;
-    }
-}
-
-// ---- stable counting sort, one 11-bit digit per pass ------------------------
+// ---- stable counting sort, one digit of <= 9 bits per pass --------------------
 // A block owns kSortTile consecutive elements; wave w of the block owns the
 // elements [w * 512, (w + 1) * 512) of the tile, visited in 8 rounds of 64
 // (element = tile + w * 512 + round * 64 + lane), so (block, wave, round, lane)
-// is index order. hist is digit-major: hist[digit * tile_stride + tile].
+// is index order. hist is tile-major: hist[tile * bins + digit] (both the
+// histogram pass and the scatter's column sums touch it coalesced).
+//
+// The digit width follows the key range (SortPlan): two passes up to 2^18
+// keys, ceil(bits / 9) beyond. Tiles are large (8192 elements) because every
+// scatter block sums the (tile, digit) table down its columns for its own
+// offsets: 512 columns x n_tiles rows, read once per block with all loads of a
+// column in flight -- 10 rows for a VGA frame cloud, 29 at 720p. (The first
+// version had 2048-element tiles and 2048 digits; that sum was 8 x n_tiles
+// dependent loads per thread and took 26 of the pass's 32 us.)
 
-// kMakeKeys: pass 0 also creates the keys (voxel id of every point) and the
-// values (point indices).
+struct SortPlan {
+    int passes, bits;  // bits per digit
+};
+inline SortPlan PlanSort(int64_t n_keys) {
+    int key_bits = 1;
+    while ((1ll << key_bits) < n_keys) ++key_bits;
+    SortPlan p;
+    p.passes = key_bits <= 2 * kSortBits ? 2
+                                         : (key_bits + kSortBits - 1) / kSortBits;
+    p.bits = (key_bits + p.passes - 1) / p.passes;
+    return p;
+}
+
+// kMakeKeys: pass 0 also creates the keys (index of the first point of every
+// point's voxel) and the values (point indices), and counts the tile's first
+// points (key == own index).
 template <bool kMakeKeys>
 __global__ void __launch_bounds__(kSortBlock)
 SortHistKernel(const int* __restrict__ slot_of_point, VdsTable tb,
                unsigned* __restrict__ keys, unsigned* __restrict__ vals,
-               const int* n_dev, int n_host, int shift, int tile_stride,
-               int* __restrict__ hist) {
+               const int* n_dev, int n_host, int shift, int bits,
+               int* __restrict__ hist, int* __restrict__ tile_firsts) {
     __shared__ int h[kSortBins];
+    __shared__ int firsts;
     const int n = LiveCount(n_dev, n_host);
     const int base = blockIdx.x * kSortTile;
     if (base >= n) return;
-    for (int b = threadIdx.x; b < kSortBins; b += kSortBlock) h[b] = 0;
+    const int bins = 1 << bits;
+    for (int b = threadIdx.x; b < bins; b += kSortBlock) h[b] = 0;
+    if (threadIdx.x == 0) firsts = 0;
     __syncthreads();
+    unsigned key[kSortItems];
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const int i = base + k * kSortBlock + threadIdx.x;
+        key[k] = 0;
+        if (i < n) {
+            if constexpr (kMakeKeys) {
+                const int slot = slot_of_point[i];
+                key[k] = slot < 0 ? (unsigned)i : (unsigned)tb.first[slot];
+            } else {
+                key[k] = keys[i];
+            }
+        }
+    }
+    int mine = 0;
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k) {
         const int i = base + k * kSortBlock + threadIdx.x;
         if (i < n) {
-            unsigned key;
             if constexpr (kMakeKeys) {
-                key = (unsigned)tb.voxel[slot_of_point[i]];
-                keys[i] = key;
+                keys[i] = key[k];
                 vals[i] = (unsigned)i;
-            } else {
-                key = keys[i];
+                mine += key[k] == (unsigned)i;
             }
-            atomicAdd(&h[(key >> shift) & (kSortBins - 1)], 1);
+            atomicAdd(&h[(key[k] >> shift) & (bins - 1)], 1);
         }
     }
+    if constexpr (kMakeKeys) {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) mine += __shfl_xor(mine, m);
+        if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&firsts, mine);
+    }
     __syncthreads();
-    for (int b = threadIdx.x; b < kSortBins; b += kSortBlock)
-        hist[(int64_t)b * tile_stride + blockIdx.x] = h[b];
+    for (int b = threadIdx.x; b < bins; b += kSortBlock)
+        hist[(int64_t)blockIdx.x * bins + b] = h[b];
+    if constexpr (kMakeKeys)
+        if (threadIdx.x == 0) tile_firsts[blockIdx.x] = firsts;
 }
 
+// kRank (pass 0, which walks the points in index order): also numbers the first
+// points -- rank_of_first[i] = how many first points precede point i = the
+// output row of the voxel that point i opens -- and block 0 publishes their
+// total, the voxel count.
+template <bool kRank>
 __global__ void __launch_bounds__(kSortBlock)
 SortScatterKernel(const unsigned* __restrict__ keys_in,
                   const unsigned* __restrict__ vals_in,
                   unsigned* __restrict__ keys_out,
                   unsigned* __restrict__ vals_out, const int* n_dev, int n_host,
-                  int shift, int tile_stride, const int* __restrict__ hist) {
-    __shared__ int wh[kSortBlock / 64][kSortBins];  // 32 KiB
-    __shared__ int dbase[kSortBins];                // 8 KiB
-    __shared__ int lds4[4];
+                  int shift, int bits, const int* __restrict__ hist,
+                  const int* __restrict__ tile_firsts,
+                  int* __restrict__ rank_of_first, int* __restrict__ m_dev) {
+    __shared__ int wh[kSortWaves][kSortBins];  // 32 KiB
+    __shared__ int dbase[kSortBins];
+    __shared__ int lds4[kSortWaves];
+    __shared__ int wave_firsts[kSortWaves];
+    __shared__ int firsts_before;
     const int n = LiveCount(n_dev, n_host);
     const int tile = blockIdx.x * kSortTile;
     if (tile >= n) return;
+    const int bins = 1 << bits;
+    const int n_tiles = (n + kSortTile - 1) / kSortTile;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int b = threadIdx.x; b < kSortBins * (kSortBlock / 64);
-         b += kSortBlock)
+    for (int b = threadIdx.x; b < kSortBins * kSortWaves; b += kSortBlock)
         (&wh[0][0])[b] = 0;
     __syncthreads();
     const int wbase = tile + wave * (kSortItems * 64);
@@ -246,65 +254,99 @@ SortScatterKernel(const unsigned* __restrict__ keys_in,
         if (e < n) {
             key[r] = keys_in[e];
             val[r] = vals_in[e];
-            atomicAdd(&wh[wave][(key[r] >> shift) & (kSortBins - 1)], 1);
         }
     }
-    __syncthreads();
-    // Where this tile's run of every digit starts: all elements with a
-    // smaller digit (over all tiles) + the same digit in the tiles before
-    // this one. The (digit, tile) table is small (2048 x a few dozen tiles
-    // for the clouds of a tracking frame), so every block sums what it needs
-    // itself -- two launches fewer per pass than a separate table scan, and
-    // this chain is launch-latency bound. Thread t owns the 8 consecutive
-    // digits 8 t .. 8 t + 7, so that the block prefix is in digit order.
-    {
-        const int n_tiles = (n + kSortTile - 1) / kSortTile;
-        int tot[kSortBins / kSortBlock], before[kSortBins / kSortBlock];
-        int mine = 0;
 #pragma unroll
-        for (int q = 0; q < kSortBins / kSortBlock; ++q) {
-            const int dgt = threadIdx.x * (kSortBins / kSortBlock) + q;
-            const int* row = hist + (int64_t)dgt * tile_stride;
-            int a = 0, bsum = 0;
-            for (int t = 0; t < n_tiles; ++t) {
-                const int c = row[t];
-                a += c;
-                if (t < (int)blockIdx.x) bsum += c;
+    for (int r = 0; r < kSortItems; ++r)
+        if (wbase + r * 64 + lane < n)
+            atomicAdd(&wh[wave][(key[r] >> shift) & (bins - 1)], 1);
+    // Where this tile's run of every digit starts: all elements with a smaller
+    // digit (over all tiles) + the same digit in the tiles before this one.
+    // Thread d sums column d of the table, sixteen rows in flight at a time.
+    {
+        int all = 0, before = 0;
+        if ((int)threadIdx.x < bins) {
+            const int* col = hist + threadIdx.x;
+            for (int t0 = 0; t0 < n_tiles; t0 += 16) {
+                int c[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    c[u] = t0 + u < n_tiles ? col[(int64_t)(t0 + u) * bins] : 0;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    all += c[u];
+                    before += t0 + u < (int)blockIdx.x ? c[u] : 0;
+                }
             }
-            tot[q] = a;
-            before[q] = bsum;
-            mine += a;
+        }
+        if constexpr (kRank) {
+            // first points in the tiles before this one (last wave: its lanes
+            // are not needed for the columns when bins <= 512)
+            if (wave == kSortWaves - 1) {
+                int fb = 0, fa = 0;
+                for (int t = lane; t < n_tiles; t += 64) {
+                    const int c = tile_firsts[t];
+                    fa += c;
+                    fb += t < (int)blockIdx.x ? c : 0;
+                }
+#pragma unroll
+                for (int m = 32; m > 0; m >>= 1) {
+                    fa += __shfl_xor(fa, m);
+                    fb += __shfl_xor(fb, m);
+                }
+                if (lane == 0) {
+                    firsts_before = fb;
+                    if (blockIdx.x == 0) *m_dev = fa;
+                }
+            }
         }
         int total;
-        int run = BlockExclusive(mine, lds4, &total);
-#pragma unroll
-        for (int q = 0; q < kSortBins / kSortBlock; ++q) {
-            dbase[threadIdx.x * (kSortBins / kSortBlock) + q] = run + before[q];
-            run += tot[q];
-        }
+        const int run = BlockExclusive(all, lds4, &total);
+        if ((int)threadIdx.x < bins) dbase[threadIdx.x] = run + before;
     }
     __syncthreads();
     // per digit: where each wave's run starts in the output
-    for (int b = threadIdx.x; b < kSortBins; b += kSortBlock) {
+    for (int b = threadIdx.x; b < bins; b += kSortBlock) {
         int off = dbase[b];
 #pragma unroll
-        for (int w = 0; w < kSortBlock / 64; ++w) {
+        for (int w = 0; w < kSortWaves; ++w) {
             const int c = wh[w][b];
             wh[w][b] = off;
             off += c;
         }
     }
-    __syncthreads();
     const unsigned long long lt = (1ull << lane) - 1ull;
+    if constexpr (kRank) {
+        // first points of this wave's 512 elements, in element order
+        int cnt = 0;
+#pragma unroll
+        for (int r = 0; r < kSortItems; ++r) {
+            const int e = wbase + r * 64 + lane;
+            cnt += __popcll(__ballot(e < n && key[r] == (unsigned)e));
+        }
+        if (lane == 0) wave_firsts[wave] = cnt;
+    }
+    __syncthreads();
+    if constexpr (kRank) {
+        int rank = firsts_before;
+        for (int w = 0; w < wave; ++w) rank += wave_firsts[w];
+#pragma unroll
+        for (int r = 0; r < kSortItems; ++r) {
+            const int e = wbase + r * 64 + lane;
+            const bool is_first = e < n && key[r] == (unsigned)e;
+            const unsigned long long fm = __ballot(is_first);
+            if (is_first) rank_of_first[e] = rank + __popcll(fm & lt);
+            rank += __popcll(fm);
+        }
+    }
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         const int e = wbase + r * 64 + lane;
         const bool valid = e < n;
-        const unsigned d = (key[r] >> shift) & (kSortBins - 1);
+        const unsigned d = (key[r] >> shift) & (bins - 1);
         // lanes of this round holding the same digit
         unsigned long long same = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < kSortBits; ++b) {
+        for (int b = 0; b < bits; ++b) {
             const bool bit = (d >> b) & 1u;
             const unsigned long long bal = __ballot(bit);
             same &= bit ? bal : ~bal;
@@ -321,38 +363,67 @@ SortScatterKernel(const unsigned* __restrict__ keys_in,
     }
 }
 
-__global__ void VdsSegmentsKernel(const unsigned* __restrict__ sorted_voxel,
-                                  const int* n_dev, int n_host,
-                                  int* __restrict__ seg_start) {
-    const int n = LiveCount(n_dev, n_host);
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n;
-         j += gridDim.x * blockDim.x) {
-        if (j == 0 || sorted_voxel[j] != sorted_voxel[j - 1])
-            seg_start[sorted_voxel[j]] = j;
-        if (j == n - 1) seg_start[sorted_voxel[j] + 1] = n;
+// Empty hash table, no first points: one launch instead of two fills.
+__global__ void VdsInitKernel(VdsTable tb, int64_t n_slots) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+         i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
+        tb.keys[i] = kEmptyKey;
+        tb.first[i] = 0x7FFFFFFF;
     }
 }
 
+// One lane per sorted element; run starts (key != left neighbour's key) walk
+// their run, kRun elements in flight at a time, adding in float32 in element
+// (= point) order; the row comes from the run's key, the index of the voxel's
+// first point.
+constexpr int kRun = 8;
 template <typename T>
 __global__ void VdsReduceKernel(const T* __restrict__ pos,
                                 const T* __restrict__ nrm,
+                                const unsigned* __restrict__ sorted_key,
                                 const unsigned* __restrict__ sorted_point,
-                                const int* __restrict__ seg_start,
-                                const int* __restrict__ m_dev,
+                                const int* __restrict__ rank_of_first,
+                                const int* n_dev, int n_host,
                                 T* __restrict__ out_pos,
                                 T* __restrict__ out_nrm) {
-    const int m = *m_dev;
-    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < m;
-         v += gridDim.x * blockDim.x) {
-        const int b = seg_start[v], e = seg_start[v + 1];
+    const int n = LiveCount(n_dev, n_host);
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n;
+         j += gridDim.x * blockDim.x) {
+        const unsigned k = sorted_key[j];
+        if (j > 0 && sorted_key[j - 1] == k) continue;
+        const int v = rank_of_first[k];
         float cnt = 0.f, sp[3] = {0.f, 0.f, 0.f}, sn[3] = {0.f, 0.f, 0.f};
-        for (int j = b; j < e; ++j) {
-            const int64_t i = sorted_point[j];
-            cnt += 1.0f;
+        bool more = true;
+        for (int j0 = j; more; j0 += kRun) {
+            unsigned kk[kRun], pi[kRun];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                sp[c] += (float)pos[3 * i + c];
-                if (nrm) sn[c] += (float)nrm[3 * i + c];
+            for (int u = 0; u < kRun; ++u) {
+                const int jj = j0 + u < n ? j0 + u : n - 1;
+                kk[u] = sorted_key[jj];
+                pi[u] = sorted_point[jj];
+            }
+            float p[kRun][3], q[kRun][3];
+#pragma unroll
+            for (int u = 0; u < kRun; ++u) {
+                // elements past the run read the run's first point (in cache)
+                const int64_t i = kk[u] == k ? pi[u] : k;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    p[u][c] = (float)pos[3 * i + c];
+                    q[u][c] = nrm ? (float)nrm[3 * i + c] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kRun; ++u) {
+                more = more && j0 + u < n && kk[u] == k;
+                if (more) {
+                    cnt += 1.0f;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        sp[c] += p[u][c];
+                        sn[c] += q[u][c];
+                    }
+                }
             }
         }
 #pragma unroll
@@ -385,55 +456,48 @@ int VdsAsyncImpl(const T* pos, const T* nrm, int64_t n_max, const int* n_dev,
     int st;
     if ((st = alloc(&tb.keys, (size_t)n_slots))) return st;
     if ((st = alloc(&tb.first, (size_t)n_slots))) return st;
-    if ((st = alloc(&tb.voxel, (size_t)n_slots))) return st;
     tb.mask = (unsigned)(n_slots - 1);
-    int *slot_of_point, *tile_counts, *hist, *seg_start;
+    int *slot_of_point, *tile_firsts, *hist, *rank_of_first;
     unsigned *keys_a, *vals_a, *keys_b, *vals_b;
     if ((st = alloc(&slot_of_point, (size_t)n_max))) return st;
-    if ((st = alloc(&tile_counts, (size_t)n_tiles))) return st;
+    if ((st = alloc(&tile_firsts, (size_t)n_tiles))) return st;
     if ((st = alloc(&hist, (size_t)kSortBins * n_tiles))) return st;
-    if ((st = alloc(&seg_start, (size_t)n_max + 2))) return st;
+    if ((st = alloc(&rank_of_first, (size_t)n_max))) return st;
     if ((st = alloc(&keys_a, (size_t)n_max))) return st;
     if ((st = alloc(&vals_a, (size_t)n_max))) return st;
     if ((st = alloc(&keys_b, (size_t)n_max))) return st;
     if ((st = alloc(&vals_b, (size_t)n_max))) return st;
-    O3DMI_HIP_CHECK(hipMemsetAsync(tb.keys, 0xFF,
-                                   sizeof(unsigned long long) * (size_t)n_slots,
-                                   s));
-    O3DMI_HIP_CHECK(hipMemsetAsync(tb.first, 0x7F,
-                                   sizeof(int) * (size_t)n_slots, s));
     const dim3 grid(GridFor(n_max, kBlock)), block(kBlock);
     const dim3 tiles((unsigned)n_tiles), sblock(kSortBlock);
+    hipLaunchKernelGGL(VdsInitKernel, dim3(GridFor(n_slots, kBlock)), block, 0,
+                       s, tb, n_slots);
     hipLaunchKernelGGL(VdsInsertKernel<T>, grid, block, 0, s, pos, n_dev,
                        n_host, (T)voxel_size, tb, slot_of_point, err_dev);
-    hipLaunchKernelGGL(VdsCountFirstKernel, tiles, sblock, 0, s, slot_of_point,
-                       n_dev, n_host, tb, tile_counts);
-    hipLaunchKernelGGL(VdsAssignKernel, tiles, sblock, 0, s, slot_of_point,
-                       n_dev, n_host, tb, tile_counts, m_dev);
-    // keys = dense voxel ids < n_max: as many 11-bit passes as they need
-    int bits = 1;
-    while ((1ll << bits) < n_max) ++bits;
-    const int passes = (bits + kSortBits - 1) / kSortBits;
+    // keys = index of the voxel's first point < n_max
+    const SortPlan plan = PlanSort(n_max);
     unsigned *ki = keys_a, *vi = vals_a, *ko = keys_b, *vo = vals_b;
-    for (int p = 0; p < passes; ++p) {
-        const int shift = p * kSortBits;
-        if (p == 0)
+    for (int p = 0; p < plan.passes; ++p) {
+        const int shift = p * plan.bits;
+        if (p == 0) {
             hipLaunchKernelGGL(SortHistKernel<true>, tiles, sblock, 0, s,
                                slot_of_point, tb, ki, vi, n_dev, n_host, shift,
-                               n_tiles, hist);
-        else
+                               plan.bits, hist, tile_firsts);
+            hipLaunchKernelGGL(SortScatterKernel<true>, tiles, sblock, 0, s, ki,
+                               vi, ko, vo, n_dev, n_host, shift, plan.bits,
+                               hist, tile_firsts, rank_of_first, m_dev);
+        } else {
             hipLaunchKernelGGL(SortHistKernel<false>, tiles, sblock, 0, s,
                                slot_of_point, tb, ki, vi, n_dev, n_host, shift,
-                               n_tiles, hist);
-        hipLaunchKernelGGL(SortScatterKernel, tiles, sblock, 0, s, ki, vi, ko,
-                           vo, n_dev, n_host, shift, n_tiles, hist);
+                               plan.bits, hist, tile_firsts);
+            hipLaunchKernelGGL(SortScatterKernel<false>, tiles, sblock, 0, s,
+                               ki, vi, ko, vo, n_dev, n_host, shift, plan.bits,
+                               hist, tile_firsts, rank_of_first, m_dev);
+        }
         std::swap(ki, ko);
         std::swap(vi, vo);
     }
-    hipLaunchKernelGGL(VdsSegmentsKernel, grid, block, 0, s, ki, n_dev, n_host,
-                       seg_start);
-    hipLaunchKernelGGL(VdsReduceKernel<T>, grid, block, 0, s, pos, nrm, vi,
-                       seg_start, m_dev, out_pos, out_nrm);
+    hipLaunchKernelGGL(VdsReduceKernel<T>, grid, block, 0, s, pos, nrm, ki, vi,
+                       rank_of_first, n_dev, n_host, out_pos, out_nrm);
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
 }

@@ -90,10 +90,22 @@ FinalSumKernel(const double* __restrict__ partials, int n_rows,
     __shared__ double lds[kFinalRowLanes][32];
     const int col = threadIdx.x & 31;
     const int rl = threadIdx.x >> 5;
+    // rows rl, rl + 32, ...: sixteen loads in flight at a time (the rows were
+    // written by other XCDs and come from the fabric, ~1 us each if taken one
+    // after the other), added in row order.
     double v = 0;
-    if (col < N)
-        for (int r = rl; r < n_rows; r += kFinalRowLanes)
-            v += partials[(int64_t)r * N + col];
+    if (col < N) {
+        for (int r0 = rl; r0 < n_rows; r0 += 16 * kFinalRowLanes) {
+            double x[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int r = r0 + k * kFinalRowLanes;
+                x[k] = r < n_rows ? partials[(int64_t)r * N + col] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v += x[k];
+        }
+    }
     lds[rl][col] = v;
     __syncthreads();
     if (threadIdx.x < N) {

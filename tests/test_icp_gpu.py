@@ -377,6 +377,26 @@ def test_voxel_down_sample_bit_exact(dtype, voxel):
     assert e.shape[0] == 0
 
 
+def test_voxel_down_sample_large_cloud_three_sort_passes():
+    """300 k points: the first-point keys need 19 bits, i.e. three sort passes,
+    37 tiles (more than one batch of the offset-table column sums); 1 cm
+    voxels on a 2 mm-spaced surface give runs of dozens of points (several
+    batches of the run walk). Also chained: the output of one level is the
+    input of the next, as the ICP pyramid does it."""
+    _lib, reg = _gpu()
+    p = _pair(300000, seed=21)
+    pts, nrm = p["target"], p["target_normals"]
+    for voxel in (0.01, 0.04):
+        wp, wn = orc.voxel_down_sample(pts, nrm, voxel)
+        gp, gn = reg.voxel_down_sample(torch.from_numpy(pts).cuda(),
+                                       torch.from_numpy(nrm).cuda(), voxel)
+        assert gp.shape[0] == wp.shape[0]
+        assert np.array_equal(gp.cpu().numpy(), wp)
+        assert np.array_equal(gn.cpu().numpy(), wn)
+        pts, nrm = wp, wn
+    assert 100 < pts.shape[0] < 100000
+
+
 def test_multiscale_icp_pose_parity():
     """BASELINE configs[2] pyramid (5 / 2.5 / 1.25 cm voxels, iterations
     20/10/5): device VoxelDownSample pyramid + per-scale index + fused

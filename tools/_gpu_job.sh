@@ -1,14 +1,23 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2r
-timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/r2r/pytest.log 2>&1; tail -3 gpurun_out/r2r/pytest.log
-timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r2r/bench.json 2> gpurun_out/r2r/bench.err; python - <<'PY'
-import json
-d=json.loads(open("gpurun_out/r2r/bench.json").read().strip().splitlines()[-1])
-print("value", round(d["value"]), "timed_s", round(d["config"]["timed_region_s"],3))
-r=d["roofline"]; print({k:r.get(k) for k in ("frac","frac_hbm","frac_valu","avg_kernel_ms","traffic","valu_insts_per_launch","avg_waves_per_simd","frames_per_launch","traffic_source")})
-s=d.get("secondary",{})
-for k,v in s.items():
-    print(k, {a:v[a] for a in v if a in ("ms_per_icp","ms_per_iteration","frames_per_s","ms_per_frame","cpu_oracle_ms_per_icp","cpu_oracle_ms_per_multiscale_icp","error")}, "frac", v.get("roofline",{}).get("frac") if isinstance(v,dict) else None)
-print(d.get("cpu_baseline"))
-PY
-tail -2 gpurun_out/r2r/bench.err
+O=gpurun_out/r2v; mkdir -p $O
+timeout 1500 python -m pytest tests/test_icp_gpu.py tests/test_normals_gpu.py tests/test_golden.py -x -q -m gpu > $O/pytest.log 2>&1; tail -5 $O/pytest.log
+timeout 900 python -m pytest tests/test_configs_gpu.py -x -q -m gpu -k configs2 > $O/pytest2.log 2>&1; tail -3 $O/pytest2.log
+timeout 300 python tools/bench_search.py 2>/dev/null | tail -1 | tee $O/search_vga.json
+timeout 300 python tools/bench_search.py --hd 2>/dev/null | tail -1 | tee $O/search_hd.json
+P='import json,sys
+for l in sys.stdin:
+    if l.startswith("{"):
+        d=json.loads(l); print({k:(round(v,3) if isinstance(v,float) else v) for k,v in d.items() if k in ("frames_per_s","ms_per_frame","icp_iterations_per_frame","ms_model_cloud_frame_cloud_icp_integrate","ms_per_icp","ms_per_iteration","iterations")})'
+for rep in 1 2; do
+for LIB in $PWD/_ab/libo3d_base.so ""; do
+  export O3DMI_LIB=$LIB; echo "=== lib ${LIB:-new} rep $rep"
+  echo -n "vga      "; timeout 300 python tools/bench_slam.py --mode slam --vga --frames 60 --no-cpu 2>/dev/null | python -c "$P"
+  echo -n "720      "; timeout 300 python tools/bench_slam.py --mode slam --frames 60 --no-cpu 2>/dev/null | python -c "$P"
+done; done
+export O3DMI_LIB=
+O3DMI_ICP_TIMING=2 timeout 300 python tools/bench_slam.py --mode slam --vga --frames 30 --no-cpu --phases > $O/t2_phases.log 2>&1
+grep "whole call" $O/t2_phases.log | sed -n 8,16p; tail -1 $O/t2_phases.log | cut -c1-500
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_vga -o vga -- python $GRAFT_REPO_ROOT/tools/bench_slam.py --mode slam --vga --frames 60 --no-cpu > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+f=$(find /tmp/prof_vga -name "*kernel_stats.csv" | head -1); cp "$f" $O/slam_vga_kernel_stats.csv
