@@ -228,6 +228,13 @@ hipStream_t SideStream() {
     return side;
 }
 
+hipEvent_t SideEvent() {
+    static thread_local hipEvent_t ev = nullptr;
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+        ev = nullptr;
+    return ev;
+}
+
 // `completed`: set by the owner once every kernel that used the index is
 // known to have finished (its results were read on the host); the destructor
 // then skips the device-wide wait of the public o3dmi_nns_destroy.
@@ -359,28 +366,33 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
     // InitializePointCloudPyramidForMultiScaleICP, Registration.cpp:221-273.
     std::vector<Level> pyr((size_t)num_scales);
     // Declared after the pyramid so that it runs first on every exit path:
-    // pooled buffers may only be released once the stream has drained.
+    // pooled buffers may only be released once the streams have drained.
     struct SyncOnExit {
-        hipStream_t s;
-        ~SyncOnExit() { (void)hipStreamSynchronize(s); }
-    } sync_on_exit{s};
+        hipStream_t s, side;
+        ~SyncOnExit() {
+            (void)hipStreamSynchronize(s);
+            if (side && side != s) (void)hipStreamSynchronize(side);
+        }
+    } sync_on_exit{s, nullptr};
     const int last = num_scales - 1;
     int st;
     // One index per scale (target_nns.HybridIndex(max_correspondence_distance),
-    // Registration.cpp:406-412), built by the target chain right behind the
-    // level it indexes -- on the side stream, while the source pyramid is
-    // still being built -- so no scale waits for its index.
+    // Registration.cpp:406-412), built right behind the pyramids.
     std::vector<NnsGuard> guards((size_t)num_scales);
     const double t_entry =
             std::chrono::duration<double, std::micro>(
                     std::chrono::steady_clock::now().time_since_epoch())
                     .count();
     // The source pyramid and the target pyramid are independent chains of
-    // VoxelDownSample calls, each a string of small launches with read-backs
-    // in between (voxel counts size the next level) -- latency, not
-    // throughput. The target chain runs on a side stream from a helper thread
-    // while this thread builds the source chain: the pyramid of a 720p frame
-    // (2 x 230 k points, 3 levels) takes about as long as one chain.
+    // VoxelDownSample levels, each a string of small launches whose sizes stay
+    // on the device (the voxel count of one level is the point count of the
+    // next; level buffers are sized by the input cloud) -- latency, not
+    // throughput. One host thread issues both, level by level, the source
+    // chain on the caller's stream and the target chain on a side stream, so
+    // the GPU works on the two chains at once; the counts of both are read
+    // back once, at the end. (Round 2 first ran the target chain from a helper
+    // thread: the thread start and its first HIP call cost more than issuing
+    // the second chain's launches from here.)
     auto clone = [&](DeviceBuffer& dst, const void* src, int64_t n,
                      hipStream_t cs) -> int {
         int e = dst.Alloc((size_t)n * 3 * esz);
@@ -389,22 +401,17 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                                        hipMemcpyDeviceToDevice, cs));
         return O3DMI_OK;
     };
-    // Every level of a chain is a string of launches whose sizes stay on the
-    // device (the voxel count of one level is the point count of the next);
-    // level buffers are sized by the input cloud, the counts are read back
-    // once per chain.
-    auto source_chain = [&](hipStream_t cs) -> int {
+    const bool finest_is_input = voxel_sizes[last] <= 0;
+    ChainCounts scc, tcc;
+    struct ChainGuard {
+        ChainCounts& c;
+        hipStream_t s;
+        ~ChainGuard() { c.Release(s); }
+    };
+    auto source_level = [&](int k, hipStream_t cs) -> int {
         int e;
-        ChainCounts cc;
-        struct Guard {
-            ChainCounts& c;
-            hipStream_t s;
-            ~Guard() { c.Release(s); }
-        } guard{cc, cs};
-        if ((e = cc.Init(num_scales, cs))) return e;
-        Level& L = pyr[(size_t)last];
-        const bool finest_is_input = voxel_sizes[last] <= 0;
-        if (finest_is_input) {
+        Level& L = pyr[(size_t)k];
+        if (k == last && finest_is_input) {
             L.ns = ns;
             // the source is moved in place every iteration: private copies
             if ((e = clone(L.src, source_dev, ns, cs))) return e;
@@ -412,185 +419,159 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                 return e;
             if (colored && (e = clone(L.srcc, source_colors_dev, ns, cs)))
                 return e;
-        } else {
-            if ((e = L.src.Alloc((size_t)ns * 3 * esz))) return e;
-            if (symmetric && (e = L.srcn.Alloc((size_t)ns * 3 * esz))) return e;
-            if (colored && (e = L.srcc.Alloc((size_t)ns * 3 * esz))) return e;
-            e = DownSampleAttrsAsync(source_dev, ns, nullptr, dtype,
-                                     voxel_sizes[last], L.src.p,
-                                     cc.Count(last), cc.Err(), cc.scratch, cs,
-                                     {{source_normals_dev, L.srcn.p},
-                                      {source_colors_dev, L.srcc.p}});
-            if (e) return e;
+            return O3DMI_OK;
         }
-        for (int k = num_scales - 2; k >= 0; --k) {
-            Level& C = pyr[(size_t)k];
-            Level& F = pyr[(size_t)k + 1];
-            if ((e = C.src.Alloc((size_t)ns * 3 * esz))) return e;
-            if (symmetric && (e = C.srcn.Alloc((size_t)ns * 3 * esz)))
-                return e;
-            if (colored && (e = C.srcc.Alloc((size_t)ns * 3 * esz))) return e;
-            const bool f_host = k + 1 == last && finest_is_input;
-            e = DownSampleAttrsAsync(F.src.p, ns,
-                                     f_host ? nullptr : cc.Count(k + 1), dtype,
-                                     voxel_sizes[k], C.src.p, cc.Count(k),
-                                     cc.Err(), cc.scratch, cs,
-                                     {{F.srcn.p, C.srcn.p},
-                                      {F.srcc.p, C.srcc.p}});
-            if (e) return e;
+        if ((e = L.src.Alloc((size_t)ns * 3 * esz))) return e;
+        if (symmetric && (e = L.srcn.Alloc((size_t)ns * 3 * esz))) return e;
+        if (colored && (e = L.srcc.Alloc((size_t)ns * 3 * esz))) return e;
+        if (k == last)
+            return DownSampleAttrsAsync(source_dev, ns, nullptr, dtype,
+                                        voxel_sizes[k], L.src.p, scc.Count(k),
+                                        scc.Err(), scc.scratch, cs,
+                                        {{source_normals_dev, L.srcn.p},
+                                         {source_colors_dev, L.srcc.p}});
+        Level& F = pyr[(size_t)k + 1];
+        const bool f_host = k + 1 == last && finest_is_input;
+        return DownSampleAttrsAsync(F.src.p, ns,
+                                    f_host ? nullptr : scc.Count(k + 1), dtype,
+                                    voxel_sizes[k], L.src.p, scc.Count(k),
+                                    scc.Err(), scc.scratch, cs,
+                                    {{F.srcn.p, L.srcn.p},
+                                     {F.srcc.p, L.srcc.p}});
+    };
+    bool finest_on_host = finest_is_input;
+    auto target_level = [&](int k, hipStream_t cs) -> int {
+        o3dmi_stream_t cstream = (o3dmi_stream_t)cs;
+        int e;
+        Level& L = pyr[(size_t)k];
+        if (k == last) {
+            if (finest_is_input) {
+                L.nt = nt;
+                L.tgt_ptr = target_dev;
+                L.nrm_ptr = target_normals_dev;
+                L.tgtc_ptr = target_colors_dev;
+                L.tgtg_ptr = target_gradients_dev;
+            } else {
+                if ((e = L.tgt.Alloc((size_t)nt * 3 * esz))) return e;
+                if (need_tn && (e = L.nrm.Alloc((size_t)nt * 3 * esz)))
+                    return e;
+                if (colored) {
+                    if ((e = L.tgtc.Alloc((size_t)nt * 3 * esz))) return e;
+                    if (target_gradients_dev &&
+                        (e = L.tgtg.Alloc((size_t)nt * 3 * esz)))
+                        return e;
+                }
+                e = DownSampleAttrsAsync(target_dev, nt, nullptr, dtype,
+                                         voxel_sizes[k], L.tgt.p,
+                                         tcc.Count(k), tcc.Err(), tcc.scratch,
+                                         cs,
+                                         {{target_normals_dev, L.nrm.p},
+                                          {target_colors_dev, L.tgtc.p},
+                                          {target_gradients_dev, L.tgtg.p}});
+                if (e) return e;
+                L.tgt_ptr = L.tgt.p;
+                L.nrm_ptr = L.nrm.p;  // stays NULL without normals
+                L.tgtc_ptr = L.tgtc.p;
+                L.tgtg_ptr = L.tgtg.p;
+            }
+            if (colored && !L.tgtg_ptr) {
+                // Registration.cpp:243-262: EstimateColorGradients(30, radius)
+                // on the finest level of the target pyramid. The operator
+                // needs the level's size on the host: this (rare) path waits.
+                if (!finest_is_input) {
+                    int host_n = 0;
+                    O3DMI_HIP_CHECK(hipMemcpyAsync(&host_n, tcc.Count(k),
+                                                   sizeof(int),
+                                                   hipMemcpyDeviceToHost, cs));
+                    O3DMI_HIP_CHECK(hipStreamSynchronize(cs));
+                    L.nt = host_n;
+                    finest_on_host = true;
+                }
+                const double radius = voxel_sizes[k] <= 0 ? max_dists[k] * 2.0
+                                                          : voxel_sizes[k] * 4.0;
+                if ((e = L.tgtg.Alloc((size_t)nt * 3 * esz))) return e;
+                e = o3dmi_pointcloud_estimate_color_gradients(
+                        L.tgt_ptr, L.nrm_ptr, L.tgtc_ptr, L.nt, dtype, 30,
+                        radius, L.tgtg.p, cstream);
+                if (e) return e;
+                L.tgtg_ptr = L.tgtg.p;
+            }
+            return O3DMI_OK;
+        }
+        Level& F = pyr[(size_t)k + 1];
+        if ((e = L.tgt.Alloc((size_t)nt * 3 * esz))) return e;
+        if (need_tn && (e = L.nrm.Alloc((size_t)nt * 3 * esz))) return e;
+        if (colored) {
+            if ((e = L.tgtc.Alloc((size_t)nt * 3 * esz))) return e;
+            if ((e = L.tgtg.Alloc((size_t)nt * 3 * esz))) return e;
+        }
+        // the finest level's size is a host number when it is the input
+        // itself (or was read back above): then n_max = that size
+        const bool f_host = k + 1 == last && finest_on_host;
+        e = DownSampleAttrsAsync(F.tgt_ptr, f_host ? F.nt : nt,
+                                 f_host ? nullptr : tcc.Count(k + 1), dtype,
+                                 voxel_sizes[k], L.tgt.p, tcc.Count(k),
+                                 tcc.Err(), tcc.scratch, cs,
+                                 {{F.nrm_ptr, L.nrm.p},
+                                  {F.tgtc_ptr, L.tgtc.p},
+                                  {F.tgtg_ptr, L.tgtg.p}});
+        if (e) return e;
+        L.tgt_ptr = L.tgt.p;
+        L.nrm_ptr = L.nrm.p;
+        L.tgtc_ptr = L.tgtc.p;
+        L.tgtg_ptr = L.tgtg.p;
+        return O3DMI_OK;
+    };
+    // Two streams unless there is nothing to overlap (a single level without
+    // down-sampling is two copies) or O3DMI_SERIAL_PYRAMID asks for one.
+    const bool overlap = (num_scales > 1 || voxel_sizes[last] > 0) &&
+                         std::getenv("O3DMI_SERIAL_PYRAMID") == nullptr;
+    hipStream_t side = s;
+    hipEvent_t ev = nullptr;
+    if (overlap) {
+        side = SideStream();
+        ev = SideEvent();
+        O3DMI_REQUIRE(side != nullptr && ev != nullptr,
+                      "side stream creation failed");
+        sync_on_exit.side = side;
+        // the caller's clouds may still be in flight on its stream
+        O3DMI_HIP_CHECK(hipEventRecord(ev, s));
+        O3DMI_HIP_CHECK(hipStreamWaitEvent(side, ev, 0));
+    }
+    bool indices_on_side = false;
+    {
+        ChainGuard sg{scc, s}, tg{tcc, side};
+        if ((st = scc.Init(num_scales, s))) return st;
+        if ((st = tcc.Init(num_scales, side))) return st;
+        for (int k = last; k >= 0; --k) {
+            if ((st = target_level(k, side))) return st;
+            if ((st = source_level(k, s))) return st;
         }
         std::vector<int> counts;
-        if ((e = cc.Fetch(counts, cs))) return e;
+        if ((st = tcc.Fetch(counts, side))) return st;
+        for (int k = 0; k < num_scales; ++k)
+            if (!(k == last && finest_on_host))
+                pyr[(size_t)k].nt = counts[(size_t)k];
+        // Indices: the first scale's on the caller's stream (its first search
+        // follows at once), the others on the side stream while the first
+        // scale iterates.
+        for (int k = 0; k < num_scales; ++k) {
+            const Level& Lk = pyr[(size_t)k];
+            hipStream_t is = k == 0 ? s : side;
+            if ((st = o3dmi_internal_nns_create_with_normals(
+                         Lk.tgt_ptr, p2plane ? Lk.nrm_ptr : nullptr, Lk.nt,
+                         dtype, max_dists[k], (o3dmi_stream_t)is,
+                         &guards[(size_t)k].nns)))
+                return st;
+        }
+        if (overlap && num_scales > 1) {
+            O3DMI_HIP_CHECK(hipEventRecord(ev, side));
+            indices_on_side = true;
+        }
+        if ((st = scc.Fetch(counts, s))) return st;
         for (int k = 0; k < num_scales; ++k)
             if (!(k == last && finest_is_input))
                 pyr[(size_t)k].ns = counts[(size_t)k];
-        return O3DMI_OK;
-    };
-    auto target_chain = [&](hipStream_t cs) -> int {
-        o3dmi_stream_t cstream = (o3dmi_stream_t)cs;
-        int e;
-        ChainCounts cc;
-        struct Guard {
-            ChainCounts& c;
-            hipStream_t s;
-            ~Guard() { c.Release(s); }
-        } guard{cc, cs};
-        if ((e = cc.Init(num_scales, cs))) return e;
-        Level& L = pyr[(size_t)last];
-        const bool finest_is_input = voxel_sizes[last] <= 0;
-        bool finest_on_host = finest_is_input;
-        if (finest_is_input) {
-            L.nt = nt;
-            L.tgt_ptr = target_dev;
-            L.nrm_ptr = target_normals_dev;
-            L.tgtc_ptr = target_colors_dev;
-            L.tgtg_ptr = target_gradients_dev;
-        } else {
-            if ((e = L.tgt.Alloc((size_t)nt * 3 * esz))) return e;
-            if (need_tn && (e = L.nrm.Alloc((size_t)nt * 3 * esz))) return e;
-            if (colored) {
-                if ((e = L.tgtc.Alloc((size_t)nt * 3 * esz))) return e;
-                if (target_gradients_dev &&
-                    (e = L.tgtg.Alloc((size_t)nt * 3 * esz)))
-                    return e;
-            }
-            e = DownSampleAttrsAsync(target_dev, nt, nullptr, dtype,
-                                     voxel_sizes[last], L.tgt.p,
-                                     cc.Count(last), cc.Err(), cc.scratch, cs,
-                                     {{target_normals_dev, L.nrm.p},
-                                      {target_colors_dev, L.tgtc.p},
-                                      {target_gradients_dev, L.tgtg.p}});
-            if (e) return e;
-            L.tgt_ptr = L.tgt.p;
-            L.nrm_ptr = L.nrm.p;  // stays NULL without normals
-            L.tgtc_ptr = L.tgtc.p;
-            L.tgtg_ptr = L.tgtg.p;
-        }
-        if (colored && !L.tgtg_ptr) {
-            // Registration.cpp:243-262: EstimateColorGradients(30, radius) on
-            // the finest level of the target pyramid. The operator needs the
-            // level's size on the host: this (rare) path waits here.
-            if (!finest_is_input) {
-                int host_n = 0;
-                O3DMI_HIP_CHECK(hipMemcpyAsync(&host_n, cc.Count(last),
-                                               sizeof(int),
-                                               hipMemcpyDeviceToHost, cs));
-                O3DMI_HIP_CHECK(hipStreamSynchronize(cs));
-                L.nt = host_n;
-                finest_on_host = true;
-            }
-            const double radius = voxel_sizes[last] <= 0
-                                          ? max_dists[last] * 2.0
-                                          : voxel_sizes[last] * 4.0;
-            if ((e = L.tgtg.Alloc((size_t)nt * 3 * esz))) return e;
-            e = o3dmi_pointcloud_estimate_color_gradients(
-                    L.tgt_ptr, L.nrm_ptr, L.tgtc_ptr, L.nt, dtype, 30, radius,
-                    L.tgtg.p, cstream);
-            if (e) return e;
-            L.tgtg_ptr = L.tgtg.p;
-        }
-        for (int k = num_scales - 2; k >= 0; --k) {
-            Level& C = pyr[(size_t)k];
-            Level& F = pyr[(size_t)k + 1];
-            if ((e = C.tgt.Alloc((size_t)nt * 3 * esz))) return e;
-            if (need_tn && (e = C.nrm.Alloc((size_t)nt * 3 * esz))) return e;
-            if (colored) {
-                if ((e = C.tgtc.Alloc((size_t)nt * 3 * esz))) return e;
-                if ((e = C.tgtg.Alloc((size_t)nt * 3 * esz))) return e;
-            }
-            // the finest level's size is a host number when it is the input
-            // itself (or was read back above): then n_max = that size
-            const bool f_host = k + 1 == last && finest_on_host;
-            e = DownSampleAttrsAsync(F.tgt_ptr, f_host ? F.nt : nt,
-                                     f_host ? nullptr : cc.Count(k + 1), dtype,
-                                     voxel_sizes[k], C.tgt.p, cc.Count(k),
-                                     cc.Err(), cc.scratch, cs,
-                                     {{F.nrm_ptr, C.nrm.p},
-                                      {F.tgtc_ptr, C.tgtc.p},
-                                      {F.tgtg_ptr, C.tgtg.p}});
-            if (e) return e;
-            C.tgt_ptr = C.tgt.p;
-            C.nrm_ptr = C.nrm.p;
-            C.tgtc_ptr = C.tgtc.p;
-            C.tgtg_ptr = C.tgtg.p;
-        }
-        std::vector<int> counts;
-        if ((e = cc.Fetch(counts, cs))) return e;
-        for (int k = 0; k < num_scales; ++k)
-            if (!(k == last && finest_is_input))
-                pyr[(size_t)k].nt = counts[(size_t)k];
-        for (int k = 0; k < num_scales; ++k) {
-            const Level& Lk = pyr[(size_t)k];
-            if ((e = o3dmi_internal_nns_create_with_normals(
-                         Lk.tgt_ptr, p2plane ? Lk.nrm_ptr : nullptr, Lk.nt,
-                         dtype, max_dists[k], cstream,
-                         &guards[(size_t)k].nns)))
-                return e;
-        }
-        return O3DMI_OK;
-    };
-    // Anything to overlap? (a single level without down-sampling is two
-    // copies and no read-back)
-    const bool overlap = (num_scales > 1 || voxel_sizes[last] > 0) &&
-                         std::getenv("O3DMI_SERIAL_PYRAMID") == nullptr;
-    if (!overlap) {
-        if ((st = source_chain(s))) return st;
-        if ((st = target_chain(s))) return st;
-    } else {
-        // inputs may still be in flight on the caller's stream
-        O3DMI_HIP_CHECK(hipStreamSynchronize(s));
-        hipStream_t side = SideStream();
-        O3DMI_REQUIRE(side != nullptr, "side stream creation failed");
-        int st_target = O3DMI_OK;
-        std::string err_target;
-        int device = 0;
-        O3DMI_HIP_CHECK(hipGetDevice(&device));
-        auto helper_body = [&] {
-            // a new thread starts on device 0: follow the caller's device
-            if (hipSetDevice(device) != hipSuccess) {
-                st_target = O3DMI_ERR_HIP;
-                err_target = "hipSetDevice failed in the pyramid helper";
-                return;
-            }
-            st_target = target_chain(side);
-            if (st_target) err_target = o3dmi_last_error();
-            (void)hipStreamSynchronize(side);
-        };
-        std::thread helper;
-        bool threaded = true;
-        try {
-            helper = std::thread(helper_body);
-        } catch (...) {  // no thread to be had: build the chains one by one
-            threaded = false;
-        }
-        st = source_chain(s);
-        if (threaded) helper.join();
-        else helper_body();
-        if (st) return st;
-        if (st_target) {
-            SetLastError(err_target);  // the message was set in the helper
-            return st_target;
-        }
     }
 
     exit_timer.Mark("pyramid");
@@ -726,6 +707,8 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         // target_nns.HybridIndex(max_correspondence_distance) :406-412:
         // built behind the target pyramid (above)
         NnsGuard& guard = guards[(size_t)scale_idx];
+        if (scale_idx == 1 && indices_on_side)
+            O3DMI_HIP_CHECK(hipStreamWaitEvent(s, ev, 0));
 
         if (timing) {
             (void)hipStreamSynchronize(s);

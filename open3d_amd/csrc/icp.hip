@@ -1096,12 +1096,13 @@ int o3dmi_internal_icp_transform_search_accumulate(
                       "Target pointcloud missing normals attribute.");
     }
     // Lanes per query, from the launch timings of tools/bench_search.py on
-    // the levels of a tracking frame (2 k ... 230 k queries): G = 32 only
-    // while it still leaves half the chip free (a lane then owns one cell,
-    // mostly an empty one); otherwise the largest G <= 16 that puts every
-    // query in flight at once (n G / 64 waves against the 4 waves per SIMD the
-    // kernel's registers allow); beyond that two rounds of waves at G = 4 / 2
-    // beat one round of lanes that own 14 or 27 cells each.
+    // the levels of a tracking frame and on the raw clouds (2 k ... 230 k
+    // queries, profiles/r2w_search_*.json): G = 32 only while it leaves half
+    // the chip free (a lane then owns one cell, mostly an empty one); G = 16
+    // while that puts every query in flight at once (n G / 64 waves against
+    // the 4 waves per SIMD the kernel's registers allow); G = 8 beyond --
+    // several rounds of waves whose lanes own 4 cells each beat one round of
+    // lanes that own 7, 14 or 27.
     static const int64_t lane_scale = [] {
         const char* e = std::getenv("O3DMI_NNS_LANES");
         const int64_t v = e ? std::atoll(e) : 0;
@@ -1110,10 +1111,7 @@ int o3dmi_internal_icp_transform_search_accumulate(
     int group;
     if (n * 32 <= lane_scale / 2) group = 32;
     else if (n * 16 <= lane_scale) group = 16;
-    else if (n * 8 <= lane_scale) group = 8;
-    else if (n * 4 <= 2 * lane_scale) group = 4;
-    else if (n * 2 <= 4 * lane_scale) group = 2;
-    else group = 1;
+    else group = 8;
     if (const char* e = std::getenv("O3DMI_NNS_GROUP")) {
         const int v = std::atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) group = v;

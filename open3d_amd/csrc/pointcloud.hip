@@ -79,13 +79,19 @@ __global__ void VdsInsertKernel(const T* __restrict__ pos, const int* n_dev,
                                 int n_host, T vs, VdsTable tb,
                                 int* __restrict__ slot_of_point,
                                 int* __restrict__ err) {
-    const int n = LiveCount(n_dev, n_host);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+    // The live count comes from device memory (the previous level wrote it):
+    // the points are fetched alongside it, bounded by the buffer size, and
+    // dropped afterwards if they turn out to lie past it -- one memory round
+    // trip less at the head of every kernel of the chain.
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_host;
          i += gridDim.x * blockDim.x) {
+        const T px = pos[3 * (int64_t)i + 0], py = pos[3 * (int64_t)i + 1],
+                pz = pos[3 * (int64_t)i + 2];
+        if (i >= LiveCount(n_dev, n_host)) break;
         // (p / vs).Floor().To(Int64)
-        const long long cx = (long long)floor(pos[3 * (int64_t)i + 0] / vs);
-        const long long cy = (long long)floor(pos[3 * (int64_t)i + 1] / vs);
-        const long long cz = (long long)floor(pos[3 * (int64_t)i + 2] / vs);
+        const long long cx = (long long)floor(px / vs);
+        const long long cy = (long long)floor(py / vs);
+        const long long cz = (long long)floor(pz / vs);
         if (cx < -kKeyBias || cx >= kKeyBias || cy < -kKeyBias ||
             cy >= kKeyBias || cz < -kKeyBias || cz >= kKeyBias) {
             // reported to the caller; the point stays a voxel of its own so
@@ -171,25 +177,30 @@ SortHistKernel(const int* __restrict__ slot_of_point, VdsTable tb,
                int* __restrict__ hist, int* __restrict__ tile_firsts) {
     __shared__ int h[kSortBins];
     __shared__ int firsts;
-    const int n = LiveCount(n_dev, n_host);
     const int base = blockIdx.x * kSortTile;
+    // fetched alongside the live count (see VdsInsertKernel)
+    unsigned key[kSortItems];
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const int i = base + k * kSortBlock + threadIdx.x;
+        key[k] = 0xFFFFFFFFu;
+        if (i < n_host)
+            key[k] = kMakeKeys ? (unsigned)slot_of_point[i] : keys[i];
+    }
+    const int n = LiveCount(n_dev, n_host);
     if (base >= n) return;
     const int bins = 1 << bits;
     for (int b = threadIdx.x; b < bins; b += kSortBlock) h[b] = 0;
     if (threadIdx.x == 0) firsts = 0;
     __syncthreads();
-    unsigned key[kSortItems];
+    if constexpr (kMakeKeys) {
 #pragma unroll
-    for (int k = 0; k < kSortItems; ++k) {
-        const int i = base + k * kSortBlock + threadIdx.x;
-        key[k] = 0;
-        if (i < n) {
-            if constexpr (kMakeKeys) {
-                const int slot = slot_of_point[i];
-                key[k] = slot < 0 ? (unsigned)i : (unsigned)tb.first[slot];
-            } else {
-                key[k] = keys[i];
-            }
+        for (int k = 0; k < kSortItems; ++k) {
+            const int i = base + k * kSortBlock + threadIdx.x;
+            const int slot = (int)key[k];
+            // a slot read past the live count is whatever the buffer held
+            key[k] = i < n && slot >= 0 ? (unsigned)tb.first[slot & tb.mask]
+                                        : (unsigned)i;
         }
     }
     int mine = 0;
@@ -235,27 +246,28 @@ SortScatterKernel(const unsigned* __restrict__ keys_in,
     __shared__ int lds4[kSortWaves];
     __shared__ int wave_firsts[kSortWaves];
     __shared__ int firsts_before;
-    const int n = LiveCount(n_dev, n_host);
     const int tile = blockIdx.x * kSortTile;
-    if (tile >= n) return;
-    const int bins = 1 << bits;
-    const int n_tiles = (n + kSortTile - 1) / kSortTile;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int b = threadIdx.x; b < kSortBins * kSortWaves; b += kSortBlock)
-        (&wh[0][0])[b] = 0;
-    __syncthreads();
     const int wbase = tile + wave * (kSortItems * 64);
+    // fetched alongside the live count (see VdsInsertKernel)
     unsigned key[kSortItems], val[kSortItems];
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         const int e = wbase + r * 64 + lane;
         key[r] = 0;
         val[r] = 0;
-        if (e < n) {
+        if (e < n_host) {
             key[r] = keys_in[e];
             val[r] = vals_in[e];
         }
     }
+    const int n = LiveCount(n_dev, n_host);
+    if (tile >= n) return;
+    const int bins = 1 << bits;
+    const int n_tiles = (n + kSortTile - 1) / kSortTile;
+    for (int b = threadIdx.x; b < kSortBins * kSortWaves; b += kSortBlock)
+        (&wh[0][0])[b] = 0;
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r)
         if (wbase + r * 64 + lane < n)
@@ -386,11 +398,14 @@ __global__ void VdsReduceKernel(const T* __restrict__ pos,
                                 const int* n_dev, int n_host,
                                 T* __restrict__ out_pos,
                                 T* __restrict__ out_nrm) {
-    const int n = LiveCount(n_dev, n_host);
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n_host;
          j += gridDim.x * blockDim.x) {
+        // fetched alongside the live count (see VdsInsertKernel)
         const unsigned k = sorted_key[j];
-        if (j > 0 && sorted_key[j - 1] == k) continue;
+        const unsigned left = j > 0 ? sorted_key[j - 1] : 0u;
+        const int n = LiveCount(n_dev, n_host);
+        if (j >= n) break;
+        if (j > 0 && left == k) continue;
         const int v = rank_of_first[k];
         float cnt = 0.f, sp[3] = {0.f, 0.f, 0.f}, sn[3] = {0.f, 0.f, 0.f};
         bool more = true;

@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r2v; mkdir -p $O
-timeout 1500 python -m pytest tests/test_icp_gpu.py tests/test_normals_gpu.py tests/test_golden.py -x -q -m gpu > $O/pytest.log 2>&1; tail -5 $O/pytest.log
-timeout 900 python -m pytest tests/test_configs_gpu.py -x -q -m gpu -k configs2 > $O/pytest2.log 2>&1; tail -3 $O/pytest2.log
+O=gpurun_out/r2w; mkdir -p $O
+timeout 1500 python -m pytest tests/test_icp_gpu.py tests/test_golden.py -x -q -m gpu > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+timeout 900 python -m pytest tests/test_configs_gpu.py -x -q -m gpu -k configs2 > $O/pytest2.log 2>&1; tail -2 $O/pytest2.log
 timeout 300 python tools/bench_search.py 2>/dev/null | tail -1 | tee $O/search_vga.json
 timeout 300 python tools/bench_search.py --hd 2>/dev/null | tail -1 | tee $O/search_hd.json
 P='import json,sys
@@ -13,6 +13,7 @@ for LIB in $PWD/_ab/libo3d_base.so ""; do
   export O3DMI_LIB=$LIB; echo "=== lib ${LIB:-new} rep $rep"
   echo -n "vga      "; timeout 300 python tools/bench_slam.py --mode slam --vga --frames 60 --no-cpu 2>/dev/null | python -c "$P"
   echo -n "720      "; timeout 300 python tools/bench_slam.py --mode slam --frames 60 --no-cpu 2>/dev/null | python -c "$P"
+  echo -n "icp      "; timeout 300 python tools/bench_slam.py --mode icp --no-cpu 2>/dev/null | python -c "$P"
 done; done
 export O3DMI_LIB=
 O3DMI_ICP_TIMING=2 timeout 300 python tools/bench_slam.py --mode slam --vga --frames 30 --no-cpu --phases > $O/t2_phases.log 2>&1
