@@ -313,6 +313,28 @@ def secondary_legs():
             "final_pose_err_rad_m", "roofline",
             "cpu_oracle_ms_per_multiscale_icp", "cpu_oracle_threads")
             if k in r}
+        out[tag]["harness"] = "Python (ctypes) caller of the C ABI"
+        # The same loop from a plain C++ caller of the C ABI
+        # (examples/icp_slam.cpp: analytic room, closed-form poses, checks its
+        # own trajectory): the rate without the interpreter between the calls.
+        exe = os.path.join(ROOT, "examples", "icp_slam")
+        if os.path.exists(exe):
+            w, h = (640, 480) if vga else (1280, 720)
+            runs, err = [], None
+            for _ in range(5):
+                pr = subprocess.run([exe, "60", str(w), str(h)],
+                                    capture_output=True, text=True, timeout=300)
+                if pr.returncode != 0 or not pr.stdout.strip():
+                    err = {"error": (pr.stderr or "failed")[-300:]}
+                    break
+                runs.append(json.loads(pr.stdout.strip().splitlines()[-1]))
+            if err is None:
+                runs.sort(key=lambda d: d["frames_per_s"])
+                med = dict(runs[len(runs) // 2])  # the median run
+                med["frames_per_s_of_5_runs"] = [d["frames_per_s"]
+                                                 for d in runs]
+                err = med
+            out[tag + "_cpp_caller"] = err
     return out
 
 

@@ -1,0 +1,283 @@
+// Frame-to-model tracking with point-cloud ICP, driven from plain C++ through
+// the C ABI only (no Python, no torch): BASELINE configs[2], the loop
+// tools/bench_slam.py --mode slam runs from Python.
+//
+// Per frame, with the calls a user of the reference's tensor API would make:
+//   VoxelBlockGrid::GetUniqueBlockCoordinates(previous depth, previous pose)
+//   VoxelBlockGrid::RayCast(depth + normal maps)            model frame
+//   PointCloud::CreateFromDepthImage(ray-cast depth, stride 2; normals ride
+//       along as the per-pixel attribute) + rotate the normals    model cloud
+//   PointCloud::CreateFromDepthImage(new depth, stride 2)        frame cloud
+//   MultiScaleICP(frame cloud -> model cloud, 5 / 2.5 / 1.25 cm voxels,
+//       20 / 10 / 5 iterations, point-to-plane)
+//   VoxelBlockGrid::Integrate(new frame at the estimated pose)
+//
+// The input is the analytic room of analytic_room.h; the trajectory is checked
+// against the closed-form poses (exit code 0 = within 8 cm / 1 degree).
+//
+//   hipcc -O2 -std=c++17 examples/icp_slam.cpp -Iinclude \
+//         -Lopen3d_amd/lib -lo3d_mi355x -Wl,-rpath,'$ORIGIN/../open3d_amd/lib' \
+//         -o examples/icp_slam
+//   examples/icp_slam [frames=60] [width=640] [height=480]
+
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "analytic_room.h"
+#include "o3d_mi355x_host.h"
+
+namespace {
+
+#define CHECK_HIP(expr)                                                      \
+    do {                                                                     \
+        hipError_t e_ = (expr);                                              \
+        if (e_ != hipSuccess) {                                              \
+            std::fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #expr, \
+                         hipGetErrorString(e_));                             \
+            std::exit(2);                                                    \
+        }                                                                    \
+    } while (0)
+
+#define CHECK_O3D(expr)                                                       \
+    do {                                                                      \
+        int s_ = (expr);                                                      \
+        if (s_ != O3DMI_OK) {                                                 \
+            std::fprintf(stderr, "%s:%d %s -> %d: %s\n", __FILE__, __LINE__,  \
+                         #expr, s_, o3dmi_last_error());                      \
+            std::exit(2);                                                     \
+        }                                                                     \
+    } while (0)
+
+using analytic_room::Camera;
+using analytic_room::RenderFrame;
+
+template <typename T>
+T* DeviceAlloc(size_t n) {
+    void* p = nullptr;
+    CHECK_HIP(hipMalloc(&p, sizeof(T) * (n ? n : 1)));
+    return (T*)p;
+}
+
+void Matmul4(const double* A, const double* B, double* out) {
+    double r[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double s = 0;
+            for (int k = 0; k < 4; ++k) s += A[i * 4 + k] * B[k * 4 + j];
+            r[i * 4 + j] = s;
+        }
+    for (int i = 0; i < 16; ++i) out[i] = r[i];
+}
+
+// inverse of a rigid transformation [R t; 0 1]
+void InvertRigid(const double* T, double* out) {
+    double r[16] = {0};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) r[i * 4 + j] = T[j * 4 + i];
+    for (int i = 0; i < 3; ++i)
+        r[i * 4 + 3] = -(r[i * 4 + 0] * T[3] + r[i * 4 + 1] * T[7] +
+                         r[i * 4 + 2] * T[11]);
+    r[15] = 1.0;
+    for (int i = 0; i < 16; ++i) out[i] = r[i];
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    const int n_frames = argc > 1 ? std::atoi(argv[1]) : 60;
+    Camera cam;
+    cam.width = argc > 2 ? std::atoi(argv[2]) : 640;
+    cam.height = argc > 3 ? std::atoi(argv[3]) : 480;
+    cam.fx = 525.0 * cam.width / 640.0;
+    cam.fy = 525.0 * cam.height / 480.0;
+    cam.cx = 0.5 * cam.width - 0.5;
+    cam.cy = 0.5 * cam.height - 0.5;
+    const double K[9] = {cam.fx, 0, cam.cx, 0, cam.fy, cam.cy, 0, 0, 1};
+    const float depth_scale = 1000.0f, depth_max = 3.0f, trunc = 8.0f;
+    const int W = cam.width, H = cam.height;
+    const size_t pixels = (size_t)W * H;
+    const int64_t stride = 2;
+    const size_t cloud_cap = (size_t)(W / stride) * (H / stride);
+
+    hipStream_t stream;
+    CHECK_HIP(hipStreamCreate(&stream));
+
+    std::vector<uint16_t*> depth_dev((size_t)n_frames);
+    std::vector<uint8_t*> color_dev((size_t)n_frames);
+    std::vector<double> eye((size_t)n_frames * 3);
+    {
+        std::vector<uint16_t> d;
+        std::vector<uint8_t> c;
+        for (int k = 0; k < n_frames; ++k) {
+            double* e = &eye[(size_t)k * 3];
+            e[0] = -0.2 + 0.005 * k;
+            e[1] = 0.03 * std::sin(0.1 * k);
+            e[2] = 0.0;
+            RenderFrame(cam, e, d, c);
+            depth_dev[(size_t)k] = DeviceAlloc<uint16_t>(pixels);
+            color_dev[(size_t)k] = DeviceAlloc<uint8_t>(pixels * 3);
+            CHECK_HIP(hipMemcpy(depth_dev[(size_t)k], d.data(),
+                                sizeof(uint16_t) * pixels,
+                                hipMemcpyHostToDevice));
+            CHECK_HIP(hipMemcpy(color_dev[(size_t)k], c.data(), pixels * 3,
+                                hipMemcpyHostToDevice));
+        }
+    }
+
+    // VoxelBlockGrid({"tsdf", "weight", "color"}, {f32, u16, u16}, {1, 1, 3},
+    //                8 mm, 16, 40000 blocks)
+    const char* names[3] = {"tsdf", "weight", "color"};
+    const int dtypes[3] = {O3DMI_F32, O3DMI_U16, O3DMI_U16};
+    const int channels[3] = {1, 1, 3};
+    o3dmi_vbg_t* grid = nullptr;
+    CHECK_O3D(o3dmi_vbg_create(3, names, dtypes, channels, 0.008f, 16, 40000,
+                               stream, &grid));
+
+    int32_t* keys = DeviceAlloc<int32_t>((size_t)(H / 4) * (W / 4) * 4 * 3);
+    float* range_map = DeviceAlloc<float>((size_t)(H / 8) * (W / 8) * 2);
+    float* rc_depth = DeviceAlloc<float>(pixels);
+    float* rc_normal = DeviceAlloc<float>(pixels * 3);
+    float* model_pts = DeviceAlloc<float>(cloud_cap * 3);
+    float* model_nrm = DeviceAlloc<float>(cloud_cap * 3);
+    float* frame_pts = DeviceAlloc<float>(cloud_cap * 3);
+    int32_t* counts = DeviceAlloc<int32_t>(2);
+    int32_t* host_counts = nullptr;  // pinned: the two cloud sizes
+    CHECK_HIP(hipHostMalloc((void**)&host_counts, sizeof(int32_t) * 2));
+
+    const double voxel_sizes[3] = {0.05, 0.025, 0.0125};
+    const o3dmi_icp_criteria_t criteria[3] = {
+            {1e-6, 1e-6, 20}, {1e-6, 1e-6, 10}, {1e-6, 1e-6, 5}};
+    const double max_dist[3] = {0.15, 0.075, 0.0375};
+
+    // extrinsic (world -> camera) of a camera at `eye` that is only translated
+    auto extrinsic_at = [](const double* e, double* X) {
+        const double t[16] = {1, 0, 0, -e[0], 0, 1, 0, -e[1],
+                              0, 0, 1, -e[2], 0, 0, 0, 1};
+        for (int i = 0; i < 16; ++i) X[i] = t[i];
+    };
+    double X[16];  // current extrinsic estimate
+    extrinsic_at(&eye[0], X);
+    CHECK_O3D(o3dmi_vbg_integrate_frame(grid, depth_dev[0], H, W, color_dev[0],
+                                        H, W, O3DMI_U16, K, K, X, depth_scale,
+                                        depth_max, trunc, stream));
+    CHECK_HIP(hipStreamSynchronize(stream));
+
+    double worst_translation = 0, worst_angle = 0;
+    long iterations = 0;
+    // host time per phase (the loop has host waits after the block touch and
+    // after the two clouds, and inside the ICP call; Integrate is queued)
+    double phase[5] = {0, 0, 0, 0, 0};
+    auto now = [] {
+        return std::chrono::duration<double, std::micro>(
+                       std::chrono::steady_clock::now().time_since_epoch())
+                .count();
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = 1; k < n_frames; ++k) {
+        const double p0 = now();
+        // ---- model cloud at the previous pose ------------------------------
+        int64_t m = 0;
+        CHECK_O3D(o3dmi_vbg_get_unique_block_coordinates(
+                grid, depth_dev[(size_t)k - 1], O3DMI_U16, H, W, K, X,
+                depth_scale, depth_max, trunc, keys, &m, stream));
+        const double p1 = now();
+        CHECK_O3D(o3dmi_vbg_ray_cast(
+                grid, keys, m, K, X, W, H, range_map, rc_depth, nullptr,
+                nullptr, rc_normal, nullptr, nullptr, nullptr, nullptr, nullptr,
+                nullptr, depth_scale, 0.1f, depth_max, 1.0f, trunc, 8, stream));
+        CHECK_O3D(o3dmi_unproject(rc_depth, O3DMI_F32, H, W, rc_normal,
+                                  model_pts, model_nrm, counts, K, X,
+                                  depth_scale, depth_max, stride, stream));
+        // ---- frame cloud of the new depth image, still at the previous pose
+        CHECK_O3D(o3dmi_unproject(depth_dev[(size_t)k], O3DMI_U16, H, W,
+                                  nullptr, frame_pts, nullptr, counts + 1, K, X,
+                                  depth_scale, depth_max, stride, stream));
+        CHECK_HIP(hipMemcpyAsync(host_counts, counts, sizeof(int32_t) * 2,
+                                 hipMemcpyDeviceToHost, stream));
+        CHECK_HIP(hipStreamSynchronize(stream));
+        const int64_t nm = host_counts[0], nf = host_counts[1];
+        const double p2 = now();
+        double Xinv[16];
+        InvertRigid(X, Xinv);  // camera -> world rotates the normals
+        CHECK_O3D(o3dmi_transform_normals(Xinv, model_nrm, nm, O3DMI_F32,
+                                          stream));
+        // ---- track ----------------------------------------------------------
+        o3dmi_registration_result_t r;
+        CHECK_O3D(o3dmi_registration_multiscale_icp(
+                frame_pts, nf, model_pts, model_nrm, nm, O3DMI_F32, 3,
+                voxel_sizes, criteria, max_dist, nullptr, /*L2Loss*/ 0, 1.0,
+                1.0, nullptr, nullptr, nullptr, nullptr, nullptr, &r, stream));
+        iterations += r.num_iterations;
+        const double p3 = now();
+        // points_world = r.T (X_prev^-1 p_cam)  =>  X_k = X_prev r.T^-1
+        double rinv[16];
+        InvertRigid(r.transformation, rinv);
+        Matmul4(X, rinv, X);
+        // ---- integrate at the estimated pose -------------------------------
+        CHECK_O3D(o3dmi_vbg_integrate_frame(
+                grid, depth_dev[(size_t)k], H, W, color_dev[(size_t)k], H, W,
+                O3DMI_U16, K, K, X, depth_scale, depth_max, trunc, stream));
+        const double p4 = now();
+        phase[0] += p1 - p0;
+        phase[1] += p2 - p1;
+        phase[2] += p3 - p2;
+        phase[3] += p4 - p3;
+
+        const double* e = &eye[(size_t)k * 3];
+        double P[16];
+        InvertRigid(X, P);  // camera pose in the world
+        const double dt = std::sqrt((P[3] - e[0]) * (P[3] - e[0]) +
+                                    (P[7] - e[1]) * (P[7] - e[1]) +
+                                    (P[11] - e[2]) * (P[11] - e[2]));
+        const double tr = (P[0] + P[5] + P[10] - 1.0) * 0.5;
+        const double ang = std::acos(std::fmax(-1.0, std::fmin(1.0, tr)));
+        const char* verbose = std::getenv("ICP_SLAM_VERBOSE");
+        if (verbose && *verbose)
+            std::fprintf(stderr, "frame %d error %.4f m, %.4f rad, %d it\n", k,
+                         dt, ang, r.num_iterations);
+        worst_translation = std::fmax(worst_translation, dt);
+        worst_angle = std::fmax(worst_angle, ang);
+    }
+    CHECK_HIP(hipStreamSynchronize(stream));
+    const double seconds =
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0)
+                    .count();
+    std::printf(
+            "{\"example\": \"icp_slam.cpp\", \"frames\": %d, \"width\": %d, "
+            "\"height\": %d, \"frames_per_s\": %.1f, \"ms_per_frame\": %.4f, "
+            "\"icp_iterations_per_frame\": %.2f, "
+            "\"host_us_block_touch_clouds_icp_integrate\": [%.0f, %.0f, %.0f, "
+            "%.0f], "
+            "\"max_translation_error_m\": %.3g, \"max_rotation_error_rad\": "
+            "%.3g}\n",
+            n_frames - 1, W, H, (n_frames - 1) / seconds,
+            seconds / (n_frames - 1) * 1e3,
+            (double)iterations / (n_frames - 1), phase[0] / (n_frames - 1),
+            phase[1] / (n_frames - 1), phase[2] / (n_frames - 1),
+            phase[3] / (n_frames - 1), worst_translation, worst_angle);
+
+    (void)hipFree(keys);
+    (void)hipFree(range_map);
+    (void)hipFree(rc_depth);
+    (void)hipFree(rc_normal);
+    (void)hipFree(model_pts);
+    (void)hipFree(model_nrm);
+    (void)hipFree(frame_pts);
+    (void)hipFree(counts);
+    (void)hipHostFree(host_counts);
+    CHECK_O3D(o3dmi_vbg_destroy(grid));
+    for (int k = 0; k < n_frames; ++k) {
+        (void)hipFree(depth_dev[(size_t)k]);
+        (void)hipFree(color_dev[(size_t)k]);
+    }
+    (void)hipStreamDestroy(stream);
+    const bool ok = worst_translation < 0.08 && worst_angle < 0.01745;
+    if (!ok) std::fprintf(stderr, "icp_slam: self-check FAILED\n");
+    return ok ? 0 : 1;
+}

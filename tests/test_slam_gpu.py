@@ -253,3 +253,23 @@ def test_cpp_host_example_runs_the_loop_through_the_c_abi():
     assert out["frames"] == 30 and out["surface_points"] > 1000
     assert out["max_translation_error_m"] < 0.08
     assert out["max_rotation_error_rad"] < 0.01745
+
+
+def test_cpp_icp_tracking_example_runs_configs2_through_the_c_abi():
+    """examples/icp_slam.cpp: BASELINE configs[2] (ray cast -> model cloud ->
+    frame cloud -> MultiScaleICP -> Integrate) from plain C++ on the C ABI; the
+    program checks its trajectory against the closed-form poses."""
+    import json
+    import subprocess
+    import __graft_entry__ as ge
+    ge.build()
+    exe = os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "examples", "icp_slam")
+    r = subprocess.run([exe, "20", "320", "240"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["frames"] == 19
+    assert out["max_translation_error_m"] < 0.08
+    assert out["max_rotation_error_rad"] < 0.01745
+    assert out["icp_iterations_per_frame"] >= 3
