@@ -87,6 +87,11 @@ def _extract(call, has_color, weight_threshold, estimated_point_number):
     return out
 
 
+class FrameBatch:
+    """Prepared arguments of VoxelBlockGrid.integrate_frames (prepare_frames)."""
+    pass
+
+
 class VoxelBlockGrid:
     _CHANNELS = {"vertex": 3, "normal": 3, "depth": 1, "color": 3, "index": 8,
                  "mask": 8, "interp_ratio": 8, "interp_ratio_dx": 8,
@@ -225,36 +230,58 @@ class VoxelBlockGrid:
             C.c_float(depth_max), C.c_float(trunc_voxel_multiplier),
             stream()), "VoxelBlockGrid.integrate_frame")
 
-    def integrate_frames(self, depths, colors, depth_intrinsic,
-                         color_intrinsic, extrinsics, depth_scale=1000.0,
-                         depth_max=3.0, trunc_voxel_multiplier=8.0,
-                         frames_per_launch=0):
-        """integrate_frame over a list of frames (same intrinsics / sizes),
-        strictly in order, in one native call. frames_per_launch (1..8, 0 =
-        4) frames are applied per launch to each touched block while its
-        voxels stay in registers; results are identical for every value."""
+    def prepare_frames(self, depths, colors, depth_intrinsic,
+                       color_intrinsic, extrinsics):
+        """The argument block of integrate_frames for a list of resident
+        frames -- checked once, pointer / pose arrays built once -- for callers
+        that integrate the same frames repeatedly (a looped stream): returns a
+        FrameBatch to pass as `depths`."""
         n = len(depths)
-        if n == 0:
-            return
         ds = [_image(d, "depth", 1) for d in depths]
-        rows, cols = ds[0].shape
+        b = FrameBatch()
+        b.n = n
+        b.keep = [ds]
+        b.rows, b.cols = ds[0].shape
         if color_intrinsic is None:
             color_intrinsic = depth_intrinsic
-        Kd = host_mat(depth_intrinsic, (3, 3), "intrinsic")
-        Kc = host_mat(color_intrinsic, (3, 3), "intrinsic")
-        Ts = np.ascontiguousarray(
+        b.Kd = host_mat(depth_intrinsic, (3, 3), "intrinsic")
+        b.Kc = host_mat(color_intrinsic, (3, 3), "intrinsic")
+        b.Ts = np.ascontiguousarray(
             np.stack([host_mat(T, (4, 4), "extrinsic") for T in extrinsics]),
             dtype=np.float64)
-        dptr = (C.c_void_p * n)(*[d.data_ptr() for d in ds])
-        cptr, crows, ccols = None, 0, 0
+        b.dptr = (C.c_void_p * n)(*[d.data_ptr() for d in ds])
+        b.cptr, b.crows, b.ccols = None, 0, 0
         if colors is not None:
             cs = [_image(c, "color", 3) for c in colors]
-            crows, ccols = cs[0].shape[:2]
-            cptr = (C.c_void_p * n)(*[c.data_ptr() for c in cs])
+            b.keep.append(cs)
+            b.crows, b.ccols = cs[0].shape[:2]
+            b.cptr = (C.c_void_p * n)(*[c.data_ptr() for c in cs])
+        b.dtype = TORCH_TO_O3DMI[ds[0].dtype]
+        return b
+
+    def integrate_frames(self, depths, colors=None, depth_intrinsic=None,
+                         color_intrinsic=None, extrinsics=None,
+                         depth_scale=1000.0, depth_max=3.0,
+                         trunc_voxel_multiplier=8.0, frames_per_launch=0):
+        """integrate_frame over a list of frames (same intrinsics / sizes),
+        strictly in order, in one native call. frames_per_launch (1..8, 0 =
+        8) frames are applied per launch to each touched block while its
+        voxels stay in registers; results are identical for every value.
+        `depths` may be a FrameBatch from prepare_frames (the other frame
+        arguments are then taken from it)."""
+        if isinstance(depths, FrameBatch):
+            b = depths
+        else:
+            if len(depths) == 0:
+                return
+            b = self.prepare_frames(depths, colors, depth_intrinsic,
+                                    color_intrinsic, extrinsics)
+        if b.n == 0:
+            return
         _lib.check(_lib.lib().o3dmi_vbg_integrate_frames(
-            self._g, n, dptr, rows, cols, cptr, crows, ccols,
-            TORCH_TO_O3DMI[ds[0].dtype], _lib.f64p(Kd), _lib.f64p(Kc),
-            _lib.f64p(Ts), C.c_float(depth_scale), C.c_float(depth_max),
+            self._g, b.n, b.dptr, b.rows, b.cols, b.cptr, b.crows, b.ccols,
+            b.dtype, _lib.f64p(b.Kd), _lib.f64p(b.Kc), _lib.f64p(b.Ts),
+            C.c_float(depth_scale), C.c_float(depth_max),
             C.c_float(trunc_voxel_multiplier), int(frames_per_launch), stream()),
             "VoxelBlockGrid.integrate_frames")
 

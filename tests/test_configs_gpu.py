@@ -2,7 +2,7 @@
 CPU path on the same inputs):
 
   configs[1]  1000 synthetic 640x480 RGB-D frames into an 8 mm / 16^3 grid:
-              the whole stream through integrate_frames (4 frames per launch)
+              the whole stream through integrate_frames (8 frames per launch)
               vs Open3D's own DepthTouchCPU / IntegrateCPU bodies (oracle/_ref)
               frame by frame -- whole grid bit for bit.
   configs[2]  1280x720 tracking loop: ray cast (model cloud) -> Unproject
@@ -63,11 +63,15 @@ def test_configs1_full_length_1000_frames_vs_reference_cpu_bodies():
             dts.append(d[i].contiguous())
             cts.append(c[i].contiguous())
             Ts.append(T[i])
-    # the bench's call pattern: 50 frames per native call, 4 frames per launch
-    for lo in range(0, n, 50):
-        g.integrate_frames(dts[lo:lo + 50], cts[lo:lo + 50], K, K,
-                           Ts[lo:lo + 50], sc.DEPTH_SCALE, sc.DEPTH_MAX,
-                           sc.TRUNC_MULT, frames_per_launch=4)
+    # the bench's call pattern: prepared argument blocks (prepare_frames),
+    # 8 frames per launch; 250 frames per native call here
+    for lo in range(0, n, 250):
+        batch = g.prepare_frames(dts[lo:lo + 250], cts[lo:lo + 250], K, K,
+                                 Ts[lo:lo + 250])
+        g.integrate_frames(batch, depth_scale=sc.DEPTH_SCALE,
+                           depth_max=sc.DEPTH_MAX,
+                           trunc_voxel_multiplier=sc.TRUNC_MULT,
+                           frames_per_launch=8)
     err, exact = _compare_grids(og, g)
     assert exact, err
     assert og.weight.max() >= 150
