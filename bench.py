@@ -6,8 +6,8 @@ with known poses (1000 distinct frames, resident in HBM before the timed region)
 integrated into an 8 mm / 16^3-block VoxelBlockGrid (tsdf f32, weight u16,
 colour u16 -- the slam::Model layout): per frame block touch + hash activation
 + per-voxel TSDF / weight / colour update. A "step" is one batch of `--batch`
-frames (default 6000 = six passes over the stream, so that the driver's 20
-timed steps last about a second); every frame does the full per-frame work, the
+frames (default 8000 = eight passes over the stream, so that the driver's 20
+timed steps last more than a second); every frame does the full per-frame work, the
 uint16 weights stay far below their range (a voxel is seen by <= 183 frames of
 a pass).
 
@@ -78,7 +78,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=6000,
+    ap.add_argument("--batch", type=int, default=8000,
                     help="frames per step (per GPU)")
     ap.add_argument("--block-count", type=int, default=262144,
                     help="initial hash capacity; the stream needs ~6 k blocks, "

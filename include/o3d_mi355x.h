@@ -312,7 +312,12 @@ int o3dmi_unproject(const void* depth_dev, int depth_dtype, int rows, int cols,
  * BuildSpatialHashTableCUDA / HybridSearchCUDA, FixedRadiusSearchOps.cu:
  * 20-57). Results follow the CPU path's nanoflann semantics
  * (core/nns/NanoFlannImpl.h:305-370): neighbours with d2 < r2 (strict),
- * nearest first, ties by lower index. dtype O3DMI_F32 or O3DMI_F64. */
+ * nearest first, ties by lower index. dtype O3DMI_F32 or O3DMI_F64.
+ * o3dmi_nns_create is stream-ordered: it queues the build (a fill and three
+ * launches) on `stream` and returns without waiting, so points_dev must stay
+ * valid until that work has run (any later call on the same stream is
+ * ordered behind it). At most 2^27 - 1 points per index (records are
+ * addressed by 32-bit byte offsets). */
 typedef struct o3dmi_nns o3dmi_nns_t;
 int o3dmi_nns_create(const void* points_dev, int64_t n, int dtype,
                      double radius, o3dmi_stream_t stream, o3dmi_nns_t** out);

@@ -35,7 +35,6 @@
 #include <initializer_list>
 #include <limits>
 #include <string>
-#include <thread>
 #include <utility>
 #include <vector>
 
