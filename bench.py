@@ -88,7 +88,7 @@ def parse():
                          "HashMap::Activate)")
     ap.add_argument("--frames-per-launch", type=int, default=8,
                     help="consecutive frames applied per launch to register-"
-                         "resident blocks (1..8); results are identical")
+                         "resident blocks (1..16); results are identical")
     ap.add_argument("--event-stride", type=int, default=16,
                     help="bracket every n-th integrate launch with HIP events "
                          "(0 = none; the roofline is then not measured)")

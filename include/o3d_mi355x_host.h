@@ -284,7 +284,7 @@ int o3dmi_vbg_integrate_frame(o3dmi_vbg_t* g, const void* depth_dev,
  * extrinsics is n_frames x 16 host doubles. Frames are integrated strictly in
  * order (frame f sees the grid left by frame f-1), so the result is identical
  * to n_frames calls of o3dmi_vbg_integrate_frame.
- * frames_per_launch (1..8, <= 0 = 8): consecutive frames are grouped; one
+ * frames_per_launch (1..16, <= 0 = 8): consecutive frames are grouped; one
  * launch applies the frames of a group, in order, to each touched block while
  * its voxel state stays in registers (state is read / written once per group
  * instead of once per frame; a block only receives the frames that touched

@@ -185,7 +185,7 @@ constexpr int kErrProbe = 8;       // probe sequence wrapped (table full)
 struct HashView {
     unsigned long long* slot_keys;  // [n_slots] packed key / empty / tombstone
     int* slot_vals;                 // [n_slots] buffer index of the slot
-    // [2][n_slots] (touch stamp << 8) | frame bits. Two planes: consecutive
+    // [2][n_slots] (touch stamp << kTouchBits) | frame bits. Two planes: consecutive
     // frame groups of the frame-stream path alternate planes, because the
     // front roles of group g+1 run in the same launch as the integrate role of
     // group g, which still reads group g's words (plane = group sequence & 1;
@@ -281,9 +281,10 @@ __device__ __forceinline__ int ClaimSlot(const HashView& hv,
 }
 
 // Marks `slot` as touched by frame `bit` of the frame group `stamp`. The word
-// holds (stamp << 8) | one bit per frame of the group; a word carrying an older
-// stamp is stale and is replaced. Returns true for exactly one caller per
+// holds (stamp << kTouchBits) | one bit per frame of the group; a word carrying
+// an older stamp is stale and is replaced. Returns true for exactly one caller per
 // (slot, stamp): the one that moved the word to this stamp.
+constexpr int kTouchBits = 16;  // frames per group (stream_path.h kMaxGroup)
 __device__ __forceinline__ unsigned long long* TouchWord(const HashView& hv,
                                                          unsigned slot,
                                                          int plane) {
@@ -295,9 +296,10 @@ __device__ __forceinline__ bool TouchSlot(const HashView& hv, unsigned slot,
     unsigned long long* w = TouchWord(hv, slot, plane);
     unsigned long long cur = *w;  // possibly stale; the CAS corrects it
     while (true) {
-        const bool fresh = (cur >> 8) != stamp;
+        const bool fresh = (cur >> kTouchBits) != stamp;
         const unsigned long long want =
-                fresh ? ((stamp << 8) | (1ull << bit)) : (cur | (1ull << bit));
+                fresh ? ((stamp << kTouchBits) | (1ull << bit))
+                      : (cur | (1ull << bit));
         if (want == cur) return false;
         const unsigned long long old = atomicCAS(w, cur, want);
         if (old == cur) return fresh;

@@ -1030,7 +1030,7 @@ int o3dmi_vbg_integrate_frames(o3dmi_vbg_t* g, int n_frames,
         frames[(size_t)f].extrinsic = extrinsics + 16 * (size_t)f;
     }
     return StreamIntegrate(g, c, frames.data(), n_frames,
-                           frames_per_launch <= 0 ? kMaxGroup
+                           frames_per_launch <= 0 ? kDefaultGroup
                                                   : frames_per_launch,
                            (hipStream_t)stream);
 }

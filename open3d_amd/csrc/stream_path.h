@@ -31,10 +31,16 @@ namespace o3dmi {
 // preserved and a block only receives the frames that touched it (per-slot
 // frame bits, TouchSlot), so the result is identical to frame-by-frame
 // integration.
-constexpr int kMaxGroup = 8;  // = the frame bits of a touch word
+constexpr int kMaxGroup = 16;  // = kTouchBits, the frame bits of a touch word
+static_assert(kMaxGroup == kTouchBits, "one touch bit per frame of a group");
+// Group size when the caller does not choose: a group may add up to (frames x
+// per-frame frustum bound) blocks, which the run-ahead capacity policy holds
+// against the hash capacity -- 8 frames fit a 262 144-block map, 16 want twice
+// that.
+constexpr int kDefaultGroup = 8;
 // The integrate role's wide form keeps the records of kGroupChunk frames in
-// registers at a time (a group of 8 = two chunks on the same register-resident
-// voxel state).
+// registers at a time (a group of 16 = four chunks on the same register-
+// resident voxel state).
 constexpr int kGroupChunk = 4;
 
 // One entry of a group's block list: hash slot + block key.

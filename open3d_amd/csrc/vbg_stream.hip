@@ -49,6 +49,33 @@ struct PrepParams {
 // LDS key set of one 16 x 16 ray tile (<= 1024 candidates).
 constexpr int kTileKeys = 2048;
 
+// Front roles of one launch: what the frames of the group share, and what
+// differs per frame (kernel arguments are limited to 4 KB; a group has up to
+// 16 frames).
+struct FrontShared {
+    TouchParams p;  // intrinsics, sizes, truncation; p.cam.e comes per frame
+    PrepParams pp;
+    const int* col_lut;
+    const int* row_lut;
+    bool depth_div_short;
+    bool prep_identity;     // tables are the identity, cols % 4 == 0
+    float inv_depth_scale;  // RN(1 / depth_scale)
+    FrameBlock* list;
+    int64_t list_capacity;
+    int* out_count;
+    unsigned long long group_stamp;
+    int touch_plane;
+    int n_touch_wg, n_prep_wg;
+};
+struct FrontFrame {
+    float pose[3][4];  // inverse extrinsic (TouchParams::cam.e)
+    const uint16_t* depth;
+    const uint8_t* color;
+    PixelRec* recs;
+    int group_bit;
+};
+
+// A frame's front parameters assembled from the two (uniform: scalar loads).
 struct FrontParams {
     TouchParams p;
     PrepParams pp;
@@ -57,8 +84,8 @@ struct FrontParams {
     const int* col_lut;
     const int* row_lut;
     bool depth_div_short;
-    bool prep_identity;     // tables are the identity, cols % 4 == 0
-    float inv_depth_scale;  // RN(1 / depth_scale)
+    bool prep_identity;
+    float inv_depth_scale;
     PixelRec* recs;
     FrameBlock* list;
     int64_t list_capacity;
@@ -67,6 +94,21 @@ struct FrontParams {
     int group_bit;
     int touch_plane;
     int n_touch_wg, n_prep_wg;
+    __device__ __forceinline__ FrontParams(const FrontShared& s,
+                                           const FrontFrame& f)
+        : p(s.p), pp(s.pp), depth(f.depth), color(f.color),
+          col_lut(s.col_lut), row_lut(s.row_lut),
+          depth_div_short(s.depth_div_short), prep_identity(s.prep_identity),
+          inv_depth_scale(s.inv_depth_scale), recs(f.recs), list(s.list),
+          list_capacity(s.list_capacity), out_count(s.out_count),
+          group_stamp(s.group_stamp), group_bit(f.group_bit),
+          touch_plane(s.touch_plane), n_touch_wg(s.n_touch_wg),
+          n_prep_wg(s.n_prep_wg) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p.cam.e[i][j] = f.pose[i][j];
+    }
 };
 
 // `wg` = index of this workgroup within one frame's front role,
@@ -336,9 +378,9 @@ __device__ __forceinline__ void FrontRole(const HashView& hv,
 // and colour come from the prepared PixelRec images (one 8-byte gather per
 // voxel and frame).
 struct IntegParams {
-    Camera cam[kMaxGroup];  // depth intrinsics + extrinsic, scale = voxel_size
-    // the same for the wide role: the group's frames share intrinsics and
-    // scale (cam[0]'s), only the extrinsics differ -- fewer scalar registers
+    // the group's frames share intrinsics and scale (cam0's, with frame 0's
+    // extrinsic), only the extrinsics differ
+    Camera cam0;  // depth intrinsics + extrinsic of frame 0, scale = voxel_size
     float ext[kMaxGroup][3][4];
     const PixelRec* recs[kMaxGroup];
     int n_frames;
@@ -523,11 +565,11 @@ __device__ __forceinline__ void IntegrateRole(const HashView& hv,
         // plane). A word of another stamp cannot occur; if it does, nothing
         // is integrated for the block and the error surfaces on the host.
         const unsigned long long word = *TouchWord(hv, slot, ip.touch_plane);
-        const bool own = (word >> 8) == ip.group_stamp;
+        const bool own = (word >> kTouchBits) == ip.group_stamp;
         if (!own && threadIdx.x == 0 && part == 0)
             atomicOr(&hv.counters[1], kErrTouchStamp);
         const unsigned bits = __builtin_amdgcn_readfirstlane(
-                own ? (unsigned)(word & 0xffull) : 0u);
+                own ? (unsigned)(word & ((1ull << kTouchBits) - 1ull)) : 0u);
         const int64_t block_base = (int64_t)block_idx * res3;
         if (part == 0 && threadIdx.x == 0 && ip.prof_frame_blocks)
             frame_blocks += __popc(bits);
@@ -550,7 +592,11 @@ __device__ __forceinline__ void IntegrateRole(const HashView& hv,
 
         for (int f = 0; f < ip.n_frames; ++f) {
             if (!((bits >> f) & 1u)) continue;  // wave-uniform
-            const Camera& cam = ip.cam[f];
+            Camera cam = ip.cam0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cam.e[i][j] = ip.ext[f][i][j];
             const PixelRec* __restrict__ recs = ip.recs[f];
             // VoxelBlockGridImpl.h:244-267 with depth taken from the record.
             float sdf[4];
@@ -726,9 +772,9 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
     const unsigned sentinel_off =
             (unsigned)(ip.rows * ip.cols) * (unsigned)sizeof(PixelRec);
     const unsigned row_bytes = (unsigned)ip.cols * (unsigned)sizeof(PixelRec);
-    const float vscale = ip.cam[0].scale;
-    const float fx = ip.cam[0].fx, fyk = ip.cam[0].fy;
-    const float cx = ip.cam[0].cx, cy = ip.cam[0].cy;
+    const float vscale = ip.cam0.scale;
+    const float fx = ip.cam0.fx, fyk = ip.cam0.fy;
+    const float cx = ip.cam0.cx, cy = ip.cam0.cy;
     const float u_max = ip.cols - 1.0f, v_max = ip.rows - 1.0f;
 
     // (Measured and dropped, profiles/r2l: persistent workgroups -- 1024 to
@@ -758,11 +804,11 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
         const int block_idx =
                 __builtin_amdgcn_readfirstlane(hv.slot_vals[slot]);
         const unsigned long long word = *TouchWord(hv, slot, ip.touch_plane);
-        const bool own = (word >> 8) == ip.group_stamp;
+        const bool own = (word >> kTouchBits) == ip.group_stamp;
         if (!own && threadIdx.x == 0 && part == 0)
             atomicOr(&hv.counters[1], kErrTouchStamp);
         const unsigned bits = __builtin_amdgcn_readfirstlane(
-                own ? (unsigned)(word & 0xffull) : 0u);
+                own ? (unsigned)(word & ((1ull << kTouchBits) - 1ull)) : 0u);
         const int64_t block_base = (int64_t)block_idx * res3;
         if (part == 0 && threadIdx.x == 0 && ip.prof_frame_blocks)
             frame_blocks += __popc(bits);
@@ -1013,7 +1059,8 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
 
 struct StepParams {
     HashView hv;
-    FrontParams front[kMaxGroup];
+    FrontShared fshared;
+    FrontFrame front[kMaxGroup];
     IntegParams integ;
     int n_fronts;
     int front_wg;  // workgroups per front role
@@ -1031,7 +1078,8 @@ FrameStepKernel(StepParams sp) {
     const int n_front_wg = sp.n_fronts * sp.front_wg;
     if (b < n_front_wg) {
         const int f = b / sp.front_wg;
-        FrontRole(sp.hv, sp.front[f], b - f * sp.front_wg);
+        const FrontParams fp(sp.fshared, sp.front[f]);
+        FrontRole(sp.hv, fp, b - f * sp.front_wg);
     } else if constexpr (kForm != 0) {
         IntegrateRoleWide<weight_t, color_t, kColor, kDiv, kGroupChunk,
                           kForm == 2 ? 1 : 2>(
@@ -1194,47 +1242,59 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
                                     0, 0, 1, 0, 0, 0, 0, 1};
     for (int i = 0; i < n_fronts; ++i) {
         const FrameFrontArgs* f = &fronts[i];
-        FrontParams& fp = sp.front[i];
         O3DMI_REQUIRE(f->group_bit >= 0 && f->group_bit < kMaxGroup &&
                               f->group_stamp > 0,
                       "bad group bit / stamp");
-        fp.p = MakeTouchParams(f->depth_intrinsic, f->extrinsic, f->rows,
-                               f->cols, f->stride, f->resolution,
-                               f->voxel_size, f->sdf_trunc, f->depth_scale,
-                               f->depth_max);
-        fp.pp.color_cam = Camera::Make(f->color_intrinsic ? f->color_intrinsic
+        const TouchParams tp = MakeTouchParams(
+                f->depth_intrinsic, f->extrinsic, f->rows, f->cols, f->stride,
+                f->resolution, f->voxel_size, f->sdf_trunc, f->depth_scale,
+                f->depth_max);
+        FrontFrame& ff = sp.front[i];
+        std::memcpy(ff.pose, tp.cam.e, sizeof(ff.pose));
+        ff.depth = f->depth;
+        ff.color = f->color;
+        ff.recs = f->recs;
+        ff.group_bit = f->group_bit;
+        FrontShared fs = {};
+        fs.p = tp;
+        fs.pp.color_cam = Camera::Make(f->color_intrinsic ? f->color_intrinsic
                                                           : f->depth_intrinsic,
                                        eye4, 1.0f);
-        fp.pp.color_rows = f->color_rows;
-        fp.pp.color_cols = f->color_cols;
-        fp.pp.with_color = f->color != nullptr;
-        fp.depth = f->depth;
-        fp.color = f->color;
-        fp.col_lut = f->col_lut;
-        fp.row_lut = f->col_lut ? f->row_lut : nullptr;
-        fp.depth_div_short = f->depth_div_short;
-        fp.prep_identity = f->col_lut && f->prep_identity &&
+        fs.pp.color_rows = f->color_rows;
+        fs.pp.color_cols = f->color_cols;
+        fs.pp.with_color = f->color != nullptr;
+        fs.col_lut = f->col_lut;
+        fs.row_lut = f->col_lut ? f->row_lut : nullptr;
+        fs.depth_div_short = f->depth_div_short;
+        fs.prep_identity = f->col_lut && f->prep_identity &&
                            (f->cols % 4) == 0 && f->rows == f->color_rows &&
                            f->cols == f->color_cols;
-        fp.inv_depth_scale = 1.0f / f->depth_scale;
-        fp.recs = f->recs;
-        fp.list = f->list;
-        fp.list_capacity = f->list_capacity;
-        fp.out_count = f->count;
-        fp.group_stamp = f->group_stamp;
-        fp.group_bit = f->group_bit;
-        fp.touch_plane = f->touch_plane & 1;
+        fs.inv_depth_scale = 1.0f / f->depth_scale;
+        fs.list = f->list;
+        fs.list_capacity = f->list_capacity;
+        fs.out_count = f->count;
+        fs.group_stamp = f->group_stamp;
+        fs.touch_plane = f->touch_plane & 1;
         // one touch workgroup per 16 x 16 tile of rays
-        fp.n_touch_wg = ((fp.p.cols_strided + 15) / 16) *
-                        ((fp.p.rows_strided + 15) / 16);
+        fs.n_touch_wg = ((tp.cols_strided + 15) / 16) *
+                        ((tp.rows_strided + 15) / 16);
         // 16 pixels per prepare lane
-        fp.n_prep_wg = (f->rows * f->cols + kBlock * 16 - 1) / (kBlock * 16);
-        if (fp.n_prep_wg < 1) fp.n_prep_wg = 1;
-        const int wg = fp.n_touch_wg + fp.n_prep_wg;
-        // all frames of a launch share the image size
-        O3DMI_REQUIRE(i == 0 || wg == sp.front_wg,
-                      "frames of one launch must share the image size");
-        sp.front_wg = wg;
+        fs.n_prep_wg = (f->rows * f->cols + kBlock * 16 - 1) / (kBlock * 16);
+        if (fs.n_prep_wg < 1) fs.n_prep_wg = 1;
+        if (i == 0) {
+            sp.fshared = fs;
+            sp.front_wg = fs.n_touch_wg + fs.n_prep_wg;
+        } else {
+            // the frames of a launch are one group: everything but the pose
+            // and the image / record pointers is shared
+            const FrontShared& g0 = sp.fshared;
+            FrontShared a0 = g0, a1 = fs;
+            std::memset(a0.p.cam.e, 0, sizeof(a0.p.cam.e));
+            std::memset(a1.p.cam.e, 0, sizeof(a1.p.cam.e));
+            O3DMI_REQUIRE(std::memcmp(&a0, &a1, sizeof(FrontShared)) == 0,
+                          "frames of one launch must share image size, "
+                          "intrinsics, scales and their group");
+        }
     }
     if (a) {
         O3DMI_REQUIRE(a->resolution % 4 == 0,
@@ -1246,9 +1306,10 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         ip.group_stamp = a->group_stamp;
         ip.touch_plane = a->touch_plane & 1;
         for (int f = 0; f < a->n_frames; ++f) {
-            ip.cam[f] = Camera::Make(a->depth_intrinsic, a->extrinsic[f],
-                                     a->voxel_size);
-            std::memcpy(ip.ext[f], ip.cam[f].e, sizeof(ip.ext[f]));
+            const Camera cf = Camera::Make(a->depth_intrinsic, a->extrinsic[f],
+                                           a->voxel_size);
+            if (f == 0) ip.cam0 = cf;
+            std::memcpy(ip.ext[f], cf.e, sizeof(ip.ext[f]));
             ip.recs[f] = a->recs[f];
         }
         ip.rows = a->rows;

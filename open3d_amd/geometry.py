@@ -264,7 +264,7 @@ class VoxelBlockGrid:
                          depth_scale=1000.0, depth_max=3.0,
                          trunc_voxel_multiplier=8.0, frames_per_launch=0):
         """integrate_frame over a list of frames (same intrinsics / sizes),
-        strictly in order, in one native call. frames_per_launch (1..8, 0 =
+        strictly in order, in one native call. frames_per_launch (1..16, 0 =
         8) frames are applied per launch to each touched block while its
         voxels stay in registers; results are identical for every value.
         `depths` may be a FrameBatch from prepare_frames (the other frame

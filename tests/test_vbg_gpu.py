@@ -345,7 +345,7 @@ def test_frame_stream_fast_path_equals_two_step_path():
     assert gb.hashmap().capacity() > 512  # grew through Reserve
 
 
-@pytest.mark.parametrize("group", [1, 2, 3, 4, 6, 8])
+@pytest.mark.parametrize("group", [1, 2, 3, 4, 6, 8, 11, 16])
 @pytest.mark.parametrize("grid_f32", [False, True])
 def test_frame_batch_equals_oracle(group, grid_f32):
     """integrate_frames (one native call; `group` frames applied per launch to
@@ -396,8 +396,11 @@ def test_fused_frame_groups_with_disjoint_frame_bits_stress():
     two groups must not see each other's words (two planes, by group parity).
     Small images and a view that jumps between frames make consecutive groups
     touch overlapping block sets with DIFFERENT frame bits, many fused groups
-    (2 to 8 frames) per call, repeated: the grid must equal frame-by-frame integration
-    (frames_per_launch = 1) bit for bit every time, and the oracle's."""
+    (2 to 16 frames) per call, repeated: the grid must equal frame-by-frame
+    integration (frames_per_launch = 1) bit for bit every time, and the
+    oracle's. The last two repetitions give the map the head-room the run-ahead
+    capacity policy wants for 16-frame groups (262 144 blocks), so that those
+    groups really run fused."""
     _lib, geometry = _gpu()
     w, h = 160, 120
     ks = [(i * 137) % 1000 for i in range(96)]
@@ -414,8 +417,9 @@ def test_fused_frame_groups_with_disjoint_frame_bits_stress():
     og = OracleGrid(False, 16384)
     for i in range(24):
         og.integrate(ds[i], cs[i], K, Ts[i])
-    for rep in range(6):
-        g = _mk_grid(geometry, False, block_count=16384)
+    for rep in range(8):
+        g = _mk_grid(geometry, False,
+                     block_count=262144 if rep >= 6 else 16384)
         if rep == 0:
             g.integrate_frames(dt[:24], ct[:24], K, K, Ts[:24], sc.DEPTH_SCALE,
                                sc.DEPTH_MAX, sc.TRUNC_MULT,
@@ -426,7 +430,7 @@ def test_fused_frame_groups_with_disjoint_frame_bits_stress():
                                frames_per_launch=4)
         else:
             g.integrate_frames(dt, ct, K, K, Ts, sc.DEPTH_SCALE, sc.DEPTH_MAX,
-                               sc.TRUNC_MULT, frames_per_launch=(2, 3, 8, 5, 8)[rep - 1])
+                               sc.TRUNC_MULT, frames_per_launch=(2, 3, 16, 5, 12, 16, 13)[rep - 1])
         got = _all_blocks(g)
         for a, b in zip(want, got):
             assert np.array_equal(a, b), rep
