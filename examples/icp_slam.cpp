@@ -4,6 +4,10 @@
 //
 // Per frame, with the calls a user of the reference's tensor API would make:
 //   VoxelBlockGrid::GetUniqueBlockCoordinates(previous depth, previous pose)
+//       -- here o3dmi_vbg_last_frame_block_coordinates: the same set, taken
+//       from the Integrate that just touched those blocks (no second touch,
+//       no host wait; `examples/icp_slam ... 1` calls the reference's
+//       function instead)
 //   VoxelBlockGrid::RayCast(depth + normal maps)            model frame
 //   PointCloud::CreateFromDepthImage(ray-cast depth, stride 2; normals ride
 //       along as the per-pixel attribute) + rotate the normals    model cloud
@@ -18,7 +22,7 @@
 //   hipcc -O2 -std=c++17 examples/icp_slam.cpp -Iinclude \
 //         -Lopen3d_amd/lib -lo3d_mi355x -Wl,-rpath,'$ORIGIN/../open3d_amd/lib' \
 //         -o examples/icp_slam
-//   examples/icp_slam [frames=60] [width=640] [height=480]
+//   examples/icp_slam [frames=60] [width=640] [height=480] [touch_again=0]
 
 #include <hip/hip_runtime_api.h>
 
@@ -94,6 +98,7 @@ int main(int argc, char** argv) {
     Camera cam;
     cam.width = argc > 2 ? std::atoi(argv[2]) : 640;
     cam.height = argc > 3 ? std::atoi(argv[3]) : 480;
+    const bool touch_again = argc > 4 && std::atoi(argv[4]) != 0;
     cam.fx = 525.0 * cam.width / 640.0;
     cam.fy = 525.0 * cam.height / 480.0;
     cam.cx = 0.5 * cam.width - 0.5;
@@ -139,7 +144,9 @@ int main(int argc, char** argv) {
     CHECK_O3D(o3dmi_vbg_create(3, names, dtypes, channels, 0.008f, 16, 40000,
                                stream, &grid));
 
-    int32_t* keys = DeviceAlloc<int32_t>((size_t)(H / 4) * (W / 4) * 4 * 3);
+    const int64_t keys_cap = (int64_t)(H / 4) * (W / 4) * 4;
+    int32_t* keys = DeviceAlloc<int32_t>((size_t)keys_cap * 3);
+    int32_t* keys_count = DeviceAlloc<int32_t>(1);
     float* range_map = DeviceAlloc<float>((size_t)(H / 8) * (W / 8) * 2);
     float* rc_depth = DeviceAlloc<float>(pixels);
     float* rc_normal = DeviceAlloc<float>(pixels * 3);
@@ -166,6 +173,8 @@ int main(int argc, char** argv) {
     CHECK_O3D(o3dmi_vbg_integrate_frame(grid, depth_dev[0], H, W, color_dev[0],
                                         H, W, O3DMI_U16, K, K, X, depth_scale,
                                         depth_max, trunc, stream));
+    CHECK_O3D(o3dmi_vbg_last_frame_block_coordinates(grid, keys, keys_cap,
+                                                     keys_count, stream));
     CHECK_HIP(hipStreamSynchronize(stream));
 
     double worst_translation = 0, worst_angle = 0;
@@ -182,15 +191,17 @@ int main(int argc, char** argv) {
     for (int k = 1; k < n_frames; ++k) {
         const double p0 = now();
         // ---- model cloud at the previous pose ------------------------------
-        int64_t m = 0;
-        CHECK_O3D(o3dmi_vbg_get_unique_block_coordinates(
-                grid, depth_dev[(size_t)k - 1], O3DMI_U16, H, W, K, X,
-                depth_scale, depth_max, trunc, keys, &m, stream));
+        int64_t m = keys_cap;
+        if (touch_again)
+            CHECK_O3D(o3dmi_vbg_get_unique_block_coordinates(
+                    grid, depth_dev[(size_t)k - 1], O3DMI_U16, H, W, K, X,
+                    depth_scale, depth_max, trunc, keys, &m, stream));
         const double p1 = now();
-        CHECK_O3D(o3dmi_vbg_ray_cast(
-                grid, keys, m, K, X, W, H, range_map, rc_depth, nullptr,
-                nullptr, rc_normal, nullptr, nullptr, nullptr, nullptr, nullptr,
-                nullptr, depth_scale, 0.1f, depth_max, 1.0f, trunc, 8, stream));
+        CHECK_O3D(o3dmi_vbg_ray_cast_dev(
+                grid, keys, m, touch_again ? nullptr : keys_count, K, X, W, H,
+                range_map, rc_depth, nullptr, nullptr, rc_normal, nullptr,
+                nullptr, nullptr, nullptr, nullptr, nullptr, depth_scale, 0.1f,
+                depth_max, 1.0f, trunc, 8, stream));
         CHECK_O3D(o3dmi_unproject(rc_depth, O3DMI_F32, H, W, rc_normal,
                                   model_pts, model_nrm, counts, K, X,
                                   depth_scale, depth_max, stride, stream));
@@ -223,6 +234,9 @@ int main(int argc, char** argv) {
         CHECK_O3D(o3dmi_vbg_integrate_frame(
                 grid, depth_dev[(size_t)k], H, W, color_dev[(size_t)k], H, W,
                 O3DMI_U16, K, K, X, depth_scale, depth_max, trunc, stream));
+        if (!touch_again)
+            CHECK_O3D(o3dmi_vbg_last_frame_block_coordinates(
+                    grid, keys, keys_cap, keys_count, stream));
         const double p4 = now();
         phase[0] += p1 - p0;
         phase[1] += p2 - p1;
@@ -252,17 +266,20 @@ int main(int argc, char** argv) {
             "{\"example\": \"icp_slam.cpp\", \"frames\": %d, \"width\": %d, "
             "\"height\": %d, \"frames_per_s\": %.1f, \"ms_per_frame\": %.4f, "
             "\"icp_iterations_per_frame\": %.2f, "
+            "\"touch_again\": %d, "
             "\"host_us_block_touch_clouds_icp_integrate\": [%.0f, %.0f, %.0f, "
             "%.0f], "
             "\"max_translation_error_m\": %.3g, \"max_rotation_error_rad\": "
             "%.3g}\n",
             n_frames - 1, W, H, (n_frames - 1) / seconds,
             seconds / (n_frames - 1) * 1e3,
-            (double)iterations / (n_frames - 1), phase[0] / (n_frames - 1),
+            (double)iterations / (n_frames - 1), (int)touch_again,
+            phase[0] / (n_frames - 1),
             phase[1] / (n_frames - 1), phase[2] / (n_frames - 1),
             phase[3] / (n_frames - 1), worst_translation, worst_angle);
 
     (void)hipFree(keys);
+    (void)hipFree(keys_count);
     (void)hipFree(range_map);
     (void)hipFree(rc_depth);
     (void)hipFree(rc_normal);

@@ -378,6 +378,21 @@ int o3dmi_rgbd_odometry_information_matrix(
         const double* source_to_target, float dist_thr, float depth_scale,
         float depth_max, double* information_host, o3dmi_stream_t stream);
 
+/* Extension (no counterpart in the reference's API): the block coordinates
+ * the most recent o3dmi_vbg_integrate_frame (or the last frame of an
+ * o3dmi_vbg_integrate_frames call with frames_per_launch = 1) touched -- the
+ * set GetUniqueBlockCoordinates returns for that frame's (depth, intrinsic,
+ * extrinsic), in the order the touch found them -- copied on the stream to
+ * out_coords_dev {capacity,3}, their number to *out_count_dev (device int32):
+ * no second block touch and no host round trip for the ray cast that follows
+ * an integration (slam::Model uses it the same way). Issue it right behind
+ * the integrate call; pass both to o3dmi_vbg_ray_cast_dev. */
+int o3dmi_vbg_last_frame_block_coordinates(o3dmi_vbg_t* g,
+                                           int32_t* out_coords_dev,
+                                           int64_t capacity,
+                                           int32_t* out_count_dev,
+                                           o3dmi_stream_t stream);
+
 /* RayCast with the number of block coordinates resident on the device
  * (*m_dev <= max_m; m_dev NULL = max_m): no host round trip between the
  * integration that produced the block list and the ray cast that uses it. */

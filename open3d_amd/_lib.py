@@ -234,6 +234,8 @@ PROTOTYPES.update({
                C.POINTER(OdometryResultC), _vp]),
     "o3dmi_rgbd_odometry_information_matrix": (
         _i32, [_vp, _vp, _i32, _i32, _i32, _dp, _dp, _f, _f, _f, _dp, _vp]),
+    "o3dmi_vbg_last_frame_block_coordinates": (_i32, [_vp, _vp, _i64, _vp,
+                                                       _vp]),
     "o3dmi_vbg_ray_cast_dev": (
         _i32, [_vp, _vp, _i64, _vp, _dp, _dp, _i32, _i32, _vp] + [_vp] * 10 +
         [_f, _f, _f, _f, _f, _i32, _vp]),

@@ -1086,6 +1086,16 @@ int o3dmi_vbg_export_last_frame_blocks(o3dmi_vbg_t* g, int32_t* out_keys_dev,
     return O3DMI_OK;
 }
 
+int o3dmi_vbg_last_frame_block_coordinates(o3dmi_vbg_t* g,
+                                           int32_t* out_coords_dev,
+                                           int64_t capacity,
+                                           int32_t* out_count_dev,
+                                           o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(capacity > 0, "capacity must be positive");
+    return o3dmi_vbg_export_last_frame_blocks(g, out_coords_dev, capacity,
+                                              out_count_dev, stream);
+}
+
 int o3dmi_vbg_ray_cast_dev(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
                            int64_t max_m, const int32_t* m_dev,
                            const double* intrinsic, const double* extrinsic,

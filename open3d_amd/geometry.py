@@ -407,10 +407,24 @@ class VoxelBlockGrid:
         return dict(integrate_ms=ti.value, launches=n.value,
                     block_frames=bf.value, frames=fr.value)
 
+    def last_frame_block_coordinates(self, capacity):
+        """Extension: the block coordinates the most recent integrate_frame
+        touched (= compute_unique_block_coordinates of that frame), without a
+        second touch or a host round trip -> (coords {capacity,3} int32, count
+        {1} int32, both on the device); give both to ray_cast(...,
+        block_count_dev=count)."""
+        out = torch.empty((int(capacity), 3), dtype=torch.int32, device="cuda")
+        cnt = torch.empty(1, dtype=torch.int32, device="cuda")
+        _lib.check(_lib.lib().o3dmi_vbg_last_frame_block_coordinates(
+            self._g, _lib.ptr(out), int(capacity), _lib.ptr(cnt), stream()),
+            "VoxelBlockGrid.last_frame_block_coordinates")
+        return out, cnt
+
     def ray_cast(self, block_coords, intrinsic, extrinsic, width, height,
                  render_attributes=("depth", "color"), depth_scale=1000.0,
                  depth_min=0.1, depth_max=3.0, weight_threshold=3.0,
-                 trunc_voxel_multiplier=8.0, range_map_down_factor=8):
+                 trunc_voxel_multiplier=8.0, range_map_down_factor=8,
+                 block_count_dev=None):
         block_coords = require_cuda(block_coords, "block_coords")
         if block_coords.dtype != torch.int32:
             raise ValueError("Unsupported block coordinate dtype %s"
@@ -430,6 +444,20 @@ class VoxelBlockGrid:
         out["range"] = torch.empty((height // d, width // d, 2),
                                    dtype=torch.float32, device="cuda")
         g = lambda a: _lib.ptr(out.get(a))
+        if block_count_dev is not None:
+            # the number of rows of block_coords in use lives on the device
+            _lib.check(_lib.lib().o3dmi_vbg_ray_cast_dev(
+                self._g, _lib.ptr(block_coords), block_coords.shape[0],
+                _lib.ptr(block_count_dev), _lib.f64p(K), _lib.f64p(T),
+                int(width), int(height), g("range"), g("depth"), g("vertex"),
+                g("color"), g("normal"), g("index"), g("mask"),
+                g("interp_ratio"), g("interp_ratio_dx"), g("interp_ratio_dy"),
+                g("interp_ratio_dz"), C.c_float(depth_scale),
+                C.c_float(depth_min), C.c_float(depth_max),
+                C.c_float(weight_threshold), C.c_float(trunc_voxel_multiplier),
+                int(range_map_down_factor), stream()),
+                "VoxelBlockGrid.ray_cast")
+            return out
         _lib.check(_lib.lib().o3dmi_vbg_ray_cast(
             self._g, _lib.ptr(block_coords), block_coords.shape[0],
             _lib.f64p(K), _lib.f64p(T), int(width), int(height), g("range"),

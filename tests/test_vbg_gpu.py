@@ -856,3 +856,34 @@ def test_frame_sharded_merge_across_two_processes():
     assert np.abs(tsdf - want[1]).max() <= 1e-5
     assert np.abs(color.astype(np.int64) - want[3].astype(np.int64)).max() \
         <= len(fr)
+
+
+def test_last_frame_block_coordinates_equal_a_second_block_touch():
+    """o3dmi_vbg_last_frame_block_coordinates (extension): after
+    integrate_frame the device-side block list is the set
+    GetUniqueBlockCoordinates returns for the same frame, and a ray cast over
+    it with the count left on the device produces the very same maps."""
+    _lib, geometry = _gpu()
+    g = _mk_grid(geometry, False, block_count=16384)
+    for k in (300, 305, 310):
+        d, c, K, T = sc.frames(k, 1)
+        dt, ct = torch.from_numpy(d[0]).cuda(), torch.from_numpy(c[0]).cuda()
+        g.integrate_frame(dt, ct, K, K, T[0], sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                          sc.TRUNC_MULT)
+        coords, cnt = g.last_frame_block_coordinates(
+            (d.shape[1] // 4) * (d.shape[2] // 4) * 4)
+        want = g.compute_unique_block_coordinates(dt, K, T[0], sc.DEPTH_SCALE,
+                                                  sc.DEPTH_MAX, sc.TRUNC_MULT)
+        n = int(cnt.item())
+        assert n == want.shape[0] and n > 100
+        assert np.array_equal(sc.sort_rows(coords[:n].cpu().numpy()),
+                              sc.sort_rows(want.cpu().numpy()))
+        h, w = d.shape[1], d.shape[2]
+        a = g.ray_cast(coords, K, T[0], w, h, ("depth", "normal", "color"),
+                       sc.DEPTH_SCALE, 0.1, sc.DEPTH_MAX, 1.0, sc.TRUNC_MULT,
+                       block_count_dev=cnt)
+        b = g.ray_cast(want, K, T[0], w, h, ("depth", "normal", "color"),
+                       sc.DEPTH_SCALE, 0.1, sc.DEPTH_MAX, 1.0, sc.TRUNC_MULT)
+        for name in ("depth", "normal", "color"):
+            assert torch.equal(a[name], b[name]), name
+        assert float((a["depth"] > 0).float().mean()) > 0.5

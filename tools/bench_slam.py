@@ -208,12 +208,14 @@ def mode_slam(a):
         PointCloud::CreateFromDepthImage(ray-cast depth, stride) with the
         normal map carried along as the per-pixel attribute, normals rotated
         into the world frame -- library calls only, no tensor glue."""
-        keys = g.compute_unique_block_coordinates(depth_pred, K, T_wc, ds, dmax,
-                                                  trunc)
-        out = g.ray_cast(keys, K, T_wc, W, H,
+        # the block coordinates of the frame integrated last, as the
+        # integration left them on the device (= GetUniqueBlockCoordinates of
+        # that frame; no second touch, no host wait)
+        out = g.ray_cast(frame_keys[0], K, T_wc, W, H,
                          render_attributes=("depth", "normal"),
                          depth_scale=ds, depth_min=0.1, depth_max=dmax,
-                         weight_threshold=1.0, trunc_voxel_multiplier=trunc)
+                         weight_threshold=1.0, trunc_voxel_multiplier=trunc,
+                         block_count_dev=frame_keys[1])
         T = np.ascontiguousarray(T_wc, dtype=np.float64)
         _lib.check(L.o3dmi_unproject(
             _lib.ptr(out["depth"]), _lib.F32, H, W, _lib.ptr(out["normal"]),
@@ -229,8 +231,9 @@ def mode_slam(a):
 
     # bootstrap with frame 0 at its true pose
     T_est = [np.array(Ts[0])]
+    keys_cap = (H // 4) * (W // 4) * 4
     g.integrate_frame(depths[0], colors[0], K, K, Ts[0], ds, dmax, trunc)
-    depth_pred = depths[0]
+    frame_keys = g.last_frame_block_coordinates(keys_cap)
     torch.cuda.synchronize()
     iters = 0
     phase = np.zeros(4)
@@ -257,7 +260,7 @@ def mode_slam(a):
         T_k = T_prev @ np.linalg.inv(r.transformation)
         T_est.append(T_k)
         g.integrate_frame(depths[k], colors[k], K, K, T_k, ds, dmax, trunc)
-        depth_pred = depths[k]
+        frame_keys = g.last_frame_block_coordinates(keys_cap)
         p4 = tick()
         phase += (p1 - p0, p2 - p1, p3 - p2, p4 - p3)
     torch.cuda.synchronize()
