@@ -1,10 +1,19 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_vbg_gpu.py tests/test_slam_gpu.py tests/test_abi.py -x -q -m gpu -k "last_frame or cpp or raycast or ray_cast" 2>&1 | tail -3
-for i in 1 2 3; do examples/icp_slam 60 640 480 0; examples/icp_slam 60 640 480 1; done
-for i in 1 2; do examples/icp_slam 60 1280 720 0; examples/icp_slam 60 1280 720 1; done
-P='import json,sys
-for l in sys.stdin:
-    if l.startswith("{"):
-        d=json.loads(l); print({k:(round(v,3) if isinstance(v,float) else v) for k,v in d.items() if k in ("frames_per_s","ms_per_frame","icp_iterations_per_frame","final_pose_err_rad_m")})'
-for i in 1 2; do timeout 300 python tools/bench_slam.py --mode slam --vga --frames 60 --no-cpu 2>/dev/null | python -c "$P"; done
-timeout 300 python tools/bench_slam.py --mode slam --frames 60 --no-cpu 2>/dev/null | python -c "$P"
+O=gpurun_out/r2z; mkdir -p $O
+timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; python - <<'PY'
+import json
+d=json.loads(open("gpurun_out/r2z/bench.json").read().strip().splitlines()[-1])
+print("value", round(d["value"]), "timed_s", round(d["config"]["timed_region_s"],3), "ms_per_step", d["ms_per_step"])
+r=d["roofline"]; print({k:r.get(k) for k in ("frac","frac_hbm","frac_valu","avg_kernel_ms","wall_ms_per_launch","empty_event_bracket_ms","traffic","avg_waves_per_simd","traffic_source")})
+s=d.get("secondary",{})
+for k,v in s.items():
+    if isinstance(v,dict): print(k, {a:v[a] for a in v if a in ("ms_per_icp","ms_per_iteration","frames_per_s","ms_per_frame","icp_iterations_per_frame","cpu_oracle_ms_per_icp","cpu_oracle_ms_per_multiscale_icp","error","frames_per_s_of_5_runs","host_us_block_touch_clouds_icp_integrate")}, "frac", v.get("roofline",{}).get("frac"))
+print(d.get("cpu_baseline"))
+PY
+tail -2 $O/bench.err
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pmc --no-secondary > $GRAFT_REPO_ROOT/$O/bench_traced.json 2>/dev/null
+cd $GRAFT_REPO_ROOT
+f=$(find /tmp/prof_b -name "*kernel_stats.csv" | head -1); cp "$f" $O/kernel_stats.csv
+f=$(find /tmp/prof_b -name "*kernel_trace.csv" | head -1); python tools/kernel_gaps.py "$f" FrameStepKernel | tee $O/kernel_gaps.txt
