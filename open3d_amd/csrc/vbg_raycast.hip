@@ -662,6 +662,16 @@ int o3dmi_vbg_raycast(o3dmi_hash_t* block_hash, const float* tsdf_dev,
                      (double)sum / hs.size(), mx, (double)wsum / nw,
                      wmaxes[wmaxes.size() / 2], wmaxes[wmaxes.size() * 9 / 10],
                      wmaxes[wmaxes.size() * 99 / 100], wmax_max);
+        const int th[6] = {8, 16, 24, 32, 48, 64};
+        long long over[6] = {0, 0, 0, 0, 0, 0}, steps_over[6] = {0};
+        for (int v : hs)
+            for (int k = 0; k < 6; ++k)
+                if (v > th[k]) { ++over[k]; steps_over[k] += v - th[k]; }
+        std::fprintf(stderr, "[o3dmi] raycast rays with more than");
+        for (int k = 0; k < 6; ++k)
+            std::fprintf(stderr, " %d steps: %lld (%lld steps beyond);", th[k],
+                         over[k], steps_over[k]);
+        std::fprintf(stderr, "\n");
     }
     return O3DMI_OK;
 }

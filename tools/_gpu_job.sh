@@ -1,19 +1,17 @@
-cd $GRAFT_REPO_ROOT
-O=gpurun_out/r2z; mkdir -p $O
-timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; tail -3 $O/pytest.log
-timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; python - <<'PY'
-import json
-d=json.loads(open("gpurun_out/r2z/bench.json").read().strip().splitlines()[-1])
-print("value", round(d["value"]), "timed_s", round(d["config"]["timed_region_s"],3), "ms_per_step", d["ms_per_step"])
-r=d["roofline"]; print({k:r.get(k) for k in ("frac","frac_hbm","frac_valu","avg_kernel_ms","wall_ms_per_launch","empty_event_bracket_ms","traffic","avg_waves_per_simd","traffic_source")})
-s=d.get("secondary",{})
-for k,v in s.items():
-    if isinstance(v,dict): print(k, {a:v[a] for a in v if a in ("ms_per_icp","ms_per_iteration","frames_per_s","ms_per_frame","icp_iterations_per_frame","cpu_oracle_ms_per_icp","cpu_oracle_ms_per_multiscale_icp","error","frames_per_s_of_5_runs","host_us_block_touch_clouds_icp_integrate")}, "frac", v.get("roofline",{}).get("frac"))
-print(d.get("cpu_baseline"))
-PY
-tail -2 $O/bench.err
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pmc --no-secondary > $GRAFT_REPO_ROOT/$O/bench_traced.json 2>/dev/null
+cat > /tmp/ks.py <<'PY'
+import csv,sys
+for r in csv.reader(open(sys.argv[1])):
+    if 'RayCastKernel' in r[0] or 'EstimateRange' in r[0]:
+        print("   ", r[0].replace('void o3dmi::(anonymous namespace)::','')[:70], "calls", r[1], "avg us", round(float(r[3])/1e3,1), "max", round(float(r[6])/1e3,1))
+PY
+for S in 0 12 16 24 32; do
+  rm -rf /tmp/prc; O3DMI_RAYCAST_SPLIT=$S timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prc -o r -- $GRAFT_REPO_ROOT/examples/icp_slam 40 640 480 > /tmp/ex.log 2>&1
+  f=$(find /tmp/prc -name "*kernel_stats.csv" | head -1); echo "VGA split $S"; python /tmp/ks.py "$f"
+done
+for S in 0 16 32; do
+  rm -rf /tmp/prc; O3DMI_RAYCAST_SPLIT=$S timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prc -o r -- $GRAFT_REPO_ROOT/examples/icp_slam 40 1280 720 > /tmp/ex.log 2>&1
+  f=$(find /tmp/prc -name "*kernel_stats.csv" | head -1); echo "720p split $S"; python /tmp/ks.py "$f"
+done
 cd $GRAFT_REPO_ROOT
-f=$(find /tmp/prof_b -name "*kernel_stats.csv" | head -1); cp "$f" $O/kernel_stats.csv
-f=$(find /tmp/prof_b -name "*kernel_trace.csv" | head -1); python tools/kernel_gaps.py "$f" FrameStepKernel | tee $O/kernel_gaps.txt
+for S in 0 16; do for i in 1 2 3; do echo -n "split $S: "; O3DMI_RAYCAST_SPLIT=$S examples/icp_slam 60 640 480 | grep -o '"frames_per_s": [0-9.]*'; done; done
