@@ -1,8 +1,10 @@
 cd $GRAFT_REPO_ROOT
-for i in 1 2 3; do
-  echo -n "base: "; LD_LIBRARY_PATH=$PWD/_ab/lib examples/icp_slam 60 640 480 | grep -o '"frames_per_s": [0-9.]*\|"host_us[^]]*\]'| tr '\n' ' '; echo
-  echo -n "new : "; examples/icp_slam 60 640 480 | grep -o '"frames_per_s": [0-9.]*\|"host_us[^]]*\]' | tr '\n' ' '; echo
-done
-echo base; LD_LIBRARY_PATH=$PWD/_ab/lib O3DMI_ICP_TIMING=2 examples/icp_slam 30 640 480 2>&1 | grep "whole call" | sed -n 10,14p
-echo new; O3DMI_ICP_TIMING=2 examples/icp_slam 30 640 480 2>&1 | grep "whole call" | sed -n 10,14p
-timeout 600 python -m pytest tests/test_icp_gpu.py -x -q -m gpu -k "multiscale or icp_pose or two_ranks or colored" 2>&1 | tail -2
+O3DMI_STEP_VARIANT=3 timeout 900 python -m pytest tests/test_vbg_gpu.py tests/test_golden.py -x -q -m gpu -k "frame or stream or group or golden or res8" 2>&1 | tail -2
+P='import json,sys
+for l in sys.stdin:
+    if l.startswith("{"):
+        d=json.loads(l); r=d["roofline"]; print(round(d["value"]), d["ms_per_step"], r.get("avg_kernel_ms"), r.get("frac"))'
+for rep in 1 2; do
+for V in 2 3; do
+  echo -n "variant $V: "; O3DMI_STEP_VARIANT=$V timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pmc --no-secondary 2>/dev/null | python -c "$P"
+done; done
