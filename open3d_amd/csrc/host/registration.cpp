@@ -13,7 +13,9 @@
 //                                     reduction kernel (no copy / sync call)
 //   29-sum kernel -> D2H sync         [optional cross-GPU all-reduce hook]
 //   6x6 solve on host (F64)           6x6 solve on host (F64), same arithmetic
-//   4x4 upload + transform kernel     transform kernel (matrix by value)
+//   4x4 upload + transform kernel     the transform rides in the NEXT search
+//                                     launch (matrix by value, points moved
+//                                     in place before they are searched)
 //
 // The source cloud is transformed incrementally in its own dtype every
 // iteration exactly like the reference (Registration.cpp:322), not re-derived
