@@ -576,9 +576,12 @@ SearchAccumulateKernel(NnsView<T> nv, const Rec4<T>* __restrict__ sorted_n,
             };
             // branch-free; `live` = entry t of the list exists. The winner is
             // remembered by its list entry and turned into a record position
-            // once per batch of cells.
+            // once per batch of cells. Float32: (d2, index) compare as ONE
+            // 64-bit key -- a non-negative float orders like its bit pattern
+            // -- so "nearer, ties to the lower index" is a single compare.
             bool have = false;
             unsigned best_t = 0;
+            unsigned long long best_key = ~0ull;
             auto consider = [&](const Rec4<T>& p, unsigned t, bool live) {
                 T result = T(0);
                 const T d0 = q[0] - p.x;
@@ -588,13 +591,25 @@ SearchAccumulateKernel(NnsView<T> nv, const Rec4<T>* __restrict__ sorted_n,
                 const T dd = q[2] - p.z;
                 result += dd * dd;
                 const int pi = RecIndex(p);
-                const bool better =
-                        live && result < nv.radius_squared &&
-                        (!have || result < d2 || (result == d2 && pi < idx));
-                best_t = better ? t : best_t;
-                idx = better ? pi : idx;
-                d2 = better ? result : d2;
-                have = have || better;
+                if constexpr (sizeof(T) == 4) {
+                    const unsigned long long key =
+                            ((unsigned long long)__float_as_uint((float)result)
+                             << 32) |
+                            (unsigned)pi;
+                    const bool better = live && result < nv.radius_squared &&
+                                        key < best_key;
+                    best_t = better ? t : best_t;
+                    best_key = better ? key : best_key;
+                } else {
+                    const bool better =
+                            live && result < nv.radius_squared &&
+                            (!have || result < d2 ||
+                             (result == d2 && pi < idx));
+                    best_t = better ? t : best_t;
+                    idx = better ? pi : idx;
+                    d2 = better ? result : d2;
+                    have = have || better;
+                }
             };
             for (int cb = 0; cb < kOwn; cb += kBatch) {
                 // ranges of the owned cells (one round trip), then their
@@ -617,13 +632,25 @@ SearchAccumulateKernel(NnsView<T> nv, const Rec4<T>* __restrict__ sorted_n,
                     first[k + 1] = first[k] + (c < 27 ? e - s0[k] : 0u);
                 }
                 const unsigned total = first[kBatch];
+                // entry t of the list is record t + off[k] of the array, k the
+                // cell it falls into
+                // (as a running sum of the offsets' differences: a chain of
+                // plain "pick off[k]" selects is turned into an indexed read
+                // of an LDS copy of the array, one LDS round trip in front of
+                // every record load)
+                unsigned step[kBatch];
+                step[0] = s0[0];  // first[0] == 0
+#pragma unroll
+                for (int k = 1; k < kBatch; ++k)
+                    step[k] = (s0[k] - first[k]) - (s0[k - 1] - first[k - 1]);
                 auto position = [&](unsigned t) {
-                    unsigned j = s0[0] + t;
+                    unsigned o = step[0];
 #pragma unroll
                     for (int k = 1; k < kBatch; ++k)
-                        j = t >= first[k] ? s0[k] + (t - first[k]) : j;
-                    return j;
+                        o += t >= first[k] ? step[k] : 0u;
+                    return t + o;
                 };
+                const unsigned long long key_before = best_key;
                 const int idx_before = idx;
                 const bool had = have;
                 for (unsigned t0 = 0; t0 < total; t0 += kFlight) {
@@ -638,8 +665,16 @@ SearchAccumulateKernel(NnsView<T> nv, const Rec4<T>* __restrict__ sorted_n,
                         consider(cand[u], t0 + u, t0 + u < total);
                 }
                 // a new winner out of this batch of cells?
-                if (have && (!had || idx != idx_before))
-                    pos = (int)position(best_t);
+                if constexpr (sizeof(T) == 4) {
+                    if (best_key != key_before) {
+                        pos = (int)position(best_t);
+                        idx = (int)(unsigned)best_key;
+                        d2 = (T)__uint_as_float((unsigned)(best_key >> 32));
+                    }
+                } else {
+                    if (have && (!had || idx != idx_before))
+                        pos = (int)position(best_t);
+                }
             }
         }
         // minimum by (d2, idx) over the G lanes of the group

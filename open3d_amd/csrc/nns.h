@@ -39,12 +39,21 @@ template <typename T> struct Rec4;  // {x,y,z,w}
 template <> struct alignas(16) Rec4<float> { float x, y, z; int w; };
 template <> struct alignas(32) Rec4<double> { double x, y, z; long long w; };
 
+// 32-bit mixing of the (wrapped) cell coordinates: three multiplies and a
+// murmur3 finaliser. (The first version went through 64-bit products and a
+// 64-bit finaliser -- five 64-bit multiplies, ~45 vector instructions per
+// visited cell, a fifth of the fused ICP search's instruction stream.)
 __device__ __forceinline__ unsigned HashCell(long long cx, long long cy,
                                              long long cz) {
-    unsigned long long k = (unsigned long long)cx * 0x9E3779B97F4A7C15ull;
-    k ^= (unsigned long long)cy * 0xC2B2AE3D27D4EB4Full + (k >> 29);
-    k ^= (unsigned long long)cz * 0x165667B19E3779F9ull + (k << 17);
-    return HashKey(k);
+    unsigned h = (unsigned)cx * 0x9E3779B1u;
+    h ^= ((unsigned)cy * 0x85EBCA77u) + (h >> 15);
+    h ^= ((unsigned)cz * 0xC2B2AE3Du) + (h << 11);
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
 }
 
 template <typename T>
