@@ -538,7 +538,7 @@ SearchAccumulateKernel(NnsView<T> nv, const Rec4<T>* __restrict__ sorted_n,
     constexpr int kOwn = (27 + G - 1) / G;        // cells a lane owns
     constexpr int kBatch = kOwn < 9 ? kOwn : 9;   // cells per batch
     // candidate records in flight per lane and round trip
-    constexpr int kFlight = sizeof(T) == 4 ? 16 : 8;
+    constexpr int kFlight = (sizeof(T) == 4 ? 16 : 8) / (G >= 16 ? 2 : 1);
     for (int64_t base = wave * kPerWave; base < n; base += n_waves * kPerWave) {
         const int64_t i = base + sub;
         const bool valid = i < n;
