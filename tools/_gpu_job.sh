@@ -1,7 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 300 python tools/bench_search.py 2>/dev/null | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read())
-for l in d['levels']: print(l['voxel'], l['source_points'], l['search_us'])"
-for i in 1 2 3; do examples/icp_slam 60 640 480 | grep -o '"frames_per_s": [0-9.]*'; done
-timeout 600 python -m pytest tests/test_icp_gpu.py -x -q -m gpu -k "pose or multiscale or sums or hybrid" 2>&1 | tail -1
+O=gpurun_out/r2z; mkdir -p $O
+timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest_final.log 2>&1; tail -3 $O/pytest_final.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
