@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r2z; mkdir -p $O
-timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest_final.log 2>&1; tail -3 $O/pytest_final.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 600 python -m pytest tests/test_icp_gpu.py -x -q -m gpu -k "voxel_down or multiscale or colored or symmetric" 2>&1 | tail -1
+for i in 1 2 3 4; do examples/icp_slam 60 640 480 | grep -o '"frames_per_s": [0-9.]*'; done
+O3DMI_ICP_TIMING=2 examples/icp_slam 30 640 480 2>&1 | grep "whole call" | sed -n 12,16p
