@@ -3,48 +3,26 @@
 // (cpp/open3d/t/geometry/PointCloud.cpp:856-976). Replaces
 //   EstimateCovariancesUsingHybridSearchCUDA  (t/geometry/kernel/PointCloudImpl.h:588-638,
 //       per-point body EstimatePointWiseRobustNormalizedCovarianceKernel :512-585)
-//   EstimateNormalsFromCovariancesCUDA        (:1011-1063, per-point body
-//       EstimatePointWiseNormalsWithFastEigen3x3 :875-1009, ComputeEigenvector0/1 :746-873)
-// Per-point arithmetic follows the reference statement by statement, including
-// where its double literals promote a sub-expression to float64; acos / cos
-// come from the device math library (a few ulp from the host's), so normals
-// agree with the CPU path to ~1e-6, not bit for bit.
+//   EstimateNormalsFromCovariancesCUDA        (:1011-1063)
+// Covariances follow the reference statement by statement (two-pass float64
+// cumulants in neighbour order: bit-exact). The eigenvector behind a normal is
+// this code base's own float64 Jacobi routine, not the reference's closed-form
+// one (:746-1009): a tolerance, not bits -- see SmallestEigenvectorSym3.
 // Gather-bound: 30 neighbours x 12 B per point, L2-resident for a sorted cloud.
-
-#include <hipcub/hipcub.hpp>
 
 #include <cmath>
 #include <cstdlib>
 
 #include "common.h"
+#include "scan.h"
 
 namespace o3dmi {
 namespace {
 
-template <typename T>
-__device__ __forceinline__ void Cross(const T* a, const T* b, T* c) {
-    c[0] = (a[1] * b[2]) - (a[2] * b[1]);
-    c[1] = (a[2] * b[0]) - (a[0] * b[2]);
-    c[2] = (a[0] * b[1]) - (a[1] * b[0]);
-}
-template <typename T>
-__device__ __forceinline__ T Dot(const T* a, const T* b) {
-    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
-}
-template <typename T>
-__device__ __forceinline__ void Matmul3x3_3x1(const T* A, const T* b, T* c) {
-    c[0] = A[0] * b[0] + A[1] * b[1] + A[2] * b[2];
-    c[1] = A[3] * b[0] + A[4] * b[1] + A[5] * b[2];
-    c[2] = A[6] * b[0] + A[7] * b[1] + A[8] * b[2];
-}
 __device__ __forceinline__ float Sqrt(float v) { return sqrtf(v); }
 __device__ __forceinline__ double Sqrt(double v) { return sqrt(v); }
 __device__ __forceinline__ float Abs(float v) { return fabsf(v); }
 __device__ __forceinline__ double Abs(double v) { return fabs(v); }
-__device__ __forceinline__ float Acos(float v) { return acosf(v); }
-__device__ __forceinline__ double Acos(double v) { return acos(v); }
-__device__ __forceinline__ float Cos(float v) { return cosf(v); }
-__device__ __forceinline__ double Cos(double v) { return cos(v); }
 
 // PointCloudImpl.h:512-585
 // Neighbour lists: fixed-width rows, or CSR when row_splits != NULL.
@@ -106,182 +84,108 @@ __global__ void CovariancesKernel(const T* __restrict__ points,
     }
 }
 
-// PointCloudImpl.h:746-793
+// ---- symmetric 3x3 eigen-decomposition (this code base's own) -----------------
+// Cyclic Jacobi: rotations in the (0,1), (0,2), (1,2) planes, each chosen to
+// annihilate that off-diagonal entry (the smaller root of t^2 + 2 theta t - 1),
+// until every off-diagonal entry is an exact zero or kJacobiSweeps sweeps have
+// run (quadratic convergence: a 3x3 is at rounding level after 4 - 5). On
+// return a is diagonal (eigenvalues, unsorted) and the columns of V are the
+// eigenvectors. Used by the normal estimation (smallest eigenvector) and by
+// the colour-gradient solve (pseudo-inverse).
+constexpr int kJacobiSweeps = 8;
 template <typename T>
-__device__ void Eigenvector0(const T* A, const T eval0, T* ev) {
-    T row0[3] = {A[0] - eval0, A[1], A[2]};
-    T row1[3] = {A[1], A[4] - eval0, A[5]};
-    T row2[3] = {A[2], A[5], A[8] - eval0};
-    T r0xr1[3], r0xr2[3], r1xr2[3];
-    Cross(row0, row1, r0xr1);
-    Cross(row0, row2, r0xr2);
-    Cross(row1, row2, r1xr2);
-    const T d0 = Dot(r0xr1, r0xr1);
-    const T d1 = Dot(r0xr2, r0xr2);
-    const T d2 = Dot(r1xr2, r1xr2);
-    T dmax = d0;
-    int imax = 0;
-    if (d1 > dmax) {
-        dmax = d1;
-        imax = 1;
-    }
-    if (d2 > dmax) imax = 2;
-    if (imax == 0) {
-        const T s = Sqrt(d0);
-        ev[0] = r0xr1[0] / s; ev[1] = r0xr1[1] / s; ev[2] = r0xr1[2] / s;
-    } else if (imax == 1) {
-        const T s = Sqrt(d1);
-        ev[0] = r0xr2[0] / s; ev[1] = r0xr2[1] / s; ev[2] = r0xr2[2] / s;
-    } else {
-        const T s = Sqrt(d2);
-        ev[0] = r1xr2[0] / s; ev[1] = r1xr2[1] / s; ev[2] = r1xr2[2] / s;
-    }
-}
-
-// PointCloudImpl.h:795-873
-template <typename T>
-__device__ void Eigenvector1(const T* A, const T* evec0, const T eval1, T* ev) {
-    T U[3];
-    if (Abs(evec0[0]) > Abs(evec0[1])) {
-        const T inv_length = (T)(
-                1.0 / (double)Sqrt(evec0[0] * evec0[0] + evec0[2] * evec0[2]));
-        U[0] = -evec0[2] * inv_length;
-        U[1] = 0.0;
-        U[2] = evec0[0] * inv_length;
-    } else {
-        const T inv_length = (T)(
-                1.0 / (double)Sqrt(evec0[1] * evec0[1] + evec0[2] * evec0[2]));
-        U[0] = 0.0;
-        U[1] = evec0[2] * inv_length;
-        U[2] = -evec0[1] * inv_length;
-    }
-    T V[3], AU[3], AV[3];
-    Cross(evec0, U, V);
-    Matmul3x3_3x1(A, U, AU);
-    Matmul3x3_3x1(A, V, AV);
-    T m00 = Dot(U, AU) - eval1;
-    T m01 = Dot(U, AV);
-    T m11 = Dot(V, AV) - eval1;
-    const T absM00 = Abs(m00), absM01 = Abs(m01), absM11 = Abs(m11);
-    if (absM00 >= absM11) {
-        const T max_abs_comp = absM00 < absM01 ? absM01 : absM00;
-        if (max_abs_comp > 0) {
-            if (absM00 >= absM01) {
-                m01 /= m00;
-                m00 = 1 / Sqrt(1 + m01 * m01);
-                m01 *= m00;
-            } else {
-                m00 /= m01;
-                m01 = 1 / Sqrt(1 + m00 * m00);
-                m00 *= m01;
-            }
-            ev[0] = m01 * U[0] - m00 * V[0];
-            ev[1] = m01 * U[1] - m00 * V[1];
-            ev[2] = m01 * U[2] - m00 * V[2];
-        } else {
-            ev[0] = U[0]; ev[1] = U[1]; ev[2] = U[2];
-        }
-    } else {
-        const T max_abs_comp = absM11 < absM01 ? absM01 : absM11;
-        if (max_abs_comp > 0) {
-            if (absM11 >= absM01) {
-                m01 /= m11;
-                m11 = 1 / Sqrt(1 + m01 * m01);
-                m01 *= m11;
-            } else {
-                m11 /= m01;
-                m01 = 1 / Sqrt(1 + m11 * m11);
-                m11 *= m01;
-            }
-            ev[0] = m11 * U[0] - m01 * V[0];
-            ev[1] = m11 * U[1] - m01 * V[1];
-            ev[2] = m11 * U[2] - m01 * V[2];
-        } else {
-            ev[0] = U[0]; ev[1] = U[1]; ev[2] = U[2];
-        }
-    }
-}
-
-// PointCloudImpl.h:875-1009
-template <typename T>
-__device__ void FastEigen3x3(const T* cov, T* nrm) {
-    T max_coeff = cov[0];
+__device__ __forceinline__ void JacobiEigenSym3(T (&a)[3][3], T (&V)[3][3]) {
 #pragma unroll
-    for (int i = 1; i < 9; ++i)
-        if (max_coeff < cov[i]) max_coeff = cov[i];
-    if (max_coeff == 0) {
-        nrm[0] = nrm[1] = nrm[2] = 0.0;
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) V[i][j] = i == j ? T(1) : T(0);
+    for (int sweep = 0; sweep < kJacobiSweeps; ++sweep) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                const T apq = a[p][q];
+                if (apq == T(0)) continue;
+                const T theta = (a[q][q] - a[p][p]) / (T(2) * apq);
+                const T t = (theta >= T(0) ? T(1) : T(-1)) /
+                            (Abs(theta) + Sqrt(theta * theta + T(1)));
+                const T c = T(1) / Sqrt(t * t + T(1));
+                const T sn = t * c;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const T akp = a[k][p], akq = a[k][q];
+                    a[k][p] = c * akp - sn * akq;
+                    a[k][q] = sn * akp + c * akq;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const T apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = c * apk - sn * aqk;
+                    a[q][k] = sn * apk + c * aqk;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const T vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+}
+
+// Normal of a neighbourhood = unit eigenvector of the smallest eigenvalue of
+// its covariance. The reference (EstimatePointWiseNormalsWithFastEigen3x3,
+// t/geometry/kernel/PointCloudImpl.h:875-1009) gets it non-iteratively in the
+// point dtype (trigonometric eigenvalues + cross products of rows); this
+// routine is NOT that one: the covariance is widened to float64 and diagonalised
+// by the converged Jacobi above, so the answer is the exact eigenvector to
+// float64 rounding for both dtypes. Against the reference's compiled body the
+// two agree to the reference's own rounding: <= 1e-4 rad (Float32) / 1e-10
+// (Float64) wherever the two smallest eigenvalues are separated by more than
+// 5 % of the largest (tests/test_normals_gpu.py); in a degenerate eigenspace
+// any of its unit vectors is a valid answer and the two routines pick
+// different ones.
+//   * sign: an eigenvector has none, the reference's is whatever its cross
+//     products produce. Pinned here: the last non-zero component is positive
+//     (z > 0, else y > 0, else x > 0) -- the convention the reference's own
+//     value test satisfies (cpp/tests/t/geometry/PointCloud.cpp:630-668);
+//   * ties between eigenvalues go to the later axis, so the identity
+//     covariance of a neighbourhood with < 3 members gives +z as in the
+//     reference; an all-zero covariance has no direction: zero vector (the
+//     caller turns it into +z when the cloud has no prior normals).
+template <typename T>
+__device__ void SmallestEigenvectorSym3(const T* cov, T* nrm) {
+    double a[3][3], V[3][3];
+    double scale = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const double m = fabs((double)cov[i]);
+        scale = m > scale ? m : scale;
+    }
+    if (!(scale > 0.0)) {
+        nrm[0] = nrm[1] = nrm[2] = T(0);
         return;
     }
-    T A[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) A[i] = cov[i] / max_coeff;
-    const T norm = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
-    if (norm > 0) {
-        T eval[3], evec0[3], evec1[3], evec2[3];
-        const T q = (T)((double)(A[0] + A[4] + A[8]) / 3.0);
-        const T b00 = A[0] - q;
-        const T b11 = A[4] - q;
-        const T b22 = A[8] - q;
-        // (b00*b00 + b11*b11 + b22*b22 + norm * 2.0) / 6.0: the sum of the
-        // three squares is scalar_t, `norm * 2.0` and everything after it
-        // float64; sqrt of the float64 value, narrowed to scalar_t.
-        const T p = (T)sqrt(((double)(b00 * b00 + b11 * b11 + b22 * b22) +
-                             (double)norm * 2.0) /
-                            6.0);
-        const T c00 = b11 * b22 - A[5] * A[5];
-        const T c01 = A[1] * b22 - A[5] * A[2];
-        const T c02 = A[1] * A[5] - b11 * A[2];
-        const T det = (b00 * c00 - A[1] * c01 + A[2] * c02) / (p * p * p);
-        T half_det = (T)((double)det * 0.5);
-        half_det = half_det < (T)-1.0 ? (T)-1.0 : half_det;  // max(half_det,-1)
-        half_det = (T)1.0 < half_det ? (T)1.0 : half_det;    // min(.., 1)
-        const T angle = (T)((double)Acos(half_det) / 3.0);
-        const T two_thrids_pi = (T)2.09439510239319549;
-        const T beta2 = (T)((double)Cos(angle) * 2.0);
-        const T beta0 = (T)((double)Cos(angle + two_thrids_pi) * 2.0);
-        const T beta1 = -(beta0 + beta2);
-        eval[0] = q + p * beta0;
-        eval[1] = q + p * beta1;
-        eval[2] = q + p * beta2;
-        if (half_det >= 0) {
-            Eigenvector0<T>(A, eval[2], evec2);
-            if (eval[2] < eval[0] && eval[2] < eval[1]) {
-                nrm[0] = evec2[0]; nrm[1] = evec2[1]; nrm[2] = evec2[2];
-                return;
-            }
-            Eigenvector1<T>(A, evec2, eval[1], evec1);
-            if (eval[1] < eval[0] && eval[1] < eval[2]) {
-                nrm[0] = evec1[0]; nrm[1] = evec1[1]; nrm[2] = evec1[2];
-                return;
-            }
-            nrm[0] = evec1[1] * evec2[2] - evec1[2] * evec2[1];
-            nrm[1] = evec1[2] * evec2[0] - evec1[0] * evec2[2];
-            nrm[2] = evec1[0] * evec2[1] - evec1[1] * evec2[0];
-        } else {
-            Eigenvector0<T>(A, eval[0], evec0);
-            if (eval[0] < eval[1] && eval[0] < eval[2]) {
-                nrm[0] = evec0[0]; nrm[1] = evec0[1]; nrm[2] = evec0[2];
-                return;
-            }
-            Eigenvector1<T>(A, evec0, eval[1], evec1);
-            if (eval[1] < eval[0] && eval[1] < eval[2]) {
-                nrm[0] = evec1[0]; nrm[1] = evec1[1]; nrm[2] = evec1[2];
-                return;
-            }
-            nrm[0] = evec0[1] * evec1[2] - evec0[2] * evec1[1];
-            nrm[1] = evec0[2] * evec1[0] - evec0[0] * evec1[2];
-            nrm[2] = evec0[0] * evec1[1] - evec0[1] * evec1[0];
-        }
-    } else {
-        if (cov[0] < cov[4] && cov[0] < cov[8]) {
-            nrm[0] = 1.0; nrm[1] = 0.0; nrm[2] = 0.0;
-        } else if (cov[4] < cov[0] && cov[4] < cov[8]) {
-            nrm[0] = 0.0; nrm[1] = 1.0; nrm[2] = 0.0;
-        } else {
-            nrm[0] = 0.0; nrm[1] = 0.0; nrm[2] = 1.0;
-        }
-    }
+    // symmetric by construction: the upper triangle is read
+    const double inv = 1.0 / scale;
+    a[0][0] = (double)cov[0] * inv;
+    a[1][1] = (double)cov[4] * inv;
+    a[2][2] = (double)cov[8] * inv;
+    a[0][1] = a[1][0] = (double)cov[1] * inv;
+    a[0][2] = a[2][0] = (double)cov[2] * inv;
+    a[1][2] = a[2][1] = (double)cov[5] * inv;
+    JacobiEigenSym3<double>(a, V);
+    int best = 0;
+    if (a[1][1] <= a[best][best]) best = 1;
+    if (a[2][2] <= a[best][best]) best = 2;
+    double v[3] = {V[0][best], V[1][best], V[2][best]};
+    const double len = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const bool flip = v[2] < 0.0 ||
+                      (v[2] == 0.0 && (v[1] < 0.0 || (v[1] == 0.0 && v[0] < 0.0)));
+    const double s = (flip ? -1.0 : 1.0) / len;
+    nrm[0] = (T)(v[0] * s);
+    nrm[1] = (T)(v[1] * s);
+    nrm[2] = (T)(v[2] * s);
 }
 
 // PointCloudImpl.h:1011-1063
@@ -295,7 +199,7 @@ __global__ void NormalsFromCovariancesKernel(const T* __restrict__ covariances,
 #pragma unroll
         for (int i = 0; i < 9; ++i) cov[i] = covariances[9 * w + i];
         T out[3] = {0, 0, 0};
-        FastEigen3x3<T>(cov, out);
+        SmallestEigenvectorSym3<T>(cov, out);
         if ((out[0] * out[0] + out[1] * out[1] + out[2] * out[2]) == 0.0 &&
             !has_normals) {
             out[0] = 0.0; out[1] = 0.0; out[2] = 1.0;
@@ -331,42 +235,8 @@ __device__ __forceinline__ void PinvSolveSym3(const T* AtA, const T* Atb,
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            a[i][j] = AtA[i * 3 + j];
-            V[i][j] = i == j ? T(1) : T(0);
-        }
-    for (int sweep = 0; sweep < 8; ++sweep) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int q = p + 1; q < 3; ++q) {
-                const T apq = a[p][q];
-                if (apq == T(0)) continue;
-                const T theta = (a[q][q] - a[p][p]) / (T(2) * apq);
-                const T t = (theta >= T(0) ? T(1) : T(-1)) /
-                            (Abs(theta) + Sqrt(theta * theta + T(1)));
-                const T c = T(1) / Sqrt(t * t + T(1));
-                const T sn = t * c;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const T akp = a[k][p], akq = a[k][q];
-                    a[k][p] = c * akp - sn * akq;
-                    a[k][q] = sn * akp + c * akq;
-                }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const T apk = a[p][k], aqk = a[q][k];
-                    a[p][k] = c * apk - sn * aqk;
-                    a[q][k] = sn * apk + c * aqk;
-                }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const T vkp = V[k][p], vkq = V[k][q];
-                    V[k][p] = c * vkp - sn * vkq;
-                    V[k][q] = sn * vkp + c * vkq;
-                }
-            }
-    }
+        for (int j = 0; j < 3; ++j) a[i][j] = AtA[i * 3 + j];
+    JacobiEigenSym3<T>(a, V);
     const T epsilon = (T)1e-10;
     x[0] = x[1] = x[2] = T(0);
 #pragma unroll
@@ -468,7 +338,7 @@ namespace {
 // Sorted neighbour lists of every point of a cloud within the index radius,
 // CSR: FixedRadiusSearch = count pass, prefix sum, write pass.
 struct CsrLists {
-    char* buf = nullptr;         // counts | splits | scan scratch
+    char* buf = nullptr;         // counts | splits | tile totals of the scan
     int64_t* splits = nullptr;   // [n + 1]
     int32_t* indices = nullptr;  // [total]
     void Free() {
@@ -485,11 +355,7 @@ int BuildRadiusLists(const o3dmi_nns_t* index, const void* points_dev,
     const size_t cnt_bytes = (sizeof(int32_t) * (size_t)n + 255) & ~(size_t)255;
     const size_t spl_bytes =
             (sizeof(int64_t) * (size_t)(n + 1) + 255) & ~(size_t)255;
-    size_t tmp_bytes = 0;
-    (void)hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes,
-                                           (int32_t*)nullptr,
-                                           (int64_t*)nullptr, (int)n, s);
-    tmp_bytes = (tmp_bytes + 255) & ~(size_t)255;
+    const size_t tmp_bytes = (ScanScratchBytes(n) + 255) & ~(size_t)255;
     int st = PoolAlloc((void**)&out->buf, cnt_bytes + spl_bytes + tmp_bytes);
     if (st) return st;
     int32_t* cnt = (int32_t*)out->buf;
@@ -498,10 +364,13 @@ int BuildRadiusLists(const o3dmi_nns_t* index, const void* points_dev,
     if ((st = o3dmi_nns_radius_count(index, points_dev, n, cnt, stream)))
         return st;
     int64_t total = 0;
-    if (hipMemsetAsync(out->splits, 0, sizeof(int64_t), s) != hipSuccess ||
-        hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, cnt, out->splits + 1,
-                                         (int)n, s) != hipSuccess ||
-        hipMemcpyAsync(&total, out->splits + n, sizeof(int64_t),
+    if (hipMemsetAsync(out->splits, 0, sizeof(int64_t), s) != hipSuccess) {
+        SetLastError("radius lists: memset failed");
+        return O3DMI_ERR_HIP;
+    }
+    if ((st = PrefixSumAsync(cnt, n, true, out->splits + 1, nullptr, tmp, s)))
+        return st;
+    if (hipMemcpyAsync(&total, out->splits + n, sizeof(int64_t),
                        hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) {
         SetLastError("radius lists: prefix sum failed");

@@ -18,7 +18,6 @@
 // HBM bound in principle (one pass over tsdf + weight of the active blocks,
 // 6 B / voxel, twice) with scattered neighbour reads at block faces.
 
-#include <hipcub/hipcub.hpp>
 
 #include "common.h"
 
@@ -340,35 +339,5 @@ extern "C" int o3dmi_vbg_extract_points(
     O3DMI_HIP_CHECK(e);
     O3DMI_HIP_CHECK(e2);
     *total_out = (int64_t)total;
-    return O3DMI_OK;
-}
-
-// Ascending sort of buffer indices (GetActiveIndices returns them in slot
-// compaction order, which differs from run to run).
-extern "C" int o3dmi_sort_indices(int32_t* indices_dev, int64_t n,
-                                  o3dmi_stream_t stream) {
-    O3DMI_REQUIRE(n >= 0 && n < (1ll << 31), "n out of range");
-    if (n <= 1) return O3DMI_OK;
-    O3DMI_REQUIRE(indices_dev != nullptr, "null argument");
-    hipStream_t s = (hipStream_t)stream;
-    size_t tmp_bytes = 0;
-    int32_t* sorted = nullptr;
-    O3DMI_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(
-            nullptr, tmp_bytes, indices_dev, sorted, (int)n, 0, 32, s));
-    char* scratch = nullptr;
-    const size_t key_bytes = (sizeof(int32_t) * (size_t)n + 255) & ~(size_t)255;
-    int st = PoolAlloc((void**)&scratch, key_bytes + tmp_bytes);
-    if (st) return st;
-    sorted = (int32_t*)scratch;
-    hipError_t e = hipcub::DeviceRadixSort::SortKeys(
-            scratch + key_bytes, tmp_bytes, indices_dev, sorted, (int)n, 0, 32,
-            s);
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(indices_dev, sorted, sizeof(int32_t) * (size_t)n,
-                           hipMemcpyDeviceToDevice, s);
-    hipError_t e2 = hipStreamSynchronize(s);
-    PoolFree(scratch);
-    O3DMI_HIP_CHECK(e);
-    O3DMI_HIP_CHECK(e2);
     return O3DMI_OK;
 }

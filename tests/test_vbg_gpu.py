@@ -887,3 +887,22 @@ def test_last_frame_block_coordinates_equal_a_second_block_touch():
         for name in ("depth", "normal", "color"):
             assert torch.equal(a[name], b[name]), name
         assert float((a["depth"] > 0).float().mean()) > 0.5
+
+
+def test_sort_indices_is_a_counting_sort():
+    """o3dmi_sort_indices (scan.hip): ascending order of buffer indices --
+    distinct ones, duplicates, a range of more than one scan tile."""
+    _lib, _ = _gpu()
+    from open3d_amd.core import stream
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    cases = [rng.permutation(300000)[:120000].astype(np.int32),
+             rng.integers(0, 50, 5000).astype(np.int32),
+             np.array([7, 3], np.int32), np.array([1 << 20, 0, 5, 5], np.int32),
+             rng.permutation(2_000_000)[:600000].astype(np.int32)]
+    for a in cases:
+        t = torch.from_numpy(a.copy()).cuda()
+        _lib.check(L.o3dmi_sort_indices(_lib.ptr(t), a.size, stream()), "sort")
+        assert np.array_equal(t.cpu().numpy(), np.sort(a))
+    bad = torch.tensor([3, -1, 2], dtype=torch.int32, device="cuda")
+    assert L.o3dmi_sort_indices(_lib.ptr(bad), 3, stream()) != 0
