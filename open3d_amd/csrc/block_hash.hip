@@ -242,39 +242,15 @@ int ClearImpl(o3dmi_hash* h, hipStream_t s) {
     return O3DMI_OK;
 }
 
-int CheckDeferred(o3dmi_hash* h, hipStream_t s, int* top_out) {
-    int host[2] = {0, 0};
-    O3DMI_HIP_CHECK(hipMemcpyAsync(host, h->view.counters, sizeof(host),
-                                   hipMemcpyDeviceToHost, s));
-    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
-    if (top_out) *top_out = host[0];
-    if (host[1] & kErrKeyRange) {
-        SetLastError("block coordinate outside +-2^20");
-        return O3DMI_ERR_KEY_RANGE;
-    }
-    if (host[1] & kErrCapacity) {
-        SetLastError("hash map capacity exceeded (caller must Reserve first)");
-        return O3DMI_ERR_CAPACITY;
-    }
-    if (host[1] & (kErrProbe | kErrTouchStamp)) {
-        SetLastError(host[1] & kErrProbe
-                             ? "hash map probe sequence wrapped (table full)"
-                             : "frame-stream touch word of another group");
-        return O3DMI_ERR_INTERNAL;
-    }
-    return O3DMI_OK;
-}
-
 // Erase leaves tombstones; inserts reuse the ones on their probe path, the
 // others stay. Once live + tombstone slots pass 3/4 of the table, the table is
 // rebuilt in place from the key buffer (live keys <= capacity <= half the
 // slots), so walks always end at an empty slot.
-int RebuildSlotsIfCrowded(o3dmi_hash* h, hipStream_t s) {
-    int host[3] = {0, 0, 0};
-    O3DMI_HIP_CHECK(hipMemcpyAsync(host, h->view.counters, sizeof(host),
-                                   hipMemcpyDeviceToHost, s));
-    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
-    if ((int64_t)host[2] * 4 < h->n_slots * 3) return O3DMI_OK;
+bool SlotsCrowded(const o3dmi_hash* h, int slots_taken) {
+    return (int64_t)slots_taken * 4 >= h->n_slots * 3;
+}
+
+int RebuildSlots(o3dmi_hash* h, hipStream_t s) {
     int* active = nullptr;
     O3DMI_HIP_CHECK(hipMalloc((void**)&active, sizeof(int) * h->capacity));
     O3DMI_HIP_CHECK(hipMemsetAsync(h->scratch_count, 0, sizeof(int), s));
@@ -301,6 +277,45 @@ int RebuildSlotsIfCrowded(o3dmi_hash* h, hipStream_t s) {
     (void)hipFree(active);
     return O3DMI_OK;
 }
+
+int RebuildSlotsIfCrowded(o3dmi_hash* h, hipStream_t s) {
+    int host[3] = {0, 0, 0};
+    O3DMI_HIP_CHECK(hipMemcpyAsync(host, h->view.counters, sizeof(host),
+                                   hipMemcpyDeviceToHost, s));
+    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    if (!SlotsCrowded(h, host[2])) return O3DMI_OK;
+    return RebuildSlots(h, s);
+}
+
+// Reads the deferred error flags (and the size). Inserts after an Erase take
+// empty slots whenever their probe path holds no tombstone, so live +
+// tombstone slots can pass the 3/4 mark without another Erase: every caller
+// that waits for the counters anyway (Size, and through it the frame stream's
+// capacity policy and Reserve) also rebuilds a crowded table here.
+int CheckDeferred(o3dmi_hash* h, hipStream_t s, int* top_out) {
+    int host[3] = {0, 0, 0};
+    O3DMI_HIP_CHECK(hipMemcpyAsync(host, h->view.counters, sizeof(host),
+                                   hipMemcpyDeviceToHost, s));
+    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    if (top_out) *top_out = host[0];
+    if (host[1] & kErrKeyRange) {
+        SetLastError("block coordinate outside +-2^20");
+        return O3DMI_ERR_KEY_RANGE;
+    }
+    if (host[1] & kErrCapacity) {
+        SetLastError("hash map capacity exceeded (caller must Reserve first)");
+        return O3DMI_ERR_CAPACITY;
+    }
+    if (host[1] & (kErrProbe | kErrTouchStamp)) {
+        SetLastError(host[1] & kErrProbe
+                             ? "hash map probe sequence wrapped (table full)"
+                             : "frame-stream touch word of another group");
+        return O3DMI_ERR_INTERNAL;
+    }
+    if (SlotsCrowded(h, host[2])) return RebuildSlots(h, s);
+    return O3DMI_OK;
+}
+
 
 }  // namespace
 }  // namespace o3dmi

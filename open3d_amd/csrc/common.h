@@ -246,13 +246,15 @@ __device__ __forceinline__ int ClaimSlot(const HashView& hv,
     constexpr unsigned kNone = 0xFFFFFFFFu;
     unsigned h = HashKey(k) & hv.mask;
     unsigned tomb = kNone;
-    // 2 x table size: a lost tombstone re-walks part of the sequence
-    for (unsigned long long step = 0; step <= 2ull * hv.mask + 1; ++step) {
+    unsigned walked = 0;  // slots seen since the walk (re)started
+    // 3 x table size: a lost target re-walks part of the sequence
+    for (unsigned long long step = 0; step <= 3ull * hv.mask + 2; ++step) {
         const unsigned long long cur = hv.slot_keys[h];
         if (cur == k) {
             slot_out = h;
             return 0;
         }
+        bool lost = false;
         if (cur == kTombKey) {
             if (tomb == kNone) tomb = h;
         } else if (cur == kEmptyKey) {
@@ -272,9 +274,26 @@ __device__ __forceinline__ int ClaimSlot(const HashView& hv,
             }
             // lost `target` to another key: go on behind it
             h = target;
-            tomb = kNone;
+            lost = true;
         }
         h = (h + 1) & hv.mask;
+        if (lost) {
+            tomb = kNone;
+            walked = 0;
+        } else if (++walked > hv.mask && tomb != kNone) {
+            // A whole cycle without an empty slot (a table crowded with
+            // tombstones): the key is absent, its place is the first
+            // tombstone of the sequence.
+            const unsigned long long old =
+                    atomicCAS(&hv.slot_keys[tomb], kTombKey, k);
+            if (old == kTombKey || old == k) {
+                slot_out = tomb;
+                return old == kTombKey ? 1 : 0;
+            }
+            h = (tomb + 1) & hv.mask;
+            tomb = kNone;
+            walked = 0;
+        }
     }
     atomicOr(&hv.counters[1], kErrProbe);
     return -1;

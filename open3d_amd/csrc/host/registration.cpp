@@ -220,20 +220,33 @@ struct ChainCounts {
     }
 };
 
-// One side stream per host thread for the overlapped pyramid build.
+// One side stream and event per host thread AND device for the overlapped
+// pyramid build (a thread may switch devices between calls: per-device pool,
+// VoxelBlockGrid::To(device)).
+constexpr int kMaxDevices = 64;
+int CurrentDevice() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return -1;
+    return d;
+}
 hipStream_t SideStream() {
-    static thread_local hipStream_t side = nullptr;
-    if (!side &&
-        hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess)
-        side = nullptr;
-    return side;
+    static thread_local hipStream_t side[kMaxDevices] = {};
+    const int d = CurrentDevice();
+    if (d < 0) return nullptr;
+    if (!side[d] &&
+        hipStreamCreateWithFlags(&side[d], hipStreamNonBlocking) != hipSuccess)
+        side[d] = nullptr;
+    return side[d];
 }
 
 hipEvent_t SideEvent() {
-    static thread_local hipEvent_t ev = nullptr;
-    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
-        ev = nullptr;
-    return ev;
+    static thread_local hipEvent_t ev[kMaxDevices] = {};
+    const int d = CurrentDevice();
+    if (d < 0) return nullptr;
+    if (!ev[d] &&
+        hipEventCreateWithFlags(&ev[d], hipEventDisableTiming) != hipSuccess)
+        ev[d] = nullptr;
+    return ev[d];
 }
 
 // `completed`: set by the owner once every kernel that used the index is

@@ -67,6 +67,33 @@ struct FrontShared {
     int touch_plane;
     int n_touch_wg, n_prep_wg;
 };
+// Field-by-field (the structs carry padding, so memcmp would compare
+// indeterminate bytes): everything the frames of a launch must agree on; the
+// pose (p.cam.e) travels per frame.
+inline bool SameIntrinsics(const Camera& a, const Camera& b) {
+    return a.fx == b.fx && a.fy == b.fy && a.cx == b.cx && a.cy == b.cy &&
+           a.scale == b.scale;
+}
+inline bool SameGroup(const FrontShared& a, const FrontShared& b) {
+    return SameIntrinsics(a.p.cam, b.p.cam) && a.p.rows == b.p.rows &&
+           a.p.cols == b.p.cols && a.p.stride == b.p.stride &&
+           a.p.rows_strided == b.p.rows_strided &&
+           a.p.cols_strided == b.p.cols_strided &&
+           a.p.block_size == b.p.block_size &&
+           a.p.sdf_trunc == b.p.sdf_trunc &&
+           a.p.depth_scale == b.p.depth_scale &&
+           a.p.depth_max == b.p.depth_max &&
+           SameIntrinsics(a.pp.color_cam, b.pp.color_cam) &&
+           a.pp.color_rows == b.pp.color_rows &&
+           a.pp.color_cols == b.pp.color_cols &&
+           a.pp.with_color == b.pp.with_color && a.col_lut == b.col_lut &&
+           a.row_lut == b.row_lut && a.depth_div_short == b.depth_div_short &&
+           a.prep_identity == b.prep_identity &&
+           a.inv_depth_scale == b.inv_depth_scale && a.list == b.list &&
+           a.list_capacity == b.list_capacity && a.out_count == b.out_count &&
+           a.group_stamp == b.group_stamp && a.touch_plane == b.touch_plane &&
+           a.n_touch_wg == b.n_touch_wg && a.n_prep_wg == b.n_prep_wg;
+}
 struct FrontFrame {
     float pose[3][4];  // inverse extrinsic (TouchParams::cam.e)
     const uint16_t* depth;
@@ -1287,11 +1314,7 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         } else {
             // the frames of a launch are one group: everything but the pose
             // and the image / record pointers is shared
-            const FrontShared& g0 = sp.fshared;
-            FrontShared a0 = g0, a1 = fs;
-            std::memset(a0.p.cam.e, 0, sizeof(a0.p.cam.e));
-            std::memset(a1.p.cam.e, 0, sizeof(a1.p.cam.e));
-            O3DMI_REQUIRE(std::memcmp(&a0, &a1, sizeof(FrontShared)) == 0,
+            O3DMI_REQUIRE(SameGroup(sp.fshared, fs),
                           "frames of one launch must share image size, "
                           "intrinsics, scales and their group");
         }
