@@ -12,15 +12,23 @@ uint16 weights stay far below their range (a voxel is seen by <= 183 frames of
 a pass).
 
 Multi-GPU (`--gpus N`; launched by torchrun, or self-spawned when WORLD_SIZE is
-unset): one process per GPU over RCCL. Frame sharding (default, weak scaling:
-rank r integrates frames r, r + N, ... of the stream into its own grid, no
-data-path collective) closes INSIDE the timed region with the exchange that
-turns N partial models into one: all-gather of the activated block IDs and of
-the blocks' voxel rows, folded in by the running-mean merge kernel
-(sharding.merge_frame_sharded_grid). `config.block_sharded` reports the other
-scheme beside it (strong scaling: every rank sees the whole stream and
-integrates only the blocks it owns; the union of the grids is bit-identical to
-one GPU's).
+unset): one process per GPU over RCCL, STRONG scaling in both schemes -- the
+job is the same stream (`--batch` frames per step in total) whatever N is.
+  blocks (headline): every rank sees every frame and runs the cheap block
+        touch, but activates / integrates only the blocks it owns; no
+        data-path collective; the union of the ranks' grids is bit-identical
+        to the single-GPU grid.
+  frames (`config.frame_sharded`, beside it): rank r integrates frames r,
+        r + N, ... of the same stream into a private grid; INSIDE the timed
+        region the owner-partitioned exchange (all-to-all of block IDs and
+        voxel rows to the owning rank, folded in by the running-mean merge
+        kernel: o3dmi_vbg_merge_frame_sharded, RCCL inside the library) turns
+        the N partial models into one, laid out as the blocks scheme leaves
+        it.
+`--dist-backend gloo` (or O3DMI_DIST_BACKEND) runs the same code with several
+ranks sharing whatever GPUs are visible (rank -> device rank % device_count):
+a functional dry run of the N > 1 path on a 1-GPU box, not a scaling number
+(`config.dry_run`).
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline      dominant kernel (FrameStepKernel): SURVEY 8(d) algorithmic
@@ -93,8 +101,17 @@ def parse():
                     help="bracket every n-th integrate launch with HIP events "
                          "(0 = none; the roofline is then not measured)")
     ap.add_argument("--sharding", choices=["frames", "blocks"],
-                    default="frames",
+                    default="blocks",
                     help="multi-GPU scheme of the headline value")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"],
+                    default=os.environ.get("O3DMI_DIST_BACKEND", "nccl"),
+                    help="torch.distributed backend; gloo = functional dry "
+                         "run with ranks sharing the visible GPUs")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="diagnostics, single process: run ONE rank's share "
+                         "of an N-rank job on this GPU (no collective) to "
+                         "read the per-rank cost of both schemes")
+    ap.add_argument("--emulate-rank", type=int, default=0)
     ap.add_argument("--depth-only", action="store_true",
                     help="diagnostics: grid without colour (tsdf + weight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -354,8 +371,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        n_dev = max(1, torch.cuda.device_count())
+        if a.dist_backend == "nccl":
+            assert world <= n_dev, \
+                "RCCL needs one GPU per rank (%d ranks, %d GPUs); use " \
+                "--dist-backend gloo for a dry run" % (world, n_dev)
+        torch.cuda.set_device(local_rank % n_dev)
+        dist.init_process_group(a.dist_backend, rank=rank, world_size=world)
         assert dist.get_world_size() == world
     else:
         torch.cuda.set_device(0)
@@ -370,7 +392,14 @@ def main():
     if dist is not None:
         dist.barrier()
     from open3d_amd import geometry, synthetic
-    from open3d_amd.sharding import merge_frame_sharded_grid
+    from open3d_amd.sharding import Comm
+    # the library's own collectives: RCCL inside the library when the job runs
+    # on it, torch.distributed calls (gloo) for the dry run
+    comm = Comm.for_backend(dist) if dist is not None else None
+    # share of the job this process does: (rank, world) of the real job, or
+    # of the emulated one
+    e_world = a.emulate_world if (world == 1 and a.emulate_world > 1) else world
+    e_rank = a.emulate_rank if e_world != world else rank
 
     K = synthetic.intrinsics(W, H)
 
@@ -447,7 +476,7 @@ def main():
         if merge:
             torch.cuda.synchronize()
             tm = time.perf_counter()
-            merge_frame_sharded_grid(g, dist)
+            g.merge_frame_sharded(comm)
             torch.cuda.synchronize()
             merge_ms = (time.perf_counter() - tm) * 1e3
         torch.cuda.synchronize()
@@ -455,27 +484,41 @@ def main():
         elapsed = time.perf_counter() - t0
         prof = g.profile_end()
         if dist is not None:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            tt = torch.tensor([elapsed], dtype=torch.float64,
+                              device="cpu" if a.dist_backend == "gloo" else dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         return elapsed, prof, merge_ms
 
-    by_blocks = a.sharding == "blocks" and world > 1
-    if by_blocks:
-        frame_ids = list(range(N_UNIQUE))
-    else:  # frame-sharded stream: rank r owns global frames r, r + world, ...
-        frame_ids = [rank + world * i for i in range(N_UNIQUE)]
-    depths, colors, Ts = render(frame_ids)
-    if a.depth_only:
-        colors = None
-    torch.cuda.synchronize()
+    # Both schemes do the SAME job: `a.batch` frames of the one stream per
+    # step. blocks: every rank walks all of them (touch + prepare) and
+    # integrates the blocks it owns. frames: rank r walks frames r, r + N, ...
+    # (a.batch / N per step) and the merge closes the timed region.
+    by_blocks = a.sharding == "blocks" and e_world > 1
 
-    g = make_grid((rank, world) if by_blocks else None)
-    elapsed, prof, merge_ms = timed_run(
-        g, depths, colors, Ts, a.steps, a.warmup,
-        merge=(dist is not None and not by_blocks))
+    def stream_for(blocks):
+        ids = list(range(N_UNIQUE)) if blocks or e_world == 1 else \
+            list(range(e_rank, N_UNIQUE, e_world))
+        d, c, t = render(ids)
+        return d, (None if a.depth_only else c), t
+
+    def run_scheme(blocks, steps, warmup):
+        depths, colors, Ts = stream_for(blocks)
+        torch.cuda.synchronize()
+        g = make_grid((e_rank, e_world) if blocks and e_world > 1 else None)
+        per_rank = a.batch if blocks or e_world == 1 else a.batch // e_world
+        saved, a.batch = a.batch, per_rank
+        try:
+            el, prof, mm = timed_run(g, depths, colors, Ts, steps, warmup,
+                                     merge=(dist is not None and not blocks))
+        finally:
+            a.batch = saved
+        return g, el, prof, mm, (depths, colors, Ts)
+
+    g, elapsed, prof, merge_ms, (depths, colors, Ts) = run_scheme(
+        by_blocks, a.steps, a.warmup)
     n_blocks = g.hashmap().size()
-    total_frames = a.steps * a.batch * (1 if by_blocks else world)
+    total_frames = a.steps * a.batch          # the job, whatever N is
     fps = total_frames / elapsed
 
     if a.pmc_inner:  # the run rocprofv3 wraps: nothing else to do
@@ -483,26 +526,16 @@ def main():
 
     # the other multi-GPU scheme beside the headline (short run)
     other = None
-    if dist is not None:
+    if e_world > 1:
         del g
         torch.cuda.empty_cache()
         o_blocks = not by_blocks
-        if o_blocks:
-            depths, colors, Ts = render(list(range(N_UNIQUE)))
-        else:
-            depths, colors, Ts = render(
-                [rank + world * i for i in range(N_UNIQUE)])
-        if a.depth_only:
-            colors = None
-        g2 = make_grid((rank, world) if o_blocks else None)
         st = max(2, a.steps // 5)
-        e2, _, m2 = timed_run(g2, depths, colors, Ts, st, 1,
-                              merge=not o_blocks)
-        f2 = st * a.batch * (1 if o_blocks else world)
+        g2, e2, _, m2, _ = run_scheme(o_blocks, st, 1)
         other = {"sharding": "blocks" if o_blocks else "frames",
-                 "scaling": "strong" if o_blocks else "weak",
-                 "frames_per_s": f2 / e2, "steps": st,
-                 "ms_per_step": e2 / st * 1e3, "merge_ms": m2}
+                 "scaling": "strong", "frames_per_s": st * a.batch / e2,
+                 "steps": st, "ms_per_step": e2 / st * 1e3, "merge_ms": m2,
+                 "active_blocks_this_rank": int(g2.hashmap().size())}
         del g2
 
     # ---- roofline of the dominant kernel over the bracketed launches --------
@@ -552,7 +585,7 @@ def main():
                     ", so it sits a few percent above rocprofv3's kernel "
                     "duration and above `wall_ms_per_launch` (timed region / "
                     "launches, the GPU being saturated)."}
-    if world == 1 and rank == 0 and not a.no_pmc:
+    if e_world == 1 and rank == 0 and not a.no_pmc:
         pmc, why = pmc_live()
         src = "live rocprofv3 passes (this run)"
         if pmc is None:
@@ -590,7 +623,7 @@ def main():
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "strong" if by_blocks else "weak", "vs_baseline": None,
+        "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "configs[1]: the 1000-frame synthetic 640x480 "
                                "RGB-D stream (looped, %d frames per GPU in the "
@@ -605,24 +638,31 @@ def main():
                    "active_blocks": int(n_blocks),
                    "avg_blocks_per_frame": prof["block_frames"] /
                                            max(1, prof["frames"]),
-                   "sharding": ("none" if world == 1 else
+                   "sharding": ("none" if e_world == 1 else
                                 "one stream, blocks split by ownership "
-                                "(no data-path collective)" if by_blocks
-                                else "frames r, r+N, ... per rank; closing "
-                                     "exchange inside the timed region: all-"
-                                     "gather of block IDs + voxel rows, "
-                                     "merged into one model on every rank"),
+                                "(no data-path collective; union of the "
+                                "grids bit-identical to one GPU's)"
+                                if by_blocks
+                                else "frames r, r+N, ... of the one stream "
+                                     "per rank; closing exchange inside the "
+                                     "timed region: all-to-all of block IDs "
+                                     "+ voxel rows to the owning rank, "
+                                     "folded in there"),
                    "merge_ms": merge_ms,
+                   "dist_backend": a.dist_backend if world > 1 else None,
+                   "dry_run": (world > 1 and a.dist_backend == "gloo") or None,
+                   "emulated_rank_of_world": [e_rank, e_world]
+                   if e_world != world else None,
                    "block_sharded" if not by_blocks else "frame_sharded":
                        other},
         "roofline": roof,
     }
-    if world == 1 and not a.no_secondary:
+    if e_world == 1 and not a.no_secondary:
         try:
             out["secondary"] = secondary_legs()
         except Exception as e:
             out["secondary"] = {"error": str(e)[:300]}
-    if world == 1 and not a.no_cpu_baseline:
+    if e_world == 1 and not a.no_cpu_baseline:
         nb = 64
         frames_cpu = [(depths[i].cpu().numpy(), colors[i].cpu().numpy())
                       for i in range(min(nb, len(depths)))]
@@ -630,6 +670,8 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
+        torch.cuda.synchronize()
+        comm.destroy()
         dist.destroy_process_group()
 
 

@@ -23,14 +23,32 @@
 //         -Lopen3d_amd/lib -lo3d_mi355x -Wl,-rpath,'$ORIGIN/../open3d_amd/lib' \
 //         -o examples/icp_slam
 //   examples/icp_slam [frames=60] [width=640] [height=480] [touch_again=0]
+//                     [ranks=1] [transport=rccl|loopback]
+//
+// ranks > 1 (BASELINE configs[3], the tracking half): one host thread per
+// rank, rank r on device r % device_count, every rank the same loop on the
+// same frames with a replicated model (the ray cast needs every block); what
+// is sharded is the Gauss-Newton work of MultiScaleICP -- o3dmi_set_comm +
+// o3dmi_set_icp_level_sharding(1): each rank searches / accumulates its slice
+// of every pyramid level and the 32 float64 sums are all-reduced inside the
+// iteration by the library itself (ncclAllReduce on the launch stream over
+// xGMI; no Python anywhere). `loopback` swaps RCCL for an in-process
+// transport (host threads meeting at a barrier), which also runs when the
+// ranks share one GPU -- RCCL refuses that -- and is how the mode is
+// exercised on a single-GPU box. Every rank must end with the same poses.
 
 #include <hip/hip_runtime_api.h>
 
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "analytic_room.h"
@@ -91,9 +109,136 @@ void InvertRigid(const double* T, double* out) {
     for (int i = 0; i < 16; ++i) out[i] = r[i];
 }
 
+// ---- in-process transport for the loopback mode -------------------------------
+struct Loopback {
+    int world;
+    std::mutex mu;
+    std::condition_variable cv;
+    int waiting = 0;
+    long generation = 0;
+    std::vector<double> rows;  // [world][32]
+    explicit Loopback(int w) : world(w), rows((size_t)w * 32, 0.0) {}
+    void Barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const long g = generation;
+        if (++waiting == world) {
+            waiting = 0;
+            ++generation;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return generation != g; });
+        }
+    }
+};
+struct LoopbackRank {
+    Loopback* shared;
+    int rank;
+};
+// o3dmi_transport_t::allreduce_sum_f64: the stream is drained, the rows meet
+// on the host, every rank adds them in rank order (identical sums everywhere)
+int LoopbackAllreduce(void* user, double* dev, int64_t n, o3dmi_stream_t s) {
+    auto* me = (LoopbackRank*)user;
+    Loopback* lb = me->shared;
+    if (n > 32) return 1;
+    if (hipStreamSynchronize((hipStream_t)s) != hipSuccess) return 1;
+    if (hipMemcpy(&lb->rows[(size_t)me->rank * 32], dev, sizeof(double) * n,
+                  hipMemcpyDeviceToHost) != hipSuccess)
+        return 1;
+    lb->Barrier();
+    double sum[32] = {0};
+    for (int r = 0; r < lb->world; ++r)
+        for (int64_t i = 0; i < n; ++i) sum[i] += lb->rows[(size_t)r * 32 + i];
+    lb->Barrier();  // everybody has read the rows
+    return hipMemcpy(dev, sum, sizeof(double) * n, hipMemcpyHostToDevice) ==
+                           hipSuccess
+                   ? 0
+                   : 1;
+}
+
+struct RankResult {
+    double seconds = 0, worst_translation = 0, worst_angle = 0;
+    double phase[4] = {0, 0, 0, 0};
+    long iterations = 0;
+    std::vector<double> poses;  // 16 per tracked frame
+};
+
+int RunRank(int argc, char** argv, int rank, int world, o3dmi_comm_t* comm,
+            RankResult* out);
+
 }  // namespace
 
 int main(int argc, char** argv) {
+    const int world = argc > 5 ? std::atoi(argv[5]) : 1;
+    const std::string transport = argc > 6 ? argv[6] : "rccl";
+    if (world <= 1) {
+        RankResult r;
+        return RunRank(argc, argv, 0, 1, nullptr, &r);
+    }
+    int n_dev = 1;
+    CHECK_HIP(hipGetDeviceCount(&n_dev));
+    std::vector<RankResult> res((size_t)world);
+    std::vector<int> rc((size_t)world, 0);
+    std::vector<std::thread> threads;
+    Loopback lb(world);
+    char ident[128] = {0};
+    if (transport == "rccl") {
+        if (world > n_dev) {
+            std::fprintf(stderr, "icp_slam: RCCL needs one GPU per rank (%d "
+                                 "ranks, %d GPUs); use the loopback "
+                                 "transport\n", world, n_dev);
+            return 2;
+        }
+        CHECK_O3D(o3dmi_rccl_unique_id(ident));
+    }
+    std::vector<LoopbackRank> lranks((size_t)world);
+    for (int r = 0; r < world; ++r) {
+        lranks[(size_t)r] = {&lb, r};
+        threads.emplace_back([&, r] {
+            CHECK_HIP(hipSetDevice(r % n_dev));
+            o3dmi_comm_t* comm = nullptr;
+            if (transport == "rccl") {
+                CHECK_O3D(o3dmi_comm_create_rccl(ident, r, world, &comm));
+            } else {
+                o3dmi_transport_t table = {};
+                table.allreduce_sum_f64 = LoopbackAllreduce;
+                CHECK_O3D(o3dmi_comm_create_custom(&table, &lranks[(size_t)r],
+                                                   r, world, &comm));
+            }
+            CHECK_O3D(o3dmi_set_comm(comm));
+            CHECK_O3D(o3dmi_set_icp_level_sharding(1));
+            rc[(size_t)r] = RunRank(argc, argv, r, world, comm,
+                                    &res[(size_t)r]);
+            CHECK_O3D(o3dmi_set_comm(nullptr));
+            CHECK_O3D(o3dmi_comm_destroy(comm));
+        });
+    }
+    for (auto& t : threads) t.join();
+    bool same = true;
+    for (int r = 1; r < world; ++r)
+        same = same && res[(size_t)r].poses == res[0].poses;
+    int worst = 0;
+    for (int r = 0; r < world; ++r) worst = rc[(size_t)r] ? rc[(size_t)r] : worst;
+    std::printf("{\"example\": \"icp_slam.cpp\", \"ranks\": %d, "
+                "\"transport\": \"%s\", \"devices\": %d, "
+                "\"frames_per_s\": %.1f, \"icp_iterations_per_frame\": "
+                "%.2f, \"poses_identical_on_all_ranks\": %s, "
+                "\"max_translation_error_m\": %.3g, "
+                "\"max_rotation_error_rad\": %.3g}\n",
+                world, transport.c_str(), n_dev,
+                (double)(res[0].poses.size() / 16) / res[0].seconds,
+                (double)res[0].iterations /
+                        (double)(res[0].poses.size() / 16),
+                same ? "true" : "false", res[0].worst_translation,
+                res[0].worst_angle);
+    if (!same) std::fprintf(stderr, "icp_slam: ranks disagree on the poses\n");
+    return worst ? worst : (same ? 0 : 1);
+}
+
+namespace {
+
+int RunRank(int argc, char** argv, int rank, int world, o3dmi_comm_t* comm,
+            RankResult* out) {
+    (void)comm;
     const int n_frames = argc > 1 ? std::atoi(argv[1]) : 60;
     Camera cam;
     cam.width = argc > 2 ? std::atoi(argv[2]) : 640;
@@ -230,6 +375,7 @@ int main(int argc, char** argv) {
         double rinv[16];
         InvertRigid(r.transformation, rinv);
         Matmul4(X, rinv, X);
+        out->poses.insert(out->poses.end(), X, X + 16);
         // ---- integrate at the estimated pose -------------------------------
         CHECK_O3D(o3dmi_vbg_integrate_frame(
                 grid, depth_dev[(size_t)k], H, W, color_dev[(size_t)k], H, W,
@@ -262,6 +408,11 @@ int main(int argc, char** argv) {
     const double seconds =
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0)
                     .count();
+    out->seconds = seconds;
+    out->worst_translation = worst_translation;
+    out->worst_angle = worst_angle;
+    out->iterations = iterations;
+    if (world == 1)
     std::printf(
             "{\"example\": \"icp_slam.cpp\", \"frames\": %d, \"width\": %d, "
             "\"height\": %d, \"frames_per_s\": %.1f, \"ms_per_frame\": %.4f, "
@@ -295,6 +446,9 @@ int main(int argc, char** argv) {
     }
     (void)hipStreamDestroy(stream);
     const bool ok = worst_translation < 0.08 && worst_angle < 0.01745;
-    if (!ok) std::fprintf(stderr, "icp_slam: self-check FAILED\n");
+    if (!ok)
+        std::fprintf(stderr, "icp_slam: self-check FAILED (rank %d)\n", rank);
     return ok ? 0 : 1;
 }
+
+}  // namespace

@@ -74,6 +74,76 @@ typedef int (*o3dmi_allreduce_device_t)(double* dev_buf, int n,
                                         o3dmi_stream_t stream, void* user);
 int o3dmi_set_device_allreduce(o3dmi_allreduce_device_t fn, void* user);
 
+/* ---- Collectives owned by the library (multi-GPU) -------
+ * One process (or host thread) per GPU. An o3dmi_comm_t carries the three
+ * exchanges the sharded hot path needs -- sum all-reduce of float64 (the ICP
+ * sums), all-gather of fixed-size records and all-to-all of byte ranges (block
+ * IDs and voxel rows to their owners) -- all enqueued on the caller's stream.
+ * Transports:
+ *   RCCL    librccl.so resolved with dlopen at first use (the instance the
+ *           process already holds, e.g. PyTorch's, else the system one;
+ *           O3DMI_RCCL_LIB overrides): ncclAllReduce / ncclAllGather / grouped
+ *           ncclSend + ncclRecv over xGMI. o3dmi_rccl_unique_id +
+ *           o3dmi_comm_create_rccl wrap ncclGetUniqueId / ncclCommInitRank on
+ *           the current device (the 128-byte id travels by the caller's own
+ *           means: MPI, a file, torch.distributed); o3dmi_comm_adopt_rccl
+ *           wraps an existing ncclComm_t (not destroyed with the wrapper).
+ *   custom  a table of functions (tests over gloo; other runtimes). Each
+ *           entry enqueues (or completes) the exchange for the given stream
+ *           and returns 0.
+ * o3dmi_set_comm(c) makes c the communicator of the calling host thread: the
+ * registration drivers (every estimator) then sum their per-iteration values
+ * through it ON THE DEVICE, between the final reduction kernel and the kernel that
+ * posts them to the host mailbox (takes precedence over both hooks below;
+ * NULL restores them). o3dmi_set_rccl_comm(ncclComm) = adopt + set in one
+ * call (NULL clears). The reference has no counterpart. */
+typedef struct o3dmi_comm o3dmi_comm_t;
+typedef struct {
+    int (*allreduce_sum_f64)(void* user, double* dev_buf, int64_t n,
+                             o3dmi_stream_t stream);
+    int (*allgather)(void* user, const void* send_dev, void* recv_dev,
+                     int64_t bytes_per_rank, o3dmi_stream_t stream);
+    int (*alltoallv)(void* user, const void* send_dev,
+                     const int64_t* send_bytes, const int64_t* send_offsets,
+                     void* recv_dev, const int64_t* recv_bytes,
+                     const int64_t* recv_offsets, o3dmi_stream_t stream);
+} o3dmi_transport_t;
+int o3dmi_rccl_available(void);
+int o3dmi_rccl_unique_id(void* id128 /* 128 bytes */);
+int o3dmi_comm_create_rccl(const void* id128, int rank, int world,
+                           o3dmi_comm_t** out);
+int o3dmi_comm_adopt_rccl(void* nccl_comm, o3dmi_comm_t** out);
+int o3dmi_comm_create_custom(const o3dmi_transport_t* table, void* user,
+                             int rank, int world, o3dmi_comm_t** out);
+int o3dmi_comm_destroy(o3dmi_comm_t* c);
+int o3dmi_comm_rank(const o3dmi_comm_t* c);
+int o3dmi_comm_world(const o3dmi_comm_t* c);
+int o3dmi_set_comm(o3dmi_comm_t* c);
+int o3dmi_set_rccl_comm(void* nccl_comm);
+/* Who shards the source cloud of an ICP call made with a communicator
+ * installed (thread-local, default 0):
+ *   0  the caller: each rank passes ITS shard of the source (the semantics of
+ *      the two hooks). A voxel pyramid is then built per shard, i.e. the
+ *      coarse levels differ from the unsharded run's.
+ *   1  the driver: every rank passes the WHOLE source; the pyramid is built
+ *      from it on every rank (it IS the unsharded pyramid), and each rank
+ *      searches and accumulates a contiguous slice of every level. The poses
+ *      equal the unsharded run's to the rounding of the float64 sums for any
+ *      number of scales. correspondences_dev: a rank fills its slice of the
+ *      finest level's rows, the other rows read -1. */
+int o3dmi_set_icp_level_sharding(int on);
+/* The exchanges themselves (what the drivers call). Counts / offsets of the
+ * all-to-all are host arrays of `world` entries, in bytes. */
+int o3dmi_comm_allreduce_sum_f64(o3dmi_comm_t* c, double* dev_buf, int64_t n,
+                                 o3dmi_stream_t stream);
+int o3dmi_comm_allgather(o3dmi_comm_t* c, const void* send_dev, void* recv_dev,
+                         int64_t bytes_per_rank, o3dmi_stream_t stream);
+int o3dmi_comm_alltoallv(o3dmi_comm_t* c, const void* send_dev,
+                         const int64_t* send_bytes,
+                         const int64_t* send_offsets, void* recv_dev,
+                         const int64_t* recv_bytes,
+                         const int64_t* recv_offsets, o3dmi_stream_t stream);
+
 /* MultiScaleICP with TransformationEstimationPointToPlane(kernel).
  * source/target/normals: device, {N,3}, dtype O3DMI_F32 or O3DMI_F64.
  * voxel_sizes[i] <= 0 means "no down-sampling" for the finest level, as in
@@ -548,6 +618,24 @@ int o3dmi_vbg_export_blocks(o3dmi_vbg_t* g, int64_t capacity,
 int o3dmi_vbg_merge_blocks(o3dmi_vbg_t* g, const int32_t* keys_dev,
                            const void* const* values_dev, int64_t n,
                            o3dmi_stream_t stream);
+
+/* The payload exchange of the frame-sharded scheme,
+ * owner-partitioned: every active block of this rank's private grid travels
+ * to the rank that OWNS it (the fixed key hash of the block-ownership scheme,
+ * o3dmi_hash_set_ownership) with one all-to-all per tensor -- keys, then each
+ * attribute's rows -- and the owner folds the partial blocks of all ranks in
+ * (o3dmi_vbg_merge_blocks, own partial first, then ascending source rank).
+ * Blocks sent away are erased and their value rows zeroed, so afterwards the
+ * ranks hold DISJOINT grids whose union is the model of the whole stream: the
+ * same layout block-ownership sharding produces. A rank moves (world - 1) /
+ * world of its blocks once (an all-gather of everything would move world x
+ * as much to every rank). Collective: every rank of `comm` must call it.
+ * o3dmi_vbg_allgather_owned_blocks then replicates the finished blocks on
+ * every rank (when each GPU is to ray-cast the whole model). */
+int o3dmi_vbg_merge_frame_sharded(o3dmi_vbg_t* g, o3dmi_comm_t* comm,
+                                  o3dmi_stream_t stream);
+int o3dmi_vbg_allgather_owned_blocks(o3dmi_vbg_t* g, o3dmi_comm_t* comm,
+                                     o3dmi_stream_t stream);
 
 /* Introspection of a grid (needed after Load): attribute count / i-th name,
  * voxel size, block resolution. */

@@ -284,7 +284,39 @@ PROTOTYPES.update({
     "o3dmi_vbg_ray_cast": (
         _i32, [_vp, _vp, _i64, _dp, _dp, _i32, _i32, _vp] + [_vp] * 10 +
         [_f, _f, _f, _f, _f, _i32, _vp]),
+    "o3dmi_rccl_available": (_i32, []),
+    "o3dmi_rccl_unique_id": (_i32, [_vp]),
+    "o3dmi_comm_create_rccl": (_i32, [_vp, _i32, _i32, C.POINTER(_vp)]),
+    "o3dmi_comm_adopt_rccl": (_i32, [_vp, C.POINTER(_vp)]),
+    "o3dmi_comm_create_custom": (_i32, [_vp, _vp, _i32, _i32,
+                                        C.POINTER(_vp)]),
+    "o3dmi_comm_destroy": (_i32, [_vp]),
+    "o3dmi_comm_rank": (_i32, [_vp]),
+    "o3dmi_comm_world": (_i32, [_vp]),
+    "o3dmi_set_comm": (_i32, [_vp]),
+    "o3dmi_set_rccl_comm": (_i32, [_vp]),
+    "o3dmi_set_icp_level_sharding": (_i32, [_i32]),
+    "o3dmi_comm_allreduce_sum_f64": (_i32, [_vp, _vp, _i64, _vp]),
+    "o3dmi_comm_allgather": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "o3dmi_comm_alltoallv": (_i32, [_vp, _vp, C.POINTER(_i64),
+                                    C.POINTER(_i64), _vp, C.POINTER(_i64),
+                                    C.POINTER(_i64), _vp]),
+    "o3dmi_vbg_merge_frame_sharded": (_i32, [_vp, _vp, _vp]),
+    "o3dmi_vbg_allgather_owned_blocks": (_i32, [_vp, _vp, _vp]),
 })
+
+# o3dmi_transport_t (include/o3d_mi355x_host.h): the caller-provided collectives
+TRANSPORT_ALLREDUCE = C.CFUNCTYPE(_i32, _vp, _vp, _i64, _vp)
+TRANSPORT_ALLGATHER = C.CFUNCTYPE(_i32, _vp, _vp, _vp, _i64, _vp)
+TRANSPORT_ALLTOALLV = C.CFUNCTYPE(_i32, _vp, _vp, C.POINTER(_i64),
+                                  C.POINTER(_i64), _vp, C.POINTER(_i64),
+                                  C.POINTER(_i64), _vp)
+
+
+class TransportC(C.Structure):
+    _fields_ = [("allreduce_sum_f64", TRANSPORT_ALLREDUCE),
+                ("allgather", TRANSPORT_ALLGATHER),
+                ("alltoallv", TRANSPORT_ALLTOALLV)]
 
 _lib = None
 

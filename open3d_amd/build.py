@@ -44,7 +44,8 @@ def sources():
 
 
 def headers():
-    out = [os.path.join(ROOT, "include", "o3d_mi355x.h")]
+    out = [os.path.join(ROOT, "include", "o3d_mi355x.h"),
+           os.path.join(ROOT, "include", "o3d_mi355x_host.h")]
     for dirpath, _, files in os.walk(CSRC):
         for f in files:
             if f.endswith(".h"):

@@ -42,6 +42,7 @@
 
 #include "../common.h"
 #include "../mailbox.h"
+#include "../collectives.h"
 #include "../vds.h"
 #include "o3d_mi355x_host.h"
 
@@ -100,6 +101,19 @@ extern "C" int o3dmi_set_device_allreduce(o3dmi_allreduce_device_t fn,
                                           void* user) {
     g_dev_allreduce = fn;
     g_dev_allreduce_user = user;
+    return O3DMI_OK;
+}
+
+// With a communicator installed (o3dmi_set_comm): who shards the source cloud.
+// 0: the caller -- it passes ITS shard (the semantics of the two hooks);
+// 1: the driver -- every rank passes the WHOLE source, the pyramid is built
+//    from it on every rank (so it is the unsharded run's pyramid, level for
+//    level), and each rank searches / accumulates its contiguous slice of
+//    every level.
+static thread_local int g_level_sharding = 0;
+
+extern "C" int o3dmi_set_icp_level_sharding(int on) {
+    g_level_sharding = on ? 1 : 0;
     return O3DMI_OK;
 }
 
@@ -621,19 +635,27 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
     //                on the launch stream (RCCL) -> post kernel -> mailbox:
     //                one host wait per iteration, nothing staged by the host
     //   host hook    as "no hook", then allreduce(host buffer)
+    //   communicator (o3dmi_set_comm / o3dmi_set_rccl_comm): the device-hook
+    //                route with the library's own collective (ncclAllReduce
+    //                on the launch stream) in the hook's place
+    o3dmi_comm* comm = ThreadComm();
+    if (comm && comm->world <= 1) comm = nullptr;
+    const bool dev_reduce = comm != nullptr || g_dev_allreduce != nullptr;
     DeviceBuffer dev_sums;
-    if (g_dev_allreduce && (st = dev_sums.Alloc(32 * sizeof(double))))
-        return st;
+    if (dev_reduce && (st = dev_sums.Alloc(32 * sizeof(double)))) return st;
     auto fetch_sums = [&](auto&& launch, double* out32, double t29, double t30,
                           double t31) -> int {
         const int seq = ++mb->seq;
-        if (g_dev_allreduce) {
+        if (dev_reduce) {
             double* d = (double*)dev_sums.p;
             int e = launch(d, (double*)nullptr, (int*)nullptr, 0);
             if (e) return e;
             if ((e = o3dmi_internal_sums_tail(d, t29, t30, t31, stream)))
                 return e;
-            if (g_dev_allreduce(d, 32, stream, g_dev_allreduce_user) != 0) {
+            if (comm) {
+                if ((e = comm->AllreduceSumF64(d, 32, s))) return e;
+            } else if (g_dev_allreduce(d, 32, stream, g_dev_allreduce_user) !=
+                       0) {
                 SetLastError("device all-reduce hook failed");
                 return O3DMI_ERR_INVALID_ARG;
             }
@@ -674,7 +696,32 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
     // search launch itself, in place, before it searches.
     double pending[16];
     bool has_pending = false;
-    auto search = [&](o3dmi_nns_t* nns, const Level& L, int64_t* corr_out,
+    // What this rank works on at a scale: the level's source cloud, or (level
+    // sharding) its slice [first, first + ns) of it.
+    struct SourceView {
+        void* src = nullptr;
+        void* srcn = nullptr;
+        void* srcc = nullptr;
+        int64_t ns = 0, first = 0;
+    };
+    const bool level_sharding = comm != nullptr && g_level_sharding != 0;
+    auto view_of = [&](const Level& L) {
+        SourceView v;
+        int64_t b = 0, e = L.ns;
+        if (level_sharding) {
+            const int64_t base = L.ns / comm->world, rem = L.ns % comm->world;
+            b = comm->rank * base + (comm->rank < rem ? comm->rank : rem);
+            e = b + base + (comm->rank < rem ? 1 : 0);
+        }
+        const size_t off = (size_t)b * 3 * esz;
+        v.src = (char*)L.src.p + off;
+        v.srcn = L.srcn.p ? (char*)L.srcn.p + off : nullptr;
+        v.srcc = L.srcc.p ? (char*)L.srcc.p + off : nullptr;
+        v.ns = e - b;
+        v.first = b;
+        return v;
+    };
+    auto search = [&](o3dmi_nns_t* nns, const SourceView& L, int64_t* corr_out,
                       SearchResult& r) -> int {
         const double* xf = has_pending ? pending : nullptr;
         has_pending = false;
@@ -682,7 +729,7 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                 [&](double* sums_dev, double* mail_data, int* mail_flag,
                     int seq) {
                     return o3dmi_internal_icp_transform_search_accumulate(
-                            nns, L.src.p, xf, nullptr, L.ns, search_mode,
+                            nns, L.src, xf, nullptr, L.ns, search_mode,
                             robust_kernel, scaling_parameter, shape_parameter,
                             corr_out, sums_dev, mail_data, mail_flag, seq,
                             stream);
@@ -703,14 +750,27 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
     };
 
     for (int scale_idx = 0; scale_idx < num_scales; ++scale_idx) {
-        Level& L = pyr[(size_t)scale_idx];
+        Level& full_level = pyr[(size_t)scale_idx];
+        struct ScaleView : SourceView {
+            const void* tgt_ptr;
+            const void* nrm_ptr;
+            const void* tgtc_ptr;
+            const void* tgtg_ptr;
+            int64_t nt;
+        } L;
+        static_cast<SourceView&>(L) = view_of(full_level);
+        L.tgt_ptr = full_level.tgt_ptr;
+        L.nrm_ptr = full_level.nrm_ptr;
+        L.tgtc_ptr = full_level.tgtc_ptr;
+        L.tgtg_ptr = full_level.tgtg_ptr;
+        L.nt = full_level.nt;
         last_ns = L.ns;
         // source_down_pyramid[scale].Transform(result.transformation_) :404
         // (positions and, when the estimator reads them, normals)
         std::memcpy(pending, T, sizeof(pending));
         has_pending = true;
         if (symmetric &&
-            (st = o3dmi_transform_normals(T, L.srcn.p, L.ns, dtype, stream)))
+            (st = o3dmi_transform_normals(T, L.srcn, L.ns, dtype, stream)))
             return st;
         DeviceBuffer corr_buf, sym_partials;
         if (symmetric || colored) {
@@ -786,7 +846,7 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                         [&](double* sums_dev, double* mail_data,
                             int* mail_flag, int seq) {
                             return o3dmi_icp_symmetric_accumulate_post(
-                                    L.src.p, L.srcn.p, L.tgt_ptr, L.nrm_ptr,
+                                    L.src, L.srcn, L.tgt_ptr, L.nrm_ptr,
                                     (const int64_t*)corr_buf.p, L.ns, dtype,
                                     ms, mt, robust_kernel, scaling_parameter,
                                     shape_parameter, sums_dev,
@@ -809,7 +869,7 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                         [&](double* sums_dev, double* mail_data,
                             int* mail_flag, int seq) {
                             return o3dmi_icp_colored_accumulate_post(
-                                    L.src.p, L.srcc.p, L.tgt_ptr, L.nrm_ptr,
+                                    L.src, L.srcc, L.tgt_ptr, L.nrm_ptr,
                                     L.tgtc_ptr, L.tgtg_ptr,
                                     (const int64_t*)corr_buf.p, L.ns, dtype,
                                     lambda_geometric, robust_kernel,
@@ -844,7 +904,7 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
             std::memcpy(pending, update, sizeof(pending));
             has_pending = true;
             if (symmetric && (st = o3dmi_transform_normals(
-                                      update, L.srcn.p, L.ns, dtype, stream)))
+                                      update, L.srcn, L.ns, dtype, stream)))
                 return st;
             if (callback)
                 callback(iteration_count + it, scale_idx, it, inlier_rmse,
@@ -874,7 +934,19 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
             // Final fitness / rmse for the stored transformation :424-431
             bool preserved = converged;
             SearchResult r;
-            if ((st = search(guard.nns, L, correspondences_dev, r))) return st;
+            // level sharding: this rank fills its rows of the level's
+            // correspondence set, the others read -1 here
+            if (level_sharding && correspondences_dev)
+                O3DMI_HIP_CHECK(hipMemsetAsync(
+                        correspondences_dev, 0xFF,
+                        sizeof(int64_t) * (size_t)full_level.ns, s));
+            if (level_sharding) last_ns = full_level.ns;
+            if ((st = search(guard.nns, L,
+                             correspondences_dev
+                                     ? correspondences_dev + L.first
+                                     : nullptr,
+                             r)))
+                return st;
             fitness = r.fitness;
             inlier_rmse = r.inlier_rmse;
             if (r.sums[30] == 0) Eye4(T);

@@ -21,6 +21,7 @@
 #include "../common.h"
 #include "../npz.h"
 #include "../stream_path.h"
+#include "../collectives.h"
 #include "o3d_mi355x_host.h"
 
 using namespace o3dmi;
@@ -269,6 +270,51 @@ __global__ void MergeBlocksKernel(const int32_t* __restrict__ indices,
             weight[d] = (W)(wsum < 65535.0f ? wsum : 65535.0f);
         else
             weight[d] = (W)wsum;
+    }
+}
+
+// ---- owner-partitioned exchange of a frame-sharded grid -----------------------
+constexpr int kMaxWorld = 64;
+struct OwnerOffsets {
+    int v[kMaxWorld];
+};
+
+// owner of every active block + blocks per owner
+__global__ void OwnerCountKernel(const int32_t* __restrict__ active, int64_t n,
+                                 const int* __restrict__ key_buffer, int world,
+                                 int32_t* __restrict__ owner,
+                                 int* __restrict__ counts) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int* k = key_buffer + 3 * (int64_t)active[i];
+        const int o = OwnerOf(PackKey(k[0], k[1], k[2]), world);
+        owner[i] = o;
+        atomicAdd(&counts[o], 1);
+    }
+}
+
+// buffer indices grouped by owner (order inside a group: as the atomics fall;
+// nothing downstream depends on it -- rows are matched by key)
+__global__ void OwnerGroupKernel(const int32_t* __restrict__ active, int64_t n,
+                                 const int32_t* __restrict__ owner,
+                                 OwnerOffsets offsets, int* __restrict__ cursor,
+                                 int32_t* __restrict__ grouped) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int o = owner[i];
+        grouped[offsets.v[o] + atomicAdd(&cursor[o], 1)] = active[i];
+    }
+}
+
+// value rows of erased blocks back to the all-zero state a fresh buffer has
+// (Activate never touches values: HashBackendBuffer.cpp:16-78)
+__global__ void ZeroRowsKernel(uint8_t* __restrict__ rows,
+                               const int32_t* __restrict__ indices, int64_t n,
+                               int64_t row_units) {
+    for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
+        uint4* d = (uint4*)rows + (int64_t)indices[r] * row_units;
+        for (int64_t i = threadIdx.x; i < row_units; i += blockDim.x)
+            d[i] = make_uint4(0, 0, 0, 0);
     }
 }
 
@@ -1181,6 +1227,272 @@ int o3dmi_vbg_extract_point_cloud(o3dmi_vbg_t* g, float weight_threshold,
     (void)hipStreamSynchronize((hipStream_t)stream);
     PoolFree(active);
     return st;
+}
+
+// SURVEY 8(e)(B), the payload step: every active block goes to the rank that
+// OWNS it (OwnerOf, the rule of the block-ownership scheme); the owner folds
+// the partial blocks of all ranks into one. Afterwards the grids of the ranks
+// are disjoint and their union is the model of the whole stream -- the layout
+// the block-ownership scheme produces directly.
+//   1. active buffer indices, ascending; owner of each; grouped by owner;
+//   2. all-gather of the per-owner counts (world x world int64);
+//   3. keys and, per attribute, the value rows gathered into owner order and
+//      exchanged with ONE all-to-all each (byte ranges; nothing to itself):
+//      a rank sends (world - 1) / world of its blocks and receives about as
+//      much, instead of world x everything with an all-gather;
+//   4. the blocks sent away are erased here and their rows zeroed;
+//   5. the received groups are folded in, ascending source rank
+//      (o3dmi_vbg_merge_blocks = Integrate's running mean).
+int o3dmi_vbg_merge_frame_sharded(o3dmi_vbg_t* g, o3dmi_comm_t* comm,
+                                  o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(g && comm, "null argument");
+    const int world = comm->world, me = comm->rank;
+    O3DMI_REQUIRE(world >= 1 && world <= kMaxWorld, "world size out of range");
+    if (world == 1) return O3DMI_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n_attr = g->attr_names.size();
+    const int64_t res = g->block_resolution;
+    std::vector<int64_t> row_bytes(n_attr);
+    for (size_t i = 0; i < n_attr; ++i) {
+        row_bytes[i] = res * res * res * g->attr_channels[i] *
+                       DtypeSize(g->attr_dtypes[i]);
+        O3DMI_REQUIRE(row_bytes[i] % 16 == 0, "value rows must be 16-byte "
+                                              "multiples");
+    }
+    struct Scratch {
+        hipStream_t s;
+        std::vector<void*> p;
+        int Alloc(void** out, size_t bytes) {
+            int e = PoolAlloc(out, bytes ? bytes : 16);
+            if (!e) p.push_back(*out);
+            return e;
+        }
+        ~Scratch() {
+            (void)hipStreamSynchronize(s);
+            for (void* q : p) PoolFree(q);
+        }
+    } scratch{s, {}};
+    int st;
+    // 1. ---------------------------------------------------------------------
+    const int64_t cap = o3dmi_hash_capacity(g->block_hashmap);
+    int32_t *active = nullptr, *owner = nullptr, *grouped = nullptr;
+    int* counters = nullptr;  // counts[world] | cursor[world]
+    if ((st = scratch.Alloc((void**)&active, sizeof(int32_t) * (size_t)cap)) ||
+        (st = scratch.Alloc((void**)&owner, sizeof(int32_t) * (size_t)cap)) ||
+        (st = scratch.Alloc((void**)&grouped, sizeof(int32_t) * (size_t)cap)) ||
+        (st = scratch.Alloc((void**)&counters, sizeof(int) * 2 * kMaxWorld)))
+        return st;
+    int64_t n = 0;
+    if ((st = o3dmi_hash_active_indices(g->block_hashmap, active, stream, &n)))
+        return st;
+    if (n > 1 && (st = o3dmi_sort_indices(active, n, stream))) return st;
+    O3DMI_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(int) * 2 * kMaxWorld, s));
+    const int* key_buffer = (const int*)o3dmi_hash_key_buffer(g->block_hashmap);
+    if (n > 0)
+        hipLaunchKernelGGL(OwnerCountKernel, dim3(GridFor(n, kBlock)),
+                           dim3(kBlock), 0, s, active, n, key_buffer, world,
+                           owner, counters);
+    int host_counts[kMaxWorld] = {0};
+    O3DMI_HIP_CHECK(hipMemcpyAsync(host_counts, counters, sizeof(int) * world,
+                                   hipMemcpyDeviceToHost, s));
+    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    OwnerOffsets off;
+    int run = 0;
+    for (int r = 0; r < kMaxWorld; ++r) {
+        off.v[r] = run;
+        if (r < world) run += host_counts[r];
+    }
+    if (n > 0)
+        hipLaunchKernelGGL(OwnerGroupKernel, dim3(GridFor(n, kBlock)),
+                           dim3(kBlock), 0, s, active, n, owner, off,
+                           counters + kMaxWorld, grouped);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    // 2. ---------------------------------------------------------------------
+    int64_t* matrix_dev = nullptr;  // [world][world]: row r = rank r's counts
+    if ((st = scratch.Alloc((void**)&matrix_dev,
+                            sizeof(int64_t) * (size_t)world * (world + 1))))
+        return st;
+    std::vector<int64_t> mine((size_t)world), matrix((size_t)world * world);
+    for (int r = 0; r < world; ++r) mine[(size_t)r] = host_counts[r];
+    int64_t* mine_dev = matrix_dev + (size_t)world * world;
+    O3DMI_HIP_CHECK(hipMemcpyAsync(mine_dev, mine.data(),
+                                   sizeof(int64_t) * world,
+                                   hipMemcpyHostToDevice, s));
+    if ((st = comm->Allgather(mine_dev, matrix_dev, sizeof(int64_t) * world, s)))
+        return st;
+    O3DMI_HIP_CHECK(hipMemcpyAsync(matrix.data(), matrix_dev,
+                                   sizeof(int64_t) * (size_t)world * world,
+                                   hipMemcpyDeviceToHost, s));
+    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    // blocks per peer: sent (nothing to itself) and received
+    std::vector<int64_t> send_n((size_t)world), recv_n((size_t)world),
+            send_first((size_t)world), recv_first((size_t)world);
+    int64_t recv_total = 0;
+    for (int r = 0; r < world; ++r) {
+        send_n[(size_t)r] = r == me ? 0 : host_counts[r];
+        send_first[(size_t)r] = off.v[r];
+        recv_n[(size_t)r] = r == me ? 0 : matrix[(size_t)r * world + me];
+        recv_first[(size_t)r] = recv_total;
+        recv_total += recv_n[(size_t)r];
+    }
+    // 3. ---------------------------------------------------------------------
+    auto exchange = [&](const void* src_rows, int64_t row, void** out) -> int {
+        char* send = nullptr;
+        char* recv = nullptr;
+        int e;
+        if ((e = scratch.Alloc((void**)&send, (size_t)(n * row))) ||
+            (e = scratch.Alloc((void**)&recv, (size_t)(recv_total * row))))
+            return e;
+        if ((e = GatherRows(src_rows, grouped, n, row, send, s))) return e;
+        std::vector<int64_t> sb((size_t)world), so((size_t)world),
+                rb((size_t)world), ro((size_t)world);
+        for (int r = 0; r < world; ++r) {
+            sb[(size_t)r] = send_n[(size_t)r] * row;
+            so[(size_t)r] = send_first[(size_t)r] * row;
+            rb[(size_t)r] = recv_n[(size_t)r] * row;
+            ro[(size_t)r] = recv_first[(size_t)r] * row;
+        }
+        *out = recv;
+        return comm->Alltoallv(send, sb.data(), so.data(), recv, rb.data(),
+                               ro.data(), s);
+    };
+    void* recv_keys = nullptr;
+    std::vector<void*> recv_vals(n_attr, nullptr);
+    if ((st = exchange(key_buffer, 12, &recv_keys))) return st;
+    for (size_t i = 0; i < n_attr; ++i)
+        if ((st = exchange(o3dmi_hash_value_buffer(g->block_hashmap, (int)i),
+                           row_bytes[i], &recv_vals[i])))
+            return st;
+    // 4. ---------------------------------------------------------------------
+    // what was sent away: the groups of the other owners = grouped[0 ..
+    // first(me)) and grouped[first(me) + count(me) .. n)
+    {
+        int32_t* gone_keys = nullptr;
+        if ((st = scratch.Alloc((void**)&gone_keys,
+                                sizeof(int32_t) * 3 * (size_t)(n ? n : 1))))
+            return st;
+        const int64_t head = off.v[me];
+        const int64_t tail_first = head + host_counts[me];
+        const int64_t tail = n - tail_first;
+        const int64_t spans[2][2] = {{0, head}, {tail_first, tail}};
+        for (const auto& sp : spans) {
+            const int64_t first = sp[0], cnt = sp[1];
+            if (cnt <= 0) continue;
+            if ((st = GatherRows(key_buffer, grouped + first, cnt, 12, gone_keys,
+                                 s)))
+                return st;
+            for (size_t i = 0; i < n_attr; ++i) {
+                const int grid = (int)(cnt < 65536 ? cnt : 65536);
+                hipLaunchKernelGGL(
+                        ZeroRowsKernel, dim3(grid), dim3(256), 0, s,
+                        (uint8_t*)o3dmi_hash_value_buffer(g->block_hashmap,
+                                                          (int)i),
+                        grouped + first, cnt, row_bytes[i] / 16);
+            }
+            O3DMI_HIP_CHECK(hipGetLastError());
+            if ((st = o3dmi_hash_erase(g->block_hashmap, gone_keys, cnt, nullptr,
+                                       stream)))
+                return st;
+        }
+        g->known_valid = false;
+        g->last_path = 0;
+    }
+    // 5. ---------------------------------------------------------------------
+    std::vector<const void*> vals(n_attr);
+    for (int r = 0; r < world; ++r) {
+        const int64_t cnt = recv_n[(size_t)r];
+        if (cnt <= 0) continue;
+        const int64_t first = recv_first[(size_t)r];
+        for (size_t i = 0; i < n_attr; ++i)
+            vals[i] = (const char*)recv_vals[i] + first * row_bytes[i];
+        if ((st = o3dmi_vbg_merge_blocks(
+                     g, (const int32_t*)recv_keys + 3 * first, vals.data(), cnt,
+                     stream)))
+            return st;
+    }
+    return O3DMI_OK;
+}
+
+// The step after it when EVERY rank wants the whole model (a ray cast on each
+// GPU): all-gather of the owners' finished blocks. Counts first, then keys and
+// rows padded to the largest rank; foreign blocks are absent here (erased and
+// zeroed above), so folding them in copies them.
+int o3dmi_vbg_allgather_owned_blocks(o3dmi_vbg_t* g, o3dmi_comm_t* comm,
+                                     o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(g && comm, "null argument");
+    const int world = comm->world, me = comm->rank;
+    O3DMI_REQUIRE(world >= 1 && world <= kMaxWorld, "world size out of range");
+    if (world == 1) return O3DMI_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n_attr = g->attr_names.size();
+    const int64_t res = g->block_resolution;
+    struct Scratch {
+        hipStream_t s;
+        std::vector<void*> p;
+        int Alloc(void** out, size_t bytes) {
+            int e = PoolAlloc(out, bytes ? bytes : 16);
+            if (!e) p.push_back(*out);
+            return e;
+        }
+        ~Scratch() {
+            (void)hipStreamSynchronize(s);
+            for (void* q : p) PoolFree(q);
+        }
+    } scratch{s, {}};
+    int st;
+    int64_t n = 0;
+    if ((st = o3dmi_vbg_export_blocks(g, 0, nullptr, nullptr, &n, stream)))
+        return st;
+    int64_t* counts_dev = nullptr;
+    if ((st = scratch.Alloc((void**)&counts_dev,
+                            sizeof(int64_t) * (size_t)(world + 1))))
+        return st;
+    O3DMI_HIP_CHECK(hipMemcpyAsync(counts_dev + world, &n, sizeof(int64_t),
+                                   hipMemcpyHostToDevice, s));
+    if ((st = comm->Allgather(counts_dev + world, counts_dev, sizeof(int64_t),
+                              s)))
+        return st;
+    std::vector<int64_t> counts((size_t)world);
+    O3DMI_HIP_CHECK(hipMemcpyAsync(counts.data(), counts_dev,
+                                   sizeof(int64_t) * world,
+                                   hipMemcpyDeviceToHost, s));
+    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    int64_t m = 0;
+    for (int64_t c : counts) m = c > m ? c : m;
+    if (m == 0) return O3DMI_OK;
+    int32_t* keys = nullptr;
+    int32_t* all_keys = nullptr;
+    if ((st = scratch.Alloc((void**)&keys, (size_t)m * 12)) ||
+        (st = scratch.Alloc((void**)&all_keys, (size_t)m * 12 * world)))
+        return st;
+    std::vector<void*> rows(n_attr), all_rows(n_attr);
+    std::vector<int64_t> row_bytes(n_attr);
+    for (size_t i = 0; i < n_attr; ++i) {
+        row_bytes[i] = res * res * res * g->attr_channels[i] *
+                       DtypeSize(g->attr_dtypes[i]);
+        if ((st = scratch.Alloc(&rows[i], (size_t)(m * row_bytes[i]))) ||
+            (st = scratch.Alloc(&all_rows[i],
+                                (size_t)(m * row_bytes[i] * world))))
+            return st;
+    }
+    int64_t n2 = 0;
+    if ((st = o3dmi_vbg_export_blocks(g, m, keys, rows.data(), &n2, stream)))
+        return st;
+    if ((st = comm->Allgather(keys, all_keys, m * 12, s))) return st;
+    for (size_t i = 0; i < n_attr; ++i)
+        if ((st = comm->Allgather(rows[i], all_rows[i], m * row_bytes[i], s)))
+            return st;
+    std::vector<const void*> vals(n_attr);
+    for (int r = 0; r < world; ++r) {
+        if (r == me || counts[(size_t)r] == 0) continue;
+        for (size_t i = 0; i < n_attr; ++i)
+            vals[i] = (const char*)all_rows[i] + (int64_t)r * m * row_bytes[i];
+        if ((st = o3dmi_vbg_merge_blocks(g, all_keys + 3 * (int64_t)r * m,
+                                         vals.data(), counts[(size_t)r],
+                                         stream)))
+            return st;
+    }
+    return O3DMI_OK;
 }
 
 int o3dmi_vbg_attribute_count(const o3dmi_vbg_t* g) {

@@ -315,6 +315,19 @@ class VoxelBlockGrid:
             assert m.value == n
         return keys, vals
 
+    def merge_frame_sharded(self, comm, replicate=False):
+        """The payload exchange of frame-sharded integration, owner-partitioned
+        (o3dmi_vbg_merge_frame_sharded): every active block travels to the
+        rank that owns it and is folded in there; afterwards the ranks hold
+        disjoint grids whose union is the model of the whole stream. With
+        `replicate` the finished blocks are then all-gathered so that every
+        rank holds the whole model. `comm`: sharding.Comm. Collective."""
+        _lib.check(_lib.lib().o3dmi_vbg_merge_frame_sharded(
+            self._g, comm.handle, stream()), "merge_frame_sharded")
+        if replicate:
+            _lib.check(_lib.lib().o3dmi_vbg_allgather_owned_blocks(
+                self._g, comm.handle, stream()), "allgather_owned_blocks")
+
     def merge_blocks(self, keys, values):
         """Folds foreign blocks (keys {n,3} int32 unique, one value tensor per
         attribute in this grid's layout) into the grid: weighted running mean

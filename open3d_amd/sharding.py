@@ -20,12 +20,24 @@ this layer is new. Exchanges are tiny and latency-bound:
     (VoxelBlockGrid.set_block_ownership(rank, world)); no data-path
     collective at all, the per-voxel work is split N ways and the union of the
     per-rank grids equals the single-GPU grid bit for bit.
-  * Frame-sharded grids are combined into one model, when one is wanted, by
-    merge_frame_sharded_grid: each rank exports its active blocks, one padded
-    all-gather of keys and value rows, and every rank folds the other ranks'
-    blocks into its own grid (VoxelBlockGrid.merge_blocks: the weighted
-    running mean Integrate itself computes, weights added).
+  * Frame-sharded grids are combined into one model by
+    merge_frame_sharded_grid -> o3dmi_vbg_merge_frame_sharded: every active
+    block travels to the rank that OWNS it (the key hash of the block-ownership
+    scheme) with one all-to-all per tensor, and the owner folds the partial
+    blocks in (the weighted running mean Integrate itself computes, weights
+    added). The ranks end with disjoint grids whose union is the model;
+    `replicate=True` all-gathers the finished blocks to every rank.
+
+The collectives themselves live in the C++ library (csrc/host/collectives.cpp):
+`Comm.rccl(dist)` builds an RCCL communicator inside the library (the unique
+id is broadcast through torch.distributed, whatever its backend), and
+`Comm.install()` makes it the ICP drivers' all-reduce -- ncclAllReduce on the
+launch stream, no Python in the iteration. `Comm.torch(dist)` is the same
+interface over torch.distributed calls (gloo in the CPU tests and when several
+ranks share one GPU, where RCCL refuses to run).
 """
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -149,14 +161,206 @@ def allgather_blocks(keys, values, dist):
             for r in range(world)]
 
 
-def merge_frame_sharded_grid(grid, dist):
-    """Folds every other rank's blocks into `grid` (ascending rank order).
-    Afterwards each rank holds the model of the whole stream: identical block
-    sets and weights on every rank, TSDF / colour equal to the single-GPU
-    stream up to the rounding of the running mean (a different association of
-    the same weighted sum; bit-identical for world = 2 on both ranks)."""
-    keys, values = grid.export_blocks()
-    rank = dist.get_rank()
-    for r, (k, v) in enumerate(allgather_blocks(keys, values, dist)):
-        if r != rank and k.shape[0]:
-            grid.merge_blocks(k.contiguous(), [x.contiguous() for x in v])
+class Comm:
+    """o3dmi_comm_t: the library-owned collectives of one rank."""
+
+    def __init__(self, handle, keep=None):
+        self.handle = handle
+        self._keep = keep  # callbacks / tables that must outlive the handle
+
+    @property
+    def rank(self):
+        from . import _lib
+        return _lib.lib().o3dmi_comm_rank(self.handle)
+
+    @property
+    def world(self):
+        from . import _lib
+        return _lib.lib().o3dmi_comm_world(self.handle)
+
+    @staticmethod
+    def rccl(dist):
+        """An RCCL communicator created INSIDE the library on the current
+        device (ncclCommInitRank); rank 0's unique id travels through
+        `dist` (any backend)."""
+        from . import _lib
+        L = _lib.lib()
+        if not L.o3dmi_rccl_available():
+            raise RuntimeError("RCCL is not available in this process")
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if dist.get_rank() == 0:
+            buf = (C.c_char * 128)()
+            _lib.check(L.o3dmi_rccl_unique_id(C.cast(buf, C.c_void_p)),
+                       "rccl_unique_id")
+            ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
+        on_dev = dist.get_backend() != "gloo"
+        t = ident.cuda() if on_dev else ident.clone()
+        dist.broadcast(t, 0)
+        raw = bytes(t.cpu().numpy().tobytes())
+        h = C.c_void_p()
+        _lib.check(L.o3dmi_comm_create_rccl(raw, dist.get_rank(),
+                                            dist.get_world_size(),
+                                            C.byref(h)), "comm_create_rccl")
+        return Comm(h)
+
+    @staticmethod
+    def torch(dist):
+        """The same three exchanges through torch.distributed calls (a custom
+        transport table). Under "gloo" device buffers are staged through the
+        host -- for correctness runs (CPU tests, several ranks on one GPU),
+        not for speed."""
+        from . import _lib
+        from .core import tensor_from_ptr
+        world, rank = dist.get_world_size(), dist.get_rank()
+        host = dist.get_backend() == "gloo"
+
+        def on_stream(stream_ptr):
+            cur = torch.cuda.current_stream().cuda_stream
+            if stream_ptr and stream_ptr != cur:
+                return torch.cuda.stream(torch.cuda.ExternalStream(stream_ptr))
+            return None
+
+        def run(stream_ptr, body):
+            ctx = on_stream(stream_ptr)
+            try:
+                if ctx is not None:
+                    ctx.__enter__()
+                try:
+                    body()
+                finally:
+                    if ctx is not None:
+                        ctx.__exit__(None, None, None)
+                return 0
+            except Exception as e:  # the C side reports a failed transport
+                import sys
+                print("open3d_amd.sharding transport: %r" % (e,),
+                      file=sys.stderr)
+                return 1
+
+        def bytes_view(ptr, n):
+            return tensor_from_ptr(ptr, (int(n),), _lib.U8, None)
+
+        def allreduce(_user, dev, n, stream_ptr):
+            def body():
+                t = tensor_from_ptr(dev, (int(n),), _lib.F64, None)
+                if host:
+                    h = t.cpu()
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                    t.copy_(h)
+                else:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return run(stream_ptr, body)
+
+        def allgather(_user, send, recv, nbytes, stream_ptr):
+            def body():
+                s = bytes_view(send, nbytes)
+                r = bytes_view(recv, nbytes * world)
+                if host:
+                    parts = [torch.empty(int(nbytes), dtype=torch.uint8)
+                             for _ in range(world)]
+                    dist.all_gather(parts, s.cpu())
+                    r.copy_(torch.cat(parts))
+                else:
+                    dist.all_gather_into_tensor(r, s)
+            return run(stream_ptr, body)
+
+        def alltoallv(_user, send, sb, so, recv, rb, ro, stream_ptr):
+            def body():
+                outs = [bytes_view(send + so[p], sb[p]) if sb[p] else
+                        torch.empty(0, dtype=torch.uint8, device="cuda")
+                        for p in range(world)]
+                ins = [bytes_view(recv + ro[p], rb[p]) if rb[p] else
+                       torch.empty(0, dtype=torch.uint8, device="cuda")
+                       for p in range(world)]
+                if host:
+                    h_out = [t.cpu() for t in outs]
+                    h_in = [torch.empty(int(rb[p]), dtype=torch.uint8)
+                            for p in range(world)]
+                    # gloo has no all_to_all: one all_gather of everybody's
+                    # ranges would move world x the bytes, so pairs exchange
+                    # with isend / irecv
+                    reqs = []
+                    for p in range(world):
+                        if p == rank:
+                            continue
+                        if rb[p]:
+                            reqs.append(dist.irecv(h_in[p], src=p))
+                        if sb[p]:
+                            reqs.append(dist.isend(h_out[p], dst=p))
+                    for q in reqs:
+                        q.wait()
+                    if sb[rank]:
+                        h_in[rank].copy_(h_out[rank])
+                    for p in range(world):
+                        if rb[p]:
+                            ins[p].copy_(h_in[p])
+                else:
+                    dist.all_to_all(ins, outs)
+            return run(stream_ptr, body)
+
+        cbs = (_lib.TRANSPORT_ALLREDUCE(allreduce),
+               _lib.TRANSPORT_ALLGATHER(allgather),
+               _lib.TRANSPORT_ALLTOALLV(alltoallv))
+        table = _lib.TransportC(*cbs)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().o3dmi_comm_create_custom(
+            C.byref(table), None, rank, world, C.byref(h)),
+            "comm_create_custom")
+        return Comm(h, keep=(cbs, table))
+
+    @staticmethod
+    def for_backend(dist):
+        """RCCL inside the library when torch.distributed itself runs on it,
+        else the torch.distributed transport."""
+        return Comm.rccl(dist) if dist.get_backend() == "nccl" \
+            else Comm.torch(dist)
+
+    def install(self, level_sharding=False):
+        """Makes this communicator the all-reduce of the ICP drivers called
+        from this host thread (o3dmi_set_comm). level_sharding: every rank
+        passes the WHOLE source cloud and the driver shards each pyramid level
+        (reference-identical pyramid); otherwise each rank passes its shard."""
+        from . import _lib
+        _lib.check(_lib.lib().o3dmi_set_comm(self.handle), "set_comm")
+        _lib.check(_lib.lib().o3dmi_set_icp_level_sharding(
+            1 if level_sharding else 0), "set_icp_level_sharding")
+
+    @staticmethod
+    def uninstall():
+        from . import _lib
+        _lib.check(_lib.lib().o3dmi_set_comm(None), "set_comm")
+        _lib.check(_lib.lib().o3dmi_set_icp_level_sharding(0),
+                   "set_icp_level_sharding")
+
+    def allreduce_sum(self, t):
+        """In-place sum of a float64 device tensor over the ranks."""
+        from . import _lib
+        from .core import stream
+        assert t.dtype == torch.float64 and t.is_cuda and t.is_contiguous()
+        _lib.check(_lib.lib().o3dmi_comm_allreduce_sum_f64(
+            self.handle, _lib.ptr(t), t.numel(), stream()), "comm_allreduce")
+
+    def destroy(self):
+        from . import _lib
+        if self.handle:
+            _lib.lib().o3dmi_comm_destroy(self.handle)
+            self.handle = None
+
+
+def merge_frame_sharded_grid(grid, comm, replicate=False):
+    """Combines the private grids of frame-sharded ranks into ONE model
+    (owner-partitioned exchange, see the module docstring). `comm`: a Comm, or
+    a torch.distributed module (a Comm is built for its backend). Block set
+    and weights equal the single-stream grid's; TSDF / colour equal it up to
+    the rounding of the running mean (another association of the same weighted
+    sum). With `replicate` every rank ends with the whole model, bit-identical
+    across ranks."""
+    own = None
+    if not isinstance(comm, Comm):
+        own = comm = Comm.for_backend(comm)
+    try:
+        grid.merge_frame_sharded(comm, replicate=replicate)
+    finally:
+        if own is not None:
+            torch.cuda.synchronize()
+            own.destroy()

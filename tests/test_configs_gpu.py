@@ -11,6 +11,13 @@ CPU path on the same inputs):
               lock-step with the oracle: pose <= 1e-6 rad / 1e-5 m per frame vs
               the float64-accumulating oracle, block sets and the final grid
               bit for bit, ray-cast maps <= 1e-4 with exact masks.
+  configs[3]  8 ranks x 1280x720, both sharding schemes, every rank run on
+              this one device: block ownership (8 classes, 56 frames: the
+              union of the 8 grids is the single grid bit for bit) and frame
+              sharding closed by the library's owner-partitioned exchange
+              (o3dmi_vbg_merge_frame_sharded over an in-process transport,
+              one host thread per rank): keys / weights exact, TSDF <= 1e-4,
+              colour bounded per voxel by its observation count.
 """
 import ctypes as C
 
@@ -206,3 +213,265 @@ def test_configs2_720p_tracking_loop_in_lock_step_with_the_oracle():
           % (n - 1, worst["pose"][0], worst["pose"][1], worst["depth"],
              worst["normal"], og.h.size(), drift[0], drift[1]))
     assert drift[0] < 0.1 and drift[1] < 0.2
+
+
+def _frames_720p(n, step=2):
+    from open3d_amd import synthetic as syn
+    K = syn.intrinsics(1280, 720)
+    ds, cs, Ts = [], [], []
+    for k in range(0, n * step, step):
+        d, c, _, T = syn.render_frames(k, 1, 1280, 720, device="cuda")
+        ds.append(d[0].contiguous())
+        cs.append(c[0].contiguous())
+        Ts.append(T[0])
+    return K, ds, cs, Ts
+
+
+def _sorted_export(g):
+    keys, vals = g.export_blocks()
+    keys = keys.cpu().numpy()
+    order = np.lexsort(keys.T[::-1])
+    return [keys[order]] + [v.cpu().numpy()[order] for v in vals]
+
+
+@pytest.mark.timeout(900)
+def test_configs3_block_ownership_8_ranks_720p_union_is_the_single_grid():
+    """BASELINE configs[3], scheme A (the bench's multi-GPU headline) at its
+    size: 8 ownership classes see the same 56-frame 1280x720 stream; each
+    grid holds exactly its class of the single grid's keys and every block is
+    bit-identical to the single grid's."""
+    _lib, geometry = _gpu()
+    from open3d_amd import sharding
+    world, n = 8, 56
+    K, ds, cs, Ts = _frames_720p(n)
+
+    def run(rank, w):
+        g = _mk_grid(geometry, False, block_count=32768)
+        if w > 1:
+            g.set_block_ownership(rank, w)
+        g.integrate_frames(ds, cs, K, K, Ts, sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                           sc.TRUNC_MULT)
+        return _sorted_export(g)
+
+    full = run(0, 1)
+    assert full[0].shape[0] > 6000
+    owner = sharding.block_owner(full[0], world)
+    seen = 0
+    for r in range(world):
+        part = run(r, world)
+        sel = owner == r
+        assert np.array_equal(part[0], full[0][sel]), r
+        for a, b in zip(part[1:], full[1:]):
+            assert a.tobytes() == b[sel].tobytes(), r
+        seen += part[0].shape[0]
+    assert seen == full[0].shape[0]
+
+
+class _Loopback:
+    """In-process transport for o3dmi_comm_create_custom: `world` host threads
+    (one rank each, all on this device) meet at barriers and copy each other's
+    device ranges -- the exchange pattern of a real transport, so the library's
+    merge runs unchanged."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.bar = threading.Barrier(world)
+        self.slots = [None] * world
+
+    def comm(self, rank):
+        from open3d_amd import _lib, sharding
+        from open3d_amd.core import tensor_from_ptr
+        world, slots, bar = self.world, self.slots, self.bar
+
+        def view(ptr, n):
+            return tensor_from_ptr(ptr, (int(n),), _lib.U8, None)
+
+        def meet():
+            torch.cuda.synchronize()
+            bar.wait()
+
+        def allreduce(_u, dev, n, _s):
+            t = tensor_from_ptr(dev, (int(n),), _lib.F64, None)
+            slots[rank] = t
+            meet()
+            total = torch.stack([slots[p] for p in range(world)]).sum(0)
+            meet()
+            t.copy_(total)
+            meet()
+            return 0
+
+        def allgather(_u, send, recv, nbytes, _s):
+            slots[rank] = view(send, nbytes)
+            meet()
+            out = view(recv, nbytes * world)
+            for p in range(world):
+                out[p * nbytes:(p + 1) * nbytes].copy_(slots[p])
+            meet()
+            return 0
+
+        def alltoallv(_u, send, sb, so, recv, rb, ro, _s):
+            slots[rank] = (send, [int(sb[p]) for p in range(world)],
+                           [int(so[p]) for p in range(world)])
+            meet()
+            ok = 0
+            for p in range(world):
+                src, psb, pso = slots[p]
+                if psb[rank] != rb[p]:
+                    ok = 1
+                elif rb[p]:
+                    view(recv + ro[p], rb[p]).copy_(
+                        view(src + pso[rank], psb[rank]))
+            meet()
+            return ok
+
+        cbs = (_lib.TRANSPORT_ALLREDUCE(allreduce),
+               _lib.TRANSPORT_ALLGATHER(allgather),
+               _lib.TRANSPORT_ALLTOALLV(alltoallv))
+        table = _lib.TransportC(*cbs)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().o3dmi_comm_create_custom(
+            C.byref(table), None, rank, world, C.byref(h)), "comm")
+        return sharding.Comm(h, keep=(cbs, table))
+
+
+def _run_ranks(world, body):
+    import threading
+    out, errs = [None] * world, []
+
+    def main(r):
+        try:
+            torch.cuda.set_device(0)
+            out[r] = body(r)
+        except BaseException as e:  # surfaced by the caller
+            errs.append((r, e))
+    ts = [threading.Thread(target=main, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        raise errs[0][1]
+    return out
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n_frames", [56, 112])
+def test_configs3_frame_sharded_8_ranks_720p_merge(n_frames):
+    """BASELINE configs[3], scheme B at its size: 8 ranks integrate frames
+    r, r + 8, ... of a 1280x720 stream into private grids; the library's
+    owner-partitioned exchange (o3dmi_vbg_merge_frame_sharded) then moves
+    every block to its owner and folds the partial blocks in. Result: 8
+    disjoint grids = the ownership classes of the single-stream grid's keys;
+    weights exact; TSDF <= 1e-4 (the same weighted sum in another
+    association); colour: both sides truncate a running mean to uint16 at
+    every step, the single stream once per frame, the merged one once per
+    frame of a shard + once per fold -- each truncation loses < 1 unit and
+    every later step scales what was lost by w / (w + 1), so per voxel
+    |merged - single| < (w + 1) / 2 + 8 with w the voxel's observation count
+    (that is the worst case of the REFERENCE's own arithmetic against the
+    exact mean, not of the merge). The bound does not depend on the stream
+    length -- the 112-frame run has the same per-voxel bound as the 56-frame
+    one -- and the observed maximum is reported and held far below it."""
+    _lib, geometry = _gpu()
+    from open3d_amd import sharding
+    world = 8
+    K, ds, cs, Ts = _frames_720p(n_frames)
+
+    def integrate(sel, grid=None):
+        g = grid or _mk_grid(geometry, False, block_count=32768)
+        g.integrate_frames([ds[i] for i in sel], [cs[i] for i in sel], K, K,
+                           [Ts[i] for i in sel], sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                           sc.TRUNC_MULT)
+        return g
+
+    full = _sorted_export(integrate(range(n_frames)))
+    parts = [integrate(range(r, n_frames, world)) for r in range(world)]
+    torch.cuda.synchronize()
+    lb = _Loopback(world)
+
+    def rank_body(r):
+        comm = lb.comm(r)
+        parts[r].merge_frame_sharded(comm)
+        torch.cuda.synchronize()
+        lb.bar.wait()
+        comm.destroy()
+        return _sorted_export(parts[r])
+
+    merged = _run_ranks(world, rank_body)
+    owner = sharding.block_owner(full[0], world)
+    worst_t, worst_c, worst_ratio = 0.0, 0, 0.0
+    for r in range(world):
+        sel = owner == r
+        keys, tsdf, weight, color = merged[r]
+        assert np.array_equal(keys, full[0][sel]), r
+        assert np.array_equal(weight, full[2][sel]), r
+        worst_t = max(worst_t, float(np.abs(tsdf - full[1][sel]).max()))
+        dc = np.abs(color.astype(np.int32) - full[3][sel].astype(np.int32))
+        bound = (weight.astype(np.int32) + 1) // 2 + world
+        assert (dc <= bound).all(), r
+        worst_c = max(worst_c, int(dc.max()))
+        worst_ratio = max(worst_ratio, float((dc / bound).max()))
+    print("frame-sharded merge, %d frames x 8 ranks at 720p: max |dTSDF| "
+          "%.3g, max |dcolour| %d units of 255 (%.2f of the per-voxel bound)"
+          % (n_frames, worst_t, worst_c, worst_ratio))
+    assert worst_t <= 1e-4
+    assert worst_c <= 24
+
+
+@pytest.mark.timeout(900)
+def test_configs3_level_sharded_multiscale_icp_8_ranks_equals_unsharded():
+    """The ICP half of configs[3]: 8 ranks (host threads on this device, the
+    library's communicator over the in-process transport, all-reduce of the 32
+    float64 sums inside every Gauss-Newton iteration) run MultiScaleICP (5 /
+    2.5 / 1.25 cm) on 720p-sized clouds with LEVEL sharding: every rank builds
+    the whole voxel pyramid and works on its slice of each level, so -- unlike
+    caller-side sharding of the raw cloud -- the sharded run is the unsharded
+    one: same iteration count, pose equal to the rounding of the float64 sums,
+    identical on every rank, and the union of the ranks' correspondence rows is
+    the unsharded correspondence set."""
+    _lib, geometry = _gpu()
+    from open3d_amd import registration as reg
+    from open3d_amd import synthetic as syn
+    world = 8
+    p = syn.make_icp_pair(230000, 230000, seed=4)
+    src = torch.from_numpy(p["source"]).cuda()
+    tgt = torch.from_numpy(p["target"]).cuda()
+    nrm = torch.from_numpy(p["target_normals"]).cuda()
+    vs = [0.05, 0.025, 0.0125]
+    crit = [reg.ICPConvergenceCriteria(1e-6, 1e-6, n) for n in (20, 10, 5)]
+    md = [0.15, 0.075, 0.0375]
+    one = reg.multi_scale_icp(src, tgt, nrm, vs, crit, md)
+    torch.cuda.synchronize()
+    lb = _Loopback(world)
+
+    def rank_body(r):
+        comm = lb.comm(r)
+        comm.install(level_sharding=True)
+        try:
+            out = reg.multi_scale_icp(src.clone(), tgt, nrm, vs, crit, md)
+            torch.cuda.synchronize()
+        finally:
+            sharding_uninstall()
+        lb.bar.wait()
+        comm.destroy()
+        return out
+
+    from open3d_amd.sharding import Comm
+    sharding_uninstall = Comm.uninstall
+    got = _run_ranks(world, rank_body)
+    n_rows = one.correspondence_set.shape[0]
+    union = torch.full((n_rows,), -1, dtype=torch.int64, device="cuda")
+    for r in range(world):
+        assert got[r].num_iterations == one.num_iterations, r
+        d = np.abs(got[r].transformation - one.transformation).max()
+        assert d <= 1e-9, (r, d)
+        assert np.array_equal(got[r].transformation, got[0].transformation)
+        assert abs(got[r].fitness - one.fitness) < 1e-12
+        assert abs(got[r].inlier_rmse - one.inlier_rmse) < 1e-9
+        c = got[r].correspondence_set
+        assert c.shape[0] == n_rows
+        mine = c >= 0
+        assert not bool((union[mine] >= 0).any())   # slices are disjoint
+        union[mine] = c[mine]
+    assert torch.equal(union, one.correspondence_set)

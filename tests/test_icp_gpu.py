@@ -1291,6 +1291,25 @@ def _icp_two_process_rank(rank, world):
         [reg.ICPConvergenceCriteria(1e-6, 1e-6, 30)], [0.07],
         device_allreduce=make_device_allreduce(dist))
     torch.cuda.synchronize()
+    # the same run through the LIBRARY's communicator (o3dmi_set_comm): RCCL
+    # created inside the library when the ranks have a GPU each, else the
+    # torch.distributed transport table; no hook, no Python closure per call
+    # on the RCCL route
+    from open3d_amd.sharding import Comm
+    comm = Comm.for_backend(dist)
+    comm.install()
+    try:
+        r2 = reg.multi_scale_icp(
+            torch.from_numpy(p["source"][b:e]).cuda(),
+            torch.from_numpy(p["target"]).cuda(),
+            torch.from_numpy(p["target_normals"]).cuda(), [-1.0],
+            [reg.ICPConvergenceCriteria(1e-6, 1e-6, 30)], [0.07])
+        torch.cuda.synchronize()
+    finally:
+        Comm.uninstall()
+        comm.destroy()
+    assert np.array_equal(r.transformation, r2.transformation)
+    assert r.num_iterations == r2.num_iterations
     return (r.transformation, r.num_iterations, r.fitness, r.inlier_rmse,
             dist.get_backend(), torch.cuda.current_device())
 
@@ -1326,3 +1345,55 @@ def test_icp_source_sharded_two_processes_device_allreduce():
     assert np.array_equal(got[0][0], got[1][0])  # identical on both ranks
     print("two-process source-sharded ICP over %s: pose equals the unsharded "
           "run" % backend)
+
+
+def test_library_rccl_communicator_single_rank():
+    """The RCCL route of the library's collectives on the hardware at hand: a
+    one-rank communicator created inside the library (ncclGetUniqueId +
+    ncclCommInitRank through dlopen), ncclAllReduce / ncclAllGather / grouped
+    send-recv enqueued on the torch stream, and an ICP call with the
+    communicator installed (world 1: the driver keeps its direct mailbox
+    route). More ranks need more GPUs than the test box has; the N > 1 logic
+    above the transport is covered by the custom-transport tests."""
+    _lib, reg = _gpu()
+    import ctypes as C
+    from open3d_amd.core import stream
+    from open3d_amd.sharding import Comm
+    L = _lib.lib()
+    if not L.o3dmi_rccl_available():
+        pytest.skip("no librccl.so in this process")
+    ident = (C.c_char * 128)()
+    _lib.check(L.o3dmi_rccl_unique_id(C.cast(ident, C.c_void_p)), "unique_id")
+    h = C.c_void_p()
+    _lib.check(L.o3dmi_comm_create_rccl(ident.raw, 0, 1, C.byref(h)),
+               "comm_create_rccl")
+    comm = Comm(h)
+    assert comm.rank == 0 and comm.world == 1
+    t = torch.arange(32, dtype=torch.float64, device="cuda")
+    want = t.clone()
+    comm.allreduce_sum(t)
+    a = torch.arange(40, dtype=torch.uint8, device="cuda")
+    b = torch.zeros(40, dtype=torch.uint8, device="cuda")
+    _lib.check(L.o3dmi_comm_allgather(h, _lib.ptr(a), _lib.ptr(b), 40,
+                                      stream()), "allgather")
+    c = torch.zeros(44, dtype=torch.uint8, device="cuda")
+    one = lambda v: (C.c_int64 * 1)(v)
+    _lib.check(L.o3dmi_comm_alltoallv(h, _lib.ptr(a), one(30), one(5),
+                                      _lib.ptr(c), one(30), one(7),
+                                      stream()), "alltoallv")
+    torch.cuda.synchronize()
+    assert torch.equal(t, want) and torch.equal(a, b)
+    assert torch.equal(c[7:37], a[5:35]) and int(c[:7].sum()) == 0
+    # adopting the ncclComm_t the library made is the o3dmi_set_rccl_comm path
+    p = _pair(4000, seed=3, dtype=np.float32)
+    args = (torch.from_numpy(p["source"]).cuda(),
+            torch.from_numpy(p["target"]).cuda(),
+            torch.from_numpy(p["target_normals"]).cuda(), 0.07)
+    plain = reg.icp(*args)
+    comm.install()
+    try:
+        with_comm = reg.icp(*args)
+    finally:
+        Comm.uninstall()
+    assert np.array_equal(plain.transformation, with_comm.transformation)
+    comm.destroy()

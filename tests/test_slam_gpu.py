@@ -273,3 +273,39 @@ def test_cpp_icp_tracking_example_runs_configs2_through_the_c_abi():
     assert out["max_translation_error_m"] < 0.08
     assert out["max_rotation_error_rad"] < 0.01745
     assert out["icp_iterations_per_frame"] >= 3
+
+
+def test_cpp_icp_tracking_example_sharded_ranks_through_the_library_comm():
+    """examples/icp_slam.cpp with ranks = 3: one host thread per rank, the
+    library's communicator installed from C++ (o3dmi_set_comm +
+    o3dmi_set_icp_level_sharding), the per-iteration all-reduce inside the
+    library. On this one-GPU box the in-process loopback transport stands in
+    for RCCL (which refuses several ranks on one device) -- and, where the box
+    has the GPUs, the RCCL transport is run as well. Every rank must end with
+    the same poses, and they must equal the single-rank run's to the rounding
+    of the float64 sums (the level pyramid is the unsharded one)."""
+    import json
+    import subprocess
+    import __graft_entry__ as ge
+    ge.build()
+    exe = os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "examples", "icp_slam")
+
+    def run(*extra):
+        r = subprocess.run([exe, "12", "320", "240", "0"] + list(extra),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout, r.stderr)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    one = run()
+    many = run("3", "loopback")
+    assert many["ranks"] == 3 and many["poses_identical_on_all_ranks"]
+    assert abs(many["max_translation_error_m"] -
+               one["max_translation_error_m"]) < 1e-6
+    assert abs(many["icp_iterations_per_frame"] -
+               one["icp_iterations_per_frame"]) < 1e-9
+    if torch.cuda.device_count() >= 2:
+        rccl = run("2", "rccl")
+        assert rccl["poses_identical_on_all_ranks"]
+        assert abs(rccl["max_translation_error_m"] -
+                   one["max_translation_error_m"]) < 1e-6

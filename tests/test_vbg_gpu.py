@@ -826,7 +826,7 @@ def _frame_sharded_rank(rank, world):
                        [torch.from_numpy(f[1][0]).cuda() for f in fr],
                        K, K, [f[3][0] for f in fr], sc.DEPTH_SCALE,
                        sc.DEPTH_MAX, sc.TRUNC_MULT)
-    merge_frame_sharded_grid(g, dist)
+    merge_frame_sharded_grid(g, dist, replicate=True)
     torch.cuda.synchronize()
     return _sorted_blocks(g)
 
@@ -834,9 +834,10 @@ def _frame_sharded_rank(rank, world):
 def test_frame_sharded_merge_across_two_processes():
     """sharding.merge_frame_sharded_grid end to end: two processes (one rank
     each, sharing this GPU; gloo as the transport) integrate the even / odd
-    frames, exchange their blocks and fold them in. Both ranks end with the
-    single-stream block set and weights, TSDF within 1e-5, bit-identical to
-    each other."""
+    frames, run the library's owner-partitioned exchange
+    (o3dmi_vbg_merge_frame_sharded) and replicate the finished blocks
+    (o3dmi_vbg_allgather_owned_blocks). Both ranks end with the single-stream
+    block set and weights, TSDF within 1e-5, bit-identical to each other."""
     from test_sharding import _run
     _lib, geometry = _gpu()
     fr = [sc.frames(k, 1, 320, 240) for k in range(0, 24, 3)]
