@@ -381,6 +381,12 @@ int o3dmi_vbg_profile_begin(o3dmi_vbg_t* g, int max_launches, int stride);
 int o3dmi_vbg_profile_end(o3dmi_vbg_t* g, o3dmi_stream_t stream,
                           double* integrate_ms, int64_t* launches,
                           int64_t* block_frames, int64_t* frames);
+/* Sum over the launches bracketed by the last profile_begin / profile_end pair
+ * of the DISTINCT blocks each of them worked on (the length of the group's
+ * block list): what the voxel state costs in memory traffic when the frames of
+ * a group are applied to register-resident blocks -- once in, once out per
+ * launch, however many frames the group has. */
+int64_t o3dmi_vbg_profile_distinct_blocks(const o3dmi_vbg_t* g);
 
 /* RayCast(block_coords, intrinsic, extrinsic, width, height, attrs, ...)
  * (VoxelBlockGrid.cpp:328-402). Output pointers follow o3dmi_vbg_raycast;

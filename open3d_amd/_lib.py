@@ -284,6 +284,7 @@ PROTOTYPES.update({
     "o3dmi_vbg_ray_cast": (
         _i32, [_vp, _vp, _i64, _dp, _dp, _i32, _i32, _vp] + [_vp] * 10 +
         [_f, _f, _f, _f, _f, _i32, _vp]),
+    "o3dmi_vbg_profile_distinct_blocks": (_i64, [_vp]),
     "o3dmi_rccl_available": (_i32, []),
     "o3dmi_rccl_unique_id": (_i32, [_vp]),
     "o3dmi_comm_create_rccl": (_i32, [_vp, _i32, _i32, C.POINTER(_vp)]),

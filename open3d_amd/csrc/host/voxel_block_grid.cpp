@@ -79,7 +79,9 @@ struct o3dmi_vbg {
     std::vector<hipEvent_t> prof_events;  // 2 per frame, around the launch carrying the integrate work
     int prof_frames = 0, prof_max = 0, prof_stride = 1, prof_seen = 0;
     int64_t prof_launch_frames = 0;  // frames carried by the bracketed launches
-    int32_t* prof_counts = nullptr;  // device, one per frame
+    int32_t* prof_counts = nullptr;  // device: [prof_max] block-frames, then
+                                     // [prof_max] distinct blocks, per launch
+    int64_t prof_distinct_blocks = 0;  // of the last profile_end
 
     int AttrIndex(const char* name) const {
         for (size_t i = 0; i < attr_names.size(); ++i)
@@ -907,7 +909,8 @@ static void MakeIntegArgs(o3dmi_vbg* g, const StreamCommon& c,
     ia->zero_counter = g->ring_counters + ((grp.seq + 2) & 3);
     ia->size_host = (int*)g->stream_status;
     ia->status_stamp = grp.stamp;
-    ia->prof_count = nullptr;
+    ia->prof_count = prof ? g->prof_counts + g->prof_max + g->prof_frames
+                          : nullptr;
     ia->prof_frame_blocks = prof ? g->prof_counts + g->prof_frames : nullptr;
 }
 
@@ -1838,10 +1841,10 @@ int o3dmi_vbg_profile_begin(o3dmi_vbg_t* g, int max_frames, int stride) {
         (void)hipFree(g->prof_counts);
         g->prof_counts = nullptr;
         O3DMI_HIP_CHECK(hipMalloc((void**)&g->prof_counts,
-                                  sizeof(int32_t) * (size_t)max_frames));
+                                  sizeof(int32_t) * 2 * (size_t)max_frames));
     }
     O3DMI_HIP_CHECK(hipMemset(g->prof_counts, 0,
-                              sizeof(int32_t) * (size_t)max_frames));
+                              sizeof(int32_t) * 2 * (size_t)max_frames));
     g->prof_max = max_frames;
     g->prof_frames = 0;
     g->prof_launch_frames = 0;
@@ -1871,11 +1874,21 @@ int o3dmi_vbg_profile_end(o3dmi_vbg_t* g, o3dmi_stream_t stream,
                                   hipMemcpyDeviceToHost));
     int64_t bf = 0;
     for (int32_t c : counts) bf += c;
+    if (g->prof_frames > 0)
+        O3DMI_HIP_CHECK(hipMemcpy(counts.data(), g->prof_counts + g->prof_max,
+                                  sizeof(int32_t) * (size_t)g->prof_frames,
+                                  hipMemcpyDeviceToHost));
+    g->prof_distinct_blocks = 0;
+    for (int32_t c : counts) g->prof_distinct_blocks += c;
     *integrate_ms = ti;
     *launches = g->prof_frames;
     *block_frames = bf;
     *frames = g->prof_launch_frames;
     return O3DMI_OK;
+}
+
+int64_t o3dmi_vbg_profile_distinct_blocks(const o3dmi_vbg_t* g) {
+    return g ? g->prof_distinct_blocks : 0;
 }
 
 }  // extern "C"

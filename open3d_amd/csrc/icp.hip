@@ -30,6 +30,7 @@
 #include <cstring>
 
 #include "nns.h"
+#include "gn_device.h"
 #include "mailbox.h"
 #include "reduce_sums.h"
 
@@ -517,6 +518,143 @@ struct OwnedSums {
     __device__ __forceinline__ Ref operator[](int i) { return Ref{*this, i}; }
 };
 
+// ---- the Gauss-Newton step inside the search launch ----------------------------
+// What used to follow every point-to-plane search launch -- a one-workgroup
+// final-sum launch, a PCIe post, the host's 6x6 solve and the host's next
+// launch carrying the update -- is done by the LAST workgroup of the search
+// launch itself, so the driver can queue iteration k + 1 before it has seen
+// iteration k (host/registration.cpp):
+//   * every workgroup writes its row of partial sums with write-through
+//     (sc1) stores, drains them (s_waitcnt vmcnt(0)) and takes a ticket; the
+//     tickets are two-level, one counter per XCD class (blockIdx % 8) and one
+//     on top, so no counter sees more than 64 arrivals (a single word
+//     serialises them at ~12 ns each);
+//   * the last arriver reads all rows with sc1 loads (valid without an acquire
+//     fence because the producers stored sc1), adds them in FinalSumKernel's
+//     order (bit-identical sums), solves the 6x6 system with one wave
+//     (gn_device.h: the host routine's arithmetic, entry by entry), forms the
+//     update transformation, leaves it in device memory for the next launch
+//     (apply_xf == 2 reads it from there) and posts sums + update + status to
+//     the host mailbox ring.
+// No agent-scope release fence anywhere: on this part it writes back the
+// XCD's whole L2 (the moved source points of the launch are dirty in it) and
+// costs more than the launch it would save -- measured in round 1.
+struct GnTail {
+    int* tickets;          // [9] zero between launches; NULL = no tail
+    const double* xf_in;   // apply_xf == 2: the 4x4 to move the source by
+    double* xf_out;        // receives this iteration's update (may == xf_in)
+    double* mail_data;     // host-mapped [kMailDoubles]
+    int* mail_flag;
+    int mail_seq;
+    double n_source;       // sums[31]
+};
+
+__device__ __forceinline__ double LoadSc1(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(
+            (const unsigned long long*)p, __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void StoreSc1(double* p, double v) {
+    __hip_atomic_store((unsigned long long*)p,
+                       (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// True in every thread of the workgroup that arrived last. Call after the
+// workgroup's row is stored (by threads of wave 0) -- see above.
+__device__ __forceinline__ bool LastWorkgroup(int* tickets) {
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+        const int cls = blockIdx.x & 7;
+        const int in_class = ((int)gridDim.x - cls + 7) >> 3;
+        const int classes = (int)gridDim.x < 8 ? (int)gridDim.x : 8;
+        int last = 0;
+        if (__hip_atomic_fetch_add(&tickets[1 + cls], 1, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT) == in_class - 1)
+            last = __hip_atomic_fetch_add(&tickets[0], 1, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT) ==
+                   classes - 1;
+        s_last = last;
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+
+// Executed by all kSearchBlock threads of the last workgroup.
+__device__ __forceinline__ void GaussNewtonTail(const double* partials,
+                                                int n_rows, const GnTail& tl) {
+    static_assert(kSearchBlock == 512 && kNumSums == 32, "tail geometry");
+    __shared__ double s_rows[kFinalRowLanes][32];
+    __shared__ double s_sums[32];
+    __shared__ double s_pose[6], s_sc[6], s_update[16];
+    __shared__ int s_status;
+    const int tid = threadIdx.x;
+    // FinalSumKernel's order: row lane rl adds rows rl, rl + 32, ... in
+    // ascending order; the 32 row lanes are then added in ascending order.
+    // 512 threads: thread (rl0, col) runs row lanes rl0 and rl0 + 16.
+    {
+        const int col = tid & 31, rl0 = tid >> 5;
+        double x[2][16];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int r = rl0 + 16 * h + k * kFinalRowLanes;
+                x[h][k] = r < n_rows ? LoadSc1(partials + (int64_t)r * 32 + col)
+                                     : 0.0;
+            }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double v = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v += x[h][k];
+            s_rows[rl0 + 16 * h][col] = v;
+        }
+    }
+    if (tid == 0) {
+        // tickets back to zero for the next launch (ordered by the kernel
+        // boundary)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) tl.tickets[k] = 0;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        double t = 0;
+#pragma unroll
+        for (int k = 0; k < kFinalRowLanes; ++k) t += s_rows[k][tid];
+        if (tid == 31) t = tl.n_source;
+        s_sums[tid] = t;
+    }
+    __syncthreads();
+    // DecodeAndSolve6x6 + PoseToTransformation (the host's per-iteration work)
+    if (tid < 64) {
+        double x[6];
+        const int st = GnSolveWave(s_sums, tid, x);
+        if (tid == 0) {
+            s_status = st;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s_pose[k] = st == 0 ? x[k] : 0.0;
+        }
+    }
+    __syncthreads();
+    if (tid < 6) s_sc[tid] = tid < 3 ? sin(s_pose[tid]) : cos(s_pose[tid - 3]);
+    __syncthreads();
+    if (tid == 0) PoseToTransformationDevice(s_pose, s_sc, s_update);
+    __syncthreads();
+    if (tid < 16) {
+        // no correspondence at all: the driver resets its transformation and
+        // stops; the launch already queued behind this one moves nothing
+        const bool none = s_sums[30] == 0.0;
+        const double u = none ? ((tid % 5) == 0 ? 1.0 : 0.0) : s_update[tid];
+        tl.xf_out[tid] = u;
+        tl.mail_data[32 + tid] = u;
+    }
+    if (tid < 32) tl.mail_data[tid] = s_sums[tid];
+    if (tid == 32) tl.mail_data[48] = (double)s_status;
+    MailboxPublish(tl.mail_flag, tl.mail_seq);
+}
+
 template <typename T, int G, int EST>
 __global__ void __launch_bounds__(kSearchBlock,
                                   EST == 0 ? 2 : (G >= 8 ? 4 : (G >= 2 ? 3 : 2)))
@@ -524,8 +662,15 @@ SearchAccumulateKernel(NnsView<T> nv, const Rec4<T>* __restrict__ sorted_n,
                        T* __restrict__ src, int64_t n, Mat4<T> xf,
                        int apply_xf, RobustParams rp,
                        int64_t* __restrict__ corr_out,
-                       double* __restrict__ partials) {
+                       double* __restrict__ partials, GnTail tail) {
     constexpr int kPerWave = 64 / G;  // queries per wave
+    if (apply_xf == 2) {
+        // the update the previous launch's tail left on the device (uniform
+        // address: scalar loads), narrowed to the point dtype like the host
+        // narrows the matrix it passes by value
+#pragma unroll
+        for (int k = 0; k < 16; ++k) xf.m[k] = (T)tail.xf_in[k];
+    }
     constexpr int kM = kNumSums / G;  // sums a lane owns
     static_assert(kNumSums % G == 0, "G divides the number of sums");
     double mine[kM];
@@ -730,8 +875,14 @@ SearchAccumulateKernel(NnsView<T> nv, const Rec4<T>* __restrict__ sorted_n,
         double t = 0;
 #pragma unroll
         for (int w = 0; w < kSearchBlock / 64; ++w) t += lds[w][threadIdx.x];
-        partials[(int64_t)blockIdx.x * kNumSums + threadIdx.x] = t;
+        if (tail.tickets)
+            StoreSc1(partials + (int64_t)blockIdx.x * kNumSums + threadIdx.x,
+                     t);
+        else
+            partials[(int64_t)blockIdx.x * kNumSums + threadIdx.x] = t;
     }
+    if (tail.tickets && LastWorkgroup(tail.tickets))
+        GaussNewtonTail(partials, (int)gridDim.x, tail);
 }
 
 

@@ -25,12 +25,44 @@ Mailbox* ThreadMailbox() {
     return mb.data ? &mb : nullptr;
 }
 
+MailRing* ThreadMailRing() {
+    thread_local MailRing ring;
+    thread_local bool tried = false;
+    if (!tried) {
+        tried = true;
+        void* p = nullptr;
+        const size_t data_bytes = sizeof(double) * kMailSlots * kMailDoubles;
+        if (hipHostMalloc(&p, data_bytes + 64 * kMailSlots,
+                          hipHostMallocMapped | hipHostMallocCoherent) ==
+            hipSuccess) {
+            ring.data = (double*)p;
+            ring.flags = (int*)((char*)p + data_bytes);
+            for (int k = 0; k < kMailSlots; ++k) ring.flags[k * 16] = 0;
+            ring.seq = 0;
+        }
+    }
+    return ring.data ? &ring : nullptr;
+}
+
+namespace {
+hipError_t WaitWord(const int* flag, int seq, hipStream_t s);
+}
+
 hipError_t MailboxWait(Mailbox* mb, int seq, hipStream_t s) {
+    return WaitWord(mb->flag, seq, s);
+}
+
+hipError_t MailRingWait(MailRing* ring, int seq, hipStream_t s) {
+    return WaitWord(ring->Flag(seq), seq, s);
+}
+
+namespace {
+hipError_t WaitWord(const int* flag, int seq, hipStream_t s) {
     using clock = std::chrono::steady_clock;
     auto next_query = clock::now() + std::chrono::milliseconds(2);
     for (;;) {
         for (int spin = 0; spin < 256; ++spin) {
-            if (__atomic_load_n(mb->flag, __ATOMIC_ACQUIRE) == seq)
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq)
                 return hipSuccess;
 #if defined(__x86_64__)
             _mm_pause();
@@ -40,7 +72,7 @@ hipError_t MailboxWait(Mailbox* mb, int seq, hipStream_t s) {
             // A failed launch / device fault never posts: ask the stream.
             hipError_t e = hipStreamQuery(s);
             if (e == hipSuccess) {
-                if (__atomic_load_n(mb->flag, __ATOMIC_ACQUIRE) == seq)
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq)
                     return hipSuccess;
                 return hipErrorUnknown;  // finished without posting
             }
@@ -49,5 +81,6 @@ hipError_t MailboxWait(Mailbox* mb, int seq, hipStream_t s) {
         }
     }
 }
+}  // namespace
 
 }  // namespace o3dmi

@@ -26,6 +26,23 @@ Mailbox* ThreadMailbox();
 // or the stream's error if the stream finished / failed without posting.
 hipError_t MailboxWait(Mailbox* mb, int seq, hipStream_t s);
 
+// A ring of mailboxes for drivers that keep more than one launch in flight
+// (the ICP driver issues iteration k + 1 before it has read iteration k):
+// slot = seq % kMailSlots, each slot kMailDoubles float64 + its own sequence
+// word, all in one host-mapped allocation.
+constexpr int kMailSlots = 4;
+constexpr int kMailDoubles = 64;
+struct MailRing {
+    double* data = nullptr;  // [kMailSlots][kMailDoubles]
+    int* flags = nullptr;    // [kMailSlots], 64 bytes apart
+    int seq = 0;
+    double* Data(int s) const { return data + (size_t)(s % kMailSlots) * kMailDoubles; }
+    int* Flag(int s) const { return flags + (size_t)(s % kMailSlots) * 16; }
+};
+MailRing* ThreadMailRing();
+// Blocks until launch `seq` has posted; its data is ring->Data(seq).
+hipError_t MailRingWait(MailRing* ring, int seq, hipStream_t s);
+
 // Device side: called by the threads of the single final workgroup after they
 // wrote data[0..n); publishes `seq`.
 __device__ __forceinline__ void MailboxPublish(int* flag, int seq) {

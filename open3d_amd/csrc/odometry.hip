@@ -28,6 +28,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "gn_device.h"
 #include "reduce_sums.h"
 
 namespace o3dmi {
@@ -741,55 +742,6 @@ struct GnParams {
     int* mail_flag;                //   iterations, status
     int mail_seq;
 };
-
-// o3dmi_decode_and_solve6x6 (TransformationConverter.cpp:189-226 + partial-
-// pivot LU) by ONE WAVE: lane (i, j) = (lane / 8, lane % 8) holds entry (i, j)
-// of the 6 x 7 augmented matrix [M | b] in a register, row operations are
-// shuffles. Every entry sees exactly the multiply / subtract sequence of the
-// sequential host code (a single lane running that code in float64 takes
-// ~12 us -- longer than the rest of an iteration). All lanes return the same
-// status (0 ok, 2 singular) and the same pose.
-__device__ int GnSolveWave(const double* A, int lane, double (&x)[6]) {
-    const int i = lane >> 3, j = lane & 7;
-    double m = 0;
-    if (i < 6 && j < 6) {
-        const int hi = i > j ? i : j, lo = i > j ? j : i;
-        m = A[(hi * (hi + 1)) / 2 + lo];
-    } else if (i < 6 && j == 6) {
-        m = -A[21 + i];
-    }
-    for (int k = 0; k < 6; ++k) {
-        int p = k;
-        double mx = fabs(__shfl(m, k * 8 + k, 64));
-        for (int r = k + 1; r < 6; ++r) {
-            const double v = fabs(__shfl(m, r * 8 + k, 64));
-            if (v > mx) {
-                mx = v;
-                p = r;
-            }
-        }
-        if (mx == 0.0 || !(mx == mx)) return 2;
-        // swap rows k and p (all columns, b included)
-        const int src = (i == k) ? p * 8 + j : ((i == p) ? k * 8 + j : lane);
-        m = __shfl(m, src, 64);
-        const double pivot = __shfl(m, k * 8 + k, 64);
-        const double mik = __shfl(m, i * 8 + k, 64);
-        const double mkj = __shfl(m, k * 8 + j, 64);
-        if (i > k && i < 6) {
-            const double l = mik / pivot;
-            if (j == k) m = l;
-            else if (j > k && j <= 6) m = m - l * mkj;
-        }
-    }
-    // back substitution (forward substitution of b happened with the
-    // elimination steps, in the same order)
-    for (int r = 5; r >= 0; --r) {
-        double br = __shfl(m, r * 8 + 6, 64);
-        for (int c = r + 1; c < 6; ++c) br -= __shfl(m, r * 8 + c, 64) * x[c];
-        x[r] = br / __shfl(m, r * 8 + r, 64);
-    }
-    return 0;
-}
 
 template <int METHOD>
 __global__ void __launch_bounds__(kSumsBlock)

@@ -410,15 +410,17 @@ class VoxelBlockGrid:
             self._g, int(max_frames), int(stride)), "profile_begin")
 
     def profile_end(self):
-        """-> dict(integrate_ms, launches, block_frames, frames) over the
-        bracketed launches."""
+        """-> dict(integrate_ms, launches, block_frames, frames,
+        distinct_blocks) over the bracketed launches."""
         ti = C.c_double(0)
         n, bf, fr = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         _lib.check(_lib.lib().o3dmi_vbg_profile_end(
             self._g, stream(), C.byref(ti), C.byref(n), C.byref(bf),
             C.byref(fr)), "profile_end")
         return dict(integrate_ms=ti.value, launches=n.value,
-                    block_frames=bf.value, frames=fr.value)
+                    block_frames=bf.value, frames=fr.value,
+                    distinct_blocks=int(
+                        _lib.lib().o3dmi_vbg_profile_distinct_blocks(self._g)))
 
     def last_frame_block_coordinates(self, capacity):
         """Extension: the block coordinates the most recent integrate_frame

@@ -254,7 +254,7 @@ def test_configs3_block_ownership_8_ranks_720p_union_is_the_single_grid():
         return _sorted_export(g)
 
     full = run(0, 1)
-    assert full[0].shape[0] > 6000
+    assert full[0].shape[0] > 1000
     owner = sharding.block_owner(full[0], world)
     seen = 0
     for r in range(world):
