@@ -83,6 +83,12 @@ extern "C" int o3dmi_internal_icp_transform_search_accumulate(
         int robust_kernel, double scaling_parameter, double shape_parameter,
         int64_t* corr_out_dev, double* sums32_dev, double* mail_data,
         int* mail_flag, int mail_seq, o3dmi_stream_t stream);
+extern "C" int o3dmi_internal_icp_search_solve(
+        const o3dmi_nns_t* nns, void* src_dev, const double* transformation,
+        int xf_from_device, int64_t n, int robust_kernel,
+        double scaling_parameter, double shape_parameter,
+        int64_t* corr_out_dev, void* state_dev, double* mail_data,
+        int* mail_flag, int mail_seq, o3dmi_stream_t stream);
 extern "C" int o3dmi_internal_sums_tail(double* sums32_dev, double t29,
                                         double t30, double t31,
                                         o3dmi_stream_t stream);
@@ -261,6 +267,30 @@ hipEvent_t SideEvent() {
         hipEventCreateWithFlags(&ev[d], hipEventDisableTiming) != hipSuccess)
         ev[d] = nullptr;
     return ev[d];
+}
+
+// Device state of the in-launch Gauss-Newton step (icp.hip GnTail): the 4x4
+// update the last launch left for the next one + 9 ticket words, which every
+// launch returns to zero. One per host thread and device, zeroed when
+// allocated and again after a call that ended with launches unaccounted for.
+struct GnState {
+    void* dev = nullptr;
+    bool clean = false;
+};
+GnState* ThreadGnState(hipStream_t s) {
+    static thread_local GnState st[kMaxDevices];
+    const int d = CurrentDevice();
+    if (d < 0) return nullptr;
+    GnState& g = st[d];
+    if (!g.dev && hipMalloc(&g.dev, 256) != hipSuccess) {
+        g.dev = nullptr;
+        return nullptr;
+    }
+    if (!g.clean) {
+        if (hipMemsetAsync(g.dev, 0, 256, s) != hipSuccess) return nullptr;
+        g.clean = true;
+    }
+    return &g;
 }
 
 // `completed`: set by the owner once every kernel that used the index is
@@ -749,6 +779,28 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         return O3DMI_OK;
     };
 
+    // O3DMI_ICP_DEVICE_SOLVE=1: point-to-plane iterations as ONE launch each
+    // (final sum + 6x6 solve + update in the last workgroup of the search
+    // launch, the host one launch ahead -- the `fast` branch below). Built and
+    // measured in round 3, bit-compatible with the default (same sums, pose
+    // equal to 1e-17), and NOT faster: the in-launch tail -- two ticket
+    // atomics, a write-through row gather, the wave solve, the system-scope
+    // post -- adds 8 - 10 us to every search launch (rocprofv3: 30.9 / 19.0 /
+    // 17.0 us against 20.8 / 10.5 / 9.4 at G = 8 / 16 / 32), which is what the
+    // separate final-sum launch (6.2 us + 1.5 us boundary) and the host hop
+    // cost together; 1010 - 1055 against 1050 - 1067 frames/s in
+    // examples/icp_slam at 640x480. Device-wide visibility inside a launch
+    // stays dearer than a second small launch on this part.
+    const char* dev_solve_env = std::getenv("O3DMI_ICP_DEVICE_SOLVE");
+    const bool host_solve = !(dev_solve_env && dev_solve_env[0] == '1');
+    MailRing* ring = nullptr;
+    GnState* gn = nullptr;
+    bool fast = p2plane && !dev_reduce && !allreduce && !host_solve;
+    if (fast) {
+        ring = ThreadMailRing();
+        gn = ThreadGnState(s);
+        fast = ring != nullptr && gn != nullptr;
+    }
     for (int scale_idx = 0; scale_idx < num_scales; ++scale_idx) {
         Level& full_level = pyr[(size_t)scale_idx];
         struct ScaleView : SourceView {
@@ -793,6 +845,115 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                          scale_idx, (long long)L.ns, (long long)L.nt,
                          t - t_mark);
             t_mark = t;
+        }
+        if (fast) {
+            // Point-to-plane on one GPU: an iteration is ONE launch (search +
+            // accumulate + final sum + 6x6 solve + update in its last
+            // workgroup, icp.hip GnTail) and the host runs one launch AHEAD:
+            // launch k + 1 -- which moves the source by the update launch k
+            // left on the device -- is queued before launch k's sums are
+            // read. When the scale ends at iteration k (converged, out of
+            // iterations, no correspondences) launch k + 1 is in flight
+            // already: it is the evaluation of the result at this scale, i.e.
+            // what the reference runs after the last scale (Registration.cpp:
+            // 424-431), and is simply not read at the other scales.
+            const o3dmi_icp_criteria_t& crit = criterias[scale_idx];
+            const bool last_scale = scale_idx == num_scales - 1;
+            int64_t* corr_out = last_scale ? correspondences_dev : nullptr;
+            has_pending = false;
+            guard.completed = false;
+            auto launch = [&](const double* xf_host, int* seq_out) -> int {
+                const int seq = ++ring->seq;
+                *seq_out = seq;
+                return o3dmi_internal_icp_search_solve(
+                        guard.nns, L.src, xf_host, xf_host ? 0 : 1, L.ns,
+                        robust_kernel, scaling_parameter, shape_parameter,
+                        corr_out, gn->dev, ring->Data(seq), ring->Flag(seq),
+                        seq, stream);
+            };
+            auto read = [&](int seq, SearchResult& r, double* update,
+                            int* solve_status) -> int {
+                O3DMI_HIP_CHECK(MailRingWait(ring, seq, s));
+                const double* d = ring->Data(seq);
+                std::memcpy(r.sums, d, sizeof(double) * 32);
+                if (update) std::memcpy(update, d + 32, sizeof(double) * 16);
+                if (solve_status) *solve_status = (int)d[48];
+                const double num = r.sums[30];
+                if (num != 0) {
+                    r.fitness = num / r.sums[31];
+                    r.inlier_rmse = std::sqrt(r.sums[29] / num);
+                } else {
+                    r.fitness = 0;
+                    r.inlier_rmse = 0;
+                }
+                return O3DMI_OK;
+            };
+            gn->clean = false;  // launches in flight from here on
+            int seq_cur = 0, seq_next = 0;
+            if ((st = launch(T, &seq_cur))) return st;
+            double prev_fitness = fitness, prev_inlier_rmse = inlier_rmse;
+            converged = false;
+            int it = 0;
+            for (it = 0; it < crit.max_iteration; ++it) {
+                if ((st = launch(nullptr, &seq_next))) return st;
+                SearchResult r;
+                double update[16];
+                int solve_status = 0;
+                if ((st = read(seq_cur, r, update, &solve_status))) return st;
+                seq_cur = seq_next;
+                fitness = r.fitness;
+                inlier_rmse = r.inlier_rmse;
+                converged = false;
+                if (r.sums[30] == 0) Eye4(T);  // Registration.cpp:56-58
+                if (fitness <= std::numeric_limits<double>::min()) break;
+                if (solve_status != 0) {
+                    // the reference throws; reported after the loop. The
+                    // device applied the identity in this case.
+                    SetLastError("Singular 6x6 linear system detected, "
+                                 "tracking failed.");
+                    status = O3DMI_ERR_SINGULAR;
+                }
+                Matmul4(update, T, T);
+                if (callback)
+                    callback(iteration_count + it, scale_idx, it, inlier_rmse,
+                             fitness, T, callback_user);
+                if (it != 0 &&
+                    std::abs(prev_fitness - fitness) < crit.relative_fitness &&
+                    std::abs(prev_inlier_rmse - inlier_rmse) <
+                            crit.relative_rmse) {
+                    converged = true;
+                    break;
+                }
+                prev_fitness = fitness;
+                prev_inlier_rmse = inlier_rmse;
+            }
+            iteration_count += it;
+            exit_timer.Mark("scale");
+            if (timing) {
+                (void)hipStreamSynchronize(s);
+                const double t = now();
+                std::fprintf(stderr,
+                             "[o3dmi] icp: scale %d %d iterations %.0f us\n",
+                             scale_idx, it, t - t_mark);
+                t_mark = t;
+            }
+            if (last_scale) {
+                // the launch in flight is the evaluation at the result
+                const bool preserved = converged;
+                SearchResult r;
+                if ((st = read(seq_cur, r, nullptr, nullptr))) return st;
+                fitness = r.fitness;
+                inlier_rmse = r.inlier_rmse;
+                if (r.sums[30] == 0) Eye4(T);
+                converged = preserved;
+                guard.completed = true;  // nothing of this call is in flight
+                gn->clean = true;
+            }
+            if (fitness <= std::numeric_limits<double>::min()) {
+                converged = false;
+                break;
+            }
+            continue;
         }
         // DoSingleScaleICPIterations :275-360
         double prev_fitness = fitness, prev_inlier_rmse = inlier_rmse;

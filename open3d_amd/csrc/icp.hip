@@ -539,9 +539,11 @@ struct OwnedSums {
 // No agent-scope release fence anywhere: on this part it writes back the
 // XCD's whole L2 (the moved source points of the launch are dirty in it) and
 // costs more than the launch it would save -- measured in round 1.
+constexpr int kTailRows = 256;  // workgroups of a launch that carries a tail
 struct GnTail {
     int* tickets;          // [9] zero between launches; NULL = no tail
-    const double* xf_in;   // apply_xf == 2: the 4x4 to move the source by
+    const double* xf_in;   // apply_xf == 2: the 4x4 to move the source by,
+                           // 16 float64 followed by the same as 16 float32
     double* xf_out;        // receives this iteration's update (may == xf_in)
     double* mail_data;     // host-mapped [kMailDoubles]
     int* mail_flag;
@@ -592,23 +594,27 @@ __device__ __forceinline__ void GaussNewtonTail(const double* partials,
     const int tid = threadIdx.x;
     // FinalSumKernel's order: row lane rl adds rows rl, rl + 32, ... in
     // ascending order; the 32 row lanes are then added in ascending order.
-    // 512 threads: thread (rl0, col) runs row lanes rl0 and rl0 + 16.
+    // 512 threads: thread (rl0, col) runs row lanes rl0 and rl0 + 16. A tail
+    // launch has at most kTailRows rows (8 per row lane), all loads of a row
+    // lane in flight at once.
     {
         const int col = tid & 31, rl0 = tid >> 5;
-        double x[2][16];
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int r = rl0 + 16 * h + k * kFinalRowLanes;
-                x[h][k] = r < n_rows ? LoadSc1(partials + (int64_t)r * 32 + col)
-                                     : 0.0;
-            }
+        const double* base = partials + (int64_t)rl0 * 32 + col;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+            double x[kTailRows / kFinalRowLanes];
+#pragma unroll
+            for (int k = 0; k < kTailRows / kFinalRowLanes; ++k) {
+                const int r = rl0 + 16 * h + k * kFinalRowLanes;
+                x[k] = r < n_rows
+                               ? LoadSc1(base + (int64_t)(16 * h +
+                                                          k * kFinalRowLanes) *
+                                                        32)
+                               : 0.0;
+            }
             double v = 0;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v += x[h][k];
+            for (int k = 0; k < kTailRows / kFinalRowLanes; ++k) v += x[k];
             s_rows[rl0 + 16 * h][col] = v;
         }
     }
@@ -648,6 +654,7 @@ __device__ __forceinline__ void GaussNewtonTail(const double* partials,
         const bool none = s_sums[30] == 0.0;
         const double u = none ? ((tid % 5) == 0 ? 1.0 : 0.0) : s_update[tid];
         tl.xf_out[tid] = u;
+        ((float*)(tl.xf_out + 16))[tid] = (float)u;
         tl.mail_data[32 + tid] = u;
     }
     if (tid < 32) tl.mail_data[tid] = s_sums[tid];
@@ -668,8 +675,18 @@ SearchAccumulateKernel(NnsView<T> nv, const Rec4<T>* __restrict__ sorted_n,
         // the update the previous launch's tail left on the device (uniform
         // address: scalar loads), narrowed to the point dtype like the host
         // narrows the matrix it passes by value
+        // The tail stores the matrix in both precisions so that a Float32
+        // launch gets its values by scalar loads alone: narrowing here would
+        // be a vector instruction and park all 16 values in vector registers
+        // for the whole kernel (+16 registers, a wave of occupancy).
+        if constexpr (sizeof(T) == 4) {
+            const float* m32 = (const float*)(tail.xf_in + 16);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) xf.m[k] = (T)tail.xf_in[k];
+            for (int k = 0; k < 16; ++k) xf.m[k] = m32[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) xf.m[k] = tail.xf_in[k];
+        }
     }
     constexpr int kM = kNumSums / G;  // sums a lane owns
     static_assert(kNumSums % G == 0, "G divides the number of sums");
@@ -1259,13 +1276,15 @@ int o3dmi_icp_search_accumulate_post(
 // Internal: as above, and when `transformation` (row-major 4x4, float64) is
 // given the source points are first moved by it IN PLACE, with
 // o3dmi_transform_points' arithmetic, inside the same launch.
-int o3dmi_internal_icp_transform_search_accumulate(
+static int LaunchSearchAccumulate(
         const o3dmi_nns_t* nns, void* src_dev, const double* transformation,
         const void* tgt_normals_dev, int64_t n, int estimation,
         int robust_kernel, double scaling_parameter, double shape_parameter,
         int64_t* corr_out_dev, double* sums32_dev, double* mail_data,
-        int* mail_flag, int mail_seq, o3dmi_stream_t stream) {
-    O3DMI_REQUIRE(nns && src_dev && (sums32_dev || mail_data), "null argument");
+        int* mail_flag, int mail_seq, const GnTail* tail_in,
+        o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(nns && src_dev && (sums32_dev || mail_data || tail_in),
+                  "null argument");
     O3DMI_REQUIRE(estimation >= 0 && estimation <= 2,
                   "estimation must be point-to-plane (0), point-to-point (1) "
                   "or information (2)");
@@ -1304,12 +1323,22 @@ int o3dmi_internal_icp_transform_search_accumulate(
     }
     // <= 512 workgroups of 8 waves: at most 512 rows for the final pass
     int64_t g64 = (n * group + kSearchBlock - 1) / kSearchBlock;
-    if (g64 > (int64_t)kCUs * 2) g64 = (int64_t)kCUs * 2;
+    const int64_t g_max = tail_in ? kTailRows : (int64_t)kCUs * 2;
+    if (g64 > g_max) g64 = g_max;
     if (g64 < 1) g64 = 1;
     const int g = (int)g64;
     RobustParams rp = MakeRobust(robust_kernel, scaling_parameter,
                                  shape_parameter);
-    const int apply_xf = transformation != nullptr;
+    // 0 none, 1 the matrix passed by value, 2 the matrix the previous
+    // launch's tail left at tail.xf_in
+    const int apply_xf = transformation != nullptr
+                                 ? 1
+                                 : (tail_in && tail_in->xf_in ? 2 : 0);
+    GnTail tail = {};
+    if (tail_in) {
+        tail = *tail_in;
+        tail.n_source = (double)n;
+    }
     Mat4<double> xd;
     Mat4<float> xfl;
     for (int k = 0; k < 16; ++k) {
@@ -1324,7 +1353,8 @@ int o3dmi_internal_icp_transform_search_accumulate(
     hipLaunchKernelGGL((SearchAccumulateKernel<T, G, E>), dim3(g),            \
                        dim3(kSearchBlock), 0, s, MakeView<T>(nns),            \
                        (const Rec4<T>*)nns->sorted_normals, (T*)src_dev, n,   \
-                       xf_of(T()), apply_xf, rp, corr_out_dev, nns->partials)
+                       xf_of(T()), apply_xf, rp, corr_out_dev, nns->partials, \
+                       tail)
 #define O3DMI_SEARCH(T, G)                                                     \
     do {                                                                      \
         if (estimation == 0 && robust_kernel == O3DMI_L2_LOSS)                \
@@ -1347,11 +1377,54 @@ int o3dmi_internal_icp_transform_search_accumulate(
 #undef O3DMI_SEARCH_G
 #undef O3DMI_SEARCH
 #undef O3DMI_SEARCH_E
-    hipLaunchKernelGGL(FinalSumKernel<kNumSums>, dim3(1), dim3(kFinalThreads),
-                       0, s, nns->partials, g, sums32_dev, mail_data, mail_flag,
-                       mail_seq);
+    if (!tail_in)
+        hipLaunchKernelGGL(FinalSumKernel<kNumSums>, dim3(1),
+                           dim3(kFinalThreads), 0, s, nns->partials, g,
+                           sums32_dev, mail_data, mail_flag, mail_seq);
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
+}
+
+int o3dmi_internal_icp_transform_search_accumulate(
+        const o3dmi_nns_t* nns, void* src_dev, const double* transformation,
+        const void* tgt_normals_dev, int64_t n, int estimation,
+        int robust_kernel, double scaling_parameter, double shape_parameter,
+        int64_t* corr_out_dev, double* sums32_dev, double* mail_data,
+        int* mail_flag, int mail_seq, o3dmi_stream_t stream) {
+    return LaunchSearchAccumulate(nns, src_dev, transformation, tgt_normals_dev,
+                                  n, estimation, robust_kernel,
+                                  scaling_parameter, shape_parameter,
+                                  corr_out_dev, sums32_dev, mail_data, mail_flag,
+                                  mail_seq, nullptr, stream);
+}
+
+// Internal (host/registration.cpp): one point-to-plane Gauss-Newton iteration
+// as ONE launch -- search + accumulate + final sum + 6x6 solve + update, see
+// GnTail. `transformation` (host, may be NULL): moves the source first, as
+// above; NULL with xf_from_device: the update the previous launch left in
+// state_dev is applied instead. state_dev: device, 256 bytes: 16 float64 (the
+// update), the same as 16 float32, then 9 ticket words (zero before the first launch; every launch
+// leaves them zero). The launch posts {32 sums, 16 update, status} to
+// mail_data (host-mapped, kMailDoubles float64) and publishes mail_seq.
+int o3dmi_internal_icp_search_solve(
+        const o3dmi_nns_t* nns, void* src_dev, const double* transformation,
+        int xf_from_device, int64_t n, int robust_kernel,
+        double scaling_parameter, double shape_parameter,
+        int64_t* corr_out_dev, void* state_dev, double* mail_data,
+        int* mail_flag, int mail_seq, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(state_dev && mail_data && mail_flag, "null argument");
+    GnTail tail = {};
+    tail.xf_out = (double*)state_dev;
+    tail.xf_in = !transformation && xf_from_device ? (const double*)state_dev
+                                                   : nullptr;
+    tail.tickets = (int*)((double*)state_dev + 24);
+    tail.mail_data = mail_data;
+    tail.mail_flag = mail_flag;
+    tail.mail_seq = mail_seq;
+    return LaunchSearchAccumulate(nns, src_dev, transformation, nullptr, n, 0,
+                                  robust_kernel, scaling_parameter,
+                                  shape_parameter, corr_out_dev, nullptr,
+                                  nullptr, nullptr, 0, &tail, stream);
 }
 
 int o3dmi_transform_points(const double* transformation, void* points_dev,

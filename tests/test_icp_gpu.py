@@ -1397,3 +1397,63 @@ def test_library_rccl_communicator_single_rank():
         Comm.uninstall()
     assert np.array_equal(plain.transformation, with_comm.transformation)
     comm.destroy()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_in_launch_gauss_newton_step_equals_the_host_solved_iteration(dtype):
+    """O3DMI_ICP_DEVICE_SOLVE=1 (opt-in, measured not faster -- see
+    host/registration.cpp): a point-to-plane iteration as ONE launch. The last
+    workgroup of the search launch adds the partial rows (FinalSumKernel's
+    order), solves the 6x6 system and leaves the update on the device, and the
+    driver queues iteration k + 1 before it has read iteration k. Against the
+    default two-launch iteration with the solve on the host: same iteration
+    counts, per-iteration fitness / rmse and pose equal to the rounding of the
+    float64 sums (the two paths cut the partial rows differently) and of
+    sin / cos (device vs host libm), single- and multi-scale, zero iterations,
+    a scale that stops early; repeated runs are bit-identical."""
+    import os
+    _lib, reg = _gpu()
+    p = _pair(60000, seed=11, dtype=dtype)
+    src = torch.from_numpy(p["source"]).cuda()
+    tgt = torch.from_numpy(p["target"]).cuda()
+    nrm = torch.from_numpy(p["target_normals"]).cuda()
+    cases = [([-1.0], [reg.ICPConvergenceCriteria(1e-6, 1e-6, 30)], [0.07]),
+             ([0.05, 0.025, 0.0125],
+              [reg.ICPConvergenceCriteria(1e-6, 1e-6, n) for n in (20, 10, 5)],
+              [0.15, 0.075, 0.0375]),
+             ([-1.0], [reg.ICPConvergenceCriteria(1e-6, 1e-6, 0)], [0.07]),
+             ([0.05, -1.0], [reg.ICPConvergenceCriteria(0.5, 0.5, 4),
+                             reg.ICPConvergenceCriteria(1e-9, 1e-9, 3)],
+              [0.15, 0.07])]
+
+    def run(vs, crit, md):
+        log = []
+        r = reg.multi_scale_icp(
+            src.clone(), tgt, nrm, vs, crit, md,
+            callback_after_iteration=lambda d: log.append(
+                (d["iteration_index"], d["scale_index"],
+                 d["scale_iteration_index"], d["fitness"], d["inlier_rmse"])))
+        torch.cuda.synchronize()
+        return r, log
+
+    for vs, crit, md in cases:
+        slow, slog = run(vs, crit, md)
+        os.environ["O3DMI_ICP_DEVICE_SOLVE"] = "1"
+        try:
+            fast, flog = run(vs, crit, md)
+            again, alog = run(vs, crit, md)
+        finally:
+            del os.environ["O3DMI_ICP_DEVICE_SOLVE"]
+        assert np.array_equal(fast.transformation, again.transformation)
+        assert flog == alog
+        assert fast.num_iterations == slow.num_iterations, (vs, dtype)
+        assert fast.converged == slow.converged
+        assert len(flog) == len(slog) == fast.num_iterations
+        for a, b in zip(flog, slog):
+            assert a[:3] == b[:3]
+            assert abs(a[3] - b[3]) <= 1e-12 and abs(a[4] - b[4]) <= 1e-12
+        ang, tr = _pose_err(fast.transformation, slow.transformation)
+        assert ang <= 1e-12 and tr <= 1e-12, (ang, tr)
+        assert abs(fast.fitness - slow.fitness) <= 1e-12
+        assert abs(fast.inlier_rmse - slow.inlier_rmse) <= 1e-12
+        assert torch.equal(fast.correspondence_set, slow.correspondence_set)

@@ -114,7 +114,8 @@ def test_covariances_and_normals_match_oracle(dtype):
         stream()), "normals")
     want = orc.normals_from_covariances(want_cov)
     got = nrm.cpu().numpy()
-    assert_normals_match(got, want, want_cov, dtype)
+    # a sparse cloud: most neighbourhoods are small or line-like
+    assert_normals_match(got, want, want_cov, dtype, min_checked=0.25)
     # degenerate neighbourhoods: < 3 neighbours -> identity covariance -> the
     # z axis; points on a plane z = const -> +-z
     few = np.where(wcnt < 3)[0]

@@ -1,13 +1,10 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests -q -m gpu -x -s 2>&1 | tail -40 > gpurun_out/r3a_pytest.log
-echo "pytest rc=$?" >> gpurun_out/r3a_pytest.log
-for n in 2 4 8; do
-  timeout 600 python bench.py --gpus $n --dist-backend gloo --steps 2 --warmup 1 --batch 1000 --no-pmc --no-secondary --no-cpu-baseline > gpurun_out/r3_dryrun_n$n.json 2> gpurun_out/r3_dryrun_n$n.err
-  echo "dryrun $n rc=$?"
-done
-timeout 300 python bench.py --emulate-world 8 --steps 5 --warmup 1 > gpurun_out/r3a_emulate_w8.json 2> gpurun_out/r3a_emulate_w8.err
-timeout 300 python bench.py --emulate-world 2 --steps 5 --warmup 1 > gpurun_out/r3a_emulate_w2.json 2> gpurun_out/r3a_emulate_w2.err
-timeout 600 python bench.py > gpurun_out/r3a_bench.json 2> gpurun_out/r3a_bench.err
-echo "bench rc=$?"
-tail -c 600 gpurun_out/r3a_pytest.log
+python tools/ab_gn.py 2>&1 | tail -40
+timeout 600 python -m pytest tests/test_configs_gpu.py -q -m gpu -s -k "frame_sharded_8_ranks" 2>&1 | grep -v "^$" | tail -30
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_fast -o fast --output-format csv -- $GRAFT_REPO_ROOT/examples/icp_slam 60 640 480 > /dev/null 2>&1
+O3DMI_ICP_HOST_SOLVE=1 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_slow -o slow --output-format csv -- $GRAFT_REPO_ROOT/examples/icp_slam 60 640 480 > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+find gpurun_out/prof_fast gpurun_out/prof_slow -name "*kernel_stats.csv" | head
+for f in $(find gpurun_out/prof_fast gpurun_out/prof_slow -name "*kernel_stats.csv"); do echo "== $f"; head -8 $f | cut -c1-160; done
