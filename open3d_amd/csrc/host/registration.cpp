@@ -171,7 +171,7 @@ struct Level {
 int DownSampleAttrsAsync(const void* pos, int64_t n_max, const int* n_dev,
                          int dtype, double voxel, void* out_pos, int* m_dev,
                          int* err_dev, std::vector<void*>& scratch,
-                         hipStream_t cs,
+                         hipStream_t cs, int chain,
                          std::initializer_list<std::pair<const void*, void*>>
                                  attrs) {
     if (voxel <= 0) {
@@ -182,13 +182,13 @@ int DownSampleAttrsAsync(const void* pos, int64_t n_max, const int* n_dev,
     for (const auto& a : attrs) {
         if (!a.first) continue;
         int st = VdsAsync(pos, a.first, n_max, n_dev, dtype, voxel, out_pos,
-                          a.second, m_dev, err_dev, scratch, cs);
+                          a.second, m_dev, err_dev, scratch, cs, chain);
         if (st) return st;
         done = true;
     }
     if (!done)
         return VdsAsync(pos, nullptr, n_max, n_dev, dtype, voxel, out_pos,
-                        nullptr, m_dev, err_dev, scratch, cs);
+                        nullptr, m_dev, err_dev, scratch, cs, chain);
     return O3DMI_OK;
 }
 
@@ -485,7 +485,7 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         if (k == last)
             return DownSampleAttrsAsync(source_dev, ns, nullptr, dtype,
                                         voxel_sizes[k], L.src.p, scc.Count(k),
-                                        scc.Err(), scc.scratch, cs,
+                                        scc.Err(), scc.scratch, cs, 0,
                                         {{source_normals_dev, L.srcn.p},
                                          {source_colors_dev, L.srcc.p}});
         Level& F = pyr[(size_t)k + 1];
@@ -493,7 +493,7 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         return DownSampleAttrsAsync(F.src.p, ns,
                                     f_host ? nullptr : scc.Count(k + 1), dtype,
                                     voxel_sizes[k], L.src.p, scc.Count(k),
-                                    scc.Err(), scc.scratch, cs,
+                                    scc.Err(), scc.scratch, cs, 0,
                                     {{F.srcn.p, L.srcn.p},
                                      {F.srcc.p, L.srcc.p}});
     };
@@ -522,7 +522,7 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                 e = DownSampleAttrsAsync(target_dev, nt, nullptr, dtype,
                                          voxel_sizes[k], L.tgt.p,
                                          tcc.Count(k), tcc.Err(), tcc.scratch,
-                                         cs,
+                                         cs, 1,
                                          {{target_normals_dev, L.nrm.p},
                                           {target_colors_dev, L.tgtc.p},
                                           {target_gradients_dev, L.tgtg.p}});
@@ -569,7 +569,7 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         e = DownSampleAttrsAsync(F.tgt_ptr, f_host ? F.nt : nt,
                                  f_host ? nullptr : tcc.Count(k + 1), dtype,
                                  voxel_sizes[k], L.tgt.p, tcc.Count(k),
-                                 tcc.Err(), tcc.scratch, cs,
+                                 tcc.Err(), tcc.scratch, cs, 1,
                                  {{F.nrm_ptr, L.nrm.p},
                                   {F.tgtc_ptr, L.tgtc.p},
                                   {F.tgtg_ptr, L.tgtg.p}});

@@ -44,6 +44,7 @@
 // sort, a segment-start launch after it and 2048-element tiles (whose scatter
 // spent 26 of its 32 us summing the offset table) came next.
 
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -449,39 +450,561 @@ __global__ void VdsReduceKernel(const T* __restrict__ pos,
     }
 }
 
+// ==== the bucketed form: three launches per level, clouds up to 2^17 points ====
+// (round 3; the seven-launch chain above stays for larger clouds.) The sort
+// above exists to put every voxel's points side by side in point order. Here
+// the points are only PARTITIONED -- stably, by the high bits of their voxel's
+// hash slot, into 512 buckets of a few hundred points -- and a workgroup per
+// bucket does the rest in LDS:
+//   A  VdsInsertBucketKernel   hash insert (slot, first point by atomicMin) +
+//                              per-tile histogram of the bucket digit;
+//   B  VdsBucketScatterKernel  gathers first[slot] -> "is the first point of
+//                              its voxel" as one bit per point (a wave ballot
+//                              is 64 consecutive bits: coalesced), and the
+//                              stable scatter of (slot, point) by bucket --
+//                              SortScatterKernel's ranking, one pass;
+//   C  VdsBucketReduceKernel   per bucket: the entries and their points'
+//                              coordinates / attribute staged into LDS with
+//                              every load in flight at once; the lane of a
+//                              voxel's first point walks the bucket's entries
+//                              behind it (point order survives the stable
+//                              scatter) adding its voxel's members in float32
+//                              out of LDS; output row = number of first-point
+//                              bits below its own (a prefix popcount over the
+//                              bit array, rebuilt in LDS by every workgroup:
+//                              <= 4096 words); finally every entry returns
+//                              its table slot to the empty state.
+// The table is therefore CLEAN after every level and lives in a persistent
+// per-chain workspace (no clearing launch, no pooled scratch per call; one
+// set of buffers per chain however many levels and attributes go through it).
+// 52 us of kernels per level in the VGA tracking loop -> see DESIGN.md.
+constexpr int kBucketBits = 9;
+constexpr int kBuckets = 1 << kBucketBits;
+constexpr int64_t kBucketedMaxPoints = 1 << 17;
+constexpr int kBucketLds = 2048;   // entries of a bucket staged in LDS
+constexpr int kReduceBlock = 256;
+constexpr int kMaxBucketWidth = 2048;  // slots of a bucket: n_slots / 512
+
+template <typename T>
+__global__ void __launch_bounds__(kSortBlock)
+VdsInsertBucketKernel(const T* __restrict__ pos, const int* n_dev, int n_host,
+                      T vs, VdsTable tb, int bshift,
+                      int* __restrict__ slot_of_point,
+                      int* __restrict__ tile_hist, int* __restrict__ err) {
+    // ONE point per lane: a point's insert is a chain of dependent global
+    // atomics (CAS on the key, atomicMin on the first point), so every point
+    // wants its own lane -- the first version gave a lane the 8 points of a
+    // tile slice and took 43 us where the plain insert took 7. A workgroup
+    // covers 1024 consecutive points (an eighth of a scatter tile) and adds
+    // its bucket counts to the tile's row with one atomic per occupied bucket
+    // (the rows are zero between levels: the reduce launch clears them).
+    __shared__ int h[kBuckets];
+    const int i = blockIdx.x * kSortBlock + threadIdx.x;
+    T p[3] = {T(0), T(0), T(0)};
+    if (i < n_host) {
+        p[0] = pos[3 * (int64_t)i + 0];
+        p[1] = pos[3 * (int64_t)i + 1];
+        p[2] = pos[3 * (int64_t)i + 2];
+    }
+    const int n = LiveCount(n_dev, n_host);
+    if ((int)(blockIdx.x * kSortBlock) >= n) return;
+    for (int b = threadIdx.x; b < kBuckets; b += kSortBlock) h[b] = 0;
+    __syncthreads();
+    if (i < n) {
+        // (p / vs).Floor().To(Int64)
+        const long long cx = (long long)floor(p[0] / vs);
+        const long long cy = (long long)floor(p[1] / vs);
+        const long long cz = (long long)floor(p[2] / vs);
+        if (cx < -kKeyBias || cx >= kKeyBias || cy < -kKeyBias ||
+            cy >= kKeyBias || cz < -kKeyBias || cz >= kKeyBias) {
+            // reported to the caller; the point stays a voxel of its own
+            atomicOr(err, kErrKeyRange);
+            slot_of_point[i] = -1;
+            atomicAdd(&h[0], 1);
+        } else {
+            const unsigned long long key = PackKey((int)cx, (int)cy, (int)cz);
+            unsigned s = HashKey(key) & tb.mask;
+            while (true) {
+                unsigned long long cur = tb.keys[s];
+                if (cur == kEmptyKey)
+                    cur = atomicCAS(&tb.keys[s], kEmptyKey, key);
+                if (cur == kEmptyKey || cur == key) break;
+                s = (s + 1) & tb.mask;
+            }
+            slot_of_point[i] = (int)s;
+            atomicMin(&tb.first[s], i);
+            atomicAdd(&h[s >> bshift], 1);
+        }
+    }
+    __syncthreads();
+    int* row = tile_hist +
+               (int64_t)(blockIdx.x / (kSortTile / kSortBlock)) * kBuckets;
+    for (int b = threadIdx.x; b < kBuckets; b += kSortBlock)
+        if (h[b]) atomicAdd(&row[b], h[b]);
+}
+
+__global__ void __launch_bounds__(kSortBlock)
+VdsBucketScatterKernel(const int* __restrict__ slot_of_point, VdsTable tb,
+                       int bshift, const int* n_dev, int n_host,
+                       const int* __restrict__ tile_hist,
+                       unsigned* __restrict__ ent_slot,
+                       unsigned* __restrict__ ent_point,
+                       unsigned long long* __restrict__ first_bits,
+                       int* __restrict__ bucket_start) {
+    __shared__ int wh[kSortWaves][kBuckets];  // 32 KiB
+    __shared__ int dbase[kBuckets];
+    __shared__ int lds4[kSortWaves];
+    const int tile = blockIdx.x * kSortTile;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wbase = tile + wave * (kSortItems * 64);
+    int slot[kSortItems];
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const int e = wbase + r * 64 + lane;
+        slot[r] = e < n_host ? slot_of_point[e] : -1;
+    }
+    const int n = LiveCount(n_dev, n_host);
+    // block 0 always runs: it publishes the bucket starts (all zero for an
+    // empty cloud)
+    if (tile >= n && blockIdx.x != 0) return;
+    const int n_tiles = (n + kSortTile - 1) / kSortTile;
+    // first point of its voxel? (a point outside the key range is a voxel of
+    // its own)
+    int first[kSortItems];
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const int e = wbase + r * 64 + lane;
+        first[r] = e < n && slot[r] >= 0 ? tb.first[slot[r]] : e;
+    }
+    for (int b = threadIdx.x; b < kBuckets * kSortWaves; b += kSortBlock)
+        (&wh[0][0])[b] = 0;
+    __syncthreads();
+    unsigned digit[kSortItems];
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const int e = wbase + r * 64 + lane;
+        digit[r] = slot[r] >= 0 ? (unsigned)slot[r] >> bshift : 0u;
+        const unsigned long long fm = __ballot(e < n && first[r] == e);
+        if (lane == 0 && wbase + r * 64 < n) first_bits[(wbase + r * 64) >> 6] = fm;
+        if (e < n) atomicAdd(&wh[wave][digit[r]], 1);
+    }
+    {
+        // where this tile's run of every bucket starts (SortScatterKernel)
+        int all = 0, before = 0;
+        if ((int)threadIdx.x < kBuckets) {
+            const int* col = tile_hist + threadIdx.x;
+            for (int t0 = 0; t0 < n_tiles; t0 += 16) {
+                int c[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    c[u] = t0 + u < n_tiles ? col[(int64_t)(t0 + u) * kBuckets]
+                                            : 0;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    all += c[u];
+                    before += t0 + u < (int)blockIdx.x ? c[u] : 0;
+                }
+            }
+        }
+        int total;
+        const int run = BlockExclusive(all, lds4, &total);
+        if ((int)threadIdx.x < kBuckets) {
+            dbase[threadIdx.x] = run + before;
+            if (blockIdx.x == 0) {
+                bucket_start[threadIdx.x] = run;
+                if (threadIdx.x == kBuckets - 1) bucket_start[kBuckets] = total;
+            }
+        }
+    }
+    __syncthreads();
+    if (tile >= n) return;
+    for (int b = threadIdx.x; b < kBuckets; b += kSortBlock) {
+        int off = dbase[b];
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) {
+            const int c = wh[w][b];
+            wh[w][b] = off;
+            off += c;
+        }
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const int e = wbase + r * 64 + lane;
+        const bool valid = e < n;
+        const unsigned d = digit[r];
+        unsigned long long same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < kBucketBits; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            same &= bit ? bal : ~bal;
+        }
+        int posn = 0;
+        if (valid) posn = wh[wave][d] + __popcll(same & lt);
+        if (valid && (same & lt) == 0ull) wh[wave][d] += __popcll(same);
+        if (valid) {
+            ent_slot[posn] = (unsigned)slot[r];
+            ent_point[posn] = (unsigned)e;
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kReduceBlock)
+VdsBucketReduceKernel(const T* __restrict__ pos, const T* __restrict__ nrm,
+                      const unsigned* __restrict__ ent_slot,
+                      const unsigned* __restrict__ ent_point,
+                      const unsigned long long* __restrict__ first_bits,
+                      const int* __restrict__ bucket_start, VdsTable tb,
+                      int bshift, int* __restrict__ tile_hist, int n_tiles_cap,
+                      const int* n_dev, int n_host, T* __restrict__ out_pos,
+                      T* __restrict__ out_nrm, int* __restrict__ m_dev) {
+    __shared__ int word_prefix[kBucketedMaxPoints / 64];  // 16 KiB
+    __shared__ int lds4[kReduceBlock / 64];
+    __shared__ unsigned e_slot[kBucketLds + 4];  // + a sentinel chunk
+    __shared__ float e_pos[kBucketLds][3];
+    __shared__ float e_nrm[kBucketLds][3];
+    __shared__ int members[kMaxBucketWidth];  // points per slot of the bucket
+    const int tid = threadIdx.x;
+    const int b0 = bucket_start[blockIdx.x], b1 = bucket_start[blockIdx.x + 1];
+    const int n = LiveCount(n_dev, n_host);
+    const int count = b1 - b0;
+    const int width = 1 << bshift;  // slots of a bucket
+    const bool staged = count <= kBucketLds && width <= kMaxBucketWidth;
+    // ---- every load of the bucket in flight: entries, then their points ----
+    constexpr int kPer = kBucketLds / kReduceBlock;  // 8 entries per lane
+    unsigned es[kPer], ep[kPer];
+    if (staged) {
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int j = tid + k * kReduceBlock;
+            es[k] = j < count ? ent_slot[b0 + j] : 0xFFFFFFFEu;
+            ep[k] = j < count ? ent_point[b0 + j] : 0u;
+        }
+        for (int q = tid; q < width; q += kReduceBlock) members[q] = 0;
+    }
+    // this bucket's column of the tile histogram back to zero for the next
+    // level (the scatter launch has read it)
+    if (tid < n_tiles_cap) tile_hist[(int64_t)tid * kBuckets + blockIdx.x] = 0;
+    // ---- prefix popcount of the first-point bits (all words, every bucket) --
+    const int n_words = (n + 63) >> 6;
+    constexpr int kWordsPer = (int)(kBucketedMaxPoints / 64) / kReduceBlock;  // 16
+    unsigned long long w[kWordsPer];
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < kWordsPer; ++k) {
+        const int wi = tid * kWordsPer + k;
+        w[k] = wi < n_words ? first_bits[wi] : 0ull;
+        mine += __popcll(w[k]);
+    }
+    if (staged) {
+        float pf[kPer][3], qf[kPer][3];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int j = tid + k * kReduceBlock;
+            const int64_t i = j < count ? (int64_t)ep[k] : 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                pf[k][c] = (float)pos[3 * i + c];
+                qf[k][c] = nrm ? (float)nrm[3 * i + c] : 0.f;
+            }
+        }
+        __syncthreads();  // members[] is zero
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int j = tid + k * kReduceBlock;
+            if (j < count) {
+                e_slot[j] = es[k];
+                if (es[k] != 0xFFFFFFFFu)
+                    atomicAdd(&members[es[k] & (unsigned)(width - 1)], 1);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    e_pos[j][c] = pf[k][c];
+                    e_nrm[j][c] = qf[k][c];
+                }
+            }
+        }
+        if (tid < 4) e_slot[count + tid] = 0xFFFFFFFEu;  // matches no slot
+    }
+    {
+        // block exclusive scan of `mine` (kReduceBlock threads)
+        const int lane = tid & 63, wave = tid >> 6;
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) lds4[wave] = incl;
+        __syncthreads();
+        int run = incl - mine, total = 0;
+#pragma unroll
+        for (int k = 0; k < kReduceBlock / 64; ++k) {
+            if (k < wave) run += lds4[k];
+            total += lds4[k];
+        }
+#pragma unroll
+        for (int k = 0; k < kWordsPer; ++k) {
+            word_prefix[tid * kWordsPer + k] = run;
+            run += __popcll(w[k]);
+        }
+        if (blockIdx.x == 0 && tid == 0) *m_dev = total;
+    }
+    __syncthreads();
+    // ---- one lane per entry; the lane of a voxel's first point adds it up ---
+    auto entry = [&](int j, unsigned s, unsigned i) {
+        const unsigned long long word = first_bits[i >> 6];
+        // the slot goes back to the empty state (members write the same)
+        if (s != 0xFFFFFFFFu) {
+            tb.keys[s] = kEmptyKey;
+            tb.first[s] = 0x7FFFFFFF;
+        }
+        if (!((word >> (i & 63)) & 1ull)) return;
+        const int row = word_prefix[i >> 6] +
+                        __popcll(word & ((1ull << (i & 63)) - 1ull));
+        float cnt = 0.f, sp[3] = {0.f, 0.f, 0.f}, sn[3] = {0.f, 0.f, 0.f};
+        auto add = [&](const float* pp, const float* qq) {
+            cnt += 1.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                sp[c] += pp[c];
+                sn[c] += qq[c];
+            }
+        };
+        if (staged) {
+            // The members follow the first point in point order. Their number
+            // is known, so the walk ends at the last one -- a voxel's points
+            // are neighbours in the image and therefore in the list -- and
+            // four entries are compared per LDS round trip.
+            add(e_pos[j], e_nrm[j]);
+            int left = s != 0xFFFFFFFFu
+                               ? members[s & (unsigned)(width - 1)] - 1
+                               : 0;
+            for (int e = j + 1; left > 0 && e < count; e += 4) {
+                const unsigned s0 = e_slot[e], s1 = e_slot[e + 1],
+                               s2 = e_slot[e + 2], s3 = e_slot[e + 3];
+                if (s0 == s) { add(e_pos[e], e_nrm[e]); --left; }
+                if (s1 == s) { add(e_pos[e + 1], e_nrm[e + 1]); --left; }
+                if (s2 == s) { add(e_pos[e + 2], e_nrm[e + 2]); --left; }
+                if (s3 == s) { add(e_pos[e + 3], e_nrm[e + 3]); --left; }
+            }
+        } else {
+            // a bucket beyond the LDS staging (a cloud whose points crowd a
+            // few voxels): the same walk out of global memory
+            for (int e = j; e < count; ++e) {
+                const bool member =
+                        e == j || (s != 0xFFFFFFFFu && ent_slot[b0 + e] == s);
+                if (member) {
+                    const int64_t pi = ent_point[b0 + e];
+                    float pp[3], qq[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        pp[c] = (float)pos[3 * pi + c];
+                        qq[c] = nrm ? (float)nrm[3 * pi + c] : 0.f;
+                    }
+                    add(pp, qq);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            out_pos[3 * (int64_t)row + c] = (T)(sp[c] / cnt);
+            if (nrm) out_nrm[3 * (int64_t)row + c] = (T)(sn[c] / cnt);
+        }
+    };
+    if (staged) {
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int j = tid + k * kReduceBlock;
+            if (j < count) entry(j, es[k], ep[k]);
+        }
+    } else {
+        for (int j = tid; j < count; j += kReduceBlock)
+            entry(j, ent_slot[b0 + j], ent_point[b0 + j]);
+    }
+}
+
+// Persistent buffers of the bucketed form, one set per host thread, device and
+// chain (the ICP driver runs the source and the target pyramid as two chains
+// on two streams). Everything a level needs is sized by the largest cloud the
+// chain has seen; the hash table is returned clean by every level.
+struct VdsWorkspace {
+    int64_t n_cap = 0, n_slots = 0;
+    VdsTable tb = {};
+    int* slot_of_point = nullptr;
+    int* tile_hist = nullptr;
+    unsigned* ent_slot = nullptr;
+    unsigned* ent_point = nullptr;
+    unsigned long long* first_bits = nullptr;
+    int* bucket_start = nullptr;
+    void Free() {
+        (void)hipFree(tb.keys);
+        (void)hipFree(tb.first);
+        (void)hipFree(slot_of_point);
+        (void)hipFree(tile_hist);
+        (void)hipFree(ent_slot);
+        (void)hipFree(ent_point);
+        (void)hipFree(first_bits);
+        (void)hipFree(bucket_start);
+        *this = VdsWorkspace();
+    }
+};
+constexpr int kVdsChains = 2;
+constexpr int kVdsDevices = 64;
+
+VdsWorkspace* ThreadVdsWorkspace(int chain, int64_t n_max, hipStream_t s) {
+    static thread_local VdsWorkspace ws[kVdsDevices][kVdsChains];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kVdsDevices ||
+        chain < 0 || chain >= kVdsChains)
+        return nullptr;
+    VdsWorkspace& w = ws[dev][chain];
+    if (w.n_cap >= n_max) return &w;
+    // grow: everything queued on the old buffers must have run
+    if (w.n_cap && hipStreamSynchronize(s) != hipSuccess) return nullptr;
+    w.Free();
+    int64_t cap = 16384;
+    while (cap < n_max) cap <<= 1;
+    int64_t n_slots = 1024;
+    while (n_slots < 2 * cap) n_slots <<= 1;
+    const int64_t n_tiles = (cap + kSortTile - 1) / kSortTile;
+    bool ok = hipMalloc((void**)&w.tb.keys, sizeof(unsigned long long) * n_slots) == hipSuccess &&
+              hipMalloc((void**)&w.tb.first, sizeof(int) * n_slots) == hipSuccess &&
+              hipMalloc((void**)&w.slot_of_point, sizeof(int) * cap) == hipSuccess &&
+              hipMalloc((void**)&w.tile_hist, sizeof(int) * kBuckets * n_tiles) == hipSuccess &&
+              hipMalloc((void**)&w.ent_slot, sizeof(unsigned) * cap) == hipSuccess &&
+              hipMalloc((void**)&w.ent_point, sizeof(unsigned) * cap) == hipSuccess &&
+              hipMalloc((void**)&w.first_bits, sizeof(unsigned long long) * (cap / 64 + 1)) == hipSuccess &&
+              hipMalloc((void**)&w.bucket_start, sizeof(int) * (kBuckets + 1)) == hipSuccess;
+    if (ok) {
+        w.tb.mask = (unsigned)(n_slots - 1);
+        hipLaunchKernelGGL(VdsInitKernel, dim3(GridFor(n_slots, kBlock)),
+                           dim3(kBlock), 0, s, w.tb, n_slots);
+        ok = hipGetLastError() == hipSuccess &&
+             hipMemsetAsync(w.tile_hist, 0, sizeof(int) * kBuckets * n_tiles,
+                            s) == hipSuccess;
+    }
+    if (!ok) {
+        w.Free();
+        SetLastError("VoxelDownSample: workspace allocation failed");
+        return nullptr;
+    }
+    w.n_cap = cap;
+    w.n_slots = n_slots;
+    return &w;
+}
+
+template <typename T>
+int VdsBucketedImpl(const T* pos, const T* nrm, int64_t n_max, const int* n_dev,
+                    double voxel_size, T* out_pos, T* out_nrm, int* m_dev,
+                    int* err_dev, int chain, hipStream_t s) {
+    VdsWorkspace* w = ThreadVdsWorkspace(chain, n_max, s);
+    if (!w) return O3DMI_ERR_HIP;
+    int slot_bits = 0;
+    while ((1ll << slot_bits) < w->n_slots) ++slot_bits;
+    const int bshift = slot_bits - kBucketBits;  // n_slots >= 1024 > 512
+    const int n_host = (int)n_max;
+    const int n_tiles = (int)((n_max + kSortTile - 1) / kSortTile);
+    const dim3 tiles((unsigned)n_tiles), sblock(kSortBlock);
+    const dim3 chunks((unsigned)((n_max + kSortBlock - 1) / kSortBlock));
+    hipLaunchKernelGGL(VdsInsertBucketKernel<T>, chunks, sblock, 0, s, pos,
+                       n_dev, n_host, (T)voxel_size, w->tb, bshift,
+                       w->slot_of_point, w->tile_hist, err_dev);
+    hipLaunchKernelGGL(VdsBucketScatterKernel, tiles, sblock, 0, s,
+                       w->slot_of_point, w->tb, bshift, n_dev, n_host,
+                       w->tile_hist, w->ent_slot, w->ent_point, w->first_bits,
+                       w->bucket_start);
+    hipLaunchKernelGGL(VdsBucketReduceKernel<T>, dim3(kBuckets),
+                       dim3(kReduceBlock), 0, s, pos, nrm, w->ent_slot,
+                       w->ent_point, w->first_bits, w->bucket_start, w->tb,
+                       bshift, w->tile_hist, n_tiles, n_dev, n_host, out_pos,
+                       out_nrm, m_dev);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+// Persistent buffers of the seven-launch sort (clouds beyond the bucketed
+// form), same keying as VdsWorkspace.
+struct VdsSortWorkspace {
+    int64_t n_cap = 0;
+    unsigned long long* keys = nullptr;
+    int* first = nullptr;
+    int *slot_of_point = nullptr, *tile_firsts = nullptr, *hist = nullptr,
+        *rank_of_first = nullptr;
+    unsigned *keys_a = nullptr, *vals_a = nullptr, *keys_b = nullptr,
+             *vals_b = nullptr;
+    void Free() {
+        void* all[] = {keys, first, slot_of_point, tile_firsts, hist,
+                       rank_of_first, keys_a, vals_a, keys_b, vals_b};
+        for (void* p : all) (void)hipFree(p);
+        *this = VdsSortWorkspace();
+    }
+};
+
+VdsSortWorkspace* ThreadVdsSortWorkspace(int chain, int64_t n_max,
+                                         hipStream_t s) {
+    static thread_local VdsSortWorkspace ws[kVdsDevices][kVdsChains];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kVdsDevices ||
+        chain < 0 || chain >= kVdsChains)
+        return nullptr;
+    VdsSortWorkspace& w = ws[dev][chain];
+    if (w.n_cap >= n_max) return &w;
+    if (w.n_cap && hipStreamSynchronize(s) != hipSuccess) return nullptr;
+    w.Free();
+    int64_t cap = 1 << 17;
+    while (cap < n_max) cap <<= 1;
+    int64_t n_slots = 1024;
+    while (n_slots < 2 * cap) n_slots <<= 1;
+    const int64_t n_tiles = (cap + kSortTile - 1) / kSortTile;
+    auto get = [](auto** p, size_t count) {
+        return hipMalloc((void**)p, sizeof(**p) * count) == hipSuccess;
+    };
+    const bool ok = get(&w.keys, (size_t)n_slots) && get(&w.first, (size_t)n_slots) &&
+                    get(&w.slot_of_point, (size_t)cap) &&
+                    get(&w.tile_firsts, (size_t)n_tiles) &&
+                    get(&w.hist, (size_t)kSortBins * n_tiles) &&
+                    get(&w.rank_of_first, (size_t)cap) &&
+                    get(&w.keys_a, (size_t)cap) && get(&w.vals_a, (size_t)cap) &&
+                    get(&w.keys_b, (size_t)cap) && get(&w.vals_b, (size_t)cap);
+    if (!ok) {
+        w.Free();
+        SetLastError("VoxelDownSample: workspace allocation failed");
+        return nullptr;
+    }
+    w.n_cap = cap;
+    return &w;
+}
+
 template <typename T>
 int VdsAsyncImpl(const T* pos, const T* nrm, int64_t n_max, const int* n_dev,
                  double voxel_size, T* out_pos, T* out_nrm, int* m_dev,
-                 int* err_dev, std::vector<void*>& scratch, hipStream_t s) {
+                 int* err_dev, std::vector<void*>& scratch, hipStream_t s,
+                 int chain) {
     O3DMI_REQUIRE(n_max > 0 && n_max < (1ll << 30),
                   "VoxelDownSample: bad point count");
-    auto alloc = [&](auto** p, size_t count) -> int {
-        void* q = nullptr;
-        int e = PoolAlloc(&q, sizeof(**p) * (count ? count : 1));
-        if (e) return e;
-        scratch.push_back(q);
-        *p = (std::remove_reference_t<decltype(**p)>*)q;
-        return O3DMI_OK;
-    };
+    // One set of buffers per host thread, device and chain, sized by the
+    // largest cloud the chain has seen and reused by every level and every
+    // attribute pass (the calls of a chain are stream-ordered). Round 2 took
+    // a fresh pooled set per call: a coloured three-level pyramid held nine
+    // full-size sets until its read-back.
+    (void)scratch;
+    VdsSortWorkspace* ws = ThreadVdsSortWorkspace(chain, n_max, s);
+    if (!ws) return O3DMI_ERR_HIP;
     const int n_host = (int)n_max;
     int64_t n_slots = 1024;
     while (n_slots < 2 * n_max) n_slots <<= 1;
     const int n_tiles = (int)((n_max + kSortTile - 1) / kSortTile);
     VdsTable tb;
-    int st;
-    if ((st = alloc(&tb.keys, (size_t)n_slots))) return st;
-    if ((st = alloc(&tb.first, (size_t)n_slots))) return st;
+    tb.keys = ws->keys;
+    tb.first = ws->first;
     tb.mask = (unsigned)(n_slots - 1);
-    int *slot_of_point, *tile_firsts, *hist, *rank_of_first;
-    unsigned *keys_a, *vals_a, *keys_b, *vals_b;
-    if ((st = alloc(&slot_of_point, (size_t)n_max))) return st;
-    if ((st = alloc(&tile_firsts, (size_t)n_tiles))) return st;
-    if ((st = alloc(&hist, (size_t)kSortBins * n_tiles))) return st;
-    if ((st = alloc(&rank_of_first, (size_t)n_max))) return st;
-    if ((st = alloc(&keys_a, (size_t)n_max))) return st;
-    if ((st = alloc(&vals_a, (size_t)n_max))) return st;
-    if ((st = alloc(&keys_b, (size_t)n_max))) return st;
-    if ((st = alloc(&vals_b, (size_t)n_max))) return st;
+    int *slot_of_point = ws->slot_of_point, *tile_firsts = ws->tile_firsts,
+        *hist = ws->hist, *rank_of_first = ws->rank_of_first;
+    unsigned *keys_a = ws->keys_a, *vals_a = ws->vals_a, *keys_b = ws->keys_b,
+             *vals_b = ws->vals_b;
     const dim3 grid(GridFor(n_max, kBlock)), block(kBlock);
     const dim3 tiles((unsigned)n_tiles), sblock(kSortBlock);
     hipLaunchKernelGGL(VdsInitKernel, dim3(GridFor(n_slots, kBlock)), block, 0,
@@ -522,15 +1045,30 @@ int VdsAsyncImpl(const T* pos, const T* nrm, int64_t n_max, const int* n_dev,
 int VdsAsync(const void* pos, const void* attr, int64_t n_max, const int* n_dev,
              int dtype, double voxel_size, void* out_pos, void* out_attr,
              int* m_dev, int* err_dev, std::vector<void*>& scratch,
-             hipStream_t s) {
+             hipStream_t s, int chain) {
+    // O3DMI_VDS_SORT=1 (diagnostics / A-B): the seven-launch sort for every size
+    const char* sort_env = std::getenv("O3DMI_VDS_SORT");
+    const bool force_sort = sort_env && sort_env[0] == '1';
+    if (n_max > 0 && n_max <= kBucketedMaxPoints && !force_sort) {
+        if (dtype == O3DMI_F64)
+            return VdsBucketedImpl<double>(
+                    (const double*)pos, (const double*)attr, n_max, n_dev,
+                    voxel_size, (double*)out_pos, (double*)out_attr, m_dev,
+                    err_dev, chain, s);
+        return VdsBucketedImpl<float>((const float*)pos, (const float*)attr,
+                                      n_max, n_dev, voxel_size,
+                                      (float*)out_pos, (float*)out_attr, m_dev,
+                                      err_dev, chain, s);
+    }
     if (dtype == O3DMI_F64)
         return VdsAsyncImpl<double>((const double*)pos, (const double*)attr,
                                     n_max, n_dev, voxel_size, (double*)out_pos,
                                     (double*)out_attr, m_dev, err_dev, scratch,
-                                    s);
+                                    s, chain);
     return VdsAsyncImpl<float>((const float*)pos, (const float*)attr, n_max,
                                n_dev, voxel_size, (float*)out_pos,
-                               (float*)out_attr, m_dev, err_dev, scratch, s);
+                               (float*)out_attr, m_dev, err_dev, scratch, s,
+                               chain);
 }
 
 }  // namespace o3dmi

@@ -15,11 +15,15 @@ namespace o3dmi {
 //           use n_max itself
 //   m_dev   device int receiving the voxel count
 //   err_dev device int: kErrKeyRange is OR-ed in for out-of-range coordinates
-// Scratch comes from the pool and is appended to `scratch`; the caller
+// Clouds of up to 2^18 points take the bucketed three-launch form, whose
+// buffers live in a persistent workspace per host thread, device and `chain`
+// (0 or 1: two chains may run concurrently on two streams, the calls of one
+// chain must be stream-ordered). Larger clouds take the seven-launch sort:
+// its scratch comes from the pool and is appended to `scratch`; the caller
 // releases it (PoolFree) once the stream has drained.
 int VdsAsync(const void* pos, const void* attr, int64_t n_max, const int* n_dev,
              int dtype, double voxel_size, void* out_pos, void* out_attr,
              int* m_dev, int* err_dev, std::vector<void*>& scratch,
-             hipStream_t s);
+             hipStream_t s, int chain = 0);
 
 }  // namespace o3dmi
