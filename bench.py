@@ -122,6 +122,10 @@ def parse():
                     help="skip the ICP legs (configs[0] / configs[2])")
     ap.add_argument("--pmc-inner", action="store_true",
                     help=argparse.SUPPRESS)  # the run rocprofv3 wraps
+    ap.add_argument("--leg", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--no-configs4", action="store_true",
+                    help="skip the configs[4] leg (4 mm voxels, > 500 k "
+                         "blocks, ICP on 2 x 1 M points)")
     return ap.parse_args()
 
 
@@ -227,19 +231,26 @@ PMC_PASSES = {
 }
 
 
-def _pmc_pass(counters, tmp, tag):
+def _pmc_pass(counters, tmp, tag, inner=None, want=None):
     """One rocprofv3 --pmc run (kernel trace only beside it, as the pool
-    requires); returns {counter: mean per FrameStepKernel launch}, n."""
+    requires); returns {counter: mean per launch of the wanted kernel}, n.
+    Default: the headline stream and the fused colour instantiation of
+    FrameStepKernel; `inner` / `want(name)` select another command / kernel.
+    "_avg_kernel_ns" = the kernel's mean duration in the same run's trace."""
     out_dir = os.path.join(tmp, tag)
-    inner = [sys.executable, os.path.abspath(__file__), "--pmc-inner",
-             "--steps", "2", "--warmup", "1", "--batch", "200",
-             "--no-cpu-baseline", "--no-pmc", "--no-secondary"]
+    if inner is None:
+        inner = [sys.executable, os.path.abspath(__file__), "--pmc-inner",
+                 "--steps", "2", "--warmup", "1", "--batch", "200",
+                 "--no-cpu-baseline", "--no-pmc", "--no-secondary"]
+    if want is None:
+        # the fused colour instantiation: <u16, u16, true, div, form>
+        want = lambda name: KERNEL in name and ", true," in name
     cmd = ["rocprofv3", "--pmc"] + counters + \
         ["--kernel-trace", "--output-format", "csv", "-d", out_dir, "-o",
          "pmc", "--"] + inner
     env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True,
-                       text=True, timeout=420)
+                       text=True, timeout=600)
     files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"),
                       recursive=True)
     if r.returncode != 0 or not files:
@@ -250,14 +261,51 @@ def _pmc_pass(counters, tmp, tag):
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 name = row["Kernel_Name"]
-                # the fused colour instantiation: <u16, u16, true, div, form>
-                if KERNEL not in name or ", true," not in name:
+                if not want(name):
                     continue
                 acc[row["Counter_Name"]] = acc.get(row["Counter_Name"], 0.0) + \
                     float(row["Counter_Value"])
                 disp.add(row["Dispatch_Id"])
     n = max(1, len(disp))
-    return {k: v / n for k, v in acc.items()}, n
+    res = {k: v / n for k, v in acc.items()}
+    durs = []
+    for f in glob.glob(os.path.join(out_dir, "**", "*kernel_trace.csv"),
+                       recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if want(row["Kernel_Name"]):
+                    durs.append(int(row["End_Timestamp"]) -
+                                int(row["Start_Timestamp"]))
+    if durs:
+        res["_avg_kernel_ns"] = float(np.mean(durs))
+    return res, n
+
+
+def hbm_counters(inner, want):
+    """FETCH_SIZE / WRITE_SIZE passes over `inner` for the kernels `want`
+    selects -> {traffic bytes per launch, kernel us (under the profiler),
+    frac_hbm} or {error}."""
+    if shutil.which("rocprofv3") is None:
+        return {"error": "rocprofv3 not on PATH"}
+    tmp = tempfile.mkdtemp(prefix="o3dmi_pmc4_", dir="/tmp")
+    try:
+        rd, n1 = _pmc_pass(["FETCH_SIZE"], tmp, "fetch", inner, want)
+        wr, _ = _pmc_pass(["WRITE_SIZE"], tmp, "write", inner, want)
+        traffic = 2.0 * rd.get("FETCH_SIZE", 0.0) * 1024.0 + \
+            wr.get("WRITE_SIZE", 0.0) * 1024.0
+        ns = rd.get("_avg_kernel_ns") or wr.get("_avg_kernel_ns")
+        out = {"traffic_bytes_per_launch": traffic,
+               "traffic_read_bytes": 2.0 * rd.get("FETCH_SIZE", 0.0) * 1024.0,
+               "traffic_write_bytes": wr.get("WRITE_SIZE", 0.0) * 1024.0,
+               "launches_profiled": n1,
+               "kernel_us_under_profiler": ns / 1e3 if ns else None}
+        if ns:
+            out["frac_hbm"] = traffic / (ns * 1e-9) / 1e9 / HBM_PEAK_GBS
+        return out
+    except Exception as e:
+        return {"error": str(e)[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def pmc_live():
@@ -298,6 +346,261 @@ def pmc_committed():
 
 # ---------------------------------------------------------------------------
 # secondary: the ICP half of the metric
+
+
+# ---------------------------------------------------------------------------
+# configs[4] on one GPU: 4 mm voxels, the scene scaled to 8 m, a map of more
+# than 524 287 blocks (the reference's `index_t = int` linear voxel index
+# overflows there, cpp/open3d/t/geometry/kernel/VoxelBlockGridImpl.h:40; ours
+# is int64) whose working set is far beyond the 256 MB Infinity Cache, and
+# point-to-plane ICP on two 1 M-point clouds.
+
+C4_VOXEL = 0.004
+C4_DEPTH_SCALE = 500.0    # the same images read at twice the metric depth
+C4_DEPTH_MAX = 6.0
+C4_CAPACITY = 1 << 21     # 2 M blocks = 96 GiB of voxel state
+C4_BALLAST = 540000       # active blocks before the stream starts
+C4_FRAMES_PER_LAUNCH = 4
+C4_FRAME_STEP = 5         # every 5th frame of the 1000-frame stream
+
+
+def configs4_integrate(n_frames=200, event_stride=1):
+    """One pass of n_frames frames into the big map; returns the measurement."""
+    import ctypes as C
+    import torch
+    from open3d_amd import _lib, geometry, synthetic
+    from open3d_amd.core import stream
+    dev = torch.device("cuda", torch.cuda.current_device())
+    K = synthetic.intrinsics(W, H)
+    ds, cs, Ts = [], [], []
+    for k in range(0, n_frames * C4_FRAME_STEP, C4_FRAME_STEP):
+        d, c, _, T = synthetic.render_frames(k, 1, W, H, device=dev)
+        ds.append(d[0].contiguous())
+        cs.append(c[0].contiguous())
+        T2 = T[0].copy()
+        T2[:3, 3] *= 2.0          # the world scaled by 2
+        Ts.append(T2)
+    g = geometry.VoxelBlockGrid(["tsdf", "weight", "color"],
+                                [torch.float32, torch.uint16, torch.uint16],
+                                [1, 1, 3], C4_VOXEL, RES, C4_CAPACITY)
+    # ballast: 540 k active blocks far from the scene, so that every block of
+    # the stream gets a buffer index beyond the reference's int range
+    i = torch.arange(C4_BALLAST, dtype=torch.int32, device=dev)
+    keys = torch.stack([100000 + i % 1000, 100000 + i // 1000,
+                        torch.full_like(i, 100000)], 1).contiguous()
+    _lib.check(_lib.lib().o3dmi_hash_activate(
+        g.hashmap()._h, _lib.ptr(keys), C4_BALLAST, None, None, None,
+        stream()), "activate ballast")
+    assert g.hashmap().size() == C4_BALLAST
+    batch = g.prepare_frames(ds, cs, K, K, Ts)
+    n_launch = n_frames // C4_FRAMES_PER_LAUNCH
+    g.profile_begin(n_launch + 8, event_stride)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g.integrate_frames(batch, depth_scale=C4_DEPTH_SCALE,
+                       depth_max=C4_DEPTH_MAX, trunc_voxel_multiplier=TRUNC,
+                       frames_per_launch=C4_FRAMES_PER_LAUNCH)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = g.profile_end()
+    hm = g.hashmap()
+    n_blocks = hm.size()
+    act = hm.active_buf_indices()
+    max_index = int(act.max().item())
+    launches = max(1, prof["launches"])
+    k_ms = prof["integrate_ms"] / launches
+    min_bytes = (prof["distinct_blocks"] * (BYTES_PER_BLOCK +
+                                            BLOCK_HEADER_BYTES) +
+                 prof["frames"] * (IMAGE_BYTES + 2 * W * H * 8)) / launches
+    alg_bytes = (prof["block_frames"] * (BYTES_PER_BLOCK + BLOCK_HEADER_BYTES)
+                 + prof["frames"] * IMAGE_BYTES) / launches
+    out = {"workload": "%d frames (every %dth of the 640x480 stream, scene "
+                       "scaled x2: depth scale %g, depth_max %g m) -> 4 mm "
+                       "VoxelBlockGrid(16^3), capacity %d blocks, %d blocks "
+                       "active before the stream (ballast), one cold pass"
+                       % (n_frames, C4_FRAME_STEP, C4_DEPTH_SCALE,
+                          C4_DEPTH_MAX, C4_CAPACITY, C4_BALLAST),
+           "frames_per_s": n_frames / dt, "ms_per_frame": dt / n_frames * 1e3,
+           "frames_per_launch": C4_FRAMES_PER_LAUNCH,
+           "active_blocks": int(n_blocks),
+           "stream_blocks": int(n_blocks - C4_BALLAST),
+           "voxel_state_bytes_of_the_stream": int(n_blocks - C4_BALLAST) *
+                                              BYTES_PER_BLOCK // 2,
+           "max_buffer_index": max_index,
+           "max_linear_voxel_index": (max_index + 1) * RES ** 3 - 1,
+           "reference_index_limit": 2 ** 31 - 1,
+           "avg_blocks_per_frame": prof["block_frames"] /
+                                   max(1, prof["frames"]),
+           "roofline": {"bound": "hbm", "kernel": KERNEL, "unit": "GB/s",
+                        "peak": HBM_PEAK_GBS, "avg_kernel_ms": k_ms,
+                        "fused_minimum_bytes_per_launch": min_bytes,
+                        "achieved": min_bytes / (k_ms * 1e-3) / 1e9
+                        if k_ms > 0 else None,
+                        "frac": min_bytes / (k_ms * 1e-3) / 1e9 /
+                                HBM_PEAK_GBS if k_ms > 0 else None,
+                        "equivalent_gbps": alg_bytes / (k_ms * 1e-3) / 1e9
+                        if k_ms > 0 else None,
+                        "distinct_blocks_per_launch":
+                            prof["distinct_blocks"] / launches}}
+    del g
+    torch.cuda.empty_cache()
+    return out
+
+
+def configs4_leg():
+    import importlib.util
+    out = {}
+    try:
+        r = configs4_integrate()
+        inner = [sys.executable, os.path.abspath(__file__), "--leg",
+                 "configs4-integrate"]
+        r["roofline"].update(hbm_counters(
+            inner, lambda name: KERNEL in name and ", true," in name))
+        out["integrate_4mm_over_500k_blocks"] = r
+    except Exception as e:
+        out["integrate_4mm_over_500k_blocks"] = {"error": str(e)[:300]}
+    try:
+        spec = importlib.util.spec_from_file_location(
+            "bench_slam", os.path.join(ROOT, "tools", "bench_slam.py"))
+        bs = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bs)
+        r = bs.mode_icp(types.SimpleNamespace(points=1000000, repeat=5,
+                                              estimation="p2plane",
+                                              no_cpu=True))
+        icp = {k: r[k] for k in ("ms_per_icp", "iterations",
+                                 "ms_per_iteration", "fitness", "inlier_rmse",
+                                 "pose_err_vs_ground_truth_rad_m", "roofline")
+               if k in r}
+        inner = [sys.executable, os.path.join(ROOT, "tools", "bench_slam.py"),
+                 "--mode", "icp", "--points", "1000000", "--repeat", "2",
+                 "--no-cpu"]
+        k = hbm_counters(inner, lambda name: "SearchAccumulateKernel" in name)
+        if "error" not in k and k.get("kernel_us_under_profiler"):
+            bpi = (icp.get("roofline") or {}).get("bytes_per_point_iteration")
+            if bpi:
+                k["algorithmic_bytes_per_launch"] = 1000000 * bpi
+                k["frac_algorithmic"] = 1000000 * bpi / (
+                    k["kernel_us_under_profiler"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+        icp["search_kernel"] = k
+        out["icp_2x1M"] = icp
+    except Exception as e:
+        out["icp_2x1M"] = {"error": str(e)[:300]}
+    return out
+
+
+# ---------------------------------------------------------------------------
+# per-kernel accounting of the tracking loop (configs[2]) from a kernel trace
+
+KERNEL_FAMILIES = [
+    ("search_G8", "SearchAccumulateKernel<float, 8,"),
+    ("search_G16", "SearchAccumulateKernel<float, 16,"),
+    ("search_G32", "SearchAccumulateKernel<float, 32,"),
+    ("final_sum", "FinalSumKernel"),
+    ("voxel_down_sample", ("Vds", "SortHist", "SortScatter")),
+    ("index_build", ("CountKernel", "AssignRangesKernel", "ScatterKernel")),
+    ("ray_cast", ("RayCastKernel", "EstimateRangeKernel", "RangeFillKernel")),
+    ("unproject", ("UnprojectKernel", "TransformNormalsKernel")),
+    ("integrate", ("FrameStepKernel", "ExportListKeysKernel")),
+    ("fill_copy", ("__amd_rocclr_fillBuffer", "__amd_rocclr_copyBuffer")),
+]
+
+
+def cpp_kernel_rooflines(exe, w, h, n_frames, levels):
+    """Runs examples/icp_slam once under `rocprofv3 --kernel-trace --stats` and
+    returns, per kernel family of the tracking frame: launches and us per
+    frame, SURVEY 8(d) algorithmic bytes per launch and the fraction of the HBM
+    peak they amount to over the family's mean launch duration; plus launches
+    per frame and the share of the loop's wall time a kernel was running.
+    `levels`: the per-level sizes of the Python leg's accounting (same stream
+    shape): [{source_points, target_points, visited_records_per_query}, ...]
+    coarse -> fine."""
+    if shutil.which("rocprofv3") is None:
+        return {"error": "rocprofv3 not on PATH"}
+    tmp = tempfile.mkdtemp(prefix="o3dmi_ktrace_", dir="/tmp")
+    try:
+        cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format",
+               "csv", "-d", tmp, "-o", "icp", "--", exe, str(n_frames), str(w),
+               str(h)]
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
+                           capture_output=True, text=True, timeout=600)
+        tr = glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"),
+                       recursive=True)
+        if r.returncode != 0 or not tr:
+            return {"error": "rocprofv3 rc %d %s" % (r.returncode,
+                                                     r.stderr[-200:])}
+        rows = []
+        with open(tr[0]) as fh:
+            for row in csv.DictReader(fh):
+                rows.append((int(row["Start_Timestamp"]),
+                             int(row["End_Timestamp"]), row["Kernel_Name"]))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    rows.sort()
+    # the tracking loop = from the first search launch to the last kernel
+    first = next((i for i, x in enumerate(rows) if "SearchAccumulate" in x[2]),
+                 0)
+    loop = rows[first:]
+    frames = max(1, n_frames - 1)
+    span = loop[-1][1] - loop[0][0]
+    busy, cur_end = 0, loop[0][0]
+    for a0, a1, _ in loop:            # union of the kernel intervals
+        if a1 > cur_end:
+            busy += a1 - max(a0, cur_end)
+            cur_end = a1
+    lv = {k: v for k, v in zip(("search_G32", "search_G16", "search_G8"),
+                               levels)} if levels and len(levels) == 3 else {}
+    pix = w * h
+    cloud = (w // 2) * (h // 2)
+
+    def alg_bytes(fam):
+        # SURVEY 8(d) (DESIGN.md section 3), per LAUNCH of the family
+        if fam in lv:
+            q = lv[fam]["source_points"]
+            return q * (12 + 12 + 27 * 8 +
+                        lv[fam]["visited_records_per_query"] * 16 + 32)
+        if fam == "final_sum":
+            return 512 * 32 * 8
+        if fam == "voxel_down_sample" and lv:
+            # per launch of a chain of ~7 (3 bucketed): 12 B x 2 + 8 B slot +
+            # 2 passes x 16 B + 24 B attributes per input point, spread over
+            # the launches of a level; input sizes: frame cloud, then levels
+            n_in = [cloud] + [l["source_points"] for l in levels[::-1][:2]]
+            return sum(n * 88 for n in n_in) / 3.0 / 7.0
+        if fam == "index_build" and lv:
+            return sum(l["target_points"] for l in levels) * 64 / 3.0 / 3.0
+        if fam == "ray_cast":
+            return pix * (7.5 * 6 + 48 + 16) / 3.0
+        if fam == "unproject":
+            return cloud * (4 + 12 + 24) * 2 / 3.0
+        return None
+
+    fams = {}
+    for name, pat in KERNEL_FAMILIES:
+        pats = (pat,) if isinstance(pat, str) else pat
+        sel = [x for x in loop if any(p in x[2] for p in pats)]
+        if not sel:
+            continue
+        tot = sum(x[1] - x[0] for x in sel) / 1e3
+        avg = tot / len(sel)
+        ent = {"launches_per_frame": len(sel) / frames,
+               "us_per_frame": tot / frames, "avg_us": avg}
+        b = alg_bytes(name)
+        if b:
+            ent["algorithmic_bytes_per_launch"] = b
+            ent["achieved_gbps"] = b / (avg * 1e-6) / 1e9
+            ent["frac"] = ent["achieved_gbps"] / HBM_PEAK_GBS
+        fams[name] = ent
+    return {"kernels": fams, "launches_per_frame": len(loop) / frames,
+            "kernel_us_per_frame": sum(x[1] - x[0] for x in loop) / 1e3 / frames,
+            "wall_us_per_frame_under_trace": span / 1e3 / frames,
+            "gpu_busy_frac": busy / span if span > 0 else None,
+            "basis": "rocprofv3 --kernel-trace of examples/icp_slam (this "
+                     "run), from the first search launch to the last kernel; "
+                     "frac = SURVEY 8(d) algorithmic bytes per launch / mean "
+                     "launch duration / 8 TB/s; level sizes and visited "
+                     "records per query from the Python leg's accounting of "
+                     "the same stream shape; a search launch also writes the "
+                     "moved query back (12 B)"}
 
 
 def secondary_legs():
@@ -350,6 +653,12 @@ def secondary_legs():
                 med = dict(runs[len(runs) // 2])  # the median run
                 med["frames_per_s_of_5_runs"] = [d["frames_per_s"]
                                                  for d in runs]
+                try:
+                    med["per_kernel"] = cpp_kernel_rooflines(
+                        exe, w, h, 60,
+                        (out[tag].get("roofline") or {}).get("levels"))
+                except Exception as e:  # evidence, not the product
+                    med["per_kernel"] = {"error": str(e)[:200]}
                 err = med
             out[tag + "_cpp_caller"] = err
     return out
@@ -360,6 +669,11 @@ def secondary_legs():
 
 def main():
     a = parse()
+    if a.leg == "configs4-integrate":  # the run rocprofv3 wraps
+        import torch
+        torch.cuda.set_device(0)
+        print(json.dumps(configs4_integrate(n_frames=48, event_stride=0)))
+        return
     maybe_spawn(a)
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -705,15 +1019,20 @@ def main():
                        other},
         "roofline": roof,
     }
+    frames_cpu = None
+    if e_world == 1 and not a.no_cpu_baseline:
+        frames_cpu = [(depths[i].cpu().numpy(), colors[i].cpu().numpy())
+                      for i in range(min(64, len(depths)))]
     if e_world == 1 and not a.no_secondary:
         try:
             out["secondary"] = secondary_legs()
         except Exception as e:
             out["secondary"] = {"error": str(e)[:300]}
-    if e_world == 1 and not a.no_cpu_baseline:
-        nb = 64
-        frames_cpu = [(depths[i].cpu().numpy(), colors[i].cpu().numpy())
-                      for i in range(min(nb, len(depths)))]
+        if not a.no_configs4:
+            del depths, colors, g
+            torch.cuda.empty_cache()
+            out["secondary"]["configs4"] = configs4_leg()
+    if frames_cpu is not None:
         out["cpu_baseline"] = cpu_baseline(frames_cpu, K, Ts, a.cpu_seconds)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -299,8 +299,6 @@ int RunRank(int argc, char** argv, int rank, int world, o3dmi_comm_t* comm,
     float* model_nrm = DeviceAlloc<float>(cloud_cap * 3);
     float* frame_pts = DeviceAlloc<float>(cloud_cap * 3);
     int32_t* counts = DeviceAlloc<int32_t>(2);
-    int32_t* host_counts = nullptr;  // pinned: the two cloud sizes
-    CHECK_HIP(hipHostMalloc((void**)&host_counts, sizeof(int32_t) * 2));
 
     const double voxel_sizes[3] = {0.05, 0.025, 0.0125};
     const o3dmi_icp_criteria_t criteria[3] = {
@@ -324,8 +322,9 @@ int RunRank(int argc, char** argv, int rank, int world, o3dmi_comm_t* comm,
 
     double worst_translation = 0, worst_angle = 0;
     long iterations = 0;
-    // host time per phase (the loop has host waits after the block touch and
-    // after the two clouds, and inside the ICP call; Integrate is queued)
+    // host time per phase (the loop's host waits are inside the ICP call: its
+    // pyramid counts and one per Gauss-Newton iteration; the clouds' sizes
+    // stay on the device and Integrate is queued)
     double phase[5] = {0, 0, 0, 0, 0};
     auto now = [] {
         return std::chrono::duration<double, std::micro>(
@@ -354,21 +353,24 @@ int RunRank(int argc, char** argv, int rank, int world, o3dmi_comm_t* comm,
         CHECK_O3D(o3dmi_unproject(depth_dev[(size_t)k], O3DMI_U16, H, W,
                                   nullptr, frame_pts, nullptr, counts + 1, K, X,
                                   depth_scale, depth_max, stride, stream));
-        CHECK_HIP(hipMemcpyAsync(host_counts, counts, sizeof(int32_t) * 2,
-                                 hipMemcpyDeviceToHost, stream));
-        CHECK_HIP(hipStreamSynchronize(stream));
-        const int64_t nm = host_counts[0], nf = host_counts[1];
         const double p2 = now();
         double Xinv[16];
         InvertRigid(X, Xinv);  // camera -> world rotates the normals
-        CHECK_O3D(o3dmi_transform_normals(Xinv, model_nrm, nm, O3DMI_F32,
-                                          stream));
+        // The two cloud sizes stay on the device (no read-back, no stream
+        // drain per frame): the normals are rotated over the whole buffer --
+        // rows past the live count are never read -- and the ICP driver takes
+        // the sizes from the device words (the host arguments are then the
+        // buffer capacities).
+        CHECK_O3D(o3dmi_transform_normals(Xinv, model_nrm, (int64_t)cloud_cap,
+                                          O3DMI_F32, stream));
         // ---- track ----------------------------------------------------------
         o3dmi_registration_result_t r;
+        CHECK_O3D(o3dmi_registration_set_device_counts(counts + 1, counts));
         CHECK_O3D(o3dmi_registration_multiscale_icp(
-                frame_pts, nf, model_pts, model_nrm, nm, O3DMI_F32, 3,
-                voxel_sizes, criteria, max_dist, nullptr, /*L2Loss*/ 0, 1.0,
-                1.0, nullptr, nullptr, nullptr, nullptr, nullptr, &r, stream));
+                frame_pts, (int64_t)cloud_cap, model_pts, model_nrm,
+                (int64_t)cloud_cap, O3DMI_F32, 3, voxel_sizes, criteria,
+                max_dist, nullptr, /*L2Loss*/ 0, 1.0, 1.0, nullptr, nullptr,
+                nullptr, nullptr, nullptr, &r, stream));
         iterations += r.num_iterations;
         const double p3 = now();
         // points_world = r.T (X_prev^-1 p_cam)  =>  X_k = X_prev r.T^-1
@@ -438,7 +440,6 @@ int RunRank(int argc, char** argv, int rank, int world, o3dmi_comm_t* comm,
     (void)hipFree(model_nrm);
     (void)hipFree(frame_pts);
     (void)hipFree(counts);
-    (void)hipHostFree(host_counts);
     CHECK_O3D(o3dmi_vbg_destroy(grid));
     for (int k = 0; k < n_frames; ++k) {
         (void)hipFree(depth_dev[(size_t)k]);

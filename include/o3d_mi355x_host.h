@@ -164,6 +164,21 @@ int o3dmi_registration_multiscale_icp(
         int64_t* correspondences_dev, o3dmi_registration_result_t* result,
         o3dmi_stream_t stream);
 
+/* Sizes that are still on the device. A tracking loop produces its clouds
+ * with o3dmi_unproject, which leaves the point counts in device words; reading
+ * them back costs the loop a stream drain per frame. After this call the NEXT
+ * o3dmi_registration_multiscale_icp[_ex] of the calling host thread takes the
+ * live source / target sizes from ns_dev / nt_dev (int32, written by work
+ * queued earlier on the call's stream; NULL = the host argument as usual) and
+ * reads its ns / nt arguments as the capacities of the buffers. With a
+ * down-sampled finest level (voxel_sizes[last] > 0, the tracking
+ * configuration) nothing waits for them: the pyramid launches bound themselves
+ * by the device words. Without one the driver fetches them first. A live size
+ * of zero is then reported through the usual "0 correspondence" result. The
+ * reference has no counterpart (its Tensor shapes live on the host). */
+int o3dmi_registration_set_device_counts(const int32_t* ns_dev,
+                                         const int32_t* nt_dev);
+
 /* TransformationEstimation choice for o3dmi_registration_multiscale_icp_ex
  * (t/pipelines/registration/TransformationEstimation.h:28-34). */
 typedef enum {

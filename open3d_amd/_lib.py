@@ -297,6 +297,7 @@ PROTOTYPES.update({
     "o3dmi_set_comm": (_i32, [_vp]),
     "o3dmi_set_rccl_comm": (_i32, [_vp]),
     "o3dmi_set_icp_level_sharding": (_i32, [_i32]),
+    "o3dmi_registration_set_device_counts": (_i32, [_vp, _vp]),
     "o3dmi_comm_allreduce_sum_f64": (_i32, [_vp, _vp, _i64, _vp]),
     "o3dmi_comm_allgather": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "o3dmi_comm_alltoallv": (_i32, [_vp, _vp, C.POINTER(_i64),

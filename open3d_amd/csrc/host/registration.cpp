@@ -110,6 +110,18 @@ extern "C" int o3dmi_set_device_allreduce(o3dmi_allreduce_device_t fn,
     return O3DMI_OK;
 }
 
+// Device-resident cloud sizes for the NEXT driver call of this host thread
+// (o3dmi_registration_set_device_counts).
+static thread_local const int32_t* g_ns_dev = nullptr;
+static thread_local const int32_t* g_nt_dev = nullptr;
+
+extern "C" int o3dmi_registration_set_device_counts(const int32_t* ns_dev,
+                                                    const int32_t* nt_dev) {
+    g_ns_dev = ns_dev;
+    g_nt_dev = nt_dev;
+    return O3DMI_OK;
+}
+
 // With a communicator installed (o3dmi_set_comm): who shards the source cloud.
 // 0: the caller -- it passes ITS shard (the semantics of the two hooks);
 // 1: the driver -- every rank passes the WHOLE source, the pyramid is built
@@ -193,38 +205,59 @@ int DownSampleAttrsAsync(const void* pos, int64_t n_max, const int* n_dev,
 }
 
 // Device-side level counts of one cloud's pyramid: [level] voxel counts, then
-// one word of error flags. Read back once, at the end of the chain.
+// one word of error flags, in a persistent buffer per host thread, device and
+// chain (zero when allocated; the posting launch re-zeroes the error word).
+// Read once, at the end of the chain, through the chain's host mailbox: no
+// clearing fill, no copy, no stream synchronisation per call.
+constexpr int kMaxDevices = 64;
+int CurrentDevice() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return -1;
+    return d;
+}
+constexpr int kMaxScales = 30;
 struct ChainCounts {
     int* dev = nullptr;
     int levels = 0;
-    std::vector<void*> scratch;
-    int Init(int n_levels, hipStream_t cs) {
+    int chain = 0;
+    std::vector<void*> scratch;  // pooled scratch of the level launches
+    int Init(int n_levels, int chain_id, hipStream_t cs) {
+        static thread_local int* bufs[kMaxDevices][2] = {};
+        O3DMI_REQUIRE(n_levels >= 1 && n_levels <= kMaxScales,
+                      "too many scales");
+        const int d = CurrentDevice();
+        O3DMI_REQUIRE(d >= 0 && (chain_id == 0 || chain_id == 1),
+                      "bad device / chain");
+        int*& b = bufs[d][chain_id];
+        if (!b) {
+            O3DMI_HIP_CHECK(hipMalloc((void**)&b,
+                                      sizeof(int) * (kMaxScales + 2)));
+            O3DMI_HIP_CHECK(hipMemsetAsync(b, 0,
+                                           sizeof(int) * (kMaxScales + 2), cs));
+        }
+        dev = b;
         levels = n_levels;
-        void* q = nullptr;
-        int st = PoolAlloc(&q, sizeof(int) * (size_t)(n_levels + 1));
-        if (st) return st;
-        dev = (int*)q;
-        scratch.push_back(q);
-        O3DMI_HIP_CHECK(hipMemsetAsync(dev, 0,
-                                       sizeof(int) * (size_t)(n_levels + 1),
-                                       cs));
+        chain = chain_id;
         return O3DMI_OK;
     }
     int* Count(int level) { return dev + level; }
     int* Err() { return dev + levels; }
-    // waits for the chain, returns the counts and releases the scratch
+    // waits for the chain and returns the counts
     int Fetch(std::vector<int>& out, hipStream_t cs) {
         out.assign((size_t)levels + 1, 0);
-        hipError_t e = hipMemcpyAsync(out.data(), dev,
-                                      sizeof(int) * (size_t)(levels + 1),
-                                      hipMemcpyDeviceToHost, cs);
-        if (e == hipSuccess) e = hipStreamSynchronize(cs);
+        Mailbox* mb = ThreadMailbox(1 + chain);
+        O3DMI_REQUIRE(mb != nullptr, "host mailbox allocation failed");
+        const int seq = ++mb->seq;
+        int st = PostCountsAsync(dev, levels + 1, mb->data, mb->flag, seq, cs);
+        if (st) return st;
+        hipError_t e = MailboxWait(mb, seq, cs);
         Release(cs);
         if (e != hipSuccess) {
             SetLastError(std::string("pyramid read-back: ") +
                          hipGetErrorString(e));
             return O3DMI_ERR_HIP;
         }
+        for (int k = 0; k <= levels; ++k) out[(size_t)k] = (int)mb->data[k];
         if (out[(size_t)levels] & kErrKeyRange) {
             SetLastError("VoxelDownSample: voxel coordinate outside +-2^20");
             return O3DMI_ERR_KEY_RANGE;
@@ -236,19 +269,12 @@ struct ChainCounts {
         (void)hipStreamSynchronize(cs);  // pooled blocks: stream drained
         for (void* p : scratch) PoolFree(p);
         scratch.clear();
-        dev = nullptr;
     }
 };
 
 // One side stream and event per host thread AND device for the overlapped
 // pyramid build (a thread may switch devices between calls: per-device pool,
 // VoxelBlockGrid::To(device)).
-constexpr int kMaxDevices = 64;
-int CurrentDevice() {
-    int d = 0;
-    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return -1;
-    return d;
-}
 hipStream_t SideStream() {
     static thread_local hipStream_t side[kMaxDevices] = {};
     const int d = CurrentDevice();
@@ -341,6 +367,10 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         o3dmi_allreduce_sum_t allreduce, void* allreduce_user,
         int64_t* correspondences_dev, o3dmi_registration_result_t* result,
         o3dmi_stream_t stream) {
+    // sizes that live on the device (consumed by this call, whatever it does)
+    const int32_t* ns_dev = g_ns_dev;
+    const int32_t* nt_dev = g_nt_dev;
+    g_ns_dev = g_nt_dev = nullptr;
     // AssertInputMultiScaleICP, Registration.cpp:119-219.
     O3DMI_REQUIRE(result != nullptr, "result is null");
     O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
@@ -460,6 +490,24 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         return O3DMI_OK;
     };
     const bool finest_is_input = voxel_sizes[last] <= 0;
+    if (finest_is_input && (ns_dev || nt_dev)) {
+        // without a down-sampled finest level the sizes size the searches:
+        // they have to come to the host (one small copy and wait)
+        int32_t host_n[2] = {(int32_t)ns, (int32_t)nt};
+        if (ns_dev)
+            O3DMI_HIP_CHECK(hipMemcpyAsync(&host_n[0], ns_dev, sizeof(int32_t),
+                                           hipMemcpyDeviceToHost, s));
+        if (nt_dev)
+            O3DMI_HIP_CHECK(hipMemcpyAsync(&host_n[1], nt_dev, sizeof(int32_t),
+                                           hipMemcpyDeviceToHost, s));
+        O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+        O3DMI_REQUIRE(host_n[0] > 0 && host_n[0] <= ns && host_n[1] > 0 &&
+                              host_n[1] <= nt,
+                      "Source and/or Target pointcloud is empty.");
+        ns = host_n[0];
+        nt = host_n[1];
+        ns_dev = nt_dev = nullptr;
+    }
     ChainCounts scc, tcc;
     struct ChainGuard {
         ChainCounts& c;
@@ -483,8 +531,9 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         if (symmetric && (e = L.srcn.Alloc((size_t)ns * 3 * esz))) return e;
         if (colored && (e = L.srcc.Alloc((size_t)ns * 3 * esz))) return e;
         if (k == last)
-            return DownSampleAttrsAsync(source_dev, ns, nullptr, dtype,
-                                        voxel_sizes[k], L.src.p, scc.Count(k),
+            return DownSampleAttrsAsync(source_dev, ns, (const int*)ns_dev,
+                                        dtype, voxel_sizes[k], L.src.p,
+                                        scc.Count(k),
                                         scc.Err(), scc.scratch, cs, 0,
                                         {{source_normals_dev, L.srcn.p},
                                          {source_colors_dev, L.srcc.p}});
@@ -519,8 +568,8 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                         (e = L.tgtg.Alloc((size_t)nt * 3 * esz)))
                         return e;
                 }
-                e = DownSampleAttrsAsync(target_dev, nt, nullptr, dtype,
-                                         voxel_sizes[k], L.tgt.p,
+                e = DownSampleAttrsAsync(target_dev, nt, (const int*)nt_dev,
+                                         dtype, voxel_sizes[k], L.tgt.p,
                                          tcc.Count(k), tcc.Err(), tcc.scratch,
                                          cs, 1,
                                          {{target_normals_dev, L.nrm.p},
@@ -599,8 +648,8 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
     bool indices_on_side = false;
     {
         ChainGuard sg{scc, s}, tg{tcc, side};
-        if ((st = scc.Init(num_scales, s))) return st;
-        if ((st = tcc.Init(num_scales, side))) return st;
+        if ((st = scc.Init(num_scales, 0, s))) return st;
+        if ((st = tcc.Init(num_scales, 1, side))) return st;
         for (int k = last; k >= 0; --k) {
             if ((st = target_level(k, side))) return st;
             if ((st = source_level(k, s))) return st;

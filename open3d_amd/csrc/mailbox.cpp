@@ -8,9 +8,12 @@
 
 namespace o3dmi {
 
-Mailbox* ThreadMailbox() {
-    thread_local Mailbox mb;
-    thread_local bool tried = false;
+Mailbox* ThreadMailbox(int which) {
+    thread_local Mailbox mbs[kThreadMailboxes];
+    thread_local bool tries[kThreadMailboxes] = {};
+    if (which < 0 || which >= kThreadMailboxes) return nullptr;
+    Mailbox& mb = mbs[which];
+    bool& tried = tries[which];
     if (!tried) {
         tried = true;
         void* p = nullptr;

@@ -20,7 +20,11 @@ struct Mailbox {
 // One mailbox per host thread, allocated on first use and kept for the life of
 // the process (a driver call is synchronous on its host thread, so a thread
 // never has two iterations in flight). nullptr if the allocation failed.
-Mailbox* ThreadMailbox();
+// `which`: 0 = the per-iteration sums of a driver; 1, 2 = the level counts of
+// the source / target pyramid chain of the ICP driver (three independent
+// sequences: the chains run on two streams while nothing else is waited for).
+constexpr int kThreadMailboxes = 3;
+Mailbox* ThreadMailbox(int which = 0);
 
 // Blocks until the kernel that was given `seq` has posted. Returns hipSuccess,
 // or the stream's error if the stream finished / failed without posting.

@@ -51,6 +51,7 @@
 
 #include "common.h"
 #include "o3d_mi355x_host.h"
+#include "mailbox.h"
 #include "vds.h"
 
 namespace o3dmi {
@@ -1041,6 +1042,31 @@ int VdsAsyncImpl(const T* pos, const T* nrm, int64_t n_max, const int* n_dev,
 }
 
 }  // namespace
+
+// The level counts of a pyramid chain straight to the host: one tiny launch at
+// the end of the chain writes them into host-mapped memory and publishes a
+// sequence word the host spins on (mailbox.h) -- instead of a copy and a
+// stream synchronisation per chain. Every word is returned to zero for the
+// next chain (the buffer is persistent; a level whose input is empty writes
+// no count).
+__global__ void PostCountsKernel(int* __restrict__ counts, int n,
+                                 double* mail_data, int* mail_flag,
+                                 int mail_seq) {
+    if ((int)threadIdx.x < n) {
+        mail_data[threadIdx.x] = (double)counts[threadIdx.x];
+        counts[threadIdx.x] = 0;
+    }
+    MailboxPublish(mail_flag, mail_seq);
+}
+
+int PostCountsAsync(int* counts_dev, int n, double* mail_data, int* mail_flag,
+                    int mail_seq, hipStream_t s) {
+    O3DMI_REQUIRE(n >= 1 && n <= 32, "too many levels");
+    hipLaunchKernelGGL(PostCountsKernel, dim3(1), dim3(64), 0, s, counts_dev, n,
+                       mail_data, mail_flag, mail_seq);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
 
 int VdsAsync(const void* pos, const void* attr, int64_t n_max, const int* n_dev,
              int dtype, double voxel_size, void* out_pos, void* out_attr,

@@ -416,7 +416,8 @@ struct IntegParams {
     int rows, cols, resolution;
     int res_shift;  // log2(resolution) when it is a power of two, else -1
     int diag;       // O3DMI_STEP_DIAG (timing experiments, WRONG results):
-                    // 1 = every gather reads record 0, 2 = no state stores
+                    // 1 = every gather reads record 0, 2 = no state stores;
+                    // 3 = no skip of fully rejected waves (RIGHT results)
     float sdf_trunc, depth_max;
     float inv_sdf_trunc;  // RN(1 / sdf_trunc), used by the kFastDiv variant
     const FrameBlock* list;
@@ -999,6 +1000,16 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                     tiny |= ok[2 * p + h] && fabsf(cl) < kDivTiny;
                     touched |= ok[2 * p + h];
                 }
+            }
+            // A wave none of whose voxels takes this frame (all behind the
+            // truncation band, outside the image or at invalid depth) skips
+            // the frame's arithmetic altogether: wave-uniform, nothing of the
+            // state changes for a rejected voxel.
+            if (ip.diag != 3) {
+                bool any = false;
+#pragma unroll
+                for (int v = 0; v < kV; ++v) any |= ok[v];
+                if (__builtin_amdgcn_ballot_w64(any) == 0ull) continue;
             }
             // sdf / sdf_trunc: short form unless a value of the wave is in the
             // underflow range

@@ -26,4 +26,9 @@ int VdsAsync(const void* pos, const void* attr, int64_t n_max, const int* n_dev,
              int* m_dev, int* err_dev, std::vector<void*>& scratch,
              hipStream_t s, int chain = 0);
 
+// counts_dev[0..n) (int) -> mail_data[0..n) (as float64) + sequence word
+// `mail_seq` (mailbox.h), on stream s; the words are zeroed afterwards.
+int PostCountsAsync(int* counts_dev, int n, double* mail_data, int* mail_flag,
+                    int mail_seq, hipStream_t s);
+
 }  // namespace o3dmi

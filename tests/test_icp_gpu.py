@@ -1519,3 +1519,41 @@ def test_voxel_down_sample_bucketed_form_edge_cases(dtype):
     with pytest.raises(Exception):
         reg.voxel_down_sample(torch.from_numpy(far).cuda(), None, 0.01)
     check(np.ascontiguousarray(pts[:5000]), None, 0.03)  # table clean again
+
+
+@pytest.mark.parametrize("voxels", [[0.05, 0.025, 0.0125], [0.05, -1.0]])
+def test_multiscale_icp_with_device_resident_cloud_sizes(voxels):
+    """o3dmi_registration_set_device_counts: the clouds sit in buffers larger
+    than their live sizes (as o3dmi_unproject leaves them) and the sizes are
+    int32 device words; the call must equal the one given exact-size tensors,
+    bit for bit, with a down-sampled finest level (nothing waits for the
+    sizes) and without one (the driver fetches them)."""
+    _lib, reg = _gpu()
+    p = _pair(50000, seed=13)
+    ns, nt, cap = 41234, 47001, 50000
+    src = torch.from_numpy(p["source"]).cuda()
+    tgt = torch.from_numpy(p["target"]).cuda()
+    nrm = torch.from_numpy(p["target_normals"]).cuda()
+    crit = [reg.ICPConvergenceCriteria(1e-6, 1e-6, 10)] * len(voxels)
+    md = [0.15, 0.07] if len(voxels) == 2 else [0.15, 0.075, 0.0375]
+    want = reg.multi_scale_icp(src[:ns].clone(), tgt[:nt].contiguous(),
+                               nrm[:nt].contiguous(), voxels, crit, md)
+    # rows past the live sizes hold junk the call must never look at
+    src_buf = src.clone()
+    src_buf[ns:] = float("nan")
+    tgt_buf, nrm_buf = tgt.clone(), nrm.clone()
+    tgt_buf[nt:] = 1e6
+    nrm_buf[nt:] = float("nan")
+    counts = torch.tensor([ns, nt], dtype=torch.int32, device="cuda")
+    L = _lib.lib()
+    _lib.check(L.o3dmi_registration_set_device_counts(
+        C.c_void_p(counts.data_ptr()), C.c_void_p(counts.data_ptr() + 4)),
+        "set_device_counts")
+    got = reg.multi_scale_icp(src_buf, tgt_buf, nrm_buf, voxels, crit, md)
+    assert np.array_equal(got.transformation, want.transformation)
+    assert got.num_iterations == want.num_iterations
+    assert got.fitness == want.fitness and got.inlier_rmse == want.inlier_rmse
+    # the setting is consumed by one call
+    again = reg.multi_scale_icp(src[:ns].clone(), tgt[:nt].contiguous(),
+                                nrm[:nt].contiguous(), voxels, crit, md)
+    assert np.array_equal(again.transformation, want.transformation)

@@ -286,8 +286,11 @@ def test_cpp_icp_tracking_example_sharded_ranks_through_the_library_comm():
     rounding of the float64 sums (the level pyramid is the unsharded one --
     tests/test_configs_gpu.py checks one call to 1e-9), which over a tracking
     loop with feedback (integrate at the estimated pose, ray cast, track
-    again) can move an iteration count by one: the trajectories are compared
-    at the millimetre."""
+    again) can move an iteration count by one -- and the unprojected clouds
+    come out in a different order on every run (compaction by atomic
+    counter), which moves the float32 voxel means of the pyramid: the
+    trajectories are compared at half a centimetre, the run-to-run spread of
+    the single-rank loop itself."""
     import json
     import subprocess
     import __graft_entry__ as ge
@@ -305,11 +308,11 @@ def test_cpp_icp_tracking_example_sharded_ranks_through_the_library_comm():
     many = run("3", "loopback")
     assert many["ranks"] == 3 and many["poses_identical_on_all_ranks"]
     assert abs(many["max_translation_error_m"] -
-               one["max_translation_error_m"]) < 2e-3
+               one["max_translation_error_m"]) < 5e-3
     assert abs(many["icp_iterations_per_frame"] -
-               one["icp_iterations_per_frame"]) < 1.0
+               one["icp_iterations_per_frame"]) < 2.0
     if torch.cuda.device_count() >= 2:
         rccl = run("2", "rccl")
         assert rccl["poses_identical_on_all_ranks"]
         assert abs(rccl["max_translation_error_m"] -
-                   one["max_translation_error_m"]) < 2e-3
+                   one["max_translation_error_m"]) < 5e-3
