@@ -299,6 +299,44 @@ __device__ __forceinline__ int ClaimSlot(const HashView& hv,
     return -1;
 }
 
+// "Am I the last of `total` workgroups to get here?" -- true in every thread
+// of exactly one workgroup, after all the others have arrived. For hand-offs
+// INSIDE a launch: the data an arriving workgroup leaves for the last one must
+// be write-through (agent-scope atomic / sc1) stores or atomics; they are
+// drained here (s_waitcnt vmcnt(0) in every wave) before the ticket is taken,
+// and the last workgroup reads them with agent-scope loads. No release fence:
+// on this part it writes back the XCD's whole L2. Tickets are two-level, one
+// counter per class (index % 8) and one on top, so that no word sees more
+// than total / 8 arrivals; tickets[0..8] must be zero beforehand and are zero
+// again afterwards.
+__device__ __forceinline__ bool LastArrival(int* tickets, int index,
+                                            int total) {
+    __shared__ int s_last_arrival;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int cls = index & 7;
+        const int in_class = (total - cls + 7) >> 3;
+        const int classes = total < 8 ? total : 8;
+        int last = 0;
+        if (__hip_atomic_fetch_add(&tickets[1 + cls], 1, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT) == in_class - 1) {
+            // this class is complete: its counter back to zero, then up
+            __hip_atomic_store(&tickets[1 + cls], 0, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            last = __hip_atomic_fetch_add(&tickets[0], 1, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT) ==
+                   classes - 1;
+            if (last)
+                __hip_atomic_store(&tickets[0], 0, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_last_arrival = last;
+    }
+    __syncthreads();
+    return s_last_arrival != 0;
+}
+
 // Marks `slot` as touched by frame `bit` of the frame group `stamp`. The word
 // holds (stamp << kTouchBits) | one bit per frame of the group; a word carrying
 // an older stamp is stale and is replaced. Returns true for exactly one caller per

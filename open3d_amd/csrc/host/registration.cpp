@@ -89,6 +89,12 @@ extern "C" int o3dmi_internal_icp_search_solve(
         double scaling_parameter, double shape_parameter,
         int64_t* corr_out_dev, void* state_dev, double* mail_data,
         int* mail_flag, int mail_seq, o3dmi_stream_t stream);
+extern "C" int o3dmi_internal_icp_search_gated(
+        const o3dmi_nns_t* nns, void* src_dev, const double* transformation,
+        const int* inbox, int gate_seq, int64_t n, int robust_kernel,
+        double scaling_parameter, double shape_parameter,
+        int64_t* corr_out_dev, double* mail_data, int* mail_flag, int mail_seq,
+        o3dmi_stream_t stream);
 extern "C" int o3dmi_internal_sums_tail(double* sums32_dev, double t29,
                                         double t30, double t31,
                                         o3dmi_stream_t stream);
@@ -850,6 +856,25 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         gn = ThreadGnState(s);
         fast = ring != nullptr && gn != nullptr;
     }
+    // O3DMI_ICP_GATE=1: host solve with the NEXT search launch queued ahead
+    // and gated on a host-mapped inbox (the `gated` branch below; icp.hip
+    // XfGate) -- the reading of "issue iteration k + 1 speculatively while
+    // the host solves" that needs no solve on the device. Built and measured
+    // in round 3: results identical to the plain loop, and far SLOWER -- every
+    // workgroup of the waiting launch polls host memory over PCIe, and 256 -
+    // 512 pollers turn the ~2 us the answer needs into tens: 500 - 730
+    // frames/s against 1115 - 1145 at 640x480, 450 - 610 against 975 - 990 at
+    // 1280x720. A hierarchy of pollers (8 on the host word, the rest on device
+    // flags) would cost about what the launch it saves costs. Opt-in only.
+    const char* gate_env = std::getenv("O3DMI_ICP_GATE");
+    GateInbox* inbox = nullptr;
+    bool gated = p2plane && !dev_reduce && !allreduce && !fast &&
+                 gate_env && gate_env[0] == '1';
+    if (gated) {
+        ring = ThreadMailRing();
+        inbox = ThreadGateInbox();
+        gated = ring != nullptr && inbox != nullptr;
+    }
     for (int scale_idx = 0; scale_idx < num_scales; ++scale_idx) {
         Level& full_level = pyr[(size_t)scale_idx];
         struct ScaleView : SourceView {
@@ -894,6 +919,137 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                          scale_idx, (long long)L.ns, (long long)L.nt,
                          t - t_mark);
             t_mark = t;
+        }
+        if (gated) {
+            // Point-to-plane on one GPU, solve on the host, the NEXT search
+            // launch queued before this one's sums are read: it is dispatched
+            // the moment the final-sum launch ends and polls the thread's
+            // inbox until the host publishes the update it has to move the
+            // source by (icp.hip XfGate). The host's launch call and the
+            // dispatch latency leave the critical path of an iteration; when
+            // the scale ends the queued launch is either the evaluation of
+            // the result (last scale: Registration.cpp:424-431) or cancelled.
+            const o3dmi_icp_criteria_t& crit = criterias[scale_idx];
+            const bool last_scale = scale_idx == num_scales - 1;
+            int64_t* corr_out = last_scale ? correspondences_dev : nullptr;
+            has_pending = false;
+            guard.completed = false;
+            struct PendingGate {
+                GateInbox* ib;
+                int seq = 0;
+                ~PendingGate() {
+                    if (seq) ib->Cancel(seq);  // never leave a launch polling
+                }
+            } pending_gate{inbox};
+            auto launch = [&](const double* xf_host, int gate_seq,
+                              int* seq_out) -> int {
+                const int seq = ++ring->seq;
+                *seq_out = seq;
+                return o3dmi_internal_icp_search_gated(
+                        guard.nns, L.src, xf_host,
+                        xf_host ? nullptr : inbox->words, gate_seq, L.ns,
+                        robust_kernel, scaling_parameter, shape_parameter,
+                        corr_out, ring->Data(seq), ring->Flag(seq), seq,
+                        stream);
+            };
+            auto read = [&](int seq, SearchResult& r) -> int {
+                O3DMI_HIP_CHECK(MailRingWait(ring, seq, s));
+                std::memcpy(r.sums, ring->Data(seq), sizeof(double) * 32);
+                r.sums[31] = (double)L.ns;
+                const double num = r.sums[30];
+                if (num != 0) {
+                    r.fitness = num / r.sums[31];
+                    r.inlier_rmse = std::sqrt(r.sums[29] / num);
+                } else {
+                    r.fitness = 0;
+                    r.inlier_rmse = 0;
+                }
+                return O3DMI_OK;
+            };
+            int seq_cur = 0, seq_next = 0;
+            if ((st = launch(T, 0, &seq_cur))) return st;
+            double prev_fitness = fitness, prev_inlier_rmse = inlier_rmse;
+            converged = false;
+            bool evaluation_queued = false;
+            int it = 0;
+            for (it = 0; it < crit.max_iteration; ++it) {
+                const int g = ++inbox->seq;
+                pending_gate.seq = g;
+                if ((st = launch(nullptr, g, &seq_next))) return st;
+                SearchResult r;
+                if ((st = read(seq_cur, r))) return st;
+                seq_cur = seq_next;
+                fitness = r.fitness;
+                inlier_rmse = r.inlier_rmse;
+                converged = false;
+                if (r.sums[30] == 0) Eye4(T);  // Registration.cpp:56-58
+                if (fitness <= std::numeric_limits<double>::min()) {
+                    inbox->Cancel(g);
+                    pending_gate.seq = 0;
+                    break;
+                }
+                double pose[6], update[16];
+                float residual;
+                int inlier_count;
+                int e = o3dmi_decode_and_solve6x6(r.sums, pose, &residual,
+                                                  &inlier_count);
+                if (e) status = e;  // reference throws; report after the loop
+                o3dmi_pose_to_transformation(pose, update);
+                Matmul4(update, T, T);
+                const bool stop =
+                        it != 0 &&
+                        std::abs(prev_fitness - fitness) <
+                                crit.relative_fitness &&
+                        std::abs(prev_inlier_rmse - inlier_rmse) <
+                                crit.relative_rmse;
+                const bool more = !stop && it + 1 < crit.max_iteration;
+                if (more || last_scale) {
+                    // the next iteration, or the evaluation of the result
+                    inbox->Release(g, update);
+                    evaluation_queued = !more;
+                } else {
+                    inbox->Cancel(g);
+                }
+                pending_gate.seq = 0;
+                if (callback)
+                    callback(iteration_count + it, scale_idx, it, inlier_rmse,
+                             fitness, T, callback_user);
+                if (stop) {
+                    converged = true;
+                    break;
+                }
+                prev_fitness = fitness;
+                prev_inlier_rmse = inlier_rmse;
+            }
+            iteration_count += it;
+            exit_timer.Mark("scale");
+            if (timing) {
+                (void)hipStreamSynchronize(s);
+                const double t = now();
+                std::fprintf(stderr,
+                             "[o3dmi] icp: scale %d %d iterations %.0f us\n",
+                             scale_idx, it, t - t_mark);
+                t_mark = t;
+            }
+            if (last_scale &&
+                (evaluation_queued || crit.max_iteration <= 0)) {
+                const bool preserved = converged;
+                SearchResult r;
+                if ((st = read(seq_cur, r))) return st;
+                fitness = r.fitness;
+                inlier_rmse = r.inlier_rmse;
+                if (r.sums[30] == 0) Eye4(T);
+                converged = preserved;
+                // the newest launch of the stream has posted: every earlier
+                // one (the cancelled launches of the coarser scales too) is
+                // done with its index
+                for (NnsGuard& gd : guards) gd.completed = true;
+            }
+            if (fitness <= std::numeric_limits<double>::min()) {
+                converged = false;
+                break;
+            }
+            continue;
         }
         if (fast) {
             // Point-to-plane on one GPU: an iteration is ONE launch (search +

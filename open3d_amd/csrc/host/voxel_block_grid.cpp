@@ -55,6 +55,8 @@ struct o3dmi_vbg {
     PixelRec* recs[2][kMaxGroup] = {};
     int64_t recs_pixels = 0;
     FrameBlock* lists[2] = {nullptr, nullptr};
+    ReadyEntry* ready[2] = {nullptr, nullptr};  // same capacity as the lists
+    int* front_tickets = nullptr;               // device int[2][16]
     int64_t lists_capacity = 0;
     int* ring_counters = nullptr;        // device int[4]
     volatile int* stream_status = nullptr;  // host-mapped int[4]
@@ -421,8 +423,10 @@ int o3dmi_vbg_destroy(o3dmi_vbg_t* g) {
     for (int i = 0; i < 2; ++i) {
         for (int f = 0; f < kMaxGroup; ++f) (void)hipFree(g->recs[i][f]);
         (void)hipFree(g->lists[i]);
+        (void)hipFree(g->ready[i]);
         if (i == 0) (void)hipFree(g->prep_col);
     }
+    (void)hipFree(g->front_tickets);
     (void)hipFree(g->ring_counters);
     if (g->stream_status) (void)hipHostFree((void*)g->stream_status);
     for (hipEvent_t e : g->prof_events) (void)hipEventDestroy(e);
@@ -652,8 +656,16 @@ static int EnsureStreamBuffers(o3dmi_vbg* g, int rows, int cols,
             g->lists[i] = nullptr;
             O3DMI_HIP_CHECK(hipMalloc((void**)&g->lists[i],
                                       sizeof(FrameBlock) * (size_t)list_cap));
+            (void)hipFree(g->ready[i]);
+            g->ready[i] = nullptr;
+            O3DMI_HIP_CHECK(hipMalloc((void**)&g->ready[i],
+                                      sizeof(ReadyEntry) * (size_t)list_cap));
         }
         g->lists_capacity = list_cap;
+    }
+    if (!g->front_tickets) {
+        O3DMI_HIP_CHECK(hipMalloc((void**)&g->front_tickets, sizeof(int) * 32));
+        O3DMI_HIP_CHECK(hipMemset(g->front_tickets, 0, sizeof(int) * 32));
     }
     if (!g->ring_counters) {
         O3DMI_HIP_CHECK(hipMalloc((void**)&g->ring_counters, sizeof(int) * 4));
@@ -872,6 +884,8 @@ static StreamGroup MakeGroup(o3dmi_vbg* g, const StreamCommon& c,
         a.list = g->lists[par];
         a.list_capacity = g->lists_capacity;
         a.count = g->ring_counters + (grp.seq & 3);
+        a.ready = g->ready[par];
+        a.tickets = g->front_tickets + 16 * par;
     }
     g->stream_seq += 1;
     g->size_bound = o3dmi_hash_capacity(g->block_hashmap);  // generic path: re-read
@@ -893,6 +907,7 @@ static void MakeIntegArgs(o3dmi_vbg* g, const StreamCommon& c,
     ia->cols = c.depth_cols;
     ia->with_color = c.with_color;
     ia->list = g->lists[par];
+    ia->ready = g->ready[par];
     ia->count = g->ring_counters + (grp.seq & 3);
     ia->list_capacity = g->lists_capacity;
     ia->grid_hint = g->last_count;

@@ -551,6 +551,22 @@ struct GnTail {
     double n_source;       // sums[31]
 };
 
+// A search launch queued AHEAD of the host: it is dispatched the moment its
+// predecessor ends, every workgroup then polls a host-mapped word until the
+// host -- which meanwhile reads the predecessor's sums and solves the 6x6
+// system -- publishes this launch's sequence number together with the
+// transformation to move the source by (or a cancel mark, when the scale
+// ended). What leaves the critical path of a Gauss-Newton iteration is the
+// host's launch call and the dispatch latency (~5 us of an ~8 us hop).
+// inbox (host-mapped, 256 B): int seq; int cancel_seq; ... 16 float32 at byte
+// 64; 16 float64 at byte 128. The spin is bounded: a host that never answers
+// (it died) makes the launch leave after ~100 ms instead of hanging the GPU.
+struct XfGate {
+    const int* inbox;  // NULL: no gate
+    int seq;
+};
+constexpr int kGateSpinLimit = 1 << 16;
+
 __device__ __forceinline__ double LoadSc1(const double* p) {
     return __longlong_as_double((long long)__hip_atomic_load(
             (const unsigned long long*)p, __ATOMIC_RELAXED,
@@ -669,8 +685,39 @@ SearchAccumulateKernel(NnsView<T> nv, const Rec4<T>* __restrict__ sorted_n,
                        T* __restrict__ src, int64_t n, Mat4<T> xf,
                        int apply_xf, RobustParams rp,
                        int64_t* __restrict__ corr_out,
-                       double* __restrict__ partials, GnTail tail) {
+                       double* __restrict__ partials, GnTail tail,
+                       XfGate gate) {
     constexpr int kPerWave = 64 / G;  // queries per wave
+    if (gate.inbox) {
+        __shared__ int s_go;
+        if (threadIdx.x == 0) {
+            int spins = 0, v;
+            while ((v = __hip_atomic_load(gate.inbox, __ATOMIC_ACQUIRE,
+                                          __HIP_MEMORY_SCOPE_SYSTEM)) -
+                           gate.seq < 0) {
+                if (++spins > kGateSpinLimit) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            const int cancel = __hip_atomic_load(gate.inbox + 1,
+                                                 __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_SYSTEM);
+            s_go = v - gate.seq >= 0 && cancel != gate.seq;
+        }
+        __syncthreads();
+        if (!s_go) return;  // cancelled (or no answer): nothing is touched
+        if (apply_xf == 3) {
+            // scalar loads, behind the acquire: see the note at apply_xf == 2
+            if constexpr (sizeof(T) == 4) {
+                const float* m32 = (const float*)(gate.inbox + 16);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) xf.m[k] = m32[k];
+            } else {
+                const double* m64 = (const double*)(gate.inbox + 32);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) xf.m[k] = m64[k];
+            }
+        }
+    }
     if (apply_xf == 2) {
         // the update the previous launch's tail left on the device (uniform
         // address: scalar loads), narrowed to the point dtype like the host
@@ -1282,7 +1329,7 @@ static int LaunchSearchAccumulate(
         int robust_kernel, double scaling_parameter, double shape_parameter,
         int64_t* corr_out_dev, double* sums32_dev, double* mail_data,
         int* mail_flag, int mail_seq, const GnTail* tail_in,
-        o3dmi_stream_t stream) {
+        const XfGate* gate_in, o3dmi_stream_t stream) {
     O3DMI_REQUIRE(nns && src_dev && (sums32_dev || mail_data || tail_in),
                   "null argument");
     O3DMI_REQUIRE(estimation >= 0 && estimation <= 2,
@@ -1331,9 +1378,15 @@ static int LaunchSearchAccumulate(
                                  shape_parameter);
     // 0 none, 1 the matrix passed by value, 2 the matrix the previous
     // launch's tail left at tail.xf_in
+    // 3: the matrix the host publishes in the gate's inbox
     const int apply_xf = transformation != nullptr
                                  ? 1
-                                 : (tail_in && tail_in->xf_in ? 2 : 0);
+                                 : (tail_in && tail_in->xf_in
+                                            ? 2
+                                            : (gate_in && gate_in->inbox ? 3
+                                                                         : 0));
+    XfGate gate = {};
+    if (gate_in) gate = *gate_in;
     GnTail tail = {};
     if (tail_in) {
         tail = *tail_in;
@@ -1354,7 +1407,7 @@ static int LaunchSearchAccumulate(
                        dim3(kSearchBlock), 0, s, MakeView<T>(nns),            \
                        (const Rec4<T>*)nns->sorted_normals, (T*)src_dev, n,   \
                        xf_of(T()), apply_xf, rp, corr_out_dev, nns->partials, \
-                       tail)
+                       tail, gate)
 #define O3DMI_SEARCH(T, G)                                                     \
     do {                                                                      \
         if (estimation == 0 && robust_kernel == O3DMI_L2_LOSS)                \
@@ -1395,7 +1448,29 @@ int o3dmi_internal_icp_transform_search_accumulate(
                                   n, estimation, robust_kernel,
                                   scaling_parameter, shape_parameter,
                                   corr_out_dev, sums32_dev, mail_data, mail_flag,
-                                  mail_seq, nullptr, stream);
+                                  mail_seq, nullptr, nullptr, stream);
+}
+
+// Internal (host/registration.cpp): the same pair of launches (search +
+// accumulate, final sum posting to mail_data / mail_flag), with the search
+// launch GATED on `inbox` (see XfGate) when inbox != NULL: it starts to work
+// when the host has published gate_seq, moving the source by the matrix in
+// the inbox; `transformation` must then be NULL.
+int o3dmi_internal_icp_search_gated(
+        const o3dmi_nns_t* nns, void* src_dev, const double* transformation,
+        const int* inbox, int gate_seq, int64_t n, int robust_kernel,
+        double scaling_parameter, double shape_parameter,
+        int64_t* corr_out_dev, double* mail_data, int* mail_flag, int mail_seq,
+        o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(!(inbox && transformation), "gated launch with a matrix");
+    XfGate gate = {};
+    gate.inbox = inbox;
+    gate.seq = gate_seq;
+    return LaunchSearchAccumulate(nns, src_dev, transformation, nullptr, n, 0,
+                                  robust_kernel, scaling_parameter,
+                                  shape_parameter, corr_out_dev, nullptr,
+                                  mail_data, mail_flag, mail_seq, nullptr,
+                                  inbox ? &gate : nullptr, stream);
 }
 
 // Internal (host/registration.cpp): one point-to-plane Gauss-Newton iteration
@@ -1424,7 +1499,7 @@ int o3dmi_internal_icp_search_solve(
     return LaunchSearchAccumulate(nns, src_dev, transformation, nullptr, n, 0,
                                   robust_kernel, scaling_parameter,
                                   shape_parameter, corr_out_dev, nullptr,
-                                  nullptr, nullptr, 0, &tail, stream);
+                                  nullptr, nullptr, 0, &tail, nullptr, stream);
 }
 
 int o3dmi_transform_points(const double* transformation, void* points_dev,

@@ -47,6 +47,20 @@ MailRing* ThreadMailRing();
 // Blocks until launch `seq` has posted; its data is ring->Data(seq).
 hipError_t MailRingWait(MailRing* ring, int seq, hipStream_t s);
 
+// The other direction: a host-mapped inbox a GATED launch polls (icp.hip
+// XfGate). words[0] = sequence number of the launch that may proceed,
+// words[1] = sequence number of a cancelled launch, 16 float32 at byte 64 and
+// 16 float64 at byte 128 = the transformation for it. One outstanding gated
+// launch per host thread.
+struct GateInbox {
+    int* words = nullptr;  // host-mapped, 256 bytes
+    int seq = 0;           // last sequence number handed out
+    // publishes `m` (row-major 4x4) for launch `s`
+    void Release(int s, const double* m) const;
+    void Cancel(int s) const;
+};
+GateInbox* ThreadGateInbox();
+
 // Device side: called by the threads of the single final workgroup after they
 // wrote data[0..n); publishes `seq`.
 __device__ __forceinline__ void MailboxPublish(int* flag, int seq) {

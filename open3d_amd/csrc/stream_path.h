@@ -48,6 +48,20 @@ struct alignas(16) FrameBlock {
     int slot, x, y, z;
 };
 
+// One entry of a group's READY list: everything the integrate role needs to
+// start on a block -- buffer index, packed block key, frame bits -- in one
+// 16-byte load. Written by the front roles' last touch workgroup once every
+// touch workgroup of the group has arrived (the frame bits of a block are
+// final only then), in the launch BEFORE the one whose integrate role reads
+// it. Without it a work item's header is two dependent round trips (list
+// entry -> buffer index + touch word) in front of its voxel state and record
+// gathers.
+struct alignas(16) ReadyEntry {
+    unsigned long long key;  // PackKey(x, y, z)
+    int block_idx;           // buffer index of the block
+    unsigned bits;           // frames of the group that touched it
+};
+
 // Per-pixel prepared record (u16 depth / u8 colour inputs).
 struct alignas(8) PixelRec {
     float d;        // float(depth) / depth_scale
@@ -84,6 +98,9 @@ struct FrameFrontArgs {
     FrameBlock* list;     // the group's list (shared by its frames)
     int64_t list_capacity;
     int* count;           // the group's count; 0 before the group's first frame
+    ReadyEntry* ready;    // the group's ready list (may be null: not built)
+    int* tickets;         // 9 arrival counters of the group's touch
+                          // workgroups, zero between launches
 };
 
 // Integrate role of ONE group.
@@ -96,6 +113,7 @@ struct IntegrateStreamArgs {
     int rows, cols;
     bool with_color;
     const FrameBlock* list;
+    const ReadyEntry* ready;  // built by the group's front roles, or null
     const int* count;     // device: live length of `list`
     int64_t list_capacity;
     int grid_hint;        // expected number of blocks (sizes the grid)

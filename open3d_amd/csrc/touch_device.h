@@ -30,7 +30,10 @@ __device__ __forceinline__ bool InsertKey(const HashView& hv, int x, int y,
         hv.key_buffer[3 * idx + 0] = x;
         hv.key_buffer[3 * idx + 1] = y;
         hv.key_buffer[3 * idx + 2] = z;
-        hv.slot_vals[h] = idx;
+        // write-through: the ready-list compaction of the frame stream reads
+        // it from another workgroup of the SAME launch (vbg_stream.hip)
+        __hip_atomic_store(&hv.slot_vals[h], idx, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
     return true;
 }

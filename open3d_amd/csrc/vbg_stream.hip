@@ -63,6 +63,9 @@ struct FrontShared {
     FrameBlock* list;
     int64_t list_capacity;
     int* out_count;
+    ReadyEntry* ready;
+    int* tickets;
+    int n_touch_total;  // touch workgroups of the whole group (all frames)
     unsigned long long group_stamp;
     int touch_plane;
     int n_touch_wg, n_prep_wg;
@@ -91,6 +94,8 @@ inline bool SameGroup(const FrontShared& a, const FrontShared& b) {
            a.prep_identity == b.prep_identity &&
            a.inv_depth_scale == b.inv_depth_scale && a.list == b.list &&
            a.list_capacity == b.list_capacity && a.out_count == b.out_count &&
+           a.ready == b.ready && a.tickets == b.tickets &&
+           a.n_touch_total == b.n_touch_total &&
            a.group_stamp == b.group_stamp && a.touch_plane == b.touch_plane &&
            a.n_touch_wg == b.n_touch_wg && a.n_prep_wg == b.n_prep_wg;
 }
@@ -117,6 +122,9 @@ struct FrontParams {
     FrameBlock* list;
     int64_t list_capacity;
     int* out_count;
+    ReadyEntry* ready;
+    int* tickets;
+    int n_touch_total;
     unsigned long long group_stamp;
     int group_bit;
     int touch_plane;
@@ -128,6 +136,7 @@ struct FrontParams {
           depth_div_short(s.depth_div_short), prep_identity(s.prep_identity),
           inv_depth_scale(s.inv_depth_scale), recs(f.recs), list(s.list),
           list_capacity(s.list_capacity), out_count(s.out_count),
+          ready(s.ready), tickets(s.tickets), n_touch_total(s.n_touch_total),
           group_stamp(s.group_stamp), group_bit(f.group_bit),
           touch_plane(s.touch_plane), n_touch_wg(s.n_touch_wg),
           n_prep_wg(s.n_prep_wg) {
@@ -210,15 +219,64 @@ __device__ __forceinline__ void FrontRole(const HashView& hv,
                           fp.touch_plane)) {
                 int o = atomicAdd(fp.out_count, 1);
                 if (o < fp.list_capacity) {
-                    FrameBlock fb;
-                    fb.slot = (int)slot;
-                    fb.x = x;
-                    fb.y = y;
-                    fb.z = z;
-                    list[o] = fb;
+                    // write-through (two 8-byte stores): the ready-list
+                    // compaction below reads the entry from another
+                    // workgroup of this launch
+                    unsigned long long* e =
+                            reinterpret_cast<unsigned long long*>(&list[o]);
+                    __hip_atomic_store(
+                            e, (unsigned long long)(unsigned)slot |
+                                       ((unsigned long long)(unsigned)x << 32),
+                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(
+                            e + 1, (unsigned long long)(unsigned)y |
+                                           ((unsigned long long)(unsigned)z << 32),
+                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
                     atomicOr(&hv.counters[1], kErrCapacity);
                 }
+            }
+        }
+        // The ready list (stream_path.h ReadyEntry). The frame bits of a block
+        // are final when EVERY touch workgroup of the group -- all its frames
+        // -- has finished, so the workgroups take a ticket (their entries,
+        // buffer indices and touch words are write-through stores / atomics,
+        // drained first) and the last arrival turns the list into ready
+        // entries: one lane per block, list entry -> buffer index + touch
+        // word (the two dependent round trips an integrate work item would
+        // otherwise spend on its header) -> one 16-byte entry. This happens
+        // at the tail of the front roles, which finish early in a fused
+        // launch; the entries are read in the NEXT launch.
+        if (fp.ready &&
+            LastArrival(fp.tickets, fp.group_bit * n_touch_wg + wg,
+                        fp.n_touch_total)) {
+            int n = __hip_atomic_load(fp.out_count, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+            if (n > fp.list_capacity) n = (int)fp.list_capacity;
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const unsigned long long* e =
+                        reinterpret_cast<const unsigned long long*>(&list[i]);
+                const unsigned long long lo = __hip_atomic_load(
+                        e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long hi = __hip_atomic_load(
+                        e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned slot = (unsigned)lo;
+                const int x = (int)(unsigned)(lo >> 32);
+                const int y = (int)(unsigned)hi, z = (int)(unsigned)(hi >> 32);
+                const int idx = __hip_atomic_load(&hv.slot_vals[slot],
+                                                  __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long word = __hip_atomic_load(
+                        TouchWord(hv, slot, fp.touch_plane), __ATOMIC_RELAXED,
+                        __HIP_MEMORY_SCOPE_AGENT);
+                const bool own = (word >> kTouchBits) == fp.group_stamp;
+                if (!own) atomicOr(&hv.counters[1], kErrTouchStamp);
+                ReadyEntry re;
+                re.key = PackKey(x, y, z);
+                re.block_idx = idx;
+                re.bits = own ? (unsigned)(word & ((1ull << kTouchBits) - 1ull))
+                              : 0u;
+                fp.ready[i] = re;
             }
         }
         return;
@@ -421,6 +479,7 @@ struct IntegParams {
     float sdf_trunc, depth_max;
     float inv_sdf_trunc;  // RN(1 / sdf_trunc), used by the kFastDiv variant
     const FrameBlock* list;
+    const ReadyEntry* ready;  // null: header from list + hash (form 0, A / B)
     const int* count;
     int64_t list_capacity;
     float* tsdf;
@@ -824,19 +883,37 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
             part = (int)(m - kb * parts);
         }
         const int64_t b = (int64_t)xcd + (kb << 3);
-        const FrameBlock fb = list[b];
-        const int slot = __builtin_amdgcn_readfirstlane(fb.slot);
-        const int xb = __builtin_amdgcn_readfirstlane(fb.x);
-        const int yb = __builtin_amdgcn_readfirstlane(fb.y);
-        const int zb = __builtin_amdgcn_readfirstlane(fb.z);
-        const int block_idx =
-                __builtin_amdgcn_readfirstlane(hv.slot_vals[slot]);
-        const unsigned long long word = *TouchWord(hv, slot, ip.touch_plane);
-        const bool own = (word >> kTouchBits) == ip.group_stamp;
-        if (!own && threadIdx.x == 0 && part == 0)
-            atomicOr(&hv.counters[1], kErrTouchStamp);
-        const unsigned bits = __builtin_amdgcn_readfirstlane(
-                own ? (unsigned)(word & ((1ull << kTouchBits) - 1ull)) : 0u);
+        int xb, yb, zb, block_idx;
+        unsigned bits;
+        if (ip.ready) {
+            // ONE round trip: the ready entry the group's front roles left
+            const ReadyEntry re = ip.ready[b];
+            const unsigned klo = __builtin_amdgcn_readfirstlane((unsigned)re.key);
+            const unsigned khi =
+                    __builtin_amdgcn_readfirstlane((unsigned)(re.key >> 32));
+            const unsigned long long key =
+                    ((unsigned long long)khi << 32) | klo;
+            xb = (int)((key >> 42) & 0x1FFFFFull) - kKeyBias;
+            yb = (int)((key >> 21) & 0x1FFFFFull) - kKeyBias;
+            zb = (int)(key & 0x1FFFFFull) - kKeyBias;
+            block_idx = __builtin_amdgcn_readfirstlane(re.block_idx);
+            bits = __builtin_amdgcn_readfirstlane(re.bits);
+        } else {
+            const FrameBlock fb = list[b];
+            const int slot = __builtin_amdgcn_readfirstlane(fb.slot);
+            xb = __builtin_amdgcn_readfirstlane(fb.x);
+            yb = __builtin_amdgcn_readfirstlane(fb.y);
+            zb = __builtin_amdgcn_readfirstlane(fb.z);
+            block_idx = __builtin_amdgcn_readfirstlane(hv.slot_vals[slot]);
+            const unsigned long long word =
+                    *TouchWord(hv, slot, ip.touch_plane);
+            const bool own = (word >> kTouchBits) == ip.group_stamp;
+            if (!own && threadIdx.x == 0 && part == 0)
+                atomicOr(&hv.counters[1], kErrTouchStamp);
+            bits = __builtin_amdgcn_readfirstlane(
+                    own ? (unsigned)(word & ((1ull << kTouchBits) - 1ull))
+                        : 0u);
+        }
         const int64_t block_base = (int64_t)block_idx * res3;
         if (part == 0 && threadIdx.x == 0 && ip.prof_frame_blocks)
             frame_blocks += __popc(bits);
@@ -1103,6 +1180,8 @@ struct StepParams {
     int n_fronts;
     int front_wg;  // workgroups per front role
 };
+static_assert(sizeof(StepParams) <= 4096, "kernel arguments are limited to 4 KB");
+
 
 // kForm: 0 = first form of the integrate role; 1 = wide form, 4 voxels per
 // lane (119 registers, 4 waves per SIMD); 2 = wide form, 2 voxels per lane
@@ -1311,6 +1390,8 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         fs.list = f->list;
         fs.list_capacity = f->list_capacity;
         fs.out_count = f->count;
+        fs.ready = f->ready;
+        fs.tickets = f->ready ? f->tickets : nullptr;
         fs.group_stamp = f->group_stamp;
         fs.touch_plane = f->touch_plane & 1;
         // one touch workgroup per 16 x 16 tile of rays
@@ -1319,6 +1400,7 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         // 16 pixels per prepare lane
         fs.n_prep_wg = (f->rows * f->cols + kBlock * 16 - 1) / (kBlock * 16);
         if (fs.n_prep_wg < 1) fs.n_prep_wg = 1;
+        fs.n_touch_total = fs.n_touch_wg * n_fronts;
         if (i == 0) {
             sp.fshared = fs;
             sp.front_wg = fs.n_touch_wg + fs.n_prep_wg;
@@ -1361,6 +1443,12 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         ip.depth_max = a->depth_max;
         fast_div = VerifyFastDivision(a->sdf_trunc, &ip.inv_sdf_trunc);
         ip.list = a->list;
+        // O3DMI_STEP_READY=0 (A / B): header from the list + the hash
+        static const bool use_ready = [] {
+            const char* e = std::getenv("O3DMI_STEP_READY");
+            return !(e && e[0] == '0');
+        }();
+        ip.ready = use_ready ? a->ready : nullptr;
         ip.count = a->count;
         ip.list_capacity = a->list_capacity;
         ip.tsdf = a->tsdf;

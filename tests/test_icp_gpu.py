@@ -1557,3 +1557,77 @@ def test_multiscale_icp_with_device_resident_cloud_sizes(voxels):
     again = reg.multi_scale_icp(src[:ns].clone(), tgt[:nt].contiguous(),
                                 nrm[:nt].contiguous(), voxels, crit, md)
     assert np.array_equal(again.transformation, want.transformation)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_gated_search_launch_equals_the_plain_loop(dtype):
+    """O3DMI_ICP_GATE=1 (opt-in; measured much slower: every workgroup of the
+    waiting launch polls host memory, see host/registration.cpp) queues
+    iteration k + 1's search launch before iteration k's sums are read; the
+    launch polls a host-mapped inbox for the update (or a cancel mark).
+    Against the plain loop everything must be IDENTICAL -- same kernels, same
+    matrices, same order: transformation, iteration counts, per-iteration
+    fitness / rmse, the correspondence set -- for single- and multi-scale
+    runs, zero iterations, scales that stop early or run out of iterations,
+    and a pair of clouds with no correspondence at all."""
+    import os
+    _lib, reg = _gpu()
+    p = _pair(60000, seed=11, dtype=dtype)
+    src = torch.from_numpy(p["source"]).cuda()
+    tgt = torch.from_numpy(p["target"]).cuda()
+    nrm = torch.from_numpy(p["target_normals"]).cuda()
+    far = (src + 50.0).contiguous()
+    cases = [(src, [-1.0], [reg.ICPConvergenceCriteria(1e-6, 1e-6, 30)],
+              [0.07]),
+             (src, [0.05, 0.025, 0.0125],
+              [reg.ICPConvergenceCriteria(1e-6, 1e-6, n) for n in (20, 10, 5)],
+              [0.15, 0.075, 0.0375]),
+             (src, [-1.0], [reg.ICPConvergenceCriteria(1e-6, 1e-6, 0)], [0.07]),
+             (src, [0.05, -1.0], [reg.ICPConvergenceCriteria(0.5, 0.5, 4),
+                                  reg.ICPConvergenceCriteria(1e-9, 1e-9, 3)],
+              [0.15, 0.07]),
+             (src, [0.05, 0.02], [reg.ICPConvergenceCriteria(1e-12, 1e-12, 2),
+                                  reg.ICPConvergenceCriteria(1e-12, 1e-12, 1)],
+              [0.15, 0.07]),
+             (far, [0.05, -1.0], [reg.ICPConvergenceCriteria(1e-6, 1e-6, 5)] * 2,
+              [0.15, 0.07])]
+
+    def run(s0, vs, crit, md):
+        log = []
+        r = reg.multi_scale_icp(
+            s0.clone(), tgt, nrm, vs, crit, md,
+            callback_after_iteration=lambda d: log.append(
+                (d["iteration_index"], d["scale_index"],
+                 d["scale_iteration_index"], d["fitness"], d["inlier_rmse"],
+                 d["transformation"].tobytes())))
+        torch.cuda.synchronize()
+        return r, log
+
+    for s0, vs, crit, md in cases:
+        plain, plog = run(s0, vs, crit, md)
+        os.environ["O3DMI_ICP_GATE"] = "1"
+        try:
+            gated, glog = run(s0, vs, crit, md)
+        finally:
+            del os.environ["O3DMI_ICP_GATE"]
+        assert np.array_equal(gated.transformation, plain.transformation)
+        assert gated.num_iterations == plain.num_iterations
+        assert gated.converged == plain.converged
+        assert gated.fitness == plain.fitness
+        assert gated.inlier_rmse == plain.inlier_rmse
+        assert glog == plog
+        assert torch.equal(gated.correspondence_set, plain.correspondence_set)
+    # 50 calls back to back: no launch is left polling, nothing drifts
+    first, _ = run(src, [0.05, 0.025],
+                   [reg.ICPConvergenceCriteria(1e-6, 1e-6, 6)] * 2,
+                   [0.15, 0.075])
+    os.environ["O3DMI_ICP_GATE"] = "1"
+    try:
+        for _ in range(50):
+            r = reg.multi_scale_icp(
+                src.clone(), tgt, nrm, [0.05, 0.025],
+                [reg.ICPConvergenceCriteria(1e-6, 1e-6, 6)] * 2, [0.15, 0.075])
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["O3DMI_ICP_GATE"]
+    assert np.array_equal(r.transformation, first.transformation)
