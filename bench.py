@@ -491,16 +491,21 @@ def configs4_leg():
 # ---------------------------------------------------------------------------
 # per-kernel accounting of the tracking loop (configs[2]) from a kernel trace
 
+# (family, substrings of the kernel name; "::X" = a name that STARTS with X
+# after its namespace, so that ScatterKernel does not match SortScatterKernel)
 KERNEL_FAMILIES = [
     ("search_G8", "SearchAccumulateKernel<float, 8,"),
     ("search_G16", "SearchAccumulateKernel<float, 16,"),
     ("search_G32", "SearchAccumulateKernel<float, 32,"),
     ("final_sum", "FinalSumKernel"),
-    ("voxel_down_sample", ("Vds", "SortHist", "SortScatter")),
-    ("index_build", ("CountKernel", "AssignRangesKernel", "ScatterKernel")),
-    ("ray_cast", ("RayCastKernel", "EstimateRangeKernel", "RangeFillKernel")),
-    ("unproject", ("UnprojectKernel", "TransformNormalsKernel")),
-    ("integrate", ("FrameStepKernel", "ExportListKeysKernel")),
+    ("voxel_down_sample", ("::Vds", "::SortHist", "::SortScatter",
+                           "::PostCounts")),
+    ("index_build", ("::CountKernel", "::AssignRangesKernel",
+                     "::ScatterKernel")),
+    ("ray_cast", ("::RayCastKernel", "::EstimateRangeKernel",
+                  "::RangeFillKernel")),
+    ("unproject", ("::UnprojectKernel", "::TransformNormalsKernel")),
+    ("integrate", ("::FrameStepKernel", "::ExportListKeysKernel")),
     ("fill_copy", ("__amd_rocclr_fillBuffer", "__amd_rocclr_copyBuffer")),
 ]
 
@@ -575,9 +580,11 @@ def cpp_kernel_rooflines(exe, w, h, n_frames, levels):
         return None
 
     fams = {}
+    counted = set()
     for name, pat in KERNEL_FAMILIES:
         pats = (pat,) if isinstance(pat, str) else pat
         sel = [x for x in loop if any(p in x[2] for p in pats)]
+        counted.update(id(x) for x in sel)
         if not sel:
             continue
         tot = sum(x[1] - x[0] for x in sel) / 1e3
@@ -590,6 +597,13 @@ def cpp_kernel_rooflines(exe, w, h, n_frames, levels):
             ent["achieved_gbps"] = b / (avg * 1e-6) / 1e9
             ent["frac"] = ent["achieved_gbps"] / HBM_PEAK_GBS
         fams[name] = ent
+    rest = [x for x in loop if id(x) not in counted]
+    if rest:
+        fams["other"] = {"launches_per_frame": len(rest) / frames,
+                         "us_per_frame": sum(x[1] - x[0] for x in rest) / 1e3 /
+                                         frames,
+                         "names": sorted({x[2].split("(")[0][-40:]
+                                          for x in rest})[:8]}
     return {"kernels": fams, "launches_per_frame": len(loop) / frames,
             "kernel_us_per_frame": sum(x[1] - x[0] for x in loop) / 1e3 / frames,
             "wall_us_per_frame_under_trace": span / 1e3 / frames,

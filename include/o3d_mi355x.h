@@ -382,9 +382,16 @@ int o3dmi_pointcloud_estimate_covariances(const void* points_dev,
                                           int max_nn, int dtype,
                                           void* covariances_dev,
                                           o3dmi_stream_t stream);
-/* EstimateNormalsFromCovariancesCUDA (PointCloudImpl.h:1011-1063, fast 3x3
- * symmetric eigen solver :746-1009). normals {n,3} is in/out when
- * has_normals (orientation is kept consistent with the existing normals). */
+/* EstimateNormalsFromCovariancesCUDA (PointCloudImpl.h:1011-1063). normals
+ * {n,3} is in/out when has_normals (orientation is kept consistent with the
+ * existing normals). The eigenvector of the smallest eigenvalue comes from
+ * this library's own routine (covariance widened to float64, converged cyclic
+ * Jacobi), NOT from the reference's closed-form solver (:746-1009): within
+ * 1e-4 rad (Float32) / 1e-10 (Float64) of it wherever the two smallest
+ * eigenvalues differ by more than 5 % of the largest, any unit vector of the
+ * eigenspace otherwise. Sign without prior normals: last non-zero component
+ * positive; an all-zero covariance gives +z (with prior normals: the zero
+ * vector), an identity covariance (< 3 neighbours) +z. */
 int o3dmi_pointcloud_normals_from_covariances(const void* covariances_dev,
                                               int64_t n, int dtype,
                                               void* normals_dev,

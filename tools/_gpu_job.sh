@@ -1,5 +1,13 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_icp_gpu.py -q -m gpu -x -k "gated or multiscale or device_resident or in_launch" 2>&1 | tail -5
-for i in 1 2 3 4; do timeout 120 examples/icp_slam 60 640 480 | grep -o '"frames_per_s": [0-9.]*' | tr '\n' ' '; echo " vga gated"; O3DMI_ICP_NO_GATE=1 timeout 120 examples/icp_slam 60 640 480 | grep -o '"frames_per_s": [0-9.]*' | tr '\n' ' '; echo " vga plain"; done
-for i in 1 2 3; do timeout 120 examples/icp_slam 60 1280 720 | grep -o '"frames_per_s": [0-9.]*' | tr '\n' ' '; echo " 720p gated"; O3DMI_ICP_NO_GATE=1 timeout 120 examples/icp_slam 60 1280 720 | grep -o '"frames_per_s": [0-9.]*' | tr '\n' ' '; echo " 720p plain"; done
+for fpl in 12 16; do
+python bench.py --no-secondary --no-cpu-baseline --no-pmc --frames-per-launch $fpl --block-count 524288 > gpurun_out/r3l_bench_fpl$fpl.json 2> gpurun_out/r3l_bench_fpl$fpl.err
+done
+python bench.py --no-secondary --no-cpu-baseline --no-pmc --block-count 524288 > gpurun_out/r3l_bench_fpl8_big.json 2> /dev/null
+python - <<'PY'
+import json
+for f in ("fpl12","fpl16","fpl8_big"):
+    d=json.loads(open("gpurun_out/r3l_bench_%s.json"%f).read().strip().splitlines()[-1])
+    r=d["roofline"]
+    print(f, "value %.0f cold %.0f kms %.4f frac %.3f equiv %.3f"%(d["value"], d["cold_pass_frames_per_s"], r["avg_kernel_ms"], r["frac"], r["equivalent_frac"]))
+PY
