@@ -914,8 +914,12 @@ int BuildIndex(o3dmi_nns* nns, const T* pts, const T* normals, hipStream_t s) {
     if (normals)
         { int st_; if ((st_ = PoolAlloc(&nns->sorted_normals, recs))) return st_; }
     { int st_; if ((st_ = PoolAlloc((void**)&nns->partials, sizeof(double) * kCUs * 4 * kNumSums))) return st_; }
-    O3DMI_HIP_CHECK(hipMemsetAsync(nns->ranges, 0,
-                                   sizeof(uint2) * (size_t)(nb + 1), s));
+    // one fill launch: a size that is not a multiple of 16 bytes is cleared
+    // by two (the pool rounds the block up to a power of two, so the padding
+    // is there)
+    O3DMI_HIP_CHECK(hipMemsetAsync(
+            nns->ranges, 0,
+            (sizeof(uint2) * (size_t)(nb + 1) + 255) & ~(size_t)255, s));
     if (n > 0) {
         hipLaunchKernelGGL(CountKernel<T>, dim3(GridFor(n, kBlock)),
                            dim3(kBlock), 0, s, pts, n, nns->inv_cell, mask,
