@@ -124,6 +124,7 @@ struct RayCastParams {
     uint8_t* mask;
     float *ratio, *ratio_dx, *ratio_dy, *ratio_dz;
     int* steps;  // diagnostics (O3DMI_RAYCAST_STEPS=1): march steps per pixel
+    int xcd_bands;  // tiles dealt to the XCDs in image bands (0: round-robin)
 };
 
 struct BlockCache {
@@ -229,7 +230,30 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
         tab.oz = (int)floorf(z_o / p.block_size);
     }
 
-    for (int tile = blockIdx.x; tile < tiles_x * tiles_y; tile += gridDim.x) {
+    // XCD-aware deal (round 3, O3DMI_RAYCAST_XCD_BANDS=1; measured SLOWER and
+    // off by default): workgroup b runs on XCD b % 8 (observed) and every XCD
+    // has its own 4 MB L2, so dealing the tiles in eight contiguous image
+    // bands, one per XCD, should keep a band's voxels in one L2 (round-robin:
+    // 58 % of the launch's L2 requests miss, profiles/
+    // r3n_raycast_counters.json). It does -- and it also hands all the
+    // long-marching tiles of a frame (the floor's grazing rays) to the same
+    // one or two XCDs: the launch is as long as its slowest tiles, 67.7
+    // against 65.4 us at VGA, 124 against 113 us per call at 720p. gridDim.x
+    // is a multiple of 8 either way.
+    const int n_tiles_all = tiles_x * tiles_y;
+    const int per_band = (n_tiles_all + 7) >> 3;
+    const int k_step = p.xcd_bands ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    for (int k = p.xcd_bands ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;;
+         k += k_step) {
+        int tile;
+        if (p.xcd_bands) {
+            if (k >= per_band) break;
+            tile = (int)(blockIdx.x & 7) * per_band + k;
+            if (tile >= n_tiles_all) break;
+        } else {
+            tile = k;
+            if (tile >= n_tiles_all) break;
+        }
         __syncthreads();  // the previous tile's readers are done
         for (int k = threadIdx.x; k < kLdsBlocks; k += blockDim.x)
             lds_blocks[k] = 0ull;
@@ -617,7 +641,11 @@ int o3dmi_vbg_raycast(o3dmi_hash_t* block_hash, const float* tsdf_dev,
     }
     // one workgroup per 32 x 8 pixel tile (grid-strided beyond 16 per CU)
     const int64_t n_tiles = (int64_t)((w + 31) / 32) * ((h + 7) / 8);
-    dim3 grid(GridFor(n_tiles, 1, kCUs * 16)), block(kBlock);
+    static const bool bands = std::getenv("O3DMI_RAYCAST_XCD_BANDS") != nullptr;
+    p.xcd_bands = bands ? 1 : 0;
+    // a multiple of 8 workgroups: every XCD gets the same number
+    dim3 grid((unsigned)((GridFor(n_tiles, 1, kCUs * 16) + 7) & ~7)),
+            block(kBlock);
     const bool full = out_index || out_mask || out_ratio || out_ratio_dx ||
                       out_ratio_dy || out_ratio_dz;
 #define O3DMI_RAYCAST(WT, CT, FULL)                                           \

@@ -1,21 +1,17 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_vbg_gpu.py tests/test_golden.py tests/test_slam_gpu.py -q -m gpu -x -k "raycast or ray_cast or golden or model or last_frame" 2>&1 | tail -3
 python tools/bench_raycast.py
-python tools/bench_raycast.py --attrs depth
+O3DMI_RAYCAST_NO_XCD=1 python tools/bench_raycast.py
 python tools/bench_raycast.py --hd
+O3DMI_RAYCAST_NO_XCD=1 python tools/bench_raycast.py --hd
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/rc_pmc -o rc -- python $GRAFT_REPO_ROOT/tools/bench_raycast.py --repeat 10 > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/rc_pmc2 -o rc -- python $GRAFT_REPO_ROOT/tools/bench_raycast.py --repeat 10 > /dev/null 2>&1
-rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCP_TOTAL_CACHE_ACCESSES_sum --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/rc_pmc3 -o rc -- python $GRAFT_REPO_ROOT/tools/bench_raycast.py --repeat 10 > /dev/null 2>&1
-cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rcA -o rc -- python $GRAFT_REPO_ROOT/tools/bench_raycast.py --repeat 20 > /dev/null 2>&1
+O3DMI_RAYCAST_NO_XCD=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rcB -o rc -- python $GRAFT_REPO_ROOT/tools/bench_raycast.py --repeat 20 > /dev/null 2>&1
+grep RayCastKernel /tmp/rcA/rc_kernel_stats.csv | cut -d, -f2-4 | tail -1
+grep RayCastKernel /tmp/rcB/rc_kernel_stats.csv | cut -d, -f2-4 | tail -1
 python - <<'PY'
-import csv,glob
-for d in ("rc_pmc","rc_pmc2","rc_pmc3"):
-    acc={}; disp=set()
-    for f in glob.glob("gpurun_out/%s/**/*counter_collection.csv"%d, recursive=True):
-        for r in csv.DictReader(open(f)):
-            if "RayCastKernel" not in r["Kernel_Name"]: continue
-            acc[r["Counter_Name"]]=acc.get(r["Counter_Name"],0)+float(r["Counter_Value"]); disp.add(r["Dispatch_Id"])
-    n=max(1,len(disp))
-    print(d, n, {k:round(v/n) for k,v in acc.items()})
+import csv
+for d in ("/tmp/rcA","/tmp/rcB"):
+    for r in csv.DictReader(open(d+"/rc_kernel_stats.csv")):
+        if "RayCastKernel" in r["Name"]: print(d, r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"])
 PY
