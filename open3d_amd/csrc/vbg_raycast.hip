@@ -230,16 +230,20 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
         tab.oz = (int)floorf(z_o / p.block_size);
     }
 
-    // XCD-aware deal (round 3, O3DMI_RAYCAST_XCD_BANDS=1; measured SLOWER and
-    // off by default): workgroup b runs on XCD b % 8 (observed) and every XCD
-    // has its own 4 MB L2, so dealing the tiles in eight contiguous image
-    // bands, one per XCD, should keep a band's voxels in one L2 (round-robin:
-    // 58 % of the launch's L2 requests miss, profiles/
-    // r3n_raycast_counters.json). It does -- and it also hands all the
-    // long-marching tiles of a frame (the floor's grazing rays) to the same
-    // one or two XCDs: the launch is as long as its slowest tiles, 67.7
-    // against 65.4 us at VGA, 124 against 113 us per call at 720p. gridDim.x
-    // is a multiple of 8 either way.
+    // XCD-aware deal (round 3): workgroup b runs on XCD b % 8 (observed; only
+    // speed depends on it) and every XCD has its own 4 MB L2. Dealt
+    // round-robin, the voxels a tile's rays meet are fetched into all eight
+    // L2s (58 % of the launch's L2 requests miss, profiles/
+    // r3n_raycast_counters.json); dealt in eight contiguous BANDS, one per
+    // XCD, into one. The bands are vertical strips (tiles numbered column by
+    // column): horizontal bands hand all the long-marching tiles of a frame --
+    // the floor's grazing rays -- to one or two XCDs and the launch, which is
+    // as long as its slowest tiles, gets slower (67.7 against 65.4 us at
+    // VGA); strips have floor, walls and ceiling each: 60.3 against 67.5 us.
+    // Only while every tile is resident at once (<= 5 workgroups per CU): at
+    // 720p the launch runs in rounds and the strips cost 4 %.
+    // O3DMI_RAYCAST_XCD_BANDS=0 / 1 forces the deal (A / B). gridDim.x is a
+    // multiple of 8 either way.
     const int n_tiles_all = tiles_x * tiles_y;
     const int per_band = (n_tiles_all + 7) >> 3;
     const int k_step = p.xcd_bands ? (int)(gridDim.x >> 3) : (int)gridDim.x;
@@ -258,7 +262,10 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
         for (int k = threadIdx.x; k < kLdsBlocks; k += blockDim.x)
             lds_blocks[k] = 0ull;
         __syncthreads();
-        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        // bands: tiles numbered column by column, so a band is a vertical
+        // strip of the image (floor, walls and ceiling in every strip)
+        const int ty = p.xcd_bands ? tile % tiles_y : tile / tiles_x;
+        const int tx = p.xcd_bands ? tile / tiles_y : tile - ty * tiles_x;
         const int x = tx * 32 + wave * 8 + (lane & 7);
         const int y = ty * 8 + (lane >> 3);
         if (x >= p.w || y >= p.h) continue;
@@ -641,8 +648,11 @@ int o3dmi_vbg_raycast(o3dmi_hash_t* block_hash, const float* tsdf_dev,
     }
     // one workgroup per 32 x 8 pixel tile (grid-strided beyond 16 per CU)
     const int64_t n_tiles = (int64_t)((w + 31) / 32) * ((h + 7) / 8);
-    static const bool bands = std::getenv("O3DMI_RAYCAST_XCD_BANDS") != nullptr;
-    p.xcd_bands = bands ? 1 : 0;
+    static const int bands_env = [] {
+        const char* e = std::getenv("O3DMI_RAYCAST_XCD_BANDS");
+        return e ? (e[0] == '0' ? 0 : 1) : -1;
+    }();
+    p.xcd_bands = bands_env >= 0 ? bands_env : (n_tiles <= kCUs * 5 ? 1 : 0);
     // a multiple of 8 workgroups: every XCD gets the same number
     dim3 grid((unsigned)((GridFor(n_tiles, 1, kCUs * 16) + 7) & ~7)),
             block(kBlock);
