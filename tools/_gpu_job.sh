@@ -1,12 +1,8 @@
 cd $GRAFT_REPO_ROOT
-cd /tmp && export TMPDIR=/tmp
-for hd in "" "--hd"; do
-O3DMI_RAYCAST_XCD_BANDS=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rcA$hd -o rc -- python $GRAFT_REPO_ROOT/tools/bench_raycast.py --repeat 20 $hd > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rcB$hd -o rc -- python $GRAFT_REPO_ROOT/tools/bench_raycast.py --repeat 20 $hd > /dev/null 2>&1
-done
-python - <<'PY'
-import csv
-for d in ("/tmp/rcA","/tmp/rcB","/tmp/rcA--hd","/tmp/rcB--hd"):
-    for r in csv.DictReader(open(d+"/rc_kernel_stats.csv")):
-        if "RayCastKernel" in r["Name"]: print(d, r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"])
-PY
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -8 > gpurun_out/r3q_pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+SECONDS=0
+timeout 1500 python bench.py > gpurun_out/r3q_bench.json 2> gpurun_out/r3q_bench.err
+echo "bench rc=$? seconds=$SECONDS"
+cat gpurun_out/r3q_pytest.log
