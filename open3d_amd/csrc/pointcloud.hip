@@ -564,11 +564,24 @@ VdsBucketScatterKernel(const int* __restrict__ slot_of_point, VdsTable tb,
         const int e = wbase + r * 64 + lane;
         slot[r] = e < n_host ? slot_of_point[e] : -1;
     }
+    // The column of the tile histogram this thread will sum, requested with
+    // the slots and the live count (one round trip instead of two): the rows
+    // of tiles past the live count are zero -- the reduce launch clears the
+    // table and the insert launch only adds to live tiles -- so all
+    // ceil(n_host / tile) <= 16 rows can be summed without knowing n.
+    constexpr int kMaxTiles = (int)(kBucketedMaxPoints / kSortTile);
+    static_assert(kMaxTiles <= 16, "one batch of column loads");
+    const int n_tiles_host = (n_host + kSortTile - 1) / kSortTile;
+    int colv[kMaxTiles];
+#pragma unroll
+    for (int u = 0; u < kMaxTiles; ++u)
+        colv[u] = (int)threadIdx.x < kBuckets && u < n_tiles_host
+                          ? tile_hist[(int64_t)u * kBuckets + threadIdx.x]
+                          : 0;
     const int n = LiveCount(n_dev, n_host);
     // block 0 always runs: it publishes the bucket starts (all zero for an
     // empty cloud)
     if (tile >= n && blockIdx.x != 0) return;
-    const int n_tiles = (n + kSortTile - 1) / kSortTile;
     // first point of its voxel? (a point outside the key range is a voxel of
     // its own)
     int first[kSortItems];
@@ -592,20 +605,10 @@ VdsBucketScatterKernel(const int* __restrict__ slot_of_point, VdsTable tb,
     {
         // where this tile's run of every bucket starts (SortScatterKernel)
         int all = 0, before = 0;
-        if ((int)threadIdx.x < kBuckets) {
-            const int* col = tile_hist + threadIdx.x;
-            for (int t0 = 0; t0 < n_tiles; t0 += 16) {
-                int c[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    c[u] = t0 + u < n_tiles ? col[(int64_t)(t0 + u) * kBuckets]
-                                            : 0;
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    all += c[u];
-                    before += t0 + u < (int)blockIdx.x ? c[u] : 0;
-                }
-            }
+        for (int u = 0; u < kMaxTiles; ++u) {
+            all += colv[u];
+            before += u < (int)blockIdx.x ? colv[u] : 0;
         }
         int total;
         const int run = BlockExclusive(all, lds4, &total);
@@ -669,6 +672,18 @@ VdsBucketReduceKernel(const T* __restrict__ pos, const T* __restrict__ nrm,
     __shared__ float e_nrm[kBucketLds][3];
     __shared__ int members[kMaxBucketWidth];  // points per slot of the bucket
     const int tid = threadIdx.x;
+    // The first-point bits of the whole cloud (<= 2048 words, 8 per lane),
+    // requested before anything that depends on the bucket's range: they
+    // depend on nothing but the buffer size (words past the live count are
+    // masked below).
+    constexpr int kWordsPer = (int)(kBucketedMaxPoints / 64) / kReduceBlock;  // 8
+    const int n_words_host = (n_host + 63) >> 6;
+    unsigned long long w[kWordsPer];
+#pragma unroll
+    for (int k = 0; k < kWordsPer; ++k) {
+        const int wi = tid * kWordsPer + k;
+        w[k] = wi < n_words_host ? first_bits[wi] : 0ull;
+    }
     const int b0 = bucket_start[blockIdx.x], b1 = bucket_start[blockIdx.x + 1];
     const int n = LiveCount(n_dev, n_host);
     const int count = b1 - b0;
@@ -691,21 +706,21 @@ VdsBucketReduceKernel(const T* __restrict__ pos, const T* __restrict__ nrm,
     if (tid < n_tiles_cap) tile_hist[(int64_t)tid * kBuckets + blockIdx.x] = 0;
     // ---- prefix popcount of the first-point bits (all words, every bucket) --
     const int n_words = (n + 63) >> 6;
-    constexpr int kWordsPer = (int)(kBucketedMaxPoints / 64) / kReduceBlock;  // 16
-    unsigned long long w[kWordsPer];
     int mine = 0;
 #pragma unroll
     for (int k = 0; k < kWordsPer; ++k) {
         const int wi = tid * kWordsPer + k;
-        w[k] = wi < n_words ? first_bits[wi] : 0ull;
+        if (wi >= n_words) w[k] = 0ull;  // never written by this level
         mine += __popcll(w[k]);
     }
+    unsigned long long ew[kPer];  // the first-point word of every entry
     if (staged) {
         float pf[kPer][3], qf[kPer][3];
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
             const int j = tid + k * kReduceBlock;
             const int64_t i = j < count ? (int64_t)ep[k] : 0;
+            ew[k] = first_bits[i >> 6];  // with the gathers: one round trip
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 pf[k][c] = (float)pos[3 * i + c];
@@ -755,8 +770,8 @@ VdsBucketReduceKernel(const T* __restrict__ pos, const T* __restrict__ nrm,
     }
     __syncthreads();
     // ---- one lane per entry; the lane of a voxel's first point adds it up ---
-    auto entry = [&](int j, unsigned s, unsigned i) {
-        const unsigned long long word = first_bits[i >> 6];
+    auto entry = [&](int j, unsigned s, unsigned i,
+                     unsigned long long word) {
         // the slot goes back to the empty state (members write the same)
         if (s != 0xFFFFFFFFu) {
             tb.keys[s] = kEmptyKey;
@@ -819,11 +834,13 @@ VdsBucketReduceKernel(const T* __restrict__ pos, const T* __restrict__ nrm,
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
             const int j = tid + k * kReduceBlock;
-            if (j < count) entry(j, es[k], ep[k]);
+            if (j < count) entry(j, es[k], ep[k], ew[k]);
         }
     } else {
-        for (int j = tid; j < count; j += kReduceBlock)
-            entry(j, ent_slot[b0 + j], ent_point[b0 + j]);
+        for (int j = tid; j < count; j += kReduceBlock) {
+            const unsigned i = ent_point[b0 + j];
+            entry(j, ent_slot[b0 + j], i, first_bits[i >> 6]);
+        }
     }
 }
 
