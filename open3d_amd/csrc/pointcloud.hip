@@ -263,9 +263,21 @@ SortScatterKernel(const unsigned* __restrict__ keys_in,
             val[r] = vals_in[e];
         }
     }
+    // The first kPre rows of this thread's column of the (tile, digit) table,
+    // requested with the elements and the live count instead of a round trip
+    // later: rows of tiles past the live count hold stale numbers and are
+    // masked when the column is summed.
+    constexpr int kPre = 32;
+    const int bins = 1 << bits;
+    const int n_tiles_host = (n_host + kSortTile - 1) / kSortTile;
+    int pre[kPre];
+#pragma unroll
+    for (int u = 0; u < kPre; ++u)
+        pre[u] = (int)threadIdx.x < bins && u < n_tiles_host
+                         ? hist[(int64_t)u * bins + threadIdx.x]
+                         : 0;
     const int n = LiveCount(n_dev, n_host);
     if (tile >= n) return;
-    const int bins = 1 << bits;
     const int n_tiles = (n + kSortTile - 1) / kSortTile;
     for (int b = threadIdx.x; b < kSortBins * kSortWaves; b += kSortBlock)
         (&wh[0][0])[b] = 0;
@@ -279,9 +291,15 @@ SortScatterKernel(const unsigned* __restrict__ keys_in,
     // Thread d sums column d of the table, sixteen rows in flight at a time.
     {
         int all = 0, before = 0;
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            const int c = u < n_tiles ? pre[u] : 0;
+            all += c;
+            before += u < (int)blockIdx.x ? c : 0;
+        }
         if ((int)threadIdx.x < bins) {
             const int* col = hist + threadIdx.x;
-            for (int t0 = 0; t0 < n_tiles; t0 += 16) {
+            for (int t0 = kPre; t0 < n_tiles; t0 += 16) {
                 int c[16];
 #pragma unroll
                 for (int u = 0; u < 16; ++u)
@@ -397,7 +415,8 @@ __global__ void VdsReduceKernel(const T* __restrict__ pos,
                                 const unsigned* __restrict__ sorted_key,
                                 const unsigned* __restrict__ sorted_point,
                                 const int* __restrict__ rank_of_first,
-                                const int* n_dev, int n_host,
+                                const int* __restrict__ slot_of_point,
+                                VdsTable tb, const int* n_dev, int n_host,
                                 T* __restrict__ out_pos,
                                 T* __restrict__ out_nrm) {
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n_host;
@@ -409,6 +428,13 @@ __global__ void VdsReduceKernel(const T* __restrict__ pos,
         if (j >= n) break;
         if (j > 0 && left == k) continue;
         const int v = rank_of_first[k];
+        // the voxel's hash slot back to the empty state: the table stays
+        // clean between levels (persistent workspace, no clearing launch)
+        const int slot = slot_of_point[k];
+        if (slot >= 0) {
+            tb.keys[slot & tb.mask] = kEmptyKey;
+            tb.first[slot & tb.mask] = 0x7FFFFFFF;
+        }
         float cnt = 0.f, sp[3] = {0.f, 0.f, 0.f}, sn[3] = {0.f, 0.f, 0.f};
         bool more = true;
         for (int j0 = j; more; j0 += kRun) {
@@ -987,7 +1013,17 @@ VdsSortWorkspace* ThreadVdsSortWorkspace(int chain, int64_t n_max,
                     get(&w.rank_of_first, (size_t)cap) &&
                     get(&w.keys_a, (size_t)cap) && get(&w.vals_a, (size_t)cap) &&
                     get(&w.keys_b, (size_t)cap) && get(&w.vals_b, (size_t)cap);
-    if (!ok) {
+    bool init_ok = ok;
+    if (ok) {
+        VdsTable tb;
+        tb.keys = w.keys;
+        tb.first = w.first;
+        tb.mask = (unsigned)(n_slots - 1);
+        hipLaunchKernelGGL(VdsInitKernel, dim3(GridFor(n_slots, kBlock)),
+                           dim3(kBlock), 0, s, tb, n_slots);
+        init_ok = hipGetLastError() == hipSuccess;
+    }
+    if (!init_ok) {
         w.Free();
         SetLastError("VoxelDownSample: workspace allocation failed");
         return nullptr;
@@ -1025,8 +1061,6 @@ int VdsAsyncImpl(const T* pos, const T* nrm, int64_t n_max, const int* n_dev,
              *vals_b = ws->vals_b;
     const dim3 grid(GridFor(n_max, kBlock)), block(kBlock);
     const dim3 tiles((unsigned)n_tiles), sblock(kSortBlock);
-    hipLaunchKernelGGL(VdsInitKernel, dim3(GridFor(n_slots, kBlock)), block, 0,
-                       s, tb, n_slots);
     hipLaunchKernelGGL(VdsInsertKernel<T>, grid, block, 0, s, pos, n_dev,
                        n_host, (T)voxel_size, tb, slot_of_point, err_dev);
     // keys = index of the voxel's first point < n_max
@@ -1053,7 +1087,8 @@ int VdsAsyncImpl(const T* pos, const T* nrm, int64_t n_max, const int* n_dev,
         std::swap(vi, vo);
     }
     hipLaunchKernelGGL(VdsReduceKernel<T>, grid, block, 0, s, pos, nrm, ki, vi,
-                       rank_of_first, n_dev, n_host, out_pos, out_nrm);
+                       rank_of_first, slot_of_point, tb, n_dev, n_host, out_pos,
+                       out_nrm);
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
 }
