@@ -637,7 +637,7 @@ def secondary_legs():
     for tag, vga in (("configs2_loop_1280x720", False),
                      ("configs2_loop_640x480", True)):
         base = dict(frames=60, frame_step=2, block_count=65536, phases=False,
-                    vga=vga, cpu_frames=1)
+                    vga=vga, cpu_frames=1, host_counts=False)
         bs.mode_slam(types.SimpleNamespace(**dict(base, frames=8,
                                                   cpu_frames=0)))  # warm-up
         r = bs.mode_slam(types.SimpleNamespace(**base))

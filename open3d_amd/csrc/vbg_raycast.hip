@@ -124,11 +124,15 @@ struct RayCastParams {
     uint8_t* mask;
     float *ratio, *ratio_dx, *ratio_dy, *ratio_dz;
     int* steps;  // diagnostics (O3DMI_RAYCAST_STEPS=1): march steps per pixel
+    long long* clocks;  // ... and per workgroup: start, march done, end (100 MHz)
     int xcd_bands;  // tiles dealt to the XCDs in image bands (0: round-robin)
+    int coop;       // idle lanes sample ahead for crawling rays (0: O3DMI_RAYCAST_COOP=0)
 };
 
 struct BlockCache {
     int x, y, z, block_idx;
+    int n_table, n_hash;  // diagnostics: look-ups past the register cache
+    bool diag;
     __device__ __forceinline__ int Check(int xi, int yi, int zi) const {
         return (xi == x && yi == y && zi == z) ? block_idx : -1;
     }
@@ -186,9 +190,11 @@ __device__ __forceinline__ int FindBlock(const HashView& hv,
     if (idx >= 0) return idx;
     unsigned rel;
     const bool in_table = tab.Encode(x_b, y_b, z_b, rel);
+    if (cache.diag) ++cache.n_table;
     if (in_table) idx = tab.Lookup(rel);
     else idx = -2;
     if (idx == -2) {
+        if (cache.diag) ++cache.n_hash;
         idx = hv.Find(x_b, y_b, z_b);
         if (in_table) tab.Store(rel, idx);
     }
@@ -200,14 +206,20 @@ __device__ __forceinline__ int FindBlock(const HashView& hv,
 // The common depth / vertex / colour / normal rendering (slam::Model) runs the
 // slim instantiation: without the 8-entry output arrays it needs half the
 // registers, so every ray of a 720p frame is resident at once.
-template <typename weight_t, typename color_t, bool FULL>
-__global__ void __launch_bounds__(256)
+template <typename weight_t, typename color_t, bool FULL, int RES, bool DIAG>
+__global__ void __launch_bounds__(256, RES ? (FULL ? 4 : 5) : 0)
 RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
               const weight_t* __restrict__ weight_base,
               const color_t* __restrict__ color_base,
               const float* __restrict__ range_map) {
     __shared__ unsigned long long lds_blocks[kLdsBlocks];
-    const int res = p.block_resolution;
+    // cooperative march (below): ray state of up to 32 rays per wave, and the
+    // samples their helper lanes fetch
+    __shared__ float coop_state[4][32][8];
+    __shared__ float coop_result[4][32][6];
+    // RES = 16 (the block resolution everything uses) folds the index
+    // arithmetic into shifts; RES = 0 takes it from the call
+    const int res = RES ? RES : p.block_resolution;
     const int res2 = res * res;
     const int res3 = res2 * res;
     const bool render_color = color_base != nullptr && p.color != nullptr;
@@ -258,6 +270,8 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
             tile = k;
             if (tile >= n_tiles_all) break;
         }
+        if (DIAG && threadIdx.x == 0)
+            p.clocks[3 * (int64_t)tile] = wall_clock64();
         __syncthreads();  // the previous tile's readers are done
         for (int k = threadIdx.x; k < kLdsBlocks; k += blockDim.x)
             lds_blocks[k] = 0ull;
@@ -268,11 +282,16 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
         const int tx = p.xcd_bands ? tile / tiles_y : tile - ty * tiles_x;
         const int x = tx * 32 + wave * 8 + (lane & 7);
         const int y = ty * 8 + (lane >> 3);
-        if (x >= p.w || y >= p.h) continue;
-        const int64_t workload_idx = (int64_t)y * p.w + x;
+        // a pixel outside the image keeps its lane in the wave (the march
+        // below is wave-uniform), it just has no ray and stores nothing
+        const bool inside = x < p.w && y < p.h;
+        const int64_t workload_idx =
+                inside ? (int64_t)y * p.w + x : (int64_t)0;
         const float* range =
-                range_map + 2 * ((int64_t)(y / p.range_down) * p.w_down +
-                                 (x / p.range_down));
+                range_map +
+                (inside ? 2 * ((int64_t)(y / p.range_down) * p.w_down +
+                               (x / p.range_down))
+                        : (int64_t)0);
 
         float* depth_ptr = p.depth ? p.depth + workload_idx : nullptr;
         float* vertex_ptr = p.vertex ? p.vertex + 3 * workload_idx : nullptr;
@@ -303,7 +322,7 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
 
         float t = range[0];
         const float t_max = range[1];
-        if (t < t_max) {
+        {
             float x_c, y_c, z_c, x_g, y_g, z_g, x_o, y_o, z_o;
             float t_prev = t;
             float tsdf_prev = -1.0f;
@@ -315,44 +334,239 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
             p.c2w.RigidTransform(x_c, y_c, z_c, x_g, y_g, z_g);
             const float x_d = x_g - x_o, y_d = y_g - y_o, z_d = z_g - z_o;
 
-            BlockCache cache{0, 0, 0, -1};
+            BlockCache cache{0, 0, 0, -1, 0, 0, DIAG};
             bool surface_found = false;
+            int n_crawl = 0;
             int n_steps = 0;
-            while (t < t_max) {
-                ++n_steps;
-                // GetLinearIdxAtT, VoxelBlockGridImpl.h:784-823
-                float xg = x_o + t * x_d;
-                float yg = y_o + t * y_d;
-                float zg = z_o + t * z_d;
-                int x_b = (int)floorf(xg / p.block_size);
-                int y_b = (int)floorf(yg / p.block_size);
-                int z_b = (int)floorf(zg / p.block_size);
+            // GetLinearIdxAtT, VoxelBlockGridImpl.h:784-823, for the sample
+            // at parameter tj of the ray with direction (dx, dy, dz); -1 if
+            // its block does not exist
+            const auto locate = [&](float tj, float dx, float dy,
+                                    float dz) -> int64_t {
+                const float xg = x_o + tj * dx;
+                const float yg = y_o + tj * dy;
+                const float zg = z_o + tj * dz;
+                const int x_b = (int)floorf(xg / p.block_size);
+                const int y_b = (int)floorf(yg / p.block_size);
+                const int z_b = (int)floorf(zg / p.block_size);
                 const int block_buf_idx =
                         FindBlock(hv, tab, cache, x_b, y_b, z_b);
-                if (block_buf_idx < 0) {
+                if (block_buf_idx < 0) return -1;
+                const int x_v =
+                        (int)((xg - x_b * p.block_size) / p.voxel_size);
+                const int y_v =
+                        (int)((yg - y_b * p.block_size) / p.voxel_size);
+                const int z_v =
+                        (int)((zg - z_b * p.block_size) / p.voxel_size);
+                return (int64_t)block_buf_idx * res3 +
+                       (z_v * res2 + y_v * res + x_v);
+            };
+            // The reference's march (VoxelBlockGridImpl.h:825-870), sample
+            // for sample. The launch lasts as long as its slowest wave, and
+            // a wave as long as its longest ray: 6.7 samples on average in
+            // the tracking scene, 67 for the worst, most of them CRAWL steps
+            // -- samples with tsdf * sdf_trunc < voxel_size (unobserved
+            // voxels of an allocated block, tsdf 0 weight 0; voxels near or
+            // behind a surface the weight threshold hides), after which the
+            // march moves exactly one voxel size. The slowest workgroup took
+            // 59 us where the median takes 17 (O3DMI_RAYCAST_STEPS=1 prints
+            // these distributions). A step is ~300 instructions plus a load,
+            // and the instructions are the larger part: sampling ahead in
+            // the ray's own lane costs what it saves, a warmed block table
+            // or fewer dependent loads change nothing (all measured, round
+            // 3). But while the long rays crawl, most lanes of their wave are
+            // idle. So the march has two phases: the plain per-lane loop
+            // while more than half of the wave is marching, then a
+            // WAVE-UNIFORM loop in which a finished lane stays, idle -- and
+            // whenever one of the rays left is crawling, every ray gets 2
+            // lanes (up to 32 rays left), 4 (16), ... 64 (the last one),
+            // which locate and load the samples at t, t + voxel, t + 2 voxel,
+            // ... at the price of one step. The window is then resolved in
+            // parallel: sample j + 1 is reached iff sample j is a crawl step
+            // inside the range, the first lane whose sample is not such a
+            // step holds the last sample consumed and works out the ray's
+            // state after it (t, t_prev, tsdf, tsdf_prev as the reference's
+            // loop would leave them). `t + voxel_size` is the same float
+            // addition in a helper lane and in the march: the sample
+            // positions, and so every output, are the reference's bit for
+            // bit. 72 -> 57.5 us per VGA launch, 113 -> 98 us at 720p, the
+            // slowest workgroup 59 -> 42 us (same box; O3DMI_RAYCAST_COOP=0
+            // switches the second phase off).
+            bool mine = inside && t < t_max;
+            bool crawling = false;
+            int it_plain = 0, it_coop = 0;  // DIAG: loop passes of the wave
+            // one sample of this lane's ray, the reference's loop body
+            const auto step = [&]() {
+                ++n_steps;
+                const int64_t lin = locate(t, x_d, y_d, z_d);
+                if (lin < 0) {
                     t_prev = t;
                     t += p.block_size;
+                    crawling = false;
                 } else {
-                    int x_v = (int)((xg - x_b * p.block_size) / p.voxel_size);
-                    int y_v = (int)((yg - y_b * p.block_size) / p.voxel_size);
-                    int z_v = (int)((zg - z_b * p.block_size) / p.voxel_size);
-                    int64_t linear_idx = (int64_t)block_buf_idx * res3 +
-                                         z_v * res2 + y_v * res + x_v;
                     tsdf_prev = tsdf;
-                    tsdf = tsdf_base[linear_idx];
-                    wgt = (float)weight_base[linear_idx];
+                    tsdf = tsdf_base[lin];
+                    wgt = (float)weight_base[lin];
                     if (tsdf_prev > 0 && wgt >= p.weight_threshold &&
                         tsdf <= 0) {
                         surface_found = true;
-                        break;
+                    } else {
+                        t_prev = t;
+                        const float delta = tsdf * p.sdf_trunc;
+                        crawling = delta < p.voxel_size;
+                        if (DIAG) n_crawl += crawling ? 1 : 0;
+                        t += crawling ? p.voxel_size : delta;
                     }
-                    t_prev = t;
-                    float delta = tsdf * p.sdf_trunc;
-                    t += delta < p.voxel_size ? p.voxel_size : delta;
                 }
+                mine = !surface_found && t < t_max;
+            };
+            // while more than half of the wave marches: the plain loop
+            while (mine) {
+                if (p.coop &&
+                    __popcll(__builtin_amdgcn_ballot_w64(true)) <= 32)
+                    break;
+                if (DIAG) ++it_plain;
+                step();
+            }
+            for (;;) {
+                const unsigned long long act =
+                        __builtin_amdgcn_ballot_w64(mine);
+                if (act == 0) break;
+                const int n_act = __popcll(act);
+                // lanes per ray, as log2: 2 lanes while up to 32 rays are
+                // left, 4 up to 16, ... 64 for the last ray
+                const int shift =
+                        n_act <= 1 ? 6 : __builtin_clz((unsigned)(n_act - 1)) - 26;
+                const bool coop =
+                        p.coop && n_act <= 32 &&
+                        __builtin_amdgcn_ballot_w64(mine && crawling) != 0;
+                if (DIAG) {
+                    it_plain += coop ? 0 : 1;
+                    it_coop += coop ? 1 : 0;
+                }
+                if (!coop) {
+                    if (mine) step();
+                    continue;
+                }
+                // ---- cooperative step: the ray of rank r gets the lanes
+                // r << shift .. ((r + 1) << shift) - 1, lane j of them the
+                // sample at t + j voxel sizes
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi(
+                        (unsigned)(act >> 32),
+                        __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
+                if (mine) {
+                    float* st = coop_state[wave][rank];
+                    st[0] = t;
+                    st[1] = x_d;
+                    st[2] = y_d;
+                    st[3] = z_d;
+                    st[4] = t_max;
+                    st[5] = tsdf;
+                    st[6] = tsdf_prev;
+                    st[7] = t_prev;
+                }
+                __builtin_amdgcn_wave_barrier();
+                {
+                    const int width = 1 << shift;
+                    const int slot = lane >> shift;
+                    const int j = lane & (width - 1);
+                    const bool helper = slot < n_act;
+                    const float* st = coop_state[wave][helper ? slot : 0];
+                    float tj = st[0];
+                    const float hx = st[1], hy = st[2], hz = st[3];
+                    const float h_max = st[4];
+                    const float o_tsdf = st[5], o_tsdf_prev = st[6];
+                    const float o_t_prev = st[7];
+                    // j additions of the voxel size, one after the other as
+                    // the march makes them
+                    for (int k = 0; k < j; ++k) tj += p.voxel_size;
+                    int64_t lin = -1;
+                    const bool sampled = helper && (j == 0 || tj < h_max);
+                    if (sampled) lin = locate(tj, hx, hy, hz);
+                    // no branch around the loads (the compiler would wait
+                    // for them inside it): a sample without a block reads
+                    // voxel 0 of the buffers and is never looked at
+                    const int64_t at = lin >= 0 ? lin : 0;
+                    const float ts = tsdf_base[at];
+                    const float wt = (float)weight_base[at];
+                    // The march over the window, all samples at once. Lane j
+                    // needs the tsdf of the one and two samples before it
+                    // (the ray's own last two for j < 2) and the t of the
+                    // sample before it; sample j + 1 is reached iff sample j
+                    // is a crawl step that stays inside the range; the first
+                    // sample that is not such a step is the last one
+                    // consumed, and its lane works out the ray's new state.
+                    float ts_1 = __shfl_up(ts, 1, width);
+                    float ts_2 = __shfl_up(ts, 2, width);
+                    float t_1 = __shfl_up(tj, 1, width);
+                    if (j < 1) { ts_1 = o_tsdf; t_1 = o_t_prev; }
+                    if (j < 2) ts_2 = j == 0 ? o_tsdf_prev : o_tsdf;
+                    const bool valid = lin >= 0;
+                    const bool surface = valid && ts_1 > 0 &&
+                                         wt >= p.weight_threshold && ts <= 0;
+                    const float delta = ts * p.sdf_trunc;
+                    const bool crawl = delta < p.voxel_size;
+                    const float t_next = tj + (crawl ? p.voxel_size : delta);
+                    const bool goes_on = sampled && valid && !surface &&
+                                         crawl && t_next < h_max;
+                    const unsigned long long stops =
+                            __builtin_amdgcn_ballot_w64(!goes_on) >>
+                            (slot << shift);
+                    // (a window always stops: its last lane at the latest)
+                    const int j_last =
+                            min(__builtin_ctzll(stops | (1ull << (width - 1))),
+                                width - 1);
+                    if (helper && j == j_last) {
+                        float* rs = coop_result[wave][slot];
+                        const bool all_on = goes_on;  // window used up
+                        if (!valid) {
+                            rs[0] = tj + p.block_size;  // t
+                            rs[1] = tj;                 // t_prev
+                            rs[2] = ts_1;               // tsdf
+                            rs[3] = ts_2;               // tsdf_prev
+                            rs[4] = 0.0f;               // 1 surface, 2 crawling
+                        } else if (surface) {
+                            rs[0] = tj;
+                            rs[1] = t_1;
+                            rs[2] = ts;
+                            rs[3] = ts_1;
+                            rs[4] = 1.0f;
+                        } else {
+                            rs[0] = t_next;
+                            rs[1] = tj;
+                            rs[2] = ts;
+                            rs[3] = ts_1;
+                            rs[4] = crawl ? 2.0f : 0.0f;
+                        }
+                        (void)all_on;
+                        rs[5] = (float)(j_last + 1);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (mine) {
+                    const float* rs = coop_result[wave][rank];
+                    t = rs[0];
+                    t_prev = rs[1];
+                    tsdf = rs[2];
+                    tsdf_prev = rs[3];
+                    surface_found = rs[4] == 1.0f;
+                    crawling = rs[4] == 2.0f;
+                    const int consumed = (int)rs[5];
+                    n_steps += consumed;
+                    if (DIAG) n_crawl += crawling ? consumed : consumed - 1;
+                    mine = !surface_found && t < t_max;
+                }
+                __builtin_amdgcn_wave_barrier();
             }
 
-            if (p.steps) p.steps[workload_idx] = n_steps;
+            if (DIAG && inside)
+                p.steps[workload_idx] = (n_steps & 255) |
+                                        ((min(it_plain, 255)) << 8) |
+                                        ((min(it_coop, 255)) << 16) |
+                                        ((n_crawl & 255) << 24);
+            if (DIAG)
+                atomicMax((unsigned long long*)&p.clocks[3 * (int64_t)tile + 1],
+                          (unsigned long long)wall_clock64());
             if (surface_found) {
                 float t_intersect =
                         (t * tsdf_prev - t_prev * tsdf) / (tsdf_prev - tsdf);
@@ -509,6 +723,7 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
             }
         }
 
+        if (!inside) continue;  // (no barrier and no wave-wide step below)
         if (depth_ptr) *depth_ptr = out_depth;
         if (vertex_ptr) {
             vertex_ptr[0] = out_vertex[0];
@@ -534,6 +749,9 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
             if (index_ptr) index_ptr[k] = o_index[k];
             if (mask_ptr) mask_ptr[k] = o_mask[k];
         }
+        if (DIAG)
+            atomicMax((unsigned long long*)&p.clocks[3 * (int64_t)tile + 2],
+                      (unsigned long long)wall_clock64());
     }
 }
 
@@ -641,10 +859,14 @@ int o3dmi_vbg_raycast(o3dmi_hash_t* block_hash, const float* tsdf_dev,
     p.ratio_dz = out_ratio_dz;
     hipStream_t s = (hipStream_t)stream;
     p.steps = nullptr;
+    p.clocks = nullptr;
     static const bool count_steps = std::getenv("O3DMI_RAYCAST_STEPS") != nullptr;
     if (count_steps) {
         O3DMI_HIP_CHECK(hipMalloc((void**)&p.steps, sizeof(int) * (size_t)h * w));
         O3DMI_HIP_CHECK(hipMemsetAsync(p.steps, 0, sizeof(int) * (size_t)h * w, s));
+        const size_t nt = (size_t)((w + 31) / 32) * ((h + 7) / 8);
+        O3DMI_HIP_CHECK(hipMalloc((void**)&p.clocks, sizeof(long long) * 3 * nt));
+        O3DMI_HIP_CHECK(hipMemsetAsync(p.clocks, 0, sizeof(long long) * 3 * nt, s));
     }
     // one workgroup per 32 x 8 pixel tile (grid-strided beyond 16 per CU)
     const int64_t n_tiles = (int64_t)((w + 31) / 32) * ((h + 7) / 8);
@@ -653,15 +875,29 @@ int o3dmi_vbg_raycast(o3dmi_hash_t* block_hash, const float* tsdf_dev,
         return e ? (e[0] == '0' ? 0 : 1) : -1;
     }();
     p.xcd_bands = bands_env >= 0 ? bands_env : (n_tiles <= kCUs * 5 ? 1 : 0);
+    static const int coop_env = [] {
+        const char* e = std::getenv("O3DMI_RAYCAST_COOP");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    p.coop = coop_env;
     // a multiple of 8 workgroups: every XCD gets the same number
     dim3 grid((unsigned)((GridFor(n_tiles, 1, kCUs * 16) + 7) & ~7)),
             block(kBlock);
     const bool full = out_index || out_mask || out_ratio || out_ratio_dx ||
                       out_ratio_dy || out_ratio_dz;
+#define O3DMI_RAYCAST_R(WT, CT, FULL, RES, DIAG)                              \
+    hipLaunchKernelGGL((RayCastKernel<WT, CT, FULL, RES, DIAG>), grid, block, \
+                       0, s, block_hash->view, p, tsdf_dev,                   \
+                       (const WT*)weight_dev, (const CT*)color_buf_dev,       \
+                       range_map_dev)
+    // (the diagnostics exist for the common case only: 16^3 blocks, slim maps)
 #define O3DMI_RAYCAST(WT, CT, FULL)                                           \
-    hipLaunchKernelGGL((RayCastKernel<WT, CT, FULL>), grid, block, 0, s,      \
-                       block_hash->view, p, tsdf_dev, (const WT*)weight_dev,  \
-                       (const CT*)color_buf_dev, range_map_dev)
+    do {                                                                      \
+        if (block_resolution != 16) O3DMI_RAYCAST_R(WT, CT, FULL, 0, false);  \
+        else if (count_steps && !FULL)                                        \
+            O3DMI_RAYCAST_R(WT, CT, false, 16, true);                         \
+        else O3DMI_RAYCAST_R(WT, CT, FULL, 16, false);                        \
+    } while (0)
     if (grid_dtype == O3DMI_F32) {
         if (full) O3DMI_RAYCAST(float, float, true);
         else O3DMI_RAYCAST(float, float, false);
@@ -670,6 +906,7 @@ int o3dmi_vbg_raycast(o3dmi_hash_t* block_hash, const float* tsdf_dev,
         else O3DMI_RAYCAST(uint16_t, uint16_t, false);
     }
 #undef O3DMI_RAYCAST
+#undef O3DMI_RAYCAST_R
     O3DMI_HIP_CHECK(hipGetLastError());
     if (count_steps) {
         std::vector<int> hs((size_t)h * w);
@@ -680,6 +917,8 @@ int o3dmi_vbg_raycast(o3dmi_hash_t* block_hash, const float* tsdf_dev,
         // per-pixel and per-8x8-tile (= per wave) statistics
         long long sum = 0, wsum = 0;
         int mx = 0, nw = 0, wmax_max = 0;
+        const std::vector<int> packed = hs;  // steps | hash << 8 | table << 16 | crawl << 24
+        for (int& v : hs) v &= 255;
         for (int v : hs) { sum += v; mx = v > mx ? v : mx; }
         std::vector<int> wmaxes;
         for (int ty = 0; ty < h / 8; ++ty)
@@ -710,6 +949,67 @@ int o3dmi_vbg_raycast(o3dmi_hash_t* block_hash, const float* tsdf_dev,
             std::fprintf(stderr, " %d steps: %lld (%lld steps beyond);", th[k],
                          over[k], steps_over[k]);
         std::fprintf(stderr, "\n");
+        // workgroup clocks (100 MHz): when the tiles start, how long their
+        // march and their whole work lasts, when the last one ends
+        const size_t nt = (size_t)((w + 31) / 32) * ((h + 7) / 8);
+        std::vector<long long> ck(3 * nt);
+        O3DMI_HIP_CHECK(hipMemcpy(ck.data(), p.clocks,
+                                  sizeof(long long) * ck.size(),
+                                  hipMemcpyDeviceToHost));
+        (void)hipFree(p.clocks);
+        long long t0 = ck[0];
+        for (size_t k = 0; k < nt; ++k) t0 = ck[3 * k] < t0 ? ck[3 * k] : t0;
+        std::vector<double> start, march, total, end;
+        for (size_t k = 0; k < nt; ++k) {
+            start.push_back((ck[3 * k] - t0) * 0.01);
+            march.push_back((ck[3 * k + 1] - ck[3 * k]) * 0.01);
+            total.push_back((ck[3 * k + 2] - ck[3 * k]) * 0.01);
+            end.push_back((ck[3 * k + 2] - t0) * 0.01);
+        }
+        const auto q = [](std::vector<double> v, double f) {
+            std::sort(v.begin(), v.end());
+            return v[(size_t)((v.size() - 1) * f)];
+        };
+        // the slowest tiles, with their rays' look-up counts
+        std::vector<size_t> order(nt);
+        for (size_t k = 0; k < nt; ++k) order[k] = k;
+        std::sort(order.begin(), order.end(),
+                  [&](size_t a, size_t b) { return total[a] > total[b]; });
+        const int tiles_x = (w + 31) / 32, tiles_y = (h + 7) / 8;
+        for (int r = 0; r < 6 && r < (int)nt; ++r) {
+            const size_t tile = order[r];
+            const int ty = p.xcd_bands ? (int)(tile % tiles_y) : (int)(tile / tiles_x);
+            const int tx = p.xcd_bands ? (int)(tile / tiles_y) : (int)(tile % tiles_x);
+            int m[4] = {0, 0, 0, 0};
+            long long sm[4] = {0, 0, 0, 0};
+            for (int dy = 0; dy < 8; ++dy)
+                for (int dx = 0; dx < 32; ++dx) {
+                    const int y = ty * 8 + dy, x = tx * 32 + dx;
+                    if (y >= h || x >= w) continue;
+                    const unsigned v = (unsigned)packed[(size_t)y * w + x];
+                    for (int c = 0; c < 4; ++c) {
+                        const int f = (v >> (8 * c)) & 255;
+                        m[c] = f > m[c] ? f : m[c];
+                        sm[c] += f;
+                    }
+                }
+            std::fprintf(stderr,
+                         "[o3dmi] raycast slow tile (%d, %d): start %.1f march "
+                         "%.1f total %.1f us; per ray max / mean: steps %d / "
+                         "%.1f, plain passes %d / %.1f, cooperative passes %d / "
+                         "%.1f, crawl steps %d / %.1f\n",
+                         tx, ty, start[tile], march[tile], total[tile], m[0],
+                         sm[0] / 256.0, m[1], sm[1] / 256.0, m[2],
+                         sm[2] / 256.0, m[3], sm[3] / 256.0);
+        }
+        const char* names[4] = {"start", "march", "total", "end"};
+        const std::vector<double>* vs[4] = {&start, &march, &total, &end};
+        for (int k = 0; k < 4; ++k)
+            std::fprintf(stderr,
+                         "[o3dmi] raycast workgroup %s us: p10 %.1f p50 %.1f "
+                         "p90 %.1f p99 %.1f max %.1f\n",
+                         names[k], q(*vs[k], 0.1), q(*vs[k], 0.5),
+                         q(*vs[k], 0.9), q(*vs[k], 0.99), q(*vs[k], 1.0));
     }
     return O3DMI_OK;
 }

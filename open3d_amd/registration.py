@@ -74,8 +74,12 @@ def multi_scale_icp(source, target, target_normals, voxel_sizes, criteria_list,
                     estimation_method=None, callback_after_iteration=None,
                     allreduce=None, source_normals=None, source_colors=None,
                     target_colors=None, target_color_gradients=None,
-                    device_allreduce=None):
-    """source/target/target_normals: device tensors {N,3}. `allreduce`
+                    device_allreduce=None, device_counts=None):
+    """source/target/target_normals: device tensors {N,3}. `device_counts`
+    (optional): (ns, nt) int32 device tensors of one element holding the LIVE
+    sizes of source / target, whose tensors are then buffers of at least that
+    many rows (o3dmi_registration_set_device_counts: no read-back of the
+    sizes). `allreduce`
     (optional) sums a length-32 numpy float64 array over ranks in place;
     `device_allreduce(dev_ptr, n, stream_ptr)` (optional, takes precedence;
     sharding.make_device_allreduce) enqueues the same sum on the device.
@@ -170,6 +174,10 @@ def multi_scale_icp(source, target, target_normals, voxel_sizes, criteria_list,
                 return 1
         dar = _lib.ALLREDUCE_DEVICE(_dar)
         _lib.lib().o3dmi_set_device_allreduce(dar, None)
+    if device_counts is not None:
+        ns_dev, nt_dev = device_counts
+        _lib.check(_lib.lib().o3dmi_registration_set_device_counts(
+            _lib.ptr(ns_dev), _lib.ptr(nt_dev)), "set_device_counts")
     try:
         st = _icp_call(source, ns, target, target_normals, nt, S, vs, crit, md,
                        init, p2point, symmetric, colored, attrs, est, cb, ar,
@@ -207,7 +215,8 @@ def icp(source, target, target_normals, max_correspondence_distance,
         init_source_to_target=None, estimation_method=None, criteria=None,
         voxel_size=-1.0, callback_after_iteration=None, allreduce=None,
         source_normals=None, source_colors=None, target_colors=None,
-        target_color_gradients=None, device_allreduce=None):
+        target_color_gradients=None, device_allreduce=None,
+        device_counts=None):
     """t::pipelines::registration::ICP (Registration.cpp:93-106)."""
     return multi_scale_icp(source, target, target_normals, [voxel_size],
                            [criteria or ICPConvergenceCriteria()],
@@ -215,7 +224,8 @@ def icp(source, target, target_normals, max_correspondence_distance,
                            init_source_to_target, estimation_method,
                            callback_after_iteration, allreduce, source_normals,
                            source_colors, target_colors,
-                           target_color_gradients, device_allreduce)
+                           target_color_gradients, device_allreduce,
+                           device_counts)
 
 
 def _check_pair(source, target):

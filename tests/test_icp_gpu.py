@@ -1557,6 +1557,11 @@ def test_multiscale_icp_with_device_resident_cloud_sizes(voxels):
     again = reg.multi_scale_icp(src[:ns].clone(), tgt[:nt].contiguous(),
                                 nrm[:nt].contiguous(), voxels, crit, md)
     assert np.array_equal(again.transformation, want.transformation)
+    # the keyword form of the Python mirror is the same setting
+    kw = reg.multi_scale_icp(src_buf, tgt_buf, nrm_buf, voxels, crit, md,
+                             device_counts=(counts[0:1], counts[1:2]))
+    assert np.array_equal(kw.transformation, want.transformation)
+    assert kw.num_iterations == want.num_iterations
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

@@ -552,6 +552,77 @@ def test_raycast_parity(grid_f32):
     assert np.array_equal((gi % res3)[m], (wi % res3)[m])
 
 
+def _raycast_case(res, width, height, down, weight_threshold, n_frames,
+                  grid_f32=False):
+    """Integrate n_frames, then EstimateRange + RayCast (depth / vertex /
+    normal / colour) on both sides; returns (oracle maps, library maps)."""
+    _lib, geometry = _gpu()
+    g = _mk_grid(geometry, grid_f32, res=res, block_count=8192)
+    og = OracleGrid(grid_f32, 8192, res=res)
+    for k in range(300, 300 + 2 * n_frames, 2):
+        d, c, K, Ts = sc.frames(k, 1, width, height)
+        keys = og.integrate(d[0], c[0], K, Ts[0])
+        g.integrate(torch.from_numpy(keys).cuda(),
+                    torch.from_numpy(d[0]).cuda(),
+                    torch.from_numpy(c[0]).cuda(), K, K, Ts[0],
+                    sc.DEPTH_SCALE, sc.DEPTH_MAX, sc.TRUNC_MULT)
+    T = Ts[0]
+    attrs = ("depth", "vertex", "normal", "color")
+    range_o, needed = orc.estimate_range(keys, K, T, height, width, down, res,
+                                         sc.VOXEL, 0.1, sc.DEPTH_MAX,
+                                         frag_buffer_size=65536)
+    assert needed < 65536
+    want = orc.raycast(og.h, og.tsdf, og.weight, og.color, range_o, K, T,
+                       height, width, res, sc.VOXEL, sc.DEPTH_SCALE, 0.1,
+                       sc.DEPTH_MAX, weight_threshold, sc.TRUNC_MULT, down,
+                       attrs)
+    got = g.ray_cast(torch.from_numpy(keys).cuda(), K, T, width, height, attrs,
+                     sc.DEPTH_SCALE, 0.1, sc.DEPTH_MAX, weight_threshold,
+                     sc.TRUNC_MULT, down)
+    assert np.array_equal(got["range"].cpu().numpy(), range_o)
+    return want, {a: got[a].cpu().numpy() for a in attrs}
+
+
+def _assert_maps(want, got):
+    assert np.array_equal(got["depth"] > 0, want["depth"] > 0)
+    assert np.abs(got["depth"] - want["depth"]).max() <= 1e-3  # mm
+    for a in ("vertex", "normal", "color"):
+        assert np.abs(got[a] - want[a]).max() <= 1e-5, a
+
+
+@pytest.mark.parametrize("res,width,height,down,min_hit", [
+    (16, 200, 148, 4, 0.9),  # tiles cut by the right and the lower border
+    (8, 320, 240, 4, 0.9),   # the kernel taking the resolution at run time
+    (16, 72, 40, 8, 0.5),    # 15 tiles: fewer than two per XCD
+])
+def test_raycast_partial_tiles_and_block_resolutions(res, width, height, down,
+                                                     min_hit):
+    """The ray cast's workgroup tile is 32 x 8 pixels and the second phase of
+    its march is a wave-wide loop: pixels past the image border keep a lane
+    but no ray. Every map against the oracle."""
+    want, got = _raycast_case(res, width, height, down, 1.0, 6)
+    assert (want["depth"] > 0).mean() > min_hit
+    _assert_maps(want, got)
+
+
+@pytest.mark.parametrize("grid_f32", [False, True])
+def test_raycast_long_crawls_through_hidden_surfaces(grid_f32):
+    """A weight threshold above every weight in the grid hides all surfaces:
+    each ray then walks through its whole truncation band one voxel at a time
+    (tsdf near or below zero => stride = voxel size) -- the case the ray
+    cast's cooperative march is for (a crawling ray's next samples are taken
+    by idle lanes of its wave). No pixel may hit; then, with a threshold that
+    only voxels seen by all 6 integrations reach, part of the surfaces are hidden and the
+    rays crawl past them to the next one. Every map against the oracle."""
+    want, got = _raycast_case(16, 320, 240, 8, 100.0, 6, grid_f32)
+    assert not (want["depth"] > 0).any()
+    _assert_maps(want, got)
+    want, got = _raycast_case(16, 320, 240, 8, 6.0, 6, grid_f32)
+    hit = (want["depth"] > 0).mean()
+    assert 0.05 < hit < 0.999, hit
+    _assert_maps(want, got)
+
+
 def test_frame_stream_long_run_matches_reference_cpu_bodies():
     """Near-full-size parity: 160 consecutive VGA frames (BASELINE configs[1]
     stream, every frame) through integrate_frames with 4-frame groups vs the

@@ -18,6 +18,10 @@ ap.add_argument("--frames", type=int, default=60)
 ap.add_argument("--repeat", type=int, default=50)
 ap.add_argument("--hd", action="store_true")
 ap.add_argument("--attrs", default="depth,normal")
+ap.add_argument("--digest", action="store_true",
+                help="add a SHA-256 of the rendered maps (A / B runs, e.g. "
+                     "O3DMI_RAYCAST_COOP=0 / 1 or O3DMI_LIB=<another build>, "
+                     "must print the same one)")
 a = ap.parse_args()
 W, H = (1280, 720) if a.hd else (640, 480)
 K = synthetic.intrinsics(W, H)
@@ -45,7 +49,16 @@ for e0, e1 in ev:
     e1.record()
 torch.cuda.synchronize()
 ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+extra = {}
+if a.digest:
+    import hashlib
+    h = hashlib.sha256()
+    for k in attrs:
+        h.update(out[k].contiguous().cpu().numpy().tobytes())
+    extra["sha256"] = h.hexdigest()[:16]
 print(json.dumps({"size": [W, H], "attrs": attrs, "blocks": int(cnt.item()),
+                  **extra,
+                  "cooperative_march": os.environ.get("O3DMI_RAYCAST_COOP", "1"),
                   "ray_cast_call_us_median": ms[len(ms) // 2] * 1e3,
                   "min": ms[0] * 1e3,
                   "valid_frac": float((out["depth"] > 0).float().mean())}))

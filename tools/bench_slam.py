@@ -196,7 +196,9 @@ def mode_slam(a):
             _lib.ptr(depth), _lib.U16, H, W, None, _lib.ptr(pts_buf), None,
             _lib.ptr(cnt), _lib.f64p(K), _lib.f64p(T), C.c_float(ds),
             C.c_float(dmax), C.c_int64(stride), stream()), "unproject")
-        return pts_buf[:int(cnt.item())]
+        if a.host_counts:
+            return pts_buf[:int(cnt.item())]
+        return pts_buf  # the live size stays in `cnt`, on the device
 
     mpts = torch.empty(((H // stride) * (W // stride), 3),
                        dtype=torch.float32, device="cuda")
@@ -222,7 +224,9 @@ def mode_slam(a):
             _lib.ptr(mpts), _lib.ptr(mnrm), _lib.ptr(mcnt), _lib.f64p(K),
             _lib.f64p(T), C.c_float(ds), C.c_float(dmax), C.c_int64(stride),
             stream()), "unproject")
-        m = int(mcnt.item())
+        # the live size stays on the device (mcnt): the normals are rotated
+        # over the whole buffer, rows past the size are never read
+        m = int(mcnt.item()) if a.host_counts else mnrm.shape[0]
         Tinv = np.ascontiguousarray(np.linalg.inv(T_wc), dtype=np.float64)
         _lib.check(L.o3dmi_transform_normals(_lib.f64p(Tinv), _lib.ptr(mnrm),
                                              m, _lib.F32, stream()),
@@ -236,6 +240,7 @@ def mode_slam(a):
     frame_keys = g.last_frame_block_coordinates(keys_cap)
     torch.cuda.synchronize()
     iters = 0
+    iters_log = []
     phase = np.zeros(4)
 
     def tick():
@@ -253,7 +258,10 @@ def mode_slam(a):
         # world-frame correction from the previous pose to the current one
         src = frame_cloud(depths[k], T_prev)
         p2 = tick()
-        r = reg.multi_scale_icp(src, tp, tn, vs, crit, md)
+        r = reg.multi_scale_icp(
+            src, tp, tn, vs, crit, md,
+            device_counts=None if a.host_counts else (cnt, mcnt))
+        iters_log.append(r.num_iterations)
         p3 = tick()
         iters += r.num_iterations
         # points_world = r.T * (T_prev^-1 * p_cam)  =>  extrinsic_k = T_prev * r.T^-1
@@ -275,12 +283,16 @@ def mode_slam(a):
            "final_pose_err_rad_m": errs[-1],
            "max_pose_err_rad_m": [max(e[0] for e in errs),
                                   max(e[1] for e in errs)],
-           "active_blocks": g.hashmap().size()}
+           "active_blocks": g.hashmap().size(),
+           "cloud_sizes": "host" if a.host_counts else "device",
+           "icp_iterations_first_frames": iters_log[:12]}
     if a.phases:
         out["ms_model_cloud_frame_cloud_icp_integrate"] = \
             [float(x) for x in phase / (n - 1) * 1e3]
-    out["source_points"] = int(src.shape[0])
-    out["target_points"] = int(tp.shape[0])
+    n_src, n_tgt = int(cnt.item()), int(mcnt.item())
+    src, tp, tn = src[:n_src], tp[:n_tgt], tn[:n_tgt]
+    out["source_points"] = n_src
+    out["target_points"] = n_tgt
     # SURVEY 8(d) accounting of the ICP leg, level by level on the last
     # frame's clouds: points of the level (one per occupied voxel of
     # VoxelDownSample) x iterations the level ran (replayed once with the
@@ -529,6 +541,10 @@ def main():
                     help="normals mode: EstimateNormals(max_nn=30) without a "
                          "radius (KNN search)")
     ap.add_argument("--cpu-frames", type=int, default=0)
+    ap.add_argument("--host-counts", action="store_true",
+                    help="slam mode: read the two cloud sizes back every "
+                         "frame (the round-2 loop) instead of leaving them "
+                         "on the device")
     ap.add_argument("--phases", action="store_true",
                     help="slam mode: synchronise between phases and report "
                          "their times")
