@@ -257,6 +257,12 @@ struct ChainCounts {
         int st = PostCountsAsync(dev, levels + 1, mb->data, mb->flag, seq, cs);
         if (st) return st;
         hipError_t e = MailboxWait(mb, seq, cs);
+        // the posting launch was the chain's last: its stream has drained
+        // (no hipStreamSynchronize, 16 us on an idle stream)
+        if (e == hipSuccess) {
+            for (void* p : scratch) PoolFree(p);
+            scratch.clear();
+        }
         Release(cs);
         if (e != hipSuccess) {
             SetLastError(std::string("pyramid read-back: ") +
@@ -461,13 +467,20 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
     std::vector<Level> pyr((size_t)num_scales);
     // Declared after the pyramid so that it runs first on every exit path:
     // pooled buffers may only be released once the streams have drained.
+    // `drained`: set once the host has SEEN the last launch of the call finish
+    // (the mailbox of the final evaluation): the caller's stream is in order,
+    // and everything the side stream did was waited for by a later launch on
+    // the caller's stream, so both are idle -- and hipStreamSynchronize costs
+    // 16 us per stream even then (measured: 32 us of every tracked frame).
     struct SyncOnExit {
         hipStream_t s, side;
+        bool drained;
         ~SyncOnExit() {
+            if (drained) return;
             (void)hipStreamSynchronize(s);
             if (side && side != s) (void)hipStreamSynchronize(side);
         }
-    } sync_on_exit{s, nullptr};
+    } sync_on_exit{s, nullptr, false};
     const int last = num_scales - 1;
     int st;
     // One index per scale (target_nns.HybridIndex(max_correspondence_distance),
@@ -1317,6 +1330,10 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
             inlier_rmse = r.inlier_rmse;
             if (r.sums[30] == 0) Eye4(T);
             converged = preserved;
+            // the search above waited for its sums: nothing of this call is
+            // in flight any more (every scale's index was waited for by the
+            // scale's first search)
+            sync_on_exit.drained = true;
         }
         if (fitness <= std::numeric_limits<double>::min()) {
             converged = false;

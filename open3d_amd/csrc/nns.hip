@@ -110,6 +110,89 @@ __global__ void ScatterKernel(const T* __restrict__ pts,
     }
 }
 
+// K1 - K3 in ONE launch for a small cloud (the coarsest level of an ICP
+// pyramid: 2 - 3 k points): a single workgroup counts into LDS, scans the
+// buckets there, writes every range (no clearing launch before it) and
+// scatters the records, cursors in LDS. The four launches it replaces are 3 -
+// 4 us each with the launch latency of a dependent chain between them -- 35 us
+// on the critical path of every tracked frame, between the pyramid and the
+// first search. The records of a bucket come out in any order, as from K3 (the
+// searches break ties by original index).
+constexpr int kSmallIndexPoints = 4096;          // => at most 8192 buckets
+constexpr int kSmallIndexBuckets = 2 * kSmallIndexPoints;
+constexpr int kSmallIndexBlock = 1024;
+template <typename T>
+__global__ void __launch_bounds__(kSmallIndexBlock)
+BuildSmallIndexKernel(const T* __restrict__ pts, const T* __restrict__ normals,
+                      int n, double inv_cell, unsigned mask, int n_buckets,
+                      uint2* __restrict__ ranges, Rec4<T>* __restrict__ sorted,
+                      Rec4<T>* __restrict__ sorted_normals) {
+    __shared__ unsigned cnt[kSmallIndexBuckets];
+    __shared__ unsigned wave_total[kSmallIndexBlock / 64];
+    constexpr int kMine = kSmallIndexPoints / kSmallIndexBlock;  // points / thread
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int b = threadIdx.x; b < n_buckets; b += kSmallIndexBlock) cnt[b] = 0;
+    __syncthreads();
+    Rec4<T> rec[kMine];
+    unsigned bucket[kMine];
+#pragma unroll
+    for (int k = 0; k < kMine; ++k) {
+        const int i = k * kSmallIndexBlock + (int)threadIdx.x;
+        bucket[k] = 0;
+        if (i < n) {
+            rec[k].x = pts[3 * (int64_t)i + 0];
+            rec[k].y = pts[3 * (int64_t)i + 1];
+            rec[k].z = pts[3 * (int64_t)i + 2];
+            rec[k].w = i;
+            const T p[3] = {rec[k].x, rec[k].y, rec[k].z};
+            long long cx, cy, cz;
+            CellOf(p, inv_cell, cx, cy, cz);
+            bucket[k] = HashCell(cx, cy, cz) & mask;
+            atomicAdd(&cnt[bucket[k]], 1u);
+        }
+    }
+    __syncthreads();
+    // exclusive scan: a thread owns n_buckets / 1024 consecutive buckets
+    const int per = n_buckets / kSmallIndexBlock;  // 1, 2, 4 or 8
+    const int b0 = (int)threadIdx.x * per;
+    unsigned mine = 0;
+    for (int k = 0; k < per; ++k) mine += cnt[b0 + k];
+    unsigned incl = mine;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const unsigned o = __shfl_up(incl, m);
+        if (lane >= m) incl += o;
+    }
+    if (lane == 63) wave_total[wave] = incl;
+    __syncthreads();
+    unsigned run = incl - mine;
+    for (int w = 0; w < wave; ++w) run += wave_total[w];
+    for (int k = 0; k < per; ++k) {
+        const unsigned c = cnt[b0 + k];
+        ranges[b0 + k] = make_uint2(run + c, c);  // {end, count}: see BucketRange
+        cnt[b0 + k] = run;                         // the scatter's cursor
+        run += c;
+    }
+    if (threadIdx.x == 0) ranges[n_buckets] = make_uint2((unsigned)n, 0u);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kMine; ++k) {
+        const int i = k * kSmallIndexBlock + (int)threadIdx.x;
+        if (i < n) {
+            const unsigned pos = atomicAdd(&cnt[bucket[k]], 1u);
+            sorted[pos] = rec[k];
+            if (normals) {
+                Rec4<T> m;
+                m.x = normals[3 * (int64_t)i + 0];
+                m.y = normals[3 * (int64_t)i + 1];
+                m.z = normals[3 * (int64_t)i + 2];
+                m.w = 0;
+                sorted_normals[pos] = m;
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ void GatherAttrKernel(const T* __restrict__ attr,
                                  const Rec4<T>* __restrict__ sorted_pts,
@@ -914,6 +997,16 @@ int BuildIndex(o3dmi_nns* nns, const T* pts, const T* normals, hipStream_t s) {
     if (normals)
         { int st_; if ((st_ = PoolAlloc(&nns->sorted_normals, recs))) return st_; }
     { int st_; if ((st_ = PoolAlloc((void**)&nns->partials, sizeof(double) * kCUs * 4 * kNumSums))) return st_; }
+    static const bool no_small = std::getenv("O3DMI_NNS_NO_SMALL") != nullptr;
+    if (n > 0 && n <= kSmallIndexPoints && !no_small) {
+        hipLaunchKernelGGL(BuildSmallIndexKernel<T>, dim3(1),
+                           dim3(kSmallIndexBlock), 0, s, pts, normals, (int)n,
+                           nns->inv_cell, mask, (int)nb, nns->ranges,
+                           (Rec4<T>*)nns->sorted_pts,
+                           (Rec4<T>*)nns->sorted_normals);
+        O3DMI_HIP_CHECK(hipGetLastError());
+        return O3DMI_OK;
+    }
     // one fill launch: a size that is not a multiple of 16 bytes is cleared
     // by two (the pool rounds the block up to a power of two, so the padding
     // is there)

@@ -150,33 +150,35 @@ __global__ void PointCloudTouchKernel(HashView hv,
 }
 
 // UnprojectCPU (t/geometry/kernel/PointCloudImpl.h:42-143): valid pixels ->
-// points, compacted. A workgroup owns a chunk of kUnprojChunk strided pixels:
-// validity ballots per wave and round, one prefix over the chunk in LDS, ONE
-// atomic per chunk on the output counter (a 720p / stride-2 image is 113
-// chunks; one atomic per wave was 3600 serialised atomics on one word, ~12 ns
-// each: 45 us of a 50 us kernel), then the points are written in pixel order
-// inside the chunk. The order of the chunks in the output follows the atomics
-// (the reference's order is its own atomic counter's).
-constexpr int kUnprojRounds = 8;
-constexpr int kUnprojChunk = kBlock * kUnprojRounds;
+// points, compacted. A workgroup owns a chunk of kBlock * ROUNDS strided
+// pixels: validity ballots per wave and round, one prefix over the chunk in
+// LDS, ONE atomic per chunk on the output counter, then the points are written
+// in pixel order inside the chunk. The order of the chunks in the output
+// follows the atomics (the reference's order is its own atomic counter's).
+// ROUNDS trades atomics on the one counter word (~12 ns each, serialised: one
+// per wave was 3600 of them and 45 us of a 50 us kernel at 720p) against
+// workgroups to spread the image over: 8 rounds left a VGA / stride-2 image
+// (76 800 pixels) to 38 workgroups and 17 us; the host picks the largest
+// ROUNDS that still gives every CU a chunk (300 chunks of one round there).
+constexpr int kUnprojMaxRounds = 8;
 
-template <typename depth_t>
+template <typename depth_t, int ROUNDS>
 __global__ void __launch_bounds__(kBlock)
 UnprojectKernel(TouchParams p, const depth_t* __restrict__ depth,
                 const float* __restrict__ image_colors,
                 float* __restrict__ points, float* __restrict__ colors,
                 int* __restrict__ count) {
-    __shared__ int offs[kUnprojRounds][kBlock / 64];
+    __shared__ int offs[ROUNDS][kBlock / 64];
     __shared__ int chunk_base;
     const int64_t n = (int64_t)p.rows_strided * p.cols_strided;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int64_t c0 = (int64_t)blockIdx.x * kUnprojChunk; c0 < n;
-         c0 += (int64_t)gridDim.x * kUnprojChunk) {
-        float d[kUnprojRounds];
-        unsigned long long ballot[kUnprojRounds];
+    for (int64_t c0 = (int64_t)blockIdx.x * (kBlock * ROUNDS); c0 < n;
+         c0 += (int64_t)gridDim.x * (kBlock * ROUNDS)) {
+        float d[ROUNDS];
+        unsigned long long ballot[ROUNDS];
 #pragma unroll
-        for (int k = 0; k < kUnprojRounds; ++k) {
+        for (int k = 0; k < ROUNDS; ++k) {
             const int64_t w = c0 + k * kBlock + threadIdx.x;
             bool valid = false;
             d[k] = 0;
@@ -192,7 +194,7 @@ UnprojectKernel(TouchParams p, const depth_t* __restrict__ depth,
         __syncthreads();
         if (threadIdx.x == 0) {
             int run = 0;
-            for (int k = 0; k < kUnprojRounds; ++k)
+            for (int k = 0; k < ROUNDS; ++k)
                 for (int wv = 0; wv < kBlock / 64; ++wv) {
                     const int c = offs[k][wv];
                     offs[k][wv] = run;
@@ -202,7 +204,7 @@ UnprojectKernel(TouchParams p, const depth_t* __restrict__ depth,
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < kUnprojRounds; ++k) {
+        for (int k = 0; k < ROUNDS; ++k) {
             if (!((ballot[k] >> lane) & 1ull)) continue;
             const int64_t w = c0 + k * kBlock + threadIdx.x;
             const int64_t y = (w / p.cols_strided) * p.stride;
@@ -349,15 +351,25 @@ int o3dmi_unproject(const void* depth_dev, int depth_dtype, int rows, int cols,
                                     depth_max);
     O3DMI_HIP_CHECK(hipMemsetAsync(out_count_dev, 0, sizeof(int), s));
     int64_t n = (int64_t)p.rows_strided * p.cols_strided;
-    dim3 grid(GridFor(n, kUnprojChunk)), block(kBlock);
-    if (depth_dtype == O3DMI_U16)
-        hipLaunchKernelGGL(UnprojectKernel<uint16_t>, grid, block, 0, s, p,
-                           (const uint16_t*)depth_dev, image_colors_dev,
-                           points_dev, colors_dev, out_count_dev);
-    else
-        hipLaunchKernelGGL(UnprojectKernel<float>, grid, block, 0, s, p,
-                           (const float*)depth_dev, image_colors_dev,
-                           points_dev, colors_dev, out_count_dev);
+    // the largest chunk that still gives every CU one
+    int rounds = kUnprojMaxRounds;
+    while (rounds > 1 && n < (int64_t)kCUs * kBlock * rounds) rounds >>= 1;
+    dim3 grid(GridFor(n, kBlock * rounds)), block(kBlock);
+#define O3DMI_UNPROJECT(T, R)                                                  \
+    hipLaunchKernelGGL((UnprojectKernel<T, R>), grid, block, 0, s, p,         \
+                       (const T*)depth_dev, image_colors_dev, points_dev,     \
+                       colors_dev, out_count_dev)
+#define O3DMI_UNPROJECT_R(T)                                                   \
+    switch (rounds) {                                                         \
+        case 8: O3DMI_UNPROJECT(T, 8); break;                                 \
+        case 4: O3DMI_UNPROJECT(T, 4); break;                                 \
+        case 2: O3DMI_UNPROJECT(T, 2); break;                                 \
+        default: O3DMI_UNPROJECT(T, 1); break;                                \
+    }
+    if (depth_dtype == O3DMI_U16) { O3DMI_UNPROJECT_R(uint16_t) }
+    else { O3DMI_UNPROJECT_R(float) }
+#undef O3DMI_UNPROJECT_R
+#undef O3DMI_UNPROJECT
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
 }
