@@ -309,8 +309,10 @@ def test_cpp_icp_tracking_example_sharded_ranks_through_the_library_comm():
     assert many["ranks"] == 3 and many["poses_identical_on_all_ranks"]
     assert abs(many["max_translation_error_m"] -
                one["max_translation_error_m"]) < 5e-3
+    # (twelve single-rank runs on one box: 11.0 ... 13.2 iterations per frame,
+    # 0.0356 ... 0.0357 m; six 3-rank runs: 11.3 ... 13.7, 0.0339 ... 0.0356 m)
     assert abs(many["icp_iterations_per_frame"] -
-               one["icp_iterations_per_frame"]) < 2.0
+               one["icp_iterations_per_frame"]) < 3.5
     if torch.cuda.device_count() >= 2:
         rccl = run("2", "rccl")
         assert rccl["poses_identical_on_all_ranks"]
