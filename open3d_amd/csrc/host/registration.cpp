@@ -248,14 +248,28 @@ struct ChainCounts {
     }
     int* Count(int level) { return dev + level; }
     int* Err() { return dev + levels; }
-    // waits for the chain and returns the counts
-    int Fetch(std::vector<int>& out, hipStream_t cs) {
-        out.assign((size_t)levels + 1, 0);
+    // Post: the counts leave for the chain's mailbox behind the chain's
+    // launches; Wait: for that, and returns them. (Both chains post before
+    // either is waited for: one host round trip, not two.)
+    int posted_seq = 0;
+    int Post(hipStream_t cs) {
         Mailbox* mb = ThreadMailbox(1 + chain);
         O3DMI_REQUIRE(mb != nullptr, "host mailbox allocation failed");
-        const int seq = ++mb->seq;
-        int st = PostCountsAsync(dev, levels + 1, mb->data, mb->flag, seq, cs);
+        posted_seq = ++mb->seq;
+        return PostCountsAsync(dev, levels + 1, mb->data, mb->flag, posted_seq,
+                               cs);
+    }
+    int Fetch(std::vector<int>& out, hipStream_t cs) {
+        int st = Post(cs);
         if (st) return st;
+        return Wait(out, cs);
+    }
+    int Wait(std::vector<int>& out, hipStream_t cs) {
+        out.assign((size_t)levels + 1, 0);
+        Mailbox* mb = ThreadMailbox(1 + chain);
+        O3DMI_REQUIRE(mb != nullptr && posted_seq != 0, "counts not posted");
+        const int seq = posted_seq;
+        posted_seq = 0;
         hipError_t e = MailboxWait(mb, seq, cs);
         // the posting launch was the chain's last: its stream has drained
         // (no hipStreamSynchronize, 16 us on an idle stream)
@@ -665,6 +679,7 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         O3DMI_HIP_CHECK(hipStreamWaitEvent(side, ev, 0));
     }
     bool indices_on_side = false;
+    int next_index = 1;  // first scale whose index is not issued yet
     {
         ChainGuard sg{scc, s}, tg{tcc, side};
         if ((st = scc.Init(num_scales, 0, s))) return st;
@@ -674,32 +689,72 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
             if ((st = source_level(k, s))) return st;
         }
         std::vector<int> counts;
-        if ((st = tcc.Fetch(counts, side))) return st;
+        if ((st = tcc.Post(side))) return st;
+        if ((st = scc.Post(s))) return st;
+        if ((st = tcc.Wait(counts, side))) return st;
         for (int k = 0; k < num_scales; ++k)
             if (!(k == last && finest_on_host))
                 pyr[(size_t)k].nt = counts[(size_t)k];
-        // Indices: the first scale's on the caller's stream (its first search
-        // follows at once), the others on the side stream while the first
-        // scale iterates.
-        for (int k = 0; k < num_scales; ++k) {
-            const Level& Lk = pyr[(size_t)k];
-            hipStream_t is = k == 0 ? s : side;
-            if ((st = o3dmi_internal_nns_create_with_normals(
-                         Lk.tgt_ptr, p2plane ? Lk.nrm_ptr : nullptr, Lk.nt,
-                         dtype, max_dists[k], (o3dmi_stream_t)is,
-                         &guards[(size_t)k].nns)))
-                return st;
-        }
-        if (overlap && num_scales > 1) {
-            O3DMI_HIP_CHECK(hipEventRecord(ev, side));
-            indices_on_side = true;
-        }
-        if ((st = scc.Fetch(counts, s))) return st;
+        if ((st = scc.Wait(counts, s))) return st;
         for (int k = 0; k < num_scales; ++k)
             if (!(k == last && finest_is_input))
                 pyr[(size_t)k].ns = counts[(size_t)k];
+        // Indices: the first scale's on the caller's stream (its first search
+        // follows at once). The others go to the side stream LATER, one per
+        // search launch of the first scale, issued while the host would
+        // otherwise spin on that launch's sums (build_next_index below):
+        // issuing them here kept the host busy for ~60 us (eight launch
+        // calls) before it got to the first search -- with the GPU idle
+        // (tools/slam_timeline.py).
+        {
+            const Level& L0 = pyr[0];
+            if ((st = o3dmi_internal_nns_create_with_normals(
+                         L0.tgt_ptr, p2plane ? L0.nrm_ptr : nullptr, L0.nt,
+                         dtype, max_dists[0], (o3dmi_stream_t)s,
+                         &guards[0].nns)))
+                return st;
+        }
+        // O3DMI_ICP_EAGER_INDEX=1: all indices up front (A / B)
+        static const bool eager = std::getenv("O3DMI_ICP_EAGER_INDEX") != nullptr;
+        if (eager) {
+            for (int k = 1; k < num_scales; ++k) {
+                const Level& Lk = pyr[(size_t)k];
+                if ((st = o3dmi_internal_nns_create_with_normals(
+                             Lk.tgt_ptr, p2plane ? Lk.nrm_ptr : nullptr, Lk.nt,
+                             dtype, max_dists[k], (o3dmi_stream_t)side,
+                             &guards[(size_t)k].nns)))
+                    return st;
+            }
+            next_index = num_scales;
+            if (overlap && num_scales > 1) {
+                O3DMI_HIP_CHECK(hipEventRecord(ev, side));
+                indices_on_side = true;
+            }
+        }
     }
 
+    // One more scale's index on the side stream (see above); the event the
+    // second scale waits for is recorded behind the last one.
+    int index_status = O3DMI_OK;
+    auto build_next_index = [&]() {
+        if (next_index >= num_scales || index_status != O3DMI_OK) return;
+        const int k = next_index++;
+        const Level& Lk = pyr[(size_t)k];
+        index_status = o3dmi_internal_nns_create_with_normals(
+                Lk.tgt_ptr, p2plane ? Lk.nrm_ptr : nullptr, Lk.nt, dtype,
+                max_dists[k], (o3dmi_stream_t)side, &guards[(size_t)k].nns);
+        if (index_status == O3DMI_OK && next_index == num_scales && overlap) {
+            if (hipEventRecord(ev, side) != hipSuccess)
+                index_status = O3DMI_ERR_HIP;
+            else
+                indices_on_side = true;
+        }
+    };
+    auto ensure_indices = [&]() -> int {
+        while (next_index < num_scales && index_status == O3DMI_OK)
+            build_next_index();
+        return index_status;
+    };
     exit_timer.Mark("pyramid");
     const char* timing_env = std::getenv("O3DMI_ICP_TIMING");
     const bool timing = timing_env && std::atoi(timing_env) != 2;
@@ -760,12 +815,14 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
             if ((e = o3dmi_internal_sums_post(d, mb->data, mb->flag, seq,
                                               stream)))
                 return e;
+            build_next_index();
             O3DMI_HIP_CHECK(MailboxWait(mb, seq, s));
             std::memcpy(out32, sums_host, sizeof(double) * 32);
             return O3DMI_OK;
         }
         int e = launch((double*)nullptr, mb->data, mb->flag, seq);
         if (e) return e;
+        build_next_index();  // in the shadow of the launch just issued
         O3DMI_HIP_CHECK(MailboxWait(mb, seq, s));
         std::memcpy(out32, sums_host, sizeof(double) * 32);
         if (t29 == t29) out32[29] = t29;
@@ -920,8 +977,10 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         // target_nns.HybridIndex(max_correspondence_distance) :406-412:
         // built behind the target pyramid (above)
         NnsGuard& guard = guards[(size_t)scale_idx];
-        if (scale_idx == 1 && indices_on_side)
-            O3DMI_HIP_CHECK(hipStreamWaitEvent(s, ev, 0));
+        if (scale_idx == 1) {
+            if ((st = ensure_indices())) return st;
+            if (indices_on_side) O3DMI_HIP_CHECK(hipStreamWaitEvent(s, ev, 0));
+        }
 
         if (timing) {
             (void)hipStreamSynchronize(s);

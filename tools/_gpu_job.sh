@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for i in 1 2 3 4 5 6 7 8 9 10 11 12; do examples/icp_slam 12 320 240 0 | grep -o '"max_translation_error_m": [0-9.]*\|"icp_iterations_per_frame": [0-9.]*' | tr '\n' ' '; echo; done
-echo "3 ranks"
-for i in 1 2 3 4 5 6; do examples/icp_slam 12 320 240 0 3 loopback | grep -o '"max_translation_error_m": [0-9.]*\|"icp_iterations_per_frame": [0-9.]*' | tr '\n' ' '; echo; done
+timeout 900 python -m pytest tests/test_icp_gpu.py tests/test_configs_gpu.py tests/test_slam_gpu.py tests/test_sharding.py -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3
+for i in 1 2 3 4 5; do examples/icp_slam 60 640 480 | grep -o '"frames_per_s": [0-9.]*' | tr '\n' ' '; done; echo " vga"
+for i in 1 2 3 4 5; do examples/icp_slam 60 1280 720 | grep -o '"frames_per_s": [0-9.]*' | tr '\n' ' '; done; echo " 720p"
+O3DMI_ICP_TIMING=2 examples/icp_slam 12 640 480 2>&1 | grep "whole call" | tail -3
