@@ -186,27 +186,36 @@ struct Level {
 // averages every attribute; the kernel takes positions + one attribute, so
 // further attributes go through it again (the voxel order, first occurrence,
 // is the same every time, and so are the positions and the count).
+// next_voxel > 0: the chain's next call down-samples out_pos by that size;
+// from_previous: pos is the out_pos of the chain's previous call (vds.h: a
+// level with a single pass then carries the next level's hash insert).
 int DownSampleAttrsAsync(const void* pos, int64_t n_max, const int* n_dev,
                          int dtype, double voxel, void* out_pos, int* m_dev,
                          int* err_dev, std::vector<void*>& scratch,
                          hipStream_t cs, int chain,
                          std::initializer_list<std::pair<const void*, void*>>
-                                 attrs) {
+                                 attrs,
+                         double next_voxel = 0, bool from_previous = false) {
     if (voxel <= 0) {
         SetLastError("voxel_size must be positive.");
         return O3DMI_ERR_INVALID_ARG;
     }
+    int passes = 0;
+    for (const auto& a : attrs) passes += a.first ? 1 : 0;
+    const bool single = passes <= 1;
     bool done = false;
     for (const auto& a : attrs) {
         if (!a.first) continue;
         int st = VdsAsync(pos, a.first, n_max, n_dev, dtype, voxel, out_pos,
-                          a.second, m_dev, err_dev, scratch, cs, chain);
+                          a.second, m_dev, err_dev, scratch, cs, chain,
+                          single ? next_voxel : 0.0, single && from_previous);
         if (st) return st;
         done = true;
     }
     if (!done)
         return VdsAsync(pos, nullptr, n_max, n_dev, dtype, voxel, out_pos,
-                        nullptr, m_dev, err_dev, scratch, cs, chain);
+                        nullptr, m_dev, err_dev, scratch, cs, chain,
+                        next_voxel, from_previous);
     return O3DMI_OK;
 }
 
@@ -563,13 +572,16 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         if ((e = L.src.Alloc((size_t)ns * 3 * esz))) return e;
         if (symmetric && (e = L.srcn.Alloc((size_t)ns * 3 * esz))) return e;
         if (colored && (e = L.srcc.Alloc((size_t)ns * 3 * esz))) return e;
+        // (the coarser level is built from this one's output: vds.h)
+        const double next_vs = k > 0 ? voxel_sizes[k - 1] : 0.0;
         if (k == last)
             return DownSampleAttrsAsync(source_dev, ns, (const int*)ns_dev,
                                         dtype, voxel_sizes[k], L.src.p,
                                         scc.Count(k),
                                         scc.Err(), scc.scratch, cs, 0,
                                         {{source_normals_dev, L.srcn.p},
-                                         {source_colors_dev, L.srcc.p}});
+                                         {source_colors_dev, L.srcc.p}},
+                                        next_vs, false);
         Level& F = pyr[(size_t)k + 1];
         const bool f_host = k + 1 == last && finest_is_input;
         return DownSampleAttrsAsync(F.src.p, ns,
@@ -577,7 +589,8 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                                     voxel_sizes[k], L.src.p, scc.Count(k),
                                     scc.Err(), scc.scratch, cs, 0,
                                     {{F.srcn.p, L.srcn.p},
-                                     {F.srcc.p, L.srcc.p}});
+                                     {F.srcc.p, L.srcc.p}},
+                                    next_vs, !f_host);
     };
     bool finest_on_host = finest_is_input;
     auto target_level = [&](int k, hipStream_t cs) -> int {
@@ -607,7 +620,9 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                                          cs, 1,
                                          {{target_normals_dev, L.nrm.p},
                                           {target_colors_dev, L.tgtc.p},
-                                          {target_gradients_dev, L.tgtg.p}});
+                                          {target_gradients_dev, L.tgtg.p}},
+                                         k > 0 ? voxel_sizes[k - 1] : 0.0,
+                                         false);
                 if (e) return e;
                 L.tgt_ptr = L.tgt.p;
                 L.nrm_ptr = L.nrm.p;  // stays NULL without normals
@@ -654,7 +669,8 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                                  tcc.Err(), tcc.scratch, cs, 1,
                                  {{F.nrm_ptr, L.nrm.p},
                                   {F.tgtc_ptr, L.tgtc.p},
-                                  {F.tgtg_ptr, L.tgtg.p}});
+                                  {F.tgtg_ptr, L.tgtg.p}},
+                                 k > 0 ? voxel_sizes[k - 1] : 0.0, !f_host);
         if (e) return e;
         L.tgt_ptr = L.tgt.p;
         L.nrm_ptr = L.nrm.p;

@@ -681,6 +681,22 @@ VdsBucketScatterKernel(const int* __restrict__ slot_of_point, VdsTable tb,
     }
 }
 
+// The NEXT (coarser) level's hash insert, carried by this level's reduce
+// launch: a pyramid is built from its own output (Registration.cpp:233-270),
+// so the lane that writes a voxel's mean can insert that point -- it has its
+// index (the output row) and its coordinates in registers -- into the next
+// level's table and count it in the next level's tile histogram, which is all
+// VdsInsertBucketKernel would do one launch later. tb.keys == NULL: no next
+// level (or a caller that makes several passes per level).
+template <typename T>
+struct VdsNext {
+    VdsTable tb;
+    T vs;
+    int* slot_of_point;
+    int* tile_hist;
+    int* err;
+};
+
 template <typename T>
 __global__ void __launch_bounds__(kReduceBlock)
 VdsBucketReduceKernel(const T* __restrict__ pos, const T* __restrict__ nrm,
@@ -690,7 +706,8 @@ VdsBucketReduceKernel(const T* __restrict__ pos, const T* __restrict__ nrm,
                       const int* __restrict__ bucket_start, VdsTable tb,
                       int bshift, int* __restrict__ tile_hist, int n_tiles_cap,
                       const int* n_dev, int n_host, T* __restrict__ out_pos,
-                      T* __restrict__ out_nrm, int* __restrict__ m_dev) {
+                      T* __restrict__ out_nrm, int* __restrict__ m_dev,
+                      VdsNext<T> next) {
     __shared__ int word_prefix[kBucketedMaxPoints / 64];  // 16 KiB
     __shared__ int lds4[kReduceBlock / 64];
     __shared__ unsigned e_slot[kBucketLds + 4];  // + a sentinel chunk
@@ -850,10 +867,39 @@ VdsBucketReduceKernel(const T* __restrict__ pos, const T* __restrict__ nrm,
                 }
             }
         }
+        T o[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            out_pos[3 * (int64_t)row + c] = (T)(sp[c] / cnt);
+            o[c] = (T)(sp[c] / cnt);
+            out_pos[3 * (int64_t)row + c] = o[c];
             if (nrm) out_nrm[3 * (int64_t)row + c] = (T)(sn[c] / cnt);
+        }
+        if (next.tb.keys) {
+            // VdsInsertBucketKernel's body for point `row` of the next level
+            int* hist = next.tile_hist + (int64_t)(row / kSortTile) * kBuckets;
+            const long long cx = (long long)floor(o[0] / next.vs);
+            const long long cy = (long long)floor(o[1] / next.vs);
+            const long long cz = (long long)floor(o[2] / next.vs);
+            if (cx < -kKeyBias || cx >= kKeyBias || cy < -kKeyBias ||
+                cy >= kKeyBias || cz < -kKeyBias || cz >= kKeyBias) {
+                atomicOr(next.err, kErrKeyRange);
+                next.slot_of_point[row] = -1;
+                atomicAdd(&hist[0], 1);
+            } else {
+                const unsigned long long key =
+                        PackKey((int)cx, (int)cy, (int)cz);
+                unsigned ns = HashKey(key) & next.tb.mask;
+                while (true) {
+                    unsigned long long cur = next.tb.keys[ns];
+                    if (cur == kEmptyKey)
+                        cur = atomicCAS(&next.tb.keys[ns], kEmptyKey, key);
+                    if (cur == kEmptyKey || cur == key) break;
+                    ns = (ns + 1) & next.tb.mask;
+                }
+                next.slot_of_point[row] = (int)ns;
+                atomicMin(&next.tb.first[ns], row);
+                atomicAdd(&hist[ns >> bshift], 1);
+            }
         }
     };
     if (staged) {
@@ -876,9 +922,20 @@ VdsBucketReduceKernel(const T* __restrict__ pos, const T* __restrict__ nrm,
 // chain has seen; the hash table is returned clean by every level.
 struct VdsWorkspace {
     int64_t n_cap = 0, n_slots = 0;
-    VdsTable tb = {};
-    int* slot_of_point = nullptr;
-    int* tile_hist = nullptr;
+    // Two sets of {table, slot of every point, tile histogram}: a level that
+    // carries the next level's insert (VdsNext) fills the other set while it
+    // empties its own.
+    VdsTable tb = {}, tb2 = {};
+    int *slot_of_point = nullptr, *slot_of_point2 = nullptr;
+    int *tile_hist = nullptr, *tile_hist2 = nullptr;
+    // the insert a reduce launch has left behind: which set, of which cloud
+    // (the reduce launch's output), for which voxel size
+    bool primed = false;
+    int primed_set = 0;
+    const void* primed_src = nullptr;
+    double primed_vs = 0;
+    int64_t primed_n_max = 0;
+    size_t primed_esz = 0;
     unsigned* ent_slot = nullptr;
     unsigned* ent_point = nullptr;
     unsigned long long* first_bits = nullptr;
@@ -888,6 +945,10 @@ struct VdsWorkspace {
         (void)hipFree(tb.first);
         (void)hipFree(slot_of_point);
         (void)hipFree(tile_hist);
+        (void)hipFree(tb2.keys);
+        (void)hipFree(tb2.first);
+        (void)hipFree(slot_of_point2);
+        (void)hipFree(tile_hist2);
         (void)hipFree(ent_slot);
         (void)hipFree(ent_point);
         (void)hipFree(first_bits);
@@ -918,16 +979,24 @@ VdsWorkspace* ThreadVdsWorkspace(int chain, int64_t n_max, hipStream_t s) {
               hipMalloc((void**)&w.tb.first, sizeof(int) * n_slots) == hipSuccess &&
               hipMalloc((void**)&w.slot_of_point, sizeof(int) * cap) == hipSuccess &&
               hipMalloc((void**)&w.tile_hist, sizeof(int) * kBuckets * n_tiles) == hipSuccess &&
+              hipMalloc((void**)&w.tb2.keys, sizeof(unsigned long long) * n_slots) == hipSuccess &&
+              hipMalloc((void**)&w.tb2.first, sizeof(int) * n_slots) == hipSuccess &&
+              hipMalloc((void**)&w.slot_of_point2, sizeof(int) * cap) == hipSuccess &&
+              hipMalloc((void**)&w.tile_hist2, sizeof(int) * kBuckets * n_tiles) == hipSuccess &&
               hipMalloc((void**)&w.ent_slot, sizeof(unsigned) * cap) == hipSuccess &&
               hipMalloc((void**)&w.ent_point, sizeof(unsigned) * cap) == hipSuccess &&
               hipMalloc((void**)&w.first_bits, sizeof(unsigned long long) * (cap / 64 + 1)) == hipSuccess &&
               hipMalloc((void**)&w.bucket_start, sizeof(int) * (kBuckets + 1)) == hipSuccess;
     if (ok) {
-        w.tb.mask = (unsigned)(n_slots - 1);
+        w.tb.mask = w.tb2.mask = (unsigned)(n_slots - 1);
         hipLaunchKernelGGL(VdsInitKernel, dim3(GridFor(n_slots, kBlock)),
                            dim3(kBlock), 0, s, w.tb, n_slots);
+        hipLaunchKernelGGL(VdsInitKernel, dim3(GridFor(n_slots, kBlock)),
+                           dim3(kBlock), 0, s, w.tb2, n_slots);
         ok = hipGetLastError() == hipSuccess &&
              hipMemsetAsync(w.tile_hist, 0, sizeof(int) * kBuckets * n_tiles,
+                            s) == hipSuccess &&
+             hipMemsetAsync(w.tile_hist2, 0, sizeof(int) * kBuckets * n_tiles,
                             s) == hipSuccess;
     }
     if (!ok) {
@@ -943,7 +1012,8 @@ VdsWorkspace* ThreadVdsWorkspace(int chain, int64_t n_max, hipStream_t s) {
 template <typename T>
 int VdsBucketedImpl(const T* pos, const T* nrm, int64_t n_max, const int* n_dev,
                     double voxel_size, T* out_pos, T* out_nrm, int* m_dev,
-                    int* err_dev, int chain, hipStream_t s) {
+                    int* err_dev, int chain, hipStream_t s,
+                    double next_voxel_size, bool from_previous) {
     VdsWorkspace* w = ThreadVdsWorkspace(chain, n_max, s);
     if (!w) return O3DMI_ERR_HIP;
     int slot_bits = 0;
@@ -951,21 +1021,61 @@ int VdsBucketedImpl(const T* pos, const T* nrm, int64_t n_max, const int* n_dev,
     const int bshift = slot_bits - kBucketBits;  // n_slots >= 1024 > 512
     const int n_host = (int)n_max;
     const int n_tiles = (int)((n_max + kSortTile - 1) / kSortTile);
+    const int64_t n_tiles_cap = (w->n_cap + kSortTile - 1) / kSortTile;
     const dim3 tiles((unsigned)n_tiles), sblock(kSortBlock);
     const dim3 chunks((unsigned)((n_max + kSortBlock - 1) / kSortBlock));
-    hipLaunchKernelGGL(VdsInsertBucketKernel<T>, chunks, sblock, 0, s, pos,
-                       n_dev, n_host, (T)voxel_size, w->tb, bshift,
-                       w->slot_of_point, w->tile_hist, err_dev);
+    static const bool no_fuse = std::getenv("O3DMI_VDS_NO_FUSE") != nullptr;
+    // Was this cloud inserted by the launch that wrote it?
+    const bool inserted = w->primed && from_previous &&
+                          w->primed_src == (const void*)pos &&
+                          w->primed_vs == voxel_size &&
+                          w->primed_n_max == n_max &&
+                          w->primed_esz == sizeof(T);
+    if (w->primed && !inserted) {
+        // an insert nobody came for (the caller changed its mind between two
+        // levels): back to the clean state
+        VdsTable& tb = w->primed_set ? w->tb2 : w->tb;
+        hipLaunchKernelGGL(VdsInitKernel, dim3(GridFor(w->n_slots, kBlock)),
+                           dim3(kBlock), 0, s, tb, w->n_slots);
+        O3DMI_HIP_CHECK(hipMemsetAsync(
+                w->primed_set ? w->tile_hist2 : w->tile_hist, 0,
+                sizeof(int) * kBuckets * n_tiles_cap, s));
+    }
+    const int cur = inserted ? w->primed_set : 0;
+    w->primed = false;
+    VdsTable& tb = cur ? w->tb2 : w->tb;
+    int* slot_of_point = cur ? w->slot_of_point2 : w->slot_of_point;
+    int* tile_hist = cur ? w->tile_hist2 : w->tile_hist;
+    VdsNext<T> next = {};
+    if (next_voxel_size > 0 && !no_fuse) {
+        next.tb = cur ? w->tb : w->tb2;
+        next.vs = (T)next_voxel_size;
+        next.slot_of_point = cur ? w->slot_of_point : w->slot_of_point2;
+        next.tile_hist = cur ? w->tile_hist : w->tile_hist2;
+        next.err = err_dev;
+    }
+    if (!inserted)
+        hipLaunchKernelGGL(VdsInsertBucketKernel<T>, chunks, sblock, 0, s, pos,
+                           n_dev, n_host, (T)voxel_size, tb, bshift,
+                           slot_of_point, tile_hist, err_dev);
     hipLaunchKernelGGL(VdsBucketScatterKernel, tiles, sblock, 0, s,
-                       w->slot_of_point, w->tb, bshift, n_dev, n_host,
-                       w->tile_hist, w->ent_slot, w->ent_point, w->first_bits,
+                       slot_of_point, tb, bshift, n_dev, n_host, tile_hist,
+                       w->ent_slot, w->ent_point, w->first_bits,
                        w->bucket_start);
     hipLaunchKernelGGL(VdsBucketReduceKernel<T>, dim3(kBuckets),
                        dim3(kReduceBlock), 0, s, pos, nrm, w->ent_slot,
-                       w->ent_point, w->first_bits, w->bucket_start, w->tb,
-                       bshift, w->tile_hist, n_tiles, n_dev, n_host, out_pos,
-                       out_nrm, m_dev);
+                       w->ent_point, w->first_bits, w->bucket_start, tb,
+                       bshift, tile_hist, n_tiles, n_dev, n_host, out_pos,
+                       out_nrm, m_dev, next);
     O3DMI_HIP_CHECK(hipGetLastError());
+    if (next.tb.keys) {
+        w->primed = true;
+        w->primed_set = 1 - cur;
+        w->primed_src = (const void*)out_pos;
+        w->primed_vs = next_voxel_size;
+        w->primed_n_max = n_max;
+        w->primed_esz = sizeof(T);
+    }
     return O3DMI_OK;
 }
 
@@ -1123,7 +1233,8 @@ int PostCountsAsync(int* counts_dev, int n, double* mail_data, int* mail_flag,
 int VdsAsync(const void* pos, const void* attr, int64_t n_max, const int* n_dev,
              int dtype, double voxel_size, void* out_pos, void* out_attr,
              int* m_dev, int* err_dev, std::vector<void*>& scratch,
-             hipStream_t s, int chain) {
+             hipStream_t s, int chain, double next_voxel_size,
+             bool from_previous) {
     // O3DMI_VDS_SORT=1 (diagnostics / A-B): the seven-launch sort for every size
     const char* sort_env = std::getenv("O3DMI_VDS_SORT");
     const bool force_sort = sort_env && sort_env[0] == '1';
@@ -1132,11 +1243,12 @@ int VdsAsync(const void* pos, const void* attr, int64_t n_max, const int* n_dev,
             return VdsBucketedImpl<double>(
                     (const double*)pos, (const double*)attr, n_max, n_dev,
                     voxel_size, (double*)out_pos, (double*)out_attr, m_dev,
-                    err_dev, chain, s);
+                    err_dev, chain, s, next_voxel_size, from_previous);
         return VdsBucketedImpl<float>((const float*)pos, (const float*)attr,
                                       n_max, n_dev, voxel_size,
                                       (float*)out_pos, (float*)out_attr, m_dev,
-                                      err_dev, chain, s);
+                                      err_dev, chain, s, next_voxel_size,
+                                      from_previous);
     }
     if (dtype == O3DMI_F64)
         return VdsAsyncImpl<double>((const double*)pos, (const double*)attr,

@@ -21,10 +21,21 @@ namespace o3dmi {
 // chain must be stream-ordered). Larger clouds take the six-launch sort:
 // its scratch comes from the pool and is appended to `scratch`; the caller
 // releases it (PoolFree) once the stream has drained.
+//   next_voxel_size  > 0: the caller's NEXT call on this chain will down-
+//           sample out_pos (same n_max, dtype) by this voxel size -- a pyramid
+//           built from its own output. The bucketed form then inserts the
+//           output into the next level's table in its last launch, and the
+//           next call starts at its second one. A next call that turns out
+//           different is still correct (the insert is discarded). Only when
+//           that next call is the ONLY pass over out_pos (no attribute passes
+//           in between).
+//   from_previous    this call IS such a next call: pos is the out_pos of the
+//           chain's previous call (anything else discards a pending insert).
 int VdsAsync(const void* pos, const void* attr, int64_t n_max, const int* n_dev,
              int dtype, double voxel_size, void* out_pos, void* out_attr,
              int* m_dev, int* err_dev, std::vector<void*>& scratch,
-             hipStream_t s, int chain = 0);
+             hipStream_t s, int chain = 0, double next_voxel_size = 0,
+             bool from_previous = false);
 
 // counts_dev[0..n) (int) -> mail_data[0..n) (as float64) + sequence word
 // `mail_seq` (mailbox.h), on stream s; the words are zeroed afterwards.

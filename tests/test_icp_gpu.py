@@ -1636,3 +1636,57 @@ def test_gated_search_launch_equals_the_plain_loop(dtype):
     finally:
         del os.environ["O3DMI_ICP_GATE"]
     assert np.array_equal(r.transformation, first.transformation)
+
+
+_FUSED_PYRAMID_SCRIPT = r"""
+import sys, json
+import numpy as np, torch
+sys.path.insert(0, %(root)r)
+from open3d_amd import registration as reg, synthetic as syn
+out = []
+for dtype, n, voxels in ((np.float32, 40000, [0.08, 0.04, 0.02, 0.01, 0.005]),
+                         (np.float64, 20000, [0.05, 0.025, 0.0125]),
+                         (np.float32, 3000, [0.05, -1.0])):
+    p = syn.make_icp_pair(n, n, seed=21, dtype=dtype)
+    src = torch.from_numpy(p["source"]).cuda()
+    tgt = torch.from_numpy(p["target"]).cuda()
+    nrm = torch.from_numpy(p["target_normals"]).cuda()
+    crit = [reg.ICPConvergenceCriteria(1e-6, 1e-6, 6)] * len(voxels)
+    md = [max(3 * abs(v), 0.05) for v in voxels]
+    log = []
+    r = reg.multi_scale_icp(src, tgt, nrm, voxels, crit, md,
+                            callback_after_iteration=log.append)
+    out.append([r.transformation.tobytes().hex(), r.num_iterations,
+                repr(r.fitness), repr(r.inlier_rmse),
+                [repr(e["inlier_rmse"]) for e in log]])
+print(json.dumps(out))
+"""
+
+
+def test_pyramid_level_that_carries_the_next_levels_insert_changes_nothing():
+    """The bucketed VoxelDownSample's last launch inserts its output into the
+    next (coarser) level's hash table (vds.h `next_voxel_size`; two table sets
+    taking turns: five levels here, Float32 and Float64, and a pyramid whose
+    finest level is the input itself). With O3DMI_VDS_NO_FUSE=1 every level
+    runs its own insert launch: every iteration's rmse, the pose, fitness and
+    iteration count must be the same bits either way."""
+    _gpu()
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _FUSED_PYRAMID_SCRIPT % {"root": root}
+
+    def run(env_extra):
+        env = dict(os.environ)
+        env.pop("O3DMI_VDS_NO_FUSE", None)
+        env.update(env_extra)
+        r = subprocess.run([sys.executable, "-c", script], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    fused = run({})
+    plain = run({"O3DMI_VDS_NO_FUSE": "1"})
+    assert fused == plain
+    assert all(case[1] > 0 for case in fused)
