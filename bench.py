@@ -681,6 +681,38 @@ def secondary_legs():
 # ---------------------------------------------------------------------------
 
 
+def pin_to_gpu_numa_node(device_index):
+    """One process per GPU, on the CPUs of the GPU's own NUMA node: the ICP
+    legs are a host in a loop with the device (a mailbox word polled over
+    PCIe, a launch per iteration), and from the far socket of the two-socket
+    host every hop is longer (examples/icp_slam at VGA: 1320 - 1337 frames/s
+    on the GPU's node, 1275 - 1311 on the other, anything between the two
+    unpinned). Child processes inherit the mask. Returns the CPU list used, or
+    None when the topology cannot be read (nothing is changed then)."""
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) != 0:
+            return None
+        bdf = buf.value.decode().lower()
+        with open("/sys/bus/pci/devices/%s/local_cpulist" % bdf) as f:
+            spec = f.read().strip()
+        cpus = set()
+        for part in spec.split(","):
+            if not part:
+                continue
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return spec
+    except Exception:
+        return None
+
+
 def main():
     a = parse()
     if a.leg == "configs4-integrate":  # the run rocprofv3 wraps
@@ -712,6 +744,8 @@ def main():
     assert a.gpus == world, \
         "--gpus %d but %d rank(s) were launched" % (a.gpus, world)
     dev = torch.device("cuda", torch.cuda.current_device())
+    all_cpus = os.sched_getaffinity(0)
+    pinned_cpus = pin_to_gpu_numa_node(torch.cuda.current_device())
 
     import __graft_entry__ as ge
     if rank == 0 and not os.path.exists(
@@ -1006,6 +1040,7 @@ def main():
                                "grid (tsdf f32, weight u16, color u16), known "
                                "poses" % (a.steps * a.batch),
                    "frames_per_step": a.batch, "block_count": a.block_count,
+                   "host_cpus": pinned_cpus,
                    "timed_region_s": elapsed,
                    "api": "integrate_frames, <= 1000 frames per call, "
                           "argument blocks prepared once (prepare_frames)",
@@ -1047,7 +1082,15 @@ def main():
             torch.cuda.empty_cache()
             out["secondary"]["configs4"] = configs4_leg()
     if frames_cpu is not None:
-        out["cpu_baseline"] = cpu_baseline(frames_cpu, K, Ts, a.cpu_seconds)
+        # the CPU baseline gets the whole host (it picks its own thread
+        # count): the GPU-node pinning is lifted for it
+        here = os.sched_getaffinity(0)
+        try:
+            os.sched_setaffinity(0, all_cpus)
+            out["cpu_baseline"] = cpu_baseline(frames_cpu, K, Ts,
+                                               a.cpu_seconds)
+        finally:
+            os.sched_setaffinity(0, here)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
