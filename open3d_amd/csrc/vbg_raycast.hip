@@ -131,8 +131,6 @@ struct RayCastParams {
 
 struct BlockCache {
     int x, y, z, block_idx;
-    int n_table, n_hash;  // diagnostics: look-ups past the register cache
-    bool diag;
     __device__ __forceinline__ int Check(int xi, int yi, int zi) const {
         return (xi == x && yi == y && zi == z) ? block_idx : -1;
     }
@@ -190,11 +188,9 @@ __device__ __forceinline__ int FindBlock(const HashView& hv,
     if (idx >= 0) return idx;
     unsigned rel;
     const bool in_table = tab.Encode(x_b, y_b, z_b, rel);
-    if (cache.diag) ++cache.n_table;
     if (in_table) idx = tab.Lookup(rel);
     else idx = -2;
     if (idx == -2) {
-        if (cache.diag) ++cache.n_hash;
         idx = hv.Find(x_b, y_b, z_b);
         if (in_table) tab.Store(rel, idx);
     }
@@ -334,7 +330,7 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
             p.c2w.RigidTransform(x_c, y_c, z_c, x_g, y_g, z_g);
             const float x_d = x_g - x_o, y_d = y_g - y_o, z_d = z_g - z_o;
 
-            BlockCache cache{0, 0, 0, -1, 0, 0, DIAG};
+            BlockCache cache{0, 0, 0, -1};
             bool surface_found = false;
             int n_crawl = 0;
             int n_steps = 0;
@@ -917,7 +913,7 @@ int o3dmi_vbg_raycast(o3dmi_hash_t* block_hash, const float* tsdf_dev,
         // per-pixel and per-8x8-tile (= per wave) statistics
         long long sum = 0, wsum = 0;
         int mx = 0, nw = 0, wmax_max = 0;
-        const std::vector<int> packed = hs;  // steps | hash << 8 | table << 16 | crawl << 24
+        const std::vector<int> packed = hs;  // steps | plain passes << 8 | cooperative passes << 16 | crawl steps << 24
         for (int& v : hs) v &= 255;
         for (int v : hs) { sum += v; mx = v > mx ? v : mx; }
         std::vector<int> wmaxes;
