@@ -152,14 +152,18 @@ extern "C" int o3dmi_rgbd_odometry_multiscale(
     int st = PoolAlloc((void**)&slab.base, total + sums_bytes + 256);
     if (st) return st;
     slab.size = total + sums_bytes + 256;
+    // `drained`: the host has seen the mailbox of the call's last launch and
+    // issued nothing since -- the stream is idle, and hipStreamSynchronize
+    // costs 16 us even then (registration.cpp SyncOnExit).
     struct SlabFree {
         hipStream_t s;
         void* p;
+        bool drained;
         ~SlabFree() {
-            (void)hipStreamSynchronize(s);
+            if (!drained) (void)hipStreamSynchronize(s);
             PoolFree(p);
         }
-    } slab_free{s, slab.base};
+    } slab_free{s, slab.base, false};
     double* scratch_dev = (double*)slab.base;
     double* sums_dev = scratch_dev + n_scratch;
     void* gn_scratch = slab.base + (sums_bytes - gn_bytes);
@@ -343,6 +347,7 @@ extern "C" int o3dmi_rgbd_odometry_multiscale(
                 fitness = mb->data[17];
                 iterations = (int)mb->data[18];
                 done = true;
+                slab_free.drained = true;
             } else if (status == 1) {
                 SetLastError("Invalid inlier_count value, must be > 0.");
                 return O3DMI_ERR_NO_INLIERS;
