@@ -88,15 +88,17 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8000,
                     help="frames per step (per GPU)")
-    ap.add_argument("--block-count", type=int, default=262144,
+    ap.add_argument("--block-count", type=int, default=524288,
                     help="initial hash capacity; the stream needs ~6 k blocks, "
                          "the rest is head-room that lets the host issue "
                          "several frame groups ahead of the GPU without "
                          "waiting for the map size (capacity policy of "
-                         "HashMap::Activate)")
-    ap.add_argument("--frames-per-launch", type=int, default=8,
+                         "HashMap::Activate: 12-frame groups need 524 288)")
+    ap.add_argument("--frames-per-launch", type=int, default=12,
                     help="consecutive frames applied per launch to register-"
-                         "resident blocks (1..16); results are identical")
+                         "resident blocks (1..16); results are identical. 12: "
+                         "128.4 k frames/s against 125.2 k for 8 and 126.1 k "
+                         "for 16 on the same box")
     ap.add_argument("--event-stride", type=int, default=16,
                     help="bracket every n-th integrate launch with HIP events "
                          "(0 = none; the roofline is then not measured)")
