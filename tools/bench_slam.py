@@ -196,7 +196,7 @@ def mode_slam(a):
             _lib.ptr(depth), _lib.U16, H, W, None, _lib.ptr(pts_buf), None,
             _lib.ptr(cnt), _lib.f64p(K), _lib.f64p(T), C.c_float(ds),
             C.c_float(dmax), C.c_int64(stride), stream()), "unproject")
-        if a.host_counts:
+        if getattr(a, "host_counts", False):
             return pts_buf[:int(cnt.item())]
         return pts_buf  # the live size stays in `cnt`, on the device
 
@@ -226,7 +226,7 @@ def mode_slam(a):
             stream()), "unproject")
         # the live size stays on the device (mcnt): the normals are rotated
         # over the whole buffer, rows past the size are never read
-        m = int(mcnt.item()) if a.host_counts else mnrm.shape[0]
+        m = int(mcnt.item()) if getattr(a, "host_counts", False) else mnrm.shape[0]
         Tinv = np.ascontiguousarray(np.linalg.inv(T_wc), dtype=np.float64)
         _lib.check(L.o3dmi_transform_normals(_lib.f64p(Tinv), _lib.ptr(mnrm),
                                              m, _lib.F32, stream()),
@@ -260,7 +260,7 @@ def mode_slam(a):
         p2 = tick()
         r = reg.multi_scale_icp(
             src, tp, tn, vs, crit, md,
-            device_counts=None if a.host_counts else (cnt, mcnt))
+            device_counts=None if getattr(a, "host_counts", False) else (cnt, mcnt))
         iters_log.append(r.num_iterations)
         p3 = tick()
         iters += r.num_iterations
@@ -284,7 +284,7 @@ def mode_slam(a):
            "max_pose_err_rad_m": [max(e[0] for e in errs),
                                   max(e[1] for e in errs)],
            "active_blocks": g.hashmap().size(),
-           "cloud_sizes": "host" if a.host_counts else "device",
+           "cloud_sizes": "host" if getattr(a, "host_counts", False) else "device",
            "icp_iterations_first_frames": iters_log[:12]}
     if a.phases:
         out["ms_model_cloud_frame_cloud_icp_integrate"] = \
