@@ -1,0 +1,62 @@
+"""CPU checks of two analysis tools (no GPU): the numpy replay of the ray-cast
+march against the oracle, and the tracking-loop timeline on a made-up trace."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_march_replay_agrees_with_the_oracles_ray_cast():
+    """tools/raycast_march_stats.py rebuilds the grid with the oracle and
+    replays the reference's march in numpy, independently of the oracle's own
+    RayCast body; it asserts that the two hit the same fraction of pixels (to
+    1e-3) before it prints its statistics. A window of one sample must cost
+    exactly the plain march's voxel loads, longer windows never more."""
+    r = subprocess.run([sys.executable,
+                        os.path.join(ROOT, "tools", "raycast_march_stats.py"),
+                        "--frames", "6", "--windows", "1,4"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    assert any("= the oracle's" in ln for ln in lines)
+
+    def wave_max(window):
+        i = lines.index("window %d:" % window)
+        row = lines[i + 2]  # "loads / wave  mean ... max N"
+        return int(row.split()[-1]), float(row.split()[4])
+    m1, mean1 = wave_max(1)
+    m4, mean4 = wave_max(4)
+    assert 0 < m4 <= m1 and mean4 <= mean1
+
+
+def test_slam_timeline_charges_idle_time_to_the_launch_that_ends_it(tmp_path):
+    rows = [
+        # start, end, name                                   (ns)
+        (1000, 3000, "void o3dmi::SearchAccumulateKernel<float, 32, 3>(...)"),
+        (3000, 4000, "void o3dmi::FinalSumKernel<32>(...)"),
+        (9000, 11000, "void o3dmi::SearchAccumulateKernel<float, 32, 3>(...)"),
+        (10000, 12000, "void o3dmi::VdsBucketReduceKernel<float>(...)"),
+        (15000, 16000, "void o3dmi::FinalSumKernel<32>(...)"),
+    ]
+    p = tmp_path / "trace.csv"
+    with open(p, "w") as f:
+        f.write("Start_Timestamp,End_Timestamp,Kernel_Name\n")
+        for s, e, n in rows:
+            f.write('%d,%d,"%s"\n' % (s, e, n))
+    r = subprocess.run([sys.executable,
+                        os.path.join(ROOT, "tools", "slam_timeline.py"),
+                        str(p), "1"], capture_output=True, text=True,
+                       timeout=60)
+    assert r.returncode == 0, r.stderr
+    table = r.stdout.split("idle gaps")[0].splitlines()
+    out = {ln.split()[0]: ln.split() for ln in table
+           if ln.split() and ln.split()[0] in ("search", "final_sum", "vds",
+                                               "total")}
+    # wall 15 us: search busy 2 + 2, idle before the second search 5 us;
+    # the reduce overlaps the search for 1 us and adds 1 us of its own;
+    # the second final sum waits 3 us
+    assert out["search"][2:] == ["4.0", "5.0"]
+    assert out["vds"][2:] == ["1.0", "0.0"]
+    assert out["final_sum"][2:] == ["2.0", "3.0"]
+    assert out["total"][2:] == ["7.0", "8.0"]
