@@ -12,8 +12,9 @@
  * (the residual is no longer exact once a * y is denormal) -- so the form is
  * exact behind a guard on |a|, which is what the integrate role does for ITS
  * constants after the same enumeration on the device (vbg_stream.hip
- * VerifyFastDivision). Not wired into the ray cast yet: a march step makes six
- * such divisions, ~60 of its ~300 instructions ("Open"). */
+ * VerifyFastDivision). Tried in the ray cast at the end of round 3 (a march step
+ * makes six such divisions): bit-identical maps, -1.4 % at VGA, but the kernel
+ * then spilled under its 96-register cap; not kept ("Open"). */
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
