@@ -209,7 +209,7 @@ def cpu_baseline(frames_cpu, K, Ts, budget_s):
     best = max(probe, key=probe.get)
     fps, n, phase_ms = run(best, frames, budget_s * 0.5)
     return {"value": fps, "unit": "frames/s", "cores": best,
-            "kind": "reference" if use_ref else "port",
+            "kind": "reference" if use_ref else "port", "frames": n,
             "ms_per_frame": {"touch": phase_ms[0],
                              "activate_find": phase_ms[1],
                              "integrate": phase_ms[2]},
@@ -247,7 +247,7 @@ def _pmc_pass(counters, tmp, tag, inner=None, want=None):
     if want is None:
         # the fused colour instantiation: <u16, u16, true, div, form>
         want = lambda name: KERNEL in name and ", true," in name
-    cmd = ["rocprofv3", "--pmc"] + counters + \
+    cmd = ["rocprofv3"] + (["--pmc"] + counters if counters else []) + \
         ["--kernel-trace", "--output-format", "csv", "-d", out_dir, "-o",
          "pmc", "--"] + inner
     env = dict(os.environ, TMPDIR="/tmp")
@@ -255,7 +255,7 @@ def _pmc_pass(counters, tmp, tag, inner=None, want=None):
                        text=True, timeout=600)
     files = glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"),
                       recursive=True)
-    if r.returncode != 0 or not files:
+    if r.returncode != 0 or (counters and not files):
         raise RuntimeError("rocprofv3 %s: rc %d %s" % (tag, r.returncode,
                                                        r.stderr[-300:]))
     acc, disp = {}, set()
@@ -270,16 +270,23 @@ def _pmc_pass(counters, tmp, tag, inner=None, want=None):
                 disp.add(row["Dispatch_Id"])
     n = max(1, len(disp))
     res = {k: v / n for k, v in acc.items()}
-    durs = []
+    durs, t_lo, t_hi = [], None, None
     for f in glob.glob(os.path.join(out_dir, "**", "*kernel_trace.csv"),
                        recursive=True):
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 if want(row["Kernel_Name"]):
-                    durs.append(int(row["End_Timestamp"]) -
-                                int(row["Start_Timestamp"]))
+                    a0, a1 = int(row["Start_Timestamp"]), \
+                        int(row["End_Timestamp"])
+                    durs.append(a1 - a0)
+                    t_lo = a0 if t_lo is None else min(t_lo, a0)
+                    t_hi = a1 if t_hi is None else max(t_hi, a1)
     if durs:
         res["_avg_kernel_ns"] = float(np.mean(durs))
+        res["_sum_kernel_ns"] = float(np.sum(durs))
+        res["_span_ns"] = float(t_hi - t_lo)
+        if not counters:
+            n = len(durs)
     return res, n
 
 
@@ -366,12 +373,16 @@ C4_FRAMES_PER_LAUNCH = 4
 C4_FRAME_STEP = 5         # every 5th frame of the 1000-frame stream
 
 
-def configs4_integrate(n_frames=200, event_stride=1):
-    """One pass of n_frames frames into the big map; returns the measurement."""
+def configs4_integrate(n_frames=200, event_stride=1, fpl=None, passes=1,
+                       per_launch=False):
+    """One cold pass of n_frames frames into the big map (+ `passes` - 1 warm
+    passes over the same frames); returns the measurement of the COLD pass
+    (and the warm ones under "warm_passes")."""
     import ctypes as C
     import torch
     from open3d_amd import _lib, geometry, synthetic
     from open3d_amd.core import stream
+    fpl = fpl or C4_FRAMES_PER_LAUNCH
     dev = torch.device("cuda", torch.cuda.current_device())
     K = synthetic.intrinsics(W, H)
     ds, cs, Ts = [], [], []
@@ -394,23 +405,41 @@ def configs4_integrate(n_frames=200, event_stride=1):
         g.hashmap()._h, _lib.ptr(keys), C4_BALLAST, None, None, None,
         stream()), "activate ballast")
     assert g.hashmap().size() == C4_BALLAST
+    # which division forms the launches of the pass use (the on-device proof
+    # was started when the grid was created; 2 / 3 = all short forms)
+    forms = int(_lib.lib().o3dmi_vbg_division_forms(
+        C.c_float(C4_VOXEL), C.c_float(TRUNC), 0))
     batch = g.prepare_frames(ds, cs, K, K, Ts)
-    n_launch = n_frames // C4_FRAMES_PER_LAUNCH
-    g.profile_begin(n_launch + 8, event_stride)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    g.integrate_frames(batch, depth_scale=C4_DEPTH_SCALE,
-                       depth_max=C4_DEPTH_MAX, trunc_voxel_multiplier=TRUNC,
-                       frames_per_launch=C4_FRAMES_PER_LAUNCH)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    prof = g.profile_end()
+    n_launch = (n_frames + fpl - 1) // fpl
+    runs = []
+    for p in range(passes):
+        g.profile_begin(n_launch + 8, event_stride)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        g.integrate_frames(batch, depth_scale=C4_DEPTH_SCALE,
+                           depth_max=C4_DEPTH_MAX,
+                           trunc_voxel_multiplier=TRUNC, frames_per_launch=fpl)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        prof = g.profile_end()
+        r = {"frames_per_s": n_frames / dt, "wall_ms": dt * 1e3, "prof": prof}
+        if per_launch:
+            per = g.profile_launches()
+            r["per_launch_ms"] = [round(float(x), 4) for x in per["ms"]]
+            r["per_launch_distinct"] = per["distinct_blocks"].tolist()
+            r["per_launch_map_size"] = per["map_size"].tolist()
+        runs.append(r)
+    dt = runs[0]["wall_ms"] * 1e-3
+    prof = runs[0]["prof"]
     hm = g.hashmap()
     n_blocks = hm.size()
     act = hm.active_buf_indices()
     max_index = int(act.max().item())
     launches = max(1, prof["launches"])
     k_ms = prof["integrate_ms"] / launches
+    min_read = (prof["distinct_blocks"] * (BYTES_PER_BLOCK // 2 +
+                                           BLOCK_HEADER_BYTES) +
+                prof["frames"] * (IMAGE_BYTES + W * H * 8)) / launches
     min_bytes = (prof["distinct_blocks"] * (BYTES_PER_BLOCK +
                                             BLOCK_HEADER_BYTES) +
                  prof["frames"] * (IMAGE_BYTES + 2 * W * H * 8)) / launches
@@ -423,7 +452,8 @@ def configs4_integrate(n_frames=200, event_stride=1):
                        % (n_frames, C4_FRAME_STEP, C4_DEPTH_SCALE,
                           C4_DEPTH_MAX, C4_CAPACITY, C4_BALLAST),
            "frames_per_s": n_frames / dt, "ms_per_frame": dt / n_frames * 1e3,
-           "frames_per_launch": C4_FRAMES_PER_LAUNCH,
+           "wall_ms_per_launch": dt * 1e3 / n_launch,
+           "frames_per_launch": fpl, "division_forms": forms,
            "active_blocks": int(n_blocks),
            "stream_blocks": int(n_blocks - C4_BALLAST),
            "voxel_state_bytes_of_the_stream": int(n_blocks - C4_BALLAST) *
@@ -433,9 +463,10 @@ def configs4_integrate(n_frames=200, event_stride=1):
            "reference_index_limit": 2 ** 31 - 1,
            "avg_blocks_per_frame": prof["block_frames"] /
                                    max(1, prof["frames"]),
-           "roofline": {"bound": "hbm", "kernel": KERNEL, "unit": "GB/s",
+           "roofline": {"bound": "valu", "kernel": KERNEL, "unit": "GB/s",
                         "peak": HBM_PEAK_GBS, "avg_kernel_ms": k_ms,
                         "fused_minimum_bytes_per_launch": min_bytes,
+                        "minimum_read_bytes_per_launch": min_read,
                         "achieved": min_bytes / (k_ms * 1e-3) / 1e9
                         if k_ms > 0 else None,
                         "frac": min_bytes / (k_ms * 1e-3) / 1e9 /
@@ -444,20 +475,95 @@ def configs4_integrate(n_frames=200, event_stride=1):
                         if k_ms > 0 else None,
                         "distinct_blocks_per_launch":
                             prof["distinct_blocks"] / launches}}
+    if per_launch:
+        out["per_launch_ms"] = runs[0]["per_launch_ms"]
+        out["per_launch_distinct_blocks"] = runs[0]["per_launch_distinct"]
+        out["per_launch_map_size"] = runs[0]["per_launch_map_size"]
+    if passes > 1:
+        out["warm_passes"] = [
+            {"frames_per_s": r["frames_per_s"],
+             "avg_kernel_ms": r["prof"]["integrate_ms"] /
+                              max(1, r["prof"]["launches"])}
+            for r in runs[1:]]
     del g
     torch.cuda.empty_cache()
     return out
+
+
+def kernel_counters(inner, want):
+    """The kernels `want` selects in the command `inner`, measured four times
+    over -- once under `rocprofv3 --kernel-trace` alone (their durations) and
+    once per counter block (FETCH_SIZE; WRITE_SIZE; the SQ set), each pass with
+    only the kernel trace beside it -> per launch: traffic bytes (FETCH_SIZE x
+    2 + WRITE_SIZE, factors calibrated in profiles/r2a_hbm_calibration.json),
+    kernel us without and with counters, VALU issue share, wave-cycle split.
+    Every pass runs the SAME command, i.e. the same frames and launches."""
+    if shutil.which("rocprofv3") is None:
+        return {"error": "rocprofv3 not on PATH"}
+    tmp = tempfile.mkdtemp(prefix="o3dmi_pmc4_", dir="/tmp")
+    try:
+        tr, n0 = _pmc_pass([], tmp, "trace", inner, want)
+        rd, n1 = _pmc_pass(["FETCH_SIZE"], tmp, "fetch", inner, want)
+        wr, _ = _pmc_pass(["WRITE_SIZE"], tmp, "write", inner, want)
+        sq, _ = _pmc_pass(PMC_PASSES["sq"], tmp, "sq", inner, want)
+        read = 2.0 * rd.get("FETCH_SIZE", 0.0) * 1024.0
+        write = wr.get("WRITE_SIZE", 0.0) * 1024.0
+        out = {"traffic_bytes_per_launch": read + write,
+               "traffic_read_bytes": read, "traffic_write_bytes": write,
+               "launches_profiled": n1 or n0,
+               "kernel_us_trace_only": (tr.get("_avg_kernel_ns") or 0) / 1e3
+               or None,
+               "kernel_us_under_counters":
+                   (rd.get("_avg_kernel_ns") or 0) / 1e3 or None,
+               "kernel_us_sum_trace_only": tr.get("_sum_kernel_ns", 0) / 1e3,
+               "span_us_trace_only": tr.get("_span_ns", 0) / 1e3}
+        if sq.get("GRBM_GUI_ACTIVE") and sq.get("SQ_ACTIVE_INST_VALU"):
+            cyc = sq["GRBM_GUI_ACTIVE"] / N_XCD
+            wc = max(1.0, sq.get("SQ_WAVE_CYCLES", 1.0))
+            out["frac_valu"] = sq["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMD * cyc)
+            out["valu_insts_per_launch"] = sq.get("SQ_INSTS_VALU")
+            out["avg_waves_per_simd"] = sq.get("SQ_WAVE_CYCLES", 0) * 4.0 / \
+                (N_SIMD * cyc)
+            out["wave_cycle_split"] = {
+                "issuing": sq.get("SQ_ACTIVE_INST_ANY", 0) / wc,
+                "waiting_memory_or_barrier": sq.get("SQ_WAIT_ANY", 0) / wc,
+                "issue_stalled": sq.get("SQ_WAIT_INST_ANY", 0) / wc}
+        return out
+    except Exception as e:
+        return {"error": str(e)[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def attach_counters(roof, k, k_ms):
+    """Counter fractions of a leg: bytes of the profiled passes over the kernel
+    time of the TIMED pass (`k_ms`, HIP events); the kernel-trace pass of the
+    same command is reported beside it."""
+    roof.update(k)
+    if "error" in k or not k_ms:
+        return
+    roof["frac_hbm"] = k["traffic_bytes_per_launch"] / (k_ms * 1e-3) / 1e9 / \
+        HBM_PEAK_GBS
+    if k.get("kernel_us_trace_only"):
+        roof["frac_hbm_on_trace_time"] = k["traffic_bytes_per_launch"] / (
+            k["kernel_us_trace_only"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+    mr = roof.get("minimum_read_bytes_per_launch")
+    if mr:
+        roof["read_overfetch"] = k["traffic_read_bytes"] / mr
 
 
 def configs4_leg():
     import importlib.util
     out = {}
     try:
-        r = configs4_integrate()
+        r = configs4_integrate(per_launch=True, passes=2)
         inner = [sys.executable, os.path.abspath(__file__), "--leg",
                  "configs4-integrate"]
-        r["roofline"].update(hbm_counters(
-            inner, lambda name: KERNEL in name and ", true," in name))
+        # the SAME 200-frame cold pass under the profiler (VERDICT r3: the
+        # counters used to come from a 48-frame run)
+        attach_counters(r["roofline"], kernel_counters(
+            inner, lambda name: KERNEL in name and ", true," in name),
+            r["roofline"]["avg_kernel_ms"])
         out["integrate_4mm_over_500k_blocks"] = r
     except Exception as e:
         out["integrate_4mm_over_500k_blocks"] = {"error": str(e)[:300]}
@@ -488,6 +594,106 @@ def configs4_leg():
     except Exception as e:
         out["icp_2x1M"] = {"error": str(e)[:300]}
     return out
+
+
+# ---------------------------------------------------------------------------
+# The headline kernel with DRAM in the loop. The looped configs[1] stream keeps
+# re-visiting 5 745 blocks = 276 MB of voxel state, about the size of the 256
+# MB Infinity Cache, and FETCH_SIZE / WRITE_SIZE count Infinity-Cache hits
+# (MI355X_MICROARCH.md): the headline's `frac_hbm` is fabric traffic, not DRAM
+# traffic. Here the same 1000 resident images are integrated into DRAM_COPIES
+# disjoint copies of the scene in turn (copy c = the scene moved by c x 16 m:
+# the extrinsics change, the images do not), so a block's state has been
+# pushed out by > 1 GB of other blocks before its next visit.
+
+DRAM_COPIES = 5
+DRAM_OFFSET_M = 16.0
+
+
+def headline_dram_resident(a, event_stride=8, passes=2):
+    import torch
+    from open3d_amd import geometry, synthetic
+    dev = torch.device("cuda", torch.cuda.current_device())
+    K = synthetic.intrinsics(W, H)
+    ds, cs, Ts = [], [], []
+    for k in range(N_UNIQUE):
+        d, c, _, T = synthetic.render_frames(k, 1, W, H, device=dev)
+        ds.append(d[0].contiguous())
+        cs.append(c[0].contiguous())
+        Ts.append(T[0])
+    g = geometry.VoxelBlockGrid(["tsdf", "weight", "color"],
+                                [torch.float32, torch.uint16, torch.uint16],
+                                [1, 1, 3], VOXEL, RES, 65536)
+    batches = []
+    for c in range(DRAM_COPIES):
+        # scene moved by o: p' = p + o, the camera sees the same image when
+        # its extrinsic becomes T . translate(-o)
+        o = np.array([DRAM_OFFSET_M * c, 0.0, 0.0])
+        Tc = []
+        for T in Ts:
+            T2 = np.array(T, dtype=np.float64, copy=True)
+            T2[:3, 3] = T2[:3, 3] - T2[:3, :3] @ o
+            Tc.append(T2)
+        batches.append(g.prepare_frames(ds, cs, K, K, Tc))
+
+    def one_pass():
+        for b in batches:
+            g.integrate_frames(b, depth_scale=DEPTH_SCALE, depth_max=DEPTH_MAX,
+                               trunc_voxel_multiplier=TRUNC,
+                               frames_per_launch=a.frames_per_launch)
+
+    one_pass()                      # creates the blocks (cold)
+    torch.cuda.synchronize()
+    n_launch = passes * DRAM_COPIES * (
+        (N_UNIQUE + a.frames_per_launch - 1) // a.frames_per_launch)
+    g.profile_begin(n_launch // max(1, event_stride) + 64, event_stride)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        one_pass()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = g.profile_end()
+    launches = max(1, prof["launches"])
+    k_ms = prof["integrate_ms"] / launches
+    n_blocks = int(g.hashmap().size())
+    min_read = (prof["distinct_blocks"] * (BYTES_PER_BLOCK // 2 +
+                                           BLOCK_HEADER_BYTES) +
+                prof["frames"] * (IMAGE_BYTES + W * H * 8)) / launches
+    min_bytes = (prof["distinct_blocks"] * (BYTES_PER_BLOCK +
+                                            BLOCK_HEADER_BYTES) +
+                 prof["frames"] * (IMAGE_BYTES + 2 * W * H * 8)) / launches
+    out = {"workload": "the configs[1] images integrated into %d disjoint "
+                       "copies of the scene in turn (poses moved by c x %g m), "
+                       "%d passes after the one that creates the blocks"
+                       % (DRAM_COPIES, DRAM_OFFSET_M, passes),
+           "frames_per_s": passes * DRAM_COPIES * N_UNIQUE / dt,
+           "active_blocks": n_blocks,
+           "voxel_state_bytes": n_blocks * BYTES_PER_BLOCK // 2,
+           "frames_per_launch": a.frames_per_launch,
+           "roofline": {"bound": "valu", "kernel": KERNEL, "unit": "GB/s",
+                        "peak": HBM_PEAK_GBS, "avg_kernel_ms": k_ms,
+                        "fused_minimum_bytes_per_launch": min_bytes,
+                        "minimum_read_bytes_per_launch": min_read,
+                        "frac": min_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                        if k_ms > 0 else None}}
+    del g, batches
+    torch.cuda.empty_cache()
+    return out
+
+
+def headline_dram_leg(a):
+    try:
+        r = headline_dram_resident(a)
+        inner = [sys.executable, os.path.abspath(__file__), "--leg",
+                 "headline-dram", "--frames-per-launch",
+                 str(a.frames_per_launch)]
+        attach_counters(r["roofline"], kernel_counters(
+            inner, lambda name: KERNEL in name and ", true," in name),
+            r["roofline"]["avg_kernel_ms"])
+        return r
+    except Exception as e:
+        return {"error": str(e)[:300]}
 
 
 # ---------------------------------------------------------------------------
@@ -720,7 +926,12 @@ def main():
     if a.leg == "configs4-integrate":  # the run rocprofv3 wraps
         import torch
         torch.cuda.set_device(0)
-        print(json.dumps(configs4_integrate(n_frames=48, event_stride=0)))
+        print(json.dumps(configs4_integrate(event_stride=0)))
+        return
+    if a.leg == "headline-dram":
+        import torch
+        torch.cuda.set_device(0)
+        print(json.dumps(headline_dram_resident(a, event_stride=0, passes=1)))
         return
     maybe_spawn(a)
     import torch
@@ -957,11 +1168,15 @@ def main():
     min_bytes = (prof["distinct_blocks"] * (BYTES_PER_BLOCK +
                                             BLOCK_HEADER_BYTES)
                  + prof["frames"] * (IMAGE_BYTES + 2 * RECORD_BYTES)) / launches
+    min_read = (prof["distinct_blocks"] * (BYTES_PER_BLOCK // 2 +
+                                           BLOCK_HEADER_BYTES)
+                + prof["frames"] * (IMAGE_BYTES + RECORD_BYTES)) / launches
     min_gbps = min_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     roof = {"bound": "valu", "kernel": KERNEL, "achieved": min_gbps,
             "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": min_gbps / HBM_PEAK_GBS,
             "fused_minimum_bytes_per_launch": min_bytes,
+            "minimum_read_bytes_per_launch": min_read,
             "distinct_blocks_per_launch": prof["distinct_blocks"] / launches,
             "equivalent_gbps": achieved,
             "equivalent_frac": achieved / HBM_PEAK_GBS,
@@ -971,29 +1186,30 @@ def main():
             "wall_ms_per_launch": elapsed * 1e3 / n_timed_launches,
             "frames_per_launch": prof["frames"] / launches,
             "traffic": None, "frac_hbm": None, "frac_valu": None,
-            "frac_bound": None,
-            "note": "`achieved` / `frac`: the fused-minimum bytes of a launch "
-                    "(distinct blocks of the frame group once in + once out, "
-                    "images in, prepared records out + in) / HIP-event kernel "
-                    "time / 8 TB/s -- a fraction of the HBM peak that cannot "
-                    "exceed 1. `equivalent_gbps` is SURVEY 8(d)'s per-frame "
-                    "convention (every voxel of an active block charged for "
-                    "every frame): how much reference-style traffic a launch "
-                    "stands for, not what DRAM carried -- it may exceed the "
-                    "peak because state crosses the fabric once per group of "
-                    "up to 8 frames. `frac_hbm` = counter bytes (FETCH_SIZE x "
-                    "2 + WRITE_SIZE, both factors calibrated on copy kernels "
-                    "with this kernel's 8 / 16 / 24 B-per-lane accesses: "
-                    "profiles/r2a_hbm_calibration.json) / the same kernel "
-                    "time / 8 TB/s. The binding roof is vector-ALU issue "
-                    "(`bound`: bit-exact float32 arithmetic per voxel): "
-                    "`frac_valu` = `frac_bound` = SQ_ACTIVE_INST_VALU x 4 "
-                    "cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), "
-                    "measured under the profiler. `avg_kernel_ms` is the HIP-"
-                    "event bracket of every 16th launch: it contains the "
-                    "dispatch latency of the bracketed launch and the event "
-                    "pair's own cost (`empty_event_bracket_ms`), so it sits a "
-                    "few percent above rocprofv3's kernel duration."}
+            "frac_bound": None, "read_overfetch": None}
+    roof_note = (
+        "`achieved` / `frac`: the fused-minimum bytes of a launch (distinct "
+        "blocks of the frame group once in + once out, images in, prepared "
+        "records out + in) / HIP-event kernel time / 8 TB/s -- a fraction of "
+        "the HBM peak that cannot exceed 1. `equivalent_gbps` is SURVEY "
+        "8(d)'s per-frame convention (every voxel of an active block charged "
+        "for every frame): how much reference-style traffic a launch stands "
+        "for, not what DRAM carried. `frac_hbm` = counter bytes (FETCH_SIZE x "
+        "2 + WRITE_SIZE, both factors calibrated on copy kernels with this "
+        "kernel's access widths: profiles/r2a_hbm_calibration.json) / the "
+        "same kernel time / 8 TB/s; the counters sit on the L2's fabric side "
+        "and count Infinity-Cache hits, and the looped stream's 276 MB of "
+        "voxel state is about the size of that cache: `frac_hbm` of the "
+        "headline is FABRIC traffic; `dram_resident` is the same kernel on a "
+        "1.4 GB working set, where the counters are DRAM traffic. "
+        "`read_overfetch` = counter reads / minimum reads. The binding roof "
+        "is vector-ALU issue (`bound`: bit-exact float32 arithmetic per "
+        "voxel): `frac_valu` = `frac_bound` = SQ_ACTIVE_INST_VALU x 4 cycles "
+        "/ (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), measured under the "
+        "profiler. `avg_kernel_ms` is the HIP-event bracket of every 16th "
+        "launch: it contains the dispatch latency of the bracketed launch and "
+        "the event pair's own cost (`empty_event_bracket_ms`), so it sits a "
+        "few percent above rocprofv3's kernel duration.")
     if e_world == 1 and rank == 0 and not a.no_pmc:
         pmc, why = pmc_live()
         src = "live rocprofv3 passes (this run)"
@@ -1008,6 +1224,7 @@ def main():
             roof["traffic_read_bytes"] = 2.0 * pmc.get("FETCH_SIZE", 0) * 1024
             roof["traffic_write_bytes"] = pmc.get("WRITE_SIZE", 0) * 1024.0
             roof["traffic_source"] = src
+            roof["read_overfetch"] = roof["traffic_read_bytes"] / min_read
             if k_ms > 0:
                 roof["frac_hbm"] = traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             if pmc.get("GRBM_GUI_ACTIVE") and pmc.get("SQ_ACTIVE_INST_VALU"):
@@ -1026,10 +1243,17 @@ def main():
                     "issue_stalled": pmc.get("SQ_WAIT_INST_ANY", 0) / wc}
             roof["counter_launches"] = pmc.get("launches")
 
+    sharding = ("none" if e_world == 1 else
+                "one stream, blocks split by ownership (no data-path "
+                "collective; union of the grids bit-identical to one GPU's)"
+                if by_blocks
+                else "frames r, r+N, ... of the one stream per rank; closing "
+                     "exchange inside the timed region: all-to-all of block "
+                     "IDs + voxel rows to the owning rank, folded in there")
     out = {
         "metric": "RGB-D frames/s (TSDF integrate into 8 mm / 16^3 "
-                  "VoxelBlockGrid: touch + activate + integrate; ICP leg in "
-                  "`secondary`)",
+                  "VoxelBlockGrid: touch + activate + integrate; ICP legs in "
+                  "configs0 / configs2)",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
         "higher_is_better": True,
@@ -1044,24 +1268,14 @@ def main():
                    "frames_per_step": a.batch, "block_count": a.block_count,
                    "host_cpus": pinned_cpus,
                    "timed_region_s": elapsed,
-                   "api": "integrate_frames, <= 1000 frames per call, "
-                          "argument blocks prepared once (prepare_frames)",
                    "frames_per_launch": a.frames_per_launch,
                    "active_blocks": int(n_blocks),
+                   "map_capacity_after": int(g.hashmap().capacity())
+                   if e_world == 1 else None,
                    "avg_blocks_per_frame": prof["block_frames"] /
                                            max(1, prof["frames"]),
-                   "sharding": ("none" if e_world == 1 else
-                                "one stream, blocks split by ownership "
-                                "(no data-path collective; union of the "
-                                "grids bit-identical to one GPU's)"
-                                if by_blocks
-                                else "frames r, r+N, ... of the one stream "
-                                     "per rank; closing exchange inside the "
-                                     "timed region: all-to-all of block IDs "
-                                     "+ voxel rows to the owning rank, "
-                                     "folded in there"),
+                   "sharding": sharding,
                    "merge_ms": merge_ms,
-                   "cold_pass": cold,
                    "dist_backend": a.dist_backend if world > 1 else None,
                    "dry_run": (world > 1 and a.dist_backend == "gloo") or None,
                    "emulated_rank_of_world": [e_rank, e_world]
@@ -1070,35 +1284,163 @@ def main():
                        other},
         "roofline": roof,
     }
+    detail = {"roofline_note": roof_note, "cold_pass": cold,
+              "api": "integrate_frames, <= 1000 frames per call, argument "
+                     "blocks prepared once (prepare_frames)"}
     frames_cpu = None
     if e_world == 1 and not a.no_cpu_baseline:
         frames_cpu = [(depths[i].cpu().numpy(), colors[i].cpu().numpy())
                       for i in range(min(64, len(depths)))]
+    secondary = None
     if e_world == 1 and not a.no_secondary:
+        del g
+        torch.cuda.empty_cache()
         try:
-            out["secondary"] = secondary_legs()
+            secondary = secondary_legs()
         except Exception as e:
-            out["secondary"] = {"error": str(e)[:300]}
+            secondary = {"error": str(e)[:300]}
+        del depths, colors
+        torch.cuda.empty_cache()
+        if not a.no_pmc:
+            secondary["headline_dram_resident"] = headline_dram_leg(a)
         if not a.no_configs4:
-            del depths, colors, g
-            torch.cuda.empty_cache()
-            out["secondary"]["configs4"] = configs4_leg()
+            secondary["configs4"] = configs4_leg()
+        detail["secondary"] = secondary
     if frames_cpu is not None:
         # the CPU baseline gets the whole host (it picks its own thread
         # count): the GPU-node pinning is lifted for it
         here = os.sched_getaffinity(0)
         try:
             os.sched_setaffinity(0, all_cpus)
-            out["cpu_baseline"] = cpu_baseline(frames_cpu, K, Ts,
-                                               a.cpu_seconds)
+            cb = cpu_baseline(frames_cpu, K, Ts, a.cpu_seconds)
         finally:
             os.sched_setaffinity(0, here)
+        detail["cpu_baseline"] = dict(cb)
+        cb["sample"] = "first %d frames of the same stream; %s; best of " \
+                       "several thread counts" % (
+                           cb["frames"],
+                           "Open3D DepthTouchCPU / IntegrateCPU bodies "
+                           "(oracle/_ref)" if cb["kind"] == "reference"
+                           else "restated oracle")
+        out["cpu_baseline"] = cb
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        line = compact_line(out, secondary)
+        detail["line"] = out
+        wrote = []
+        for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+            if os.path.isdir(d):
+                try:
+                    with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                        json.dump(detail, f)
+                    wrote.append(os.path.relpath(
+                        os.path.join(d, "bench_detail.json"), ROOT))
+                except OSError:
+                    pass
+        line["detail"] = wrote[0] if wrote else None
+        print(json.dumps(line), flush=True)
     if dist is not None:
         torch.cuda.synchronize()
         comm.destroy()
         dist.destroy_process_group()
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and
+            d[k] is not None}
+
+
+def _r(x, n=4):
+    """Numbers of the line rounded to n significant digits (keeps it short)."""
+    if isinstance(x, float):
+        return float("%.*g" % (n, x))
+    if isinstance(x, dict):
+        return {k: _r(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, n) for v in x]
+    return x
+
+
+def compact_line(out, secondary):
+    """The ONE line the driver keeps (it stores ~8 KB): the contract fields,
+    `roofline`, `cpu_baseline` and one small object per BASELINE config; small
+    objects first. Everything else -- notes, per-kernel tables, per-launch
+    series, workload descriptions -- goes to bench_detail.json."""
+    line = {k: out[k] for k in (
+        "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+        "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+        "cold_pass_frames_per_s")}
+    sec = secondary or {}
+    c0 = sec.get("configs0_icp_2x100k") or {}
+    if c0:
+        line["configs0"] = _r(dict(
+            _pick(c0, ("ms_per_icp", "iterations", "ms_per_iteration",
+                       "pose_err_vs_oracle_rad_m", "same_iterations_as_oracle",
+                       "cpu_oracle_ms_per_icp", "cpu_oracle_threads")),
+            frac=(c0.get("roofline") or {}).get("frac")))
+    c2 = {}
+    for tag, key in (("1280x720", "configs2_loop_1280x720"),
+                     ("640x480", "configs2_loop_640x480")):
+        py, cpp = sec.get(key) or {}, sec.get(key + "_cpp_caller") or {}
+        if not py and not cpp:
+            continue
+        pk = cpp.get("per_kernel") or {}
+        c2[tag] = _r(dict(
+            frames_per_s=cpp.get("frames_per_s"),
+            runs=cpp.get("frames_per_s_of_5_runs"),
+            icp_iterations_per_frame=cpp.get("icp_iterations_per_frame",
+                                             py.get("icp_iterations_per_frame")),
+            launches_per_frame=pk.get("launches_per_frame"),
+            gpu_busy_frac=pk.get("gpu_busy_frac"),
+            kernel_us_per_frame=pk.get("kernel_us_per_frame"),
+            python_frames_per_s=py.get("frames_per_s"),
+            cpu_oracle_ms_per_multiscale_icp=py.get(
+                "cpu_oracle_ms_per_multiscale_icp"),
+            error=cpp.get("error")))
+        c2[tag] = {k: v for k, v in c2[tag].items() if v is not None}
+    if c2:
+        c2["caller"] = "examples/icp_slam (C++, median of 5 runs)"
+        line["configs2"] = c2
+    c4 = (sec.get("configs4") or {})
+    c4i = c4.get("integrate_4mm_over_500k_blocks") or {}
+    if c4i:
+        ro = c4i.get("roofline") or {}
+        line["configs4"] = _r(dict(
+            _pick(c4i, ("frames_per_s", "wall_ms_per_launch",
+                        "frames_per_launch", "active_blocks",
+                        "max_linear_voxel_index", "division_forms", "error")),
+            **_pick(ro, ("avg_kernel_ms", "kernel_us_trace_only", "frac",
+                         "frac_hbm", "frac_hbm_on_trace_time", "frac_valu",
+                         "read_overfetch", "traffic_bytes_per_launch",
+                         "fused_minimum_bytes_per_launch"))))
+        icp = c4.get("icp_2x1M") or {}
+        if icp:
+            sk = icp.get("search_kernel") or {}
+            line["configs4"]["icp_2x1M"] = _r(dict(
+                _pick(icp, ("ms_per_icp", "iterations", "ms_per_iteration",
+                            "error")),
+                search_kernel_us=sk.get("kernel_us_under_profiler"),
+                search_frac_hbm=sk.get("frac_hbm"),
+                search_frac_algorithmic=sk.get("frac_algorithmic")))
+    dr = sec.get("headline_dram_resident") or {}
+    if dr:
+        ro = dr.get("roofline") or {}
+        line["dram_resident"] = _r(dict(
+            _pick(dr, ("frames_per_s", "active_blocks", "voxel_state_bytes",
+                       "error")),
+            **_pick(ro, ("avg_kernel_ms", "kernel_us_trace_only", "frac",
+                         "frac_hbm", "frac_valu", "read_overfetch",
+                         "traffic_bytes_per_launch",
+                         "fused_minimum_bytes_per_launch"))))
+    cfg = dict(out["config"])
+    cfg["workload"] = cfg["workload"][:200]
+    line["config"] = _r({k: v for k, v in cfg.items() if v is not None})
+    line["roofline"] = _r({k: v for k, v in out["roofline"].items()
+                           if k not in ("traffic_source",)})
+    if "cpu_baseline" in out:
+        line["cpu_baseline"] = _r(out["cpu_baseline"])
+    if secondary and "error" in secondary:
+        line["secondary_error"] = secondary["error"]
+    return line
 
 
 if __name__ == "__main__":

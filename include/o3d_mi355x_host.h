@@ -397,6 +397,64 @@ int o3dmi_vbg_integrate_frames(o3dmi_vbg_t* g, int n_frames,
                                float depth_max, float trunc_voxel_multiplier,
                                int frames_per_launch, o3dmi_stream_t stream);
 
+/* ---- block-ownership sharding with a SLICED block touch (scheme
+ * A as specified: "every GPU runs DepthTouch on a 1/G pixel slice, all-gathers
+ * the candidate keys, keeps hash(key) mod G == rank"; the loop being sliced is
+ * DepthTouchCPU, VoxelBlockGridCPU.cpp:117-201).
+ *
+ * With o3dmi_vbg_set_block_ownership(rank, world > 1) AND a communicator on the
+ * calling thread (o3dmi_set_comm), o3dmi_vbg_integrate_frames takes this path
+ * by itself whenever depth and colour images share size and intrinsics:
+ * frames go in chunks of 16 launches; on a side stream rank r touches only its
+ * band of ray tiles, the candidate {block key, frame bits} records of all
+ * ranks are all-gathered (ONE collective per chunk, fixed-size segments) and
+ * the keys a rank owns are activated; on the caller's stream one launch per
+ * group integrates the owned blocks straight from the raw depth / colour
+ * images (no per-pixel prepare pass). Each rank's grid is bit-identical to
+ * what the replicated touch produces: the blocks it owns of the single-GPU
+ * grid. The functions below expose the two halves for callers with their own
+ * exchange, for tests and for bench.py --emulate-world. */
+
+/* Frames per chunk for a frames_per_launch setting (16 launches). */
+int o3dmi_vbg_slice_chunk_frames(int frames_per_launch);
+/* Wire format sizes: a rank's segment holds 16 x records_per_group 16-byte
+ * records + a 128-byte header. Default 1024 records per (rank, launch) and
+ * per-launch tables of 8192 slots; with a communicator both double by
+ * themselves when a chunk does not fit (every rank reads the same headers and
+ * takes the same decision), with caller-provided segments an overflow is
+ * O3DMI_ERR_CAPACITY. */
+int o3dmi_vbg_set_slice_capacity(o3dmi_vbg_t* g, int records_per_group,
+                                 int table_slots);
+int64_t o3dmi_vbg_slice_segment_bytes(const o3dmi_vbg_t* g);
+/* Rank slice_rank's band of the ray tiles of up to one chunk of frames ->
+ * its wire segment (device buffer of o3dmi_vbg_slice_segment_bytes bytes).
+ * The grid only lends its scratch tables; its map is not touched. */
+int o3dmi_vbg_touch_slice(o3dmi_vbg_t* g, int n_frames,
+                          const void* const* depth_devs, int depth_rows,
+                          int depth_cols, const double* depth_intrinsic,
+                          const double* extrinsics, float depth_scale,
+                          float depth_max, float trunc_voxel_multiplier,
+                          int frames_per_launch, int slice_rank,
+                          int slice_world, void* segment_out_dev,
+                          o3dmi_stream_t stream);
+/* o3dmi_vbg_integrate_frames through the sliced path. gathered_devs: for each
+ * chunk of the call a device buffer with the `world` wire segments of all
+ * ranks (rank-major; the own segment is recomputed and replaced), or NULL: the
+ * all-gather runs over the calling thread's communicator. */
+int o3dmi_vbg_integrate_frames_sliced(
+        o3dmi_vbg_t* g, int n_frames, const void* const* depth_devs,
+        int depth_rows, int depth_cols, const void* const* color_devs,
+        int color_rows, int color_cols, int input_dtype,
+        const double* depth_intrinsic, const double* color_intrinsic,
+        const double* extrinsics, float depth_scale, float depth_max,
+        float trunc_voxel_multiplier, int frames_per_launch,
+        const void* const* gathered_devs, o3dmi_stream_t stream);
+/* Chunks integrated through the sliced path, chunks applied a second time
+ * (Reserve of the block map, or grown segments), current sizes. */
+int o3dmi_vbg_sliced_stats(const o3dmi_vbg_t* g, int64_t* chunks,
+                           int64_t* reapplied, int* capacity,
+                           int* table_slots);
+
 /* Measurement hook for bench.py: while profiling is on, every stride-th
  * launch that carries integrate work (o3dmi_vbg_integrate_frame(s)) is
  * bracketed with HIP events on the stream it is launched on (stride 0 = none).
@@ -414,6 +472,24 @@ int o3dmi_vbg_profile_end(o3dmi_vbg_t* g, o3dmi_stream_t stream,
  * a group are applied to register-resident blocks -- once in, once out per
  * launch, however many frames the group has. */
 int64_t o3dmi_vbg_profile_distinct_blocks(const o3dmi_vbg_t* g);
+/* Diagnostics: which of the frame stream's exact short division forms are in
+ * use for the truncation distance voxel_size * trunc_voxel_multiplier on the
+ * current device -- 0 = IEEE divisions only (the on-device proof is still
+ * running, failed, or O3DMI_EXACT_DIV is set), 1 = sdf / trunc and 1 / (w + 1),
+ * 2 / 3 = also 1 / z with one / two Newton steps. The proof runs asynchronously
+ * (started by o3dmi_vbg_create for multiplier 8 and by the first integration
+ * with any other); launches take the IEEE forms until it has finished, the
+ * results are the same either way. wait != 0 blocks until it has. */
+int o3dmi_vbg_division_forms(float voxel_size, float trunc_voxel_multiplier,
+                             int wait);
+/* The same measurement per bracketed launch (any output may be null): HIP-event
+ * duration (ms), block-frames, distinct blocks, and the map size (blocks
+ * active) the launch's integrate role saw when it started. Returns the number
+ * of launches bracketed; at most `capacity` entries are written. */
+int64_t o3dmi_vbg_profile_launches(const o3dmi_vbg_t* g, int64_t capacity,
+                                   float* ms, int32_t* block_frames,
+                                   int32_t* distinct_blocks,
+                                   int32_t* map_size);
 
 /* RayCast(block_coords, intrinsic, extrinsic, width, height, attrs, ...)
  * (VoxelBlockGrid.cpp:328-402). Output pointers follow o3dmi_vbg_raycast;

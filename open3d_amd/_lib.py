@@ -224,6 +224,18 @@ PROTOTYPES.update({
     "o3dmi_vbg_integrate_frames": (
         _i32, [_vp, _i32, C.POINTER(_vp), _i32, _i32, C.POINTER(_vp), _i32,
                _i32, _i32, _dp, _dp, _dp, _f, _f, _f, _i32, _vp]),
+    "o3dmi_vbg_slice_chunk_frames": (_i32, [_i32]),
+    "o3dmi_vbg_set_slice_capacity": (_i32, [_vp, _i32, _i32]),
+    "o3dmi_vbg_slice_segment_bytes": (_i64, [_vp]),
+    "o3dmi_vbg_touch_slice": (
+        _i32, [_vp, _i32, C.POINTER(_vp), _i32, _i32, _dp, _dp, _f, _f, _f,
+               _i32, _i32, _i32, _vp, _vp]),
+    "o3dmi_vbg_integrate_frames_sliced": (
+        _i32, [_vp, _i32, C.POINTER(_vp), _i32, _i32, C.POINTER(_vp), _i32,
+               _i32, _i32, _dp, _dp, _dp, _f, _f, _f, _i32, C.POINTER(_vp),
+               _vp]),
+    "o3dmi_vbg_sliced_stats": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64),
+                                      C.POINTER(_i32), C.POINTER(_i32)]),
     "o3dmi_vbg_profile_begin": (_i32, [_vp, _i32, _i32]),
     "o3dmi_vbg_profile_end": (_i32, [_vp, _vp, C.POINTER(_d), C.POINTER(_i64),
                                      C.POINTER(_i64), C.POINTER(_i64)]),
@@ -285,6 +297,8 @@ PROTOTYPES.update({
         _i32, [_vp, _vp, _i64, _dp, _dp, _i32, _i32, _vp] + [_vp] * 10 +
         [_f, _f, _f, _f, _f, _i32, _vp]),
     "o3dmi_vbg_profile_distinct_blocks": (_i64, [_vp]),
+    "o3dmi_vbg_division_forms": (_i32, [_f, _f, _i32]),
+    "o3dmi_vbg_profile_launches": (_i64, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "o3dmi_rccl_available": (_i32, []),
     "o3dmi_rccl_unique_id": (_i32, [_vp]),
     "o3dmi_comm_create_rccl": (_i32, [_vp, _i32, _i32, C.POINTER(_vp)]),

@@ -170,6 +170,23 @@ __global__ void ReinsertKernel(HashView hv, const int* __restrict__ active,
     }
 }
 
+// RecoverOverflow (stream_path.h): slots whose insert found no buffer index
+// (marker -1) become tombstones; one thread settles the counters.
+__global__ void RecoverOverflowKernel(HashView hv, int64_t n_slots,
+                                      int* __restrict__ wanted) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+         i < n_slots; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long k = hv.slot_keys[i];
+        if (k != kEmptyKey && k != kTombKey && hv.slot_vals[i] == -1)
+            hv.slot_keys[i] = kTombKey;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *wanted = hv.counters[0];
+        if (hv.counters[0] > hv.capacity) hv.counters[0] = hv.capacity;
+        hv.counters[3] = 0;
+    }
+}
+
 template <typename T>
 int DevAlloc(T** p, int64_t n) {
     O3DMI_HIP_CHECK(hipMalloc((void**)p, (size_t)(n > 0 ? n : 1) * sizeof(T)));
@@ -293,11 +310,18 @@ int RebuildSlotsIfCrowded(o3dmi_hash* h, hipStream_t s) {
 // that waits for the counters anyway (Size, and through it the frame stream's
 // capacity policy and Reserve) also rebuilds a crowded table here.
 int CheckDeferred(o3dmi_hash* h, hipStream_t s, int* top_out) {
-    int host[3] = {0, 0, 0};
+    int host[4] = {0, 0, 0, 0};
     O3DMI_HIP_CHECK(hipMemcpyAsync(host, h->view.counters, sizeof(host),
                                    hipMemcpyDeviceToHost, s));
     O3DMI_HIP_CHECK(hipStreamSynchronize(s));
     if (top_out) *top_out = host[0];
+    if (host[3] != 0) {
+        // a frame-stream group ran out of buffer indices and the stream has
+        // not been recovered yet (RecoverOverflow): the slot table holds keys
+        // without a block; nothing may size or export the map before
+        SetLastError("hash map: frame-stream overflow not recovered");
+        return O3DMI_ERR_INTERNAL;
+    }
     if (host[1] & kErrKeyRange) {
         SetLastError("block coordinate outside +-2^20");
         return O3DMI_ERR_KEY_RANGE;
@@ -318,6 +342,21 @@ int CheckDeferred(o3dmi_hash* h, hipStream_t s, int* top_out) {
 
 
 }  // namespace
+
+int RecoverOverflow(o3dmi_hash* h, hipStream_t s, int64_t* wanted) {
+    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    hipLaunchKernelGGL(RecoverOverflowKernel,
+                       dim3(GridFor(h->n_slots, kBlock)), dim3(kBlock), 0, s,
+                       h->view, h->n_slots, h->scratch_count);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    int w = 0;
+    O3DMI_HIP_CHECK(hipMemcpyAsync(&w, h->scratch_count, sizeof(int),
+                                   hipMemcpyDeviceToHost, s));
+    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    if (wanted) *wanted = w;
+    return O3DMI_OK;
+}
+
 }  // namespace o3dmi
 
 using namespace o3dmi;

@@ -194,7 +194,10 @@ struct HashView {
     int* heap;                      // [capacity] free buffer indices
     int* counters;                  // [0]=heap_top, [1]=error flags,
                                     // [2]=slots ever taken from the empty
-                                    //     state (live + tombstones)
+                                    //     state (live + tombstones),
+                                    // [3]=stamp of the first frame-stream
+                                    //     group that ran out of buffer
+                                    //     indices (0 = none; InsertKey)
     int* key_buffer;                // [capacity,3]
     unsigned mask;                  // n_slots - 1
     int capacity;

@@ -154,7 +154,12 @@ extern "C" int o3dmi_rgbd_odometry_multiscale(
     slab.size = total + sums_bytes + 256;
     // `drained`: the host has seen the mailbox of the call's last launch and
     // issued nothing since -- the stream is idle, and hipStreamSynchronize
-    // costs 16 us even then (registration.cpp SyncOnExit).
+    // costs 16 us even then (registration.cpp SyncOnExit). Only valid when
+    // that last launch is a single-workgroup tail (the final-sum / posting
+    // launches of the host-driven loop): a mailbox word of the persistent
+    // multi-workgroup Gauss-Newton kernel does NOT mean the kernel has ended
+    // (other workgroups may still poll gn_scratch), so that path keeps the
+    // synchronisation.
     struct SlabFree {
         hipStream_t s;
         void* p;
@@ -347,7 +352,6 @@ extern "C" int o3dmi_rgbd_odometry_multiscale(
                 fitness = mb->data[17];
                 iterations = (int)mb->data[18];
                 done = true;
-                slab_free.drained = true;
             } else if (status == 1) {
                 SetLastError("Invalid inlier_count value, must be > 0.");
                 return O3DMI_ERR_NO_INLIERS;

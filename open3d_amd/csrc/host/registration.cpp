@@ -236,6 +236,18 @@ struct ChainCounts {
     int levels = 0;
     int chain = 0;
     std::vector<void*> scratch;  // pooled scratch of the level launches
+    // The counts, the error word and the VoxelDownSample workspaces of a
+    // chain are cleaned by the chain's own last launches (the posting launch,
+    // the levels' reduce launches). `open`: a chain was started on this
+    // thread / device / chain slot and its counts were never waited for -- an
+    // error return somewhere between its first launch and Wait. The next
+    // chain then starts from re-zeroed counts and fresh workspaces instead of
+    // inheriting a stale error bit or stale table entries.
+    static bool& Open(int d, int chain_id) {
+        static thread_local bool open[kMaxDevices][2] = {};
+        return open[d][chain_id];
+    }
+    int device = -1;
     int Init(int n_levels, int chain_id, hipStream_t cs) {
         static thread_local int* bufs[kMaxDevices][2] = {};
         O3DMI_REQUIRE(n_levels >= 1 && n_levels <= kMaxScales,
@@ -244,15 +256,23 @@ struct ChainCounts {
         O3DMI_REQUIRE(d >= 0 && (chain_id == 0 || chain_id == 1),
                       "bad device / chain");
         int*& b = bufs[d][chain_id];
-        if (!b) {
+        const bool fresh = !b;
+        if (!b)
             O3DMI_HIP_CHECK(hipMalloc((void**)&b,
                                       sizeof(int) * (kMaxScales + 2)));
+        if (fresh || Open(d, chain_id)) {
+            if (!fresh) {
+                O3DMI_HIP_CHECK(hipDeviceSynchronize());
+                VdsChainInvalidate(chain_id);
+            }
             O3DMI_HIP_CHECK(hipMemsetAsync(b, 0,
                                            sizeof(int) * (kMaxScales + 2), cs));
         }
+        Open(d, chain_id) = true;
         dev = b;
         levels = n_levels;
         chain = chain_id;
+        device = d;
         return O3DMI_OK;
     }
     int* Count(int level) { return dev + level; }
@@ -292,6 +312,9 @@ struct ChainCounts {
                          hipGetErrorString(e));
             return O3DMI_ERR_HIP;
         }
+        // the posting launch has run: counts and error word are zero again,
+        // every level's last launch has cleaned its workspace
+        if (device >= 0) Open(device, chain) = false;
         for (int k = 0; k <= levels; ++k) out[(size_t)k] = (int)mb->data[k];
         if (out[(size_t)levels] & kErrKeyRange) {
             SetLastError("VoxelDownSample: voxel coordinate outside +-2^20");

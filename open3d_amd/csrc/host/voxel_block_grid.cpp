@@ -21,6 +21,8 @@
 #include "../common.h"
 #include "../npz.h"
 #include "../stream_path.h"
+#include "../sliced_path.h"
+#include "../touch_device.h"
 #include "../collectives.h"
 #include "o3d_mi355x_host.h"
 
@@ -59,7 +61,18 @@ struct o3dmi_vbg {
     int* front_tickets = nullptr;               // device int[2][16]
     int64_t lists_capacity = 0;
     int* ring_counters = nullptr;        // device int[4]
-    volatile int* stream_status = nullptr;  // host-mapped int[4]
+    volatile int* stream_status = nullptr;  // host-mapped int[8]: [0..3]
+                                         // published by the integrate roles,
+                                         // [4..7] by the groups' last touch
+                                         // workgroup (stream_path.h)
+    int touch_seen_stamp = 0;            // newest touch status taken in
+    int touch_seen_size = 0;
+    int stream_overflow = 0;             // stamp of the first group that ran
+                                         // out of buffer indices (sticky until
+                                         // StreamIntegrate has recovered)
+    // What recent groups really added to the map (for the run-ahead policy).
+    int recent_new[4] = {0, 0, 0, 0};
+    int recent_n = 0;
     int64_t stream_seq = 0;              // groups issued on the fast path
     int known_size = 0;                  // map size after frame `known_stamp`
     int known_stamp = 0;
@@ -82,8 +95,38 @@ struct o3dmi_vbg {
     int prof_frames = 0, prof_max = 0, prof_stride = 1, prof_seen = 0;
     int64_t prof_launch_frames = 0;  // frames carried by the bracketed launches
     int32_t* prof_counts = nullptr;  // device: [prof_max] block-frames, then
-                                     // [prof_max] distinct blocks, per launch
+                                     // [prof_max] distinct blocks, then
+                                     // [prof_max] map size, per launch
     int64_t prof_distinct_blocks = 0;  // of the last profile_end
+    // per bracketed launch of the last profile_end (o3dmi_vbg_profile_launches)
+    std::vector<float> prof_launch_ms;
+    std::vector<int32_t> prof_launch_counts;  // 3 x launches, as prof_counts
+
+    // Sliced block touch (sliced_path.h): block-ownership sharding with the
+    // touch split over the ranks. Buffers are per grid; the side stream runs
+    // chunk c + 1's touch / exchange / apply while the caller's stream runs
+    // chunk c's integrate launches.
+    struct Sliced {
+        hipStream_t side = nullptr;
+        hipEvent_t ev_side[2] = {nullptr, nullptr};  // chunk set ready
+        hipEvent_t ev_main[2] = {nullptr, nullptr};  // chunk set consumed
+        hipEvent_t ev_enter = nullptr;
+        GroupTables send_tables = {}, recv_tables = {};
+        int table_slots = 0;
+        int capacity = 0;  // records per (rank, group) of a wire segment
+        int world = 0;
+        void* send_seg[2] = {nullptr, nullptr};
+        void* gathered[2] = {nullptr, nullptr};
+        ReadyEntry* ready[2] = {nullptr, nullptr};  // [kChunkGroups][ready_cap]
+        int* ready_count[2] = {nullptr, nullptr};   // device int[kChunkGroups]
+        int ready_cap = 0;
+        SliceFrame* frames_dev = nullptr;
+        int64_t frames_cap = 0;
+        std::vector<SliceFrame> frames_host;
+        int64_t chunks_done = 0;  // statistics (o3dmi_vbg_sliced_stats)
+        int64_t reapplied = 0;
+    } sliced;
+    int sliced_slots_wanted = 8192;
 
     int AttrIndex(const char* name) const {
         for (size_t i = 0; i < attr_names.size(); ++i)
@@ -324,6 +367,8 @@ __global__ void ZeroRowsKernel(uint8_t* __restrict__ rows,
 
 }  // namespace
 
+static void FreeSliced(o3dmi_vbg* g);
+
 extern "C" {
 
 int o3dmi_vbg_create(int n_attrs, const char* const* attr_names,
@@ -368,8 +413,19 @@ int o3dmi_vbg_create(int n_attrs, const char* const* attr_names,
         o3dmi_vbg_destroy(g);
         return st;
     }
+    // The frame stream's short division forms are proven per truncation
+    // distance on the device, asynchronously (vbg_stream.hip): start the proof
+    // for the API's default multiplier now, so that it is over before frames
+    // arrive.
+    if (block_resolution % 4 == 0)
+        (void)PrefetchFastDivision(voxel_size * 8.0f, false);
     *out = g;
     return O3DMI_OK;
+}
+
+int o3dmi_vbg_division_forms(float voxel_size, float trunc_voxel_multiplier,
+                             int wait) {
+    return PrefetchFastDivision(voxel_size * trunc_voxel_multiplier, wait != 0);
 }
 
 // VoxelBlockGrid::To(device, copy) (VoxelBlockGrid.cpp, via
@@ -431,6 +487,7 @@ int o3dmi_vbg_destroy(o3dmi_vbg_t* g) {
     if (g->stream_status) (void)hipHostFree((void*)g->stream_status);
     for (hipEvent_t e : g->prof_events) (void)hipEventDestroy(e);
     (void)hipFree(g->prof_counts);
+    FreeSliced(g);
     delete g;
     return O3DMI_OK;
 }
@@ -671,10 +728,10 @@ static int EnsureStreamBuffers(o3dmi_vbg* g, int rows, int cols,
         O3DMI_HIP_CHECK(hipMalloc((void**)&g->ring_counters, sizeof(int) * 4));
         O3DMI_HIP_CHECK(hipMemset(g->ring_counters, 0, sizeof(int) * 4));
         int* st = nullptr;
-        O3DMI_HIP_CHECK(hipHostMalloc((void**)&st, sizeof(int) * 4,
+        O3DMI_HIP_CHECK(hipHostMalloc((void**)&st, sizeof(int) * 8,
                                       hipHostMallocMapped |
                                               hipHostMallocCoherent));
-        st[0] = st[1] = st[2] = st[3] = 0;
+        for (int i = 0; i < 8; ++i) st[i] = 0;
         g->stream_status = st;
     }
     return O3DMI_OK;
@@ -717,9 +774,36 @@ static int EnsurePrepTables(o3dmi_vbg* g, const double* dk, const double* ck,
     return O3DMI_OK;
 }
 
-// Reads the status word the integrate roles publish ({map size, error flags,
-// group block count, stamp}); never blocks.
-static int PollStreamStatus(o3dmi_vbg* g) {
+// Reads the status words the device publishes -- by every integrate role as
+// its first action ({map size, error flags, group block count, stamp}) and by
+// the last touch workgroup of every group ({map size after the group's touch,
+// overflow stamp, group block count, stamp}); never blocks. `overflow` (may be
+// null) receives the stamp of the first group that ran out of buffer indices,
+// 0 when none did.
+static int PollStreamStatus(o3dmi_vbg* g, int* overflow = nullptr) {
+    const volatile int* ts = g->stream_status + 4;
+    const int tstamp = __atomic_load_n((const int*)&ts[3], __ATOMIC_ACQUIRE);
+    if (tstamp - g->touch_seen_stamp > 0) {
+        const int size = ts[0], ovf = ts[1];
+        const int tstamp2 =
+                __atomic_load_n((const int*)&ts[3], __ATOMIC_ACQUIRE);
+        if (tstamp2 == tstamp) {
+            // what the groups since the last word seen added, per group
+            const int groups = tstamp - g->touch_seen_stamp;
+            if (size >= g->touch_seen_size && g->known_valid) {
+                const int per = (size - g->touch_seen_size + groups - 1) / groups;
+                g->recent_new[g->recent_n++ & 3] = per;
+            }
+            g->touch_seen_stamp = tstamp;
+            g->touch_seen_size = size;
+            if (tstamp - g->known_stamp > 0) {
+                g->known_size = size;
+                g->known_stamp = tstamp;
+            }
+            if (ovf != 0 && g->stream_overflow == 0) g->stream_overflow = ovf;
+        }
+    }
+    if (overflow) *overflow = g->stream_overflow;
     const int stamp = __atomic_load_n((const int*)&g->stream_status[3],
                                       __ATOMIC_ACQUIRE);
     if (stamp != g->known_stamp && stamp != 0) {
@@ -730,9 +814,14 @@ static int PollStreamStatus(o3dmi_vbg* g) {
         const int stamp2 = __atomic_load_n((const int*)&g->stream_status[3],
                                            __ATOMIC_ACQUIRE);
         if (stamp2 == stamp) {
-            g->known_size = size;
+            if (stamp - g->known_stamp > 0) {
+                g->known_size = size < o3dmi_hash_capacity(g->block_hashmap)
+                                        ? size
+                                        : (int)o3dmi_hash_capacity(
+                                                  g->block_hashmap);
+                g->known_stamp = stamp;
+            }
             g->last_count = count;
-            g->known_stamp = stamp;
         }
         if (err & kErrKeyRange) {
             SetLastError("block coordinate outside +-2^20");
@@ -752,20 +841,91 @@ static int PollStreamStatus(o3dmi_vbg* g) {
     return O3DMI_OK;
 }
 
-// HashMap::Activate's capacity policy (HashMap.cpp:166-176) for the fast
-// path, blocking form: Reserve when Size() + (most blocks the groups in flight
-// plus the next one can still create) exceeds the capacity. Only called while
-// the pipeline is drained (every issued front role has its integrate role
-// launched), so waiting for the newest status word cannot dead-lock.
-static int StreamEnsureCapacity(o3dmi_vbg* g, int64_t group_new,
-                                hipStream_t s) {
-    int st = PollStreamStatus(g);
-    if (st) return st;
+// ---- run-ahead capacity policy ------------------------------------------------
+// HashMap::Activate reserves when Size() + M would pass the capacity
+// (HashMap.cpp:166-176), M being the frame's block count, which the reference
+// has on the host because it synchronises every frame. The frame stream
+// issues groups ahead of the GPU, so neither Size() nor M is known when a
+// group is issued. Two bounds:
+//   strict   known size + (groups not yet reported + 1) x the frustum bound of
+//            a group (FrustumBlockBound per frame): cannot overflow, needs no
+//            confirmation. A map with a few hundred thousand blocks of
+//            head-room is issued this way, as in rounds 1-3.
+//   estimate the same with what recent groups REALLY added (twice the largest
+//            of the last four + a margin) in place of the frustum bound. A
+//            group issued on the estimate may run out of buffer indices: the
+//            device then drops that group and every later one as a whole
+//            (InsertKey / the last touch workgroup, vbg_stream.hip), reports
+//            the stamp, and StreamIntegrate reserves and replays from the
+//            dropped group's first frame. Such groups are CONFIRMED before the
+//            call that issued them returns (their frames are only known to be
+//            alive until then).
+// A Reserve therefore happens when the map really is too small (or, drained,
+// when even the estimate does not fit), not because of the frustum bound.
+static int64_t EstimatedGroupNew(const o3dmi_vbg* g, int64_t strict) {
+    if (g->recent_n == 0) return strict;  // nothing observed yet
+    int m = 0;
+    for (int i = 0; i < 4 && i < g->recent_n; ++i)
+        if (g->recent_new[i] > m) m = g->recent_new[i];
+    const int64_t est = 2 * (int64_t)m + 64;
+    return est < strict ? est : strict;
+}
+
+enum class Issue { kStrict, kEstimate, kNo };
+
+// The map size is exact again (stream drained, size read from the map).
+static void SetExactSize(o3dmi_vbg* g, int64_t size) {
+    g->known_size = (int)size;
+    g->known_stamp = g->frame_stamp;
+    g->touch_seen_stamp = g->frame_stamp;
+    g->touch_seen_size = (int)size;
+    g->known_valid = true;
+}
+
+// Non-blocking: may one more group be issued behind those in flight?
+static Issue StreamMayIssue(o3dmi_vbg* g, int64_t strict_new, bool allow_est,
+                            bool may_spin = true) {
+    if (!g->known_valid) return Issue::kNo;
     const int64_t capacity = o3dmi_hash_capacity(g->block_hashmap);
-    auto bound = [&]() {
+    // The host runs ahead of the GPU; when a bound fails only because too
+    // many issued groups have not reported their map size yet, give the
+    // status words a moment to catch up instead of draining the pipeline.
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        if (PollStreamStatus(g) != O3DMI_OK) return Issue::kNo;  // surfaced later
+        if (g->stream_overflow != 0) return Issue::kNo;  // recovery first
         const int64_t unknown = (int64_t)g->frame_stamp - g->known_stamp;
-        return (int64_t)g->known_size + (unknown + 1) * group_new;
-    };
+        if ((int64_t)g->known_size + (unknown + 1) * strict_new <= capacity)
+            return Issue::kStrict;
+        const int64_t est = EstimatedGroupNew(g, strict_new);
+        if (allow_est && est < strict_new &&
+            (int64_t)g->known_size + (unknown + 1) * est <= capacity)
+            return Issue::kEstimate;
+        // Even a fully reported pipeline would not fit: the blocking path
+        // decides (drained go-ahead or Reserve).
+        if ((int64_t)g->known_size + 2 * (allow_est ? est : strict_new) >
+            capacity)
+            return Issue::kNo;
+        if (unknown <= 1 || !may_spin) return Issue::kNo;
+        if (std::chrono::steady_clock::now() - t0 >
+            std::chrono::microseconds(500))
+            return Issue::kNo;
+    }
+}
+
+// Blocking form, for a group issued with nothing overlapping it: waits until
+// every issued group has reported (they complete without the host), then
+// applies the policy to the exact size. With `allow_est` a drained map that is
+// not full issues the group whatever the bounds say -- the device reports an
+// overflow and the caller recovers -- unless even the estimate says it cannot
+// fit, in which case the map is reserved first (max(need, 2 x capacity), the
+// reference's growth rule).
+static int StreamEnsureCapacity(o3dmi_vbg* g, int64_t strict_new,
+                                bool allow_est, hipStream_t s, Issue* how,
+                                int* overflow) {
+    *how = Issue::kStrict;
+    int st = PollStreamStatus(g, overflow);
+    if (st || *overflow) return st;
     if (!g->known_valid) {
         // Something else activated blocks since the last fast-path group (or
         // this is the first one): take the exact size from the map itself.
@@ -773,49 +933,37 @@ static int StreamEnsureCapacity(o3dmi_vbg* g, int64_t group_new,
         int64_t size = 0;
         st = o3dmi_hash_size(g->block_hashmap, (o3dmi_stream_t)s, &size);
         if (st) return st;
-        g->known_size = (int)size;
-        g->known_stamp = g->frame_stamp;
-        g->known_valid = true;
+        SetExactSize(g, size);
+        g->recent_n = 0;
     }
-    if (bound() <= capacity) return O3DMI_OK;
+    const Issue quick = StreamMayIssue(g, strict_new, allow_est, false);
+    if (quick != Issue::kNo) {
+        *how = quick;
+        return O3DMI_OK;
+    }
     O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    // a group issued on the estimate may have overflowed the map meanwhile:
+    // the caller recovers (the map must not be sized or reserved before)
+    if ((st = PollStreamStatus(g, overflow)) || *overflow) return st;
     int64_t size = 0;
     st = o3dmi_hash_size(g->block_hashmap, (o3dmi_stream_t)s, &size);
     if (st) return st;
-    g->known_size = (int)size;
-    g->known_stamp = g->frame_stamp;
-    if (size + group_new > capacity) {
-        const int64_t need = size + group_new;
+    SetExactSize(g, size);
+    const int64_t capacity = o3dmi_hash_capacity(g->block_hashmap);
+    const int64_t need_new =
+            allow_est ? (g->recent_n ? EstimatedGroupNew(g, strict_new) : 1)
+                      : strict_new;
+    if (size + need_new > capacity) {
+        const int64_t need = size + need_new;
         const int64_t target = need > capacity * 2 ? need : capacity * 2;
         st = o3dmi_hash_reserve(g->block_hashmap, target, (o3dmi_stream_t)s);
         if (st) return st;
         O3DMI_HIP_CHECK(hipStreamSynchronize(s));
     }
+    *how = size + strict_new <= o3dmi_hash_capacity(g->block_hashmap)
+                   ? Issue::kStrict
+                   : Issue::kEstimate;
     return O3DMI_OK;
-}
-
-// Non-blocking form: true when the map provably has room for one more group
-// on top of every group whose front roles are already issued.
-static bool StreamCapacityBoundOK(o3dmi_vbg* g, int64_t group_new) {
-    if (!g->known_valid) return false;
-    const int64_t capacity = o3dmi_hash_capacity(g->block_hashmap);
-    // The host runs ahead of the GPU; when the bound fails only because too
-    // many issued groups have not reported their map size yet, give the
-    // status word a moment to catch up (each integrate role publishes it as
-    // its first action) instead of draining the pipeline.
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-        if (PollStreamStatus(g) != O3DMI_OK) return false;  // surfaced later
-        const int64_t unknown = (int64_t)g->frame_stamp - g->known_stamp;
-        if ((int64_t)g->known_size + (unknown + 1) * group_new <= capacity)
-            return true;
-        // Even a fully reported pipeline would not fit: a Reserve is due.
-        if ((int64_t)g->known_size + 2 * group_new > capacity) return false;
-        if (unknown <= 1) return false;
-        if (std::chrono::steady_clock::now() - t0 >
-            std::chrono::microseconds(500))
-            return false;
-    }
 }
 
 // Per-frame inputs of the fast path.
@@ -886,6 +1034,7 @@ static StreamGroup MakeGroup(o3dmi_vbg* g, const StreamCommon& c,
         a.count = g->ring_counters + (grp.seq & 3);
         a.ready = g->ready[par];
         a.tickets = g->front_tickets + 16 * par;
+        a.touch_status = (int*)g->stream_status + 4;
     }
     g->stream_seq += 1;
     g->size_bound = o3dmi_hash_capacity(g->block_hashmap);  // generic path: re-read
@@ -927,6 +1076,11 @@ static void MakeIntegArgs(o3dmi_vbg* g, const StreamCommon& c,
     ia->prof_count = prof ? g->prof_counts + g->prof_max + g->prof_frames
                           : nullptr;
     ia->prof_frame_blocks = prof ? g->prof_counts + g->prof_frames : nullptr;
+    ia->prof_map_size =
+            prof ? g->prof_counts + 2 * g->prof_max + g->prof_frames : nullptr;
+    ia->raw = false;
+    ia->depth_scale = c.depth_scale;
+    ia->depth_div_short = false;
 }
 
 static bool StreamPathApplies(const o3dmi_vbg* g, int input_dtype) {
@@ -935,9 +1089,28 @@ static bool StreamPathApplies(const o3dmi_vbg* g, int input_dtype) {
            ti >= 0 && wi >= 0 && g->attr_dtypes[(size_t)ti] == O3DMI_F32;
 }
 
+// Waits (spinning on the host-mapped words; no runtime call) until the touch
+// of group `stamp` has reported or `overflow` is set.
+static int WaitTouchReported(o3dmi_vbg* g, int stamp, hipStream_t s,
+                             int* overflow) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        int st = PollStreamStatus(g, overflow);
+        if (st) return st;
+        if (*overflow != 0 || g->touch_seen_stamp - stamp >= 0) return O3DMI_OK;
+        if (std::chrono::steady_clock::now() - t0 >
+            std::chrono::milliseconds(20)) {
+            // not a spin any more: let the runtime wait, then read once more
+            O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+            if ((st = PollStreamStatus(g, overflow))) return st;
+            return O3DMI_OK;
+        }
+    }
+}
+
 // Integrates frames[0..n) strictly in order on stream `s`, `group` frames per
 // integrate launch. The front roles of group k+1 share the launch of group
-// k's integrate role whenever the capacity bound allows it without waiting.
+// k's integrate role whenever the capacity policy allows it without waiting.
 static int StreamIntegrate(o3dmi_vbg* g, const StreamCommon& c0,
                            const StreamFrame* frames, int n, int group,
                            hipStream_t s) {
@@ -969,53 +1142,477 @@ static int StreamIntegrate(o3dmi_vbg* g, const StreamCommon& c0,
                                       c.depth_scale, s))) {
         return st;
     }
+    // O3DMI_STRICT_CAPACITY=1 (A / B): rounds 1-3's policy, the frustum bound
+    // only. Groups on the estimate need more than one frame per call to pay
+    // (the confirmation is a wait).
+    static const bool strict_only =
+            std::getenv("O3DMI_STRICT_CAPACITY") != nullptr;
+    const bool allow_est = !strict_only && n > 1;
 
+    // Groups issued on the estimate and not yet confirmed: {stamp, first
+    // frame}. All of them belong to this call.
+    struct Pending {
+        int stamp, f0;
+    };
+    std::vector<Pending> pending;
     bool issued = false;  // front roles of `cur` already in flight
     StreamGroup cur;
     FrameFrontArgs fa[kMaxGroup];
     int f = 0;
-    while (f < n) {
-        if (!issued) {
-            if ((st = StreamEnsureCapacity(g, group_new, s))) return st;
-            const int m = n - f < group ? n - f : group;
-            cur = MakeGroup(g, c, frames + f, m, fa);
-            if ((st = LaunchFrameStep(g->block_hashmap, fa, m, nullptr, s)))
+    for (;;) {
+        int overflow = 0;
+        while (f < n && overflow == 0) {
+            if (!issued) {
+                Issue how;
+                if ((st = StreamEnsureCapacity(g, group_new, allow_est, s,
+                                               &how, &overflow)))
+                    return st;
+                if (overflow != 0) break;
+                const int m = n - f < group ? n - f : group;
+                cur = MakeGroup(g, c, frames + f, m, fa);
+                if (how == Issue::kEstimate)
+                    pending.push_back({cur.stamp, f});
+                if ((st = LaunchFrameStep(g->block_hashmap, fa, m, nullptr, s)))
+                    return st;
+            }
+            g->last_path = 1;
+            g->last_seq = cur.seq;
+            const int next_f = f + cur.n;
+            const bool prof = g->profiling && g->prof_frames < g->prof_max &&
+                              g->prof_stride > 0 &&
+                              (g->prof_seen++ % g->prof_stride) == 0;
+            hipEvent_t* pe = prof ? &g->prof_events[(size_t)g->prof_frames * 2]
+                                  : nullptr;
+            IntegrateStreamArgs ia;
+            MakeIntegArgs(g, c, cur, prof, &ia);
+            StreamGroup nxt;
+            // O3DMI_NO_FUSE=1 (diagnostics): front roles in their own launches
+            // so that a kernel trace shows the two roles separately.
+            static const bool no_fuse = std::getenv("O3DMI_NO_FUSE") != nullptr;
+            Issue how = Issue::kNo;
+            if (!no_fuse && next_f < n)
+                how = StreamMayIssue(g, group_new, allow_est);
+            const bool fuse = how != Issue::kNo;
+            int m = 0;
+            if (fuse) {
+                m = n - next_f < group ? n - next_f : group;
+                nxt = MakeGroup(g, c, frames + next_f, m, fa);
+                if (how == Issue::kEstimate)
+                    pending.push_back({nxt.stamp, next_f});
+            }
+            if (pe) O3DMI_HIP_CHECK(hipEventRecord(pe[0], s));
+            if ((st = LaunchFrameStep(g->block_hashmap, fuse ? fa : nullptr, m,
+                                      &ia, s)))
                 return st;
+            if (pe) {
+                O3DMI_HIP_CHECK(hipEventRecord(pe[1], s));
+                g->prof_launch_frames += cur.n;
+                g->prof_frames += 1;
+            }
+            issued = fuse;
+            if (fuse) cur = nxt;
+            f = next_f;
+            // confirmations that have arrived (never waits)
+            if (!pending.empty()) {
+                if ((st = PollStreamStatus(g, &overflow))) return st;
+                while (!pending.empty() && overflow == 0 &&
+                       g->touch_seen_stamp - pending.front().stamp >= 0)
+                    pending.erase(pending.begin());
+            }
         }
-        g->last_path = 1;
-        g->last_seq = cur.seq;
-        const int next_f = f + cur.n;
-        const bool prof = g->profiling && g->prof_frames < g->prof_max &&
-                          g->prof_stride > 0 &&
-                          (g->prof_seen++ % g->prof_stride) == 0;
-        hipEvent_t* pe = prof ? &g->prof_events[(size_t)g->prof_frames * 2]
-                              : nullptr;
-        IntegrateStreamArgs ia;
-        MakeIntegArgs(g, c, cur, prof, &ia);
-        StreamGroup nxt;
-        // O3DMI_NO_FUSE=1 (diagnostics): front roles in their own launches so
-        // that a kernel trace shows the two roles separately.
-        static const bool no_fuse = std::getenv("O3DMI_NO_FUSE") != nullptr;
-        const bool fuse = !no_fuse && next_f < n &&
-                          StreamCapacityBoundOK(g, group_new);
-        int m = 0;
-        if (fuse) {
-            m = n - next_f < group ? n - next_f : group;
-            nxt = MakeGroup(g, c, frames + next_f, m, fa);
+        // Every group issued on the estimate is confirmed before the call
+        // returns: its touch reports from inside the launch BEFORE the one
+        // that integrates it, so this wait ends while that launch is still
+        // queued or running -- the GPU does not go idle over it.
+        if (overflow == 0 && !pending.empty())
+            if ((st = WaitTouchReported(g, pending.back().stamp, s, &overflow)))
+                return st;
+        if (overflow == 0) break;
+        // A group ran out of buffer indices: it and every later group were
+        // dropped on the device. Drain, make the map consistent, reserve,
+        // replay from the dropped group's first frame.
+        int replay_from = -1;
+        for (const Pending& pg : pending)
+            if (pg.stamp == overflow) replay_from = pg.f0;
+        if (replay_from < 0) {
+            SetLastError("frame stream: overflow reported for a group this "
+                         "call did not issue on an estimate");
+            return O3DMI_ERR_INTERNAL;
         }
-        if (pe) O3DMI_HIP_CHECK(hipEventRecord(pe[0], s));
-        if ((st = LaunchFrameStep(g->block_hashmap, fuse ? fa : nullptr, m,
-                                  &ia, s)))
+        int64_t wanted = 0;
+        if ((st = RecoverOverflow(g->block_hashmap, s, &wanted))) return st;
+        O3DMI_HIP_CHECK(hipMemsetAsync(g->ring_counters, 0, sizeof(int) * 4, s));
+        O3DMI_HIP_CHECK(hipMemsetAsync(g->front_tickets, 0, sizeof(int) * 32, s));
+        const int64_t capacity = o3dmi_hash_capacity(g->block_hashmap);
+        const int64_t target = wanted > capacity * 2 ? wanted : capacity * 2;
+        if ((st = o3dmi_hash_reserve(g->block_hashmap, target,
+                                     (o3dmi_stream_t)s)))
             return st;
-        if (pe) {
-            O3DMI_HIP_CHECK(hipEventRecord(pe[1], s));
-            g->prof_launch_frames += cur.n;
-            g->prof_frames += 1;
-        }
-        issued = fuse;
-        if (fuse) cur = nxt;
-        f = next_f;
+        O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+        int64_t size = 0;
+        if ((st = o3dmi_hash_size(g->block_hashmap, (o3dmi_stream_t)s, &size)))
+            return st;
+        SetExactSize(g, size);
+        g->stream_overflow = 0;
+        pending.clear();
+        issued = false;
+        f = replay_from;
     }
+    return O3DMI_OK;
+}
+
+// ---- sliced block touch (block-ownership sharding, sliced_path.h) -----------
+
+static void FreeSliced(o3dmi_vbg* g) {
+    o3dmi_vbg::Sliced& z = g->sliced;
+    if (z.side) (void)hipStreamDestroy(z.side);
+    for (int i = 0; i < 2; ++i) {
+        if (z.ev_side[i]) (void)hipEventDestroy(z.ev_side[i]);
+        if (z.ev_main[i]) (void)hipEventDestroy(z.ev_main[i]);
+        (void)hipFree(z.send_seg[i]);
+        (void)hipFree(z.gathered[i]);
+        (void)hipFree(z.ready[i]);
+        (void)hipFree(z.ready_count[i]);
+    }
+    if (z.ev_enter) (void)hipEventDestroy(z.ev_enter);
+    if (z.table_slots) {
+        FreeGroupTables(&z.send_tables);
+        FreeGroupTables(&z.recv_tables);
+    }
+    (void)hipFree(z.frames_dev);
+    z = o3dmi_vbg::Sliced();
+}
+
+// Buffers for `world` ranks, `capacity` records per (rank, group) on the wire
+// and per-group tables of `slots` slots. Growing frees and re-creates
+// everything (the streams are drained first).
+static int EnsureSliced(o3dmi_vbg* g, int world, int capacity, int slots,
+                        hipStream_t s) {
+    o3dmi_vbg::Sliced& z = g->sliced;
+    if (z.side && z.world >= world && z.capacity >= capacity &&
+        z.table_slots >= slots)
+        return O3DMI_OK;
+    if (z.side) {
+        O3DMI_HIP_CHECK(hipStreamSynchronize(z.side));
+        O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    if (world < z.world) world = z.world;
+    if (capacity < z.capacity) capacity = z.capacity;
+    if (slots < z.table_slots) slots = z.table_slots;
+    SliceFrame* keep_frames = z.frames_dev;
+    const int64_t keep_cap = z.frames_cap;
+    z.frames_dev = nullptr;
+    FreeSliced(g);
+    z.frames_dev = keep_frames;
+    z.frames_cap = keep_cap;
+    O3DMI_HIP_CHECK(hipStreamCreateWithFlags(&z.side, hipStreamNonBlocking));
+    const int64_t seg = SliceSegmentBytes(capacity);
+    for (int i = 0; i < 2; ++i) {
+        O3DMI_HIP_CHECK(hipEventCreateWithFlags(&z.ev_side[i],
+                                                hipEventDisableTiming));
+        O3DMI_HIP_CHECK(hipEventCreateWithFlags(&z.ev_main[i],
+                                                hipEventDisableTiming));
+        O3DMI_HIP_CHECK(hipMalloc(&z.send_seg[i], (size_t)seg));
+        O3DMI_HIP_CHECK(hipMalloc(&z.gathered[i], (size_t)seg * world));
+        O3DMI_HIP_CHECK(hipMalloc((void**)&z.ready[i],
+                                  sizeof(ReadyEntry) * (size_t)kChunkGroups *
+                                          (size_t)(slots / 2)));
+        O3DMI_HIP_CHECK(hipMalloc((void**)&z.ready_count[i],
+                                  sizeof(int) * kChunkGroups));
+        O3DMI_HIP_CHECK(hipMemsetAsync(z.ready_count[i], 0,
+                                       sizeof(int) * kChunkGroups, z.side));
+    }
+    O3DMI_HIP_CHECK(hipEventCreateWithFlags(&z.ev_enter, hipEventDisableTiming));
+    int st;
+    if ((st = AllocGroupTables(&z.send_tables, slots, false, z.side))) return st;
+    if ((st = AllocGroupTables(&z.recv_tables, slots, true, z.side))) return st;
+    z.table_slots = slots;
+    z.ready_cap = slots / 2;
+    z.capacity = capacity;
+    z.world = world;
+    O3DMI_HIP_CHECK(hipStreamSynchronize(z.side));
+    return O3DMI_OK;
+}
+
+// Per-frame table of the side-stream kernels (pose as TouchParams keeps it).
+static int UploadSliceFrames(o3dmi_vbg* g, const StreamCommon& c,
+                             const StreamFrame* frames, int n, hipStream_t side,
+                             TouchParams* shared) {
+    o3dmi_vbg::Sliced& z = g->sliced;
+    if (z.frames_cap < n) {
+        if (z.frames_dev) O3DMI_HIP_CHECK(hipStreamSynchronize(side));
+        (void)hipFree(z.frames_dev);
+        z.frames_dev = nullptr;
+        int64_t cap = 256;
+        while (cap < n) cap <<= 1;
+        O3DMI_HIP_CHECK(hipMalloc((void**)&z.frames_dev,
+                                  sizeof(SliceFrame) * (size_t)cap));
+        z.frames_cap = cap;
+    }
+    z.frames_host.resize((size_t)n);
+    for (int f = 0; f < n; ++f) {
+        const TouchParams tp = MakeTouchParams(
+                c.depth_intrinsic, frames[f].extrinsic, c.depth_rows,
+                c.depth_cols, 4, (int)g->block_resolution, g->voxel_size,
+                g->voxel_size * c.trunc, c.depth_scale, c.depth_max);
+        std::memcpy(z.frames_host[(size_t)f].pose, tp.cam.e,
+                    sizeof(z.frames_host[(size_t)f].pose));
+        z.frames_host[(size_t)f].depth = (const uint16_t*)frames[f].depth;
+        if (f == 0) *shared = tp;
+    }
+    // Synchronous: the table is free (every touch launch of the previous call
+    // was waited for through its chunk status before that call returned) and
+    // complete before the first launch below is issued.
+    (void)side;
+    O3DMI_HIP_CHECK(hipMemcpy(z.frames_dev, z.frames_host.data(),
+                              sizeof(SliceFrame) * (size_t)n,
+                              hipMemcpyHostToDevice));
+    return O3DMI_OK;
+}
+
+// What a chunk's apply reported (host-mapped words 4..7 of stream_status).
+struct ChunkStatus {
+    int map_size, overflow, blocks;
+};
+static int WaitChunkStatus(o3dmi_vbg* g, int stamp, hipStream_t side,
+                           ChunkStatus* out) {
+    const volatile int* ts = g->stream_status + 4;
+    const auto t0 = std::chrono::steady_clock::now();
+    bool synced = false;
+    for (;;) {
+        if (__atomic_load_n((const int*)&ts[3], __ATOMIC_ACQUIRE) == stamp) {
+            out->map_size = ts[0];
+            out->overflow = ts[1];
+            out->blocks = ts[2];
+            return O3DMI_OK;
+        }
+        if (synced) {
+            SetLastError("sliced touch: the chunk's apply never reported");
+            return O3DMI_ERR_INTERNAL;
+        }
+        if (std::chrono::steady_clock::now() - t0 >
+            std::chrono::milliseconds(50)) {
+            O3DMI_HIP_CHECK(hipStreamSynchronize(side));
+            synced = true;
+        }
+    }
+}
+
+// Can this call take the sliced path? Depth and colour images of one size and
+// intrinsics (the raw-image integrate role gathers both at the depth pixel),
+// uint16 depth, the wide 2-voxel form of the role.
+static bool SlicedPathApplies(o3dmi_vbg* g, const StreamCommon& c,
+                              const StreamFrame* frames, int n) {
+    if (n <= 0 || !g->prep_valid || !g->prep_identity) return false;
+    if ((c.depth_cols % 4) != 0) return false;
+    const char* e = std::getenv("O3DMI_STEP_VARIANT");
+    if (e && e[0] != '2') return false;
+    (void)frames;
+    return true;
+}
+
+// The frames of one call through the sliced path. `gathered_in`: per chunk the
+// `world` wire segments of all ranks (emulation / tests: the stand-in for the
+// all-gather; the own segment is replaced by the one computed here), or null:
+// all-gather over `comm`.
+static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
+                                 const StreamFrame* frames, int n, int group,
+                                 hipStream_t s, o3dmi_comm* comm,
+                                 const void* const* gathered_in) {
+    StreamCommon c = c0;
+    if (group < 1) group = 1;
+    if (group > kMaxGroup) group = kMaxGroup;
+    const int world = g->owner_world, rank = g->owner_rank;
+    O3DMI_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad ownership");
+    O3DMI_REQUIRE(!comm || (comm->world == world && comm->rank == rank),
+                  "sliced touch: the communicator's rank / world differ from "
+                  "the grid's block ownership");
+    c.frame_new = FrustumBlockBound(
+            c.depth_intrinsic, c.depth_rows, c.depth_cols, c.depth_max,
+            g->voxel_size * (float)g->block_resolution, 4);
+    O3DMI_REQUIRE(c.frame_new > 0, "depth image too small");
+    c.ti = g->AttrIndex("tsdf");
+    c.wi = g->AttrIndex("weight");
+    c.ci = g->AttrIndex("color");
+    c.with_color = c.ci >= 0 && (int64_t)c.color_rows * c.color_cols > 0 &&
+                   n > 0 && frames[0].color != nullptr;
+    int st = GridDtype(g, &c.grid_dtype);
+    if (st) return st;
+    if ((st = EnsureStreamBuffers(g, c.depth_rows, c.depth_cols,
+                                  c.frame_new * kMaxGroup)))
+        return st;
+    if ((st = EnsurePrepTables(g, c.depth_intrinsic, c.color_intrinsic,
+                               c.depth_rows, c.depth_cols, c.color_rows,
+                               c.color_cols, c.depth_scale, s)))
+        return st;
+    O3DMI_REQUIRE(SlicedPathApplies(g, c, frames, n),
+                  "sliced touch needs depth and colour images of one size and "
+                  "intrinsics (width % 4 == 0)");
+    o3dmi_vbg::Sliced& z = g->sliced;
+    // Sizes: a rank's band sees about 1 / world of a group's blocks plus the
+    // band's rim; start from a generous guess and double on overflow (every
+    // rank reads the same headers, so every rank doubles together).
+    int capacity = z.capacity ? z.capacity : 1024;
+    int slots = z.table_slots ? z.table_slots : g->sliced_slots_wanted;
+    if ((st = EnsureSliced(g, world, capacity, slots, s))) return st;
+
+    TouchParams shared;
+    // the caller's images may still be in flight on its stream
+    O3DMI_HIP_CHECK(hipEventRecord(z.ev_enter, s));
+    O3DMI_HIP_CHECK(hipStreamWaitEvent(z.side, z.ev_enter, 0));
+    if ((st = UploadSliceFrames(g, c, frames, n, z.side, &shared))) return st;
+
+    const int chunk_frames = kChunkGroups * group;
+    const int n_chunks = (n + chunk_frames - 1) / chunk_frames;
+    std::vector<int> chunk_stamp((size_t)n_chunks, 0);
+
+    auto issue_side = [&](int ci, bool touch) -> int {
+        const int set = ci & 1;
+        const int f0 = ci * chunk_frames;
+        const int nc = n - f0 < chunk_frames ? n - f0 : chunk_frames;
+        int st2;
+        if (touch) {
+            // the set's ready lists were read by chunk ci - 2's launches
+            if (ci >= 2)
+                O3DMI_HIP_CHECK(hipStreamWaitEvent(z.side, z.ev_main[set], 0));
+            if ((st2 = LaunchTouchSlice(shared, z.frames_dev, f0, nc, group,
+                                        rank, world, z.send_tables, z.side)))
+                return st2;
+            if ((st2 = LaunchPackSlice(z.send_tables, z.send_seg[set],
+                                       z.capacity, z.side)))
+                return st2;
+            const int64_t seg = SliceSegmentBytes(z.capacity);
+            if (comm && world > 1) {
+                if ((st2 = comm->Allgather(z.send_seg[set], z.gathered[set],
+                                           seg, z.side)))
+                    return st2;
+            } else {
+                if (gathered_in && world > 1)
+                    O3DMI_HIP_CHECK(hipMemcpyAsync(
+                            z.gathered[set], gathered_in[ci],
+                            (size_t)seg * world, hipMemcpyDeviceToDevice,
+                            z.side));
+                O3DMI_HIP_CHECK(hipMemcpyAsync(
+                        (char*)z.gathered[set] + (size_t)seg * rank,
+                        z.send_seg[set], (size_t)seg, hipMemcpyDeviceToDevice,
+                        z.side));
+            }
+        }
+        g->frame_stamp += 1;
+        chunk_stamp[(size_t)ci] = g->frame_stamp;
+        O3DMI_HIP_CHECK(hipMemsetAsync(z.recv_tables.flags, 0, sizeof(int),
+                                       z.side));
+        if ((st2 = LaunchApplySlice(g->block_hashmap, z.gathered[set], world,
+                                    z.capacity, z.recv_tables, g->frame_stamp,
+                                    z.side)))
+            return st2;
+        if ((st2 = LaunchBuildReady(g->block_hashmap, z.recv_tables,
+                                    z.ready[set], z.ready_cap,
+                                    z.ready_count[set],
+                                    (int*)g->stream_status + 4, g->frame_stamp,
+                                    z.side)))
+            return st2;
+        O3DMI_HIP_CHECK(hipEventRecord(z.ev_side[set], z.side));
+        return O3DMI_OK;
+    };
+
+    if ((st = issue_side(0, true))) return st;
+    for (int ci = 0; ci < n_chunks; ++ci) {
+        const int set = ci & 1;
+        const int f0 = ci * chunk_frames;
+        const int nc = n - f0 < chunk_frames ? n - f0 : chunk_frames;
+        // What the chunk's apply found: normally long there (it was issued a
+        // chunk ago).
+        for (int attempt = 0;; ++attempt) {
+            ChunkStatus cs;
+            if ((st = WaitChunkStatus(g, chunk_stamp[(size_t)ci], z.side, &cs)))
+                return st;
+            if (cs.overflow == 0) break;
+            O3DMI_REQUIRE(attempt < 24, "sliced touch: cannot make room");
+            O3DMI_HIP_CHECK(hipDeviceSynchronize());
+            z.reapplied += 1;
+            g->stream_overflow = 0;  // (PollStreamStatus reads the same words)
+            if (cs.overflow > 0) {
+                // the block hash ran out of buffer indices: the chunk was
+                // dropped; reserve, apply the same records again
+                int64_t wanted = 0;
+                if ((st = RecoverOverflow(g->block_hashmap, s, &wanted)))
+                    return st;
+                const int64_t cap = o3dmi_hash_capacity(g->block_hashmap);
+                if ((st = o3dmi_hash_reserve(g->block_hashmap,
+                                             wanted > 2 * cap ? wanted : 2 * cap,
+                                             (o3dmi_stream_t)s)))
+                    return st;
+                O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+                if ((st = issue_side(ci, false))) return st;
+            } else {
+                // a wire segment or a per-group table was too small (the
+                // flags travel in the all-gathered headers: every rank takes
+                // this branch for the same chunk): double both, touch again
+                if (gathered_in) {
+                    SetLastError("sliced touch: the given wire segments are "
+                                 "too small for this stream "
+                                 "(o3dmi_vbg_set_slice_capacity)");
+                    return O3DMI_ERR_CAPACITY;
+                }
+                if ((st = EnsureSliced(g, world, z.capacity * 2,
+                                       z.table_slots * 2, s)))
+                    return st;
+                if ((st = issue_side(ci, true))) return st;
+            }
+        }
+        if (ci + 1 < n_chunks)
+            if ((st = issue_side(ci + 1, true))) return st;
+        // the chunk's integrate launches, one per group, integrate role only
+        O3DMI_HIP_CHECK(hipStreamWaitEvent(s, z.ev_side[set], 0));
+        for (int gi = 0; gi * group < nc; ++gi) {
+            StreamGroup grp;
+            grp.n = nc - gi * group < group ? nc - gi * group : group;
+            grp.seq = g->stream_seq++;
+            g->frame_stamp += 1;
+            grp.stamp = g->frame_stamp;
+            grp.frames = frames + f0 + gi * group;
+            const bool prof = g->profiling && g->prof_frames < g->prof_max &&
+                              g->prof_stride > 0 &&
+                              (g->prof_seen++ % g->prof_stride) == 0;
+            hipEvent_t* pe = prof ? &g->prof_events[(size_t)g->prof_frames * 2]
+                                  : nullptr;
+            IntegrateStreamArgs ia;
+            MakeIntegArgs(g, c, grp, prof, &ia);
+            ia.list = nullptr;
+            ia.ready = z.ready[set] + (size_t)gi * z.ready_cap;
+            ia.count = z.ready_count[set] + gi;
+            ia.list_capacity = z.ready_cap;
+            ia.zero_counter = nullptr;
+            ia.raw = true;
+            ia.depth_div_short = g->prep_div_short;
+            for (int f = 0; f < grp.n; ++f) {
+                ia.recs[f] = nullptr;
+                ia.depth[f] = (const uint16_t*)grp.frames[f].depth;
+                ia.color_img[f] = c.with_color
+                                          ? (const uint8_t*)grp.frames[f].color
+                                          : nullptr;
+            }
+            if (pe) O3DMI_HIP_CHECK(hipEventRecord(pe[0], s));
+            if ((st = LaunchFrameStep(g->block_hashmap, nullptr, 0, &ia, s)))
+                return st;
+            if (pe) {
+                O3DMI_HIP_CHECK(hipEventRecord(pe[1], s));
+                g->prof_launch_frames += grp.n;
+                g->prof_frames += 1;
+            }
+            // keeps last_count (the next launch's grid size) current
+            if ((st = PollStreamStatus(g))) return st;
+        }
+        O3DMI_HIP_CHECK(hipEventRecord(z.ev_main[set], s));
+        z.chunks_done += 1;
+    }
+    // the next call's side-stream work must not pass this call's launches
+    // (the frame table, the ready sets)
+    O3DMI_HIP_CHECK(hipStreamWaitEvent(z.side, z.ev_main[(n_chunks - 1) & 1], 0));
+    g->known_valid = false;  // the other paths take the size from the map
+    g->stream_overflow = 0;
+    g->last_path = 0;
     return O3DMI_OK;
 }
 
@@ -1093,10 +1690,166 @@ int o3dmi_vbg_integrate_frames(o3dmi_vbg_t* g, int n_frames,
         frames[(size_t)f].color = color_devs ? color_devs[f] : nullptr;
         frames[(size_t)f].extrinsic = extrinsics + 16 * (size_t)f;
     }
+    // Block ownership with a communicator on this thread: the touch is split
+    // over the ranks and the candidate keys all-gathered (sliced_path.h)
+    // instead of every rank touching every ray -- when the images allow the
+    // raw-image integrate role (else the replicated touch below: same grids).
+    if (g->owner_world > 1 && n_frames > 1) {
+        o3dmi_comm* comm = ThreadComm();
+        static const bool no_slice = std::getenv("O3DMI_NO_SLICED_TOUCH") != nullptr;
+        if (comm && !no_slice && comm->world == g->owner_world &&
+            comm->rank == g->owner_rank && color_rows == depth_rows &&
+            color_cols == depth_cols && (depth_cols % 4) == 0 &&
+            (!color_intrinsic ||
+             std::memcmp(color_intrinsic, depth_intrinsic,
+                         sizeof(double) * 9) == 0 || !color_devs)) {
+            const char* e = std::getenv("O3DMI_STEP_VARIANT");
+            if (!e || e[0] == '2')
+                return StreamIntegrateSliced(
+                        g, c, frames.data(), n_frames,
+                        frames_per_launch <= 0 ? kDefaultGroup
+                                               : frames_per_launch,
+                        (hipStream_t)stream, comm, nullptr);
+        }
+    }
     return StreamIntegrate(g, c, frames.data(), n_frames,
                            frames_per_launch <= 0 ? kDefaultGroup
                                                   : frames_per_launch,
                            (hipStream_t)stream);
+}
+
+int o3dmi_vbg_set_slice_capacity(o3dmi_vbg_t* g, int records_per_group,
+                                 int table_slots) {
+    O3DMI_REQUIRE(g != nullptr, "grid is null");
+    O3DMI_REQUIRE(records_per_group >= 16 && table_slots >= 64 &&
+                          (table_slots & (table_slots - 1)) == 0,
+                  "slice capacity: records >= 16, table slots a power of two "
+                  ">= 64");
+    o3dmi_vbg::Sliced& z = g->sliced;
+    if (z.side) {
+        O3DMI_HIP_CHECK(hipDeviceSynchronize());
+        SliceFrame* keep = z.frames_dev;
+        const int64_t keep_cap = z.frames_cap;
+        z.frames_dev = nullptr;
+        FreeSliced(g);
+        z.frames_dev = keep;
+        z.frames_cap = keep_cap;
+    }
+    z.capacity = records_per_group;
+    z.table_slots = 0;
+    g->sliced_slots_wanted = table_slots;
+    return O3DMI_OK;
+}
+
+int64_t o3dmi_vbg_slice_segment_bytes(const o3dmi_vbg_t* g) {
+    if (!g) return 0;
+    return SliceSegmentBytes(g->sliced.capacity ? g->sliced.capacity : 1024);
+}
+
+int o3dmi_vbg_slice_chunk_frames(int frames_per_launch) {
+    int group = frames_per_launch <= 0 ? kDefaultGroup : frames_per_launch;
+    if (group > kMaxGroup) group = kMaxGroup;
+    return kChunkGroups * group;
+}
+
+int o3dmi_vbg_touch_slice(o3dmi_vbg_t* g, int n_frames,
+                          const void* const* depth_devs, int depth_rows,
+                          int depth_cols, const double* depth_intrinsic,
+                          const double* extrinsics, float depth_scale,
+                          float depth_max, float trunc_voxel_multiplier,
+                          int frames_per_launch, int slice_rank,
+                          int slice_world, void* segment_out_dev,
+                          o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(g && depth_devs && depth_intrinsic && extrinsics &&
+                          segment_out_dev,
+                  "null argument");
+    int group = frames_per_launch <= 0 ? kDefaultGroup : frames_per_launch;
+    if (group > kMaxGroup) group = kMaxGroup;
+    O3DMI_REQUIRE(n_frames >= 1 && n_frames <= kChunkGroups * group,
+                  "touch slice: at most one chunk of frames per call");
+    hipStream_t s = (hipStream_t)stream;
+    o3dmi_vbg::Sliced& z = g->sliced;
+    int st = EnsureSliced(g, slice_world > z.world ? slice_world : z.world,
+                          z.capacity ? z.capacity : 1024,
+                          z.table_slots ? z.table_slots
+                                        : g->sliced_slots_wanted,
+                          s);
+    if (st) return st;
+    StreamCommon c = {};
+    c.depth_rows = depth_rows;
+    c.depth_cols = depth_cols;
+    c.depth_intrinsic = depth_intrinsic;
+    c.depth_scale = depth_scale;
+    c.depth_max = depth_max;
+    c.trunc = trunc_voxel_multiplier;
+    std::vector<StreamFrame> frames((size_t)n_frames);
+    for (int f = 0; f < n_frames; ++f) {
+        frames[(size_t)f].depth = depth_devs[f];
+        frames[(size_t)f].color = nullptr;
+        frames[(size_t)f].extrinsic = extrinsics + 16 * (size_t)f;
+    }
+    // everything on the side stream, behind the caller's stream and in front
+    // of whatever the caller does next on it
+    O3DMI_HIP_CHECK(hipEventRecord(z.ev_enter, s));
+    O3DMI_HIP_CHECK(hipStreamWaitEvent(z.side, z.ev_enter, 0));
+    TouchParams shared;
+    if ((st = UploadSliceFrames(g, c, frames.data(), n_frames, z.side,
+                                &shared)))
+        return st;
+    if ((st = LaunchTouchSlice(shared, z.frames_dev, 0, n_frames, group,
+                               slice_rank, slice_world, z.send_tables, z.side)))
+        return st;
+    if ((st = LaunchPackSlice(z.send_tables, segment_out_dev, z.capacity,
+                              z.side)))
+        return st;
+    O3DMI_HIP_CHECK(hipEventRecord(z.ev_enter, z.side));
+    O3DMI_HIP_CHECK(hipStreamWaitEvent(s, z.ev_enter, 0));
+    return O3DMI_OK;
+}
+
+int o3dmi_vbg_integrate_frames_sliced(
+        o3dmi_vbg_t* g, int n_frames, const void* const* depth_devs,
+        int depth_rows, int depth_cols, const void* const* color_devs,
+        int color_rows, int color_cols, int input_dtype,
+        const double* depth_intrinsic, const double* color_intrinsic,
+        const double* extrinsics, float depth_scale, float depth_max,
+        float trunc_voxel_multiplier, int frames_per_launch,
+        const void* const* gathered_devs, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(g && depth_devs && depth_intrinsic && extrinsics &&
+                          n_frames >= 0,
+                  "null argument");
+    O3DMI_REQUIRE(StreamPathApplies(g, input_dtype),
+                  "sliced touch: uint16 depth, float32 tsdf and a block "
+                  "resolution divisible by 4 are required");
+    o3dmi_comm* comm = gathered_devs ? nullptr : ThreadComm();
+    O3DMI_REQUIRE(gathered_devs || comm || g->owner_world == 1,
+                  "sliced touch: neither wire segments nor a communicator "
+                  "(o3dmi_set_comm)");
+    if (n_frames == 0) return O3DMI_OK;
+    StreamCommon c = MakeCommon(depth_rows, depth_cols, color_rows, color_cols,
+                                depth_intrinsic, color_intrinsic, depth_scale,
+                                depth_max, trunc_voxel_multiplier);
+    std::vector<StreamFrame> frames((size_t)n_frames);
+    for (int f = 0; f < n_frames; ++f) {
+        frames[(size_t)f].depth = depth_devs[f];
+        frames[(size_t)f].color = color_devs ? color_devs[f] : nullptr;
+        frames[(size_t)f].extrinsic = extrinsics + 16 * (size_t)f;
+    }
+    return StreamIntegrateSliced(g, c, frames.data(), n_frames,
+                                 frames_per_launch <= 0 ? kDefaultGroup
+                                                        : frames_per_launch,
+                                 (hipStream_t)stream, comm, gathered_devs);
+}
+
+int o3dmi_vbg_sliced_stats(const o3dmi_vbg_t* g, int64_t* chunks,
+                           int64_t* reapplied, int* capacity,
+                           int* table_slots) {
+    O3DMI_REQUIRE(g != nullptr, "grid is null");
+    if (chunks) *chunks = g->sliced.chunks_done;
+    if (reapplied) *reapplied = g->sliced.reapplied;
+    if (capacity) *capacity = g->sliced.capacity;
+    if (table_slots) *table_slots = g->sliced.table_slots;
+    return O3DMI_OK;
 }
 
 int o3dmi_vbg_ray_cast(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
@@ -1856,10 +2609,10 @@ int o3dmi_vbg_profile_begin(o3dmi_vbg_t* g, int max_frames, int stride) {
         (void)hipFree(g->prof_counts);
         g->prof_counts = nullptr;
         O3DMI_HIP_CHECK(hipMalloc((void**)&g->prof_counts,
-                                  sizeof(int32_t) * 2 * (size_t)max_frames));
+                                  sizeof(int32_t) * 3 * (size_t)max_frames));
     }
     O3DMI_HIP_CHECK(hipMemset(g->prof_counts, 0,
-                              sizeof(int32_t) * 2 * (size_t)max_frames));
+                              sizeof(int32_t) * 3 * (size_t)max_frames));
     g->prof_max = max_frames;
     g->prof_frames = 0;
     g->prof_launch_frames = 0;
@@ -1875,13 +2628,22 @@ int o3dmi_vbg_profile_end(o3dmi_vbg_t* g, o3dmi_stream_t stream,
     g->profiling = false;
     O3DMI_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     double ti = 0;
+    g->prof_launch_ms.assign((size_t)g->prof_frames, 0.0f);
     for (int f = 0; f < g->prof_frames; ++f) {
         float ms = 0;
         O3DMI_HIP_CHECK(hipEventElapsedTime(
                 &ms, g->prof_events[(size_t)f * 2 + 0],
                 g->prof_events[(size_t)f * 2 + 1]));
         ti += ms;
+        g->prof_launch_ms[(size_t)f] = ms;
     }
+    g->prof_launch_counts.assign(3 * (size_t)g->prof_frames, 0);
+    for (int k = 0; k < 3 && g->prof_frames > 0; ++k)
+        O3DMI_HIP_CHECK(hipMemcpy(
+                g->prof_launch_counts.data() + (size_t)k * g->prof_frames,
+                g->prof_counts + (size_t)k * g->prof_max,
+                sizeof(int32_t) * (size_t)g->prof_frames,
+                hipMemcpyDeviceToHost));
     std::vector<int32_t> counts((size_t)g->prof_frames);
     if (g->prof_frames > 0)
         O3DMI_HIP_CHECK(hipMemcpy(counts.data(), g->prof_counts,
@@ -1904,6 +2666,23 @@ int o3dmi_vbg_profile_end(o3dmi_vbg_t* g, o3dmi_stream_t stream,
 
 int64_t o3dmi_vbg_profile_distinct_blocks(const o3dmi_vbg_t* g) {
     return g ? g->prof_distinct_blocks : 0;
+}
+
+int64_t o3dmi_vbg_profile_launches(const o3dmi_vbg_t* g, int64_t capacity,
+                                   float* ms, int32_t* block_frames,
+                                   int32_t* distinct_blocks,
+                                   int32_t* map_size) {
+    if (!g) return 0;
+    const int64_t n = (int64_t)g->prof_launch_ms.size();
+    const int64_t m = n < capacity ? n : capacity;
+    for (int64_t i = 0; i < m; ++i) {
+        if (ms) ms[i] = g->prof_launch_ms[(size_t)i];
+        if (block_frames) block_frames[i] = g->prof_launch_counts[(size_t)i];
+        if (distinct_blocks)
+            distinct_blocks[i] = g->prof_launch_counts[(size_t)(n + i)];
+        if (map_size) map_size[i] = g->prof_launch_counts[(size_t)(2 * n + i)];
+    }
+    return n;
 }
 
 }  // extern "C"

@@ -959,6 +959,20 @@ struct VdsWorkspace {
 constexpr int kVdsChains = 2;
 constexpr int kVdsDevices = 64;
 
+// The workspaces are self-cleaning: the LAST launch of a level returns the
+// table slots, histograms and `primed` state it used to their idle values. A
+// chain that is abandoned between its first launch and that last one (an error
+// return in the driver, a failed launch) leaves them dirty; the driver says so
+// (VdsChainInvalidate) and the next user of the workspace throws it away and
+// starts from freshly initialised buffers. [bucketed form, sort form]
+static thread_local bool g_vds_dirty[kVdsDevices][kVdsChains][2];
+
+static bool TakeVdsDirty(int dev, int chain, int which) {
+    const bool d = g_vds_dirty[dev][chain][which];
+    g_vds_dirty[dev][chain][which] = false;
+    return d;
+}
+
 VdsWorkspace* ThreadVdsWorkspace(int chain, int64_t n_max, hipStream_t s) {
     static thread_local VdsWorkspace ws[kVdsDevices][kVdsChains];
     int dev = 0;
@@ -966,6 +980,11 @@ VdsWorkspace* ThreadVdsWorkspace(int chain, int64_t n_max, hipStream_t s) {
         chain < 0 || chain >= kVdsChains)
         return nullptr;
     VdsWorkspace& w = ws[dev][chain];
+    if (TakeVdsDirty(dev, chain, 0) && w.n_cap) {
+        // whatever the abandoned chain queued (on whichever stream) is over
+        if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+        w.Free();
+    }
     if (w.n_cap >= n_max) return &w;
     // grow: everything queued on the old buffers must have run
     if (w.n_cap && hipStreamSynchronize(s) != hipSuccess) return nullptr;
@@ -1105,6 +1124,10 @@ VdsSortWorkspace* ThreadVdsSortWorkspace(int chain, int64_t n_max,
         chain < 0 || chain >= kVdsChains)
         return nullptr;
     VdsSortWorkspace& w = ws[dev][chain];
+    if (TakeVdsDirty(dev, chain, 1) && w.n_cap) {
+        if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+        w.Free();
+    }
     if (w.n_cap >= n_max) return &w;
     if (w.n_cap && hipStreamSynchronize(s) != hipSuccess) return nullptr;
     w.Free();
@@ -1228,6 +1251,14 @@ int PostCountsAsync(int* counts_dev, int n, double* mail_data, int* mail_flag,
                        mail_data, mail_flag, mail_seq);
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
+}
+
+void VdsChainInvalidate(int chain) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kVdsDevices ||
+        chain < 0 || chain >= kVdsChains)
+        return;
+    g_vds_dirty[dev][chain][0] = g_vds_dirty[dev][chain][1] = true;
 }
 
 int VdsAsync(const void* pos, const void* attr, int64_t n_max, const int* n_dev,

@@ -101,6 +101,9 @@ struct FrameFrontArgs {
     ReadyEntry* ready;    // the group's ready list (may be null: not built)
     int* tickets;         // 9 arrival counters of the group's touch
                           // workgroups, zero between launches
+    int* touch_status;    // host-mapped {map size, overflow stamp, group block
+                          // count, group stamp}: published by the group's last
+                          // touch workgroup (may be null)
 };
 
 // Integrate role of ONE group.
@@ -131,6 +134,17 @@ struct IntegrateStreamArgs {
     int* prof_count;      // device int receiving the live count
     int* prof_frame_blocks;  // device int receiving sum over blocks of
                              // popcount(frame bits) = block-frames integrated
+    int* prof_map_size;      // device int receiving the map size (heap top) the
+                             // role sees when it starts
+    // RAW form (sliced_path.h): depth / colour gathered from the frames' own
+    // images, no prepared records (recs unused). Needs `ready`, depth and
+    // colour images of the same size and intrinsics, no front roles in the
+    // launch.
+    bool raw;
+    const uint16_t* depth[kMaxGroup];
+    const uint8_t* color_img[kMaxGroup];
+    float depth_scale;
+    bool depth_div_short;    // PrepTables' verdict for this depth scale
 };
 
 // One launch running the front roles of up to kMaxGroup frames and / or the
@@ -144,6 +158,22 @@ struct IntegrateStreamArgs {
 int LaunchFrameStep(o3dmi_hash* block_hash, const FrameFrontArgs* fronts,
                     int n_fronts, const IntegrateStreamArgs* integ,
                     hipStream_t s);
+
+// Starts (without waiting for it) the on-device proof that the integrate
+// role's short division forms are exact for this truncation distance; launches
+// use them once it has finished (vbg_stream.hip VerifyFastDivision).
+// Returns the forms usable now: 0 = IEEE only (proof running, failed or
+// disabled), 1 = sdf / trunc and 1 / (w + 1), 2 / 3 = also 1 / z with one /
+// two Newton steps. `wait`: block until the proof has finished.
+int PrefetchFastDivision(float sdf_trunc, bool wait);
+
+// After a frame-stream group ran out of buffer indices (HashView::counters[3],
+// InsertKey): with the stream drained, turns the slots that got no index into
+// tombstones, brings heap_top back to the capacity and clears the overflow
+// stamp, so that the map is a consistent FULL map again (ready for Reserve).
+// `wanted` receives the number of indices the dropped groups asked for in all
+// (>= capacity).
+int RecoverOverflow(o3dmi_hash* block_hash, hipStream_t s, int64_t* wanted);
 
 // Host evaluation of the prepare pass's per-column / per-row sub-expressions
 // (IntegrateCPU's colour-pixel selection, VoxelBlockGridImpl.h:277-289, with

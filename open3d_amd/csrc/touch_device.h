@@ -11,15 +11,30 @@ namespace o3dmi {
 // Insert-if-absent of a packed key; returns the slot index and whether this
 // thread created the entry. `val_out` receives the buffer index for creators
 // when kAllocate (main block hash); scratch hashes do not allocate.
+//
+// Running out of buffer indices: callers that reserved for an exact count
+// never do, and for them it is an error (kErrCapacity, reported at the next
+// sync). The frame stream issues groups on an ESTIMATE of what they add
+// (host/voxel_block_grid.cpp): it passes its group stamp as `overflow_stamp`,
+// an overflow then records the first failing group in counters[3] and leaves
+// the slot with the marker index -1 (Find: absent); the group's work is
+// dropped on the device, the host reserves and replays it (RecoverOverflow).
 template <bool kAllocate>
 __device__ __forceinline__ bool InsertKey(const HashView& hv, int x, int y,
-                                          int z, unsigned& slot_out) {
+                                          int z, unsigned& slot_out,
+                                          int overflow_stamp = 0) {
     slot_out = 0;
     if (ClaimSlot(hv, PackKey(x, y, z), slot_out) != 1) return false;
     if (kAllocate) {
         const unsigned h = slot_out;
         int top = atomicAdd(&hv.counters[0], 1);
         if (top >= hv.capacity) {
+            if (overflow_stamp != 0) {
+                atomicCAS(&hv.counters[3], 0, overflow_stamp);
+                __hip_atomic_store(&hv.slot_vals[h], -1, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                return true;
+            }
             atomicOr(&hv.counters[1], kErrCapacity);
             // Leave a valid (but shared) index so later kernels stay in
             // bounds; the error is reported at sync.

@@ -65,6 +65,7 @@ struct FrontShared {
     int* out_count;
     ReadyEntry* ready;
     int* tickets;
+    int* touch_status;
     int n_touch_total;  // touch workgroups of the whole group (all frames)
     unsigned long long group_stamp;
     int touch_plane;
@@ -95,6 +96,7 @@ inline bool SameGroup(const FrontShared& a, const FrontShared& b) {
            a.inv_depth_scale == b.inv_depth_scale && a.list == b.list &&
            a.list_capacity == b.list_capacity && a.out_count == b.out_count &&
            a.ready == b.ready && a.tickets == b.tickets &&
+           a.touch_status == b.touch_status &&
            a.n_touch_total == b.n_touch_total &&
            a.group_stamp == b.group_stamp && a.touch_plane == b.touch_plane &&
            a.n_touch_wg == b.n_touch_wg && a.n_prep_wg == b.n_prep_wg;
@@ -124,6 +126,7 @@ struct FrontParams {
     int* out_count;
     ReadyEntry* ready;
     int* tickets;
+    int* touch_status;
     int n_touch_total;
     unsigned long long group_stamp;
     int group_bit;
@@ -136,7 +139,8 @@ struct FrontParams {
           depth_div_short(s.depth_div_short), prep_identity(s.prep_identity),
           inv_depth_scale(s.inv_depth_scale), recs(f.recs), list(s.list),
           list_capacity(s.list_capacity), out_count(s.out_count),
-          ready(s.ready), tickets(s.tickets), n_touch_total(s.n_touch_total),
+          ready(s.ready), tickets(s.tickets), touch_status(s.touch_status),
+          n_touch_total(s.n_touch_total),
           group_stamp(s.group_stamp), group_bit(f.group_bit),
           touch_plane(s.touch_plane), n_touch_wg(s.n_touch_wg),
           n_prep_wg(s.n_prep_wg) {
@@ -214,7 +218,7 @@ __device__ __forceinline__ void FrontRole(const HashView& hv,
             const int y = (int)((k >> 21) & 0x1FFFFFull) - kKeyBias;
             const int z = (int)(k & 0x1FFFFFull) - kKeyBias;
             unsigned slot;
-            InsertKey<true>(hv, x, y, z, slot);
+            InsertKey<true>(hv, x, y, z, slot, (int)fp.group_stamp);
             if (TouchSlot(hv, slot, fp.group_stamp, fp.group_bit,
                           fp.touch_plane)) {
                 int o = atomicAdd(fp.out_count, 1);
@@ -253,6 +257,28 @@ __device__ __forceinline__ void FrontRole(const HashView& hv,
             int n = __hip_atomic_load(fp.out_count, __ATOMIC_RELAXED,
                                       __HIP_MEMORY_SCOPE_AGENT);
             if (n > fp.list_capacity) n = (int)fp.list_capacity;
+            // A group that ran out of buffer indices -- or comes after one
+            // that did -- is dropped as a whole: its integrate role finds an
+            // empty list, the host reserves and replays from the first
+            // dropped group (frames must be applied in order).
+            const int overflow = __hip_atomic_load(
+                    &hv.counters[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (overflow != 0) {
+                n = 0;
+                if (threadIdx.x == 0)
+                    __hip_atomic_store(fp.out_count, 0, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (threadIdx.x == 0 && fp.touch_status) {
+                const int top = __hip_atomic_load(&hv.counters[0],
+                                                  __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT);
+                fp.touch_status[0] = top < hv.capacity ? top : hv.capacity;
+                fp.touch_status[1] = overflow;
+                fp.touch_status[2] = n;
+                __hip_atomic_store(&fp.touch_status[3], (int)fp.group_stamp,
+                                   __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             for (int i = threadIdx.x; i < n; i += blockDim.x) {
                 const unsigned long long* e =
                         reinterpret_cast<const unsigned long long*>(&list[i]);
@@ -490,6 +516,14 @@ struct IntegParams {
     int status_stamp;
     int* prof_count;
     int* prof_frame_blocks;
+    int* prof_map_size;
+    // RAW form (sliced block-ownership path, sliced_path.h): no prepared
+    // records -- depth / colour are gathered from the frames' own images
+    // (same size and intrinsics for both: the identity case of PrepTables)
+    const uint16_t* raw_depth[kMaxGroup];
+    const uint8_t* raw_color[kMaxGroup];
+    float depth_scale, inv_depth_scale;
+    bool depth_div_short;
 };
 
 // ---- exact division without the division sequence ---------------------------
@@ -615,6 +649,7 @@ __device__ __forceinline__ void IntegrateRole(const HashView& hv,
     if (wg == 0 && threadIdx.x == 0) {
         if (ip.zero_counter) *ip.zero_counter = 0;
         if (ip.prof_count) *ip.prof_count = (int)n_blocks;
+        if (ip.prof_map_size) *ip.prof_map_size = hv.counters[0];
         if (ip.size_host) {
             // The front roles of this group completed in an earlier launch,
             // so heap_top is at least the map size after this group's
@@ -808,8 +843,16 @@ __device__ __forceinline__ f2 PkFma(f2 a, f2 b, f2 c) {
 // kP = voxel pairs per lane: 2 (a lane owns 4 x-consecutive voxels; 16 / 8 /
 // 24-byte state accesses, ~127 registers, 4 waves per SIMD) or 1 (2 voxels per
 // lane: twice the work items at half the size and ~2/3 of the registers).
+// kRaw: depth and colour come from the frames' raw uint16 / uint8 images
+// instead of the prepared 8-byte records (IntegParams::raw_depth / raw_color): one
+// 2-byte and one (unaligned) 4-byte gather per voxel and frame, the depth
+// division float(depth) / depth_scale per voxel instead of per pixel -- the
+// same float32 operations on the same operands, so the results are the
+// records path's bit for bit. For ranks that integrate a fraction of the
+// blocks (block-ownership sharding) this removes the per-pixel prepare pass,
+// which every rank would otherwise run in full.
 template <typename weight_t, typename color_t, bool kColor, int kDiv,
-          int kChunk, int kP>
+          int kChunk, int kP, bool kRaw = false>
 __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                                                   const IntegParams& ip,
                                                   int wg, int n_wg,
@@ -830,6 +873,7 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
     if (wg == 0 && threadIdx.x == 0) {
         if (ip.zero_counter) *ip.zero_counter = 0;
         if (ip.prof_count) *ip.prof_count = (int)n_blocks;
+        if (ip.prof_map_size) *ip.prof_map_size = hv.counters[0];
         if (ip.size_host) {
             ip.size_host[0] = hv.counters[0];
             ip.size_host[1] = hv.counters[1];
@@ -863,6 +907,7 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
     const float fx = ip.cam0.fx, fyk = ip.cam0.fy;
     const float cx = ip.cam0.cx, cy = ip.cam0.cy;
     const float u_max = ip.cols - 1.0f, v_max = ip.rows - 1.0f;
+    const unsigned last_pix = (unsigned)(ip.rows * ip.cols) - 1u;
 
     // (Measured and dropped, profiles/r2l: persistent workgroups -- 1024 to
     // 1536 of them striding over the items, with the next item's block header
@@ -988,6 +1033,7 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
         if (((bits >> c0) & ((1u << kChunk) - 1u)) == 0u) continue;  // uniform
         f2 zc[kChunk][kP];
         PixelRec rec[kChunk][kV];
+        unsigned in_mask = 0u;  // kRaw: voxel projects into the image
 #pragma unroll
         for (int fk = 0; fk < kChunk; ++fk) {
             const int f = c0 + fk;
@@ -999,7 +1045,11 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                     *reinterpret_cast<const float(*)[3][4]>(
                             &ip.ext[f][0][0] + opaque);
             const char* __restrict__ recs = reinterpret_cast<const char*>(
-                    *(&ip.recs[f] + opaque));
+                    kRaw ? nullptr : *(&ip.recs[f] + opaque));
+            const char* __restrict__ dimg = reinterpret_cast<const char*>(
+                    kRaw ? *(&ip.raw_depth[f] + opaque) : nullptr);
+            const char* __restrict__ cimg = reinterpret_cast<const char*>(
+                    kRaw ? *(&ip.raw_color[f] + opaque) : nullptr);
             const float y0 = ys * e[0][1], z0 = zs * e[0][2];
             const float y1 = ys * e[1][1], z1 = zs * e[1][2];
             const float y2 = ys * e[2][1], z2 = zs * e[2][2];
@@ -1045,12 +1095,43 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                     // sentinel record (depth 0) for voxels outside the image
                     // (24-bit multiply: rows and the row pitch are far below
                     // 2^24, and it issues at full rate)
+                    if constexpr (kRaw) {
+                        // pixel index; lanes outside the image read pixel 0
+                        // and carry a cleared bit in in_mask
+                        const unsigned pix =
+                                in ? __umul24((unsigned)(int)vh,
+                                              (unsigned)ip.cols) +
+                                             (unsigned)(int)uh
+                                   : 0u;
+                        in_mask |= (in ? 1u : 0u) << (fk * kV + 2 * p + h);
+                        PixelRec r;
+                        // .d holds the raw uint16 depth (converted below)
+                        r.d = __uint_as_float((unsigned)*reinterpret_cast<
+                                              const uint16_t*>(dimg + 2u * pix));
+                        r.rgba = 0u;
+                        if constexpr (kColor) {
+                            // 3 bytes at 3 * pix as ONE dword load (the
+                            // hardware takes unaligned global addresses); the
+                            // last pixel reads one byte earlier and shifts, so
+                            // that no load passes the end of the image
+                            struct __attribute__((packed)) U32 {
+                                unsigned v;
+                            };
+                            const unsigned adj = pix == last_pix ? 1u : 0u;
+                            r.rgba = reinterpret_cast<const U32*>(
+                                             cimg + 3u * pix - adj)
+                                             ->v >>
+                                     (8u * adj);
+                        }
+                        rec[fk][2 * p + h] = r;
+                    } else {
                     const unsigned off =
                             __umul24((unsigned)(int)vh, row_bytes) +
                             (unsigned)(int)uh * (unsigned)sizeof(PixelRec);
                     rec[fk][2 * p + h] = *reinterpret_cast<const PixelRec*>(
                             recs + (ip.diag == 1 ? 0u
                                                  : (in ? off : sentinel_off)));
+                    }
                 }
             }
         }
@@ -1063,6 +1144,31 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
             f2 sdf[kP];
             bool ok[kV];
             bool tiny = false;
+            if constexpr (kRaw) {
+                // float(depth) / depth_scale (VoxelBlockGridImpl.h:258-262),
+                // what the prepare pass does per pixel: the short constant-
+                // divisor form when the host verified it for all 65536 depths
+#pragma unroll
+                for (int p = 0; p < kP; ++p) {
+                    f2 a = f2{(float)__float_as_uint(rec[fk][2 * p].d),
+                              (float)__float_as_uint(rec[fk][2 * p + 1].d)};
+                    f2 q;
+                    if (ip.depth_div_short) {
+                        const f2 q0 = a * ip.inv_depth_scale;
+                        const f2 r = PkFma(Splat(-ip.depth_scale), q0, a);
+                        q = PkFma(r, Splat(ip.inv_depth_scale), q0);
+                    } else {
+                        q = f2{a.x / ip.depth_scale, a.y / ip.depth_scale};
+                    }
+                    // outside the image: depth 0 = invalid (the records
+                    // path's sentinel)
+                    rec[fk][2 * p].d =
+                            ((in_mask >> (fk * kV + 2 * p)) & 1u) ? q.x : 0.0f;
+                    rec[fk][2 * p + 1].d =
+                            ((in_mask >> (fk * kV + 2 * p + 1)) & 1u) ? q.y
+                                                                      : 0.0f;
+                }
+            }
 #pragma unroll
             for (int p = 0; p < kP; ++p) {
 #pragma unroll
@@ -1122,8 +1228,10 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                 if constexpr (kColor) {
                     const unsigned rg0 = rec[fk][2 * p].rgba;
                     const unsigned rg1 = rec[fk][2 * p + 1].rgba;
-                    const bool has0 = ok[2 * p] && (rg0 >> 24);
-                    const bool has1 = ok[2 * p + 1] && (rg1 >> 24);
+                    // (raw form: the colour pixel IS the depth pixel, inside
+                    // the image whenever the voxel is ok)
+                    const bool has0 = ok[2 * p] && (kRaw || (rg0 >> 24));
+                    const bool has1 = ok[2 * p + 1] && (kRaw || (rg1 >> 24));
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
                         const f2 in = f2{(float)((rg0 >> (8 * i)) & 0xffu),
@@ -1188,7 +1296,7 @@ static_assert(sizeof(StepParams) <= 4096, "kernel arguments are limited to 4 KB"
 // (72 registers, 7 waves per SIMD). Both wide forms apply a group of up to 8
 // frames in chunks of kGroupChunk = 4 to the register-resident voxel state.
 template <typename weight_t, typename color_t, bool kColor, int kDiv,
-          int kForm>
+          int kForm, bool kRaw = false>
 __global__ void __launch_bounds__(256, kForm == 0 ? 1 : (kForm == 1 ? 4 : 7))
 FrameStepKernel(StepParams sp) {
     const int b = (int)blockIdx.x;
@@ -1199,7 +1307,7 @@ FrameStepKernel(StepParams sp) {
         FrontRole(sp.hv, fp, b - f * sp.front_wg);
     } else if constexpr (kForm != 0) {
         IntegrateRoleWide<weight_t, color_t, kColor, kDiv, kGroupChunk,
-                          kForm == 2 ? 1 : 2>(
+                          kForm == 2 ? 1 : 2, kRaw>(
                 sp.hv, sp.integ, b - n_front_wg, (int)gridDim.x - n_front_wg,
                 n_front_wg);
     } else {
@@ -1276,59 +1384,112 @@ int64_t FrustumBlockBound(const double* K, int rows, int cols, float depth_max,
 
 // Exhaustive on-device proof that the short division forms equal the IEEE
 // division for this truncation distance (see DivByConst); cached per value.
-static int VerifyFastDivision(float b, float* y_out) {
-    static std::mutex mu;
-    static std::map<unsigned, int> cache;
+//
+// The proof is ~3 x 10^9 divisions (a few ms of the whole chip) and runs
+// ASYNCHRONOUSLY on a private stream: until it has finished, launches take the
+// IEEE forms (kDiv = 0: the same results, ~4 % slower), so no caller ever
+// waits for it. (Rounds 1-3 waited: the first integrate launch of a process
+// with a new truncation distance stalled the host for 8-10 ms --
+// profiles/r4a_c4_before.json shows it as a 9.6 ms gap in the kernel trace of
+// the configs[4] leg, a quarter of that leg's timed pass.)
+// o3dmi_vbg_create starts it for the API's default truncation multiplier, so
+// that it is normally over before the first frame arrives.
+struct DivProof {
+    int result = -1;  // -1: still running
+    hipEvent_t done = nullptr;
+    hipStream_t stream = nullptr;
+    int* flag_dev = nullptr;
+    int* flag_host = nullptr;  // pinned
+};
+static std::mutex g_div_mu;
+static std::map<std::pair<int, unsigned>, DivProof> g_div_proofs;
+
+static int DivFormsFromFlags(int host) {
+    // bits 1|2: sdf / w forms; 4: 1/z one step; 8: two steps
+    return (host & 3) ? 0 : (!(host & 4) ? 2 : (!(host & 8) ? 3 : 1));
+}
+
+static void DivProofReport(float b, int ok, int flags) {
+    if (!std::getenv("O3DMI_VERBOSE")) return;
+    std::fprintf(stderr,
+                 "[o3dmi] exact short division for sdf_trunc = %.9g: %s "
+                 "(flags %d)\n",
+                 (double)b,
+                 ok == 0 ? "not used"
+                         : (ok == 1 ? "sdf, 1/(w+1)"
+                                    : (ok == 2 ? "sdf, 1/(w+1), 1/z (1 step)"
+                                               : "sdf, 1/(w+1), 1/z (2 steps)")),
+                 flags);
+}
+
+// Starts the proof for `b` on the current device if it has not been started;
+// returns the forms that may be used NOW (0 while it runs). `wait`: block until
+// it has finished (O3DMI_DIV_PROOF_WAIT=1, tests of the short forms).
+static int VerifyFastDivision(float b, float* y_out, bool wait = false) {
     unsigned key;
     std::memcpy(&key, &b, sizeof(key));
     const float y = 1.0f / b;  // IEEE: correctly rounded reciprocal
-    *y_out = y;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = cache.find(key);
-    if (it != cache.end()) return it->second;
-    int ok = 0;
+    if (y_out) *y_out = y;
     static const bool disabled = std::getenv("O3DMI_EXACT_DIV") != nullptr;
-    if (!disabled && b > 0.0f && std::isfinite(b) && std::isfinite(y)) {
-        int* flag = nullptr;
-        if (hipMalloc((void**)&flag, sizeof(int)) == hipSuccess) {
-            // A private stream: the caller's stream may be mid-pipeline.
-            hipStream_t vs = nullptr;
-            if (hipStreamCreateWithFlags(&vs, hipStreamNonBlocking) ==
-                hipSuccess) {
-                int host = -1;
-                (void)hipMemsetAsync(flag, 0, sizeof(int), vs);
-                hipLaunchKernelGGL(VerifyDivKernel, dim3(kCUs * 16), dim3(256),
-                                   0, vs, b, y, key, flag);
-                hipLaunchKernelGGL(VerifyRcpKernel, dim3(256), dim3(256), 0, vs,
-                                   flag);
-                hipLaunchKernelGGL(VerifyRcpZKernel<1>, dim3(kCUs * 16),
-                                   dim3(256), 0, vs, flag, 4);
-                hipLaunchKernelGGL(VerifyRcpZKernel<2>, dim3(kCUs * 16),
-                                   dim3(256), 0, vs, flag, 8);
-                if (hipGetLastError() == hipSuccess &&
-                    hipMemcpyAsync(&host, flag, sizeof(int),
-                                   hipMemcpyDeviceToHost, vs) == hipSuccess &&
-                    hipStreamSynchronize(vs) == hipSuccess)
-                    // bits 1|2: sdf / w forms; 4: 1/z one step; 8: two steps
-                    ok = (host & 3) ? 0 : (!(host & 4) ? 2 : (!(host & 8) ? 3 : 1));
-                if (std::getenv("O3DMI_VERBOSE"))
-                    std::fprintf(stderr, "[o3dmi] division check flags: %d\n",
-                                 host);
-                (void)hipStreamDestroy(vs);
-            }
-            (void)hipFree(flag);
+    static const bool always_wait =
+            std::getenv("O3DMI_DIV_PROOF_WAIT") != nullptr;
+    if (disabled || !(b > 0.0f) || !std::isfinite(b) || !std::isfinite(y))
+        return 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    std::lock_guard<std::mutex> lock(g_div_mu);
+    DivProof& p = g_div_proofs[std::make_pair(dev, key)];
+    if (p.result >= 0) return p.result;
+    if (!p.done) {
+        // not started yet
+        bool ok = hipMalloc((void**)&p.flag_dev, sizeof(int)) == hipSuccess &&
+                  hipHostMalloc((void**)&p.flag_host, sizeof(int)) ==
+                          hipSuccess &&
+                  hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking) ==
+                          hipSuccess &&
+                  hipEventCreateWithFlags(&p.done, hipEventDisableTiming) ==
+                          hipSuccess;
+        if (ok) {
+            *p.flag_host = -1;
+            (void)hipMemsetAsync(p.flag_dev, 0, sizeof(int), p.stream);
+            hipLaunchKernelGGL(VerifyDivKernel, dim3(kCUs * 16), dim3(256), 0,
+                               p.stream, b, y, key, p.flag_dev);
+            hipLaunchKernelGGL(VerifyRcpKernel, dim3(256), dim3(256), 0,
+                               p.stream, p.flag_dev);
+            hipLaunchKernelGGL(VerifyRcpZKernel<1>, dim3(kCUs * 16), dim3(256),
+                               0, p.stream, p.flag_dev, 4);
+            hipLaunchKernelGGL(VerifyRcpZKernel<2>, dim3(kCUs * 16), dim3(256),
+                               0, p.stream, p.flag_dev, 8);
+            ok = hipGetLastError() == hipSuccess &&
+                 hipMemcpyAsync(p.flag_host, p.flag_dev, sizeof(int),
+                                hipMemcpyDeviceToHost, p.stream) ==
+                         hipSuccess &&
+                 hipEventRecord(p.done, p.stream) == hipSuccess;
+        }
+        if (!ok) {
+            (void)hipGetLastError();
+            p.result = 0;  // could not run the proof: IEEE forms
+            DivProofReport(b, 0, -1);
+            return 0;
         }
     }
-    if (std::getenv("O3DMI_VERBOSE"))
-        std::fprintf(stderr,
-                     "[o3dmi] exact short division for sdf_trunc = %.9g: %s\n",
-                     (double)b,
-                     ok == 0 ? "not used"
-                             : (ok == 1 ? "sdf, 1/(w+1)"
-                                        : (ok == 2 ? "sdf, 1/(w+1), 1/z (1 step)"
-                                                   : "sdf, 1/(w+1), 1/z (2 steps)")));
-    cache[key] = ok;
-    return ok;
+    if (wait || always_wait) (void)hipEventSynchronize(p.done);
+    if (hipEventQuery(p.done) != hipSuccess) {
+        (void)hipGetLastError();  // hipErrorNotReady is not an error here
+        return 0;
+    }
+    const int flags = *p.flag_host;
+    p.result = flags < 0 ? 0 : DivFormsFromFlags(flags);
+    DivProofReport(b, p.result, flags);
+    // (stream, event and the two words stay allocated: freeing device memory
+    // synchronises the device, and there are a handful of distances per
+    // process)
+    return p.result;
+}
+
+int PrefetchFastDivision(float sdf_trunc, bool wait) {
+    float y;
+    return VerifyFastDivision(sdf_trunc, &y, wait);
 }
 
 // O3DMI_STEP_VARIANT (diagnostics / A-B measurements, results identical):
@@ -1354,6 +1515,7 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
     int n_int_wg = 0;
     int grid_dtype = O3DMI_U16;
     bool col = false;
+    bool raw = false;
     int fast_div = 0;
     static const double eye4[16] = {1, 0, 0, 0, 0, 1, 0, 0,
                                     0, 0, 1, 0, 0, 0, 0, 1};
@@ -1392,6 +1554,7 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         fs.out_count = f->count;
         fs.ready = f->ready;
         fs.tickets = f->ready ? f->tickets : nullptr;
+        fs.touch_status = f->ready ? f->touch_status : nullptr;
         fs.group_stamp = f->group_stamp;
         fs.touch_plane = f->touch_plane & 1;
         // one touch workgroup per 16 x 16 tile of rays
@@ -1427,7 +1590,17 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
             if (f == 0) ip.cam0 = cf;
             std::memcpy(ip.ext[f], cf.e, sizeof(ip.ext[f]));
             ip.recs[f] = a->recs[f];
+            ip.raw_depth[f] = a->raw ? a->depth[f] : nullptr;
+            ip.raw_color[f] = a->raw ? a->color_img[f] : nullptr;
         }
+        raw = a->raw;
+        O3DMI_REQUIRE(!raw || (n_fronts == 0 && a->ready != nullptr &&
+                               a->depth_scale > 0),
+                      "raw-image integrate role: ready list and depth scale "
+                      "required, no front roles");
+        ip.depth_scale = a->depth_scale;
+        ip.inv_depth_scale = raw ? 1.0f / a->depth_scale : 0.0f;
+        ip.depth_div_short = a->depth_div_short;
         ip.rows = a->rows;
         ip.cols = a->cols;
         ip.resolution = a->resolution;
@@ -1459,6 +1632,7 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         ip.status_stamp = a->status_stamp;
         ip.prof_count = a->prof_count;
         ip.prof_frame_blocks = a->prof_frame_blocks;
+        ip.prof_map_size = a->prof_map_size;
         const int n_quads =
                 (a->resolution * a->resolution * a->resolution) >>
                 (StepForm() == 2 ? 1 : 2);
@@ -1484,6 +1658,8 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
     // O3DMI_STEP_VARIANT=0 selects the first form of the integrate role
     // (diagnostics / A-B measurements); results are identical.
     const int form = StepForm();
+    O3DMI_REQUIRE(!raw || form == 2,
+                  "the raw-image integrate role exists for form 2 only");
 #define O3DMI_LAUNCH_STEP_D(WT, VT, COLOR, D)                                 \
     do {                                                                      \
         switch (form) {                                                       \
@@ -1496,8 +1672,14 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
                                    grid, block, 0, s, sp);                    \
                 break;                                                        \
             default:                                                          \
-                hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR, D, 2>),    \
-                                   grid, block, 0, s, sp);                    \
+                if (raw)                                                      \
+                    hipLaunchKernelGGL(                                       \
+                            (FrameStepKernel<WT, VT, COLOR, D, 2, true>),     \
+                            grid, block, 0, s, sp);                           \
+                else                                                          \
+                    hipLaunchKernelGGL(                                       \
+                            (FrameStepKernel<WT, VT, COLOR, D, 2>), grid,     \
+                            block, 0, s, sp);                                 \
         }                                                                     \
     } while (0)
 #define O3DMI_LAUNCH_STEP(WT, VT, COLOR)                                      \

@@ -37,6 +37,12 @@ int VdsAsync(const void* pos, const void* attr, int64_t n_max, const int* n_dev,
              hipStream_t s, int chain = 0, double next_voxel_size = 0,
              bool from_previous = false);
 
+// The calling thread's workspaces of `chain` on the current device may have
+// been left dirty by a chain that was abandoned mid-way (error return between
+// its first launch and the wait for its counts): their next user discards
+// them and starts from freshly initialised buffers.
+void VdsChainInvalidate(int chain);
+
 // counts_dev[0..n) (int) -> mail_data[0..n) (as float64) + sequence word
 // `mail_seq` (mailbox.h), on stream s; the words are zeroed afterwards.
 int PostCountsAsync(int* counts_dev, int n, double* mail_data, int* mail_flag,

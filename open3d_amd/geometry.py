@@ -285,6 +285,87 @@ class VoxelBlockGrid:
             C.c_float(trunc_voxel_multiplier), int(frames_per_launch), stream()),
             "VoxelBlockGrid.integrate_frames")
 
+    # ---- sliced block touch (block-ownership sharding; include/
+    # o3d_mi355x_host.h "SLICED block touch") --------------------------------
+
+    @staticmethod
+    def slice_chunk_frames(frames_per_launch):
+        return int(_lib.lib().o3dmi_vbg_slice_chunk_frames(
+            int(frames_per_launch)))
+
+    def set_slice_capacity(self, records_per_group, table_slots):
+        _lib.check(_lib.lib().o3dmi_vbg_set_slice_capacity(
+            self._g, int(records_per_group), int(table_slots)),
+            "VoxelBlockGrid.set_slice_capacity")
+
+    def slice_segment_bytes(self):
+        return int(_lib.lib().o3dmi_vbg_slice_segment_bytes(self._g))
+
+    def touch_slice(self, batch, lo, n, slice_rank, slice_world,
+                    depth_scale=1000.0, depth_max=3.0,
+                    trunc_voxel_multiplier=8.0, frames_per_launch=0,
+                    out=None):
+        """Wire segment (uint8 device tensor) of rank `slice_rank`'s band of
+        ray tiles for frames [lo, lo + n) of a FrameBatch (n <= one chunk)."""
+        if out is None:
+            out = torch.empty(self.slice_segment_bytes(), dtype=torch.uint8,
+                              device="cuda")
+        dptr = (C.c_void_p * n)(*[batch.dptr[lo + i] for i in range(n)])
+        Ts = np.ascontiguousarray(batch.Ts[lo:lo + n])
+        _lib.check(_lib.lib().o3dmi_vbg_touch_slice(
+            self._g, n, dptr, batch.rows, batch.cols, _lib.f64p(batch.Kd),
+            _lib.f64p(Ts), C.c_float(depth_scale), C.c_float(depth_max),
+            C.c_float(trunc_voxel_multiplier), int(frames_per_launch),
+            int(slice_rank), int(slice_world), _lib.ptr(out), stream()),
+            "VoxelBlockGrid.touch_slice")
+        return out
+
+    def gather_slices(self, batch, world, depth_scale=1000.0, depth_max=3.0,
+                      trunc_voxel_multiplier=8.0, frames_per_launch=0):
+        """What the all-gather of the sliced path delivers, computed on ONE
+        device (tests, bench.py --emulate-world): per chunk of the batch a
+        uint8 tensor holding the wire segments of ranks 0 .. world - 1."""
+        cf = self.slice_chunk_frames(frames_per_launch)
+        seg = self.slice_segment_bytes()
+        out = []
+        for lo in range(0, batch.n, cf):
+            n = min(cf, batch.n - lo)
+            buf = torch.empty(world * seg, dtype=torch.uint8, device="cuda")
+            for r in range(world):
+                self.touch_slice(batch, lo, n, r, world, depth_scale,
+                                 depth_max, trunc_voxel_multiplier,
+                                 frames_per_launch,
+                                 out=buf[r * seg:(r + 1) * seg])
+            out.append(buf)
+        return out
+
+    def integrate_frames_sliced(self, batch, gathered=None, depth_scale=1000.0,
+                                depth_max=3.0, trunc_voxel_multiplier=8.0,
+                                frames_per_launch=0):
+        """integrate_frames through the sliced path. `gathered`: list of per-
+        chunk tensors from gather_slices (or an exchange of one's own), or
+        None: all-gather over the communicator installed on this thread."""
+        gp = None
+        if gathered is not None:
+            gp = (C.c_void_p * len(gathered))(
+                *[t.data_ptr() for t in gathered])
+        _lib.check(_lib.lib().o3dmi_vbg_integrate_frames_sliced(
+            self._g, batch.n, batch.dptr, batch.rows, batch.cols, batch.cptr,
+            batch.crows, batch.ccols, batch.dtype, _lib.f64p(batch.Kd),
+            _lib.f64p(batch.Kc), _lib.f64p(batch.Ts), C.c_float(depth_scale),
+            C.c_float(depth_max), C.c_float(trunc_voxel_multiplier),
+            int(frames_per_launch), gp, stream()),
+            "VoxelBlockGrid.integrate_frames_sliced")
+
+    def sliced_stats(self):
+        ch, re = C.c_int64(0), C.c_int64(0)
+        cap, sl = C.c_int32(0), C.c_int32(0)
+        _lib.check(_lib.lib().o3dmi_vbg_sliced_stats(
+            self._g, C.byref(ch), C.byref(re), C.byref(cap), C.byref(sl)),
+            "sliced_stats")
+        return dict(chunks=ch.value, reapplied=re.value, capacity=cap.value,
+                    table_slots=sl.value)
+
     def _attr_layout(self):
         out = []
         for nm in self.attr_names:
@@ -421,6 +502,21 @@ class VoxelBlockGrid:
                     block_frames=bf.value, frames=fr.value,
                     distinct_blocks=int(
                         _lib.lib().o3dmi_vbg_profile_distinct_blocks(self._g)))
+
+    def profile_launches(self):
+        """Per bracketed launch of the last profile_end -> dict of numpy
+        arrays: ms, block_frames, distinct_blocks, map_size."""
+        import numpy as np
+        L = _lib.lib()
+        n = int(L.o3dmi_vbg_profile_launches(self._g, 0, None, None, None,
+                                             None))
+        ms = np.zeros(n, np.float32)
+        bf, db, sz = (np.zeros(n, np.int32) for _ in range(3))
+        L.o3dmi_vbg_profile_launches(
+            self._g, n, ms.ctypes.data_as(C.c_void_p),
+            bf.ctypes.data_as(C.c_void_p), db.ctypes.data_as(C.c_void_p),
+            sz.ctypes.data_as(C.c_void_p))
+        return dict(ms=ms, block_frames=bf, distinct_blocks=db, map_size=sz)
 
     def last_frame_block_coordinates(self, capacity):
         """Extension: the block coordinates the most recent integrate_frame

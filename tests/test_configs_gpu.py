@@ -71,16 +71,20 @@ def test_configs1_full_length_1000_frames_vs_reference_cpu_bodies():
             cts.append(c[i].contiguous())
             Ts.append(T[i])
     # the bench's call pattern: prepared argument blocks (prepare_frames),
-    # 8 frames per launch; 250 frames per native call here
+    # 12 frames per launch (bench.py's default group); 250 frames per native
+    # call here. The map (16 384 blocks for a stream that creates 5 745) is far
+    # below the frustum bound of one group (12 x 9 353): the groups are issued
+    # on the estimate of what they add and no Reserve happens.
     for lo in range(0, n, 250):
         batch = g.prepare_frames(dts[lo:lo + 250], cts[lo:lo + 250], K, K,
                                  Ts[lo:lo + 250])
         g.integrate_frames(batch, depth_scale=sc.DEPTH_SCALE,
                            depth_max=sc.DEPTH_MAX,
                            trunc_voxel_multiplier=sc.TRUNC_MULT,
-                           frames_per_launch=8)
+                           frames_per_launch=12)
     err, exact = _compare_grids(og, g)
     assert exact, err
+    assert g.hashmap().capacity() == cap
     assert og.weight.max() >= 150
     print("configs[1]: 1000 frames, %d blocks, max weight %d, whole grid "
           "bit-exact vs %s" % (og.h.size(), int(og.weight.max()),

@@ -377,6 +377,95 @@ def test_frame_batch_equals_oracle(group, grid_f32):
     assert g.hashmap().capacity() > 600
 
 
+def _stream_frames(ks, w=None, h=None):
+    ds, cs, Ts, K = [], [], [], None
+    for k in ks:
+        d, c, K, T = sc.frames(k, 1) if w is None else sc.frames(k, 1, w, h)
+        ds.append(d[0]); cs.append(c[0]); Ts.append(T[0])
+    dt = [torch.from_numpy(d).cuda() for d in ds]
+    ct = [torch.from_numpy(c).cuda() for c in cs]
+    return ds, cs, dt, ct, Ts, K
+
+
+def test_division_forms_are_proven_asynchronously():
+    """The short division forms of the integrate role are switched on by an
+    on-device proof that runs beside the stream (vbg_stream.hip
+    VerifyFastDivision): asking with wait = 1 returns the forms in use from
+    then on -- all three verify on gfx950."""
+    _lib, geometry = _gpu()
+    L = _lib.lib()
+    forms = L.o3dmi_vbg_division_forms(C.c_float(sc.VOXEL),
+                                       C.c_float(sc.TRUNC_MULT), 1)
+    assert forms in (2, 3), forms
+    assert L.o3dmi_vbg_division_forms(C.c_float(sc.VOXEL),
+                                      C.c_float(sc.TRUNC_MULT), 0) == forms
+
+
+@pytest.mark.parametrize("group", [4, 12])
+def test_run_ahead_on_the_estimate_needs_no_reserve(group):
+    """Capacity policy (HashMap.cpp:166-176 without a per-frame sync): a map
+    far too small for the frustum bound of a group in flight (9 353 blocks per
+    VGA frame) but large enough for what the frames really add is integrated
+    with groups issued on the ESTIMATE -- bit-identical to the oracle and
+    without a Reserve (the capacity the caller chose stays)."""
+    _lib, geometry = _gpu()
+    ds, cs, dt, ct, Ts, K = _stream_frames(list(range(100, 340, 10)))
+    og = OracleGrid(False, 16384)
+    for i in range(len(ds)):
+        og.integrate(ds[i], cs[i], K, Ts[i])
+    need = og.h.size()
+    cap = need + 1500
+    assert cap < 9353 * 2  # the strict bound of even one frame pair fails
+    g = _mk_grid(geometry, False, block_count=cap)
+    g.integrate_frames(dt, ct, K, K, Ts, sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                       sc.TRUNC_MULT, frames_per_launch=group)
+    assert _compare_grids(og, g)[1]
+    assert g.hashmap().capacity() == cap
+    # and once more over the same frames (no block is new any more)
+    for i in range(len(ds)):
+        og.integrate(ds[i], cs[i], K, Ts[i])
+    g.integrate_frames(dt, ct, K, K, Ts, sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                       sc.TRUNC_MULT, frames_per_launch=group)
+    assert _compare_grids(og, g)[1]
+    assert g.hashmap().capacity() == cap
+
+
+@pytest.mark.parametrize("group,slack", [(1, 40), (3, 5), (4, 200), (8, 1),
+                                         (12, 300), (16, 64)])
+def test_group_that_overflows_the_map_is_dropped_and_replayed(group, slack):
+    """A group issued on the estimate that runs out of buffer indices is
+    dropped on the device as a whole, with every group behind it; the host
+    reserves (max(wanted, 2 x capacity), the reference's growth rule) and
+    replays from the dropped group's first frame: the grid equals the
+    frame-by-frame oracle bit for bit wherever in the stream the map fills
+    up."""
+    _lib, geometry = _gpu()
+    ks = [(i * 53) % 600 for i in range(30)]  # a view that jumps: new blocks
+    ds, cs, dt, ct, Ts, K = _stream_frames(ks, 320, 240)
+    og = OracleGrid(False, 32768)
+    sizes = []
+    for i in range(len(ds)):
+        og.integrate(ds[i], cs[i], K, Ts[i])
+        sizes.append(og.h.size())
+    cap = sizes[len(sizes) // 2] + slack  # fills up in the middle of the call
+    assert cap < sizes[-1]
+    g = _mk_grid(geometry, False, block_count=cap)
+    g.integrate_frames(dt, ct, K, K, Ts, sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                       sc.TRUNC_MULT, frames_per_launch=group)
+    assert _compare_grids(og, g)[1]
+    assert g.hashmap().capacity() >= 2 * cap
+    # the map is a normal map afterwards: two-step API on top of it
+    d, c, K2, T = sc.frames(700, 1, 320, 240)
+    og.integrate(d[0], c[0], K, T[0])
+    keys = g.compute_unique_block_coordinates(torch.from_numpy(d[0]).cuda(), K,
+                                              T[0], sc.DEPTH_SCALE,
+                                              sc.DEPTH_MAX, sc.TRUNC_MULT)
+    g.integrate(keys, torch.from_numpy(d[0]).cuda(),
+                torch.from_numpy(c[0]).cuda(), K, K, T[0], sc.DEPTH_SCALE,
+                sc.DEPTH_MAX, sc.TRUNC_MULT)
+    assert _compare_grids(og, g)[1]
+
+
 def _all_blocks(g):
     """{key: (tsdf, weight, colour) bytes} of every active block."""
     hm = g.hashmap()
@@ -786,6 +875,103 @@ def test_block_ownership_sharding_is_bit_identical(path):
             assert a.tobytes() == b[sel].tobytes()
         total += part[0].shape[0]
     assert total == full[0].shape[0]
+
+
+def _blocks_sorted(g, with_color=True):
+    hm = g.hashmap()
+    act = hm.active_buf_indices().cpu().numpy().astype(np.int64)
+    keys = hm.key_tensor().cpu().numpy()[act]
+    order = np.lexsort(keys.T[::-1])
+    out = [keys[order], g.attribute("tsdf").cpu().numpy()[act][order],
+           g.attribute("weight").cpu().numpy()[act][order]]
+    if with_color:
+        out.append(g.attribute("color").cpu().numpy()[act][order])
+    return out
+
+
+@pytest.mark.parametrize("world,group,grid_f32,with_color", [
+    (1, 4, False, True), (3, 2, False, True), (8, 3, False, True),
+    (8, 12, False, True), (2, 16, True, True), (4, 5, False, False)])
+def test_sliced_touch_ownership_union_is_the_single_grid(world, group,
+                                                         grid_f32, with_color):
+    """SURVEY 8(e) scheme A as specified: rank r touches only its band of ray
+    tiles, the candidate records of all ranks are gathered (here computed on
+    one device: gather_slices), rank r activates the keys it owns and
+    integrates them from the RAW images. The `world` grids are the ownership
+    classes of the single grid the ordinary stream builds, bit for bit --
+    several chunks per call, groups that do not divide the chunk, depth-only
+    and float32 grids."""
+    _lib, geometry = _gpu()
+    from open3d_amd import sharding
+    n = 2 * 16 * group + 3 if group <= 3 else 16 * group + 5
+    ks = [(i * 7) % 900 for i in range(n)]
+    ds, cs, dt, ct, Ts, K = _stream_frames(ks, 320, 240)
+    full_g = _mk_grid(geometry, grid_f32, block_count=8192,
+                      with_color=with_color)
+    full_g.integrate_frames(dt, ct if with_color else None, K, K, Ts,
+                            sc.DEPTH_SCALE, sc.DEPTH_MAX, sc.TRUNC_MULT,
+                            frames_per_launch=group)
+    full = _blocks_sorted(full_g, with_color)
+    owner = sharding.block_owner(full[0], world)
+    total = 0
+    gathered = None
+    for r in range(world):
+        g = _mk_grid(geometry, grid_f32, block_count=8192,
+                     with_color=with_color)
+        g.set_block_ownership(r, world)
+        batch = g.prepare_frames(dt, ct if with_color else None, K, K, Ts)
+        if gathered is None:
+            gathered = g.gather_slices(batch, world, sc.DEPTH_SCALE,
+                                       sc.DEPTH_MAX, sc.TRUNC_MULT, group)
+            assert len(gathered) == -(-n // (16 * group))
+        g.integrate_frames_sliced(batch, [t.clone() for t in gathered],
+                                  sc.DEPTH_SCALE, sc.DEPTH_MAX, sc.TRUNC_MULT,
+                                  frames_per_launch=group)
+        part = _blocks_sorted(g, with_color)
+        sel = owner == r
+        assert np.array_equal(part[0], full[0][sel]), r
+        for a, b in zip(part[1:], full[1:]):
+            assert a.tobytes() == b[sel].tobytes(), r
+        total += part[0].shape[0]
+        assert g.sliced_stats()["reapplied"] == 0
+    assert total == full[0].shape[0]
+
+
+def test_sliced_touch_reserves_and_applies_the_chunk_again():
+    """A block map too small for a chunk's keys: the chunk is dropped on the
+    device, the map reserved and the SAME gathered records applied again; a
+    wire segment too small for a slice is an error when the segments are the
+    caller's."""
+    _lib, geometry = _gpu()
+    ks = [(i * 11) % 900 for i in range(70)]
+    ds, cs, dt, ct, Ts, K = _stream_frames(ks, 320, 240)
+    og = OracleGrid(False, 16384)
+    for i in range(len(ds)):
+        og.integrate(ds[i], cs[i], K, Ts[i])
+    g = _mk_grid(geometry, False, block_count=300)
+    batch = g.prepare_frames(dt, ct, K, K, Ts)
+    gathered = g.gather_slices(batch, 1, sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                               sc.TRUNC_MULT, 4)
+    g.integrate_frames_sliced(batch, gathered, sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                              sc.TRUNC_MULT, frames_per_launch=4)
+    assert _compare_grids(og, g)[1]
+    st = g.sliced_stats()
+    assert st["reapplied"] >= 1 and g.hashmap().capacity() >= og.h.size()
+    # the ordinary stream continues on the same map
+    d, c, K2, T = sc.frames(950, 1, 320, 240)
+    og.integrate(d[0], c[0], K, T[0])
+    g.integrate_frame(torch.from_numpy(d[0]).cuda(),
+                      torch.from_numpy(c[0]).cuda(), K, K, T[0],
+                      sc.DEPTH_SCALE, sc.DEPTH_MAX, sc.TRUNC_MULT)
+    assert _compare_grids(og, g)[1]
+    g2 = _mk_grid(geometry, False, block_count=8192)
+    g2.set_slice_capacity(16, 64)
+    b2 = g2.prepare_frames(dt, ct, K, K, Ts)
+    small = g2.gather_slices(b2, 1, sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                             sc.TRUNC_MULT, 4)
+    with pytest.raises(_lib.O3DMIError):
+        g2.integrate_frames_sliced(b2, small, sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                                   sc.TRUNC_MULT, frames_per_launch=4)
 
 
 def _sorted_blocks(g):
