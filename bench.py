@@ -88,12 +88,14 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8000,
                     help="frames per step (per GPU)")
-    ap.add_argument("--block-count", type=int, default=524288,
-                    help="initial hash capacity; the stream needs ~6 k blocks, "
-                         "the rest is head-room that lets the host issue "
-                         "several frame groups ahead of the GPU without "
-                         "waiting for the map size (capacity policy of "
-                         "HashMap::Activate: 12-frame groups need 524 288)")
+    ap.add_argument("--block-count", type=int, default=50000,
+                    help="initial hash capacity: the reference's advised map "
+                         "size (docs/tutorial/t_reconstruction_system/"
+                         "voxel_block_grid.rst: 50 000; the stream creates "
+                         "5 745 blocks). Rounds 1-3 needed 524 288 here for "
+                         "the run-ahead bound of 12-frame groups; since round "
+                         "4 groups are issued on an estimate of what they add "
+                         "(within 0.4 % of the 524 288 figure)")
     ap.add_argument("--frames-per-launch", type=int, default=12,
                     help="consecutive frames applied per launch to register-"
                          "resident blocks (1..16); results are identical. 12: "
@@ -114,6 +116,17 @@ def parse():
                          "of an N-rank job on this GPU (no collective) to "
                          "read the per-rank cost of both schemes")
     ap.add_argument("--emulate-rank", type=int, default=0)
+    ap.add_argument("--touch", choices=["sliced", "replicated"],
+                    default="sliced",
+                    help="block-ownership scheme at N > 1: `sliced` = rank r "
+                         "touches its band of ray tiles, candidate keys are "
+                         "all-gathered per chunk of 16 launches, blocks are "
+                         "integrated from the raw images (SURVEY 8(e) as "
+                         "specified); `replicated` = every rank runs the "
+                         "whole front role (rounds 1-3)")
+    ap.add_argument("--force-sliced", action="store_true",
+                    help="diagnostics: the sliced path (band touch, gathered "
+                         "records, raw-image integrate role) on ONE rank")
     ap.add_argument("--depth-only", action="store_true",
                     help="diagnostics: grid without colour (tsdf + weight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -369,7 +382,7 @@ C4_DEPTH_SCALE = 500.0    # the same images read at twice the metric depth
 C4_DEPTH_MAX = 6.0
 C4_CAPACITY = 1 << 21     # 2 M blocks = 96 GiB of voxel state
 C4_BALLAST = 540000       # active blocks before the stream starts
-C4_FRAMES_PER_LAUNCH = 4
+C4_FRAMES_PER_LAUNCH = 12
 C4_FRAME_STEP = 5         # every 5th frame of the 1000-frame stream
 
 
@@ -971,6 +984,13 @@ def main():
     # the library's own collectives: RCCL inside the library when the job runs
     # on it, torch.distributed calls (gloo) for the dry run
     comm = Comm.for_backend(dist) if dist is not None else None
+    if comm is not None and a.touch == "sliced":
+        # integrate_frames on a grid with block ownership then splits the
+        # touch over the ranks and all-gathers the candidate keys (RCCL inside
+        # the library on the "nccl" backend)
+        comm.install()
+    elif a.touch == "replicated":
+        os.environ["O3DMI_NO_SLICED_TOUCH"] = "1"
     # share of the job this process does: (rank, world) of the real job, or
     # of the emulated one
     e_world = a.emulate_world if (world == 1 and a.emulate_world > 1) else world
@@ -997,8 +1017,10 @@ def main():
                 ["tsdf", "weight", "color"],
                 [torch.float32, torch.uint16, torch.uint16], [1, 1, 3], VOXEL,
                 RES, a.block_count)
+        g.owner_world = 1
         if owner is not None:
             g.set_block_ownership(*owner)
+            g.owner_world = owner[1]
         return g
 
     def barrier():
@@ -1013,13 +1035,24 @@ def main():
         # and pose arrays are marshalled once (a C++ caller would hand the
         # arrays over as they are), keyed by the slice of the stream.
         prepared = {}
+        # One rank's share of an N-rank job on this GPU with the sliced touch:
+        # what the all-gather would deliver (every rank's wire segments, per
+        # chunk) is computed once per slice of the stream, OUTSIDE the timed
+        # region; inside it the rank touches its own band, copies the
+        # gathered segments (the stand-in for the collective) and applies them.
+        sliced_emu = (world == 1 and a.touch == "sliced" and
+                      (g.owner_world > 1 or a.force_sliced))
 
         def batch_of(lo, m):
             if (lo, m) not in prepared:
-                prepared[(lo, m)] = g.prepare_frames(
+                b = g.prepare_frames(
                     depths[lo:lo + m],
                     colors[lo:lo + m] if colors is not None else None, K, K,
                     Ts[lo:lo + m])
+                gath = g.gather_slices(
+                    b, max(1, g.owner_world), DEPTH_SCALE, DEPTH_MAX, TRUNC,
+                    a.frames_per_launch) if sliced_emu else None
+                prepared[(lo, m)] = (b, gath)
             return prepared[(lo, m)]
 
         def run_step(s):
@@ -1027,10 +1060,17 @@ def main():
             left = a.batch
             while left > 0:
                 m = min(left, n_u - lo)
-                g.integrate_frames(batch_of(lo, m), depth_scale=DEPTH_SCALE,
-                                   depth_max=DEPTH_MAX,
-                                   trunc_voxel_multiplier=TRUNC,
-                                   frames_per_launch=a.frames_per_launch)
+                b, gath = batch_of(lo, m)
+                if gath is not None:
+                    g.integrate_frames_sliced(
+                        b, gath, depth_scale=DEPTH_SCALE, depth_max=DEPTH_MAX,
+                        trunc_voxel_multiplier=TRUNC,
+                        frames_per_launch=a.frames_per_launch)
+                else:
+                    g.integrate_frames(b, depth_scale=DEPTH_SCALE,
+                                       depth_max=DEPTH_MAX,
+                                       trunc_voxel_multiplier=TRUNC,
+                                       frames_per_launch=a.frames_per_launch)
                 left -= m
                 lo = (lo + m) % n_u
 
@@ -1275,6 +1315,7 @@ def main():
                    "avg_blocks_per_frame": prof["block_frames"] /
                                            max(1, prof["frames"]),
                    "sharding": sharding,
+                   "touch": (a.touch if by_blocks else None),
                    "merge_ms": merge_ms,
                    "dist_backend": a.dist_backend if world > 1 else None,
                    "dry_run": (world > 1 and a.dist_backend == "gloo") or None,

@@ -405,25 +405,27 @@ int o3dmi_vbg_integrate_frames(o3dmi_vbg_t* g, int n_frames,
  * With o3dmi_vbg_set_block_ownership(rank, world > 1) AND a communicator on the
  * calling thread (o3dmi_set_comm), o3dmi_vbg_integrate_frames takes this path
  * by itself whenever depth and colour images share size and intrinsics:
- * frames go in chunks of 16 launches; on a side stream rank r touches only its
- * band of ray tiles, the candidate {block key, frame bits} records of all
- * ranks are all-gathered (ONE collective per chunk, fixed-size segments) and
- * the keys a rank owns are activated; on the caller's stream one launch per
- * group integrates the owned blocks straight from the raw depth / colour
- * images (no per-pixel prepare pass). Each rank's grid is bit-identical to
- * what the replicated touch produces: the blocks it owns of the single-GPU
- * grid. The functions below expose the two halves for callers with their own
- * exchange, for tests and for bench.py --emulate-world. */
+ * frames go in chunks of 16 x frames_per_launch (<= 256); on a side stream
+ * rank r touches only its band of ray tiles, the candidate {block key, one bit
+ * per frame of the chunk} records of all ranks are all-gathered (ONE
+ * collective per chunk, fixed-size segments) and the keys a rank owns are
+ * activated; on the caller's stream ONE launch per chunk applies all its
+ * frames, in order, to the owned blocks' register-resident voxels, straight
+ * from the raw depth / colour images (no per-pixel prepare pass). Each rank's
+ * grid is bit-identical to what the replicated touch produces: the blocks it
+ * owns of the single-GPU grid. The functions below expose the two halves for
+ * callers with their own exchange, for tests and for bench.py
+ * --emulate-world. */
 
 /* Frames per chunk for a frames_per_launch setting (16 launches). */
 int o3dmi_vbg_slice_chunk_frames(int frames_per_launch);
-/* Wire format sizes: a rank's segment holds 16 x records_per_group 16-byte
- * records + a 128-byte header. Default 1024 records per (rank, launch) and
- * per-launch tables of 8192 slots; with a communicator both double by
- * themselves when a chunk does not fit (every rank reads the same headers and
- * takes the same decision), with caller-provided segments an overflow is
+/* Wire format sizes: a rank's segment of a chunk holds `records` 48-byte
+ * records {key, 256 frame bits} + a 128-byte header. Default 4096 records and
+ * chunk tables of 8192 slots; with a communicator both double by themselves
+ * when a chunk does not fit (every rank reads the same headers and takes the
+ * same decision), with caller-provided segments an overflow is
  * O3DMI_ERR_CAPACITY. */
-int o3dmi_vbg_set_slice_capacity(o3dmi_vbg_t* g, int records_per_group,
+int o3dmi_vbg_set_slice_capacity(o3dmi_vbg_t* g, int records,
                                  int table_slots);
 int64_t o3dmi_vbg_slice_segment_bytes(const o3dmi_vbg_t* g);
 /* Rank slice_rank's band of the ray tiles of up to one chunk of frames ->

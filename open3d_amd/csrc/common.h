@@ -245,7 +245,8 @@ struct HashView {
 // key during the walk and a stale read is always corrected by the CAS result.
 __device__ __forceinline__ int ClaimSlot(const HashView& hv,
                                          unsigned long long k,
-                                         unsigned& slot_out) {
+                                         unsigned& slot_out,
+                                         bool report_wrap = true) {
     constexpr unsigned kNone = 0xFFFFFFFFu;
     unsigned h = HashKey(k) & hv.mask;
     unsigned tomb = kNone;
@@ -298,7 +299,7 @@ __device__ __forceinline__ int ClaimSlot(const HashView& hv,
             walked = 0;
         }
     }
-    atomicOr(&hv.counters[1], kErrProbe);
+    if (report_wrap) atomicOr(&hv.counters[1], kErrProbe);
     return -1;
 }
 

@@ -111,18 +111,20 @@ struct o3dmi_vbg {
         hipEvent_t ev_side[2] = {nullptr, nullptr};  // chunk set ready
         hipEvent_t ev_main[2] = {nullptr, nullptr};  // chunk set consumed
         hipEvent_t ev_enter = nullptr;
-        GroupTables send_tables = {}, recv_tables = {};
+        ChunkTable send_table = {}, recv_table = {};
         int table_slots = 0;
-        int capacity = 0;  // records per (rank, group) of a wire segment
+        int capacity = 0;  // records of a wire segment
         int world = 0;
         void* send_seg[2] = {nullptr, nullptr};
         void* gathered[2] = {nullptr, nullptr};
-        ReadyEntry* ready[2] = {nullptr, nullptr};  // [kChunkGroups][ready_cap]
-        int* ready_count[2] = {nullptr, nullptr};   // device int[kChunkGroups]
-        int ready_cap = 0;
-        SliceFrame* frames_dev = nullptr;
+        ChunkEntry* entries[2] = {nullptr, nullptr};  // [entries_cap]
+        int* entries_count[2] = {nullptr, nullptr};   // device int
+        int entries_cap = 0;
+        SliceFrame* frames_dev = nullptr;   // touch: pose (inverse extrinsic)
+        IntegFrame* iframes_dev = nullptr;  // integrate: extrinsic + images
         int64_t frames_cap = 0;
         std::vector<SliceFrame> frames_host;
+        std::vector<IntegFrame> iframes_host;
         int64_t chunks_done = 0;  // statistics (o3dmi_vbg_sliced_stats)
         int64_t reapplied = 0;
     } sliced;
@@ -917,9 +919,8 @@ static Issue StreamMayIssue(o3dmi_vbg* g, int64_t strict_new, bool allow_est,
 // every issued group has reported (they complete without the host), then
 // applies the policy to the exact size. With `allow_est` a drained map that is
 // not full issues the group whatever the bounds say -- the device reports an
-// overflow and the caller recovers -- unless even the estimate says it cannot
-// fit, in which case the map is reserved first (max(need, 2 x capacity), the
-// reference's growth rule).
+// overflow and the caller recovers (Reserve to max(wanted, 2 x capacity), the
+// reference's growth rule, then replay).
 static int StreamEnsureCapacity(o3dmi_vbg* g, int64_t strict_new,
                                 bool allow_est, hipStream_t s, Issue* how,
                                 int* overflow) {
@@ -950,9 +951,10 @@ static int StreamEnsureCapacity(o3dmi_vbg* g, int64_t strict_new,
     if (st) return st;
     SetExactSize(g, size);
     const int64_t capacity = o3dmi_hash_capacity(g->block_hashmap);
-    const int64_t need_new =
-            allow_est ? (g->recent_n ? EstimatedGroupNew(g, strict_new) : 1)
-                      : strict_new;
+    // Drained, on the estimate: go unless the map is outright full -- an
+    // overflow is recoverable (drop + replay), a Reserve the stream did not
+    // need is not. The estimate only decides how far AHEAD groups are issued.
+    const int64_t need_new = allow_est ? 1 : strict_new;
     if (size + need_new > capacity) {
         const int64_t need = size + need_new;
         const int64_t target = need > capacity * 2 ? need : capacity * 2;
@@ -1078,9 +1080,6 @@ static void MakeIntegArgs(o3dmi_vbg* g, const StreamCommon& c,
     ia->prof_frame_blocks = prof ? g->prof_counts + g->prof_frames : nullptr;
     ia->prof_map_size =
             prof ? g->prof_counts + 2 * g->prof_max + g->prof_frames : nullptr;
-    ia->raw = false;
-    ia->depth_scale = c.depth_scale;
-    ia->depth_div_short = false;
 }
 
 static bool StreamPathApplies(const o3dmi_vbg* g, int input_dtype) {
@@ -1271,40 +1270,44 @@ static void FreeSliced(o3dmi_vbg* g) {
         if (z.ev_main[i]) (void)hipEventDestroy(z.ev_main[i]);
         (void)hipFree(z.send_seg[i]);
         (void)hipFree(z.gathered[i]);
-        (void)hipFree(z.ready[i]);
-        (void)hipFree(z.ready_count[i]);
+        (void)hipFree(z.entries[i]);
+        (void)hipFree(z.entries_count[i]);
     }
     if (z.ev_enter) (void)hipEventDestroy(z.ev_enter);
     if (z.table_slots) {
-        FreeGroupTables(&z.send_tables);
-        FreeGroupTables(&z.recv_tables);
+        FreeChunkTable(&z.send_table);
+        FreeChunkTable(&z.recv_table);
     }
     (void)hipFree(z.frames_dev);
+    (void)hipFree(z.iframes_dev);
     z = o3dmi_vbg::Sliced();
 }
 
-// Buffers for `world` ranks, `capacity` records per (rank, group) on the wire
-// and per-group tables of `slots` slots. Growing frees and re-creates
-// everything (the streams are drained first).
+// Buffers for `world` ranks, `capacity` records per wire segment and chunk
+// tables of `slots` slots. Growing frees and re-creates everything (the
+// streams are drained first).
 static int EnsureSliced(o3dmi_vbg* g, int world, int capacity, int slots,
                         hipStream_t s) {
     o3dmi_vbg::Sliced& z = g->sliced;
     if (z.side && z.world >= world && z.capacity >= capacity &&
         z.table_slots >= slots)
         return O3DMI_OK;
-    if (z.side) {
-        O3DMI_HIP_CHECK(hipStreamSynchronize(z.side));
-        O3DMI_HIP_CHECK(hipStreamSynchronize(s));
-    }
+    if (z.side) O3DMI_HIP_CHECK(hipDeviceSynchronize());
     if (world < z.world) world = z.world;
     if (capacity < z.capacity) capacity = z.capacity;
     if (slots < z.table_slots) slots = z.table_slots;
     SliceFrame* keep_frames = z.frames_dev;
+    IntegFrame* keep_iframes = z.iframes_dev;
     const int64_t keep_cap = z.frames_cap;
+    const int64_t keep_chunks = z.chunks_done, keep_re = z.reapplied;
     z.frames_dev = nullptr;
+    z.iframes_dev = nullptr;
     FreeSliced(g);
     z.frames_dev = keep_frames;
+    z.iframes_dev = keep_iframes;
     z.frames_cap = keep_cap;
+    z.chunks_done = keep_chunks;
+    z.reapplied = keep_re;
     O3DMI_HIP_CHECK(hipStreamCreateWithFlags(&z.side, hipStreamNonBlocking));
     const int64_t seg = SliceSegmentBytes(capacity);
     for (int i = 0; i < 2; ++i) {
@@ -1314,42 +1317,46 @@ static int EnsureSliced(o3dmi_vbg* g, int world, int capacity, int slots,
                                                 hipEventDisableTiming));
         O3DMI_HIP_CHECK(hipMalloc(&z.send_seg[i], (size_t)seg));
         O3DMI_HIP_CHECK(hipMalloc(&z.gathered[i], (size_t)seg * world));
-        O3DMI_HIP_CHECK(hipMalloc((void**)&z.ready[i],
-                                  sizeof(ReadyEntry) * (size_t)kChunkGroups *
-                                          (size_t)(slots / 2)));
-        O3DMI_HIP_CHECK(hipMalloc((void**)&z.ready_count[i],
-                                  sizeof(int) * kChunkGroups));
-        O3DMI_HIP_CHECK(hipMemsetAsync(z.ready_count[i], 0,
-                                       sizeof(int) * kChunkGroups, z.side));
+        O3DMI_HIP_CHECK(hipMalloc((void**)&z.entries[i],
+                                  sizeof(ChunkEntry) * (size_t)(slots / 2)));
+        O3DMI_HIP_CHECK(hipMalloc((void**)&z.entries_count[i], sizeof(int)));
+        O3DMI_HIP_CHECK(hipMemsetAsync(z.entries_count[i], 0, sizeof(int),
+                                       z.side));
     }
     O3DMI_HIP_CHECK(hipEventCreateWithFlags(&z.ev_enter, hipEventDisableTiming));
     int st;
-    if ((st = AllocGroupTables(&z.send_tables, slots, false, z.side))) return st;
-    if ((st = AllocGroupTables(&z.recv_tables, slots, true, z.side))) return st;
+    if ((st = AllocChunkTable(&z.send_table, slots, false, z.side))) return st;
+    if ((st = AllocChunkTable(&z.recv_table, slots, true, z.side))) return st;
     z.table_slots = slots;
-    z.ready_cap = slots / 2;
+    z.entries_cap = slots / 2;
     z.capacity = capacity;
     z.world = world;
     O3DMI_HIP_CHECK(hipStreamSynchronize(z.side));
     return O3DMI_OK;
 }
 
-// Per-frame table of the side-stream kernels (pose as TouchParams keeps it).
+// Per-frame tables of the side-stream touch (pose as TouchParams keeps it) and
+// of the chunk integrate launch (extrinsic as Camera::Make keeps it, images).
 static int UploadSliceFrames(o3dmi_vbg* g, const StreamCommon& c,
-                             const StreamFrame* frames, int n, hipStream_t side,
+                             const StreamFrame* frames, int n,
                              TouchParams* shared) {
     o3dmi_vbg::Sliced& z = g->sliced;
     if (z.frames_cap < n) {
-        if (z.frames_dev) O3DMI_HIP_CHECK(hipStreamSynchronize(side));
+        if (z.frames_dev) O3DMI_HIP_CHECK(hipDeviceSynchronize());
         (void)hipFree(z.frames_dev);
+        (void)hipFree(z.iframes_dev);
         z.frames_dev = nullptr;
+        z.iframes_dev = nullptr;
         int64_t cap = 256;
         while (cap < n) cap <<= 1;
         O3DMI_HIP_CHECK(hipMalloc((void**)&z.frames_dev,
                                   sizeof(SliceFrame) * (size_t)cap));
+        O3DMI_HIP_CHECK(hipMalloc((void**)&z.iframes_dev,
+                                  sizeof(IntegFrame) * (size_t)cap));
         z.frames_cap = cap;
     }
     z.frames_host.resize((size_t)n);
+    z.iframes_host.resize((size_t)n);
     for (int f = 0; f < n; ++f) {
         const TouchParams tp = MakeTouchParams(
                 c.depth_intrinsic, frames[f].extrinsic, c.depth_rows,
@@ -1359,13 +1366,23 @@ static int UploadSliceFrames(o3dmi_vbg* g, const StreamCommon& c,
                     sizeof(z.frames_host[(size_t)f].pose));
         z.frames_host[(size_t)f].depth = (const uint16_t*)frames[f].depth;
         if (f == 0) *shared = tp;
+        const Camera cf = Camera::Make(c.depth_intrinsic, frames[f].extrinsic,
+                                       g->voxel_size);
+        std::memcpy(z.iframes_host[(size_t)f].ext, cf.e,
+                    sizeof(z.iframes_host[(size_t)f].ext));
+        z.iframes_host[(size_t)f].depth = (const uint16_t*)frames[f].depth;
+        z.iframes_host[(size_t)f].color =
+                c.with_color ? (const uint8_t*)frames[f].color : nullptr;
     }
-    // Synchronous: the table is free (every touch launch of the previous call
-    // was waited for through its chunk status before that call returned) and
-    // complete before the first launch below is issued.
-    (void)side;
+    // Synchronous copies: the tables are free (every launch of the previous
+    // call that reads them has completed: the touch launches were waited for
+    // through their chunk status, the integrate launches by the wait below)
+    // and complete before the first launch of this call is issued.
     O3DMI_HIP_CHECK(hipMemcpy(z.frames_dev, z.frames_host.data(),
                               sizeof(SliceFrame) * (size_t)n,
+                              hipMemcpyHostToDevice));
+    O3DMI_HIP_CHECK(hipMemcpy(z.iframes_dev, z.iframes_host.data(),
+                              sizeof(IntegFrame) * (size_t)n,
                               hipMemcpyHostToDevice));
     return O3DMI_OK;
 }
@@ -1398,19 +1415,6 @@ static int WaitChunkStatus(o3dmi_vbg* g, int stamp, hipStream_t side,
     }
 }
 
-// Can this call take the sliced path? Depth and colour images of one size and
-// intrinsics (the raw-image integrate role gathers both at the depth pixel),
-// uint16 depth, the wide 2-voxel form of the role.
-static bool SlicedPathApplies(o3dmi_vbg* g, const StreamCommon& c,
-                              const StreamFrame* frames, int n) {
-    if (n <= 0 || !g->prep_valid || !g->prep_identity) return false;
-    if ((c.depth_cols % 4) != 0) return false;
-    const char* e = std::getenv("O3DMI_STEP_VARIANT");
-    if (e && e[0] != '2') return false;
-    (void)frames;
-    return true;
-}
-
 // The frames of one call through the sliced path. `gathered_in`: per chunk the
 // `world` wire segments of all ranks (emulation / tests: the stand-in for the
 // all-gather; the own segment is replaced by the one computed here), or null:
@@ -1427,10 +1431,6 @@ static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
     O3DMI_REQUIRE(!comm || (comm->world == world && comm->rank == rank),
                   "sliced touch: the communicator's rank / world differ from "
                   "the grid's block ownership");
-    c.frame_new = FrustumBlockBound(
-            c.depth_intrinsic, c.depth_rows, c.depth_cols, c.depth_max,
-            g->voxel_size * (float)g->block_resolution, 4);
-    O3DMI_REQUIRE(c.frame_new > 0, "depth image too small");
     c.ti = g->AttrIndex("tsdf");
     c.wi = g->AttrIndex("weight");
     c.ci = g->AttrIndex("color");
@@ -1438,29 +1438,39 @@ static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
                    n > 0 && frames[0].color != nullptr;
     int st = GridDtype(g, &c.grid_dtype);
     if (st) return st;
-    if ((st = EnsureStreamBuffers(g, c.depth_rows, c.depth_cols,
-                                  c.frame_new * kMaxGroup)))
+    O3DMI_REQUIRE((c.depth_cols % 4) == 0 &&
+                          (!c.with_color || (c.color_rows == c.depth_rows &&
+                                             c.color_cols == c.depth_cols)),
+                  "sliced touch needs depth and colour images of one size "
+                  "(width % 4 == 0)");
+    // status words, depth-division verdict (PrepTables) for this depth scale
+    if ((st = EnsureStreamBuffers(g, c.depth_rows, c.depth_cols, 1024)))
         return st;
     if ((st = EnsurePrepTables(g, c.depth_intrinsic, c.color_intrinsic,
                                c.depth_rows, c.depth_cols, c.color_rows,
                                c.color_cols, c.depth_scale, s)))
         return st;
-    O3DMI_REQUIRE(SlicedPathApplies(g, c, frames, n),
-                  "sliced touch needs depth and colour images of one size and "
-                  "intrinsics (width % 4 == 0)");
+    O3DMI_REQUIRE(!c.with_color || g->prep_identity,
+                  "sliced touch needs the same intrinsics for depth and "
+                  "colour");
     o3dmi_vbg::Sliced& z = g->sliced;
-    // Sizes: a rank's band sees about 1 / world of a group's blocks plus the
+    // Sizes: a rank's band sees about 1 / world of a chunk's blocks plus the
     // band's rim; start from a generous guess and double on overflow (every
     // rank reads the same headers, so every rank doubles together).
-    int capacity = z.capacity ? z.capacity : 1024;
-    int slots = z.table_slots ? z.table_slots : g->sliced_slots_wanted;
-    if ((st = EnsureSliced(g, world, capacity, slots, s))) return st;
+    if ((st = EnsureSliced(g, world, z.capacity ? z.capacity : 4096,
+                           z.table_slots ? z.table_slots
+                                         : g->sliced_slots_wanted,
+                           s)))
+        return st;
 
+    // every launch of the previous call that reads the frame tables is over
+    // once its last integrate launch is (the side stream waited for it)
+    O3DMI_HIP_CHECK(hipStreamSynchronize(z.side));
     TouchParams shared;
+    if ((st = UploadSliceFrames(g, c, frames, n, &shared))) return st;
     // the caller's images may still be in flight on its stream
     O3DMI_HIP_CHECK(hipEventRecord(z.ev_enter, s));
     O3DMI_HIP_CHECK(hipStreamWaitEvent(z.side, z.ev_enter, 0));
-    if ((st = UploadSliceFrames(g, c, frames, n, z.side, &shared))) return st;
 
     const int chunk_frames = kChunkGroups * group;
     const int n_chunks = (n + chunk_frames - 1) / chunk_frames;
@@ -1472,13 +1482,13 @@ static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
         const int nc = n - f0 < chunk_frames ? n - f0 : chunk_frames;
         int st2;
         if (touch) {
-            // the set's ready lists were read by chunk ci - 2's launches
+            // the set's work list was read by chunk ci - 2's launch
             if (ci >= 2)
                 O3DMI_HIP_CHECK(hipStreamWaitEvent(z.side, z.ev_main[set], 0));
-            if ((st2 = LaunchTouchSlice(shared, z.frames_dev, f0, nc, group,
-                                        rank, world, z.send_tables, z.side)))
+            if ((st2 = LaunchTouchSlice(shared, z.frames_dev, f0, nc, rank,
+                                        world, z.send_table, z.side)))
                 return st2;
-            if ((st2 = LaunchPackSlice(z.send_tables, z.send_seg[set],
+            if ((st2 = LaunchPackSlice(z.send_table, z.send_seg[set],
                                        z.capacity, z.side)))
                 return st2;
             const int64_t seg = SliceSegmentBytes(z.capacity);
@@ -1500,15 +1510,13 @@ static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
         }
         g->frame_stamp += 1;
         chunk_stamp[(size_t)ci] = g->frame_stamp;
-        O3DMI_HIP_CHECK(hipMemsetAsync(z.recv_tables.flags, 0, sizeof(int),
-                                       z.side));
         if ((st2 = LaunchApplySlice(g->block_hashmap, z.gathered[set], world,
-                                    z.capacity, z.recv_tables, g->frame_stamp,
+                                    z.capacity, z.recv_table, g->frame_stamp,
                                     z.side)))
             return st2;
-        if ((st2 = LaunchBuildReady(g->block_hashmap, z.recv_tables,
-                                    z.ready[set], z.ready_cap,
-                                    z.ready_count[set],
+        if ((st2 = LaunchBuildChunk(g->block_hashmap, z.recv_table,
+                                    z.entries[set], z.entries_cap,
+                                    z.entries_count[set],
                                     (int*)g->stream_status + 4, g->frame_stamp,
                                     z.side)))
             return st2;
@@ -1523,8 +1531,8 @@ static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
         const int nc = n - f0 < chunk_frames ? n - f0 : chunk_frames;
         // What the chunk's apply found: normally long there (it was issued a
         // chunk ago).
+        ChunkStatus cs = {};
         for (int attempt = 0;; ++attempt) {
-            ChunkStatus cs;
             if ((st = WaitChunkStatus(g, chunk_stamp[(size_t)ci], z.side, &cs)))
                 return st;
             if (cs.overflow == 0) break;
@@ -1546,9 +1554,9 @@ static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
                 O3DMI_HIP_CHECK(hipStreamSynchronize(s));
                 if ((st = issue_side(ci, false))) return st;
             } else {
-                // a wire segment or a per-group table was too small (the
-                // flags travel in the all-gathered headers: every rank takes
-                // this branch for the same chunk): double both, touch again
+                // a wire segment or a chunk table was too small (the flags
+                // travel in the all-gathered headers: every rank takes this
+                // branch for the same chunk): double both, touch again
                 if (gathered_in) {
                     SetLastError("sliced touch: the given wire segments are "
                                  "too small for this stream "
@@ -1563,52 +1571,58 @@ static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
         }
         if (ci + 1 < n_chunks)
             if ((st = issue_side(ci + 1, true))) return st;
-        // the chunk's integrate launches, one per group, integrate role only
+        // the chunk's integrate launch
         O3DMI_HIP_CHECK(hipStreamWaitEvent(s, z.ev_side[set], 0));
-        for (int gi = 0; gi * group < nc; ++gi) {
-            StreamGroup grp;
-            grp.n = nc - gi * group < group ? nc - gi * group : group;
-            grp.seq = g->stream_seq++;
-            g->frame_stamp += 1;
-            grp.stamp = g->frame_stamp;
-            grp.frames = frames + f0 + gi * group;
-            const bool prof = g->profiling && g->prof_frames < g->prof_max &&
-                              g->prof_stride > 0 &&
-                              (g->prof_seen++ % g->prof_stride) == 0;
-            hipEvent_t* pe = prof ? &g->prof_events[(size_t)g->prof_frames * 2]
-                                  : nullptr;
-            IntegrateStreamArgs ia;
-            MakeIntegArgs(g, c, grp, prof, &ia);
-            ia.list = nullptr;
-            ia.ready = z.ready[set] + (size_t)gi * z.ready_cap;
-            ia.count = z.ready_count[set] + gi;
-            ia.list_capacity = z.ready_cap;
-            ia.zero_counter = nullptr;
-            ia.raw = true;
-            ia.depth_div_short = g->prep_div_short;
-            for (int f = 0; f < grp.n; ++f) {
-                ia.recs[f] = nullptr;
-                ia.depth[f] = (const uint16_t*)grp.frames[f].depth;
-                ia.color_img[f] = c.with_color
-                                          ? (const uint8_t*)grp.frames[f].color
-                                          : nullptr;
-            }
-            if (pe) O3DMI_HIP_CHECK(hipEventRecord(pe[0], s));
-            if ((st = LaunchFrameStep(g->block_hashmap, nullptr, 0, &ia, s)))
-                return st;
-            if (pe) {
-                O3DMI_HIP_CHECK(hipEventRecord(pe[1], s));
-                g->prof_launch_frames += grp.n;
-                g->prof_frames += 1;
-            }
-            // keeps last_count (the next launch's grid size) current
-            if ((st = PollStreamStatus(g))) return st;
+        g->frame_stamp += 1;
+        const bool prof = g->profiling && g->prof_frames < g->prof_max &&
+                          g->prof_stride > 0 &&
+                          (g->prof_seen++ % g->prof_stride) == 0;
+        hipEvent_t* pe = prof ? &g->prof_events[(size_t)g->prof_frames * 2]
+                              : nullptr;
+        ChunkIntegrateArgs ia = {};
+        ia.n_frames = nc;
+        ia.frames = z.iframes_dev + f0;
+        ia.entries = z.entries[set];
+        ia.count = z.entries_count[set];
+        ia.entries_cap = z.entries_cap;
+        ia.grid_hint = cs.blocks;
+        ia.rows = c.depth_rows;
+        ia.cols = c.depth_cols;
+        ia.with_color = c.with_color;
+        ia.tsdf = (float*)o3dmi_hash_value_buffer(g->block_hashmap, c.ti);
+        ia.weight = o3dmi_hash_value_buffer(g->block_hashmap, c.wi);
+        ia.color = c.with_color
+                           ? o3dmi_hash_value_buffer(g->block_hashmap, c.ci)
+                           : nullptr;
+        ia.grid_dtype = c.grid_dtype;
+        ia.depth_intrinsic = c.depth_intrinsic;
+        ia.resolution = (int)g->block_resolution;
+        ia.voxel_size = g->voxel_size;
+        ia.sdf_trunc = g->voxel_size * c.trunc;
+        ia.depth_max = c.depth_max;
+        ia.depth_scale = c.depth_scale;
+        ia.depth_div_short = g->prep_div_short;
+        ia.size_host = (int*)g->stream_status;
+        ia.status_stamp = g->frame_stamp;
+        ia.prof_count = prof ? g->prof_counts + g->prof_max + g->prof_frames
+                             : nullptr;
+        ia.prof_frame_blocks = prof ? g->prof_counts + g->prof_frames : nullptr;
+        ia.prof_map_size =
+                prof ? g->prof_counts + 2 * g->prof_max + g->prof_frames
+                     : nullptr;
+        if (pe) O3DMI_HIP_CHECK(hipEventRecord(pe[0], s));
+        if ((st = LaunchChunkIntegrate(g->block_hashmap, ia, s))) return st;
+        if (pe) {
+            O3DMI_HIP_CHECK(hipEventRecord(pe[1], s));
+            g->prof_launch_frames += nc;
+            g->prof_frames += 1;
         }
         O3DMI_HIP_CHECK(hipEventRecord(z.ev_main[set], s));
+        if ((st = PollStreamStatus(g))) return st;  // deferred error flags
         z.chunks_done += 1;
     }
     // the next call's side-stream work must not pass this call's launches
-    // (the frame table, the ready sets)
+    // (the frame tables, the work lists)
     O3DMI_HIP_CHECK(hipStreamWaitEvent(z.side, z.ev_main[(n_chunks - 1) & 1], 0));
     g->known_valid = false;  // the other paths take the size from the map
     g->stream_overflow = 0;
@@ -1728,12 +1742,7 @@ int o3dmi_vbg_set_slice_capacity(o3dmi_vbg_t* g, int records_per_group,
     o3dmi_vbg::Sliced& z = g->sliced;
     if (z.side) {
         O3DMI_HIP_CHECK(hipDeviceSynchronize());
-        SliceFrame* keep = z.frames_dev;
-        const int64_t keep_cap = z.frames_cap;
-        z.frames_dev = nullptr;
         FreeSliced(g);
-        z.frames_dev = keep;
-        z.frames_cap = keep_cap;
     }
     z.capacity = records_per_group;
     z.table_slots = 0;
@@ -1743,7 +1752,7 @@ int o3dmi_vbg_set_slice_capacity(o3dmi_vbg_t* g, int records_per_group,
 
 int64_t o3dmi_vbg_slice_segment_bytes(const o3dmi_vbg_t* g) {
     if (!g) return 0;
-    return SliceSegmentBytes(g->sliced.capacity ? g->sliced.capacity : 1024);
+    return SliceSegmentBytes(g->sliced.capacity ? g->sliced.capacity : 4096);
 }
 
 int o3dmi_vbg_slice_chunk_frames(int frames_per_launch) {
@@ -1770,7 +1779,7 @@ int o3dmi_vbg_touch_slice(o3dmi_vbg_t* g, int n_frames,
     hipStream_t s = (hipStream_t)stream;
     o3dmi_vbg::Sliced& z = g->sliced;
     int st = EnsureSliced(g, slice_world > z.world ? slice_world : z.world,
-                          z.capacity ? z.capacity : 1024,
+                          z.capacity ? z.capacity : 4096,
                           z.table_slots ? z.table_slots
                                         : g->sliced_slots_wanted,
                           s);
@@ -1793,13 +1802,13 @@ int o3dmi_vbg_touch_slice(o3dmi_vbg_t* g, int n_frames,
     O3DMI_HIP_CHECK(hipEventRecord(z.ev_enter, s));
     O3DMI_HIP_CHECK(hipStreamWaitEvent(z.side, z.ev_enter, 0));
     TouchParams shared;
-    if ((st = UploadSliceFrames(g, c, frames.data(), n_frames, z.side,
-                                &shared)))
+    O3DMI_HIP_CHECK(hipStreamSynchronize(z.side));
+    if ((st = UploadSliceFrames(g, c, frames.data(), n_frames, &shared)))
         return st;
-    if ((st = LaunchTouchSlice(shared, z.frames_dev, 0, n_frames, group,
-                               slice_rank, slice_world, z.send_tables, z.side)))
+    if ((st = LaunchTouchSlice(shared, z.frames_dev, 0, n_frames, slice_rank,
+                               slice_world, z.send_table, z.side)))
         return st;
-    if ((st = LaunchPackSlice(z.send_tables, segment_out_dev, z.capacity,
+    if ((st = LaunchPackSlice(z.send_table, segment_out_dev, z.capacity,
                               z.side)))
         return st;
     O3DMI_HIP_CHECK(hipEventRecord(z.ev_enter, z.side));

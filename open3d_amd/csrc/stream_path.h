@@ -136,15 +136,6 @@ struct IntegrateStreamArgs {
                              // popcount(frame bits) = block-frames integrated
     int* prof_map_size;      // device int receiving the map size (heap top) the
                              // role sees when it starts
-    // RAW form (sliced_path.h): depth / colour gathered from the frames' own
-    // images, no prepared records (recs unused). Needs `ready`, depth and
-    // colour images of the same size and intrinsics, no front roles in the
-    // launch.
-    bool raw;
-    const uint16_t* depth[kMaxGroup];
-    const uint8_t* color_img[kMaxGroup];
-    float depth_scale;
-    bool depth_div_short;    // PrepTables' verdict for this depth scale
 };
 
 // One launch running the front roles of up to kMaxGroup frames and / or the

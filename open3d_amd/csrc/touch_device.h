@@ -24,7 +24,19 @@ __device__ __forceinline__ bool InsertKey(const HashView& hv, int x, int y,
                                           int z, unsigned& slot_out,
                                           int overflow_stamp = 0) {
     slot_out = 0;
-    if (ClaimSlot(hv, PackKey(x, y, z), slot_out) != 1) return false;
+    if (kAllocate && overflow_stamp != 0 &&
+        __hip_atomic_load(&hv.counters[3], __ATOMIC_RELAXED,
+                          __HIP_MEMORY_SCOPE_AGENT) != 0)
+        return false;  // the group is dropped already: no walk in a full table
+    const int claim = ClaimSlot(hv, PackKey(x, y, z), slot_out,
+                                !(kAllocate && overflow_stamp != 0));
+    if (claim == -1 && kAllocate && overflow_stamp != 0) {
+        // more new keys than the table has slots: the same overflow
+        atomicCAS(&hv.counters[3], 0, overflow_stamp);
+        slot_out = 0;
+        return false;
+    }
+    if (claim != 1) return false;
     if (kAllocate) {
         const unsigned h = slot_out;
         int top = atomicAdd(&hv.counters[0], 1);

@@ -25,6 +25,7 @@
 #include <mutex>
 
 #include "stream_path.h"
+#include "sliced_path.h"
 #include "touch_device.h"
 
 namespace o3dmi {
@@ -524,6 +525,11 @@ struct IntegParams {
     const uint8_t* raw_color[kMaxGroup];
     float depth_scale, inv_depth_scale;
     bool depth_div_short;
+    // LONG form (one launch per chunk of the sliced path): the work list
+    // carries one bit per frame of the chunk, the frames' poses and images come
+    // from a device table (n_frames <= kChunkFrames of them)
+    const ChunkEntry* entries;
+    const IntegFrame* frame_tab;
 };
 
 // ---- exact division without the division sequence ---------------------------
@@ -851,8 +857,11 @@ __device__ __forceinline__ f2 PkFma(f2 a, f2 b, f2 c) {
 // records path's bit for bit. For ranks that integrate a fraction of the
 // blocks (block-ownership sharding) this removes the per-pixel prepare pass,
 // which every rank would otherwise run in full.
+// kLong (with kRaw): the chunk launch of the sliced path -- a work item applies
+// up to kChunkFrames frames (ChunkEntry::bits) to its register-resident voxels,
+// kChunk at a time; per-frame constants come from IntegParams::frame_tab.
 template <typename weight_t, typename color_t, bool kColor, int kDiv,
-          int kChunk, int kP, bool kRaw = false>
+          int kChunk, int kP, bool kRaw = false, bool kLong = false>
 __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                                                   const IntegParams& ip,
                                                   int wg, int n_wg,
@@ -907,7 +916,7 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
     const float fx = ip.cam0.fx, fyk = ip.cam0.fy;
     const float cx = ip.cam0.cx, cy = ip.cam0.cy;
     const float u_max = ip.cols - 1.0f, v_max = ip.rows - 1.0f;
-    const unsigned last_pix = (unsigned)(ip.rows * ip.cols) - 1u;
+    const unsigned last_col8 = (unsigned)(ip.rows * ip.cols) * 3u - 8u;
 
     // (Measured and dropped, profiles/r2l: persistent workgroups -- 1024 to
     // 1536 of them striding over the items, with the next item's block header
@@ -930,7 +939,33 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
         const int64_t b = (int64_t)xcd + (kb << 3);
         int xb, yb, zb, block_idx;
         unsigned bits;
-        if (ip.ready) {
+        unsigned long_bits = 0u;  // kLong: lane l holds word l & 7
+        if constexpr (kLong) {
+            const ChunkEntry* __restrict__ ce = ip.entries + b;
+            const unsigned klo =
+                    __builtin_amdgcn_readfirstlane((unsigned)ce->key);
+            const unsigned khi =
+                    __builtin_amdgcn_readfirstlane((unsigned)(ce->key >> 32));
+            const unsigned long long key =
+                    ((unsigned long long)khi << 32) | klo;
+            xb = (int)((key >> 42) & 0x1FFFFFull) - kKeyBias;
+            yb = (int)((key >> 21) & 0x1FFFFFull) - kKeyBias;
+            zb = (int)(key & 0x1FFFFFull) - kKeyBias;
+            block_idx = __builtin_amdgcn_readfirstlane(ce->block_idx);
+            // lane l keeps word l & 7 of the frame bits: a round takes its
+            // word with one v_readlane instead of a memory round trip
+            long_bits = ce->bits[threadIdx.x & (kChunkWords - 1)];
+            unsigned any = 0u;
+#pragma unroll
+            for (int w = 0; w < kChunkWords; ++w) {
+                const unsigned bw =
+                        (unsigned)__builtin_amdgcn_readlane((int)long_bits, w);
+                any |= bw;
+                if (part == 0 && threadIdx.x == 0 && ip.prof_frame_blocks)
+                    frame_blocks += __popc(bw);
+            }
+            bits = any;  // "any frame at all"
+        } else if (ip.ready) {
             // ONE round trip: the ready entry the group's front roles left
             const ReadyEntry re = ip.ready[b];
             const unsigned klo = __builtin_amdgcn_readfirstlane((unsigned)re.key);
@@ -960,7 +995,7 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                         : 0u);
         }
         const int64_t block_base = (int64_t)block_idx * res3;
-        if (part == 0 && threadIdx.x == 0 && ip.prof_frame_blocks)
+        if (!kLong && part == 0 && threadIdx.x == 0 && ip.prof_frame_blocks)
             frame_blocks += __popc(bits);
         int opaque = 0;  // a zero the optimiser cannot see through
         asm volatile("" : "+s"(opaque));
@@ -1029,27 +1064,44 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
         // the live registers)
         bool touched = false;
 #pragma nounroll
-        for (int c0 = 0; c0 < kMaxGroup; c0 += kChunk) {
-        if (((bits >> c0) & ((1u << kChunk) - 1u)) == 0u) continue;  // uniform
+        for (int c0 = 0; c0 < (kLong ? ip.n_frames : kMaxGroup); c0 += kChunk) {
+        // the round's frame bits (kChunk divides 32)
+        unsigned cbits;
+        if constexpr (kLong)
+            cbits = ((unsigned)__builtin_amdgcn_readlane((int)long_bits,
+                                                         c0 >> 5) >>
+                     (c0 & 31)) &
+                    ((1u << kChunk) - 1u);
+        else
+            cbits = (bits >> c0) & ((1u << kChunk) - 1u);
+        if (cbits == 0u) continue;  // wave-uniform
         f2 zc[kChunk][kP];
         PixelRec rec[kChunk][kV];
         unsigned in_mask = 0u;  // kRaw: voxel projects into the image
+        // kRaw: upper half of the 8 colour bytes, bit offset of the pixel
+        unsigned chi[kRaw && kColor ? kChunk : 1][kV];
+        unsigned csh[kRaw && kColor ? kChunk : 1][kV];
 #pragma unroll
         for (int fk = 0; fk < kChunk; ++fk) {
             const int f = c0 + fk;
-            if (!((bits >> f) & 1u)) continue;  // wave-uniform
+            if (!((cbits >> fk) & 1u)) continue;  // wave-uniform
             // The frame's constants are fetched here, per work item (scalar
-            // loads from the argument block): hoisted out of the item loop
-            // they would occupy ~60 scalar registers and spill.
+            // loads from the argument block / the frame table): hoisted out of
+            // the item loop they would occupy ~60 scalar registers and spill.
             const float(&e)[3][4] =
-                    *reinterpret_cast<const float(*)[3][4]>(
-                            &ip.ext[f][0][0] + opaque);
+                    kLong ? ip.frame_tab[f].ext
+                          : *reinterpret_cast<const float(*)[3][4]>(
+                                    &ip.ext[kLong ? 0 : f][0][0] + opaque);
             const char* __restrict__ recs = reinterpret_cast<const char*>(
-                    kRaw ? nullptr : *(&ip.recs[f] + opaque));
+                    kRaw ? nullptr : *(&ip.recs[kLong ? 0 : f] + opaque));
             const char* __restrict__ dimg = reinterpret_cast<const char*>(
-                    kRaw ? *(&ip.raw_depth[f] + opaque) : nullptr);
+                    kLong ? ip.frame_tab[f].depth
+                          : (kRaw ? *(&ip.raw_depth[kLong ? 0 : f] + opaque)
+                                  : nullptr));
             const char* __restrict__ cimg = reinterpret_cast<const char*>(
-                    kRaw ? *(&ip.raw_color[f] + opaque) : nullptr);
+                    kLong ? ip.frame_tab[f].color
+                          : (kRaw ? *(&ip.raw_color[kLong ? 0 : f] + opaque)
+                                  : nullptr));
             const float y0 = ys * e[0][1], z0 = zs * e[0][2];
             const float y1 = ys * e[1][1], z1 = zs * e[1][2];
             const float y2 = ys * e[2][1], z2 = zs * e[2][2];
@@ -1110,18 +1162,18 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                                               const uint16_t*>(dimg + 2u * pix));
                         r.rgba = 0u;
                         if constexpr (kColor) {
-                            // 3 bytes at 3 * pix as ONE dword load (the
-                            // hardware takes unaligned global addresses); the
-                            // last pixel reads one byte earlier and shifts, so
-                            // that no load passes the end of the image
-                            struct __attribute__((packed)) U32 {
-                                unsigned v;
-                            };
-                            const unsigned adj = pix == last_pix ? 1u : 0u;
-                            r.rgba = reinterpret_cast<const U32*>(
-                                             cimg + 3u * pix - adj)
-                                             ->v >>
-                                     (8u * adj);
+                            // the 3 bytes at 3 * pix out of ONE aligned 8-byte
+                            // load (an unaligned 4-byte load is split by the
+                            // memory pipeline); the address is clamped so that
+                            // no load passes the end of the image
+                            const unsigned b3 = 3u * pix;
+                            unsigned al = b3 & ~3u;
+                            al = al < last_col8 ? al : last_col8;
+                            const uint2 q =
+                                    *reinterpret_cast<const uint2*>(cimg + al);
+                            r.rgba = q.x;
+                            chi[fk][2 * p + h] = q.y;
+                            csh[fk][2 * p + h] = (b3 - al) * 8u;
                         }
                         rec[fk][2 * p + h] = r;
                     } else {
@@ -1139,8 +1191,7 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
         // 3. frames applied in order (VoxelBlockGridImpl.h:258-302)
 #pragma unroll
         for (int fk = 0; fk < kChunk; ++fk) {
-            const int f = c0 + fk;
-            if (!((bits >> f) & 1u)) continue;  // wave-uniform
+            if (!((cbits >> fk) & 1u)) continue;  // wave-uniform
             f2 sdf[kP];
             bool ok[kV];
             bool tiny = false;
@@ -1226,8 +1277,15 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                 ts[p] = f2{ok[2 * p] ? t_new.x : ts[p].x,
                            ok[2 * p + 1] ? t_new.y : ts[p].y};
                 if constexpr (kColor) {
-                    const unsigned rg0 = rec[fk][2 * p].rgba;
-                    const unsigned rg1 = rec[fk][2 * p + 1].rgba;
+                    unsigned rg0 = rec[fk][2 * p].rgba;
+                    unsigned rg1 = rec[fk][2 * p + 1].rgba;
+                    if constexpr (kRaw) {
+                        rg0 = (unsigned)((((unsigned long long)chi[fk][2 * p]
+                                           << 32) | rg0) >> csh[fk][2 * p]);
+                        rg1 = (unsigned)((((unsigned long long)
+                                                   chi[fk][2 * p + 1] << 32) |
+                                          rg1) >> csh[fk][2 * p + 1]);
+                    }
                     // (raw form: the colour pixel IS the depth pixel, inside
                     // the image whenever the voxel is ok)
                     const bool has0 = ok[2 * p] && (kRaw || (rg0 >> 24));
@@ -1295,8 +1353,15 @@ static_assert(sizeof(StepParams) <= 4096, "kernel arguments are limited to 4 KB"
 // lane (119 registers, 4 waves per SIMD); 2 = wide form, 2 voxels per lane
 // (72 registers, 7 waves per SIMD). Both wide forms apply a group of up to 8
 // frames in chunks of kGroupChunk = 4 to the register-resident voxel state.
+// Frames of a round of the raw / long form (the chunk launch of the sliced
+// path): a rank's share of a chunk is a few hundred blocks, about one round of
+// the chip, so a work item's chain of dependent memory round trips is what the
+// launch lasts -- twice the frames in flight per round halve the rounds; the
+// registers this costs (2 waves per SIMD allowed) are not needed for occupancy
+// there.
+constexpr int kRawChunk = 4;
 template <typename weight_t, typename color_t, bool kColor, int kDiv,
-          int kForm, bool kRaw = false>
+          int kForm>
 __global__ void __launch_bounds__(256, kForm == 0 ? 1 : (kForm == 1 ? 4 : 7))
 FrameStepKernel(StepParams sp) {
     const int b = (int)blockIdx.x;
@@ -1307,13 +1372,27 @@ FrameStepKernel(StepParams sp) {
         FrontRole(sp.hv, fp, b - f * sp.front_wg);
     } else if constexpr (kForm != 0) {
         IntegrateRoleWide<weight_t, color_t, kColor, kDiv, kGroupChunk,
-                          kForm == 2 ? 1 : 2, kRaw>(
+                          kForm == 2 ? 1 : 2>(
                 sp.hv, sp.integ, b - n_front_wg, (int)gridDim.x - n_front_wg,
                 n_front_wg);
     } else {
         IntegrateRole<weight_t, color_t, kColor, kDiv>(
                 sp.hv, sp.integ, b - n_front_wg, (int)gridDim.x - n_front_wg);
     }
+}
+
+// The chunk launch of the sliced block-ownership path (sliced_path.h): the
+// integrate role in its raw-image, long form -- nothing else in the launch.
+struct ChunkParams {
+    HashView hv;
+    IntegParams integ;
+};
+template <typename weight_t, typename color_t, bool kColor, int kDiv>
+__global__ void __launch_bounds__(256, 5)
+ChunkIntegrateKernel(ChunkParams cp) {
+    IntegrateRoleWide<weight_t, color_t, kColor, kDiv, kRawChunk, 1, true,
+                      true>(cp.hv, cp.integ, (int)blockIdx.x, (int)gridDim.x,
+                            0);
 }
 
 }  // namespace
@@ -1515,7 +1594,6 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
     int n_int_wg = 0;
     int grid_dtype = O3DMI_U16;
     bool col = false;
-    bool raw = false;
     int fast_div = 0;
     static const double eye4[16] = {1, 0, 0, 0, 0, 1, 0, 0,
                                     0, 0, 1, 0, 0, 0, 0, 1};
@@ -1590,17 +1668,9 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
             if (f == 0) ip.cam0 = cf;
             std::memcpy(ip.ext[f], cf.e, sizeof(ip.ext[f]));
             ip.recs[f] = a->recs[f];
-            ip.raw_depth[f] = a->raw ? a->depth[f] : nullptr;
-            ip.raw_color[f] = a->raw ? a->color_img[f] : nullptr;
+            ip.raw_depth[f] = nullptr;
+            ip.raw_color[f] = nullptr;
         }
-        raw = a->raw;
-        O3DMI_REQUIRE(!raw || (n_fronts == 0 && a->ready != nullptr &&
-                               a->depth_scale > 0),
-                      "raw-image integrate role: ready list and depth scale "
-                      "required, no front roles");
-        ip.depth_scale = a->depth_scale;
-        ip.inv_depth_scale = raw ? 1.0f / a->depth_scale : 0.0f;
-        ip.depth_div_short = a->depth_div_short;
         ip.rows = a->rows;
         ip.cols = a->cols;
         ip.resolution = a->resolution;
@@ -1658,8 +1728,6 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
     // O3DMI_STEP_VARIANT=0 selects the first form of the integrate role
     // (diagnostics / A-B measurements); results are identical.
     const int form = StepForm();
-    O3DMI_REQUIRE(!raw || form == 2,
-                  "the raw-image integrate role exists for form 2 only");
 #define O3DMI_LAUNCH_STEP_D(WT, VT, COLOR, D)                                 \
     do {                                                                      \
         switch (form) {                                                       \
@@ -1672,14 +1740,8 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
                                    grid, block, 0, s, sp);                    \
                 break;                                                        \
             default:                                                          \
-                if (raw)                                                      \
-                    hipLaunchKernelGGL(                                       \
-                            (FrameStepKernel<WT, VT, COLOR, D, 2, true>),     \
-                            grid, block, 0, s, sp);                           \
-                else                                                          \
-                    hipLaunchKernelGGL(                                       \
-                            (FrameStepKernel<WT, VT, COLOR, D, 2>), grid,     \
-                            block, 0, s, sp);                                 \
+                hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR, D, 2>),    \
+                                   grid, block, 0, s, sp);                    \
         }                                                                     \
     } while (0)
 #define O3DMI_LAUNCH_STEP(WT, VT, COLOR)                                      \
@@ -1700,6 +1762,80 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
     }
 #undef O3DMI_LAUNCH_STEP
 #undef O3DMI_LAUNCH_STEP_D
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+int LaunchChunkIntegrate(o3dmi_hash* bh, const ChunkIntegrateArgs& a,
+                         hipStream_t s) {
+    O3DMI_REQUIRE(a.resolution % 4 == 0 && a.n_frames >= 1 &&
+                          a.n_frames <= kChunkFrames && a.frames &&
+                          a.entries && a.count && a.depth_scale > 0,
+                  "chunk integrate: bad arguments");
+    ChunkParams cp = {};
+    cp.hv = bh->view;
+    IntegParams& ip = cp.integ;
+    ip.n_frames = a.n_frames;
+    static const double eye4[16] = {1, 0, 0, 0, 0, 1, 0, 0,
+                                    0, 0, 1, 0, 0, 0, 0, 1};
+    ip.cam0 = Camera::Make(a.depth_intrinsic, eye4, a.voxel_size);
+    ip.rows = a.rows;
+    ip.cols = a.cols;
+    ip.resolution = a.resolution;
+    ip.diag = 0;
+    ip.res_shift = -1;
+    for (int sh = 2; sh < 12; ++sh)
+        if ((1 << sh) == a.resolution) ip.res_shift = sh;
+    ip.sdf_trunc = a.sdf_trunc;
+    ip.depth_max = a.depth_max;
+    const int fast_div = VerifyFastDivision(a.sdf_trunc, &ip.inv_sdf_trunc);
+    ip.list = nullptr;
+    ip.ready = nullptr;
+    ip.entries = a.entries;
+    ip.frame_tab = a.frames;
+    ip.count = a.count;
+    ip.list_capacity = a.entries_cap;
+    ip.tsdf = a.tsdf;
+    ip.weight = a.weight;
+    ip.color = a.color;
+    ip.zero_counter = nullptr;
+    ip.size_host = a.size_host;
+    ip.status_stamp = a.status_stamp;
+    ip.prof_count = a.prof_count;
+    ip.prof_frame_blocks = a.prof_frame_blocks;
+    ip.prof_map_size = a.prof_map_size;
+    ip.depth_scale = a.depth_scale;
+    ip.inv_depth_scale = 1.0f / a.depth_scale;
+    ip.depth_div_short = a.depth_div_short;
+    const int n_quads = (a.resolution * a.resolution * a.resolution) >> 1;
+    const int parts = (n_quads + 255) >> 8;
+    int64_t g = ((int64_t)a.grid_hint + (a.grid_hint >> 2) + 64) * parts;
+    const int64_t g_max = (int64_t)kCUs * 32;
+    if (g > g_max) g = g_max;
+    if (g < kCUs) g = kCUs;
+    const dim3 grid((unsigned)g), block(256);
+    const bool col = a.with_color && a.color != nullptr;
+#define O3DMI_LAUNCH_CHUNK_D(WT, VT, COLOR, D)                                \
+    hipLaunchKernelGGL((ChunkIntegrateKernel<WT, VT, COLOR, D>), grid, block, \
+                       0, s, cp)
+#define O3DMI_LAUNCH_CHUNK(WT, VT, COLOR)                                     \
+    do {                                                                      \
+        switch (fast_div) {                                                   \
+            case 3: O3DMI_LAUNCH_CHUNK_D(WT, VT, COLOR, 3); break;            \
+            case 2: O3DMI_LAUNCH_CHUNK_D(WT, VT, COLOR, 2); break;            \
+            case 1: O3DMI_LAUNCH_CHUNK_D(WT, VT, COLOR, 1); break;            \
+            default: O3DMI_LAUNCH_CHUNK_D(WT, VT, COLOR, 0); break;           \
+        }                                                                     \
+    } while (0)
+    if (a.grid_dtype == O3DMI_U16) {
+        if (col) O3DMI_LAUNCH_CHUNK(uint16_t, uint16_t, true);
+        else O3DMI_LAUNCH_CHUNK(uint16_t, uint16_t, false);
+    } else {
+        if (col) O3DMI_LAUNCH_CHUNK(float, float, true);
+        else O3DMI_LAUNCH_CHUNK(float, float, false);
+    }
+#undef O3DMI_LAUNCH_CHUNK
+#undef O3DMI_LAUNCH_CHUNK_D
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
 }

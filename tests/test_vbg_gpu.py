@@ -447,8 +447,8 @@ def test_group_that_overflows_the_map_is_dropped_and_replayed(group, slack):
     for i in range(len(ds)):
         og.integrate(ds[i], cs[i], K, Ts[i])
         sizes.append(og.h.size())
-    cap = sizes[len(sizes) // 2] + slack  # fills up in the middle of the call
-    assert cap < sizes[-1]
+    cap = sizes[-1] - 400 + slack  # fills up in the course of the call
+    assert sizes[0] < cap < sizes[-1]
     g = _mk_grid(geometry, False, block_count=cap)
     g.integrate_frames(dt, ct, K, K, Ts, sc.DEPTH_SCALE, sc.DEPTH_MAX,
                        sc.TRUNC_MULT, frames_per_launch=group)

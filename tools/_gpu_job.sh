@@ -1,8 +1,17 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r4c
-timeout 1500 python -m pytest tests/test_vbg_gpu.py -q -m gpu -x > gpurun_out/r4c/vbg.log 2>&1
-grep -n "passed\|failed\|Fatal\|Error\|Aborted\|core" gpurun_out/r4c/vbg.log | head
-tail -5 gpurun_out/r4c/vbg.log
-timeout 600 python -m pytest tests/test_configs_gpu.py -q -m gpu -x -k configs1 2>&1 | tail -3
-timeout 900 python -m pytest tests/test_icp_gpu.py tests/test_odometry_gpu.py tests/test_slam_gpu.py -q -m gpu -x > gpurun_out/r4c/icp.log 2>&1
-tail -3 gpurun_out/r4c/icp.log
+mkdir -p gpurun_out/r4g
+export TMPDIR=/tmp
+B="python $PWD/bench.py --no-secondary --no-cpu-baseline --no-pmc"
+for w in 8; do
+timeout 600 $B --emulate-world $w > gpurun_out/r4g/emu_w$w.json 2> gpurun_out/r4g/emu_w$w.err
+python -c "
+import json;d=json.load(open('gpurun_out/r4g/emu_w$w.json'));print('emu $w', d['value'], d['roofline']['avg_kernel_ms'], d['config']['active_blocks'])"
+done
+timeout 600 $B --force-sliced > gpurun_out/r4g/n1_sliced.json 2> gpurun_out/r4g/n1_sliced.err
+python -c "
+import json;d=json.load(open('gpurun_out/r4g/n1_sliced.json'));print('n1 sliced', d['value'], d['roofline']['avg_kernel_ms'], d['config']['active_blocks'])"
+/usr/bin/time -v timeout 1500 python bench.py > gpurun_out/r4g/bench.json 2> gpurun_out/r4g/bench.err
+tail -25 gpurun_out/r4g/bench.err | grep -E "Elapsed|Maximum resident|Error|error" 
+wc -c gpurun_out/r4g/bench.json
+cat gpurun_out/r4g/bench.json
+cp bench_detail.json gpurun_out/r4g/bench_detail.json 2>/dev/null
