@@ -902,6 +902,24 @@ def secondary_legs():
 # ---------------------------------------------------------------------------
 
 
+def gpu_partition_modes():
+    """Compute / memory partition modes of the box (rocm-smi), or None: the
+    DRAM-resident legs read differently on boxes in different modes."""
+    try:
+        r = subprocess.run(["rocm-smi", "--showcomputepartition",
+                            "--showmemorypartition"], capture_output=True,
+                           text=True, timeout=20)
+        out = {}
+        for ln in r.stdout.splitlines():
+            low = ln.lower()
+            if "gpu[0]" in low and "partition" in low and ":" in ln:
+                k = "compute" if "compute" in low else "memory"
+                out[k] = ln.rsplit(":", 1)[1].strip()
+        return out or None
+    except Exception:
+        return None
+
+
 def pin_to_gpu_numa_node(device_index):
     """One process per GPU, on the CPUs of the GPU's own NUMA node: the ICP
     legs are a host in a loop with the device (a mailbox word polled over
@@ -1197,7 +1215,11 @@ def main():
         e1.record()
     torch.cuda.synchronize()
     bracket_ms = float(np.median([e0.elapsed_time(e1) for e0, e1 in evs]))
-    n_timed_launches = a.steps * a.batch / max(1, a.frames_per_launch)
+    # (frames per launch as bracketed: 12 per group launch, up to 192 per chunk
+    # launch of the sliced path)
+    n_timed_launches = a.steps * a.batch / max(
+        1.0, prof["frames"] / launches if prof["frames"] else
+        a.frames_per_launch)
     # What has to cross the fabric per launch when the frames of a group are
     # applied to register-resident blocks (the fused minimum): every DISTINCT
     # block of the group once in and once out (98 304 B + header), every
@@ -1212,7 +1234,10 @@ def main():
                                            BLOCK_HEADER_BYTES)
                 + prof["frames"] * (IMAGE_BYTES + RECORD_BYTES)) / launches
     min_gbps = min_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    roof = {"bound": "valu", "kernel": KERNEL, "achieved": min_gbps,
+    sliced_launches = e_world > 1 and by_blocks and a.touch == "sliced"
+    roof = {"bound": "valu",
+            "kernel": "ChunkIntegrateKernel" if sliced_launches else KERNEL,
+            "achieved": min_gbps,
             "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": min_gbps / HBM_PEAK_GBS,
             "fused_minimum_bytes_per_launch": min_bytes,
@@ -1307,6 +1332,8 @@ def main():
                                "poses" % (a.steps * a.batch),
                    "frames_per_step": a.batch, "block_count": a.block_count,
                    "host_cpus": pinned_cpus,
+                   "gpu_partition": gpu_partition_modes()
+                   if rank == 0 and e_world == 1 else None,
                    "timed_region_s": elapsed,
                    "frames_per_launch": a.frames_per_launch,
                    "active_blocks": int(n_blocks),
@@ -1449,6 +1476,10 @@ def compact_line(out, secondary):
             _pick(c4i, ("frames_per_s", "wall_ms_per_launch",
                         "frames_per_launch", "active_blocks",
                         "max_linear_voxel_index", "division_forms", "error")),
+            warm_pass_frames_per_s=((c4i.get("warm_passes") or [{}])[0]).get(
+                "frames_per_s"),
+            warm_pass_kernel_ms=((c4i.get("warm_passes") or [{}])[0]).get(
+                "avg_kernel_ms"),
             **_pick(ro, ("avg_kernel_ms", "kernel_us_trace_only", "frac",
                          "frac_hbm", "frac_hbm_on_trace_time", "frac_valu",
                          "read_overfetch", "traffic_bytes_per_launch",

@@ -125,6 +125,10 @@ struct o3dmi_vbg {
         int64_t frames_cap = 0;
         std::vector<SliceFrame> frames_host;
         std::vector<IntegFrame> iframes_host;
+        // records form: the prepared records of a chunk's frames, two sets of
+        // kChunkFrames images of (pixels + 1) records
+        PixelRec* chunk_recs[2] = {nullptr, nullptr};
+        int64_t chunk_recs_pixels = 0;
         int64_t chunks_done = 0;  // statistics (o3dmi_vbg_sliced_stats)
         int64_t reapplied = 0;
     } sliced;
@@ -865,7 +869,14 @@ static int PollStreamStatus(o3dmi_vbg* g, int* overflow = nullptr) {
 // A Reserve therefore happens when the map really is too small (or, drained,
 // when even the estimate does not fit), not because of the frustum bound.
 static int64_t EstimatedGroupNew(const o3dmi_vbg* g, int64_t strict) {
-    if (g->recent_n == 0) return strict;  // nothing observed yet
+    if (g->recent_n == 0) {
+        // nothing observed yet (a cold start): an eighth of the free map per
+        // group in flight, so that the first groups of a stream pipeline too
+        const int64_t room = o3dmi_hash_capacity(g->block_hashmap) -
+                             (int64_t)g->known_size;
+        const int64_t guess = room / 8 > 1024 ? room / 8 : 1024;
+        return guess < strict ? guess : strict;
+    }
     int m = 0;
     for (int i = 0; i < 4 && i < g->recent_n; ++i)
         if (g->recent_new[i] > m) m = g->recent_new[i];
@@ -1037,6 +1048,7 @@ static StreamGroup MakeGroup(o3dmi_vbg* g, const StreamCommon& c,
         a.ready = g->ready[par];
         a.tickets = g->front_tickets + 16 * par;
         a.touch_status = (int*)g->stream_status + 4;
+        a.prepare_only = false;
     }
     g->stream_seq += 1;
     g->size_bound = o3dmi_hash_capacity(g->block_hashmap);  // generic path: re-read
@@ -1141,6 +1153,13 @@ static int StreamIntegrate(o3dmi_vbg* g, const StreamCommon& c0,
                                       c.depth_scale, s))) {
         return st;
     }
+    // The short division forms are proven asynchronously (vbg_stream.hip); a
+    // batch call never waits for the proof (its launches take the IEEE forms
+    // until it is over). A ONE-frame call is the interactive API -- a loop of
+    // them is latency-bound and would run beside the proof's kernels for its
+    // first ~10 ms: there the (one-time) wait is taken up front, as rounds 1-3
+    // did for every caller.
+    (void)PrefetchFastDivision(g->voxel_size * c.trunc, n == 1);
     // O3DMI_STRICT_CAPACITY=1 (A / B): rounds 1-3's policy, the frustum bound
     // only. Groups on the estimate need more than one frame per call to pay
     // (the confirmation is a wait).
@@ -1280,6 +1299,8 @@ static void FreeSliced(o3dmi_vbg* g) {
     }
     (void)hipFree(z.frames_dev);
     (void)hipFree(z.iframes_dev);
+    (void)hipFree(z.chunk_recs[0]);
+    (void)hipFree(z.chunk_recs[1]);
     z = o3dmi_vbg::Sliced();
 }
 
@@ -1300,12 +1321,18 @@ static int EnsureSliced(o3dmi_vbg* g, int world, int capacity, int slots,
     IntegFrame* keep_iframes = z.iframes_dev;
     const int64_t keep_cap = z.frames_cap;
     const int64_t keep_chunks = z.chunks_done, keep_re = z.reapplied;
+    PixelRec* keep_recs[2] = {z.chunk_recs[0], z.chunk_recs[1]};
+    const int64_t keep_px = z.chunk_recs_pixels;
     z.frames_dev = nullptr;
     z.iframes_dev = nullptr;
+    z.chunk_recs[0] = z.chunk_recs[1] = nullptr;
     FreeSliced(g);
     z.frames_dev = keep_frames;
     z.iframes_dev = keep_iframes;
     z.frames_cap = keep_cap;
+    z.chunk_recs[0] = keep_recs[0];
+    z.chunk_recs[1] = keep_recs[1];
+    z.chunk_recs_pixels = keep_px;
     z.chunks_done = keep_chunks;
     z.reapplied = keep_re;
     O3DMI_HIP_CHECK(hipStreamCreateWithFlags(&z.side, hipStreamNonBlocking));
@@ -1339,7 +1366,7 @@ static int EnsureSliced(o3dmi_vbg* g, int world, int capacity, int slots,
 // of the chunk integrate launch (extrinsic as Camera::Make keeps it, images).
 static int UploadSliceFrames(o3dmi_vbg* g, const StreamCommon& c,
                              const StreamFrame* frames, int n,
-                             TouchParams* shared) {
+                             TouchParams* shared, int chunk_frames = 0) {
     o3dmi_vbg::Sliced& z = g->sliced;
     if (z.frames_cap < n) {
         if (z.frames_dev) O3DMI_HIP_CHECK(hipDeviceSynchronize());
@@ -1373,6 +1400,14 @@ static int UploadSliceFrames(o3dmi_vbg* g, const StreamCommon& c,
         z.iframes_host[(size_t)f].depth = (const uint16_t*)frames[f].depth;
         z.iframes_host[(size_t)f].color =
                 c.with_color ? (const uint8_t*)frames[f].color : nullptr;
+        // records form: frame f = slot f % chunk of chunk set (f / chunk) & 1
+        z.iframes_host[(size_t)f].recs =
+                (chunk_frames > 0 && z.chunk_recs[0])
+                        ? z.chunk_recs[(f / chunk_frames) & 1] +
+                                  (size_t)(f % chunk_frames) *
+                                          (size_t)(z.chunk_recs_pixels + 1)
+                        : nullptr;
+        z.iframes_host[(size_t)f].pad = nullptr;
     }
     // Synchronous copies: the tables are free (every launch of the previous
     // call that reads them has completed: the touch launches were waited for
@@ -1450,9 +1485,11 @@ static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
                                c.depth_rows, c.depth_cols, c.color_rows,
                                c.color_cols, c.depth_scale, s)))
         return st;
-    O3DMI_REQUIRE(!c.with_color || g->prep_identity,
-                  "sliced touch needs the same intrinsics for depth and "
-                  "colour");
+    O3DMI_REQUIRE(!c.with_color || g->prep_identity ||
+                          !(std::getenv("O3DMI_SLICED_RAW") &&
+                            std::getenv("O3DMI_SLICED_RAW")[0] == '1'),
+                  "sliced touch, raw form, needs the same intrinsics for depth "
+                  "and colour");
     o3dmi_vbg::Sliced& z = g->sliced;
     // Sizes: a rank's band sees about 1 / world of a chunk's blocks plus the
     // band's rim; start from a generous guess and double on overflow (every
@@ -1463,18 +1500,96 @@ static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
                            s)))
         return st;
 
+    // Two forms of the chunk's integrate launch (same results):
+    //   records  the per-pixel prepare pass of the chunk's frames runs on the
+    //           side stream (every rank prepares every pixel: 4.3 MB of
+    //           traffic per frame, replicated); the launch gathers one 8-byte
+    //           record per voxel and frame, as the single-GPU stream does
+    //   raw     no prepare pass and no record buffers (2 x 256 images of
+    //           8 B / pixel); the launch gathers depth and colour separately
+    //           and divides per voxel: 1 088 instead of 877 VALU instructions
+    //           per 4 frames
+    // Emulated shares (profiles/r4k_emu_*): records is ahead up to 4 ranks
+    // (186 k / 273 k frames/s at 2 / 4 against 152 k / 255 k), raw beyond,
+    // where the replicated prepare pass weighs as much as a rank's share of
+    // the voxel work (403 k against 371 k at 8). O3DMI_SLICED_RAW=0 / 1 picks
+    // one (read per call: tests switch it).
+    const char* raw_env = std::getenv("O3DMI_SLICED_RAW");
+    const bool raw_form = raw_env ? raw_env[0] == '1'
+                                  : (world >= 6 && (!c.with_color ||
+                                                    g->prep_identity));
+    const int chunk_frames = kChunkGroups * group;
+    const int64_t px = (int64_t)c.depth_rows * c.depth_cols;
+    if (!raw_form && z.chunk_recs_pixels < px) {
+        O3DMI_HIP_CHECK(hipDeviceSynchronize());
+        for (int i = 0; i < 2; ++i) {
+            (void)hipFree(z.chunk_recs[i]);
+            z.chunk_recs[i] = nullptr;
+            O3DMI_HIP_CHECK(hipMalloc((void**)&z.chunk_recs[i],
+                                      sizeof(PixelRec) * (size_t)(px + 1) *
+                                              (size_t)kChunkFrames));
+        }
+        z.chunk_recs_pixels = px;
+    }
     // every launch of the previous call that reads the frame tables is over
     // once its last integrate launch is (the side stream waited for it)
     O3DMI_HIP_CHECK(hipStreamSynchronize(z.side));
     TouchParams shared;
-    if ((st = UploadSliceFrames(g, c, frames, n, &shared))) return st;
+    if ((st = UploadSliceFrames(g, c, frames, n, &shared,
+                                raw_form ? 0 : chunk_frames)))
+        return st;
     // the caller's images may still be in flight on its stream
     O3DMI_HIP_CHECK(hipEventRecord(z.ev_enter, s));
     O3DMI_HIP_CHECK(hipStreamWaitEvent(z.side, z.ev_enter, 0));
 
-    const int chunk_frames = kChunkGroups * group;
     const int n_chunks = (n + chunk_frames - 1) / chunk_frames;
     std::vector<int> chunk_stamp((size_t)n_chunks, 0);
+
+    // The prepare pass of a chunk's frames (front roles without the block
+    // touch), kMaxGroup frames per launch, into the chunk set's records.
+    auto issue_prepare = [&](int ci) -> int {
+        const int set = ci & 1;
+        const int f0 = ci * chunk_frames;
+        const int nc = n - f0 < chunk_frames ? n - f0 : chunk_frames;
+        FrameFrontArgs fa[kMaxGroup];
+        for (int b0 = 0; b0 < nc; b0 += kMaxGroup) {
+            const int m = nc - b0 < kMaxGroup ? nc - b0 : kMaxGroup;
+            for (int k = 0; k < m; ++k) {
+                FrameFrontArgs& a = fa[k];
+                a = FrameFrontArgs{};
+                const StreamFrame& fr = frames[f0 + b0 + k];
+                a.depth = (const uint16_t*)fr.depth;
+                a.color = c.with_color ? (const uint8_t*)fr.color : nullptr;
+                a.rows = c.depth_rows;
+                a.cols = c.depth_cols;
+                a.color_rows = c.color_rows;
+                a.color_cols = c.color_cols;
+                a.depth_intrinsic = c.depth_intrinsic;
+                a.color_intrinsic = c.color_intrinsic ? c.color_intrinsic
+                                                      : c.depth_intrinsic;
+                a.extrinsic = fr.extrinsic;
+                a.resolution = (int)g->block_resolution;
+                a.voxel_size = g->voxel_size;
+                a.sdf_trunc = g->voxel_size * c.trunc;
+                a.depth_scale = c.depth_scale;
+                a.depth_max = c.depth_max;
+                a.stride = 4;
+                a.group_stamp = 0;
+                a.group_bit = k;
+                a.touch_plane = 0;
+                a.col_lut = g->prep_valid ? g->prep_col : nullptr;
+                a.row_lut = g->prep_valid ? g->prep_row : nullptr;
+                a.depth_div_short = g->prep_valid && g->prep_div_short;
+                a.prep_identity = g->prep_valid && g->prep_identity;
+                a.recs = z.chunk_recs[set] +
+                         (size_t)(b0 + k) * (size_t)(z.chunk_recs_pixels + 1);
+                a.prepare_only = true;
+            }
+            int st2 = LaunchFrameStep(g->block_hashmap, fa, m, nullptr, z.side);
+            if (st2) return st2;
+        }
+        return O3DMI_OK;
+    };
 
     auto issue_side = [&](int ci, bool touch) -> int {
         const int set = ci & 1;
@@ -1488,11 +1603,12 @@ static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
             if ((st2 = LaunchTouchSlice(shared, z.frames_dev, f0, nc, rank,
                                         world, z.send_table, z.side)))
                 return st2;
+            if (!raw_form && (st2 = issue_prepare(ci))) return st2;
             if ((st2 = LaunchPackSlice(z.send_table, z.send_seg[set],
                                        z.capacity, z.side)))
                 return st2;
             const int64_t seg = SliceSegmentBytes(z.capacity);
-            if (comm && world > 1) {
+            if (comm) {
                 if ((st2 = comm->Allgather(z.send_seg[set], z.gathered[set],
                                            seg, z.side)))
                     return st2;
@@ -1602,6 +1718,7 @@ static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
         ia.depth_max = c.depth_max;
         ia.depth_scale = c.depth_scale;
         ia.depth_div_short = g->prep_div_short;
+        ia.raw = raw_form;
         ia.size_host = (int*)g->stream_status;
         ia.status_stamp = g->frame_stamp;
         ia.prof_count = prof ? g->prof_counts + g->prof_max + g->prof_frames

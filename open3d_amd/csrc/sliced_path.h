@@ -117,6 +117,8 @@ struct IntegFrame {
     float ext[3][4];  // extrinsic, as Camera::Make keeps it
     const uint16_t* depth;
     const uint8_t* color;
+    const PixelRec* recs;  // the frame's prepared records (records form)
+    const void* pad;
 };
 
 // Per-frame inputs of the side-stream kernels (device array, one per frame of
@@ -166,6 +168,9 @@ struct ChunkIntegrateArgs {
     int resolution;
     float voxel_size, sdf_trunc, depth_max, depth_scale;
     bool depth_div_short;
+    bool raw;                     // gather from the raw images (IntegFrame::
+                                  // depth / color) instead of the prepared
+                                  // records (IntegFrame::recs)
     int* size_host;               // host-mapped status of the integrate roles
     int status_stamp;
     int* prof_count;

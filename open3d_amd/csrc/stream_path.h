@@ -104,6 +104,9 @@ struct FrameFrontArgs {
     int* touch_status;    // host-mapped {map size, overflow stamp, group block
                           // count, group stamp}: published by the group's last
                           // touch workgroup (may be null)
+    bool prepare_only;    // no block touch: only the per-pixel prepare pass
+                          // (the sliced path touches per rank band and
+                          // prepares per chunk, sliced_path.h)
 };
 
 // Integrate role of ONE group.

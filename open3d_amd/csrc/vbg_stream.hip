@@ -500,6 +500,7 @@ struct IntegParams {
     int touch_plane;
     int rows, cols, resolution;
     int res_shift;  // log2(resolution) when it is a power of two, else -1
+    int deal;       // 1: an XCD takes a contiguous eighth of the block list
     int diag;       // O3DMI_STEP_DIAG (timing experiments, WRONG results):
                     // 1 = every gather reads record 0, 2 = no state stores;
                     // 3 = no skip of fully rejected waves (RIGHT results)
@@ -907,7 +908,20 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
     const int rank = (wg - first_of_xcd) >> 3;
     const int n_on_xcd =
             first_of_xcd < n_wg ? ((n_wg - 1 - first_of_xcd) >> 3) + 1 : 0;
-    const int64_t blocks_on_xcd = (n_blocks + 7 - xcd) >> 3;  // b = xcd + 8k
+    // Which blocks an XCD takes: every eighth one (deal 0: b = xcd + 8k), or a
+    // CONTIGUOUS eighth of the list (deal 1). The list is appended to by the
+    // touch workgroups roughly in ray-tile order, so a contiguous eighth is a
+    // band of the image: its blocks gather from the same record rows, which
+    // then sit in ONE XCD's L2 instead of in all eight (`read_overfetch`).
+    const int64_t per_xcd = (n_blocks + 7) >> 3;
+    const int64_t first_b = ip.deal ? xcd * per_xcd : xcd;
+    const int64_t blocks_on_xcd =
+            ip.deal ? (n_blocks - first_b < 0
+                               ? 0
+                               : (n_blocks - first_b < per_xcd
+                                          ? n_blocks - first_b
+                                          : per_xcd))
+                    : (n_blocks + 7 - xcd) >> 3;
     const int64_t n_items = blocks_on_xcd * parts;
     const unsigned sentinel_off =
             (unsigned)(ip.rows * ip.cols) * (unsigned)sizeof(PixelRec);
@@ -936,7 +950,7 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
             kb = m / parts;
             part = (int)(m - kb * parts);
         }
-        const int64_t b = (int64_t)xcd + (kb << 3);
+        const int64_t b = ip.deal ? first_b + kb : first_b + (kb << 3);
         int xb, yb, zb, block_idx;
         unsigned bits;
         unsigned long_bits = 0u;  // kLong: lane l holds word l & 7
@@ -965,6 +979,21 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                     frame_blocks += __popc(bw);
             }
             bits = any;  // "any frame at all"
+            // The launch lasts as long as its longest work item (a block seen
+            // by all frames of the chunk applies them one round after the
+            // other while its SIMD is shared with ~5 other waves): items with
+            // many frames get the issue priority, items with few fill in.
+            {
+                int n_set = 0;
+#pragma unroll
+                for (int w = 0; w < kChunkWords; ++w)
+                    n_set += __popc((unsigned)__builtin_amdgcn_readlane(
+                            (int)long_bits, w));
+                if (n_set >= 3 * ip.n_frames / 4) __builtin_amdgcn_s_setprio(3);
+                else if (n_set >= ip.n_frames / 2) __builtin_amdgcn_s_setprio(2);
+                else if (n_set >= ip.n_frames / 4) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
         } else if (ip.ready) {
             // ONE round trip: the ready entry the group's front roles left
             const ReadyEntry re = ip.ready[b];
@@ -1063,28 +1092,34 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
         // not hoisted above the first chunk's arithmetic -- they would double
         // the live registers)
         bool touched = false;
-#pragma nounroll
-        for (int c0 = 0; c0 < (kLong ? ip.n_frames : kMaxGroup); c0 += kChunk) {
-        // the round's frame bits (kChunk divides 32)
-        unsigned cbits;
-        if constexpr (kLong)
-            cbits = ((unsigned)__builtin_amdgcn_readlane((int)long_bits,
-                                                         c0 >> 5) >>
-                     (c0 & 31)) &
-                    ((1u << kChunk) - 1u);
-        else
-            cbits = (bits >> c0) & ((1u << kChunk) - 1u);
-        if (cbits == 0u) continue;  // wave-uniform
-        f2 zc[kChunk][kP];
-        PixelRec rec[kChunk][kV];
-        unsigned in_mask = 0u;  // kRaw: voxel projects into the image
-        // kRaw: upper half of the 8 colour bytes, bit offset of the pixel
-        unsigned chi[kRaw && kColor ? kChunk : 1][kV];
-        unsigned csh[kRaw && kColor ? kChunk : 1][kV];
+        // One ROUND = kChunk frames: `issue` projects the lane's voxels into
+        // the round's frames and requests their records, `apply` applies the
+        // frames in order from registers.
+        struct Round {
+            f2 zc[kChunk][kP];
+            PixelRec rec[kChunk][kV];
+            // kRaw: upper half of the 8 colour bytes, bit offset of the pixel
+            unsigned chi[kRaw && kColor ? kChunk : 1][kV];
+            unsigned csh[kRaw && kColor ? kChunk : 1][kV];
+            unsigned in_mask;  // kRaw: voxel projects into the image
+            unsigned cbits;    // frames of the round that touch the block
+        };
+        auto round_bits = [&](int c0) -> unsigned {
+            // (kChunk divides 32)
+            if constexpr (kLong)
+                return ((unsigned)__builtin_amdgcn_readlane((int)long_bits,
+                                                            c0 >> 5) >>
+                        (c0 & 31)) &
+                       ((1u << kChunk) - 1u);
+            else
+                return (bits >> c0) & ((1u << kChunk) - 1u);
+        };
+        auto issue = [&](int c0, Round& R) {
+        R.in_mask = 0u;
 #pragma unroll
         for (int fk = 0; fk < kChunk; ++fk) {
             const int f = c0 + fk;
-            if (!((cbits >> fk) & 1u)) continue;  // wave-uniform
+            if (!((R.cbits >> fk) & 1u)) continue;  // wave-uniform
             // The frame's constants are fetched here, per work item (scalar
             // loads from the argument block / the frame table): hoisted out of
             // the item loop they would occupy ~60 scalar registers and spill.
@@ -1093,7 +1128,9 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                           : *reinterpret_cast<const float(*)[3][4]>(
                                     &ip.ext[kLong ? 0 : f][0][0] + opaque);
             const char* __restrict__ recs = reinterpret_cast<const char*>(
-                    kRaw ? nullptr : *(&ip.recs[kLong ? 0 : f] + opaque));
+                    kRaw ? nullptr
+                         : (kLong ? ip.frame_tab[f].recs
+                                  : *(&ip.recs[kLong ? 0 : f] + opaque)));
             const char* __restrict__ dimg = reinterpret_cast<const char*>(
                     kLong ? ip.frame_tab[f].depth
                           : (kRaw ? *(&ip.raw_depth[kLong ? 0 : f] + opaque)
@@ -1110,26 +1147,26 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
             for (int p = 0; p < kP; ++p) {
                 xc[p] = xs[p] * e[0][0] + y0 + z0 + e[0][3];
                 yc[p] = xs[p] * e[1][0] + y1 + z1 + e[1][3];
-                zc[fk][p] = xs[p] * e[2][0] + y2 + z2 + e[2][3];
+                R.zc[fk][p] = xs[p] * e[2][0] + y2 + z2 + e[2][3];
             }
             // Camera::Project's 1 / z: the verified short reciprocal unless a
             // lane of the wave is outside its range. z is monotone along the
             // lane's 4 voxels, so the two end voxels decide.
             f2 inv_z[kP];
-            const bool out = RcpOutOfRange(zc[fk][0].x) ||
-                             RcpOutOfRange(zc[fk][kP - 1].y);
+            const bool out = RcpOutOfRange(R.zc[fk][0].x) ||
+                             RcpOutOfRange(R.zc[fk][kP - 1].y);
             if (kDiv < 2 || __builtin_amdgcn_ballot_w64(out) != 0ull) {
 #pragma unroll
                 for (int p = 0; p < kP; ++p)
-                    inv_z[p] = f2{1.0f / zc[fk][p].x, 1.0f / zc[fk][p].y};
+                    inv_z[p] = f2{1.0f / R.zc[fk][p].x, 1.0f / R.zc[fk][p].y};
             } else {
 #pragma unroll
                 for (int p = 0; p < kP; ++p) {
-                    f2 r = f2{__builtin_amdgcn_rcpf(zc[fk][p].x),
-                              __builtin_amdgcn_rcpf(zc[fk][p].y)};
+                    f2 r = f2{__builtin_amdgcn_rcpf(R.zc[fk][p].x),
+                              __builtin_amdgcn_rcpf(R.zc[fk][p].y)};
 #pragma unroll
                     for (int k = 0; k < (kDiv >= 2 ? kDiv - 1 : 1); ++k)
-                        r = PkFma(PkFma(-zc[fk][p], r, Splat(1.0f)), r, r);
+                        r = PkFma(PkFma(-R.zc[fk][p], r, Splat(1.0f)), r, r);
                     inv_z[p] = r;
                 }
             }
@@ -1149,13 +1186,13 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                     // 2^24, and it issues at full rate)
                     if constexpr (kRaw) {
                         // pixel index; lanes outside the image read pixel 0
-                        // and carry a cleared bit in in_mask
+                        // and carry a cleared bit in R.in_mask
                         const unsigned pix =
                                 in ? __umul24((unsigned)(int)vh,
                                               (unsigned)ip.cols) +
                                              (unsigned)(int)uh
                                    : 0u;
-                        in_mask |= (in ? 1u : 0u) << (fk * kV + 2 * p + h);
+                        R.in_mask |= (in ? 1u : 0u) << (fk * kV + 2 * p + h);
                         PixelRec r;
                         // .d holds the raw uint16 depth (converted below)
                         r.d = __uint_as_float((unsigned)*reinterpret_cast<
@@ -1172,15 +1209,15 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                             const uint2 q =
                                     *reinterpret_cast<const uint2*>(cimg + al);
                             r.rgba = q.x;
-                            chi[fk][2 * p + h] = q.y;
-                            csh[fk][2 * p + h] = (b3 - al) * 8u;
+                            R.chi[fk][2 * p + h] = q.y;
+                            R.csh[fk][2 * p + h] = (b3 - al) * 8u;
                         }
-                        rec[fk][2 * p + h] = r;
+                        R.rec[fk][2 * p + h] = r;
                     } else {
                     const unsigned off =
                             __umul24((unsigned)(int)vh, row_bytes) +
                             (unsigned)(int)uh * (unsigned)sizeof(PixelRec);
-                    rec[fk][2 * p + h] = *reinterpret_cast<const PixelRec*>(
+                    R.rec[fk][2 * p + h] = *reinterpret_cast<const PixelRec*>(
                             recs + (ip.diag == 1 ? 0u
                                                  : (in ? off : sentinel_off)));
                     }
@@ -1188,10 +1225,12 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
             }
         }
 
+        };
+        auto apply = [&](Round& R) {
         // 3. frames applied in order (VoxelBlockGridImpl.h:258-302)
 #pragma unroll
         for (int fk = 0; fk < kChunk; ++fk) {
-            if (!((cbits >> fk) & 1u)) continue;  // wave-uniform
+            if (!((R.cbits >> fk) & 1u)) continue;  // wave-uniform
             f2 sdf[kP];
             bool ok[kV];
             bool tiny = false;
@@ -1201,8 +1240,8 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                 // divisor form when the host verified it for all 65536 depths
 #pragma unroll
                 for (int p = 0; p < kP; ++p) {
-                    f2 a = f2{(float)__float_as_uint(rec[fk][2 * p].d),
-                              (float)__float_as_uint(rec[fk][2 * p + 1].d)};
+                    f2 a = f2{(float)__float_as_uint(R.rec[fk][2 * p].d),
+                              (float)__float_as_uint(R.rec[fk][2 * p + 1].d)};
                     f2 q;
                     if (ip.depth_div_short) {
                         const f2 q0 = a * ip.inv_depth_scale;
@@ -1213,10 +1252,10 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                     }
                     // outside the image: depth 0 = invalid (the records
                     // path's sentinel)
-                    rec[fk][2 * p].d =
-                            ((in_mask >> (fk * kV + 2 * p)) & 1u) ? q.x : 0.0f;
-                    rec[fk][2 * p + 1].d =
-                            ((in_mask >> (fk * kV + 2 * p + 1)) & 1u) ? q.y
+                    R.rec[fk][2 * p].d =
+                            ((R.in_mask >> (fk * kV + 2 * p)) & 1u) ? q.x : 0.0f;
+                    R.rec[fk][2 * p + 1].d =
+                            ((R.in_mask >> (fk * kV + 2 * p + 1)) & 1u) ? q.y
                                                                       : 0.0f;
                 }
             }
@@ -1224,8 +1263,8 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
             for (int p = 0; p < kP; ++p) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const float dh = rec[fk][2 * p + h].d;
-                    const float zh = h ? zc[fk][p].y : zc[fk][p].x;
+                    const float dh = R.rec[fk][2 * p + h].d;
+                    const float zh = h ? R.zc[fk][p].y : R.zc[fk][p].x;
                     const float sh = dh - zh;
                     ok[2 * p + h] = !(dh <= 0) && !(dh > ip.depth_max) &&
                                     !(zh <= 0) && !(sh < -ip.sdf_trunc);
@@ -1277,14 +1316,14 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                 ts[p] = f2{ok[2 * p] ? t_new.x : ts[p].x,
                            ok[2 * p + 1] ? t_new.y : ts[p].y};
                 if constexpr (kColor) {
-                    unsigned rg0 = rec[fk][2 * p].rgba;
-                    unsigned rg1 = rec[fk][2 * p + 1].rgba;
+                    unsigned rg0 = R.rec[fk][2 * p].rgba;
+                    unsigned rg1 = R.rec[fk][2 * p + 1].rgba;
                     if constexpr (kRaw) {
-                        rg0 = (unsigned)((((unsigned long long)chi[fk][2 * p]
-                                           << 32) | rg0) >> csh[fk][2 * p]);
+                        rg0 = (unsigned)((((unsigned long long)R.chi[fk][2 * p]
+                                           << 32) | rg0) >> R.csh[fk][2 * p]);
                         rg1 = (unsigned)((((unsigned long long)
-                                                   chi[fk][2 * p + 1] << 32) |
-                                          rg1) >> csh[fk][2 * p + 1]);
+                                                   R.chi[fk][2 * p + 1] << 32) |
+                                          rg1) >> R.csh[fk][2 * p + 1]);
                     }
                     // (raw form: the colour pixel IS the depth pixel, inside
                     // the image whenever the voxel is ok)
@@ -1309,7 +1348,37 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                            ok[2 * p + 1] ? w_new.y : weight.y};
             }
         }
-        }  // chunk
+        };
+        if constexpr (kLong) {
+            // (Measured and dropped, profiles/r4i: a software pipeline over the
+            // rounds -- the next round's gathers in flight while this round's
+            // frames are applied. The double set of round registers costs two
+            // waves of occupancy and the launch got 4 - 10 % SLOWER: with ~5
+            // waves per SIMD a round's latency is the other waves' arithmetic,
+            // not its own gathers.)
+#pragma nounroll
+            for (int c0 = 0; c0 < ip.n_frames; c0 += kChunk) {
+                Round r;
+                r.cbits = round_bits(c0);
+                if (r.cbits == 0u) continue;  // wave-uniform
+                issue(c0, r);
+                apply(r);
+            }
+        } else {
+            // (kChunk frames at a time: a group of up to kMaxGroup frames is
+            // applied chunk after chunk to the same register-resident state;
+            // the chunk loop is a real loop, so that the second chunk's
+            // gathers are not hoisted above the first chunk's arithmetic --
+            // they would double the live registers)
+#pragma nounroll
+            for (int c0 = 0; c0 < kMaxGroup; c0 += kChunk) {
+                Round r;
+                r.cbits = round_bits(c0);
+                if (r.cbits == 0u) continue;  // wave-uniform
+                issue(c0, r);
+                apply(r);
+            }
+        }
         if (touched && ip.diag != 2) {
             TVec t_out;
             WVec w4;
@@ -1387,12 +1456,15 @@ struct ChunkParams {
     HashView hv;
     IntegParams integ;
 };
-template <typename weight_t, typename color_t, bool kColor, int kDiv>
-__global__ void __launch_bounds__(256, 5)
+// kRaw = false: the frames' prepared records (one 8-byte gather per voxel and
+// frame, the per-group role's registers and occupancy); true: raw images.
+template <typename weight_t, typename color_t, bool kColor, int kDiv,
+          bool kRaw>
+__global__ void __launch_bounds__(256, kRaw ? 5 : 7)
 ChunkIntegrateKernel(ChunkParams cp) {
-    IntegrateRoleWide<weight_t, color_t, kColor, kDiv, kRawChunk, 1, true,
-                      true>(cp.hv, cp.integ, (int)blockIdx.x, (int)gridDim.x,
-                            0);
+    IntegrateRoleWide<weight_t, color_t, kColor, kDiv,
+                      kRaw ? kRawChunk : kGroupChunk, 1, kRaw, true>(
+            cp.hv, cp.integ, (int)blockIdx.x, (int)gridDim.x, 0);
 }
 
 }  // namespace
@@ -1560,9 +1632,16 @@ static int VerifyFastDivision(float b, float* y_out, bool wait = false) {
     const int flags = *p.flag_host;
     p.result = flags < 0 ? 0 : DivFormsFromFlags(flags);
     DivProofReport(b, p.result, flags);
-    // (stream, event and the two words stay allocated: freeing device memory
-    // synchronises the device, and there are a handful of distances per
-    // process)
+    // The private stream goes back at once: a process has few hardware queues,
+    // and the NEXT stream somebody creates (the ICP driver's side stream, in
+    // the middle of a tracking loop) costs ~8 ms instead of ~2 ms when it
+    // cannot reuse this one (profiles/r4j). The event and the two words stay
+    // (freeing device memory synchronises the device; there are a handful of
+    // distances per process).
+    if (p.stream) {
+        (void)hipStreamDestroy(p.stream);
+        p.stream = nullptr;
+    }
     return p.result;
 }
 
@@ -1600,7 +1679,7 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
     for (int i = 0; i < n_fronts; ++i) {
         const FrameFrontArgs* f = &fronts[i];
         O3DMI_REQUIRE(f->group_bit >= 0 && f->group_bit < kMaxGroup &&
-                              f->group_stamp > 0,
+                              (f->group_stamp > 0 || f->prepare_only),
                       "bad group bit / stamp");
         const TouchParams tp = MakeTouchParams(
                 f->depth_intrinsic, f->extrinsic, f->rows, f->cols, f->stride,
@@ -1636,8 +1715,10 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         fs.group_stamp = f->group_stamp;
         fs.touch_plane = f->touch_plane & 1;
         // one touch workgroup per 16 x 16 tile of rays
-        fs.n_touch_wg = ((tp.cols_strided + 15) / 16) *
-                        ((tp.rows_strided + 15) / 16);
+        fs.n_touch_wg = f->prepare_only
+                                ? 0
+                                : ((tp.cols_strided + 15) / 16) *
+                                          ((tp.rows_strided + 15) / 16);
         // 16 pixels per prepare lane
         fs.n_prep_wg = (f->rows * f->cols + kBlock * 16 - 1) / (kBlock * 16);
         if (fs.n_prep_wg < 1) fs.n_prep_wg = 1;
@@ -1679,6 +1760,11 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
             return e ? std::atoi(e) : 0;
         }();
         ip.diag = diag;
+        static const int deal = []() {
+            const char* e = std::getenv("O3DMI_STEP_DEAL");
+            return e ? std::atoi(e) : 1;
+        }();
+        ip.deal = deal;
         ip.res_shift = -1;
         for (int sh = 2; sh < 12; ++sh)
             if ((1 << sh) == a->resolution) ip.res_shift = sh;
@@ -1783,6 +1869,7 @@ int LaunchChunkIntegrate(o3dmi_hash* bh, const ChunkIntegrateArgs& a,
     ip.cols = a.cols;
     ip.resolution = a.resolution;
     ip.diag = 0;
+    ip.deal = 0;
     ip.res_shift = -1;
     for (int sh = 2; sh < 12; ++sh)
         if ((1 << sh) == a.resolution) ip.res_shift = sh;
@@ -1816,8 +1903,15 @@ int LaunchChunkIntegrate(o3dmi_hash* bh, const ChunkIntegrateArgs& a,
     const dim3 grid((unsigned)g), block(256);
     const bool col = a.with_color && a.color != nullptr;
 #define O3DMI_LAUNCH_CHUNK_D(WT, VT, COLOR, D)                                \
-    hipLaunchKernelGGL((ChunkIntegrateKernel<WT, VT, COLOR, D>), grid, block, \
-                       0, s, cp)
+    do {                                                                      \
+        if (a.raw)                                                            \
+            hipLaunchKernelGGL((ChunkIntegrateKernel<WT, VT, COLOR, D, true>), \
+                               grid, block, 0, s, cp);                        \
+        else                                                                  \
+            hipLaunchKernelGGL(                                               \
+                    (ChunkIntegrateKernel<WT, VT, COLOR, D, false>), grid,    \
+                    block, 0, s, cp);                                         \
+    } while (0)
 #define O3DMI_LAUNCH_CHUNK(WT, VT, COLOR)                                     \
     do {                                                                      \
         switch (fast_div) {                                                   \

@@ -889,20 +889,24 @@ def _blocks_sorted(g, with_color=True):
     return out
 
 
+@pytest.mark.parametrize("raw", [False, True])
 @pytest.mark.parametrize("world,group,grid_f32,with_color", [
     (1, 4, False, True), (3, 2, False, True), (8, 3, False, True),
     (8, 12, False, True), (2, 16, True, True), (4, 5, False, False)])
 def test_sliced_touch_ownership_union_is_the_single_grid(world, group,
-                                                         grid_f32, with_color):
+                                                         grid_f32, with_color,
+                                                         raw, monkeypatch):
     """SURVEY 8(e) scheme A as specified: rank r touches only its band of ray
     tiles, the candidate records of all ranks are gathered (here computed on
     one device: gather_slices), rank r activates the keys it owns and
-    integrates them from the RAW images. The `world` grids are the ownership
-    classes of the single grid the ordinary stream builds, bit for bit --
-    several chunks per call, groups that do not divide the chunk, depth-only
-    and float32 grids."""
+    integrates them with ONE launch per chunk -- from records prepared on the
+    side stream, or (raw) straight from the images. The `world` grids are the
+    ownership classes of the single grid the ordinary stream builds, bit for
+    bit -- several chunks per call, chunks that end mid-way, depth-only and
+    float32 grids."""
     _lib, geometry = _gpu()
     from open3d_amd import sharding
+    monkeypatch.setenv("O3DMI_SLICED_RAW", "1" if raw else "0")
     n = 2 * 16 * group + 3 if group <= 3 else 16 * group + 5
     ks = [(i * 7) % 900 for i in range(n)]
     ds, cs, dt, ct, Ts, K = _stream_frames(ks, 320, 240)
@@ -1114,6 +1118,94 @@ def test_frame_sharded_merge_across_two_processes():
     assert np.abs(tsdf - want[1]).max() <= 1e-5
     assert np.abs(color.astype(np.int64) - want[3].astype(np.int64)).max() \
         <= len(fr)
+
+
+def _sliced_rank(rank, world):
+    """One rank of the multi-process block-ownership run with the sliced touch:
+    integrate_frames on a grid with an ownership and the library's
+    communicator installed (torch.distributed / gloo as its transport)."""
+    import torch.distributed as dist
+    from open3d_amd.sharding import Comm
+    _lib, geometry = _gpu()
+    ks = [(i * 7) % 900 for i in range(70)]
+    ds, cs, dt, ct, Ts, K = _stream_frames(ks, 320, 240)
+    g = _mk_grid(geometry, False, block_count=8192)
+    g.set_block_ownership(rank, world)
+    comm = Comm.torch(dist)
+    comm.install()
+    try:
+        # two calls: the second starts while the side stream still holds the
+        # first one's last chunk
+        g.integrate_frames(dt[:40], ct[:40], K, K, Ts[:40], sc.DEPTH_SCALE,
+                           sc.DEPTH_MAX, sc.TRUNC_MULT, frames_per_launch=2)
+        g.integrate_frames(dt[40:], ct[40:], K, K, Ts[40:], sc.DEPTH_SCALE,
+                           sc.DEPTH_MAX, sc.TRUNC_MULT, frames_per_launch=2)
+        torch.cuda.synchronize()
+        st = g.sliced_stats()
+    finally:
+        Comm.uninstall()
+        comm.destroy()
+    return _blocks_sorted(g), st
+
+
+def test_sliced_touch_across_two_processes():
+    """The sliced path end to end with a REAL exchange: two processes (one
+    rank each, sharing this GPU), the library's communicator over
+    torch.distributed (gloo), `integrate_frames` dispatching to the sliced
+    path by itself. The two grids are the two ownership classes of the single
+    grid, bit for bit, and every chunk went through the all-gather."""
+    from test_sharding import _run
+    from open3d_amd import sharding
+    _lib, geometry = _gpu()
+    ks = [(i * 7) % 900 for i in range(70)]
+    ds, cs, dt, ct, Ts, K = _stream_frames(ks, 320, 240)
+    full_g = _mk_grid(geometry, False, block_count=8192)
+    full_g.integrate_frames(dt, ct, K, K, Ts, sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                            sc.TRUNC_MULT, frames_per_launch=2)
+    full = _blocks_sorted(full_g)
+    owner = sharding.block_owner(full[0], 2)
+    got = _run(_sliced_rank)
+    for r in range(2):
+        part, st = got[r]
+        assert st["chunks"] == 2 + 1  # 40 frames = 2 chunks of 32, 30 = 1
+        sel = owner == r
+        assert np.array_equal(part[0], full[0][sel])
+        for a, b in zip(part[1:], full[1:]):
+            assert a.tobytes() == b[sel].tobytes()
+
+
+def test_sliced_touch_all_gather_over_rccl_single_rank():
+    """ncclAllGather on the side stream of the sliced path, on the hardware at
+    hand: a one-rank RCCL communicator (more ranks need more GPUs than the
+    test box has) -- the grid equals the ordinary stream's."""
+    _lib, geometry = _gpu()
+    from open3d_amd.sharding import Comm
+    L = _lib.lib()
+    if not L.o3dmi_rccl_available():
+        pytest.skip("no librccl.so in this process")
+    ident = (C.c_char * 128)()
+    _lib.check(L.o3dmi_rccl_unique_id(C.cast(ident, C.c_void_p)), "unique_id")
+    h = C.c_void_p()
+    _lib.check(L.o3dmi_comm_create_rccl(ident.raw, 0, 1, C.byref(h)),
+               "comm_create_rccl")
+    comm = Comm(h)
+    ks = [(i * 7) % 900 for i in range(40)]
+    ds, cs, dt, ct, Ts, K = _stream_frames(ks, 320, 240)
+    want_g = _mk_grid(geometry, False, block_count=8192)
+    want_g.integrate_frames(dt, ct, K, K, Ts, sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                            sc.TRUNC_MULT, frames_per_launch=2)
+    g = _mk_grid(geometry, False, block_count=8192)
+    batch = g.prepare_frames(dt, ct, K, K, Ts)
+    comm.install()
+    try:
+        g.integrate_frames_sliced(batch, None, sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                                  sc.TRUNC_MULT, frames_per_launch=2)
+        torch.cuda.synchronize()
+    finally:
+        Comm.uninstall()
+        comm.destroy()
+    for a, b in zip(_blocks_sorted(g), _blocks_sorted(want_g)):
+        assert a.tobytes() == b.tobytes()
 
 
 def test_last_frame_block_coordinates_equal_a_second_block_touch():
