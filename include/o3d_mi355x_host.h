@@ -740,7 +740,11 @@ int o3dmi_vbg_merge_blocks(o3dmi_vbg_t* g, const int32_t* keys_dev,
  * ranks hold DISJOINT grids whose union is the model of the whole stream: the
  * same layout block-ownership sharding produces. A rank moves (world - 1) /
  * world of its blocks once (an all-gather of everything would move world x
- * as much to every rank). Collective: every rank of `comm` must call it.
+ * as much to every rank). Collective: every rank of `comm` must call it --
+ * also a rank that has an error of its own to report, or the others wait in
+ * the exchange. Room for the arriving blocks is reserved BEFORE anything is
+ * erased; after o3dmi_vbg_allgather_owned_blocks a further merge is refused
+ * (the replicated blocks would be counted again).
  * o3dmi_vbg_allgather_owned_blocks then replicates the finished blocks on
  * every rank (when each GPU is to ray-cast the whole model). */
 int o3dmi_vbg_merge_frame_sharded(o3dmi_vbg_t* g, o3dmi_comm_t* comm,

@@ -15,6 +15,7 @@
 
 #include <cstdlib>
 #include <mutex>
+#include <set>
 #include <string>
 
 #include "../collectives.h"
@@ -49,12 +50,18 @@ struct Rccl {
 };
 constexpr int kNcclUint8 = 1, kNcclFloat64 = 8, kNcclSum = 0;
 
+// Why RCCL could not be loaded: written once, inside LoadRccl's call_once
+// (it used to be assigned on every failing call, a data race when
+// several rank threads probe RCCL).
 std::string g_rccl_why;
 
 Rccl* LoadRccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
+        struct SetWhy {
+            ~SetWhy() { g_rccl_why = r.why; }
+        } set_why;
         const char* env = std::getenv("O3DMI_RCCL_LIB");
         const char* names[] = {env, "librccl.so.1", "librccl.so"};
         // an instance the process already holds first (RTLD_NOLOAD)
@@ -87,7 +94,7 @@ Rccl* LoadRccl() {
                 (decltype(r.GetErrorString))sym("ncclGetErrorString");
         if (!r.why.empty()) r.handle = nullptr;
     });
-    if (!r.handle) g_rccl_why = r.why;
+    // (r.why is written once, inside call_once: immutable from here on)
     return r.handle ? &r : nullptr;
 }
 
@@ -108,10 +115,32 @@ thread_local o3dmi_comm* g_thread_comm = nullptr;
 // the communicator o3dmi_set_rccl_comm made for the calling thread
 thread_local o3dmi_comm* g_adopted = nullptr;
 
+// Communicators alive in this process. A communicator may be installed
+// (o3dmi_set_comm) on one thread and destroyed on another: the installing
+// thread's slot cannot be reached from there, so ThreadComm() checks that
+// what the slot names is still alive instead (a dangling slot).
+std::mutex g_live_mu;
+std::set<const o3dmi_comm*> g_live;
+void Register(const o3dmi_comm* c) {
+    std::lock_guard<std::mutex> lock(g_live_mu);
+    g_live.insert(c);
+}
+bool Unregister(const o3dmi_comm* c) {
+    std::lock_guard<std::mutex> lock(g_live_mu);
+    return g_live.erase(c) != 0;
+}
+bool Alive(const o3dmi_comm* c) {
+    std::lock_guard<std::mutex> lock(g_live_mu);
+    return g_live.count(c) != 0;
+}
+
 }  // namespace
 
 namespace o3dmi {
-o3dmi_comm* ThreadComm() { return g_thread_comm; }
+o3dmi_comm* ThreadComm() {
+    if (g_thread_comm && !Alive(g_thread_comm)) g_thread_comm = nullptr;
+    return g_thread_comm;
+}
 }  // namespace o3dmi
 
 int o3dmi_comm::AllreduceSumF64(double* dev, int64_t n, hipStream_t s) {
@@ -228,6 +257,7 @@ int o3dmi_comm_create_rccl(const void* id128, int rank, int world,
     c->world = world;
     c->nccl = nccl;
     c->owns_nccl = true;
+    Register(c);
     *out = c;
     return O3DMI_OK;
 }
@@ -244,6 +274,7 @@ int o3dmi_comm_adopt_rccl(void* nccl_comm, o3dmi_comm_t** out) {
     c->rank = rank;
     c->world = world;
     c->nccl = nccl_comm;
+    Register(c);
     *out = c;
     return O3DMI_OK;
 }
@@ -258,12 +289,17 @@ int o3dmi_comm_create_custom(const o3dmi_transport_t* table, void* user,
     c->custom = true;
     c->table = *table;
     c->user = user;
+    Register(c);
     *out = c;
     return O3DMI_OK;
 }
 
 int o3dmi_comm_destroy(o3dmi_comm_t* c) {
     if (!c) return O3DMI_OK;
+    if (!Unregister(c)) {
+        SetLastError("o3dmi_comm_destroy: not a live communicator");
+        return O3DMI_ERR_INVALID_ARG;
+    }
     if (g_thread_comm == c) g_thread_comm = nullptr;
     if (g_adopted == c) g_adopted = nullptr;
     int st = O3DMI_OK;
@@ -288,6 +324,7 @@ int o3dmi_set_rccl_comm(void* nccl_comm) {
         o3dmi_comm* old = g_adopted;
         g_adopted = nullptr;
         if (g_thread_comm == old) g_thread_comm = nullptr;
+        (void)Unregister(old);
         delete old;  // adopted: the ncclComm_t stays the caller's
     }
     if (!nccl_comm) {

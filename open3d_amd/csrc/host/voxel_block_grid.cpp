@@ -133,6 +133,10 @@ struct o3dmi_vbg {
         int64_t reapplied = 0;
     } sliced;
     int sliced_slots_wanted = 8192;
+    // o3dmi_vbg_allgather_owned_blocks has replicated the other ranks' blocks
+    // here: a further owner-partitioned merge would send them back to their
+    // owners and count their weights again
+    bool replicated = false;
 
     int AttrIndex(const char* name) const {
         for (size_t i = 0; i < attr_names.size(); ++i)
@@ -2146,6 +2150,10 @@ int o3dmi_vbg_merge_frame_sharded(o3dmi_vbg_t* g, o3dmi_comm_t* comm,
     const int world = comm->world, me = comm->rank;
     O3DMI_REQUIRE(world >= 1 && world <= kMaxWorld, "world size out of range");
     if (world == 1) return O3DMI_OK;
+    O3DMI_REQUIRE(!g->replicated,
+                  "merge_frame_sharded after allgather_owned_blocks: the grid "
+                  "holds the other ranks' finished blocks, merging again would "
+                  "count them twice");
     hipStream_t s = (hipStream_t)stream;
     const size_t n_attr = g->attr_names.size();
     const int64_t res = g->block_resolution;
@@ -2171,39 +2179,53 @@ int o3dmi_vbg_merge_frame_sharded(o3dmi_vbg_t* g, o3dmi_comm_t* comm,
     } scratch{s, {}};
     int st;
     // 1. ---------------------------------------------------------------------
-    const int64_t cap = o3dmi_hash_capacity(g->block_hashmap);
+    // (a function: run again after a Reserve, which renumbers the buffer
+    // indices `grouped` holds)
     int32_t *active = nullptr, *owner = nullptr, *grouped = nullptr;
     int* counters = nullptr;  // counts[world] | cursor[world]
-    if ((st = scratch.Alloc((void**)&active, sizeof(int32_t) * (size_t)cap)) ||
-        (st = scratch.Alloc((void**)&owner, sizeof(int32_t) * (size_t)cap)) ||
-        (st = scratch.Alloc((void**)&grouped, sizeof(int32_t) * (size_t)cap)) ||
-        (st = scratch.Alloc((void**)&counters, sizeof(int) * 2 * kMaxWorld)))
-        return st;
     int64_t n = 0;
-    if ((st = o3dmi_hash_active_indices(g->block_hashmap, active, stream, &n)))
-        return st;
-    if (n > 1 && (st = o3dmi_sort_indices(active, n, stream))) return st;
-    O3DMI_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(int) * 2 * kMaxWorld, s));
-    const int* key_buffer = (const int*)o3dmi_hash_key_buffer(g->block_hashmap);
-    if (n > 0)
-        hipLaunchKernelGGL(OwnerCountKernel, dim3(GridFor(n, kBlock)),
-                           dim3(kBlock), 0, s, active, n, key_buffer, world,
-                           owner, counters);
+    const int* key_buffer = nullptr;
     int host_counts[kMaxWorld] = {0};
-    O3DMI_HIP_CHECK(hipMemcpyAsync(host_counts, counters, sizeof(int) * world,
-                                   hipMemcpyDeviceToHost, s));
-    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
     OwnerOffsets off;
-    int run = 0;
-    for (int r = 0; r < kMaxWorld; ++r) {
-        off.v[r] = run;
-        if (r < world) run += host_counts[r];
-    }
-    if (n > 0)
-        hipLaunchKernelGGL(OwnerGroupKernel, dim3(GridFor(n, kBlock)),
-                           dim3(kBlock), 0, s, active, n, owner, off,
-                           counters + kMaxWorld, grouped);
-    O3DMI_HIP_CHECK(hipGetLastError());
+    auto group_by_owner = [&]() -> int {
+        const int64_t cap = o3dmi_hash_capacity(g->block_hashmap);
+        int e;
+        if ((e = scratch.Alloc((void**)&active, sizeof(int32_t) * (size_t)cap)) ||
+            (e = scratch.Alloc((void**)&owner, sizeof(int32_t) * (size_t)cap)) ||
+            (e = scratch.Alloc((void**)&grouped,
+                               sizeof(int32_t) * (size_t)cap)) ||
+            (e = scratch.Alloc((void**)&counters, sizeof(int) * 2 * kMaxWorld)))
+            return e;
+        n = 0;
+        if ((e = o3dmi_hash_active_indices(g->block_hashmap, active, stream,
+                                           &n)))
+            return e;
+        if (n > 1 && (e = o3dmi_sort_indices(active, n, stream))) return e;
+        O3DMI_HIP_CHECK(hipMemsetAsync(counters, 0,
+                                       sizeof(int) * 2 * kMaxWorld, s));
+        key_buffer = (const int*)o3dmi_hash_key_buffer(g->block_hashmap);
+        if (n > 0)
+            hipLaunchKernelGGL(OwnerCountKernel, dim3(GridFor(n, kBlock)),
+                               dim3(kBlock), 0, s, active, n, key_buffer, world,
+                               owner, counters);
+        for (int r = 0; r < kMaxWorld; ++r) host_counts[r] = 0;
+        O3DMI_HIP_CHECK(hipMemcpyAsync(host_counts, counters,
+                                       sizeof(int) * world,
+                                       hipMemcpyDeviceToHost, s));
+        O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+        int run = 0;
+        for (int r = 0; r < kMaxWorld; ++r) {
+            off.v[r] = run;
+            if (r < world) run += host_counts[r];
+        }
+        if (n > 0)
+            hipLaunchKernelGGL(OwnerGroupKernel, dim3(GridFor(n, kBlock)),
+                               dim3(kBlock), 0, s, active, n, owner, off,
+                               counters + kMaxWorld, grouped);
+        O3DMI_HIP_CHECK(hipGetLastError());
+        return O3DMI_OK;
+    };
+    if ((st = group_by_owner())) return st;
     // 2. ---------------------------------------------------------------------
     int64_t* matrix_dev = nullptr;  // [world][world]: row r = rank r's counts
     if ((st = scratch.Alloc((void**)&matrix_dev,
@@ -2231,6 +2253,22 @@ int o3dmi_vbg_merge_frame_sharded(o3dmi_vbg_t* g, o3dmi_comm_t* comm,
         recv_n[(size_t)r] = r == me ? 0 : matrix[(size_t)r * world + me];
         recv_first[(size_t)r] = recv_total;
         recv_total += recv_n[(size_t)r];
+    }
+    // Room for every block that will arrive BEFORE anything is sent away or
+    // erased (a capacity / allocation failure in step 5 used to
+    // leave a grid whose foreign blocks were already gone). The map keeps its
+    // own host_counts[me] blocks; a Reserve renumbers the buffer indices, so
+    // the grouping is redone (the counts the ranks exchanged do not change).
+    if ((int64_t)host_counts[me] + recv_total >
+        o3dmi_hash_capacity(g->block_hashmap)) {
+        const int64_t cap0 = o3dmi_hash_capacity(g->block_hashmap);
+        const int64_t need = (int64_t)n + recv_total;
+        if ((st = o3dmi_hash_reserve(g->block_hashmap,
+                                     need > 2 * cap0 ? need : 2 * cap0,
+                                     stream)))
+            return st;
+        g->known_valid = false;
+        if ((st = group_by_owner())) return st;
     }
     // 3. ---------------------------------------------------------------------
     auto exchange = [&](const void* src_rows, int64_t row, void** out) -> int {
@@ -2389,6 +2427,7 @@ int o3dmi_vbg_allgather_owned_blocks(o3dmi_vbg_t* g, o3dmi_comm_t* comm,
                                          stream)))
             return st;
     }
+    g->replicated = world > 1;
     return O3DMI_OK;
 }
 

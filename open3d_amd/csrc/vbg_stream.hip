@@ -1760,9 +1760,13 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
             return e ? std::atoi(e) : 0;
         }();
         ip.diag = diag;
+        // O3DMI_STEP_DEAL=1 (A / B, profiles/r4m): contiguous eighths -- reads
+        // 2.03 -> 1.95 x the minimum, 2 % SLOWER (128.3 k -> 125.5 k frames/s:
+        // the list is only roughly in tile order, and eighths of it are less
+        // even than every eighth block)
         static const int deal = []() {
             const char* e = std::getenv("O3DMI_STEP_DEAL");
-            return e ? std::atoi(e) : 1;
+            return e ? std::atoi(e) : 0;
         }();
         ip.deal = deal;
         ip.res_shift = -1;

@@ -174,11 +174,11 @@ def multi_scale_icp(source, target, target_normals, voxel_sizes, criteria_list,
                 return 1
         dar = _lib.ALLREDUCE_DEVICE(_dar)
         _lib.lib().o3dmi_set_device_allreduce(dar, None)
-    if device_counts is not None:
-        ns_dev, nt_dev = device_counts
-        _lib.check(_lib.lib().o3dmi_registration_set_device_counts(
-            _lib.ptr(ns_dev), _lib.ptr(nt_dev)), "set_device_counts")
     try:
+        if device_counts is not None:
+            ns_dev, nt_dev = device_counts
+            _lib.check(_lib.lib().o3dmi_registration_set_device_counts(
+                _lib.ptr(ns_dev), _lib.ptr(nt_dev)), "set_device_counts")
         st = _icp_call(source, ns, target, target_normals, nt, S, vs, crit, md,
                        init, p2point, symmetric, colored, attrs, est, cb, ar,
                        corr, res)
@@ -186,6 +186,11 @@ def multi_scale_icp(source, target, target_normals, voxel_sizes, criteria_list,
         if dar is not None:
             _lib.lib().o3dmi_set_device_allreduce(_lib.ALLREDUCE_DEVICE(0),
                                                   None)
+        if device_counts is not None:
+            # the driver consumes the pointers on entry; if Python raised
+            # before it got there they must not wait for the NEXT call of this
+            # thread
+            _lib.lib().o3dmi_registration_set_device_counts(None, None)
     _lib.check(st, "multi_scale_icp")
     out = RegistrationResult()
     out.transformation = np.array(res.transformation[:]).reshape(4, 4)

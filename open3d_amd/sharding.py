@@ -161,6 +161,13 @@ def allgather_blocks(keys, values, dist):
             for r in range(world)]
 
 
+# The Comm installed on this thread (o3dmi_set_comm): kept alive here until it
+# is uninstalled -- the library calls the ctypes thunks of a custom transport
+# through it, and a Comm that was garbage-collected while installed would leave
+# the driver calling freed callbacks.
+_installed = None
+
+
 class Comm:
     """o3dmi_comm_t: the library-owned collectives of one rank."""
 
@@ -321,14 +328,18 @@ class Comm:
         passes the WHOLE source cloud and the driver shards each pyramid level
         (reference-identical pyramid); otherwise each rank passes its shard."""
         from . import _lib
+        global _installed
         _lib.check(_lib.lib().o3dmi_set_comm(self.handle), "set_comm")
+        _installed = self
         _lib.check(_lib.lib().o3dmi_set_icp_level_sharding(
             1 if level_sharding else 0), "set_icp_level_sharding")
 
     @staticmethod
     def uninstall():
         from . import _lib
+        global _installed
         _lib.check(_lib.lib().o3dmi_set_comm(None), "set_comm")
+        _installed = None
         _lib.check(_lib.lib().o3dmi_set_icp_level_sharding(0),
                    "set_icp_level_sharding")
 
@@ -342,7 +353,10 @@ class Comm:
 
     def destroy(self):
         from . import _lib
+        global _installed
         if self.handle:
+            if _installed is self:
+                Comm.uninstall()
             _lib.lib().o3dmi_comm_destroy(self.handle)
             self.handle = None
 

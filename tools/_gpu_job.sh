@@ -1,9 +1,10 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r4l
+mkdir -p gpurun_out/r4m
 export TMPDIR=/tmp
-for n in 2 8; do
-timeout 900 python bench.py --gpus $n --dist-backend gloo --steps 2 --warmup 1 --batch 2000 --no-secondary --no-cpu-baseline --no-pmc > gpurun_out/r4l/dry_n$n.json 2> gpurun_out/r4l/dry_n$n.err
-echo "dry run n=$n rc $?"; tail -c 1500 gpurun_out/r4l/dry_n$n.json; echo; tail -3 gpurun_out/r4l/dry_n$n.err | cut -c1-300
+B="python $PWD/bench.py --no-secondary --no-cpu-baseline"
+for d in 0 1 0 1; do
+O3DMI_STEP_DEAL=$d timeout 600 $B > gpurun_out/r4m/deal$d.json 2> gpurun_out/r4m/deal$d.err
+python -c "
+import json;d=json.load(open('gpurun_out/r4m/deal$d.json'));r=d['roofline'];print('deal $d', round(d['value']), r['avg_kernel_ms'], 'read_overfetch', r['read_overfetch'], 'frac_hbm', r['frac_hbm'], 'valu', r['frac_valu'], 'traffic', r['traffic'])"
 done
-timeout 900 python bench.py --gpus 2 --dist-backend gloo --sharding frames --steps 2 --warmup 1 --batch 2000 --no-secondary --no-cpu-baseline --no-pmc > gpurun_out/r4l/dry_frames_n2.json 2> gpurun_out/r4l/dry_frames_n2.err
-echo "dry run frames n=2 rc $?"; tail -c 600 gpurun_out/r4l/dry_frames_n2.json
+timeout 600 python -m pytest tests/test_vbg_gpu.py -q -m gpu -x -k "frame_batch or fused or long_run" 2>&1 | tail -2

@@ -11,7 +11,7 @@ import json
 import os
 import sys
 
-KERNEL = "FrameStepKernel"
+KERNEL = os.environ.get("O3DMI_SUMMARIZE_KERNEL", "FrameStepKernel")
 
 
 def _rows(d, pattern):
