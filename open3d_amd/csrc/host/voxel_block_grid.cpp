@@ -112,7 +112,8 @@ struct o3dmi_vbg {
         hipEvent_t ev_main[2] = {nullptr, nullptr};  // chunk set consumed
         hipEvent_t ev_enter = nullptr;
         ChunkTable send_table = {}, recv_table = {};
-        int table_slots = 0;
+        int table_slots = 0;  // sender table (doubles on every rank alike)
+        int recv_slots = 0;   // receiver table (may grow on one rank alone)
         int capacity = 0;  // records of a wire segment
         int world = 0;
         void* send_seg[2] = {nullptr, nullptr};
@@ -1325,6 +1326,7 @@ static int EnsureSliced(o3dmi_vbg* g, int world, int capacity, int slots,
     IntegFrame* keep_iframes = z.iframes_dev;
     const int64_t keep_cap = z.frames_cap;
     const int64_t keep_chunks = z.chunks_done, keep_re = z.reapplied;
+    const int keep_recv_slots = z.recv_slots;
     PixelRec* keep_recs[2] = {z.chunk_recs[0], z.chunk_recs[1]};
     const int64_t keep_px = z.chunk_recs_pixels;
     z.frames_dev = nullptr;
@@ -1348,18 +1350,24 @@ static int EnsureSliced(o3dmi_vbg* g, int world, int capacity, int slots,
                                                 hipEventDisableTiming));
         O3DMI_HIP_CHECK(hipMalloc(&z.send_seg[i], (size_t)seg));
         O3DMI_HIP_CHECK(hipMalloc(&z.gathered[i], (size_t)seg * world));
-        O3DMI_HIP_CHECK(hipMalloc((void**)&z.entries[i],
-                                  sizeof(ChunkEntry) * (size_t)(slots / 2)));
+        O3DMI_HIP_CHECK(hipMalloc(
+                (void**)&z.entries[i],
+                sizeof(ChunkEntry) *
+                        (size_t)((keep_recv_slots > slots ? keep_recv_slots
+                                                          : slots) / 2)));
         O3DMI_HIP_CHECK(hipMalloc((void**)&z.entries_count[i], sizeof(int)));
         O3DMI_HIP_CHECK(hipMemsetAsync(z.entries_count[i], 0, sizeof(int),
                                        z.side));
     }
     O3DMI_HIP_CHECK(hipEventCreateWithFlags(&z.ev_enter, hipEventDisableTiming));
     int st;
+    const int recv_slots = keep_recv_slots > slots ? keep_recv_slots : slots;
     if ((st = AllocChunkTable(&z.send_table, slots, false, z.side))) return st;
-    if ((st = AllocChunkTable(&z.recv_table, slots, true, z.side))) return st;
+    if ((st = AllocChunkTable(&z.recv_table, recv_slots, true, z.side)))
+        return st;
     z.table_slots = slots;
-    z.entries_cap = slots / 2;
+    z.recv_slots = recv_slots;
+    z.entries_cap = recv_slots / 2;
     z.capacity = capacity;
     z.world = world;
     O3DMI_HIP_CHECK(hipStreamSynchronize(z.side));
@@ -1522,6 +1530,16 @@ static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
     const bool raw_form = raw_env ? raw_env[0] == '1'
                                   : (world >= 6 && (!c.with_color ||
                                                     g->prep_identity));
+    // O3DMI_SLICED_PIPE=1: the chunk launch's software-pipelined form (next
+    // round's gathers in flight during this round's arithmetic, 2-frame
+    // rounds). Measured at 4 and 8 emulated ranks, raw and records form
+    // (profiles/r4p): no difference (404 k against 402 k frames/s at 8) -- a
+    // rank's share is not bound by gather latency but by how fast ONE wave
+    // issues its chain of frames: 2.8 waves per SIMD on average
+    // (profiles/r4o_pmc_chunk_w8.json), the blocks seen by most frames of the
+    // chunk finish last. Kept as a switch, off.
+    const char* pipe_env = std::getenv("O3DMI_SLICED_PIPE");
+    const bool pipe_form = pipe_env && pipe_env[0] == '1';
     const int chunk_frames = kChunkGroups * group;
     const int64_t px = (int64_t)c.depth_rows * c.depth_cols;
     if (!raw_form && z.chunk_recs_pixels < px) {
@@ -1673,8 +1691,29 @@ static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
                     return st;
                 O3DMI_HIP_CHECK(hipStreamSynchronize(s));
                 if ((st = issue_side(ci, false))) return st;
+            } else if (cs.overflow == -2) {
+                // THIS rank's receiver table was too small for the blocks it
+                // owns in the chunk: a local matter (the other ranks are not
+                // waiting for anything) -- a larger table and work lists, the
+                // same gathered records applied again
+                FreeChunkTable(&z.recv_table);
+                for (int i = 0; i < 2; ++i) {
+                    (void)hipFree(z.entries[i]);
+                    z.entries[i] = nullptr;
+                }
+                z.recv_slots *= 2;
+                if ((st = AllocChunkTable(&z.recv_table, z.recv_slots, true,
+                                          z.side)))
+                    return st;
+                for (int i = 0; i < 2; ++i)
+                    O3DMI_HIP_CHECK(hipMalloc(
+                            (void**)&z.entries[i],
+                            sizeof(ChunkEntry) * (size_t)(z.recv_slots / 2)));
+                z.entries_cap = z.recv_slots / 2;
+                O3DMI_HIP_CHECK(hipStreamSynchronize(z.side));
+                if ((st = issue_side(ci, false))) return st;
             } else {
-                // a wire segment or a chunk table was too small (the flags
+                // a SENDER's wire segment or table was too small (the flags
                 // travel in the all-gathered headers: every rank takes this
                 // branch for the same chunk): double both, touch again
                 if (gathered_in) {
@@ -1723,6 +1762,7 @@ static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
         ia.depth_scale = c.depth_scale;
         ia.depth_div_short = g->prep_div_short;
         ia.raw = raw_form;
+        ia.pipelined = pipe_form;
         ia.size_host = (int*)g->stream_status;
         ia.status_stamp = g->frame_stamp;
         ia.prof_count = prof ? g->prof_counts + g->prof_max + g->prof_frames

@@ -80,6 +80,8 @@ struct SliceHeader {
 static_assert(sizeof(SliceHeader) == 128, "wire format");
 constexpr int kSliceFlagTable = 1;   // a chunk table overflowed
 constexpr int kSliceFlagKeyRange = 2;
+constexpr int kSliceFlagSender = 4;  // (receiver side) a SENDER's slice did not
+                                     // fit: seen by every rank alike
 
 inline int64_t SliceSegmentBytes(int capacity) {
     return (int64_t)sizeof(SliceHeader) +
@@ -144,8 +146,11 @@ int LaunchApplySlice(o3dmi_hash* block_hash, const void* gathered_dev,
                      int world, int capacity, const ChunkTable& table,
                      int overflow_stamp, hipStream_t s);
 // receiver table -> the chunk's work list + its length, table cleaned;
-// publishes {map size, overflow stamp (-1: a table / segment overflowed),
-// blocks of the chunk, stamp} in the host-mapped status (may be null).
+// publishes {map size, overflow, blocks of the chunk, stamp} in the host-mapped
+// status (may be null). overflow: > 0 = stamp of the chunk that ran out of
+// buffer indices; -1 = a sender's segment / table was too small (every rank
+// reads that in the gathered headers: a collective redo); -2 = THIS rank's
+// receiver table was too small (a local redo, no collective).
 int LaunchBuildChunk(o3dmi_hash* block_hash, const ChunkTable& table,
                      ChunkEntry* entries, int entries_cap, int* entries_count,
                      int* status_host, int stamp, hipStream_t s);
@@ -168,6 +173,8 @@ struct ChunkIntegrateArgs {
     int resolution;
     float voxel_size, sdf_trunc, depth_max, depth_scale;
     bool depth_div_short;
+    bool pipelined;               // software-pipelined 2-frame rounds (a
+                                  // rank's share is latency-bound)
     bool raw;                     // gather from the raw images (IntegFrame::
                                   // depth / color) instead of the prepared
                                   // records (IntegFrame::recs)

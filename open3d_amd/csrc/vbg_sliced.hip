@@ -175,7 +175,7 @@ ApplySliceKernel(ApplySliceArgs a) {
         // the sender's slice did not fit its segment / its table: flagged in
         // the receiver's status (BuildChunkKernel), the host redoes the chunk
         if (blockIdx.x == 0 && threadIdx.x == 0)
-            atomicOr(a.table.flags, kSliceFlagTable);
+            atomicOr(a.table.flags, kSliceFlagSender);
         if (n > a.capacity) n = a.capacity;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 &&
@@ -223,7 +223,8 @@ BuildChunkKernel(BuildChunkArgs a) {
     int n = n_claimed < t.list_cap ? n_claimed : t.list_cap;
     const bool table_full = n_claimed > t.list_cap;
     // (flags: set by ApplySliceKernel, cleared by the host before it)
-    const bool flagged = (*t.flags & kSliceFlagTable) != 0;
+    const int fl = *t.flags;
+    const bool flagged = (fl & (kSliceFlagTable | kSliceFlagSender)) != 0;
     // a chunk that ran out of buffer indices (or whose records did not fit)
     // is dropped as a whole: empty list; the host makes room and applies it
     // again
@@ -259,9 +260,12 @@ BuildChunkKernel(BuildChunkArgs a) {
         if (a.status_host) {
             const int top = a.hv.counters[0];
             a.status_host[0] = top < a.hv.capacity ? top : a.hv.capacity;
-            a.status_host[1] = a.hv.counters[3] != 0
-                                       ? a.hv.counters[3]
-                                       : ((flagged || table_full) ? -1 : 0);
+            a.status_host[1] =
+                    a.hv.counters[3] != 0
+                            ? a.hv.counters[3]
+                            : ((fl & kSliceFlagSender)
+                                       ? -1
+                                       : ((flagged || table_full) ? -2 : 0));
             a.status_host[2] = n;
             __hip_atomic_store(&a.status_host[3], a.stamp, __ATOMIC_RELEASE,
                                __HIP_MEMORY_SCOPE_SYSTEM);

@@ -862,7 +862,8 @@ __device__ __forceinline__ f2 PkFma(f2 a, f2 b, f2 c) {
 // up to kChunkFrames frames (ChunkEntry::bits) to its register-resident voxels,
 // kChunk at a time; per-frame constants come from IntegParams::frame_tab.
 template <typename weight_t, typename color_t, bool kColor, int kDiv,
-          int kChunk, int kP, bool kRaw = false, bool kLong = false>
+          int kChunk, int kP, bool kRaw = false, bool kLong = false,
+          bool kPipe = false>
 __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                                                   const IntegParams& ip,
                                                   int wg, int n_wg,
@@ -1349,13 +1350,32 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
             }
         }
         };
-        if constexpr (kLong) {
-            // (Measured and dropped, profiles/r4i: a software pipeline over the
-            // rounds -- the next round's gathers in flight while this round's
-            // frames are applied. The double set of round registers costs two
-            // waves of occupancy and the launch got 4 - 10 % SLOWER: with ~5
-            // waves per SIMD a round's latency is the other waves' arithmetic,
-            // not its own gathers.)
+        if constexpr (kLong && kPipe) {
+            // Software pipeline over the rounds (O3DMI_SLICED_PIPE=1): the NEXT
+            // round's gathers are in flight while this round's frames are
+            // applied; rounds of kPipeChunk = 2 frames keep the double set of
+            // round registers within five waves per SIMD. Measured: no gain
+            // (profiles/r4p) -- see StreamIntegrateSliced.
+            const int n_fr = ip.n_frames;
+            auto next_round = [&](int from, Round& R) -> int {
+                for (int c = from; c < n_fr; c += kChunk) {
+                    R.cbits = round_bits(c);
+                    if (R.cbits != 0u) return c;  // wave-uniform
+                }
+                return -1;
+            };
+            Round ra, rb;
+            int ca = next_round(0, ra);
+            if (ca >= 0) issue(ca, ra);
+#pragma nounroll
+            while (ca >= 0) {
+                const int cb = next_round(ca + kChunk, rb);
+                if (cb >= 0) issue(cb, rb);
+                apply(ra);
+                ca = cb;
+                ra = rb;
+            }
+        } else if constexpr (kLong) {
 #pragma nounroll
             for (int c0 = 0; c0 < ip.n_frames; c0 += kChunk) {
                 Round r;
@@ -1458,13 +1478,17 @@ struct ChunkParams {
 };
 // kRaw = false: the frames' prepared records (one 8-byte gather per voxel and
 // frame, the per-group role's registers and occupancy); true: raw images.
+// kPipe: software-pipelined rounds of kPipeChunk frames (few ranks' worth of
+// blocks per launch: latency-bound); else 4-frame rounds at full occupancy.
+constexpr int kPipeChunk = 2;
 template <typename weight_t, typename color_t, bool kColor, int kDiv,
-          bool kRaw>
-__global__ void __launch_bounds__(256, kRaw ? 5 : 7)
+          bool kRaw, bool kPipe>
+__global__ void __launch_bounds__(256, kPipe ? 5 : (kRaw ? 5 : 7))
 ChunkIntegrateKernel(ChunkParams cp) {
     IntegrateRoleWide<weight_t, color_t, kColor, kDiv,
-                      kRaw ? kRawChunk : kGroupChunk, 1, kRaw, true>(
-            cp.hv, cp.integ, (int)blockIdx.x, (int)gridDim.x, 0);
+                      kPipe ? kPipeChunk : (kRaw ? kRawChunk : kGroupChunk), 1,
+                      kRaw, true, kPipe>(cp.hv, cp.integ, (int)blockIdx.x,
+                                         (int)gridDim.x, 0);
 }
 
 }  // namespace
@@ -1908,13 +1932,22 @@ int LaunchChunkIntegrate(o3dmi_hash* bh, const ChunkIntegrateArgs& a,
     const bool col = a.with_color && a.color != nullptr;
 #define O3DMI_LAUNCH_CHUNK_D(WT, VT, COLOR, D)                                \
     do {                                                                      \
-        if (a.raw)                                                            \
-            hipLaunchKernelGGL((ChunkIntegrateKernel<WT, VT, COLOR, D, true>), \
-                               grid, block, 0, s, cp);                        \
+        if (a.raw && a.pipelined)                                             \
+            hipLaunchKernelGGL(                                               \
+                    (ChunkIntegrateKernel<WT, VT, COLOR, D, true, true>),     \
+                    grid, block, 0, s, cp);                                   \
+        else if (a.raw)                                                       \
+            hipLaunchKernelGGL(                                               \
+                    (ChunkIntegrateKernel<WT, VT, COLOR, D, true, false>),    \
+                    grid, block, 0, s, cp);                                   \
+        else if (a.pipelined)                                                 \
+            hipLaunchKernelGGL(                                               \
+                    (ChunkIntegrateKernel<WT, VT, COLOR, D, false, true>),    \
+                    grid, block, 0, s, cp);                                   \
         else                                                                  \
             hipLaunchKernelGGL(                                               \
-                    (ChunkIntegrateKernel<WT, VT, COLOR, D, false>), grid,    \
-                    block, 0, s, cp);                                         \
+                    (ChunkIntegrateKernel<WT, VT, COLOR, D, false, false>),   \
+                    grid, block, 0, s, cp);                                   \
     } while (0)
 #define O3DMI_LAUNCH_CHUNK(WT, VT, COLOR)                                     \
     do {                                                                      \

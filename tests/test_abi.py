@@ -77,3 +77,14 @@ def test_headers_are_plain_c(tmp_path):
                         "-fsyntax-only", str(src)], capture_output=True,
                        text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_sliced_touch_wire_constants(built):
+    """Pure functions of the sliced block touch (no GPU): a chunk is 16 launches
+    worth of frames, at most 256 (one frame bit each in a 48-byte record)."""
+    L = built.lib()
+    assert L.o3dmi_vbg_slice_chunk_frames(12) == 192
+    assert L.o3dmi_vbg_slice_chunk_frames(16) == 256
+    assert L.o3dmi_vbg_slice_chunk_frames(100) == 256   # clamped to 16 frames
+    assert L.o3dmi_vbg_slice_chunk_frames(0) == 16 * 8  # the default group
+    assert L.o3dmi_vbg_slice_segment_bytes(None) == 0

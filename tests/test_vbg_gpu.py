@@ -889,13 +889,15 @@ def _blocks_sorted(g, with_color=True):
     return out
 
 
-@pytest.mark.parametrize("raw", [False, True])
+@pytest.mark.parametrize("raw,pipe", [(False, False), (True, False),
+                                      (False, True), (True, True)])
 @pytest.mark.parametrize("world,group,grid_f32,with_color", [
     (1, 4, False, True), (3, 2, False, True), (8, 3, False, True),
     (8, 12, False, True), (2, 16, True, True), (4, 5, False, False)])
 def test_sliced_touch_ownership_union_is_the_single_grid(world, group,
                                                          grid_f32, with_color,
-                                                         raw, monkeypatch):
+                                                         raw, pipe,
+                                                         monkeypatch):
     """SURVEY 8(e) scheme A as specified: rank r touches only its band of ray
     tiles, the candidate records of all ranks are gathered (here computed on
     one device: gather_slices), rank r activates the keys it owns and
@@ -907,6 +909,7 @@ def test_sliced_touch_ownership_union_is_the_single_grid(world, group,
     _lib, geometry = _gpu()
     from open3d_amd import sharding
     monkeypatch.setenv("O3DMI_SLICED_RAW", "1" if raw else "0")
+    monkeypatch.setenv("O3DMI_SLICED_PIPE", "1" if pipe else "0")
     n = 2 * 16 * group + 3 if group <= 3 else 16 * group + 5
     ks = [(i * 7) % 900 for i in range(n)]
     ds, cs, dt, ct, Ts, K = _stream_frames(ks, 320, 240)
