@@ -1,15 +1,12 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r4p
-export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_vbg_gpu.py -q -m gpu -x -k "sliced_touch_ownership" > gpurun_out/r4p/vbg.log 2>&1
-grep -n "passed\|failed\|Fatal\|Aborted" gpurun_out/r4p/vbg.log | head -3
+mkdir -p gpurun_out/r4q
 B="python $PWD/bench.py --no-secondary --no-cpu-baseline --no-pmc"
-for w in 8 4; do
- for raw in 1 0; do
-  for pipe in 0 1; do
-   O3DMI_SLICED_RAW=$raw O3DMI_SLICED_PIPE=$pipe timeout 600 $B --emulate-world $w > gpurun_out/r4p/emu_w${w}_raw${raw}_pipe${pipe}.json 2> gpurun_out/r4p/emu.err
-   python -c "
-import json;d=json.load(open('gpurun_out/r4p/emu_w${w}_raw${raw}_pipe${pipe}.json'));print('emu w$w raw$raw pipe$pipe', round(d['value']), d['roofline']['avg_kernel_ms'])"
-  done
- done
+for i in 1 2; do
+timeout 600 $B > gpurun_out/r4q/n1_$i.json 2> gpurun_out/r4q/n1.err
+python -c "
+import json;d=json.load(open('gpurun_out/r4q/n1_$i.json'));print('headline', round(d['value']), 'cold', round(d['cold_pass_frames_per_s']), d['roofline']['avg_kernel_ms'])"
+O3DMI_STRICT_CAPACITY=1 timeout 600 $B --block-count 524288 > gpurun_out/r4q/n1_strict_$i.json 2> gpurun_out/r4q/n1.err
+python -c "
+import json;d=json.load(open('gpurun_out/r4q/n1_strict_$i.json'));print('strict 524288', round(d['value']), 'cold', round(d['cold_pass_frames_per_s']), d['roofline']['avg_kernel_ms'])"
 done
+timeout 600 python -m pytest tests/test_vbg_gpu.py -q -m gpu -x -k "overflow or run_ahead or frame_batch" 2>&1 | tail -2
