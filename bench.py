@@ -1190,12 +1190,16 @@ def main():
         torch.cuda.empty_cache()
         o_blocks = not by_blocks
         st = max(2, a.steps // 5)
-        g2, e2, _, m2, _ = run_scheme(o_blocks, st, 1)
-        other = {"sharding": "blocks" if o_blocks else "frames",
-                 "scaling": "strong", "frames_per_s": st * a.batch / e2,
-                 "steps": st, "ms_per_step": e2 / st * 1e3, "merge_ms": m2,
-                 "active_blocks_this_rank": int(g2.hashmap().size())}
-        del g2
+        try:
+            g2, e2, _, m2, _ = run_scheme(o_blocks, st, 1)
+            other = {"sharding": "blocks" if o_blocks else "frames",
+                     "scaling": "strong", "frames_per_s": st * a.batch / e2,
+                     "steps": st, "ms_per_step": e2 / st * 1e3, "merge_ms": m2,
+                     "active_blocks_this_rank": int(g2.hashmap().size())}
+            del g2
+        except Exception as e:  # the headline above must still be printed
+            other = {"sharding": "blocks" if o_blocks else "frames",
+                     "error": str(e)[:300]}
 
     # ---- roofline of the dominant kernel over the bracketed launches --------
     # 8(d) unit = one active block x one frame (98 304 B of voxel state
