@@ -162,12 +162,19 @@ __global__ void PointCloudTouchKernel(HashView hv,
 // ROUNDS that still gives every CU a chunk (300 chunks of one round there).
 constexpr int kUnprojMaxRounds = 8;
 
-template <typename depth_t, int ROUNDS>
+// MODE 0: a chunk takes its output range off one atomic counter (the order of
+// the chunks in the output is the order they get there: as the reference's
+// atomic compaction, PointCloudImpl.h:42-143, not reproducible run to run).
+// MODE 1 / 2 (O3DMI_UNPROJECT_ORDERED=1): count pass / write pass around a
+// scan of the chunk counts -- the points come out in PIXEL order, the same on
+// every run, so that a composed tracking loop can be made run-to-run
+// identical for debugging; three launches instead of one.
+template <typename depth_t, int ROUNDS, int MODE>
 __global__ void __launch_bounds__(kBlock)
 UnprojectKernel(TouchParams p, const depth_t* __restrict__ depth,
                 const float* __restrict__ image_colors,
                 float* __restrict__ points, float* __restrict__ colors,
-                int* __restrict__ count) {
+                int* __restrict__ count, int* __restrict__ chunk_counts) {
     __shared__ int offs[ROUNDS][kBlock / 64];
     __shared__ int chunk_base;
     const int64_t n = (int64_t)p.rows_strided * p.cols_strided;
@@ -200,9 +207,13 @@ UnprojectKernel(TouchParams p, const depth_t* __restrict__ depth,
                     offs[k][wv] = run;
                     run += c;
                 }
-            chunk_base = run ? atomicAdd(count, run) : 0;
+            const int64_t chunk = c0 / (kBlock * ROUNDS);
+            if (MODE == 0) chunk_base = run ? atomicAdd(count, run) : 0;
+            else if (MODE == 1) chunk_counts[chunk] = run;
+            else chunk_base = chunk_counts[chunk];  // scanned: exclusive
         }
         __syncthreads();
+        if (MODE == 1) continue;  // (uniform; offs are rewritten next chunk)
 #pragma unroll
         for (int k = 0; k < ROUNDS; ++k) {
             if (!((ballot[k] >> lane) & 1ull)) continue;
@@ -225,6 +236,37 @@ UnprojectKernel(TouchParams p, const depth_t* __restrict__ depth,
             }
         }
         __syncthreads();  // offs / chunk_base are reused by the next chunk
+    }
+}
+
+// Exclusive scan of the chunk counts (one workgroup; <= a few thousand
+// chunks) + the total.
+__global__ void __launch_bounds__(kBlock)
+UnprojectScanKernel(int* __restrict__ chunk_counts, int n_chunks,
+                    int* __restrict__ count) {
+    __shared__ int part[kBlock];
+    const int per = (n_chunks + kBlock - 1) / kBlock;
+    const int lo = threadIdx.x * per;
+    const int hi = lo + per < n_chunks ? lo + per : n_chunks;
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += chunk_counts[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int t = 0; t < kBlock; ++t) {
+            const int c = part[t];
+            part[t] = run;
+            run += c;
+        }
+        *count = run;
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int i = lo; i < hi; ++i) {
+        const int c = chunk_counts[i];
+        chunk_counts[i] = run;
+        run += c;
     }
 }
 
@@ -355,10 +397,47 @@ int o3dmi_unproject(const void* depth_dev, int depth_dtype, int rows, int cols,
     int rounds = kUnprojMaxRounds;
     while (rounds > 1 && n < (int64_t)kCUs * kBlock * rounds) rounds >>= 1;
     dim3 grid(GridFor(n, kBlock * rounds)), block(kBlock);
-#define O3DMI_UNPROJECT(T, R)                                                  \
-    hipLaunchKernelGGL((UnprojectKernel<T, R>), grid, block, 0, s, p,         \
+    // O3DMI_UNPROJECT_ORDERED=1 (read per call): pixel-order output
+    const char* ord_env = std::getenv("O3DMI_UNPROJECT_ORDERED");
+    const bool ordered = ord_env && ord_env[0] == '1';
+    int* chunk_counts = nullptr;
+    const int n_chunks = (int)((n + (int64_t)kBlock * rounds - 1) /
+                               ((int64_t)kBlock * rounds));
+    if (ordered) {
+        // per host thread and device, grown on demand (a few KB)
+        static thread_local int* bufs[64] = {};
+        static thread_local int caps[64] = {};
+        int dev = 0;
+        O3DMI_HIP_CHECK(hipGetDevice(&dev));
+        O3DMI_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
+        if (caps[dev] < n_chunks) {
+            if (bufs[dev]) {
+                O3DMI_HIP_CHECK(hipDeviceSynchronize());
+                (void)hipFree(bufs[dev]);
+                bufs[dev] = nullptr;
+            }
+            int cap = 4096;
+            while (cap < n_chunks) cap <<= 1;
+            O3DMI_HIP_CHECK(hipMalloc((void**)&bufs[dev], sizeof(int) * cap));
+            caps[dev] = cap;
+        }
+        chunk_counts = bufs[dev];
+    }
+#define O3DMI_UNPROJECT_M(T, R, M)                                            \
+    hipLaunchKernelGGL((UnprojectKernel<T, R, M>), grid, block, 0, s, p,      \
                        (const T*)depth_dev, image_colors_dev, points_dev,     \
-                       colors_dev, out_count_dev)
+                       colors_dev, out_count_dev, chunk_counts)
+#define O3DMI_UNPROJECT(T, R)                                                  \
+    do {                                                                      \
+        if (!ordered) {                                                       \
+            O3DMI_UNPROJECT_M(T, R, 0);                                       \
+        } else {                                                              \
+            O3DMI_UNPROJECT_M(T, R, 1);                                       \
+            hipLaunchKernelGGL(UnprojectScanKernel, dim3(1), dim3(kBlock), 0, \
+                               s, chunk_counts, n_chunks, out_count_dev);     \
+            O3DMI_UNPROJECT_M(T, R, 2);                                       \
+        }                                                                     \
+    } while (0)
 #define O3DMI_UNPROJECT_R(T)                                                   \
     switch (rounds) {                                                         \
         case 8: O3DMI_UNPROJECT(T, 8); break;                                 \
@@ -370,6 +449,7 @@ int o3dmi_unproject(const void* depth_dev, int depth_dtype, int rows, int cols,
     else { O3DMI_UNPROJECT_R(float) }
 #undef O3DMI_UNPROJECT_R
 #undef O3DMI_UNPROJECT
+#undef O3DMI_UNPROJECT_M
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
 }

@@ -37,6 +37,7 @@ interface over torch.distributed calls (gloo in the CPU tests and when several
 ranks share one GPU, where RCCL refuses to run).
 """
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -165,7 +166,7 @@ def allgather_blocks(keys, values, dist):
 # is uninstalled -- the library calls the ctypes thunks of a custom transport
 # through it, and a Comm that was garbage-collected while installed would leave
 # the driver calling freed callbacks.
-_installed = None
+_tls = threading.local()  # .installed: the Comm o3dmi_set_comm holds (per thread)
 
 
 class Comm:
@@ -328,18 +329,16 @@ class Comm:
         passes the WHOLE source cloud and the driver shards each pyramid level
         (reference-identical pyramid); otherwise each rank passes its shard."""
         from . import _lib
-        global _installed
         _lib.check(_lib.lib().o3dmi_set_comm(self.handle), "set_comm")
-        _installed = self
+        _tls.installed = self
         _lib.check(_lib.lib().o3dmi_set_icp_level_sharding(
             1 if level_sharding else 0), "set_icp_level_sharding")
 
     @staticmethod
     def uninstall():
         from . import _lib
-        global _installed
         _lib.check(_lib.lib().o3dmi_set_comm(None), "set_comm")
-        _installed = None
+        _tls.installed = None
         _lib.check(_lib.lib().o3dmi_set_icp_level_sharding(0),
                    "set_icp_level_sharding")
 
@@ -353,9 +352,8 @@ class Comm:
 
     def destroy(self):
         from . import _lib
-        global _installed
         if self.handle:
-            if _installed is self:
+            if getattr(_tls, "installed", None) is self:
                 Comm.uninstall()
             _lib.lib().o3dmi_comm_destroy(self.handle)
             self.handle = None

@@ -237,6 +237,80 @@ def test_configs2_720p_tracking_loop_in_lock_step_with_the_oracle():
     assert 5 <= np.mean(iters) <= 25
 
 
+def _track_vga(n_frames):
+    """A short VGA tracking loop (predict -> Unproject x2 -> MultiScaleICP ->
+    integrate at the estimate); returns the ICP transformations and the grid."""
+    _lib, geometry = _gpu()
+    from open3d_amd import registration as reg, synthetic as syn
+    from open3d_amd.core import stream
+    L = _lib.lib()
+    W, H, stride = 640, 480, 2
+    ds, dmax, trunc = sc.DEPTH_SCALE, sc.DEPTH_MAX, sc.TRUNC_MULT
+    K = syn.intrinsics(W, H)
+    g = _mk_grid(geometry, False, block_count=16384)
+    vs = [0.05, 0.025, 0.0125]
+    crit = [reg.ICPConvergenceCriteria(1e-6, 1e-6, i) for i in (20, 10, 5)]
+    md = [0.15, 0.075, 0.0375]
+    npx = (H // stride) * (W // stride)
+    bufs = [torch.empty((npx, 3), dtype=torch.float32, device="cuda")
+            for _ in range(3)]
+    cnts = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(2)]
+    T_prev, d_prev, out = None, None, []
+    for k in range(n_frames):
+        d, c, _, T = syn.render_frames(k * 2, 1, W, H, device="cuda")
+        d, c = d[0].contiguous(), c[0].contiguous()
+        if k == 0:
+            T_k = np.array(T[0])
+        else:
+            keys = g.compute_unique_block_coordinates(d_prev, K, T_prev, ds,
+                                                      dmax, trunc)
+            rc = g.ray_cast(keys, K, T_prev, W, H,
+                            render_attributes=("depth", "normal"),
+                            depth_scale=ds, depth_min=0.1, depth_max=dmax,
+                            weight_threshold=1.0, trunc_voxel_multiplier=trunc)
+            Tp = np.ascontiguousarray(T_prev, dtype=np.float64)
+            _lib.check(L.o3dmi_unproject(
+                _lib.ptr(rc["depth"]), _lib.F32, H, W, _lib.ptr(rc["normal"]),
+                _lib.ptr(bufs[0]), _lib.ptr(bufs[1]), _lib.ptr(cnts[0]),
+                _lib.f64p(K), _lib.f64p(Tp), C.c_float(ds), C.c_float(dmax),
+                C.c_int64(stride), stream()), "unproject")
+            m = int(cnts[0].item())
+            Tinv = np.ascontiguousarray(np.linalg.inv(T_prev), dtype=np.float64)
+            _lib.check(L.o3dmi_transform_normals(
+                _lib.f64p(Tinv), _lib.ptr(bufs[1]), m, _lib.F32, stream()),
+                "transform_normals")
+            _lib.check(L.o3dmi_unproject(
+                _lib.ptr(d), _lib.U16, H, W, None, _lib.ptr(bufs[2]), None,
+                _lib.ptr(cnts[1]), _lib.f64p(K), _lib.f64p(Tp), C.c_float(ds),
+                C.c_float(dmax), C.c_int64(stride), stream()), "unproject")
+            src = bufs[2][:int(cnts[1].item())]
+            r = reg.multi_scale_icp(src, bufs[0][:m], bufs[1][:m], vs, crit, md)
+            out.append((np.array(r.transformation), r.num_iterations,
+                        r.inlier_rmse, r.fitness, src.cpu().numpy().copy()))
+            T_k = T_prev @ np.linalg.inv(r.transformation)
+        g.integrate_frame(d, c, K, K, T_k, ds, dmax, trunc)
+        T_prev, d_prev = T_k, d
+    return out, _sorted_export(g)
+
+
+def test_tracking_loop_is_reproducible_with_the_ordered_unproject(monkeypatch):
+    """With O3DMI_UNPROJECT_ORDERED=1 the clouds the tracker sees are in pixel
+    order, so nothing in the loop depends on an atomic counter's arrival order:
+    two runs of the same loop give the same bits -- clouds, poses, iteration
+    counts and the integrated grid. (In the default mode the point SET is the
+    same but its order, and so the float sums' last bits, may differ.)"""
+    monkeypatch.setenv("O3DMI_UNPROJECT_ORDERED", "1")
+    a, ga = _track_vga(5)
+    b, gb = _track_vga(5)
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x[4], y[4]), k           # frame cloud, in order
+        assert np.array_equal(x[0], y[0]), (k, x[0] - y[0])
+        assert x[1:4] == y[1:4], k
+    assert len(ga) == len(gb)
+    for u, v in zip(ga, gb):
+        assert np.array_equal(u, v)
+
+
 def _frames_720p(n, step=2):
     from open3d_amd import synthetic as syn
     K = syn.intrinsics(1280, 720)
@@ -375,6 +449,56 @@ def _run_ranks(world, body):
     if errs:
         raise errs[0][1]
     return out
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("frames_per_launch", [2, 12])
+def test_configs3_sliced_touch_8_rank_threads_720p(frames_per_launch):
+    """BASELINE configs[3] with the sliced block touch and a REAL exchange: 8
+    ranks as host threads on this device, the library's communicator over the
+    in-process transport, `integrate_frames` on grids with an ownership (the
+    call a C++ rank makes). Rank r touches its band of the 1280x720 ray tiles,
+    the candidate records are all-gathered per chunk, each rank integrates the
+    blocks it owns with one launch per chunk: the 8 grids are the 8 ownership
+    classes of the single grid, bit for bit."""
+    _lib, geometry = _gpu()
+    from open3d_amd import sharding
+    world, n = 8, 56
+    K, ds, cs, Ts = _frames_720p(n)
+    full_g = _mk_grid(geometry, False, block_count=32768)
+    full_g.integrate_frames(ds, cs, K, K, Ts, sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                            sc.TRUNC_MULT, frames_per_launch=frames_per_launch)
+    full = _sorted_export(full_g)
+    owner = sharding.block_owner(full[0], world)
+    lb = _Loopback(world)
+
+    def body(r):
+        g = _mk_grid(geometry, False, block_count=8192)
+        g.set_block_ownership(r, world)
+        comm = lb.comm(r)
+        comm.install()
+        try:
+            g.integrate_frames(ds, cs, K, K, Ts, sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                               sc.TRUNC_MULT,
+                               frames_per_launch=frames_per_launch)
+            torch.cuda.synchronize()
+            st = g.sliced_stats()
+        finally:
+            sharding.Comm.uninstall()
+            comm.destroy()
+        return _sorted_export(g), st
+
+    got = _run_ranks(world, body)
+    seen = 0
+    for r in range(world):
+        part, st = got[r]
+        assert st["chunks"] == -(-n // (16 * frames_per_launch)), st
+        sel = owner == r
+        assert np.array_equal(part[0], full[0][sel]), r
+        for a, b in zip(part[1:], full[1:]):
+            assert a.tobytes() == b[sel].tobytes(), r
+        seen += part[0].shape[0]
+    assert seen == full[0].shape[0]
 
 
 @pytest.mark.timeout(900)

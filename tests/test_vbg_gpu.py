@@ -254,6 +254,42 @@ def test_depth_touch_no_blocks_is_an_error():
     assert "No block is touched" in str(e.value)
 
 
+def test_unproject_ordered_is_the_row_major_scan(monkeypatch):
+    """O3DMI_UNPROJECT_ORDERED=1: count -> scan -> write, so the points come
+    out in the row-major scan order of the strided pixels (the oracle's order;
+    the reference's atomic-counter order is unspecified), identical from run
+    to run, with no sort in the comparison."""
+    _lib, geometry = _gpu()
+    from open3d_amd.core import stream
+    L = _lib.lib()
+    monkeypatch.setenv("O3DMI_UNPROJECT_ORDERED", "1")
+    d, c, K, Ts = sc.frames(33, 2)
+    for f, stride in ((0, 1), (1, 1), (0, 4), (1, 3)):
+        cf = (c[f].astype(np.float32) / 255.0).astype(np.float32)
+        want_p, want_c = orc.unproject(d[f], cf, K, Ts[f], sc.DEPTH_SCALE,
+                                       sc.DEPTH_MAX, stride)
+        n = (480 // stride) * (640 // stride)
+        runs = []
+        for _ in range(2):
+            pts = torch.full((n, 3), -7.0, dtype=torch.float32, device="cuda")
+            cols = torch.full((n, 3), -7.0, dtype=torch.float32, device="cuda")
+            cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+            _lib.check(L.o3dmi_unproject(
+                _lib.ptr(torch.from_numpy(d[f]).cuda()), _lib.U16, 480, 640,
+                _lib.ptr(torch.from_numpy(cf).cuda()), _lib.ptr(pts),
+                _lib.ptr(cols), _lib.ptr(cnt), _lib.f64p(K), _lib.f64p(Ts[f]),
+                C.c_float(sc.DEPTH_SCALE), C.c_float(sc.DEPTH_MAX), stride,
+                stream()), "unproject")
+            m = int(cnt.item())
+            assert m == want_p.shape[0]
+            runs.append((pts.cpu().numpy(), cols.cpu().numpy()))
+        assert np.array_equal(runs[0][0][:m], want_p)
+        assert np.array_equal(runs[0][1][:m], want_c)
+        assert np.array_equal(runs[0][0], runs[1][0])
+        assert np.array_equal(runs[0][1], runs[1][1])
+        assert (runs[0][0][m:] == -7.0).all()       # nothing written past count
+
+
 @pytest.mark.parametrize("input_f32", [False, True])
 @pytest.mark.parametrize("grid_f32", [False, True])
 def test_integrate_parity_all_dtype_combos(input_f32, grid_f32):
