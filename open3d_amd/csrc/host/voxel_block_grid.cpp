@@ -1521,23 +1521,24 @@ static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
     //           8 B / pixel); the launch gathers depth and colour separately
     //           and divides per voxel: 1 088 instead of 877 VALU instructions
     //           per 4 frames
-    // Emulated shares (profiles/r4k_emu_*): records is ahead up to 4 ranks
-    // (186 k / 273 k frames/s at 2 / 4 against 152 k / 255 k), raw beyond,
-    // where the replicated prepare pass weighs as much as a rank's share of
-    // the voxel work (403 k against 371 k at 8). O3DMI_SLICED_RAW=0 / 1 picks
-    // one (read per call: tests switch it).
+    // Emulated shares (profiles/r4zb_emu_*, r4zg_emu_*; work list longest
+    // first, compact lane map): records is ahead at 2 ranks (207 k frames/s
+    // against 175 k), raw from 4 on, where the replicated prepare pass weighs
+    // as much as a rank's share of the voxel work (328 k against 296 k at 4,
+    // 527 k against 413 k at 8). O3DMI_SLICED_RAW=0 / 1 picks one (read per
+    // call: tests switch it).
     const char* raw_env = std::getenv("O3DMI_SLICED_RAW");
     const bool raw_form = raw_env ? raw_env[0] == '1'
-                                  : (world >= 6 && (!c.with_color ||
+                                  : (world >= 4 && (!c.with_color ||
                                                     g->prep_identity));
     // O3DMI_SLICED_PIPE=1: the chunk launch's software-pipelined form (next
     // round's gathers in flight during this round's arithmetic, 2-frame
     // rounds). Measured at 4 and 8 emulated ranks, raw and records form
-    // (profiles/r4p): no difference (404 k against 402 k frames/s at 8) -- a
-    // rank's share is not bound by gather latency but by how fast ONE wave
-    // issues its chain of frames: 2.8 waves per SIMD on average
-    // (profiles/r4o_pmc_chunk_w8.json), the blocks seen by most frames of the
-    // chunk finish last. Kept as a switch, off.
+    // (profiles/r4p, and again with the sorted work list, r4zc): no
+    // difference (492 k against 495 k frames/s at 8); 8-frame rounds at four
+    // waves per SIMD: +1 % at 8, -9 % at 4 (r4zg). Neither more loads in
+    // flight per wave nor more waves move it; fewer cache lines per gather
+    // (the compact lane map) does, +8 %. Kept as a switch, off.
     const char* pipe_env = std::getenv("O3DMI_SLICED_PIPE");
     const bool pipe_form = pipe_env && pipe_env[0] == '1';
     const int chunk_frames = kChunkGroups * group;

@@ -212,6 +212,7 @@ struct BuildChunkArgs {
     int* entries_count;
     int* status_host;
     int stamp;
+    int longest_first;  // O3DMI_CHUNK_ORDER != 0 (default)
 };
 
 // After ApplySliceKernel has completed (kernel boundary: every buffer index is
@@ -229,17 +230,54 @@ BuildChunkKernel(BuildChunkArgs a) {
     // is dropped as a whole: empty list; the host makes room and applies it
     // again
     const bool dropped = a.hv.counters[3] != 0 || table_full || flagged;
+    // Longest first: the chunk launch takes one workgroup per (entry, part)
+    // in list order and lasts as long as its slowest SIMD, and the entries'
+    // work is very uneven (a rank's share at 8 ranks: 27 frames on average,
+    // 192 for the blocks every frame of the chunk sees). With the entries in
+    // descending order of their frame count the dispatcher's in-order issue
+    // is longest-processing-time-first scheduling: the long chains start at
+    // time 0 and the short items fill the machine behind them. A counting
+    // sort over the 1..kChunkFrames possible counts; the order among equal
+    // counts is arrival order (any order gives the same grid: entries are
+    // distinct blocks).
+    __shared__ int sort_pos[kChunkFrames + 2];
+    for (int c = threadIdx.x; c < kChunkFrames + 2; c += blockDim.x)
+        sort_pos[c] = 0;
+    __syncthreads();
+    if (!dropped)
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const unsigned h = t.list[i];
+            int c = 0;
+#pragma unroll
+            for (int w = 0; w < kChunkWords; ++w)
+                c += __popc(t.bits[(size_t)h * kChunkWords + w]);
+            atomicAdd(&sort_pos[a.longest_first ? c : 0], 1);
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;  // descending counts -> ascending positions
+        for (int c = kChunkFrames; c >= 0; --c) {
+            const int k = sort_pos[c];
+            sort_pos[c] = run;
+            run += k;
+        }
+    }
+    __syncthreads();
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const unsigned h = t.list[i];
-        if (!dropped && i < a.entries_cap) {
+        if (!dropped) {
             ChunkEntry ce;
             ce.key = t.keys[h];
             ce.block_idx = a.hv.slot_vals[t.hslot[h]];
             ce.pad = 0;
+            int c = 0;
 #pragma unroll
-            for (int w = 0; w < kChunkWords; ++w)
+            for (int w = 0; w < kChunkWords; ++w) {
                 ce.bits[w] = t.bits[(size_t)h * kChunkWords + w];
-            a.entries[i] = ce;
+                c += __popc(ce.bits[w]);
+            }
+            const int pos = atomicAdd(&sort_pos[a.longest_first ? c : 0], 1);
+            if (pos < a.entries_cap) a.entries[pos] = ce;
         }
         t.keys[h] = kEmptyKey;
 #pragma unroll
@@ -382,6 +420,11 @@ int LaunchBuildChunk(o3dmi_hash* bh, const ChunkTable& table,
     a.entries_count = entries_count;
     a.status_host = status_host;
     a.stamp = stamp;
+    static const int order = [] {
+        const char* e = getenv("O3DMI_CHUNK_ORDER");
+        return e ? atoi(e) : 1;
+    }();
+    a.longest_first = order;
     hipLaunchKernelGGL(BuildChunkKernel, dim3(1), dim3(256), 0, s, a);
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;

@@ -501,6 +501,7 @@ struct IntegParams {
     int rows, cols, resolution;
     int res_shift;  // log2(resolution) when it is a power of two, else -1
     int deal;       // 1: an XCD takes a contiguous eighth of the block list
+    int cube;       // 1: a wave's lanes cover a compact cube of the block
     int diag;       // O3DMI_STEP_DIAG (timing experiments, WRONG results):
                     // 1 = every gather reads record 0, 2 = no state stores;
                     // 3 = no skip of fully rejected waves (RIGHT results)
@@ -517,6 +518,7 @@ struct IntegParams {
     int* size_host;
     int status_stamp;
     int* prof_count;
+    unsigned long long* prof_items;  // kLong timeline: 4 words per (entry, part)
     int* prof_frame_blocks;
     int* prof_map_size;
     // RAW form (sliced block-ownership path, sliced_path.h): no prepared
@@ -952,6 +954,9 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
             part = (int)(m - kb * parts);
         }
         const int64_t b = ip.deal ? first_b + kb : first_b + (kb << 3);
+        unsigned long long item_t0 = 0ull;
+        if constexpr (kLong)
+            if (ip.prof_items && threadIdx.x == 0) item_t0 = wall_clock64();
         int xb, yb, zb, block_idx;
         unsigned bits;
         unsigned long_bits = 0u;  // kLong: lane l holds word l & 7
@@ -1033,7 +1038,27 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
         const int q = (part << 8) + threadIdx.x;
         if (q >= n_quads || bits == 0u) continue;
         int qx, yv, zv;
-        if (res_shift >= 0) {
+        int lin_q = q;  // index of the lane's first voxel / kV in the block
+        if (res_shift - kVShift >= 2 && ip.cube) {
+            // Lane -> voxel by a permutation of q's bits: the 64 lanes of a
+            // wave take a compact (4 << kVShift) x 4 x 4 cube of the block
+            // instead of a (res x 8 x 1) slab, so that one gather instruction
+            // touches the image rows of a 4-voxel-high patch, not those of a
+            // slab res voxels long (the vector memory pipeline takes a cycle
+            // per distinct cache line of an instruction). Any bijection gives
+            // the same grid: voxels are independent.
+            const int nx = res_shift - kVShift;  // bits of qx (>= 2: res >= 8)
+            const unsigned uq = (unsigned)q;
+            unsigned rest = uq >> 6;
+            const unsigned qx_hi = rest & ((1u << (nx - 2)) - 1u);
+            rest >>= (nx - 2);
+            const unsigned y_hi = rest & ((1u << (res_shift - 2)) - 1u);
+            rest >>= (res_shift - 2);
+            qx = (int)((uq & 3u) | (qx_hi << 2));
+            yv = (int)(((uq >> 2) & 3u) | (y_hi << 2));
+            zv = (int)(((uq >> 4) & 3u) | (rest << 2));
+            lin_q = (((zv << res_shift) | yv) << nx) | qx;
+        } else if (res_shift >= 0) {
             qx = q & (quads_per_row - 1);
             const int row = q >> (res_shift - kVShift);
             yv = row & (res - 1);
@@ -1047,7 +1072,7 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
         const int x0 = xb * res + (qx << kVShift);
         const float fy = (float)(yb * res + yv);
         const float fz = (float)(zb * res + zv);
-        const int64_t lin0 = block_base + ((int64_t)q << kVShift);
+        const int64_t lin0 = block_base + ((int64_t)lin_q << kVShift);
 
         // 1. voxel state, widened to float once per work item. A uint16
         // weight / colour is an exact float; between the frames of the group
@@ -1423,6 +1448,23 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                 *reinterpret_cast<CVec*>(color_base + 3 * lin0) = c12;
             }
         }
+        if constexpr (kLong) {
+            // O3DMI_CHUNK_TIMELINE: {start, end} on the 100 MHz clock, the
+            // entry's frame count and where the workgroup ran
+            if (ip.prof_items && threadIdx.x == 0) {
+                int n_set = 0;
+#pragma unroll
+                for (int w = 0; w < kChunkWords; ++w)
+                    n_set += __popc((unsigned)__builtin_amdgcn_readlane(
+                            (int)long_bits, w));
+                unsigned long long* o = ip.prof_items + (b * parts + part) * 4;
+                o[0] = item_t0;
+                o[1] = wall_clock64();
+                o[2] = ((unsigned long long)n_set << 32) |
+                       (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+                o[3] = ((unsigned long long)(unsigned)xcd << 32) | (unsigned)wg;
+            }
+        }
     }
     if (frame_blocks) atomicAdd(ip.prof_frame_blocks, frame_blocks);
 }
@@ -1448,7 +1490,13 @@ static_assert(sizeof(StepParams) <= 4096, "kernel arguments are limited to 4 KB"
 // launch lasts -- twice the frames in flight per round halve the rounds; the
 // registers this costs (2 waves per SIMD allowed) are not needed for occupancy
 // there.
-constexpr int kRawChunk = 4;
+#ifndef O3DMI_RAW_CHUNK
+#define O3DMI_RAW_CHUNK 4
+#endif
+#ifndef O3DMI_RAW_WAVES
+#define O3DMI_RAW_WAVES 5
+#endif
+constexpr int kRawChunk = O3DMI_RAW_CHUNK;
 template <typename weight_t, typename color_t, bool kColor, int kDiv,
           int kForm>
 __global__ void __launch_bounds__(256, kForm == 0 ? 1 : (kForm == 1 ? 4 : 7))
@@ -1483,7 +1531,7 @@ struct ChunkParams {
 constexpr int kPipeChunk = 2;
 template <typename weight_t, typename color_t, bool kColor, int kDiv,
           bool kRaw, bool kPipe>
-__global__ void __launch_bounds__(256, kPipe ? 5 : (kRaw ? 5 : 7))
+__global__ void __launch_bounds__(256, kPipe ? 5 : (kRaw ? O3DMI_RAW_WAVES : 7))
 ChunkIntegrateKernel(ChunkParams cp) {
     IntegrateRoleWide<weight_t, color_t, kColor, kDiv,
                       kPipe ? kPipeChunk : (kRaw ? kRawChunk : kGroupChunk), 1,
@@ -1492,6 +1540,18 @@ ChunkIntegrateKernel(ChunkParams cp) {
 }
 
 }  // namespace
+
+// The compact lane -> voxel map of the wide integrate role (default; needs a
+// power-of-two resolution >= 8; O3DMI_LANE_CUBE=0 = the slab map, for A / B:
+// profiles/r4zf -- chunk launch at 8 ranks 486 k -> 525 k frames/s, single-GPU
+// stream 127.6 k -> 128.6 k).
+static int LaneCube(int res_shift) {
+    static const int want = []() {
+        const char* e = std::getenv("O3DMI_LANE_CUBE");
+        return e ? std::atoi(e) : 1;
+    }();
+    return (want && res_shift >= 3) ? 1 : 0;
+}
 
 bool PrepTables(const double* depth_intrinsic, const double* color_intrinsic,
                 int rows, int cols, int color_rows, int color_cols,
@@ -1796,6 +1856,7 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         ip.res_shift = -1;
         for (int sh = 2; sh < 12; ++sh)
             if ((1 << sh) == a->resolution) ip.res_shift = sh;
+        ip.cube = LaneCube(ip.res_shift);
         ip.sdf_trunc = a->sdf_trunc;
         ip.depth_max = a->depth_max;
         fast_div = VerifyFastDivision(a->sdf_trunc, &ip.inv_sdf_trunc);
@@ -1901,6 +1962,7 @@ int LaunchChunkIntegrate(o3dmi_hash* bh, const ChunkIntegrateArgs& a,
     ip.res_shift = -1;
     for (int sh = 2; sh < 12; ++sh)
         if ((1 << sh) == a.resolution) ip.res_shift = sh;
+    ip.cube = LaneCube(ip.res_shift);
     ip.sdf_trunc = a.sdf_trunc;
     ip.depth_max = a.depth_max;
     const int fast_div = VerifyFastDivision(a.sdf_trunc, &ip.inv_sdf_trunc);
@@ -1930,6 +1992,23 @@ int LaunchChunkIntegrate(o3dmi_hash* bh, const ChunkIntegrateArgs& a,
     if (g < kCUs) g = kCUs;
     const dim3 grid((unsigned)g), block(256);
     const bool col = a.with_color && a.color != nullptr;
+    // O3DMI_CHUNK_TIMELINE=<file>: launch number O3DMI_CHUNK_TIMELINE_LAUNCH
+    // (default 20) of the process records a per-work-item timeline (analysis
+    // tool: tools/chunk_timeline.py); the launch is synchronised, every other
+    // launch is untouched.
+    static const char* tl_path = std::getenv("O3DMI_CHUNK_TIMELINE");
+    static const int tl_launch = [] {
+        const char* e = std::getenv("O3DMI_CHUNK_TIMELINE_LAUNCH");
+        return e ? atoi(e) : 20;
+    }();
+    static int tl_seen = 0;
+    unsigned long long* tl_dev = nullptr;
+    const size_t tl_words = (size_t)a.entries_cap * parts * 4;
+    if (tl_path && tl_seen++ == tl_launch) {
+        O3DMI_HIP_CHECK(hipMalloc((void**)&tl_dev, tl_words * 8));
+        O3DMI_HIP_CHECK(hipMemsetAsync(tl_dev, 0, tl_words * 8, s));
+        ip.prof_items = tl_dev;
+    }
 #define O3DMI_LAUNCH_CHUNK_D(WT, VT, COLOR, D)                                \
     do {                                                                      \
         if (a.raw && a.pipelined)                                             \
@@ -1968,6 +2047,20 @@ int LaunchChunkIntegrate(o3dmi_hash* bh, const ChunkIntegrateArgs& a,
 #undef O3DMI_LAUNCH_CHUNK
 #undef O3DMI_LAUNCH_CHUNK_D
     O3DMI_HIP_CHECK(hipGetLastError());
+    if (tl_dev) {
+        O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h(tl_words);
+        O3DMI_HIP_CHECK(hipMemcpy(h.data(), tl_dev, tl_words * 8,
+                                  hipMemcpyDeviceToHost));
+        (void)hipFree(tl_dev);
+        if (FILE* f = std::fopen(tl_path, "wb")) {
+            const long long head[4] = {(long long)a.entries_cap, parts,
+                                       a.n_frames, (long long)g};
+            std::fwrite(head, sizeof(head), 1, f);
+            std::fwrite(h.data(), 8, tl_words, f);
+            std::fclose(f);
+        }
+    }
     return O3DMI_OK;
 }
 
