@@ -60,3 +60,41 @@ def test_slam_timeline_charges_idle_time_to_the_launch_that_ends_it(tmp_path):
     assert out["vds"][2:] == ["1.0", "0.0"]
     assert out["final_sum"][2:] == ["2.0", "3.0"]
     assert out["total"][2:] == ["7.0", "8.0"]
+
+
+def test_chunk_timeline_reads_the_librarys_record_layout(tmp_path):
+    """tools/chunk_timeline.py on a made-up record file in the layout
+    LaunchChunkIntegrate writes (vbg_stream.hip: 4-word head, then 4 words per
+    (entry, part): start, end on the 100 MHz clock, frames << 32 | HW_ID,
+    xcd << 32 | workgroup): two compute units, the busier one ends last."""
+    import json
+    import numpy as np
+    head = np.array([8, 2, 192, 16], np.int64).view(np.uint64)
+
+    def hw(cu, se):
+        return (cu << 8) | (se << 13)
+    recs = np.zeros((16, 4), np.uint64)
+    items = [  # start, end (ticks of 10 ns), frames, cu, se, xcd, wg
+        (1000, 21000, 180, 3, 0, 0, 0),
+        (1000, 9000, 60, 3, 0, 0, 8),
+        (1010, 5010, 20, 5, 1, 1, 1),
+        (5010, 7010, 10, 5, 1, 1, 9),
+    ]
+    for i, (t0, t1, n, cu, se, xcd, wg) in enumerate(items):
+        recs[2 * i] = (t0, t1, (n << 32) | hw(cu, se), (xcd << 32) | wg)
+    f = tmp_path / "tl.bin"
+    np.concatenate([head, recs.reshape(-1)]).tofile(f)
+    r = subprocess.run([sys.executable,
+                        os.path.join(ROOT, "tools", "chunk_timeline.py"),
+                        str(f), "--json"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout)
+    assert d["items"] == 4 and d["n_frames"] == 192 and d["grid"] == 16
+    assert abs(d["span_us"] - 200.0) < 1e-9          # 20 000 ticks
+    assert d["frames_per_item_max"] == 180
+    assert d["compute_units_seen"] == 2
+    assert abs(d["cu_end_us"]["max"] - 200.0) < 1e-9
+    assert abs(d["cu_end_us"]["min"] - 60.1) < 1e-9
+    assert d["cu_work_frames"] == {"min": 30, "mean": 135.0, "max": 240}
+    assert d["last_items"][-1]["frames"] == 180
