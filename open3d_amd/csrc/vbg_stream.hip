@@ -28,6 +28,12 @@
 #include "sliced_path.h"
 #include "touch_device.h"
 
+// Compile-time switches of the raw chunk launch (tools/build_variant.sh builds
+// A/B libraries with other values).
+#ifndef O3DMI_RAW_TWO_PHASE
+#define O3DMI_RAW_TWO_PHASE 0
+#endif
+
 namespace o3dmi {
 namespace {
 
@@ -872,6 +878,25 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                                                   int first_wg) {
     constexpr int kV = 2 * kP;             // voxels per lane
     constexpr int kVShift = kP == 2 ? 2 : 1;
+    // Raw form with colour, two phases per round: the depth gathers first;
+    // the colour pixel is fetched only by the lanes whose voxel the frame
+    // really updates (valid depth inside the truncation band -- a fraction of
+    // a touched block's voxels, and none at all in the waves a frame skips).
+    // The launch is bound by the vector-memory path, not by latency (DESIGN
+    // 7), and colour is 60 % of the raw form's cache lines.
+    constexpr bool kTwoPhase = kRaw && kColor && (O3DMI_RAW_TWO_PHASE != 0);
+    // kLong: the frame table is read through the CONSTANT address space and
+    // the images through the GLOBAL one. A plain pointer makes the table's
+    // loads vector loads (stores of earlier work items may alias it as far as
+    // the compiler knows) -- one more dependent trip through the vector
+    // memory queue per round, and in order with the gathers -- and the image
+    // pointers, coming out of memory, generic: flat loads.
+    using FrameTabC = const IntegFrame __attribute__((address_space(4)));
+    using ByteG = const char __attribute__((address_space(1)));
+    using U16G = const uint16_t __attribute__((address_space(1)));
+    typedef unsigned U2v __attribute__((ext_vector_type(2)));
+    using U2G = const U2v __attribute__((address_space(1)));
+    FrameTabC* const ftab = (FrameTabC*)ip.frame_tab;
     using TVec = Vec<float, kV, 4 * kV>;
     using WVec = Vec<weight_t, kV, kV * sizeof(weight_t)>;
     using CVec = Vec<color_t, 3 * kV, kV * sizeof(color_t)>;
@@ -1149,20 +1174,27 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
             // The frame's constants are fetched here, per work item (scalar
             // loads from the argument block / the frame table): hoisted out of
             // the item loop they would occupy ~60 scalar registers and spill.
+            float e_tab[3][4];
+            if constexpr (kLong) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) e_tab[i][j] = ftab[f].ext[i][j];
+            }
             const float(&e)[3][4] =
-                    kLong ? ip.frame_tab[f].ext
+                    kLong ? e_tab
                           : *reinterpret_cast<const float(*)[3][4]>(
                                     &ip.ext[kLong ? 0 : f][0][0] + opaque);
             const char* __restrict__ recs = reinterpret_cast<const char*>(
                     kRaw ? nullptr
-                         : (kLong ? ip.frame_tab[f].recs
+                         : (kLong ? (const void*)ftab[f].recs
                                   : *(&ip.recs[kLong ? 0 : f] + opaque)));
-            const char* __restrict__ dimg = reinterpret_cast<const char*>(
-                    kLong ? ip.frame_tab[f].depth
+            ByteG* __restrict__ dimg = (ByteG*)(
+                    kLong ? (const void*)ftab[f].depth
                           : (kRaw ? *(&ip.raw_depth[kLong ? 0 : f] + opaque)
                                   : nullptr));
-            const char* __restrict__ cimg = reinterpret_cast<const char*>(
-                    kLong ? ip.frame_tab[f].color
+            ByteG* __restrict__ cimg = (ByteG*)(
+                    kLong ? (const void*)ftab[f].color
                           : (kRaw ? *(&ip.raw_color[kLong ? 0 : f] + opaque)
                                   : nullptr));
             const float y0 = ys * e[0][1], z0 = zs * e[0][2];
@@ -1221,10 +1253,14 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                         R.in_mask |= (in ? 1u : 0u) << (fk * kV + 2 * p + h);
                         PixelRec r;
                         // .d holds the raw uint16 depth (converted below)
-                        r.d = __uint_as_float((unsigned)*reinterpret_cast<
-                                              const uint16_t*>(dimg + 2u * pix));
+                        r.d = __uint_as_float(
+                                (unsigned)*(U16G*)(dimg + 2u * pix));
                         r.rgba = 0u;
-                        if constexpr (kColor) {
+                        if constexpr (kTwoPhase) {
+                            // the colour is fetched in `apply`, by the lanes
+                            // that need it: keep the pixel
+                            R.csh[fk][2 * p + h] = pix;
+                        } else if constexpr (kColor) {
                             // the 3 bytes at 3 * pix out of ONE aligned 8-byte
                             // load (an unaligned 4-byte load is split by the
                             // memory pipeline); the address is clamped so that
@@ -1232,8 +1268,7 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                             const unsigned b3 = 3u * pix;
                             unsigned al = b3 & ~3u;
                             al = al < last_col8 ? al : last_col8;
-                            const uint2 q =
-                                    *reinterpret_cast<const uint2*>(cimg + al);
+                            const U2v q = *(U2G*)(cimg + al);
                             r.rgba = q.x;
                             R.chi[fk][2 * p + h] = q.y;
                             R.csh[fk][2 * p + h] = (b3 - al) * 8u;
@@ -1252,7 +1287,70 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
         }
 
         };
-        auto apply = [&](Round& R) {
+        // kRaw: float(depth) / depth_scale (VoxelBlockGridImpl.h:258-262),
+        // what the prepare pass does per pixel: the short constant-divisor
+        // form when the host verified it for all 65536 depths
+        auto convert_depth = [&](int fk, Round& R) {
+#pragma unroll
+            for (int p = 0; p < kP; ++p) {
+                f2 a = f2{(float)__float_as_uint(R.rec[fk][2 * p].d),
+                          (float)__float_as_uint(R.rec[fk][2 * p + 1].d)};
+                f2 q;
+                if (ip.depth_div_short) {
+                    const f2 q0 = a * ip.inv_depth_scale;
+                    const f2 r = PkFma(Splat(-ip.depth_scale), q0, a);
+                    q = PkFma(r, Splat(ip.inv_depth_scale), q0);
+                } else {
+                    q = f2{a.x / ip.depth_scale, a.y / ip.depth_scale};
+                }
+                // outside the image: depth 0 = invalid (the records path's
+                // sentinel)
+                R.rec[fk][2 * p].d =
+                        ((R.in_mask >> (fk * kV + 2 * p)) & 1u) ? q.x : 0.0f;
+                R.rec[fk][2 * p + 1].d =
+                        ((R.in_mask >> (fk * kV + 2 * p + 1)) & 1u) ? q.y : 0.0f;
+            }
+        };
+        auto apply = [&](int c0, Round& R) {
+        if constexpr (kTwoPhase) {
+            // second phase of the round's gathers: colour, for the voxels the
+            // frame updates (`ok` below, evaluated the same way)
+#pragma unroll
+            for (int fk = 0; fk < kChunk; ++fk) {
+                if (!((R.cbits >> fk) & 1u)) continue;  // wave-uniform
+                const int f = c0 + fk;
+                ByteG* __restrict__ cimg = (ByteG*)(
+                        kLong ? (const void*)ftab[f].color
+                              : *(&ip.raw_color[kLong ? 0 : f] + opaque));
+                convert_depth(fk, R);
+#pragma unroll
+                for (int p = 0; p < kP; ++p) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float dh = R.rec[fk][2 * p + h].d;
+                        const float zh = h ? R.zc[fk][p].y : R.zc[fk][p].x;
+                        const bool okv = !(dh <= 0) && !(dh > ip.depth_max) &&
+                                         !(zh <= 0) &&
+                                         !((dh - zh) < -ip.sdf_trunc);
+                        unsigned lo = 0u, hi = 0u, shf = 0u;
+                        if (okv) {
+                            // the 3 bytes at 3 * pix out of ONE aligned 8-byte
+                            // load, clamped to the end of the image
+                            const unsigned b3 = 3u * R.csh[fk][2 * p + h];
+                            unsigned al = b3 & ~3u;
+                            al = al < last_col8 ? al : last_col8;
+                            const U2v q = *(U2G*)(cimg + al);
+                            lo = q.x;
+                            hi = q.y;
+                            shf = (b3 - al) * 8u;
+                        }
+                        R.rec[fk][2 * p + h].rgba = lo;
+                        R.chi[fk][2 * p + h] = hi;
+                        R.csh[fk][2 * p + h] = shf;
+                    }
+                }
+            }
+        }
         // 3. frames applied in order (VoxelBlockGridImpl.h:258-302)
 #pragma unroll
         for (int fk = 0; fk < kChunk; ++fk) {
@@ -1260,31 +1358,7 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
             f2 sdf[kP];
             bool ok[kV];
             bool tiny = false;
-            if constexpr (kRaw) {
-                // float(depth) / depth_scale (VoxelBlockGridImpl.h:258-262),
-                // what the prepare pass does per pixel: the short constant-
-                // divisor form when the host verified it for all 65536 depths
-#pragma unroll
-                for (int p = 0; p < kP; ++p) {
-                    f2 a = f2{(float)__float_as_uint(R.rec[fk][2 * p].d),
-                              (float)__float_as_uint(R.rec[fk][2 * p + 1].d)};
-                    f2 q;
-                    if (ip.depth_div_short) {
-                        const f2 q0 = a * ip.inv_depth_scale;
-                        const f2 r = PkFma(Splat(-ip.depth_scale), q0, a);
-                        q = PkFma(r, Splat(ip.inv_depth_scale), q0);
-                    } else {
-                        q = f2{a.x / ip.depth_scale, a.y / ip.depth_scale};
-                    }
-                    // outside the image: depth 0 = invalid (the records
-                    // path's sentinel)
-                    R.rec[fk][2 * p].d =
-                            ((R.in_mask >> (fk * kV + 2 * p)) & 1u) ? q.x : 0.0f;
-                    R.rec[fk][2 * p + 1].d =
-                            ((R.in_mask >> (fk * kV + 2 * p + 1)) & 1u) ? q.y
-                                                                      : 0.0f;
-                }
-            }
+            if constexpr (kRaw && !kTwoPhase) convert_depth(fk, R);
 #pragma unroll
             for (int p = 0; p < kP; ++p) {
 #pragma unroll
@@ -1396,7 +1470,7 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
             while (ca >= 0) {
                 const int cb = next_round(ca + kChunk, rb);
                 if (cb >= 0) issue(cb, rb);
-                apply(ra);
+                apply(ca, ra);
                 ca = cb;
                 ra = rb;
             }
@@ -1407,7 +1481,7 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                 r.cbits = round_bits(c0);
                 if (r.cbits == 0u) continue;  // wave-uniform
                 issue(c0, r);
-                apply(r);
+                apply(c0, r);
             }
         } else {
             // (kChunk frames at a time: a group of up to kMaxGroup frames is
@@ -1421,7 +1495,7 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                 r.cbits = round_bits(c0);
                 if (r.cbits == 0u) continue;  // wave-uniform
                 issue(c0, r);
-                apply(r);
+                apply(c0, r);
             }
         }
         if (touched && ip.diag != 2) {
