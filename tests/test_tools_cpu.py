@@ -98,3 +98,45 @@ def test_chunk_timeline_reads_the_librarys_record_layout(tmp_path):
     assert abs(d["cu_end_us"]["min"] - 60.1) < 1e-9
     assert d["cu_work_frames"] == {"min": 30, "mean": 135.0, "max": 240}
     assert d["last_items"][-1]["frames"] == 180
+
+
+def test_isa_scan_reads_kernels_and_ignores_labels_in_a_diff():
+    """tools/isa_scan.py's parser on a made-up assembly listing: kernel
+    metadata, flat / scratch instruction counts, and a diff that ignores label
+    numbers and comments but sees a changed instruction."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_scan
+
+    def listing(label, op, vgpr):
+        return (
+            "\t.text\n"
+            "_ZN5o3dmi12_GLOBAL__N_18MyKernelEv: ; @_ZN5o3dmi12_GLOBAL__N_18MyKernelEv\n"
+            "; %bb.0:\n"
+            "\ts_load_dwordx2 s[0:1], s[4:5], 0x0\n"
+            ".LBB%d_1:                              ; in Loop\n"
+            "\t%s v1, v[2:3]   ; a comment\n"
+            "\tscratch_store_dword off, v1, off\n"
+            "\ts_cbranch_scc1 .LBB%d_1\n"
+            "\ts_endpgm\n"
+            ".Lfunc_end0:\n"
+            "_ZN5o3dmi6HelperEv: ; a device function, not a kernel\n"
+            "\ts_setpc_b64 s[30:31]\n"
+            ".Lfunc_end1:\n"
+            "\t.amdhsa_kernel _ZN5o3dmi12_GLOBAL__N_18MyKernelEv\n"
+            "\t\t.amdhsa_group_segment_fixed_size 1024\n"
+            "\t\t.amdhsa_private_segment_fixed_size 8\n"
+            "\t\t.amdhsa_next_free_vgpr %d\n"
+            "\t\t.amdhsa_next_free_sgpr 20\n"
+            "\t.end_amdhsa_kernel\n" % (label, op, label, vgpr))
+    a = listing(3, "flat_load_dword", 24)
+    rows = isa_scan.scan_text(a)
+    assert len(rows) == 1                      # the helper is not a kernel
+    r = rows[0]
+    assert r["kernel"] == "MyKernelEv" and r["vgpr"] == 24 and r["sgpr"] == 20
+    assert r["scratch_bytes"] == 8 and r["lds_bytes"] == 1024
+    assert r["flat"] == 1 and r["scratch_ops"] == 1
+    same = isa_scan.diff_texts(a, listing(7, "flat_load_dword", 24))
+    assert same["same"] == ["MyKernelEv"] and not same["changed"]
+    ch = isa_scan.diff_texts(a, listing(3, "global_load_dword", 24))
+    assert not ch["same"] and ch["changed"][0]["kernel"] == "MyKernelEv"
+    assert ch["changed"][0]["same_opcode_multiset"] is False
