@@ -111,7 +111,7 @@ def test_isa_scan_reads_kernels_and_ignores_labels_in_a_diff():
         return (
             "\t.text\n"
             "_ZN5o3dmi12_GLOBAL__N_18MyKernelEv: ; @_ZN5o3dmi12_GLOBAL__N_18MyKernelEv\n"
-            "; %bb.0:\n"
+            "; %%bb.0:\n"
             "\ts_load_dwordx2 s[0:1], s[4:5], 0x0\n"
             ".LBB%d_1:                              ; in Loop\n"
             "\t%s v1, v[2:3]   ; a comment\n"
