@@ -14,6 +14,9 @@
 // each key appends it to the output list. Counts stay on the device.
 
 #include "common.h"
+#include <map>
+#include <utility>
+
 #include "touch_device.h"
 
 namespace o3dmi {
@@ -404,24 +407,29 @@ int o3dmi_unproject(const void* depth_dev, int depth_dtype, int rows, int cols,
     const int n_chunks = (int)((n + (int64_t)kBlock * rounds - 1) /
                                ((int64_t)kBlock * rounds));
     if (ordered) {
-        // per host thread and device, grown on demand (a few KB)
-        static thread_local int* bufs[64] = {};
-        static thread_local int caps[64] = {};
+        // per host thread, device and stream (two calls of one thread on two
+        // streams may overlap on the device), grown on demand (a few KB each)
+        struct Counts {
+            int* buf = nullptr;
+            int cap = 0;
+        };
+        static thread_local std::map<std::pair<int, hipStream_t>, Counts> bufs;
         int dev = 0;
         O3DMI_HIP_CHECK(hipGetDevice(&dev));
-        O3DMI_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
-        if (caps[dev] < n_chunks) {
-            if (bufs[dev]) {
-                O3DMI_HIP_CHECK(hipDeviceSynchronize());
-                (void)hipFree(bufs[dev]);
-                bufs[dev] = nullptr;
+        Counts& c = bufs[std::make_pair(dev, s)];
+        if (c.cap < n_chunks) {
+            if (c.buf) {
+                O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+                (void)hipFree(c.buf);
+                c.buf = nullptr;
+                c.cap = 0;
             }
             int cap = 4096;
             while (cap < n_chunks) cap <<= 1;
-            O3DMI_HIP_CHECK(hipMalloc((void**)&bufs[dev], sizeof(int) * cap));
-            caps[dev] = cap;
+            O3DMI_HIP_CHECK(hipMalloc((void**)&c.buf, sizeof(int) * cap));
+            c.cap = cap;
         }
-        chunk_counts = bufs[dev];
+        chunk_counts = c.buf;
     }
 #define O3DMI_UNPROJECT_M(T, R, M)                                            \
     hipLaunchKernelGGL((UnprojectKernel<T, R, M>), grid, block, 0, s, p,      \
