@@ -140,3 +140,21 @@ def test_isa_scan_reads_kernels_and_ignores_labels_in_a_diff():
     ch = isa_scan.diff_texts(a, listing(3, "global_load_dword", 24))
     assert not ch["same"] and ch["changed"][0]["kernel"] == "MyKernelEv"
     assert ch["changed"][0]["same_opcode_multiset"] is False
+
+
+def test_every_environment_switch_of_the_library_is_documented():
+    """docs/switches.md lists every O3DMI_* variable the library reads."""
+    import re
+    names = set()
+    csrc = os.path.join(ROOT, "open3d_amd", "csrc")
+    for dirpath, _, files in os.walk(csrc):
+        for f in files:
+            if f.endswith((".hip", ".cpp", ".h")):
+                with open(os.path.join(dirpath, f)) as fh:
+                    names |= set(re.findall(r'getenv\("(O3DMI_[A-Z0-9_]+)"\)',
+                                            fh.read()))
+    assert len(names) > 30
+    with open(os.path.join(ROOT, "docs", "switches.md")) as fh:
+        doc = fh.read()
+    missing = sorted(n for n in names if n not in doc)
+    assert not missing, missing
