@@ -52,7 +52,6 @@ import glob
 import json
 import os
 import shutil
-import socket
 import subprocess
 import sys
 import tempfile
@@ -153,15 +152,15 @@ def maybe_spawn(a):
     torch.distributed.run, one rank per GPU."""
     if a.gpus <= 1 or "WORLD_SIZE" in os.environ:
         return
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    # No port is picked here: the c10d rendezvous binds port 0 itself and the
+    # workers reuse the agent's store (picking a port by bind-close and
+    # handing the number on raced with EADDRINUSE in round 4).
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("MASTER_PORT", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-           "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + \
-        sys.argv[1:]
+           "--nproc-per-node", str(a.gpus), "--rdzv-backend=c10d",
+           "--rdzv-endpoint=127.0.0.1:0", "--local-addr", "127.0.0.1",
+           os.path.abspath(__file__)] + sys.argv[1:]
     sys.exit(subprocess.call(cmd, env=env))
 
 

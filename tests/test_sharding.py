@@ -1,6 +1,7 @@
 """world_size-2 gloo tests (CPU) of the multi-GPU exchange steps."""
 import os
-import socket
+import shutil
+import tempfile
 
 import numpy as np
 import torch
@@ -10,21 +11,21 @@ import torch.multiprocessing as mp
 import _oracle as orc
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+RENDEZVOUS_TIMEOUT_S = 120
 
 
-def _worker(rank, world, port, fn, ret, backend="gloo"):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
+def _worker(rank, world, rdzv, fn, ret, backend="gloo"):
+    # Rendezvous through a FileStore on a fresh temporary path: no TCP port is
+    # picked, so nothing can take it between the pick and the listen (the
+    # bind-close-rebind pattern this replaces raced with EADDRINUSE).
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.pop("MASTER_PORT", None)
     if backend == "nccl":  # RCCL: one GPU per rank
         torch.cuda.set_device(rank)
-    dist.init_process_group(backend, rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group(
+        backend, init_method="file://" + rdzv, rank=rank, world_size=world,
+        timeout=datetime.timedelta(seconds=RENDEZVOUS_TIMEOUT_S))
     try:
         ret[rank] = fn(rank, world)
     finally:
@@ -34,8 +35,12 @@ def _worker(rank, world, port, fn, ret, backend="gloo"):
 def _run(fn, world=2, backend="gloo"):
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), fn, ret, backend),
-             nprocs=world, join=True)
+    tmp = tempfile.mkdtemp(prefix="o3dmi_rdzv_")
+    try:
+        mp.spawn(_worker, args=(world, os.path.join(tmp, "store"), fn, ret,
+                                backend), nprocs=world, join=True)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
     return [ret[r] for r in range(world)]
 
 
