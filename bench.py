@@ -76,6 +76,27 @@ BYTES_PER_BLOCK = 4096 * 24
 IMAGE_BYTES = W * H * 2 + W * H * 3
 BLOCK_HEADER_BYTES = 16   # buf index + key
 N_SIMD = 256 * 4
+# VALU issue cost of a wave64 instruction on gfx950, MEASURED (tools/
+# calib_valu.hip, profiles/r5b_valu_calibration.json): 2.4 cycles for plain
+# float32 mul / add / fma, integer add, shift, move; 4.3 for packed float32,
+# conversions, compares, selects, truncation, 24-bit multiplies; 8.3 for
+# v_rcp_f32. No counter tells the classes apart (SQ_ACTIVE_INST_VALU reads 1
+# per instruction whatever its class, 2 for a transcendental); the integrate
+# role's mix on the path of a frame that updates its voxels, walked through
+# its ISA and priced per class (tools/valu_cost.py, profiles/r5_valu_mix.txt:
+# 118 instructions, 415 cycles per wave and frame), averages:
+VALU_FULL, VALU_HALF = 2.4, 4.3
+VALU_CYCLES_PER_INST = 3.5
+
+
+def valu_fractions(insts, simd_cycles):
+    """SQ_INSTS_VALU of a launch -> share of the SIMDs' cycles that issue
+    vector-ALU work: at the kernel's own instruction mix, and the bounds the
+    two cost classes put on any mix."""
+    if not insts or not simd_cycles:
+        return None, None
+    per = insts / (N_SIMD * simd_cycles)
+    return per * VALU_CYCLES_PER_INST, [per * VALU_FULL, per * VALU_HALF]
 N_XCD = 8
 KERNEL = "FrameStepKernel"
 
@@ -222,6 +243,10 @@ def cpu_baseline(frames_cpu, K, Ts, budget_s):
     fps, n, phase_ms = run(best, frames, budget_s * 0.5)
     return {"value": fps, "unit": "frames/s", "cores": best,
             "kind": "reference" if use_ref else "port", "frames": n,
+            # the choice made visible: frames/s of the 6-frame
+            # probe at every thread count tried
+            "thread_scaling_frames_per_s": {str(c): round(v, 1)
+                                            for c, v in sorted(probe.items())},
             "ms_per_frame": {"touch": phase_ms[0],
                              "activate_find": phase_ms[1],
                              "integrate": phase_ms[2]},
@@ -532,7 +557,8 @@ def kernel_counters(inner, want):
         if sq.get("GRBM_GUI_ACTIVE") and sq.get("SQ_ACTIVE_INST_VALU"):
             cyc = sq["GRBM_GUI_ACTIVE"] / N_XCD
             wc = max(1.0, sq.get("SQ_WAVE_CYCLES", 1.0))
-            out["frac_valu"] = sq["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMD * cyc)
+            out["frac_valu"], out["frac_valu_bounds"] = valu_fractions(
+                sq.get("SQ_INSTS_VALU"), cyc)
             out["valu_insts_per_launch"] = sq.get("SQ_INSTS_VALU")
             out["avg_waves_per_simd"] = sq.get("SQ_WAVE_CYCLES", 0) * 4.0 / \
                 (N_SIMD * cyc)
@@ -1072,12 +1098,30 @@ def main():
                 prepared[(lo, m)] = (b, gath)
             return prepared[(lo, m)]
 
+        def batch_of_step(lo):
+            # ONE native call per step: the step's a.batch frames (the stream
+            # looped) as one pointer / pose array -- the sliced path's first
+            # chunks of a call have nothing to overlap with, so a call per
+            # 1000-frame pass paid that 8 times per step (DESIGN r4 10.1)
+            key = ("step", lo)
+            if key not in prepared:
+                ids = [(lo + i) % n_u for i in range(a.batch)]
+                b = g.prepare_frames(
+                    [depths[i] for i in ids],
+                    [colors[i] for i in ids] if colors is not None else None,
+                    K, K, [Ts[i] for i in ids])
+                gath = g.gather_slices(
+                    b, max(1, g.owner_world), DEPTH_SCALE, DEPTH_MAX, TRUNC,
+                    a.frames_per_launch) if sliced_emu else None
+                prepared[key] = (b, gath)
+            return prepared[key]
+
         def run_step(s):
             lo = (s * a.batch) % n_u
             left = a.batch
             while left > 0:
-                m = min(left, n_u - lo)
-                b, gath = batch_of(lo, m)
+                m = left
+                b, gath = batch_of_step(lo)
                 if gath is not None:
                     g.integrate_frames_sliced(
                         b, gath, depth_scale=DEPTH_SCALE, depth_max=DEPTH_MAX,
@@ -1182,6 +1226,106 @@ def main():
                         "created grid (capacity %d), grid creation outside "
                         "the timed region" % (len(depths), a.block_count)}
 
+    # What a drop-in user gets: the reference's own call shape
+    # -- GetUniqueBlockCoordinates -> Integrate, one frame per pair of calls
+    # (VoxelBlockGrid.cpp:212-245,292-326; caller slam/Model.cpp:91-106) -- the
+    # fused one-call-per-frame form, and the batch call fed from HOST memory.
+    api_legs = None
+    if e_world == 1:
+        api_legs = {}
+        n_api = min(300, len(depths))
+
+        def timed(fn, n):
+            fn(0)  # warm-up (first-call allocations)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for i in range(n):
+                fn(i)
+            torch.cuda.synchronize()
+            return n / (time.perf_counter() - t)
+        try:
+            ga = make_grid()
+            ga.integrate_frames(depths, colors, K, K, Ts,
+                                depth_scale=DEPTH_SCALE, depth_max=DEPTH_MAX,
+                                trunc_voxel_multiplier=TRUNC)  # blocks exist
+
+            def two_step(i):
+                bc = ga.compute_unique_block_coordinates(
+                    depths[i], K, Ts[i], DEPTH_SCALE, DEPTH_MAX, TRUNC)
+                ga.integrate(bc, depths[i],
+                             colors[i] if colors is not None else None, K, K,
+                             Ts[i], DEPTH_SCALE, DEPTH_MAX, TRUNC)
+
+            def one_call(i):
+                ga.integrate_frame(depths[i],
+                                   colors[i] if colors is not None else None,
+                                   K, K, Ts[i], DEPTH_SCALE, DEPTH_MAX, TRUNC)
+            api_legs["api_two_step_frames_per_s"] = timed(two_step, n_api)
+            api_legs["integrate_frame_frames_per_s"] = timed(one_call, n_api)
+            api_legs["what"] = (
+                "%d frames of the same stream into a grid that holds its "
+                "blocks; api_two_step = get_unique_block_coordinates (one "
+                "host wait for the count, as upstream) + integrate per "
+                "frame through the Python mirror; integrate_frame = the "
+                "fused one-call form" % n_api)
+            del ga
+        except Exception as e:
+            api_legs["error"] = str(e)[:300]
+        # host-fed: the same stream from PINNED HOST memory, copied in slices
+        # on a copy stream into two device staging sets while the previous
+        # slice integrates (PCIe Gen5 x16: 1.536 MB per frame)
+        try:
+            n_hf, sl = min(960, len(depths)), 96
+            gh = make_grid()
+            hd = torch.stack([depths[i] for i in range(n_hf)]).cpu().pin_memory()
+            hc = torch.stack([colors[i] for i in range(n_hf)]).cpu().pin_memory() \
+                if colors is not None else None
+            dd = [torch.empty_like(hd[:sl], device=dev) for _ in range(2)]
+            dc = [torch.empty_like(hc[:sl], device=dev) for _ in range(2)] \
+                if hc is not None else None
+            copy_stream = torch.cuda.Stream()
+            main_stream = torch.cuda.current_stream()
+            ev_copied = [torch.cuda.Event() for _ in range(2)]
+            ev_used = [torch.cuda.Event() for _ in range(2)]
+
+            def host_fed_pass():
+                for k, lo in enumerate(range(0, n_hf, sl)):
+                    b = k & 1
+                    with torch.cuda.stream(copy_stream):
+                        if k >= 2:
+                            copy_stream.wait_event(ev_used[b])
+                        dd[b].copy_(hd[lo:lo + sl], non_blocking=True)
+                        if dc is not None:
+                            dc[b].copy_(hc[lo:lo + sl], non_blocking=True)
+                        ev_copied[b].record(copy_stream)
+                    main_stream.wait_event(ev_copied[b])
+                    gh.integrate_frames(
+                        [dd[b][i] for i in range(sl)],
+                        [dc[b][i] for i in range(sl)] if dc is not None
+                        else None, K, K, Ts[lo:lo + sl],
+                        depth_scale=DEPTH_SCALE, depth_max=DEPTH_MAX,
+                        trunc_voxel_multiplier=TRUNC,
+                        frames_per_launch=a.frames_per_launch)
+                    ev_used[b].record(main_stream)
+            host_fed_pass()  # creates the blocks, warms the staging
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(2):
+                host_fed_pass()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t
+            api_legs["host_fed_frames_per_s"] = 2 * n_hf / dt
+            api_legs["host_fed_pcie_gbps"] = 2 * n_hf * IMAGE_BYTES / dt / 1e9
+            api_legs["host_fed_what"] = (
+                "%d frames from pinned host memory, %d-frame slices copied "
+                "on a copy stream into two device staging sets while the "
+                "previous slice integrates (integrate_frames per slice)"
+                % (n_hf, sl))
+            del gh, hd, hc, dd, dc
+        except Exception as e:
+            api_legs["host_fed_error"] = str(e)[:300]
+        torch.cuda.empty_cache()
+
     # the other multi-GPU scheme beside the headline (short run)
     other = None
     if e_world > 1:
@@ -1230,20 +1374,39 @@ def main():
     # by the front role of the launch that prepared them and in once by the
     # integrate role of the next.
     RECORD_BYTES = W * H * 8
+    sliced_launches = e_world > 1 and by_blocks and a.touch == "sliced"
+    # which form of the chunk launch the library takes (StreamIntegrateSliced:
+    # O3DMI_SLICED_RAW, else raw from 4 ranks): the RAW form reads the images
+    # themselves (2 + 3 B per pixel) and has no records at all
+    raw_env = os.environ.get("O3DMI_SLICED_RAW")
+    sliced_raw = sliced_launches and (
+        raw_env[0] == "1" if raw_env else e_world >= 4)
+    rec_rw = 0 if sliced_raw else 2 * RECORD_BYTES
+    rec_r = 0 if sliced_raw else RECORD_BYTES
     min_bytes = (prof["distinct_blocks"] * (BYTES_PER_BLOCK +
                                             BLOCK_HEADER_BYTES)
-                 + prof["frames"] * (IMAGE_BYTES + 2 * RECORD_BYTES)) / launches
+                 + prof["frames"] * (IMAGE_BYTES + rec_rw)) / launches
     min_read = (prof["distinct_blocks"] * (BYTES_PER_BLOCK // 2 +
                                            BLOCK_HEADER_BYTES)
-                + prof["frames"] * (IMAGE_BYTES + RECORD_BYTES)) / launches
+                + prof["frames"] * (IMAGE_BYTES + rec_r)) / launches
+    # the STRICT minimum: distinct blocks once in and out + the raw images --
+    # without the kernel's own prepared records (written by one launch's front
+    # role and read back by the next launch's integrate role)
+    strict_bytes = (prof["distinct_blocks"] * (BYTES_PER_BLOCK +
+                                               BLOCK_HEADER_BYTES)
+                    + prof["frames"] * IMAGE_BYTES) / launches
     min_gbps = min_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    sliced_launches = e_world > 1 and by_blocks and a.touch == "sliced"
     roof = {"bound": "valu",
             "kernel": "ChunkIntegrateKernel" if sliced_launches else KERNEL,
             "achieved": min_gbps,
             "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": min_gbps / HBM_PEAK_GBS,
             "fused_minimum_bytes_per_launch": min_bytes,
+            "strict_minimum_bytes_per_launch": strict_bytes,
+            "frac_strict": (strict_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                            if k_ms > 0 else None),
+            "sliced_form": ("raw" if sliced_raw else "records")
+            if sliced_launches else None,
             "minimum_read_bytes_per_launch": min_read,
             "distinct_blocks_per_launch": prof["distinct_blocks"] / launches,
             "equivalent_gbps": achieved,
@@ -1272,9 +1435,16 @@ def main():
         "1.4 GB working set, where the counters are DRAM traffic. "
         "`read_overfetch` = counter reads / minimum reads. The binding roof "
         "is vector-ALU issue (`bound`: bit-exact float32 arithmetic per "
-        "voxel): `frac_valu` = `frac_bound` = SQ_ACTIVE_INST_VALU x 4 cycles "
-        "/ (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), measured under the "
-        "profiler. `avg_kernel_ms` is the HIP-event bracket of every 16th "
+        "voxel): `frac_valu` = `frac_bound` = SQ_INSTS_VALU x 3.5 cycles "
+        "(the integrate role's instruction mix priced with the MEASURED "
+        "issue cost of each class: 2.4 cycles plain float32 / integer, 4.3 "
+        "packed float32 / compare / select / convert, 8.3 reciprocal -- "
+        "profiles/r5b_valu_calibration.json, r5_valu_mix.txt) / (1024 SIMDs "
+        "x GRBM_GUI_ACTIVE / 8 XCDs), under the profiler; "
+        "`frac_valu_bounds` = the same at 2.4 and at 4.3 cycles for every "
+        "instruction. `frac_strict` = distinct blocks once in + out and the "
+        "raw images, WITHOUT the kernel's own prepared records, over the "
+        "same time and peak. `avg_kernel_ms` is the HIP-event bracket of every 16th "
         "launch: it contains the dispatch latency of the bracketed launch and "
         "the event pair's own cost (`empty_event_bracket_ms`), so it sits a "
         "few percent above rocprofv3's kernel duration.")
@@ -1297,8 +1467,8 @@ def main():
                 roof["frac_hbm"] = traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             if pmc.get("GRBM_GUI_ACTIVE") and pmc.get("SQ_ACTIVE_INST_VALU"):
                 cyc = pmc["GRBM_GUI_ACTIVE"] / N_XCD
-                roof["frac_valu"] = pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / \
-                    (N_SIMD * cyc)
+                roof["frac_valu"], roof["frac_valu_bounds"] = valu_fractions(
+                    pmc.get("SQ_INSTS_VALU"), cyc)
                 roof["frac_bound"] = roof["frac_valu"]
                 roof["valu_insts_per_launch"] = pmc.get("SQ_INSTS_VALU")
                 roof["kernel_cycles_profiled"] = cyc
@@ -1328,6 +1498,8 @@ def main():
         "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "cold_pass_frames_per_s": cold["frames_per_s"] if cold else None,
+        "drop_in": ({k: v for k, v in api_legs.items()
+                     if not k.endswith("what")} if api_legs else None),
         "config": {"workload": "configs[1]: the 1000-frame synthetic 640x480 "
                                "RGB-D stream (looped, %d frames per GPU in the "
                                "timed region) -> 8 mm VoxelBlockGrid(16^3), "
@@ -1356,8 +1528,10 @@ def main():
         "roofline": roof,
     }
     detail = {"roofline_note": roof_note, "cold_pass": cold,
-              "api": "integrate_frames, <= 1000 frames per call, argument "
-                     "blocks prepared once (prepare_frames)"}
+              "drop_in": api_legs,
+              "api": "integrate_frames, one call per step of %d frames, "
+                     "argument blocks prepared once (prepare_frames)"
+                     % a.batch}
     frames_cpu = None
     if e_world == 1 and not a.no_cpu_baseline:
         frames_cpu = [(depths[i].cpu().numpy(), colors[i].cpu().numpy())
@@ -1440,6 +1614,8 @@ def compact_line(out, secondary):
         "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
         "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
         "cold_pass_frames_per_s")}
+    if out.get("drop_in"):
+        line["drop_in"] = _r(out["drop_in"])
     sec = secondary or {}
     c0 = sec.get("configs0_icp_2x100k") or {}
     if c0:

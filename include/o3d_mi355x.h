@@ -47,7 +47,9 @@ typedef enum {
     O3DMI_ERR_NO_BLOCKS = 6,    /* "No block is touched in TSDF volume"    */
     O3DMI_ERR_UNSUPPORTED = 7,
     O3DMI_ERR_NO_INLIERS = 8,   /* "Invalid inlier_count value, must be > 0." */
-    O3DMI_ERR_INTERNAL = 9      /* a device-side consistency check failed  */
+    O3DMI_ERR_INTERNAL = 9,     /* a device-side consistency check failed  */
+    O3DMI_ERR_PEER = 10         /* another rank left a collective call with
+                                   an error (multi-GPU sliced block touch) */
 } o3dmi_status_t;
 
 typedef enum {

@@ -382,6 +382,8 @@ const char* o3dmi_status_string(int status) {
         case O3DMI_ERR_NO_INLIERS:
             return "Invalid inlier_count value, must be > 0.";
         case O3DMI_ERR_INTERNAL: return "device-side consistency check failed";
+        case O3DMI_ERR_PEER:
+            return "another rank left the collective call with an error";
         default: return "unknown status";
     }
 }

@@ -37,15 +37,7 @@ extern "C" int o3dmi_odometry_sums_post(
         float intensity_huber_delta, double* scratch_dev, double* sums29_dev,
         double* mail_data, int* mail_flag, int mail_seq, o3dmi_stream_t stream);
 
-extern "C" size_t o3dmi_odometry_gn_scratch_bytes(void);
-extern "C" int o3dmi_odometry_gauss_newton(
-        int method, int n_levels, const int* rows, const int* cols,
-        const float* const* maps11_per_level, const double* intrinsics_per_level,
-        const int* max_iterations, const double* relative_rmse,
-        const double* relative_fitness, const double* init_source_to_target,
-        float depth_outlier_trunc, float depth_huber_delta,
-        float intensity_huber_delta, void* scratch_dev, double* mail_data,
-        int* mail_flag, int mail_seq, o3dmi_stream_t stream);
+
 
 using namespace o3dmi;
 
@@ -144,22 +136,17 @@ extern "C" int o3dmi_rgbd_odometry_multiscale(
         }
     }
     const int n_scratch = o3dmi_odometry_sums_scratch_doubles();
-    const size_t gn_bytes = (o3dmi_odometry_gn_scratch_bytes() + 255) & ~(size_t)255;
     const size_t sums_bytes =
-            ((sizeof(double) * ((size_t)n_scratch + 32) + 255) & ~(size_t)255) +
-            gn_bytes;
+            (sizeof(double) * ((size_t)n_scratch + 32) + 255) & ~(size_t)255;
     Slab slab;
     int st = PoolAlloc((void**)&slab.base, total + sums_bytes + 256);
     if (st) return st;
     slab.size = total + sums_bytes + 256;
     // `drained`: the host has seen the mailbox of the call's last launch and
     // issued nothing since -- the stream is idle, and hipStreamSynchronize
-    // costs 16 us even then (registration.cpp SyncOnExit). Only valid when
-    // that last launch is a single-workgroup tail (the final-sum / posting
-    // launches of the host-driven loop): a mailbox word of the persistent
-    // multi-workgroup Gauss-Newton kernel does NOT mean the kernel has ended
-    // (other workgroups may still poll gn_scratch), so that path keeps the
-    // synchronisation.
+    // costs 16 us even then (registration.cpp SyncOnExit). Valid because that
+    // last launch is a single-workgroup tail (the final-sum / posting launch
+    // of the host-driven loop).
     struct SlabFree {
         hipStream_t s;
         void* p;
@@ -171,7 +158,6 @@ extern "C" int o3dmi_rgbd_odometry_multiscale(
     } slab_free{s, slab.base, false};
     double* scratch_dev = (double*)slab.base;
     double* sums_dev = scratch_dev + n_scratch;
-    void* gn_scratch = slab.base + (sums_bytes - gn_bytes);
     slab.used = (sums_bytes + 255) & ~(size_t)255;
 
     Mailbox* mb = ThreadMailbox();
@@ -291,81 +277,11 @@ extern "C" int o3dmi_rgbd_odometry_multiscale(
         for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
     double inlier_rmse = 0.0, fitness = 1.0;
     int iterations = 0;
-    // Persistent Gauss-Newton (O3DMI_PERSISTENT_GN=1): every iteration of every
-    // level in one launch (odometry.hip). Measured on MI355X it is on par with,
-    // not ahead of, the per-iteration driver below (an iteration is ~4 us of
-    // accumulation against ~6 us of 256-workgroup barrier, ~9 us of gathering
-    // the partial vectors and ~4 us of in-kernel solve; the host-driven
-    // iteration is ~19 us), so the simpler host-driven loop stays the default;
-    // it also takes over if the in-kernel exchange ever gives up.
-    static const bool host_gn = std::getenv("O3DMI_PERSISTENT_GN") == nullptr;
-    bool done = false;
-    if (!host_gn && n_levels <= 8) {
-        int lr[8], lc[8], lit[8];
-        double lK[8 * 9], lrr[8], lrf[8];
-        const float* lmaps[8 * 11];
-        for (int i = 0; i < n_levels; ++i) {
-            const Level& L = levels[(size_t)i];
-            lr[i] = L.rows;
-            lc[i] = L.cols;
-            lit[i] = criteria[i].max_iteration;
-            lrr[i] = criteria[i].relative_rmse;
-            lrf[i] = criteria[i].relative_fitness;
-            std::memcpy(lK + 9 * i, L.K, sizeof(L.K));
-            const float* m[11] = {L.source_depth,        L.target_depth,
-                                  L.source_intensity,    L.target_intensity,
-                                  L.target_depth_dx,     L.target_depth_dy,
-                                  L.target_intensity_dx, L.target_intensity_dy,
-                                  L.source_vertex,       L.target_vertex,
-                                  L.target_normal};
-            std::memcpy(lmaps + 11 * i, m, sizeof(m));
-        }
-        const int seq = ++mb->seq;
-        st = o3dmi_odometry_gauss_newton(
-                method, n_levels, lr, lc, lmaps, lK, lit, lrr, lrf, T,
-                depth_outlier_trunc, depth_huber_delta, intensity_huber_delta,
-                gn_scratch, mb->data, mb->flag, seq, stream);
-        if (st) return st;
-        if (MailboxWait(mb, seq, s) == hipSuccess) {
-            if (std::getenv("O3DMI_GN_STAMPS")) {
-                // debug: wall-clock (100 MHz) stamps of workgroup 0 per iteration
-                unsigned long long st64[64 * 6];
-                (void)hipStreamSynchronize(s);
-                (void)hipMemcpy(st64,
-                                (char*)gn_scratch + sizeof(unsigned long long) * 2 * 256 * 32 + 8 + 64,
-                                sizeof(st64), hipMemcpyDeviceToHost);
-                const int nit = (int)mb->data[18];
-                for (int e = 0; e < nit && e < 64; ++e)
-                    std::fprintf(stderr,
-                                 "[gn] it %2d  acc %5.2f  barrier %5.2f  gather "
-                                 "%5.2f  solve %5.2f us  (next start +%5.2f)\n",
-                                 e, (st64[e * 6 + 1] - st64[e * 6 + 0]) * 0.01,
-                                 (st64[e * 6 + 2] - st64[e * 6 + 1]) * 0.01,
-                                 (st64[e * 6 + 3] - st64[e * 6 + 2]) * 0.01,
-                                 (st64[e * 6 + 4] - st64[e * 6 + 3]) * 0.01,
-                                 e + 1 < nit ? (st64[(e + 1) * 6] - st64[e * 6 + 4]) * 0.01 : 0.0);
-            }
-            const int status = (int)mb->data[19];
-            if (status == 0) {
-                std::memcpy(T, mb->data, sizeof(T));
-                inlier_rmse = mb->data[16];
-                fitness = mb->data[17];
-                iterations = (int)mb->data[18];
-                done = true;
-            } else if (status == 1) {
-                SetLastError("Invalid inlier_count value, must be > 0.");
-                return O3DMI_ERR_NO_INLIERS;
-            } else if (status == 2) {
-                SetLastError(
-                        "Singular 6x6 linear system detected, tracking failed.");
-                return O3DMI_ERR_SINGULAR;
-            }
-            // status 3: exchange timed out -> per-iteration driver
-        } else {
-            (void)hipStreamSynchronize(s);
-        }
-    }
-    for (int i = 0; !done && i < n_levels; ++i) {
+    // (Round 1 also had ALL iterations of all levels in ONE persistent launch
+    // with an in-kernel all-to-all of the partial sums and an in-kernel solve:
+    // 23 us per iteration against 19 us for this host-driven loop. Dropped;
+    // docs/rounds.md.)
+    for (int i = 0; i < n_levels; ++i) {
         const Level& L = levels[(size_t)i];
         for (int iter = 0; iter < criteria[i].max_iteration; ++iter) {
             const float* maps[11] = {

@@ -83,18 +83,6 @@ extern "C" int o3dmi_internal_icp_transform_search_accumulate(
         int robust_kernel, double scaling_parameter, double shape_parameter,
         int64_t* corr_out_dev, double* sums32_dev, double* mail_data,
         int* mail_flag, int mail_seq, o3dmi_stream_t stream);
-extern "C" int o3dmi_internal_icp_search_solve(
-        const o3dmi_nns_t* nns, void* src_dev, const double* transformation,
-        int xf_from_device, int64_t n, int robust_kernel,
-        double scaling_parameter, double shape_parameter,
-        int64_t* corr_out_dev, void* state_dev, double* mail_data,
-        int* mail_flag, int mail_seq, o3dmi_stream_t stream);
-extern "C" int o3dmi_internal_icp_search_gated(
-        const o3dmi_nns_t* nns, void* src_dev, const double* transformation,
-        const int* inbox, int gate_seq, int64_t n, int robust_kernel,
-        double scaling_parameter, double shape_parameter,
-        int64_t* corr_out_dev, double* mail_data, int* mail_flag, int mail_seq,
-        o3dmi_stream_t stream);
 extern "C" int o3dmi_internal_sums_tail(double* sums32_dev, double t29,
                                         double t30, double t31,
                                         o3dmi_stream_t stream);
@@ -351,30 +339,6 @@ hipEvent_t SideEvent() {
         hipEventCreateWithFlags(&ev[d], hipEventDisableTiming) != hipSuccess)
         ev[d] = nullptr;
     return ev[d];
-}
-
-// Device state of the in-launch Gauss-Newton step (icp.hip GnTail): the 4x4
-// update the last launch left for the next one + 9 ticket words, which every
-// launch returns to zero. One per host thread and device, zeroed when
-// allocated and again after a call that ended with launches unaccounted for.
-struct GnState {
-    void* dev = nullptr;
-    bool clean = false;
-};
-GnState* ThreadGnState(hipStream_t s) {
-    static thread_local GnState st[kMaxDevices];
-    const int d = CurrentDevice();
-    if (d < 0) return nullptr;
-    GnState& g = st[d];
-    if (!g.dev && hipMalloc(&g.dev, 256) != hipSuccess) {
-        g.dev = nullptr;
-        return nullptr;
-    }
-    if (!g.clean) {
-        if (hipMemsetAsync(g.dev, 0, 256, s) != hipSuccess) return nullptr;
-        g.clean = true;
-    }
-    return &g;
 }
 
 // `completed`: set by the owner once every kernel that used the index is
@@ -702,9 +666,8 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         return O3DMI_OK;
     };
     // Two streams unless there is nothing to overlap (a single level without
-    // down-sampling is two copies) or O3DMI_SERIAL_PYRAMID asks for one.
-    const bool overlap = (num_scales > 1 || voxel_sizes[last] > 0) &&
-                         std::getenv("O3DMI_SERIAL_PYRAMID") == nullptr;
+    // down-sampling is two copies).
+    const bool overlap = num_scales > 1 || voxel_sizes[last] > 0;
     hipStream_t side = s;
     hipEvent_t ev = nullptr;
     if (overlap) {
@@ -752,23 +715,6 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                          dtype, max_dists[0], (o3dmi_stream_t)s,
                          &guards[0].nns)))
                 return st;
-        }
-        // O3DMI_ICP_EAGER_INDEX=1: all indices up front (A / B)
-        static const bool eager = std::getenv("O3DMI_ICP_EAGER_INDEX") != nullptr;
-        if (eager) {
-            for (int k = 1; k < num_scales; ++k) {
-                const Level& Lk = pyr[(size_t)k];
-                if ((st = o3dmi_internal_nns_create_with_normals(
-                             Lk.tgt_ptr, p2plane ? Lk.nrm_ptr : nullptr, Lk.nt,
-                             dtype, max_dists[k], (o3dmi_stream_t)side,
-                             &guards[(size_t)k].nns)))
-                    return st;
-            }
-            next_index = num_scales;
-            if (overlap && num_scales > 1) {
-                O3DMI_HIP_CHECK(hipEventRecord(ev, side));
-                indices_on_side = true;
-            }
         }
     }
 
@@ -943,47 +889,12 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         return O3DMI_OK;
     };
 
-    // O3DMI_ICP_DEVICE_SOLVE=1: point-to-plane iterations as ONE launch each
-    // (final sum + 6x6 solve + update in the last workgroup of the search
-    // launch, the host one launch ahead -- the `fast` branch below). Built and
-    // measured in round 3, bit-compatible with the default (same sums, pose
-    // equal to 1e-17), and NOT faster: the in-launch tail -- two ticket
-    // atomics, a write-through row gather, the wave solve, the system-scope
-    // post -- adds 8 - 10 us to every search launch (rocprofv3: 30.9 / 19.0 /
-    // 17.0 us against 20.8 / 10.5 / 9.4 at G = 8 / 16 / 32), which is what the
-    // separate final-sum launch (6.2 us + 1.5 us boundary) and the host hop
-    // cost together; 1010 - 1055 against 1050 - 1067 frames/s in
-    // examples/icp_slam at 640x480. Device-wide visibility inside a launch
-    // stays dearer than a second small launch on this part.
-    const char* dev_solve_env = std::getenv("O3DMI_ICP_DEVICE_SOLVE");
-    const bool host_solve = !(dev_solve_env && dev_solve_env[0] == '1');
-    MailRing* ring = nullptr;
-    GnState* gn = nullptr;
-    bool fast = p2plane && !dev_reduce && !allreduce && !host_solve;
-    if (fast) {
-        ring = ThreadMailRing();
-        gn = ThreadGnState(s);
-        fast = ring != nullptr && gn != nullptr;
-    }
-    // O3DMI_ICP_GATE=1: host solve with the NEXT search launch queued ahead
-    // and gated on a host-mapped inbox (the `gated` branch below; icp.hip
-    // XfGate) -- the reading of "issue iteration k + 1 speculatively while
-    // the host solves" that needs no solve on the device. Built and measured
-    // in round 3: results identical to the plain loop, and far SLOWER -- every
-    // workgroup of the waiting launch polls host memory over PCIe, and 256 -
-    // 512 pollers turn the ~2 us the answer needs into tens: 500 - 730
-    // frames/s against 1115 - 1145 at 640x480, 450 - 610 against 975 - 990 at
-    // 1280x720. A hierarchy of pollers (8 on the host word, the rest on device
-    // flags) would cost about what the launch it saves costs. Opt-in only.
-    const char* gate_env = std::getenv("O3DMI_ICP_GATE");
-    GateInbox* inbox = nullptr;
-    bool gated = p2plane && !dev_reduce && !allreduce && !fast &&
-                 gate_env && gate_env[0] == '1';
-    if (gated) {
-        ring = ThreadMailRing();
-        inbox = ThreadGateInbox();
-        gated = ring != nullptr && inbox != nullptr;
-    }
+    // (Rounds 3-4 carried two more forms of the point-to-plane loop, both
+    // bit-compatible and both measured slower -- the 6x6 solve in the search
+    // launch's last workgroup with the host one launch ahead, and a next
+    // launch queued ahead and gated on a host inbox: docs/rounds.md. What
+    // stayed of them is the final sum in the search launch's last workgroup,
+    // icp.hip SumTail.)
     for (int scale_idx = 0; scale_idx < num_scales; ++scale_idx) {
         Level& full_level = pyr[(size_t)scale_idx];
         struct ScaleView : SourceView {
@@ -1030,246 +941,6 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                          scale_idx, (long long)L.ns, (long long)L.nt,
                          t - t_mark);
             t_mark = t;
-        }
-        if (gated) {
-            // Point-to-plane on one GPU, solve on the host, the NEXT search
-            // launch queued before this one's sums are read: it is dispatched
-            // the moment the final-sum launch ends and polls the thread's
-            // inbox until the host publishes the update it has to move the
-            // source by (icp.hip XfGate). The host's launch call and the
-            // dispatch latency leave the critical path of an iteration; when
-            // the scale ends the queued launch is either the evaluation of
-            // the result (last scale: Registration.cpp:424-431) or cancelled.
-            const o3dmi_icp_criteria_t& crit = criterias[scale_idx];
-            const bool last_scale = scale_idx == num_scales - 1;
-            int64_t* corr_out = last_scale ? correspondences_dev : nullptr;
-            has_pending = false;
-            guard.completed = false;
-            struct PendingGate {
-                GateInbox* ib;
-                int seq = 0;
-                ~PendingGate() {
-                    if (seq) ib->Cancel(seq);  // never leave a launch polling
-                }
-            } pending_gate{inbox};
-            auto launch = [&](const double* xf_host, int gate_seq,
-                              int* seq_out) -> int {
-                const int seq = ++ring->seq;
-                *seq_out = seq;
-                return o3dmi_internal_icp_search_gated(
-                        guard.nns, L.src, xf_host,
-                        xf_host ? nullptr : inbox->words, gate_seq, L.ns,
-                        robust_kernel, scaling_parameter, shape_parameter,
-                        corr_out, ring->Data(seq), ring->Flag(seq), seq,
-                        stream);
-            };
-            auto read = [&](int seq, SearchResult& r) -> int {
-                O3DMI_HIP_CHECK(MailRingWait(ring, seq, s));
-                std::memcpy(r.sums, ring->Data(seq), sizeof(double) * 32);
-                r.sums[31] = (double)L.ns;
-                const double num = r.sums[30];
-                if (num != 0) {
-                    r.fitness = num / r.sums[31];
-                    r.inlier_rmse = std::sqrt(r.sums[29] / num);
-                } else {
-                    r.fitness = 0;
-                    r.inlier_rmse = 0;
-                }
-                return O3DMI_OK;
-            };
-            int seq_cur = 0, seq_next = 0;
-            if ((st = launch(T, 0, &seq_cur))) return st;
-            double prev_fitness = fitness, prev_inlier_rmse = inlier_rmse;
-            converged = false;
-            bool evaluation_queued = false;
-            int it = 0;
-            for (it = 0; it < crit.max_iteration; ++it) {
-                const int g = ++inbox->seq;
-                pending_gate.seq = g;
-                if ((st = launch(nullptr, g, &seq_next))) return st;
-                SearchResult r;
-                if ((st = read(seq_cur, r))) return st;
-                seq_cur = seq_next;
-                fitness = r.fitness;
-                inlier_rmse = r.inlier_rmse;
-                converged = false;
-                if (r.sums[30] == 0) Eye4(T);  // Registration.cpp:56-58
-                if (fitness <= std::numeric_limits<double>::min()) {
-                    inbox->Cancel(g);
-                    pending_gate.seq = 0;
-                    break;
-                }
-                double pose[6], update[16];
-                float residual;
-                int inlier_count;
-                int e = o3dmi_decode_and_solve6x6(r.sums, pose, &residual,
-                                                  &inlier_count);
-                if (e) status = e;  // reference throws; report after the loop
-                o3dmi_pose_to_transformation(pose, update);
-                Matmul4(update, T, T);
-                const bool stop =
-                        it != 0 &&
-                        std::abs(prev_fitness - fitness) <
-                                crit.relative_fitness &&
-                        std::abs(prev_inlier_rmse - inlier_rmse) <
-                                crit.relative_rmse;
-                const bool more = !stop && it + 1 < crit.max_iteration;
-                if (more || last_scale) {
-                    // the next iteration, or the evaluation of the result
-                    inbox->Release(g, update);
-                    evaluation_queued = !more;
-                } else {
-                    inbox->Cancel(g);
-                }
-                pending_gate.seq = 0;
-                if (callback)
-                    callback(iteration_count + it, scale_idx, it, inlier_rmse,
-                             fitness, T, callback_user);
-                if (stop) {
-                    converged = true;
-                    break;
-                }
-                prev_fitness = fitness;
-                prev_inlier_rmse = inlier_rmse;
-            }
-            iteration_count += it;
-            exit_timer.Mark("scale");
-            if (timing) {
-                (void)hipStreamSynchronize(s);
-                const double t = now();
-                std::fprintf(stderr,
-                             "[o3dmi] icp: scale %d %d iterations %.0f us\n",
-                             scale_idx, it, t - t_mark);
-                t_mark = t;
-            }
-            if (last_scale &&
-                (evaluation_queued || crit.max_iteration <= 0)) {
-                const bool preserved = converged;
-                SearchResult r;
-                if ((st = read(seq_cur, r))) return st;
-                fitness = r.fitness;
-                inlier_rmse = r.inlier_rmse;
-                if (r.sums[30] == 0) Eye4(T);
-                converged = preserved;
-                // the newest launch of the stream has posted: every earlier
-                // one (the cancelled launches of the coarser scales too) is
-                // done with its index
-                for (NnsGuard& gd : guards) gd.completed = true;
-            }
-            if (fitness <= std::numeric_limits<double>::min()) {
-                converged = false;
-                break;
-            }
-            continue;
-        }
-        if (fast) {
-            // Point-to-plane on one GPU: an iteration is ONE launch (search +
-            // accumulate + final sum + 6x6 solve + update in its last
-            // workgroup, icp.hip GnTail) and the host runs one launch AHEAD:
-            // launch k + 1 -- which moves the source by the update launch k
-            // left on the device -- is queued before launch k's sums are
-            // read. When the scale ends at iteration k (converged, out of
-            // iterations, no correspondences) launch k + 1 is in flight
-            // already: it is the evaluation of the result at this scale, i.e.
-            // what the reference runs after the last scale (Registration.cpp:
-            // 424-431), and is simply not read at the other scales.
-            const o3dmi_icp_criteria_t& crit = criterias[scale_idx];
-            const bool last_scale = scale_idx == num_scales - 1;
-            int64_t* corr_out = last_scale ? correspondences_dev : nullptr;
-            has_pending = false;
-            guard.completed = false;
-            auto launch = [&](const double* xf_host, int* seq_out) -> int {
-                const int seq = ++ring->seq;
-                *seq_out = seq;
-                return o3dmi_internal_icp_search_solve(
-                        guard.nns, L.src, xf_host, xf_host ? 0 : 1, L.ns,
-                        robust_kernel, scaling_parameter, shape_parameter,
-                        corr_out, gn->dev, ring->Data(seq), ring->Flag(seq),
-                        seq, stream);
-            };
-            auto read = [&](int seq, SearchResult& r, double* update,
-                            int* solve_status) -> int {
-                O3DMI_HIP_CHECK(MailRingWait(ring, seq, s));
-                const double* d = ring->Data(seq);
-                std::memcpy(r.sums, d, sizeof(double) * 32);
-                if (update) std::memcpy(update, d + 32, sizeof(double) * 16);
-                if (solve_status) *solve_status = (int)d[48];
-                const double num = r.sums[30];
-                if (num != 0) {
-                    r.fitness = num / r.sums[31];
-                    r.inlier_rmse = std::sqrt(r.sums[29] / num);
-                } else {
-                    r.fitness = 0;
-                    r.inlier_rmse = 0;
-                }
-                return O3DMI_OK;
-            };
-            gn->clean = false;  // launches in flight from here on
-            int seq_cur = 0, seq_next = 0;
-            if ((st = launch(T, &seq_cur))) return st;
-            double prev_fitness = fitness, prev_inlier_rmse = inlier_rmse;
-            converged = false;
-            int it = 0;
-            for (it = 0; it < crit.max_iteration; ++it) {
-                if ((st = launch(nullptr, &seq_next))) return st;
-                SearchResult r;
-                double update[16];
-                int solve_status = 0;
-                if ((st = read(seq_cur, r, update, &solve_status))) return st;
-                seq_cur = seq_next;
-                fitness = r.fitness;
-                inlier_rmse = r.inlier_rmse;
-                converged = false;
-                if (r.sums[30] == 0) Eye4(T);  // Registration.cpp:56-58
-                if (fitness <= std::numeric_limits<double>::min()) break;
-                if (solve_status != 0) {
-                    // the reference throws; reported after the loop. The
-                    // device applied the identity in this case.
-                    SetLastError("Singular 6x6 linear system detected, "
-                                 "tracking failed.");
-                    status = O3DMI_ERR_SINGULAR;
-                }
-                Matmul4(update, T, T);
-                if (callback)
-                    callback(iteration_count + it, scale_idx, it, inlier_rmse,
-                             fitness, T, callback_user);
-                if (it != 0 &&
-                    std::abs(prev_fitness - fitness) < crit.relative_fitness &&
-                    std::abs(prev_inlier_rmse - inlier_rmse) <
-                            crit.relative_rmse) {
-                    converged = true;
-                    break;
-                }
-                prev_fitness = fitness;
-                prev_inlier_rmse = inlier_rmse;
-            }
-            iteration_count += it;
-            exit_timer.Mark("scale");
-            if (timing) {
-                (void)hipStreamSynchronize(s);
-                const double t = now();
-                std::fprintf(stderr,
-                             "[o3dmi] icp: scale %d %d iterations %.0f us\n",
-                             scale_idx, it, t - t_mark);
-                t_mark = t;
-            }
-            if (last_scale) {
-                // the launch in flight is the evaluation at the result
-                const bool preserved = converged;
-                SearchResult r;
-                if ((st = read(seq_cur, r, nullptr, nullptr))) return st;
-                fitness = r.fitness;
-                inlier_rmse = r.inlier_rmse;
-                if (r.sums[30] == 0) Eye4(T);
-                converged = preserved;
-                guard.completed = true;  // nothing of this call is in flight
-                gn->clean = true;
-            }
-            if (fitness <= std::numeric_limits<double>::min()) {
-                converged = false;
-                break;
-            }
-            continue;
         }
         // DoSingleScaleICPIterations :275-360
         double prev_fitness = fitness, prev_inlier_rmse = inlier_rmse;

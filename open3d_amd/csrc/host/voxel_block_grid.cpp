@@ -130,6 +130,7 @@ struct o3dmi_vbg {
         // kChunkFrames images of (pixels + 1) records
         PixelRec* chunk_recs[2] = {nullptr, nullptr};
         int64_t chunk_recs_pixels = 0;
+        int chunk_recs_frames = 0;  // frames each set holds
         int64_t chunks_done = 0;  // statistics (o3dmi_vbg_sliced_stats)
         int64_t reapplied = 0;
     } sliced;
@@ -1149,10 +1150,7 @@ static int StreamIntegrate(o3dmi_vbg* g, const StreamCommon& c0,
                                   c.frame_new * kMaxGroup)))
         return st;
 
-    static const bool no_tables = std::getenv("O3DMI_NO_PREP_TABLES") != nullptr;
-    if (no_tables) {
-        g->prep_valid = false;
-    } else if ((st = EnsurePrepTables(g, c.depth_intrinsic, c.color_intrinsic,
+    if ((st = EnsurePrepTables(g, c.depth_intrinsic, c.color_intrinsic,
                                       c.depth_rows, c.depth_cols,
                                       c.color_rows, c.color_cols,
                                       c.depth_scale, s))) {
@@ -1258,8 +1256,27 @@ static int StreamIntegrate(o3dmi_vbg* g, const StreamCommon& c0,
         for (const Pending& pg : pending)
             if (pg.stamp == overflow) replay_from = pg.f0;
         if (replay_from < 0) {
+            // An overflow stamp of a group this call issued on the STRICT
+            // bound (or a one-frame call): a probe wrap recorded as an
+            // overflow (touch_device.h). Nothing to replay from -- but the map
+            // must not stay in the "overflow not recovered" state, in which
+            // every later size / export / reserve call is refused: recover
+            // the slots, rebuild the crowded table, then report.
+            (void)hipStreamSynchronize(s);
+            int64_t w = 0;
+            (void)RecoverOverflow(g->block_hashmap, s, &w);
+            (void)hipMemsetAsync(g->ring_counters, 0, sizeof(int) * 4, s);
+            (void)hipMemsetAsync(g->front_tickets, 0, sizeof(int) * 32, s);
+            const int64_t cap = o3dmi_hash_capacity(g->block_hashmap);
+            (void)o3dmi_hash_reserve(g->block_hashmap, w > cap ? w : cap,
+                                     (o3dmi_stream_t)s);
+            (void)hipStreamSynchronize(s);
+            g->stream_overflow = 0;
+            g->known_valid = false;
             SetLastError("frame stream: overflow reported for a group this "
-                         "call did not issue on an estimate");
+                         "call did not issue on an estimate (hash table probe "
+                         "sequence wrapped); the map was recovered, the "
+                         "call's remaining frames were not integrated");
             return O3DMI_ERR_INTERNAL;
         }
         int64_t wanted = 0;
@@ -1329,6 +1346,7 @@ static int EnsureSliced(o3dmi_vbg* g, int world, int capacity, int slots,
     const int keep_recv_slots = z.recv_slots;
     PixelRec* keep_recs[2] = {z.chunk_recs[0], z.chunk_recs[1]};
     const int64_t keep_px = z.chunk_recs_pixels;
+    const int keep_recs_frames = z.chunk_recs_frames;
     z.frames_dev = nullptr;
     z.iframes_dev = nullptr;
     z.chunk_recs[0] = z.chunk_recs[1] = nullptr;
@@ -1339,6 +1357,7 @@ static int EnsureSliced(o3dmi_vbg* g, int world, int capacity, int slots,
     z.chunk_recs[0] = keep_recs[0];
     z.chunk_recs[1] = keep_recs[1];
     z.chunk_recs_pixels = keep_px;
+    z.chunk_recs_frames = keep_recs_frames;
     z.chunks_done = keep_chunks;
     z.reapplied = keep_re;
     O3DMI_HIP_CHECK(hipStreamCreateWithFlags(&z.side, hipStreamNonBlocking));
@@ -1462,14 +1481,24 @@ static int WaitChunkStatus(o3dmi_vbg* g, int stamp, hipStream_t side,
     }
 }
 
+// How far a call of the sliced path got with its collectives: what an error
+// exit needs to leave the other ranks in step (StreamIntegrateSliced).
+struct SlicedProgress {
+    int n_chunks = 0;
+    int first_gathers = 0;  // chunks whose FIRST all-gather was issued (the
+                            // redo of a chunk is collective by construction:
+                            // every rank reads the same gathered headers)
+};
+
 // The frames of one call through the sliced path. `gathered_in`: per chunk the
 // `world` wire segments of all ranks (emulation / tests: the stand-in for the
 // all-gather; the own segment is replaced by the one computed here), or null:
 // all-gather over `comm`.
-static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
-                                 const StreamFrame* frames, int n, int group,
-                                 hipStream_t s, o3dmi_comm* comm,
-                                 const void* const* gathered_in) {
+static int StreamIntegrateSlicedBody(o3dmi_vbg* g, const StreamCommon& c0,
+                                     const StreamFrame* frames, int n,
+                                     int group, hipStream_t s, o3dmi_comm* comm,
+                                     const void* const* gathered_in,
+                                     SlicedProgress* progress) {
     StreamCommon c = c0;
     if (group < 1) group = 1;
     if (group > kMaxGroup) group = kMaxGroup;
@@ -1531,28 +1560,41 @@ static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
     const bool raw_form = raw_env ? raw_env[0] == '1'
                                   : (world >= 4 && (!c.with_color ||
                                                     g->prep_identity));
-    // O3DMI_SLICED_PIPE=1: the chunk launch's software-pipelined form (next
-    // round's gathers in flight during this round's arithmetic, 2-frame
-    // rounds). Measured at 4 and 8 emulated ranks, raw and records form
-    // (profiles/r4p, and again with the sorted work list, r4zc): no
-    // difference (492 k against 495 k frames/s at 8); 8-frame rounds at four
-    // waves per SIMD: +1 % at 8, -9 % at 4 (r4zg). Neither more loads in
-    // flight per wave nor more waves move it; fewer cache lines per gather
-    // (the compact lane map) does, +8 %. Kept as a switch, off.
-    const char* pipe_env = std::getenv("O3DMI_SLICED_PIPE");
-    const bool pipe_form = pipe_env && pipe_env[0] == '1';
+    // (A software-pipelined form of the chunk launch -- next round's gathers
+    // in flight during this round's arithmetic -- made no difference at 4 and
+    // 8 emulated ranks, profiles/r4p, r4zc: dropped.)
     const int chunk_frames = kChunkGroups * group;
     const int64_t px = (int64_t)c.depth_rows * c.depth_cols;
-    if (!raw_form && z.chunk_recs_pixels < px) {
+    // The records form keeps two sets of prepared records, sized by what the
+    // call needs (a chunk of this call's frames -- not the 256-frame maximum:
+    // 0.6 GB per set at VGA); a call that takes the raw form gives them back.
+    const int recs_frames = n < chunk_frames ? n : chunk_frames;
+    if (raw_form && z.chunk_recs[0]) {
         O3DMI_HIP_CHECK(hipDeviceSynchronize());
         for (int i = 0; i < 2; ++i) {
             (void)hipFree(z.chunk_recs[i]);
             z.chunk_recs[i] = nullptr;
-            O3DMI_HIP_CHECK(hipMalloc((void**)&z.chunk_recs[i],
-                                      sizeof(PixelRec) * (size_t)(px + 1) *
-                                              (size_t)kChunkFrames));
         }
-        z.chunk_recs_pixels = px;
+        z.chunk_recs_pixels = 0;
+        z.chunk_recs_frames = 0;
+    }
+    if (!raw_form &&
+        (z.chunk_recs_pixels < px || z.chunk_recs_frames < recs_frames)) {
+        O3DMI_HIP_CHECK(hipDeviceSynchronize());
+        const int64_t new_px = z.chunk_recs_pixels > px ? z.chunk_recs_pixels
+                                                        : px;
+        const int new_fr = z.chunk_recs_frames > recs_frames
+                                   ? z.chunk_recs_frames
+                                   : recs_frames;
+        for (int i = 0; i < 2; ++i) {
+            (void)hipFree(z.chunk_recs[i]);
+            z.chunk_recs[i] = nullptr;
+            O3DMI_HIP_CHECK(hipMalloc((void**)&z.chunk_recs[i],
+                                      sizeof(PixelRec) * (size_t)(new_px + 1) *
+                                              (size_t)new_fr));
+        }
+        z.chunk_recs_pixels = new_px;
+        z.chunk_recs_frames = new_fr;
     }
     // every launch of the previous call that reads the frame tables is over
     // once its last integrate launch is (the side stream waited for it)
@@ -1567,6 +1609,7 @@ static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
 
     const int n_chunks = (n + chunk_frames - 1) / chunk_frames;
     std::vector<int> chunk_stamp((size_t)n_chunks, 0);
+    progress->n_chunks = n_chunks;
 
     // The prepare pass of a chunk's frames (front roles without the block
     // touch), kMaxGroup frames per launch, into the chunk set's records.
@@ -1635,6 +1678,8 @@ static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
                 if ((st2 = comm->Allgather(z.send_seg[set], z.gathered[set],
                                            seg, z.side)))
                     return st2;
+                if (ci >= progress->first_gathers)
+                    progress->first_gathers = ci + 1;
             } else {
                 if (gathered_in && world > 1)
                     O3DMI_HIP_CHECK(hipMemcpyAsync(
@@ -1675,6 +1720,15 @@ static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
             if ((st = WaitChunkStatus(g, chunk_stamp[(size_t)ci], z.side, &cs)))
                 return st;
             if (cs.overflow == 0) break;
+            if (cs.overflow == -3) {
+                // a rank left the call with an error and said so in its wire
+                // segment: every rank leaves at this chunk, in step (none has
+                // a collective outstanding)
+                O3DMI_HIP_CHECK(hipDeviceSynchronize());
+                SetLastError("sliced touch: another rank left the call with an "
+                             "error");
+                return O3DMI_ERR_PEER;
+            }
             O3DMI_REQUIRE(attempt < 24, "sliced touch: cannot make room");
             O3DMI_HIP_CHECK(hipDeviceSynchronize());
             z.reapplied += 1;
@@ -1763,7 +1817,6 @@ static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
         ia.depth_scale = c.depth_scale;
         ia.depth_div_short = g->prep_div_short;
         ia.raw = raw_form;
-        ia.pipelined = pipe_form;
         ia.size_host = (int*)g->stream_status;
         ia.status_stamp = g->frame_stamp;
         ia.prof_count = prof ? g->prof_counts + g->prof_max + g->prof_frames
@@ -1790,6 +1843,53 @@ static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
     g->stream_overflow = 0;
     g->last_path = 0;
     return O3DMI_OK;
+}
+
+// o3dmi_vbg_integrate_frames on a grid with block ownership and a communicator
+// is a COLLECTIVE call (one all-gather per chunk of frames). A rank that has to
+// leave it with an error of its own (no room after 24 attempts, an allocation
+// that failed, a deferred device-side flag) would leave the others waiting in
+// the next all-gather: it delivers that one all-gather with an empty segment
+// flagged kSliceFlagAbort first, and every rank returns O3DMI_ERR_PEER at the
+// same chunk. The map is left usable (a dropped chunk's slots are recovered,
+// the stream's overflow state cleared). Best effort after a HIP runtime error:
+// the abort segment is then issued on a device that may not execute it.
+static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
+                                 const StreamFrame* frames, int n, int group,
+                                 hipStream_t s, o3dmi_comm* comm,
+                                 const void* const* gathered_in) {
+    SlicedProgress pr;
+    const int st = StreamIntegrateSlicedBody(g, c0, frames, n, group, s, comm,
+                                             gathered_in, &pr);
+    if (st == O3DMI_OK) return st;
+    const std::string why = o3dmi_last_error();
+    o3dmi_vbg::Sliced& z = g->sliced;
+    if (st != O3DMI_ERR_PEER && comm && z.side && pr.n_chunks > 0 &&
+        pr.first_gathers > 0 && pr.first_gathers < pr.n_chunks) {
+        // the all-gather the other ranks will wait in next
+        const int set = pr.first_gathers & 1;
+        SliceHeader hd = {};
+        hd.count = 0;
+        hd.flags = kSliceFlagAbort;
+        hd.capacity = z.capacity;
+        if (hipMemcpyAsync(z.send_seg[set], &hd, sizeof(hd),
+                           hipMemcpyHostToDevice, z.side) == hipSuccess &&
+            hipStreamSynchronize(z.side) == hipSuccess)
+            (void)comm->Allgather(z.send_seg[set], z.gathered[set],
+                                  SliceSegmentBytes(z.capacity), z.side);
+    }
+    (void)hipDeviceSynchronize();
+    // leave the map usable: a chunk dropped for lack of buffer indices left
+    // keys without a block behind (CheckDeferred would refuse every later
+    // size / export call)
+    int64_t wanted = 0;
+    (void)RecoverOverflow(g->block_hashmap, s, &wanted);
+    (void)hipStreamSynchronize(s);
+    g->stream_overflow = 0;
+    g->known_valid = false;
+    g->last_path = 0;
+    SetLastError(why.c_str());
+    return st;
 }
 
 static StreamCommon MakeCommon(int depth_rows, int depth_cols, int color_rows,
@@ -1879,13 +1979,11 @@ int o3dmi_vbg_integrate_frames(o3dmi_vbg_t* g, int n_frames,
             (!color_intrinsic ||
              std::memcmp(color_intrinsic, depth_intrinsic,
                          sizeof(double) * 9) == 0 || !color_devs)) {
-            const char* e = std::getenv("O3DMI_STEP_VARIANT");
-            if (!e || e[0] == '2')
-                return StreamIntegrateSliced(
-                        g, c, frames.data(), n_frames,
-                        frames_per_launch <= 0 ? kDefaultGroup
-                                               : frames_per_launch,
-                        (hipStream_t)stream, comm, nullptr);
+            return StreamIntegrateSliced(
+                    g, c, frames.data(), n_frames,
+                    frames_per_launch <= 0 ? kDefaultGroup
+                                           : frames_per_launch,
+                    (hipStream_t)stream, comm, nullptr);
         }
     }
     return StreamIntegrate(g, c, frames.data(), n_frames,

@@ -30,7 +30,6 @@
 #include <cstring>
 
 #include "nns.h"
-#include "gn_device.h"
 #include "mailbox.h"
 #include "reduce_sums.h"
 
@@ -518,12 +517,10 @@ struct OwnedSums {
     __device__ __forceinline__ Ref operator[](int i) { return Ref{*this, i}; }
 };
 
-// ---- the Gauss-Newton step inside the search launch ----------------------------
-// What used to follow every point-to-plane search launch -- a one-workgroup
-// final-sum launch, a PCIe post, the host's 6x6 solve and the host's next
-// launch carrying the update -- is done by the LAST workgroup of the search
-// launch itself, so the driver can queue iteration k + 1 before it has seen
-// iteration k (host/registration.cpp):
+// ---- the final sum inside the search launch -----------------------------------
+// What used to follow every search launch -- a one-workgroup final-sum launch
+// (6.2 us + the launch boundary, 14 times per tracking frame) -- is done by the
+// LAST workgroup of the search launch itself:
 //   * every workgroup writes its row of partial sums with write-through
 //     (sc1) stores, drains them (s_waitcnt vmcnt(0)) and takes a ticket; the
 //     tickets are two-level, one counter per XCD class (blockIdx % 8) and one
@@ -531,41 +528,23 @@ struct OwnedSums {
 //     serialises them at ~12 ns each);
 //   * the last arriver reads all rows with sc1 loads (valid without an acquire
 //     fence because the producers stored sc1), adds them in FinalSumKernel's
-//     order (bit-identical sums), solves the 6x6 system with one wave
-//     (gn_device.h: the host routine's arithmetic, entry by entry), forms the
-//     update transformation, leaves it in device memory for the next launch
-//     (apply_xf == 2 reads it from there) and posts sums + update + status to
-//     the host mailbox ring.
+//     order (bit-identical sums) and posts them to the host mailbox (and / or
+//     a device buffer).
 // No agent-scope release fence anywhere: on this part it writes back the
 // XCD's whole L2 (the moved source points of the launch are dirty in it) and
 // costs more than the launch it would save -- measured in round 1.
+// (Rounds 3-4 also solved the 6x6 system and formed the update in that last
+// workgroup, the host one launch ahead: +8-10 us per search launch, what the
+// host hop it removed cost -- and a variant whose NEXT launch was queued ahead
+// and polled a host inbox: 2x slower. Both dropped; docs/rounds.md.)
 constexpr int kTailRows = 256;  // workgroups of a launch that carries a tail
-struct GnTail {
-    int* tickets;          // [9] zero between launches; NULL = no tail
-    const double* xf_in;   // apply_xf == 2: the 4x4 to move the source by,
-                           // 16 float64 followed by the same as 16 float32
-    double* xf_out;        // receives this iteration's update (may == xf_in)
-    double* mail_data;     // host-mapped [kMailDoubles]
+struct SumTail {
+    int* tickets;      // [9] zero between launches; NULL = no tail
+    double* out;       // device [32] or NULL
+    double* mail_data; // host-mapped [32] or NULL
     int* mail_flag;
     int mail_seq;
-    double n_source;       // sums[31]
 };
-
-// A search launch queued AHEAD of the host: it is dispatched the moment its
-// predecessor ends, every workgroup then polls a host-mapped word until the
-// host -- which meanwhile reads the predecessor's sums and solves the 6x6
-// system -- publishes this launch's sequence number together with the
-// transformation to move the source by (or a cancel mark, when the scale
-// ended). What leaves the critical path of a Gauss-Newton iteration is the
-// host's launch call and the dispatch latency (~5 us of an ~8 us hop).
-// inbox (host-mapped, 256 B): int seq; int cancel_seq; ... 16 float32 at byte
-// 64; 16 float64 at byte 128. The spin is bounded: a host that never answers
-// (it died) makes the launch leave after ~100 ms instead of hanging the GPU.
-struct XfGate {
-    const int* inbox;  // NULL: no gate
-    int seq;
-};
-constexpr int kGateSpinLimit = 1 << 16;
 
 __device__ __forceinline__ double LoadSc1(const double* p) {
     return __longlong_as_double((long long)__hip_atomic_load(
@@ -600,13 +579,10 @@ __device__ __forceinline__ bool LastWorkgroup(int* tickets) {
 }
 
 // Executed by all kSearchBlock threads of the last workgroup.
-__device__ __forceinline__ void GaussNewtonTail(const double* partials,
-                                                int n_rows, const GnTail& tl) {
+__device__ __forceinline__ void RowSumTail(const double* partials, int n_rows,
+                                           const SumTail& tl) {
     static_assert(kSearchBlock == 512 && kNumSums == 32, "tail geometry");
     __shared__ double s_rows[kFinalRowLanes][32];
-    __shared__ double s_sums[32];
-    __shared__ double s_pose[6], s_sc[6], s_update[16];
-    __shared__ int s_status;
     const int tid = threadIdx.x;
     // FinalSumKernel's order: row lane rl adds rows rl, rl + 32, ... in
     // ascending order; the 32 row lanes are then added in ascending order.
@@ -645,37 +621,10 @@ __device__ __forceinline__ void GaussNewtonTail(const double* partials,
         double t = 0;
 #pragma unroll
         for (int k = 0; k < kFinalRowLanes; ++k) t += s_rows[k][tid];
-        if (tid == 31) t = tl.n_source;
-        s_sums[tid] = t;
+        if (tl.out) tl.out[tid] = t;
+        if (tl.mail_data) tl.mail_data[tid] = t;
     }
-    __syncthreads();
-    // DecodeAndSolve6x6 + PoseToTransformation (the host's per-iteration work)
-    if (tid < 64) {
-        double x[6];
-        const int st = GnSolveWave(s_sums, tid, x);
-        if (tid == 0) {
-            s_status = st;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) s_pose[k] = st == 0 ? x[k] : 0.0;
-        }
-    }
-    __syncthreads();
-    if (tid < 6) s_sc[tid] = tid < 3 ? sin(s_pose[tid]) : cos(s_pose[tid - 3]);
-    __syncthreads();
-    if (tid == 0) PoseToTransformationDevice(s_pose, s_sc, s_update);
-    __syncthreads();
-    if (tid < 16) {
-        // no correspondence at all: the driver resets its transformation and
-        // stops; the launch already queued behind this one moves nothing
-        const bool none = s_sums[30] == 0.0;
-        const double u = none ? ((tid % 5) == 0 ? 1.0 : 0.0) : s_update[tid];
-        tl.xf_out[tid] = u;
-        ((float*)(tl.xf_out + 16))[tid] = (float)u;
-        tl.mail_data[32 + tid] = u;
-    }
-    if (tid < 32) tl.mail_data[tid] = s_sums[tid];
-    if (tid == 32) tl.mail_data[48] = (double)s_status;
-    MailboxPublish(tl.mail_flag, tl.mail_seq);
+    if (tl.mail_flag) MailboxPublish(tl.mail_flag, tl.mail_seq);
 }
 
 template <typename T, int G, int EST>
@@ -685,56 +634,8 @@ SearchAccumulateKernel(NnsView<T> nv, const Rec4<T>* __restrict__ sorted_n,
                        T* __restrict__ src, int64_t n, Mat4<T> xf,
                        int apply_xf, RobustParams rp,
                        int64_t* __restrict__ corr_out,
-                       double* __restrict__ partials, GnTail tail,
-                       XfGate gate) {
+                       double* __restrict__ partials, SumTail tail) {
     constexpr int kPerWave = 64 / G;  // queries per wave
-    if (gate.inbox) {
-        __shared__ int s_go;
-        if (threadIdx.x == 0) {
-            int spins = 0, v;
-            while ((v = __hip_atomic_load(gate.inbox, __ATOMIC_ACQUIRE,
-                                          __HIP_MEMORY_SCOPE_SYSTEM)) -
-                           gate.seq < 0) {
-                if (++spins > kGateSpinLimit) break;
-                __builtin_amdgcn_s_sleep(4);
-            }
-            const int cancel = __hip_atomic_load(gate.inbox + 1,
-                                                 __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_SYSTEM);
-            s_go = v - gate.seq >= 0 && cancel != gate.seq;
-        }
-        __syncthreads();
-        if (!s_go) return;  // cancelled (or no answer): nothing is touched
-        if (apply_xf == 3) {
-            // scalar loads, behind the acquire: see the note at apply_xf == 2
-            if constexpr (sizeof(T) == 4) {
-                const float* m32 = (const float*)(gate.inbox + 16);
-#pragma unroll
-                for (int k = 0; k < 16; ++k) xf.m[k] = m32[k];
-            } else {
-                const double* m64 = (const double*)(gate.inbox + 32);
-#pragma unroll
-                for (int k = 0; k < 16; ++k) xf.m[k] = m64[k];
-            }
-        }
-    }
-    if (apply_xf == 2) {
-        // the update the previous launch's tail left on the device (uniform
-        // address: scalar loads), narrowed to the point dtype like the host
-        // narrows the matrix it passes by value
-        // The tail stores the matrix in both precisions so that a Float32
-        // launch gets its values by scalar loads alone: narrowing here would
-        // be a vector instruction and park all 16 values in vector registers
-        // for the whole kernel (+16 registers, a wave of occupancy).
-        if constexpr (sizeof(T) == 4) {
-            const float* m32 = (const float*)(tail.xf_in + 16);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) xf.m[k] = m32[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) xf.m[k] = tail.xf_in[k];
-        }
-    }
     constexpr int kM = kNumSums / G;  // sums a lane owns
     static_assert(kNumSums % G == 0, "G divides the number of sums");
     double mine[kM];
@@ -946,7 +847,7 @@ SearchAccumulateKernel(NnsView<T> nv, const Rec4<T>* __restrict__ sorted_n,
             partials[(int64_t)blockIdx.x * kNumSums + threadIdx.x] = t;
     }
     if (tail.tickets && LastWorkgroup(tail.tickets))
-        GaussNewtonTail(partials, (int)gridDim.x, tail);
+        RowSumTail(partials, (int)gridDim.x, tail);
 }
 
 
@@ -1328,9 +1229,8 @@ static int LaunchSearchAccumulate(
         const void* tgt_normals_dev, int64_t n, int estimation,
         int robust_kernel, double scaling_parameter, double shape_parameter,
         int64_t* corr_out_dev, double* sums32_dev, double* mail_data,
-        int* mail_flag, int mail_seq, const GnTail* tail_in,
-        const XfGate* gate_in, o3dmi_stream_t stream) {
-    O3DMI_REQUIRE(nns && src_dev && (sums32_dev || mail_data || tail_in),
+        int* mail_flag, int mail_seq, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(nns && src_dev && (sums32_dev || mail_data),
                   "null argument");
     O3DMI_REQUIRE(estimation >= 0 && estimation <= 2,
                   "estimation must be point-to-plane (0), point-to-point (1) "
@@ -1355,42 +1255,35 @@ static int LaunchSearchAccumulate(
     // the 4 waves per SIMD the kernel's registers allow); G = 8 beyond --
     // several rounds of waves whose lanes own 4 cells each beat one round of
     // lanes that own 7, 14 or 27.
-    static const int64_t lane_scale = [] {
-        const char* e = std::getenv("O3DMI_NNS_LANES");
-        const int64_t v = e ? std::atoll(e) : 0;
-        return v > 0 ? v : (int64_t)kCUs * 1024;  // 4 waves per SIMD
-    }();
+    const int64_t lane_scale = (int64_t)kCUs * 1024;  // 4 waves per SIMD
     int group;
     if (n * 32 <= lane_scale / 2) group = 32;
     else if (n * 16 <= lane_scale) group = 16;
     else group = 8;
-    if (const char* e = std::getenv("O3DMI_NNS_GROUP")) {
-        const int v = std::atoi(e);
-        if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) group = v;
-    }
-    // <= 512 workgroups of 8 waves: at most 512 rows for the final pass
+    // The final sum rides in the launch's last workgroup (SumTail) when the
+    // index carries ticket words: <= kTailRows workgroups then; else a
+    // separate one-workgroup launch over <= 512 rows.
+    // TEMPORARY A/B switch of round 5 (removed once measured).
+    static const bool row_tail = [] {
+        const char* e = std::getenv("O3DMI_ICP_ROW_TAIL");
+        return !(e && e[0] == '0');
+    }();
+    const bool use_tail = row_tail && nns->tickets != nullptr;
     int64_t g64 = (n * group + kSearchBlock - 1) / kSearchBlock;
-    const int64_t g_max = tail_in ? kTailRows : (int64_t)kCUs * 2;
+    const int64_t g_max = use_tail ? kTailRows : (int64_t)kCUs * 2;
     if (g64 > g_max) g64 = g_max;
     if (g64 < 1) g64 = 1;
     const int g = (int)g64;
     RobustParams rp = MakeRobust(robust_kernel, scaling_parameter,
                                  shape_parameter);
-    // 0 none, 1 the matrix passed by value, 2 the matrix the previous
-    // launch's tail left at tail.xf_in
-    // 3: the matrix the host publishes in the gate's inbox
-    const int apply_xf = transformation != nullptr
-                                 ? 1
-                                 : (tail_in && tail_in->xf_in
-                                            ? 2
-                                            : (gate_in && gate_in->inbox ? 3
-                                                                         : 0));
-    XfGate gate = {};
-    if (gate_in) gate = *gate_in;
-    GnTail tail = {};
-    if (tail_in) {
-        tail = *tail_in;
-        tail.n_source = (double)n;
+    const int apply_xf = transformation != nullptr ? 1 : 0;
+    SumTail tail = {};
+    if (use_tail) {
+        tail.tickets = nns->tickets;
+        tail.out = sums32_dev;
+        tail.mail_data = mail_data;
+        tail.mail_flag = mail_flag;
+        tail.mail_seq = mail_seq;
     }
     Mat4<double> xd;
     Mat4<float> xfl;
@@ -1407,7 +1300,7 @@ static int LaunchSearchAccumulate(
                        dim3(kSearchBlock), 0, s, MakeView<T>(nns),            \
                        (const Rec4<T>*)nns->sorted_normals, (T*)src_dev, n,   \
                        xf_of(T()), apply_xf, rp, corr_out_dev, nns->partials, \
-                       tail, gate)
+                       tail)
 #define O3DMI_SEARCH(T, G)                                                     \
     do {                                                                      \
         if (estimation == 0 && robust_kernel == O3DMI_L2_LOSS)                \
@@ -1420,17 +1313,14 @@ static int LaunchSearchAccumulate(
     switch (group) {                                                          \
         case 32: O3DMI_SEARCH(T, 32); break;                                  \
         case 16: O3DMI_SEARCH(T, 16); break;                                  \
-        case 8: O3DMI_SEARCH(T, 8); break;                                    \
-        case 4: O3DMI_SEARCH(T, 4); break;                                    \
-        case 2: O3DMI_SEARCH(T, 2); break;                                    \
-        default: O3DMI_SEARCH(T, 1); break;                                   \
+        default: O3DMI_SEARCH(T, 8); break;                                   \
     }
     if (nns->dtype == O3DMI_F64) { O3DMI_SEARCH_G(double) }
     else { O3DMI_SEARCH_G(float) }
 #undef O3DMI_SEARCH_G
 #undef O3DMI_SEARCH
 #undef O3DMI_SEARCH_E
-    if (!tail_in)
+    if (!use_tail)
         hipLaunchKernelGGL(FinalSumKernel<kNumSums>, dim3(1),
                            dim3(kFinalThreads), 0, s, nns->partials, g,
                            sums32_dev, mail_data, mail_flag, mail_seq);
@@ -1448,58 +1338,7 @@ int o3dmi_internal_icp_transform_search_accumulate(
                                   n, estimation, robust_kernel,
                                   scaling_parameter, shape_parameter,
                                   corr_out_dev, sums32_dev, mail_data, mail_flag,
-                                  mail_seq, nullptr, nullptr, stream);
-}
-
-// Internal (host/registration.cpp): the same pair of launches (search +
-// accumulate, final sum posting to mail_data / mail_flag), with the search
-// launch GATED on `inbox` (see XfGate) when inbox != NULL: it starts to work
-// when the host has published gate_seq, moving the source by the matrix in
-// the inbox; `transformation` must then be NULL.
-int o3dmi_internal_icp_search_gated(
-        const o3dmi_nns_t* nns, void* src_dev, const double* transformation,
-        const int* inbox, int gate_seq, int64_t n, int robust_kernel,
-        double scaling_parameter, double shape_parameter,
-        int64_t* corr_out_dev, double* mail_data, int* mail_flag, int mail_seq,
-        o3dmi_stream_t stream) {
-    O3DMI_REQUIRE(!(inbox && transformation), "gated launch with a matrix");
-    XfGate gate = {};
-    gate.inbox = inbox;
-    gate.seq = gate_seq;
-    return LaunchSearchAccumulate(nns, src_dev, transformation, nullptr, n, 0,
-                                  robust_kernel, scaling_parameter,
-                                  shape_parameter, corr_out_dev, nullptr,
-                                  mail_data, mail_flag, mail_seq, nullptr,
-                                  inbox ? &gate : nullptr, stream);
-}
-
-// Internal (host/registration.cpp): one point-to-plane Gauss-Newton iteration
-// as ONE launch -- search + accumulate + final sum + 6x6 solve + update, see
-// GnTail. `transformation` (host, may be NULL): moves the source first, as
-// above; NULL with xf_from_device: the update the previous launch left in
-// state_dev is applied instead. state_dev: device, 256 bytes: 16 float64 (the
-// update), the same as 16 float32, then 9 ticket words (zero before the first launch; every launch
-// leaves them zero). The launch posts {32 sums, 16 update, status} to
-// mail_data (host-mapped, kMailDoubles float64) and publishes mail_seq.
-int o3dmi_internal_icp_search_solve(
-        const o3dmi_nns_t* nns, void* src_dev, const double* transformation,
-        int xf_from_device, int64_t n, int robust_kernel,
-        double scaling_parameter, double shape_parameter,
-        int64_t* corr_out_dev, void* state_dev, double* mail_data,
-        int* mail_flag, int mail_seq, o3dmi_stream_t stream) {
-    O3DMI_REQUIRE(state_dev && mail_data && mail_flag, "null argument");
-    GnTail tail = {};
-    tail.xf_out = (double*)state_dev;
-    tail.xf_in = !transformation && xf_from_device ? (const double*)state_dev
-                                                   : nullptr;
-    tail.tickets = (int*)((double*)state_dev + 24);
-    tail.mail_data = mail_data;
-    tail.mail_flag = mail_flag;
-    tail.mail_seq = mail_seq;
-    return LaunchSearchAccumulate(nns, src_dev, transformation, nullptr, n, 0,
-                                  robust_kernel, scaling_parameter,
-                                  shape_parameter, corr_out_dev, nullptr,
-                                  nullptr, nullptr, 0, &tail, nullptr, stream);
+                                  mail_seq, stream);
 }
 
 int o3dmi_transform_points(const double* transformation, void* points_dev,

@@ -30,37 +30,6 @@ Mailbox* ThreadMailbox(int which = 0);
 // or the stream's error if the stream finished / failed without posting.
 hipError_t MailboxWait(Mailbox* mb, int seq, hipStream_t s);
 
-// A ring of mailboxes for drivers that keep more than one launch in flight
-// (the ICP driver issues iteration k + 1 before it has read iteration k):
-// slot = seq % kMailSlots, each slot kMailDoubles float64 + its own sequence
-// word, all in one host-mapped allocation.
-constexpr int kMailSlots = 4;
-constexpr int kMailDoubles = 64;
-struct MailRing {
-    double* data = nullptr;  // [kMailSlots][kMailDoubles]
-    int* flags = nullptr;    // [kMailSlots], 64 bytes apart
-    int seq = 0;
-    double* Data(int s) const { return data + (size_t)(s % kMailSlots) * kMailDoubles; }
-    int* Flag(int s) const { return flags + (size_t)(s % kMailSlots) * 16; }
-};
-MailRing* ThreadMailRing();
-// Blocks until launch `seq` has posted; its data is ring->Data(seq).
-hipError_t MailRingWait(MailRing* ring, int seq, hipStream_t s);
-
-// The other direction: a host-mapped inbox a GATED launch polls (icp.hip
-// XfGate). words[0] = sequence number of the launch that may proceed,
-// words[1] = sequence number of a cancelled launch, 16 float32 at byte 64 and
-// 16 float64 at byte 128 = the transformation for it. One outstanding gated
-// launch per host thread.
-struct GateInbox {
-    int* words = nullptr;  // host-mapped, 256 bytes
-    int seq = 0;           // last sequence number handed out
-    // publishes `m` (row-major 4x4) for launch `s`
-    void Release(int s, const double* m) const;
-    void Cancel(int s) const;
-};
-GateInbox* ThreadGateInbox();
-
 // Device side: called by the threads of the single final workgroup after they
 // wrote data[0..n); publishes `seq`.
 __device__ __forceinline__ void MailboxPublish(int* flag, int seq) {

@@ -29,6 +29,10 @@ struct o3dmi_nns {
     uint2* ranges = nullptr;         // [n_buckets + 1] {end, count}; the last
                                      // entry is the build's running total
     double* partials = nullptr;      // [kCUs*4, kNumSums]
+    int* tickets = nullptr;          // 9 ticket words of the search launch's
+                                     // final-sum tail (icp.hip SumTail), in
+                                     // the last row of `partials`; zero
+                                     // between launches
 };
 
 namespace o3dmi {

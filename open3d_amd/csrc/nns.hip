@@ -997,8 +997,10 @@ int BuildIndex(o3dmi_nns* nns, const T* pts, const T* normals, hipStream_t s) {
     if (normals)
         { int st_; if ((st_ = PoolAlloc(&nns->sorted_normals, recs))) return st_; }
     { int st_; if ((st_ = PoolAlloc((void**)&nns->partials, sizeof(double) * kCUs * 4 * kNumSums))) return st_; }
-    static const bool no_small = std::getenv("O3DMI_NNS_NO_SMALL") != nullptr;
-    if (n > 0 && n <= kSmallIndexPoints && !no_small) {
+    // (a search launch writes <= 512 rows; the last row holds the tickets)
+    nns->tickets = (int*)(nns->partials + (size_t)(kCUs * 4 - 1) * kNumSums);
+    O3DMI_HIP_CHECK(hipMemsetAsync(nns->tickets, 0, sizeof(int) * 16, s));
+    if (n > 0 && n <= kSmallIndexPoints) {
         hipLaunchKernelGGL(BuildSmallIndexKernel<T>, dim3(1),
                            dim3(kSmallIndexBlock), 0, s, pts, normals, (int)n,
                            nns->inv_cell, mask, (int)nb, nns->ranges,
@@ -1332,10 +1334,6 @@ int o3dmi_nns_knn_search_counts(const void* points_dev, int64_t n,
     // distance prunes shell 2. Measured on MI355X, k = 30, 100 k queries:
     // 3 per cell 1.8 ms, 4.5: 0.71 ms, 6: 0.84 ms, 8: 1.26 ms, 15: 2.5 ms.
     double target = k * 0.15 < 2.0 ? 2.0 : k * 0.15;
-    if (const char* e_ = std::getenv("O3DMI_KNN_PPC")) {  // tuning knob
-        const double v = std::atof(e_);
-        if (v > 0) target = v;
-    }
     // First guess: a surface spanning the two largest extents, a filled
     // volume or a line, whichever gives the largest cell (shrinking is the
     // cheap direction: few occupied cells estimate the density reliably).

@@ -28,7 +28,6 @@
 #include <cstring>
 
 #include "common.h"
-#include "gn_device.h"
 #include "reduce_sums.h"
 
 namespace o3dmi {
@@ -701,250 +700,6 @@ OdometrySumsKernel(OdoMaps m, Camera ti, float trunc, float depth_delta,
     BlockSumAndStore<kOdoSums>(A, partials);
 }
 
-// ---------------------------------------------------------------------------
-// Persistent Gauss-Newton loop: ALL iterations of ALL pyramid levels of one
-// RGBDOdometryMultiScale call in ONE launch (RGBDOdometry.cpp:155-186 and its
-// two siblings). Per iteration the host-driven form costs two launches, a PCIe
-// post and a host solve (~25 us, of which ~17 us is launch + dependent-load
-// latency, not work); here kGnBlocks co-resident workgroups
-//   1. accumulate their pixels and reduce to one 29-vector per workgroup,
-//   2. exchange the vectors all-to-all: write-through (agent-scope) 8-byte
-//      stores of the float64 bit patterns, one arrival counter per epoch parity
-//      polled by ONE lane per workgroup, agent-scope loads of everybody's
-//      vectors afterwards (no fences, no second kernel; rows and counters are
-//      double buffered by epoch parity),
-//   3. every workgroup adds the kGnBlocks vectors in the same fixed order,
-//      solves the 6x6 system in float64 (same partial-pivot LU and Euler-angle
-//      conversion as the host helpers) and updates its copy of T --
-//      identical in all workgroups, so nothing is broadcast.
-// Workgroup 0 posts the final transformation to the host mailbox.
-// Polling is bounded: a workgroup that gives up raises `timeout` and the host
-// falls back to the per-iteration driver.
-constexpr int kGnBlocks = 256;          // <= CUs: all workgroups co-resident
-constexpr unsigned kGnSpinLimit = 1u << 22;
-
-struct GnLevel {
-    OdoMaps maps;
-    float fx, fy, cx, cy;
-    int max_iteration;
-    double relative_rmse, relative_fitness;
-};
-struct GnParams {
-    GnLevel level[8];
-    int n_levels;
-    double T0[16];
-    float trunc, depth_delta, intensity_delta;
-    unsigned long long* granules;  // [2][kGnBlocks][32] float64 bit patterns
-    unsigned* counters;            // [2] arrival counters, zeroed per call
-    int* timeout;                  // device word, zeroed per call
-    unsigned long long* stamps;    // optional [64][6] wall-clock stamps (debug)
-    double* mail_data;             // host mailbox: T[16], rmse, fitness,
-    int* mail_flag;                //   iterations, status
-    int mail_seq;
-};
-
-template <int METHOD>
-__global__ void __launch_bounds__(kSumsBlock)
-OdometryGaussNewtonKernel(GnParams gp) {
-    __shared__ double s_T[16];
-    __shared__ Camera s_cam;
-    __shared__ double s_wave[kSumsBlock / 64][32];
-    __shared__ double s_part[kSumsBlock / 32][32];
-    __shared__ double s_sums[32];
-    __shared__ int s_ctl[4];  // 0 status, 1 stop level, 2 iterations
-    __shared__ double s_pose[6], s_sc[6], s_dT[16];
-    __shared__ double s_fit[2];  // inlier_rmse, fitness
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    if (tid < 16) s_T[tid] = gp.T0[tid];
-    if (tid == 0) {
-        s_ctl[0] = 0;
-        s_ctl[2] = 0;
-        s_fit[0] = 0.0;
-        s_fit[1] = 1.0;
-    }
-    __syncthreads();
-    unsigned epoch = 0;
-    for (int li = 0; li < gp.n_levels; ++li) {
-        const GnLevel& L = gp.level[li];
-        const int64_t n = (int64_t)L.maps.rows * L.maps.cols;
-        for (int iter = 0; iter < L.max_iteration; ++iter) {
-            ++epoch;
-#define O3DMI_GN_STAMP(slot)                                                  \
-    if (gp.stamps && blockIdx.x == 0 && tid == 0 && epoch <= 64)              \
-        gp.stamps[(epoch - 1) * 6 + (slot)] = wall_clock64();
-            O3DMI_GN_STAMP(0)
-            if (tid == 0) {
-                Camera c;
-                for (int i = 0; i < 3; ++i)
-                    for (int j = 0; j < 4; ++j) c.e[i][j] = (float)s_T[i * 4 + j];
-                c.fx = L.fx; c.fy = L.fy; c.cx = L.cx; c.cy = L.cy;
-                c.scale = 1.0f;
-                s_cam = c;
-                s_ctl[1] = 0;
-            }
-            __syncthreads();
-            const Camera ti = s_cam;
-            // 1. this workgroup's share of the pixels
-            double A[kOdoSums];
-#pragma unroll
-            for (int k = 0; k < kOdoSums; ++k) A[k] = 0;
-            for (int64_t w = blockIdx.x * (int64_t)kSumsBlock + tid; w < n;
-                 w += (int64_t)kGnBlocks * kSumsBlock)
-                AccumulatePixel<METHOD>(A, L.maps, ti, w, gp.trunc,
-                                        gp.depth_delta, gp.intensity_delta);
-            {
-                const double t = WaveReduceScatter<kOdoSums>(A);
-                if ((lane & 1) == 0) s_wave[wave][lane >> 1] = t;
-            }
-            __syncthreads();
-            // 2. publish this workgroup's vector (write-through stores), arrive
-            //    at the epoch's counter, ONE lane polls it, then everybody
-            //    reads all vectors with agent-scope loads and adds them in the
-            //    same fixed order -> identical sums in every workgroup
-            const unsigned par = epoch & 1u;
-            unsigned long long* rows =
-                    gp.granules + (size_t)par * kGnBlocks * 32;
-            if (tid < kOdoSums) {
-                double v = 0;
-#pragma unroll
-                for (int wv = 0; wv < kSumsBlock / 64; ++wv) v += s_wave[wv][tid];
-                __hip_atomic_store(rows + (size_t)blockIdx.x * 32 + tid,
-                                   (unsigned long long)__double_as_longlong(v),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            O3DMI_GN_STAMP(1)
-            bool failed = false;
-            if (tid == 0) {
-                unsigned* counter = gp.counters + par;
-                // k-th use of this parity: everybody has arrived at k * blocks
-                const unsigned target = (unsigned)kGnBlocks * ((epoch + 1u) >> 1);
-                __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                unsigned spins = 0;
-                while (__hip_atomic_load(counter, __ATOMIC_RELAXED,
-                                         __HIP_MEMORY_SCOPE_AGENT) < target) {
-                    if (++spins > kGnSpinLimit ||
-                        ((spins & 255u) == 0 &&
-                         __hip_atomic_load(gp.timeout, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                        failed = true;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                if (failed)
-                    __hip_atomic_store(gp.timeout, 1, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-            }
-            const int any_failed = __syncthreads_or(failed ? 1 : 0);
-            if (any_failed) {
-                if (tid == 0) s_ctl[0] = 3;  // timeout
-                __syncthreads();
-                break;
-            }
-            O3DMI_GN_STAMP(2)
-            {
-                // lane r reads workgroup r's vector (29 independent loads in
-                // flight), then the same wave / LDS tree as above adds the
-                // kGnBlocks vectors column by column.
-                static_assert(kGnBlocks == kSumsBlock,
-                              "one gathered row per lane");
-                double R[kOdoSums];
-#pragma unroll
-                for (int k = 0; k < kOdoSums; ++k)
-                    R[k] = __longlong_as_double((long long)__hip_atomic_load(
-                            rows + (size_t)tid * 32 + k, __ATOMIC_RELAXED,
-                            __HIP_MEMORY_SCOPE_AGENT));
-                const double t = WaveReduceScatter<kOdoSums>(R);
-                if ((lane & 1) == 0) s_part[wave][lane >> 1] = t;
-            }
-            __syncthreads();
-            if (tid < kOdoSums) {
-                double v = 0;
-#pragma unroll
-                for (int k = 0; k < kSumsBlock / 64; ++k) v += s_part[k][tid];
-                s_sums[tid] = v;
-            }
-            __syncthreads();
-            O3DMI_GN_STAMP(3)
-            // 3. solve (wave 0), Euler angles -> dT (6 lanes take one sin / cos
-            //    each), T <- dT * T (16 lanes), convergence test (lane 0)
-            if (wave == 0) {
-                double x[6];
-                const int st = GnSolveWave(s_sums, lane, x);
-                if (lane == 0) {
-                    const int count = (int)s_sums[28];
-                    s_ctl[0] = st != 0 ? st : (count <= 0 ? 1 : 0);
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) s_pose[k] = st == 0 ? x[k] : 0.0;
-                }
-            }
-            __syncthreads();
-            if (s_ctl[0] != 0) break;
-            if (tid < 6) s_sc[tid] = tid < 3 ? sin(s_pose[tid]) : cos(s_pose[tid - 3]);
-            __syncthreads();
-            if (tid == 0) {
-                // TransformationConverterImpl.h:23-42 with s = sin, c = cos of
-                // (alpha, beta, gamma) = pose[0..2]
-                const double s0 = s_sc[0], s1 = s_sc[1], s2 = s_sc[2];
-                const double c0 = s_sc[3], c1 = s_sc[4], c2 = s_sc[5];
-                double* T = s_dT;
-                for (int q = 0; q < 16; ++q) T[q] = 0;
-                T[0] = c2 * c1;
-                T[1] = -1 * s2 * c0 + c2 * s1 * s0;
-                T[2] = s2 * s0 + c2 * s1 * c0;
-                T[4] = s2 * c1;
-                T[5] = c2 * c0 + s2 * s1 * s0;
-                T[6] = -1 * c2 * s0 + s2 * s1 * c0;
-                T[8] = -1 * s1;
-                T[9] = c1 * s0;
-                T[10] = c1 * c0;
-                T[3] = s_pose[3];
-                T[7] = s_pose[4];
-                T[11] = s_pose[5];
-                T[15] = 1;
-                const float residual = (float)s_sums[27];
-                const int count = (int)s_sums[28];
-                s_ctl[2] += 1;
-                const double delta_rmse = (double)(residual / count);
-                const double delta_fitness = (double)count / (double)n;
-                const double rmse = s_fit[0], fit = s_fit[1];
-                if (fabs(fit - delta_fitness) / fit < L.relative_fitness &&
-                    fabs(rmse - delta_rmse) / rmse < L.relative_rmse) {
-                    s_ctl[1] = 1;  // early exit at this level
-                } else {
-                    s_fit[0] = delta_rmse;
-                    s_fit[1] = delta_fitness;
-                }
-            }
-            __syncthreads();
-            double tn = 0;
-            if (tid < 16) {
-                const int r = tid >> 2, c = tid & 3;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) tn += s_dT[r * 4 + k] * s_T[k * 4 + c];
-            }
-            __syncthreads();
-            if (tid < 16) s_T[tid] = tn;
-            __syncthreads();
-            O3DMI_GN_STAMP(4)
-            if (s_ctl[0] != 0 || s_ctl[1] != 0) break;
-        }
-        if (s_ctl[0] != 0) break;
-    }
-    if (blockIdx.x == 0) {
-        if (tid < 16) gp.mail_data[tid] = s_T[tid];
-        if (tid == 16) gp.mail_data[16] = s_fit[0];
-        if (tid == 17) gp.mail_data[17] = s_fit[1];
-        if (tid == 18) gp.mail_data[18] = (double)s_ctl[2];
-        if (tid == 19) gp.mail_data[19] = (double)s_ctl[0];
-        MailboxPublish(gp.mail_flag, gp.mail_seq);
-    }
-}
-
 constexpr int kInfoSums = 21;
 
 // ComputeOdometryInformationMatrixCPU (RGBDOdometryCPU.cpp:26-96) with
@@ -1447,92 +1202,6 @@ int o3dmi_odometry_sums_post(int method, int rows, int cols,
         PoolFree(partials);
     }
     O3DMI_HIP_CHECK(e);
-    return O3DMI_OK;
-}
-
-// Internal (host/odometry.cpp): the persistent Gauss-Newton launch. levels are
-// ordered coarse to fine; maps11 as in o3dmi_odometry_sums_post. scratch_dev
-// must hold o3dmi_odometry_gn_scratch_bytes() bytes. Results arrive in the
-// mailbox: T[16], inlier_rmse, fitness, iterations, status (0 ok, 1 no
-// inliers, 2 singular, 3 exchange timed out).
-size_t o3dmi_odometry_gn_scratch_bytes(void) {
-    return sizeof(unsigned long long) * 2 * kGnBlocks * 32 + 256 +
-           sizeof(unsigned long long) * 64 * 6;
-}
-
-int o3dmi_odometry_gauss_newton(
-        int method, int n_levels, const int* rows, const int* cols,
-        const float* const* maps11_per_level, const double* intrinsics_per_level,
-        const int* max_iterations, const double* relative_rmse,
-        const double* relative_fitness, const double* init_source_to_target,
-        float depth_outlier_trunc, float depth_huber_delta,
-        float intensity_huber_delta, void* scratch_dev, double* mail_data,
-        int* mail_flag, int mail_seq, o3dmi_stream_t stream) {
-    O3DMI_REQUIRE(method >= 0 && method <= 2, "Odometry method not implemented.");
-    O3DMI_REQUIRE(n_levels >= 1 && n_levels <= 8, "1..8 pyramid levels");
-    O3DMI_REQUIRE(rows && cols && maps11_per_level && intrinsics_per_level &&
-                          max_iterations && relative_rmse && relative_fitness &&
-                          init_source_to_target && scratch_dev && mail_data &&
-                          mail_flag,
-                  "null argument");
-    hipStream_t s = (hipStream_t)stream;
-    GnParams gp;
-    std::memset(&gp, 0, sizeof(gp));
-    gp.n_levels = n_levels;
-    for (int l = 0; l < n_levels; ++l) {
-        const float* const* m = maps11_per_level + 11 * l;
-        GnLevel& L = gp.level[l];
-        L.maps.source_depth = m[0];
-        L.maps.target_depth = m[1];
-        L.maps.source_intensity = m[2];
-        L.maps.target_intensity = m[3];
-        L.maps.target_depth_dx = m[4];
-        L.maps.target_depth_dy = m[5];
-        L.maps.target_intensity_dx = m[6];
-        L.maps.target_intensity_dy = m[7];
-        L.maps.source_vertex = m[8];
-        L.maps.target_vertex = m[9];
-        L.maps.target_normal = m[10];
-        L.maps.rows = rows[l];
-        L.maps.cols = cols[l];
-        const double* K = intrinsics_per_level + 9 * l;
-        L.fx = (float)K[0];
-        L.fy = (float)K[4];
-        L.cx = (float)K[2];
-        L.cy = (float)K[5];
-        L.max_iteration = max_iterations[l];
-        L.relative_rmse = relative_rmse[l];
-        L.relative_fitness = relative_fitness[l];
-        O3DMI_REQUIRE(m[8] != nullptr && rows[l] > 0 && cols[l] > 0,
-                      "bad pyramid level");
-    }
-    for (int i = 0; i < 16; ++i) gp.T0[i] = init_source_to_target[i];
-    gp.trunc = depth_outlier_trunc;
-    gp.depth_delta = depth_huber_delta;
-    gp.intensity_delta = intensity_huber_delta;
-    gp.granules = (unsigned long long*)scratch_dev;
-    gp.counters = (unsigned*)((char*)scratch_dev +
-                              sizeof(unsigned long long) * 2 * kGnBlocks * 32);
-    gp.timeout = (int*)(gp.counters + 2);
-    gp.stamps = std::getenv("O3DMI_GN_STAMPS")
-                        ? (unsigned long long*)((char*)gp.timeout + 64)
-                        : nullptr;
-    gp.mail_data = mail_data;
-    gp.mail_flag = mail_flag;
-    gp.mail_seq = mail_seq;
-    // every polled word starts from zero on every call (epochs start at 1)
-    O3DMI_HIP_CHECK(hipMemsetAsync(scratch_dev, 0,
-                                   o3dmi_odometry_gn_scratch_bytes(), s));
-    if (method == 0)
-        hipLaunchKernelGGL(OdometryGaussNewtonKernel<0>, dim3(kGnBlocks),
-                           dim3(kSumsBlock), 0, s, gp);
-    else if (method == 1)
-        hipLaunchKernelGGL(OdometryGaussNewtonKernel<1>, dim3(kGnBlocks),
-                           dim3(kSumsBlock), 0, s, gp);
-    else
-        hipLaunchKernelGGL(OdometryGaussNewtonKernel<2>, dim3(kGnBlocks),
-                           dim3(kSumsBlock), 0, s, gp);
-    O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
 }
 

@@ -1266,10 +1266,7 @@ int VdsAsync(const void* pos, const void* attr, int64_t n_max, const int* n_dev,
              int* m_dev, int* err_dev, std::vector<void*>& scratch,
              hipStream_t s, int chain, double next_voxel_size,
              bool from_previous) {
-    // O3DMI_VDS_SORT=1 (diagnostics / A-B): the seven-launch sort for every size
-    const char* sort_env = std::getenv("O3DMI_VDS_SORT");
-    const bool force_sort = sort_env && sort_env[0] == '1';
-    if (n_max > 0 && n_max <= kBucketedMaxPoints && !force_sort) {
+    if (n_max > 0 && n_max <= kBucketedMaxPoints) {
         if (dtype == O3DMI_F64)
             return VdsBucketedImpl<double>(
                     (const double*)pos, (const double*)attr, n_max, n_dev,

@@ -82,6 +82,12 @@ constexpr int kSliceFlagTable = 1;   // a chunk table overflowed
 constexpr int kSliceFlagKeyRange = 2;
 constexpr int kSliceFlagSender = 4;  // (receiver side) a SENDER's slice did not
                                      // fit: seen by every rank alike
+constexpr int kSliceFlagAbort = 8;   // (wire) the sending rank is leaving the
+                                     // call with an error: its segment is
+                                     // empty and every rank leaves at this
+                                     // chunk (o3dmi_vbg_integrate_frames is
+                                     // COLLECTIVE on the sliced path)
+constexpr int kSliceFlagPeerAbort = 16;  // (receiver side) a segment said so
 
 inline int64_t SliceSegmentBytes(int capacity) {
     return (int64_t)sizeof(SliceHeader) +
@@ -150,7 +156,8 @@ int LaunchApplySlice(o3dmi_hash* block_hash, const void* gathered_dev,
 // status (may be null). overflow: > 0 = stamp of the chunk that ran out of
 // buffer indices; -1 = a sender's segment / table was too small (every rank
 // reads that in the gathered headers: a collective redo); -2 = THIS rank's
-// receiver table was too small (a local redo, no collective).
+// receiver table was too small (a local redo, no collective); -3 = a rank is
+// leaving the call with an error (kSliceFlagAbort): every rank leaves.
 int LaunchBuildChunk(o3dmi_hash* block_hash, const ChunkTable& table,
                      ChunkEntry* entries, int entries_cap, int* entries_count,
                      int* status_host, int stamp, hipStream_t s);
@@ -173,8 +180,6 @@ struct ChunkIntegrateArgs {
     int resolution;
     float voxel_size, sdf_trunc, depth_max, depth_scale;
     bool depth_div_short;
-    bool pipelined;               // software-pipelined 2-frame rounds (a
-                                  // rank's share is latency-bound)
     bool raw;                     // gather from the raw images (IntegFrame::
                                   // depth / color) instead of the prepared
                                   // records (IntegFrame::recs)

@@ -126,7 +126,7 @@ struct RayCastParams {
     int* steps;  // diagnostics (O3DMI_RAYCAST_STEPS=1): march steps per pixel
     long long* clocks;  // ... and per workgroup: start, march done, end (100 MHz)
     int xcd_bands;  // tiles dealt to the XCDs in image bands (0: round-robin)
-    int coop;       // idle lanes sample ahead for crawling rays (0: O3DMI_RAYCAST_COOP=0)
+    int coop;       // idle lanes sample ahead for crawling rays
 };
 
 struct BlockCache {
@@ -250,8 +250,7 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
     // VGA); strips have floor, walls and ceiling each: 60.3 against 67.5 us.
     // Only while every tile is resident at once (<= 5 workgroups per CU): at
     // 720p the launch runs in rounds and the strips cost 4 %.
-    // O3DMI_RAYCAST_XCD_BANDS=0 / 1 forces the deal (A / B). gridDim.x is a
-    // multiple of 8 either way.
+    // gridDim.x is a multiple of 8 either way.
     const int n_tiles_all = tiles_x * tiles_y;
     const int per_band = (n_tiles_all + 7) >> 3;
     const int k_step = p.xcd_bands ? (int)(gridDim.x >> 3) : (int)gridDim.x;
@@ -386,8 +385,7 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
             // addition in a helper lane and in the march: the sample
             // positions, and so every output, are the reference's bit for
             // bit. 72 -> 57.5 us per VGA launch, 113 -> 98 us at 720p, the
-            // slowest workgroup 59 -> 42 us (same box; O3DMI_RAYCAST_COOP=0
-            // switches the second phase off).
+            // slowest workgroup 59 -> 42 us (same box).
             bool mine = inside && t < t_max;
             bool crawling = false;
             int it_plain = 0, it_coop = 0;  // DIAG: loop passes of the wave
@@ -866,16 +864,8 @@ int o3dmi_vbg_raycast(o3dmi_hash_t* block_hash, const float* tsdf_dev,
     }
     // one workgroup per 32 x 8 pixel tile (grid-strided beyond 16 per CU)
     const int64_t n_tiles = (int64_t)((w + 31) / 32) * ((h + 7) / 8);
-    static const int bands_env = [] {
-        const char* e = std::getenv("O3DMI_RAYCAST_XCD_BANDS");
-        return e ? (e[0] == '0' ? 0 : 1) : -1;
-    }();
-    p.xcd_bands = bands_env >= 0 ? bands_env : (n_tiles <= kCUs * 5 ? 1 : 0);
-    static const int coop_env = [] {
-        const char* e = std::getenv("O3DMI_RAYCAST_COOP");
-        return (e && e[0] == '0') ? 0 : 1;
-    }();
-    p.coop = coop_env;
+    p.xcd_bands = n_tiles <= kCUs * 5 ? 1 : 0;
+    p.coop = 1;
     // a multiple of 8 workgroups: every XCD gets the same number
     dim3 grid((unsigned)((GridFor(n_tiles, 1, kCUs * 16) + 7) & ~7)),
             block(kBlock);

@@ -171,6 +171,13 @@ ApplySliceKernel(ApplySliceArgs a) {
     const SliceHeader* hd = (const SliceHeader*)seg;
     const SliceRecord* rec = (const SliceRecord*)(seg + sizeof(SliceHeader));
     int n = hd->count;
+    if (hd->flags & kSliceFlagAbort) {
+        // the sender is leaving the call with an error: every rank drops the
+        // chunk and leaves with it (status -3, BuildChunkKernel)
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            atomicOr(a.table.flags, kSliceFlagPeerAbort);
+        n = 0;
+    }
     if (n > a.capacity || (hd->flags & kSliceFlagTable)) {
         // the sender's slice did not fit its segment / its table: flagged in
         // the receiver's status (BuildChunkKernel), the host redoes the chunk
@@ -212,7 +219,7 @@ struct BuildChunkArgs {
     int* entries_count;
     int* status_host;
     int stamp;
-    int longest_first;  // O3DMI_CHUNK_ORDER != 0 (default)
+    int longest_first;  // counting sort by frame count (arrival order: 0)
 };
 
 // After ApplySliceKernel has completed (kernel boundary: every buffer index is
@@ -225,7 +232,8 @@ BuildChunkKernel(BuildChunkArgs a) {
     const bool table_full = n_claimed > t.list_cap;
     // (flags: set by ApplySliceKernel, cleared by the host before it)
     const int fl = *t.flags;
-    const bool flagged = (fl & (kSliceFlagTable | kSliceFlagSender)) != 0;
+    const bool flagged = (fl & (kSliceFlagTable | kSliceFlagSender |
+                                kSliceFlagPeerAbort)) != 0;
     // a chunk that ran out of buffer indices (or whose records did not fit)
     // is dropped as a whole: empty list; the host makes room and applies it
     // again
@@ -299,11 +307,15 @@ BuildChunkKernel(BuildChunkArgs a) {
             const int top = a.hv.counters[0];
             a.status_host[0] = top < a.hv.capacity ? top : a.hv.capacity;
             a.status_host[1] =
-                    a.hv.counters[3] != 0
-                            ? a.hv.counters[3]
-                            : ((fl & kSliceFlagSender)
-                                       ? -1
-                                       : ((flagged || table_full) ? -2 : 0));
+                    (fl & kSliceFlagPeerAbort)
+                            ? -3
+                            : (a.hv.counters[3] != 0
+                                       ? a.hv.counters[3]
+                                       : ((fl & kSliceFlagSender)
+                                                  ? -1
+                                                  : ((flagged || table_full)
+                                                             ? -2
+                                                             : 0)));
             a.status_host[2] = n;
             __hip_atomic_store(&a.status_host[3], a.stamp, __ATOMIC_RELEASE,
                                __HIP_MEMORY_SCOPE_SYSTEM);
@@ -420,11 +432,7 @@ int LaunchBuildChunk(o3dmi_hash* bh, const ChunkTable& table,
     a.entries_count = entries_count;
     a.status_host = status_host;
     a.stamp = stamp;
-    static const int order = [] {
-        const char* e = getenv("O3DMI_CHUNK_ORDER");
-        return e ? atoi(e) : 1;
-    }();
-    a.longest_first = order;
+    a.longest_first = 1;
     hipLaunchKernelGGL(BuildChunkKernel, dim3(1), dim3(256), 0, s, a);
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;

@@ -28,12 +28,6 @@
 #include "sliced_path.h"
 #include "touch_device.h"
 
-// Compile-time switches of the raw chunk launch (tools/build_variant.sh builds
-// A/B libraries with other values).
-#ifndef O3DMI_RAW_TWO_PHASE
-#define O3DMI_RAW_TWO_PHASE 0
-#endif
-
 namespace o3dmi {
 namespace {
 
@@ -506,11 +500,7 @@ struct IntegParams {
     int touch_plane;
     int rows, cols, resolution;
     int res_shift;  // log2(resolution) when it is a power of two, else -1
-    int deal;       // 1: an XCD takes a contiguous eighth of the block list
     int cube;       // 1: a wave's lanes cover a compact cube of the block
-    int diag;       // O3DMI_STEP_DIAG (timing experiments, WRONG results):
-                    // 1 = every gather reads record 0, 2 = no state stores;
-                    // 3 = no skip of fully rejected waves (RIGHT results)
     float sdf_trunc, depth_max;
     float inv_sdf_trunc;  // RN(1 / sdf_trunc), used by the kFastDiv variant
     const FrameBlock* list;
@@ -645,184 +635,9 @@ __global__ void VerifyRcpKernel(int* __restrict__ mismatch) {
         atomicOr(mismatch, 2);
 }
 
-// kDiv: 0 = IEEE divisions; 1 = short sdf / trunc and 1 / (w + 1); 2, 3 = also
-// the short 1 / z with one / two Newton steps (whichever verified).
-template <typename weight_t, typename color_t, bool kColor, int kDiv>
-__device__ __forceinline__ void IntegrateRole(const HashView& hv,
-                                              const IntegParams& ip, int wg,
-                                              int n_wg) {
-    using TVec = Vec<float, 4, 16>;
-    using WVec = Vec<weight_t, 4, 4 * sizeof(weight_t)>;
-    using CVec = Vec<color_t, 12, 4 * sizeof(color_t)>;
-    float* __restrict__ tsdf_base = ip.tsdf;
-    weight_t* __restrict__ weight_base = (weight_t*)ip.weight;
-    color_t* __restrict__ color_base = (color_t*)ip.color;
-    const FrameBlock* __restrict__ list = ip.list;
-    int64_t n_blocks = *ip.count;
-    if (n_blocks > ip.list_capacity) n_blocks = ip.list_capacity;
-
-    if (wg == 0 && threadIdx.x == 0) {
-        if (ip.zero_counter) *ip.zero_counter = 0;
-        if (ip.prof_count) *ip.prof_count = (int)n_blocks;
-        if (ip.prof_map_size) *ip.prof_map_size = hv.counters[0];
-        if (ip.size_host) {
-            // The front roles of this group completed in an earlier launch,
-            // so heap_top is at least the map size after this group's
-            // activation (front roles of the next group may already be adding
-            // to it; the host only needs an upper bound).
-            ip.size_host[0] = hv.counters[0];
-            ip.size_host[1] = hv.counters[1];
-            ip.size_host[2] = (int)n_blocks;
-            __hip_atomic_store(&ip.size_host[3], ip.status_stamp,
-                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-
-    const int res = ip.resolution;
-    const int res3 = res * res * res;
-    const int quads_per_row = res >> 2;
-    const int n_quads = res3 >> 2;
-    const int parts = (n_quads + 255) >> 8;
-    const int64_t n_items = n_blocks * parts;
-    int frame_blocks = 0;  // lane 0 of part 0 counts block-frames
-
-    for (int64_t item = wg; item < n_items; item += n_wg) {
-        const int64_t b = item / parts;
-        const int part = (int)(item - b * parts);
-        // Wave-uniform block header: {slot, key} -> buffer index, frame bits.
-        const FrameBlock fb = list[b];
-        const int slot = __builtin_amdgcn_readfirstlane(fb.slot);
-        const int xb = __builtin_amdgcn_readfirstlane(fb.x);
-        const int yb = __builtin_amdgcn_readfirstlane(fb.y);
-        const int zb = __builtin_amdgcn_readfirstlane(fb.z);
-        const int block_idx =
-                __builtin_amdgcn_readfirstlane(hv.slot_vals[slot]);
-        // Frame bits of THIS group: its own plane of touch words (the front
-        // roles of the next group, running beside this role, write the other
-        // plane). A word of another stamp cannot occur; if it does, nothing
-        // is integrated for the block and the error surfaces on the host.
-        const unsigned long long word = *TouchWord(hv, slot, ip.touch_plane);
-        const bool own = (word >> kTouchBits) == ip.group_stamp;
-        if (!own && threadIdx.x == 0 && part == 0)
-            atomicOr(&hv.counters[1], kErrTouchStamp);
-        const unsigned bits = __builtin_amdgcn_readfirstlane(
-                own ? (unsigned)(word & ((1ull << kTouchBits) - 1ull)) : 0u);
-        const int64_t block_base = (int64_t)block_idx * res3;
-        if (part == 0 && threadIdx.x == 0 && ip.prof_frame_blocks)
-            frame_blocks += __popc(bits);
-
-        const int q = (part << 8) + threadIdx.x;
-        if (q >= n_quads) continue;
-        const int qx = q % quads_per_row;
-        const int row = q / quads_per_row;
-        const int yv = row % res;
-        const int zv = row / res;
-        const int x0 = xb * res + (qx << 2);
-        const float fy = (float)(yb * res + yv);
-        const float fz = (float)(zb * res + zv);
-        const int64_t lin0 = block_base + ((int64_t)q << 2);
-
-        TVec t4;
-        WVec w4;
-        CVec c12;
-        bool loaded = false;
-
-        for (int f = 0; f < ip.n_frames; ++f) {
-            if (!((bits >> f) & 1u)) continue;  // wave-uniform
-            Camera cam = ip.cam0;
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) cam.e[i][j] = ip.ext[f][i][j];
-            const PixelRec* __restrict__ recs = ip.recs[f];
-            // VoxelBlockGridImpl.h:244-267 with depth taken from the record.
-            float sdf[4];
-            unsigned rgba[4];
-            bool ok[4];
-            bool any = false;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float xc, yc, zc, u, v;
-                cam.RigidTransform((float)(x0 + j), fy, fz, xc, yc, zc);
-                if constexpr (kDiv >= 2) {
-                    // Camera::Project with the verified short reciprocal
-                    const float inv_z = RcpGuarded<kDiv - 1>(zc);
-                    u = cam.fx * xc * inv_z + cam.cx;
-                    v = cam.fy * yc * inv_z + cam.cy;
-                } else {
-                    cam.Project(xc, yc, zc, u, v);
-                }
-                ok[j] = InBoundary2D(u, v, ip.rows, ip.cols);
-                sdf[j] = 0.f;
-                rgba[j] = 0u;
-                if (ok[j]) {
-                    const int ui = (int)u;
-                    const int vi = (int)v;
-                    const PixelRec r = recs[(int64_t)vi * ip.cols + ui];
-                    const float d = r.d;
-                    float sd = d - zc;
-                    if (d <= 0 || d > ip.depth_max || zc <= 0 ||
-                        sd < -ip.sdf_trunc) {
-                        ok[j] = false;
-                    } else {
-                        sd = sd < ip.sdf_trunc ? sd : ip.sdf_trunc;
-                        sdf[j] = kDiv >= 1
-                                         ? DivByConstGuarded(sd, ip.sdf_trunc,
-                                                             ip.inv_sdf_trunc)
-                                         : sd / ip.sdf_trunc;
-                        rgba[j] = r.rgba;
-                    }
-                }
-                any |= ok[j];
-            }
-            if (!any) continue;
-            if (!loaded) {
-                t4 = *reinterpret_cast<const TVec*>(tsdf_base + lin0);
-                w4 = *reinterpret_cast<const WVec*>(weight_base + lin0);
-                if constexpr (kColor)
-                    c12 = *reinterpret_cast<const CVec*>(color_base + 3 * lin0);
-                loaded = true;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (!ok[j]) continue;
-                // VoxelBlockGridImpl.h:269-302
-                float inv_wsum;
-                if constexpr (sizeof(weight_t) == 2)
-                    inv_wsum = kDiv >= 1
-                                       ? RcpSmallInt((float)((int)w4.v[j] + 1))
-                                       : 1.0f / (float)((int)w4.v[j] + 1);
-                else
-                    inv_wsum = 1.0f / (w4.v[j] + 1);
-                const float weight = (float)w4.v[j];
-                t4.v[j] = (weight * t4.v[j] + sdf[j]) * inv_wsum;
-                if constexpr (kColor) {
-                    if (rgba[j] >> 24) {
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) {
-                            // colour multiplier is 1 for uint8 input
-                            const float in =
-                                    (float)((rgba[j] >> (8 * i)) & 0xffu);
-                            c12.v[3 * j + i] = (color_t)(
-                                    (weight * (float)c12.v[3 * j + i] + in) *
-                                    inv_wsum);
-                        }
-                    }
-                }
-                w4.v[j] = (weight_t)(weight + 1);
-            }
-        }
-        if (loaded) {
-            *reinterpret_cast<TVec*>(tsdf_base + lin0) = t4;
-            *reinterpret_cast<WVec*>(weight_base + lin0) = w4;
-            if constexpr (kColor)
-                *reinterpret_cast<CVec*>(color_base + 3 * lin0) = c12;
-        }
-    }
-    if (frame_blocks) atomicAdd(ip.prof_frame_blocks, frame_blocks);
-}
-
-// ---- integrate role, wide form ---------------------------------------------
+// kDiv: 0 = IEEE divisions; 2 = the short sdf / trunc, 1 / (w + 1) and 1 / z
+// (one Newton step) forms, used once the on-device proof of all three is in.
+// ---- integrate role ---------------------------------------------------------
 // Same arithmetic, different schedule and instruction selection. The role is
 // bound by vector-ALU issue (profiles/r2a: ~55 % of the SIMD cycles issue VALU
 // work, HBM traffic is a third of what the fabric can carry), so the form
@@ -855,9 +670,9 @@ __device__ __forceinline__ f2 PkFma(f2 a, f2 b, f2 c) {
     return __builtin_elementwise_fma(a, b, c);
 }
 
-// kP = voxel pairs per lane: 2 (a lane owns 4 x-consecutive voxels; 16 / 8 /
-// 24-byte state accesses, ~127 registers, 4 waves per SIMD) or 1 (2 voxels per
-// lane: twice the work items at half the size and ~2/3 of the registers).
+// kP = voxel pairs per lane: 1 (2 x-consecutive voxels per lane, 72 registers,
+// 7 waves per SIMD; 4 voxels per lane -- kP = 2, ~127 registers -- measured 9 %
+// slower, profiles/r2q, and is no longer instantiated).
 // kRaw: depth and colour come from the frames' raw uint16 / uint8 images
 // instead of the prepared 8-byte records (IntegParams::raw_depth / raw_color): one
 // 2-byte and one (unaligned) 4-byte gather per voxel and frame, the depth
@@ -870,21 +685,13 @@ __device__ __forceinline__ f2 PkFma(f2 a, f2 b, f2 c) {
 // up to kChunkFrames frames (ChunkEntry::bits) to its register-resident voxels,
 // kChunk at a time; per-frame constants come from IntegParams::frame_tab.
 template <typename weight_t, typename color_t, bool kColor, int kDiv,
-          int kChunk, int kP, bool kRaw = false, bool kLong = false,
-          bool kPipe = false>
+          int kChunk, int kP, bool kRaw = false, bool kLong = false>
 __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                                                   const IntegParams& ip,
                                                   int wg, int n_wg,
                                                   int first_wg) {
     constexpr int kV = 2 * kP;             // voxels per lane
     constexpr int kVShift = kP == 2 ? 2 : 1;
-    // Raw form with colour, two phases per round: the depth gathers first;
-    // the colour pixel is fetched only by the lanes whose voxel the frame
-    // really updates (valid depth inside the truncation band -- a fraction of
-    // a touched block's voxels, and none at all in the waves a frame skips).
-    // The launch is bound by the vector-memory path, not by latency (DESIGN
-    // 7), and colour is 60 % of the raw form's cache lines.
-    constexpr bool kTwoPhase = kRaw && kColor && (O3DMI_RAW_TWO_PHASE != 0);
     // kLong: the frame table is read through the CONSTANT address space and
     // the images through the GLOBAL one. A plain pointer makes the table's
     // loads vector loads (stores of earlier work items may alias it as far as
@@ -936,20 +743,12 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
     const int rank = (wg - first_of_xcd) >> 3;
     const int n_on_xcd =
             first_of_xcd < n_wg ? ((n_wg - 1 - first_of_xcd) >> 3) + 1 : 0;
-    // Which blocks an XCD takes: every eighth one (deal 0: b = xcd + 8k), or a
-    // CONTIGUOUS eighth of the list (deal 1). The list is appended to by the
-    // touch workgroups roughly in ray-tile order, so a contiguous eighth is a
-    // band of the image: its blocks gather from the same record rows, which
-    // then sit in ONE XCD's L2 instead of in all eight (`read_overfetch`).
-    const int64_t per_xcd = (n_blocks + 7) >> 3;
-    const int64_t first_b = ip.deal ? xcd * per_xcd : xcd;
-    const int64_t blocks_on_xcd =
-            ip.deal ? (n_blocks - first_b < 0
-                               ? 0
-                               : (n_blocks - first_b < per_xcd
-                                          ? n_blocks - first_b
-                                          : per_xcd))
-                    : (n_blocks + 7 - xcd) >> 3;
+    // An XCD takes every eighth block (b = xcd + 8k). (A CONTIGUOUS eighth of
+    // the list -- roughly a band of the image per XCD, whose record rows then
+    // sit in one L2 -- read 4 % fewer bytes and was 2 % slower: the eighths are
+    // less even. profiles/r4m, dropped.)
+    const int64_t first_b = xcd;
+    const int64_t blocks_on_xcd = (n_blocks + 7 - xcd) >> 3;
     const int64_t n_items = blocks_on_xcd * parts;
     const unsigned sentinel_off =
             (unsigned)(ip.rows * ip.cols) * (unsigned)sizeof(PixelRec);
@@ -957,7 +756,8 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
     const float vscale = ip.cam0.scale;
     const float fx = ip.cam0.fx, fyk = ip.cam0.fy;
     const float cx = ip.cam0.cx, cy = ip.cam0.cy;
-    const float u_max = ip.cols - 1.0f, v_max = ip.rows - 1.0f;
+    const unsigned u_max_bits = __float_as_uint(ip.cols - 1.0f);
+    const unsigned v_max_bits = __float_as_uint(ip.rows - 1.0f);
     const unsigned last_col8 = (unsigned)(ip.rows * ip.cols) * 3u - 8u;
 
     // (Measured and dropped, profiles/r2l: persistent workgroups -- 1024 to
@@ -978,7 +778,7 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
             kb = m / parts;
             part = (int)(m - kb * parts);
         }
-        const int64_t b = ip.deal ? first_b + kb : first_b + (kb << 3);
+        const int64_t b = first_b + (kb << 3);
         unsigned long long item_t0 = 0ull;
         if constexpr (kLong)
             if (ip.prof_items && threadIdx.x == 0) item_t0 = wall_clock64();
@@ -1106,25 +906,23 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
         // below 65536; the weight's wrap at 65536 = what the uint16 store
         // keeps of it). Voxel pair p = voxels 2p, 2p + 1 of the lane.
         const TVec t4 = *reinterpret_cast<const TVec*>(tsdf_base + lin0);
-        f2 ts[kP];
-        f2 wf[kP];
-        f2 cf[kP][3];
+        float ts[kV];
+        float wf[kV];
+        float cf[kV][3];
 #pragma unroll
-        for (int p = 0; p < kP; ++p) ts[p] = f2{t4.v[2 * p], t4.v[2 * p + 1]};
+        for (int v = 0; v < kV; ++v) ts[v] = t4.v[v];
         {
             const WVec w4 = *reinterpret_cast<const WVec*>(weight_base + lin0);
 #pragma unroll
-            for (int p = 0; p < kP; ++p)
-                wf[p] = f2{(float)w4.v[2 * p], (float)w4.v[2 * p + 1]};
+            for (int v = 0; v < kV; ++v) wf[v] = (float)w4.v[v];
             if constexpr (kColor) {
                 const CVec c12 =
                         *reinterpret_cast<const CVec*>(color_base + 3 * lin0);
 #pragma unroll
-                for (int p = 0; p < kP; ++p)
+                for (int v = 0; v < kV; ++v)
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
-                        cf[p][i] = f2{(float)c12.v[6 * p + i],
-                                      (float)c12.v[6 * p + 3 + i]};
+                        cf[v][i] = (float)c12.v[3 * v + i];
             }
         }
 
@@ -1222,9 +1020,7 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                 for (int p = 0; p < kP; ++p) {
                     f2 r = f2{__builtin_amdgcn_rcpf(R.zc[fk][p].x),
                               __builtin_amdgcn_rcpf(R.zc[fk][p].y)};
-#pragma unroll
-                    for (int k = 0; k < (kDiv >= 2 ? kDiv - 1 : 1); ++k)
-                        r = PkFma(PkFma(-R.zc[fk][p], r, Splat(1.0f)), r, r);
+                    r = PkFma(PkFma(-R.zc[fk][p], r, Splat(1.0f)), r, r);
                     inv_z[p] = r;
                 }
             }
@@ -1236,8 +1032,16 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const float uh = h ? u.y : u.x, vh = h ? v.y : v.x;
-                    const bool in = vh >= 0 && uh >= 0 && vh <= v_max &&
-                                    uh <= u_max;
+                    // InBoundary (0 <= u <= W - 1, 0 <= v <= H - 1 on the
+                    // floats, GeometryIndexer.h) as ONE unsigned compare per
+                    // coordinate: non-negative floats order like their bit
+                    // patterns, every negative float (sign bit), NaN and inf
+                    // compare above the pattern of the non-negative bound.
+                    // The one value that would differ, u = -0.0f (>= 0 in
+                    // IEEE), needs a principal point of -0.0f, which the host
+                    // turns into +0.0f (same sums bit for bit).
+                    const bool in = __float_as_uint(vh) <= v_max_bits &&
+                                    __float_as_uint(uh) <= u_max_bits;
                     // 32-bit byte offset from a wave-uniform base; the
                     // sentinel record (depth 0) for voxels outside the image
                     // (24-bit multiply: rows and the row pitch are far below
@@ -1256,11 +1060,7 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                         r.d = __uint_as_float(
                                 (unsigned)*(U16G*)(dimg + 2u * pix));
                         r.rgba = 0u;
-                        if constexpr (kTwoPhase) {
-                            // the colour is fetched in `apply`, by the lanes
-                            // that need it: keep the pixel
-                            R.csh[fk][2 * p + h] = pix;
-                        } else if constexpr (kColor) {
+                        if constexpr (kColor) {
                             // the 3 bytes at 3 * pix out of ONE aligned 8-byte
                             // load (an unaligned 4-byte load is split by the
                             // memory pipeline); the address is clamped so that
@@ -1279,8 +1079,7 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                             __umul24((unsigned)(int)vh, row_bytes) +
                             (unsigned)(int)uh * (unsigned)sizeof(PixelRec);
                     R.rec[fk][2 * p + h] = *reinterpret_cast<const PixelRec*>(
-                            recs + (ip.diag == 1 ? 0u
-                                                 : (in ? off : sentinel_off)));
+                            recs + (in ? off : sentinel_off));
                     }
                 }
             }
@@ -1312,53 +1111,23 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
             }
         };
         auto apply = [&](int c0, Round& R) {
-        if constexpr (kTwoPhase) {
-            // second phase of the round's gathers: colour, for the voxels the
-            // frame updates (`ok` below, evaluated the same way)
-#pragma unroll
-            for (int fk = 0; fk < kChunk; ++fk) {
-                if (!((R.cbits >> fk) & 1u)) continue;  // wave-uniform
-                const int f = c0 + fk;
-                ByteG* __restrict__ cimg = (ByteG*)(
-                        kLong ? (const void*)ftab[f].color
-                              : *(&ip.raw_color[kLong ? 0 : f] + opaque));
-                convert_depth(fk, R);
-#pragma unroll
-                for (int p = 0; p < kP; ++p) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const float dh = R.rec[fk][2 * p + h].d;
-                        const float zh = h ? R.zc[fk][p].y : R.zc[fk][p].x;
-                        const bool okv = !(dh <= 0) && !(dh > ip.depth_max) &&
-                                         !(zh <= 0) &&
-                                         !((dh - zh) < -ip.sdf_trunc);
-                        unsigned lo = 0u, hi = 0u, shf = 0u;
-                        if (okv) {
-                            // the 3 bytes at 3 * pix out of ONE aligned 8-byte
-                            // load, clamped to the end of the image
-                            const unsigned b3 = 3u * R.csh[fk][2 * p + h];
-                            unsigned al = b3 & ~3u;
-                            al = al < last_col8 ? al : last_col8;
-                            const U2v q = *(U2G*)(cimg + al);
-                            lo = q.x;
-                            hi = q.y;
-                            shf = (b3 - al) * 8u;
-                        }
-                        R.rec[fk][2 * p + h].rgba = lo;
-                        R.chi[fk][2 * p + h] = hi;
-                        R.csh[fk][2 * p + h] = shf;
-                    }
-                }
-            }
-        }
-        // 3. frames applied in order (VoxelBlockGridImpl.h:258-302)
+        // 3. frames applied in order (VoxelBlockGridImpl.h:258-302). The
+        // update of a voxel runs under the voxel's own predicate (an
+        // exec-masked region per voxel of the lane) instead of being computed
+        // for every lane and selected. Why: on gfx950 a v_cndmask, a v_cmp, a
+        // v_trunc or a conversion occupies the SIMD's issue for 4.3 cycles, a
+        // plain float32 multiply / add / fma for 2.4, and a PACKED float32
+        // instruction for 4.3 -- no cheaper than the two plain ones it
+        // replaces (profiles/r5b_valu_calibration.json). Rounds 2-4 ran this
+        // block as packed pairs with two selects per state value; the selects
+        // were a quarter of its cycles. A region whose predicate is false in
+        // every lane of the wave is jumped over (s_cbranch_execz): the
+        // wave-level "no voxel takes this frame" test of the packed form is
+        // implied. Same IEEE operations, operands and order: same bits.
 #pragma unroll
         for (int fk = 0; fk < kChunk; ++fk) {
             if (!((R.cbits >> fk) & 1u)) continue;  // wave-uniform
-            f2 sdf[kP];
-            bool ok[kV];
-            bool tiny = false;
-            if constexpr (kRaw && !kTwoPhase) convert_depth(fk, R);
+            if constexpr (kRaw) convert_depth(fk, R);
 #pragma unroll
             for (int p = 0; p < kP; ++p) {
 #pragma unroll
@@ -1366,115 +1135,67 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                     const float dh = R.rec[fk][2 * p + h].d;
                     const float zh = h ? R.zc[fk][p].y : R.zc[fk][p].x;
                     const float sh = dh - zh;
-                    ok[2 * p + h] = !(dh <= 0) && !(dh > ip.depth_max) &&
+                    const bool ok = !(dh <= 0) && !(dh > ip.depth_max) &&
                                     !(zh <= 0) && !(sh < -ip.sdf_trunc);
-                    const float cl = sh < ip.sdf_trunc ? sh : ip.sdf_trunc;
-                    if (h) sdf[p].y = cl; else sdf[p].x = cl;
-                    tiny |= ok[2 * p + h] && fabsf(cl) < kDivTiny;
-                    touched |= ok[2 * p + h];
-                }
-            }
-            // A wave none of whose voxels takes this frame (all behind the
-            // truncation band, outside the image or at invalid depth) skips
-            // the frame's arithmetic altogether: wave-uniform, nothing of the
-            // state changes for a rejected voxel.
-            if (ip.diag != 3) {
-                bool any = false;
+                    if (!ok) continue;
+                    touched = true;
+                    // sh < trunc ? sh : trunc as ONE v_min_f32 (2.4 cycles
+                    // against 11 for move + compare + select): the same
+                    // value for every input -- sh comes out of a subtraction,
+                    // so it is no signalling NaN, and for a quiet NaN both
+                    // forms give trunc; -0.0 stays -0.0.
+                    float cl;
+                    asm("v_min_f32 %0, %1, %2"  // src0 may be a scalar register
+                        : "=v"(cl)
+                        : "s"(ip.sdf_trunc), "v"(sh));
+                    // sdf / sdf_trunc: the verified short form, the IEEE
+                    // sequence in the underflow range
+                    float sd;
+                    if (kDiv < 1 || fabsf(cl) < kDivTiny)
+                        sd = cl / ip.sdf_trunc;
+                    else
+                        sd = DivByConst(cl, ip.sdf_trunc, ip.inv_sdf_trunc);
+                    const int vx = 2 * p + h;
+                    const float weight = wf[vx];
+                    const float wsum = weight + 1.0f;  // exact (<= 65536)
+                    float inv_wsum;
+                    if constexpr (kU16 && kDiv >= 1) inv_wsum = RcpSmallInt(wsum);
+                    else inv_wsum = 1.0f / wsum;
+                    const float t_new = (weight * ts[vx] + sd) * inv_wsum;
+                    ts[vx] = t_new;
+                    if constexpr (kColor) {
+                        unsigned rg = R.rec[fk][2 * p + h].rgba;
+                        if constexpr (kRaw)
+                            rg = (unsigned)((((unsigned long long)
+                                                      R.chi[fk][2 * p + h]
+                                              << 32) | rg) >>
+                                            R.csh[fk][2 * p + h]);
+                        // (raw form: the colour pixel IS the depth pixel,
+                        // inside the image whenever the voxel is ok)
+                        if (kRaw || (rg >> 24)) {
 #pragma unroll
-                for (int v = 0; v < kV; ++v) any |= ok[v];
-                if (__builtin_amdgcn_ballot_w64(any) == 0ull) continue;
-            }
-            // sdf / sdf_trunc: short form unless a value of the wave is in the
-            // underflow range
-            if (kDiv < 1 || __builtin_amdgcn_ballot_w64(tiny) != 0ull) {
-#pragma unroll
-                for (int p = 0; p < kP; ++p)
-                    sdf[p] = f2{sdf[p].x / ip.sdf_trunc,
-                                sdf[p].y / ip.sdf_trunc};
-            } else {
-#pragma unroll
-                for (int p = 0; p < kP; ++p) {
-                    const f2 q0 = sdf[p] * ip.inv_sdf_trunc;
-                    const f2 r = PkFma(Splat(-ip.sdf_trunc), q0, sdf[p]);
-                    sdf[p] = PkFma(r, Splat(ip.inv_sdf_trunc), q0);
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < kP; ++p) {
-                const f2 weight = wf[p];
-                const f2 wsum = weight + 1.0f;  // exact (integers <= 65536)
-                f2 inv_wsum;
-                if constexpr (kU16 && kDiv >= 1) {
-                    // RcpSmallInt, packed
-                    const f2 r0 = f2{__builtin_amdgcn_rcpf(wsum.x),
-                                     __builtin_amdgcn_rcpf(wsum.y)};
-                    inv_wsum = PkFma(PkFma(-wsum, r0, Splat(1.0f)), r0, r0);
-                } else {
-                    inv_wsum = f2{1.0f / wsum.x, 1.0f / wsum.y};
-                }
-                const f2 t_new = (weight * ts[p] + sdf[p]) * inv_wsum;
-                ts[p] = f2{ok[2 * p] ? t_new.x : ts[p].x,
-                           ok[2 * p + 1] ? t_new.y : ts[p].y};
-                if constexpr (kColor) {
-                    unsigned rg0 = R.rec[fk][2 * p].rgba;
-                    unsigned rg1 = R.rec[fk][2 * p + 1].rgba;
-                    if constexpr (kRaw) {
-                        rg0 = (unsigned)((((unsigned long long)R.chi[fk][2 * p]
-                                           << 32) | rg0) >> R.csh[fk][2 * p]);
-                        rg1 = (unsigned)((((unsigned long long)
-                                                   R.chi[fk][2 * p + 1] << 32) |
-                                          rg1) >> R.csh[fk][2 * p + 1]);
+                            for (int i = 0; i < 3; ++i) {
+                                const float in =
+                                        (float)((rg >> (8 * i)) & 0xffu);
+                                float c_new =
+                                        (weight * cf[vx][i] + in) * inv_wsum;
+                                if constexpr (sizeof(color_t) == 2)
+                                    c_new = truncf(c_new);
+                                cf[vx][i] = c_new;
+                            }
+                        }
                     }
-                    // (raw form: the colour pixel IS the depth pixel, inside
-                    // the image whenever the voxel is ok)
-                    const bool has0 = ok[2 * p] && (kRaw || (rg0 >> 24));
-                    const bool has1 = ok[2 * p + 1] && (kRaw || (rg1 >> 24));
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        const f2 in = f2{(float)((rg0 >> (8 * i)) & 0xffu),
-                                         (float)((rg1 >> (8 * i)) & 0xffu)};
-                        f2 c_new = (weight * cf[p][i] + in) * inv_wsum;
-                        if constexpr (sizeof(color_t) == 2)
-                            c_new = f2{truncf(c_new.x), truncf(c_new.y)};
-                        cf[p][i] = f2{has0 ? c_new.x : cf[p][i].x,
-                                      has1 ? c_new.y : cf[p][i].y};
+                    wf[vx] = wsum;
+                    if constexpr (kU16) {
+                        // what the uint16 store keeps of 65536 (a branch that
+                        // is taken once in 65536 frames, not a select)
+                        if (wsum >= 65536.0f) wf[vx] = 0.0f;
                     }
                 }
-                f2 w_new = wsum;
-                if constexpr (kU16)
-                    w_new = f2{w_new.x >= 65536.0f ? 0.0f : w_new.x,
-                               w_new.y >= 65536.0f ? 0.0f : w_new.y};
-                wf[p] = f2{ok[2 * p] ? w_new.x : weight.x,
-                           ok[2 * p + 1] ? w_new.y : weight.y};
             }
         }
         };
-        if constexpr (kLong && kPipe) {
-            // Software pipeline over the rounds (O3DMI_SLICED_PIPE=1): the NEXT
-            // round's gathers are in flight while this round's frames are
-            // applied; rounds of kPipeChunk = 2 frames keep the double set of
-            // round registers within five waves per SIMD. Measured: no gain
-            // (profiles/r4p) -- see StreamIntegrateSliced.
-            const int n_fr = ip.n_frames;
-            auto next_round = [&](int from, Round& R) -> int {
-                for (int c = from; c < n_fr; c += kChunk) {
-                    R.cbits = round_bits(c);
-                    if (R.cbits != 0u) return c;  // wave-uniform
-                }
-                return -1;
-            };
-            Round ra, rb;
-            int ca = next_round(0, ra);
-            if (ca >= 0) issue(ca, ra);
-#pragma nounroll
-            while (ca >= 0) {
-                const int cb = next_round(ca + kChunk, rb);
-                if (cb >= 0) issue(cb, rb);
-                apply(ca, ra);
-                ca = cb;
-                ra = rb;
-            }
-        } else if constexpr (kLong) {
+        if constexpr (kLong) {
 #pragma nounroll
             for (int c0 = 0; c0 < ip.n_frames; c0 += kChunk) {
                 Round r;
@@ -1498,15 +1219,15 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                 apply(c0, r);
             }
         }
-        if (touched && ip.diag != 2) {
+        if (touched) {
             TVec t_out;
             WVec w4;
 #pragma unroll
             for (int p = 0; p < kP; ++p) {
-                t_out.v[2 * p] = ts[p].x;
-                t_out.v[2 * p + 1] = ts[p].y;
-                w4.v[2 * p] = (weight_t)wf[p].x;
-                w4.v[2 * p + 1] = (weight_t)wf[p].y;
+                t_out.v[2 * p] = ts[2 * p];
+                t_out.v[2 * p + 1] = ts[2 * p + 1];
+                w4.v[2 * p] = (weight_t)wf[2 * p];
+                w4.v[2 * p + 1] = (weight_t)wf[2 * p + 1];
             }
             *reinterpret_cast<TVec*>(tsdf_base + lin0) = t_out;
             *reinterpret_cast<WVec*>(weight_base + lin0) = w4;
@@ -1516,8 +1237,8 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                 for (int p = 0; p < kP; ++p)
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
-                        c12.v[6 * p + i] = (color_t)cf[p][i].x;
-                        c12.v[6 * p + 3 + i] = (color_t)cf[p][i].y;
+                        c12.v[6 * p + i] = (color_t)cf[2 * p][i];
+                        c12.v[6 * p + 3 + i] = (color_t)cf[2 * p + 1][i];
                     }
                 *reinterpret_cast<CVec*>(color_base + 3 * lin0) = c12;
             }
@@ -1554,10 +1275,10 @@ struct StepParams {
 static_assert(sizeof(StepParams) <= 4096, "kernel arguments are limited to 4 KB");
 
 
-// kForm: 0 = first form of the integrate role; 1 = wide form, 4 voxels per
-// lane (119 registers, 4 waves per SIMD); 2 = wide form, 2 voxels per lane
-// (72 registers, 7 waves per SIMD). Both wide forms apply a group of up to 8
-// frames in chunks of kGroupChunk = 4 to the register-resident voxel state.
+// The launch of a frame group: front roles of the NEXT group + the integrate
+// role of this one (2 voxels per lane: 72 registers, 7 waves per SIMD), which
+// applies the group's frames in chunks of kGroupChunk = 4 to the register-
+// resident voxel state.
 // Frames of a round of the raw / long form (the chunk launch of the sliced
 // path): a rank's share of a chunk is a few hundred blocks, about one round of
 // the chip, so a work item's chain of dependent memory round trips is what the
@@ -1571,9 +1292,8 @@ static_assert(sizeof(StepParams) <= 4096, "kernel arguments are limited to 4 KB"
 #define O3DMI_RAW_WAVES 5
 #endif
 constexpr int kRawChunk = O3DMI_RAW_CHUNK;
-template <typename weight_t, typename color_t, bool kColor, int kDiv,
-          int kForm>
-__global__ void __launch_bounds__(256, kForm == 0 ? 1 : (kForm == 1 ? 4 : 7))
+template <typename weight_t, typename color_t, bool kColor, int kDiv>
+__global__ void __launch_bounds__(256, 7)
 FrameStepKernel(StepParams sp) {
     const int b = (int)blockIdx.x;
     const int n_front_wg = sp.n_fronts * sp.front_wg;
@@ -1581,14 +1301,10 @@ FrameStepKernel(StepParams sp) {
         const int f = b / sp.front_wg;
         const FrontParams fp(sp.fshared, sp.front[f]);
         FrontRole(sp.hv, fp, b - f * sp.front_wg);
-    } else if constexpr (kForm != 0) {
-        IntegrateRoleWide<weight_t, color_t, kColor, kDiv, kGroupChunk,
-                          kForm == 2 ? 1 : 2>(
+    } else {
+        IntegrateRoleWide<weight_t, color_t, kColor, kDiv, kGroupChunk, 1>(
                 sp.hv, sp.integ, b - n_front_wg, (int)gridDim.x - n_front_wg,
                 n_front_wg);
-    } else {
-        IntegrateRole<weight_t, color_t, kColor, kDiv>(
-                sp.hv, sp.integ, b - n_front_wg, (int)gridDim.x - n_front_wg);
     }
 }
 
@@ -1600,32 +1316,25 @@ struct ChunkParams {
 };
 // kRaw = false: the frames' prepared records (one 8-byte gather per voxel and
 // frame, the per-group role's registers and occupancy); true: raw images.
-// kPipe: software-pipelined rounds of kPipeChunk frames (few ranks' worth of
-// blocks per launch: latency-bound); else 4-frame rounds at full occupancy.
-constexpr int kPipeChunk = 2;
+// (Software-pipelined rounds -- the next round's gathers in flight during this
+// round's arithmetic -- cost two waves of occupancy and were 0-10 % slower:
+// profiles/r4p, dropped.)
 template <typename weight_t, typename color_t, bool kColor, int kDiv,
-          bool kRaw, bool kPipe>
-__global__ void __launch_bounds__(256, kPipe ? 5 : (kRaw ? O3DMI_RAW_WAVES : 7))
+          bool kRaw>
+__global__ void __launch_bounds__(256, kRaw ? O3DMI_RAW_WAVES : 7)
 ChunkIntegrateKernel(ChunkParams cp) {
     IntegrateRoleWide<weight_t, color_t, kColor, kDiv,
-                      kPipe ? kPipeChunk : (kRaw ? kRawChunk : kGroupChunk), 1,
-                      kRaw, true, kPipe>(cp.hv, cp.integ, (int)blockIdx.x,
-                                         (int)gridDim.x, 0);
+                      kRaw ? kRawChunk : kGroupChunk, 1, kRaw, true>(
+            cp.hv, cp.integ, (int)blockIdx.x, (int)gridDim.x, 0);
 }
 
 }  // namespace
 
 // The compact lane -> voxel map of the wide integrate role (default; needs a
-// power-of-two resolution >= 8; O3DMI_LANE_CUBE=0 = the slab map, for A / B:
+// power-of-two resolution >= 8, else the slab map; against the slab map:
 // profiles/r4zf -- chunk launch at 8 ranks 486 k -> 525 k frames/s, single-GPU
 // stream 127.6 k -> 128.6 k).
-static int LaneCube(int res_shift) {
-    static const int want = []() {
-        const char* e = std::getenv("O3DMI_LANE_CUBE");
-        return e ? std::atoi(e) : 1;
-    }();
-    return (want && res_shift >= 3) ? 1 : 0;
-}
+static int LaneCube(int res_shift) { return res_shift >= 3 ? 1 : 0; }
 
 bool PrepTables(const double* depth_intrinsic, const double* color_intrinsic,
                 int rows, int cols, int color_rows, int color_cols,
@@ -1714,8 +1423,10 @@ static std::mutex g_div_mu;
 static std::map<std::pair<int, unsigned>, DivProof> g_div_proofs;
 
 static int DivFormsFromFlags(int host) {
-    // bits 1|2: sdf / w forms; 4: 1/z one step; 8: two steps
-    return (host & 3) ? 0 : (!(host & 4) ? 2 : (!(host & 8) ? 3 : 1));
+    // bits 1|2: sdf / w forms failed; 4: 1/z with one Newton step failed.
+    // All three short forms or none (the parts this was measured on verify
+    // all of them; IEEE forms are ~4 % slower, never wrong).
+    return (host & 7) ? 0 : 2;
 }
 
 static void DivProofReport(float b, int ok, int flags) {
@@ -1724,10 +1435,7 @@ static void DivProofReport(float b, int ok, int flags) {
                  "[o3dmi] exact short division for sdf_trunc = %.9g: %s "
                  "(flags %d)\n",
                  (double)b,
-                 ok == 0 ? "not used"
-                         : (ok == 1 ? "sdf, 1/(w+1)"
-                                    : (ok == 2 ? "sdf, 1/(w+1), 1/z (1 step)"
-                                               : "sdf, 1/(w+1), 1/z (2 steps)")),
+                 ok == 0 ? "not used" : "sdf, 1/(w+1), 1/z (1 step)",
                  flags);
 }
 
@@ -1767,8 +1475,6 @@ static int VerifyFastDivision(float b, float* y_out, bool wait = false) {
                                p.stream, p.flag_dev);
             hipLaunchKernelGGL(VerifyRcpZKernel<1>, dim3(kCUs * 16), dim3(256),
                                0, p.stream, p.flag_dev, 4);
-            hipLaunchKernelGGL(VerifyRcpZKernel<2>, dim3(kCUs * 16), dim3(256),
-                               0, p.stream, p.flag_dev, 8);
             ok = hipGetLastError() == hipSuccess &&
                  hipMemcpyAsync(p.flag_host, p.flag_dev, sizeof(int),
                                 hipMemcpyDeviceToHost, p.stream) ==
@@ -1808,17 +1514,14 @@ int PrefetchFastDivision(float sdf_trunc, bool wait) {
     return VerifyFastDivision(sdf_trunc, &y, wait);
 }
 
-// O3DMI_STEP_VARIANT (diagnostics / A-B measurements, results identical):
-// 0 = first form of the integrate role, 1 = wide form with 4 voxels per lane,
-// 2 = wide form with 2 voxels per lane (default: 72 registers, 7 waves per
-// SIMD; with 8-frame groups 107 k frames/s against 98 k for form 1 and 72 k
-// for form 0, profiles/r2q).
-static int StepForm() {
-    static const int form = []() {
-        const char* e = std::getenv("O3DMI_STEP_VARIANT");
-        return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 2;
-    }();
-    return form;
+// The integrate role tests InBoundary with unsigned compares on the float
+// patterns (IntegrateRoleWide), which read u = -0.0f as outside; u = x + cx is
+// -0.0f only if cx is: a principal point of -0.0f becomes +0.0f (x + -0.0f and
+// x + 0.0f differ for x = -0.0f alone, where both are inside and truncate to
+// pixel 0 -- results do not change).
+static void CanonicalPrincipalPoint(Camera& c) {
+    if (c.cx == 0.0f) c.cx = 0.0f;
+    if (c.cy == 0.0f) c.cy = 0.0f;
 }
 
 int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
@@ -1904,7 +1607,10 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         for (int f = 0; f < a->n_frames; ++f) {
             const Camera cf = Camera::Make(a->depth_intrinsic, a->extrinsic[f],
                                            a->voxel_size);
-            if (f == 0) ip.cam0 = cf;
+            if (f == 0) {
+                ip.cam0 = cf;
+                CanonicalPrincipalPoint(ip.cam0);
+            }
             std::memcpy(ip.ext[f], cf.e, sizeof(ip.ext[f]));
             ip.recs[f] = a->recs[f];
             ip.raw_depth[f] = nullptr;
@@ -1913,20 +1619,6 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         ip.rows = a->rows;
         ip.cols = a->cols;
         ip.resolution = a->resolution;
-        static const int diag = []() {
-            const char* e = std::getenv("O3DMI_STEP_DIAG");
-            return e ? std::atoi(e) : 0;
-        }();
-        ip.diag = diag;
-        // O3DMI_STEP_DEAL=1 (A / B, profiles/r4m): contiguous eighths -- reads
-        // 2.03 -> 1.95 x the minimum, 2 % SLOWER (128.3 k -> 125.5 k frames/s:
-        // the list is only roughly in tile order, and eighths of it are less
-        // even than every eighth block)
-        static const int deal = []() {
-            const char* e = std::getenv("O3DMI_STEP_DEAL");
-            return e ? std::atoi(e) : 0;
-        }();
-        ip.deal = deal;
         ip.res_shift = -1;
         for (int sh = 2; sh < 12; ++sh)
             if ((1 << sh) == a->resolution) ip.res_shift = sh;
@@ -1935,12 +1627,7 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         ip.depth_max = a->depth_max;
         fast_div = VerifyFastDivision(a->sdf_trunc, &ip.inv_sdf_trunc);
         ip.list = a->list;
-        // O3DMI_STEP_READY=0 (A / B): header from the list + the hash
-        static const bool use_ready = [] {
-            const char* e = std::getenv("O3DMI_STEP_READY");
-            return !(e && e[0] == '0');
-        }();
-        ip.ready = use_ready ? a->ready : nullptr;
+        ip.ready = a->ready;
         ip.count = a->count;
         ip.list_capacity = a->list_capacity;
         ip.tsdf = a->tsdf;
@@ -1953,8 +1640,7 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         ip.prof_frame_blocks = a->prof_frame_blocks;
         ip.prof_map_size = a->prof_map_size;
         const int n_quads =
-                (a->resolution * a->resolution * a->resolution) >>
-                (StepForm() == 2 ? 1 : 2);
+                (a->resolution * a->resolution * a->resolution) >> 1;
         const int parts = (n_quads + 255) >> 8;
         // Grid from the expected block count (previous group + slack); the
         // role strides, so an under-estimate only costs balance.
@@ -1962,45 +1648,19 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         const int64_t g_max = (int64_t)kCUs * 32;
         if (g > g_max) g = g_max;
         if (g < kCUs) g = kCUs;
-        // O3DMI_STEP_GRID=n (diagnostics): fixed number of integrate
-        // workgroups, e.g. 1024 = the resident set, each striding over items
-        static const int fixed_grid = []() {
-            const char* e = std::getenv("O3DMI_STEP_GRID");
-            return e ? std::atoi(e) : 0;
-        }();
-        if (fixed_grid > 0) g = fixed_grid;
         n_int_wg = (int)g;
         grid_dtype = a->grid_dtype;
         col = a->with_color && a->color != nullptr;
     }
     dim3 grid((unsigned)(n_fronts * sp.front_wg + n_int_wg)), block(256);
-    // O3DMI_STEP_VARIANT=0 selects the first form of the integrate role
-    // (diagnostics / A-B measurements); results are identical.
-    const int form = StepForm();
-#define O3DMI_LAUNCH_STEP_D(WT, VT, COLOR, D)                                 \
-    do {                                                                      \
-        switch (form) {                                                       \
-            case 0:                                                           \
-                hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR, D, 0>),    \
-                                   grid, block, 0, s, sp);                    \
-                break;                                                        \
-            case 1:                                                           \
-                hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR, D, 1>),    \
-                                   grid, block, 0, s, sp);                    \
-                break;                                                        \
-            default:                                                          \
-                hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR, D, 2>),    \
-                                   grid, block, 0, s, sp);                    \
-        }                                                                     \
-    } while (0)
 #define O3DMI_LAUNCH_STEP(WT, VT, COLOR)                                      \
     do {                                                                      \
-        switch (fast_div) {                                                   \
-            case 3: O3DMI_LAUNCH_STEP_D(WT, VT, COLOR, 3); break;             \
-            case 2: O3DMI_LAUNCH_STEP_D(WT, VT, COLOR, 2); break;             \
-            case 1: O3DMI_LAUNCH_STEP_D(WT, VT, COLOR, 1); break;             \
-            default: O3DMI_LAUNCH_STEP_D(WT, VT, COLOR, 0); break;            \
-        }                                                                     \
+        if (fast_div == 2)                                                    \
+            hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR, 2>), grid,     \
+                               block, 0, s, sp);                              \
+        else                                                                  \
+            hipLaunchKernelGGL((FrameStepKernel<WT, VT, COLOR, 0>), grid,     \
+                               block, 0, s, sp);                              \
     } while (0)
     if (grid_dtype == O3DMI_U16) {
         if (col) O3DMI_LAUNCH_STEP(uint16_t, uint16_t, true);
@@ -2010,7 +1670,6 @@ int LaunchFrameStep(o3dmi_hash* bh, const FrameFrontArgs* fronts, int n_fronts,
         else O3DMI_LAUNCH_STEP(float, float, false);
     }
 #undef O3DMI_LAUNCH_STEP
-#undef O3DMI_LAUNCH_STEP_D
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
 }
@@ -2028,11 +1687,10 @@ int LaunchChunkIntegrate(o3dmi_hash* bh, const ChunkIntegrateArgs& a,
     static const double eye4[16] = {1, 0, 0, 0, 0, 1, 0, 0,
                                     0, 0, 1, 0, 0, 0, 0, 1};
     ip.cam0 = Camera::Make(a.depth_intrinsic, eye4, a.voxel_size);
+    CanonicalPrincipalPoint(ip.cam0);
     ip.rows = a.rows;
     ip.cols = a.cols;
     ip.resolution = a.resolution;
-    ip.diag = 0;
-    ip.deal = 0;
     ip.res_shift = -1;
     for (int sh = 2; sh < 12; ++sh)
         if ((1 << sh) == a.resolution) ip.res_shift = sh;
@@ -2085,31 +1743,19 @@ int LaunchChunkIntegrate(o3dmi_hash* bh, const ChunkIntegrateArgs& a,
     }
 #define O3DMI_LAUNCH_CHUNK_D(WT, VT, COLOR, D)                                \
     do {                                                                      \
-        if (a.raw && a.pipelined)                                             \
+        if (a.raw)                                                            \
             hipLaunchKernelGGL(                                               \
-                    (ChunkIntegrateKernel<WT, VT, COLOR, D, true, true>),     \
-                    grid, block, 0, s, cp);                                   \
-        else if (a.raw)                                                       \
-            hipLaunchKernelGGL(                                               \
-                    (ChunkIntegrateKernel<WT, VT, COLOR, D, true, false>),    \
-                    grid, block, 0, s, cp);                                   \
-        else if (a.pipelined)                                                 \
-            hipLaunchKernelGGL(                                               \
-                    (ChunkIntegrateKernel<WT, VT, COLOR, D, false, true>),    \
-                    grid, block, 0, s, cp);                                   \
+                    (ChunkIntegrateKernel<WT, VT, COLOR, D, true>), grid,     \
+                    block, 0, s, cp);                                         \
         else                                                                  \
             hipLaunchKernelGGL(                                               \
-                    (ChunkIntegrateKernel<WT, VT, COLOR, D, false, false>),   \
-                    grid, block, 0, s, cp);                                   \
+                    (ChunkIntegrateKernel<WT, VT, COLOR, D, false>), grid,    \
+                    block, 0, s, cp);                                         \
     } while (0)
 #define O3DMI_LAUNCH_CHUNK(WT, VT, COLOR)                                     \
     do {                                                                      \
-        switch (fast_div) {                                                   \
-            case 3: O3DMI_LAUNCH_CHUNK_D(WT, VT, COLOR, 3); break;            \
-            case 2: O3DMI_LAUNCH_CHUNK_D(WT, VT, COLOR, 2); break;            \
-            case 1: O3DMI_LAUNCH_CHUNK_D(WT, VT, COLOR, 1); break;            \
-            default: O3DMI_LAUNCH_CHUNK_D(WT, VT, COLOR, 0); break;           \
-        }                                                                     \
+        if (fast_div == 2) O3DMI_LAUNCH_CHUNK_D(WT, VT, COLOR, 2);            \
+        else O3DMI_LAUNCH_CHUNK_D(WT, VT, COLOR, 0);                          \
     } while (0)
     if (a.grid_dtype == O3DMI_U16) {
         if (col) O3DMI_LAUNCH_CHUNK(uint16_t, uint16_t, true);

@@ -1090,8 +1090,6 @@ def test_multiscale_icp_is_run_to_run_identical(monkeypatch):
     first = run()
     for _ in range(19):
         assert run() == first
-    monkeypatch.setenv("O3DMI_SERIAL_PYRAMID", "1")
-    assert run() == first
 
 
 # ------------------------------------------------ TransformationEstimation RMSE
@@ -1400,70 +1398,9 @@ def test_library_rccl_communicator_single_rank():
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_in_launch_gauss_newton_step_equals_the_host_solved_iteration(dtype):
-    """O3DMI_ICP_DEVICE_SOLVE=1 (opt-in, measured not faster -- see
-    host/registration.cpp): a point-to-plane iteration as ONE launch. The last
-    workgroup of the search launch adds the partial rows (FinalSumKernel's
-    order), solves the 6x6 system and leaves the update on the device, and the
-    driver queues iteration k + 1 before it has read iteration k. Against the
-    default two-launch iteration with the solve on the host: same iteration
-    counts, per-iteration fitness / rmse and pose equal to the rounding of the
-    float64 sums (the two paths cut the partial rows differently) and of
-    sin / cos (device vs host libm), single- and multi-scale, zero iterations,
-    a scale that stops early; repeated runs are bit-identical."""
-    import os
-    _lib, reg = _gpu()
-    p = _pair(60000, seed=11, dtype=dtype)
-    src = torch.from_numpy(p["source"]).cuda()
-    tgt = torch.from_numpy(p["target"]).cuda()
-    nrm = torch.from_numpy(p["target_normals"]).cuda()
-    cases = [([-1.0], [reg.ICPConvergenceCriteria(1e-6, 1e-6, 30)], [0.07]),
-             ([0.05, 0.025, 0.0125],
-              [reg.ICPConvergenceCriteria(1e-6, 1e-6, n) for n in (20, 10, 5)],
-              [0.15, 0.075, 0.0375]),
-             ([-1.0], [reg.ICPConvergenceCriteria(1e-6, 1e-6, 0)], [0.07]),
-             ([0.05, -1.0], [reg.ICPConvergenceCriteria(0.5, 0.5, 4),
-                             reg.ICPConvergenceCriteria(1e-9, 1e-9, 3)],
-              [0.15, 0.07])]
-
-    def run(vs, crit, md):
-        log = []
-        r = reg.multi_scale_icp(
-            src.clone(), tgt, nrm, vs, crit, md,
-            callback_after_iteration=lambda d: log.append(
-                (d["iteration_index"], d["scale_index"],
-                 d["scale_iteration_index"], d["fitness"], d["inlier_rmse"])))
-        torch.cuda.synchronize()
-        return r, log
-
-    for vs, crit, md in cases:
-        slow, slog = run(vs, crit, md)
-        os.environ["O3DMI_ICP_DEVICE_SOLVE"] = "1"
-        try:
-            fast, flog = run(vs, crit, md)
-            again, alog = run(vs, crit, md)
-        finally:
-            del os.environ["O3DMI_ICP_DEVICE_SOLVE"]
-        assert np.array_equal(fast.transformation, again.transformation)
-        assert flog == alog
-        assert fast.num_iterations == slow.num_iterations, (vs, dtype)
-        assert fast.converged == slow.converged
-        assert len(flog) == len(slog)
-        for a, b in zip(flog, slog):
-            assert a[:3] == b[:3]
-            assert abs(a[3] - b[3]) <= 1e-12 and abs(a[4] - b[4]) <= 1e-12
-        ang, tr = _pose_err(fast.transformation, slow.transformation)
-        assert ang <= 1e-12 and tr <= 1e-12, (ang, tr)
-        assert abs(fast.fitness - slow.fitness) <= 1e-12
-        assert abs(fast.inlier_rmse - slow.inlier_rmse) <= 1e-12
-        assert torch.equal(fast.correspondence_set, slow.correspondence_set)
-
-
-@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_voxel_down_sample_bucketed_form_edge_cases(dtype):
     """The three-launch bucketed VoxelDownSample (clouds up to 2^17 points)
-    against the oracle, bit for bit, and against the seven-launch sort it
-    replaces (O3DMI_VDS_SORT=1): tile boundaries (8192-point tiles), a single
+    against the oracle, bit for bit: tile boundaries (8192-point tiles), a single
     point, one voxel holding thousands of points (a bucket beyond the LDS
     staging: the walk out of global memory), many points per voxel next to
     empty space, the largest size of the form, and the workspace growing and
@@ -1481,13 +1418,6 @@ def test_voxel_down_sample_bucketed_form_edge_cases(dtype):
         assert np.array_equal(gp.cpu().numpy(), wp)
         if nrm is not None:
             assert np.array_equal(gn.cpu().numpy(), wn)
-        os.environ["O3DMI_VDS_SORT"] = "1"
-        try:
-            sp, sn = reg.voxel_down_sample(torch.from_numpy(pts).cuda(), tn,
-                                           voxel)
-        finally:
-            del os.environ["O3DMI_VDS_SORT"]
-        assert torch.equal(sp, gp) and (nrm is None or torch.equal(sn, gn))
         return wp.shape[0]
 
     p = _pair(70000, seed=5, dtype=dtype)
@@ -1562,80 +1492,6 @@ def test_multiscale_icp_with_device_resident_cloud_sizes(voxels):
                              device_counts=(counts[0:1], counts[1:2]))
     assert np.array_equal(kw.transformation, want.transformation)
     assert kw.num_iterations == want.num_iterations
-
-
-@pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_gated_search_launch_equals_the_plain_loop(dtype):
-    """O3DMI_ICP_GATE=1 (opt-in; measured much slower: every workgroup of the
-    waiting launch polls host memory, see host/registration.cpp) queues
-    iteration k + 1's search launch before iteration k's sums are read; the
-    launch polls a host-mapped inbox for the update (or a cancel mark).
-    Against the plain loop everything must be IDENTICAL -- same kernels, same
-    matrices, same order: transformation, iteration counts, per-iteration
-    fitness / rmse, the correspondence set -- for single- and multi-scale
-    runs, zero iterations, scales that stop early or run out of iterations,
-    and a pair of clouds with no correspondence at all."""
-    import os
-    _lib, reg = _gpu()
-    p = _pair(60000, seed=11, dtype=dtype)
-    src = torch.from_numpy(p["source"]).cuda()
-    tgt = torch.from_numpy(p["target"]).cuda()
-    nrm = torch.from_numpy(p["target_normals"]).cuda()
-    far = (src + 50.0).contiguous()
-    cases = [(src, [-1.0], [reg.ICPConvergenceCriteria(1e-6, 1e-6, 30)],
-              [0.07]),
-             (src, [0.05, 0.025, 0.0125],
-              [reg.ICPConvergenceCriteria(1e-6, 1e-6, n) for n in (20, 10, 5)],
-              [0.15, 0.075, 0.0375]),
-             (src, [-1.0], [reg.ICPConvergenceCriteria(1e-6, 1e-6, 0)], [0.07]),
-             (src, [0.05, -1.0], [reg.ICPConvergenceCriteria(0.5, 0.5, 4),
-                                  reg.ICPConvergenceCriteria(1e-9, 1e-9, 3)],
-              [0.15, 0.07]),
-             (src, [0.05, 0.02], [reg.ICPConvergenceCriteria(1e-12, 1e-12, 2),
-                                  reg.ICPConvergenceCriteria(1e-12, 1e-12, 1)],
-              [0.15, 0.07]),
-             (far, [0.05, -1.0], [reg.ICPConvergenceCriteria(1e-6, 1e-6, 5)] * 2,
-              [0.15, 0.07])]
-
-    def run(s0, vs, crit, md):
-        log = []
-        r = reg.multi_scale_icp(
-            s0.clone(), tgt, nrm, vs, crit, md,
-            callback_after_iteration=lambda d: log.append(
-                (d["iteration_index"], d["scale_index"],
-                 d["scale_iteration_index"], d["fitness"], d["inlier_rmse"],
-                 d["transformation"].tobytes())))
-        torch.cuda.synchronize()
-        return r, log
-
-    for s0, vs, crit, md in cases:
-        plain, plog = run(s0, vs, crit, md)
-        os.environ["O3DMI_ICP_GATE"] = "1"
-        try:
-            gated, glog = run(s0, vs, crit, md)
-        finally:
-            del os.environ["O3DMI_ICP_GATE"]
-        assert np.array_equal(gated.transformation, plain.transformation)
-        assert gated.num_iterations == plain.num_iterations
-        assert gated.converged == plain.converged
-        assert gated.fitness == plain.fitness
-        assert gated.inlier_rmse == plain.inlier_rmse
-        assert glog == plog
-        assert torch.equal(gated.correspondence_set, plain.correspondence_set)
-    # 50 calls back to back: no launch is left polling, nothing drifts
-    first, _ = run(src, [0.05, 0.025],
-                   [reg.ICPConvergenceCriteria(1e-6, 1e-6, 6)] * 2,
-                   [0.15, 0.075])
-    os.environ["O3DMI_ICP_GATE"] = "1"
-    try:
-        for _ in range(50):
-            r = reg.multi_scale_icp(
-                src.clone(), tgt, nrm, [0.05, 0.025],
-                [reg.ICPConvergenceCriteria(1e-6, 1e-6, 6)] * 2, [0.15, 0.075])
-        torch.cuda.synchronize()
-    finally:
-        del os.environ["O3DMI_ICP_GATE"]
-    assert np.array_equal(r.transformation, first.transformation)
 
 
 _FUSED_PYRAMID_SCRIPT = r"""

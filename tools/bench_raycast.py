@@ -58,7 +58,6 @@ if a.digest:
     extra["sha256"] = h.hexdigest()[:16]
 print(json.dumps({"size": [W, H], "attrs": attrs, "blocks": int(cnt.item()),
                   **extra,
-                  "cooperative_march": os.environ.get("O3DMI_RAYCAST_COOP", "1"),
                   "ray_cast_call_us_median": ms[len(ms) // 2] * 1e3,
                   "min": ms[0] * 1e3,
                   "valid_frac": float((out["depth"] > 0).float().mean())}))

@@ -83,19 +83,12 @@ def main():
                "target_points": int(t.shape[0]),
                "vds_us_incl_readback": round(vds_us, 1),
                "vds_input_points": int(n_in), "search_us": {}}
-        first = True
-        for G in (32, 16, 8, 4, 2, 1):
-            os.environ["O3DMI_NNS_GROUP"] = str(G)
-
-            def launch():
-                _lib.check(L.o3dmi_icp_search_accumulate(
-                    nns, _lib.ptr(s), _lib.ptr(tn) if first else None,
-                    s.shape[0], 0, C.c_double(1.0), C.c_double(1.0), None,
-                    _lib.ptr(sums), stream()), "search")
-            launch()
-            first = False
-            row["search_us"][str(G)] = round(timed(launch, a.reps), 1)
-        os.environ.pop("O3DMI_NNS_GROUP", None)
+        # (rounds 2-4 swept the lanes per query here through an environment
+        # switch; the library now picks 8 / 16 / 32 by size -- the measured
+        # table is profiles/r2w_search_*.json)
+        _lib.check(L.o3dmi_icp_search_accumulate(
+            nns, _lib.ptr(s), _lib.ptr(tn), s.shape[0], 0, C.c_double(1.0),
+            C.c_double(1.0), None, _lib.ptr(sums), stream()), "search")
 
         def launch_auto():
             _lib.check(L.o3dmi_icp_search_accumulate(

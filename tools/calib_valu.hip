@@ -47,13 +47,17 @@ struct Stamp {
 
 enum Kind {
     kMulF32, kFmaF32, kAddF32, kPkMulF32, kPkFmaF32, kPkAddF32, kCvtF32U32,
-    kCvtU32F32, kCndmask, kRcpF32, kMulU24, kLshr, kAndOr, kCmpSel, kNumKinds
+    kCvtU32F32, kCndmask, kRcpF32, kMulU24, kLshr, kAndOr, kCmpSel,
+    kCndmaskSgpr, kCmpOnly, kTrunc, kCvtI32, kCvtUbyte, kMadU24, kFmac, kMov,
+    kAddU32, kNumKinds
 };
 static const char* kNames[kNumKinds] = {
     "v_mul_f32", "v_fma_f32", "v_add_f32", "v_pk_mul_f32", "v_pk_fma_f32",
     "v_pk_add_f32", "v_cvt_f32_u32", "v_cvt_u32_f32", "v_cndmask_b32",
     "v_rcp_f32", "v_mul_u32_u24", "v_lshrrev_b32", "v_and_or_b32",
-    "v_cmp_lt_f32+v_cndmask_b32"};
+    "v_cmp_lt_f32+v_cndmask_b32", "v_cndmask_b32_e64(sgpr mask)",
+    "v_cmp_lt_f32(vcc)", "v_trunc_f32", "v_cvt_i32_f32", "v_cvt_f32_ubyte1",
+    "v_mad_u32_u24", "v_fmac_f32", "v_mov_b32", "v_add_u32"};
 
 #define R16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 #define R16x16(M) R16(M) R16(M) R16(M) R16(M) R16(M) R16(M) R16(M) R16(M) R16(M) R16(M) R16(M) R16(M) R16(M) R16(M) R16(M) R16(M)
@@ -71,7 +75,8 @@ __global__ void __launch_bounds__(256) Stream(Stamp* __restrict__ out,
     }
     float c = seed * 0.999f + 1.0f, d = seed + 0.25f;
     f2 pc = f2{c, c}, pd = f2{d, d};
-    asm volatile("s_mov_b64 vcc, 0x55555555" ::: "vcc");
+    asm volatile("s_mov_b64 vcc, 0x55555555\n\ts_mov_b64 s[20:21], 0x33333333"
+                 ::: "vcc", "s20", "s21");
     __syncthreads();
     const unsigned long long t0 = __builtin_readcyclecounter();
     const unsigned long long r0 = wall_clock64();
@@ -127,6 +132,42 @@ __global__ void __launch_bounds__(256) Stream(Stamp* __restrict__ out,
 #undef M
         } else if constexpr (K == kAndOr) {
 #define M(i) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(d));
+            R16x16(M)
+#undef M
+        } else if constexpr (K == kCndmaskSgpr) {
+#define M(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a[i]) : "v"(c));
+            R16x16(M)
+#undef M
+        } else if constexpr (K == kCmpOnly) {
+#define M(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a[i]), "v"(c) : "vcc");
+            R16x16(M)
+#undef M
+        } else if constexpr (K == kTrunc) {
+#define M(i) asm volatile("v_trunc_f32 %0, %0" : "+v"(a[i]));
+            R16x16(M)
+#undef M
+        } else if constexpr (K == kCvtI32) {
+#define M(i) asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(a[i]));
+            R16x16(M)
+#undef M
+        } else if constexpr (K == kCvtUbyte) {
+#define M(i) asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(a[i]));
+            R16x16(M)
+#undef M
+        } else if constexpr (K == kMadU24) {
+#define M(i) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(d));
+            R16x16(M)
+#undef M
+        } else if constexpr (K == kFmac) {
+#define M(i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(d));
+            R16x16(M)
+#undef M
+        } else if constexpr (K == kMov) {
+#define M(i) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(c));
+            R16x16(M)
+#undef M
+        } else if constexpr (K == kAddU32) {
+#define M(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
             R16x16(M)
 #undef M
         } else if constexpr (K == kCmpSel) {
@@ -234,6 +275,15 @@ int main() {
     RunAll<kLshr>(n_cu, d_out, d_sink, host, first);
     RunAll<kAndOr>(n_cu, d_out, d_sink, host, first);
     RunAll<kCmpSel>(n_cu, d_out, d_sink, host, first);
+    RunAll<kCndmaskSgpr>(n_cu, d_out, d_sink, host, first);
+    RunAll<kCmpOnly>(n_cu, d_out, d_sink, host, first);
+    RunAll<kTrunc>(n_cu, d_out, d_sink, host, first);
+    RunAll<kCvtI32>(n_cu, d_out, d_sink, host, first);
+    RunAll<kCvtUbyte>(n_cu, d_out, d_sink, host, first);
+    RunAll<kMadU24>(n_cu, d_out, d_sink, host, first);
+    RunAll<kFmac>(n_cu, d_out, d_sink, host, first);
+    RunAll<kMov>(n_cu, d_out, d_sink, host, first);
+    RunAll<kAddU32>(n_cu, d_out, d_sink, host, first);
     std::printf("\n]}\n");
     return 0;
 }

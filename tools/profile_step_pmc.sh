@@ -2,7 +2,7 @@
 # Runs on the GPU box (via gpurun): PMC passes of bench.py for the dominant
 # kernel (FrameStepKernel) and the FETCH_SIZE / WRITE_SIZE calibration binary.
 # Each counter set is its own rocprofv3 run (--pmc with --kernel-trace only).
-# Usage: tools/profile_step_pmc.sh <tag> [env assignments for bench, e.g. O3DMI_STEP_VARIANT=0]
+# Usage: tools/profile_step_pmc.sh <tag> [env assignments for bench, e.g. O3DMI_EXACT_DIV=1]
 # Summaries land in gpurun_out/profiles_<tag>/ (copied into profiles/ by hand).
 set -u
 TAG=${1:-r2}; shift || true

@@ -30,6 +30,15 @@ for f in glob.glob(os.path.join(out, "sq", "**", "*counter_collection.csv"),
             continue
         acc[(int(m.group(1)), int(r["Grid_Size"]))][r["Counter_Name"]].append(
             float(r["Counter_Value"]))
+acc2 = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(out, "sq2", "**", "*counter_collection.csv"),
+                   recursive=True):
+    for r in csv.DictReader(open(f)):
+        m = re.search(r"Stream<(\d+)>", r["Kernel_Name"])
+        if not m:
+            continue
+        acc2[(int(m.group(1)), int(r["Grid_Size"]))][r["Counter_Name"]].append(
+            float(r["Counter_Value"]))
 names = []
 for r in alone["runs"]:
     if r["stream"] not in names:
@@ -63,6 +72,13 @@ for r in alone["runs"]:
             row["frac_valu_4cycle_form"] = \
                 m.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (n_simd * cyc)
             row["insts_per_simd_cycle"] = insts / (n_simd * cyc)
+    c2 = acc2.get((names.index(r["stream"]), n_cu * w * 256))
+    if c2:
+        m2 = {k: sum(v) / len(v) for k, v in c2.items()}
+        i2 = m2.get("SQ_INSTS_VALU", 0.0)
+        for k in ("SQ_INST_CYCLES_VALU", "SQ_THREAD_CYCLES_VALU"):
+            if k in m2 and i2:
+                row[k + "_per_inst"] = m2[k] / i2
     rows.append(row)
 
 # the roof bench.py uses: wave-instructions per SIMD per cycle of the plain
