@@ -273,6 +273,26 @@ int o3dmi_vbg_raycast(o3dmi_hash_t* block_hash, const float* tsdf_dev,
                       float weight_threshold, float trunc_voxel_multiplier,
                       int range_map_down_factor, o3dmi_stream_t stream);
 
+/* The same launch over the pixel rows [row_begin, row_end) of the {h, w}
+ * image only (whole 8-row tiles: row_begin % 8 == 0, row_end % 8 == 0 or
+ * row_end == h); the output pointers are still those of the WHOLE maps, rows
+ * outside the band are not written. A pixel's result does not depend on the
+ * band it is rendered in: the bands of several ranks put together are
+ * o3dmi_vbg_raycast's maps bit for bit (RayCast row: pixel-tile
+ * sharding over a replicated grid; no counterpart in the reference, whose
+ * RayCastCUDA renders the whole image on one device). */
+int o3dmi_vbg_raycast_rows(
+        o3dmi_hash_t* block_hash, const float* tsdf_dev, const void* weight_dev,
+        const void* color_buf_dev, int grid_dtype, const float* range_map_dev,
+        float* out_depth, float* out_vertex, float* out_color,
+        float* out_normal, int64_t* out_index, uint8_t* out_mask,
+        float* out_ratio, float* out_ratio_dx, float* out_ratio_dy,
+        float* out_ratio_dz, const double* intrinsic, const double* extrinsic,
+        int h, int w, int row_begin, int row_end, int block_resolution,
+        float voxel_size, float depth_scale, float depth_min, float depth_max,
+        float weight_threshold, float trunc_voxel_multiplier,
+        int range_map_down_factor, o3dmi_stream_t stream);
+
 /* ExtractPointCloudCUDA<tsdf_t,weight_t,color_t> (VoxelBlockGridImpl.h:
  * 1122-1365) fused with BufferRadiusNeighbors (t/geometry/VoxelBlockGrid.cpp:
  * 22-51): zero crossings of the TSDF along +x/+y/+z between voxels with

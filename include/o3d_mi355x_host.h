@@ -508,6 +508,23 @@ int o3dmi_vbg_ray_cast(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
                        float trunc_voxel_multiplier, int range_map_down_factor,
                        o3dmi_stream_t stream);
 
+/* RayCast of a REPLICATED grid sharded by pixel rows over the ranks of the
+ * calling thread's communicator (o3dmi_set_comm; SURVEY 8(e), RayCast row --
+ * the tracking frame of a multi-GPU loop, whose model every rank holds): rank
+ * r renders rows [r B, (r + 1) B) (B = whole 8-row tiles, ceil(tiles / world)
+ * of them) of depth / vertex / colour / normal, one all-gather per requested
+ * map delivers every rank's band, and every rank ends with the maps
+ * o3dmi_vbg_ray_cast produces, bit for bit. COLLECTIVE: every rank calls it
+ * with the same arguments. Without a communicator (or with one rank) it is
+ * o3dmi_vbg_ray_cast. */
+int o3dmi_vbg_ray_cast_sharded(
+        o3dmi_vbg_t* g, const int32_t* block_coords_dev, int64_t m,
+        const double* intrinsic, const double* extrinsic, int width, int height,
+        float* range_map_dev, float* out_depth, float* out_vertex,
+        float* out_color, float* out_normal, float depth_scale, float depth_min,
+        float depth_max, float weight_threshold, float trunc_voxel_multiplier,
+        int range_map_down_factor, o3dmi_stream_t stream);
+
 /* ------------------------------------------------------------------------ */
 /* RGB-D odometry (t/pipelines/odometry/RGBDOdometry.h)                      */
 /* ------------------------------------------------------------------------ */

@@ -70,6 +70,10 @@ PROTOTYPES = {
     "o3dmi_vbg_raycast": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp] + [_vp] * 10 +
                           [_dp, _dp, _i32, _i32, _i32, _f, _f, _f, _f, _f, _f,
                            _i32, _vp]),
+    "o3dmi_vbg_raycast_rows": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp] +
+                               [_vp] * 10 +
+                               [_dp, _dp, _i32, _i32, _i32, _i32, _i32, _f, _f,
+                                _f, _f, _f, _f, _i32, _vp]),
     "o3dmi_unproject": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _dp,
                                _dp, _f, _f, _i64, _vp]),
     "o3dmi_nns_create": (_i32, [_vp, _i64, _i32, _d, _vp, C.POINTER(_vp)]),
@@ -295,6 +299,9 @@ PROTOTYPES.update({
     "o3dmi_vbg_block_resolution": (_i64, [_vp]),
     "o3dmi_vbg_ray_cast": (
         _i32, [_vp, _vp, _i64, _dp, _dp, _i32, _i32, _vp] + [_vp] * 10 +
+        [_f, _f, _f, _f, _f, _i32, _vp]),
+    "o3dmi_vbg_ray_cast_sharded": (
+        _i32, [_vp, _vp, _i64, _dp, _dp, _i32, _i32, _vp] + [_vp] * 4 +
         [_f, _f, _f, _f, _f, _i32, _vp]),
     "o3dmi_vbg_profile_distinct_blocks": (_i64, [_vp]),
     "o3dmi_vbg_division_forms": (_i32, [_f, _f, _i32]),

@@ -781,8 +781,11 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
     const bool dev_reduce = comm != nullptr || g_dev_allreduce != nullptr;
     DeviceBuffer dev_sums;
     if (dev_reduce && (st = dev_sums.Alloc(32 * sizeof(double)))) return st;
+    // `sealed`: the launch posts through the search launch's final-sum tail
+    // (mailbox.h MailboxWaitSealed), else through a final-sum kernel's fenced
+    // post.
     auto fetch_sums = [&](auto&& launch, double* out32, double t29, double t30,
-                          double t31) -> int {
+                          double t31, bool sealed = false) -> int {
         const int seq = ++mb->seq;
         if (dev_reduce) {
             double* d = (double*)dev_sums.p;
@@ -808,8 +811,12 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         int e = launch((double*)nullptr, mb->data, mb->flag, seq);
         if (e) return e;
         build_next_index();  // in the shadow of the launch just issued
-        O3DMI_HIP_CHECK(MailboxWait(mb, seq, s));
-        std::memcpy(out32, sums_host, sizeof(double) * 32);
+        if (sealed) {
+            O3DMI_HIP_CHECK(MailboxWaitSealed(mb, seq, s, out32));
+        } else {
+            O3DMI_HIP_CHECK(MailboxWait(mb, seq, s));
+            std::memcpy(out32, sums_host, sizeof(double) * 32);
+        }
         if (t29 == t29) out32[29] = t29;
         if (t30 == t30) out32[30] = t30;
         if (t31 == t31) out32[31] = t31;
@@ -874,7 +881,7 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                             corr_out, sums_dev, mail_data, mail_flag, seq,
                             stream);
                 },
-                r.sums, kKeep, kKeep, (double)L.ns);
+                r.sums, kKeep, kKeep, (double)L.ns, /*sealed=*/true);
         if (e) return e;
         const double num_correspondences = r.sums[30];
         if (num_correspondences != 0) {
@@ -1160,8 +1167,8 @@ int TransformSearch(const void* source_dev, int64_t ns, const void* target_dev,
                  guard.nns, src.p, nullptr, ns, estimation, 0, 1.0, 1.0,
                  corr_dev, nullptr, mb->data, mb->flag, seq, stream)))
         return st;
-    O3DMI_HIP_CHECK(MailboxWait(mb, seq, s));
-    std::memcpy(sums32, mb->data, sizeof(double) * 32);
+    // (the search launch's tail posts a sealed block, mailbox.h)
+    O3DMI_HIP_CHECK(MailboxWaitSealed(mb, seq, s, sums32));
     return O3DMI_OK;
 }
 

@@ -2228,6 +2228,117 @@ int o3dmi_vbg_ray_cast_dev(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
             range_map_down_factor, stream);
 }
 
+int o3dmi_vbg_ray_cast_sharded(
+        o3dmi_vbg_t* g, const int32_t* block_coords_dev, int64_t m,
+        const double* intrinsic, const double* extrinsic, int width, int height,
+        float* range_map_dev, float* out_depth, float* out_vertex,
+        float* out_color, float* out_normal, float depth_scale, float depth_min,
+        float depth_max, float weight_threshold, float trunc_voxel_multiplier,
+        int range_map_down_factor, o3dmi_stream_t stream) {
+    o3dmi_comm* comm = ThreadComm();
+    if (!comm || comm->world <= 1)
+        return o3dmi_vbg_ray_cast(
+                g, block_coords_dev, m, intrinsic, extrinsic, width, height,
+                range_map_dev, out_depth, out_vertex, out_color, out_normal,
+                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                depth_scale, depth_min, depth_max, weight_threshold,
+                trunc_voxel_multiplier, range_map_down_factor, stream);
+    O3DMI_REQUIRE(g && range_map_dev && intrinsic && extrinsic &&
+                          width > 0 && height > 0,
+                  "bad argument");
+    int ti = g->AttrIndex("tsdf"), wi = g->AttrIndex("weight"),
+        ci = g->AttrIndex("color");
+    if (ti < 0 || wi < 0) {
+        SetLastError(
+                "TSDF and/or weight not allocated in blocks, please implement "
+                "customized integration.");
+        return O3DMI_ERR_INVALID_ARG;
+    }
+    int grid_dtype;
+    int st = GridDtype(g, &grid_dtype);
+    if (st) return st;
+    hipStream_t s = (hipStream_t)stream;
+    const int world = comm->world, rank = comm->rank;
+    // the range map is cheap (one pass over the frustum's block keys) and
+    // replicated: every rank needs the cells of its band only, but all of it
+    // is an output of the call
+    if ((st = o3dmi_vbg_estimate_range_dev(
+                 block_coords_dev, m, nullptr, range_map_dev, intrinsic,
+                 extrinsic, height, width, range_map_down_factor,
+                 g->block_resolution, g->voxel_size, depth_min, depth_max,
+                 stream)))
+        return st;
+    const int tiles = (height + 7) / 8;
+    const int band_tiles = (tiles + world - 1) / world;
+    const int band_rows = band_tiles * 8;
+    const int padded = band_rows * world;  // rows of the gathered maps
+    int r0 = rank * band_rows, r1 = r0 + band_rows;
+    if (r0 > height) r0 = height;
+    if (r1 > height) r1 = height;
+    // Maps of `padded` rows, gathered in place (a rank's band is a contiguous
+    // run of rows); the caller's {height, width, C} maps are their first
+    // rows.
+    struct Map {
+        float* out;
+        int channels;
+        float* staged;
+    } maps[4] = {{out_depth, 1, nullptr},
+                 {out_vertex, 3, nullptr},
+                 {out_color, 3, nullptr},
+                 {out_normal, 3, nullptr}};
+    size_t floats = 0;
+    for (Map& mp : maps)
+        if (mp.out) floats += (size_t)padded * width * mp.channels;
+    if (floats == 0) return O3DMI_OK;
+    float* stage = nullptr;
+    if ((st = PoolAlloc((void**)&stage, floats * sizeof(float)))) return st;
+    struct Free {
+        hipStream_t s;
+        void* p;
+        ~Free() {
+            (void)hipStreamSynchronize(s);
+            PoolFree(p);
+        }
+    } free_stage{s, stage};
+    {
+        float* q = stage;
+        for (Map& mp : maps)
+            if (mp.out) {
+                mp.staged = q;
+                q += (size_t)padded * width * mp.channels;
+            }
+    }
+    const void* cbuf = (ci >= 0 && out_color)
+                               ? o3dmi_hash_value_buffer(g->block_hashmap, ci)
+                               : nullptr;
+    // the band renders into rows [r0, r1) of the staged maps (the kernel
+    // addresses pixels of the whole image)
+    if ((st = o3dmi_vbg_raycast_rows(
+                 g->block_hashmap,
+                 (const float*)o3dmi_hash_value_buffer(g->block_hashmap, ti),
+                 o3dmi_hash_value_buffer(g->block_hashmap, wi), cbuf,
+                 grid_dtype, range_map_dev, maps[0].staged, maps[1].staged,
+                 maps[2].staged, maps[3].staged, nullptr, nullptr, nullptr,
+                 nullptr, nullptr, nullptr, intrinsic, extrinsic, height, width,
+                 r0, r1, (int)g->block_resolution, g->voxel_size, depth_scale,
+                 depth_min, depth_max, weight_threshold, trunc_voxel_multiplier,
+                 range_map_down_factor, stream)))
+        return st;
+    for (Map& mp : maps) {
+        if (!mp.out) continue;
+        const int64_t seg = (int64_t)band_rows * width * mp.channels *
+                            (int64_t)sizeof(float);
+        if ((st = comm->Allgather((char*)mp.staged + (size_t)seg * rank,
+                                  mp.staged, seg, s)))
+            return st;
+        O3DMI_HIP_CHECK(hipMemcpyAsync(
+                mp.out, mp.staged,
+                (size_t)height * width * mp.channels * sizeof(float),
+                hipMemcpyDeviceToDevice, s));
+    }
+    return O3DMI_OK;
+}
+
 int o3dmi_vbg_extract_point_cloud(o3dmi_vbg_t* g, float weight_threshold,
                                   int64_t capacity, float* points_dev,
                                   float* normals_dev, float* colors_dev,

@@ -537,7 +537,7 @@ struct OwnedSums {
 // workgroup, the host one launch ahead: +8-10 us per search launch, what the
 // host hop it removed cost -- and a variant whose NEXT launch was queued ahead
 // and polled a host inbox: 2x slower. Both dropped; docs/rounds.md.)
-constexpr int kTailRows = 256;  // workgroups of a launch that carries a tail
+constexpr int kTailRows = 512;  // workgroups of a launch that carries a tail
 struct SumTail {
     int* tickets;      // [9] zero between launches; NULL = no tail
     double* out;       // device [32] or NULL
@@ -586,28 +586,28 @@ __device__ __forceinline__ void RowSumTail(const double* partials, int n_rows,
     const int tid = threadIdx.x;
     // FinalSumKernel's order: row lane rl adds rows rl, rl + 32, ... in
     // ascending order; the 32 row lanes are then added in ascending order.
-    // 512 threads: thread (rl0, col) runs row lanes rl0 and rl0 + 16. A tail
-    // launch has at most kTailRows rows (8 per row lane), all loads of a row
-    // lane in flight at once.
+    // 512 threads: thread (rl0, col) runs row lanes rl0 and rl0 + 16, eight
+    // loads of a row lane in flight at a time (<= kTailRows rows: at most two
+    // rounds).
     {
         const int col = tid & 31, rl0 = tid >> 5;
-        const double* base = partials + (int64_t)rl0 * 32 + col;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            double x[kTailRows / kFinalRowLanes];
-#pragma unroll
-            for (int k = 0; k < kTailRows / kFinalRowLanes; ++k) {
-                const int r = rl0 + 16 * h + k * kFinalRowLanes;
-                x[k] = r < n_rows
-                               ? LoadSc1(base + (int64_t)(16 * h +
-                                                          k * kFinalRowLanes) *
-                                                        32)
-                               : 0.0;
-            }
+            const int rl = rl0 + 16 * h;
             double v = 0;
+            for (int r0 = rl; r0 < n_rows; r0 += 8 * kFinalRowLanes) {
+                double x[8];
 #pragma unroll
-            for (int k = 0; k < kTailRows / kFinalRowLanes; ++k) v += x[k];
-            s_rows[rl0 + 16 * h][col] = v;
+                for (int k = 0; k < 8; ++k) {
+                    const int r = r0 + k * kFinalRowLanes;
+                    x[k] = r < n_rows
+                                   ? LoadSc1(partials + (int64_t)r * 32 + col)
+                                   : 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v += x[k];
+            }
+            s_rows[rl][col] = v;
         }
     }
     if (tid == 0) {
@@ -617,14 +617,39 @@ __device__ __forceinline__ void RowSumTail(const double* partials, int n_rows,
         for (int k = 0; k < 9; ++k) tl.tickets[k] = 0;
     }
     __syncthreads();
-    if (tid < 32) {
+    if (tid < 64) {
         double t = 0;
+        if (tid < 32) {
 #pragma unroll
-        for (int k = 0; k < kFinalRowLanes; ++k) t += s_rows[k][tid];
-        if (tl.out) tl.out[tid] = t;
-        if (tl.mail_data) tl.mail_data[tid] = t;
+            for (int k = 0; k < kFinalRowLanes; ++k) t += s_rows[k][tid];
+            if (tl.out) tl.out[tid] = t;
+        }
+        if (tl.mail_data) {
+            // SEALED post (mailbox.h): no system-scope release fence -- inside
+            // this launch it would write back the XCD's whole L2, dirty with
+            // the moved source points. The 32 values and a seal word (their
+            // XOR mixed with the sequence number) go out as write-through
+            // system-scope stores; the host accepts the block only when the
+            // seal fits, whatever order the stores land in.
+            unsigned long long b =
+                    tid < 32 ? (unsigned long long)__double_as_longlong(t)
+                             : 0ull;
+            unsigned long long x = b;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) x ^= __shfl_xor(x, d, 64);
+            if (tid < 32)
+                __hip_atomic_store((unsigned long long*)tl.mail_data + tid, b,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (tid == 32)
+                __hip_atomic_store((unsigned long long*)tl.mail_data + 32,
+                                   x ^ MailSeal(tl.mail_seq), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tid == 0)
+                __hip_atomic_store(tl.mail_flag, tl.mail_seq, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
-    if (tl.mail_flag) MailboxPublish(tl.mail_flag, tl.mail_seq);
 }
 
 template <typename T, int G, int EST>
@@ -1260,17 +1285,15 @@ static int LaunchSearchAccumulate(
     if (n * 32 <= lane_scale / 2) group = 32;
     else if (n * 16 <= lane_scale) group = 16;
     else group = 8;
-    // The final sum rides in the launch's last workgroup (SumTail) when the
-    // index carries ticket words: <= kTailRows workgroups then; else a
-    // separate one-workgroup launch over <= 512 rows.
-    // TEMPORARY A/B switch of round 5 (removed once measured).
-    static const bool row_tail = [] {
-        const char* e = std::getenv("O3DMI_ICP_ROW_TAIL");
-        return !(e && e[0] == '0');
-    }();
-    const bool use_tail = row_tail && nns->tickets != nullptr;
+    // The final sum rides in the launch's last workgroup (SumTail, <= 512
+    // workgroups of 8 waves). Against the separate one-workgroup final-sum
+    // launch of rounds 1-4 (examples/icp_slam, same box, gpurun r5c): 64 -> 53
+    // launches per VGA frame, 1265 -> 1337 frames/s (mean of 3), level with
+    // it at 1280x720 while the post still carried a system-scope fence.
+    O3DMI_REQUIRE(nns->tickets != nullptr, "index without ticket words");
     int64_t g64 = (n * group + kSearchBlock - 1) / kSearchBlock;
-    const int64_t g_max = use_tail ? kTailRows : (int64_t)kCUs * 2;
+    const int64_t g_max = kTailRows;
+    static_assert(kTailRows <= kCUs * 4 - 1, "rows of nns->partials");
     if (g64 > g_max) g64 = g_max;
     if (g64 < 1) g64 = 1;
     const int g = (int)g64;
@@ -1278,13 +1301,11 @@ static int LaunchSearchAccumulate(
                                  shape_parameter);
     const int apply_xf = transformation != nullptr ? 1 : 0;
     SumTail tail = {};
-    if (use_tail) {
-        tail.tickets = nns->tickets;
-        tail.out = sums32_dev;
-        tail.mail_data = mail_data;
-        tail.mail_flag = mail_flag;
-        tail.mail_seq = mail_seq;
-    }
+    tail.tickets = nns->tickets;
+    tail.out = sums32_dev;
+    tail.mail_data = mail_data;
+    tail.mail_flag = mail_flag;
+    tail.mail_seq = mail_seq;
     Mat4<double> xd;
     Mat4<float> xfl;
     for (int k = 0; k < 16; ++k) {
@@ -1320,10 +1341,6 @@ static int LaunchSearchAccumulate(
 #undef O3DMI_SEARCH_G
 #undef O3DMI_SEARCH
 #undef O3DMI_SEARCH_E
-    if (!use_tail)
-        hipLaunchKernelGGL(FinalSumKernel<kNumSums>, dim3(1),
-                           dim3(kFinalThreads), 0, s, nns->partials, g,
-                           sums32_dev, mail_data, mail_flag, mail_seq);
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
 }

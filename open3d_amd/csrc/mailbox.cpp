@@ -1,6 +1,7 @@
 #include "mailbox.h"
 
 #include <chrono>
+#include <cstring>
 
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -34,6 +35,30 @@ hipError_t WaitWord(const int* flag, int seq, hipStream_t s);
 
 hipError_t MailboxWait(Mailbox* mb, int seq, hipStream_t s) {
     return WaitWord(mb->flag, seq, s);
+}
+
+hipError_t MailboxWaitSealed(Mailbox* mb, int seq, hipStream_t s,
+                             double* out32) {
+    using clock = std::chrono::steady_clock;
+    hipError_t e = WaitWord(mb->flag, seq, s);
+    if (e != hipSuccess) return e;
+    const auto give_up = clock::now() + std::chrono::seconds(2);
+    for (;;) {
+        unsigned long long v[33], x = 0;
+        const volatile unsigned long long* src =
+                (const volatile unsigned long long*)mb->data;
+        for (int k = 0; k < 33; ++k) v[k] = src[k];
+        for (int k = 0; k < 32; ++k) x ^= v[k];
+        if ((x ^ MailSeal(seq)) == v[32]) {
+            std::memcpy(out32, v, sizeof(double) * 32);
+            return hipSuccess;
+        }
+        // the sequence word overtook part of the block: read again
+        if (clock::now() > give_up) return hipErrorUnknown;
+#if defined(__x86_64__)
+        _mm_pause();
+#endif
+    }
 }
 
 namespace {

@@ -30,6 +30,19 @@ Mailbox* ThreadMailbox(int which = 0);
 // or the stream's error if the stream finished / failed without posting.
 hipError_t MailboxWait(Mailbox* mb, int seq, hipStream_t s);
 
+// SEALED post (the final-sum tail of the ICP search launch, icp.hip
+// RowSumTail): 32 float64 + data[32] = XOR of their bit patterns ^
+// MailSeal(seq), written with write-through system-scope stores and NO release
+// fence, then the sequence word. MailboxWaitSealed accepts the block only when
+// the seal fits the values it read, so the order in which the stores land in
+// host memory does not matter (a torn read fails the seal and is read again).
+__host__ __device__ inline unsigned long long MailSeal(int seq) {
+    return 0x9E3779B97F4A7C15ull * (unsigned long long)(unsigned)(seq + 1);
+}
+// Blocks until launch `seq` has posted a sealed block; copies its 32 values.
+hipError_t MailboxWaitSealed(Mailbox* mb, int seq, hipStream_t s,
+                             double* out32);
+
 // Device side: called by the threads of the single final workgroup after they
 // wrote data[0..n); publishes `seq`.
 __device__ __forceinline__ void MailboxPublish(int* flag, int seq) {

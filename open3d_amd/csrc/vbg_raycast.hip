@@ -127,6 +127,9 @@ struct RayCastParams {
     long long* clocks;  // ... and per workgroup: start, march done, end (100 MHz)
     int xcd_bands;  // tiles dealt to the XCDs in image bands (0: round-robin)
     int coop;       // idle lanes sample ahead for crawling rays
+    int band_ty0, band_tys;  // the launch renders tile rows [ty0, ty0 + tys)
+                             // only (o3dmi_vbg_raycast_rows: a rank's band of
+                             // a pixel-sharded ray cast); tys = 0: the image
 };
 
 struct BlockCache {
@@ -224,7 +227,7 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
                                  p.ratio_dy || p.ratio_dz;
     // Workgroup tile 32 x 8 pixels, wave tile 8 x 8.
     const int tiles_x = (p.w + 31) / 32;
-    const int tiles_y = (p.h + 7) / 8;
+    const int tiles_y = p.band_tys > 0 ? p.band_tys : (p.h + 7) / 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     LdsBlockTable tab;
     tab.e = lds_blocks;
@@ -276,7 +279,7 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
         const int ty = p.xcd_bands ? tile % tiles_y : tile / tiles_x;
         const int tx = p.xcd_bands ? tile / tiles_y : tile - ty * tiles_x;
         const int x = tx * 32 + wave * 8 + (lane & 7);
-        const int y = ty * 8 + (lane >> 3);
+        const int y = (ty + p.band_ty0) * 8 + (lane >> 3);
         // a pixel outside the image keeps its lane in the wave (the march
         // below is wave-uniform), it just has no ray and stores nothing
         const bool inside = x < p.w && y < p.h;
@@ -818,11 +821,36 @@ int o3dmi_vbg_raycast(o3dmi_hash_t* block_hash, const float* tsdf_dev,
                       float depth_scale, float depth_min, float depth_max,
                       float weight_threshold, float trunc_voxel_multiplier,
                       int range_map_down_factor, o3dmi_stream_t stream) {
+    return o3dmi_vbg_raycast_rows(
+            block_hash, tsdf_dev, weight_dev, color_buf_dev, grid_dtype,
+            range_map_dev, out_depth, out_vertex, out_color, out_normal,
+            out_index, out_mask, out_ratio, out_ratio_dx, out_ratio_dy,
+            out_ratio_dz, intrinsic, extrinsic, h, w, 0, h, block_resolution,
+            voxel_size, depth_scale, depth_min, depth_max, weight_threshold,
+            trunc_voxel_multiplier, range_map_down_factor, stream);
+}
+
+int o3dmi_vbg_raycast_rows(
+        o3dmi_hash_t* block_hash, const float* tsdf_dev, const void* weight_dev,
+        const void* color_buf_dev, int grid_dtype, const float* range_map_dev,
+        float* out_depth, float* out_vertex, float* out_color,
+        float* out_normal, int64_t* out_index, uint8_t* out_mask,
+        float* out_ratio, float* out_ratio_dx, float* out_ratio_dy,
+        float* out_ratio_dz, const double* intrinsic, const double* extrinsic,
+        int h, int w, int row_begin, int row_end, int block_resolution,
+        float voxel_size, float depth_scale, float depth_min, float depth_max,
+        float weight_threshold, float trunc_voxel_multiplier,
+        int range_map_down_factor, o3dmi_stream_t stream) {
     (void)depth_min;
     (void)depth_max;
     O3DMI_REQUIRE(block_hash && tsdf_dev && weight_dev && range_map_dev &&
                           intrinsic && extrinsic,
                   "null argument");
+    O3DMI_REQUIRE(row_begin >= 0 && row_begin <= row_end && row_end <= h &&
+                          (row_begin % 8) == 0 &&
+                          ((row_end % 8) == 0 || row_end == h),
+                  "ray cast rows: a band of whole 8-row tiles of the image");
+    if (row_begin == row_end) return O3DMI_OK;
     O3DMI_REQUIRE(grid_dtype == O3DMI_U16 || grid_dtype == O3DMI_F32,
                   "Unsupported value data type combination.");
     O3DMI_REQUIRE(h > 0 && w > 0 && range_map_down_factor > 0, "bad size");
@@ -863,7 +891,11 @@ int o3dmi_vbg_raycast(o3dmi_hash_t* block_hash, const float* tsdf_dev,
         O3DMI_HIP_CHECK(hipMemsetAsync(p.clocks, 0, sizeof(long long) * 3 * nt, s));
     }
     // one workgroup per 32 x 8 pixel tile (grid-strided beyond 16 per CU)
-    const int64_t n_tiles = (int64_t)((w + 31) / 32) * ((h + 7) / 8);
+    const bool whole = row_begin == 0 && row_end == h;
+    p.band_ty0 = whole ? 0 : row_begin / 8;
+    p.band_tys = whole ? 0 : (row_end - row_begin + 7) / 8;
+    const int64_t n_tiles = (int64_t)((w + 31) / 32) *
+                            (whole ? (h + 7) / 8 : p.band_tys);
     p.xcd_bands = n_tiles <= kCUs * 5 ? 1 : 0;
     p.coop = 1;
     // a multiple of 8 workgroups: every XCD gets the same number

@@ -535,7 +535,11 @@ class VoxelBlockGrid:
                  render_attributes=("depth", "color"), depth_scale=1000.0,
                  depth_min=0.1, depth_max=3.0, weight_threshold=3.0,
                  trunc_voxel_multiplier=8.0, range_map_down_factor=8,
-                 block_count_dev=None):
+                 block_count_dev=None, sharded=False):
+        """sharded: the rows of the maps are rendered by the ranks of the
+        calling thread's communicator (sharding.Comm.install) and all-gathered
+        -- a collective call on a replicated grid; depth / vertex / color /
+        normal only."""
         block_coords = require_cuda(block_coords, "block_coords")
         if block_coords.dtype != torch.int32:
             raise ValueError("Unsupported block coordinate dtype %s"
@@ -555,6 +559,21 @@ class VoxelBlockGrid:
         out["range"] = torch.empty((height // d, width // d, 2),
                                    dtype=torch.float32, device="cuda")
         g = lambda a: _lib.ptr(out.get(a))
+        if sharded:
+            extra = set(out) - {"depth", "vertex", "color", "normal", "range"}
+            if extra:
+                raise ValueError("sharded ray cast renders depth / vertex / "
+                                 "color / normal, not %s" % sorted(extra))
+            _lib.check(_lib.lib().o3dmi_vbg_ray_cast_sharded(
+                self._g, _lib.ptr(block_coords), block_coords.shape[0],
+                _lib.f64p(K), _lib.f64p(T), int(width), int(height),
+                g("range"), g("depth"), g("vertex"), g("color"), g("normal"),
+                C.c_float(depth_scale), C.c_float(depth_min),
+                C.c_float(depth_max), C.c_float(weight_threshold),
+                C.c_float(trunc_voxel_multiplier),
+                int(range_map_down_factor), stream()),
+                "VoxelBlockGrid.ray_cast(sharded)")
+            return out
         if block_count_dev is not None:
             # the number of rows of block_coords in use lives on the device
             _lib.check(_lib.lib().o3dmi_vbg_ray_cast_dev(

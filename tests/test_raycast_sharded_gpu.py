@@ -1,0 +1,166 @@
+"""SURVEY 8(e), RayCast row: the ray cast of a replicated grid sharded by pixel
+rows over the ranks of a communicator (o3dmi_vbg_ray_cast_sharded: a band of
+whole 8-row tiles per rank through o3dmi_vbg_raycast_rows, one all-gather per
+requested map). Every rank must end with the maps of the single-rank ray cast
+BIT FOR BIT -- a pixel's result does not depend on the band it is rendered in.
+
+The ranks are host threads sharing the one GPU (each with its own stream and
+its own thread-local communicator over a loopback transport table), the way
+the sharded-ICP tests run theirs."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import _scene as sc
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from open3d_amd import _lib, geometry
+    return _lib, geometry
+
+
+class _Loopback:
+    """All-gather between host threads of one process: every rank copies its
+    segment into a shared device buffer between two barriers."""
+
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world, timeout=120)
+        self.shared = {}
+        self.lock = threading.Lock()
+
+    def comm(self, rank):
+        from open3d_amd import _lib
+        from open3d_amd.core import tensor_from_ptr
+        from open3d_amd.sharding import Comm
+        world = self.world
+
+        def allgather(_user, send, recv, nbytes, stream_ptr):
+            try:
+                n = int(nbytes)
+                torch.cuda.ExternalStream(stream_ptr).synchronize() \
+                    if stream_ptr else torch.cuda.synchronize()
+                with self.lock:
+                    if n not in self.shared:
+                        self.shared[n] = torch.empty(n * world,
+                                                     dtype=torch.uint8,
+                                                     device="cuda")
+                buf = self.shared[n]
+                # (the send segment may lie inside recv: in-place gather)
+                seg = tensor_from_ptr(send, (n,), _lib.U8, None).clone()
+                self.barrier.wait()
+                buf[rank * n:(rank + 1) * n].copy_(seg)
+                torch.cuda.synchronize()
+                self.barrier.wait()
+                tensor_from_ptr(recv, (n * world,), _lib.U8, None).copy_(buf)
+                torch.cuda.synchronize()
+                self.barrier.wait()
+                return 0
+            except BaseException as e:  # noqa: BLE001
+                print("loopback all-gather: %r" % (e,))
+                self.barrier.abort()
+                return 1
+
+        def allreduce(_user, dev, n, stream_ptr):
+            return 1
+
+        def alltoallv(_user, send, sb, so, recv, rb, ro, stream_ptr):
+            return 1
+        cbs = (_lib.TRANSPORT_ALLREDUCE(allreduce),
+               _lib.TRANSPORT_ALLGATHER(allgather),
+               _lib.TRANSPORT_ALLTOALLV(alltoallv))
+        table = _lib.TransportC(*cbs)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().o3dmi_comm_create_custom(
+            C.byref(table), None, rank, world, C.byref(h)),
+            "comm_create_custom")
+        return Comm(h, keep=(cbs, table))
+
+
+def _grid_with_frames(geometry, first, n, w, h):
+    from open3d_amd import synthetic
+    g = geometry.VoxelBlockGrid(["tsdf", "weight", "color"],
+                                [torch.float32, torch.uint16, torch.uint16],
+                                [1, 1, 3], sc.VOXEL, sc.RES, 8192)
+    d, c, K, Ts = synthetic.render_frames(first, n, w, h, device="cuda")
+    for i in range(n):
+        g.integrate_frame(d[i], c[i], K, K, Ts[i], sc.DEPTH_SCALE,
+                          sc.DEPTH_MAX, sc.TRUNC_MULT)
+    torch.cuda.synchronize()
+    return g, d, K, Ts
+
+
+@pytest.mark.parametrize("world,w,h", [(3, 320, 240), (3, 160, 100),
+                                       (2, 64, 8), (4, 640, 480)])
+def test_sharded_ray_cast_equals_the_single_rank_maps_bit_for_bit(world, w, h):
+    _lib, geometry = _gpu()
+    g, d, K, Ts = _grid_with_frames(geometry, 100, 4, w, h)
+    T = Ts[2]
+    keys = g.compute_unique_block_coordinates(d[2], K, T, sc.DEPTH_SCALE,
+                                              sc.DEPTH_MAX, sc.TRUNC_MULT)
+    attrs = ("depth", "vertex", "color", "normal")
+    want = g.ray_cast(keys, K, T, w, h, attrs, sc.DEPTH_SCALE, 0.1,
+                      sc.DEPTH_MAX, 1.0, sc.TRUNC_MULT, 8)
+    torch.cuda.synchronize()
+    assert float((want["depth"] > 0).float().mean()) > 0.3
+    # rows of a band alone: o3dmi_vbg_raycast_rows through the operator with
+    # one rank is the plain call
+    lb = _Loopback(world)
+    out = [None] * world
+
+    def rank_main(rank):
+        try:
+            comm = lb.comm(rank)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                comm.install()
+                try:
+                    out[rank] = g.ray_cast(keys, K, T, w, h, attrs,
+                                           sc.DEPTH_SCALE, 0.1, sc.DEPTH_MAX,
+                                           1.0, sc.TRUNC_MULT, 8, sharded=True)
+                    torch.cuda.synchronize()
+                finally:
+                    comm.uninstall()
+            comm.destroy()
+        except BaseException as ex:  # noqa: BLE001 - reported below
+            out[rank] = ex
+            lb.barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,))
+               for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(180)
+    for r in range(world):
+        assert not isinstance(out[r], BaseException), out[r]
+        assert out[r] is not None, "rank %d did not finish" % r
+        for a in attrs + ("range",):
+            got = out[r][a].contiguous().view(torch.int32)
+            exp = want[a].contiguous().view(torch.int32)
+            assert torch.equal(got, exp), (r, a)
+
+
+def test_band_rows_are_validated():
+    _lib, geometry = _gpu()
+    g, d, K, Ts = _grid_with_frames(geometry, 100, 1, 64, 48)
+    L = _lib.lib()
+    # rows that are not whole tiles are refused by the kernel seam
+    hm = g.hashmap()
+    rng = torch.zeros((6, 8, 2), dtype=torch.float32, device="cuda")
+    dep = torch.zeros((48, 64, 1), dtype=torch.float32, device="cuda")
+    st = L.o3dmi_vbg_raycast_rows(
+        hm._h, _lib.ptr(g.attribute("tsdf")), _lib.ptr(g.attribute("weight")),
+        None, _lib.U16, _lib.ptr(rng), _lib.ptr(dep), *([None] * 9),
+        _lib.f64p(np.ascontiguousarray(K, np.float64)),
+        _lib.f64p(np.ascontiguousarray(Ts[0], np.float64)), 48, 64, 4, 16,
+        sc.RES, C.c_float(sc.VOXEL), C.c_float(sc.DEPTH_SCALE),
+        C.c_float(0.1), C.c_float(sc.DEPTH_MAX), C.c_float(1.0),
+        C.c_float(sc.TRUNC_MULT), 8, None)
+    assert st == 1  # O3DMI_ERR_INVALID_ARG
