@@ -280,7 +280,8 @@ __device__ __forceinline__ void FrontRole(const HashView& hv,
                 __hip_atomic_store(&fp.touch_status[3], (int)fp.group_stamp,
                                    __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
-            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            // One lane per block: list entry -> buffer index + touch word.
+            const auto make_entry = [&](int i) -> ReadyEntry {
                 const unsigned long long* e =
                         reinterpret_cast<const unsigned long long*>(&list[i]);
                 const unsigned long long lo = __hip_atomic_load(
@@ -303,7 +304,56 @@ __device__ __forceinline__ void FrontRole(const HashView& hv,
                 re.block_idx = idx;
                 re.bits = own ? (unsigned)(word & ((1ull << kTouchBits) - 1ull))
                               : 0u;
-                fp.ready[i] = re;
+                return re;
+            };
+            // LONGEST FIRST (round 5): the integrate role takes one workgroup
+            // per (entry, part) in list order, and an entry's work is its
+            // number of frames -- 1 to 12 of them. In arrival order the long
+            // items start anywhere and the launch ends on the last of them;
+            // a counting sort by frame count (the dispatcher's in-order issue
+            // then is longest-processing-time-first scheduling, as for the
+            // chunk launch of the sliced path) lets the short items fill the
+            // tail. Up to kSortable entries (4 per lane, all their loads in
+            // flight at once); a larger group keeps arrival order. Blocks are
+            // independent: the order changes nothing but time.
+            constexpr int kPerLane = 4;
+            const int kSortable = kPerLane * (int)blockDim.x;
+            __shared__ int s_bins[kTouchBits + 2];
+            if (n <= kSortable) {
+                if (threadIdx.x < kTouchBits + 2) s_bins[threadIdx.x] = 0;
+                __syncthreads();
+                ReadyEntry mine[kPerLane];
+                int pc[kPerLane];
+#pragma unroll
+                for (int k = 0; k < kPerLane; ++k) {
+                    const int i = (int)threadIdx.x + k * (int)blockDim.x;
+                    pc[k] = -1;
+                    if (i < n) {
+                        mine[k] = make_entry(i);
+                        pc[k] = __popc(mine[k].bits);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < kPerLane; ++k)
+                    if (pc[k] >= 0) atomicAdd(&s_bins[pc[k]], 1);
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    // start of every bin, most frames first
+                    int run = 0;
+                    for (int b = kTouchBits; b >= 0; --b) {
+                        const int c = s_bins[b];
+                        s_bins[b] = run;
+                        run += c;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < kPerLane; ++k)
+                    if (pc[k] >= 0)
+                        fp.ready[atomicAdd(&s_bins[pc[k]], 1)] = mine[k];
+            } else {
+                for (int i = threadIdx.x; i < n; i += blockDim.x)
+                    fp.ready[i] = make_entry(i);
             }
         }
         return;

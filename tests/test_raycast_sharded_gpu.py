@@ -97,11 +97,17 @@ def _grid_with_frames(geometry, first, n, w, h):
     return g, d, K, Ts
 
 
-@pytest.mark.parametrize("world,w,h", [(3, 320, 240), (3, 160, 100),
-                                       (2, 64, 8), (4, 640, 480)])
+# (heights are multiples of the range map's down factor, as the reference's
+# {h / 8, w / 8, 2} range map requires; 104 rows = 13 tile rows over 3 ranks,
+# 24 rows = 3 tile rows over 5 ranks: two ranks without a band)
+@pytest.mark.parametrize("world,w,h", [(3, 320, 240), (3, 160, 104),
+                                       (5, 320, 24), (4, 640, 480)])
 def test_sharded_ray_cast_equals_the_single_rank_maps_bit_for_bit(world, w, h):
     _lib, geometry = _gpu()
-    g, d, K, Ts = _grid_with_frames(geometry, 100, 4, w, h)
+    # the grid comes from whole frames; the ray cast renders the top-left
+    # w x h pixels of that view (same intrinsics)
+    gw, gh = (640, 480) if w > 320 else (320, 240)
+    g, d, K, Ts = _grid_with_frames(geometry, 100, 4, gw, gh)
     T = Ts[2]
     keys = g.compute_unique_block_coordinates(d[2], K, T, sc.DEPTH_SCALE,
                                               sc.DEPTH_MAX, sc.TRUNC_MULT)
@@ -109,7 +115,7 @@ def test_sharded_ray_cast_equals_the_single_rank_maps_bit_for_bit(world, w, h):
     want = g.ray_cast(keys, K, T, w, h, attrs, sc.DEPTH_SCALE, 0.1,
                       sc.DEPTH_MAX, 1.0, sc.TRUNC_MULT, 8)
     torch.cuda.synchronize()
-    assert float((want["depth"] > 0).float().mean()) > 0.3
+    assert float((want["depth"] > 0).float().mean()) > 0.2
     # rows of a band alone: o3dmi_vbg_raycast_rows through the operator with
     # one rank is the plain call
     lb = _Loopback(world)

@@ -925,15 +925,13 @@ def _blocks_sorted(g, with_color=True):
     return out
 
 
-@pytest.mark.parametrize("raw,pipe", [(False, False), (True, False),
-                                      (False, True), (True, True)])
+@pytest.mark.parametrize("raw", [False, True])
 @pytest.mark.parametrize("world,group,grid_f32,with_color", [
     (1, 4, False, True), (3, 2, False, True), (8, 3, False, True),
     (8, 12, False, True), (2, 16, True, True), (4, 5, False, False)])
 def test_sliced_touch_ownership_union_is_the_single_grid(world, group,
                                                          grid_f32, with_color,
-                                                         raw, pipe,
-                                                         monkeypatch):
+                                                         raw, monkeypatch):
     """SURVEY 8(e) scheme A as specified: rank r touches only its band of ray
     tiles, the candidate records of all ranks are gathered (here computed on
     one device: gather_slices), rank r activates the keys it owns and
@@ -945,7 +943,6 @@ def test_sliced_touch_ownership_union_is_the_single_grid(world, group,
     _lib, geometry = _gpu()
     from open3d_amd import sharding
     monkeypatch.setenv("O3DMI_SLICED_RAW", "1" if raw else "0")
-    monkeypatch.setenv("O3DMI_SLICED_PIPE", "1" if pipe else "0")
     n = 2 * 16 * group + 3 if group <= 3 else 16 * group + 5
     ks = [(i * 7) % 900 for i in range(n)]
     ds, cs, dt, ct, Ts, K = _stream_frames(ks, 320, 240)
@@ -1015,6 +1012,61 @@ def test_sliced_touch_reserves_and_applies_the_chunk_again():
     with pytest.raises(_lib.O3DMIError):
         g2.integrate_frames_sliced(b2, small, sc.DEPTH_SCALE, sc.DEPTH_MAX,
                                    sc.TRUNC_MULT, frames_per_launch=4)
+
+
+def test_a_peers_abort_flag_ends_the_call_and_leaves_the_map_usable():
+    """o3dmi_vbg_integrate_frames on the sliced path is collective: a rank
+    that has to leave it with an error delivers its next all-gather with an
+    empty segment flagged kSliceFlagAbort (sliced_path.h), and every rank
+    returns O3DMI_ERR_PEER at that chunk instead of waiting in a collective
+    nobody else will enter. Receiver side, on one device: the second chunk's
+    gathered segments carry the flag in rank 1's header -> the call ends with
+    status 10 after the first chunk, the map is consistent (size / export
+    work), and integrating the remaining frames afterwards gives the grid of
+    an undisturbed run."""
+    _lib, geometry = _gpu()
+    group, world = 2, 2
+    n = 16 * group * 2 + 5  # three chunks
+    ks = [(i * 13) % 900 for i in range(n)]
+    ds, cs, dt, ct, Ts, K = _stream_frames(ks, 320, 240)
+
+    def grid():
+        g = _mk_grid(geometry, False, block_count=8192)
+        g.set_block_ownership(0, world)
+        return g
+    clean = grid()
+    batch = clean.prepare_frames(dt, ct, K, K, Ts)
+    gathered = clean.gather_slices(batch, world, sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                                   sc.TRUNC_MULT, group)
+    assert len(gathered) == 3
+    clean.integrate_frames_sliced(batch, [t.clone() for t in gathered],
+                                  sc.DEPTH_SCALE, sc.DEPTH_MAX, sc.TRUNC_MULT,
+                                  frames_per_launch=group)
+    want = _blocks_sorted(clean, True)
+
+    g = grid()
+    b = g.prepare_frames(dt, ct, K, K, Ts)
+    seg = g.slice_segment_bytes()
+    bad = [t.clone() for t in gathered]
+    hdr = bad[1][seg:seg + 8].view(torch.int32)  # rank 1: {count, flags}
+    hdr[0] = 0
+    hdr[1] = 8  # kSliceFlagAbort
+    with pytest.raises(_lib.O3DMIError) as ei:
+        g.integrate_frames_sliced(b, bad, sc.DEPTH_SCALE, sc.DEPTH_MAX,
+                                  sc.TRUNC_MULT, frames_per_launch=group)
+    assert ei.value.status == 10  # O3DMI_ERR_PEER
+    # the map answers (no "overflow not recovered"), holds the first chunk
+    first = g.hashmap().size()
+    assert 0 < first <= want[0].shape[0]
+    # the rest of the stream, undisturbed, on the same grid
+    cf = 16 * group
+    rest = g.prepare_frames(dt[cf:], ct[cf:], K, K, Ts[cf:])
+    g.integrate_frames_sliced(rest, [t.clone() for t in gathered[1:]],
+                              sc.DEPTH_SCALE, sc.DEPTH_MAX, sc.TRUNC_MULT,
+                              frames_per_launch=group)
+    got = _blocks_sorted(g, True)
+    for a, c in zip(got, want):
+        assert a.tobytes() == c.tobytes()
 
 
 def _sorted_blocks(g):

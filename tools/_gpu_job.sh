@@ -1,12 +1,9 @@
 #!/bin/bash
-# scratch job of the round (run through gpurun)
+# scratch job of the round (run through gpurun); every step under its own timeout
 set -u
-O=gpurun_out/r5d; mkdir -p $O
-python -m pytest tests/test_icp_gpu.py tests/test_slam_gpu.py tests/test_configs_gpu.py -x -q -m gpu > $O/tests.log 2>&1; tail -2 $O/tests.log
-python -m pytest tests/test_vbg_gpu.py -x -q -m gpu -k "slice or shard or sliced" > $O/tests_sliced.log 2>&1; tail -2 $O/tests_sliced.log
-for res in "640 480" "1280 720"; do
-  for i in 1 2 3 4 5; do
-   ./examples/icp_slam 60 $res 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('sealed_tail', '$res', d['frames_per_s'], d.get('icp_iterations_per_frame'))"
-  done
-done 2>&1 | tee $O/icp_slam.txt
-bash tools/emu_table.sh r5d "2 4 8" "0 1" 2>&1 | tail -20
+O=gpurun_out/r5f; mkdir -p $O
+timeout -k 5 240 python -m pytest tests/test_raycast_sharded_gpu.py -x -q -m gpu > $O/t_raycast.log 2>&1; tail -2 $O/t_raycast.log
+timeout -k 5 300 python -m pytest tests/test_vbg_gpu.py tests/test_vbg_io_gpu.py tests/test_slam_gpu.py -x -q -m gpu > $O/t_vbg.log 2>&1; tail -2 $O/t_vbg.log
+for fpl in 12 16 8; do
+timeout -k 5 120 python bench.py --no-secondary --no-cpu-baseline --no-pmc --frames-per-launch $fpl 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('fpl $fpl', round(d['value']), d['roofline']['avg_kernel_ms'])"
+done
