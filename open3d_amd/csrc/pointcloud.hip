@@ -477,7 +477,7 @@ __global__ void VdsReduceKernel(const T* __restrict__ pos,
     }
 }
 
-// ==== the bucketed form: three launches per level, clouds up to 2^18 points ====
+// ==== the bucketed form: three launches per level, clouds up to 2^17 points ====
 // (round 3; the seven-launch chain above stays for larger clouds.) The sort
 // above exists to put every voxel's points side by side in point order. Here
 // the points are only PARTITIONED -- stably, by the high bits of their voxel's
@@ -507,12 +507,14 @@ __global__ void VdsReduceKernel(const T* __restrict__ pos,
 // 52 us of kernels per level in the VGA tracking loop -> see DESIGN.md.
 constexpr int kBucketBits = 9;
 constexpr int kBuckets = 1 << kBucketBits;
-// (round 5: 2^18, so that the finest level of a 1280x720 frame -- 230 400
-// points at stride 2 -- takes the three launches instead of the sort's seven)
-constexpr int64_t kBucketedMaxPoints = 1 << 18;
+// (Round 5 tried 2^18, so that the finest level of a 1280x720 frame -- 230 400
+// points -- would take the three launches instead of the sort's seven: the
+// tracking loop got SLOWER, 1177-1207 -> 1127-1133 frames/s; buckets of ~450
+// entries make the reduce launch's in-bucket walk the long pole. Kept at 2^17.)
+constexpr int64_t kBucketedMaxPoints = 1 << 17;
 constexpr int kBucketLds = 2048;   // entries of a bucket staged in LDS
 constexpr int kReduceBlock = 256;
-constexpr int kMaxBucketWidth = 1024;  // slots of a bucket: n_slots / 512 (n_slots <= 2^19)
+constexpr int kMaxBucketWidth = 2048;  // slots of a bucket: n_slots / 512
 
 template <typename T>
 __global__ void __launch_bounds__(kSortBlock)
@@ -596,9 +598,9 @@ VdsBucketScatterKernel(const int* __restrict__ slot_of_point, VdsTable tb,
     // the slots and the live count (one round trip instead of two): the rows
     // of tiles past the live count are zero -- the reduce launch clears the
     // table and the insert launch only adds to live tiles -- so all
-    // ceil(n_host / tile) <= 32 rows can be summed without knowing n.
+    // ceil(n_host / tile) <= 16 rows can be summed without knowing n.
     constexpr int kMaxTiles = (int)(kBucketedMaxPoints / kSortTile);
-    static_assert(kMaxTiles <= 32, "one batch of column loads");
+    static_assert(kMaxTiles <= 16, "one batch of column loads");
     const int n_tiles_host = (n_host + kSortTile - 1) / kSortTile;
     int colv[kMaxTiles];
 #pragma unroll

@@ -15,7 +15,7 @@ namespace o3dmi {
 //           use n_max itself
 //   m_dev   device int receiving the voxel count
 //   err_dev device int: kErrKeyRange is OR-ed in for out-of-range coordinates
-// Clouds of up to 2^18 points take the bucketed three-launch form, whose
+// Clouds of up to 2^17 points take the bucketed three-launch form, whose
 // buffers live in a persistent workspace per host thread, device and `chain`
 // (0 or 1: two chains may run concurrently on two streams, the calls of one
 // chain must be stream-ordered). Larger clouds take the six-launch sort:

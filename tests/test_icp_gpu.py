@@ -1425,8 +1425,8 @@ def test_voxel_down_sample_bucketed_form_edge_cases(dtype):
     for n in (1, 2, 63, 64, 65, 8191, 8192, 8193, 16385, 70000):
         check(np.ascontiguousarray(pts[:n]), np.ascontiguousarray(nrm[:n]),
               0.03)
-    # the upper end of the form (2^18 points since round 5: the finest level
-    # of a 1280x720 frame): 32 scatter tiles, 16 first-point words per lane
+    # beyond the form's 2^17 points (the sort form; the finest level of a
+    # 1280x720 frame is this size), and just past the boundary
     big = _pair(240000, seed=6, dtype=dtype)
     assert check(big["target"], big["target_normals"], 0.0125) > 10000
     check(np.ascontiguousarray(big["target"][:131073]), None, 0.02)
