@@ -259,7 +259,10 @@ int o3dmi_vbg_estimate_range_dev(const int32_t* block_keys_dev,
 /* RayCastCUDA<tsdf_t,weight_t,color_t> (VoxelBlockGridImpl.h:578-1120).
  * Output maps may be NULL when not requested: depth {h,w,1}, vertex/color/
  * normal {h,w,3} float32; index {h,w,8} int64; mask {h,w,8} bool;
- * interp_ratio{,_dx,_dy,_dz} {h,w,8} float32. */
+ * interp_ratio{,_dx,_dy,_dz} {h,w,8} float32. h and w must be multiples of
+ * range_map_down_factor (O3DMI_ERR_INVALID_ARG otherwise: the {h / down,
+ * w / down, 2} range map has no cell for the remainder -- upstream reads past
+ * it). */
 int o3dmi_vbg_raycast(o3dmi_hash_t* block_hash, const float* tsdf_dev,
                       const void* weight_dev, const void* color_buf_dev,
                       int grid_dtype, const float* range_map_dev,

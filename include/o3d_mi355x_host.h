@@ -413,9 +413,20 @@ int o3dmi_vbg_integrate_frames(o3dmi_vbg_t* g, int n_frames,
  * frames, in order, to the owned blocks' register-resident voxels, straight
  * from the raw depth / colour images (no per-pixel prepare pass). Each rank's
  * grid is bit-identical to what the replicated touch produces: the blocks it
- * owns of the single-GPU grid. The functions below expose the two halves for
- * callers with their own exchange, for tests and for bench.py
- * --emulate-world. */
+ * owns of the single-GPU grid.
+ *
+ * In this mode o3dmi_vbg_integrate_frames is
+ *  - COLLECTIVE: every rank calls it with the same frames. A rank that has to
+ *    leave it with an error of its own first delivers the all-gather the
+ *    others will wait in next with an empty segment flagged "abort"; every
+ *    rank then returns O3DMI_ERR_PEER at the same chunk (nobody is left in a
+ *    collective), the failing rank its own status, with its map left usable;
+ *  - NOT purely stream-ordered on the host: it waits for the previous call's
+ *    side-stream work, uploads the call's frame tables synchronously and
+ *    follows each chunk's status word, so back-to-back calls serialise on the
+ *    host (hand over long batches: bench.py passes 8000 frames per call).
+ * The functions below expose the two halves for callers with their own
+ * exchange, for tests and for bench.py --emulate-world. */
 
 /* Frames per chunk for a frames_per_launch setting (16 launches). */
 int o3dmi_vbg_slice_chunk_frames(int frames_per_launch);

@@ -846,6 +846,15 @@ int o3dmi_vbg_raycast_rows(
     O3DMI_REQUIRE(block_hash && tsdf_dev && weight_dev && range_map_dev &&
                           intrinsic && extrinsic,
                   "null argument");
+    // The range map is {h / down, w / down, 2} (VoxelBlockGrid.cpp:357-360) and
+    // a pixel reads cell (y / down, x / down): an image that is not a multiple
+    // of the down factor reads PAST the map (upstream does too: undefined
+    // behaviour there; here the march of such a pixel may never end). Refused.
+    O3DMI_REQUIRE(h % range_map_down_factor == 0 &&
+                          w % range_map_down_factor == 0,
+                  "ray cast: height and width must be multiples of "
+                  "range_map_down_factor (the range map has h / down x w / "
+                  "down cells)");
     O3DMI_REQUIRE(row_begin >= 0 && row_begin <= row_end && row_end <= h &&
                           (row_begin % 8) == 0 &&
                           ((row_end % 8) == 0 || row_end == h),

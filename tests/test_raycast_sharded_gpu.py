@@ -170,3 +170,10 @@ def test_band_rows_are_validated():
         C.c_float(0.1), C.c_float(sc.DEPTH_MAX), C.c_float(1.0),
         C.c_float(sc.TRUNC_MULT), 8, None)
     assert st == 1  # O3DMI_ERR_INVALID_ARG
+    # an image that is not a multiple of the range map's down factor has no
+    # range cell for its last rows (upstream reads past the map): refused
+    with pytest.raises(_lib.O3DMIError):
+        g.ray_cast(g.compute_unique_block_coordinates(
+            d[0], K, Ts[0], sc.DEPTH_SCALE, sc.DEPTH_MAX, sc.TRUNC_MULT),
+            K, Ts[0], 64, 44, ("depth",), sc.DEPTH_SCALE, 0.1, sc.DEPTH_MAX,
+            1.0, sc.TRUNC_MULT, 8)
