@@ -1,10 +1,9 @@
 #!/bin/bash
 # scratch job of the round (run through gpurun); every step under its own timeout
 set -u
-O=gpurun_out/r5h; mkdir -p $O
-timeout -k 5 560 python -m pytest tests -x -q -m gpu > $O/gpu_tests.log 2>&1; tail -3 $O/gpu_tests.log | cut -c1-200
-for res in "640 480" "1280 720"; do
-  for i in 1 2 3; do
-   timeout -k 5 60 ./examples/icp_slam 60 $res 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('vds18', '$res', d['frames_per_s'], d.get('icp_iterations_per_frame'))"
-  done
-done 2>&1 | tee $O/icp_slam.txt
+O=gpurun_out/r5i; mkdir -p $O
+timeout -k 5 240 python -m pytest tests/test_vbg_gpu.py tests/test_configs_gpu.py tests/test_raycast_sharded_gpu.py -x -q -m gpu -k "not sliced and not slice" > $O/tests.log 2>&1; tail -2 $O/tests.log | cut -c1-200
+for i in 1 2; do
+timeout -k 5 100 python bench.py --no-secondary --no-cpu-baseline --no-pmc 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('defer', round(d['value']), d['roofline']['avg_kernel_ms'])"
+O3DMI_LIB=$PWD/_ab/nodefer/libo3d_mi355x.so timeout -k 5 100 python bench.py --no-secondary --no-cpu-baseline --no-pmc 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('nodefer', round(d['value']), d['roofline']['avg_kernel_ms'])"
+done
