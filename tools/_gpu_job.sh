@@ -1,9 +1,6 @@
 #!/bin/bash
 # scratch job of the round (run through gpurun); every step under its own timeout
 set -u
-O=gpurun_out/r5i; mkdir -p $O
-timeout -k 5 240 python -m pytest tests/test_vbg_gpu.py tests/test_configs_gpu.py tests/test_raycast_sharded_gpu.py -x -q -m gpu -k "not sliced and not slice" > $O/tests.log 2>&1; tail -2 $O/tests.log | cut -c1-200
-for i in 1 2; do
-timeout -k 5 100 python bench.py --no-secondary --no-cpu-baseline --no-pmc 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('defer', round(d['value']), d['roofline']['avg_kernel_ms'])"
-O3DMI_LIB=$PWD/_ab/nodefer/libo3d_mi355x.so timeout -k 5 100 python bench.py --no-secondary --no-cpu-baseline --no-pmc 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('nodefer', round(d['value']), d['roofline']['avg_kernel_ms'])"
-done
+O=gpurun_out/r5j; mkdir -p $O
+timeout -k 5 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 --dist-backend gloo > $O/dry_n2.json 2> $O/dry_n2.err; tail -c 700 $O/dry_n2.json; tail -3 $O/dry_n2.err | cut -c1-300
+timeout -k 5 200 python bench.py --gpus 2 --steps 2 --warmup 1 --dist-backend gloo > $O/dry_spawn_n2.json 2> $O/dry_spawn_n2.err; tail -c 300 $O/dry_spawn_n2.json
