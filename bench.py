@@ -1482,8 +1482,14 @@ def main():
             roof["counter_launches"] = pmc.get("launches")
 
     sharding = ("none" if e_world == 1 else
-                "one stream, blocks split by ownership (no data-path "
-                "collective; union of the grids bit-identical to one GPU's)"
+                ("one stream, blocks split by ownership, block touch sliced "
+                 "over the ranks: ONE all-gather of candidate {key, frame "
+                 "bits} records per chunk of frames (RCCL inside the library); "
+                 "union of the grids bit-identical to one GPU's"
+                 if a.touch == "sliced" else
+                 "one stream, blocks split by ownership, every rank touches "
+                 "every ray (no data-path collective); union of the grids "
+                 "bit-identical to one GPU's")
                 if by_blocks
                 else "frames r, r+N, ... of the one stream per rank; closing "
                      "exchange inside the timed region: all-to-all of block "
