@@ -1978,7 +1978,12 @@ int o3dmi_vbg_integrate_frames(o3dmi_vbg_t* g, int n_frames,
             color_cols == depth_cols && (depth_cols % 4) == 0 &&
             (!color_intrinsic ||
              std::memcmp(color_intrinsic, depth_intrinsic,
-                         sizeof(double) * 9) == 0 || !color_devs)) {
+                         sizeof(double) * 9) == 0 || !color_devs) &&
+            // (the chunk launch needs the proven short division forms: every
+            // rank takes the same decision -- the proof is a property of the
+            // part and the truncation distance -- else the replicated touch)
+            PrefetchFastDivision(g->voxel_size * trunc_voxel_multiplier,
+                                 true) == 2) {
             return StreamIntegrateSliced(
                     g, c, frames.data(), n_frames,
                     frames_per_launch <= 0 ? kDefaultGroup

@@ -23,6 +23,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <string>
 
 #include "stream_path.h"
 #include "sliced_path.h"
@@ -1747,7 +1748,18 @@ int LaunchChunkIntegrate(o3dmi_hash* bh, const ChunkIntegrateArgs& a,
     ip.cube = LaneCube(ip.res_shift);
     ip.sdf_trunc = a.sdf_trunc;
     ip.depth_max = a.depth_max;
-    const int fast_div = VerifyFastDivision(a.sdf_trunc, &ip.inv_sdf_trunc);
+    // The chunk launch exists in the proven short-division forms only (the
+    // IEEE forms of it were half of this file's chunk kernels for a case that
+    // does not occur on gfx950): the sliced path waits for the proof, and
+    // where it fails the caller takes the replicated touch (same grids).
+    const int fast_div =
+            VerifyFastDivision(a.sdf_trunc, &ip.inv_sdf_trunc, /*wait=*/true);
+    if (fast_div != 2) {
+        SetLastError("chunk integrate: the short division forms are not "
+                     "proven for this truncation distance (O3DMI_EXACT_DIV?) "
+                     "-- use the replicated block touch");
+        return O3DMI_ERR_UNSUPPORTED;
+    }
     ip.list = nullptr;
     ip.ready = nullptr;
     ip.entries = a.entries;
@@ -1774,15 +1786,26 @@ int LaunchChunkIntegrate(o3dmi_hash* bh, const ChunkIntegrateArgs& a,
     if (g < kCUs) g = kCUs;
     const dim3 grid((unsigned)g), block(256);
     const bool col = a.with_color && a.color != nullptr;
-    // O3DMI_CHUNK_TIMELINE=<file>: launch number O3DMI_CHUNK_TIMELINE_LAUNCH
-    // (default 20) of the process records a per-work-item timeline (analysis
-    // tool: tools/chunk_timeline.py); the launch is synchronised, every other
-    // launch is untouched.
-    static const char* tl_path = std::getenv("O3DMI_CHUNK_TIMELINE");
+    // O3DMI_CHUNK_TIMELINE=<file>[:<k>]: chunk launch number k (default 20)
+    // of the process records a per-work-item timeline (analysis tool:
+    // tools/chunk_timeline.py); the launch is synchronised, every other launch
+    // is untouched.
+    static std::string tl_file;
     static const int tl_launch = [] {
-        const char* e = std::getenv("O3DMI_CHUNK_TIMELINE_LAUNCH");
-        return e ? atoi(e) : 20;
+        const char* e = std::getenv("O3DMI_CHUNK_TIMELINE");
+        if (!e) return -1;
+        tl_file = e;
+        int k = 20;
+        const size_t colon = tl_file.rfind(':');
+        if (colon != std::string::npos && colon + 1 < tl_file.size() &&
+            tl_file.find_first_not_of("0123456789", colon + 1) ==
+                    std::string::npos) {
+            k = std::atoi(tl_file.c_str() + colon + 1);
+            tl_file.resize(colon);
+        }
+        return k;
     }();
+    const char* tl_path = tl_launch >= 0 ? tl_file.c_str() : nullptr;
     static int tl_seen = 0;
     unsigned long long* tl_dev = nullptr;
     const size_t tl_words = (size_t)a.entries_cap * parts * 4;
@@ -1802,11 +1825,7 @@ int LaunchChunkIntegrate(o3dmi_hash* bh, const ChunkIntegrateArgs& a,
                     (ChunkIntegrateKernel<WT, VT, COLOR, D, false>), grid,    \
                     block, 0, s, cp);                                         \
     } while (0)
-#define O3DMI_LAUNCH_CHUNK(WT, VT, COLOR)                                     \
-    do {                                                                      \
-        if (fast_div == 2) O3DMI_LAUNCH_CHUNK_D(WT, VT, COLOR, 2);            \
-        else O3DMI_LAUNCH_CHUNK_D(WT, VT, COLOR, 0);                          \
-    } while (0)
+#define O3DMI_LAUNCH_CHUNK(WT, VT, COLOR) O3DMI_LAUNCH_CHUNK_D(WT, VT, COLOR, 2)
     if (a.grid_dtype == O3DMI_U16) {
         if (col) O3DMI_LAUNCH_CHUNK(uint16_t, uint16_t, true);
         else O3DMI_LAUNCH_CHUNK(uint16_t, uint16_t, false);
