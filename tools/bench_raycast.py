@@ -20,8 +20,7 @@ ap.add_argument("--hd", action="store_true")
 ap.add_argument("--attrs", default="depth,normal")
 ap.add_argument("--digest", action="store_true",
                 help="add a SHA-256 of the rendered maps (A / B runs, e.g. "
-                     "O3DMI_RAYCAST_COOP=0 / 1 or O3DMI_LIB=<another build>, "
-                     "must print the same one)")
+                     "O3DMI_LIB=<another build>, must print the same one)")
 a = ap.parse_args()
 W, H = (1280, 720) if a.hd else (640, 480)
 K = synthetic.intrinsics(W, H)
