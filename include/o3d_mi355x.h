@@ -49,7 +49,10 @@ typedef enum {
     O3DMI_ERR_NO_INLIERS = 8,   /* "Invalid inlier_count value, must be > 0." */
     O3DMI_ERR_INTERNAL = 9,     /* a device-side consistency check failed  */
     O3DMI_ERR_PEER = 10         /* another rank left a collective call with
-                                   an error (multi-GPU sliced block touch) */
+                                   an error of its own (the sliced block
+                                   touch, the sharded ray cast, the block
+                                   exchanges): this rank left it as well,
+                                   before any payload moved */
 } o3dmi_status_t;
 
 typedef enum {

@@ -526,7 +526,12 @@ int o3dmi_vbg_ray_cast(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
  * of them) of depth / vertex / colour / normal, one all-gather per requested
  * map delivers every rank's band, and every rank ends with the maps
  * o3dmi_vbg_ray_cast produces, bit for bit. COLLECTIVE: every rank calls it
- * with the same arguments. Without a communicator (or with one rank) it is
+ * with the same arguments. What can fail on one rank alone (its arguments,
+ * scratch memory, the band's launch) happens before the first all-gather and
+ * the ranks agree on its status (one 4-byte all-gather, one host wait): the
+ * failing rank returns its error, every other rank O3DMI_ERR_PEER, and no
+ * rank waits in an exchange. The call blocks the host until the maps are
+ * complete. Without a communicator (or with one rank) it is
  * o3dmi_vbg_ray_cast. */
 int o3dmi_vbg_ray_cast_sharded(
         o3dmi_vbg_t* g, const int32_t* block_coords_dev, int64_t m,
@@ -768,10 +773,13 @@ int o3dmi_vbg_merge_blocks(o3dmi_vbg_t* g, const int32_t* keys_dev,
  * ranks hold DISJOINT grids whose union is the model of the whole stream: the
  * same layout block-ownership sharding produces. A rank moves (world - 1) /
  * world of its blocks once (an all-gather of everything would move world x
- * as much to every rank). Collective: every rank of `comm` must call it --
- * also a rank that has an error of its own to report, or the others wait in
- * the exchange. Room for the arriving blocks is reserved BEFORE anything is
- * erased; after o3dmi_vbg_allgather_owned_blocks a further merge is refused
+ * as much to every rank). Collective: every rank of `comm` must call it. A
+ * rank that cannot list its blocks, or cannot reserve room for the arriving
+ * ones, says so in the count exchange / in a status all-gather before the
+ * first payload all-to-all: it returns its own error, the others
+ * O3DMI_ERR_PEER, and every grid still holds what it held (same for the counting and
+ * export stages of o3dmi_vbg_allgather_owned_blocks). Room for the arriving
+ * blocks is reserved BEFORE anything is erased; after o3dmi_vbg_allgather_owned_blocks a further merge is refused
  * (the replicated blocks would be counted again).
  * o3dmi_vbg_allgather_owned_blocks then replicates the finished blocks on
  * every rank (when each GPU is to ray-cast the whole model). */

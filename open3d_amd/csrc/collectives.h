@@ -21,6 +21,12 @@ struct o3dmi_comm {
     o3dmi_transport_t table = {};
     void* user = nullptr;
 
+    // AgreeStatus's words: one per rank on the device, mirrored in pinned
+    // host memory (allocated at the first use, released with the communicator)
+    int* status_dev = nullptr;
+    int* status_host = nullptr;
+    ~o3dmi_comm();
+
     int AllreduceSumF64(double* dev, int64_t n, hipStream_t s);
     int Allgather(const void* send_dev, void* recv_dev, int64_t bytes_per_rank,
                   hipStream_t s);
@@ -29,6 +35,13 @@ struct o3dmi_comm {
                   const int64_t* send_offsets, void* recv_dev,
                   const int64_t* recv_bytes, const int64_t* recv_offsets,
                   hipStream_t s);
+    // For host calls that are collectives with a rank-local stage in front
+    // (render a band, build a chunk ...): every rank passes what its stage
+    // returned and every rank gets the same verdict -- O3DMI_OK if all stages
+    // succeeded, its own status if its own stage failed, O3DMI_ERR_PEER if
+    // only a peer's did -- so that no rank enters the data collectives without
+    // the others. One 4-byte all-gather and one host wait on `s`.
+    int AgreeStatus(int local_status, hipStream_t s);
 };
 
 namespace o3dmi {

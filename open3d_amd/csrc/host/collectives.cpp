@@ -186,6 +186,50 @@ int o3dmi_comm::Allgather(const void* send_dev, void* recv_dev,
                  "ncclAllGather");
 }
 
+o3dmi_comm::~o3dmi_comm() {
+    if (status_dev) (void)hipFree(status_dev);
+    if (status_host) (void)hipHostFree(status_host);
+}
+
+int o3dmi_comm::AgreeStatus(int local_status, hipStream_t s) {
+    if (world <= 1) return local_status;
+    if (!status_dev) {
+        if (hipMalloc((void**)&status_dev, sizeof(int) * (size_t)world) !=
+                    hipSuccess ||
+            hipHostMalloc((void**)&status_host, sizeof(int) * (size_t)world) !=
+                    hipSuccess) {
+            (void)hipGetLastError();
+            if (status_dev) (void)hipFree(status_dev);
+            status_dev = nullptr;
+            // nothing to exchange the status through: the peers cannot be
+            // told
+            if (local_status) return local_status;
+            SetLastError("AgreeStatus: no memory for " +
+                         std::to_string(world) + " status words");
+            return O3DMI_ERR_HIP;
+        }
+    }
+    O3DMI_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)(status_dev + rank),
+                                      local_status, 1, s));
+    // (SetLastError below must not hide the stage's own message)
+    int st = Allgather(status_dev + rank, status_dev, sizeof(int), s);
+    if (st) return local_status ? local_status : st;
+    O3DMI_HIP_CHECK(hipMemcpyAsync(status_host, status_dev,
+                                   sizeof(int) * (size_t)world,
+                                   hipMemcpyDeviceToHost, s));
+    O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    if (local_status) return local_status;
+    for (int r = 0; r < world; ++r)
+        if (status_host[r] != 0) {
+            SetLastError("rank " + std::to_string(r) +
+                         " failed its part of a collective call (status " +
+                         std::to_string(status_host[r]) +
+                         "); nothing was exchanged");
+            return O3DMI_ERR_PEER;
+        }
+    return O3DMI_OK;
+}
+
 int o3dmi_comm::Alltoallv(const void* send_dev, const int64_t* send_bytes,
                           const int64_t* send_offsets, void* recv_dev,
                           const int64_t* recv_bytes,

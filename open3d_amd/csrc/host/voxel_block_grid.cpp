@@ -2248,41 +2248,13 @@ int o3dmi_vbg_ray_cast_sharded(
                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                 depth_scale, depth_min, depth_max, weight_threshold,
                 trunc_voxel_multiplier, range_map_down_factor, stream);
-    O3DMI_REQUIRE(g && range_map_dev && intrinsic && extrinsic &&
-                          width > 0 && height > 0,
-                  "bad argument");
-    int ti = g->AttrIndex("tsdf"), wi = g->AttrIndex("weight"),
-        ci = g->AttrIndex("color");
-    if (ti < 0 || wi < 0) {
-        SetLastError(
-                "TSDF and/or weight not allocated in blocks, please implement "
-                "customized integration.");
-        return O3DMI_ERR_INVALID_ARG;
-    }
-    int grid_dtype;
-    int st = GridDtype(g, &grid_dtype);
-    if (st) return st;
+    // A collective call: what can fail on one rank alone (arguments, the
+    // pool, a launch) is the rank-local stage below, whose status the ranks
+    // AGREE on before the first all-gather -- a rank whose stage failed does
+    // not leave its peers waiting in a collective it never enters; they
+    // return O3DMI_ERR_PEER.
     hipStream_t s = (hipStream_t)stream;
     const int world = comm->world, rank = comm->rank;
-    // the range map is cheap (one pass over the frustum's block keys) and
-    // replicated: every rank needs the cells of its band only, but all of it
-    // is an output of the call
-    if ((st = o3dmi_vbg_estimate_range_dev(
-                 block_coords_dev, m, nullptr, range_map_dev, intrinsic,
-                 extrinsic, height, width, range_map_down_factor,
-                 g->block_resolution, g->voxel_size, depth_min, depth_max,
-                 stream)))
-        return st;
-    const int tiles = (height + 7) / 8;
-    const int band_tiles = (tiles + world - 1) / world;
-    const int band_rows = band_tiles * 8;
-    const int padded = band_rows * world;  // rows of the gathered maps
-    int r0 = rank * band_rows, r1 = r0 + band_rows;
-    if (r0 > height) r0 = height;
-    if (r1 > height) r1 = height;
-    // Maps of `padded` rows, gathered in place (a rank's band is a contiguous
-    // run of rows); the caller's {height, width, C} maps are their first
-    // rows.
     struct Map {
         float* out;
         int channels;
@@ -2291,44 +2263,81 @@ int o3dmi_vbg_ray_cast_sharded(
                  {out_vertex, 3, nullptr},
                  {out_color, 3, nullptr},
                  {out_normal, 3, nullptr}};
-    size_t floats = 0;
-    for (Map& mp : maps)
-        if (mp.out) floats += (size_t)padded * width * mp.channels;
-    if (floats == 0) return O3DMI_OK;
-    float* stage = nullptr;
-    if ((st = PoolAlloc((void**)&stage, floats * sizeof(float)))) return st;
-    struct Free {
+    struct Staging {
         hipStream_t s;
-        void* p;
-        ~Free() {
+        void* p = nullptr;
+        ~Staging() {
+            if (!p) return;
             (void)hipStreamSynchronize(s);
             PoolFree(p);
         }
-    } free_stage{s, stage};
-    {
-        float* q = stage;
+    } staging{s};
+    int band_rows = 0;
+    // ---- rank-local stage: the range map and this rank's band of tile rows,
+    // rendered into rows [r0, r1) of maps of `band_rows * world` rows (the
+    // kernel addresses pixels of the whole image)
+    const auto render_band = [&]() -> int {
+        O3DMI_REQUIRE(g && range_map_dev && intrinsic && extrinsic &&
+                              width > 0 && height > 0,
+                      "bad argument");
+        int ti = g->AttrIndex("tsdf"), wi = g->AttrIndex("weight"),
+            ci = g->AttrIndex("color");
+        if (ti < 0 || wi < 0) {
+            SetLastError(
+                    "TSDF and/or weight not allocated in blocks, please "
+                    "implement customized integration.");
+            return O3DMI_ERR_INVALID_ARG;
+        }
+        int grid_dtype;
+        int st = GridDtype(g, &grid_dtype);
+        if (st) return st;
+        // the range map is cheap (one pass over the frustum's block keys)
+        // and replicated: every rank needs the cells of its band only, but
+        // all of it is an output of the call
+        if ((st = o3dmi_vbg_estimate_range_dev(
+                     block_coords_dev, m, nullptr, range_map_dev, intrinsic,
+                     extrinsic, height, width, range_map_down_factor,
+                     g->block_resolution, g->voxel_size, depth_min, depth_max,
+                     stream)))
+            return st;
+        const int tiles = (height + 7) / 8;
+        const int band_tiles = (tiles + world - 1) / world;
+        band_rows = band_tiles * 8;
+        const int padded = band_rows * world;  // rows of the gathered maps
+        int r0 = rank * band_rows, r1 = r0 + band_rows;
+        if (r0 > height) r0 = height;
+        if (r1 > height) r1 = height;
+        size_t floats = 0;
+        for (Map& mp : maps)
+            if (mp.out) floats += (size_t)padded * width * mp.channels;
+        if (floats == 0) return O3DMI_OK;
+        if ((st = PoolAlloc(&staging.p, floats * sizeof(float)))) return st;
+        float* q = (float*)staging.p;
         for (Map& mp : maps)
             if (mp.out) {
                 mp.staged = q;
                 q += (size_t)padded * width * mp.channels;
             }
-    }
-    const void* cbuf = (ci >= 0 && out_color)
-                               ? o3dmi_hash_value_buffer(g->block_hashmap, ci)
-                               : nullptr;
-    // the band renders into rows [r0, r1) of the staged maps (the kernel
-    // addresses pixels of the whole image)
-    if ((st = o3dmi_vbg_raycast_rows(
-                 g->block_hashmap,
-                 (const float*)o3dmi_hash_value_buffer(g->block_hashmap, ti),
-                 o3dmi_hash_value_buffer(g->block_hashmap, wi), cbuf,
-                 grid_dtype, range_map_dev, maps[0].staged, maps[1].staged,
-                 maps[2].staged, maps[3].staged, nullptr, nullptr, nullptr,
-                 nullptr, nullptr, nullptr, intrinsic, extrinsic, height, width,
-                 r0, r1, (int)g->block_resolution, g->voxel_size, depth_scale,
-                 depth_min, depth_max, weight_threshold, trunc_voxel_multiplier,
-                 range_map_down_factor, stream)))
-        return st;
+        const void* cbuf =
+                (ci >= 0 && out_color)
+                        ? o3dmi_hash_value_buffer(g->block_hashmap, ci)
+                        : nullptr;
+        return o3dmi_vbg_raycast_rows(
+                g->block_hashmap,
+                (const float*)o3dmi_hash_value_buffer(g->block_hashmap, ti),
+                o3dmi_hash_value_buffer(g->block_hashmap, wi), cbuf,
+                grid_dtype, range_map_dev, maps[0].staged, maps[1].staged,
+                maps[2].staged, maps[3].staged, nullptr, nullptr, nullptr,
+                nullptr, nullptr, nullptr, intrinsic, extrinsic, height, width,
+                r0, r1, (int)g->block_resolution, g->voxel_size, depth_scale,
+                depth_min, depth_max, weight_threshold, trunc_voxel_multiplier,
+                range_map_down_factor, stream);
+    };
+    int st = comm->AgreeStatus(render_band(), s);
+    if (st) return st;
+    // ---- collective stage: a rank's band is a contiguous run of rows, so
+    // the maps are gathered in place; the caller's {height, width, C} maps
+    // are their first rows
     for (Map& mp : maps) {
         if (!mp.out) continue;
         const int64_t seg = (int64_t)band_rows * width * mp.channels *
@@ -2480,7 +2489,11 @@ int o3dmi_vbg_merge_frame_sharded(o3dmi_vbg_t* g, o3dmi_comm_t* comm,
         O3DMI_HIP_CHECK(hipGetLastError());
         return O3DMI_OK;
     };
-    if ((st = group_by_owner())) return st;
+    // (A rank-local failure must not leave the peers waiting in an exchange
+    // this rank never enters: step 1's status travels with the counts of step
+    // 2 -- a negative first count --, the Reserve's is agreed on before step 3;
+    // every rank then returns, its own error or O3DMI_ERR_PEER.)
+    const int grouped_st = group_by_owner();
     // 2. ---------------------------------------------------------------------
     int64_t* matrix_dev = nullptr;  // [world][world]: row r = rank r's counts
     if ((st = scratch.Alloc((void**)&matrix_dev,
@@ -2488,6 +2501,7 @@ int o3dmi_vbg_merge_frame_sharded(o3dmi_vbg_t* g, o3dmi_comm_t* comm,
         return st;
     std::vector<int64_t> mine((size_t)world), matrix((size_t)world * world);
     for (int r = 0; r < world; ++r) mine[(size_t)r] = host_counts[r];
+    if (grouped_st) mine[0] = -(int64_t)grouped_st;
     int64_t* mine_dev = matrix_dev + (size_t)world * world;
     O3DMI_HIP_CHECK(hipMemcpyAsync(mine_dev, mine.data(),
                                    sizeof(int64_t) * world,
@@ -2498,6 +2512,15 @@ int o3dmi_vbg_merge_frame_sharded(o3dmi_vbg_t* g, o3dmi_comm_t* comm,
                                    sizeof(int64_t) * (size_t)world * world,
                                    hipMemcpyDeviceToHost, s));
     O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    if (grouped_st) return grouped_st;
+    for (int r = 0; r < world; ++r)
+        if (matrix[(size_t)r * world] < 0) {
+            SetLastError("merge_frame_sharded: rank " + std::to_string(r) +
+                         " could not list its blocks (status " +
+                         std::to_string(-matrix[(size_t)r * world]) +
+                         "); nothing was exchanged");
+            return O3DMI_ERR_PEER;
+        }
     // blocks per peer: sent (nothing to itself) and received
     std::vector<int64_t> send_n((size_t)world), recv_n((size_t)world),
             send_first((size_t)world), recv_first((size_t)world);
@@ -2514,17 +2537,17 @@ int o3dmi_vbg_merge_frame_sharded(o3dmi_vbg_t* g, o3dmi_comm_t* comm,
     // leave a grid whose foreign blocks were already gone). The map keeps its
     // own host_counts[me] blocks; a Reserve renumbers the buffer indices, so
     // the grouping is redone (the counts the ranks exchanged do not change).
+    int room_st = O3DMI_OK;
     if ((int64_t)host_counts[me] + recv_total >
         o3dmi_hash_capacity(g->block_hashmap)) {
         const int64_t cap0 = o3dmi_hash_capacity(g->block_hashmap);
         const int64_t need = (int64_t)n + recv_total;
-        if ((st = o3dmi_hash_reserve(g->block_hashmap,
-                                     need > 2 * cap0 ? need : 2 * cap0,
-                                     stream)))
-            return st;
+        room_st = o3dmi_hash_reserve(g->block_hashmap,
+                                     need > 2 * cap0 ? need : 2 * cap0, stream);
         g->known_valid = false;
-        if ((st = group_by_owner())) return st;
+        if (!room_st) room_st = group_by_owner();
     }
+    if ((st = comm->AgreeStatus(room_st, s))) return st;
     // 3. ---------------------------------------------------------------------
     auto exchange = [&](const void* src_rows, int64_t row, void** out) -> int {
         char* send = nullptr;
@@ -2630,9 +2653,13 @@ int o3dmi_vbg_allgather_owned_blocks(o3dmi_vbg_t* g, o3dmi_comm_t* comm,
         }
     } scratch{s, {}};
     int st;
+    // (Rank-local failures do not leave the peers waiting: the status of the
+    // count travels as a negative count, the status of the export is agreed
+    // on before the payload all-gathers.)
     int64_t n = 0;
-    if ((st = o3dmi_vbg_export_blocks(g, 0, nullptr, nullptr, &n, stream)))
-        return st;
+    const int count_st =
+            o3dmi_vbg_export_blocks(g, 0, nullptr, nullptr, &n, stream);
+    if (count_st) n = -(int64_t)count_st;
     int64_t* counts_dev = nullptr;
     if ((st = scratch.Alloc((void**)&counts_dev,
                             sizeof(int64_t) * (size_t)(world + 1))))
@@ -2647,27 +2674,42 @@ int o3dmi_vbg_allgather_owned_blocks(o3dmi_vbg_t* g, o3dmi_comm_t* comm,
                                    sizeof(int64_t) * world,
                                    hipMemcpyDeviceToHost, s));
     O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+    if (count_st) return count_st;
     int64_t m = 0;
-    for (int64_t c : counts) m = c > m ? c : m;
+    for (int r = 0; r < world; ++r) {
+        const int64_t c = counts[(size_t)r];
+        if (c < 0) {
+            SetLastError("allgather_owned_blocks: rank " + std::to_string(r) +
+                         " could not count its blocks (status " +
+                         std::to_string(-c) + "); nothing was exchanged");
+            return O3DMI_ERR_PEER;
+        }
+        m = c > m ? c : m;
+    }
     if (m == 0) return O3DMI_OK;
     int32_t* keys = nullptr;
     int32_t* all_keys = nullptr;
-    if ((st = scratch.Alloc((void**)&keys, (size_t)m * 12)) ||
-        (st = scratch.Alloc((void**)&all_keys, (size_t)m * 12 * world)))
-        return st;
     std::vector<void*> rows(n_attr), all_rows(n_attr);
     std::vector<int64_t> row_bytes(n_attr);
-    for (size_t i = 0; i < n_attr; ++i) {
+    for (size_t i = 0; i < n_attr; ++i)
         row_bytes[i] = res * res * res * g->attr_channels[i] *
                        DtypeSize(g->attr_dtypes[i]);
-        if ((st = scratch.Alloc(&rows[i], (size_t)(m * row_bytes[i]))) ||
-            (st = scratch.Alloc(&all_rows[i],
-                                (size_t)(m * row_bytes[i] * world))))
-            return st;
-    }
-    int64_t n2 = 0;
-    if ((st = o3dmi_vbg_export_blocks(g, m, keys, rows.data(), &n2, stream)))
-        return st;
+    // the scratch scales with the LARGEST rank's share: the likely place for
+    // one rank alone to run out of memory
+    const auto export_mine = [&]() -> int {
+        int e;
+        if ((e = scratch.Alloc((void**)&keys, (size_t)m * 12)) ||
+            (e = scratch.Alloc((void**)&all_keys, (size_t)m * 12 * world)))
+            return e;
+        for (size_t i = 0; i < n_attr; ++i)
+            if ((e = scratch.Alloc(&rows[i], (size_t)(m * row_bytes[i]))) ||
+                (e = scratch.Alloc(&all_rows[i],
+                                   (size_t)(m * row_bytes[i] * world))))
+                return e;
+        int64_t n2 = 0;
+        return o3dmi_vbg_export_blocks(g, m, keys, rows.data(), &n2, stream);
+    };
+    if ((st = comm->AgreeStatus(export_mine(), s))) return st;
     if ((st = comm->Allgather(keys, all_keys, m * 12, s))) return st;
     for (size_t i = 0; i < n_attr; ++i)
         if ((st = comm->Allgather(rows[i], all_rows[i], m * row_bytes[i], s)))

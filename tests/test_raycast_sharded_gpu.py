@@ -153,6 +153,68 @@ def test_sharded_ray_cast_equals_the_single_rank_maps_bit_for_bit(world, w, h):
             assert torch.equal(got, exp), (r, a)
 
 
+def test_a_rank_whose_own_stage_fails_does_not_leave_its_peers_waiting():
+    """The call is a collective with a rank-local stage in front (arguments,
+    scratch, the band's launch): the ranks agree on that stage's status before
+    the first all-gather. Rank 1 asks for a width the kernel seam refuses --
+    it gets its own error, the others O3DMI_ERR_PEER, promptly, and the same
+    communicators then render the maps."""
+    _lib, geometry = _gpu()
+    world, w, h = 3, 320, 240
+    g, d, K, Ts = _grid_with_frames(geometry, 100, 3, w, h)
+    T = Ts[1]
+    keys = g.compute_unique_block_coordinates(d[1], K, T, sc.DEPTH_SCALE,
+                                              sc.DEPTH_MAX, sc.TRUNC_MULT)
+    want = g.ray_cast(keys, K, T, w, h, ("depth",), sc.DEPTH_SCALE, 0.1,
+                      sc.DEPTH_MAX, 1.0, sc.TRUNC_MULT, 8)
+    torch.cuda.synchronize()
+    lb = _Loopback(world)
+    status = [None] * world
+    again = [None] * world
+
+    def rank_main(rank):
+        try:
+            comm = lb.comm(rank)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                comm.install()
+                try:
+                    try:
+                        g.ray_cast(keys, K, T, w + 4 if rank == 1 else w, h,
+                                   ("depth",), sc.DEPTH_SCALE, 0.1,
+                                   sc.DEPTH_MAX, 1.0, sc.TRUNC_MULT, 8,
+                                   sharded=True)
+                        status[rank] = 0
+                    except _lib.O3DMIError as e:
+                        status[rank] = (e.status, str(e))
+                    again[rank] = g.ray_cast(keys, K, T, w, h, ("depth",),
+                                             sc.DEPTH_SCALE, 0.1, sc.DEPTH_MAX,
+                                             1.0, sc.TRUNC_MULT, 8,
+                                             sharded=True)
+                    torch.cuda.synchronize()
+                finally:
+                    comm.uninstall()
+            comm.destroy()
+        except BaseException as ex:  # noqa: BLE001 - reported below
+            again[rank] = ex
+            lb.barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,))
+               for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(60)
+    assert not any(t.is_alive() for t in threads), "a rank is still waiting"
+    assert status[1] is not None and status[1][0] == 1, status  # INVALID_ARG
+    for r in (0, 2):
+        assert status[r] is not None and status[r][0] == 10, status  # PEER
+        assert "rank 1" in status[r][1], status[r]
+    for r in range(world):
+        assert not isinstance(again[r], BaseException), again[r]
+        assert torch.equal(again[r]["depth"].view(torch.int32),
+                           want["depth"].view(torch.int32)), r
+
+
 def test_band_rows_are_validated():
     _lib, geometry = _gpu()
     g, d, K, Ts = _grid_with_frames(geometry, 100, 1, 64, 48)
