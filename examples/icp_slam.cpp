@@ -28,11 +28,14 @@
 // ranks > 1 (BASELINE configs[3], the tracking half): one host thread per
 // rank, rank r on device r % device_count, every rank the same loop on the
 // same frames with a replicated model (the ray cast needs every block); what
-// is sharded is the Gauss-Newton work of MultiScaleICP -- o3dmi_set_comm +
+// is sharded is (1) the Gauss-Newton work of MultiScaleICP -- o3dmi_set_comm +
 // o3dmi_set_icp_level_sharding(1): each rank searches / accumulates its slice
 // of every pyramid level and the 32 float64 sums are all-reduced inside the
 // iteration by the library itself (ncclAllReduce on the launch stream over
-// xGMI; no Python anywhere). `loopback` swaps RCCL for an in-process
+// xGMI; no Python anywhere) -- and (2) the model frame's ray cast --
+// o3dmi_vbg_ray_cast_sharded: a band of pixel rows per rank, one all-gather
+// per map, every rank ends with the single-rank maps bit for bit.
+// `loopback` swaps RCCL for an in-process
 // transport (host threads meeting at a barrier), which also runs when the
 // ranks share one GPU -- RCCL refuses that -- and is how the mode is
 // exercised on a single-GPU box. Every rank must end with the same poses.
@@ -117,6 +120,7 @@ struct Loopback {
     int waiting = 0;
     long generation = 0;
     std::vector<double> rows;  // [world][32]
+    std::vector<char> gathered;  // all-gather: [world][bytes per rank]
     explicit Loopback(int w) : world(w), rows((size_t)w * 32, 0.0) {}
     void Barrier() {
         std::unique_lock<std::mutex> lk(mu);
@@ -153,6 +157,26 @@ int LoopbackAllreduce(void* user, double* dev, int64_t n, o3dmi_stream_t s) {
                            hipSuccess
                    ? 0
                    : 1;
+}
+
+// o3dmi_transport_t::allgather the same way (send may lie inside recv: the
+// segment is on the host before anybody writes recv)
+int LoopbackAllgather(void* user, const void* send, void* recv, int64_t bytes,
+                      o3dmi_stream_t s) {
+    auto* me = (LoopbackRank*)user;
+    Loopback* lb = me->shared;
+    if (hipStreamSynchronize((hipStream_t)s) != hipSuccess) return 1;
+    if (me->rank == 0) lb->gathered.resize((size_t)bytes * lb->world);
+    lb->Barrier();
+    if (hipMemcpy(&lb->gathered[(size_t)bytes * me->rank], send, (size_t)bytes,
+                  hipMemcpyDeviceToHost) != hipSuccess)
+        return 1;
+    lb->Barrier();
+    const bool ok = hipMemcpy(recv, lb->gathered.data(),
+                              (size_t)bytes * lb->world,
+                              hipMemcpyHostToDevice) == hipSuccess;
+    lb->Barrier();  // everybody has read the segments
+    return ok ? 0 : 1;
 }
 
 struct RankResult {
@@ -201,6 +225,7 @@ int main(int argc, char** argv) {
             } else {
                 o3dmi_transport_t table = {};
                 table.allreduce_sum_f64 = LoopbackAllreduce;
+                table.allgather = LoopbackAllgather;
                 CHECK_O3D(o3dmi_comm_create_custom(&table, &lranks[(size_t)r],
                                                    r, world, &comm));
             }
@@ -341,11 +366,27 @@ int RunRank(int argc, char** argv, int rank, int world, o3dmi_comm_t* comm,
                     grid, depth_dev[(size_t)k - 1], O3DMI_U16, H, W, K, X,
                     depth_scale, depth_max, trunc, keys, &m, stream));
         const double p1 = now();
-        CHECK_O3D(o3dmi_vbg_ray_cast_dev(
-                grid, keys, m, touch_again ? nullptr : keys_count, K, X, W, H,
-                range_map, rc_depth, nullptr, nullptr, rc_normal, nullptr,
-                nullptr, nullptr, nullptr, nullptr, nullptr, depth_scale, 0.1f,
-                depth_max, 1.0f, trunc, 8, stream));
+        if (world > 1) {
+            // the model frame by all ranks together: a band of rows each (the
+            // collective takes the number of keys from the host)
+            if (!touch_again) {
+                int32_t live = 0;
+                CHECK_HIP(hipMemcpyAsync(&live, keys_count, sizeof(live),
+                                         hipMemcpyDeviceToHost, stream));
+                CHECK_HIP(hipStreamSynchronize(stream));
+                m = live < keys_cap ? live : keys_cap;
+            }
+            CHECK_O3D(o3dmi_vbg_ray_cast_sharded(
+                    grid, keys, m, K, X, W, H, range_map, rc_depth, nullptr,
+                    nullptr, rc_normal, depth_scale, 0.1f, depth_max, 1.0f,
+                    trunc, 8, stream));
+        } else {
+            CHECK_O3D(o3dmi_vbg_ray_cast_dev(
+                    grid, keys, m, touch_again ? nullptr : keys_count, K, X, W,
+                    H, range_map, rc_depth, nullptr, nullptr, rc_normal,
+                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                    depth_scale, 0.1f, depth_max, 1.0f, trunc, 8, stream));
+        }
         CHECK_O3D(o3dmi_unproject(rc_depth, O3DMI_F32, H, W, rc_normal,
                                   model_pts, model_nrm, counts, K, X,
                                   depth_scale, depth_max, stride, stream));

@@ -777,10 +777,11 @@ int o3dmi_vbg_merge_blocks(o3dmi_vbg_t* g, const int32_t* keys_dev,
  * rank that cannot list its blocks, or cannot reserve room for the arriving
  * ones, says so in the count exchange / in a status all-gather before the
  * first payload all-to-all: it returns its own error, the others
- * O3DMI_ERR_PEER, and every grid still holds what it held (same for the counting and
- * export stages of o3dmi_vbg_allgather_owned_blocks). Room for the arriving
- * blocks is reserved BEFORE anything is erased; after o3dmi_vbg_allgather_owned_blocks a further merge is refused
- * (the replicated blocks would be counted again).
+ * O3DMI_ERR_PEER, and every grid still holds what it held (same for the
+ * counting and export stages of o3dmi_vbg_allgather_owned_blocks). Room for
+ * the arriving blocks is reserved BEFORE anything is erased; after
+ * o3dmi_vbg_allgather_owned_blocks a further merge is refused (the replicated
+ * blocks would be counted again).
  * o3dmi_vbg_allgather_owned_blocks then replicates the finished blocks on
  * every rank (when each GPU is to ray-cast the whole model). */
 int o3dmi_vbg_merge_frame_sharded(o3dmi_vbg_t* g, o3dmi_comm_t* comm,

@@ -215,6 +215,62 @@ def test_a_rank_whose_own_stage_fails_does_not_leave_its_peers_waiting():
                            want["depth"].view(torch.int32)), r
 
 
+def _two_process_rank(rank, world):
+    """One rank of the two-process sharded ray cast: own process, own HIP
+    context, own replica of the grid (the same frames integrated), the maps
+    all-gathered through sharding.Comm.for_backend -- RCCL inside the library
+    when every rank has its own GPU, else torch.distributed's gloo staged
+    through the host."""
+    import torch.distributed as dist
+    from open3d_amd import geometry
+    from open3d_amd.sharding import Comm
+    w, h = 320, 240
+    g, d, K, Ts = _grid_with_frames(geometry, 100, 3, w, h)
+    T = Ts[1]
+    keys = g.compute_unique_block_coordinates(d[1], K, T, sc.DEPTH_SCALE,
+                                              sc.DEPTH_MAX, sc.TRUNC_MULT)
+    attrs = ("depth", "vertex", "color", "normal")
+    args = (keys, K, T, w, h, attrs, sc.DEPTH_SCALE, 0.1, sc.DEPTH_MAX, 1.0,
+            sc.TRUNC_MULT, 8)
+    want = g.ray_cast(*args)
+    torch.cuda.synchronize()
+    comm = Comm.for_backend(dist)
+    comm.install()
+    try:
+        got = g.ray_cast(*args, sharded=True)
+        torch.cuda.synchronize()
+    finally:
+        Comm.uninstall()
+        comm.destroy()
+    same = all(torch.equal(got[a].view(torch.int32), want[a].view(torch.int32))
+               for a in attrs + ("range",))
+    import hashlib
+    digest = hashlib.sha256(b"".join(
+        got[a].cpu().numpy().tobytes() for a in attrs)).hexdigest()
+    return (same, float((want["depth"] > 0).float().mean()), digest,
+            dist.get_backend())
+
+
+@pytest.mark.timeout(600)
+def test_sharded_ray_cast_two_processes_over_torch_distributed():
+    """The same call with real processes and the transport a multi-GPU run
+    uses (`bench.py --gpus N` ranks are processes of torch.distributed.run):
+    two ranks, each its own process and grid replica; RCCL when the box has
+    two GPUs, gloo with both ranks on this GPU otherwise. Each rank's maps
+    equal its own single-rank maps bit for bit, and the ranks' maps each
+    other's."""
+    from test_sharding import _run
+    _gpu()
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    got = _run(_two_process_rank, backend=backend)
+    for r in range(2):
+        same, covered, _, be = got[r]
+        assert be == backend
+        assert covered > 0.2
+        assert same, r
+    assert got[0][2] == got[1][2]
+
+
 def test_band_rows_are_validated():
     _lib, geometry = _gpu()
     g, d, K, Ts = _grid_with_frames(geometry, 100, 1, 64, 48)

@@ -279,7 +279,9 @@ def test_cpp_icp_tracking_example_sharded_ranks_through_the_library_comm():
     """examples/icp_slam.cpp with ranks = 3: one host thread per rank, the
     library's communicator installed from C++ (o3dmi_set_comm +
     o3dmi_set_icp_level_sharding), the per-iteration all-reduce inside the
-    library. On this one-GPU box the in-process loopback transport stands in
+    library, and the model frame rendered by the ranks together
+    (o3dmi_vbg_ray_cast_sharded: a band of rows each, all-gathered -- the whole
+    multi-GPU tracking frame of SURVEY 8(e)). On this one-GPU box the in-process loopback transport stands in
     for RCCL (which refuses several ranks on one device) -- and, where the box
     has the GPUs, the RCCL transport is run as well. Every rank must end with
     the same poses; against the single-rank run the ICP calls agree to the
