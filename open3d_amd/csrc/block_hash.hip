@@ -24,10 +24,19 @@ void SetLastError(const std::string& msg) { g_last_error = msg; }
 
 namespace {
 
-__global__ void InitHeapKernel(int* heap, int capacity) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < capacity;
-         i += gridDim.x * blockDim.x)
-        heap[i] = i;
+// Clear(): every slot empty, the free-index heap the identity, the counters
+// zero -- one launch (three fills and a heap launch until round 5: 19 us in
+// front of every frame's DepthTouch, whose own kernel takes 14;
+// profiles/r5r_api_legs.txt). `also_zero`: a caller's counter cleared in the
+// same launch (the touch kernels' output count), may be null.
+__global__ void ClearKernel(HashView v, long long n_slots, int capacity,
+                            int* also_zero) {
+    const long long i0 = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (long long i = i0; i < n_slots; i += step) v.slot_keys[i] = ~0ull;
+    for (long long i = i0; i < capacity; i += step) v.heap[i] = (int)i;
+    if (i0 < 4) v.counters[i0] = 0;
+    if (i0 == 4 && also_zero) *also_zero = 0;
 }
 
 // Insert-if-absent. One thread per input key; duplicates in the same launch
@@ -247,14 +256,14 @@ void FreeStorage(o3dmi_hash* h) {
     v.owner_world = owner_world;
 }
 
-int ClearImpl(o3dmi_hash* h, hipStream_t s) {
-    HashView& v = h->view;
-    O3DMI_HIP_CHECK(hipMemsetAsync(v.slot_keys, 0xFF,
-                                   sizeof(unsigned long long) *
-                                           (size_t)h->n_slots, s));
-    O3DMI_HIP_CHECK(hipMemsetAsync(v.counters, 0, sizeof(int) * 4, s));
-    hipLaunchKernelGGL(InitHeapKernel, dim3(GridFor(h->capacity, kBlock)),
-                       dim3(kBlock), 0, s, v.heap, (int)h->capacity);
+int ClearImpl(o3dmi_hash* h, hipStream_t s, int* also_zero = nullptr) {
+    // 8 slots per thread: a 50 000-block map (2^17 slots) is 64 workgroups
+    int64_t groups = (h->n_slots / 8 + kBlock - 1) / kBlock;
+    if (groups < 1) groups = 1;
+    if (groups > 4096) groups = 4096;
+    hipLaunchKernelGGL(ClearKernel, dim3((unsigned)groups), dim3(kBlock), 0, s,
+                       h->view, (long long)h->n_slots, (int)h->capacity,
+                       also_zero);
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
 }
@@ -310,8 +319,17 @@ int RebuildSlotsIfCrowded(o3dmi_hash* h, hipStream_t s) {
 // that waits for the counters anyway (Size, and through it the frame stream's
 // capacity policy and Reserve) also rebuilds a crowded table here.
 int CheckDeferred(o3dmi_hash* h, hipStream_t s, int* top_out) {
-    int host[4] = {0, 0, 0, 0};
-    O3DMI_HIP_CHECK(hipMemcpyAsync(host, h->view.counters, sizeof(host),
+    // into pinned memory: one asynchronous copy and one wait (a copy into
+    // pageable memory is staged by the runtime, a second round trip)
+    if (!h->counters_host &&
+        hipHostMalloc((void**)&h->counters_host, sizeof(int) * 4) !=
+                hipSuccess) {
+        (void)hipGetLastError();
+        h->counters_host = nullptr;
+    }
+    int stack[4] = {0, 0, 0, 0};
+    int* host = h->counters_host ? h->counters_host : stack;
+    O3DMI_HIP_CHECK(hipMemcpyAsync(host, h->view.counters, sizeof(int) * 4,
                                    hipMemcpyDeviceToHost, s));
     O3DMI_HIP_CHECK(hipStreamSynchronize(s));
     if (top_out) *top_out = host[0];
@@ -342,6 +360,10 @@ int CheckDeferred(o3dmi_hash* h, hipStream_t s, int* top_out) {
 
 
 }  // namespace
+
+int ClearHashAndCounter(o3dmi_hash* h, int* counter_dev, hipStream_t s) {
+    return ClearImpl(h, s, counter_dev);
+}
 
 int RecoverOverflow(o3dmi_hash* h, hipStream_t s, int64_t* wanted) {
     O3DMI_HIP_CHECK(hipStreamSynchronize(s));
@@ -431,6 +453,7 @@ int o3dmi_hash_destroy(o3dmi_hash_t* h) {
     if (!h) return O3DMI_OK;
     FreeStorage(h);
     (void)hipFree(h->scratch_count);
+    if (h->counters_host) (void)hipHostFree(h->counters_host);
     delete h;
     return O3DMI_OK;
 }

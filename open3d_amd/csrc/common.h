@@ -380,4 +380,12 @@ struct o3dmi_hash {
     int64_t value_dsizes[8] = {0};
     void* value_buffers[8] = {nullptr};
     int* scratch_count = nullptr;  // device int for compaction kernels
+    int* counters_host = nullptr;  // pinned mirror of view.counters (4 ints):
+                                   // size queries wait for one async copy
 };
+
+namespace o3dmi {
+// o3dmi_hash_clear and one more device counter zeroed by the same launch
+// (block_hash.hip; the touch kernels' output count).
+int ClearHashAndCounter(o3dmi_hash* h, int* counter_dev, hipStream_t s);
+}  // namespace o3dmi

@@ -559,13 +559,17 @@ int o3dmi_vbg_get_unique_block_coordinates(
             g->voxel_size * trunc_voxel_multiplier, depth_scale, depth_max,
             (int)down_factor, stream);
     if (st) return st;
-    int32_t count = 0;
-    O3DMI_HIP_CHECK(hipMemcpyAsync(&count, g->frame_count, sizeof(int32_t),
-                                   hipMemcpyDeviceToHost,
+    // The count rides to pinned memory in front of the size query's own copy
+    // and wait: one round trip to the host per call (as upstream: the size of
+    // the returned tensor), not one per word.
+    g->size_host[2] = 0;
+    O3DMI_HIP_CHECK(hipMemcpyAsync(&g->size_host[2], g->frame_count,
+                                   sizeof(int32_t), hipMemcpyDeviceToHost,
                                    (hipStream_t)stream));
     int64_t dummy = 0;
     st = o3dmi_hash_size(g->frustum_hashmap, stream, &dummy);  // syncs + errors
     if (st) return st;
+    const int32_t count = g->size_host[2];
     *m_out = count;
     if (count == 0) {
         SetLastError(o3dmi_status_string(O3DMI_ERR_NO_BLOCKS));

@@ -299,9 +299,9 @@ int o3dmi_vbg_depth_touch(o3dmi_hash_t* fh, const void* depth_dev,
     TouchParams p = MakeTouchParams(intrinsic, extrinsic, rows, cols, stride,
                                     resolution, voxel_size, sdf_trunc,
                                     depth_scale, depth_max);
-    int st = o3dmi_hash_clear(fh, stream);
+    // frustum map and output count cleared by one launch
+    int st = ClearHashAndCounter(fh, out_count_dev, s);
     if (st != O3DMI_OK) return st;
-    O3DMI_HIP_CHECK(hipMemsetAsync(out_count_dev, 0, sizeof(int), s));
     int n = p.rows_strided * p.cols_strided;
     dim3 grid(GridFor(n, kBlock)), block(kBlock);
     if (depth_dtype == O3DMI_U16)
@@ -365,9 +365,8 @@ int o3dmi_vbg_pointcloud_touch(o3dmi_hash_t* fh, const float* points_dev,
     O3DMI_REQUIRE(fh && points_dev && out_coords_dev && out_count_dev,
                   "null argument");
     hipStream_t s = (hipStream_t)stream;
-    int st = o3dmi_hash_clear(fh, stream);
+    int st = ClearHashAndCounter(fh, out_count_dev, s);
     if (st != O3DMI_OK) return st;
-    O3DMI_HIP_CHECK(hipMemsetAsync(out_count_dev, 0, sizeof(int), s));
     if (n == 0) return O3DMI_OK;
     hipLaunchKernelGGL(PointCloudTouchKernel, dim3(GridFor(n, kBlock)),
                        dim3(kBlock), 0, s, fh->view, points_dev, n,
