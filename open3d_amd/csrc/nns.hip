@@ -46,10 +46,14 @@ __global__ void CountKernel(const T* __restrict__ pts, int64_t n,
 // n_buckets is a power of two >= 1024, so every workgroup is full.
 constexpr int kAssignBlock = 1024;
 __global__ void __launch_bounds__(kAssignBlock)
-AssignRangesKernel(uint2* __restrict__ ranges, int64_t n_buckets) {
+AssignRangesKernel(uint2* __restrict__ ranges, int64_t n_buckets,
+                   int* __restrict__ tickets) {
     __shared__ unsigned wave_total[kAssignBlock / 64];
     __shared__ unsigned block_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the search launches' final-sum tickets start at zero (a fill launch per
+    // index build until round 5)
+    if (tickets && blockIdx.x == 0 && threadIdx.x < 16) tickets[threadIdx.x] = 0;
     for (int64_t b0 = (int64_t)blockIdx.x * kAssignBlock; b0 < n_buckets;
          b0 += (int64_t)gridDim.x * kAssignBlock) {
         const int64_t b = b0 + threadIdx.x;
@@ -126,11 +130,13 @@ __global__ void __launch_bounds__(kSmallIndexBlock)
 BuildSmallIndexKernel(const T* __restrict__ pts, const T* __restrict__ normals,
                       int n, double inv_cell, unsigned mask, int n_buckets,
                       uint2* __restrict__ ranges, Rec4<T>* __restrict__ sorted,
-                      Rec4<T>* __restrict__ sorted_normals) {
+                      Rec4<T>* __restrict__ sorted_normals,
+                      int* __restrict__ tickets) {
     __shared__ unsigned cnt[kSmallIndexBuckets];
     __shared__ unsigned wave_total[kSmallIndexBlock / 64];
     constexpr int kMine = kSmallIndexPoints / kSmallIndexBlock;  // points / thread
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (tickets && threadIdx.x < 16) tickets[threadIdx.x] = 0;
     for (int b = threadIdx.x; b < n_buckets; b += kSmallIndexBlock) cnt[b] = 0;
     __syncthreads();
     Rec4<T> rec[kMine];
@@ -999,13 +1005,15 @@ int BuildIndex(o3dmi_nns* nns, const T* pts, const T* normals, hipStream_t s) {
     { int st_; if ((st_ = PoolAlloc((void**)&nns->partials, sizeof(double) * kCUs * 4 * kNumSums))) return st_; }
     // (a search launch writes <= 512 rows; the last row holds the tickets)
     nns->tickets = (int*)(nns->partials + (size_t)(kCUs * 4 - 1) * kNumSums);
-    O3DMI_HIP_CHECK(hipMemsetAsync(nns->tickets, 0, sizeof(int) * 16, s));
+    // zeroed by the build launch that runs anyway (none for an empty cloud)
+    if (n <= 0)
+        O3DMI_HIP_CHECK(hipMemsetAsync(nns->tickets, 0, sizeof(int) * 16, s));
     if (n > 0 && n <= kSmallIndexPoints) {
         hipLaunchKernelGGL(BuildSmallIndexKernel<T>, dim3(1),
                            dim3(kSmallIndexBlock), 0, s, pts, normals, (int)n,
                            nns->inv_cell, mask, (int)nb, nns->ranges,
                            (Rec4<T>*)nns->sorted_pts,
-                           (Rec4<T>*)nns->sorted_normals);
+                           (Rec4<T>*)nns->sorted_normals, nns->tickets);
         O3DMI_HIP_CHECK(hipGetLastError());
         return O3DMI_OK;
     }
@@ -1021,7 +1029,7 @@ int BuildIndex(o3dmi_nns* nns, const T* pts, const T* normals, hipStream_t s) {
                            nns->ranges);
         hipLaunchKernelGGL(AssignRangesKernel,
                            dim3(GridFor(nb, kAssignBlock)), dim3(kAssignBlock),
-                           0, s, nns->ranges, nb);
+                           0, s, nns->ranges, nb, nns->tickets);
         hipLaunchKernelGGL(ScatterKernel<T>, dim3(GridFor(n, kBlock)),
                            dim3(kBlock), 0, s, pts, normals, n, nns->inv_cell,
                            mask, nns->ranges, (Rec4<T>*)nns->sorted_pts,

@@ -211,7 +211,9 @@ UnprojectKernel(TouchParams p, const depth_t* __restrict__ depth,
                     run += c;
                 }
             const int64_t chunk = c0 / (kBlock * ROUNDS);
-            if (MODE == 0) chunk_base = run ? atomicAdd(count, run) : 0;
+            // MODE 0 counts in the library's own accumulator (chunk_counts[0],
+            // zero at rest), not in the caller's word: see the tail below
+            if (MODE == 0) chunk_base = run ? atomicAdd(chunk_counts, run) : 0;
             else if (MODE == 1) chunk_counts[chunk] = run;
             else chunk_base = chunk_counts[chunk];  // scanned: exclusive
         }
@@ -239,6 +241,19 @@ UnprojectKernel(TouchParams p, const depth_t* __restrict__ depth,
             }
         }
         __syncthreads();  // offs / chunk_base are reused by the next chunk
+    }
+    // MODE 0: the last workgroup to finish (a ticket in chunk_counts[1]) hands
+    // the total to the caller's count and leaves accumulator and ticket zero
+    // for the next launch -- the caller's word is written once and needs no
+    // clearing launch in front of this one (a fill per call until round 5: two
+    // of the seven fill / copy launches of a tracking frame).
+    if (MODE == 0 && threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(chunk_counts + 1, 1) == (int)gridDim.x - 1) {
+            __threadfence();
+            *count = atomicExch(chunk_counts, 0);
+            chunk_counts[1] = 0;
+        }
     }
 }
 
@@ -393,7 +408,6 @@ int o3dmi_unproject(const void* depth_dev, int depth_dtype, int rows, int cols,
     TouchParams p = MakeTouchParams(intrinsic, extrinsic, rows, cols,
                                     (int)stride, 1, 1.0f, 0.0f, depth_scale,
                                     depth_max);
-    O3DMI_HIP_CHECK(hipMemsetAsync(out_count_dev, 0, sizeof(int), s));
     int64_t n = (int64_t)p.rows_strided * p.cols_strided;
     // the largest chunk that still gives every CU one
     int rounds = kUnprojMaxRounds;
@@ -405,27 +419,34 @@ int o3dmi_unproject(const void* depth_dev, int depth_dtype, int rows, int cols,
     int* chunk_counts = nullptr;
     const int n_chunks = (int)((n + (int64_t)kBlock * rounds - 1) /
                                ((int64_t)kBlock * rounds));
-    if (ordered) {
-        // per host thread, device and stream (two calls of one thread on two
-        // streams may overlap on the device), grown on demand (a few KB each)
+    {
+        // The launch's scratch words, per host thread, device and stream (two
+        // calls of one thread on two streams may overlap on the device),
+        // grown on demand (a few KB each). Ordered mode: a count per chunk.
+        // Default mode: words 0 and 1, the accumulator and the ticket, which
+        // every launch leaves ZERO (allocated zeroed, never touched by the
+        // ordered mode's launches: those use their own buffer).
         struct Counts {
             int* buf = nullptr;
             int cap = 0;
         };
-        static thread_local std::map<std::pair<int, hipStream_t>, Counts> bufs;
+        static thread_local std::map<std::pair<int, hipStream_t>, Counts>
+                bufs[2];
         int dev = 0;
         O3DMI_HIP_CHECK(hipGetDevice(&dev));
-        Counts& c = bufs[std::make_pair(dev, s)];
-        if (c.cap < n_chunks) {
+        Counts& c = bufs[ordered ? 1 : 0][std::make_pair(dev, s)];
+        const int want = ordered ? n_chunks : 2;
+        if (c.cap < want) {
             if (c.buf) {
                 O3DMI_HIP_CHECK(hipStreamSynchronize(s));
                 (void)hipFree(c.buf);
                 c.buf = nullptr;
                 c.cap = 0;
             }
-            int cap = 4096;
-            while (cap < n_chunks) cap <<= 1;
+            int cap = ordered ? 4096 : 16;
+            while (cap < want) cap <<= 1;
             O3DMI_HIP_CHECK(hipMalloc((void**)&c.buf, sizeof(int) * cap));
+            O3DMI_HIP_CHECK(hipMemsetAsync(c.buf, 0, sizeof(int) * cap, s));
             c.cap = cap;
         }
         chunk_counts = c.buf;
