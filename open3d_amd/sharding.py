@@ -162,6 +162,18 @@ def allgather_blocks(keys, values, dist):
             for r in range(world)]
 
 
+def _backend(dist):
+    return dist.get_backend()
+
+
+def _all_ranks(dist, ok):
+    """True iff `ok` is true on every rank (one small all-reduce)."""
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item()) == 1
+
+
 # The Comm installed on this thread (o3dmi_set_comm): kept alive here until it
 # is uninstalled -- the library calls the ctypes thunks of a custom transport
 # through it, and a Comm that was garbage-collected while installed would leave
@@ -195,16 +207,20 @@ class Comm:
         L = _lib.lib()
         if not L.o3dmi_rccl_available():
             raise RuntimeError("RCCL is not available in this process")
+        # Rank 0's failure to make an id must not leave the others waiting in
+        # the broadcast: it sends the all-zero id, which every rank rejects.
         ident = torch.zeros(128, dtype=torch.uint8)
         if dist.get_rank() == 0:
             buf = (C.c_char * 128)()
-            _lib.check(L.o3dmi_rccl_unique_id(C.cast(buf, C.c_void_p)),
-                       "rccl_unique_id")
-            ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
+            if L.o3dmi_rccl_unique_id(C.cast(buf, C.c_void_p)) == _lib.OK:
+                ident = torch.frombuffer(bytearray(buf.raw),
+                                         dtype=torch.uint8)
         on_dev = dist.get_backend() != "gloo"
         t = ident.cuda() if on_dev else ident.clone()
         dist.broadcast(t, 0)
         raw = bytes(t.cpu().numpy().tobytes())
+        if not any(raw):
+            raise RuntimeError("rank 0 could not create an RCCL unique id")
         h = C.c_void_p()
         _lib.check(L.o3dmi_comm_create_rccl(raw, dist.get_rank(),
                                             dist.get_world_size(),
@@ -319,9 +335,27 @@ class Comm:
     @staticmethod
     def for_backend(dist):
         """RCCL inside the library when torch.distributed itself runs on it,
-        else the torch.distributed transport."""
-        return Comm.rccl(dist) if dist.get_backend() == "nccl" \
-            else Comm.torch(dist)
+        else the torch.distributed transport. If the library's own
+        communicator cannot be made on ANY rank (librccl not resolvable by
+        dlopen, ncclCommInitRank refused ...) every rank falls back to the
+        torch.distributed transport -- the ranks agree on it, so that no rank
+        enters a collective of a communicator the others do not have."""
+        if _backend(dist) != "nccl":
+            return Comm.torch(dist)
+        comm, why = None, None
+        try:
+            comm = Comm.rccl(dist)
+        except Exception as e:  # noqa: BLE001 - reported below
+            why = e
+        if _all_ranks(dist, comm is not None):
+            return comm
+        if comm is not None:
+            comm.destroy()
+        import sys
+        print("open3d_amd.sharding: the library's RCCL communicator is not "
+              "available on every rank (%r here); using the torch.distributed "
+              "transport" % (why,), file=sys.stderr)
+        return Comm.torch(dist)
 
     def install(self, level_sharding=False):
         """Makes this communicator the all-reduce of the ICP drivers called

@@ -252,6 +252,57 @@ def test_library_comm_over_a_custom_transport():
         assert ok
 
 
+def _comm_fallback(rank, world):
+    """Comm.for_backend on the "nccl" route when the library's own RCCL
+    communicator cannot be made on one rank (mode 0) or on any rank (mode 1):
+    every rank must end with the torch.distributed transport, and a
+    communicator that was made on the other rank is destroyed."""
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    dist.barrier()
+    from open3d_amd import sharding
+    from open3d_amd.sharding import Comm
+    real_rccl, real_backend = Comm.rccl, sharding._backend
+    out = []
+    for mode in (0, 1):
+        destroyed = []
+
+        class FakeRccl:
+            def destroy(self):
+                destroyed.append(True)
+
+        def rccl(_dist, mode=mode):
+            if mode == 1 or rank == 1:
+                raise RuntimeError("no RCCL here")
+            return FakeRccl()
+        Comm.rccl = staticmethod(rccl)
+        sharding._backend = lambda _d: "nccl"
+        try:
+            comm = Comm.for_backend(dist)
+        finally:
+            Comm.rccl, sharding._backend = real_rccl, real_backend
+        is_custom = isinstance(comm, Comm) and comm._keep is not None
+        world_seen = comm.world
+        comm.destroy()
+        out.append((is_custom, world_seen, len(destroyed)))
+    # and the plain routes are what they were
+    plain = Comm.for_backend(dist)   # gloo -> torch transport
+    ok = plain._keep is not None
+    plain.destroy()
+    return out, ok
+
+
+def test_comm_for_backend_falls_back_together():
+    out = _run(_comm_fallback, world=2)
+    for rank, (modes, ok) in enumerate(out):
+        assert ok
+        for mode, (is_custom, world_seen, destroyed) in enumerate(modes):
+            assert is_custom and world_seen == 2, (rank, mode)
+            # mode 0: rank 0 had made its communicator and gave it up
+            assert destroyed == (1 if (mode == 0 and rank == 0) else 0)
+
+
 def test_rccl_is_resolved_at_run_time_only():
     """The library carries no link dependency on RCCL (dlopen at first use);
     without a communicator the exchange entry points fail cleanly."""
