@@ -167,3 +167,51 @@ def test_every_environment_switch_of_the_library_is_documented():
     documented -= {"O3DMI_RAW_CHUNK", "O3DMI_RAW_WAVES", "O3DMI_LIB"}
     stale = sorted(documented - names)
     assert not stale, stale
+
+
+def test_hot_kernels_keep_their_register_budget(tmp_path):
+    """Static guard (no GPU): the kernels the headline and the tracking loop
+    run in must stay inside the budgets their occupancy was measured at --
+    the frame stream's step kernel no scratch, no flat accesses and <= 72
+    vector registers (7 waves per SIMD), the chunk launch of the
+    sliced path no scratch, the ray cast at most the one spilled pair it has
+    today, the fused ICP search no flat accesses and at most the handful of spilled
+    loop invariants it has today (the 8-lanes-per-query float form: <= 24
+    bytes, reloaded once per query round, outside the candidate loop)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_scan
+    csrc = os.path.join(ROOT, "open3d_amd", "csrc")
+
+    def scan(name):
+        asm = isa_scan.compile_to_asm(os.path.join(csrc, name),
+                                      str(tmp_path / (name + ".s")))
+        return isa_scan.scan_text(open(asm).read())
+
+    stream = scan("vbg_stream.hip")
+    step = [r for r in stream if r["kernel"].startswith("FrameStepKernel")]
+    chunk = [r for r in stream if r["kernel"].startswith("ChunkIntegrateKernel")]
+    assert len(step) == 8 and len(chunk) == 8, (len(step), len(chunk))
+    for r in step:
+        assert r["scratch_bytes"] == 0 and r["scratch_ops"] == 0, r
+        assert r["flat"] == 0, r
+        assert r["vgpr"] <= 72, r
+    for r in chunk:
+        assert r["scratch_bytes"] == 0 and r["flat"] == 0, r
+        assert r["vgpr"] <= 96, r
+    # (the band arguments of the pixel-row sharded ray cast, round 5, cost the
+    # slim 16^3 forms one 8-byte spill at their 96-register cap: a store at
+    # entry and a reload per tile, outside the march; no change in the
+    # launch's duration -- profiles/r5o against r4z)
+    rays = [r for r in scan("vbg_raycast.hip")
+            if r["kernel"].startswith("RayCastKernel")]
+    assert len(rays) == 10, len(rays)
+    for r in rays:
+        assert r["flat"] == 0, r
+        assert r["scratch_bytes"] <= 12 and r["scratch_ops"] <= 2, r
+    icp = [r for r in scan("icp.hip")
+           if r["kernel"].startswith("SearchAccumulateKernel")]
+    assert len(icp) == 24, len(icp)   # 2 dtypes x G in {8, 16, 32} x 4 forms
+    for r in icp:
+        assert r["flat"] == 0, r
+        assert r["scratch_bytes"] <= 24 and r["scratch_ops"] <= 6, r
+
