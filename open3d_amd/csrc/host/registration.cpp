@@ -183,7 +183,8 @@ int DownSampleAttrsAsync(const void* pos, int64_t n_max, const int* n_dev,
                          hipStream_t cs, int chain,
                          std::initializer_list<std::pair<const void*, void*>>
                                  attrs,
-                         double next_voxel = 0, bool from_previous = false) {
+                         double next_voxel = 0, bool from_previous = false,
+                         VdsLevelJob* defer = nullptr) {
     if (voxel <= 0) {
         SetLastError("voxel_size must be positive.");
         return O3DMI_ERR_INVALID_ARG;
@@ -191,6 +192,26 @@ int DownSampleAttrsAsync(const void* pos, int64_t n_max, const int* n_dev,
     int passes = 0;
     for (const auto& a : attrs) passes += a.first ? 1 : 0;
     const bool single = passes <= 1;
+    if (defer && single) {
+        // one pass: the caller launches it together with the other cloud's
+        // level (VdsPairAsync)
+        defer->pos = pos;
+        defer->n_max = n_max;
+        defer->n_dev = n_dev;
+        defer->voxel_size = voxel;
+        defer->out_pos = out_pos;
+        defer->m_dev = m_dev;
+        defer->err_dev = err_dev;
+        defer->chain = chain;
+        defer->next_voxel_size = next_voxel;
+        defer->from_previous = from_previous;
+        for (const auto& a : attrs)
+            if (a.first) {
+                defer->attr = a.first;
+                defer->out_attr = a.second;
+            }
+        return O3DMI_OK;
+    }
     bool done = false;
     for (const auto& a : attrs) {
         if (!a.first) continue;
@@ -275,6 +296,18 @@ struct ChainCounts {
         posted_seq = ++mb->seq;
         return PostCountsAsync(dev, levels + 1, mb->data, mb->flag, posted_seq,
                                cs);
+    }
+    // both chains were built in the same launches: one posting launch
+    static int PostPair(ChainCounts& a, ChainCounts& b, hipStream_t cs) {
+        Mailbox* ma = ThreadMailbox(1 + a.chain);
+        Mailbox* mb = ThreadMailbox(1 + b.chain);
+        O3DMI_REQUIRE(ma != nullptr && mb != nullptr && a.levels == b.levels,
+                      "host mailbox allocation failed");
+        a.posted_seq = ++ma->seq;
+        b.posted_seq = ++mb->seq;
+        return PostCountsPairAsync(a.dev, ma->data, ma->flag, a.posted_seq,
+                                   b.dev, mb->data, mb->flag, b.posted_seq,
+                                   a.levels + 1, cs);
     }
     int Fetch(std::vector<int>& out, hipStream_t cs) {
         int st = Post(cs);
@@ -543,7 +576,7 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         hipStream_t s;
         ~ChainGuard() { c.Release(s); }
     };
-    auto source_level = [&](int k, hipStream_t cs) -> int {
+    auto source_level = [&](int k, hipStream_t cs, VdsLevelJob* job) -> int {
         int e;
         Level& L = pyr[(size_t)k];
         if (k == last && finest_is_input) {
@@ -568,7 +601,7 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                                         scc.Err(), scc.scratch, cs, 0,
                                         {{source_normals_dev, L.srcn.p},
                                          {source_colors_dev, L.srcc.p}},
-                                        next_vs, false);
+                                        next_vs, false, job);
         Level& F = pyr[(size_t)k + 1];
         const bool f_host = k + 1 == last && finest_is_input;
         return DownSampleAttrsAsync(F.src.p, ns,
@@ -577,10 +610,10 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                                     scc.Err(), scc.scratch, cs, 0,
                                     {{F.srcn.p, L.srcn.p},
                                      {F.srcc.p, L.srcc.p}},
-                                    next_vs, !f_host);
+                                    next_vs, !f_host, job);
     };
     bool finest_on_host = finest_is_input;
-    auto target_level = [&](int k, hipStream_t cs) -> int {
+    auto target_level = [&](int k, hipStream_t cs, VdsLevelJob* job) -> int {
         o3dmi_stream_t cstream = (o3dmi_stream_t)cs;
         int e;
         Level& L = pyr[(size_t)k];
@@ -609,7 +642,7 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                                           {target_colors_dev, L.tgtc.p},
                                           {target_gradients_dev, L.tgtg.p}},
                                          k > 0 ? voxel_sizes[k - 1] : 0.0,
-                                         false);
+                                         false, job);
                 if (e) return e;
                 L.tgt_ptr = L.tgt.p;
                 L.nrm_ptr = L.nrm.p;  // stays NULL without normals
@@ -657,7 +690,8 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                                  {{F.nrm_ptr, L.nrm.p},
                                   {F.tgtc_ptr, L.tgtc.p},
                                   {F.tgtg_ptr, L.tgtg.p}},
-                                 k > 0 ? voxel_sizes[k - 1] : 0.0, !f_host);
+                                 k > 0 ? voxel_sizes[k - 1] : 0.0, !f_host,
+                                 job);
         if (e) return e;
         L.tgt_ptr = L.tgt.p;
         L.nrm_ptr = L.nrm.p;
@@ -683,17 +717,41 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
     bool indices_on_side = false;
     int next_index = 1;  // first scale whose index is not issued yet
     {
-        ChainGuard sg{scc, s}, tg{tcc, side};
+        // Round 6: the two pyramids advance level by level in the SAME
+        // launches on the caller's stream (VdsPairAsync: blockIdx.y = cloud)
+        // -- 7 launches + one posting launch for a three-level pair of
+        // pyramids instead of two chains of 8 on two streams. Coloured ICP
+        // (three attribute passes per target level) keeps the two chains.
+        static const bool unpaired = std::getenv("O3DMI_VDS_UNPAIRED") != nullptr;
+        const bool paired = !colored && !unpaired;
+        hipStream_t ts = paired ? s : side;
+        ChainGuard sg{scc, s}, tg{tcc, ts};
         if ((st = scc.Init(num_scales, 0, s))) return st;
-        if ((st = tcc.Init(num_scales, 1, side))) return st;
+        if ((st = tcc.Init(num_scales, 1, ts))) return st;
         for (int k = last; k >= 0; --k) {
-            if ((st = target_level(k, side))) return st;
-            if ((st = source_level(k, s))) return st;
+            VdsLevelJob jobs[2];
+            if ((st = target_level(k, ts, paired ? &jobs[1] : nullptr)))
+                return st;
+            if ((st = source_level(k, s, paired ? &jobs[0] : nullptr)))
+                return st;
+            if (!paired) continue;
+            // (a level that is the input itself leaves its job empty)
+            VdsLevelJob both[2];
+            int n_jobs = 0;
+            if (jobs[0].pos) both[n_jobs++] = jobs[0];
+            if (jobs[1].pos) both[n_jobs++] = jobs[1];
+            if (n_jobs &&
+                (st = VdsPairAsync(both, n_jobs, dtype, scc.scratch, s)))
+                return st;
         }
         std::vector<int> counts;
-        if ((st = tcc.Post(side))) return st;
-        if ((st = scc.Post(s))) return st;
-        if ((st = tcc.Wait(counts, side))) return st;
+        if (paired) {
+            if ((st = ChainCounts::PostPair(scc, tcc, s))) return st;
+        } else {
+            if ((st = tcc.Post(ts))) return st;
+            if ((st = scc.Post(s))) return st;
+        }
+        if ((st = tcc.Wait(counts, ts))) return st;
         for (int k = 0; k < num_scales; ++k)
             if (!(k == last && finest_on_host))
                 pyr[(size_t)k].nt = counts[(size_t)k];

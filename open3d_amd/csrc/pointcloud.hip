@@ -477,461 +477,478 @@ __global__ void VdsReduceKernel(const T* __restrict__ pos,
     }
 }
 
-// ==== the bucketed form: three launches per level, clouds up to 2^17 points ====
-// (round 3; the seven-launch chain above stays for larger clouds.) The sort
-// above exists to put every voxel's points side by side in point order. Here
-// the points are only PARTITIONED -- stably, by the high bits of their voxel's
-// hash slot, into 512 buckets of a few hundred points -- and a workgroup per
-// bucket does the rest in LDS:
-//   A  VdsInsertBucketKernel   hash insert (slot, first point by atomicMin) +
-//                              per-tile histogram of the bucket digit;
-//   B  VdsBucketScatterKernel  gathers first[slot] -> "is the first point of
-//                              its voxel" as one bit per point (a wave ballot
-//                              is 64 consecutive bits: coalesced), and the
-//                              stable scatter of (slot, point) by bucket --
-//                              SortScatterKernel's ranking, one pass;
-//   C  VdsBucketReduceKernel   per bucket: the entries and their points'
-//                              coordinates / attribute staged into LDS with
-//                              every load in flight at once; the lane of a
-//                              voxel's first point walks the bucket's entries
-//                              behind it (point order survives the stable
-//                              scatter) adding its voxel's members in float32
-//                              out of LDS; output row = number of first-point
-//                              bits below its own (a prefix popcount over the
-//                              bit array, rebuilt in LDS by every workgroup:
-//                              <= 4096 words); finally every entry returns
-//                              its table slot to the empty state.
-// The table is therefore CLEAN after every level and lives in a persistent
-// per-chain workspace (no clearing launch, no pooled scratch per call; one
-// set of buffers per chain however many levels and attributes go through it).
-// 52 us of kernels per level in the VGA tracking loop -> see DESIGN.md.
-constexpr int kBucketBits = 9;
-constexpr int kBuckets = 1 << kBucketBits;
-// (Round 5 tried 2^18, so that the finest level of a 1280x720 frame -- 230 400
-// points -- would take the three launches instead of the sort's seven: the
-// tracking loop got SLOWER, 1177-1207 -> 1127-1133 frames/s; buckets of ~450
-// entries make the reduce launch's in-bucket walk the long pole. Kept at 2^17.)
-constexpr int64_t kBucketedMaxPoints = 1 << 17;
-constexpr int kBucketLds = 2048;   // entries of a bucket staged in LDS
+// ==== the tiled form: two launches per level, clouds up to 2^20 points ========
+// (round 6; replaces round 3's three-launch bucketed form, whose launches ran
+// 10-17 us each for <= 3 MB of traffic: ten 8192-point scatter workgroups on a
+// 256-CU chip, 512 global histogram atomics per insert workgroup, the
+// first-point bits of the whole cloud re-read by every reduce workgroup. The
+// seven-launch sort above stays for larger clouds.)
+//
+// The sort exists to put every voxel's points side by side in point order.
+// Here the points are only PARTITIONED by the high bits of their voxel's hash
+// slot (a bucket = 1024 or 2048 consecutive slots, a few hundred points), and
+// the partition is never materialised globally: a 1024-point TILE is split
+// stably in LDS by its own workgroup and written back tile by tile, with the
+// tile's bucket offsets; the bucket's workgroup then picks its segment out of
+// every tile, in tile order -- which is point order. No global histogram, no
+// column sums, no global scatter.
+//   I  VdsTileInsertKernel     (finest level only) hash insert: slot of every
+//                              point, first point of every voxel (atomicMin);
+//   P  VdsTilePartitionKernel  per tile: "is the first point of its voxel"
+//                              (first[slot] == i) with its rank among the
+//                              tile's first points, the stable split by bucket
+//                              in LDS, 32-byte entries {slot, index | rank |
+//                              first flag, position, attribute} written in
+//                              bucket order + the tile's bucket offsets and
+//                              first-point count;
+//   R  VdsTileReduceKernel     per bucket: scans the tiles' segment lengths and
+//                              first-point counts (<= 1024 tiles), stages its
+//                              entries into LDS with every load in flight, the
+//                              lane of a voxel's first point walks the entries
+//                              behind it adding its voxel's members in float32
+//                              (point order survives the stable split), output
+//                              row = first points of the tiles before + rank
+//                              in the tile; every entry returns its table slot
+//                              to the empty state; and the lane that writes a
+//                              voxel's mean inserts it into the NEXT level's
+//                              table (VdsNext), so a pyramid is I P R P R P R.
+// One or TWO clouds per launch (blockIdx.y): the ICP driver builds the source
+// and the target pyramid level by level in the same launches.
+constexpr int kTile = kSortBlock;          // 1024 points, one per lane
+constexpr int kMaxTiles = 1024;
+constexpr int64_t kTiledMaxPoints = (int64_t)kTile * kMaxTiles;  // 2^20
+constexpr int kMaxBuckets = 1024;
+constexpr int kBucketLds = 2048;           // entries of a bucket staged in LDS
 constexpr int kReduceBlock = 256;
-constexpr int kMaxBucketWidth = 2048;  // slots of a bucket: n_slots / 512
-
-template <typename T>
-__global__ void __launch_bounds__(kSortBlock)
-VdsInsertBucketKernel(const T* __restrict__ pos, const int* n_dev, int n_host,
-                      T vs, VdsTable tb, int bshift,
-                      int* __restrict__ slot_of_point,
-                      int* __restrict__ tile_hist, int* __restrict__ err) {
-    // ONE point per lane: a point's insert is a chain of dependent global
-    // atomics (CAS on the key, atomicMin on the first point), so every point
-    // wants its own lane -- the first version gave a lane the 8 points of a
-    // tile slice and took 43 us where the plain insert took 7. A workgroup
-    // covers 1024 consecutive points (an eighth of a scatter tile) and adds
-    // its bucket counts to the tile's row with one atomic per occupied bucket
-    // (the rows are zero between levels: the reduce launch clears them).
-    __shared__ int h[kBuckets];
-    const int i = blockIdx.x * kSortBlock + threadIdx.x;
-    T p[3] = {T(0), T(0), T(0)};
-    if (i < n_host) {
-        p[0] = pos[3 * (int64_t)i + 0];
-        p[1] = pos[3 * (int64_t)i + 1];
-        p[2] = pos[3 * (int64_t)i + 2];
-    }
-    const int n = LiveCount(n_dev, n_host);
-    if ((int)(blockIdx.x * kSortBlock) >= n) return;
-    for (int b = threadIdx.x; b < kBuckets; b += kSortBlock) h[b] = 0;
-    __syncthreads();
-    if (i < n) {
-        // (p / vs).Floor().To(Int64)
-        const long long cx = (long long)floor(p[0] / vs);
-        const long long cy = (long long)floor(p[1] / vs);
-        const long long cz = (long long)floor(p[2] / vs);
-        if (cx < -kKeyBias || cx >= kKeyBias || cy < -kKeyBias ||
-            cy >= kKeyBias || cz < -kKeyBias || cz >= kKeyBias) {
-            // reported to the caller; the point stays a voxel of its own
-            atomicOr(err, kErrKeyRange);
-            slot_of_point[i] = -1;
-            atomicAdd(&h[0], 1);
-        } else {
-            const unsigned long long key = PackKey((int)cx, (int)cy, (int)cz);
-            unsigned s = HashKey(key) & tb.mask;
-            while (true) {
-                unsigned long long cur = tb.keys[s];
-                if (cur == kEmptyKey)
-                    cur = atomicCAS(&tb.keys[s], kEmptyKey, key);
-                if (cur == kEmptyKey || cur == key) break;
-                s = (s + 1) & tb.mask;
-            }
-            slot_of_point[i] = (int)s;
-            atomicMin(&tb.first[s], i);
-            atomicAdd(&h[s >> bshift], 1);
-        }
-    }
-    __syncthreads();
-    int* row = tile_hist +
-               (int64_t)(blockIdx.x / (kSortTile / kSortBlock)) * kBuckets;
-    for (int b = threadIdx.x; b < kBuckets; b += kSortBlock)
-        if (h[b]) atomicAdd(&row[b], h[b]);
-}
-
-__global__ void __launch_bounds__(kSortBlock)
-VdsBucketScatterKernel(const int* __restrict__ slot_of_point, VdsTable tb,
-                       int bshift, const int* n_dev, int n_host,
-                       const int* __restrict__ tile_hist,
-                       unsigned* __restrict__ ent_slot,
-                       unsigned* __restrict__ ent_point,
-                       unsigned long long* __restrict__ first_bits,
-                       int* __restrict__ bucket_start) {
-    __shared__ int wh[kSortWaves][kBuckets];  // 32 KiB
-    __shared__ int dbase[kBuckets];
-    __shared__ int lds4[kSortWaves];
-    const int tile = blockIdx.x * kSortTile;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wbase = tile + wave * (kSortItems * 64);
-    int slot[kSortItems];
-#pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
-        const int e = wbase + r * 64 + lane;
-        slot[r] = e < n_host ? slot_of_point[e] : -1;
-    }
-    // The column of the tile histogram this thread will sum, requested with
-    // the slots and the live count (one round trip instead of two): the rows
-    // of tiles past the live count are zero -- the reduce launch clears the
-    // table and the insert launch only adds to live tiles -- so all
-    // ceil(n_host / tile) <= 16 rows can be summed without knowing n.
-    constexpr int kMaxTiles = (int)(kBucketedMaxPoints / kSortTile);
-    static_assert(kMaxTiles <= 16, "one batch of column loads");
-    const int n_tiles_host = (n_host + kSortTile - 1) / kSortTile;
-    int colv[kMaxTiles];
-#pragma unroll
-    for (int u = 0; u < kMaxTiles; ++u)
-        colv[u] = (int)threadIdx.x < kBuckets && u < n_tiles_host
-                          ? tile_hist[(int64_t)u * kBuckets + threadIdx.x]
-                          : 0;
-    const int n = LiveCount(n_dev, n_host);
-    // block 0 always runs: it publishes the bucket starts (all zero for an
-    // empty cloud)
-    if (tile >= n && blockIdx.x != 0) return;
-    // first point of its voxel? (a point outside the key range is a voxel of
-    // its own)
-    int first[kSortItems];
-#pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
-        const int e = wbase + r * 64 + lane;
-        first[r] = e < n && slot[r] >= 0 ? tb.first[slot[r]] : e;
-    }
-    for (int b = threadIdx.x; b < kBuckets * kSortWaves; b += kSortBlock)
-        (&wh[0][0])[b] = 0;
-    __syncthreads();
-    unsigned digit[kSortItems];
-#pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
-        const int e = wbase + r * 64 + lane;
-        digit[r] = slot[r] >= 0 ? (unsigned)slot[r] >> bshift : 0u;
-        const unsigned long long fm = __ballot(e < n && first[r] == e);
-        if (lane == 0 && wbase + r * 64 < n) first_bits[(wbase + r * 64) >> 6] = fm;
-        if (e < n) atomicAdd(&wh[wave][digit[r]], 1);
-    }
-    {
-        // where this tile's run of every bucket starts (SortScatterKernel)
-        int all = 0, before = 0;
-#pragma unroll
-        for (int u = 0; u < kMaxTiles; ++u) {
-            all += colv[u];
-            before += u < (int)blockIdx.x ? colv[u] : 0;
-        }
-        int total;
-        const int run = BlockExclusive(all, lds4, &total);
-        if ((int)threadIdx.x < kBuckets) {
-            dbase[threadIdx.x] = run + before;
-            if (blockIdx.x == 0) {
-                bucket_start[threadIdx.x] = run;
-                if (threadIdx.x == kBuckets - 1) bucket_start[kBuckets] = total;
-            }
-        }
-    }
-    __syncthreads();
-    if (tile >= n) return;
-    for (int b = threadIdx.x; b < kBuckets; b += kSortBlock) {
-        int off = dbase[b];
-#pragma unroll
-        for (int w = 0; w < kSortWaves; ++w) {
-            const int c = wh[w][b];
-            wh[w][b] = off;
-            off += c;
-        }
-    }
-    __syncthreads();
-    const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int r = 0; r < kSortItems; ++r) {
-        const int e = wbase + r * 64 + lane;
-        const bool valid = e < n;
-        const unsigned d = digit[r];
-        unsigned long long same = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < kBucketBits; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const unsigned long long bal = __ballot(bit);
-            same &= bit ? bal : ~bal;
-        }
-        int posn = 0;
-        if (valid) posn = wh[wave][d] + __popcll(same & lt);
-        if (valid && (same & lt) == 0ull) wh[wave][d] += __popcll(same);
-        if (valid) {
-            ent_slot[posn] = (unsigned)slot[r];
-            ent_point[posn] = (unsigned)e;
-        }
-    }
-}
+constexpr int kMaxBucketWidth = 2048;      // slots of a bucket
+constexpr unsigned kNoSlot = 0xFFFFFFFFu;  // a point outside the key range
+constexpr unsigned kEntryFirst = 0x80000000u;
+constexpr int kEntryRankShift = 20;        // index 20 bits, rank 10 bits
 
 // The NEXT (coarser) level's hash insert, carried by this level's reduce
 // launch: a pyramid is built from its own output (Registration.cpp:233-270),
 // so the lane that writes a voxel's mean can insert that point -- it has its
 // index (the output row) and its coordinates in registers -- into the next
-// level's table and count it in the next level's tile histogram, which is all
-// VdsInsertBucketKernel would do one launch later. tb.keys == NULL: no next
-// level (or a caller that makes several passes per level).
+// level's table. tb.keys == NULL: no next level (or a caller that makes
+// several passes per level).
 template <typename T>
 struct VdsNext {
     VdsTable tb;
     T vs;
     int* slot_of_point;
-    int* tile_hist;
-    int* err;
 };
 
 template <typename T>
-__global__ void __launch_bounds__(kReduceBlock)
-VdsBucketReduceKernel(const T* __restrict__ pos, const T* __restrict__ nrm,
-                      const unsigned* __restrict__ ent_slot,
-                      const unsigned* __restrict__ ent_point,
-                      const unsigned long long* __restrict__ first_bits,
-                      const int* __restrict__ bucket_start, VdsTable tb,
-                      int bshift, int* __restrict__ tile_hist, int n_tiles_cap,
-                      const int* n_dev, int n_host, T* __restrict__ out_pos,
-                      T* __restrict__ out_nrm, int* __restrict__ m_dev,
-                      VdsNext<T> next) {
-    __shared__ int word_prefix[kBucketedMaxPoints / 64];  // 16 KiB
-    __shared__ int lds4[kReduceBlock / 64];
-    __shared__ unsigned e_slot[kBucketLds + 4];  // + a sentinel chunk
-    __shared__ float e_pos[kBucketLds][3];
-    __shared__ float e_nrm[kBucketLds][3];
-    __shared__ int members[kMaxBucketWidth];  // points per slot of the bucket
-    const int tid = threadIdx.x;
-    // The first-point bits of the whole cloud (<= 2048 words, 8 per lane),
-    // requested before anything that depends on the bucket's range: they
-    // depend on nothing but the buffer size (words past the live count are
-    // masked below).
-    constexpr int kWordsPer = (int)(kBucketedMaxPoints / 64) / kReduceBlock;  // 8
-    const int n_words_host = (n_host + 63) >> 6;
-    unsigned long long w[kWordsPer];
-#pragma unroll
-    for (int k = 0; k < kWordsPer; ++k) {
-        const int wi = tid * kWordsPer + k;
-        w[k] = wi < n_words_host ? first_bits[wi] : 0ull;
+struct VdsJob {
+    const T* pos;
+    const T* attr;
+    const int* n_dev;
+    int n_host;           // 0: nothing to do for this cloud in this launch
+    T vs;
+    VdsTable tb;
+    int* slot_of_point;
+    int bshift;           // bucket = slot >> bshift
+    int bucket_bits;      // log2(number of buckets)
+    uint4* ent;           // two per entry, tile-major
+    int* tile_off;        // [tile][buckets + 1]
+    int* tile_firsts;     // [tile]
+    T* out_pos;
+    T* out_attr;
+    int* m_dev;
+    int* err;
+    VdsNext<T> next;
+};
+
+// (p / vs).Floor().To(Int64) -> hash insert; the voxel's first point.
+template <typename T>
+__device__ __forceinline__ void VdsInsertPoint(T px, T py, T pz, T vs,
+                                               const VdsTable& tb, int i,
+                                               int* __restrict__ slot_of_point,
+                                               int* __restrict__ err) {
+    const long long cx = (long long)floor(px / vs);
+    const long long cy = (long long)floor(py / vs);
+    const long long cz = (long long)floor(pz / vs);
+    if (cx < -kKeyBias || cx >= kKeyBias || cy < -kKeyBias || cy >= kKeyBias ||
+        cz < -kKeyBias || cz >= kKeyBias) {
+        // reported to the caller; the point stays a voxel of its own so that
+        // the rest of the chain sees consistent keys
+        atomicOr(err, kErrKeyRange);
+        slot_of_point[i] = -1;
+        return;
     }
-    const int b0 = bucket_start[blockIdx.x], b1 = bucket_start[blockIdx.x + 1];
-    const int n = LiveCount(n_dev, n_host);
-    const int count = b1 - b0;
-    const int width = 1 << bshift;  // slots of a bucket
-    const bool staged = count <= kBucketLds && width <= kMaxBucketWidth;
-    // ---- every load of the bucket in flight: entries, then their points ----
-    constexpr int kPer = kBucketLds / kReduceBlock;  // 8 entries per lane
-    unsigned es[kPer], ep[kPer];
-    if (staged) {
+    const unsigned long long key = PackKey((int)cx, (int)cy, (int)cz);
+    unsigned s = HashKey(key) & tb.mask;
+    while (true) {
+        unsigned long long cur = tb.keys[s];
+        if (cur == kEmptyKey) cur = atomicCAS(&tb.keys[s], kEmptyKey, key);
+        if (cur == kEmptyKey || cur == key) break;
+        s = (s + 1) & tb.mask;
+    }
+    slot_of_point[i] = (int)s;
+    atomicMin(&tb.first[s], i);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+VdsTileInsertKernel(VdsJob<T> job_a, VdsJob<T> job_b) {
+    const VdsJob<T>& job = blockIdx.y ? job_b : job_a;
+    // ONE point per lane: an insert is a chain of dependent global atomics.
+    // The point is fetched alongside the live count (which the previous
+    // level or Unproject wrote) and dropped if it lies past it.
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    T p[3] = {T(0), T(0), T(0)};
+    if (i < job.n_host) {
+        p[0] = job.pos[3 * (int64_t)i + 0];
+        p[1] = job.pos[3 * (int64_t)i + 1];
+        p[2] = job.pos[3 * (int64_t)i + 2];
+    }
+    if (i >= LiveCount(job.n_dev, job.n_host)) return;
+    VdsInsertPoint(p[0], p[1], p[2], job.vs, job.tb, i, job.slot_of_point,
+                   job.err);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kTile)
+VdsTilePartitionKernel(VdsJob<T> job_a, VdsJob<T> job_b) {
+    __shared__ int wh[kTile / 64][kMaxBuckets];  // 64 KiB
+    __shared__ int lds4[kTile / 64];
+    __shared__ int wave_firsts[kTile / 64];
+    const VdsJob<T>& job = blockIdx.y ? job_b : job_a;
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int i = tile * kTile + tid;
+    // everything that depends on the buffer size only, requested with the
+    // live count
+    int slot = -1;
+    float pf[3] = {0.f, 0.f, 0.f}, af[3] = {0.f, 0.f, 0.f};
+    if (i < job.n_host) {
+        slot = job.slot_of_point[i];
 #pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            const int j = tid + k * kReduceBlock;
-            es[k] = j < count ? ent_slot[b0 + j] : 0xFFFFFFFEu;
-            ep[k] = j < count ? ent_point[b0 + j] : 0u;
+        for (int c = 0; c < 3; ++c) {
+            pf[c] = (float)job.pos[3 * (int64_t)i + c];
+            if (job.attr) af[c] = (float)job.attr[3 * (int64_t)i + c];
         }
-        for (int q = tid; q < width; q += kReduceBlock) members[q] = 0;
     }
-    // this bucket's column of the tile histogram back to zero for the next
-    // level (the scatter launch has read it)
-    if (tid < n_tiles_cap) tile_hist[(int64_t)tid * kBuckets + blockIdx.x] = 0;
-    // ---- prefix popcount of the first-point bits (all words, every bucket) --
-    const int n_words = (n + 63) >> 6;
+    const int n = LiveCount(job.n_dev, job.n_host);
+    if (tile * kTile >= n) return;
+    const bool valid = i < n;
+    // (a slot read past the live count is whatever the buffer held)
+    const bool keyed = valid && slot >= 0;
+    const int first = keyed ? job.tb.first[(unsigned)slot & job.tb.mask] : i;
+    const bool is_first = valid && first == i;
+    const int bits = job.bucket_bits, buckets = 1 << bits;
+    for (int q = tid; q < (kTile / 64) << bits; q += kTile)
+        wh[q >> bits][q & (buckets - 1)] = 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned long long fm = __ballot(is_first);
+    if (lane == 0) wave_firsts[wave] = __popcll(fm);
+    __syncthreads();
+    const unsigned d = keyed ? ((unsigned)slot & job.tb.mask) >> job.bshift : 0u;
+    if (valid) atomicAdd(&wh[wave][d], 1);
+    __syncthreads();
+    // bucket b of this tile: its size, then where each wave's share starts
     int mine = 0;
+    if (tid < buckets) {
 #pragma unroll
-    for (int k = 0; k < kWordsPer; ++k) {
-        const int wi = tid * kWordsPer + k;
-        if (wi >= n_words) w[k] = 0ull;  // never written by this level
-        mine += __popcll(w[k]);
+        for (int w = 0; w < kTile / 64; ++w) mine += wh[w][tid];
     }
-    unsigned long long ew[kPer];  // the first-point word of every entry
-    if (staged) {
-        float pf[kPer][3], qf[kPer][3];
+    int tile_total;
+    const int start = BlockExclusive(mine, lds4, &tile_total);
+    int* row = job.tile_off + (int64_t)tile * (buckets + 1);
+    if (tid < buckets) {
+        row[tid] = start;
+        int off = start;
 #pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            const int j = tid + k * kReduceBlock;
-            const int64_t i = j < count ? (int64_t)ep[k] : 0;
-            ew[k] = first_bits[i >> 6];  // with the gathers: one round trip
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                pf[k][c] = (float)pos[3 * i + c];
-                qf[k][c] = nrm ? (float)nrm[3 * i + c] : 0.f;
-            }
+        for (int w = 0; w < kTile / 64; ++w) {
+            const int c = wh[w][tid];
+            wh[w][tid] = off;
+            off += c;
         }
-        __syncthreads();  // members[] is zero
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            const int j = tid + k * kReduceBlock;
-            if (j < count) {
-                e_slot[j] = es[k];
-                if (es[k] != 0xFFFFFFFFu)
-                    atomicAdd(&members[es[k] & (unsigned)(width - 1)], 1);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    e_pos[j][c] = pf[k][c];
-                    e_nrm[j][c] = qf[k][c];
-                }
-            }
-        }
-        if (tid < 4) e_slot[count + tid] = 0xFFFFFFFEu;  // matches no slot
     }
-    {
-        // block exclusive scan of `mine` (kReduceBlock threads)
-        const int lane = tid & 63, wave = tid >> 6;
-        int incl = mine;
+    int rank = __popcll(fm & lt), firsts = 0;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(incl, d);
-            if (lane >= d) incl += t;
-        }
-        if (lane == 63) lds4[wave] = incl;
-        __syncthreads();
-        int run = incl - mine, total = 0;
-#pragma unroll
-        for (int k = 0; k < kReduceBlock / 64; ++k) {
-            if (k < wave) run += lds4[k];
-            total += lds4[k];
-        }
-#pragma unroll
-        for (int k = 0; k < kWordsPer; ++k) {
-            word_prefix[tid * kWordsPer + k] = run;
-            run += __popcll(w[k]);
-        }
-        if (blockIdx.x == 0 && tid == 0) *m_dev = total;
+    for (int w = 0; w < kTile / 64; ++w) {
+        const int c = wave_firsts[w];
+        rank += w < wave ? c : 0;
+        firsts += c;
+    }
+    if (tid == 0) {
+        row[buckets] = tile_total;
+        job.tile_firsts[tile] = firsts;
     }
     __syncthreads();
+    // lanes of this wave in the same bucket, in lane (= point) order
+    unsigned long long same = __ballot(valid);
+    for (int b = 0; b < bits; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        same &= bit ? bal : ~bal;
+    }
+    if (!valid) return;
+    const int posn = wh[wave][d] + __popcll(same & lt);
+    uint4 e0, e1;
+    e0.x = keyed ? (unsigned)slot & job.tb.mask : kNoSlot;
+    e0.y = (unsigned)i | ((unsigned)rank << kEntryRankShift) |
+           (is_first ? kEntryFirst : 0u);
+    e0.z = __float_as_uint(pf[0]);
+    e0.w = __float_as_uint(pf[1]);
+    e1.x = __float_as_uint(pf[2]);
+    e1.y = __float_as_uint(af[0]);
+    e1.z = __float_as_uint(af[1]);
+    e1.w = __float_as_uint(af[2]);
+    uint4* dst = job.ent + 2 * ((int64_t)tile * kTile + posn);
+    dst[0] = e0;
+    dst[1] = e1;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kReduceBlock)
+VdsTileReduceKernel(VdsJob<T> job_a, VdsJob<T> job_b) {
+    __shared__ int seg_lo[kMaxTiles];         // bucket's start inside tile t
+    __shared__ int seg_start[kMaxTiles + 1];  // entries in the tiles before t
+    __shared__ int first_base[kMaxTiles];     // first points in tiles before t
+    __shared__ int lds4[2][kReduceBlock / 64];
+    __shared__ unsigned e_slot[kBucketLds + 4];  // + a sentinel chunk
+    __shared__ float e_pos[kBucketLds][3];
+    __shared__ float e_attr[kBucketLds][3];
+    __shared__ int members[kMaxBucketWidth];  // points per slot of the bucket
+    const VdsJob<T>& job = blockIdx.y ? job_b : job_a;
+    const int bucket = blockIdx.x, tid = threadIdx.x;
+    const int buckets = 1 << job.bucket_bits;
+    if (bucket >= buckets || job.n_host <= 0) return;
+    const int width = 1 << job.bshift;  // slots of a bucket (<= 2048)
+    // ---- the tiles' tables: kPerT consecutive tiles per lane ---------------
+    constexpr int kPerT = kMaxTiles / kReduceBlock;  // 4
+    const int tiles_host = (job.n_host + kTile - 1) / kTile;
+    int lo[kPerT], len[kPerT], fc[kPerT];
+#pragma unroll
+    for (int u = 0; u < kPerT; ++u) {
+        const int t = tid * kPerT + u;
+        lo[u] = len[u] = fc[u] = 0;
+        if (t < tiles_host) {
+            const int* row = job.tile_off + (int64_t)t * (buckets + 1) + bucket;
+            lo[u] = row[0];
+            len[u] = row[1];
+            fc[u] = job.tile_firsts[t];
+        }
+    }
+    const int n = LiveCount(job.n_dev, job.n_host);
+    const int tiles = (n + kTile - 1) / kTile;
+    for (int q = tid; q < width; q += kReduceBlock) members[q] = 0;
+    int my_len = 0, my_fc = 0;
+#pragma unroll
+    for (int u = 0; u < kPerT; ++u) {
+        const int t = tid * kPerT + u;
+        // rows of tiles past the live count hold an earlier level's numbers
+        len[u] = t < tiles ? len[u] - lo[u] : 0;
+        fc[u] = t < tiles ? fc[u] : 0;
+        my_len += len[u];
+        my_fc += fc[u];
+    }
+    int count, voxels;
+    {
+        // block exclusive scans of my_len and my_fc (kReduceBlock threads)
+        const int lane = tid & 63, wave = tid >> 6;
+        int il = my_len, ic = my_fc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int tl = __shfl_up(il, d), tc = __shfl_up(ic, d);
+            if (lane >= d) {
+                il += tl;
+                ic += tc;
+            }
+        }
+        if (lane == 63) {
+            lds4[0][wave] = il;
+            lds4[1][wave] = ic;
+        }
+        __syncthreads();
+        int rl = il - my_len, rc = ic - my_fc;
+        count = voxels = 0;
+#pragma unroll
+        for (int k = 0; k < kReduceBlock / 64; ++k) {
+            if (k < wave) {
+                rl += lds4[0][k];
+                rc += lds4[1][k];
+            }
+            count += lds4[0][k];
+            voxels += lds4[1][k];
+        }
+#pragma unroll
+        for (int u = 0; u < kPerT; ++u) {
+            const int t = tid * kPerT + u;
+            seg_lo[t] = lo[u];
+            seg_start[t] = rl;
+            first_base[t] = rc;
+            rl += len[u];
+            rc += fc[u];
+        }
+        if (tid == 0) seg_start[kMaxTiles] = count;
+        if (bucket == 0 && tid == 0) *job.m_dev = voxels;
+    }
+    __syncthreads();
+    // entry j of the bucket -> where it lies: the last tile that starts at or
+    // before j (empty segments share their successor's start)
+    auto locate = [&](int j) -> int64_t {
+        int t = 0;
+#pragma unroll
+        for (int step = kMaxTiles / 2; step > 0; step >>= 1)
+            if (seg_start[t + step] <= j) t += step;
+        return (int64_t)t * kTile + seg_lo[t] + (j - seg_start[t]);
+    };
     // ---- one lane per entry; the lane of a voxel's first point adds it up ---
-    auto entry = [&](int j, unsigned s, unsigned i,
-                     unsigned long long word) {
-        // the slot goes back to the empty state (members write the same)
-        if (s != 0xFFFFFFFFu) {
-            tb.keys[s] = kEmptyKey;
-            tb.first[s] = 0x7FFFFFFF;
-        }
-        if (!((word >> (i & 63)) & 1ull)) return;
-        const int row = word_prefix[i >> 6] +
-                        __popcll(word & ((1ull << (i & 63)) - 1ull));
-        float cnt = 0.f, sp[3] = {0.f, 0.f, 0.f}, sn[3] = {0.f, 0.f, 0.f};
-        auto add = [&](const float* pp, const float* qq) {
-            cnt += 1.0f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                sp[c] += pp[c];
-                sn[c] += qq[c];
-            }
-        };
-        if (staged) {
-            // The members follow the first point in point order. Their number
-            // is known, so the walk ends at the last one -- a voxel's points
-            // are neighbours in the image and therefore in the list -- and
-            // four entries are compared per LDS round trip.
-            add(e_pos[j], e_nrm[j]);
-            int left = s != 0xFFFFFFFFu
-                               ? members[s & (unsigned)(width - 1)] - 1
-                               : 0;
-            for (int e = j + 1; left > 0 && e < count; e += 4) {
-                const unsigned s0 = e_slot[e], s1 = e_slot[e + 1],
-                               s2 = e_slot[e + 2], s3 = e_slot[e + 3];
-                if (s0 == s) { add(e_pos[e], e_nrm[e]); --left; }
-                if (s1 == s) { add(e_pos[e + 1], e_nrm[e + 1]); --left; }
-                if (s2 == s) { add(e_pos[e + 2], e_nrm[e + 2]); --left; }
-                if (s3 == s) { add(e_pos[e + 3], e_nrm[e + 3]); --left; }
-            }
-        } else {
-            // a bucket beyond the LDS staging (a cloud whose points crowd a
-            // few voxels): the same walk out of global memory
-            for (int e = j; e < count; ++e) {
-                const bool member =
-                        e == j || (s != 0xFFFFFFFFu && ent_slot[b0 + e] == s);
-                if (member) {
-                    const int64_t pi = ent_point[b0 + e];
-                    float pp[3], qq[3];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        pp[c] = (float)pos[3 * pi + c];
-                        qq[c] = nrm ? (float)nrm[3 * pi + c] : 0.f;
-                    }
-                    add(pp, qq);
-                }
-            }
-        }
+    auto finish = [&](unsigned s, unsigned iw, float cnt, const float* sp,
+                      const float* sn) {
+        const int i = (int)(iw & ((1u << kEntryRankShift) - 1u));
+        const int row = first_base[i / kTile] +
+                        (int)((iw >> kEntryRankShift) & (unsigned)(kTile - 1));
+        (void)s;
         T o[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             o[c] = (T)(sp[c] / cnt);
-            out_pos[3 * (int64_t)row + c] = o[c];
-            if (nrm) out_nrm[3 * (int64_t)row + c] = (T)(sn[c] / cnt);
+            job.out_pos[3 * (int64_t)row + c] = o[c];
+            if (job.attr) job.out_attr[3 * (int64_t)row + c] = (T)(sn[c] / cnt);
         }
-        if (next.tb.keys) {
-            // VdsInsertBucketKernel's body for point `row` of the next level
-            int* hist = next.tile_hist + (int64_t)(row / kSortTile) * kBuckets;
-            const long long cx = (long long)floor(o[0] / next.vs);
-            const long long cy = (long long)floor(o[1] / next.vs);
-            const long long cz = (long long)floor(o[2] / next.vs);
-            if (cx < -kKeyBias || cx >= kKeyBias || cy < -kKeyBias ||
-                cy >= kKeyBias || cz < -kKeyBias || cz >= kKeyBias) {
-                atomicOr(next.err, kErrKeyRange);
-                next.slot_of_point[row] = -1;
-                atomicAdd(&hist[0], 1);
-            } else {
-                const unsigned long long key =
-                        PackKey((int)cx, (int)cy, (int)cz);
-                unsigned ns = HashKey(key) & next.tb.mask;
-                while (true) {
-                    unsigned long long cur = next.tb.keys[ns];
-                    if (cur == kEmptyKey)
-                        cur = atomicCAS(&next.tb.keys[ns], kEmptyKey, key);
-                    if (cur == kEmptyKey || cur == key) break;
-                    ns = (ns + 1) & next.tb.mask;
-                }
-                next.slot_of_point[row] = (int)ns;
-                atomicMin(&next.tb.first[ns], row);
-                atomicAdd(&hist[ns >> bshift], 1);
-            }
+        if (job.next.tb.keys)
+            VdsInsertPoint(o[0], o[1], o[2], job.next.vs, job.next.tb, row,
+                           job.next.slot_of_point, job.err);
+    };
+    auto clean = [&](unsigned s) {
+        // the slot goes back to the empty state (members write the same): the
+        // table is clean after every level
+        if (s != kNoSlot) {
+            job.tb.keys[s] = kEmptyKey;
+            job.tb.first[s] = 0x7FFFFFFF;
         }
     };
-    if (staged) {
+    if (count <= kBucketLds) {
+        constexpr int kPer = kBucketLds / kReduceBlock;  // 8 entries per lane
+        uint4 e0[kPer], e1[kPer];
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
             const int j = tid + k * kReduceBlock;
-            if (j < count) entry(j, es[k], ep[k], ew[k]);
+            e0[k] = make_uint4(0xFFFFFFFEu, 0u, 0u, 0u);
+            e1[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (j < count) {
+                const uint4* src = job.ent + 2 * locate(j);
+                e0[k] = src[0];
+                e1[k] = src[1];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int j = tid + k * kReduceBlock;
+            if (j < count) {
+                e_slot[j] = e0[k].x;
+                if (e0[k].x != kNoSlot)
+                    atomicAdd(&members[e0[k].x & (unsigned)(width - 1)], 1);
+                e_pos[j][0] = __uint_as_float(e0[k].z);
+                e_pos[j][1] = __uint_as_float(e0[k].w);
+                e_pos[j][2] = __uint_as_float(e1[k].x);
+                e_attr[j][0] = __uint_as_float(e1[k].y);
+                e_attr[j][1] = __uint_as_float(e1[k].z);
+                e_attr[j][2] = __uint_as_float(e1[k].w);
+            }
+        }
+        if (tid < 4) e_slot[count + tid] = 0xFFFFFFFEu;  // matches no slot
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int j = tid + k * kReduceBlock;
+            if (j >= count) continue;
+            const unsigned s = e0[k].x;
+            clean(s);
+            if (!(e0[k].y & kEntryFirst)) continue;
+            float cnt = 0.f, sp[3] = {0.f, 0.f, 0.f}, sn[3] = {0.f, 0.f, 0.f};
+            auto add = [&](int e) {
+                cnt += 1.0f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    sp[c] += e_pos[e][c];
+                    sn[c] += e_attr[e][c];
+                }
+            };
+            // The members follow the first point in point order. Their number
+            // is known, so the walk ends at the last one -- a voxel's points
+            // are neighbours in the image and therefore in the list -- and
+            // four entries are compared per LDS round trip.
+            add(j);
+            int left = s != kNoSlot ? members[s & (unsigned)(width - 1)] - 1 : 0;
+            for (int e = j + 1; left > 0 && e < count; e += 4) {
+                const unsigned s0 = e_slot[e], s1 = e_slot[e + 1],
+                               s2 = e_slot[e + 2], s3 = e_slot[e + 3];
+                if (s0 == s) { add(e); --left; }
+                if (s1 == s) { add(e + 1); --left; }
+                if (s2 == s) { add(e + 2); --left; }
+                if (s3 == s) { add(e + 3); --left; }
+            }
+            finish(s, e0[k].y, cnt, sp, sn);
         }
     } else {
+        // a bucket beyond the LDS staging (a cloud whose points crowd a few
+        // voxels): the same walk out of global memory, four entries in flight
         for (int j = tid; j < count; j += kReduceBlock) {
-            const unsigned i = ent_point[b0 + j];
-            entry(j, ent_slot[b0 + j], i, first_bits[i >> 6]);
+            const unsigned s = job.ent[2 * locate(j)].x;
+            if (s != kNoSlot) atomicAdd(&members[s & (unsigned)(width - 1)], 1);
         }
+        __syncthreads();
+        for (int j = tid; j < count; j += kReduceBlock) {
+            const uint4* own = job.ent + 2 * locate(j);
+            const uint4 o0 = own[0], o1 = own[1];
+            const unsigned s = o0.x;
+            if (!(o0.y & kEntryFirst)) continue;
+            float cnt = 1.0f;
+            float sp[3] = {__uint_as_float(o0.z), __uint_as_float(o0.w),
+                           __uint_as_float(o1.x)};
+            float sn[3] = {__uint_as_float(o1.y), __uint_as_float(o1.z),
+                           __uint_as_float(o1.w)};
+            int left = s != kNoSlot ? members[s & (unsigned)(width - 1)] - 1 : 0;
+            for (int e = j + 1; left > 0 && e < count; e += 4) {
+                uint4 m0[4], m1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    m0[u] = make_uint4(0xFFFFFFFEu, 0u, 0u, 0u);
+                    m1[u] = make_uint4(0u, 0u, 0u, 0u);
+                    if (e + u < count) {
+                        const uint4* src = job.ent + 2 * locate(e + u);
+                        m0[u] = src[0];
+                        m1[u] = src[1];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (m0[u].x == s) {
+                        cnt += 1.0f;
+                        sp[0] += __uint_as_float(m0[u].z);
+                        sp[1] += __uint_as_float(m0[u].w);
+                        sp[2] += __uint_as_float(m1[u].x);
+                        sn[0] += __uint_as_float(m1[u].y);
+                        sn[1] += __uint_as_float(m1[u].z);
+                        sn[2] += __uint_as_float(m1[u].w);
+                        --left;
+                    }
+            }
+            finish(s, o0.y, cnt, sp, sn);
+        }
+        // (only when every walk of the bucket has read its slots)
+        __syncthreads();
+        for (int j = tid; j < count; j += kReduceBlock)
+            clean(job.ent[2 * locate(j)].x);
     }
 }
 
-// Persistent buffers of the bucketed form, one set per host thread, device and
-// chain (the ICP driver runs the source and the target pyramid as two chains
-// on two streams). Everything a level needs is sized by the largest cloud the
-// chain has seen; the hash table is returned clean by every level.
+// Persistent buffers of the tiled form, one set per host thread, device and
+// chain (the source and the target pyramid of the ICP driver are two chains,
+// built in the same launches). Everything a level needs is sized by the
+// largest cloud the chain has seen; the hash table is returned clean by every
+// level.
 struct VdsWorkspace {
     int64_t n_cap = 0, n_slots = 0;
-    // Two sets of {table, slot of every point, tile histogram}: a level that
-    // carries the next level's insert (VdsNext) fills the other set while it
-    // empties its own.
+    // Two sets of {table, slot of every point}: a level that carries the next
+    // level's insert (VdsNext) fills the other set while it empties its own.
     VdsTable tb = {}, tb2 = {};
     int *slot_of_point = nullptr, *slot_of_point2 = nullptr;
-    int *tile_hist = nullptr, *tile_hist2 = nullptr;
     // the insert a reduce launch has left behind: which set, of which cloud
     // (the reduce launch's output), for which voxel size
     bool primed = false;
@@ -940,23 +957,19 @@ struct VdsWorkspace {
     double primed_vs = 0;
     int64_t primed_n_max = 0;
     size_t primed_esz = 0;
-    unsigned* ent_slot = nullptr;
-    unsigned* ent_point = nullptr;
-    unsigned long long* first_bits = nullptr;
-    int* bucket_start = nullptr;
+    uint4* ent = nullptr;        // [2 * n_cap]
+    int* tile_off = nullptr;     // [n_cap / kTile][kMaxBuckets + 1]
+    int* tile_firsts = nullptr;  // [n_cap / kTile]
     void Free() {
         (void)hipFree(tb.keys);
         (void)hipFree(tb.first);
         (void)hipFree(slot_of_point);
-        (void)hipFree(tile_hist);
         (void)hipFree(tb2.keys);
         (void)hipFree(tb2.first);
         (void)hipFree(slot_of_point2);
-        (void)hipFree(tile_hist2);
-        (void)hipFree(ent_slot);
-        (void)hipFree(ent_point);
-        (void)hipFree(first_bits);
-        (void)hipFree(bucket_start);
+        (void)hipFree(ent);
+        (void)hipFree(tile_off);
+        (void)hipFree(tile_firsts);
         *this = VdsWorkspace();
     }
 };
@@ -964,11 +977,11 @@ constexpr int kVdsChains = 2;
 constexpr int kVdsDevices = 64;
 
 // The workspaces are self-cleaning: the LAST launch of a level returns the
-// table slots, histograms and `primed` state it used to their idle values. A
-// chain that is abandoned between its first launch and that last one (an error
-// return in the driver, a failed launch) leaves them dirty; the driver says so
+// table slots and `primed` state it used to their idle values. A chain that is
+// abandoned between its first launch and that last one (an error return in
+// the driver, a failed launch) leaves them dirty; the driver says so
 // (VdsChainInvalidate) and the next user of the workspace throws it away and
-// starts from freshly initialised buffers. [bucketed form, sort form]
+// starts from freshly initialised buffers. [tiled form, sort form]
 static thread_local bool g_vds_dirty[kVdsDevices][kVdsChains][2];
 
 static bool TakeVdsDirty(int dev, int chain, int which) {
@@ -995,32 +1008,27 @@ VdsWorkspace* ThreadVdsWorkspace(int chain, int64_t n_max, hipStream_t s) {
     w.Free();
     int64_t cap = 16384;
     while (cap < n_max) cap <<= 1;
-    int64_t n_slots = 1024;
-    while (n_slots < 2 * cap) n_slots <<= 1;
-    const int64_t n_tiles = (cap + kSortTile - 1) / kSortTile;
-    bool ok = hipMalloc((void**)&w.tb.keys, sizeof(unsigned long long) * n_slots) == hipSuccess &&
-              hipMalloc((void**)&w.tb.first, sizeof(int) * n_slots) == hipSuccess &&
-              hipMalloc((void**)&w.slot_of_point, sizeof(int) * cap) == hipSuccess &&
-              hipMalloc((void**)&w.tile_hist, sizeof(int) * kBuckets * n_tiles) == hipSuccess &&
-              hipMalloc((void**)&w.tb2.keys, sizeof(unsigned long long) * n_slots) == hipSuccess &&
-              hipMalloc((void**)&w.tb2.first, sizeof(int) * n_slots) == hipSuccess &&
-              hipMalloc((void**)&w.slot_of_point2, sizeof(int) * cap) == hipSuccess &&
-              hipMalloc((void**)&w.tile_hist2, sizeof(int) * kBuckets * n_tiles) == hipSuccess &&
-              hipMalloc((void**)&w.ent_slot, sizeof(unsigned) * cap) == hipSuccess &&
-              hipMalloc((void**)&w.ent_point, sizeof(unsigned) * cap) == hipSuccess &&
-              hipMalloc((void**)&w.first_bits, sizeof(unsigned long long) * (cap / 64 + 1)) == hipSuccess &&
-              hipMalloc((void**)&w.bucket_start, sizeof(int) * (kBuckets + 1)) == hipSuccess;
+    const int64_t n_slots = 2 * cap;
+    const int64_t n_tiles = cap / kTile;
+    auto get = [](auto** p, size_t count) {
+        return hipMalloc((void**)p, sizeof(**p) * count) == hipSuccess;
+    };
+    bool ok = get(&w.tb.keys, (size_t)n_slots) &&
+              get(&w.tb.first, (size_t)n_slots) &&
+              get(&w.slot_of_point, (size_t)cap) &&
+              get(&w.tb2.keys, (size_t)n_slots) &&
+              get(&w.tb2.first, (size_t)n_slots) &&
+              get(&w.slot_of_point2, (size_t)cap) &&
+              get(&w.ent, (size_t)(2 * cap)) &&
+              get(&w.tile_off, (size_t)(n_tiles * (kMaxBuckets + 1))) &&
+              get(&w.tile_firsts, (size_t)n_tiles);
     if (ok) {
         w.tb.mask = w.tb2.mask = (unsigned)(n_slots - 1);
         hipLaunchKernelGGL(VdsInitKernel, dim3(GridFor(n_slots, kBlock)),
                            dim3(kBlock), 0, s, w.tb, n_slots);
         hipLaunchKernelGGL(VdsInitKernel, dim3(GridFor(n_slots, kBlock)),
                            dim3(kBlock), 0, s, w.tb2, n_slots);
-        ok = hipGetLastError() == hipSuccess &&
-             hipMemsetAsync(w.tile_hist, 0, sizeof(int) * kBuckets * n_tiles,
-                            s) == hipSuccess &&
-             hipMemsetAsync(w.tile_hist2, 0, sizeof(int) * kBuckets * n_tiles,
-                            s) == hipSuccess;
+        ok = hipGetLastError() == hipSuccess;
     }
     if (!ok) {
         w.Free();
@@ -1032,71 +1040,99 @@ VdsWorkspace* ThreadVdsWorkspace(int chain, int64_t n_max, hipStream_t s) {
     return &w;
 }
 
+// One level of one or two clouds (two chains) in the same launches.
 template <typename T>
-int VdsBucketedImpl(const T* pos, const T* nrm, int64_t n_max, const int* n_dev,
-                    double voxel_size, T* out_pos, T* out_nrm, int* m_dev,
-                    int* err_dev, int chain, hipStream_t s,
-                    double next_voxel_size, bool from_previous) {
-    VdsWorkspace* w = ThreadVdsWorkspace(chain, n_max, s);
-    if (!w) return O3DMI_ERR_HIP;
-    int slot_bits = 0;
-    while ((1ll << slot_bits) < w->n_slots) ++slot_bits;
-    const int bshift = slot_bits - kBucketBits;  // n_slots >= 1024 > 512
-    const int n_host = (int)n_max;
-    const int n_tiles = (int)((n_max + kSortTile - 1) / kSortTile);
-    const int64_t n_tiles_cap = (w->n_cap + kSortTile - 1) / kSortTile;
-    const dim3 tiles((unsigned)n_tiles), sblock(kSortBlock);
-    const dim3 chunks((unsigned)((n_max + kSortBlock - 1) / kSortBlock));
+int VdsTiledImpl(const VdsLevelJob* jobs, int n_jobs, hipStream_t s) {
+    O3DMI_REQUIRE(n_jobs == 1 || (n_jobs == 2 && jobs[0].chain != jobs[1].chain),
+                  "VoxelDownSample: one cloud per chain");
     static const bool no_fuse = std::getenv("O3DMI_VDS_NO_FUSE") != nullptr;
-    // Was this cloud inserted by the launch that wrote it?
-    const bool inserted = w->primed && from_previous &&
-                          w->primed_src == (const void*)pos &&
-                          w->primed_vs == voxel_size &&
-                          w->primed_n_max == n_max &&
-                          w->primed_esz == sizeof(T);
-    if (w->primed && !inserted) {
-        // an insert nobody came for (the caller changed its mind between two
-        // levels): back to the clean state
-        VdsTable& tb = w->primed_set ? w->tb2 : w->tb;
-        hipLaunchKernelGGL(VdsInitKernel, dim3(GridFor(w->n_slots, kBlock)),
-                           dim3(kBlock), 0, s, tb, w->n_slots);
-        O3DMI_HIP_CHECK(hipMemsetAsync(
-                w->primed_set ? w->tile_hist2 : w->tile_hist, 0,
-                sizeof(int) * kBuckets * n_tiles_cap, s));
+    VdsJob<T> run[2] = {}, ins[2] = {};
+    VdsWorkspace* wss[2] = {nullptr, nullptr};
+    int cur[2] = {0, 0};
+    bool any_insert = false;
+    int64_t most_points = 0;
+    int most_tiles = 0, most_buckets = 0;
+    for (int q = 0; q < n_jobs; ++q) {
+        const VdsLevelJob& J = jobs[q];
+        O3DMI_REQUIRE(J.n_max > 0 && J.n_max <= kTiledMaxPoints,
+                      "VoxelDownSample: bad point count");
+        VdsWorkspace* w = ThreadVdsWorkspace(J.chain, J.n_max, s);
+        if (!w) return O3DMI_ERR_HIP;
+        wss[q] = w;
+        // this call's share of the (clean) table: 2 slots per point; a bucket
+        // is 1024 slots (2048 for the largest clouds: <= 1024 buckets)
+        int slot_bits = 15;
+        while ((1ll << slot_bits) < 2 * J.n_max) ++slot_bits;
+        const int bshift = slot_bits > 20 ? 11 : 10;
+        // Was this cloud inserted by the launch that wrote it?
+        const bool inserted = w->primed && J.from_previous &&
+                              w->primed_src == J.pos &&
+                              w->primed_vs == J.voxel_size &&
+                              w->primed_n_max == J.n_max &&
+                              w->primed_esz == sizeof(T);
+        if (w->primed && !inserted) {
+            // an insert nobody came for (the caller changed its mind between
+            // two levels): back to the clean state
+            VdsTable& tb = w->primed_set ? w->tb2 : w->tb;
+            hipLaunchKernelGGL(VdsInitKernel,
+                               dim3(GridFor(w->n_slots, kBlock)), dim3(kBlock),
+                               0, s, tb, w->n_slots);
+        }
+        cur[q] = inserted ? w->primed_set : 0;
+        w->primed = false;
+        VdsJob<T>& d = run[q];
+        d.pos = (const T*)J.pos;
+        d.attr = (const T*)J.attr;
+        d.n_dev = J.n_dev;
+        d.n_host = (int)J.n_max;
+        d.vs = (T)J.voxel_size;
+        d.tb = cur[q] ? w->tb2 : w->tb;
+        d.tb.mask = (unsigned)((1ll << slot_bits) - 1);
+        d.slot_of_point = cur[q] ? w->slot_of_point2 : w->slot_of_point;
+        d.bshift = bshift;
+        d.bucket_bits = slot_bits - bshift;
+        d.ent = w->ent;
+        d.tile_off = w->tile_off;
+        d.tile_firsts = w->tile_firsts;
+        d.out_pos = (T*)J.out_pos;
+        d.out_attr = (T*)J.out_attr;
+        d.m_dev = J.m_dev;
+        d.err = J.err_dev;
+        if (J.next_voxel_size > 0 && !no_fuse) {
+            d.next.tb = cur[q] ? w->tb : w->tb2;
+            d.next.tb.mask = d.tb.mask;
+            d.next.vs = (T)J.next_voxel_size;
+            d.next.slot_of_point =
+                    cur[q] ? w->slot_of_point : w->slot_of_point2;
+        }
+        ins[q] = d;
+        if (inserted) ins[q].n_host = 0;
+        else any_insert = true;
+        most_points = J.n_max > most_points ? J.n_max : most_points;
+        const int tiles = (int)((J.n_max + kTile - 1) / kTile);
+        most_tiles = tiles > most_tiles ? tiles : most_tiles;
+        most_buckets = (1 << d.bucket_bits) > most_buckets ? 1 << d.bucket_bits
+                                                           : most_buckets;
     }
-    const int cur = inserted ? w->primed_set : 0;
-    w->primed = false;
-    VdsTable& tb = cur ? w->tb2 : w->tb;
-    int* slot_of_point = cur ? w->slot_of_point2 : w->slot_of_point;
-    int* tile_hist = cur ? w->tile_hist2 : w->tile_hist;
-    VdsNext<T> next = {};
-    if (next_voxel_size > 0 && !no_fuse) {
-        next.tb = cur ? w->tb : w->tb2;
-        next.vs = (T)next_voxel_size;
-        next.slot_of_point = cur ? w->slot_of_point : w->slot_of_point2;
-        next.tile_hist = cur ? w->tile_hist : w->tile_hist2;
-        next.err = err_dev;
-    }
-    if (!inserted)
-        hipLaunchKernelGGL(VdsInsertBucketKernel<T>, chunks, sblock, 0, s, pos,
-                           n_dev, n_host, (T)voxel_size, tb, bshift,
-                           slot_of_point, tile_hist, err_dev);
-    hipLaunchKernelGGL(VdsBucketScatterKernel, tiles, sblock, 0, s,
-                       slot_of_point, tb, bshift, n_dev, n_host, tile_hist,
-                       w->ent_slot, w->ent_point, w->first_bits,
-                       w->bucket_start);
-    hipLaunchKernelGGL(VdsBucketReduceKernel<T>, dim3(kBuckets),
-                       dim3(kReduceBlock), 0, s, pos, nrm, w->ent_slot,
-                       w->ent_point, w->first_bits, w->bucket_start, tb,
-                       bshift, tile_hist, n_tiles, n_dev, n_host, out_pos,
-                       out_nrm, m_dev, next);
+    const unsigned gy = (unsigned)n_jobs;
+    if (any_insert)
+        hipLaunchKernelGGL(VdsTileInsertKernel<T>,
+                           dim3((unsigned)((most_points + kBlock - 1) / kBlock),
+                                gy),
+                           dim3(kBlock), 0, s, ins[0], ins[1]);
+    hipLaunchKernelGGL(VdsTilePartitionKernel<T>, dim3((unsigned)most_tiles, gy),
+                       dim3(kTile), 0, s, run[0], run[1]);
+    hipLaunchKernelGGL(VdsTileReduceKernel<T>, dim3((unsigned)most_buckets, gy),
+                       dim3(kReduceBlock), 0, s, run[0], run[1]);
     O3DMI_HIP_CHECK(hipGetLastError());
-    if (next.tb.keys) {
+    for (int q = 0; q < n_jobs; ++q) {
+        if (!run[q].next.tb.keys) continue;
+        VdsWorkspace* w = wss[q];
         w->primed = true;
-        w->primed_set = 1 - cur;
-        w->primed_src = (const void*)out_pos;
-        w->primed_vs = next_voxel_size;
-        w->primed_n_max = n_max;
+        w->primed_set = 1 - cur[q];
+        w->primed_src = jobs[q].out_pos;
+        w->primed_vs = jobs[q].next_voxel_size;
+        w->primed_n_max = jobs[q].n_max;
         w->primed_esz = sizeof(T);
     }
     return O3DMI_OK;
@@ -1257,6 +1293,34 @@ int PostCountsAsync(int* counts_dev, int n, double* mail_data, int* mail_flag,
     return O3DMI_OK;
 }
 
+__global__ void PostCountsPairKernel(int* __restrict__ counts_a,
+                                     double* mail_data_a, int* mail_flag_a,
+                                     int mail_seq_a, int* __restrict__ counts_b,
+                                     double* mail_data_b, int* mail_flag_b,
+                                     int mail_seq_b, int n) {
+    // one wave per chain
+    int* counts = blockIdx.x ? counts_b : counts_a;
+    double* mail_data = blockIdx.x ? mail_data_b : mail_data_a;
+    if ((int)threadIdx.x < n) {
+        mail_data[threadIdx.x] = (double)counts[threadIdx.x];
+        counts[threadIdx.x] = 0;
+    }
+    MailboxPublish(blockIdx.x ? mail_flag_b : mail_flag_a,
+                   blockIdx.x ? mail_seq_b : mail_seq_a);
+}
+
+int PostCountsPairAsync(int* counts_a, double* mail_data_a, int* mail_flag_a,
+                        int mail_seq_a, int* counts_b, double* mail_data_b,
+                        int* mail_flag_b, int mail_seq_b, int n,
+                        hipStream_t s) {
+    O3DMI_REQUIRE(n >= 1 && n <= 32, "too many levels");
+    hipLaunchKernelGGL(PostCountsPairKernel, dim3(2), dim3(64), 0, s, counts_a,
+                       mail_data_a, mail_flag_a, mail_seq_a, counts_b,
+                       mail_data_b, mail_flag_b, mail_seq_b, n);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
 void VdsChainInvalidate(int chain) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kVdsDevices ||
@@ -1265,32 +1329,56 @@ void VdsChainInvalidate(int chain) {
     g_vds_dirty[dev][chain][0] = g_vds_dirty[dev][chain][1] = true;
 }
 
+int VdsPairAsync(const VdsLevelJob* jobs, int n_jobs, int dtype,
+                 std::vector<void*>& scratch, hipStream_t s) {
+    O3DMI_REQUIRE(jobs && (n_jobs == 1 || n_jobs == 2), "bad job count");
+    bool tiled = true;
+    for (int q = 0; q < n_jobs; ++q)
+        tiled = tiled && jobs[q].n_max > 0 && jobs[q].n_max <= kTiledMaxPoints;
+    if (tiled)
+        return dtype == O3DMI_F64 ? VdsTiledImpl<double>(jobs, n_jobs, s)
+                                  : VdsTiledImpl<float>(jobs, n_jobs, s);
+    for (int q = 0; q < n_jobs; ++q) {
+        const VdsLevelJob& J = jobs[q];
+        int st;
+        if (J.n_max > 0 && J.n_max <= kTiledMaxPoints)
+            st = dtype == O3DMI_F64 ? VdsTiledImpl<double>(&J, 1, s)
+                                    : VdsTiledImpl<float>(&J, 1, s);
+        else if (dtype == O3DMI_F64)
+            st = VdsAsyncImpl<double>((const double*)J.pos,
+                                      (const double*)J.attr, J.n_max, J.n_dev,
+                                      J.voxel_size, (double*)J.out_pos,
+                                      (double*)J.out_attr, J.m_dev, J.err_dev,
+                                      scratch, s, J.chain);
+        else
+            st = VdsAsyncImpl<float>((const float*)J.pos, (const float*)J.attr,
+                                     J.n_max, J.n_dev, J.voxel_size,
+                                     (float*)J.out_pos, (float*)J.out_attr,
+                                     J.m_dev, J.err_dev, scratch, s, J.chain);
+        if (st) return st;
+    }
+    return O3DMI_OK;
+}
+
 int VdsAsync(const void* pos, const void* attr, int64_t n_max, const int* n_dev,
              int dtype, double voxel_size, void* out_pos, void* out_attr,
              int* m_dev, int* err_dev, std::vector<void*>& scratch,
              hipStream_t s, int chain, double next_voxel_size,
              bool from_previous) {
-    if (n_max > 0 && n_max <= kBucketedMaxPoints) {
-        if (dtype == O3DMI_F64)
-            return VdsBucketedImpl<double>(
-                    (const double*)pos, (const double*)attr, n_max, n_dev,
-                    voxel_size, (double*)out_pos, (double*)out_attr, m_dev,
-                    err_dev, chain, s, next_voxel_size, from_previous);
-        return VdsBucketedImpl<float>((const float*)pos, (const float*)attr,
-                                      n_max, n_dev, voxel_size,
-                                      (float*)out_pos, (float*)out_attr, m_dev,
-                                      err_dev, chain, s, next_voxel_size,
-                                      from_previous);
-    }
-    if (dtype == O3DMI_F64)
-        return VdsAsyncImpl<double>((const double*)pos, (const double*)attr,
-                                    n_max, n_dev, voxel_size, (double*)out_pos,
-                                    (double*)out_attr, m_dev, err_dev, scratch,
-                                    s, chain);
-    return VdsAsyncImpl<float>((const float*)pos, (const float*)attr, n_max,
-                               n_dev, voxel_size, (float*)out_pos,
-                               (float*)out_attr, m_dev, err_dev, scratch, s,
-                               chain);
+    VdsLevelJob J;
+    J.pos = pos;
+    J.attr = attr;
+    J.n_max = n_max;
+    J.n_dev = n_dev;
+    J.voxel_size = voxel_size;
+    J.out_pos = out_pos;
+    J.out_attr = out_attr;
+    J.m_dev = m_dev;
+    J.err_dev = err_dev;
+    J.chain = chain;
+    J.next_voxel_size = next_voxel_size;
+    J.from_previous = from_previous;
+    return VdsPairAsync(&J, 1, dtype, scratch, s);
 }
 
 }  // namespace o3dmi

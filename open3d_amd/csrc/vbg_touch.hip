@@ -153,38 +153,41 @@ __global__ void PointCloudTouchKernel(HashView hv,
 }
 
 // UnprojectCPU (t/geometry/kernel/PointCloudImpl.h:42-143): valid pixels ->
-// points, compacted. A workgroup owns a chunk of kBlock * ROUNDS strided
-// pixels: validity ballots per wave and round, one prefix over the chunk in
-// LDS, ONE atomic per chunk on the output counter, then the points are written
-// in pixel order inside the chunk. The order of the chunks in the output
-// follows the atomics (the reference's order is its own atomic counter's).
-// ROUNDS trades atomics on the one counter word (~12 ns each, serialised: one
-// per wave was 3600 of them and 45 us of a 50 us kernel at 720p) against
-// workgroups to spread the image over: 8 rounds left a VGA / stride-2 image
-// (76 800 pixels) to 38 workgroups and 17 us; the host picks the largest
-// ROUNDS that still gives every CU a chunk (300 chunks of one round there).
+// points, compacted IN PIXEL ORDER by one launch. A workgroup owns a chunk of
+// kBlock * ROUNDS consecutive strided pixels: validity ballots per wave and
+// round, one prefix over the chunk in LDS; the chunk's total goes out as ONE
+// write-through 8-byte word {launch sequence number, total}, and the
+// workgroup reads the words of every chunk before its own (<= 4 per lane,
+// polled until they carry this launch's number: chunks are dispatched in
+// index order and publish before they wait, so a chunk only ever waits for
+// workgroups that are already running) -- their sum is where its points go.
+// The last chunk writes the cloud's size.
+// (Rounds 1-5 took the chunk's range off one atomic counter: arrival order,
+// not reproducible run to run -- the one such output of the tracking loop --
+// 300 serialised returning atomics per VGA cloud, and since round 5 a fenced
+// ticket per workgroup to hand the total over: 11.5 us per launch. A
+// pixel-order mode existed as three launches, count -> scan -> write.)
+// ROUNDS trades words to poll against workgroups to spread the image over:
+// the host picks the largest ROUNDS that still gives every CU a chunk.
 constexpr int kUnprojMaxRounds = 8;
+constexpr int kUnprojSpinLimit = 1 << 22;  // never hang the device
 
-// MODE 0: a chunk takes its output range off one atomic counter (the order of
-// the chunks in the output is the order they get there: as the reference's
-// atomic compaction, PointCloudImpl.h:42-143, not reproducible run to run).
-// MODE 1 / 2 (O3DMI_UNPROJECT_ORDERED=1): count pass / write pass around a
-// scan of the chunk counts -- the points come out in PIXEL order, the same on
-// every run, so that a composed tracking loop can be made run-to-run
-// identical for debugging; three launches instead of one.
-template <typename depth_t, int ROUNDS, int MODE>
+template <typename depth_t, int ROUNDS>
 __global__ void __launch_bounds__(kBlock)
 UnprojectKernel(TouchParams p, const depth_t* __restrict__ depth,
                 const float* __restrict__ image_colors,
                 float* __restrict__ points, float* __restrict__ colors,
-                int* __restrict__ count, int* __restrict__ chunk_counts) {
+                int* __restrict__ count, unsigned long long* chunk_words,
+                unsigned seq, int n_chunks) {
     __shared__ int offs[ROUNDS][kBlock / 64];
-    __shared__ int chunk_base;
+    __shared__ int before[kBlock / 64];
+    __shared__ int chunk_total;
     const int64_t n = (int64_t)p.rows_strided * p.cols_strided;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int64_t c0 = (int64_t)blockIdx.x * (kBlock * ROUNDS); c0 < n;
-         c0 += (int64_t)gridDim.x * (kBlock * ROUNDS)) {
+    {
+        const int chunk = blockIdx.x;
+        const int64_t c0 = (int64_t)chunk * (kBlock * ROUNDS);
         float d[ROUNDS];
         unsigned long long ballot[ROUNDS];
 #pragma unroll
@@ -204,29 +207,46 @@ UnprojectKernel(TouchParams p, const depth_t* __restrict__ depth,
         __syncthreads();
         if (threadIdx.x == 0) {
             int run = 0;
+#pragma unroll
             for (int k = 0; k < ROUNDS; ++k)
+#pragma unroll
                 for (int wv = 0; wv < kBlock / 64; ++wv) {
                     const int c = offs[k][wv];
                     offs[k][wv] = run;
                     run += c;
                 }
-            const int64_t chunk = c0 / (kBlock * ROUNDS);
-            // MODE 0 counts in the library's own accumulator (chunk_counts[0],
-            // zero at rest), not in the caller's word: see the tail below
-            if (MODE == 0) chunk_base = run ? atomicAdd(chunk_counts, run) : 0;
-            else if (MODE == 1) chunk_counts[chunk] = run;
-            else chunk_base = chunk_counts[chunk];  // scanned: exclusive
+            __hip_atomic_store(&chunk_words[chunk],
+                               ((unsigned long long)seq << 32) | (unsigned)run,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            chunk_total = run;
         }
+        // the chunks before this one
+        int sum = 0;
+        for (int q = threadIdx.x; q < chunk; q += kBlock) {
+            unsigned long long w;
+            int spins = 0;
+            do {
+                w = __hip_atomic_load(&chunk_words[q], __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+            } while ((unsigned)(w >> 32) != seq && ++spins < kUnprojSpinLimit);
+            sum += (int)(unsigned)w;
+        }
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m);
+        if (lane == 0) before[wave] = sum;
         __syncthreads();
-        if (MODE == 1) continue;  // (uniform; offs are rewritten next chunk)
+        int64_t base = 0;
+#pragma unroll
+        for (int wv = 0; wv < kBlock / 64; ++wv) base += before[wv];
+        if (chunk == n_chunks - 1 && threadIdx.x == 0)
+            *count = (int)base + chunk_total;
 #pragma unroll
         for (int k = 0; k < ROUNDS; ++k) {
             if (!((ballot[k] >> lane) & 1ull)) continue;
             const int64_t w = c0 + k * kBlock + threadIdx.x;
             const int64_t y = (w / p.cols_strided) * p.stride;
             const int64_t x = (w % p.cols_strided) * p.stride;
-            const int64_t idx = (int64_t)chunk_base + offs[k][wave] +
-                                __popcll(ballot[k] & lt);
+            const int64_t idx = base + offs[k][wave] + __popcll(ballot[k] & lt);
             float x_c, y_c, z_c, xo, yo, zo;
             p.cam.Unproject((float)x, (float)y, d[k], x_c, y_c, z_c);
             p.cam.RigidTransform(x_c, y_c, z_c, xo, yo, zo);
@@ -240,51 +260,6 @@ UnprojectKernel(TouchParams p, const depth_t* __restrict__ depth,
                 colors[3 * idx + 2] = ip[2];
             }
         }
-        __syncthreads();  // offs / chunk_base are reused by the next chunk
-    }
-    // MODE 0: the last workgroup to finish (a ticket in chunk_counts[1]) hands
-    // the total to the caller's count and leaves accumulator and ticket zero
-    // for the next launch -- the caller's word is written once and needs no
-    // clearing launch in front of this one (a fill per call until round 5: two
-    // of the seven fill / copy launches of a tracking frame).
-    if (MODE == 0 && threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(chunk_counts + 1, 1) == (int)gridDim.x - 1) {
-            __threadfence();
-            *count = atomicExch(chunk_counts, 0);
-            chunk_counts[1] = 0;
-        }
-    }
-}
-
-// Exclusive scan of the chunk counts (one workgroup; <= a few thousand
-// chunks) + the total.
-__global__ void __launch_bounds__(kBlock)
-UnprojectScanKernel(int* __restrict__ chunk_counts, int n_chunks,
-                    int* __restrict__ count) {
-    __shared__ int part[kBlock];
-    const int per = (n_chunks + kBlock - 1) / kBlock;
-    const int lo = threadIdx.x * per;
-    const int hi = lo + per < n_chunks ? lo + per : n_chunks;
-    int sum = 0;
-    for (int i = lo; i < hi; ++i) sum += chunk_counts[i];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int t = 0; t < kBlock; ++t) {
-            const int c = part[t];
-            part[t] = run;
-            run += c;
-        }
-        *count = run;
-    }
-    __syncthreads();
-    int run = part[threadIdx.x];
-    for (int i = lo; i < hi; ++i) {
-        const int c = chunk_counts[i];
-        chunk_counts[i] = run;
-        run += c;
     }
 }
 
@@ -412,60 +387,52 @@ int o3dmi_unproject(const void* depth_dev, int depth_dtype, int rows, int cols,
     // the largest chunk that still gives every CU one
     int rounds = kUnprojMaxRounds;
     while (rounds > 1 && n < (int64_t)kCUs * kBlock * rounds) rounds >>= 1;
-    dim3 grid(GridFor(n, kBlock * rounds)), block(kBlock);
-    // O3DMI_UNPROJECT_ORDERED=1 (read per call): pixel-order output
-    const char* ord_env = std::getenv("O3DMI_UNPROJECT_ORDERED");
-    const bool ordered = ord_env && ord_env[0] == '1';
-    int* chunk_counts = nullptr;
     const int n_chunks = (int)((n + (int64_t)kBlock * rounds - 1) /
                                ((int64_t)kBlock * rounds));
+    // one workgroup per chunk, all of them: a chunk waits for the chunks
+    // before it only, and workgroups are dispatched in index order
+    dim3 grid((unsigned)n_chunks), block(kBlock);
+    unsigned long long* chunk_words = nullptr;
+    unsigned seq = 0;
     {
-        // The launch's scratch words, per host thread, device and stream (two
-        // calls of one thread on two streams may overlap on the device),
-        // grown on demand (a few KB each). Ordered mode: a count per chunk.
-        // Default mode: words 0 and 1, the accumulator and the ticket, which
-        // every launch leaves ZERO (allocated zeroed, never touched by the
-        // ordered mode's launches: those use their own buffer).
-        struct Counts {
-            int* buf = nullptr;
+        // The chunk totals' words, per host thread, device and stream (two
+        // calls of one thread on two streams may overlap on the device; the
+        // launches of one stream follow each other), grown on demand. A word
+        // is valid for the launch whose sequence number it carries: nothing
+        // is cleared between launches.
+        struct Words {
+            unsigned long long* buf = nullptr;
             int cap = 0;
+            unsigned seq = 0;
         };
-        static thread_local std::map<std::pair<int, hipStream_t>, Counts>
-                bufs[2];
+        static thread_local std::map<std::pair<int, hipStream_t>, Words> bufs;
         int dev = 0;
         O3DMI_HIP_CHECK(hipGetDevice(&dev));
-        Counts& c = bufs[ordered ? 1 : 0][std::make_pair(dev, s)];
-        const int want = ordered ? n_chunks : 2;
-        if (c.cap < want) {
+        Words& c = bufs[std::make_pair(dev, s)];
+        if (c.cap < n_chunks) {
             if (c.buf) {
                 O3DMI_HIP_CHECK(hipStreamSynchronize(s));
                 (void)hipFree(c.buf);
                 c.buf = nullptr;
                 c.cap = 0;
             }
-            int cap = ordered ? 4096 : 16;
-            while (cap < want) cap <<= 1;
-            O3DMI_HIP_CHECK(hipMalloc((void**)&c.buf, sizeof(int) * cap));
-            O3DMI_HIP_CHECK(hipMemsetAsync(c.buf, 0, sizeof(int) * cap, s));
+            int cap = 4096;
+            while (cap < n_chunks) cap <<= 1;
+            O3DMI_HIP_CHECK(hipMalloc((void**)&c.buf,
+                                      sizeof(unsigned long long) * cap));
+            O3DMI_HIP_CHECK(hipMemsetAsync(
+                    c.buf, 0, sizeof(unsigned long long) * cap, s));
             c.cap = cap;
+            c.seq = 0;
         }
-        chunk_counts = c.buf;
+        if (++c.seq == 0) ++c.seq;  // 0 = the cleared buffer
+        chunk_words = c.buf;
+        seq = c.seq;
     }
-#define O3DMI_UNPROJECT_M(T, R, M)                                            \
-    hipLaunchKernelGGL((UnprojectKernel<T, R, M>), grid, block, 0, s, p,      \
-                       (const T*)depth_dev, image_colors_dev, points_dev,     \
-                       colors_dev, out_count_dev, chunk_counts)
 #define O3DMI_UNPROJECT(T, R)                                                  \
-    do {                                                                      \
-        if (!ordered) {                                                       \
-            O3DMI_UNPROJECT_M(T, R, 0);                                       \
-        } else {                                                              \
-            O3DMI_UNPROJECT_M(T, R, 1);                                       \
-            hipLaunchKernelGGL(UnprojectScanKernel, dim3(1), dim3(kBlock), 0, \
-                               s, chunk_counts, n_chunks, out_count_dev);     \
-            O3DMI_UNPROJECT_M(T, R, 2);                                       \
-        }                                                                     \
-    } while (0)
+    hipLaunchKernelGGL((UnprojectKernel<T, R>), grid, block, 0, s, p,         \
+                       (const T*)depth_dev, image_colors_dev, points_dev,     \
+                       colors_dev, out_count_dev, chunk_words, seq, n_chunks)
 #define O3DMI_UNPROJECT_R(T)                                                   \
     switch (rounds) {                                                         \
         case 8: O3DMI_UNPROJECT(T, 8); break;                                 \
@@ -477,7 +444,6 @@ int o3dmi_unproject(const void* depth_dev, int depth_dtype, int rows, int cols,
     else { O3DMI_UNPROJECT_R(float) }
 #undef O3DMI_UNPROJECT_R
 #undef O3DMI_UNPROJECT
-#undef O3DMI_UNPROJECT_M
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
 }

@@ -15,15 +15,15 @@ namespace o3dmi {
 //           use n_max itself
 //   m_dev   device int receiving the voxel count
 //   err_dev device int: kErrKeyRange is OR-ed in for out-of-range coordinates
-// Clouds of up to 2^17 points take the bucketed three-launch form, whose
-// buffers live in a persistent workspace per host thread, device and `chain`
-// (0 or 1: two chains may run concurrently on two streams, the calls of one
-// chain must be stream-ordered). Larger clouds take the six-launch sort:
-// its scratch comes from the pool and is appended to `scratch`; the caller
-// releases it (PoolFree) once the stream has drained.
+// Clouds of up to 2^20 points take the tiled form (insert, then partition +
+// reduce per level), whose buffers live in a persistent workspace per host
+// thread, device and `chain` (0 or 1; the calls of one chain must be
+// stream-ordered). Larger clouds take the seven-launch sort, with a
+// persistent workspace of its own (`scratch` is unused nowadays and kept for
+// the callers' release paths).
 //   next_voxel_size  > 0: the caller's NEXT call on this chain will down-
 //           sample out_pos (same n_max, dtype) by this voxel size -- a pyramid
-//           built from its own output. The bucketed form then inserts the
+//           built from its own output. The tiled form then inserts the
 //           output into the next level's table in its last launch, and the
 //           next call starts at its second one. A next call that turns out
 //           different is still correct (the insert is discarded). Only when
@@ -37,6 +37,29 @@ int VdsAsync(const void* pos, const void* attr, int64_t n_max, const int* n_dev,
              hipStream_t s, int chain = 0, double next_voxel_size = 0,
              bool from_previous = false);
 
+// The same level for one or two clouds at once: the launches of the tiled form
+// take two jobs (blockIdx.y), so the source and the target pyramid of
+// MultiScaleICP advance level by level in the SAME launches on one stream
+// (round 5: two chains of launches on two streams, 16 launches per frame
+// pair of pyramids; now 7 + 1). The jobs of one call must name different
+// chains; clouds beyond the tiled form fall back to one call each.
+struct VdsLevelJob {
+    const void* pos = nullptr;
+    const void* attr = nullptr;
+    int64_t n_max = 0;
+    const int* n_dev = nullptr;
+    double voxel_size = 0;
+    void* out_pos = nullptr;
+    void* out_attr = nullptr;
+    int* m_dev = nullptr;
+    int* err_dev = nullptr;
+    int chain = 0;
+    double next_voxel_size = 0;
+    bool from_previous = false;
+};
+int VdsPairAsync(const VdsLevelJob* jobs, int n_jobs, int dtype,
+                 std::vector<void*>& scratch, hipStream_t s);
+
 // The calling thread's workspaces of `chain` on the current device may have
 // been left dirty by a chain that was abandoned mid-way (error return between
 // its first launch and the wait for its counts): their next user discards
@@ -47,5 +70,10 @@ void VdsChainInvalidate(int chain);
 // `mail_seq` (mailbox.h), on stream s; the words are zeroed afterwards.
 int PostCountsAsync(int* counts_dev, int n, double* mail_data, int* mail_flag,
                     int mail_seq, hipStream_t s);
+// Two chains' counts (built in the same launches) posted by one launch.
+int PostCountsPairAsync(int* counts_a, double* mail_data_a, int* mail_flag_a,
+                        int mail_seq_a, int* counts_b, double* mail_data_b,
+                        int* mail_flag_b, int mail_seq_b, int n,
+                        hipStream_t s);
 
 }  // namespace o3dmi
