@@ -324,11 +324,12 @@ int o3dmi_sort_indices(int32_t* indices_dev, int64_t n, o3dmi_stream_t stream);
 
 /* UnprojectCUDA (t/geometry/kernel/PointCloudImpl.h:42-143): strided depth ->
  * compacted world points. points_dev holds (rows/stride)*(cols/stride) x 3
- * floats; count to *out_count_dev. Order: unspecified (one atomic counter per
- * workgroup, as upstream) by default; with O3DMI_UNPROJECT_ORDERED=1 in the
- * environment (read per call) the row-major scan order of the strided pixels
- * (count -> scan -> write, three launches), which makes everything downstream
- * of the cloud reproducible bit for bit. */
+ * floats; count to *out_count_dev. Order: the row-major scan order of the
+ * strided pixels, the same on every run (upstream's order is its atomic
+ * counter's arrival order, i.e. unspecified; this is one instance of it): one
+ * launch, every workgroup publishes its chunk's total and reads the chunks
+ * before it. Everything downstream of the cloud is then reproducible bit for
+ * bit. */
 int o3dmi_unproject(const void* depth_dev, int depth_dtype, int rows, int cols,
                     const float* image_colors_dev, float* points_dev,
                     float* colors_dev, int32_t* out_count_dev,

@@ -118,6 +118,11 @@ int o3dmi_comm_create_custom(const o3dmi_transport_t* table, void* user,
 int o3dmi_comm_destroy(o3dmi_comm_t* c);
 int o3dmi_comm_rank(const o3dmi_comm_t* c);
 int o3dmi_comm_world(const o3dmi_comm_t* c);
+/* ncclCommCount of the RCCL communicator behind `c`, asked of RCCL at the
+ * time of the call; 0 for a custom transport (or a NULL handle): lets a
+ * caller record which transport carried its collectives and over how many
+ * ranks (bench.py config.transport / config.rccl_ranks). */
+int o3dmi_comm_rccl_ranks(const o3dmi_comm_t* c);
 int o3dmi_set_comm(o3dmi_comm_t* c);
 int o3dmi_set_rccl_comm(void* nccl_comm);
 /* Who shards the source cloud of an ICP call made with a communicator

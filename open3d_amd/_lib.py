@@ -315,6 +315,7 @@ PROTOTYPES.update({
     "o3dmi_comm_destroy": (_i32, [_vp]),
     "o3dmi_comm_rank": (_i32, [_vp]),
     "o3dmi_comm_world": (_i32, [_vp]),
+    "o3dmi_comm_rccl_ranks": (_i32, [_vp]),
     "o3dmi_set_comm": (_i32, [_vp]),
     "o3dmi_set_rccl_comm": (_i32, [_vp]),
     "o3dmi_set_icp_level_sharding": (_i32, [_i32]),

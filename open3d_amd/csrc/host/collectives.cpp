@@ -358,6 +358,17 @@ int o3dmi_comm_destroy(o3dmi_comm_t* c) {
 int o3dmi_comm_rank(const o3dmi_comm_t* c) { return c ? c->rank : 0; }
 int o3dmi_comm_world(const o3dmi_comm_t* c) { return c ? c->world : 1; }
 
+int o3dmi_comm_rccl_ranks(const o3dmi_comm_t* c) {
+    // asked of RCCL itself, not the number remembered at creation: what a
+    // scaling line reports as the span of the communicator that carried it
+    if (!c || !c->nccl) return 0;
+    Rccl* r = LoadRccl();
+    int world = 0;
+    if (!r || Check(r, r->CommCount(c->nccl, &world), "ncclCommCount"))
+        return 0;
+    return world;
+}
+
 int o3dmi_set_comm(o3dmi_comm_t* c) {
     g_thread_comm = c;
     return O3DMI_OK;

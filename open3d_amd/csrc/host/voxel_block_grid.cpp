@@ -116,6 +116,11 @@ struct o3dmi_vbg {
         int recv_slots = 0;   // receiver table (may grow on one rank alone)
         int capacity = 0;  // records of a wire segment
         int world = 0;
+        // the ranks' agreed verdict on the proven short divisions for one
+        // truncation distance (0 = not asked yet, 1 = all have them, -1 = no)
+        float agreed_trunc = 0.0f;
+        int agreed_fast_div = 0;
+        const void* agreed_comm = nullptr;
         void* send_seg[2] = {nullptr, nullptr};
         void* gathered[2] = {nullptr, nullptr};
         ChunkEntry* entries[2] = {nullptr, nullptr};  // [entries_cap]
@@ -1327,7 +1332,15 @@ static void FreeSliced(o3dmi_vbg* g) {
     (void)hipFree(z.iframes_dev);
     (void)hipFree(z.chunk_recs[0]);
     (void)hipFree(z.chunk_recs[1]);
+    // (what the ranks agreed on is not a buffer: it outlives a re-allocation
+    // that one rank may do on its own)
+    const float agreed_trunc = z.agreed_trunc;
+    const int agreed_fast_div = z.agreed_fast_div;
+    const void* agreed_comm = z.agreed_comm;
     z = o3dmi_vbg::Sliced();
+    z.agreed_trunc = agreed_trunc;
+    z.agreed_fast_div = agreed_fast_div;
+    z.agreed_comm = agreed_comm;
 }
 
 // Buffers for `world` ranks, `capacity` records per wire segment and chunk
@@ -1492,6 +1505,9 @@ struct SlicedProgress {
     int first_gathers = 0;  // chunks whose FIRST all-gather was issued (the
                             // redo of a chunk is collective by construction:
                             // every rank reads the same gathered headers)
+    bool left_in_step = false;  // the error exit was agreed on by all ranks
+                                // (o3dmi_comm::AgreeStatus): nobody waits in
+                                // an all-gather, no abort segment to send
 };
 
 // The frames of one call through the sliced path. `gathered_in`: per chunk the
@@ -1516,6 +1532,17 @@ static int StreamIntegrateSlicedBody(o3dmi_vbg* g, const StreamCommon& c0,
     c.ci = g->AttrIndex("color");
     c.with_color = c.ci >= 0 && (int64_t)c.color_rows * c.color_cols > 0 &&
                    n > 0 && frames[0].color != nullptr;
+    // Everything rank-local in front of the first all-gather -- argument
+    // checks that depend on this rank's grid, buffers, tables, the frame-table
+    // upload -- runs as ONE stage whose status the ranks agree on (ADVICE r5:
+    // a rank whose hipMalloc failed here used to return with no all-gather
+    // issued, and its peers waited in chunk 0's for ever).
+    int st;
+    o3dmi_vbg::Sliced& z = g->sliced;
+    bool raw_form = false;
+    int chunk_frames = 0;
+    TouchParams shared;
+    auto setup = [&]() -> int {
     int st = GridDtype(g, &c.grid_dtype);
     if (st) return st;
     O3DMI_REQUIRE((c.depth_cols % 4) == 0 &&
@@ -1535,7 +1562,6 @@ static int StreamIntegrateSlicedBody(o3dmi_vbg* g, const StreamCommon& c0,
                             std::getenv("O3DMI_SLICED_RAW")[0] == '1'),
                   "sliced touch, raw form, needs the same intrinsics for depth "
                   "and colour");
-    o3dmi_vbg::Sliced& z = g->sliced;
     // Sizes: a rank's band sees about 1 / world of a chunk's blocks plus the
     // band's rim; start from a generous guess and double on overflow (every
     // rank reads the same headers, so every rank doubles together).
@@ -1561,13 +1587,12 @@ static int StreamIntegrateSlicedBody(o3dmi_vbg* g, const StreamCommon& c0,
     // 527 k against 413 k at 8). O3DMI_SLICED_RAW=0 / 1 picks one (read per
     // call: tests switch it).
     const char* raw_env = std::getenv("O3DMI_SLICED_RAW");
-    const bool raw_form = raw_env ? raw_env[0] == '1'
-                                  : (world >= 4 && (!c.with_color ||
-                                                    g->prep_identity));
+    raw_form = raw_env ? raw_env[0] == '1'
+                       : (world >= 4 && (!c.with_color || g->prep_identity));
     // (A software-pipelined form of the chunk launch -- next round's gathers
     // in flight during this round's arithmetic -- made no difference at 4 and
     // 8 emulated ranks, profiles/r4p, r4zc: dropped.)
-    const int chunk_frames = kChunkGroups * group;
+    chunk_frames = kChunkGroups * group;
     const int64_t px = (int64_t)c.depth_rows * c.depth_cols;
     // The records form keeps two sets of prepared records, sized by what the
     // call needs (a chunk of this call's frames -- not the 256-frame maximum:
@@ -1603,13 +1628,24 @@ static int StreamIntegrateSlicedBody(o3dmi_vbg* g, const StreamCommon& c0,
     // every launch of the previous call that reads the frame tables is over
     // once its last integrate launch is (the side stream waited for it)
     O3DMI_HIP_CHECK(hipStreamSynchronize(z.side));
-    TouchParams shared;
     if ((st = UploadSliceFrames(g, c, frames, n, &shared,
                                 raw_form ? 0 : chunk_frames)))
         return st;
     // the caller's images may still be in flight on its stream
     O3DMI_HIP_CHECK(hipEventRecord(z.ev_enter, s));
     O3DMI_HIP_CHECK(hipStreamWaitEvent(z.side, z.ev_enter, 0));
+    return O3DMI_OK;
+    };
+    st = setup();
+    if (comm && world > 1) {
+        const int agreed = comm->AgreeStatus(st, s);
+        if (agreed) {
+            progress->left_in_step = true;
+            return agreed;
+        }
+    } else if (st) {
+        return st;
+    }
 
     const int n_chunks = (n + chunk_frames - 1) / chunk_frames;
     std::vector<int> chunk_stamp((size_t)n_chunks, 0);
@@ -1781,9 +1817,21 @@ static int StreamIntegrateSlicedBody(o3dmi_vbg* g, const StreamCommon& c0,
                                  "(o3dmi_vbg_set_slice_capacity)");
                     return O3DMI_ERR_CAPACITY;
                 }
-                if ((st = EnsureSliced(g, world, z.capacity * 2,
-                                       z.table_slots * 2, s)))
+                // (every rank is here for the same chunk with nothing in
+                // flight: a rank that cannot grow its buffers says so before
+                // the others enter the redone all-gather -- its own send
+                // segment is gone by then, no abort segment could be sent)
+                st = EnsureSliced(g, world, z.capacity * 2, z.table_slots * 2,
+                                  s);
+                if (comm && world > 1) {
+                    const int agreed = comm->AgreeStatus(st, s);
+                    if (agreed) {
+                        progress->left_in_step = true;
+                        return agreed;
+                    }
+                } else if (st) {
                     return st;
+                }
                 if ((st = issue_side(ci, true))) return st;
             }
         }
@@ -1868,8 +1916,9 @@ static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
     if (st == O3DMI_OK) return st;
     const std::string why = o3dmi_last_error();
     o3dmi_vbg::Sliced& z = g->sliced;
-    if (st != O3DMI_ERR_PEER && comm && z.side && pr.n_chunks > 0 &&
-        pr.first_gathers > 0 && pr.first_gathers < pr.n_chunks) {
+    if (st != O3DMI_ERR_PEER && !pr.left_in_step && comm && z.side &&
+        pr.n_chunks > 0 && pr.first_gathers > 0 &&
+        pr.first_gathers < pr.n_chunks) {
         // the all-gather the other ranks will wait in next
         const int set = pr.first_gathers & 1;
         SliceHeader hd = {};
@@ -1982,17 +2031,33 @@ int o3dmi_vbg_integrate_frames(o3dmi_vbg_t* g, int n_frames,
             color_cols == depth_cols && (depth_cols % 4) == 0 &&
             (!color_intrinsic ||
              std::memcmp(color_intrinsic, depth_intrinsic,
-                         sizeof(double) * 9) == 0 || !color_devs) &&
-            // (the chunk launch needs the proven short division forms: every
-            // rank takes the same decision -- the proof is a property of the
-            // part and the truncation distance -- else the replicated touch)
-            PrefetchFastDivision(g->voxel_size * trunc_voxel_multiplier,
-                                 true) == 2) {
-            return StreamIntegrateSliced(
-                    g, c, frames.data(), n_frames,
-                    frames_per_launch <= 0 ? kDefaultGroup
-                                           : frames_per_launch,
-                    (hipStream_t)stream, comm, nullptr);
+                         sizeof(double) * 9) == 0 || !color_devs)) {
+            // The chunk launch needs the proven short division forms. The
+            // proof is a property of the part and the truncation distance,
+            // but whether THIS rank has it is rank-local (a failed allocation
+            // of the proof's scratch, O3DMI_EXACT_DIV in one rank's
+            // environment): the ranks agree once per truncation distance and
+            // communicator -- a rank that silently took the
+            // non-collective path below would leave its peers in chunk 0's
+            // all-gather.
+            o3dmi_vbg::Sliced& z = g->sliced;
+            const float trunc = g->voxel_size * trunc_voxel_multiplier;
+            if (z.agreed_fast_div == 0 || z.agreed_trunc != trunc ||
+                z.agreed_comm != (const void*)comm) {
+                const int mine = PrefetchFastDivision(trunc, true) == 2
+                                         ? O3DMI_OK
+                                         : O3DMI_ERR_INTERNAL;
+                const int all = comm->AgreeStatus(mine, (hipStream_t)stream);
+                z.agreed_fast_div = all == O3DMI_OK ? 1 : -1;
+                z.agreed_trunc = trunc;
+                z.agreed_comm = (const void*)comm;
+            }
+            if (z.agreed_fast_div == 1)
+                return StreamIntegrateSliced(
+                        g, c, frames.data(), n_frames,
+                        frames_per_launch <= 0 ? kDefaultGroup
+                                               : frames_per_launch,
+                        (hipStream_t)stream, comm, nullptr);
         }
     }
     return StreamIntegrate(g, c, frames.data(), n_frames,
@@ -2309,8 +2374,10 @@ int o3dmi_vbg_ray_cast_sharded(
         band_rows = band_tiles * 8;
         const int padded = band_rows * world;  // rows of the gathered maps
         int r0 = rank * band_rows, r1 = r0 + band_rows;
-        if (r0 > height) r0 = height;
         if (r1 > height) r1 = height;
+        // a rank past the last tile row has no band (rows 0..0: the clipped
+        // start `height` is no tile boundary when height % 8 != 0)
+        if (r0 >= height) r0 = r1 = 0;
         size_t floats = 0;
         for (Map& mp : maps)
             if (mp.out) floats += (size_t)padded * width * mp.channels;

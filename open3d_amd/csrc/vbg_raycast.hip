@@ -846,6 +846,7 @@ int o3dmi_vbg_raycast_rows(
     O3DMI_REQUIRE(block_hash && tsdf_dev && weight_dev && range_map_dev &&
                           intrinsic && extrinsic,
                   "null argument");
+    O3DMI_REQUIRE(h > 0 && w > 0 && range_map_down_factor > 0, "bad size");
     // The range map is {h / down, w / down, 2} (VoxelBlockGrid.cpp:357-360) and
     // a pixel reads cell (y / down, x / down): an image that is not a multiple
     // of the down factor reads PAST the map (upstream does too: undefined
@@ -862,7 +863,6 @@ int o3dmi_vbg_raycast_rows(
     if (row_begin == row_end) return O3DMI_OK;
     O3DMI_REQUIRE(grid_dtype == O3DMI_U16 || grid_dtype == O3DMI_F32,
                   "Unsupported value data type combination.");
-    O3DMI_REQUIRE(h > 0 && w > 0 && range_map_down_factor > 0, "bad size");
     RayCastParams p;
     double pose[16];
     InverseTransformation(extrinsic, pose);

@@ -29,6 +29,13 @@
 #include "sliced_path.h"
 #include "touch_device.h"
 
+// Measurement builds only (tools/build_variant.sh -DO3DMI_ABLATE_GATHER=1):
+// the integrate role's record gathers collapse to one cache line per
+// instruction. Never defined in the product build.
+#ifndef O3DMI_ABLATE_GATHER
+#define O3DMI_ABLATE_GATHER 0
+#endif
+
 namespace o3dmi {
 namespace {
 
@@ -1126,11 +1133,22 @@ __device__ __forceinline__ void IntegrateRoleWide(const HashView& hv,
                         }
                         R.rec[fk][2 * p + h] = r;
                     } else {
-                    const unsigned off =
+                    unsigned off =
                             __umul24((unsigned)(int)vh, row_bytes) +
                             (unsigned)(int)uh * (unsigned)sizeof(PixelRec);
+#if O3DMI_ABLATE_GATHER
+                    // MEASUREMENT BUILD ONLY (tools/build_variant.sh, wrong
+                    // results): every lane of the wave reads the record of
+                    // its first lane -- one cache line per gather instruction
+                    // -- to bound what any record-staging scheme could gain
+                    off = __builtin_amdgcn_readfirstlane(in ? off
+                                                            : sentinel_off);
+                    R.rec[fk][2 * p + h] =
+                            *reinterpret_cast<const PixelRec*>(recs + off);
+#else
                     R.rec[fk][2 * p + h] = *reinterpret_cast<const PixelRec*>(
                             recs + (in ? off : sentinel_off));
+#endif
                     }
                 }
             }

@@ -184,9 +184,46 @@ _tls = threading.local()  # .installed: the Comm o3dmi_set_comm holds (per threa
 class Comm:
     """o3dmi_comm_t: the library-owned collectives of one rank."""
 
-    def __init__(self, handle, keep=None):
+    def __init__(self, handle, keep=None, transport="custom"):
         self.handle = handle
         self._keep = keep  # callbacks / tables that must outlive the handle
+        # what carries the collectives: "rccl" (ncclCommInitRank inside the
+        # library), "torch" (torch.distributed calls behind a transport
+        # table) or "custom"
+        self.transport = transport
+
+    def rccl_ranks(self):
+        """ncclCommCount of the communicator behind this handle (asked of
+        RCCL, not remembered), 0 when another transport carries it."""
+        from . import _lib
+        return int(_lib.lib().o3dmi_comm_rccl_ranks(self.handle))
+
+    def self_check(self):
+        """One all-gather and one all-reduce through THIS communicator on the
+        current stream; returns {"allgather_rank_sum", "allreduce_rank_sum",
+        "expected", "ok"}: both must equal 0 + 1 + ... + (world - 1)."""
+        from . import _lib
+        from .core import stream
+        L = _lib.lib()
+        world, rank = self.world, self.rank
+        send = torch.full((1,), float(rank), dtype=torch.float64,
+                          device="cuda")
+        recv = torch.full((world,), -1.0, dtype=torch.float64, device="cuda")
+        _lib.check(L.o3dmi_comm_allgather(
+            self.handle, _lib.ptr(send), _lib.ptr(recv), 8, stream()),
+            "comm_allgather")
+        red = torch.full((1,), float(rank), dtype=torch.float64,
+                         device="cuda")
+        _lib.check(L.o3dmi_comm_allreduce_sum_f64(
+            self.handle, _lib.ptr(red), 1, stream()), "comm_allreduce")
+        torch.cuda.synchronize()
+        want = world * (world - 1) // 2
+        got_g, got_r = float(recv.sum().item()), float(red.item())
+        in_order = bool((recv.cpu() == torch.arange(
+            world, dtype=torch.float64)).all())
+        return {"allgather_rank_sum": got_g, "allreduce_rank_sum": got_r,
+                "expected": want,
+                "ok": got_g == want and got_r == want and in_order}
 
     @property
     def rank(self):
@@ -205,8 +242,15 @@ class Comm:
         `dist` (any backend)."""
         from . import _lib
         L = _lib.lib()
-        if not L.o3dmi_rccl_available():
-            raise RuntimeError("RCCL is not available in this process")
+        # Every rank joins this agreement BEFORE any of them enters the
+        # broadcast below (ADVICE r5): a rank without a loadable librccl that
+        # raised here on its own would leave the others waiting in a
+        # collective it never enters.
+        if not _all_ranks(dist, bool(L.o3dmi_rccl_available())):
+            raise RuntimeError(
+                "RCCL is not available on every rank (%s here)" % (
+                    "available" if L.o3dmi_rccl_available()
+                    else "librccl not loadable"))
         # Rank 0's failure to make an id must not leave the others waiting in
         # the broadcast: it sends the all-zero id, which every rank rejects.
         ident = torch.zeros(128, dtype=torch.uint8)
@@ -225,7 +269,7 @@ class Comm:
         _lib.check(L.o3dmi_comm_create_rccl(raw, dist.get_rank(),
                                             dist.get_world_size(),
                                             C.byref(h)), "comm_create_rccl")
-        return Comm(h)
+        return Comm(h, transport="rccl")
 
     @staticmethod
     def torch(dist):
@@ -330,16 +374,20 @@ class Comm:
         _lib.check(_lib.lib().o3dmi_comm_create_custom(
             C.byref(table), None, rank, world, C.byref(h)),
             "comm_create_custom")
-        return Comm(h, keep=(cbs, table))
+        return Comm(h, keep=(cbs, table), transport="torch")
 
     @staticmethod
-    def for_backend(dist):
+    def for_backend(dist, allow_fallback=False):
         """RCCL inside the library when torch.distributed itself runs on it,
-        else the torch.distributed transport. If the library's own
-        communicator cannot be made on ANY rank (librccl not resolvable by
-        dlopen, ncclCommInitRank refused ...) every rank falls back to the
-        torch.distributed transport -- the ranks agree on it, so that no rank
-        enters a collective of a communicator the others do not have."""
+        else the torch.distributed transport (gloo: the functional dry run).
+        On the nccl backend a library communicator that cannot be made on
+        EVERY rank (librccl not resolvable by dlopen, ncclCommInitRank refused
+        ...) is an ERROR on every rank -- a scaling measurement must not
+        degrade quietly to staging through torch.distributed -- unless
+        `allow_fallback`, in which case every rank takes the torch transport
+        together (the ranks agree on it, so that no rank enters a collective
+        of a communicator the others do not have) and `Comm.transport` says
+        "torch"."""
         if _backend(dist) != "nccl":
             return Comm.torch(dist)
         comm, why = None, None
@@ -351,10 +399,15 @@ class Comm:
             return comm
         if comm is not None:
             comm.destroy()
+        msg = ("open3d_amd.sharding: the library's RCCL communicator is not "
+               "available on every rank (%r here)" % (why,))
+        if not allow_fallback:
+            raise RuntimeError(
+                msg + "; refusing to fall back to the torch.distributed "
+                "transport silently (pass allow_fallback=True / bench.py "
+                "--allow-transport-fallback to accept it)")
         import sys
-        print("open3d_amd.sharding: the library's RCCL communicator is not "
-              "available on every rank (%r here); using the torch.distributed "
-              "transport" % (why,), file=sys.stderr)
+        print(msg + "; using the torch.distributed transport", file=sys.stderr)
         return Comm.torch(dist)
 
     def install(self, level_sharding=False):

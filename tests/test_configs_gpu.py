@@ -293,13 +293,11 @@ def _track_vga(n_frames):
     return out, _sorted_export(g)
 
 
-def test_tracking_loop_is_reproducible_with_the_ordered_unproject(monkeypatch):
-    """With O3DMI_UNPROJECT_ORDERED=1 the clouds the tracker sees are in pixel
-    order, so nothing in the loop depends on an atomic counter's arrival order:
-    two runs of the same loop give the same bits -- clouds, poses, iteration
-    counts and the integrated grid. (In the default mode the point SET is the
-    same but its order, and so the float sums' last bits, may differ.)"""
-    monkeypatch.setenv("O3DMI_UNPROJECT_ORDERED", "1")
+def test_tracking_loop_is_reproducible_run_to_run():
+    """The clouds the tracker sees are in pixel order (Unproject compacts by a
+    look-back over chunk totals, not an atomic counter), so nothing in the loop
+    depends on arrival order: two runs of the same loop give the same bits --
+    clouds, poses, iteration counts and the integrated grid."""
     a, ga = _track_vga(5)
     b, gb = _track_vga(5)
     for k, (x, y) in enumerate(zip(a, b)):

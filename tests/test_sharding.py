@@ -254,9 +254,11 @@ def test_library_comm_over_a_custom_transport():
 
 def _comm_fallback(rank, world):
     """Comm.for_backend on the "nccl" route when the library's own RCCL
-    communicator cannot be made on one rank (mode 0) or on any rank (mode 1):
-    every rank must end with the torch.distributed transport, and a
-    communicator that was made on the other rank is destroyed."""
+    communicator cannot be made on one rank (mode 0) or on any rank (mode 1).
+    By default that is an ERROR on every rank (a scaling run must not degrade
+    to the torch transport quietly); with allow_fallback every rank must end
+    with the torch.distributed transport, and a communicator that was made on
+    the other rank is destroyed either way."""
     import __graft_entry__ as ge
     if rank == 0:
         ge.build()
@@ -266,41 +268,91 @@ def _comm_fallback(rank, world):
     real_rccl, real_backend = Comm.rccl, sharding._backend
     out = []
     for mode in (0, 1):
-        destroyed = []
+        for allow in (False, True):
+            destroyed = []
 
-        class FakeRccl:
-            def destroy(self):
-                destroyed.append(True)
+            class FakeRccl:
+                def destroy(self):
+                    destroyed.append(True)
 
-        def rccl(_dist, mode=mode):
-            if mode == 1 or rank == 1:
-                raise RuntimeError("no RCCL here")
-            return FakeRccl()
-        Comm.rccl = staticmethod(rccl)
-        sharding._backend = lambda _d: "nccl"
-        try:
-            comm = Comm.for_backend(dist)
-        finally:
-            Comm.rccl, sharding._backend = real_rccl, real_backend
-        is_custom = isinstance(comm, Comm) and comm._keep is not None
-        world_seen = comm.world
-        comm.destroy()
-        out.append((is_custom, world_seen, len(destroyed)))
+            def rccl(_dist, mode=mode):
+                if mode == 1 or rank == 1:
+                    raise RuntimeError("no RCCL here")
+                return FakeRccl()
+            Comm.rccl = staticmethod(rccl)
+            sharding._backend = lambda _d: "nccl"
+            comm, refused = None, None
+            try:
+                comm = Comm.for_backend(dist, allow_fallback=allow)
+            except RuntimeError as e:
+                refused = str(e)
+            finally:
+                Comm.rccl, sharding._backend = real_rccl, real_backend
+            if comm is None:
+                out.append((allow, False, refused, 0, len(destroyed), None))
+                continue
+            is_custom = isinstance(comm, Comm) and comm._keep is not None
+            world_seen, transport = comm.world, comm.transport
+            ranks = comm.rccl_ranks()
+            comm.destroy()
+            out.append((allow, is_custom, transport, world_seen,
+                        len(destroyed), ranks))
     # and the plain routes are what they were
     plain = Comm.for_backend(dist)   # gloo -> torch transport
-    ok = plain._keep is not None
+    ok = plain._keep is not None and plain.transport == "torch"
     plain.destroy()
     return out, ok
 
 
-def test_comm_for_backend_falls_back_together():
+def test_comm_for_backend_refuses_a_silent_fallback_and_falls_back_together():
     out = _run(_comm_fallback, world=2)
-    for rank, (modes, ok) in enumerate(out):
+    for rank, (cases, ok) in enumerate(out):
         assert ok
-        for mode, (is_custom, world_seen, destroyed) in enumerate(modes):
-            assert is_custom and world_seen == 2, (rank, mode)
+        assert len(cases) == 4
+        for k, (allow, is_custom, what, world_seen, destroyed,
+                ranks) in enumerate(cases):
+            mode = k // 2
+            if not allow:
+                # fatal on EVERY rank, also the one whose own communicator
+                # was fine, and the message names the switch
+                assert not is_custom and "refusing to fall back" in what, \
+                    (rank, mode, what)
+            else:
+                assert is_custom and what == "torch" and world_seen == 2, \
+                    (rank, mode)
+                assert ranks == 0          # no RCCL communicator behind it
             # mode 0: rank 0 had made its communicator and gave it up
             assert destroyed == (1 if (mode == 0 and rank == 0) else 0)
+
+
+def _rccl_availability_agreement(rank, world):
+    """Comm.rccl: a rank on which librccl cannot be loaded must not skip the
+    collectives the others enter: the ranks agree on availability
+    FIRST, and all of them raise."""
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    dist.barrier()
+    from open3d_amd import _lib
+    from open3d_amd.sharding import Comm
+    L = _lib.lib()
+    real = L.o3dmi_rccl_available
+    L.o3dmi_rccl_available = (lambda: 0) if rank == 1 else (lambda: 1)
+    try:
+        try:
+            Comm.rccl(dist)
+            return "no error"
+        except RuntimeError as e:
+            return str(e)
+    finally:
+        L.o3dmi_rccl_available = real
+
+
+def test_comm_rccl_agrees_on_availability_before_any_collective():
+    out = _run(_rccl_availability_agreement, world=2)
+    assert "librccl not loadable" in out[1]
+    assert "not available on every rank" in out[0]
+    assert "available here" in out[0] or "(available" in out[0]
 
 
 def test_rccl_is_resolved_at_run_time_only():

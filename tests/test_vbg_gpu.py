@@ -254,15 +254,16 @@ def test_depth_touch_no_blocks_is_an_error():
     assert "No block is touched" in str(e.value)
 
 
-def test_unproject_ordered_is_the_row_major_scan(monkeypatch):
-    """O3DMI_UNPROJECT_ORDERED=1: count -> scan -> write, so the points come
-    out in the row-major scan order of the strided pixels (the oracle's order;
-    the reference's atomic-counter order is unspecified), identical from run
-    to run, with no sort in the comparison."""
+def test_unproject_is_the_row_major_scan():
+    """o3dmi_unproject compacts in ONE launch and in pixel order: the points
+    come out in the row-major scan order of the strided pixels (the oracle's
+    order; the reference's atomic-counter order is unspecified), identical
+    from run to run, with no sort in the comparison. (Rounds 1-5: an atomic
+    counter's arrival order by default, this order behind a switch as three
+    launches.)"""
     _lib, geometry = _gpu()
     from open3d_amd.core import stream
     L = _lib.lib()
-    monkeypatch.setenv("O3DMI_UNPROJECT_ORDERED", "1")
     d, c, K, Ts = sc.frames(33, 2)
     for f, stride in ((0, 1), (1, 1), (0, 4), (1, 3)):
         cf = (c[f].astype(np.float32) / 255.0).astype(np.float32)
