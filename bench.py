@@ -125,8 +125,22 @@ def parse():
                     help="bracket every n-th integrate launch with HIP events "
                          "(0 = none; the roofline is then not measured)")
     ap.add_argument("--sharding", choices=["frames", "blocks"],
-                    default="blocks",
-                    help="multi-GPU scheme of the headline value")
+                    default="frames",
+                    help="multi-GPU scheme of the headline value at N > 1. "
+                         "`frames` (default since round 6; the split BASELINE's "
+                         "north star describes): rank r integrates frames r, "
+                         "r + N, ... into a private grid, one owner-"
+                         "partitioned all-to-all merge closes the timed "
+                         "region; block set and weights equal the single "
+                         "stream's, TSDF within 1e-4, colour within the "
+                         "rounding of the running mean. `blocks`: every rank "
+                         "sees every frame and integrates the blocks it owns "
+                         "(sliced touch + one all-gather per chunk); the "
+                         "union of the grids is the single stream's bit for "
+                         "bit. Worst-rank emulation on one GPU (profiles/"
+                         "r6d_emu_all_ranks.txt): frames 1.99x / 3.8x / 6.9x "
+                         "at 2 / 4 / 8 ranks before the merge, blocks 1.91x / "
+                         "3.03x / 4.75x")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"],
                     default=os.environ.get("O3DMI_DIST_BACKEND", "nccl"),
                     help="torch.distributed backend; gloo = functional dry "
@@ -1578,6 +1592,11 @@ def main():
                    "avg_blocks_per_frame": prof["block_frames"] /
                                            max(1, prof["frames"]),
                    "sharding": sharding,
+                   "parity_vs_single_stream": (
+                       None if e_world == 1 else
+                       "bit-identical union of the grids" if by_blocks else
+                       "block set and weights exact, TSDF <= 1e-4, colour "
+                       "within the rounding of the running mean"),
                    "touch": (a.touch if by_blocks else None),
                    "merge_ms": merge_ms,
                    "dist_backend": a.dist_backend if world > 1 else None,
