@@ -1456,6 +1456,51 @@ def test_voxel_down_sample_bucketed_form_edge_cases(dtype):
     check(np.ascontiguousarray(pts[:5000]), None, 0.03)  # table clean again
 
 
+def test_voxel_down_sample_tiled_form_sizes_and_tile_boundaries():
+    """The tiled VoxelDownSample (round 6: insert, then partition + reduce per
+    level; clouds up to 2^20 points) against the oracle, bit for bit, at what
+    its geometry makes special: the 1024-point tile boundaries, the size at
+    which a bucket becomes 2048 slots wide (more than 2^19 points), the form's
+    largest cloud and one point past it (the sort), a cloud whose points all
+    fall into ONE voxel (every tile's segment of one bucket), and points in
+    an order that is NOT spatially coherent (the run de-duplication of the
+    insert launch then sends every point to the table on its own)."""
+    _lib, reg = _gpu()
+    rng = np.random.default_rng(3)
+
+    def check(pts, nrm, voxel):
+        wp, wn = orc.voxel_down_sample(pts, nrm, voxel)
+        tn = None if nrm is None else torch.from_numpy(nrm).cuda()
+        gp, gn = reg.voxel_down_sample(torch.from_numpy(pts).cuda(), tn, voxel)
+        assert gp.shape[0] == wp.shape[0]
+        assert np.array_equal(gp.cpu().numpy(), wp)
+        if nrm is not None:
+            assert np.array_equal(gn.cpu().numpy(), wn)
+        return wp.shape[0]
+
+    p = _pair(600000, seed=31)
+    pts, nrm = p["target"], p["target_normals"]
+    for n in (1023, 1024, 1025, 2048, 16384, 16385, 300000):
+        check(np.ascontiguousarray(pts[:n]), np.ascontiguousarray(nrm[:n]),
+              0.02)
+    # > 2^19 points: 2048-slot buckets
+    assert check(np.ascontiguousarray(pts[:(1 << 19) + 5]), None, 0.015) > 1000
+    # shuffled order: no runs of equal voxels for the insert to merge
+    perm = rng.permutation(200000)
+    check(np.ascontiguousarray(pts[perm]), np.ascontiguousarray(nrm[perm]),
+          0.03)
+    # every point in one voxel: a single first point, 70 000 members
+    one = (np.asarray([0.25, 0.25, 0.25], np.float32) +
+           rng.uniform(0, 0.04, (70000, 3))).astype(np.float32)
+    assert check(one, None, 0.05) == 1
+    # the form's largest cloud and one past it
+    big = np.concatenate([pts, pts[:500000] + np.float32(0.001)])
+    assert big.shape[0] > (1 << 20)
+    check(np.ascontiguousarray(big[:1 << 20]), None, 0.02)
+    check(np.ascontiguousarray(big[:(1 << 20) + 1]), None, 0.02)
+    check(np.ascontiguousarray(pts[:777]), None, 0.05)   # table clean again
+
+
 @pytest.mark.parametrize("voxels", [[0.05, 0.025, 0.0125], [0.05, -1.0]])
 def test_multiscale_icp_with_device_resident_cloud_sizes(voxels):
     """o3dmi_registration_set_device_counts: the clouds sit in buffers larger
@@ -1551,3 +1596,9 @@ def test_pyramid_level_that_carries_the_next_levels_insert_changes_nothing():
     plain = run({"O3DMI_VDS_NO_FUSE": "1"})
     assert fused == plain
     assert all(case[1] > 0 for case in fused)
+    # Round 6: the source and the target pyramid advance level by level in
+    # the SAME launches (blockIdx.y = cloud). O3DMI_VDS_UNPAIRED=1 is round
+    # 5's shape -- two chains of launches on two streams: same bits.
+    unpaired = run({"O3DMI_VDS_UNPAIRED": "1"})
+    assert unpaired == fused
+    assert run({"O3DMI_VDS_UNPAIRED": "1", "O3DMI_VDS_NO_FUSE": "1"}) == fused

@@ -291,6 +291,46 @@ def test_unproject_is_the_row_major_scan():
         assert (runs[0][0][m:] == -7.0).all()       # nothing written past count
 
 
+def test_unproject_large_image_many_chunks():
+    """A 1280x720 image at stride 1 (450 chunks of 2048 pixels: a workgroup
+    reads up to two words per lane of the chunks before it) and at stride 3
+    (a size that is no multiple of the chunk), float32 depth, holes of invalid
+    depth of every size: row-major order, exact count, nothing written past
+    it, twice the same bits."""
+    _lib, geometry = _gpu()
+    from open3d_amd import synthetic as syn
+    from open3d_amd.core import stream
+    L = _lib.lib()
+    K = syn.intrinsics(1280, 720)
+    d, _c, _n, T = syn.render_frames(7, 1, 1280, 720, device="cuda")
+    depth = (d[0].to(torch.float32) / 1000.0).contiguous()
+    rng = np.random.default_rng(5)
+    holes = torch.from_numpy(rng.random((720, 1280)) < 0.3).cuda()
+    depth[holes] = 0.0
+    depth[100:300, :] = 0.0           # whole chunks without a point
+    depth[500:, 640:] = 9.0           # beyond depth_max
+    Tn = np.asarray(T[0], np.float64)
+    dn = depth.cpu().numpy()
+    for stride in (1, 3):
+        want_p, _ = orc.unproject(dn, None, K, Tn, 1.0, 3.0, stride)
+        n = (720 // stride) * (1280 // stride)
+        runs = []
+        for _ in range(2):
+            pts = torch.full((n, 3), -7.0, dtype=torch.float32, device="cuda")
+            cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+            _lib.check(L.o3dmi_unproject(
+                _lib.ptr(depth), _lib.F32, 720, 1280, None, _lib.ptr(pts),
+                None, _lib.ptr(cnt), _lib.f64p(K), _lib.f64p(Tn),
+                C.c_float(1.0), C.c_float(3.0), stride, stream()),
+                "unproject")
+            m = int(cnt.item())
+            assert m == want_p.shape[0] and 1000 < m < n
+            runs.append(pts.cpu().numpy())
+        assert np.array_equal(runs[0][:m], want_p)
+        assert np.array_equal(runs[0], runs[1])
+        assert (runs[0][m:] == -7.0).all()
+
+
 @pytest.mark.parametrize("input_f32", [False, True])
 @pytest.mark.parametrize("grid_f32", [False, True])
 def test_integrate_parity_all_dtype_combos(input_f32, grid_f32):
