@@ -77,6 +77,10 @@ extern "C" int o3dmi_internal_nns_destroy_completed(o3dmi_nns_t* nns);
 extern "C" int o3dmi_internal_nns_create_with_normals(
         const void* points_dev, const void* normals_dev, int64_t n, int dtype,
         double radius, o3dmi_stream_t stream, o3dmi_nns_t** out);
+extern "C" int o3dmi_internal_nns_create_small_deferred(
+        const void* points_dev, const void* normals_dev, const int* n_dev,
+        int dtype, double radius, o3dmi_stream_t stream, o3dmi_nns_t** out);
+extern "C" int o3dmi_internal_nns_adopt_count(o3dmi_nns_t* nns, int64_t n);
 extern "C" int o3dmi_internal_icp_transform_search_accumulate(
         const o3dmi_nns_t* nns, void* src_dev, const double* transformation,
         const void* tgt_normals_dev, int64_t n, int estimation,
@@ -240,6 +244,7 @@ int CurrentDevice() {
     return d;
 }
 constexpr int kMaxScales = 30;
+static_assert(kMaxScales + 2 <= kCountsKeep, "counts and their kept copies");
 struct ChainCounts {
     int* dev = nullptr;
     int levels = 0;
@@ -268,14 +273,14 @@ struct ChainCounts {
         const bool fresh = !b;
         if (!b)
             O3DMI_HIP_CHECK(hipMalloc((void**)&b,
-                                      sizeof(int) * (kMaxScales + 2)));
+                                      sizeof(int) * 2 * kCountsKeep));
         if (fresh || Open(d, chain_id)) {
             if (!fresh) {
                 O3DMI_HIP_CHECK(hipDeviceSynchronize());
                 VdsChainInvalidate(chain_id);
             }
             O3DMI_HIP_CHECK(hipMemsetAsync(b, 0,
-                                           sizeof(int) * (kMaxScales + 2), cs));
+                                           sizeof(int) * 2 * kCountsKeep, cs));
         }
         Open(d, chain_id) = true;
         dev = b;
@@ -285,6 +290,8 @@ struct ChainCounts {
         return O3DMI_OK;
     }
     int* Count(int level) { return dev + level; }
+    // (valid behind the posting launch, PostCountsPairAsync)
+    const int* KeptCount(int level) const { return dev + kCountsKeep + level; }
     int* Err() { return dev + levels; }
     // Post: the counts leave for the chain's mailbox behind the chain's
     // launches; Wait: for that, and returns them. (Both chains post before
@@ -745,8 +752,23 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
                 return st;
         }
         std::vector<int> counts;
+        // The coarsest scale's index, queued behind the posting launch BEFORE
+        // the sizes are read back (its one-workgroup build takes the target
+        // level's size from the count the posting launch keeps): it runs while
+        // the counts cross PCIe and the host gets ready to launch the first
+        // search -- that search used to wait for count -> host -> allocation ->
+        // build launch -> build (a 20 us hole in every tracked frame, r6a).
+        NnsGuard early;  // (destroyed with a device-wide wait if not adopted)
+        const bool early_build =
+                paired && !(last == 0 && finest_is_input) && pyr[0].tgt_ptr;
         if (paired) {
             if ((st = ChainCounts::PostPair(scc, tcc, s))) return st;
+            if (early_build &&
+                (st = o3dmi_internal_nns_create_small_deferred(
+                         pyr[0].tgt_ptr, p2plane ? pyr[0].nrm_ptr : nullptr,
+                         tcc.KeptCount(0), dtype, max_dists[0],
+                         (o3dmi_stream_t)s, &early.nns)))
+                return st;
         } else {
             if ((st = tcc.Post(ts))) return st;
             if ((st = scc.Post(s))) return st;
@@ -766,7 +788,11 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         // issuing them here kept the host busy for ~60 us (eight launch
         // calls) before it got to the first search -- with the GPU idle
         // (tools/slam_timeline.py).
-        {
+        if (early.nns &&
+            o3dmi_internal_nns_adopt_count(early.nns, pyr[0].nt)) {
+            guards[0].nns = early.nns;
+            early.nns = nullptr;
+        } else {
             const Level& L0 = pyr[0];
             if ((st = o3dmi_internal_nns_create_with_normals(
                          L0.tgt_ptr, p2plane ? L0.nrm_ptr : nullptr, L0.nt,

@@ -128,8 +128,9 @@ constexpr int kSmallIndexBlock = 1024;
 template <typename T>
 __global__ void __launch_bounds__(kSmallIndexBlock)
 BuildSmallIndexKernel(const T* __restrict__ pts, const T* __restrict__ normals,
-                      int n, double inv_cell, unsigned mask, int n_buckets,
-                      uint2* __restrict__ ranges, Rec4<T>* __restrict__ sorted,
+                      int n, const int* __restrict__ n_dev, double inv_cell,
+                      unsigned mask, int n_buckets, uint2* __restrict__ ranges,
+                      Rec4<T>* __restrict__ sorted,
                       Rec4<T>* __restrict__ sorted_normals,
                       int* __restrict__ tickets) {
     __shared__ unsigned cnt[kSmallIndexBuckets];
@@ -137,6 +138,14 @@ BuildSmallIndexKernel(const T* __restrict__ pts, const T* __restrict__ normals,
     constexpr int kMine = kSmallIndexPoints / kSmallIndexBlock;  // points / thread
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (tickets && threadIdx.x < 16) tickets[threadIdx.x] = 0;
+    // n_dev: the size lives on the device (the ICP driver queues this build
+    // behind the pyramid BEFORE it has read the level sizes back); a cloud
+    // that turns out too large for this launch is left unbuilt -- the host,
+    // which learns the size a moment later, builds it the long way
+    if (n_dev) {
+        n = *n_dev;
+        if (n < 0 || n > kSmallIndexPoints) return;
+    }
     for (int b = threadIdx.x; b < n_buckets; b += kSmallIndexBlock) cnt[b] = 0;
     __syncthreads();
     Rec4<T> rec[kMine];
@@ -1011,7 +1020,8 @@ int BuildIndex(o3dmi_nns* nns, const T* pts, const T* normals, hipStream_t s) {
     if (n > 0 && n <= kSmallIndexPoints) {
         hipLaunchKernelGGL(BuildSmallIndexKernel<T>, dim3(1),
                            dim3(kSmallIndexBlock), 0, s, pts, normals, (int)n,
-                           nns->inv_cell, mask, (int)nb, nns->ranges,
+                           (const int*)nullptr, nns->inv_cell, mask, (int)nb,
+                           nns->ranges,
                            (Rec4<T>*)nns->sorted_pts,
                            (Rec4<T>*)nns->sorted_normals, nns->tickets);
         O3DMI_HIP_CHECK(hipGetLastError());
@@ -1113,6 +1123,78 @@ int o3dmi_internal_nns_create_with_normals(const void* points_dev,
     }
     *out = nns;
     return O3DMI_OK;
+}
+
+// Internal (ICP driver): the index of a SMALL cloud (<= 4096 points: the
+// coarsest level of a pyramid) whose size is still a device word -- the
+// one-workgroup build is queued now, sized for the largest cloud it can take
+// (8192 buckets); o3dmi_internal_nns_adopt_count tells the index its size once
+// the host knows it. The build does nothing when the cloud is larger.
+int o3dmi_internal_nns_destroy_completed(o3dmi_nns_t* nns);
+
+int o3dmi_internal_nns_create_small_deferred(const void* points_dev,
+                                             const void* normals_dev,
+                                             const int* n_dev, int dtype,
+                                             double radius,
+                                             o3dmi_stream_t stream,
+                                             o3dmi_nns_t** out) {
+    O3DMI_REQUIRE(out && points_dev && n_dev, "null argument");
+    O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
+                  "points must be Float32 or Float64");
+    O3DMI_REQUIRE(radius > 0, "radius must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    auto* nns = new o3dmi_nns();
+    nns->dtype = dtype;
+    nns->n = kSmallIndexPoints;  // until adopt_count
+    nns->radius = radius;
+    nns->inv_cell = 1.0 / (radius * 1.001);
+    nns->n_buckets = kSmallIndexBuckets;
+    const size_t rec = dtype == O3DMI_F64 ? sizeof(Rec4<double>)
+                                          : sizeof(Rec4<float>);
+    int st = PoolAlloc((void**)&nns->ranges,
+                       sizeof(uint2) * (size_t)(kSmallIndexBuckets + 1));
+    if (!st) st = PoolAlloc(&nns->sorted_pts, rec * kSmallIndexPoints);
+    if (!st && normals_dev)
+        st = PoolAlloc(&nns->sorted_normals, rec * kSmallIndexPoints);
+    if (!st)
+        st = PoolAlloc((void**)&nns->partials,
+                       sizeof(double) * kCUs * 4 * kNumSums);
+    if (st) {
+        o3dmi_internal_nns_destroy_completed(nns);
+        return st;
+    }
+    nns->tickets = (int*)(nns->partials + (size_t)(kCUs * 4 - 1) * kNumSums);
+    const unsigned mask = (unsigned)(kSmallIndexBuckets - 1);
+    if (dtype == O3DMI_F64)
+        hipLaunchKernelGGL(BuildSmallIndexKernel<double>, dim3(1),
+                           dim3(kSmallIndexBlock), 0, s,
+                           (const double*)points_dev,
+                           (const double*)normals_dev, 0, n_dev, nns->inv_cell,
+                           mask, kSmallIndexBuckets, nns->ranges,
+                           (Rec4<double>*)nns->sorted_pts,
+                           (Rec4<double>*)nns->sorted_normals, nns->tickets);
+    else
+        hipLaunchKernelGGL(BuildSmallIndexKernel<float>, dim3(1),
+                           dim3(kSmallIndexBlock), 0, s,
+                           (const float*)points_dev, (const float*)normals_dev,
+                           0, n_dev, nns->inv_cell, mask, kSmallIndexBuckets,
+                           nns->ranges, (Rec4<float>*)nns->sorted_pts,
+                           (Rec4<float>*)nns->sorted_normals, nns->tickets);
+    if (hipGetLastError() != hipSuccess) {
+        o3dmi_nns_destroy(nns);
+        SetLastError("small index: launch failed");
+        return O3DMI_ERR_HIP;
+    }
+    *out = nns;
+    return O3DMI_OK;
+}
+
+// 1: the deferred index above was built for this size (it now knows it);
+// 0: the cloud was too large (or empty) -- the caller builds it the long way.
+int o3dmi_internal_nns_adopt_count(o3dmi_nns_t* nns, int64_t n) {
+    if (!nns || n <= 0 || n > kSmallIndexPoints) return 0;
+    nns->n = n;
+    return 1;
 }
 
 // Internal (host drivers): the caller knows that every kernel using the index

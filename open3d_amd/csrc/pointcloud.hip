@@ -1344,7 +1344,12 @@ __global__ void PostCountsPairKernel(int* __restrict__ counts_a,
     int* counts = blockIdx.x ? counts_b : counts_a;
     double* mail_data = blockIdx.x ? mail_data_b : mail_data_a;
     if ((int)threadIdx.x < n) {
-        mail_data[threadIdx.x] = (double)counts[threadIdx.x];
+        const int c = counts[threadIdx.x];
+        mail_data[threadIdx.x] = (double)c;
+        // a copy that survives the re-zeroing, for launches queued behind
+        // this one that size themselves by a level count (the deferred small
+        // index build of the ICP driver)
+        counts[kCountsKeep + threadIdx.x] = c;
         counts[threadIdx.x] = 0;
     }
     MailboxPublish(blockIdx.x ? mail_flag_b : mail_flag_a,

@@ -70,7 +70,10 @@ void VdsChainInvalidate(int chain);
 // `mail_seq` (mailbox.h), on stream s; the words are zeroed afterwards.
 int PostCountsAsync(int* counts_dev, int n, double* mail_data, int* mail_flag,
                     int mail_seq, hipStream_t s);
-// Two chains' counts (built in the same launches) posted by one launch.
+// Two chains' counts (built in the same launches) posted by one launch; every
+// count is also copied to counts[kCountsKeep + i], where it stays until the
+// next posting launch (counts buffers hold 2 * kCountsKeep ints).
+constexpr int kCountsKeep = 32;
 int PostCountsPairAsync(int* counts_a, double* mail_data_a, int* mail_flag_a,
                         int mail_seq_a, int* counts_b, double* mail_data_b,
                         int* mail_flag_b, int mail_seq_b, int n,
