@@ -4,10 +4,10 @@
 //
 // Per frame, with the calls a user of the reference's tensor API would make:
 //   VoxelBlockGrid::GetUniqueBlockCoordinates(previous depth, previous pose)
-//       -- here o3dmi_vbg_last_frame_block_coordinates: the same set, taken
-//       from the Integrate that just touched those blocks (no second touch,
-//       no host wait; `examples/icp_slam ... 1` calls the reference's
-//       function instead)
+//       -- here the same set, taken from the Integrate that just touched
+//       those blocks: o3dmi_vbg_ray_cast_dev without block coordinates reads
+//       the grid's own list (no second touch, no export launch, no host wait;
+//       `examples/icp_slam ... 1` calls the reference's function instead)
 //   VoxelBlockGrid::RayCast(depth + normal maps)            model frame
 //   PointCloud::CreateFromDepthImage(ray-cast depth, stride 2; normals ride
 //       along as the per-pixel attribute) + rotate the normals    model cloud
@@ -341,8 +341,11 @@ int RunRank(int argc, char** argv, int rank, int world, o3dmi_comm_t* comm,
     CHECK_O3D(o3dmi_vbg_integrate_frame(grid, depth_dev[0], H, W, color_dev[0],
                                         H, W, O3DMI_U16, K, K, X, depth_scale,
                                         depth_max, trunc, stream));
-    CHECK_O3D(o3dmi_vbg_last_frame_block_coordinates(grid, keys, keys_cap,
-                                                     keys_count, stream));
+    // (one rank: the ray cast reads the grid's own block list; the sharded
+    // cast takes the coordinates as a buffer)
+    if (world > 1)
+        CHECK_O3D(o3dmi_vbg_last_frame_block_coordinates(grid, keys, keys_cap,
+                                                         keys_count, stream));
     CHECK_HIP(hipStreamSynchronize(stream));
 
     double worst_translation = 0, worst_angle = 0;
@@ -381,9 +384,12 @@ int RunRank(int argc, char** argv, int rank, int world, o3dmi_comm_t* comm,
                     nullptr, rc_normal, depth_scale, 0.1f, depth_max, 1.0f,
                     trunc, 8, stream));
         } else {
+            // (without touch_again: the block list and the range map are
+            // the grid's own -- no export launch, no clearing launch)
             CHECK_O3D(o3dmi_vbg_ray_cast_dev(
-                    grid, keys, m, touch_again ? nullptr : keys_count, K, X, W,
-                    H, range_map, rc_depth, nullptr, nullptr, rc_normal,
+                    grid, touch_again ? keys : nullptr, m, nullptr, K, X, W, H,
+                    touch_again ? range_map : nullptr, rc_depth, nullptr,
+                    nullptr, rc_normal,
                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                     depth_scale, 0.1f, depth_max, 1.0f, trunc, 8, stream));
         }
@@ -423,7 +429,7 @@ int RunRank(int argc, char** argv, int rank, int world, o3dmi_comm_t* comm,
         CHECK_O3D(o3dmi_vbg_integrate_frame(
                 grid, depth_dev[(size_t)k], H, W, color_dev[(size_t)k], H, W,
                 O3DMI_U16, K, K, X, depth_scale, depth_max, trunc, stream));
-        if (!touch_again)
+        if (!touch_again && world > 1)
             CHECK_O3D(o3dmi_vbg_last_frame_block_coordinates(
                     grid, keys, keys_cap, keys_count, stream));
         const double p4 = now();

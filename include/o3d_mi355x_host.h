@@ -614,7 +614,14 @@ int o3dmi_vbg_last_frame_block_coordinates(o3dmi_vbg_t* g,
 
 /* RayCast with the number of block coordinates resident on the device
  * (*m_dev <= max_m; m_dev NULL = max_m): no host round trip between the
- * integration that produced the block list and the ray cast that uses it. */
+ * integration that produced the block list and the ray cast that uses it.
+ * block_coords_dev NULL: the blocks the most recent frame-stream integration
+ * touched (what o3dmi_vbg_last_frame_block_coordinates would copy out), read
+ * from the grid's own list -- no export launch; max_m / m_dev are ignored.
+ * range_map_dev NULL: the range map is the grid's own scratch, as in the
+ * reference (VoxelBlockGrid.cpp:357-360 allocates it inside RayCast); with
+ * the default down factor of 8 the ray cast that consumes it leaves it clean
+ * for the next call, which then needs no clearing launch. */
 int o3dmi_vbg_ray_cast_dev(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
                            int64_t max_m, const int32_t* m_dev,
                            const double* intrinsic, const double* extrinsic,

@@ -81,6 +81,10 @@ extern "C" int o3dmi_internal_nns_create_small_deferred(
         const void* points_dev, const void* normals_dev, const int* n_dev,
         int dtype, double radius, o3dmi_stream_t stream, o3dmi_nns_t** out);
 extern "C" int o3dmi_internal_nns_adopt_count(o3dmi_nns_t* nns, int64_t n);
+extern "C" int o3dmi_internal_nns_create_many(
+        int count, const void* const* points_dev,
+        const void* const* normals_dev, const int64_t* n, int dtype,
+        const double* radius, o3dmi_stream_t stream, o3dmi_nns_t** out);
 extern "C" int o3dmi_internal_icp_transform_search_accumulate(
         const o3dmi_nns_t* nns, void* src_dev, const double* transformation,
         const void* tgt_normals_dev, int64_t n, int estimation,
@@ -805,14 +809,34 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
     // One more scale's index on the side stream (see above); the event the
     // second scale waits for is recorded behind the last one.
     int index_status = O3DMI_OK;
+    // ALL the later scales' indices in the same four launches (round 6,
+    // nns.hip BuildIndexMany; up to four per call), issued in the shadow of
+    // the first search launch. One build per search launch (rounds 2-5) was a
+    // fill + three launches + four pool allocations each: ~20 us of host time
+    // behind an 11 us search -- two late hops per tracked frame.
     auto build_next_index = [&]() {
-        if (next_index >= num_scales || index_status != O3DMI_OK) return;
-        const int k = next_index++;
-        const Level& Lk = pyr[(size_t)k];
-        index_status = o3dmi_internal_nns_create_with_normals(
-                Lk.tgt_ptr, p2plane ? Lk.nrm_ptr : nullptr, Lk.nt, dtype,
-                max_dists[k], (o3dmi_stream_t)side, &guards[(size_t)k].nns);
-        if (index_status == O3DMI_OK && next_index == num_scales && overlap) {
+        while (next_index < num_scales && index_status == O3DMI_OK) {
+            const void* pts[4];
+            const void* nrm[4];
+            int64_t nn[4];
+            double rad[4];
+            o3dmi_nns_t* made[4] = {};
+            int cnt = 0;
+            const int first = next_index;
+            for (; cnt < 4 && next_index < num_scales; ++cnt, ++next_index) {
+                const Level& Lk = pyr[(size_t)next_index];
+                pts[cnt] = Lk.tgt_ptr;
+                nrm[cnt] = p2plane ? Lk.nrm_ptr : nullptr;
+                nn[cnt] = Lk.nt;
+                rad[cnt] = max_dists[next_index];
+            }
+            index_status = o3dmi_internal_nns_create_many(
+                    cnt, pts, nrm, nn, dtype, rad, (o3dmi_stream_t)side, made);
+            for (int q = 0; q < cnt; ++q)
+                guards[(size_t)(first + q)].nns = made[q];
+        }
+        if (index_status == O3DMI_OK && overlap && !indices_on_side &&
+            num_scales > 1) {
             if (hipEventRecord(ev, side) != hipSuccess)
                 index_status = O3DMI_ERR_HIP;
             else

@@ -32,8 +32,6 @@ struct o3dmi_slam_model {
     int32_t* frustum_count_dev = nullptr;
     bool count_on_device = false;
     bool integrated = false;
-    float* range_map = nullptr;
-    int64_t range_capacity = 0;
 };
 
 extern "C" {
@@ -67,7 +65,6 @@ int o3dmi_slam_model_destroy(o3dmi_slam_model_t* m) {
     o3dmi_vbg_destroy(m->grid);
     (void)hipFree(m->frustum_coords);
     (void)hipFree(m->frustum_count_dev);
-    (void)hipFree(m->range_map);
     delete m;
     return O3DMI_OK;
 }
@@ -109,23 +106,18 @@ int o3dmi_slam_model_synthesize_model_frame(
                   "SynthesizeModelFrame needs a previous Integrate");
     if (weight_threshold < 0)
         weight_threshold = std::fmin(m->frame_id * 1.0f, 3.0f);  // Model.cpp:45-47
+    // (the range map is the grid's own scratch -- as in the reference, where
+    // RayCast allocates it -- and the ray cast leaves it clean: no clearing
+    // launch per frame)
     const int down = 8;
-    const int64_t range_n = (int64_t)(height / down) * (width / down) * 2;
-    if (m->range_capacity < range_n) {
-        (void)hipFree(m->range_map);
-        m->range_map = nullptr;
-        O3DMI_HIP_CHECK(hipMalloc((void**)&m->range_map,
-                                  sizeof(float) * (size_t)(range_n > 0 ? range_n : 1)));
-        m->range_capacity = range_n;
-    }
     double extrinsic[16];
     InverseTransformation(m->T_frame_to_world, extrinsic);
     return o3dmi_vbg_ray_cast_dev(
             m->grid, m->frustum_coords,
             m->count_on_device ? m->frustum_capacity : m->frustum_count,
             m->count_on_device ? m->frustum_count_dev : nullptr, intrinsics,
-            extrinsic, width, height, m->range_map, depth_out_dev, nullptr,
-            color_out_dev,
+            extrinsic, width, height, /*range_map=*/nullptr, depth_out_dev,
+            nullptr, color_out_dev,
             nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
             depth_scale, depth_min, depth_max, weight_threshold,
             trunc_voxel_multiplier, down, stream);

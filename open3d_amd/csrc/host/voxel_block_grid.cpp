@@ -61,6 +61,12 @@ struct o3dmi_vbg {
     int* front_tickets = nullptr;               // device int[2][16]
     int64_t lists_capacity = 0;
     int* ring_counters = nullptr;        // device int[4]
+    // o3dmi_vbg_ray_cast_dev without a caller's range map: the grid's own,
+    // left clean ({lo, hi} in every cell) by the ray cast that consumed it
+    float* own_range = nullptr;
+    int64_t own_range_cells = 0;
+    bool own_range_clean = false;
+    float own_range_lo = 0, own_range_hi = 0;
     volatile int* stream_status = nullptr;  // host-mapped int[8]: [0..3]
                                          // published by the integrate roles,
                                          // [4..7] by the groups' last touch
@@ -501,6 +507,7 @@ int o3dmi_vbg_destroy(o3dmi_vbg_t* g) {
     }
     (void)hipFree(g->front_tickets);
     (void)hipFree(g->ring_counters);
+    (void)hipFree(g->own_range);
     if (g->stream_status) (void)hipHostFree((void*)g->stream_status);
     for (hipEvent_t e : g->prof_events) (void)hipEventDestroy(e);
     (void)hipFree(g->prof_counts);
@@ -1945,6 +1952,15 @@ static int StreamIntegrateSliced(o3dmi_vbg* g, const StreamCommon& c0,
     return st;
 }
 
+extern "C" int o3dmi_internal_estimate_range(
+        const int32_t* block_keys_dev, int key_stride, int64_t max_blocks,
+        const int32_t* n_blocks_dev, float* range_minmax_map_dev,
+        int map_is_clean, const double* intrinsic, const double* extrinsic,
+        int h, int w, int down_factor, int64_t block_resolution,
+        float voxel_size, float depth_min, float depth_max,
+        o3dmi_stream_t stream);
+extern "C" int o3dmi_internal_raycast_reset_range(void);
+
 static StreamCommon MakeCommon(int depth_rows, int depth_cols, int color_rows,
                                int color_cols, const double* depth_intrinsic,
                                const double* color_intrinsic, float depth_scale,
@@ -2269,8 +2285,7 @@ int o3dmi_vbg_ray_cast_dev(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
                            float weight_threshold,
                            float trunc_voxel_multiplier,
                            int range_map_down_factor, o3dmi_stream_t stream) {
-    O3DMI_REQUIRE(g && range_map_dev && intrinsic && extrinsic,
-                  "null argument");
+    O3DMI_REQUIRE(g && intrinsic && extrinsic, "null argument");
     int ti = g->AttrIndex("tsdf"), wi = g->AttrIndex("weight"),
         ci = g->AttrIndex("color");
     if (ti < 0 || wi < 0) {
@@ -2282,15 +2297,76 @@ int o3dmi_vbg_ray_cast_dev(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
     int grid_dtype;
     int st = GridDtype(g, &grid_dtype);
     if (st) return st;
-    st = o3dmi_vbg_estimate_range_dev(
-            block_coords_dev, max_m, m_dev, range_map_dev, intrinsic, extrinsic,
-            height, width, range_map_down_factor, g->block_resolution,
-            g->voxel_size, depth_min, depth_max, stream);
-    if (st) return st;
+    O3DMI_REQUIRE(range_map_down_factor > 0 && height >= range_map_down_factor &&
+                          width >= range_map_down_factor,
+                  "bad image size / down factor");
+    // block_coords_dev == NULL: the blocks the last frame-stream integration
+    // touched, read straight from the grid's own list (no export launch, no
+    // caller-side copy) -- what o3dmi_vbg_last_frame_block_coordinates would
+    // hand over.
+    int key_stride = 3;
+    if (!block_coords_dev) {
+        O3DMI_REQUIRE(g->last_path == 1 && g->lists[0] != nullptr,
+                      "ray cast without block coordinates: no frame-stream "
+                      "integration to take them from "
+                      "(o3dmi_vbg_integrate_frame first, or pass the "
+                      "coordinates)");
+        block_coords_dev = (const int32_t*)g->lists[g->last_seq & 1] + 1;
+        m_dev = g->ring_counters + (g->last_seq & 3);
+        max_m = g->lists_capacity;
+        key_stride = 4;
+    }
+    // range_map_dev == NULL: the range map is the grid's own scratch (as in
+    // the reference, where RayCast allocates it), and the ray cast that
+    // consumes it leaves it clean for the next call: no clearing launch per
+    // frame.
+    int map_is_clean = 0;
+    if (!range_map_dev) {
+        const int64_t cells = (int64_t)(height / range_map_down_factor) *
+                              (width / range_map_down_factor);
+        if (g->own_range_cells != cells) {
+            if (g->own_range) {
+                O3DMI_HIP_CHECK(hipDeviceSynchronize());
+                (void)hipFree(g->own_range);
+                g->own_range = nullptr;
+            }
+            // (+ one cell: the clean state's {lo, hi} for the resetting cast)
+            O3DMI_HIP_CHECK(hipMalloc((void**)&g->own_range,
+                                      sizeof(float) * 2 * (size_t)(cells + 1)));
+            g->own_range_cells = cells;
+            g->own_range_clean = false;
+        }
+        range_map_dev = g->own_range;
+        map_is_clean = g->own_range_clean && g->own_range_lo == depth_max &&
+                       g->own_range_hi == depth_min;
+        // the cast below re-cleans what it reads (8-pixel cells only)
+        g->own_range_clean = range_map_down_factor == 8 && (height % 8) == 0 &&
+                             (width % 8) == 0;
+        g->own_range_lo = depth_max;
+        g->own_range_hi = depth_min;
+        if (g->own_range_clean) {
+            if (!map_is_clean) {
+                const float lohi[2] = {depth_max, depth_min};
+                O3DMI_HIP_CHECK(hipMemcpyAsync(
+                        g->own_range + 2 * cells, lohi, sizeof(lohi),
+                        hipMemcpyHostToDevice, (hipStream_t)stream));
+            }
+            (void)o3dmi_internal_raycast_reset_range();
+        }
+    }
+    st = o3dmi_internal_estimate_range(
+            block_coords_dev, key_stride, max_m, m_dev, range_map_dev,
+            map_is_clean, intrinsic, extrinsic, height, width,
+            range_map_down_factor, g->block_resolution, g->voxel_size,
+            depth_min, depth_max, stream);
+    if (st) {
+        g->own_range_clean = false;
+        return st;
+    }
     const void* cbuf = (ci >= 0 && out_color)
                                ? o3dmi_hash_value_buffer(g->block_hashmap, ci)
                                : nullptr;
-    return o3dmi_vbg_raycast(
+    st = o3dmi_vbg_raycast(
             g->block_hashmap,
             (const float*)o3dmi_hash_value_buffer(g->block_hashmap, ti),
             o3dmi_hash_value_buffer(g->block_hashmap, wi), cbuf, grid_dtype,
@@ -2300,6 +2376,8 @@ int o3dmi_vbg_ray_cast_dev(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
             (int)g->block_resolution, g->voxel_size, depth_scale, depth_min,
             depth_max, weight_threshold, trunc_voxel_multiplier,
             range_map_down_factor, stream);
+    if (st) g->own_range_clean = false;
+    return st;
 }
 
 int o3dmi_vbg_ray_cast_sharded(

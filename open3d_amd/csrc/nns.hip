@@ -114,6 +114,127 @@ __global__ void ScatterKernel(const T* __restrict__ pts,
     }
 }
 
+// ---- several indices in the same launches (round 6) -----------------------------
+// The ICP driver builds the indices of its later scales while the first scale
+// iterates. One build is a clearing fill and three small launches (plus four
+// pool allocations): ~20 us of HOST time, issued behind an 11 us search launch
+// whose sums the host should be waiting for -- two builds cost a tracked frame
+// two late hops. Here up to kIndexJobs indices share every launch
+// (blockIdx.y = index): clear, count, assign, scatter -- four launches for all
+// of them, the fill one of ours instead of a runtime call per index.
+constexpr int kIndexJobs = 4;
+template <typename T>
+struct IndexJob {
+    const T* pts;
+    const T* normals;
+    int64_t n;
+    double inv_cell;
+    unsigned mask;
+    int64_t nb;
+    uint2* ranges;
+    Rec4<T>* sorted;
+    Rec4<T>* sorted_normals;
+    int* tickets;
+};
+template <typename T>
+__device__ __forceinline__ const IndexJob<T>& PickJob(const IndexJob<T>& a,
+                                                      const IndexJob<T>& b,
+                                                      const IndexJob<T>& c,
+                                                      const IndexJob<T>& d) {
+    return blockIdx.y == 0 ? a : (blockIdx.y == 1 ? b : (blockIdx.y == 2 ? c : d));
+}
+
+template <typename T>
+__global__ void ClearManyKernel(IndexJob<T> a, IndexJob<T> b, IndexJob<T> c,
+                                IndexJob<T> d) {
+    const IndexJob<T>& job = PickJob(a, b, c, d);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+         i <= job.nb; i += (int64_t)gridDim.x * blockDim.x)
+        job.ranges[i] = make_uint2(0u, 0u);
+}
+
+template <typename T>
+__global__ void CountManyKernel(IndexJob<T> a, IndexJob<T> b, IndexJob<T> c,
+                                IndexJob<T> d) {
+    const IndexJob<T>& job = PickJob(a, b, c, d);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < job.n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        long long cx, cy, cz;
+        CellOf(job.pts + 3 * i, job.inv_cell, cx, cy, cz);
+        atomicAdd(&job.ranges[HashCell(cx, cy, cz) & job.mask].y, 1u);
+    }
+}
+
+// AssignRangesKernel's body for one index
+__device__ __forceinline__ void AssignRangesBody(uint2* __restrict__ ranges,
+                                                 int64_t n_buckets,
+                                                 int* __restrict__ tickets) {
+    __shared__ unsigned wave_total_m[kAssignBlock / 64];
+    __shared__ unsigned block_base_m;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (tickets && blockIdx.x == 0 && threadIdx.x < 16) tickets[threadIdx.x] = 0;
+    for (int64_t b0 = (int64_t)blockIdx.x * kAssignBlock; b0 < n_buckets;
+         b0 += (int64_t)gridDim.x * kAssignBlock) {
+        const int64_t b = b0 + threadIdx.x;
+        const unsigned c = ranges[b].y;
+        unsigned incl = c;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const unsigned o = __shfl_up(incl, m);
+            if (lane >= m) incl += o;
+        }
+        if (lane == 63) wave_total_m[wave] = incl;
+        __syncthreads();
+        unsigned before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kAssignBlock / 64; ++w) {
+            const unsigned t = wave_total_m[w];
+            before += w < wave ? t : 0u;
+            total += t;
+        }
+        if (threadIdx.x == 0)
+            block_base_m = total ? atomicAdd(&ranges[n_buckets].x, total) : 0u;
+        __syncthreads();
+        ranges[b].x = block_base_m + before + incl - c;
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kAssignBlock)
+AssignManyKernel(IndexJob<T> a, IndexJob<T> b, IndexJob<T> c, IndexJob<T> d) {
+    const IndexJob<T>& job = PickJob(a, b, c, d);
+    AssignRangesBody(job.ranges, job.nb, job.tickets);
+}
+
+template <typename T>
+__global__ void ScatterManyKernel(IndexJob<T> a, IndexJob<T> b, IndexJob<T> c,
+                                  IndexJob<T> d) {
+    const IndexJob<T>& job = PickJob(a, b, c, d);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < job.n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        Rec4<T> r;
+        r.x = job.pts[3 * i + 0];
+        r.y = job.pts[3 * i + 1];
+        r.z = job.pts[3 * i + 2];
+        r.w = i;
+        const T p[3] = {r.x, r.y, r.z};
+        long long cx, cy, cz;
+        CellOf(p, job.inv_cell, cx, cy, cz);
+        const unsigned bk = HashCell(cx, cy, cz) & job.mask;
+        const unsigned pos = atomicAdd(&job.ranges[bk].x, 1u);
+        job.sorted[pos] = r;
+        if (job.normals) {
+            Rec4<T> m;
+            m.x = job.normals[3 * i + 0];
+            m.y = job.normals[3 * i + 1];
+            m.z = job.normals[3 * i + 2];
+            m.w = 0;
+            job.sorted_normals[pos] = m;
+        }
+    }
+}
+
 // K1 - K3 in ONE launch for a small cloud (the coarsest level of an ICP
 // pyramid: 2 - 3 k points): a single workgroup counts into LDS, scans the
 // buckets there, writes every range (no clearing launch before it) and
@@ -1049,6 +1170,69 @@ int BuildIndex(o3dmi_nns* nns, const T* pts, const T* normals, hipStream_t s) {
     return O3DMI_OK;
 }
 
+// The large-cloud build (clear, count, assign, scatter) of up to kIndexJobs
+// indices in four launches. Indices of <= 4096 points take their own
+// one-launch build.
+template <typename T>
+int BuildIndexMany(o3dmi_nns** nns, const void* const* pts,
+                   const void* const* normals, int count, hipStream_t s) {
+    IndexJob<T> jobs[kIndexJobs] = {};
+    int n_jobs = 0;
+    int64_t most_n = 0, most_nb = 0;
+    for (int q = 0; q < count; ++q) {
+        o3dmi_nns* x = nns[q];
+        if (x->n <= kSmallIndexPoints) {
+            int st = BuildIndex<T>(x, (const T*)pts[q], (const T*)normals[q], s);
+            if (st) return st;
+            continue;
+        }
+        const int64_t n = x->n;
+        int64_t nb = 1024;
+        while (nb < 2 * n && nb < (1ll << 27)) nb <<= 1;
+        x->n_buckets = nb;
+        const size_t recs = sizeof(Rec4<T>) * (size_t)n;
+        int st;
+        if ((st = PoolAlloc((void**)&x->ranges, sizeof(uint2) * (size_t)(nb + 1))))
+            return st;
+        if ((st = PoolAlloc(&x->sorted_pts, recs))) return st;
+        if (normals[q] && (st = PoolAlloc(&x->sorted_normals, recs))) return st;
+        if ((st = PoolAlloc((void**)&x->partials,
+                            sizeof(double) * kCUs * 4 * kNumSums)))
+            return st;
+        x->tickets = (int*)(x->partials + (size_t)(kCUs * 4 - 1) * kNumSums);
+        IndexJob<T>& j = jobs[n_jobs++];
+        j.pts = (const T*)pts[q];
+        j.normals = (const T*)normals[q];
+        j.n = n;
+        j.inv_cell = x->inv_cell;
+        j.mask = (unsigned)(nb - 1);
+        j.nb = nb;
+        j.ranges = x->ranges;
+        j.sorted = (Rec4<T>*)x->sorted_pts;
+        j.sorted_normals = (Rec4<T>*)x->sorted_normals;
+        j.tickets = x->tickets;
+        most_n = n > most_n ? n : most_n;
+        most_nb = nb > most_nb ? nb : most_nb;
+    }
+    if (n_jobs == 0) return O3DMI_OK;
+    // (unused jobs: n = 0, nb = -1: their workgroups find nothing to do)
+    for (int q = n_jobs; q < kIndexJobs; ++q) jobs[q].nb = -1;
+    const unsigned gy = (unsigned)n_jobs;
+    hipLaunchKernelGGL(ClearManyKernel<T>,
+                       dim3(GridFor(most_nb + 1, kBlock), gy), dim3(kBlock), 0,
+                       s, jobs[0], jobs[1], jobs[2], jobs[3]);
+    hipLaunchKernelGGL(CountManyKernel<T>, dim3(GridFor(most_n, kBlock), gy),
+                       dim3(kBlock), 0, s, jobs[0], jobs[1], jobs[2], jobs[3]);
+    hipLaunchKernelGGL(AssignManyKernel<T>,
+                       dim3(GridFor(most_nb, kAssignBlock), gy),
+                       dim3(kAssignBlock), 0, s, jobs[0], jobs[1], jobs[2],
+                       jobs[3]);
+    hipLaunchKernelGGL(ScatterManyKernel<T>, dim3(GridFor(most_n, kBlock), gy),
+                       dim3(kBlock), 0, s, jobs[0], jobs[1], jobs[2], jobs[3]);
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
 template <typename T>
 int EnsureSortedNormals(o3dmi_nns* nns, const T* normals, hipStream_t s) {
     if (!nns->sorted_normals)
@@ -1122,6 +1306,50 @@ int o3dmi_internal_nns_create_with_normals(const void* points_dev,
         return st;
     }
     *out = nns;
+    return O3DMI_OK;
+}
+
+// Internal (ICP driver): `count` (<= 4) indices with their normals, built in
+// the SAME launches (BuildIndexMany); all of one dtype. On an error the
+// indices created so far are destroyed and out[] is left NULL.
+int o3dmi_internal_nns_create_many(int count, const void* const* points_dev,
+                                   const void* const* normals_dev,
+                                   const int64_t* n, int dtype,
+                                   const double* radius, o3dmi_stream_t stream,
+                                   o3dmi_nns_t** out) {
+    O3DMI_REQUIRE(out && points_dev && normals_dev && n && radius &&
+                          count >= 1 && count <= kIndexJobs,
+                  "bad argument");
+    O3DMI_REQUIRE(dtype == O3DMI_F32 || dtype == O3DMI_F64,
+                  "points must be Float32 or Float64");
+    o3dmi_nns* made[kIndexJobs] = {};
+    for (int q = 0; q < count; ++q) {
+        out[q] = nullptr;
+        if (!(radius[q] > 0) || n[q] < 0 || n[q] >= (1ll << 27) ||
+            (n[q] > 0 && !points_dev[q])) {
+            for (int k = 0; k < q; ++k) o3dmi_nns_destroy(made[k]);
+            SetLastError("nns_create_many: bad size / radius / points");
+            return O3DMI_ERR_INVALID_ARG;
+        }
+        auto* x = new o3dmi_nns();
+        x->dtype = dtype;
+        x->n = n[q];
+        x->radius = radius[q];
+        x->inv_cell = 1.0 / (radius[q] * 1.001);
+        made[q] = x;
+    }
+    const int st = dtype == O3DMI_F64
+                           ? BuildIndexMany<double>(made, points_dev,
+                                                    normals_dev, count,
+                                                    (hipStream_t)stream)
+                           : BuildIndexMany<float>(made, points_dev,
+                                                   normals_dev, count,
+                                                   (hipStream_t)stream);
+    if (st != O3DMI_OK) {
+        for (int q = 0; q < count; ++q) o3dmi_nns_destroy(made[q]);
+        return st;
+    }
+    for (int q = 0; q < count; ++q) out[q] = made[q];
     return O3DMI_OK;
 }
 

@@ -54,7 +54,7 @@ __global__ void RangeFillKernel(float* __restrict__ range, int64_t n,
 
 // One wave per block key (4 waves per workgroup).
 __global__ void EstimateRangeKernel(const int* __restrict__ block_keys,
-                                    int64_t n_blocks,
+                                    int key_stride, int64_t n_blocks,
                                     const int* __restrict__ n_blocks_dev,
                                     float* __restrict__ range,
                                     Camera cam, int h_down, int w_down,
@@ -72,7 +72,9 @@ __global__ void EstimateRangeKernel(const int* __restrict__ block_keys,
         if (live < n_blocks) n_blocks = live;
     }
     for (int64_t b = wave_id; b < n_blocks; b += n_waves) {
-        const int* key = block_keys + 3 * b;
+        // ({n,3} keys, or the x, y, z of a frame stream's {slot, x, y, z}
+        // block list: stride 4)
+        const int* key = block_keys + (int64_t)key_stride * b;
         int u_min = w_down - 1, v_min = h_down - 1, u_max = 0, v_max = 0;
         float z_min = depth_max, z_max = depth_min;
         // VoxelBlockGridImpl.h:386-412 (all lanes compute the same rectangle)
@@ -126,7 +128,16 @@ struct RayCastParams {
     int* steps;  // diagnostics (O3DMI_RAYCAST_STEPS=1): march steps per pixel
     long long* clocks;  // ... and per workgroup: start, march done, end (100 MHz)
     int xcd_bands;  // tiles dealt to the XCDs in image bands (0: round-robin)
-    int coop;       // idle lanes sample ahead for crawling rays
+    int coop;       // bit 0: idle lanes sample ahead for crawling rays
+                    // bit 1: a grid-owned range map is left CLEAN by the
+                    // launch that consumes it -- with an 8-pixel down factor a
+                    // wave's 8 x 8 pixels are exactly one cell, read by that
+                    // wave alone: its lane 0 writes the cell back to the
+                    // {depth_max, depth_min} EstimateRange starts from (kept
+                    // in the two floats behind the map's last cell), so the
+                    // next frame needs no clearing launch. (A flag bit and a
+                    // load, not three more scalar arguments: the slim 16^3
+                    // form sits at its register cap.)
     int band_ty0, band_tys;  // the launch renders tile rows [ty0, ty0 + tys)
                              // only (o3dmi_vbg_raycast_rows: a rank's band of
                              // a pixel-sharded ray cast); tys = 0: the image
@@ -210,7 +221,7 @@ __global__ void __launch_bounds__(256, RES ? (FULL ? 4 : 5) : 0)
 RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
               const weight_t* __restrict__ weight_base,
               const color_t* __restrict__ color_base,
-              const float* __restrict__ range_map) {
+              const float* range_map) {
     __shared__ unsigned long long lds_blocks[kLdsBlocks];
     // cooperative march (below): ray state of up to 32 rays per wave, and the
     // samples their helper lanes fetch
@@ -320,6 +331,17 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
 
         float t = range[0];
         const float t_max = range[1];
+        if (p.coop & 2) {
+            // (the two loads above are this cell's only readers)
+            asm volatile("" ::: "memory");
+            if (lane == 0 && inside) {
+                const float* clean =
+                        range_map + 2 * (int64_t)(p.h / 8) * p.w_down;
+                float* cell = const_cast<float*>(range);
+                cell[0] = clean[0];
+                cell[1] = clean[1];
+            }
+        }
         {
             float x_c, y_c, z_c, x_g, y_g, z_g, x_o, y_o, z_o;
             float t_prev = t;
@@ -419,7 +441,7 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
             };
             // while more than half of the wave marches: the plain loop
             while (mine) {
-                if (p.coop &&
+                if ((p.coop & 1) &&
                     __popcll(__builtin_amdgcn_ballot_w64(true)) <= 32)
                     break;
                 if (DIAG) ++it_plain;
@@ -435,7 +457,7 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
                 const int shift =
                         n_act <= 1 ? 6 : __builtin_clz((unsigned)(n_act - 1)) - 26;
                 const bool coop =
-                        p.coop && n_act <= 32 &&
+                        (p.coop & 1) && n_act <= 32 &&
                         __builtin_amdgcn_ballot_w64(mine && crawling) != 0;
                 if (DIAG) {
                     it_plain += coop ? 0 : 1;
@@ -772,6 +794,29 @@ int o3dmi_vbg_estimate_range(const int32_t* block_keys_dev, int64_t n_blocks,
             depth_min, depth_max, stream);
 }
 
+// Internal (o3dmi_vbg_ray_cast_dev with a grid-owned range map / block list):
+// the keys are every `key_stride`-th int triple from block_keys_dev; a map the
+// last ray cast left clean skips the clearing launch.
+int o3dmi_internal_estimate_range(const int32_t* block_keys_dev, int key_stride,
+                                  int64_t max_blocks,
+                                  const int32_t* n_blocks_dev,
+                                  float* range_minmax_map_dev, int map_is_clean,
+                                  const double* intrinsic,
+                                  const double* extrinsic, int h, int w,
+                                  int down_factor, int64_t block_resolution,
+                                  float voxel_size, float depth_min,
+                                  float depth_max, o3dmi_stream_t stream);
+
+// The NEXT ray-cast launch of this host thread writes every range cell it
+// reads back to the {lo, hi} stored in the two floats behind the map's last
+// cell (consumed by that launch; whole-image launches with a down factor of 8
+// only).
+static thread_local int g_reset_range = 0;
+int o3dmi_internal_raycast_reset_range(void) {
+    g_reset_range = 1;
+    return O3DMI_OK;
+}
+
 int o3dmi_vbg_estimate_range_dev(const int32_t* block_keys_dev,
                                  int64_t max_blocks,
                                  const int32_t* n_blocks_dev,
@@ -781,6 +826,21 @@ int o3dmi_vbg_estimate_range_dev(const int32_t* block_keys_dev,
                                  int down_factor, int64_t block_resolution,
                                  float voxel_size, float depth_min,
                                  float depth_max, o3dmi_stream_t stream) {
+    return o3dmi_internal_estimate_range(
+            block_keys_dev, 3, max_blocks, n_blocks_dev, range_minmax_map_dev,
+            0, intrinsic, extrinsic, h, w, down_factor, block_resolution,
+            voxel_size, depth_min, depth_max, stream);
+}
+
+int o3dmi_internal_estimate_range(const int32_t* block_keys_dev, int key_stride,
+                                  int64_t max_blocks,
+                                  const int32_t* n_blocks_dev,
+                                  float* range_minmax_map_dev, int map_is_clean,
+                                  const double* intrinsic,
+                                  const double* extrinsic, int h, int w,
+                                  int down_factor, int64_t block_resolution,
+                                  float voxel_size, float depth_min,
+                                  float depth_max, o3dmi_stream_t stream) {
     O3DMI_REQUIRE(range_minmax_map_dev && intrinsic && extrinsic,
                   "null argument");
     O3DMI_REQUIRE(down_factor > 0 && h >= down_factor && w >= down_factor,
@@ -790,9 +850,10 @@ int o3dmi_vbg_estimate_range_dev(const int32_t* block_keys_dev,
     hipStream_t s = (hipStream_t)stream;
     int h_down = h / down_factor, w_down = w / down_factor;
     int64_t n_px = (int64_t)h_down * w_down;
-    hipLaunchKernelGGL(RangeFillKernel, dim3(GridFor(n_px, kBlock)),
-                       dim3(kBlock), 0, s, range_minmax_map_dev, n_px,
-                       depth_min, depth_max);
+    if (!map_is_clean)
+        hipLaunchKernelGGL(RangeFillKernel, dim3(GridFor(n_px, kBlock)),
+                           dim3(kBlock), 0, s, range_minmax_map_dev, n_px,
+                           depth_min, depth_max);
     if (max_blocks > 0) {
         Camera cam = Camera::Make(intrinsic, extrinsic, 1.0f);
         // With a device-resident count the list is usually far shorter than
@@ -800,7 +861,7 @@ int o3dmi_vbg_estimate_range_dev(const int32_t* block_keys_dev,
         const int grid = n_blocks_dev ? GridFor(max_blocks, 4, kCUs * 2)
                                       : GridFor(max_blocks, 4);
         hipLaunchKernelGGL(EstimateRangeKernel, dim3(grid), dim3(kBlock), 0, s,
-                           block_keys_dev, max_blocks, n_blocks_dev,
+                           block_keys_dev, key_stride, max_blocks, n_blocks_dev,
                            range_minmax_map_dev, cam, h_down, w_down,
                            down_factor, block_resolution, voxel_size, depth_min,
                            depth_max);
@@ -907,6 +968,9 @@ int o3dmi_vbg_raycast_rows(
                             (whole ? (h + 7) / 8 : p.band_tys);
     p.xcd_bands = n_tiles <= kCUs * 5 ? 1 : 0;
     p.coop = 1;
+    // (o3dmi_internal_raycast_reset_range: consumed by this launch)
+    if (g_reset_range && whole && range_map_down_factor == 8) p.coop |= 2;
+    g_reset_range = 0;
     // a multiple of 8 workgroups: every XCD gets the same number
     dim3 grid((unsigned)((GridFor(n_tiles, 1, kCUs * 16) + 7) & ~7)),
             block(kBlock);

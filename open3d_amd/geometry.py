@@ -531,6 +531,36 @@ class VoxelBlockGrid:
             "VoxelBlockGrid.last_frame_block_coordinates")
         return out, cnt
 
+    def ray_cast_last_frame(self, intrinsic, extrinsic, width, height,
+                            render_attributes=("depth", "normal"),
+                            depth_scale=1000.0, depth_min=0.1, depth_max=3.0,
+                            weight_threshold=3.0, trunc_voxel_multiplier=8.0,
+                            range_map_down_factor=8):
+        """Extension: ray cast over the blocks the most recent integrate_frame
+        touched, read from the grid's own list, with the grid's own range map
+        (o3dmi_vbg_ray_cast_dev without block coordinates and without a range
+        map: no export launch, and the ray cast leaves the map clean for the
+        next call). Same maps as ray_cast(last_frame_block_coordinates(...))."""
+        K = host_mat(intrinsic, (3, 3), "intrinsic")
+        T = host_mat(extrinsic, (4, 4), "extrinsic")
+        out = {}
+        for a in render_attributes:
+            if a not in ("depth", "vertex", "color", "normal"):
+                raise ValueError("ray_cast_last_frame renders depth / vertex "
+                                 "/ color / normal, not %s" % a)
+            out[a] = torch.empty((height, width, self._CHANNELS[a]),
+                                 dtype=torch.float32, device="cuda")
+        g = lambda a: _lib.ptr(out.get(a))
+        _lib.check(_lib.lib().o3dmi_vbg_ray_cast_dev(
+            self._g, None, 0, None, _lib.f64p(K), _lib.f64p(T), int(width),
+            int(height), None, g("depth"), g("vertex"), g("color"),
+            g("normal"), None, None, None, None, None, None,
+            C.c_float(depth_scale), C.c_float(depth_min), C.c_float(depth_max),
+            C.c_float(weight_threshold), C.c_float(trunc_voxel_multiplier),
+            int(range_map_down_factor), stream()),
+            "VoxelBlockGrid.ray_cast_last_frame")
+        return out
+
     def ray_cast(self, block_coords, intrinsic, extrinsic, width, height,
                  render_attributes=("depth", "color"), depth_scale=1000.0,
                  depth_min=0.1, depth_max=3.0, weight_threshold=3.0,

@@ -1369,6 +1369,37 @@ def test_last_frame_block_coordinates_equal_a_second_block_touch():
         for name in ("depth", "normal", "color"):
             assert torch.equal(a[name], b[name]), name
         assert float((a["depth"] > 0).float().mean()) > 0.5
+        # Round 6: no block coordinates and no range map at all -- the grid's
+        # own list and its own range map, which the ray cast that consumes it
+        # leaves clean (second and third frame: no clearing launch); a call
+        # with other depth limits in between must refill it, and a call with
+        # a caller's map must not disturb it
+        for lim in ((0.1, sc.DEPTH_MAX), (0.1, sc.DEPTH_MAX), (0.3, 2.0),
+                    (0.1, sc.DEPTH_MAX)):
+            own = g.ray_cast_last_frame(K, T[0], w, h, ("depth", "normal"),
+                                        sc.DEPTH_SCALE, lim[0], lim[1], 1.0,
+                                        sc.TRUNC_MULT)
+            ref = g.ray_cast(want, K, T[0], w, h, ("depth", "normal"),
+                             sc.DEPTH_SCALE, lim[0], lim[1], 1.0,
+                             sc.TRUNC_MULT)
+            for name in ("depth", "normal"):
+                assert torch.equal(own[name], ref[name]), (name, lim)
+    # a size whose range map cannot be self-cleaning (down factor 4), and an
+    # image size change: both render what the explicit call renders
+    own = g.ray_cast_last_frame(K, T[0], w, h, ("depth",), sc.DEPTH_SCALE,
+                                0.1, sc.DEPTH_MAX, 1.0, sc.TRUNC_MULT,
+                                range_map_down_factor=4)
+    ref = g.ray_cast(want, K, T[0], w, h, ("depth",), sc.DEPTH_SCALE, 0.1,
+                     sc.DEPTH_MAX, 1.0, sc.TRUNC_MULT,
+                     range_map_down_factor=4)
+    assert torch.equal(own["depth"], ref["depth"])
+    own = g.ray_cast_last_frame(K, T[0], w, h, ("depth",), sc.DEPTH_SCALE,
+                                0.1, sc.DEPTH_MAX, 1.0, sc.TRUNC_MULT)
+    assert torch.equal(own["depth"], a["depth"])
+    # without a frame-stream integration there is no list to take
+    g2 = _mk_grid(geometry, False, block_count=1024)
+    with pytest.raises(_lib.O3DMIError):
+        g2.ray_cast_last_frame(K, T[0], w, h, ("depth",))
 
 
 def test_sort_indices_is_a_counting_sort():
