@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 #include <cstdio>
@@ -746,42 +747,39 @@ SearchAccumulateKernel(NnsView<T> nv, const Rec4<T>* __restrict__ sorted_n,
                     have = have || better;
                 }
             };
-            for (int cb = 0; cb < kOwn; cb += kBatch) {
-                // ranges of the owned cells (one round trip), then their
-                // records as ONE list: entry t of the list is record
-                // t - first[k] of the cell k it falls into, so a round trip
-                // fetches kFlight candidates whatever the bucket sizes are
-                unsigned s0[kBatch], first[kBatch + 1];
+            // One batch of cells: the ranges of the lane's cells (one round
+            // trip), then their records as ONE list: entry t of the list is
+            // record t - first[k] of the cell k it falls into, so a round trip
+            // fetches kFlight candidates whatever the bucket sizes are.
+            // bucket[k] / use[k]: the cells of the batch and which of them
+            // count (an unused cell's range is read and dropped).
+            auto scan_batch = [&](auto n_tag, const unsigned* bucket,
+                                  const bool* use) {
+                constexpr int kN = decltype(n_tag)::value;
+                unsigned s0[kN], first[kN + 1];
                 first[0] = 0;
 #pragma unroll
-                for (int k = 0; k < kBatch; ++k) {
-                    // cells past the 27th: look at cell 26 again, keep nothing
-                    const int c = c0 + (cb + k) * G;
-                    const int cc = c < 27 ? c : 26;
-                    const int dz = cc / 9 - 1, dy = (cc % 9) / 3 - 1,
-                              dx = cc % 3 - 1;
-                    const unsigned b =
-                            HashCell(cx + dx, cy + dy, cz + dz) & nv.mask;
+                for (int k = 0; k < kN; ++k) {
                     unsigned e;
-                    BucketRange(nv, b, s0[k], e);
-                    first[k + 1] = first[k] + (c < 27 ? e - s0[k] : 0u);
+                    BucketRange(nv, bucket[k], s0[k], e);
+                    first[k + 1] = first[k] + (use[k] ? e - s0[k] : 0u);
                 }
-                const unsigned total = first[kBatch];
+                const unsigned total = first[kN];
                 // entry t of the list is record t + off[k] of the array, k the
                 // cell it falls into
                 // (as a running sum of the offsets' differences: a chain of
                 // plain "pick off[k]" selects is turned into an indexed read
                 // of an LDS copy of the array, one LDS round trip in front of
                 // every record load)
-                unsigned step[kBatch];
+                unsigned step[kN];
                 step[0] = s0[0];  // first[0] == 0
 #pragma unroll
-                for (int k = 1; k < kBatch; ++k)
+                for (int k = 1; k < kN; ++k)
                     step[k] = (s0[k] - first[k]) - (s0[k - 1] - first[k - 1]);
                 auto position = [&](unsigned t) {
                     unsigned o = step[0];
 #pragma unroll
-                    for (int k = 1; k < kBatch; ++k)
+                    for (int k = 1; k < kN; ++k)
                         o += t >= first[k] ? step[k] : 0u;
                     return t + o;
                 };
@@ -809,6 +807,104 @@ SearchAccumulateKernel(NnsView<T> nv, const Rec4<T>* __restrict__ sorted_n,
                 } else {
                     if (have && (!had || idx != idx_before))
                         pos = (int)position(best_t);
+                }
+            };
+            if constexpr (G == 8) {
+                // NEAREST neighbour only (max_knn = 1): most of the 27 cells
+                // cannot hold it. Phase 1: the 2 x 2 x 2 cells on the query's
+                // side of its own cell -- one per lane -- where the nearest
+                // point of a sampled surface almost always lies. Phase 2: of
+                // the other 19 cells only those whose box comes closer to the
+                // query than the best so far (or than the radius, if nothing
+                // was found); skipped by the whole wave when no lane needs
+                // it. A skipped cell lies strictly farther than the winner:
+                // the winner by (d2, index) is the one the full scan finds,
+                // bit for bit. (Round 6: 85 -> ~37 candidate records and 27
+                // -> 8 ranges per query on the finest scale of a tracked
+                // frame, where the launch is bound by the per-CU vector
+                // memory path.)
+                const double ux = (double)q[0] * nv.inv_cell - (double)cx;
+                const double uy = (double)q[1] * nv.inv_cell - (double)cy;
+                const double uz = (double)q[2] * nv.inv_cell - (double)cz;
+                const int sx = ux >= 0.5 ? 1 : -1, sy = uy >= 0.5 ? 1 : -1,
+                          sz = uz >= 0.5 ? 1 : -1;
+                {
+                    const unsigned b1[1] = {
+                            HashCell(cx + ((c0 & 1) ? sx : 0),
+                                     cy + ((c0 & 2) ? sy : 0),
+                                     cz + ((c0 & 4) ? sz : 0)) &
+                            nv.mask};
+                    const bool u1[1] = {true};
+                    scan_batch(std::integral_constant<int, 1>(), b1, u1);
+                }
+                // the group's best so far (every lane of a group is here)
+                T bound = nv.radius_squared;
+                {
+                    int gp = pos, gi = idx;
+                    T gd = d2;
+#pragma unroll
+                    for (int m = G / 2; m > 0; m >>= 1) {
+                        const int opos = __shfl_xor(gp, m, G);
+                        const int oidx = __shfl_xor(gi, m, G);
+                        const T od2 = __shfl_xor(gd, m, G);
+                        const bool take =
+                                opos >= 0 && (gp < 0 || od2 < gd ||
+                                              (od2 == gd && oidx < gi));
+                        if (take) {
+                            gp = opos;
+                            gi = oidx;
+                            gd = od2;
+                        }
+                    }
+                    if (gp >= 0) bound = gd;
+                }
+                // distance (in cells) from the query to the cell beside its
+                // own, per axis and side; a hair under the true one, so that
+                // rounding can only make a cell count, never drop it
+                const double cell = 1.0 / nv.inv_cell;
+                const double bound_c =
+                        (double)bound * nv.inv_cell * nv.inv_cell;
+                (void)cell;
+                unsigned b2[kOwn];
+                bool u2[kOwn];
+                bool any = false;
+#pragma unroll
+                for (int k = 0; k < kOwn; ++k) {
+                    const int c = c0 + k * G;
+                    const int cc = c < 27 ? c : 26;
+                    const int dz = cc / 9 - 1, dy = (cc % 9) / 3 - 1,
+                              dx = cc % 3 - 1;
+                    const bool in_octant = (dx == 0 || dx == sx) &&
+                                           (dy == 0 || dy == sy) &&
+                                           (dz == 0 || dz == sz);
+                    const double ax = dx == 0 ? 0.0 : (dx > 0 ? 1.0 - ux : ux);
+                    const double ay = dy == 0 ? 0.0 : (dy > 0 ? 1.0 - uy : uy);
+                    const double az = dz == 0 ? 0.0 : (dz > 0 ? 1.0 - uz : uz);
+                    const double lb = (ax * ax + ay * ay + az * az) * 0.9999;
+                    u2[k] = c < 27 && !in_octant && lb <= bound_c;
+                    any = any || u2[k];
+                    b2[k] = HashCell(cx + dx, cy + dy, cz + dz) & nv.mask;
+                }
+                if (__builtin_amdgcn_ballot_w64(any) != 0ull)
+                    scan_batch(std::integral_constant<int, kOwn>(), b2, u2);
+            } else {
+                for (int cb = 0; cb < kOwn; cb += kBatch) {
+                    unsigned bucket[kBatch];
+                    bool use[kBatch];
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) {
+                        // cells past the 27th: look at cell 26 again, keep
+                        // nothing
+                        const int c = c0 + (cb + k) * G;
+                        const int cc = c < 27 ? c : 26;
+                        const int dz = cc / 9 - 1, dy = (cc % 9) / 3 - 1,
+                                  dx = cc % 3 - 1;
+                        bucket[k] = HashCell(cx + dx, cy + dy, cz + dz) &
+                                    nv.mask;
+                        use[k] = c < 27;
+                    }
+                    scan_batch(std::integral_constant<int, kBatch>(), bucket,
+                               use);
                 }
             }
         }
@@ -1272,6 +1368,9 @@ static int LaunchSearchAccumulate(
         O3DMI_REQUIRE(nns->sorted_normals != nullptr,
                       "Target pointcloud missing normals attribute.");
     }
+    // (Round 6: with the 8-lane form's pruned scan, 8 lanes at EVERY scale was
+    // tried -- 12.6 / 13.5 us per coarse launch against 11.6 / 13.8: no gain,
+    // the coarse scales are bound by the chain of trips, not by the scan.)
     // Lanes per query, from the launch timings of tools/bench_search.py on
     // the levels of a tracking frame and on the raw clouds (2 k ... 230 k
     // queries, profiles/r2w_search_*.json): G = 32 only while it leaves half
