@@ -518,7 +518,6 @@ constexpr int kTile = kSortBlock;          // 1024 points, one per lane
 constexpr int kMaxTiles = 1024;
 constexpr int64_t kTiledMaxPoints = (int64_t)kTile * kMaxTiles;  // 2^20
 constexpr int kMaxBuckets = 1024;
-constexpr int kBucketLds = 2048;           // entries of a bucket staged in LDS
 constexpr int kReduceBlock = 256;
 constexpr int kMaxBucketWidth = 2048;      // slots of a bucket
 constexpr unsigned kNoSlot = 0xFFFFFFFFu;  // a point outside the key range
@@ -743,54 +742,76 @@ VdsTilePartitionKernel(VdsJob<T> job_a, VdsJob<T> job_b) {
     dst[1] = e1;
 }
 
+// LDS of the reduce launch, carved out of one dynamic block sized by the host
+// (VdsReduceLdsBytes): the tile tables by the cloud's tile count, the member
+// counters by the bucket width, the staging area by kStage entries. 39 KB for
+// a 640 x 360 cloud (four workgroups per CU; round 6's first form held 77 KB
+// statically and ran the 1024 workgroups of a 720p level in two rounds).
+constexpr int kStage = 1024;  // entries of a bucket staged in LDS at a time
+struct VdsReduceLds {
+    int* seg_lo;         // [tiles_p2] bucket's start inside tile t
+    int* seg_start;      // [tiles_p2] entries in the tiles before t
+    int* first_base;     // [tiles_p2] first points in the tiles before t
+    int* members;        // [width] points per slot of the bucket
+    unsigned* e_slot;    // [kStage + 4] (+ a sentinel chunk)
+    unsigned* e_iw;      // [kStage] index | rank | first flag
+    float* e_pos;        // [kStage][3]
+    float* e_attr;       // [kStage][3]
+};
+inline size_t VdsReduceLdsBytes(int tiles_p2, int width) {
+    return sizeof(int) * (3 * (size_t)tiles_p2 + (size_t)width) +
+           sizeof(unsigned) * (2 * kStage + 4) + sizeof(float) * 6 * kStage;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kReduceBlock)
-VdsTileReduceKernel(VdsJob<T> job_a, VdsJob<T> job_b) {
-    __shared__ int seg_lo[kMaxTiles];         // bucket's start inside tile t
-    __shared__ int seg_start[kMaxTiles + 1];  // entries in the tiles before t
-    __shared__ int first_base[kMaxTiles];     // first points in tiles before t
+VdsTileReduceKernel(VdsJob<T> job_a, VdsJob<T> job_b, int tiles_p2,
+                    int members_n) {
+    extern __shared__ int lds_raw[];
     __shared__ int lds4[2][kReduceBlock / 64];
-    __shared__ unsigned e_slot[kBucketLds + 4];  // + a sentinel chunk
-    __shared__ float e_pos[kBucketLds][3];
-    __shared__ float e_attr[kBucketLds][3];
-    __shared__ int members[kMaxBucketWidth];  // points per slot of the bucket
+    __shared__ int wave_sel[kReduceBlock / 64];
     const VdsJob<T>& job = blockIdx.y ? job_b : job_a;
     const int bucket = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int buckets = 1 << job.bucket_bits;
     if (bucket >= buckets || job.n_host <= 0) return;
-    const int width = 1 << job.bshift;  // slots of a bucket (<= 2048)
-    // ---- the tiles' tables: kPerT consecutive tiles per lane ---------------
-    constexpr int kPerT = kMaxTiles / kReduceBlock;  // 4
+    const int width = 1 << job.bshift;  // slots of a bucket (<= members_n)
+    VdsReduceLds L;
+    L.seg_lo = lds_raw;
+    L.seg_start = L.seg_lo + tiles_p2;
+    L.first_base = L.seg_start + tiles_p2;
+    L.members = L.first_base + tiles_p2;
+    L.e_slot = (unsigned*)(L.members + members_n);
+    L.e_iw = L.e_slot + kStage + 4;
+    L.e_pos = (float*)(L.e_iw + kStage);
+    L.e_attr = L.e_pos + 3 * kStage;
+    // ---- the tiles' tables: `per` consecutive tiles per lane ----------------
+    const int per = tiles_p2 >= kReduceBlock ? tiles_p2 / kReduceBlock : 1;
     const int tiles_host = (job.n_host + kTile - 1) / kTile;
-    int lo[kPerT], len[kPerT], fc[kPerT];
-#pragma unroll
-    for (int u = 0; u < kPerT; ++u) {
-        const int t = tid * kPerT + u;
-        lo[u] = len[u] = fc[u] = 0;
-        if (t < tiles_host) {
-            const int* row = job.tile_off + (int64_t)t * (buckets + 1) + bucket;
-            lo[u] = row[0];
-            len[u] = row[1];
-            fc[u] = job.tile_firsts[t];
-        }
-    }
     const int n = LiveCount(job.n_dev, job.n_host);
     const int tiles = (n + kTile - 1) / kTile;
-    for (int q = tid; q < width; q += kReduceBlock) members[q] = 0;
     int my_len = 0, my_fc = 0;
-#pragma unroll
-    for (int u = 0; u < kPerT; ++u) {
-        const int t = tid * kPerT + u;
+    for (int u = 0; u < per; ++u) {
+        const int t = tid * per + u;
+        int lo = 0, len = 0, fc = 0;
         // rows of tiles past the live count hold an earlier level's numbers
-        len[u] = t < tiles ? len[u] - lo[u] : 0;
-        fc[u] = t < tiles ? fc[u] : 0;
-        my_len += len[u];
-        my_fc += fc[u];
+        if (t < tiles_host && t < tiles) {
+            const int* row = job.tile_off + (int64_t)t * (buckets + 1) + bucket;
+            lo = row[0];
+            len = row[1] - lo;
+            fc = job.tile_firsts[t];
+        }
+        if (t < tiles_p2) {
+            L.seg_lo[t] = lo;
+            L.seg_start[t] = len;    // (lengths; scanned below)
+            L.first_base[t] = fc;
+        }
+        my_len += len;
+        my_fc += fc;
     }
     int count, voxels;
     {
         // block exclusive scans of my_len and my_fc (kReduceBlock threads)
-        const int lane = tid & 63, wave = tid >> 6;
         int il = my_len, ic = my_fc;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -816,16 +837,16 @@ VdsTileReduceKernel(VdsJob<T> job_a, VdsJob<T> job_b) {
             count += lds4[0][k];
             voxels += lds4[1][k];
         }
-#pragma unroll
-        for (int u = 0; u < kPerT; ++u) {
-            const int t = tid * kPerT + u;
-            seg_lo[t] = lo[u];
-            seg_start[t] = rl;
-            first_base[t] = rc;
-            rl += len[u];
-            rc += fc[u];
+        for (int u = 0; u < per; ++u) {
+            const int t = tid * per + u;
+            if (t < tiles_p2) {
+                const int len = L.seg_start[t], fc = L.first_base[t];
+                L.seg_start[t] = rl;
+                L.first_base[t] = rc;
+                rl += len;
+                rc += fc;
+            }
         }
-        if (tid == 0) seg_start[kMaxTiles] = count;
         if (bucket == 0 && tid == 0) *job.m_dev = voxels;
     }
     __syncthreads();
@@ -833,18 +854,15 @@ VdsTileReduceKernel(VdsJob<T> job_a, VdsJob<T> job_b) {
     // before j (empty segments share their successor's start)
     auto locate = [&](int j) -> int64_t {
         int t = 0;
-#pragma unroll
-        for (int step = kMaxTiles / 2; step > 0; step >>= 1)
-            if (seg_start[t + step] <= j) t += step;
-        return (int64_t)t * kTile + seg_lo[t] + (j - seg_start[t]);
+        for (int step = tiles_p2 >> 1; step > 0; step >>= 1)
+            if (L.seg_start[t + step] <= j) t += step;
+        return (int64_t)t * kTile + L.seg_lo[t] + (j - L.seg_start[t]);
     };
-    // ---- one lane per entry; the lane of a voxel's first point adds it up ---
-    auto finish = [&](unsigned s, unsigned iw, float cnt, const float* sp,
+    auto finish = [&](unsigned iw, float cnt, const float* sp,
                       const float* sn) {
         const int i = (int)(iw & ((1u << kEntryRankShift) - 1u));
-        const int row = first_base[i / kTile] +
+        const int row = L.first_base[i / kTile] +
                         (int)((iw >> kEntryRankShift) & (unsigned)(kTile - 1));
-        (void)s;
         T o[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -864,88 +882,147 @@ VdsTileReduceKernel(VdsJob<T> job_a, VdsJob<T> job_b) {
             job.tb.first[s] = 0x7FFFFFFF;
         }
     };
-    if (count <= kBucketLds) {
-        constexpr int kPer = kBucketLds / kReduceBlock;  // 8 entries per lane
+    // The staged entries 0..m: one lane per entry; the lane of a voxel's first
+    // point adds the voxel up. Its members follow it in point order (the
+    // stable split), their number is known, so the walk ends at the last one
+    // -- a voxel's points are neighbours in the cloud and therefore in the
+    // list -- and four entries are compared per LDS round trip.
+    auto process_staged = [&](int m) {
+        if (tid < 4) L.e_slot[m + tid] = 0xFFFFFFFEu;  // matches no slot
+        __syncthreads();
+        for (int q = tid; q < m; q += kReduceBlock) {
+            const unsigned s = L.e_slot[q];
+            const unsigned iw = L.e_iw[q];
+            clean(s);
+            if (!(iw & kEntryFirst)) continue;
+            float cnt = 0.f, sp[3] = {0.f, 0.f, 0.f}, sn[3] = {0.f, 0.f, 0.f};
+            auto add = [&](int e) {
+                cnt += 1.0f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    sp[c] += L.e_pos[3 * e + c];
+                    sn[c] += L.e_attr[3 * e + c];
+                }
+            };
+            add(q);
+            int left = s != kNoSlot ? L.members[s & (unsigned)(width - 1)] - 1
+                                    : 0;
+            for (int e = q + 1; left > 0 && e < m; e += 4) {
+                const unsigned s0 = L.e_slot[e], s1 = L.e_slot[e + 1],
+                               s2 = L.e_slot[e + 2], s3 = L.e_slot[e + 3];
+                if (s0 == s) { add(e); --left; }
+                if (s1 == s) { add(e + 1); --left; }
+                if (s2 == s) { add(e + 2); --left; }
+                if (s3 == s) { add(e + 3); --left; }
+            }
+            finish(iw, cnt, sp, sn);
+        }
+    };
+    auto stage_entry = [&](int at, const uint4& e0, const uint4& e1) {
+        L.e_slot[at] = e0.x;
+        L.e_iw[at] = e0.y;
+        if (e0.x != kNoSlot)
+            atomicAdd(&L.members[e0.x & (unsigned)(width - 1)], 1);
+        L.e_pos[3 * at + 0] = __uint_as_float(e0.z);
+        L.e_pos[3 * at + 1] = __uint_as_float(e0.w);
+        L.e_pos[3 * at + 2] = __uint_as_float(e1.x);
+        L.e_attr[3 * at + 0] = __uint_as_float(e1.y);
+        L.e_attr[3 * at + 1] = __uint_as_float(e1.z);
+        L.e_attr[3 * at + 2] = __uint_as_float(e1.w);
+    };
+    for (int q = tid; q < width; q += kReduceBlock) L.members[q] = 0;
+    if (count <= kStage) {
+        // ---- the usual case: the whole bucket at once, every load in flight -
+        constexpr int kPer = kStage / kReduceBlock;  // 4 entries per lane
         uint4 e0[kPer], e1[kPer];
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
             const int j = tid + k * kReduceBlock;
-            e0[k] = make_uint4(0xFFFFFFFEu, 0u, 0u, 0u);
-            e1[k] = make_uint4(0u, 0u, 0u, 0u);
             if (j < count) {
                 const uint4* src = job.ent + 2 * locate(j);
                 e0[k] = src[0];
                 e1[k] = src[1];
             }
         }
+        __syncthreads();  // members[] is zero
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
             const int j = tid + k * kReduceBlock;
+            if (j < count) stage_entry(j, e0[k], e1[k]);
+        }
+        process_staged(count);
+        return;
+    }
+    // ---- a crowded bucket (a cloud whose points pile up in few voxels): in
+    // passes over 2^k ranges of its slots, each pass staging the entries of
+    // its range -- stably: in entry order -- and running the same walk. A
+    // range that still overflows the staging area (one voxel with more than
+    // kStage points) is walked out of global memory.
+    int passes = 2;
+    while (passes < width && (int64_t)passes * kStage < 2 * (int64_t)count)
+        passes <<= 1;
+    const int sub_shift = job.bshift - (31 - __clz(passes));  // log2(slots / pass)
+    auto range_of = [&](unsigned s) -> int {
+        return s == kNoSlot ? 0 : (int)((s & (unsigned)(width - 1)) >> sub_shift);
+    };
+    for (int p = 0; p < passes; ++p) {
+        __syncthreads();  // the previous pass is through with the staging area
+        for (int q = tid; q < width; q += kReduceBlock) L.members[q] = 0;
+        __syncthreads();
+        int base = 0;  // entries of this range before chunk j0 (uniform)
+        for (int j0 = 0; j0 < count; j0 += kReduceBlock) {
+            const int j = j0 + tid;
+            uint4 e0 = make_uint4(0u, 0u, 0u, 0u), e1 = e0;
+            bool sel = false;
             if (j < count) {
-                e_slot[j] = e0[k].x;
-                if (e0[k].x != kNoSlot)
-                    atomicAdd(&members[e0[k].x & (unsigned)(width - 1)], 1);
-                e_pos[j][0] = __uint_as_float(e0[k].z);
-                e_pos[j][1] = __uint_as_float(e0[k].w);
-                e_pos[j][2] = __uint_as_float(e1[k].x);
-                e_attr[j][0] = __uint_as_float(e1[k].y);
-                e_attr[j][1] = __uint_as_float(e1[k].z);
-                e_attr[j][2] = __uint_as_float(e1[k].w);
+                const uint4* src = job.ent + 2 * locate(j);
+                e0 = src[0];
+                sel = range_of(e0.x) == p;
+                if (sel) e1 = src[1];
             }
-        }
-        if (tid < 4) e_slot[count + tid] = 0xFFFFFFFEu;  // matches no slot
-        __syncthreads();
+            const unsigned long long bal = __ballot(sel);
+            if (lane == 0) wave_sel[wave] = __popcll(bal);
+            __syncthreads();
+            int before = 0, total = 0;
 #pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            const int j = tid + k * kReduceBlock;
-            if (j >= count) continue;
-            const unsigned s = e0[k].x;
-            clean(s);
-            if (!(e0[k].y & kEntryFirst)) continue;
-            float cnt = 0.f, sp[3] = {0.f, 0.f, 0.f}, sn[3] = {0.f, 0.f, 0.f};
-            auto add = [&](int e) {
-                cnt += 1.0f;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    sp[c] += e_pos[e][c];
-                    sn[c] += e_attr[e][c];
+            for (int w = 0; w < kReduceBlock / 64; ++w) {
+                const int c = wave_sel[w];
+                before += w < wave ? c : 0;
+                total += c;
+            }
+            const int at = base + before +
+                           __popcll(bal & ((1ull << lane) - 1ull));
+            if (sel) {
+                if (at < kStage) {
+                    stage_entry(at, e0, e1);
+                } else if (e0.x != kNoSlot) {
+                    // (beyond the staging area: only the member counts)
+                    atomicAdd(&L.members[e0.x & (unsigned)(width - 1)], 1);
                 }
-            };
-            // The members follow the first point in point order. Their number
-            // is known, so the walk ends at the last one -- a voxel's points
-            // are neighbours in the image and therefore in the list -- and
-            // four entries are compared per LDS round trip.
-            add(j);
-            int left = s != kNoSlot ? members[s & (unsigned)(width - 1)] - 1 : 0;
-            for (int e = j + 1; left > 0 && e < count; e += 4) {
-                const unsigned s0 = e_slot[e], s1 = e_slot[e + 1],
-                               s2 = e_slot[e + 2], s3 = e_slot[e + 3];
-                if (s0 == s) { add(e); --left; }
-                if (s1 == s) { add(e + 1); --left; }
-                if (s2 == s) { add(e + 2); --left; }
-                if (s3 == s) { add(e + 3); --left; }
             }
-            finish(s, e0[k].y, cnt, sp, sn);
+            base += total;
+            __syncthreads();  // wave_sel is reused
         }
-    } else {
-        // a bucket beyond the LDS staging (a cloud whose points crowd a few
-        // voxels): the same walk out of global memory, four entries in flight
-        for (int j = tid; j < count; j += kReduceBlock) {
-            const unsigned s = job.ent[2 * locate(j)].x;
-            if (s != kNoSlot) atomicAdd(&members[s & (unsigned)(width - 1)], 1);
+        if (base <= kStage) {
+            process_staged(base);
+            continue;
         }
-        __syncthreads();
+        // this range alone overflows: walk it out of global memory, four
+        // entries in flight
+        __syncthreads();  // members[] complete
         for (int j = tid; j < count; j += kReduceBlock) {
             const uint4* own = job.ent + 2 * locate(j);
-            const uint4 o0 = own[0], o1 = own[1];
+            const uint4 o0 = own[0];
+            if (range_of(o0.x) != p || !(o0.y & kEntryFirst)) continue;
+            const uint4 o1 = own[1];
             const unsigned s = o0.x;
-            if (!(o0.y & kEntryFirst)) continue;
             float cnt = 1.0f;
             float sp[3] = {__uint_as_float(o0.z), __uint_as_float(o0.w),
                            __uint_as_float(o1.x)};
             float sn[3] = {__uint_as_float(o1.y), __uint_as_float(o1.z),
                            __uint_as_float(o1.w)};
-            int left = s != kNoSlot ? members[s & (unsigned)(width - 1)] - 1 : 0;
+            int left = s != kNoSlot ? L.members[s & (unsigned)(width - 1)] - 1
+                                    : 0;
             for (int e = j + 1; left > 0 && e < count; e += 4) {
                 uint4 m0[4], m1[4];
 #pragma unroll
@@ -971,12 +1048,14 @@ VdsTileReduceKernel(VdsJob<T> job_a, VdsJob<T> job_b) {
                         --left;
                     }
             }
-            finish(s, o0.y, cnt, sp, sn);
+            finish(o0.y, cnt, sp, sn);
         }
-        // (only when every walk of the bucket has read its slots)
+        // (only when every walk of the range has read its slots)
         __syncthreads();
-        for (int j = tid; j < count; j += kReduceBlock)
-            clean(job.ent[2 * locate(j)].x);
+        for (int j = tid; j < count; j += kReduceBlock) {
+            const unsigned s = job.ent[2 * locate(j)].x;
+            if (range_of(s) == p) clean(s);
+        }
     }
 }
 
@@ -1164,8 +1243,15 @@ int VdsTiledImpl(const VdsLevelJob* jobs, int n_jobs, hipStream_t s) {
                            dim3(kBlock), 0, s, ins[0], ins[1]);
     hipLaunchKernelGGL(VdsTilePartitionKernel<T>, dim3((unsigned)most_tiles, gy),
                        dim3(kTile), 0, s, run[0], run[1]);
+    int tiles_p2 = 64;
+    while (tiles_p2 < most_tiles) tiles_p2 <<= 1;
+    int widest = 0;
+    for (int q = 0; q < n_jobs; ++q)
+        widest = (1 << run[q].bshift) > widest ? 1 << run[q].bshift : widest;
     hipLaunchKernelGGL(VdsTileReduceKernel<T>, dim3((unsigned)most_buckets, gy),
-                       dim3(kReduceBlock), 0, s, run[0], run[1]);
+                       dim3(kReduceBlock),
+                       (unsigned)VdsReduceLdsBytes(tiles_p2, widest), s, run[0],
+                       run[1], tiles_p2, widest);
     O3DMI_HIP_CHECK(hipGetLastError());
     for (int q = 0; q < n_jobs; ++q) {
         if (!run[q].next.tb.keys) continue;
