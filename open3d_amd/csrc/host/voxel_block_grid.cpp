@@ -67,6 +67,12 @@ struct o3dmi_vbg {
     int64_t own_range_cells = 0;
     bool own_range_clean = false;
     float own_range_lo = 0, own_range_hi = 0;
+    // ... and, for images whose ray cast runs in rounds, the last cast's
+    // per-tile durations and this cast's tile order (longest first)
+    unsigned long long* rc_cost = nullptr;
+    int* rc_order = nullptr;
+    int64_t rc_tiles = 0;
+    unsigned rc_seq = 0;
     volatile int* stream_status = nullptr;  // host-mapped int[8]: [0..3]
                                          // published by the integrate roles,
                                          // [4..7] by the groups' last touch
@@ -508,6 +514,8 @@ int o3dmi_vbg_destroy(o3dmi_vbg_t* g) {
     (void)hipFree(g->front_tickets);
     (void)hipFree(g->ring_counters);
     (void)hipFree(g->own_range);
+    (void)hipFree(g->rc_cost);
+    (void)hipFree(g->rc_order);
     if (g->stream_status) (void)hipHostFree((void*)g->stream_status);
     for (hipEvent_t e : g->prof_events) (void)hipEventDestroy(e);
     (void)hipFree(g->prof_counts);
@@ -1960,6 +1968,10 @@ extern "C" int o3dmi_internal_estimate_range(
         float voxel_size, float depth_min, float depth_max,
         o3dmi_stream_t stream);
 extern "C" int o3dmi_internal_raycast_reset_range(void);
+extern "C" int o3dmi_internal_raycast_tile_order(unsigned long long* cost,
+                                                 int* order, int n_tiles,
+                                                 unsigned want_seq,
+                                                 unsigned seq);
 
 static StreamCommon MakeCommon(int depth_rows, int depth_cols, int color_rows,
                                int color_cols, const double* depth_intrinsic,
@@ -2352,6 +2364,38 @@ int o3dmi_vbg_ray_cast_dev(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
                         hipMemcpyHostToDevice, (hipStream_t)stream));
             }
             (void)o3dmi_internal_raycast_reset_range();
+        }
+        // An image of more tiles than the chip holds workgroups (1280 x 720:
+        // 3600 against 1280) is rendered longest tile first, by the last
+        // cast's measured tile times (vbg_raycast.hip TileOrder).
+        const int64_t n_tiles =
+                (int64_t)((width + 31) / 32) * ((height + 7) / 8);
+        if (n_tiles > kCUs * 5 && n_tiles <= kCUs * 16 && max_m > 0) {
+            if (g->rc_tiles != n_tiles) {
+                if (g->rc_cost) {
+                    O3DMI_HIP_CHECK(hipDeviceSynchronize());
+                    (void)hipFree(g->rc_cost);
+                    (void)hipFree(g->rc_order);
+                    g->rc_cost = nullptr;
+                    g->rc_order = nullptr;
+                    g->rc_tiles = 0;
+                }
+                O3DMI_HIP_CHECK(hipMalloc((void**)&g->rc_cost,
+                                          sizeof(unsigned long long) *
+                                                  (size_t)n_tiles));
+                O3DMI_HIP_CHECK(hipMalloc((void**)&g->rc_order,
+                                          sizeof(int) * (size_t)n_tiles));
+                O3DMI_HIP_CHECK(hipMemsetAsync(
+                        g->rc_cost, 0,
+                        sizeof(unsigned long long) * (size_t)n_tiles,
+                        (hipStream_t)stream));
+                g->rc_tiles = n_tiles;
+                g->rc_seq = 0;
+            }
+            const unsigned last = g->rc_seq;
+            g->rc_seq = last + 1 == 0 ? 1 : last + 1;
+            (void)o3dmi_internal_raycast_tile_order(
+                    g->rc_cost, g->rc_order, (int)n_tiles, last, g->rc_seq);
         }
     }
     st = o3dmi_internal_estimate_range(

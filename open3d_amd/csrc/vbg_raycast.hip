@@ -53,6 +53,71 @@ __global__ void RangeFillKernel(float* __restrict__ range, int64_t n,
 }
 
 // One wave per block key (4 waves per workgroup).
+// What the ray cast of the LAST frame measured per tile, turned into this
+// frame's tile order, longest first (round 6). A 1280 x 720 image is 3600
+// tiles for 1280 resident workgroups: the launch runs in ~3 rounds and lasted
+// as long as whatever long-marching tiles (the floor's grazing rays) happened
+// to start in the last one. Workgroups are dispatched in index order, so
+// handing workgroup k the k-th longest tile of the previous frame (the camera
+// moves a few millimetres between frames) is longest-processing-time-first
+// scheduling. Costs are {frame number, 10 ns ticks of the tile's slowest
+// wave}, written with atomicMax by the ray cast itself; a tile without a cost
+// of the wanted frame sorts last. Which tile a workgroup renders changes no
+// pixel. The sort is one extra workgroup of the range-estimate launch.
+struct TileOrder {
+    const unsigned long long* cost;  // [n_tiles] or NULL
+    int* order;                      // [n_tiles]
+    int n_tiles;
+    unsigned want_seq;
+};
+__device__ __forceinline__ void SortTilesLongestFirst(const TileOrder& to) {
+    __shared__ int hist[256];
+    __shared__ int wave_sum[4];
+    constexpr int kPerThread = 16;  // <= 4096 tiles, kBlock = 256 threads
+    for (int c = threadIdx.x; c < 256; c += blockDim.x) hist[c] = 0;
+    // every load of the thread in flight at once (a loop of load -> LDS
+    // atomic is one memory round trip per tile: 14 of them for 3600 tiles)
+    int cls[kPerThread];
+#pragma unroll
+    for (int u = 0; u < kPerThread; ++u) {
+        const int t = (int)threadIdx.x + u * 256;
+        cls[u] = -1;
+        if (t < to.n_tiles) {
+            const unsigned long long v = to.cost[t];
+            const unsigned ticks = (unsigned)v >> 5;  // 320 ns classes
+            cls[u] = (unsigned)(v >> 32) != to.want_seq
+                             ? 0
+                             : (int)(ticks < 255u ? ticks : 255u);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kPerThread; ++u)
+        if (cls[u] >= 0) atomicAdd(&hist[cls[u]], 1);
+    __syncthreads();
+    // class c starts behind every longer class: an exclusive scan over the
+    // classes in descending order (thread t holds class 255 - t)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = hist[255 - (int)threadIdx.x];
+    int incl = h;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    int before = incl - h;
+    for (int w = 0; w < wave; ++w) before += wave_sum[w];
+    hist[255 - (int)threadIdx.x] = before;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kPerThread; ++u)
+        if (cls[u] >= 0)
+            to.order[atomicAdd(&hist[cls[u]], 1)] =
+                    (int)threadIdx.x + u * 256;
+}
+
 __global__ void EstimateRangeKernel(const int* __restrict__ block_keys,
                                     int key_stride, int64_t n_blocks,
                                     const int* __restrict__ n_blocks_dev,
@@ -60,11 +125,17 @@ __global__ void EstimateRangeKernel(const int* __restrict__ block_keys,
                                     Camera cam, int h_down, int w_down,
                                     int down_factor, int64_t block_resolution,
                                     float voxel_size, float depth_min,
-                                    float depth_max) {
+                                    float depth_max, TileOrder to) {
+    if (to.cost && blockIdx.x == gridDim.x - 1) {
+        // (the launch was given one workgroup more for this)
+        SortTilesLongestFirst(to);
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const int64_t wave_id =
             ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t n_waves =
+            ((int64_t)(gridDim.x - (to.cost ? 1 : 0)) * blockDim.x) >> 6;
     // Device-resident count (frame-stream callers): the live length of the
     // key list, bounded by the host-side capacity n_blocks.
     if (n_blocks_dev) {
@@ -138,6 +209,11 @@ struct RayCastParams {
                     // next frame needs no clearing launch. (A flag bit and a
                     // load, not three more scalar arguments: the slim 16^3
                     // form sits at its register cap.)
+    // longest-first tile order (TileOrder above): workgroup k renders tile
+    // tile_order[k] and leaves its duration in tile_cost; NULL: tile k
+    const int* tile_order;
+    unsigned long long* tile_cost;
+    unsigned cost_seq;
     int band_ty0, band_tys;  // the launch renders tile rows [ty0, ty0 + tys)
                              // only (o3dmi_vbg_raycast_rows: a rank's band of
                              // a pixel-sharded ray cast); tys = 0: the image
@@ -278,7 +354,9 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
         } else {
             tile = k;
             if (tile >= n_tiles_all) break;
+            if (p.tile_order) tile = p.tile_order[k];
         }
+        const unsigned long long tile_t0 = p.tile_cost ? wall_clock64() : 0ull;
         if (DIAG && threadIdx.x == 0)
             p.clocks[3 * (int64_t)tile] = wall_clock64();
         __syncthreads();  // the previous tile's readers are done
@@ -742,6 +820,13 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
             }
         }
 
+        if (p.tile_cost && lane == 0) {
+            // this wave's time on the tile; the slowest wave's counts
+            const unsigned long long dt = wall_clock64() - tile_t0;
+            atomicMax(&p.tile_cost[tile],
+                      ((unsigned long long)p.cost_seq << 32) |
+                              (dt < 0xFFFFFFFFull ? dt : 0xFFFFFFFFull));
+        }
         if (!inside) continue;  // (no barrier and no wave-wide step below)
         if (depth_ptr) *depth_ptr = out_depth;
         if (vertex_ptr) {
@@ -816,6 +901,26 @@ int o3dmi_internal_raycast_reset_range(void) {
     g_reset_range = 1;
     return O3DMI_OK;
 }
+// The NEXT ray-cast launch of this host thread takes its tiles in `order`
+// (NULL: index order) and writes their durations to `cost` tagged `seq`;
+// the NEXT range-estimate launch sorts `cost` entries tagged `want_seq` into
+// `order` first (n_tiles of them). Consumed by those launches.
+static thread_local TileOrder g_sort_tiles = {};
+static thread_local const int* g_tile_order = nullptr;
+static thread_local unsigned long long* g_tile_cost = nullptr;
+static thread_local unsigned g_cost_seq = 0;
+int o3dmi_internal_raycast_tile_order(unsigned long long* cost, int* order,
+                                      int n_tiles, unsigned want_seq,
+                                      unsigned seq) {
+    g_sort_tiles.cost = cost;
+    g_sort_tiles.order = order;
+    g_sort_tiles.n_tiles = n_tiles;
+    g_sort_tiles.want_seq = want_seq;
+    g_tile_order = order;
+    g_tile_cost = cost;
+    g_cost_seq = seq;
+    return O3DMI_OK;
+}
 
 int o3dmi_vbg_estimate_range_dev(const int32_t* block_keys_dev,
                                  int64_t max_blocks,
@@ -858,13 +963,18 @@ int o3dmi_internal_estimate_range(const int32_t* block_keys_dev, int key_stride,
         Camera cam = Camera::Make(intrinsic, extrinsic, 1.0f);
         // With a device-resident count the list is usually far shorter than
         // its capacity: a fixed grid (2 workgroups per CU) strides over it.
-        const int grid = n_blocks_dev ? GridFor(max_blocks, 4, kCUs * 2)
-                                      : GridFor(max_blocks, 4);
+        const TileOrder to = g_sort_tiles;
+        g_sort_tiles = TileOrder{};
+        const int grid = (n_blocks_dev ? GridFor(max_blocks, 4, kCUs * 2)
+                                       : GridFor(max_blocks, 4)) +
+                         (to.cost ? 1 : 0);
         hipLaunchKernelGGL(EstimateRangeKernel, dim3(grid), dim3(kBlock), 0, s,
                            block_keys_dev, key_stride, max_blocks, n_blocks_dev,
                            range_minmax_map_dev, cam, h_down, w_down,
                            down_factor, block_resolution, voxel_size, depth_min,
-                           depth_max);
+                           depth_max, to);
+    } else {
+        g_sort_tiles = TileOrder{};
     }
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
@@ -971,6 +1081,18 @@ int o3dmi_vbg_raycast_rows(
     // (o3dmi_internal_raycast_reset_range: consumed by this launch)
     if (g_reset_range && whole && range_map_down_factor == 8) p.coop |= 2;
     g_reset_range = 0;
+    // (o3dmi_internal_raycast_tile_order: consumed by this launch; only for
+    // launches that run in rounds, whose grid is one workgroup per tile)
+    p.tile_order = nullptr;
+    p.tile_cost = nullptr;
+    p.cost_seq = 0;
+    if (g_tile_cost && whole && !p.xcd_bands && n_tiles <= kCUs * 16) {
+        p.tile_order = g_tile_order;
+        p.tile_cost = g_tile_cost;
+        p.cost_seq = g_cost_seq;
+    }
+    g_tile_order = nullptr;
+    g_tile_cost = nullptr;
     // a multiple of 8 workgroups: every XCD gets the same number
     dim3 grid((unsigned)((GridFor(n_tiles, 1, kCUs * 16) + 7) & ~7)),
             block(kBlock);
