@@ -942,18 +942,31 @@ def secondary_legs():
                 return subprocess.run(
                     [exe, "60", str(w), str(h)], capture_output=True,
                     text=True, timeout=300,
-                    preexec_fn=(lambda: os.sched_setaffinity(0, one))
+                    preexec_fn=(lambda: os.sched_setaffinity(0, pin))
                     if pin else None)
+            # (the host is shared: a CPU may be somebody else's -- one probe
+            # run on each of three candidates, the fastest takes the five)
+            best = None
+            for c in sorted({cpus[min(2, len(cpus) - 1)], cpus[len(cpus) // 4],
+                             cpus[len(cpus) // 2]}):
+                pr = run_once({c})
+                if pr.returncode == 0 and pr.stdout.strip():
+                    f = json.loads(
+                        pr.stdout.strip().splitlines()[-1])["frames_per_s"]
+                    if best is None or f > best[0]:
+                        best = (f, c)
+            if best is not None:
+                one = {best[1]}
             runs, err = [], None
             for _ in range(5):
-                pr = run_once(True)
+                pr = run_once(one)
                 if pr.returncode != 0 or not pr.stdout.strip():
                     err = {"error": (pr.stderr or "failed")[-300:]}
                     break
                 runs.append(json.loads(pr.stdout.strip().splitlines()[-1]))
             unpinned = []
             for _ in range(3 if err is None else 0):
-                pr = run_once(False)
+                pr = run_once(None)
                 if pr.returncode == 0 and pr.stdout.strip():
                     unpinned.append(json.loads(
                         pr.stdout.strip().splitlines()[-1])["frames_per_s"])
