@@ -1604,7 +1604,9 @@ def main():
         "metric": "RGB-D frames/s, TSDF integrate with known poses "
                   "(configs[1]: touch + activate + integrate into an 8 mm / "
                   "16^3 VoxelBlockGrid); the ICP + integrate + ray-cast loop "
-                  "(configs[2]) is in loop_frames_per_s",
+                  "(configs[2]) is in loop_frames_per_s (its first tracked "
+                  "frame untimed as warm-up; the whole run in "
+                  "loop_frames_per_s_with_first_frame)",
         "loop_frames_per_s": None,  # filled from the configs[2] legs
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
@@ -1742,7 +1744,8 @@ def compact_line(out, secondary):
     line = {k: out.get(k) for k in (
         "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
         "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-        "loop_frames_per_s", "cold_pass_frames_per_s")}
+        "loop_frames_per_s", "loop_frames_per_s_with_first_frame",
+        "cold_pass_frames_per_s")}
     if out.get("drop_in"):
         line["drop_in"] = _r(out["drop_in"])
     sec = secondary or {}
@@ -1762,6 +1765,10 @@ def compact_line(out, secondary):
         pk = cpp.get("per_kernel") or {}
         c2[tag] = _r(dict(
             frames_per_s=cpp.get("frames_per_s"),
+            # (behind the first tracked frame = the warm-up; the whole run,
+            # as rounds 1-5 reported it, is with_first_frame)
+            with_first_frame=cpp.get("frames_per_s_with_first_frame"),
+            first_frame_ms=cpp.get("first_frame_ms"),
             runs=cpp.get("frames_per_s_of_5_runs"),
             runs_unpinned=cpp.get("frames_per_s_unpinned"),
             pinned_to_cpu=cpp.get("pinned_to_cpu"),
@@ -1787,11 +1794,18 @@ def compact_line(out, secondary):
                 if c2[tag].get("frames_per_s") is not None}
         if loop:
             # the loop BASELINE's metric names (ICP + integrate + ray cast),
-            # at top level next to `value`
+            # at top level next to `value`: behind the first tracked frame
+            # (the warm-up), and over the whole 59-frame run as rounds 1-5
+            # reported it
             line["loop_frames_per_s"] = loop
-        c2["caller"] = ("examples/icp_slam (C++, median of 5 runs, each "
-                        "started under a one-CPU affinity mask of the GPU's "
-                        "NUMA node; runs_unpinned: left to the scheduler)")
+            whole = {tag: c2[tag].get("with_first_frame") for tag in c2
+                     if c2[tag].get("with_first_frame") is not None}
+            if whole:
+                line["loop_frames_per_s_with_first_frame"] = whole
+        c2["caller"] = ("examples/icp_slam (C++, median of 5 runs of 60 "
+                        "frames, the first tracked frame untimed as warm-up, "
+                        "each run started under a one-CPU affinity mask; "
+                        "runs_unpinned: left to the scheduler)")
         line["configs2"] = c2
     c4 = (sec.get("configs4") or {})
     c4i = c4.get("integrate_4mm_over_500k_blocks") or {}
