@@ -282,6 +282,8 @@ int RunRank(int argc, char** argv, int rank, int world, o3dmi_comm_t* comm,
 
     hipStream_t stream;
     CHECK_HIP(hipStreamCreate(&stream));
+    // start-up: the library's kernels are loaded now, not by the first frame
+    CHECK_O3D(o3dmi_preload());
 
     std::vector<uint16_t*> depth_dev((size_t)n_frames);
     std::vector<uint8_t*> color_dev((size_t)n_frames);

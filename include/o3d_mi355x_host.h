@@ -597,6 +597,12 @@ int o3dmi_rgbd_odometry_information_matrix(
         const double* source_to_target, float dist_thr, float depth_scale,
         float depth_max, double* information_host, o3dmi_stream_t stream);
 
+/* Extension: loads the kernels of the tracking / integration path now. HIP
+ * loads a translation unit's device code at the first launch of one of its
+ * kernels (1.5-2.8 ms each for the large ones); an application that cares about
+ * the latency of its FIRST frame calls this once at start-up. */
+int o3dmi_preload(void);
+
 /* Extension (no counterpart in the reference's API): the block coordinates
  * the most recent o3dmi_vbg_integrate_frame (or the last frame of an
  * o3dmi_vbg_integrate_frames call with frames_per_launch = 1) touched -- the

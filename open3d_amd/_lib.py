@@ -314,6 +314,7 @@ PROTOTYPES.update({
                                         C.POINTER(_vp)]),
     "o3dmi_comm_destroy": (_i32, [_vp]),
     "o3dmi_comm_rank": (_i32, [_vp]),
+    "o3dmi_preload": (_i32, []),
     "o3dmi_comm_world": (_i32, [_vp]),
     "o3dmi_comm_rccl_ranks": (_i32, [_vp]),
     "o3dmi_set_comm": (_i32, [_vp]),

@@ -379,6 +379,16 @@ int RecoverOverflow(o3dmi_hash* h, hipStream_t s, int64_t* wanted) {
     return O3DMI_OK;
 }
 
+// o3dmi_preload: HIP loads this translation unit's code object at the first
+// launch of one of its kernels; asking for a kernel's attributes does it now.
+int PreloadBlockHash() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(
+                                               &ClearKernel)) == hipSuccess
+                   ? 0
+                   : 1;
+}
+
 }  // namespace o3dmi
 
 using namespace o3dmi;

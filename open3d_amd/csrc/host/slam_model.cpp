@@ -50,6 +50,9 @@ int o3dmi_slam_model_create(float voxel_size, int block_resolution,
         delete m;
         return st;
     }
+    // a tracking pipeline is being set up: its kernels are loaded now, not by
+    // its first frame (best effort)
+    (void)o3dmi_preload();
     if (T_init)
         std::memcpy(m->T_frame_to_world, T_init, sizeof(m->T_frame_to_world));
     else

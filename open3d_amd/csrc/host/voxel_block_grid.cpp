@@ -1973,6 +1973,48 @@ extern "C" int o3dmi_internal_raycast_tile_order(unsigned long long* cost,
                                                  unsigned want_seq,
                                                  unsigned seq);
 
+extern "C++" {
+namespace o3dmi {
+int PreloadBlockHash();
+int PreloadIcp();
+int PreloadNns();
+int PreloadPointcloud();
+int PreloadRaycast();
+int PreloadStream();
+int PreloadTouch();
+}  // namespace o3dmi
+}  // extern "C++"
+
+// Extension: everything a first frame would otherwise pay for besides its own
+// buffers. HIP loads a translation unit's code object at the first launch of
+// one of its kernels -- 1.5-2.8 ms each for the large ones (ICP search,
+// VoxelDownSample, the search index): of the 8.7 ms a first tracked frame
+// took, most was that (profiles/r6k_first_frame.txt). Loads them now; safe to
+// call more than once and from any thread.
+extern "C" int o3dmi_preload(void) {
+    int bad = 0;
+    bad += o3dmi::PreloadBlockHash();
+    bad += o3dmi::PreloadTouch();
+    bad += o3dmi::PreloadStream();
+    bad += o3dmi::PreloadRaycast();
+    bad += o3dmi::PreloadPointcloud();
+    bad += o3dmi::PreloadNns();
+    bad += o3dmi::PreloadIcp();
+    {
+        hipFuncAttributes attr;
+        bad += hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(
+                                                   &ExportListKeysKernel)) ==
+                               hipSuccess
+                       ? 0
+                       : 1;
+    }
+    if (bad) {
+        SetLastError("o3dmi_preload: a code object could not be loaded");
+        return O3DMI_ERR_HIP;
+    }
+    return O3DMI_OK;
+}
+
 static StreamCommon MakeCommon(int depth_rows, int depth_cols, int color_rows,
                                int color_cols, const double* depth_intrinsic,
                                const double* color_intrinsic, float depth_scale,

@@ -1017,6 +1017,16 @@ int ReduceGrid(int64_t n) {
 }
 
 }  // namespace
+// o3dmi_preload: HIP loads this translation unit's code object at the first
+// launch of one of its kernels; asking for a kernel's attributes does it now.
+int PreloadIcp() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(
+                                               &TransformNormalsKernel<float>)) == hipSuccess
+                   ? 0
+                   : 1;
+}
+
 }  // namespace o3dmi
 
 using namespace o3dmi;

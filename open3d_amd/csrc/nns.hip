@@ -1114,6 +1114,16 @@ __global__ void CountOccupiedKernel(const uint2* __restrict__ ranges,
 }
 
 }  // namespace
+// o3dmi_preload: HIP loads this translation unit's code object at the first
+// launch of one of its kernels; asking for a kernel's attributes does it now.
+int PreloadNns() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(
+                                               &CountKernel<float>)) == hipSuccess
+                   ? 0
+                   : 1;
+}
+
 }  // namespace o3dmi
 
 using namespace o3dmi;

@@ -1514,6 +1514,16 @@ int VdsAsync(const void* pos, const void* attr, int64_t n_max, const int* n_dev,
     return VdsPairAsync(&J, 1, dtype, scratch, s);
 }
 
+// o3dmi_preload: HIP loads this translation unit's code object at the first
+// launch of one of its kernels; asking for a kernel's attributes does it now.
+int PreloadPointcloud() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(
+                                               &VdsInitKernel)) == hipSuccess
+                   ? 0
+                   : 1;
+}
+
 }  // namespace o3dmi
 
 using namespace o3dmi;

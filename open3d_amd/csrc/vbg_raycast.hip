@@ -860,6 +860,16 @@ RayCastKernel(HashView hv, RayCastParams p, const float* __restrict__ tsdf_base,
 }
 
 }  // namespace
+// o3dmi_preload: HIP loads this translation unit's code object at the first
+// launch of one of its kernels; asking for a kernel's attributes does it now.
+int PreloadRaycast() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(
+                                               &RangeFillKernel)) == hipSuccess
+                   ? 0
+                   : 1;
+}
+
 }  // namespace o3dmi
 
 using namespace o3dmi;

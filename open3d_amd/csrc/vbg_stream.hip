@@ -1871,4 +1871,14 @@ int LaunchChunkIntegrate(o3dmi_hash* bh, const ChunkIntegrateArgs& a,
     return O3DMI_OK;
 }
 
+// o3dmi_preload: HIP loads this translation unit's code object at the first
+// launch of one of its kernels; asking for a kernel's attributes does it now.
+int PreloadStream() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(
+                                               &VerifyRcpKernel)) == hipSuccess
+                   ? 0
+                   : 1;
+}
+
 }  // namespace o3dmi

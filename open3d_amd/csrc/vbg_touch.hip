@@ -265,6 +265,16 @@ UnprojectKernel(TouchParams p, const depth_t* __restrict__ depth,
 
 }  // namespace
 
+// o3dmi_preload: HIP loads this translation unit's code object at the first
+// launch of one of its kernels; asking for a kernel's attributes does it now.
+int PreloadTouch() {
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(
+                                               &DepthTouchKernel<uint16_t>)) == hipSuccess
+                   ? 0
+                   : 1;
+}
+
 }  // namespace o3dmi
 
 using namespace o3dmi;

@@ -1402,6 +1402,15 @@ def test_last_frame_block_coordinates_equal_a_second_block_touch():
         g2.ray_cast_last_frame(K, T[0], w, h, ("depth",))
 
 
+def test_preload_loads_the_kernels_and_may_be_repeated():
+    """o3dmi_preload (extension): loads the code objects of the tracking /
+    integration path; idempotent."""
+    _lib, _ = _gpu()
+    L = _lib.lib()
+    assert L.o3dmi_preload() == 0
+    assert L.o3dmi_preload() == 0
+
+
 def test_sort_indices_is_a_counting_sort():
     """o3dmi_sort_indices (scan.hip): ascending order of buffer indices --
     distinct ones, duplicates, a range of more than one scan tile."""
