@@ -408,23 +408,26 @@ int RunRank(int argc, char** argv, int rank, int world, o3dmi_comm_t* comm,
                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                     depth_scale, 0.1f, depth_max, 1.0f, trunc, 8, stream));
         }
-        CHECK_O3D(o3dmi_unproject(rc_depth, O3DMI_F32, H, W, rc_normal,
-                                  model_pts, model_nrm, counts, K, X,
-                                  depth_scale, depth_max, stride, stream));
-        // ---- frame cloud of the new depth image, still at the previous pose
-        CHECK_O3D(o3dmi_unproject(depth_dev[(size_t)k], O3DMI_U16, H, W,
-                                  nullptr, frame_pts, nullptr, counts + 1, K, X,
-                                  depth_scale, depth_max, stride, stream));
+        // Both clouds in the PREVIOUS CAMERA's frame, where the ray cast
+        // leaves its vertex and normal maps (the frame the reference's
+        // slam::Model tracks in, Model.cpp:69-89: the synthesised model frame
+        // against the input frame): the model's normals are used as rendered
+        // -- until round 6 this example moved both clouds to the world and
+        // rotated the normals after them, one more launch per frame.
+        static const double kEye[16] = {1, 0, 0, 0, 0, 1, 0, 0,
+                                        0, 0, 1, 0, 0, 0, 0, 1};
+        // ... and the frame cloud of the new depth image, in its own camera's
+        // frame (the identity is ICP's initial guess for the motion between
+        // the two), by the same launch.
+        CHECK_O3D(o3dmi_unproject_pair(
+                rc_depth, O3DMI_F32, rc_normal, model_pts, model_nrm, counts,
+                kEye, depth_dev[(size_t)k], O3DMI_U16, nullptr, frame_pts,
+                nullptr, counts + 1, kEye, H, W, K, depth_scale, depth_max,
+                stride, stream));
         const double p2 = now();
-        double Xinv[16];
-        InvertRigid(X, Xinv);  // camera -> world rotates the normals
         // The two cloud sizes stay on the device (no read-back, no stream
-        // drain per frame): the normals are rotated over the whole buffer --
-        // rows past the live count are never read -- and the ICP driver takes
-        // the sizes from the device words (the host arguments are then the
-        // buffer capacities).
-        CHECK_O3D(o3dmi_transform_normals(Xinv, model_nrm, (int64_t)cloud_cap,
-                                          O3DMI_F32, stream));
+        // drain per frame): the ICP driver takes them from the device words
+        // (the host arguments are then the buffer capacities).
         // ---- track ----------------------------------------------------------
         o3dmi_registration_result_t r;
         CHECK_O3D(o3dmi_registration_set_device_counts(counts + 1, counts));
@@ -435,10 +438,11 @@ int RunRank(int argc, char** argv, int rank, int world, o3dmi_comm_t* comm,
                 nullptr, nullptr, nullptr, &r, stream));
         iterations += r.num_iterations;
         const double p3 = now();
-        // points_world = r.T (X_prev^-1 p_cam)  =>  X_k = X_prev r.T^-1
+        // p_prev_cam = r.T p_cam, p_prev_cam = X_prev p_world
+        //   =>  X_k = r.T^-1 X_prev
         double rinv[16];
         InvertRigid(r.transformation, rinv);
-        Matmul4(X, rinv, X);
+        Matmul4(rinv, X, X);
         out->poses.insert(out->poses.end(), X, X + 16);
         // ---- integrate at the estimated pose -------------------------------
         CHECK_O3D(o3dmi_vbg_integrate_frame(

@@ -336,6 +336,22 @@ int o3dmi_unproject(const void* depth_dev, int depth_dtype, int rows, int cols,
                     const double* intrinsic, const double* extrinsic,
                     float depth_scale, float depth_max, int64_t stride,
                     o3dmi_stream_t stream);
+/* Two images of ONE size, intrinsic matrix, scale and stride in one launch --
+ * the two clouds a frame-to-model tracking step starts from: the model frame
+ * a ray cast rendered (depth F32 + its normal map as image_colors) and the
+ * camera's new frame (U16). Each cloud is, to the bit and in the same order,
+ * what o3dmi_unproject gives for its arguments (extrinsic_a / extrinsic_b
+ * may differ); the outputs must not alias. */
+int o3dmi_unproject_pair(
+        const void* depth_a_dev, int depth_a_dtype,
+        const float* image_colors_a_dev, float* points_a_dev,
+        float* colors_a_dev, int32_t* out_count_a_dev,
+        const double* extrinsic_a, const void* depth_b_dev, int depth_b_dtype,
+        const float* image_colors_b_dev, float* points_b_dev,
+        float* colors_b_dev, int32_t* out_count_b_dev,
+        const double* extrinsic_b, int rows, int cols, const double* intrinsic,
+        float depth_scale, float depth_max, int64_t stride,
+        o3dmi_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
 /* ICP kernels.                                                              */

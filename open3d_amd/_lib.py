@@ -76,6 +76,9 @@ PROTOTYPES = {
                                 _f, _f, _f, _f, _i32, _vp]),
     "o3dmi_unproject": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _dp,
                                _dp, _f, _f, _i64, _vp]),
+    "o3dmi_unproject_pair": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _dp,
+                                    _vp, _i32, _vp, _vp, _vp, _vp, _dp,
+                                    _i32, _i32, _dp, _f, _f, _i64, _vp]),
     "o3dmi_nns_create": (_i32, [_vp, _i64, _i32, _d, _vp, C.POINTER(_vp)]),
     "o3dmi_nns_destroy": (_i32, [_vp]),
     "o3dmi_nns_hybrid_search_k1": (_i32, [_vp, _vp, _i64, _vp, _vp, _vp,

@@ -248,7 +248,8 @@ int CurrentDevice() {
     return d;
 }
 constexpr int kMaxScales = 30;
-static_assert(kMaxScales + 2 <= kCountsKeep, "counts and their kept copies");
+static_assert(kMaxScales + 1 <= kCountsErr && kMaxScales + 1 <= 32,
+              "level counts below the error word; a post carries <= 32 values");
 struct ChainCounts {
     int* dev = nullptr;
     int levels = 0;
@@ -296,7 +297,7 @@ struct ChainCounts {
     int* Count(int level) { return dev + level; }
     // (valid behind the posting launch, PostCountsPairAsync)
     const int* KeptCount(int level) const { return dev + kCountsKeep + level; }
-    int* Err() { return dev + levels; }
+    int* Err() { return dev + kCountsErr; }  // (a post's value `levels`)
     // Post: the counts leave for the chain's mailbox behind the chain's
     // launches; Wait: for that, and returns them. (Both chains post before
     // either is waited for: one host round trip, not two.)
@@ -307,6 +308,26 @@ struct ChainCounts {
         posted_seq = ++mb->seq;
         return PostCountsAsync(dev, levels + 1, mb->data, mb->flag, posted_seq,
                                cs);
+    }
+    // The post carried by the chain's last level launch (vds.h VdsPost): the
+    // request to hand to that level's job, then Posted() if it was taken up.
+    bool sealed = false;
+    int offered_seq = 0;
+    VdsPost OfferPost() {
+        VdsPost p;
+        Mailbox* mb = ThreadMailbox(1 + chain);
+        if (!mb) return p;
+        offered_seq = ++mb->seq;
+        p.counts = dev;
+        p.n = levels + 1;
+        p.mail_data = mb->data;
+        p.mail_flag = mb->flag;
+        p.mail_seq = offered_seq;
+        return p;
+    }
+    void Posted() {
+        posted_seq = offered_seq;
+        sealed = true;
     }
     // both chains were built in the same launches: one posting launch
     static int PostPair(ChainCounts& a, ChainCounts& b, hipStream_t cs) {
@@ -331,10 +352,16 @@ struct ChainCounts {
         O3DMI_REQUIRE(mb != nullptr && posted_seq != 0, "counts not posted");
         const int seq = posted_seq;
         posted_seq = 0;
-        hipError_t e = MailboxWait(mb, seq, cs);
+        double sealed32[32];
+        hipError_t e = sealed ? MailboxWaitSealed(mb, seq, cs, sealed32)
+                              : MailboxWait(mb, seq, cs);
+        const bool was_sealed = sealed;
+        sealed = false;
         // the posting launch was the chain's last: its stream has drained
-        // (no hipStreamSynchronize, 16 us on an idle stream)
-        if (e == hipSuccess) {
+        // (no hipStreamSynchronize, 16 us on an idle stream). (A sealed post
+        // comes from the last level's launch while it runs: only chains of
+        // the tiled form, which hold no pooled scratch.)
+        if (e == hipSuccess && !was_sealed) {
             for (void* p : scratch) PoolFree(p);
             scratch.clear();
         }
@@ -347,7 +374,8 @@ struct ChainCounts {
         // the posting launch has run: counts and error word are zero again,
         // every level's last launch has cleaned its workspace
         if (device >= 0) Open(device, chain) = false;
-        for (int k = 0; k <= levels; ++k) out[(size_t)k] = (int)mb->data[k];
+        for (int k = 0; k <= levels; ++k)
+            out[(size_t)k] = (int)(was_sealed ? sealed32[k] : mb->data[k]);
         if (out[(size_t)levels] & kErrKeyRange) {
             SetLastError("VoxelDownSample: voxel coordinate outside +-2^20");
             return O3DMI_ERR_KEY_RANGE;
@@ -736,6 +764,9 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         static const bool unpaired = std::getenv("O3DMI_VDS_UNPAIRED") != nullptr;
         const bool paired = !colored && !unpaired;
         hipStream_t ts = paired ? s : side;
+        static const bool no_folded_post =
+                std::getenv("O3DMI_VDS_POST_LAUNCH") != nullptr;
+        bool counts_posted = false;
         ChainGuard sg{scc, s}, tg{tcc, ts};
         if ((st = scc.Init(num_scales, 0, s))) return st;
         if ((st = tcc.Init(num_scales, 1, ts))) return st;
@@ -751,9 +782,22 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
             int n_jobs = 0;
             if (jobs[0].pos) both[n_jobs++] = jobs[0];
             if (jobs[1].pos) both[n_jobs++] = jobs[1];
+            // the coarsest level's launch posts both chains' counts itself
+            const bool offer = k == 0 && n_jobs == 2 && !no_folded_post;
+            if (offer) {
+                both[0].post = scc.OfferPost();
+                both[1].post = tcc.OfferPost();
+            }
+            bool posted = false;
             if (n_jobs &&
-                (st = VdsPairAsync(both, n_jobs, dtype, scc.scratch, s)))
+                (st = VdsPairAsync(both, n_jobs, dtype, scc.scratch, s,
+                                   &posted)))
                 return st;
+            if (posted) {
+                scc.Posted();
+                tcc.Posted();
+                counts_posted = true;
+            }
         }
         std::vector<int> counts;
         // The coarsest scale's index, queued behind the posting launch BEFORE
@@ -766,7 +810,9 @@ extern "C" int o3dmi_registration_multiscale_icp_ex(
         const bool early_build =
                 paired && !(last == 0 && finest_is_input) && pyr[0].tgt_ptr;
         if (paired) {
-            if ((st = ChainCounts::PostPair(scc, tcc, s))) return st;
+            if (!counts_posted &&
+                (st = ChainCounts::PostPair(scc, tcc, s)))
+                return st;
             if (early_build &&
                 (st = o3dmi_internal_nns_create_small_deferred(
                          pyr[0].tgt_ptr, p2plane ? pyr[0].nrm_ptr : nullptr,

@@ -43,6 +43,29 @@ __host__ __device__ inline unsigned long long MailSeal(int seq) {
 hipError_t MailboxWaitSealed(Mailbox* mb, int seq, hipStream_t s,
                              double* out32);
 
+// Device side of a sealed post by ONE FULL WAVE (64 lanes, all active): lane
+// k < 32 hands in value k. For a post from inside a launch that is still
+// running (no fence, no workgroup barrier).
+__device__ __forceinline__ void MailboxPostSealedWave(double* data, int* flag,
+                                                      int seq, double value) {
+    const int lane = (int)(threadIdx.x & 63);
+    const unsigned long long b =
+            lane < 32 ? (unsigned long long)__double_as_longlong(value) : 0ull;
+    unsigned long long x = b;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) x ^= __shfl_xor(x, d, 64);
+    if (lane < 32)
+        __hip_atomic_store((unsigned long long*)data + lane, b,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane == 32)
+        __hip_atomic_store((unsigned long long*)data + 32, x ^ MailSeal(seq),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0)
+        __hip_atomic_store(flag, seq, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Device side: called by the threads of the single final workgroup after they
 // wrote data[0..n); publishes `seq`.
 __device__ __forceinline__ void MailboxPublish(int* flag, int seq) {

@@ -519,7 +519,6 @@ constexpr int kMaxTiles = 1024;
 constexpr int64_t kTiledMaxPoints = (int64_t)kTile * kMaxTiles;  // 2^20
 constexpr int kMaxBuckets = 1024;
 constexpr int kReduceBlock = 256;
-constexpr int kMaxBucketWidth = 2048;      // slots of a bucket
 constexpr unsigned kNoSlot = 0xFFFFFFFFu;  // a point outside the key range
 constexpr unsigned kEntryFirst = 0x80000000u;
 constexpr int kEntryRankShift = 20;        // index 20 bits, rank 10 bits
@@ -556,6 +555,7 @@ struct VdsJob {
     int* m_dev;
     int* err;
     VdsNext<T> next;
+    VdsPost post;         // the chain's counts leave with this level (vds.h)
 };
 
 // (p / vs).Floor().To(Int64) -> hash insert; the voxel's first point.
@@ -848,6 +848,26 @@ VdsTileReduceKernel(VdsJob<T> job_a, VdsJob<T> job_b, int tiles_p2,
             }
         }
         if (bucket == 0 && tid == 0) *job.m_dev = voxels;
+        if (bucket == 0 && wave == 0 && job.post.counts) {
+            // The chain's last level: every count of the chain is known NOW
+            // -- the earlier levels' and the error word in memory (launches
+            // before this one; this level inserts nothing), this level's in
+            // `voxels` -- so the host gets them while the level is still
+            // being reduced, instead of from a posting launch behind it
+            // (4.7 us + a launch boundary per tracked frame).
+            int c = 0;
+            if (lane < job.post.n) {
+                int* cp = job.post.counts +
+                          (lane == job.post.n - 1 ? kCountsErr : lane);
+                c = cp == job.m_dev ? voxels : *cp;
+                job.post.counts[kCountsKeep + lane] = c;
+                // zero again for the next chain -- but for the two counts
+                // this launch's other workgroups are reading or writing
+                if (cp != job.m_dev && cp != job.n_dev) *cp = 0;
+            }
+            MailboxPostSealedWave(job.post.mail_data, job.post.mail_flag,
+                                  job.post.mail_seq, (double)c);
+        }
     }
     __syncthreads();
     // entry j of the bucket -> where it lies: the last tile that starts at or
@@ -1163,7 +1183,8 @@ VdsWorkspace* ThreadVdsWorkspace(int chain, int64_t n_max, hipStream_t s) {
 
 // One level of one or two clouds (two chains) in the same launches.
 template <typename T>
-int VdsTiledImpl(const VdsLevelJob* jobs, int n_jobs, hipStream_t s) {
+int VdsTiledImpl(const VdsLevelJob* jobs, int n_jobs, hipStream_t s,
+                 bool* posted = nullptr) {
     O3DMI_REQUIRE(n_jobs == 1 || (n_jobs == 2 && jobs[0].chain != jobs[1].chain),
                   "VoxelDownSample: one cloud per chain");
     static const bool no_fuse = std::getenv("O3DMI_VDS_NO_FUSE") != nullptr;
@@ -1235,6 +1256,16 @@ int VdsTiledImpl(const VdsLevelJob* jobs, int n_jobs, hipStream_t s) {
         most_buckets = (1 << d.bucket_bits) > most_buckets ? 1 << d.bucket_bits
                                                            : most_buckets;
     }
+    // the counts posted by this level's reduce launch: only if every job asks
+    // and none of them inserts into a next level (the error word is final)
+    bool post = true;
+    for (int q = 0; q < n_jobs; ++q)
+        post = post && jobs[q].post.counts && jobs[q].post.mail_data &&
+               jobs[q].post.mail_flag && jobs[q].post.n >= 1 &&
+               jobs[q].post.n <= 32 && !run[q].next.tb.keys;
+    if (post)
+        for (int q = 0; q < n_jobs; ++q) run[q].post = jobs[q].post;
+    if (posted) *posted = post;
     const unsigned gy = (unsigned)n_jobs;
     if (any_insert)
         hipLaunchKernelGGL(VdsTileInsertKernel<T>,
@@ -1406,8 +1437,10 @@ __global__ void PostCountsKernel(int* __restrict__ counts, int n,
                                  double* mail_data, int* mail_flag,
                                  int mail_seq) {
     if ((int)threadIdx.x < n) {
-        mail_data[threadIdx.x] = (double)counts[threadIdx.x];
-        counts[threadIdx.x] = 0;
+        int* cp = counts + ((int)threadIdx.x == n - 1 ? kCountsErr
+                                                       : (int)threadIdx.x);
+        mail_data[threadIdx.x] = (double)*cp;
+        *cp = 0;
     }
     MailboxPublish(mail_flag, mail_seq);
 }
@@ -1430,13 +1463,15 @@ __global__ void PostCountsPairKernel(int* __restrict__ counts_a,
     int* counts = blockIdx.x ? counts_b : counts_a;
     double* mail_data = blockIdx.x ? mail_data_b : mail_data_a;
     if ((int)threadIdx.x < n) {
-        const int c = counts[threadIdx.x];
+        int* cp = counts + ((int)threadIdx.x == n - 1 ? kCountsErr
+                                                       : (int)threadIdx.x);
+        const int c = *cp;
         mail_data[threadIdx.x] = (double)c;
         // a copy that survives the re-zeroing, for launches queued behind
         // this one that size themselves by a level count (the deferred small
         // index build of the ICP driver)
         counts[kCountsKeep + threadIdx.x] = c;
-        counts[threadIdx.x] = 0;
+        *cp = 0;
     }
     MailboxPublish(blockIdx.x ? mail_flag_b : mail_flag_a,
                    blockIdx.x ? mail_seq_b : mail_seq_a);
@@ -1463,14 +1498,16 @@ void VdsChainInvalidate(int chain) {
 }
 
 int VdsPairAsync(const VdsLevelJob* jobs, int n_jobs, int dtype,
-                 std::vector<void*>& scratch, hipStream_t s) {
+                 std::vector<void*>& scratch, hipStream_t s, bool* posted) {
     O3DMI_REQUIRE(jobs && (n_jobs == 1 || n_jobs == 2), "bad job count");
+    if (posted) *posted = false;
     bool tiled = true;
     for (int q = 0; q < n_jobs; ++q)
         tiled = tiled && jobs[q].n_max > 0 && jobs[q].n_max <= kTiledMaxPoints;
     if (tiled)
-        return dtype == O3DMI_F64 ? VdsTiledImpl<double>(jobs, n_jobs, s)
-                                  : VdsTiledImpl<float>(jobs, n_jobs, s);
+        return dtype == O3DMI_F64
+                       ? VdsTiledImpl<double>(jobs, n_jobs, s, posted)
+                       : VdsTiledImpl<float>(jobs, n_jobs, s, posted);
     for (int q = 0; q < n_jobs; ++q) {
         const VdsLevelJob& J = jobs[q];
         int st;

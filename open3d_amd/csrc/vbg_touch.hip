@@ -263,6 +263,116 @@ UnprojectKernel(TouchParams p, const depth_t* __restrict__ depth,
     }
 }
 
+// Two images of one size in ONE launch (o3dmi_unproject_pair: the model frame
+// a ray cast rendered and the camera's new frame, the two clouds a tracking
+// step starts from): workgroups [0, a.n_chunks) are cloud a's chunks, the rest
+// cloud b's. A chunk still waits only for chunks of its own cloud before it,
+// all of them dispatched earlier. The depth type is a per-cloud run-time flag
+// (uniform over the workgroup); everything else is UnprojectKernel's body, to
+// the bit.
+struct UnprojectJob {
+    TouchParams p;
+    const void* depth;
+    int depth_is_u16;
+    const float* image_colors;
+    float* points;
+    float* colors;
+    int* count;
+    unsigned long long* chunk_words;
+    int n_chunks;
+};
+
+template <int ROUNDS>
+__global__ void __launch_bounds__(kBlock)
+UnprojectPairKernel(UnprojectJob job_a, UnprojectJob job_b, unsigned seq) {
+    __shared__ int offs[ROUNDS][kBlock / 64];
+    __shared__ int before[kBlock / 64];
+    __shared__ int chunk_total;
+    const bool second = (int)blockIdx.x >= job_a.n_chunks;
+    const UnprojectJob& J = second ? job_b : job_a;
+    const TouchParams& p = J.p;
+    const int chunk = (int)blockIdx.x - (second ? job_a.n_chunks : 0);
+    const int64_t n = (int64_t)p.rows_strided * p.cols_strided;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int64_t c0 = (int64_t)chunk * (kBlock * ROUNDS);
+    float d[ROUNDS];
+    unsigned long long ballot[ROUNDS];
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+        const int64_t w = c0 + k * kBlock + threadIdx.x;
+        bool valid = false;
+        d[k] = 0;
+        if (w < n) {
+            const int64_t y = (w / p.cols_strided) * p.stride;
+            const int64_t x = (w % p.cols_strided) * p.stride;
+            const int64_t at = y * p.cols + x;
+            const float raw = J.depth_is_u16
+                                      ? (float)((const uint16_t*)J.depth)[at]
+                                      : ((const float*)J.depth)[at];
+            d[k] = raw / p.depth_scale;
+            valid = d[k] > 0 && d[k] < p.depth_max;
+        }
+        ballot[k] = __ballot(valid);
+        if (lane == 0) offs[k][wave] = __popcll(ballot[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k)
+#pragma unroll
+            for (int wv = 0; wv < kBlock / 64; ++wv) {
+                const int c = offs[k][wv];
+                offs[k][wv] = run;
+                run += c;
+            }
+        __hip_atomic_store(&J.chunk_words[chunk],
+                           ((unsigned long long)seq << 32) | (unsigned)run,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        chunk_total = run;
+    }
+    int sum = 0;
+    for (int q = threadIdx.x; q < chunk; q += kBlock) {
+        unsigned long long w;
+        int spins = 0;
+        do {
+            w = __hip_atomic_load(&J.chunk_words[q], __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT);
+        } while ((unsigned)(w >> 32) != seq && ++spins < kUnprojSpinLimit);
+        sum += (int)(unsigned)w;
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m);
+    if (lane == 0) before[wave] = sum;
+    __syncthreads();
+    int64_t base = 0;
+#pragma unroll
+    for (int wv = 0; wv < kBlock / 64; ++wv) base += before[wv];
+    if (chunk == J.n_chunks - 1 && threadIdx.x == 0)
+        *J.count = (int)base + chunk_total;
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+        if (!((ballot[k] >> lane) & 1ull)) continue;
+        const int64_t w = c0 + k * kBlock + threadIdx.x;
+        const int64_t y = (w / p.cols_strided) * p.stride;
+        const int64_t x = (w % p.cols_strided) * p.stride;
+        const int64_t idx = base + offs[k][wave] + __popcll(ballot[k] & lt);
+        float x_c, y_c, z_c, xo, yo, zo;
+        p.cam.Unproject((float)x, (float)y, d[k], x_c, y_c, z_c);
+        p.cam.RigidTransform(x_c, y_c, z_c, xo, yo, zo);
+        J.points[3 * idx + 0] = xo;
+        J.points[3 * idx + 1] = yo;
+        J.points[3 * idx + 2] = zo;
+        if (J.colors && J.image_colors) {
+            const float* ip = J.image_colors + 3 * (y * p.cols + x);
+            J.colors[3 * idx + 0] = ip[0];
+            J.colors[3 * idx + 1] = ip[1];
+            J.colors[3 * idx + 2] = ip[2];
+        }
+    }
+}
+
 }  // namespace
 
 // o3dmi_preload: HIP loads this translation unit's code object at the first
@@ -376,6 +486,44 @@ int o3dmi_vbg_pointcloud_touch(o3dmi_hash_t* fh, const float* points_dev,
     return O3DMI_OK;
 }
 
+// The chunk totals' words of a launch, per host thread, device and stream (two
+// calls of one thread on two streams may overlap on the device; the launches
+// of one stream follow each other), grown on demand. A word is valid for the
+// launch whose sequence number it carries: nothing is cleared between
+// launches.
+static int UnprojectWords(int n_chunks, hipStream_t s,
+                          unsigned long long** words, unsigned* seq) {
+    struct Words {
+        unsigned long long* buf = nullptr;
+        int cap = 0;
+        unsigned seq = 0;
+    };
+    static thread_local std::map<std::pair<int, hipStream_t>, Words> bufs;
+    int dev = 0;
+    O3DMI_HIP_CHECK(hipGetDevice(&dev));
+    Words& c = bufs[std::make_pair(dev, s)];
+    if (c.cap < n_chunks) {
+        if (c.buf) {
+            O3DMI_HIP_CHECK(hipStreamSynchronize(s));
+            (void)hipFree(c.buf);
+            c.buf = nullptr;
+            c.cap = 0;
+        }
+        int cap = 4096;
+        while (cap < n_chunks) cap <<= 1;
+        O3DMI_HIP_CHECK(hipMalloc((void**)&c.buf,
+                                  sizeof(unsigned long long) * cap));
+        O3DMI_HIP_CHECK(hipMemsetAsync(c.buf, 0,
+                                       sizeof(unsigned long long) * cap, s));
+        c.cap = cap;
+        c.seq = 0;
+    }
+    if (++c.seq == 0) ++c.seq;  // 0 = the cleared buffer
+    *words = c.buf;
+    *seq = c.seq;
+    return O3DMI_OK;
+}
+
 int o3dmi_unproject(const void* depth_dev, int depth_dtype, int rows, int cols,
                     const float* image_colors_dev, float* points_dev,
                     float* colors_dev, int32_t* out_count_dev,
@@ -405,39 +553,8 @@ int o3dmi_unproject(const void* depth_dev, int depth_dtype, int rows, int cols,
     unsigned long long* chunk_words = nullptr;
     unsigned seq = 0;
     {
-        // The chunk totals' words, per host thread, device and stream (two
-        // calls of one thread on two streams may overlap on the device; the
-        // launches of one stream follow each other), grown on demand. A word
-        // is valid for the launch whose sequence number it carries: nothing
-        // is cleared between launches.
-        struct Words {
-            unsigned long long* buf = nullptr;
-            int cap = 0;
-            unsigned seq = 0;
-        };
-        static thread_local std::map<std::pair<int, hipStream_t>, Words> bufs;
-        int dev = 0;
-        O3DMI_HIP_CHECK(hipGetDevice(&dev));
-        Words& c = bufs[std::make_pair(dev, s)];
-        if (c.cap < n_chunks) {
-            if (c.buf) {
-                O3DMI_HIP_CHECK(hipStreamSynchronize(s));
-                (void)hipFree(c.buf);
-                c.buf = nullptr;
-                c.cap = 0;
-            }
-            int cap = 4096;
-            while (cap < n_chunks) cap <<= 1;
-            O3DMI_HIP_CHECK(hipMalloc((void**)&c.buf,
-                                      sizeof(unsigned long long) * cap));
-            O3DMI_HIP_CHECK(hipMemsetAsync(
-                    c.buf, 0, sizeof(unsigned long long) * cap, s));
-            c.cap = cap;
-            c.seq = 0;
-        }
-        if (++c.seq == 0) ++c.seq;  // 0 = the cleared buffer
-        chunk_words = c.buf;
-        seq = c.seq;
+        int st = UnprojectWords(n_chunks, s, &chunk_words, &seq);
+        if (st != O3DMI_OK) return st;
     }
 #define O3DMI_UNPROJECT(T, R)                                                  \
     hipLaunchKernelGGL((UnprojectKernel<T, R>), grid, block, 0, s, p,         \
@@ -454,6 +571,84 @@ int o3dmi_unproject(const void* depth_dev, int depth_dtype, int rows, int cols,
     else { O3DMI_UNPROJECT_R(float) }
 #undef O3DMI_UNPROJECT_R
 #undef O3DMI_UNPROJECT
+    O3DMI_HIP_CHECK(hipGetLastError());
+    return O3DMI_OK;
+}
+
+int o3dmi_unproject_pair(
+        const void* depth_a_dev, int depth_a_dtype,
+        const float* image_colors_a_dev, float* points_a_dev,
+        float* colors_a_dev, int32_t* out_count_a_dev,
+        const double* extrinsic_a, const void* depth_b_dev, int depth_b_dtype,
+        const float* image_colors_b_dev, float* points_b_dev,
+        float* colors_b_dev, int32_t* out_count_b_dev,
+        const double* extrinsic_b, int rows, int cols, const double* intrinsic,
+        float depth_scale, float depth_max, int64_t stride,
+        o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(depth_a_dev && points_a_dev && out_count_a_dev &&
+                          extrinsic_a && depth_b_dev && points_b_dev &&
+                          out_count_b_dev && extrinsic_b && intrinsic,
+                  "null argument");
+    O3DMI_REQUIRE((depth_a_dtype == O3DMI_U16 || depth_a_dtype == O3DMI_F32) &&
+                          (depth_b_dtype == O3DMI_U16 ||
+                           depth_b_dtype == O3DMI_F32),
+                  "depth dtype must be UInt16 or Float32");
+    O3DMI_REQUIRE(stride > 0 && rows >= stride && cols >= stride,
+                  "bad image size / stride");
+    O3DMI_REQUIRE(points_a_dev != points_b_dev &&
+                          out_count_a_dev != out_count_b_dev,
+                  "the two clouds share an output");
+    hipStream_t s = (hipStream_t)stream;
+    UnprojectJob ja = {}, jb = {};
+    ja.p = MakeTouchParams(intrinsic, extrinsic_a, rows, cols, (int)stride, 1,
+                           1.0f, 0.0f, depth_scale, depth_max);
+    jb.p = MakeTouchParams(intrinsic, extrinsic_b, rows, cols, (int)stride, 1,
+                           1.0f, 0.0f, depth_scale, depth_max);
+    const int64_t n = (int64_t)ja.p.rows_strided * ja.p.cols_strided;
+    // the largest chunk that still gives every CU one (two clouds' chunks)
+    int rounds = kUnprojMaxRounds;
+    while (rounds > 1 && 2 * n < (int64_t)kCUs * kBlock * rounds) rounds >>= 1;
+    const int n_chunks = (int)((n + (int64_t)kBlock * rounds - 1) /
+                               ((int64_t)kBlock * rounds));
+    unsigned long long* words = nullptr;
+    unsigned seq = 0;
+    int st = UnprojectWords(2 * n_chunks, s, &words, &seq);
+    if (st != O3DMI_OK) return st;
+    ja.depth = depth_a_dev;
+    ja.depth_is_u16 = depth_a_dtype == O3DMI_U16;
+    ja.image_colors = image_colors_a_dev;
+    ja.points = points_a_dev;
+    ja.colors = colors_a_dev;
+    ja.count = out_count_a_dev;
+    ja.chunk_words = words;
+    ja.n_chunks = n_chunks;
+    jb.depth = depth_b_dev;
+    jb.depth_is_u16 = depth_b_dtype == O3DMI_U16;
+    jb.image_colors = image_colors_b_dev;
+    jb.points = points_b_dev;
+    jb.colors = colors_b_dev;
+    jb.count = out_count_b_dev;
+    jb.chunk_words = words + n_chunks;
+    jb.n_chunks = n_chunks;
+    dim3 grid((unsigned)(2 * n_chunks)), block(kBlock);
+    switch (rounds) {
+        case 8:
+            hipLaunchKernelGGL(UnprojectPairKernel<8>, grid, block, 0, s, ja,
+                               jb, seq);
+            break;
+        case 4:
+            hipLaunchKernelGGL(UnprojectPairKernel<4>, grid, block, 0, s, ja,
+                               jb, seq);
+            break;
+        case 2:
+            hipLaunchKernelGGL(UnprojectPairKernel<2>, grid, block, 0, s, ja,
+                               jb, seq);
+            break;
+        default:
+            hipLaunchKernelGGL(UnprojectPairKernel<1>, grid, block, 0, s, ja,
+                               jb, seq);
+            break;
+    }
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
 }

@@ -43,7 +43,23 @@ int VdsAsync(const void* pos, const void* attr, int64_t n_max, const int* n_dev,
 // (round 5: two chains of launches on two streams, 16 launches per frame
 // pair of pyramids; now 7 + 1). The jobs of one call must name different
 // chains; clouds beyond the tiled form fall back to one call each.
+// The counts of a chain posted to its host mailbox by the chain's LAST level
+// launch itself (the reduce launch knows the level's voxel count when it
+// starts): counts[0..n - 1) -- the level written by this call taken from the
+// launch, the others from memory -- and the error word counts[kCountsErr] as
+// value n - 1 go out as a sealed block (mailbox.h), are copied to
+// counts[kCountsKeep + i], and the error word is cleared. Only on a level
+// without a fused next-level insert.
+struct VdsPost {
+    int* counts = nullptr;   // NULL: no post
+    int n = 0;               // levels + 1
+    double* mail_data = nullptr;
+    int* mail_flag = nullptr;
+    int mail_seq = 0;
+};
+
 struct VdsLevelJob {
+    VdsPost post;
     const void* pos = nullptr;
     const void* attr = nullptr;
     int64_t n_max = 0;
@@ -57,8 +73,12 @@ struct VdsLevelJob {
     double next_voxel_size = 0;
     bool from_previous = false;
 };
+// *posted (optional): whether the jobs' VdsPost requests were carried out
+// (tiled form, every job of the call asking); if not, the caller posts with
+// PostCountsPairAsync as before.
 int VdsPairAsync(const VdsLevelJob* jobs, int n_jobs, int dtype,
-                 std::vector<void*>& scratch, hipStream_t s);
+                 std::vector<void*>& scratch, hipStream_t s,
+                 bool* posted = nullptr);
 
 // The calling thread's workspaces of `chain` on the current device may have
 // been left dirty by a chain that was abandoned mid-way (error return between
@@ -66,14 +86,20 @@ int VdsPairAsync(const VdsLevelJob* jobs, int n_jobs, int dtype,
 // them and starts from freshly initialised buffers.
 void VdsChainInvalidate(int chain);
 
-// counts_dev[0..n) (int) -> mail_data[0..n) (as float64) + sequence word
-// `mail_seq` (mailbox.h), on stream s; the words are zeroed afterwards.
+// counts_dev[0..n - 1) and the error word counts_dev[kCountsErr] (int) ->
+// mail_data[0..n) (as float64) + sequence word `mail_seq` (mailbox.h), on
+// stream s; the words are zeroed afterwards.
 int PostCountsAsync(int* counts_dev, int n, double* mail_data, int* mail_flag,
                     int mail_seq, hipStream_t s);
 // Two chains' counts (built in the same launches) posted by one launch; every
 // count is also copied to counts[kCountsKeep + i], where it stays until the
 // next posting launch (counts buffers hold 2 * kCountsKeep ints).
 constexpr int kCountsKeep = 32;
+// The chain's error word lives at a FIXED slot of the counts buffer (not
+// behind the last level: chains of different depths share the buffer, and a
+// post that leaves with the last level's launch cannot zero the count that
+// launch is still reading); a post delivers it as value n - 1.
+constexpr int kCountsErr = kCountsKeep - 1;
 int PostCountsPairAsync(int* counts_a, double* mail_data_a, int* mail_flag_a,
                         int mail_seq_a, int* counts_b, double* mail_data_b,
                         int* mail_flag_b, int mail_seq_b, int n,

@@ -1602,3 +1602,8 @@ def test_pyramid_level_that_carries_the_next_levels_insert_changes_nothing():
     unpaired = run({"O3DMI_VDS_UNPAIRED": "1"})
     assert unpaired == fused
     assert run({"O3DMI_VDS_UNPAIRED": "1", "O3DMI_VDS_NO_FUSE": "1"}) == fused
+    # ... and the coarsest level's reduce launch posts both chains' counts to
+    # the host itself (vds.h VdsPost); O3DMI_VDS_POST_LAUNCH=1 keeps the
+    # separate posting launch: same counts, same everything.
+    assert run({"O3DMI_VDS_POST_LAUNCH": "1"}) == fused
+    assert run({"O3DMI_VDS_POST_LAUNCH": "1", "O3DMI_VDS_NO_FUSE": "1"}) == fused

@@ -291,6 +291,88 @@ def test_unproject_is_the_row_major_scan():
         assert (runs[0][0][m:] == -7.0).all()       # nothing written past count
 
 
+def test_unproject_pair_is_two_unprojects():
+    """o3dmi_unproject_pair (the model frame's and the camera frame's cloud of
+    a tracking step in one launch) gives, for each cloud, o3dmi_unproject's
+    points, attributes, count and order to the bit -- float32 depth with an
+    attribute image beside uint16 depth without one, two extrinsics, VGA and
+    720p, strides 1 / 2 / 3 -- and writes nothing past the counts."""
+    _lib, geometry = _gpu()
+    from open3d_amd import synthetic as syn
+    from open3d_amd.core import stream
+    L = _lib.lib()
+    rng = np.random.default_rng(11)
+    for (W, H) in ((640, 480), (1280, 720)):
+        K = syn.intrinsics(W, H)
+        d, c, _n, T = syn.render_frames(3, 2, W, H, device="cuda")
+        da = (d[0].to(torch.float32)).contiguous()      # depth_scale units
+        holes = torch.from_numpy(rng.random((H, W)) < 0.25).cuda()
+        da[holes] = 0.0
+        da[H // 3:H // 2, :] = 0.0
+        attr = torch.from_numpy(
+            rng.random((H, W, 3)).astype(np.float32)).cuda()
+        db = d[1].contiguous()
+        Ta = np.ascontiguousarray(T[0], np.float64)
+        Tb = np.ascontiguousarray(np.eye(4), np.float64)
+        for stride in (1, 2, 3):
+            n = (H // stride) * (W // stride)
+
+            def single(depth, dt, img, Tx):
+                pts = torch.full((n, 3), -7.0, dtype=torch.float32,
+                                 device="cuda")
+                cols = torch.full((n, 3), -7.0, dtype=torch.float32,
+                                  device="cuda")
+                cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+                _lib.check(L.o3dmi_unproject(
+                    _lib.ptr(depth), dt, H, W,
+                    _lib.ptr(img) if img is not None else None, _lib.ptr(pts),
+                    _lib.ptr(cols) if img is not None else None,
+                    _lib.ptr(cnt), _lib.f64p(K), _lib.f64p(Tx),
+                    C.c_float(sc.DEPTH_SCALE), C.c_float(sc.DEPTH_MAX),
+                    stride, stream()), "unproject")
+                return pts.cpu().numpy(), cols.cpu().numpy(), int(cnt.item())
+
+            wa = single(da, _lib.F32, attr, Ta)
+            wb = single(db, _lib.U16, None, Tb)
+            assert 0 < wa[2] < n and 0 < wb[2] <= n
+            for _ in range(2):
+                pa = torch.full((n, 3), -7.0, dtype=torch.float32,
+                                device="cuda")
+                ca = torch.full((n, 3), -7.0, dtype=torch.float32,
+                                device="cuda")
+                pb = torch.full((n, 3), -7.0, dtype=torch.float32,
+                                device="cuda")
+                na = torch.zeros(1, dtype=torch.int32, device="cuda")
+                nb = torch.zeros(1, dtype=torch.int32, device="cuda")
+                _lib.check(L.o3dmi_unproject_pair(
+                    _lib.ptr(da), _lib.F32, _lib.ptr(attr), _lib.ptr(pa),
+                    _lib.ptr(ca), _lib.ptr(na), _lib.f64p(Ta),
+                    _lib.ptr(db), _lib.U16, None, _lib.ptr(pb), None,
+                    _lib.ptr(nb), _lib.f64p(Tb), H, W, _lib.f64p(K),
+                    C.c_float(sc.DEPTH_SCALE), C.c_float(sc.DEPTH_MAX),
+                    stride, stream()), "unproject_pair")
+                assert (int(na.item()), int(nb.item())) == (wa[2], wb[2])
+                assert np.array_equal(pa.cpu().numpy(), wa[0])
+                assert np.array_equal(ca.cpu().numpy(), wa[1])
+                assert np.array_equal(pb.cpu().numpy(), wb[0])
+    # refusals: aliased outputs, a bad dtype
+    pts = torch.zeros((480 * 640, 3), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(2, dtype=torch.int32, device="cuda")
+    K = syn.intrinsics(640, 480)
+    E = np.ascontiguousarray(np.eye(4), np.float64)
+    dd = torch.zeros((480, 640), dtype=torch.uint16, device="cuda")
+    assert L.o3dmi_unproject_pair(
+        _lib.ptr(dd), _lib.U16, None, _lib.ptr(pts), None, _lib.ptr(cnt),
+        _lib.f64p(E), _lib.ptr(dd), _lib.U16, None, _lib.ptr(pts), None,
+        _lib.ptr(cnt[1:]), _lib.f64p(E), 480, 640, _lib.f64p(K),
+        C.c_float(1000.0), C.c_float(3.0), 1, stream()) != 0
+    assert L.o3dmi_unproject_pair(
+        _lib.ptr(dd), _lib.F64, None, _lib.ptr(pts), None, _lib.ptr(cnt),
+        _lib.f64p(E), _lib.ptr(dd), _lib.U16, None, _lib.ptr(pts[1000:]),
+        None, _lib.ptr(cnt[1:]), _lib.f64p(E), 480, 640, _lib.f64p(K),
+        C.c_float(1000.0), C.c_float(3.0), 1, stream()) != 0
+
+
 def test_unproject_large_image_many_chunks():
     """A 1280x720 image at stride 1 (450 chunks of 2048 pixels: a workgroup
     reads up to two words per lane of the chunks before it) and at stride 3

@@ -189,27 +189,19 @@ def mode_slam(a):
                           dtype=torch.float32, device="cuda")
     cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
 
-    def frame_cloud(depth, T_wc):
-        """PointCloud::CreateFromDepthImage(depth, K, T, scale, max, stride)."""
-        T = np.ascontiguousarray(T_wc, dtype=np.float64)
-        _lib.check(L.o3dmi_unproject(
-            _lib.ptr(depth), _lib.U16, H, W, None, _lib.ptr(pts_buf), None,
-            _lib.ptr(cnt), _lib.f64p(K), _lib.f64p(T), C.c_float(ds),
-            C.c_float(dmax), C.c_int64(stride), stream()), "unproject")
-        if getattr(a, "host_counts", False):
-            return pts_buf[:int(cnt.item())]
-        return pts_buf  # the live size stays in `cnt`, on the device
-
     mpts = torch.empty(((H // stride) * (W // stride), 3),
                        dtype=torch.float32, device="cuda")
     mnrm = torch.empty_like(mpts)
     mcnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    EYE = np.ascontiguousarray(np.eye(4), dtype=np.float64)
 
-    def model_cloud(T_wc):
-        """Model cloud at the previous pose: ray-cast depth + normal maps,
+    def clouds(T_wc, depth):
+        """Model cloud at the previous pose -- ray-cast depth + normal maps,
         PointCloud::CreateFromDepthImage(ray-cast depth, stride) with the
-        normal map carried along as the per-pixel attribute, normals rotated
-        into the world frame -- library calls only, no tensor glue."""
+        normal map carried along as the per-pixel attribute -- and the frame
+        cloud of the new depth image, each in its own camera's frame, by one
+        Unproject launch (as examples/icp_slam.cpp since round 6: the normals
+        as rendered, no rotation launch). Library calls only, no tensor glue."""
         # the block coordinates of the frame integrated last, as the
         # integration left them on the device (= GetUniqueBlockCoordinates of
         # that frame; no second touch, no host wait)
@@ -218,20 +210,17 @@ def mode_slam(a):
                          depth_scale=ds, depth_min=0.1, depth_max=dmax,
                          weight_threshold=1.0, trunc_voxel_multiplier=trunc,
                          block_count_dev=frame_keys[1])
-        T = np.ascontiguousarray(T_wc, dtype=np.float64)
-        _lib.check(L.o3dmi_unproject(
-            _lib.ptr(out["depth"]), _lib.F32, H, W, _lib.ptr(out["normal"]),
-            _lib.ptr(mpts), _lib.ptr(mnrm), _lib.ptr(mcnt), _lib.f64p(K),
-            _lib.f64p(T), C.c_float(ds), C.c_float(dmax), C.c_int64(stride),
-            stream()), "unproject")
-        # the live size stays on the device (mcnt): the normals are rotated
-        # over the whole buffer, rows past the size are never read
-        m = int(mcnt.item()) if getattr(a, "host_counts", False) else mnrm.shape[0]
-        Tinv = np.ascontiguousarray(np.linalg.inv(T_wc), dtype=np.float64)
-        _lib.check(L.o3dmi_transform_normals(_lib.f64p(Tinv), _lib.ptr(mnrm),
-                                             m, _lib.F32, stream()),
-                   "transform_normals")
-        return mpts[:m], mnrm[:m], out["depth"]
+        _lib.check(L.o3dmi_unproject_pair(
+            _lib.ptr(out["depth"]), _lib.F32, _lib.ptr(out["normal"]),
+            _lib.ptr(mpts), _lib.ptr(mnrm), _lib.ptr(mcnt), _lib.f64p(EYE),
+            _lib.ptr(depth), _lib.U16, None, _lib.ptr(pts_buf), None,
+            _lib.ptr(cnt), _lib.f64p(EYE), H, W, _lib.f64p(K), C.c_float(ds),
+            C.c_float(dmax), C.c_int64(stride), stream()), "unproject_pair")
+        # the live sizes stay on the device (mcnt, cnt)
+        if getattr(a, "host_counts", False):
+            m = int(mcnt.item())
+            return mpts[:m], mnrm[:m], pts_buf[:int(cnt.item())]
+        return mpts, mnrm, pts_buf
 
     # bootstrap with frame 0 at its true pose
     T_est = [np.array(Ts[0])]
@@ -252,20 +241,19 @@ def mode_slam(a):
     for k in range(1, n):
         T_prev = T_est[-1]
         p0 = tick()
-        tp, tn, dpred = model_cloud(T_prev)
+        # source in its own camera's frame: ICP estimates the motion from
+        # this camera to the previous one, starting from the identity
+        tp, tn, src = clouds(T_prev, depths[k])
         p1 = tick()
-        # source in the previous camera's world alignment: ICP estimates the
-        # world-frame correction from the previous pose to the current one
-        src = frame_cloud(depths[k], T_prev)
-        p2 = tick()
+        p2 = p1
         r = reg.multi_scale_icp(
             src, tp, tn, vs, crit, md,
             device_counts=None if getattr(a, "host_counts", False) else (cnt, mcnt))
         iters_log.append(r.num_iterations)
         p3 = tick()
         iters += r.num_iterations
-        # points_world = r.T * (T_prev^-1 * p_cam)  =>  extrinsic_k = T_prev * r.T^-1
-        T_k = T_prev @ np.linalg.inv(r.transformation)
+        # p_prev_cam = r.T p_cam = T_prev p_world  =>  extrinsic_k = r.T^-1 T_prev
+        T_k = np.linalg.inv(r.transformation) @ T_prev
         T_est.append(T_k)
         g.integrate_frame(depths[k], colors[k], K, K, T_k, ds, dmax, trunc)
         frame_keys = g.last_frame_block_coordinates(keys_cap)
