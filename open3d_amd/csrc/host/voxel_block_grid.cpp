@@ -1968,6 +1968,7 @@ extern "C" int o3dmi_internal_estimate_range(
         float voxel_size, float depth_min, float depth_max,
         o3dmi_stream_t stream);
 extern "C" int o3dmi_internal_raycast_reset_range(void);
+extern "C" int o3dmi_internal_raycast_forget(void);
 extern "C" int o3dmi_internal_raycast_tile_order(unsigned long long* cost,
                                                  int* order, int n_tiles,
                                                  unsigned want_seq,
@@ -2375,6 +2376,11 @@ int o3dmi_vbg_ray_cast_dev(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
     // consumes it leaves it clean for the next call: no clearing launch per
     // frame.
     int map_is_clean = 0;
+    // (what the calls below leave for the range-estimate and the ray-cast
+    // launch of this thread does not outlive this call, whichever way it ends)
+    struct ForgetSideChannels {
+        ~ForgetSideChannels() { (void)o3dmi_internal_raycast_forget(); }
+    } forget_side_channels;
     if (!range_map_dev) {
         const int64_t cells = (int64_t)(height / range_map_down_factor) *
                               (width / range_map_down_factor);

@@ -932,6 +932,17 @@ int o3dmi_internal_raycast_tile_order(unsigned long long* cost, int* order,
     return O3DMI_OK;
 }
 
+// Drops whatever the two calls above left for launches that were never made
+// (an error return between the call and its launch): the caller's scope guard.
+int o3dmi_internal_raycast_forget(void) {
+    g_reset_range = 0;
+    g_sort_tiles = TileOrder{};
+    g_tile_order = nullptr;
+    g_tile_cost = nullptr;
+    g_cost_seq = 0;
+    return O3DMI_OK;
+}
+
 int o3dmi_vbg_estimate_range_dev(const int32_t* block_keys_dev,
                                  int64_t max_blocks,
                                  const int32_t* n_blocks_dev,
@@ -956,6 +967,9 @@ int o3dmi_internal_estimate_range(const int32_t* block_keys_dev, int key_stride,
                                   int down_factor, int64_t block_resolution,
                                   float voxel_size, float depth_min,
                                   float depth_max, o3dmi_stream_t stream) {
+    // (the side channel is this call's whether or not it gets to its launch)
+    const TileOrder to = g_sort_tiles;
+    g_sort_tiles = TileOrder{};
     O3DMI_REQUIRE(range_minmax_map_dev && intrinsic && extrinsic,
                   "null argument");
     O3DMI_REQUIRE(down_factor > 0 && h >= down_factor && w >= down_factor,
@@ -973,8 +987,6 @@ int o3dmi_internal_estimate_range(const int32_t* block_keys_dev, int key_stride,
         Camera cam = Camera::Make(intrinsic, extrinsic, 1.0f);
         // With a device-resident count the list is usually far shorter than
         // its capacity: a fixed grid (2 workgroups per CU) strides over it.
-        const TileOrder to = g_sort_tiles;
-        g_sort_tiles = TileOrder{};
         const int grid = (n_blocks_dev ? GridFor(max_blocks, 4, kCUs * 2)
                                        : GridFor(max_blocks, 4)) +
                          (to.cost ? 1 : 0);
@@ -983,8 +995,6 @@ int o3dmi_internal_estimate_range(const int32_t* block_keys_dev, int key_stride,
                            range_minmax_map_dev, cam, h_down, w_down,
                            down_factor, block_resolution, voxel_size, depth_min,
                            depth_max, to);
-    } else {
-        g_sort_tiles = TileOrder{};
     }
     O3DMI_HIP_CHECK(hipGetLastError());
     return O3DMI_OK;
@@ -1024,6 +1034,15 @@ int o3dmi_vbg_raycast_rows(
         int range_map_down_factor, o3dmi_stream_t stream) {
     (void)depth_min;
     (void)depth_max;
+    // (the side channels are this call's whether or not it gets to its launch)
+    const int reset_range = g_reset_range;
+    const int* const tile_order = g_tile_order;
+    unsigned long long* const tile_cost = g_tile_cost;
+    const unsigned cost_seq = g_cost_seq;
+    g_reset_range = 0;
+    g_tile_order = nullptr;
+    g_tile_cost = nullptr;
+    g_cost_seq = 0;
     O3DMI_REQUIRE(block_hash && tsdf_dev && weight_dev && range_map_dev &&
                           intrinsic && extrinsic,
                   "null argument");
@@ -1089,20 +1108,17 @@ int o3dmi_vbg_raycast_rows(
     p.xcd_bands = n_tiles <= kCUs * 5 ? 1 : 0;
     p.coop = 1;
     // (o3dmi_internal_raycast_reset_range: consumed by this launch)
-    if (g_reset_range && whole && range_map_down_factor == 8) p.coop |= 2;
-    g_reset_range = 0;
+    if (reset_range && whole && range_map_down_factor == 8) p.coop |= 2;
     // (o3dmi_internal_raycast_tile_order: consumed by this launch; only for
     // launches that run in rounds, whose grid is one workgroup per tile)
     p.tile_order = nullptr;
     p.tile_cost = nullptr;
     p.cost_seq = 0;
-    if (g_tile_cost && whole && !p.xcd_bands && n_tiles <= kCUs * 16) {
-        p.tile_order = g_tile_order;
-        p.tile_cost = g_tile_cost;
-        p.cost_seq = g_cost_seq;
+    if (tile_cost && whole && !p.xcd_bands && n_tiles <= kCUs * 16) {
+        p.tile_order = tile_order;
+        p.tile_cost = tile_cost;
+        p.cost_seq = cost_seq;
     }
-    g_tile_order = nullptr;
-    g_tile_cost = nullptr;
     // a multiple of 8 workgroups: every XCD gets the same number
     dim3 grid((unsigned)((GridFor(n_tiles, 1, kCUs * 16) + 7) & ~7)),
             block(kBlock);
