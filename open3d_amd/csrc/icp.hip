@@ -32,6 +32,10 @@
 
 #include "nns.h"
 #include "mailbox.h"
+
+#ifndef O3DMI_ABLATE_TAIL
+#define O3DMI_ABLATE_TAIL 0
+#endif
 #include "reduce_sums.h"
 
 namespace o3dmi {
@@ -967,8 +971,15 @@ SearchAccumulateKernel(NnsView<T> nv, const Rec4<T>* __restrict__ sorted_n,
         else
             partials[(int64_t)blockIdx.x * kNumSums + threadIdx.x] = t;
     }
+#if O3DMI_ABLATE_TAIL == 1
+    // (variant builds only, tools/build_variant.sh-style: what the final sum
+    // inside the launch costs -- sums are NOT delivered)
+#elif O3DMI_ABLATE_TAIL == 2
+    if (tail.tickets) (void)LastWorkgroup(tail.tickets);
+#else
     if (tail.tickets && LastWorkgroup(tail.tickets))
         RowSumTail(partials, (int)gridDim.x, tail);
+#endif
 }
 
 
