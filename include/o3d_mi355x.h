@@ -203,6 +203,36 @@ int o3dmi_vbg_pointcloud_touch(o3dmi_hash_t* frustum_hash,
                                float voxel_size, float sdf_trunc,
                                o3dmi_stream_t stream);
 
+/* GetVoxelCoordinatesAndFlattenedIndicesCUDA
+ * (t/geometry/kernel/VoxelBlockGridImpl.h:43-92): for the n_blocks buffer
+ * indices given, the world coordinates {n_blocks * res^3, 3} Float32 of every
+ * voxel's origin corner, (key * res + voxel) * voxel_size, and its linear
+ * index into the value tensors {n_blocks * res^3} Int64, voxels of a block in
+ * x-fastest order. block_keys_dev: the hash map's {capacity, 3} key buffer
+ * (o3dmi_hash_key_buffer). Either output may be NULL. The linear index is
+ * formed in 64 bits (upstream: int, overflowing past 2^31 voxels; equal below
+ * that). Asynchronous. */
+int o3dmi_vbg_voxel_coordinates_and_flattened_indices(
+        const int32_t* buf_indices_dev, int64_t n_blocks,
+        const int32_t* block_keys_dev, int resolution, float voxel_size,
+        float* voxel_coords_dev, int64_t* flattened_indices_dev,
+        o3dmi_stream_t stream);
+/* VoxelBlockGrid::GetVoxelIndices (t/geometry/VoxelBlockGrid.cpp:145-178):
+ * {4, n_blocks * res^3} Int64 -- row 0 the buffer index of the voxel's block,
+ * rows 1-3 its x, y, z inside the block. Asynchronous. */
+int o3dmi_vbg_voxel_indices(const int32_t* buf_indices_dev, int64_t n_blocks,
+                            int resolution, int64_t* voxel_indices_dev,
+                            o3dmi_stream_t stream);
+/* VoxelBlockGrid::GetVoxelCoordinates (VoxelBlockGrid.cpp:130-143): {4, n}
+ * voxel indices -> {3, n} Int64 voxel coordinates key * res + (x, y, z). A
+ * buffer index outside [0, key_capacity) sets bit 0 of *err_dev (optional)
+ * and yields zeros (upstream's IndexGet throws). Asynchronous. */
+int o3dmi_vbg_voxel_coordinates(const int64_t* voxel_indices_dev, int64_t n,
+                                const int32_t* block_keys_dev,
+                                int64_t key_capacity, int resolution,
+                                int64_t* voxel_coords_dev, int32_t* err_dev,
+                                o3dmi_stream_t stream);
+
 /* IntegrateCUDA<input_depth_t,input_color_t,tsdf_t,weight_t,color_t>
  * (t/geometry/kernel/VoxelBlockGridImpl.h:151-308). input_dtype: O3DMI_U16
  * (u16 depth + u8 colour) or O3DMI_F32 (f32 depth + f32 colour in [0,1]);

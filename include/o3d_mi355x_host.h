@@ -353,6 +353,37 @@ int o3dmi_vbg_get_unique_block_coordinates(
         float depth_scale, float depth_max, float trunc_voxel_multiplier,
         int32_t* out_coords_dev, int64_t* m_out, o3dmi_stream_t stream);
 
+/* GetUniqueBlockCoordinates(pcd, trunc_voxel_multiplier)
+ * (VoxelBlockGrid.cpp:246-267): the blocks within +-voxel_size *
+ * trunc_voxel_multiplier of each of the n points {n, 3} Float32. The frustum
+ * map is (re)created for n * 8 entries, upstream's estimate; out_coords_dev
+ * holds out_capacity rows (n * 8 always suffices); *m_out = number of unique
+ * blocks (synchronises). */
+int o3dmi_vbg_get_unique_block_coordinates_pcd(
+        o3dmi_vbg_t* g, const float* points_dev, int64_t n,
+        float trunc_voxel_multiplier, int32_t* out_coords_dev,
+        int64_t out_capacity, int64_t* m_out, o3dmi_stream_t stream);
+
+/* GetVoxelIndices(buf_indices) / GetVoxelCoordinates(voxel_indices) /
+ * GetVoxelCoordinatesAndFlattenedIndices(buf_indices) of this grid
+ * (VoxelBlockGrid.cpp:130-211): the kernel-seam functions of the same names
+ * (o3d_mi355x.h) with the grid's key buffer, block resolution and voxel size.
+ * The forms without an argument upstream take GetActiveIndices():
+ * o3dmi_hash_active_indices(o3dmi_vbg_hashmap(g), ...). get_voxel_coordinates
+ * synchronises (a buffer index outside the map is O3DMI_ERR_INVALID_ARG, as
+ * upstream's IndexGet throws); the other two are asynchronous. */
+int o3dmi_vbg_get_voxel_indices(o3dmi_vbg_t* g, const int32_t* buf_indices_dev,
+                                int64_t n_blocks, int64_t* voxel_indices_dev,
+                                o3dmi_stream_t stream);
+int o3dmi_vbg_get_voxel_coordinates(o3dmi_vbg_t* g,
+                                    const int64_t* voxel_indices_dev,
+                                    int64_t n_voxels, int64_t* voxel_coords_dev,
+                                    o3dmi_stream_t stream);
+int o3dmi_vbg_get_voxel_coordinates_and_flattened_indices(
+        o3dmi_vbg_t* g, const int32_t* buf_indices_dev, int64_t n_blocks,
+        float* voxel_coords_dev, int64_t* flattened_indices_dev,
+        o3dmi_stream_t stream);
+
 /* Integrate(block_coords, depth, color, depth_intrinsic, color_intrinsic,
  * extrinsic, depth_scale, depth_max, trunc_voxel_multiplier)
  * (VoxelBlockGrid.cpp:292-326): Activate + Find + per-voxel update. May

@@ -56,6 +56,11 @@ PROTOTYPES = {
                                      _i32, _vp]),
     "o3dmi_vbg_pointcloud_touch": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp,
                                           _i32, _f, _f, _vp]),
+    "o3dmi_vbg_voxel_coordinates_and_flattened_indices": (
+        _i32, [_vp, _i64, _vp, _i32, _f, _vp, _vp, _vp]),
+    "o3dmi_vbg_voxel_indices": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "o3dmi_vbg_voxel_coordinates": (_i32, [_vp, _i64, _vp, _i64, _i32, _vp,
+                                           _vp, _vp]),
     "o3dmi_vbg_integrate": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _i32,
                                    _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32,
                                    _dp, _dp, _dp, _i32, _f, _f, _f, _f, _vp]),
@@ -222,6 +227,12 @@ PROTOTYPES.update({
     "o3dmi_vbg_get_unique_block_coordinates": (
         _i32, [_vp, _vp, _i32, _i32, _i32, _dp, _dp, _f, _f, _f, _vp,
                C.POINTER(_i64), _vp]),
+    "o3dmi_vbg_get_unique_block_coordinates_pcd": (
+        _i32, [_vp, _vp, _i64, _f, _vp, _i64, C.POINTER(_i64), _vp]),
+    "o3dmi_vbg_get_voxel_indices": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "o3dmi_vbg_get_voxel_coordinates": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "o3dmi_vbg_get_voxel_coordinates_and_flattened_indices": (
+        _i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "o3dmi_vbg_integrate_blocks": (
         _i32, [_vp, _vp, _i64, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _dp,
                _dp, _dp, _f, _f, _f, _vp]),

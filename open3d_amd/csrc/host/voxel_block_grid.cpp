@@ -598,6 +598,98 @@ int o3dmi_vbg_get_unique_block_coordinates(
     return O3DMI_OK;
 }
 
+int o3dmi_vbg_get_unique_block_coordinates_pcd(
+        o3dmi_vbg_t* g, const float* points_dev, int64_t n,
+        float trunc_voxel_multiplier, int32_t* out_coords_dev,
+        int64_t out_capacity, int64_t* m_out, o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(g && m_out && n >= 0 && out_capacity >= 0, "null argument");
+    *m_out = 0;
+    if (n == 0) return O3DMI_OK;
+    O3DMI_REQUIRE(points_dev && out_coords_dev, "null argument");
+    const int64_t est_neighbor_multiplier = 8;  // VoxelBlockGrid.cpp:251
+    const int64_t capacity = n * est_neighbor_multiplier;
+    if (g->frustum_hashmap == nullptr || g->frustum_capacity < capacity) {
+        o3dmi_hash_destroy(g->frustum_hashmap);
+        g->frustum_hashmap = nullptr;
+        g->frustum_capacity = 0;
+        int st = o3dmi_hash_create(capacity, 0, nullptr, stream,
+                                   &g->frustum_hashmap);
+        if (st) return st;
+        g->frustum_capacity = capacity;
+        if ((st = o3dmi_hash_set_ownership(g->frustum_hashmap, g->owner_rank,
+                                           g->owner_world)))
+            return st;
+    }
+    int st = o3dmi_vbg_pointcloud_touch(
+            g->frustum_hashmap, points_dev, n, out_coords_dev, out_capacity,
+            g->frame_count, (int)g->block_resolution, g->voxel_size,
+            g->voxel_size * trunc_voxel_multiplier, stream);
+    if (st) return st;
+    g->size_host[2] = 0;
+    O3DMI_HIP_CHECK(hipMemcpyAsync(&g->size_host[2], g->frame_count,
+                                   sizeof(int32_t), hipMemcpyDeviceToHost,
+                                   (hipStream_t)stream));
+    int64_t dummy = 0;
+    st = o3dmi_hash_size(g->frustum_hashmap, stream, &dummy);  // syncs + errors
+    if (st) return st;
+    const int64_t count = g->size_host[2];
+    if (count > out_capacity) {
+        *m_out = out_capacity;
+        SetLastError("GetUniqueBlockCoordinates: more blocks than "
+                     "out_capacity rows");
+        return O3DMI_ERR_CAPACITY;
+    }
+    *m_out = count;
+    return O3DMI_OK;
+}
+
+int o3dmi_vbg_get_voxel_indices(o3dmi_vbg_t* g, const int32_t* buf_indices_dev,
+                                int64_t n_blocks, int64_t* voxel_indices_dev,
+                                o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(g, "null argument");
+    return o3dmi_vbg_voxel_indices(buf_indices_dev, n_blocks,
+                                   (int)g->block_resolution, voxel_indices_dev,
+                                   stream);
+}
+
+int o3dmi_vbg_get_voxel_coordinates(o3dmi_vbg_t* g,
+                                    const int64_t* voxel_indices_dev,
+                                    int64_t n_voxels, int64_t* voxel_coords_dev,
+                                    o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(g && n_voxels >= 0, "null argument");
+    if (n_voxels == 0) return O3DMI_OK;
+    // the word the kernel flags a bad buffer index in: the frame counter's
+    // neighbour of the grid's device scratch, read back with the result
+    int32_t* err = g->frame_count + 1;
+    O3DMI_HIP_CHECK(hipMemsetAsync(err, 0, sizeof(int32_t),
+                                   (hipStream_t)stream));
+    int st = o3dmi_vbg_voxel_coordinates(
+            voxel_indices_dev, n_voxels,
+            o3dmi_hash_key_buffer(g->block_hashmap),
+            o3dmi_hash_capacity(g->block_hashmap), (int)g->block_resolution,
+            voxel_coords_dev, err, stream);
+    if (st) return st;
+    g->size_host[2] = 0;
+    O3DMI_HIP_CHECK(hipMemcpyAsync(&g->size_host[2], err, sizeof(int32_t),
+                                   hipMemcpyDeviceToHost,
+                                   (hipStream_t)stream));
+    O3DMI_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    O3DMI_REQUIRE(g->size_host[2] == 0,
+                  "GetVoxelCoordinates: buffer index out of range");
+    return O3DMI_OK;
+}
+
+int o3dmi_vbg_get_voxel_coordinates_and_flattened_indices(
+        o3dmi_vbg_t* g, const int32_t* buf_indices_dev, int64_t n_blocks,
+        float* voxel_coords_dev, int64_t* flattened_indices_dev,
+        o3dmi_stream_t stream) {
+    O3DMI_REQUIRE(g, "null argument");
+    return o3dmi_vbg_voxel_coordinates_and_flattened_indices(
+            buf_indices_dev, n_blocks, o3dmi_hash_key_buffer(g->block_hashmap),
+            (int)g->block_resolution, g->voxel_size, voxel_coords_dev,
+            flattened_indices_dev, stream);
+}
+
 int o3dmi_vbg_integrate_blocks(o3dmi_vbg_t* g, const int32_t* block_coords_dev,
                                int64_t m, const void* depth_dev,
                                int depth_rows, int depth_cols,

@@ -172,6 +172,73 @@ class VoxelBlockGrid:
             "VoxelBlockGrid.compute_unique_block_coordinates")
         return out[:m.value]
 
+    def compute_unique_block_coordinates_pcd(self, points,
+                                             trunc_voxel_multiplier=8.0):
+        """GetUniqueBlockCoordinates(pcd, trunc_voxel_multiplier)
+        (VoxelBlockGrid.cpp:246-267): the blocks within the truncation
+        distance of a point cloud {n, 3} Float32."""
+        if not (points.is_cuda and points.dtype == torch.float32 and
+                points.dim() == 2 and points.shape[1] == 3):
+            raise ValueError("points must be a CUDA Float32 {n, 3} tensor")
+        points = points.contiguous()
+        n = points.shape[0]
+        out = torch.empty((max(1, n * 8), 3), dtype=torch.int32, device="cuda")
+        m = C.c_int64(0)
+        _lib.check(_lib.lib().o3dmi_vbg_get_unique_block_coordinates_pcd(
+            self._g, _lib.ptr(points), n, C.c_float(trunc_voxel_multiplier),
+            _lib.ptr(out), out.shape[0], C.byref(m), stream()),
+            "VoxelBlockGrid.compute_unique_block_coordinates_pcd")
+        return out[:m.value]
+
+    def _buf_indices(self, buf_indices):
+        if buf_indices is None:        # upstream: GetActiveIndices()
+            buf_indices = self.hashmap().active_buf_indices()
+        if not (buf_indices.is_cuda and buf_indices.dtype == torch.int32 and
+                buf_indices.dim() == 1):
+            raise ValueError("buf_indices must be a CUDA Int32 vector")
+        return buf_indices.contiguous()
+
+    def voxel_indices(self, buf_indices=None):
+        """GetVoxelIndices (VoxelBlockGrid.cpp:145-183): {4, n * res^3}
+        Int64 -- buffer index, x, y, z of every voxel of the blocks."""
+        b = self._buf_indices(buf_indices)
+        res = int(_lib.lib().o3dmi_vbg_block_resolution(self._g))
+        out = torch.empty((4, b.shape[0] * res ** 3), dtype=torch.int64,
+                          device="cuda")
+        _lib.check(_lib.lib().o3dmi_vbg_get_voxel_indices(
+            self._g, _lib.ptr(b), b.shape[0], _lib.ptr(out), stream()),
+            "VoxelBlockGrid.voxel_indices")
+        return out
+
+    def voxel_coordinates(self, voxel_indices):
+        """GetVoxelCoordinates (VoxelBlockGrid.cpp:130-143): {4, n} voxel
+        indices -> {3, n} Int64 voxel coordinates."""
+        if not (voxel_indices.is_cuda and voxel_indices.dtype == torch.int64
+                and voxel_indices.dim() == 2 and voxel_indices.shape[0] == 4):
+            raise ValueError("voxel_indices must be a CUDA Int64 {4, n} tensor")
+        v = voxel_indices.contiguous()
+        out = torch.empty((3, v.shape[1]), dtype=torch.int64, device="cuda")
+        _lib.check(_lib.lib().o3dmi_vbg_get_voxel_coordinates(
+            self._g, _lib.ptr(v), v.shape[1], _lib.ptr(out), stream()),
+            "VoxelBlockGrid.voxel_coordinates")
+        return out
+
+    def voxel_coordinates_and_flattened_indices(self, buf_indices=None):
+        """GetVoxelCoordinatesAndFlattenedIndices (VoxelBlockGrid.cpp:185-211):
+        ({n * res^3, 3} Float32 world coordinates, {n * res^3} Int64 linear
+        indices into the value tensors)."""
+        b = self._buf_indices(buf_indices)
+        res = int(_lib.lib().o3dmi_vbg_block_resolution(self._g))
+        nv = b.shape[0] * res ** 3
+        coords = torch.empty((nv, 3), dtype=torch.float32, device="cuda")
+        flat = torch.empty((nv,), dtype=torch.int64, device="cuda")
+        _lib.check(
+            _lib.lib().o3dmi_vbg_get_voxel_coordinates_and_flattened_indices(
+                self._g, _lib.ptr(b), b.shape[0], _lib.ptr(coords),
+                _lib.ptr(flat), stream()),
+            "VoxelBlockGrid.voxel_coordinates_and_flattened_indices")
+        return coords, flat
+
     def integrate(self, block_coords, depth, color=None, depth_intrinsic=None,
                   color_intrinsic=None, extrinsic=None, depth_scale=1000.0,
                   depth_max=3.0, trunc_voxel_multiplier=8.0):

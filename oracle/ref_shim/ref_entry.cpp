@@ -153,6 +153,22 @@ int64_t ref_pointcloud_touch(const float* pcd, int64_t n, int resolution,
     return m;
 }
 
+// GetVoxelCoordinatesAndFlattenedIndicesCPU, VoxelBlockGridImpl.h:43-92.
+int ref_voxel_coords_flat(const int* buf_indices, int64_t n_blocks,
+                          const int* block_keys, int64_t key_capacity,
+                          int resolution, float voxel_size,
+                          float* voxel_coords, int64_t* flattened) {
+    return Guard([&] {
+        const int64_t n = n_blocks * resolution * resolution * resolution;
+        Tensor bi = Wrap(buf_indices, {n_blocks}, core::Int32);
+        Tensor keys = Wrap(block_keys, {key_capacity, 3}, core::Int32);
+        Tensor vc = Wrap(voxel_coords, {n, 3}, core::Float32);
+        Tensor fl = Wrap(flattened, {n}, core::Int64);
+        vg::GetVoxelCoordinatesAndFlattenedIndicesCPU(bi, keys, vc, fl,
+                                                      resolution, voxel_size);
+    });
+}
+
 // IntegrateCPU<...>, t/geometry/kernel/VoxelBlockGridImpl.h:151-308, with the
 // dtype dispatch of t/geometry/kernel/VoxelBlockGrid.cpp:107-146.
 int ref_integrate(const void* depth, int depth_rows, int depth_cols,

@@ -954,6 +954,37 @@ int64_t orc_pointcloud_touch(const float* pcd, int64_t n, int resolution,
                                out_coords, out_capacity);
 }
 
+// GetVoxelCoordinatesAndFlattenedIndicesCPU, VoxelBlockGridImpl.h:43-92:
+// workload w -> block buf_indices[w / res^3], voxel w % res^3 (x fastest,
+// WorkloadToCoord of a {res, res, res} indexer, GeometryIndexer.h:270-278);
+// coordinate (key * res + voxel) * voxel_size with the integer part formed in
+// int; flattened index block * res^3 + voxel in the reference's index_t (int:
+// the oracle keeps that width, callers stay below 2^31 voxels).
+void orc_voxel_coords_flat(const int* buf_indices, int64_t n_blocks,
+                           const int* block_keys, int resolution,
+                           float voxel_size, float* voxel_coords,
+                           int64_t* flattened) {
+    const int res3 = resolution * resolution * resolution;
+    const int n = (int)(n_blocks * res3);
+    for (int w = 0; w < n; ++w) {
+        const int block_idx = buf_indices[w / res3];
+        const int voxel_idx = w % res3;
+        const int xb = block_keys[block_idx * 3 + 0];
+        const int yb = block_keys[block_idx * 3 + 1];
+        const int zb = block_keys[block_idx * 3 + 2];
+        int rem = voxel_idx;
+        const int xv = rem % resolution;
+        rem /= resolution;
+        const int yv = rem % resolution;
+        rem /= resolution;
+        const int zv = rem;
+        flattened[w] = block_idx * res3 + voxel_idx;
+        voxel_coords[w * 3 + 0] = (xb * resolution + xv) * voxel_size;
+        voxel_coords[w * 3 + 1] = (yb * resolution + yv) * voxel_size;
+        voxel_coords[w * 3 + 2] = (zb * resolution + zv) * voxel_size;
+    }
+}
+
 // --- hash map (insert-if-absent, heap-ordered buffer indices) --------------
 // HashMap.cpp:166-216 + TBBHashBackend.h:203-247 + buffer accessor heap
 // (heap initialised to identity; DeviceAllocate = heap[top++]).

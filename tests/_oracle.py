@@ -101,6 +101,47 @@ def pointcloud_touch(points, resolution, voxel_size, sdf_trunc):
     return out[:m].copy()
 
 
+def voxel_coords_flat(buf_indices, block_keys, resolution, voxel_size):
+    """GetVoxelCoordinatesAndFlattenedIndicesCPU (VoxelBlockGridImpl.h:43-92)."""
+    buf_indices = np.ascontiguousarray(buf_indices, dtype=np.int32)
+    block_keys = np.ascontiguousarray(block_keys, dtype=np.int32)
+    n = buf_indices.shape[0] * resolution ** 3
+    coords = np.zeros((n, 3), np.float32)
+    flat = np.zeros(n, np.int64)
+    lib().orc_voxel_coords_flat(_p(buf_indices), C.c_int64(buf_indices.shape[0]),
+                                _p(block_keys), int(resolution),
+                                C.c_float(voxel_size), _p(coords), _p(flat))
+    return coords, flat
+
+
+def voxel_indices(buf_indices, resolution):
+    """VoxelBlockGrid::GetVoxelIndices (t/geometry/VoxelBlockGrid.cpp:145-178),
+    its tensor expressions one for one (numpy Int64)."""
+    buf_indices = np.asarray(buf_indices)
+    n_blocks = buf_indices.shape[0]
+    r, r2, r3 = resolution, resolution ** 2, resolution ** 3
+    lin = np.arange(0, n_blocks * r3, 1, dtype=np.int64)
+    block_idx = lin // r3
+    rem = lin - block_idx * r3
+    voxel_z = rem // r2
+    rem = rem - voxel_z * r2
+    voxel_y = rem // r
+    voxel_x = rem - voxel_y * r
+    out = np.zeros((4, n_blocks * r3), np.int64)
+    out[0] = buf_indices[block_idx].astype(np.int64)
+    out[1], out[2], out[3] = voxel_x, voxel_y, voxel_z
+    return out
+
+
+def voxel_coordinates(voxel_indices_, key_tensor, resolution):
+    """VoxelBlockGrid::GetVoxelCoordinates (VoxelBlockGrid.cpp:130-143)."""
+    vc = key_tensor[voxel_indices_[0]].T.astype(np.int64) * resolution
+    vc[0] += voxel_indices_[1]
+    vc[1] += voxel_indices_[2]
+    vc[2] += voxel_indices_[3]
+    return vc
+
+
 class HashMap:
     """Insert-if-absent map int3 -> buf_index with heap-ordered indices."""
 

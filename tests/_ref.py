@@ -112,6 +112,19 @@ def pointcloud_touch(points, resolution, voxel_size, sdf_trunc):
     return out[:m].copy()
 
 
+def voxel_coords_flat(buf_indices, block_keys, resolution, voxel_size):
+    buf_indices = np.ascontiguousarray(buf_indices, dtype=np.int32)
+    block_keys = np.ascontiguousarray(block_keys, dtype=np.int32)
+    n = buf_indices.shape[0] * resolution ** 3
+    coords = np.zeros((n, 3), np.float32)
+    flat = np.zeros(n, np.int64)
+    _check(lib().ref_voxel_coords_flat(
+        _p(buf_indices), C.c_int64(buf_indices.shape[0]), _p(block_keys),
+        C.c_int64(block_keys.shape[0]), int(resolution), C.c_float(voxel_size),
+        _p(coords), _p(flat)), "ref_voxel_coords_flat")
+    return coords, flat
+
+
 def integrate(depth, color, indices, block_keys, tsdf, weight, color_buf, K_d,
               K_c, T, resolution, voxel_size, sdf_trunc, depth_scale,
               depth_max):

@@ -49,6 +49,31 @@ def test_pointcloud_touch_same_block_set():
     assert np.array_equal(sc.sort_rows(a), sc.sort_rows(b))
 
 
+@pytest.mark.parametrize("res,voxel", [(16, 0.008), (8, 0.0125), (3, 0.1)])
+def test_voxel_coordinates_and_flattened_indices(res, voxel):
+    """GetVoxelCoordinatesAndFlattenedIndicesCPU compiled from the reference
+    against the restatement, bit for bit: random (repeated, unordered) buffer
+    indices into a key buffer with negative and large block coordinates."""
+    rng = np.random.default_rng(17)
+    cap = 300
+    keys = rng.integers(-2000, 2000, (cap, 3)).astype(np.int32)
+    keys[5] = (-(1 << 19), (1 << 19) - 1, 0)
+    buf = rng.integers(0, cap, 77).astype(np.int32)
+    buf[:3] = (5, 0, cap - 1)
+    ca, fa = orc.voxel_coords_flat(buf, keys, res, voxel)
+    cb, fb = ref.voxel_coords_flat(buf, keys, res, voxel)
+    assert np.array_equal(ca, cb) and np.array_equal(fa, fb)
+    assert fa.shape == (77 * res ** 3,) and ca.dtype == np.float32
+    # the numpy restatements of GetVoxelIndices / GetVoxelCoordinates agree
+    # with the kernel's enumeration: same voxel order, same integer coordinates
+    vi = orc.voxel_indices(buf, res)
+    assert np.array_equal(vi[0] * res ** 3 + vi[3] * res * res + vi[2] * res +
+                          vi[1], fa)
+    vc = orc.voxel_coordinates(vi, keys, res)
+    assert np.array_equal((vc.T.astype(np.int32) *
+                           np.float32(voxel)).astype(np.float32), ca)
+
+
 def _grids(grid_f32, cap, res, with_color=True):
     wd = np.float32 if grid_f32 else np.uint16
     mk = lambda: (np.zeros((cap, res, res, res), np.float32),

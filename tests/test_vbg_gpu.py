@@ -719,6 +719,100 @@ def test_pointcloud_touch_parity():
     L.o3dmi_hash_destroy(h)
 
 
+def test_unique_block_coordinates_of_a_point_cloud_and_integrate_from_them():
+    """VoxelBlockGrid::GetUniqueBlockCoordinates(pcd, trunc)
+    (VoxelBlockGrid.cpp:246-267) through the grid: the block set of the
+    oracle's PointCloudTouch for clouds of 1, 5000 and 60 000 points (the
+    frustum map is re-created when the cloud outgrows it, and reused after a
+    depth-image touch), an empty cloud, and an output buffer that is too
+    small."""
+    _lib, geometry = _gpu()
+    from open3d_amd.core import stream
+    g = _mk_grid(geometry, False, block_count=8192)
+    rng = np.random.RandomState(5)
+    d, c, K, Ts = sc.frames(3, 1)
+    g.compute_unique_block_coordinates(torch.from_numpy(d[0]).cuda(), K, Ts[0])
+    for n, trunc in ((1, 8.0), (5000, 8.0), (60000, 4.0), (300, 8.0)):
+        pts = rng.uniform(-1.5, 1.5, (n, 3)).astype(np.float32)
+        want = orc.pointcloud_touch(pts, sc.RES, sc.VOXEL, sc.VOXEL * trunc)
+        got = g.compute_unique_block_coordinates_pcd(
+            torch.from_numpy(pts).cuda(), trunc)
+        assert got.dtype == torch.int32 and got.shape[1] == 3
+        assert np.array_equal(sc.sort_rows(got.cpu().numpy()),
+                              sc.sort_rows(want)), n
+    empty = g.compute_unique_block_coordinates_pcd(
+        torch.zeros((0, 3), dtype=torch.float32, device="cuda"))
+    assert empty.shape == (0, 3)
+    # too few output rows: refused, not overrun
+    pts = torch.from_numpy(rng.uniform(-1, 1, (2000, 3)).astype(np.float32)).cuda()
+    out = torch.full((10 + 4, 3), -9, dtype=torch.int32, device="cuda")
+    m = C.c_int64(0)
+    st = _lib.lib().o3dmi_vbg_get_unique_block_coordinates_pcd(
+        g._g, _lib.ptr(pts), 2000, C.c_float(8.0), _lib.ptr(out), 10,
+        C.byref(m), stream())
+    assert st != 0
+    assert (out[10:].cpu().numpy() == -9).all()
+
+
+@pytest.mark.parametrize("res", [16, 8])
+def test_voxel_indices_coordinates_and_flattened_indices(res):
+    """GetVoxelIndices / GetVoxelCoordinates /
+    GetVoxelCoordinatesAndFlattenedIndices (VoxelBlockGrid.cpp:130-211,
+    kernel VoxelBlockGridImpl.h:43-92) on a grid with integrated frames: the
+    forms that take the active indices and the forms given buffer indices
+    (repeated, unordered), against the oracle on the grid's own key tensor,
+    bit for bit; the flattened indices address the voxels they name in the
+    value tensor; a buffer index outside the map is refused."""
+    _lib, geometry = _gpu()
+    g = _mk_grid(geometry, False, block_count=4096, res=res)
+    for k in (0, 7):
+        d, c, K, Ts = sc.frames(k, 1, 320, 240)
+        g.integrate_frame(torch.from_numpy(d[0]).cuda(),
+                          torch.from_numpy(c[0]).cuda(), K, K, Ts[0])
+    hm = g.hashmap()
+    keys = hm.key_tensor().cpu().numpy()
+    active = hm.active_buf_indices()
+    assert active.shape[0] > 50
+    voxel = sc.VOXEL
+    rng = np.random.default_rng(2)
+    picks = torch.from_numpy(
+        active.cpu().numpy()[rng.integers(0, active.shape[0], 37)]).cuda()
+    act_sorted = np.sort(active.cpu().numpy())
+    for buf in (None, picks, active[:1], active[:0]):
+        vi = g.voxel_indices(buf)
+        if buf is None:
+            # GetActiveIndices' order is unspecified (here as upstream): the
+            # blocks are the active ones, in the order the result shows
+            b_np = vi[0, ::res ** 3].cpu().numpy().astype(np.int32)
+            assert np.array_equal(np.sort(b_np), act_sorted)
+        else:
+            b_np = buf.cpu().numpy()
+        want_vi = orc.voxel_indices(b_np, res)
+        assert vi.dtype == torch.int64 and vi.shape == want_vi.shape
+        assert np.array_equal(vi.cpu().numpy(), want_vi)
+        vc = g.voxel_coordinates(vi)
+        assert np.array_equal(vc.cpu().numpy(),
+                              orc.voxel_coordinates(want_vi, keys, res))
+        coords, flat = g.voxel_coordinates_and_flattened_indices(buf)
+        if buf is None:
+            b_np = (flat[::res ** 3] // res ** 3).cpu().numpy().astype(np.int32)
+            assert np.array_equal(np.sort(b_np), act_sorted)
+        wc, wf = orc.voxel_coords_flat(b_np, keys, res, voxel)
+        assert coords.dtype == torch.float32 and flat.dtype == torch.int64
+        assert np.array_equal(coords.cpu().numpy(), wc)
+        assert np.array_equal(flat.cpu().numpy(), wf)
+    # the flattened index names the voxel in the value tensor {cap, r, r, r, 1}
+    coords, flat = g.voxel_coordinates_and_flattened_indices(picks)
+    tsdf = g.attribute("tsdf")
+    vi = g.voxel_indices(picks)
+    direct = tsdf[vi[0], vi[3], vi[2], vi[1], 0]
+    assert torch.equal(tsdf.reshape(-1)[flat], direct)
+    bad = vi.clone()
+    bad[0, 5] = hm.capacity()
+    with pytest.raises(Exception):
+        g.voxel_coordinates(bad)
+
+
 def test_unproject_parity():
     _lib, geometry = _gpu()
     from open3d_amd.core import stream
